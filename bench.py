@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the coupling-layer hot path on MI355X.
+
+Workload (BASELINE.json configs[1], the one `metric` is quoted on): 32 x [CoupledRationalQuadraticSpline(64, 2
+blocks, 128 hidden, K=8, tails linear, tail_bound 3) + LULinearPermute(64)], DiagGaussian(64) base, fp32, batch
+65 536 synthetic N(0, I) rows per GPU.  A "step" is one `log_prob` pass of the whole flow over the batch (every
+layer's inverse + log|det J| accumulation + base log-density), inputs resident in HBM.  Weights: seeded
+construction (bit-identical to constructing the reference with the same seed, tests/test_state_dict_compat.py)
+plus the sigma = 0.01 parameter perturbation of SURVEY.md section 8d so that no layer is the identity.
+
+    python bench.py --gpus N --steps K --warmup W
+For N > 1 the driver launches one rank per GPU with torch.distributed.run; the batch is sharded by rows
+(weak scaling: 65 536 rows per rank), the only collective is the 16-byte NLL all-reduce.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+DIM, HIDDEN, BLOCKS, BINS, LAYERS, BATCH = 64, 128, 2, 8, 32, 65536
+SIGMA = 0.01
+
+
+def build_c2_model(num_layers=LAYERS, dim=DIM, hidden=HIDDEN, blocks=BLOCKS, bins=BINS, seed=0, sigma=SIGMA, lib=None):
+    """The benchmark model.  `lib` may be the reference package (tests only) -- same constructor calls."""
+    if lib is None:
+        import normflows_amd as lib
+    torch.manual_seed(seed)
+    flows = []
+    for _ in range(num_layers):
+        flows += [lib.flows.CoupledRationalQuadraticSpline(dim, blocks, hidden, num_bins=bins)]
+        flows += [lib.flows.LULinearPermute(dim)]
+    q0 = lib.distributions.DiagGaussian(dim, trainable=False)
+    model = lib.NormalizingFlow(q0, flows)
+    perturb_(model, sigma)
+    return model
+
+
+def perturb_(model, sigma, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(sigma * torch.randn(p.shape, generator=g, dtype=p.dtype))
+    return g
+
+
+def c2_inputs(batch=BATCH, dim=DIM, seed=1234, rank=0):
+    g = torch.Generator().manual_seed(seed + 7919 * (rank + 1))
+    return torch.randn(batch, dim, generator=g)
+
+
+def state_to_numpy(model):
+    return {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+
+
+# ---- algorithmic work per sample of one full pass ------------------
+def c2_flops_per_sample(dim=DIM, hidden=HIDDEN, blocks=BLOCKS, bins=BINS, layers=LAYERS):
+    nI = (dim + 1) // 2
+    nT = dim // 2
+    out = nT * (3 * bins - 1)
+    cond = 2 * (nI * hidden + 2 * blocks * hidden * hidden + hidden * out)
+    lu = 2 * 2 * dim * dim  # two dense 64x64 mat-vecs, SURVEY.md 8d
+    return layers * (cond + lu)
+
+
+def c2_bytes_per_sample(dim=DIM, bins=BINS, layers=LAYERS, fused=False):
+    nT = dim // 2
+    rqs = 2 * dim * 4 + 8 + (0 if fused else nT * (3 * bins - 1) * 4)
+    lu = 2 * dim * 4 + 8
+    return layers * (rqs + lu) + dim * 4 + 4
+
+
+def _events_ms(fn, reps):
+    """Average duration (ms) of fn() measured with HIP events on torch's current stream (the launch stream)."""
+    start = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+    stop = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+    for i in range(reps):
+        start[i].record()
+        fn()
+        stop[i].record()
+    torch.cuda.synchronize()
+    ts = sorted(s.elapsed_time(e) for s, e in zip(start, stop))
+    return sum(ts) / len(ts), ts[len(ts) // 2]
+
+
+def kernel_breakdown(model, x, reps=3):
+    """Per-kernel-class HIP-event timing of one eager log_prob pass (instrumented run, not the timed region)."""
+    import normflows_amd as nfa
+    from normflows_amd import ops
+    acc = {"rqs_coupling": [], "lu_linear_permute": [], "conditioner": []}
+    z = x
+    log_q = torch.zeros(len(x), device=x.device)
+    for _ in range(reps):
+        z = x
+        for flow in reversed(model.flows):
+            if isinstance(flow, nfa.flows.CoupledRationalQuadraticSpline):
+                p = flow.prqct
+                cond_holder = {}
+                ms, _ = _events_ms(lambda: cond_holder.__setitem__("c", p._conditioner(z, None)), 1)
+                acc["conditioner"].append(ms)
+                uw, uh, ud = p._uncond()
+                out = {}
+                ms, _ = _events_ms(lambda: out.__setitem__("y", ops.rqs_coupling(
+                    z, cond_holder["c"], uw, uh, ud, p.identity_features, p.transform_features, p.num_bins, 0,
+                    logdet=log_q, acc=1, **p._kernel_kwargs())[0]), 1)
+                acc["rqs_coupling"].append(ms)
+                z = out["y"]
+            else:
+                out = {}
+                ms, _ = _events_ms(lambda: out.__setitem__("y", flow._run(z, True, log_q, +1)), 1)
+                acc["lu_linear_permute"].append(ms)
+                z = out["y"]
+    return {k: (sum(v) / len(v) if v else 0.0, len(v) // reps) for k, v in acc.items()}
+
+
+def cpu_baseline(model, rows):
+    """The CPU oracle (a port of the reference algorithm, OpenMP over rows) timed on this host on a bounded sample
+    of the same workload: log_prob of the same 32-layer model on `rows` benchmark rows."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nf_oracle
+    ora = nf_oracle.OracleNSF(state_to_numpy(model), num_layers=len(model.flows), K=BINS, tail_bound=3.0)
+    x = c2_inputs(rows, DIM).numpy()
+    ora.log_prob(x[: min(rows, 256)])  # warm-up (page in, thread pool)
+    t0 = time.perf_counter()
+    lp = ora.log_prob(x)
+    dt = time.perf_counter() - t0
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": rows / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "log_prob of the same %d-layer model on %d rows (oracle/nf_oracle.c, OpenMP, %.1f s)"
+                      % (len(model.flows) // 2, rows, dt), "nll_nats_per_dim": float(-lp.mean() / DIM)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH, help="rows per GPU")
+    ap.add_argument("--layers", type=int, default=LAYERS)
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=16384, help="rows of the same workload timed on the host oracle")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    import normflows_amd as nfa
+    from normflows_amd import dp
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    model = build_c2_model(num_layers=args.layers).to(dev)
+    x = c2_inputs(args.batch, DIM, rank=rank).to(dev)
+    model.use_graphs(not args.no_graph)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1 if not args.no_graph else 0)):
+            lp = model.log_prob(x)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            lp = model.log_prob(x)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    nll = float(dp.global_nll(lp).item()) / DIM      # the single 16-byte all-reduce of the path
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * args.batch * args.steps / elapsed
+
+    out = {
+        "metric": "samples/sec + NLL (nats/dim), 32-layer RQ-NSF d=64 B=65536",
+        "value": value, "unit": "samples/s", "nll_nats_per_dim": nll,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: log_prob of %d x [CoupledRQS(d=64, 2 blocks, 128 hidden, K=8, "
+                               "tail 3) + LULinearPermute(64)] + DiagGaussian, batch %d rows/GPU, N(0,I) inputs, "
+                               "sigma=0.01 perturbed seeded weights" % (args.layers, args.batch),
+                   "rows_per_gpu": args.batch, "global_rows": world * args.batch, "layers": args.layers,
+                   "launch": "eager" if args.no_graph else "hipGraph replay", "parallelism": "dp%d" % world},
+    }
+    if rank == 0:
+        flops = c2_flops_per_sample(layers=args.layers)
+        out["end_to_end"] = {"tflops": flops * value / 1e12 / world, "frac_of_fp32_mfma_peak":
+                             flops * value / world / 157.3e12, "flop_per_sample": flops}
+        if not args.no_breakdown:
+            model.use_graphs(False)
+            with torch.no_grad():
+                bd = kernel_breakdown(model, x)
+            model.use_graphs(not args.no_graph)
+            out["kernel_ms"] = {k: {"avg_ms": v[0], "launches_per_pass": v[1]} for k, v in bd.items()}
+            rqs_ms = bd["rqs_coupling"][0]
+            alg_bytes = (2 * DIM * 4 + (DIM // 2) * (3 * BINS - 1) * 4 + 8) * args.batch
+            ach = alg_bytes / (rqs_ms * 1e-3) / 1e9
+            out["roofline"] = {"kernel": "nf::rqs_coupling_kernel<float>", "bound": "hbm", "achieved": ach,
+                               "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                               "bytes_per_launch": alg_bytes, "avg_launch_ms": rqs_ms}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(model, args.cpu_rows)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

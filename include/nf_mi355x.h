@@ -1,0 +1,185 @@
+/*
+ * nf_mi355x.h -- C ABI of libnf_mi355x.so: the MI355X (gfx950 / CDNA4) implementation of the
+ * coupling-layer forward/inverse + log|det J| hot path of normflows 1.7.3.
+ *
+ * Every entry point replaces one reference function (cited as file:line relative to the normflows
+ * repository root).  The library is the drop-in boundary: plain pointers and sizes only, no torch
+ * types.  A Python binding (ctypes) lives in normalizing-flows_amd/_lib.py; the stub a normflows
+ * maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - All data pointers are DEVICE pointers (HBM) owned by the caller.  Kernels never allocate,
+ *     free or retain pointers.  Outputs must not alias inputs unless a function says so.
+ *   - `stream` is a hipStream_t passed as void*.  Calls only enqueue work on it and return; no host
+ *     synchronisation, no internal streams.  Safe to capture into a hipGraph.
+ *   - `dtype`: NF_F32 or NF_F64 selects the element type of every floating-point buffer of the call.
+ *   - Return value: NF_OK (0) or a negative errno-style code; nf_strerror() explains it.
+ *   - `acc` (log-det accumulation mode): NF_LD_WRITE  logdet[b]  = ld_b
+ *                                        NF_LD_ADD    logdet[b] += ld_b   (core.py:193-195 `log_q += log_det`)
+ *                                        NF_LD_SUB    logdet[b] -= ld_b   (core.py:177-179 `log_q -= log_det`)
+ *   - Direction naming follows normflows: "forward" is generative (z -> x), "inverse" is
+ *     normalising (x -> z); log_prob runs every layer's inverse, sample runs every layer's forward.
+ */
+#ifndef NF_MI355X_H
+#define NF_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *nf_stream_t; /* hipStream_t */
+
+enum { NF_OK = 0, NF_EIO = -5, NF_EFAULT = -14, NF_EINVAL = -22, NF_ERANGE = -34, NF_ENOTSUP = -95 };
+enum { NF_F32 = 0, NF_F64 = 1 };
+enum { NF_LD_WRITE = 0, NF_LD_ADD = 1, NF_LD_SUB = -1 };
+enum { NF_TAILS_NONE = 0, NF_TAILS_LINEAR = 1, NF_TAILS_CIRCULAR = 2 };
+enum { NF_SCALE_EXP = 0, NF_SCALE_SIGMOID = 1, NF_SCALE_SIGMOID_INV = 2, NF_SCALE_NONE = 3 };
+enum { NF_RQS_DENSITY = 0, NF_RQS_SAMPLE_IDENTITY = 1, NF_RQS_SAMPLE_TRANSFORM = 2 };
+
+/* Library identification / diagnostics. */
+const char *nf_version(void);
+const char *nf_strerror(int code);
+/* Largest number of spline bins the compiled kernels accept. */
+int nf_max_bins(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rational-quadratic spline, element-wise.
+ * Replaces normflows/utils/splines.py:16-97 (unconstrained_rational_quadratic_spline, tails =
+ * linear/circular) and :100-219 (rational_quadratic_spline, tails = NF_TAILS_NONE).
+ *
+ * N elements; element n reads K unnormalised widths at w + n*ldw, K heights at h + n*ldh and
+ * (K-1 | K | K+1) unnormalised derivatives (linear | circular | none) at d + n*ldd (strides in
+ * elements, so the three blocks may be slices of one (N, 3K-1) conditioner output).
+ * Widths and heights are divided by `wh_div` first (nsf/coupling.py:334-339; pass 1.0 for none).
+ * tails != NONE: the spline acts on [-tail_bound, tail_bound]^2, elements outside (and NaN/inf)
+ * pass through with logabsdet 0.  tails == NONE: the spline maps [left,right] -> [bottom,top]; the
+ * reference raises on out-of-domain inputs (torch.gather index error), here the bin index is clamped.
+ * inverse = 0: y = spline(x); inverse = 1: y = spline^{-1}(x).  logabsdet may be NULL.
+ */
+int nf_rqs_spline(const void *x, const void *w, int64_t ldw, const void *h, int64_t ldh, const void *d,
+                  int64_t ldd, void *y, void *logabsdet, int64_t N, int K, int tails, double tail_bound,
+                  double left, double right, double bottom, double top, double min_bin_width,
+                  double min_bin_height, double min_derivative, double wh_div, int inverse, int dtype,
+                  nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * NSF coupling transform on (B, D) rows with conditioner outputs materialised in HBM.
+ * Replaces normflows/flows/neural_spline/coupling.py:71-128 (Coupling.forward/inverse: index split,
+ * coupling transform, unconditional transform of the identity half, scatter), :150-164
+ * (PiecewiseCoupling._coupling_transform, row-sum of logabsdet), :221-253
+ * (PiecewiseRationalQuadraticCDF._spline, batch-shared parameters), :329-362
+ * (PiecewiseRationalQuadraticCoupling._piecewise_cdf) for 2-D inputs.
+ *
+ *   x, y          (B, D) row-major.  y receives every column the mode owns (see below).
+ *   identity_idx  (nI) int64, transform_idx (nT) int64: the `identity_features` /
+ *                 `transform_features` buffers (coupling.py:42-47).
+ *   cond          (B, nT, M) conditioner output, M = 3K-1 | 3K | 3K+1 (linear | circular | none);
+ *                 row layout [w_0..w_{K-1} | h_0..h_{K-1} | d...].  Unused (may be NULL) in
+ *                 NF_RQS_SAMPLE_IDENTITY.
+ *   uw, uh, ud    unconditional transform parameters (nI,K), (nI,K), (nI,M-2K), or all NULL when the
+ *                 layer has no unconditional transform (identity columns are then copied).
+ *   mode  NF_RQS_DENSITY           prqct.forward (coupling.py:71-98):  y[:,T] = spline(x[:,T]; cond),
+ *                                   y[:,I] = cdf(x[:,I]); ld = sum of both.
+ *         NF_RQS_SAMPLE_IDENTITY   first half of prqct.inverse (coupling.py:110-116):
+ *                                   y[:,I] = cdf^{-1}(x[:,I]); ld = its row sum; y[:,T] untouched.
+ *         NF_RQS_SAMPLE_TRANSFORM  second half (coupling.py:118-128):
+ *                                   y[:,T] = spline^{-1}(x[:,T]; cond); ld = its row sum; y[:,I] untouched.
+ *   logdet (B): combined with ld according to `acc`.
+ */
+int nf_rqs_coupling(const void *x, void *y, void *logdet, const void *cond, const void *uw, const void *uh,
+                    const void *ud, const int64_t *identity_idx, int nI, const int64_t *transform_idx,
+                    int nT, int64_t B, int D, int K, int tails, double tail_bound, double min_bin_width,
+                    double min_bin_height, double min_derivative, double wh_div, int mode, int acc,
+                    int dtype, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LULinearPermute.  Replaces normflows/flows/mixing.py:535-563 (LULinearPermute), :229-244
+ * (_Permutation), :402-473 (_LULinear forward_no_cache / inverse_no_cache), :514-532 (upper_diag,
+ * logabsdet).
+ *   perm (D) int64 = `permutation._permutation`; lower_entries, upper_entries (D(D-1)/2) in
+ *   np.tril_indices(D,-1) / np.triu_indices(D,1) order; unconstrained_upper_diag (D); bias (D).
+ *   direction 0 = density  (LULinearPermute.inverse): y = L (U x[:,perm]) + bias, ld = +sum log diag
+ *   direction 1 = sample   (LULinearPermute.forward): solve L, U on (x - bias), y[:,perm[j]] = t[:,j],
+ *                                                      ld = -sum log diag
+ *   diag = softplus(unconstrained_upper_diag) + eps.
+ */
+int nf_lu_linear_permute(const void *x, void *y, void *logdet, const int64_t *perm, const void *lower_entries,
+                         const void *upper_entries, const void *unconstrained_upper_diag, const void *bias,
+                         int64_t B, int D, double eps, int direction, int acc, int dtype, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * MaskedAffineFlow (RealNVP).  Replaces normflows/flows/affine/coupling.py:209-229.
+ *   z, y (B, inner); b (inner) mask; s, t (B, inner) outputs of the scale / translation maps evaluated
+ *   on b*z, either may be NULL (= zeros, coupling.py:199-207).  Non-finite s/t become NaN (:212-215).
+ *   direction 0 = forward:  y = b z + (1-b)(z e^{s} + t),   ld = +sum (1-b) s
+ *   direction 1 = inverse:  y = b z + (1-b)(z - t) e^{-s},  ld = -sum (1-b) s
+ */
+int nf_masked_affine(const void *z, const void *b, const void *s, const void *t, void *y, void *logdet,
+                     int64_t B, int64_t inner, int direction, int acc, int dtype, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * AffineCoupling + Split/Merge (AffineCouplingBlock).  Replaces normflows/flows/affine/coupling.py:117-171
+ * and :232-267 together with flows/reshape.py:30-33, 57-61 (channel / channel_inv split and merge).
+ *   z, y   (B, C, HW) contiguous.  The first `c1` channels (channel mode) or the last `c1` channels
+ *          (channel_inv: flip = 1) are z1 (copied), the remaining c2 = C - c1 channels are z2.
+ *   param  (B, P, HW): output of param_map(z1); P = 2*c2 interleaved shift = param[:,0::2],
+ *          scale_ = param[:,1::2] (coupling.py:131-132) or P = c2 (pure shift) when
+ *          scale_map == NF_SCALE_NONE.
+ *   direction 0 = forward, 1 = inverse.  ld = per-sample sum over c2*HW elements.
+ */
+int nf_affine_coupling(const void *z, const void *param, void *y, void *logdet, int64_t B, int C, int c1,
+                       int flip, int64_t HW, int scale_map, int direction, int acc, int dtype,
+                       nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * AffineConstFlow / ActNorm.  Replaces normflows/flows/affine/coupling.py:38-54 and the data-dependent
+ * initialisation of flows/normalization.py:19-39.
+ *   z, y (B, C, HW); s, t (C).  direction 0 = forward y = z e^{s} + t, 1 = inverse y = (z - t) e^{-s}.
+ *   logdet_scalar (1 element, may be NULL) receives  +-HW * sum(s)  (0-dim log_det of the reference).
+ *   logdet (B) (may be NULL) is combined with the same value according to `acc`.
+ * nf_actnorm_stats: per-channel mean and UNBIASED std over (B, HW) (torch.std default).
+ * nf_actnorm_init: writes s, t from mean/std:  direction 0 (forward-first): s = -log(std+1e-6),
+ *   t = -mean e^{s};  direction 1 (inverse-first): s = log(std+1e-6), t = mean.
+ */
+int nf_actnorm(const void *z, const void *s, const void *t, void *y, void *logdet_scalar, void *logdet,
+               int64_t B, int C, int64_t HW, int direction, int acc, int dtype, nf_stream_t stream);
+int nf_actnorm_stats(const void *z, void *mean, void *std_unbiased, int64_t B, int C, int64_t HW, int dtype,
+                     nf_stream_t stream);
+int nf_actnorm_init(const void *mean, const void *std_unbiased, void *s, void *t, int C, int direction,
+                    int dtype, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Invertible1x1Conv.  Replaces normflows/flows/mixing.py:88-133.
+ * nf_inv1x1_assemble: W (C,C) from the LU parametrisation (P, L, U, sign_S, log_S) (:88-104);
+ *   inverse = 0:  W = P (tril(L,-1)+I) (triu(U,1)+diag(sign_S e^{log_S}))      (density direction)
+ *   inverse = 1:  W = U'^{-1} L'^{-1} P^T with the triangular inverses taken in fp64 (:94-101)
+ *   logdet_unit (1 element): +sum(log_S) (inverse=0) or -sum(log_S) (inverse=1).
+ * nf_inv1x1_conv: y[b,o,p] = sum_c W[o,c] z[b,c,p];  logdet_scalar = logdet_unit * HW (may be NULL);
+ *   logdet (B) (may be NULL) combined according to `acc`.
+ */
+int nf_inv1x1_assemble(const void *P, const void *L, const void *U, const void *sign_S, const void *log_S,
+                       void *W, void *logdet_unit, int C, int inverse, int dtype, nf_stream_t stream);
+int nf_inv1x1_conv(const void *z, const void *W, const void *logdet_unit, void *y, void *logdet_scalar,
+                   void *logdet, int64_t B, int C, int64_t HW, int acc, int dtype, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * DiagGaussian.log_prob.  Replaces normflows/distributions/base.py:94-103.
+ *   z (B, d); loc, log_scale (d);  log_p[b] = -d/2 log(2 pi) - sum_j (log_scale_j + 0.5 ((z-loc)/e^{log_scale})^2)
+ *   `log_scale_shift` is added to log_scale (temperature, base.py:95-98).  out (B) combined per `acc`.
+ */
+int nf_diag_gaussian_log_prob(const void *z, const void *loc, const void *log_scale, double log_scale_shift,
+                              void *out, int64_t B, int64_t d, int acc, int dtype, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Squeeze (flows/reshape.py:116-128).  direction 0 = forward (C,H,W)->(C/4,2H,2W),
+ * 1 = inverse (C,H,W)->(4C,H/2,W/2).  z, y contiguous NCHW with the shapes implied.
+ */
+int nf_squeeze(const void *z, void *y, int64_t B, int C, int H, int W, int direction, int dtype,
+               nf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NF_MI355X_H */

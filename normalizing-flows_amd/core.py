@@ -1,0 +1,255 @@
+"""Model containers: the callers of the hot path.
+
+Mirrors normflows/core.py:9-213 (NormalizingFlow) and :455-655 (MultiscaleFlow): same constructor
+signatures, method names, return values and state_dict layout (`q0.*`, `flows.{i}.*`, `merges.*`), so
+reference checkpoints load with strict=True and user code written against nf.NormalizingFlow keeps working.
+
+Differences that are deliberate (MI355X-first):
+  * the per-layer `log_q += log_det` is folded into each layer's kernel through the `_run` accumulate
+    protocol (flows/base.py) instead of one extra elementwise launch per layer;
+  * `use_graphs(True)` records a whole log_prob / sample pass (64+ launches for the 32-layer RQ-NSF) into a
+    hipGraph per batch shape and replays it, removing the per-launch host overhead;
+  * inference only: kernels do not build an autograd graph (forward_kld returns the loss VALUE).
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .flows.base import run_flow
+
+
+class _GraphCache:
+    """hipGraph replay of a fixed-shape pass.  Inputs are copied into a static buffer; outputs are static."""
+
+    def __init__(self):
+        self.enabled = False
+        self.graphs = {}
+
+    def clear(self):
+        self.graphs = {}
+
+    def run(self, key, fn, *inputs):
+        if not self.enabled:
+            return fn(*inputs)
+        entry = self.graphs.get(key)
+        if entry is None:
+            static_in = [t.clone() for t in inputs]
+            # warm-up on a side stream (also triggers lazy initialisations such as ActNorm's)
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                fn(*static_in)
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                static_out = fn(*static_in)
+            entry = (g, static_in, static_out)
+            self.graphs[key] = entry
+        g, static_in, static_out = entry
+        for dst, src in zip(static_in, inputs):
+            dst.copy_(src)
+        g.replay()
+        return static_out
+
+
+class NormalizingFlow(nn.Module):
+    """Normalizing flow model (core.py:9-213)."""
+
+    def __init__(self, q0, flows, p=None):
+        super().__init__()
+        self.q0 = q0
+        self.flows = nn.ModuleList(flows)
+        self.p = p
+        self._graphs = _GraphCache()
+
+    # -- MI355X extensions ---------------------------------------------------------------------------------
+    def use_graphs(self, mode=True):
+        """Replay log_prob / sample_from_noise as hipGraphs (one per batch shape)."""
+        self._graphs.enabled = bool(mode)
+        if not mode:
+            self._graphs.clear()
+        return self
+
+    def _apply(self, fn, *a, **k):  # .to() / .double() invalidate recorded graphs
+        self._graphs.clear()
+        return super()._apply(fn, *a, **k)
+
+    # -- reference API -------------------------------------------------------------------------------------
+    def forward(self, z):
+        for flow in self.flows:
+            z, _ = flow(z)
+        return z
+
+    def forward_and_log_det(self, z):
+        log_det = torch.zeros(len(z), dtype=z.dtype, device=z.device)
+        for flow in self.flows:
+            z = run_flow(flow, z, False, log_det, +1)
+        return z, log_det
+
+    def inverse(self, x):
+        for i in range(len(self.flows) - 1, -1, -1):
+            x, _ = self.flows[i].inverse(x)
+        return x
+
+    def inverse_and_log_det(self, x):
+        log_det = torch.zeros(len(x), dtype=x.dtype, device=x.device)
+        for i in range(len(self.flows) - 1, -1, -1):
+            x = run_flow(self.flows[i], x, True, log_det, +1)
+        return x, log_det
+
+    def _log_prob_impl(self, x):
+        log_q = torch.zeros(len(x), dtype=x.dtype, device=x.device)
+        z = x
+        for i in range(len(self.flows) - 1, -1, -1):
+            z = run_flow(self.flows[i], z, True, log_q, +1)
+        if hasattr(self.q0, "_log_prob_acc"):
+            self.q0._log_prob_acc(z, log_q, +1)
+        else:
+            log_q += self.q0.log_prob(z)
+        return log_q
+
+    def log_prob(self, x):
+        """log q(x): every layer's inverse, accumulated log-dets, base log-density (core.py:182-197)."""
+        return self._graphs.run(("log_prob", tuple(x.shape), x.dtype), self._log_prob_impl, x)
+
+    def forward_kld(self, x):
+        """-mean(log q(x)) (core.py:87-102); value only (no autograd)."""
+        return -torch.mean(self.log_prob(x))
+
+    def _sample_impl(self, eps):
+        z, log_q = self.q0.from_noise(eps)
+        for flow in self.flows:
+            z = run_flow(flow, z, False, log_q, -1)
+        return z, log_q
+
+    def sample_from_noise(self, eps):
+        """sample() with the base standard-normal noise given (deterministic; used by parity tests)."""
+        return self._graphs.run(("sample", tuple(eps.shape), eps.dtype), self._sample_impl, eps)
+
+    def sample(self, num_samples=1):
+        """(x, log q(x)) for x ~ q (core.py:167-180)."""
+        if hasattr(self.q0, "from_noise"):
+            eps = torch.randn((num_samples,) + tuple(self.q0.shape), dtype=self.q0.loc.dtype,
+                              device=self.q0.loc.device)
+            return self.sample_from_noise(eps)
+        z, log_q = self.q0(num_samples)
+        for flow in self.flows:
+            z = run_flow(flow, z, False, log_q, -1)
+        return z, log_q
+
+    def reverse_kld(self, num_samples=1, beta=1.0, score_fn=True):
+        """mean(log q) - beta mean(log p) on samples of q (core.py:104-131); value only."""
+        z, log_q = self.sample(num_samples)
+        log_p = self.p.log_prob(z)
+        return torch.mean(log_q) - beta * torch.mean(log_p)
+
+    def save(self, path):
+        torch.save(self.state_dict(), path)
+
+    def load(self, path):
+        self.load_state_dict(torch.load(path))
+
+
+class MultiscaleFlow(nn.Module):
+    """Multi-scale (RealNVP / Glow) flow (core.py:455-655)."""
+
+    def __init__(self, q0, flows, merges, transform=None, class_cond=True):
+        super().__init__()
+        self.q0 = nn.ModuleList(q0)
+        self.num_levels = len(self.q0)
+        self.flows = torch.nn.ModuleList([nn.ModuleList(flow) for flow in flows])
+        self.merges = torch.nn.ModuleList(merges)
+        self.transform = transform
+        self.class_cond = class_cond
+
+    def forward_kld(self, x, y=None):
+        return -torch.mean(self.log_prob(x, y))
+
+    def forward(self, x, y=None):
+        return -self.log_prob(x, y)
+
+    def forward_and_log_det(self, z):
+        log_det = torch.zeros(len(z[0]), dtype=z[0].dtype, device=z[0].device)
+        for i in range(len(self.q0)):
+            if i == 0:
+                z_ = z[0]
+            else:
+                z_, _ = self.merges[i - 1]([z_, z[i]])
+            for flow in self.flows[i]:
+                z_ = run_flow(flow, z_, False, log_det, +1)
+        if self.transform is not None:
+            z_ = run_flow(self.transform, z_, False, log_det, +1)
+        return z_, log_det
+
+    def inverse_and_log_det(self, x):
+        log_det = torch.zeros(len(x), dtype=x.dtype, device=x.device)
+        if self.transform is not None:
+            x = run_flow(self.transform, x, True, log_det, +1)
+        z = [None] * len(self.q0)
+        for i in range(len(self.q0) - 1, -1, -1):
+            for flow in reversed(self.flows[i]):
+                x = run_flow(flow, x, True, log_det, +1)
+            if i == 0:
+                z[i] = x
+            else:
+                [x, z[i]], _ = self.merges[i - 1].inverse(x)
+        return z, log_det
+
+    def sample(self, num_samples=1, y=None, temperature=None):
+        if temperature is not None:
+            self.set_temperature(temperature)
+        for i in range(len(self.q0)):
+            if self.class_cond:
+                z_, log_q_ = self.q0[i](num_samples, y)
+            else:
+                z_, log_q_ = self.q0[i](num_samples)
+            if i == 0:
+                log_q = log_q_
+                z = z_
+            else:
+                log_q += log_q_
+                z, _ = self.merges[i - 1]([z, z_])
+            for flow in self.flows[i]:
+                z = run_flow(flow, z, False, log_q, -1)
+        if self.transform is not None:
+            z = run_flow(self.transform, z, False, log_q, -1)
+        if temperature is not None:
+            self.reset_temperature()
+        return z, log_q
+
+    def log_prob(self, x, y=None):
+        """core.py:588-616."""
+        log_q = torch.zeros(len(x), dtype=x.dtype, device=x.device)
+        z = x
+        if self.transform is not None:
+            z = run_flow(self.transform, z, True, log_q, +1)
+        for i in range(len(self.q0) - 1, -1, -1):
+            for j in range(len(self.flows[i]) - 1, -1, -1):
+                z = run_flow(self.flows[i][j], z, True, log_q, +1)
+            if i > 0:
+                [z, z_], _ = self.merges[i - 1].inverse(z)
+            else:
+                z_ = z
+            if self.class_cond:
+                log_q += self.q0[i].log_prob(z_, y)
+            elif hasattr(self.q0[i], "_log_prob_acc"):
+                self.q0[i]._log_prob_acc(z_.contiguous(), log_q, +1)
+            else:
+                log_q += self.q0[i].log_prob(z_)
+        return log_q
+
+    def save(self, path):
+        torch.save(self.state_dict(), path)
+
+    def load(self, path):
+        self.load_state_dict(torch.load(path))
+
+    def set_temperature(self, temperature):
+        for q0 in self.q0:
+            if hasattr(q0, "temperature"):
+                q0.temperature = temperature
+            else:
+                raise NotImplementedError("One base function does not support temperature annealed sampling")
+
+    def reset_temperature(self):
+        self.set_temperature(None)

@@ -1,0 +1,354 @@
+// affine.hip -- affine family: MaskedAffineFlow, AffineCoupling(+Split/Merge), AffineConstFlow/ActNorm,
+// DiagGaussian.log_prob, Squeeze.  gfx950 only.  All kernels are HBM-bound streams: one read of every input
+// element, one write of every output element, one fp value of log-det per sample.
+//
+// Reference behaviour: normflows/flows/affine/coupling.py:38-54, :117-171, :209-229, :232-267;
+// flows/normalization.py:19-39; flows/reshape.py:30-33, :57-61, :116-128; distributions/base.py:94-103.
+#include "common.hpp"
+
+namespace nf {
+
+// ---------------------------------------------------------------------------------------------------------
+// MaskedAffineFlow: one workgroup per sample row-chunk; per-sample reduction of (1-b)*s.
+template <typename T>
+__global__ void __launch_bounds__(256)
+masked_affine_kernel(const T *__restrict__ z, const T *__restrict__ b, const T *__restrict__ s,
+                     const T *__restrict__ t, T *__restrict__ y, T *__restrict__ logdet, int64_t B, int64_t inner,
+                     int direction, int acc) {
+    __shared__ T sred[16];
+    if (inner <= 64) {
+        // small rows (2-D toy problems): one lane per sample, no cross-lane reduction
+        for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < B; r += (int64_t)gridDim.x * blockDim.x) {
+            T ld = T(0);
+            for (int64_t i = 0; i < inner; ++i) {
+                const int64_t o = r * inner + i;
+                const T bi = b[i], zi = z[o];
+                T si = s ? s[o] : T(0), ti = t ? t[o] : T(0);
+                if (!M<T>::finite(si)) si = M<T>::nan();
+                if (!M<T>::finite(ti)) ti = M<T>::nan();
+                const T zm = bi * zi;
+                if (direction == 0) y[o] = zm + (T(1) - bi) * (zi * M<T>::exp(si) + ti);
+                else y[o] = zm + (T(1) - bi) * (zi - ti) * M<T>::exp(-si);
+                ld += (T(1) - bi) * si;
+            }
+            ld_store(logdet + r, direction == 0 ? ld : -ld, acc);
+        }
+        return;
+    }
+    for (int64_t r = blockIdx.x; r < B; r += gridDim.x) {
+        T ld = T(0);
+        for (int64_t i = threadIdx.x; i < inner; i += blockDim.x) {
+            const int64_t o = r * inner + i;
+            const T bi = b[i], zi = z[o];
+            T si = s ? s[o] : T(0), ti = t ? t[o] : T(0);
+            if (!M<T>::finite(si)) si = M<T>::nan();
+            if (!M<T>::finite(ti)) ti = M<T>::nan();
+            const T zm = bi * zi;
+            if (direction == 0) y[o] = zm + (T(1) - bi) * (zi * M<T>::exp(si) + ti);
+            else y[o] = zm + (T(1) - bi) * (zi - ti) * M<T>::exp(-si);
+            ld += (T(1) - bi) * si;
+        }
+        ld = block_sum(ld, sred);
+        if (threadIdx.x == 0) ld_store(logdet + r, direction == 0 ? ld : -ld, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// AffineCouplingBlock: one workgroup per sample.  z1 channels are copied, z2 channels transformed with the
+// interleaved (shift, scale_) parameter planes.
+template <typename T>
+__global__ void __launch_bounds__(256)
+affine_coupling_kernel(const T *__restrict__ z, const T *__restrict__ param, T *__restrict__ y,
+                       T *__restrict__ logdet, int64_t B, int C, int c1, int flip, int64_t HW, int scale_map,
+                       int direction, int acc) {
+    __shared__ T sred[16];
+    const int c2 = C - c1;
+    const int z1_off = flip ? c2 : 0, z2_off = flip ? 0 : c1;  // channel offsets inside a sample
+    const int P = scale_map == NF_SCALE_NONE ? c2 : 2 * c2;
+    const int64_t n1 = (int64_t)c1 * HW, n2 = (int64_t)c2 * HW;
+    for (int64_t r = blockIdx.x; r < B; r += gridDim.x) {
+        const T *zr = z + r * (int64_t)C * HW;
+        T *yr = y + r * (int64_t)C * HW;
+        const T *pr = param + r * (int64_t)P * HW;
+        for (int64_t i = threadIdx.x; i < n1; i += blockDim.x) yr[(int64_t)z1_off * HW + i] = zr[(int64_t)z1_off * HW + i];
+        T ld = T(0);
+        for (int64_t i = threadIdx.x; i < n2; i += blockDim.x) {
+            const int64_t c = i / HW, p = i - c * HW;
+            const T v = zr[(int64_t)z2_off * HW + i];
+            T o;
+            if (scale_map == NF_SCALE_NONE) {
+                const T sh = pr[i];
+                o = direction == 0 ? v + sh : v - sh;
+            } else {
+                const T sh = pr[(2 * c) * HW + p], sc = pr[(2 * c + 1) * HW + p];
+                if (scale_map == NF_SCALE_EXP) {
+                    o = direction == 0 ? v * M<T>::exp(sc) + sh : (v - sh) * M<T>::exp(-sc);
+                    ld += sc;  // +sum (forward) / -sum (inverse)
+                } else {
+                    const T sg = sigmoid(sc + T(2));
+                    const T lg = M<T>::log(sg);
+                    if (scale_map == NF_SCALE_SIGMOID) {
+                        o = direction == 0 ? v / sg + sh : (v - sh) * sg;
+                        ld -= lg;  // forward: -sum log scale; inverse: +sum log scale
+                    } else {
+                        o = direction == 0 ? v * sg + sh : (v - sh) / sg;
+                        ld += lg;
+                    }
+                }
+            }
+            yr[(int64_t)z2_off * HW + i] = o;
+        }
+        ld = block_sum(ld, sred);
+        if (threadIdx.x == 0) ld_store(logdet + r, direction == 0 ? ld : -ld, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// AffineConstFlow / ActNorm apply.  logdet value = +-HW * sum(s) is recomputed per workgroup (C words).
+template <typename T>
+__global__ void __launch_bounds__(256)
+actnorm_kernel(const T *__restrict__ z, const T *__restrict__ s, const T *__restrict__ t, T *__restrict__ y,
+               T *__restrict__ logdet_scalar, T *__restrict__ logdet, int64_t B, int C, int64_t HW, int direction,
+               int acc) {
+    __shared__ T sred[16];
+    T part = T(0);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) part += s[c];
+    T ssum = block_sum(part, sred);
+    const T ldv = (direction == 0 ? T(1) : T(-1)) * (T)HW * ssum;
+    const int64_t N = B * (int64_t)C * HW;
+    const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gstride) {
+        const int c = (int)((i / HW) % C);
+        const T v = z[i];
+        y[i] = direction == 0 ? v * M<T>::exp(s[c]) + t[c] : (v - t[c]) * M<T>::exp(-s[c]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && logdet_scalar) *logdet_scalar = ldv;
+    if (logdet)
+        for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < B; r += gstride) ld_store(logdet + r, ldv, acc);
+}
+
+// Per-channel mean and unbiased std over (B, HW): one workgroup per channel, fp64 accumulation of the sum
+// then of the squared deviations (two passes, like torch.std's numerically safe formulation).
+template <typename T>
+__global__ void __launch_bounds__(256)
+actnorm_stats_kernel(const T *__restrict__ z, T *__restrict__ mean, T *__restrict__ stdu, int64_t B, int C, int64_t HW) {
+    __shared__ double sred[16];
+    const int c = blockIdx.x;
+    const int64_t n = B * HW;
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const int64_t b = i / HW, p = i - b * HW;
+        acc += (double)z[(b * C + c) * HW + p];
+    }
+    const double mu = block_sum(acc, sred) / (double)n;
+    double acc2 = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const int64_t b = i / HW, p = i - b * HW;
+        const double dlt = (double)z[(b * C + c) * HW + p] - mu;
+        acc2 += dlt * dlt;
+    }
+    const double var = block_sum(acc2, sred) / (double)(n - 1);  // n == 1 -> nan, as torch
+    if (threadIdx.x == 0) {
+        mean[c] = (T)mu;
+        stdu[c] = (T)::sqrt(var);
+    }
+}
+
+template <typename T>
+__global__ void actnorm_init_kernel(const T *__restrict__ mean, const T *__restrict__ stdu, T *__restrict__ s,
+                                    T *__restrict__ t, int C, int direction) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (direction == 0) {  // normalization.py:23-27
+        const T sv = -M<T>::log(stdu[c] + T(1e-6));
+        s[c] = sv;
+        t[c] = -mean[c] * M<T>::exp(sv);
+    } else {  // normalization.py:35-37
+        s[c] = M<T>::log(stdu[c] + T(1e-6));
+        t[c] = mean[c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// DiagGaussian.log_prob: one wave per sample row for d >= 64, one lane per row otherwise.
+template <typename T>
+__global__ void __launch_bounds__(256)
+diag_gaussian_kernel(const T *__restrict__ z, const T *__restrict__ loc, const T *__restrict__ log_scale,
+                     T ls_shift, T *__restrict__ out, int64_t B, int64_t d, T cst, int acc) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < B; r += nwaves) {
+        T a = T(0);
+        for (int64_t j = lane; j < d; j += 64) {
+            const T ls = log_scale[j] + ls_shift;
+            const T q = (z[r * d + j] - loc[j]) / M<T>::exp(ls);
+            a += ls + T(0.5) * q * q;
+        }
+        a = wave_sum(a);
+        if (lane == 0) ld_store(out + r, cst - a, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Squeeze (reshape.py:116-128).  forward: (C,H,W)->(C/4,2H,2W): out[c, 2h+i, 2w+j] = in[4c+2i+j, h, w];
+// inverse is the opposite mapping.
+template <typename T>
+__global__ void __launch_bounds__(256)
+squeeze_kernel(const T *__restrict__ z, T *__restrict__ y, int64_t B, int C, int H, int W, int direction) {
+    const int64_t N = B * (int64_t)C * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        // index the OUTPUT element i, gather from the input
+        if (direction == 0) {
+            const int Co = C / 4, Ho = 2 * H, Wo = 2 * W;
+            int64_t r = i;
+            const int wo = (int)(r % Wo); r /= Wo;
+            const int ho = (int)(r % Ho); r /= Ho;
+            const int co = (int)(r % Co); r /= Co;
+            const int ci = 4 * co + 2 * (ho & 1) + (wo & 1);
+            y[i] = z[((r * C + ci) * H + (ho >> 1)) * W + (wo >> 1)];
+        } else {
+            const int Co = 4 * C, Ho = H / 2, Wo = W / 2;
+            int64_t r = i;
+            const int wo = (int)(r % Wo); r /= Wo;
+            const int ho = (int)(r % Ho); r /= Ho;
+            const int co = (int)(r % Co); r /= Co;
+            const int ci = co >> 2, di = (co >> 1) & 1, dj = co & 1;
+            y[i] = z[((r * C + ci) * H + (2 * ho + di)) * W + (2 * wo + dj)];
+        }
+    }
+}
+
+}  // namespace nf
+
+using namespace nf;
+
+#define NF_DISPATCH(dtype, CALL_F32, CALL_F64) \
+    do {                                       \
+        if ((dtype) == NF_F32) { CALL_F32; }   \
+        else if ((dtype) == NF_F64) { CALL_F64; } \
+        else return NF_ENOTSUP;                \
+    } while (0)
+
+extern "C" int nf_masked_affine(const void *z, const void *b, const void *s, const void *t, void *y, void *logdet,
+                                int64_t B, int64_t inner, int direction, int acc, int dtype, nf_stream_t stream) {
+    if (B < 0 || inner < 1 || (direction != 0 && direction != 1) || acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!z || !b || !y || !logdet) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = inner <= 64 ? grid_for(B, 256) : grid_for(B, 1, 256 * 16);
+    NF_DISPATCH(dtype,
+                hipLaunchKernelGGL(masked_affine_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)z,
+                                   (const float *)b, (const float *)s, (const float *)t, (float *)y, (float *)logdet, B,
+                                   inner, direction, acc),
+                hipLaunchKernelGGL(masked_affine_kernel<double>, dim3(grid), dim3(256), 0, st, (const double *)z,
+                                   (const double *)b, (const double *)s, (const double *)t, (double *)y,
+                                   (double *)logdet, B, inner, direction, acc));
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_affine_coupling(const void *z, const void *param, void *y, void *logdet, int64_t B, int C, int c1,
+                                  int flip, int64_t HW, int scale_map, int direction, int acc, int dtype,
+                                  nf_stream_t stream) {
+    if (B < 0 || C < 1 || c1 < 0 || c1 >= C || HW < 1 || (direction != 0 && direction != 1)) return NF_EINVAL;
+    if (scale_map < NF_SCALE_EXP || scale_map > NF_SCALE_NONE || acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!z || !param || !y || !logdet) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_for(B, 1, 256 * 16);
+    NF_DISPATCH(dtype,
+                hipLaunchKernelGGL(affine_coupling_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)z,
+                                   (const float *)param, (float *)y, (float *)logdet, B, C, c1, flip, HW, scale_map,
+                                   direction, acc),
+                hipLaunchKernelGGL(affine_coupling_kernel<double>, dim3(grid), dim3(256), 0, st, (const double *)z,
+                                   (const double *)param, (double *)y, (double *)logdet, B, C, c1, flip, HW, scale_map,
+                                   direction, acc));
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_actnorm(const void *z, const void *s, const void *t, void *y, void *logdet_scalar, void *logdet,
+                          int64_t B, int C, int64_t HW, int direction, int acc, int dtype, nf_stream_t stream) {
+    if (B < 0 || C < 1 || HW < 1 || (direction != 0 && direction != 1) || acc < NF_LD_SUB || acc > NF_LD_ADD)
+        return NF_EINVAL;
+    if (!s || !t) return NF_EFAULT;
+    if (B > 0 && (!z || !y)) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_for(B * (int64_t)C * HW, 256 * 4);
+    NF_DISPATCH(dtype,
+                hipLaunchKernelGGL(actnorm_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)z,
+                                   (const float *)s, (const float *)t, (float *)y, (float *)logdet_scalar,
+                                   (float *)logdet, B, C, HW, direction, acc),
+                hipLaunchKernelGGL(actnorm_kernel<double>, dim3(grid), dim3(256), 0, st, (const double *)z,
+                                   (const double *)s, (const double *)t, (double *)y, (double *)logdet_scalar,
+                                   (double *)logdet, B, C, HW, direction, acc));
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_actnorm_stats(const void *z, void *mean, void *std_unbiased, int64_t B, int C, int64_t HW, int dtype,
+                                nf_stream_t stream) {
+    if (B < 1 || C < 1 || HW < 1) return NF_EINVAL;
+    if (!z || !mean || !std_unbiased) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    NF_DISPATCH(dtype,
+                hipLaunchKernelGGL(actnorm_stats_kernel<float>, dim3(C), dim3(256), 0, st, (const float *)z,
+                                   (float *)mean, (float *)std_unbiased, B, C, HW),
+                hipLaunchKernelGGL(actnorm_stats_kernel<double>, dim3(C), dim3(256), 0, st, (const double *)z,
+                                   (double *)mean, (double *)std_unbiased, B, C, HW));
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_actnorm_init(const void *mean, const void *std_unbiased, void *s, void *t, int C, int direction,
+                               int dtype, nf_stream_t stream) {
+    if (C < 1 || (direction != 0 && direction != 1)) return NF_EINVAL;
+    if (!mean || !std_unbiased || !s || !t) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (C + 255) / 256;
+    NF_DISPATCH(dtype,
+                hipLaunchKernelGGL(actnorm_init_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)mean,
+                                   (const float *)std_unbiased, (float *)s, (float *)t, C, direction),
+                hipLaunchKernelGGL(actnorm_init_kernel<double>, dim3(grid), dim3(256), 0, st, (const double *)mean,
+                                   (const double *)std_unbiased, (double *)s, (double *)t, C, direction));
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_diag_gaussian_log_prob(const void *z, const void *loc, const void *log_scale, double log_scale_shift,
+                                         void *out, int64_t B, int64_t d, int acc, int dtype, nf_stream_t stream) {
+    if (B < 0 || d < 1 || acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!z || !loc || !log_scale || !out) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    const double cst = -0.5 * (double)d * log(2.0 * M_PI);  // base.py:99
+    const int grid = grid_for(B, 4);
+    NF_DISPATCH(dtype,
+                hipLaunchKernelGGL(diag_gaussian_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)z,
+                                   (const float *)loc, (const float *)log_scale, (float)log_scale_shift, (float *)out,
+                                   B, d, (float)cst, acc),
+                hipLaunchKernelGGL(diag_gaussian_kernel<double>, dim3(grid), dim3(256), 0, st, (const double *)z,
+                                   (const double *)loc, (const double *)log_scale, log_scale_shift, (double *)out, B,
+                                   d, cst, acc));
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_squeeze(const void *z, void *y, int64_t B, int C, int H, int W, int direction, int dtype,
+                          nf_stream_t stream) {
+    if (B < 0 || C < 1 || H < 1 || W < 1 || (direction != 0 && direction != 1)) return NF_EINVAL;
+    if (direction == 0 && (C % 4)) return NF_EINVAL;
+    if (direction == 1 && ((H % 2) || (W % 2))) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!z || !y) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_for(B * (int64_t)C * H * W, 256 * 4);
+    NF_DISPATCH(dtype,
+                hipLaunchKernelGGL(squeeze_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)z, (float *)y, B,
+                                   C, H, W, direction),
+                hipLaunchKernelGGL(squeeze_kernel<double>, dim3(grid), dim3(256), 0, st, (const double *)z,
+                                   (double *)y, B, C, H, W, direction));
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

@@ -1,0 +1,204 @@
+// inv1x1.hip -- Glow Invertible1x1Conv (normflows/flows/mixing.py:88-133).
+//
+// nf_inv1x1_assemble: single-workgroup kernel building W (C x C) from (P, L, U, sign_S, log_S) in LDS; for the
+//   sampling direction the two triangular factors are inverted by substitution in fp64 (the reference calls
+//   torch.inverse on .double() copies every forward, mixing.py:94-101), rounded to the working dtype and
+//   multiplied as (U^-1 L^-1) P^T in that dtype, like the reference.
+// nf_inv1x1_conv: per-pixel C x C mat-vec with W^T held in LDS (broadcast 16-B reads); lanes run along the
+//   pixel axis so every channel plane is read and written with unit stride.  Algorithmic HBM bytes: one read
+//   and one write of z (the ceil(C/8) re-reads of a pixel column hit L1/L2).
+#include "common.hpp"
+
+namespace nf {
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+inv1x1_assemble_kernel(const T *__restrict__ P, const T *__restrict__ L, const T *__restrict__ U,
+                       const T *__restrict__ sign_S, const T *__restrict__ log_S, T *__restrict__ W,
+                       T *__restrict__ logdet_unit, int C, int inverse) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int n = C * C;
+    double *Dd = reinterpret_cast<double *>(smem_raw);  // fp64 triangular factor
+    double *Ed = Dd + n;                                // fp64 inverse of it
+    T *Lt = reinterpret_cast<T *>(Ed + n);              // L' or L'^-1 in T
+    T *Ut = Lt + n;                                     // U' or U'^-1 in T
+    T *Tm = Ut + n;                                     // temp product
+    __shared__ T sred[16];
+    const int tid = threadIdx.x;
+
+    T part = T(0);
+    for (int i = tid; i < C; i += 256) part += log_S[i];
+    const T ls = block_sum(part, sred);
+    if (tid == 0 && logdet_unit) *logdet_unit = inverse ? -ls : ls;
+
+    // L' = tril(L,-1) + I ; U' = triu(U,1) + diag(sign_S * exp(log_S))   (mixing.py:90-93)
+    for (int i = tid; i < n; i += 256) {
+        const int r = i / C, c = i - r * C;
+        Lt[i] = c < r ? L[i] : (c == r ? T(1) : T(0));
+        Ut[i] = c > r ? U[i] : (c == r ? sign_S[r] * M<T>::exp(log_S[r]) : T(0));
+    }
+    __syncthreads();
+
+    if (!inverse) {
+        // W = (P @ L') @ U'
+        for (int i = tid; i < n; i += 256) {
+            const int r = i / C, c = i - r * C;
+            T a = T(0);
+            for (int k = 0; k < C; ++k) a += P[r * C + k] * Lt[k * C + c];
+            Tm[i] = a;
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            const int r = i / C, c = i - r * C;
+            T a = T(0);
+            for (int k = 0; k < C; ++k) a += Tm[r * C + k] * Ut[k * C + c];
+            W[i] = a;
+        }
+        return;
+    }
+
+    // ---- L'^-1 in fp64: thread c solves L' x = e_c (forward substitution) ----
+    for (int i = tid; i < n; i += 256) { Dd[i] = (double)Lt[i]; Ed[i] = 0.0; }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        for (int r = c; r < C; ++r) {
+            double a = (r == c) ? 1.0 : 0.0;
+            for (int k = c; k < r; ++k) a -= Dd[r * C + k] * Ed[k * C + c];
+            Ed[r * C + c] = a / Dd[r * C + r];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) Lt[i] = (T)Ed[i];
+    __syncthreads();
+    // ---- U'^-1 in fp64: thread c solves U' x = e_c (back substitution) ----
+    for (int i = tid; i < n; i += 256) { Dd[i] = (double)Ut[i]; Ed[i] = 0.0; }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        for (int r = c; r >= 0; --r) {
+            double a = (r == c) ? 1.0 : 0.0;
+            for (int k = r + 1; k <= c; ++k) a -= Dd[r * C + k] * Ed[k * C + c];
+            Ed[r * C + c] = a / Dd[r * C + r];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) Ut[i] = (T)Ed[i];
+    __syncthreads();
+    // ---- W = (U'^-1 @ L'^-1) @ P^T ----
+    for (int i = tid; i < n; i += 256) {
+        const int r = i / C, c = i - r * C;
+        T a = T(0);
+        for (int k = 0; k < C; ++k) a += Ut[r * C + k] * Lt[k * C + c];
+        Tm[i] = a;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int r = i / C, c = i - r * C;
+        T a = T(0);
+        for (int k = 0; k < C; ++k) a += Tm[r * C + k] * P[c * C + k];
+        W[i] = a;
+    }
+}
+
+constexpr int OT = 8;  // output channels per lane
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+inv1x1_conv_kernel(const T *__restrict__ z, const T *__restrict__ W, const T *__restrict__ logdet_unit,
+                   T *__restrict__ y, T *__restrict__ logdet_scalar, T *__restrict__ logdet, int64_t B, int C,
+                   int64_t HW, int acc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *Wt = reinterpret_cast<T *>(smem_raw);  // [c][Cp] : Wt[c][o] = W[o][c], row pitch Cp = roundup(C, OT)
+    const int Cp = (C + OT - 1) / OT * OT;
+    for (int i = threadIdx.x; i < C * Cp; i += blockDim.x) {
+        const int c = i / Cp, o = i - c * Cp;
+        Wt[i] = o < C ? W[o * C + c] : T(0);
+    }
+    __syncthreads();
+    const int64_t npix = B * HW;
+    const int otiles = Cp / OT;
+    const int64_t nwork = npix * otiles;
+    for (int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; wi < nwork; wi += (int64_t)gridDim.x * blockDim.x) {
+        const int ot = (int)(wi / npix);
+        const int64_t pix = wi - (int64_t)ot * npix;
+        const int64_t b = pix / HW, p = pix - b * HW;
+        const T *zb = z + b * (int64_t)C * HW + p;
+        T a[OT];
+#pragma unroll
+        for (int j = 0; j < OT; ++j) a[j] = T(0);
+        const T *wrow = Wt + ot * OT;
+        for (int c = 0; c < C; ++c) {
+            const T zc = zb[(int64_t)c * HW];
+#pragma unroll
+            for (int j = 0; j < OT; ++j) a[j] += wrow[c * Cp + j] * zc;
+        }
+        T *yb = y + b * (int64_t)C * HW + p;
+#pragma unroll
+        for (int j = 0; j < OT; ++j) {
+            const int o = ot * OT + j;
+            if (o < C) yb[(int64_t)o * HW] = a[j];
+        }
+    }
+    const T ldv = logdet_unit ? (*logdet_unit) * (T)HW : T(0);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && logdet_scalar) *logdet_scalar = ldv;
+    if (logdet)
+        for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < B; r += (int64_t)gridDim.x * blockDim.x)
+            ld_store(logdet + r, ldv, acc);
+}
+
+template <typename T>
+static int launch_assemble(const void *P, const void *L, const void *U, const void *sign_S, const void *log_S, void *W,
+                           void *logdet_unit, int C, int inverse, hipStream_t st) {
+    const size_t lds = (size_t)C * C * (2 * sizeof(double) + 3 * sizeof(T));
+    if (lds > 158 * 1024) return NF_ENOTSUP;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&inv1x1_assemble_kernel<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return NF_ENOTSUP;
+    }
+    hipLaunchKernelGGL(inv1x1_assemble_kernel<T>, dim3(1), dim3(256), lds, st, (const T *)P, (const T *)L, (const T *)U,
+                       (const T *)sign_S, (const T *)log_S, (T *)W, (T *)logdet_unit, C, inverse);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+template <typename T>
+static int launch_conv(const void *z, const void *W, const void *logdet_unit, void *y, void *logdet_scalar, void *logdet,
+                       int64_t B, int C, int64_t HW, int acc, hipStream_t st) {
+    const int Cp = (C + OT - 1) / OT * OT;
+    const size_t lds = (size_t)C * Cp * sizeof(T);
+    if (lds > 160 * 1024) return NF_ENOTSUP;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&inv1x1_conv_kernel<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return NF_ENOTSUP;
+    }
+    const int64_t nwork = B * HW * (Cp / OT);
+    const int grid = grid_for(nwork > 0 ? nwork : 1, 256);
+    hipLaunchKernelGGL(inv1x1_conv_kernel<T>, dim3(grid), dim3(256), lds, st, (const T *)z, (const T *)W,
+                       (const T *)logdet_unit, (T *)y, (T *)logdet_scalar, (T *)logdet, B, C, HW, acc);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+}  // namespace nf
+
+extern "C" int nf_inv1x1_assemble(const void *P, const void *L, const void *U, const void *sign_S, const void *log_S,
+                                  void *W, void *logdet_unit, int C, int inverse, int dtype, nf_stream_t stream) {
+    if (C < 1 || (inverse != 0 && inverse != 1)) return NF_EINVAL;
+    if (!P || !L || !U || !sign_S || !log_S || !W) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == NF_F32) return nf::launch_assemble<float>(P, L, U, sign_S, log_S, W, logdet_unit, C, inverse, st);
+    if (dtype == NF_F64) return nf::launch_assemble<double>(P, L, U, sign_S, log_S, W, logdet_unit, C, inverse, st);
+    return NF_ENOTSUP;
+}
+
+extern "C" int nf_inv1x1_conv(const void *z, const void *W, const void *logdet_unit, void *y, void *logdet_scalar,
+                              void *logdet, int64_t B, int C, int64_t HW, int acc, int dtype, nf_stream_t stream) {
+    if (B < 0 || C < 1 || HW < 1 || acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
+    if (!W) return NF_EFAULT;
+    if (B > 0 && (!z || !y)) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == NF_F32) return nf::launch_conv<float>(z, W, logdet_unit, y, logdet_scalar, logdet, B, C, HW, acc, st);
+    if (dtype == NF_F64) return nf::launch_conv<double>(z, W, logdet_unit, y, logdet_scalar, logdet, B, C, HW, acc, st);
+    return NF_ENOTSUP;
+}

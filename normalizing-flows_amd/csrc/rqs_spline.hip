@@ -1,0 +1,259 @@
+// rqs_spline.hip -- rational-quadratic spline kernels (element-wise and NSF coupling with conditioner
+// outputs materialised in HBM).  gfx950 only.
+//
+// Reference behaviour: normflows/utils/splines.py:11-219, normflows/flows/neural_spline/coupling.py:71-128,
+// :150-164, :221-253, :329-362.  The arithmetic lives in common.hpp (rqs_element / rqs_eval_table).
+//
+// nf_rqs_coupling data movement per workgroup (256 threads, TS samples per tile):
+//   HBM -> LDS : the tile's conditioner rows, TS*nT*M contiguous floats, coalesced 16-B loads, w/h
+//                pre-divided by sqrt(hidden) on the way in; row pitch padded to an odd number of words
+//                so that the per-lane walk over one row's K bins is bank-conflict free;
+//   HBM -> LDS : the tile's x rows (TS*D contiguous);
+//   once per workgroup: knot tables of the batch-shared unconditional spline (nI * 3(K+1) words);
+//   compute    : one lane per (sample, feature) element; results land in the LDS y tile (scatter by the
+//                identity/transform index lists happens in LDS, not in HBM);
+//   LDS -> HBM : y rows, coalesced; per-sample log-det = row sum of the per-element values.
+// Algorithmic HBM bytes per sample (fp32, D=64, nT=32, K=8): 256 (x) + 2944 (cond) + 256 (y) + 8 (ld rmw).
+#include "common.hpp"
+
+namespace nf {
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+rqs_spline_kernel(const T *__restrict__ x, const T *__restrict__ w, int64_t ldw, const T *__restrict__ h,
+                  int64_t ldh, const T *__restrict__ d, int64_t ldd, T *__restrict__ y, T *__restrict__ lad_out,
+                  int64_t N, RqsParams<T> p, int inverse) {
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        const T *wn = w + n * ldw, *hn = h + n * ldh, *dn = d + n * ldd;
+        const T div = p.wh_div;
+        auto wacc = [=](int k) { return wn[k] / div; };
+        auto hacc = [=](int k) { return hn[k] / div; };
+        auto dacc = [=](int j) { return dn[j]; };
+        T yy, ll;
+        rqs_element<T>(p, x[n], wacc, hacc, dacc, inverse != 0, yy, ll);
+        y[n] = yy;
+        if (lad_out) lad_out[n] = ll;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+rqs_coupling_kernel(const T *__restrict__ x, T *__restrict__ y, T *__restrict__ logdet, const T *__restrict__ cond,
+                    const T *__restrict__ uw, const T *__restrict__ uh, const T *__restrict__ ud,
+                    const int64_t *__restrict__ iidx, int nI, const int64_t *__restrict__ tidx, int nT, int64_t B,
+                    int D, RqsParams<T> p, int mode, int acc, int TS, int Mp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int K = p.K;
+    const int M = 2 * K + p.nd;
+    const int TW = 3 * (K + 1);  // table words per identity feature
+    T *s_cond = reinterpret_cast<T *>(smem_raw);               // TS * nT * Mp
+    T *s_x = s_cond + (size_t)TS * nT * Mp;                    // TS * D
+    T *s_y = s_x + (size_t)TS * D;                             // TS * D
+    T *s_lad = s_y + (size_t)TS * D;                           // TS * (nT + nI)
+    T *s_tab = s_lad + (size_t)TS * (nT + nI);                 // nI * TW
+    int *s_iidx = reinterpret_cast<int *>(s_tab + (size_t)nI * TW);  // nI
+    int *s_tidx = s_iidx + nI;                                 // nT
+
+    const bool has_uncond = uw != nullptr;
+    const bool do_t = mode != NF_RQS_SAMPLE_IDENTITY;
+    const bool do_i = mode != NF_RQS_SAMPLE_TRANSFORM;
+    const bool inverse = mode != NF_RQS_DENSITY;
+    const int tid = threadIdx.x, nth = blockDim.x;
+
+    for (int j = tid; j < nI; j += nth) s_iidx[j] = (int)iidx[j];
+    for (int j = tid; j < nT; j += nth) s_tidx[j] = (int)tidx[j];
+    if (do_i && has_uncond) {
+        RqsParams<T> pu = p;  // the unconditional transform is not scaled (nsf/coupling.py:224-232)
+        for (int j = tid; j < nI; j += nth) {
+            const T *wj = uw + (size_t)j * K, *hj = uh + (size_t)j * K, *dj = ud + (size_t)j * p.nd;
+            auto wacc = [=](int k) { return wj[k]; };
+            auto hacc = [=](int k) { return hj[k]; };
+            auto dacc = [=](int k) { return dj[k]; };
+            rqs_build_table<T>(pu, wacc, hacc, dacc, s_tab + (size_t)j * TW);
+        }
+    }
+    __syncthreads();
+
+    const int64_t ntiles = (B + TS - 1) / TS;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t b0 = tile * TS;
+        const int ts = (int)((B - b0) < TS ? (B - b0) : TS);
+        // ---- stage x rows (contiguous ts*D) ----
+        {
+            const T *src = x + b0 * D;
+            const int n = ts * D;
+            for (int i = tid; i < n; i += nth) {
+                const T v = src[i];
+                s_x[i] = v;
+                s_y[i] = v;  // columns this mode does not own are re-written unchanged only if owned below
+            }
+        }
+        // ---- stage conditioner rows (contiguous ts*nT*M), divide w/h by sqrt(hidden) once ----
+        if (do_t) {
+            const T *src = cond + b0 * (int64_t)nT * M;
+            const int n = ts * nT * M;
+            const T div = p.wh_div;
+            for (int i = tid; i < n; i += nth) {
+                const int row = i / M, col = i - row * M;
+                T v = src[i];
+                if (col < 2 * K) v = v / div;
+                s_cond[(size_t)row * Mp + col] = v;
+            }
+        }
+        __syncthreads();
+        // ---- transform features: per-element parameters ----
+        if (do_t) {
+            const int n = ts * nT;
+            for (int e = tid; e < n; e += nth) {
+                const int s = e / nT, j = e - s * nT;
+                const T *row = s_cond + (size_t)e * Mp;
+                auto wacc = [=](int k) { return row[k]; };
+                auto hacc = [=](int k) { return row[K + k]; };
+                auto dacc = [=](int k) { return row[2 * K + k]; };
+                T yy, ll;
+                rqs_element<T>(p, s_x[s * D + s_tidx[j]], wacc, hacc, dacc, inverse, yy, ll);
+                s_y[s * D + s_tidx[j]] = yy;
+                s_lad[s * (nT + nI) + j] = ll;
+            }
+        }
+        // ---- identity features: batch-shared tables ----
+        if (do_i) {
+            const int n = ts * nI;
+            for (int e = tid; e < n; e += nth) {
+                const int s = e / nI, j = e - s * nI;
+                T yy = s_x[s * D + s_iidx[j]], ll = T(0);
+                if (has_uncond) rqs_eval_table<T>(p, yy, s_tab + (size_t)j * TW, inverse, yy, ll);
+                s_y[s * D + s_iidx[j]] = yy;
+                s_lad[s * (nT + nI) + nT + j] = ll;
+            }
+        }
+        __syncthreads();
+        // ---- write back: only the columns this mode owns (the others keep the caller's y) ----
+        if (mode == NF_RQS_DENSITY) {
+            T *dst = y + b0 * D;
+            const int n = ts * D;
+            for (int i = tid; i < n; i += nth) dst[i] = s_y[i];
+        } else {
+            const int nown = do_t ? nT : nI;
+            const int *own = do_t ? s_tidx : s_iidx;
+            const int n = ts * nown;
+            for (int e = tid; e < n; e += nth) {
+                const int s = e / nown, j = e - s * nown;
+                y[(b0 + s) * D + own[j]] = s_y[s * D + own[j]];
+            }
+        }
+        for (int s = tid; s < ts; s += nth) {
+            T sum_t = T(0), sum_i = T(0);
+            if (do_t)
+                for (int j = 0; j < nT; ++j) sum_t += s_lad[s * (nT + nI) + j];
+            if (do_i)
+                for (int j = 0; j < nI; ++j) sum_i += s_lad[s * (nT + nI) + nT + j];
+            ld_store(logdet + b0 + s, sum_t + sum_i, acc);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+static int launch_rqs_coupling(const void *x, void *y, void *logdet, const void *cond, const void *uw, const void *uh,
+                               const void *ud, const int64_t *iidx, int nI, const int64_t *tidx, int nT, int64_t B,
+                               int D, const RqsParams<T> &p, int mode, int acc, hipStream_t st) {
+    const int K = p.K;
+    const int M = 2 * K + p.nd;
+    const int Mp = M | 1;
+    const int nmax = nT > nI ? nT : nI;
+    int TS = 256 / (nmax > 0 ? nmax : 1);
+    if (TS < 1) TS = 1;
+    if (TS > 64) TS = 64;
+    auto lds_bytes = [&](int ts) -> size_t {
+        size_t words = (size_t)ts * nT * Mp + 2 * (size_t)ts * D + (size_t)ts * (nT + nI) + (size_t)nI * 3 * (K + 1);
+        return words * sizeof(T) + (size_t)(nI + nT) * sizeof(int) + 16;
+    };
+    while (TS > 1 && lds_bytes(TS) > 64 * 1024) TS >>= 1;
+    const size_t lds = lds_bytes(TS);
+    if (lds > 160 * 1024) return NF_ENOTSUP;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&rqs_coupling_kernel<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return NF_ENOTSUP;
+    }
+    const int64_t ntiles = (B + TS - 1) / TS;
+    const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
+    hipLaunchKernelGGL(rqs_coupling_kernel<T>, dim3(grid), dim3(256), lds, st, (const T *)x, (T *)y, (T *)logdet,
+                       (const T *)cond, (const T *)uw, (const T *)uh, (const T *)ud, iidx, nI, tidx, nT, B, D, p, mode,
+                       acc, TS, Mp);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+}  // namespace nf
+
+using namespace nf;
+
+static int check_spline_args(int K, int tails, double min_w, double min_h) {
+    if (K < 1 || K > NF_MAX_BINS) return NF_ERANGE;
+    if (tails != NF_TAILS_NONE && tails != NF_TAILS_LINEAR && tails != NF_TAILS_CIRCULAR) return NF_EINVAL;
+    // utils/splines.py:121-124 raises ValueError
+    if (min_w * K > 1.0 || min_h * K > 1.0) return NF_EINVAL;
+    return NF_OK;
+}
+
+extern "C" int nf_rqs_spline(const void *x, const void *w, int64_t ldw, const void *h, int64_t ldh, const void *d,
+                             int64_t ldd, void *y, void *logabsdet, int64_t N, int K, int tails, double tail_bound,
+                             double left, double right, double bottom, double top, double min_bin_width,
+                             double min_bin_height, double min_derivative, double wh_div, int inverse, int dtype,
+                             nf_stream_t stream) {
+    int rc = check_spline_args(K, tails, min_bin_width, min_bin_height);
+    if (rc) return rc;
+    if (N < 0) return NF_EINVAL;
+    if (N == 0) return NF_OK;
+    if (!x || !w || !h || !d || !y) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_for(N, 256);
+    if (dtype == NF_F32) {
+        auto p = make_rqs_params<float>(K, tails, tail_bound, left, right, bottom, top, min_bin_width, min_bin_height,
+                                        min_derivative, wh_div);
+        hipLaunchKernelGGL(rqs_spline_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, (const float *)w,
+                           ldw, (const float *)h, ldh, (const float *)d, ldd, (float *)y, (float *)logabsdet, N, p,
+                           inverse);
+    } else if (dtype == NF_F64) {
+        auto p = make_rqs_params<double>(K, tails, tail_bound, left, right, bottom, top, min_bin_width, min_bin_height,
+                                         min_derivative, wh_div);
+        hipLaunchKernelGGL(rqs_spline_kernel<double>, dim3(grid), dim3(256), 0, st, (const double *)x,
+                           (const double *)w, ldw, (const double *)h, ldh, (const double *)d, ldd, (double *)y,
+                           (double *)logabsdet, N, p, inverse);
+    } else
+        return NF_ENOTSUP;
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_rqs_coupling(const void *x, void *y, void *logdet, const void *cond, const void *uw, const void *uh,
+                               const void *ud, const int64_t *identity_idx, int nI, const int64_t *transform_idx,
+                               int nT, int64_t B, int D, int K, int tails, double tail_bound, double min_bin_width,
+                               double min_bin_height, double min_derivative, double wh_div, int mode, int acc,
+                               int dtype, nf_stream_t stream) {
+    int rc = check_spline_args(K, tails, min_bin_width, min_bin_height);
+    if (rc) return rc;
+    if (B < 0 || D < 1 || nI < 0 || nT < 0 || nI + nT != D) return NF_EINVAL;
+    if (mode < NF_RQS_DENSITY || mode > NF_RQS_SAMPLE_TRANSFORM) return NF_EINVAL;
+    if (acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!x || !y || !logdet || (nI && !identity_idx) || (nT && !transform_idx)) return NF_EFAULT;
+    if (mode != NF_RQS_SAMPLE_IDENTITY && nT && !cond) return NF_EFAULT;
+    if ((uw || uh || ud) && !(uw && uh && ud)) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == NF_F32) {
+        auto p = make_rqs_params<float>(K, tails, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
+                                        min_derivative, wh_div);
+        return launch_rqs_coupling<float>(x, y, logdet, cond, uw, uh, ud, identity_idx, nI, transform_idx, nT, B, D, p,
+                                          mode, acc, st);
+    } else if (dtype == NF_F64) {
+        auto p = make_rqs_params<double>(K, tails, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
+                                         min_derivative, wh_div);
+        return launch_rqs_coupling<double>(x, y, logdet, cond, uw, uh, ud, identity_idx, nI, transform_idx, nT, B, D,
+                                           p, mode, acc, st);
+    }
+    return NF_ENOTSUP;
+}

@@ -1,0 +1,71 @@
+"""Base distributions at the end of the path: DiagGaussian (normflows/distributions/base.py:8-103).
+
+log_prob is one launch of nf_diag_gaussian_log_prob (optionally accumulating into the caller's log_q);
+sampling draws torch.randn on the device and evaluates the same closed form.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+
+
+class BaseDistribution(nn.Module):
+    def __init__(self):
+        super().__init__()
+
+    def forward(self, num_samples=1):
+        raise NotImplementedError
+
+    def log_prob(self, z):
+        raise NotImplementedError
+
+    def sample(self, num_samples=1, **kwargs):
+        z, _ = self.forward(num_samples, **kwargs)
+        return z
+
+
+class DiagGaussian(BaseDistribution):
+    """Multivariate Gaussian with diagonal covariance (base.py:52-103)."""
+
+    def __init__(self, shape, trainable=True):
+        super().__init__()
+        if isinstance(shape, int):
+            shape = (shape,)
+        if isinstance(shape, list):
+            shape = tuple(shape)
+        self.shape = shape
+        self.n_dim = len(shape)
+        self.d = np.prod(shape)
+        if trainable:
+            self.loc = nn.Parameter(torch.zeros(1, *self.shape))
+            self.log_scale = nn.Parameter(torch.zeros(1, *self.shape))
+        else:
+            self.register_buffer("loc", torch.zeros(1, *self.shape))
+            self.register_buffer("log_scale", torch.zeros(1, *self.shape))
+        self.temperature = None
+
+    def _shift(self):
+        return 0.0 if self.temperature is None else float(np.log(self.temperature))
+
+    def forward(self, num_samples=1, context=None):
+        eps = torch.randn((num_samples,) + self.shape, dtype=self.loc.dtype, device=self.loc.device)
+        return self.from_noise(eps)
+
+    def from_noise(self, eps):
+        """z = loc + exp(log_scale) eps and log p(z) (base.py:80-92) for given standard-normal noise."""
+        log_scale = self.log_scale.detach() + self._shift()
+        z = self.loc.detach() + torch.exp(log_scale) * eps
+        # log_p = -d/2 log(2 pi) - sum(log_scale + eps^2/2): the same closed form as log_prob at (z - loc)/scale = eps
+        zeros = torch.zeros_like(self.loc.detach())
+        log_p = ops.diag_gaussian_log_prob(eps, zeros, zeros, 0.0)
+        log_p = log_p - log_scale.sum()
+        return z, log_p
+
+    def log_prob(self, z, context=None):
+        return ops.diag_gaussian_log_prob(z, self.loc.detach(), self.log_scale.detach(), self._shift())
+
+    def _log_prob_acc(self, z, log_q, acc=+1):
+        """log_q (+|-)= log_prob(z), fused into the kernel's store."""
+        ops.diag_gaussian_log_prob(z, self.loc.detach(), self.log_scale.detach(), self._shift(), out=log_q, acc=acc)
+        return log_q

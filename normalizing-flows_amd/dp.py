@@ -1,0 +1,41 @@
+"""Data-parallel evaluation of the hot path: one process per GPU, batch sharded by rows, weights replicated.
+
+The path is embarrassingly parallel over samples: no data-path collective.  The only
+exchange is ONE all-reduce of [sum log_q, count] (fp64, 16 bytes) per evaluated batch for the NLL -- RCCL over
+xGMI when the process group backend is "nccl", gloo in the CPU tests.  The reference has no distributed code
+(`grep torch.distributed normflows/` is empty); semantics are those of core.py:87-102 `-mean(log_q)` over the
+GLOBAL batch.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_rows, world_size, rank):
+    """Contiguous row range [lo, hi) of `rank`: rows are split as evenly as possible, low ranks get the extras."""
+    base, extra = divmod(n_rows, world_size)
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    return lo, hi
+
+
+def shard_rows(x, world_size=None, rank=None):
+    if world_size is None:
+        world_size = dist.get_world_size() if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    lo, hi = shard_bounds(x.shape[0], world_size, rank)
+    return x[lo:hi]
+
+
+def global_nll(log_q_local, group=None):
+    """-mean(log_q) over all ranks' rows: one all_reduce(SUM) of a 2-element fp64 tensor."""
+    acc = torch.stack([log_q_local.double().sum(), torch.tensor(float(log_q_local.numel()), dtype=torch.float64,
+                                                                device=log_q_local.device)])
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+    return -(acc[0] / acc[1])
+
+
+def sharded_forward_kld(log_prob_fn, x_local, group=None):
+    """forward_kld of core.py:87-102 on a row-sharded batch: local log_prob, then the single NLL all-reduce."""
+    return global_nll(log_prob_fn(x_local), group=group)

@@ -1,0 +1,177 @@
+"""Affine family: AffineConstFlow, AffineCoupling, MaskedAffineFlow, AffineCouplingBlock.
+
+Mirrors normflows/flows/affine/coupling.py:9-54, :99-171, :174-229, :232-267 (constructor signatures,
+state_dict keys, forward/inverse semantics).  The arithmetic of every layer is one HIP kernel
+(nf_actnorm, nf_affine_coupling, nf_masked_affine); the parameter maps (`param_map`, `s`, `t`) are arbitrary
+nn.Modules evaluated by the caller-supplied network, exactly as in the reference.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from .base import Flow, new_ld, run_flow
+from .reshape import Merge, Split
+
+
+class AffineConstFlow(Flow):
+    """Per-dimension learned scale and shift (coupling.py:9-54); base class of ActNorm."""
+
+    def __init__(self, shape, scale=True, shift=True):
+        super().__init__()
+        if scale:
+            self.s = nn.Parameter(torch.zeros(shape)[None])
+        else:
+            self.register_buffer("s", torch.zeros(shape)[None])
+        if shift:
+            self.t = nn.Parameter(torch.zeros(shape)[None])
+        else:
+            self.register_buffer("t", torch.zeros(shape)[None])
+        self.n_dim = self.s.dim()
+        self.batch_dims = torch.nonzero(torch.tensor(self.s.shape) == 1, as_tuple=False)[:, 0].tolist()
+        shp = tuple(self.s.shape[1:])
+        # kernels index parameters as (i / HW) % C: parameter shapes (C,), (C,1), (C,1,1), ... are supported
+        self._per_channel = len(shp) >= 1 and all(d == 1 for d in shp[1:])
+        self._elementwise = len(self.batch_dims) == 1  # no broadcast dims besides the batch
+
+    def _geometry(self, z):
+        if self._per_channel:
+            return z
+        if self._elementwise:  # every element has its own (s, t): treat as C = prod(shape), HW = 1
+            return z.reshape(z.shape[0], -1)
+        raise NotImplementedError("AffineConstFlow parameters of shape %s (broadcast over inner dims other than "
+                                  "trailing ones) are not supported by the HIP kernel" % (tuple(self.s.shape),))
+
+    def _apply_kernel(self, z, inverse, ld=None, acc=None, want_scalar=True):
+        zz = self._geometry(z)
+        y, lds = ops.actnorm(zz, self.s.detach(), self.t.detach(), 1 if inverse else 0, logdet=ld, acc=acc,
+                             want_scalar=want_scalar)
+        return y.view(z.shape), lds
+
+    def forward(self, z):
+        return self._apply_kernel(z, False)  # 0-dim log_det like the reference (coupling.py:44)
+
+    def inverse(self, z):
+        return self._apply_kernel(z, True)
+
+    def _run(self, z, inverse, ld, acc, **kw):
+        y, _ = self._apply_kernel(z, inverse, ld=ld, acc=acc, want_scalar=False)
+        return y
+
+
+class AffineCoupling(Flow):
+    """Affine coupling on a list [z1, z2] (coupling.py:99-171)."""
+
+    def __init__(self, param_map, scale=True, scale_map="exp"):
+        super().__init__()
+        self.add_module("param_map", param_map)
+        self.scale = scale
+        self.scale_map = scale_map
+        if scale and scale_map not in ("exp", "sigmoid", "sigmoid_inv"):
+            raise NotImplementedError("This scale map is not implemented.")
+
+    def _smap(self):
+        return self.scale_map if self.scale else None
+
+    def _transform(self, z, inverse, ld=None, acc=None):
+        z1, z2 = z
+        param = self.param_map(z1)
+        y2, ld = ops.affine_coupling(z2, param, 0, False, self._smap(), 1 if inverse else 0, logdet=ld, acc=acc)
+        return [z1, y2], ld
+
+    def forward(self, z):
+        return self._transform(z, False)
+
+    def inverse(self, z):
+        return self._transform(z, True)
+
+    def _run(self, z, inverse, ld, acc, **kw):
+        out, _ = self._transform(z, inverse, ld=ld, acc=acc)
+        return out
+
+
+class MaskedAffineFlow(Flow):
+    """RealNVP masked affine flow f(z) = b z + (1-b)(z exp(s(b z)) + t(b z)) (coupling.py:174-229)."""
+
+    def __init__(self, b, t=None, s=None):
+        super().__init__()
+        self.b_cpu = b.view(1, *b.size())
+        self.register_buffer("b", self.b_cpu)
+        if s is None:
+            self.s = None
+        else:
+            self.add_module("s", s)
+        if t is None:
+            self.t = None
+        else:
+            self.add_module("t", t)
+
+    def _transform(self, z, inverse, ld=None, acc=None):
+        need_net = self.s is not None or self.t is not None
+        z_masked = self.b * z if need_net else None
+        scale = self.s(z_masked) if self.s is not None else None
+        trans = self.t(z_masked) if self.t is not None else None
+        return ops.masked_affine(z, self.b, scale, trans, 1 if inverse else 0, logdet=ld, acc=acc)
+
+    def forward(self, z):
+        return self._transform(z, False)
+
+    def inverse(self, z):
+        return self._transform(z, True)
+
+    def _run(self, z, inverse, ld, acc, **kw):
+        y, _ = self._transform(z, inverse, ld=ld, acc=acc)
+        return y
+
+
+class AffineCouplingBlock(Flow):
+    """Split -> AffineCoupling -> Merge (coupling.py:232-267).
+
+    `flows` keeps the reference's three sub-modules (state_dict keys `flows.1.param_map.*`).  For the
+    channel / channel_inv split modes the three steps run as ONE kernel that reads z, copies the identity
+    half and writes the transformed half into the merged output; checkerboard modes compose the three
+    sub-flows like the reference.
+    """
+
+    def __init__(self, param_map, scale=True, scale_map="exp", split_mode="channel"):
+        super().__init__()
+        self.flows = nn.ModuleList([])
+        self.flows += [Split(split_mode)]
+        self.flows += [AffineCoupling(param_map, scale, scale_map)]
+        self.flows += [Merge(split_mode)]
+        self.split_mode = split_mode
+
+    def _fused(self, z, inverse, ld, acc):
+        C = z.shape[1]
+        coupling = self.flows[1]
+        if self.split_mode == "channel":
+            c1, flip = (C + 1) // 2, False  # chunk(2): first ceil(C/2) channels are z1 (reshape.py:31)
+            z1 = z[:, :c1]
+        else:
+            c1, flip = C // 2, True          # channel_inv: z2 = first ceil(C/2), z1 = the rest (reshape.py:33)
+            z1 = z[:, C - c1:]
+        param = coupling.param_map(z1)
+        return ops.affine_coupling(z, param, c1, flip, coupling._smap(), 1 if inverse else 0, logdet=ld, acc=acc)
+
+    def _compose(self, z, inverse, ld, acc):
+        seq = reversed(self.flows) if inverse else self.flows
+        for f in seq:
+            z = run_flow(f, z, inverse, ld, acc)
+        return z
+
+    def _go(self, z, inverse, ld, acc):
+        if self.split_mode in ("channel", "channel_inv") and z.shape[1] >= 2:
+            y, _ = self._fused(z, inverse, ld, acc)
+            return y
+        return self._compose(z, inverse, ld, acc)
+
+    def forward(self, z):
+        ld = torch.zeros(z.shape[0], dtype=z.dtype, device=z.device)
+        return self._go(z, False, ld, +1), ld
+
+    def inverse(self, z):
+        ld = torch.zeros(z.shape[0], dtype=z.dtype, device=z.device)
+        return self._go(z, True, ld, +1), ld
+
+    def _run(self, z, inverse, ld, acc, **kw):
+        return self._go(z, inverse, ld, acc)

@@ -1,0 +1,199 @@
+"""Mixing layers: Permute, Invertible1x1Conv, LULinearPermute.
+
+Mirrors normflows/flows/mixing.py:9-54 (Permute), :57-133 (Invertible1x1Conv), :213-254 (_Permutation,
+_RandomPermutation), :368-532 (_LULinear), :535-563 (LULinearPermute): constructor signatures, RNG
+consumption order at construction (so a seeded build reproduces the reference's permutations / QR
+initialisation bit for bit) and state_dict keys.  The arithmetic runs in nf_lu_linear_permute,
+nf_inv1x1_assemble and nf_inv1x1_conv.
+"""
+import numpy as np
+import torch
+from torch import nn
+from torch.nn import init
+
+from .. import ops
+from .base import Flow
+
+
+class Permute(Flow):
+    """Channel permutation, mode 'shuffle' (random, fixed) or 'swap' (halves) (mixing.py:9-54).
+    Pure data movement (torch indexing); log-det is zero."""
+
+    def __init__(self, num_channels, mode="shuffle"):
+        super().__init__()
+        self.mode = mode
+        self.num_channels = num_channels
+        if self.mode == "shuffle":
+            perm = torch.randperm(self.num_channels)
+            inv_perm = torch.empty_like(perm).scatter_(dim=0, index=perm, src=torch.arange(self.num_channels))
+            self.register_buffer("perm", perm)
+            self.register_buffer("inv_perm", inv_perm)
+
+    def _move(self, z, inverse):
+        if self.mode == "shuffle":
+            return z[:, self.inv_perm if inverse else self.perm, ...]
+        if self.mode == "swap":
+            cut = (self.num_channels + 1) // 2 if inverse else self.num_channels // 2
+            return torch.cat([z[:, cut:, ...], z[:, :cut, ...]], dim=1)
+        raise NotImplementedError("The mode " + self.mode + " is not implemented.")
+
+    def forward(self, z, context=None):
+        return self._move(z, False), torch.zeros(len(z), device=z.device)
+
+    def inverse(self, z, context=None):
+        return self._move(z, True), torch.zeros(len(z), device=z.device)
+
+    def _run(self, z, inverse, ld, acc, **kw):
+        return self._move(z, inverse)
+
+
+class Invertible1x1Conv(Flow):
+    """Glow's invertible 1x1 convolution on NCHW tensors (mixing.py:57-133).
+
+    use_lu=True: W = P L U with fixed P, learnable L, U, log_S; assembled on the device by
+    nf_inv1x1_assemble (triangular inverses in fp64 for the sampling direction) and applied by
+    nf_inv1x1_conv.  use_lu=False keeps the raw W parameter; its inverse / slogdet are taken with
+    torch.linalg (library call, non-default parametrisation) and only the conv runs in our kernel.
+    """
+
+    def __init__(self, num_channels, use_lu=False):
+        super().__init__()
+        self.num_channels = num_channels
+        self.use_lu = use_lu
+        Q, _ = torch.linalg.qr(torch.randn(self.num_channels, self.num_channels))
+        if use_lu:
+            P, L, U = torch.lu_unpack(*Q.lu())
+            self.register_buffer("P", P)
+            self.L = nn.Parameter(L)
+            S = U.diag()
+            self.register_buffer("sign_S", torch.sign(S))
+            self.log_S = nn.Parameter(torch.log(torch.abs(S)))
+            self.U = nn.Parameter(torch.triu(U, diagonal=1))
+            self.register_buffer("eye", torch.diag(torch.ones(self.num_channels)))
+        else:
+            self.W = nn.Parameter(Q)
+
+    def _weight(self, inverse_dir):
+        """W and the per-pixel log|det| (0-dim) for flow.inverse (inverse_dir=True) or flow.forward."""
+        if self.use_lu:
+            return ops.inv1x1_assemble(self.P, self.L.detach(), self.U.detach(), self.sign_S, self.log_S.detach(),
+                                       inverse=not inverse_dir)
+        W = self.W.detach()
+        sld = torch.slogdet(W)[1]
+        if inverse_dir:
+            return W.contiguous(), sld
+        Winv = torch.inverse(W) if W.dtype == torch.float64 else torch.inverse(W.double()).type(W.dtype)
+        return Winv.contiguous(), -sld
+
+    def _conv(self, z, inverse_dir, ld=None, acc=None, want_scalar=True):
+        W, ldu = self._weight(inverse_dir)
+        return ops.inv1x1_conv(z, W, ldu, logdet=ld, acc=acc, want_scalar=want_scalar)
+
+    def forward(self, z):
+        return self._conv(z, False)
+
+    def inverse(self, z):
+        return self._conv(z, True)
+
+    def _run(self, z, inverse, ld, acc, **kw):
+        y, _ = self._conv(z, inverse, ld=ld, acc=acc, want_scalar=False)
+        return y
+
+
+# ---- LU linear + permutation used by neural spline flows ---------------------------------------------------
+class _Permutation(Flow):
+    """Holds a fixed permutation of dimension `dim` (mixing.py:213-247)."""
+
+    def __init__(self, permutation, dim=1):
+        if permutation.ndimension() != 1:
+            raise ValueError("Permutation must be a 1D tensor.")
+        super().__init__()
+        self._dim = dim
+        self.register_buffer("_permutation", permutation)
+
+    @property
+    def _inverse_permutation(self):
+        return torch.argsort(self._permutation)
+
+    @staticmethod
+    def _permute(inputs, permutation, dim):
+        if dim >= inputs.ndimension():
+            raise ValueError("No dimension {} in inputs.".format(dim))
+        if inputs.shape[dim] != len(permutation):
+            raise ValueError("Dimension {} in inputs must be of size {}.".format(dim, len(permutation)))
+        outputs = torch.index_select(inputs, dim, permutation)
+        return outputs, torch.zeros(inputs.shape[0], dtype=inputs.dtype, device=inputs.device)
+
+    def forward(self, inputs, context=None):
+        return self._permute(inputs, self._permutation, self._dim)
+
+    def inverse(self, inputs, context=None):
+        return self._permute(inputs, self._inverse_permutation, self._dim)
+
+
+class _RandomPermutation(_Permutation):
+    def __init__(self, features, dim=1):
+        super().__init__(torch.randperm(features), dim)
+
+
+class _LULinear(Flow):
+    """Parameter holder of the LU-parametrised linear map (mixing.py:274-365, :368-532): packed strictly-lower and
+    strictly-upper entries, softplus-constrained diagonal, bias."""
+
+    def __init__(self, features, using_cache=False, identity_init=True, eps=1e-3):
+        super().__init__()
+        self.features = features
+        self.bias = nn.Parameter(torch.zeros(features))
+        self.using_cache = using_cache
+        self.eps = eps
+        n_triangular_entries = ((features - 1) * features) // 2
+        self.lower_entries = nn.Parameter(torch.zeros(n_triangular_entries))
+        self.upper_entries = nn.Parameter(torch.zeros(n_triangular_entries))
+        self.unconstrained_upper_diag = nn.Parameter(torch.zeros(features))
+        self._initialize(identity_init)
+
+    def _initialize(self, identity_init):
+        init.zeros_(self.bias)
+        if identity_init:
+            init.zeros_(self.lower_entries)
+            init.zeros_(self.upper_entries)
+            init.constant_(self.unconstrained_upper_diag, np.log(np.exp(1 - self.eps) - 1))
+        else:
+            stdv = 1.0 / np.sqrt(self.features)
+            init.uniform_(self.lower_entries, -stdv, stdv)
+            init.uniform_(self.upper_entries, -stdv, stdv)
+            init.uniform_(self.unconstrained_upper_diag, -stdv, stdv)
+
+    def use_cache(self, mode=True):
+        # The kernel re-assembles L and U in LDS on every launch (8 KB of parameters); nothing to cache.
+        self.using_cache = mode
+
+
+class LULinearPermute(Flow):
+    """Fixed random permutation followed by an LU-parametrised linear map (mixing.py:535-563)."""
+
+    def __init__(self, num_channels, identity_init=True):
+        super().__init__()
+        self.permutation = _RandomPermutation(num_channels)
+        self.linear = _LULinear(num_channels, identity_init=identity_init)
+
+    def _apply_kernel(self, z, inverse, ld=None, acc=None):
+        if z.dim() != 2:
+            raise ValueError("LULinearPermute expects (batch, features) inputs.")
+        if z.shape[1] != self.linear.features:
+            raise ValueError("Dimension 1 in inputs must be of size {}.".format(self.linear.features))
+        lin = self.linear
+        # flow.inverse (density) = kernel direction 0, flow.forward (sample) = kernel direction 1
+        return ops.lu_linear_permute(z, self.permutation._permutation, lin.lower_entries.detach(),
+                                     lin.upper_entries.detach(), lin.unconstrained_upper_diag.detach(),
+                                     lin.bias.detach(), 0 if inverse else 1, eps=lin.eps, logdet=ld, acc=acc)
+
+    def forward(self, z, context=None):
+        return self._apply_kernel(z, False)
+
+    def inverse(self, z, context=None):
+        return self._apply_kernel(z, True)
+
+    def _run(self, z, inverse, ld, acc, **kw):
+        y, _ = self._apply_kernel(z, inverse, ld=ld, acc=acc)
+        return y

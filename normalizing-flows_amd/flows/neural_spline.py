@@ -1,0 +1,252 @@
+"""Neural spline flow coupling layers.
+
+Mirrors normflows/flows/neural_spline/coupling.py:16-362 (Coupling, PiecewiseCoupling,
+PiecewiseRationalQuadraticCDF, PiecewiseRationalQuadraticCoupling) and
+normflows/flows/neural_spline/wrapper.py:14-85 (CoupledRationalQuadraticSpline): constructor signatures,
+buffers `identity_features` / `transform_features`, module tree `prqct.transform_net.*`,
+`prqct.unconditional_transform.unnormalized_{widths,heights,derivatives}` (state_dict compatible).
+
+The coupling transform (index split, spline on the transform half with conditioner outputs, batch-shared
+spline on the identity half, scatter, per-sample log-det) is one launch of nf_rqs_coupling per direction
+phase; the spline arithmetic of normflows/utils/splines.py lives in csrc/common.hpp.
+"""
+import warnings
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import _lib as L
+from .. import ops
+from ..nets import ResidualNet
+from ..utils.masks import create_alternating_binary_mask
+from .base import Flow
+
+DEFAULT_MIN_BIN_WIDTH = 1e-3
+DEFAULT_MIN_BIN_HEIGHT = 1e-3
+DEFAULT_MIN_DERIVATIVE = 1e-3
+
+
+def _check_tails(tails, tail_bound):
+    if isinstance(tails, (list, tuple)) or torch.is_tensor(tail_bound):
+        raise NotImplementedError("per-feature tails / tensor tail_bound (circular-coordinate variants) are not "
+                                  "implemented by the HIP spline kernels")
+    if tails not in (None, "linear", "circular"):
+        raise RuntimeError("{} tails are not implemented.".format(tails))
+
+
+class PiecewiseRationalQuadraticCDF(Flow):
+    """Batch-shared monotone RQ spline per feature (nsf/coupling.py:170-259).  2-D inputs (B, features)."""
+
+    def __init__(self, shape, num_bins=10, tails=None, tail_bound=1.0, identity_init=True,
+                 min_bin_width=DEFAULT_MIN_BIN_WIDTH, min_bin_height=DEFAULT_MIN_BIN_HEIGHT,
+                 min_derivative=DEFAULT_MIN_DERIVATIVE):
+        super().__init__()
+        _check_tails(tails, tail_bound)
+        self.min_bin_width = min_bin_width
+        self.min_bin_height = min_bin_height
+        self.min_derivative = min_derivative
+        self.tail_bound = tail_bound
+        self.tails = tails
+        self.num_bins = num_bins
+        if self.tails == "linear":
+            num_derivatives = num_bins - 1
+        elif self.tails == "circular":
+            num_derivatives = num_bins
+        else:
+            num_derivatives = num_bins + 1
+        if identity_init:
+            self.unnormalized_widths = nn.Parameter(torch.zeros(*shape, num_bins))
+            self.unnormalized_heights = nn.Parameter(torch.zeros(*shape, num_bins))
+            constant = np.log(np.exp(1 - min_derivative) - 1)
+            self.unnormalized_derivatives = nn.Parameter(constant * torch.ones(*shape, num_derivatives))
+        else:
+            self.unnormalized_widths = nn.Parameter(torch.rand(*shape, num_bins))
+            self.unnormalized_heights = nn.Parameter(torch.rand(*shape, num_bins))
+            self.unnormalized_derivatives = nn.Parameter(torch.rand(*shape, num_derivatives))
+
+    def _spline(self, inputs, inverse, ld=None, acc=None):
+        if inputs.dim() != 2 or self.unnormalized_widths.dim() != 2:
+            raise NotImplementedError("PiecewiseRationalQuadraticCDF: only (batch, features) inputs are implemented")
+        D = inputs.shape[1]
+        idx = torch.arange(D, device=inputs.device)
+        none = idx[:0]
+        return ops.rqs_coupling(inputs, None, self.unnormalized_widths.detach(), self.unnormalized_heights.detach(),
+                                self.unnormalized_derivatives.detach(), idx, none, self.num_bins,
+                                L.RQS_SAMPLE_IDENTITY if inverse else L.RQS_DENSITY, logdet=ld, acc=acc,
+                                tails=self.tails, tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
+                                min_bin_height=self.min_bin_height, min_derivative=self.min_derivative)
+
+    def forward(self, inputs, context=None):
+        return self._spline(inputs, False)
+
+    def inverse(self, inputs, context=None):
+        return self._spline(inputs, True)
+
+    def _run(self, z, inverse, ld, acc, **kw):
+        y, _ = self._spline(z, inverse, ld=ld, acc=acc)
+        return y
+
+
+class Coupling(Flow):
+    """Coupling layer base: 1-D mask -> identity / transform feature index buffers, conditioner network,
+    optional unconditional transform of the identity half (nsf/coupling.py:16-140)."""
+
+    def __init__(self, mask, transform_net_create_fn, unconditional_transform=None):
+        mask = torch.as_tensor(mask)
+        if mask.dim() != 1:
+            raise ValueError("Mask must be a 1-dim tensor.")
+        if mask.numel() <= 0:
+            raise ValueError("Mask can't be empty.")
+        super().__init__()
+        self.features = len(mask)
+        features_vector = torch.arange(self.features)
+        self.register_buffer("identity_features", features_vector.masked_select(mask <= 0))
+        self.register_buffer("transform_features", features_vector.masked_select(mask > 0))
+        assert self.num_identity_features + self.num_transform_features == self.features
+        self.transform_net = transform_net_create_fn(
+            self.num_identity_features, self.num_transform_features * self._transform_dim_multiplier())
+        if unconditional_transform is None:
+            self.unconditional_transform = None
+        else:
+            self.unconditional_transform = unconditional_transform(features=self.num_identity_features)
+
+    @property
+    def num_identity_features(self):
+        return len(self.identity_features)
+
+    @property
+    def num_transform_features(self):
+        return len(self.transform_features)
+
+    def _check(self, inputs):
+        if inputs.dim() not in [2, 4]:
+            raise ValueError("Inputs must be a 2D or a 4D tensor.")
+        if inputs.shape[1] != self.features:
+            raise ValueError("Expected features = {}, got {}.".format(self.features, inputs.shape[1]))
+        if inputs.dim() == 4:
+            raise NotImplementedError("image (NCHW) neural-spline coupling is not implemented by the HIP kernels yet")
+
+    def _transform_dim_multiplier(self):
+        raise NotImplementedError()
+
+
+class PiecewiseRationalQuadraticCoupling(Coupling):
+    """RQ-spline coupling (nsf/coupling.py:262-362).  forward = density direction of the spline,
+    inverse = quadratic-root direction."""
+
+    def __init__(self, mask, transform_net_create_fn, num_bins=10, tails=None, tail_bound=1.0,
+                 apply_unconditional_transform=False, img_shape=None, min_bin_width=DEFAULT_MIN_BIN_WIDTH,
+                 min_bin_height=DEFAULT_MIN_BIN_HEIGHT, min_derivative=DEFAULT_MIN_DERIVATIVE):
+        _check_tails(tails, tail_bound)
+        self.num_bins = num_bins
+        self.min_bin_width = min_bin_width
+        self.min_bin_height = min_bin_height
+        self.min_derivative = min_derivative
+        self.tails = tails
+        self.tail_bound = tail_bound
+        if apply_unconditional_transform:
+            unconditional_transform = lambda features: PiecewiseRationalQuadraticCDF(
+                shape=[features] + (img_shape if img_shape else []), num_bins=num_bins, tails=tails,
+                tail_bound=tail_bound, min_bin_width=min_bin_width, min_bin_height=min_bin_height,
+                min_derivative=min_derivative)
+        else:
+            unconditional_transform = None
+        super().__init__(mask, transform_net_create_fn, unconditional_transform=unconditional_transform)
+
+    def _transform_dim_multiplier(self):
+        if self.tails == "linear":
+            return self.num_bins * 3 - 1
+        elif self.tails == "circular":
+            return self.num_bins * 3
+        return self.num_bins * 3 + 1
+
+    def _wh_div(self):
+        net = self.transform_net
+        if hasattr(net, "hidden_features"):
+            return float(np.sqrt(net.hidden_features))
+        if hasattr(net, "hidden_channels"):
+            return float(np.sqrt(net.hidden_channels))
+        warnings.warn("Inputs to the softmax are not scaled down: initialization might be bad.")
+        return 1.0
+
+    def _kernel_kwargs(self):
+        return dict(tails=self.tails, tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
+                    min_bin_height=self.min_bin_height, min_derivative=self.min_derivative, wh_div=self._wh_div())
+
+    def _uncond(self):
+        u = self.unconditional_transform
+        if u is None:
+            return None, None, None
+        return u.unnormalized_widths.detach(), u.unnormalized_heights.detach(), u.unnormalized_derivatives.detach()
+
+    def _conditioner(self, rows, context):
+        ident = rows.index_select(1, self.identity_features)
+        out = self.transform_net(ident, context)
+        return out.contiguous()
+
+    def _density(self, inputs, context=None, ld=None, acc=None):
+        """prqct.forward (nsf/coupling.py:71-98): conditioner on the raw identity features."""
+        self._check(inputs)
+        cond = self._conditioner(inputs, context)
+        uw, uh, ud = self._uncond()
+        return ops.rqs_coupling(inputs, cond, uw, uh, ud, self.identity_features, self.transform_features,
+                                self.num_bins, L.RQS_DENSITY, logdet=ld, acc=acc, **self._kernel_kwargs())
+
+    def _sample(self, inputs, context=None, ld=None, acc=None):
+        """prqct.inverse (nsf/coupling.py:100-128): CDF^-1 on the identity half first, conditioner on ITS output."""
+        self._check(inputs)
+        uw, uh, ud = self._uncond()
+        kw = self._kernel_kwargs()
+        y, ld = ops.rqs_coupling(inputs, None, uw, uh, ud, self.identity_features, self.transform_features,
+                                 self.num_bins, L.RQS_SAMPLE_IDENTITY, logdet=ld, acc=acc, **kw)
+        cond = self._conditioner(y, context)
+        acc2 = acc if acc not in (None, L.LD_WRITE) else L.LD_ADD
+        return ops.rqs_coupling(inputs, cond, uw, uh, ud, self.identity_features, self.transform_features,
+                                self.num_bins, L.RQS_SAMPLE_TRANSFORM, y=y, logdet=ld, acc=acc2, **kw)
+
+    def forward(self, inputs, context=None):
+        return self._density(inputs, context)
+
+    def inverse(self, inputs, context=None):
+        return self._sample(inputs, context)
+
+
+class CoupledRationalQuadraticSpline(Flow):
+    """Neural spline flow coupling layer (wrapper.py:14-85).  NOTE the direction swap of the reference:
+    forward (generative) = prqct.inverse, inverse (normalising) = prqct.forward."""
+
+    def __init__(self, num_input_channels, num_blocks, num_hidden_channels, num_context_channels=None, num_bins=8,
+                 tails="linear", tail_bound=3.0, activation=nn.ReLU, dropout_probability=0.0, reverse_mask=False,
+                 init_identity=True):
+        super().__init__()
+
+        def transform_net_create_fn(in_features, out_features):
+            net = ResidualNet(in_features=in_features, out_features=out_features,
+                              context_features=num_context_channels, hidden_features=num_hidden_channels,
+                              num_blocks=num_blocks, activation=activation(),
+                              dropout_probability=dropout_probability, use_batch_norm=False)
+            if init_identity:
+                torch.nn.init.constant_(net.final_layer.weight, 0.0)
+                torch.nn.init.constant_(net.final_layer.bias, np.log(np.exp(1 - DEFAULT_MIN_DERIVATIVE) - 1))
+            return net
+
+        self.prqct = PiecewiseRationalQuadraticCoupling(
+            mask=create_alternating_binary_mask(num_input_channels, even=reverse_mask),
+            transform_net_create_fn=transform_net_create_fn, num_bins=num_bins, tails=tails, tail_bound=tail_bound,
+            apply_unconditional_transform=True)
+
+    def forward(self, z, context=None):
+        z, log_det = self.prqct._sample(z, context)
+        return z, log_det.view(-1)
+
+    def inverse(self, z, context=None):
+        z, log_det = self.prqct._density(z, context)
+        return z, log_det.view(-1)
+
+    def _run(self, z, inverse, ld, acc, context=None, **kw):
+        if inverse:
+            y, _ = self.prqct._density(z, context, ld=ld, acc=acc)
+        else:
+            y, _ = self.prqct._sample(z, context, ld=ld, acc=acc)
+        return y

@@ -1,0 +1,231 @@
+"""Tensor-level wrappers: one Python function per C-ABI entry point of include/nf_mi355x.h.
+
+Each wrapper validates devices/dtypes, allocates outputs with torch.empty on the input's device and
+enqueues exactly one kernel on torch's current HIP stream.  No arithmetic happens in Python.
+"""
+import math
+
+import torch
+
+from . import _lib as L
+from ._lib import f64, i32, i64, ptr
+
+
+def _ld_buffer(logdet, B, like):
+    if logdet is None:
+        return torch.empty(B, dtype=like.dtype, device=like.device), L.LD_WRITE
+    return logdet, None
+
+
+def rqs_spline(x, w, h, d, inverse=False, tails="linear", tail_bound=1.0, left=0.0, right=1.0, bottom=0.0, top=1.0,
+               min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, wh_div=1.0):
+    """utils/splines.py:16-97 / :100-219.  x (...,), w/h (..., K), d (..., K-1|K|K+1); last-dim strided views of one
+    parameter block are accepted (row stride taken from .stride(-2))."""
+    L.require_device(x, w, h, d)
+    K = w.shape[-1]
+    xs = x.contiguous().view(-1)
+    N = xs.numel()
+
+    def rows(a):
+        a2 = a.reshape(N, a.shape[-1]) if N > 0 else a.reshape(0, a.shape[-1])
+        if a2.stride(-1) != 1:
+            a2 = a2.contiguous()
+        return a2
+
+    w2, h2, d2 = rows(w), rows(h), rows(d)
+    y = torch.empty_like(xs)
+    lad = torch.empty_like(xs)
+    rc = L.lib().nf_rqs_spline(ptr_any(xs), ptr_any(w2), i64(w2.stride(0) if N else K), ptr_any(h2),
+                               i64(h2.stride(0) if N else K), ptr_any(d2), i64(d2.stride(0) if N else 1), ptr_any(y),
+                               ptr_any(lad), i64(N), i32(K), i32(L.TAILS[tails]), f64(tail_bound), f64(left), f64(right),
+                               f64(bottom), f64(top), f64(min_bin_width), f64(min_bin_height), f64(min_derivative),
+                               f64(wh_div), i32(int(inverse)), i32(L.dtype_code(x)), L.stream())
+    L.check(rc, "nf_rqs_spline")
+    return y.view(x.shape), lad.view(x.shape)
+
+
+def ptr_any(t):
+    """Device pointer of a tensor whose rows may be strided (last dim unit stride)."""
+    import ctypes
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def rqs_coupling(x, cond, uw, uh, ud, identity_idx, transform_idx, K, mode, y=None, logdet=None, acc=None,
+                 tails="linear", tail_bound=3.0, min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3,
+                 wh_div=1.0):
+    """nsf/coupling.py:71-128 given the conditioner output `cond` (B, nT*M) or (B, nT, M)."""
+    L.require_device(x, cond, uw, uh, ud, identity_idx, transform_idx)
+    B, D = x.shape
+    x = x.contiguous()
+    if y is None:
+        y = torch.empty_like(x)
+    if logdet is None:
+        logdet = torch.empty(B, dtype=x.dtype, device=x.device)
+        acc = L.LD_WRITE
+    elif acc is None:
+        acc = L.LD_ADD
+    rc = L.lib().nf_rqs_coupling(ptr(x), ptr(y), ptr(logdet), ptr(cond), ptr(uw), ptr(uh), ptr(ud),
+                                 ptr(identity_idx), i32(identity_idx.numel()), ptr(transform_idx),
+                                 i32(transform_idx.numel()), i64(B), i32(D), i32(K), i32(L.TAILS[tails]),
+                                 f64(tail_bound), f64(min_bin_width), f64(min_bin_height), f64(min_derivative),
+                                 f64(wh_div), i32(mode), i32(acc), i32(L.dtype_code(x)), L.stream())
+    L.check(rc, "nf_rqs_coupling")
+    return y, logdet
+
+
+def lu_linear_permute(x, perm, lower_entries, upper_entries, unconstrained_upper_diag, bias, direction, eps=1e-3,
+                      logdet=None, acc=None):
+    """mixing.py:535-563.  direction 0 = density (LULinearPermute.inverse), 1 = sample (.forward)."""
+    L.require_device(x, perm, lower_entries, upper_entries, unconstrained_upper_diag, bias)
+    B, D = x.shape
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    if logdet is None:
+        logdet = torch.empty(B, dtype=x.dtype, device=x.device)
+        acc = L.LD_WRITE
+    elif acc is None:
+        acc = L.LD_ADD
+    rc = L.lib().nf_lu_linear_permute(ptr(x), ptr(y), ptr(logdet), ptr(perm), ptr(lower_entries), ptr(upper_entries),
+                                      ptr(unconstrained_upper_diag), ptr(bias), i64(B), i32(D), f64(eps),
+                                      i32(direction), i32(acc), i32(L.dtype_code(x)), L.stream())
+    L.check(rc, "nf_lu_linear_permute")
+    return y, logdet
+
+
+def masked_affine(z, b, s, t, direction, logdet=None, acc=None):
+    """affine/coupling.py:209-229.  b broadcastable to z.shape[1:]; s, t same shape as z or None."""
+    L.require_device(z, b, s, t)
+    z = z.contiguous()
+    B = z.shape[0]
+    inner = z[0].numel() if B else int(math.prod(z.shape[1:]))
+    bb = b.to(z.dtype)
+    if bb.numel() != inner:
+        bb = bb.expand((1,) + tuple(z.shape[1:]))
+    bb = bb.contiguous().view(-1)
+    y = torch.empty_like(z)
+    if logdet is None:
+        logdet = torch.empty(B, dtype=z.dtype, device=z.device)
+        acc = L.LD_WRITE
+    elif acc is None:
+        acc = L.LD_ADD
+    s = None if s is None else s.contiguous()
+    t = None if t is None else t.contiguous()
+    rc = L.lib().nf_masked_affine(ptr(z), ptr(bb), ptr(s), ptr(t), ptr(y), ptr(logdet), i64(B), i64(inner),
+                                  i32(direction), i32(acc), i32(L.dtype_code(z)), L.stream())
+    L.check(rc, "nf_masked_affine")
+    return y, logdet
+
+
+def affine_coupling(z, param, c1, flip, scale_map, direction, logdet=None, acc=None):
+    """affine/coupling.py:117-171 + channel Split/Merge.  z (B, C, *spatial), param (B, P, *spatial)."""
+    L.require_device(z, param)
+    z = z.contiguous()
+    param = param.contiguous()
+    B, Cc = z.shape[:2]
+    HW = int(math.prod(z.shape[2:])) if z.dim() > 2 else 1
+    y = torch.empty_like(z)
+    if logdet is None:
+        logdet = torch.empty(B, dtype=z.dtype, device=z.device)
+        acc = L.LD_WRITE
+    elif acc is None:
+        acc = L.LD_ADD
+    rc = L.lib().nf_affine_coupling(ptr(z), ptr(param), ptr(y), ptr(logdet), i64(B), i32(Cc), i32(c1), i32(int(flip)),
+                                    i64(HW), i32(L.SCALE[scale_map]), i32(direction), i32(acc),
+                                    i32(L.dtype_code(z)), L.stream())
+    L.check(rc, "nf_affine_coupling")
+    return y, logdet
+
+
+def actnorm(z, s, t, direction, logdet=None, acc=None, want_scalar=True):
+    """affine/coupling.py:38-54 with s, t of C elements (shape (1,C,1,..,1) flattened)."""
+    L.require_device(z, s, t)
+    z = z.contiguous()
+    B, Cc = z.shape[:2]
+    HW = int(math.prod(z.shape[2:])) if z.dim() > 2 else 1
+    y = torch.empty_like(z)
+    lds = torch.empty((), dtype=z.dtype, device=z.device) if want_scalar else None
+    if logdet is not None and acc is None:
+        acc = L.LD_ADD
+    rc = L.lib().nf_actnorm(ptr(z), ptr(s.contiguous().view(-1)), ptr(t.contiguous().view(-1)), ptr(y), ptr(lds),
+                            ptr(logdet), i64(B), i32(Cc), i64(HW), i32(direction), i32(acc or 0), i32(L.dtype_code(z)),
+                            L.stream())
+    L.check(rc, "nf_actnorm")
+    return y, lds
+
+
+def actnorm_stats(z):
+    L.require_device(z)
+    z = z.contiguous()
+    B, Cc = z.shape[:2]
+    HW = int(math.prod(z.shape[2:])) if z.dim() > 2 else 1
+    mean = torch.empty(Cc, dtype=z.dtype, device=z.device)
+    std = torch.empty(Cc, dtype=z.dtype, device=z.device)
+    rc = L.lib().nf_actnorm_stats(ptr(z), ptr(mean), ptr(std), i64(B), i32(Cc), i64(HW), i32(L.dtype_code(z)),
+                                  L.stream())
+    L.check(rc, "nf_actnorm_stats")
+    return mean, std
+
+
+def actnorm_init(mean, std, s_out, t_out, direction):
+    L.require_device(mean, std, s_out, t_out)
+    rc = L.lib().nf_actnorm_init(ptr(mean), ptr(std), ptr(s_out), ptr(t_out), i32(mean.numel()), i32(direction),
+                                 i32(L.dtype_code(mean)), L.stream())
+    L.check(rc, "nf_actnorm_init")
+
+
+def inv1x1_assemble(P, Lm, U, sign_S, log_S, inverse):
+    L.require_device(P, Lm, U, sign_S, log_S)
+    Cc = Lm.shape[0]
+    W = torch.empty((Cc, Cc), dtype=Lm.dtype, device=Lm.device)
+    ldu = torch.empty((), dtype=Lm.dtype, device=Lm.device)
+    rc = L.lib().nf_inv1x1_assemble(ptr(P.contiguous()), ptr(Lm.contiguous()), ptr(U.contiguous()),
+                                    ptr(sign_S.contiguous()), ptr(log_S.contiguous()), ptr(W), ptr(ldu), i32(Cc),
+                                    i32(int(inverse)), i32(L.dtype_code(Lm)), L.stream())
+    L.check(rc, "nf_inv1x1_assemble")
+    return W, ldu
+
+
+def inv1x1_conv(z, W, logdet_unit, logdet=None, acc=None, want_scalar=True):
+    L.require_device(z, W, logdet_unit)
+    z = z.contiguous()
+    B, Cc = z.shape[:2]
+    HW = int(math.prod(z.shape[2:]))
+    y = torch.empty_like(z)
+    lds = torch.empty((), dtype=z.dtype, device=z.device) if want_scalar else None
+    if logdet is not None and acc is None:
+        acc = L.LD_ADD
+    rc = L.lib().nf_inv1x1_conv(ptr(z), ptr(W.contiguous()), ptr(logdet_unit), ptr(y), ptr(lds), ptr(logdet), i64(B),
+                                i32(Cc), i64(HW), i32(acc or 0), i32(L.dtype_code(z)), L.stream())
+    L.check(rc, "nf_inv1x1_conv")
+    return y, lds
+
+
+def diag_gaussian_log_prob(z, loc, log_scale, log_scale_shift=0.0, out=None, acc=None):
+    """distributions/base.py:94-103."""
+    L.require_device(z, loc, log_scale)
+    z = z.contiguous()
+    B = z.shape[0]
+    d = int(math.prod(z.shape[1:]))
+    if out is None:
+        out = torch.empty(B, dtype=z.dtype, device=z.device)
+        acc = L.LD_WRITE
+    elif acc is None:
+        acc = L.LD_ADD
+    rc = L.lib().nf_diag_gaussian_log_prob(ptr(z), ptr(loc.contiguous().view(-1)), ptr(log_scale.contiguous().view(-1)),
+                                           f64(log_scale_shift), ptr(out), i64(B), i64(d), i32(acc),
+                                           i32(L.dtype_code(z)), L.stream())
+    L.check(rc, "nf_diag_gaussian_log_prob")
+    return out
+
+
+def squeeze(z, direction):
+    """flows/reshape.py:116-128.  direction 0 = Squeeze.forward, 1 = Squeeze.inverse."""
+    L.require_device(z)
+    z = z.contiguous()
+    B, Cc, H, W = z.shape
+    shape = (B, Cc // 4, 2 * H, 2 * W) if direction == 0 else (B, 4 * Cc, H // 2, W // 2)
+    y = torch.empty(shape, dtype=z.dtype, device=z.device)
+    rc = L.lib().nf_squeeze(ptr(z), ptr(y), i64(B), i32(Cc), i32(H), i32(W), i32(direction), i32(L.dtype_code(z)),
+                            L.stream())
+    L.check(rc, "nf_squeeze")
+    return y

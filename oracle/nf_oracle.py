@@ -1,0 +1,316 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle/libnf_oracle.so).
+
+TEST INFRASTRUCTURE ONLY -- see the header of oracle/nf_oracle.c.  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg import this module; the product package (normalizing-flows_amd/) never does.
+
+Every function takes and returns numpy arrays (float32 or float64, C-contiguous) and mirrors one entry
+point of include/nf_mi355x.h; `OracleNSF` chains them into the NormalizingFlow.log_prob / sample loops of
+normflows/core.py:167-197 for a stack of [CoupledRationalQuadraticSpline, LULinearPermute] layers.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libnf_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("nf_oracle.c", "nf_oracle_impl.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+    return _LIB
+
+
+def _sfx(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return "_f32"
+    if dtype == np.float64:
+        return "_f64"
+    raise TypeError("oracle supports float32/float64, got %s" % dtype)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dtype):
+    return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+_TAILS = {None: 0, "linear": 1, "circular": 2}
+
+
+def rqs_spline(x, w, h, d, inverse=False, tails="linear", tail_bound=1.0, left=0.0, right=1.0, bottom=0.0, top=1.0,
+               min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, wh_div=1.0):
+    """utils/splines.py:16-97 / :100-219 on arrays x (...,), w,h (..., K), d (..., K-1|K|K+1)."""
+    dt = x.dtype
+    K = w.shape[-1]
+    xs = _c(x, dt).reshape(-1)
+    N = xs.size
+    w2, h2, d2 = (_c(a, dt).reshape(N, -1) for a in (w, h, d))
+    y = np.empty_like(xs)
+    lad = np.empty_like(xs)
+    f = getattr(lib(), "nfo_rqs_spline" + _sfx(dt))
+    f(_p(xs), _p(w2), C.c_int64(w2.shape[1]), _p(h2), C.c_int64(h2.shape[1]), _p(d2), C.c_int64(d2.shape[1]), _p(y),
+      _p(lad), C.c_int64(N), C.c_int(K), C.c_int(_TAILS[tails]), C.c_double(tail_bound), C.c_double(left),
+      C.c_double(right), C.c_double(bottom), C.c_double(top), C.c_double(min_bin_width), C.c_double(min_bin_height),
+      C.c_double(min_derivative), C.c_double(wh_div), C.c_int(int(inverse)))
+    return y.reshape(x.shape), lad.reshape(x.shape)
+
+
+def rqs_coupling(x, cond, uw, uh, ud, identity_idx, transform_idx, K, mode, y=None, logdet=None, acc=0,
+                 tails="linear", tail_bound=3.0, min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3,
+                 wh_div=1.0):
+    dt = x.dtype
+    x = _c(x, dt)
+    B, D = x.shape
+    ii, ti = _i64(identity_idx), _i64(transform_idx)
+    y = x.copy() if y is None else y
+    logdet = np.zeros(B, dt) if logdet is None else logdet
+    cond, uw, uh, ud = (_c(a, dt) for a in (cond, uw, uh, ud))
+    f = getattr(lib(), "nfo_rqs_coupling" + _sfx(dt))
+    f(_p(x), _p(y), _p(logdet), _p(cond), _p(uw), _p(uh), _p(ud), _p(ii), C.c_int(ii.size), _p(ti), C.c_int(ti.size),
+      C.c_int64(B), C.c_int(D), C.c_int(K), C.c_int(_TAILS[tails]), C.c_double(tail_bound), C.c_double(min_bin_width),
+      C.c_double(min_bin_height), C.c_double(min_derivative), C.c_double(wh_div), C.c_int(mode), C.c_int(acc))
+    return y, logdet
+
+
+def resnet_mlp(x, idx, w_init, b_init, w_blocks, b_blocks, w_final, b_final):
+    """nets/resnet.py:92-104; w_blocks/b_blocks are flat lists [blk0.lin0, blk0.lin1, blk1.lin0, ...]."""
+    dt = x.dtype
+    x = _c(x, dt)
+    B, ldx = x.shape
+    hidden, in_f = w_init.shape
+    out_f = w_final.shape[0]
+    assert hidden <= 1024
+    idx_a = None if idx is None else _i64(idx)
+    ws = [_c(a, dt) for a in w_blocks]
+    bs = [_c(a, dt) for a in b_blocks]
+    wp = (C.c_void_p * len(ws))(*[a.ctypes.data for a in ws])
+    bp = (C.c_void_p * len(bs))(*[a.ctypes.data for a in bs])
+    out = np.empty((B, out_f), dt)
+    w_init, b_init, w_final, b_final = (_c(a, dt) for a in (w_init, b_init, w_final, b_final))
+    f = getattr(lib(), "nfo_resnet_mlp" + _sfx(dt))
+    f(_p(x), C.c_int64(ldx), _p(idx_a), C.c_int(in_f), _p(w_init), _p(b_init), wp, bp, C.c_int(len(ws) // 2),
+      _p(w_final), _p(b_final), C.c_int(hidden), C.c_int(out_f), _p(out), C.c_int64(B))
+    return out
+
+
+def lu_linear_permute(x, perm, lower_entries, upper_entries, udiag_raw, bias, direction, eps=1e-3, logdet=None, acc=0):
+    dt = x.dtype
+    x = _c(x, dt)
+    B, D = x.shape
+    assert D <= 1024
+    y = np.empty_like(x)
+    logdet = np.zeros(B, dt) if logdet is None else logdet
+    pm = _i64(perm)
+    lo, up, ud, bi = (_c(a, dt) for a in (lower_entries, upper_entries, udiag_raw, bias))
+    f = getattr(lib(), "nfo_lu_linear_permute" + _sfx(dt))
+    f(_p(x), _p(y), _p(logdet), _p(pm), _p(lo), _p(up), _p(ud), _p(bi), C.c_int64(B), C.c_int(D), C.c_double(eps),
+      C.c_int(direction), C.c_int(acc))
+    return y, logdet
+
+
+def masked_affine(z, b, s, t, direction, logdet=None, acc=0):
+    dt = z.dtype
+    z = _c(z, dt)
+    B = z.shape[0]
+    inner = int(np.prod(z.shape[1:]))
+    y = np.empty_like(z)
+    logdet = np.zeros(B, dt) if logdet is None else logdet
+    b, s, t = _c(np.broadcast_to(b, z.shape[1:]) if b is not None else None, dt), _c(s, dt), _c(t, dt)
+    f = getattr(lib(), "nfo_masked_affine" + _sfx(dt))
+    f(_p(z), _p(b), _p(s), _p(t), _p(y), _p(logdet), C.c_int64(B), C.c_int64(inner), C.c_int(direction), C.c_int(acc))
+    return y, logdet
+
+
+_SCALE = {"exp": 0, "sigmoid": 1, "sigmoid_inv": 2, None: 3}
+
+
+def affine_coupling(z, param, c1, flip, scale_map, direction, logdet=None, acc=0):
+    dt = z.dtype
+    z = _c(z, dt)
+    B, Cc = z.shape[:2]
+    HW = int(np.prod(z.shape[2:])) if z.ndim > 2 else 1
+    y = np.empty_like(z)
+    logdet = np.zeros(B, dt) if logdet is None else logdet
+    param = _c(param, dt)
+    f = getattr(lib(), "nfo_affine_coupling" + _sfx(dt))
+    f(_p(z), _p(param), _p(y), _p(logdet), C.c_int64(B), C.c_int(Cc), C.c_int(c1), C.c_int(int(flip)), C.c_int64(HW),
+      C.c_int(_SCALE[scale_map]), C.c_int(direction), C.c_int(acc))
+    return y, logdet
+
+
+def actnorm(z, s, t, direction, logdet=None, acc=0):
+    dt = z.dtype
+    z = _c(z, dt)
+    B, Cc = z.shape[:2]
+    HW = int(np.prod(z.shape[2:])) if z.ndim > 2 else 1
+    y = np.empty_like(z)
+    lds = np.zeros(1, dt)
+    s, t = _c(s, dt).reshape(-1), _c(t, dt).reshape(-1)
+    f = getattr(lib(), "nfo_actnorm" + _sfx(dt))
+    f(_p(z), _p(s), _p(t), _p(y), _p(lds), _p(logdet), C.c_int64(B), C.c_int(Cc), C.c_int64(HW), C.c_int(direction),
+      C.c_int(acc))
+    return y, lds[0]
+
+
+def actnorm_stats(z):
+    dt = z.dtype
+    z = _c(z, dt)
+    B, Cc = z.shape[:2]
+    HW = int(np.prod(z.shape[2:])) if z.ndim > 2 else 1
+    mean, std = np.empty(Cc, dt), np.empty(Cc, dt)
+    getattr(lib(), "nfo_actnorm_stats" + _sfx(dt))(_p(z), _p(mean), _p(std), C.c_int64(B), C.c_int(Cc), C.c_int64(HW))
+    return mean, std
+
+
+def actnorm_init(mean, std, direction):
+    dt = mean.dtype
+    s, t = np.empty_like(mean), np.empty_like(mean)
+    getattr(lib(), "nfo_actnorm_init" + _sfx(dt))(_p(_c(mean, dt)), _p(_c(std, dt)), _p(s), _p(t), C.c_int(mean.size),
+                                                 C.c_int(direction))
+    return s, t
+
+
+def inv1x1_assemble(P, L, U, sign_S, log_S, inverse):
+    dt = L.dtype
+    Cc = L.shape[0]
+    W = np.empty((Cc, Cc), dt)
+    ldu = np.zeros(1, dt)
+    P, L, U, sign_S, log_S = (_c(a, dt) for a in (P, L, U, sign_S, log_S))
+    getattr(lib(), "nfo_inv1x1_assemble" + _sfx(dt))(_p(P), _p(L), _p(U), _p(sign_S), _p(log_S), _p(W), _p(ldu),
+                                                    C.c_int(Cc), C.c_int(int(inverse)))
+    return W, ldu
+
+
+def inv1x1_conv(z, W, logdet_unit):
+    dt = z.dtype
+    z = _c(z, dt)
+    B, Cc = z.shape[:2]
+    HW = int(np.prod(z.shape[2:]))
+    y = np.empty_like(z)
+    lds = np.zeros(1, dt)
+    getattr(lib(), "nfo_inv1x1_conv" + _sfx(dt))(_p(z), _p(_c(W, dt)), _p(_c(logdet_unit, dt)), _p(y), _p(lds), None,
+                                                C.c_int64(B), C.c_int(Cc), C.c_int64(HW), C.c_int(0))
+    return y, lds[0]
+
+
+def diag_gaussian_log_prob(z, loc, log_scale, ls_shift=0.0, out=None, acc=0):
+    dt = z.dtype
+    z = _c(z, dt)
+    B = z.shape[0]
+    d = int(np.prod(z.shape[1:]))
+    out = np.zeros(B, dt) if out is None else out
+    loc, log_scale = _c(loc, dt).reshape(-1), _c(log_scale, dt).reshape(-1)
+    getattr(lib(), "nfo_diag_gaussian_log_prob" + _sfx(dt))(_p(z), _p(loc), _p(log_scale), C.c_double(ls_shift),
+                                                           _p(out), C.c_int64(B), C.c_int64(d), C.c_int(acc))
+    return out
+
+
+def squeeze(z, direction):
+    dt = z.dtype
+    z = _c(z, dt)
+    B, Cc, H, W = z.shape
+    y = np.empty((B, Cc // 4, 2 * H, 2 * W) if direction == 0 else (B, 4 * Cc, H // 2, W // 2), dt)
+    getattr(lib(), "nfo_squeeze" + _sfx(dt))(_p(z), _p(y), C.c_int64(B), C.c_int(Cc), C.c_int(H), C.c_int(W),
+                                            C.c_int(direction))
+    return y
+
+
+# ---------------------------------------------------------------------------------------------------------
+class OracleNSF:
+    """NormalizingFlow([CoupledRationalQuadraticSpline, LULinearPermute] * L, DiagGaussian) on the CPU oracle.
+
+    `state` is the normflows state_dict as {name: numpy array}; layer i lives under "flows.{i}.".
+    log_prob follows core.py:182-197, sample follows core.py:167-180 (given the base noise eps).
+    """
+
+    def __init__(self, state, num_layers, K=8, tail_bound=3.0, hidden=None):
+        self.st = {k: np.asarray(v) for k, v in state.items()}
+        self.n = num_layers
+        self.K = K
+        self.tail_bound = tail_bound
+
+    def _coupling_params(self, i):
+        p = "flows.%d.prqct." % i
+        s = self.st
+        nb = 0
+        while (p + "transform_net.blocks.%d.linear_layers.0.weight" % nb) in s:
+            nb += 1
+        wb, bb = [], []
+        for b in range(nb):
+            for l in range(2):
+                wb.append(s[p + "transform_net.blocks.%d.linear_layers.%d.weight" % (b, l)])
+                bb.append(s[p + "transform_net.blocks.%d.linear_layers.%d.bias" % (b, l)])
+        return dict(ii=s[p + "identity_features"], ti=s[p + "transform_features"],
+                    w0=s[p + "transform_net.initial_layer.weight"], b0=s[p + "transform_net.initial_layer.bias"],
+                    wb=wb, bb=bb, wf=s[p + "transform_net.final_layer.weight"],
+                    bf=s[p + "transform_net.final_layer.bias"], uw=s[p + "unconditional_transform.unnormalized_widths"],
+                    uh=s[p + "unconditional_transform.unnormalized_heights"],
+                    ud=s[p + "unconditional_transform.unnormalized_derivatives"])
+
+    def _lu_params(self, i):
+        p = "flows.%d." % i
+        s = self.st
+        return dict(perm=s[p + "permutation._permutation"], lo=s[p + "linear.lower_entries"],
+                    up=s[p + "linear.upper_entries"], ud=s[p + "linear.unconstrained_upper_diag"],
+                    bias=s[p + "linear.bias"])
+
+    def _is_coupling(self, i):
+        return ("flows.%d.prqct.identity_features" % i) in self.st
+
+    def coupling(self, i, z, direction, logq, acc):
+        c = self._coupling_params(i)
+        hidden = c["w0"].shape[0]
+        kw = dict(K=self.K, tail_bound=self.tail_bound, wh_div=float(np.sqrt(hidden)))
+        if direction == 0:  # density: wrapper.inverse -> prqct.forward
+            cond = resnet_mlp(z, c["ii"], c["w0"], c["b0"], c["wb"], c["bb"], c["wf"], c["bf"])
+            y, _ = rqs_coupling(z, cond, c["uw"], c["uh"], c["ud"], c["ii"], c["ti"], mode=0, logdet=logq, acc=acc, **kw)
+        else:  # sample: wrapper.forward -> prqct.inverse
+            y, _ = rqs_coupling(z, None, c["uw"], c["uh"], c["ud"], c["ii"], c["ti"], mode=1, logdet=logq, acc=acc, **kw)
+            cond = resnet_mlp(y, c["ii"], c["w0"], c["b0"], c["wb"], c["bb"], c["wf"], c["bf"])
+            y, _ = rqs_coupling(z, cond, c["uw"], c["uh"], c["ud"], c["ii"], c["ti"], mode=2, y=y, logdet=logq, acc=acc,
+                                **kw)
+        return y
+
+    def lu(self, i, z, direction, logq, acc):
+        l = self._lu_params(i)
+        y, _ = lu_linear_permute(z, l["perm"], l["lo"], l["up"], l["ud"], l["bias"], direction, logdet=logq, acc=acc)
+        return y
+
+    def log_prob(self, x):
+        z = np.ascontiguousarray(x)
+        logq = np.zeros(z.shape[0], z.dtype)
+        for i in range(self.n - 1, -1, -1):
+            z = (self.coupling if self._is_coupling(i) else self.lu)(i, z, 0, logq, +1)
+        loc, ls = self.st["q0.loc"], self.st["q0.log_scale"]
+        diag_gaussian_log_prob(z, loc, ls, out=logq, acc=+1)
+        return logq
+
+    def sample_from(self, eps):
+        """sample() of core.py:167-180 with the base noise given: z0 = loc + exp(log_scale) * eps."""
+        loc, ls = self.st["q0.loc"].reshape(1, -1), self.st["q0.log_scale"].reshape(1, -1)
+        dt = eps.dtype
+        z = np.ascontiguousarray(loc + np.exp(ls) * eps, dtype=dt)
+        d = z.shape[1]
+        logq = (-0.5 * d * np.log(2 * np.pi) - np.sum(ls + 0.5 * eps.astype(dt) ** 2, axis=1)).astype(dt)
+        for i in range(self.n):
+            z = (self.coupling if self._is_coupling(i) else self.lu)(i, z, 1, logq, -1)
+        return z, logq

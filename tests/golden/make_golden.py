@@ -1,0 +1,362 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz by running the REAL reference (normflows 1.7.3 at /root/reference, PyTorch CPU).
+
+Run in the build container only (the GPU box has no /root/reference):
+    python tests/golden/make_golden.py
+The fixtures pin the CPU oracle (tests/test_oracle_golden.py) and the HIP kernels (tests/test_gpu_parity.py).
+The reference's own tests contain no value-level golden vectors for this path; these
+files are outputs of the reference itself on seeded inputs, which is the strongest pin available.
+Every case stores its inputs, the parameters / conditioner outputs involved and the reference outputs, in
+float32 and (where cheap) float64.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, "/root/reference")
+import normflows as nf  # noqa: E402
+from normflows.utils import splines  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(4)
+
+
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote %-34s %6.1f KB" % (name + ".npz", os.path.getsize(os.path.join(OUT, name + ".npz")) / 1024))
+
+
+def sd(module, prefix=""):
+    return {prefix + k.replace(".", "__"): v for k, v in module.state_dict().items()}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def gen_splines():
+    """utils/splines.py: bounded (tails None), linear and circular tails, K in {2, 8, 10, 16}, edge inputs."""
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        g = torch.Generator().manual_seed(11)
+        for K in (2, 8, 10, 16):
+            shape = [6, 5]
+            w = torch.randn(*shape, K, generator=g, dtype=dt)
+            h = torch.randn(*shape, K, generator=g, dtype=dt)
+            # bounded spline on [0, 1]: inputs strictly inside
+            d_none = torch.randn(*shape, K + 1, generator=g, dtype=dt)
+            x01 = torch.rand(*shape, generator=g, dtype=dt) * 0.998 + 0.001
+            y, lad = splines.rational_quadratic_spline(x01, w.clone(), h.clone(), d_none.clone(), inverse=False)
+            xi, ladi = splines.rational_quadratic_spline(y, w.clone(), h.clone(), d_none.clone(), inverse=True)
+            # linear tails, bound 3: heavy-tailed inputs + explicit edge list
+            d_lin = torch.randn(*shape, K - 1, generator=g, dtype=dt)
+            xl = 4 * torch.randn(*shape, generator=g, dtype=dt)
+            edge = torch.tensor([3.0, -3.0, 3.0 * (1 + 2 ** -23), -3.0 * (1 + 2 ** -23), 3.0 * (1 - 2 ** -23), 0.0,
+                                 float("nan"), float("inf"), float("-inf"), 2.9999, -2.9999, 1e-30], dtype=dt)
+            xl.view(-1)[: edge.numel()] = edge
+            yl, ladl = splines.unconstrained_rational_quadratic_spline(xl, w.clone(), h.clone(), d_lin.clone(),
+                                                                       inverse=False, tails="linear", tail_bound=3.0)
+            xli, ladli = splines.unconstrained_rational_quadratic_spline(xl, w.clone(), h.clone(), d_lin.clone(),
+                                                                         inverse=True, tails="linear", tail_bound=3.0)
+            # circular tails
+            d_cir = torch.randn(*shape, K, generator=g, dtype=dt)
+            yc, ladc = splines.unconstrained_rational_quadratic_spline(xl, w.clone(), h.clone(), d_cir.clone(),
+                                                                       inverse=False, tails="circular", tail_bound=2.5)
+            yci, ladci = splines.unconstrained_rational_quadratic_spline(xl, w.clone(), h.clone(), d_cir.clone(),
+                                                                         inverse=True, tails="circular", tail_bound=2.5)
+            npz("spline_K%d_%s" % (K, tag), w=w, h=h, d_none=d_none, x01=x01, y01=y, lad01=lad, x01_inv=xi, lad01_inv=ladi,
+                d_lin=d_lin, xl=xl, yl=yl, ladl=ladl, yl_inv=xli, ladl_inv=ladli, d_cir=d_cir, yc=yc, ladc=ladc,
+                yc_inv=yci, ladc_inv=ladci)
+        # inputs exactly on interior knots (K = 8, linear tails): bin k, maps to knot_y_k
+        K = 8
+        w = torch.randn(4, K, generator=g, dtype=dt)
+        h = torch.randn(4, K, generator=g, dtype=dt)
+        dl = torch.randn(4, K - 1, generator=g, dtype=dt)
+        wn = 1e-3 + (1 - 1e-3 * K) * torch.softmax(w, -1)
+        cw = torch.nn.functional.pad(torch.cumsum(wn, -1), (1, 0)) * 6.0 - 3.0
+        cw[..., 0] = -3.0
+        cw[..., -1] = 3.0
+        xk = cw[:, 1:K].contiguous()  # (4, 7) interior knots
+        wk = w[:, None, :].expand(4, K - 1, K).contiguous()
+        hk = h[:, None, :].expand(4, K - 1, K).contiguous()
+        dk = dl[:, None, :].expand(4, K - 1, K - 1).contiguous()
+        yk, ladk = splines.unconstrained_rational_quadratic_spline(xk, wk.clone(), hk.clone(), dk.clone(), inverse=False,
+                                                                   tails="linear", tail_bound=3.0)
+        npz("spline_knots_%s" % tag, w=wk, h=hk, d=dk, x=xk, y=yk, lad=ladk)
+
+
+def perturb(module, sigma, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in module.parameters():
+            p.add_(sigma * torch.randn(p.shape, generator=g, dtype=p.dtype))
+
+
+def gen_nsf_layers():
+    """CoupledRationalQuadraticSpline (wrapper.py) and LULinearPermute (mixing.py), per layer, both directions."""
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        for d, hidden, K in ((2, 16, 8), (5, 16, 4), (64, 32, 8), (7, 24, 10)):
+            torch.manual_seed(100 + d)
+            layer = nf.flows.CoupledRationalQuadraticSpline(d, 2, hidden, num_bins=K, init_identity=False,
+                                                            reverse_mask=(d == 5))
+            perturb(layer, 0.3, 5)
+            with torch.no_grad():
+                layer.prqct.unconditional_transform.unnormalized_widths.normal_()
+                layer.prqct.unconditional_transform.unnormalized_heights.normal_()
+                layer.prqct.unconditional_transform.unnormalized_derivatives.normal_()
+            layer = layer.to(dt)
+            g = torch.Generator().manual_seed(d)
+            x = 2.0 * torch.randn(24, d, generator=g, dtype=dt)
+            x[0, 0] = 3.0
+            x[1, -1] = -3.0
+            x[2, 0] = 5.5
+            with torch.no_grad():
+                # conditioner outputs seen by each direction (for kernel-level tests)
+                ident = x[:, layer.prqct.identity_features]
+                cond_density = layer.prqct.transform_net(ident)
+                z_inv, ld_inv = layer.inverse(x)       # density direction
+                z_fwd, ld_fwd = layer.forward(x)       # sampling direction
+                ident_s = z_fwd[:, layer.prqct.identity_features]
+                cond_sample = layer.prqct.transform_net(ident_s)
+            npz("crqs_d%d_%s" % (d, tag), x=x, cond_density=cond_density, cond_sample=cond_sample, z_inv=z_inv,
+                ld_inv=ld_inv, z_fwd=z_fwd, ld_fwd=ld_fwd, hidden=hidden, K=K, **sd(layer, "sd__"))
+        for d in (3, 4, 64):
+            torch.manual_seed(200 + d)
+            layer = nf.flows.LULinearPermute(d, identity_init=False)
+            perturb(layer, 0.2, 6)
+            layer = layer.to(dt)
+            g = torch.Generator().manual_seed(50 + d)
+            x = torch.randn(19, d, generator=g, dtype=dt)
+            with torch.no_grad():
+                z_inv, ld_inv = layer.inverse(x)
+                z_fwd, ld_fwd = layer.forward(x)
+            npz("lulinear_d%d_%s" % (d, tag), x=x, z_inv=z_inv, ld_inv=ld_inv, z_fwd=z_fwd, ld_fwd=ld_fwd,
+                **sd(layer, "sd__"))
+
+
+def gen_affine():
+    """MaskedAffineFlow, AffineCouplingBlock, ActNorm, Invertible1x1Conv, GlowBlock, DiagGaussian, Squeeze."""
+    dt = torch.float32
+    for d in (2, 7):
+        torch.manual_seed(300 + d)
+        b = torch.tensor([1.0 if i % 2 == 0 else 0.0 for i in range(d)])
+        s = nf.nets.MLP([d, 2 * d, d])
+        t = nf.nets.MLP([d, 2 * d, d])
+        layer = nf.flows.MaskedAffineFlow(b, t, s)
+        g = torch.Generator().manual_seed(d)
+        z = torch.randn(9, d, generator=g)
+        with torch.no_grad():
+            sv, tv = s(b * z), t(b * z)
+            zf, ldf = layer.forward(z)
+            zi, ldi = layer.inverse(z)
+        npz("masked_affine_d%d" % d, z=z, b=b, s=sv, t=tv, z_fwd=zf, ld_fwd=ldf, z_inv=zi, ld_inv=ldi, **sd(layer, "sd__"))
+    # non-finite s / t handling (coupling.py:212-215)
+    z = torch.randn(4, 2)
+    b = torch.tensor([0.0, 1.0])
+
+    class Const(torch.nn.Module):
+        def __init__(self, v):
+            super().__init__()
+            self.v = v
+
+        def forward(self, x):
+            return self.v
+
+    sv = torch.tensor([[0.1, 0.2], [float("inf"), 0.0], [0.3, float("nan")], [-0.2, 0.5]])
+    tv = torch.tensor([[0.0, 1.0], [1.0, 1.0], [2.0, 0.0], [float("-inf"), 0.1]])
+    layer = nf.flows.MaskedAffineFlow(b, Const(tv), Const(sv))
+    zf, ldf = layer.forward(z)
+    zi, ldi = layer.inverse(z)
+    npz("masked_affine_nonfinite", z=z, b=b, s=sv, t=tv, z_fwd=zf, ld_fwd=ldf, z_inv=zi, ld_inv=ldi)
+
+    for C, split, smap, scale in ((4, "channel", "exp", True), (5, "channel", "sigmoid", True),
+                                  (5, "channel_inv", "sigmoid_inv", True), (3, "channel_inv", "exp", False),
+                                  (4, "checkerboard", "sigmoid", True), (6, "checkerboard_inv", "exp", True)):
+        torch.manual_seed(400 + C)
+        if "checkerboard" in split:
+            ch = (C, 8, 8, (2 if scale else 1) * C)
+        elif split == "channel":
+            ch = ((C + 1) // 2, 8, 8, (2 if scale else 1) * (C // 2))
+        else:
+            ch = (C // 2, 8, 8, (2 if scale else 1) * ((C + 1) // 2))
+        net = nf.nets.ConvNet2d(ch, (3, 1, 3), 0.0, init_zeros=False)
+        layer = nf.flows.AffineCouplingBlock(net, scale, smap, split)
+        g = torch.Generator().manual_seed(C)
+        z = torch.randn(3, C, 4, 4, generator=g)
+        with torch.no_grad():
+            [z1, z2], _ = layer.flows[0](z)
+            param = net(z1)
+            zf, ldf = layer.forward(z)
+            zi, ldi = layer.inverse(z)
+        npz("affine_block_C%d_%s_%s" % (C, split, smap if scale else "noscale"), z=z, param=param, z_fwd=zf, ld_fwd=ldf,
+            z_inv=zi, ld_inv=ldi, **sd(layer, "sd__"))
+    # 2-D AffineCouplingBlock with an MLP (real_nvp_colab / README path)
+    torch.manual_seed(410)
+    layer = nf.flows.AffineCouplingBlock(nf.nets.MLP([1, 16, 16, 2], init_zeros=False))
+    z = torch.randn(11, 2)
+    with torch.no_grad():
+        param = layer.flows[1].param_map(z[:, :1])
+        zf, ldf = layer.forward(z)
+        zi, ldi = layer.inverse(z)
+    npz("affine_block_2d", z=z, param=param, z_fwd=zf, ld_fwd=ldf, z_inv=zi, ld_inv=ldi, **sd(layer, "sd__"))
+
+    # ActNorm: data-dependent init, forward-first and inverse-first (normalization.py:19-39)
+    for shape, zshape in (((6, 1, 1), (5, 6, 4, 4)), ((3,), (17, 3))):
+        g = torch.Generator().manual_seed(len(zshape))
+        z = torch.randn(*zshape, generator=g) * 1.7 + 0.4
+        z2 = torch.randn(*zshape, generator=g)
+        a = nf.flows.ActNorm(shape)
+        with torch.no_grad():
+            zf, ldf = a.forward(z)
+            s_f, t_f = a.s.clone(), a.t.clone()
+            zf2, ldf2 = a.forward(z2)     # second call: no re-init
+            zi2, ldi2 = a.inverse(z2)
+        bnew = nf.flows.ActNorm(shape)
+        with torch.no_grad():
+            zi, ldi = bnew.inverse(z)
+            s_i, t_i = bnew.s.clone(), bnew.t.clone()
+        npz("actnorm_%dd" % len(zshape), z=z, z2=z2, z_fwd=zf, ld_fwd=ldf, s_fwd=s_f, t_fwd=t_f, z2_fwd=zf2, ld2_fwd=ldf2,
+            z2_inv=zi2, ld2_inv=ldi2, z_inv=zi, ld_inv=ldi, s_inv=s_i, t_inv=t_i)
+
+    # Invertible1x1Conv (LU and plain), mixing.py:57-133
+    for C, use_lu in ((3, True), (4, True), (12, True), (48, True), (4, False)):
+        torch.manual_seed(500 + C)
+        layer = nf.flows.Invertible1x1Conv(C, use_lu)
+        perturb(layer, 0.1, 9)
+        g = torch.Generator().manual_seed(C)
+        z = torch.randn(2, C, 3, 5, generator=g)
+        with torch.no_grad():
+            zf, ldf = layer.forward(z)
+            zi, ldi = layer.inverse(z)
+            extra = {}
+            if use_lu:
+                extra = dict(W_inv_dir=layer._assemble_W(), W_fwd_dir=layer._assemble_W(inverse=True))
+        npz("inv1x1_C%d_%s" % (C, "lu" if use_lu else "plain"), z=z, z_fwd=zf, ld_fwd=ldf, z_inv=zi, ld_inv=ldi,
+            **extra, **sd(layer, "sd__"))
+
+    # GlowBlock end to end (glow.py:11-84); first call initialises ActNorm
+    for C, split, use_lu in ((4, "channel", True), (5, "channel_inv", True), (3, "checkerboard", True)):
+        torch.manual_seed(600 + C)
+        layer = nf.flows.GlowBlock(C, 8, split_mode=split, use_lu=use_lu, init_zeros=False)
+        g = torch.Generator().manual_seed(C)
+        z = torch.randn(4, C, 4, 4, generator=g)
+        sd0 = sd(layer, "sd0__")
+        with torch.no_grad():
+            zi, ldi = layer.inverse(z)            # density direction, triggers inverse-first ActNorm init
+            zf, ldf = layer.forward(zi)           # round trip with initialised ActNorm
+        npz("glowblock_C%d_%s" % (C, split), z=z, z_inv=zi, ld_inv=ldi, z_fwd=zf, ld_fwd=ldf, **sd0, **sd(layer, "sd__"))
+
+    # DiagGaussian.log_prob (base.py:94-103)
+    torch.manual_seed(700)
+    q = nf.distributions.DiagGaussian((3, 2, 2))
+    with torch.no_grad():
+        q.loc.normal_()
+        q.log_scale.normal_(std=0.3)
+        z = torch.randn(6, 3, 2, 2)
+        lp = q.log_prob(z)
+        q.temperature = 0.7
+        lpt = q.log_prob(z)
+    npz("diag_gaussian", z=z, loc=q.loc, log_scale=q.log_scale, log_prob=lp, log_prob_t07=lpt)
+
+    # Squeeze (reshape.py:103-128)
+    z = torch.randn(2, 8, 4, 6)
+    s = nf.flows.Squeeze()
+    npz("squeeze", z=z, fwd=s.forward(z)[0], inv=s.inverse(z)[0])
+
+
+def gen_models():
+    """Whole-model fixtures: NormalizingFlow.log_prob / sample (core.py:167-197), MultiscaleFlow.log_prob."""
+    sys.path.insert(0, os.path.join(OUT, "..", ".."))
+    from bench import build_c2_model, c2_inputs
+
+    # C2-mini: 4 x [CoupledRQS(16, 2, 32) + LULinearPermute(16)], sigma 0.05
+    m = build_c2_model(num_layers=4, dim=16, hidden=32, seed=0, sigma=0.05, lib=nf)
+    x = c2_inputs(64, 16)
+    torch.manual_seed(3)
+    eps = torch.randn(64, 16)
+    with torch.no_grad():
+        lp = m.log_prob(x)
+        z, logq = eps.clone(), None
+        z0 = m.q0.loc + torch.exp(m.q0.log_scale) * eps
+        logq = -0.5 * 16 * np.log(2 * np.pi) - torch.sum(m.q0.log_scale + 0.5 * eps ** 2, 1)
+        z = z0
+        for f in m.flows:
+            z, ld = f(z)
+            logq = logq - ld
+    npz("model_c2mini", x=x, log_prob=lp, eps=eps, sample=z, sample_logq=logq, **sd(m, "sd__"))
+
+    # C2 at full width, first 128 rows of the benchmark batch: pins the bench model itself.  Only outputs are
+    # stored (the 21.8 MB of weights are reproduced by seeded construction, tests/test_state_dict_compat.py).
+    m = build_c2_model(lib=nf)
+    x = c2_inputs(65536, 64)[:128]
+    with torch.no_grad():
+        lp = m.log_prob(x)
+    npz("model_c2_head", x=x, log_prob=lp)
+
+    # C1: 4 x [MaskedAffineFlow(MLP[2,4,2]) + ActNorm(2)] on TwoMoons, B = 1024 (BASELINE config 1)
+    torch.manual_seed(0)
+    b = torch.tensor([1.0, 0.0])
+    fl = []
+    for i in range(4):
+        s = nf.nets.MLP([2, 4, 2], init_zeros=True)
+        t = nf.nets.MLP([2, 4, 2], init_zeros=True)
+        fl += [nf.flows.MaskedAffineFlow(b if i % 2 == 0 else 1 - b, t, s), nf.flows.ActNorm(2)]
+    m = nf.NormalizingFlow(nf.distributions.DiagGaussian(2), fl)
+    g = torch.Generator().manual_seed(1234)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.1 * torch.randn(p.shape, generator=g))
+    torch.manual_seed(0)
+    x = nf.distributions.TwoMoons().sample(1024)
+    sd0 = sd(m, "sd0__")
+    with torch.no_grad():
+        lp = m.log_prob(x)       # triggers inverse-first ActNorm init
+        lp2 = m.log_prob(x)
+        torch.manual_seed(5)
+        eps = torch.randn(1024, 2)
+        z = m.q0.loc + torch.exp(m.q0.log_scale) * eps
+        logq = -0.5 * 2 * np.log(2 * np.pi) - torch.sum(m.q0.log_scale + 0.5 * eps ** 2, 1)
+        for f in m.flows:
+            z, ld = f(z)
+            logq = logq - ld
+    npz("model_c1_realnvp", x=x, log_prob=lp, log_prob_second=lp2, eps=eps, sample=z, sample_logq=logq, **sd0,
+        **sd(m, "sd__"))
+
+    # C4-mini: Glow multiscale L=2, K=2, hidden 16, 8x8x3 images, B=6, DiagGaussian bases (class_cond False)
+    torch.manual_seed(0)
+    L_, K_, hidden = 2, 2, 16
+    input_shape = (3, 8, 8)
+    channels = 3
+    q0, merges, flows = [], [], []
+    for i in range(L_):
+        flows_ = []
+        for j in range(K_):
+            flows_ += [nf.flows.GlowBlock(channels * 2 ** (L_ + 1 - i), hidden, split_mode="channel", scale=True,
+                                          init_zeros=False)]
+        flows_ += [nf.flows.Squeeze()]
+        flows += [flows_]
+        if i > 0:
+            merges += [nf.flows.Merge()]
+            latent_shape = (input_shape[0] * 2 ** (L_ - i), input_shape[1] // 2 ** (L_ - i),
+                            input_shape[2] // 2 ** (L_ - i))
+        else:
+            latent_shape = (input_shape[0] * 2 ** (L_ + 1), input_shape[1] // 2 ** L_, input_shape[2] // 2 ** L_)
+        q0 += [nf.distributions.DiagGaussian(latent_shape)]
+    m = nf.MultiscaleFlow(q0, flows, merges, class_cond=False)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(6, 3, 8, 8, generator=g)
+    sd0 = sd(m, "sd0__")
+    with torch.no_grad():
+        lp = m.log_prob(x)
+        lp2 = m.log_prob(x)
+    npz("model_c4mini_glow", x=x, log_prob=lp, log_prob_second=lp2, **sd0, **sd(m, "sd__"))
+
+
+if __name__ == "__main__":
+    gen_splines()
+    gen_nsf_layers()
+    gen_affine()
+    gen_models()

@@ -1,0 +1,424 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every kernel through the C ABI (normflows_amd.ops / layer
+classes) against (a) the golden vectors produced by the real reference and (b) the CPU oracle on seeded inputs,
+plus size-independent properties at the benchmark's full size (round trip, sample/log_prob consistency)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import TOL, assert_close, golden_state, load_golden
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def nfa():
+    import normflows_amd
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    # fail loudly if the native library is not the one in-tree
+    assert normflows_amd.native_library_path().endswith("normalizing-flows_amd/lib/libnf_mi355x.so")
+    normflows_amd._lib.lib()
+    return normflows_amd
+
+
+def T(a, dev=DEV):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def load_layer(layer, state, dtype):
+    layer.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()}, strict=True)
+    return layer.to(dtype).to(DEV)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("K", [2, 8, 10, 16])
+def test_spline_kernel_vs_reference(nfa, K, tag):
+    g = load_golden("spline_K%d_%s" % (K, tag))
+    tol = TOL[g["w"].dtype]
+    t10 = dict(rtol=tol["rtol"] * 10, atol=tol["atol"] * 10)
+    t50 = dict(rtol=tol["rtol"] * 50, atol=tol["atol"] * 50)
+    y, lad = nfa.ops.rqs_spline(T(g["x01"]), T(g["w"]), T(g["h"]), T(g["d_none"]), inverse=False, tails=None)
+    assert_close(N(y), g["y01"], what="y01", **t10)
+    assert_close(N(lad), g["lad01"], what="lad01", **t50)
+    y, lad = nfa.ops.rqs_spline(T(g["y01"]), T(g["w"]), T(g["h"]), T(g["d_none"]), inverse=True, tails=None)
+    assert_close(N(y), g["x01_inv"], what="x01_inv", **t10)
+    assert_close(N(lad), g["lad01_inv"], what="lad01_inv", **t50)
+    for tails, dkey, bound, keys in (("linear", "d_lin", 3.0, ("yl", "ladl", "yl_inv", "ladl_inv")),
+                                     ("circular", "d_cir", 2.5, ("yc", "ladc", "yc_inv", "ladc_inv"))):
+        for inv in (False, True):
+            y, lad = nfa.ops.rqs_spline(T(g["xl"]), T(g["w"]), T(g["h"]), T(g[dkey]), inverse=inv, tails=tails,
+                                        tail_bound=bound)
+            assert_close(N(y), g[keys[2 * inv]], what=keys[2 * inv], **t10)
+            assert_close(N(lad), g[keys[2 * inv + 1]], what=keys[2 * inv + 1], **t50)
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_spline_on_knots_and_edges(nfa, oracle, tag):
+    g = load_golden("spline_knots_" + tag)
+    tol = TOL[g["w"].dtype]
+    y, lad = nfa.ops.rqs_spline(T(g["x"]), T(g["w"]), T(g["h"]), T(g["d"]), tails="linear", tail_bound=3.0)
+    assert_close(N(y), g["y"], what="y", **tol)
+    assert_close(N(lad), g["lad"], what="lad", rtol=tol["rtol"] * 10, atol=tol["atol"] * 10)
+    # edge semantics: +-3 inside, nextafter(3) outside, NaN / +-inf pass through with logabsdet exactly 0
+    K = 8
+    rng = np.random.default_rng(0)
+    dt = g["w"].dtype
+    w, h, d = (rng.standard_normal((7, n)).astype(dt) for n in (K, K, K - 1))
+    x = np.array([3.0, -3.0, np.nextafter(np.float32(3), np.float32(4)), np.nan, np.inf, -np.inf, 0.0], dt)
+    y, lad = nfa.ops.rqs_spline(T(x), T(w), T(h), T(d), tails="linear", tail_bound=3.0)
+    y, lad = N(y), N(lad)
+    yo, lo = oracle.rqs_spline(x, w, h, d, tails="linear", tail_bound=3.0)
+    assert_close(y, yo, what="edge y", rtol=1e-5, atol=1e-5)
+    assert y[2] == x[2] and lad[2] == 0.0
+    assert np.isnan(y[3]) and lad[3] == 0.0 and y[4] == np.inf and lad[4] == 0.0 and y[5] == -np.inf and lad[5] == 0.0
+
+
+def test_spline_empty_and_ragged(nfa):
+    K = 8
+    e = torch.empty(0, device=DEV)
+    y, lad = nfa.ops.rqs_spline(e, torch.empty(0, K, device=DEV), torch.empty(0, K, device=DEV),
+                                torch.empty(0, K - 1, device=DEV), tails="linear", tail_bound=3.0)
+    assert y.numel() == 0 and lad.numel() == 0
+    # min bin width too large for K -> ValueError like utils/splines.py:121-124
+    with pytest.raises(ValueError):
+        nfa.ops.rqs_spline(torch.zeros(3, device=DEV), torch.zeros(3, K, device=DEV), torch.zeros(3, K, device=DEV),
+                           torch.zeros(3, K - 1, device=DEV), tails="linear", tail_bound=3.0, min_bin_width=0.2)
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("d", [2, 5, 7, 64])
+def test_coupled_rqs_layer_vs_reference(nfa, d, tag):
+    g = load_golden("crqs_d%d_%s" % (d, tag))
+    dt = torch.float32 if tag == "f32" else torch.float64
+    tol = TOL[g["x"].dtype]
+    K, hidden = int(g["K"]), int(g["hidden"])
+    layer = nfa.flows.CoupledRationalQuadraticSpline(d, 2, hidden, num_bins=K, init_identity=False,
+                                                     reverse_mask=(d == 5))
+    layer = load_layer(layer, golden_state(g), dt)
+    x = T(g["x"])
+    # kernel alone, fed with the REFERENCE conditioner output (isolates nf_rqs_coupling)
+    p = layer.prqct
+    uw, uh, ud = p._uncond()
+    kw = p._kernel_kwargs()
+    y, ld = nfa.ops.rqs_coupling(x, T(g["cond_density"]), uw, uh, ud, p.identity_features, p.transform_features, K, 0,
+                                 **kw)
+    assert_close(N(y), g["z_inv"], what="kernel z_inv", rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
+    assert_close(N(ld), g["ld_inv"], what="kernel ld_inv", rtol=tol["rtol"] * 50, atol=tol["atol"] * 50)
+    # layer end to end, both directions (conditioner included)
+    z, ld = layer.inverse(x)
+    assert z.dtype == x.dtype and z.shape == x.shape and ld.shape == (x.shape[0],)
+    assert_close(N(z), g["z_inv"], what="z_inv", rtol=tol["rtol"] * 10, atol=tol["atol"] * 10)
+    assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=tol["rtol"] * 50, atol=tol["atol"] * 50)
+    z, ld = layer.forward(x)
+    assert_close(N(z), g["z_fwd"], what="z_fwd", rtol=tol["rtol"] * 20, atol=tol["atol"] * 20)
+    assert_close(N(ld), g["ld_fwd"], what="ld_fwd", rtol=tol["rtol"] * 50, atol=tol["atol"] * 50)
+    # round trip (flows/flow_test.py:40-48)
+    xr, ldr = layer.inverse(z)
+    inside = np.abs(g["x"]) < 2.9
+    assert_close(N(xr)[inside], g["x"][inside], what="roundtrip", rtol=1e-4 if tag == "f32" else 1e-9,
+                 atol=1e-4 if tag == "f32" else 1e-9)
+    assert_close(N(ld + ldr), np.zeros(x.shape[0], g["x"].dtype), what="ld cancel", rtol=0,
+                 atol=2e-3 if tag == "f32" else 1e-8)
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("d", [3, 4, 64])
+def test_lu_linear_permute_vs_reference(nfa, d, tag):
+    g = load_golden("lulinear_d%d_%s" % (d, tag))
+    dt = torch.float32 if tag == "f32" else torch.float64
+    tol = TOL[g["x"].dtype]
+    layer = load_layer(nfa.flows.LULinearPermute(d, identity_init=False), golden_state(g), dt)
+    x = T(g["x"])
+    z, ld = layer.inverse(x)
+    assert_close(N(z), g["z_inv"], what="z_inv", rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
+    assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
+    z, ld = layer.forward(x)
+    assert_close(N(z), g["z_fwd"], what="z_fwd", rtol=tol["rtol"] * 200, atol=tol["atol"] * 200)
+    assert_close(N(ld), g["ld_fwd"], what="ld_fwd", rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
+    # permutation is bit exact: a layer with L = U = I and zero bias reproduces index_select exactly
+    with torch.no_grad():
+        layer.linear.lower_entries.zero_()
+        layer.linear.upper_entries.zero_()
+        layer.linear.bias.zero_()
+        layer.linear.unconstrained_upper_diag.fill_(50.0)   # softplus(50)+eps = 50.001 -> scale only
+    z, _ = layer.inverse(x)
+    perm = golden_state(g)["permutation._permutation"]
+    scale = N(z)[:, 0] / g["x"][:, perm[0]]
+    assert np.allclose(N(z), g["x"][:, perm] * scale[:, None], rtol=1e-6)
+
+
+def test_lu_accumulate_modes(nfa):
+    torch.manual_seed(0)
+    layer = nfa.flows.LULinearPermute(8, identity_init=False).to(DEV)
+    x = torch.randn(300, 8, device=DEV)
+    z, ld = layer.inverse(x)
+    acc = torch.full((300,), 2.0, device=DEV)
+    z2 = layer._run(x, True, acc, +1)
+    assert torch.equal(z, z2) and torch.allclose(acc, 2.0 + ld)
+    z3 = layer._run(x, True, acc, -1)
+    assert torch.allclose(acc, torch.full_like(acc, 2.0), atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["masked_affine_d2", "masked_affine_d7", "masked_affine_nonfinite"])
+def test_masked_affine_vs_reference(nfa, name):
+    g = load_golden(name)
+    tol = TOL[g["z"].dtype]
+    for direction, zk, lk in ((0, "z_fwd", "ld_fwd"), (1, "z_inv", "ld_inv")):
+        y, ld = nfa.ops.masked_affine(T(g["z"]), T(g["b"]), T(g["s"]), T(g["t"]), direction)
+        assert_close(N(y), g[zk], what=zk, **tol)
+        assert_close(N(ld), g[lk], what=lk, **tol)
+    if "sd__b" in g:  # full layer incl. MLP maps
+        d = g["z"].shape[1]
+        b = torch.tensor([1.0 if i % 2 == 0 else 0.0 for i in range(d)])
+        layer = nfa.flows.MaskedAffineFlow(b, nfa.nets.MLP([d, 2 * d, d]), nfa.nets.MLP([d, 2 * d, d]))
+        layer = load_layer(layer, golden_state(g), torch.float32)
+        z, ld = layer.forward(T(g["z"]))
+        assert_close(N(z), g["z_fwd"], what="layer fwd", rtol=1e-4, atol=1e-5)
+        z, ld = layer.inverse(T(g["z"]))
+        assert_close(N(ld), g["ld_inv"], what="layer ld_inv", rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name,C,split,smap,scale", [
+    ("affine_block_C4_channel_exp", 4, "channel", "exp", True),
+    ("affine_block_C5_channel_sigmoid", 5, "channel", "sigmoid", True),
+    ("affine_block_C5_channel_inv_sigmoid_inv", 5, "channel_inv", "sigmoid_inv", True),
+    ("affine_block_C3_channel_inv_noscale", 3, "channel_inv", "exp", False),
+    ("affine_block_C4_checkerboard_sigmoid", 4, "checkerboard", "sigmoid", True),
+    ("affine_block_C6_checkerboard_inv_exp", 6, "checkerboard_inv", "exp", True),
+])
+def test_affine_coupling_block_vs_reference(nfa, name, C, split, smap, scale):
+    g = load_golden(name)
+    if "checkerboard" in split:
+        ch = (C, 8, 8, (2 if scale else 1) * C)
+    elif split == "channel":
+        ch = ((C + 1) // 2, 8, 8, (2 if scale else 1) * (C // 2))
+    else:
+        ch = (C // 2, 8, 8, (2 if scale else 1) * ((C + 1) // 2))
+    net = nfa.nets.ConvNet2d(ch, (3, 1, 3), 0.0, init_zeros=False)
+    layer = load_layer(nfa.flows.AffineCouplingBlock(net, scale, smap, split), golden_state(g), torch.float32)
+    for fn, zk, lk in ((layer.forward, "z_fwd", "ld_fwd"), (layer.inverse, "z_inv", "ld_inv")):
+        z, ld = fn(T(g["z"]))
+        assert_close(N(z), g[zk], what=zk, rtol=1e-4, atol=1e-4)   # conv conditioner goes through MIOpen
+        assert_close(N(ld), g[lk], what=lk, rtol=1e-4, atol=1e-4)
+    if "checkerboard" not in split:  # kernel alone on the reference's param tensor
+        c1 = (C + 1) // 2 if split == "channel" else C // 2
+        for direction, zk, lk in ((0, "z_fwd", "ld_fwd"), (1, "z_inv", "ld_inv")):
+            y, ld = nfa.ops.affine_coupling(T(g["z"]), T(g["param"]), c1, split == "channel_inv", smap if scale else None,
+                                            direction)
+            assert_close(N(y), g[zk], what="kernel " + zk, rtol=2e-5, atol=2e-5)
+            assert_close(N(ld), g[lk], what="kernel " + lk, rtol=1e-4, atol=1e-4)
+
+
+def test_affine_block_2d(nfa):
+    g = load_golden("affine_block_2d")
+    layer = load_layer(nfa.flows.AffineCouplingBlock(nfa.nets.MLP([1, 16, 16, 2], init_zeros=False)), golden_state(g),
+                       torch.float32)
+    z, ld = layer.forward(T(g["z"]))
+    assert_close(N(z), g["z_fwd"], what="fwd", rtol=1e-5, atol=1e-5)
+    assert_close(N(ld), g["ld_fwd"], what="ld_fwd", rtol=1e-5, atol=1e-5)
+    z, ld = layer.inverse(T(g["z"]))
+    assert_close(N(z), g["z_inv"], what="inv", rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name,shape", [("actnorm_4d", (6, 1, 1)), ("actnorm_2d", (3,))])
+def test_actnorm_vs_reference(nfa, name, shape):
+    g = load_golden(name)
+    a = nfa.flows.ActNorm(shape).to(DEV)
+    z, ld = a.forward(T(g["z"]))                 # forward-first data-dependent init
+    assert ld.dim() == 0                          # 0-dim log_det like the reference
+    assert_close(N(a.s), g["s_fwd"], what="s_fwd", rtol=1e-5, atol=1e-5)
+    assert_close(N(a.t), g["t_fwd"], what="t_fwd", rtol=1e-5, atol=1e-5)
+    assert_close(N(z), g["z_fwd"], what="z_fwd", rtol=1e-5, atol=2e-5)
+    assert_close(N(ld), g["ld_fwd"], what="ld_fwd", rtol=1e-4, atol=1e-4)
+    assert float(a.data_dep_init_done) == 1.0
+    z, ld = a.forward(T(g["z2"]))                # no re-init
+    assert_close(N(z), g["z2_fwd"], what="z2_fwd", rtol=1e-5, atol=2e-5)
+    z, ld = a.inverse(T(g["z2"]))
+    assert_close(N(z), g["z2_inv"], what="z2_inv", rtol=1e-5, atol=2e-5)
+    assert_close(N(ld), g["ld2_inv"], what="ld2_inv", rtol=1e-4, atol=1e-4)
+    b = nfa.flows.ActNorm(shape).to(DEV)
+    z, ld = b.inverse(T(g["z"]))                 # inverse-first init
+    assert_close(N(b.s), g["s_inv"], what="s_inv", rtol=1e-5, atol=1e-5)
+    assert_close(N(b.t), g["t_inv"], what="t_inv", rtol=1e-5, atol=1e-5)
+    assert_close(N(z), g["z_inv"], what="z_inv", rtol=1e-5, atol=2e-5)
+    assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("C,use_lu", [(3, True), (4, True), (12, True), (48, True), (4, False)])
+def test_inv1x1_vs_reference(nfa, C, use_lu):
+    g = load_golden("inv1x1_C%d_%s" % (C, "lu" if use_lu else "plain"))
+    layer = load_layer(nfa.flows.Invertible1x1Conv(C, use_lu), golden_state(g), torch.float32)
+    if use_lu:
+        W, _ = layer._weight(True)
+        assert_close(N(W), g["W_inv_dir"], what="W", rtol=1e-5, atol=1e-5)
+        W, _ = layer._weight(False)
+        assert_close(N(W), g["W_fwd_dir"], what="W^-1", rtol=1e-4, atol=1e-4)
+    z, ld = layer.inverse(T(g["z"]))
+    assert ld.dim() == 0
+    assert_close(N(z), g["z_inv"], what="z_inv", rtol=1e-4, atol=1e-4)
+    assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=1e-5, atol=1e-4)
+    z, ld = layer.forward(T(g["z"]))
+    assert_close(N(z), g["z_fwd"], what="z_fwd", rtol=1e-3, atol=1e-3)
+    assert_close(N(ld), g["ld_fwd"], what="ld_fwd", rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("C,split", [(4, "channel"), (5, "channel_inv"), (3, "checkerboard")])
+def test_glowblock_vs_reference(nfa, C, split):
+    g = load_golden("glowblock_C%d_%s" % (C, split))
+    layer = nfa.flows.GlowBlock(C, 8, split_mode=split, use_lu=True, init_zeros=False)
+    layer = load_layer(layer, golden_state(g, "sd0__"), torch.float32)   # un-initialised ActNorm state
+    z, ld = layer.inverse(T(g["z"]))
+    assert_close(N(z), g["z_inv"], what="z_inv", rtol=2e-4, atol=2e-4)
+    assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=2e-4, atol=2e-3)
+    post = golden_state(g)
+    assert_close(N(layer.flows[-1].s), post["flows.%d.s" % (len(layer.flows) - 1)], what="actnorm s", rtol=1e-4, atol=1e-4)
+    zf, ldf = layer.forward(z)
+    assert_close(N(zf), g["z_fwd"], what="z_fwd", rtol=1e-3, atol=1e-3)
+    assert_close(N(ldf), g["ld_fwd"], what="ld_fwd", rtol=2e-4, atol=2e-3)
+
+
+def test_diag_gaussian_and_squeeze(nfa):
+    g = load_golden("diag_gaussian")
+    q = nfa.distributions.DiagGaussian((3, 2, 2)).to(DEV)
+    with torch.no_grad():
+        q.loc.copy_(T(g["loc"]))
+        q.log_scale.copy_(T(g["log_scale"]))
+    assert_close(N(q.log_prob(T(g["z"]))), g["log_prob"], what="log_prob", rtol=1e-5, atol=1e-5)
+    q.temperature = 0.7
+    assert_close(N(q.log_prob(T(g["z"]))), g["log_prob_t07"], what="log_prob_t", rtol=1e-5, atol=1e-5)
+    g = load_golden("squeeze")
+    s = nfa.flows.Squeeze()
+    assert np.array_equal(N(s.forward(T(g["z"]))[0]), g["fwd"])
+    assert np.array_equal(N(s.inverse(T(g["z"]))[0]), g["inv"])
+
+
+# ---- whole models ---------------------------------------------------------------------------------------------
+def _rel(a, b):
+    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
+
+
+def test_model_c2mini_vs_reference(nfa):
+    from bench import build_c2_model
+    g = load_golden("model_c2mini")
+    m = build_c2_model(num_layers=4, dim=16, hidden=32, seed=0, sigma=0.05)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in golden_state(g).items()}, strict=True)
+    m = m.to(DEV)
+    lp = N(m.log_prob(T(g["x"])))
+    assert _rel(lp, g["log_prob"]) < 1e-4          # north-star: fp32 log_prob within 1e-4 rel
+    xs, lq = m.sample_from_noise(T(g["eps"]))
+    assert_close(N(xs), g["sample"], what="sample", rtol=1e-4, atol=1e-4)
+    assert _rel(N(lq), g["sample_logq"]) < 1e-4
+    # hipGraph replay gives bit-identical results to eager launches
+    m.use_graphs(True)
+    lp_g = N(m.log_prob(T(g["x"])))
+    lp_g2 = N(m.log_prob(T(g["x"])))
+    assert np.array_equal(lp_g, lp) and np.array_equal(lp_g2, lp)
+
+
+def test_model_c2_full_width_head_vs_reference(nfa):
+    """The benchmark model itself (32 layers, d=64, hidden 128): seeded construction reproduces the reference's
+    weights, so the reference's log_prob on the first 128 benchmark rows is a golden vector for it."""
+    from bench import build_c2_model
+    g = load_golden("model_c2_head")
+    m = build_c2_model().to(DEV)
+    lp = N(m.log_prob(T(g["x"])))
+    assert _rel(lp, g["log_prob"]) < 1e-4, _rel(lp, g["log_prob"])
+
+
+def test_model_c2_full_size_properties(nfa, oracle):
+    """B = 65 536 (BASELINE config 2): oracle on a slice, determinism, sample/log_prob consistency
+    (core_test.py:187), in-bound fraction."""
+    from bench import build_c2_model, c2_inputs, state_to_numpy
+    m = build_c2_model().to(DEV)
+    x = c2_inputs().to(DEV)
+    lp = m.log_prob(x)
+    lp2 = m.log_prob(x)
+    assert torch.equal(lp, lp2)                                        # deterministic
+    assert torch.isfinite(lp).all()
+    ora = oracle.OracleNSF(state_to_numpy(m), num_layers=len(m.flows))
+    sl = slice(1000, 1256)
+    ref = ora.log_prob(N(x[sl]))
+    assert _rel(N(lp[sl]), ref) < 1e-4
+    nll = float(-lp.mean() / 64)
+    assert 1.3 < nll < 1.8, nll                                        # reference: 1.5415 nats/dim
+    g = torch.Generator().manual_seed(5)
+    eps = torch.randn(65536, 64, generator=g).to(DEV)
+    xs, lq = m.sample_from_noise(eps)
+    lp_s = m.log_prob(xs)
+    assert _rel(N(lp_s), N(lq)) < 1e-4                                 # log_prob(sample) == returned log_q
+
+
+def test_model_c1_realnvp_vs_reference(nfa):
+    g = load_golden("model_c1_realnvp")
+    b = torch.tensor([1.0, 0.0])
+    fl = []
+    for i in range(4):
+        s = nfa.nets.MLP([2, 4, 2], init_zeros=True)
+        t = nfa.nets.MLP([2, 4, 2], init_zeros=True)
+        fl += [nfa.flows.MaskedAffineFlow(b if i % 2 == 0 else 1 - b, t, s), nfa.flows.ActNorm(2)]
+    m = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(2), fl)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in golden_state(g, "sd0__").items()}, strict=True)
+    m = m.to(DEV)
+    lp = N(m.log_prob(T(g["x"])))                  # triggers the ActNorm data-dependent init (inverse-first)
+    assert _rel(lp, g["log_prob"]) < 1e-4
+    assert _rel(N(m.log_prob(T(g["x"]))), g["log_prob_second"]) < 1e-4
+    xs, lq = m.sample_from_noise(T(g["eps"]))
+    assert_close(N(xs), g["sample"], what="sample", rtol=1e-4, atol=1e-4)
+    assert _rel(N(lq), g["sample_logq"]) < 1e-4
+
+
+def test_model_c4mini_glow_vs_reference(nfa):
+    g = load_golden("model_c4mini_glow")
+    L_, K_, hidden, channels = 2, 2, 16, 3
+    input_shape = (3, 8, 8)
+    q0, merges, flows = [], [], []
+    for i in range(L_):
+        fl = [nfa.flows.GlowBlock(channels * 2 ** (L_ + 1 - i), hidden, split_mode="channel", scale=True,
+                                  init_zeros=False) for _ in range(K_)]
+        fl += [nfa.flows.Squeeze()]
+        flows += [fl]
+        if i > 0:
+            merges += [nfa.flows.Merge()]
+            latent = (input_shape[0] * 2 ** (L_ - i), input_shape[1] // 2 ** (L_ - i), input_shape[2] // 2 ** (L_ - i))
+        else:
+            latent = (input_shape[0] * 2 ** (L_ + 1), input_shape[1] // 2 ** L_, input_shape[2] // 2 ** L_)
+        q0 += [nfa.distributions.DiagGaussian(latent)]
+    m = nfa.MultiscaleFlow(q0, flows, merges, class_cond=False)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in golden_state(g, "sd0__").items()}, strict=True)
+    m = m.to(DEV)
+    lp = N(m.log_prob(T(g["x"])))
+    assert _rel(lp, g["log_prob"]) < 2e-4, _rel(lp, g["log_prob"])
+    assert _rel(N(m.log_prob(T(g["x"]))), g["log_prob_second"]) < 2e-4
+    # sample / log_prob consistency (core_test.py:144-196)
+    torch.manual_seed(0)
+    xs, lq = m.sample(8)
+    assert _rel(N(m.log_prob(xs)), N(lq)) < 1e-3
+
+
+def test_drop_in_under_reference_style_container(nfa):
+    """Duck-typed use: a container that only calls flow(z) / flow.inverse(z) and `log_q += log_det`
+    (the loops of normflows/core.py:36-38, 193-195) works with our layers, including 0-dim log-dets."""
+    torch.manual_seed(0)
+    flows = [nfa.flows.ActNorm(6), nfa.flows.LULinearPermute(6), nfa.flows.CoupledRationalQuadraticSpline(6, 1, 16)]
+    flows = [f.to(DEV) for f in flows]
+    x = torch.randn(33, 6, device=DEV)
+    log_q = torch.zeros(33, device=DEV)
+    z = x
+    for f in reversed(flows):
+        z, ld = f.inverse(z)
+        log_q += ld
+    m = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(6, trainable=False), flows).to(DEV)
+    z2, ld2 = m.inverse_and_log_det(x)
+    assert torch.allclose(z, z2) and torch.allclose(log_q, ld2, atol=1e-5)
+
+
+def test_cpu_tensor_is_rejected(nfa):
+    layer = nfa.flows.LULinearPermute(4)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        layer.inverse(torch.randn(3, 4))

@@ -1,0 +1,193 @@
+"""Pins the CPU oracle (oracle/nf_oracle.c) against golden vectors produced by the real normflows reference
+(tests/golden/make_golden.py).  CPU only; this is what makes the oracle trustworthy as the GPU checker."""
+import numpy as np
+import pytest
+
+from conftest import TOL, assert_close, golden_state, load_golden
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("K", [2, 8, 10, 16])
+def test_spline_matches_reference(oracle, K, tag):
+    g = load_golden("spline_K%d_%s" % (K, tag))
+    tol = TOL[g["w"].dtype]
+    # bounded spline (utils/splines.py:100-219)
+    y, lad = oracle.rqs_spline(g["x01"], g["w"], g["h"], g["d_none"], inverse=False, tails=None)
+    assert_close(y, g["y01"], what="y01", **tol)
+    assert_close(lad, g["lad01"], what="lad01", rtol=tol["rtol"] * 10, atol=tol["atol"] * 10)
+    xi, ladi = oracle.rqs_spline(g["y01"], g["w"], g["h"], g["d_none"], inverse=True, tails=None)
+    assert_close(xi, g["x01_inv"], what="x01_inv", rtol=tol["rtol"] * 10, atol=tol["atol"] * 10)
+    assert_close(ladi, g["lad01_inv"], what="lad01_inv", rtol=tol["rtol"] * 50, atol=tol["atol"] * 50)
+    # linear tails incl. edge inputs (+-3, next-after, NaN, +-inf pass through with logabsdet 0)
+    for inv, ykey, lkey in ((False, "yl", "ladl"), (True, "yl_inv", "ladl_inv")):
+        y, lad = oracle.rqs_spline(g["xl"], g["w"], g["h"], g["d_lin"], inverse=inv, tails="linear", tail_bound=3.0)
+        assert_close(y, g[ykey], what=ykey, rtol=tol["rtol"] * 10, atol=tol["atol"] * 10)
+        assert_close(lad, g[lkey], what=lkey, rtol=tol["rtol"] * 50, atol=tol["atol"] * 50)
+    for inv, ykey, lkey in ((False, "yc", "ladc"), (True, "yc_inv", "ladc_inv")):
+        y, lad = oracle.rqs_spline(g["xl"], g["w"], g["h"], g["d_cir"], inverse=inv, tails="circular", tail_bound=2.5)
+        assert_close(y, g[ykey], what=ykey, rtol=tol["rtol"] * 10, atol=tol["atol"] * 10)
+        assert_close(lad, g[lkey], what=lkey, rtol=tol["rtol"] * 50, atol=tol["atol"] * 50)
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_spline_on_knots(oracle, tag):
+    g = load_golden("spline_knots_" + tag)
+    tol = TOL[g["w"].dtype]
+    y, lad = oracle.rqs_spline(g["x"], g["w"], g["h"], g["d"], tails="linear", tail_bound=3.0)
+    assert_close(y, g["y"], what="y", **tol)
+    assert_close(lad, g["lad"], what="lad", rtol=tol["rtol"] * 10, atol=tol["atol"] * 10)
+
+
+def test_edge_semantics(oracle):
+    """SURVEY section 8a 'semantics to preserve'."""
+    K = 8
+    rng = np.random.default_rng(0)
+    w, h, d = (rng.standard_normal((7, n)).astype(np.float32) for n in (K, K, K - 1))
+    x = np.array([3.0, -3.0, np.nextafter(np.float32(3), np.float32(4)), np.nan, np.inf, -np.inf, 0.0], np.float32)
+    y, lad = oracle.rqs_spline(x, w, h, d, tails="linear", tail_bound=3.0)
+    assert y[0] == pytest.approx(3.0, abs=1e-5) and y[1] == pytest.approx(-3.0, abs=1e-5)  # +-3 are inside
+    assert abs(lad[0]) < 1e-5 and abs(lad[1]) < 1e-5             # boundary derivative is 1 (linear tails)
+    assert y[2] == x[2] and lad[2] == 0.0                       # just outside: identity, logabsdet 0
+    assert np.isnan(y[3]) and lad[3] == 0.0                     # NaN passes through with logabsdet 0 (not NaN)
+    assert y[4] == np.inf and lad[4] == 0.0 and y[5] == -np.inf and lad[5] == 0.0
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("d", [2, 5, 7, 64])
+def test_coupled_rqs_layer(oracle, d, tag):
+    g = load_golden("crqs_d%d_%s" % (d, tag))
+    st = golden_state(g)
+    tol = TOL[g["x"].dtype]
+    K, hidden = int(g["K"]), int(g["hidden"])
+    ii, ti = st["prqct.identity_features"], st["prqct.transform_features"]
+    uw, uh, ud = (st["prqct.unconditional_transform.unnormalized_" + n] for n in ("widths", "heights", "derivatives"))
+    nb = 2
+    wb = [st["prqct.transform_net.blocks.%d.linear_layers.%d.weight" % (b, l)] for b in range(nb) for l in range(2)]
+    bb = [st["prqct.transform_net.blocks.%d.linear_layers.%d.bias" % (b, l)] for b in range(nb) for l in range(2)]
+    net = lambda rows: oracle.resnet_mlp(rows, ii, st["prqct.transform_net.initial_layer.weight"],
+                                         st["prqct.transform_net.initial_layer.bias"], wb, bb,
+                                         st["prqct.transform_net.final_layer.weight"],
+                                         st["prqct.transform_net.final_layer.bias"])
+    kw = dict(K=K, tail_bound=3.0, wh_div=float(np.sqrt(hidden)))
+    # conditioner restatement vs reference ResidualNet
+    cond = net(g["x"])
+    assert_close(cond, g["cond_density"], what="cond", rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
+    # density direction: coupling given the REFERENCE conditioner output (isolates the spline) ...
+    y, ld = oracle.rqs_coupling(g["x"], g["cond_density"], uw, uh, ud, ii, ti, mode=0, **kw)
+    assert_close(y, g["z_inv"], what="z_inv", rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
+    assert_close(ld, g["ld_inv"], what="ld_inv", rtol=tol["rtol"] * 50, atol=tol["atol"] * 50)
+    # ... and end to end with the oracle conditioner
+    y, ld = oracle.rqs_coupling(g["x"], cond, uw, uh, ud, ii, ti, mode=0, **kw)
+    assert_close(y, g["z_inv"], what="z_inv(e2e)", rtol=tol["rtol"] * 10, atol=tol["atol"] * 10)
+    # sampling direction
+    y, ld = oracle.rqs_coupling(g["x"], None, uw, uh, ud, ii, ti, mode=1, **kw)
+    cond_s = net(y)
+    assert_close(cond_s, g["cond_sample"], what="cond_s", rtol=tol["rtol"] * 10, atol=tol["atol"] * 10)
+    y, ld = oracle.rqs_coupling(g["x"], g["cond_sample"], uw, uh, ud, ii, ti, mode=2, y=y, logdet=ld, acc=1, **kw)
+    assert_close(y, g["z_fwd"], what="z_fwd", rtol=tol["rtol"] * 10, atol=tol["atol"] * 10)
+    assert_close(ld, g["ld_fwd"], what="ld_fwd", rtol=tol["rtol"] * 50, atol=tol["atol"] * 50)
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+@pytest.mark.parametrize("d", [3, 4, 64])
+def test_lu_linear_permute(oracle, d, tag):
+    g = load_golden("lulinear_d%d_%s" % (d, tag))
+    st = golden_state(g)
+    tol = TOL[g["x"].dtype]
+    args = (st["permutation._permutation"], st["linear.lower_entries"], st["linear.upper_entries"],
+            st["linear.unconstrained_upper_diag"], st["linear.bias"])
+    y, ld = oracle.lu_linear_permute(g["x"], *args, direction=0)
+    assert_close(y, g["z_inv"], what="z_inv", rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
+    assert_close(ld, g["ld_inv"], what="ld_inv", rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
+    y, ld = oracle.lu_linear_permute(g["x"], *args, direction=1)
+    assert_close(y, g["z_fwd"], what="z_fwd", rtol=tol["rtol"] * 100, atol=tol["atol"] * 100)
+    assert_close(ld, g["ld_fwd"], what="ld_fwd", rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
+
+
+@pytest.mark.parametrize("name", ["masked_affine_d2", "masked_affine_d7", "masked_affine_nonfinite"])
+def test_masked_affine(oracle, name):
+    g = load_golden(name)
+    tol = TOL[g["z"].dtype]
+    y, ld = oracle.masked_affine(g["z"], g["b"], g["s"], g["t"], 0)
+    assert_close(y, g["z_fwd"], what="fwd", **tol)
+    assert_close(ld, g["ld_fwd"], what="ld_fwd", **tol)
+    y, ld = oracle.masked_affine(g["z"], g["b"], g["s"], g["t"], 1)
+    assert_close(y, g["z_inv"], what="inv", **tol)
+    assert_close(ld, g["ld_inv"], what="ld_inv", **tol)
+
+
+@pytest.mark.parametrize("name,C,c1,flip,smap", [
+    ("affine_block_C4_channel_exp", 4, 2, False, "exp"),
+    ("affine_block_C5_channel_sigmoid", 5, 3, False, "sigmoid"),
+    ("affine_block_C5_channel_inv_sigmoid_inv", 5, 2, True, "sigmoid_inv"),
+    ("affine_block_C3_channel_inv_noscale", 3, 1, True, None),
+    ("affine_block_2d", 2, 1, False, "exp"),
+])
+def test_affine_coupling_block(oracle, name, C, c1, flip, smap):
+    g = load_golden(name)
+    tol = TOL[g["z"].dtype]
+    for direction, zk, lk in ((0, "z_fwd", "ld_fwd"), (1, "z_inv", "ld_inv")):
+        y, ld = oracle.affine_coupling(g["z"], g["param"], c1, flip, smap, direction)
+        assert_close(y, g[zk], what=zk, **tol)
+        assert_close(ld, g[lk], what=lk, rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
+
+
+@pytest.mark.parametrize("name", ["actnorm_4d", "actnorm_2d"])
+def test_actnorm(oracle, name):
+    g = load_golden(name)
+    tol = TOL[g["z"].dtype]
+    mean, std = oracle.actnorm_stats(g["z"])
+    s, t = oracle.actnorm_init(mean, std, 0)
+    assert_close(s, g["s_fwd"].reshape(-1), what="s_fwd", **tol)
+    assert_close(t, g["t_fwd"].reshape(-1), what="t_fwd", **tol)
+    y, ld = oracle.actnorm(g["z"], s, t, 0)
+    assert_close(y, g["z_fwd"], what="z_fwd", **tol)
+    assert_close(ld, g["ld_fwd"], what="ld_fwd", rtol=1e-4, atol=1e-4)
+    y, ld = oracle.actnorm(g["z2"], s, t, 1)
+    assert_close(y, g["z2_inv"], what="z2_inv", **tol)
+    assert_close(ld, g["ld2_inv"], what="ld2_inv", rtol=1e-4, atol=1e-4)
+    s, t = oracle.actnorm_init(mean, std, 1)
+    assert_close(s, g["s_inv"].reshape(-1), what="s_inv", **tol)
+    assert_close(t, g["t_inv"].reshape(-1), what="t_inv", **tol)
+    y, ld = oracle.actnorm(g["z"], s, t, 1)
+    assert_close(y, g["z_inv"], what="z_inv", **tol)
+
+
+@pytest.mark.parametrize("C", [3, 4, 12, 48])
+def test_inv1x1(oracle, C):
+    g = load_golden("inv1x1_C%d_lu" % C)
+    st = golden_state(g)
+    W, ldu = oracle.inv1x1_assemble(st["P"], st["L"], st["U"], st["sign_S"], st["log_S"], inverse=False)
+    assert_close(W, g["W_inv_dir"], what="W", rtol=1e-5, atol=1e-5)
+    y, ld = oracle.inv1x1_conv(g["z"], W, ldu)
+    assert_close(y, g["z_inv"], what="z_inv", rtol=1e-4, atol=1e-4)
+    assert_close(ld, g["ld_inv"], what="ld_inv", rtol=1e-5, atol=1e-5)
+    W, ldu = oracle.inv1x1_assemble(st["P"], st["L"], st["U"], st["sign_S"], st["log_S"], inverse=True)
+    assert_close(W, g["W_fwd_dir"], what="Winv", rtol=1e-4, atol=1e-4)
+    y, ld = oracle.inv1x1_conv(g["z"], W, ldu)
+    assert_close(y, g["z_fwd"], what="z_fwd", rtol=1e-3, atol=1e-3)
+    assert_close(ld, g["ld_fwd"], what="ld_fwd", rtol=1e-5, atol=1e-5)
+
+
+def test_diag_gaussian_and_squeeze(oracle):
+    g = load_golden("diag_gaussian")
+    lp = oracle.diag_gaussian_log_prob(g["z"], g["loc"], g["log_scale"])
+    assert_close(lp, g["log_prob"], what="log_prob", rtol=1e-5, atol=1e-5)
+    lp = oracle.diag_gaussian_log_prob(g["z"], g["loc"], g["log_scale"], ls_shift=float(np.log(0.7)))
+    assert_close(lp, g["log_prob_t07"], what="log_prob_t", rtol=1e-5, atol=1e-5)
+    g = load_golden("squeeze")
+    assert np.array_equal(oracle.squeeze(g["z"], 0), g["fwd"])   # pure data movement: bit exact
+    assert np.array_equal(oracle.squeeze(g["z"], 1), g["inv"])
+
+
+def test_c2mini_model(oracle):
+    """NormalizingFlow.log_prob / sample of the reference on the C2-mini model vs the oracle's layer chain."""
+    g = load_golden("model_c2mini")
+    ora = oracle.OracleNSF(golden_state(g), num_layers=8, K=8, tail_bound=3.0)
+    lp = ora.log_prob(g["x"])
+    rel = np.abs(lp - g["log_prob"]) / np.maximum(1.0, np.abs(g["log_prob"]))
+    assert rel.max() < 1e-5, rel.max()
+    xs, lq = ora.sample_from(g["eps"])
+    assert_close(xs, g["sample"], what="sample", rtol=1e-4, atol=1e-4)
+    rel = np.abs(lq - g["sample_logq"]) / np.maximum(1.0, np.abs(g["sample_logq"]))
+    assert rel.max() < 1e-5, rel.max()
