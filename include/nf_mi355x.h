@@ -95,6 +95,40 @@ int nf_rqs_coupling(const void *x, void *y, void *logdet, const void *cond, cons
                     int dtype, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fully fused NSF coupling layer: ResidualNet conditioner (fp32 MFMA) + spline epilogue, one launch.
+ * Replaces the whole of CoupledRationalQuadraticSpline.forward/inverse
+ * (normflows/flows/neural_spline/wrapper.py:79-85) for 2-D inputs without context:
+ * nets/resnet.py:92-104 (ResidualNet.forward, ReLU, no batch-norm, dropout 0) +
+ * nsf/coupling.py:71-128 + utils/splines.py:16-219, tails = linear.
+ *
+ * Supported shape (anything else returns NF_ENOTSUP and the caller uses nf_rqs_coupling): D = 64 with
+ * the alternating mask of wrapper.py:69 (nI = nT = 32), hidden = 128, K = 8, fp32.
+ *   mask_parity 0: reverse_mask = False (identity = even columns, transform = odd), 1: the opposite.
+ * `wpack` is the layer's weights re-laid-out in MFMA operand order by nf_rqs_fused_pack() (device
+ * buffer of nf_rqs_fused_pack_size() bytes, 16-byte aligned); weights are torch nn.Linear layout
+ * (out, in); w_blocks/b_blocks are HOST arrays of 2*num_blocks DEVICE pointers
+ * [blk0.linear0, blk0.linear1, blk1.linear0, ...].  direction 0 = density (wrapper.inverse),
+ * 1 = sample (wrapper.forward).
+ */
+int64_t nf_rqs_fused_pack_size(int nI, int nT, int hidden, int num_blocks, int K);
+int nf_rqs_fused_pack(void *wpack, const void *w_init, const void *b_init, const void *const *w_blocks,
+                      const void *const *b_blocks, const void *w_final, const void *b_final, const void *uw,
+                      const void *uh, const void *ud, int nI, int nT, int hidden, int num_blocks, int K,
+                      double tail_bound, double min_bin_width, double min_bin_height, double min_derivative,
+                      nf_stream_t stream);
+/* nf_rqs_fused_pack_lu adds the layer's LULinearPermute (normflows/flows/mixing.py:535-563) to the blob as one
+ * dense 64 x 64 matrix per direction (L U P, resp. P^T U^-1 L^-1 and -W b, composed in fp64, rounded to fp32).
+ * With fuse_lu = 1, nf_rqs_fused also applies it: density = LULinearPermute.inverse BEFORE the coupling
+ * (core.py:193-195 runs flows in reverse), sample = LULinearPermute.forward AFTER it; its constant log|det| is
+ * folded into the per-sample log-det. */
+int nf_rqs_fused_pack_lu(void *wpack, int num_blocks, const int64_t *perm, const void *lower_entries,
+                         const void *upper_entries, const void *unconstrained_upper_diag, const void *bias, int D,
+                         double eps, nf_stream_t stream);
+int nf_rqs_fused(const void *x, void *y, void *logdet, const void *wpack, int mask_parity, int fuse_lu, int64_t B,
+                 int D, int hidden, int num_blocks, int K, double tail_bound, double min_bin_width,
+                 double min_bin_height, double min_derivative, int direction, int acc, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * LULinearPermute.  Replaces normflows/flows/mixing.py:535-563 (LULinearPermute), :229-244
  * (_Permutation), :402-473 (_LULinear forward_no_cache / inverse_no_cache), :514-532 (upper_diag,
  * logabsdet).

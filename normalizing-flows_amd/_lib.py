@@ -85,6 +85,8 @@ def lib():
         _lib = C.CDLL(LIBPATH)
         _lib.nf_version.restype = C.c_char_p
         _lib.nf_strerror.restype = C.c_char_p
+        if hasattr(_lib, "nf_rqs_fused_pack_size"):
+            _lib.nf_rqs_fused_pack_size.restype = C.c_int64
     return _lib
 
 

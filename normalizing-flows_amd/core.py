@@ -16,6 +16,38 @@ import torch
 from torch import nn
 
 from .flows.base import run_flow
+from .flows.mixing import LULinearPermute
+from .flows.neural_spline import CoupledRationalQuadraticSpline
+
+
+def run_chain(flows, z, inverse, ld, acc):
+    """Run a list of flows in order (inverse=False) or reversed with .inverse (inverse=True), folding log-dets into
+    `ld`.  Adjacent [CoupledRationalQuadraticSpline, LULinearPermute] pairs of the supported shape are issued as one
+    fused kernel (csrc/rqs_fused.hip); everything else goes layer by layer."""
+    n = len(flows)
+    if inverse:
+        i = n - 1
+        while i >= 0:
+            f = flows[i]
+            if (i > 0 and isinstance(f, LULinearPermute) and isinstance(flows[i - 1], CoupledRationalQuadraticSpline)
+                    and flows[i - 1]._pair_eligible(z, f)):
+                z = flows[i - 1]._run_pair(z, f, True, ld, acc)
+                i -= 2
+            else:
+                z = run_flow(f, z, True, ld, acc)
+                i -= 1
+    else:
+        i = 0
+        while i < n:
+            f = flows[i]
+            if (i + 1 < n and isinstance(f, CoupledRationalQuadraticSpline) and isinstance(flows[i + 1], LULinearPermute)
+                    and f._pair_eligible(z, flows[i + 1])):
+                z = f._run_pair(z, flows[i + 1], False, ld, acc)
+                i += 2
+            else:
+                z = run_flow(f, z, False, ld, acc)
+                i += 1
+    return z
 
 
 class _GraphCache:
@@ -82,8 +114,7 @@ class NormalizingFlow(nn.Module):
 
     def forward_and_log_det(self, z):
         log_det = torch.zeros(len(z), dtype=z.dtype, device=z.device)
-        for flow in self.flows:
-            z = run_flow(flow, z, False, log_det, +1)
+        z = run_chain(self.flows, z, False, log_det, +1)
         return z, log_det
 
     def inverse(self, x):
@@ -93,15 +124,12 @@ class NormalizingFlow(nn.Module):
 
     def inverse_and_log_det(self, x):
         log_det = torch.zeros(len(x), dtype=x.dtype, device=x.device)
-        for i in range(len(self.flows) - 1, -1, -1):
-            x = run_flow(self.flows[i], x, True, log_det, +1)
+        x = run_chain(self.flows, x, True, log_det, +1)
         return x, log_det
 
     def _log_prob_impl(self, x):
         log_q = torch.zeros(len(x), dtype=x.dtype, device=x.device)
-        z = x
-        for i in range(len(self.flows) - 1, -1, -1):
-            z = run_flow(self.flows[i], z, True, log_q, +1)
+        z = run_chain(self.flows, x, True, log_q, +1)
         if hasattr(self.q0, "_log_prob_acc"):
             self.q0._log_prob_acc(z, log_q, +1)
         else:
@@ -118,8 +146,7 @@ class NormalizingFlow(nn.Module):
 
     def _sample_impl(self, eps):
         z, log_q = self.q0.from_noise(eps)
-        for flow in self.flows:
-            z = run_flow(flow, z, False, log_q, -1)
+        z = run_chain(self.flows, z, False, log_q, -1)
         return z, log_q
 
     def sample_from_noise(self, eps):

@@ -1,0 +1,682 @@
+// rqs_fused.hip -- one NSF coupling layer (CoupledRationalQuadraticSpline, optionally followed/preceded by its
+// LULinearPermute) as ONE kernel: ResidualNet conditioner on fp32 MFMA + rational-quadratic spline epilogue.
+//
+// Reference behaviour: normflows/flows/neural_spline/wrapper.py:79-85, nsf/coupling.py:71-128, :150-164, :221-253,
+// :329-362, nets/resnet.py:37-50, :92-104, utils/splines.py:16-219; mixing.py:535-563 for the fused LU layer.
+//
+// Shape handled by this kernel (the benchmark shape; everything else takes the unfused path):
+//   D = 64 features, alternating mask (32 identity / 32 transform), hidden = 128, K = 8 bins, linear tails,
+//   ReLU ResidualNet with any number of blocks, no context, fp32.
+//
+// Work decomposition
+//   workgroup = 4 waves, wave = 32 samples (MFMA N = 32).  All GEMMs are evaluated transposed,
+//       Out^T[out, sample] = W[out, k] * Act^T[k, sample],
+//   with v_mfma_f32_32x32x2_f32: A operand = weights (one VGPR), B operand = activations (one VGPR), C = 16 VGPRs
+//   holding, for the lane's sample (lane & 31), the output rows (reg&3) + 8 (reg>>2) + 4 (lane>>5) of a 32-row block.
+//   Because the contraction order is free, step t of the next layer lets lane-half hh contract over exactly the 64
+//   hidden units whose values that half already holds in its C registers: activations never leave the register
+//   file between layers (no LDS round trip, no cross-lane traffic); ReLU and bias are VALU ops on C registers.
+//   The final layer's 736 rows are re-ordered (and padded to 768) at pack time so that after three 32-row blocks a
+//   lane holds the complete 23-parameter sets of two (sample, feature) spline elements: the conditioner output is
+//   never materialised (2944 B/sample/layer of HBM traffic in the unfused path -> 0).
+//
+// Weight stream
+//   The layer's weights are packed once (nf_rqs_fused_pack) into MFMA A-operand order: 16 KB "stages", each a
+//   32-row block x 128-k panel stored as [16 k-groups][64 lanes][4 floats], so that a wave's ds_read_b128 /
+//   global_load_lds accesses are lane-linear (conflict-free, perfectly coalesced).  Stages are streamed through a
+//   2-slot LDS ring with global_load_lds (DMA, no VGPR staging): while the 4 waves run the 64 MFMAs of stage s,
+//   stage s+1 lands.  One barrier per stage (per 64 MFMAs = 4096 SIMD cycles).
+//
+// HBM traffic per sample: 256 B in + 256 B out + 8 B log-det (the 0.66 MB of weights per layer are read from L2).
+// Arithmetic: 2 * 167 936 MAC per sample (768-row padded final layer) at the fp32 MFMA rate.
+#include "common.hpp"
+
+namespace nf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int F_D = 64;            // features
+constexpr int F_NI = 32;           // identity features (= transform features)
+constexpr int F_H = 128;           // hidden units
+constexpr int F_K = 8;             // bins
+constexpr int F_M = 3 * F_K - 1;   // 23 parameters per transform feature
+constexpr int F_STAGE = 4096;      // floats per stage (16 KB)
+constexpr int F_TABW = 3 * (F_K + 1);  // 27 words per unconditional-spline table row
+constexpr int F_HDR = 64;          // header floats
+
+// ---- packed blob layout (floats) ------------------------------------------------------------------------------
+//   [0, F_HDR)                         header: [0] = magic, [1] = num_blocks, [2] = has_lu, [3] = lu log|det|
+//   small section (copied to LDS at kernel start):
+//     bias_init   [4 rowblocks][2 halves][16]                       128
+//     bias_hidden [2*nblk][4][2][16]                                 256 * nblk
+//     bias_final  [8 groups][3 rowblocks][2][16]                     768
+//     tables      [32 identity features][27]                         864
+//     bias_lu     [2 directions][2 rowblocks][2][16]                 128
+//   stages (16 KB each, 16-byte aligned): init | hidden (8 per block) | final (24) | lu density | lu sample
+struct FusedLayout {
+    int nblk;
+    __host__ __device__ int small_floats() const { return 128 + 256 * nblk + 768 + F_NI * F_TABW + 128; }
+    __host__ __device__ int off_bias_init() const { return 0; }
+    __host__ __device__ int off_bias_hidden(int lin) const { return 128 + 128 * lin; }
+    __host__ __device__ int off_bias_final() const { return 128 + 256 * nblk; }
+    __host__ __device__ int off_tables() const { return off_bias_final() + 768; }
+    __host__ __device__ int off_bias_lu(int dir) const { return off_tables() + F_NI * F_TABW + 64 * dir; }
+    __host__ __device__ int lu_stage(int dir) const { return 1 + 8 * nblk + 24 + dir; }
+    __host__ __device__ int small_padded() const { return (small_floats() + 1023) / 1024 * 1024; }
+    __host__ __device__ int off_stages() const { return F_HDR + small_padded(); }  // multiple of 4 floats
+    __host__ __device__ int nstages(bool lu) const { return 1 + 8 * nblk + 24 + (lu ? 1 : 0); }
+    __host__ __device__ int64_t total_floats() const { return (int64_t)off_stages() + (int64_t)(nstages(false) + 2) * F_STAGE; }
+};
+
+// Row of the final layer (0..735) held by MFMA row `rho` (0..31) of row-block rb (0..2) of group g (0..7), or -1
+// for a padding row.  A lane-half hh ends up with features tf(g, hh, f), f = 0,1, 24 slots each (23 used).
+__host__ __device__ inline int final_row(int g, int rb, int rho) {
+    const int q = rho >> 3, hh = (rho >> 2) & 1, r = rho & 3;
+    const int v = 16 * rb + 4 * q + r;  // 0..47: position in the lane's parameter list
+    const int f = v / 24, prm = v % 24;
+    if (prm >= F_M) return -1;
+    const int tf = 8 * (g >> 1) + 4 * hh + 2 * (g & 1) + f;
+    return tf * F_M + prm;
+}
+
+// ---- pack kernels ---------------------------------------------------------------------------------------------
+// A-operand image of one 32-row block: dst[s][lane][r4] = W[row(lane & 31)][kcol(s, lane >> 5, r4)]
+__global__ void pack_init_kernel(const float *__restrict__ W /*128x32*/, const float *__restrict__ b, float *__restrict__ stage,
+                                 float *__restrict__ bias_dst) {
+    // stage 0: 4 row-blocks x (4 k-groups x 64 lanes x 4)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < F_STAGE; i += gridDim.x * blockDim.x) {
+        const int r4 = i & 3, lane = (i >> 2) & 63, s = (i >> 8) & 3, m = i >> 10;
+        const int row = 32 * m + (lane & 31);
+        const int k = 8 * s + 4 * (lane >> 5) + r4;  // identity-feature index
+        stage[i] = W[row * F_NI + k];
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 128; i += gridDim.x * blockDim.x) {
+        const int reg = i & 15, hh = (i >> 4) & 1, m = i >> 5;
+        bias_dst[i] = b[32 * m + 8 * (reg >> 2) + 4 * hh + (reg & 3)];
+    }
+}
+
+__global__ void pack_hidden_kernel(const float *__restrict__ W /*128x128*/, const float *__restrict__ b,
+                                   float *__restrict__ stages /*4 stages*/, float *__restrict__ bias_dst) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 4 * F_STAGE; i += gridDim.x * blockDim.x) {
+        const int r4 = i & 3, lane = (i >> 2) & 63, s = (i >> 8) & 15, m = i >> 12;
+        const int row = 32 * m + (lane & 31);
+        const int k = 8 * s + 4 * (lane >> 5) + r4;
+        stages[i] = W[row * F_H + k];
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 128; i += gridDim.x * blockDim.x) {
+        const int reg = i & 15, hh = (i >> 4) & 1, m = i >> 5;
+        bias_dst[i] = b[32 * m + 8 * (reg >> 2) + 4 * hh + (reg & 3)];
+    }
+}
+
+__global__ void pack_final_kernel(const float *__restrict__ W /*736x128*/, const float *__restrict__ b,
+                                  float *__restrict__ stages /*24 stages*/, float *__restrict__ bias_dst) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 24 * F_STAGE; i += gridDim.x * blockDim.x) {
+        const int r4 = i & 3, lane = (i >> 2) & 63, s = (i >> 8) & 15, st = i >> 12;
+        const int g = st / 3, rb = st % 3;
+        const int row = final_row(g, rb, lane & 31);
+        const int k = 8 * s + 4 * (lane >> 5) + r4;
+        stages[i] = row >= 0 ? W[row * F_H + k] : 0.0f;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 768; i += gridDim.x * blockDim.x) {
+        const int reg = i & 15, hh = (i >> 4) & 1, st = i >> 5;
+        const int g = st / 3, rb = st % 3;
+        const int row = final_row(g, rb, 8 * (reg >> 2) + 4 * hh + (reg & 3));
+        bias_dst[i] = row >= 0 ? b[row] : 0.0f;
+    }
+}
+
+__global__ void pack_tables_kernel(const float *__restrict__ uw, const float *__restrict__ uh, const float *__restrict__ ud,
+                                   float *__restrict__ tab, RqsParams<float> p) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= F_NI) return;
+    const float *wj = uw + j * F_K, *hj = uh + j * F_K, *dj = ud + j * (F_K - 1);
+    auto wacc = [=](int k) { return wj[k]; };
+    auto hacc = [=](int k) { return hj[k]; };
+    auto dacc = [=](int k) { return dj[k]; };
+    rqs_build_table<float>(p, wacc, hacc, dacc, tab + j * F_TABW);
+}
+
+__global__ void pack_header_kernel(float *__restrict__ hdr, int nblk) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        hdr[0] = 355.0f;
+        hdr[1] = (float)nblk;
+        hdr[2] = 0.0f;
+        hdr[3] = 0.0f;
+    }
+}
+
+
+// Output column of MFMA row rho (0..31) of LU row-block m (0..1): chosen so that C register `reg` of row-block m is
+// the lane's stash slot 16 m + reg (slot c = 8 Q + column-in-chunk, chunk Q = columns [16 Q + 8 hh, +8)).
+__host__ __device__ inline int lu_out_col(int m, int rho) {
+    const int q = rho >> 3, hh = (rho >> 2) & 1, r = rho & 3;
+    return 16 * (2 * m + (q >> 1)) + 8 * hh + 4 * (q & 1) + r;
+}
+// Input column contracted by k-group s (0..7), k-half hk, element r4: the lane's stash slot 4 s + r4.
+__host__ __device__ inline int lu_in_col(int s, int hk, int r4) { return 16 * (s >> 1) + 8 * hk + 4 * (s & 1) + r4; }
+
+// LULinearPermute as ONE dense 64 x 64 matrix per direction (mixing.py:402-473, :535-563), composed in fp64:
+//   density: y = L (U x[perm]) + b            -> W_d[i][perm[j]] = (L U)[i][j],            bias_d = b
+//   sample : y[perm[j]] = (U^-1 L^-1 (x - b))_j -> W_s[perm[j]][k] = (U^-1 L^-1)[j][k],   bias_s = -W_s b
+// Single workgroup; four 64 x 64 fp64 matrices in LDS.
+__global__ void __launch_bounds__(256)
+pack_lu_kernel(const int64_t *__restrict__ perm, const float *__restrict__ lower_entries,
+               const float *__restrict__ upper_entries, const float *__restrict__ udiag_raw,
+               const float *__restrict__ bias, float eps, float *__restrict__ stage_d, float *__restrict__ stage_s,
+               float *__restrict__ bias_d, float *__restrict__ bias_s, float *__restrict__ hdr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lu_raw[];
+    constexpr int D = F_D, N = F_D * F_D;
+    double *A = reinterpret_cast<double *>(lu_raw), *Bm = A + N, *Cm = Bm + N, *Dm = Cm + N;
+    int *inv = reinterpret_cast<int *>(Dm + N);
+    double *bs = reinterpret_cast<double *>(inv + D);  // sample bias, by output column
+    __shared__ float sred[16];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N; i += 256) {
+        const int r = i / D, c = i - r * D;
+        double l = 0.0, u = 0.0;
+        if (c < r) l = (double)lower_entries[r * (r - 1) / 2 + c];
+        else if (c == r) { l = 1.0; u = (double)(softplus(udiag_raw[r]) + eps); }
+        else u = (double)upper_entries[r * (D - 1) - r * (r - 1) / 2 + (c - r - 1)];
+        A[i] = l;
+        Bm[i] = u;
+    }
+    for (int i = tid; i < D; i += 256) inv[(int)perm[i]] = i;
+    float part = 0.0f;
+    for (int i = tid; i < D; i += 256) part += logf(softplus(udiag_raw[i]) + eps);  // mixing.py:514-532
+    const float lad = block_sum(part, sred);
+    if (tid == 0) { hdr[2] = 1.0f; hdr[3] = lad; }
+    __syncthreads();
+    // ---- density: C = L U ----
+    for (int i = tid; i < N; i += 256) {
+        const int r = i / D, c = i - r * D;
+        double a = 0.0;
+        for (int k = 0; k <= (r < c ? r : c); ++k) a += A[r * D + k] * Bm[k * D + c];
+        Cm[i] = a;
+    }
+    __syncthreads();
+    for (int i = tid; i < F_STAGE; i += 256) {
+        const int r4 = i & 3, lane = (i >> 2) & 63, sg = (i >> 8) & 7, m = i >> 11;
+        const int row = lu_out_col(m, lane & 31), k = lu_in_col(sg, lane >> 5, r4);
+        stage_d[i] = (float)Cm[row * D + inv[k]];  // W_d[row][k] = (LU)[row][perm^-1[k]]
+    }
+    for (int i = tid; i < 64; i += 256) {
+        const int reg = i & 15, hh = (i >> 4) & 1, m = i >> 5;
+        bias_d[i] = bias[lu_out_col(m, 8 * (reg >> 2) + 4 * hh + (reg & 3))];
+    }
+    __syncthreads();
+    // ---- sample: C = L^-1, D = U^-1 (column solves in fp64), A = D C ----
+    for (int i = tid; i < N; i += 256) { Cm[i] = 0.0; Dm[i] = 0.0; }
+    __syncthreads();
+    for (int c = tid; c < D; c += 256) {
+        for (int r = c; r < D; ++r) {
+            double a = (r == c) ? 1.0 : 0.0;
+            for (int k = c; k < r; ++k) a -= A[r * D + k] * Cm[k * D + c];
+            Cm[r * D + c] = a;  // unit diagonal
+        }
+        for (int r = c; r >= 0; --r) {
+            double a = (r == c) ? 1.0 : 0.0;
+            for (int k = r + 1; k <= c; ++k) a -= Bm[r * D + k] * Dm[k * D + c];
+            Dm[r * D + c] = a / Bm[r * D + r];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += 256) {
+        const int r = i / D, c = i - r * D;
+        double a = 0.0;
+        for (int k = (r > c ? r : c); k < D; ++k) a += Dm[r * D + k] * Cm[k * D + c];  // U^-1 upper, L^-1 lower
+        A[i] = a;
+    }
+    __syncthreads();
+    for (int j = tid; j < D; j += 256) {  // bias_s[perm[j]] = -sum_k (U^-1 L^-1)[j][k] b[k]
+        double a = 0.0;
+        for (int k = 0; k < D; ++k) a += A[j * D + k] * (double)bias[k];
+        bs[(int)perm[j]] = -a;
+    }
+    __syncthreads();
+    for (int i = tid; i < F_STAGE; i += 256) {
+        const int r4 = i & 3, lane = (i >> 2) & 63, sg = (i >> 8) & 7, m = i >> 11;
+        const int row = lu_out_col(m, lane & 31), k = lu_in_col(sg, lane >> 5, r4);
+        stage_s[i] = (float)A[inv[row] * D + k];  // W_s[row][k] = (U^-1 L^-1)[perm^-1[row]][k]
+    }
+    for (int i = tid; i < 64; i += 256) {
+        const int reg = i & 15, hh = (i >> 4) & 1, m = i >> 5;
+        bias_s[i] = (float)bs[lu_out_col(m, 8 * (reg >> 2) + 4 * hh + (reg & 3))];
+    }
+}
+
+// ---- spline on register-resident parameters (K = 8, linear tails), static indexing only ---------------------
+// prm[0..7] raw widths, prm[8..15] raw heights, prm[16..22] raw derivative logits.
+template <bool INVERSE>
+__device__ __forceinline__ void rqs_regs(const RqsParams<float> &p, float x, const float (&prm)[24], float inv_div,
+                                         float &y, float &lad) {
+    if (!(x >= p.left && x <= p.right)) {
+        y = x;
+        lad = 0.0f;
+        return;
+    }
+    float w[F_K], h[F_K];
+#pragma unroll
+    for (int k = 0; k < F_K; ++k) {
+        w[k] = prm[k] * inv_div;
+        h[k] = prm[F_K + k] * inv_div;
+    }
+    float mw = w[0], mh = h[0];
+#pragma unroll
+    for (int k = 1; k < F_K; ++k) {
+        mw = fmaxf(mw, w[k]);
+        mh = fmaxf(mh, h[k]);
+    }
+    float sw = 0.0f, sh = 0.0f;
+#pragma unroll
+    for (int k = 0; k < F_K; ++k) {
+        w[k] = expf(w[k] - mw);
+        h[k] = expf(h[k] - mh);
+        sw += w[k];
+        sh += h[k];
+    }
+    const float isw = 1.0f / sw, ish = 1.0f / sh;
+    float kw[F_K + 1], kh[F_K + 1];
+    kw[0] = p.left;
+    kh[0] = p.bottom;
+    float cw = 0.0f, ch = 0.0f;
+#pragma unroll
+    for (int k = 0; k < F_K; ++k) {
+        cw += p.min_w + p.scale_w * (w[k] * isw);
+        ch += p.min_h + p.scale_h * (h[k] * ish);
+        kw[k + 1] = (k == F_K - 1) ? p.right : (p.right - p.left) * cw + p.left;
+        kh[k + 1] = (k == F_K - 1) ? p.top : (p.top - p.bottom) * ch + p.bottom;
+    }
+    int bin = 0;
+    float slo = INVERSE ? kh[0] : kw[0], shi = INVERSE ? kh[1] : kw[1];
+    float olo = INVERSE ? kw[0] : kh[0], ohi = INVERSE ? kw[1] : kh[1];
+#pragma unroll
+    for (int k = 1; k < F_K; ++k) {
+        const bool ge = x >= (INVERSE ? kh[k] : kw[k]);
+        bin = ge ? k : bin;
+        slo = ge ? (INVERSE ? kh[k] : kw[k]) : slo;
+        shi = ge ? (INVERSE ? kh[k + 1] : kw[k + 1]) : shi;
+        olo = ge ? (INVERSE ? kw[k] : kh[k]) : olo;
+        ohi = ge ? (INVERSE ? kw[k + 1] : kh[k + 1]) : ohi;
+    }
+    float dl0 = p.edge_logit, dl1 = p.edge_logit;
+#pragma unroll
+    for (int k = 0; k < F_K - 1; ++k) {
+        dl0 = (bin == k + 1) ? prm[2 * F_K + k] : dl0;  // padded logit j = bin  -> raw index bin - 1
+        dl1 = (bin == k) ? prm[2 * F_K + k] : dl1;      // padded logit j = bin+1 -> raw index bin
+    }
+    const float d0 = p.min_d + softplus(dl0), d1 = p.min_d + softplus(dl1);
+    if (!INVERSE)
+        rqs_eval_bin<float>(x, slo, shi - slo, olo, ohi - olo, d0, d1, false, y, lad);
+    else
+        rqs_eval_bin<float>(x, olo, ohi - olo, slo, shi - slo, d0, d1, true, y, lad);
+}
+
+// ---- the fused layer kernel -----------------------------------------------------------------------------------
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ f32x16 load_bias16(const float *src) {
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(src), b = *reinterpret_cast<const f32x4 *>(src + 4),
+                c = *reinterpret_cast<const f32x4 *>(src + 8), d = *reinterpret_cast<const f32x4 *>(src + 12);
+    f32x16 v;
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    v[8] = c[0]; v[9] = c[1]; v[10] = c[2]; v[11] = c[3];
+    v[12] = d[0]; v[13] = d[1]; v[14] = d[2]; v[15] = d[3];
+    return v;
+}
+
+// acc += Wblock(32 x 128) * B, where the B operand for (k-group s, r) is `bsrc[s >> 2][4 (s & 3) + r]`
+// (optionally through ReLU): 16 ds_read_b128 + 64 MFMA.
+template <bool RELU>
+__device__ __forceinline__ void mm128(const float *buf, int lane, f32x16 &acc, const f32x16 &b0, const f32x16 &b1,
+                                      const f32x16 &b2, const f32x16 &b3) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(buf + s * 256 + lane * 4);
+        const f32x16 &bs = (s >> 2) == 0 ? b0 : ((s >> 2) == 1 ? b1 : ((s >> 2) == 2 ? b2 : b3));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float bv = bs[4 * (s & 3) + r];
+            if (RELU) bv = fmaxf(bv, 0.0f);
+            acc = MFMA(a[r], bv, acc);
+        }
+    }
+}
+
+// 2 row-blocks x 8 k-groups of the composed 64 x 64 LU matrix: out[slot 16 m + reg] = bias + sum_k W[.][k] xin[k-slot]
+__device__ __forceinline__ void lu_mm(const float *buf, int lane, const float (&xin)[32], f32x16 &o0, f32x16 &o1) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        f32x16 &o = m == 0 ? o0 : o1;
+#pragma unroll
+        for (int sg = 0; sg < 8; ++sg) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(buf + (m * 8 + sg) * 256 + lane * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o = MFMA(a[r], xin[4 * sg + r], o);
+        }
+    }
+}
+
+// DIR: 0 = density (wrapper.inverse), 1 = sample (wrapper.forward).  LU: fuse the layer's LULinearPermute
+// (density: LULinearPermute.inverse BEFORE the coupling; sample: LULinearPermute.forward AFTER it).
+template <int DIR, bool LU>
+__global__ void __launch_bounds__(256, 2)
+rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ logdet,
+                 const float *__restrict__ pack, int64_t B, int nblk, int par_t /* column parity of transform features */,
+                 RqsParams<float> p, float inv_div, int acc) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    FusedLayout lay;
+    lay.nblk = nblk;
+    float *ring = smem;                       // 2 x 4096
+    float *stash = ring + 2 * F_STAGE;        // 4 waves x 32 x 64
+    float *small = stash + 4 * 32 * 64;       // biases + tables
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
+    const int64_t row = (int64_t)blockIdx.x * 128 + wid * 32 + (lane & 31);
+    const bool valid = row < B;
+    const int par_i = par_t ^ 1;
+    const float *stages = pack + lay.off_stages();
+    const int nbase = lay.nstages(false);
+    const int nstages = lay.nstages(LU);
+    // logical -> physical stage: the LU stage comes first in the density direction, last in the sample direction
+    auto phys = [&](int s) -> int {
+        if (!LU) return s;
+        if (DIR == 0) return s == 0 ? lay.lu_stage(0) : s - 1;
+        return s < nbase ? s : lay.lu_stage(1);
+    };
+    float *st = stash + wid * 2048 + lane;  // value c (0..31) of this lane at st[c * 64]; c = 8 Q + column-in-chunk
+
+    // ---- weight-stream helpers (2-slot ring, global -> LDS DMA) ----
+    int stage = 0;
+    auto issue = [&](int s) {
+        const float *src = stages + (size_t)phys(s) * F_STAGE + (wid * 4) * 256 + lane * 4;
+        float *dst = ring + (s & 1) * F_STAGE + (wid * 4) * 256;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds(src + i * 256, (__attribute__((address_space(3))) void *)(dst + i * 256), 16, 0, 0);
+    };
+    auto acquire = [&]() -> const float * {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (stage + 1 < nstages) issue(stage + 1);
+        const float *buf = ring + (stage & 1) * F_STAGE;
+        ++stage;
+        return buf;
+    };
+
+    // ---- prologue: x rows -> LDS stash, small section -> LDS, first stage in flight ----
+    issue(0);
+    for (int i = tid; i < lay.small_floats(); i += 256) small[i] = pack[F_HDR + i];
+    float xin[32];  // the lane's 32 row values, slot c = 8 Q + column-in-chunk
+#pragma unroll
+    for (int Q = 0; Q < 4; ++Q) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+            const float *src = x + row * F_D + 16 * Q + 8 * hh;
+            a = *reinterpret_cast<const f32x4 *>(src);
+            b = *reinterpret_cast<const f32x4 *>(src + 4);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            xin[8 * Q + c] = a[c];
+            xin[8 * Q + 4 + c] = b[c];
+        }
+    }
+    __syncthreads();
+    float ld = 0.0f;
+    if (LU && DIR == 0) {
+        // LULinearPermute.inverse (mixing.py:560-563) as one dense 64 x 64 product on MFMA; C register `reg` of
+        // row-block m is the new value of slot 16 m + reg
+        const float *bsrc = small + lay.off_bias_lu(0) + hh * 16;
+        f32x16 o0 = load_bias16(bsrc), o1 = load_bias16(bsrc + 32);
+        lu_mm(acquire(), lane, xin, o0, o1);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            st[c * 64] = o0[c];
+            st[(16 + c) * 64] = o1[c];
+        }
+        if (hh == 0) ld += pack[3];  // constant log|det| of the LU layer, once per sample
+    } else {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) st[c * 64] = xin[c];
+    }
+
+    // ---- unconditional spline on the identity half (nsf/coupling.py:88-92 density / :112-116 sample) ----
+    float bx[16];
+    {
+        const float *tabs = small + lay.off_tables();
+#pragma unroll
+        for (int Q = 0; Q < 4; ++Q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 8 * Q + 2 * r + par_i;
+                const int f = 8 * Q + 4 * hh + r;  // identity feature index
+                const float xi = st[c * 64];
+                float yi, l;
+                rqs_eval_table<float>(p, xi, tabs + f * F_TABW, DIR == 1, yi, l);
+                st[c * 64] = yi;
+                ld += l;
+                bx[4 * Q + r] = DIR == 0 ? xi : yi;  // conditioner input: raw (density) / transformed (sample)
+            }
+    }
+
+    // ---- initial layer: H = W0 xi + b0 (K = 32: 4 row-blocks x 4 k-groups in ONE stage) ----
+    f32x16 H0, H1, H2, H3;
+    {
+        const float *bsrc = small + lay.off_bias_init() + hh * 16;
+        H0 = load_bias16(bsrc);
+        H1 = load_bias16(bsrc + 32);
+        H2 = load_bias16(bsrc + 64);
+        H3 = load_bias16(bsrc + 96);
+        const float *buf = acquire();
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            f32x16 &acc_m = m == 0 ? H0 : (m == 1 ? H1 : (m == 2 ? H2 : H3));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(buf + (m * 4 + s) * 256 + lane * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc_m = MFMA(a[r], bx[4 * s + r], acc_m);
+            }
+        }
+    }
+
+    // ---- residual blocks: H += W2 relu(W1 relu(H) + b1) + b2 (resnet.py:37-50) ----
+    for (int blk = 0; blk < nblk; ++blk) {
+        f32x16 T0, T1, T2, T3;
+        {
+            const float *bsrc = small + lay.off_bias_hidden(2 * blk) + hh * 16;
+            T0 = load_bias16(bsrc);
+            T1 = load_bias16(bsrc + 32);
+            T2 = load_bias16(bsrc + 64);
+            T3 = load_bias16(bsrc + 96);
+        }
+        mm128<true>(acquire(), lane, T0, H0, H1, H2, H3);
+        mm128<true>(acquire(), lane, T1, H0, H1, H2, H3);
+        mm128<true>(acquire(), lane, T2, H0, H1, H2, H3);
+        mm128<true>(acquire(), lane, T3, H0, H1, H2, H3);
+        {
+            const float *bsrc = small + lay.off_bias_hidden(2 * blk + 1) + hh * 16;
+            H0 += load_bias16(bsrc);
+            H1 += load_bias16(bsrc + 32);
+            H2 += load_bias16(bsrc + 64);
+            H3 += load_bias16(bsrc + 96);
+        }
+        mm128<true>(acquire(), lane, H0, T0, T1, T2, T3);
+        mm128<true>(acquire(), lane, H1, T0, T1, T2, T3);
+        mm128<true>(acquire(), lane, H2, T0, T1, T2, T3);
+        mm128<true>(acquire(), lane, H3, T0, T1, T2, T3);
+    }
+
+    // ---- final layer in 8 groups of 3 row-blocks; each group yields the parameters of 2 spline elements ----
+    for (int g = 0; g < 8; ++g) {
+        const float *bsrc = small + lay.off_bias_final() + (g * 3) * 32 + hh * 16;
+        f32x16 A0 = load_bias16(bsrc), A1 = load_bias16(bsrc + 32), A2 = load_bias16(bsrc + 64);
+        mm128<false>(acquire(), lane, A0, H0, H1, H2, H3);
+        mm128<false>(acquire(), lane, A1, H0, H1, H2, H3);
+        mm128<false>(acquire(), lane, A2, H0, H1, H2, H3);
+        // lane's parameter list v = 16 rb + reg: feature f = v / 24, parameter v % 24
+        float prm0[24], prm1[24];
+#pragma unroll
+        for (int v = 0; v < 24; ++v) {
+            prm0[v] = v < 16 ? A0[v] : A1[v - 16];
+            prm1[v] = (v + 24) < 32 ? A1[v + 24 - 16] : A2[v + 24 - 32];
+        }
+        const int cbase = 8 * (g >> 1) + 4 * (g & 1) + par_t;  // stash slot of feature f = 0; f = 1 is +2
+        {
+            const float xt = st[cbase * 64];
+            float yt, l;
+            rqs_regs<DIR == 1>(p, xt, prm0, inv_div, yt, l);
+            st[cbase * 64] = yt;
+            ld += l;
+        }
+        {
+            const float xt = st[(cbase + 2) * 64];
+            float yt, l;
+            rqs_regs<DIR == 1>(p, xt, prm1, inv_div, yt, l);
+            st[(cbase + 2) * 64] = yt;
+            ld += l;
+        }
+    }
+
+    // ---- epilogue: rows back to HBM, per-sample log-det (both lane halves of a sample) ----
+    ld += __shfl_xor(ld, 32, 64);
+    float yout[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) yout[c] = st[c * 64];
+    if (LU && DIR == 1) {
+        // LULinearPermute.forward (mixing.py:555-558): triangular solves + inverse permutation as one dense product
+        const float *bsrc = small + lay.off_bias_lu(1) + hh * 16;
+        f32x16 o0 = load_bias16(bsrc), o1 = load_bias16(bsrc + 32);
+        lu_mm(acquire(), lane, yout, o0, o1);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            yout[c] = o0[c];
+            yout[16 + c] = o1[c];
+        }
+        ld -= pack[3];
+    }
+    if (valid) {
+#pragma unroll
+        for (int Q = 0; Q < 4; ++Q) {
+            f32x4 a, b;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                a[c] = yout[8 * Q + c];
+                b[c] = yout[8 * Q + 4 + c];
+            }
+            float *dst = y + row * F_D + 16 * Q + 8 * hh;
+            *reinterpret_cast<f32x4 *>(dst) = a;
+            *reinterpret_cast<f32x4 *>(dst + 4) = b;
+        }
+        if (hh == 0) ld_store(logdet + row, ld, acc);
+    }
+}
+
+}  // namespace nf
+
+using namespace nf;
+
+extern "C" int64_t nf_rqs_fused_pack_size(int nI, int nT, int hidden, int num_blocks, int K) {
+    if (nI != F_NI || nT != F_NI || hidden != F_H || K != F_K || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
+    FusedLayout lay;
+    lay.nblk = num_blocks;
+    return lay.total_floats() * (int64_t)sizeof(float);
+}
+
+extern "C" int nf_rqs_fused_pack(void *wpack, const void *w_init, const void *b_init, const void *const *w_blocks,
+                                 const void *const *b_blocks, const void *w_final, const void *b_final, const void *uw,
+                                 const void *uh, const void *ud, int nI, int nT, int hidden, int num_blocks, int K,
+                                 double tail_bound, double min_bin_width, double min_bin_height, double min_derivative,
+                                 nf_stream_t stream) {
+    if (nI != F_NI || nT != F_NI || hidden != F_H || K != F_K || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
+    if (!wpack || !w_init || !b_init || !w_final || !b_final || !uw || !uh || !ud) return NF_EFAULT;
+    if (num_blocks > 0 && (!w_blocks || !b_blocks)) return NF_EFAULT;
+    if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    FusedLayout lay;
+    lay.nblk = num_blocks;
+    float *blob = (float *)wpack;
+    float *small = blob + F_HDR;
+    float *stages = blob + lay.off_stages();
+    hipLaunchKernelGGL(pack_header_kernel, dim3(1), dim3(64), 0, st, blob, num_blocks);
+    hipLaunchKernelGGL(pack_init_kernel, dim3(16), dim3(256), 0, st, (const float *)w_init, (const float *)b_init, stages,
+                       small + lay.off_bias_init());
+    for (int l = 0; l < 2 * num_blocks; ++l) {
+        if (!w_blocks[l] || !b_blocks[l]) return NF_EFAULT;
+        hipLaunchKernelGGL(pack_hidden_kernel, dim3(64), dim3(256), 0, st, (const float *)w_blocks[l],
+                           (const float *)b_blocks[l], stages + (size_t)(1 + 4 * l) * F_STAGE,
+                           small + lay.off_bias_hidden(l));
+    }
+    hipLaunchKernelGGL(pack_final_kernel, dim3(384), dim3(256), 0, st, (const float *)w_final, (const float *)b_final,
+                       stages + (size_t)(1 + 8 * num_blocks) * F_STAGE, small + lay.off_bias_final());
+    auto p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
+                                    min_derivative, 1.0);
+    hipLaunchKernelGGL(pack_tables_kernel, dim3(1), dim3(64), 0, st, (const float *)uw, (const float *)uh,
+                       (const float *)ud, small + lay.off_tables(), p);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_rqs_fused_pack_lu(void *wpack, int num_blocks, const int64_t *perm, const void *lower_entries,
+                                    const void *upper_entries, const void *unconstrained_upper_diag, const void *bias,
+                                    int D, double eps, nf_stream_t stream) {
+    if (D != F_D || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
+    if (!wpack || !perm || !lower_entries || !upper_entries || !unconstrained_upper_diag || !bias) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    FusedLayout lay;
+    lay.nblk = num_blocks;
+    float *blob = (float *)wpack;
+    float *small = blob + F_HDR;
+    float *stages = blob + lay.off_stages();
+    const size_t lds = (size_t)4 * F_D * F_D * sizeof(double) + F_D * sizeof(int) + F_D * sizeof(double) + 64;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&pack_lu_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return NF_ENOTSUP;
+    hipLaunchKernelGGL(pack_lu_kernel, dim3(1), dim3(256), lds, st, perm, (const float *)lower_entries,
+                       (const float *)upper_entries, (const float *)unconstrained_upper_diag, (const float *)bias,
+                       (float)eps, stages + (size_t)lay.lu_stage(0) * F_STAGE, stages + (size_t)lay.lu_stage(1) * F_STAGE,
+                       small + lay.off_bias_lu(0), small + lay.off_bias_lu(1), blob);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+template <int DIR, bool LU>
+static int launch_fused(const void *x, void *y, void *logdet, const void *wpack, int64_t B, int num_blocks, int par_t,
+                        const RqsParams<float> &p, float inv_div, int acc, size_t lds, hipStream_t st) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&rqs_fused_kernel<DIR, LU>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return NF_ENOTSUP;
+    const int grid = (int)((B + 127) / 128);
+    hipLaunchKernelGGL((rqs_fused_kernel<DIR, LU>), dim3(grid), dim3(256), lds, st, (const float *)x, (float *)y,
+                       (float *)logdet, (const float *)wpack, B, num_blocks, par_t, p, inv_div, acc);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_rqs_fused(const void *x, void *y, void *logdet, const void *wpack, int mask_parity, int fuse_lu,
+                            int64_t B, int D, int hidden, int num_blocks, int K, double tail_bound, double min_bin_width,
+                            double min_bin_height, double min_derivative, int direction, int acc, nf_stream_t stream) {
+    if (D != F_D || hidden != F_H || K != F_K || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
+    if (B < 0 || (direction != 0 && direction != 1) || (mask_parity != 0 && mask_parity != 1)) return NF_EINVAL;
+    if (acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!x || !y || !logdet || !wpack) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    FusedLayout lay;
+    lay.nblk = num_blocks;
+    auto p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
+                                    min_derivative, sqrt((double)hidden));
+    const float inv_div = (float)(1.0 / sqrt((double)hidden));
+    const size_t lds = (size_t)(2 * F_STAGE + 4 * 32 * 64 + lay.small_floats()) * sizeof(float);
+    if (lds > 80 * 1024) return NF_ENOTSUP;
+    // transform features sit on odd columns for reverse_mask = False (mask_parity 0), on even columns otherwise
+    const int par_t = mask_parity == 0 ? 1 : 0;
+    if (direction == 0)
+        return fuse_lu ? launch_fused<0, true>(x, y, logdet, wpack, B, num_blocks, par_t, p, inv_div, acc, lds, st)
+                       : launch_fused<0, false>(x, y, logdet, wpack, B, num_blocks, par_t, p, inv_div, acc, lds, st);
+    return fuse_lu ? launch_fused<1, true>(x, y, logdet, wpack, B, num_blocks, par_t, p, inv_div, acc, lds, st)
+                   : launch_fused<1, false>(x, y, logdet, wpack, B, num_blocks, par_t, p, inv_div, acc, lds, st);
+}

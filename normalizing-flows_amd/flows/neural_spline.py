@@ -153,6 +153,10 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
         else:
             unconditional_transform = None
         super().__init__(mask, transform_net_create_fn, unconditional_transform=unconditional_transform)
+        self._fused_ok = None      # lazily decided: shape handled by the fused MFMA kernel?
+        self._fused_parity = 0
+        self._fused_cache = None   # (parameter-version key, packed weight blob)
+        self.use_fused = True      # set False to force the unfused (library GEMM + nf_rqs_coupling) path
 
     def _transform_dim_multiplier(self):
         if self.tails == "linear":
@@ -188,6 +192,8 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
     def _density(self, inputs, context=None, ld=None, acc=None):
         """prqct.forward (nsf/coupling.py:71-98): conditioner on the raw identity features."""
         self._check(inputs)
+        if self.use_fused and self._fused_eligible(inputs, context):
+            return self._fused(inputs, 0, ld, acc)
         cond = self._conditioner(inputs, context)
         uw, uh, ud = self._uncond()
         return ops.rqs_coupling(inputs, cond, uw, uh, ud, self.identity_features, self.transform_features,
@@ -196,6 +202,8 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
     def _sample(self, inputs, context=None, ld=None, acc=None):
         """prqct.inverse (nsf/coupling.py:100-128): CDF^-1 on the identity half first, conditioner on ITS output."""
         self._check(inputs)
+        if self.use_fused and self._fused_eligible(inputs, context):
+            return self._fused(inputs, 1, ld, acc)
         uw, uh, ud = self._uncond()
         kw = self._kernel_kwargs()
         y, ld = ops.rqs_coupling(inputs, None, uw, uh, ud, self.identity_features, self.transform_features,
@@ -210,6 +218,63 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
 
     def inverse(self, inputs, context=None):
         return self._sample(inputs, context)
+
+    # -- fused path: conditioner on MFMA + spline epilogue in one kernel (csrc/rqs_fused.hip) -----------------
+    def _fused_eligible(self, inputs, context):
+        net = self.transform_net
+        if not (isinstance(net, ResidualNet) and net.is_plain_relu()):
+            return False
+        if context is not None or inputs.dim() != 2 or inputs.dtype != torch.float32 or not inputs.is_cuda:
+            return False
+        if self.tails != "linear" or self.unconditional_transform is None:
+            return False
+        if self._fused_ok is None:
+            ii = self.identity_features.cpu()
+            ti = self.transform_features.cpu()
+            n = self.features
+            alt0 = torch.equal(ii, torch.arange(0, n, 2)) and torch.equal(ti, torch.arange(1, n, 2))
+            alt1 = torch.equal(ii, torch.arange(1, n, 2)) and torch.equal(ti, torch.arange(0, n, 2))
+            ok = (alt0 or alt1) and ops.rqs_fused_supported(len(ii), len(ti), net.hidden_features, len(net.blocks),
+                                                            self.num_bins)
+            self._fused_ok = bool(ok)
+            self._fused_parity = 0 if alt0 else 1
+        return self._fused_ok
+
+    def _fused_blob(self, lu=None):
+        net, u = self.transform_net, self.unconditional_transform
+        tensors = [net.initial_layer.weight, net.initial_layer.bias]
+        for b in net.blocks:
+            for lin in b.linear_layers:
+                tensors += [lin.weight, lin.bias]
+        tensors += [net.final_layer.weight, net.final_layer.bias, u.unnormalized_widths, u.unnormalized_heights,
+                    u.unnormalized_derivatives]
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        if lu is not None:
+            lin = lu.linear
+            lu_t = [lu.permutation._permutation, lin.lower_entries, lin.upper_entries, lin.unconstrained_upper_diag,
+                    lin.bias]
+            key = key + tuple((t.data_ptr(), t._version) for t in lu_t) + (lin.eps,)
+        if self._fused_cache is None or self._fused_cache[0] != key:
+            d = [t.detach() for t in tensors]
+            nb = len(net.blocks)
+            wb = [d[2 + 2 * i] for i in range(2 * nb)]
+            bb = [d[3 + 2 * i] for i in range(2 * nb)]
+            o = 2 + 4 * nb
+            blob = ops.rqs_fused_pack(d[0], d[1], wb, bb, d[o], d[o + 1], d[o + 2], d[o + 3], d[o + 4], self.num_bins,
+                                      self.tail_bound, self.min_bin_width, self.min_bin_height, self.min_derivative)
+            if lu is not None:
+                ops.rqs_fused_pack_lu(blob, nb, lu_t[0], lu_t[1].detach(), lu_t[2].detach(), lu_t[3].detach(),
+                                      lu_t[4].detach(), eps=lin.eps)
+            self._fused_cache = (key, blob)
+        return self._fused_cache[1]
+
+    def _fused(self, inputs, direction, ld=None, acc=None, lu=None):
+        self._check(inputs)
+        net = self.transform_net
+        return ops.rqs_fused(inputs, self._fused_blob(lu), self._fused_parity, net.hidden_features, len(net.blocks),
+                             self.num_bins, direction, logdet=ld, acc=acc, tail_bound=self.tail_bound,
+                             min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+                             min_derivative=self.min_derivative, fuse_lu=lu is not None)
 
 
 class CoupledRationalQuadraticSpline(Flow):
@@ -249,4 +314,16 @@ class CoupledRationalQuadraticSpline(Flow):
             y, _ = self.prqct._density(z, context, ld=ld, acc=acc)
         else:
             y, _ = self.prqct._sample(z, context, ld=ld, acc=acc)
+        return y
+
+    # -- pair fusion with the LULinearPermute that follows this layer in the flow list ----------------------------
+    def _pair_eligible(self, z, lu):
+        """True when [this layer, lu] can run as ONE kernel: density = lu.inverse then self.inverse (the order
+        NormalizingFlow.log_prob visits them, core.py:193-195), sample = self.forward then lu.forward."""
+        p = self.prqct
+        return (p.use_fused and p._fused_eligible(z, None) and lu.linear.features == p.features
+                and lu.linear.bias.dtype == torch.float32 and lu.linear.bias.is_cuda)
+
+    def _run_pair(self, z, lu, inverse, ld, acc):
+        y, _ = self.prqct._fused(z, 0 if inverse else 1, ld, acc, lu=lu)
         return y

@@ -229,3 +229,68 @@ def squeeze(z, direction):
                             L.stream())
     L.check(rc, "nf_squeeze")
     return y
+
+
+# ---- fused NSF coupling layer (conditioner on MFMA + spline epilogue) ------------------------------------------
+def rqs_fused_supported(nI, nT, hidden, num_blocks, K):
+    return L.lib().nf_rqs_fused_pack_size(i32(nI), i32(nT), i32(hidden), i32(num_blocks), i32(K)) > 0
+
+
+def rqs_fused_pack(w_init, b_init, w_blocks, b_blocks, w_final, b_final, uw, uh, ud, K, tail_bound, min_bin_width,
+                   min_bin_height, min_derivative):
+    """Re-lay-out one layer's weights in MFMA operand order (nf_rqs_fused_pack).  Returns the packed device blob."""
+    import ctypes
+    L.require_device(w_init, b_init, w_final, b_final, uw, uh, ud, *w_blocks, *b_blocks)
+    hidden, nI = w_init.shape
+    nT = uw.shape[0]
+    nb = len(w_blocks) // 2
+    lib = L.lib()
+    lib.nf_rqs_fused_pack_size.restype = ctypes.c_int64
+    size = lib.nf_rqs_fused_pack_size(i32(nI), i32(nT), i32(hidden), i32(nb), i32(K))
+    if size <= 0:
+        raise NotImplementedError("nf_rqs_fused: shape not supported")
+    blob = torch.empty(size // 4, dtype=torch.float32, device=w_init.device)
+    keep = [t.contiguous() for t in (w_init, b_init, w_final, b_final, uw, uh, ud)]
+    wb = [t.contiguous() for t in w_blocks]
+    bb = [t.contiguous() for t in b_blocks]
+    wp = (ctypes.c_void_p * max(len(wb), 1))(*[t.data_ptr() for t in wb])
+    bp = (ctypes.c_void_p * max(len(bb), 1))(*[t.data_ptr() for t in bb])
+    rc = lib.nf_rqs_fused_pack(ptr(blob), ptr(keep[0]), ptr(keep[1]), wp, bp, ptr(keep[2]), ptr(keep[3]), ptr(keep[4]),
+                               ptr(keep[5]), ptr(keep[6]), i32(nI), i32(nT), i32(hidden), i32(nb), i32(K),
+                               f64(tail_bound), f64(min_bin_width), f64(min_bin_height), f64(min_derivative), L.stream())
+    L.check(rc, "nf_rqs_fused_pack")
+    return blob
+
+
+def rqs_fused_pack_lu(blob, num_blocks, perm, lower_entries, upper_entries, unconstrained_upper_diag, bias, eps=1e-3):
+    """Add the layer's LULinearPermute (composed dense 64 x 64 matrices, both directions) to a packed blob."""
+    L.require_device(blob, perm, lower_entries, upper_entries, unconstrained_upper_diag, bias)
+    D = bias.numel()
+    rc = L.lib().nf_rqs_fused_pack_lu(ptr(blob), i32(num_blocks), ptr(perm), ptr(lower_entries.contiguous()),
+                                      ptr(upper_entries.contiguous()), ptr(unconstrained_upper_diag.contiguous()),
+                                      ptr(bias.contiguous()), i32(D), f64(eps), L.stream())
+    L.check(rc, "nf_rqs_fused_pack_lu")
+    return blob
+
+
+def rqs_fused(x, blob, mask_parity, hidden, num_blocks, K, direction, logdet=None, acc=None, tail_bound=3.0,
+              min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, fuse_lu=False):
+    """One launch for a whole CoupledRationalQuadraticSpline layer (+ its LULinearPermute when fuse_lu).
+    direction 0 = density, 1 = sample."""
+    L.require_device(x, blob)
+    if x.dtype != torch.float32:
+        raise TypeError("nf_rqs_fused is fp32 only")
+    x = x.contiguous()
+    B, D = x.shape
+    y = torch.empty_like(x)
+    if logdet is None:
+        logdet = torch.empty(B, dtype=x.dtype, device=x.device)
+        acc = L.LD_WRITE
+    elif acc is None:
+        acc = L.LD_ADD
+    rc = L.lib().nf_rqs_fused(ptr(x), ptr(y), ptr(logdet), ptr(blob), i32(mask_parity), i32(int(fuse_lu)), i64(B),
+                              i32(D), i32(hidden),
+                              i32(num_blocks), i32(K), f64(tail_bound), f64(min_bin_width), f64(min_bin_height),
+                              f64(min_derivative), i32(direction), i32(acc), L.stream())
+    L.check(rc, "nf_rqs_fused")
+    return y, logdet
