@@ -92,34 +92,42 @@ def _events_ms(fn, reps):
     return sum(ts) / len(ts), ts[len(ts) // 2]
 
 
-def kernel_breakdown(model, x, reps=3):
-    """Per-kernel-class HIP-event timing of one eager log_prob pass (instrumented run, not the timed region)."""
+def kernel_breakdown(model, x, reps=5):
+    """HIP-event timing of the launches of one eager log_prob pass (instrumented run, NOT the timed region).
+    The 32 fused [LULinearPermute + CoupledRQS] launches are issued back to back between ONE event pair recorded on
+    torch's current stream (= the stream the C ABI launches on), so the quotient is the kernel's average duration
+    (a 190 us kernel hides the ~5 us host launch cost; bracketing every launch separately would add the launch
+    latency to each sample).  Returns {name: (avg_ms, launches_per_pass)}."""
     import normflows_amd as nfa
-    from normflows_amd import ops
-    acc = {"rqs_coupling": [], "lu_linear_permute": [], "conditioner": []}
+    flows = list(model.flows)
+    pairs = []
+    i = len(flows) - 1
+    while i >= 0:
+        f = flows[i]
+        if (i > 0 and isinstance(f, nfa.flows.LULinearPermute)
+                and isinstance(flows[i - 1], nfa.flows.CoupledRationalQuadraticSpline)
+                and flows[i - 1]._pair_eligible(x, f)):
+            flows[i - 1].prqct._fused_blob(f)  # one-off packing stays outside the timed launches
+            pairs.append((flows[i - 1], f))
+            i -= 2
+        else:
+            i -= 1
+    out = {"rqs_fused_pair": (0.0, 0), "diag_gaussian": (0.0, 1)}
+    if pairs:
+        def chain():
+            z = x
+            log_q = torch.zeros(len(x), device=x.device)
+            for c, f in pairs:
+                z = c._run_pair(z, f, True, log_q, +1)
+            return z, log_q
+        chain()
+        avg, med = _events_ms(lambda: chain(), reps)
+        out["rqs_fused_pair"] = (med / len(pairs), len(pairs))
     z = x
     log_q = torch.zeros(len(x), device=x.device)
-    for _ in range(reps):
-        z = x
-        for flow in reversed(model.flows):
-            if isinstance(flow, nfa.flows.CoupledRationalQuadraticSpline):
-                p = flow.prqct
-                cond_holder = {}
-                ms, _ = _events_ms(lambda: cond_holder.__setitem__("c", p._conditioner(z, None)), 1)
-                acc["conditioner"].append(ms)
-                uw, uh, ud = p._uncond()
-                out = {}
-                ms, _ = _events_ms(lambda: out.__setitem__("y", ops.rqs_coupling(
-                    z, cond_holder["c"], uw, uh, ud, p.identity_features, p.transform_features, p.num_bins, 0,
-                    logdet=log_q, acc=1, **p._kernel_kwargs())[0]), 1)
-                acc["rqs_coupling"].append(ms)
-                z = out["y"]
-            else:
-                out = {}
-                ms, _ = _events_ms(lambda: out.__setitem__("y", flow._run(z, True, log_q, +1)), 1)
-                acc["lu_linear_permute"].append(ms)
-                z = out["y"]
-    return {k: (sum(v) / len(v) if v else 0.0, len(v) // reps) for k, v in acc.items()}
+    avg, med = _events_ms(lambda: model.q0._log_prob_acc(z, log_q, +1), reps)
+    out["diag_gaussian"] = (med, 1)
+    return out
 
 
 def cpu_baseline(model, rows):
@@ -218,12 +226,16 @@ def main():
                 bd = kernel_breakdown(model, x)
             model.use_graphs(not args.no_graph)
             out["kernel_ms"] = {k: {"avg_ms": v[0], "launches_per_pass": v[1]} for k, v in bd.items()}
-            rqs_ms = bd["rqs_coupling"][0]
-            alg_bytes = (2 * DIM * 4 + (DIM // 2) * (3 * BINS - 1) * 4 + 8) * args.batch
-            ach = alg_bytes / (rqs_ms * 1e-3) / 1e9
-            out["roofline"] = {"kernel": "nf::rqs_coupling_kernel<float>", "bound": "hbm", "achieved": ach,
-                               "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
-                               "bytes_per_launch": alg_bytes, "avg_launch_ms": rqs_ms}
+            pair_ms = bd["rqs_fused_pair"][0]
+            if pair_ms > 0:
+                # dominant kernel: nf::rqs_fused_kernel<0, true>.  Algorithmic FLOPs per launch:
+                # (327 680 conditioner + 16 384 LU) FLOP per sample-layer x rows per launch; MFMA-bound.
+                fl = (c2_flops_per_sample(layers=1)) * args.batch
+                ach = fl / (pair_ms * 1e-3) / 1e12
+                out["roofline"] = {"kernel": "nf::rqs_fused_kernel<0, true>", "bound": "mfma", "achieved": ach,
+                                   "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,
+                                   "flop_per_launch": fl, "avg_launch_ms": pair_ms,
+                                   "hbm_algorithmic_bytes_per_launch": (2 * DIM * 4 + 8) * args.batch}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, args.cpu_rows)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -247,16 +247,60 @@ pack_lu_kernel(const int64_t *__restrict__ perm, const float *__restrict__ lower
     }
 }
 
-// ---- spline on register-resident parameters (K = 8, linear tails), static indexing only ---------------------
+// ---- branch-free fp32 math for the epilogue -------------------------------------------------------------------
+// The spline evaluations must live in the same basic block as the MFMAs they hide behind, so nothing here may
+// branch.  Hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32 / v_sqrt_f32, <= 1 ulp each) replace the libm
+// calls of the unfused kernels; softmax arguments are <= 0 and bounded, log arguments are O(1), so the absolute
+// error stays at the 1e-7 level (parity tests: fused vs unfused vs oracle vs reference golden vectors).
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+// softplus = log1p(exp(x)) (threshold 20 like torch); log1p(t) = log(1+t) * t / ((1+t) - 1) keeps full relative
+// accuracy for tiny t (Kahan), selected against the t itself when 1+t rounds to 1.
+__device__ __forceinline__ float fsoftplus(float x) {
+    const float t = fexp(fminf(x, 20.0f));
+    const float u = 1.0f + t;
+    const float w = u - 1.0f;
+    const float l1p = (w == 0.0f) ? t : flog(u) * (t * frcp(w));
+    return x > 20.0f ? x : l1p;
+}
+
+// utils/splines.py:159-219 once the bin is known; same formulas as rqs_eval_bin, branch-free.
+template <bool INVERSE>
+__device__ __forceinline__ void rqs_eval_bin_fast(float x, float cw, float bw, float ch, float bh, float d0, float d1,
+                                                  float &y, float &lad) {
+    const float delta = bh * frcp(bw);
+    const float dsum = d0 + d1 - 2.0f * delta;
+    float theta, den;
+    if (!INVERSE) {
+        theta = (x - cw) * frcp(bw);
+        const float t1mt = theta * (1.0f - theta);
+        const float num = bh * (delta * theta * theta + d0 * t1mt);
+        den = delta + dsum * t1mt;
+        y = ch + num * frcp(den);
+    } else {
+        const float dy = x - ch;
+        const float a = dy * dsum + bh * (delta - d0);
+        const float b = bh * d0 - dy * dsum;
+        const float c = -delta * dy;
+        const float disc = b * b - 4.0f * a * c;
+        theta = (2.0f * c) * frcp(-b - fsqrt(disc));
+        y = theta * bw + cw;
+        den = delta + dsum * (theta * (1.0f - theta));
+    }
+    const float omt = 1.0f - theta;
+    const float dnum = delta * delta * (d1 * theta * theta + 2.0f * delta * (theta * omt) + d0 * omt * omt);
+    const float l = flog(dnum) - 2.0f * flog(den);
+    lad = INVERSE ? -l : l;
+}
+
+// ---- spline on register-resident parameters (K = 8, linear tails), static indexing only, branch-free ------
 // prm[0..7] raw widths, prm[8..15] raw heights, prm[16..22] raw derivative logits.
 template <bool INVERSE>
 __device__ __forceinline__ void rqs_regs(const RqsParams<float> &p, float x, const float (&prm)[24], float inv_div,
                                          float &y, float &lad) {
-    if (!(x >= p.left && x <= p.right)) {
-        y = x;
-        lad = 0.0f;
-        return;
-    }
+    const bool inside = x >= p.left && x <= p.right;  // false for NaN (utils/splines.py:28)
     float w[F_K], h[F_K];
 #pragma unroll
     for (int k = 0; k < F_K; ++k) {
@@ -272,20 +316,20 @@ __device__ __forceinline__ void rqs_regs(const RqsParams<float> &p, float x, con
     float sw = 0.0f, sh = 0.0f;
 #pragma unroll
     for (int k = 0; k < F_K; ++k) {
-        w[k] = expf(w[k] - mw);
-        h[k] = expf(h[k] - mh);
+        w[k] = fexp(w[k] - mw);
+        h[k] = fexp(h[k] - mh);
         sw += w[k];
         sh += h[k];
     }
-    const float isw = 1.0f / sw, ish = 1.0f / sh;
+    const float isw = p.scale_w * frcp(sw), ish = p.scale_h * frcp(sh);
     float kw[F_K + 1], kh[F_K + 1];
     kw[0] = p.left;
     kh[0] = p.bottom;
     float cw = 0.0f, ch = 0.0f;
 #pragma unroll
     for (int k = 0; k < F_K; ++k) {
-        cw += p.min_w + p.scale_w * (w[k] * isw);
-        ch += p.min_h + p.scale_h * (h[k] * ish);
+        cw += p.min_w + w[k] * isw;
+        ch += p.min_h + h[k] * ish;
         kw[k + 1] = (k == F_K - 1) ? p.right : (p.right - p.left) * cw + p.left;
         kh[k + 1] = (k == F_K - 1) ? p.top : (p.top - p.bottom) * ch + p.bottom;
     }
@@ -307,15 +351,53 @@ __device__ __forceinline__ void rqs_regs(const RqsParams<float> &p, float x, con
         dl0 = (bin == k + 1) ? prm[2 * F_K + k] : dl0;  // padded logit j = bin  -> raw index bin - 1
         dl1 = (bin == k) ? prm[2 * F_K + k] : dl1;      // padded logit j = bin+1 -> raw index bin
     }
-    const float d0 = p.min_d + softplus(dl0), d1 = p.min_d + softplus(dl1);
+    const float d0 = p.min_d + fsoftplus(dl0), d1 = p.min_d + fsoftplus(dl1);
+    float yy, ll;
     if (!INVERSE)
-        rqs_eval_bin<float>(x, slo, shi - slo, olo, ohi - olo, d0, d1, false, y, lad);
+        rqs_eval_bin_fast<false>(x, slo, shi - slo, olo, ohi - olo, d0, d1, yy, ll);
     else
-        rqs_eval_bin<float>(x, olo, ohi - olo, slo, shi - slo, d0, d1, true, y, lad);
+        rqs_eval_bin_fast<true>(x, olo, ohi - olo, slo, shi - slo, d0, d1, yy, ll);
+    y = inside ? yy : x;       // linear tails: identity outside, also for NaN / +-inf (utils/splines.py:40-41)
+    lad = inside ? ll : 0.0f;
+}
+
+// Batch-shared spline from its LDS knot table (cumw[9] | cumh[9] | deriv[9]), branch-free.
+template <bool INVERSE>
+__device__ __forceinline__ void rqs_table_fast(const RqsParams<float> &p, float x, const float *tab, float &y, float &lad) {
+    const bool inside = x >= p.left && x <= p.right;
+    const float *srch = INVERSE ? tab + (F_K + 1) : tab;
+    int bin = 0;
+#pragma unroll
+    for (int k = 1; k < F_K; ++k) bin = (x >= srch[k]) ? k : bin;
+    const float cw0 = tab[bin], cw1 = tab[bin + 1], ch0 = tab[F_K + 1 + bin], ch1 = tab[F_K + 2 + bin];
+    const float d0 = tab[2 * (F_K + 1) + bin], d1 = tab[2 * (F_K + 1) + bin + 1];
+    float yy, ll;
+    rqs_eval_bin_fast<INVERSE>(x, cw0, cw1 - cw0, ch0, ch1 - ch0, d0, d1, yy, ll);
+    y = inside ? yy : x;
+    lad = inside ? ll : 0.0f;
 }
 
 // ---- the fused layer kernel -----------------------------------------------------------------------------------
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// Ask the scheduler to lay a region out as 16 x { 1 LDS read, 4 x { 1 MFMA, NF_PIPE_VALU VALU } }.
+#ifndef NF_PIPE_VALU
+#define NF_PIPE_VALU 10
+#endif
+#ifndef NF_USE_SCHED_PIPE
+#define NF_SCHED_PIPE() do {} while (0)
+#else
+#define NF_SCHED_PIPE()                                                        \
+    do {                                                                       \
+        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                    \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                 \
+            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                 \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             \
+                __builtin_amdgcn_sched_group_barrier(0x002, NF_PIPE_VALU, 0);  \
+            }                                                                  \
+        }                                                                      \
+    } while (0)
+#endif
 
 __device__ __forceinline__ f32x16 load_bias16(const float *src) {
     const f32x4 a = *reinterpret_cast<const f32x4 *>(src), b = *reinterpret_cast<const f32x4 *>(src + 4),
@@ -340,7 +422,9 @@ __device__ __forceinline__ void mm128(const float *buf, int lane, f32x16 &acc, c
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float bv = bs[4 * (s & 3) + r];
+#ifndef NF_ABL_NORELU
             if (RELU) bv = fmaxf(bv, 0.0f);
+#endif
             acc = MFMA(a[r], bv, acc);
         }
     }
@@ -373,7 +457,8 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     float *ring = smem;                       // 2 x 4096
     float *stash = ring + 2 * F_STAGE;        // 4 waves x 32 x 64
     float *small = stash + 4 * 32 * 64;       // biases + tables
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases are wave-uniform
     const int64_t row = (int64_t)blockIdx.x * 128 + wid * 32 + (lane & 31);
     const bool valid = row < B;
     const int par_i = par_t ^ 1;
@@ -399,7 +484,9 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     };
     auto acquire = [&]() -> const float * {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef NF_ABL_NOBAR
         __syncthreads();
+#endif
         if (stage + 1 < nstages) issue(stage + 1);
         const float *buf = ring + (stage & 1) * F_STAGE;
         ++stage;
@@ -444,6 +531,8 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     }
 
     // ---- unconditional spline on the identity half (nsf/coupling.py:88-92 density / :112-116 sample) ----
+    // sample: CDF^-1 first, its output feeds the conditioner.  density: the conditioner sees the raw values; the CDF
+    // itself is evaluated later in the shadow of the final layer's MFMAs (uncond_pair below).
     float bx[16];
     {
         const float *tabs = small + lay.off_tables();
@@ -454,11 +543,15 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
                 const int c = 8 * Q + 2 * r + par_i;
                 const int f = 8 * Q + 4 * hh + r;  // identity feature index
                 const float xi = st[c * 64];
-                float yi, l;
-                rqs_eval_table<float>(p, xi, tabs + f * F_TABW, DIR == 1, yi, l);
-                st[c * 64] = yi;
-                ld += l;
-                bx[4 * Q + r] = DIR == 0 ? xi : yi;  // conditioner input: raw (density) / transformed (sample)
+                if (DIR == 1) {
+                    float yi, l;
+                    rqs_table_fast<true>(p, xi, tabs + f * F_TABW, yi, l);
+                    st[c * 64] = yi;
+                    ld += l;
+                    bx[4 * Q + r] = yi;
+                } else {
+                    bx[4 * Q + r] = xi;
+                }
             }
     }
 
@@ -511,35 +604,74 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     }
 
     // ---- final layer in 8 groups of 3 row-blocks; each group yields the parameters of 2 spline elements ----
-    for (int g = 0; g < 8; ++g) {
-        const float *bsrc = small + lay.off_bias_final() + (g * 3) * 32 + hh * 16;
-        f32x16 A0 = load_bias16(bsrc), A1 = load_bias16(bsrc + 32), A2 = load_bias16(bsrc + 64);
-        mm128<false>(acquire(), lane, A0, H0, H1, H2, H3);
-        mm128<false>(acquire(), lane, A1, H0, H1, H2, H3);
-        mm128<false>(acquire(), lane, A2, H0, H1, H2, H3);
+    // Software pipeline: the spline evaluations of group g-1 (pure VALU work on registers) are placed in the same
+    // scheduling regions as the 3 x 64 MFMAs of group g, so that they issue in the shadow of the 64-cycle MFMAs
+    // instead of leaving the matrix pipe idle (ablation: epilogue + unconditional splines exposed = 22 % of the
+    // kernel).  Region 1: element 0, region 2: element 1, region 3: two unconditional-spline elements (density).
+    float prm0[24], prm1[24];
+    auto extract = [&](const f32x16 &A0, const f32x16 &A1, const f32x16 &A2) {
         // lane's parameter list v = 16 rb + reg: feature f = v / 24, parameter v % 24
-        float prm0[24], prm1[24];
 #pragma unroll
         for (int v = 0; v < 24; ++v) {
             prm0[v] = v < 16 ? A0[v] : A1[v - 16];
             prm1[v] = (v + 24) < 32 ? A1[v + 24 - 16] : A2[v + 24 - 32];
         }
-        const int cbase = 8 * (g >> 1) + 4 * (g & 1) + par_t;  // stash slot of feature f = 0; f = 1 is +2
-        {
-            const float xt = st[cbase * 64];
-            float yt, l;
-            rqs_regs<DIR == 1>(p, xt, prm0, inv_div, yt, l);
-            st[cbase * 64] = yt;
+    };
+    auto element = [&](int g, int f, const float (&prm)[24]) {
+        const int slot = 8 * (g >> 1) + 4 * (g & 1) + par_t + 2 * f;
+        const float xt = st[slot * 64];
+        float yt, l;
+        rqs_regs<DIR == 1>(p, xt, prm, inv_div, yt, l);
+        st[slot * 64] = yt;
+        ld += l;
+    };
+    auto uncond_pair = [&](int g) {  // density only: identity slots of chunk Q = g >> 1, r = 2 (g & 1) + {0, 1}
+        const float *tabs = small + lay.off_tables();
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int r = 2 * (g & 1) + e;
+            const int c = 8 * (g >> 1) + 2 * r + par_i;
+            const int f = 8 * (g >> 1) + 4 * hh + r;
+            float yi, l;
+            rqs_table_fast<false>(p, st[c * 64], tabs + f * F_TABW, yi, l);
+            st[c * 64] = yi;
             ld += l;
         }
-        {
-            const float xt = st[(cbase + 2) * 64];
-            float yt, l;
-            rqs_regs<DIR == 1>(p, xt, prm1, inv_div, yt, l);
-            st[(cbase + 2) * 64] = yt;
-            ld += l;
-        }
+    };
+    {   // group 0: MFMAs only
+        const float *bsrc = small + lay.off_bias_final() + hh * 16;
+        f32x16 A0 = load_bias16(bsrc), A1 = load_bias16(bsrc + 32), A2 = load_bias16(bsrc + 64);
+        mm128<false>(acquire(), lane, A0, H0, H1, H2, H3);
+        mm128<false>(acquire(), lane, A1, H0, H1, H2, H3);
+        mm128<false>(acquire(), lane, A2, H0, H1, H2, H3);
+        extract(A0, A1, A2);
     }
+    for (int g = 1; g < 8; ++g) {
+        const float *bsrc = small + lay.off_bias_final() + (g * 3) * 32 + hh * 16;
+        f32x16 A0 = load_bias16(bsrc), A1 = load_bias16(bsrc + 32), A2 = load_bias16(bsrc + 64);
+        {
+            const float *buf = acquire();
+            mm128<false>(buf, lane, A0, H0, H1, H2, H3);
+            element(g - 1, 0, prm0);
+            NF_SCHED_PIPE();
+        }
+        {
+            const float *buf = acquire();
+            mm128<false>(buf, lane, A1, H0, H1, H2, H3);
+            element(g - 1, 1, prm1);
+            NF_SCHED_PIPE();
+        }
+        {
+            const float *buf = acquire();
+            mm128<false>(buf, lane, A2, H0, H1, H2, H3);
+            if (DIR == 0) uncond_pair(g - 1);
+            NF_SCHED_PIPE();
+        }
+        extract(A0, A1, A2);
+    }
+    element(7, 0, prm0);
+    element(7, 1, prm1);
+    if (DIR == 0) uncond_pair(7);
 
     // ---- epilogue: rows back to HBM, per-sample log-det (both lane halves of a sample) ----
     ld += __shfl_xor(ld, 32, 64);

@@ -436,7 +436,7 @@ def test_fused_layer_vs_unfused_and_oracle(nfa, oracle, reverse_mask, B):
                                                      reverse_mask=reverse_mask)
     with torch.no_grad():
         for p_ in layer.parameters():
-            p_.add_(0.2 * torch.randn_like(p_))
+            p_.add_(0.04 * torch.randn_like(p_))   # larger steps blow the hidden activations up (128-wide sums)
         u = layer.prqct.unconditional_transform
         u.unnormalized_widths.normal_()
         u.unnormalized_heights.normal_()

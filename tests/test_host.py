@@ -1,0 +1,196 @@
+"""CPU-side tests (run here without a GPU): the C-ABI library loads and exports every declared symbol, argument
+validation of the C ABI (no compute), host logic (masks, state_dict compatibility with the reference, pair
+scheduling), the fail-loud behaviour without a HIP device, and the data-parallel path under gloo (world_size 2)."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden_state, load_golden
+
+REF = "/root/reference"
+
+
+@pytest.fixture(scope="module")
+def nfa():
+    import __graft_entry__
+    import normflows_amd
+    if not os.path.exists(normflows_amd.native_library_path()):
+        __graft_entry__.build()
+    return normflows_amd
+
+
+def test_library_loads_and_exports_every_declared_symbol(nfa):
+    lib = nfa._lib.lib()
+    declared = nfa._lib.exported_symbols_declared()
+    assert len(declared) >= 18
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert b"gfx950" in lib.nf_version()
+    assert lib.nf_max_bins() >= 16
+    assert lib.nf_strerror(-22) == b"invalid argument"
+
+
+def test_c_abi_argument_validation_without_gpu(nfa):
+    """Bad arguments are rejected before any launch (errno-style codes)."""
+    lib = nfa._lib.lib()
+    i32, i64, f64, vp = ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
+    null = vp(0)
+    one = vp(16)  # never dereferenced on the host
+    # utils/splines.py:121-124: min_bin_width * K > 1 -> ValueError (EINVAL)
+    rc = lib.nf_rqs_spline(one, one, i64(8), one, i64(8), one, i64(7), one, one, i64(4), i32(8), i32(1), f64(3.0), f64(0),
+                           f64(1), f64(0), f64(1), f64(0.2), f64(1e-3), f64(1e-3), f64(1.0), i32(0), i32(0), null)
+    assert rc == -22
+    # K beyond the compiled range -> ERANGE
+    rc = lib.nf_rqs_spline(one, one, i64(8), one, i64(8), one, i64(7), one, one, i64(4), i32(1000), i32(1), f64(3.0),
+                           f64(0), f64(1), f64(0), f64(1), f64(1e-5), f64(1e-5), f64(1e-3), f64(1.0), i32(0), i32(0), null)
+    assert rc == -34
+    # null buffer -> EFAULT
+    rc = lib.nf_lu_linear_permute(null, one, one, one, one, one, one, one, i64(4), i32(4), f64(1e-3), i32(0), i32(0),
+                                  i32(0), null)
+    assert rc == -14
+    # unknown dtype -> ENOTSUP ; bad direction -> EINVAL ; empty batch -> OK without touching pointers
+    assert lib.nf_masked_affine(one, one, null, null, one, one, i64(4), i64(2), i32(0), i32(0), i32(7), null) == -95
+    assert lib.nf_masked_affine(one, one, null, null, one, one, i64(4), i64(2), i32(3), i32(0), i32(0), null) == -22
+    assert lib.nf_masked_affine(null, null, null, null, null, null, i64(0), i64(2), i32(0), i32(0), i32(0), null) == 0
+    # fused kernel only takes the benchmark shape
+    lib.nf_rqs_fused_pack_size.restype = ctypes.c_int64
+    assert lib.nf_rqs_fused_pack_size(i32(32), i32(32), i32(128), i32(2), i32(8)) > 600 * 1024
+    assert lib.nf_rqs_fused_pack_size(i32(8), i32(8), i32(32), i32(2), i32(8)) == -95
+
+
+def test_masks_bit_exact(nfa):
+    m = nfa.utils.create_alternating_binary_mask(7, even=False)
+    assert m.dtype == torch.uint8 and m.tolist() == [0, 1, 0, 1, 0, 1, 0]
+    assert nfa.utils.create_alternating_binary_mask(4, even=True).tolist() == [1, 0, 1, 0]
+    assert nfa.utils.create_mid_split_binary_mask(5).tolist() == [1, 1, 1, 0, 0]
+    a = nfa.utils.create_random_binary_mask(9, seed=3)
+    b = nfa.utils.create_random_binary_mask(9, seed=3)
+    assert torch.equal(a, b) and int(a.sum()) == 5
+
+
+def test_layers_refuse_cpu_tensors(nfa):
+    for layer, z in ((nfa.flows.LULinearPermute(4), torch.randn(3, 4)),
+                     (nfa.flows.CoupledRationalQuadraticSpline(4, 1, 8), torch.randn(3, 4)),
+                     (nfa.flows.ActNorm(4), torch.randn(3, 4)),
+                     (nfa.flows.Invertible1x1Conv(4, True), torch.randn(2, 4, 3, 3)),
+                     (nfa.flows.MaskedAffineFlow(torch.tensor([1.0, 0.0, 1.0, 0.0])), torch.randn(3, 4))):
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            layer.inverse(z)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        nfa.distributions.DiagGaussian(4).log_prob(torch.randn(3, 4))
+
+
+def test_missing_library_fails_loudly(nfa, tmp_path, monkeypatch):
+    monkeypatch.setattr(nfa._lib, "_lib", None)
+    monkeypatch.setattr(nfa._lib, "LIBPATH", str(tmp_path / "nope.so"))
+    with pytest.raises(nfa._lib.NativeLibraryError, match="no CPU or eager fallback"):
+        nfa._lib.lib()
+
+
+def test_golden_state_dicts_load_strict(nfa):
+    """Reference checkpoints (state_dict = the on-disk format, core.py:199-213) load with strict=True."""
+    g = load_golden("model_c2mini")
+    from bench import build_c2_model
+    m = build_c2_model(num_layers=4, dim=16, hidden=32, seed=0, sigma=0.05)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in golden_state(g).items()}, strict=True)
+    g = load_golden("glowblock_C4_channel")
+    blk = nfa.flows.GlowBlock(4, 8, split_mode="channel", use_lu=True, init_zeros=False)
+    blk.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in golden_state(g, "sd0__").items()}, strict=True)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout only exists in the build container")
+def test_seeded_construction_is_bit_identical_to_reference(nfa):
+    """Same constructor calls under the same seed give bit-identical parameters, permutations and masks
+    (the bench model is reproduced on the GPU box without shipping 21.8 MB of weights)."""
+    sys.path.insert(0, REF)
+    import normflows as nf
+    from bench import build_c2_model
+    a = build_c2_model(num_layers=3, lib=nf).state_dict()
+    b = build_c2_model(num_layers=3, lib=nfa).state_dict()
+    assert list(a.keys()) == list(b.keys())
+    for k in a:
+        assert a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]), k
+    torch.manual_seed(3)
+    ga = nf.flows.GlowBlock(12, 16, use_lu=True)
+    torch.manual_seed(3)
+    gb = nfa.flows.GlowBlock(12, 16, use_lu=True)
+    sa, sb = ga.state_dict(), gb.state_dict()
+    assert list(sa.keys()) == list(sb.keys()) and all(torch.equal(sa[k], sb[k]) for k in sa)
+    # both directions of strict loading
+    gb.load_state_dict(sa, strict=True)
+    ga.load_state_dict(sb, strict=True)
+
+
+def test_pair_scheduler_orders(nfa, monkeypatch):
+    """run_chain visits [CoupledRQS, LULinearPermute] pairs in the reference's order (core.py:177-179, 193-195)."""
+    from normflows_amd import core
+    calls = []
+
+    class Fake(nfa.flows.Flow):
+        def __init__(self, name):
+            super().__init__()
+            self.name = name
+
+        def _run(self, z, inverse, ld, acc, **kw):
+            calls.append((self.name, inverse))
+            return z
+
+    flows = [Fake("a"), Fake("b"), Fake("c")]
+    ld = torch.zeros(2)
+    core.run_chain(flows, torch.zeros(2, 3), True, ld, +1)
+    assert calls == [("c", True), ("b", True), ("a", True)]
+    calls.clear()
+    core.run_chain(flows, torch.zeros(2, 3), False, ld, -1)
+    assert calls == [("a", False), ("b", False), ("c", False)]
+
+
+def test_dp_shard_bounds(nfa):
+    from normflows_amd import dp
+    for n, w in ((10, 3), (524288, 8), (5, 8), (0, 2)):
+        spans = [dp.shard_bounds(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+_DP_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["NF_ROOT"]); sys.path.insert(0, os.path.join(os.environ["NF_ROOT"], "oracle"))
+import numpy as np, torch, torch.distributed as dist
+import normflows_amd as nfa, nf_oracle
+from bench import build_c2_model, state_to_numpy
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+m = build_c2_model(num_layers=2, dim=8, hidden=16, seed=0, sigma=0.05)
+ora = nf_oracle.OracleNSF(state_to_numpy(m), num_layers=4)
+g = torch.Generator().manual_seed(99)
+x = torch.randn(37, 8, generator=g)                       # same global batch on every rank
+log_prob = lambda t: torch.from_numpy(ora.log_prob(t.numpy()))   # CPU stand-in for the HIP log_prob (tests only)
+local = nfa.dp.shard_rows(x)
+nll = nfa.dp.sharded_forward_kld(log_prob, local)
+full = -log_prob(x).double().mean()
+assert abs(float(nll) - float(full)) < 1e-6, (float(nll), float(full))
+lo, hi = nfa.dp.shard_bounds(37, world, rank)
+assert local.shape[0] == hi - lo
+if rank == 0:
+    print("DP_OK", float(nll))
+dist.destroy_process_group()
+"""
+
+
+def test_dp_nll_matches_unsharded_under_gloo(nfa, tmp_path):
+    """world_size 2, gloo: the row-sharded NLL (one all-reduce of [sum log_q, n]) equals the unsharded NLL."""
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_DP_WORKER)
+    env = dict(os.environ, NF_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29671", str(script)], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "DP_OK" in out.stdout
