@@ -130,6 +130,23 @@ def kernel_breakdown(model, x, reps=5):
     return out
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+    (profiles/*_pmc.json, produced by tools/summarize_profiles.py: FETCH_SIZE and WRITE_SIZE collected in separate
+    passes, KB -> bytes, FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM).  None when no summary is present;
+    counters cannot be read from inside the timed process."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    for path in reversed(cands):
+        try:
+            d = json.load(open(path))
+            if "rqs_fused" in d.get("kernel", "") and "hbm_traffic_bytes" in d.get("derived", {}):
+                return d["derived"]["hbm_traffic_bytes"]
+        except Exception:
+            pass
+    return None
+
+
 def cpu_baseline(model, rows):
     """The CPU oracle (a port of the reference algorithm, OpenMP over rows) timed on this host on a bounded sample
     of the same workload: log_prob of the same 32-layer model on `rows` benchmark rows."""
@@ -233,7 +250,7 @@ def main():
                 fl = (c2_flops_per_sample(layers=1)) * args.batch
                 ach = fl / (pair_ms * 1e-3) / 1e12
                 out["roofline"] = {"kernel": "nf::rqs_fused_kernel<0, true>", "bound": "mfma", "achieved": ach,
-                                   "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,
+                                   "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": pmc_traffic(),
                                    "flop_per_launch": fl, "avg_launch_ms": pair_ms,
                                    "hbm_algorithmic_bytes_per_launch": (2 * DIM * 4 + 8) * args.batch}
         if not args.no_cpu_baseline and world == 1:
