@@ -148,20 +148,33 @@ def pmc_traffic():
 
 
 def cpu_baseline(model, rows):
-    """The CPU oracle (a port of the reference algorithm, OpenMP over rows) timed on this host on a bounded sample
-    of the same workload: log_prob of the same 32-layer model on `rows` benchmark rows."""
+    """The CPU oracle (a port of the reference algorithm) timed on this host on a bounded sample of the same workload:
+    log_prob of the same 32-layer model on `rows` benchmark rows.  Rows are split into one chunk per hardware thread
+    and every chunk runs the whole 64-layer chain on its own thread (ctypes releases the GIL; OpenMP inside the
+    library is pinned to 1 thread), which scales far better than 64 x N small parallel regions."""
+    import concurrent.futures as cf
+    import ctypes
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nf_oracle
     ora = nf_oracle.OracleNSF(state_to_numpy(model), num_layers=len(model.flows), K=BINS, tail_bound=3.0)
     x = c2_inputs(rows, DIM).numpy()
-    ora.log_prob(x[: min(rows, 256)])  # warm-up (page in, thread pool)
-    t0 = time.perf_counter()
-    lp = ora.log_prob(x)
-    dt = time.perf_counter() - t0
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    return {"value": rows / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "log_prob of the same %d-layer model on %d rows (oracle/nf_oracle.c, OpenMP, %.1f s)"
-                      % (len(model.flows) // 2, rows, dt), "nll_nats_per_dim": float(-lp.mean() / DIM)}
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(1)
+    except OSError:
+        pass
+    nchunks = max(1, min(cores, rows // 32))
+    bounds = [(rows * i // nchunks, rows * (i + 1) // nchunks) for i in range(nchunks)]
+    ora.log_prob(x[:64])  # warm-up
+    with cf.ThreadPoolExecutor(max_workers=nchunks) as pool:
+        t0 = time.perf_counter()
+        parts = list(pool.map(lambda b: ora.log_prob(x[b[0]:b[1]]), bounds))
+        dt = time.perf_counter() - t0
+    import numpy as np
+    lp = np.concatenate(parts)
+    return {"value": rows / dt, "unit": "samples/s", "cores": nchunks, "kind": "port",
+            "sample": "log_prob of the same %d-layer model on %d rows (oracle/nf_oracle.c, %d threads x row chunks, %.1f s)"
+                      % (len(model.flows) // 2, rows, nchunks, dt), "nll_nats_per_dim": float(-lp.mean() / DIM)}
 
 
 def main():
@@ -174,7 +187,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=16384, help="rows of the same workload timed on the host oracle")
+    ap.add_argument("--cpu-rows", type=int, default=65536, help="rows of the same workload timed on the host oracle")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -253,6 +266,20 @@ def main():
                                    "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": pmc_traffic(),
                                    "flop_per_launch": fl, "avg_launch_ms": pair_ms,
                                    "hbm_algorithmic_bytes_per_launch": (2 * DIM * 4 + 8) * args.batch}
+        if not args.no_breakdown:
+            # secondary (SURVEY.md 8d reports both directions): generative pass = every layer's forward + log_q
+            g = torch.Generator().manual_seed(4321)
+            eps = torch.randn(args.batch, DIM, generator=g).to(dev)
+            with torch.no_grad():
+                for _ in range(2):
+                    model.sample_from_noise(eps)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(max(args.steps // 2, 3)):
+                    xs, lq = model.sample_from_noise(eps)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / max(args.steps // 2, 3)
+            out["sample_direction"] = {"value": args.batch / dt, "unit": "samples/s", "ms_per_step": 1e3 * dt}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, args.cpu_rows)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

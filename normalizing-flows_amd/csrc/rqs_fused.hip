@@ -111,20 +111,25 @@ __global__ void pack_hidden_kernel(const float *__restrict__ W /*128x128*/, cons
     }
 }
 
+// Rows holding unnormalised widths / heights are pre-multiplied by wh_scale = log2(e) / sqrt(hidden): the division of
+// nsf/coupling.py:334-339 and the exp -> exp2 conversion of the softmax cost nothing in the epilogue.
 __global__ void pack_final_kernel(const float *__restrict__ W /*736x128*/, const float *__restrict__ b,
-                                  float *__restrict__ stages /*24 stages*/, float *__restrict__ bias_dst) {
+                                  float *__restrict__ stages /*24 stages*/, float *__restrict__ bias_dst,
+                                  float wh_scale) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 24 * F_STAGE; i += gridDim.x * blockDim.x) {
         const int r4 = i & 3, lane = (i >> 2) & 63, s = (i >> 8) & 15, st = i >> 12;
         const int g = st / 3, rb = st % 3;
         const int row = final_row(g, rb, lane & 31);
         const int k = 8 * s + 4 * (lane >> 5) + r4;
-        stages[i] = row >= 0 ? W[row * F_H + k] : 0.0f;
+        const float sc = (row >= 0 && (row % F_M) < 2 * F_K) ? wh_scale : 1.0f;
+        stages[i] = row >= 0 ? W[row * F_H + k] * sc : 0.0f;
     }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 768; i += gridDim.x * blockDim.x) {
         const int reg = i & 15, hh = (i >> 4) & 1, st = i >> 5;
         const int g = st / 3, rb = st % 3;
         const int row = final_row(g, rb, 8 * (reg >> 2) + 4 * hh + (reg & 3));
-        bias_dst[i] = row >= 0 ? b[row] : 0.0f;
+        const float sc = (row >= 0 && (row % F_M) < 2 * F_K) ? wh_scale : 1.0f;
+        bias_dst[i] = row >= 0 ? b[row] * sc : 0.0f;
     }
 }
 
@@ -298,40 +303,35 @@ __device__ __forceinline__ void rqs_eval_bin_fast(float x, float cw, float bw, f
 // ---- spline on register-resident parameters (K = 8, linear tails), static indexing only, branch-free ------
 // prm[0..7] raw widths, prm[8..15] raw heights, prm[16..22] raw derivative logits.
 template <bool INVERSE>
-__device__ __forceinline__ void rqs_regs(const RqsParams<float> &p, float x, const float (&prm)[24], float inv_div,
-                                         float &y, float &lad) {
+__device__ __forceinline__ void rqs_regs(const RqsParams<float> &p, float x, const float (&prm)[24], float &y,
+                                         float &lad) {
+    // prm[0..7] / prm[8..15] arrive pre-multiplied by log2(e)/sqrt(hidden) (pack_final_kernel): softmax = exp2(. - max)/sum.
     const bool inside = x >= p.left && x <= p.right;  // false for NaN (utils/splines.py:28)
-    float w[F_K], h[F_K];
-#pragma unroll
-    for (int k = 0; k < F_K; ++k) {
-        w[k] = prm[k] * inv_div;
-        h[k] = prm[F_K + k] * inv_div;
-    }
-    float mw = w[0], mh = h[0];
+    float mw = prm[0], mh = prm[F_K];
 #pragma unroll
     for (int k = 1; k < F_K; ++k) {
-        mw = fmaxf(mw, w[k]);
-        mh = fmaxf(mh, h[k]);
+        mw = fmaxf(mw, prm[k]);
+        mh = fmaxf(mh, prm[F_K + k]);
     }
-    float sw = 0.0f, sh = 0.0f;
+    // inclusive prefix sums of the un-normalised softmax terms; knot_k = lo + (hi - lo) (k min + scale P_{k-1} / P_7)
+    float pw[F_K], ph[F_K];
 #pragma unroll
     for (int k = 0; k < F_K; ++k) {
-        w[k] = fexp(w[k] - mw);
-        h[k] = fexp(h[k] - mh);
-        sw += w[k];
-        sh += h[k];
+        const float ew = __builtin_amdgcn_exp2f(prm[k] - mw), eh = __builtin_amdgcn_exp2f(prm[F_K + k] - mh);
+        pw[k] = k == 0 ? ew : pw[k - 1] + ew;
+        ph[k] = k == 0 ? eh : ph[k - 1] + eh;
     }
-    const float isw = p.scale_w * frcp(sw), ish = p.scale_h * frcp(sh);
+    const float cw = (p.right - p.left) * p.scale_w * frcp(pw[F_K - 1]);
+    const float ch = (p.top - p.bottom) * p.scale_h * frcp(ph[F_K - 1]);
     float kw[F_K + 1], kh[F_K + 1];
     kw[0] = p.left;
     kh[0] = p.bottom;
-    float cw = 0.0f, ch = 0.0f;
+    kw[F_K] = p.right;
+    kh[F_K] = p.top;
 #pragma unroll
-    for (int k = 0; k < F_K; ++k) {
-        cw += p.min_w + w[k] * isw;
-        ch += p.min_h + h[k] * ish;
-        kw[k + 1] = (k == F_K - 1) ? p.right : (p.right - p.left) * cw + p.left;
-        kh[k + 1] = (k == F_K - 1) ? p.top : (p.top - p.bottom) * ch + p.bottom;
+    for (int k = 1; k < F_K; ++k) {
+        kw[k] = fmaf(pw[k - 1], cw, p.left + (p.right - p.left) * p.min_w * (float)k);
+        kh[k] = fmaf(ph[k - 1], ch, p.bottom + (p.top - p.bottom) * p.min_h * (float)k);
     }
     int bin = 0;
     float slo = INVERSE ? kh[0] : kw[0], shi = INVERSE ? kh[1] : kw[1];
@@ -380,22 +380,21 @@ __device__ __forceinline__ void rqs_table_fast(const RqsParams<float> &p, float 
 // ---- the fused layer kernel -----------------------------------------------------------------------------------
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-// Ask the scheduler to lay a region out as 16 x { 1 LDS read, 4 x { 1 MFMA, NF_PIPE_VALU VALU } }.
+// Ask the scheduler to lay a region out as 64 x { 1 MFMA, NF_PIPE_VALU VALU/transcendental instructions }: the
+// default (bottom-up) list scheduler clusters the epilogue at ~15 VALU per MFMA behind the last third of the region's
+// MFMAs, which overflows the 64-cycle MFMA shadow when both waves of a SIMD are in that phase.
 #ifndef NF_PIPE_VALU
-#define NF_PIPE_VALU 10
+#define NF_PIPE_VALU 5
 #endif
-#ifndef NF_USE_SCHED_PIPE
+#ifndef NF_USE_SCHED_PIPE  /* measured: no gain over the default schedule (tools/fused_ablate.py) */
 #define NF_SCHED_PIPE() do {} while (0)
 #else
-#define NF_SCHED_PIPE()                                                        \
-    do {                                                                       \
-        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                    \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                 \
-            _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                 \
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             \
-                __builtin_amdgcn_sched_group_barrier(0x002, NF_PIPE_VALU, 0);  \
-            }                                                                  \
-        }                                                                      \
+#define NF_SCHED_PIPE()                                                         \
+    do {                                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 64; ++i_) {                     \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  \
+            __builtin_amdgcn_sched_group_barrier(0x402, NF_PIPE_VALU, 0);       \
+        }                                                                       \
     } while (0)
 #endif
 
@@ -415,9 +414,21 @@ __device__ __forceinline__ f32x16 load_bias16(const float *src) {
 template <bool RELU>
 __device__ __forceinline__ void mm128(const float *buf, int lane, f32x16 &acc, const f32x16 &b0, const f32x16 &b1,
                                       const f32x16 &b2, const f32x16 &b3) {
+#ifdef NF_EXP_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
+#ifdef NF_EXP_PREFETCH
+    // A operand one k-group ahead of its use
+    f32x4 a_next = *reinterpret_cast<const f32x4 *>(buf + lane * 4);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const f32x4 a = a_next;
+        if (s + 1 < 16) a_next = *reinterpret_cast<const f32x4 *>(buf + (s + 1) * 256 + lane * 4);
+#else
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         const f32x4 a = *reinterpret_cast<const f32x4 *>(buf + s * 256 + lane * 4);
+#endif
         const f32x16 &bs = (s >> 2) == 0 ? b0 : ((s >> 2) == 1 ? b1 : ((s >> 2) == 2 ? b2 : b3));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -428,6 +439,9 @@ __device__ __forceinline__ void mm128(const float *buf, int lane, f32x16 &acc, c
             acc = MFMA(a[r], bv, acc);
         }
     }
+#ifdef NF_EXP_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 // 2 row-blocks x 8 k-groups of the composed 64 x 64 LU matrix: out[slot 16 m + reg] = bias + sum_k W[.][k] xin[k-slot]
@@ -597,10 +611,25 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
             H2 += load_bias16(bsrc + 64);
             H3 += load_bias16(bsrc + 96);
         }
+#ifdef NF_EXP_RELU_PER_USE
         mm128<true>(acquire(), lane, H0, T0, T1, T2, T3);
         mm128<true>(acquire(), lane, H1, T0, T1, T2, T3);
         mm128<true>(acquire(), lane, H2, T0, T1, T2, T3);
         mm128<true>(acquire(), lane, H3, T0, T1, T2, T3);
+#else
+        // T is dead after this linear: ReLU it once in place (64 v_max) instead of once per use (256)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            T0[c] = fmaxf(T0[c], 0.0f);
+            T1[c] = fmaxf(T1[c], 0.0f);
+            T2[c] = fmaxf(T2[c], 0.0f);
+            T3[c] = fmaxf(T3[c], 0.0f);
+        }
+        mm128<false>(acquire(), lane, H0, T0, T1, T2, T3);
+        mm128<false>(acquire(), lane, H1, T0, T1, T2, T3);
+        mm128<false>(acquire(), lane, H2, T0, T1, T2, T3);
+        mm128<false>(acquire(), lane, H3, T0, T1, T2, T3);
+#endif
     }
 
     // ---- final layer in 8 groups of 3 row-blocks; each group yields the parameters of 2 spline elements ----
@@ -618,14 +647,22 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
         }
     };
     auto element = [&](int g, int f, const float (&prm)[24]) {
+#ifdef NF_ABL_NOEPI
+#pragma unroll
+        for (int v = 0; v < 24; ++v) asm volatile("" ::"v"(prm[v]));
+        return;
+#endif
         const int slot = 8 * (g >> 1) + 4 * (g & 1) + par_t + 2 * f;
         const float xt = st[slot * 64];
         float yt, l;
-        rqs_regs<DIR == 1>(p, xt, prm, inv_div, yt, l);
+        rqs_regs<DIR == 1>(p, xt, prm, yt, l);
         st[slot * 64] = yt;
         ld += l;
     };
     auto uncond_pair = [&](int g) {  // density only: identity slots of chunk Q = g >> 1, r = 2 (g & 1) + {0, 1}
+#ifdef NF_ABL_NOUNCOND
+        return;
+#endif
         const float *tabs = small + lay.off_tables();
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -743,7 +780,8 @@ extern "C" int nf_rqs_fused_pack(void *wpack, const void *w_init, const void *b_
                            small + lay.off_bias_hidden(l));
     }
     hipLaunchKernelGGL(pack_final_kernel, dim3(384), dim3(256), 0, st, (const float *)w_final, (const float *)b_final,
-                       stages + (size_t)(1 + 8 * num_blocks) * F_STAGE, small + lay.off_bias_final());
+                       stages + (size_t)(1 + 8 * num_blocks) * F_STAGE, small + lay.off_bias_final(),
+                       (float)(1.4426950408889634 / sqrt((double)hidden)));
     auto p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
                                     min_derivative, 1.0);
     hipLaunchKernelGGL(pack_tables_kernel, dim3(1), dim3(64), 0, st, (const float *)uw, (const float *)uh,

@@ -89,25 +89,29 @@ rqs_coupling_kernel(const T *__restrict__ x, T *__restrict__ y, T *__restrict__ 
                 s_y[i] = v;  // columns this mode does not own are re-written unchanged only if owned below
             }
         }
-        // ---- stage conditioner rows (contiguous ts*nT*M), divide w/h by sqrt(hidden) once ----
+        // ---- stage conditioner rows (contiguous ts*nT*M) into rows of pitch Mp (odd => conflict-free walks) ----
         if (do_t) {
             const T *src = cond + b0 * (int64_t)nT * M;
             const int n = ts * nT * M;
-            const T div = p.wh_div;
-            for (int i = tid; i < n; i += nth) {
-                const int row = i / M, col = i - row * M;
-                T v = src[i];
-                if (col < 2 * K) v = v / div;
-                s_cond[(size_t)row * Mp + col] = v;
+            if (Mp == M) {
+                for (int i = tid; i < n; i += nth) s_cond[i] = src[i];  // straight coalesced copy
+            } else {
+                const float invM = 1.0f / (float)M;
+                for (int i = tid; i < n; i += nth) {
+                    const int row = (int)(((float)i + 0.5f) * invM);  // exact for i < 2^22 / M
+                    s_cond[(size_t)row * Mp + (i - row * M)] = src[i];
+                }
             }
         }
         __syncthreads();
         // ---- transform features: per-element parameters ----
         if (do_t) {
             const int n = ts * nT;
+            const T div = p.wh_div;
             for (int e = tid; e < n; e += nth) {
                 const int s = e / nT, j = e - s * nT;
-                const T *row = s_cond + (size_t)e * Mp;
+                T *row = s_cond + (size_t)e * Mp;
+                for (int k = 0; k < 2 * K; ++k) row[k] = row[k] / div;  // nsf/coupling.py:334-339, once per value
                 auto wacc = [=](int k) { return row[k]; };
                 auto hacc = [=](int k) { return row[K + k]; };
                 auto dacc = [=](int k) { return row[2 * K + k]; };
@@ -143,13 +147,18 @@ rqs_coupling_kernel(const T *__restrict__ x, T *__restrict__ y, T *__restrict__ 
                 y[(b0 + s) * D + own[j]] = s_y[s * D + own[j]];
             }
         }
-        for (int s = tid; s < ts; s += nth) {
-            T sum_t = T(0), sum_i = T(0);
-            if (do_t)
-                for (int j = 0; j < nT; ++j) sum_t += s_lad[s * (nT + nI) + j];
-            if (do_i)
-                for (int j = 0; j < nI; ++j) sum_i += s_lad[s * (nT + nI) + nT + j];
-            ld_store(logdet + b0 + s, sum_t + sum_i, acc);
+        {   // per-sample log-det: one wave per sample, lanes stride over the row, fixed-order wave reduction
+            const int lane = tid & 63, wv = tid >> 6, nwv = nth >> 6;
+            for (int s = wv; s < ts; s += nwv) {
+                T a = T(0);
+                const T *row = s_lad + s * (nT + nI);
+                if (do_t)
+                    for (int j = lane; j < nT; j += 64) a += row[j];
+                if (do_i)
+                    for (int j = lane; j < nI; j += 64) a += row[nT + j];
+                a = wave_sum(a);
+                if (lane == 0) ld_store(logdet + b0 + s, a, acc);
+            }
         }
         __syncthreads();
     }

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Times the stand-alone (unfused) C-ABI kernels on an MI355X and prints achieved GB/s against algorithmic bytes.
+    python tools/kernel_bench.py            (on the GPU box)"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import normflows_amd as nfa  # noqa: E402
+from normflows_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e-3
+
+
+def report(name, sec, nbytes):
+    print("%-44s %9.1f us  %8.1f GB/s  (%.1f%% of 8 TB/s)" % (name, sec * 1e6, nbytes / sec / 1e9, nbytes / sec / 8e12 * 100))
+
+
+def main():
+    torch.manual_seed(0)
+    B, D, K = 65536, 64, 8
+    layer = nfa.flows.CoupledRationalQuadraticSpline(D, 2, 128, num_bins=K).to(dev)
+    p = layer.prqct
+    x = torch.randn(B, D, device=dev)
+    cond = (0.3 * torch.randn(B, 32 * 23, device=dev)).contiguous()
+    uw, uh, ud = p._uncond()
+    kw = p._kernel_kwargs()
+    ld = torch.zeros(B, device=dev)
+    for mode, nm in ((0, "density"), (1, "sample/identity"), (2, "sample/transform")):
+        y = torch.empty_like(x)
+        t = timeit(lambda: ops.rqs_coupling(x, cond, uw, uh, ud, p.identity_features, p.transform_features, K, mode, y=y,
+                                            logdet=ld, acc=1, **kw))
+        nb = B * (2 * D * 4 + 8 + (32 * 23 * 4 if mode != 1 else 0))
+        report("nf_rqs_coupling f32 " + nm, t, nb)
+    xd, cd = x.double(), cond.double()
+    ldd = torch.zeros(B, device=dev, dtype=torch.float64)
+    t = timeit(lambda: ops.rqs_coupling(xd, cd, uw.double(), uh.double(), ud.double(), p.identity_features,
+                                        p.transform_features, K, 0, logdet=ldd, acc=1, **kw), reps=5)
+    report("nf_rqs_coupling f64 density", t, B * (2 * D * 8 + 16 + 32 * 23 * 8))
+    lu = nfa.flows.LULinearPermute(D, identity_init=False).to(dev)
+    for inverse, nm in ((True, "density"), (False, "sample")):
+        t = timeit(lambda: lu._run(x, inverse, ld, +1))
+        report("nf_lu_linear_permute f32 " + nm, t, B * (2 * D * 4 + 8))
+    w = torch.randn(B, D, K, device=dev)
+    h = torch.randn(B, D, K, device=dev)
+    d = torch.randn(B, D, K - 1, device=dev)
+    t = timeit(lambda: ops.rqs_spline(x, w, h, d, tails="linear", tail_bound=3.0), reps=5)
+    report("nf_rqs_spline f32 (elementwise)", t, B * D * (23 * 4 + 12))
+    q = nfa.distributions.DiagGaussian(D, trainable=False).to(dev)
+    t = timeit(lambda: q._log_prob_acc(x, ld, +1))
+    report("nf_diag_gaussian_log_prob f32", t, B * (D * 4 + 8))
+    # image-side kernels at the Glow shapes of BASELINE configs[3] (B = 256)
+    for C, HW in ((12, 16), (24, 8), (48, 4)):
+        z = torch.randn(256, C, HW, HW, device=dev)
+        an = nfa.flows.ActNorm((C, 1, 1)).to(dev)
+        an.inverse(z)
+        ldz = torch.zeros(256, device=dev)
+        t = timeit(lambda: an._run(z, True, ldz, +1))
+        report("nf_actnorm (256,%d,%d,%d)" % (C, HW, HW), t, z.numel() * 8)
+        conv = nfa.flows.Invertible1x1Conv(C, True).to(dev)
+        t = timeit(lambda: conv._run(z, True, ldz, +1))
+        report("nf_inv1x1 assemble+conv (256,%d,%d,%d)" % (C, HW, HW), t, z.numel() * 8)
+        param = torch.randn(256, 2 * (C // 2), HW, HW, device=dev)
+        t = timeit(lambda: ops.affine_coupling(z, param, (C + 1) // 2, False, "sigmoid", 1, logdet=ldz, acc=1))
+        report("nf_affine_coupling (256,%d,%d,%d)" % (C, HW, HW), t, z.numel() * 8 + param.numel() * 4)
+    zi = torch.randn(256, 3, 32, 32, device=dev)
+    t = timeit(lambda: ops.squeeze(zi, 1))
+    report("nf_squeeze (256,3,32,32)", t, zi.numel() * 8)
+    z2 = torch.randn(1024, 2, device=dev)
+    b = torch.tensor([1.0, 0.0], device=dev)
+    s2, t2 = torch.randn(1024, 2, device=dev), torch.randn(1024, 2, device=dev)
+    ld2 = torch.zeros(1024, device=dev)
+    t = timeit(lambda: ops.masked_affine(z2, b, s2, t2, 0, logdet=ld2, acc=1))
+    report("nf_masked_affine (1024,2) [latency]", t, 1024 * 2 * 16)
+
+
+if __name__ == "__main__":
+    main()
