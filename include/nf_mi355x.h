@@ -95,6 +95,22 @@ int nf_rqs_coupling(const void *x, void *y, void *logdet, const void *cond, cons
                     int dtype, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Backward (vector-Jacobian product) of nf_rqs_coupling, for training.  The reference differentiates
+ * normflows/utils/splines.py:16-219 and nsf/coupling.py:71-128 with PyTorch autograd (training step:
+ * core.py:87-102 + loss.backward()); there is no hand-written backward to cite.
+ *   grad_y (B, D), grad_logdet (B): upstream gradients of the forward call's outputs (same mode).
+ *   grad_x (B, D): written for every column the mode owns.  grad_cond (B, nT, M): per-element
+ *   gradients of the conditioner output.  grad_uw/uh/ud: gradients of the batch-shared parameters,
+ *   ACCUMULATED (atomics) -- the caller zero-initialises them.
+ */
+int nf_rqs_coupling_bwd(const void *x, const void *grad_y, const void *grad_logdet, const void *cond,
+                        const void *uw, const void *uh, const void *ud, const int64_t *identity_idx, int nI,
+                        const int64_t *transform_idx, int nT, int64_t B, int D, int K, int tails,
+                        double tail_bound, double min_bin_width, double min_bin_height, double min_derivative,
+                        double wh_div, int mode, void *grad_x, void *grad_cond, void *grad_uw, void *grad_uh,
+                        void *grad_ud, int dtype, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fully fused NSF coupling layer: ResidualNet conditioner (fp32 MFMA) + spline epilogue, one launch.
  * Replaces the whole of CoupledRationalQuadraticSpline.forward/inverse
  * (normflows/flows/neural_spline/wrapper.py:79-85) for 2-D inputs without context:

@@ -1,0 +1,328 @@
+// rqs_bwd.hip -- backward (vector-Jacobian product) of the NSF coupling transform, for training
+// (the reference differentiates normflows/utils/splines.py:16-219 and nsf/coupling.py:71-128 with PyTorch autograd;
+// there is no hand-written backward in the reference).
+//
+// For every spline element  (y, lad) = f(x; w[K], h[K], d[...])  and upstream gradients (gy, gl) this kernel returns
+//   gx      = gy dy/dx + gl dlad/dx
+//   g(w_i), g(h_i), g(d_j)  for the raw (unnormalised) parameters.
+// The Jacobian of the closed-form bin evaluation w.r.t. (x, knot_lo, knot_hi, other_lo, other_hi, d0, d1) is obtained
+// with forward-mode dual numbers (7 tangents) on exactly the forward arithmetic of common.hpp::rqs_eval_bin; the knots'
+// dependence on the raw parameters is analytic:
+//   knot_j = lo + (hi - lo) (j min + scale C_j),  C_j = sum_{i<j} softmax_i   (knot_0, knot_K pinned: no gradient)
+//   d knot_j / d raw_i = (hi - lo) scale softmax_i ([i < j] - C_j) / wh_div
+//   d deriv_j / d raw  = sigmoid(raw)  (softplus', torch threshold 20 -> 1)
+// Bin selection is piecewise constant (no gradient), elements outside the tails pass gx = gy through.
+//
+// Transform half: per-element parameter gradients go to dcond (B, nT, M).  Identity half (batch-shared parameters):
+// gradients are accumulated per workgroup in LDS and then atomically into (nI, K | K | nd) buffers that the caller
+// zero-initialises (summation order across workgroups is not deterministic; fp32 atomics).
+#include "common.hpp"
+
+namespace nf {
+
+template <typename T, int N> struct Dual {
+    T v;
+    T d[N];
+    __device__ __forceinline__ Dual() {}
+    __device__ __forceinline__ Dual(T c) : v(c) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) d[i] = T(0);
+    }
+    static __device__ __forceinline__ Dual var(T c, int idx) {
+        Dual r(c);
+        r.d[idx] = T(1);
+        return r;
+    }
+};
+#define DU template <typename T, int N> __device__ __forceinline__ Dual<T, N>
+DU operator+(const Dual<T, N> &a, const Dual<T, N> &b) { Dual<T, N> r; r.v = a.v + b.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+DU operator-(const Dual<T, N> &a, const Dual<T, N> &b) { Dual<T, N> r; r.v = a.v - b.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+DU operator-(const Dual<T, N> &a) { Dual<T, N> r; r.v = -a.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = -a.d[i]; return r; }
+DU operator*(const Dual<T, N> &a, const Dual<T, N> &b) { Dual<T, N> r; r.v = a.v * b.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+DU operator/(const Dual<T, N> &a, const Dual<T, N> &b) { Dual<T, N> r; const T inv = T(1) / b.v; r.v = a.v * inv;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv; return r; }
+DU dlog(const Dual<T, N> &a) { Dual<T, N> r; r.v = M<T>::log(a.v); const T inv = T(1) / a.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * inv; return r; }
+DU dsqrt(const Dual<T, N> &a) { Dual<T, N> r; r.v = M<T>::sqrt(a.v); const T h = T(0.5) / r.v;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * h; return r; }
+#undef DU
+
+// Same arithmetic as common.hpp::rqs_eval_bin on dual numbers.
+// variables: 0 = x, 1 = cw (x-axis knot lo), 2 = cw_hi, 3 = ch (y-axis knot lo), 4 = ch_hi, 5 = d0, 6 = d1
+template <typename T>
+__device__ __forceinline__ void rqs_eval_bin_dual(T x, T cw, T cwh, T ch, T chh, T d0, T d1, bool inverse, T (&gy)[7],
+                                                  T (&gl)[7]) {
+    typedef Dual<T, 7> D7;
+    const D7 X = D7::var(x, 0), CW = D7::var(cw, 1), CWH = D7::var(cwh, 2), CH = D7::var(ch, 3), CHH = D7::var(chh, 4),
+             D0 = D7::var(d0, 5), D1 = D7::var(d1, 6);
+    const D7 bw = CWH - CW, bh = CHH - CH;
+    const D7 delta = bh / bw;
+    const D7 two(T(2)), one(T(1)), four(T(4));
+    const D7 dsum = D0 + D1 - two * delta;
+    D7 y, lad;
+    if (!inverse) {
+        const D7 theta = (X - CW) / bw;
+        const D7 omt = one - theta;
+        const D7 t1mt = theta * omt;
+        const D7 num = bh * (delta * theta * theta + D0 * t1mt);
+        const D7 den = delta + dsum * t1mt;
+        y = CH + num / den;
+        const D7 dnum = delta * delta * (D1 * theta * theta + two * delta * t1mt + D0 * omt * omt);
+        lad = dlog(dnum) - two * dlog(den);
+    } else {
+        const D7 dy = X - CH;
+        const D7 a = dy * dsum + bh * (delta - D0);
+        const D7 b = bh * D0 - dy * dsum;
+        const D7 c = -(delta * dy);
+        const D7 disc = b * b - four * a * c;
+        const D7 root = (two * c) / (-b - dsqrt(disc));
+        y = root * bw + CW;
+        const D7 omr = one - root;
+        const D7 t1mt = root * omr;
+        const D7 den = delta + dsum * t1mt;
+        const D7 dnum = delta * delta * (D1 * root * root + two * delta * t1mt + D0 * omr * omr);
+        lad = -(dlog(dnum) - two * dlog(den));
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        gy[i] = y.d[i];
+        gl[i] = lad.d[i];
+    }
+}
+
+// Gradient of one spline element w.r.t. x and its raw parameters.  wacc/hacc return the parameters divided by
+// wh_div; dacc the raw derivative logits.  add_w(i, g), add_h(i, g), add_d(j, g) receive the gradients of the RAW
+// parameters (already including 1 / wh_div).  Returns gx.
+template <typename T, typename WAcc, typename HAcc, typename DAcc, typename AW, typename AH, typename AD>
+__device__ __forceinline__ T rqs_element_bwd(const RqsParams<T> &p, T x, T gy_up, T gl_up, const WAcc &wacc,
+                                             const HAcc &hacc, const DAcc &dacc, bool inverse, const AW &add_w,
+                                             const AH &add_h, const AD &add_d) {
+    if (!rqs_inside(p, x)) return gy_up;  // identity outside the tails (utils/splines.py:40-41), lad = 0
+    const int K = p.K;
+    T mw = wacc(0), mh = hacc(0);
+    for (int k = 1; k < K; ++k) {
+        mw = M<T>::fmax(mw, wacc(k));
+        mh = M<T>::fmax(mh, hacc(k));
+    }
+    T sw = T(0), sh = T(0);
+    for (int k = 0; k < K; ++k) {
+        sw += M<T>::exp(wacc(k) - mw);
+        sh += M<T>::exp(hacc(k) - mh);
+    }
+    // knots of both axes around the bin (searched axis: widths for forward, heights for inverse)
+    int bin = 0;
+    T cw_lo = p.left, cw_hi = p.left, Cw_lo = T(0), Cw_hi = T(0);
+    {
+        T cum = T(0), csm = T(0), knot = p.left, cprev = T(0);
+        T ch_dummy = T(0);
+        (void)ch_dummy;
+        // first pass: widths knots with bin search if !inverse, else just record all needed later
+        if (!inverse) {
+            for (int k = 0; k < K; ++k) {
+                const T sm = M<T>::exp(wacc(k) - mw) / sw;
+                cum += p.min_w + p.scale_w * sm;
+                const T next = (k == K - 1) ? p.right : (p.right - p.left) * cum + p.left;
+                if (k == 0 || x >= knot) { bin = k; cw_lo = knot; cw_hi = next; Cw_lo = cprev; Cw_hi = csm + sm; }
+                knot = next;
+                cprev = csm + sm;
+                csm += sm;
+            }
+        }
+    }
+    T ch_lo = p.bottom, ch_hi = p.bottom, Ch_lo = T(0), Ch_hi = T(0);
+    if (inverse) {
+        T cum = T(0), csm = T(0), knot = p.bottom, cprev = T(0);
+        for (int k = 0; k < K; ++k) {
+            const T sm = M<T>::exp(hacc(k) - mh) / sh;
+            cum += p.min_h + p.scale_h * sm;
+            const T next = (k == K - 1) ? p.top : (p.top - p.bottom) * cum + p.bottom;
+            if (k == 0 || x >= knot) { bin = k; ch_lo = knot; ch_hi = next; Ch_lo = cprev; Ch_hi = csm + sm; }
+            knot = next;
+            cprev = csm + sm;
+            csm += sm;
+        }
+        cum = T(0); csm = T(0); knot = p.left;
+        for (int k = 0; k <= bin; ++k) {
+            const T sm = M<T>::exp(wacc(k) - mw) / sw;
+            cum += p.min_w + p.scale_w * sm;
+            const T next = (k == K - 1) ? p.right : (p.right - p.left) * cum + p.left;
+            cw_lo = knot; cw_hi = next; Cw_lo = csm; Cw_hi = csm + sm;
+            knot = next;
+            csm += sm;
+        }
+    } else {
+        T cum = T(0), csm = T(0), knot = p.bottom;
+        for (int k = 0; k <= bin; ++k) {
+            const T sm = M<T>::exp(hacc(k) - mh) / sh;
+            cum += p.min_h + p.scale_h * sm;
+            const T next = (k == K - 1) ? p.top : (p.top - p.bottom) * cum + p.bottom;
+            ch_lo = knot; ch_hi = next; Ch_lo = csm; Ch_hi = csm + sm;
+            knot = next;
+            csm += sm;
+        }
+    }
+    const T r0 = rqs_dlogit(p, dacc, bin), r1 = rqs_dlogit(p, dacc, bin + 1);
+    const T d0 = p.min_d + softplus(r0), d1 = p.min_d + softplus(r1);
+    T gy[7], gl[7];
+    rqs_eval_bin_dual<T>(x, cw_lo, cw_hi, ch_lo, ch_hi, d0, d1, inverse, gy, gl);
+    T g[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) g[i] = gy_up * gy[i] + gl_up * gl[i];
+    // ---- knots -> raw widths / heights ----
+    const T g_cw_lo = bin == 0 ? T(0) : g[1], g_cw_hi = bin == K - 1 ? T(0) : g[2];  // pinned end knots are constants
+    const T g_ch_lo = bin == 0 ? T(0) : g[3], g_ch_hi = bin == K - 1 ? T(0) : g[4];
+    const T fw = (p.right - p.left) * p.scale_w / p.wh_div, fh = (p.top - p.bottom) * p.scale_h / p.wh_div;
+    for (int i = 0; i < K; ++i) {
+        const T smw = M<T>::exp(wacc(i) - mw) / sw, smh = M<T>::exp(hacc(i) - mh) / sh;
+        const T tw = g_cw_lo * ((i < bin ? T(1) : T(0)) - Cw_lo) + g_cw_hi * ((i < bin + 1 ? T(1) : T(0)) - Cw_hi);
+        const T th = g_ch_lo * ((i < bin ? T(1) : T(0)) - Ch_lo) + g_ch_hi * ((i < bin + 1 ? T(1) : T(0)) - Ch_hi);
+        add_w(i, fw * smw * tw);
+        add_h(i, fh * smh * th);
+    }
+    // ---- derivatives -> raw logits (softplus' = sigmoid; padded/edge logits are constants) ----
+    auto raw_index = [&](int j) -> int {  // padded logit j -> raw index, or -1 for a constant
+        if (p.tails == NF_TAILS_LINEAR) return (j == 0 || j == K) ? -1 : j - 1;
+        if (p.tails == NF_TAILS_CIRCULAR) return j == K ? 0 : j;
+        return j;
+    };
+    const int j0 = raw_index(bin), j1 = raw_index(bin + 1);
+    if (j0 >= 0) add_d(j0, g[5] * (r0 > T(20) ? T(1) : sigmoid(r0)));
+    if (j1 >= 0) add_d(j1, g[6] * (r1 > T(20) ? T(1) : sigmoid(r1)));
+    return g[0];
+}
+
+// One lane per (sample, feature) element.  mode as in the forward: 0 density (both halves, forward splines),
+// 1 identity half with the inverse spline, 2 transform half with the inverse spline.
+template <typename T>
+__global__ void __launch_bounds__(256)
+rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const T *__restrict__ gld,
+                        const T *__restrict__ cond, const T *__restrict__ uw, const T *__restrict__ uh,
+                        const T *__restrict__ ud, const int64_t *__restrict__ iidx, int nI,
+                        const int64_t *__restrict__ tidx, int nT, int64_t B, int D, RqsParams<T> p, int mode,
+                        T *__restrict__ gx, T *__restrict__ gcond, T *__restrict__ guw, T *__restrict__ guh,
+                        T *__restrict__ gud) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int K = p.K, nd = p.nd, M = 2 * K + nd;
+    T *s_acc = reinterpret_cast<T *>(smem_raw);  // nI * M block-local accumulators of the shared parameters
+    const bool do_t = mode != NF_RQS_SAMPLE_IDENTITY, do_i = mode != NF_RQS_SAMPLE_TRANSFORM;
+    const bool inverse = mode != NF_RQS_DENSITY;
+    const bool has_uncond = uw != nullptr;
+    if (do_i && has_uncond) {
+        for (int i = threadIdx.x; i < nI * M; i += blockDim.x) s_acc[i] = T(0);
+    }
+    __syncthreads();
+    const int64_t nelem = B * (int64_t)D;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nelem; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = e / D;
+        const int f = (int)(e - b * D);  // 0..nT-1: transform feature f, nT..D-1: identity feature f - nT
+        if (f < nT) {
+            const int col = (int)tidx[f];
+            if (!do_t) continue;
+            const T *row = cond + (b * nT + f) * (int64_t)M;
+            T *grow = gcond + (b * nT + f) * (int64_t)M;
+            const T div = p.wh_div;
+            for (int k = 0; k < M; ++k) grow[k] = T(0);
+            auto wacc = [=](int k) { return row[k] / div; };
+            auto hacc = [=](int k) { return row[K + k] / div; };
+            auto dacc = [=](int k) { return row[2 * K + k]; };
+            auto aw = [=](int i, T g) { grow[i] = g; };
+            auto ah = [=](int i, T g) { grow[K + i] = g; };
+            auto ad = [=](int j, T g) { grow[2 * K + j] += g; };
+            gx[b * D + col] = rqs_element_bwd<T>(p, x[b * D + col], gy[b * D + col], gld[b], wacc, hacc, dacc, inverse,
+                                                 aw, ah, ad);
+        } else {
+            const int j = f - nT;
+            const int col = (int)iidx[j];
+            if (!do_i) continue;
+            if (!has_uncond) {
+                gx[b * D + col] = gy[b * D + col];
+                continue;
+            }
+            RqsParams<T> pu = p;
+            pu.wh_div = T(1);  // the unconditional transform is not scaled (nsf/coupling.py:224-232)
+            const T *wj = uw + (size_t)j * K, *hj = uh + (size_t)j * K, *dj = ud + (size_t)j * nd;
+            T *acc = s_acc + (size_t)j * M;
+            auto wacc = [=](int k) { return wj[k]; };
+            auto hacc = [=](int k) { return hj[k]; };
+            auto dacc = [=](int k) { return dj[k]; };
+            auto aw = [=](int i, T g) { atomicAdd(acc + i, g); };
+            auto ah = [=](int i, T g) { atomicAdd(acc + K + i, g); };
+            auto ad = [=](int jj, T g) { atomicAdd(acc + 2 * K + jj, g); };
+            gx[b * D + col] = rqs_element_bwd<T>(pu, x[b * D + col], gy[b * D + col], gld[b], wacc, hacc, dacc, inverse,
+                                                 aw, ah, ad);
+        }
+    }
+    __syncthreads();
+    if (do_i && has_uncond) {
+        for (int i = threadIdx.x; i < nI * M; i += blockDim.x) {
+            const int j = i / M, c = i - j * M;
+            const T v = s_acc[i];
+            if (v != T(0)) {
+                if (c < K) atomicAdd(guw + (size_t)j * K + c, v);
+                else if (c < 2 * K) atomicAdd(guh + (size_t)j * K + (c - K), v);
+                else atomicAdd(gud + (size_t)j * nd + (c - 2 * K), v);
+            }
+        }
+    }
+}
+
+}  // namespace nf
+
+using namespace nf;
+
+template <typename T>
+static int launch_bwd(const void *x, const void *gy, const void *gld, const void *cond, const void *uw, const void *uh,
+                      const void *ud, const int64_t *iidx, int nI, const int64_t *tidx, int nT, int64_t B, int D,
+                      const RqsParams<T> &p, int mode, void *gx, void *gcond, void *guw, void *guh, void *gud,
+                      hipStream_t st) {
+    const int M = 2 * p.K + p.nd;
+    const size_t lds = (size_t)nI * M * sizeof(T) + 16;
+    if (lds > 64 * 1024) return NF_ENOTSUP;
+    const int grid = grid_for(B * (int64_t)D, 256, 1024);
+    hipLaunchKernelGGL(rqs_coupling_bwd_kernel<T>, dim3(grid), dim3(256), lds, st, (const T *)x, (const T *)gy,
+                       (const T *)gld, (const T *)cond, (const T *)uw, (const T *)uh, (const T *)ud, iidx, nI, tidx, nT,
+                       B, D, p, mode, (T *)gx, (T *)gcond, (T *)guw, (T *)guh, (T *)gud);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_rqs_coupling_bwd(const void *x, const void *grad_y, const void *grad_logdet, const void *cond,
+                                   const void *uw, const void *uh, const void *ud, const int64_t *identity_idx, int nI,
+                                   const int64_t *transform_idx, int nT, int64_t B, int D, int K, int tails,
+                                   double tail_bound, double min_bin_width, double min_bin_height, double min_derivative,
+                                   double wh_div, int mode, void *grad_x, void *grad_cond, void *grad_uw, void *grad_uh,
+                                   void *grad_ud, int dtype, nf_stream_t stream) {
+    if (K < 1 || K > NF_MAX_BINS) return NF_ERANGE;
+    if (tails < NF_TAILS_NONE || tails > NF_TAILS_CIRCULAR) return NF_EINVAL;
+    if (B < 0 || D < 1 || nI < 0 || nT < 0 || nI + nT != D || mode < 0 || mode > 2) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!x || !grad_y || !grad_logdet || !grad_x) return NF_EFAULT;
+    if (mode != NF_RQS_SAMPLE_IDENTITY && nT && (!cond || !grad_cond || !transform_idx)) return NF_EFAULT;
+    if (mode != NF_RQS_SAMPLE_TRANSFORM && nI && !identity_idx) return NF_EFAULT;
+    if (uw && (!uh || !ud || !grad_uw || !grad_uh || !grad_ud)) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == NF_F32) {
+        auto p = make_rqs_params<float>(K, tails, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height, min_derivative,
+                                        wh_div);
+        return launch_bwd<float>(x, grad_y, grad_logdet, cond, uw, uh, ud, identity_idx, nI, transform_idx, nT, B, D, p,
+                                 mode, grad_x, grad_cond, grad_uw, grad_uh, grad_ud, st);
+    }
+    if (dtype == NF_F64) {
+        auto p = make_rqs_params<double>(K, tails, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
+                                         min_derivative, wh_div);
+        return launch_bwd<double>(x, grad_y, grad_logdet, cond, uw, uh, ud, identity_idx, nI, transform_idx, nT, B, D,
+                                  p, mode, grad_x, grad_cond, grad_uw, grad_uh, grad_ud, st);
+    }
+    return NF_ENOTSUP;
+}

@@ -8,6 +8,7 @@ import torch
 from torch import nn
 
 from . import ops
+from .autograd import DiagGaussianLogProbFn, needs_grad
 
 
 class BaseDistribution(nn.Module):
@@ -63,9 +64,18 @@ class DiagGaussian(BaseDistribution):
         return z, log_p
 
     def log_prob(self, z, context=None):
+        if needs_grad(z, self.loc, self.log_scale):
+            return DiagGaussianLogProbFn.apply(z, self.loc, self.log_scale, self._shift())
         return ops.diag_gaussian_log_prob(z, self.loc.detach(), self.log_scale.detach(), self._shift())
 
     def _log_prob_acc(self, z, log_q, acc=+1):
         """log_q (+|-)= log_prob(z), fused into the kernel's store."""
+        if needs_grad(z, self.loc, self.log_scale):
+            lp = self.log_prob(z)
+            if acc > 0:
+                log_q += lp
+            else:
+                log_q -= lp
+            return log_q
         ops.diag_gaussian_log_prob(z, self.loc.detach(), self.log_scale.detach(), self._shift(), out=log_q, acc=acc)
         return log_q

@@ -39,3 +39,34 @@ def global_nll(log_q_local, group=None):
 def sharded_forward_kld(log_prob_fn, x_local, group=None):
     """forward_kld of core.py:87-102 on a row-sharded batch: local log_prob, then the single NLL all-reduce."""
     return global_nll(log_prob_fn(x_local), group=group)
+
+
+def allreduce_gradients(params, group=None, bucket_bytes=64 << 20):
+    """Average the gradients of `params` over all ranks: flat fp32/fp64 buckets (<= bucket_bytes each, sized for
+    per-link-bound ring collectives on point-to-point xGMI: few large messages), one all_reduce(SUM) per bucket, then a
+    scale by 1 / world_size.  Same math as the reference's single-process `-mean(log_q)` over the global batch when
+    every rank holds an equal share of the rows.  No-op without an initialised process group."""
+    params = [p for p in params if p.grad is not None]
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1) or not params:
+        return 0
+    world = dist.get_world_size(group)
+    buckets, cur, cur_bytes = [], [], 0
+    for p in params:
+        nb = p.grad.numel() * p.grad.element_size()
+        if cur and (cur_bytes + nb > bucket_bytes or p.grad.dtype != cur[0].grad.dtype):
+            buckets.append(cur)
+            cur, cur_bytes = [], 0
+        cur.append(p)
+        cur_bytes += nb
+    if cur:
+        buckets.append(cur)
+    for bucket in buckets:
+        flat = torch.cat([p.grad.reshape(-1) for p in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(world)
+        off = 0
+        for p in bucket:
+            n = p.grad.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
+    return len(buckets)

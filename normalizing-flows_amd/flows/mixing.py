@@ -12,6 +12,7 @@ from torch import nn
 from torch.nn import init
 
 from .. import ops
+from ..autograd import LULinearPermuteFn, needs_grad
 from .base import Flow
 
 
@@ -183,6 +184,16 @@ class LULinearPermute(Flow):
         if z.shape[1] != self.linear.features:
             raise ValueError("Dimension 1 in inputs must be of size {}.".format(self.linear.features))
         lin = self.linear
+        if needs_grad(z, self):   # training path (autograd.py): same forward kernel, GEMM-based backward
+            y, log_det = LULinearPermuteFn.apply(z, self.permutation._permutation, lin.lower_entries, lin.upper_entries,
+                                                 lin.unconstrained_upper_diag, lin.bias, lin.eps, 0 if inverse else 1)
+            if ld is not None:
+                if acc is None or acc > 0:
+                    ld += log_det
+                else:
+                    ld -= log_det
+                return y, ld
+            return y, log_det
         # flow.inverse (density) = kernel direction 0, flow.forward (sample) = kernel direction 1
         return ops.lu_linear_permute(z, self.permutation._permutation, lin.lower_entries.detach(),
                                      lin.upper_entries.detach(), lin.unconstrained_upper_diag.detach(),

@@ -18,6 +18,7 @@ from torch import nn
 
 from .. import _lib as L
 from .. import ops
+from ..autograd import SplineFn, needs_grad
 from ..nets import ResidualNet
 from ..utils.masks import create_alternating_binary_mask
 from .base import Flow
@@ -192,6 +193,8 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
     def _density(self, inputs, context=None, ld=None, acc=None):
         """prqct.forward (nsf/coupling.py:71-98): conditioner on the raw identity features."""
         self._check(inputs)
+        if needs_grad(inputs, context, self):
+            return self._autograd(inputs, context, False, ld, acc)
         if self.use_fused and self._fused_eligible(inputs, context):
             return self._fused(inputs, 0, ld, acc)
         cond = self._conditioner(inputs, context)
@@ -202,6 +205,8 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
     def _sample(self, inputs, context=None, ld=None, acc=None):
         """prqct.inverse (nsf/coupling.py:100-128): CDF^-1 on the identity half first, conditioner on ITS output."""
         self._check(inputs)
+        if needs_grad(inputs, context, self):
+            return self._autograd(inputs, context, True, ld, acc)
         if self.use_fused and self._fused_eligible(inputs, context):
             return self._fused(inputs, 1, ld, acc)
         uw, uh, ud = self._uncond()
@@ -218,6 +223,36 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
 
     def inverse(self, inputs, context=None):
         return self._sample(inputs, context)
+
+    # -- training path: same kernels through torch.autograd.Function (autograd.py), split/merge by torch indexing ---
+    def _autograd(self, inputs, context, sample, ld, acc):
+        kw = self._kernel_kwargs()
+        u = self.unconditional_transform
+        ident = inputs.index_select(1, self.identity_features)
+        trans = inputs.index_select(1, self.transform_features)
+        ld_i = None
+        if not sample:   # nsf/coupling.py:71-98
+            cond = self.transform_net(ident, context)
+            trans, ld_t = SplineFn.apply(trans, cond, None, None, None, self.num_bins, False, kw)
+            if u is not None:
+                ident, ld_i = SplineFn.apply(ident, None, u.unnormalized_widths, u.unnormalized_heights,
+                                             u.unnormalized_derivatives, self.num_bins, False, kw)
+        else:            # nsf/coupling.py:100-128
+            if u is not None:
+                ident, ld_i = SplineFn.apply(ident, None, u.unnormalized_widths, u.unnormalized_heights,
+                                             u.unnormalized_derivatives, self.num_bins, True, kw)
+            cond = self.transform_net(ident, context)
+            trans, ld_t = SplineFn.apply(trans, cond, None, None, None, self.num_bins, True, kw)
+        log_det = ld_t if ld_i is None else ld_t + ld_i
+        outputs = torch.empty_like(inputs)
+        outputs = outputs.index_copy(1, self.identity_features, ident).index_copy(1, self.transform_features, trans)
+        if ld is not None:
+            if acc is None or acc > 0:
+                ld += log_det
+            else:
+                ld -= log_det
+            return outputs, ld
+        return outputs, log_det
 
     # -- fused path: conditioner on MFMA + spline epilogue in one kernel (csrc/rqs_fused.hip) -----------------
     def _fused_eligible(self, inputs, context):
@@ -321,6 +356,8 @@ class CoupledRationalQuadraticSpline(Flow):
         """True when [this layer, lu] can run as ONE kernel: density = lu.inverse then self.inverse (the order
         NormalizingFlow.log_prob visits them, core.py:193-195), sample = self.forward then lu.forward."""
         p = self.prqct
+        if needs_grad(z, self, lu):
+            return False
         return (p.use_fused and p._fused_eligible(z, None) and lu.linear.features == p.features
                 and lu.linear.bias.dtype == torch.float32 and lu.linear.bias.is_cuda)
 

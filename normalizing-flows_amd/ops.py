@@ -294,3 +294,24 @@ def rqs_fused(x, blob, mask_parity, hidden, num_blocks, K, direction, logdet=Non
                               f64(min_derivative), i32(direction), i32(acc), L.stream())
     L.check(rc, "nf_rqs_fused")
     return y, logdet
+
+
+def rqs_coupling_bwd(x, grad_y, grad_logdet, cond, uw, uh, ud, identity_idx, transform_idx, K, mode, tails="linear",
+                     tail_bound=3.0, min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, wh_div=1.0):
+    """Vector-Jacobian product of rqs_coupling (nf_rqs_coupling_bwd).  Returns (gx, gcond, guw, guh, gud)."""
+    L.require_device(x, grad_y, grad_logdet, cond, uw, uh, ud, identity_idx, transform_idx)
+    B, D = x.shape
+    x, grad_y, grad_logdet = x.contiguous(), grad_y.contiguous(), grad_logdet.contiguous()
+    gx = torch.zeros_like(x)
+    gcond = torch.empty_like(cond) if cond is not None else None
+    guw = torch.zeros_like(uw) if uw is not None else None
+    guh = torch.zeros_like(uh) if uh is not None else None
+    gud = torch.zeros_like(ud) if ud is not None else None
+    rc = L.lib().nf_rqs_coupling_bwd(ptr(x), ptr(grad_y), ptr(grad_logdet), ptr(cond), ptr(uw), ptr(uh), ptr(ud),
+                                     ptr(identity_idx), i32(identity_idx.numel()), ptr(transform_idx),
+                                     i32(transform_idx.numel()), i64(B), i32(D), i32(K), i32(L.TAILS[tails]),
+                                     f64(tail_bound), f64(min_bin_width), f64(min_bin_height), f64(min_derivative),
+                                     f64(wh_div), i32(mode), ptr(gx), ptr(gcond), ptr(guw), ptr(guh), ptr(gud),
+                                     i32(L.dtype_code(x)), L.stream())
+    L.check(rc, "nf_rqs_coupling_bwd")
+    return gx, gcond, guw, guh, gud

@@ -355,8 +355,68 @@ def gen_models():
     npz("model_c4mini_glow", x=x, log_prob=lp, log_prob_second=lp2, **sd0, **sd(m, "sd__"))
 
 
+def gen_grads():
+    """Gradients from the reference's autograd (training path): per layer with random
+    cotangents (both directions) and the forward-KL training loss of core.py:87-102 on the C2-mini model."""
+    def layer_grads(layer, x, tag):
+        out = {}
+        g = torch.Generator().manual_seed(77)
+        cz = torch.randn(x.shape, generator=g, dtype=x.dtype)
+        cl = torch.randn(x.shape[0], generator=g, dtype=x.dtype)
+        for name, fn in (("inv", layer.inverse), ("fwd", layer.forward)):
+            xx = x.clone().requires_grad_(True)
+            layer.zero_grad()
+            z, ld = fn(xx)
+            loss = (z * cz).sum() + (ld * cl).sum()
+            loss.backward()
+            out["gx_" + name] = xx.grad.clone()
+            for k, p_ in layer.named_parameters():
+                out["g_%s__%s" % (name, k.replace(".", "__"))] = p_.grad.clone()
+        npz(tag, x=x, cz=cz, cl=cl, **out, **sd(layer, "sd__"))
+
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        for d, hidden, K in ((6, 16, 8), (64, 32, 8)):
+            torch.manual_seed(900 + d)
+            layer = nf.flows.CoupledRationalQuadraticSpline(d, 2, hidden, num_bins=K, init_identity=False)
+            perturb(layer, 0.2, 5)
+            with torch.no_grad():
+                u = layer.prqct.unconditional_transform
+                u.unnormalized_widths.normal_()
+                u.unnormalized_heights.normal_()
+                u.unnormalized_derivatives.normal_()
+            layer = layer.to(dt)
+            x = 1.5 * torch.randn(12, d, generator=torch.Generator().manual_seed(d), dtype=dt)
+            x[0, 0] = 4.0   # outside the tails
+            layer_grads(layer, x, "grad_crqs_d%d_%s" % (d, tag))
+        for d in (5, 64):
+            torch.manual_seed(950 + d)
+            layer = nf.flows.LULinearPermute(d, identity_init=False)
+            perturb(layer, 0.1, 6)
+            layer = layer.to(dt)
+            x = torch.randn(9, d, generator=torch.Generator().manual_seed(d), dtype=dt)
+            layer_grads(layer, x, "grad_lulinear_d%d_%s" % (d, tag))
+    # training loss on the C2-mini model (trainable base distribution)
+    sys.path.insert(0, os.path.join(OUT, "..", ".."))
+    from bench import c2_inputs, perturb_
+    torch.manual_seed(0)
+    flows = []
+    for _ in range(4):
+        flows += [nf.flows.CoupledRationalQuadraticSpline(16, 2, 32, num_bins=8), nf.flows.LULinearPermute(16)]
+    m = nf.NormalizingFlow(nf.distributions.DiagGaussian(16, trainable=True), flows)
+    perturb_(m, 0.05)
+    x = c2_inputs(48, 16)
+    loss = m.forward_kld(x)
+    loss.backward()
+    grads = {"g__" + k.replace(".", "__"): p_.grad for k, p_ in m.named_parameters()}
+    npz("grad_model_c2mini", x=x, loss=loss.detach(), **grads, **sd(m, "sd__"))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "grads":
+        gen_grads()
+        sys.exit(0)
     gen_splines()
     gen_nsf_layers()
     gen_affine()
     gen_models()
+    gen_grads()

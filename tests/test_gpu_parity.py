@@ -12,6 +12,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    """Parity tests exercise the inference kernels (fused paths included); the training path has its own module."""
+    with torch.no_grad():
+        yield
+
+
 @pytest.fixture(scope="module")
 def nfa():
     import normflows_amd

@@ -178,6 +178,14 @@ full = -log_prob(x).double().mean()
 assert abs(float(nll) - float(full)) < 1e-6, (float(nll), float(full))
 lo, hi = nfa.dp.shard_bounds(37, world, rank)
 assert local.shape[0] == hi - lo
+# gradient averaging: rank-dependent gradients -> identical averaged gradients on every rank, bucketed
+lin = torch.nn.Linear(5, 3)
+for p in lin.parameters():
+    p.grad = torch.full_like(p, float(rank + 1))
+nb = nfa.dp.allreduce_gradients(lin.parameters(), bucket_bytes=32)   # tiny buckets: forces several collectives
+assert nb >= 2
+for p in lin.parameters():
+    assert torch.allclose(p.grad, torch.full_like(p, (1 + world) / 2.0))
 if rank == 0:
     print("DP_OK", float(nll))
 dist.destroy_process_group()
