@@ -149,32 +149,21 @@ def pmc_traffic():
 
 def cpu_baseline(model, rows):
     """The CPU oracle (a port of the reference algorithm) timed on this host on a bounded sample of the same workload:
-    log_prob of the same 32-layer model on `rows` benchmark rows.  Rows are split into one chunk per hardware thread
-    and every chunk runs the whole 64-layer chain on its own thread (ctypes releases the GIL; OpenMP inside the
-    library is pinned to 1 thread), which scales far better than 64 x N small parallel regions."""
-    import concurrent.futures as cf
-    import ctypes
+    log_prob of the same 32-layer model on `rows` benchmark rows through ONE C call (oracle/nf_oracle.c
+    nfo_nsf_log_prob: OpenMP over 64-row chunks, every chunk runs the whole 64-layer chain)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nf_oracle
     ora = nf_oracle.OracleNSF(state_to_numpy(model), num_layers=len(model.flows), K=BINS, tail_bound=3.0)
     x = c2_inputs(rows, DIM).numpy()
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(1)
-    except OSError:
-        pass
-    nchunks = max(1, min(cores, rows // 32))
-    bounds = [(rows * i // nchunks, rows * (i + 1) // nchunks) for i in range(nchunks)]
-    ora.log_prob(x[:64])  # warm-up
-    with cf.ThreadPoolExecutor(max_workers=nchunks) as pool:
-        t0 = time.perf_counter()
-        parts = list(pool.map(lambda b: ora.log_prob(x[b[0]:b[1]]), bounds))
-        dt = time.perf_counter() - t0
-    import numpy as np
-    lp = np.concatenate(parts)
-    return {"value": rows / dt, "unit": "samples/s", "cores": nchunks, "kind": "port",
-            "sample": "log_prob of the same %d-layer model on %d rows (oracle/nf_oracle.c, %d threads x row chunks, %.1f s)"
-                      % (len(model.flows) // 2, rows, nchunks, dt), "nll_nats_per_dim": float(-lp.mean() / DIM)}
+    cores = int(os.environ.get("OMP_NUM_THREADS", cores))
+    ora.log_prob_whole(x[:256])  # warm-up (thread pool, page-in)
+    t0 = time.perf_counter()
+    lp = ora.log_prob_whole(x)
+    dt = time.perf_counter() - t0
+    return {"value": rows / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "log_prob of the same %d-layer model on %d rows (oracle/nf_oracle.c nfo_nsf_log_prob, OpenMP, %.1f s)"
+                      % (len(model.flows) // 2, rows, dt), "nll_nats_per_dim": float(-lp.mean() / DIM)}
 
 
 def main():
@@ -187,7 +176,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=65536, help="rows of the same workload timed on the host oracle")
+    ap.add_argument("--cpu-rows", type=int, default=131072, help="rows of the same workload timed on the host oracle")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -280,6 +269,31 @@ def main():
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t1) / max(args.steps // 2, 3)
             out["sample_direction"] = {"value": args.batch / dt, "unit": "samples/s", "ms_per_step": 1e3 * dt}
+        if not args.no_breakdown:
+            # secondary: the same pass with the fused kernel's GEMMs on the bf16 matrix pipe by error-compensated
+            # splitting (fp32 = hi + mid + lo bf16, six products, fp32 accumulation; csrc/rqs_fused_x3.hip).  Same
+            # parity tests as the exact-fp32 kernel; reported separately, `value` above is the exact-fp32 MFMA path.
+            nfa.config.set_fused_gemm("bf16x3")
+            model.use_graphs(False)
+            model.use_graphs(not args.no_graph)
+            with torch.no_grad():
+                for _ in range(2):
+                    lp3 = model.log_prob(x)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    lp3 = model.log_prob(x)
+                torch.cuda.synchronize()
+                dt3 = (time.perf_counter() - t1) / args.steps
+            rel = float(((lp3 - lp).abs() / lp.abs().clamp_min(1.0)).max())
+            out["bf16x3_split_gemm"] = {"value": args.batch / dt3, "unit": "samples/s", "ms_per_step": 1e3 * dt3,
+                                        "nll_nats_per_dim": float(-lp3.mean()) / DIM,
+                                        "max_rel_diff_log_prob_vs_exact_f32": rel,
+                                        "executed_bf16_tflops": 6 * c2_flops_per_sample(layers=args.layers) * args.batch / dt3 / 1e12,
+                                        "frac_of_bf16_mfma_peak_2500": 6 * c2_flops_per_sample(layers=args.layers) * args.batch / dt3 / 2.5e15}
+            nfa.config.set_fused_gemm("f32")
+            model.use_graphs(False)
+            model.use_graphs(not args.no_graph)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, args.cpu_rows)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -145,6 +145,18 @@ int nf_rqs_fused(const void *x, void *y, void *logdet, const void *wpack, int ma
                  double min_bin_height, double min_derivative, int direction, int acc, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The same fused layer with the GEMMs on the bf16 matrix pipe by error-compensated splitting
+ * (fp32 operand = hi + mid + lo bf16, six products accumulated in fp32; csrc/rqs_fused_x3.hip).
+ * Results are fp32-equivalent (same parity tests and tolerances as nf_rqs_fused).  The x3 blob is
+ * derived from an nf_rqs_fused_pack[_lu] blob of the same layer.
+ */
+int64_t nf_rqs_fused_x3_pack_size(int nI, int nT, int hidden, int num_blocks, int K);
+int nf_rqs_fused_x3_pack(void *x3pack, const void *f32pack, int num_blocks, int has_lu, nf_stream_t stream);
+int nf_rqs_fused_x3(const void *x, void *y, void *logdet, const void *x3pack, int mask_parity, int fuse_lu,
+                    int64_t B, int D, int hidden, int num_blocks, int K, double tail_bound, double min_bin_width,
+                    double min_bin_height, double min_derivative, int direction, int acc, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * LULinearPermute.  Replaces normflows/flows/mixing.py:535-563 (LULinearPermute), :229-244
  * (_Permutation), :402-473 (_LULinear forward_no_cache / inverse_no_cache), :514-532 (upper_diag,
  * logabsdet).

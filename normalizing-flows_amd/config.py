@@ -1,0 +1,15 @@
+"""Run-time switches of normflows_amd.
+
+fused_gemm: how the fused NSF coupling-layer kernel evaluates its GEMMs
+  "f32"    exact fp32 MFMA (v_mfma_f32_32x32x2_f32), the default;
+  "bf16x3" error-compensated split-bf16 MFMA (csrc/rqs_fused_x3.hip): fp32 operands as hi+mid+lo bf16, six products
+           accumulated in fp32 -- fp32-equivalent results (same parity tests), ~2x the throughput on gfx950.
+"""
+fused_gemm = "f32"
+
+
+def set_fused_gemm(mode):
+    global fused_gemm
+    if mode not in ("f32", "bf16x3"):
+        raise ValueError("fused_gemm must be 'f32' or 'bf16x3'")
+    fused_gemm = mode

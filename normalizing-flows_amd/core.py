@@ -188,6 +188,19 @@ class MultiscaleFlow(nn.Module):
         self.merges = torch.nn.ModuleList(merges)
         self.transform = transform
         self.class_cond = class_cond
+        self._graphs = _GraphCache()
+
+    def use_graphs(self, mode=True):
+        """Replay log_prob (without class labels) as a hipGraph per input shape: a Glow pass is hundreds of small
+        launches (3 per GlowBlock + the conv conditioner), i.e. launch-bound when issued eagerly."""
+        self._graphs.enabled = bool(mode)
+        if not mode:
+            self._graphs.clear()
+        return self
+
+    def _apply(self, fn, *a, **k):
+        self._graphs.clear()
+        return super()._apply(fn, *a, **k)
 
     def forward_kld(self, x, y=None):
         return -torch.mean(self.log_prob(x, y))
@@ -246,6 +259,11 @@ class MultiscaleFlow(nn.Module):
 
     def log_prob(self, x, y=None):
         """core.py:588-616."""
+        if y is None and self._graphs.enabled and not torch.is_grad_enabled():
+            return self._graphs.run(("log_prob", tuple(x.shape), x.dtype), self._log_prob_impl, x)
+        return self._log_prob_impl(x, y)
+
+    def _log_prob_impl(self, x, y=None):
         log_q = torch.zeros(len(x), dtype=x.dtype, device=x.device)
         z = x
         if self.transform is not None:

@@ -157,6 +157,7 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
         self._fused_ok = None      # lazily decided: shape handled by the fused MFMA kernel?
         self._fused_parity = 0
         self._fused_cache = None   # (parameter-version key, packed weight blob)
+        self._fused_x3_cache = None  # (same key object, split-bf16 blob)
         self.use_fused = True      # set False to force the unfused (library GEMM + nf_rqs_coupling) path
 
     def _transform_dim_multiplier(self):
@@ -306,6 +307,17 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
     def _fused(self, inputs, direction, ld=None, acc=None, lu=None):
         self._check(inputs)
         net = self.transform_net
+        from .. import config
+        if config.fused_gemm == "bf16x3":
+            blob = self._fused_blob(lu)
+            key = self._fused_cache[0]
+            if self._fused_x3_cache is None or self._fused_x3_cache[0] is not key:
+                self._fused_x3_cache = (key, ops.rqs_fused_x3_pack(blob, len(net.blocks), lu is not None))
+            return ops.rqs_fused_x3(inputs, self._fused_x3_cache[1], self._fused_parity, net.hidden_features,
+                                    len(net.blocks), self.num_bins, direction, logdet=ld, acc=acc,
+                                    tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
+                                    min_bin_height=self.min_bin_height, min_derivative=self.min_derivative,
+                                    fuse_lu=lu is not None)
         return ops.rqs_fused(inputs, self._fused_blob(lu), self._fused_parity, net.hidden_features, len(net.blocks),
                              self.num_bins, direction, logdet=ld, acc=acc, tail_bound=self.tail_bound,
                              min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,

@@ -315,3 +315,39 @@ def rqs_coupling_bwd(x, grad_y, grad_logdet, cond, uw, uh, ud, identity_idx, tra
                                      i32(L.dtype_code(x)), L.stream())
     L.check(rc, "nf_rqs_coupling_bwd")
     return gx, gcond, guw, guh, gud
+
+
+# ---- bf16x3 (error-compensated split-bf16 MFMA) variant of the fused layer ----------------------------------------
+def rqs_fused_x3_pack(f32_blob, num_blocks, has_lu, nI=32, nT=32, hidden=128, K=8):
+    """Derive the split-bf16 weight blob from an rqs_fused_pack blob of the same layer (nf_rqs_fused_x3_pack)."""
+    import ctypes
+    L.require_device(f32_blob)
+    lib = L.lib()
+    lib.nf_rqs_fused_x3_pack_size.restype = ctypes.c_int64
+    size = lib.nf_rqs_fused_x3_pack_size(i32(nI), i32(nT), i32(hidden), i32(num_blocks), i32(K))
+    if size <= 0:
+        raise NotImplementedError("nf_rqs_fused_x3: shape not supported")
+    blob = torch.zeros((size + 3) // 4, dtype=torch.float32, device=f32_blob.device)
+    rc = lib.nf_rqs_fused_x3_pack(ptr(blob), ptr(f32_blob), i32(num_blocks), i32(int(has_lu)), L.stream())
+    L.check(rc, "nf_rqs_fused_x3_pack")
+    return blob
+
+
+def rqs_fused_x3(x, blob, mask_parity, hidden, num_blocks, K, direction, logdet=None, acc=None, tail_bound=3.0,
+                 min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, fuse_lu=False):
+    L.require_device(x, blob)
+    if x.dtype != torch.float32:
+        raise TypeError("nf_rqs_fused_x3 is fp32 only")
+    x = x.contiguous()
+    B, D = x.shape
+    y = torch.empty_like(x)
+    if logdet is None:
+        logdet = torch.empty(B, dtype=x.dtype, device=x.device)
+        acc = L.LD_WRITE
+    elif acc is None:
+        acc = L.LD_ADD
+    rc = L.lib().nf_rqs_fused_x3(ptr(x), ptr(y), ptr(logdet), ptr(blob), i32(mask_parity), i32(int(fuse_lu)), i64(B),
+                                 i32(D), i32(hidden), i32(num_blocks), i32(K), f64(tail_bound), f64(min_bin_width),
+                                 f64(min_bin_height), f64(min_derivative), i32(direction), i32(acc), L.stream())
+    L.check(rc, "nf_rqs_fused_x3")
+    return y, logdet

@@ -295,6 +295,38 @@ class OracleNSF:
         y, _ = lu_linear_permute(z, l["perm"], l["lo"], l["up"], l["ud"], l["bias"], direction, logdet=logq, acc=acc)
         return y
 
+    def log_prob_whole(self, x):
+        """log_prob through the single C entry point nfo_nsf_log_prob (row chunks in parallel under OpenMP, every
+        chunk runs the whole layer chain) -- the timed CPU baseline of bench.py.  Requires alternating
+        [CoupledRQS, LULinearPermute] layers."""
+        x = np.ascontiguousarray(x)
+        dt = x.dtype
+        B, D = x.shape
+        L = self.n // 2
+        keep, ptrs = [], []
+
+        def add(a, dtype=None):
+            a = np.ascontiguousarray(a, dtype=dtype or dt)
+            keep.append(a)
+            ptrs.append(a.ctypes.data)
+
+        nblk = hidden = None
+        for l in range(L):
+            c, u = self._coupling_params(2 * l), self._lu_params(2 * l + 1)
+            nblk, hidden = len(c["wb"]) // 2, c["w0"].shape[0]
+            add(c["ii"], np.int64), add(c["ti"], np.int64), add(c["w0"]), add(c["b0"])
+            for w, b in zip(c["wb"], c["bb"]):
+                add(w), add(b)
+            add(c["wf"]), add(c["bf"]), add(c["uw"]), add(c["uh"]), add(c["ud"])
+            add(u["perm"], np.int64), add(u["lo"]), add(u["up"]), add(u["ud"]), add(u["bias"])
+        arr = (C.c_void_p * len(ptrs))(*ptrs)
+        out = np.empty(B, dt)
+        loc, ls = _c(self.st["q0.loc"], dt).reshape(-1), _c(self.st["q0.log_scale"], dt).reshape(-1)
+        f = getattr(lib(), "nfo_nsf_log_prob" + _sfx(dt))
+        f(_p(x), _p(out), C.c_int64(B), C.c_int(D), C.c_int(L), arr, C.c_int(nblk), C.c_int(hidden), C.c_int(self.K),
+          C.c_double(self.tail_bound), _p(loc), _p(ls), C.c_double(1e-3))
+        return out
+
     def log_prob(self, x):
         z = np.ascontiguousarray(x)
         logq = np.zeros(z.shape[0], z.dtype)

@@ -488,3 +488,116 @@ void FN(nfo_squeeze)(const REAL *z, REAL *y, int64_t B, int C, int H, int W, int
                                     z[((b * C + c) * H + 2 * h + i) * W + 2 * w + j];
     }
 }
+
+
+/* Whole-flow log_prob of core.py:182-197 for a stack of L [CoupledRationalQuadraticSpline, LULinearPermute] pairs and
+ * a DiagGaussian base, parallel over row chunks (each thread runs the complete 2L-layer chain on its rows).  Same
+ * per-layer arithmetic as the functions above; used for the timed CPU baseline.
+ * ptrs: per pair (9 + 4 nblk + 5) pointers:
+ *   [ii, ti, w0, b0, (w, b) x 2 nblk, wf, bf, uw, uh, ud, perm, lower, upper, udiag, bias]   (w* pre-transposed = NULL) */
+void FN(nfo_nsf_log_prob)(const REAL *x, REAL *logq, int64_t B, int D, int L, const void *const *ptrs, int nblk, int hidden,
+                          int K, double tail_bound, const REAL *loc, const REAL *log_scale, double eps) {
+    const int per = 9 + 4 * nblk + 5;
+    const int nI = (D + 1) / 2, nT = D / 2, Mrow = 3 * K - 1, out_f = nT * Mrow;
+    /* pre-transposed conditioner weights and assembled LU factors, once */
+    REAL **Wi = (REAL **)malloc(sizeof(REAL *) * L), **Wf = (REAL **)malloc(sizeof(REAL *) * L);
+    REAL **Wb = (REAL **)malloc(sizeof(REAL *) * L * 2 * (nblk > 0 ? nblk : 1));
+    REAL **Lm = (REAL **)malloc(sizeof(REAL *) * L), **Um = (REAL **)malloc(sizeof(REAL *) * L);
+    REAL *lad = (REAL *)malloc(sizeof(REAL) * L);
+    int l, q, r, c;
+    int64_t c0;
+    for (l = 0; l < L; ++l) {
+        const void *const *P = ptrs + (size_t)l * per;
+        Wi[l] = FN(transpose)((const REAL *)P[2], hidden, nI);
+        for (q = 0; q < 2 * nblk; ++q) Wb[l * 2 * nblk + q] = FN(transpose)((const REAL *)P[4 + 2 * q], hidden, hidden);
+        Wf[l] = FN(transpose)((const REAL *)P[4 + 4 * nblk], out_f, hidden);
+        {
+            const REAL *lo = (const REAL *)P[per - 4], *up = (const REAL *)P[per - 3], *ud = (const REAL *)P[per - 2];
+            size_t li = 0, ui = 0;
+            REAL a = 0;
+            Lm[l] = (REAL *)calloc((size_t)D * D, sizeof(REAL));
+            Um[l] = (REAL *)calloc((size_t)D * D, sizeof(REAL));
+            for (r = 0; r < D; ++r)
+                for (c = 0; c < D; ++c) {
+                    if (c < r) Lm[l][r * D + c] = lo[li++];
+                    else if (c == r) { Lm[l][r * D + c] = 1; Um[l][r * D + c] = FN(softplus)(ud[r]) + (REAL)eps; }
+                }
+            for (r = 0; r < D; ++r)
+                for (c = r + 1; c < D; ++c) Um[l][r * D + c] = up[ui++];
+            for (r = 0; r < D; ++r) a += LOG(Um[l][r * D + r]);
+            lad[l] = a;
+        }
+    }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (c0 = 0; c0 < B; c0 += 64) {
+        const int n = (int)((B - c0) < 64 ? (B - c0) : 64);
+        REAL *z = (REAL *)malloc(sizeof(REAL) * 64 * D), *z2 = (REAL *)malloc(sizeof(REAL) * 64 * D);
+        REAL *cond = (REAL *)malloc(sizeof(REAL) * out_f);
+        REAL lq[64];
+        int s, i, j, k, ll, blk;
+        memcpy(z, x + c0 * D, sizeof(REAL) * n * D);
+        for (s = 0; s < n; ++s) lq[s] = 0;
+        for (ll = L - 1; ll >= 0; --ll) {
+            const void *const *P = ptrs + (size_t)ll * per;
+            const int64_t *ii = (const int64_t *)P[0], *ti = (const int64_t *)P[1], *perm = (const int64_t *)P[per - 5];
+            const REAL *b0 = (const REAL *)P[3], *bfin = (const REAL *)P[5 + 4 * nblk];
+            const REAL *uw = (const REAL *)P[6 + 4 * nblk], *uh = (const REAL *)P[7 + 4 * nblk], *ud = (const REAL *)P[8 + 4 * nblk];
+            const REAL *bias = (const REAL *)P[per - 1];
+            for (s = 0; s < n; ++s) {
+                REAL t[1024], u[1024], t0[1024], t1[1024], t2[1024], xin[1024];
+                REAL *zr = z + s * D, *yr = z2 + s * D;
+                /* LULinearPermute.inverse (mixing.py:560-563) */
+                for (j = 0; j < D; ++j) t[j] = zr[perm[j]];
+                for (i = 0; i < D; ++i) { REAL a = 0; for (j = i; j < D; ++j) a += Um[ll][i * D + j] * t[j]; u[i] = a; }
+                for (i = 0; i < D; ++i) { REAL a = 0; for (j = 0; j <= i; ++j) a += Lm[ll][i * D + j] * u[j]; yr[i] = a + bias[i]; }
+                lq[s] += lad[ll];
+                /* CoupledRationalQuadraticSpline.inverse = prqct.forward (nsf/coupling.py:71-98) */
+                for (k = 0; k < nI; ++k) xin[k] = yr[ii[k]];
+                FN(dense)(Wi[ll], b0, xin, t0, nI, hidden);
+                for (blk = 0; blk < nblk; ++blk) {
+                    for (i = 0; i < hidden; ++i) t1[i] = t0[i] > 0 ? t0[i] : 0;
+                    FN(dense)(Wb[ll * 2 * nblk + 2 * blk], (const REAL *)P[5 + 4 * blk], t1, t2, hidden, hidden);
+                    for (i = 0; i < hidden; ++i) t2[i] = t2[i] > 0 ? t2[i] : 0;
+                    FN(dense)(Wb[ll * 2 * nblk + 2 * blk + 1], (const REAL *)P[7 + 4 * blk], t2, t1, hidden, hidden);
+                    for (i = 0; i < hidden; ++i) t0[i] = t0[i] + t1[i];
+                }
+                FN(dense)(Wf[ll], bfin, t0, cond, hidden, out_f);
+                {
+                    REAL st = 0, si = 0;
+                    for (j = 0; j < nT; ++j) {
+                        const REAL *row = cond + (size_t)j * Mrow;
+                        REAL yy, l2;
+                        FN(urqs_one)(yr[ti[j]], row, row + K, row + 2 * K, K, 1, (REAL)tail_bound, 0, 1, 0, 1,
+                                     SQRT((REAL)hidden), 0, (REAL)1e-3, (REAL)1e-3, (REAL)1e-3, &yy, &l2);
+                        zr[ti[j]] = yy;
+                        st += l2;
+                    }
+                    for (j = 0; j < nI; ++j) {
+                        REAL yy, l2;
+                        FN(urqs_one)(yr[ii[j]], uw + (size_t)j * K, uh + (size_t)j * K, ud + (size_t)j * (K - 1), K, 1,
+                                     (REAL)tail_bound, 0, 1, 0, 1, (REAL)1, 0, (REAL)1e-3, (REAL)1e-3, (REAL)1e-3, &yy, &l2);
+                        zr[ii[j]] = yy;
+                        si += l2;
+                    }
+                    lq[s] += st + si;
+                }
+            }
+        }
+        for (s = 0; s < n; ++s) { /* DiagGaussian.log_prob (distributions/base.py:94-103) */
+            const REAL cst = (REAL)(-0.5 * (double)D * log(2.0 * M_PI));
+            REAL a = 0;
+            int j2;
+            for (j2 = 0; j2 < D; ++j2) {
+                const REAL qv = (z[s * D + j2] - loc[j2]) / EXP(log_scale[j2]);
+                a += log_scale[j2] + (REAL)0.5 * (qv * qv);
+            }
+            logq[c0 + s] = lq[s] + (cst - a);
+        }
+        free(z); free(z2); free(cond);
+    }
+    for (l = 0; l < L; ++l) {
+        free(Wi[l]); free(Wf[l]); free(Lm[l]); free(Um[l]);
+        for (q = 0; q < 2 * nblk; ++q) free(Wb[l * 2 * nblk + q]);
+    }
+    free(Wi); free(Wf); free(Wb); free(Lm); free(Um); free(lad);
+}

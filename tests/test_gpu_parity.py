@@ -519,3 +519,37 @@ def test_fused_pair_with_lu_vs_layerwise_and_oracle(nfa, oracle, B):
         assert_close(N(zf), z, what="pair vs oracle z", rtol=1e-3, atol=1e-3)
         assert_close(N(ld_f), logq, what="pair vs oracle ld", rtol=1e-3, atol=2e-3)
         assert np.mean(np.abs(N(zf) - z) < 5e-5) > 0.98
+
+
+# ---- split-bf16 ("bf16x3") variant of the fused kernel: same fixtures, same tolerances --------------------------
+@pytest.fixture
+def bf16x3(nfa):
+    nfa.config.set_fused_gemm("bf16x3")
+    yield
+    nfa.config.set_fused_gemm("f32")
+
+
+@pytest.mark.parametrize("B", [33, 1000])
+def test_x3_fused_layer_vs_unfused_and_oracle(nfa, oracle, bf16x3, B):
+    test_fused_layer_vs_unfused_and_oracle(nfa, oracle, False, B)
+    test_fused_layer_vs_unfused_and_oracle(nfa, oracle, True, B)
+
+
+def test_x3_fused_pair_with_lu(nfa, oracle, bf16x3):
+    test_fused_pair_with_lu_vs_layerwise_and_oracle(nfa, oracle, 300)
+
+
+def test_x3_model_c2_head_vs_reference_and_exact_kernel(nfa, bf16x3):
+    from bench import build_c2_model
+    g = load_golden("model_c2_head")
+    m = build_c2_model().to(DEV)
+    lp = N(m.log_prob(T(g["x"])))
+    assert _rel(lp, g["log_prob"]) < 1e-4, _rel(lp, g["log_prob"])
+    nfa.config.set_fused_gemm("f32")
+    lp32 = N(m.log_prob(T(g["x"])))
+    # split-bf16 agrees with the exact-fp32 MFMA kernel at the fp32 rounding level
+    assert _rel(lp, lp32) < 2e-5, _rel(lp, lp32)
+
+
+def test_x3_model_c2_full_size_properties(nfa, oracle, bf16x3):
+    test_model_c2_full_size_properties(nfa, oracle)

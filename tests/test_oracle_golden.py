@@ -191,3 +191,15 @@ def test_c2mini_model(oracle):
     assert_close(xs, g["sample"], what="sample", rtol=1e-4, atol=1e-4)
     rel = np.abs(lq - g["sample_logq"]) / np.maximum(1.0, np.abs(g["sample_logq"]))
     assert rel.max() < 1e-5, rel.max()
+
+
+def test_whole_flow_entry_point_matches_layerwise_oracle_and_reference(oracle):
+    """nfo_nsf_log_prob (the single-call, OpenMP-over-rows routine timed as bench.py's cpu_baseline) is bit-identical
+    to the layer-by-layer oracle chain and matches the reference's log_prob on the C2-mini fixture."""
+    g = load_golden("model_c2mini")
+    ora = oracle.OracleNSF(golden_state(g), num_layers=8, K=8, tail_bound=3.0)
+    a = ora.log_prob(g["x"])
+    b = ora.log_prob_whole(g["x"])
+    assert np.array_equal(a, b)
+    rel = np.abs(b - g["log_prob"]) / np.maximum(1.0, np.abs(g["log_prob"]))
+    assert rel.max() < 1e-5

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Secondary measurements on an MI355X for the BASELINE configs that are parity-test cases, not bench lines:
+config 1 (RealNVP 4 x [MaskedAffineFlow + ActNorm], TwoMoons-like 2-D batch 1024) and config 4 (Glow L=3, K=32,
+hidden 256, 32x32x3, batch 256).  log_prob only, eager and hipGraph replay.  python tools/config_bench.py"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import normflows_amd as nfa  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timed(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def c1():
+    torch.manual_seed(0)
+    b = torch.tensor([1.0, 0.0])
+    fl = []
+    for i in range(4):
+        s = nfa.nets.MLP([2, 4, 2], init_zeros=True)
+        t = nfa.nets.MLP([2, 4, 2], init_zeros=True)
+        fl += [nfa.flows.MaskedAffineFlow(b if i % 2 == 0 else 1 - b, t, s), nfa.flows.ActNorm(2)]
+    m = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(2), fl).to(dev)
+    x = torch.randn(1024, 2, device=dev)
+    with torch.no_grad():
+        m.log_prob(x)
+        e = timed(lambda: m.log_prob(x), 50)
+        m.use_graphs(True)
+        g = timed(lambda: m.log_prob(x), 200)
+    print("config 1 RealNVP B=1024: eager %.1f us (%.2f M samples/s), hipGraph %.1f us (%.2f M samples/s)" % (
+        e * 1e6, 1024 / e / 1e6, g * 1e6, 1024 / g / 1e6))
+
+
+def c4():
+    torch.manual_seed(0)
+    L_, K_, hidden, channels = 3, 32, 256, 3
+    input_shape = (3, 32, 32)
+    q0, merges, flows = [], [], []
+    for i in range(L_):
+        fl = [nfa.flows.GlowBlock(channels * 2 ** (L_ + 1 - i), hidden, split_mode="channel", scale=True) for _ in range(K_)]
+        fl += [nfa.flows.Squeeze()]
+        flows += [fl]
+        if i > 0:
+            merges += [nfa.flows.Merge()]
+            latent = (input_shape[0] * 2 ** (L_ - i), input_shape[1] // 2 ** (L_ - i), input_shape[2] // 2 ** (L_ - i))
+        else:
+            latent = (input_shape[0] * 2 ** (L_ + 1), input_shape[1] // 2 ** L_, input_shape[2] // 2 ** L_)
+        q0 += [nfa.distributions.DiagGaussian(latent)]
+    m = nfa.MultiscaleFlow(q0, flows, merges, class_cond=False).to(dev)
+    x = torch.rand(256, 3, 32, 32, device=dev)
+    with torch.no_grad():
+        m.log_prob(x)  # ActNorm data-dependent init
+        e = timed(lambda: m.log_prob(x), 5)
+        m.use_graphs(True)
+        g = timed(lambda: m.log_prob(x), 10)
+    print("config 4 Glow L=3 K=32 B=256: eager %.1f ms (%.0f img/s), hipGraph %.1f ms (%.0f img/s)" % (
+        e * 1e3, 256 / e, g * 1e3, 256 / g))
+
+
+if __name__ == "__main__":
+    c1()
+    c4()

@@ -23,10 +23,13 @@ os.makedirs(OUT, exist_ok=True)
 def build(flags, idx):
     so = os.path.join(OUT, "v%d.so" % idx)
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", so,
-           os.path.join(CSRC, "rqs_fused.hip")] + flags.split()
+           os.path.join(CSRC, "rqs_fused.hip"), os.path.join(CSRC, "rqs_fused_x3.hip")] + [f for f in flags.split() if f != "X3"]
     subprocess.check_call(cmd)
     lib = C.CDLL(so)
     return lib
+
+
+DIRECTION = int(os.environ.get("NF_DIR", "0"))
 
 
 def main():
@@ -41,9 +44,17 @@ def main():
     ld = torch.zeros(len(x), device=dev)
     st = nfa._lib.stream()
 
+    from normflows_amd import ops
+    blob3 = ops.rqs_fused_x3_pack(blob, 2, True)
+    use_x3 = ["X3" in f.split() for f in variants]
+
     def launch(lib):
-        rc = lib.nf_rqs_fused(ptr(x), ptr(y), ptr(ld), ptr(blob), i32(0), i32(1), i64(len(x)), i32(64), i32(128), i32(2),
-                              i32(8), f64(3.0), f64(1e-3), f64(1e-3), f64(1e-3), i32(0), i32(1), st)
+        if use_x3[libs.index(lib)]:
+            rc = lib.nf_rqs_fused_x3(ptr(x), ptr(y), ptr(ld), ptr(blob3), i32(0), i32(1), i64(len(x)), i32(64), i32(128),
+                                     i32(2), i32(8), f64(3.0), f64(1e-3), f64(1e-3), f64(1e-3), i32(DIRECTION), i32(1), st)
+        else:
+            rc = lib.nf_rqs_fused(ptr(x), ptr(y), ptr(ld), ptr(blob), i32(0), i32(1), i64(len(x)), i32(64), i32(128),
+                                  i32(2), i32(8), f64(3.0), f64(1e-3), f64(1e-3), f64(1e-3), i32(DIRECTION), i32(1), st)
         assert rc == 0, rc
 
     for lib in libs:

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Secondary measurement: one training step (forward_kld + backward + Adam) of the BASELINE configs[1] model on an
+MI355X through the autograd path (HIP forward kernels, HIP spline backward, library GEMMs for the conditioner and
+the LU parameter gradients).  python tools/train_bench.py [--batch 65536] [--steps 5]"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import build_c2_model, c2_inputs  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=65536)
+ap.add_argument("--steps", type=int, default=5)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+m = build_c2_model().to(dev)
+x = c2_inputs(a.batch).to(dev)
+opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+for i in range(2 + a.steps):
+    if i == 2:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+    opt.zero_grad(set_to_none=True)
+    loss = m.forward_kld(x)
+    loss.backward()
+    opt.step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.steps
+print("train step: %.1f ms  -> %.0f samples/s  (loss %.4f, peak mem %.1f GB)" % (
+    dt * 1e3, a.batch / dt, float(loss), torch.cuda.max_memory_allocated() / 2 ** 30))
