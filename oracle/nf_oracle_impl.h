@@ -490,6 +490,29 @@ void FN(nfo_squeeze)(const REAL *z, REAL *y, int64_t B, int C, int H, int W, int
 }
 
 
+/* Y[s][i] = bias[i] + sum_k Wt[k][i] X[s][k] for a chunk of n rows: the k-ordered accumulation per output is the same
+ * rounding sequence as FN(dense); blocking over outputs keeps the Y tile in L1 and reads each weight once per chunk. */
+static void FN(dense_batch)(const REAL *Wt, const REAL *bias, const REAL *X, int ldx, REAL *Y, int ldy, int n, int in_f,
+                            int out_f, int relu_in) {
+    int i0, s, k, i;
+    for (i0 = 0; i0 < out_f; i0 += 128) {
+        const int nb = (out_f - i0) < 128 ? (out_f - i0) : 128;
+        for (s = 0; s < n; ++s)
+            for (i = 0; i < nb; ++i) Y[(size_t)s * ldy + i0 + i] = 0;
+        for (k = 0; k < in_f; ++k) {
+            const REAL *wr = Wt + (size_t)k * out_f + i0;
+            for (s = 0; s < n; ++s) {
+                REAL xk = X[(size_t)s * ldx + k];
+                REAL *yr = Y + (size_t)s * ldy + i0;
+                if (relu_in && !(xk > 0)) xk = 0;
+                for (i = 0; i < nb; ++i) yr[i] += wr[i] * xk;
+            }
+        }
+        for (s = 0; s < n; ++s)
+            for (i = 0; i < nb; ++i) Y[(size_t)s * ldy + i0 + i] += bias[i0 + i];
+    }
+}
+
 /* Whole-flow log_prob of core.py:182-197 for a stack of L [CoupledRationalQuadraticSpline, LULinearPermute] pairs and
  * a DiagGaussian base, parallel over row chunks (each thread runs the complete 2L-layer chain on its rows).  Same
  * per-layer arithmetic as the functions above; used for the timed CPU baseline.
@@ -532,7 +555,9 @@ void FN(nfo_nsf_log_prob)(const REAL *x, REAL *logq, int64_t B, int D, int L, co
     for (c0 = 0; c0 < B; c0 += 64) {
         const int n = (int)((B - c0) < 64 ? (B - c0) : 64);
         REAL *z = (REAL *)malloc(sizeof(REAL) * 64 * D), *z2 = (REAL *)malloc(sizeof(REAL) * 64 * D);
-        REAL *cond = (REAL *)malloc(sizeof(REAL) * out_f);
+        REAL *xin = (REAL *)malloc(sizeof(REAL) * 64 * nI), *t0 = (REAL *)malloc(sizeof(REAL) * 64 * hidden);
+        REAL *t1 = (REAL *)malloc(sizeof(REAL) * 64 * hidden), *t2 = (REAL *)malloc(sizeof(REAL) * 64 * hidden);
+        REAL *cond = (REAL *)malloc(sizeof(REAL) * 64 * out_f);
         REAL lq[64];
         int s, i, j, k, ll, blk;
         memcpy(z, x + c0 * D, sizeof(REAL) * n * D);
@@ -543,44 +568,42 @@ void FN(nfo_nsf_log_prob)(const REAL *x, REAL *logq, int64_t B, int D, int L, co
             const REAL *b0 = (const REAL *)P[3], *bfin = (const REAL *)P[5 + 4 * nblk];
             const REAL *uw = (const REAL *)P[6 + 4 * nblk], *uh = (const REAL *)P[7 + 4 * nblk], *ud = (const REAL *)P[8 + 4 * nblk];
             const REAL *bias = (const REAL *)P[per - 1];
-            for (s = 0; s < n; ++s) {
-                REAL t[1024], u[1024], t0[1024], t1[1024], t2[1024], xin[1024];
+            for (s = 0; s < n; ++s) { /* LULinearPermute.inverse (mixing.py:560-563) */
+                REAL t[1024], u[1024];
                 REAL *zr = z + s * D, *yr = z2 + s * D;
-                /* LULinearPermute.inverse (mixing.py:560-563) */
                 for (j = 0; j < D; ++j) t[j] = zr[perm[j]];
                 for (i = 0; i < D; ++i) { REAL a = 0; for (j = i; j < D; ++j) a += Um[ll][i * D + j] * t[j]; u[i] = a; }
                 for (i = 0; i < D; ++i) { REAL a = 0; for (j = 0; j <= i; ++j) a += Lm[ll][i * D + j] * u[j]; yr[i] = a + bias[i]; }
                 lq[s] += lad[ll];
-                /* CoupledRationalQuadraticSpline.inverse = prqct.forward (nsf/coupling.py:71-98) */
-                for (k = 0; k < nI; ++k) xin[k] = yr[ii[k]];
-                FN(dense)(Wi[ll], b0, xin, t0, nI, hidden);
-                for (blk = 0; blk < nblk; ++blk) {
-                    for (i = 0; i < hidden; ++i) t1[i] = t0[i] > 0 ? t0[i] : 0;
-                    FN(dense)(Wb[ll * 2 * nblk + 2 * blk], (const REAL *)P[5 + 4 * blk], t1, t2, hidden, hidden);
-                    for (i = 0; i < hidden; ++i) t2[i] = t2[i] > 0 ? t2[i] : 0;
-                    FN(dense)(Wb[ll * 2 * nblk + 2 * blk + 1], (const REAL *)P[7 + 4 * blk], t2, t1, hidden, hidden);
-                    for (i = 0; i < hidden; ++i) t0[i] = t0[i] + t1[i];
+                for (k = 0; k < nI; ++k) xin[s * nI + k] = yr[ii[k]];
+            }
+            /* ResidualNet conditioner (nets/resnet.py:92-104) on the chunk */
+            FN(dense_batch)(Wi[ll], b0, xin, nI, t0, hidden, n, nI, hidden, 0);
+            for (blk = 0; blk < nblk; ++blk) {
+                FN(dense_batch)(Wb[ll * 2 * nblk + 2 * blk], (const REAL *)P[5 + 4 * blk], t0, hidden, t2, hidden, n, hidden, hidden, 1);
+                FN(dense_batch)(Wb[ll * 2 * nblk + 2 * blk + 1], (const REAL *)P[7 + 4 * blk], t2, hidden, t1, hidden, n, hidden, hidden, 1);
+                for (i = 0; i < n * hidden; ++i) t0[i] = t0[i] + t1[i];
+            }
+            FN(dense_batch)(Wf[ll], bfin, t0, hidden, cond, out_f, n, hidden, out_f, 0);
+            for (s = 0; s < n; ++s) { /* CoupledRationalQuadraticSpline.inverse = prqct.forward (nsf/coupling.py:71-98) */
+                REAL *zr = z + s * D, *yr = z2 + s * D;
+                REAL st = 0, si = 0;
+                for (j = 0; j < nT; ++j) {
+                    const REAL *row = cond + (size_t)s * out_f + (size_t)j * Mrow;
+                    REAL yy, l2;
+                    FN(urqs_one)(yr[ti[j]], row, row + K, row + 2 * K, K, 1, (REAL)tail_bound, 0, 1, 0, 1,
+                                 SQRT((REAL)hidden), 0, (REAL)1e-3, (REAL)1e-3, (REAL)1e-3, &yy, &l2);
+                    zr[ti[j]] = yy;
+                    st += l2;
                 }
-                FN(dense)(Wf[ll], bfin, t0, cond, hidden, out_f);
-                {
-                    REAL st = 0, si = 0;
-                    for (j = 0; j < nT; ++j) {
-                        const REAL *row = cond + (size_t)j * Mrow;
-                        REAL yy, l2;
-                        FN(urqs_one)(yr[ti[j]], row, row + K, row + 2 * K, K, 1, (REAL)tail_bound, 0, 1, 0, 1,
-                                     SQRT((REAL)hidden), 0, (REAL)1e-3, (REAL)1e-3, (REAL)1e-3, &yy, &l2);
-                        zr[ti[j]] = yy;
-                        st += l2;
-                    }
-                    for (j = 0; j < nI; ++j) {
-                        REAL yy, l2;
-                        FN(urqs_one)(yr[ii[j]], uw + (size_t)j * K, uh + (size_t)j * K, ud + (size_t)j * (K - 1), K, 1,
-                                     (REAL)tail_bound, 0, 1, 0, 1, (REAL)1, 0, (REAL)1e-3, (REAL)1e-3, (REAL)1e-3, &yy, &l2);
-                        zr[ii[j]] = yy;
-                        si += l2;
-                    }
-                    lq[s] += st + si;
+                for (j = 0; j < nI; ++j) {
+                    REAL yy, l2;
+                    FN(urqs_one)(yr[ii[j]], uw + (size_t)j * K, uh + (size_t)j * K, ud + (size_t)j * (K - 1), K, 1,
+                                 (REAL)tail_bound, 0, 1, 0, 1, (REAL)1, 0, (REAL)1e-3, (REAL)1e-3, (REAL)1e-3, &yy, &l2);
+                    zr[ii[j]] = yy;
+                    si += l2;
                 }
+                lq[s] += st + si;
             }
         }
         for (s = 0; s < n; ++s) { /* DiagGaussian.log_prob (distributions/base.py:94-103) */
@@ -593,7 +616,7 @@ void FN(nfo_nsf_log_prob)(const REAL *x, REAL *logq, int64_t B, int D, int L, co
             }
             logq[c0 + s] = lq[s] + (cst - a);
         }
-        free(z); free(z2); free(cond);
+        free(z); free(z2); free(xin); free(t0); free(t1); free(t2); free(cond);
     }
     for (l = 0; l < L; ++l) {
         free(Wi[l]); free(Wf[l]); free(Lm[l]); free(Um[l]);
