@@ -186,14 +186,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # NF_BENCH_ONE_DEVICE=1 (testing only): all ranks share cuda:0 and talk over gloo, to exercise the N > 1 code path on
+    # a 1-GPU box; the real multi-GPU run uses one rank per GPU over RCCL (backend "nccl").
+    one_dev = os.environ.get("NF_BENCH_ONE_DEVICE") == "1"
+    dev_index = 0 if (world == 1 or one_dev) else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
 
     model = build_c2_model(num_layers=args.layers).to(dev)
     x = c2_inputs(args.batch, DIM, rank=rank).to(dev)

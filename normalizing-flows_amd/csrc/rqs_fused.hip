@@ -266,10 +266,19 @@ __device__ __forceinline__ void lu_mm(const float *buf, int lane, const float (&
     }
 }
 
+// Waves per workgroup (each wave = 32 samples).  8 waves share one weight stream: half the LDS-DMA instructions and
+// barriers per wave of the 4-wave layout (measured: DMA issue costs 9 us of a 188 us launch at 4 waves).
+#ifndef NF_FUSED_WAVES
+#define NF_FUSED_WAVES 8
+#endif
+constexpr int F_NW = NF_FUSED_WAVES;
+constexpr int F_THREADS = 64 * F_NW;
+constexpr int F_ROWS = 32 * F_NW;
+
 // DIR: 0 = density (wrapper.inverse), 1 = sample (wrapper.forward).  LU: fuse the layer's LULinearPermute
 // (density: LULinearPermute.inverse BEFORE the coupling; sample: LULinearPermute.forward AFTER it).
 template <int DIR, bool LU>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(F_THREADS, 2)
 rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ logdet,
                  const float *__restrict__ pack, int64_t B, int nblk, int par_t /* column parity of transform features */,
                  RqsParams<float> p, float inv_div, int acc) {
@@ -277,11 +286,11 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     FusedLayout lay;
     lay.nblk = nblk;
     float *ring = smem;                       // 2 x 4096
-    float *stash = ring + 2 * F_STAGE;        // 4 waves x 32 x 64
-    float *small = stash + 4 * 32 * 64;       // biases + tables
+    float *stash = ring + 2 * F_STAGE;        // F_NW waves x 32 x 64
+    float *small = stash + F_NW * 32 * 64;    // biases + tables
     const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases are wave-uniform
-    const int64_t row = (int64_t)blockIdx.x * 128 + wid * 32 + (lane & 31);
+    const int64_t row = (int64_t)blockIdx.x * F_ROWS + wid * 32 + (lane & 31);
     const bool valid = row < B;
     const int par_i = par_t ^ 1;
     const float *stages = pack + lay.off_stages();
@@ -298,10 +307,11 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     // ---- weight-stream helpers (2-slot ring, global -> LDS DMA) ----
     int stage = 0;
     auto issue = [&](int s) {
-        const float *src = stages + (size_t)phys(s) * F_STAGE + (wid * 4) * 256 + lane * 4;
-        float *dst = ring + (s & 1) * F_STAGE + (wid * 4) * 256;
+        constexpr int PPW = 16 / F_NW;  // 1 KB pieces per wave (16 per stage)
+        const float *src = stages + (size_t)phys(s) * F_STAGE + (wid * PPW) * 256 + lane * 4;
+        float *dst = ring + (s & 1) * F_STAGE + (wid * PPW) * 256;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < PPW; ++i)
             __builtin_amdgcn_global_load_lds(src + i * 256, (__attribute__((address_space(3))) void *)(dst + i * 256), 16, 0, 0);
     };
     auto acquire = [&]() -> const float * {
@@ -319,7 +329,7 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
 
     // ---- prologue: x rows -> LDS stash, small section -> LDS, first stage in flight ----
     issue(0);
-    for (int i = tid; i < lay.small_floats(); i += 256) small[i] = pack[F_HDR + i];
+    for (int i = tid; i < lay.small_floats(); i += F_THREADS) small[i] = pack[F_HDR + i];
     float xin[32];  // the lane's 32 row values, slot c = 8 Q + column-in-chunk
 #pragma unroll
     for (int Q = 0; Q < 4; ++Q) {
@@ -629,8 +639,8 @@ static int launch_fused(const void *x, void *y, void *logdet, const void *wpack,
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&rqs_fused_kernel<DIR, LU>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return NF_ENOTSUP;
-    const int grid = (int)((B + 127) / 128);
-    hipLaunchKernelGGL((rqs_fused_kernel<DIR, LU>), dim3(grid), dim3(256), lds, st, (const float *)x, (float *)y,
+    const int grid = (int)((B + F_ROWS - 1) / F_ROWS);
+    hipLaunchKernelGGL((rqs_fused_kernel<DIR, LU>), dim3(grid), dim3(F_THREADS), lds, st, (const float *)x, (float *)y,
                        (float *)logdet, (const float *)wpack, B, num_blocks, par_t, p, inv_div, acc);
     NF_CHECK_LAUNCH();
     return NF_OK;
@@ -650,8 +660,8 @@ extern "C" int nf_rqs_fused(const void *x, void *y, void *logdet, const void *wp
     auto p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
                                     min_derivative, sqrt((double)hidden));
     const float inv_div = (float)(1.0 / sqrt((double)hidden));
-    const size_t lds = (size_t)(2 * F_STAGE + 4 * 32 * 64 + lay.small_floats()) * sizeof(float);
-    if (lds > 80 * 1024) return NF_ENOTSUP;
+    const size_t lds = (size_t)(2 * F_STAGE + F_NW * 32 * 64 + lay.small_floats()) * sizeof(float);
+    if (lds > 160 * 1024) return NF_ENOTSUP;
     // transform features sit on odd columns for reverse_mask = False (mask_parity 0), on even columns otherwise
     const int par_t = mask_parity == 0 ? 1 : 0;
     if (direction == 0)
