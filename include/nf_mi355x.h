@@ -235,6 +235,17 @@ int nf_diag_gaussian_log_prob(const void *z, const void *loc, const void *log_sc
                               void *out, int64_t B, int64_t d, int acc, int dtype, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * MaskedAffineAutoregressive element-wise transform (MAF).  Replaces
+ * normflows/flows/affine/autoregressive.py:98-128 (_elementwise_forward / _elementwise_inverse).
+ *   params (B, D, 2): MADE output viewed as (unconstrained_scale, shift) per feature (:124-128);
+ *   scale = sigmoid(unconstrained_scale + 2) + 1e-3.
+ *   direction 0: y = scale x + shift, ld = +sum log scale; 1: y = (x - shift)/scale, ld = -sum log scale.
+ *   logdet (B) may be NULL (intermediate passes of the D-step inverse, autoregressive.py:29-38).
+ */
+int nf_maf_affine(const void *x, const void *params, void *y, void *logdet, int64_t B, int D, int direction, int acc,
+                  int dtype, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Squeeze (flows/reshape.py:116-128).  direction 0 = forward (C,H,W)->(C/4,2H,2W),
  * 1 = inverse (C,H,W)->(4C,H/2,W/2).  z, y contiguous NCHW with the shapes implied.
  */

@@ -6,3 +6,4 @@ from .mixing import Permute, Invertible1x1Conv, LULinearPermute
 from .glow import GlowBlock
 from .neural_spline import (CoupledRationalQuadraticSpline, PiecewiseRationalQuadraticCoupling,
                             PiecewiseRationalQuadraticCDF)
+from .autoregressive import Autoregressive, MaskedAffineAutoregressive

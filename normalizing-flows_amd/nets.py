@@ -175,3 +175,167 @@ class ConvNet2d(nn.Module):
 
     def forward(self, x):
         return self.net(x)
+
+
+# ---- MADE (conditioner of the autoregressive flows) ---------------------------------------------------------------
+def _tile(x, n):
+    """utils/nn.py tile: repeat every element n times, keeping order."""
+    return x.reshape(-1).repeat(n).reshape(n, -1).transpose(1, 0).reshape(-1)
+
+
+def _get_input_degrees(in_features):
+    return torch.arange(1, in_features + 1)
+
+
+class MaskedLinear(nn.Linear):
+    """Linear layer whose weight is multiplied by a fixed autoregressive mask (nets/made.py:19-81).  The masked
+    weight is cached per parameter version, so the D sequential passes of the MAF inverse do not re-mask it."""
+
+    def __init__(self, in_degrees, out_features, autoregressive_features, random_mask, is_output, bias=True,
+                 out_degrees_=None):
+        super().__init__(in_features=len(in_degrees), out_features=out_features, bias=bias)
+        mask, degrees = self._get_mask_and_degrees(in_degrees=in_degrees, out_features=out_features,
+                                                   autoregressive_features=autoregressive_features,
+                                                   random_mask=random_mask, is_output=is_output,
+                                                   out_degrees_=out_degrees_)
+        self.register_buffer("mask", mask)
+        self.register_buffer("degrees", degrees)
+        self._masked_cache = None
+
+    @classmethod
+    def _get_mask_and_degrees(cls, in_degrees, out_features, autoregressive_features, random_mask, is_output,
+                              out_degrees_=None):
+        if is_output:
+            if out_degrees_ is None:
+                out_degrees_ = _get_input_degrees(autoregressive_features)
+            out_degrees = _tile(out_degrees_, out_features // autoregressive_features)
+            mask = (out_degrees[..., None] > in_degrees).float()
+        else:
+            if random_mask:
+                min_in_degree = torch.min(in_degrees).item()
+                min_in_degree = min(min_in_degree, autoregressive_features - 1)
+                out_degrees = torch.randint(low=min_in_degree, high=autoregressive_features, size=[out_features],
+                                            dtype=torch.long)
+            else:
+                max_ = max(1, autoregressive_features - 1)
+                min_ = min(1, autoregressive_features - 1)
+                out_degrees = torch.arange(out_features) % max_ + min_
+            mask = (out_degrees[..., None] >= in_degrees).float()
+        return mask, out_degrees
+
+    def masked_weight(self):
+        if torch.is_grad_enabled() and self.weight.requires_grad:
+            return self.weight * self.mask
+        key = (self.weight.data_ptr(), self.weight._version, self.mask.data_ptr())
+        if self._masked_cache is None or self._masked_cache[0] != key:
+            self._masked_cache = (key, (self.weight.detach() * self.mask).contiguous())
+        return self._masked_cache[1]
+
+    def forward(self, x):
+        return F.linear(x, self.masked_weight(), self.bias)
+
+
+class MaskedFeedforwardBlock(nn.Module):
+    """nets/made.py:84-137."""
+
+    def __init__(self, in_degrees, autoregressive_features, context_features=None, random_mask=False,
+                 activation=F.relu, dropout_probability=0.0, use_batch_norm=False):
+        super().__init__()
+        features = len(in_degrees)
+        self.batch_norm = nn.BatchNorm1d(features, eps=1e-3) if use_batch_norm else None
+        if context_features is not None:
+            raise NotImplementedError()
+        self.linear = MaskedLinear(in_degrees=in_degrees, out_features=features,
+                                   autoregressive_features=autoregressive_features, random_mask=random_mask,
+                                   is_output=False)
+        self.degrees = self.linear.degrees
+        self.activation = activation
+        self.dropout = nn.Dropout(p=dropout_probability)
+
+    def forward(self, inputs, context=None):
+        if context is not None:
+            raise NotImplementedError()
+        outputs = self.batch_norm(inputs) if self.batch_norm else inputs
+        return self.dropout(self.activation(self.linear(outputs)))
+
+
+class MaskedResidualBlock(nn.Module):
+    """nets/made.py:140-214."""
+
+    def __init__(self, in_degrees, autoregressive_features, context_features=None, random_mask=False,
+                 activation=F.relu, dropout_probability=0.0, use_batch_norm=False, zero_initialization=True):
+        if random_mask:
+            raise ValueError("Masked residual block can't be used with random masks.")
+        super().__init__()
+        features = len(in_degrees)
+        if context_features is not None:
+            self.context_layer = nn.Linear(context_features, features)
+        self.use_batch_norm = use_batch_norm
+        if use_batch_norm:
+            self.batch_norm_layers = nn.ModuleList([nn.BatchNorm1d(features, eps=1e-3) for _ in range(2)])
+        linear_0 = MaskedLinear(in_degrees=in_degrees, out_features=features,
+                                autoregressive_features=autoregressive_features, random_mask=False, is_output=False)
+        linear_1 = MaskedLinear(in_degrees=linear_0.degrees, out_features=features,
+                                autoregressive_features=autoregressive_features, random_mask=False, is_output=False)
+        self.linear_layers = nn.ModuleList([linear_0, linear_1])
+        self.degrees = linear_1.degrees
+        if torch.all(self.degrees >= in_degrees).item() != 1:
+            raise RuntimeError("In a masked residual block, the output degrees can't be less than the corresponding "
+                               "input degrees.")
+        self.activation = activation
+        self.dropout = nn.Dropout(p=dropout_probability)
+        if zero_initialization:
+            init.uniform_(self.linear_layers[-1].weight, a=-1e-3, b=1e-3)
+            init.uniform_(self.linear_layers[-1].bias, a=-1e-3, b=1e-3)
+
+    def forward(self, inputs, context=None):
+        temps = inputs
+        if self.use_batch_norm:
+            temps = self.batch_norm_layers[0](temps)
+        temps = self.linear_layers[0](self.activation(temps))
+        if self.use_batch_norm:
+            temps = self.batch_norm_layers[1](temps)
+        temps = self.linear_layers[1](self.dropout(self.activation(temps)))
+        if context is not None:
+            temps = F.glu(torch.cat((temps, self.context_layer(context)), dim=1), dim=1)
+        return inputs + temps
+
+
+class MADE(nn.Module):
+    """Masked autoencoder for distribution estimation (nets/made.py:217-304)."""
+
+    def __init__(self, features, hidden_features, context_features=None, num_blocks=2, output_multiplier=1,
+                 use_residual_blocks=True, random_mask=False, permute_mask=False, activation=F.relu,
+                 dropout_probability=0.0, use_batch_norm=False, preprocessing=None):
+        if use_residual_blocks and random_mask:
+            raise ValueError("Residual blocks can't be used with random masks.")
+        super().__init__()
+        self.preprocessing = torch.nn.Identity() if preprocessing is None else preprocessing
+        input_degrees_ = _get_input_degrees(features)
+        if permute_mask:
+            input_degrees_ = input_degrees_[torch.randperm(features)]
+        self.initial_layer = MaskedLinear(in_degrees=input_degrees_, out_features=hidden_features,
+                                          autoregressive_features=features, random_mask=random_mask, is_output=False)
+        if context_features is not None:
+            self.context_layer = nn.Linear(context_features, hidden_features)
+        blocks = []
+        block_constructor = MaskedResidualBlock if use_residual_blocks else MaskedFeedforwardBlock
+        prev_out_degrees = self.initial_layer.degrees
+        for _ in range(num_blocks):
+            blocks.append(block_constructor(in_degrees=prev_out_degrees, autoregressive_features=features,
+                                            context_features=context_features, random_mask=random_mask,
+                                            activation=activation, dropout_probability=dropout_probability,
+                                            use_batch_norm=use_batch_norm))
+            prev_out_degrees = blocks[-1].degrees
+        self.blocks = nn.ModuleList(blocks)
+        self.final_layer = MaskedLinear(in_degrees=prev_out_degrees, out_features=features * output_multiplier,
+                                        autoregressive_features=features, random_mask=random_mask, is_output=True,
+                                        out_degrees_=input_degrees_)
+
+    def forward(self, inputs, context=None):
+        outputs = self.initial_layer(self.preprocessing(inputs))
+        if context is not None:
+            outputs = outputs + self.context_layer(context)
+        for block in self.blocks:
+            outputs = block(outputs, context)
+        return self.final_layer(outputs)

@@ -351,3 +351,21 @@ def rqs_fused_x3(x, blob, mask_parity, hidden, num_blocks, K, direction, logdet=
                                  f64(min_bin_height), f64(min_derivative), i32(direction), i32(acc), L.stream())
     L.check(rc, "nf_rqs_fused_x3")
     return y, logdet
+
+
+def maf_affine(x, params, direction, logdet=None, acc=None, want_logdet=True):
+    """affine/autoregressive.py:98-128.  params (B, D*2) or (B, D, 2).  direction 0 = forward, 1 = inverse."""
+    L.require_device(x, params)
+    x = x.contiguous()
+    params = params.contiguous()
+    B, D = x.shape
+    y = torch.empty_like(x)
+    if logdet is None and want_logdet:
+        logdet = torch.empty(B, dtype=x.dtype, device=x.device)
+        acc = L.LD_WRITE
+    elif acc is None:
+        acc = L.LD_ADD
+    rc = L.lib().nf_maf_affine(ptr(x), ptr(params), ptr(y), ptr(logdet), i64(B), i32(D), i32(direction), i32(acc or 0),
+                               i32(L.dtype_code(x)), L.stream())
+    L.check(rc, "nf_maf_affine")
+    return y, logdet

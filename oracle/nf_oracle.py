@@ -234,6 +234,42 @@ def squeeze(z, direction):
     return y
 
 
+def maf_affine(x, params, direction):
+    dt = x.dtype
+    x = _c(x, dt)
+    B, D = x.shape
+    y = np.empty_like(x)
+    ld = np.empty(B, dt)
+    getattr(lib(), "nfo_maf_affine" + _sfx(dt))(_p(x), _p(_c(params, dt)), _p(y), _p(ld), C.c_int64(B), C.c_int(D),
+                                               C.c_int(direction))
+    return y, ld
+
+
+def made_forward(st, x, prefix="autoregressive_net."):
+    """nets/made.py:292-304 with residual blocks (:196-214), ReLU, masked weights W * mask (:80-81); numpy."""
+    def lin(name, v):
+        return v @ (st[prefix + name + ".weight"] * st[prefix + name + ".mask"]).T + st[prefix + name + ".bias"]
+    h = lin("initial_layer", x)
+    b = 0
+    while (prefix + "blocks.%d.linear_layers.0.weight" % b) in st:
+        t = lin("blocks.%d.linear_layers.0" % b, np.maximum(h, 0))
+        t = lin("blocks.%d.linear_layers.1" % b, np.maximum(t, 0))
+        h = h + t
+        b += 1
+    return lin("final_layer", h)
+
+
+def maf_layer(st, x, inverse, prefix="autoregressive_net."):
+    """Autoregressive.forward / .inverse (affine/autoregressive.py:24-38)."""
+    if not inverse:
+        return maf_affine(x, made_forward(st, x, prefix).astype(x.dtype), 0)
+    out = np.zeros_like(x)
+    ld = None
+    for _ in range(x.shape[1]):
+        out, ld = maf_affine(x, made_forward(st, out, prefix).astype(x.dtype), 1)
+    return out, ld
+
+
 # ---------------------------------------------------------------------------------------------------------
 class OracleNSF:
     """NormalizingFlow([CoupledRationalQuadraticSpline, LULinearPermute] * L, DiagGaussian) on the CPU oracle.

@@ -624,3 +624,21 @@ void FN(nfo_nsf_log_prob)(const REAL *x, REAL *logq, int64_t B, int D, int L, co
     }
     free(Wi); free(Wf); free(Wb); free(Lm); free(Um); free(lad);
 }
+
+
+/* affine/autoregressive.py:98-128 MaskedAffineAutoregressive._elementwise_forward (direction 0) / _inverse (1);
+ * params (B, D, 2) = (unconstrained_scale, shift). */
+void FN(nfo_maf_affine)(const REAL *x, const REAL *params, REAL *y, REAL *logdet, int64_t B, int D, int direction) {
+    int64_t b;
+    for (b = 0; b < B; ++b) {
+        REAL a = 0;
+        int j;
+        for (j = 0; j < D; ++j) {
+            const REAL u = params[(b * D + j) * 2], sh = params[(b * D + j) * 2 + 1];
+            const REAL scale = 1 / (1 + EXP(-(u + 2))) + (REAL)1e-3;
+            y[b * D + j] = direction == 0 ? scale * x[b * D + j] + sh : (x[b * D + j] - sh) / scale;
+            a += LOG(scale);
+        }
+        if (logdet) logdet[b] = direction == 0 ? a : -a;
+    }
+}

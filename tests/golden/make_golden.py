@@ -411,7 +411,25 @@ def gen_grads():
     npz("grad_model_c2mini", x=x, loss=loss.detach(), **grads, **sd(m, "sd__"))
 
 
+def gen_maf():
+    """MaskedAffineAutoregressive (affine/autoregressive.py): forward = one MADE pass, inverse = D passes."""
+    for d, hidden, B in ((20, 40, 9), (128, 512, 4)):
+        torch.manual_seed(1000 + d)
+        layer = nf.flows.MaskedAffineAutoregressive(d, hidden, num_blocks=2)
+        perturb(layer, 0.05, 8)
+        x = torch.randn(B, d, generator=torch.Generator().manual_seed(d))
+        with torch.no_grad():
+            params = layer.autoregressive_net(x)
+            zf, ldf = layer.forward(x)
+            zi, ldi = layer.inverse(x)
+        st = sd(layer, "sd__") if d == 20 else {}   # the d=128 weights are reproduced by seeded construction
+        npz("maf_d%d" % d, x=x, params=params, z_fwd=zf, ld_fwd=ldf, z_inv=zi, ld_inv=ldi, **st)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "maf":
+        gen_maf()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "grads":
         gen_grads()
         sys.exit(0)
@@ -420,3 +438,4 @@ if __name__ == "__main__":
     gen_affine()
     gen_models()
     gen_grads()
+    gen_maf()

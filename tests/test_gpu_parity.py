@@ -553,3 +553,52 @@ def test_x3_model_c2_head_vs_reference_and_exact_kernel(nfa, bf16x3):
 
 def test_x3_model_c2_full_size_properties(nfa, oracle, bf16x3):
     test_model_c2_full_size_properties(nfa, oracle)
+
+
+# ---- MAF (BASELINE configs[4]: inverse pass = D sequential MADE passes) ------------------------------------------
+def _perturb(module, sigma, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p_ in module.parameters():
+            p_.add_(sigma * torch.randn(p_.shape, generator=g, dtype=p_.dtype))
+
+
+def test_maf_layer_vs_reference(nfa, oracle):
+    g = load_golden("maf_d20")
+    layer = load_layer(nfa.flows.MaskedAffineAutoregressive(20, 40, num_blocks=2), golden_state(g), torch.float32)
+    y, ld = nfa.ops.maf_affine(T(g["x"]), T(g["params"]), 0)              # kernel alone on the reference's MADE output
+    assert_close(N(y), g["z_fwd"], what="kernel z_fwd", rtol=1e-5, atol=1e-5)
+    assert_close(N(ld), g["ld_fwd"], what="kernel ld_fwd", rtol=1e-5, atol=1e-5)
+    z, ld = layer.forward(T(g["x"]))
+    assert_close(N(z), g["z_fwd"], what="z_fwd", rtol=1e-4, atol=1e-5)
+    assert_close(N(ld), g["ld_fwd"], what="ld_fwd", rtol=1e-4, atol=1e-5)
+    z, ld = layer.inverse(T(g["x"]))
+    assert_close(N(z), g["z_inv"], what="z_inv", rtol=1e-4, atol=1e-4)
+    assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=1e-4, atol=1e-4)
+    xr, ldr = layer.forward(z)                                            # round trip (autoregressive_test.py:9-28)
+    assert_close(N(xr), g["x"], what="roundtrip", rtol=1e-4, atol=1e-4)
+
+
+def test_maf_config5_width_vs_reference(nfa):
+    """d = 128, hidden 512 (the BASELINE config-5 layer): seeded construction + the fixture's perturbation reproduce the
+    reference's weights; forward and the 128-pass inverse match its outputs."""
+    g = load_golden("maf_d128")
+    torch.manual_seed(1000 + 128)
+    layer = nfa.flows.MaskedAffineAutoregressive(128, 512, num_blocks=2)
+    _perturb(layer, 0.05, 8)
+    layer = layer.to(DEV)
+    z, ld = layer.forward(T(g["x"]))
+    assert_close(N(z), g["z_fwd"], what="z_fwd", rtol=2e-4, atol=2e-4)
+    assert_close(N(ld), g["ld_fwd"], what="ld_fwd", rtol=2e-4, atol=2e-4)
+    z, ld = layer.inverse(T(g["x"]))
+    assert_close(N(z), g["z_inv"], what="z_inv", rtol=1e-3, atol=1e-3)
+    assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=1e-3, atol=1e-3)
+    # MADE mask structure (nets/made_test.py:77-105): the product of all masks is strictly lower triangular
+    net = layer.autoregressive_net
+    total = net.initial_layer.mask
+    for blk in net.blocks:
+        for lin in blk.linear_layers:
+            total = lin.mask @ total
+    total = net.final_layer.mask @ total
+    conn = (total[0::2] > 0).float()
+    assert torch.equal(conn, torch.tril(torch.ones_like(conn), -1))

@@ -203,3 +203,17 @@ def test_whole_flow_entry_point_matches_layerwise_oracle_and_reference(oracle):
     assert np.array_equal(a, b)
     rel = np.abs(b - g["log_prob"]) / np.maximum(1.0, np.abs(g["log_prob"]))
     assert rel.max() < 1e-5
+
+
+def test_maf_layer(oracle):
+    """MaskedAffineAutoregressive forward (1 MADE pass) and inverse (D passes) vs the reference (d = 20)."""
+    g = load_golden("maf_d20")
+    st = golden_state(g)
+    params = oracle.made_forward(st, g["x"])
+    assert_close(params, g["params"], what="made", rtol=1e-4, atol=1e-5)
+    y, ld = oracle.maf_affine(g["x"], g["params"], 0)
+    assert_close(y, g["z_fwd"], what="z_fwd", rtol=1e-5, atol=1e-5)
+    assert_close(ld, g["ld_fwd"], what="ld_fwd", rtol=1e-5, atol=1e-5)
+    y, ld = oracle.maf_layer(st, g["x"], inverse=True)
+    assert_close(y, g["z_inv"], what="z_inv", rtol=1e-4, atol=1e-4)
+    assert_close(ld, g["ld_inv"], what="ld_inv", rtol=1e-4, atol=1e-4)
