@@ -33,6 +33,12 @@ constexpr int X3_FINAL_BYTES = 12288;
 constexpr int X3_FINAL_BYTES = 9216;          // final-layer stage: 3 row-blocks x 3 splits x 1 KB
 #endif
 constexpr int X3_SLOT_FLOATS = X3_SLOT_BYTES / 4;
+// The kernel consumes the blob's K-step stages in PAIRS ("super-stages": 24 KB, or 18 KB in the final layer): 8 waves
+// x 3 LDS-DMA instructions each per super-stage, one barrier per 2 K steps.
+constexpr int X3_NW = 8;
+constexpr int X3_THREADS = 64 * X3_NW;
+constexpr int X3_ROWS = 32 * X3_NW;
+constexpr int X3_RING_FLOATS = 2 * X3_SLOT_FLOATS;  // one ring slot = one super-stage
 
 // ---- x3 blob: header | small section (identical to the fp32 blob) | stages ------------------------------------
 struct X3Layout {
@@ -211,36 +217,38 @@ __device__ __forceinline__ Split3 split_regs(const f32x16 &src, int half) {  // 
 
 // DIR: 0 = density (wrapper.inverse), 1 = sample (wrapper.forward).  LU: fuse the layer's LULinearPermute.
 template <int DIR, bool LU>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(X3_THREADS, 2)
 rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ logdet,
                     const float *__restrict__ pack, int64_t B, int nblk, int par_t, RqsParams<float> p, int acc) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     X3Layout lay;
     lay.nblk = nblk;
     const FusedLayout fl = lay.f32();
-    float *ring = smem;                            // 3 x 12 KB
-    float *stash = ring + 3 * X3_SLOT_FLOATS;      // 4 waves x 32 x 64
-    float *small = stash + 4 * 32 * 64;            // biases + tables
+    float *ring = smem;                            // 3 x 24 KB
+    float *stash = ring + 3 * X3_RING_FLOATS;      // 8 waves x 32 x 64
+    float *small = stash + X3_NW * 32 * 64;        // biases + tables
     const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t row = (int64_t)blockIdx.x * 128 + wid * 32 + (lane & 31);
+    const int64_t row = (int64_t)blockIdx.x * X3_ROWS + wid * 32 + (lane & 31);
     const bool valid = row < B;
     const int par_i = par_t ^ 1;
     const char *stages = reinterpret_cast<const char *>(pack) + lay.off_stage_bytes();
     const int nbase = lay.n_base();
-    const int nstages = nbase + (LU ? 2 : 0);
+    const int nstages = nbase + (LU ? 2 : 0);  // in K-step stages; the kernel walks them two at a time
+    (void)nstages;
     float *st = stash + wid * 2048 + lane;
 
     // logical stage -> byte offset and shape (wide: 12 KB stage = 12 x 1 KB pieces; else 9 KB = 12 x 768 B pieces)
-    auto stage_off = [&](int s, bool &wide) -> int64_t {
+    auto stage_off = [&](int S, bool &wide) -> int64_t {
+        const int s = 2 * S;  // first K-step stage of the pair (pairs are contiguous in the blob)
         int b = s;
         if (LU && DIR == 0) {
-            if (s < 2) { wide = true; return lay.off_lu(0) + (int64_t)s * X3_SLOT_BYTES; }
+            if (s < 2) { wide = true; return lay.off_lu(0); }
             b = s - 2;
         }
         if (b >= nbase) {
             wide = true;
-            if (LU && DIR == 1 && b < nbase + 2) return lay.off_lu(1) + (int64_t)(b - nbase) * X3_SLOT_BYTES;
+            if (LU && DIR == 1 && b < nbase + 2) return lay.off_lu(1);
             return lay.off_pad();  // prefetch past the end lands in padding
         }
 #ifdef NF_X3_WIDE_FINAL
@@ -254,16 +262,16 @@ rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *_
     auto issue = [&](int s) {
         bool wide;
         const char *src = stages + stage_off(s, wide);
-        float *slot = ring + (s % 3) * X3_SLOT_FLOATS;
+        float *slot = ring + (s % 3) * X3_RING_FLOATS;
         if (wide) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int piece = wid * 3 + i;  // 12 pieces of 1 KB
+                const int piece = wid * 3 + i;  // 24 pieces of 1 KB
                 __builtin_amdgcn_global_load_lds(src + piece * 1024 + lane * 16,
                                                  (__attribute__((address_space(3))) void *)((char *)slot + piece * 1024), 16, 0, 0);
             }
         } else {
-            // 9 KB stage as 12 pieces of 768 B: 16-byte DMA with 48 active lanes (the 12-byte-per-lane form of
+            // 18 KB super-stage as 24 pieces of 768 B: 16-byte DMA with 48 active lanes (the 12-byte-per-lane form of
             // global_load_lds did not produce a contiguous LDS image on gfx950; every wave still issues 3 DMAs)
             if (lane < 48) {
 #pragma unroll
@@ -288,7 +296,7 @@ rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *_
 #ifndef NF_ABL_NODMA
         issue(stage + 2);
 #endif
-        const unsigned short *buf = reinterpret_cast<const unsigned short *>(ring + (stage % 3) * X3_SLOT_FLOATS);
+        const unsigned short *buf = reinterpret_cast<const unsigned short *>(ring + (stage % 3) * X3_RING_FLOATS);
         ++stage;
         return buf;
     };
@@ -309,7 +317,7 @@ rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *_
             xin[8 * Q + 4 + c] = b[c];
         }
     }
-    for (int i = tid; i < fl.small_floats(); i += 256) small[i] = pack[F_HDR + i];
+    for (int i = tid; i < fl.small_floats(); i += X3_THREADS) small[i] = pack[F_HDR + i];
     issue(0);
     issue(1);
     __syncthreads();  // small section visible to all waves
@@ -323,17 +331,16 @@ rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *_
     if (LU && DIR == 0) {
         const float *bsrc = small + fl.off_bias_lu(0) + hh * 16;
         f32x16 o0 = load_bias16(bsrc), o1 = load_bias16(bsrc + 32);
+        {
+            const unsigned short *buf = acquire();  // 4 K steps: [t][m][split][lane][8]
 #pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-            const unsigned short *buf = acquire();  // K steps 2 sp, 2 sp + 1: [t&1][m][split][lane][8]
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl) {
+            for (int t = 0; t < 4; ++t) {
                 float v[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = xin[8 * (2 * sp + tl) + i];
+                for (int i = 0; i < 8; ++i) v[i] = xin[8 * t + i];
                 const Split3 b = split8(v);
-                mm_x3(buf + ((tl * 2 + 0) * 3) * 512, lane, b, o0);
-                mm_x3(buf + ((tl * 2 + 1) * 3) * 512, lane, b, o1);
+                mm_x3(buf + ((t * 2 + 0) * 3) * 512, lane, b, o0);
+                mm_x3(buf + ((t * 2 + 1) * 3) * 512, lane, b, o1);
             }
         }
 #pragma unroll
@@ -378,9 +385,10 @@ rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *_
         H1 = load_bias16(bsrc + 32);
         H2 = load_bias16(bsrc + 64);
         H3 = load_bias16(bsrc + 96);
+        const unsigned short *buf2 = acquire();
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const unsigned short *buf = acquire();
+            const unsigned short *buf = buf2 + t * (X3_SLOT_BYTES / 2);
             float v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = bx[8 * t + i];
@@ -400,11 +408,14 @@ rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *_
             T3 = load_bias16(bsrc + 96);
         }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const unsigned short *buf = acquire();
-            const f32x16 &src = (t >> 1) == 0 ? H0 : ((t >> 1) == 1 ? H1 : ((t >> 1) == 2 ? H2 : H3));
-            const Split3 b = split_regs<true>(src, t & 1);
-            mm_x3_4(buf, lane, b, T0, T1, T2, T3);
+        for (int tp = 0; tp < 4; ++tp) {
+            const unsigned short *buf2 = acquire();
+            const f32x16 &src = tp == 0 ? H0 : (tp == 1 ? H1 : (tp == 2 ? H2 : H3));
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+                const Split3 b = split_regs<true>(src, tl);
+                mm_x3_4(buf2 + tl * (X3_SLOT_BYTES / 2), lane, b, T0, T1, T2, T3);
+            }
         }
         {
             const float *bsrc = small + fl.off_bias_hidden(2 * blk + 1) + hh * 16;
@@ -414,11 +425,14 @@ rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *_
             H3 += load_bias16(bsrc + 96);
         }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const unsigned short *buf = acquire();
-            const f32x16 &src = (t >> 1) == 0 ? T0 : ((t >> 1) == 1 ? T1 : ((t >> 1) == 2 ? T2 : T3));
-            const Split3 b = split_regs<true>(src, t & 1);
-            mm_x3_4(buf, lane, b, H0, H1, H2, H3);
+        for (int tp = 0; tp < 4; ++tp) {
+            const unsigned short *buf2 = acquire();
+            const f32x16 &src = tp == 0 ? T0 : (tp == 1 ? T1 : (tp == 2 ? T2 : T3));
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+                const Split3 b = split_regs<true>(src, tl);
+                mm_x3_4(buf2 + tl * (X3_SLOT_BYTES / 2), lane, b, H0, H1, H2, H3);
+            }
         }
     }
 
@@ -472,9 +486,10 @@ rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *_
         A1 = load_bias16(bsrc + 32);
         A2 = load_bias16(bsrc + 64);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const unsigned short *buf = acquire();  // [rb (3)][split (3)][lane][8]
-            mm_x3_3(buf, lane, hs[t], A0, A1, A2);
+        for (int tp = 0; tp < 4; ++tp) {
+            const unsigned short *buf2 = acquire();  // 2 K steps x [rb (3)][split (3)][lane][8]
+            mm_x3_3(buf2, lane, hs[2 * tp], A0, A1, A2);
+            mm_x3_3(buf2 + X3_FINAL_BYTES / 2, lane, hs[2 * tp + 1], A0, A1, A2);
         }
     };
     {
@@ -503,17 +518,16 @@ rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *_
     if (LU && DIR == 1) {
         const float *bsrc = small + fl.off_bias_lu(1) + hh * 16;
         f32x16 o0 = load_bias16(bsrc), o1 = load_bias16(bsrc + 32);
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
+        {
             const unsigned short *buf = acquire();
 #pragma unroll
-            for (int tl = 0; tl < 2; ++tl) {
+            for (int t = 0; t < 4; ++t) {
                 float v[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = yout[8 * (2 * sp + tl) + i];
+                for (int i = 0; i < 8; ++i) v[i] = yout[8 * t + i];
                 const Split3 b = split8(v);
-                mm_x3(buf + ((tl * 2 + 0) * 3) * 512, lane, b, o0);
-                mm_x3(buf + ((tl * 2 + 1) * 3) * 512, lane, b, o1);
+                mm_x3(buf + ((t * 2 + 0) * 3) * 512, lane, b, o0);
+                mm_x3(buf + ((t * 2 + 1) * 3) * 512, lane, b, o1);
             }
         }
 #pragma unroll
@@ -547,8 +561,8 @@ static int launch_x3(const void *x, void *y, void *logdet, const void *wpack, in
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&rqs_fused_x3_kernel<DIR, LU>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return NF_ENOTSUP;
-    const int grid = (int)((B + 127) / 128);
-    hipLaunchKernelGGL((rqs_fused_x3_kernel<DIR, LU>), dim3(grid), dim3(256), lds, st, (const float *)x, (float *)y,
+    const int grid = (int)((B + X3_ROWS - 1) / X3_ROWS);
+    hipLaunchKernelGGL((rqs_fused_x3_kernel<DIR, LU>), dim3(grid), dim3(X3_THREADS), lds, st, (const float *)x, (float *)y,
                        (float *)logdet, (const float *)wpack, B, num_blocks, par_t, p, acc);
     NF_CHECK_LAUNCH();
     return NF_OK;
@@ -615,8 +629,8 @@ extern "C" int nf_rqs_fused_x3(const void *x, void *y, void *logdet, const void 
     lay.nblk = num_blocks;
     auto p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
                                     min_derivative, sqrt((double)hidden));
-    const size_t lds = (size_t)(3 * X3_SLOT_FLOATS + 4 * 32 * 64 + lay.f32().small_floats()) * sizeof(float);
-    if (lds > 80 * 1024) return NF_ENOTSUP;
+    const size_t lds = (size_t)(3 * X3_RING_FLOATS + X3_NW * 32 * 64 + lay.f32().small_floats()) * sizeof(float);
+    if (lds > 160 * 1024) return NF_ENOTSUP;
     const int par_t = mask_parity == 0 ? 1 : 0;
     if (direction == 0)
         return fuse_lu ? launch_x3<0, true>(x, y, logdet, x3pack, B, num_blocks, par_t, p, acc, lds, st)
