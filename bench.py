@@ -94,39 +94,26 @@ def _events_ms(fn, reps):
 
 def kernel_breakdown(model, x, reps=5):
     """HIP-event timing of the launches of one eager log_prob pass (instrumented run, NOT the timed region).
-    The 32 fused [LULinearPermute + CoupledRQS] launches are issued back to back between ONE event pair recorded on
-    torch's current stream (= the stream the C ABI launches on), so the quotient is the kernel's average duration
-    (a 190 us kernel hides the ~5 us host launch cost; bracketing every launch separately would add the launch
-    latency to each sample).  Returns {name: (avg_ms, launches_per_pass)}."""
+    All fused [LULinearPermute + CoupledRQS] layer pairs of the model run as ONE persistent launch of
+    nf::rqs_fused_kernel<0, true> (core.run_chain -> nf_rqs_fused_chain); it is bracketed by one event pair recorded on
+    torch's current stream (= the stream the C ABI launches on).  Returns {name: (avg_ms, launches_per_pass, layers)}."""
     import normflows_amd as nfa
+    from normflows_amd.core import run_chain
     flows = list(model.flows)
-    pairs = []
-    i = len(flows) - 1
-    while i >= 0:
-        f = flows[i]
-        if (i > 0 and isinstance(f, nfa.flows.LULinearPermute)
-                and isinstance(flows[i - 1], nfa.flows.CoupledRationalQuadraticSpline)
-                and flows[i - 1]._pair_eligible(x, f)):
-            flows[i - 1].prqct._fused_blob(f)  # one-off packing stays outside the timed launches
-            pairs.append((flows[i - 1], f))
-            i -= 2
-        else:
-            i -= 1
-    out = {"rqs_fused_pair": (0.0, 0), "diag_gaussian": (0.0, 1)}
-    if pairs:
-        def chain():
-            z = x
-            log_q = torch.zeros(len(x), device=x.device)
-            for c, f in pairs:
-                z = c._run_pair(z, f, True, log_q, +1)
-            return z, log_q
-        chain()
-        avg, med = _events_ms(lambda: chain(), reps)
-        out["rqs_fused_pair"] = (med / len(pairs), len(pairs))
-    z = x
-    log_q = torch.zeros(len(x), device=x.device)
+    npairs = sum(1 for i in range(1, len(flows)) if isinstance(flows[i], nfa.flows.LULinearPermute)
+                 and isinstance(flows[i - 1], nfa.flows.CoupledRationalQuadraticSpline)
+                 and flows[i - 1]._pair_eligible(x, flows[i]))
+    out = {}
+
+    def chain():
+        log_q = torch.zeros(len(x), device=x.device)
+        return run_chain(flows, x, True, log_q, +1), log_q
+
+    z, log_q = chain()  # one-off weight packing stays outside the timed launches
+    avg, med = _events_ms(lambda: chain(), reps)
+    out["rqs_fused_chain"] = (med, 1 if npairs == len(flows) // 2 else None, npairs)
     avg, med = _events_ms(lambda: model.q0._log_prob_acc(z, log_q, +1), reps)
-    out["diag_gaussian"] = (med, 1)
+    out["diag_gaussian"] = (med, 1, 0)
     return out
 
 
@@ -249,16 +236,20 @@ def main():
             with torch.no_grad():
                 bd = kernel_breakdown(model, x)
             model.use_graphs(not args.no_graph)
-            out["kernel_ms"] = {k: {"avg_ms": v[0], "launches_per_pass": v[1]} for k, v in bd.items()}
-            pair_ms = bd["rqs_fused_pair"][0]
-            if pair_ms > 0:
-                # dominant kernel: nf::rqs_fused_kernel<0, true>.  Algorithmic FLOPs per launch:
-                # (327 680 conditioner + 16 384 LU) FLOP per sample-layer x rows per launch; MFMA-bound.
-                fl = (c2_flops_per_sample(layers=1)) * args.batch
-                ach = fl / (pair_ms * 1e-3) / 1e12
+            out["kernel_ms"] = {k: {"avg_ms": v[0], "launches_per_pass": v[1], "layer_pairs_per_launch": v[2]}
+                                for k, v in bd.items()}
+            chain_ms, _, npairs = bd["rqs_fused_chain"]
+            if npairs:
+                # dominant kernel: nf::rqs_fused_kernel<0, true>, ONE persistent launch over all layer pairs.
+                # Algorithmic FLOPs per launch: (327 680 conditioner + 16 384 LU) FLOP per sample and layer
+                # pair x rows x pairs; MFMA-bound (exact-fp32 MFMA, 157.3 TFLOP/s peak).  chain_ms also contains the
+                # torch.zeros fill of log_q (one 256 KB memset).
+                fl = c2_flops_per_sample(layers=npairs) * args.batch
+                ach = fl / (chain_ms * 1e-3) / 1e12
+                tr = pmc_traffic()
                 out["roofline"] = {"kernel": "nf::rqs_fused_kernel<0, true>", "bound": "mfma", "achieved": ach,
-                                   "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": pmc_traffic(),
-                                   "flop_per_launch": fl, "avg_launch_ms": pair_ms,
+                                   "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": tr,
+                                   "flop_per_launch": fl, "avg_launch_ms": chain_ms, "layer_pairs_per_launch": npairs,
                                    "hbm_algorithmic_bytes_per_launch": (2 * DIM * 4 + 8) * args.batch}
         if not args.no_breakdown:
             # secondary (SURVEY.md 8d reports both directions): generative pass = every layer's forward + log_q

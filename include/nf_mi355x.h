@@ -143,6 +143,14 @@ int nf_rqs_fused_pack_lu(void *wpack, int num_blocks, const int64_t *perm, const
 int nf_rqs_fused(const void *x, void *y, void *logdet, const void *wpack, int mask_parity, int fuse_lu, int64_t B,
                  int D, int hidden, int num_blocks, int K, double tail_bound, double min_bin_width,
                  double min_bin_height, double min_derivative, int direction, int acc, nf_stream_t stream);
+/* A chain of num_layers (<= 64) fused layers of identical shape in ONE persistent launch: replaces num_layers
+ * iterations of the container loops normflows/core.py:177-179 / :193-195.  wpacks / mask_parities are HOST arrays in
+ * PROCESSING order (for log_prob: last flow first).  The rows stay on chip between layers (x read once, y written once,
+ * the accumulated log-det written once). */
+int nf_rqs_fused_chain(const void *x, void *y, void *logdet, const void *const *wpacks, const int *mask_parities,
+                       int num_layers, int fuse_lu, int64_t B, int D, int hidden, int num_blocks, int K,
+                       double tail_bound, double min_bin_width, double min_bin_height, double min_derivative,
+                       int direction, int acc, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * The same fused layer with the GEMMs on the bf16 matrix pipe by error-compensated splitting

@@ -20,34 +20,66 @@ from .flows.mixing import LULinearPermute
 from .flows.neural_spline import CoupledRationalQuadraticSpline
 
 
+def _pair_signature(crqs):
+    p = crqs.prqct
+    return (p.features, p.transform_net.hidden_features, len(p.transform_net.blocks), p.num_bins, p.tail_bound,
+            p.min_bin_width, p.min_bin_height, p.min_derivative)
+
+
+def _run_pairs(pairs, z, inverse, ld, acc):
+    """`pairs` = [(CoupledRQS, LULinearPermute), ...] in processing order, all of one shape: one persistent launch
+    (exact-fp32 kernel) or one launch per pair (bf16x3 variant)."""
+    from . import config, ops
+    if config.fused_gemm != "f32" or len(pairs) == 1:
+        for c, lu in pairs:
+            z = c._run_pair(z, lu, inverse, ld, acc)
+        return z
+    feats, hidden, nblk, K, tb, mw, mh, md = _pair_signature(pairs[0][0])
+    for i in range(0, len(pairs), 64):
+        chunk = pairs[i:i + 64]
+        blobs = [c.prqct._fused_blob(lu) for c, lu in chunk]
+        pars = [c.prqct._fused_parity for c, lu in chunk]
+        z, _ = ops.rqs_fused_chain(z, blobs, pars, hidden, nblk, K, 0 if inverse else 1, logdet=ld, acc=acc, tail_bound=tb,
+                                   min_bin_width=mw, min_bin_height=mh, min_derivative=md, fuse_lu=True)
+    return z
+
+
 def run_chain(flows, z, inverse, ld, acc):
     """Run a list of flows in order (inverse=False) or reversed with .inverse (inverse=True), folding log-dets into
-    `ld`.  Adjacent [CoupledRationalQuadraticSpline, LULinearPermute] pairs of the supported shape are issued as one
-    fused kernel (csrc/rqs_fused.hip); everything else goes layer by layer."""
+    `ld`.  Adjacent [CoupledRationalQuadraticSpline, LULinearPermute] pairs of the supported shape are fused
+    (csrc/rqs_fused.hip) and consecutive fused pairs of one shape run as ONE persistent launch; everything else goes
+    layer by layer."""
     n = len(flows)
-    if inverse:
-        i = n - 1
-        while i >= 0:
-            f = flows[i]
-            if (i > 0 and isinstance(f, LULinearPermute) and isinstance(flows[i - 1], CoupledRationalQuadraticSpline)
-                    and flows[i - 1]._pair_eligible(z, f)):
-                z = flows[i - 1]._run_pair(z, f, True, ld, acc)
-                i -= 2
-            else:
-                z = run_flow(f, z, True, ld, acc)
-                i -= 1
-    else:
-        i = 0
-        while i < n:
-            f = flows[i]
-            if (i + 1 < n and isinstance(f, CoupledRationalQuadraticSpline) and isinstance(flows[i + 1], LULinearPermute)
-                    and f._pair_eligible(z, flows[i + 1])):
-                z = f._run_pair(z, flows[i + 1], False, ld, acc)
-                i += 2
-            else:
-                z = run_flow(f, z, False, ld, acc)
-                i += 1
-    return z
+    order = list(range(n - 1, -1, -1)) if inverse else list(range(n))
+    k = 0
+    pending = []  # consecutive fusable pairs of one shape
+
+    def flush(zz):
+        if pending:
+            zz = _run_pairs(list(pending), zz, inverse, ld, acc)
+            pending.clear()
+        return zz
+
+    while k < n:
+        i = order[k]
+        f = flows[i]
+        pair = None
+        if k + 1 < n:
+            j = order[k + 1]
+            a, b = (flows[j], f) if inverse else (f, flows[j])   # a = CoupledRQS candidate, b = LU candidate
+            if (isinstance(a, CoupledRationalQuadraticSpline) and isinstance(b, LULinearPermute)
+                    and a._pair_eligible(z, b)):
+                pair = (a, b)
+        if pair is not None:
+            if pending and _pair_signature(pending[0][0]) != _pair_signature(pair[0]):
+                z = flush(z)
+            pending.append(pair)
+            k += 2
+        else:
+            z = flush(z)
+            z = run_flow(f, z, inverse, ld, acc)
+            k += 1
+    return flush(z)
 
 
 class _GraphCache:

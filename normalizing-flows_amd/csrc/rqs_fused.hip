@@ -275,27 +275,36 @@ constexpr int F_NW = NF_FUSED_WAVES;
 constexpr int F_THREADS = 64 * F_NW;
 constexpr int F_ROWS = 32 * F_NW;
 
-// DIR: 0 = density (wrapper.inverse), 1 = sample (wrapper.forward).  LU: fuse the layer's LULinearPermute
+// A chain of up to F_MAX_LAYERS fused layers handled by ONE persistent launch: the workgroup keeps its 256 rows in the
+// LDS stash across all layers (x is read from HBM once, y written once, the log-det lives in a register), the weight
+// stream runs straight through the layer boundaries and the next layer's small section is DMA-prefetched.
+constexpr int F_MAX_LAYERS = 64;
+struct FlowArgs {
+    const float *blob[F_MAX_LAYERS];  // packed blobs in PROCESSING order
+    unsigned long long parity;        // bit l: mask parity of layer l (0: transform features on odd columns)
+    int nlayers;
+};
+
+// DIR: 0 = density (wrapper.inverse), 1 = sample (wrapper.forward).  LU: fuse each layer's LULinearPermute
 // (density: LULinearPermute.inverse BEFORE the coupling; sample: LULinearPermute.forward AFTER it).
 template <int DIR, bool LU>
 __global__ void __launch_bounds__(F_THREADS, 2)
-rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ logdet,
-                 const float *__restrict__ pack, int64_t B, int nblk, int par_t /* column parity of transform features */,
-                 RqsParams<float> p, float inv_div, int acc) {
+rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ logdet, FlowArgs fa,
+                 int64_t B, int nblk, RqsParams<float> p, int acc) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     FusedLayout lay;
     lay.nblk = nblk;
     float *ring = smem;                       // 2 x 4096
     float *stash = ring + 2 * F_STAGE;        // F_NW waves x 32 x 64
-    float *small = stash + F_NW * 32 * 64;    // biases + tables
+    float *small2 = stash + F_NW * 32 * 64;   // 2 x small_padded: biases + tables of the current / next layer
+    const int small_pitch = lay.small_padded();
     const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases are wave-uniform
     const int64_t row = (int64_t)blockIdx.x * F_ROWS + wid * 32 + (lane & 31);
     const bool valid = row < B;
-    const int par_i = par_t ^ 1;
-    const float *stages = pack + lay.off_stages();
     const int nbase = lay.nstages(false);
     const int nstages = lay.nstages(LU);
+    const int total_stages = nstages * fa.nlayers;
     // logical -> physical stage: the LU stage comes first in the density direction, last in the sample direction
     auto phys = [&](int s) -> int {
         if (!LU) return s;
@@ -304,15 +313,23 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     };
     float *st = stash + wid * 2048 + lane;  // value c (0..31) of this lane at st[c * 64]; c = 8 Q + column-in-chunk
 
-    // ---- weight-stream helpers (2-slot ring, global -> LDS DMA) ----
+    // ---- weight-stream helpers (2-slot ring, global -> LDS DMA); the stage counter runs across layers ----
     int stage = 0;
-    auto issue = [&](int s) {
+    auto issue = [&](int gs) {
         constexpr int PPW = 16 / F_NW;  // 1 KB pieces per wave (16 per stage)
-        const float *src = stages + (size_t)phys(s) * F_STAGE + (wid * PPW) * 256 + lane * 4;
-        float *dst = ring + (s & 1) * F_STAGE + (wid * PPW) * 256;
+        const int layer = gs / nstages, s = gs - layer * nstages;
+        const float *src = fa.blob[layer] + lay.off_stages() + (size_t)phys(s) * F_STAGE + (wid * PPW) * 256 + lane * 4;
+        float *dst = ring + (gs & 1) * F_STAGE + (wid * PPW) * 256;
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
             __builtin_amdgcn_global_load_lds(src + i * 256, (__attribute__((address_space(3))) void *)(dst + i * 256), 16, 0, 0);
+    };
+    auto issue_small = [&](int layer) {  // small section of `layer` -> LDS buffer layer & 1 (1 KB pieces round-robin)
+        const float *src = fa.blob[layer] + F_HDR;
+        float *dst = small2 + (layer & 1) * small_pitch;
+        for (int piece = wid; piece * 256 < small_pitch; piece += F_NW)
+            __builtin_amdgcn_global_load_lds(src + piece * 256 + lane * 4,
+                                             (__attribute__((address_space(3))) void *)(dst + piece * 256), 16, 0, 0);
     };
     auto acquire = [&]() -> const float * {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -320,17 +337,16 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
         __syncthreads();
 #endif
 #ifndef NF_ABL_NODMA
-        if (stage + 1 < nstages) issue(stage + 1);
+        if (stage + 1 < total_stages) issue(stage + 1);
 #endif
         const float *buf = ring + (stage & 1) * F_STAGE;
         ++stage;
         return buf;
     };
 
-    // ---- prologue: x rows -> LDS stash, small section -> LDS, first stage in flight ----
+    // ---- prologue: first stage and first small section in flight, x rows -> LDS stash ----
     issue(0);
-    for (int i = tid; i < lay.small_floats(); i += F_THREADS) small[i] = pack[F_HDR + i];
-    float xin[32];  // the lane's 32 row values, slot c = 8 Q + column-in-chunk
+    issue_small(0);
 #pragma unroll
     for (int Q = 0; Q < 4; ++Q) {
         f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
@@ -341,28 +357,43 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            xin[8 * Q + c] = a[c];
-            xin[8 * Q + 4 + c] = b[c];
+            st[(8 * Q + c) * 64] = a[c];
+            st[(8 * Q + 4 + c) * 64] = b[c];
         }
     }
-    __syncthreads();
     float ld = 0.0f;
+
+    for (int layer = 0; layer < fa.nlayers; ++layer) {
+    const float *small = small2 + (layer & 1) * small_pitch;
+    const int par_t = ((fa.parity >> layer) & 1ull) ? 0 : 1;  // column parity of the transform features
+    const int par_i = par_t ^ 1;
+    const float lu_lad = LU ? fa.blob[layer][3] : 0.0f;       // constant log|det| of the layer's LU (header word 3)
+    if (layer > 0 || !LU || DIR == 1) {
+        // the small section must have landed before its first use; in the LU-first (density) order of layer 0 the
+        // acquire() below does it.  (Later layers' sections were issued a whole layer ago.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     if (LU && DIR == 0) {
         // LULinearPermute.inverse (mixing.py:560-563) as one dense 64 x 64 product on MFMA; C register `reg` of
         // row-block m is the new value of slot 16 m + reg
+        float xin[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) xin[c] = st[c * 64];
+        const float *buf = acquire();  // also publishes this layer's small section
         const float *bsrc = small + lay.off_bias_lu(0) + hh * 16;
         f32x16 o0 = load_bias16(bsrc), o1 = load_bias16(bsrc + 32);
-        lu_mm(acquire(), lane, xin, o0, o1);
+        lu_mm(buf, lane, xin, o0, o1);
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             st[c * 64] = o0[c];
             st[(16 + c) * 64] = o1[c];
         }
-        if (hh == 0) ld += pack[3];  // constant log|det| of the LU layer, once per sample
-    } else {
-#pragma unroll
-        for (int c = 0; c < 32; ++c) st[c * 64] = xin[c];
+        if (hh == 0) ld += lu_lad;  // once per sample (the two lane halves are summed at the end)
     }
+    // prefetch the NEXT layer's small section into the other buffer (its previous user, layer - 1, is done: every
+    // wave has passed a barrier of this layer)
+    if (layer + 1 < fa.nlayers) issue_small(layer + 1);
 
     // ---- unconditional spline on the identity half (nsf/coupling.py:88-92 density / :112-116 sample) ----
     // sample: CDF^-1 first, its output feeds the conditioner.  density: the conditioner sees the raw values; the CDF
@@ -530,31 +561,33 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     element(7, 1, prm1);
     if (DIR == 0) uncond_pair(7);
 
-    // ---- epilogue: rows back to HBM, per-sample log-det (both lane halves of a sample) ----
-    ld += __shfl_xor(ld, 32, 64);
-    float yout[32];
-#pragma unroll
-    for (int c = 0; c < 32; ++c) yout[c] = st[c * 64];
     if (LU && DIR == 1) {
         // LULinearPermute.forward (mixing.py:555-558): triangular solves + inverse permutation as one dense product
+        float yin[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) yin[c] = st[c * 64];
         const float *bsrc = small + lay.off_bias_lu(1) + hh * 16;
         f32x16 o0 = load_bias16(bsrc), o1 = load_bias16(bsrc + 32);
-        lu_mm(acquire(), lane, yout, o0, o1);
+        lu_mm(acquire(), lane, yin, o0, o1);
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-            yout[c] = o0[c];
-            yout[16 + c] = o1[c];
+            st[c * 64] = o0[c];
+            st[(16 + c) * 64] = o1[c];
         }
-        ld -= pack[3];
+        if (hh == 0) ld -= lu_lad;
     }
+    }  // layers
+
+    // ---- epilogue: rows back to HBM, per-sample log-det (both lane halves of a sample) ----
+    ld += __shfl_xor(ld, 32, 64);
     if (valid) {
 #pragma unroll
         for (int Q = 0; Q < 4; ++Q) {
             f32x4 a, b;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                a[c] = yout[8 * Q + c];
-                b[c] = yout[8 * Q + 4 + c];
+                a[c] = st[(8 * Q + c) * 64];
+                b[c] = st[(8 * Q + 4 + c) * 64];
             }
             float *dst = y + row * F_D + 16 * Q + 8 * hh;
             *reinterpret_cast<f32x4 *>(dst) = a;
@@ -634,39 +667,58 @@ extern "C" int nf_rqs_fused_pack_lu(void *wpack, int num_blocks, const int64_t *
 }
 
 template <int DIR, bool LU>
-static int launch_fused(const void *x, void *y, void *logdet, const void *wpack, int64_t B, int num_blocks, int par_t,
-                        const RqsParams<float> &p, float inv_div, int acc, size_t lds, hipStream_t st) {
+static int launch_fused(const void *x, void *y, void *logdet, const FlowArgs &fa, int64_t B, int num_blocks,
+                        const RqsParams<float> &p, int acc, size_t lds, hipStream_t st) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&rqs_fused_kernel<DIR, LU>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return NF_ENOTSUP;
     const int grid = (int)((B + F_ROWS - 1) / F_ROWS);
     hipLaunchKernelGGL((rqs_fused_kernel<DIR, LU>), dim3(grid), dim3(F_THREADS), lds, st, (const float *)x, (float *)y,
-                       (float *)logdet, (const float *)wpack, B, num_blocks, par_t, p, inv_div, acc);
+                       (float *)logdet, fa, B, num_blocks, p, acc);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
 
-extern "C" int nf_rqs_fused(const void *x, void *y, void *logdet, const void *wpack, int mask_parity, int fuse_lu,
-                            int64_t B, int D, int hidden, int num_blocks, int K, double tail_bound, double min_bin_width,
-                            double min_bin_height, double min_derivative, int direction, int acc, nf_stream_t stream) {
+extern "C" int nf_rqs_fused_chain(const void *x, void *y, void *logdet, const void *const *wpacks,
+                                  const int *mask_parities, int num_layers, int fuse_lu, int64_t B, int D, int hidden,
+                                  int num_blocks, int K, double tail_bound, double min_bin_width, double min_bin_height,
+                                  double min_derivative, int direction, int acc, nf_stream_t stream) {
     if (D != F_D || hidden != F_H || K != F_K || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
-    if (B < 0 || (direction != 0 && direction != 1) || (mask_parity != 0 && mask_parity != 1)) return NF_EINVAL;
+    if (num_layers < 1 || num_layers > F_MAX_LAYERS) return NF_ERANGE;
+    if (B < 0 || (direction != 0 && direction != 1)) return NF_EINVAL;
     if (acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
     if (B == 0) return NF_OK;
-    if (!x || !y || !logdet || !wpack) return NF_EFAULT;
+    if (!x || !y || !logdet || !wpacks || !mask_parities) return NF_EFAULT;
+    FlowArgs fa;
+    fa.parity = 0ull;
+    fa.nlayers = num_layers;
+    for (int l = 0; l < F_MAX_LAYERS; ++l) fa.blob[l] = nullptr;
+    for (int l = 0; l < num_layers; ++l) {
+        if (!wpacks[l]) return NF_EFAULT;
+        if (mask_parities[l] != 0 && mask_parities[l] != 1) return NF_EINVAL;
+        fa.blob[l] = (const float *)wpacks[l];
+        if (mask_parities[l]) fa.parity |= 1ull << l;
+    }
     hipStream_t st = (hipStream_t)stream;
     FusedLayout lay;
     lay.nblk = num_blocks;
     auto p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
                                     min_derivative, sqrt((double)hidden));
-    const float inv_div = (float)(1.0 / sqrt((double)hidden));
-    const size_t lds = (size_t)(2 * F_STAGE + F_NW * 32 * 64 + lay.small_floats()) * sizeof(float);
+    const size_t lds = (size_t)(2 * F_STAGE + F_NW * 32 * 64 + 2 * lay.small_padded()) * sizeof(float);
     if (lds > 160 * 1024) return NF_ENOTSUP;
-    // transform features sit on odd columns for reverse_mask = False (mask_parity 0), on even columns otherwise
-    const int par_t = mask_parity == 0 ? 1 : 0;
     if (direction == 0)
-        return fuse_lu ? launch_fused<0, true>(x, y, logdet, wpack, B, num_blocks, par_t, p, inv_div, acc, lds, st)
-                       : launch_fused<0, false>(x, y, logdet, wpack, B, num_blocks, par_t, p, inv_div, acc, lds, st);
-    return fuse_lu ? launch_fused<1, true>(x, y, logdet, wpack, B, num_blocks, par_t, p, inv_div, acc, lds, st)
-                   : launch_fused<1, false>(x, y, logdet, wpack, B, num_blocks, par_t, p, inv_div, acc, lds, st);
+        return fuse_lu ? launch_fused<0, true>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st)
+                       : launch_fused<0, false>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st);
+    return fuse_lu ? launch_fused<1, true>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st)
+                   : launch_fused<1, false>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st);
+}
+
+extern "C" int nf_rqs_fused(const void *x, void *y, void *logdet, const void *wpack, int mask_parity, int fuse_lu,
+                            int64_t B, int D, int hidden, int num_blocks, int K, double tail_bound, double min_bin_width,
+                            double min_bin_height, double min_derivative, int direction, int acc, nf_stream_t stream) {
+    const void *packs[1] = {wpack};
+    const int par[1] = {mask_parity};
+    if (!wpack) return NF_EFAULT;
+    return nf_rqs_fused_chain(x, y, logdet, packs, par, 1, fuse_lu, B, D, hidden, num_blocks, K, tail_bound, min_bin_width,
+                              min_bin_height, min_derivative, direction, acc, stream);
 }

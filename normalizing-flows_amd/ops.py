@@ -369,3 +369,29 @@ def maf_affine(x, params, direction, logdet=None, acc=None, want_logdet=True):
                                i32(L.dtype_code(x)), L.stream())
     L.check(rc, "nf_maf_affine")
     return y, logdet
+
+
+def rqs_fused_chain(x, blobs, parities, hidden, num_blocks, K, direction, logdet=None, acc=None, tail_bound=3.0,
+                    min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, fuse_lu=True):
+    """Up to 64 fused layers of identical shape in ONE persistent launch (nf_rqs_fused_chain).  `blobs` / `parities`
+    are in processing order."""
+    import ctypes
+    L.require_device(x, *blobs)
+    if x.dtype != torch.float32:
+        raise TypeError("nf_rqs_fused_chain is fp32 only")
+    x = x.contiguous()
+    B, D = x.shape
+    y = torch.empty_like(x)
+    if logdet is None:
+        logdet = torch.empty(B, dtype=x.dtype, device=x.device)
+        acc = L.LD_WRITE
+    elif acc is None:
+        acc = L.LD_ADD
+    n = len(blobs)
+    bp = (ctypes.c_void_p * n)(*[b.data_ptr() for b in blobs])
+    pp = (ctypes.c_int * n)(*[int(v) for v in parities])
+    rc = L.lib().nf_rqs_fused_chain(ptr(x), ptr(y), ptr(logdet), bp, pp, i32(n), i32(int(fuse_lu)), i64(B), i32(D),
+                                    i32(hidden), i32(num_blocks), i32(K), f64(tail_bound), f64(min_bin_width),
+                                    f64(min_bin_height), f64(min_derivative), i32(direction), i32(acc), L.stream())
+    L.check(rc, "nf_rqs_fused_chain")
+    return y, logdet
