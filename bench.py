@@ -123,8 +123,8 @@ def pmc_traffic():
     passes, KB -> bytes, FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM).  None when no summary is present;
     counters cannot be read from inside the timed process."""
     import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
-    for path in reversed(cands):
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=lambda q: ("chain" in q, q))
+    for path in reversed(cands):  # the persistent-chain profile (the kernel as benchmarked) first
         try:
             d = json.load(open(path))
             if "rqs_fused" in d.get("kernel", "") and "hbm_traffic_bytes" in d.get("derived", {}):
