@@ -128,15 +128,31 @@ class NormalizingFlow(nn.Module):
 
     # -- MI355X extensions ---------------------------------------------------------------------------------
     def use_graphs(self, mode=True):
-        """Replay log_prob / sample_from_noise as hipGraphs (one per batch shape)."""
+        """Replay log_prob / sample_from_noise as hipGraphs (one per batch shape).
+
+        A recorded graph holds the device pointers of the packed weights it was captured with: it is an inference
+        feature for frozen parameters.  Graphs are dropped automatically by .to()/.double(), load_state_dict() and
+        train(); after changing parameters in place (an optimizer step) call refresh_graphs()."""
         self._graphs.enabled = bool(mode)
-        if not mode:
-            self._graphs.clear()
+        self._graphs.clear()
+        return self
+
+    def refresh_graphs(self):
+        """Forget the recorded graphs (they are re-captured, with freshly packed weights, on the next call)."""
+        self._graphs.clear()
         return self
 
     def _apply(self, fn, *a, **k):  # .to() / .double() invalidate recorded graphs
         self._graphs.clear()
         return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._graphs.clear()
+        return super().load_state_dict(*a, **k)
+
+    def train(self, mode=True):
+        self._graphs.clear()
+        return super().train(mode)
 
     # -- reference API -------------------------------------------------------------------------------------
     def forward(self, z):

@@ -526,6 +526,7 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
             ld += l;
         }
     };
+#ifdef NF_F32_SWPIPE
     {   // group 0: MFMAs only
         const float *bsrc = small + lay.off_bias_final() + hh * 16;
         f32x16 A0 = load_bias16(bsrc), A1 = load_bias16(bsrc + 32), A2 = load_bias16(bsrc + 64);
@@ -560,6 +561,22 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     element(7, 0, prm0);
     element(7, 1, prm1);
     if (DIR == 0) uncond_pair(7);
+#else
+    // The exact-fp32 MFMA shares the vector ALU (tools/ubench/overlap.py): there is nothing to hide the epilogue
+    // behind, so each group's spline elements are evaluated straight from its accumulators (no parameter copies, lower
+    // register pressure); the software-pipelined order (NF_F32_SWPIPE) only pays on the bf16 matrix pipe.
+    for (int g = 0; g < 8; ++g) {
+        const float *bsrc = small + lay.off_bias_final() + (g * 3) * 32 + hh * 16;
+        f32x16 A0 = load_bias16(bsrc), A1 = load_bias16(bsrc + 32), A2 = load_bias16(bsrc + 64);
+        mm128<false>(acquire(), lane, A0, H0, H1, H2, H3);
+        mm128<false>(acquire(), lane, A1, H0, H1, H2, H3);
+        mm128<false>(acquire(), lane, A2, H0, H1, H2, H3);
+        extract(A0, A1, A2);
+        element(g, 0, prm0);
+        element(g, 1, prm1);
+        if (DIR == 0) uncond_pair(g);
+    }
+#endif
 
     if (LU && DIR == 1) {
         // LULinearPermute.forward (mixing.py:555-558): triangular solves + inverse permutation as one dense product
