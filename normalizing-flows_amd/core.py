@@ -186,6 +186,8 @@ class NormalizingFlow(nn.Module):
 
     def log_prob(self, x):
         """log q(x): every layer's inverse, accumulated log-dets, base log-density (core.py:182-197)."""
+        if self._graphs.enabled and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._log_prob_impl(x)  # training: autograd path, never recorded into a graph
         return self._graphs.run(("log_prob", tuple(x.shape), x.dtype), self._log_prob_impl, x)
 
     def forward_kld(self, x):
@@ -199,6 +201,8 @@ class NormalizingFlow(nn.Module):
 
     def sample_from_noise(self, eps):
         """sample() with the base standard-normal noise given (deterministic; used by parity tests)."""
+        if self._graphs.enabled and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._sample_impl(eps)
         return self._graphs.run(("sample", tuple(eps.shape), eps.dtype), self._sample_impl, eps)
 
     def sample(self, num_samples=1):
