@@ -267,4 +267,13 @@ static inline int grid_for(int64_t work_items, int per_block, int max_blocks = 2
     return (int)g;
 }
 
+// Dynamic LDS above 64 KB needs a per-kernel opt-in.  hipFuncSetAttribute is a slow, synchronising host call (measured
+// in milliseconds when it lands between launches), so each launch site remembers the largest size it has opted in.
+inline int opt_in_lds(const void *kernel, size_t lds, size_t &opted) {
+    if (lds <= opted) return NF_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return NF_ENOTSUP;
+    opted = lds;
+    return NF_OK;
+}
+
 }  // namespace nf

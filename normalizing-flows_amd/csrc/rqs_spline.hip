@@ -182,11 +182,8 @@ static int launch_rqs_coupling(const void *x, void *y, void *logdet, const void 
     while (TS > 1 && lds_bytes(TS) > 64 * 1024) TS >>= 1;
     const size_t lds = lds_bytes(TS);
     if (lds > 160 * 1024) return NF_ENOTSUP;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&rqs_coupling_kernel<T>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return NF_ENOTSUP;
-    }
+    static size_t opted = 64 * 1024;
+    if (opt_in_lds(reinterpret_cast<const void *>(&rqs_coupling_kernel<T>), lds, opted) != NF_OK) return NF_ENOTSUP;
     const int64_t ntiles = (B + TS - 1) / TS;
     const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
     hipLaunchKernelGGL(rqs_coupling_kernel<T>, dim3(grid), dim3(256), lds, st, (const T *)x, (T *)y, (T *)logdet,
