@@ -254,6 +254,22 @@ int nf_maf_affine(const void *x, const void *params, void *y, void *logdet, int6
                   int dtype, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * MaskedAffineAutoregressive inverse (MAF sampling direction) in ONE pass.  Replaces the D-pass loop of
+ * normflows/flows/affine/autoregressive.py:29-38 over MADE (nets/made.py:217-304, residual blocks :140-214,
+ * masks :63-81) together with _elementwise_inverse (:114-128): every hidden unit is finalised once, right after
+ * the last feature it may see is known.  Supported structure: 2 residual blocks, ReLU, no context / batch norm /
+ * dropout, sequential degrees, every degree 1..D-1 owning 1..32 hidden units, float32.
+ *   blob, table : device copies of the arrays produced by the host packer (normflows_amd/flows/maf_pack.py;
+ *                 layout documented there); table[3] = hidden_padded.
+ *   scratch     : nf_maf_inverse_scratch_floats(B, D, hidden_padded) floats of device memory owned by the caller
+ *                 (per-wave activation state, 10.5 KB per sample for D=128, H=512); contents need not be initialised.
+ *   z, y (B, D) row-major; logdet (B) accumulated as `acc` says with -sum log(scale).
+ */
+int64_t nf_maf_inverse_scratch_floats(int64_t B, int D, int hidden_padded);
+int nf_maf_inverse(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, void *scratch,
+                   int64_t B, int D, int hidden_padded, int acc, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Squeeze (flows/reshape.py:116-128).  direction 0 = forward (C,H,W)->(C/4,2H,2W),
  * 1 = inverse (C,H,W)->(4C,H/2,W/2).  z, y contiguous NCHW with the shapes implied.
  */

@@ -1,0 +1,237 @@
+// Incremental inverse of a masked autoregressive affine layer (MAF sampling direction) for gfx950.
+//
+// Reference semantics: normflows/flows/affine/autoregressive.py:29-38 runs D full MADE passes
+// (nets/made.py:217-304, residual blocks :140-214) and keeps the last iterate; :114-128 is the element-wise affine
+// inverse x = (z - shift) / (sigmoid(u + 2) + 1e-3), logabsdet = -sum log(scale).  The fixed point it reaches is
+// computed here in ONE pass: a hidden unit of degree m depends only on features of degree <= m (made.py:63-81), so
+// it is finalised right after feature m is known.
+//
+// One wave owns 64 samples for the whole layer (samples are independent: no grid-level synchronisation).  Hidden units
+// are sorted by degree and cut into tiles of <= 32 units / <= 16 degrees (host side: flows/maf_pack.py).  Per tile:
+//   block part  : contributions of all EARLIER tiles = dense [32 x K] x [K x 64] products on v_mfma_f32_32x32x2_f32
+//                 (A = packed weights straight from L2, B = the wave's own activation scratch in HBM/L2, stored in
+//                 MFMA B-operand order [k/8][half][sample][4] so both operands are 16-byte loads), transposed through
+//                 8 KB of LDS so that afterwards lane = sample holds all 32 units of a layer in registers;
+//   sequential  : the tile's degrees one after the other; the 32x32 diagonal blocks are read as SCALARS (uniform
+//                 addresses), every hidden layer's activations live in VGPRs with static indices; after each degree
+//                 the next feature is produced from its two final-layer rows.
+// Work per sample = one MADE pass (0.6 MMAC for D=128, H=512) instead of D passes (153 MMAC).
+#include "common.hpp"
+#include "fused_common.hpp"
+
+namespace nf {
+
+constexpr int MT = 32;    // units per tile
+constexpr int MS = 16;    // degrees per tile
+constexpr int MW = 4;     // waves per workgroup
+constexpr int M_HDR = 8, M_ENT = 24;
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// out[u] (lane = sample) = sum_k A[u][k] * act[k][sample] for the wave's 64 samples; K is a multiple of 8.
+__device__ __forceinline__ void block_part(const float *__restrict__ A, const float *Sl, int K, float *ldsw, int lane,
+                                           float (&out)[MT]) {
+    f32x16 c0 = {0}, c1 = {0};
+    const int half = lane >> 5, l31 = lane & 31;
+    const f32x4 *pa = reinterpret_cast<const f32x4 *>(A) + half * 32 + l31;
+    const f32x4 *pb = reinterpret_cast<const f32x4 *>(Sl) + half * 64 + l31;
+    const int nkb = K >> 3;
+    if (nkb > 0) {
+        f32x4 a = pa[0], b0 = pb[0], b1 = pb[32];
+        for (int kb = 0; kb < nkb; ++kb) {
+            const int nx = kb + 1 < nkb ? kb + 1 : kb;
+            const f32x4 an = pa[nx * 64], b0n = pb[nx * 128], b1n = pb[nx * 128 + 32];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                c0 = MFMA32(a[i], b0[i], c0);
+                c1 = MFMA32(a[i], b1[i], c1);
+            }
+            a = an; b0 = b0n; b1 = b1n;
+        }
+    }
+    // C layout: row = (reg & 3) + 8 (reg >> 2) + 4 half, col = lane & 31  ->  LDS [unit][64 samples]  ->  lane = sample
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        ldsw[row * 64 + l31] = c0[r];
+        ldsw[row * 64 + 32 + l31] = c1[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < MT; ++u) out[u] = ldsw[u * 64 + lane];
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void maf_finish(float us, float sh, float zf, float &xn, float &ld) {
+    const float scale = 1.0f / (1.0f + __expf(-(us + 2.0f))) + 1e-3f;
+    xn = (zf - sh) / scale;
+    ld -= __logf(scale);
+}
+
+// One hidden layer of the sequential part: units of the current degree (bitmask m) read `src` (all 32, static regs).
+#define MAF_LAYER(W, DST_EXPR)                                                                  \
+    _Pragma("unroll") for (int u = 0; u < MT; ++u) {                                            \
+        if ((m >> u) & 1u) {                                                                    \
+            DST_EXPR                                                                            \
+        }                                                                                       \
+    }
+
+__global__ void __launch_bounds__(64 * MW)
+maf_inverse_kernel(const float *__restrict__ z, float *__restrict__ y, float *__restrict__ logdet,
+                   const float *__restrict__ blob, const int *__restrict__ table, float *S, float *Xs, int64_t B, int acc) {
+    __shared__ float lds[MW][MT * 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float *ldsw = lds[wid];
+    const int64_t wt = (int64_t)blockIdx.x * MW + wid;
+    if (wt * 64 >= B) return;
+    const int D = table[0], Dp = table[1], Hp = table[3], T = table[4];
+    const int64_t sample = wt * 64 + lane;
+    const bool valid = sample < B;
+    const float *zr = z + (valid ? sample : B - 1) * D;
+    float *Sw = S + wt * ((int64_t)5 * Hp * 64);   // [layer][Hp/8][2][64][4]
+    float *Xw = Xs + wt * ((int64_t)Dp * 64);      // [Dp/8][2][64][4]
+    float ld = 0.0f, xcarry;
+    maf_finish(blob[0], blob[1], zr[0], xcarry, ld);   // feature 0 depends on no hidden unit
+    Xw[lane * 4] = xcarry;
+    if (valid) y[sample * D] = xcarry;
+
+    for (int t = 0; t < T; ++t) {
+        const int *te = table + M_HDR + M_ENT * t;
+        const int dlo = te[0], ns = te[1], K0 = te[2];
+        const int Kh = MT * t;
+        const float *rec = blob + te[3];
+        const float *A0 = rec;
+        const float *Ah = A0 + K0 * MT;             // A1..A4, AF : Kh*32 floats each
+        const float *bias = Ah + (size_t)5 * Kh * MT;
+        const float *biasF = bias + 5 * MT;
+        const float *W0d = biasF + MT;
+        const float *Wd = W0d + MT * MS;
+        const float *WFd = Wd + 4 * MT * MT;
+
+        float zin[MS];
+#pragma unroll
+        for (int j = 0; j < MS; ++j) zin[j] = (j < ns) ? zr[dlo + j] : 0.0f;
+
+        __threadfence_block();  // the activation scratch written by the other lanes of this wave is read below
+        float p0[MT], p1[MT], p2[MT], p3[MT], p4[MT], pF[MT];
+        block_part(A0, Xw, K0, ldsw, lane, p0);
+        block_part(Ah + (size_t)0 * Kh * MT, Sw + (size_t)0 * Hp * 64, Kh, ldsw, lane, p1);
+        block_part(Ah + (size_t)1 * Kh * MT, Sw + (size_t)1 * Hp * 64, Kh, ldsw, lane, p2);
+        block_part(Ah + (size_t)2 * Kh * MT, Sw + (size_t)2 * Hp * 64, Kh, ldsw, lane, p3);
+        block_part(Ah + (size_t)3 * Kh * MT, Sw + (size_t)3 * Hp * 64, Kh, ldsw, lane, p4);
+        block_part(Ah + (size_t)4 * Kh * MT, Sw + (size_t)4 * Hp * 64, Kh, ldsw, lane, pF);
+#pragma unroll
+        for (int u = 0; u < MT; ++u) {
+            p0[u] += bias[u];
+            p1[u] += bias[MT + u];
+            p2[u] += bias[2 * MT + u];
+            p3[u] += bias[3 * MT + u];
+            p4[u] += bias[4 * MT + u];
+            pF[u] += biasF[u];
+        }
+        float xg[MS + 1];
+        xg[0] = xcarry;
+#pragma unroll
+        for (int j = 1; j <= MS; ++j) xg[j] = 0.0f;
+
+        for (int s = 0; s < ns; ++s) {
+            const unsigned m = (unsigned)te[4 + s];
+            // initial layer: h0 = pre + W0[window] . x ; the residual h0 is folded into the pre-activation of block 1's
+            // second linear (p2), p0 keeps relu(h0) = input of block 1's first linear
+            MAF_LAYER(W0d, {
+                float a = p0[u];
+                _Pragma("unroll") for (int f = 0; f < MS; ++f) a = fmaf(W0d[u * MS + f], xg[f], a);
+                p2[u] += a;
+                p0[u] = fmaxf(a, 0.0f);
+            })
+            MAF_LAYER(Wd, {
+                float a = p1[u];
+                _Pragma("unroll") for (int v = 0; v < MT; ++v) a = fmaf(Wd[u * MT + v], p0[v], a);
+                p1[u] = fmaxf(a, 0.0f);
+            })
+            MAF_LAYER(Wd, {
+                float a = p2[u];
+                _Pragma("unroll") for (int v = 0; v < MT; ++v) a = fmaf(Wd[MT * MT + u * MT + v], p1[v], a);
+                p4[u] += a;                 // residual stream after block 1 feeds block 2's output
+                p2[u] = fmaxf(a, 0.0f);
+            })
+            MAF_LAYER(Wd, {
+                float a = p3[u];
+                _Pragma("unroll") for (int v = 0; v < MT; ++v) a = fmaf(Wd[2 * MT * MT + u * MT + v], p2[v], a);
+                p3[u] = fmaxf(a, 0.0f);
+            })
+            MAF_LAYER(Wd, {
+                float a = p4[u];
+                _Pragma("unroll") for (int v = 0; v < MT; ++v) a = fmaf(Wd[3 * MT * MT + u * MT + v], p3[v], a);
+                p4[u] = a;                  // = h2, the final layer's input (made.py:304: no activation before it)
+            })
+#pragma unroll
+            for (int j = 0; j < MS; ++j) {
+                if (j == s) {
+                    float us = pF[2 * j], sh = pF[2 * j + 1];
+#pragma unroll
+                    for (int v = 0; v < MT; ++v) {
+                        us = fmaf(WFd[(2 * j) * MT + v], p4[v], us);
+                        sh = fmaf(WFd[(2 * j + 1) * MT + v], p4[v], sh);
+                    }
+                    float xn;
+                    maf_finish(us, sh, zin[j], xn, ld);
+                    xg[j + 1] = xn;
+                    xcarry = xn;
+                }
+            }
+        }
+        // ---- publish the tile: activations in B-operand order, the new features to y and to the feature scratch ----
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const size_t o = ((size_t)((4 * t + q) * 2 + hh) * 64 + lane) * 4;
+                const int u0 = 8 * q + 4 * hh;
+                *reinterpret_cast<f32x4 *>(Sw + (size_t)0 * Hp * 64 + o) = f32x4{p0[u0], p0[u0 + 1], p0[u0 + 2], p0[u0 + 3]};
+                *reinterpret_cast<f32x4 *>(Sw + (size_t)1 * Hp * 64 + o) = f32x4{p1[u0], p1[u0 + 1], p1[u0 + 2], p1[u0 + 3]};
+                *reinterpret_cast<f32x4 *>(Sw + (size_t)2 * Hp * 64 + o) = f32x4{p2[u0], p2[u0 + 1], p2[u0 + 2], p2[u0 + 3]};
+                *reinterpret_cast<f32x4 *>(Sw + (size_t)3 * Hp * 64 + o) = f32x4{p3[u0], p3[u0 + 1], p3[u0 + 2], p3[u0 + 3]};
+                *reinterpret_cast<f32x4 *>(Sw + (size_t)4 * Hp * 64 + o) = f32x4{p4[u0], p4[u0 + 1], p4[u0 + 2], p4[u0 + 3]};
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MS; ++j) {
+            if (j < ns) {
+                const int f = dlo + j;
+                Xw[((size_t)((f >> 3) * 2 + ((f >> 2) & 1)) * 64 + lane) * 4 + (f & 3)] = xg[j + 1];
+                if (valid) y[sample * D + f] = xg[j + 1];
+            }
+        }
+    }
+    if (valid) ld_store(logdet + sample, ld, acc);
+}
+
+}  // namespace nf
+
+extern "C" int64_t nf_maf_inverse_scratch_floats(int64_t B, int D, int hidden_padded) {
+    if (B < 0 || D < 1 || hidden_padded < 0) return NF_EINVAL;
+    const int64_t nwt = (B + 63) / 64;
+    const int64_t Dp = (D + 7) / 8 * 8;
+    return nwt * 64 * ((int64_t)5 * hidden_padded + Dp);
+}
+
+extern "C" int nf_maf_inverse(const void *z, void *y, void *logdet, const void *blob, const int32_t *table,
+                              void *scratch, int64_t B, int D, int hidden_padded, int acc, nf_stream_t stream) {
+    if (B < 0 || D < 2 || hidden_padded < 32 || hidden_padded % 32) return NF_EINVAL;
+    if (acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!z || !y || !logdet || !blob || !table || !scratch) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nwt = (B + 63) / 64;
+    const int64_t Dp = (D + 7) / 8 * 8;
+    float *S = (float *)scratch;
+    float *Xs = S + nwt * 64 * (int64_t)5 * hidden_padded;
+    // the feature scratch is read with zero weights before it is written (K0 is padded to 8): it must hold finite values
+    if (hipMemsetAsync(Xs, 0, (size_t)nwt * 64 * Dp * sizeof(float), st) != hipSuccess) return NF_EIO;
+    const int grid = (int)((nwt + nf::MW - 1) / nf::MW);
+    hipLaunchKernelGGL(nf::maf_inverse_kernel, dim3(grid), dim3(64 * nf::MW), 0, st, (const float *)z, (float *)y,
+                       (float *)logdet, (const float *)blob, (const int *)table, S, Xs, B, acc);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

@@ -5,15 +5,16 @@ keys, direction semantics: `forward` = one MADE pass, `inverse` = D sequential M
 affine transform and its log-det are one HIP kernel (nf_maf_affine); MADE's masked linears are library GEMMs on
 pre-masked weights (cached per parameter version).
 
-NOTE: the inverse is implemented with the reference's D-pass structure; the
-masked-aware incremental evaluation (each hidden unit finalised once, total work = ONE MADE pass) is the planned
-persistent-kernel replacement, see DESIGN.md section 7.
+The inverse of MaskedAffineAutoregressive runs as ONE launch of nf_maf_inverse when
+the MADE has the supported structure (flows/maf_pack.py): every hidden unit is finalised once, total work = one MADE
+pass instead of D.  Other structures, float64 and gradient-tracking calls keep the reference's D-pass loop.
 """
 import numpy as np
 import torch
 from torch.nn import functional as F
 
-from .. import nets, ops
+from .. import autograd, nets, ops
+from . import maf_pack
 from .base import Flow
 
 
@@ -61,6 +62,26 @@ class MaskedAffineAutoregressive(Autoregressive):
 
     def _output_dim_multiplier(self):
         return 2
+
+    def _packed(self, device):
+        """Device copies of the incremental-inverse pack, rebuilt when any MADE parameter changes."""
+        key = tuple((p.data_ptr(), p._version) for p in self.autoregressive_net.parameters()) + (str(device),)
+        cache = getattr(self, "_maf_pack_cache", None)
+        if cache is None or cache[0] != key:
+            packed = maf_pack.pack_made(self.autoregressive_net)
+            if packed is not None:
+                blob, table = packed
+                packed = (torch.from_numpy(blob).to(device), torch.from_numpy(table).to(device), int(table[3]))
+            self._maf_pack_cache = cache = (key, packed)
+        return cache[1]
+
+    def inverse(self, inputs, context=None):
+        if (context is None and inputs.dim() == 2 and inputs.dtype == torch.float32 and inputs.is_cuda
+                and not autograd.needs_grad(inputs, *self.autoregressive_net.parameters())):
+            packed = self._packed(inputs.device)
+            if packed is not None:
+                return ops.maf_inverse(inputs, packed[0], packed[1], packed[2])
+        return super().inverse(inputs, context)
 
     def _elementwise(self, inputs, params, direction, want_logdet=True):
         if inputs.dim() != 2:

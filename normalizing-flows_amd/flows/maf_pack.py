@@ -1,0 +1,189 @@
+"""Host-side packing for the incremental MAF inverse kernel (nf_maf_inverse, csrc/maf_inverse.hip).
+
+The reference inverts a masked autoregressive layer with D full MADE passes (normflows/flows/affine/
+autoregressive.py:29-38).  Because hidden unit j of degree m only sees inputs of degree <= m (nets/made.py:63-81),
+every unit can be finalised ONCE, right after feature m is known: total work = one MADE pass.  The kernel walks the
+degrees in order; hidden units are sorted by degree and cut into tiles of <= 32 units that hold whole degrees:
+
+  * contributions from earlier tiles are dense 32-row GEMM blocks (MFMA; "block part", weights stored in the
+    MFMA A-operand order [k/8][half][unit][4]),
+  * contributions inside the tile (the 32x32 diagonal blocks, masked) run in the sequential per-degree part
+    (weights read as scalars).
+
+This module only rearranges weights (no arithmetic on data).  Layout of the float blob (all offsets in floats):
+
+  [0:2]                       final-layer bias of feature 0 (unconstrained scale, shift): it depends on no hidden unit
+  per tile t, at table[t].rec : A0 [K0/8][2][32][4] | A1..A4, AF [4t][2][32][4] each | bias[5][32] | biasF[32]
+                                | W0d[32][16] | Wd[4][32][32] | WFd[32][32]
+and of the int32 table: [D, Dp, H, Hp, T, 0, 0, 0] then per tile 24 ints
+  [dlo, nsteps, K0, rec, mask[0..15], 0, 0, 0, 0]   (mask[s] = bitmask of the tile's units that have degree dlo+s).
+"""
+import numpy as np
+import torch
+from torch.nn import functional as F
+
+TILE = 32        # hidden units per tile (MFMA rows)
+MAX_STEPS = 16   # degrees per tile (two final-layer rows per step -> 32 MFMA rows)
+TABLE_HDR = 8
+TABLE_ENT = 24
+
+
+def plan_tiles(D, hidden_degrees):
+    """Sort units by degree (stable) and cut into tiles.  Returns (order, tiles) with tiles = list of
+    (dlo, nsteps, [unit-count per step]) or None when the structure is outside what the kernel handles."""
+    deg = np.asarray(hidden_degrees, dtype=np.int64)
+    if D < 2 or deg.min() < 1 or deg.max() > D - 1:
+        return None
+    counts = np.bincount(deg, minlength=D)[1:D]          # degrees 1..D-1
+    if (counts < 1).any() or (counts > TILE).any():
+        return None                                       # every degree needs 1..32 units
+    order = np.argsort(deg, kind="stable")
+    tiles, d = [], 1
+    while d <= D - 1:
+        n_units, steps = 0, []
+        while d <= D - 1 and len(steps) < MAX_STEPS and n_units + counts[d - 1] <= TILE:
+            steps.append(int(counts[d - 1]))
+            n_units += counts[d - 1]
+            d += 1
+        tiles.append((d - len(steps), len(steps), steps))
+    return order, tiles
+
+
+def _a_operand(w_rows_by_k):
+    """(32, K) row-major block -> MFMA A-operand order [K/8][2][32][4] (k = 8*kb + 4*half + i)."""
+    rows, K = w_rows_by_k.shape
+    assert rows == TILE and K % 8 == 0
+    return np.ascontiguousarray(w_rows_by_k.reshape(TILE, K // 8, 2, 4).transpose(1, 2, 0, 3)).reshape(-1)
+
+
+def supported(made):
+    from .. import nets
+    if not isinstance(made, nets.MADE):
+        return False
+    if not isinstance(made.preprocessing, torch.nn.Identity) or hasattr(made, "context_layer"):
+        return False
+    if len(made.blocks) != 2 or not all(isinstance(b, nets.MaskedResidualBlock) for b in made.blocks):
+        return False
+    for b in made.blocks:
+        if b.use_batch_norm or b.activation is not F.relu or b.dropout.p != 0.0 or hasattr(b, "context_layer"):
+            return False
+    D = made.initial_layer.in_features
+    if made.final_layer.out_features != 2 * D or made.initial_layer.weight.dtype != torch.float32:
+        return False
+    return True
+
+
+def pack_made(made):
+    """Returns (blob float32 ndarray, table int32 ndarray) or None if the MADE is not the supported structure."""
+    if not supported(made):
+        return None
+    D = made.initial_layer.in_features
+    H = made.initial_layer.out_features
+    hid_deg = made.initial_layer.degrees.cpu().numpy()
+    lin = [made.initial_layer, made.blocks[0].linear_layers[0], made.blocks[0].linear_layers[1],
+           made.blocks[1].linear_layers[0], made.blocks[1].linear_layers[1]]
+    for l in lin[1:]:
+        if not np.array_equal(l.degrees.cpu().numpy(), hid_deg):
+            return None
+    fin = made.final_layer
+    # input degrees must be arange(1..D) and the output rows feature-major (2 rows per feature)
+    m0 = made.initial_layer.mask.cpu().numpy()
+    if not np.array_equal(m0, (hid_deg[:, None] >= np.arange(1, D + 1)[None, :]).astype(m0.dtype)):
+        return None
+    mf = fin.mask.cpu().numpy()
+    out_deg = np.repeat(np.arange(1, D + 1), 2)
+    if not np.array_equal(mf, (out_deg[:, None] > hid_deg[None, :]).astype(mf.dtype)):
+        return None
+    plan = plan_tiles(D, hid_deg)
+    if plan is None:
+        return None
+    order, tiles = plan
+    T = len(tiles)
+    Hp, Dp = T * TILE, (D + 7) // 8 * 8
+
+    # position of every sorted unit in the padded index space, and the degree of every padded slot (0 = pad)
+    pos = np.zeros(H, dtype=np.int64)
+    slot_deg = np.zeros(Hp, dtype=np.int64)
+    k = 0
+    for t, (dlo, ns, steps) in enumerate(tiles):
+        base = t * TILE
+        for s, c in enumerate(steps):
+            for _ in range(c):
+                pos[k] = base
+                slot_deg[base] = dlo + s
+                base += 1
+                k += 1
+    assert k == H
+    unit_of_slot = -np.ones(Hp, dtype=np.int64)
+    unit_of_slot[pos] = order
+
+    def padded(lyr, in_map, in_size):
+        """Masked weight and bias of `lyr` with rows moved to padded slots and columns to `in_map` positions."""
+        w = (lyr.weight.detach() * lyr.mask).cpu().numpy().astype(np.float32)
+        b = lyr.bias.detach().cpu().numpy().astype(np.float32)
+        W = np.zeros((Hp, in_size), dtype=np.float32)
+        Bv = np.zeros(Hp, dtype=np.float32)
+        rows = unit_of_slot >= 0
+        tmp = np.zeros((int(rows.sum()), in_size), dtype=np.float32)
+        tmp[:, in_map] = w[unit_of_slot[rows]]
+        W[rows] = tmp
+        Bv[rows] = b[unit_of_slot[rows]]
+        return W, Bv
+
+    feat_map = np.arange(D)
+    hid_map = np.zeros(H, dtype=np.int64)
+    hid_map[order] = pos            # original hidden index -> padded slot
+    W0, b0 = padded(lin[0], feat_map, Dp)
+    Wh, bh = [], []
+    for l in lin[1:]:
+        w, b = padded(l, hid_map, Hp)
+        Wh.append(w)
+        bh.append(b)
+    wf = (fin.weight.detach() * fin.mask).cpu().numpy().astype(np.float32)   # (2D, H), row 2f+p
+    bf = fin.bias.detach().cpu().numpy().astype(np.float32)
+    WF = np.zeros((2 * D, Hp), dtype=np.float32)
+    WF[:, hid_map] = wf
+
+    chunks = [bf[0:2].copy()]
+    off = 2
+    table = np.zeros(TABLE_HDR + TABLE_ENT * T, dtype=np.int32)
+    table[0:5] = [D, Dp, H, Hp, T]
+    for t, (dlo, ns, steps) in enumerate(tiles):
+        r0, r1 = t * TILE, (t + 1) * TILE
+        nprev = dlo - 1                    # features (0-based) 0..dlo-2 come from the block part; dlo-1.. from the window
+        K0 = (nprev + 7) // 8 * 8
+        a0 = np.zeros((TILE, K0), dtype=np.float32)
+        a0[:, :nprev] = W0[r0:r1, :nprev]
+        rec = [_a_operand(a0)] if K0 else []
+        for w in Wh:
+            if t:
+                rec.append(_a_operand(w[r0:r1, :r0]))
+        fo = np.zeros((TILE, Hp), dtype=np.float32)      # final rows of the tile's output features dlo..dlo+ns-1 (0-based)
+        bfo = np.zeros(TILE, dtype=np.float32)
+        for j in range(ns):
+            f = dlo + j
+            fo[2 * j:2 * j + 2] = WF[2 * f:2 * f + 2]
+            bfo[2 * j:2 * j + 2] = bf[2 * f:2 * f + 2]
+        if t:
+            rec.append(_a_operand(fo[:, :r0]))
+        rec.append(np.concatenate([b0[r0:r1]] + [b[r0:r1] for b in bh]))
+        rec.append(bfo)
+        w0d = np.zeros((TILE, MAX_STEPS), dtype=np.float32)  # window features dlo-1 .. dlo-1+ns-1 (0-based)
+        nwin = min(MAX_STEPS, D - (dlo - 1))
+        w0d[:, :nwin] = W0[r0:r1, dlo - 1:dlo - 1 + nwin]
+        # a unit of degree dlo+s must not see window features above its own degree: the mask already guarantees it
+        rec.append(w0d.reshape(-1))
+        for w in Wh:
+            rec.append(np.ascontiguousarray(w[r0:r1, r0:r1]).reshape(-1))
+        rec.append(np.ascontiguousarray(fo[:, r0:r1]).reshape(-1))
+        rec = np.concatenate(rec)
+        e = TABLE_HDR + TABLE_ENT * t
+        table[e + 0], table[e + 1], table[e + 2], table[e + 3] = dlo, ns, K0, off
+        u = 0
+        for s, c in enumerate(steps):
+            table[e + 4 + s] = np.array([((1 << c) - 1) << u], dtype=np.uint64).astype(np.uint32).view(np.int32)[0]
+            u += c
+        chunks.append(rec)
+        off += rec.size
+    blob = np.concatenate(chunks).astype(np.float32)
+    return blob, table

@@ -395,3 +395,24 @@ def rqs_fused_chain(x, blobs, parities, hidden, num_blocks, K, direction, logdet
                                     f64(min_bin_height), f64(min_derivative), i32(direction), i32(acc), L.stream())
     L.check(rc, "nf_rqs_fused_chain")
     return y, logdet
+
+
+def maf_inverse(z, blob, table, hidden_padded, logdet=None, acc=None):
+    """autoregressive.py:29-38 + :114-128 in one pass (nf_maf_inverse); blob/table from flows/maf_pack.pack_made."""
+    L.require_device(z, blob, table)
+    if z.dtype != torch.float32:
+        raise NotImplementedError("maf_inverse: float32 only")
+    B, D = z.shape
+    z = z.contiguous()
+    y = torch.empty_like(z)
+    if logdet is None:
+        logdet = torch.empty(B, dtype=z.dtype, device=z.device)
+        acc = L.LD_WRITE
+    elif acc is None:
+        acc = L.LD_ADD
+    n = L.lib().nf_maf_inverse_scratch_floats(i64(B), i32(D), i32(hidden_padded))
+    scratch = torch.empty(max(int(n), 1), dtype=torch.float32, device=z.device)
+    rc = L.lib().nf_maf_inverse(ptr(z), ptr(y), ptr(logdet), ptr(blob), ptr(table), ptr(scratch), i64(B), i32(D),
+                                i32(hidden_padded), i32(acc), L.stream())
+    L.check(rc, "nf_maf_inverse")
+    return y, logdet

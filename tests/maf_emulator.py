@@ -1,0 +1,72 @@
+"""numpy walk-through of the incremental MAF inverse exactly as csrc/maf_inverse.hip performs it, driven by the packed
+blob/table of flows/maf_pack.py.  Test infrastructure: validates the packing and the schedule on CPU."""
+import numpy as np
+
+TILE, MAX_STEPS, HDR, ENT = 32, 16, 8, 24
+
+
+def _from_a_operand(a, K):
+    return a.reshape(K // 8, 2, TILE, 4).transpose(2, 0, 1, 3).reshape(TILE, K)
+
+
+def emulate_inverse(blob, table, z):
+    z = np.asarray(z, dtype=np.float64)
+    B = z.shape[0]
+    D, Dp, H, Hp, T = [int(v) for v in table[:5]]
+    blob = blob.astype(np.float64)
+    x = np.zeros((B, Dp))
+    S = np.zeros((5, B, Hp))
+    ld = np.zeros(B)
+
+    def finish(us, sh, zf):
+        scale = 1.0 / (1.0 + np.exp(-(us + 2.0))) + 1e-3
+        return (zf - sh) / scale, -np.log(scale)
+
+    x[:, 0], d = finish(blob[0], blob[1], z[:, 0])
+    ld += d
+    for t in range(T):
+        e = HDR + ENT * t
+        dlo, ns, K0, off = [int(v) for v in table[e:e + 4]]
+        masks = table[e + 4:e + 4 + MAX_STEPS].view(np.uint32)
+        Kh = TILE * t
+        A0 = _from_a_operand(blob[off:off + K0 * TILE], K0) if K0 else np.zeros((TILE, 0)); off += K0 * TILE
+        Ah = []
+        for _ in range(5):  # A1..A4, AF
+            Ah.append(_from_a_operand(blob[off:off + Kh * TILE], Kh) if Kh else np.zeros((TILE, 0))); off += Kh * TILE
+        bias = blob[off:off + 5 * TILE].reshape(5, TILE); off += 5 * TILE
+        biasF = blob[off:off + TILE]; off += TILE
+        W0d = blob[off:off + TILE * MAX_STEPS].reshape(TILE, MAX_STEPS); off += TILE * MAX_STEPS
+        Wd = blob[off:off + 4 * TILE * TILE].reshape(4, TILE, TILE); off += 4 * TILE * TILE
+        WFd = blob[off:off + TILE * TILE].reshape(TILE, TILE); off += TILE * TILE
+        pre = np.zeros((5, B, TILE))
+        pre[0] = x[:, :K0] @ A0.T + bias[0]
+        for l in range(1, 5):
+            pre[l] = S[l - 1][:, :Kh] @ Ah[l - 1].T + bias[l]
+        preF = S[4][:, :Kh] @ Ah[4].T + biasF
+        xg = np.zeros((B, MAX_STEPS + 1))
+        xg[:, 0] = x[:, dlo - 1]
+        for s in range(ns):
+            units = [u for u in range(TILE) if (int(masks[s]) >> u) & 1]
+            for u in units:
+                h = pre[0][:, u] + xg[:, :MAX_STEPS] @ W0d[u]
+                pre[2][:, u] += h
+                pre[0][:, u] = np.maximum(h, 0)
+            for u in units:
+                pre[1][:, u] = np.maximum(pre[1][:, u] + pre[0] @ Wd[0][u], 0)
+            for u in units:
+                h1 = pre[2][:, u] + pre[1] @ Wd[1][u]
+                pre[4][:, u] += h1
+                pre[2][:, u] = np.maximum(h1, 0)
+            for u in units:
+                pre[3][:, u] = np.maximum(pre[3][:, u] + pre[2] @ Wd[2][u], 0)
+            for u in units:
+                pre[4][:, u] = pre[4][:, u] + pre[3] @ Wd[3][u]
+            us = preF[:, 2 * s] + pre[4] @ WFd[2 * s]
+            sh = preF[:, 2 * s + 1] + pre[4] @ WFd[2 * s + 1]
+            xn, d = finish(us, sh, z[:, dlo + s])
+            ld += d
+            x[:, dlo + s] = xn
+            xg[:, s + 1] = xn
+        for l in range(5):
+            S[l][:, TILE * t:TILE * (t + 1)] = pre[l]
+    return x[:, :D], ld

@@ -602,3 +602,40 @@ def test_maf_config5_width_vs_reference(nfa):
     total = net.final_layer.mask @ total
     conn = (total[0::2] > 0).float()
     assert torch.equal(conn, torch.tril(torch.ones_like(conn), -1))
+
+
+@pytest.mark.parametrize("D,H,B", [(128, 512, 300), (17, 40, 64), (3, 2, 5), (40, 39, 129), (6, 150, 1)])
+def test_maf_incremental_inverse_vs_d_pass(nfa, D, H, B):
+    """nf_maf_inverse (one pass, every hidden unit finalised once) against the reference's D-pass structure
+    (autoregressive.py:29-38) run through the same MADE; ragged batches; degrees with 1..32 units."""
+    from normflows_amd.flows.autoregressive import Autoregressive
+    torch.manual_seed(D * 1000 + H)
+    layer = nfa.flows.MaskedAffineAutoregressive(D, H, num_blocks=2)
+    _perturb(layer, 0.05 if D < 100 else 0.02, 3)
+    layer = layer.to(DEV)
+    assert layer._packed(DEV) is not None
+    z = torch.randn(B, D, generator=torch.Generator().manual_seed(5)).to(DEV)
+    x1, ld1 = layer.inverse(z)                       # incremental kernel
+    x0, ld0 = Autoregressive.inverse(layer, z)       # D MADE passes
+    assert_close(N(x1), N(x0), what="x", rtol=2e-4, atol=2e-4)
+    assert_close(N(ld1), N(ld0), what="ld", rtol=2e-4, atol=2e-4)
+    xr, ldr = layer.forward(x1)
+    assert_close(N(xr), N(z), what="roundtrip", rtol=1e-3, atol=1e-3)
+    assert_close(N(ldr), -N(ld1), what="roundtrip ld", rtol=1e-3, atol=1e-3)
+    # parameter update invalidates the pack
+    with torch.no_grad():
+        layer.autoregressive_net.final_layer.bias.add_(0.1)
+    x2, _ = layer.inverse(z)
+    x3, _ = Autoregressive.inverse(layer, z)
+    assert_close(N(x2), N(x3), what="x after update", rtol=2e-4, atol=2e-4)
+
+
+def test_maf_incremental_unsupported_falls_back_to_d_pass(nfa):
+    """hidden < D-1 leaves degrees without units: outside the kernel's structure -> the D-pass loop is used."""
+    torch.manual_seed(0)
+    layer = nfa.flows.MaskedAffineAutoregressive(12, 4, num_blocks=2).to(DEV)
+    assert layer._packed(DEV) is None
+    z = torch.randn(7, 12, device=DEV)
+    x, ld = layer.inverse(z)
+    xr, _ = layer.forward(x)
+    assert_close(N(xr), N(z), what="roundtrip", rtol=1e-4, atol=1e-4)

@@ -202,3 +202,41 @@ def test_dp_nll_matches_unsharded_under_gloo(nfa, tmp_path):
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "DP_OK" in out.stdout
+
+
+@pytest.mark.parametrize("D,H", [(128, 512), (17, 40), (3, 2), (40, 39), (6, 150)])
+def test_maf_pack_schedule_matches_d_pass(D, H):
+    """flows/maf_pack.py + the kernel's tile/step schedule (tests/maf_emulator.py restates it in numpy) reproduce the
+    fixed point of the reference's D-pass inverse (autoregressive.py:29-38) computed with plain torch in fp64."""
+    import normflows_amd as nfa
+    from normflows_amd import nets
+    from normflows_amd.flows import maf_pack
+    from maf_emulator import emulate_inverse
+    torch.manual_seed(D + H)
+    made = nets.MADE(features=D, hidden_features=H, num_blocks=2, output_multiplier=2)
+    with torch.no_grad():
+        for p in made.parameters():
+            p.add_((0.1 if D < 100 else 0.01) * torch.randn_like(p))
+    blob, table = maf_pack.pack_made(made)
+    assert table[0] == D and table[3] % 32 == 0 and table[3] >= H
+    z = torch.randn(16, D)
+    m64 = made.double()
+    with torch.no_grad():
+        out = torch.zeros(16, D, dtype=torch.float64)
+        for _ in range(D):
+            prm = m64(out).view(16, D, 2)
+            scale = torch.sigmoid(prm[..., 0] + 2.0) + 1e-3
+            out = (z.double() - prm[..., 1]) / scale
+        ldref = -torch.log(scale).sum(1)
+    x, ld = emulate_inverse(blob, table, z.numpy())
+    np.testing.assert_allclose(x, out.numpy(), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(ld, ldref.numpy(), rtol=1e-9, atol=1e-9)
+
+
+def test_maf_pack_rejects_unsupported():
+    from normflows_amd import nets
+    from normflows_amd.flows import maf_pack
+    assert maf_pack.pack_made(nets.MADE(features=12, hidden_features=4, num_blocks=2, output_multiplier=2)) is None
+    assert maf_pack.pack_made(nets.MADE(features=8, hidden_features=16, num_blocks=3, output_multiplier=2)) is None
+    assert maf_pack.pack_made(nets.MADE(features=8, hidden_features=16, num_blocks=2, output_multiplier=2,
+                                        use_residual_blocks=False)) is None
