@@ -25,29 +25,54 @@ constexpr int MT = 32;    // units per tile
 constexpr int MS = 16;    // degrees per tile
 constexpr int MW = 4;     // waves per workgroup
 constexpr int M_HDR = 8, M_ENT = 24;
+constexpr int M_SEQ = 5 * MT + MT + MT * MS + 4 * MT * MT + MT * MT;  // floats of a tile record after the A operands
+
+typedef float f32x32 __attribute__((ext_vector_type(32)));
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-// out[u] (lane = sample) = sum_k A[u][k] * act[k][sample] for the wave's 64 samples; K is a multiple of 8.
+// out[u] (lane = sample) = sum_k A[u][k] * act[k][sample] for the wave's 64 samples; K is a multiple of 32.
 __device__ __forceinline__ void block_part(const float *__restrict__ A, const float *Sl, int K, float *ldsw, int lane,
-                                           float (&out)[MT]) {
+                                           f32x32 &out) {
     f32x16 c0 = {0}, c1 = {0};
     const int half = lane >> 5, l31 = lane & 31;
     const f32x4 *pa = reinterpret_cast<const f32x4 *>(A) + half * 32 + l31;
     const f32x4 *pb = reinterpret_cast<const f32x4 *>(Sl) + half * 64 + l31;
+#ifdef NF_MAF_ABL_NOBLOCK
+    const int nkb = 0;
+#else
     const int nkb = K >> 3;
+#endif
     if (nkb > 0) {
-        f32x4 a = pa[0], b0 = pb[0], b1 = pb[32];
-        for (int kb = 0; kb < nkb; ++kb) {
-            const int nx = kb + 1 < nkb ? kb + 1 : kb;
-            const f32x4 an = pa[nx * 64], b0n = pb[nx * 128], b1n = pb[nx * 128 + 32];
+        // K is a multiple of 32 (host packer), i.e. nkb of 4: eight named operand stages, each refilled right after it is
+        // consumed (prefetch distance = 8 k-blocks = 4096 MFMA cycles, no register rotation moves).
+        // With one wave per SIMD nothing else hides the HBM/L2 latency of the activation scratch.
+        struct Stage { f32x4 a, b0, b1; };
+        auto ld = [&](int kb, Stage &st) {
+            const int k = kb < nkb ? kb : nkb - 1;
+            st.a = pa[k * 64]; st.b0 = pb[k * 128]; st.b1 = pb[k * 128 + 32];
+        };
+        auto mm = [&](const Stage &st) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                c0 = MFMA32(a[i], b0[i], c0);
-                c1 = MFMA32(a[i], b1[i], c1);
+                c0 = MFMA32(st.a[i], st.b0[i], c0);
+                c1 = MFMA32(st.a[i], st.b1[i], c1);
             }
-            a = an; b0 = b0n; b1 = b1n;
+        };
+        Stage s0, s1, s2, s3, s4, s5, s6, s7;
+        ld(0, s0); ld(1, s1); ld(2, s2); ld(3, s3); ld(4, s4); ld(5, s5); ld(6, s6); ld(7, s7);
+        int kb = 0;
+        for (; kb + 8 <= nkb; kb += 8) {
+            mm(s0); ld(kb + 8, s0);
+            mm(s1); ld(kb + 9, s1);
+            mm(s2); ld(kb + 10, s2);
+            mm(s3); ld(kb + 11, s3);
+            mm(s4); ld(kb + 12, s4);
+            mm(s5); ld(kb + 13, s5);
+            mm(s6); ld(kb + 14, s6);
+            mm(s7); ld(kb + 15, s7);
         }
+        if (kb < nkb) { mm(s0); mm(s1); mm(s2); mm(s3); }
     }
     // C layout: row = (reg & 3) + 8 (reg >> 2) + 4 half, col = lane & 31  ->  LDS [unit][64 samples]  ->  lane = sample
 #pragma unroll
@@ -68,31 +93,25 @@ __device__ __forceinline__ void maf_finish(float us, float sh, float zf, float &
     ld -= __logf(scale);
 }
 
-// One hidden layer of the sequential part: units of the current degree (bitmask m) read `src` (all 32, static regs).
-#define MAF_LAYER(W, DST_EXPR)                                                                  \
-    _Pragma("unroll") for (int u = 0; u < MT; ++u) {                                            \
-        if ((m >> u) & 1u) {                                                                    \
-            DST_EXPR                                                                            \
-        }                                                                                       \
-    }
-
 __global__ void __launch_bounds__(64 * MW)
 maf_inverse_kernel(const float *__restrict__ z, float *__restrict__ y, float *__restrict__ logdet,
                    const float *__restrict__ blob, const int *__restrict__ table, float *S, float *Xs, int64_t B, int acc) {
     __shared__ float lds[MW][MT * 64];
+    __shared__ __attribute__((aligned(16))) float seqw[M_SEQ];  // the tile's biases and diagonal blocks, shared by the 4 waves
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     float *ldsw = lds[wid];
     const int64_t wt = (int64_t)blockIdx.x * MW + wid;
-    if (wt * 64 >= B) return;
+    const bool active = wt * 64 < B;  // idle waves of the last workgroup still take part in the staging barriers
     const int D = table[0], Dp = table[1], Hp = table[3], T = table[4];
     const int64_t sample = wt * 64 + lane;
     const bool valid = sample < B;
+    const int64_t wts = active ? wt : 0;
     const float *zr = z + (valid ? sample : B - 1) * D;
-    float *Sw = S + wt * ((int64_t)5 * Hp * 64);   // [layer][Hp/8][2][64][4]
-    float *Xw = Xs + wt * ((int64_t)Dp * 64);      // [Dp/8][2][64][4]
+    float *Sw = S + wts * ((int64_t)5 * Hp * 64);   // [layer][Hp/8][2][64][4]
+    float *Xw = Xs + wts * ((int64_t)Dp * 64);      // [Dp/8][2][64][4]
     float ld = 0.0f, xcarry;
     maf_finish(blob[0], blob[1], zr[0], xcarry, ld);   // feature 0 depends on no hidden unit
-    Xw[lane * 4] = xcarry;
+    if (active) Xw[lane * 4] = xcarry;
     if (valid) y[sample * D] = xcarry;
 
     for (int t = 0; t < T; ++t) {
@@ -102,18 +121,26 @@ maf_inverse_kernel(const float *__restrict__ z, float *__restrict__ y, float *__
         const float *rec = blob + te[3];
         const float *A0 = rec;
         const float *Ah = A0 + K0 * MT;             // A1..A4, AF : Kh*32 floats each
-        const float *bias = Ah + (size_t)5 * Kh * MT;
+        // stage the sequential part's weights: 23 KB, one copy per workgroup, read back as LDS broadcasts
+        __syncthreads();
+        {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(Ah + (size_t)5 * Kh * MT);
+            for (int i = threadIdx.x; i < M_SEQ / 4; i += 64 * MW) reinterpret_cast<f32x4 *>(seqw)[i] = src[i];
+        }
+        __syncthreads();
+        if (!active) continue;
+        const float *bias = seqw;
         const float *biasF = bias + 5 * MT;
         const float *W0d = biasF + MT;
         const float *Wd = W0d + MT * MS;
         const float *WFd = Wd + 4 * MT * MT;
 
-        float zin[MS];
+        f32x16 zin;
 #pragma unroll
         for (int j = 0; j < MS; ++j) zin[j] = (j < ns) ? zr[dlo + j] : 0.0f;
 
         __threadfence_block();  // the activation scratch written by the other lanes of this wave is read below
-        float p0[MT], p1[MT], p2[MT], p3[MT], p4[MT], pF[MT];
+        f32x32 p0, p1, p2, p3, p4, pF;
         block_part(A0, Xw, K0, ldsw, lane, p0);
         block_part(Ah + (size_t)0 * Kh * MT, Sw + (size_t)0 * Hp * 64, Kh, ldsw, lane, p1);
         block_part(Ah + (size_t)1 * Kh * MT, Sw + (size_t)1 * Hp * 64, Kh, ldsw, lane, p2);
@@ -129,59 +156,86 @@ maf_inverse_kernel(const float *__restrict__ z, float *__restrict__ y, float *__
             p4[u] += bias[4 * MT + u];
             pF[u] += biasF[u];
         }
-        float xg[MS + 1];
+        f32x16 xg = {0};   // window features dlo-1 .. dlo+14 (0-based): xg[0] is the carry, xg[s+1] the output of step s
         xg[0] = xcarry;
-#pragma unroll
-        for (int j = 1; j <= MS; ++j) xg[j] = 0.0f;
 
+        // The sequential part indexes the register vectors with the (wave-uniform) unit number: one compact copy of each
+        // layer's code instead of 32 predicated ones, and a scalar loop over the units of the current degree.
+#ifdef NF_MAF_ABL_NOSEQ
+        for (int s = 0; s < (B == 12345 ? ns : 0); ++s) {
+#else
         for (int s = 0; s < ns; ++s) {
+#endif
             const unsigned m = (unsigned)te[4 + s];
             // initial layer: h0 = pre + W0[window] . x ; the residual h0 is folded into the pre-activation of block 1's
             // second linear (p2), p0 keeps relu(h0) = input of block 1's first linear
-            MAF_LAYER(W0d, {
+            for (unsigned mm = m; mm; mm &= mm - 1) {
+                const int u = __builtin_amdgcn_readfirstlane(__builtin_ctz(mm));
+                const f32x4 *w_ = reinterpret_cast<const f32x4 *>(W0d) + u * (MS / 4);
                 float a = p0[u];
-                _Pragma("unroll") for (int f = 0; f < MS; ++f) a = fmaf(W0d[u * MS + f], xg[f], a);
+#pragma unroll
+                for (int f = 0; f < MS; f += 4) {
+                    const f32x4 w = w_[f / 4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a = fmaf(w[i], xg[f + i], a);
+                }
                 p2[u] += a;
                 p0[u] = fmaxf(a, 0.0f);
-            })
-            MAF_LAYER(Wd, {
-                float a = p1[u];
-                _Pragma("unroll") for (int v = 0; v < MT; ++v) a = fmaf(Wd[u * MT + v], p0[v], a);
-                p1[u] = fmaxf(a, 0.0f);
-            })
-            MAF_LAYER(Wd, {
-                float a = p2[u];
-                _Pragma("unroll") for (int v = 0; v < MT; ++v) a = fmaf(Wd[MT * MT + u * MT + v], p1[v], a);
-                p4[u] += a;                 // residual stream after block 1 feeds block 2's output
-                p2[u] = fmaxf(a, 0.0f);
-            })
-            MAF_LAYER(Wd, {
-                float a = p3[u];
-                _Pragma("unroll") for (int v = 0; v < MT; ++v) a = fmaf(Wd[2 * MT * MT + u * MT + v], p2[v], a);
-                p3[u] = fmaxf(a, 0.0f);
-            })
-            MAF_LAYER(Wd, {
-                float a = p4[u];
-                _Pragma("unroll") for (int v = 0; v < MT; ++v) a = fmaf(Wd[3 * MT * MT + u * MT + v], p3[v], a);
-                p4[u] = a;                  // = h2, the final layer's input (made.py:304: no activation before it)
-            })
-#pragma unroll
-            for (int j = 0; j < MS; ++j) {
-                if (j == s) {
-                    float us = pF[2 * j], sh = pF[2 * j + 1];
-#pragma unroll
-                    for (int v = 0; v < MT; ++v) {
-                        us = fmaf(WFd[(2 * j) * MT + v], p4[v], us);
-                        sh = fmaf(WFd[(2 * j + 1) * MT + v], p4[v], sh);
-                    }
-                    float xn;
-                    maf_finish(us, sh, zin[j], xn, ld);
-                    xg[j + 1] = xn;
-                    xcarry = xn;
+            }
+#define MAF_DOT(WBASE, SRC)                                                                    \
+            const f32x4 *w_ = reinterpret_cast<const f32x4 *>(WBASE) + u * (MT / 4);           \
+            float a0 = 0.0f, a1 = 0.0f;                                                        \
+            _Pragma("unroll") for (int v = 0; v < MT; v += 8) {                                \
+                const f32x4 wa = w_[v / 4], wb = w_[v / 4 + 1];                                \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                \
+                    a0 = fmaf(wa[i], SRC[v + i], a0);                                          \
+                    a1 = fmaf(wb[i], SRC[v + 4 + i], a1);                                      \
+                }                                                                              \
+            }
+            for (unsigned mm = m; mm; mm &= mm - 1) {
+                const int u = __builtin_amdgcn_readfirstlane(__builtin_ctz(mm));
+                MAF_DOT(Wd, p0)
+                p1[u] = fmaxf(p1[u] + (a0 + a1), 0.0f);
+            }
+            for (unsigned mm = m; mm; mm &= mm - 1) {
+                const int u = __builtin_amdgcn_readfirstlane(__builtin_ctz(mm));
+                MAF_DOT(Wd + MT * MT, p1)
+                const float h1 = p2[u] + (a0 + a1);
+                p4[u] += h1;                 // residual stream after block 1 feeds block 2's output
+                p2[u] = fmaxf(h1, 0.0f);
+            }
+            for (unsigned mm = m; mm; mm &= mm - 1) {
+                const int u = __builtin_amdgcn_readfirstlane(__builtin_ctz(mm));
+                MAF_DOT(Wd + 2 * MT * MT, p2)
+                p3[u] = fmaxf(p3[u] + (a0 + a1), 0.0f);
+            }
+            for (unsigned mm = m; mm; mm &= mm - 1) {
+                const int u = __builtin_amdgcn_readfirstlane(__builtin_ctz(mm));
+                MAF_DOT(Wd + 3 * MT * MT, p3)
+                p4[u] = p4[u] + (a0 + a1);   // = h2, the final layer's input (made.py:304: no activation before it)
+            }
+            {
+                float us, sh;
+                {
+                    const int u = 2 * s;
+                    MAF_DOT(WFd, p4)
+                    us = pF[u] + (a0 + a1);
                 }
+                {
+                    const int u = 2 * s + 1;
+                    MAF_DOT(WFd, p4)
+                    sh = pF[u] + (a0 + a1);
+                }
+                float xn;
+                maf_finish(us, sh, zin[s], xn, ld);
+                if (s + 1 < MS) xg[s + 1] = xn;
+                xcarry = xn;
+                const int f = dlo + s;
+                Xw[((size_t)((f >> 3) * 2 + ((f >> 2) & 1)) * 64 + lane) * 4 + (f & 3)] = xn;
+                if (valid) y[sample * D + f] = xn;
             }
         }
-        // ---- publish the tile: activations in B-operand order, the new features to y and to the feature scratch ----
+        // ---- publish the tile: activations in B-operand order ----
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -195,14 +249,6 @@ maf_inverse_kernel(const float *__restrict__ z, float *__restrict__ y, float *__
                 *reinterpret_cast<f32x4 *>(Sw + (size_t)4 * Hp * 64 + o) = f32x4{p4[u0], p4[u0 + 1], p4[u0 + 2], p4[u0 + 3]};
             }
         }
-#pragma unroll
-        for (int j = 0; j < MS; ++j) {
-            if (j < ns) {
-                const int f = dlo + j;
-                Xw[((size_t)((f >> 3) * 2 + ((f >> 2) & 1)) * 64 + lane) * 4 + (f & 3)] = xg[j + 1];
-                if (valid) y[sample * D + f] = xg[j + 1];
-            }
-        }
     }
     if (valid) ld_store(logdet + sample, ld, acc);
 }
@@ -212,7 +258,7 @@ maf_inverse_kernel(const float *__restrict__ z, float *__restrict__ y, float *__
 extern "C" int64_t nf_maf_inverse_scratch_floats(int64_t B, int D, int hidden_padded) {
     if (B < 0 || D < 1 || hidden_padded < 0) return NF_EINVAL;
     const int64_t nwt = (B + 63) / 64;
-    const int64_t Dp = (D + 7) / 8 * 8;
+    const int64_t Dp = (D + 31) / 32 * 32;
     return nwt * 64 * ((int64_t)5 * hidden_padded + Dp);
 }
 
@@ -224,10 +270,10 @@ extern "C" int nf_maf_inverse(const void *z, void *y, void *logdet, const void *
     if (!z || !y || !logdet || !blob || !table || !scratch) return NF_EFAULT;
     hipStream_t st = (hipStream_t)stream;
     const int64_t nwt = (B + 63) / 64;
-    const int64_t Dp = (D + 7) / 8 * 8;
+    const int64_t Dp = (D + 31) / 32 * 32;
     float *S = (float *)scratch;
     float *Xs = S + nwt * 64 * (int64_t)5 * hidden_padded;
-    // the feature scratch is read with zero weights before it is written (K0 is padded to 8): it must hold finite values
+    // the feature scratch is read with zero weights before it is written (K0 is padded to 32): it must hold finite values
     if (hipMemsetAsync(Xs, 0, (size_t)nwt * 64 * Dp * sizeof(float), st) != hipSuccess) return NF_EIO;
     const int grid = (int)((nwt + nf::MW - 1) / nf::MW);
     hipLaunchKernelGGL(nf::maf_inverse_kernel, dim3(grid), dim3(64 * nf::MW), 0, st, (const float *)z, (float *)y,

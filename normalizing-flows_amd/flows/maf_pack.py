@@ -12,7 +12,7 @@ degrees in order; hidden units are sorted by degree and cut into tiles of <= 32 
 
 This module only rearranges weights (no arithmetic on data).  Layout of the float blob (all offsets in floats):
 
-  [0:2]                       final-layer bias of feature 0 (unconstrained scale, shift): it depends on no hidden unit
+  [0:4]                       final-layer bias of feature 0 (unconstrained scale, shift) + 2 pad: depends on no hidden unit
   per tile t, at table[t].rec : A0 [K0/8][2][32][4] | A1..A4, AF [4t][2][32][4] each | bias[5][32] | biasF[32]
                                 | W0d[32][16] | Wd[4][32][32] | WFd[32][32]
 and of the int32 table: [D, Dp, H, Hp, T, 0, 0, 0] then per tile 24 ints
@@ -99,7 +99,7 @@ def pack_made(made):
         return None
     order, tiles = plan
     T = len(tiles)
-    Hp, Dp = T * TILE, (D + 7) // 8 * 8
+    Hp, Dp = T * TILE, (D + 31) // 32 * 32
 
     # position of every sorted unit in the padded index space, and the degree of every padded slot (0 = pad)
     pos = np.zeros(H, dtype=np.int64)
@@ -144,14 +144,14 @@ def pack_made(made):
     WF = np.zeros((2 * D, Hp), dtype=np.float32)
     WF[:, hid_map] = wf
 
-    chunks = [bf[0:2].copy()]
-    off = 2
+    chunks = [np.array([bf[0], bf[1], 0.0, 0.0], dtype=np.float32)]   # 16-byte header keeps every section aligned
+    off = 4
     table = np.zeros(TABLE_HDR + TABLE_ENT * T, dtype=np.int32)
     table[0:5] = [D, Dp, H, Hp, T]
     for t, (dlo, ns, steps) in enumerate(tiles):
         r0, r1 = t * TILE, (t + 1) * TILE
         nprev = dlo - 1                    # features (0-based) 0..dlo-2 come from the block part; dlo-1.. from the window
-        K0 = (nprev + 7) // 8 * 8
+        K0 = (nprev + 31) // 32 * 32          # the kernel's k loop is unrolled by 32
         a0 = np.zeros((TILE, K0), dtype=np.float32)
         a0[:, :nprev] = W0[r0:r1, :nprev]
         rec = [_a_operand(a0)] if K0 else []
