@@ -6,4 +6,5 @@ from .mixing import Permute, Invertible1x1Conv, LULinearPermute
 from .glow import GlowBlock
 from .neural_spline import (CoupledRationalQuadraticSpline, PiecewiseRationalQuadraticCoupling,
                             PiecewiseRationalQuadraticCDF)
-from .autoregressive import Autoregressive, MaskedAffineAutoregressive
+from .autoregressive import (Autoregressive, MaskedAffineAutoregressive,
+                             MaskedPiecewiseRationalQuadraticAutoregressive, AutoregressiveRationalQuadraticSpline)

@@ -1,4 +1,5 @@
-"""Masked autoregressive flow (MAF): Autoregressive, MaskedAffineAutoregressive.
+"""Autoregressive flows: Autoregressive, MaskedAffineAutoregressive (MAF), MaskedPiecewiseRationalQuadraticAutoregressive
+and its wrapper AutoregressiveRationalQuadraticSpline (AR-NSF).
 
 Mirrors normflows/flows/affine/autoregressive.py:10-128 (constructor signature, `autoregressive_net.*` state_dict
 keys, direction semantics: `forward` = one MADE pass, `inverse` = D sequential MADE passes).  The element-wise
@@ -87,3 +88,84 @@ class MaskedAffineAutoregressive(Autoregressive):
         if inputs.dim() != 2:
             raise NotImplementedError("MaskedAffineAutoregressive: (batch, features) inputs only")
         return ops.maf_affine(inputs, params, direction, want_logdet=want_logdet)
+
+
+class MaskedPiecewiseRationalQuadraticAutoregressive(Autoregressive):
+    """Autoregressive rational-quadratic spline transform (neural_spline/autoregressive.py:17-140).  MADE produces
+    3K-1 | 3K | 3K+1 numbers per feature (linear | circular | no tails); the element-wise spline and its row-summed
+    log-det are ONE launch of nf_rqs_coupling with every column a transform column (no identity half).  The widths and
+    heights are NOT divided by sqrt(hidden): the reference tests `hasattr(net, "hidden_features")` (:107-109) and its
+    MADE never sets that attribute."""
+
+    def __init__(self, features, hidden_features, context_features=None, num_bins=10, tails=None, tail_bound=1.0,
+                 num_blocks=2, use_residual_blocks=True, random_mask=False, permute_mask=False, activation=F.relu,
+                 dropout_probability=0.0, use_batch_norm=False, init_identity=True, min_bin_width=1e-3,
+                 min_bin_height=1e-3, min_derivative=1e-3):
+        if isinstance(tails, (list, tuple)) or torch.is_tensor(tail_bound):
+            raise NotImplementedError("per-feature tails / tensor tail_bound (periodic features) are out of scope")
+        if tails not in (None, "linear", "circular"):
+            raise RuntimeError("{} tails are not implemented.".format(tails))
+        self.num_bins = num_bins
+        self.min_bin_width = min_bin_width
+        self.min_bin_height = min_bin_height
+        self.min_derivative = min_derivative
+        self.tails = tails
+        self.features = features
+        made = nets.MADE(features=features, hidden_features=hidden_features, context_features=context_features,
+                         num_blocks=num_blocks, output_multiplier=self._output_dim_multiplier(),
+                         use_residual_blocks=use_residual_blocks, random_mask=random_mask, permute_mask=permute_mask,
+                         activation=activation, dropout_probability=dropout_probability,
+                         use_batch_norm=use_batch_norm)
+        if init_identity:
+            torch.nn.init.constant_(made.final_layer.weight, 0.0)
+            torch.nn.init.constant_(made.final_layer.bias, float(np.log(np.exp(1 - min_derivative) - 1)))
+        super().__init__(made)
+        self.tail_bound = tail_bound
+
+    def _output_dim_multiplier(self):
+        if self.tails == "linear":
+            return self.num_bins * 3 - 1
+        if self.tails == "circular":
+            return self.num_bins * 3
+        return self.num_bins * 3 + 1
+
+    def _elementwise(self, inputs, params, direction, want_logdet=True):
+        if inputs.dim() != 2:
+            raise NotImplementedError("MaskedPiecewiseRationalQuadraticAutoregressive: (batch, features) inputs only")
+        B, D = inputs.shape
+        idx = getattr(self, "_all_idx", None)
+        if idx is None or idx[0].device != inputs.device or idx[1].numel() != D:
+            idx = (torch.empty(0, dtype=torch.long, device=inputs.device),
+                   torch.arange(D, dtype=torch.long, device=inputs.device))
+            self._all_idx = idx
+        wh_div = float(np.sqrt(self.autoregressive_net.hidden_features)) \
+            if hasattr(self.autoregressive_net, "hidden_features") else 1.0
+        mode = ops.L.RQS_DENSITY if direction == 0 else ops.L.RQS_SAMPLE_TRANSFORM
+        return ops.rqs_coupling(inputs, params.contiguous(), None, None, None, idx[0], idx[1], self.num_bins, mode,
+                                tails=self.tails, tail_bound=float(self.tail_bound),
+                                min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+                                min_derivative=self.min_derivative, wh_div=wh_div)
+
+
+class AutoregressiveRationalQuadraticSpline(Flow):
+    """NSF autoregressive layer (neural_spline/wrapper.py:188-245): like the coupling wrapper the directions are
+    swapped, forward (generative) = D-pass inverse of the transform, inverse (density) = one MADE pass + spline."""
+
+    def __init__(self, num_input_channels, num_blocks, num_hidden_channels, num_context_channels=None, num_bins=8,
+                 tail_bound=3, activation=torch.nn.ReLU, dropout_probability=0.0, permute_mask=False,
+                 init_identity=True):
+        super().__init__()
+        act = activation()
+        self.mprqat = MaskedPiecewiseRationalQuadraticAutoregressive(
+            features=num_input_channels, hidden_features=num_hidden_channels, context_features=num_context_channels,
+            num_bins=num_bins, tails="linear", tail_bound=tail_bound, num_blocks=num_blocks, use_residual_blocks=True,
+            random_mask=False, permute_mask=permute_mask, activation=F.relu if isinstance(act, torch.nn.ReLU) else act,
+            dropout_probability=dropout_probability, use_batch_norm=False, init_identity=init_identity)
+
+    def forward(self, z, context=None):
+        z, log_det = self.mprqat.inverse(z, context=context)
+        return z, log_det.view(-1)
+
+    def inverse(self, z, context=None):
+        z, log_det = self.mprqat(z, context=context)
+        return z, log_det.view(-1)

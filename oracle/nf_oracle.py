@@ -270,6 +270,25 @@ def maf_layer(st, x, inverse, prefix="autoregressive_net."):
     return out, ld
 
 
+def arnsf_transform(st, x, inverse, K, tails="linear", tail_bound=3.0, prefix="mprqat.autoregressive_net."):
+    """MaskedPiecewiseRationalQuadraticAutoregressive.forward / .inverse (neural_spline/autoregressive.py:94-140 over
+    affine/autoregressive.py:24-38): MADE -> (B, D, 3K-1|3K|3K+1) -> element-wise spline, row-summed log-det; no
+    sqrt(hidden) scaling (the reference's MADE has no `hidden_features` attribute, :107-109)."""
+    def elementwise(inp, params, inv):
+        B, D = inp.shape
+        prm = params.reshape(B, D, -1).astype(inp.dtype)
+        y, lad = rqs_spline(inp, prm[..., :K], prm[..., K:2 * K], prm[..., 2 * K:], inverse=inv, tails=tails,
+                            tail_bound=tail_bound)
+        return y, lad.sum(1)
+    if not inverse:
+        return elementwise(x, made_forward(st, x, prefix), False)
+    out = np.zeros_like(x)
+    ld = None
+    for _ in range(x.shape[1]):
+        out, ld = elementwise(x, made_forward(st, out, prefix), True)
+    return out, ld
+
+
 # ---------------------------------------------------------------------------------------------------------
 class OracleNSF:
     """NormalizingFlow([CoupledRationalQuadraticSpline, LULinearPermute] * L, DiagGaussian) on the CPU oracle.

@@ -426,7 +426,36 @@ def gen_maf():
         npz("maf_d%d" % d, x=x, params=params, z_fwd=zf, ld_fwd=ldf, z_inv=zi, ld_inv=ldi, **st)
 
 
+def gen_arnsf():
+    """AutoregressiveRationalQuadraticSpline (neural_spline/wrapper.py:188-245 over autoregressive.py:17-140):
+    wrapper.forward = mprqat.inverse (D MADE passes), wrapper.inverse = one MADE pass + spline."""
+    for name, d, hidden, K, B, ident in (("arnsf_d6", 6, 16, 8, 11, False), ("arnsf_d5_ident", 5, 12, 4, 7, True)):
+        torch.manual_seed(2000 + d)
+        layer = nf.flows.AutoregressiveRationalQuadraticSpline(d, 2, hidden, num_bins=K, tail_bound=3,
+                                                               init_identity=ident)
+        perturb(layer, 0.3 if not ident else 0.0, 9)
+        x = 1.7 * torch.randn(B, d, generator=torch.Generator().manual_seed(d))
+        x[0, 0], x[1, 1] = 3.5, -4.0   # outside the tails
+        with torch.no_grad():
+            zf, ldf = layer.forward(x)
+            zi, ldi = layer.inverse(x)
+        npz(name, x=x, z_fwd=zf, ld_fwd=ldf, z_inv=zi, ld_inv=ldi, **sd(layer, "sd__"))
+    # the bare transform with tails=None on [0, 1] (autoregressive.py:87-93, :113-115)
+    torch.manual_seed(77)
+    t = nf.flows.neural_spline.autoregressive.MaskedPiecewiseRationalQuadraticAutoregressive(
+        4, 10, num_bins=5, tails=None, num_blocks=2, init_identity=False)
+    perturb(t, 0.3, 10)
+    x = torch.rand(9, 4, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        zf, ldf = t.forward(x)
+        zi, ldi = t.inverse(x)
+    npz("arnsf_notails", x=x, z_fwd=zf, ld_fwd=ldf, z_inv=zi, ld_inv=ldi, **sd(t, "sd__"))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "arnsf":
+        gen_arnsf()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "maf":
         gen_maf()
         sys.exit(0)
@@ -439,3 +468,4 @@ if __name__ == "__main__":
     gen_models()
     gen_grads()
     gen_maf()
+    gen_arnsf()

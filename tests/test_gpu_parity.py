@@ -639,3 +639,45 @@ def test_maf_incremental_unsupported_falls_back_to_d_pass(nfa):
     x, ld = layer.inverse(z)
     xr, _ = layer.forward(x)
     assert_close(N(xr), N(z), what="roundtrip", rtol=1e-4, atol=1e-4)
+
+
+# ---- AR-NSF (neural_spline/autoregressive.py, wrapper.py:188-245) ------------------------------------------------
+@pytest.mark.parametrize("name,d,hidden,K,ident", [("arnsf_d6", 6, 16, 8, False), ("arnsf_d5_ident", 5, 12, 4, True)])
+def test_arnsf_wrapper_vs_reference(nfa, name, d, hidden, K, ident):
+    g = load_golden(name)
+    layer = load_layer(nfa.flows.AutoregressiveRationalQuadraticSpline(d, 2, hidden, num_bins=K, tail_bound=3,
+                                                                       init_identity=ident), golden_state(g), torch.float32)
+    z, ld = layer.inverse(T(g["x"]))                 # density direction: one MADE pass + spline kernel
+    assert_close(N(z), g["z_inv"], what="z_inv", rtol=1e-4, atol=1e-5)
+    assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=1e-4, atol=1e-5)
+    z, ld = layer.forward(T(g["x"]))                 # generative direction: D MADE passes
+    assert_close(N(z), g["z_fwd"], what="z_fwd", rtol=1e-4, atol=1e-4)
+    assert_close(N(ld), g["ld_fwd"], what="ld_fwd", rtol=1e-4, atol=1e-4)
+    xr, ldr = layer.inverse(z)
+    assert_close(N(xr), g["x"], what="roundtrip", rtol=1e-4, atol=1e-4)
+    assert_close(N(ldr), -N(ld), what="roundtrip ld", rtol=1e-4, atol=1e-4)
+
+
+def test_arnsf_transform_without_tails_vs_reference(nfa):
+    g = load_golden("arnsf_notails")
+    t = load_layer(nfa.flows.MaskedPiecewiseRationalQuadraticAutoregressive(4, 10, num_bins=5, tails=None, num_blocks=2,
+                                                                            init_identity=False),
+                   golden_state(g), torch.float32)
+    z, ld = t.forward(T(g["x"]))
+    assert_close(N(z), g["z_fwd"], what="z_fwd", rtol=1e-4, atol=1e-5)
+    assert_close(N(ld), g["ld_fwd"], what="ld_fwd", rtol=1e-4, atol=1e-5)
+    z, ld = t.inverse(T(g["x"]))
+    assert_close(N(z), g["z_inv"], what="z_inv", rtol=1e-4, atol=1e-4)
+    assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=1e-4, atol=1e-4)
+
+
+def test_arnsf_in_normalizing_flow(nfa):
+    """Stack of AR-NSF layers + LULinearPermute inside NormalizingFlow: sample() log_q == log_prob (core_test.py:187)."""
+    torch.manual_seed(3)
+    flows = []
+    for _ in range(3):
+        flows += [nfa.flows.AutoregressiveRationalQuadraticSpline(5, 2, 16, num_bins=6, init_identity=False),
+                  nfa.flows.LULinearPermute(5)]
+    m = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(5, trainable=False), flows).to(DEV)
+    x, lq = m.sample(64)
+    assert_close(N(m.log_prob(x)), N(lq), what="log_prob(sample)", rtol=2e-4, atol=2e-4)

@@ -217,3 +217,28 @@ def test_maf_layer(oracle):
     y, ld = oracle.maf_layer(st, g["x"], inverse=True)
     assert_close(y, g["z_inv"], what="z_inv", rtol=1e-4, atol=1e-4)
     assert_close(ld, g["ld_inv"], what="ld_inv", rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("name,K", [("arnsf_d6", 8), ("arnsf_d5_ident", 4)])
+def test_arnsf_layer(oracle, name, K):
+    """AutoregressiveRationalQuadraticSpline vs the reference: wrapper.inverse = transform.forward (one MADE pass),
+    wrapper.forward = transform.inverse (D passes) (neural_spline/wrapper.py:236-245)."""
+    g = load_golden(name)
+    st = golden_state(g)
+    y, ld = oracle.arnsf_transform(st, g["x"], False, K)
+    assert_close(y, g["z_inv"], what="z_inv", rtol=1e-4, atol=1e-5)
+    assert_close(ld, g["ld_inv"], what="ld_inv", rtol=1e-4, atol=1e-5)
+    y, ld = oracle.arnsf_transform(st, g["x"], True, K)
+    assert_close(y, g["z_fwd"], what="z_fwd", rtol=1e-4, atol=1e-4)
+    assert_close(ld, g["ld_fwd"], what="ld_fwd", rtol=1e-4, atol=1e-4)
+
+
+def test_arnsf_transform_without_tails(oracle):
+    g = load_golden("arnsf_notails")
+    st = golden_state(g)
+    y, ld = oracle.arnsf_transform(st, g["x"], False, 5, tails=None, tail_bound=1.0, prefix="autoregressive_net.")
+    assert_close(y, g["z_fwd"], what="z_fwd", rtol=1e-4, atol=1e-5)
+    assert_close(ld, g["ld_fwd"], what="ld_fwd", rtol=1e-4, atol=1e-5)
+    y, ld = oracle.arnsf_transform(st, g["x"], True, 5, tails=None, tail_bound=1.0, prefix="autoregressive_net.")
+    assert_close(y, g["z_inv"], what="z_inv", rtol=1e-4, atol=1e-4)
+    assert_close(ld, g["ld_inv"], what="ld_inv", rtol=1e-4, atol=1e-4)
