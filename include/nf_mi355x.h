@@ -243,6 +243,30 @@ int nf_diag_gaussian_log_prob(const void *z, const void *loc, const void *log_sc
                               void *out, int64_t B, int64_t d, int acc, int dtype, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Logit preprocessing transform of image tensors.  Replaces normflows/transforms.py:8-47.
+ *   z, y (B, inner) contiguous (inner = C*H*W); beta = 1 - 2 alpha, 0 <= alpha < 0.5.
+ *   direction 0 = Logit.forward (:25-32): y = (sigmoid(z) - alpha)/beta,
+ *                 ld = -inner log(beta) + sum logsigmoid(z) + sum logsigmoid(-z);
+ *   direction 1 = Logit.inverse (:34-47): u = alpha + beta z, y = log u - log(1 - u),
+ *                 ld = inner log(beta) - sum log u - sum log(1 - u).
+ *   logdet (B) combined according to `acc`.
+ */
+int nf_logit(const void *z, void *y, void *logdet, int64_t B, int64_t inner, double alpha, int direction, int acc,
+             int dtype, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Diagonal Gaussian log-density with a mean / log-scale ROW per sample.  Replaces
+ * normflows/distributions/base.py:326-345 (ClassCondDiagGaussian.log_prob).
+ *   loc_rows, log_scale_rows (num_rows, d) row-major: for class labels the transposed parameters
+ *   (num_classes, d) with row_idx (B) int64 = labels (an out-of-range label yields NaN for that sample);
+ *   for soft labels the blended rows (B, d) with row_idx = NULL (row b belongs to sample b).
+ *   out[b] (acc)= -d/2 log(2 pi) - sum_j (ls_j + 0.5 ((z_bj - loc_j) / exp(ls_j))^2), ls = log_scale + log_scale_shift.
+ */
+int nf_diag_gaussian_log_prob_rows(const void *z, const void *loc_rows, const void *log_scale_rows,
+                                   const int64_t *row_idx, int64_t num_rows, double log_scale_shift, void *out,
+                                   int64_t B, int64_t d, int acc, int dtype, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * MaskedAffineAutoregressive element-wise transform (MAF).  Replaces
  * normflows/flows/affine/autoregressive.py:98-128 (_elementwise_forward / _elementwise_inverse).
  *   params (B, D, 2): MADE output viewed as (unconstrained_scale, shift) per feature (:124-128);

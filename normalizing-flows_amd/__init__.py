@@ -8,9 +8,9 @@ eager fallback: layers raise if the library is missing or a tensor is not on a H
 The on-disk package directory is `normalizing-flows_amd/`; import it as `normflows_amd` (see normflows_amd.py
 at the repository root).
 """
-from . import _lib, config, ops, nets, flows, distributions, utils, dp
+from . import _lib, config, ops, nets, flows, distributions, transforms, utils, dp
 from .core import NormalizingFlow, MultiscaleFlow
-from .distributions import DiagGaussian
+from .distributions import DiagGaussian, ClassCondDiagGaussian
 
 __version__ = "0.1.0"
 

@@ -1,4 +1,5 @@
-"""Base distributions at the end of the path: DiagGaussian (normflows/distributions/base.py:8-103).
+"""Base distributions at the end of the path: DiagGaussian (normflows/distributions/base.py:8-103) and
+ClassCondDiagGaussian (:273-345, the base of the reference's Glow example).
 
 log_prob is one launch of nf_diag_gaussian_log_prob (optionally accumulating into the caller's log_q);
 sampling draws torch.randn on the device and evaluates the same closed form.
@@ -79,3 +80,69 @@ class DiagGaussian(BaseDistribution):
             return log_q
         ops.diag_gaussian_log_prob(z, self.loc.detach(), self.log_scale.detach(), self._shift(), out=log_q, acc=acc)
         return log_q
+
+
+class ClassCondDiagGaussian(BaseDistribution):
+    """Class-conditional diagonal Gaussian (base.py:273-345).  Parameters keep the reference layout (*shape,
+    num_classes) so state_dicts interchange; the kernel reads the transposed (num_classes, d) rows, refreshed when a
+    parameter changes.  y is a vector of labels (row gather inside the kernel) or a (B, num_classes) weight matrix
+    (rows blended by one library GEMM, as the reference's `loc @ y`)."""
+
+    def __init__(self, shape, num_classes):
+        super().__init__()
+        if isinstance(shape, int):
+            shape = (shape,)
+        if isinstance(shape, list):
+            shape = tuple(shape)
+        self.shape = shape
+        self.n_dim = len(shape)
+        self.perm = [self.n_dim] + list(range(self.n_dim))
+        self.d = np.prod(shape)
+        self.num_classes = num_classes
+        self.loc = nn.Parameter(torch.zeros(*self.shape, num_classes))
+        self.log_scale = nn.Parameter(torch.zeros(*self.shape, num_classes))
+        self.temperature = None
+        self._rows_cache = None
+
+    def _shift(self):
+        return 0.0 if self.temperature is None else float(np.log(self.temperature))
+
+    def _rows(self):
+        """(num_classes, d) copies of loc / log_scale."""
+        key = (self.loc.data_ptr(), self.loc._version, self.log_scale.data_ptr(), self.log_scale._version)
+        if self._rows_cache is None or self._rows_cache[0] != key:
+            d = int(self.d)
+            self._rows_cache = (key, self.loc.detach().reshape(d, self.num_classes).t().contiguous(),
+                                self.log_scale.detach().reshape(d, self.num_classes).t().contiguous())
+        return self._rows_cache[1], self._rows_cache[2]
+
+    def _select(self, y, num_samples):
+        """Per-sample (loc, log_scale) rows and the row index the kernel should use."""
+        loc_r, ls_r = self._rows()
+        if y.dim() == 1:
+            return loc_r, ls_r, y
+        w = y.to(loc_r.dtype)
+        return w @ loc_r, w @ ls_r, None
+
+    def forward(self, num_samples=1, y=None):
+        if y is not None:
+            num_samples = len(y)
+        else:
+            y = torch.randint(self.num_classes, (num_samples,), device=self.loc.device)
+        loc_r, ls_r, idx = self._select(y, num_samples)
+        eps = torch.randn((num_samples,) + self.shape, dtype=self.loc.dtype, device=self.loc.device)
+        if idx is not None:
+            loc_b, ls_b = loc_r[idx], ls_r[idx]
+        else:
+            loc_b, ls_b = loc_r, ls_r
+        ls_b = (ls_b + self._shift()).view((num_samples,) + self.shape)
+        z = loc_b.view((num_samples,) + self.shape) + torch.exp(ls_b) * eps
+        zeros = torch.zeros(1, int(self.d), dtype=z.dtype, device=z.device)
+        log_p = ops.diag_gaussian_log_prob(eps, zeros, zeros, 0.0) - ls_b.reshape(num_samples, -1).sum(1)
+        return z, log_p
+
+    def log_prob(self, z, y):
+        if needs_grad(z, self.loc, self.log_scale):
+            raise NotImplementedError("ClassCondDiagGaussian: inference only (no autograd through the HIP kernel yet)")
+        loc_r, ls_r, idx = self._select(y, len(z))
+        return ops.diag_gaussian_log_prob_rows(z, loc_r, ls_r, idx, self._shift())

@@ -416,3 +416,43 @@ def maf_inverse(z, blob, table, hidden_padded, logdet=None, acc=None):
                                 i32(hidden_padded), i32(acc), L.stream())
     L.check(rc, "nf_maf_inverse")
     return y, logdet
+
+
+def logit(z, alpha, direction, logdet=None, acc=None):
+    """transforms.py:8-47.  direction 0 = Logit.forward (sigmoid side), 1 = Logit.inverse (logit side)."""
+    L.require_device(z)
+    z = z.contiguous()
+    B = z.shape[0]
+    inner = z[0].numel() if B else int(math.prod(z.shape[1:]))
+    y = torch.empty_like(z)
+    if logdet is None:
+        logdet = torch.empty(B, dtype=z.dtype, device=z.device)
+        acc = L.LD_WRITE
+    elif acc is None:
+        acc = L.LD_ADD
+    rc = L.lib().nf_logit(ptr(z), ptr(y), ptr(logdet), i64(B), i64(inner), f64(alpha), i32(direction), i32(acc),
+                          i32(L.dtype_code(z)), L.stream())
+    L.check(rc, "nf_logit")
+    return y, logdet
+
+
+def diag_gaussian_log_prob_rows(z, loc_rows, log_scale_rows, row_idx=None, ls_shift=0.0, out=None, acc=None):
+    """distributions/base.py:326-345: one (loc, log_scale) row per sample, picked by `row_idx` (class labels) or row b."""
+    L.require_device(z, loc_rows, log_scale_rows, row_idx)
+    B = z.shape[0]
+    z = z.contiguous()
+    d = z[0].numel() if B else int(math.prod(z.shape[1:]))
+    loc_rows = loc_rows.contiguous().view(-1, d)
+    log_scale_rows = log_scale_rows.contiguous().view(-1, d)
+    if out is None:
+        out = torch.empty(B, dtype=z.dtype, device=z.device)
+        acc = L.LD_WRITE
+    elif acc is None:
+        acc = L.LD_ADD
+    if row_idx is not None:
+        row_idx = row_idx.to(torch.long).contiguous()
+    rc = L.lib().nf_diag_gaussian_log_prob_rows(ptr(z), ptr(loc_rows), ptr(log_scale_rows), ptr(row_idx),
+                                                i64(loc_rows.shape[0]), f64(ls_shift), ptr(out), i64(B), i64(d), i32(acc),
+                                                i32(L.dtype_code(z)), L.stream())
+    L.check(rc, "nf_diag_gaussian_log_prob_rows")
+    return out

@@ -1,1 +1,3 @@
 from .masks import create_alternating_binary_mask, create_mid_split_binary_mask, create_random_binary_mask
+from .eval import bitsPerDim, bitsPerDimDataset
+from .preprocessing import Logit, Jitter, Scale

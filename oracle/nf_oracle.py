@@ -224,6 +224,31 @@ def diag_gaussian_log_prob(z, loc, log_scale, ls_shift=0.0, out=None, acc=0):
     return out
 
 
+def diag_gaussian_log_prob_rows(z, loc_rows, log_scale_rows, row_idx=None, ls_shift=0.0):
+    dt = z.dtype
+    z = _c(z, dt)
+    B = z.shape[0]
+    d = int(np.prod(z.shape[1:]))
+    out = np.zeros(B, dt)
+    idx = None if row_idx is None else np.ascontiguousarray(row_idx, dtype=np.int64)
+    getattr(lib(), "nfo_diag_gaussian_log_prob_rows" + _sfx(dt))(
+        _p(z), _p(_c(loc_rows, dt).reshape(-1, d)), _p(_c(log_scale_rows, dt).reshape(-1, d)),
+        _p(idx) if idx is not None else None, C.c_double(ls_shift), _p(out), C.c_int64(B), C.c_int64(d))
+    return out
+
+
+def logit(z, alpha, direction):
+    dt = z.dtype
+    z = _c(z, dt)
+    B = z.shape[0]
+    inner = int(np.prod(z.shape[1:]))
+    y = np.empty_like(z)
+    ld = np.empty(B, dt)
+    getattr(lib(), "nfo_logit" + _sfx(dt))(_p(z), _p(y), _p(ld), C.c_int64(B), C.c_int64(inner), C.c_double(alpha),
+                                           C.c_int(direction))
+    return y, ld
+
+
 def squeeze(z, direction):
     dt = z.dtype
     z = _c(z, dt)

@@ -462,6 +462,48 @@ void FN(nfo_diag_gaussian_log_prob)(const REAL *z, const REAL *loc, const REAL *
     }
 }
 
+/* distributions/base.py:326-345 ClassCondDiagGaussian.log_prob: sample b uses row row_idx[b] (or b when NULL) of the
+ * (num_rows, d) mean / log-scale tables (the transposed (*shape, num_classes) parameters, or the blended rows). */
+void FN(nfo_diag_gaussian_log_prob_rows)(const REAL *z, const REAL *loc, const REAL *log_scale, const int64_t *row_idx,
+                                         double ls_shift, REAL *out, int64_t B, int64_t d) {
+    const REAL cst = (REAL)(-0.5 * (double)d * log(2.0 * M_PI));
+    int64_t b, j;
+    for (b = 0; b < B; ++b) {
+        const int64_t row = row_idx ? row_idx[b] : b;
+        REAL a = 0;
+        for (j = 0; j < d; ++j) {
+            const REAL ls = log_scale[row * d + j] + (REAL)ls_shift;
+            const REAL q = (z[b * d + j] - loc[row * d + j]) / EXP(ls);
+            a += ls + (REAL)0.5 * (q * q);
+        }
+        out[b] = cst - a;
+    }
+}
+
+/* transforms.py:25-47 Logit.forward (direction 0) / Logit.inverse (direction 1); logsigmoid(v) = -softplus(-v) */
+void FN(nfo_logit)(const REAL *z, REAL *y, REAL *logdet, int64_t B, int64_t inner, double alpha, int direction) {
+    const REAL al = (REAL)alpha, beta = (REAL)(1.0 - 2.0 * alpha), log_beta = (REAL)log(1.0 - 2.0 * alpha);
+    int64_t b, j;
+    for (b = 0; b < B; ++b) {
+        REAL a = 0;
+        for (j = 0; j < inner; ++j) {
+            const REAL v = z[b * inner + j];
+            if (direction == 0) {
+                const REAL spn = (-v > (REAL)20) ? -v : LOG1P(EXP(-v));
+                const REAL spp = (v > (REAL)20) ? v : LOG1P(EXP(v));
+                a -= spn + spp;
+                y[b * inner + j] = ((REAL)1 / ((REAL)1 + EXP(-v)) - al) / beta;
+            } else {
+                const REAL u = al + beta * v;
+                const REAL lu = LOG(u), l1 = LOG((REAL)1 - u);
+                a -= lu + l1;
+                y[b * inner + j] = lu - l1;
+            }
+        }
+        logdet[b] = a + (direction == 0 ? -log_beta : log_beta) * (REAL)inner;
+    }
+}
+
 /* reshape.py:116-128 Squeeze.forward (direction 0) / inverse (direction 1) */
 void FN(nfo_squeeze)(const REAL *z, REAL *y, int64_t B, int C, int H, int W, int direction) {
     int64_t b;

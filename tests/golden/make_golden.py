@@ -452,7 +452,58 @@ def gen_arnsf():
     npz("arnsf_notails", x=x, z_fwd=zf, ld_fwd=ldf, z_inv=zi, ld_inv=ldi, **sd(t, "sd__"))
 
 
+def gen_glue():
+    """Image-side glue: transforms.Logit, ClassCondDiagGaussian, and both inside a class-conditional
+    MultiscaleFlow as in examples/glow.ipynb (reduced: L=2, K=2, hidden 8, 3x8x8)."""
+    g = torch.Generator().manual_seed(21)
+    t = nf.transforms.Logit(alpha=0.05)
+    u = torch.rand(5, 3, 4, 4, generator=g)
+    v = 3.0 * torch.randn(5, 3, 4, 4, generator=g)
+    xi, ldi = t.inverse(u)
+    xf, ldf = t.forward(v)
+    npz("logit_transform", u=u, v=v, x_inv=xi, ld_inv=ldi, x_fwd=xf, ld_fwd=ldf)
+    q = nf.distributions.ClassCondDiagGaussian((3, 2, 2), 4)
+    with torch.no_grad():
+        q.loc.copy_(torch.randn(q.loc.shape, generator=g))
+        q.log_scale.copy_(0.3 * torch.randn(q.log_scale.shape, generator=g))
+    z = torch.randn(7, 3, 2, 2, generator=g)
+    y = torch.tensor([0, 3, 1, 1, 2, 0, 3])
+    ysoft = torch.softmax(torch.randn(7, 4, generator=g), 1)
+    with torch.no_grad():
+        lp = q.log_prob(z, y)
+        lps = q.log_prob(z, ysoft)
+        q.temperature = 0.7
+        lpt = q.log_prob(z, y)
+        q.temperature = None
+    npz("class_cond_gauss", z=z, y=y, ysoft=ysoft, log_prob=lp, log_prob_soft=lps, log_prob_temp=lpt, **sd(q, "sd__"))
+    torch.manual_seed(5)
+    L_, K_, hidden, input_shape, ncls = 2, 2, 8, (3, 8, 8), 3
+    q0, merges, flows = [], [], []
+    for i in range(L_):
+        fl = [nf.flows.GlowBlock(3 * 2 ** (L_ + 1 - i), hidden, split_mode="channel", scale=True) for _ in range(K_)]
+        fl += [nf.flows.Squeeze()]
+        flows += [fl]
+        if i > 0:
+            merges += [nf.flows.Merge()]
+            latent = (input_shape[0] * 2 ** (L_ - i), input_shape[1] // 2 ** (L_ - i), input_shape[2] // 2 ** (L_ - i))
+        else:
+            latent = (input_shape[0] * 2 ** (L_ + 1), input_shape[1] // 2 ** L_, input_shape[2] // 2 ** L_)
+        q0 += [nf.distributions.ClassCondDiagGaussian(latent, ncls)]
+    m = nf.MultiscaleFlow(q0, flows, merges, transform=nf.transforms.Logit(0.05), class_cond=True)
+    perturb(m, 0.05, 11)
+    x = torch.rand(6, *input_shape, generator=g) * 0.98 + 0.01
+    yl = torch.tensor([0, 1, 2, 2, 1, 0])
+    sd0 = sd(m, "sd0__")                      # before the data-dependent ActNorm init
+    with torch.no_grad():
+        lp = m.log_prob(x, yl)
+        lp2 = m.log_prob(x, yl)
+    npz("model_glow_classcond", x=x, y=yl, log_prob=lp, log_prob_second=lp2, **sd0, **sd(m, "sd__"))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "glue":
+        gen_glue()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "arnsf":
         gen_arnsf()
         sys.exit(0)
@@ -469,3 +520,4 @@ if __name__ == "__main__":
     gen_grads()
     gen_maf()
     gen_arnsf()
+    gen_glue()

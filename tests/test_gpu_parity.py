@@ -681,3 +681,73 @@ def test_arnsf_in_normalizing_flow(nfa):
     m = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(5, trainable=False), flows).to(DEV)
     x, lq = m.sample(64)
     assert_close(N(m.log_prob(x)), N(lq), what="log_prob(sample)", rtol=2e-4, atol=2e-4)
+
+
+# ---- image-side glue: Logit transform, class-conditional base, both inside MultiscaleFlow ----------
+def test_logit_transform_vs_reference(nfa):
+    g = load_golden("logit_transform")
+    t = nfa.transforms.Logit(alpha=0.05)
+    x, ld = t.inverse(T(g["u"]))
+    assert_close(N(x), g["x_inv"], what="x_inv", rtol=1e-5, atol=1e-5)
+    assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=1e-5, atol=1e-4)
+    x, ld = t.forward(T(g["v"]))
+    assert_close(N(x), g["x_fwd"], what="x_fwd", rtol=1e-5, atol=1e-6)
+    assert_close(N(ld), g["ld_fwd"], what="ld_fwd", rtol=1e-5, atol=1e-4)
+    xr, ldr = t.forward(t.inverse(T(g["u"]))[0])
+    assert_close(N(xr), g["u"], what="roundtrip", rtol=1e-5, atol=1e-6)
+    x64, ld64 = t.inverse(T(g["u"]).double())
+    assert x64.dtype == torch.float64
+    assert_close(N(x64), g["x_inv"].astype(np.float64), what="fp64", rtol=1e-5, atol=1e-5)
+
+
+def test_class_cond_diag_gaussian_vs_reference(nfa):
+    g = load_golden("class_cond_gauss")
+    q = nfa.distributions.ClassCondDiagGaussian((3, 2, 2), 4)
+    q.load_state_dict({k: torch.from_numpy(v) for k, v in golden_state(g).items()}, strict=True)
+    q = q.to(DEV)
+    y = torch.from_numpy(g["y"]).to(DEV)
+    with torch.no_grad():
+        assert_close(N(q.log_prob(T(g["z"]), y)), g["log_prob"], what="labels", rtol=1e-5, atol=1e-5)
+        assert_close(N(q.log_prob(T(g["z"]), T(g["ysoft"]))), g["log_prob_soft"], what="soft labels", rtol=1e-5, atol=1e-5)
+        q.temperature = 0.7
+        assert_close(N(q.log_prob(T(g["z"]), y)), g["log_prob_temp"], what="temperature", rtol=1e-5, atol=1e-5)
+        q.temperature = None
+        torch.manual_seed(1)
+        z, lp = q(y=y)                                   # forward: sample + its log-density (base.py:296-324)
+        assert z.shape == (7, 3, 2, 2)
+        assert_close(N(q.log_prob(z, y)), N(lp), what="sample log_p", rtol=1e-4, atol=1e-4)
+        bad = q.log_prob(T(g["z"]), torch.full((7,), 9, device=DEV))
+        assert torch.isnan(bad).all()                    # out-of-range label: NaN, not a wild read
+
+
+def test_model_glow_classcond_vs_reference(nfa):
+    """examples/glow.ipynb structure (reduced): GlowBlocks + Squeeze + Merge, ClassCondDiagGaussian bases, Logit
+    transform; log_prob(x, y) before / after the data-dependent ActNorm init; bits per dim helper runs."""
+    g = load_golden("model_glow_classcond")
+    L_, K_, hidden, input_shape, ncls = 2, 2, 8, (3, 8, 8), 3
+    q0, merges, flows = [], [], []
+    for i in range(L_):
+        fl = [nfa.flows.GlowBlock(3 * 2 ** (L_ + 1 - i), hidden, split_mode="channel", scale=True) for _ in range(K_)]
+        fl += [nfa.flows.Squeeze()]
+        flows += [fl]
+        if i > 0:
+            merges += [nfa.flows.Merge()]
+            latent = (input_shape[0] * 2 ** (L_ - i), input_shape[1] // 2 ** (L_ - i), input_shape[2] // 2 ** (L_ - i))
+        else:
+            latent = (input_shape[0] * 2 ** (L_ + 1), input_shape[1] // 2 ** L_, input_shape[2] // 2 ** L_)
+        q0 += [nfa.distributions.ClassCondDiagGaussian(latent, ncls)]
+    m = nfa.MultiscaleFlow(q0, flows, merges, transform=nfa.transforms.Logit(0.05), class_cond=True)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in golden_state(g, "sd0__").items()}, strict=True)
+    m = m.to(DEV)
+    y = torch.from_numpy(g["y"]).to(DEV)
+    lp = N(m.log_prob(T(g["x"]), y))
+    assert _rel(lp, g["log_prob"]) < 2e-4, _rel(lp, g["log_prob"])
+    assert _rel(N(m.log_prob(T(g["x"]), y)), g["log_prob_second"]) < 2e-4
+    ref_sd = golden_state(g, "sd__")                     # ActNorm parameters after the init agree with the reference's
+    for k, v in m.state_dict().items():
+        assert_close(N(v).astype(np.float64), ref_sd[k].astype(np.float64), what=k, rtol=2e-3, atol=2e-3)
+    torch.manual_seed(0)
+    xs, lq = m.sample(y=y)
+    assert _rel(N(m.log_prob(xs, y)), N(lq)) < 1e-3
+    b = nfa.utils.bitsPerDim(m, T(g["x"]), y)
+    assert b.shape == (6,) and torch.isfinite(b).all()

@@ -242,3 +242,28 @@ def test_arnsf_transform_without_tails(oracle):
     y, ld = oracle.arnsf_transform(st, g["x"], True, 5, tails=None, tail_bound=1.0, prefix="autoregressive_net.")
     assert_close(y, g["z_inv"], what="z_inv", rtol=1e-4, atol=1e-4)
     assert_close(ld, g["ld_inv"], what="ld_inv", rtol=1e-4, atol=1e-4)
+
+
+def test_logit_transform(oracle):
+    g = load_golden("logit_transform")
+    x, ld = oracle.logit(g["u"], 0.05, 1)
+    assert_close(x, g["x_inv"], what="x_inv", rtol=1e-5, atol=1e-5)
+    assert_close(ld, g["ld_inv"], what="ld_inv", rtol=1e-5, atol=1e-4)
+    x, ld = oracle.logit(g["v"], 0.05, 0)
+    assert_close(x, g["x_fwd"], what="x_fwd", rtol=1e-5, atol=1e-6)
+    assert_close(ld, g["ld_fwd"], what="ld_fwd", rtol=1e-5, atol=1e-4)
+
+
+def test_class_cond_diag_gaussian(oracle):
+    g = load_golden("class_cond_gauss")
+    st = golden_state(g)
+    d = 12
+    loc_r = st["loc"].reshape(d, 4).T
+    ls_r = st["log_scale"].reshape(d, 4).T
+    assert_close(oracle.diag_gaussian_log_prob_rows(g["z"], loc_r, ls_r, g["y"]), g["log_prob"], what="labels",
+                 rtol=1e-5, atol=1e-5)
+    w = g["ysoft"]
+    assert_close(oracle.diag_gaussian_log_prob_rows(g["z"], w @ loc_r, w @ ls_r), g["log_prob_soft"], what="soft",
+                 rtol=1e-5, atol=1e-5)
+    assert_close(oracle.diag_gaussian_log_prob_rows(g["z"], loc_r, ls_r, g["y"], float(np.log(0.7))), g["log_prob_temp"],
+                 what="temperature", rtol=1e-5, atol=1e-5)
