@@ -243,6 +243,17 @@ int nf_diag_gaussian_log_prob(const void *z, const void *loc, const void *log_sc
                               void *out, int64_t B, int64_t d, int acc, int dtype, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Weight and bias gradient of a Linear layer over the batch (training step, core.py:87-102 + loss.backward();
+ * the conditioner layers nets/resnet.py:37-50, 92-104): dW[m][n] (+)= sum_b dY[b][m] X[b][n], db[m] (+)= sum_b dY[b][m].
+ *   dY (B, M), X (B, N) row-major float32, N <= 128; dW (M, N), db (M) or NULL; accumulate 0 = overwrite, 1 = add.
+ *   scratch: nf_linear_wgrad_scratch_floats(B, M, N) floats owned by the caller (per-K-chunk partial tiles, summed in
+ *   a fixed order: results are run-to-run deterministic).
+ */
+int64_t nf_linear_wgrad_scratch_floats(int64_t B, int M, int N);
+int nf_linear_wgrad(const void *dY, const void *X, void *dW, void *db, void *scratch, int64_t B, int M, int N,
+                    int accumulate, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Logit preprocessing transform of image tensors.  Replaces normflows/transforms.py:8-47.
  *   z, y (B, inner) contiguous (inner = C*H*W); beta = 1 - 2 alpha, 0 <= alpha < 0.5.
  *   direction 0 = Logit.forward (:25-32): y = (sigmoid(z) - alpha)/beta,

@@ -87,6 +87,8 @@ def lib():
         _lib.nf_strerror.restype = C.c_char_p
         if hasattr(_lib, "nf_rqs_fused_pack_size"):
             _lib.nf_rqs_fused_pack_size.restype = C.c_int64
+        if hasattr(_lib, "nf_linear_wgrad_scratch_floats"):
+            _lib.nf_linear_wgrad_scratch_floats.restype = C.c_int64
         if hasattr(_lib, "nf_maf_inverse_scratch_floats"):
             _lib.nf_maf_inverse_scratch_floats.restype = C.c_int64
     return _lib

@@ -11,6 +11,15 @@ from torch import nn
 from torch.nn import functional as F, init
 
 
+class Linear(nn.Linear):
+    """nn.Linear whose weight / bias gradients use the split-K HIP kernel at training batch sizes (autograd.linear);
+    same parameters and state_dict keys."""
+
+    def forward(self, x):
+        from . import autograd
+        return autograd.linear(x, self.weight, self.bias)
+
+
 class ResidualBlock(nn.Module):
     """Pre-activation residual block x + W2 act(W1 act(x)) with optional GLU context gate (resnet.py:7-50)."""
 
@@ -23,7 +32,7 @@ class ResidualBlock(nn.Module):
             self.batch_norm_layers = nn.ModuleList([nn.BatchNorm1d(features, eps=1e-3) for _ in range(2)])
         if context_features is not None:
             self.context_layer = nn.Linear(context_features, features)
-        self.linear_layers = nn.ModuleList([nn.Linear(features, features) for _ in range(2)])
+        self.linear_layers = nn.ModuleList([Linear(features, features) for _ in range(2)])
         self.dropout = nn.Dropout(p=dropout_probability)
         if zero_initialization:
             init.uniform_(self.linear_layers[-1].weight, -1e-3, 1e-3)
@@ -52,15 +61,15 @@ class ResidualNet(nn.Module):
         self.context_features = context_features
         self.preprocessing = preprocessing
         if context_features is not None:
-            self.initial_layer = nn.Linear(in_features + context_features, hidden_features)
+            self.initial_layer = Linear(in_features + context_features, hidden_features)
         else:
-            self.initial_layer = nn.Linear(in_features, hidden_features)
+            self.initial_layer = Linear(in_features, hidden_features)
         self.blocks = nn.ModuleList([
             ResidualBlock(features=hidden_features, context_features=context_features, activation=activation,
                           dropout_probability=dropout_probability, use_batch_norm=use_batch_norm)
             for _ in range(num_blocks)
         ])
-        self.final_layer = nn.Linear(hidden_features, out_features)
+        self.final_layer = Linear(hidden_features, out_features)
         self.dropout_probability = dropout_probability
         self.use_batch_norm = use_batch_norm
 

@@ -456,3 +456,21 @@ def diag_gaussian_log_prob_rows(z, loc_rows, log_scale_rows, row_idx=None, ls_sh
                                                 i32(L.dtype_code(z)), L.stream())
     L.check(rc, "nf_diag_gaussian_log_prob_rows")
     return out
+
+
+def linear_wgrad(dy, x, want_bias=True):
+    """dW = dy^T x, db = dy.sum(0) for a Linear layer (nf_linear_wgrad, split-K fp32 MFMA, deterministic reduction)."""
+    L.require_device(dy, x)
+    if dy.dtype != torch.float32 or x.dtype != torch.float32:
+        raise NotImplementedError("linear_wgrad: float32 only")
+    dy, x = dy.contiguous(), x.contiguous()
+    B, M = dy.shape
+    N = x.shape[1]
+    dW = torch.empty(M, N, dtype=torch.float32, device=dy.device)
+    db = torch.empty(M, dtype=torch.float32, device=dy.device) if want_bias else None
+    n = L.lib().nf_linear_wgrad_scratch_floats(i64(B), i32(M), i32(N))
+    scratch = torch.empty(max(int(n), 1), dtype=torch.float32, device=dy.device)
+    rc = L.lib().nf_linear_wgrad(ptr(dy), ptr(x), ptr(dW), ptr(db), ptr(scratch), i64(B), i32(M), i32(N), i32(0),
+                                 L.stream())
+    L.check(rc, "nf_linear_wgrad")
+    return dW, db
