@@ -2,11 +2,13 @@
 // (the backward of the conditioner's nn.Linear layers, nets/resnet.py:37-50, 92-104, in the training step core.py:87-102).
 //
 // Shape: M, N <= a few hundred, K = batch = 65 536: a split-K problem.  Both operands of v_mfma_f32_32x32x2_f32 come
-// straight from the row-major activations: for a k-pair (two batch rows) lane (i = lane & 31, h = lane >> 5) supplies
-// A = dY[b + h][m0 + i] and B = X[b + h][n0 + i] -- 128-byte coalesced rows, no LDS, no transposes.  A wave owns one
-// 32-row m-tile and up to four n-tiles (64 accumulator registers); a workgroup = 4 m-tiles over one K-chunk, so the X rows
-// are shared through L1.  Partial tiles go to a caller-owned scratch [chunk][M][N] and a second kernel sums the chunks in
-// a fixed order: deterministic, unlike atomics.
+// straight from the row-major activations, no LDS, no transposes: for a k-pair (two batch rows) lane (i = lane & 31,
+// h = lane >> 5) loads dY[b + h][64 p + 2 i .. +1] (8 bytes) and X[b + h][4 i .. +3] (16 bytes) and feeds 2 x 4 MFMAs:
+// the wave's tiles are the INTERLEAVED row sets {64 p + 2 i + s} x column sets {4 i + t}, so one load per operand serves
+// eight 32 x 32 tiles (128 accumulator registers).  One wave = one workgroup = 64 rows of M x 128 columns over one
+// K-chunk; operands are fetched two trips (8 k-pairs, 64 MFMAs) ahead, two waves per SIMD.  Partial tiles go to a caller-owned scratch
+// [chunk][M*N + M] and a second kernel sums the chunks in a fixed order: deterministic, unlike atomics.
+// N not a multiple of 4 takes the dword path below (NT column tiles, lane i = column 32 t + i).
 #include "common.hpp"
 #include "fused_common.hpp"
 
@@ -14,12 +16,112 @@ namespace nf {
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---- vector path: N % 4 == 0, N <= 128 ------------------------------------------------------------------
+template <bool A_VEC>   // 8-byte dY loads need even M; a template parameter keeps the k loop a single basic block
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+wgrad_partial_vec_kernel(const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ part, int64_t B,
+                         int M, int N, int chunk_rows, int want_bias) {
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * 64 + 2 * i;      // rows m0, m0 + 1 of dW
+    const int n0 = 4 * i;                        // columns n0 .. n0 + 3
+    const bool mv0 = m0 < M, mv1 = m0 + 1 < M;
+    const bool nv = n0 < N;                      // N % 4 == 0: all four or none
+    const int mc = mv1 ? m0 : 0, nc = nv ? n0 : 0;  // out-of-range lanes read valid addresses; their tiles are never stored
+    const int64_t b0 = (int64_t)blockIdx.x * chunk_rows;
+    int64_t b1 = b0 + chunk_rows;
+    if (b1 > B) b1 = B;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[s][t] = f32x16{0};
+    float bs0 = 0.0f, bs1 = 0.0f;
+    // Loads are unconditional (row index clamped): a load under a lane-dependent branch forces a wait right behind it and
+    // the two-trip prefetch collapses.  Rows past the chunk end are zeroed when consumed instead.
+    struct Trip { f32x2 a[4]; f32x4 x[4]; };
+    auto load = [&](int64_t b, Trip &tr) {
+#ifdef NF_WG_ABL_NOLOAD
+        if (B != 12345) return;
+#endif
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int64_t r = b + 2 * j + h;
+            r = r < B ? r : B - 1;
+            if (A_VEC) tr.a[j] = *reinterpret_cast<const f32x2 *>(dY + r * M + mc);
+            else tr.a[j] = f32x2{dY[r * M + (mv0 ? m0 : 0)], dY[r * M + mc + (mv1 ? 1 : 0)]};
+            tr.x[j] = *reinterpret_cast<const f32x4 *>(X + r * N + nc);
+        }
+    };
+    auto mma = [&](int64_t b, const Trip &tr) {
+#ifdef NF_WG_ABL_NOMMA
+        bs0 += tr.a[0][0] + tr.x[0][0] + tr.a[1][0] + tr.x[1][0] + tr.a[2][0] + tr.x[2][0] + tr.a[3][0] + tr.x[3][0];
+        if (B != 12345) return;
+#endif
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool live = b + 2 * j + h < b1;
+            const float a0 = live ? tr.a[j][0] : 0.0f, a1 = live ? tr.a[j][1] : 0.0f;
+            bs0 += a0;
+            bs1 += a1;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc[0][t] = MFMA32(a0, tr.x[j][t], acc[0][t]);
+                acc[1][t] = MFMA32(a1, tr.x[j][t], acc[1][t]);
+            }
+        }
+    };
+    // three named trip buffers, each refilled right after it is consumed (two trips = 64 MFMAs of loads in flight, no
+    // register copies: a copy of a loaded value is a wait on it).  sched_barrier: the machine scheduler otherwise sinks
+    // every load to just before its use (to save registers), which turns the prefetch into a wait per k-pair.  The
+    // kernel is held to 256 registers so that two waves share a SIMD and cover each other's waits.
+    Trip t0, t1, t2;
+    load(b0, t0);
+    load(b0 + 8, t1);
+    load(b0 + 16, t2);
+#define NF_WG_STEP(OFF, T)                      \
+    mma(b + (OFF), T);                          \
+    __builtin_amdgcn_sched_barrier(0);          \
+    load(b + 24 + (OFF), T);                    \
+    __builtin_amdgcn_sched_barrier(0);
+    for (int64_t b = b0; b < b1; b += 24) {
+        NF_WG_STEP(0, t0)
+        NF_WG_STEP(8, t1)
+        NF_WG_STEP(16, t2)
+    }
+#undef NF_WG_STEP
+    // C layout of tile (s, t): row index ri = (reg & 3) + 8 (reg >> 2) + 4 h  ->  m = 64 p + 2 ri + s;  col = lane & 31 -> n = 4 i + t
+    float *out = part + (size_t)blockIdx.x * ((size_t)M * N + M);
+    if (nv) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mm = blockIdx.y * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * h) + s;
+                if (mm < M)
+                    *reinterpret_cast<f32x4 *>(out + (size_t)mm * N + n0) =
+                        f32x4{acc[s][0][r], acc[s][1][r], acc[s][2][r], acc[s][3][r]};
+            }
+        }
+    }
+    if (want_bias) {
+        bs0 += __shfl_xor(bs0, 32);
+        bs1 += __shfl_xor(bs1, 32);
+        if (h == 0) {
+            if (mv0) out[(size_t)M * N + m0] = bs0;
+            if (mv1) out[(size_t)M * N + m0 + 1] = bs1;
+        }
+    }
+}
+
+// ---- general path: any N <= 128 -----------------------------------------------------------------------
 constexpr int WG_MT = 4;  // m-tiles (waves) per workgroup
 
 template <int NT>
 __global__ void __launch_bounds__(64 * WG_MT)
-wgrad_partial_kernel(const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ part,
-                     float *__restrict__ bpart, int64_t B, int M, int N, int chunk_rows) {
+wgrad_partial_kernel(const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ part, int64_t B,
+                     int M, int N, int chunk_rows, int want_bias) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int mt = blockIdx.y * WG_MT + wid;     // m-tile of this wave
@@ -68,7 +170,7 @@ wgrad_partial_kernel(const float *__restrict__ dY, const float *__restrict__ X, 
             for (int t = 0; t < NT; ++t) acc[t] = MFMA32(a, (nval[t] && rv) ? pb[t][r * N] : 0.0f, acc[t]);
         }
         // C layout: row = (reg & 3) + 8 (reg >> 2) + 4 h (m within the tile), col = lane & 31 (n within the tile)
-        float *out = part + (size_t)blockIdx.x * M * N;
+        float *out = part + (size_t)blockIdx.x * ((size_t)M * N + M);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int n = t * 32 + i;
@@ -78,38 +180,51 @@ wgrad_partial_kernel(const float *__restrict__ dY, const float *__restrict__ X, 
                 if (mm < M && n < N) out[(size_t)mm * N + n] = acc[t][r];
             }
         }
-        if (bpart) {
+        if (want_bias) {
             bsum += __shfl_xor(bsum, 32);
-            if (h == 0 && mval) bpart[(size_t)blockIdx.x * M + m] = bsum;
+            if (h == 0 && mval) out[(size_t)M * N + m] = bsum;
         }
     }
 }
 
-// out[e] (=|+=) sum over chunks of part[c][e], fixed order.
+// out (dW then db) (=|+=) sum over chunks of part[c][e] in a fixed order; e < nW goes to dW, the rest to db.
+// Block = 64 elements x 4 chunk lanes (lane q sums chunks q, q+4, ...), combined through LDS as ((0+1)+(2+3)).
 __global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ out, int64_t n, int chunks, int accumulate) {
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-        int c = 0;
-        for (; c + 4 <= chunks; c += 4) {
-            s0 += part[(size_t)c * n + e];
-            s1 += part[(size_t)(c + 1) * n + e];
-            s2 += part[(size_t)(c + 2) * n + e];
-            s3 += part[(size_t)(c + 3) * n + e];
+wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, float *__restrict__ db, int64_t nW, int64_t n,
+                    int64_t stride, int chunks, int accumulate) {
+    __shared__ float sm[4][64];
+    const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
+    for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < n; e0 += (int64_t)gridDim.x * 64) {
+        const int64_t e = e0 + el;
+        float s0 = 0.0f, s1 = 0.0f;
+        if (e < n) {
+            int c = q;
+            for (; c + 4 < chunks; c += 8) {
+                s0 += part[(size_t)c * stride + e];
+                s1 += part[(size_t)(c + 4) * stride + e];
+            }
+            if (c < chunks) s0 += part[(size_t)c * stride + e];
         }
-        for (; c < chunks; ++c) s0 += part[(size_t)c * n + e];
-        const float s = (s0 + s1) + (s2 + s3);
-        out[e] = accumulate ? out[e] + s : s;
+        sm[q][el] = s0 + s1;
+        __syncthreads();
+        if (q == 0 && e < n) {
+            const float s = (sm[0][el] + sm[1][el]) + (sm[2][el] + sm[3][el]);
+            float *o = e < nW ? dW + e : db + (e - nW);
+            *o = accumulate ? *o + s : s;
+        }
+        __syncthreads();
     }
 }
 
-static int wgrad_chunks(int64_t B, int M) {
-    // aim at >= 1024 waves in flight: (#chunks) x (m-tiles) >= 1024, chunk rows a multiple of 8, at least 64
-    const int mtiles = (M + 31) / 32;
-    int64_t want = (1024 + mtiles - 1) / mtiles;
+static int wgrad_chunk_rows(int64_t B, int M, bool vec) {
+    // vector path: ~2048 waves in flight (two per SIMD), chunk rows a multiple of its 24-row loop step;
+    // general path: ~1024 waves, multiple of 8.  At least 48 rows (fewer, longer chunks = less partial traffic).
+    const int mgroups = vec ? (M + 63) / 64 : (M + 31) / 32;
+    // small outputs: the partial-tile traffic (chunks x M x N) outweighs the second wave per SIMD
+    int64_t want = (((vec && M > 256) ? 2048 : 1024) + mgroups - 1) / mgroups;
     int64_t rows = (B + want - 1) / want;
-    rows = (rows + 7) / 8 * 8;
-    if (rows < 64) rows = 64;
+    rows = (rows + 23) / 24 * 24;
+    if (rows < 48) rows = 48;
     return (int)rows;
 }
 
@@ -117,7 +232,7 @@ static int wgrad_chunks(int64_t B, int M) {
 
 extern "C" int64_t nf_linear_wgrad_scratch_floats(int64_t B, int M, int N) {
     if (B < 0 || M < 1 || N < 1) return NF_EINVAL;
-    const int rows = nf::wgrad_chunks(B, M);
+    const int rows = nf::wgrad_chunk_rows(B, M, N % 4 == 0);
     const int64_t chunks = (B + rows - 1) / rows;
     return chunks * ((int64_t)M * N + M);
 }
@@ -128,30 +243,35 @@ extern "C" int nf_linear_wgrad(const void *dY, const void *X, void *dW, void *db
     if (N > 128) return NF_ENOTSUP;  // four 32-column tiles of accumulators per wave
     if (!dY || !X || !dW || !scratch) return NF_EFAULT;
     hipStream_t st = (hipStream_t)stream;
-    const int rows = nf::wgrad_chunks(B, M);
+    const bool vec = N % 4 == 0;
+    const int rows = nf::wgrad_chunk_rows(B, M, vec);
     const int chunks = (int)((B + rows - 1) / rows);
     float *part = (float *)scratch;
-    float *bpart = db ? part + (size_t)chunks * M * N : nullptr;
-    const int mtiles = (M + 31) / 32;
-    dim3 grid(chunks, (mtiles + nf::WG_MT - 1) / nf::WG_MT);
-    const int nt = (N + 31) / 32;
+    const int want_bias = db ? 1 : 0;
+    if (vec) {
+        if (M % 2 == 0)
+            hipLaunchKernelGGL(nf::wgrad_partial_vec_kernel<true>, dim3(chunks, (M + 63) / 64), dim3(64), 0, st,
+                               (const float *)dY, (const float *)X, part, B, M, N, rows, want_bias);
+        else
+            hipLaunchKernelGGL(nf::wgrad_partial_vec_kernel<false>, dim3(chunks, (M + 63) / 64), dim3(64), 0, st,
+                               (const float *)dY, (const float *)X, part, B, M, N, rows, want_bias);
+    } else {
+        const int mtiles = (M + 31) / 32;
+        dim3 grid(chunks, (mtiles + nf::WG_MT - 1) / nf::WG_MT);
+        const int nt = (N + 31) / 32;
 #define NF_WGRAD_LAUNCH(NT)                                                                                         \
     hipLaunchKernelGGL(nf::wgrad_partial_kernel<NT>, grid, dim3(64 * nf::WG_MT), 0, st, (const float *)dY,           \
-                       (const float *)X, part, bpart, B, M, N, rows)
-    if (nt == 1) NF_WGRAD_LAUNCH(1);
-    else if (nt == 2) NF_WGRAD_LAUNCH(2);
-    else if (nt == 3) NF_WGRAD_LAUNCH(3);
-    else NF_WGRAD_LAUNCH(4);
+                       (const float *)X, part, B, M, N, rows, want_bias)
+        if (nt == 1) NF_WGRAD_LAUNCH(1);
+        else if (nt == 2) NF_WGRAD_LAUNCH(2);
+        else if (nt == 3) NF_WGRAD_LAUNCH(3);
+        else NF_WGRAD_LAUNCH(4);
 #undef NF_WGRAD_LAUNCH
-    NF_CHECK_LAUNCH();
-    const int64_t n = (int64_t)M * N;
-    hipLaunchKernelGGL(nf::wgrad_reduce_kernel, dim3(nf::grid_for(n, 256)), dim3(256), 0, st, part, (float *)dW, n, chunks,
-                       accumulate);
-    NF_CHECK_LAUNCH();
-    if (db) {
-        hipLaunchKernelGGL(nf::wgrad_reduce_kernel, dim3(nf::grid_for(M, 256)), dim3(256), 0, st, bpart, (float *)db,
-                           (int64_t)M, chunks, accumulate);
-        NF_CHECK_LAUNCH();
     }
+    NF_CHECK_LAUNCH();
+    const int64_t nW = (int64_t)M * N, n = nW + (db ? M : 0);
+    hipLaunchKernelGGL(nf::wgrad_reduce_kernel, dim3(nf::grid_for(n, 64)), dim3(256), 0, st, part, (float *)dW, (float *)db,
+                       nW, n, nW + M, chunks, accumulate);
+    NF_CHECK_LAUNCH();
     return NF_OK;
 }
