@@ -204,6 +204,9 @@ __device__ __forceinline__ T rqs_element_bwd(const RqsParams<T> &p, T x, T gy_up
 
 // One lane per (sample, feature) element.  mode as in the forward: 0 density (both halves, forward splines),
 // 1 identity half with the inverse spline, 2 transform half with the inverse spline.
+// Tiles of TS samples: the tile's conditioner rows (TS*nT rows of M numbers, one contiguous span of `cond`) are staged
+// into LDS with unit-stride loads, their gradient rows are built in LDS (odd pitch: lane-per-row access is
+// conflict-free) and leave with unit-stride stores; a lane touching its 92-byte row directly in HBM costs ~4x.
 template <typename T>
 __global__ void __launch_bounds__(256)
 rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const T *__restrict__ gld,
@@ -211,56 +214,84 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
                         const T *__restrict__ ud, const int64_t *__restrict__ iidx, int nI,
                         const int64_t *__restrict__ tidx, int nT, int64_t B, int D, RqsParams<T> p, int mode,
                         T *__restrict__ gx, T *__restrict__ gcond, T *__restrict__ guw, T *__restrict__ guh,
-                        T *__restrict__ gud) {
+                        T *__restrict__ gud, int TS) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int K = p.K, nd = p.nd, M = 2 * K + nd;
+    const int P = M | 1;                         // LDS row pitch (odd)
     T *s_acc = reinterpret_cast<T *>(smem_raw);  // nI * M block-local accumulators of the shared parameters
+    T *s_cond = s_acc + (size_t)nI * M;          // TS*nT rows, pitch P
+    T *s_g = s_cond + (size_t)TS * nT * P;       // gradient rows, pitch P
     const bool do_t = mode != NF_RQS_SAMPLE_IDENTITY, do_i = mode != NF_RQS_SAMPLE_TRANSFORM;
     const bool inverse = mode != NF_RQS_DENSITY;
     const bool has_uncond = uw != nullptr;
+    const bool stage = do_t && nT > 0;
     if (do_i && has_uncond) {
         for (int i = threadIdx.x; i < nI * M; i += blockDim.x) s_acc[i] = T(0);
     }
     __syncthreads();
-    const int64_t nelem = B * (int64_t)D;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nelem; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t b = e / D;
-        const int f = (int)(e - b * D);  // 0..nT-1: transform feature f, nT..D-1: identity feature f - nT
-        if (f < nT) {
-            const int col = (int)tidx[f];
-            if (!do_t) continue;
-            const T *row = cond + (b * nT + f) * (int64_t)M;
-            T *grow = gcond + (b * nT + f) * (int64_t)M;
-            const T div = p.wh_div;
-            for (int k = 0; k < M; ++k) grow[k] = T(0);
-            auto wacc = [=](int k) { return row[k] / div; };
-            auto hacc = [=](int k) { return row[K + k] / div; };
-            auto dacc = [=](int k) { return row[2 * K + k]; };
-            auto aw = [=](int i, T g) { grow[i] = g; };
-            auto ah = [=](int i, T g) { grow[K + i] = g; };
-            auto ad = [=](int j, T g) { grow[2 * K + j] += g; };
-            gx[b * D + col] = rqs_element_bwd<T>(p, x[b * D + col], gy[b * D + col], gld[b], wacc, hacc, dacc, inverse,
-                                                 aw, ah, ad);
-        } else {
-            const int j = f - nT;
-            const int col = (int)iidx[j];
-            if (!do_i) continue;
-            if (!has_uncond) {
-                gx[b * D + col] = gy[b * D + col];
-                continue;
+    const int64_t ntiles = (B + TS - 1) / TS;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t bt = tile * TS;
+        const int ts = (int)((B - bt) < TS ? (B - bt) : TS);
+        if (stage) {
+            const T *src = cond + bt * nT * (int64_t)M;
+            const int n = ts * nT * M;
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const int r = i / M, k = i - r * M;
+                s_cond[r * P + k] = src[i];
+                s_g[r * P + k] = T(0);
             }
-            RqsParams<T> pu = p;
-            pu.wh_div = T(1);  // the unconditional transform is not scaled (nsf/coupling.py:224-232)
-            const T *wj = uw + (size_t)j * K, *hj = uh + (size_t)j * K, *dj = ud + (size_t)j * nd;
-            T *acc = s_acc + (size_t)j * M;
-            auto wacc = [=](int k) { return wj[k]; };
-            auto hacc = [=](int k) { return hj[k]; };
-            auto dacc = [=](int k) { return dj[k]; };
-            auto aw = [=](int i, T g) { atomicAdd(acc + i, g); };
-            auto ah = [=](int i, T g) { atomicAdd(acc + K + i, g); };
-            auto ad = [=](int jj, T g) { atomicAdd(acc + 2 * K + jj, g); };
-            gx[b * D + col] = rqs_element_bwd<T>(pu, x[b * D + col], gy[b * D + col], gld[b], wacc, hacc, dacc, inverse,
-                                                 aw, ah, ad);
+            __syncthreads();
+        }
+        for (int el = threadIdx.x; el < ts * D; el += blockDim.x) {
+            const int bl = el / D;
+            const int f = el - bl * D;  // 0..nT-1: transform feature f, nT..D-1: identity feature f - nT
+            const int64_t b = bt + bl;
+            if (f < nT) {
+                if (!do_t) continue;
+                const int col = (int)tidx[f];
+                const T *row = s_cond + (size_t)(bl * nT + f) * P;
+                T *grow = s_g + (size_t)(bl * nT + f) * P;
+                const T div = p.wh_div;
+                auto wacc = [=](int k) { return row[k] / div; };
+                auto hacc = [=](int k) { return row[K + k] / div; };
+                auto dacc = [=](int k) { return row[2 * K + k]; };
+                auto aw = [=](int i, T g) { grow[i] = g; };
+                auto ah = [=](int i, T g) { grow[K + i] = g; };
+                auto ad = [=](int j, T g) { grow[2 * K + j] += g; };
+                gx[b * D + col] = rqs_element_bwd<T>(p, x[b * D + col], gy[b * D + col], gld[b], wacc, hacc, dacc,
+                                                     inverse, aw, ah, ad);
+            } else {
+                if (!do_i) continue;
+                const int j = f - nT;
+                const int col = (int)iidx[j];
+                if (!has_uncond) {
+                    gx[b * D + col] = gy[b * D + col];
+                    continue;
+                }
+                RqsParams<T> pu = p;
+                pu.wh_div = T(1);  // the unconditional transform is not scaled (nsf/coupling.py:224-232)
+                const T *wj = uw + (size_t)j * K, *hj = uh + (size_t)j * K, *dj = ud + (size_t)j * nd;
+                T *acc = s_acc + (size_t)j * M;
+                auto wacc = [=](int k) { return wj[k]; };
+                auto hacc = [=](int k) { return hj[k]; };
+                auto dacc = [=](int k) { return dj[k]; };
+                auto aw = [=](int i, T g) { atomicAdd(acc + i, g); };
+                auto ah = [=](int i, T g) { atomicAdd(acc + K + i, g); };
+                auto ad = [=](int jj, T g) { atomicAdd(acc + 2 * K + jj, g); };
+                gx[b * D + col] = rqs_element_bwd<T>(pu, x[b * D + col], gy[b * D + col], gld[b], wacc, hacc, dacc,
+                                                     inverse, aw, ah, ad);
+            }
+        }
+        if (stage) {
+            __syncthreads();
+            T *dst = gcond + bt * nT * (int64_t)M;
+            const int n = ts * nT * M;
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const int r = i / M, k = i - r * M;
+                dst[i] = s_g[r * P + k];
+            }
+            __syncthreads();
         }
     }
     __syncthreads();
@@ -286,13 +317,21 @@ static int launch_bwd(const void *x, const void *gy, const void *gld, const void
                       const void *ud, const int64_t *iidx, int nI, const int64_t *tidx, int nT, int64_t B, int D,
                       const RqsParams<T> &p, int mode, void *gx, void *gcond, void *guw, void *guh, void *gud,
                       hipStream_t st) {
-    const int M = 2 * p.K + p.nd;
-    const size_t lds = (size_t)nI * M * sizeof(T) + 16;
-    if (lds > 64 * 1024) return NF_ENOTSUP;
-    const int grid = grid_for(B * (int64_t)D, 256, 1024);
+    const int M = 2 * p.K + p.nd, P = M | 1;
+    const bool stage = mode != NF_RQS_SAMPLE_IDENTITY && nT > 0;
+    auto lds_bytes = [&](int ts) {
+        return ((size_t)nI * M + (stage ? (size_t)2 * ts * nT * P : 0)) * sizeof(T) + 16;
+    };
+    int TS = 256 / D > 0 ? 256 / D : 1;          // samples per tile: ~one element per lane
+    while (TS > 1 && lds_bytes(TS) > 64 * 1024) TS >>= 1;
+    const size_t lds = lds_bytes(TS);
+    if (lds > 150 * 1024) return NF_ENOTSUP;
+    static size_t opted = 64 * 1024;
+    if (opt_in_lds(reinterpret_cast<const void *>(&rqs_coupling_bwd_kernel<T>), lds, opted) != NF_OK) return NF_ENOTSUP;
+    const int grid = grid_for((B + TS - 1) / TS, 1, 2048);
     hipLaunchKernelGGL(rqs_coupling_bwd_kernel<T>, dim3(grid), dim3(256), lds, st, (const T *)x, (const T *)gy,
                        (const T *)gld, (const T *)cond, (const T *)uw, (const T *)uh, (const T *)ud, iidx, nI, tidx, nT,
-                       B, D, p, mode, (T *)gx, (T *)gcond, (T *)guw, (T *)guh, (T *)gud);
+                       B, D, p, mode, (T *)gx, (T *)gcond, (T *)guw, (T *)guh, (T *)gud, TS);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
