@@ -77,6 +77,13 @@ def _assemble_lu(lower_entries, upper_entries, udiag_raw, eps):
     return Lm, Um, diag, li, ui
 
 
+def _batch_outer(a, b, want_colsum=False):
+    """a^T b (and the column sums of a) over the batch: the split-K HIP kernel where it applies (fp32, b <= 128 wide)."""
+    if a.dtype == torch.float32 and a.is_cuda and b.shape[1] <= 128 and a.shape[0] >= 1024:
+        return ops.linear_wgrad(a, b, want_bias=want_colsum)
+    return a.t() @ b, (a.sum(0) if want_colsum else None)
+
+
 class LULinearPermuteFn(torch.autograd.Function):
     """LULinearPermute (mixing.py:535-563).  direction 0 = .inverse (density), 1 = .forward (sample)."""
 
@@ -104,10 +111,9 @@ class LULinearPermuteFn(torch.autograd.Function):
             gxp = gu @ Um           # d/dx_p
             gx = torch.empty_like(x)
             gx.index_copy_(1, perm, gxp)
-            gL = gy.t() @ u
-            gU = gu.t() @ xp
+            gL, g_bias = _batch_outer(gy, u, want_colsum=True)
+            gU, _ = _batch_outer(gu, xp)
             gdiag = torch.diagonal(gU) + gl_sum / diag
-            g_bias = gy.sum(0)
         else:
             # y[:, perm] = t,  U t = u,  L u = x - b ; logdet = -sum log diag
             t = y.index_select(1, perm)
@@ -116,9 +122,9 @@ class LULinearPermuteFn(torch.autograd.Function):
             gu = torch.linalg.solve_triangular(Um.t(), gt.t(), upper=False).t()      # U^T gu = gt
             gv = torch.linalg.solve_triangular(Lm.t(), gu.t(), upper=True, unitriangular=True).t()  # L^T gv = gu
             gx = gv
-            g_bias = -gv.sum(0)
-            gU = -(gu.t() @ t)
-            gL = -(gv.t() @ u)
+            gL, g_bias = _batch_outer(gv, u, want_colsum=True)
+            gU, _ = _batch_outer(gu, t)
+            gL, gU, g_bias = -gL, -gU, -g_bias
             gdiag = torch.diagonal(gU) - gl_sum / diag
         g_lower = gL[li[0], li[1]]
         g_upper = gU[ui[0], ui[1]]
