@@ -266,6 +266,14 @@ int nf_logit(const void *z, void *y, void *logdet, int64_t B, int64_t inner, dou
              int dtype, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Bias + LeakyReLU behind a bias-free convolution of the Glow conditioner (normflows/nets/cnn.py:40-50:
+ * Conv2d(bias=True) followed by LeakyReLU(leaky)), in place on y (B, C, H*W) contiguous NCHW:
+ *   y = leaky_relu(y + bias[c], negative_slope).
+ */
+int nf_bias_leaky_relu(void *y, const void *bias, int64_t B, int C, int64_t HW, double negative_slope, int dtype,
+                       nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Diagonal Gaussian log-density with a mean / log-scale ROW per sample.  Replaces
  * normflows/distributions/base.py:326-345 (ClassCondDiagGaussian.log_prob).
  *   loc_rows, log_scale_rows (num_rows, d) row-major: for class labels the transposed parameters

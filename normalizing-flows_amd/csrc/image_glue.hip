@@ -64,6 +64,18 @@ diag_gaussian_rows_kernel(const T *__restrict__ z, const T *__restrict__ loc, co
     }
 }
 
+// y[b][c][hw] = leaky_relu(y[b][c][hw] + bias[c]) in place: the two element-wise passes that follow a bias-free
+// library convolution in ConvNet2d (nets/cnn.py:40-50), as one read + one write.
+template <typename T>
+__global__ void __launch_bounds__(256)
+bias_leaky_relu_kernel(T *__restrict__ y, const T *__restrict__ bias, int64_t n, int C, int64_t HW, T slope) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i / HW) % C);
+        const T v = y[i] + bias[c];
+        y[i] = v > T(0) ? v : v * slope;
+    }
+}
+
 }  // namespace nf
 
 #define NF_DISPATCH(dtype, CALL_F32, CALL_F64) \
@@ -108,6 +120,23 @@ extern "C" int nf_diag_gaussian_log_prob_rows(const void *z, const void *loc_row
                 hipLaunchKernelGGL(nf::diag_gaussian_rows_kernel<double>, dim3(grid), dim3(256), 0, st, (const double *)z,
                                    (const double *)loc_rows, (const double *)log_scale_rows, row_idx, num_rows,
                                    log_scale_shift, (double *)out, B, d, cst, acc));
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_bias_leaky_relu(void *y, const void *bias, int64_t B, int C, int64_t HW, double negative_slope, int dtype,
+                                  nf_stream_t stream) {
+    if (B < 0 || C < 1 || HW < 1) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!y || !bias) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = B * C * HW;
+    const int grid = nf::grid_for(n, 256 * 4);
+    NF_DISPATCH(dtype,
+                hipLaunchKernelGGL(nf::bias_leaky_relu_kernel<float>, dim3(grid), dim3(256), 0, st, (float *)y,
+                                   (const float *)bias, n, C, HW, (float)negative_slope),
+                hipLaunchKernelGGL(nf::bias_leaky_relu_kernel<double>, dim3(grid), dim3(256), 0, st, (double *)y,
+                                   (const double *)bias, n, C, HW, negative_slope));
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

@@ -75,10 +75,16 @@ class Invertible1x1Conv(Flow):
             self.W = nn.Parameter(Q)
 
     def _weight(self, inverse_dir):
-        """W and the per-pixel log|det| (0-dim) for flow.inverse (inverse_dir=True) or flow.forward."""
+        """W and the per-pixel log|det| (0-dim) for flow.inverse (inverse_dir=True) or flow.forward.  The assembled
+        matrix is kept until a parameter changes: the reference re-assembles (and re-inverts) it on every call."""
         if self.use_lu:
-            return ops.inv1x1_assemble(self.P, self.L.detach(), self.U.detach(), self.sign_S, self.log_S.detach(),
-                                       inverse=not inverse_dir)
+            key = (inverse_dir,) + tuple((t.data_ptr(), t._version) for t in (self.L, self.U, self.log_S, self.P))
+            cache = getattr(self, "_w_cache", None)
+            if cache is None or cache[0] != key:
+                cache = (key, ops.inv1x1_assemble(self.P, self.L.detach(), self.U.detach(), self.sign_S,
+                                                  self.log_S.detach(), inverse=not inverse_dir))
+                self._w_cache = cache
+            return cache[1]
         W = self.W.detach()
         sld = torch.slogdet(W)[1]
         if inverse_dir:

@@ -183,7 +183,28 @@ class ConvNet2d(nn.Module):
         self.net = nn.Sequential(*net)
 
     def forward(self, x):
+        if x.is_cuda and not torch.is_grad_enabled():
+            return self._forward_inference(x)
         return self.net(x)
+
+    def _forward_inference(self, x):
+        """Library convolution without bias, then ONE HIP pass for bias + LeakyReLU (instead of a bias pass inside the
+        library call and a separate activation pass)."""
+        from . import ops
+        mods = list(self.net)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if (isinstance(m, nn.Conv2d) and isinstance(nxt, nn.LeakyReLU) and m.bias is not None
+                    and x.dtype in (torch.float32, torch.float64)):
+                x = F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups)
+                x = ops.bias_leaky_relu_(x.contiguous(), m.bias, nxt.negative_slope)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
 
 
 # ---- MADE (conditioner of the autoregressive flows) ---------------------------------------------------------------

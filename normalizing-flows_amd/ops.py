@@ -474,3 +474,16 @@ def linear_wgrad(dy, x, want_bias=True):
                                  L.stream())
     L.check(rc, "nf_linear_wgrad")
     return dW, db
+
+
+def bias_leaky_relu_(y, bias, negative_slope):
+    """In place y = leaky_relu(y + bias[c]) on a contiguous NCHW tensor (nf_bias_leaky_relu)."""
+    L.require_device(y, bias)
+    if not y.is_contiguous():
+        raise ValueError("bias_leaky_relu_: contiguous NCHW tensor required")
+    B, Cc = y.shape[0], y.shape[1]
+    HW = int(math.prod(y.shape[2:]))
+    rc = L.lib().nf_bias_leaky_relu(ptr(y), ptr(bias.contiguous()), i64(B), i32(Cc), i64(HW), f64(negative_slope),
+                                    i32(L.dtype_code(y)), L.stream())
+    L.check(rc, "nf_bias_leaky_relu")
+    return y

@@ -90,6 +90,7 @@ def c5():
 
 
 if __name__ == "__main__":
-    c1()
-    c4()
-    c5()
+    import sys
+    which = sys.argv[1:] or ["1", "4", "5"]
+    for w in which:
+        {"1": c1, "4": c4, "5": c5}[w]()
