@@ -751,3 +751,58 @@ def test_model_glow_classcond_vs_reference(nfa):
     assert _rel(N(m.log_prob(xs, y)), N(lq)) < 1e-3
     b = nfa.utils.bitsPerDim(m, T(g["x"]), y)
     assert b.shape == (6,) and torch.isfinite(b).all()
+
+
+# ---- batch-size edge cases through every layer type ------------------------------------------------------------------
+def _edge_layers(nfa):
+    torch.manual_seed(11)
+    mk = lambda f: f.to(DEV)
+    b = torch.tensor([1.0, 0.0, 1.0, 0.0, 1.0, 0.0])
+    return [
+        ("crqs_unfused", mk(nfa.flows.CoupledRationalQuadraticSpline(6, 1, 16, num_bins=4)), (6,)),
+        ("crqs_fused_shape", mk(nfa.flows.CoupledRationalQuadraticSpline(64, 2, 128, num_bins=8)), (64,)),
+        ("lu", mk(nfa.flows.LULinearPermute(6)), (6,)),
+        ("lu64", mk(nfa.flows.LULinearPermute(64)), (64,)),
+        ("masked_affine", mk(nfa.flows.MaskedAffineFlow(b, nfa.nets.MLP([6, 8, 6], init_zeros=False),
+                                                       nfa.nets.MLP([6, 8, 6], init_zeros=False))), (6,)),
+        ("maf", mk(nfa.flows.MaskedAffineAutoregressive(6, 16, num_blocks=2)), (6,)),
+        ("arnsf", mk(nfa.flows.AutoregressiveRationalQuadraticSpline(5, 2, 12, num_bins=4)), (5,)),
+        ("glowblock", mk(nfa.flows.GlowBlock(4, 8, init_zeros=False)), (4, 4, 4)),
+        ("squeeze", mk(nfa.flows.Squeeze()), (4, 4, 4)),
+        ("logit", nfa.transforms.Logit(0.05), (3, 2, 2)),
+    ]
+
+
+@pytest.mark.parametrize("B", [0, 1, 63, 257])
+def test_batch_size_edges_every_layer(nfa, B):
+    """Empty, single-row and ragged batches (tile / wave / workgroup remainders) through every layer type: shapes,
+    finite values, round trip, and row-wise agreement with a larger batch (no cross-row leakage)."""
+    for name, layer, shape in _edge_layers(nfa):
+        g = torch.Generator().manual_seed(5)
+        big = torch.randn((300,) + shape, generator=g).to(DEV)
+        if name == "logit":
+            big = torch.sigmoid(big) * 0.98 + 0.01
+        if name == "glowblock":
+            layer.inverse(big)                      # ActNorm data-dependent init on a fixed batch first
+        x = big[:B].contiguous()
+        z, ld = layer.inverse(x)
+        assert z.shape[0] == B, name
+        per_row = torch.is_tensor(ld) and ld.dim() == 1 and ld.shape[0] == B
+        assert per_row or not torch.is_tensor(ld) or ld.numel() == 1, name      # (B,) or the reference's 0-dim / int 0
+        zb, ldb = layer.inverse(big)
+        if B:
+            assert torch.isfinite(z).all(), name
+            assert_close(N(z), N(zb[:B]), what=name + " rows", rtol=1e-5, atol=1e-5)
+            if per_row:
+                assert_close(N(ld), N(ldb[:B]), what=name + " ld rows", rtol=1e-5, atol=1e-5)
+            xr, ldr = layer.forward(z)
+            assert_close(N(xr), N(x), what=name + " roundtrip", rtol=2e-3, atol=2e-3)
+
+
+def test_model_with_empty_batch(nfa):
+    m = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(64, trainable=False),
+                            [nfa.flows.CoupledRationalQuadraticSpline(64, 2, 128), nfa.flows.LULinearPermute(64)] * 2).to(DEV)
+    lp = m.log_prob(torch.empty(0, 64, device=DEV))
+    assert lp.shape == (0,)
+    x, lq = m.sample(0)
+    assert x.shape == (0, 64) and lq.shape == (0,)
