@@ -20,9 +20,15 @@ namespace nf {
 // ---- scalar math, precise variants (parity with the reference's fp32/fp64 CPU path, not fast-math) ----
 template <typename T> struct M;
 template <> struct M<float> {
+#ifdef NF_FAST_F32_MATH   // hardware v_exp_f32 / v_log_f32 (about 1-2 ulp), as the fused kernel's epilogue uses
+    static __device__ __forceinline__ float exp(float x) { return __expf(x); }
+    static __device__ __forceinline__ float log(float x) { return __logf(x); }
+    static __device__ __forceinline__ float log1p(float x) { return __logf(1.0f + x); }
+#else
     static __device__ __forceinline__ float exp(float x) { return ::expf(x); }
     static __device__ __forceinline__ float log(float x) { return ::logf(x); }
     static __device__ __forceinline__ float log1p(float x) { return ::log1pf(x); }
+#endif
     static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
     static __device__ __forceinline__ float fmax(float a, float b) { return ::fmaxf(a, b); }
     static __device__ __forceinline__ bool finite(float x) { return ::isfinite(x); }
