@@ -10,7 +10,7 @@ at the repository root).
 """
 from . import _lib, config, ops, nets, flows, distributions, transforms, utils, dp
 from .core import NormalizingFlow, MultiscaleFlow
-from .distributions import DiagGaussian, ClassCondDiagGaussian
+from .distributions import DiagGaussian, ClassCondDiagGaussian, GlowBase
 
 __version__ = "0.1.0"
 

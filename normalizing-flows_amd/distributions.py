@@ -146,3 +146,76 @@ class ClassCondDiagGaussian(BaseDistribution):
             raise NotImplementedError("ClassCondDiagGaussian: inference only (no autograd through the HIP kernel yet)")
         loc_r, ls_r, idx = self._select(y, len(z))
         return ops.diag_gaussian_log_prob_rows(z, loc_r, ls_r, idx, self._shift())
+
+
+class GlowBase(BaseDistribution):
+    """Base distribution of the Glow model: one mean / log-scale per channel, scaled by exp(logs * logscale_factor),
+    optionally class conditional (base.py:348-471).  log_prob expands the per-channel rows over the pixels and runs
+    nf_diag_gaussian_log_prob_rows (rows picked by label inside the kernel, or blended per sample for soft labels)."""
+
+    def __init__(self, shape, num_classes=None, logscale_factor=3.0):
+        super().__init__()
+        if isinstance(shape, int):
+            shape = (shape,)
+        if isinstance(shape, list):
+            shape = tuple(shape)
+        self.shape = shape
+        self.n_dim = len(shape)
+        self.num_pix = int(np.prod(shape[1:]))
+        self.d = np.prod(shape)
+        self.sum_dim = list(range(1, self.n_dim + 1))
+        self.num_classes = num_classes
+        self.class_cond = num_classes is not None
+        self.logscale_factor = logscale_factor
+        pshape = (1, self.shape[0]) + (self.n_dim - 1) * (1,)
+        self.loc = nn.Parameter(torch.zeros(*pshape))
+        self.loc_logs = nn.Parameter(torch.zeros(*pshape))
+        self.log_scale = nn.Parameter(torch.zeros(*pshape))
+        self.log_scale_logs = nn.Parameter(torch.zeros(*pshape))
+        if self.class_cond:
+            self.loc_cc = nn.Parameter(torch.zeros(self.num_classes, self.shape[0]))
+            self.log_scale_cc = nn.Parameter(torch.zeros(self.num_classes, self.shape[0]))
+        self.temperature = None
+
+    def _channel_params(self, y, num_samples):
+        """(rows, C) mean and log-scale and the row index per sample (None: row b is sample b)."""
+        C = self.shape[0]
+        loc = (self.loc.detach() * torch.exp(self.loc_logs.detach() * self.logscale_factor)).view(1, C)
+        ls = (self.log_scale.detach() * torch.exp(self.log_scale_logs.detach() * self.logscale_factor)).view(1, C)
+        idx = None
+        if self.class_cond:
+            if y.dim() == 1:
+                loc, ls, idx = loc + self.loc_cc.detach(), ls + self.log_scale_cc.detach(), y
+            else:
+                w = y.to(loc.dtype)
+                loc, ls = loc + w @ self.loc_cc.detach(), ls + w @ self.log_scale_cc.detach()
+        elif num_samples is not None:
+            idx = torch.zeros(num_samples, dtype=torch.long, device=loc.device)
+        if self.temperature is not None:
+            ls = ls + float(np.log(self.temperature))
+        return loc, ls, idx
+
+    def _expand(self, rows):
+        return rows.unsqueeze(-1).expand(rows.shape[0], rows.shape[1], self.num_pix).reshape(rows.shape[0], -1)
+
+    def forward(self, num_samples=1, y=None):
+        if self.class_cond:
+            if y is not None:
+                num_samples = len(y)
+            else:
+                y = torch.randint(self.num_classes, (num_samples,), device=self.loc.device)
+        loc, ls, idx = self._channel_params(y, num_samples)
+        if idx is not None:
+            loc, ls = loc[idx], ls[idx]
+        pshape = (num_samples, self.shape[0]) + (self.n_dim - 1) * (1,)
+        eps = torch.randn((num_samples,) + self.shape, dtype=self.loc.dtype, device=self.loc.device)
+        z = loc.view(pshape) + torch.exp(ls.view(pshape)) * eps
+        zeros = torch.zeros(1, int(self.d), dtype=z.dtype, device=z.device)
+        log_p = ops.diag_gaussian_log_prob(eps, zeros, zeros, 0.0) - self.num_pix * ls.sum(1)
+        return z, log_p
+
+    def log_prob(self, z, y=None):
+        if needs_grad(z, *self.parameters()):
+            raise NotImplementedError("GlowBase: inference only (no autograd through the HIP kernel yet)")
+        loc, ls, idx = self._channel_params(y, len(z))
+        return ops.diag_gaussian_log_prob_rows(z, self._expand(loc), self._expand(ls), idx, 0.0)

@@ -59,6 +59,41 @@ class AffineConstFlow(Flow):
         return y
 
 
+class CCAffineConst(Flow):
+    """Affine constant flow with class-conditional parameters (coupling.py:57-97): s = s0 + y @ s_cc, t = t0 + y @ t_cc
+    per sample (y is the (B, num_classes) one-hot / weight matrix the reference multiplies with); the transform and
+    its log-det are one launch of nf_masked_affine with an all-zero mask (every element transformed)."""
+
+    def __init__(self, shape, num_classes):
+        super().__init__()
+        if isinstance(shape, int):
+            shape = (shape,)
+        self.shape = shape
+        self.s = nn.Parameter(torch.zeros(shape)[None])
+        self.t = nn.Parameter(torch.zeros(shape)[None])
+        self.s_cc = nn.Parameter(torch.zeros(num_classes, int(np.prod(shape))))
+        self.t_cc = nn.Parameter(torch.zeros(num_classes, int(np.prod(shape))))
+        self.n_dim = self.s.dim()
+        self.batch_dims = torch.nonzero(torch.tensor(self.s.shape) == 1, as_tuple=False)[:, 0].tolist()
+
+    def _st(self, z, y):
+        y = y.to(self.s.dtype)
+        s = self.s.detach() + (y @ self.s_cc.detach()).view(-1, *self.shape)
+        t = self.t.detach() + (y @ self.t_cc.detach()).view(-1, *self.shape)
+        return s.expand_as(z).contiguous(), t.expand_as(z).contiguous()
+
+    def _transform(self, z, y, direction, ld=None, acc=None):
+        s, t = self._st(z, y)
+        zero = torch.zeros(z.shape[1:], dtype=z.dtype, device=z.device)
+        return ops.masked_affine(z, zero, s, t, direction, logdet=ld, acc=acc)
+
+    def forward(self, z, y):
+        return self._transform(z, y, 0)
+
+    def inverse(self, z, y):
+        return self._transform(z, y, 1)
+
+
 class AffineCoupling(Flow):
     """Affine coupling on a list [z1, z2] (coupling.py:99-171)."""
 

@@ -107,6 +107,64 @@ class Invertible1x1Conv(Flow):
         return y
 
 
+class InvertibleAffine(Flow):
+    """One-dimensional version of the invertible 1x1 convolution, z_ = z @ W (mixing.py:136-207).  Same parameters as
+    Invertible1x1Conv; `z @ W` is the per-sample product with W^T, so the HIP mat-vec kernel runs on (B, C, 1, 1)
+    with the transposed assembled matrix (kept until a parameter changes)."""
+
+    def __init__(self, num_channels, use_lu=True):
+        super().__init__()
+        self.num_channels = num_channels
+        self.use_lu = use_lu
+        Q, _ = torch.linalg.qr(torch.randn(self.num_channels, self.num_channels))
+        if use_lu:
+            P, L, U = torch.lu_unpack(*Q.lu())
+            self.register_buffer("P", P)
+            self.L = nn.Parameter(L)
+            S = U.diag()
+            self.register_buffer("sign_S", torch.sign(S))
+            self.log_S = nn.Parameter(torch.log(torch.abs(S)))
+            self.U = nn.Parameter(torch.triu(U, diagonal=1))
+            self.register_buffer("eye", torch.diag(torch.ones(self.num_channels)))
+        else:
+            self.W = nn.Parameter(Q)
+
+    def _weight_t(self, inverse_dir):
+        params = (self.L, self.U, self.log_S, self.P) if self.use_lu else (self.W,)
+        key = (inverse_dir,) + tuple((t.data_ptr(), t._version) for t in params)
+        cache = getattr(self, "_w_cache", None)
+        if cache is None or cache[0] != key:
+            if self.use_lu:
+                W, ldu = ops.inv1x1_assemble(self.P, self.L.detach(), self.U.detach(), self.sign_S, self.log_S.detach(),
+                                             inverse=not inverse_dir)
+            else:
+                W = self.W.detach()
+                ldu = torch.slogdet(W)[1]
+                if not inverse_dir:
+                    W = torch.inverse(W) if W.dtype == torch.float64 else torch.inverse(W.double()).type(W.dtype)
+                    ldu = -ldu
+            cache = (key, (W.t().contiguous(), ldu))
+            self._w_cache = cache
+        return cache[1]
+
+    def _mul(self, z, inverse_dir, ld=None, acc=None, want_scalar=True):
+        if z.dim() != 2:
+            raise NotImplementedError("InvertibleAffine: (batch, channels) inputs")
+        Wt, ldu = self._weight_t(inverse_dir)
+        y, lds = ops.inv1x1_conv(z.reshape(z.shape[0], -1, 1, 1), Wt, ldu, logdet=ld, acc=acc, want_scalar=want_scalar)
+        return y.view(z.shape), lds
+
+    def forward(self, z, context=None):
+        return self._mul(z, False)
+
+    def inverse(self, z, context=None):
+        return self._mul(z, True)
+
+    def _run(self, z, inverse, ld, acc, **kw):
+        y, _ = self._mul(z, inverse, ld=ld, acc=acc, want_scalar=False)
+        return y
+
+
 # ---- LU linear + permutation used by neural spline flows ---------------------------------------------------
 class _Permutation(Flow):
     """Holds a fixed permutation of dimension `dim` (mixing.py:213-247)."""

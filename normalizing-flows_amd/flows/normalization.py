@@ -10,6 +10,7 @@ import torch
 
 from .. import ops
 from .affine import AffineConstFlow
+from .base import Flow
 
 
 class ActNorm(AffineConstFlow):
@@ -46,3 +47,23 @@ class ActNorm(AffineConstFlow):
     def _run(self, z, inverse, ld, acc, **kw):
         self._maybe_init(z, inverse)
         return super()._run(z, inverse, ld, acc)
+
+
+class BatchNorm(Flow):
+    """Batch normalisation flow without gradients through the batch statistics (normalization.py:42-62; forward only,
+    like the reference).  Statistics over dim 0 come from nf_actnorm_stats (mean, unbiased std per element), the
+    normalisation and its log-det are nf_actnorm with s = -log sqrt(std^2 + eps), t = -mean e^s."""
+
+    def __init__(self, eps=1.0e-10):
+        super().__init__()
+        self.eps_cpu = torch.tensor(eps)
+        self.register_buffer("eps", self.eps_cpu)
+
+    def forward(self, z):
+        zz = z.reshape(z.shape[0], -1)
+        mean, std = ops.actnorm_stats(zz)
+        s = -0.5 * torch.log(std ** 2 + self.eps.to(z.dtype))
+        t = -mean * torch.exp(s)
+        ld = torch.zeros(z.shape[0], dtype=z.dtype, device=z.device)
+        y, _ = ops.actnorm(zz, s, t, 0, logdet=ld, acc=1, want_scalar=False)
+        return y.view(z.shape), ld

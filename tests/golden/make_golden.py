@@ -500,7 +500,53 @@ def gen_glue():
     npz("model_glow_classcond", x=x, y=yl, log_prob=lp, log_prob_second=lp2, **sd0, **sd(m, "sd__"))
 
 
+def gen_misc():
+    """Remaining classes of the hot-path files: CCAffineConst (affine/coupling.py:57-97), InvertibleAffine
+    (mixing.py:136-207), BatchNorm flow (normalization.py:42-62), GlowBase (distributions/base.py:348-471)."""
+    g = torch.Generator().manual_seed(31)
+    cc = nf.flows.affine.coupling.CCAffineConst((3, 1, 1), 4)
+    with torch.no_grad():
+        for p_ in cc.parameters():
+            p_.copy_(0.3 * torch.randn(p_.shape, generator=g))
+    z = torch.randn(5, 3, 2, 2, generator=g)
+    y = torch.nn.functional.one_hot(torch.tensor([0, 3, 1, 2, 3]), 4).float()
+    with torch.no_grad():
+        zf, ldf = cc.forward(z, y)
+        zi, ldi = cc.inverse(z, y)
+    npz("cc_affine_const", z=z, y=y, z_fwd=zf, ld_fwd=ldf, z_inv=zi, ld_inv=ldi, **sd(cc, "sd__"))
+    torch.manual_seed(8)
+    for use_lu in (True, False):
+        ia = nf.flows.InvertibleAffine(7, use_lu=use_lu)
+        perturb(ia, 0.1, 12)
+        z = torch.randn(6, 7, generator=g)
+        with torch.no_grad():
+            zf, ldf = ia.forward(z)
+            zi, ldi = ia.inverse(z)
+        npz("invertible_affine_lu%d" % int(use_lu), z=z, z_fwd=zf, ld_fwd=ldf, z_inv=zi, ld_inv=ldi, **sd(ia, "sd__"))
+    bn = nf.flows.BatchNorm()
+    z = 2.0 * torch.randn(9, 5, generator=g) + 1.0
+    with torch.no_grad():
+        zf, ldf = bn.forward(z)
+    npz("batchnorm_flow", z=z, z_fwd=zf, ld_fwd=ldf)
+    for ncls in (None, 3):
+        gb = nf.distributions.GlowBase((4, 2, 2), num_classes=ncls)
+        with torch.no_grad():
+            for p_ in gb.parameters():
+                p_.copy_(0.2 * torch.randn(p_.shape, generator=g))
+        z = torch.randn(6, 4, 2, 2, generator=g)
+        yl = torch.tensor([0, 2, 1, 1, 0, 2])
+        with torch.no_grad():
+            lp = gb.log_prob(z, yl) if ncls else gb.log_prob(z)
+            gb.temperature = 0.8
+            lpt = gb.log_prob(z, yl) if ncls else gb.log_prob(z)
+            gb.temperature = None
+        npz("glow_base_cc%d" % (ncls or 0), z=z, y=yl, log_prob=lp, log_prob_temp=lpt, **sd(gb, "sd__"))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "misc":
+        gen_misc()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "glue":
         gen_glue()
         sys.exit(0)
@@ -521,3 +567,4 @@ if __name__ == "__main__":
     gen_maf()
     gen_arnsf()
     gen_glue()
+    gen_misc()

@@ -806,3 +806,63 @@ def test_model_with_empty_batch(nfa):
     assert lp.shape == (0,)
     x, lq = m.sample(0)
     assert x.shape == (0, 64) and lq.shape == (0,)
+
+
+# ---- remaining classes of the hot-path files -------------------------------------------------------------------------
+def test_cc_affine_const_vs_reference(nfa):
+    g = load_golden("cc_affine_const")
+    cc = nfa.flows.CCAffineConst((3, 1, 1), 4)
+    cc.load_state_dict({k: torch.from_numpy(v) for k, v in golden_state(g).items()}, strict=True)
+    cc = cc.to(DEV)
+    z, ld = cc.forward(T(g["z"]), T(g["y"]))
+    assert_close(N(z), g["z_fwd"], what="z_fwd", rtol=1e-5, atol=1e-5)
+    assert_close(N(ld), g["ld_fwd"], what="ld_fwd", rtol=1e-5, atol=1e-5)
+    z, ld = cc.inverse(T(g["z"]), T(g["y"]))
+    assert_close(N(z), g["z_inv"], what="z_inv", rtol=1e-5, atol=1e-5)
+    assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("use_lu", [True, False])
+def test_invertible_affine_vs_reference(nfa, use_lu):
+    g = load_golden("invertible_affine_lu%d" % int(use_lu))
+    ia = nfa.flows.InvertibleAffine(7, use_lu=use_lu)
+    ia.load_state_dict({k: torch.from_numpy(v) for k, v in golden_state(g).items()}, strict=True)
+    ia = ia.to(DEV)
+    z, ld = ia.forward(T(g["z"]))
+    assert_close(N(z), g["z_fwd"], what="z_fwd", rtol=1e-4, atol=1e-5)
+    assert_close(N(ld), g["ld_fwd"], what="ld_fwd", rtol=1e-5, atol=1e-5)
+    z, ld = ia.inverse(T(g["z"]))
+    assert_close(N(z), g["z_inv"], what="z_inv", rtol=1e-4, atol=1e-5)
+    assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=1e-5, atol=1e-5)
+    xr, _ = ia.forward(z)
+    assert_close(N(xr), g["z"], what="roundtrip", rtol=1e-4, atol=1e-4)
+
+
+def test_batchnorm_flow_vs_reference(nfa):
+    g = load_golden("batchnorm_flow")
+    z, ld = nfa.flows.BatchNorm().to(DEV).forward(T(g["z"]))
+    assert_close(N(z), g["z_fwd"], what="z_fwd", rtol=1e-4, atol=1e-5)
+    assert_close(N(ld), g["ld_fwd"], what="ld_fwd", rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("ncls", [0, 3])
+def test_glow_base_vs_reference(nfa, ncls):
+    g = load_golden("glow_base_cc%d" % ncls)
+    gb = nfa.distributions.GlowBase((4, 2, 2), num_classes=ncls or None)
+    gb.load_state_dict({k: torch.from_numpy(v) for k, v in golden_state(g).items()}, strict=True)
+    gb = gb.to(DEV)
+    y = torch.from_numpy(g["y"]).to(DEV)
+    with torch.no_grad():
+        lp = gb.log_prob(T(g["z"]), y) if ncls else gb.log_prob(T(g["z"]))
+        assert_close(N(lp), g["log_prob"], what="log_prob", rtol=1e-5, atol=1e-5)
+        gb.temperature = 0.8
+        lp = gb.log_prob(T(g["z"]), y) if ncls else gb.log_prob(T(g["z"]))
+        assert_close(N(lp), g["log_prob_temp"], what="temperature", rtol=1e-5, atol=1e-5)
+        gb.temperature = None
+        if ncls:
+            soft = torch.nn.functional.one_hot(y, ncls).float()
+            assert_close(N(gb.log_prob(T(g["z"]), soft)), g["log_prob"], what="one-hot", rtol=1e-5, atol=1e-5)
+        torch.manual_seed(2)
+        z, lq = gb(y=y) if ncls else gb(6)
+        lp2 = gb.log_prob(z, y) if ncls else gb.log_prob(z)
+        assert_close(N(lp2), N(lq), what="sample log_p", rtol=1e-4, atol=1e-4)
