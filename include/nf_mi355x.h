@@ -34,7 +34,7 @@ typedef void *nf_stream_t; /* hipStream_t */
 enum { NF_OK = 0, NF_EIO = -5, NF_EFAULT = -14, NF_EINVAL = -22, NF_ERANGE = -34, NF_ENOTSUP = -95 };
 enum { NF_F32 = 0, NF_F64 = 1 };
 enum { NF_LD_WRITE = 0, NF_LD_ADD = 1, NF_LD_SUB = -1 };
-enum { NF_TAILS_NONE = 0, NF_TAILS_LINEAR = 1, NF_TAILS_CIRCULAR = 2 };
+enum { NF_TAILS_NONE = 0, NF_TAILS_LINEAR = 1, NF_TAILS_CIRCULAR = 2, NF_TAILS_FEATURE = 3 /* nf_rqs_coupling_ft only */ };
 enum { NF_SCALE_EXP = 0, NF_SCALE_SIGMOID = 1, NF_SCALE_SIGMOID_INV = 2, NF_SCALE_NONE = 3 };
 enum { NF_RQS_DENSITY = 0, NF_RQS_SAMPLE_IDENTITY = 1, NF_RQS_SAMPLE_TRANSFORM = 2 };
 
@@ -93,6 +93,23 @@ int nf_rqs_coupling(const void *x, void *y, void *logdet, const void *cond, cons
                     int nT, int64_t B, int D, int K, int tails, double tail_bound, double min_bin_width,
                     double min_bin_height, double min_derivative, double wh_div, int mode, int acc,
                     int dtype, nf_stream_t stream);
+
+/* Same transform with tails and / or tail bounds given PER FEATURE (utils/splines.py:48-57 list of tails, :61-66 tensor
+ * tail_bound; the circular-coordinate layers of neural_spline/wrapper.py:88-185, 247-330 and coupling.py:283-318):
+ *   tails = NF_TAILS_FEATURE: tails_t (nT) / tails_i (nI) int32 hold NF_TAILS_LINEAR or NF_TAILS_CIRCULAR for every
+ *     transform / identity feature (in the order of transform_idx / identity_idx); rows carry K+1 derivative logits
+ *     (M = 3K+1) whose edge entries are overwritten per type; as in the reference's list branch, inputs outside
+ *     their interval produce OUTPUT 0 and log-det 0 (that branch never copies them through).
+ *   bound_t (nT) / bound_i (nI): per-feature tail bounds of the data dtype, or NULL for the scalar tail_bound; usable
+ *     with any `tails` other than NF_TAILS_NONE.
+ * With all four arrays NULL this is nf_rqs_coupling.
+ */
+int nf_rqs_coupling_ft(const void *x, void *y, void *logdet, const void *cond, const void *uw, const void *uh,
+                    const void *ud, const int64_t *identity_idx, int nI, const int64_t *transform_idx,
+                    int nT, int64_t B, int D, int K, int tails, double tail_bound, double min_bin_width,
+                    double min_bin_height, double min_derivative, double wh_div, int mode, int acc,
+                    int dtype, const int32_t *tails_t, const void *bound_t,
+                       const int32_t *tails_i, const void *bound_i, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Backward (vector-Jacobian product) of nf_rqs_coupling, for training.  The reference differentiates

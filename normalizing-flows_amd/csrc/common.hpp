@@ -62,6 +62,8 @@ template <typename T> struct RqsParams {
     T wh_div;            // sqrt(hidden_features) or 1       (nsf/coupling.py:334-339)
     T edge_logit;        // log(exp(1 - min_d) - 1)          (utils/splines.py:36)
     T eps;               // searchsorted eps = 1e-6          (utils/splines.py:11)
+    int dfull;           // 1: per-feature tails (utils/splines.py:48-57): K+1 derivative logits per element, the edge
+                         // ones overridden according to the feature's tails type; out-of-interval outputs are 0
 };
 
 template <typename T>
@@ -70,7 +72,8 @@ static inline RqsParams<T> make_rqs_params(int K, int tails, double tail_bound, 
                                            double wh_div) {
     RqsParams<T> p;
     p.K = K;
-    p.tails = tails;
+    p.dfull = tails == NF_TAILS_FEATURE ? 1 : 0;
+    p.tails = tails == NF_TAILS_FEATURE ? NF_TAILS_LINEAR : tails;  // per-feature type is set by rqs_feature_params
     p.nd = tails == NF_TAILS_LINEAR ? K - 1 : (tails == NF_TAILS_CIRCULAR ? K : K + 1);
     if (tails != NF_TAILS_NONE) {
         left = -tail_bound; right = tail_bound; bottom = -tail_bound; top = tail_bound;
@@ -90,9 +93,26 @@ template <typename T> __device__ __forceinline__ bool rqs_inside(const RqsParams
     return p.tails == NF_TAILS_NONE ? true : (x >= p.left && x <= p.right);
 }
 
+// Parameters of one feature when tails / tail_bound are given per feature (utils/splines.py:48-57, :61-66); ft / fb may
+// each be null (then the launch-wide value applies).
+template <typename T>
+__device__ __forceinline__ RqsParams<T> rqs_feature_params(const RqsParams<T> &p, const int *ft, const T *fb, int j) {
+    RqsParams<T> q = p;
+    if (ft) q.tails = ft[j];
+    if (fb) {
+        const T tb = fb[j];
+        q.left = -tb; q.right = tb; q.bottom = -tb; q.top = tb;
+    }
+    return q;
+}
+
 // Unnormalised derivative logit j in [0, K] after the padding of utils/splines.py:34-44.
 template <typename T, typename Acc>
 __device__ __forceinline__ T rqs_dlogit(const RqsParams<T> &p, const Acc &dacc, int j) {
+    if (p.dfull) {  // utils/splines.py:48-57: the K+1 logits are kept, edges overwritten per tails type
+        if (p.tails == NF_TAILS_LINEAR) return (j == 0 || j == p.K) ? p.edge_logit : dacc(j);
+        return j == p.K ? dacc(0) : dacc(j);
+    }
     if (p.tails == NF_TAILS_LINEAR) return (j == 0 || j == p.K) ? p.edge_logit : dacc(j - 1);
     if (p.tails == NF_TAILS_CIRCULAR) return j == p.K ? dacc(0) : dacc(j);
     return dacc(j);
@@ -138,8 +158,8 @@ __device__ __forceinline__ void rqs_eval_bin(T x, T cw, T bw, T ch, T bh, T d0, 
 template <typename T, typename WAcc, typename HAcc, typename DAcc>
 __device__ __forceinline__ void rqs_element(const RqsParams<T> &p, T x, const WAcc &wacc, const HAcc &hacc,
                                             const DAcc &dacc, bool inverse, T &y, T &lad) {
-    if (!rqs_inside(p, x)) {  // linear / circular tails: identity outside, also for NaN / inf (:40-41)
-        y = x;
+    if (!rqs_inside(p, x)) {  // linear / circular tails: identity outside, also for NaN / inf (:40-41);
+        y = p.dfull ? T(0) : x;  // the per-feature branch (:48-57) never copies the outside inputs: they stay 0
         lad = T(0);
         return;
     }
@@ -227,7 +247,7 @@ template <typename T>
 __device__ __forceinline__ void rqs_eval_table(const RqsParams<T> &p, T x, const T *tab, bool inverse, T &y,
                                                T &lad) {
     if (!rqs_inside(p, x)) {
-        y = x;
+        y = p.dfull ? T(0) : x;
         lad = T(0);
         return;
     }

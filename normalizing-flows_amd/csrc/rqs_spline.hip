@@ -42,7 +42,8 @@ __global__ void __launch_bounds__(256)
 rqs_coupling_kernel(const T *__restrict__ x, T *__restrict__ y, T *__restrict__ logdet, const T *__restrict__ cond,
                     const T *__restrict__ uw, const T *__restrict__ uh, const T *__restrict__ ud,
                     const int64_t *__restrict__ iidx, int nI, const int64_t *__restrict__ tidx, int nT, int64_t B,
-                    int D, RqsParams<T> p, int mode, int acc, int TS, int Mp) {
+                    int D, RqsParams<T> p, int mode, int acc, int TS, int Mp, const int *__restrict__ tails_t,
+                    const T *__restrict__ bound_t, const int *__restrict__ tails_i, const T *__restrict__ bound_i) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int K = p.K;
     const int M = 2 * K + p.nd;
@@ -64,8 +65,9 @@ rqs_coupling_kernel(const T *__restrict__ x, T *__restrict__ y, T *__restrict__ 
     for (int j = tid; j < nI; j += nth) s_iidx[j] = (int)iidx[j];
     for (int j = tid; j < nT; j += nth) s_tidx[j] = (int)tidx[j];
     if (do_i && has_uncond) {
-        RqsParams<T> pu = p;  // the unconditional transform is not scaled (nsf/coupling.py:224-232)
         for (int j = tid; j < nI; j += nth) {
+            // the unconditional transform is not scaled by sqrt(hidden) (nsf/coupling.py:224-232): wh_div is not used here
+            const RqsParams<T> pu = rqs_feature_params(p, tails_i, bound_i, j);
             const T *wj = uw + (size_t)j * K, *hj = uh + (size_t)j * K, *dj = ud + (size_t)j * p.nd;
             auto wacc = [=](int k) { return wj[k]; };
             auto hacc = [=](int k) { return hj[k]; };
@@ -116,7 +118,8 @@ rqs_coupling_kernel(const T *__restrict__ x, T *__restrict__ y, T *__restrict__ 
                 auto hacc = [=](int k) { return row[K + k]; };
                 auto dacc = [=](int k) { return row[2 * K + k]; };
                 T yy, ll;
-                rqs_element<T>(p, s_x[s * D + s_tidx[j]], wacc, hacc, dacc, inverse, yy, ll);
+                rqs_element<T>(rqs_feature_params(p, tails_t, bound_t, j), s_x[s * D + s_tidx[j]], wacc, hacc, dacc,
+                               inverse, yy, ll);
                 s_y[s * D + s_tidx[j]] = yy;
                 s_lad[s * (nT + nI) + j] = ll;
             }
@@ -127,7 +130,8 @@ rqs_coupling_kernel(const T *__restrict__ x, T *__restrict__ y, T *__restrict__ 
             for (int e = tid; e < n; e += nth) {
                 const int s = e / nI, j = e - s * nI;
                 T yy = s_x[s * D + s_iidx[j]], ll = T(0);
-                if (has_uncond) rqs_eval_table<T>(p, yy, s_tab + (size_t)j * TW, inverse, yy, ll);
+                if (has_uncond)
+                    rqs_eval_table<T>(rqs_feature_params(p, tails_i, bound_i, j), yy, s_tab + (size_t)j * TW, inverse, yy, ll);
                 s_y[s * D + s_iidx[j]] = yy;
                 s_lad[s * (nT + nI) + nT + j] = ll;
             }
@@ -167,7 +171,9 @@ rqs_coupling_kernel(const T *__restrict__ x, T *__restrict__ y, T *__restrict__ 
 template <typename T>
 static int launch_rqs_coupling(const void *x, void *y, void *logdet, const void *cond, const void *uw, const void *uh,
                                const void *ud, const int64_t *iidx, int nI, const int64_t *tidx, int nT, int64_t B,
-                               int D, const RqsParams<T> &p, int mode, int acc, hipStream_t st) {
+                               int D, const RqsParams<T> &p, int mode, int acc, hipStream_t st,
+                               const int32_t *tails_t = nullptr, const void *bound_t = nullptr,
+                               const int32_t *tails_i = nullptr, const void *bound_i = nullptr) {
     const int K = p.K;
     const int M = 2 * K + p.nd;
     const int Mp = M | 1;
@@ -188,7 +194,7 @@ static int launch_rqs_coupling(const void *x, void *y, void *logdet, const void 
     const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
     hipLaunchKernelGGL(rqs_coupling_kernel<T>, dim3(grid), dim3(256), lds, st, (const T *)x, (T *)y, (T *)logdet,
                        (const T *)cond, (const T *)uw, (const T *)uh, (const T *)ud, iidx, nI, tidx, nT, B, D, p, mode,
-                       acc, TS, Mp);
+                       acc, TS, Mp, (const int *)tails_t, (const T *)bound_t, (const int *)tails_i, (const T *)bound_i);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -260,6 +266,39 @@ extern "C" int nf_rqs_coupling(const void *x, void *y, void *logdet, const void 
                                          min_derivative, wh_div);
         return launch_rqs_coupling<double>(x, y, logdet, cond, uw, uh, ud, identity_idx, nI, transform_idx, nT, B, D,
                                            p, mode, acc, st);
+    }
+    return NF_ENOTSUP;
+}
+
+extern "C" int nf_rqs_coupling_ft(const void *x, void *y, void *logdet, const void *cond, const void *uw, const void *uh,
+                               const void *ud, const int64_t *identity_idx, int nI, const int64_t *transform_idx,
+                               int nT, int64_t B, int D, int K, int tails, double tail_bound, double min_bin_width,
+                               double min_bin_height, double min_derivative, double wh_div, int mode, int acc,
+                               int dtype,
+                                  const int32_t *tails_t, const void *bound_t, const int32_t *tails_i,
+                                  const void *bound_i, nf_stream_t stream) {
+    int rc = check_spline_args(K, tails == NF_TAILS_FEATURE ? NF_TAILS_LINEAR : tails, min_bin_width, min_bin_height);
+    if (rc) return rc;
+    if (tails == NF_TAILS_FEATURE && ((nT && !tails_t) || (nI && uw && !tails_i))) return NF_EFAULT;
+    if (tails != NF_TAILS_FEATURE && (tails_t || tails_i)) return NF_EINVAL;
+    if (B < 0 || D < 1 || nI < 0 || nT < 0 || nI + nT != D) return NF_EINVAL;
+    if (mode < NF_RQS_DENSITY || mode > NF_RQS_SAMPLE_TRANSFORM) return NF_EINVAL;
+    if (acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!x || !y || !logdet || (nI && !identity_idx) || (nT && !transform_idx)) return NF_EFAULT;
+    if (mode != NF_RQS_SAMPLE_IDENTITY && nT && !cond) return NF_EFAULT;
+    if ((uw || uh || ud) && !(uw && uh && ud)) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == NF_F32) {
+        auto p = make_rqs_params<float>(K, tails, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
+                                        min_derivative, wh_div);
+        return launch_rqs_coupling<float>(x, y, logdet, cond, uw, uh, ud, identity_idx, nI, transform_idx, nT, B, D, p,
+                                          mode, acc, st, tails_t, bound_t, tails_i, bound_i);
+    } else if (dtype == NF_F64) {
+        auto p = make_rqs_params<double>(K, tails, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
+                                         min_derivative, wh_div);
+        return launch_rqs_coupling<double>(x, y, logdet, cond, uw, uh, ud, identity_idx, nI, transform_idx, nT, B, D,
+                                           p, mode, acc, st, tails_t, bound_t, tails_i, bound_i);
     }
     return NF_ENOTSUP;
 }

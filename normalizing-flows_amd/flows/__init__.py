@@ -4,7 +4,9 @@ from .affine import AffineConstFlow, CCAffineConst, AffineCoupling, MaskedAffine
 from .normalization import ActNorm, BatchNorm
 from .mixing import Permute, Invertible1x1Conv, InvertibleAffine, LULinearPermute
 from .glow import GlowBlock
-from .neural_spline import (CoupledRationalQuadraticSpline, PiecewiseRationalQuadraticCoupling,
-                            PiecewiseRationalQuadraticCDF)
+from .neural_spline import (CoupledRationalQuadraticSpline, CircularCoupledRationalQuadraticSpline,
+                            PiecewiseRationalQuadraticCoupling, PiecewiseRationalQuadraticCDF)
 from .autoregressive import (Autoregressive, MaskedAffineAutoregressive,
-                             MaskedPiecewiseRationalQuadraticAutoregressive, AutoregressiveRationalQuadraticSpline)
+                             MaskedPiecewiseRationalQuadraticAutoregressive, AutoregressiveRationalQuadraticSpline,
+                             CircularAutoregressiveRationalQuadraticSpline)
+from .periodic import PeriodicWrap, PeriodicShift

@@ -101,26 +101,33 @@ class MaskedPiecewiseRationalQuadraticAutoregressive(Autoregressive):
                  num_blocks=2, use_residual_blocks=True, random_mask=False, permute_mask=False, activation=F.relu,
                  dropout_probability=0.0, use_batch_norm=False, init_identity=True, min_bin_width=1e-3,
                  min_bin_height=1e-3, min_derivative=1e-3):
-        if isinstance(tails, (list, tuple)) or torch.is_tensor(tail_bound):
-            raise NotImplementedError("per-feature tails / tensor tail_bound (periodic features) are out of scope")
-        if tails not in (None, "linear", "circular"):
-            raise RuntimeError("{} tails are not implemented.".format(tails))
+        from .neural_spline import _check_tails
+        _check_tails(tails, tail_bound)
         self.num_bins = num_bins
         self.min_bin_width = min_bin_width
         self.min_bin_height = min_bin_height
         self.min_derivative = min_derivative
         self.tails = tails
         self.features = features
+        if isinstance(self.tails, (list, tuple)):   # periodic features of the circular coordinates (:44-55)
+            ind_circ = [i for i in range(features) if self.tails[i] == "circular"]
+            scale_pf = np.pi / tail_bound[ind_circ] if torch.is_tensor(tail_bound) else np.pi / tail_bound
+            preprocessing = nets.PeriodicFeaturesElementwise(features, ind_circ, scale_pf)
+        else:
+            preprocessing = None
         made = nets.MADE(features=features, hidden_features=hidden_features, context_features=context_features,
                          num_blocks=num_blocks, output_multiplier=self._output_dim_multiplier(),
                          use_residual_blocks=use_residual_blocks, random_mask=random_mask, permute_mask=permute_mask,
                          activation=activation, dropout_probability=dropout_probability,
-                         use_batch_norm=use_batch_norm)
+                         use_batch_norm=use_batch_norm, preprocessing=preprocessing)
         if init_identity:
             torch.nn.init.constant_(made.final_layer.weight, 0.0)
             torch.nn.init.constant_(made.final_layer.bias, float(np.log(np.exp(1 - min_derivative) - 1)))
         super().__init__(made)
-        self.tail_bound = tail_bound
+        if torch.is_tensor(tail_bound):
+            self.register_buffer("tail_bound", tail_bound)
+        else:
+            self.tail_bound = tail_bound
 
     def _output_dim_multiplier(self):
         if self.tails == "linear":
@@ -141,10 +148,11 @@ class MaskedPiecewiseRationalQuadraticAutoregressive(Autoregressive):
         wh_div = float(np.sqrt(self.autoregressive_net.hidden_features)) \
             if hasattr(self.autoregressive_net, "hidden_features") else 1.0
         mode = ops.L.RQS_DENSITY if direction == 0 else ops.L.RQS_SAMPLE_TRANSFORM
+        from .neural_spline import _tails_kwargs
+        kw = _tails_kwargs(self.tails, self.tail_bound, "t", inputs.device, self.__dict__.setdefault("_tcache", {}))
         return ops.rqs_coupling(inputs, params.contiguous(), None, None, None, idx[0], idx[1], self.num_bins, mode,
-                                tails=self.tails, tail_bound=float(self.tail_bound),
                                 min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
-                                min_derivative=self.min_derivative, wh_div=wh_div)
+                                min_derivative=self.min_derivative, wh_div=wh_div, **kw)
 
 
 class AutoregressiveRationalQuadraticSpline(Flow):
@@ -159,6 +167,30 @@ class AutoregressiveRationalQuadraticSpline(Flow):
         self.mprqat = MaskedPiecewiseRationalQuadraticAutoregressive(
             features=num_input_channels, hidden_features=num_hidden_channels, context_features=num_context_channels,
             num_bins=num_bins, tails="linear", tail_bound=tail_bound, num_blocks=num_blocks, use_residual_blocks=True,
+            random_mask=False, permute_mask=permute_mask, activation=F.relu if isinstance(act, torch.nn.ReLU) else act,
+            dropout_probability=dropout_probability, use_batch_norm=False, init_identity=init_identity)
+
+    def forward(self, z, context=None):
+        z, log_det = self.mprqat.inverse(z, context=context)
+        return z, log_det.view(-1)
+
+    def inverse(self, z, context=None):
+        z, log_det = self.mprqat(z, context=context)
+        return z, log_det.view(-1)
+
+
+class CircularAutoregressiveRationalQuadraticSpline(Flow):
+    """Autoregressive NSF layer with circular coordinates (wrapper.py:247-330)."""
+
+    def __init__(self, num_input_channels, num_blocks, num_hidden_channels, ind_circ, num_context_channels=None,
+                 num_bins=8, tail_bound=3, activation=torch.nn.ReLU, dropout_probability=0.0, permute_mask=True,
+                 init_identity=True):
+        super().__init__()
+        tails = ["circular" if i in ind_circ else "linear" for i in range(num_input_channels)]
+        act = activation()
+        self.mprqat = MaskedPiecewiseRationalQuadraticAutoregressive(
+            features=num_input_channels, hidden_features=num_hidden_channels, context_features=num_context_channels,
+            num_bins=num_bins, tails=tails, tail_bound=tail_bound, num_blocks=num_blocks, use_residual_blocks=True,
             random_mask=False, permute_mask=permute_mask, activation=F.relu if isinstance(act, torch.nn.ReLU) else act,
             dropout_probability=dropout_probability, use_batch_norm=False, init_identity=init_identity)
 

@@ -19,7 +19,7 @@ from torch import nn
 from .. import _lib as L
 from .. import ops
 from ..autograd import SplineFn, needs_grad
-from ..nets import ResidualNet
+from ..nets import PeriodicFeaturesElementwise, ResidualNet
 from ..utils.masks import create_alternating_binary_mask
 from .base import Flow
 
@@ -28,12 +28,42 @@ DEFAULT_MIN_BIN_HEIGHT = 1e-3
 DEFAULT_MIN_DERIVATIVE = 1e-3
 
 
+_TAIL_CODE = {"linear": 1, "circular": 2}
+
+
 def _check_tails(tails, tail_bound):
-    if isinstance(tails, (list, tuple)) or torch.is_tensor(tail_bound):
-        raise NotImplementedError("per-feature tails / tensor tail_bound (circular-coordinate variants) are not "
-                                  "implemented by the HIP spline kernels")
-    if tails not in (None, "linear", "circular"):
+    if isinstance(tails, (list, tuple)):
+        for t in tails:
+            if t not in _TAIL_CODE:
+                raise RuntimeError("{} tails are not implemented.".format(t))
+    elif tails not in (None, "linear", "circular"):
         raise RuntimeError("{} tails are not implemented.".format(tails))
+
+
+def _tails_kwargs(tails, tail_bound, role, device=None, cache=None):
+    """Kernel arguments for scalar or per-feature tails / bounds (utils/splines.py:48-66); role = "t" | "i".
+    `cache` (a dict owned by the module) keeps the device copy of the type codes."""
+    kw = {}
+    if isinstance(tails, (list, tuple)):
+        kw["tails"] = "feature"
+        key = (role, str(device))
+        if cache is not None and key in cache:
+            codes = cache[key]
+        else:
+            codes = torch.tensor([_TAIL_CODE[t] for t in tails], dtype=torch.int32, device=device)
+            if cache is not None:
+                cache[key] = codes
+        kw["tails_" + role] = codes
+    else:
+        kw["tails"] = tails
+    if torch.is_tensor(tail_bound):
+        if tails is None:
+            raise NotImplementedError("tensor tail_bound without tails")
+        kw["bound_" + role] = tail_bound.reshape(-1)
+        kw["tail_bound"] = 1.0
+    else:
+        kw["tail_bound"] = tail_bound
+    return kw
 
 
 class PiecewiseRationalQuadraticCDF(Flow):
@@ -47,7 +77,10 @@ class PiecewiseRationalQuadraticCDF(Flow):
         self.min_bin_width = min_bin_width
         self.min_bin_height = min_bin_height
         self.min_derivative = min_derivative
-        self.tail_bound = tail_bound
+        if torch.is_tensor(tail_bound):
+            self.register_buffer("tail_bound", tail_bound)
+        else:
+            self.tail_bound = tail_bound
         self.tails = tails
         self.num_bins = num_bins
         if self.tails == "linear":
@@ -75,8 +108,9 @@ class PiecewiseRationalQuadraticCDF(Flow):
         return ops.rqs_coupling(inputs, None, self.unnormalized_widths.detach(), self.unnormalized_heights.detach(),
                                 self.unnormalized_derivatives.detach(), idx, none, self.num_bins,
                                 L.RQS_SAMPLE_IDENTITY if inverse else L.RQS_DENSITY, logdet=ld, acc=acc,
-                                tails=self.tails, tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
-                                min_bin_height=self.min_bin_height, min_derivative=self.min_derivative)
+                                min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+                                min_derivative=self.min_derivative,
+                                **_tails_kwargs(self.tails, self.tail_bound, "i", inputs.device, self.__dict__.setdefault("_tcache", {})))
 
     def forward(self, inputs, context=None):
         return self._spline(inputs, False)
@@ -144,16 +178,33 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
         self.min_bin_width = min_bin_width
         self.min_bin_height = min_bin_height
         self.min_derivative = min_derivative
-        self.tails = tails
-        self.tail_bound = tail_bound
+        # per-feature tails / bounds are split between the two halves (nsf/coupling.py:283-318)
+        mask_t = torch.as_tensor(mask)
+        features_vector = torch.arange(len(mask_t))
+        identity_features = features_vector.masked_select(mask_t <= 0)
+        transform_features = features_vector.masked_select(mask_t > 0)
+        if isinstance(tails, (list, tuple)):
+            self.tails = [tails[i] for i in transform_features]
+            tails_ = [tails[i] for i in identity_features]
+        else:
+            self.tails = tails
+            tails_ = tails
+        if torch.is_tensor(tail_bound):
+            tail_bound_ = tail_bound[identity_features]
+        else:
+            self.tail_bound = tail_bound
+            tail_bound_ = tail_bound
         if apply_unconditional_transform:
             unconditional_transform = lambda features: PiecewiseRationalQuadraticCDF(
-                shape=[features] + (img_shape if img_shape else []), num_bins=num_bins, tails=tails,
-                tail_bound=tail_bound, min_bin_width=min_bin_width, min_bin_height=min_bin_height,
+                shape=[features] + (img_shape if img_shape else []), num_bins=num_bins, tails=tails_,
+                tail_bound=tail_bound_, min_bin_width=min_bin_width, min_bin_height=min_bin_height,
                 min_derivative=min_derivative)
         else:
             unconditional_transform = None
         super().__init__(mask, transform_net_create_fn, unconditional_transform=unconditional_transform)
+        if torch.is_tensor(tail_bound):
+            self.register_buffer("tail_bound", tail_bound[transform_features])
+        self._per_feature = isinstance(self.tails, list) or torch.is_tensor(tail_bound)
         self._fused_ok = None      # lazily decided: shape handled by the fused MFMA kernel?
         self._fused_parity = 0
         self._fused_cache = None   # (parameter-version key, packed weight blob)
@@ -177,8 +228,18 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
         return 1.0
 
     def _kernel_kwargs(self):
-        return dict(tails=self.tails, tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
-                    min_bin_height=self.min_bin_height, min_derivative=self.min_derivative, wh_div=self._wh_div())
+        kw = dict(min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+                  min_derivative=self.min_derivative, wh_div=self._wh_div())
+        dev = self.identity_features.device
+        cache = self.__dict__.setdefault("_tcache", {})
+        kw.update(_tails_kwargs(self.tails, self.tail_bound, "t", dev, cache))
+        u = self.unconditional_transform
+        if self._per_feature and u is not None:   # the identity half carries its own per-feature description
+            ki = _tails_kwargs(u.tails, u.tail_bound, "i", dev, cache)
+            for k in ("tails_i", "bound_i"):
+                if k in ki:
+                    kw[k] = ki[k]
+        return kw
 
     def _uncond(self):
         u = self.unconditional_transform
@@ -195,6 +256,8 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
         """prqct.forward (nsf/coupling.py:71-98): conditioner on the raw identity features."""
         self._check(inputs)
         if needs_grad(inputs, context, self):
+            if self._per_feature:
+                raise NotImplementedError("per-feature tails: inference only (no backward kernel yet)")
             return self._autograd(inputs, context, False, ld, acc)
         if self.use_fused and self._fused_eligible(inputs, context):
             return self._fused(inputs, 0, ld, acc)
@@ -207,6 +270,8 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
         """prqct.inverse (nsf/coupling.py:100-128): CDF^-1 on the identity half first, conditioner on ITS output."""
         self._check(inputs)
         if needs_grad(inputs, context, self):
+            if self._per_feature:
+                raise NotImplementedError("per-feature tails: inference only (no backward kernel yet)")
             return self._autograd(inputs, context, True, ld, acc)
         if self.use_fused and self._fused_eligible(inputs, context):
             return self._fused(inputs, 1, ld, acc)
@@ -262,7 +327,7 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
             return False
         if context is not None or inputs.dim() != 2 or inputs.dtype != torch.float32 or not inputs.is_cuda:
             return False
-        if self.tails != "linear" or self.unconditional_transform is None:
+        if self.tails != "linear" or self._per_feature or self.unconditional_transform is None:
             return False
         if self._fused_ok is None:
             ii = self.identity_features.cpu()
@@ -376,3 +441,47 @@ class CoupledRationalQuadraticSpline(Flow):
     def _run_pair(self, z, lu, inverse, ld, acc):
         y, _ = self.prqct._fused(z, 0 if inverse else 1, ld, acc, lu=lu)
         return y
+
+
+class CircularCoupledRationalQuadraticSpline(Flow):
+    """NSF coupling layer with circular coordinates (wrapper.py:88-185): the features `ind_circ` get circular tails,
+    the others linear ones, and the conditioner sees periodic features of the circular identity coordinates."""
+
+    def __init__(self, num_input_channels, num_blocks, num_hidden_channels, ind_circ, num_context_channels=None,
+                 num_bins=8, tail_bound=3.0, activation=nn.ReLU, dropout_probability=0.0, reverse_mask=False,
+                 mask=None, init_identity=True):
+        super().__init__()
+        if mask is None:
+            mask = create_alternating_binary_mask(num_input_channels, even=reverse_mask)
+        features_vector = torch.arange(num_input_channels)
+        identity_features = features_vector.masked_select(mask <= 0)
+        ind_circ = torch.tensor(ind_circ)
+        ind_circ_id = [i for i, idf in enumerate(identity_features) if idf in ind_circ]
+        if torch.is_tensor(tail_bound):
+            scale_pf = np.pi / tail_bound[ind_circ_id]
+        else:
+            scale_pf = np.pi / tail_bound
+
+        def transform_net_create_fn(in_features, out_features):
+            pf = PeriodicFeaturesElementwise(in_features, ind_circ_id, scale_pf) if len(ind_circ_id) > 0 else None
+            net = ResidualNet(in_features=in_features, out_features=out_features,
+                              context_features=num_context_channels, hidden_features=num_hidden_channels,
+                              num_blocks=num_blocks, activation=activation(), dropout_probability=dropout_probability,
+                              use_batch_norm=False, preprocessing=pf)
+            if init_identity:
+                torch.nn.init.constant_(net.final_layer.weight, 0.0)
+                torch.nn.init.constant_(net.final_layer.bias, float(np.log(np.exp(1 - DEFAULT_MIN_DERIVATIVE) - 1)))
+            return net
+
+        tails = ["circular" if i in ind_circ else "linear" for i in range(num_input_channels)]
+        self.prqct = PiecewiseRationalQuadraticCoupling(mask=mask, transform_net_create_fn=transform_net_create_fn,
+                                                        num_bins=num_bins, tails=tails, tail_bound=tail_bound,
+                                                        apply_unconditional_transform=True)
+
+    def forward(self, z, context=None):
+        z, log_det = self.prqct.inverse(z, context)
+        return z, log_det.view(-1)
+
+    def inverse(self, z, context=None):
+        z, log_det = self.prqct(z, context)
+        return z, log_det.view(-1)

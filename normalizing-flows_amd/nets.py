@@ -90,6 +90,44 @@ class ResidualNet(nn.Module):
                 and (self.dropout_probability == 0.0 or not self.training))
 
 
+class PeriodicFeaturesElementwise(nn.Module):
+    """Replaces the features `ind` by w1 sin(scale f) + w2 cos(scale f) (utils/nn.py:64-129): preprocessing of the
+    conditioner for circular coordinates (plain tensor arithmetic in front of the GEMMs)."""
+
+    def __init__(self, ndim, ind, scale=1.0, bias=False, activation=None):
+        super().__init__()
+        self.ndim = ndim
+        if torch.is_tensor(ind):
+            self.register_buffer("ind", ind.long())
+        else:
+            self.register_buffer("ind", torch.tensor(ind, dtype=torch.long))
+        ind_ = [i for i in range(self.ndim) if i not in self.ind]
+        self.register_buffer("ind_", torch.tensor(ind_, dtype=torch.long))
+        perm_ = torch.cat((self.ind, self.ind_))
+        inv_perm_ = torch.zeros_like(perm_)
+        for i in range(self.ndim):
+            inv_perm_[perm_[i]] = i
+        self.register_buffer("inv_perm", inv_perm_)
+        self.weights = nn.Parameter(torch.ones(len(self.ind), 2))
+        if torch.is_tensor(scale):
+            self.register_buffer("scale", scale)
+        else:
+            self.scale = scale
+        self.apply_bias = bias
+        if self.apply_bias:
+            self.bias = nn.Parameter(torch.zeros(len(self.ind)))
+        self.activation = torch.nn.Identity() if activation is None else activation
+
+    def forward(self, inputs):
+        inputs_ = self.scale * inputs[..., self.ind]
+        inputs_ = self.weights[:, 0] * torch.sin(inputs_) + self.weights[:, 1] * torch.cos(inputs_)
+        if self.apply_bias:
+            inputs_ = inputs_ + self.bias
+        inputs_ = self.activation(inputs_)
+        out = torch.cat((inputs_, inputs[..., self.ind_]), -1)
+        return out[..., self.inv_perm]
+
+
 class ConstScaleLayer(nn.Module):
     """utils/nn.py ConstScaleLayer: multiply by a constant."""
 

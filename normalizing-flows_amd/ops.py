@@ -52,9 +52,11 @@ def ptr_any(t):
 
 def rqs_coupling(x, cond, uw, uh, ud, identity_idx, transform_idx, K, mode, y=None, logdet=None, acc=None,
                  tails="linear", tail_bound=3.0, min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3,
-                 wh_div=1.0):
-    """nsf/coupling.py:71-128 given the conditioner output `cond` (B, nT*M) or (B, nT, M)."""
-    L.require_device(x, cond, uw, uh, ud, identity_idx, transform_idx)
+                 wh_div=1.0, tails_t=None, bound_t=None, tails_i=None, bound_i=None):
+    """nsf/coupling.py:71-128 given the conditioner output `cond` (B, nT*M) or (B, nT, M).  tails="feature" with
+    int32 tensors tails_t / tails_i (1 linear, 2 circular) and / or per-feature bound tensors bound_t / bound_i select
+    the per-feature variant (nf_rqs_coupling_ft, utils/splines.py:48-66)."""
+    L.require_device(x, cond, uw, uh, ud, identity_idx, transform_idx, tails_t, bound_t, tails_i, bound_i)
     B, D = x.shape
     x = x.contiguous()
     if y is None:
@@ -64,12 +66,27 @@ def rqs_coupling(x, cond, uw, uh, ud, identity_idx, transform_idx, K, mode, y=No
         acc = L.LD_WRITE
     elif acc is None:
         acc = L.LD_ADD
-    rc = L.lib().nf_rqs_coupling(ptr(x), ptr(y), ptr(logdet), ptr(cond), ptr(uw), ptr(uh), ptr(ud),
-                                 ptr(identity_idx), i32(identity_idx.numel()), ptr(transform_idx),
-                                 i32(transform_idx.numel()), i64(B), i32(D), i32(K), i32(L.TAILS[tails]),
-                                 f64(tail_bound), f64(min_bin_width), f64(min_bin_height), f64(min_derivative),
-                                 f64(wh_div), i32(mode), i32(acc), i32(L.dtype_code(x)), L.stream())
-    L.check(rc, "nf_rqs_coupling")
+    per_feature = tails == "feature" or bound_t is not None or bound_i is not None
+    if not per_feature:
+        rc = L.lib().nf_rqs_coupling(ptr(x), ptr(y), ptr(logdet), ptr(cond), ptr(uw), ptr(uh), ptr(ud),
+                                     ptr(identity_idx), i32(identity_idx.numel()), ptr(transform_idx),
+                                     i32(transform_idx.numel()), i64(B), i32(D), i32(K), i32(L.TAILS[tails]),
+                                     f64(tail_bound), f64(min_bin_width), f64(min_bin_height), f64(min_derivative),
+                                     f64(wh_div), i32(mode), i32(acc), i32(L.dtype_code(x)), L.stream())
+        L.check(rc, "nf_rqs_coupling")
+        return y, logdet
+    fix_b = lambda t: None if t is None else t.to(device=x.device, dtype=x.dtype).contiguous()
+    fix_t = lambda t: None if t is None else t.to(device=x.device, dtype=torch.int32).contiguous()
+    bt, bi, tt, ti = fix_b(bound_t), fix_b(bound_i), fix_t(tails_t), fix_t(tails_i)
+    code = 3 if tails == "feature" else L.TAILS[tails]
+    scalar_bound = float(tail_bound) if not torch.is_tensor(tail_bound) else 1.0
+    rc = L.lib().nf_rqs_coupling_ft(ptr(x), ptr(y), ptr(logdet), ptr(cond), ptr(uw), ptr(uh), ptr(ud),
+                                    ptr(identity_idx), i32(identity_idx.numel()), ptr(transform_idx),
+                                    i32(transform_idx.numel()), i64(B), i32(D), i32(K), i32(code), f64(scalar_bound),
+                                    f64(min_bin_width), f64(min_bin_height), f64(min_derivative), f64(wh_div),
+                                    i32(mode), i32(acc), i32(L.dtype_code(x)), ptr(tt), ptr(bt), ptr(ti), ptr(bi),
+                                    L.stream())
+    L.check(rc, "nf_rqs_coupling_ft")
     return y, logdet
 
 

@@ -543,7 +543,50 @@ def gen_misc():
         npz("glow_base_cc%d" % (ncls or 0), z=z, y=yl, log_prob=lp, log_prob_temp=lpt, **sd(gb, "sd__"))
 
 
+def gen_circular():
+    """Circular-coordinate spline layers (wrapper.py:88-185, 247-330): per-feature tails (utils/splines.py:48-57),
+    scalar and tensor tail bounds (:61-66), periodic conditioner features (utils/nn.py:64-129)."""
+    g = torch.Generator().manual_seed(41)
+    for name, tb in (("circ_coupled_scalar", 3.0), ("circ_coupled_tensor", torch.tensor([3.0, np.pi, 2.0, np.pi, 3.5, 1.5]))):
+        torch.manual_seed(9)
+        layer = nf.flows.CircularCoupledRationalQuadraticSpline(6, 2, 16, ind_circ=[1, 3, 4], num_bins=5, tail_bound=tb,
+                                                                init_identity=False)
+        perturb(layer, 0.3, 13)
+        bound = tb if torch.is_tensor(tb) else torch.full((6,), tb)
+        x = (torch.rand(12, 6, generator=g) * 2 - 1) * bound * 0.98     # inside every interval
+        x[0, 0], x[1, 2] = 50.0, -60.0                                    # linear features outside: the list branch zeroes them
+        with torch.no_grad():
+            zf, ldf = layer.forward(x)
+            zi, ldi = layer.inverse(x)
+        npz(name, x=x, z_fwd=zf, ld_fwd=ldf, z_inv=zi, ld_inv=ldi, **sd(layer, "sd__"))
+    torch.manual_seed(10)
+    layer = nf.flows.CircularAutoregressiveRationalQuadraticSpline(5, 2, 12, ind_circ=[0, 3], num_bins=4, tail_bound=2.5,
+                                                                   permute_mask=False, init_identity=False)
+    perturb(layer, 0.3, 14)
+    x = (torch.rand(9, 5, generator=g) * 2 - 1) * 2.4
+    with torch.no_grad():
+        zf, ldf = layer.forward(x)
+        zi, ldi = layer.inverse(x)
+    npz("circ_autoregressive", x=x, z_fwd=zf, ld_fwd=ldf, z_inv=zi, ld_inv=ldi, **sd(layer, "sd__"))
+    # string tails + tensor bound on the bare coupling transform
+    torch.manual_seed(11)
+    tbv = torch.tensor([2.0, 3.0, 1.5, 2.5])
+    mask = nf.utils.masks.create_alternating_binary_mask(4, even=False)
+    mk = lambda i, o: nf.nets.ResidualNet(i, o, hidden_features=8, num_blocks=1)
+    t = nf.flows.neural_spline.coupling.PiecewiseRationalQuadraticCoupling(mask, mk, num_bins=4, tails="linear",
+                                                                           tail_bound=tbv, apply_unconditional_transform=True)
+    perturb(t, 0.3, 15)
+    x = 1.5 * torch.randn(10, 4, generator=g)
+    with torch.no_grad():
+        zf, ldf = t.forward(x)
+        zi, ldi = t.inverse(x)
+    npz("coupling_tensor_bound", x=x, z_fwd=zf, ld_fwd=ldf, z_inv=zi, ld_inv=ldi, **sd(t, "sd__"))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "circular":
+        gen_circular()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "misc":
         gen_misc()
         sys.exit(0)
@@ -568,3 +611,4 @@ if __name__ == "__main__":
     gen_arnsf()
     gen_glue()
     gen_misc()
+    gen_circular()

@@ -866,3 +866,65 @@ def test_glow_base_vs_reference(nfa, ncls):
         z, lq = gb(y=y) if ncls else gb(6)
         lp2 = gb.log_prob(z, y) if ncls else gb.log_prob(z)
         assert_close(N(lp2), N(lq), what="sample log_p", rtol=1e-4, atol=1e-4)
+
+
+# ---- circular-coordinate spline layers: per-feature tails and bounds (utils/splines.py:48-66) --------------------------
+@pytest.mark.parametrize("name,tb", [("circ_coupled_scalar", 3.0),
+                                     ("circ_coupled_tensor", [3.0, np.pi, 2.0, np.pi, 3.5, 1.5])])
+def test_circular_coupled_spline_vs_reference(nfa, name, tb):
+    g = load_golden(name)
+    tbv = torch.tensor(tb) if isinstance(tb, list) else tb
+    layer = nfa.flows.CircularCoupledRationalQuadraticSpline(6, 2, 16, ind_circ=[1, 3, 4], num_bins=5, tail_bound=tbv,
+                                                             init_identity=False)
+    layer = load_layer(layer, golden_state(g), torch.float32)
+    with torch.no_grad():
+        z, ld = layer.inverse(T(g["x"]))
+        assert_close(N(z), g["z_inv"], what="z_inv", rtol=1e-4, atol=1e-4)
+        assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=1e-4, atol=1e-4)
+        z, ld = layer.forward(T(g["x"]))
+        assert_close(N(z), g["z_fwd"], what="z_fwd", rtol=1e-4, atol=1e-4)
+        assert_close(N(ld), g["ld_fwd"], what="ld_fwd", rtol=1e-4, atol=1e-4)
+        x_in = T(g["x"])[2:]                       # rows with every coordinate inside its interval: exact round trip
+        xr, _ = layer.inverse(layer.forward(x_in)[0])
+        assert_close(N(xr), N(x_in), what="roundtrip", rtol=1e-3, atol=1e-3)
+
+
+def test_circular_autoregressive_spline_vs_reference(nfa):
+    g = load_golden("circ_autoregressive")
+    layer = nfa.flows.CircularAutoregressiveRationalQuadraticSpline(5, 2, 12, ind_circ=[0, 3], num_bins=4, tail_bound=2.5,
+                                                                    permute_mask=False, init_identity=False)
+    layer = load_layer(layer, golden_state(g), torch.float32)
+    with torch.no_grad():
+        z, ld = layer.inverse(T(g["x"]))
+        assert_close(N(z), g["z_inv"], what="z_inv", rtol=1e-4, atol=1e-4)
+        assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=1e-4, atol=1e-4)
+        z, ld = layer.forward(T(g["x"]))
+        assert_close(N(z), g["z_fwd"], what="z_fwd", rtol=1e-4, atol=1e-4)
+        assert_close(N(ld), g["ld_fwd"], what="ld_fwd", rtol=1e-4, atol=1e-4)
+
+
+def test_coupling_with_tensor_tail_bound_vs_reference(nfa):
+    g = load_golden("coupling_tensor_bound")
+    mask = nfa.utils.create_alternating_binary_mask(4, even=False)
+    mk = lambda i, o: nfa.nets.ResidualNet(i, o, hidden_features=8, num_blocks=1)
+    t = nfa.flows.PiecewiseRationalQuadraticCoupling(mask, mk, num_bins=4, tails="linear",
+                                                     tail_bound=torch.tensor([2.0, 3.0, 1.5, 2.5]),
+                                                     apply_unconditional_transform=True)
+    t = load_layer(t, golden_state(g), torch.float32)
+    with torch.no_grad():
+        z, ld = t.forward(T(g["x"]))
+        assert_close(N(z), g["z_fwd"], what="z_fwd", rtol=1e-4, atol=1e-5)
+        assert_close(N(ld), g["ld_fwd"], what="ld_fwd", rtol=1e-4, atol=1e-5)
+        z, ld = t.inverse(T(g["x"]))
+        assert_close(N(z), g["z_inv"], what="z_inv", rtol=1e-4, atol=1e-4)
+        assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=1e-4, atol=1e-4)
+
+
+def test_periodic_wrap_and_shift(nfa):
+    z = torch.tensor([[3.5, 0.2, -4.0], [0.1, 7.0, 2.0]], device=DEV)
+    w, ld = nfa.flows.PeriodicWrap([0, 2], bound=3.0).inverse(z)
+    assert_close(N(w), np.array([[-2.5, 0.2, 2.0], [0.1, 7.0, 2.0]], dtype=np.float32), what="wrap", rtol=1e-6, atol=1e-6)
+    sh = nfa.flows.PeriodicShift([0], bound=3.0, shift=1.0)
+    f, _ = sh.forward(z)
+    b, _ = sh.inverse(f)
+    assert_close(N(b)[:, 0], np.array([-2.5, 0.1], dtype=np.float32), what="shift roundtrip", rtol=1e-6, atol=1e-6)
