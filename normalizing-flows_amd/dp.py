@@ -70,3 +70,22 @@ def allreduce_gradients(params, group=None, bucket_bytes=64 << 20):
             p.grad.copy_(flat[off:off + n].view_as(p.grad))
             off += n
     return len(buckets)
+
+
+def combine_moments(mean, std, count, group=None):
+    """Per-channel mean and UNBIASED std of the GLOBAL batch from every rank's local (mean, std, count): one
+    all_reduce(SUM) of 2C + 1 fp64 numbers.  Used by ActNorm's data-dependent initialisation (normalization.py:19-39)
+    so that N data-parallel replicas initialise to exactly the parameters a single process would compute on the whole
+    batch -- with shard-local statistics the replicas' weights would silently differ."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return mean, std
+    n = float(count)
+    m64, s64 = mean.double(), std.double()
+    packed = torch.cat([n * m64, (n - 1.0) * s64 * s64 + n * m64 * m64,
+                        torch.tensor([n], dtype=torch.float64, device=mean.device)])
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    C = mean.numel()
+    N = packed[-1]
+    gmean = packed[:C] / N
+    gvar = (packed[C:2 * C] - N * gmean * gmean) / (N - 1.0)
+    return gmean.to(mean.dtype), gvar.clamp_min(0).sqrt().to(std.dtype)

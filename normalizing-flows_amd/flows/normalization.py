@@ -32,6 +32,8 @@ class ActNorm(AffineConstFlow):
         assert self.s is not None and self.t is not None
         zz = self._geometry(z)
         mean, std = ops.actnorm_stats(zz)
+        from .. import dp
+        mean, std = dp.combine_moments(mean, std, zz.numel() // zz.shape[1])   # identity unless data parallel
         ops.actnorm_init(mean, std, self.s.data.view(-1), self.t.data.view(-1), 1 if inverse else 0)
         self.data_dep_init_done.fill_(1.0)
         self._init_known = True

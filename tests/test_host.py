@@ -186,6 +186,13 @@ nb = nfa.dp.allreduce_gradients(lin.parameters(), bucket_bytes=32)   # tiny buck
 assert nb >= 2
 for p in lin.parameters():
     assert torch.allclose(p.grad, torch.full_like(p, (1 + world) / 2.0))
+# ActNorm data-dependent init under DP: global per-channel mean / unbiased std from the ranks' local moments
+xa = torch.randn(23, 5, 3, generator=g) * 2.0 + 0.7            # (rows, channels, pixels), same on every rank
+lo, hi = nfa.dp.shard_bounds(23, world, rank)
+loc = xa[lo:hi].transpose(0, 1).reshape(5, -1)                 # channel-major local elements
+gm, gs = nfa.dp.combine_moments(loc.mean(1), loc.std(1), loc.shape[1])
+ref = xa.transpose(0, 1).reshape(5, -1)
+assert torch.allclose(gm, ref.mean(1), atol=1e-6) and torch.allclose(gs, ref.std(1), atol=1e-6), (gm, ref.mean(1))
 if rank == 0:
     print("DP_OK", float(nll))
 dist.destroy_process_group()
@@ -193,7 +200,8 @@ dist.destroy_process_group()
 
 
 def test_dp_nll_matches_unsharded_under_gloo(nfa, tmp_path):
-    """world_size 2, gloo: the row-sharded NLL (one all-reduce of [sum log_q, n]) equals the unsharded NLL."""
+    """world_size 2, gloo: the row-sharded NLL (one all-reduce of [sum log_q, n]) equals the unsharded NLL; bucketed
+    gradient averaging; ActNorm's global initialisation statistics from per-rank moments."""
     script = tmp_path / "dp_worker.py"
     script.write_text(_DP_WORKER)
     env = dict(os.environ, NF_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
