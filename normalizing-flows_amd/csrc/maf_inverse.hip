@@ -105,7 +105,11 @@ maf_inverse_kernel(const float *__restrict__ z, float *__restrict__ y, float *__
     const int D = table[0], Dp = table[1], Hp = table[3], T = table[4];
     const int64_t sample = wt * 64 + lane;
     const bool valid = sample < B;
+#ifdef NF_MAF_ABL_HOT   // every wave on the same scratch slab: L2-resident state, timing only
+    const int64_t wts = 0;
+#else
     const int64_t wts = active ? wt : 0;
+#endif
     const float *zr = z + (valid ? sample : B - 1) * D;
     float *Sw = S + wts * ((int64_t)5 * Hp * 64);   // [layer][Hp/8][2][64][4]
     float *Xw = Xs + wts * ((int64_t)Dp * 64);      // [Dp/8][2][64][4]
