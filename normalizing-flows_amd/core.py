@@ -229,6 +229,55 @@ class NormalizingFlow(nn.Module):
         self.load_state_dict(torch.load(path))
 
 
+class ConditionalNormalizingFlow(NormalizingFlow):
+    """Normalizing flow whose layers and base distribution receive a context (core.py:216-366): same loops, every
+    call carries `context=context`; log-dets are folded into the accumulator by the kernels (Flow._run)."""
+
+    def forward(self, z, context=None):
+        for flow in self.flows:
+            z, _ = flow(z, context=context)
+        return z
+
+    def forward_and_log_det(self, z, context=None):
+        log_det = torch.zeros(len(z), dtype=z.dtype, device=z.device)
+        for flow in self.flows:
+            z = run_flow(flow, z, False, log_det, +1, context=context)
+        return z, log_det
+
+    def inverse(self, x, context=None):
+        for i in range(len(self.flows) - 1, -1, -1):
+            x, _ = self.flows[i].inverse(x, context=context)
+        return x
+
+    def inverse_and_log_det(self, x, context=None):
+        log_det = torch.zeros(len(x), dtype=x.dtype, device=x.device)
+        for i in range(len(self.flows) - 1, -1, -1):
+            x = run_flow(self.flows[i], x, True, log_det, +1, context=context)
+        return x, log_det
+
+    def sample(self, num_samples=1, context=None):
+        z, log_q = self.q0(num_samples, context=context)
+        for flow in self.flows:
+            z = run_flow(flow, z, False, log_q, -1, context=context)
+        return z, log_q
+
+    def log_prob(self, x, context=None):
+        log_q = torch.zeros(len(x), dtype=x.dtype, device=x.device)
+        z = x
+        for i in range(len(self.flows) - 1, -1, -1):
+            z = run_flow(self.flows[i], z, True, log_q, +1, context=context)
+        log_q += self.q0.log_prob(z, context=context)
+        return log_q
+
+    def forward_kld(self, x, context=None):
+        return -torch.mean(self.log_prob(x, context=context))
+
+    def reverse_kld(self, num_samples=1, context=None, beta=1.0, score_fn=True):
+        z, log_q = self.sample(num_samples, context=context)
+        log_p = self.p.log_prob(z, context=context)
+        return torch.mean(log_q) - beta * torch.mean(log_p)
+
+
 class MultiscaleFlow(nn.Module):
     """Multi-scale (RealNVP / Glow) flow (core.py:455-655)."""
 

@@ -219,3 +219,41 @@ class GlowBase(BaseDistribution):
             raise NotImplementedError("GlowBase: inference only (no autograd through the HIP kernel yet)")
         loc, ls, idx = self._channel_params(y, len(z))
         return ops.diag_gaussian_log_prob_rows(z, self._expand(loc), self._expand(ls), idx, 0.0)
+
+
+class ConditionalDiagGaussian(BaseDistribution):
+    """Diagonal Gaussian whose mean and log-scale come from a context encoder (base.py:106-155): first half of the
+    encoder output = mean, second half = log std; log_prob is nf_diag_gaussian_log_prob_rows with one row per sample."""
+
+    def __init__(self, shape, context_encoder):
+        super().__init__()
+        if isinstance(shape, int):
+            shape = (shape,)
+        if isinstance(shape, list):
+            shape = tuple(shape)
+        self.shape = shape
+        self.n_dim = len(shape)
+        self.d = np.prod(shape)
+        self.context_encoder = context_encoder
+
+    def _params(self, context):
+        out = self.context_encoder(context)
+        split = out.shape[-1] // 2
+        return out[..., :split], out[..., split:]
+
+    def forward(self, num_samples=1, context=None):
+        mean, log_scale = self._params(context)
+        eps = torch.randn((num_samples,) + self.shape, dtype=mean.dtype, device=mean.device)
+        z = mean + torch.exp(log_scale) * eps
+        log_p = -0.5 * self.d * np.log(2 * np.pi) - torch.sum(log_scale + 0.5 * torch.pow(eps, 2),
+                                                              list(range(1, self.n_dim + 1)))
+        return z, log_p
+
+    def log_prob(self, z, context=None):
+        mean, log_scale = self._params(context)
+        if needs_grad(z, mean, log_scale):
+            return -0.5 * self.d * np.log(2 * np.pi) - torch.sum(
+                log_scale + 0.5 * torch.pow((z - mean) / torch.exp(log_scale), 2), list(range(1, self.n_dim + 1)))
+        B = z.shape[0]
+        return ops.diag_gaussian_log_prob_rows(z, mean.expand(B, *mean.shape[1:]).contiguous(),
+                                               log_scale.expand(B, *log_scale.shape[1:]).contiguous(), None, 0.0)

@@ -583,7 +583,33 @@ def gen_circular():
     npz("coupling_tensor_bound", x=x, z_fwd=zf, ld_fwd=ldf, z_inv=zi, ld_inv=ldi, **sd(t, "sd__"))
 
 
+def gen_conditional():
+    """ConditionalNormalizingFlow (core.py:216-366): context reaches the conditioners (ResidualNet concat + GLU gate,
+    MADE context layers) and the base distribution (ConditionalDiagGaussian, distributions/base.py:106-155)."""
+    g = torch.Generator().manual_seed(51)
+    torch.manual_seed(12)
+    flows = []
+    for _ in range(2):
+        flows += [nf.flows.CoupledRationalQuadraticSpline(4, 1, 8, num_context_channels=3, num_bins=4, init_identity=False),
+                  nf.flows.LULinearPermute(4)]
+    flows += [nf.flows.AutoregressiveRationalQuadraticSpline(4, 1, 8, num_context_channels=3, num_bins=4,
+                                                             init_identity=False)]
+    q0 = nf.distributions.base.ConditionalDiagGaussian(4, torch.nn.Linear(3, 8))
+    m = nf.ConditionalNormalizingFlow(q0, flows)
+    perturb(m, 0.2, 16)
+    x = 1.2 * torch.randn(9, 4, generator=g)
+    c = torch.randn(9, 3, generator=g)
+    with torch.no_grad():
+        lp = m.log_prob(x, c)
+        z, ld = m.inverse_and_log_det(x, c)
+        xf, ldf = m.forward_and_log_det(x, c)
+    npz("model_conditional_nsf", x=x, context=c, log_prob=lp, z_inv=z, ld_inv=ld, z_fwd=xf, ld_fwd=ldf, **sd(m, "sd__"))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "conditional":
+        gen_conditional()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "circular":
         gen_circular()
         sys.exit(0)
@@ -612,3 +638,4 @@ if __name__ == "__main__":
     gen_glue()
     gen_misc()
     gen_circular()
+    gen_conditional()

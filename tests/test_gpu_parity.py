@@ -928,3 +928,31 @@ def test_periodic_wrap_and_shift(nfa):
     f, _ = sh.forward(z)
     b, _ = sh.inverse(f)
     assert_close(N(b)[:, 0], np.array([-2.5, 0.1], dtype=np.float32), what="shift roundtrip", rtol=1e-6, atol=1e-6)
+
+
+def test_conditional_flow_vs_reference(nfa):
+    """ConditionalNormalizingFlow: context through coupling conditioners (concat + GLU gate), MADE context layers and
+    the conditional base distribution (core.py:216-366)."""
+    g = load_golden("model_conditional_nsf")
+    flows = []
+    for _ in range(2):
+        flows += [nfa.flows.CoupledRationalQuadraticSpline(4, 1, 8, num_context_channels=3, num_bins=4, init_identity=False),
+                  nfa.flows.LULinearPermute(4)]
+    flows += [nfa.flows.AutoregressiveRationalQuadraticSpline(4, 1, 8, num_context_channels=3, num_bins=4,
+                                                              init_identity=False)]
+    q0 = nfa.distributions.ConditionalDiagGaussian(4, torch.nn.Linear(3, 8))
+    m = nfa.ConditionalNormalizingFlow(q0, flows)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in golden_state(g).items()}, strict=True)
+    m = m.to(DEV)
+    x, c = T(g["x"]), T(g["context"])
+    with torch.no_grad():
+        assert_close(N(m.log_prob(x, c)), g["log_prob"], what="log_prob", rtol=1e-4, atol=1e-4)
+        z, ld = m.inverse_and_log_det(x, c)
+        assert_close(N(z), g["z_inv"], what="z_inv", rtol=1e-4, atol=1e-4)
+        assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=1e-4, atol=1e-4)
+        xf, ldf = m.forward_and_log_det(x, c)
+        assert_close(N(xf), g["z_fwd"], what="z_fwd", rtol=1e-4, atol=1e-4)
+        assert_close(N(ldf), g["ld_fwd"], what="ld_fwd", rtol=1e-4, atol=1e-4)
+        torch.manual_seed(4)
+        xs, lq = m.sample(9, context=c)
+        assert_close(N(m.log_prob(xs, c)), N(lq), what="log_prob(sample)", rtol=1e-3, atol=1e-3)
