@@ -114,6 +114,7 @@ def dtype_code(t):
 
 
 def require_device(*tensors):
+    cur = None
     for t in tensors:
         if t is None:
             continue
@@ -121,6 +122,11 @@ def require_device(*tensors):
             raise RuntimeError(
                 "normflows_amd layers run only on an MI355X (HIP) device; got a %s tensor. There is no CPU path."
                 % t.device)
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:   # kernels are enqueued on the CURRENT device's stream (one process per GPU)
+            raise RuntimeError("tensor on %s but the current device is cuda:%d: call torch.cuda.set_device first"
+                               % (t.device, cur))
 
 
 def ptr(t):

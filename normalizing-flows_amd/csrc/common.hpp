@@ -294,11 +294,19 @@ static inline int grid_for(int64_t work_items, int per_block, int max_blocks = 2
 }
 
 // Dynamic LDS above 64 KB needs a per-kernel opt-in.  hipFuncSetAttribute is a slow, synchronising host call (measured
-// in milliseconds when it lands between launches), so each launch site remembers the largest size it has opted in.
-inline int opt_in_lds(const void *kernel, size_t lds, size_t &opted) {
-    if (lds <= opted) return NF_OK;
+// in milliseconds when it lands between launches), so each launch site remembers, per device, the largest size it has
+// opted in (the attribute belongs to the kernel image of the CURRENT device).
+constexpr int NF_MAX_DEVICES = 64;
+struct LdsOptIn {
+    size_t opted[NF_MAX_DEVICES];  // 0 = nothing beyond the default 64 KB yet
+};
+inline int opt_in_lds(const void *kernel, size_t lds, LdsOptIn &state) {
+    if (lds <= 64 * 1024) return NF_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NF_MAX_DEVICES) return NF_EIO;
+    if (lds <= state.opted[dev]) return NF_OK;
     if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return NF_ENOTSUP;
-    opted = lds;
+    state.opted[dev] = lds;
     return NF_OK;
 }
 

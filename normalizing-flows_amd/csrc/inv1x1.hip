@@ -150,7 +150,7 @@ static int launch_assemble(const void *P, const void *L, const void *U, const vo
                            void *logdet_unit, int C, int inverse, hipStream_t st) {
     const size_t lds = (size_t)C * C * (2 * sizeof(double) + 3 * sizeof(T));
     if (lds > 158 * 1024) return NF_ENOTSUP;
-    static size_t opted = 64 * 1024;
+    static LdsOptIn opted = {};
     if (opt_in_lds(reinterpret_cast<const void *>(&inv1x1_assemble_kernel<T>), lds, opted) != NF_OK) return NF_ENOTSUP;
     hipLaunchKernelGGL(inv1x1_assemble_kernel<T>, dim3(1), dim3(256), lds, st, (const T *)P, (const T *)L, (const T *)U,
                        (const T *)sign_S, (const T *)log_S, (T *)W, (T *)logdet_unit, C, inverse);
@@ -164,7 +164,7 @@ static int launch_conv(const void *z, const void *W, const void *logdet_unit, vo
     const int Cp = (C + OT - 1) / OT * OT;
     const size_t lds = (size_t)C * Cp * sizeof(T);
     if (lds > 160 * 1024) return NF_ENOTSUP;
-    static size_t opted = 64 * 1024;
+    static LdsOptIn opted = {};
     if (opt_in_lds(reinterpret_cast<const void *>(&inv1x1_conv_kernel<T>), lds, opted) != NF_OK) return NF_ENOTSUP;
     const int64_t nwork = B * HW * (Cp / OT);
     const int grid = grid_for(nwork > 0 ? nwork : 1, 256);

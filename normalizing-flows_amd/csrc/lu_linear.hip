@@ -291,7 +291,7 @@ static int launch_lu(const void *x, void *y, void *logdet, const int64_t *perm, 
         int nw = 4;  // one 64-sample tile per wave; the factors are rebuilt per block, so prefer wide blocks
         while (nw > 1 && tile_lds(nw) > 160 * 1024) nw >>= 1;
         const size_t lds = tile_lds(nw);
-        static size_t opted = 64 * 1024;
+        static LdsOptIn opted = {};
         if (opt_in_lds(reinterpret_cast<const void *>(&lu_tile_kernel<T>), lds, opted) != NF_OK) return NF_ENOTSUP;
         const int64_t nwt = (B + 63) / 64;
         int64_t g = (nwt + nw - 1) / nw;
@@ -306,7 +306,7 @@ static int launch_lu(const void *x, void *y, void *logdet, const int64_t *perm, 
     while (NT > 64 && lds_bytes(NT) > 80 * 1024) NT >>= 1;  // keep two workgroups per CU when possible
     const size_t lds = lds_bytes(NT);
     if (lds > 160 * 1024) return NF_ENOTSUP;
-    static size_t opted = 64 * 1024;
+    static LdsOptIn opted = {};
     if (opt_in_lds(reinterpret_cast<const void *>(&lu_linear_permute_kernel<T>), lds, opted) != NF_OK) return NF_ENOTSUP;
     const int64_t ntiles = (B + NT - 1) / NT;
     const int grid = (int)(ntiles < 2048 ? ntiles : 2048);

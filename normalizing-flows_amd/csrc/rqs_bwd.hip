@@ -326,7 +326,7 @@ static int launch_bwd(const void *x, const void *gy, const void *gld, const void
     while (TS > 1 && lds_bytes(TS) > 64 * 1024) TS >>= 1;
     const size_t lds = lds_bytes(TS);
     if (lds > 150 * 1024) return NF_ENOTSUP;
-    static size_t opted = 64 * 1024;
+    static LdsOptIn opted = {};
     if (opt_in_lds(reinterpret_cast<const void *>(&rqs_coupling_bwd_kernel<T>), lds, opted) != NF_OK) return NF_ENOTSUP;
     const int grid = grid_for((B + TS - 1) / TS, 1, 2048);
     hipLaunchKernelGGL(rqs_coupling_bwd_kernel<T>, dim3(grid), dim3(256), lds, st, (const T *)x, (const T *)gy,

@@ -672,7 +672,7 @@ extern "C" int nf_rqs_fused_pack_lu(void *wpack, int num_blocks, const int64_t *
     float *small = blob + F_HDR;
     float *stages = blob + lay.off_stages();
     const size_t lds = (size_t)4 * F_D * F_D * sizeof(double) + F_D * sizeof(int) + F_D * sizeof(double) + 64;
-    static size_t opted = 64 * 1024;
+    static LdsOptIn opted = {};
     if (opt_in_lds(reinterpret_cast<const void *>(&pack_lu_kernel), lds, opted) != NF_OK) return NF_ENOTSUP;
     hipLaunchKernelGGL(pack_lu_kernel, dim3(1), dim3(256), lds, st, perm, (const float *)lower_entries,
                        (const float *)upper_entries, (const float *)unconstrained_upper_diag, (const float *)bias,
@@ -685,7 +685,7 @@ extern "C" int nf_rqs_fused_pack_lu(void *wpack, int num_blocks, const int64_t *
 template <int DIR, bool LU>
 static int launch_fused(const void *x, void *y, void *logdet, const FlowArgs &fa, int64_t B, int num_blocks,
                         const RqsParams<float> &p, int acc, size_t lds, hipStream_t st) {
-    static size_t opted = 64 * 1024;  // one per <DIR, LU> instantiation
+    static LdsOptIn opted = {};  // one per <DIR, LU> instantiation
     if (opt_in_lds(reinterpret_cast<const void *>(&rqs_fused_kernel<DIR, LU>), lds, opted) != NF_OK) return NF_ENOTSUP;
     const int grid = (int)((B + F_ROWS - 1) / F_ROWS);
     hipLaunchKernelGGL((rqs_fused_kernel<DIR, LU>), dim3(grid), dim3(F_THREADS), lds, st, (const float *)x, (float *)y,

@@ -558,7 +558,7 @@ rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *_
 template <int DIR, bool LU>
 static int launch_x3(const void *x, void *y, void *logdet, const void *wpack, int64_t B, int num_blocks, int par_t,
                      const RqsParams<float> &p, int acc, size_t lds, hipStream_t st) {
-    static size_t opted = 64 * 1024;  // one per <DIR, LU> instantiation
+    static LdsOptIn opted = {};  // one per <DIR, LU> instantiation
     if (opt_in_lds(reinterpret_cast<const void *>(&rqs_fused_x3_kernel<DIR, LU>), lds, opted) != NF_OK) return NF_ENOTSUP;
     const int grid = (int)((B + X3_ROWS - 1) / X3_ROWS);
     hipLaunchKernelGGL((rqs_fused_x3_kernel<DIR, LU>), dim3(grid), dim3(X3_THREADS), lds, st, (const float *)x, (float *)y,

@@ -188,7 +188,7 @@ static int launch_rqs_coupling(const void *x, void *y, void *logdet, const void 
     while (TS > 1 && lds_bytes(TS) > 64 * 1024) TS >>= 1;
     const size_t lds = lds_bytes(TS);
     if (lds > 160 * 1024) return NF_ENOTSUP;
-    static size_t opted = 64 * 1024;
+    static LdsOptIn opted = {};
     if (opt_in_lds(reinterpret_cast<const void *>(&rqs_coupling_kernel<T>), lds, opted) != NF_OK) return NF_ENOTSUP;
     const int64_t ntiles = (B + TS - 1) / TS;
     const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
