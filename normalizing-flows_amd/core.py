@@ -216,9 +216,23 @@ class NormalizingFlow(nn.Module):
             z = run_flow(flow, z, False, log_q, -1)
         return z, log_q
 
-    def reverse_kld(self, num_samples=1, beta=1.0, score_fn=True):
-        """mean(log q) - beta mean(log p) on samples of q (core.py:104-131); value only."""
-        z, log_q = self.sample(num_samples)
+    def reverse_kld(self, num_samples=1, beta=1.0, score_fn=True, eps=None):
+        """mean(log q) - beta mean(log p) on samples of q (core.py:104-131); differentiable through the sampling path
+        (reparametrised base sample + the layers' autograd Functions).  score_fn=False re-evaluates log q with the
+        parameters frozen (arXiv 1703.09194), as the reference does.  `eps` fixes the base noise (tests)."""
+        if eps is None:
+            z, log_q = self.sample(num_samples)
+        else:
+            z, log_q = self.sample_from_noise(eps)
+        if not score_fn:
+            req = [p_.requires_grad for p_ in self.parameters()]
+            for p_ in self.parameters():
+                p_.requires_grad_(False)
+            log_q = torch.zeros(len(z), dtype=z.dtype, device=z.device)
+            z_ = run_chain(self.flows, z, True, log_q, +1)
+            log_q = log_q + self.q0.log_prob(z_)
+            for p_, r in zip(self.parameters(), req):
+                p_.requires_grad_(r)
         log_p = self.p.log_prob(z)
         return torch.mean(log_q) - beta * torch.mean(log_p)
 

@@ -56,6 +56,12 @@ class DiagGaussian(BaseDistribution):
 
     def from_noise(self, eps):
         """z = loc + exp(log_scale) eps and log p(z) (base.py:80-92) for given standard-normal noise."""
+        if needs_grad(eps, self.loc, self.log_scale):   # reparametrised sample: gradients reach loc / log_scale
+            log_scale = self.log_scale + self._shift()
+            z = self.loc + torch.exp(log_scale) * eps
+            log_p = -0.5 * self.d * np.log(2 * np.pi) - torch.sum(log_scale + 0.5 * torch.pow(eps, 2),
+                                                                  list(range(1, self.n_dim + 1)))
+            return z, log_p
         log_scale = self.log_scale.detach() + self._shift()
         z = self.loc.detach() + torch.exp(log_scale) * eps
         # log_p = -d/2 log(2 pi) - sum(log_scale + eps^2/2): the same closed form as log_prob at (z - loc)/scale = eps

@@ -606,7 +606,33 @@ def gen_conditional():
     npz("model_conditional_nsf", x=x, context=c, log_prob=lp, z_inv=z, ld_inv=ld, z_fwd=xf, ld_fwd=ldf, **sd(m, "sd__"))
 
 
+def gen_reverse_kld():
+    """reverse_kld (core.py:104-131): loss and gradients through the SAMPLING path (reparametrised base sample, layer
+    .forward) for both gradient estimators; the base noise is the first torch.randn after the seed."""
+    for score_fn in (True, False):
+        torch.manual_seed(14)
+        flows = []
+        for _ in range(2):
+            flows += [nf.flows.CoupledRationalQuadraticSpline(6, 1, 16, num_bins=4, init_identity=False),
+                      nf.flows.LULinearPermute(6)]
+        target = nf.distributions.DiagGaussian(6, trainable=False)
+        target.loc.add_(0.5)
+        target.log_scale.add_(-0.3)
+        m = nf.NormalizingFlow(nf.distributions.DiagGaussian(6, trainable=True), flows, p=target)
+        perturb(m, 0.1, 17)
+        torch.manual_seed(99)
+        eps = torch.randn(32, 6)
+        torch.manual_seed(99)
+        loss = m.reverse_kld(32, beta=0.7, score_fn=score_fn)
+        loss.backward()
+        grads = {"g__" + k.replace(".", "__"): p_.grad for k, p_ in m.named_parameters() if p_.grad is not None}
+        npz("grad_reverse_kld_sf%d" % int(score_fn), eps=eps, loss=loss.detach(), **grads, **sd(m, "sd__"))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "reverse_kld":
+        gen_reverse_kld()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "conditional":
         gen_conditional()
         sys.exit(0)
@@ -639,3 +665,4 @@ if __name__ == "__main__":
     gen_misc()
     gen_circular()
     gen_conditional()
+    gen_reverse_kld()

@@ -159,3 +159,32 @@ def test_linear_autograd_matches_torch(nfa):
     assert torch.allclose(gw, lin.weight.grad, rtol=1e-4, atol=1e-3)
     assert torch.allclose(gb, lin.bias.grad, rtol=1e-4, atol=1e-3)
     assert torch.allclose(gx, x.grad, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("score_fn", [True, False])
+def test_reverse_kld_gradients_vs_reference(nfa, score_fn):
+    """reverse_kld (core.py:104-131): loss and every parameter gradient through the sampling direction, for the plain
+    and the frozen-parameter (score_fn=False) estimators, on the reference's base noise."""
+    g = load_golden("grad_reverse_kld_sf%d" % int(score_fn))
+    flows = []
+    for _ in range(2):
+        flows += [nfa.flows.CoupledRationalQuadraticSpline(6, 1, 16, num_bins=4, init_identity=False),
+                  nfa.flows.LULinearPermute(6)]
+    target = nfa.distributions.DiagGaussian(6, trainable=False)
+    m = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(6, trainable=True), flows, p=target)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in golden_state(g).items()}, strict=True)
+    m = m.to(DEV)
+    loss = m.reverse_kld(32, beta=0.7, score_fn=score_fn, eps=T(g["eps"]))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-4 * max(1.0, abs(float(g["loss"])))
+    checked = 0
+    for k, p_ in m.named_parameters():
+        key = "g__" + k.replace(".", "__")
+        if key not in g:
+            continue
+        ref = g[key]
+        got = p_.grad.detach().cpu().numpy() if p_.grad is not None else np.zeros_like(ref)
+        scale = max(1e-3, float(np.abs(ref).max()))
+        assert float(np.abs(got - ref).max()) < 3e-3 * scale + 1e-5, (k, float(np.abs(got - ref).max()), scale)
+        checked += 1
+    assert checked >= 20
