@@ -10,6 +10,8 @@ backward is
 The conditioner networks are ordinary torch modules and are differentiated by autograd itself.  Layers switch to
 these Functions only when gradients are needed (`needs_grad`); under torch.no_grad() the fused inference kernels run.
 """
+import math
+
 import torch
 
 from . import _lib as L
@@ -182,3 +184,187 @@ def linear(x, weight, bias):
             and torch.is_grad_enabled() and (weight.requires_grad or (bias is not None and bias.requires_grad))):
         return LinearFn.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)
+
+
+# ---- affine / Glow layers: HIP forward, backward by differentiating the reference formula on the saved inputs ----------
+def _vjp(formula, inputs, cotangents):
+    """Vector-Jacobian product of `formula(*inputs) -> (y, log_det)` (plain torch, reference arithmetic) -- backward only."""
+    with torch.enable_grad():
+        leaves = [None if t is None else t.detach().requires_grad_(t.is_floating_point()) for t in inputs]
+        outs = formula(*leaves)
+        pairs = [(o, c) for o, c in zip(outs, cotangents) if c is not None and o.requires_grad]
+        wanted = [t for t in leaves if t is not None and t.requires_grad]
+        grads = torch.autograd.grad([o for o, _ in pairs], wanted, [c for _, c in pairs], allow_unused=True)
+    it = iter(grads)
+    return [None if (t is None or not t.requires_grad) else next(it) for t in leaves]
+
+
+def _sum_rows(t):
+    return t.reshape(t.shape[0], -1).sum(1)
+
+
+class MaskedAffineFn(torch.autograd.Function):
+    """MaskedAffineFlow (affine/coupling.py:209-229) on given s(b z), t(b z)."""
+
+    @staticmethod
+    def forward(ctx, z, b, s, t, direction):
+        y, ld = ops.masked_affine(z, b, None if s is None else s.contiguous(), None if t is None else t.contiguous(),
+                                  direction)
+        ctx.save_for_backward(z, b, s, t)
+        ctx.direction = direction
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, gy, gld):
+        z, b, s, t = ctx.saved_tensors
+        direction = ctx.direction
+
+        def formula(z_, s_, t_):
+            s0 = torch.zeros_like(z_) if s_ is None else s_
+            t0 = torch.zeros_like(z_) if t_ is None else t_
+            if direction == 0:
+                return b * z_ + (1 - b) * (z_ * torch.exp(s0) + t0), _sum_rows((1 - b) * s0)
+            return b * z_ + (1 - b) * (z_ - t0) * torch.exp(-s0), -_sum_rows((1 - b) * s0)
+
+        gz, gs, gt = _vjp(formula, (z, s, t), (gy, gld))
+        return gz, None, gs, gt, None
+
+
+def _coupling_formula(z, param, c1, flip, scale_map, direction):
+    """Split -> AffineCoupling -> Merge for the channel modes (coupling.py:117-171, reshape.py:30-85); c1 = 0: z is z2."""
+    C = z.shape[1]
+    if c1 == 0:
+        z1, z2 = None, z
+    elif not flip:
+        z1, z2 = z[:, :c1], z[:, c1:]
+    else:
+        z1, z2 = z[:, C - c1:], z[:, :C - c1]
+    if scale_map is None:
+        y2 = z2 + param if direction == 0 else z2 - param
+        ld = torch.zeros(z.shape[0], dtype=z.dtype, device=z.device) + 0.0 * _sum_rows(param)
+    else:
+        shift, s_ = param[:, 0::2, ...], param[:, 1::2, ...]
+        if scale_map == "exp":
+            if direction == 0:
+                y2, ld = z2 * torch.exp(s_) + shift, _sum_rows(s_)
+            else:
+                y2, ld = (z2 - shift) * torch.exp(-s_), -_sum_rows(s_)
+        else:
+            scale = torch.sigmoid(s_ + 2)
+            mult = (scale_map == "sigmoid_inv") == (direction == 0)   # True: multiply by scale
+            if direction == 0:
+                y2 = (z2 * scale if mult else z2 / scale) + shift
+            else:
+                y2 = (z2 - shift) * scale if mult else (z2 - shift) / scale
+            ld = _sum_rows(torch.log(scale)) * (1.0 if mult else -1.0)
+    if z1 is None:
+        return y2, ld
+    return (torch.cat([z1, y2], 1) if not flip else torch.cat([y2, z1], 1)), ld
+
+
+class AffineCouplingFn(torch.autograd.Function):
+    """nf_affine_coupling (coupling.py:117-171 with the channel split / merge folded in) on a given `param`."""
+
+    @staticmethod
+    def forward(ctx, z, param, c1, flip, scale_map, direction):
+        y, ld = ops.affine_coupling(z, param.contiguous(), c1, flip, scale_map, direction)
+        ctx.save_for_backward(z, param)
+        ctx.cfg = (c1, flip, scale_map, direction)
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, gy, gld):
+        z, param = ctx.saved_tensors
+        cfg = ctx.cfg
+        gz, gp = _vjp(lambda z_, p_: _coupling_formula(z_, p_, *cfg), (z, param), (gy, gld))
+        return gz, gp, None, None, None, None
+
+
+class ActNormFn(torch.autograd.Function):
+    """AffineConstFlow / ActNorm (coupling.py:38-54) with per-channel s, t; log-det returned per sample."""
+
+    @staticmethod
+    def forward(ctx, z, s, t, direction):
+        ld = torch.zeros(z.shape[0], dtype=z.dtype, device=z.device)
+        y, _ = ops.actnorm(z, s.detach(), t.detach(), direction, logdet=ld, acc=1, want_scalar=False)
+        ctx.save_for_backward(z, s, t)
+        ctx.direction = direction
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, gy, gld):
+        z, s, t = ctx.saved_tensors
+        direction = ctx.direction
+        hw = z[0, 0].numel() if z.dim() > 2 else 1
+
+        def formula(z_, s_, t_):
+            shp = (1, -1) + (1,) * (z_.dim() - 2)
+            sv, tv = s_.reshape(shp), t_.reshape(shp)
+            ones = torch.ones(z_.shape[0], dtype=z_.dtype, device=z_.device)
+            if direction == 0:
+                return z_ * torch.exp(sv) + tv, hw * s_.sum() * ones
+            return (z_ - tv) * torch.exp(-sv), -hw * s_.sum() * ones
+
+        gz, gs, gt = _vjp(formula, (z, s, t), (gy, gld))
+        return gz, gs, gt, None
+
+
+class Inv1x1Fn(torch.autograd.Function):
+    """Per-pixel C x C product (mixing.py:106-133) with a given matrix W and per-pixel log|det| `ldu` (0-dim)."""
+
+    @staticmethod
+    def forward(ctx, z, W, ldu):
+        ld = torch.zeros(z.shape[0], dtype=z.dtype, device=z.device)
+        y, _ = ops.inv1x1_conv(z, W.detach().contiguous(), ldu.detach(), logdet=ld, acc=1, want_scalar=False)
+        ctx.save_for_backward(z, W, ldu)
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, gy, gld):
+        z, W, ldu = ctx.saved_tensors
+        hw = z[0, 0].numel() if z.dim() > 2 else 1
+
+        def formula(z_, W_, l_):
+            y = torch.einsum("oc,bc...->bo...", W_, z_)
+            return y, hw * l_ * torch.ones(z_.shape[0], dtype=z_.dtype, device=z_.device)
+
+        gz, gW, gl = _vjp(formula, (z, W, ldu), (gy, gld))
+        return gz, gW, gl
+
+
+class SqueezeFn(torch.autograd.Function):
+    """Squeeze (reshape.py:116-128) is a permutation: the backward is the opposite direction on the cotangent."""
+
+    @staticmethod
+    def forward(ctx, z, direction):
+        ctx.direction = direction
+        return ops.squeeze(z, direction)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return ops.squeeze(gy.contiguous(), 1 - ctx.direction), None
+
+
+class GaussianRowsLogProbFn(torch.autograd.Function):
+    """nf_diag_gaussian_log_prob_rows (base.py:326-345): per-sample (loc, log_scale) rows, picked by `idx` or row b."""
+
+    @staticmethod
+    def forward(ctx, z, loc_rows, ls_rows, idx, shift):
+        ctx.save_for_backward(z, loc_rows, ls_rows, idx)
+        ctx.shift = shift
+        return ops.diag_gaussian_log_prob_rows(z, loc_rows.detach(), ls_rows.detach(), idx, shift)
+
+    @staticmethod
+    def backward(ctx, g):
+        z, loc_rows, ls_rows, idx = ctx.saved_tensors
+        shift = ctx.shift
+        d = z[0].numel()
+
+        def formula(z_, loc_, ls_):
+            zz = z_.reshape(z_.shape[0], -1)
+            lo = loc_ if idx is None else loc_.index_select(0, idx)
+            ls = (ls_ if idx is None else ls_.index_select(0, idx)) + shift
+            return (-0.5 * d * math.log(2 * math.pi) - torch.sum(ls + 0.5 * torch.pow((zz - lo) / torch.exp(ls), 2), 1),)
+
+        gz, gl, gs = _vjp(formula, (z, loc_rows, ls_rows), (g,))
+        return gz, gl, gs, None, None

@@ -9,7 +9,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .autograd import DiagGaussianLogProbFn, needs_grad
+from .autograd import DiagGaussianLogProbFn, GaussianRowsLogProbFn, needs_grad
 
 
 class BaseDistribution(nn.Module):
@@ -148,8 +148,16 @@ class ClassCondDiagGaussian(BaseDistribution):
         return z, log_p
 
     def log_prob(self, z, y):
-        if needs_grad(z, self.loc, self.log_scale):
-            raise NotImplementedError("ClassCondDiagGaussian: inference only (no autograd through the HIP kernel yet)")
+        if needs_grad(z, self.loc, self.log_scale):   # training: differentiable row tables, HIP forward
+            d = int(self.d)
+            loc_r = self.loc.reshape(d, self.num_classes).t()
+            ls_r = self.log_scale.reshape(d, self.num_classes).t()
+            if y.dim() == 1:
+                idx = y
+            else:
+                w = y.to(loc_r.dtype)
+                loc_r, ls_r, idx = w @ loc_r, w @ ls_r, None
+            return GaussianRowsLogProbFn.apply(z.contiguous(), loc_r.contiguous(), ls_r.contiguous(), idx, self._shift())
         loc_r, ls_r, idx = self._select(y, len(z))
         return ops.diag_gaussian_log_prob_rows(z, loc_r, ls_r, idx, self._shift())
 

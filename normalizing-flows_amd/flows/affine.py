@@ -10,8 +10,20 @@ import torch
 from torch import nn
 
 from .. import ops
+from ..autograd import ActNormFn, AffineCouplingFn, MaskedAffineFn, needs_grad
 from .base import Flow, new_ld, run_flow
 from .reshape import Merge, Split
+
+
+def _fold_ld(ld, acc, log_det):
+    """Accumulate protocol under autograd: the kernels' in-place accumulation is not differentiable."""
+    if ld is None:
+        return log_det
+    if acc is None or acc > 0:
+        ld += log_det
+    else:
+        ld -= log_det
+    return ld
 
 
 class AffineConstFlow(Flow):
@@ -44,6 +56,9 @@ class AffineConstFlow(Flow):
 
     def _apply_kernel(self, z, inverse, ld=None, acc=None, want_scalar=True):
         zz = self._geometry(z)
+        if needs_grad(z, self.s, self.t):   # training: HIP forward through ActNormFn, per-sample log-det
+            y, log_det = ActNormFn.apply(zz.contiguous(), self.s.reshape(-1), self.t.reshape(-1), 1 if inverse else 0)
+            return y.view(z.shape), _fold_ld(ld, acc, log_det)
         y, lds = ops.actnorm(zz, self.s.detach(), self.t.detach(), 1 if inverse else 0, logdet=ld, acc=acc,
                              want_scalar=want_scalar)
         return y.view(z.shape), lds
@@ -111,6 +126,9 @@ class AffineCoupling(Flow):
     def _transform(self, z, inverse, ld=None, acc=None):
         z1, z2 = z
         param = self.param_map(z1)
+        if needs_grad(z1, z2, param):
+            y2, log_det = AffineCouplingFn.apply(z2.contiguous(), param, 0, False, self._smap(), 1 if inverse else 0)
+            return [z1, y2], _fold_ld(ld, acc, log_det)
         y2, ld = ops.affine_coupling(z2, param, 0, False, self._smap(), 1 if inverse else 0, logdet=ld, acc=acc)
         return [z1, y2], ld
 
@@ -146,6 +164,9 @@ class MaskedAffineFlow(Flow):
         z_masked = self.b * z if need_net else None
         scale = self.s(z_masked) if self.s is not None else None
         trans = self.t(z_masked) if self.t is not None else None
+        if needs_grad(z, scale, trans):
+            y, log_det = MaskedAffineFn.apply(z.contiguous(), self.b, scale, trans, 1 if inverse else 0)
+            return y, _fold_ld(ld, acc, log_det)
         return ops.masked_affine(z, self.b, scale, trans, 1 if inverse else 0, logdet=ld, acc=acc)
 
     def forward(self, z):
@@ -186,6 +207,9 @@ class AffineCouplingBlock(Flow):
             c1, flip = C // 2, True          # channel_inv: z2 = first ceil(C/2), z1 = the rest (reshape.py:33)
             z1 = z[:, C - c1:]
         param = coupling.param_map(z1)
+        if needs_grad(z, param):
+            y, log_det = AffineCouplingFn.apply(z.contiguous(), param, c1, flip, coupling._smap(), 1 if inverse else 0)
+            return y, _fold_ld(ld, acc, log_det)
         return ops.affine_coupling(z, param, c1, flip, coupling._smap(), 1 if inverse else 0, logdet=ld, acc=acc)
 
     def _compose(self, z, inverse, ld, acc):

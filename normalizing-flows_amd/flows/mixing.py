@@ -92,7 +92,37 @@ class Invertible1x1Conv(Flow):
         Winv = torch.inverse(W) if W.dtype == torch.float64 else torch.inverse(W.double()).type(W.dtype)
         return Winv.contiguous(), -sld
 
+    def _weight_train(self, inverse_dir):
+        """Differentiable assembly of W (mixing.py:88-104) with torch ops on the C x C matrices."""
+        if not self.use_lu:
+            W = self.W
+            sld = torch.slogdet(W)[1]
+            if inverse_dir:
+                return W, sld
+            Winv = torch.inverse(W) if W.dtype == torch.float64 else torch.inverse(W.double()).type(W.dtype)
+            return Winv, -sld
+        Lm = torch.tril(self.L, diagonal=-1) + self.eye
+        Um = torch.triu(self.U, diagonal=1) + torch.diag(self.sign_S * torch.exp(self.log_S))
+        if inverse_dir:
+            return self.P @ Lm @ Um, torch.sum(self.log_S)
+        if self.log_S.dtype == torch.float64:
+            Li, Ui = torch.inverse(Lm), torch.inverse(Um)
+        else:
+            Li, Ui = torch.inverse(Lm.double()).type(self.log_S.dtype), torch.inverse(Um.double()).type(self.log_S.dtype)
+        return Ui @ Li @ self.P.t(), -torch.sum(self.log_S)
+
     def _conv(self, z, inverse_dir, ld=None, acc=None, want_scalar=True):
+        from ..autograd import Inv1x1Fn, needs_grad
+        if needs_grad(z, self):
+            W, ldu = self._weight_train(inverse_dir)
+            y, log_det = Inv1x1Fn.apply(z.contiguous(), W, ldu)
+            if ld is None:
+                return y, log_det
+            if acc is None or acc > 0:
+                ld += log_det
+            else:
+                ld -= log_det
+            return y, ld
         W, ldu = self._weight(inverse_dir)
         return ops.inv1x1_conv(z, W, ldu, logdet=ld, acc=acc, want_scalar=want_scalar)
 

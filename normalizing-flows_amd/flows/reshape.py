@@ -86,11 +86,18 @@ class Squeeze(Flow):
     def __init__(self):
         super().__init__()
 
+    @staticmethod
+    def _sq(z, direction):
+        from ..autograd import SqueezeFn, needs_grad
+        if needs_grad(z):
+            return SqueezeFn.apply(z.contiguous(), direction)
+        return ops.squeeze(z, direction)
+
     def forward(self, z):
-        return ops.squeeze(z, 0), 0
+        return self._sq(z, 0), 0
 
     def inverse(self, z):
-        return ops.squeeze(z, 1), 0
+        return self._sq(z, 1), 0
 
     def _run(self, z, inverse, ld, acc, **kw):
-        return ops.squeeze(z, 1 if inverse else 0)
+        return self._sq(z, 1 if inverse else 0)

@@ -629,7 +629,58 @@ def gen_reverse_kld():
         npz("grad_reverse_kld_sf%d" % int(score_fn), eps=eps, loss=loss.detach(), **grads, **sd(m, "sd__"))
 
 
+def gen_glow_grads():
+    """Training step of the class-conditional Glow model of examples/glow.ipynb (reduced) and of the RealNVP model of
+    examples/real_nvp.ipynb: forward_kld loss and every parameter gradient from the reference's autograd."""
+    g = torch.Generator().manual_seed(61)
+    torch.manual_seed(5)
+    L_, K_, hidden, input_shape, ncls = 2, 2, 8, (3, 8, 8), 3
+    q0, merges, flows = [], [], []
+    for i in range(L_):
+        fl = [nf.flows.GlowBlock(3 * 2 ** (L_ + 1 - i), hidden, split_mode="channel", scale=True) for _ in range(K_)]
+        fl += [nf.flows.Squeeze()]
+        flows += [fl]
+        if i > 0:
+            merges += [nf.flows.Merge()]
+            latent = (input_shape[0] * 2 ** (L_ - i), input_shape[1] // 2 ** (L_ - i), input_shape[2] // 2 ** (L_ - i))
+        else:
+            latent = (input_shape[0] * 2 ** (L_ + 1), input_shape[1] // 2 ** L_, input_shape[2] // 2 ** L_)
+        q0 += [nf.distributions.ClassCondDiagGaussian(latent, ncls)]
+    m = nf.MultiscaleFlow(q0, flows, merges, class_cond=True)
+    perturb(m, 0.05, 18)
+    x = torch.rand(6, *input_shape, generator=g)
+    yl = torch.tensor([0, 1, 2, 2, 1, 0])
+    with torch.no_grad():
+        m.log_prob(x, yl)                       # data-dependent ActNorm init
+    m.zero_grad()
+    loss = m.forward_kld(x, yl)
+    loss.backward()
+    grads = {"g__" + k.replace(".", "__"): p_.grad for k, p_ in m.named_parameters() if p_.grad is not None}
+    npz("grad_glow_classcond", x=x, y=yl, loss=loss.detach(), **grads, **sd(m, "sd__"))
+    # RealNVP (config 1 structure): MaskedAffineFlow with MLP s, t + ActNorm
+    torch.manual_seed(6)
+    b = torch.tensor([1.0, 0.0])
+    flows = []
+    for i in range(4):
+        s_ = nf.nets.MLP([2, 8, 2], init_zeros=True)
+        t_ = nf.nets.MLP([2, 8, 2], init_zeros=True)
+        flows += [nf.flows.MaskedAffineFlow(b if i % 2 == 0 else 1 - b, t_, s_), nf.flows.ActNorm(2)]
+    m = nf.NormalizingFlow(nf.distributions.DiagGaussian(2), flows)
+    perturb(m, 0.2, 19)
+    x = torch.randn(40, 2, generator=g) * 1.5
+    with torch.no_grad():
+        m.log_prob(x)
+    m.zero_grad()
+    loss = m.forward_kld(x)
+    loss.backward()
+    grads = {"g__" + k.replace(".", "__"): p_.grad for k, p_ in m.named_parameters() if p_.grad is not None}
+    npz("grad_realnvp", x=x, loss=loss.detach(), **grads, **sd(m, "sd__"))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "glow_grads":
+        gen_glow_grads()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "reverse_kld":
         gen_reverse_kld()
         sys.exit(0)
@@ -666,3 +717,4 @@ if __name__ == "__main__":
     gen_circular()
     gen_conditional()
     gen_reverse_kld()
+    gen_glow_grads()
