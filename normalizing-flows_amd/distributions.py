@@ -191,18 +191,19 @@ class GlowBase(BaseDistribution):
             self.log_scale_cc = nn.Parameter(torch.zeros(self.num_classes, self.shape[0]))
         self.temperature = None
 
-    def _channel_params(self, y, num_samples):
+    def _channel_params(self, y, num_samples, detach=True):
         """(rows, C) mean and log-scale and the row index per sample (None: row b is sample b)."""
         C = self.shape[0]
-        loc = (self.loc.detach() * torch.exp(self.loc_logs.detach() * self.logscale_factor)).view(1, C)
-        ls = (self.log_scale.detach() * torch.exp(self.log_scale_logs.detach() * self.logscale_factor)).view(1, C)
+        dt = (lambda t: t.detach()) if detach else (lambda t: t)
+        loc = (dt(self.loc) * torch.exp(dt(self.loc_logs) * self.logscale_factor)).view(1, C)
+        ls = (dt(self.log_scale) * torch.exp(dt(self.log_scale_logs) * self.logscale_factor)).view(1, C)
         idx = None
         if self.class_cond:
             if y.dim() == 1:
-                loc, ls, idx = loc + self.loc_cc.detach(), ls + self.log_scale_cc.detach(), y
+                loc, ls, idx = loc + dt(self.loc_cc), ls + dt(self.log_scale_cc), y
             else:
                 w = y.to(loc.dtype)
-                loc, ls = loc + w @ self.loc_cc.detach(), ls + w @ self.log_scale_cc.detach()
+                loc, ls = loc + w @ dt(self.loc_cc), ls + w @ dt(self.log_scale_cc)
         elif num_samples is not None:
             idx = torch.zeros(num_samples, dtype=torch.long, device=loc.device)
         if self.temperature is not None:
@@ -230,7 +231,9 @@ class GlowBase(BaseDistribution):
 
     def log_prob(self, z, y=None):
         if needs_grad(z, *self.parameters()):
-            raise NotImplementedError("GlowBase: inference only (no autograd through the HIP kernel yet)")
+            loc, ls, idx = self._channel_params(y, len(z), detach=False)
+            return GaussianRowsLogProbFn.apply(z.contiguous(), self._expand(loc).contiguous(),
+                                               self._expand(ls).contiguous(), idx, 0.0)
         loc, ls, idx = self._channel_params(y, len(z))
         return ops.diag_gaussian_log_prob_rows(z, self._expand(loc), self._expand(ls), idx, 0.0)
 

@@ -677,7 +677,48 @@ def gen_glow_grads():
     npz("grad_realnvp", x=x, loss=loss.detach(), **grads, **sd(m, "sd__"))
 
 
+def gen_ar_grads():
+    """Gradients through the autoregressive layers (MAF, AR-NSF) in both directions and through GlowBase.log_prob."""
+    def layer_grads(layer, x, tag):
+        out = {}
+        g = torch.Generator().manual_seed(78)
+        cz = torch.randn(x.shape, generator=g)
+        cl = torch.randn(x.shape[0], generator=g)
+        for name, fn in (("inv", layer.inverse), ("fwd", layer.forward)):
+            xx = x.clone().requires_grad_(True)
+            layer.zero_grad()
+            z, ld = fn(xx)
+            ((z * cz).sum() + (ld * cl).sum()).backward()
+            out["gx_" + name] = xx.grad.clone()
+            for k, p_ in layer.named_parameters():
+                out["g_%s__%s" % (name, k.replace(".", "__"))] = p_.grad.clone()
+        npz(tag, x=x, cz=cz, cl=cl, **out, **sd(layer, "sd__"))
+
+    torch.manual_seed(21)
+    maf = nf.flows.MaskedAffineAutoregressive(5, 12, num_blocks=2)
+    perturb(maf, 0.2, 20)
+    layer_grads(maf, torch.randn(7, 5, generator=torch.Generator().manual_seed(1)), "grad_maf_d5")
+    torch.manual_seed(22)
+    ar = nf.flows.AutoregressiveRationalQuadraticSpline(4, 1, 10, num_bins=4, init_identity=False)
+    perturb(ar, 0.2, 21)
+    layer_grads(ar, 1.2 * torch.randn(6, 4, generator=torch.Generator().manual_seed(2)), "grad_arnsf_d4")
+    g = torch.Generator().manual_seed(3)
+    gb = nf.distributions.GlowBase((3, 2, 2), num_classes=2)
+    with torch.no_grad():
+        for p_ in gb.parameters():
+            p_.copy_(0.2 * torch.randn(p_.shape, generator=g))
+    z = torch.randn(5, 3, 2, 2, generator=g).requires_grad_(True)
+    yl = torch.tensor([0, 1, 1, 0, 1])
+    cl = torch.randn(5, generator=g)
+    (gb.log_prob(z, yl) * cl).sum().backward()
+    grads = {"g__" + k: p_.grad for k, p_ in gb.named_parameters()}
+    npz("grad_glow_base", z=z.detach(), y=yl, cl=cl, gz=z.grad, **grads, **sd(gb, "sd__"))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ar_grads":
+        gen_ar_grads()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "glow_grads":
         gen_glow_grads()
         sys.exit(0)
@@ -718,3 +759,4 @@ if __name__ == "__main__":
     gen_conditional()
     gen_reverse_kld()
     gen_glow_grads()
+    gen_ar_grads()

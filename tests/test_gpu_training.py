@@ -252,3 +252,29 @@ def test_realnvp_training_step_vs_reference(nfa):
     loss.backward()
     assert abs(float(loss.detach()) - float(g["loss"])) < 2e-4 * abs(float(g["loss"]))
     _check_grads(m, g, min_checked=30)
+
+
+def test_maf_gradients_vs_reference_autograd(nfa):
+    """MaskedAffineAutoregressive, both directions (inverse = the D-pass loop under autograd)."""
+    g = load_golden("grad_maf_d5")
+    layer = load_layer(nfa.flows.MaskedAffineAutoregressive(5, 12, num_blocks=2), golden_state(g), torch.float32)
+    check_layer_grads(layer, g, rtol=2e-3, atol=2e-4)
+
+
+def test_arnsf_gradients_vs_reference_autograd(nfa):
+    g = load_golden("grad_arnsf_d4")
+    layer = load_layer(nfa.flows.AutoregressiveRationalQuadraticSpline(4, 1, 10, num_bins=4, init_identity=False),
+                       golden_state(g), torch.float32)
+    check_layer_grads(layer, g, rtol=2e-3, atol=2e-4)
+
+
+def test_glow_base_gradients_vs_reference_autograd(nfa):
+    g = load_golden("grad_glow_base")
+    gb = nfa.distributions.GlowBase((3, 2, 2), num_classes=2)
+    gb.load_state_dict({k: torch.from_numpy(v) for k, v in golden_state(g).items()}, strict=True)
+    gb = gb.to(DEV)
+    z = T(g["z"]).requires_grad_(True)
+    (gb.log_prob(z, torch.from_numpy(g["y"]).to(DEV)) * T(g["cl"])).sum().backward()
+    assert_close(N(z.grad), g["gz"], what="gz", rtol=2e-3, atol=2e-4)
+    for k, p_ in gb.named_parameters():
+        assert_close(N(p_.grad), g["g__" + k], what="grad " + k, rtol=2e-3, atol=2e-4)
