@@ -6,7 +6,7 @@
 // h = lane >> 5) loads dY[b + h][64 p + 2 i .. +1] (8 bytes) and X[b + h][4 i .. +3] (16 bytes) and feeds 2 x 4 MFMAs:
 // the wave's tiles are the INTERLEAVED row sets {64 p + 2 i + s} x column sets {4 i + t}, so one load per operand serves
 // eight 32 x 32 tiles (128 accumulator registers).  One wave = one workgroup = 64 rows of M x 128 columns over one
-// K-chunk; operands are fetched two trips (8 k-pairs, 64 MFMAs) ahead, two waves per SIMD.  Partial tiles go to a caller-owned scratch
+// K-chunk; operands are fetched a buffer set (8 k-pairs, 64 MFMAs) ahead, two waves per SIMD.  Partial tiles go to a caller-owned scratch
 // [chunk][M*N + M] and a second kernel sums the chunks in a fixed order: deterministic, unlike atomics.
 // N not a multiple of 4 takes the dword path below (NT column tiles, lane i = column 32 t + i).
 #include "common.hpp"
@@ -72,25 +72,27 @@ wgrad_partial_vec_kernel(const float *__restrict__ dY, const float *__restrict__
             }
         }
     };
-    // three named trip buffers, each refilled right after it is consumed (two trips = 64 MFMAs of loads in flight, no
-    // register copies: a copy of a loaded value is a wait on it).  sched_barrier: the machine scheduler otherwise sinks
-    // every load to just before its use (to save registers), which turns the prefetch into a wait per k-pair.  The
-    // kernel is held to 256 registers so that two waves share a SIMD and cover each other's waits.
-    Trip t0, t1, t2;
-    load(b0, t0);
-    load(b0 + 8, t1);
-    load(b0 + 16, t2);
-#define NF_WG_STEP(OFF, T)                      \
-    mma(b + (OFF), T);                          \
-    __builtin_amdgcn_sched_barrier(0);          \
-    load(b + 24 + (OFF), T);                    \
-    __builtin_amdgcn_sched_barrier(0);
-    for (int64_t b = b0; b < b1; b += 24) {
-        NF_WG_STEP(0, t0)
-        NF_WG_STEP(8, t1)
-        NF_WG_STEP(16, t2)
+    // Two buffer SETS of two trips each, used alternately: a set is refilled as soon as the loop starts consuming the
+    // other one, so every load has 64 MFMAs (~2 us) to land before the (compiler-placed, conservative vmcnt(0)) wait
+    // in front of its first use; no register copies.  sched_barrier keeps the machine scheduler from sinking the loads
+    // to their uses.  The kernel is held to 256 registers so that two waves share a SIMD and cover each other's waits.
+    Trip a0, a1, c0, c1;
+    load(b0, a0);
+    load(b0 + 8, a1);
+    for (int64_t b = b0; b < b1; b += 32) {
+        load(b + 16, c0);
+        load(b + 24, c1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(b, a0);
+        mma(b + 8, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        load(b + 32, a0);
+        load(b + 40, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(b + 16, c0);
+        mma(b + 24, c1);
+        __builtin_amdgcn_sched_barrier(0);
     }
-#undef NF_WG_STEP
     // C layout of tile (s, t): row index ri = (reg & 3) + 8 (reg >> 2) + 4 h  ->  m = 64 p + 2 ri + s;  col = lane & 31 -> n = 4 i + t
     float *out = part + (size_t)blockIdx.x * ((size_t)M * N + M);
     if (nv) {
@@ -217,14 +219,14 @@ wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, floa
 }
 
 static int wgrad_chunk_rows(int64_t B, int M, bool vec) {
-    // vector path: ~2048 waves in flight (two per SIMD), chunk rows a multiple of its 24-row loop step;
-    // general path: ~1024 waves, multiple of 8.  At least 48 rows (fewer, longer chunks = less partial traffic).
+    // vector path: ~2048 waves in flight (two per SIMD), chunk rows a multiple of its 32-row loop step;
+    // general path: ~1024 waves.  At least 64 rows (fewer, longer chunks = less partial traffic).
     const int mgroups = vec ? (M + 63) / 64 : (M + 31) / 32;
     // small outputs: the partial-tile traffic (chunks x M x N) outweighs the second wave per SIMD
     int64_t want = (((vec && M > 256) ? 2048 : 1024) + mgroups - 1) / mgroups;
     int64_t rows = (B + want - 1) / want;
-    rows = (rows + 23) / 24 * 24;
-    if (rows < 48) rows = 48;
+    rows = (rows + 31) / 32 * 32;
+    if (rows < 64) rows = 64;
     return (int)rows;
 }
 
