@@ -30,4 +30,4 @@ for B, M, N in [(65536, 128, 128), (65536, 128, 32), (65536, 736, 128), (65536, 
     t_ours = timeit(lambda: nfa.ops.linear_wgrad(dy, x))
     t_lib = timeit(lambda: (dy.t() @ x, dy.sum(0)))
     gf = 2.0 * B * M * N / 1e9
-    print("B=%d M=%d N=%d: nf_linear_wgrad %.1f us (%.1f TFLOP/s)   torch mm+sum %.1f us" % (B, M, N, t_ours, gf / t_ours, t_lib))
+    print("B=%d M=%d N=%d: nf_linear_wgrad %.1f us (%.1f TFLOP/s)   torch mm+sum %.1f us" % (B, M, N, t_ours, gf / t_ours * 1e3, t_lib))
