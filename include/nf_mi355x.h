@@ -219,6 +219,12 @@ int nf_masked_affine(const void *z, const void *b, const void *s, const void *t,
 int nf_affine_coupling(const void *z, const void *param, void *y, void *logdet, int64_t B, int C, int c1,
                        int flip, int64_t HW, int scale_map, int direction, int acc, int dtype,
                        nf_stream_t stream);
+/* Same with a per-channel bias added to `param` on the fly (param_bias, 2*c2 or c2 values, may be NULL): lets the
+ * conditioner's last convolution (nets/cnn.py:51-56) run bias-free in the library while its bias costs no extra pass. */
+int nf_affine_coupling_pb(const void *z, const void *param, const void *param_bias, void *y, void *logdet, int64_t B,
+                          int C, int c1, int flip, int64_t HW, int scale_map, int direction, int acc, int dtype,
+                          nf_stream_t stream);
+
 
 /* ------------------------------------------------------------------------------------------------
  * AffineConstFlow / ActNorm.  Replaces normflows/flows/affine/coupling.py:38-54 and the data-dependent
@@ -250,6 +256,13 @@ int nf_inv1x1_assemble(const void *P, const void *L, const void *U, const void *
                        void *W, void *logdet_unit, int C, int inverse, int dtype, nf_stream_t stream);
 int nf_inv1x1_conv(const void *z, const void *W, const void *logdet_unit, void *y, void *logdet_scalar,
                    void *logdet, int64_t B, int C, int64_t HW, int acc, int dtype, nf_stream_t stream);
+/* y = W z + bias per pixel (bias (C) may be NULL): the 1x1 convolution with the neighbouring ActNorm
+ * (normalization.py:7-39) folded into W / bias / logdet_unit by the caller -- GlowBlock's [Invertible1x1Conv, ActNorm]
+ * pair (affine/glow.py:72-84) as ONE pass over the tensor. */
+int nf_inv1x1_conv_affine(const void *z, const void *W, const void *bias, const void *logdet_unit, void *y,
+                          void *logdet_scalar, void *logdet, int64_t B, int C, int64_t HW, int acc, int dtype,
+                          nf_stream_t stream);
+
 
 /* ------------------------------------------------------------------------------------------------
  * DiagGaussian.log_prob.  Replaces normflows/distributions/base.py:94-103.

@@ -60,7 +60,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 affine_coupling_kernel(const T *__restrict__ z, const T *__restrict__ param, T *__restrict__ y,
                        T *__restrict__ logdet, int64_t B, int C, int c1, int flip, int64_t HW, int scale_map,
-                       int direction, int acc) {
+                       int direction, int acc, const T *__restrict__ pbias) {
     __shared__ T sred[16];
     const int c2 = C - c1;
     const int z1_off = flip ? c2 : 0, z2_off = flip ? 0 : c1;  // channel offsets inside a sample
@@ -77,10 +77,12 @@ affine_coupling_kernel(const T *__restrict__ z, const T *__restrict__ param, T *
             const T v = zr[(int64_t)z2_off * HW + i];
             T o;
             if (scale_map == NF_SCALE_NONE) {
-                const T sh = pr[i];
+                const T sh = pr[i] + (pbias ? pbias[c] : T(0));
                 o = direction == 0 ? v + sh : v - sh;
             } else {
-                const T sh = pr[(2 * c) * HW + p], sc = pr[(2 * c + 1) * HW + p];
+                // pbias: bias of the conditioner's last (bias-free) convolution, per parameter channel
+                const T sh = pr[(2 * c) * HW + p] + (pbias ? pbias[2 * c] : T(0));
+                const T sc = pr[(2 * c + 1) * HW + p] + (pbias ? pbias[2 * c + 1] : T(0));
                 if (scale_map == NF_SCALE_EXP) {
                     o = direction == 0 ? v * M<T>::exp(sc) + sh : (v - sh) * M<T>::exp(-sc);
                     ld += sc;  // +sum (forward) / -sum (inverse)
@@ -276,9 +278,9 @@ extern "C" int nf_masked_affine(const void *z, const void *b, const void *s, con
     return NF_OK;
 }
 
-extern "C" int nf_affine_coupling(const void *z, const void *param, void *y, void *logdet, int64_t B, int C, int c1,
-                                  int flip, int64_t HW, int scale_map, int direction, int acc, int dtype,
-                                  nf_stream_t stream) {
+extern "C" int nf_affine_coupling_pb(const void *z, const void *param, const void *param_bias, void *y, void *logdet,
+                                     int64_t B, int C, int c1, int flip, int64_t HW, int scale_map, int direction,
+                                     int acc, int dtype, nf_stream_t stream) {
     if (B < 0 || C < 1 || c1 < 0 || c1 >= C || HW < 1 || (direction != 0 && direction != 1)) return NF_EINVAL;
     if (scale_map < NF_SCALE_EXP || scale_map > NF_SCALE_NONE || acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
     if (B == 0) return NF_OK;
@@ -288,12 +290,18 @@ extern "C" int nf_affine_coupling(const void *z, const void *param, void *y, voi
     NF_DISPATCH(dtype,
                 hipLaunchKernelGGL(affine_coupling_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)z,
                                    (const float *)param, (float *)y, (float *)logdet, B, C, c1, flip, HW, scale_map,
-                                   direction, acc),
+                                   direction, acc, (const float *)param_bias),
                 hipLaunchKernelGGL(affine_coupling_kernel<double>, dim3(grid), dim3(256), 0, st, (const double *)z,
                                    (const double *)param, (double *)y, (double *)logdet, B, C, c1, flip, HW, scale_map,
-                                   direction, acc));
+                                   direction, acc, (const double *)param_bias));
     NF_CHECK_LAUNCH();
     return NF_OK;
+}
+
+extern "C" int nf_affine_coupling(const void *z, const void *param, void *y, void *logdet, int64_t B, int C, int c1,
+                                  int flip, int64_t HW, int scale_map, int direction, int acc, int dtype,
+                                  nf_stream_t stream) {
+    return nf_affine_coupling_pb(z, param, nullptr, y, logdet, B, C, c1, flip, HW, scale_map, direction, acc, dtype, stream);
 }
 
 extern "C" int nf_actnorm(const void *z, const void *s, const void *t, void *y, void *logdet_scalar, void *logdet,

@@ -105,7 +105,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 inv1x1_conv_kernel(const T *__restrict__ z, const T *__restrict__ W, const T *__restrict__ logdet_unit,
                    T *__restrict__ y, T *__restrict__ logdet_scalar, T *__restrict__ logdet, int64_t B, int C,
-                   int64_t HW, int acc) {
+                   int64_t HW, int acc, const T *__restrict__ obias) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *Wt = reinterpret_cast<T *>(smem_raw);  // [c][Cp] : Wt[c][o] = W[o][c], row pitch Cp = roundup(C, OT)
     const int Cp = (C + OT - 1) / OT * OT;
@@ -124,7 +124,7 @@ inv1x1_conv_kernel(const T *__restrict__ z, const T *__restrict__ W, const T *__
         const T *zb = z + b * (int64_t)C * HW + p;
         T a[OT];
 #pragma unroll
-        for (int j = 0; j < OT; ++j) a[j] = T(0);
+        for (int j = 0; j < OT; ++j) a[j] = (obias && ot * OT + j < C) ? obias[ot * OT + j] : T(0);
         const T *wrow = Wt + ot * OT;
         for (int c = 0; c < C; ++c) {
             const T zc = zb[(int64_t)c * HW];
@@ -160,7 +160,7 @@ static int launch_assemble(const void *P, const void *L, const void *U, const vo
 
 template <typename T>
 static int launch_conv(const void *z, const void *W, const void *logdet_unit, void *y, void *logdet_scalar, void *logdet,
-                       int64_t B, int C, int64_t HW, int acc, hipStream_t st) {
+                       int64_t B, int C, int64_t HW, int acc, hipStream_t st, const void *obias = nullptr) {
     const int Cp = (C + OT - 1) / OT * OT;
     const size_t lds = (size_t)C * Cp * sizeof(T);
     if (lds > 160 * 1024) return NF_ENOTSUP;
@@ -169,7 +169,7 @@ static int launch_conv(const void *z, const void *W, const void *logdet_unit, vo
     const int64_t nwork = B * HW * (Cp / OT);
     const int grid = grid_for(nwork > 0 ? nwork : 1, 256);
     hipLaunchKernelGGL(inv1x1_conv_kernel<T>, dim3(grid), dim3(256), lds, st, (const T *)z, (const T *)W,
-                       (const T *)logdet_unit, (T *)y, (T *)logdet_scalar, (T *)logdet, B, C, HW, acc);
+                       (const T *)logdet_unit, (T *)y, (T *)logdet_scalar, (T *)logdet, B, C, HW, acc, (const T *)obias);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -194,5 +194,20 @@ extern "C" int nf_inv1x1_conv(const void *z, const void *W, const void *logdet_u
     hipStream_t st = (hipStream_t)stream;
     if (dtype == NF_F32) return nf::launch_conv<float>(z, W, logdet_unit, y, logdet_scalar, logdet, B, C, HW, acc, st);
     if (dtype == NF_F64) return nf::launch_conv<double>(z, W, logdet_unit, y, logdet_scalar, logdet, B, C, HW, acc, st);
+    return NF_ENOTSUP;
+}
+
+// y = W z + bias per pixel: the 1x1 convolution with the neighbouring ActNorm folded into W and bias by the caller.
+extern "C" int nf_inv1x1_conv_affine(const void *z, const void *W, const void *bias, const void *logdet_unit, void *y,
+                                     void *logdet_scalar, void *logdet, int64_t B, int C, int64_t HW, int acc, int dtype,
+                                     nf_stream_t stream) {
+    if (B < 0 || C < 1 || HW < 1 || acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
+    if (!W) return NF_EFAULT;
+    if (B > 0 && (!z || !y)) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == NF_F32)
+        return nf::launch_conv<float>(z, W, logdet_unit, y, logdet_scalar, logdet, B, C, HW, acc, st, bias);
+    if (dtype == NF_F64)
+        return nf::launch_conv<double>(z, W, logdet_unit, y, logdet_scalar, logdet, B, C, HW, acc, st, bias);
     return NF_ENOTSUP;
 }

@@ -206,6 +206,10 @@ class AffineCouplingBlock(Flow):
         else:
             c1, flip = C // 2, True          # channel_inv: z2 = first ceil(C/2), z1 = the rest (reshape.py:33)
             z1 = z[:, C - c1:]
+        split = coupling.param_map.forward_split(z1) if hasattr(coupling.param_map, "forward_split") else None
+        if split is not None:   # inference: the last convolution's bias is added inside the coupling kernel
+            return ops.affine_coupling(z, split[0], c1, flip, coupling._smap(), 1 if inverse else 0, logdet=ld, acc=acc,
+                                       param_bias=split[1])
         param = coupling.param_map(z1)
         if needs_grad(z, param):
             y, log_det = AffineCouplingFn.apply(z.contiguous(), param, c1, flip, coupling._smap(), 1 if inverse else 0)

@@ -33,7 +33,50 @@ class GlowBlock(Flow):
             self.flows += [Invertible1x1Conv(channels, use_lu)]
         self.flows += [ActNorm((channels,) + (1, 1))]
 
+    def _fused_mix(self, inverse):
+        """[Invertible1x1Conv, ActNorm] as ONE per-pixel affine map y = W' z + b' (inference, parameters frozen between
+        updates): inverse  y = W (z - t) e^-s  ->  W' = W diag(e^-s), b' = -W' t, log|det| per pixel = ld_W - sum s;
+        forward  y = (W^-1 z) e^s + t  ->  W' = diag(e^s) W^-1, b' = t, log|det| = ld_Winv + sum s."""
+        conv, an = self.flows[1], self.flows[2]
+        if not (isinstance(conv, Invertible1x1Conv) and isinstance(an, ActNorm) and an._per_channel):
+            return None
+        if an._init_known is None:
+            an._init_known = bool(an.data_dep_init_done.item() > 0.0)
+        if not an._init_known:
+            return None
+        params = [an.s, an.t] + ([conv.L, conv.U, conv.log_S] if conv.use_lu else [conv.W])
+        key = (inverse,) + tuple((p_.data_ptr(), p_._version) for p_ in params)
+        cache = getattr(self, "_mix_cache", None)
+        if cache is None or cache[0] != key:
+            W, ldu = conv._weight(inverse)
+            s_, t_ = an.s.detach().reshape(-1), an.t.detach().reshape(-1)
+            if inverse:
+                Wp = W * torch.exp(-s_)[None, :]
+                bp = -(Wp @ t_)
+                ldp = ldu - s_.sum()
+            else:
+                Wp = torch.exp(s_)[:, None] * W
+                bp = t_.clone()
+                ldp = ldu + s_.sum()
+            cache = (key, (Wp.contiguous(), bp.contiguous(), ldp))
+            self._mix_cache = cache
+        return cache[1]
+
     def _run(self, z, inverse, ld, acc, **kw):
+        from .. import ops
+        from ..autograd import needs_grad
+        if len(self.flows) == 3 and z.dim() == 4 and not needs_grad(z, self):
+            if inverse:                       # ActNorm's data-dependent init sees the block input first
+                self.flows[2]._maybe_init(z, True)
+            mix = self._fused_mix(inverse)
+            if mix is not None:
+                Wp, bp, ldp = mix
+                if inverse:
+                    z, _ = ops.inv1x1_conv(z, Wp, ldp, logdet=ld, acc=acc, want_scalar=False, bias=bp)
+                    return run_flow(self.flows[0], z, True, ld, acc)
+                z = run_flow(self.flows[0], z, False, ld, acc)
+                z, _ = ops.inv1x1_conv(z, Wp, ldp, logdet=ld, acc=acc, want_scalar=False, bias=bp)
+                return z
         seq = reversed(self.flows) if inverse else self.flows
         for f in seq:
             z = run_flow(f, z, inverse, ld, acc)

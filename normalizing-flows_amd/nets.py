@@ -225,11 +225,21 @@ class ConvNet2d(nn.Module):
             return self._forward_inference(x)
         return self.net(x)
 
-    def _forward_inference(self, x):
+    def forward_split(self, x):
+        """(output without the last convolution's bias, that bias) for callers that fold the bias into their own kernel
+        (the affine coupling); None when not applicable."""
+        last = self.net[-1]
+        if (torch.is_grad_enabled() or not x.is_cuda or not isinstance(last, nn.Conv2d) or last.bias is None
+                or x.dtype not in (torch.float32, torch.float64)):
+            return None
+        h = self._forward_inference(x, upto=len(self.net) - 1)
+        return F.conv2d(h, last.weight, None, last.stride, last.padding, last.dilation, last.groups), last.bias
+
+    def _forward_inference(self, x, upto=None):
         """Library convolution without bias, then ONE HIP pass for bias + LeakyReLU (instead of a bias pass inside the
         library call and a separate activation pass)."""
         from . import ops
-        mods = list(self.net)
+        mods = list(self.net) if upto is None else list(self.net)[:upto]
         i = 0
         while i < len(mods):
             m = mods[i]

@@ -133,9 +133,10 @@ def masked_affine(z, b, s, t, direction, logdet=None, acc=None):
     return y, logdet
 
 
-def affine_coupling(z, param, c1, flip, scale_map, direction, logdet=None, acc=None):
-    """affine/coupling.py:117-171 + channel Split/Merge.  z (B, C, *spatial), param (B, P, *spatial)."""
-    L.require_device(z, param)
+def affine_coupling(z, param, c1, flip, scale_map, direction, logdet=None, acc=None, param_bias=None):
+    """affine/coupling.py:117-171 + channel Split/Merge.  z (B, C, *spatial), param (B, P, *spatial); param_bias (P)
+    is added to param inside the kernel (bias of a bias-free last convolution)."""
+    L.require_device(z, param, param_bias)
     z = z.contiguous()
     param = param.contiguous()
     B, Cc = z.shape[:2]
@@ -146,10 +147,10 @@ def affine_coupling(z, param, c1, flip, scale_map, direction, logdet=None, acc=N
         acc = L.LD_WRITE
     elif acc is None:
         acc = L.LD_ADD
-    rc = L.lib().nf_affine_coupling(ptr(z), ptr(param), ptr(y), ptr(logdet), i64(B), i32(Cc), i32(c1), i32(int(flip)),
-                                    i64(HW), i32(L.SCALE[scale_map]), i32(direction), i32(acc),
-                                    i32(L.dtype_code(z)), L.stream())
-    L.check(rc, "nf_affine_coupling")
+    rc = L.lib().nf_affine_coupling_pb(ptr(z), ptr(param), ptr(None if param_bias is None else param_bias.contiguous()),
+                                       ptr(y), ptr(logdet), i64(B), i32(Cc), i32(c1), i32(int(flip)), i64(HW),
+                                       i32(L.SCALE[scale_map]), i32(direction), i32(acc), i32(L.dtype_code(z)), L.stream())
+    L.check(rc, "nf_affine_coupling_pb")
     return y, logdet
 
 
@@ -202,8 +203,8 @@ def inv1x1_assemble(P, Lm, U, sign_S, log_S, inverse):
     return W, ldu
 
 
-def inv1x1_conv(z, W, logdet_unit, logdet=None, acc=None, want_scalar=True):
-    L.require_device(z, W, logdet_unit)
+def inv1x1_conv(z, W, logdet_unit, logdet=None, acc=None, want_scalar=True, bias=None):
+    L.require_device(z, W, logdet_unit, bias)
     z = z.contiguous()
     B, Cc = z.shape[:2]
     HW = int(math.prod(z.shape[2:]))
@@ -211,9 +212,10 @@ def inv1x1_conv(z, W, logdet_unit, logdet=None, acc=None, want_scalar=True):
     lds = torch.empty((), dtype=z.dtype, device=z.device) if want_scalar else None
     if logdet is not None and acc is None:
         acc = L.LD_ADD
-    rc = L.lib().nf_inv1x1_conv(ptr(z), ptr(W.contiguous()), ptr(logdet_unit), ptr(y), ptr(lds), ptr(logdet), i64(B),
-                                i32(Cc), i64(HW), i32(acc or 0), i32(L.dtype_code(z)), L.stream())
-    L.check(rc, "nf_inv1x1_conv")
+    rc = L.lib().nf_inv1x1_conv_affine(ptr(z), ptr(W.contiguous()), ptr(None if bias is None else bias.contiguous()),
+                                       ptr(logdet_unit), ptr(y), ptr(lds), ptr(logdet), i64(B), i32(Cc), i64(HW),
+                                       i32(acc or 0), i32(L.dtype_code(z)), L.stream())
+    L.check(rc, "nf_inv1x1_conv_affine")
     return y, lds
 
 
