@@ -1,5 +1,7 @@
 """GPU tests of the training path: gradients of our autograd Functions (HIP forward,
 HIP / GEMM backward) against gradients produced by the reference's autograd (tests/golden/grad_*.npz)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -278,3 +280,19 @@ def test_glow_base_gradients_vs_reference_autograd(nfa):
     assert_close(N(z.grad), g["gz"], what="gz", rtol=2e-3, atol=2e-4)
     for k, p_ in gb.named_parameters():
         assert_close(N(p_.grad), g["g__" + k], what="grad " + k, rtol=2e-3, atol=2e-4)
+
+
+def test_example_nsf_density_trains(nfa):
+    """examples/nsf_density.py (reference-style training loop on our layers): the loss goes down."""
+    import importlib.util
+    import sys as _sys
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "nsf_density.py")
+    spec = importlib.util.spec_from_file_location("nsf_density_example", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv, _sys.argv = _sys.argv, ["nsf_density.py", "--steps", "40", "--batch", "1024", "--dim", "8", "--layers", "3"]
+    try:
+        first, last = mod.main()
+    finally:
+        _sys.argv = argv
+    assert last < first - 0.5, (first, last)
