@@ -20,6 +20,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -134,7 +136,7 @@ def pmc_traffic():
     return None
 
 
-def cpu_baseline(model, rows):
+def cpu_baseline(model, rows, gpu_lp=None, gpu_lp3=None):
     """The CPU oracle (a port of the reference algorithm) timed on this host on a bounded sample of the same workload:
     log_prob of the same 32-layer model on `rows` benchmark rows through ONE C call (oracle/nf_oracle.c
     nfo_nsf_log_prob: OpenMP over 64-row chunks, every chunk runs the whole 64-layer chain)."""
@@ -148,9 +150,21 @@ def cpu_baseline(model, rows):
     t0 = time.perf_counter()
     lp = ora.log_prob_whole(x)
     dt = time.perf_counter() - t0
-    return {"value": rows / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "log_prob of the same %d-layer model on %d rows (oracle/nf_oracle.c nfo_nsf_log_prob, OpenMP, %.1f s)"
-                      % (len(model.flows) // 2, rows, dt), "nll_nats_per_dim": float(-lp.mean() / DIM)}
+    res = {"value": rows / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+           "sample": "log_prob of the same %d-layer model on %d rows (oracle/nf_oracle.c nfo_nsf_log_prob, OpenMP, %.1f s)"
+                     % (len(model.flows) // 2, rows, dt), "nll_nats_per_dim": float(-lp.mean() / DIM)}
+    # accuracy of the GPU results against the oracle in DOUBLE precision on the first rows of the benchmark batch
+    # (the fp32 oracle itself is shown for scale): relative error of log_prob, max over the rows
+    n64 = min(2048, rows)
+    ref64 = ora.log_prob(x[:n64].astype(np.float64))
+    rel = lambda a: float(np.max(np.abs(a.astype(np.float64) - ref64) / np.maximum(1.0, np.abs(ref64))))
+    acc = {"rows": n64, "oracle_f32": rel(lp[:n64])}
+    if gpu_lp is not None:
+        acc["gpu_exact_f32"] = rel(gpu_lp[:n64])
+    if gpu_lp3 is not None:
+        acc["gpu_bf16x3"] = rel(gpu_lp3[:n64])
+    res["max_rel_err_log_prob_vs_fp64_oracle"] = acc
+    return res
 
 
 def main():
@@ -291,7 +305,8 @@ def main():
             model.use_graphs(False)
             model.use_graphs(not args.no_graph)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(model, args.cpu_rows)
+            out["cpu_baseline"] = cpu_baseline(model, args.cpu_rows, lp.cpu().numpy(),
+                                               lp3.cpu().numpy() if not args.no_breakdown else None)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:
