@@ -159,8 +159,6 @@ class Coupling(Flow):
             raise ValueError("Inputs must be a 2D or a 4D tensor.")
         if inputs.shape[1] != self.features:
             raise ValueError("Expected features = {}, got {}.".format(self.features, inputs.shape[1]))
-        if inputs.dim() == 4:
-            raise NotImplementedError("image (NCHW) neural-spline coupling is not implemented by the HIP kernels yet")
 
     def _transform_dim_multiplier(self):
         raise NotImplementedError()
@@ -255,6 +253,8 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
     def _density(self, inputs, context=None, ld=None, acc=None):
         """prqct.forward (nsf/coupling.py:71-98): conditioner on the raw identity features."""
         self._check(inputs)
+        if inputs.dim() == 4:
+            return self._image(inputs, context, False, ld, acc)
         if needs_grad(inputs, context, self):
             if self._per_feature:
                 raise NotImplementedError("per-feature tails: inference only (no backward kernel yet)")
@@ -269,6 +269,8 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
     def _sample(self, inputs, context=None, ld=None, acc=None):
         """prqct.inverse (nsf/coupling.py:100-128): CDF^-1 on the identity half first, conditioner on ITS output."""
         self._check(inputs)
+        if inputs.dim() == 4:
+            return self._image(inputs, context, True, ld, acc)
         if needs_grad(inputs, context, self):
             if self._per_feature:
                 raise NotImplementedError("per-feature tails: inference only (no backward kernel yet)")
@@ -289,6 +291,63 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
 
     def inverse(self, inputs, context=None):
         return self._sample(inputs, context)
+
+    # -- images (nsf/coupling.py:150-160): every pixel is a row of C channel features for the 2-D coupling kernel ----
+    def _image(self, inputs, context, sample, ld, acc):
+        """4-D inputs: mask over channels, conv conditioner output (B, nT*M, H, W) -> per pixel (nT, M) parameter rows
+        (:152-156); the unconditional transform carries per-pixel parameters (`img_shape`), so it runs through the same
+        kernel as a second 'conditioner' whose rows are shared across the batch."""
+        if needs_grad(inputs, context, self):
+            raise NotImplementedError("image neural-spline coupling: inference only")
+        B, C, H, W = inputs.shape
+        HW = H * W
+        I, Tf = self.identity_features, self.transform_features
+        rows = inputs.permute(0, 2, 3, 1).reshape(B * HW, C).contiguous()
+        kw = self._kernel_kwargs()
+        kw.pop("tails_i", None)
+        kw.pop("bound_i", None)
+        u = self.unconditional_transform
+        ld_rows = torch.zeros(B * HW, dtype=inputs.dtype, device=inputs.device)
+
+        def to_rows(p, n):   # (B, n*M, H, W) -> (B*HW, n*M) with the M numbers of a feature contiguous
+            return p.reshape(B, n, -1, H, W).permute(0, 3, 4, 1, 2).reshape(B * HW, -1).contiguous()
+
+        def uncond_call(x_rows, mode, y=None):
+            prm = torch.cat([u.unnormalized_widths.detach(), u.unnormalized_heights.detach(),
+                             u.unnormalized_derivatives.detach()], -1)          # (nI, H, W, M_i)
+            if prm.dim() != 4:
+                raise NotImplementedError("image coupling needs an unconditional transform built with img_shape")
+            prm = prm.permute(1, 2, 0, 3).reshape(1, HW, -1).expand(B, HW, -1).reshape(B * HW, -1).contiguous()
+            ukw = dict(min_bin_width=u.min_bin_width, min_bin_height=u.min_bin_height,
+                       min_derivative=u.min_derivative, wh_div=1.0)
+            ukw.update(_tails_kwargs(u.tails, u.tail_bound, "t", inputs.device, self.__dict__.setdefault("_tcache_u", {})))
+            return ops.rqs_coupling(x_rows, prm, None, None, None, Tf, I, self.num_bins, mode, y=y, logdet=ld_rows,
+                                    acc=L.LD_ADD, **ukw)   # roles swapped: the identity half is the 'transform' set here
+
+        if not sample:
+            cond = to_rows(self.transform_net(inputs[:, I, ...], context), len(Tf))
+            y_rows, _ = ops.rqs_coupling(rows, cond, None, None, None, I, Tf, self.num_bins, L.RQS_DENSITY,
+                                         logdet=ld_rows, acc=L.LD_ADD, **kw)
+            if u is not None:
+                yi, _ = uncond_call(rows, L.RQS_DENSITY)
+                y_rows.index_copy_(1, I, yi.index_select(1, I))
+        else:
+            y_rows = rows.clone()
+            if u is not None:
+                uncond_call(rows, L.RQS_SAMPLE_TRANSFORM, y=y_rows)
+            img = y_rows.view(B, H, W, C).permute(0, 3, 1, 2)
+            cond = to_rows(self.transform_net(img[:, I, ...].contiguous(), context), len(Tf))
+            ops.rqs_coupling(rows, cond, None, None, None, I, Tf, self.num_bins, L.RQS_SAMPLE_TRANSFORM, y=y_rows,
+                             logdet=ld_rows, acc=L.LD_ADD, **kw)
+        out = y_rows.view(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+        log_det = ld_rows.view(B, HW).sum(1)
+        if ld is not None:
+            if acc is None or acc > 0:
+                ld += log_det
+            else:
+                ld -= log_det
+            return out, ld
+        return out, log_det
 
     # -- training path: same kernels through torch.autograd.Function (autograd.py), split/merge by torch indexing ---
     def _autograd(self, inputs, context, sample, ld, acc):

@@ -715,7 +715,35 @@ def gen_ar_grads():
     npz("grad_glow_base", z=z.detach(), y=yl, cl=cl, gz=z.grad, **grads, **sd(gb, "sd__"))
 
 
+def gen_image_coupling():
+    """PiecewiseRationalQuadraticCoupling on NCHW inputs (nsf/coupling.py:150-160): channel mask, conv conditioner,
+    per-pixel unconditional transform (img_shape)."""
+    g = torch.Generator().manual_seed(71)
+    torch.manual_seed(23)
+    mask = nf.utils.masks.create_alternating_binary_mask(4, even=False)
+    class CtxConv(torch.nn.Module):          # the reference ships no conv conditioner taking (x, context): thin wrapper
+        def __init__(self, i, o):
+            super().__init__()
+            self.net = nf.nets.ConvNet2d([i, 8, o], [3, 3], init_zeros=False)
+
+        def forward(self, x, context=None):
+            return self.net(x)
+
+    t = nf.flows.neural_spline.coupling.PiecewiseRationalQuadraticCoupling(
+        mask, CtxConv, num_bins=4, tails="linear", tail_bound=3.0, apply_unconditional_transform=True, img_shape=[4, 4])
+    perturb(t, 0.3, 22)
+    x = 1.5 * torch.randn(3, 4, 4, 4, generator=g)
+    x[0, 1, 0, 0] = 5.0
+    with torch.no_grad():
+        zf, ldf = t.forward(x)
+        zi, ldi = t.inverse(x)
+    npz("coupling_image", x=x, z_fwd=zf, ld_fwd=ldf, z_inv=zi, ld_inv=ldi, **sd(t, "sd__"))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "image_coupling":
+        gen_image_coupling()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ar_grads":
         gen_ar_grads()
         sys.exit(0)
@@ -760,3 +788,4 @@ if __name__ == "__main__":
     gen_reverse_kld()
     gen_glow_grads()
     gen_ar_grads()
+    gen_image_coupling()

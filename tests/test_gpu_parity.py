@@ -956,3 +956,33 @@ def test_conditional_flow_vs_reference(nfa):
         torch.manual_seed(4)
         xs, lq = m.sample(9, context=c)
         assert_close(N(m.log_prob(xs, c)), N(lq), what="log_prob(sample)", rtol=1e-3, atol=1e-3)
+
+
+def test_image_spline_coupling_vs_reference(nfa):
+    """NCHW inputs through PiecewiseRationalQuadraticCoupling (nsf/coupling.py:150-160): conv conditioner, channel mask,
+    per-pixel unconditional transform."""
+    import warnings
+    g = load_golden("coupling_image")
+    mask = nfa.utils.create_alternating_binary_mask(4, even=False)
+    class CtxConv(torch.nn.Module):
+        def __init__(self, i, o):
+            super().__init__()
+            self.net = nfa.nets.ConvNet2d([i, 8, o], [3, 3], init_zeros=False)
+
+        def forward(self, x, context=None):
+            return self.net(x)
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        t = nfa.flows.PiecewiseRationalQuadraticCoupling(mask, CtxConv, num_bins=4, tails="linear", tail_bound=3.0,
+                                                         apply_unconditional_transform=True, img_shape=[4, 4])
+        t = load_layer(t, golden_state(g), torch.float32)
+        with torch.no_grad():
+            z, ld = t.forward(T(g["x"]))
+            assert_close(N(z), g["z_fwd"], what="z_fwd", rtol=1e-4, atol=1e-5)
+            assert_close(N(ld), g["ld_fwd"], what="ld_fwd", rtol=1e-4, atol=1e-4)
+            z, ld = t.inverse(T(g["x"]))
+            assert_close(N(z), g["z_inv"], what="z_inv", rtol=1e-4, atol=1e-4)
+            assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=1e-4, atol=1e-4)
+            xr, ldr = t.forward(z)
+            assert_close(N(xr), g["x"], what="roundtrip", rtol=1e-4, atol=1e-4)
