@@ -63,6 +63,42 @@ def test_c_abi_argument_validation_without_gpu(nfa):
     assert lib.nf_rqs_fused_pack_size(i32(8), i32(8), i32(32), i32(2), i32(8)) == -95
 
 
+def test_c_abi_argument_validation_newer_entry_points(nfa):
+    """Same discipline for the entry points added after the first bench: nothing is launched on bad arguments."""
+    lib = nfa._lib.lib()
+    i32, i64, f64, vp = ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
+    null, one = vp(0), vp(16)
+    lib.nf_maf_inverse_scratch_floats.restype = ctypes.c_int64
+    lib.nf_linear_wgrad_scratch_floats.restype = ctypes.c_int64
+    # MAF inverse: padded hidden size must be a positive multiple of 32; scratch = 64-row tiles x (5 Hp + Dp)
+    assert lib.nf_maf_inverse(one, one, one, one, one, one, i64(8), i32(128), i32(500), i32(0), null) == -22
+    assert lib.nf_maf_inverse(one, one, one, null, one, one, i64(8), i32(128), i32(512), i32(0), null) == -14
+    assert lib.nf_maf_inverse(null, null, null, null, null, null, i64(0), i32(128), i32(512), i32(0), null) == 0
+    assert lib.nf_maf_inverse_scratch_floats(i64(65), i32(128), i32(512)) == 2 * 64 * (5 * 512 + 128)
+    # weight gradient: N <= 128 columns per launch, accumulate is 0 / 1
+    assert lib.nf_linear_wgrad(one, one, one, one, one, i64(64), i32(8), i32(200), i32(0), null) == -95
+    assert lib.nf_linear_wgrad(one, one, one, one, one, i64(64), i32(8), i32(8), i32(2), null) == -22
+    assert lib.nf_linear_wgrad(one, one, null, one, one, i64(64), i32(8), i32(8), i32(0), null) == -14
+    assert lib.nf_linear_wgrad_scratch_floats(i64(65536), i32(128), i32(128)) > 0
+    # logit: alpha in [0, 0.5)
+    assert lib.nf_logit(one, one, one, i64(4), i64(12), f64(0.5), i32(0), i32(0), i32(0), null) == -22
+    assert lib.nf_logit(one, one, one, i64(4), i64(12), f64(0.05), i32(2), i32(0), i32(0), null) == -22
+    assert lib.nf_logit(null, null, null, i64(0), i64(12), f64(0.05), i32(0), i32(0), i32(0), null) == 0
+    # row-wise Gaussian: without an index the table needs one row per sample
+    assert lib.nf_diag_gaussian_log_prob_rows(one, one, one, null, i64(3), f64(0), one, i64(8), i64(4), i32(0), i32(0),
+                                              null) == -22
+    assert lib.nf_diag_gaussian_log_prob_rows(one, null, one, one, i64(3), f64(0), one, i64(8), i64(4), i32(0), i32(0),
+                                              null) == -14
+    # per-feature tails: type arrays only with NF_TAILS_FEATURE (3), and required with it
+    args = lambda tails, tt: (one, one, one, one, null, null, null, one, i32(2), one, i32(2), i64(4), i32(4), i32(4),
+                              i32(tails), f64(3.0), f64(1e-3), f64(1e-3), f64(1e-3), f64(1.0), i32(0), i32(0), i32(0), tt,
+                              null, null, null, null)
+    assert lib.nf_rqs_coupling_ft(*args(1, one)) == -22
+    assert lib.nf_rqs_coupling_ft(*args(3, null)) == -14
+    assert lib.nf_bias_leaky_relu(one, null, i64(2), i32(3), i64(4), f64(0.0), i32(0), null) == -14
+    assert lib.nf_bias_leaky_relu(one, one, i64(2), i32(0), i64(4), f64(0.0), i32(0), null) == -22
+
+
 def test_masks_bit_exact(nfa):
     m = nfa.utils.create_alternating_binary_mask(7, even=False)
     assert m.dtype == torch.uint8 and m.tolist() == [0, 1, 0, 1, 0, 1, 0]
