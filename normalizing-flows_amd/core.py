@@ -11,7 +11,6 @@ Differences that are deliberate (MI355X-first):
     hipGraph per batch shape and replays it, removing the per-launch host overhead;
   * inference only: kernels do not build an autograd graph (forward_kld returns the loss VALUE).
 """
-import numpy as np
 import torch
 from torch import nn
 

@@ -11,7 +11,7 @@ from torch import nn
 
 from .. import ops
 from ..autograd import ActNormFn, AffineCouplingFn, MaskedAffineFn, needs_grad
-from .base import Flow, new_ld, run_flow
+from .base import Flow, run_flow
 from .reshape import Merge, Split
 
 

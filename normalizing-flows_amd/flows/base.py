@@ -12,7 +12,7 @@ fresh tensor that the container then adds with another launch.
 import torch
 from torch import nn
 
-from .. import _lib as L
+
 
 
 class Flow(nn.Module):
