@@ -9,7 +9,8 @@ Differences that are deliberate (MI355X-first):
     protocol (flows/base.py) instead of one extra elementwise launch per layer;
   * `use_graphs(True)` records a whole log_prob / sample pass (64+ launches for the 32-layer RQ-NSF) into a
     hipGraph per batch shape and replays it, removing the per-launch host overhead;
-  * inference only: kernels do not build an autograd graph (forward_kld returns the loss VALUE).
+  * training runs the same HIP forward kernels inside torch.autograd.Functions (autograd.py); recorded graphs are
+    bypassed whenever gradients are required.
 """
 import torch
 from torch import nn
@@ -190,7 +191,7 @@ class NormalizingFlow(nn.Module):
         return self._graphs.run(("log_prob", tuple(x.shape), x.dtype), self._log_prob_impl, x)
 
     def forward_kld(self, x):
-        """-mean(log q(x)) (core.py:87-102); value only (no autograd)."""
+        """-mean(log q(x)) (core.py:87-102); differentiable when the parameters require gradients."""
         return -torch.mean(self.log_prob(x))
 
     def _sample_impl(self, eps):
