@@ -37,12 +37,16 @@ def c1():
     m = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(2), fl).to(dev)
     x = torch.randn(1024, 2, device=dev)
     with torch.no_grad():
-        m.log_prob(x)
+        nll = float(-m.log_prob(x).mean()) / 2
         e = timed(lambda: m.log_prob(x), 50)
+        es = timed(lambda: m.sample(1024), 50)
         m.use_graphs(True)
         g = timed(lambda: m.log_prob(x), 200)
-    print("config 1 RealNVP B=1024: eager %.1f us (%.2f M samples/s), hipGraph %.1f us (%.2f M samples/s)" % (
-        e * 1e6, 1024 / e / 1e6, g * 1e6, 1024 / g / 1e6))
+        eps = torch.randn(1024, 2, device=dev)
+        gs = timed(lambda: m.sample_from_noise(eps), 200)
+    print("config 1 RealNVP B=1024: log_prob eager %.1f us (%.2f M samples/s), hipGraph %.1f us (%.2f M samples/s); "
+          "sample eager %.1f us, hipGraph %.1f us (%.2f M samples/s); NLL %.4f nats/dim" % (
+              e * 1e6, 1024 / e / 1e6, g * 1e6, 1024 / g / 1e6, es * 1e6, gs * 1e6, 1024 / gs / 1e6, nll))
 
 
 def c4():
@@ -63,12 +67,14 @@ def c4():
     m = nfa.MultiscaleFlow(q0, flows, merges, class_cond=False).to(dev)
     x = torch.rand(256, 3, 32, 32, device=dev)
     with torch.no_grad():
-        m.log_prob(x)  # ActNorm data-dependent init
+        nll = float(-m.log_prob(x).mean()) / (3 * 32 * 32)  # first call: ActNorm data-dependent init
         e = timed(lambda: m.log_prob(x), 5)
+        es = timed(lambda: m.sample(256), 5)
         m.use_graphs(True)
         g = timed(lambda: m.log_prob(x), 10)
-    print("config 4 Glow L=3 K=32 B=256: eager %.1f ms (%.0f img/s), hipGraph %.1f ms (%.0f img/s)" % (
-        e * 1e3, 256 / e, g * 1e3, 256 / g))
+    print("config 4 Glow L=3 K=32 B=256: log_prob eager %.1f ms (%.0f img/s), hipGraph %.1f ms (%.0f img/s); "
+          "sample %.1f ms (%.0f img/s); NLL %.4f nats/dim (untrained, after ActNorm init)" % (
+              e * 1e3, 256 / e, g * 1e3, 256 / g, es * 1e3, 256 / es, nll))
 
 
 def c5():
