@@ -316,6 +316,17 @@ int nf_diag_gaussian_log_prob_rows(const void *z, const void *loc_rows, const vo
                                    int64_t B, int64_t d, int acc, int dtype, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * A RealNVP-style stack as ONE launch: MaskedAffineFlow layers (affine/coupling.py:209-229) whose s / t
+ * conditioners are small MLPs (nets/mlp.py:5-58, Linear + LeakyReLU, widths <= 64), interleaved with
+ * AffineConstFlow / ActNorm layers (coupling.py:38-54); the model of examples/real_nvp.ipynb (BASELINE configs[0]).
+ *   z, y (B, d) float32, d <= 16; blob: host-packed parameters of the stack (normflows_amd/core.py documents the
+ *   layout); hmax = widest MLP layer; direction 0 applies the records in order with the forward formulas,
+ *   1 in reverse order with the inverse formulas; logdet (B) combined according to `acc`.
+ */
+int nf_realnvp_chain(const void *z, void *y, void *logdet, const void *blob, int64_t B, int d, int hmax, int direction,
+                     int acc, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * MaskedAffineAutoregressive element-wise transform (MAF).  Replaces
  * normflows/flows/affine/autoregressive.py:98-128 (_elementwise_forward / _elementwise_inverse).
  *   params (B, D, 2): MADE output viewed as (unconstrained_scale, shift) per feature (:124-128);

@@ -44,6 +44,98 @@ def _run_pairs(pairs, z, inverse, ld, acc):
     return z
 
 
+# ---- RealNVP-style runs: MaskedAffineFlow(MLP, MLP) / ActNorm stacks as one launch (csrc/realnvp_chain.hip) --------------
+def _plain_mlp(net):
+    """(linears, slope) if `net` is a nets.MLP made of Linear + LeakyReLU only (mlp.py:5-58 without output_fn/dropout)."""
+    from . import nets
+    if not isinstance(net, nets.MLP):
+        return None
+    lin, slope = [], 0.0
+    mods = list(net.net)
+    for i, m in enumerate(mods):
+        if isinstance(m, nn.Linear):
+            lin.append(m)
+        elif isinstance(m, nn.LeakyReLU):
+            if i == 0 or not isinstance(mods[i - 1], nn.Linear) or i == len(mods) - 1:
+                return None
+            slope = float(m.negative_slope)
+        else:
+            return None
+    if not lin or any(isinstance(mods[i], nn.Linear) and isinstance(mods[i + 1], nn.Linear) for i in range(len(mods) - 1)):
+        return None
+    return lin, slope
+
+
+def _realnvp_record_ok(f, d):
+    """True when flow `f` can be a record of the RealNVP chain kernel for (B, d) inputs."""
+    from .flows.affine import AffineConstFlow, MaskedAffineFlow
+    from .flows.normalization import ActNorm
+    if isinstance(f, MaskedAffineFlow):
+        if f.b.numel() != d:
+            return False
+        for net in (f.s, f.t):
+            if net is None:
+                continue
+            pm = _plain_mlp(net)
+            if pm is None or pm[0][0].in_features != d or pm[0][-1].out_features != d:
+                return False
+            if any(l.out_features > 64 or l.bias is None for l in pm[0]):
+                return False
+        return True
+    if isinstance(f, AffineConstFlow):
+        if f.s.numel() != d or f.t.numel() != d:
+            return False
+        if isinstance(f, ActNorm):
+            if f._init_known is None:
+                f._init_known = bool(f.data_dep_init_done.item() > 0.0)
+            return f._init_known          # the data-dependent initialisation needs the layer-by-layer path once
+        return True
+    return False
+
+
+def _pack_realnvp(run, d, device):
+    """Blob of csrc/realnvp_chain.hip for the flows `run` (stored in forward order)."""
+    from .flows.affine import MaskedAffineFlow
+    recs, hmax = [], d
+    for f in run:
+        if isinstance(f, MaskedAffineFlow):
+            r = [torch.tensor([2.0, float(f.s is not None), float(f.t is not None), 0.0]), f.b.detach().reshape(-1).float().cpu()]
+            for net in (f.s, f.t):
+                if net is None:
+                    continue
+                lin, slope = _plain_mlp(net)
+                sizes = [lin[0].in_features] + [l.out_features for l in lin]
+                hmax = max(hmax, max(sizes))
+                r.append(torch.tensor([float(len(lin)), slope] + [float(v) for v in sizes]))
+                for l in lin:
+                    r += [l.weight.detach().reshape(-1).float().cpu(), l.bias.detach().reshape(-1).float().cpu()]
+            recs.append(torch.cat(r))
+        else:
+            recs.append(torch.cat([torch.tensor([1.0, 0.0, 0.0, 0.0]), f.s.detach().reshape(-1).float().cpu(),
+                                   f.t.detach().reshape(-1).float().cpu()]))
+    offs, o = [], 4 + len(recs)
+    for r in recs:
+        offs.append(float(o))
+        o += r.numel()
+    blob = torch.cat([torch.tensor([float(len(recs)), float(d), float(hmax), 0.0] + offs)] + recs)
+    return blob.to(device), hmax
+
+
+def _run_realnvp(run, cache, z, inverse, ld, acc):
+    from . import ops
+    d = z.shape[1]
+    key = tuple((p.data_ptr(), p._version) for f in run for p in list(f.parameters()) + list(f.buffers())) + (str(z.device),)
+    ent = cache.get(id(run[0]))
+    if ent is None or ent[0] != key:
+        ent = (key,) + _pack_realnvp(run, d, z.device)
+        cache[id(run[0])] = ent
+    y, _ = ops.realnvp_chain(z, ent[1], d, ent[2], 1 if inverse else 0, logdet=ld, acc=acc)
+    return y
+
+
+_realnvp_cache = {}
+
+
 def run_chain(flows, z, inverse, ld, acc):
     """Run a list of flows in order (inverse=False) or reversed with .inverse (inverse=True), folding log-dets into
     `ld`.  Adjacent [CoupledRationalQuadraticSpline, LULinearPermute] pairs of the supported shape are fused
@@ -60,9 +152,21 @@ def run_chain(flows, z, inverse, ld, acc):
             pending.clear()
         return zz
 
+    rn_ok = (z.dim() == 2 and z.dtype == torch.float32 and z.is_cuda and z.shape[1] <= 16
+             and not (torch.is_grad_enabled() and any(p.requires_grad for f_ in flows for p in f_.parameters())))
     while k < n:
         i = order[k]
         f = flows[i]
+        if rn_ok and _realnvp_record_ok(f, z.shape[1]):
+            k2 = k
+            while k2 < n and _realnvp_record_ok(flows[order[k2]], z.shape[1]):
+                k2 += 1
+            if k2 - k >= 2:   # a run of at least two layers: one launch
+                z = flush(z)
+                idx = sorted(order[k:k2])
+                z = _run_realnvp([flows[q] for q in idx], _realnvp_cache, z, inverse, ld, acc)
+                k = k2
+                continue
         pair = None
         if k + 1 < n:
             j = order[k + 1]

@@ -506,3 +506,22 @@ def bias_leaky_relu_(y, bias, negative_slope):
                                     i32(L.dtype_code(y)), L.stream())
     L.check(rc, "nf_bias_leaky_relu")
     return y
+
+
+def realnvp_chain(z, blob, d, hmax, direction, logdet=None, acc=None):
+    """A stack of MaskedAffineFlow(MLP s, MLP t) / ActNorm layers in one launch (nf_realnvp_chain)."""
+    L.require_device(z, blob)
+    if z.dtype != torch.float32:
+        raise NotImplementedError("realnvp_chain: float32 only")
+    z = z.contiguous()
+    B = z.shape[0]
+    y = torch.empty_like(z)
+    if logdet is None:
+        logdet = torch.empty(B, dtype=z.dtype, device=z.device)
+        acc = L.LD_WRITE
+    elif acc is None:
+        acc = L.LD_ADD
+    rc = L.lib().nf_realnvp_chain(ptr(z), ptr(y), ptr(logdet), ptr(blob), i64(B), i32(d), i32(hmax), i32(direction),
+                                  i32(acc), L.stream())
+    L.check(rc, "nf_realnvp_chain")
+    return y, logdet

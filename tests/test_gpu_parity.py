@@ -1026,3 +1026,56 @@ def test_fused_chain_vs_unfused_randomized(nfa, seed):
     # use different transcendental implementations, so their samples -- and log q at those samples -- drift apart more
     assert float(((lq - lq2).abs() / lq2.abs().clamp_min(1.0)).max()) < 1e-3
     assert_close(N(xs), N(xs2), what="samples", rtol=2e-3, atol=2e-3)
+
+
+# ---- RealNVP stack as one launch (csrc/realnvp_chain.hip) ------------------------------------------------------------
+def _realnvp_model(nfa, d, hidden, nlayers, seed, leaky=0.0):
+    torch.manual_seed(seed)
+    b = torch.tensor([1.0 if i % 2 == 0 else 0.0 for i in range(d)])
+    fl = []
+    for i in range(nlayers):
+        s_ = nfa.nets.MLP([d] + hidden + [d], leaky=leaky, init_zeros=False)
+        t_ = nfa.nets.MLP([d] + hidden + [d], leaky=leaky, init_zeros=False) if i % 3 != 2 else None
+        fl += [nfa.flows.MaskedAffineFlow(b if i % 2 == 0 else 1 - b, t_, s_), nfa.flows.ActNorm(d)]
+    return nfa.NormalizingFlow(nfa.distributions.DiagGaussian(d, trainable=False), fl).to(DEV)
+
+
+@pytest.mark.parametrize("d,hidden,nl,B,leaky", [(2, [4], 4, 1024, 0.0), (5, [16, 8], 3, 333, 0.1), (16, [64], 2, 65, 0.0),
+                                                 (3, [], 2, 7, 0.0)])
+def test_realnvp_chain_kernel_vs_layerwise(nfa, d, hidden, nl, B, leaky):
+    """The one-launch RealNVP chain (MaskedAffineFlow with MLP conditioners + ActNorm) against the layer-by-layer kernels,
+    both directions, after the data-dependent ActNorm initialisation."""
+    from normflows_amd import core
+    m = _realnvp_model(nfa, d, hidden, nl, seed=d + B, leaky=leaky)
+    x = torch.randn(B, d, generator=torch.Generator().manual_seed(B)).to(DEV)
+    with torch.no_grad():
+        m.log_prob(x)                                   # ActNorm init (layer-by-layer path)
+        calls = []
+        orig = core._run_realnvp
+        core._run_realnvp = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            lp = m.log_prob(x)
+            z1, ld1 = m.inverse_and_log_det(x)
+            x1, lf1 = m.forward_and_log_det(x)
+        finally:
+            core._run_realnvp = orig
+        assert len(calls) == 3                          # every pass was one chain launch
+        lp0 = torch.zeros(B, device=DEV)
+        zz = x
+        for f in reversed(list(m.flows)):
+            zz, l_ = f.inverse(zz)
+            lp0 = lp0 + l_
+        ref_lp = lp0 + m.q0.log_prob(zz)
+        assert_close(N(lp), N(ref_lp), what="log_prob", rtol=1e-5, atol=1e-5)
+        assert_close(N(z1), N(zz), what="z", rtol=1e-5, atol=1e-5)
+        assert_close(N(ld1), N(lp0), what="ld", rtol=1e-5, atol=1e-5)
+        xf, lf = x, torch.zeros(B, device=DEV)
+        for f in m.flows:
+            xf, l_ = f.forward(xf)
+            lf = lf + l_
+        assert_close(N(x1), N(xf), what="forward", rtol=1e-5, atol=1e-5)
+        assert_close(N(lf1), N(lf), what="forward ld", rtol=1e-5, atol=1e-5)
+        # a parameter update re-packs the blob
+        m.flows[1].t.add_(0.25)           # in place under no_grad, as an optimiser step: bumps the version counter
+        lp2 = m.log_prob(x)
+        assert float((lp2 - lp).abs().max()) > 1e-3
