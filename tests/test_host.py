@@ -97,6 +97,11 @@ def test_c_abi_argument_validation_newer_entry_points(nfa):
     assert lib.nf_rqs_coupling_ft(*args(3, null)) == -14
     assert lib.nf_bias_leaky_relu(one, null, i64(2), i32(3), i64(4), f64(0.0), i32(0), null) == -14
     assert lib.nf_bias_leaky_relu(one, one, i64(2), i32(0), i64(4), f64(0.0), i32(0), null) == -22
+    # RealNVP chain: at most 16 coordinates and 64-wide conditioners
+    assert lib.nf_realnvp_chain(one, one, one, one, i64(8), i32(17), i32(8), i32(0), i32(0), null) == -95
+    assert lib.nf_realnvp_chain(one, one, one, one, i64(8), i32(2), i32(65), i32(0), i32(0), null) == -95
+    assert lib.nf_realnvp_chain(one, one, one, null, i64(8), i32(2), i32(4), i32(0), i32(0), null) == -14
+    assert lib.nf_realnvp_chain(one, one, one, one, i64(8), i32(2), i32(4), i32(2), i32(0), null) == -22
 
 
 def test_masks_bit_exact(nfa):
