@@ -10,57 +10,57 @@ from .. import ops
 from .base import Flow
 
 
-def _checkerboard(z_size, inv, device):
-    """Checkerboard colouring of reshape.py:35-46 for a tensor of size z_size (batch dim included)."""
-    n_dims = len(z_size)
-    cb0, cb1 = 0, 1
-    for i in range(1, n_dims):
-        cb0_, cb1_ = cb0, cb1
-        cb0 = [cb0_ if j % 2 == 0 else cb1_ for j in range(z_size[n_dims - i])]
-        cb1 = [cb1_ if j % 2 == 0 else cb0_ for j in range(z_size[n_dims - i])]
-    cb = cb1 if inv else cb0
-    cb = torch.tensor(cb)[None].repeat(z_size[0], *((n_dims - 1) * [1]))
-    return cb.to(device)
+def _checkerboard(shape, inverted, device):
+    """Boolean checkerboard over the non-batch dims of `shape`: True where the coordinate sum is odd (reshape.py:35-46
+    builds the same colouring by nested alternation); `inverted` flips it."""
+    parity = torch.zeros(shape[1:], dtype=torch.long, device=device)
+    for axis, n in enumerate(shape[1:]):
+        view = [1] * (len(shape) - 1)
+        view[axis] = n
+        parity = parity + torch.arange(n, device=device).view(view)
+    odd = (parity % 2 == 1)
+    return (~odd if inverted else odd).expand(shape)
+
+
+_CHANNEL_ORDER = {"channel": (0, 1), "channel_inv": (1, 0)}   # which chunk is z1 / z2
 
 
 class Split(Flow):
-    """Split features into two sets (reshape.py:9-85); modes channel, channel_inv, checkerboard[_inv]."""
+    """Split features into two sets (reshape.py:9-85); modes channel, channel_inv, checkerboard[_inv].  The checkerboard
+    halves keep the row-major order of their elements and halve the last dim."""
 
     def __init__(self, mode="channel"):
         super().__init__()
         self.mode = mode
 
-    def forward(self, z):
-        if self.mode == "channel":
-            z1, z2 = z.chunk(2, dim=1)
-        elif self.mode == "channel_inv":
-            z2, z1 = z.chunk(2, dim=1)
-        elif "checkerboard" in self.mode:
-            cb = _checkerboard(list(z.size()), "inv" in self.mode, z.device)
-            z_size = z.size()
-            z1 = z.reshape(-1)[torch.nonzero(cb.view(-1), as_tuple=False)].view(*z_size[:-1], -1)
-            z2 = z.reshape(-1)[torch.nonzero((1 - cb).view(-1), as_tuple=False)].view(*z_size[:-1], -1)
-        else:
+    def _check_mode(self):
+        if self.mode not in _CHANNEL_ORDER and "checkerboard" not in self.mode:
             raise NotImplementedError("Mode " + self.mode + " is not implemented.")
-        return [z1, z2], 0
+
+    def forward(self, z):
+        self._check_mode()
+        if self.mode in _CHANNEL_ORDER:
+            halves = z.chunk(2, dim=1)
+            i1, i2 = _CHANNEL_ORDER[self.mode]
+            return [halves[i1], halves[i2]], 0
+        pick = _checkerboard(tuple(z.shape), "inv" in self.mode, z.device)
+        half_shape = tuple(z.shape[:-1]) + (-1,)
+        return [z[pick].view(half_shape), z[~pick].view(half_shape)], 0
 
     def inverse(self, z):
+        self._check_mode()
         z1, z2 = z
-        if self.mode == "channel":
-            z = torch.cat([z1, z2], 1)
-        elif self.mode == "channel_inv":
-            z = torch.cat([z2, z1], 1)
-        elif "checkerboard" in self.mode:
-            n_dims = z1.dim()
-            z_size = list(z1.size())
-            z_size[-1] *= 2
-            cb = _checkerboard(z_size, "inv" in self.mode, z1.device)
-            z1 = z1[..., None].repeat(*(n_dims * [1]), 2).view(*z_size[:-1], -1)
-            z2 = z2[..., None].repeat(*(n_dims * [1]), 2).view(*z_size[:-1], -1)
-            z = cb * z1 + (1 - cb) * z2
-        else:
-            raise NotImplementedError("Mode " + self.mode + " is not implemented.")
-        return z, 0
+        if self.mode in _CHANNEL_ORDER:
+            parts = [None, None]
+            i1, i2 = _CHANNEL_ORDER[self.mode]
+            parts[i1], parts[i2] = z1, z2
+            return torch.cat(parts, 1), 0
+        shape = tuple(z1.shape[:-1]) + (2 * z1.shape[-1],)
+        pick = _checkerboard(shape, "inv" in self.mode, z1.device)
+        out = torch.empty(shape, dtype=z1.dtype, device=z1.device)
+        out[pick] = z1.reshape(-1)
+        out[~pick] = z2.reshape(-1)
+        return out, 0
 
     def _run(self, z, inverse, ld, acc, **kw):
         z, _ = self.inverse(z) if inverse else self.forward(z)
@@ -74,10 +74,10 @@ class Merge(Split):
         super().__init__(mode)
 
     def forward(self, z):
-        return super().inverse(z)
+        return Split.inverse(self, z)
 
     def inverse(self, z):
-        return super().forward(z)
+        return Split.forward(self, z)
 
 
 class Squeeze(Flow):

@@ -1,26 +1,36 @@
-"""Bits per dimension of image models (normflows/utils/eval.py:5-64): host-side bookkeeping around model.log_prob."""
-import numpy as np
+"""Bits per dimension of image models (normflows/utils/eval.py:5-64): host-side bookkeeping around model.log_prob for
+data that was logit-transformed with parameter alpha = trans_param[0] before training."""
+import math
+
 import torch
+
+_LN2 = math.log(2.0)
+
+
+def _logit_correction_bits(x):
+    """Per-sample sum of log2 sigmoid(x) + log2 sigmoid(-x): the Jacobian of the logit preprocessing, in bits."""
+    ls = torch.nn.functional.logsigmoid
+    per_elem = (ls(x) + ls(-x)) / _LN2
+    return per_elem.flatten(1).sum(1)
 
 
 def bitsPerDim(model, x, y=None, trans="logit", trans_param=[0.05]):
-    """eval.py:5-34: bits/dim of a batch that was logit-transformed for training."""
+    """Bits per dimension of a batch under `model` (eval.py:5-34)."""
     if trans != "logit":
         raise NotImplementedError("The transformation " + trans + " is not implemented.")
-    dims = int(np.prod(x.shape[1:]))
-    log_q = model.log_prob(x) if y is None else model.log_prob(x, y)
-    sum_dims = list(range(1, x.dim()))
-    ls = torch.nn.functional.logsigmoid
-    sig = (torch.sum(ls(x), sum_dims) + torch.sum(ls(-x), sum_dims)) / np.log(2)
-    return -log_q / dims / np.log(2) - np.log2(1 - trans_param[0]) + 8 + sig / dims
+    dims = x[0].numel()
+    log_q = model.log_prob(x, y) if y is not None else model.log_prob(x)
+    nats_to_bits = 1.0 / (dims * _LN2)
+    return 8.0 - math.log2(1.0 - trans_param[0]) - log_q * nats_to_bits + _logit_correction_bits(x) / dims
 
 
 def bitsPerDimDataset(model, data_loader, class_cond=True, trans="logit", trans_param=[0.05]):
-    """eval.py:37-64: NaN-skipping average over a data loader."""
-    n, b_cum = 0, 0.0
+    """NaN-skipping average of bitsPerDim over a data loader (eval.py:37-64)."""
+    total, count = 0.0, 0
     with torch.no_grad():
-        for x, y in iter(data_loader):
-            b = bitsPerDim(model, x, y.to(x.device) if class_cond else None, trans, trans_param).to("cpu").numpy()
-            b_cum += np.nansum(b)
-            n += len(x) - np.sum(np.isnan(b))
-    return b_cum / n
+        for x, y in data_loader:
+            b = bitsPerDim(model, x, y.to(x.device) if class_cond else None, trans, trans_param)
+            ok = ~torch.isnan(b)
+            total += float(b[ok].sum())
+            count += int(ok.sum())
+    return total / count
