@@ -66,6 +66,30 @@ class SplineFn(torch.autograd.Function):
         return gx, gcond, guw, guh, gud, None, None, None
 
 
+class CouplingDensityFn(torch.autograd.Function):
+    """The whole density-direction coupling transform (nsf/coupling.py:71-98) on full (B, D) rows as ONE forward and ONE
+    backward launch: transform columns with the per-element parameters `cond`, identity columns with the batch-shared
+    unconditional spline (or copied), split / merge inside the kernels."""
+
+    @staticmethod
+    def forward(ctx, x, cond, uw, uh, ud, iidx, tidx, K, kw):
+        y, ld = ops.rqs_coupling(x, cond.contiguous(), uw, uh, ud, iidx, tidx, K, L.RQS_DENSITY, **kw)
+        ctx.save_for_backward(x, cond, uw, uh, ud, iidx, tidx)
+        ctx.K, ctx.kw = K, kw
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, gy, gld):
+        x, cond, uw, uh, ud, iidx, tidx = ctx.saved_tensors
+        if gy is None:
+            gy = torch.zeros_like(x)
+        if gld is None:
+            gld = torch.zeros(x.shape[0], dtype=x.dtype, device=x.device)
+        gx, gcond, guw, guh, gud = ops.rqs_coupling_bwd(x, gy, gld, cond, uw, uh, ud, iidx, tidx, ctx.K, L.RQS_DENSITY,
+                                                        **ctx.kw)
+        return gx, gcond, guw, guh, gud, None, None, None, None
+
+
 def _assemble_lu(lower_entries, upper_entries, udiag_raw, eps):
     D = udiag_raw.numel()
     dev, dt = udiag_raw.device, udiag_raw.dtype

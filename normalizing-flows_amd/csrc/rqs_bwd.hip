@@ -243,16 +243,16 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
             }
             __syncthreads();
         }
-        for (int el = threadIdx.x; el < ts * D; el += blockDim.x) {
-            const int bl = el / D;
-            const int f = el - bl * D;  // 0..nT-1: transform feature f, nT..D-1: identity feature f - nT
-            const int64_t b = bt + bl;
-            if (f < nT) {
-                if (!do_t) continue;
+        // transform elements and identity elements in two separate passes: within a pass every lane runs the same code
+        // (one mixed pass made each wave execute both heavy branches)
+        if (do_t) {
+            const T div = p.wh_div;
+            for (int el = threadIdx.x; el < ts * nT; el += blockDim.x) {
+                const int bl = el / nT, f = el - bl * nT;
+                const int64_t b = bt + bl;
                 const int col = (int)tidx[f];
-                const T *row = s_cond + (size_t)(bl * nT + f) * P;
-                T *grow = s_g + (size_t)(bl * nT + f) * P;
-                const T div = p.wh_div;
+                const T *row = s_cond + (size_t)el * P;
+                T *grow = s_g + (size_t)el * P;
                 auto wacc = [=](int k) { return row[k] / div; };
                 auto hacc = [=](int k) { return row[K + k] / div; };
                 auto dacc = [=](int k) { return row[2 * K + k]; };
@@ -261,9 +261,12 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
                 auto ad = [=](int j, T g) { grow[2 * K + j] += g; };
                 gx[b * D + col] = rqs_element_bwd<T>(p, x[b * D + col], gy[b * D + col], gld[b], wacc, hacc, dacc,
                                                      inverse, aw, ah, ad);
-            } else {
-                if (!do_i) continue;
-                const int j = f - nT;
+            }
+        }
+        if (do_i) {
+            for (int el = threadIdx.x; el < ts * nI; el += blockDim.x) {
+                const int bl = el / nI, j = el - bl * nI;
+                const int64_t b = bt + bl;
                 const int col = (int)iidx[j];
                 if (!has_uncond) {
                     gx[b * D + col] = gy[b * D + col];
@@ -322,7 +325,8 @@ static int launch_bwd(const void *x, const void *gy, const void *gld, const void
     auto lds_bytes = [&](int ts) {
         return ((size_t)nI * M + (stage ? (size_t)2 * ts * nT * P : 0)) * sizeof(T) + 16;
     };
-    int TS = 256 / D > 0 ? 256 / D : 1;          // samples per tile: ~one element per lane
+    const int nmax = nT > nI ? nT : nI;
+    int TS = nmax > 0 && 256 / nmax > 0 ? 256 / nmax : 1;   // samples per tile: ~one element per lane in each pass
     while (TS > 1 && lds_bytes(TS) > 64 * 1024) TS >>= 1;
     const size_t lds = lds_bytes(TS);
     if (lds > 150 * 1024) return NF_ENOTSUP;

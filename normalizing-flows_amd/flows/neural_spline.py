@@ -18,7 +18,7 @@ from torch import nn
 
 from .. import _lib as L
 from .. import ops
-from ..autograd import SplineFn, needs_grad
+from ..autograd import CouplingDensityFn, SplineFn, needs_grad
 from ..nets import PeriodicFeaturesElementwise, ResidualNet
 from ..utils.masks import create_alternating_binary_mask
 from .base import Flow
@@ -354,9 +354,22 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
         kw = self._kernel_kwargs()
         u = self.unconditional_transform
         ident = inputs.index_select(1, self.identity_features)
+        if not sample:   # nsf/coupling.py:71-98 as one forward + one backward kernel on full rows
+            cond = self.transform_net(ident, context)
+            uw, uh, ud = (u.unnormalized_widths, u.unnormalized_heights, u.unnormalized_derivatives) if u is not None \
+                else (None, None, None)
+            outputs, log_det = CouplingDensityFn.apply(inputs.contiguous(), cond, uw, uh, ud, self.identity_features,
+                                                       self.transform_features, self.num_bins, kw)
+            if ld is not None:
+                if acc is None or acc > 0:
+                    ld += log_det
+                else:
+                    ld -= log_det
+                return outputs, ld
+            return outputs, log_det
         trans = inputs.index_select(1, self.transform_features)
         ld_i = None
-        if not sample:   # nsf/coupling.py:71-98
+        if not sample:
             cond = self.transform_net(ident, context)
             trans, ld_t = SplineFn.apply(trans, cond, None, None, None, self.num_bins, False, kw)
             if u is not None:
