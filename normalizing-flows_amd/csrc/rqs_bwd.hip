@@ -101,77 +101,62 @@ __device__ __forceinline__ void rqs_eval_bin_dual(T x, T cw, T cwh, T ch, T chh,
     }
 }
 
-// Gradient of one spline element w.r.t. x and its raw parameters.  wacc/hacc return the parameters divided by
-// wh_div; dacc the raw derivative logits.  add_w(i, g), add_h(i, g), add_d(j, g) receive the gradients of the RAW
-// parameters (already including 1 / wh_div).  Returns gx.
-template <typename T, typename WAcc, typename HAcc, typename DAcc, typename AW, typename AH, typename AD>
-__device__ __forceinline__ T rqs_element_bwd(const RqsParams<T> &p, T x, T gy_up, T gl_up, const WAcc &wacc,
-                                             const HAcc &hacc, const DAcc &dacc, bool inverse, const AW &add_w,
-                                             const AH &add_h, const AD &add_d) {
+// Softmax probabilities of K logits read through `acc` (already divided by wh_div), written through `put`: the only
+// transcendental pass over the widths / heights; everything downstream works on the probabilities.
+template <typename T, typename Acc, typename Put>
+__device__ __forceinline__ void rqs_softmax_probs(int K, const Acc &acc, const Put &put) {
+    T m = acc(0);
+    for (int k = 1; k < K; ++k) m = M<T>::fmax(m, acc(k));
+    T s = T(0);
+    for (int k = 0; k < K; ++k) s += M<T>::exp(acc(k) - m);
+    const T inv = T(1) / s;
+    for (int k = 0; k < K; ++k) put(k, M<T>::exp(acc(k) - m) * inv);
+}
+
+// Gradient of one spline element w.r.t. x and its raw parameters, given the softmax probabilities pw(k), ph(k) of its
+// widths / heights (rqs_softmax_probs) and the raw derivative logits dacc(j).  add_w(i, g), add_h(i, g), add_d(j, g)
+// receive the gradients of the RAW parameters (already including 1 / wh_div).  Returns gx.
+template <typename T, typename PW, typename PH, typename DAcc, typename AW, typename AH, typename AD>
+__device__ __forceinline__ T rqs_element_bwd(const RqsParams<T> &p, T x, T gy_up, T gl_up, const PW &pw, const PH &ph,
+                                             const DAcc &dacc, bool inverse, const AW &add_w, const AH &add_h,
+                                             const AD &add_d) {
     if (!rqs_inside(p, x)) return gy_up;  // identity outside the tails (utils/splines.py:40-41), lad = 0
     const int K = p.K;
-    T mw = wacc(0), mh = hacc(0);
-    for (int k = 1; k < K; ++k) {
-        mw = M<T>::fmax(mw, wacc(k));
-        mh = M<T>::fmax(mh, hacc(k));
-    }
-    T sw = T(0), sh = T(0);
-    for (int k = 0; k < K; ++k) {
-        sw += M<T>::exp(wacc(k) - mw);
-        sh += M<T>::exp(hacc(k) - mh);
-    }
-    // knots of both axes around the bin (searched axis: widths for forward, heights for inverse)
+    // knots of both axes around the bin: knot_j = lo + (hi - lo)(j min + scale C_j), C_j = sum_{i<j} prob_i, ends pinned.
+    // searched axis: widths for the forward spline, heights for the inverse.
+    const T s_lo = inverse ? p.bottom : p.left, s_hi = inverse ? p.top : p.right;
+    const T s_min = inverse ? p.min_h : p.min_w, s_scale = inverse ? p.scale_h : p.scale_w;
     int bin = 0;
-    T cw_lo = p.left, cw_hi = p.left, Cw_lo = T(0), Cw_hi = T(0);
+    T sk_lo = s_lo, sk_hi = s_lo, Cs_lo = T(0), Cs_hi = T(0);
     {
-        T cum = T(0), csm = T(0), knot = p.left, cprev = T(0);
-        T ch_dummy = T(0);
-        (void)ch_dummy;
-        // first pass: widths knots with bin search if !inverse, else just record all needed later
-        if (!inverse) {
-            for (int k = 0; k < K; ++k) {
-                const T sm = M<T>::exp(wacc(k) - mw) / sw;
-                cum += p.min_w + p.scale_w * sm;
-                const T next = (k == K - 1) ? p.right : (p.right - p.left) * cum + p.left;
-                if (k == 0 || x >= knot) { bin = k; cw_lo = knot; cw_hi = next; Cw_lo = cprev; Cw_hi = csm + sm; }
-                knot = next;
-                cprev = csm + sm;
-                csm += sm;
-            }
-        }
-    }
-    T ch_lo = p.bottom, ch_hi = p.bottom, Ch_lo = T(0), Ch_hi = T(0);
-    if (inverse) {
-        T cum = T(0), csm = T(0), knot = p.bottom, cprev = T(0);
+        T cum = T(0), csm = T(0), knot = s_lo;
         for (int k = 0; k < K; ++k) {
-            const T sm = M<T>::exp(hacc(k) - mh) / sh;
-            cum += p.min_h + p.scale_h * sm;
-            const T next = (k == K - 1) ? p.top : (p.top - p.bottom) * cum + p.bottom;
-            if (k == 0 || x >= knot) { bin = k; ch_lo = knot; ch_hi = next; Ch_lo = cprev; Ch_hi = csm + sm; }
-            knot = next;
-            cprev = csm + sm;
-            csm += sm;
-        }
-        cum = T(0); csm = T(0); knot = p.left;
-        for (int k = 0; k <= bin; ++k) {
-            const T sm = M<T>::exp(wacc(k) - mw) / sw;
-            cum += p.min_w + p.scale_w * sm;
-            const T next = (k == K - 1) ? p.right : (p.right - p.left) * cum + p.left;
-            cw_lo = knot; cw_hi = next; Cw_lo = csm; Cw_hi = csm + sm;
-            knot = next;
-            csm += sm;
-        }
-    } else {
-        T cum = T(0), csm = T(0), knot = p.bottom;
-        for (int k = 0; k <= bin; ++k) {
-            const T sm = M<T>::exp(hacc(k) - mh) / sh;
-            cum += p.min_h + p.scale_h * sm;
-            const T next = (k == K - 1) ? p.top : (p.top - p.bottom) * cum + p.bottom;
-            ch_lo = knot; ch_hi = next; Ch_lo = csm; Ch_hi = csm + sm;
+            const T sm = inverse ? ph(k) : pw(k);
+            cum += s_min + s_scale * sm;
+            const T next = (k == K - 1) ? s_hi : (s_hi - s_lo) * cum + s_lo;
+            if (k == 0 || x >= knot) { bin = k; sk_lo = knot; sk_hi = next; Cs_lo = csm; Cs_hi = csm + sm; }
             knot = next;
             csm += sm;
         }
     }
+    const T o_lo = inverse ? p.left : p.bottom, o_hi = inverse ? p.right : p.top;
+    const T o_min = inverse ? p.min_w : p.min_h, o_scale = inverse ? p.scale_w : p.scale_h;
+    T ok_lo = o_lo, ok_hi = o_lo, Co_lo = T(0), Co_hi = T(0);
+    {
+        T cum = T(0), csm = T(0), knot = o_lo;
+        for (int k = 0; k <= bin; ++k) {
+            const T sm = inverse ? pw(k) : ph(k);
+            cum += o_min + o_scale * sm;
+            const T next = (k == K - 1) ? o_hi : (o_hi - o_lo) * cum + o_lo;
+            ok_lo = knot; ok_hi = next; Co_lo = csm; Co_hi = csm + sm;
+            knot = next;
+            csm += sm;
+        }
+    }
+    const T cw_lo = inverse ? ok_lo : sk_lo, cw_hi = inverse ? ok_hi : sk_hi;
+    const T ch_lo = inverse ? sk_lo : ok_lo, ch_hi = inverse ? sk_hi : ok_hi;
+    const T Cw_lo = inverse ? Co_lo : Cs_lo, Cw_hi = inverse ? Co_hi : Cs_hi;
+    const T Ch_lo = inverse ? Cs_lo : Co_lo, Ch_hi = inverse ? Cs_hi : Co_hi;
     const T r0 = rqs_dlogit(p, dacc, bin), r1 = rqs_dlogit(p, dacc, bin + 1);
     const T d0 = p.min_d + softplus(r0), d1 = p.min_d + softplus(r1);
     T gy[7], gl[7];
@@ -179,16 +164,16 @@ __device__ __forceinline__ T rqs_element_bwd(const RqsParams<T> &p, T x, T gy_up
     T g[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) g[i] = gy_up * gy[i] + gl_up * gl[i];
-    // ---- knots -> raw widths / heights ----
+    // ---- knots -> raw widths / heights: d knot_j / d raw_i = (hi - lo) scale prob_i ([i < j] - C_j) / wh_div ----
     const T g_cw_lo = bin == 0 ? T(0) : g[1], g_cw_hi = bin == K - 1 ? T(0) : g[2];  // pinned end knots are constants
     const T g_ch_lo = bin == 0 ? T(0) : g[3], g_ch_hi = bin == K - 1 ? T(0) : g[4];
     const T fw = (p.right - p.left) * p.scale_w / p.wh_div, fh = (p.top - p.bottom) * p.scale_h / p.wh_div;
+    const T base_w = g_cw_lo * Cw_lo + g_cw_hi * Cw_hi, base_h = g_ch_lo * Ch_lo + g_ch_hi * Ch_hi;
     for (int i = 0; i < K; ++i) {
-        const T smw = M<T>::exp(wacc(i) - mw) / sw, smh = M<T>::exp(hacc(i) - mh) / sh;
-        const T tw = g_cw_lo * ((i < bin ? T(1) : T(0)) - Cw_lo) + g_cw_hi * ((i < bin + 1 ? T(1) : T(0)) - Cw_hi);
-        const T th = g_ch_lo * ((i < bin ? T(1) : T(0)) - Ch_lo) + g_ch_hi * ((i < bin + 1 ? T(1) : T(0)) - Ch_hi);
-        add_w(i, fw * smw * tw);
-        add_h(i, fh * smh * th);
+        const T tw = (i < bin ? g_cw_lo : T(0)) + (i < bin + 1 ? g_cw_hi : T(0)) - base_w;
+        const T th = (i < bin ? g_ch_lo : T(0)) + (i < bin + 1 ? g_ch_hi : T(0)) - base_h;
+        add_w(i, fw * pw(i) * tw);
+        add_h(i, fh * ph(i) * th);
     }
     // ---- derivatives -> raw logits (softplus' = sigmoid; padded/edge logits are constants) ----
     auto raw_index = [&](int j) -> int {  // padded logit j -> raw index, or -1 for a constant
@@ -219,7 +204,8 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
     const int K = p.K, nd = p.nd, M = 2 * K + nd;
     const int P = M | 1;                         // LDS row pitch (odd)
     T *s_acc = reinterpret_cast<T *>(smem_raw);  // nI * M block-local accumulators of the shared parameters
-    T *s_cond = s_acc + (size_t)nI * M;          // TS*nT rows, pitch P
+    T *s_prob = s_acc + (size_t)nI * M;          // nI * 2K softmax probabilities of the shared widths / heights
+    T *s_cond = s_prob + (size_t)nI * 2 * K;     // TS*nT rows, pitch P
     T *s_g = s_cond + (size_t)TS * nT * P;       // gradient rows, pitch P
     const bool do_t = mode != NF_RQS_SAMPLE_IDENTITY, do_i = mode != NF_RQS_SAMPLE_TRANSFORM;
     const bool inverse = mode != NF_RQS_DENSITY;
@@ -227,6 +213,13 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
     const bool stage = do_t && nT > 0;
     if (do_i && has_uncond) {
         for (int i = threadIdx.x; i < nI * M; i += blockDim.x) s_acc[i] = T(0);
+        // batch-shared parameters: their softmax is computed once per workgroup, not once per element
+        for (int j = threadIdx.x; j < nI; j += blockDim.x) {
+            const T *wj = uw + (size_t)j * K, *hj = uh + (size_t)j * K;
+            T *pj = s_prob + (size_t)j * 2 * K;
+            rqs_softmax_probs<T>(K, [=](int k) { return wj[k]; }, [=](int k, T v) { pj[k] = v; });
+            rqs_softmax_probs<T>(K, [=](int k) { return hj[k]; }, [=](int k, T v) { pj[K + k] = v; });
+        }
     }
     __syncthreads();
     const int64_t ntiles = (B + TS - 1) / TS;
@@ -251,16 +244,19 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
                 const int bl = el / nT, f = el - bl * nT;
                 const int64_t b = bt + bl;
                 const int col = (int)tidx[f];
-                const T *row = s_cond + (size_t)el * P;
+                T *row = s_cond + (size_t)el * P;
                 T *grow = s_g + (size_t)el * P;
-                auto wacc = [=](int k) { return row[k] / div; };
-                auto hacc = [=](int k) { return row[K + k] / div; };
+                // the row's raw widths / heights are replaced by their softmax probabilities (one exp pass)
+                rqs_softmax_probs<T>(K, [=](int k) { return row[k] / div; }, [=](int k, T v) { row[k] = v; });
+                rqs_softmax_probs<T>(K, [=](int k) { return row[K + k] / div; }, [=](int k, T v) { row[K + k] = v; });
+                auto pw = [=](int k) { return row[k]; };
+                auto ph = [=](int k) { return row[K + k]; };
                 auto dacc = [=](int k) { return row[2 * K + k]; };
                 auto aw = [=](int i, T g) { grow[i] = g; };
                 auto ah = [=](int i, T g) { grow[K + i] = g; };
                 auto ad = [=](int j, T g) { grow[2 * K + j] += g; };
-                gx[b * D + col] = rqs_element_bwd<T>(p, x[b * D + col], gy[b * D + col], gld[b], wacc, hacc, dacc,
-                                                     inverse, aw, ah, ad);
+                gx[b * D + col] = rqs_element_bwd<T>(p, x[b * D + col], gy[b * D + col], gld[b], pw, ph, dacc, inverse,
+                                                     aw, ah, ad);
             }
         }
         if (do_i) {
@@ -274,16 +270,16 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
                 }
                 RqsParams<T> pu = p;
                 pu.wh_div = T(1);  // the unconditional transform is not scaled (nsf/coupling.py:224-232)
-                const T *wj = uw + (size_t)j * K, *hj = uh + (size_t)j * K, *dj = ud + (size_t)j * nd;
+                const T *pj = s_prob + (size_t)j * 2 * K, *dj = ud + (size_t)j * nd;
                 T *acc = s_acc + (size_t)j * M;
-                auto wacc = [=](int k) { return wj[k]; };
-                auto hacc = [=](int k) { return hj[k]; };
+                auto pw = [=](int k) { return pj[k]; };
+                auto ph = [=](int k) { return pj[K + k]; };
                 auto dacc = [=](int k) { return dj[k]; };
                 auto aw = [=](int i, T g) { atomicAdd(acc + i, g); };
                 auto ah = [=](int i, T g) { atomicAdd(acc + K + i, g); };
                 auto ad = [=](int jj, T g) { atomicAdd(acc + 2 * K + jj, g); };
-                gx[b * D + col] = rqs_element_bwd<T>(pu, x[b * D + col], gy[b * D + col], gld[b], wacc, hacc, dacc,
-                                                     inverse, aw, ah, ad);
+                gx[b * D + col] = rqs_element_bwd<T>(pu, x[b * D + col], gy[b * D + col], gld[b], pw, ph, dacc, inverse,
+                                                     aw, ah, ad);
             }
         }
         if (stage) {
@@ -323,7 +319,7 @@ static int launch_bwd(const void *x, const void *gy, const void *gld, const void
     const int M = 2 * p.K + p.nd, P = M | 1;
     const bool stage = mode != NF_RQS_SAMPLE_IDENTITY && nT > 0;
     auto lds_bytes = [&](int ts) {
-        return ((size_t)nI * M + (stage ? (size_t)2 * ts * nT * P : 0)) * sizeof(T) + 16;
+        return ((size_t)nI * M + (size_t)nI * 2 * p.K + (stage ? (size_t)2 * ts * nT * P : 0)) * sizeof(T) + 16;
     };
     const int nmax = nT > nI ? nT : nI;
     int TS = nmax > 0 && 256 / nmax > 0 ? 256 / nmax : 1;   // samples per tile: ~one element per lane in each pass
