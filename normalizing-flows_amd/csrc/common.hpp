@@ -214,6 +214,65 @@ __device__ __forceinline__ void rqs_element(const RqsParams<T> &p, T x, const WA
         rqs_eval_bin<T>(x, olo, ohi - olo, blo, bhi - blo, d0, d1, true, y, lad);
 }
 
+// In-place softmax of K logits stored at row[0..K) (divided by `div` first): ONE exp per logit.
+template <typename T> __device__ __forceinline__ void rqs_softmax_row(T *row, int K, T div) {
+    T m = row[0] / div;
+    for (int k = 1; k < K; ++k) m = M<T>::fmax(m, row[k] / div);
+    T s = T(0);
+    for (int k = 0; k < K; ++k) {
+        const T e = M<T>::exp(row[k] / div - m);
+        row[k] = e;
+        s += e;
+    }
+    const T inv = T(1) / s;
+    for (int k = 0; k < K; ++k) row[k] *= inv;
+}
+
+// rqs_element on softmax PROBABILITIES pw(k), ph(k) (rqs_softmax_row) instead of logits: the knot walk needs no
+// transcendental any more (utils/splines.py:126-157 evaluates the softmax once as well).
+template <typename T, typename PW, typename PH, typename DAcc>
+__device__ __forceinline__ void rqs_element_probs(const RqsParams<T> &p, T x, const PW &pw, const PH &ph,
+                                                  const DAcc &dacc, bool inverse, T &y, T &lad) {
+    if (!rqs_inside(p, x)) {
+        y = p.dfull ? T(0) : x;
+        lad = T(0);
+        return;
+    }
+    const int K = p.K;
+    const T s_lo = inverse ? p.bottom : p.left, s_hi = inverse ? p.top : p.right;
+    const T o_lo = inverse ? p.left : p.bottom, o_hi = inverse ? p.right : p.top;
+    const T s_min = inverse ? p.min_h : p.min_w, s_scale = inverse ? p.scale_h : p.scale_w;
+    const T o_min = inverse ? p.min_w : p.min_h, o_scale = inverse ? p.scale_w : p.scale_h;
+    int bin = 0;
+    T cum = T(0), knot = s_lo, blo = s_lo, bhi = s_lo;
+    for (int k = 0; k < K; ++k) {
+        cum += s_min + s_scale * (inverse ? ph(k) : pw(k));
+        const T next = (k == K - 1) ? s_hi : (s_hi - s_lo) * cum + s_lo;
+        if (k == 0 || x >= knot) {
+            bin = k;
+            blo = knot;
+            bhi = next;
+        }
+        knot = next;
+    }
+    cum = T(0);
+    knot = o_lo;
+    T olo = o_lo, ohi = o_lo;
+    for (int k = 0; k <= bin; ++k) {
+        cum += o_min + o_scale * (inverse ? pw(k) : ph(k));
+        const T next = (k == K - 1) ? o_hi : (o_hi - o_lo) * cum + o_lo;
+        olo = knot;
+        ohi = next;
+        knot = next;
+    }
+    const T d0 = p.min_d + softplus(rqs_dlogit(p, dacc, bin));
+    const T d1 = p.min_d + softplus(rqs_dlogit(p, dacc, bin + 1));
+    if (!inverse)
+        rqs_eval_bin<T>(x, blo, bhi - blo, olo, ohi - olo, d0, d1, false, y, lad);
+    else
+        rqs_eval_bin<T>(x, olo, ohi - olo, blo, bhi - blo, d0, d1, true, y, lad);
+}
+
 // Knot table of one batch-shared spline (PiecewiseRationalQuadraticCDF, nsf/coupling.py:221-253): the
 // reference expands the (features, K) parameters to the batch and recomputes identical tables B
 // times; here they are built once per workgroup.  Layout per feature: cumw[K+1] | cumh[K+1] | deriv[K+1].

@@ -113,13 +113,15 @@ rqs_coupling_kernel(const T *__restrict__ x, T *__restrict__ y, T *__restrict__ 
             for (int e = tid; e < n; e += nth) {
                 const int s = e / nT, j = e - s * nT;
                 T *row = s_cond + (size_t)e * Mp;
-                for (int k = 0; k < 2 * K; ++k) row[k] = row[k] / div;  // nsf/coupling.py:334-339, once per value
-                auto wacc = [=](int k) { return row[k]; };
-                auto hacc = [=](int k) { return row[K + k]; };
+                // nsf/coupling.py:334-339 (division by sqrt(hidden)) and the two softmaxes, once per value, in place
+                rqs_softmax_row<T>(row, K, div);
+                rqs_softmax_row<T>(row + K, K, div);
+                auto pw = [=](int k) { return row[k]; };
+                auto ph = [=](int k) { return row[K + k]; };
                 auto dacc = [=](int k) { return row[2 * K + k]; };
                 T yy, ll;
-                rqs_element<T>(rqs_feature_params(p, tails_t, bound_t, j), s_x[s * D + s_tidx[j]], wacc, hacc, dacc,
-                               inverse, yy, ll);
+                rqs_element_probs<T>(rqs_feature_params(p, tails_t, bound_t, j), s_x[s * D + s_tidx[j]], pw, ph, dacc,
+                                     inverse, yy, ll);
                 s_y[s * D + s_tidx[j]] = yy;
                 s_lad[s * (nT + nI) + j] = ll;
             }
