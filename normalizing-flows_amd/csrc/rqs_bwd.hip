@@ -204,19 +204,21 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
     const int K = p.K, nd = p.nd, M = 2 * K + nd;
     const int P = M | 1;                         // LDS row pitch (odd)
     T *s_acc = reinterpret_cast<T *>(smem_raw);  // nI * M block-local accumulators of the shared parameters
-    T *s_prob = s_acc + (size_t)nI * M;          // nI * 2K softmax probabilities of the shared widths / heights
-    T *s_cond = s_prob + (size_t)nI * 2 * K;     // TS*nT rows, pitch P
+    const int PP = (2 * K) | 1;                  // odd pitch: lanes on different features hit different banks
+    T *s_prob = s_acc + (size_t)nI * M;          // nI rows of 2K softmax probabilities of the shared widths / heights
+    T *s_cond = s_prob + (size_t)nI * PP;        // TS*nT rows, pitch P
     T *s_g = s_cond + (size_t)TS * nT * P;       // gradient rows, pitch P
     const bool do_t = mode != NF_RQS_SAMPLE_IDENTITY, do_i = mode != NF_RQS_SAMPLE_TRANSFORM;
     const bool inverse = mode != NF_RQS_DENSITY;
     const bool has_uncond = uw != nullptr;
     const bool stage = do_t && nT > 0;
+    const float invM = 1.0f / (float)M;
     if (do_i && has_uncond) {
         for (int i = threadIdx.x; i < nI * M; i += blockDim.x) s_acc[i] = T(0);
         // batch-shared parameters: their softmax is computed once per workgroup, not once per element
         for (int j = threadIdx.x; j < nI; j += blockDim.x) {
             const T *wj = uw + (size_t)j * K, *hj = uh + (size_t)j * K;
-            T *pj = s_prob + (size_t)j * 2 * K;
+            T *pj = s_prob + (size_t)j * PP;
             rqs_softmax_probs<T>(K, [=](int k) { return wj[k]; }, [=](int k, T v) { pj[k] = v; });
             rqs_softmax_probs<T>(K, [=](int k) { return hj[k]; }, [=](int k, T v) { pj[K + k] = v; });
         }
@@ -230,7 +232,7 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
             const T *src = cond + bt * nT * (int64_t)M;
             const int n = ts * nT * M;
             for (int i = threadIdx.x; i < n; i += blockDim.x) {
-                const int r = i / M, k = i - r * M;
+                const int r = (int)(((float)i + 0.5f) * invM), k = i - r * M;  // exact for i < 2^22 / M
                 s_cond[r * P + k] = src[i];
                 s_g[r * P + k] = T(0);
             }
@@ -238,6 +240,7 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
         }
         // transform elements and identity elements in two separate passes: within a pass every lane runs the same code
         // (one mixed pass made each wave execute both heavy branches)
+#ifndef NF_BWD_ABL_NOT
         if (do_t) {
             const T div = p.wh_div;
             for (int el = threadIdx.x; el < ts * nT; el += blockDim.x) {
@@ -259,6 +262,8 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
                                                      aw, ah, ad);
             }
         }
+#endif
+#ifndef NF_BWD_ABL_NOI
         if (do_i) {
             for (int el = threadIdx.x; el < ts * nI; el += blockDim.x) {
                 const int bl = el / nI, j = el - bl * nI;
@@ -270,7 +275,7 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
                 }
                 RqsParams<T> pu = p;
                 pu.wh_div = T(1);  // the unconditional transform is not scaled (nsf/coupling.py:224-232)
-                const T *pj = s_prob + (size_t)j * 2 * K, *dj = ud + (size_t)j * nd;
+                const T *pj = s_prob + (size_t)j * PP, *dj = ud + (size_t)j * nd;
                 T *acc = s_acc + (size_t)j * M;
                 auto pw = [=](int k) { return pj[k]; };
                 auto ph = [=](int k) { return pj[K + k]; };
@@ -282,12 +287,13 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
                                                      aw, ah, ad);
             }
         }
+#endif
         if (stage) {
             __syncthreads();
             T *dst = gcond + bt * nT * (int64_t)M;
             const int n = ts * nT * M;
             for (int i = threadIdx.x; i < n; i += blockDim.x) {
-                const int r = i / M, k = i - r * M;
+                const int r = (int)(((float)i + 0.5f) * invM), k = i - r * M;
                 dst[i] = s_g[r * P + k];
             }
             __syncthreads();
@@ -319,7 +325,7 @@ static int launch_bwd(const void *x, const void *gy, const void *gld, const void
     const int M = 2 * p.K + p.nd, P = M | 1;
     const bool stage = mode != NF_RQS_SAMPLE_IDENTITY && nT > 0;
     auto lds_bytes = [&](int ts) {
-        return ((size_t)nI * M + (size_t)nI * 2 * p.K + (stage ? (size_t)2 * ts * nT * P : 0)) * sizeof(T) + 16;
+        return ((size_t)nI * M + (size_t)nI * ((2 * p.K) | 1) + (stage ? (size_t)2 * ts * nT * P : 0)) * sizeof(T) + 16;
     };
     const int nmax = nT > nI ? nT : nI;
     int TS = nmax > 0 && 256 / nmax > 0 ? 256 / nmax : 1;   // samples per tile: ~one element per lane in each pass
