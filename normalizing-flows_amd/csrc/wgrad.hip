@@ -190,27 +190,33 @@ wgrad_partial_kernel(const float *__restrict__ dY, const float *__restrict__ X, 
 }
 
 // out (dW then db) (=|+=) sum over chunks of part[c][e] in a fixed order; e < nW goes to dW, the rest to db.
-// Block = 64 elements x 4 chunk lanes (lane q sums chunks q, q+4, ...), combined through LDS as ((0+1)+(2+3)).
-__global__ void __launch_bounds__(256)
+// Block = 64 elements x RL chunk lanes (lane q sums chunks q, q + RL, ... with four loads in flight), combined through
+// LDS in lane order: deterministic, and short dependent chains (the kernel is pure load latency).
+constexpr int RL = 16;
+__global__ void __launch_bounds__(64 * RL)
 wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, float *__restrict__ db, int64_t nW, int64_t n,
                     int64_t stride, int chunks, int accumulate) {
-    __shared__ float sm[4][64];
+    __shared__ float sm[RL][64];
     const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
     for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < n; e0 += (int64_t)gridDim.x * 64) {
         const int64_t e = e0 + el;
-        float s0 = 0.0f, s1 = 0.0f;
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
         if (e < n) {
             int c = q;
-            for (; c + 4 < chunks; c += 8) {
+            for (; c + 3 * RL < chunks; c += 4 * RL) {
                 s0 += part[(size_t)c * stride + e];
-                s1 += part[(size_t)(c + 4) * stride + e];
+                s1 += part[(size_t)(c + RL) * stride + e];
+                s2 += part[(size_t)(c + 2 * RL) * stride + e];
+                s3 += part[(size_t)(c + 3 * RL) * stride + e];
             }
-            if (c < chunks) s0 += part[(size_t)c * stride + e];
+            for (; c < chunks; c += RL) s0 += part[(size_t)c * stride + e];
         }
-        sm[q][el] = s0 + s1;
+        sm[q][el] = (s0 + s1) + (s2 + s3);
         __syncthreads();
         if (q == 0 && e < n) {
-            const float s = (sm[0][el] + sm[1][el]) + (sm[2][el] + sm[3][el]);
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < RL; ++i) s += sm[i][el];
             float *o = e < nW ? dW + e : db + (e - nW);
             *o = accumulate ? *o + s : s;
         }
@@ -272,7 +278,7 @@ extern "C" int nf_linear_wgrad(const void *dY, const void *X, void *dW, void *db
     }
     NF_CHECK_LAUNCH();
     const int64_t nW = (int64_t)M * N, n = nW + (db ? M : 0);
-    hipLaunchKernelGGL(nf::wgrad_reduce_kernel, dim3(nf::grid_for(n, 64)), dim3(256), 0, st, part, (float *)dW, (float *)db,
+    hipLaunchKernelGGL(nf::wgrad_reduce_kernel, dim3(nf::grid_for(n, 64)), dim3(64 * nf::RL), 0, st, part, (float *)dW, (float *)db,
                        nW, n, nW + M, chunks, accumulate);
     NF_CHECK_LAUNCH();
     return NF_OK;
