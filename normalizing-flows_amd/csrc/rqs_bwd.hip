@@ -115,11 +115,13 @@ __device__ __forceinline__ void rqs_softmax_probs(int K, const Acc &acc, const P
 
 // Gradient of one spline element w.r.t. x and its raw parameters, given the softmax probabilities pw(k), ph(k) of its
 // widths / heights (rqs_softmax_probs) and the raw derivative logits dacc(j).  add_w(i, g), add_h(i, g), add_d(j, g)
-// receive the gradients of the RAW parameters (already including 1 / wh_div).  Returns gx.
-template <typename T, typename PW, typename PH, typename DAcc, typename AW, typename AH, typename AD>
+// receive the gradients of the RAW parameters (already including 1 / wh_div); add_w(i) / add_h(i) are called after the
+// last read of pw(i) / ph(i), before_d() after the last read of dacc: gradients may overwrite the parameters in place.
+// Returns gx.
+template <typename T, typename PW, typename PH, typename DAcc, typename AW, typename AH, typename AD, typename ZD>
 __device__ __forceinline__ T rqs_element_bwd(const RqsParams<T> &p, T x, T gy_up, T gl_up, const PW &pw, const PH &ph,
                                              const DAcc &dacc, bool inverse, const AW &add_w, const AH &add_h,
-                                             const AD &add_d) {
+                                             const AD &add_d, const ZD &before_d) {
     if (!rqs_inside(p, x)) return gy_up;  // identity outside the tails (utils/splines.py:40-41), lad = 0
     const int K = p.K;
     // knots of both axes around the bin: knot_j = lo + (hi - lo)(j min + scale C_j), C_j = sum_{i<j} prob_i, ends pinned.
@@ -182,6 +184,7 @@ __device__ __forceinline__ T rqs_element_bwd(const RqsParams<T> &p, T x, T gy_up
         return j;
     };
     const int j0 = raw_index(bin), j1 = raw_index(bin + 1);
+    before_d();   // every read of the raw logits is done: the caller may recycle their storage for the gradients
     if (j0 >= 0) add_d(j0, g[5] * (r0 > T(20) ? T(1) : sigmoid(r0)));
     if (j1 >= 0) add_d(j1, g[6] * (r1 > T(20) ? T(1) : sigmoid(r1)));
     return g[0];
@@ -190,8 +193,8 @@ __device__ __forceinline__ T rqs_element_bwd(const RqsParams<T> &p, T x, T gy_up
 // One lane per (sample, feature) element.  mode as in the forward: 0 density (both halves, forward splines),
 // 1 identity half with the inverse spline, 2 transform half with the inverse spline.
 // Tiles of TS samples: the tile's conditioner rows (TS*nT rows of M numbers, one contiguous span of `cond`) are staged
-// into LDS with unit-stride loads, their gradient rows are built in LDS (odd pitch: lane-per-row access is
-// conflict-free) and leave with unit-stride stores; a lane touching its 92-byte row directly in HBM costs ~4x.
+// into LDS with unit-stride loads, every row is turned into its gradient row IN PLACE (odd pitch: lane-per-row access is
+// conflict-free) and leaves with unit-stride stores; a lane touching its 92-byte row directly in HBM costs ~4x.
 template <typename T>
 __global__ void __launch_bounds__(256)
 rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const T *__restrict__ gld,
@@ -207,7 +210,6 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
     const int PP = (2 * K) | 1;                  // odd pitch: lanes on different features hit different banks
     T *s_prob = s_acc + (size_t)nI * M;          // nI rows of 2K softmax probabilities of the shared widths / heights
     T *s_cond = s_prob + (size_t)nI * PP;        // TS*nT rows, pitch P
-    T *s_g = s_cond + (size_t)TS * nT * P;       // gradient rows, pitch P
     const bool do_t = mode != NF_RQS_SAMPLE_IDENTITY, do_i = mode != NF_RQS_SAMPLE_TRANSFORM;
     const bool inverse = mode != NF_RQS_DENSITY;
     const bool has_uncond = uw != nullptr;
@@ -234,7 +236,6 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
             for (int i = threadIdx.x; i < n; i += blockDim.x) {
                 const int r = (int)(((float)i + 0.5f) * invM), k = i - r * M;  // exact for i < 2^22 / M
                 s_cond[r * P + k] = src[i];
-                s_g[r * P + k] = T(0);
             }
             __syncthreads();
         }
@@ -247,19 +248,24 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
                 const int bl = el / nT, f = el - bl * nT;
                 const int64_t b = bt + bl;
                 const int col = (int)tidx[f];
-                T *row = s_cond + (size_t)el * P;
-                T *grow = s_g + (size_t)el * P;
+                T *row = s_cond + (size_t)el * P;   // parameters in, gradients out: the row is recycled in place
+                const T xv = x[b * D + col];
+                if (!rqs_inside(p, xv)) {            // identity outside the tails: no parameter gradient
+                    for (int k = 0; k < M; ++k) row[k] = T(0);
+                    gx[b * D + col] = gy[b * D + col];
+                    continue;
+                }
                 // the row's raw widths / heights are replaced by their softmax probabilities (one exp pass)
                 rqs_softmax_probs<T>(K, [=](int k) { return row[k] / div; }, [=](int k, T v) { row[k] = v; });
                 rqs_softmax_probs<T>(K, [=](int k) { return row[K + k] / div; }, [=](int k, T v) { row[K + k] = v; });
                 auto pw = [=](int k) { return row[k]; };
                 auto ph = [=](int k) { return row[K + k]; };
                 auto dacc = [=](int k) { return row[2 * K + k]; };
-                auto aw = [=](int i, T g) { grow[i] = g; };
-                auto ah = [=](int i, T g) { grow[K + i] = g; };
-                auto ad = [=](int j, T g) { grow[2 * K + j] += g; };
-                gx[b * D + col] = rqs_element_bwd<T>(p, x[b * D + col], gy[b * D + col], gld[b], pw, ph, dacc, inverse,
-                                                     aw, ah, ad);
+                auto aw = [=](int i, T g) { row[i] = g; };
+                auto ah = [=](int i, T g) { row[K + i] = g; };
+                auto ad = [=](int j, T g) { row[2 * K + j] = g; };
+                auto zd = [=]() { for (int k = 2 * K; k < M; ++k) row[k] = T(0); };
+                gx[b * D + col] = rqs_element_bwd<T>(p, xv, gy[b * D + col], gld[b], pw, ph, dacc, inverse, aw, ah, ad, zd);
             }
         }
 #endif
@@ -284,7 +290,7 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
                 auto ah = [=](int i, T g) { atomicAdd(acc + K + i, g); };
                 auto ad = [=](int jj, T g) { atomicAdd(acc + 2 * K + jj, g); };
                 gx[b * D + col] = rqs_element_bwd<T>(pu, x[b * D + col], gy[b * D + col], gld[b], pw, ph, dacc, inverse,
-                                                     aw, ah, ad);
+                                                     aw, ah, ad, []() {});
             }
         }
 #endif
@@ -294,7 +300,7 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
             const int n = ts * nT * M;
             for (int i = threadIdx.x; i < n; i += blockDim.x) {
                 const int r = (int)(((float)i + 0.5f) * invM), k = i - r * M;
-                dst[i] = s_g[r * P + k];
+                dst[i] = s_cond[r * P + k];
             }
             __syncthreads();
         }
@@ -325,10 +331,10 @@ static int launch_bwd(const void *x, const void *gy, const void *gld, const void
     const int M = 2 * p.K + p.nd, P = M | 1;
     const bool stage = mode != NF_RQS_SAMPLE_IDENTITY && nT > 0;
     auto lds_bytes = [&](int ts) {
-        return ((size_t)nI * M + (size_t)nI * ((2 * p.K) | 1) + (stage ? (size_t)2 * ts * nT * P : 0)) * sizeof(T) + 16;
+        return ((size_t)nI * M + (size_t)nI * ((2 * p.K) | 1) + (stage ? (size_t)ts * nT * P : 0)) * sizeof(T) + 16;
     };
     const int nmax = nT > nI ? nT : nI;
-    int TS = nmax > 0 && 256 / nmax > 0 ? 256 / nmax : 1;   // samples per tile: ~one element per lane in each pass
+    int TS = nmax > 0 && 512 / nmax > 0 ? 512 / nmax : 1;   // samples per tile: ~two elements per lane in each pass
     while (TS > 1 && lds_bytes(TS) > 64 * 1024) TS >>= 1;
     const size_t lds = lds_bytes(TS);
     if (lds > 150 * 1024) return NF_ENOTSUP;
