@@ -170,6 +170,10 @@ rqs_coupling_kernel(const T *__restrict__ x, T *__restrict__ y, T *__restrict__ 
     }
 }
 
+#ifndef NF_FWD_TS_ELEMS
+#define NF_FWD_TS_ELEMS 256   // elements per tile and pass: ~one per lane
+#endif
+
 template <typename T>
 static int launch_rqs_coupling(const void *x, void *y, void *logdet, const void *cond, const void *uw, const void *uh,
                                const void *ud, const int64_t *iidx, int nI, const int64_t *tidx, int nT, int64_t B,
@@ -180,7 +184,7 @@ static int launch_rqs_coupling(const void *x, void *y, void *logdet, const void 
     const int M = 2 * K + p.nd;
     const int Mp = M | 1;
     const int nmax = nT > nI ? nT : nI;
-    int TS = 256 / (nmax > 0 ? nmax : 1);
+    int TS = NF_FWD_TS_ELEMS / (nmax > 0 ? nmax : 1);
     if (TS < 1) TS = 1;
     if (TS > 64) TS = 64;
     auto lds_bytes = [&](int ts) -> size_t {
