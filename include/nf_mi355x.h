@@ -354,6 +354,21 @@ int nf_maf_inverse(const void *z, void *y, void *logdet, const void *blob, const
                    int64_t B, int D, int hidden_padded, int acc, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * MaskedPiecewiseRationalQuadraticAutoregressive inverse (AR-NSF sampling direction) in ONE pass.  Replaces the D-pass
+ * loop of normflows/flows/affine/autoregressive.py:29-38 over MADE with the element-wise inverse spline of
+ * neural_spline/autoregressive.py:94-134 (utils/splines.py:16-219); same incremental schedule, same supported MADE
+ * structure and the same scratch (nf_maf_inverse_scratch_floats) as nf_maf_inverse.
+ *   blob, table : host packer's rows layout (maf_pack.pack_made(made, mult, rows=True)), mult = 3K-1 | 3K | 3K+1 for
+ *                 tails linear | circular | none; mult <= 32, otherwise NF_ENOTSUP.
+ *   tails / tail_bound / min_*: as nf_rqs_coupling (NF_TAILS_NONE: the unit interval); widths and heights are NOT
+ *                 divided by sqrt(hidden) (the reference's MADE has no hidden_features attribute, :107-109).
+ *   z, y (B, D) row-major; logdet (B) accumulated as `acc` says with the row sum of the inverse spline's logabsdet.
+ */
+int nf_arnsf_inverse(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, void *scratch,
+                     int64_t B, int D, int hidden_padded, int K, int tails, double tail_bound, double min_bin_width,
+                     double min_bin_height, double min_derivative, int acc, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Squeeze (flows/reshape.py:116-128).  direction 0 = forward (C,H,W)->(C/4,2H,2W),
  * 1 = inverse (C,H,W)->(4C,H/2,W/2).  z, y contiguous NCHW with the shapes implied.
  */

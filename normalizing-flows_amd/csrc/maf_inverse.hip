@@ -16,6 +16,12 @@
 //                 addresses), every hidden layer's activations live in VGPRs with static indices; after each degree
 //                 the next feature is produced from its two final-layer rows.
 // Work per sample = one MADE pass (0.6 MMAC for D=128, H=512) instead of D passes (153 MMAC).
+//
+// The same schedule inverts the autoregressive rational-quadratic spline layer (AR-NSF sampling direction,
+// normflows/flows/neural_spline/autoregressive.py:94-134 over affine/autoregressive.py:29-38): there a feature needs
+// 3K-1 | 3K | 3K+1 final-layer outputs, so every step has its own 32-row final block (block part on MFMA, left in
+// the wave's LDS tile where lane = sample reads its column), followed by the element-wise inverse spline
+// (utils/splines.py:16-219 through common.hpp::rqs_element).
 #include "common.hpp"
 #include "fused_common.hpp"
 
@@ -31,9 +37,8 @@ typedef float f32x32 __attribute__((ext_vector_type(32)));
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-// out[u] (lane = sample) = sum_k A[u][k] * act[k][sample] for the wave's 64 samples; K is a multiple of 32.
-__device__ __forceinline__ void block_part(const float *__restrict__ A, const float *Sl, int K, float *ldsw, int lane,
-                                           f32x32 &out) {
+// ldsw[u][sample] = sum_k A[u][k] * act[k][sample] for the wave's 64 samples; K is a multiple of 32.
+__device__ __forceinline__ void block_part_lds(const float *__restrict__ A, const float *Sl, int K, float *ldsw, int lane) {
     f32x16 c0 = {0}, c1 = {0};
     const int half = lane >> 5, l31 = lane & 31;
     const f32x4 *pa = reinterpret_cast<const f32x4 *>(A) + half * 32 + l31;
@@ -82,6 +87,12 @@ __device__ __forceinline__ void block_part(const float *__restrict__ A, const fl
         ldsw[row * 64 + 32 + l31] = c1[r];
     }
     __builtin_amdgcn_wave_barrier();
+}
+
+// Same product with lane = sample holding all 32 units in registers afterwards.
+__device__ __forceinline__ void block_part(const float *__restrict__ A, const float *Sl, int K, float *ldsw, int lane,
+                                           f32x32 &out) {
+    block_part_lds(A, Sl, K, ldsw, lane);
 #pragma unroll
     for (int u = 0; u < MT; ++u) out[u] = ldsw[u * 64 + lane];
     __builtin_amdgcn_wave_barrier();
@@ -93,13 +104,23 @@ __device__ __forceinline__ void maf_finish(float us, float sh, float zf, float &
     ld -= __logf(scale);
 }
 
+// Floats of the spline variant's dynamic LDS: the waves' transpose tiles, then the staged sequential-part weights.
+static inline size_t arnsf_lds_floats(int R) {
+    return (size_t)MW * MT * 64 + 5 * MT + MT * MS + 4 * MT * MT + MS * MT + (size_t)MS * R * MT;
+}
+
+// SPL = false: affine element (MAF); true: rational-quadratic spline element with `sp` and R final rows per feature.
+template <bool SPL>
 __global__ void __launch_bounds__(64 * MW)
 maf_inverse_kernel(const float *__restrict__ z, float *__restrict__ y, float *__restrict__ logdet,
-                   const float *__restrict__ blob, const int *__restrict__ table, float *S, float *Xs, int64_t B, int acc) {
-    __shared__ float lds[MW][MT * 64];
-    __shared__ __attribute__((aligned(16))) float seqw[M_SEQ];  // the tile's biases and diagonal blocks, shared by the 4 waves
+                   const float *__restrict__ blob, const int *__restrict__ table, float *S, float *Xs, int64_t B, int acc,
+                   RqsParams<float> sp, int R) {
+    __shared__ float lds[SPL ? 1 : MW][SPL ? 4 : MT * 64];
+    __shared__ __attribute__((aligned(16))) float seqs[SPL ? 4 : M_SEQ];  // the tile's biases and diagonal blocks, shared by the 4 waves
+    extern __shared__ __attribute__((aligned(16))) float dyn[];            // spline variant: everything lives here
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    float *ldsw = lds[wid];
+    float *ldsw = SPL ? dyn + wid * (MT * 64) : lds[SPL ? 0 : wid];
+    float *seqw = SPL ? dyn + MW * MT * 64 : seqs;
     const int64_t wt = (int64_t)blockIdx.x * MW + wid;
     const bool active = wt * 64 < B;  // idle waves of the last workgroup still take part in the staging barriers
     const int D = table[0], Dp = table[1], Hp = table[3], T = table[4];
@@ -114,7 +135,15 @@ maf_inverse_kernel(const float *__restrict__ z, float *__restrict__ y, float *__
     float *Sw = S + wts * ((int64_t)5 * Hp * 64);   // [layer][Hp/8][2][64][4]
     float *Xw = Xs + wts * ((int64_t)Dp * 64);      // [Dp/8][2][64][4]
     float ld = 0.0f, xcarry;
-    maf_finish(blob[0], blob[1], zr[0], xcarry, ld);   // feature 0 depends on no hidden unit
+    if constexpr (SPL) {   // feature 0 depends on no hidden unit: its parameters are the final layer's bias
+        const int K = sp.K;
+        float lad;
+        rqs_element<float>(sp, zr[0], [&](int k) { return blob[k]; }, [&](int k) { return blob[K + k]; },
+                           [&](int j) { return blob[2 * K + j]; }, true, xcarry, lad);
+        ld += lad;
+    } else {
+        maf_finish(blob[0], blob[1], zr[0], xcarry, ld);
+    }
     if (active) Xw[lane * 4] = xcarry;
     if (valid) y[sample * D] = xcarry;
 
@@ -124,20 +153,23 @@ maf_inverse_kernel(const float *__restrict__ z, float *__restrict__ y, float *__
         const int Kh = MT * t;
         const float *rec = blob + te[3];
         const float *A0 = rec;
-        const float *Ah = A0 + K0 * MT;             // A1..A4, AF : Kh*32 floats each
-        // stage the sequential part's weights: 23 KB, one copy per workgroup, read back as LDS broadcasts
+        const float *Ah = A0 + K0 * MT;             // A1..A4, then AF (affine) or AF_0..AF_{ns-1} (spline): Kh*32 floats each
+        // stage the sequential part's weights (affine: 23 KB), one copy per workgroup, read back as LDS broadcasts
+        const int nblk = SPL ? 4 + ns : 5;
+        const int nseq = SPL ? 5 * MT + MT * MS + 4 * MT * MT + ns * MT + ns * R * MT : M_SEQ;
         __syncthreads();
         {
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(Ah + (size_t)5 * Kh * MT);
-            for (int i = threadIdx.x; i < M_SEQ / 4; i += 64 * MW) reinterpret_cast<f32x4 *>(seqw)[i] = src[i];
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(Ah + (size_t)nblk * Kh * MT);
+            for (int i = threadIdx.x; i < nseq / 4; i += 64 * MW) reinterpret_cast<f32x4 *>(seqw)[i] = src[i];
         }
         __syncthreads();
         if (!active) continue;
         const float *bias = seqw;
-        const float *biasF = bias + 5 * MT;
-        const float *W0d = biasF + MT;
+        const float *biasF = bias + 5 * MT;                            // affine layout only
+        const float *W0d = SPL ? bias + 5 * MT : biasF + MT;
         const float *Wd = W0d + MT * MS;
-        const float *WFd = Wd + 4 * MT * MT;
+        const float *WFd = SPL ? Wd + 4 * MT * MT + ns * MT : Wd + 4 * MT * MT;
+        const float *biasFs = Wd + 4 * MT * MT;                       // spline layout: [ns][32]
 
         f32x16 zin;
 #pragma unroll
@@ -150,7 +182,7 @@ maf_inverse_kernel(const float *__restrict__ z, float *__restrict__ y, float *__
         block_part(Ah + (size_t)1 * Kh * MT, Sw + (size_t)1 * Hp * 64, Kh, ldsw, lane, p2);
         block_part(Ah + (size_t)2 * Kh * MT, Sw + (size_t)2 * Hp * 64, Kh, ldsw, lane, p3);
         block_part(Ah + (size_t)3 * Kh * MT, Sw + (size_t)3 * Hp * 64, Kh, ldsw, lane, p4);
-        block_part(Ah + (size_t)4 * Kh * MT, Sw + (size_t)4 * Hp * 64, Kh, ldsw, lane, pF);
+        if constexpr (!SPL) block_part(Ah + (size_t)4 * Kh * MT, Sw + (size_t)4 * Hp * 64, Kh, ldsw, lane, pF);
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
             p0[u] += bias[u];
@@ -158,7 +190,7 @@ maf_inverse_kernel(const float *__restrict__ z, float *__restrict__ y, float *__
             p2[u] += bias[2 * MT + u];
             p3[u] += bias[3 * MT + u];
             p4[u] += bias[4 * MT + u];
-            pF[u] += biasF[u];
+            if constexpr (!SPL) pF[u] += biasF[u];
         }
         f32x16 xg = {0};   // window features dlo-1 .. dlo+14 (0-based): xg[0] is the carry, xg[s+1] the output of step s
         xg[0] = xcarry;
@@ -219,19 +251,38 @@ maf_inverse_kernel(const float *__restrict__ z, float *__restrict__ y, float *__
                 p4[u] = p4[u] + (a0 + a1);   // = h2, the final layer's input (made.py:304: no activation before it)
             }
             {
-                float us, sh;
-                {
-                    const int u = 2 * s;
-                    MAF_DOT(WFd, p4)
-                    us = pF[u] + (a0 + a1);
-                }
-                {
-                    const int u = 2 * s + 1;
-                    MAF_DOT(WFd, p4)
-                    sh = pF[u] + (a0 + a1);
-                }
                 float xn;
-                maf_finish(us, sh, zin[s], xn, ld);
+                if constexpr (SPL) {
+                    // this feature's R final rows: earlier tiles on MFMA (left in the LDS tile, lane = sample owns a
+                    // column), the tile's own units from registers, then the inverse spline on the column
+                    block_part_lds(Ah + (size_t)(4 + s) * Kh * MT, Sw + (size_t)4 * Hp * 64, Kh, ldsw, lane);
+                    const float *wfs = WFd + (size_t)s * R * MT;
+                    const float *bfs = biasFs + s * MT;
+                    for (int u = 0; u < R; ++u) {
+                        MAF_DOT(wfs, p4)
+                        ldsw[u * 64 + lane] += (a0 + a1) + bfs[u];
+                    }
+                    const int K = sp.K;
+                    float lad;
+                    rqs_element<float>(sp, zin[s], [&](int k) { return ldsw[k * 64 + lane]; },
+                                       [&](int k) { return ldsw[(K + k) * 64 + lane]; },
+                                       [&](int j) { return ldsw[(2 * K + j) * 64 + lane]; }, true, xn, lad);
+                    ld += lad;
+                    __builtin_amdgcn_wave_barrier();
+                } else {
+                    float us, sh;
+                    {
+                        const int u = 2 * s;
+                        MAF_DOT(WFd, p4)
+                        us = pF[u] + (a0 + a1);
+                    }
+                    {
+                        const int u = 2 * s + 1;
+                        MAF_DOT(WFd, p4)
+                        sh = pF[u] + (a0 + a1);
+                    }
+                    maf_finish(us, sh, zin[s], xn, ld);
+                }
                 if (s + 1 < MS) xg[s + 1] = xn;
                 xcarry = xn;
                 const int f = dlo + s;
@@ -280,8 +331,38 @@ extern "C" int nf_maf_inverse(const void *z, void *y, void *logdet, const void *
     // the feature scratch is read with zero weights before it is written (K0 is padded to 32): it must hold finite values
     if (hipMemsetAsync(Xs, 0, (size_t)nwt * 64 * Dp * sizeof(float), st) != hipSuccess) return NF_EIO;
     const int grid = (int)((nwt + nf::MW - 1) / nf::MW);
-    hipLaunchKernelGGL(nf::maf_inverse_kernel, dim3(grid), dim3(64 * nf::MW), 0, st, (const float *)z, (float *)y,
-                       (float *)logdet, (const float *)blob, (const int *)table, S, Xs, B, acc);
+    hipLaunchKernelGGL(nf::maf_inverse_kernel<false>, dim3(grid), dim3(64 * nf::MW), 0, st, (const float *)z, (float *)y,
+                       (float *)logdet, (const float *)blob, (const int *)table, S, Xs, B, acc, nf::RqsParams<float>{}, 2);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_arnsf_inverse(const void *z, void *y, void *logdet, const void *blob, const int32_t *table,
+                                void *scratch, int64_t B, int D, int hidden_padded, int K, int tails, double tail_bound,
+                                double min_bin_width, double min_bin_height, double min_derivative, int acc,
+                                nf_stream_t stream) {
+    if (K < 1 || tails < NF_TAILS_NONE || tails > NF_TAILS_CIRCULAR) return NF_EINVAL;
+    if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_EINVAL;   // utils/splines.py:121-124
+    const int R = tails == NF_TAILS_LINEAR ? 3 * K - 1 : (tails == NF_TAILS_CIRCULAR ? 3 * K : 3 * K + 1);
+    if (R > nf::MT) return NF_ENOTSUP;
+    if (B < 0 || D < 2 || hidden_padded < 32 || hidden_padded % 32) return NF_EINVAL;
+    if (acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!z || !y || !logdet || !blob || !table || !scratch) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nwt = (B + 63) / 64;
+    const int64_t Dp = (D + 31) / 32 * 32;
+    float *S = (float *)scratch;
+    float *Xs = S + nwt * 64 * (int64_t)5 * hidden_padded;
+    if (hipMemsetAsync(Xs, 0, (size_t)nwt * 64 * Dp * sizeof(float), st) != hipSuccess) return NF_EIO;
+    auto sp = nf::make_rqs_params<float>(K, tails, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height, min_derivative,
+                                         1.0);
+    const size_t lds = nf::arnsf_lds_floats(R) * sizeof(float);
+    static nf::LdsOptIn opted;
+    if (nf::opt_in_lds(reinterpret_cast<const void *>(&nf::maf_inverse_kernel<true>), lds, opted) != NF_OK) return NF_ENOTSUP;
+    const int grid = (int)((nwt + nf::MW - 1) / nf::MW);
+    hipLaunchKernelGGL(nf::maf_inverse_kernel<true>, dim3(grid), dim3(64 * nf::MW), lds, st, (const float *)z, (float *)y,
+                       (float *)logdet, (const float *)blob, (const int *)table, S, Xs, B, acc, sp, R);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

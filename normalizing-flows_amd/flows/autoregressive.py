@@ -8,7 +8,8 @@ pre-masked weights (cached per parameter version).
 
 The inverse of MaskedAffineAutoregressive runs as ONE launch of nf_maf_inverse when
 the MADE has the supported structure (flows/maf_pack.py): every hidden unit is finalised once, total work = one MADE
-pass instead of D.  Other structures, float64 and gradient-tracking calls keep the reference's D-pass loop.
+pass instead of D; the autoregressive spline layer (AR-NSF sampling) does the same through nf_arnsf_inverse.  Other
+structures, float64 and gradient-tracking calls keep the reference's D-pass loop.
 """
 import numpy as np
 import torch
@@ -137,6 +138,32 @@ class MaskedPiecewiseRationalQuadraticAutoregressive(Autoregressive):
         if self.tails == "circular":
             return self.num_bins * 3
         return self.num_bins * 3 + 1
+
+    def _packed(self, device):
+        """Device copies of the incremental-inverse pack (rows layout), rebuilt when any MADE parameter changes."""
+        key = tuple((p.data_ptr(), p._version) for p in self.autoregressive_net.parameters()) + (str(device),)
+        cache = getattr(self, "_arnsf_pack_cache", None)
+        if cache is None or cache[0] != key:
+            packed = maf_pack.pack_made(self.autoregressive_net, mult=self._output_dim_multiplier(), rows=True)
+            if packed is not None:
+                blob, table = packed
+                packed = (torch.from_numpy(blob).to(device), torch.from_numpy(table).to(device), int(table[3]))
+            self._arnsf_pack_cache = cache = (key, packed)
+        return cache[1]
+
+    def inverse(self, inputs, context=None):
+        """One launch of nf_arnsf_inverse for the supported MADE structure (scalar tails, float32, no context, no
+        sqrt(hidden) scaling, no gradient tracking); the reference's D-pass loop otherwise."""
+        if (context is None and inputs.dim() == 2 and inputs.dtype == torch.float32 and inputs.is_cuda
+                and (self.tails is None or isinstance(self.tails, str)) and not torch.is_tensor(self.tail_bound)
+                and not hasattr(self.autoregressive_net, "hidden_features")
+                and not autograd.needs_grad(inputs, *self.autoregressive_net.parameters())):
+            packed = self._packed(inputs.device)
+            if packed is not None:
+                return ops.arnsf_inverse(inputs, packed[0], packed[1], packed[2], self.num_bins, self.tails,
+                                         float(self.tail_bound), self.min_bin_width, self.min_bin_height,
+                                         self.min_derivative)
+        return super().inverse(inputs, context)
 
     def _elementwise(self, inputs, params, direction, want_logdet=True):
         if inputs.dim() != 2:

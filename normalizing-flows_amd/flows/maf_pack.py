@@ -15,8 +15,16 @@ This module only rearranges weights (no arithmetic on data).  Layout of the floa
   [0:4]                       final-layer bias of feature 0 (unconstrained scale, shift) + 2 pad: depends on no hidden unit
   per tile t, at table[t].rec : A0 [K0/8][2][32][4] | A1..A4, AF [4t][2][32][4] each | bias[5][32] | biasF[32]
                                 | W0d[32][16] | Wd[4][32][32] | WFd[32][32]
-and of the int32 table: [D, Dp, H, Hp, T, 0, 0, 0] then per tile 24 ints
+and of the int32 table: [D, Dp, H, Hp, T, mult, 0, 0] then per tile 24 ints
   [dlo, nsteps, K0, rec, mask[0..15], 0, 0, 0, 0]   (mask[s] = bitmask of the tile's units that have degree dlo+s).
+
+With `mult` = 2 (affine: unconstrained scale, shift) the final-layer rows of a tile's <= 16 features fit ONE 32-row
+block (layout above).  With `mult` > 2 (autoregressive spline: 3K-1 | 3K | 3K+1 <= 32 numbers per feature, kernel
+nf_arnsf_inverse) every feature gets its own 32-row block, zero-padded:
+
+  [0:32]                      final-layer bias of feature 0
+  per tile t                  A0 | A1..A4 [4t][2][32][4] | AF_s [4t][2][32][4] for each step s | bias[5][32]
+                              | W0d[32][16] | Wd[4][32][32] | biasF[nsteps][32] | WFd[nsteps][mult][32]
 """
 import numpy as np
 import torch
@@ -56,7 +64,7 @@ def _a_operand(w_rows_by_k):
     return np.ascontiguousarray(w_rows_by_k.reshape(TILE, K // 8, 2, 4).transpose(1, 2, 0, 3)).reshape(-1)
 
 
-def supported(made):
+def supported(made, mult=2):
     from .. import nets
     if not isinstance(made, nets.MADE):
         return False
@@ -68,14 +76,16 @@ def supported(made):
         if b.use_batch_norm or b.activation is not F.relu or b.dropout.p != 0.0 or hasattr(b, "context_layer"):
             return False
     D = made.initial_layer.in_features
-    if made.final_layer.out_features != 2 * D or made.initial_layer.weight.dtype != torch.float32:
+    if made.final_layer.out_features != mult * D or made.initial_layer.weight.dtype != torch.float32:
         return False
-    return True
+    return 2 <= mult <= TILE
 
 
-def pack_made(made):
-    """Returns (blob float32 ndarray, table int32 ndarray) or None if the MADE is not the supported structure."""
-    if not supported(made):
+def pack_made(made, mult=2, rows=False):
+    """Returns (blob float32 ndarray, table int32 ndarray) or None if the MADE is not the supported structure.
+    `mult` = final-layer outputs per feature (MADE's output_multiplier); `rows` selects the one-block-per-feature
+    layout of nf_arnsf_inverse."""
+    if not supported(made, mult):
         return None
     D = made.initial_layer.in_features
     H = made.initial_layer.out_features
@@ -86,12 +96,12 @@ def pack_made(made):
         if not np.array_equal(l.degrees.cpu().numpy(), hid_deg):
             return None
     fin = made.final_layer
-    # input degrees must be arange(1..D) and the output rows feature-major (2 rows per feature)
+    # input degrees must be arange(1..D) and the output rows feature-major (`mult` rows per feature)
     m0 = made.initial_layer.mask.cpu().numpy()
     if not np.array_equal(m0, (hid_deg[:, None] >= np.arange(1, D + 1)[None, :]).astype(m0.dtype)):
         return None
     mf = fin.mask.cpu().numpy()
-    out_deg = np.repeat(np.arange(1, D + 1), 2)
+    out_deg = np.repeat(np.arange(1, D + 1), mult)
     if not np.array_equal(mf, (out_deg[:, None] > hid_deg[None, :]).astype(mf.dtype)):
         return None
     plan = plan_tiles(D, hid_deg)
@@ -139,15 +149,19 @@ def pack_made(made):
         w, b = padded(l, hid_map, Hp)
         Wh.append(w)
         bh.append(b)
-    wf = (fin.weight.detach() * fin.mask).cpu().numpy().astype(np.float32)   # (2D, H), row 2f+p
+    wf = (fin.weight.detach() * fin.mask).cpu().numpy().astype(np.float32)   # (mult D, H), row mult f + p
     bf = fin.bias.detach().cpu().numpy().astype(np.float32)
-    WF = np.zeros((2 * D, Hp), dtype=np.float32)
+    WF = np.zeros((mult * D, Hp), dtype=np.float32)
     WF[:, hid_map] = wf
 
-    chunks = [np.array([bf[0], bf[1], 0.0, 0.0], dtype=np.float32)]   # 16-byte header keeps every section aligned
-    off = 4
+    if mult != 2 and not rows:
+        return None                        # the per-tile final block holds exactly two rows per feature
+    head = np.zeros(TILE if rows else 4, dtype=np.float32)   # 16-byte multiples keep every section aligned
+    head[:mult] = bf[:mult]
+    chunks = [head]
+    off = head.size
     table = np.zeros(TABLE_HDR + TABLE_ENT * T, dtype=np.int32)
-    table[0:5] = [D, Dp, H, Hp, T]
+    table[0:6] = [D, Dp, H, Hp, T, mult]
     for t, (dlo, ns, steps) in enumerate(tiles):
         r0, r1 = t * TILE, (t + 1) * TILE
         nprev = dlo - 1                    # features (0-based) 0..dlo-2 come from the block part; dlo-1.. from the window
@@ -158,16 +172,28 @@ def pack_made(made):
         for w in Wh:
             if t:
                 rec.append(_a_operand(w[r0:r1, :r0]))
-        fo = np.zeros((TILE, Hp), dtype=np.float32)      # final rows of the tile's output features dlo..dlo+ns-1 (0-based)
-        bfo = np.zeros(TILE, dtype=np.float32)
-        for j in range(ns):
-            f = dlo + j
-            fo[2 * j:2 * j + 2] = WF[2 * f:2 * f + 2]
-            bfo[2 * j:2 * j + 2] = bf[2 * f:2 * f + 2]
-        if t:
-            rec.append(_a_operand(fo[:, :r0]))
+        # final rows of the tile's output features dlo..dlo+ns-1 (0-based)
+        if rows:
+            fo = np.zeros((ns, TILE, Hp), dtype=np.float32)
+            bfo = np.zeros((ns, TILE), dtype=np.float32)
+            for j in range(ns):
+                f = dlo + j
+                fo[j, :mult] = WF[mult * f:mult * (f + 1)]
+                bfo[j, :mult] = bf[mult * f:mult * (f + 1)]
+                if t:
+                    rec.append(_a_operand(fo[j][:, :r0]))
+        else:
+            fo = np.zeros((TILE, Hp), dtype=np.float32)
+            bfo = np.zeros(TILE, dtype=np.float32)
+            for j in range(ns):
+                f = dlo + j
+                fo[2 * j:2 * j + 2] = WF[2 * f:2 * f + 2]
+                bfo[2 * j:2 * j + 2] = bf[2 * f:2 * f + 2]
+            if t:
+                rec.append(_a_operand(fo[:, :r0]))
         rec.append(np.concatenate([b0[r0:r1]] + [b[r0:r1] for b in bh]))
-        rec.append(bfo)
+        if not rows:
+            rec.append(bfo)
         w0d = np.zeros((TILE, MAX_STEPS), dtype=np.float32)  # window features dlo-1 .. dlo-1+ns-1 (0-based)
         nwin = min(MAX_STEPS, D - (dlo - 1))
         w0d[:, :nwin] = W0[r0:r1, dlo - 1:dlo - 1 + nwin]
@@ -175,7 +201,11 @@ def pack_made(made):
         rec.append(w0d.reshape(-1))
         for w in Wh:
             rec.append(np.ascontiguousarray(w[r0:r1, r0:r1]).reshape(-1))
-        rec.append(np.ascontiguousarray(fo[:, r0:r1]).reshape(-1))
+        if rows:
+            rec.append(bfo.reshape(-1))
+            rec.append(np.ascontiguousarray(fo[:, :mult, r0:r1]).reshape(-1))
+        else:
+            rec.append(np.ascontiguousarray(fo[:, r0:r1]).reshape(-1))
         rec = np.concatenate(rec)
         e = TABLE_HDR + TABLE_ENT * t
         table[e + 0], table[e + 1], table[e + 2], table[e + 3] = dlo, ns, K0, off

@@ -437,6 +437,30 @@ def maf_inverse(z, blob, table, hidden_padded, logdet=None, acc=None):
     return y, logdet
 
 
+def arnsf_inverse(z, blob, table, hidden_padded, K, tails, tail_bound, min_bin_width=1e-3, min_bin_height=1e-3,
+                  min_derivative=1e-3, logdet=None, acc=None):
+    """neural_spline/autoregressive.py:94-134 inverse over affine/autoregressive.py:29-38 in one pass
+    (nf_arnsf_inverse); blob/table from flows/maf_pack.pack_made(made, mult, rows=True)."""
+    L.require_device(z, blob, table)
+    if z.dtype != torch.float32:
+        raise NotImplementedError("arnsf_inverse: float32 only")
+    B, D = z.shape
+    z = z.contiguous()
+    y = torch.empty_like(z)
+    if logdet is None:
+        logdet = torch.empty(B, dtype=z.dtype, device=z.device)
+        acc = L.LD_WRITE
+    elif acc is None:
+        acc = L.LD_ADD
+    n = L.lib().nf_maf_inverse_scratch_floats(i64(B), i32(D), i32(hidden_padded))
+    scratch = torch.empty(max(int(n), 1), dtype=torch.float32, device=z.device)
+    rc = L.lib().nf_arnsf_inverse(ptr(z), ptr(y), ptr(logdet), ptr(blob), ptr(table), ptr(scratch), i64(B), i32(D),
+                                  i32(hidden_padded), i32(K), i32(L.TAILS[tails]), f64(tail_bound),
+                                  f64(min_bin_width), f64(min_bin_height), f64(min_derivative), i32(acc), L.stream())
+    L.check(rc, "nf_arnsf_inverse")
+    return y, logdet
+
+
 def logit(z, alpha, direction, logdet=None, acc=None):
     """transforms.py:8-47.  direction 0 = Logit.forward (sigmoid side), 1 = Logit.inverse (logit side)."""
     L.require_device(z)

@@ -9,10 +9,14 @@ def _from_a_operand(a, K):
     return a.reshape(K // 8, 2, TILE, 4).transpose(2, 0, 1, 3).reshape(TILE, K)
 
 
-def emulate_inverse(blob, table, z):
+def emulate_inverse(blob, table, z, element=None):
+    """`element(params (B, mult), z_f (B,)) -> (x_f, logabsdet_f)`: the element-wise inverse of the rows layout (one
+    final-layer block per feature, nf_arnsf_inverse); None = the affine layout of nf_maf_inverse."""
     z = np.asarray(z, dtype=np.float64)
     B = z.shape[0]
     D, Dp, H, Hp, T = [int(v) for v in table[:5]]
+    if element is not None:
+        return _emulate_rows(blob.astype(np.float64), table, z, element)
     blob = blob.astype(np.float64)
     x = np.zeros((B, Dp))
     S = np.zeros((5, B, Hp))
@@ -65,6 +69,64 @@ def emulate_inverse(blob, table, z):
             sh = preF[:, 2 * s + 1] + pre[4] @ WFd[2 * s + 1]
             xn, d = finish(us, sh, z[:, dlo + s])
             ld += d
+            x[:, dlo + s] = xn
+            xg[:, s + 1] = xn
+        for l in range(5):
+            S[l][:, TILE * t:TILE * (t + 1)] = pre[l]
+    return x[:, :D], ld
+
+
+def _emulate_rows(blob, table, z, element):
+    B = z.shape[0]
+    D, Dp, H, Hp, T, mult = [int(v) for v in table[:6]]
+    x = np.zeros((B, Dp))
+    S = np.zeros((5, B, Hp))
+    x[:, 0], ld = element(np.broadcast_to(blob[:mult], (B, mult)), z[:, 0])
+    ld = np.array(ld, dtype=np.float64)
+    for t in range(T):
+        e = HDR + ENT * t
+        dlo, ns, K0, off = [int(v) for v in table[e:e + 4]]
+        masks = table[e + 4:e + 4 + MAX_STEPS].view(np.uint32)
+        Kh = TILE * t
+
+        def a_block(K):
+            nonlocal off
+            a = _from_a_operand(blob[off:off + K * TILE], K) if K else np.zeros((TILE, 0))
+            off += K * TILE
+            return a
+        A0 = a_block(K0)
+        Ah = [a_block(Kh) for _ in range(4)]
+        AF = [a_block(Kh) for _ in range(ns)]
+        bias = blob[off:off + 5 * TILE].reshape(5, TILE); off += 5 * TILE
+        W0d = blob[off:off + TILE * MAX_STEPS].reshape(TILE, MAX_STEPS); off += TILE * MAX_STEPS
+        Wd = blob[off:off + 4 * TILE * TILE].reshape(4, TILE, TILE); off += 4 * TILE * TILE
+        biasF = blob[off:off + ns * TILE].reshape(ns, TILE); off += ns * TILE
+        WFd = blob[off:off + ns * mult * TILE].reshape(ns, mult, TILE); off += ns * mult * TILE
+        pre = np.zeros((5, B, TILE))
+        pre[0] = x[:, :K0] @ A0.T + bias[0]
+        for l in range(1, 5):
+            pre[l] = S[l - 1][:, :Kh] @ Ah[l - 1].T + bias[l]
+        xg = np.zeros((B, MAX_STEPS + 1))
+        xg[:, 0] = x[:, dlo - 1]
+        for s in range(ns):
+            units = [u for u in range(TILE) if (int(masks[s]) >> u) & 1]
+            for u in units:
+                h = pre[0][:, u] + xg[:, :MAX_STEPS] @ W0d[u]
+                pre[2][:, u] += h
+                pre[0][:, u] = np.maximum(h, 0)
+            for u in units:
+                pre[1][:, u] = np.maximum(pre[1][:, u] + pre[0] @ Wd[0][u], 0)
+            for u in units:
+                h1 = pre[2][:, u] + pre[1] @ Wd[1][u]
+                pre[4][:, u] += h1
+                pre[2][:, u] = np.maximum(h1, 0)
+            for u in units:
+                pre[3][:, u] = np.maximum(pre[3][:, u] + pre[2] @ Wd[2][u], 0)
+            for u in units:
+                pre[4][:, u] = pre[4][:, u] + pre[3] @ Wd[3][u]
+            prm = (S[4][:, :Kh] @ AF[s].T + biasF[s])[:, :mult] + pre[4] @ WFd[s].T
+            xn, d = element(prm, z[:, dlo + s])
+            ld = ld + d
             x[:, dlo + s] = xn
             xg[:, s + 1] = xn
         for l in range(5):

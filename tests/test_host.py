@@ -75,6 +75,15 @@ def test_c_abi_argument_validation_newer_entry_points(nfa):
     assert lib.nf_maf_inverse(one, one, one, null, one, one, i64(8), i32(128), i32(512), i32(0), null) == -14
     assert lib.nf_maf_inverse(null, null, null, null, null, null, i64(0), i32(128), i32(512), i32(0), null) == 0
     assert lib.nf_maf_inverse_scratch_floats(i64(65), i32(128), i32(512)) == 2 * 64 * (5 * 512 + 128)
+
+    def arnsf(K, tails, hp=512, B=8, blob=one):
+        return lib.nf_arnsf_inverse(one, one, one, blob, one, one, i64(B), i32(64), i32(hp), i32(K), i32(tails), f64(3.0),
+                                    f64(1e-3), f64(1e-3), f64(1e-3), i32(0), null)
+    assert arnsf(12, 1) == -95          # K = 11: the 3K-1 = 32 rows of linear tails fit one block, 3K / 3K+1 do not
+    assert arnsf(11, 0) == -95 and arnsf(11, 2) == -95
+    assert arnsf(8, 3) == -22 and arnsf(0, 1) == -22 and arnsf(8, 1, hp=500) == -22
+    assert arnsf(8, 1, blob=null) == -14
+    assert arnsf(8, 1, B=0) == 0
     # weight gradient: N <= 128 columns per launch, accumulate is 0 / 1
     assert lib.nf_linear_wgrad(one, one, one, one, one, i64(64), i32(8), i32(200), i32(0), null) == -95
     assert lib.nf_linear_wgrad(one, one, one, one, one, i64(64), i32(8), i32(8), i32(2), null) == -22
@@ -280,6 +289,43 @@ def test_maf_pack_schedule_matches_d_pass(D, H):
     x, ld = emulate_inverse(blob, table, z.numpy())
     np.testing.assert_allclose(x, out.numpy(), rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(ld, ldref.numpy(), rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("D,H,K,tails", [(64, 256, 8, "linear"), (9, 40, 4, None), (5, 12, 10, "circular"), (3, 2, 1, "linear")])
+def test_arnsf_pack_schedule_matches_d_pass(D, H, K, tails):
+    """Rows layout of flows/maf_pack.py (one final-layer block per feature, nf_arnsf_inverse): the emulated schedule
+    reproduces the fixed point of the D-pass inverse of neural_spline/autoregressive.py:94-134 (oracle spline, fp64)."""
+    import nf_oracle
+    from normflows_amd import nets
+    from normflows_amd.flows import maf_pack
+    from maf_emulator import emulate_inverse
+    mult = {"linear": 3 * K - 1, "circular": 3 * K, None: 3 * K + 1}[tails]
+    torch.manual_seed(D * K + H)
+    made = nets.MADE(features=D, hidden_features=H, num_blocks=2, output_multiplier=mult)
+    with torch.no_grad():
+        for p in made.parameters():
+            p.add_(0.1 * torch.randn_like(p))
+    blob, table = maf_pack.pack_made(made, mult=mult, rows=True)
+    assert table[5] == mult and blob.size % 4 == 0
+    tb = 2.5
+    z = (torch.rand(16, D) if tails is None else 2.0 * torch.randn(16, D)).double().numpy()
+
+    def element(prm, zf):
+        prm = np.ascontiguousarray(prm)
+        y, lad = nf_oracle.rqs_spline(np.ascontiguousarray(zf), prm[:, :K], prm[:, K:2 * K], prm[:, 2 * K:], inverse=True,
+                                      tails=tails, tail_bound=tb)
+        return y, lad
+    m64 = made.double()
+    out = np.zeros((16, D))
+    with torch.no_grad():
+        for _ in range(D):
+            prm = m64(torch.from_numpy(out)).view(16, D, mult).numpy()
+            cols = [element(prm[:, f], z[:, f]) for f in range(D)]
+            out = np.stack([c[0] for c in cols], 1)
+        ldref = np.stack([c[1] for c in cols], 1).sum(1)
+    x, ld = emulate_inverse(blob, table, z, element=element)
+    np.testing.assert_allclose(x, out, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(ld, ldref, rtol=1e-9, atol=1e-9)
 
 
 def test_maf_pack_rejects_unsupported():
