@@ -316,6 +316,7 @@ def main():
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:
+        barrier()   # rank 0's untimed extras are done: every rank tears the communicator down together
         dist.destroy_process_group()
 
 

@@ -32,3 +32,22 @@ def test_bench_emits_one_contract_line():
     assert abs(d["nll_nats_per_dim"] - 1.5416) < 5e-3          # the reference's NLL on this model is 1.5415
     acc = c["max_rel_err_log_prob_vs_fp64_oracle"]
     assert acc["gpu_exact_f32"] < 1e-4 and acc.get("gpu_bf16x3", 0.0) < 1e-4
+
+
+def test_bench_two_ranks_on_one_device():
+    """The N > 1 code path of bench.py (rank-seeded shards, barrier + max-over-ranks timing, the NLL all-reduce, rank 0
+    printing) with two ranks sharing cuda:0 over gloo (NF_BENCH_ONE_DEVICE=1; the real run is one rank per GPU over
+    RCCL).  The global NLL must equal the mean of the two shards' NLLs."""
+    env = dict(os.environ, NF_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29683", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8192", "--no-breakdown"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2500:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_rows"] == 16384 and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 2 * 8192 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert "cpu_baseline" not in d                              # rank 0 at N = 1 only
+    assert abs(d["nll_nats_per_dim"] - 1.5416) < 2e-2
