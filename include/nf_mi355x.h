@@ -127,6 +127,18 @@ int nf_rqs_coupling_bwd(const void *x, const void *grad_y, const void *grad_logd
                         double wh_div, int mode, void *grad_x, void *grad_cond, void *grad_uw, void *grad_uh,
                         void *grad_ud, int dtype, nf_stream_t stream);
 
+/* Backward of nf_rqs_coupling_ft: the same arrays tails_t / bound_t / tails_i / bound_i as the forward call.  In the
+ * per-feature branch (tails = NF_TAILS_FEATURE) an input outside its interval produced the constant 0, so its grad_x
+ * is 0 (utils/splines.py:48-57 never copies those inputs); the edge derivative logits a feature's tails type
+ * overrides receive no gradient (linear) or the gradient of the logit they alias (circular: logit K -> logit 0). */
+int nf_rqs_coupling_bwd_ft(const void *x, const void *grad_y, const void *grad_logdet, const void *cond,
+                           const void *uw, const void *uh, const void *ud, const int64_t *identity_idx, int nI,
+                           const int64_t *transform_idx, int nT, int64_t B, int D, int K, int tails,
+                           double tail_bound, double min_bin_width, double min_bin_height, double min_derivative,
+                           double wh_div, int mode, void *grad_x, void *grad_cond, void *grad_uw, void *grad_uh,
+                           void *grad_ud, int dtype, const int32_t *tails_t, const void *bound_t,
+                           const int32_t *tails_i, const void *bound_i, nf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fully fused NSF coupling layer: ResidualNet conditioner (fp32 MFMA) + spline epilogue, one launch.
  * Replaces the whole of CoupledRationalQuadraticSpline.forward/inverse

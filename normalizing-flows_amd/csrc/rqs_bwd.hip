@@ -122,7 +122,9 @@ template <typename T, typename PW, typename PH, typename DAcc, typename AW, type
 __device__ __forceinline__ T rqs_element_bwd(const RqsParams<T> &p, T x, T gy_up, T gl_up, const PW &pw, const PH &ph,
                                              const DAcc &dacc, bool inverse, const AW &add_w, const AH &add_h,
                                              const AD &add_d, const ZD &before_d) {
-    if (!rqs_inside(p, x)) return gy_up;  // identity outside the tails (utils/splines.py:40-41), lad = 0
+    // identity outside the tails (utils/splines.py:40-41), lad = 0; the per-feature branch (:48-57) leaves zeros there,
+    // which do not depend on x
+    if (!rqs_inside(p, x)) return p.dfull ? T(0) : gy_up;
     const int K = p.K;
     // knots of both axes around the bin: knot_j = lo + (hi - lo)(j min + scale C_j), C_j = sum_{i<j} prob_i, ends pinned.
     // searched axis: widths for the forward spline, heights for the inverse.
@@ -179,6 +181,10 @@ __device__ __forceinline__ T rqs_element_bwd(const RqsParams<T> &p, T x, T gy_up
     }
     // ---- derivatives -> raw logits (softplus' = sigmoid; padded/edge logits are constants) ----
     auto raw_index = [&](int j) -> int {  // padded logit j -> raw index, or -1 for a constant
+        if (p.dfull) {  // K + 1 raw logits per element, edges overridden per tails type (common.hpp::rqs_dlogit)
+            if (p.tails == NF_TAILS_LINEAR) return (j == 0 || j == K) ? -1 : j;
+            return j == K ? 0 : j;
+        }
         if (p.tails == NF_TAILS_LINEAR) return (j == 0 || j == K) ? -1 : j - 1;
         if (p.tails == NF_TAILS_CIRCULAR) return j == K ? 0 : j;
         return j;
@@ -202,7 +208,8 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
                         const T *__restrict__ ud, const int64_t *__restrict__ iidx, int nI,
                         const int64_t *__restrict__ tidx, int nT, int64_t B, int D, RqsParams<T> p, int mode,
                         T *__restrict__ gx, T *__restrict__ gcond, T *__restrict__ guw, T *__restrict__ guh,
-                        T *__restrict__ gud, int TS) {
+                        T *__restrict__ gud, int TS, const int *__restrict__ tails_t, const T *__restrict__ bound_t,
+                        const int *__restrict__ tails_i, const T *__restrict__ bound_i) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int K = p.K, nd = p.nd, M = 2 * K + nd;
     const int P = M | 1;                         // LDS row pitch (odd)
@@ -250,9 +257,10 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
                 const int col = (int)tidx[f];
                 T *row = s_cond + (size_t)el * P;   // parameters in, gradients out: the row is recycled in place
                 const T xv = x[b * D + col];
-                if (!rqs_inside(p, xv)) {            // identity outside the tails: no parameter gradient
+                const RqsParams<T> pf = rqs_feature_params(p, tails_t, bound_t, f);
+                if (!rqs_inside(pf, xv)) {           // identity (or zeros, per-feature branch) outside the tails: no parameter gradient
                     for (int k = 0; k < M; ++k) row[k] = T(0);
-                    gx[b * D + col] = gy[b * D + col];
+                    gx[b * D + col] = pf.dfull ? T(0) : gy[b * D + col];
                     continue;
                 }
                 // the row's raw widths / heights are replaced by their softmax probabilities (one exp pass)
@@ -265,7 +273,7 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
                 auto ah = [=](int i, T g) { row[K + i] = g; };
                 auto ad = [=](int j, T g) { row[2 * K + j] = g; };
                 auto zd = [=]() { for (int k = 2 * K; k < M; ++k) row[k] = T(0); };
-                gx[b * D + col] = rqs_element_bwd<T>(p, xv, gy[b * D + col], gld[b], pw, ph, dacc, inverse, aw, ah, ad, zd);
+                gx[b * D + col] = rqs_element_bwd<T>(pf, xv, gy[b * D + col], gld[b], pw, ph, dacc, inverse, aw, ah, ad, zd);
             }
         }
 #endif
@@ -279,7 +287,7 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
                     gx[b * D + col] = gy[b * D + col];
                     continue;
                 }
-                RqsParams<T> pu = p;
+                RqsParams<T> pu = rqs_feature_params(p, tails_i, bound_i, j);
                 pu.wh_div = T(1);  // the unconditional transform is not scaled (nsf/coupling.py:224-232)
                 const T *pj = s_prob + (size_t)j * PP, *dj = ud + (size_t)j * nd;
                 T *acc = s_acc + (size_t)j * M;
@@ -327,7 +335,8 @@ template <typename T>
 static int launch_bwd(const void *x, const void *gy, const void *gld, const void *cond, const void *uw, const void *uh,
                       const void *ud, const int64_t *iidx, int nI, const int64_t *tidx, int nT, int64_t B, int D,
                       const RqsParams<T> &p, int mode, void *gx, void *gcond, void *guw, void *guh, void *gud,
-                      hipStream_t st) {
+                      hipStream_t st, const int32_t *tails_t = nullptr, const void *bound_t = nullptr,
+                      const int32_t *tails_i = nullptr, const void *bound_i = nullptr) {
     const int M = 2 * p.K + p.nd, P = M | 1;
     const bool stage = mode != NF_RQS_SAMPLE_IDENTITY && nT > 0;
     auto lds_bytes = [&](int ts) {
@@ -343,20 +352,27 @@ static int launch_bwd(const void *x, const void *gy, const void *gld, const void
     const int grid = grid_for((B + TS - 1) / TS, 1, 2048);
     hipLaunchKernelGGL(rqs_coupling_bwd_kernel<T>, dim3(grid), dim3(256), lds, st, (const T *)x, (const T *)gy,
                        (const T *)gld, (const T *)cond, (const T *)uw, (const T *)uh, (const T *)ud, iidx, nI, tidx, nT,
-                       B, D, p, mode, (T *)gx, (T *)gcond, (T *)guw, (T *)guh, (T *)gud, TS);
+                       B, D, p, mode, (T *)gx, (T *)gcond, (T *)guw, (T *)guh, (T *)gud, TS, (const int *)tails_t,
+                       (const T *)bound_t, (const int *)tails_i, (const T *)bound_i);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
 
-extern "C" int nf_rqs_coupling_bwd(const void *x, const void *grad_y, const void *grad_logdet, const void *cond,
-                                   const void *uw, const void *uh, const void *ud, const int64_t *identity_idx, int nI,
-                                   const int64_t *transform_idx, int nT, int64_t B, int D, int K, int tails,
-                                   double tail_bound, double min_bin_width, double min_bin_height, double min_derivative,
-                                   double wh_div, int mode, void *grad_x, void *grad_cond, void *grad_uw, void *grad_uh,
-                                   void *grad_ud, int dtype, nf_stream_t stream) {
+extern "C" int nf_rqs_coupling_bwd_ft(const void *x, const void *grad_y, const void *grad_logdet, const void *cond,
+                                      const void *uw, const void *uh, const void *ud, const int64_t *identity_idx, int nI,
+                                      const int64_t *transform_idx, int nT, int64_t B, int D, int K, int tails,
+                                      double tail_bound, double min_bin_width, double min_bin_height,
+                                      double min_derivative, double wh_div, int mode, void *grad_x, void *grad_cond,
+                                      void *grad_uw, void *grad_uh, void *grad_ud, int dtype, const int32_t *tails_t,
+                                      const void *bound_t, const int32_t *tails_i, const void *bound_i,
+                                      nf_stream_t stream) {
     if (K < 1 || K > NF_MAX_BINS) return NF_ERANGE;
-    if (tails < NF_TAILS_NONE || tails > NF_TAILS_CIRCULAR) return NF_EINVAL;
+    if (tails < NF_TAILS_NONE || tails > NF_TAILS_FEATURE) return NF_EINVAL;
     if (B < 0 || D < 1 || nI < 0 || nT < 0 || nI + nT != D || mode < 0 || mode > 2) return NF_EINVAL;
+    if (tails == NF_TAILS_FEATURE && ((nT && mode != NF_RQS_SAMPLE_IDENTITY && !tails_t) ||
+                                      (nI && uw && mode != NF_RQS_SAMPLE_TRANSFORM && !tails_i))) return NF_EFAULT;
+    if (tails != NF_TAILS_FEATURE && (tails_t || tails_i)) return NF_EINVAL;
+    if (tails == NF_TAILS_NONE && (bound_t || bound_i)) return NF_EINVAL;
     if (B == 0) return NF_OK;
     if (!x || !grad_y || !grad_logdet || !grad_x) return NF_EFAULT;
     if (mode != NF_RQS_SAMPLE_IDENTITY && nT && (!cond || !grad_cond || !transform_idx)) return NF_EFAULT;
@@ -367,13 +383,26 @@ extern "C" int nf_rqs_coupling_bwd(const void *x, const void *grad_y, const void
         auto p = make_rqs_params<float>(K, tails, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height, min_derivative,
                                         wh_div);
         return launch_bwd<float>(x, grad_y, grad_logdet, cond, uw, uh, ud, identity_idx, nI, transform_idx, nT, B, D, p,
-                                 mode, grad_x, grad_cond, grad_uw, grad_uh, grad_ud, st);
+                                 mode, grad_x, grad_cond, grad_uw, grad_uh, grad_ud, st, tails_t, bound_t, tails_i, bound_i);
     }
     if (dtype == NF_F64) {
         auto p = make_rqs_params<double>(K, tails, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
                                          min_derivative, wh_div);
         return launch_bwd<double>(x, grad_y, grad_logdet, cond, uw, uh, ud, identity_idx, nI, transform_idx, nT, B, D,
-                                  p, mode, grad_x, grad_cond, grad_uw, grad_uh, grad_ud, st);
+                                  p, mode, grad_x, grad_cond, grad_uw, grad_uh, grad_ud, st, tails_t, bound_t, tails_i,
+                                  bound_i);
     }
     return NF_ENOTSUP;
+}
+
+extern "C" int nf_rqs_coupling_bwd(const void *x, const void *grad_y, const void *grad_logdet, const void *cond,
+                                   const void *uw, const void *uh, const void *ud, const int64_t *identity_idx, int nI,
+                                   const int64_t *transform_idx, int nT, int64_t B, int D, int K, int tails,
+                                   double tail_bound, double min_bin_width, double min_bin_height, double min_derivative,
+                                   double wh_div, int mode, void *grad_x, void *grad_cond, void *grad_uw, void *grad_uh,
+                                   void *grad_ud, int dtype, nf_stream_t stream) {
+    if (tails == NF_TAILS_FEATURE) return NF_EINVAL;
+    return nf_rqs_coupling_bwd_ft(x, grad_y, grad_logdet, cond, uw, uh, ud, identity_idx, nI, transform_idx, nT, B, D, K,
+                                  tails, tail_bound, min_bin_width, min_bin_height, min_derivative, wh_div, mode, grad_x,
+                                  grad_cond, grad_uw, grad_uh, grad_ud, dtype, nullptr, nullptr, nullptr, nullptr, stream);
 }

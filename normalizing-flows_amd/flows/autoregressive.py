@@ -176,15 +176,13 @@ class MaskedPiecewiseRationalQuadraticAutoregressive(Autoregressive):
             self._all_idx = idx
         wh_div = float(np.sqrt(self.autoregressive_net.hidden_features)) \
             if hasattr(self.autoregressive_net, "hidden_features") else 1.0
-        if autograd.needs_grad(inputs, params):
-            if isinstance(self.tails, (list, tuple)) or torch.is_tensor(self.tail_bound):
-                raise NotImplementedError("per-feature tails: inference only (no backward kernel yet)")
-            kw = dict(tails=self.tails, tail_bound=float(self.tail_bound), min_bin_width=self.min_bin_width,
-                      min_bin_height=self.min_bin_height, min_derivative=self.min_derivative, wh_div=wh_div)
-            return autograd.SplineFn.apply(inputs, params, None, None, None, self.num_bins, direction == 1, kw)
-        mode = ops.L.RQS_DENSITY if direction == 0 else ops.L.RQS_SAMPLE_TRANSFORM
         from .neural_spline import _tails_kwargs
         kw = _tails_kwargs(self.tails, self.tail_bound, "t", inputs.device, self.__dict__.setdefault("_tcache", {}))
+        if autograd.needs_grad(inputs, params):
+            kw = dict(kw, min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+                      min_derivative=self.min_derivative, wh_div=wh_div)
+            return autograd.SplineFn.apply(inputs, params, None, None, None, self.num_bins, direction == 1, kw)
+        mode = ops.L.RQS_DENSITY if direction == 0 else ops.L.RQS_SAMPLE_TRANSFORM
         return ops.rqs_coupling(inputs, params.contiguous(), None, None, None, idx[0], idx[1], self.num_bins, mode,
                                 min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
                                 min_derivative=self.min_derivative, wh_div=wh_div, **kw)

@@ -103,14 +103,24 @@ class PiecewiseRationalQuadraticCDF(Flow):
         if inputs.dim() != 2 or self.unnormalized_widths.dim() != 2:
             raise NotImplementedError("PiecewiseRationalQuadraticCDF: only (batch, features) inputs are implemented")
         D = inputs.shape[1]
+        kw = dict(min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+                  min_derivative=self.min_derivative,
+                  **_tails_kwargs(self.tails, self.tail_bound, "i", inputs.device, self.__dict__.setdefault("_tcache", {})))
+        if needs_grad(inputs, self):   # standalone use in a trained model: forward kernel + backward kernel
+            y, log_det = SplineFn.apply(inputs.contiguous(), None, self.unnormalized_widths, self.unnormalized_heights,
+                                        self.unnormalized_derivatives, self.num_bins, inverse, kw)
+            if ld is None:
+                return y, log_det
+            if acc is None or acc > 0:
+                ld += log_det
+            else:
+                ld -= log_det
+            return y, ld
         idx = torch.arange(D, device=inputs.device)
         none = idx[:0]
         return ops.rqs_coupling(inputs, None, self.unnormalized_widths.detach(), self.unnormalized_heights.detach(),
                                 self.unnormalized_derivatives.detach(), idx, none, self.num_bins,
-                                L.RQS_SAMPLE_IDENTITY if inverse else L.RQS_DENSITY, logdet=ld, acc=acc,
-                                min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
-                                min_derivative=self.min_derivative,
-                                **_tails_kwargs(self.tails, self.tail_bound, "i", inputs.device, self.__dict__.setdefault("_tcache", {})))
+                                L.RQS_SAMPLE_IDENTITY if inverse else L.RQS_DENSITY, logdet=ld, acc=acc, **kw)
 
     def forward(self, inputs, context=None):
         return self._spline(inputs, False)
@@ -256,8 +266,6 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
         if inputs.dim() == 4:
             return self._image(inputs, context, False, ld, acc)
         if needs_grad(inputs, context, self):
-            if self._per_feature:
-                raise NotImplementedError("per-feature tails: inference only (no backward kernel yet)")
             return self._autograd(inputs, context, False, ld, acc)
         if self.use_fused and self._fused_eligible(inputs, context):
             return self._fused(inputs, 0, ld, acc)
@@ -272,8 +280,6 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
         if inputs.dim() == 4:
             return self._image(inputs, context, True, ld, acc)
         if needs_grad(inputs, context, self):
-            if self._per_feature:
-                raise NotImplementedError("per-feature tails: inference only (no backward kernel yet)")
             return self._autograd(inputs, context, True, ld, acc)
         if self.use_fused and self._fused_eligible(inputs, context):
             return self._fused(inputs, 1, ld, acc)

@@ -316,9 +316,11 @@ def rqs_fused(x, blob, mask_parity, hidden, num_blocks, K, direction, logdet=Non
 
 
 def rqs_coupling_bwd(x, grad_y, grad_logdet, cond, uw, uh, ud, identity_idx, transform_idx, K, mode, tails="linear",
-                     tail_bound=3.0, min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, wh_div=1.0):
-    """Vector-Jacobian product of rqs_coupling (nf_rqs_coupling_bwd).  Returns (gx, gcond, guw, guh, gud)."""
-    L.require_device(x, grad_y, grad_logdet, cond, uw, uh, ud, identity_idx, transform_idx)
+                     tail_bound=3.0, min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, wh_div=1.0,
+                     tails_t=None, bound_t=None, tails_i=None, bound_i=None):
+    """Vector-Jacobian product of rqs_coupling (nf_rqs_coupling_bwd[_ft]).  Returns (gx, gcond, guw, guh, gud)."""
+    L.require_device(x, grad_y, grad_logdet, cond, uw, uh, ud, identity_idx, transform_idx, tails_t, bound_t, tails_i,
+                     bound_i)
     B, D = x.shape
     x, grad_y, grad_logdet = x.contiguous(), grad_y.contiguous(), grad_logdet.contiguous()
     gx = torch.zeros_like(x)
@@ -326,6 +328,21 @@ def rqs_coupling_bwd(x, grad_y, grad_logdet, cond, uw, uh, ud, identity_idx, tra
     guw = torch.zeros_like(uw) if uw is not None else None
     guh = torch.zeros_like(uh) if uh is not None else None
     gud = torch.zeros_like(ud) if ud is not None else None
+    if tails == "feature" or bound_t is not None or bound_i is not None:
+        fix_b = lambda t: None if t is None else t.to(device=x.device, dtype=x.dtype).contiguous()
+        fix_t = lambda t: None if t is None else t.to(device=x.device, dtype=torch.int32).contiguous()
+        bt, bi, tt, ti = fix_b(bound_t), fix_b(bound_i), fix_t(tails_t), fix_t(tails_i)
+        code = 3 if tails == "feature" else L.TAILS[tails]
+        scalar_bound = float(tail_bound) if not torch.is_tensor(tail_bound) else 1.0
+        rc = L.lib().nf_rqs_coupling_bwd_ft(ptr(x), ptr(grad_y), ptr(grad_logdet), ptr(cond), ptr(uw), ptr(uh), ptr(ud),
+                                            ptr(identity_idx), i32(identity_idx.numel()), ptr(transform_idx),
+                                            i32(transform_idx.numel()), i64(B), i32(D), i32(K), i32(code),
+                                            f64(scalar_bound), f64(min_bin_width), f64(min_bin_height),
+                                            f64(min_derivative), f64(wh_div), i32(mode), ptr(gx), ptr(gcond), ptr(guw),
+                                            ptr(guh), ptr(gud), i32(L.dtype_code(x)), ptr(tt), ptr(bt), ptr(ti), ptr(bi),
+                                            L.stream())
+        L.check(rc, "nf_rqs_coupling_bwd_ft")
+        return gx, gcond, guw, guh, gud
     rc = L.lib().nf_rqs_coupling_bwd(ptr(x), ptr(grad_y), ptr(grad_logdet), ptr(cond), ptr(uw), ptr(uh), ptr(ud),
                                      ptr(identity_idx), i32(identity_idx.numel()), ptr(transform_idx),
                                      i32(transform_idx.numel()), i64(B), i32(D), i32(K), i32(L.TAILS[tails]),

@@ -677,23 +677,55 @@ def gen_glow_grads():
     npz("grad_realnvp", x=x, loss=loss.detach(), **grads, **sd(m, "sd__"))
 
 
+def layer_grads(layer, x, tag):
+    """Reference autograd through one layer in both directions: loss = sum(z * cz) + sum(log_det * cl)."""
+    out = {}
+    g = torch.Generator().manual_seed(78)
+    cz = torch.randn(x.shape, generator=g)
+    cl = torch.randn(x.shape[0], generator=g)
+    for name, fn in (("inv", layer.inverse), ("fwd", layer.forward)):
+        xx = x.clone().requires_grad_(True)
+        layer.zero_grad()
+        z, ld = fn(xx)
+        ((z * cz).sum() + (ld * cl).sum()).backward()
+        out["gx_" + name] = xx.grad.clone()
+        for k, p_ in layer.named_parameters():
+            out["g_%s__%s" % (name, k.replace(".", "__"))] = torch.zeros_like(p_) if p_.grad is None else p_.grad.clone()
+    npz(tag, x=x, cz=cz, cl=cl, **out, **sd(layer, "sd__"))
+
+
+def gen_circular_grads():
+    """Gradients through the per-feature-tails layers (utils/splines.py:48-66): circular coupled NSF with scalar and
+    tensor bounds (some linear features outside their interval: zero output, zero gradient), circular AR-NSF, and the
+    bare coupling transform with string tails + tensor bound."""
+    g = torch.Generator().manual_seed(43)
+    for name, tb in (("grad_circ_coupled_scalar", 3.0),
+                     ("grad_circ_coupled_tensor", torch.tensor([3.0, np.pi, 2.0, np.pi, 3.5, 1.5]))):
+        torch.manual_seed(12)
+        layer = nf.flows.CircularCoupledRationalQuadraticSpline(6, 2, 16, ind_circ=[1, 3, 4], num_bins=5, tail_bound=tb,
+                                                                init_identity=False)
+        perturb(layer, 0.3, 16)
+        bound = tb if torch.is_tensor(tb) else torch.full((6,), tb)
+        x = (torch.rand(12, 6, generator=g) * 2 - 1) * bound * 0.98
+        x[0, 0], x[1, 2], x[2, 5] = 50.0, -60.0, 7.0
+        layer_grads(layer, x, name)
+    torch.manual_seed(13)
+    layer = nf.flows.CircularAutoregressiveRationalQuadraticSpline(5, 2, 12, ind_circ=[0, 3], num_bins=4, tail_bound=2.5,
+                                                                   permute_mask=False, init_identity=False)
+    perturb(layer, 0.3, 17)
+    layer_grads(layer, (torch.rand(9, 5, generator=g) * 2 - 1) * 2.4, "grad_circ_autoregressive")
+    torch.manual_seed(14)
+    tbv = torch.tensor([2.0, 3.0, 1.5, 2.5])
+    mask = nf.utils.masks.create_alternating_binary_mask(4, even=False)
+    mk = lambda i, o: nf.nets.ResidualNet(i, o, hidden_features=8, num_blocks=1)
+    t = nf.flows.neural_spline.coupling.PiecewiseRationalQuadraticCoupling(mask, mk, num_bins=4, tails="linear",
+                                                                           tail_bound=tbv, apply_unconditional_transform=True)
+    perturb(t, 0.3, 18)
+    layer_grads(t, 1.5 * torch.randn(10, 4, generator=g), "grad_coupling_tensor_bound")
+
+
 def gen_ar_grads():
     """Gradients through the autoregressive layers (MAF, AR-NSF) in both directions and through GlowBase.log_prob."""
-    def layer_grads(layer, x, tag):
-        out = {}
-        g = torch.Generator().manual_seed(78)
-        cz = torch.randn(x.shape, generator=g)
-        cl = torch.randn(x.shape[0], generator=g)
-        for name, fn in (("inv", layer.inverse), ("fwd", layer.forward)):
-            xx = x.clone().requires_grad_(True)
-            layer.zero_grad()
-            z, ld = fn(xx)
-            ((z * cz).sum() + (ld * cl).sum()).backward()
-            out["gx_" + name] = xx.grad.clone()
-            for k, p_ in layer.named_parameters():
-                out["g_%s__%s" % (name, k.replace(".", "__"))] = p_.grad.clone()
-        npz(tag, x=x, cz=cz, cl=cl, **out, **sd(layer, "sd__"))
-
     torch.manual_seed(21)
     maf = nf.flows.MaskedAffineAutoregressive(5, 12, num_blocks=2)
     perturb(maf, 0.2, 20)
@@ -759,6 +791,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "circular":
         gen_circular()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "circular_grads":
+        gen_circular_grads()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "misc":
         gen_misc()
         sys.exit(0)
@@ -789,3 +824,4 @@ if __name__ == "__main__":
     gen_glow_grads()
     gen_ar_grads()
     gen_image_coupling()
+    gen_circular_grads()

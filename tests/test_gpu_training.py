@@ -44,7 +44,8 @@ def check_layer_grads(layer, g, rtol, atol):
         for k, p_ in layer.named_parameters():
             ref = g["g_%s__%s" % (name, k.replace(".", "__"))]
             scale = max(1.0, float(np.abs(ref).max()))
-            assert_close(N(p_.grad), ref, what="%s grad %s" % (name, k), rtol=rtol, atol=atol * scale)
+            got = np.zeros_like(ref) if p_.grad is None else N(p_.grad)
+            assert_close(got, ref, what="%s grad %s" % (name, k), rtol=rtol, atol=atol * scale)
 
 
 @pytest.mark.parametrize("tag", ["f32", "f64"])
@@ -268,6 +269,35 @@ def test_arnsf_gradients_vs_reference_autograd(nfa):
     layer = load_layer(nfa.flows.AutoregressiveRationalQuadraticSpline(4, 1, 10, num_bins=4, init_identity=False),
                        golden_state(g), torch.float32)
     check_layer_grads(layer, g, rtol=2e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("name,tb", [("grad_circ_coupled_scalar", 3.0),
+                                     ("grad_circ_coupled_tensor", [3.0, np.pi, 2.0, np.pi, 3.5, 1.5])])
+def test_circular_coupled_gradients_vs_reference_autograd(nfa, name, tb):
+    """Per-feature tails (utils/splines.py:48-66) through nf_rqs_coupling_bwd_ft: circular / linear features side by
+    side, scalar and tensor bounds, linear features outside their interval (zero output, zero gradient)."""
+    g = load_golden(name)
+    tbv = torch.tensor(tb) if isinstance(tb, list) else tb
+    layer = nfa.flows.CircularCoupledRationalQuadraticSpline(6, 2, 16, ind_circ=[1, 3, 4], num_bins=5, tail_bound=tbv,
+                                                             init_identity=False)
+    check_layer_grads(load_layer(layer, golden_state(g), torch.float32), g, rtol=2e-3, atol=2e-4)
+
+
+def test_circular_autoregressive_gradients_vs_reference_autograd(nfa):
+    g = load_golden("grad_circ_autoregressive")
+    layer = nfa.flows.CircularAutoregressiveRationalQuadraticSpline(5, 2, 12, ind_circ=[0, 3], num_bins=4, tail_bound=2.5,
+                                                                    permute_mask=False, init_identity=False)
+    check_layer_grads(load_layer(layer, golden_state(g), torch.float32), g, rtol=2e-3, atol=2e-4)
+
+
+def test_coupling_tensor_bound_gradients_vs_reference_autograd(nfa):
+    g = load_golden("grad_coupling_tensor_bound")
+    mask = nfa.utils.create_alternating_binary_mask(4, even=False)
+    mk = lambda i, o: nfa.nets.ResidualNet(i, o, hidden_features=8, num_blocks=1)
+    t = nfa.flows.PiecewiseRationalQuadraticCoupling(mask, mk, num_bins=4, tails="linear",
+                                                     tail_bound=torch.tensor([2.0, 3.0, 1.5, 2.5]),
+                                                     apply_unconditional_transform=True)
+    check_layer_grads(load_layer(t, golden_state(g), torch.float32), g, rtol=2e-3, atol=2e-4)
 
 
 def test_glow_base_gradients_vs_reference_autograd(nfa):

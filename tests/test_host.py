@@ -84,6 +84,16 @@ def test_c_abi_argument_validation_newer_entry_points(nfa):
     assert arnsf(8, 3) == -22 and arnsf(0, 1) == -22 and arnsf(8, 1, hp=500) == -22
     assert arnsf(8, 1, blob=null) == -14
     assert arnsf(8, 1, B=0) == 0
+    # per-feature backward: type codes required with NF_TAILS_FEATURE, refused otherwise
+    def bwd_ft(tails, tt, ti=null, uw=null):
+        return lib.nf_rqs_coupling_bwd_ft(one, one, one, one, uw, uw, uw, one, i32(2), one, i32(2), i64(4), i32(4), i32(4),
+                                          i32(tails), f64(3.0), f64(1e-3), f64(1e-3), f64(1e-3), f64(1.0), i32(0), one, one,
+                                          uw, uw, uw, i32(0), tt, null, ti, null, null)
+    assert bwd_ft(3, null) == -14 and bwd_ft(3, one, null, one) == -14
+    assert bwd_ft(1, one) == -22 and bwd_ft(4, one) == -22
+    assert lib.nf_rqs_coupling_bwd(one, one, one, one, null, null, null, one, i32(2), one, i32(2), i64(4), i32(4), i32(4),
+                                   i32(3), f64(3.0), f64(1e-3), f64(1e-3), f64(1e-3), f64(1.0), i32(0), one, one, null,
+                                   null, null, i32(0), null) == -22
     # weight gradient: N <= 128 columns per launch, accumulate is 0 / 1
     assert lib.nf_linear_wgrad(one, one, one, one, one, i64(64), i32(8), i32(200), i32(0), null) == -95
     assert lib.nf_linear_wgrad(one, one, one, one, one, i64(64), i32(8), i32(8), i32(2), null) == -22
