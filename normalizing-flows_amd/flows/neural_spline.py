@@ -304,7 +304,7 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
         (:152-156); the unconditional transform carries per-pixel parameters (`img_shape`), so it runs through the same
         kernel as a second 'conditioner' whose rows are shared across the batch."""
         if needs_grad(inputs, context, self):
-            raise NotImplementedError("image neural-spline coupling: inference only")
+            return self._image_autograd(inputs, context, sample, ld, acc)
         B, C, H, W = inputs.shape
         HW = H * W
         I, Tf = self.identity_features, self.transform_features
@@ -345,6 +345,58 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
             cond = to_rows(self.transform_net(img[:, I, ...].contiguous(), context), len(Tf))
             ops.rqs_coupling(rows, cond, None, None, None, I, Tf, self.num_bins, L.RQS_SAMPLE_TRANSFORM, y=y_rows,
                              logdet=ld_rows, acc=L.LD_ADD, **kw)
+        out = y_rows.view(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+        log_det = ld_rows.view(B, HW).sum(1)
+        if ld is not None:
+            if acc is None or acc > 0:
+                ld += log_det
+            else:
+                ld -= log_det
+            return out, ld
+        return out, log_det
+
+    def _image_autograd(self, inputs, context, sample, ld, acc):
+        """Training path of _image: the same pixel-row view, each half through SplineFn (forward + backward kernel); the
+        per-pixel unconditional parameters are expanded over the batch by torch, whose autograd sums their gradient."""
+        B, C, H, W = inputs.shape
+        HW = H * W
+        I, Tf = self.identity_features, self.transform_features
+        K = self.num_bins
+        rows = inputs.permute(0, 2, 3, 1).reshape(B * HW, C)
+        ident, trans = rows.index_select(1, I), rows.index_select(1, Tf)
+        kw = self._kernel_kwargs()
+        kw.pop("tails_i", None)
+        kw.pop("bound_i", None)
+        u = self.unconditional_transform
+
+        def to_rows(p, n):
+            return p.reshape(B, n, -1, H, W).permute(0, 3, 4, 1, 2).reshape(B * HW, -1).contiguous()
+
+        def uncond(x_rows, inverse):
+            prm = torch.cat([u.unnormalized_widths, u.unnormalized_heights, u.unnormalized_derivatives], -1)
+            if prm.dim() != 4:
+                raise NotImplementedError("image coupling needs an unconditional transform built with img_shape")
+            prm = prm.permute(1, 2, 0, 3).reshape(1, HW, -1).expand(B, HW, -1).reshape(B * HW, -1).contiguous()
+            ukw = dict(min_bin_width=u.min_bin_width, min_bin_height=u.min_bin_height,
+                       min_derivative=u.min_derivative, wh_div=1.0)
+            ukw.update(_tails_kwargs(u.tails, u.tail_bound, "t", inputs.device, self.__dict__.setdefault("_tcache_u", {})))
+            return SplineFn.apply(x_rows.contiguous(), prm, None, None, None, K, inverse, ukw)
+
+        ld_i = None
+        if not sample:
+            cond = to_rows(self.transform_net(inputs[:, I, ...], context), len(Tf))
+            trans, ld_t = SplineFn.apply(trans.contiguous(), cond, None, None, None, K, False, kw)
+            if u is not None:
+                ident, ld_i = uncond(ident, False)
+        else:
+            if u is not None:
+                ident, ld_i = uncond(ident, True)
+            img_i = ident.reshape(B, H, W, len(I)).permute(0, 3, 1, 2).contiguous()
+            cond = to_rows(self.transform_net(img_i, context), len(Tf))
+            trans, ld_t = SplineFn.apply(trans.contiguous(), cond, None, None, None, K, True, kw)
+        ld_rows = ld_t if ld_i is None else ld_t + ld_i
+        y_rows = torch.empty(B * HW, C, dtype=inputs.dtype, device=inputs.device)
+        y_rows = y_rows.index_copy(1, I, ident).index_copy(1, Tf, trans)
         out = y_rows.view(B, H, W, C).permute(0, 3, 1, 2).contiguous()
         log_det = ld_rows.view(B, HW).sum(1)
         if ld is not None:

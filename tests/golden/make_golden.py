@@ -770,6 +770,7 @@ def gen_image_coupling():
         zf, ldf = t.forward(x)
         zi, ldi = t.inverse(x)
     npz("coupling_image", x=x, z_fwd=zf, ld_fwd=ldf, z_inv=zi, ld_inv=ldi, **sd(t, "sd__"))
+    layer_grads(t, x, "grad_coupling_image")     # reference autograd through both directions of the same layer
 
 
 if __name__ == "__main__":

@@ -300,6 +300,28 @@ def test_coupling_tensor_bound_gradients_vs_reference_autograd(nfa):
     check_layer_grads(load_layer(t, golden_state(g), torch.float32), g, rtol=2e-3, atol=2e-4)
 
 
+def test_image_spline_coupling_gradients_vs_reference_autograd(nfa):
+    """NCHW spline coupling (nsf/coupling.py:150-160) under autograd: conv conditioner, per-pixel unconditional
+    transform whose gradient is summed over the batch."""
+    import warnings
+    g = load_golden("grad_coupling_image")
+    mask = nfa.utils.create_alternating_binary_mask(4, even=False)
+
+    class CtxConv(torch.nn.Module):
+        def __init__(self, i, o):
+            super().__init__()
+            self.net = nfa.nets.ConvNet2d([i, 8, o], [3, 3], init_zeros=False)
+
+        def forward(self, x, context=None):
+            return self.net(x)
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        t = nfa.flows.PiecewiseRationalQuadraticCoupling(mask, CtxConv, num_bins=4, tails="linear", tail_bound=3.0,
+                                                         apply_unconditional_transform=True, img_shape=[4, 4])
+    check_layer_grads(load_layer(t, golden_state(g), torch.float32), g, rtol=2e-3, atol=2e-4)
+
+
 def test_glow_base_gradients_vs_reference_autograd(nfa):
     g = load_golden("grad_glow_base")
     gb = nfa.distributions.GlowBase((3, 2, 2), num_classes=2)
