@@ -67,7 +67,7 @@ def _tails_kwargs(tails, tail_bound, role, device=None, cache=None):
 
 
 class PiecewiseRationalQuadraticCDF(Flow):
-    """Batch-shared monotone RQ spline per feature (nsf/coupling.py:170-259).  2-D inputs (B, features)."""
+    """Batch-shared monotone RQ spline per feature (nsf/coupling.py:170-259).  Inputs (B, *shape)."""
 
     def __init__(self, shape, num_bins=10, tails=None, tail_bound=1.0, identity_init=True,
                  min_bin_width=DEFAULT_MIN_BIN_WIDTH, min_bin_height=DEFAULT_MIN_BIN_HEIGHT,
@@ -100,15 +100,28 @@ class PiecewiseRationalQuadraticCDF(Flow):
             self.unnormalized_derivatives = nn.Parameter(torch.rand(*shape, num_derivatives))
 
     def _spline(self, inputs, inverse, ld=None, acc=None):
-        if inputs.dim() != 2 or self.unnormalized_widths.dim() != 2:
-            raise NotImplementedError("PiecewiseRationalQuadraticCDF: only (batch, features) inputs are implemented")
-        D = inputs.shape[1]
+        uw, uh, ud = self.unnormalized_widths, self.unnormalized_heights, self.unnormalized_derivatives
+        tails, bound = self.tails, self.tail_bound
+        shape = tuple(uw.shape[:-1])
+        if tuple(inputs.shape[1:]) != shape:
+            raise ValueError("PiecewiseRationalQuadraticCDF: inputs of shape (batch,) + %s expected" % (shape,))
+        x2 = inputs
+        if len(shape) != 1:   # (B, *shape) inputs (nsf/coupling.py:221-253 expands the parameters over the batch): the
+            x2 = inputs.reshape(inputs.shape[0], -1)   # kernel sees prod(shape) independent features
+            uw, uh, ud = uw.reshape(-1, uw.shape[-1]), uh.reshape(-1, uh.shape[-1]), ud.reshape(-1, ud.shape[-1])
+            outer = int(np.prod(shape[:-1]))
+            if isinstance(tails, (list, tuple)):
+                tails = list(tails) * outer             # the list runs along the last feature dim (utils/splines.py:51-57)
+            if torch.is_tensor(bound):
+                bound = torch.broadcast_to(bound, shape).reshape(-1)
+        elif torch.is_tensor(bound):
+            bound = torch.broadcast_to(bound, shape)
+        cache = self.__dict__.setdefault("_tcache", {})
         kw = dict(min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
-                  min_derivative=self.min_derivative,
-                  **_tails_kwargs(self.tails, self.tail_bound, "i", inputs.device, self.__dict__.setdefault("_tcache", {})))
+                  min_derivative=self.min_derivative, **_tails_kwargs(tails, bound, "i", inputs.device, cache))
         if needs_grad(inputs, self):   # standalone use in a trained model: forward kernel + backward kernel
-            y, log_det = SplineFn.apply(inputs.contiguous(), None, self.unnormalized_widths, self.unnormalized_heights,
-                                        self.unnormalized_derivatives, self.num_bins, inverse, kw)
+            y, log_det = SplineFn.apply(x2.contiguous(), None, uw, uh, ud, self.num_bins, inverse, kw)
+            y = y.reshape(inputs.shape)
             if ld is None:
                 return y, log_det
             if acc is None or acc > 0:
@@ -116,11 +129,11 @@ class PiecewiseRationalQuadraticCDF(Flow):
             else:
                 ld -= log_det
             return y, ld
-        idx = torch.arange(D, device=inputs.device)
+        idx = torch.arange(x2.shape[1], device=inputs.device)
         none = idx[:0]
-        return ops.rqs_coupling(inputs, None, self.unnormalized_widths.detach(), self.unnormalized_heights.detach(),
-                                self.unnormalized_derivatives.detach(), idx, none, self.num_bins,
-                                L.RQS_SAMPLE_IDENTITY if inverse else L.RQS_DENSITY, logdet=ld, acc=acc, **kw)
+        y, ld = ops.rqs_coupling(x2, None, uw.detach(), uh.detach(), ud.detach(), idx, none, self.num_bins,
+                                 L.RQS_SAMPLE_IDENTITY if inverse else L.RQS_DENSITY, logdet=ld, acc=acc, **kw)
+        return y.reshape(inputs.shape), ld
 
     def forward(self, inputs, context=None):
         return self._spline(inputs, False)

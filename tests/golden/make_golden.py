@@ -724,6 +724,26 @@ def gen_circular_grads():
     layer_grads(t, 1.5 * torch.randn(10, 4, generator=g), "grad_coupling_tensor_bound")
 
 
+def gen_cdf():
+    """Standalone PiecewiseRationalQuadraticCDF (nsf/coupling.py:170-259): 1-D and N-D parameter shapes, every tails
+    variant, values and reference-autograd gradients in both directions."""
+    CDF = nf.flows.neural_spline.coupling.PiecewiseRationalQuadraticCDF
+    g = torch.Generator().manual_seed(51)
+    cases = [("cdf_linear_d5", [5], dict(tails="linear", tail_bound=2.0), 2.5 * torch.randn(7, 5, generator=g)),
+             ("cdf_none_img", [3, 4, 4], dict(tails=None), torch.rand(4, 3, 4, 4, generator=g)),
+             ("cdf_list_2x3", [2, 3], dict(tails=["linear", "circular", "linear"],
+                                          tail_bound=torch.tensor([2.0, 3.0, 1.5])),
+              1.4 * torch.randn(6, 2, 3, generator=g))]
+    for i, (name, shape, kw, x) in enumerate(cases):
+        torch.manual_seed(30 + i)
+        t = CDF(shape, num_bins=5, identity_init=False, **kw)
+        with torch.no_grad():
+            zf, ldf = t.forward(x)
+            zi, ldi = t.inverse(x)
+        npz(name, x=x, z_fwd=zf, ld_fwd=ldf, z_inv=zi, ld_inv=ldi, **sd(t, "sd__"))
+        layer_grads(t, x, "grad_" + name)
+
+
 def gen_ar_grads():
     """Gradients through the autoregressive layers (MAF, AR-NSF) in both directions and through GlowBase.log_prob."""
     torch.manual_seed(21)
@@ -792,6 +812,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "circular":
         gen_circular()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "cdf":
+        gen_cdf()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "circular_grads":
         gen_circular_grads()
         sys.exit(0)
@@ -826,3 +849,4 @@ if __name__ == "__main__":
     gen_ar_grads()
     gen_image_coupling()
     gen_circular_grads()
+    gen_cdf()

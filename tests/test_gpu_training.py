@@ -322,6 +322,27 @@ def test_image_spline_coupling_gradients_vs_reference_autograd(nfa):
     check_layer_grads(load_layer(t, golden_state(g), torch.float32), g, rtol=2e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("name,shape,kw", [
+    ("cdf_linear_d5", [5], dict(tails="linear", tail_bound=2.0)),
+    ("cdf_none_img", [3, 4, 4], dict(tails=None)),
+    ("cdf_list_2x3", [2, 3], dict(tails=["linear", "circular", "linear"], tail_bound=[2.0, 3.0, 1.5]))])
+def test_standalone_cdf_values_and_gradients_vs_reference(nfa, name, shape, kw):
+    """PiecewiseRationalQuadraticCDF on its own (nsf/coupling.py:170-259): (B, *shape) inputs, every tails variant."""
+    kw = dict(kw)
+    if isinstance(kw.get("tail_bound"), list):
+        kw["tail_bound"] = torch.tensor(kw["tail_bound"])
+    g = load_golden(name)
+    t = load_layer(nfa.flows.PiecewiseRationalQuadraticCDF(shape, num_bins=5, identity_init=False, **kw),
+                   golden_state(g), torch.float32)
+    with torch.no_grad():
+        for d, fn in (("fwd", t.forward), ("inv", t.inverse)):
+            z, ld = fn(T(g["x"]))
+            assert z.shape == g["x"].shape
+            assert_close(N(z), g["z_" + d], what="z_" + d, rtol=1e-4, atol=1e-5)
+            assert_close(N(ld), g["ld_" + d], what="ld_" + d, rtol=1e-4, atol=1e-4)
+    check_layer_grads(t, load_golden("grad_" + name), rtol=2e-3, atol=2e-4)
+
+
 def test_glow_base_gradients_vs_reference_autograd(nfa):
     g = load_golden("grad_glow_base")
     gb = nfa.distributions.GlowBase((3, 2, 2), num_classes=2)
