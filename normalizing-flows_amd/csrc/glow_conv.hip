@@ -1,0 +1,323 @@
+// glow_conv.hip -- the conditioner of a GlowBlock, ConvNet2d([Cin, 256, 256, Cout], kernel sizes (3, 1, 3)) =
+// conv3x3 -> LeakyReLU -> conv1x1 -> LeakyReLU -> conv3x3 (normflows/nets/cnn.py:5-63 as built by
+// normflows/flows/affine/glow.py:41-62), as ONE kernel on exact-fp32 MFMA for gfx950.
+//
+// A workgroup owns 256 pixels = 256 / (H W) WHOLE images (H W must divide 256: 16x16, 8x8, 4x4 ...), so the two 3x3
+// convolutions never need pixels of another workgroup and the zero padding of cnn.py:33 is the image border itself.
+// Per pixel the network is then an MLP with a gather in front and a scatter behind:
+//   conv3x3 #1 : im2col -- the B operand of GEMM 1 is gathered from the zero-padded input image in LDS,
+//                k = 9 c + tap (the natural (256, Cin, 3, 3) weight order), K1 = 9 Cin padded to a multiple of 8;
+//   conv1x1    : GEMM 2, 256 x 256;
+//   conv3x3 #2 : col2im -- GEMM 3 produces, per pixel, the 9 Cout partial products P[co, tap] = W3[co, :, tap] . h2,
+//                and out[co, y, x] = b3[co] + sum_tap P[co, tap][y + ky - 1, x + kx - 1] is a 9-term gather over
+//                neighbouring pixels through LDS (fixed summation order: deterministic).  Output rows are grouped 3
+//                channels (27 rows, 5 padding) per 32-row MFMA block.
+// The 256-channel hidden tensors never leave the chip: h1 = 8 x 16 accumulator registers per lane (wave = 32 pixels,
+// v_mfma_f32_32x32x2_f32, transposed GEMMs as in rqs_fused.hip); h2 is produced 32 channels at a time and consumed
+// at once as the K = 32 slice of GEMM 3 (its C registers ARE the B operand: lane-half hh contracts over exactly the
+// units it holds).  Up to 4 output blocks (12 channels) are accumulated per sweep over h2; more output channels take
+// further sweeps (h2 recomputed).  Weights stream through a 2-slot LDS ring by global_load_lds, one barrier per
+// 16 KB stage, shared by the 8 waves.
+//
+// HBM traffic per pixel: 4 Cin bytes in, 4 Cout bytes out (the library path writes and re-reads the two 1 KB hidden
+// tensors and runs two extra bias / activation passes).
+#include "fused_common.hpp"
+
+namespace nf {
+
+constexpr int GC_HID = 256;          // hidden channels
+constexpr int GC_NW = 8;             // waves per workgroup
+constexpr int GC_PX = 32 * GC_NW;    // pixels per workgroup
+constexpr int GC_HDR = 64;
+constexpr int GC_STAGE = 4096;       // floats per stage (16 KB)
+constexpr int GC_OBP = 4;            // output row-blocks (x 3 channels) per sweep
+
+struct GcMeta {
+    int Cin, Cout;
+    int K1;      // 9 Cin
+    int nkg1;    // k-groups (of 8) of GEMM 1
+    int nst1;    // stages per row-block of GEMM 1 (16 k-groups each)
+    int OB;      // output row-blocks = ceil(Cout / 3)
+    int npass;   // sweeps = ceil(OB / 4)
+    int small;   // floats of the small section: b1 (256, register order) | b2 (256, register order) | b3 (12 npass)
+    float slope;
+};
+
+static inline GcMeta gc_meta(int Cin, int Cout, double slope) {
+    GcMeta m;
+    m.Cin = Cin; m.Cout = Cout;
+    m.K1 = 9 * Cin;
+    m.nkg1 = (m.K1 + 7) / 8;
+    m.nst1 = (m.nkg1 + 15) / 16;
+    m.OB = (Cout + 2) / 3;
+    m.npass = (m.OB + GC_OBP - 1) / GC_OBP;
+    m.small = 2 * GC_HID + 3 * GC_OBP * m.npass;
+    m.slope = (float)slope;
+    return m;
+}
+__host__ __device__ inline int gc_small_padded(const GcMeta &m) { return (m.small + 63) / 64 * 64; }
+__host__ __device__ inline int gc_off_stages(const GcMeta &m) { return GC_HDR + gc_small_padded(m); }
+__host__ __device__ inline int gc_nstages_blob(const GcMeta &m) { return 8 * m.nst1 + 16 + 8 * m.npass; }
+
+// One thread per blob float.  Stage image = MFMA A-operand order [k-group][lane][4]: row = lane & 31,
+// k = 8 kg + 4 (lane >> 5) + r4 (rqs_fused.hip has the same convention).
+__global__ void gc_pack_kernel(const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W2,
+                               const float *__restrict__ b2, const float *__restrict__ W3, const float *__restrict__ b3,
+                               float *__restrict__ blob, GcMeta m, int64_t total) {
+    const int offs = gc_off_stages(m);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = 0.0f;
+        if (i < GC_HDR) {
+            v = i == 0 ? 356.0f : (i == 1 ? (float)m.Cin : (i == 2 ? (float)m.Cout : 0.0f));
+        } else if (i < offs) {
+            const int j = (int)i - GC_HDR;
+            if (j < 2 * GC_HID) {
+                const int q = j & 255, reg = q & 15, hh = (q >> 4) & 1, mb = q >> 5;
+                const int row = 32 * mb + 8 * (reg >> 2) + 4 * hh + (reg & 3);
+                v = j < GC_HID ? b1[row] : b2[row];
+            } else if (j - 2 * GC_HID < m.Cout) {
+                v = b3[j - 2 * GC_HID];
+            }
+        } else {
+            const int64_t t = i - offs;
+            const int st = (int)(t / GC_STAGE), e = (int)(t % GC_STAGE);
+            const int r4 = e & 3, lane = (e >> 2) & 63, kg = (e >> 8) & 15, rho = lane & 31, hk = lane >> 5;
+            if (st < 8 * m.nst1) {
+                const int mb = st / m.nst1, c = st % m.nst1;
+                const int k = 8 * (16 * c + kg) + 4 * hk + r4;
+                if (k < m.K1) v = W1[(size_t)(32 * mb + rho) * m.K1 + k];
+            } else if (st < 8 * m.nst1 + 16) {
+                const int q = st - 8 * m.nst1, j = q >> 1, half = q & 1;
+                const int k = 128 * half + 8 * kg + 4 * hk + r4;
+                v = W2[(size_t)(32 * j + rho) * GC_HID + k];
+            } else {
+                const int q = st - 8 * m.nst1 - 16, pass = q >> 3, j = q & 7;
+                const int mm = kg >> 2, s = kg & 3;
+                const int cc = rho / 9, tap = rho - 9 * cc;
+                const int co = 3 * (GC_OBP * pass + mm) + cc;
+                const int k = 32 * j + 8 * s + 4 * hk + r4;
+                if (rho < 27 && co < m.Cout) v = W3[((size_t)co * GC_HID + k) * 9 + tap];
+            }
+        }
+        blob[i] = v;
+    }
+}
+
+#define GC_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// acc += Wblock(32 x 128) * B with the B operand of (k-group s, r) = bsrc[s >> 2][4 (s & 3) + r]: 16 ds_read_b128 + 64 MFMA
+__device__ __forceinline__ void gc_mm128(const float *buf, int lane, f32x16 &acc, const f32x16 &b0, const f32x16 &b1,
+                                         const f32x16 &b2, const f32x16 &b3) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(buf + s * 256 + lane * 4);
+        const f32x16 &bs = (s >> 2) == 0 ? b0 : ((s >> 2) == 1 ? b1 : ((s >> 2) == 2 ? b2 : b3));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = GC_MFMA(a[r], bs[4 * (s & 3) + r], acc);
+    }
+}
+
+__device__ __forceinline__ void gc_leaky(f32x16 &v, float slope) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) v[c] = fmaxf(v[c], v[c] * slope);   // 0 <= slope <= 1 (cnn.py:38 LeakyReLU)
+}
+
+__global__ void __launch_bounds__(64 * GC_NW, 2)
+glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restrict__ out, const float *__restrict__ blob,
+                    GcMeta mt, int64_t B, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int HW = H * W, PH = H + 2, PW = W + 2, IPW = GC_PX / HW;
+    const int K1p = 8 * mt.nkg1;
+    float *ring = smem;                          // 2 x 16 KB weight stages
+    float *P = ring + 2 * GC_STAGE;              // 32 rows x 256 pixels: one output block's tap products
+    float *small = P + 32 * GC_PX;               // biases
+    int *koff = reinterpret_cast<int *>(small + gc_small_padded(mt));   // im2col offset of every k
+    float *xin = reinterpret_cast<float *>(koff + K1p);                  // zero-padded input images [img][c][PH][PW]
+    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = wid * 32 + (lane & 31);
+    const int li = px / HW, pin = px - li * HW, py = pin / W, pxx = pin - py * W;
+    const int base0 = li * mt.Cin * PH * PW + py * PW + pxx;
+    const int64_t img0 = (int64_t)blockIdx.x * IPW;
+
+    const int nst_l1 = 8 * mt.nst1;
+    const int total_stages = nst_l1 + 24 * mt.npass;
+    auto phys = [&](int s) -> int {   // stream position -> stage of the blob (GEMM 2's stages are re-streamed every sweep)
+        if (s < nst_l1) return s;
+        const int q = s - nst_l1, pass = q / 24, w = q - 24 * pass, j = w / 3, t = w - 3 * j;
+        return t < 2 ? nst_l1 + 2 * j + t : nst_l1 + 16 + 8 * pass + j;
+    };
+    const float *stages = blob + gc_off_stages(mt);
+    int stage = 0;
+    auto issue = [&](int gs) {
+        constexpr int PPW = 16 / GC_NW;  // 1 KB pieces per wave
+        const float *src = stages + (size_t)phys(gs) * GC_STAGE + (wid * PPW) * 256 + lane * 4;
+        float *dst = ring + (gs & 1) * GC_STAGE + (wid * PPW) * 256;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+            __builtin_amdgcn_global_load_lds(src + i * 256, (__attribute__((address_space(3))) void *)(dst + i * 256), 16, 0, 0);
+    };
+    auto acquire = [&]() -> const float * {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (stage + 1 < total_stages) issue(stage + 1);
+        const float *buf = ring + (stage & 1) * GC_STAGE;
+        ++stage;
+        return buf;
+    };
+
+    // ---- prologue: first stage in flight; biases, im2col offsets and the padded input images into LDS ----
+    issue(0);
+    for (int i = tid; i < mt.small; i += 64 * GC_NW) small[i] = blob[GC_HDR + i];
+    for (int k = tid; k < K1p; k += 64 * GC_NW) {
+        const int kk = k < mt.K1 ? k : mt.K1 - 1;   // padded k: zero weight, any valid address
+        const int c = kk / 9, t = kk - 9 * c, ky = t / 3;
+        koff[k] = c * PH * PW + ky * PW + (t - 3 * ky);
+    }
+    {
+        const int per_img = mt.Cin * PH * PW, n = IPW * per_img;
+        for (int i = tid; i < n; i += 64 * GC_NW) {
+            const int im = i / per_img, rem = i - im * per_img, c = rem / (PH * PW), rr = rem - c * PH * PW;
+            const int yy = rr / PW - 1, xx = rr - (yy + 1) * PW - 1;
+            const int64_t g = img0 + im;
+            float v = 0.0f;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W && g < B) v = x[g * xs_img + (int64_t)c * HW + yy * W + xx];
+            xin[i] = v;
+        }
+    }
+
+    // ---- GEMM 1 (conv3x3 #1 by im2col): h1 = LeakyReLU(W1 col(x) + b1) ----
+    f32x16 H0, H1, H2, H3, H4, H5, H6, H7;
+    auto gemm1 = [&](f32x16 &acc) {
+        for (int c = 0; c < mt.nst1; ++c) {
+            const float *buf = acquire();
+            const int ng = (mt.nkg1 - 16 * c) < 16 ? (mt.nkg1 - 16 * c) : 16;
+            for (int s = 0; s < ng; ++s) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(buf + s * 256 + lane * 4);
+                const int kb = 8 * (16 * c + s) + 4 * hh;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = GC_MFMA(a[r], xin[base0 + koff[kb + r]], acc);
+            }
+        }
+        gc_leaky(acc, mt.slope);
+    };
+    __syncthreads();   // the prologue's LDS writes
+    {
+        const float *bsrc = small + hh * 16;
+        H0 = load_bias16(bsrc);       H1 = load_bias16(bsrc + 32);  H2 = load_bias16(bsrc + 64);  H3 = load_bias16(bsrc + 96);
+        H4 = load_bias16(bsrc + 128); H5 = load_bias16(bsrc + 160); H6 = load_bias16(bsrc + 192); H7 = load_bias16(bsrc + 224);
+    }
+    gemm1(H0); gemm1(H1); gemm1(H2); gemm1(H3); gemm1(H4); gemm1(H5); gemm1(H6); gemm1(H7);
+
+    // ---- sweeps over h2: GEMM 2 block by block, each block consumed at once by GEMM 3 ----
+    for (int pass = 0; pass < mt.npass; ++pass) {
+        f32x16 O0 = {0}, O1 = {0}, O2 = {0}, O3 = {0};
+        for (int j = 0; j < 8; ++j) {
+            f32x16 T = load_bias16(small + GC_HID + j * 32 + hh * 16);
+            gc_mm128(acquire(), lane, T, H0, H1, H2, H3);
+            gc_mm128(acquire(), lane, T, H4, H5, H6, H7);
+            gc_leaky(T, mt.slope);
+            const float *buf = acquire();
+#pragma unroll
+            for (int mm = 0; mm < GC_OBP; ++mm) {
+                f32x16 &o = mm == 0 ? O0 : (mm == 1 ? O1 : (mm == 2 ? O2 : O3));
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(buf + (mm * 4 + s) * 256 + lane * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o = GC_MFMA(a[r], T[4 * s + r], o);
+                }
+            }
+        }
+        // ---- col2im: per output block, tap products -> LDS, 9-term neighbour gather, + bias, -> HBM ----
+#pragma unroll
+        for (int mm = 0; mm < GC_OBP; ++mm) {
+            const int blk = GC_OBP * pass + mm;
+            if (blk >= mt.OB) break;
+            const f32x16 &o = mm == 0 ? O0 : (mm == 1 ? O1 : (mm == 2 ? O2 : O3));
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) P[(8 * (reg >> 2) + 4 * hh + (reg & 3)) * GC_PX + px] = o[reg];
+            __syncthreads();
+            for (int e = tid; e < 3 * GC_PX; e += 64 * GC_NW) {
+                const int cc = e / GC_PX, p = e - cc * GC_PX;
+                const int co = 3 * blk + cc;
+                const int im = p / HW, q = p - im * HW, y = q / W, xq = q - y * W;
+                const int64_t g = img0 + im;
+                if (co < mt.Cout && g < B) {
+                    float sum = small[2 * GC_HID + co];
+                    const float *pr = P + (cc * 9) * GC_PX + p;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int yy = y + ky - 1, xx = xq + kx - 1;
+                            if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+                                sum += pr[(ky * 3 + kx) * GC_PX + (ky - 1) * W + (kx - 1)];
+                        }
+                    }
+                    out[(g * mt.Cout + co) * HW + q] = sum;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+static inline size_t gc_lds_bytes(const GcMeta &m, int H, int W) {
+    const int IPW = GC_PX / (H * W);
+    return ((size_t)2 * GC_STAGE + 32 * GC_PX + gc_small_padded(m) + 8 * m.nkg1 +
+            (size_t)IPW * m.Cin * (H + 2) * (W + 2)) * sizeof(float) + 16;
+}
+
+}  // namespace nf
+
+using namespace nf;
+
+static int gc_check(int Cin, int Cout, int hidden, double slope) {
+    if (Cin < 1 || Cout < 1) return NF_EINVAL;
+    if (!(slope >= 0.0 && slope <= 1.0)) return NF_EINVAL;
+    if (hidden != GC_HID || Cin > 64 || Cout > 192) return NF_ENOTSUP;
+    return NF_OK;
+}
+
+extern "C" int64_t nf_glow_convnet_pack_size(int Cin, int Cout, int hidden) {
+    const int rc = gc_check(Cin, Cout, hidden, 0.0);
+    if (rc) return rc;
+    const GcMeta m = gc_meta(Cin, Cout, 0.0);
+    return ((int64_t)gc_off_stages(m) + (int64_t)gc_nstages_blob(m) * GC_STAGE) * (int64_t)sizeof(float);
+}
+
+extern "C" int nf_glow_convnet_pack(void *wpack, const void *w1, const void *b1, const void *w2, const void *b2,
+                                    const void *w3, const void *b3, int Cin, int Cout, int hidden, nf_stream_t stream) {
+    const int rc = gc_check(Cin, Cout, hidden, 0.0);
+    if (rc) return rc;
+    if (!wpack || !w1 || !b1 || !w2 || !b2 || !w3 || !b3) return NF_EFAULT;
+    const GcMeta m = gc_meta(Cin, Cout, 0.0);
+    const int64_t total = (int64_t)gc_off_stages(m) + (int64_t)gc_nstages_blob(m) * GC_STAGE;
+    hipLaunchKernelGGL(gc_pack_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, (const float *)w1, (const float *)b1,
+                       (const float *)w2, (const float *)b2, (const float *)w3, (const float *)b3, (float *)wpack, m, total);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_glow_convnet(const void *x, int64_t x_image_stride, void *out, const void *wpack, int64_t B, int Cin,
+                               int H, int W, int Cout, int hidden, double leaky_slope, nf_stream_t stream) {
+    const int rc = gc_check(Cin, Cout, hidden, leaky_slope);
+    if (rc) return rc;
+    if (B < 0 || H < 1 || W < 1 || x_image_stride < (int64_t)Cin * H * W) return NF_EINVAL;
+    if (H * W > GC_PX || GC_PX % (H * W) != 0) return NF_ENOTSUP;   // whole images per 256-pixel workgroup
+    if (B == 0) return NF_OK;
+    if (!x || !out || !wpack) return NF_EFAULT;
+    const GcMeta m = gc_meta(Cin, Cout, leaky_slope);
+    const size_t lds = gc_lds_bytes(m, H, W);
+    if (lds > 160 * 1024) return NF_ENOTSUP;
+    static LdsOptIn opted = {};
+    if (opt_in_lds(reinterpret_cast<const void *>(&glow_convnet_kernel), lds, opted) != NF_OK) return NF_ENOTSUP;
+    const int IPW = GC_PX / (H * W);
+    const int64_t grid = (B + IPW - 1) / IPW;
+    if (grid > 0x7fffffff) return NF_ERANGE;
+    hipLaunchKernelGGL(glow_convnet_kernel, dim3((unsigned)grid), dim3(64 * GC_NW), lds, (hipStream_t)stream,
+                       (const float *)x, x_image_stride, (float *)out, (const float *)wpack, m, B, H, W);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

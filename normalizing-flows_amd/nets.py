@@ -222,8 +222,46 @@ class ConvNet2d(nn.Module):
 
     def forward(self, x):
         if x.is_cuda and not torch.is_grad_enabled():
+            blob = self._fused_pack(x)
+            if blob is not None:
+                from . import ops
+                return ops.glow_convnet(x, blob, self.net[-1].out_channels, self.net[1].negative_slope)
             return self._forward_inference(x)
         return self.net(x)
+
+    # the one-launch kernel only pays when its 256-pixel workgroups can fill the chip
+    FUSED_MIN_PIXELS = 128 * 256
+
+    def _fused_pack(self, x):
+        """Packed weights for ops.glow_convnet when this is the GlowBlock network (3x3 -> 1x1 -> 3x3 around 256 hidden
+        channels, biases, equal LeakyReLU slopes) and the call is one the kernel takes; None otherwise.  Repacked when a
+        parameter changes."""
+        mods = list(self.net)
+        if len(mods) != 5 or not x.is_cuda or x.dtype != torch.float32 or torch.is_grad_enabled() or x.dim() != 4:
+            return None
+        c1, a1, c2, a2, c3 = mods
+        if not (isinstance(c1, nn.Conv2d) and isinstance(c2, nn.Conv2d) and isinstance(c3, nn.Conv2d)
+                and isinstance(a1, nn.LeakyReLU) and isinstance(a2, nn.LeakyReLU)):
+            return None
+        if (c1.kernel_size, c2.kernel_size, c3.kernel_size) != ((3, 3), (1, 1), (3, 3)):
+            return None
+        if c1.out_channels != 256 or c2.out_channels != 256 or any(c.bias is None for c in (c1, c2, c3)):
+            return None
+        if a1.negative_slope != a2.negative_slope or not 0.0 <= a1.negative_slope <= 1.0:
+            return None
+        B, Cin, H, W = x.shape
+        if 256 % (H * W) != 0 or B * H * W < self.FUSED_MIN_PIXELS:
+            return None
+        if x.stride(3) != 1 or x.stride(2) != W or x.stride(1) != H * W:
+            return None
+        params = [c1.weight, c1.bias, c2.weight, c2.bias, c3.weight, c3.bias]
+        key = tuple((p_.data_ptr(), p_._version) for p_ in params)
+        cache = getattr(self, "_gc_cache", None)
+        if cache is None or cache[0] != key:
+            from . import ops
+            cache = (key, ops.glow_convnet_pack(*[p_.detach() for p_ in params]))
+            self._gc_cache = cache
+        return cache[1]
 
     def forward_split(self, x):
         """(output without the last convolution's bias, that bias) for callers that fold the bias into their own kernel
@@ -232,6 +270,8 @@ class ConvNet2d(nn.Module):
         if (torch.is_grad_enabled() or not x.is_cuda or not isinstance(last, nn.Conv2d) or last.bias is None
                 or x.dtype not in (torch.float32, torch.float64)):
             return None
+        if self._fused_pack(x) is not None:
+            return None      # the one-launch kernel adds the bias itself: callers use forward()
         h = self._forward_inference(x, upto=len(self.net) - 1)
         return F.conv2d(h, last.weight, None, last.stride, last.padding, last.dilation, last.groups), last.bias
 

@@ -724,6 +724,28 @@ def gen_circular_grads():
     layer_grads(t, 1.5 * torch.randn(10, 4, generator=g), "grad_coupling_tensor_bound")
 
 
+GLOW_CONVNET_CASES = [   # (name, seed, Cin, Cout, leaky, B, H, W)
+    ("convnet_6_12_16x16", 31, 6, 12, 0.0, 3, 16, 16),
+    ("convnet_12_24_8x8", 32, 12, 24, 0.1, 5, 8, 8),
+    ("convnet_24_48_4x4", 33, 24, 48, 0.0, 17, 4, 4),
+    ("convnet_3_5_4x8", 34, 3, 5, 0.2, 3, 4, 8),
+]
+
+
+def gen_glow_convnet():
+    """GlowBlock conditioner at its real width (cnn.py:5-63 with 256 hidden channels, glow.py:41-62).  Only inputs and
+    outputs are stored: the weights are the seeded default initialisation, which our ConvNet2d reproduces draw for
+    draw (checked through the stored weight checksum)."""
+    for name, seed, cin, cout, leaky, B, H, W in GLOW_CONVNET_CASES:
+        torch.manual_seed(seed)
+        net = nf.nets.ConvNet2d([cin, 256, 256, cout], [3, 1, 3], leaky, init_zeros=False)
+        x = torch.randn(B, cin, H, W, generator=torch.Generator().manual_seed(seed + 100))
+        with torch.no_grad():
+            out = net(x)
+        chk = torch.stack([p_.double().abs().sum() for p_ in net.parameters()])
+        npz(name, x=x, out=out, weight_checksum=chk)
+
+
 def gen_cdf():
     """Standalone PiecewiseRationalQuadraticCDF (nsf/coupling.py:170-259): 1-D and N-D parameter shapes, every tails
     variant, values and reference-autograd gradients in both directions."""
@@ -812,6 +834,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "circular":
         gen_circular()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "glow_convnet":
+        gen_glow_convnet()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cdf":
         gen_cdf()
         sys.exit(0)
@@ -850,3 +875,4 @@ if __name__ == "__main__":
     gen_image_coupling()
     gen_circular_grads()
     gen_cdf()
+    gen_glow_convnet()

@@ -291,6 +291,42 @@ def test_glowblock_vs_reference(nfa, C, split):
     assert_close(N(ldf), g["ld_fwd"], what="ld_fwd", rtol=2e-4, atol=2e-3)
 
 
+@pytest.mark.parametrize("name,seed,cin,cout,leaky,B,H,W", [
+    ("convnet_6_12_16x16", 31, 6, 12, 0.0, 3, 16, 16), ("convnet_12_24_8x8", 32, 12, 24, 0.1, 5, 8, 8),
+    ("convnet_24_48_4x4", 33, 24, 48, 0.0, 17, 4, 4), ("convnet_3_5_4x8", 34, 3, 5, 0.2, 3, 4, 8)])
+def test_glow_convnet_kernel_vs_reference(nfa, name, seed, cin, cout, leaky, B, H, W):
+    """nf_glow_convnet (conv3x3 -> LeakyReLU -> conv1x1 -> LeakyReLU -> conv3x3 in one launch) against the reference's
+    ConvNet2d output; weights = the seeded default initialisation on both sides (checksum in the fixture)."""
+    g = load_golden(name)
+    torch.manual_seed(seed)
+    net = nfa.nets.ConvNet2d([cin, 256, 256, cout], [3, 1, 3], leaky, init_zeros=False)
+    chk = np.array([float(p_.double().abs().sum()) for p_ in net.parameters()])
+    np.testing.assert_allclose(chk, g["weight_checksum"], rtol=1e-12)
+    net = net.to(DEV)
+    c1, _, c2, _, c3 = net.net
+    blob = nfa.ops.glow_convnet_pack(c1.weight.detach(), c1.bias.detach(), c2.weight.detach(), c2.bias.detach(),
+                                     c3.weight.detach(), c3.bias.detach())
+    x = T(g["x"])
+    out = nfa.ops.glow_convnet(x, blob, cout, leaky)
+    assert_close(N(out), g["out"], what="out", rtol=1e-4, atol=1e-4)
+    # a channel slice of a wider NCHW tensor is read in place (image stride != Cin H W)
+    wide = torch.randn(B, cin + 3, H, W, device=DEV)
+    wide[:, 2:2 + cin] = x
+    out2 = nfa.ops.glow_convnet(wide[:, 2:2 + cin], blob, cout, leaky)
+    assert torch.equal(out2, out)
+    # the module takes this path on its own once the batch fills the chip, and agrees with its library path
+    with torch.no_grad():
+        lib = net._forward_inference(x)
+        old, type(net).FUSED_MIN_PIXELS = type(net).FUSED_MIN_PIXELS, 0
+        try:
+            assert net._fused_pack(x) is not None and net.forward_split(x) is None
+            fused = net(x)
+        finally:
+            type(net).FUSED_MIN_PIXELS = old
+    assert torch.equal(fused, out)
+    assert_close(N(fused), N(lib), what="fused vs library", rtol=1e-4, atol=1e-4)
+
+
 def test_diag_gaussian_and_squeeze(nfa):
     g = load_golden("diag_gaussian")
     q = nfa.distributions.DiagGaussian((3, 2, 2)).to(DEV)
