@@ -384,20 +384,26 @@ int nf_arnsf_inverse(const void *z, void *y, void *logdet, const void *blob, con
  * GlowBlock conditioner in one launch.  Replaces ConvNet2d.forward (normflows/nets/cnn.py:5-63) for the network
  * built by normflows/flows/affine/glow.py:41-62: Conv2d(Cin, 256, 3, padding 1) -> LeakyReLU(slope) ->
  * Conv2d(256, 256, 1) -> LeakyReLU(slope) -> Conv2d(256, Cout, 3, padding 1), all with bias, float32.
+ *   nf_glow_convnet_layout    : which of the two kernels fits a call: NF_GLOW_CONV_WIDE (256-pixel workgroups, waves of
+ *                               32 pixels; needs H W | 256 and pays from ~128 workgroups on) or NF_GLOW_CONV_SMALL
+ *                               (64-pixel workgroups, waves of 16 pixels; H W | 64, <= 48 output channels); a negative
+ *                               code when neither applies.  The packed weights are specific to the layout.
  *   nf_glow_convnet_pack_size : bytes of the packed weights (negative error code for an unsupported shape).
  *   nf_glow_convnet_pack      : w1 (256, Cin, 3, 3), b1 (256), w2 (256, 256[, 1, 1]), b2 (256), w3 (Cout, 256, 3, 3),
  *                               b3 (Cout), all contiguous -> wpack (MFMA operand order; repack after a weight update).
  *   nf_glow_convnet           : x = first input channel of image 0; image g starts at x + g * x_image_stride floats
  *                               and holds Cin contiguous (H, W) planes (a channel slice of an NCHW tensor is passed
  *                               without a copy); out (B, Cout, H, W) contiguous.
- * A workgroup processes 256 / (H W) whole images: H W must divide 256 (NF_ENOTSUP otherwise; callers fall back to
- * library convolutions).  hidden must be 256.
+ * A workgroup processes whole images (the 3x3 zero padding is the image border): H W must divide the workgroup's pixel
+ * count (NF_ENOTSUP otherwise; callers fall back to library convolutions).  hidden must be 256.
  */
+enum { NF_GLOW_CONV_WIDE = 0, NF_GLOW_CONV_SMALL = 1 };
+int nf_glow_convnet_layout(int64_t B, int H, int W);
 int64_t nf_glow_convnet_pack_size(int Cin, int Cout, int hidden);
 int nf_glow_convnet_pack(void *wpack, const void *w1, const void *b1, const void *w2, const void *b2, const void *w3,
-                         const void *b3, int Cin, int Cout, int hidden, nf_stream_t stream);
+                         const void *b3, int Cin, int Cout, int hidden, int layout, nf_stream_t stream);
 int nf_glow_convnet(const void *x, int64_t x_image_stride, void *out, const void *wpack, int64_t B, int Cin, int H,
-                    int W, int Cout, int hidden, double leaky_slope, nf_stream_t stream);
+                    int W, int Cout, int hidden, double leaky_slope, int layout, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Squeeze (flows/reshape.py:116-128).  direction 0 = forward (C,H,W)->(C/4,2H,2W),

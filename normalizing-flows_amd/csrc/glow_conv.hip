@@ -31,6 +31,7 @@ constexpr int GC_PX = 32 * GC_NW;    // pixels per workgroup
 constexpr int GC_HDR = 64;
 constexpr int GC_STAGE = 4096;       // floats per stage (16 KB)
 constexpr int GC_OBP = 4;            // output row-blocks (x 3 channels) per sweep
+constexpr int GC_KG1MAX = 16;        // k-groups of GEMM 1 whose gathered operands are kept in registers (one stage)
 
 struct GcMeta {
     int Cin, Cout;
@@ -59,11 +60,15 @@ __host__ __device__ inline int gc_small_padded(const GcMeta &m) { return (m.smal
 __host__ __device__ inline int gc_off_stages(const GcMeta &m) { return GC_HDR + gc_small_padded(m); }
 __host__ __device__ inline int gc_nstages_blob(const GcMeta &m) { return 8 * m.nst1 + 16 + 8 * m.npass; }
 
-// One thread per blob float.  Stage image = MFMA A-operand order [k-group][lane][4]: row = lane & 31,
-// k = 8 kg + 4 (lane >> 5) + r4 (rqs_fused.hip has the same convention).
+// One thread per blob float.  A stage always holds 32 rows x 128 k (GEMM 1 / 2) or 4 output blocks x 32 k (GEMM 3);
+// only the order inside a stage depends on the MFMA shape the kernel uses:
+//   wide  (v_mfma_f32_32x32x2): [k-group 0..15][lane][4], row = lane & 31, k = 8 kg + 4 (lane >> 5) + r4
+//                               (GEMM 3: k-group = 4 mm + s); biases in accumulator-register order;
+//   small (v_mfma_f32_16x16x4): [unit 0..15][lane][4], unit = 8 ob + kb, row = 16 ob + (lane & 15),
+//                               k = 16 kb + 4 (lane >> 4) + r4 (GEMM 3: unit = 4 mm + 2 ob + kb); biases in natural order.
 __global__ void gc_pack_kernel(const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W2,
                                const float *__restrict__ b2, const float *__restrict__ W3, const float *__restrict__ b3,
-                               float *__restrict__ blob, GcMeta m, int64_t total) {
+                               float *__restrict__ blob, GcMeta m, int64_t total, int small_layout) {
     const int offs = gc_off_stages(m);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         float v = 0.0f;
@@ -73,7 +78,7 @@ __global__ void gc_pack_kernel(const float *__restrict__ W1, const float *__rest
             const int j = (int)i - GC_HDR;
             if (j < 2 * GC_HID) {
                 const int q = j & 255, reg = q & 15, hh = (q >> 4) & 1, mb = q >> 5;
-                const int row = 32 * mb + 8 * (reg >> 2) + 4 * hh + (reg & 3);
+                const int row = small_layout ? q : 32 * mb + 8 * (reg >> 2) + 4 * hh + (reg & 3);
                 v = j < GC_HID ? b1[row] : b2[row];
             } else if (j - 2 * GC_HID < m.Cout) {
                 v = b3[j - 2 * GC_HID];
@@ -81,22 +86,29 @@ __global__ void gc_pack_kernel(const float *__restrict__ W1, const float *__rest
         } else {
             const int64_t t = i - offs;
             const int st = (int)(t / GC_STAGE), e = (int)(t % GC_STAGE);
-            const int r4 = e & 3, lane = (e >> 2) & 63, kg = (e >> 8) & 15, rho = lane & 31, hk = lane >> 5;
+            const int r4 = e & 3, lane = (e >> 2) & 63, kg = (e >> 8) & 15;
+            const bool gemm3 = st >= 8 * m.nst1 + 16;
+            int rho, kin, mm = 0;   // row inside the 32-row block, k inside the stage's k range, output block (GEMM 3)
+            if (!small_layout) {
+                rho = lane & 31;
+                if (gemm3) { mm = kg >> 2; kin = 8 * (kg & 3) + 4 * (lane >> 5) + r4; }
+                else kin = 8 * kg + 4 * (lane >> 5) + r4;
+            } else {
+                if (gemm3) { mm = kg >> 2; rho = 16 * ((kg >> 1) & 1) + (lane & 15); kin = 16 * (kg & 1) + 4 * (lane >> 4) + r4; }
+                else { rho = 16 * (kg >> 3) + (lane & 15); kin = 16 * (kg & 7) + 4 * (lane >> 4) + r4; }
+            }
             if (st < 8 * m.nst1) {
                 const int mb = st / m.nst1, c = st % m.nst1;
-                const int k = 8 * (16 * c + kg) + 4 * hk + r4;
+                const int k = 128 * c + kin;
                 if (k < m.K1) v = W1[(size_t)(32 * mb + rho) * m.K1 + k];
-            } else if (st < 8 * m.nst1 + 16) {
+            } else if (!gemm3) {
                 const int q = st - 8 * m.nst1, j = q >> 1, half = q & 1;
-                const int k = 128 * half + 8 * kg + 4 * hk + r4;
-                v = W2[(size_t)(32 * j + rho) * GC_HID + k];
+                v = W2[(size_t)(32 * j + rho) * GC_HID + 128 * half + kin];
             } else {
                 const int q = st - 8 * m.nst1 - 16, pass = q >> 3, j = q & 7;
-                const int mm = kg >> 2, s = kg & 3;
                 const int cc = rho / 9, tap = rho - 9 * cc;
                 const int co = 3 * (GC_OBP * pass + mm) + cc;
-                const int k = 32 * j + 8 * s + 4 * hk + r4;
-                if (rho < 27 && co < m.Cout) v = W3[((size_t)co * GC_HID + k) * 9 + tap];
+                if (rho < 27 && co < m.Cout) v = W3[((size_t)co * GC_HID + 32 * j + kin) * 9 + tap];
             }
         }
         blob[i] = v;
@@ -188,20 +200,42 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
 
     // ---- GEMM 1 (conv3x3 #1 by im2col): h1 = LeakyReLU(W1 col(x) + b1) ----
     f32x16 H0, H1, H2, H3, H4, H5, H6, H7;
+    // the lane's im2col column (its pixel, k = 8 kg + 4 hh + r) is the B operand of all 8 row blocks: gathered once into
+    // registers when K1 <= 128 (Cin <= 14), per use otherwise
+    float bx[4 * GC_KG1MAX];
+    const bool bx_cached = mt.nkg1 <= GC_KG1MAX;
     auto gemm1 = [&](f32x16 &acc) {
-        for (int c = 0; c < mt.nst1; ++c) {
+        if (bx_cached) {
             const float *buf = acquire();
-            const int ng = (mt.nkg1 - 16 * c) < 16 ? (mt.nkg1 - 16 * c) : 16;
-            for (int s = 0; s < ng; ++s) {
-                const f32x4 a = *reinterpret_cast<const f32x4 *>(buf + s * 256 + lane * 4);
-                const int kb = 8 * (16 * c + s) + 4 * hh;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc = GC_MFMA(a[r], xin[base0 + koff[kb + r]], acc);
+            for (int s = 0; s < GC_KG1MAX; ++s) {
+                if (s < mt.nkg1) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(buf + s * 256 + lane * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = GC_MFMA(a[r], bx[4 * s + r], acc);
+                }
+            }
+        } else {
+            for (int c = 0; c < mt.nst1; ++c) {
+                const float *buf = acquire();
+                const int ng = (mt.nkg1 - 16 * c) < 16 ? (mt.nkg1 - 16 * c) : 16;
+                for (int s = 0; s < ng; ++s) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(buf + s * 256 + lane * 4);
+                    const int kb = 8 * (16 * c + s) + 4 * hh;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = GC_MFMA(a[r], xin[base0 + koff[kb + r]], acc);
+                }
             }
         }
         gc_leaky(acc, mt.slope);
     };
     __syncthreads();   // the prologue's LDS writes
+#pragma unroll
+    for (int s = 0; s < GC_KG1MAX; ++s) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            bx[4 * s + r] = (bx_cached && s < mt.nkg1) ? xin[base0 + koff[8 * s + 4 * hh + r]] : 0.0f;
+    }
     {
         const float *bsrc = small + hh * 16;
         H0 = load_bias16(bsrc);       H1 = load_bias16(bsrc + 32);  H2 = load_bias16(bsrc + 64);  H3 = load_bias16(bsrc + 96);
@@ -233,7 +267,7 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
 #pragma unroll
         for (int mm = 0; mm < GC_OBP; ++mm) {
             const int blk = GC_OBP * pass + mm;
-            if (blk >= mt.OB) break;
+            if (blk < mt.OB) {
             const f32x16 &o = mm == 0 ? O0 : (mm == 1 ? O1 : (mm == 2 ? O2 : O3));
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) P[(8 * (reg >> 2) + 4 * hh + (reg & 3)) * GC_PX + px] = o[reg];
@@ -259,8 +293,247 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
                 }
             }
             __syncthreads();
+            }
         }
     }
+}
+
+// ---- small images: 64-pixel workgroups of 4 waves x 16 pixels on v_mfma_f32_16x16x4_f32 ------------------------------
+// With B H W << 256 x 256 pixels the 256-pixel workgroups above cannot fill the chip (config 4: 8x8 images = 64
+// workgroups).  Here a wave owns 16 pixels: h1 = 16 x f32x4 per lane, every output block fits the register file, so ONE
+// sweep over h2 serves all output channels (OBT = capacity in 32-row output blocks).  C layout of the 16x16x4 MFMA:
+// lane (g = lane >> 4, pixel = lane & 15) holds rows 4 g + r; the contraction k = 16 b + 4 g + r pairs lane group g with
+// the rows it holds, as in the wide kernel.  One wave per SIMD: the weight ring is 4 stages deep to cover L2 latency.
+#define GC_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+constexpr int GS_NW = 4;
+constexpr int GS_PX = 16 * GS_NW;
+constexpr int GS_RING = 4;
+constexpr int GS_KB1MAX = 16;   // k-blocks of GEMM 1 whose gathered operands fit the register file (Cin <= 28)
+
+__device__ __forceinline__ void gs_leaky(f32x4 &v, float slope) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], v[c] * slope);
+}
+
+template <int OBT>
+__global__ void __launch_bounds__(64 * GS_NW)
+glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__restrict__ out,
+                          const float *__restrict__ blob, GcMeta mt, int64_t B, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int HW = H * W, PH = H + 2, PW = W + 2, IPW = GS_PX / HW;
+    const int nkb1 = (mt.K1 + 15) / 16, K1p = 16 * nkb1;
+    float *ring = smem;                          // 4 x 16 KB weight stages
+    float *P = ring + GS_RING * GC_STAGE;        // 32 rows x 64 pixels
+    float *small = P + 32 * GS_PX;
+    int *koff = reinterpret_cast<int *>(small + gc_small_padded(mt));
+    float *xin = reinterpret_cast<float *>(koff + K1p);
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = wid * 16 + (lane & 15);
+    const int li = px / HW, pin = px - li * HW, py = pin / W, pxx = pin - py * W;
+    const int base0 = li * mt.Cin * PH * PW + py * PW + pxx;
+    const int64_t img0 = (int64_t)blockIdx.x * IPW;
+
+    const int nst_l1 = 8 * mt.nst1, per_j = 2 + mt.npass;   // per h2 block: 2 stages of GEMM 2, npass stages of GEMM 3
+    const int total_stages = nst_l1 + 8 * per_j;
+    auto phys = [&](int s) -> int {
+        if (s < nst_l1) return s;
+        const int q = s - nst_l1, j = q / per_j, t = q - per_j * j;
+        return t < 2 ? nst_l1 + 2 * j + t : nst_l1 + 16 + 8 * (t - 2) + j;
+    };
+    const float *stages = blob + gc_off_stages(mt);
+    constexpr int PPW = 16 / GS_NW;
+    int stage = 0;
+    auto issue = [&](int gs) {
+        const float *src = stages + (size_t)phys(gs) * GC_STAGE + (wid * PPW) * 256 + lane * 4;
+        float *dst = ring + (gs % GS_RING) * GC_STAGE + (wid * PPW) * 256;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+            __builtin_amdgcn_global_load_lds(src + i * 256, (__attribute__((address_space(3))) void *)(dst + i * 256), 16, 0, 0);
+    };
+    auto acquire = [&]() -> const float * {
+        // stages stage+1 and stage+2 may stay in flight (loads retire in order); the tail drains everything
+        if (stage + 2 < total_stages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // everyone's pieces of `stage` have landed; everyone is done with stage - 1 (slot reused below)
+        if (stage + GS_RING - 1 < total_stages) issue(stage + GS_RING - 1);
+        const float *buf = ring + (stage % GS_RING) * GC_STAGE;
+        ++stage;
+        return buf;
+    };
+
+    // ---- prologue ----
+    for (int i = tid; i < mt.small; i += 64 * GS_NW) small[i] = blob[GC_HDR + i];
+    for (int k = tid; k < K1p; k += 64 * GS_NW) {
+        const int kk = k < mt.K1 ? k : mt.K1 - 1;
+        const int c = kk / 9, t = kk - 9 * c, ky = t / 3;
+        koff[k] = c * PH * PW + ky * PW + (t - 3 * ky);
+    }
+    {
+        const int per_img = mt.Cin * PH * PW, n = IPW * per_img;
+        for (int i = tid; i < n; i += 64 * GS_NW) {
+            const int im = i / per_img, rem = i - im * per_img, c = rem / (PH * PW), rr = rem - c * PH * PW;
+            const int yy = rr / PW - 1, xx = rr - (yy + 1) * PW - 1;
+            const int64_t gi = img0 + im;
+            float v = 0.0f;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W && gi < B) v = x[gi * xs_img + (int64_t)c * HW + yy * W + xx];
+            xin[i] = v;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's in-order accounting starts from an empty queue
+    issue(0);
+    if (total_stages > 1) issue(1);
+    if (total_stages > 2) issue(2);
+    __syncthreads();
+
+    // ---- GEMM 1: h1 (16 blocks of 16 channels) ----
+    f32x4 Hh[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) Hh[b] = *reinterpret_cast<const f32x4 *>(small + 16 * b + 4 * g);
+    if (nkb1 <= GS_KB1MAX) {
+        // the lane's im2col column (its pixel, k = 16 kb + 4 g + r) is the B operand of all 16 row blocks: gathered once
+        float bv[4 * GS_KB1MAX];
+#pragma unroll
+        for (int kb = 0; kb < GS_KB1MAX; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[4 * kb + r] = kb < nkb1 ? xin[base0 + koff[16 * kb + 4 * g + r]] : 0.0f;
+        }
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) {
+#pragma unroll
+            for (int c = 0; c < GS_KB1MAX / 8; ++c) {
+                if (c < mt.nst1) {
+                    const float *buf = acquire();
+#pragma unroll
+                    for (int kb = 0; kb < 8; ++kb) {
+                        if (8 * c + kb < nkb1) {
+                            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(buf + kb * 256 + lane * 4);
+                            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(buf + (8 + kb) * 256 + lane * 4);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                Hh[2 * mb] = GC_MFMA16(a0[r], bv[4 * (8 * c + kb) + r], Hh[2 * mb]);
+                                Hh[2 * mb + 1] = GC_MFMA16(a1[r], bv[4 * (8 * c + kb) + r], Hh[2 * mb + 1]);
+                            }
+                        }
+                    }
+                }
+            }
+            gs_leaky(Hh[2 * mb], mt.slope);
+            gs_leaky(Hh[2 * mb + 1], mt.slope);
+        }
+    } else {
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) {
+            for (int c = 0; c < mt.nst1; ++c) {
+                const float *buf = acquire();
+                const int nkb = (nkb1 - 8 * c) < 8 ? (nkb1 - 8 * c) : 8;
+                for (int kb = 0; kb < nkb; ++kb) {
+                    const int k0 = 16 * (8 * c + kb) + 4 * g;
+                    float bw[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bw[r] = xin[base0 + koff[k0 + r]];
+                    const f32x4 a0 = *reinterpret_cast<const f32x4 *>(buf + kb * 256 + lane * 4);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4 *>(buf + (8 + kb) * 256 + lane * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        Hh[2 * mb] = GC_MFMA16(a0[r], bw[r], Hh[2 * mb]);
+                        Hh[2 * mb + 1] = GC_MFMA16(a1[r], bw[r], Hh[2 * mb + 1]);
+                    }
+                }
+            }
+            gs_leaky(Hh[2 * mb], mt.slope);
+            gs_leaky(Hh[2 * mb + 1], mt.slope);
+        }
+    }
+
+    // ---- one sweep: h2 block by block (GEMM 2), each consumed at once by GEMM 3 ----
+    f32x4 O[2 * OBT];
+#pragma unroll
+    for (int i = 0; i < 2 * OBT; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 8; ++j) {
+        f32x4 T0 = *reinterpret_cast<const f32x4 *>(small + GC_HID + 32 * j + 4 * g);
+        f32x4 T1 = *reinterpret_cast<const f32x4 *>(small + GC_HID + 32 * j + 16 + 4 * g);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const float *buf = acquire();
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4 *>(buf + kb * 256 + lane * 4);
+                const f32x4 a1 = *reinterpret_cast<const f32x4 *>(buf + (8 + kb) * 256 + lane * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    T0 = GC_MFMA16(a0[r], Hh[8 * half + kb][r], T0);
+                    T1 = GC_MFMA16(a1[r], Hh[8 * half + kb][r], T1);
+                }
+            }
+        }
+        gs_leaky(T0, mt.slope);
+        gs_leaky(T1, mt.slope);
+#pragma unroll
+        for (int q4 = 0; q4 < OBT / 4; ++q4) {
+            if (q4 < mt.npass) {
+            const float *buf = acquire();
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm) {
+                // units of output block mm: [ob][kb]; consecutive MFMAs alternate between the two accumulators
+                const f32x4 a00 = *reinterpret_cast<const f32x4 *>(buf + (mm * 4 + 0) * 256 + lane * 4);
+                const f32x4 a01 = *reinterpret_cast<const f32x4 *>(buf + (mm * 4 + 1) * 256 + lane * 4);
+                const f32x4 a10 = *reinterpret_cast<const f32x4 *>(buf + (mm * 4 + 2) * 256 + lane * 4);
+                const f32x4 a11 = *reinterpret_cast<const f32x4 *>(buf + (mm * 4 + 3) * 256 + lane * 4);
+                f32x4 &o0 = O[(4 * q4 + mm) * 2], &o1 = O[(4 * q4 + mm) * 2 + 1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o0 = GC_MFMA16(a00[r], T0[r], o0);
+                    o1 = GC_MFMA16(a10[r], T0[r], o1);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o0 = GC_MFMA16(a01[r], T1[r], o0);
+                    o1 = GC_MFMA16(a11[r], T1[r], o1);
+                }
+            }
+            }
+        }
+    }
+
+    // ---- col2im per output block ----
+#pragma unroll
+    for (int blk = 0; blk < OBT; ++blk) {
+        if (blk < mt.OB) {
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[(16 * ob + 4 * g + r) * GS_PX + px] = O[2 * blk + ob][r];
+        __syncthreads();
+        for (int e = tid; e < 3 * GS_PX; e += 64 * GS_NW) {
+            const int cc = e / GS_PX, p = e - cc * GS_PX;
+            const int co = 3 * blk + cc;
+            const int im = p / HW, q = p - im * HW, y = q / W, xq = q - y * W;
+            const int64_t gi = img0 + im;
+            if (co < mt.Cout && gi < B) {
+                float sum = small[2 * GC_HID + co];
+                const float *pr = P + (cc * 9) * GS_PX + p;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int yy = y + ky - 1, xx = xq + kx - 1;
+                        if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+                            sum += pr[(ky * 3 + kx) * GS_PX + (ky - 1) * W + (kx - 1)];
+                    }
+                }
+                out[(gi * mt.Cout + co) * HW + q] = sum;
+            }
+        }
+        __syncthreads();
+        }
+    }
+}
+
+static inline size_t gs_lds_bytes(const GcMeta &m, int H, int W) {
+    const int IPW = GS_PX / (H * W);
+    return ((size_t)GS_RING * GC_STAGE + 32 * GS_PX + gc_small_padded(m) + 16 * ((m.K1 + 15) / 16) +
+            (size_t)IPW * m.Cin * (H + 2) * (W + 2)) * sizeof(float) + 16;
 }
 
 static inline size_t gc_lds_bytes(const GcMeta &m, int H, int W) {
@@ -288,27 +561,64 @@ extern "C" int64_t nf_glow_convnet_pack_size(int Cin, int Cout, int hidden) {
 }
 
 extern "C" int nf_glow_convnet_pack(void *wpack, const void *w1, const void *b1, const void *w2, const void *b2,
-                                    const void *w3, const void *b3, int Cin, int Cout, int hidden, nf_stream_t stream) {
+                                    const void *w3, const void *b3, int Cin, int Cout, int hidden, int layout,
+                                    nf_stream_t stream) {
     const int rc = gc_check(Cin, Cout, hidden, 0.0);
     if (rc) return rc;
+    if (layout != NF_GLOW_CONV_WIDE && layout != NF_GLOW_CONV_SMALL) return NF_EINVAL;
     if (!wpack || !w1 || !b1 || !w2 || !b2 || !w3 || !b3) return NF_EFAULT;
     const GcMeta m = gc_meta(Cin, Cout, 0.0);
     const int64_t total = (int64_t)gc_off_stages(m) + (int64_t)gc_nstages_blob(m) * GC_STAGE;
     hipLaunchKernelGGL(gc_pack_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, (const float *)w1, (const float *)b1,
-                       (const float *)w2, (const float *)b2, (const float *)w3, (const float *)b3, (float *)wpack, m, total);
+                       (const float *)w2, (const float *)b2, (const float *)w3, (const float *)b3, (float *)wpack, m, total,
+                       layout == NF_GLOW_CONV_SMALL ? 1 : 0);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_glow_convnet_layout(int64_t B, int H, int W) {
+    if (B < 0 || H < 1 || W < 1) return NF_EINVAL;
+    const int64_t HW = (int64_t)H * W;
+    if (HW <= GC_PX && GC_PX % HW == 0 && B * HW >= (int64_t)128 * GC_PX) return NF_GLOW_CONV_WIDE;   // >= 128 workgroups
+    if (HW <= GS_PX && GS_PX % HW == 0) return NF_GLOW_CONV_SMALL;
+    if (HW <= GC_PX && GC_PX % HW == 0) return NF_GLOW_CONV_WIDE;
+    return NF_ENOTSUP;
+}
+
+template <int OBT>
+static int launch_small(const void *x, int64_t xs, void *out, const void *wpack, const GcMeta &m, int64_t B, int H, int W,
+                        hipStream_t st) {
+    const size_t lds = gs_lds_bytes(m, H, W);
+    if (lds > 160 * 1024) return NF_ENOTSUP;
+    static LdsOptIn opted = {};
+    if (opt_in_lds(reinterpret_cast<const void *>(&glow_convnet_small_kernel<OBT>), lds, opted) != NF_OK) return NF_ENOTSUP;
+    const int IPW = GS_PX / (H * W);
+    const int64_t grid = (B + IPW - 1) / IPW;
+    if (grid > 0x7fffffff) return NF_ERANGE;
+    hipLaunchKernelGGL(glow_convnet_small_kernel<OBT>, dim3((unsigned)grid), dim3(64 * GS_NW), lds, st, (const float *)x, xs,
+                       (float *)out, (const float *)wpack, m, B, H, W);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
 
 extern "C" int nf_glow_convnet(const void *x, int64_t x_image_stride, void *out, const void *wpack, int64_t B, int Cin,
-                               int H, int W, int Cout, int hidden, double leaky_slope, nf_stream_t stream) {
+                               int H, int W, int Cout, int hidden, double leaky_slope, int layout, nf_stream_t stream) {
     const int rc = gc_check(Cin, Cout, hidden, leaky_slope);
     if (rc) return rc;
+    if (layout != NF_GLOW_CONV_WIDE && layout != NF_GLOW_CONV_SMALL) return NF_EINVAL;
     if (B < 0 || H < 1 || W < 1 || x_image_stride < (int64_t)Cin * H * W) return NF_EINVAL;
-    if (H * W > GC_PX || GC_PX % (H * W) != 0) return NF_ENOTSUP;   // whole images per 256-pixel workgroup
+    const int PXW = layout == NF_GLOW_CONV_WIDE ? GC_PX : GS_PX;
+    if (H * W > PXW || PXW % (H * W) != 0) return NF_ENOTSUP;   // whole images per workgroup
     if (B == 0) return NF_OK;
     if (!x || !out || !wpack) return NF_EFAULT;
     const GcMeta m = gc_meta(Cin, Cout, leaky_slope);
+    hipStream_t st = (hipStream_t)stream;
+    if (layout == NF_GLOW_CONV_SMALL) {
+        if (m.OB <= 4) return launch_small<4>(x, x_image_stride, out, wpack, m, B, H, W, st);
+        if (m.OB <= 8) return launch_small<8>(x, x_image_stride, out, wpack, m, B, H, W, st);
+        if (m.OB <= 16) return launch_small<16>(x, x_image_stride, out, wpack, m, B, H, W, st);
+        return NF_ENOTSUP;
+    }
     const size_t lds = gc_lds_bytes(m, H, W);
     if (lds > 160 * 1024) return NF_ENOTSUP;
     static LdsOptIn opted = {};
@@ -316,8 +626,8 @@ extern "C" int nf_glow_convnet(const void *x, int64_t x_image_stride, void *out,
     const int IPW = GC_PX / (H * W);
     const int64_t grid = (B + IPW - 1) / IPW;
     if (grid > 0x7fffffff) return NF_ERANGE;
-    hipLaunchKernelGGL(glow_convnet_kernel, dim3((unsigned)grid), dim3(64 * GC_NW), lds, (hipStream_t)stream,
-                       (const float *)x, x_image_stride, (float *)out, (const float *)wpack, m, B, H, W);
+    hipLaunchKernelGGL(glow_convnet_kernel, dim3((unsigned)grid), dim3(64 * GC_NW), lds, st, (const float *)x,
+                       x_image_stride, (float *)out, (const float *)wpack, m, B, H, W);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

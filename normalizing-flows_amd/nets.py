@@ -222,20 +222,20 @@ class ConvNet2d(nn.Module):
 
     def forward(self, x):
         if x.is_cuda and not torch.is_grad_enabled():
-            blob = self._fused_pack(x)
-            if blob is not None:
+            fused = self._fused_pack(x)
+            if fused is not None:
                 from . import ops
-                return ops.glow_convnet(x, blob, self.net[-1].out_channels, self.net[1].negative_slope)
+                return ops.glow_convnet(x, fused[0], self.net[-1].out_channels, self.net[1].negative_slope, fused[1])
             return self._forward_inference(x)
         return self.net(x)
 
-    # the one-launch kernel only pays when its 256-pixel workgroups can fill the chip
-    FUSED_MIN_PIXELS = 128 * 256
+    # below this many pixels per call the library path stays (the one-launch kernels are built for full-chip batches)
+    FUSED_MIN_PIXELS = 2048
 
     def _fused_pack(self, x):
-        """Packed weights for ops.glow_convnet when this is the GlowBlock network (3x3 -> 1x1 -> 3x3 around 256 hidden
-        channels, biases, equal LeakyReLU slopes) and the call is one the kernel takes; None otherwise.  Repacked when a
-        parameter changes."""
+        """(packed weights, layout) for ops.glow_convnet when this is the GlowBlock network (3x3 -> 1x1 -> 3x3 around 256
+        hidden channels, biases, equal LeakyReLU slopes) and the call is one a kernel takes; None otherwise.  Repacked
+        when a parameter changes; one pack per layout (256-pixel or 64-pixel workgroups)."""
         mods = list(self.net)
         if len(mods) != 5 or not x.is_cuda or x.dtype != torch.float32 or torch.is_grad_enabled() or x.dim() != 4:
             return None
@@ -249,19 +249,22 @@ class ConvNet2d(nn.Module):
             return None
         if a1.negative_slope != a2.negative_slope or not 0.0 <= a1.negative_slope <= 1.0:
             return None
+        from . import ops
         B, Cin, H, W = x.shape
-        if 256 % (H * W) != 0 or B * H * W < self.FUSED_MIN_PIXELS:
+        if B * H * W < self.FUSED_MIN_PIXELS:
+            return None
+        layout = ops.glow_convnet_layout(B, H, W)
+        if layout is None or (layout == ops.GLOW_CONV_WIDE and B * H * W < 128 * 256):
             return None
         if x.stride(3) != 1 or x.stride(2) != W or x.stride(1) != H * W:
             return None
         params = [c1.weight, c1.bias, c2.weight, c2.bias, c3.weight, c3.bias]
         key = tuple((p_.data_ptr(), p_._version) for p_ in params)
-        cache = getattr(self, "_gc_cache", None)
-        if cache is None or cache[0] != key:
-            from . import ops
-            cache = (key, ops.glow_convnet_pack(*[p_.detach() for p_ in params]))
-            self._gc_cache = cache
-        return cache[1]
+        cache = self.__dict__.setdefault("_gc_cache", {})
+        hit = cache.get(layout)
+        if hit is None or hit[0] != key:
+            hit = cache[layout] = (key, ops.glow_convnet_pack(*[p_.detach() for p_ in params], layout=layout))
+        return None if hit[1] is None else (hit[1], layout)
 
     def forward_split(self, x):
         """(output without the last convolution's bias, that bias) for callers that fold the bias into their own kernel

@@ -478,7 +478,16 @@ def arnsf_inverse(z, blob, table, hidden_padded, K, tails, tail_bound, min_bin_w
     return y, logdet
 
 
-def glow_convnet_pack(w1, b1, w2, b2, w3, b3):
+GLOW_CONV_WIDE, GLOW_CONV_SMALL = 0, 1
+
+
+def glow_convnet_layout(B, H, W):
+    """Which nf_glow_convnet kernel takes (B, *, H, W) inputs: GLOW_CONV_WIDE, GLOW_CONV_SMALL or None."""
+    code = L.lib().nf_glow_convnet_layout(i64(B), i32(H), i32(W))
+    return code if code >= 0 else None
+
+
+def glow_convnet_pack(w1, b1, w2, b2, w3, b3, layout=GLOW_CONV_WIDE):
     """Packed weights of a GlowBlock conditioner for glow_convnet (nf_glow_convnet_pack); None for unsupported shapes."""
     import ctypes
     L.require_device(w1, b1, w2, b2, w3, b3)
@@ -486,26 +495,26 @@ def glow_convnet_pack(w1, b1, w2, b2, w3, b3):
     lib = L.lib()
     lib.nf_glow_convnet_pack_size.restype = ctypes.c_int64
     size = lib.nf_glow_convnet_pack_size(i32(Cin), i32(Cout), i32(hidden))
-    if size <= 0:
+    if size <= 0 or (layout == GLOW_CONV_SMALL and Cout > 48):
         return None
     blob = torch.empty(size // 4, dtype=torch.float32, device=w1.device)
     rc = lib.nf_glow_convnet_pack(ptr(blob), ptr(w1.contiguous()), ptr(b1.contiguous()), ptr(w2.contiguous()),
                                   ptr(b2.contiguous()), ptr(w3.contiguous()), ptr(b3.contiguous()), i32(Cin), i32(Cout),
-                                  i32(hidden), L.stream())
+                                  i32(hidden), i32(layout), L.stream())
     L.check(rc, "nf_glow_convnet_pack")
     return blob
 
 
-def glow_convnet(x, blob, Cout, slope, hidden=256):
+def glow_convnet(x, blob, Cout, slope, layout=GLOW_CONV_WIDE, hidden=256):
     """cnn.py:5-63 for the GlowBlock network in one launch (nf_glow_convnet).  x: (B, Cin, H, W), possibly a channel
-    slice of a contiguous NCHW tensor (planes contiguous, arbitrary image stride)."""
+    slice of a contiguous NCHW tensor (planes contiguous, arbitrary image stride); blob packed for the same layout."""
     L.require_device(x, blob)
     B, Cin, H, W = x.shape
     if x.dtype != torch.float32 or x.stride(3) != 1 or x.stride(2) != W or x.stride(1) != H * W:
         raise NotImplementedError("glow_convnet: float32 with contiguous (H, W) planes")
     out = torch.empty(B, Cout, H, W, dtype=x.dtype, device=x.device)
-    rc = L.lib().nf_glow_convnet(ptr_any(x), i64(x.stride(0) if B > 1 else Cin * H * W), ptr(out), ptr(blob), i64(B), i32(Cin),
-                                 i32(H), i32(W), i32(Cout), i32(hidden), f64(slope), L.stream())
+    rc = L.lib().nf_glow_convnet(ptr_any(x), i64(x.stride(0) if B > 1 else Cin * H * W), ptr(out), ptr(blob), i64(B),
+                                 i32(Cin), i32(H), i32(W), i32(Cout), i32(hidden), f64(slope), i32(layout), L.stream())
     L.check(rc, "nf_glow_convnet")
     return out
 

@@ -304,27 +304,35 @@ def test_glow_convnet_kernel_vs_reference(nfa, name, seed, cin, cout, leaky, B, 
     np.testing.assert_allclose(chk, g["weight_checksum"], rtol=1e-12)
     net = net.to(DEV)
     c1, _, c2, _, c3 = net.net
-    blob = nfa.ops.glow_convnet_pack(c1.weight.detach(), c1.bias.detach(), c2.weight.detach(), c2.bias.detach(),
-                                     c3.weight.detach(), c3.bias.detach())
+    prm = [p_.detach() for p_ in (c1.weight, c1.bias, c2.weight, c2.bias, c3.weight, c3.bias)]
     x = T(g["x"])
-    out = nfa.ops.glow_convnet(x, blob, cout, leaky)
-    assert_close(N(out), g["out"], what="out", rtol=1e-4, atol=1e-4)
-    # a channel slice of a wider NCHW tensor is read in place (image stride != Cin H W)
     wide = torch.randn(B, cin + 3, H, W, device=DEV)
     wide[:, 2:2 + cin] = x
-    out2 = nfa.ops.glow_convnet(wide[:, 2:2 + cin], blob, cout, leaky)
-    assert torch.equal(out2, out)
-    # the module takes this path on its own once the batch fills the chip, and agrees with its library path
+    outs = []
+    for layout in (nfa.ops.GLOW_CONV_WIDE, nfa.ops.GLOW_CONV_SMALL):   # 256-pixel / 64-pixel workgroups
+        if layout == nfa.ops.GLOW_CONV_SMALL and 64 % (H * W) != 0:
+            continue
+        blob = nfa.ops.glow_convnet_pack(*prm, layout=layout)
+        out = nfa.ops.glow_convnet(x, blob, cout, leaky, layout)
+        assert_close(N(out), g["out"], what="out (layout %d)" % layout, rtol=1e-4, atol=1e-4)
+        # a channel slice of a wider NCHW tensor is read in place (image stride != Cin H W)
+        assert torch.equal(nfa.ops.glow_convnet(wide[:, 2:2 + cin], blob, cout, leaky, layout), out)
+        assert torch.equal(nfa.ops.glow_convnet(x, blob, cout, leaky, layout), out)          # run-to-run identical
+        outs.append(out)
+    # the module takes this path on its own for chip-filling batches, and agrees with its library path
     with torch.no_grad():
         lib = net._forward_inference(x)
         old, type(net).FUSED_MIN_PIXELS = type(net).FUSED_MIN_PIXELS, 0
         try:
-            assert net._fused_pack(x) is not None and net.forward_split(x) is None
-            fused = net(x)
+            fused = net._fused_pack(x)
+            if H * W <= 64:
+                assert fused is not None and fused[1] == nfa.ops.GLOW_CONV_SMALL and net.forward_split(x) is None
+                assert torch.equal(net(x), outs[-1])
+            else:
+                assert fused is None      # 16x16 images: the wide kernel waits for >= 128 workgroups
         finally:
             type(net).FUSED_MIN_PIXELS = old
-    assert torch.equal(fused, out)
-    assert_close(N(fused), N(lib), what="fused vs library", rtol=1e-4, atol=1e-4)
+    assert_close(N(outs[0]), N(lib), what="fused vs library", rtol=1e-4, atol=1e-4)
 
 
 def test_diag_gaussian_and_squeeze(nfa):
