@@ -406,6 +406,24 @@ int nf_glow_convnet(const void *x, int64_t x_image_stride, void *out, const void
                     int W, int Cout, int hidden, double leaky_slope, int layout, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * A whole GlowBlock in the conditioner's launch (inference, parameters frozen between updates).  Replaces
+ * GlowBlock.forward / .inverse (normflows/flows/affine/glow.py:72-84) for split_mode "channel", scale = True:
+ * AffineCouplingBlock (coupling.py:232-267: Split, AffineCoupling :117-171, Merge) + Invertible1x1Conv
+ * (mixing.py:88-133) + ActNorm (normalization.py:19-39, initialised).  The last two are handed over as ONE per-pixel
+ * affine map:  mix_w (C, C), mix_b (C), mix_logdet (device scalar: log|det| per pixel), composed for the direction,
+ *   direction 1 (inverse, density):  m = mix_w z + mix_b with mix_w = W diag(e^-s), mix_b = -mix_w t; then the coupling
+ *                                    inverse on m with the conditioner reading m's first ceil(C/2) channels;
+ *   direction 0 (forward, sampling): coupling forward on z, then y = mix_w (.) + mix_b with mix_w = diag(e^s) W^-1,
+ *                                    mix_b = t.
+ *   wpack: nf_glow_convnet_pack of the conditioner (Cin = ceil(C/2), Cout = 2 floor(C/2)) for `layout`.
+ *   z, y (B, C, H, W) contiguous, y != z; logdet (B) combined per `acc` with the block's log-det
+ *   (H W mix_logdet + the coupling's row sum).
+ */
+int nf_glow_block(const void *z, void *y, void *logdet, const void *wpack, const void *mix_w, const void *mix_b,
+                  const void *mix_logdet, int64_t B, int C, int H, int W, int hidden, double leaky_slope, int scale_map,
+                  int direction, int acc, int layout, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Squeeze (flows/reshape.py:116-128).  direction 0 = forward (C,H,W)->(C/4,2H,2W),
  * 1 = inverse (C,H,W)->(4C,H/2,W/2).  z, y contiguous NCHW with the shapes implied.
  */

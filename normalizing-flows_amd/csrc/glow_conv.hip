@@ -134,9 +134,155 @@ __device__ __forceinline__ void gc_leaky(f32x16 &v, float slope) {
     for (int c = 0; c < 16; ++c) v[c] = fmaxf(v[c], v[c] * slope);   // 0 <= slope <= 1 (cnn.py:38 LeakyReLU)
 }
 
+// ---- optional fusion of the rest of the GlowBlock around the conditioner ----------------------------------------------
+// GlowBlock = [AffineCouplingBlock(split "channel"), Invertible1x1Conv, ActNorm] (glow.py:11-84).  With parameters frozen
+// the last two are ONE per-pixel affine map m = Wp z + bp with a constant log|det| per pixel (flows/glow.py::_fused_mix);
+// the workgroup holds whole images, so the block runs inside the conditioner's launch:
+//   direction 1 (GlowBlock.inverse, the density direction): mix first, conditioner on the mixed identity half,
+//               coupling inverse (coupling.py:150-171) on the mixed other half;
+//   direction 0 (GlowBlock.forward): conditioner on the raw identity half, coupling forward (:117-148), then the mix.
+struct GbFuse {
+    int on;            // 0: conditioner only
+    int C, c1;         // channels of z; the identity half = the first c1 = ceil(C / 2) channels (reshape.py:31)
+    int scale_map;     // NF_SCALE_EXP | NF_SCALE_SIGMOID | NF_SCALE_SIGMOID_INV
+    int direction, acc;
+    const float *Wp;   // (C, C)
+    const float *bp;   // (C)
+    const float *ldu;  // log|det| of the mix per pixel (device scalar)
+    float *logdet;     // (B)
+};
+
+__host__ __device__ inline int gb_lds_floats(const GbFuse &fu, int Cout, int PXW) {
+    return fu.on ? (2 * fu.C + Cout + (fu.C - fu.c1)) * PXW : 0;   // zr | zm | prm | ldt
+}
+
+// Padded input images of the conditioner from global memory (plain call).
+template <int PXW, int NT>
+__device__ __forceinline__ void gc_fill_xin_global(const float *__restrict__ x, int64_t xs_img, float *xin, int Cin, int H, int W,
+                                                   int64_t img0, int64_t B, int tid) {
+    const int HW = H * W, PH = H + 2, PW = W + 2, IPW = PXW / HW, per_img = Cin * PH * PW, n = IPW * per_img;
+    for (int i = tid; i < n; i += NT) {
+        const int im = i / per_img, rem = i - im * per_img, c = rem / (PH * PW), rr = rem - c * PH * PW;
+        const int yy = rr / PW - 1, xx = rr - (yy + 1) * PW - 1;
+        const int64_t g = img0 + im;
+        float v = 0.0f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W && g < B) v = x[g * xs_img + (int64_t)c * HW + yy * W + xx];
+        xin[i] = v;
+    }
+}
+
+// Fused block: the workgroup's images -> zr[c][p]; direction 1 also mixes them (zm) and writes the identity half of the
+// result; the conditioner's padded input comes from the identity half of zm / zr.  Ends with a barrier.
+template <int PXW, int NT>
+__device__ __forceinline__ void gb_prologue(const GbFuse &fu, const float *__restrict__ z, float *__restrict__ y, float *zr,
+                                            float *zm, float *xin, int H, int W, int64_t img0, int64_t B, int tid) {
+    const int HW = H * W, PH = H + 2, PW = W + 2, IPW = PXW / HW, C = fu.C;
+    for (int i = tid; i < C * PXW; i += NT) {
+        const int c = i / PXW, p = i - c * PXW, im = p / HW, q = p - im * HW;
+        const int64_t g = img0 + im;
+        zr[i] = g < B ? z[(g * C + c) * HW + q] : 0.0f;
+    }
+    __syncthreads();
+    const float *src = zr;
+    if (fu.direction == 1) {
+        for (int i = tid; i < C * PXW; i += NT) {
+            const int c = i / PXW, p = i - c * PXW, im = p / HW, q = p - im * HW;
+            const int64_t g = img0 + im;
+            float a = fu.bp[c];
+            for (int k = 0; k < C; ++k) a = fmaf(fu.Wp[c * C + k], zr[k * PXW + p], a);
+            zm[i] = a;
+            if (c < fu.c1 && g < B) y[(g * C + c) * HW + q] = a;
+        }
+        __syncthreads();
+        src = zm;
+    }
+    const int per_img = fu.c1 * PH * PW, n = IPW * per_img;
+    for (int i = tid; i < n; i += NT) {
+        const int im = i / per_img, rem = i - im * per_img, c = rem / (PH * PW), rr = rem - c * PH * PW;
+        const int yy = rr / PW - 1, xx = rr - (yy + 1) * PW - 1;
+        xin[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? src[c * PXW + im * HW + yy * W + xx] : 0.0f;
+    }
+}
+
+// col2im of one output block: 9-term neighbour gather over the tap products in P, + bias; to HBM (plain call) or to the
+// LDS parameter planes prm[co][p] (fused block).
+template <int PXW, int NT>
+__device__ __forceinline__ void gc_gather_block(const float *P, int blk, const GcMeta &mt, int H, int W, int64_t img0, int64_t B,
+                                                const float *small, float *__restrict__ out, float *prm, int tid) {
+    const int HW = H * W;
+    for (int e = tid; e < 3 * PXW; e += NT) {
+        const int cc = e / PXW, p = e - cc * PXW;
+        const int co = 3 * blk + cc;
+        const int im = p / HW, q = p - im * HW, y = q / W, xq = q - y * W;
+        const int64_t g = img0 + im;
+        if (co < mt.Cout && (prm || g < B)) {
+            float sum = small[2 * GC_HID + co];
+            const float *pr = P + (cc * 9) * PXW + p;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int yy = y + ky - 1, xx = xq + kx - 1;
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) sum += pr[(ky * 3 + kx) * PXW + (ky - 1) * W + (kx - 1)];
+                }
+            }
+            if (prm) prm[co * PXW + p] = sum;
+            else out[(g * mt.Cout + co) * HW + q] = sum;
+        }
+    }
+}
+
+// Fused block after the conditioner: coupling on the other half (parameter planes 2 i = shift, 2 i + 1 = scale,
+// coupling.py:117-171), direction 0 then applies the mix; per-image log-det in a fixed order (one wave per image).
+template <int PXW, int NT>
+__device__ __forceinline__ void gb_epilogue(const GbFuse &fu, float *__restrict__ y, float *zr, const float *zm, const float *prm,
+                                            float *ldt, int H, int W, int64_t img0, int64_t B, int tid) {
+    const int HW = H * W, IPW = PXW / HW, C = fu.C, c1 = fu.c1, n2 = C - c1;
+    __syncthreads();   // parameter planes complete
+    const float *z2 = (fu.direction == 1 ? zm : zr) + c1 * PXW;
+    for (int e = tid; e < n2 * PXW; e += NT) {
+        const int i = e / PXW, p = e - i * PXW, im = p / HW, q = p - im * HW;
+        const int64_t g = img0 + im;
+        const float sh = prm[(2 * i) * PXW + p], sc = prm[(2 * i + 1) * PXW + p], v = z2[e];
+        float o, l;
+        if (fu.scale_map == NF_SCALE_EXP) {
+            o = fu.direction == 0 ? v * M<float>::exp(sc) + sh : (v - sh) * M<float>::exp(-sc);
+            l = sc;
+        } else {
+            const float sg = sigmoid(sc + 2.0f), lg = M<float>::log(sg);
+            if (fu.scale_map == NF_SCALE_SIGMOID) { o = fu.direction == 0 ? v / sg + sh : (v - sh) * sg; l = -lg; }
+            else { o = fu.direction == 0 ? v * sg + sh : (v - sh) / sg; l = lg; }
+        }
+        ldt[e] = fu.direction == 0 ? l : -l;
+        if (fu.direction == 1) { if (g < B) y[(g * C + c1 + i) * HW + q] = o; }
+        else zr[(c1 + i) * PXW + p] = o;
+    }
+    __syncthreads();
+    if (fu.direction == 0) {
+        for (int i = tid; i < C * PXW; i += NT) {
+            const int c = i / PXW, p = i - c * PXW, im = p / HW, q = p - im * HW;
+            const int64_t g = img0 + im;
+            float a = fu.bp[c];
+            for (int k = 0; k < C; ++k) a = fmaf(fu.Wp[c * C + k], zr[k * PXW + p], a);
+            if (g < B) y[(g * C + c) * HW + q] = a;
+        }
+    }
+    const int lane = tid & 63, wv = tid >> 6;
+    const float ldu = *fu.ldu;
+    for (int im = wv; im < IPW; im += NT / 64) {
+        float a = 0.0f;
+        for (int t = lane; t < n2 * HW; t += 64) {
+            const int i = t / HW, q = t - i * HW;
+            a += ldt[i * PXW + im * HW + q];
+        }
+        a = wave_sum(a);
+        if (lane == 0 && img0 + im < B) ld_store(fu.logdet + img0 + im, a + (float)HW * ldu, fu.acc);
+    }
+}
+
 __global__ void __launch_bounds__(64 * GC_NW, 2)
 glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restrict__ out, const float *__restrict__ blob,
-                    GcMeta mt, int64_t B, int H, int W) {
+                    GcMeta mt, int64_t B, int H, int W, GbFuse fu) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int HW = H * W, PH = H + 2, PW = W + 2, IPW = GC_PX / HW;
     const int K1p = 8 * mt.nkg1;
@@ -145,6 +291,8 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
     float *small = P + 32 * GC_PX;               // biases
     int *koff = reinterpret_cast<int *>(small + gc_small_padded(mt));   // im2col offset of every k
     float *xin = reinterpret_cast<float *>(koff + K1p);                  // zero-padded input images [img][c][PH][PW]
+    float *zr = xin + IPW * mt.Cin * PH * PW;    // fused block only: raw z | mixed z | parameter planes | log-det terms
+    float *zm = zr + fu.C * GC_PX, *prm = zm + fu.C * GC_PX, *ldt = prm + mt.Cout * GC_PX;
     const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = wid * 32 + (lane & 31);
@@ -186,17 +334,8 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
         const int c = kk / 9, t = kk - 9 * c, ky = t / 3;
         koff[k] = c * PH * PW + ky * PW + (t - 3 * ky);
     }
-    {
-        const int per_img = mt.Cin * PH * PW, n = IPW * per_img;
-        for (int i = tid; i < n; i += 64 * GC_NW) {
-            const int im = i / per_img, rem = i - im * per_img, c = rem / (PH * PW), rr = rem - c * PH * PW;
-            const int yy = rr / PW - 1, xx = rr - (yy + 1) * PW - 1;
-            const int64_t g = img0 + im;
-            float v = 0.0f;
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W && g < B) v = x[g * xs_img + (int64_t)c * HW + yy * W + xx];
-            xin[i] = v;
-        }
-    }
+    if (fu.on) gb_prologue<GC_PX, 64 * GC_NW>(fu, x, out, zr, zm, xin, H, W, img0, B, tid);
+    else gc_fill_xin_global<GC_PX, 64 * GC_NW>(x, xs_img, xin, mt.Cin, H, W, img0, B, tid);
 
     // ---- GEMM 1 (conv3x3 #1 by im2col): h1 = LeakyReLU(W1 col(x) + b1) ----
     f32x16 H0, H1, H2, H3, H4, H5, H6, H7;
@@ -272,30 +411,12 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) P[(8 * (reg >> 2) + 4 * hh + (reg & 3)) * GC_PX + px] = o[reg];
             __syncthreads();
-            for (int e = tid; e < 3 * GC_PX; e += 64 * GC_NW) {
-                const int cc = e / GC_PX, p = e - cc * GC_PX;
-                const int co = 3 * blk + cc;
-                const int im = p / HW, q = p - im * HW, y = q / W, xq = q - y * W;
-                const int64_t g = img0 + im;
-                if (co < mt.Cout && g < B) {
-                    float sum = small[2 * GC_HID + co];
-                    const float *pr = P + (cc * 9) * GC_PX + p;
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const int yy = y + ky - 1, xx = xq + kx - 1;
-                            if (yy >= 0 && yy < H && xx >= 0 && xx < W)
-                                sum += pr[(ky * 3 + kx) * GC_PX + (ky - 1) * W + (kx - 1)];
-                        }
-                    }
-                    out[(g * mt.Cout + co) * HW + q] = sum;
-                }
-            }
+            gc_gather_block<GC_PX, 64 * GC_NW>(P, blk, mt, H, W, img0, B, small, out, fu.on ? prm : nullptr, tid);
             __syncthreads();
             }
         }
     }
+    if (fu.on) gb_epilogue<GC_PX, 64 * GC_NW>(fu, out, zr, zm, prm, ldt, H, W, img0, B, tid);
 }
 
 // ---- small images: 64-pixel workgroups of 4 waves x 16 pixels on v_mfma_f32_16x16x4_f32 ------------------------------
@@ -318,7 +439,7 @@ __device__ __forceinline__ void gs_leaky(f32x4 &v, float slope) {
 template <int OBT>
 __global__ void __launch_bounds__(64 * GS_NW)
 glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__restrict__ out,
-                          const float *__restrict__ blob, GcMeta mt, int64_t B, int H, int W) {
+                          const float *__restrict__ blob, GcMeta mt, int64_t B, int H, int W, GbFuse fu) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int HW = H * W, PH = H + 2, PW = W + 2, IPW = GS_PX / HW;
     const int nkb1 = (mt.K1 + 15) / 16, K1p = 16 * nkb1;
@@ -327,6 +448,8 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
     float *small = P + 32 * GS_PX;
     int *koff = reinterpret_cast<int *>(small + gc_small_padded(mt));
     float *xin = reinterpret_cast<float *>(koff + K1p);
+    float *zr = xin + IPW * mt.Cin * PH * PW;
+    float *zm = zr + fu.C * GS_PX, *prm = zm + fu.C * GS_PX, *ldt = prm + mt.Cout * GS_PX;
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = wid * 16 + (lane & 15);
@@ -369,17 +492,8 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
         const int c = kk / 9, t = kk - 9 * c, ky = t / 3;
         koff[k] = c * PH * PW + ky * PW + (t - 3 * ky);
     }
-    {
-        const int per_img = mt.Cin * PH * PW, n = IPW * per_img;
-        for (int i = tid; i < n; i += 64 * GS_NW) {
-            const int im = i / per_img, rem = i - im * per_img, c = rem / (PH * PW), rr = rem - c * PH * PW;
-            const int yy = rr / PW - 1, xx = rr - (yy + 1) * PW - 1;
-            const int64_t gi = img0 + im;
-            float v = 0.0f;
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W && gi < B) v = x[gi * xs_img + (int64_t)c * HW + yy * W + xx];
-            xin[i] = v;
-        }
-    }
+    if (fu.on) gb_prologue<GS_PX, 64 * GS_NW>(fu, x, out, zr, zm, xin, H, W, img0, B, tid);
+    else gc_fill_xin_global<GS_PX, 64 * GS_NW>(x, xs_img, xin, mt.Cin, H, W, img0, B, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's in-order accounting starts from an empty queue
     issue(0);
     if (total_stages > 1) issue(1);
@@ -505,41 +619,23 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
 #pragma unroll
             for (int r = 0; r < 4; ++r) P[(16 * ob + 4 * g + r) * GS_PX + px] = O[2 * blk + ob][r];
         __syncthreads();
-        for (int e = tid; e < 3 * GS_PX; e += 64 * GS_NW) {
-            const int cc = e / GS_PX, p = e - cc * GS_PX;
-            const int co = 3 * blk + cc;
-            const int im = p / HW, q = p - im * HW, y = q / W, xq = q - y * W;
-            const int64_t gi = img0 + im;
-            if (co < mt.Cout && gi < B) {
-                float sum = small[2 * GC_HID + co];
-                const float *pr = P + (cc * 9) * GS_PX + p;
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int yy = y + ky - 1, xx = xq + kx - 1;
-                        if (yy >= 0 && yy < H && xx >= 0 && xx < W)
-                            sum += pr[(ky * 3 + kx) * GS_PX + (ky - 1) * W + (kx - 1)];
-                    }
-                }
-                out[(gi * mt.Cout + co) * HW + q] = sum;
-            }
-        }
+        gc_gather_block<GS_PX, 64 * GS_NW>(P, blk, mt, H, W, img0, B, small, out, fu.on ? prm : nullptr, tid);
         __syncthreads();
         }
     }
+    if (fu.on) gb_epilogue<GS_PX, 64 * GS_NW>(fu, out, zr, zm, prm, ldt, H, W, img0, B, tid);
 }
 
-static inline size_t gs_lds_bytes(const GcMeta &m, int H, int W) {
+static inline size_t gs_lds_bytes(const GcMeta &m, int H, int W, const GbFuse &fu) {
     const int IPW = GS_PX / (H * W);
     return ((size_t)GS_RING * GC_STAGE + 32 * GS_PX + gc_small_padded(m) + 16 * ((m.K1 + 15) / 16) +
-            (size_t)IPW * m.Cin * (H + 2) * (W + 2)) * sizeof(float) + 16;
+            (size_t)IPW * m.Cin * (H + 2) * (W + 2) + gb_lds_floats(fu, m.Cout, GS_PX)) * sizeof(float) + 16;
 }
 
-static inline size_t gc_lds_bytes(const GcMeta &m, int H, int W) {
+static inline size_t gc_lds_bytes(const GcMeta &m, int H, int W, const GbFuse &fu) {
     const int IPW = GC_PX / (H * W);
     return ((size_t)2 * GC_STAGE + 32 * GC_PX + gc_small_padded(m) + 8 * m.nkg1 +
-            (size_t)IPW * m.Cin * (H + 2) * (W + 2)) * sizeof(float) + 16;
+            (size_t)IPW * m.Cin * (H + 2) * (W + 2) + gb_lds_floats(fu, m.Cout, GC_PX)) * sizeof(float) + 16;
 }
 
 }  // namespace nf
@@ -587,8 +683,8 @@ extern "C" int nf_glow_convnet_layout(int64_t B, int H, int W) {
 
 template <int OBT>
 static int launch_small(const void *x, int64_t xs, void *out, const void *wpack, const GcMeta &m, int64_t B, int H, int W,
-                        hipStream_t st) {
-    const size_t lds = gs_lds_bytes(m, H, W);
+                        const GbFuse &fu, hipStream_t st) {
+    const size_t lds = gs_lds_bytes(m, H, W, fu);
     if (lds > 160 * 1024) return NF_ENOTSUP;
     static LdsOptIn opted = {};
     if (opt_in_lds(reinterpret_cast<const void *>(&glow_convnet_small_kernel<OBT>), lds, opted) != NF_OK) return NF_ENOTSUP;
@@ -596,7 +692,30 @@ static int launch_small(const void *x, int64_t xs, void *out, const void *wpack,
     const int64_t grid = (B + IPW - 1) / IPW;
     if (grid > 0x7fffffff) return NF_ERANGE;
     hipLaunchKernelGGL(glow_convnet_small_kernel<OBT>, dim3((unsigned)grid), dim3(64 * GS_NW), lds, st, (const float *)x, xs,
-                       (float *)out, (const float *)wpack, m, B, H, W);
+                       (float *)out, (const float *)wpack, m, B, H, W, fu);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+static int gc_launch(const void *x, int64_t xs, void *out, const void *wpack, const GcMeta &m, int64_t B, int H, int W,
+                     int layout, const GbFuse &fu, hipStream_t st) {
+    const int PXW = layout == NF_GLOW_CONV_WIDE ? GC_PX : GS_PX;
+    if (H * W > PXW || PXW % (H * W) != 0) return NF_ENOTSUP;   // whole images per workgroup
+    if (layout == NF_GLOW_CONV_SMALL) {
+        if (m.OB <= 4) return launch_small<4>(x, xs, out, wpack, m, B, H, W, fu, st);
+        if (m.OB <= 8) return launch_small<8>(x, xs, out, wpack, m, B, H, W, fu, st);
+        if (m.OB <= 16) return launch_small<16>(x, xs, out, wpack, m, B, H, W, fu, st);
+        return NF_ENOTSUP;
+    }
+    const size_t lds = gc_lds_bytes(m, H, W, fu);
+    if (lds > 160 * 1024) return NF_ENOTSUP;
+    static LdsOptIn opted = {};
+    if (opt_in_lds(reinterpret_cast<const void *>(&glow_convnet_kernel), lds, opted) != NF_OK) return NF_ENOTSUP;
+    const int IPW = GC_PX / (H * W);
+    const int64_t grid = (B + IPW - 1) / IPW;
+    if (grid > 0x7fffffff) return NF_ERANGE;
+    hipLaunchKernelGGL(glow_convnet_kernel, dim3((unsigned)grid), dim3(64 * GC_NW), lds, st, (const float *)x, xs, (float *)out,
+                       (const float *)wpack, m, B, H, W, fu);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -607,27 +726,29 @@ extern "C" int nf_glow_convnet(const void *x, int64_t x_image_stride, void *out,
     if (rc) return rc;
     if (layout != NF_GLOW_CONV_WIDE && layout != NF_GLOW_CONV_SMALL) return NF_EINVAL;
     if (B < 0 || H < 1 || W < 1 || x_image_stride < (int64_t)Cin * H * W) return NF_EINVAL;
-    const int PXW = layout == NF_GLOW_CONV_WIDE ? GC_PX : GS_PX;
-    if (H * W > PXW || PXW % (H * W) != 0) return NF_ENOTSUP;   // whole images per workgroup
     if (B == 0) return NF_OK;
     if (!x || !out || !wpack) return NF_EFAULT;
-    const GcMeta m = gc_meta(Cin, Cout, leaky_slope);
-    hipStream_t st = (hipStream_t)stream;
-    if (layout == NF_GLOW_CONV_SMALL) {
-        if (m.OB <= 4) return launch_small<4>(x, x_image_stride, out, wpack, m, B, H, W, st);
-        if (m.OB <= 8) return launch_small<8>(x, x_image_stride, out, wpack, m, B, H, W, st);
-        if (m.OB <= 16) return launch_small<16>(x, x_image_stride, out, wpack, m, B, H, W, st);
-        return NF_ENOTSUP;
-    }
-    const size_t lds = gc_lds_bytes(m, H, W);
-    if (lds > 160 * 1024) return NF_ENOTSUP;
-    static LdsOptIn opted = {};
-    if (opt_in_lds(reinterpret_cast<const void *>(&glow_convnet_kernel), lds, opted) != NF_OK) return NF_ENOTSUP;
-    const int IPW = GC_PX / (H * W);
-    const int64_t grid = (B + IPW - 1) / IPW;
-    if (grid > 0x7fffffff) return NF_ERANGE;
-    hipLaunchKernelGGL(glow_convnet_kernel, dim3((unsigned)grid), dim3(64 * GC_NW), lds, st, (const float *)x,
-                       x_image_stride, (float *)out, (const float *)wpack, m, B, H, W);
-    NF_CHECK_LAUNCH();
-    return NF_OK;
+    GbFuse fu = {};
+    return gc_launch(x, x_image_stride, out, wpack, gc_meta(Cin, Cout, leaky_slope), B, H, W, layout, fu, (hipStream_t)stream);
+}
+
+extern "C" int nf_glow_block(const void *z, void *y, void *logdet, const void *wpack, const void *mix_w, const void *mix_b,
+                             const void *mix_logdet, int64_t B, int C, int H, int W, int hidden, double leaky_slope,
+                             int scale_map, int direction, int acc, int layout, nf_stream_t stream) {
+    if (C < 2) return NF_EINVAL;
+    const int c1 = (C + 1) / 2, Cout = 2 * (C - c1);
+    const int rc = gc_check(c1, Cout, hidden, leaky_slope);
+    if (rc) return rc;
+    if (layout != NF_GLOW_CONV_WIDE && layout != NF_GLOW_CONV_SMALL) return NF_EINVAL;
+    if (scale_map < NF_SCALE_EXP || scale_map > NF_SCALE_SIGMOID_INV) return NF_EINVAL;
+    if ((direction != 0 && direction != 1) || acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
+    if (B < 0 || H < 1 || W < 1) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!z || !y || !logdet || !wpack || !mix_w || !mix_b || !mix_logdet) return NF_EFAULT;
+    GbFuse fu = {};
+    fu.on = 1; fu.C = C; fu.c1 = c1; fu.scale_map = scale_map; fu.direction = direction; fu.acc = acc;
+    fu.Wp = (const float *)mix_w; fu.bp = (const float *)mix_b; fu.ldu = (const float *)mix_logdet;
+    fu.logdet = (float *)logdet;
+    return gc_launch(z, (int64_t)C * H * W, y, wpack, gc_meta(c1, Cout, leaky_slope), B, H, W, layout, fu,
+                     (hipStream_t)stream);
 }

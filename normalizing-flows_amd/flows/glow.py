@@ -62,6 +62,23 @@ class GlowBlock(Flow):
             self._mix_cache = cache
         return cache[1]
 
+    def _whole_block(self, z):
+        """(packed conditioner, layout, LeakyReLU slope, scale map) when the block is the shape nf_glow_block takes:
+        channel split, scale = True, the 3x3 -> 1x1 -> 3x3 conditioner around 256 channels, float32, enough pixels."""
+        blk = self.flows[0]
+        if not isinstance(blk, AffineCouplingBlock) or blk.split_mode != "channel" or z.shape[1] < 2:
+            return None
+        coupling = blk.flows[1]
+        net = coupling.param_map
+        if not coupling.scale or not isinstance(net, nets.ConvNet2d) or z.dtype != torch.float32:
+            return None
+        zc = z if z.is_contiguous() else z.contiguous()
+        c1 = (z.shape[1] + 1) // 2
+        fused = net._fused_pack(zc[:, :c1])
+        if fused is None or net.net[-1].out_channels != 2 * (z.shape[1] - c1):
+            return None
+        return fused[0], fused[1], net.net[1].negative_slope, coupling.scale_map
+
     def _run(self, z, inverse, ld, acc, **kw):
         from .. import ops
         from ..autograd import needs_grad
@@ -71,6 +88,12 @@ class GlowBlock(Flow):
             mix = self._fused_mix(inverse)
             if mix is not None:
                 Wp, bp, ldp = mix
+                whole = self._whole_block(z)
+                if whole is not None:   # coupling + conditioner + mix: one launch (csrc/glow_conv.hip, nf_glow_block)
+                    blob, layout, slope, smap = whole
+                    y, _ = ops.glow_block(z, blob, layout, Wp, bp, ldp, slope, smap, 1 if inverse else 0, logdet=ld,
+                                          acc=acc)
+                    return y
                 if inverse:
                     z, _ = ops.inv1x1_conv(z, Wp, ldp, logdet=ld, acc=acc, want_scalar=False, bias=bp)
                     return run_flow(self.flows[0], z, True, ld, acc)

@@ -231,6 +231,7 @@ class ConvNet2d(nn.Module):
 
     # below this many pixels per call the library path stays (the one-launch kernels are built for full-chip batches)
     FUSED_MIN_PIXELS = 2048
+    FUSED_WIDE_MIN_PIXELS = 128 * 256   # the 256-pixel-workgroup kernel wants >= 128 workgroups
 
     def _fused_pack(self, x):
         """(packed weights, layout) for ops.glow_convnet when this is the GlowBlock network (3x3 -> 1x1 -> 3x3 around 256
@@ -254,7 +255,7 @@ class ConvNet2d(nn.Module):
         if B * H * W < self.FUSED_MIN_PIXELS:
             return None
         layout = ops.glow_convnet_layout(B, H, W)
-        if layout is None or (layout == ops.GLOW_CONV_WIDE and B * H * W < 128 * 256):
+        if layout is None or (layout == ops.GLOW_CONV_WIDE and B * H * W < self.FUSED_WIDE_MIN_PIXELS):
             return None
         if x.stride(3) != 1 or x.stride(2) != W or x.stride(1) != H * W:
             return None

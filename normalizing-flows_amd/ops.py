@@ -519,6 +519,28 @@ def glow_convnet(x, blob, Cout, slope, layout=GLOW_CONV_WIDE, hidden=256):
     return out
 
 
+def glow_block(z, blob, layout, mix_w, mix_b, mix_logdet, slope, scale_map, direction, logdet=None, acc=None, hidden=256):
+    """GlowBlock.forward (direction 0) / .inverse (1) in one launch (nf_glow_block): channel-split affine coupling with
+    the packed conditioner `blob`, and [Invertible1x1Conv, ActNorm] as the per-pixel affine map (mix_w, mix_b) with
+    log|det| per pixel mix_logdet (0-dim device tensor)."""
+    L.require_device(z, blob, mix_w, mix_b, mix_logdet)
+    if z.dtype != torch.float32:
+        raise NotImplementedError("glow_block: float32 only")
+    z = z.contiguous()
+    B, C, H, W = z.shape
+    y = torch.empty_like(z)
+    if logdet is None:
+        logdet = torch.empty(B, dtype=z.dtype, device=z.device)
+        acc = L.LD_WRITE
+    elif acc is None:
+        acc = L.LD_ADD
+    rc = L.lib().nf_glow_block(ptr(z), ptr(y), ptr(logdet), ptr(blob), ptr(mix_w.contiguous()), ptr(mix_b.contiguous()),
+                               ptr(mix_logdet.to(z.dtype).contiguous()), i64(B), i32(C), i32(H), i32(W), i32(hidden), f64(slope),
+                               i32(L.SCALE[scale_map]), i32(direction), i32(acc), i32(layout), L.stream())
+    L.check(rc, "nf_glow_block")
+    return y, logdet
+
+
 def logit(z, alpha, direction, logdet=None, acc=None):
     """transforms.py:8-47.  direction 0 = Logit.forward (sigmoid side), 1 = Logit.inverse (logit side)."""
     L.require_device(z)

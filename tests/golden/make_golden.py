@@ -746,6 +746,32 @@ def gen_glow_convnet():
         npz(name, x=x, out=out, weight_checksum=chk)
 
 
+GLOW_BLOCK_CASES = [   # (name, seed, C, scale_map, leaky, B, H, W)
+    ("glowblock256_C12_16x16", 41, 12, "sigmoid", 0.0, 3, 16, 16),
+    ("glowblock256_C24_8x8", 42, 24, "exp", 0.1, 5, 8, 8),
+    ("glowblock256_C48_4x4", 43, 48, "sigmoid_inv", 0.0, 19, 4, 4),
+    ("glowblock256_C5_4x4", 44, 5, "sigmoid", 0.0, 6, 4, 4),
+]
+
+
+def gen_glow_block256():
+    """GlowBlock at its real width (256 hidden channels, glow.py:11-84) in both directions; weights = the seeded default
+    construction (checksums stored), the last conditioner layer scaled down so that `exp` scales stay moderate."""
+    for name, seed, C, smap, leaky, B, H, W in GLOW_BLOCK_CASES:
+        torch.manual_seed(seed)
+        blk = nf.flows.GlowBlock(C, 256, scale_map=smap, leaky=leaky, init_zeros=False)
+        with torch.no_grad():
+            last = blk.flows[0].flows[1].param_map.net[-1]
+            last.weight.mul_(0.2)
+        x = torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(seed + 100))
+        with torch.no_grad():
+            zi, ldi = blk.inverse(x)          # first call: ActNorm's data-dependent initialisation
+            zi2, ldi2 = blk.inverse(x)
+            zf, ldf = blk.forward(x)
+        chk = torch.stack([p_.double().abs().sum() for p_ in blk.parameters()])
+        npz(name, x=x, z_inv=zi2, ld_inv=ldi2, z_fwd=zf, ld_fwd=ldf, checksum=chk)
+
+
 def gen_cdf():
     """Standalone PiecewiseRationalQuadraticCDF (nsf/coupling.py:170-259): 1-D and N-D parameter shapes, every tails
     variant, values and reference-autograd gradients in both directions."""
@@ -834,6 +860,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "circular":
         gen_circular()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "glow_block256":
+        gen_glow_block256()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "glow_convnet":
         gen_glow_convnet()
         sys.exit(0)
@@ -876,3 +905,4 @@ if __name__ == "__main__":
     gen_circular_grads()
     gen_cdf()
     gen_glow_convnet()
+    gen_glow_block256()

@@ -335,6 +335,47 @@ def test_glow_convnet_kernel_vs_reference(nfa, name, seed, cin, cout, leaky, B, 
     assert_close(N(outs[0]), N(lib), what="fused vs library", rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("name,seed,C,smap,leaky,B,H,W", [
+    ("glowblock256_C12_16x16", 41, 12, "sigmoid", 0.0, 3, 16, 16), ("glowblock256_C24_8x8", 42, 24, "exp", 0.1, 5, 8, 8),
+    ("glowblock256_C48_4x4", 43, 48, "sigmoid_inv", 0.0, 19, 4, 4), ("glowblock256_C5_4x4", 44, 5, "sigmoid", 0.0, 6, 4, 4)])
+def test_glow_block_one_launch_vs_reference(nfa, name, seed, C, smap, leaky, B, H, W):
+    """nf_glow_block (coupling + conditioner + [1x1 conv, ActNorm] in one launch, both directions) against the
+    reference's GlowBlock outputs and against the layer-by-layer path; seeded default weights on both sides."""
+    g = load_golden(name)
+    torch.manual_seed(seed)
+    blk = nfa.flows.GlowBlock(C, 256, scale_map=smap, leaky=leaky, init_zeros=False)
+    with torch.no_grad():
+        blk.flows[0].flows[1].param_map.net[-1].weight.mul_(0.2)
+    blk = blk.to(DEV)
+    x = T(g["x"])
+    cls = nfa.nets.ConvNet2d
+    saved = cls.FUSED_MIN_PIXELS, cls.FUSED_WIDE_MIN_PIXELS
+    with torch.no_grad():
+        try:
+            cls.FUSED_MIN_PIXELS = 1 << 40                       # layer by layer (library convolutions)
+            blk.inverse(x)                                       # ActNorm's data-dependent initialisation
+            chk = np.array([float(p_.double().abs().sum()) for p_ in blk.parameters()])
+            np.testing.assert_allclose(chk, g["checksum"], rtol=1e-5)
+            zi0, ldi0 = blk.inverse(x)
+            zf0, ldf0 = blk.forward(x)
+            cls.FUSED_MIN_PIXELS, cls.FUSED_WIDE_MIN_PIXELS = 0, 0
+            assert blk._whole_block(x) is not None
+            zi, ldi = blk.inverse(x)
+            zf, ldf = blk.forward(x)
+            acc = torch.ones(B, device=DEV)
+            blk._run(x, True, acc, nfa.ops.L.LD_SUB)
+        finally:
+            cls.FUSED_MIN_PIXELS, cls.FUSED_WIDE_MIN_PIXELS = saved
+    for got, ref, what in ((zi, g["z_inv"], "z_inv"), (ldi, g["ld_inv"], "ld_inv"), (zf, g["z_fwd"], "z_fwd"),
+                           (ldf, g["ld_fwd"], "ld_fwd")):
+        assert_close(N(got), ref, what=what, rtol=2e-4, atol=2e-3 if what.startswith("ld") else 2e-4)
+    assert_close(N(zi), N(zi0), what="z_inv vs layers", rtol=1e-4, atol=1e-4)
+    assert_close(N(ldi), N(ldi0), what="ld_inv vs layers", rtol=1e-4, atol=1e-3)
+    assert_close(N(zf), N(zf0), what="z_fwd vs layers", rtol=1e-4, atol=1e-4)
+    assert_close(N(ldf), N(ldf0), what="ld_fwd vs layers", rtol=1e-4, atol=1e-3)
+    assert_close(N(acc), 1.0 - N(ldi), what="acc", rtol=1e-5, atol=1e-4)
+
+
 def test_diag_gaussian_and_squeeze(nfa):
     g = load_golden("diag_gaussian")
     q = nfa.distributions.DiagGaussian((3, 2, 2)).to(DEV)
