@@ -386,8 +386,10 @@ int nf_arnsf_inverse(const void *z, void *y, void *logdet, const void *blob, con
  * Conv2d(256, 256, 1) -> LeakyReLU(slope) -> Conv2d(256, Cout, 3, padding 1), all with bias, float32.
  *   nf_glow_convnet_layout    : which of the two kernels fits a call: NF_GLOW_CONV_WIDE (256-pixel workgroups, waves of
  *                               32 pixels; needs H W | 256 and pays from ~128 workgroups on) or NF_GLOW_CONV_SMALL
- *                               (64-pixel workgroups, waves of 16 pixels; H W | 64, <= 48 output channels); a negative
- *                               code when neither applies.  The packed weights are specific to the layout.
+ *                               (64-pixel workgroups, waves of 16 pixels; H W | 64, <= 48 output channels) or
+ *                               NF_GLOW_CONV_TINY (16-pixel workgroups whose four waves split the rows of every GEMM;
+ *                               H W | 16, for batches too small to fill the chip otherwise); a negative code when none
+ *                               applies.  The packed weights are specific to the layout.
  *   nf_glow_convnet_pack_size : bytes of the packed weights (negative error code for an unsupported shape).
  *   nf_glow_convnet_pack      : w1 (256, Cin, 3, 3), b1 (256), w2 (256, 256[, 1, 1]), b2 (256), w3 (Cout, 256, 3, 3),
  *                               b3 (Cout), all contiguous -> wpack (MFMA operand order; repack after a weight update).
@@ -397,7 +399,7 @@ int nf_arnsf_inverse(const void *z, void *y, void *logdet, const void *blob, con
  * A workgroup processes whole images (the 3x3 zero padding is the image border): H W must divide the workgroup's pixel
  * count (NF_ENOTSUP otherwise; callers fall back to library convolutions).  hidden must be 256.
  */
-enum { NF_GLOW_CONV_WIDE = 0, NF_GLOW_CONV_SMALL = 1 };
+enum { NF_GLOW_CONV_WIDE = 0, NF_GLOW_CONV_SMALL = 1, NF_GLOW_CONV_TINY = 2 };
 int nf_glow_convnet_layout(int64_t B, int H, int W);
 int64_t nf_glow_convnet_pack_size(int Cin, int Cout, int hidden);
 int nf_glow_convnet_pack(void *wpack, const void *w1, const void *b1, const void *w2, const void *b2, const void *w3,

@@ -626,6 +626,201 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
     if (fu.on) gb_epilogue<GS_PX, 64 * GS_NW>(fu, out, zr, zm, prm, ldt, H, W, img0, B, tid);
 }
 
+// ---- tiny images (H W | 16): one 16-pixel tile per workgroup, the four waves split the ROWS of every GEMM ---------------
+// Config 4's last level has 4096 pixels: pixel-parallel waves leave most SIMDs idle (64 workgroups of the kernel above),
+// and a wave's chain of ~4000 dependent-issue MFMAs is the run time.  Here a workgroup owns ONE tile of 16 pixels (whole
+// images again) and wave w computes rows [64 w, 64 w + 64) of h1 and h2 and a quarter of the output rows, for all 16
+// pixels.  Activations go through LDS in B-operand order acts[k / 16][(k / 4) % 4][pixel][k % 4] (one ds_read_b128 per
+// lane = the 4 B values of a 16-k block; one ds_write_b128 per lane stores a finished 16-row block), with a barrier
+// between the GEMMs.  Every wave streams only ITS rows' weights through a private 4-slot ring of 4 KB (no barrier in
+// the streaming loops).  256 workgroups x 4 waves fill every SIMD; each workgroup streams all weights once, so the
+// kernel is bound by the L2 -> LDS stream (0.93 MB per workgroup at the 4x4 level), not by MFMA issue.
+constexpr int GT_PX = 16;
+constexpr int GT_NW = 4;
+constexpr int GT_RING = 4;         // slots per wave
+constexpr int GT_SLOT = 1024;      // floats per slot: 4 units of [64 lanes][4] = 16 rows x 64 k
+
+struct GtMeta {
+    int nkb1;    // 16-k blocks of GEMM 1, padded to a multiple of 4 (a slot = 4 blocks)
+    int NB3;     // 16-row output blocks per wave = ceil(2 OB / 4)
+    int slots;   // slots per wave = nkb1 + 16 + 4 NB3
+};
+__host__ __device__ inline GtMeta gt_meta(const GcMeta &m) {
+    GtMeta t;
+    t.nkb1 = 4 * ((m.K1 + 63) / 64);
+    t.NB3 = (2 * m.OB + 3) / 4;
+    t.slots = t.nkb1 + 16 + 4 * t.NB3;
+    return t;
+}
+__host__ __device__ inline int64_t gt_total_floats(const GcMeta &m) {
+    return (int64_t)gc_off_stages(m) + (int64_t)GT_NW * gt_meta(m).slots * GT_SLOT;
+}
+
+// blob: header | biases (natural order) | wave 0's slots | wave 1's | wave 2's | wave 3's, each in consumption order:
+// GEMM 1 (own 4 row blocks x nkb1), GEMM 2 (own 4 x 16), GEMM 3 (own NB3 x 16); unit (16 rows x 16 k): lane (i = lane & 15,
+// g = lane >> 4) holds W[row i][16 kb + 4 g + r4].
+__global__ void gt_pack_kernel(const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W2,
+                               const float *__restrict__ b2, const float *__restrict__ W3, const float *__restrict__ b3,
+                               float *__restrict__ blob, GcMeta m, GtMeta t, int64_t total) {
+    const int offs = gc_off_stages(m);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = 0.0f;
+        if (i < GC_HDR) {
+            v = i == 0 ? 357.0f : (i == 1 ? (float)m.Cin : (i == 2 ? (float)m.Cout : 0.0f));
+        } else if (i < offs) {
+            const int j = (int)i - GC_HDR;
+            if (j < GC_HID) v = b1[j];
+            else if (j < 2 * GC_HID) v = b2[j - GC_HID];
+            else if (j - 2 * GC_HID < m.Cout) v = b3[j - 2 * GC_HID];
+        } else {
+            const int64_t e = i - offs;
+            const int w = (int)(e / ((int64_t)t.slots * GT_SLOT));
+            const int q0 = (int)(e % ((int64_t)t.slots * GT_SLOT));
+            const int r4 = q0 & 3, lane = (q0 >> 2) & 63, ri = lane & 15, g = lane >> 4;
+            int q = q0 >> 8;   // unit index in the wave's stream
+            if (q < 4 * t.nkb1) {
+                const int bl = q / t.nkb1, kb = q - bl * t.nkb1;
+                const int k = 16 * kb + 4 * g + r4;
+                if (k < m.K1) v = W1[(size_t)(64 * w + 16 * bl + ri) * m.K1 + k];
+            } else if ((q -= 4 * t.nkb1) < 64) {
+                const int bl = q >> 4, kb = q & 15;
+                v = W2[(size_t)(64 * w + 16 * bl + ri) * GC_HID + 16 * kb + 4 * g + r4];
+            } else {
+                q -= 64;
+                const int ol = q >> 4, kb = q & 15;
+                const int o16 = w * t.NB3 + ol, blk = o16 >> 1, rho = 16 * (o16 & 1) + ri;
+                const int cc = rho / 9, tap = rho - 9 * cc, co = 3 * blk + cc;
+                if (rho < 27 && co < m.Cout) v = W3[((size_t)co * GC_HID + 16 * kb + 4 * g + r4) * 9 + tap];
+            }
+        }
+        blob[i] = v;
+    }
+}
+
+__global__ void __launch_bounds__(64 * GT_NW)
+glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__restrict__ out, const float *__restrict__ blob,
+                         GcMeta mt, GtMeta tm, int64_t B, int H, int W, GbFuse fu) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int HW = H * W, PH = H + 2, PW = W + 2, IPW = GT_PX / HW;
+    const int K1p = 16 * tm.nkb1;
+    const int p_floats = GT_NW * tm.NB3 * 16 * GT_PX, a_floats = K1p * GT_PX + GC_HID * GT_PX;
+    float *ring = smem;                                     // 4 waves x 4 slots x 4 KB
+    float *cols = ring + GT_NW * GT_RING * GT_SLOT;         // im2col columns in B-operand order (K1p x 16)
+    float *h1s = cols + K1p * GT_PX;                        // h1 in B-operand order (256 x 16)
+    float *P = cols;                                        // tap products: reuse cols + h1s once GEMM 2 is done
+    float *h2s = cols + (p_floats > a_floats ? p_floats : a_floats);
+    float *small = h2s + GC_HID * GT_PX;
+    int *koff = reinterpret_cast<int *>(small + gc_small_padded(mt));
+    float *xin = reinterpret_cast<float *>(koff + K1p);
+    float *zr = xin + IPW * mt.Cin * PH * PW;
+    float *zm = zr + fu.C * GT_PX, *prm = zm + fu.C * GT_PX, *ldt = prm + mt.Cout * GT_PX;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, j16 = lane & 15;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t img0 = (int64_t)blockIdx.x * IPW;
+
+    // ---- prologue (shared): biases, im2col offsets, padded images, im2col columns ----
+    for (int i = tid; i < mt.small; i += 64 * GT_NW) small[i] = blob[GC_HDR + i];
+    for (int k = tid; k < K1p; k += 64 * GT_NW) {
+        const int kk = k < mt.K1 ? k : mt.K1 - 1;
+        const int c = kk / 9, t = kk - 9 * c, ky = t / 3;
+        koff[k] = c * PH * PW + ky * PW + (t - 3 * ky);
+    }
+    if (fu.on) gb_prologue<GT_PX, 64 * GT_NW>(fu, x, out, zr, zm, xin, H, W, img0, B, tid);
+    else gc_fill_xin_global<GT_PX, 64 * GT_NW>(x, xs_img, xin, mt.Cin, H, W, img0, B, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the private rings' in-order accounting starts from an empty queue
+    // the wave's weight stream
+    const float *stream = blob + gc_off_stages(mt) + (size_t)wid * tm.slots * GT_SLOT + lane * 4;
+    float *ringw = ring + wid * GT_RING * GT_SLOT;
+    int slot = 0;
+    auto issue = [&](int s) {
+        const float *src = stream + (size_t)s * GT_SLOT;
+        float *dst = ringw + (s % GT_RING) * GT_SLOT;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            __builtin_amdgcn_global_load_lds(src + u * 256, (__attribute__((address_space(3))) void *)(dst + u * 256), 16, 0, 0);
+    };
+    auto acquire = [&]() -> const float * {
+        if (slot + GT_RING - 2 < tm.slots) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (GT_RING - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (slot + GT_RING - 1 < tm.slots) issue(slot + GT_RING - 1);   // into the slot read one step ago (data already in VGPRs)
+        const float *buf = ringw + (slot % GT_RING) * GT_SLOT + lane * 4;
+        ++slot;
+        return buf;
+    };
+    issue(0); issue(1); issue(2);
+    __syncthreads();
+    for (int i = tid; i < K1p * GT_PX; i += 64 * GT_NW) {
+        // element (kb, g', px, r) of the column block: k = 16 kb + 4 g' + r
+        const int r = i & 3, px = (i >> 2) & 15, gg = (i >> 6) & 3, kb = i >> 8;
+        const int li = px / HW, pin = px - li * HW, py = pin / W, pxx = pin - py * W;
+        cols[i] = xin[li * mt.Cin * PH * PW + py * PW + pxx + koff[16 * kb + 4 * gg + r]];
+    }
+    __syncthreads();
+
+    // acc (16 rows x 16 pixels) = sum over nkb 16-k blocks of A (the stream) x B (LDS, B-operand order); two accumulators
+    // alternate so that consecutive MFMAs are independent
+    auto gemm_block = [&](const float *bsrc, int nkb, f32x4 &acc) {
+        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int kb4 = 0; kb4 < nkb; kb4 += 4) {
+            const float *buf = acquire();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(buf + u * 256);
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(bsrc + (((kb4 + u) * 4 + g) * GT_PX + j16) * 4);
+                if (u & 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc1 = GC_MFMA16(a[r], b[r], acc1);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = GC_MFMA16(a[r], b[r], acc);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += acc1[r];
+    };
+
+    // ---- GEMM 1 -> h1s ----
+    for (int bl = 0; bl < 4; ++bl) {
+        const int b16 = 4 * wid + bl;
+        f32x4 acc = *reinterpret_cast<const f32x4 *>(small + 16 * b16 + 4 * g);
+        gemm_block(cols, tm.nkb1, acc);
+        gs_leaky(acc, mt.slope);
+        *reinterpret_cast<f32x4 *>(h1s + ((b16 * 4 + g) * GT_PX + j16) * 4) = acc;
+    }
+    __syncthreads();
+    // ---- GEMM 2 -> h2s ----
+    for (int bl = 0; bl < 4; ++bl) {
+        const int b16 = 4 * wid + bl;
+        f32x4 acc = *reinterpret_cast<const f32x4 *>(small + GC_HID + 16 * b16 + 4 * g);
+        gemm_block(h1s, 16, acc);
+        gs_leaky(acc, mt.slope);
+        *reinterpret_cast<f32x4 *>(h2s + ((b16 * 4 + g) * GT_PX + j16) * 4) = acc;
+    }
+    __syncthreads();   // h2 complete; cols / h1s are dead: P may overwrite them
+    // ---- GEMM 3 -> tap products ----
+    for (int ol = 0; ol < tm.NB3; ++ol) {
+        const int o16 = wid * tm.NB3 + ol;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        gemm_block(h2s, 16, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[(16 * o16 + 4 * g + r) * GT_PX + j16] = acc[r];
+    }
+    __syncthreads();
+    // ---- col2im over all output blocks ----
+    for (int blk = 0; blk < mt.OB; ++blk)
+        gc_gather_block<GT_PX, 64 * GT_NW>(P + blk * 32 * GT_PX, blk, mt, H, W, img0, B, small, out, fu.on ? prm : nullptr, tid);
+    if (fu.on) gb_epilogue<GT_PX, 64 * GT_NW>(fu, out, zr, zm, prm, ldt, H, W, img0, B, tid);
+}
+
+static inline size_t gt_lds_bytes(const GcMeta &m, const GtMeta &t, int H, int W, const GbFuse &fu) {
+    const int IPW = GT_PX / (H * W), K1p = 16 * t.nkb1;
+    const int p_floats = GT_NW * t.NB3 * 16 * GT_PX, a_floats = K1p * GT_PX + GC_HID * GT_PX;
+    return ((size_t)GT_NW * GT_RING * GT_SLOT + (p_floats > a_floats ? p_floats : a_floats) + GC_HID * GT_PX +
+            gc_small_padded(m) + K1p + (size_t)IPW * m.Cin * (H + 2) * (W + 2) + gb_lds_floats(fu, m.Cout, GT_PX)) *
+               sizeof(float) + 16;
+}
+
 static inline size_t gs_lds_bytes(const GcMeta &m, int H, int W, const GbFuse &fu) {
     const int IPW = GS_PX / (H * W);
     return ((size_t)GS_RING * GC_STAGE + 32 * GS_PX + gc_small_padded(m) + 16 * ((m.K1 + 15) / 16) +
@@ -653,7 +848,8 @@ extern "C" int64_t nf_glow_convnet_pack_size(int Cin, int Cout, int hidden) {
     const int rc = gc_check(Cin, Cout, hidden, 0.0);
     if (rc) return rc;
     const GcMeta m = gc_meta(Cin, Cout, 0.0);
-    return ((int64_t)gc_off_stages(m) + (int64_t)gc_nstages_blob(m) * GC_STAGE) * (int64_t)sizeof(float);
+    const int64_t a = (int64_t)gc_off_stages(m) + (int64_t)gc_nstages_blob(m) * GC_STAGE, b = gt_total_floats(m);
+    return (a > b ? a : b) * (int64_t)sizeof(float);   // one size for every layout
 }
 
 extern "C" int nf_glow_convnet_pack(void *wpack, const void *w1, const void *b1, const void *w2, const void *b2,
@@ -661,9 +857,17 @@ extern "C" int nf_glow_convnet_pack(void *wpack, const void *w1, const void *b1,
                                     nf_stream_t stream) {
     const int rc = gc_check(Cin, Cout, hidden, 0.0);
     if (rc) return rc;
-    if (layout != NF_GLOW_CONV_WIDE && layout != NF_GLOW_CONV_SMALL) return NF_EINVAL;
+    if (layout < NF_GLOW_CONV_WIDE || layout > NF_GLOW_CONV_TINY) return NF_EINVAL;
     if (!wpack || !w1 || !b1 || !w2 || !b2 || !w3 || !b3) return NF_EFAULT;
     const GcMeta m = gc_meta(Cin, Cout, 0.0);
+    if (layout == NF_GLOW_CONV_TINY) {
+        const int64_t tot = gt_total_floats(m);
+        hipLaunchKernelGGL(gt_pack_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, (const float *)w1, (const float *)b1,
+                           (const float *)w2, (const float *)b2, (const float *)w3, (const float *)b3, (float *)wpack, m,
+                           gt_meta(m), tot);
+        NF_CHECK_LAUNCH();
+        return NF_OK;
+    }
     const int64_t total = (int64_t)gc_off_stages(m) + (int64_t)gc_nstages_blob(m) * GC_STAGE;
     hipLaunchKernelGGL(gc_pack_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, (const float *)w1, (const float *)b1,
                        (const float *)w2, (const float *)b2, (const float *)w3, (const float *)b3, (float *)wpack, m, total,
@@ -676,6 +880,7 @@ extern "C" int nf_glow_convnet_layout(int64_t B, int H, int W) {
     if (B < 0 || H < 1 || W < 1) return NF_EINVAL;
     const int64_t HW = (int64_t)H * W;
     if (HW <= GC_PX && GC_PX % HW == 0 && B * HW >= (int64_t)128 * GC_PX) return NF_GLOW_CONV_WIDE;   // >= 128 workgroups
+    if (HW <= GT_PX && GT_PX % HW == 0 && B * HW < (int64_t)256 * GS_PX) return NF_GLOW_CONV_TINY;    // < 256 64-pixel workgroups
     if (HW <= GS_PX && GS_PX % HW == 0) return NF_GLOW_CONV_SMALL;
     if (HW <= GC_PX && GC_PX % HW == 0) return NF_GLOW_CONV_WIDE;
     return NF_ENOTSUP;
@@ -699,8 +904,22 @@ static int launch_small(const void *x, int64_t xs, void *out, const void *wpack,
 
 static int gc_launch(const void *x, int64_t xs, void *out, const void *wpack, const GcMeta &m, int64_t B, int H, int W,
                      int layout, const GbFuse &fu, hipStream_t st) {
-    const int PXW = layout == NF_GLOW_CONV_WIDE ? GC_PX : GS_PX;
+    const int PXW = layout == NF_GLOW_CONV_WIDE ? GC_PX : (layout == NF_GLOW_CONV_SMALL ? GS_PX : GT_PX);
     if (H * W > PXW || PXW % (H * W) != 0) return NF_ENOTSUP;   // whole images per workgroup
+    if (layout == NF_GLOW_CONV_TINY) {
+        const GtMeta t = gt_meta(m);
+        const size_t lds = gt_lds_bytes(m, t, H, W, fu);
+        if (lds > 160 * 1024) return NF_ENOTSUP;
+        static LdsOptIn opted = {};
+        if (opt_in_lds(reinterpret_cast<const void *>(&glow_convnet_tiny_kernel), lds, opted) != NF_OK) return NF_ENOTSUP;
+        const int IPW = GT_PX / (H * W);
+        const int64_t grid = (B + IPW - 1) / IPW;
+        if (grid > 0x7fffffff) return NF_ERANGE;
+        hipLaunchKernelGGL(glow_convnet_tiny_kernel, dim3((unsigned)grid), dim3(64 * GT_NW), lds, st, (const float *)x, xs,
+                           (float *)out, (const float *)wpack, m, t, B, H, W, fu);
+        NF_CHECK_LAUNCH();
+        return NF_OK;
+    }
     if (layout == NF_GLOW_CONV_SMALL) {
         if (m.OB <= 4) return launch_small<4>(x, xs, out, wpack, m, B, H, W, fu, st);
         if (m.OB <= 8) return launch_small<8>(x, xs, out, wpack, m, B, H, W, fu, st);
@@ -724,7 +943,7 @@ extern "C" int nf_glow_convnet(const void *x, int64_t x_image_stride, void *out,
                                int H, int W, int Cout, int hidden, double leaky_slope, int layout, nf_stream_t stream) {
     const int rc = gc_check(Cin, Cout, hidden, leaky_slope);
     if (rc) return rc;
-    if (layout != NF_GLOW_CONV_WIDE && layout != NF_GLOW_CONV_SMALL) return NF_EINVAL;
+    if (layout < NF_GLOW_CONV_WIDE || layout > NF_GLOW_CONV_TINY) return NF_EINVAL;
     if (B < 0 || H < 1 || W < 1 || x_image_stride < (int64_t)Cin * H * W) return NF_EINVAL;
     if (B == 0) return NF_OK;
     if (!x || !out || !wpack) return NF_EFAULT;
@@ -739,7 +958,7 @@ extern "C" int nf_glow_block(const void *z, void *y, void *logdet, const void *w
     const int c1 = (C + 1) / 2, Cout = 2 * (C - c1);
     const int rc = gc_check(c1, Cout, hidden, leaky_slope);
     if (rc) return rc;
-    if (layout != NF_GLOW_CONV_WIDE && layout != NF_GLOW_CONV_SMALL) return NF_EINVAL;
+    if (layout < NF_GLOW_CONV_WIDE || layout > NF_GLOW_CONV_TINY) return NF_EINVAL;
     if (scale_map < NF_SCALE_EXP || scale_map > NF_SCALE_SIGMOID_INV) return NF_EINVAL;
     if ((direction != 0 && direction != 1) || acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
     if (B < 0 || H < 1 || W < 1) return NF_EINVAL;

@@ -91,9 +91,15 @@ class GlowBlock(Flow):
                 whole = self._whole_block(z)
                 if whole is not None:   # coupling + conditioner + mix: one launch (csrc/glow_conv.hip, nf_glow_block)
                     blob, layout, slope, smap = whole
-                    y, _ = ops.glow_block(z, blob, layout, Wp, bp, ldp, slope, smap, 1 if inverse else 0, logdet=ld,
-                                          acc=acc)
-                    return y
+                    refused = self.__dict__.setdefault("_whole_refused", set())
+                    key = (layout, tuple(z.shape[1:]))
+                    if key not in refused:
+                        try:
+                            y, _ = ops.glow_block(z, blob, layout, Wp, bp, ldp, slope, smap, 1 if inverse else 0,
+                                                  logdet=ld, acc=acc)
+                            return y
+                        except NotImplementedError:   # the block's working set does not fit one workgroup's LDS:
+                            refused.add(key)          # nothing was launched; keep the layer-by-layer path for this shape
                 if inverse:
                     z, _ = ops.inv1x1_conv(z, Wp, ldp, logdet=ld, acc=acc, want_scalar=False, bias=bp)
                     return run_flow(self.flows[0], z, True, ld, acc)

@@ -478,11 +478,11 @@ def arnsf_inverse(z, blob, table, hidden_padded, K, tails, tail_bound, min_bin_w
     return y, logdet
 
 
-GLOW_CONV_WIDE, GLOW_CONV_SMALL = 0, 1
+GLOW_CONV_WIDE, GLOW_CONV_SMALL, GLOW_CONV_TINY = 0, 1, 2
 
 
 def glow_convnet_layout(B, H, W):
-    """Which nf_glow_convnet kernel takes (B, *, H, W) inputs: GLOW_CONV_WIDE, GLOW_CONV_SMALL or None."""
+    """Which nf_glow_convnet kernel takes (B, *, H, W) inputs: GLOW_CONV_WIDE, _SMALL, _TINY or None."""
     code = L.lib().nf_glow_convnet_layout(i64(B), i32(H), i32(W))
     return code if code >= 0 else None
 

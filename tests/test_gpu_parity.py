@@ -309,8 +309,8 @@ def test_glow_convnet_kernel_vs_reference(nfa, name, seed, cin, cout, leaky, B, 
     wide = torch.randn(B, cin + 3, H, W, device=DEV)
     wide[:, 2:2 + cin] = x
     outs = []
-    for layout in (nfa.ops.GLOW_CONV_WIDE, nfa.ops.GLOW_CONV_SMALL):   # 256-pixel / 64-pixel workgroups
-        if layout == nfa.ops.GLOW_CONV_SMALL and 64 % (H * W) != 0:
+    for layout in (nfa.ops.GLOW_CONV_WIDE, nfa.ops.GLOW_CONV_SMALL, nfa.ops.GLOW_CONV_TINY):   # 256 / 64 / 16-pixel workgroups
+        if (layout == nfa.ops.GLOW_CONV_SMALL and 64 % (H * W) != 0) or (layout == nfa.ops.GLOW_CONV_TINY and 16 % (H * W) != 0):
             continue
         blob = nfa.ops.glow_convnet_pack(*prm, layout=layout)
         out = nfa.ops.glow_convnet(x, blob, cout, leaky, layout)
@@ -326,7 +326,8 @@ def test_glow_convnet_kernel_vs_reference(nfa, name, seed, cin, cout, leaky, B, 
         try:
             fused = net._fused_pack(x)
             if H * W <= 64:
-                assert fused is not None and fused[1] == nfa.ops.GLOW_CONV_SMALL and net.forward_split(x) is None
+                want = nfa.ops.GLOW_CONV_TINY if 16 % (H * W) == 0 else nfa.ops.GLOW_CONV_SMALL
+                assert fused is not None and fused[1] == want and net.forward_split(x) is None
                 assert torch.equal(net(x), outs[-1])
             else:
                 assert fused is None      # 16x16 images: the wide kernel waits for >= 128 workgroups
@@ -364,6 +365,23 @@ def test_glow_block_one_launch_vs_reference(nfa, name, seed, C, smap, leaky, B, 
             zf, ldf = blk.forward(x)
             acc = torch.ones(B, device=DEV)
             blk._run(x, True, acc, nfa.ops.L.LD_SUB)
+            # every kernel that takes this image size, called directly
+            net = blk.flows[0].flows[1].param_map
+            prm = [p_.detach() for p_ in (net.net[0].weight, net.net[0].bias, net.net[2].weight, net.net[2].bias,
+                                          net.net[4].weight, net.net[4].bias)]
+            for layout, pxw in ((nfa.ops.GLOW_CONV_WIDE, 256), (nfa.ops.GLOW_CONV_SMALL, 64), (nfa.ops.GLOW_CONV_TINY, 16)):
+                if pxw % (H * W) != 0:
+                    continue
+                blob = nfa.ops.glow_convnet_pack(*prm, layout=layout)
+                for inverse, zr_, ldr_ in ((True, zi0, ldi0), (False, zf0, ldf0)):
+                    Wp, bp, ldp = blk._fused_mix(inverse)
+                    try:
+                        y_, ld_ = nfa.ops.glow_block(x, blob, layout, Wp, bp, ldp, leaky, smap, 1 if inverse else 0)
+                    except NotImplementedError:      # many channels at 256 pixels per workgroup: beyond the LDS
+                        assert layout == nfa.ops.GLOW_CONV_WIDE and C >= 24
+                        continue
+                    assert_close(N(y_), N(zr_), what="layout %d dir %d z" % (layout, inverse), rtol=1e-4, atol=1e-4)
+                    assert_close(N(ld_), N(ldr_), what="layout %d dir %d ld" % (layout, inverse), rtol=1e-4, atol=1e-3)
         finally:
             cls.FUSED_MIN_PIXELS, cls.FUSED_WIDE_MIN_PIXELS = saved
     for got, ref, what in ((zi, g["z_inv"], "z_inv"), (ldi, g["ld_inv"], "ld_inv"), (zf, g["z_fwd"], "z_fwd"),
