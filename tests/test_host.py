@@ -88,13 +88,14 @@ def test_c_abi_argument_validation_newer_entry_points(nfa):
     lib.nf_glow_convnet_pack_size.restype = ctypes.c_int64
     assert lib.nf_glow_convnet_layout(i64(256), i32(16), i32(16)) == 0      # 256 workgroups of 256 pixels
     assert lib.nf_glow_convnet_layout(i64(256), i32(8), i32(8)) == 1        # 64 such workgroups: the 64-pixel kernel
+    assert lib.nf_glow_convnet_layout(i64(256), i32(4), i32(4)) == 2        # 4096 pixels: 16-pixel row-split workgroups
     assert lib.nf_glow_convnet_layout(i64(4), i32(16), i32(16)) == 0 and lib.nf_glow_convnet_layout(i64(4), i32(5), i32(5)) == -95
     assert lib.nf_glow_convnet_pack_size(i32(6), i32(12), i32(256)) == 4 * (64 + 576 + (8 + 16 + 8) * 4096)
     assert lib.nf_glow_convnet_pack_size(i32(6), i32(12), i32(128)) == -95
     gc = lambda B, H, W, layout, slope=0.0, x=one: lib.nf_glow_convnet(x, i64(6 * H * W), one, one, i64(B), i32(6), i32(H),
                                                                      i32(W), i32(12), i32(256), f64(slope), i32(layout), null)
     assert gc(4, 16, 16, 1) == -95 and gc(4, 5, 5, 0) == -95                 # whole images must tile the workgroup
-    assert gc(4, 16, 16, 2) == -22 and gc(4, 16, 16, 0, slope=1.5) == -22
+    assert gc(4, 16, 16, 3) == -22 and gc(4, 16, 16, 2) == -95 and gc(4, 16, 16, 0, slope=1.5) == -22
     assert gc(4, 16, 16, 0, x=null) == -14 and gc(0, 16, 16, 0) == 0
     gb = lambda C, smap, direction: lib.nf_glow_block(one, one, one, one, one, one, one, i64(0), i32(C), i32(8), i32(8), i32(256),
                                                       f64(0.0), i32(smap), i32(direction), i32(0), i32(1), null)
