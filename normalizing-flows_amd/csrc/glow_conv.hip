@@ -1,6 +1,10 @@
 // glow_conv.hip -- the conditioner of a GlowBlock, ConvNet2d([Cin, 256, 256, Cout], kernel sizes (3, 1, 3)) =
 // conv3x3 -> LeakyReLU -> conv1x1 -> LeakyReLU -> conv3x3 (normflows/nets/cnn.py:5-63 as built by
-// normflows/flows/affine/glow.py:41-62), as ONE kernel on exact-fp32 MFMA for gfx950.
+// normflows/flows/affine/glow.py:41-62), as ONE kernel on exact-fp32 MFMA for gfx950 -- optionally with the rest of the
+// GlowBlock (1x1 convolution + ActNorm, affine coupling) in the same launch (nf_glow_block, GbFuse below).
+// Three kernels share the decomposition and differ in how the pixels and rows are spread over waves: glow_convnet_kernel
+// (256-pixel workgroups, described first), glow_convnet_small_kernel (64 pixels) and glow_convnet_tiny_kernel (16 pixels,
+// rows split across the waves); nf_glow_convnet_layout picks one per call.
 //
 // A workgroup owns 256 pixels = 256 / (H W) WHOLE images (H W must divide 256: 16x16, 8x8, 4x4 ...), so the two 3x3
 // convolutions never need pixels of another workgroup and the zero padding of cnn.py:33 is the image border itself.
