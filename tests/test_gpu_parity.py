@@ -394,6 +394,54 @@ def test_glow_block_one_launch_vs_reference(nfa, name, seed, C, smap, leaky, B, 
     assert_close(N(acc), 1.0 - N(ldi), what="acc", rtol=1e-5, atol=1e-4)
 
 
+def test_glow_config4_shapes_through_the_block_kernels(nfa):
+    """BASELINE configs[4] geometry (L = 3, hidden 256, 32x32x3, batch 256; 3 blocks per level instead of 32): the three
+    levels run through the three GlowBlock kernels (256- / 64- / 16-pixel workgroups).  Size-independent properties at the
+    full batch: log_prob through the block kernels == log_prob layer by layer, and sample()'s log_q == log_prob(sample)
+    (core_test.py:144-196)."""
+    torch.manual_seed(5)
+    L_, K_, hidden, channels = 3, 3, 256, 3
+    input_shape = (3, 32, 32)
+    q0, merges, flows = [], [], []
+    for i in range(L_):
+        fl = [nfa.flows.GlowBlock(channels * 2 ** (L_ + 1 - i), hidden, split_mode="channel", scale=True, init_zeros=False)
+              for _ in range(K_)]
+        for b in fl:
+            with torch.no_grad():
+                b.flows[0].flows[1].param_map.net[-1].weight.mul_(0.1)
+        fl += [nfa.flows.Squeeze()]
+        flows += [fl]
+        if i > 0:
+            merges += [nfa.flows.Merge()]
+            latent = (input_shape[0] * 2 ** (L_ - i), input_shape[1] // 2 ** (L_ - i), input_shape[2] // 2 ** (L_ - i))
+        else:
+            latent = (input_shape[0] * 2 ** (L_ + 1), input_shape[1] // 2 ** L_, input_shape[2] // 2 ** L_)
+        q0 += [nfa.distributions.DiagGaussian(latent)]
+    m = nfa.MultiscaleFlow(q0, flows, merges, class_cond=False).to(DEV)
+    x = torch.rand(256, 3, 32, 32, device=DEV)
+    cls = nfa.nets.ConvNet2d
+    saved = cls.FUSED_MIN_PIXELS
+    with torch.no_grad():
+        m.log_prob(x)                                   # ActNorm initialisation
+        layouts = set()
+        for lvl, shape in enumerate(((256, 48, 4, 4), (256, 24, 8, 8), (256, 12, 16, 16))):
+            w = flows[lvl][0]._whole_block(torch.empty(shape, device=DEV))
+            assert w is not None
+            layouts.add(w[1])
+        assert layouts == {nfa.ops.GLOW_CONV_WIDE, nfa.ops.GLOW_CONV_SMALL, nfa.ops.GLOW_CONV_TINY}
+        lp = m.log_prob(x)
+        torch.manual_seed(1)
+        xs, lq = m.sample(256)
+        lps = m.log_prob(xs)
+        try:
+            cls.FUSED_MIN_PIXELS = 1 << 40
+            lp_layers = m.log_prob(x)
+        finally:
+            cls.FUSED_MIN_PIXELS = saved
+    assert _rel(N(lp), N(lp_layers)) < 1e-5, _rel(N(lp), N(lp_layers))
+    assert _rel(N(lps), N(lq)) < 1e-4, _rel(N(lps), N(lq))
+
+
 def test_diag_gaussian_and_squeeze(nfa):
     g = load_golden("diag_gaussian")
     q = nfa.distributions.DiagGaussian((3, 2, 2)).to(DEV)
