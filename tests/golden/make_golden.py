@@ -772,6 +772,43 @@ def gen_glow_block256():
         npz(name, x=x, z_inv=zi2, ld_inv=ldi2, z_fwd=zf, ld_fwd=ldf, checksum=chk)
 
 
+def build_glow_c4(nfmod, L_, K_, hidden, seed, scale_last=0.1):
+    """BASELINE configs[4] architecture (examples/glow.ipynb cell 2) with a seeded default construction; the conditioners'
+    last layers (zero-initialised in the notebook) get the default init scaled down so that the couplings are not
+    trivial.  Works for the reference (`nfmod` = normflows) and for our package alike."""
+    torch.manual_seed(seed)
+    input_shape, channels = (3, 32, 32), 3
+    q0, merges, flows = [], [], []
+    for i in range(L_):
+        fl = [nfmod.flows.GlowBlock(channels * 2 ** (L_ + 1 - i), hidden, split_mode="channel", scale=True, init_zeros=False)
+              for _ in range(K_)]
+        with torch.no_grad():
+            for b in fl:
+                b.flows[0].flows[1].param_map.net[-1].weight.mul_(scale_last)
+        fl += [nfmod.flows.Squeeze()]
+        flows += [fl]
+        if i > 0:
+            merges += [nfmod.flows.Merge()]
+            latent = (input_shape[0] * 2 ** (L_ - i), input_shape[1] // 2 ** (L_ - i), input_shape[2] // 2 ** (L_ - i))
+        else:
+            latent = (input_shape[0] * 2 ** (L_ + 1), input_shape[1] // 2 ** L_, input_shape[2] // 2 ** L_)
+        q0 += [nfmod.distributions.DiagGaussian(latent)]
+    return nfmod.MultiscaleFlow(q0, flows, merges, class_cond=False)
+
+
+def gen_glow_model256():
+    """The config-4 model at its real width (L = 3, hidden 256, 32x32x3) with 2 blocks per level: log_prob of 12 images
+    (after the data-dependent ActNorm initialisation on the same batch).  Only inputs / outputs / a weight checksum are
+    stored; both sides construct the weights from the seed."""
+    m = build_glow_c4(nf, 3, 2, 256, seed=61)
+    x = torch.rand(12, 3, 32, 32, generator=torch.Generator().manual_seed(62))
+    with torch.no_grad():
+        lp0 = m.log_prob(x)
+        lp = m.log_prob(x)
+    chk = torch.stack([p_.double().abs().sum() for p_ in m.parameters()]).sum()
+    npz("model_glow_c4_hidden256", x=x, log_prob_first=lp0, log_prob=lp, checksum=chk)
+
+
 def gen_cdf():
     """Standalone PiecewiseRationalQuadraticCDF (nsf/coupling.py:170-259): 1-D and N-D parameter shapes, every tails
     variant, values and reference-autograd gradients in both directions."""
@@ -860,6 +897,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "circular":
         gen_circular()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "glow_model256":
+        gen_glow_model256()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "glow_block256":
         gen_glow_block256()
         sys.exit(0)
@@ -906,3 +946,4 @@ if __name__ == "__main__":
     gen_cdf()
     gen_glow_convnet()
     gen_glow_block256()
+    gen_glow_model256()

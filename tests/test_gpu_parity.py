@@ -1,6 +1,8 @@
 """GPU parity tests (run with -m gpu on an MI355X): every kernel through the C ABI (normflows_amd.ops / layer
 classes) against (a) the golden vectors produced by the real reference and (b) the CPU oracle on seeded inputs,
 plus size-independent properties at the benchmark's full size (round trip, sample/log_prob consistency)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -392,6 +394,35 @@ def test_glow_block_one_launch_vs_reference(nfa, name, seed, C, smap, leaky, B, 
     assert_close(N(zf), N(zf0), what="z_fwd vs layers", rtol=1e-4, atol=1e-4)
     assert_close(N(ldf), N(ldf0), what="ld_fwd vs layers", rtol=1e-4, atol=1e-3)
     assert_close(N(acc), 1.0 - N(ldi), what="acc", rtol=1e-5, atol=1e-4)
+
+
+def test_glow_model_hidden256_vs_reference(nfa):
+    """The config-4 architecture at its real width against the reference's log_prob (fixture: seeded construction on both
+    sides), with every GlowBlock forced through the one-launch kernels (12 images: thresholds lowered for the test)."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden.py")
+    src = open(path).read()
+    ns = {"torch": torch}
+    exec(src[src.index("def build_glow_c4("):src.index("def gen_glow_model256(")], ns)   # the shared model builder only
+    g = load_golden("model_glow_c4_hidden256")
+    m = ns["build_glow_c4"](nfa, 3, 2, 256, seed=61)
+    x = T(g["x"])
+    cls = nfa.nets.ConvNet2d
+    saved = cls.FUSED_MIN_PIXELS, cls.FUSED_WIDE_MIN_PIXELS
+    m = m.to(DEV)
+    with torch.no_grad():
+        lp0 = m.log_prob(x)          # ActNorm initialisation (layer by layer: the mix needs initialised ActNorms)
+        chk = float(sum(p_.double().abs().sum() for p_ in m.parameters()))
+        assert abs(chk - float(g["checksum"])) < 1e-5 * abs(chk)
+        try:
+            cls.FUSED_MIN_PIXELS, cls.FUSED_WIDE_MIN_PIXELS = 0, 0
+            assert all(b._whole_block(torch.empty(12, *shape, device=DEV)) is not None
+                       for fl, shape in zip(m.flows, ((48, 4, 4), (24, 8, 8), (12, 16, 16))) for b in fl[:-1])
+            lp = m.log_prob(x)
+        finally:
+            cls.FUSED_MIN_PIXELS, cls.FUSED_WIDE_MIN_PIXELS = saved
+    assert _rel(N(lp0), g["log_prob_first"]) < 2e-4, _rel(N(lp0), g["log_prob_first"])
+    assert _rel(N(lp), g["log_prob"]) < 2e-4, _rel(N(lp), g["log_prob"])
 
 
 def test_glow_config4_shapes_through_the_block_kernels(nfa):
