@@ -212,6 +212,23 @@ def inv1x1_conv(z, W, logdet_unit):
     return y, lds[0]
 
 
+def convnet2d(x, weights, biases, leaky=0.0):
+    """nets/cnn.py:5-63: Conv2d(padding = k // 2) + LeakyReLU(leaky) for every layer but the last, which has no
+    activation.  weights[i] (Cout_i, Cin_i, k_i, k_i), biases[i] (Cout_i)."""
+    dt = x.dtype
+    h = _c(x, dt)
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        w, b = _c(w, dt), _c(b, dt)
+        B, Cin, H, W = h.shape
+        y = np.empty((B, w.shape[0], H, W), dt)
+        real = C.c_float if dt == np.float32 else C.c_double
+        getattr(lib(), "nfo_conv2d_same" + _sfx(dt))(_p(h), _p(w), _p(b), _p(y), C.c_int64(B), C.c_int(Cin), C.c_int(H),
+                                                     C.c_int(W), C.c_int(w.shape[0]), C.c_int(w.shape[2]),
+                                                     C.c_int(1 if i + 1 < len(weights) else 0), real(leaky))
+        h = y
+    return h
+
+
 def diag_gaussian_log_prob(z, loc, log_scale, ls_shift=0.0, out=None, acc=0):
     dt = z.dtype
     z = _c(z, dt)

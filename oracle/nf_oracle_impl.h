@@ -684,3 +684,33 @@ void FN(nfo_maf_affine)(const REAL *x, const REAL *params, REAL *y, REAL *logdet
         if (logdet) logdet[b] = direction == 0 ? a : -a;
     }
 }
+
+/* nets/cnn.py:5-63 (ConvNet2d): one Conv2d(Cin, Cout, k, padding = k / 2, stride 1) with bias, NCHW, optionally followed by
+ * LeakyReLU(slope) (torch.nn.LeakyReLU: x if x > 0 else slope x).  w (Cout, Cin, k, k), cross-correlation as torch.conv2d. */
+void FN(nfo_conv2d_same)(const REAL *x, const REAL *w, const REAL *b, REAL *y, int64_t B, int Cin, int H, int W, int Cout,
+                         int k, int leaky_on, REAL slope) {
+    const int pad = k / 2;
+    int64_t n;
+#pragma omp parallel for schedule(static)
+    for (n = 0; n < B * Cout; ++n) {
+        const int64_t img = n / Cout;
+        const int co = (int)(n - img * Cout);
+        int yy, xx, ci, ky, kx;
+        for (yy = 0; yy < H; ++yy)
+            for (xx = 0; xx < W; ++xx) {
+                REAL a = b ? b[co] : 0;
+                for (ci = 0; ci < Cin; ++ci)
+                    for (ky = 0; ky < k; ++ky) {
+                        const int sy = yy + ky - pad;
+                        if (sy < 0 || sy >= H) continue;
+                        for (kx = 0; kx < k; ++kx) {
+                            const int sx = xx + kx - pad;
+                            if (sx < 0 || sx >= W) continue;
+                            a += w[((co * (int64_t)Cin + ci) * k + ky) * k + kx] * x[((img * Cin + ci) * H + sy) * W + sx];
+                        }
+                    }
+                if (leaky_on && !(a > 0)) a = a * slope;
+                y[((img * Cout + co) * H + yy) * W + xx] = a;
+            }
+    }
+}

@@ -396,6 +396,30 @@ def test_glow_block_one_launch_vs_reference(nfa, name, seed, C, smap, leaky, B, 
     assert_close(N(acc), 1.0 - N(ldi), what="acc", rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("cin,cout,H,W,B,leaky", [(6, 12, 16, 16, 2, 0.3), (5, 7, 8, 8, 9, 0.0), (9, 13, 4, 4, 33, 0.05),
+                                                  (1, 2, 2, 2, 70, 1.0), (2, 3, 1, 4, 5, 0.0)])
+def test_glow_convnet_kernels_vs_oracle(nfa, oracle, cin, cout, H, W, B, leaky):
+    """Every GlowBlock-conditioner kernel that takes the image size against the CPU oracle (oracle.convnet2d) on random
+    normal weights: odd channel counts, non-square and 1-pixel-high images, batches off the workgroup size, slopes 0..1."""
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    w1 = 0.3 * torch.randn(256, cin, 3, 3, generator=g); b1 = torch.randn(256, generator=g)
+    w2 = 0.08 * torch.randn(256, 256, 1, 1, generator=g); b2 = torch.randn(256, generator=g)
+    w3 = 0.05 * torch.randn(cout, 256, 3, 3, generator=g); b3 = torch.randn(cout, generator=g)
+    x = torch.randn(B, cin, H, W, generator=g)
+    ref = oracle.convnet2d(x.numpy().astype(np.float64), [t.numpy().astype(np.float64) for t in (w1, w2, w3)],
+                           [t.numpy().astype(np.float64) for t in (b1, b2, b3)], leaky)
+    prm = [t.to(DEV) for t in (w1, b1, w2, b2, w3, b3)]
+    ran = 0
+    for layout, pxw in ((nfa.ops.GLOW_CONV_WIDE, 256), (nfa.ops.GLOW_CONV_SMALL, 64), (nfa.ops.GLOW_CONV_TINY, 16)):
+        if pxw % (H * W) != 0:
+            continue
+        blob = nfa.ops.glow_convnet_pack(*prm, layout=layout)
+        out = nfa.ops.glow_convnet(x.to(DEV), blob, cout, leaky, layout)
+        assert_close(N(out).astype(np.float64), ref, what="layout %d" % layout, rtol=1e-4, atol=1e-4)
+        ran += 1
+    assert ran >= 1
+
+
 def test_glow_model_hidden256_vs_reference(nfa):
     """The config-4 architecture at its real width against the reference's log_prob (fixture: seeded construction on both
     sides), with every GlowBlock forced through the one-launch kernels (12 images: thresholds lowered for the test)."""

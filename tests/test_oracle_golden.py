@@ -267,3 +267,25 @@ def test_class_cond_diag_gaussian(oracle):
                  rtol=1e-5, atol=1e-5)
     assert_close(oracle.diag_gaussian_log_prob_rows(g["z"], loc_r, ls_r, g["y"], float(np.log(0.7))), g["log_prob_temp"],
                  what="temperature", rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name,seed,cin,cout,leaky", [("convnet_6_12_16x16", 31, 6, 12, 0.0), ("convnet_12_24_8x8", 32, 12, 24, 0.1),
+                                                     ("convnet_24_48_4x4", 33, 24, 48, 0.0), ("convnet_3_5_4x8", 34, 3, 5, 0.2)])
+def test_convnet2d(oracle, name, seed, cin, cout, leaky):
+    """nfo_conv2d_same chained as ConvNet2d (nets/cnn.py:5-63) against the reference's output at 256 hidden channels.  The
+    fixture stores inputs / outputs / a weight checksum; the weights are the seeded default construction."""
+    import torch
+    import normflows_amd as nfa      # host-side module construction only (seeded default weights); no kernels involved
+    g = load_golden(name)
+    torch.manual_seed(seed)
+    net = nfa.nets.ConvNet2d([cin, 256, 256, cout], [3, 1, 3], leaky, init_zeros=False)
+    chk = np.array([float(p_.double().abs().sum()) for p_ in net.parameters()])
+    np.testing.assert_allclose(chk, g["weight_checksum"], rtol=1e-12)
+    convs = [m for m in net.net if isinstance(m, torch.nn.Conv2d)]
+    ws = [c.weight.detach().numpy() for c in convs]
+    bs = [c.bias.detach().numpy() for c in convs]
+    assert_close(oracle.convnet2d(g["x"], ws, bs, leaky), g["out"], what="out f32", rtol=1e-4, atol=1e-4)
+    out64 = oracle.convnet2d(g["x"].astype(np.float64), [w.astype(np.float64) for w in ws], [b.astype(np.float64) for b in bs],
+                             leaky)
+    assert out64.dtype == np.float64
+    assert_close(out64, g["out"].astype(np.float64), what="out f64", rtol=1e-4, atol=1e-4)
