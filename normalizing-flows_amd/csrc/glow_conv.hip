@@ -479,8 +479,8 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
             __builtin_amdgcn_global_load_lds(src + i * 256, (__attribute__((address_space(3))) void *)(dst + i * 256), 16, 0, 0);
     };
     auto acquire = [&]() -> const float * {
-        // stages stage+1 and stage+2 may stay in flight (loads retire in order); the tail drains everything
-        if (stage + 2 < total_stages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        // stages stage+1 .. stage+RING-2 may stay in flight (loads retire in order); the tail drains everything
+        if (stage + GS_RING - 2 < total_stages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((GS_RING - 2) * PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // everyone's pieces of `stage` have landed; everyone is done with stage - 1 (slot reused below)
         if (stage + GS_RING - 1 < total_stages) issue(stage + GS_RING - 1);
@@ -499,9 +499,9 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
     if (fu.on) gb_prologue<GS_PX, 64 * GS_NW>(fu, x, out, zr, zm, xin, H, W, img0, B, tid);
     else gc_fill_xin_global<GS_PX, 64 * GS_NW>(x, xs_img, xin, mt.Cin, H, W, img0, B, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's in-order accounting starts from an empty queue
-    issue(0);
-    if (total_stages > 1) issue(1);
-    if (total_stages > 2) issue(2);
+#pragma unroll
+    for (int i = 0; i < GS_RING - 1; ++i)
+        if (i < total_stages) issue(i);
     __syncthreads();
 
     // ---- GEMM 1: h1 (16 blocks of 16 channels) ----
