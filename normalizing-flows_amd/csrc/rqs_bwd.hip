@@ -18,6 +18,9 @@
 // zero-initialises (summation order across workgroups is not deterministic; fp32 atomics).
 #include "common.hpp"
 
+// the unroll hints below are meant for the compile-time bin count (KT > 0); with a run-time K they cannot apply
+#pragma clang diagnostic ignored "-Wpass-failed"
+
 namespace nf {
 
 template <typename T, int N> struct Dual {
@@ -103,14 +106,24 @@ __device__ __forceinline__ void rqs_eval_bin_dual(T x, T cw, T cwh, T ch, T chh,
 
 // Softmax probabilities of K logits read through `acc` (already divided by wh_div), written through `put`: the only
 // transcendental pass over the widths / heights; everything downstream works on the probabilities.
-template <typename T, typename Acc, typename Put>
-__device__ __forceinline__ void rqs_softmax_probs(int K, const Acc &acc, const Put &put) {
+// KT > 0: bin count known at compile time (loops unrolled: the LDS reads of a row become independent, pipelined accesses).
+template <typename T, int KT = 0, typename Acc, typename Put>
+__device__ __forceinline__ void rqs_softmax_probs(int Krt, const Acc &acc, const Put &put) {
+    const int K = KT ? KT : Krt;
     T m = acc(0);
+#pragma unroll
     for (int k = 1; k < K; ++k) m = M<T>::fmax(m, acc(k));
+    T e[KT ? KT : 1];
     T s = T(0);
-    for (int k = 0; k < K; ++k) s += M<T>::exp(acc(k) - m);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const T v = M<T>::exp(acc(k) - m);
+        if (KT) e[k] = v;
+        s += v;
+    }
     const T inv = T(1) / s;
-    for (int k = 0; k < K; ++k) put(k, M<T>::exp(acc(k) - m) * inv);
+#pragma unroll
+    for (int k = 0; k < K; ++k) put(k, (KT ? e[k] : M<T>::exp(acc(k) - m)) * inv);
 }
 
 // Gradient of one spline element w.r.t. x and its raw parameters, given the softmax probabilities pw(k), ph(k) of its
@@ -118,14 +131,14 @@ __device__ __forceinline__ void rqs_softmax_probs(int K, const Acc &acc, const P
 // receive the gradients of the RAW parameters (already including 1 / wh_div); add_w(i) / add_h(i) are called after the
 // last read of pw(i) / ph(i), before_d() after the last read of dacc: gradients may overwrite the parameters in place.
 // Returns gx.
-template <typename T, typename PW, typename PH, typename DAcc, typename AW, typename AH, typename AD, typename ZD>
+template <typename T, int KT = 0, typename PW, typename PH, typename DAcc, typename AW, typename AH, typename AD, typename ZD>
 __device__ __forceinline__ T rqs_element_bwd(const RqsParams<T> &p, T x, T gy_up, T gl_up, const PW &pw, const PH &ph,
                                              const DAcc &dacc, bool inverse, const AW &add_w, const AH &add_h,
                                              const AD &add_d, const ZD &before_d) {
     // identity outside the tails (utils/splines.py:40-41), lad = 0; the per-feature branch (:48-57) leaves zeros there,
     // which do not depend on x
     if (!rqs_inside(p, x)) return p.dfull ? T(0) : gy_up;
-    const int K = p.K;
+    const int K = KT ? KT : p.K;
     // knots of both axes around the bin: knot_j = lo + (hi - lo)(j min + scale C_j), C_j = sum_{i<j} prob_i, ends pinned.
     // searched axis: widths for the forward spline, heights for the inverse.
     const T s_lo = inverse ? p.bottom : p.left, s_hi = inverse ? p.top : p.right;
@@ -134,6 +147,7 @@ __device__ __forceinline__ T rqs_element_bwd(const RqsParams<T> &p, T x, T gy_up
     T sk_lo = s_lo, sk_hi = s_lo, Cs_lo = T(0), Cs_hi = T(0);
     {
         T cum = T(0), csm = T(0), knot = s_lo;
+#pragma unroll
         for (int k = 0; k < K; ++k) {
             const T sm = inverse ? ph(k) : pw(k);
             cum += s_min + s_scale * sm;
@@ -148,11 +162,12 @@ __device__ __forceinline__ T rqs_element_bwd(const RqsParams<T> &p, T x, T gy_up
     T ok_lo = o_lo, ok_hi = o_lo, Co_lo = T(0), Co_hi = T(0);
     {
         T cum = T(0), csm = T(0), knot = o_lo;
-        for (int k = 0; k <= bin; ++k) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
             const T sm = inverse ? pw(k) : ph(k);
             cum += o_min + o_scale * sm;
             const T next = (k == K - 1) ? o_hi : (o_hi - o_lo) * cum + o_lo;
-            ok_lo = knot; ok_hi = next; Co_lo = csm; Co_hi = csm + sm;
+            if (k <= bin) { ok_lo = knot; ok_hi = next; Co_lo = csm; Co_hi = csm + sm; }   // same sums as a walk that stops at bin
             knot = next;
             csm += sm;
         }
@@ -173,6 +188,7 @@ __device__ __forceinline__ T rqs_element_bwd(const RqsParams<T> &p, T x, T gy_up
     const T g_ch_lo = bin == 0 ? T(0) : g[3], g_ch_hi = bin == K - 1 ? T(0) : g[4];
     const T fw = (p.right - p.left) * p.scale_w / p.wh_div, fh = (p.top - p.bottom) * p.scale_h / p.wh_div;
     const T base_w = g_cw_lo * Cw_lo + g_cw_hi * Cw_hi, base_h = g_ch_lo * Ch_lo + g_ch_hi * Ch_hi;
+#pragma unroll
     for (int i = 0; i < K; ++i) {
         const T tw = (i < bin ? g_cw_lo : T(0)) + (i < bin + 1 ? g_cw_hi : T(0)) - base_w;
         const T th = (i < bin ? g_ch_lo : T(0)) + (i < bin + 1 ? g_ch_hi : T(0)) - base_h;
@@ -264,8 +280,6 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
                     continue;
                 }
                 // the row's raw widths / heights are replaced by their softmax probabilities (one exp pass)
-                rqs_softmax_probs<T>(K, [=](int k) { return row[k] / div; }, [=](int k, T v) { row[k] = v; });
-                rqs_softmax_probs<T>(K, [=](int k) { return row[K + k] / div; }, [=](int k, T v) { row[K + k] = v; });
                 auto pw = [=](int k) { return row[k]; };
                 auto ph = [=](int k) { return row[K + k]; };
                 auto dacc = [=](int k) { return row[2 * K + k]; };
@@ -273,7 +287,15 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
                 auto ah = [=](int i, T g) { row[K + i] = g; };
                 auto ad = [=](int j, T g) { row[2 * K + j] = g; };
                 auto zd = [=]() { for (int k = 2 * K; k < M; ++k) row[k] = T(0); };
-                gx[b * D + col] = rqs_element_bwd<T>(pf, xv, gy[b * D + col], gld[b], pw, ph, dacc, inverse, aw, ah, ad, zd);
+                if (K == 8) {   // the default bin count: unrolled walks
+                    rqs_softmax_probs<T, 8>(8, [=](int k) { return row[k] / div; }, [=](int k, T v) { row[k] = v; });
+                    rqs_softmax_probs<T, 8>(8, [=](int k) { return row[8 + k] / div; }, [=](int k, T v) { row[8 + k] = v; });
+                    gx[b * D + col] = rqs_element_bwd<T, 8>(pf, xv, gy[b * D + col], gld[b], pw, ph, dacc, inverse, aw, ah, ad, zd);
+                } else {
+                    rqs_softmax_probs<T>(K, [=](int k) { return row[k] / div; }, [=](int k, T v) { row[k] = v; });
+                    rqs_softmax_probs<T>(K, [=](int k) { return row[K + k] / div; }, [=](int k, T v) { row[K + k] = v; });
+                    gx[b * D + col] = rqs_element_bwd<T>(pf, xv, gy[b * D + col], gld[b], pw, ph, dacc, inverse, aw, ah, ad, zd);
+                }
             }
         }
 #endif
@@ -297,8 +319,12 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
                 auto aw = [=](int i, T g) { atomicAdd(acc + i, g); };
                 auto ah = [=](int i, T g) { atomicAdd(acc + K + i, g); };
                 auto ad = [=](int jj, T g) { atomicAdd(acc + 2 * K + jj, g); };
-                gx[b * D + col] = rqs_element_bwd<T>(pu, x[b * D + col], gy[b * D + col], gld[b], pw, ph, dacc, inverse,
-                                                     aw, ah, ad, []() {});
+                if (K == 8)
+                    gx[b * D + col] = rqs_element_bwd<T, 8>(pu, x[b * D + col], gy[b * D + col], gld[b], pw, ph, dacc, inverse,
+                                                            aw, ah, ad, []() {});
+                else
+                    gx[b * D + col] = rqs_element_bwd<T>(pu, x[b * D + col], gy[b * D + col], gld[b], pw, ph, dacc, inverse,
+                                                         aw, ah, ad, []() {});
             }
         }
 #endif

@@ -15,6 +15,8 @@
 //   LDS -> HBM : y rows, coalesced; per-sample log-det = row sum of the per-element values.
 // Algorithmic HBM bytes per sample (fp32, D=64, nT=32, K=8): 256 (x) + 2944 (cond) + 256 (y) + 8 (ld rmw).
 #include "common.hpp"
+#include "fused_common.hpp"
+#include <type_traits>
 
 namespace nf {
 
@@ -170,6 +172,163 @@ rqs_coupling_kernel(const T *__restrict__ x, T *__restrict__ y, T *__restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Same transform with WAVE-private tiles: a wave owns SPW samples at a time (SPW x max(nT, nI) <= ~64 elements per pass),
+// stages their conditioner rows / x rows into its own LDS region with unit-stride loads and never meets the other waves
+// of the workgroup again after the shared tables are built -- no workgroup barrier in the main loop (the tiled kernel
+// above spends most of its time in four barriers per 256 elements).  LDS operations of one wave execute in order, so a
+// wave-level fence is all the staging needs.  Per-sample log-det: one lane per sample sums the element terms in feature
+// order (fixed order: deterministic).
+template <typename T>
+__global__ void __launch_bounds__(256)
+rqs_coupling_wave_kernel(const T *__restrict__ x, T *__restrict__ y, T *__restrict__ logdet, const T *__restrict__ cond,
+                         const T *__restrict__ uw, const T *__restrict__ uh, const T *__restrict__ ud,
+                         const int64_t *__restrict__ iidx, int nI, const int64_t *__restrict__ tidx, int nT, int64_t B,
+                         int D, RqsParams<T> p, int mode, int acc, int SPW, int Mp, const int *__restrict__ tails_t,
+                         const T *__restrict__ bound_t, const int *__restrict__ tails_i, const T *__restrict__ bound_i) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int K = p.K;
+    const int M = 2 * K + p.nd;
+    const int TW = 3 * (K + 1);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nwv = blockDim.x >> 6;
+    const int per_wave = SPW * nT * Mp + 2 * SPW * D + SPW * (nT + nI);
+    T *s_tab = reinterpret_cast<T *>(smem_raw);                         // nI * TW (shared)
+    T *w_cond = s_tab + (size_t)nI * TW + (size_t)wid * per_wave;       // SPW * nT * Mp
+    T *w_x = w_cond + (size_t)SPW * nT * Mp;                            // SPW * D
+    T *w_y = w_x + (size_t)SPW * D;                                     // SPW * D
+    T *w_lad = w_y + (size_t)SPW * D;                                   // SPW * (nT + nI)
+    int *s_iidx = reinterpret_cast<int *>(s_tab + (size_t)nI * TW + (size_t)nwv * per_wave);
+    int *s_tidx = s_iidx + nI;
+
+    const bool has_uncond = uw != nullptr;
+    const bool do_t = mode != NF_RQS_SAMPLE_IDENTITY;
+    const bool do_i = mode != NF_RQS_SAMPLE_TRANSFORM;
+    const bool inverse = mode != NF_RQS_DENSITY;
+
+    for (int j = tid; j < nI; j += blockDim.x) s_iidx[j] = (int)iidx[j];
+    for (int j = tid; j < nT; j += blockDim.x) s_tidx[j] = (int)tidx[j];
+    if (do_i && has_uncond) {
+        for (int j = tid; j < nI; j += blockDim.x) {
+            const RqsParams<T> pu = rqs_feature_params(p, tails_i, bound_i, j);
+            const T *wj = uw + (size_t)j * K, *hj = uh + (size_t)j * K, *dj = ud + (size_t)j * p.nd;
+            rqs_build_table<T>(pu, [=](int k) { return wj[k]; }, [=](int k) { return hj[k]; }, [=](int k) { return dj[k]; },
+                               s_tab + (size_t)j * TW);
+        }
+    }
+    __syncthreads();   // the only workgroup barrier
+
+    // the default NSF parametrisation (8 bins, linear tails, float32, launch-wide tails): the branch-free routines of the
+    // fused kernel on register-resident parameters (fused_common.hpp: hardware exp2 / log / rcp, <= 1 ulp each) instead of
+    // the run-time-K walks over LDS rows
+    const bool fast = std::is_same<T, float>::value && K == F_K && p.tails == NF_TAILS_LINEAR && !p.dfull && !tails_t &&
+                      !bound_t && !tails_i && !bound_i;
+    const float invM = 1.0f / (float)M;
+    const int64_t gw = (int64_t)blockIdx.x * nwv + wid, GW = (int64_t)gridDim.x * nwv;
+    for (int64_t b0 = gw * SPW; b0 < B; b0 += GW * SPW) {
+        const int ns = (int)((B - b0) < SPW ? (B - b0) : SPW);
+        {
+            const T *src = x + b0 * D;
+            for (int i = lane; i < ns * D; i += 64) {
+                const T v = src[i];
+                w_x[i] = v;
+                w_y[i] = v;
+            }
+        }
+        if (do_t) {
+            const T *src = cond + b0 * (int64_t)nT * M;
+            const int n = ns * nT * M;
+            if (Mp == M) {
+                for (int i = lane; i < n; i += 64) w_cond[i] = src[i];
+            } else {
+                for (int i = lane; i < n; i += 64) {
+                    const int row = (int)(((float)i + 0.5f) * invM);   // exact for i < 2^22 / M
+                    w_cond[(size_t)row * Mp + (i - row * M)] = src[i];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (do_t) {
+            const T div = p.wh_div;
+            for (int e = lane; e < ns * nT; e += 64) {
+                const int s = e / nT, j = e - s * nT;
+                T *row = w_cond + (size_t)e * Mp;
+                if constexpr (std::is_same<T, float>::value) {
+                    if (fast) {
+                        float prm[24];
+                        const float sc = 1.44269504088896340736f / p.wh_div;
+#pragma unroll
+                        for (int k = 0; k < 2 * F_K; ++k) prm[k] = row[k] * sc;
+#pragma unroll
+                        for (int k = 2 * F_K; k < F_M; ++k) prm[k] = row[k];
+                        prm[F_M] = 0.0f;
+                        float yy, ll;
+                        const float xv = w_x[s * D + s_tidx[j]];
+                        if (inverse) rqs_regs<true>(p, xv, prm, yy, ll);
+                        else rqs_regs<false>(p, xv, prm, yy, ll);
+                        w_y[s * D + s_tidx[j]] = yy;
+                        w_lad[s * (nT + nI) + j] = ll;
+                        continue;
+                    }
+                }
+                rqs_softmax_row<T>(row, K, div);
+                rqs_softmax_row<T>(row + K, K, div);
+                auto pw = [=](int k) { return row[k]; };
+                auto ph = [=](int k) { return row[K + k]; };
+                auto dacc = [=](int k) { return row[2 * K + k]; };
+                T yy, ll;
+                rqs_element_probs<T>(rqs_feature_params(p, tails_t, bound_t, j), w_x[s * D + s_tidx[j]], pw, ph, dacc, inverse,
+                                     yy, ll);
+                w_y[s * D + s_tidx[j]] = yy;
+                w_lad[s * (nT + nI) + j] = ll;
+            }
+        }
+        if (do_i) {
+            for (int e = lane; e < ns * nI; e += 64) {
+                const int s = e / nI, j = e - s * nI;
+                T yy = w_x[s * D + s_iidx[j]], ll = T(0);
+                if constexpr (std::is_same<T, float>::value) {
+                    if (fast && has_uncond) {
+                        const float xv = yy;
+                        if (inverse) rqs_table_fast<true>(p, xv, s_tab + (size_t)j * TW, yy, ll);
+                        else rqs_table_fast<false>(p, xv, s_tab + (size_t)j * TW, yy, ll);
+                        w_y[s * D + s_iidx[j]] = yy;
+                        w_lad[s * (nT + nI) + nT + j] = ll;
+                        continue;
+                    }
+                }
+                if (has_uncond)
+                    rqs_eval_table<T>(rqs_feature_params(p, tails_i, bound_i, j), yy, s_tab + (size_t)j * TW, inverse, yy, ll);
+                w_y[s * D + s_iidx[j]] = yy;
+                w_lad[s * (nT + nI) + nT + j] = ll;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (mode == NF_RQS_DENSITY) {
+            T *dst = y + b0 * D;
+            for (int i = lane; i < ns * D; i += 64) dst[i] = w_y[i];
+        } else {
+            const int nown = do_t ? nT : nI;
+            const int *own = do_t ? s_tidx : s_iidx;
+            for (int e = lane; e < ns * nown; e += 64) {
+                const int s = e / nown, j = e - s * nown;
+                y[(b0 + s) * D + own[j]] = w_y[s * D + own[j]];
+            }
+        }
+        for (int s = lane; s < ns; s += 64) {
+            T a = T(0);
+            const T *row = w_lad + s * (nT + nI);
+            if (do_t)
+                for (int j = 0; j < nT; ++j) a += row[j];
+            if (do_i)
+                for (int j = 0; j < nI; ++j) a += row[nT + j];
+            ld_store(logdet + b0 + s, a, acc);
+        }
+        __builtin_amdgcn_wave_barrier();   // the next pass overwrites the wave's tiles
+    }
+}
+
 #ifndef NF_FWD_TS_ELEMS
 #define NF_FWD_TS_ELEMS 256   // elements per tile and pass: ~one per lane
 #endif
@@ -184,6 +343,25 @@ static int launch_rqs_coupling(const void *x, void *y, void *logdet, const void 
     const int M = 2 * K + p.nd;
     const int Mp = M | 1;
     const int nmax = nT > nI ? nT : nI;
+#ifndef NF_FWD_NO_WAVE_KERNEL
+    {   // wave-private tiles when four waves' regions fit 64 KB of LDS
+        int SPW = nmax > 0 ? 64 / nmax : 1;
+        if (SPW < 1) SPW = 1;
+        const size_t per_wave = (size_t)SPW * nT * Mp + 2 * (size_t)SPW * D + (size_t)SPW * (nT + nI);
+        const size_t ldsw = ((size_t)nI * 3 * (K + 1) + 4 * per_wave) * sizeof(T) + (size_t)(nI + nT) * sizeof(int) + 16;
+        if (ldsw <= 64 * 1024 && mode != NF_RQS_SAMPLE_IDENTITY) {   // (table look-ups alone: the tiled kernel is as fast)
+            const int64_t nwaves = (B + SPW - 1) / SPW;
+            const int64_t g = (nwaves + 3) / 4;
+            const int grid = (int)(g < 2048 ? g : 2048);
+            hipLaunchKernelGGL(rqs_coupling_wave_kernel<T>, dim3(grid), dim3(256), ldsw, st, (const T *)x, (T *)y, (T *)logdet,
+                               (const T *)cond, (const T *)uw, (const T *)uh, (const T *)ud, iidx, nI, tidx, nT, B, D, p, mode,
+                               acc, SPW, Mp, (const int *)tails_t, (const T *)bound_t, (const int *)tails_i,
+                               (const T *)bound_i);
+            NF_CHECK_LAUNCH();
+            return NF_OK;
+        }
+    }
+#endif
     int TS = NF_FWD_TS_ELEMS / (nmax > 0 ? nmax : 1);
     if (TS < 1) TS = 1;
     if (TS > 64) TS = 64;
