@@ -17,9 +17,10 @@
 // gradients are accumulated per workgroup in LDS and then atomically into (nI, K | K | nd) buffers that the caller
 // zero-initialises (summation order across workgroups is not deterministic; fp32 atomics).
 #include "common.hpp"
+#include "fused_common.hpp"
 
-// the unroll hints below are meant for the compile-time bin count (KT > 0); with a run-time K they cannot apply
-#pragma clang diagnostic ignored "-Wpass-failed"
+// (the unroll hints below are meant for the compile-time bin count, KT > 0; the build passes -Wno-pass-failed for the
+// run-time-K instantiations, where they cannot apply)
 
 namespace nf {
 
@@ -353,6 +354,252 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
     }
 }
 
+
+// ---- default parametrisation (8 bins, linear tails, float32): everything in registers, static indexing ----------------
+// Same derivation as rqs_element_bwd on the register layout of fused_common.hpp::rqs_regs: prm[0..7] / prm[8..15] arrive
+// multiplied by log2(e) / wh_div (softmax through exp2), prm[16..22] are the raw derivative logits.  Writes the gradients
+// of the RAW parameters to g[0..22] and returns gx.
+template <bool INVERSE>
+__device__ __forceinline__ float rqs_regs_bwd(const RqsParams<float> &p, float x, const float (&prm)[24], float gy_up,
+                                              float gl_up, float (&g)[24], float inv_div) {
+    const bool inside = x >= p.left && x <= p.right;
+    float mw = prm[0], mh = prm[F_K];
+#pragma unroll
+    for (int k = 1; k < F_K; ++k) {
+        mw = fmaxf(mw, prm[k]);
+        mh = fmaxf(mh, prm[F_K + k]);
+    }
+    float ew[F_K], eh[F_K], pw[F_K], ph[F_K];
+#pragma unroll
+    for (int k = 0; k < F_K; ++k) {
+        ew[k] = __builtin_amdgcn_exp2f(prm[k] - mw);
+        eh[k] = __builtin_amdgcn_exp2f(prm[F_K + k] - mh);
+        pw[k] = k == 0 ? ew[k] : pw[k - 1] + ew[k];
+        ph[k] = k == 0 ? eh[k] : ph[k - 1] + eh[k];
+    }
+    const float rsw = frcp(pw[F_K - 1]), rsh = frcp(ph[F_K - 1]);
+    const float cw = (p.right - p.left) * p.scale_w * rsw, ch = (p.top - p.bottom) * p.scale_h * rsh;
+    float kw[F_K + 1], kh[F_K + 1];
+    kw[0] = p.left; kh[0] = p.bottom; kw[F_K] = p.right; kh[F_K] = p.top;
+#pragma unroll
+    for (int k = 1; k < F_K; ++k) {
+        kw[k] = fmaf(pw[k - 1], cw, p.left + (p.right - p.left) * p.min_w * (float)k);
+        kh[k] = fmaf(ph[k - 1], ch, p.bottom + (p.top - p.bottom) * p.min_h * (float)k);
+    }
+    // bin on the searched axis (x axis for the forward spline, y axis for the inverse); knots and cumulative softmax
+    // C_bin, C_{bin+1} of BOTH axes at that bin
+    int bin = 0;
+    float xlo = kw[0], xhi = kw[1], ylo = kh[0], yhi = kh[1];
+    float Cw_lo = 0.0f, Cw_hi = pw[0] * rsw, Ch_lo = 0.0f, Ch_hi = ph[0] * rsh;
+#pragma unroll
+    for (int k = 1; k < F_K; ++k) {
+        const bool ge = x >= (INVERSE ? kh[k] : kw[k]);
+        bin = ge ? k : bin;
+        xlo = ge ? kw[k] : xlo; xhi = ge ? kw[k + 1] : xhi;
+        ylo = ge ? kh[k] : ylo; yhi = ge ? kh[k + 1] : yhi;
+        Cw_lo = ge ? pw[k - 1] * rsw : Cw_lo; Cw_hi = ge ? pw[k] * rsw : Cw_hi;
+        Ch_lo = ge ? ph[k - 1] * rsh : Ch_lo; Ch_hi = ge ? ph[k] * rsh : Ch_hi;
+    }
+    float dl0 = p.edge_logit, dl1 = p.edge_logit;
+#pragma unroll
+    for (int k = 0; k < F_K - 1; ++k) {
+        dl0 = (bin == k + 1) ? prm[2 * F_K + k] : dl0;
+        dl1 = (bin == k) ? prm[2 * F_K + k] : dl1;
+    }
+    const float d0 = p.min_d + fsoftplus(dl0), d1 = p.min_d + fsoftplus(dl1);
+    float jy[7], jl[7];
+    rqs_eval_bin_dual<float>(x, xlo, xhi, ylo, yhi, d0, d1, INVERSE, jy, jl);
+    float gv[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) gv[i] = gy_up * jy[i] + gl_up * jl[i];
+    const float g_cw_lo = bin == 0 ? 0.0f : gv[1], g_cw_hi = bin == F_K - 1 ? 0.0f : gv[2];   // pinned end knots
+    const float g_ch_lo = bin == 0 ? 0.0f : gv[3], g_ch_hi = bin == F_K - 1 ? 0.0f : gv[4];
+    const float fw = (p.right - p.left) * p.scale_w * inv_div, fh = (p.top - p.bottom) * p.scale_h * inv_div;
+    const float base_w = g_cw_lo * Cw_lo + g_cw_hi * Cw_hi, base_h = g_ch_lo * Ch_lo + g_ch_hi * Ch_hi;
+#pragma unroll
+    for (int i = 0; i < F_K; ++i) {
+        const float tw = (i < bin ? g_cw_lo : 0.0f) + (i <= bin ? g_cw_hi : 0.0f) - base_w;
+        const float th = (i < bin ? g_ch_lo : 0.0f) + (i <= bin ? g_ch_hi : 0.0f) - base_h;
+        g[i] = inside ? fw * (ew[i] * rsw) * tw : 0.0f;
+        g[F_K + i] = inside ? fh * (eh[i] * rsh) * th : 0.0f;
+    }
+    const float s0 = dl0 > 20.0f ? 1.0f : sigmoid(dl0), s1 = dl1 > 20.0f ? 1.0f : sigmoid(dl1);
+#pragma unroll
+    for (int k = 0; k < F_K - 1; ++k) {
+        const float a = (bin == k + 1 ? gv[5] * s0 : 0.0f) + (bin == k ? gv[6] * s1 : 0.0f);
+        g[2 * F_K + k] = inside ? a : 0.0f;
+    }
+    g[F_M] = 0.0f;
+    return inside ? gv[0] : gy_up;
+}
+
+// Wave-private tiles (as rqs_coupling_wave_kernel): SPW samples per pass; conditioner rows in, gradient rows out through
+// the wave's own LDS region with unit-stride global accesses, x / grad_y rows staged, gx rows written whole.  The shared
+// (identity-half) parameters accumulate in workgroup LDS by atomics as in the tiled kernel.  float32, 8 bins, linear tails.
+#ifndef NF_BWD_WAVE_OCC
+#define NF_BWD_WAVE_OCC 2   // waves per SIMD the register allocation aims at (3: 168 VGPRs + spills, measured slower)
+#endif
+#ifndef NF_BWD_WAVE_WAVES
+#define NF_BWD_WAVE_WAVES 8  // waves per workgroup: one workgroup per CU = fewest rounds of end-of-kernel global atomics
+#endif
+__global__ void __launch_bounds__(64 * NF_BWD_WAVE_WAVES, NF_BWD_WAVE_OCC)
+rqs_coupling_bwd_wave_kernel(const float *__restrict__ x, const float *__restrict__ gy, const float *__restrict__ gld,
+                             const float *__restrict__ cond, const float *__restrict__ uw, const float *__restrict__ uh,
+                             const float *__restrict__ ud, const int64_t *__restrict__ iidx, int nI,
+                             const int64_t *__restrict__ tidx, int nT, int64_t B, int D, RqsParams<float> p, int mode,
+                             float *__restrict__ gx, float *__restrict__ gcond, float *__restrict__ guw,
+                             float *__restrict__ guh, float *__restrict__ gud, int SPW) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int K = F_K, M = F_M, nd = F_K - 1;
+    const int PP = (2 * K) | 1;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nwv = blockDim.x >> 6;
+    const int per_wave = SPW * nT * M + 3 * SPW * D;
+    float *s_acc = reinterpret_cast<float *>(smem_raw);           // nI * M
+    float *s_prob = s_acc + (size_t)nI * M;                      // nI * PP
+    float *s_ud = s_prob + (size_t)nI * PP;                      // nI * nd
+    float *s_prm = s_ud + (size_t)nI * nd;                       // nI * 24: shared parameters in rqs_regs order (w, h x log2 e)
+    float *w_cond = s_prm + (size_t)nI * 24 + (size_t)wid * per_wave;
+    float *w_x = w_cond + (size_t)SPW * nT * M, *w_gy = w_x + (size_t)SPW * D, *w_gx = w_gy + (size_t)SPW * D;
+    int *s_iidx = reinterpret_cast<int *>(s_prm + (size_t)nI * 24 + (size_t)nwv * per_wave);
+    int *s_tidx = s_iidx + nI;
+    const bool do_t = mode != NF_RQS_SAMPLE_IDENTITY, do_i = mode != NF_RQS_SAMPLE_TRANSFORM;
+    const bool inverse = mode != NF_RQS_DENSITY;
+    const bool has_uncond = uw != nullptr;
+
+    for (int j = tid; j < nI; j += blockDim.x) s_iidx[j] = (int)iidx[j];
+    for (int j = tid; j < nT; j += blockDim.x) s_tidx[j] = (int)tidx[j];
+    if (do_i && has_uncond) {
+        for (int i = tid; i < nI * M; i += blockDim.x) s_acc[i] = 0.0f;
+        for (int i = tid; i < nI * nd; i += blockDim.x) s_ud[i] = ud[i];
+        for (int i = tid; i < nI * 24; i += blockDim.x) {
+            const int j = i / 24, c = i - 24 * j;
+            s_prm[i] = c < K ? uw[(size_t)j * K + c] * 1.44269504088896340736f
+                             : (c < 2 * K ? uh[(size_t)j * K + c - K] * 1.44269504088896340736f
+                                          : (c < M ? ud[(size_t)j * nd + c - 2 * K] : 0.0f));
+        }
+        for (int j = tid; j < nI; j += blockDim.x) {
+            const float *wj = uw + (size_t)j * K, *hj = uh + (size_t)j * K;
+            float *pj = s_prob + (size_t)j * PP;
+            rqs_softmax_probs<float, 8>(8, [=](int k) { return wj[k]; }, [=](int k, float v) { pj[k] = v; });
+            rqs_softmax_probs<float, 8>(8, [=](int k) { return hj[k]; }, [=](int k, float v) { pj[K + k] = v; });
+        }
+    }
+    __syncthreads();
+
+    const float sc = 1.44269504088896340736f / p.wh_div, inv_div = 1.0f / p.wh_div;
+    const int64_t gw = (int64_t)blockIdx.x * nwv + wid, GW = (int64_t)gridDim.x * nwv;
+    // identity half: when one pass covers its elements with one lane each (SPW nI <= 64), a lane keeps the same shared
+    // feature for the whole launch: its parameter gradients accumulate in REGISTERS and meet the other lanes once, at the end
+    const bool reg_acc = do_i && has_uncond && SPW * nI <= 64;
+    float racc[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) racc[k] = 0.0f;
+    for (int64_t b0 = gw * SPW; b0 < B; b0 += GW * SPW) {
+        const int ns = (int)((B - b0) < SPW ? (B - b0) : SPW);
+        for (int i = lane; i < ns * D; i += 64) {
+            w_x[i] = x[b0 * D + i];
+            w_gy[i] = gy[b0 * D + i];
+            w_gx[i] = 0.0f;
+        }
+        if (do_t) {
+            const float *src = cond + b0 * (int64_t)nT * M;
+            for (int i = lane; i < ns * nT * M; i += 64) w_cond[i] = src[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#ifndef NF_BWD_ABL_NOT
+        if (do_t) {
+            for (int e = lane; e < ns * nT; e += 64) {
+                const int s_ = e / nT, j = e - s_ * nT, col = s_tidx[j];
+                float *row = w_cond + (size_t)e * M;
+                float prm[24], g[24];
+#pragma unroll
+                for (int k = 0; k < 2 * K; ++k) prm[k] = row[k] * sc;
+#pragma unroll
+                for (int k = 2 * K; k < M; ++k) prm[k] = row[k];
+                prm[M] = 0.0f;
+                const float xv = w_x[s_ * D + col], gyv = w_gy[s_ * D + col], gl = gld[b0 + s_];
+                const float gxv = inverse ? rqs_regs_bwd<true>(p, xv, prm, gyv, gl, g, inv_div)
+                                          : rqs_regs_bwd<false>(p, xv, prm, gyv, gl, g, inv_div);
+#pragma unroll
+                for (int k = 0; k < M; ++k) row[k] = g[k];
+                w_gx[s_ * D + col] = gxv;
+            }
+        }
+#endif
+#ifndef NF_BWD_ABL_NOI
+        if (do_i) {
+            for (int e = lane; e < ns * nI; e += 64) {
+                const int s_ = e / nI, j = e - s_ * nI, col = s_iidx[j];
+                const float xv = w_x[s_ * D + col], gyv = w_gy[s_ * D + col];
+                if (!has_uncond) {
+                    w_gx[s_ * D + col] = gyv;
+                    continue;
+                }
+                if (reg_acc) {
+                    float prm[24], g[24];
+                    const float *pr = s_prm + (size_t)j * 24;
+#pragma unroll
+                    for (int k = 0; k < 24; ++k) prm[k] = pr[k];
+                    const float gl = gld[b0 + s_];
+                    w_gx[s_ * D + col] = inverse ? rqs_regs_bwd<true>(p, xv, prm, gyv, gl, g, 1.0f)
+                                                 : rqs_regs_bwd<false>(p, xv, prm, gyv, gl, g, 1.0f);
+#pragma unroll
+                    for (int k = 0; k < M; ++k) racc[k] += g[k];
+                    continue;
+                }
+                RqsParams<float> pu = p;
+                pu.wh_div = 1.0f;
+                const float *pj = s_prob + (size_t)j * PP, *dj = s_ud + (size_t)j * nd;
+                float *accj = s_acc + (size_t)j * M;
+                auto pwf = [=](int k) { return pj[k]; };
+                auto phf = [=](int k) { return pj[K + k]; };
+                auto dacc = [=](int k) { return dj[k]; };
+                auto aw = [=](int i, float v) { atomicAdd(accj + i, v); };
+                auto ah = [=](int i, float v) { atomicAdd(accj + K + i, v); };
+                auto ad = [=](int jj, float v) { atomicAdd(accj + 2 * K + jj, v); };
+                w_gx[s_ * D + col] = rqs_element_bwd<float, 8>(pu, xv, gyv, gld[b0 + s_], pwf, phf, dacc, inverse, aw, ah, ad,
+                                                               []() {});
+            }
+        }
+#endif
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (do_t) {
+            float *dst = gcond + b0 * (int64_t)nT * M;
+            for (int i = lane; i < ns * nT * M; i += 64) dst[i] = w_cond[i];
+        }
+        if (mode == NF_RQS_DENSITY) {
+            for (int i = lane; i < ns * D; i += 64) gx[b0 * D + i] = w_gx[i];
+        } else {
+            const int nown = do_t ? nT : nI;
+            const int *own = do_t ? s_tidx : s_iidx;
+            for (int e = lane; e < ns * nown; e += 64) {
+                const int s_ = e / nown, j = e - s_ * nown;
+                gx[(b0 + s_) * D + own[j]] = w_gx[s_ * D + own[j]];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (reg_acc && lane < SPW * nI) {
+        float *accj = s_acc + (size_t)(lane % nI) * M;
+#pragma unroll
+        for (int k = 0; k < M; ++k) atomicAdd(accj + k, racc[k]);
+    }
+    __syncthreads();
+    if (do_i && has_uncond) {
+        for (int i = tid; i < nI * M; i += blockDim.x) {
+            const int j = i / M, c = i - j * M;
+            const float v = s_acc[i];
+            if (v != 0.0f) {
+                if (c < K) atomicAdd(guw + (size_t)j * K + c, v);
+                else if (c < 2 * K) atomicAdd(guh + (size_t)j * K + (c - K), v);
+                else atomicAdd(gud + (size_t)j * nd + (c - 2 * K), v);
+            }
+        }
+    }
+}
+
 }  // namespace nf
 
 using namespace nf;
@@ -375,7 +622,7 @@ static int launch_bwd(const void *x, const void *gy, const void *gld, const void
     if (lds > 150 * 1024) return NF_ENOTSUP;
     static LdsOptIn opted = {};
     if (opt_in_lds(reinterpret_cast<const void *>(&rqs_coupling_bwd_kernel<T>), lds, opted) != NF_OK) return NF_ENOTSUP;
-    const int grid = grid_for((B + TS - 1) / TS, 1, 2048);
+    const int grid = grid_for((B + TS - 1) / TS, 1, 512);   // resident workgroups; each one ends with 23 nI global atomics
     hipLaunchKernelGGL(rqs_coupling_bwd_kernel<T>, dim3(grid), dim3(256), lds, st, (const T *)x, (const T *)gy,
                        (const T *)gld, (const T *)cond, (const T *)uw, (const T *)uh, (const T *)ud, iidx, nI, tidx, nT,
                        B, D, p, mode, (T *)gx, (T *)gcond, (T *)guw, (T *)guh, (T *)gud, TS, (const int *)tails_t,
@@ -408,6 +655,31 @@ extern "C" int nf_rqs_coupling_bwd_ft(const void *x, const void *grad_y, const v
     if (dtype == NF_F32) {
         auto p = make_rqs_params<float>(K, tails, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height, min_derivative,
                                         wh_div);
+        if (K == F_K && tails == NF_TAILS_LINEAR && !tails_t && !bound_t && !tails_i && !bound_i) {
+            // default parametrisation: wave-private tiles + register-resident element routine
+            const int nmax = nT > nI ? nT : nI;
+            int SPW = nmax > 0 ? 64 / nmax : 1;
+            if (SPW < 1) SPW = 1;
+            const size_t per_wave = (size_t)SPW * nT * F_M + 3 * (size_t)SPW * D;
+            const size_t ldsw = ((size_t)nI * F_M + (size_t)nI * ((2 * F_K) | 1) + (size_t)nI * (F_K - 1) + (size_t)nI * 24 +
+                                 NF_BWD_WAVE_WAVES * per_wave) * sizeof(float) + (size_t)(nI + nT) * sizeof(int) + 16;
+            if (ldsw <= 128 * 1024) {
+                // 8 waves per CU are resident (register-bound): one 8-wave workgroup per CU; more workgroups only add rounds
+                // of global atomics on the shared parameters' 23 nI addresses at the end of each
+                const int64_t nwaves = (B + SPW - 1) / SPW, gq = (nwaves + NF_BWD_WAVE_WAVES - 1) / NF_BWD_WAVE_WAVES;
+                const int grid = (int)(gq < 2048 / NF_BWD_WAVE_WAVES ? gq : 2048 / NF_BWD_WAVE_WAVES);
+                static LdsOptIn opted = {};
+                if (opt_in_lds(reinterpret_cast<const void *>(&rqs_coupling_bwd_wave_kernel), ldsw, opted) != NF_OK)
+                    return NF_ENOTSUP;
+                hipLaunchKernelGGL(rqs_coupling_bwd_wave_kernel, dim3(grid), dim3(64 * NF_BWD_WAVE_WAVES), ldsw, st, (const float *)x,
+                                   (const float *)grad_y, (const float *)grad_logdet, (const float *)cond, (const float *)uw,
+                                   (const float *)uh, (const float *)ud, identity_idx, nI, transform_idx, nT, B, D, p, mode,
+                                   (float *)grad_x, (float *)grad_cond, (float *)grad_uw, (float *)grad_uh, (float *)grad_ud,
+                                   SPW);
+                NF_CHECK_LAUNCH();
+                return NF_OK;
+            }
+        }
         return launch_bwd<float>(x, grad_y, grad_logdet, cond, uw, uh, ud, identity_idx, nI, transform_idx, nT, B, D, p,
                                  mode, grad_x, grad_cond, grad_uw, grad_uh, grad_ud, st, tails_t, bound_t, tails_i, bound_i);
     }
