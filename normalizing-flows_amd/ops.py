@@ -323,7 +323,8 @@ def rqs_coupling_bwd(x, grad_y, grad_logdet, cond, uw, uh, ud, identity_idx, tra
                      bound_i)
     B, D = x.shape
     x, grad_y, grad_logdet = x.contiguous(), grad_y.contiguous(), grad_logdet.contiguous()
-    gx = torch.zeros_like(x)
+    # density mode owns (writes) every column of gx; the two sampling modes own one half and leave the rest zero
+    gx = torch.empty_like(x) if mode == L.RQS_DENSITY else torch.zeros_like(x)
     gcond = torch.empty_like(cond) if cond is not None else None
     guw = torch.zeros_like(uw) if uw is not None else None
     guh = torch.zeros_like(uh) if uh is not None else None
