@@ -231,7 +231,8 @@ class ConvNet2d(nn.Module):
 
     # below this many pixels per call the library path stays (the one-launch kernels are built for full-chip batches)
     FUSED_MIN_PIXELS = 2048
-    FUSED_WIDE_MIN_PIXELS = 128 * 256   # the 256-pixel-workgroup kernel wants >= 128 workgroups
+    FUSED_WIDE_MIN_PIXELS = 64 * 256    # the 256-pixel-workgroup kernel's run time does not depend on the batch (one
+                                        # round of workgroups): it overtakes the library path at about 64 workgroups
 
     def _fused_pack(self, x):
         """(packed weights, layout) for ops.glow_convnet when this is the GlowBlock network (3x3 -> 1x1 -> 3x3 around 256
