@@ -167,6 +167,48 @@ def cpu_baseline(model, rows, gpu_lp=None, gpu_lp3=None):
     return res
 
 
+def secondary(model, x):
+    """Untimed extras for the record (never part of `value`; any failure is reported, not raised): the other BASELINE
+    configurations through tools/config_bench.py and one training step of the benchmark model (forward_kld + backward +
+    Adam through the autograd path).  stdout of the helpers is swallowed: the contract is ONE JSON line."""
+    import contextlib
+    import importlib.util
+    import io
+    res = {}
+    try:
+        spec = importlib.util.spec_from_file_location("nf_config_bench", os.path.join(ROOT, "tools", "config_bench.py"))
+        cb = importlib.util.module_from_spec(spec)
+        with contextlib.redirect_stdout(io.StringIO()):
+            spec.loader.exec_module(cb)
+            for key, fn in (("config1_realnvp", cb.c1), ("config4_glow", cb.c4), ("config5_maf", cb.c5)):
+                try:
+                    res[key] = fn()
+                except Exception as exc:   # noqa: BLE001
+                    res[key] = {"error": repr(exc)[:200]}
+    except Exception as exc:   # noqa: BLE001
+        res["config_bench"] = {"error": repr(exc)[:200]}
+    try:
+        model.use_graphs(False)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+        steps = 4
+        for i in range(2 + steps):
+            if i == 2:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            opt.zero_grad(set_to_none=True)
+            loss = model.forward_kld(x)
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res["train_step"] = {"workload": "forward_kld + backward + Adam on the benchmark model and batch", "ms_per_step": dt * 1e3,
+                             "samples_per_s": x.shape[0] / dt, "loss": float(loss),
+                             "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
+    except Exception as exc:   # noqa: BLE001
+        res["train_step"] = {"error": repr(exc)[:200]}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,6 +219,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the untimed extra measurements (other BASELINE configs, "
+                    "training step) that rank 0 appends under \"secondary\" at N = 1")
     ap.add_argument("--cpu-rows", type=int, default=131072, help="rows of the same workload timed on the host oracle")
     args = ap.parse_args()
 
@@ -314,6 +358,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(model, args.cpu_rows, lp.cpu().numpy(),
                                                lp3.cpu().numpy() if not args.no_breakdown else None)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if world == 1 and not args.no_secondary:
+            out["secondary"] = secondary(model, x)
         print(json.dumps(out))
     if world > 1:
         barrier()   # rank 0's untimed extras are done: every rank tears the communicator down together

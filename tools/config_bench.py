@@ -44,9 +44,12 @@ def c1():
         g = timed(lambda: m.log_prob(x), 200)
         eps = torch.randn(1024, 2, device=dev)
         gs = timed(lambda: m.sample_from_noise(eps), 200)
+    res = {"workload": "BASELINE configs[0]: 4 x [MaskedAffineFlow + ActNorm], d=2, batch 1024", "log_prob_us_hipgraph": g * 1e6,
+           "log_prob_us_eager": e * 1e6, "sample_us_hipgraph": gs * 1e6, "nll_nats_per_dim": nll}
     print("config 1 RealNVP B=1024: log_prob eager %.1f us (%.2f M samples/s), hipGraph %.1f us (%.2f M samples/s); "
           "sample eager %.1f us, hipGraph %.1f us (%.2f M samples/s); NLL %.4f nats/dim" % (
               e * 1e6, 1024 / e / 1e6, g * 1e6, 1024 / g / 1e6, es * 1e6, gs * 1e6, 1024 / gs / 1e6, nll))
+    return res
 
 
 def c4():
@@ -72,9 +75,12 @@ def c4():
         es = timed(lambda: m.sample(256), 5)
         m.use_graphs(True)
         g = timed(lambda: m.log_prob(x), 10)
+    res = {"workload": "BASELINE configs[3]: Glow L=3, K=32, hidden 256, 32x32x3, batch 256", "log_prob_ms": g * 1e3,
+           "log_prob_ms_eager": e * 1e3, "sample_ms": es * 1e3, "images_per_s": 256 / g, "nll_nats_per_dim": nll}
     print("config 4 Glow L=3 K=32 B=256: log_prob eager %.1f ms (%.0f img/s), hipGraph %.1f ms (%.0f img/s); "
           "sample %.1f ms (%.0f img/s); NLL %.4f nats/dim (untrained, after ActNorm init)" % (
               e * 1e3, 256 / e, g * 1e3, 256 / g, es * 1e3, 256 / es, nll))
+    return res
 
 
 def c5():
@@ -93,6 +99,9 @@ def c5():
     err = float((zf - x).abs().max())
     print("config 5 MAF 10 layers d=128 B=65536: inverse pass %.1f ms (%.0f samples/s), forward pass %.1f ms, round-trip max err %.2e"
           % (dt * 1e3, 65536 / dt, dtf * 1e3, err))
+    return {"workload": "BASELINE configs[4]: 10 x MaskedAffineAutoregressive(128, hidden 512), batch 65536",
+            "inverse_pass_ms": dt * 1e3, "forward_pass_ms": dtf * 1e3, "inverse_samples_per_s": 65536 / dt,
+            "round_trip_max_abs_err": err}
 
 
 if __name__ == "__main__":
