@@ -208,20 +208,22 @@ __device__ __forceinline__ void gb_prologue(const GbFuse &fu, const float *__res
     }
 }
 
-// col2im of one output block: 9-term neighbour gather over the tap products in P, + bias; to HBM (plain call) or to the
-// LDS parameter planes prm[co][p] (fused block).
+// col2im of `nblk` consecutive output blocks starting at blk0 (their tap products at P + (b - blk0) 32 PXW): 9-term
+// neighbour gather, + bias; to HBM (plain call) or to the LDS parameter planes prm[co][p] (fused block).
 template <int PXW, int NT>
-__device__ __forceinline__ void gc_gather_block(const float *P, int blk, const GcMeta &mt, int H, int W, int64_t img0, int64_t B,
-                                                const float *small, float *__restrict__ out, float *prm, int tid) {
+__device__ __forceinline__ void gc_gather_block(const float *P, int blk0, const GcMeta &mt, int H, int W, int64_t img0, int64_t B,
+                                                const float *small, float *__restrict__ out, float *prm, int tid,
+                                                int nblk = 1) {
     const int HW = H * W;
-    for (int e = tid; e < 3 * PXW; e += NT) {
-        const int cc = e / PXW, p = e - cc * PXW;
-        const int co = 3 * blk + cc;
+    for (int e = tid; e < nblk * 3 * PXW; e += NT) {
+        const int bl = e / (3 * PXW), e3 = e - bl * 3 * PXW;
+        const int cc = e3 / PXW, p = e3 - cc * PXW;
+        const int co = 3 * (blk0 + bl) + cc;
         const int im = p / HW, q = p - im * HW, y = q / W, xq = q - y * W;
         const int64_t g = img0 + im;
         if (co < mt.Cout && (prm || g < B)) {
             float sum = small[2 * GC_HID + co];
-            const float *pr = P + (cc * 9) * PXW + p;
+            const float *pr = P + (bl * 32 + cc * 9) * PXW + p;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
@@ -636,22 +638,23 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
 // images again) and wave w computes rows [64 w, 64 w + 64) of h1 and h2 and a quarter of the output rows, for all 16
 // pixels.  Activations go through LDS in B-operand order acts[k / 16][(k / 4) % 4][pixel][k % 4] (one ds_read_b128 per
 // lane = the 4 B values of a 16-k block; one ds_write_b128 per lane stores a finished 16-row block), with a barrier
-// between the GEMMs.  Every wave streams only ITS rows' weights through a private 4-slot ring of 4 KB (no barrier in
-// the streaming loops).  256 workgroups x 4 waves fill every SIMD; each workgroup streams all weights once, so the
-// kernel is bound by the L2 -> LDS stream (0.93 MB per workgroup at the 4x4 level), not by MFMA issue.
+// between the GEMMs.  Every wave streams only ITS rows' weights, and each weight is used by exactly one wave of the
+// workgroup: the A operands come straight from L2 into registers (global_load_dwordx4, 16 units = 16 KB per wave in
+// flight; a first version went through private LDS-DMA rings and was bound by the ~25 GB/s per CU that path delivers).
+// 256 workgroups x 4 waves fill every SIMD; each workgroup streams all weights once (0.93 MB at the 4x4 level).
 constexpr int GT_PX = 16;
 constexpr int GT_NW = 4;
-constexpr int GT_RING = 4;         // slots per wave
-constexpr int GT_SLOT = 1024;      // floats per slot: 4 units of [64 lanes][4] = 16 rows x 64 k
+constexpr int GT_PF = 16;          // units (16 rows x 16 k = [64 lanes][4] = 1 KB) a wave keeps in flight
+constexpr int GT_SLOT = 1024;      // floats of 4 units (blob granularity)
 
 struct GtMeta {
-    int nkb1;    // 16-k blocks of GEMM 1, padded to a multiple of 4 (a slot = 4 blocks)
+    int nkb1;    // 16-k blocks of GEMM 1, padded to a multiple of 16 (the register prefetch advances 16 units at a time)
     int NB3;     // 16-row output blocks per wave = ceil(2 OB / 4)
     int slots;   // slots per wave = nkb1 + 16 + 4 NB3
 };
 __host__ __device__ inline GtMeta gt_meta(const GcMeta &m) {
     GtMeta t;
-    t.nkb1 = 4 * ((m.K1 + 63) / 64);
+    t.nkb1 = 16 * ((m.K1 + 255) / 256);
     t.NB3 = (2 * m.OB + 3) / 4;
     t.slots = t.nkb1 + 16 + 4 * t.NB3;
     return t;
@@ -708,8 +711,7 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
     const int HW = H * W, PH = H + 2, PW = W + 2, IPW = GT_PX / HW;
     const int K1p = 16 * tm.nkb1;
     const int p_floats = GT_NW * tm.NB3 * 16 * GT_PX, a_floats = K1p * GT_PX + GC_HID * GT_PX;
-    float *ring = smem;                                     // 4 waves x 4 slots x 4 KB
-    float *cols = ring + GT_NW * GT_RING * GT_SLOT;         // im2col columns in B-operand order (K1p x 16)
+    float *cols = smem;                                     // im2col columns in B-operand order (K1p x 16)
     float *h1s = cols + K1p * GT_PX;                        // h1 in B-operand order (256 x 16)
     float *P = cols;                                        // tap products: reuse cols + h1s once GEMM 2 is done
     float *h2s = cols + (p_floats > a_floats ? p_floats : a_floats);
@@ -722,6 +724,18 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t img0 = (int64_t)blockIdx.x * IPW;
 
+    // the wave's weight stream: units in consumption order; the first 16 go out before anything else
+    const f32x4 *stream = reinterpret_cast<const f32x4 *>(blob + gc_off_stages(mt) + (size_t)wid * tm.slots * GT_SLOT) + lane;
+    const int nunits = 4 * tm.slots;
+    // All workgroups walk the same stream: in lockstep every CU of an XCD would ask the L2 for the same line at the same
+    // moment.  Each workgroup therefore takes the 16 units of a group in its own rotation (register slot u holds unit
+    // (u + rot) mod 16 of the group; the sums over k are taken in that order).
+    const int rot = (int)((blockIdx.x * 5u) & (GT_PF - 1));
+    f32x4 pf[GT_PF];
+#pragma unroll
+    for (int i = 0; i < GT_PF; ++i) pf[i] = stream[(size_t)((i + rot) & (GT_PF - 1)) * 64];
+    int unit = 0;   // first unit of the group being consumed
+
     // ---- prologue (shared): biases, im2col offsets, padded images, im2col columns ----
     for (int i = tid; i < mt.small; i += 64 * GT_NW) small[i] = blob[GC_HDR + i];
     for (int k = tid; k < K1p; k += 64 * GT_NW) {
@@ -731,27 +745,6 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
     }
     if (fu.on) gb_prologue<GT_PX, 64 * GT_NW>(fu, x, out, zr, zm, xin, H, W, img0, B, tid);
     else gc_fill_xin_global<GT_PX, 64 * GT_NW>(x, xs_img, xin, mt.Cin, H, W, img0, B, tid);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the private rings' in-order accounting starts from an empty queue
-    // the wave's weight stream
-    const float *stream = blob + gc_off_stages(mt) + (size_t)wid * tm.slots * GT_SLOT + lane * 4;
-    float *ringw = ring + wid * GT_RING * GT_SLOT;
-    int slot = 0;
-    auto issue = [&](int s) {
-        const float *src = stream + (size_t)s * GT_SLOT;
-        float *dst = ringw + (s % GT_RING) * GT_SLOT;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            __builtin_amdgcn_global_load_lds(src + u * 256, (__attribute__((address_space(3))) void *)(dst + u * 256), 16, 0, 0);
-    };
-    auto acquire = [&]() -> const float * {
-        if (slot + GT_RING - 2 < tm.slots) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (GT_RING - 2)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (slot + GT_RING - 1 < tm.slots) issue(slot + GT_RING - 1);   // into the slot read one step ago (data already in VGPRs)
-        const float *buf = ringw + (slot % GT_RING) * GT_SLOT + lane * 4;
-        ++slot;
-        return buf;
-    };
-    issue(0); issue(1); issue(2);
     __syncthreads();
     for (int i = tid; i < K1p * GT_PX; i += 64 * GT_NW) {
         // element (kb, g', px, r) of the column block: k = 16 kb + 4 g' + r
@@ -761,27 +754,37 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
     }
     __syncthreads();
 
-    // acc (16 rows x 16 pixels) = sum over nkb 16-k blocks of A (the stream) x B (LDS, B-operand order); two accumulators
-    // alternate so that consecutive MFMAs are independent
+    // acc (16 rows x 16 pixels) = sum over nkb (a multiple of 16) 16-k blocks of A (the stream) x B (LDS, B-operand order);
+    // every consumed unit is replaced by the load of the unit 16 ahead; two accumulators alternate so that consecutive
+    // MFMAs are independent
     auto gemm_block = [&](const float *bsrc, int nkb, f32x4 &acc) {
-        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
-        for (int kb4 = 0; kb4 < nkb; kb4 += 4) {
-            const float *buf = acquire();
+        // four accumulators (one per r): a 16x16x4 MFMA has 40 cycles of dependent latency against 32 of issue, and the
+        // B operand of the NEXT unit is read from LDS while this unit's MFMAs run
+        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
+        auto bload = [&](int kb) { return *reinterpret_cast<const f32x4 *>(bsrc + ((kb * 4 + g) * GT_PX + j16) * 4); };
+        f32x4 b = bload(rot);
+        for (int kb0 = 0; kb0 < nkb; kb0 += GT_PF) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const f32x4 a = *reinterpret_cast<const f32x4 *>(buf + u * 256);
-                const f32x4 b = *reinterpret_cast<const f32x4 *>(bsrc + (((kb4 + u) * 4 + g) * GT_PX + j16) * 4);
-                if (u & 1) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc1 = GC_MFMA16(a[r], b[r], acc1);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc = GC_MFMA16(a[r], b[r], acc);
-                }
+            for (int u = 0; u < GT_PF; ++u) {
+                const f32x4 a = pf[u];
+                const int ur = (u + rot) & (GT_PF - 1);
+                const int nxt = unit + GT_PF + ur;
+                pf[u] = stream[(size_t)(nxt < nunits ? nxt : nunits - 1) * 64];
+                // B of the following unit (same group, or the first of the next group; clamped at the block's end)
+                const int kbn = u + 1 < GT_PF ? kb0 + ((u + 1 + rot) & (GT_PF - 1)) : kb0 + GT_PF + rot;
+                const f32x4 bn = bload(kbn < nkb ? kbn : rot);
+                __builtin_amdgcn_sched_barrier(0);   // keep both loads HERE: the scheduler otherwise sinks them to the group's end
+                acc = GC_MFMA16(a[0], b[0], acc);
+                acc1 = GC_MFMA16(a[1], b[1], acc1);
+                acc2 = GC_MFMA16(a[2], b[2], acc2);
+                acc3 = GC_MFMA16(a[3], b[3], acc3);
+                b = bn;
+                (void)ur;
             }
+            unit += GT_PF;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] += acc1[r];
+        for (int r = 0; r < 4; ++r) acc[r] += (acc1[r] + acc2[r]) + acc3[r];
     };
 
     // ---- GEMM 1 -> h1s ----
@@ -811,16 +814,15 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
         for (int r = 0; r < 4; ++r) P[(16 * o16 + 4 * g + r) * GT_PX + j16] = acc[r];
     }
     __syncthreads();
-    // ---- col2im over all output blocks ----
-    for (int blk = 0; blk < mt.OB; ++blk)
-        gc_gather_block<GT_PX, 64 * GT_NW>(P + blk * 32 * GT_PX, blk, mt, H, W, img0, B, small, out, fu.on ? prm : nullptr, tid);
+    // ---- col2im over all output blocks in one flat loop ----
+    gc_gather_block<GT_PX, 64 * GT_NW>(P, 0, mt, H, W, img0, B, small, out, fu.on ? prm : nullptr, tid, mt.OB);
     if (fu.on) gb_epilogue<GT_PX, 64 * GT_NW>(fu, out, zr, zm, prm, ldt, H, W, img0, B, tid);
 }
 
 static inline size_t gt_lds_bytes(const GcMeta &m, const GtMeta &t, int H, int W, const GbFuse &fu) {
     const int IPW = GT_PX / (H * W), K1p = 16 * t.nkb1;
     const int p_floats = GT_NW * t.NB3 * 16 * GT_PX, a_floats = K1p * GT_PX + GC_HID * GT_PX;
-    return ((size_t)GT_NW * GT_RING * GT_SLOT + (p_floats > a_floats ? p_floats : a_floats) + GC_HID * GT_PX +
+    return ((size_t)(p_floats > a_floats ? p_floats : a_floats) + GC_HID * GT_PX +
             gc_small_padded(m) + K1p + (size_t)IPW * m.Cin * (H + 2) * (W + 2) + gb_lds_floats(fu, m.Cout, GT_PX)) *
                sizeof(float) + 16;
 }
