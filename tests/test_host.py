@@ -90,7 +90,8 @@ def test_c_abi_argument_validation_newer_entry_points(nfa):
     assert lib.nf_glow_convnet_layout(i64(256), i32(8), i32(8)) == 1        # 64 such workgroups: the 64-pixel kernel
     assert lib.nf_glow_convnet_layout(i64(256), i32(4), i32(4)) == 2        # 4096 pixels: 16-pixel row-split workgroups
     assert lib.nf_glow_convnet_layout(i64(4), i32(16), i32(16)) == 0 and lib.nf_glow_convnet_layout(i64(4), i32(5), i32(5)) == -95
-    assert lib.nf_glow_convnet_pack_size(i32(6), i32(12), i32(256)) == 4 * (64 + 576 + (8 + 16 + 8) * 4096)
+    # one size for every layout: header + biases + max(32 stages of 16 KB, 4 waves x (16 + 16 + 4 x 2) slots of 4 KB)
+    assert lib.nf_glow_convnet_pack_size(i32(6), i32(12), i32(256)) == 4 * (64 + 576 + max((8 + 16 + 8) * 4096, 4 * 40 * 1024))
     assert lib.nf_glow_convnet_pack_size(i32(6), i32(12), i32(128)) == -95
     gc = lambda B, H, W, layout, slope=0.0, x=one: lib.nf_glow_convnet(x, i64(6 * H * W), one, one, i64(B), i32(6), i32(H),
                                                                      i32(W), i32(12), i32(256), f64(slope), i32(layout), null)
