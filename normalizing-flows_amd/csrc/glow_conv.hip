@@ -616,17 +616,33 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
         }
     }
 
-    // ---- col2im per output block ----
+    // ---- col2im: the weight ring is dead now; when all output blocks' tap products fit its 64 KB they go there at once
+    // and ONE flat gather follows (two barriers in all), otherwise block by block through P ----
+    if (mt.OB * 32 * GS_PX <= GS_RING * GC_STAGE) {
+        __syncthreads();   // every wave is done reading the last stage
 #pragma unroll
-    for (int blk = 0; blk < OBT; ++blk) {
-        if (blk < mt.OB) {
+        for (int blk = 0; blk < OBT; ++blk) {
+            if (blk < mt.OB) {
 #pragma unroll
-        for (int ob = 0; ob < 2; ++ob)
+                for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) P[(16 * ob + 4 * g + r) * GS_PX + px] = O[2 * blk + ob][r];
+                    for (int r = 0; r < 4; ++r) ring[(32 * blk + 16 * ob + 4 * g + r) * GS_PX + px] = O[2 * blk + ob][r];
+            }
+        }
         __syncthreads();
-        gc_gather_block<GS_PX, 64 * GS_NW>(P, blk, mt, H, W, img0, B, small, out, fu.on ? prm : nullptr, tid);
-        __syncthreads();
+        gc_gather_block<GS_PX, 64 * GS_NW>(ring, 0, mt, H, W, img0, B, small, out, fu.on ? prm : nullptr, tid, mt.OB);
+    } else {
+#pragma unroll
+        for (int blk = 0; blk < OBT; ++blk) {
+            if (blk < mt.OB) {
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) P[(16 * ob + 4 * g + r) * GS_PX + px] = O[2 * blk + ob][r];
+                __syncthreads();
+                gc_gather_block<GS_PX, 64 * GS_NW>(P, blk, mt, H, W, img0, B, small, out, fu.on ? prm : nullptr, tid);
+                __syncthreads();
+            }
         }
     }
     if (fu.on) gb_epilogue<GS_PX, 64 * GS_NW>(fu, out, zr, zm, prm, ldt, H, W, img0, B, tid);
