@@ -743,13 +743,11 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
     // the wave's weight stream: units in consumption order; the first 16 go out before anything else
     const f32x4 *stream = reinterpret_cast<const f32x4 *>(blob + gc_off_stages(mt) + (size_t)wid * tm.slots * GT_SLOT) + lane;
     const int nunits = 4 * tm.slots;
-    // All workgroups walk the same stream: in lockstep every CU of an XCD would ask the L2 for the same line at the same
-    // moment.  Each workgroup therefore takes the 16 units of a group in its own rotation (register slot u holds unit
-    // (u + rot) mod 16 of the group; the sums over k are taken in that order).
-    const int rot = (int)((blockIdx.x * 5u) & (GT_PF - 1));
+    // (A per-workgroup rotation of the unit order, to keep the CUs of an XCD from asking the L2 for the same line at the
+    // same moment, was measured: no gain -- and it made the summation order depend on the image's position in the batch.)
     f32x4 pf[GT_PF];
 #pragma unroll
-    for (int i = 0; i < GT_PF; ++i) pf[i] = stream[(size_t)((i + rot) & (GT_PF - 1)) * 64];
+    for (int i = 0; i < GT_PF; ++i) pf[i] = stream[(size_t)(i < nunits ? i : nunits - 1) * 64];
     int unit = 0;   // first unit of the group being consumed
 
     // ---- prologue (shared): biases, im2col offsets, padded images, im2col columns ----
@@ -778,24 +776,22 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
         // B operand of the NEXT unit is read from LDS while this unit's MFMAs run
         f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
         auto bload = [&](int kb) { return *reinterpret_cast<const f32x4 *>(bsrc + ((kb * 4 + g) * GT_PX + j16) * 4); };
-        f32x4 b = bload(rot);
+        f32x4 b = bload(0);
         for (int kb0 = 0; kb0 < nkb; kb0 += GT_PF) {
 #pragma unroll
             for (int u = 0; u < GT_PF; ++u) {
                 const f32x4 a = pf[u];
-                const int ur = (u + rot) & (GT_PF - 1);
-                const int nxt = unit + GT_PF + ur;
+                const int nxt = unit + GT_PF + u;
                 pf[u] = stream[(size_t)(nxt < nunits ? nxt : nunits - 1) * 64];
-                // B of the following unit (same group, or the first of the next group; clamped at the block's end)
-                const int kbn = u + 1 < GT_PF ? kb0 + ((u + 1 + rot) & (GT_PF - 1)) : kb0 + GT_PF + rot;
-                const f32x4 bn = bload(kbn < nkb ? kbn : rot);
+                // B of the following unit (clamped at the block's end)
+                const int kbn = kb0 + u + 1;
+                const f32x4 bn = bload(kbn < nkb ? kbn : 0);
                 __builtin_amdgcn_sched_barrier(0);   // keep both loads HERE: the scheduler otherwise sinks them to the group's end
                 acc = GC_MFMA16(a[0], b[0], acc);
                 acc1 = GC_MFMA16(a[1], b[1], acc1);
                 acc2 = GC_MFMA16(a[2], b[2], acc2);
                 acc3 = GC_MFMA16(a[3], b[3], acc3);
                 b = bn;
-                (void)ur;
             }
             unit += GT_PF;
         }
