@@ -229,6 +229,49 @@ def convnet2d(x, weights, biases, leaky=0.0):
     return h
 
 
+def glow_block(st, z, inverse, leaky=0.0, scale_map="sigmoid", init_actnorm=False):
+    """GlowBlock.forward / .inverse (affine/glow.py:72-84) = [AffineCouplingBlock(split "channel", ConvNet2d), Invertible1x1Conv,
+    ActNorm] composed from the oracle's layer functions; `st` = the block's state_dict as numpy arrays (ActNorm's s / t are
+    (re)initialised from `z` when init_actnorm is set and the call is the inverse: normalization.py:30-39 on the block input).
+    Returns (z', log_det (B,), st)."""
+    dt = z.dtype
+    z = _c(z, dt)
+    B, Cc = z.shape[:2]
+    HW = int(np.prod(z.shape[2:]))
+    ld = np.zeros(B, dt)
+    net = "flows.0.flows.1.param_map.net."
+    ws = [st[net + "%d.weight" % i] for i in (0, 2, 4)]
+    bs = [st[net + "%d.bias" % i] for i in (0, 2, 4)]
+    c1 = (Cc + 1) // 2
+
+    def coupling(v, direction):
+        param = convnet2d(np.ascontiguousarray(v[:, :c1]), ws, bs, leaky)
+        y, l = affine_coupling(v, param, c1, False, scale_map, direction)
+        return y, l
+
+    if inverse:
+        if init_actnorm:
+            mean, std = actnorm_stats(z)
+            s_, t_ = actnorm_init(mean, std, 1)
+            st = dict(st, **{"flows.2.s": s_.reshape(1, Cc, 1, 1), "flows.2.t": t_.reshape(1, Cc, 1, 1)})
+        z, l = actnorm(z, st["flows.2.s"], st["flows.2.t"], 1)
+        ld += l
+        W, ldu = inv1x1_assemble(st["flows.1.P"], st["flows.1.L"], st["flows.1.U"], st["flows.1.sign_S"], st["flows.1.log_S"], False)
+        z, l = inv1x1_conv(z, W, ldu)
+        ld += l
+        z, l = coupling(z, 1)
+        ld += l
+    else:
+        z, l = coupling(z, 0)
+        ld += l
+        W, ldu = inv1x1_assemble(st["flows.1.P"], st["flows.1.L"], st["flows.1.U"], st["flows.1.sign_S"], st["flows.1.log_S"], True)
+        z, l = inv1x1_conv(z, W, ldu)
+        ld += l
+        z, l = actnorm(z, st["flows.2.s"], st["flows.2.t"], 0)
+        ld += l
+    return z, ld, st
+
+
 def diag_gaussian_log_prob(z, loc, log_scale, ls_shift=0.0, out=None, acc=0):
     dt = z.dtype
     z = _c(z, dt)

@@ -289,3 +289,26 @@ def test_convnet2d(oracle, name, seed, cin, cout, leaky):
                              leaky)
     assert out64.dtype == np.float64
     assert_close(out64, g["out"].astype(np.float64), what="out f64", rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("name,seed,C,smap,leaky", [("glowblock256_C12_16x16", 41, 12, "sigmoid", 0.0), ("glowblock256_C24_8x8", 42, 24, "exp", 0.1),
+                                                    ("glowblock256_C48_4x4", 43, 48, "sigmoid_inv", 0.0), ("glowblock256_C5_4x4", 44, 5, "sigmoid", 0.0)])
+def test_glow_block_composite(oracle, name, seed, C, smap, leaky):
+    """The oracle's GlowBlock (conv conditioner + coupling + 1x1 conv + ActNorm with data-dependent initialisation) against
+    the reference's block at 256 hidden channels, both directions; weights = the seeded construction (checksum in the fixture)."""
+    import torch
+    import normflows_amd as nfa      # host-side module construction only
+    g = load_golden(name)
+    torch.manual_seed(seed)
+    blk = nfa.flows.GlowBlock(C, 256, scale_map=smap, leaky=leaky, init_zeros=False)
+    with torch.no_grad():
+        blk.flows[0].flows[1].param_map.net[-1].weight.mul_(0.2)
+    st = {k: v.detach().numpy() for k, v in blk.state_dict().items()}
+    x = g["x"]
+    _, _, st = oracle.glow_block(st, x, True, leaky, smap, init_actnorm=True)
+    zi, ldi, _ = oracle.glow_block(st, x, True, leaky, smap)
+    zf, ldf, _ = oracle.glow_block(st, x, False, leaky, smap)
+    assert_close(zi, g["z_inv"], what="z_inv", rtol=2e-4, atol=2e-4)
+    assert_close(ldi, g["ld_inv"], what="ld_inv", rtol=2e-4, atol=2e-3)
+    assert_close(zf, g["z_fwd"], what="z_fwd", rtol=2e-4, atol=2e-4)
+    assert_close(ldf, g["ld_fwd"], what="ld_fwd", rtol=2e-4, atol=2e-3)
