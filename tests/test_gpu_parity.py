@@ -420,6 +420,39 @@ def test_glow_convnet_kernels_vs_oracle(nfa, oracle, cin, cout, H, W, B, leaky):
     assert ran >= 1
 
 
+@pytest.mark.parametrize("C,H,W,B,smap,leaky", [(12, 16, 16, 2, "exp", 0.2), (7, 8, 8, 5, "sigmoid", 0.0), (10, 4, 4, 21, "sigmoid_inv", 0.05)])
+def test_glow_block_one_launch_vs_oracle(nfa, oracle, C, H, W, B, smap, leaky):
+    """nf_glow_block against the CPU oracle's GlowBlock composite on perturbed (non-default) parameters, both directions."""
+    torch.manual_seed(C + H)
+    blk = nfa.flows.GlowBlock(C, 256, scale_map=smap, leaky=leaky, init_zeros=False)
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            p_.add_(0.02 * torch.randn_like(p_))
+        blk.flows[0].flows[1].param_map.net[-1].weight.mul_(0.2)
+    blk = blk.to(DEV)
+    x = torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(3)).to(DEV)
+    cls = nfa.nets.ConvNet2d
+    saved = cls.FUSED_MIN_PIXELS, cls.FUSED_WIDE_MIN_PIXELS
+    with torch.no_grad():
+        try:
+            cls.FUSED_MIN_PIXELS = 1 << 40
+            blk.inverse(x)                                   # ActNorm initialisation, layer by layer
+            cls.FUSED_MIN_PIXELS, cls.FUSED_WIDE_MIN_PIXELS = 0, 0
+            assert blk._whole_block(x) is not None
+            zi, ldi = blk.inverse(x)
+            zf, ldf = blk.forward(x)
+        finally:
+            cls.FUSED_MIN_PIXELS, cls.FUSED_WIDE_MIN_PIXELS = saved
+    st = {k: N(v).astype(np.float64) for k, v in blk.state_dict().items()}
+    x64 = N(x).astype(np.float64)
+    ozi, oldi, _ = oracle.glow_block(st, x64, True, leaky, smap)
+    ozf, oldf, _ = oracle.glow_block(st, x64, False, leaky, smap)
+    assert_close(N(zi).astype(np.float64), ozi, what="z_inv", rtol=2e-4, atol=2e-4)
+    assert_close(N(ldi).astype(np.float64), oldi, what="ld_inv", rtol=2e-4, atol=2e-3)
+    assert_close(N(zf).astype(np.float64), ozf, what="z_fwd", rtol=2e-4, atol=2e-4)
+    assert_close(N(ldf).astype(np.float64), oldf, what="ld_fwd", rtol=2e-4, atol=2e-3)
+
+
 def test_glow_model_hidden256_vs_reference(nfa):
     """The config-4 architecture at its real width against the reference's log_prob (fixture: seeded construction on both
     sides), with every GlowBlock forced through the one-launch kernels (12 images: thresholds lowered for the test)."""
