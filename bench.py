@@ -130,7 +130,26 @@ def pmc_traffic():
         try:
             d = json.load(open(path))
             if "rqs_fused" in d.get("kernel", "") and "hbm_traffic_bytes" in d.get("derived", {}):
-                return d["derived"]["hbm_traffic_bytes"]
+                return d["derived"]["hbm_traffic_bytes"], "profiles/%s (static: committed rocprofv3 --pmc passes, not this run)" % os.path.basename(path)
+        except Exception:
+            pass
+    return None, None
+
+
+def reference_cpu_leg():
+    """The `kind: "reference"` leg: normflows itself (PyTorch CPU) timed by tools/cpu_reference.py in the build container --
+    /root/reference does not exist on the GPU box, so the committed JSON is reported, with where it was measured."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*cpu_reference.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            return {"value": d["log_prob"]["samples_per_s"], "unit": "samples/s", "cores": d["cores"], "kind": "reference",
+                    "where": d.get("where", "build container"), "cpu_model": d.get("cpu_model"), "torch": d.get("torch"),
+                    "sample": "normflows (PyTorch CPU, %d threads) log_prob of the same model on all %d benchmark rows, best of %d "
+                              "(%.1f s); tools/cpu_reference.py" % (d["torch_threads"], d["rows"], d["repeats"], d["log_prob"]["best_s"]),
+                    "nll_nats_per_dim": d["log_prob"]["nll_nats_per_dim"],
+                    "sample_direction_samples_per_s": d["sample"]["samples_per_s"],
+                    "source": "profiles/" + os.path.basename(path)}
         except Exception:
             pass
     return None
@@ -190,19 +209,22 @@ def secondary(model, x):
     try:
         model.use_graphs(False)
         opt = torch.optim.Adam(model.parameters(), lr=1e-4)
-        steps = 4
-        for i in range(2 + steps):
-            if i == 2:
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
+        steps, ts = 10, []
+        for i in range(3 + steps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
             opt.zero_grad(set_to_none=True)
             loss = model.forward_kld(x)
             loss.backward()
             opt.step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
+            torch.cuda.synchronize()
+            if i >= 3:
+                ts.append(time.perf_counter() - t0)
+        ts.sort()
+        dt = ts[len(ts) // 2]      # median of 10 individually synchronised steps (the mean is sensitive to allocator warm-up)
         res["train_step"] = {"workload": "forward_kld + backward + Adam on the benchmark model and batch", "ms_per_step": dt * 1e3,
-                             "samples_per_s": x.shape[0] / dt, "loss": float(loss),
+                             "ms_min": ts[0] * 1e3, "ms_max": ts[-1] * 1e3, "steps": steps, "statistic": "median",
+                             "samples_per_s": x.shape[0] / dt, "loss": float(loss.detach()),
                              "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
     except Exception as exc:   # noqa: BLE001
         res["train_step"] = {"error": repr(exc)[:200]}
@@ -310,9 +332,10 @@ def main():
                 # torch.zeros fill of log_q (one 256 KB memset).
                 fl = c2_flops_per_sample(layers=npairs) * args.batch
                 ach = fl / (chain_ms * 1e-3) / 1e12
-                tr = pmc_traffic()
+                tr, tr_src = pmc_traffic()
                 out["roofline"] = {"kernel": "nf::rqs_fused_kernel<0, true>", "bound": "mfma", "achieved": ach,
                                    "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": tr,
+                                   "traffic_source": tr_src,
                                    "flop_per_launch": fl, "avg_launch_ms": chain_ms, "layer_pairs_per_launch": npairs,
                                    "hbm_algorithmic_bytes_per_launch": (2 * DIM * 4 + 8) * args.batch}
         if not args.no_breakdown:
@@ -358,6 +381,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(model, args.cpu_rows, lp.cpu().numpy(),
                                                lp3.cpu().numpy() if not args.no_breakdown else None)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            ref_leg = reference_cpu_leg()
+            if ref_leg is not None:
+                out["cpu_baseline"]["reference"] = ref_leg
+                out["gpu_over_cpu_reference"] = value / ref_leg["value"]
         if world == 1 and not args.no_secondary:
             out["secondary"] = secondary(model, x)
         print(json.dumps(out))

@@ -18,6 +18,13 @@ from . import _lib as L
 from . import ops
 
 
+def refuse_grad(what, *tensors_or_modules):
+    """Layers without a training path fail loudly instead of silently cutting the autograd graph."""
+    if needs_grad(*tensors_or_modules):
+        raise NotImplementedError("%s has no differentiable path in normflows_amd (inference kernels only): call it under "
+                                  "torch.no_grad() or freeze its parameters and inputs" % what)
+
+
 def needs_grad(*tensors_or_modules):
     if not torch.is_grad_enabled():
         return False

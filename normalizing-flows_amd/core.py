@@ -153,7 +153,8 @@ def run_chain(flows, z, inverse, ld, acc):
         return zz
 
     rn_ok = (z.dim() == 2 and z.dtype == torch.float32 and z.is_cuda and z.shape[1] <= 16
-             and not (torch.is_grad_enabled() and any(p.requires_grad for f_ in flows for p in f_.parameters())))
+             and not (torch.is_grad_enabled() and (z.requires_grad
+                                                   or any(p.requires_grad for f_ in flows for p in f_.parameters()))))
     while k < n:
         i = order[k]
         f = flows[i]
@@ -186,12 +187,39 @@ def run_chain(flows, z, inverse, ld, acc):
     return flush(z)
 
 
-class _GraphCache:
-    """hipGraph replay of a fixed-shape pass.  Inputs are copied into a static buffer; outputs are static."""
+def _cached_tensors(obj, out, depth=0):
+    if torch.is_tensor(obj):
+        out.append(obj)
+    elif isinstance(obj, (tuple, list)) and depth < 4:
+        for o in obj:
+            _cached_tensors(o, out, depth + 1)
+    elif isinstance(obj, dict) and depth < 4:
+        for o in obj.values():
+            _cached_tensors(o, out, depth + 1)
 
-    def __init__(self):
+
+def _packed_blobs(owner):
+    """Every tensor held by a `*_cache` attribute of the modules under `owner` (packed weight blobs keyed by parameter
+    version) and by the RealNVP chain cache: what a recorded graph has baked pointers to."""
+    out = []
+    if owner is not None:
+        for m in owner.modules():
+            for k, v in m.__dict__.items():
+                if k.endswith("_cache"):
+                    _cached_tensors(v, out)
+    _cached_tensors(list(_realnvp_cache.values()), out)
+    return out
+
+
+class _GraphCache:
+    """hipGraph replay of a fixed-shape pass.  Inputs are copied into a static buffer; outputs are static.  The entry
+    keeps the packed weight blobs it was captured with alive, so a replay after a repack reads stale -- never freed --
+    memory (parameters are meant to be frozen while graphs are on; refresh_graphs() re-captures)."""
+
+    def __init__(self, owner=None):
         self.enabled = False
         self.graphs = {}
+        self.owner = None if owner is None else __import__("weakref").ref(owner)
 
     def clear(self):
         self.graphs = {}
@@ -211,13 +239,17 @@ class _GraphCache:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 static_out = fn(*static_in)
-            entry = (g, static_in, static_out)
+            entry = (g, static_in, static_out, _packed_blobs(self.owner() if self.owner is not None else None))
             self.graphs[key] = entry
-        g, static_in, static_out = entry
+        g, static_in, static_out = entry[:3]
         for dst, src in zip(static_in, inputs):
             dst.copy_(src)
         g.replay()
-        return static_out
+        # fresh tensors per call: a caller that keeps results of several replays (lps.append(model.log_prob(x))) must not
+        # see them all alias the graph's static output
+        if torch.is_tensor(static_out):
+            return static_out.clone()
+        return tuple(t.clone() if torch.is_tensor(t) else t for t in static_out)
 
 
 class NormalizingFlow(nn.Module):
@@ -228,7 +260,7 @@ class NormalizingFlow(nn.Module):
         self.q0 = q0
         self.flows = nn.ModuleList(flows)
         self.p = p
-        self._graphs = _GraphCache()
+        self._graphs = _GraphCache(self)
 
     # -- MI355X extensions ---------------------------------------------------------------------------------
     def use_graphs(self, mode=True):
@@ -391,7 +423,19 @@ class ConditionalNormalizingFlow(NormalizingFlow):
         return -torch.mean(self.log_prob(x, context=context))
 
     def reverse_kld(self, num_samples=1, context=None, beta=1.0, score_fn=True):
+        """core.py:338-366; score_fn=False re-evaluates log q with the parameters frozen, as the reference does."""
         z, log_q = self.sample(num_samples, context=context)
+        if not score_fn:
+            req = [p_.requires_grad for p_ in self.parameters()]
+            for p_ in self.parameters():
+                p_.requires_grad_(False)
+            log_q = torch.zeros(len(z), dtype=z.dtype, device=z.device)
+            z_ = z
+            for i in range(len(self.flows) - 1, -1, -1):
+                z_ = run_flow(self.flows[i], z_, True, log_q, +1, context=context)
+            log_q = log_q + self.q0.log_prob(z_, context=context)
+            for p_, r in zip(self.parameters(), req):
+                p_.requires_grad_(r)
         log_p = self.p.log_prob(z, context=context)
         return torch.mean(log_q) - beta * torch.mean(log_p)
 
@@ -407,19 +451,36 @@ class MultiscaleFlow(nn.Module):
         self.merges = torch.nn.ModuleList(merges)
         self.transform = transform
         self.class_cond = class_cond
-        self._graphs = _GraphCache()
+        self._graphs = _GraphCache(self)
 
     def use_graphs(self, mode=True):
-        """Replay log_prob (without class labels) as a hipGraph per input shape: a Glow pass is hundreds of small
-        launches (3 per GlowBlock + the conv conditioner), i.e. launch-bound when issued eagerly."""
+        """Replay log_prob (without class labels) as a hipGraph per input shape: a Glow pass is ~100 small launches, i.e.
+        launch-bound when issued eagerly.
+
+        A recorded graph holds the device pointers of the packed weights it was captured with (ConvNet2d / GlowBlock /
+        Invertible1x1Conv blobs, keyed by parameter version): an inference feature for FROZEN parameters.  Graphs are
+        dropped by use_graphs(), .to()/.double(), load_state_dict() and train(); after changing parameters in place (an
+        optimizer step) call refresh_graphs().  The blobs a graph was captured with stay referenced by the graph entry,
+        so a stale replay can never read freed memory."""
         self._graphs.enabled = bool(mode)
-        if not mode:
-            self._graphs.clear()
+        self._graphs.clear()
+        return self
+
+    def refresh_graphs(self):
+        self._graphs.clear()
         return self
 
     def _apply(self, fn, *a, **k):
         self._graphs.clear()
         return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._graphs.clear()
+        return super().load_state_dict(*a, **k)
+
+    def train(self, mode=True):
+        self._graphs.clear()
+        return super().train(mode)
 
     def forward_kld(self, x, y=None):
         return -torch.mean(self.log_prob(x, y))
@@ -474,6 +535,22 @@ class MultiscaleFlow(nn.Module):
             z = run_flow(self.transform, z, False, log_q, -1)
         if temperature is not None:
             self.reset_temperature()
+        return z, log_q
+
+    def sample_from_noise(self, eps):
+        """sample() (core.py:553-586) with the base noise of every level given: `eps[i]` has the shape of q0[i]'s sample
+        (deterministic; used by the parity tests against reference fixtures).  DiagGaussian bases only."""
+        for i in range(len(self.q0)):
+            z_, log_q_ = self.q0[i].from_noise(eps[i])
+            if i == 0:
+                log_q, z = log_q_, z_
+            else:
+                log_q = log_q + log_q_
+                z, _ = self.merges[i - 1]([z, z_])
+            for flow in self.flows[i]:
+                z = run_flow(flow, z, False, log_q, -1)
+        if self.transform is not None:
+            z = run_flow(self.transform, z, False, log_q, -1)
         return z, log_q
 
     def log_prob(self, x, y=None):

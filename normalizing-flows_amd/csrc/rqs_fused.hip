@@ -402,7 +402,7 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     {
         const float *tabs = small + lay.off_tables();
 #pragma unroll
-        for (int Q = 0; Q < 4; ++Q)
+        for (int Q = 0; Q < 4; ++Q) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = 8 * Q + 2 * r + par_i;
@@ -418,6 +418,11 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
                     bx[4 * Q + r] = xi;
                 }
             }
+        }
+        // sample direction: the 16 log-det terms must be FINISHED here.  Nothing reads `ld` before the end of the layer, so
+        // the compiler otherwise sinks the two logs of every element below the conditioner and carries their operands
+        // (4 values x 16 elements) across all the MFMA phases: 75 spilled VGPRs, 304 B of scratch per lane.
+        if (DIR == 1) asm volatile("" : "+v"(ld));
     }
 
     // ---- initial layer: H = W0 xi + b0 (K = 32: 4 row-blocks x 4 k-groups in ONE stage) ----

@@ -375,6 +375,8 @@ rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *_
                     bx[4 * Q + r] = xi;
                 }
             }
+        // the log-det terms are finished here (see rqs_fused.hip: otherwise their operands stay live across the MFMA phases)
+        if (DIR == 1) asm volatile("" : "+v"(ld));
     }
 
     // ---- initial layer (K = 32: two K steps, each stage = 4 row-blocks x 3 splits) ----

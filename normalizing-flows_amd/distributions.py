@@ -135,7 +135,15 @@ class ClassCondDiagGaussian(BaseDistribution):
             num_samples = len(y)
         else:
             y = torch.randint(self.num_classes, (num_samples,), device=self.loc.device)
-        loc_r, ls_r, idx = self._select(y, num_samples)
+        grad = needs_grad(self.loc, self.log_scale)
+        if grad:                         # differentiable rows (the cached copies are detached)
+            d = int(self.d)
+            loc_r, ls_r = self.loc.reshape(d, self.num_classes).t(), self.log_scale.reshape(d, self.num_classes).t()
+            idx = y if y.dim() == 1 else None
+            if idx is None:
+                loc_r, ls_r = y.to(loc_r.dtype) @ loc_r, y.to(loc_r.dtype) @ ls_r
+        else:
+            loc_r, ls_r, idx = self._select(y, num_samples)
         eps = torch.randn((num_samples,) + self.shape, dtype=self.loc.dtype, device=self.loc.device)
         if idx is not None:
             loc_b, ls_b = loc_r[idx], ls_r[idx]
@@ -143,6 +151,9 @@ class ClassCondDiagGaussian(BaseDistribution):
             loc_b, ls_b = loc_r, ls_r
         ls_b = (ls_b + self._shift()).view((num_samples,) + self.shape)
         z = loc_b.view((num_samples,) + self.shape) + torch.exp(ls_b) * eps
+        if grad:                         # reparametrised sample: closed form under autograd (base.py:296-316)
+            log_p = -0.5 * self.d * np.log(2 * np.pi) - (ls_b + 0.5 * eps ** 2).reshape(num_samples, -1).sum(1)
+            return z, log_p
         zeros = torch.zeros(1, int(self.d), dtype=z.dtype, device=z.device)
         log_p = ops.diag_gaussian_log_prob(eps, zeros, zeros, 0.0) - ls_b.reshape(num_samples, -1).sum(1)
         return z, log_p
@@ -219,12 +230,17 @@ class GlowBase(BaseDistribution):
                 num_samples = len(y)
             else:
                 y = torch.randint(self.num_classes, (num_samples,), device=self.loc.device)
-        loc, ls, idx = self._channel_params(y, num_samples)
+        grad = needs_grad(*self.parameters())
+        loc, ls, idx = self._channel_params(y, num_samples, detach=not grad)
         if idx is not None:
             loc, ls = loc[idx], ls[idx]
         pshape = (num_samples, self.shape[0]) + (self.n_dim - 1) * (1,)
         eps = torch.randn((num_samples,) + self.shape, dtype=self.loc.dtype, device=self.loc.device)
         z = loc.view(pshape) + torch.exp(ls.view(pshape)) * eps
+        if grad:                        # reparametrised sample: closed form under autograd (base.py:430-448)
+            log_p = (-0.5 * self.d * np.log(2 * np.pi) - self.num_pix * ls.sum(1)
+                     - 0.5 * (eps ** 2).reshape(num_samples, -1).sum(1))
+            return z, log_p
         zeros = torch.zeros(1, int(self.d), dtype=z.dtype, device=z.device)
         log_p = ops.diag_gaussian_log_prob(eps, zeros, zeros, 0.0) - self.num_pix * ls.sum(1)
         return z, log_p

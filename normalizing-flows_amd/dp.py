@@ -1,8 +1,7 @@
 """Data-parallel evaluation of the hot path: one process per GPU, batch sharded by rows, weights replicated.
 
 The path is embarrassingly parallel over samples: no data-path collective.  The only
-exchange is ONE all-reduce of sum log_q (fp64, 8 bytes; the row counts are exchanged once per batch shape) per
-evaluated batch for the NLL -- RCCL over
+exchange is ONE all-reduce of the fp64 pair [sum log_q, row count] (16 bytes) per evaluated batch for the NLL -- RCCL over
 xGMI when the process group backend is "nccl", gloo in the CPU tests.  The reference has no distributed code
 (`grep torch.distributed normflows/` is empty); semantics are those of core.py:87-102 `-mean(log_q)` over the
 GLOBAL batch.
@@ -28,29 +27,16 @@ def shard_rows(x, world_size=None, rank=None):
     return x[lo:hi]
 
 
-_count_cache = {}
-
-
-def _global_count(n_local, device, group=None):
-    """Total number of rows over all ranks; all-reduced once per (local count, group) and remembered."""
-    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
-        return float(n_local)
-    key = (n_local, id(group), dist.get_world_size(group))
-    if key not in _count_cache:
-        c = torch.tensor([float(n_local)], dtype=torch.float64, device=device)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
-        _count_cache[key] = float(c.item())
-    return _count_cache[key]
-
-
 def global_nll(log_q_local, group=None):
-    """-mean(log_q) over all ranks' rows: per call ONE all_reduce(SUM) of the fp64 sum of log_q (8 bytes; the row
-    counts are exchanged once per batch shape), i.e. two small kernels around the collective."""
-    n = _global_count(log_q_local.numel(), log_q_local.device, group)
+    """-mean(log_q) over all ranks' rows: per call ONE all_reduce(SUM) of the fp64 pair [sum log_q, row count] (16 bytes).
+    The count travels with the sum on every call -- shards may be uneven and may change from call to call, so nothing is
+    cached (a cached count keyed by the local row count would desynchronise the ranks' collectives)."""
     s = log_q_local.sum(dtype=torch.float64)
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
-    return s * (-1.0 / n)
+        packed = torch.stack([s, torch.full((), float(log_q_local.numel()), dtype=torch.float64, device=s.device)])
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        return -packed[0] / packed[1]
+    return s * (-1.0 / max(log_q_local.numel(), 1))
 
 
 def sharded_forward_kld(log_prob_fn, x_local, group=None):

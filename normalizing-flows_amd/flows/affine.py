@@ -10,7 +10,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from ..autograd import ActNormFn, AffineCouplingFn, MaskedAffineFn, needs_grad
+from ..autograd import ActNormFn, AffineCouplingFn, MaskedAffineFn, needs_grad, refuse_grad
 from .base import Flow, run_flow
 from .reshape import Merge, Split
 
@@ -98,6 +98,7 @@ class CCAffineConst(Flow):
         return s.expand_as(z).contiguous(), t.expand_as(z).contiguous()
 
     def _transform(self, z, y, direction, ld=None, acc=None):
+        refuse_grad("CCAffineConst", z, self)
         s, t = self._st(z, y)
         zero = torch.zeros(z.shape[1:], dtype=z.dtype, device=z.device)
         return ops.masked_affine(z, zero, s, t, direction, logdet=ld, acc=acc)

@@ -12,7 +12,7 @@ from torch import nn
 from torch.nn import init
 
 from .. import ops
-from ..autograd import LULinearPermuteFn, needs_grad
+from ..autograd import LULinearPermuteFn, needs_grad, refuse_grad
 from .base import Flow
 
 
@@ -180,6 +180,7 @@ class InvertibleAffine(Flow):
     def _mul(self, z, inverse_dir, ld=None, acc=None, want_scalar=True):
         if z.dim() != 2:
             raise NotImplementedError("InvertibleAffine: (batch, channels) inputs")
+        refuse_grad("InvertibleAffine", z, self)
         Wt, ldu = self._weight_t(inverse_dir)
         y, lds = ops.inv1x1_conv(z.reshape(z.shape[0], -1, 1, 1), Wt, ldu, logdet=ld, acc=acc, want_scalar=want_scalar)
         return y.view(z.shape), lds

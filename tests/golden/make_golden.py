@@ -809,6 +809,59 @@ def gen_glow_model256():
     npz("model_glow_c4_hidden256", x=x, log_prob_first=lp0, log_prob=lp, checksum=chk)
 
 
+def gen_glow_model_full():
+    """BASELINE configs[3] at FULL depth (L = 3, K = 32 blocks per level, hidden 256, 32x32x3; core.py:588-616 over
+    affine/glow.py:72-84): reference log_prob of 8 images on the first call (data-dependent ActNorm initialisation of all
+    96 blocks, normalization.py:19-39) and on the second call, and the sampling direction (core.py:553-586) on fixed
+    per-level base noise: x and log_q.  Only inputs / outputs / a weight checksum are stored; both sides construct the
+    weights from the seed."""
+    m = build_glow_c4(nf, 3, 32, 256, seed=63)
+    x = torch.rand(8, 3, 32, 32, generator=torch.Generator().manual_seed(64))
+    with torch.no_grad():
+        lp0 = m.log_prob(x)
+        lp = m.log_prob(x)
+        g = torch.Generator().manual_seed(65)
+        eps = [torch.randn((8,) + tuple(q.shape), generator=g) for q in m.q0]
+        for i, q in enumerate(m.q0):     # MultiscaleFlow.sample with the base noise given (distributions/base.py:80-92)
+            z_ = q.loc + torch.exp(q.log_scale) * eps[i]
+            lq_ = -0.5 * q.d * np.log(2 * np.pi) - torch.sum(q.log_scale + 0.5 * eps[i] ** 2, dim=(1, 2, 3))
+            if i == 0:
+                log_q, z = lq_, z_
+            else:
+                log_q = log_q + lq_
+                z, _ = m.merges[i - 1]([z, z_])
+            for flow in m.flows[i]:
+                z, ld = flow(z)
+                log_q = log_q - ld
+        lps = m.log_prob(z)
+    chk = torch.stack([p_.double().abs().sum() for p_ in m.parameters()]).sum()
+    npz("model_glow_c4_full", x=x, log_prob_first=lp0, log_prob=lp, checksum=chk, eps0=eps[0], eps1=eps[1], eps2=eps[2],
+        sample=z, sample_logq=log_q, log_prob_of_sample=lps)
+
+
+def gen_maf_model_full():
+    """BASELINE configs[4] as a MODEL: 10 x MaskedAffineAutoregressive(128, 512, num_blocks=2) under a DiagGaussian base
+    (core.py:182-197 over affine/autoregressive.py:29-38, 98-128), 64 rows: `inverse` direction of every layer
+    (= log_prob: one MADE pass per layer... the reference's NormalizingFlow.log_prob calls flow.inverse = the D-pass loop),
+    the `forward` direction (sampling from fixed noise) and both log-densities.  Weights by seeded construction + the
+    seeded perturbation below on both sides; the fixture carries a checksum."""
+    torch.manual_seed(2000)
+    flows = [nf.flows.MaskedAffineAutoregressive(128, 512, num_blocks=2) for _ in range(10)]
+    m = nf.NormalizingFlow(nf.distributions.DiagGaussian(128, trainable=False), flows)
+    perturb(m, 0.02, 9)
+    g = torch.Generator().manual_seed(2001)
+    x = torch.randn(64, 128, generator=g)
+    eps = torch.randn(64, 128, generator=g)
+    with torch.no_grad():
+        z_inv, ld_inv = m.inverse_and_log_det(x)      # 10 x the 128-pass inverse
+        lp = m.log_prob(x)
+        z_fwd, ld_fwd = m.forward_and_log_det(eps)    # 10 x one MADE pass
+        logq = m.q0.log_prob(eps) - ld_fwd
+    chk = torch.stack([p_.double().abs().sum() for p_ in m.parameters()]).sum()
+    npz("model_maf_c5_full", x=x, eps=eps, z_inv=z_inv, ld_inv=ld_inv, log_prob=lp, z_fwd=z_fwd, ld_fwd=ld_fwd,
+        sample_logq=logq, checksum=chk)
+
+
 def gen_cdf():
     """Standalone PiecewiseRationalQuadraticCDF (nsf/coupling.py:170-259): 1-D and N-D parameter shapes, every tails
     variant, values and reference-autograd gradients in both directions."""
@@ -897,6 +950,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "circular":
         gen_circular()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "full_models":
+        gen_glow_model_full()
+        gen_maf_model_full()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "glow_model256":
         gen_glow_model256()
         sys.exit(0)
@@ -947,3 +1004,5 @@ if __name__ == "__main__":
     gen_glow_convnet()
     gen_glow_block256()
     gen_glow_model256()
+    gen_glow_model_full()
+    gen_maf_model_full()

@@ -478,8 +478,104 @@ def test_glow_model_hidden256_vs_reference(nfa):
             lp = m.log_prob(x)
         finally:
             cls.FUSED_MIN_PIXELS, cls.FUSED_WIDE_MIN_PIXELS = saved
-    assert _rel(N(lp0), g["log_prob_first"]) < 2e-4, _rel(N(lp0), g["log_prob_first"])
-    assert _rel(N(lp), g["log_prob"]) < 2e-4, _rel(N(lp), g["log_prob"])
+    assert _rel(N(lp0), g["log_prob_first"]) < 1e-4, _rel(N(lp0), g["log_prob_first"])   # north_star: fp32 log_prob <= 1e-4 rel
+    assert _rel(N(lp), g["log_prob"]) < 1e-4, _rel(N(lp), g["log_prob"])
+
+
+def _glow_c4_builder():
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden.py")
+    src = open(path).read()
+    ns = {"torch": torch}
+    exec(src[src.index("def build_glow_c4("):src.index("def gen_glow_model256(")], ns)   # the shared model builder only
+    return ns["build_glow_c4"]
+
+
+@pytest.mark.parametrize("force_block_kernels", [False, True])
+def test_glow_config4_full_depth_vs_reference(nfa, force_block_kernels):
+    """BASELINE configs[3] at FULL depth -- MultiscaleFlow L = 3, K = 32 blocks per level, hidden 256, 32x32x3 -- against the
+    reference (core.py:588-616, :553-586; fixture model_glow_c4_full: seeded construction on both sides, 8 images):
+    log_prob on the first call (data-dependent ActNorm initialisation of all 96 blocks), log_prob on the second call, and
+    the sampling direction on fixed per-level base noise.  96 blocks of fp32 accumulation at the north-star bar of 1e-4
+    relative; once with the library's own dispatch, once with every GlowBlock forced through the one-launch kernels."""
+    g = load_golden("model_glow_c4_full")
+    m = _glow_c4_builder()(nfa, 3, 32, 256, seed=63).to(DEV)
+    x = T(g["x"])
+    cls = nfa.nets.ConvNet2d
+    saved = cls.FUSED_MIN_PIXELS, cls.FUSED_WIDE_MIN_PIXELS
+    try:
+        if force_block_kernels:
+            cls.FUSED_MIN_PIXELS, cls.FUSED_WIDE_MIN_PIXELS = 0, 0
+        lp0 = m.log_prob(x)          # ActNorm initialisation
+        chk = float(sum(p_.double().abs().sum() for p_ in m.parameters()))
+        if force_block_kernels:
+            assert all(b._whole_block(torch.empty(8, *shape, device=DEV)) is not None
+                       for fl, shape in zip(m.flows, ((48, 4, 4), (24, 8, 8), (12, 16, 16))) for b in fl[:-1])
+        lp = m.log_prob(x)
+        xs, lq = m.sample_from_noise([T(g["eps0"]), T(g["eps1"]), T(g["eps2"])])
+        lps = m.log_prob(xs)
+    finally:
+        cls.FUSED_MIN_PIXELS, cls.FUSED_WIDE_MIN_PIXELS = saved
+    assert _rel(N(lp0), g["log_prob_first"]) < 1e-4, _rel(N(lp0), g["log_prob_first"])
+    # the initialisation wrote the same ActNorm parameters as the reference's (checksum of every parameter after it)
+    assert abs(chk - float(g["checksum"])) < 1e-5 * abs(chk), (chk, float(g["checksum"]))
+    assert _rel(N(lp), g["log_prob"]) < 1e-4, _rel(N(lp), g["log_prob"])
+    assert_close(N(xs), g["sample"], what="sample", rtol=1e-4, atol=1e-4)
+    assert _rel(N(lq), g["sample_logq"]) < 1e-4, _rel(N(lq), g["sample_logq"])
+    assert _rel(N(lps), N(lq)) < 1e-4, _rel(N(lps), N(lq))          # core_test.py:144-196
+
+
+def test_maf_config5_full_model_vs_reference(nfa):
+    """BASELINE configs[4] as a MODEL: 10 x MaskedAffineAutoregressive(128, 512) under a DiagGaussian base against the
+    reference (core.py:182-197 over affine/autoregressive.py:29-38, 98-128; fixture model_maf_c5_full, 64 rows):
+    inverse direction (the reference's 128-pass loop per layer; here one nf_maf_inverse launch per layer), log_prob, the
+    forward direction on fixed noise and its log_q."""
+    g = load_golden("model_maf_c5_full")
+    torch.manual_seed(2000)
+    flows = [nfa.flows.MaskedAffineAutoregressive(128, 512, num_blocks=2) for _ in range(10)]
+    m = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(128, trainable=False), flows)
+    _perturb(m, 0.02, 9)
+    chk = float(sum(p_.double().abs().sum() for p_ in m.parameters()))
+    assert abs(chk - float(g["checksum"])) < 1e-6 * abs(chk)
+    m = m.to(DEV)
+    z, ld = m.inverse_and_log_det(T(g["x"]))
+    assert_close(N(z), g["z_inv"], what="z_inv", rtol=2e-4, atol=2e-4)
+    assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=1e-4, atol=1e-4)
+    assert _rel(N(m.log_prob(T(g["x"]))), g["log_prob"]) < 2e-4
+    zf, ldf = m.forward_and_log_det(T(g["eps"]))
+    assert_close(N(zf), g["z_fwd"], what="z_fwd", rtol=1e-4, atol=1e-4)
+    assert_close(N(ldf), g["ld_fwd"], what="ld_fwd", rtol=1e-4, atol=1e-4)
+    xs, lq = m.sample_from_noise(T(g["eps"]))
+    assert _rel(N(lq), g["sample_logq"]) < 1e-4
+
+
+def test_multiscale_graphs_follow_parameter_reloads_and_do_not_alias(nfa):
+    """MultiscaleFlow.use_graphs: results of successive replays are separate tensors, and load_state_dict / train() /
+    refresh_graphs() drop recorded graphs so that a replay never evaluates stale packed weights."""
+    m = _glow_c4_builder()(nfa, 3, 2, 256, seed=5).to(DEV)
+    x1 = torch.rand(16, 3, 32, 32, device=DEV)
+    x2 = torch.rand(16, 3, 32, 32, device=DEV)
+    m.log_prob(x1)                                  # ActNorm initialisation
+    e1, e2 = N(m.log_prob(x1)), N(m.log_prob(x2))
+    m.use_graphs(True)
+    outs = [m.log_prob(x1), m.log_prob(x2)]         # second replay must not overwrite the first result
+    assert np.array_equal(N(outs[0]), e1) and np.array_equal(N(outs[1]), e2)
+    sd2 = {k: (v * 1.01 if v.is_floating_point() and v.dim() > 0 and "flows" in k and k.endswith(".t") else v)
+           for k, v in m.state_dict().items()}
+    m.load_state_dict(sd2)                          # drops the graphs
+    g3 = N(m.log_prob(x1))
+    m.use_graphs(False)
+    assert np.array_equal(g3, N(m.log_prob(x1)))
+    assert not np.array_equal(g3, e1)
+    # in-place update + refresh_graphs()
+    m.use_graphs(True)
+    m.log_prob(x1)
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.mul_(0.999)
+    m.refresh_graphs()
+    g4 = N(m.log_prob(x1))
+    m.use_graphs(False)
+    assert np.array_equal(g4, N(m.log_prob(x1)))
 
 
 def test_glow_config4_shapes_through_the_block_kernels(nfa):
@@ -640,12 +736,12 @@ def test_model_c4mini_glow_vs_reference(nfa):
     m.load_state_dict({k: torch.from_numpy(v) for k, v in golden_state(g, "sd0__").items()}, strict=True)
     m = m.to(DEV)
     lp = N(m.log_prob(T(g["x"])))
-    assert _rel(lp, g["log_prob"]) < 2e-4, _rel(lp, g["log_prob"])
-    assert _rel(N(m.log_prob(T(g["x"]))), g["log_prob_second"]) < 2e-4
+    assert _rel(lp, g["log_prob"]) < 1e-4, _rel(lp, g["log_prob"])
+    assert _rel(N(m.log_prob(T(g["x"]))), g["log_prob_second"]) < 1e-4
     # sample / log_prob consistency (core_test.py:144-196)
     torch.manual_seed(0)
     xs, lq = m.sample(8)
-    assert _rel(N(m.log_prob(xs)), N(lq)) < 1e-3
+    assert _rel(N(m.log_prob(xs)), N(lq)) < 1e-4, _rel(N(m.log_prob(xs)), N(lq))
 
 
 def test_drop_in_under_reference_style_container(nfa):
@@ -708,6 +804,23 @@ def test_fused_layer_vs_unfused_and_oracle(nfa, oracle, reverse_mask, B):
         assert_close(N(zf), zo, what="fused vs oracle z", rtol=2e-3, atol=2e-3)
         assert np.mean(np.abs(N(zf) - zo)[np.isfinite(zo)] < 2e-5) > 0.98   # the bulk agrees to fp32 rounding
         assert_close(N(ldf), logq, what="fused vs oracle ld", rtol=2e-4, atol=2e-3)
+        # condition-aware bound: against the oracle evaluated in DOUBLE precision the kernel may be no worse than a small
+        # multiple of what the reference's own fp32 arithmetic (the fp32 oracle) loses on the same elements -- at the
+        # tail quantiles and at the maximum, so that a 1e-3 regression in a few per cent of the elements cannot hide
+        # behind the ill-conditioned ones
+        st64 = {k: v.astype(np.float64) if v.dtype == np.float32 else v for k, v in st.items()}
+        ora64 = oracle.OracleNSF(st64, num_layers=1)
+        logq64 = np.zeros(B, np.float64)
+        z64 = ora64.coupling(0, x.numpy().astype(np.float64), 0 if inverse else 1, logq64, +1)
+        fin = np.isfinite(z64)
+        e_gpu = (np.abs(N(zf).astype(np.float64) - z64) / (1 + np.abs(z64)))[fin]
+        e_o32 = (np.abs(zo.astype(np.float64) - z64) / (1 + np.abs(z64)))[fin]
+        for q in (0.9, 0.99, 0.999, 1.0):
+            assert np.quantile(e_gpu, q) <= 4 * np.quantile(e_o32, q) + 4e-6, (q, np.quantile(e_gpu, q), np.quantile(e_o32, q))
+        finl = np.isfinite(logq64)
+        l_gpu = (np.abs(N(ldf).astype(np.float64) - logq64) / np.maximum(1, np.abs(logq64)))[finl]
+        l_o32 = (np.abs(logq.astype(np.float64) - logq64) / np.maximum(1, np.abs(logq64)))[finl]
+        assert l_gpu.max() <= 4 * l_o32.max() + 2e-5, (l_gpu.max(), l_o32.max())
     # accumulate modes and repacking after a parameter update
     layer.prqct.use_fused = True
     acc = torch.full((B,), 1.5, device=DEV)
@@ -830,8 +943,8 @@ def test_maf_config5_width_vs_reference(nfa):
     assert_close(N(z), g["z_fwd"], what="z_fwd", rtol=2e-4, atol=2e-4)
     assert_close(N(ld), g["ld_fwd"], what="ld_fwd", rtol=2e-4, atol=2e-4)
     z, ld = layer.inverse(T(g["x"]))
-    assert_close(N(z), g["z_inv"], what="z_inv", rtol=1e-3, atol=1e-3)
-    assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=1e-3, atol=1e-3)
+    assert_close(N(z), g["z_inv"], what="z_inv", rtol=2e-4, atol=2e-4)
+    assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=2e-4, atol=2e-4)
     # MADE mask structure (nets/made_test.py:77-105): the product of all masks is strictly lower triangular
     net = layer.autoregressive_net
     total = net.initial_layer.mask

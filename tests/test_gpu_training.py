@@ -369,3 +369,60 @@ def test_example_nsf_density_trains(nfa):
     finally:
         _sys.argv = argv
     assert last < first - 0.5, (first, last)
+
+
+def test_frozen_realnvp_stack_keeps_the_input_gradient(nfa):
+    """A frozen RealNVP / ActNorm stack evaluated on an input that requires grad (reverse_kld(score_fn=False),
+    core.py:104-131; the score grad_x log q(x)): the one-launch chain kernel has no autograd path, so run_chain must not
+    take it -- d log_q / dx has to equal the gradient obtained with trainable parameters (the layer-by-layer autograd path)."""
+    g = load_golden("grad_realnvp")
+    b = torch.tensor([1.0, 0.0])
+    flows = []
+    for i in range(4):
+        s_ = nfa.nets.MLP([2, 8, 2], init_zeros=True)
+        t_ = nfa.nets.MLP([2, 8, 2], init_zeros=True)
+        flows += [nfa.flows.MaskedAffineFlow(b if i % 2 == 0 else 1 - b, t_, s_), nfa.flows.ActNorm(2)]
+    m = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(2), flows)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in golden_state(g).items()}, strict=True)
+    m = m.to(DEV)
+    with torch.no_grad():
+        m.log_prob(T(g["x"]))                      # ActNorm initialisation
+    x1 = T(g["x"]).requires_grad_(True)
+    m.log_prob(x1).sum().backward()                # trainable parameters: autograd path
+    for p_ in m.parameters():
+        p_.requires_grad_(False)
+    x2 = T(g["x"]).requires_grad_(True)
+    lp = m.log_prob(x2)
+    assert lp.requires_grad, "frozen stack on an input that requires grad lost the graph"
+    lp.sum().backward()
+    assert float(x2.grad.abs().sum()) > 0
+    assert_close(N(x2.grad), N(x1.grad), what="d log_q / dx", rtol=1e-5, atol=1e-5)
+    # and the estimator that hits this path: reverse_kld(score_fn=False) on a trainable model yields finite, non-zero gradients
+    for p_ in m.parameters():
+        p_.requires_grad_(True)
+    m.p = nfa.distributions.DiagGaussian(2, trainable=False).to(DEV)
+    torch.manual_seed(0)
+    loss = m.reverse_kld(num_samples=256, score_fn=False)
+    m.zero_grad()
+    loss.backward()
+    gs = [p_.grad for p_ in m.flows.parameters() if p_.grad is not None]
+    assert gs and all(torch.isfinite(g_).all() for g_ in gs) and sum(float(g_.abs().sum()) for g_ in gs) > 0
+
+
+def test_layers_without_training_path_refuse_gradients(nfa):
+    """Inference-only layers raise instead of silently detaching (the reference is differentiable there)."""
+    lay = nfa.flows.InvertibleAffine(4).to(DEV)
+    x = torch.randn(5, 4, device=DEV)
+    with pytest.raises(NotImplementedError):
+        lay.forward(x)
+    with torch.no_grad():
+        lay.forward(x)
+    lg = nfa.transforms.Logit(0.05)
+    z = (torch.rand(3, 2, 4, 4, device=DEV) * 0.9 + 0.05)
+    with torch.no_grad():
+        y0, ld0 = lg.inverse(z)
+    zz = z.clone().requires_grad_(True)
+    y1, ld1 = lg.inverse(zz)
+    assert y1.requires_grad
+    assert_close(N(y1), N(y0), what="logit torch vs kernel", rtol=1e-5, atol=1e-5)
+    assert_close(N(ld1), N(ld0), what="logit ld torch vs kernel", rtol=1e-5, atol=1e-4)

@@ -255,6 +255,12 @@ full = -log_prob(x).double().mean()
 assert abs(float(nll) - float(full)) < 1e-6, (float(nll), float(full))
 lo, hi = nfa.dp.shard_bounds(37, world, rank)
 assert local.shape[0] == hi - lo
+# uneven shards whose global size changes while one rank's local size does not (37 -> 38 rows over 2 ranks: 19/18 then
+# 19/19): the count travels with the sum in the SAME collective, so the ranks cannot desynchronise or reuse a stale count
+x2 = torch.randn(38, 8, generator=g)
+nll2 = nfa.dp.sharded_forward_kld(log_prob, nfa.dp.shard_rows(x2))
+full2 = -log_prob(x2).double().mean()
+assert abs(float(nll2) - float(full2)) < 1e-6, (float(nll2), float(full2))
 # gradient averaging: rank-dependent gradients -> identical averaged gradients on every rank, bucketed
 lin = torch.nn.Linear(5, 3)
 for p in lin.parameters():
@@ -362,3 +368,19 @@ def test_maf_pack_rejects_unsupported():
     assert maf_pack.pack_made(nets.MADE(features=8, hidden_features=16, num_blocks=3, output_multiplier=2)) is None
     assert maf_pack.pack_made(nets.MADE(features=8, hidden_features=16, num_blocks=2, output_multiplier=2,
                                         use_residual_blocks=False)) is None
+
+
+def test_fused_kernels_have_no_register_spills(nfa):
+    """AMDGPU metadata of the built objects (tools/kernel_resources.py): the register-resident fused NSF kernels -- exact
+    fp32 and split-bf16, both directions, with and without the fused LU -- use no scratch memory at all."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as kr
+    objdir = os.path.join(ROOT, "normalizing-flows_amd", "lib", "obj")
+    seen = 0
+    for obj, tag in (("rqs_fused.o", "rqs_fused_kernel"), ("rqs_fused_x3.o", "rqs_fused_x3_kernel")):
+        for name, d in kr.resources(os.path.join(objdir, obj)).items():
+            if tag in name:
+                seen += 1
+                assert d["vgpr_spill_count"] == 0 and d["sgpr_spill_count"] == 0 and d["private_segment_fixed_size"] == 0, (name, d)
+                assert d["vgpr_count"] <= 256
+    assert seen == 8, seen
