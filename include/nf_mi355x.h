@@ -408,22 +408,33 @@ int nf_glow_convnet(const void *x, int64_t x_image_stride, void *out, const void
                     int W, int Cout, int hidden, double leaky_slope, int layout, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * A whole GlowBlock in the conditioner's launch (inference, parameters frozen between updates).  Replaces
- * GlowBlock.forward / .inverse (normflows/flows/affine/glow.py:72-84) for split_mode "channel", scale = True:
- * AffineCouplingBlock (coupling.py:232-267: Split, AffineCoupling :117-171, Merge) + Invertible1x1Conv
- * (mixing.py:88-133) + ActNorm (normalization.py:19-39, initialised).  The last two are handed over as ONE per-pixel
- * affine map:  mix_w (C, C), mix_b (C), mix_logdet (device scalar: log|det| per pixel), composed for the direction,
- *   direction 1 (inverse, density):  m = mix_w z + mix_b with mix_w = W diag(e^-s), mix_b = -mix_w t; then the coupling
- *                                    inverse on m with the conditioner reading m's first ceil(C/2) channels;
- *   direction 0 (forward, sampling): coupling forward on z, then y = mix_w (.) + mix_b with mix_w = diag(e^s) W^-1,
- *                                    mix_b = t.
- *   wpack: nf_glow_convnet_pack of the conditioner (Cin = ceil(C/2), Cout = 2 floor(C/2)) for `layout`.
- *   z, y (B, C, H, W) contiguous, y != z; logdet (B) combined per `acc` with the block's log-det
- *   (H W mix_logdet + the coupling's row sum).
+ * GlowBlocks in the conditioner's launch (inference, parameters frozen between updates), one block (nblocks = 1:
+ * replaces GlowBlock.forward / .inverse, normflows/flows/affine/glow.py:72-84, for split_mode "channel", scale = True:
+ * AffineCouplingBlock -- coupling.py:232-267: Split, AffineCoupling :117-171, Merge -- + Invertible1x1Conv + ActNorm) or
+ * a whole LEVEL of the multi-scale flow in one persistent launch: replaces the inner loops of
+ * MultiscaleFlow.log_prob (core.py:600-611: Squeeze.inverse, the level's GlowBlock.inverse calls,
+ * Merge.inverse = channel Split) and MultiscaleFlow.sample (core.py:570-582: Merge, GlowBlock.forward
+ * calls, Squeeze.forward) for `nblocks` (1..32) consecutive GlowBlocks of one shape (affine/glow.py:72-84),
+ * given in PROCESSING order.  A workgroup keeps its whole images in LDS across all blocks; z is read from
+ * HBM once and written once; the glue is folded into that load / store:
+ *   input : in_squeezed = 1: in0 = (B, C/4, 2H, 2W), read through Squeeze.inverse (reshape.py:122-128);
+ *           otherwise channels [0, cin0) from in0 (B, cin0, H, W) and the rest from in1 (B, C - cin0, H, W)
+ *           (Merge, reshape.py:88-100; cin0 = C: in1 unused);
+ *   output: out_squeezed = 1: out0 = (B, C/4, 2H, 2W), written through Squeeze.forward (reshape.py:116-121);
+ *           otherwise channels [0, cout0) to out0 and the rest to out1 (Split "channel", reshape.py:30-34).
+ * block_table: DEVICE array of 4 nblocks pointers, block b at [4 b .. 4 b + 3]: nf_glow_convnet_pack of its conditioner
+ *   (Cin = ceil(C/2), Cout = 2 floor(C/2)) for `layout` | mix_w (C, C) | mix_b (C) | mix_logdet (device scalar): with
+ *   parameters frozen [Invertible1x1Conv, ActNorm] (mixing.py:88-133, normalization.py:19-39) is one per-pixel affine map
+ *   m = mix_w z + mix_b with log|det| mix_logdet per pixel, composed by the caller per parameter version.  direction 1
+ *   (GlowBlock.inverse, density): mix, conditioner on the mixed identity half, coupling inverse (coupling.py:150-171);
+ *   direction 0 (GlowBlock.forward): conditioner on the raw identity half, coupling forward (:117-148), then the mix.
+ * logdet (B) combined per `acc` with the sum of the blocks' log-dets (accumulated per image in block order).
+ * No input tensor may alias an output tensor.  Returns NF_ERANGE for nblocks outside 1..32, NF_ENOTSUP when
+ * the level's working set does not fit one workgroup's LDS.
  */
-int nf_glow_block(const void *z, void *y, void *logdet, const void *wpack, const void *mix_w, const void *mix_b,
-                  const void *mix_logdet, int64_t B, int C, int H, int W, int hidden, double leaky_slope, int scale_map,
-                  int direction, int acc, int layout, nf_stream_t stream);
+int nf_glow_level(const void *in0, const void *in1, int cin0, int in_squeezed, void *out0, void *out1, int cout0,
+                  int out_squeezed, void *logdet, const void *block_table, int nblocks, int64_t B, int C, int H, int W,
+                  int hidden, double leaky_slope, int scale_map, int direction, int acc, int layout, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Squeeze (flows/reshape.py:116-128).  direction 0 = forward (C,H,W)->(C/4,2H,2W),

@@ -78,6 +78,14 @@ def exported_symbols_declared():
 def lib():
     global _lib
     if _lib is None:
+        override = os.environ.get("NF_MI355X_LIB")   # ablation builds (tools/*_ablate.py): another build of the SAME sources
+        if override:
+            _lib = C.CDLL(override)
+            _lib.nf_version.restype = C.c_char_p
+            _lib.nf_strerror.restype = C.c_char_p
+            for fn in ("nf_rqs_fused_pack_size", "nf_linear_wgrad_scratch_floats", "nf_maf_inverse_scratch_floats"):
+                getattr(_lib, fn).restype = C.c_int64
+            return _lib
         if not os.path.exists(LIBPATH):
             raise NativeLibraryError(
                 "libnf_mi355x.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'`."

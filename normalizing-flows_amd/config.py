@@ -13,3 +13,13 @@ def set_fused_gemm(mode):
     if mode not in ("f32", "bf16x3"):
         raise ValueError("fused_gemm must be 'f32' or 'bf16x3'")
     fused_gemm = mode
+
+
+# Runs of GlowBlocks of one shape inside MultiscaleFlow go out as ONE persistent launch per level (nf_glow_level, Squeeze /
+# Split / Merge folded in).  False: one launch per GlowBlock plus the glue kernels (ablation / debugging).
+glow_level_chains = True
+
+
+def set_glow_level_chains(mode=True):
+    global glow_level_chains
+    glow_level_chains = bool(mode)

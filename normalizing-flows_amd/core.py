@@ -515,6 +515,72 @@ class MultiscaleFlow(nn.Module):
                 [x, z[i]], _ = self.merges[i - 1].inverse(x)
         return z, log_det
 
+    def _level_pass(self, i, z, z_other, inverse, ld, acc):
+        """Level i of the multi-scale flow with the log-dets folded into `ld`.
+        inverse (density, core.py:600-611): flows[i] reversed, then the level's split -> (z, z_); z_ is None at i == 0.
+        forward (sample, core.py:570-582): merge z with `z_other` (None at i == 0), then flows[i] -> (z, None).
+        Runs of GlowBlocks of one shape go out as ONE persistent launch (nf_glow_level) with the neighbouring
+        Squeeze / channel Split / Merge folded into its load and store; anything else goes layer by layer."""
+        from .autograd import needs_grad
+        from .flows.glow import GlowBlock, plan_level, run_level
+        from .flows.reshape import Merge, Squeeze
+        flows = list(self.flows[i])
+        seq = flows[::-1] if inverse else flows
+        merge = self.merges[i - 1] if i > 0 else None
+        chan = merge is not None and type(merge) is Merge and merge.mode == "channel"
+        from . import config
+        fast = (config.glow_level_chains and z.is_cuda and z.dtype == torch.float32 and z.dim() == 4
+                and not needs_grad(z, z_other) and (z_other is None or z_other.dtype == torch.float32))
+        pending_merge = (not inverse) and merge is not None      # sample direction: the merge is not applied yet
+        refused = self.__dict__.setdefault("_level_refused", set())
+        k = 0
+        while k < len(seq):
+            f = seq[k]
+            if fast:
+                sq_in = (inverse and isinstance(f, Squeeze) and k + 1 < len(seq) and isinstance(seq[k + 1], GlowBlock)
+                         and z.shape[2] % 2 == 0 and z.shape[3] % 2 == 0)
+                start = k + 1 if sq_in else k
+                if isinstance(seq[start], GlowBlock) and not (pending_merge and not chan):
+                    B = z.shape[0]
+                    if pending_merge:
+                        C, H, W = z.shape[1] + z_other.shape[1], z.shape[2], z.shape[3]
+                    elif sq_in:
+                        C, H, W = 4 * z.shape[1], z.shape[2] // 2, z.shape[3] // 2
+                    else:
+                        C, H, W = z.shape[1:]
+                    key = (i, inverse, start, B, C, H, W)
+                    n = 0
+                    if key not in refused:
+                        n, entries, layout, slope, smap = plan_level(seq[start:], B, C, H, W, inverse)
+                    if n:
+                        end = start + n
+                        sq_out = (not inverse) and end < len(seq) and isinstance(seq[end], Squeeze) and C % 4 == 0
+                        split_out = inverse and end == len(seq) and chan
+                        try:
+                            out0, out1 = run_level(seq[start:end], entries, layout, slope, smap, z,
+                                                   z_other if pending_merge else None, sq_in, inverse, ld, acc,
+                                                   cout0=(C + 1) // 2 if split_out else None, out_squeezed=sq_out)
+                        except NotImplementedError:     # working set beyond one workgroup's LDS: nothing was launched
+                            refused.add(key)
+                        else:
+                            pending_merge = False
+                            k = end + (1 if sq_out else 0)
+                            z = out0
+                            if split_out:
+                                return out0, out1
+                            continue
+            if pending_merge:
+                z, _ = merge([z, z_other])
+                pending_merge = False
+            z = run_flow(f, z, inverse, ld, acc)
+            k += 1
+        if pending_merge:
+            z, _ = merge([z, z_other])
+        if inverse and merge is not None:
+            [z, z_], _ = merge.inverse(z)
+            return z, z_
+        return z, None
+
     def sample(self, num_samples=1, y=None, temperature=None):
         if temperature is not None:
             self.set_temperature(temperature)
@@ -525,12 +591,10 @@ class MultiscaleFlow(nn.Module):
                 z_, log_q_ = self.q0[i](num_samples)
             if i == 0:
                 log_q = log_q_
-                z = z_
+                z, _ = self._level_pass(0, z_, None, False, log_q, -1)
             else:
                 log_q += log_q_
-                z, _ = self.merges[i - 1]([z, z_])
-            for flow in self.flows[i]:
-                z = run_flow(flow, z, False, log_q, -1)
+                z, _ = self._level_pass(i, z, z_, False, log_q, -1)
         if self.transform is not None:
             z = run_flow(self.transform, z, False, log_q, -1)
         if temperature is not None:
@@ -543,12 +607,11 @@ class MultiscaleFlow(nn.Module):
         for i in range(len(self.q0)):
             z_, log_q_ = self.q0[i].from_noise(eps[i])
             if i == 0:
-                log_q, z = log_q_, z_
+                log_q = log_q_
+                z, _ = self._level_pass(0, z_, None, False, log_q, -1)
             else:
                 log_q = log_q + log_q_
-                z, _ = self.merges[i - 1]([z, z_])
-            for flow in self.flows[i]:
-                z = run_flow(flow, z, False, log_q, -1)
+                z, _ = self._level_pass(i, z, z_, False, log_q, -1)
         if self.transform is not None:
             z = run_flow(self.transform, z, False, log_q, -1)
         return z, log_q
@@ -565,11 +628,8 @@ class MultiscaleFlow(nn.Module):
         if self.transform is not None:
             z = run_flow(self.transform, z, True, log_q, +1)
         for i in range(len(self.q0) - 1, -1, -1):
-            for j in range(len(self.flows[i]) - 1, -1, -1):
-                z = run_flow(self.flows[i][j], z, True, log_q, +1)
-            if i > 0:
-                [z, z_], _ = self.merges[i - 1].inverse(z)
-            else:
+            z, z_ = self._level_pass(i, z, None, True, log_q, +1)
+            if i == 0:
                 z_ = z
             if self.class_cond:
                 log_q += self.q0[i].log_prob(z_, y)

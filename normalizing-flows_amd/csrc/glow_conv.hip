@@ -1,7 +1,7 @@
 // glow_conv.hip -- the conditioner of a GlowBlock, ConvNet2d([Cin, 256, 256, Cout], kernel sizes (3, 1, 3)) =
 // conv3x3 -> LeakyReLU -> conv1x1 -> LeakyReLU -> conv3x3 (normflows/nets/cnn.py:5-63 as built by
 // normflows/flows/affine/glow.py:41-62), as ONE kernel on exact-fp32 MFMA for gfx950 -- optionally with the rest of the
-// GlowBlock (1x1 convolution + ActNorm, affine coupling) in the same launch (nf_glow_block, GbFuse below).
+// GlowBlock (1x1 convolution + ActNorm, affine coupling) in the same launch, or a whole level of GlowBlocks (nf_glow_block / nf_glow_level, GlowLevel below).
 // Three kernels share the decomposition and differ in how the pixels and rows are spread over waves: glow_convnet_kernel
 // (256-pixel workgroups, described first), glow_convnet_small_kernel (64 pixels) and glow_convnet_tiny_kernel (16 pixels,
 // rows split across the waves); nf_glow_convnet_layout picks one per call.
@@ -138,26 +138,163 @@ __device__ __forceinline__ void gc_leaky(f32x16 &v, float slope) {
     for (int c = 0; c < 16; ++c) v[c] = fmaxf(v[c], v[c] * slope);   // 0 <= slope <= 1 (cnn.py:38 LeakyReLU)
 }
 
-// ---- optional fusion of the rest of the GlowBlock around the conditioner ----------------------------------------------
+// ---- optional fusion of the rest of the GlowBlock(s) around the conditioner --------------------------------------------
 // GlowBlock = [AffineCouplingBlock(split "channel"), Invertible1x1Conv, ActNorm] (glow.py:11-84).  With parameters frozen
 // the last two are ONE per-pixel affine map m = Wp z + bp with a constant log|det| per pixel (flows/glow.py::_fused_mix);
 // the workgroup holds whole images, so the block runs inside the conditioner's launch:
 //   direction 1 (GlowBlock.inverse, the density direction): mix first, conditioner on the mixed identity half,
 //               coupling inverse (coupling.py:150-171) on the mixed other half;
 //   direction 0 (GlowBlock.forward): conditioner on the raw identity half, coupling forward (:117-148), then the mix.
-struct GbFuse {
-    int on;            // 0: conditioner only
-    int C, c1;         // channels of z; the identity half = the first c1 = ceil(C / 2) channels (reshape.py:31)
-    int scale_map;     // NF_SCALE_EXP | NF_SCALE_SIGMOID | NF_SCALE_SIGMOID_INV
+// A whole LEVEL of the multi-scale flow (core.py:588-616 / :553-586: up to GL_MAXB consecutive GlowBlocks of one shape) is
+// one persistent launch: no block needs another workgroup's pixels, so the workgroup keeps its images in LDS (two
+// ping-pong planes of C x pixels) across all blocks, z goes HBM -> LDS once and back once, the per-image log-det is
+// accumulated in LDS in block order (deterministic) and stored once.  The glue around the level is folded into that one
+// load / store: the input is the channel concatenation of two tensors (Merge, reshape.py:88-100) or the
+// Squeeze.inverse view of an un-squeezed tensor (reshape.py:122-128); the output is split after cout0 channels into two
+// tensors (Split, reshape.py:30-85 "channel") or written through the Squeeze.forward view (:116-121).
+constexpr int GL_MAXB = 64;
+struct GlowLevel {
+    // DEVICE table of 4 nblocks pointers, block b (PROCESSING order) at [4 b .. 4 b + 3]: packed conditioner | (C, C) mix
+    // matrix | (C) mix bias | log|det| of the mix per pixel (device scalar).  (A by-value array in the kernel arguments
+    // makes the compiler hold all of it in SGPRs: hundreds of spilled scalars.)
+    const float *const *tbl;
+    __device__ __forceinline__ const float *blob(int b) const { return tbl[4 * b]; }
+    __device__ __forceinline__ const float *Wp(int b) const { return tbl[4 * b + 1]; }
+    __device__ __forceinline__ const float *bp(int b) const { return tbl[4 * b + 2]; }
+    __device__ __forceinline__ const float *ldu(int b) const { return tbl[4 * b + 3]; }
+    int nblocks;                  // 0: conditioner only (nf_glow_convnet)
+    int C, c1;                    // channels of z; the identity half = the first c1 = ceil(C / 2) channels (reshape.py:31)
+    int scale_map;                // NF_SCALE_EXP | NF_SCALE_SIGMOID | NF_SCALE_SIGMOID_INV
     int direction, acc;
-    const float *Wp;   // (C, C)
-    const float *bp;   // (C)
-    const float *ldu;  // log|det| of the mix per pixel (device scalar)
-    float *logdet;     // (B)
+    const float *in0, *in1;       // level input: channels [0, cin0) of in0 (B, cin0, H, W) then in1 (B, C - cin0, H, W); or,
+    int cin0, in_sq;              //   in_sq = 1, the Squeeze.inverse view of in0 = (B, C / 4, 2H, 2W)
+    float *out0, *out1;           // level output: channels [0, cout0) -> out0, the rest -> out1; or, out_sq = 1, through
+    int cout0, out_sq;            //   the Squeeze.forward view into out0 = (B, C / 4, 2H, 2W)
+    float *logdet;                // (B)
 };
 
-__host__ __device__ inline int gb_lds_floats(const GbFuse &fu, int Cout, int PXW) {
-    return fu.on ? (2 * fu.C + Cout + (fu.C - fu.c1)) * PXW : 0;   // zr | zm | prm | ldt
+__host__ __device__ inline int gb_lds_floats(const GlowLevel &lv, int Cout, int PXW) {
+    // zA | zB (ping-pong planes) | prm (parameter planes) | ldt (log-det terms) | ldacc (per-image log-det) | Wp | bp
+    return lv.nblocks ? (2 * lv.C + Cout + (lv.C - lv.c1)) * PXW + PXW + (lv.C * lv.C + lv.C + 3) / 4 * 4 : 0;
+}
+
+// Squeeze correspondence (reshape.py:116-128): small[b, 4 c + 2 i + j, h, w] <-> big[b, c, 2 h + i, 2 w + j]
+__device__ __forceinline__ int64_t gl_sq_index(int64_t g, int C, int c, int H, int W, int h, int w) {
+    return ((g * (C >> 2) + (c >> 2)) * (2 * H) + 2 * h + ((c >> 1) & 1)) * (int64_t)(2 * W) + 2 * w + (c & 1);
+}
+
+// Level input -> zin[c][p] (whole images of the workgroup), log-det accumulators cleared.
+template <int PXW, int NT>
+__device__ __forceinline__ void gl_load(const GlowLevel &lv, float *zin, float *ldacc, int H, int W, int64_t img0, int64_t B,
+                                        int tid) {
+    const int HW = H * W, C = lv.C;
+    for (int i = tid; i < C * PXW; i += NT) {
+        const int c = i / PXW, p = i - c * PXW, im = p / HW, q = p - im * HW;
+        const int64_t g = img0 + im;
+        float v = 0.0f;
+        if (g < B) {
+            if (lv.in_sq) { const int h = q / W; v = lv.in0[gl_sq_index(g, C, c, H, W, h, q - h * W)]; }
+            else if (c < lv.cin0) v = lv.in0[(g * lv.cin0 + c) * HW + q];
+            else v = lv.in1[(g * (C - lv.cin0) + (c - lv.cin0)) * HW + q];
+        }
+        zin[i] = v;
+    }
+    for (int i = tid; i < PXW; i += NT) ldacc[i] = 0.0f;
+}
+
+// zfin[c][p] -> level output; accumulated per-image log-dets -> logdet (one store per image).
+template <int PXW, int NT>
+__device__ __forceinline__ void gl_store(const GlowLevel &lv, const float *zfin, const float *ldacc, int H, int W, int64_t img0,
+                                         int64_t B, int tid) {
+    const int HW = H * W, C = lv.C, IPW = PXW / HW;
+    for (int i = tid; i < C * PXW; i += NT) {
+        const int c = i / PXW, p = i - c * PXW, im = p / HW, q = p - im * HW;
+        const int64_t g = img0 + im;
+        if (g < B) {
+            const float v = zfin[i];
+            if (lv.out_sq) { const int h = q / W; lv.out0[gl_sq_index(g, C, c, H, W, h, q - h * W)] = v; }
+            else if (c < lv.cout0) lv.out0[(g * lv.cout0 + c) * HW + q] = v;
+            else lv.out1[(g * (C - lv.cout0) + (c - lv.cout0)) * HW + q] = v;
+        }
+    }
+    for (int im = tid; im < IPW; im += NT)
+        if (img0 + im < B) ld_store(lv.logdet + img0 + im, ldacc[im], lv.acc);
+}
+
+// Start of block b: the block's mix matrix into LDS; direction 1 mixes zin -> zalt; the conditioner's zero-padded input
+// images come from the identity half of the mixed (direction 1) / raw (direction 0) planes.  Ends WITHOUT a barrier
+// (the caller's next barrier publishes xin).
+template <int PXW, int NT>
+__device__ __forceinline__ void gl_pre(const GlowLevel &lv, int b, const float *zin, float *zalt, float *wmix, float *xin,
+                                       int H, int W, int tid) {
+    const int HW = H * W, PH = H + 2, PW = W + 2, IPW = PXW / HW, C = lv.C;
+    const float *Wp = lv.Wp(b), *bp = lv.bp(b);
+    for (int i = tid; i < C * C + C; i += NT) wmix[i] = i < C * C ? Wp[i] : bp[i - C * C];
+    __syncthreads();   // wmix, and zin (the level load / the previous block's output)
+    const float *src = zin;
+    if (lv.direction == 1) {
+        for (int i = tid; i < C * PXW; i += NT) {
+            const int c = i / PXW, p = i - c * PXW;
+            float a = wmix[C * C + c];
+            for (int k = 0; k < C; ++k) a = fmaf(wmix[c * C + k], zin[k * PXW + p], a);
+            zalt[i] = a;
+        }
+        __syncthreads();
+        src = zalt;
+    }
+    const int per_img = lv.c1 * PH * PW, n = IPW * per_img;
+    for (int i = tid; i < n; i += NT) {
+        const int im = i / per_img, rem = i - im * per_img, c = rem / (PH * PW), rr = rem - c * PH * PW;
+        const int yy = rr / PW - 1, xx = rr - (yy + 1) * PW - 1;
+        xin[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? src[c * PXW + im * HW + yy * W + xx] : 0.0f;
+    }
+}
+
+// End of block b: coupling on the other half in place (parameter planes 2 i = shift, 2 i + 1 = scale, coupling.py:117-171);
+// direction 0 then mixes zin -> zalt.  Either way the block's output is in zalt.  Per-image log-det in a fixed order (one
+// wave per image), added to the level's accumulator.  Ends with a barrier.
+template <int PXW, int NT>
+__device__ __forceinline__ void gl_post(const GlowLevel &lv, int b, float *zin, float *zalt, const float *wmix, const float *prm,
+                                        float *ldt, float *ldacc, int H, int W, int tid) {
+    const int HW = H * W, IPW = PXW / HW, C = lv.C, c1 = lv.c1, n2 = C - c1;
+    __syncthreads();   // parameter planes complete
+    float *z2 = (lv.direction == 1 ? zalt : zin) + c1 * PXW;
+    for (int e = tid; e < n2 * PXW; e += NT) {
+        const int i = e / PXW, p = e - i * PXW;
+        const float sh = prm[(2 * i) * PXW + p], sc = prm[(2 * i + 1) * PXW + p], v = z2[e];
+        float o, l;
+        if (lv.scale_map == NF_SCALE_EXP) {
+            o = lv.direction == 0 ? v * M<float>::exp(sc) + sh : (v - sh) * M<float>::exp(-sc);
+            l = sc;
+        } else {
+            const float sg = sigmoid(sc + 2.0f), lg = M<float>::log(sg);
+            if (lv.scale_map == NF_SCALE_SIGMOID) { o = lv.direction == 0 ? v / sg + sh : (v - sh) * sg; l = -lg; }
+            else { o = lv.direction == 0 ? v * sg + sh : (v - sh) / sg; l = lg; }
+        }
+        ldt[e] = lv.direction == 0 ? l : -l;
+        z2[e] = o;
+    }
+    __syncthreads();
+    if (lv.direction == 0) {
+        for (int i = tid; i < C * PXW; i += NT) {
+            const int c = i / PXW, p = i - c * PXW;
+            float a = wmix[C * C + c];
+            for (int k = 0; k < C; ++k) a = fmaf(wmix[c * C + k], zin[k * PXW + p], a);
+            zalt[i] = a;
+        }
+    }
+    const int lane = tid & 63, wv = tid >> 6;
+    const float ldu = *lv.ldu(b);
+    for (int im = wv; im < IPW; im += NT / 64) {
+        float a = 0.0f;
+        for (int t = lane; t < n2 * HW; t += 64) {
+            const int i = t / HW, q = t - i * HW;
+            a += ldt[i * PXW + im * HW + q];
+        }
+        a = wave_sum(a);
+        if (lane == 0) ldacc[im] += a + (float)HW * ldu;
+    }
+    __syncthreads();
 }
 
 // Padded input images of the conditioner from global memory (plain call).
@@ -172,39 +309,6 @@ __device__ __forceinline__ void gc_fill_xin_global(const float *__restrict__ x, 
         float v = 0.0f;
         if (yy >= 0 && yy < H && xx >= 0 && xx < W && g < B) v = x[g * xs_img + (int64_t)c * HW + yy * W + xx];
         xin[i] = v;
-    }
-}
-
-// Fused block: the workgroup's images -> zr[c][p]; direction 1 also mixes them (zm) and writes the identity half of the
-// result; the conditioner's padded input comes from the identity half of zm / zr.  Ends with a barrier.
-template <int PXW, int NT>
-__device__ __forceinline__ void gb_prologue(const GbFuse &fu, const float *__restrict__ z, float *__restrict__ y, float *zr,
-                                            float *zm, float *xin, int H, int W, int64_t img0, int64_t B, int tid) {
-    const int HW = H * W, PH = H + 2, PW = W + 2, IPW = PXW / HW, C = fu.C;
-    for (int i = tid; i < C * PXW; i += NT) {
-        const int c = i / PXW, p = i - c * PXW, im = p / HW, q = p - im * HW;
-        const int64_t g = img0 + im;
-        zr[i] = g < B ? z[(g * C + c) * HW + q] : 0.0f;
-    }
-    __syncthreads();
-    const float *src = zr;
-    if (fu.direction == 1) {
-        for (int i = tid; i < C * PXW; i += NT) {
-            const int c = i / PXW, p = i - c * PXW, im = p / HW, q = p - im * HW;
-            const int64_t g = img0 + im;
-            float a = fu.bp[c];
-            for (int k = 0; k < C; ++k) a = fmaf(fu.Wp[c * C + k], zr[k * PXW + p], a);
-            zm[i] = a;
-            if (c < fu.c1 && g < B) y[(g * C + c) * HW + q] = a;
-        }
-        __syncthreads();
-        src = zm;
-    }
-    const int per_img = fu.c1 * PH * PW, n = IPW * per_img;
-    for (int i = tid; i < n; i += NT) {
-        const int im = i / per_img, rem = i - im * per_img, c = rem / (PH * PW), rr = rem - c * PH * PW;
-        const int yy = rr / PW - 1, xx = rr - (yy + 1) * PW - 1;
-        xin[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? src[c * PXW + im * HW + yy * W + xx] : 0.0f;
     }
 }
 
@@ -238,57 +342,31 @@ __device__ __forceinline__ void gc_gather_block(const float *P, int blk0, const 
     }
 }
 
-// Fused block after the conditioner: coupling on the other half (parameter planes 2 i = shift, 2 i + 1 = scale,
-// coupling.py:117-171), direction 0 then applies the mix; per-image log-det in a fixed order (one wave per image).
-template <int PXW, int NT>
-__device__ __forceinline__ void gb_epilogue(const GbFuse &fu, float *__restrict__ y, float *zr, const float *zm, const float *prm,
-                                            float *ldt, int H, int W, int64_t img0, int64_t B, int tid) {
-    const int HW = H * W, IPW = PXW / HW, C = fu.C, c1 = fu.c1, n2 = C - c1;
-    __syncthreads();   // parameter planes complete
-    const float *z2 = (fu.direction == 1 ? zm : zr) + c1 * PXW;
-    for (int e = tid; e < n2 * PXW; e += NT) {
-        const int i = e / PXW, p = e - i * PXW, im = p / HW, q = p - im * HW;
-        const int64_t g = img0 + im;
-        const float sh = prm[(2 * i) * PXW + p], sc = prm[(2 * i + 1) * PXW + p], v = z2[e];
-        float o, l;
-        if (fu.scale_map == NF_SCALE_EXP) {
-            o = fu.direction == 0 ? v * M<float>::exp(sc) + sh : (v - sh) * M<float>::exp(-sc);
-            l = sc;
-        } else {
-            const float sg = sigmoid(sc + 2.0f), lg = M<float>::log(sg);
-            if (fu.scale_map == NF_SCALE_SIGMOID) { o = fu.direction == 0 ? v / sg + sh : (v - sh) * sg; l = -lg; }
-            else { o = fu.direction == 0 ? v * sg + sh : (v - sh) / sg; l = lg; }
-        }
-        ldt[e] = fu.direction == 0 ? l : -l;
-        if (fu.direction == 1) { if (g < B) y[(g * C + c1 + i) * HW + q] = o; }
-        else zr[(c1 + i) * PXW + p] = o;
-    }
-    __syncthreads();
-    if (fu.direction == 0) {
-        for (int i = tid; i < C * PXW; i += NT) {
-            const int c = i / PXW, p = i - c * PXW, im = p / HW, q = p - im * HW;
-            const int64_t g = img0 + im;
-            float a = fu.bp[c];
-            for (int k = 0; k < C; ++k) a = fmaf(fu.Wp[c * C + k], zr[k * PXW + p], a);
-            if (g < B) y[(g * C + c) * HW + q] = a;
-        }
-    }
-    const int lane = tid & 63, wv = tid >> 6;
-    const float ldu = *fu.ldu;
-    for (int im = wv; im < IPW; im += NT / 64) {
-        float a = 0.0f;
-        for (int t = lane; t < n2 * HW; t += 64) {
-            const int i = t / HW, q = t - i * HW;
-            a += ldt[i * PXW + im * HW + q];
-        }
-        a = wave_sum(a);
-        if (lane == 0 && img0 + im < B) ld_store(fu.logdet + img0 + im, a + (float)HW * ldu, fu.acc);
-    }
+// Opaque copy of a per-thread value, taken once per block of a level chain: everything derived from it is recomputed per
+// block instead of being hoisted out of the block loop and carried (spilled) across the MFMA phases.
+__device__ __forceinline__ int gl_opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// LDS planes of the fused level behind the conditioner's own buffers (all kernels): zA | zB | prm | ldt | ldacc | wmix
+struct GlPlanes {
+    float *zA, *zB, *prm, *ldt, *ldacc, *wmix;
+};
+__device__ __forceinline__ GlPlanes gl_planes(float *base, const GlowLevel &lv, int Cout, int PXW) {
+    GlPlanes q;
+    q.zA = base;
+    q.zB = q.zA + lv.C * PXW;
+    q.prm = q.zB + lv.C * PXW;
+    q.ldt = q.prm + Cout * PXW;
+    q.ldacc = q.ldt + (lv.C - lv.c1) * PXW;
+    q.wmix = q.ldacc + PXW;
+    return q;
 }
 
 __global__ void __launch_bounds__(64 * GC_NW, 2)
-glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restrict__ out, const float *__restrict__ blob,
-                    GcMeta mt, int64_t B, int H, int W, GbFuse fu) {
+glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restrict__ out, const float *__restrict__ blob0,
+                    GcMeta mt, int64_t B, int H, int W, GlowLevel lv) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int HW = H * W, PH = H + 2, PW = W + 2, IPW = GC_PX / HW;
     const int K1p = 8 * mt.nkg1;
@@ -297,27 +375,27 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
     float *small = P + 32 * GC_PX;               // biases
     int *koff = reinterpret_cast<int *>(small + gc_small_padded(mt));   // im2col offset of every k
     float *xin = reinterpret_cast<float *>(koff + K1p);                  // zero-padded input images [img][c][PH][PW]
-    float *zr = xin + IPW * mt.Cin * PH * PW;    // fused block only: raw z | mixed z | parameter planes | log-det terms
-    float *zm = zr + fu.C * GC_PX, *prm = zm + fu.C * GC_PX, *ldt = prm + mt.Cout * GC_PX;
-    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int px = wid * 32 + (lane & 31);
-    const int li = px / HW, pin = px - li * HW, py = pin / W, pxx = pin - py * W;
-    const int base0 = li * mt.Cin * PH * PW + py * PW + pxx;
+    const GlPlanes pl = gl_planes(xin + IPW * mt.Cin * PH * PW, lv, mt.Cout, GC_PX);   // fused level only
+    const int tid0 = threadIdx.x;
+    const int wid = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int64_t img0 = (int64_t)blockIdx.x * IPW;
+    const bool fused = lv.nblocks > 0;
+    const int nb = fused ? lv.nblocks : 1;
 
     const int nst_l1 = 8 * mt.nst1;
-    const int total_stages = nst_l1 + 24 * mt.npass;
+    const int total_stages = nst_l1 + 24 * mt.npass;     // per block
+    const int all_stages = total_stages * nb;            // the stream runs straight through the block boundaries
     auto phys = [&](int s) -> int {   // stream position -> stage of the blob (GEMM 2's stages are re-streamed every sweep)
         if (s < nst_l1) return s;
         const int q = s - nst_l1, pass = q / 24, w = q - 24 * pass, j = w / 3, t = w - 3 * j;
         return t < 2 ? nst_l1 + 2 * j + t : nst_l1 + 16 + 8 * pass + j;
     };
-    const float *stages = blob + gc_off_stages(mt);
-    int stage = 0;
+    int stage = 0;   // global stage counter (all blocks)
     auto issue = [&](int gs) {
         constexpr int PPW = 16 / GC_NW;  // 1 KB pieces per wave
-        const float *src = stages + (size_t)phys(gs) * GC_STAGE + (wid * PPW) * 256 + lane * 4;
+        const int bb = gs / total_stages, s = gs - bb * total_stages;
+        const float *stages = (fused ? lv.blob(bb) : blob0) + gc_off_stages(mt);
+        const float *src = stages + (size_t)phys(s) * GC_STAGE + (wid * PPW) * 256 + (tid0 & 63) * 4;
         float *dst = ring + (gs & 1) * GC_STAGE + (wid * PPW) * 256;
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
@@ -326,21 +404,31 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
     auto acquire = [&]() -> const float * {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (stage + 1 < total_stages) issue(stage + 1);
+        if (stage + 1 < all_stages) issue(stage + 1);   // at a block's last stage: the NEXT block's first stage
         const float *buf = ring + (stage & 1) * GC_STAGE;
         ++stage;
         return buf;
     };
 
-    // ---- prologue: first stage in flight; biases, im2col offsets and the padded input images into LDS ----
+    // ---- prologue: first stage in flight; im2col offsets; the level's images into LDS ----
     issue(0);
-    for (int i = tid; i < mt.small; i += 64 * GC_NW) small[i] = blob[GC_HDR + i];
-    for (int k = tid; k < K1p; k += 64 * GC_NW) {
+    for (int k = tid0; k < K1p; k += 64 * GC_NW) {
         const int kk = k < mt.K1 ? k : mt.K1 - 1;   // padded k: zero weight, any valid address
         const int c = kk / 9, t = kk - 9 * c, ky = t / 3;
         koff[k] = c * PH * PW + ky * PW + (t - 3 * ky);
     }
-    if (fu.on) gb_prologue<GC_PX, 64 * GC_NW>(fu, x, out, zr, zm, xin, H, W, img0, B, tid);
+    float *zin = pl.zA, *zalt = pl.zB;
+    if (fused) gl_load<GC_PX, 64 * GC_NW>(lv, zin, pl.ldacc, H, W, img0, B, tid0);
+
+    for (int b = 0; b < nb; ++b) {
+    const int tid = gl_opaque(tid0), lane = tid & 63, hh = lane >> 5;
+    const int px = wid * 32 + (lane & 31);
+    const int li = px / HW, pin = px - li * HW, py = pin / W, pxx = pin - py * W;
+    const int base0 = li * mt.Cin * PH * PW + py * PW + pxx;
+    const float *blob = fused ? lv.blob(b) : blob0;
+    // biases of this block (the previous block's last reader, its col2im gather, is behind a barrier), padded input images
+    for (int i = tid; i < mt.small; i += 64 * GC_NW) small[i] = blob[GC_HDR + i];
+    if (fused) gl_pre<GC_PX, 64 * GC_NW>(lv, b, zin, zalt, pl.wmix, xin, H, W, tid);
     else gc_fill_xin_global<GC_PX, 64 * GC_NW>(x, xs_img, xin, mt.Cin, H, W, img0, B, tid);
 
     // ---- GEMM 1 (conv3x3 #1 by im2col): h1 = LeakyReLU(W1 col(x) + b1) ----
@@ -417,12 +505,17 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) P[(8 * (reg >> 2) + 4 * hh + (reg & 3)) * GC_PX + px] = o[reg];
             __syncthreads();
-            gc_gather_block<GC_PX, 64 * GC_NW>(P, blk, mt, H, W, img0, B, small, out, fu.on ? prm : nullptr, tid);
+            gc_gather_block<GC_PX, 64 * GC_NW>(P, blk, mt, H, W, img0, B, small, out, fused ? pl.prm : nullptr, tid);
             __syncthreads();
             }
         }
     }
-    if (fu.on) gb_epilogue<GC_PX, 64 * GC_NW>(fu, out, zr, zm, prm, ldt, H, W, img0, B, tid);
+    if (fused) {
+        gl_post<GC_PX, 64 * GC_NW>(lv, b, zin, zalt, pl.wmix, pl.prm, pl.ldt, pl.ldacc, H, W, tid);
+        float *t_ = zin; zin = zalt; zalt = t_;
+    }
+    }  // blocks
+    if (fused) gl_store<GC_PX, 64 * GC_NW>(lv, zin, pl.ldacc, H, W, img0, B, tid0);
 }
 
 // ---- small images: 64-pixel workgroups of 4 waves x 16 pixels on v_mfma_f32_16x16x4_f32 ------------------------------
@@ -445,7 +538,7 @@ __device__ __forceinline__ void gs_leaky(f32x4 &v, float slope) {
 template <int OBT>
 __global__ void __launch_bounds__(64 * GS_NW)
 glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__restrict__ out,
-                          const float *__restrict__ blob, GcMeta mt, int64_t B, int H, int W, GbFuse fu) {
+                          const float *__restrict__ blob0, GcMeta mt, int64_t B, int H, int W, GlowLevel lv) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int HW = H * W, PH = H + 2, PW = W + 2, IPW = GS_PX / HW;
     const int nkb1 = (mt.K1 + 15) / 16, K1p = 16 * nkb1;
@@ -454,14 +547,15 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
     float *small = P + 32 * GS_PX;
     int *koff = reinterpret_cast<int *>(small + gc_small_padded(mt));
     float *xin = reinterpret_cast<float *>(koff + K1p);
-    float *zr = xin + IPW * mt.Cin * PH * PW;
-    float *zm = zr + fu.C * GS_PX, *prm = zm + fu.C * GS_PX, *ldt = prm + mt.Cout * GS_PX;
+    const GlPlanes pl = gl_planes(xin + IPW * mt.Cin * PH * PW, lv, mt.Cout, GS_PX);
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = wid * 16 + (lane & 15);
     const int li = px / HW, pin = px - li * HW, py = pin / W, pxx = pin - py * W;
     const int base0 = li * mt.Cin * PH * PW + py * PW + pxx;
     const int64_t img0 = (int64_t)blockIdx.x * IPW;
+    const bool fused = lv.nblocks > 0;
+    const int nb = fused ? lv.nblocks : 1;
 
     const int nst_l1 = 8 * mt.nst1, per_j = 2 + mt.npass;   // per h2 block: 2 stages of GEMM 2, npass stages of GEMM 3
     const int total_stages = nst_l1 + 8 * per_j;
@@ -470,9 +564,19 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
         const int q = s - nst_l1, j = q / per_j, t = q - per_j * j;
         return t < 2 ? nst_l1 + 2 * j + t : nst_l1 + 16 + 8 * (t - 2) + j;
     };
-    const float *stages = blob + gc_off_stages(mt);
     constexpr int PPW = 16 / GS_NW;
-    int stage = 0;
+    for (int k = tid; k < K1p; k += 64 * GS_NW) {
+        const int kk = k < mt.K1 ? k : mt.K1 - 1;
+        const int c = kk / 9, t = kk - 9 * c, ky = t / 3;
+        koff[k] = c * PH * PW + ky * PW + (t - 3 * ky);
+    }
+    float *zin = pl.zA, *zalt = pl.zB;
+    if (fused) gl_load<GS_PX, 64 * GS_NW>(lv, zin, pl.ldacc, H, W, img0, B, tid);
+
+    for (int b = 0; b < nb; ++b) {
+    const float *blob = fused ? lv.blob(b) : blob0;
+    const float *stages = blob + gc_off_stages(mt);
+    int stage = 0;   // per block: the ring is the col2im scratch at the end of a block, so the stream restarts
     auto issue = [&](int gs) {
         const float *src = stages + (size_t)phys(gs) * GC_STAGE + (wid * PPW) * 256 + lane * 4;
         float *dst = ring + (gs % GS_RING) * GC_STAGE + (wid * PPW) * 256;
@@ -491,19 +595,16 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
         return buf;
     };
 
-    // ---- prologue ----
-    for (int i = tid; i < mt.small; i += 64 * GS_NW) small[i] = blob[GC_HDR + i];
-    for (int k = tid; k < K1p; k += 64 * GS_NW) {
-        const int kk = k < mt.K1 ? k : mt.K1 - 1;
-        const int c = kk / 9, t = kk - 9 * c, ky = t / 3;
-        koff[k] = c * PH * PW + ky * PW + (t - 3 * ky);
-    }
-    if (fu.on) gb_prologue<GS_PX, 64 * GS_NW>(fu, x, out, zr, zm, xin, H, W, img0, B, tid);
-    else gc_fill_xin_global<GS_PX, 64 * GS_NW>(x, xs_img, xin, mt.Cin, H, W, img0, B, tid);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's in-order accounting starts from an empty queue
+    // ---- block prologue ----
+    // the first stages go out FIRST (the ring is free: the previous block's col2im is behind a barrier) and land while
+    // the biases, the mix and the padded images are prepared.  The ring's in-order accounting needs an empty queue in front.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < GS_RING - 1; ++i)
         if (i < total_stages) issue(i);
+    for (int i = tid; i < mt.small; i += 64 * GS_NW) small[i] = blob[GC_HDR + i];
+    if (fused) gl_pre<GS_PX, 64 * GS_NW>(lv, b, zin, zalt, pl.wmix, xin, H, W, tid);
+    else gc_fill_xin_global<GS_PX, 64 * GS_NW>(x, xs_img, xin, mt.Cin, H, W, img0, B, tid);
     __syncthreads();
 
     // ---- GEMM 1: h1 (16 blocks of 16 channels) ----
@@ -630,7 +731,7 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
             }
         }
         __syncthreads();
-        gc_gather_block<GS_PX, 64 * GS_NW>(ring, 0, mt, H, W, img0, B, small, out, fu.on ? prm : nullptr, tid, mt.OB);
+        gc_gather_block<GS_PX, 64 * GS_NW>(ring, 0, mt, H, W, img0, B, small, out, fused ? pl.prm : nullptr, tid, mt.OB);
     } else {
 #pragma unroll
         for (int blk = 0; blk < OBT; ++blk) {
@@ -640,52 +741,66 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
 #pragma unroll
                     for (int r = 0; r < 4; ++r) P[(16 * ob + 4 * g + r) * GS_PX + px] = O[2 * blk + ob][r];
                 __syncthreads();
-                gc_gather_block<GS_PX, 64 * GS_NW>(P, blk, mt, H, W, img0, B, small, out, fu.on ? prm : nullptr, tid);
+                gc_gather_block<GS_PX, 64 * GS_NW>(P, blk, mt, H, W, img0, B, small, out, fused ? pl.prm : nullptr, tid);
                 __syncthreads();
             }
         }
     }
-    if (fu.on) gb_epilogue<GS_PX, 64 * GS_NW>(fu, out, zr, zm, prm, ldt, H, W, img0, B, tid);
+    if (fused) {
+        gl_post<GS_PX, 64 * GS_NW>(lv, b, zin, zalt, pl.wmix, pl.prm, pl.ldt, pl.ldacc, H, W, tid);
+        float *t_ = zin; zin = zalt; zalt = t_;
+    } else {
+        __syncthreads();
+    }
+    }  // blocks
+    if (fused) gl_store<GS_PX, 64 * GS_NW>(lv, zin, pl.ldacc, H, W, img0, B, tid);
 }
 
-// ---- tiny images (H W | 16): one 16-pixel tile per workgroup, the four waves split the ROWS of every GEMM ---------------
+// ---- tiny images (H W | 16): one 16-pixel tile per workgroup, the waves split the ROWS of every GEMM -------------------
 // Config 4's last level has 4096 pixels: pixel-parallel waves leave most SIMDs idle (64 workgroups of the kernel above),
 // and a wave's chain of ~4000 dependent-issue MFMAs is the run time.  Here a workgroup owns ONE tile of 16 pixels (whole
-// images again) and wave w computes rows [64 w, 64 w + 64) of h1 and h2 and a quarter of the output rows, for all 16
-// pixels.  Activations go through LDS in B-operand order acts[k / 16][(k / 4) % 4][pixel][k % 4] (one ds_read_b128 per
-// lane = the 4 B values of a 16-k block; one ds_write_b128 per lane stores a finished 16-row block), with a barrier
+// images again) and wave w computes rows [R w, R w + R), R = 256 / GT_NW, of h1 and h2 and its share of the output rows, for
+// all 16 pixels.  Activations go through LDS in B-operand order acts[k / 16][(k / 4) % 4][pixel][k % 4] (one ds_read_b128
+// per lane = the 4 B values of a 16-k block; one ds_write_b128 per lane stores a finished 16-row block), with a barrier
 // between the GEMMs.  Every wave streams only ITS rows' weights, and each weight is used by exactly one wave of the
 // workgroup: the A operands come straight from L2 into registers (global_load_dwordx4, 16 units = 16 KB per wave in
 // flight; a first version went through private LDS-DMA rings and was bound by the ~25 GB/s per CU that path delivers).
-// 256 workgroups x 4 waves fill every SIMD; each workgroup streams all weights once (0.93 MB at the 4x4 level).
+// 256 workgroups x GT_NW waves fill every SIMD (GT_NW = 8: two waves per SIMD, one's barrier / LDS / load waits under the
+// other's MFMAs); each workgroup streams all weights once (0.93 MB at the 4x4 level).  In a level chain the register
+// prefetch runs straight on into the next block's stream.
 constexpr int GT_PX = 16;
-constexpr int GT_NW = 4;
+#ifndef NF_GT_NW
+#define NF_GT_NW 8
+#endif
+constexpr int GT_NW = NF_GT_NW;
+constexpr int GT_BPW = 16 / GT_NW;   // 16-row blocks of h1 / h2 per wave
 constexpr int GT_PF = 16;          // units (16 rows x 16 k = [64 lanes][4] = 1 KB) a wave keeps in flight
 constexpr int GT_SLOT = 1024;      // floats of 4 units (blob granularity)
 
 struct GtMeta {
     int nkb1;    // 16-k blocks of GEMM 1, padded to a multiple of 16 (the register prefetch advances 16 units at a time)
-    int NB3;     // 16-row output blocks per wave = ceil(2 OB / 4)
-    int slots;   // slots per wave = nkb1 + 16 + 4 NB3
+    int NB3;     // 16-row output blocks per wave = ceil(2 OB / GT_NW)
+    int slots;   // slots (4 units) per wave = (GT_BPW nkb1 + GT_BPW 16 + 16 NB3) / 4
 };
 __host__ __device__ inline GtMeta gt_meta(const GcMeta &m) {
     GtMeta t;
     t.nkb1 = 16 * ((m.K1 + 255) / 256);
-    t.NB3 = (2 * m.OB + 3) / 4;
-    t.slots = t.nkb1 + 16 + 4 * t.NB3;
+    t.NB3 = (2 * m.OB + GT_NW - 1) / GT_NW;
+    t.slots = (GT_BPW * t.nkb1 + GT_BPW * 16 + 16 * t.NB3) / 4;
     return t;
 }
 __host__ __device__ inline int64_t gt_total_floats(const GcMeta &m) {
     return (int64_t)gc_off_stages(m) + (int64_t)GT_NW * gt_meta(m).slots * GT_SLOT;
 }
 
-// blob: header | biases (natural order) | wave 0's slots | wave 1's | wave 2's | wave 3's, each in consumption order:
-// GEMM 1 (own 4 row blocks x nkb1), GEMM 2 (own 4 x 16), GEMM 3 (own NB3 x 16); unit (16 rows x 16 k): lane (i = lane & 15,
-// g = lane >> 4) holds W[row i][16 kb + 4 g + r4].
+// blob: header | biases (natural order) | wave 0's slots | wave 1's | ..., each in consumption order:
+// GEMM 1 (own GT_BPW row blocks x nkb1), GEMM 2 (own GT_BPW x 16), GEMM 3 (own NB3 x 16); unit (16 rows x 16 k): lane
+// (i = lane & 15, g = lane >> 4) holds W[row i][16 kb + 4 g + r4].
 __global__ void gt_pack_kernel(const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W2,
                                const float *__restrict__ b2, const float *__restrict__ W3, const float *__restrict__ b3,
                                float *__restrict__ blob, GcMeta m, GtMeta t, int64_t total) {
     const int offs = gc_off_stages(m);
+    constexpr int R = 16 * GT_BPW;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         float v = 0.0f;
         if (i < GC_HDR) {
@@ -701,15 +816,15 @@ __global__ void gt_pack_kernel(const float *__restrict__ W1, const float *__rest
             const int q0 = (int)(e % ((int64_t)t.slots * GT_SLOT));
             const int r4 = q0 & 3, lane = (q0 >> 2) & 63, ri = lane & 15, g = lane >> 4;
             int q = q0 >> 8;   // unit index in the wave's stream
-            if (q < 4 * t.nkb1) {
+            if (q < GT_BPW * t.nkb1) {
                 const int bl = q / t.nkb1, kb = q - bl * t.nkb1;
                 const int k = 16 * kb + 4 * g + r4;
-                if (k < m.K1) v = W1[(size_t)(64 * w + 16 * bl + ri) * m.K1 + k];
-            } else if ((q -= 4 * t.nkb1) < 64) {
+                if (k < m.K1) v = W1[(size_t)(R * w + 16 * bl + ri) * m.K1 + k];
+            } else if ((q -= GT_BPW * t.nkb1) < GT_BPW * 16) {
                 const int bl = q >> 4, kb = q & 15;
-                v = W2[(size_t)(64 * w + 16 * bl + ri) * GC_HID + 16 * kb + 4 * g + r4];
+                v = W2[(size_t)(R * w + 16 * bl + ri) * GC_HID + 16 * kb + 4 * g + r4];
             } else {
-                q -= 64;
+                q -= GT_BPW * 16;
                 const int ol = q >> 4, kb = q & 15;
                 const int o16 = w * t.NB3 + ol, blk = o16 >> 1, rho = 16 * (o16 & 1) + ri;
                 const int cc = rho / 9, tap = rho - 9 * cc, co = 3 * blk + cc;
@@ -721,8 +836,8 @@ __global__ void gt_pack_kernel(const float *__restrict__ W1, const float *__rest
 }
 
 __global__ void __launch_bounds__(64 * GT_NW)
-glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__restrict__ out, const float *__restrict__ blob,
-                         GcMeta mt, GtMeta tm, int64_t B, int H, int W, GbFuse fu) {
+glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__restrict__ out, const float *__restrict__ blob0,
+                         GcMeta mt, GtMeta tm, int64_t B, int H, int W, GlowLevel lv) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int HW = H * W, PH = H + 2, PW = W + 2, IPW = GT_PX / HW;
     const int K1p = 16 * tm.nkb1;
@@ -734,30 +849,83 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
     float *small = h2s + GC_HID * GT_PX;
     int *koff = reinterpret_cast<int *>(small + gc_small_padded(mt));
     float *xin = reinterpret_cast<float *>(koff + K1p);
-    float *zr = xin + IPW * mt.Cin * PH * PW;
-    float *zm = zr + fu.C * GT_PX, *prm = zm + fu.C * GT_PX, *ldt = prm + mt.Cout * GT_PX;
+    const GlPlanes pl = gl_planes(xin + IPW * mt.Cin * PH * PW, lv, mt.Cout, GT_PX);
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, j16 = lane & 15;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t img0 = (int64_t)blockIdx.x * IPW;
+    const bool fused = lv.nblocks > 0;
+    const int nb = fused ? lv.nblocks : 1;
 
-    // the wave's weight stream: units in consumption order; the first 16 go out before anything else
-    const f32x4 *stream = reinterpret_cast<const f32x4 *>(blob + gc_off_stages(mt) + (size_t)wid * tm.slots * GT_SLOT) + lane;
+    // the wave's weight stream: units in consumption order, block after block; the first 16 go out before anything else.
+    // All stream bookkeeping is wave-uniform (scalar): pf_base = next unit to request, pf_left = units left in its block.
     const int nunits = 4 * tm.slots;
+    auto stream_of = [&](int bb) -> const float * {
+        return (fused ? lv.blob(bb) : blob0) + gc_off_stages(mt) + (size_t)wid * tm.slots * GT_SLOT;
+    };
+    const float *pf_base = stream_of(0);
+    int pf_left = nunits, pf_stride = 256;
+    const float *cross = nb > 1 ? stream_of(1) : pf_base + (size_t)(nunits - 1) * 256;   // where the stream goes on after this block
+    bool cross_last = nb <= 1;          // ... which is the dummy tail (the last unit again and again)
+    auto pf_next = [&]() -> f32x4 {
+        const f32x4 v = *(reinterpret_cast<const f32x4 *>(pf_base) + lane);
+        --pf_left;
+        const bool cr = pf_left == 0;
+        pf_base = cr ? cross : pf_base + pf_stride;
+        pf_stride = (cr && cross_last) ? 0 : pf_stride;
+        pf_left = cr ? (cross_last ? 0x40000000 : nunits) : pf_left;
+        return v;
+    };
     // (A per-workgroup rotation of the unit order, to keep the CUs of an XCD from asking the L2 for the same line at the
     // same moment, was measured: no gain -- and it made the summation order depend on the image's position in the batch.)
     f32x4 pf[GT_PF];
 #pragma unroll
-    for (int i = 0; i < GT_PF; ++i) pf[i] = stream[(size_t)(i < nunits ? i : nunits - 1) * 64];
-    int unit = 0;   // first unit of the group being consumed
+    for (int i = 0; i < GT_PF; ++i) pf[i] = pf_next();
 
-    // ---- prologue (shared): biases, im2col offsets, padded images, im2col columns ----
-    for (int i = tid; i < mt.small; i += 64 * GT_NW) small[i] = blob[GC_HDR + i];
     for (int k = tid; k < K1p; k += 64 * GT_NW) {
         const int kk = k < mt.K1 ? k : mt.K1 - 1;
         const int c = kk / 9, t = kk - 9 * c, ky = t / 3;
         koff[k] = c * PH * PW + ky * PW + (t - 3 * ky);
     }
-    if (fu.on) gb_prologue<GT_PX, 64 * GT_NW>(fu, x, out, zr, zm, xin, H, W, img0, B, tid);
+    float *zin = pl.zA, *zalt = pl.zB;
+    if (fused) gl_load<GT_PX, 64 * GT_NW>(lv, zin, pl.ldacc, H, W, img0, B, tid);
+
+    // acc (16 rows x 16 pixels) = sum over nkb (a multiple of 16) 16-k blocks of A (the stream) x B (LDS, B-operand order);
+    // every consumed unit is replaced by the load of the unit 16 ahead
+    auto gemm_block = [&](const float *bsrc, int nkb, f32x4 &acc) {
+        // four accumulators (one per r): a 16x16x4 MFMA has 40 cycles of dependent latency against 32 of issue, and the
+        // B operand of the NEXT unit is read from LDS while this unit's MFMAs run
+        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
+        auto bload = [&](int kb) { return *reinterpret_cast<const f32x4 *>(bsrc + ((kb * 4 + g) * GT_PX + j16) * 4); };
+        f32x4 bq = bload(0);
+        for (int kb0 = 0; kb0 < nkb; kb0 += GT_PF) {
+#pragma unroll
+            for (int u = 0; u < GT_PF; ++u) {
+                const f32x4 a = pf[u];
+                pf[u] = pf_next();
+                // B of the following unit (clamped at the block's end)
+                const int kbn = kb0 + u + 1;
+                const f32x4 bn = bload(kbn < nkb ? kbn : 0);
+                __builtin_amdgcn_sched_barrier(0);   // keep both loads HERE: the scheduler otherwise sinks them to the group's end
+                acc = GC_MFMA16(a[0], bq[0], acc);
+                acc1 = GC_MFMA16(a[1], bq[1], acc1);
+                acc2 = GC_MFMA16(a[2], bq[2], acc2);
+                acc3 = GC_MFMA16(a[3], bq[3], acc3);
+                bq = bn;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += (acc1[r] + acc2[r]) + acc3[r];
+    };
+
+    for (int b = 0; b < nb; ++b) {
+    const float *blob = fused ? lv.blob(b) : blob0;
+    // where the prefetch continues when it runs off the end of THIS block's stream (it does so 16 units before the end)
+    cross = (b + 1 < nb) ? stream_of(b + 1) : stream_of(b) + (size_t)(nunits - 1) * 256;
+    cross_last = b + 1 >= nb;
+
+    // ---- block prologue (shared): biases, padded images, im2col columns ----
+    for (int i = tid; i < mt.small; i += 64 * GT_NW) small[i] = blob[GC_HDR + i];
+    if (fused) gl_pre<GT_PX, 64 * GT_NW>(lv, b, zin, zalt, pl.wmix, xin, H, W, tid);
     else gc_fill_xin_global<GT_PX, 64 * GT_NW>(x, xs_img, xin, mt.Cin, H, W, img0, B, tid);
     __syncthreads();
     for (int i = tid; i < K1p * GT_PX; i += 64 * GT_NW) {
@@ -768,40 +936,9 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
     }
     __syncthreads();
 
-    // acc (16 rows x 16 pixels) = sum over nkb (a multiple of 16) 16-k blocks of A (the stream) x B (LDS, B-operand order);
-    // every consumed unit is replaced by the load of the unit 16 ahead; two accumulators alternate so that consecutive
-    // MFMAs are independent
-    auto gemm_block = [&](const float *bsrc, int nkb, f32x4 &acc) {
-        // four accumulators (one per r): a 16x16x4 MFMA has 40 cycles of dependent latency against 32 of issue, and the
-        // B operand of the NEXT unit is read from LDS while this unit's MFMAs run
-        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
-        auto bload = [&](int kb) { return *reinterpret_cast<const f32x4 *>(bsrc + ((kb * 4 + g) * GT_PX + j16) * 4); };
-        f32x4 b = bload(0);
-        for (int kb0 = 0; kb0 < nkb; kb0 += GT_PF) {
-#pragma unroll
-            for (int u = 0; u < GT_PF; ++u) {
-                const f32x4 a = pf[u];
-                const int nxt = unit + GT_PF + u;
-                pf[u] = stream[(size_t)(nxt < nunits ? nxt : nunits - 1) * 64];
-                // B of the following unit (clamped at the block's end)
-                const int kbn = kb0 + u + 1;
-                const f32x4 bn = bload(kbn < nkb ? kbn : 0);
-                __builtin_amdgcn_sched_barrier(0);   // keep both loads HERE: the scheduler otherwise sinks them to the group's end
-                acc = GC_MFMA16(a[0], b[0], acc);
-                acc1 = GC_MFMA16(a[1], b[1], acc1);
-                acc2 = GC_MFMA16(a[2], b[2], acc2);
-                acc3 = GC_MFMA16(a[3], b[3], acc3);
-                b = bn;
-            }
-            unit += GT_PF;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] += (acc1[r] + acc2[r]) + acc3[r];
-    };
-
     // ---- GEMM 1 -> h1s ----
-    for (int bl = 0; bl < 4; ++bl) {
-        const int b16 = 4 * wid + bl;
+    for (int bl = 0; bl < GT_BPW; ++bl) {
+        const int b16 = GT_BPW * wid + bl;
         f32x4 acc = *reinterpret_cast<const f32x4 *>(small + 16 * b16 + 4 * g);
         gemm_block(cols, tm.nkb1, acc);
         gs_leaky(acc, mt.slope);
@@ -809,8 +946,8 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
     }
     __syncthreads();
     // ---- GEMM 2 -> h2s ----
-    for (int bl = 0; bl < 4; ++bl) {
-        const int b16 = 4 * wid + bl;
+    for (int bl = 0; bl < GT_BPW; ++bl) {
+        const int b16 = GT_BPW * wid + bl;
         f32x4 acc = *reinterpret_cast<const f32x4 *>(small + GC_HID + 16 * b16 + 4 * g);
         gemm_block(h1s, 16, acc);
         gs_leaky(acc, mt.slope);
@@ -827,11 +964,18 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
     }
     __syncthreads();
     // ---- col2im over all output blocks in one flat loop ----
-    gc_gather_block<GT_PX, 64 * GT_NW>(P, 0, mt, H, W, img0, B, small, out, fu.on ? prm : nullptr, tid, mt.OB);
-    if (fu.on) gb_epilogue<GT_PX, 64 * GT_NW>(fu, out, zr, zm, prm, ldt, H, W, img0, B, tid);
+    gc_gather_block<GT_PX, 64 * GT_NW>(P, 0, mt, H, W, img0, B, small, out, fused ? pl.prm : nullptr, tid, mt.OB);
+    if (fused) {
+        gl_post<GT_PX, 64 * GT_NW>(lv, b, zin, zalt, pl.wmix, pl.prm, pl.ldt, pl.ldacc, H, W, tid);
+        float *t_ = zin; zin = zalt; zalt = t_;
+    } else {
+        __syncthreads();
+    }
+    }  // blocks
+    if (fused) gl_store<GT_PX, 64 * GT_NW>(lv, zin, pl.ldacc, H, W, img0, B, tid);
 }
 
-static inline size_t gt_lds_bytes(const GcMeta &m, const GtMeta &t, int H, int W, const GbFuse &fu) {
+static inline size_t gt_lds_bytes(const GcMeta &m, const GtMeta &t, int H, int W, const GlowLevel &fu) {
     const int IPW = GT_PX / (H * W), K1p = 16 * t.nkb1;
     const int p_floats = GT_NW * t.NB3 * 16 * GT_PX, a_floats = K1p * GT_PX + GC_HID * GT_PX;
     return ((size_t)(p_floats > a_floats ? p_floats : a_floats) + GC_HID * GT_PX +
@@ -839,13 +983,13 @@ static inline size_t gt_lds_bytes(const GcMeta &m, const GtMeta &t, int H, int W
                sizeof(float) + 16;
 }
 
-static inline size_t gs_lds_bytes(const GcMeta &m, int H, int W, const GbFuse &fu) {
+static inline size_t gs_lds_bytes(const GcMeta &m, int H, int W, const GlowLevel &fu) {
     const int IPW = GS_PX / (H * W);
     return ((size_t)GS_RING * GC_STAGE + 32 * GS_PX + gc_small_padded(m) + 16 * ((m.K1 + 15) / 16) +
             (size_t)IPW * m.Cin * (H + 2) * (W + 2) + gb_lds_floats(fu, m.Cout, GS_PX)) * sizeof(float) + 16;
 }
 
-static inline size_t gc_lds_bytes(const GcMeta &m, int H, int W, const GbFuse &fu) {
+static inline size_t gc_lds_bytes(const GcMeta &m, int H, int W, const GlowLevel &fu) {
     const int IPW = GC_PX / (H * W);
     return ((size_t)2 * GC_STAGE + 32 * GC_PX + gc_small_padded(m) + 8 * m.nkg1 +
             (size_t)IPW * m.Cin * (H + 2) * (W + 2) + gb_lds_floats(fu, m.Cout, GC_PX)) * sizeof(float) + 16;
@@ -906,7 +1050,7 @@ extern "C" int nf_glow_convnet_layout(int64_t B, int H, int W) {
 
 template <int OBT>
 static int launch_small(const void *x, int64_t xs, void *out, const void *wpack, const GcMeta &m, int64_t B, int H, int W,
-                        const GbFuse &fu, hipStream_t st) {
+                        const GlowLevel &fu, hipStream_t st) {
     const size_t lds = gs_lds_bytes(m, H, W, fu);
     if (lds > 160 * 1024) return NF_ENOTSUP;
     static LdsOptIn opted = {};
@@ -921,7 +1065,7 @@ static int launch_small(const void *x, int64_t xs, void *out, const void *wpack,
 }
 
 static int gc_launch(const void *x, int64_t xs, void *out, const void *wpack, const GcMeta &m, int64_t B, int H, int W,
-                     int layout, const GbFuse &fu, hipStream_t st) {
+                     int layout, const GlowLevel &fu, hipStream_t st) {
     const int PXW = layout == NF_GLOW_CONV_WIDE ? GC_PX : (layout == NF_GLOW_CONV_SMALL ? GS_PX : GT_PX);
     if (H * W > PXW || PXW % (H * W) != 0) return NF_ENOTSUP;   // whole images per workgroup
     if (layout == NF_GLOW_CONV_TINY) {
@@ -965,13 +1109,14 @@ extern "C" int nf_glow_convnet(const void *x, int64_t x_image_stride, void *out,
     if (B < 0 || H < 1 || W < 1 || x_image_stride < (int64_t)Cin * H * W) return NF_EINVAL;
     if (B == 0) return NF_OK;
     if (!x || !out || !wpack) return NF_EFAULT;
-    GbFuse fu = {};
-    return gc_launch(x, x_image_stride, out, wpack, gc_meta(Cin, Cout, leaky_slope), B, H, W, layout, fu, (hipStream_t)stream);
+    GlowLevel lv = {};
+    return gc_launch(x, x_image_stride, out, wpack, gc_meta(Cin, Cout, leaky_slope), B, H, W, layout, lv, (hipStream_t)stream);
 }
 
-extern "C" int nf_glow_block(const void *z, void *y, void *logdet, const void *wpack, const void *mix_w, const void *mix_b,
-                             const void *mix_logdet, int64_t B, int C, int H, int W, int hidden, double leaky_slope,
-                             int scale_map, int direction, int acc, int layout, nf_stream_t stream) {
+extern "C" int nf_glow_level(const void *in0, const void *in1, int cin0, int in_squeezed, void *out0, void *out1, int cout0,
+                             int out_squeezed, void *logdet, const void *block_table, int nblocks, int64_t B, int C, int H,
+                             int W, int hidden, double leaky_slope, int scale_map, int direction, int acc, int layout,
+                             nf_stream_t stream) {
     if (C < 2) return NF_EINVAL;
     const int c1 = (C + 1) / 2, Cout = 2 * (C - c1);
     const int rc = gc_check(c1, Cout, hidden, leaky_slope);
@@ -980,12 +1125,21 @@ extern "C" int nf_glow_block(const void *z, void *y, void *logdet, const void *w
     if (scale_map < NF_SCALE_EXP || scale_map > NF_SCALE_SIGMOID_INV) return NF_EINVAL;
     if ((direction != 0 && direction != 1) || acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
     if (B < 0 || H < 1 || W < 1) return NF_EINVAL;
+    if (nblocks < 1 || nblocks > GL_MAXB) return NF_ERANGE;
+    if ((in_squeezed || out_squeezed) && (C % 4) != 0) return NF_EINVAL;
+    if (!in_squeezed && (cin0 < 1 || cin0 > C)) return NF_EINVAL;
+    if (!out_squeezed && (cout0 < 1 || cout0 > C)) return NF_EINVAL;
     if (B == 0) return NF_OK;
-    if (!z || !y || !logdet || !wpack || !mix_w || !mix_b || !mix_logdet) return NF_EFAULT;
-    GbFuse fu = {};
-    fu.on = 1; fu.C = C; fu.c1 = c1; fu.scale_map = scale_map; fu.direction = direction; fu.acc = acc;
-    fu.Wp = (const float *)mix_w; fu.bp = (const float *)mix_b; fu.ldu = (const float *)mix_logdet;
-    fu.logdet = (float *)logdet;
-    return gc_launch(z, (int64_t)C * H * W, y, wpack, gc_meta(c1, Cout, leaky_slope), B, H, W, layout, fu,
+    if (!in0 || !out0 || !logdet || !block_table) return NF_EFAULT;
+    if (!in_squeezed && cin0 < C && !in1) return NF_EFAULT;
+    if (!out_squeezed && cout0 < C && !out1) return NF_EFAULT;
+    GlowLevel lv = {};
+    lv.tbl = (const float *const *)block_table;
+    lv.nblocks = nblocks;
+    lv.C = C; lv.c1 = c1; lv.scale_map = scale_map; lv.direction = direction; lv.acc = acc;
+    lv.in0 = (const float *)in0; lv.in1 = (const float *)in1; lv.cin0 = in_squeezed ? C : cin0; lv.in_sq = in_squeezed ? 1 : 0;
+    lv.out0 = (float *)out0; lv.out1 = (float *)out1; lv.cout0 = out_squeezed ? C : cout0; lv.out_sq = out_squeezed ? 1 : 0;
+    lv.logdet = (float *)logdet;
+    return gc_launch(in0, (int64_t)C * H * W, out0, nullptr, gc_meta(c1, Cout, leaky_slope), B, H, W, layout, lv,
                      (hipStream_t)stream);
 }

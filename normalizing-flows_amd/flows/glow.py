@@ -63,21 +63,38 @@ class GlowBlock(Flow):
         return cache[1]
 
     def _whole_block(self, z):
-        """(packed conditioner, layout, LeakyReLU slope, scale map) when the block is the shape nf_glow_block takes:
-        channel split, scale = True, the 3x3 -> 1x1 -> 3x3 conditioner around 256 channels, float32, enough pixels."""
+        """(packed conditioner, layout, LeakyReLU slope, scale map) when the block runs as one launch for inputs like `z`
+        (channel split, scale = True, the 3x3 -> 1x1 -> 3x3 conditioner around 256 channels, float32, enough pixels)."""
+        if z.dim() != 4 or z.dtype != torch.float32 or not z.is_cuda:
+            return None
+        ent = self._level_entry(*z.shape, True)
+        return None if ent is None else (ent[0][0], ent[1], ent[2], ent[3])
+
+    def _level_entry(self, B, C, H, W, inverse):
+        """What nf_glow_level needs from this block for (B, C, H, W) float32 inputs -- (table entry, layout, slope, scale
+        map) -- or None when the block is not the shape the kernels take, its ActNorm is not initialised yet, or gradients
+        are required."""
+        from ..autograd import needs_grad
+        if len(self.flows) != 3 or C < 2 or needs_grad(self):
+            return None
         blk = self.flows[0]
-        if not isinstance(blk, AffineCouplingBlock) or blk.split_mode != "channel" or z.shape[1] < 2:
+        if not isinstance(blk, AffineCouplingBlock) or blk.split_mode != "channel":
             return None
         coupling = blk.flows[1]
         net = coupling.param_map
-        if not coupling.scale or not isinstance(net, nets.ConvNet2d) or z.dtype != torch.float32:
+        if not coupling.scale or not isinstance(net, nets.ConvNet2d):
             return None
-        zc = z if z.is_contiguous() else z.contiguous()
-        c1 = (z.shape[1] + 1) // 2
-        fused = net._fused_pack(zc[:, :c1])
-        if fused is None or net.net[-1].out_channels != 2 * (z.shape[1] - c1):
+        mix = self._fused_mix(inverse)
+        if mix is None or mix[0].dtype != torch.float32 or mix[0].shape[0] != C:
             return None
-        return fused[0], fused[1], net.net[1].negative_slope, coupling.scale_map
+        c1 = (C + 1) // 2
+        if net.net[0].in_channels != c1 or net.net[-1].out_channels != 2 * (C - c1):
+            return None
+        fused = net._fused_pack_for(B, H, W)
+        if fused is None:
+            return None
+        Wp, bp, ldp = mix
+        return (fused[0], Wp, bp, ldp), fused[1], net.net[1].negative_slope, coupling.scale_map
 
     def _run(self, z, inverse, ld, acc, **kw):
         from .. import ops
@@ -88,15 +105,14 @@ class GlowBlock(Flow):
             mix = self._fused_mix(inverse)
             if mix is not None:
                 Wp, bp, ldp = mix
-                whole = self._whole_block(z)
-                if whole is not None:   # coupling + conditioner + mix: one launch (csrc/glow_conv.hip, nf_glow_block)
-                    blob, layout, slope, smap = whole
+                ent = self._level_entry(*z.shape, inverse) if z.dtype == torch.float32 and z.is_cuda else None
+                if ent is not None:   # coupling + conditioner + mix: one launch (csrc/glow_conv.hip, nf_glow_level)
+                    entry, layout, slope, smap = ent
                     refused = self.__dict__.setdefault("_whole_refused", set())
                     key = (layout, tuple(z.shape[1:]))
                     if key not in refused:
                         try:
-                            y, _ = ops.glow_block(z, blob, layout, Wp, bp, ldp, slope, smap, 1 if inverse else 0,
-                                                  logdet=ld, acc=acc)
+                            y, _ = run_level([self], [entry], layout, slope, smap, z, None, False, inverse, ld, acc)
                             return y
                         except NotImplementedError:   # the block's working set does not fit one workgroup's LDS:
                             refused.add(key)          # nothing was launched; keep the layer-by-layer path for this shape
@@ -118,3 +134,45 @@ class GlowBlock(Flow):
     def inverse(self, z):
         ld = torch.zeros(z.shape[0], dtype=z.dtype, device=z.device)
         return self._run(z, True, ld, +1), ld
+
+
+_MAX_LEVEL_BLOCKS = 64     # GL_MAXB of csrc/glow_conv.hip
+
+
+def run_level(blocks, entries, layout, slope, scale_map, in0, in1, in_squeezed, inverse, ld, acc, cout0=None,
+              out_squeezed=False):
+    """`blocks` (GlowBlocks in PROCESSING order, with their _level_entry table entries) as one persistent launch.  The
+    device pointer table is cached on the first block per (direction, member tensors): building it is a host -> device copy,
+    and a recorded hipGraph bakes its address in."""
+    from .. import ops
+    first = blocks[0]
+    key = (inverse, layout) + tuple(t.data_ptr() for e in entries for t in e)
+    cache = first.__dict__.setdefault("_level_tbl_cache", {})
+    hit = cache.get((inverse, len(blocks)))
+    if hit is None or hit[0] != key:
+        ents = [(b_, w_.contiguous(), bb_.contiguous(), l_.to(torch.float32).contiguous()) for b_, w_, bb_, l_ in entries]
+        hit = cache[(inverse, len(blocks))] = (key,) + ops.glow_block_table(ents, in0.device)
+    if in_squeezed:
+        C, H, W = in0.shape[1] * 4, in0.shape[2] // 2, in0.shape[3] // 2
+    else:
+        C, H, W = in0.shape[1] + (0 if in1 is None else in1.shape[1]), in0.shape[2], in0.shape[3]
+    out0, out1, _ = ops.glow_level(in0, in1, in_squeezed, C, H, W, hit[1], len(blocks), layout, slope, scale_map,
+                                   1 if inverse else 0, cout0=cout0, out_squeezed=out_squeezed, logdet=ld, acc=acc)
+    return out0, out1
+
+
+def plan_level(flows, B, C, H, W, inverse):
+    """Longest prefix of `flows` (GlowBlocks in processing order, <= 64) that nf_glow_level takes as ONE launch on
+    (B, C, H, W) float32 inputs: (n, entries, layout, slope, scale_map); n = 0 when the first block is not eligible."""
+    entries, sig = [], None
+    for f in flows[:_MAX_LEVEL_BLOCKS]:
+        if not isinstance(f, GlowBlock):
+            break
+        ent = f._level_entry(B, C, H, W, inverse)
+        if ent is None or (sig is not None and ent[1:] != sig):
+            break
+        sig = ent[1:]
+        entries.append(ent[0])
+    if not entries:
+        return 0, None, None, None, None
+    return (len(entries), entries) + sig

@@ -237,9 +237,18 @@ class ConvNet2d(nn.Module):
     def _fused_pack(self, x):
         """(packed weights, layout) for ops.glow_convnet when this is the GlowBlock network (3x3 -> 1x1 -> 3x3 around 256
         hidden channels, biases, equal LeakyReLU slopes) and the call is one a kernel takes; None otherwise.  Repacked
-        when a parameter changes; one pack per layout (256-pixel or 64-pixel workgroups)."""
+        when a parameter changes; one pack per layout (256-, 64- or 16-pixel workgroups)."""
+        if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
+            return None
+        B, Cin, H, W = x.shape
+        if x.stride(3) != 1 or x.stride(2) != W or x.stride(1) != H * W:
+            return None
+        return self._fused_pack_for(B, H, W)
+
+    def _fused_pack_for(self, B, H, W):
+        """_fused_pack for a float32 device input of shape (B, Cin, H, W) that need not exist yet (level chains)."""
         mods = list(self.net)
-        if len(mods) != 5 or not x.is_cuda or x.dtype != torch.float32 or torch.is_grad_enabled() or x.dim() != 4:
+        if len(mods) != 5 or torch.is_grad_enabled():
             return None
         c1, a1, c2, a2, c3 = mods
         if not (isinstance(c1, nn.Conv2d) and isinstance(c2, nn.Conv2d) and isinstance(c3, nn.Conv2d)
@@ -251,14 +260,13 @@ class ConvNet2d(nn.Module):
             return None
         if a1.negative_slope != a2.negative_slope or not 0.0 <= a1.negative_slope <= 1.0:
             return None
+        if not c1.weight.is_cuda or c1.weight.dtype != torch.float32:
+            return None
         from . import ops
-        B, Cin, H, W = x.shape
         if B * H * W < self.FUSED_MIN_PIXELS:
             return None
         layout = ops.glow_convnet_layout(B, H, W)
         if layout is None or (layout == ops.GLOW_CONV_WIDE and B * H * W < self.FUSED_WIDE_MIN_PIXELS):
-            return None
-        if x.stride(3) != 1 or x.stride(2) != W or x.stride(1) != H * W:
             return None
         params = [c1.weight, c1.bias, c2.weight, c2.bias, c3.weight, c3.bias]
         key = tuple((p_.data_ptr(), p_._version) for p_ in params)

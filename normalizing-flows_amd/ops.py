@@ -520,25 +520,69 @@ def glow_convnet(x, blob, Cout, slope, layout=GLOW_CONV_WIDE, hidden=256):
     return out
 
 
-def glow_block(z, blob, layout, mix_w, mix_b, mix_logdet, slope, scale_map, direction, logdet=None, acc=None, hidden=256):
-    """GlowBlock.forward (direction 0) / .inverse (1) in one launch (nf_glow_block): channel-split affine coupling with
-    the packed conditioner `blob`, and [Invertible1x1Conv, ActNorm] as the per-pixel affine map (mix_w, mix_b) with
-    log|det| per pixel mix_logdet (0-dim device tensor)."""
-    L.require_device(z, blob, mix_w, mix_b, mix_logdet)
-    if z.dtype != torch.float32:
-        raise NotImplementedError("glow_block: float32 only")
-    z = z.contiguous()
-    B, C, H, W = z.shape
-    y = torch.empty_like(z)
+def glow_block_table(entries, device):
+    """DEVICE pointer table of nf_glow_level: `entries` = [(blob, mix_w, mix_b, mix_logdet), ...] in processing order (all
+    float32, contiguous, on `device`).  Returns (int64 tensor of 4 n pointers, the entries -- keep both alive while a launch
+    or a recorded graph may use the table)."""
+    ptrs = []
+    for blob, w, b_, l in entries:
+        L.require_device(blob, w, b_, l)
+        for t in (blob, w, b_, l):
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError("glow_block_table: float32 contiguous tensors")
+            ptrs.append(t.data_ptr())
+    return torch.tensor(ptrs, dtype=torch.int64).to(device), entries
+
+
+def glow_level(in0, in1, in_squeezed, C, H, W, table, nblocks, layout, slope, scale_map, direction, cout0=None,
+               out_squeezed=False, logdet=None, acc=None, hidden=256):
+    """`nblocks` GlowBlocks of one shape in ONE persistent launch (nf_glow_level) with the level's glue folded in.
+    Input: in_squeezed -> in0 is (B, C/4, 2H, 2W) read through Squeeze.inverse; else channels of in0 (B, cin0, H, W) then
+    in1 (B, C - cin0, H, W) (in1 None: in0 has all C channels).  Output: out_squeezed -> (B, C/4, 2H, 2W) through
+    Squeeze.forward; cout0 < C -> two tensors split after cout0 channels; else one (B, C, H, W) tensor.
+    Returns (out0, out1 or None, logdet)."""
+    L.require_device(in0, in1, table)
+    if in0.dtype != torch.float32 or (in1 is not None and in1.dtype != torch.float32):
+        raise NotImplementedError("glow_level: float32 only")
+    in0 = in0.contiguous()
+    in1 = None if in1 is None else in1.contiguous()
+    B = in0.shape[0]
+    cin0 = C if in_squeezed else in0.shape[1]
+    if in_squeezed:
+        assert tuple(in0.shape[1:]) == (C // 4, 2 * H, 2 * W), (in0.shape, C, H, W)
+    else:
+        assert tuple(in0.shape[2:]) == (H, W) and (cin0 == C or (in1 is not None and in1.shape[1] == C - cin0))
+    if cout0 is None or out_squeezed:
+        cout0 = C
+    if out_squeezed:
+        out0, out1 = torch.empty(B, C // 4, 2 * H, 2 * W, dtype=in0.dtype, device=in0.device), None
+    else:
+        out0 = torch.empty(B, cout0, H, W, dtype=in0.dtype, device=in0.device)
+        out1 = torch.empty(B, C - cout0, H, W, dtype=in0.dtype, device=in0.device) if cout0 < C else None
     if logdet is None:
-        logdet = torch.empty(B, dtype=z.dtype, device=z.device)
+        logdet = torch.empty(B, dtype=in0.dtype, device=in0.device)
         acc = L.LD_WRITE
     elif acc is None:
         acc = L.LD_ADD
-    rc = L.lib().nf_glow_block(ptr(z), ptr(y), ptr(logdet), ptr(blob), ptr(mix_w.contiguous()), ptr(mix_b.contiguous()),
-                               ptr(mix_logdet.to(z.dtype).contiguous()), i64(B), i32(C), i32(H), i32(W), i32(hidden), f64(slope),
-                               i32(L.SCALE[scale_map]), i32(direction), i32(acc), i32(layout), L.stream())
-    L.check(rc, "nf_glow_block")
+    rc = L.lib().nf_glow_level(ptr(in0), ptr(in1), i32(cin0), i32(1 if in_squeezed else 0), ptr(out0), ptr(out1), i32(cout0),
+                               i32(1 if out_squeezed else 0), ptr(logdet), ptr(table), i32(nblocks), i64(B), i32(C), i32(H),
+                               i32(W), i32(hidden), f64(slope), i32(L.SCALE[scale_map]), i32(direction), i32(acc), i32(layout),
+                               L.stream())
+    L.check(rc, "nf_glow_level")
+    return out0, out1, logdet
+
+
+def glow_block(z, blob, layout, mix_w, mix_b, mix_logdet, slope, scale_map, direction, logdet=None, acc=None, hidden=256,
+               table=None):
+    """GlowBlock.forward (direction 0) / .inverse (1) in one launch (nf_glow_level with one block): channel-split affine
+    coupling with the packed conditioner `blob`, and [Invertible1x1Conv, ActNorm] as the per-pixel affine map (mix_w,
+    mix_b) with log|det| per pixel mix_logdet (0-dim device tensor).  `table`: a cached glow_block_table of the block."""
+    if table is None:
+        table = glow_block_table([(blob, mix_w.contiguous(), mix_b.contiguous(), mix_logdet.to(z.dtype).contiguous())],
+                                 z.device)[0]
+    B, C, H, W = z.shape
+    y, _, logdet = glow_level(z, None, False, C, H, W, table, 1, layout, slope, scale_map, direction, logdet=logdet, acc=acc,
+                              hidden=hidden)
     return y, logdet
 
 

@@ -558,14 +558,15 @@ def test_multiscale_graphs_follow_parameter_reloads_and_do_not_alias(nfa):
     e1, e2 = N(m.log_prob(x1)), N(m.log_prob(x2))
     m.use_graphs(True)
     outs = [m.log_prob(x1), m.log_prob(x2)]         # second replay must not overwrite the first result
-    assert np.array_equal(N(outs[0]), e1) and np.array_equal(N(outs[1]), e2)
-    sd2 = {k: (v * 1.01 if v.is_floating_point() and v.dim() > 0 and "flows" in k and k.endswith(".t") else v)
+    # (16 images leave some levels on the library convolutions, whose summation order may differ run to run: 1e-6, not bits)
+    assert _rel(N(outs[0]), e1) < 1e-6 and _rel(N(outs[1]), e2) < 1e-6 and outs[0].data_ptr() != outs[1].data_ptr()
+    sd2 = {k: (v * 1.1 if v.is_floating_point() and v.dim() > 0 and "flows" in k and k.endswith(".t") else v)
            for k, v in m.state_dict().items()}
     m.load_state_dict(sd2)                          # drops the graphs
     g3 = N(m.log_prob(x1))
     m.use_graphs(False)
-    assert np.array_equal(g3, N(m.log_prob(x1)))
-    assert not np.array_equal(g3, e1)
+    assert _rel(g3, N(m.log_prob(x1))) < 1e-6
+    assert _rel(g3, e1) > 1e-5
     # in-place update + refresh_graphs()
     m.use_graphs(True)
     m.log_prob(x1)
@@ -575,7 +576,7 @@ def test_multiscale_graphs_follow_parameter_reloads_and_do_not_alias(nfa):
     m.refresh_graphs()
     g4 = N(m.log_prob(x1))
     m.use_graphs(False)
-    assert np.array_equal(g4, N(m.log_prob(x1)))
+    assert _rel(g4, N(m.log_prob(x1))) < 1e-6
 
 
 def test_glow_config4_shapes_through_the_block_kernels(nfa):

@@ -90,17 +90,24 @@ def test_c_abi_argument_validation_newer_entry_points(nfa):
     assert lib.nf_glow_convnet_layout(i64(256), i32(8), i32(8)) == 1        # 64 such workgroups: the 64-pixel kernel
     assert lib.nf_glow_convnet_layout(i64(256), i32(4), i32(4)) == 2        # 4096 pixels: 16-pixel row-split workgroups
     assert lib.nf_glow_convnet_layout(i64(4), i32(16), i32(16)) == 0 and lib.nf_glow_convnet_layout(i64(4), i32(5), i32(5)) == -95
-    # one size for every layout: header + biases + max(32 stages of 16 KB, 4 waves x (16 + 16 + 4 x 2) slots of 4 KB)
-    assert lib.nf_glow_convnet_pack_size(i32(6), i32(12), i32(256)) == 4 * (64 + 576 + max((8 + 16 + 8) * 4096, 4 * 40 * 1024))
+    # one size for every layout: header + biases + max(32 stages of 16 KB, 8 waves x (2 x 16 + 2 x 16 + 16) / 4 slots of 4 KB)
+    assert lib.nf_glow_convnet_pack_size(i32(6), i32(12), i32(256)) == 4 * (64 + 576 + max((8 + 16 + 8) * 4096, 8 * 20 * 1024))
     assert lib.nf_glow_convnet_pack_size(i32(6), i32(12), i32(128)) == -95
     gc = lambda B, H, W, layout, slope=0.0, x=one: lib.nf_glow_convnet(x, i64(6 * H * W), one, one, i64(B), i32(6), i32(H),
                                                                      i32(W), i32(12), i32(256), f64(slope), i32(layout), null)
     assert gc(4, 16, 16, 1) == -95 and gc(4, 5, 5, 0) == -95                 # whole images must tile the workgroup
     assert gc(4, 16, 16, 3) == -22 and gc(4, 16, 16, 2) == -95 and gc(4, 16, 16, 0, slope=1.5) == -22
     assert gc(4, 16, 16, 0, x=null) == -14 and gc(0, 16, 16, 0) == 0
-    gb = lambda C, smap, direction: lib.nf_glow_block(one, one, one, one, one, one, one, i64(0), i32(C), i32(8), i32(8), i32(256),
-                                                      f64(0.0), i32(smap), i32(direction), i32(0), i32(1), null)
-    assert gb(12, 1, 1) == 0 and gb(1, 1, 1) == -22 and gb(12, 3, 1) == -22 and gb(12, 1, 2) == -22
+    # nf_glow_level(in0, in1, cin0, in_sq, out0, out1, cout0, out_sq, logdet, table, nblocks, B, C, H, W, hidden, slope, smap,
+    #               direction, acc, layout, stream)
+    def gl(C=12, smap=1, direction=1, nblocks=1, B=0, in_sq=0, out_sq=0, cin0=12, cout0=12, in1=null, out1=null, table=one):
+        return lib.nf_glow_level(one, in1, i32(cin0), i32(in_sq), one, out1, i32(cout0), i32(out_sq), one, table, i32(nblocks),
+                                 i64(B), i32(C), i32(8), i32(8), i32(256), f64(0.0), i32(smap), i32(direction), i32(0), i32(1), null)
+    assert gl() == 0 and gl(C=1) == -22 and gl(smap=3) == -22 and gl(direction=2) == -22
+    assert gl(nblocks=0) == -34 and gl(nblocks=65) == -34                  # 1..64 blocks per launch
+    assert gl(C=10, cin0=10, cout0=10, in_sq=1) == -22                      # the squeeze views need C % 4 == 0
+    assert gl(B=4, cin0=6) == -14 and gl(B=4, cout0=6) == -14               # the second tensor of a merge / split is missing
+    assert gl(B=4, table=null) == -14 and gl(B=4, cin0=13) == -22
     # per-feature backward: type codes required with NF_TAILS_FEATURE, refused otherwise
     def bwd_ft(tails, tt, ti=null, uw=null):
         return lib.nf_rqs_coupling_bwd_ft(one, one, one, one, uw, uw, uw, one, i32(2), one, i32(2), i64(4), i32(4), i32(4),

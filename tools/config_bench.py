@@ -53,6 +53,8 @@ def c1():
 
 
 def c4():
+    if os.environ.get("NF_GLOW_CHAINS") == "0":       # ablation: one launch per GlowBlock + separate Squeeze / Split glue
+        nfa.config.set_glow_level_chains(False)
     torch.manual_seed(0)
     L_, K_, hidden, channels = 3, 32, 256, 3
     input_shape = (3, 32, 32)
