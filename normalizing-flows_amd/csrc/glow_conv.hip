@@ -34,6 +34,10 @@ constexpr int GC_NW = 8;             // waves per workgroup
 constexpr int GC_PX = 32 * GC_NW;    // pixels per workgroup
 constexpr int GC_HDR = 64;
 constexpr int GC_STAGE = 4096;       // floats per stage (16 KB)
+#ifndef NF_GC_RING
+#define NF_GC_RING 3
+#endif
+constexpr int GC_RING = NF_GC_RING;  // weight-ring slots of the 256-pixel kernel
 constexpr int GC_OBP = 4;            // output row-blocks (x 3 channels) per sweep
 constexpr int GC_KG1MAX = 16;        // k-groups of GEMM 1 whose gathered operands are kept in registers (one stage)
 
@@ -171,11 +175,24 @@ struct GlowLevel {
     float *out0, *out1;           // level output: channels [0, cout0) -> out0, the rest -> out1; or, out_sq = 1, through
     int cout0, out_sq;            //   the Squeeze.forward view into out0 = (B, C / 4, 2H, 2W)
     float *logdet;                // (B)
+#ifdef NF_GL_TRACE
+    unsigned long long *trace;    // debug builds: phase timestamps of workgroup 0 (100 MHz wall clock), 8 per block
+#endif
 };
+#ifdef NF_GL_TRACE
+static unsigned long long *g_gl_trace = nullptr;
+extern "C" void nf_glow_debug_trace(void *buf) { g_gl_trace = (unsigned long long *)buf; }
+#define GL_T(b, idx) do { if (lv.trace && blockIdx.x == 0 && threadIdx.x == 0) lv.trace[(b) * 8 + (idx)] = wall_clock64(); } while (0)
+#else
+#define GL_T(b, idx) do {} while (0)
+#endif
 
+__host__ __device__ inline int gl_wmix_padded(int C) { return (C * C + C + 63) / 64 * 64; }
 __host__ __device__ inline int gb_lds_floats(const GlowLevel &lv, int Cout, int PXW) {
-    // zA | zB (ping-pong planes) | prm (parameter planes) | ldt (log-det terms) | ldacc (per-image log-det) | Wp | bp
-    return lv.nblocks ? (2 * lv.C + Cout + (lv.C - lv.c1)) * PXW + PXW + (lv.C * lv.C + lv.C + 3) / 4 * 4 : 0;
+    // zA | zB (ping-pong planes) | prm (parameter planes) | ldt (log-det terms) | ldacc (per-image log-det) | 2 x (Wp | bp)
+    // | the second bias section (both double-buffered: the next block's are DMA-prefetched under this block's GEMMs)
+    return lv.nblocks ? (2 * lv.C + Cout + (lv.C - lv.c1)) * PXW + PXW + 2 * gl_wmix_padded(lv.C) + 2 * GC_HID + 64 +
+                            (Cout + 63) / 64 * 64 : 0;
 }
 
 // Squeeze correspondence (reshape.py:116-128): small[b, 4 c + 2 i + j, h, w] <-> big[b, c, 2 h + i, 2 w + j]
@@ -221,16 +238,35 @@ __device__ __forceinline__ void gl_store(const GlowLevel &lv, const float *zfin,
         if (img0 + im < B) ld_store(lv.logdet + img0 + im, ldacc[im], lv.acc);
 }
 
-// Start of block b: the block's mix matrix into LDS; direction 1 mixes zin -> zalt; the conditioner's zero-padded input
+// DMA prefetch (global -> LDS, no registers) of block b's bias section and mix matrix | bias into the given LDS buffers;
+// 1 KB / 256 B pieces round-robin over the NW waves.  Completion: any later s_waitcnt vmcnt(0) + barrier.
+template <int NW>
+__device__ __forceinline__ void gl_prefetch(const GlowLevel &lv, int b, int nsmall, float *small_dst, float *wmix_dst, int wid,
+                                            int lane) {
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    const float *blob = lv.blob(b) + GC_HDR;
+    for (int piece = wid; piece * 256 < nsmall; piece += NW)      // nsmall is a multiple of 4
+        if (piece * 256 + lane * 4 < nsmall)
+            __builtin_amdgcn_global_load_lds(blob + piece * 256 + lane * 4, (lds_ptr)(small_dst + piece * 256), 16, 0, 0);
+    const int C = lv.C, nw = C * C;
+    const float *Wp = lv.Wp(b), *bp = lv.bp(b);
+    for (int piece = wid; piece * 64 < nw; piece += NW)
+        if (piece * 64 + lane < nw) __builtin_amdgcn_global_load_lds(Wp + piece * 64 + lane, (lds_ptr)(wmix_dst + piece * 64), 4, 0, 0);
+    if (wid == NW - 1 && lane < C) __builtin_amdgcn_global_load_lds(bp + lane, (lds_ptr)(wmix_dst + nw), 4, 0, 0);   // C <= 64
+}
+
+// Start of block b (its mix matrix `wmix` was prefetched): direction 1 mixes zin -> zalt; the conditioner's zero-padded input
 // images come from the identity half of the mixed (direction 1) / raw (direction 0) planes.  Ends WITHOUT a barrier
 // (the caller's next barrier publishes xin).
-template <int PXW, int NT>
-__device__ __forceinline__ void gl_pre(const GlowLevel &lv, int b, const float *zin, float *zalt, float *wmix, float *xin,
+// INFLIGHT: vector-memory operations issued AFTER this block's prefetch that may stay outstanding (weight-ring DMAs).
+template <int PXW, int NT, int INFLIGHT>
+__device__ __forceinline__ void gl_pre(const GlowLevel &lv, int b, const float *zin, float *zalt, const float *wmix, float *xin,
                                        int H, int W, int tid) {
     const int HW = H * W, PH = H + 2, PW = W + 2, IPW = PXW / HW, C = lv.C;
-    const float *Wp = lv.Wp(b), *bp = lv.bp(b);
-    for (int i = tid; i < C * C + C; i += NT) wmix[i] = i < C * C ? Wp[i] : bp[i - C * C];
-    __syncthreads();   // wmix, and zin (the level load / the previous block's output)
+    // the prefetched sections of this block (block 0's were issued last, just before this call)
+    if (b == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+    __syncthreads();   // ... and zin (the level load / the previous block's output)
     const float *src = zin;
     if (lv.direction == 1) {
         for (int i = tid; i < C * PXW; i += NT) {
@@ -349,9 +385,9 @@ __device__ __forceinline__ int gl_opaque(int v) {
     return v;
 }
 
-// LDS planes of the fused level behind the conditioner's own buffers (all kernels): zA | zB | prm | ldt | ldacc | wmix
+// LDS planes of the fused level behind the conditioner's own buffers (all kernels): zA | zB | prm | ldt | ldacc | wmix x 2 | second bias section
 struct GlPlanes {
-    float *zA, *zB, *prm, *ldt, *ldacc, *wmix;
+    float *zA, *zB, *prm, *ldt, *ldacc, *wmix, *wmix2, *small2;
 };
 __device__ __forceinline__ GlPlanes gl_planes(float *base, const GlowLevel &lv, int Cout, int PXW) {
     GlPlanes q;
@@ -361,6 +397,8 @@ __device__ __forceinline__ GlPlanes gl_planes(float *base, const GlowLevel &lv, 
     q.ldt = q.prm + Cout * PXW;
     q.ldacc = q.ldt + (lv.C - lv.c1) * PXW;
     q.wmix = q.ldacc + PXW;
+    q.wmix2 = q.wmix + gl_wmix_padded(lv.C);
+    q.small2 = q.wmix2 + gl_wmix_padded(lv.C);
     return q;
 }
 
@@ -370,10 +408,10 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int HW = H * W, PH = H + 2, PW = W + 2, IPW = GC_PX / HW;
     const int K1p = 8 * mt.nkg1;
-    float *ring = smem;                          // 2 x 16 KB weight stages
-    float *P = ring + 2 * GC_STAGE;              // 32 rows x 256 pixels: one output block's tap products
-    float *small = P + 32 * GC_PX;               // biases
-    int *koff = reinterpret_cast<int *>(small + gc_small_padded(mt));   // im2col offset of every k
+    float *ring = smem;                          // GC_RING x 16 KB weight stages
+    float *P = ring + GC_RING * GC_STAGE;        // 32 rows x 256 pixels: one output block's tap products
+    float *small0 = P + 32 * GC_PX;              // biases
+    int *koff = reinterpret_cast<int *>(small0 + gc_small_padded(mt));   // im2col offset of every k
     float *xin = reinterpret_cast<float *>(koff + K1p);                  // zero-padded input images [img][c][PH][PW]
     const GlPlanes pl = gl_planes(xin + IPW * mt.Cin * PH * PW, lv, mt.Cout, GC_PX);   // fused level only
     const int tid0 = threadIdx.x;
@@ -391,45 +429,62 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
         return t < 2 ? nst_l1 + 2 * j + t : nst_l1 + 16 + 8 * pass + j;
     };
     int stage = 0;   // global stage counter (all blocks)
+    constexpr int PPW = 16 / GC_NW;  // 1 KB pieces per wave
     auto issue = [&](int gs) {
-        constexpr int PPW = 16 / GC_NW;  // 1 KB pieces per wave
         const int bb = gs / total_stages, s = gs - bb * total_stages;
         const float *stages = (fused ? lv.blob(bb) : blob0) + gc_off_stages(mt);
         const float *src = stages + (size_t)phys(s) * GC_STAGE + (wid * PPW) * 256 + (tid0 & 63) * 4;
-        float *dst = ring + (gs & 1) * GC_STAGE + (wid * PPW) * 256;
+        float *dst = ring + (gs % GC_RING) * GC_STAGE + (wid * PPW) * 256;
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
             __builtin_amdgcn_global_load_lds(src + i * 256, (__attribute__((address_space(3))) void *)(dst + i * 256), 16, 0, 0);
     };
+    // GC_RING-slot ring, DMA GC_RING - 1 stages ahead: the wait leaves the younger stages' pieces in flight (vector-memory
+    // operations retire in order; anything else a wave has outstanding only makes the wait stricter).  With one stage ahead
+    // the L2 -> LDS latency of a stage (~2 us under load) had to fit under the 28..64 MFMAs of ONE stage: GEMM 1 ran at 2/3.
     auto acquire = [&]() -> const float * {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (stage + GC_RING - 2 < all_stages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((GC_RING - 2) * PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (stage + 1 < all_stages) issue(stage + 1);   // at a block's last stage: the NEXT block's first stage
-        const float *buf = ring + (stage & 1) * GC_STAGE;
+        if (stage + GC_RING - 1 < all_stages) issue(stage + GC_RING - 1);   // runs on into the NEXT block's first stages
+        const float *buf = ring + (stage % GC_RING) * GC_STAGE;
         ++stage;
         return buf;
     };
 
     // ---- prologue: first stage in flight; im2col offsets; the level's images into LDS ----
-    issue(0);
+#pragma unroll
+    for (int i = 0; i < GC_RING - 1; ++i)
+        if (i < all_stages) issue(i);
     for (int k = tid0; k < K1p; k += 64 * GC_NW) {
         const int kk = k < mt.K1 ? k : mt.K1 - 1;   // padded k: zero weight, any valid address
         const int c = kk / 9, t = kk - 9 * c, ky = t / 3;
         koff[k] = c * PH * PW + ky * PW + (t - 3 * ky);
     }
     float *zin = pl.zA, *zalt = pl.zB;
-    if (fused) gl_load<GC_PX, 64 * GC_NW>(lv, zin, pl.ldacc, H, W, img0, B, tid0);
+    if (fused) {
+        gl_prefetch<GC_NW>(lv, 0, mt.small, small0, pl.wmix, wid, tid0 & 63);
+        gl_load<GC_PX, 64 * GC_NW>(lv, zin, pl.ldacc, H, W, img0, B, tid0);
+    }
 
     for (int b = 0; b < nb; ++b) {
+    GL_T(b, 0);
     const int tid = gl_opaque(tid0), lane = tid & 63, hh = lane >> 5;
     const int px = wid * 32 + (lane & 31);
     const int li = px / HW, pin = px - li * HW, py = pin / W, pxx = pin - py * W;
     const int base0 = li * mt.Cin * PH * PW + py * PW + pxx;
     const float *blob = fused ? lv.blob(b) : blob0;
-    // biases of this block (the previous block's last reader, its col2im gather, is behind a barrier), padded input images
-    for (int i = tid; i < mt.small; i += 64 * GC_NW) small[i] = blob[GC_HDR + i];
-    if (fused) gl_pre<GC_PX, 64 * GC_NW>(lv, b, zin, zalt, pl.wmix, xin, H, W, tid);
-    else gc_fill_xin_global<GC_PX, 64 * GC_NW>(x, xs_img, xin, mt.Cin, H, W, img0, B, tid);
+    // biases and mix of this block: prefetched (fused level; double-buffered), padded input images
+    float *small = (fused && (b & 1)) ? pl.small2 : small0;
+    const float *wmix = (b & 1) ? pl.wmix2 : pl.wmix;
+    if (fused) {
+        gl_pre<GC_PX, 64 * GC_NW, (GC_RING - 1) * (16 / GC_NW)>(lv, b, zin, zalt, wmix, xin, H, W, tid);
+        // the next block's sections go out now (their buffers' last readers are behind the barriers above)
+        if (b + 1 < nb) gl_prefetch<GC_NW>(lv, b + 1, mt.small, (b & 1) ? small0 : pl.small2, (b & 1) ? pl.wmix : pl.wmix2, wid, lane);
+    } else {
+        for (int i = tid; i < mt.small; i += 64 * GC_NW) small[i] = blob[GC_HDR + i];
+        gc_fill_xin_global<GC_PX, 64 * GC_NW>(x, xs_img, xin, mt.Cin, H, W, img0, B, tid);
+    }
 
     // ---- GEMM 1 (conv3x3 #1 by im2col): h1 = LeakyReLU(W1 col(x) + b1) ----
     f32x16 H0, H1, H2, H3, H4, H5, H6, H7;
@@ -463,6 +518,7 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
         gc_leaky(acc, mt.slope);
     };
     __syncthreads();   // the prologue's LDS writes
+    GL_T(b, 1);
 #pragma unroll
     for (int s = 0; s < GC_KG1MAX; ++s) {
 #pragma unroll
@@ -475,6 +531,7 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
         H4 = load_bias16(bsrc + 128); H5 = load_bias16(bsrc + 160); H6 = load_bias16(bsrc + 192); H7 = load_bias16(bsrc + 224);
     }
     gemm1(H0); gemm1(H1); gemm1(H2); gemm1(H3); gemm1(H4); gemm1(H5); gemm1(H6); gemm1(H7);
+    GL_T(b, 2);
 
     // ---- sweeps over h2: GEMM 2 block by block, each block consumed at once by GEMM 3 ----
     for (int pass = 0; pass < mt.npass; ++pass) {
@@ -497,6 +554,7 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
             }
         }
         // ---- col2im: per output block, tap products -> LDS, 9-term neighbour gather, + bias, -> HBM ----
+        GL_T(b, 3);
 #pragma unroll
         for (int mm = 0; mm < GC_OBP; ++mm) {
             const int blk = GC_OBP * pass + mm;
@@ -510,10 +568,12 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
             }
         }
     }
+    GL_T(b, 4);
     if (fused) {
-        gl_post<GC_PX, 64 * GC_NW>(lv, b, zin, zalt, pl.wmix, pl.prm, pl.ldt, pl.ldacc, H, W, tid);
+        gl_post<GC_PX, 64 * GC_NW>(lv, b, zin, zalt, wmix, pl.prm, pl.ldt, pl.ldacc, H, W, tid);
         float *t_ = zin; zin = zalt; zalt = t_;
     }
+    GL_T(b, 5);
     }  // blocks
     if (fused) gl_store<GC_PX, 64 * GC_NW>(lv, zin, pl.ldacc, H, W, img0, B, tid0);
 }
@@ -544,8 +604,8 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
     const int nkb1 = (mt.K1 + 15) / 16, K1p = 16 * nkb1;
     float *ring = smem;                          // 4 x 16 KB weight stages
     float *P = ring + GS_RING * GC_STAGE;        // 32 rows x 64 pixels
-    float *small = P + 32 * GS_PX;
-    int *koff = reinterpret_cast<int *>(small + gc_small_padded(mt));
+    float *small0 = P + 32 * GS_PX;
+    int *koff = reinterpret_cast<int *>(small0 + gc_small_padded(mt));
     float *xin = reinterpret_cast<float *>(koff + K1p);
     const GlPlanes pl = gl_planes(xin + IPW * mt.Cin * PH * PW, lv, mt.Cout, GS_PX);
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
@@ -571,9 +631,13 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
         koff[k] = c * PH * PW + ky * PW + (t - 3 * ky);
     }
     float *zin = pl.zA, *zalt = pl.zB;
-    if (fused) gl_load<GS_PX, 64 * GS_NW>(lv, zin, pl.ldacc, H, W, img0, B, tid);
+    if (fused) {
+        gl_prefetch<GS_NW>(lv, 0, mt.small, small0, pl.wmix, wid, lane);
+        gl_load<GS_PX, 64 * GS_NW>(lv, zin, pl.ldacc, H, W, img0, B, tid);
+    }
 
     for (int b = 0; b < nb; ++b) {
+    GL_T(b, 0);
     const float *blob = fused ? lv.blob(b) : blob0;
     const float *stages = blob + gc_off_stages(mt);
     int stage = 0;   // per block: the ring is the col2im scratch at the end of a block, so the stream restarts
@@ -602,10 +666,17 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
 #pragma unroll
     for (int i = 0; i < GS_RING - 1; ++i)
         if (i < total_stages) issue(i);
-    for (int i = tid; i < mt.small; i += 64 * GS_NW) small[i] = blob[GC_HDR + i];
-    if (fused) gl_pre<GS_PX, 64 * GS_NW>(lv, b, zin, zalt, pl.wmix, xin, H, W, tid);
-    else gc_fill_xin_global<GS_PX, 64 * GS_NW>(x, xs_img, xin, mt.Cin, H, W, img0, B, tid);
+    float *small = (fused && (b & 1)) ? pl.small2 : small0;
+    const float *wmix = (b & 1) ? pl.wmix2 : pl.wmix;
+    if (fused) {
+        gl_pre<GS_PX, 64 * GS_NW, (GS_RING - 1) * (16 / GS_NW)>(lv, b, zin, zalt, wmix, xin, H, W, tid);
+        if (b + 1 < nb) gl_prefetch<GS_NW>(lv, b + 1, mt.small, (b & 1) ? small0 : pl.small2, (b & 1) ? pl.wmix : pl.wmix2, wid, lane);
+    } else {
+        for (int i = tid; i < mt.small; i += 64 * GS_NW) small[i] = blob[GC_HDR + i];
+        gc_fill_xin_global<GS_PX, 64 * GS_NW>(x, xs_img, xin, mt.Cin, H, W, img0, B, tid);
+    }
     __syncthreads();
+    GL_T(b, 1);
 
     // ---- GEMM 1: h1 (16 blocks of 16 channels) ----
     f32x4 Hh[16];
@@ -667,6 +738,7 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
         }
     }
 
+    GL_T(b, 2);
     // ---- one sweep: h2 block by block (GEMM 2), each consumed at once by GEMM 3 ----
     f32x4 O[2 * OBT];
 #pragma unroll
@@ -717,6 +789,7 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
         }
     }
 
+    GL_T(b, 3);
     // ---- col2im: the weight ring is dead now; when all output blocks' tap products fit its 64 KB they go there at once
     // and ONE flat gather follows (two barriers in all), otherwise block by block through P ----
     if (mt.OB * 32 * GS_PX <= GS_RING * GC_STAGE) {
@@ -746,12 +819,14 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
             }
         }
     }
+    GL_T(b, 4);
     if (fused) {
-        gl_post<GS_PX, 64 * GS_NW>(lv, b, zin, zalt, pl.wmix, pl.prm, pl.ldt, pl.ldacc, H, W, tid);
+        gl_post<GS_PX, 64 * GS_NW>(lv, b, zin, zalt, wmix, pl.prm, pl.ldt, pl.ldacc, H, W, tid);
         float *t_ = zin; zin = zalt; zalt = t_;
     } else {
         __syncthreads();
     }
+    GL_T(b, 5);
     }  // blocks
     if (fused) gl_store<GS_PX, 64 * GS_NW>(lv, zin, pl.ldacc, H, W, img0, B, tid);
 }
@@ -846,8 +921,8 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
     float *h1s = cols + K1p * GT_PX;                        // h1 in B-operand order (256 x 16)
     float *P = cols;                                        // tap products: reuse cols + h1s once GEMM 2 is done
     float *h2s = cols + (p_floats > a_floats ? p_floats : a_floats);
-    float *small = h2s + GC_HID * GT_PX;
-    int *koff = reinterpret_cast<int *>(small + gc_small_padded(mt));
+    float *small0 = h2s + GC_HID * GT_PX;
+    int *koff = reinterpret_cast<int *>(small0 + gc_small_padded(mt));
     float *xin = reinterpret_cast<float *>(koff + K1p);
     const GlPlanes pl = gl_planes(xin + IPW * mt.Cin * PH * PW, lv, mt.Cout, GT_PX);
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, j16 = lane & 15;
@@ -887,7 +962,10 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
         koff[k] = c * PH * PW + ky * PW + (t - 3 * ky);
     }
     float *zin = pl.zA, *zalt = pl.zB;
-    if (fused) gl_load<GT_PX, 64 * GT_NW>(lv, zin, pl.ldacc, H, W, img0, B, tid);
+    if (fused) {
+        gl_prefetch<GT_NW>(lv, 0, mt.small, small0, pl.wmix, wid, lane);
+        gl_load<GT_PX, 64 * GT_NW>(lv, zin, pl.ldacc, H, W, img0, B, tid);
+    }
 
     // acc (16 rows x 16 pixels) = sum over nkb (a multiple of 16) 16-k blocks of A (the stream) x B (LDS, B-operand order);
     // every consumed unit is replaced by the load of the unit 16 ahead
@@ -918,15 +996,22 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
     };
 
     for (int b = 0; b < nb; ++b) {
+    GL_T(b, 0);
     const float *blob = fused ? lv.blob(b) : blob0;
     // where the prefetch continues when it runs off the end of THIS block's stream (it does so 16 units before the end)
     cross = (b + 1 < nb) ? stream_of(b + 1) : stream_of(b) + (size_t)(nunits - 1) * 256;
     cross_last = b + 1 >= nb;
 
     // ---- block prologue (shared): biases, padded images, im2col columns ----
-    for (int i = tid; i < mt.small; i += 64 * GT_NW) small[i] = blob[GC_HDR + i];
-    if (fused) gl_pre<GT_PX, 64 * GT_NW>(lv, b, zin, zalt, pl.wmix, xin, H, W, tid);
-    else gc_fill_xin_global<GT_PX, 64 * GT_NW>(x, xs_img, xin, mt.Cin, H, W, img0, B, tid);
+    float *small = (fused && (b & 1)) ? pl.small2 : small0;
+    const float *wmix = (b & 1) ? pl.wmix2 : pl.wmix;
+    if (fused) {
+        gl_pre<GT_PX, 64 * GT_NW, 0>(lv, b, zin, zalt, wmix, xin, H, W, tid);
+        if (b + 1 < nb) gl_prefetch<GT_NW>(lv, b + 1, mt.small, (b & 1) ? small0 : pl.small2, (b & 1) ? pl.wmix : pl.wmix2, wid, lane);
+    } else {
+        for (int i = tid; i < mt.small; i += 64 * GT_NW) small[i] = blob[GC_HDR + i];
+        gc_fill_xin_global<GT_PX, 64 * GT_NW>(x, xs_img, xin, mt.Cin, H, W, img0, B, tid);
+    }
     __syncthreads();
     for (int i = tid; i < K1p * GT_PX; i += 64 * GT_NW) {
         // element (kb, g', px, r) of the column block: k = 16 kb + 4 g' + r
@@ -935,6 +1020,7 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
         cols[i] = xin[li * mt.Cin * PH * PW + py * PW + pxx + koff[16 * kb + 4 * gg + r]];
     }
     __syncthreads();
+    GL_T(b, 1);
 
     // ---- GEMM 1 -> h1s ----
     for (int bl = 0; bl < GT_BPW; ++bl) {
@@ -945,6 +1031,7 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
         *reinterpret_cast<f32x4 *>(h1s + ((b16 * 4 + g) * GT_PX + j16) * 4) = acc;
     }
     __syncthreads();
+    GL_T(b, 2);
     // ---- GEMM 2 -> h2s ----
     for (int bl = 0; bl < GT_BPW; ++bl) {
         const int b16 = GT_BPW * wid + bl;
@@ -963,14 +1050,17 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
         for (int r = 0; r < 4; ++r) P[(16 * o16 + 4 * g + r) * GT_PX + j16] = acc[r];
     }
     __syncthreads();
+    GL_T(b, 3);
     // ---- col2im over all output blocks in one flat loop ----
     gc_gather_block<GT_PX, 64 * GT_NW>(P, 0, mt, H, W, img0, B, small, out, fused ? pl.prm : nullptr, tid, mt.OB);
+    GL_T(b, 4);
     if (fused) {
-        gl_post<GT_PX, 64 * GT_NW>(lv, b, zin, zalt, pl.wmix, pl.prm, pl.ldt, pl.ldacc, H, W, tid);
+        gl_post<GT_PX, 64 * GT_NW>(lv, b, zin, zalt, wmix, pl.prm, pl.ldt, pl.ldacc, H, W, tid);
         float *t_ = zin; zin = zalt; zalt = t_;
     } else {
         __syncthreads();
     }
+    GL_T(b, 5);
     }  // blocks
     if (fused) gl_store<GT_PX, 64 * GT_NW>(lv, zin, pl.ldacc, H, W, img0, B, tid);
 }
@@ -991,7 +1081,7 @@ static inline size_t gs_lds_bytes(const GcMeta &m, int H, int W, const GlowLevel
 
 static inline size_t gc_lds_bytes(const GcMeta &m, int H, int W, const GlowLevel &fu) {
     const int IPW = GC_PX / (H * W);
-    return ((size_t)2 * GC_STAGE + 32 * GC_PX + gc_small_padded(m) + 8 * m.nkg1 +
+    return ((size_t)GC_RING * GC_STAGE + 32 * GC_PX + gc_small_padded(m) + 8 * m.nkg1 +
             (size_t)IPW * m.Cin * (H + 2) * (W + 2) + gb_lds_floats(fu, m.Cout, GC_PX)) * sizeof(float) + 16;
 }
 
@@ -1140,6 +1230,9 @@ extern "C" int nf_glow_level(const void *in0, const void *in1, int cin0, int in_
     lv.in0 = (const float *)in0; lv.in1 = (const float *)in1; lv.cin0 = in_squeezed ? C : cin0; lv.in_sq = in_squeezed ? 1 : 0;
     lv.out0 = (float *)out0; lv.out1 = (float *)out1; lv.cout0 = out_squeezed ? C : cout0; lv.out_sq = out_squeezed ? 1 : 0;
     lv.logdet = (float *)logdet;
+#ifdef NF_GL_TRACE
+    lv.trace = g_gl_trace;
+#endif
     return gc_launch(in0, (int64_t)C * H * W, out0, nullptr, gc_meta(c1, Cout, leaky_slope), B, H, W, layout, lv,
                      (hipStream_t)stream);
 }
