@@ -437,6 +437,37 @@ int nf_glow_level(const void *in0, const void *in1, int cin0, int in_squeezed, v
                   int hidden, double leaky_slope, int scale_map, int direction, int acc, int layout, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Backward of the affine family for the training path (core.py:87-102 `loss.backward()`; the reference leaves these
+ * layers to PyTorch autograd).  Vector-Jacobian products in closed form, one HBM pass each; cotangents gy (like z) and
+ * gld (B, may be NULL = zeros) of the layer's outputs (y, log_det per sample); batch reductions in a fixed order.
+ *   nf_masked_affine_bwd   : coupling.py:209-229 -> gz, gs, gt (like z; gs / gt NULL when s / t is NULL)
+ *   nf_affine_coupling_bwd : coupling.py:117-171 with the channel split / merge -> gz (B, C, HW), gparam like param
+ *   nf_actnorm_bwd         : coupling.py:38-54, per-channel s, t, log-det HW sum(s) returned per sample -> gz, gs (C), gt (C)
+ *   nf_inv1x1_wgrad        : mixing.py:106-133, y = W z per pixel with per-pixel log|det| ldu -> gW (C, C) = sum over
+ *                            pixels gy z^T, gldu (scalar) = HW sum gld; scratch of nf_inv1x1_wgrad_scratch_elems(B, C)
+ *                            elements; C <= 64.  (gz = W^T gy is nf_inv1x1_conv_affine on the transposed matrix.)
+ */
+int nf_masked_affine_bwd(const void *z, const void *b, const void *s, const void *t, const void *gy, const void *gld,
+                         void *gz, void *gs, void *gt, int64_t B, int64_t inner, int direction, int dtype,
+                         nf_stream_t stream);
+int nf_affine_coupling_bwd(const void *z, const void *param, const void *gy, const void *gld, void *gz, void *gparam,
+                           int64_t B, int C, int c1, int flip, int64_t HW, int scale_map, int direction, int dtype,
+                           nf_stream_t stream);
+int nf_actnorm_bwd(const void *z, const void *s, const void *t, const void *gy, const void *gld, void *gz, void *gs,
+                   void *gt, int64_t B, int C, int64_t HW, int direction, int dtype, nf_stream_t stream);
+int64_t nf_inv1x1_wgrad_scratch_elems(int64_t B, int C);
+int nf_inv1x1_wgrad(const void *z, const void *gy, const void *gld, void *gW, void *gldu, void *scratch, int64_t B, int C,
+                    int64_t HW, int dtype, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * y_b = W x_b for every row of a row-major (B, D) float32 matrix, W (D, D) row-major, D <= 64, on exact-fp32 MFMA
+ * (HBM-bound: one read and one write of the rows).  The batch-side products of LULinearPermute's backward
+ * (mixing.py:535-563 under autograd: u = U x[perm], gu = L^T gy, gx = P U^T gu) with the permutation folded into W.
+ * y must not alias x.
+ */
+int nf_rows_matvec(const void *x, const void *W, void *y, int64_t B, int D, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Squeeze (flows/reshape.py:116-128).  direction 0 = forward (C,H,W)->(C/4,2H,2W),
  * 1 = inverse (C,H,W)->(4C,H/2,W/2).  z, y contiguous NCHW with the shapes implied.
  */

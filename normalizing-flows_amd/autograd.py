@@ -135,25 +135,37 @@ class LULinearPermuteFn(torch.autograd.Function):
         sig = torch.where(udiag_raw > 20, torch.ones_like(sig), sig)  # softplus threshold
         if gy is None:
             gy = torch.zeros_like(y)
+        gy = gy.contiguous()
         gl_sum = gld.sum() if gld is not None else torch.zeros((), dtype=x.dtype, device=x.device)
+        D = x.shape[1]
+        # Row-wise products with the D x D factors run on nf_rows_matvec (exact-fp32 MFMA, csrc/rows_matvec.hip) -- no library
+        # GEMM / triangular solve touches the batch; the permutation is folded into the matrices:
+        # Up[:, perm[j]] = U[:, j]  =>  Up x = U x[perm],  Up^T g = scatter of U^T g back through perm.
+        hip_rows = x.is_cuda and D <= 64 and x.dtype == torch.float32
+
+        def rows(v, W):   # r_b = W v_b for every row b
+            return ops.rows_matvec(v, W) if hip_rows else v @ W.t()
+
+        Up = torch.zeros_like(Um)
+        Up[:, perm] = Um
         if ctx.direction == 0:
             # y = L (U x_p) + b ; logdet = sum log diag
-            xp = x.index_select(1, perm)
-            u = xp @ Um.t()
-            gu = gy @ Lm            # d/du
-            gxp = gu @ Um           # d/dx_p
-            gx = torch.empty_like(x)
-            gx.index_copy_(1, perm, gxp)
+            u = rows(x, Up)                 # U x[perm]
+            gu = rows(gy, Lm.t())           # d/du = L^T gy
+            gx = rows(gu, Up.t())           # d/dx = P (U^T gu)
             gL, g_bias = _batch_outer(gy, u, want_colsum=True)
-            gU, _ = _batch_outer(gu, xp)
+            gU, _ = _batch_outer(gu, x.index_select(1, perm))
             gdiag = torch.diagonal(gU) + gl_sum / diag
         else:
-            # y[:, perm] = t,  U t = u,  L u = x - b ; logdet = -sum log diag
+            # y[:, perm] = t,  U t = u,  L u = x - b ; logdet = -sum log diag.  The D x D inverses are parameter-side work
+            # (float64, like the reference's torch.inverse in mixing.py); the batch only sees mat-vec kernels.
+            eye = torch.eye(D, dtype=torch.float64, device=x.device)
+            Linv = torch.linalg.solve_triangular(Lm.double(), eye, upper=False, unitriangular=True)
+            Uinv = torch.linalg.solve_triangular(Um.double(), eye, upper=True)
             t = y.index_select(1, perm)
-            u = t @ Um.t()
-            gt = gy.index_select(1, perm)
-            gu = torch.linalg.solve_triangular(Um.t(), gt.t(), upper=False).t()      # U^T gu = gt
-            gv = torch.linalg.solve_triangular(Lm.t(), gu.t(), upper=True, unitriangular=True).t()  # L^T gv = gu
+            u = rows(y, Up)                                       # U t
+            gu = rows(gy.index_select(1, perm), Uinv.t().to(x.dtype))     # U^T gu = gt
+            gv = rows(gu, Linv.t().to(x.dtype))                   # L^T gv = gu
             gx = gv
             gL, g_bias = _batch_outer(gv, u, want_colsum=True)
             gU, _ = _batch_outer(gu, t)
@@ -217,7 +229,8 @@ def linear(x, weight, bias):
     return torch.nn.functional.linear(x, weight, bias)
 
 
-# ---- affine / Glow layers: HIP forward, backward by differentiating the reference formula on the saved inputs ----------
+# ---- affine / Glow layers: HIP forward and HIP backward (csrc/affine_bwd.hip: closed-form vector-Jacobian products); the
+# torch re-evaluation `_vjp` stays for the shapes the kernels do not take (and for the row-wise Gaussian / MAF element maps) ------
 def _vjp(formula, inputs, cotangents):
     """Vector-Jacobian product of `formula(*inputs) -> (y, log_det)` (plain torch, reference arithmetic) -- backward only."""
     with torch.enable_grad():
@@ -248,16 +261,9 @@ class MaskedAffineFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, gld):
         z, b, s, t = ctx.saved_tensors
-        direction = ctx.direction
-
-        def formula(z_, s_, t_):
-            s0 = torch.zeros_like(z_) if s_ is None else s_
-            t0 = torch.zeros_like(z_) if t_ is None else t_
-            if direction == 0:
-                return b * z_ + (1 - b) * (z_ * torch.exp(s0) + t0), _sum_rows((1 - b) * s0)
-            return b * z_ + (1 - b) * (z_ - t0) * torch.exp(-s0), -_sum_rows((1 - b) * s0)
-
-        gz, gs, gt = _vjp(formula, (z, s, t), (gy, gld))
+        if gy is None:
+            gy = torch.zeros_like(z)
+        gz, gs, gt = ops.masked_affine_bwd(z, b, s, t, gy, gld, ctx.direction)     # csrc/affine_bwd.hip
         return gz, None, gs, gt, None
 
 
@@ -306,8 +312,13 @@ class AffineCouplingFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, gld):
         z, param = ctx.saved_tensors
-        cfg = ctx.cfg
-        gz, gp = _vjp(lambda z_, p_: _coupling_formula(z_, p_, *cfg), (z, param), (gy, gld))
+        c1, flip, scale_map, direction = ctx.cfg
+        if gy is None:
+            gy = torch.zeros_like(z)
+        if z.dim() < 2 or scale_map not in L.SCALE:
+            gz, gp = _vjp(lambda z_, p_: _coupling_formula(z_, p_, *ctx.cfg), (z, param), (gy, gld))
+        else:
+            gz, gp = ops.affine_coupling_bwd(z, param, gy, gld, c1, flip, scale_map, direction)   # csrc/affine_bwd.hip
         return gz, gp, None, None, None, None
 
 
@@ -325,19 +336,10 @@ class ActNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, gld):
         z, s, t = ctx.saved_tensors
-        direction = ctx.direction
-        hw = z[0, 0].numel() if z.dim() > 2 else 1
-
-        def formula(z_, s_, t_):
-            shp = (1, -1) + (1,) * (z_.dim() - 2)
-            sv, tv = s_.reshape(shp), t_.reshape(shp)
-            ones = torch.ones(z_.shape[0], dtype=z_.dtype, device=z_.device)
-            if direction == 0:
-                return z_ * torch.exp(sv) + tv, hw * s_.sum() * ones
-            return (z_ - tv) * torch.exp(-sv), -hw * s_.sum() * ones
-
-        gz, gs, gt = _vjp(formula, (z, s, t), (gy, gld))
-        return gz, gs, gt, None
+        if gy is None:
+            gy = torch.zeros_like(z)
+        gz, gs, gt = ops.actnorm_bwd(z, s.detach(), t.detach(), gy, gld, ctx.direction)   # csrc/affine_bwd.hip
+        return gz, gs.view_as(s), gt.view_as(t), None
 
 
 class Inv1x1Fn(torch.autograd.Function):
@@ -353,6 +355,16 @@ class Inv1x1Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, gld):
         z, W, ldu = ctx.saved_tensors
+        if gy is None:
+            gy = torch.zeros_like(z)
+        gz = gW = gl = None
+        if z.shape[1] <= 64:
+            zero = torch.zeros((), dtype=z.dtype, device=z.device)
+            if ctx.needs_input_grad[0]:      # gz = W^T gy per pixel: the forward kernel on the transposed matrix
+                gz, _ = ops.inv1x1_conv(gy.contiguous(), W.detach().t().contiguous(), zero, want_scalar=False)
+            if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                gW, gl = ops.inv1x1_wgrad(z, gy, gld)                                 # csrc/affine_bwd.hip
+            return gz, gW, gl
         hw = z[0, 0].numel() if z.dim() > 2 else 1
 
         def formula(z_, W_, l_):

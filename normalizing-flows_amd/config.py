@@ -23,3 +23,9 @@ glow_level_chains = True
 def set_glow_level_chains(mode=True):
     global glow_level_chains
     glow_level_chains = bool(mode)
+
+
+def set_roctx(mode=True):
+    """roctx ranges per layer type around every layer call of the containers (also NF_ROCTX=1); see _prof.py."""
+    from . import _prof
+    _prof.enabled = bool(mode)

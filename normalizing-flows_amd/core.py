@@ -29,6 +29,12 @@ def _pair_signature(crqs):
 def _run_pairs(pairs, z, inverse, ld, acc):
     """`pairs` = [(CoupledRQS, LULinearPermute), ...] in processing order, all of one shape: one persistent launch
     (exact-fp32 kernel) or one launch per pair (bf16x3 variant)."""
+    from . import _prof
+    with _prof.range_("rqs_fused_chain[%d x (CoupledRQS + LULinearPermute)].%s" % (len(pairs), "inverse" if inverse else "forward")):
+        return _run_pairs_impl(pairs, z, inverse, ld, acc)
+
+
+def _run_pairs_impl(pairs, z, inverse, ld, acc):
     from . import config, ops
     if config.fused_gemm != "f32" or len(pairs) == 1:
         for c, lu in pairs:
@@ -528,7 +534,7 @@ class MultiscaleFlow(nn.Module):
         seq = flows[::-1] if inverse else flows
         merge = self.merges[i - 1] if i > 0 else None
         chan = merge is not None and type(merge) is Merge and merge.mode == "channel"
-        from . import config
+        from . import _prof, config
         fast = (config.glow_level_chains and z.is_cuda and z.dtype == torch.float32 and z.dim() == 4
                 and not needs_grad(z, z_other) and (z_other is None or z_other.dtype == torch.float32))
         pending_merge = (not inverse) and merge is not None      # sample direction: the merge is not applied yet
@@ -557,9 +563,11 @@ class MultiscaleFlow(nn.Module):
                         sq_out = (not inverse) and end < len(seq) and isinstance(seq[end], Squeeze) and C % 4 == 0
                         split_out = inverse and end == len(seq) and chan
                         try:
-                            out0, out1 = run_level(seq[start:end], entries, layout, slope, smap, z,
-                                                   z_other if pending_merge else None, sq_in, inverse, ld, acc,
-                                                   cout0=(C + 1) // 2 if split_out else None, out_squeezed=sq_out)
+                            with _prof.range_("glow_level[%d x GlowBlock %dx%dx%d].%s" % (
+                                    n, C, H, W, "inverse" if inverse else "forward")):
+                                out0, out1 = run_level(seq[start:end], entries, layout, slope, smap, z,
+                                                       z_other if pending_merge else None, sq_in, inverse, ld, acc,
+                                                       cout0=(C + 1) // 2 if split_out else None, out_squeezed=sq_out)
                         except NotImplementedError:     # working set beyond one workgroup's LDS: nothing was launched
                             refused.add(key)
                         else:

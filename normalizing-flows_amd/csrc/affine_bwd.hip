@@ -1,0 +1,290 @@
+// affine_bwd.hip -- backward (vector-Jacobian products) of the affine family for the training path: MaskedAffineFlow,
+// AffineCoupling (+ channel Split / Merge), AffineConstFlow / ActNorm, the per-pixel C x C product of Invertible1x1Conv.
+// gfx950 only.  The reference differentiates these layers with PyTorch autograd (core.py:87-102 `loss.backward()` over
+// affine/coupling.py:38-54, :117-171, :209-229, mixing.py:106-133); here every gradient is a closed form evaluated in one
+// HBM-bound pass: one read of every input / cotangent element, one write of every gradient element.  Reductions over the
+// batch (ActNorm's s, t; the 1x1 matrix) are done in a fixed order (deterministic run to run).
+#include "common.hpp"
+
+namespace nf {
+
+// ---- MaskedAffineFlow (coupling.py:209-229) ------------------------------------------------------------------------------
+//   direction 0: y = b z + (1 - b)(z e^s + t), ld = sum (1 - b) s
+//   direction 1: y = b z + (1 - b)(z - t) e^-s, ld = -sum (1 - b) s
+template <typename T>
+__global__ void __launch_bounds__(256)
+masked_affine_bwd_kernel(const T *__restrict__ z, const T *__restrict__ b, const T *__restrict__ s, const T *__restrict__ t,
+                         const T *__restrict__ gy, const T *__restrict__ gld, T *__restrict__ gz, T *__restrict__ gs,
+                         T *__restrict__ gt, int64_t B, int64_t inner, int direction) {
+    const int64_t N = B * inner;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < N; o += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = o / inner, i = o - r * inner;
+        const T bi = b[i], nb = T(1) - bi, zi = z[o], g = gy[o], gl = gld ? gld[r] : T(0);
+        T si = s ? s[o] : T(0), ti = t ? t[o] : T(0);
+        if (!M<T>::finite(si)) si = M<T>::nan();
+        if (!M<T>::finite(ti)) ti = M<T>::nan();
+        if (direction == 0) {
+            const T e = M<T>::exp(si);
+            gz[o] = g * (bi + nb * e);
+            if (gs) gs[o] = nb * (g * zi * e + gl);
+            if (gt) gt[o] = nb * g;
+        } else {
+            const T e = M<T>::exp(-si);
+            gz[o] = g * (bi + nb * e);
+            if (gs) gs[o] = -nb * (g * (zi - ti) * e + gl);
+            if (gt) gt[o] = -nb * g * e;
+        }
+    }
+}
+
+// ---- AffineCoupling with the channel split / merge folded in (coupling.py:117-171, reshape.py:30-85) -------------------
+// z (B, C, HW): z1 = c1 identity channels (copied: gz = gy there), z2 transformed with the interleaved parameter planes
+// param (B, P, HW), P = 2 (C - c1) (shift at 2 c, scale at 2 c + 1) or C - c1 (scale_map NONE: shift only).
+template <typename T>
+__global__ void __launch_bounds__(256)
+affine_coupling_bwd_kernel(const T *__restrict__ z, const T *__restrict__ param, const T *__restrict__ gy,
+                           const T *__restrict__ gld, T *__restrict__ gz, T *__restrict__ gparam, int64_t B, int C, int c1,
+                           int flip, int64_t HW, int scale_map, int direction) {
+    const int c2 = C - c1;
+    const int z1_off = flip ? c2 : 0, z2_off = flip ? 0 : c1;
+    const int P = scale_map == NF_SCALE_NONE ? c2 : 2 * c2;
+    const int64_t n1 = (int64_t)c1 * HW, n2 = (int64_t)c2 * HW;
+    for (int64_t r = blockIdx.x; r < B; r += gridDim.x) {
+        const T *zr = z + r * (int64_t)C * HW, *gyr = gy + r * (int64_t)C * HW, *pr = param + r * (int64_t)P * HW;
+        T *gzr = gz + r * (int64_t)C * HW, *gpr = gparam + r * (int64_t)P * HW;
+        const T gl = gld ? gld[r] : T(0);
+        for (int64_t i = threadIdx.x; i < n1; i += blockDim.x) gzr[(int64_t)z1_off * HW + i] = gyr[(int64_t)z1_off * HW + i];
+        for (int64_t i = threadIdx.x; i < n2; i += blockDim.x) {
+            const int64_t c = i / HW, p = i - c * HW;
+            const T v = zr[(int64_t)z2_off * HW + i], g = gyr[(int64_t)z2_off * HW + i];
+            T gv;
+            if (scale_map == NF_SCALE_NONE) {
+                gv = g;
+                gpr[i] = direction == 0 ? g : -g;
+            } else {
+                const T sh = pr[(2 * c) * HW + p], sc = pr[(2 * c + 1) * HW + p];
+                T gsh, gsc;
+                if (scale_map == NF_SCALE_EXP) {
+                    if (direction == 0) {          // y = v e^sc + sh, ld = +sum sc
+                        const T e = M<T>::exp(sc);
+                        gv = g * e; gsh = g; gsc = g * v * e + gl;
+                    } else {                       // y = (v - sh) e^-sc, ld = -sum sc
+                        const T e = M<T>::exp(-sc);
+                        gv = g * e; gsh = -g * e; gsc = -(g * (v - sh) * e + gl);
+                    }
+                } else {
+                    const T sg = sigmoid(sc + T(2)), om = T(1) - sg;   // d sg / d sc = sg (1 - sg), d log sg / d sc = 1 - sg
+                    const bool mult = (scale_map == NF_SCALE_SIGMOID_INV) == (direction == 0);   // y uses * sg (else / sg)
+                    if (direction == 0) {
+                        if (mult) { gv = g * sg; gsh = g; gsc = g * v * sg * om + gl * om; }            // ld = +sum log sg
+                        else { gv = g / sg; gsh = g; gsc = -(g * v * om / sg + gl * om); }              // ld = -sum log sg
+                    } else {
+                        if (mult) { gv = g * sg; gsh = -g * sg; gsc = g * (v - sh) * sg * om + gl * om; }   // ld = +sum log sg
+                        else { gv = g / sg; gsh = -g / sg; gsc = -(g * (v - sh) * om / sg + gl * om); }     // ld = -sum log sg
+                    }
+                }
+                gpr[(2 * c) * HW + p] = gsh;
+                gpr[(2 * c + 1) * HW + p] = gsc;
+            }
+            gzr[(int64_t)z2_off * HW + i] = gv;
+        }
+    }
+}
+
+// ---- AffineConstFlow / ActNorm with per-channel s, t (coupling.py:38-54) ---------------------------------------------
+//   direction 0: y = z e^s + t, ld (every sample) = +HW sum s;   direction 1: y = (z - t) e^-s, ld = -HW sum s.
+// One workgroup per channel: gz in the same pass as the two per-channel reductions (fp64 accumulation, fixed order).
+template <typename T>
+__global__ void __launch_bounds__(1024)
+actnorm_bwd_kernel(const T *__restrict__ z, const T *__restrict__ s, const T *__restrict__ t, const T *__restrict__ gy,
+                   const T *__restrict__ gld, T *__restrict__ gz, T *__restrict__ gs, T *__restrict__ gt, int64_t B, int C,
+                   int64_t HW, int direction) {
+    __shared__ double sred[16];
+    const int c = blockIdx.x;
+    const int64_t n = B * HW;
+    const T sc = s[c], tc = t[c];
+    const T e = M<T>::exp(direction == 0 ? sc : -sc);
+    double as = 0.0, at = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const int64_t bb = i / HW, p = i - bb * HW;
+        const int64_t o = (bb * C + c) * HW + p;
+        const T g = gy[o], v = z[o];
+        gz[o] = g * e;
+        if (direction == 0) { as += (double)(g * v * e); at += (double)g; }
+        else { as -= (double)(g * (v - tc) * e); at -= (double)(g * e); }
+    }
+    double gl = 0.0;   // d ld / d s_c = +-HW for every sample
+    if (gld)
+        for (int64_t r = threadIdx.x; r < B; r += blockDim.x) gl += (double)gld[r];
+    as = block_sum(as, sred);
+    at = block_sum(at, sred);
+    gl = block_sum(gl, sred);
+    if (threadIdx.x == 0) {
+        gs[c] = (T)(as + (direction == 0 ? 1.0 : -1.0) * (double)HW * gl);
+        gt[c] = (T)at;
+    }
+}
+
+// ---- per-pixel C x C product y = W z (mixing.py:106-133): gW = sum over pixels of gy z^T -------------------------------
+// Workgroup w handles images [w ipw, (w + 1) ipw): the C x C partial sums in registers (thread = entry (i, j), strided),
+// pixels staged through LDS; a second kernel adds the partials in a fixed order.  C <= 64.
+template <typename T>
+__global__ void __launch_bounds__(256)
+inv1x1_wgrad_partial_kernel(const T *__restrict__ z, const T *__restrict__ gy, T *__restrict__ partial, int64_t B, int C,
+                            int64_t HW, int ipw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
+    T *zs = reinterpret_cast<T *>(raw);          // [C][64]
+    T *gs = zs + C * 64;                         // [C][64]
+    const int tid = threadIdx.x, CC = C * C;
+    T acc[16];                                   // entries tid, tid + 256, ... (C <= 64 -> <= 16 per thread)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = T(0);
+    const int64_t b0 = (int64_t)blockIdx.x * ipw, b1 = b0 + ipw < B ? b0 + ipw : B;
+    for (int64_t bb = b0; bb < b1; ++bb) {
+        for (int64_t p0 = 0; p0 < HW; p0 += 64) {
+            const int np = (int)(HW - p0 < 64 ? HW - p0 : 64);
+            __syncthreads();
+            for (int e = tid; e < C * 64; e += 256) {
+                const int c = e >> 6, p = e & 63;
+                const int64_t o = (bb * C + c) * HW + p0 + p;
+                zs[e] = p < np ? z[o] : T(0);
+                gs[e] = p < np ? gy[o] : T(0);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int ent = tid + 256 * k;
+                if (ent < CC) {
+                    const int i = ent / C, j = ent - i * C;
+                    T a = T(0);
+                    for (int p = 0; p < 64; ++p) a += gs[i * 64 + p] * zs[j * 64 + p];
+                    acc[k] += a;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int ent = tid + 256 * k;
+        if (ent < CC) partial[(int64_t)blockIdx.x * CC + ent] = acc[k];
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+inv1x1_wgrad_reduce_kernel(const T *__restrict__ partial, const T *__restrict__ gld, T *__restrict__ gW, T *__restrict__ gl,
+                           int nparts, int CC, int64_t B, int64_t HW) {
+    __shared__ double sred[16];
+    for (int ent = blockIdx.x * blockDim.x + threadIdx.x; ent < CC; ent += gridDim.x * blockDim.x) {
+        double a = 0.0;
+        for (int w = 0; w < nparts; ++w) a += (double)partial[(int64_t)w * CC + ent];
+        gW[ent] = (T)a;
+    }
+    if (blockIdx.x == 0 && gl) {   // ld (every sample) = HW ldu  ->  d / d ldu = HW sum_b gld
+        double a = 0.0;
+        if (gld)
+            for (int64_t r = threadIdx.x; r < B; r += blockDim.x) a += (double)gld[r];
+        a = block_sum(a, sred);
+        if (threadIdx.x == 0) *gl = (T)((double)HW * a);
+    }
+}
+
+}  // namespace nf
+
+using namespace nf;
+
+#define NF_DISPATCH(dtype, CALL_F32, CALL_F64) \
+    do {                                       \
+        if ((dtype) == NF_F32) { CALL_F32; }   \
+        else if ((dtype) == NF_F64) { CALL_F64; } \
+        else return NF_ENOTSUP;                \
+    } while (0)
+
+extern "C" int nf_masked_affine_bwd(const void *z, const void *b, const void *s, const void *t, const void *gy,
+                                    const void *gld, void *gz, void *gs, void *gt, int64_t B, int64_t inner, int direction,
+                                    int dtype, nf_stream_t stream) {
+    if (B < 0 || inner < 1 || (direction != 0 && direction != 1)) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!z || !b || !gy || !gz) return NF_EFAULT;
+    if ((gs && !s) || (gt && !t)) return NF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_for(B * inner, 256 * 4);
+    NF_DISPATCH(dtype,
+                hipLaunchKernelGGL(masked_affine_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)z,
+                                   (const float *)b, (const float *)s, (const float *)t, (const float *)gy,
+                                   (const float *)gld, (float *)gz, (float *)gs, (float *)gt, B, inner, direction),
+                hipLaunchKernelGGL(masked_affine_bwd_kernel<double>, dim3(grid), dim3(256), 0, st, (const double *)z,
+                                   (const double *)b, (const double *)s, (const double *)t, (const double *)gy,
+                                   (const double *)gld, (double *)gz, (double *)gs, (double *)gt, B, inner, direction));
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_affine_coupling_bwd(const void *z, const void *param, const void *gy, const void *gld, void *gz,
+                                      void *gparam, int64_t B, int C, int c1, int flip, int64_t HW, int scale_map,
+                                      int direction, int dtype, nf_stream_t stream) {
+    if (B < 0 || C < 1 || c1 < 0 || c1 >= C || HW < 1 || (direction != 0 && direction != 1)) return NF_EINVAL;
+    if (scale_map < NF_SCALE_EXP || scale_map > NF_SCALE_NONE) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!z || !param || !gy || !gz || !gparam) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_for(B, 1, 256 * 16);
+    NF_DISPATCH(dtype,
+                hipLaunchKernelGGL(affine_coupling_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)z,
+                                   (const float *)param, (const float *)gy, (const float *)gld, (float *)gz, (float *)gparam,
+                                   B, C, c1, flip, HW, scale_map, direction),
+                hipLaunchKernelGGL(affine_coupling_bwd_kernel<double>, dim3(grid), dim3(256), 0, st, (const double *)z,
+                                   (const double *)param, (const double *)gy, (const double *)gld, (double *)gz,
+                                   (double *)gparam, B, C, c1, flip, HW, scale_map, direction));
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_actnorm_bwd(const void *z, const void *s, const void *t, const void *gy, const void *gld, void *gz,
+                              void *gs, void *gt, int64_t B, int C, int64_t HW, int direction, int dtype,
+                              nf_stream_t stream) {
+    if (B < 0 || C < 1 || HW < 1 || (direction != 0 && direction != 1)) return NF_EINVAL;
+    if (!s || !t || !gs || !gt) return NF_EFAULT;
+    if (B > 0 && (!z || !gy || !gz)) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    NF_DISPATCH(dtype,
+                hipLaunchKernelGGL(actnorm_bwd_kernel<float>, dim3(C), dim3(1024), 0, st, (const float *)z, (const float *)s,
+                                   (const float *)t, (const float *)gy, (const float *)gld, (float *)gz, (float *)gs,
+                                   (float *)gt, B, C, HW, direction),
+                hipLaunchKernelGGL(actnorm_bwd_kernel<double>, dim3(C), dim3(1024), 0, st, (const double *)z,
+                                   (const double *)s, (const double *)t, (const double *)gy, (const double *)gld,
+                                   (double *)gz, (double *)gs, (double *)gt, B, C, HW, direction));
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int64_t nf_inv1x1_wgrad_scratch_elems(int64_t B, int C) {
+    if (B < 0 || C < 1 || C > 64) return NF_EINVAL;
+    const int64_t parts = B < 256 ? (B > 0 ? B : 1) : 256;
+    return parts * (int64_t)C * C;
+}
+
+extern "C" int nf_inv1x1_wgrad(const void *z, const void *gy, const void *gld, void *gW, void *gldu, void *scratch, int64_t B,
+                               int C, int64_t HW, int dtype, nf_stream_t stream) {
+    if (B < 1 || C < 1 || HW < 1) return NF_EINVAL;
+    if (C > 64) return NF_ENOTSUP;
+    if (!z || !gy || !gW || !scratch) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    const int parts = (int)(B < 256 ? B : 256);
+    const int ipw = (int)((B + parts - 1) / parts);
+    const int nparts = (int)((B + ipw - 1) / ipw);
+    const size_t esz = dtype == NF_F64 ? 8 : 4;
+    const size_t lds = (size_t)2 * C * 64 * esz;
+    NF_DISPATCH(dtype,
+                hipLaunchKernelGGL(inv1x1_wgrad_partial_kernel<float>, dim3(nparts), dim3(256), lds, st, (const float *)z,
+                                   (const float *)gy, (float *)scratch, B, C, HW, ipw);
+                hipLaunchKernelGGL(inv1x1_wgrad_reduce_kernel<float>, dim3((C * C + 255) / 256), dim3(256), 0, st,
+                                   (const float *)scratch, (const float *)gld, (float *)gW, (float *)gldu, nparts, C * C, B, HW),
+                hipLaunchKernelGGL(inv1x1_wgrad_partial_kernel<double>, dim3(nparts), dim3(256), lds, st, (const double *)z,
+                                   (const double *)gy, (double *)scratch, B, C, HW, ipw);
+                hipLaunchKernelGGL(inv1x1_wgrad_reduce_kernel<double>, dim3((C * C + 255) / 256), dim3(256), 0, st,
+                                   (const double *)scratch, (const double *)gld, (double *)gW, (double *)gldu, nparts, C * C, B,
+                                   HW));
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

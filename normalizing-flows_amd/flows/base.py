@@ -12,6 +12,8 @@ fresh tensor that the container then adds with another launch.
 import torch
 from torch import nn
 
+from .. import _prof
+
 
 
 
@@ -40,6 +42,13 @@ class Flow(nn.Module):
 
 def run_flow(flow, z, inverse, ld, acc, **kw):
     """Drive any flow (ours or a reference/duck-typed one) through the accumulate protocol."""
+    if _prof.enabled:     # roctx range per layer type (NF_ROCTX=1)
+        with _prof.range_("%s.%s" % (type(flow).__name__, "inverse" if inverse else "forward")):
+            return _run_flow(flow, z, inverse, ld, acc, **kw)
+    return _run_flow(flow, z, inverse, ld, acc, **kw)
+
+
+def _run_flow(flow, z, inverse, ld, acc, **kw):
     if hasattr(flow, "_run"):
         return flow._run(z, inverse, ld, acc, **kw)
     z, log_det = (flow.inverse(z, **kw) if inverse else flow(z, **kw))

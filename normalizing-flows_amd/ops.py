@@ -219,6 +219,92 @@ def inv1x1_conv(z, W, logdet_unit, logdet=None, acc=None, want_scalar=True, bias
     return y, lds
 
 
+# ---- backward of the affine family (csrc/affine_bwd.hip): closed-form vector-Jacobian products ------------------------
+def masked_affine_bwd(z, b, s, t, gy, gld, direction):
+    """(gz, gs, gt) of nf_masked_affine for cotangents gy (like z) and gld (B) -- coupling.py:209-229 under autograd."""
+    L.require_device(z, b, s, t, gy, gld)
+    z, gy = z.contiguous(), gy.contiguous()
+    B = z.shape[0]
+    inner = z[0].numel() if B else int(math.prod(z.shape[1:]))
+    bb = b.to(z.dtype)
+    if bb.numel() != inner:
+        bb = bb.expand((1,) + tuple(z.shape[1:]))
+    bb = bb.contiguous().view(-1)
+    gz = torch.empty_like(z)
+    gs = None if s is None else torch.empty_like(z)
+    gt = None if t is None else torch.empty_like(z)
+    rc = L.lib().nf_masked_affine_bwd(ptr(z), ptr(bb), ptr(None if s is None else s.contiguous()),
+                                      ptr(None if t is None else t.contiguous()), ptr(gy),
+                                      ptr(None if gld is None else gld.contiguous()), ptr(gz), ptr(gs), ptr(gt), i64(B),
+                                      i64(inner), i32(direction), i32(L.dtype_code(z)), L.stream())
+    L.check(rc, "nf_masked_affine_bwd")
+    return gz, gs, gt
+
+
+def affine_coupling_bwd(z, param, gy, gld, c1, flip, scale_map, direction):
+    """(gz, gparam) of nf_affine_coupling -- coupling.py:117-171 with the channel split / merge under autograd."""
+    L.require_device(z, param, gy, gld)
+    z, param, gy = z.contiguous(), param.contiguous(), gy.contiguous()
+    B, Cc = z.shape[:2]
+    HW = int(math.prod(z.shape[2:])) if z.dim() > 2 else 1
+    gz, gp = torch.empty_like(z), torch.empty_like(param)
+    rc = L.lib().nf_affine_coupling_bwd(ptr(z), ptr(param), ptr(gy), ptr(None if gld is None else gld.contiguous()), ptr(gz),
+                                        ptr(gp), i64(B), i32(Cc), i32(c1), i32(int(flip)), i64(HW), i32(L.SCALE[scale_map]),
+                                        i32(direction), i32(L.dtype_code(z)), L.stream())
+    L.check(rc, "nf_affine_coupling_bwd")
+    return gz, gp
+
+
+def actnorm_bwd(z, s, t, gy, gld, direction):
+    """(gz, gs (C), gt (C)) of nf_actnorm with the log-det returned per sample -- coupling.py:38-54 under autograd."""
+    L.require_device(z, s, t, gy, gld)
+    z, gy = z.contiguous(), gy.contiguous()
+    B, Cc = z.shape[:2]
+    HW = int(math.prod(z.shape[2:])) if z.dim() > 2 else 1
+    gz = torch.empty_like(z)
+    gs = torch.empty(Cc, dtype=z.dtype, device=z.device)
+    gt = torch.empty(Cc, dtype=z.dtype, device=z.device)
+    rc = L.lib().nf_actnorm_bwd(ptr(z), ptr(s.contiguous().view(-1)), ptr(t.contiguous().view(-1)), ptr(gy),
+                                ptr(None if gld is None else gld.contiguous()), ptr(gz), ptr(gs), ptr(gt), i64(B), i32(Cc),
+                                i64(HW), i32(direction), i32(L.dtype_code(z)), L.stream())
+    L.check(rc, "nf_actnorm_bwd")
+    return gz, gs, gt
+
+
+def rows_matvec(x, W):
+    """y_b = W x_b for every row of x (B, D) float32, D <= 64 (nf_rows_matvec, csrc/rows_matvec.hip)."""
+    L.require_device(x, W)
+    if x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] > 64:
+        raise NotImplementedError("rows_matvec: (B, D <= 64) float32")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    rc = L.lib().nf_rows_matvec(ptr(x), ptr(W.to(torch.float32).contiguous()), ptr(y), i64(x.shape[0]), i32(x.shape[1]), L.stream())
+    L.check(rc, "nf_rows_matvec")
+    return y
+
+
+def inv1x1_wgrad(z, gy, gld):
+    """(gW (C, C), g log|det|-per-pixel (0-dim)) of the per-pixel product y = W z (mixing.py:106-133): gW = sum over
+    pixels of gy z^T, partial sums per group of images added in a fixed order."""
+    import ctypes
+    L.require_device(z, gy, gld)
+    z, gy = z.contiguous(), gy.contiguous()
+    B, Cc = z.shape[:2]
+    HW = int(math.prod(z.shape[2:])) if z.dim() > 2 else 1
+    lib = L.lib()
+    lib.nf_inv1x1_wgrad_scratch_elems.restype = ctypes.c_int64
+    n = lib.nf_inv1x1_wgrad_scratch_elems(i64(B), i32(Cc))
+    if n < 0:
+        raise NotImplementedError("inv1x1_wgrad: C <= 64")
+    scratch = torch.empty(int(n), dtype=z.dtype, device=z.device)
+    gW = torch.empty(Cc, Cc, dtype=z.dtype, device=z.device)
+    gl = torch.empty((), dtype=z.dtype, device=z.device)
+    rc = lib.nf_inv1x1_wgrad(ptr(z), ptr(gy), ptr(None if gld is None else gld.contiguous()), ptr(gW), ptr(gl), ptr(scratch),
+                             i64(B), i32(Cc), i64(HW), i32(L.dtype_code(z)), L.stream())
+    L.check(rc, "nf_inv1x1_wgrad")
+    return gW, gl
+
+
 def diag_gaussian_log_prob(z, loc, log_scale, log_scale_shift=0.0, out=None, acc=None):
     """distributions/base.py:94-103."""
     L.require_device(z, loc, log_scale)

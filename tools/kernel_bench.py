@@ -27,8 +27,13 @@ def timeit(fn, reps=20):
     return s.elapsed_time(e) / reps * 1e-3
 
 
+ROWS = []
+
+
 def report(name, sec, nbytes):
-    print("%-44s %9.1f us  %8.1f GB/s  (%.1f%% of 8 TB/s)" % (name, sec * 1e6, nbytes / sec / 1e9, nbytes / sec / 8e12 * 100))
+    print("%-52s %9.1f us  %8.1f GB/s  (%.1f%% of 8 TB/s)" % (name, sec * 1e6, nbytes / sec / 1e9, nbytes / sec / 8e12 * 100))
+    ROWS.append({"kernel": name, "us": sec * 1e6, "algorithmic_bytes": nbytes, "GBps": nbytes / sec / 1e9,
+                 "frac_of_8TBps": nbytes / sec / 8e12})
 
 
 def main():
@@ -81,6 +86,42 @@ def main():
     zi = torch.randn(256, 3, 32, 32, device=dev)
     t = timeit(lambda: ops.squeeze(zi, 1))
     report("nf_squeeze (256,3,32,32)", t, zi.numel() * 8)
+    # the same layer kernels at sizes that can saturate HBM (transform kernels as GB/s / 8 TB/s)
+    Bi = 8192
+    for C, HW in ((12, 16), (48, 4)):
+        z = torch.randn(Bi, C, HW, HW, device=dev)
+        gyz = torch.randn_like(z)
+        ldz = torch.zeros(Bi, device=dev)
+        an = nfa.flows.ActNorm((C, 1, 1)).to(dev)
+        an.inverse(z)
+        t = timeit(lambda: an._run(z, True, ldz, +1))
+        report("nf_actnorm (%d,%d,%d,%d)" % (Bi, C, HW, HW), t, z.numel() * 8)
+        t = timeit(lambda: ops.actnorm_bwd(z, an.s.detach().view(-1), an.t.detach().view(-1), gyz, ldz, 1))
+        report("nf_actnorm_bwd (%d,%d,%d,%d)" % (Bi, C, HW, HW), t, z.numel() * 12)
+        conv = nfa.flows.Invertible1x1Conv(C, True).to(dev)
+        conv._run(z, True, ldz, +1)
+        t = timeit(lambda: conv._run(z, True, ldz, +1))
+        report("nf_inv1x1 conv (%d,%d,%d,%d)" % (Bi, C, HW, HW), t, z.numel() * 8)
+        t = timeit(lambda: ops.inv1x1_wgrad(z, gyz, ldz))
+        report("nf_inv1x1_wgrad (%d,%d,%d,%d)" % (Bi, C, HW, HW), t, z.numel() * 8)
+        param = torch.randn(Bi, 2 * (C // 2), HW, HW, device=dev)
+        t = timeit(lambda: ops.affine_coupling(z, param, (C + 1) // 2, False, "sigmoid", 1, logdet=ldz, acc=1))
+        report("nf_affine_coupling (%d,%d,%d,%d)" % (Bi, C, HW, HW), t, z.numel() * 8 + param.numel() * 4)
+        t = timeit(lambda: ops.affine_coupling_bwd(z, param, gyz, ldz, (C + 1) // 2, False, "sigmoid", 1))
+        report("nf_affine_coupling_bwd (%d,%d,%d,%d)" % (Bi, C, HW, HW), t, z.numel() * 12 + param.numel() * 8)
+    zi = torch.randn(Bi, 3, 32, 32, device=dev)
+    t = timeit(lambda: ops.squeeze(zi, 1))
+    report("nf_squeeze (%d,3,32,32)" % Bi, t, zi.numel() * 8)
+    zr = torch.randn(B, D, device=dev)
+    bm = (torch.arange(D, device=dev) % 2).float()
+    sr, tr = 0.1 * torch.randn(B, D, device=dev), torch.randn(B, D, device=dev)
+    t = timeit(lambda: ops.masked_affine(zr, bm, sr, tr, 0, logdet=ld, acc=1))
+    report("nf_masked_affine (%d,%d)" % (B, D), t, B * D * 16 + B * 8)
+    t = timeit(lambda: ops.masked_affine_bwd(zr, bm, sr, tr, tr, ld, 0))
+    report("nf_masked_affine_bwd (%d,%d)" % (B, D), t, B * D * 28 + B * 4)
+    Wm = torch.randn(D, D, device=dev)
+    t = timeit(lambda: ops.rows_matvec(zr, Wm))
+    report("nf_rows_matvec (%d,%d)" % (B, D), t, B * D * 8)
     z2 = torch.randn(1024, 2, device=dev)
     b = torch.tensor([1.0, 0.0], device=dev)
     s2, t2 = torch.randn(1024, 2, device=dev), torch.randn(1024, 2, device=dev)
@@ -91,3 +132,7 @@ def main():
 
 if __name__ == "__main__":
     main()
+    if len(sys.argv) > 2 and sys.argv[1] == "--json":
+        import json
+        json.dump({"what": "stand-alone layer kernels: HIP-event time per launch, algorithmic bytes / time against the 8 TB/s HBM "
+                           "peak (tools/kernel_bench.py, 1x MI355X)", "rows": ROWS}, open(sys.argv[2], "w"), indent=1)
