@@ -453,8 +453,9 @@ int nf_masked_affine_bwd(const void *z, const void *b, const void *s, const void
 int nf_affine_coupling_bwd(const void *z, const void *param, const void *gy, const void *gld, void *gz, void *gparam,
                            int64_t B, int C, int c1, int flip, int64_t HW, int scale_map, int direction, int dtype,
                            nf_stream_t stream);
+int64_t nf_actnorm_bwd_scratch_doubles(int64_t B, int C);   /* fp64 partial sums of nf_actnorm_bwd (caller-owned scratch) */
 int nf_actnorm_bwd(const void *z, const void *s, const void *t, const void *gy, const void *gld, void *gz, void *gs,
-                   void *gt, int64_t B, int C, int64_t HW, int direction, int dtype, nf_stream_t stream);
+                   void *gt, void *scratch, int64_t B, int C, int64_t HW, int direction, int dtype, nf_stream_t stream);
 int64_t nf_inv1x1_wgrad_scratch_elems(int64_t B, int C);
 int nf_inv1x1_wgrad(const void *z, const void *gy, const void *gld, void *gW, void *gldu, void *scratch, int64_t B, int C,
                     int64_t HW, int dtype, nf_stream_t stream);
@@ -466,6 +467,16 @@ int nf_inv1x1_wgrad(const void *z, const void *gy, const void *gld, void *gW, vo
  * y must not alias x.
  */
 int nf_rows_matvec(const void *x, const void *W, void *y, int64_t B, int D, nf_stream_t stream);
+/* Same with a bias (D, may be NULL) and, when logdet != NULL, logdet[b] (acc) ld_sign * (*ld_const) for every row. */
+int nf_rows_matvec_affine(const void *x, const void *W, const void *bias, void *y, void *logdet, const void *ld_const,
+                          double ld_sign, int acc, int64_t B, int D, nf_stream_t stream);
+/* LULinearPermute (mixing.py:402-473, :535-563) composed into one dense matrix per direction (fp64 arithmetic in one
+ * workgroup; D <= 64, float32 parameters), once per parameter version: out = Wd (D, D) | Ws (D, D) | bias_d (D) |
+ * bias_s (D) | log|det| (1) with  .inverse (density): y = Wd x + bias_d, log_det = +log|det|;  .forward (sample):
+ * y = Ws x + bias_s, log_det = -log|det|.  The layer then is ONE nf_rows_matvec_affine launch (HBM-bound). */
+int nf_lu_compose(const int64_t *perm, const void *lower_entries, const void *upper_entries,
+                  const void *unconstrained_upper_diag, const void *bias, double eps, void *out, int D,
+                  nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Squeeze (flows/reshape.py:116-128).  direction 0 = forward (C,H,W)->(C/4,2H,2W),

@@ -17,10 +17,18 @@ masked_affine_kernel(const T *__restrict__ z, const T *__restrict__ b, const T *
                      int direction, int acc) {
     __shared__ T sred[16];
     if (inner <= 64) {
-        // small rows (2-D toy problems): one lane per sample, no cross-lane reduction
-        for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < B; r += (int64_t)gridDim.x * blockDim.x) {
+        // short rows: a wave holds 64 / P whole rows (P = inner rounded up to a power of two), lane = element -- unit-stride
+        // loads and stores -- and the per-sample sum is a butterfly inside the row's P lanes
+        int P = 1;
+        while (P < (int)inner) P <<= 1;
+        const int rpw = 64 / P, lane = threadIdx.x & 63, rin = lane / P, i = lane - rin * P;
+        const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+        for (int64_t r0 = wave * rpw; r0 < B; r0 += nwaves * rpw) {
+            const int64_t r = r0 + rin;
+            const bool on = r < B && i < (int)inner;
             T ld = T(0);
-            for (int64_t i = 0; i < inner; ++i) {
+            if (on) {
                 const int64_t o = r * inner + i;
                 const T bi = b[i], zi = z[o];
                 T si = s ? s[o] : T(0), ti = t ? t[o] : T(0);
@@ -29,9 +37,10 @@ masked_affine_kernel(const T *__restrict__ z, const T *__restrict__ b, const T *
                 const T zm = bi * zi;
                 if (direction == 0) y[o] = zm + (T(1) - bi) * (zi * M<T>::exp(si) + ti);
                 else y[o] = zm + (T(1) - bi) * (zi - ti) * M<T>::exp(-si);
-                ld += (T(1) - bi) * si;
+                ld = (T(1) - bi) * si;
             }
-            ld_store(logdet + r, direction == 0 ? ld : -ld, acc);
+            for (int off = P >> 1; off >= 1; off >>= 1) ld += __shfl_xor(ld, off, 64);
+            if (on && i == 0) ld_store(logdet + r, direction == 0 ? ld : -ld, acc);
         }
         return;
     }
@@ -266,7 +275,7 @@ extern "C" int nf_masked_affine(const void *z, const void *b, const void *s, con
     if (B == 0) return NF_OK;
     if (!z || !b || !y || !logdet) return NF_EFAULT;
     hipStream_t st = (hipStream_t)stream;
-    const int grid = inner <= 64 ? grid_for(B, 256) : grid_for(B, 1, 256 * 16);
+    const int grid = inner <= 64 ? grid_for(B * inner, 256 * 4) : grid_for(B, 1, 256 * 16);
     NF_DISPATCH(dtype,
                 hipLaunchKernelGGL(masked_affine_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)z,
                                    (const float *)b, (const float *)s, (const float *)t, (float *)y, (float *)logdet, B,

@@ -93,34 +93,50 @@ affine_coupling_bwd_kernel(const T *__restrict__ z, const T *__restrict__ param,
 
 // ---- AffineConstFlow / ActNorm with per-channel s, t (coupling.py:38-54) ---------------------------------------------
 //   direction 0: y = z e^s + t, ld (every sample) = +HW sum s;   direction 1: y = (z - t) e^-s, ld = -HW sum s.
-// One workgroup per channel: gz in the same pass as the two per-channel reductions (fp64 accumulation, fixed order).
+// Grid (C, nsplit): workgroup (c, j) handles images j, j + nsplit, ... of channel c: gz in the same pass as the partial
+// per-channel sums (fp64); the second kernel adds the nsplit partials in a fixed order (deterministic).
 template <typename T>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(256)
 actnorm_bwd_kernel(const T *__restrict__ z, const T *__restrict__ s, const T *__restrict__ t, const T *__restrict__ gy,
-                   const T *__restrict__ gld, T *__restrict__ gz, T *__restrict__ gs, T *__restrict__ gt, int64_t B, int C,
-                   int64_t HW, int direction) {
+                   T *__restrict__ gz, double *__restrict__ partial, int64_t B, int C, int64_t HW, int direction) {
     __shared__ double sred[16];
-    const int c = blockIdx.x;
-    const int64_t n = B * HW;
+    const int c = blockIdx.x, j = blockIdx.y, nsplit = gridDim.y;
     const T sc = s[c], tc = t[c];
     const T e = M<T>::exp(direction == 0 ? sc : -sc);
     double as = 0.0, at = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const int64_t bb = i / HW, p = i - bb * HW;
-        const int64_t o = (bb * C + c) * HW + p;
+    const int64_t nimg = (B - j + nsplit - 1) / nsplit;       // images j, j + nsplit, ...
+    for (int64_t e_ = threadIdx.x; e_ < nimg * HW; e_ += blockDim.x) {
+        const int64_t k = e_ / HW, p = e_ - k * HW;
+        const int64_t o = ((j + k * nsplit) * C + c) * HW + p;
         const T g = gy[o], v = z[o];
         gz[o] = g * e;
         if (direction == 0) { as += (double)(g * v * e); at += (double)g; }
         else { as -= (double)(g * (v - tc) * e); at -= (double)(g * e); }
     }
+    as = block_sum(as, sred);
+    at = block_sum(at, sred);
+    if (threadIdx.x == 0) {
+        partial[((int64_t)j * C + c) * 2] = as;
+        partial[((int64_t)j * C + c) * 2 + 1] = at;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+actnorm_bwd_reduce_kernel(const double *__restrict__ partial, const T *__restrict__ gld, T *__restrict__ gs, T *__restrict__ gt,
+                          int nsplit, int64_t B, int C, int64_t HW, int direction) {
+    __shared__ double sred[16];
     double gl = 0.0;   // d ld / d s_c = +-HW for every sample
     if (gld)
         for (int64_t r = threadIdx.x; r < B; r += blockDim.x) gl += (double)gld[r];
-    as = block_sum(as, sred);
-    at = block_sum(at, sred);
     gl = block_sum(gl, sred);
-    if (threadIdx.x == 0) {
-        gs[c] = (T)(as + (direction == 0 ? 1.0 : -1.0) * (double)HW * gl);
+    __shared__ double glb;
+    if (threadIdx.x == 0) glb = gl;
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double as = 0.0, at = 0.0;
+        for (int j = 0; j < nsplit; ++j) { as += partial[((int64_t)j * C + c) * 2]; at += partial[((int64_t)j * C + c) * 2 + 1]; }
+        gs[c] = (T)(as + (direction == 0 ? 1.0 : -1.0) * (double)HW * glb);
         gt[c] = (T)at;
     }
 }
@@ -240,20 +256,35 @@ extern "C" int nf_affine_coupling_bwd(const void *z, const void *param, const vo
     return NF_OK;
 }
 
+static inline int actnorm_bwd_nsplit(int64_t B, int C) {
+    int64_t n = (2048 + C - 1) / C;     // ~2048 workgroups in all
+    if (n > B) n = B;
+    return (int)(n < 1 ? 1 : n);
+}
+
+extern "C" int64_t nf_actnorm_bwd_scratch_doubles(int64_t B, int C) {
+    if (B < 0 || C < 1) return NF_EINVAL;
+    return (int64_t)actnorm_bwd_nsplit(B, C) * C * 2;
+}
+
 extern "C" int nf_actnorm_bwd(const void *z, const void *s, const void *t, const void *gy, const void *gld, void *gz,
-                              void *gs, void *gt, int64_t B, int C, int64_t HW, int direction, int dtype,
+                              void *gs, void *gt, void *scratch, int64_t B, int C, int64_t HW, int direction, int dtype,
                               nf_stream_t stream) {
-    if (B < 0 || C < 1 || HW < 1 || (direction != 0 && direction != 1)) return NF_EINVAL;
-    if (!s || !t || !gs || !gt) return NF_EFAULT;
-    if (B > 0 && (!z || !gy || !gz)) return NF_EFAULT;
+    if (B < 1 || C < 1 || HW < 1 || (direction != 0 && direction != 1)) return NF_EINVAL;
+    if (!s || !t || !gs || !gt || !scratch || !z || !gy || !gz) return NF_EFAULT;
     hipStream_t st = (hipStream_t)stream;
+    const int nsplit = actnorm_bwd_nsplit(B, C);
     NF_DISPATCH(dtype,
-                hipLaunchKernelGGL(actnorm_bwd_kernel<float>, dim3(C), dim3(1024), 0, st, (const float *)z, (const float *)s,
-                                   (const float *)t, (const float *)gy, (const float *)gld, (float *)gz, (float *)gs,
-                                   (float *)gt, B, C, HW, direction),
-                hipLaunchKernelGGL(actnorm_bwd_kernel<double>, dim3(C), dim3(1024), 0, st, (const double *)z,
-                                   (const double *)s, (const double *)t, (const double *)gy, (const double *)gld,
-                                   (double *)gz, (double *)gs, (double *)gt, B, C, HW, direction));
+                hipLaunchKernelGGL(actnorm_bwd_kernel<float>, dim3(C, nsplit), dim3(256), 0, st, (const float *)z,
+                                   (const float *)s, (const float *)t, (const float *)gy, (float *)gz, (double *)scratch, B, C,
+                                   HW, direction);
+                hipLaunchKernelGGL(actnorm_bwd_reduce_kernel<float>, dim3(1), dim3(256), 0, st, (const double *)scratch,
+                                   (const float *)gld, (float *)gs, (float *)gt, nsplit, B, C, HW, direction),
+                hipLaunchKernelGGL(actnorm_bwd_kernel<double>, dim3(C, nsplit), dim3(256), 0, st, (const double *)z,
+                                   (const double *)s, (const double *)t, (const double *)gy, (double *)gz, (double *)scratch, B,
+                                   C, HW, direction);
+                hipLaunchKernelGGL(actnorm_bwd_reduce_kernel<double>, dim3(1), dim3(256), 0, st, (const double *)scratch,
+                                   (const double *)gld, (double *)gs, (double *)gt, nsplit, B, C, HW, direction));
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

@@ -14,8 +14,80 @@ namespace nf {
 constexpr int RM_D = 64;
 constexpr int RM_NW = 4;
 
+// LULinearPermute (mixing.py:402-473, :535-563) as ONE dense D x D matrix per direction, composed in fp64 by a single
+// workgroup (parameter-side work, once per parameter version):
+//   density (.inverse): y = L (U x[perm]) + b              -> Wd[i][perm[j]] = (L U)[i][j],            bias_d = b
+//   sample  (.forward): y[perm[j]] = (U^-1 L^-1 (x - b))_j  -> Ws[perm[j]][k] = (U^-1 L^-1)[j][k],     bias_s = -Ws b
+// out: Wd (D x D) | Ws (D x D) | bias_d (D) | bias_s (D) | log|det| = sum log(softplus(u_diag) + eps) (1), row-major fp32.
+__global__ void __launch_bounds__(256)
+lu_compose_kernel(const int64_t *__restrict__ perm, const float *__restrict__ lower_entries,
+                  const float *__restrict__ upper_entries, const float *__restrict__ udiag_raw,
+                  const float *__restrict__ bias, float eps, float *__restrict__ out, int D) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lu_raw[];
+    const int N = D * D;
+    double *A = reinterpret_cast<double *>(lu_raw), *Bm = A + N, *Cm = Bm + N, *Dm = Cm + N;
+    __shared__ float sred[16];
+    const int tid = threadIdx.x;
+    float *Wd = out, *Ws = out + N, *bd = out + 2 * N, *bs = bd + D, *lad = bs + D;
+    for (int i = tid; i < N; i += 256) {
+        const int r = i / D, c = i - r * D;
+        double l = 0.0, u = 0.0;
+        if (c < r) l = (double)lower_entries[r * (r - 1) / 2 + c];
+        else if (c == r) { l = 1.0; u = (double)(softplus(udiag_raw[r]) + eps); }
+        else u = (double)upper_entries[r * (D - 1) - r * (r - 1) / 2 + (c - r - 1)];
+        A[i] = l;
+        Bm[i] = u;
+    }
+    float part = 0.0f;
+    for (int i = tid; i < D; i += 256) part += logf(softplus(udiag_raw[i]) + eps);  // mixing.py:514-532
+    const float ladv = block_sum(part, sred);
+    if (tid == 0) *lad = ladv;
+    __syncthreads();
+    for (int i = tid; i < N; i += 256) {            // density: (L U)[r][c] -> column perm[c]
+        const int r = i / D, c = i - r * D;
+        double a = 0.0;
+        for (int k = 0; k <= (r < c ? r : c); ++k) a += A[r * D + k] * Bm[k * D + c];
+        Wd[r * D + (int)perm[c]] = (float)a;
+    }
+    for (int i = tid; i < D; i += 256) bd[i] = bias[i];
+    for (int i = tid; i < N; i += 256) { Cm[i] = 0.0; Dm[i] = 0.0; }
+    __syncthreads();
+    for (int c = tid; c < D; c += 256) {            // Cm = L^-1, Dm = U^-1 (column solves)
+        for (int r = c; r < D; ++r) {
+            double a = (r == c) ? 1.0 : 0.0;
+            for (int k = c; k < r; ++k) a -= A[r * D + k] * Cm[k * D + c];
+            Cm[r * D + c] = a;
+        }
+        for (int r = c; r >= 0; --r) {
+            double a = (r == c) ? 1.0 : 0.0;
+            for (int k = r + 1; k <= c; ++k) a -= Bm[r * D + k] * Dm[k * D + c];
+            Dm[r * D + c] = a / Bm[r * D + r];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += 256) {            // A := U^-1 L^-1
+        const int r = i / D, c = i - r * D;
+        double a = 0.0;
+        for (int k = (r > c ? r : c); k < D; ++k) a += Dm[r * D + k] * Cm[k * D + c];
+        A[i] = a;
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += 256) {
+        const int j = i / D, k = i - j * D;
+        Ws[(int)perm[j] * D + k] = (float)A[i];
+    }
+    for (int j = tid; j < D; j += 256) {
+        double a = 0.0;
+        for (int k = 0; k < D; ++k) a += A[j * D + k] * (double)bias[k];
+        bs[(int)perm[j]] = (float)(-a);
+    }
+}
+
+// y_b = W x_b (+ bias); optionally logdet[b] (op)= ld_sign * (*ld_const) for every row (LULinearPermute's constant log-det).
 __global__ void __launch_bounds__(64 * RM_NW)
-rows_matvec_kernel(const float *__restrict__ x, const float *__restrict__ W, float *__restrict__ y, int64_t B, int D) {
+rows_matvec_kernel(const float *__restrict__ x, const float *__restrict__ W, float *__restrict__ y, int64_t B, int D,
+                   const float *__restrict__ bias, float *__restrict__ logdet, const float *__restrict__ ld_const,
+                   float ld_sign, int acc) {
     // Wl[m][s4][lane][4]: W[32 m + (lane & 31)][4 s4 + r + 32 (lane >> 5)], s4 = 0..7  (2 x 8 x 64 x 4 floats = 16 KB)
     __shared__ __attribute__((aligned(16))) float Wl[2 * 8 * 64 * 4];
     const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
@@ -39,6 +111,14 @@ rows_matvec_kernel(const float *__restrict__ x, const float *__restrict__ W, flo
     }
     __syncthreads();
     f32x16 o0 = {0}, o1 = {0};
+    if (bias) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int r0 = 8 * (c >> 2) + 4 * hh + (c & 3);
+            o0[c] = r0 < D ? bias[r0] : 0.0f;
+            o1[c] = 32 + r0 < D ? bias[32 + r0] : 0.0f;
+        }
+    }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         f32x16 &o = m == 0 ? o0 : o1;
@@ -50,6 +130,7 @@ rows_matvec_kernel(const float *__restrict__ x, const float *__restrict__ W, flo
         }
     }
     if (row < B) {
+        if (logdet && hh == 0) ld_store(logdet + row, ld_sign * (*ld_const), acc);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const f32x16 &o = m == 0 ? o0 : o1;
@@ -73,15 +154,37 @@ rows_matvec_kernel(const float *__restrict__ x, const float *__restrict__ W, flo
 
 using namespace nf;
 
-extern "C" int nf_rows_matvec(const void *x, const void *W, void *y, int64_t B, int D, nf_stream_t stream) {
-    if (B < 0 || D < 1) return NF_EINVAL;
+extern "C" int nf_rows_matvec_affine(const void *x, const void *W, const void *bias, void *y, void *logdet,
+                                     const void *ld_const, double ld_sign, int acc, int64_t B, int D, nf_stream_t stream) {
+    if (B < 0 || D < 1 || acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
     if (D > RM_D) return NF_ENOTSUP;
     if (B == 0) return NF_OK;
-    if (!x || !W || !y) return NF_EFAULT;
+    if (!x || !W || !y || (logdet && !ld_const)) return NF_EFAULT;
     const int64_t grid = (B + 32 * RM_NW - 1) / (32 * RM_NW);
     if (grid > 0x7fffffff) return NF_ERANGE;
     hipLaunchKernelGGL(rows_matvec_kernel, dim3((unsigned)grid), dim3(64 * RM_NW), 0, (hipStream_t)stream, (const float *)x,
-                       (const float *)W, (float *)y, B, D);
+                       (const float *)W, (float *)y, B, D, (const float *)bias, (float *)logdet, (const float *)ld_const,
+                       (float)ld_sign, acc);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_rows_matvec(const void *x, const void *W, void *y, int64_t B, int D, nf_stream_t stream) {
+    return nf_rows_matvec_affine(x, W, nullptr, y, nullptr, nullptr, 0.0, NF_LD_WRITE, B, D, stream);
+}
+
+extern "C" int nf_lu_compose(const int64_t *perm, const void *lower_entries, const void *upper_entries,
+                             const void *unconstrained_upper_diag, const void *bias, double eps, void *out, int D,
+                             nf_stream_t stream) {
+    if (D < 1) return NF_EINVAL;
+    if (D > RM_D) return NF_ENOTSUP;
+    if (!perm || !unconstrained_upper_diag || !bias || !out || (D > 1 && (!lower_entries || !upper_entries))) return NF_EFAULT;
+    const size_t lds = (size_t)4 * D * D * sizeof(double);
+    static LdsOptIn opted = {};
+    if (opt_in_lds(reinterpret_cast<const void *>(&lu_compose_kernel), lds, opted) != NF_OK) return NF_ENOTSUP;
+    hipLaunchKernelGGL(lu_compose_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, perm, (const float *)lower_entries,
+                       (const float *)upper_entries, (const float *)unconstrained_upper_diag, (const float *)bias, (float)eps,
+                       (float *)out, D);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

@@ -272,6 +272,7 @@ class LULinearPermute(Flow):
         super().__init__()
         self.permutation = _RandomPermutation(num_channels)
         self.linear = _LULinear(num_channels, identity_init=identity_init)
+        self.use_dense = True    # False: the LDS-tile kernel nf_lu_linear_permute also for D <= 64 float32 (tests / ablation)
 
     def _apply_kernel(self, z, inverse, ld=None, acc=None):
         if z.dim() != 2:
@@ -289,6 +290,19 @@ class LULinearPermute(Flow):
                     ld -= log_det
                 return y, ld
             return y, log_det
+        if z.dtype == torch.float32 and z.is_cuda and lin.features <= 64 and self.use_dense:
+            # the layer as ONE dense D x D product on fp32 MFMA (nf_lu_compose once per parameter version + nf_rows_matvec_affine):
+            # HBM-bound, 5x the LDS-tile kernel below, which stays for D > 64 and float64
+            params = (lin.lower_entries, lin.upper_entries, lin.unconstrained_upper_diag, lin.bias)
+            key = tuple((p_.data_ptr(), p_._version) for p_ in params)
+            cache = self.__dict__.get("_dense_cache")
+            if cache is None or cache[0] != key:
+                cache = self._dense_cache = (key, ops.lu_compose(self.permutation._permutation, *[p_.detach() for p_ in params],
+                                                                 eps=lin.eps))
+            Wd, Ws, bd, bs, lad = cache[1]
+            if inverse:
+                return ops.rows_matvec_affine(z, Wd, bd, lad, +1.0, logdet=ld, acc=acc)
+            return ops.rows_matvec_affine(z, Ws, bs, lad, -1.0, logdet=ld, acc=acc)
         # flow.inverse (density) = kernel direction 0, flow.forward (sample) = kernel direction 1
         return ops.lu_linear_permute(z, self.permutation._permutation, lin.lower_entries.detach(),
                                      lin.upper_entries.detach(), lin.unconstrained_upper_diag.detach(),

@@ -264,9 +264,15 @@ def actnorm_bwd(z, s, t, gy, gld, direction):
     gz = torch.empty_like(z)
     gs = torch.empty(Cc, dtype=z.dtype, device=z.device)
     gt = torch.empty(Cc, dtype=z.dtype, device=z.device)
-    rc = L.lib().nf_actnorm_bwd(ptr(z), ptr(s.contiguous().view(-1)), ptr(t.contiguous().view(-1)), ptr(gy),
-                                ptr(None if gld is None else gld.contiguous()), ptr(gz), ptr(gs), ptr(gt), i64(B), i32(Cc),
-                                i64(HW), i32(direction), i32(L.dtype_code(z)), L.stream())
+    if B == 0:
+        return gz, gs.zero_(), gt.zero_()
+    import ctypes
+    lib = L.lib()
+    lib.nf_actnorm_bwd_scratch_doubles.restype = ctypes.c_int64
+    scratch = torch.empty(int(lib.nf_actnorm_bwd_scratch_doubles(i64(B), i32(Cc))), dtype=torch.float64, device=z.device)
+    rc = lib.nf_actnorm_bwd(ptr(z), ptr(s.contiguous().view(-1)), ptr(t.contiguous().view(-1)), ptr(gy),
+                            ptr(None if gld is None else gld.contiguous()), ptr(gz), ptr(gs), ptr(gt), ptr(scratch), i64(B),
+                            i32(Cc), i64(HW), i32(direction), i32(L.dtype_code(z)), L.stream())
     L.check(rc, "nf_actnorm_bwd")
     return gz, gs, gt
 
@@ -281,6 +287,37 @@ def rows_matvec(x, W):
     rc = L.lib().nf_rows_matvec(ptr(x), ptr(W.to(torch.float32).contiguous()), ptr(y), i64(x.shape[0]), i32(x.shape[1]), L.stream())
     L.check(rc, "nf_rows_matvec")
     return y
+
+
+def lu_compose(perm, lower_entries, upper_entries, unconstrained_upper_diag, bias, eps=1e-3):
+    """LULinearPermute as dense matrices (nf_lu_compose): (Wd, Ws, bias_d, bias_s, log|det| (1-element)) views of one
+    buffer; float32, D <= 64."""
+    L.require_device(perm, lower_entries, upper_entries, unconstrained_upper_diag, bias)
+    D = bias.numel()
+    out = torch.empty(2 * D * D + 2 * D + 1, dtype=torch.float32, device=bias.device)
+    rc = L.lib().nf_lu_compose(ptr(perm), ptr(lower_entries.contiguous()), ptr(upper_entries.contiguous()),
+                               ptr(unconstrained_upper_diag.contiguous()), ptr(bias.contiguous()), f64(eps), ptr(out), i32(D),
+                               L.stream())
+    L.check(rc, "nf_lu_compose")
+    N = D * D
+    return out[:N].view(D, D), out[N:2 * N].view(D, D), out[2 * N:2 * N + D], out[2 * N + D:2 * N + 2 * D], out[2 * N + 2 * D:]
+
+
+def rows_matvec_affine(x, W, bias, ld_const=None, ld_sign=1.0, logdet=None, acc=None):
+    """y_b = W x_b + bias and logdet[b] (acc) ld_sign * ld_const (nf_rows_matvec_affine); (B, D <= 64) float32."""
+    L.require_device(x, W, bias, ld_const, logdet)
+    x = x.contiguous()
+    B, D = x.shape
+    y = torch.empty_like(x)
+    if ld_const is not None and logdet is None:
+        logdet = torch.empty(B, dtype=x.dtype, device=x.device)
+        acc = L.LD_WRITE
+    elif acc is None:
+        acc = L.LD_ADD
+    rc = L.lib().nf_rows_matvec_affine(ptr(x), ptr(W), ptr(bias), ptr(y), ptr(logdet if ld_const is not None else None),
+                                       ptr(ld_const), f64(ld_sign), i32(acc), i64(B), i32(D), L.stream())
+    L.check(rc, "nf_rows_matvec_affine")
+    return y, logdet
 
 
 def inv1x1_wgrad(z, gy, gld):

@@ -121,22 +121,30 @@ def test_output_buffers_keep_their_canaries(nfa, guarded):
         try:
             cls.FUSED_MIN_PIXELS, cls.FUSED_WIDE_MIN_PIXELS = 0, 0
             blocks = [nfa.flows.GlowBlock(24, 256, init_zeros=False).to(DEV) for _ in range(3)]
+            done = 0
             for H in (8, 4, 16):
                 B = 37
                 zz = torch.randn(B, 24, H, H, device=DEV)
                 for bk in blocks:
                     zz, _ = bk.inverse(zz)           # initialises the ActNorms (layer by layer), later calls: one launch each
                 from normflows_amd.flows.glow import plan_level, run_level
-                for inverse in (True, False):
-                    seq = blocks[::-1] if inverse else blocks
-                    n, entries, layout, slope, smap = plan_level(seq, B, 24, H, H, inverse)
-                    assert n == 3
-                    ld = torch.zeros(B, device=DEV)
-                    big = torch.randn(B, 6, 2 * H, 2 * H, device=DEV)
-                    o0, o1 = run_level(seq, entries, layout, slope, smap, big, None, True, inverse, ld, +1, cout0=12)
-                    o0, o1 = run_level(seq, entries, layout, slope, smap, o0, o1, False, inverse, ld, +1, out_squeezed=True)
-                    assert torch.isfinite(o0).all()
+                try:
+                    for inverse in (True, False):
+                        seq = blocks[::-1] if inverse else blocks
+                        n, entries, layout, slope, smap = plan_level(seq, B, 24, H, H, inverse)
+                        assert n == 3
+                        ld = torch.zeros(B, device=DEV)
+                        big = torch.randn(B, 6, 2 * H, 2 * H, device=DEV)
+                        o0, o1 = run_level(seq, entries, layout, slope, smap, big, None, True, inverse, ld, +1, cout0=12)
+                        o0, o1 = run_level(seq, entries, layout, slope, smap, o0, o1, False, inverse, ld, +1, out_squeezed=True)
+                        assert torch.isfinite(o0).all()
+                except NotImplementedError:          # 24 channels x 256 pixels: beyond one workgroup's LDS (nothing launched)
+                    assert H == 16
+                    guarded.allocs = []
+                    continue
+                done += 1
                 assert guarded.check() >= 4
+            assert done >= 2
         finally:
             cls.FUSED_MIN_PIXELS, cls.FUSED_WIDE_MIN_PIXELS = saved
 

@@ -816,12 +816,13 @@ def test_fused_layer_vs_unfused_and_oracle(nfa, oracle, reverse_mask, B):
         fin = np.isfinite(z64)
         e_gpu = (np.abs(N(zf).astype(np.float64) - z64) / (1 + np.abs(z64)))[fin]
         e_o32 = (np.abs(zo.astype(np.float64) - z64) / (1 + np.abs(z64)))[fin]
-        for q in (0.9, 0.99, 0.999, 1.0):
+        for q in ((0.9, 0.99, 0.999, 1.0) if fin.any() else ()):
             assert np.quantile(e_gpu, q) <= 4 * np.quantile(e_o32, q) + 4e-6, (q, np.quantile(e_gpu, q), np.quantile(e_o32, q))
         finl = np.isfinite(logq64)
         l_gpu = (np.abs(N(ldf).astype(np.float64) - logq64) / np.maximum(1, np.abs(logq64)))[finl]
         l_o32 = (np.abs(logq.astype(np.float64) - logq64) / np.maximum(1, np.abs(logq64)))[finl]
-        assert l_gpu.max() <= 4 * l_o32.max() + 2e-5, (l_gpu.max(), l_o32.max())
+        if finl.any():
+            assert l_gpu.max() <= 4 * l_o32.max() + 2e-5, (l_gpu.max(), l_o32.max())
     # accumulate modes and repacking after a parameter update
     layer.prqct.use_fused = True
     acc = torch.full((B,), 1.5, device=DEV)

@@ -59,8 +59,14 @@ def main():
     report("nf_rqs_coupling f64 density", t, B * (2 * D * 8 + 16 + 32 * 23 * 8))
     lu = nfa.flows.LULinearPermute(D, identity_init=False).to(dev)
     for inverse, nm in ((True, "density"), (False, "sample")):
-        t = timeit(lambda: lu._run(x, inverse, ld, +1))
-        report("nf_lu_linear_permute f32 " + nm, t, B * (2 * D * 4 + 8))
+        with torch.no_grad():       # inference path: nf_lu_compose (cached) + nf_rows_matvec_affine
+            t = timeit(lambda: lu._run(x, inverse, ld, +1))
+        report("LULinearPermute f32 %s (dense MFMA mat-vec)" % nm, t, B * (2 * D * 4 + 8))
+        lu.use_dense = False
+        with torch.no_grad():
+            t = timeit(lambda: lu._run(x, inverse, ld, +1))
+        lu.use_dense = True
+        report("nf_lu_linear_permute f32 %s (LDS tile)" % nm, t, B * (2 * D * 4 + 8))
     w = torch.randn(B, D, K, device=dev)
     h = torch.randn(B, D, K, device=dev)
     d = torch.randn(B, D, K - 1, device=dev)
