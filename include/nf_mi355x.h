@@ -294,6 +294,10 @@ int nf_diag_gaussian_log_prob(const void *z, const void *loc, const void *log_sc
 int64_t nf_linear_wgrad_scratch_floats(int64_t B, int M, int N);
 int nf_linear_wgrad(const void *dY, const void *X, void *dW, void *db, void *scratch, int64_t B, int M, int N,
                     int accumulate, nf_stream_t stream);
+/* Same with relu_x = 1: the second operand is relu(X), applied as the values are consumed (the caller keeps only the
+ * pre-activation of the block, resnet.py:41-47). */
+int nf_linear_wgrad_act(const void *dY, const void *X, void *dW, void *db, void *scratch, int64_t B, int M, int N,
+                        int accumulate, int relu_x, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Logit preprocessing transform of image tensors.  Replaces normflows/transforms.py:8-47.
@@ -477,6 +481,22 @@ int nf_rows_matvec_affine(const void *x, const void *W, const void *bias, void *
 int nf_lu_compose(const int64_t *perm, const void *lower_entries, const void *upper_entries,
                   const void *unconstrained_upper_diag, const void *bias, double eps, void *out, int D,
                   nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * One <= 128 x 128 panel of a Linear layer over batch rows on exact-fp32 MFMA with the neighbouring element-wise work
+ * folded in -- the conditioner's forward and input-gradient GEMMs of the training path (nets/resnet.py:37-50, :92-104
+ * under core.py:87-102), float32:
+ *     out[b, j] (op)= post( sum_{k < Kc} pre(x[b, k]) Wp[j][k] + bias[j] ),   j < Nc
+ *   pre  = ReLU on load when relu_in;  Wp[j][k] = W[j * ldw + k], or W[k * ldw + j] when trans_w (gx = gy W);
+ *   post = zero where mask_src[b, j] <= 0 (ReLU backward through the saved pre-activation), then + residual[b, j];
+ *   op   = store, or += when accumulate (K split over several launches).  bias / mask_src / residual may be NULL.
+ * x, mask_src, residual, out: row-major with row pitches ldx / ldm / ldr / ldo (floats, multiples of 4, 16-byte aligned
+ * origins) so that 128-column panels of wider tensors are addressed in place; Kc, Nc <= 128 (NF_ENOTSUP beyond:
+ * callers split wider layers into panels).  out must not alias x.
+ */
+int nf_rows_linear(const void *x, int64_t ldx, const void *W, int64_t ldw, int trans_w, const void *bias,
+                   const void *mask_src, int64_t ldm, const void *residual, int64_t ldr, void *out, int64_t ldo, int64_t B,
+                   int Kc, int Nc, int relu_in, int accumulate, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Squeeze (flows/reshape.py:116-128).  direction 0 = forward (C,H,W)->(C/4,2H,2W),

@@ -199,14 +199,23 @@ class DiagGaussianLogProbFn(torch.autograd.Function):
         return gz, gloc.view_as(loc), gls.view_as(log_scale), None
 
 
+def _rows_ok(x, weight):
+    """nf_rows_linear takes this Linear: float32 rows on the device, widths multiples of 4."""
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and weight.shape[0] % 4 == 0 and weight.shape[1] % 4 == 0 and x.shape[0] > 0)
+
+
 class LinearFn(torch.autograd.Function):
-    """y = x W^T + b with the weight / bias gradients on the split-K HIP kernel: at the training batch sizes of the
-    path (K = 65 536 rows, 128 x 128 outputs) the library GEMM runs at a few percent of peak."""
+    """y = x W^T + b on the hand-written kernels: forward and input gradient on the fp32-MFMA row-panel kernel
+    (nf_rows_linear), weight / bias gradients on the split-K kernel (nf_linear_wgrad) -- at the training batch sizes of the
+    path (65 536 rows against 128 x 128 outputs) the library GEMMs run at 0.3-0.4 of the fp32 MFMA peak."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        if _rows_ok(x, weight):
+            return ops.rows_linear(x, weight.detach(), None if bias is None else bias.detach())
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
@@ -215,18 +224,59 @@ class LinearFn(torch.autograd.Function):
         gx = gw = gb = None
         gy = gy.contiguous()
         if ctx.needs_input_grad[0]:
-            gx = gy @ weight
+            gx = ops.rows_linear(gy, weight.detach(), trans_w=True) if _rows_ok(gy, weight) else gy @ weight
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw, gb = ops.linear_wgrad(gy, x, want_bias=ctx.has_bias)
+            if weight.shape[1] <= 128:
+                gw, gb = ops.linear_wgrad(gy, x, want_bias=ctx.has_bias)
+            else:
+                gw, gb = gy.t() @ x, (gy.sum(0) if ctx.has_bias else None)
         return gx, gw, gb
 
 
 def linear(x, weight, bias):
-    """F.linear, routed through LinearFn where the custom weight-gradient kernel applies."""
-    if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.shape[1] <= 128 and x.shape[0] >= 1024
-            and torch.is_grad_enabled() and (weight.requires_grad or (bias is not None and bias.requires_grad))):
+    """F.linear, routed through LinearFn where the custom kernels apply."""
+    if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= 1024 and torch.is_grad_enabled()
+            and (weight.shape[1] <= 128 or _rows_ok(x, weight))
+            and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad))):
         return LinearFn.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)
+
+
+class ResidualBlockFn(torch.autograd.Function):
+    """The plain pre-activation block y = x + W2 relu(W1 relu(x) + b1) + b2 (resnet.py:37-50 without batch norm, dropout,
+    context) as two launches forward and two backward of nf_rows_linear: the ReLUs are applied on load, the biases and the
+    residual in the epilogue, the ReLU derivatives as masks by the saved pre-activations -- no element-wise kernels; weight
+    and bias gradients on nf_linear_wgrad (ReLU of its second operand applied on load)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x = x.contiguous()
+        t = ops.rows_linear(x, w1.detach(), b1.detach(), relu_in=True)
+        y = ops.rows_linear(t, w2.detach(), b2.detach(), relu_in=True, residual=x)
+        ctx.save_for_backward(x, t, w1, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, t, w1, w2 = ctx.saved_tensors
+        gy = gy.contiguous()
+        gt = ops.rows_linear(gy, w2.detach(), trans_w=True, mask_src=t)                 # (gy W2) * (t > 0)
+        gx = ops.rows_linear(gt, w1.detach(), trans_w=True, mask_src=x, residual=gy)    # gy + (gt W1) * (x > 0)
+        gw2, gb2 = ops.linear_wgrad(gy, t, want_bias=True, relu_x=True)
+        gw1, gb1 = ops.linear_wgrad(gt, x, want_bias=True, relu_x=True)
+        return gx, gw1, gb1, gw2, gb2
+
+
+def residual_block_fused_ok(block, x):
+    """True when `block` (nets.ResidualBlock) is the plain ReLU block on float32 device rows that ResidualBlockFn covers."""
+    lin = block.linear_layers
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= 1024 and torch.is_grad_enabled()
+            and not block.use_batch_norm and block.dropout.p == 0.0
+            and (block.activation is torch.nn.functional.relu or isinstance(block.activation, torch.nn.ReLU))
+            and all(l.bias is not None and l.weight.dtype == torch.float32 for l in lin)
+            and lin[0].weight.shape[0] % 4 == 0 and lin[0].weight.shape[1] % 4 == 0 and lin[0].weight.shape[1] <= 128
+            and lin[0].weight.shape[0] <= 128
+            and (x.requires_grad or any(p.requires_grad for p in block.parameters())))
 
 
 # ---- affine / Glow layers: HIP forward and HIP backward (csrc/affine_bwd.hip: closed-form vector-Jacobian products); the

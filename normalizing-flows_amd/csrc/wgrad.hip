@@ -19,7 +19,9 @@ namespace nf {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---- vector path: N % 4 == 0, N <= 128 ------------------------------------------------------------------
-template <bool A_VEC>   // 8-byte dY loads need even M; a template parameter keeps the k loop a single basic block
+// X_RELU: the second operand is relu(X) (the block's activation in front of the layer, applied when the value is consumed:
+// the caller keeps only the pre-activation)
+template <bool A_VEC, bool X_RELU>   // 8-byte dY loads need even M; template parameters keep the k loop a single basic block
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wgrad_partial_vec_kernel(const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ part, int64_t B,
                          int M, int N, int chunk_rows, int want_bias) {
@@ -67,8 +69,9 @@ wgrad_partial_vec_kernel(const float *__restrict__ dY, const float *__restrict__
             bs1 += a1;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                acc[0][t] = MFMA32(a0, tr.x[j][t], acc[0][t]);
-                acc[1][t] = MFMA32(a1, tr.x[j][t], acc[1][t]);
+                const float xv = X_RELU ? fmaxf(tr.x[j][t], 0.0f) : tr.x[j][t];
+                acc[0][t] = MFMA32(a0, xv, acc[0][t]);
+                acc[1][t] = MFMA32(a1, xv, acc[1][t]);
             }
         }
     };
@@ -123,7 +126,7 @@ constexpr int WG_MT = 4;  // m-tiles (waves) per workgroup
 template <int NT>
 __global__ void __launch_bounds__(64 * WG_MT)
 wgrad_partial_kernel(const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ part, int64_t B,
-                     int M, int N, int chunk_rows, int want_bias) {
+                     int M, int N, int chunk_rows, int want_bias, int x_relu) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int mt = blockIdx.y * WG_MT + wid;     // m-tile of this wave
@@ -154,7 +157,10 @@ wgrad_partial_kernel(const float *__restrict__ dY, const float *__restrict__ X, 
                 const int64_t r = b + 2 * j + h;
                 a[j] = mval ? pa[r * M] : 0.0f;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) x[j][t] = nval[t] ? pb[t][r * N] : 0.0f;
+                for (int t = 0; t < NT; ++t) {
+                    x[j][t] = nval[t] ? pb[t][r * N] : 0.0f;
+                    if (x_relu) x[j][t] = fmaxf(x[j][t], 0.0f);
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -169,7 +175,11 @@ wgrad_partial_kernel(const float *__restrict__ dY, const float *__restrict__ X, 
             const float a = (mval && rv) ? pa[r * M] : 0.0f;
             bsum += a;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = MFMA32(a, (nval[t] && rv) ? pb[t][r * N] : 0.0f, acc[t]);
+            for (int t = 0; t < NT; ++t) {
+                float xv = (nval[t] && rv) ? pb[t][r * N] : 0.0f;
+                if (x_relu) xv = fmaxf(xv, 0.0f);
+                acc[t] = MFMA32(a, xv, acc[t]);
+            }
         }
         // C layout: row = (reg & 3) + 8 (reg >> 2) + 4 h (m within the tile), col = lane & 31 (n within the tile)
         float *out = part + (size_t)blockIdx.x * ((size_t)M * N + M);
@@ -245,9 +255,16 @@ extern "C" int64_t nf_linear_wgrad_scratch_floats(int64_t B, int M, int N) {
     return chunks * ((int64_t)M * N + M);
 }
 
+extern "C" int nf_linear_wgrad_act(const void *dY, const void *X, void *dW, void *db, void *scratch, int64_t B, int M, int N,
+                                   int accumulate, int relu_x, nf_stream_t stream);
 extern "C" int nf_linear_wgrad(const void *dY, const void *X, void *dW, void *db, void *scratch, int64_t B, int M, int N,
                                int accumulate, nf_stream_t stream) {
-    if (B < 1 || M < 1 || N < 1 || (accumulate != 0 && accumulate != 1)) return NF_EINVAL;
+    return nf_linear_wgrad_act(dY, X, dW, db, scratch, B, M, N, accumulate, 0, stream);
+}
+
+extern "C" int nf_linear_wgrad_act(const void *dY, const void *X, void *dW, void *db, void *scratch, int64_t B, int M, int N,
+                                   int accumulate, int relu_x, nf_stream_t stream) {
+    if (B < 1 || M < 1 || N < 1 || (accumulate != 0 && accumulate != 1) || (relu_x != 0 && relu_x != 1)) return NF_EINVAL;
     if (N > 128) return NF_ENOTSUP;  // four 32-column tiles of accumulators per wave
     if (!dY || !X || !dW || !scratch) return NF_EFAULT;
     hipStream_t st = (hipStream_t)stream;
@@ -257,19 +274,19 @@ extern "C" int nf_linear_wgrad(const void *dY, const void *X, void *dW, void *db
     float *part = (float *)scratch;
     const int want_bias = db ? 1 : 0;
     if (vec) {
-        if (M % 2 == 0)
-            hipLaunchKernelGGL(nf::wgrad_partial_vec_kernel<true>, dim3(chunks, (M + 63) / 64), dim3(64), 0, st,
-                               (const float *)dY, (const float *)X, part, B, M, N, rows, want_bias);
-        else
-            hipLaunchKernelGGL(nf::wgrad_partial_vec_kernel<false>, dim3(chunks, (M + 63) / 64), dim3(64), 0, st,
-                               (const float *)dY, (const float *)X, part, B, M, N, rows, want_bias);
+#define NF_WGRAD_VEC(AV, XR)                                                                                          \
+    hipLaunchKernelGGL((nf::wgrad_partial_vec_kernel<AV, XR>), dim3(chunks, (M + 63) / 64), dim3(64), 0, st,          \
+                       (const float *)dY, (const float *)X, part, B, M, N, rows, want_bias)
+        if (M % 2 == 0) { if (relu_x) NF_WGRAD_VEC(true, true); else NF_WGRAD_VEC(true, false); }
+        else { if (relu_x) NF_WGRAD_VEC(false, true); else NF_WGRAD_VEC(false, false); }
+#undef NF_WGRAD_VEC
     } else {
         const int mtiles = (M + 31) / 32;
         dim3 grid(chunks, (mtiles + nf::WG_MT - 1) / nf::WG_MT);
         const int nt = (N + 31) / 32;
 #define NF_WGRAD_LAUNCH(NT)                                                                                         \
     hipLaunchKernelGGL(nf::wgrad_partial_kernel<NT>, grid, dim3(64 * nf::WG_MT), 0, st, (const float *)dY,           \
-                       (const float *)X, part, B, M, N, rows, want_bias)
+                       (const float *)X, part, B, M, N, rows, want_bias, relu_x)
         if (nt == 1) NF_WGRAD_LAUNCH(1);
         else if (nt == 2) NF_WGRAD_LAUNCH(2);
         else if (nt == 3) NF_WGRAD_LAUNCH(3);

@@ -39,6 +39,11 @@ class ResidualBlock(nn.Module):
             init.uniform_(self.linear_layers[-1].bias, -1e-3, 1e-3)
 
     def forward(self, inputs, context=None):
+        if context is None:
+            from . import autograd
+            if autograd.residual_block_fused_ok(self, inputs):   # training: four launches of the MFMA row-panel kernel
+                l1, l2 = self.linear_layers
+                return autograd.ResidualBlockFn.apply(inputs, l1.weight, l1.bias, l2.weight, l2.bias)
         temps = inputs
         if self.use_batch_norm:
             temps = self.batch_norm_layers[0](temps)
@@ -420,6 +425,11 @@ class MaskedResidualBlock(nn.Module):
             init.uniform_(self.linear_layers[-1].bias, a=-1e-3, b=1e-3)
 
     def forward(self, inputs, context=None):
+        if context is None:
+            from . import autograd
+            if autograd.residual_block_fused_ok(self, inputs):   # training: four launches of the MFMA row-panel kernel
+                l1, l2 = self.linear_layers
+                return autograd.ResidualBlockFn.apply(inputs, l1.weight, l1.bias, l2.weight, l2.bias)
         temps = inputs
         if self.use_batch_norm:
             temps = self.batch_norm_layers[0](temps)

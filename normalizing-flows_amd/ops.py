@@ -3,6 +3,7 @@
 Each wrapper validates devices/dtypes, allocates outputs with torch.empty on the input's device and
 enqueues exactly one kernel on torch's current HIP stream.  No arithmetic happens in Python.
 """
+import ctypes as C
 import math
 
 import torch
@@ -287,6 +288,44 @@ def rows_matvec(x, W):
     rc = L.lib().nf_rows_matvec(ptr(x), ptr(W.to(torch.float32).contiguous()), ptr(y), i64(x.shape[0]), i32(x.shape[1]), L.stream())
     L.check(rc, "nf_rows_matvec")
     return y
+
+
+def rows_linear(x, W, bias=None, relu_in=False, trans_w=False, mask_src=None, residual=None):
+    """out = post(pre(x) Wp^T + bias) for a whole Linear layer (nf_rows_linear, csrc/rows_linear.hip), any width: the layer
+    is cut into <= 128-column output panels and <= 128-wide contraction chunks (later chunks accumulate).
+    x (B, K) float32; W (N, K), or (K, N) with trans_w (the input gradient gx = gy W of a layer with weight W (K, N)... i.e.
+    out[b, j] = sum_k x[b, k] W[k, j]); pre = ReLU when relu_in; post: zero where mask_src <= 0, then + residual."""
+    L.require_device(x, W, bias, mask_src, residual)
+    if x.dtype != torch.float32 or x.dim() != 2:
+        raise NotImplementedError("rows_linear: (B, K) float32")
+    x = x.contiguous()
+    W = W.contiguous()
+    B, K = x.shape
+    N = W.shape[1] if trans_w else W.shape[0]
+    assert (W.shape[0] if trans_w else W.shape[1]) == K, (W.shape, K, trans_w)
+    if K % 4 or N % 4:
+        raise NotImplementedError("rows_linear: widths must be multiples of 4")
+    out = torch.empty(B, N, dtype=torch.float32, device=x.device)
+    bias = None if bias is None else bias.contiguous()
+    mask_src = None if mask_src is None else mask_src.contiguous()
+    residual = None if residual is None else residual.contiguous()
+    ldw = W.shape[1]
+    lib, st = L.lib(), L.stream()
+    e = 4   # bytes per element
+    for n0 in range(0, N, 128):
+        nc = min(128, N - n0)
+        for ki, k0 in enumerate(range(0, K, 128)):
+            kc = min(128, K - k0)
+            last = k0 + kc >= K
+            woff = (k0 * ldw + n0) if trans_w else (n0 * ldw + k0)
+            off = lambda t, c: None if t is None else C.c_void_p(t.data_ptr() + c * e)   # noqa: E731
+            rc = lib.nf_rows_linear(off(x, k0), i64(K), off(W, woff), i64(ldw), i32(int(trans_w)),
+                                    off(bias, n0) if ki == 0 else None,
+                                    off(mask_src, n0), i64(N),   # a 0/1 factor: applied to every chunk's contribution
+                                    off(residual, n0) if last else None, i64(N), off(out, n0), i64(N), i64(B), i32(kc), i32(nc),
+                                    i32(int(relu_in)), i32(1 if ki > 0 else 0), st)
+            L.check(rc, "nf_rows_linear")
+    return out
 
 
 def lu_compose(perm, lower_entries, upper_entries, unconstrained_upper_diag, bias, eps=1e-3):
@@ -749,8 +788,9 @@ def diag_gaussian_log_prob_rows(z, loc_rows, log_scale_rows, row_idx=None, ls_sh
     return out
 
 
-def linear_wgrad(dy, x, want_bias=True):
-    """dW = dy^T x, db = dy.sum(0) for a Linear layer (nf_linear_wgrad, split-K fp32 MFMA, deterministic reduction)."""
+def linear_wgrad(dy, x, want_bias=True, relu_x=False):
+    """dW = dy^T x (x -> relu(x) with relu_x), db = dy.sum(0) for a Linear layer (nf_linear_wgrad[_act], split-K fp32 MFMA,
+    deterministic reduction)."""
     L.require_device(dy, x)
     if dy.dtype != torch.float32 or x.dtype != torch.float32:
         raise NotImplementedError("linear_wgrad: float32 only")
@@ -761,9 +801,9 @@ def linear_wgrad(dy, x, want_bias=True):
     db = torch.empty(M, dtype=torch.float32, device=dy.device) if want_bias else None
     n = L.lib().nf_linear_wgrad_scratch_floats(i64(B), i32(M), i32(N))
     scratch = torch.empty(max(int(n), 1), dtype=torch.float32, device=dy.device)
-    rc = L.lib().nf_linear_wgrad(ptr(dy), ptr(x), ptr(dW), ptr(db), ptr(scratch), i64(B), i32(M), i32(N), i32(0),
-                                 L.stream())
-    L.check(rc, "nf_linear_wgrad")
+    rc = L.lib().nf_linear_wgrad_act(ptr(dy), ptr(x), ptr(dW), ptr(db), ptr(scratch), i64(B), i32(M), i32(N), i32(0),
+                                     i32(int(relu_x)), L.stream())
+    L.check(rc, "nf_linear_wgrad_act")
     return dW, db
 
 

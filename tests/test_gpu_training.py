@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_close, golden_state, load_golden
+from conftest import assert_close, golden_state, load_golden  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -426,3 +426,64 @@ def test_layers_without_training_path_refuse_gradients(nfa):
     assert y1.requires_grad
     assert_close(N(y1), N(y0), what="logit torch vs kernel", rtol=1e-5, atol=1e-5)
     assert_close(N(ld1), N(ld0), what="logit ld torch vs kernel", rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,K,N", [(1024, 128, 128), (1500, 32, 128), (2048, 128, 736), (1100, 736, 128), (1024, 128, 32),
+                                   (65536, 128, 128), (1, 64, 96)])
+def test_rows_linear_kernel_vs_torch(nfa, B, K, N):
+    """nf_rows_linear (csrc/rows_linear.hip) against float64 torch arithmetic: plain, with bias, ReLU on load, transposed
+    weight, ReLU mask by a saved pre-activation, residual; widths beyond one 128 x 128 panel (column panels, K chunks)."""
+    torch.manual_seed(B + K + N)
+    x = torch.randn(B, K, device=DEV)
+    W = torch.randn(N, K, device=DEV) / np.sqrt(K)
+    b = torch.randn(N, device=DEV)
+    m = torch.randn(B, N, device=DEV)
+    r = torch.randn(B, N, device=DEV)
+    x64, W64 = x.double(), W.double()
+    tol = dict(rtol=2e-5, atol=2e-5 * np.sqrt(K))
+    y = nfa.ops.rows_linear(x, W, b)
+    assert_close(N_(y), N_((x64 @ W64.t() + b.double()).float()), what="linear", **tol)
+    y = nfa.ops.rows_linear(x, W, b, relu_in=True, residual=r)
+    assert_close(N_(y), N_((x64.clamp_min(0) @ W64.t() + b.double() + r.double()).float()), what="relu_in + residual", **tol)
+    Wt = torch.randn(K, N, device=DEV) / np.sqrt(K)          # gx = gy W for a layer with weight (K_out = K, N_in = N)
+    y = nfa.ops.rows_linear(x, Wt, trans_w=True, mask_src=m, residual=r)
+    ref = (x64 @ Wt.double()) * (m > 0) + r.double()
+    assert_close(N_(y), N_(ref.float()), what="trans_w + mask + residual", **tol)
+    assert torch.equal(y, nfa.ops.rows_linear(x, Wt, trans_w=True, mask_src=m, residual=r))    # deterministic
+
+
+def N_(t):
+    return t.detach().cpu().numpy()
+
+
+def test_residual_block_and_linear_functions_vs_torch_autograd(nfa):
+    """ResidualBlockFn / LinearFn (HIP forward, HIP input gradient, HIP weight gradients with ReLU on load) against PyTorch
+    autograd of the reference block x + W2 relu(W1 relu(x) + b1) + b2 (resnet.py:37-50) and of the 736-row final layer."""
+    from normflows_amd import autograd as ag
+    torch.manual_seed(3)
+    B, H = 4096, 128
+    net = nfa.nets.ResidualNet(32, 736, H, num_blocks=2).to(DEV)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.add_(0.05 * torch.randn_like(p_))
+    x = torch.randn(B, 32, device=DEV)
+    cy = torch.randn(B, 736, device=DEV)
+    assert ag.residual_block_fused_ok(net.blocks[0], torch.randn(B, H, device=DEV))
+    xa = x.clone().requires_grad_(True)
+    (net(xa) * cy).sum().backward()                                        # our Functions (B >= 1024)
+    got = [xa.grad.clone()] + [p_.grad.clone() for p_ in net.parameters()]
+    net.zero_grad()
+    xb = x.clone().requires_grad_(True)
+    h = torch.nn.functional.linear(xb, net.initial_layer.weight, net.initial_layer.bias)
+    for blk in net.blocks:
+        l1, l2 = blk.linear_layers
+        t = torch.nn.functional.linear(torch.relu(h), l1.weight, l1.bias)
+        h = h + torch.nn.functional.linear(torch.relu(t), l2.weight, l2.bias)
+    out = torch.nn.functional.linear(h, net.final_layer.weight, net.final_layer.bias)
+    (out * cy).sum().backward()
+    ref = [xb.grad] + [p_.grad for p_ in net.parameters()]
+    with torch.no_grad():
+        assert_close(N_(net(x)), N_(out), what="forward (inference path vs torch)", rtol=1e-4, atol=1e-4)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        scale = float(b.abs().max())
+        assert_close(N_(a), N_(b), what="grad %d" % i, rtol=2e-4, atol=2e-4 * max(scale, 1.0))
