@@ -498,6 +498,19 @@ int nf_rows_linear(const void *x, int64_t ldx, const void *W, int64_t ldw, int t
                    const void *mask_src, int64_t ldm, const void *residual, int64_t ldr, void *out, int64_t ldo, int64_t B,
                    int Kc, int Nc, int relu_in, int accumulate, nf_stream_t stream);
 
+/* A whole plain residual block (resnet.py:37-50: x + W2 relu(W1 relu(x) + b1) + b2, H <= 128 columns, float32) or its
+ * backward in ONE launch:   out1 = mask1( M1 pre1(in) + c1 ),   out2 = in + mask2( M2 pre2(out1) + c2 )
+ * with pre = ReLU when relu1 / relu2, mask = zero where the mask source is <= 0 (NULL: none), Mi[j][k] = Mi[j * ldw + k] or,
+ * transposed, Mi[k * ldw + j].  forward: in = x, M1 = W1, c1 = b1, M2 = W2, c2 = b2, relu1 = relu2 = 1 -> out1 = t (the
+ * pre-activation kept for the backward), out2 = y.  backward: in = gy, M1 = W2 (transposed), mask1 = t, M2 = W1
+ * (transposed), mask2 = x -> out1 = gt, out2 = gx.  Both weight panels stay in LDS, out1 feeds the second product from
+ * registers; per row one read of `in` and the mask sources, one write of out1 and out2.  Row pitches in floats, multiples
+ * of 4; 16-byte aligned origins. */
+int nf_rows_block(const void *in, int64_t ldi, const void *M1, int64_t ldw1, int trans1, const void *c1, const void *mask1,
+                  int64_t ldm1, void *out1, int64_t ldo1, const void *M2, int64_t ldw2, int trans2, const void *c2,
+                  const void *mask2, int64_t ldm2, void *out2, int64_t ldo2, int64_t B, int H, int relu1, int relu2,
+                  nf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Squeeze (flows/reshape.py:116-128).  direction 0 = forward (C,H,W)->(C/4,2H,2W),
  * 1 = inverse (C,H,W)->(4C,H/2,W/2).  z, y contiguous NCHW with the shapes implied.

@@ -206,15 +206,20 @@ def _rows_ok(x, weight):
 
 
 class LinearFn(torch.autograd.Function):
-    """y = x W^T + b on the hand-written kernels: forward and input gradient on the fp32-MFMA row-panel kernel
-    (nf_rows_linear), weight / bias gradients on the split-K kernel (nf_linear_wgrad) -- at the training batch sizes of the
-    path (65 536 rows against 128 x 128 outputs) the library GEMMs run at 0.3-0.4 of the fp32 MFMA peak."""
+    """y = x W^T + b with the weight / bias gradients on the split-K HIP kernel (nf_linear_wgrad): at the training batch
+    sizes of the path (K = 65 536 rows, 128 x 128 outputs) the library runs that reduction at a few percent of peak.  The
+    forward and input-gradient products stay library GEMMs by default: measured on MI355X (tools/kernel_bench.py) hipBLASLt
+    does the 65 536 x 128 x 128 product in 28 us (77 TFLOP/s) and the 736-row final layer at 0.55-0.85 of the fp32 MFMA peak,
+    ahead of the stand-alone row-panel kernel nf_rows_linear (44 us; `config.set_train_gemm("rows")` routes them there);
+    what beats the library is keeping the block's intermediate on chip (ResidualBlockFn below)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
+        from . import config
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        if _rows_ok(x, weight):
+        ctx.rows = config.train_gemm == "rows" and _rows_ok(x, weight)
+        if ctx.rows:
             return ops.rows_linear(x, weight.detach(), None if bias is None else bias.detach())
         return torch.nn.functional.linear(x, weight, bias)
 
@@ -224,7 +229,7 @@ class LinearFn(torch.autograd.Function):
         gx = gw = gb = None
         gy = gy.contiguous()
         if ctx.needs_input_grad[0]:
-            gx = ops.rows_linear(gy, weight.detach(), trans_w=True) if _rows_ok(gy, weight) else gy @ weight
+            gx = ops.rows_linear(gy, weight.detach(), trans_w=True) if (ctx.rows and _rows_ok(gy, weight)) else gy @ weight
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             if weight.shape[1] <= 128:
                 gw, gb = ops.linear_wgrad(gy, x, want_bias=ctx.has_bias)
@@ -236,7 +241,7 @@ class LinearFn(torch.autograd.Function):
 def linear(x, weight, bias):
     """F.linear, routed through LinearFn where the custom kernels apply."""
     if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= 1024 and torch.is_grad_enabled()
-            and (weight.shape[1] <= 128 or _rows_ok(x, weight))
+            and weight.shape[1] <= 128
             and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad))):
         return LinearFn.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)
@@ -244,15 +249,16 @@ def linear(x, weight, bias):
 
 class ResidualBlockFn(torch.autograd.Function):
     """The plain pre-activation block y = x + W2 relu(W1 relu(x) + b1) + b2 (resnet.py:37-50 without batch norm, dropout,
-    context) as two launches forward and two backward of nf_rows_linear: the ReLUs are applied on load, the biases and the
-    residual in the epilogue, the ReLU derivatives as masks by the saved pre-activations -- no element-wise kernels; weight
-    and bias gradients on nf_linear_wgrad (ReLU of its second operand applied on load)."""
+    context) as ONE launch forward and ONE backward (nf_rows_block, csrc/rows_linear.hip): both weight panels in LDS, the
+    intermediate goes from the first product's accumulators straight into the second product (it is written once, for the
+    backward, never read back), ReLUs on registers, biases / residual / ReLU masks in the epilogues -- the library path is
+    two GEMMs plus three element-wise kernels each way.  Weight and bias gradients on nf_linear_wgrad (ReLU of its second
+    operand applied on load)."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2):
         x = x.contiguous()
-        t = ops.rows_linear(x, w1.detach(), b1.detach(), relu_in=True)
-        y = ops.rows_linear(t, w2.detach(), b2.detach(), relu_in=True, residual=x)
+        t, y = ops.rows_block(x, w1.detach(), b1.detach(), w2.detach(), b2.detach(), trans=False, relu=True)
         ctx.save_for_backward(x, t, w1, w2)
         return y
 
@@ -260,8 +266,8 @@ class ResidualBlockFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, t, w1, w2 = ctx.saved_tensors
         gy = gy.contiguous()
-        gt = ops.rows_linear(gy, w2.detach(), trans_w=True, mask_src=t)                 # (gy W2) * (t > 0)
-        gx = ops.rows_linear(gt, w1.detach(), trans_w=True, mask_src=x, residual=gy)    # gy + (gt W1) * (x > 0)
+        # gt = (gy W2) * (t > 0);  gx = gy + (gt W1) * (x > 0)
+        gt, gx = ops.rows_block(gy, w2.detach(), None, w1.detach(), None, trans=True, mask1=t, mask2=x, relu=False)
         gw2, gb2 = ops.linear_wgrad(gy, t, want_bias=True, relu_x=True)
         gw1, gb1 = ops.linear_wgrad(gt, x, want_bias=True, relu_x=True)
         return gx, gw1, gb1, gw2, gb2
@@ -275,7 +281,8 @@ def residual_block_fused_ok(block, x):
             and (block.activation is torch.nn.functional.relu or isinstance(block.activation, torch.nn.ReLU))
             and all(l.bias is not None and l.weight.dtype == torch.float32 for l in lin)
             and lin[0].weight.shape[0] % 4 == 0 and lin[0].weight.shape[1] % 4 == 0 and lin[0].weight.shape[1] <= 128
-            and lin[0].weight.shape[0] <= 128
+            and lin[0].weight.shape[0] <= 128 and lin[0].weight.shape[0] == lin[0].weight.shape[1]
+            and tuple(lin[1].weight.shape) == tuple(lin[0].weight.shape)
             and (x.requires_grad or any(p.requires_grad for p in block.parameters())))
 
 

@@ -328,6 +328,25 @@ def rows_linear(x, W, bias=None, relu_in=False, trans_w=False, mask_src=None, re
     return out
 
 
+def rows_block(x, M1, c1, M2, c2, trans=False, mask1=None, mask2=None, relu=True):
+    """(out1, out2) of nf_rows_block: out1 = mask1(M1 pre(x) + c1), out2 = x + mask2(M2 pre(out1) + c2); (B, H <= 128)
+    float32.  trans: M1 / M2 are used transposed (the block's backward); relu: pre = ReLU on both products."""
+    L.require_device(x, M1, c1, M2, c2, mask1, mask2)
+    x = x.contiguous()
+    B, H = x.shape
+    if x.dtype != torch.float32 or H > 128 or H % 4:
+        raise NotImplementedError("rows_block: (B, H <= 128, H % 4 == 0) float32")
+    M1, M2 = M1.contiguous(), M2.contiguous()
+    assert tuple(M1.shape) == (H, H) and tuple(M2.shape) == (H, H)
+    out1, out2 = torch.empty_like(x), torch.empty_like(x)
+    c = lambda t: None if t is None else t.contiguous()   # noqa: E731
+    rc = L.lib().nf_rows_block(ptr(x), i64(H), ptr(M1), i64(H), i32(int(trans)), ptr(c(c1)), ptr(c(mask1)), i64(H), ptr(out1),
+                               i64(H), ptr(M2), i64(H), i32(int(trans)), ptr(c(c2)), ptr(c(mask2)), i64(H), ptr(out2), i64(H),
+                               i64(B), i32(H), i32(int(relu)), i32(int(relu)), L.stream())
+    L.check(rc, "nf_rows_block")
+    return out1, out2
+
+
 def lu_compose(perm, lower_entries, upper_entries, unconstrained_upper_diag, bias, eps=1e-3):
     """LULinearPermute as dense matrices (nf_lu_compose): (Wd, Ws, bias_d, bias_s, log|det| (1-element)) views of one
     buffer; float32, D <= 64."""

@@ -469,10 +469,16 @@ def test_residual_block_and_linear_functions_vs_torch_autograd(nfa):
     x = torch.randn(B, 32, device=DEV)
     cy = torch.randn(B, 736, device=DEV)
     assert ag.residual_block_fused_ok(net.blocks[0], torch.randn(B, H, device=DEV))
-    xa = x.clone().requires_grad_(True)
-    (net(xa) * cy).sum().backward()                                        # our Functions (B >= 1024)
-    got = [xa.grad.clone()] + [p_.grad.clone() for p_ in net.parameters()]
-    net.zero_grad()
+    results = []
+    for mode in ("library", "rows"):       # Linear layers on the library / on nf_rows_linear; the blocks on nf_rows_block
+        nfa.config.set_train_gemm(mode)
+        try:
+            xa = x.clone().requires_grad_(True)
+            (net(xa) * cy).sum().backward()                                # our Functions (B >= 1024)
+        finally:
+            nfa.config.set_train_gemm("library")
+        results.append([xa.grad.clone()] + [p_.grad.clone() for p_ in net.parameters()])
+        net.zero_grad()
     xb = x.clone().requires_grad_(True)
     h = torch.nn.functional.linear(xb, net.initial_layer.weight, net.initial_layer.bias)
     for blk in net.blocks:
@@ -484,6 +490,39 @@ def test_residual_block_and_linear_functions_vs_torch_autograd(nfa):
     ref = [xb.grad] + [p_.grad for p_ in net.parameters()]
     with torch.no_grad():
         assert_close(N_(net(x)), N_(out), what="forward (inference path vs torch)", rtol=1e-4, atol=1e-4)
-    for i, (a, b) in enumerate(zip(got, ref)):
-        scale = float(b.abs().max())
-        assert_close(N_(a), N_(b), what="grad %d" % i, rtol=2e-4, atol=2e-4 * max(scale, 1.0))
+    # The two forwards are different fp32 summation orders: a pre-activation within rounding of zero may get the other ReLU
+    # branch (a handful of the 2 M hidden values), which moves that row's gradients by O(1): every gradient is held to
+    # 1e-4 of its scale at the median, 1e-3 at the 90th percentile and 2 % everywhere.
+    for got in results:
+        for i, (a, b) in enumerate(zip(got, ref)):
+            scale = max(float(b.abs().max()), 1.0)
+            err = np.abs(N_(a) - N_(b))
+            assert np.median(err) < 1e-4 * scale and np.quantile(err, 0.9) < 1e-3 * scale, (i, np.median(err), scale)
+            assert err.max() < 2e-2 * scale, (i, err.max(), scale)
+
+
+@pytest.mark.parametrize("B,H", [(1024, 128), (1000, 64), (65536, 128), (3, 36)])
+def test_rows_block_kernel_vs_torch(nfa, B, H):
+    """nf_rows_block: the residual block forward and its backward form (transposed panels, ReLU masks) in one launch each,
+    against float64 torch arithmetic; ragged batches, widths below 128."""
+    torch.manual_seed(B + H)
+    x = torch.randn(B, H, device=DEV)
+    W1, W2 = torch.randn(H, H, device=DEV) / np.sqrt(H), torch.randn(H, H, device=DEV) / np.sqrt(H)
+    b1, b2 = torch.randn(H, device=DEV), torch.randn(H, device=DEV)
+    t, y = nfa.ops.rows_block(x, W1, b1, W2, b2)
+    x64 = x.double()
+    t64 = x64.clamp_min(0) @ W1.double().t() + b1.double()
+    y64 = x64 + t64.clamp_min(0) @ W2.double().t() + b2.double()
+    tol = dict(rtol=3e-5, atol=3e-5 * np.sqrt(H))
+    assert_close(N_(t), N_(t64.float()), what="t", **tol)
+    # y through OUR t (a t within rounding of zero may take the other ReLU branch in float64)
+    y_ref = x64 + t.double().clamp_min(0) @ W2.double().t() + b2.double()
+    assert_close(N_(y), N_(y_ref.float()), what="y", **tol)
+    gy = torch.randn(B, H, device=DEV)
+    gt, gx = nfa.ops.rows_block(gy, W2, None, W1, None, trans=True, mask1=t, mask2=x, relu=False)
+    gt64 = (gy.double() @ W2.double()) * (t > 0)
+    assert_close(N_(gt), N_(gt64.float()), what="gt", **tol)
+    gx64 = gy.double() + (gt.double() @ W1.double()) * (x > 0)
+    assert_close(N_(gx), N_(gx64.float()), what="gx", **tol)
+    t2, y2 = nfa.ops.rows_block(x, W1, b1, W2, b2)
+    assert torch.equal(t, t2) and torch.equal(y, y2)

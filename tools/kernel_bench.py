@@ -128,6 +128,33 @@ def main():
     Wm = torch.randn(D, D, device=dev)
     t = timeit(lambda: ops.rows_matvec(zr, Wm))
     report("nf_rows_matvec (%d,%d)" % (B, D), t, B * D * 8)
+    # conditioner GEMMs of the training path: the MFMA row-panel kernel against the library call it replaces
+    for K_, N_ in ((128, 128), (32, 128), (128, 736), (736, 128)):
+        xa = torch.randn(B, K_, device=dev)
+        Wa = torch.randn(N_, K_, device=dev)
+        ba = torch.randn(N_, device=dev)
+        ra = torch.randn(B, N_, device=dev)
+        t = timeit(lambda: ops.rows_linear(xa, Wa, ba, relu_in=True, residual=ra))
+        fl = 2.0 * B * K_ * N_
+        report("nf_rows_linear %dx%d relu+bias+residual [%.0f TF]" % (K_, N_, fl / t / 1e12), t, B * (K_ + 2 * N_) * 4)
+        t = timeit(lambda: torch.nn.functional.linear(xa, Wa, ba))
+        report("  library F.linear %dx%d (bias only) [%.0f TF]" % (K_, N_, fl / t / 1e12), t, B * (K_ + N_) * 4)
+        Wt = torch.randn(K_, N_, device=dev)
+        t = timeit(lambda: ops.rows_linear(xa, Wt, trans_w=True, mask_src=ra, residual=ra))
+        report("nf_rows_linear %dx%d trans+mask+residual [%.0f TF]" % (K_, N_, fl / t / 1e12), t, B * (K_ + 3 * N_) * 4)
+    xa, W1, W2 = torch.randn(B, 128, device=dev), torch.randn(128, 128, device=dev), torch.randn(128, 128, device=dev)
+    b1 = torch.randn(128, device=dev)
+    t = timeit(lambda: ops.rows_block(xa, W1, b1, W2, b1))
+    report("nf_rows_block forward (residual block, 128) [%.0f TF]" % (4.0 * B * 128 * 128 / t / 1e12), t, B * 128 * 12)
+    tt = torch.randn(B, 128, device=dev)
+    t = timeit(lambda: ops.rows_block(xa, W2, None, W1, None, trans=True, mask1=tt, mask2=xa, relu=False))
+    report("nf_rows_block backward (residual block, 128) [%.0f TF]" % (4.0 * B * 128 * 128 / t / 1e12), t, B * 128 * 20)
+
+    def lib_block():
+        h = torch.nn.functional.linear(torch.relu(xa), W1, b1)
+        return xa + torch.nn.functional.linear(torch.relu(h), W2, b1)
+    t = timeit(lib_block)
+    report("  library residual block forward (2 GEMM + 3 elementwise)", t, B * 128 * 12)
     z2 = torch.randn(1024, 2, device=dev)
     b = torch.tensor([1.0, 0.0], device=dev)
     s2, t2 = torch.randn(1024, 2, device=dev), torch.randn(1024, 2, device=dev)
