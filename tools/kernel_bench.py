@@ -164,7 +164,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    with torch.no_grad():      # the inference kernels (layers route to their autograd Functions when gradients are on)
+        main()
     if len(sys.argv) > 2 and sys.argv[1] == "--json":
         import json
         json.dump({"what": "stand-alone layer kernels: HIP-event time per launch, algorithmic bytes / time against the 8 TB/s HBM "
