@@ -192,7 +192,18 @@ namespace nf {
 // rqs_fused.hip).  Per row: one read of `in`, the mask sources, one write of out1 and out2.
 constexpr int RB_NW = 8;
 
+#ifdef NF_RB_TRACE
+static unsigned long long *g_rb_trace = nullptr;
+extern "C" void nf_rows_block_debug_trace(void *buf) { g_rb_trace = (unsigned long long *)buf; }
+#define RB_T(i) do { if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[i] = wall_clock64(); } while (0)
+#else
+#define RB_T(i) do {} while (0)
+#endif
+
 struct RowsBlockArgs {
+#ifdef NF_RB_TRACE
+    unsigned long long *trace;
+#endif
     const float *in; int64_t ldi;
     const float *M1; int64_t ldw1; int trans1;
     const float *c1;
@@ -208,26 +219,34 @@ struct RowsBlockArgs {
 
 // Panel (H x H, zero padded to 128 x 128) -> LDS image [m][s4][lane][4]: element = Mp[32 m + (lane & 31)][k(s4, r, lane >> 5)],
 // PERM = false: k = 4 s4 + r + 64 hk;  PERM = true: k = 32 (s4 >> 2) + 8 (s4 & 3) + 4 hk + r (the C-register order).
-template <bool PERM, int NT>
-__device__ __forceinline__ void rb_load_panel(const float *__restrict__ W, int64_t ldw, int trans, int H, float *Wl, int tid) {
+template <int NT>
+struct RbPanelRegs { f32x4 v[128 / (NT / 32)]; };
+
+template <int NT>
+__device__ __forceinline__ void rb_fetch_panel(const float *__restrict__ W, int64_t ldw, int H, RbPanelRegs<NT> &pr, int tid) {
     const int c = tid & 31, g = tid / 32;       // chunk of 4 along the contiguous axis; NT / 32 lines per pass
     constexpr int LPP = NT / 32, NPASS = 128 / LPP;
-    f32x4 v[NPASS];
     const bool vec_ok = ((ldw & 3) == 0) && (((uintptr_t)W & 15) == 0);
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
         const int line = LPP * ps + g;
-        v[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+        pr.v[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (line < H && 4 * c < H) {
             const float *src = W + (int64_t)line * ldw + 4 * c;
-            if (4 * c + 3 < H && vec_ok) v[ps] = *reinterpret_cast<const f32x4 *>(src);
+            if (4 * c + 3 < H && vec_ok) pr.v[ps] = *reinterpret_cast<const f32x4 *>(src);
             else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (4 * c + r < H) v[ps][r] = src[r];
+                    if (4 * c + r < H) pr.v[ps][r] = src[r];
             }
         }
     }
+}
+
+template <bool PERM, int NT>
+__device__ __forceinline__ void rb_commit_panel(const RbPanelRegs<NT> &pr, int trans, float *Wl, int tid) {
+    const int c = tid & 31, g = tid / 32;
+    constexpr int LPP = NT / 32, NPASS = 128 / LPP;
     auto slot = [](int j, int k) -> int {       // LDS float index of Mp[j][k]
         int s4, hk, r;
         if (!PERM) { hk = k >> 6; s4 = (k & 63) >> 2; r = k & 3; }
@@ -238,10 +257,10 @@ __device__ __forceinline__ void rb_load_panel(const float *__restrict__ W, int64
     for (int ps = 0; ps < NPASS; ++ps) {
         const int line = LPP * ps + g;
         if (!trans) {       // line = output j, the chunk holds k = 4 c .. 4 c + 3 (one aligned group: one 16-byte store)
-            *reinterpret_cast<f32x4 *>(Wl + slot(line, 4 * c)) = v[ps];
+            *reinterpret_cast<f32x4 *>(Wl + slot(line, 4 * c)) = pr.v[ps];
         } else {            // line = k, the chunk holds j = 4 c .. 4 c + 3
 #pragma unroll
-            for (int e = 0; e < 4; ++e) Wl[slot(4 * c + e, line)] = v[ps][e];
+            for (int e = 0; e < 4; ++e) Wl[slot(4 * c + e, line)] = pr.v[ps][e];
         }
     }
 }
@@ -251,9 +270,18 @@ rows_block_kernel(RowsBlockArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem_rb[];
     float *W1l = smem_rb, *W2l = smem_rb + 4 * 16 * 64 * 4;
     const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
-    rb_load_panel<false, 64 * RB_NW>(a.M1, a.ldw1, a.trans1, a.H, W1l, tid);
-    rb_load_panel<true, 64 * RB_NW>(a.M2, a.ldw2, a.trans2, a.H, W2l, tid);
+    RB_T(0);
+    // Both panels -> LDS, each thread's 16 loads in flight before its first LDS write.  (Deferring the second panel's
+    // commit behind the first product was measured: the 32 registers it pins cost what the shorter prologue gains.)
+    {
+        RbPanelRegs<64 * RB_NW> p1r, p2r;
+        rb_fetch_panel<64 * RB_NW>(a.M1, a.ldw1, a.H, p1r, tid);
+        rb_fetch_panel<64 * RB_NW>(a.M2, a.ldw2, a.H, p2r, tid);
+        rb_commit_panel<false, 64 * RB_NW>(p1r, a.trans1, W1l, tid);
+        rb_commit_panel<true, 64 * RB_NW>(p2r, a.trans2, W2l, tid);
+    }
     __syncthreads();
+    RB_T(1);
     const int nmb = (a.H + 31) >> 5;
     const int64_t ntiles = (a.B + 32 * RB_NW - 1) / (32 * RB_NW);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -278,6 +306,15 @@ rows_block_kernel(RowsBlockArgs a) {
         for (int m = 0; m < 4; ++m) {
             T[m] = f32x16{0};
             if (m < nmb) {
+                // the epilogue's inputs are requested BEFORE the MFMAs (clamped row, valid columns): one HBM round trip per
+                // 32-row block was exposed when they were loaded where they are used
+                f32x4 mk[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c0 = 32 * m + 8 * q + 4 * hh;
+                    mk[q] = f32x4{1.f, 1.f, 1.f, 1.f};
+                    if (a.m1 && c0 < a.H) mk[q] = *reinterpret_cast<const f32x4 *>(a.m1 + rc * a.ldm1 + c0);
+                }
                 const float *wl = W1l + (size_t)m * 16 * 256 + lane * 4;
 #pragma unroll
                 for (int s4 = 0; s4 < 16; ++s4) {
@@ -291,11 +328,8 @@ rows_block_kernel(RowsBlockArgs a) {
                     f32x4 v = {T[m][4 * q], T[m][4 * q + 1], T[m][4 * q + 2], T[m][4 * q + 3]};
                     if (c0 < a.H) {
                         if (a.c1) v += *reinterpret_cast<const f32x4 *>(a.c1 + c0);
-                        if (a.m1) {
-                            const f32x4 mk = *reinterpret_cast<const f32x4 *>(a.m1 + rc * a.ldm1 + c0);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.0f ? v[r] : 0.0f;
-                        }
+                        for (int r = 0; r < 4; ++r) v[r] = mk[q][r] > 0.0f ? v[r] : 0.0f;
                         if (rv) *reinterpret_cast<f32x4 *>(a.out1 + row * a.ldo1 + c0) = v;
                     } else {
                         v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -305,8 +339,20 @@ rows_block_kernel(RowsBlockArgs a) {
                 }
             }
         }
+        RB_T(3);
         // ---- second product + residual ----
         for (int mo = 0; mo < nmb; ++mo) {
+            f32x4 mk[4], rs[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = 32 * mo + 8 * q + 4 * hh;
+                mk[q] = f32x4{1.f, 1.f, 1.f, 1.f};
+                rs[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (c0 < a.H) {
+                    if (a.m2) mk[q] = *reinterpret_cast<const f32x4 *>(a.m2 + rc * a.ldm2 + c0);
+                    rs[q] = *reinterpret_cast<const f32x4 *>(a.in + rc * a.ldi + c0);      // the residual: `in` itself (cache-hot)
+                }
+            }
             f32x16 o = {0};
             const float *wl = W2l + (size_t)mo * 16 * 256 + lane * 4;
 #pragma unroll
@@ -322,15 +368,13 @@ rows_block_kernel(RowsBlockArgs a) {
                 if (!rv || c0 >= a.H) continue;
                 f32x4 v = {o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
                 if (a.c2) v += *reinterpret_cast<const f32x4 *>(a.c2 + c0);
-                if (a.m2) {
-                    const f32x4 mk = *reinterpret_cast<const f32x4 *>(a.m2 + row * a.ldm2 + c0);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.0f ? v[r] : 0.0f;
-                }
-                v += *reinterpret_cast<const f32x4 *>(a.in + row * a.ldi + c0);      // the residual: `in` itself (cache-hot)
+                for (int r = 0; r < 4; ++r) v[r] = mk[q][r] > 0.0f ? v[r] : 0.0f;
+                v += rs[q];
                 *reinterpret_cast<f32x4 *>(a.out2 + row * a.ldo2 + c0) = v;
             }
         }
+        RB_T(4);
     }
 }
 
@@ -356,6 +400,9 @@ extern "C" int nf_rows_block(const void *in, int64_t ldi, const void *M1, int64_
     a.M2 = (const float *)M2; a.ldw2 = ldw2; a.trans2 = trans2 ? 1 : 0;
     a.c2 = (const float *)c2; a.m2 = (const float *)mask2; a.ldm2 = ldm2; a.out2 = (float *)out2; a.ldo2 = ldo2;
     a.B = B; a.H = H; a.relu1 = relu1 ? 1 : 0; a.relu2 = relu2 ? 1 : 0;
+#ifdef NF_RB_TRACE
+    a.trace = g_rb_trace;
+#endif
     const size_t lds = (size_t)2 * 4 * 16 * 64 * 4 * sizeof(float);   // two 64 KB panels
     static LdsOptIn opted = {};
     if (opt_in_lds(reinterpret_cast<const void *>(&rows_block_kernel), lds, opted) != NF_OK) return NF_ENOTSUP;
