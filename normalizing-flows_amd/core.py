@@ -41,13 +41,17 @@ def _run_pairs_impl(pairs, z, inverse, ld, acc):
             z = c._run_pair(z, lu, inverse, ld, acc)
         return z
     feats, hidden, nblk, K, tb, mw, mh, md = _pair_signature(pairs[0][0])
+    from .flows.neural_spline import FUSED_D, FUSED_H
+    narrow = z.shape[1] != FUSED_D
+    if narrow:        # narrower layers ride the kernel's 64 columns; the padding sits in the splines' tails (log-det 0)
+        z = pairs[0][0].prqct._pad_rows(z)
     for i in range(0, len(pairs), 64):
         chunk = pairs[i:i + 64]
         blobs = [c.prqct._fused_blob(lu) for c, lu in chunk]
         pars = [c.prqct._fused_parity for c, lu in chunk]
-        z, _ = ops.rqs_fused_chain(z, blobs, pars, hidden, nblk, K, 0 if inverse else 1, logdet=ld, acc=acc, tail_bound=tb,
+        z, _ = ops.rqs_fused_chain(z, blobs, pars, FUSED_H, nblk, K, 0 if inverse else 1, logdet=ld, acc=acc, tail_bound=tb,
                                    min_bin_width=mw, min_bin_height=mh, min_derivative=md, fuse_lu=True)
-    return z
+    return z[:, :feats].contiguous() if narrow else z
 
 
 # ---- RealNVP-style runs: MaskedAffineFlow(MLP, MLP) / ActNorm stacks as one launch (csrc/realnvp_chain.hip) --------------

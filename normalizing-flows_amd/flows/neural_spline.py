@@ -66,6 +66,9 @@ def _tails_kwargs(tails, tail_bound, role, device=None, cache=None):
     return kw
 
 
+FUSED_D, FUSED_H = 64, 128     # the shape of csrc/rqs_fused.hip (narrower layers are zero-padded into it)
+
+
 class PiecewiseRationalQuadraticCDF(Flow):
     """Batch-shared monotone RQ spline per feature (nsf/coupling.py:170-259).  Inputs (B, *shape)."""
 
@@ -478,11 +481,72 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
             n = self.features
             alt0 = torch.equal(ii, torch.arange(0, n, 2)) and torch.equal(ti, torch.arange(1, n, 2))
             alt1 = torch.equal(ii, torch.arange(1, n, 2)) and torch.equal(ti, torch.arange(0, n, 2))
-            ok = (alt0 or alt1) and ops.rqs_fused_supported(len(ii), len(ti), net.hidden_features, len(net.blocks),
-                                                            self.num_bins)
+            # the kernel's shape is (64 features, 128 hidden units, 8 bins); narrower layers run on it zero-padded
+            # (_fused_blob / _pad_rows below): 2 <= features <= 64, hidden <= 128, any number of blocks
+            ok = ((alt0 or alt1) and 2 <= n <= FUSED_D and net.hidden_features <= FUSED_H and self.num_bins == 8
+                  and ops.rqs_fused_supported(FUSED_D // 2, FUSED_D // 2, FUSED_H, len(net.blocks), self.num_bins))
             self._fused_ok = bool(ok)
             self._fused_parity = 0 if alt0 else 1
         return self._fused_ok
+
+    def _fused_padded(self):
+        return self.features != FUSED_D or self.transform_net.hidden_features != FUSED_H
+
+    def _pad_rows(self, x):
+        """(B, D) rows -> (B, 64): the padding columns hold tail_bound + 1, outside every spline's interval, so they pass
+        through the layer (and the padded LU's identity block) unchanged with log-det 0 (utils/splines.py:28, :40-41)."""
+        if x.shape[1] == FUSED_D:
+            return x
+        xp = torch.full((x.shape[0], FUSED_D), float(self.tail_bound) + 1.0, dtype=x.dtype, device=x.device)
+        xp[:, :x.shape[1]] = x
+        return xp
+
+    def _padded_tensors(self, d, lu_t, eps):
+        """The layer's weights embedded in the kernel's shape: zero rows / columns for the missing hidden units and features
+        (a zero hidden unit stays zero through bias-free ReLU blocks; a padding transform feature's parameters never matter,
+        its x sits in the tail), the width / height rows of the final layer rescaled for the kernel's fixed 1 / sqrt(128)
+        (nsf/coupling.py:334-339 divides by sqrt(hidden)), LU factors extended by an identity block."""
+        net = self.transform_net
+        h, nb = net.hidden_features, len(net.blocks)
+        nI, nT = len(self.identity_features), len(self.transform_features)
+        dev = d[0].device
+        M = 3 * self.num_bins - 1
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)   # noqa: E731
+        w0, b0 = z(FUSED_H, FUSED_D // 2), z(FUSED_H)
+        w0[:h, :nI], b0[:h] = d[0], d[1]
+        out = [w0, b0]
+        for i in range(2 * nb):
+            w, b = z(FUSED_H, FUSED_H), z(FUSED_H)
+            w[:h, :h], b[:h] = d[2 + 2 * i], d[3 + 2 * i]
+            out += [w, b]
+        o = 2 + 4 * nb
+        wf, bf = z(FUSED_D // 2 * M, FUSED_H), z(FUSED_D // 2 * M)
+        sc = torch.ones(M, dtype=torch.float32, device=dev)
+        sc[:2 * self.num_bins] = float(np.sqrt(FUSED_H / h))
+        wf[:nT * M, :h] = (d[o].view(nT, M, h) * sc.view(1, M, 1)).reshape(nT * M, h)
+        bf[:nT * M] = (d[o + 1].view(nT, M) * sc.view(1, M)).reshape(-1)
+        out += [wf, bf]
+        for t, width in ((d[o + 2], self.num_bins), (d[o + 3], self.num_bins), (d[o + 4], self.num_bins - 1)):
+            u = z(FUSED_D // 2, width)
+            u[:nI] = t
+            out.append(u)
+        lu_out = None
+        if lu_t is not None:
+            perm, low, up, diag, bias = lu_t
+            D = self.features
+            li, ui = torch.tril_indices(D, D, -1, device=dev), torch.triu_indices(D, D, 1, device=dev)
+            Lm, Um = z(FUSED_D, FUSED_D), z(FUSED_D, FUSED_D)
+            Lm[li[0], li[1]] = low
+            Um[ui[0], ui[1]] = up
+            LI, UI = torch.tril_indices(FUSED_D, FUSED_D, -1, device=dev), torch.triu_indices(FUSED_D, FUSED_D, 1, device=dev)
+            dg = torch.full((FUSED_D,), float(np.log(np.exp(1.0 - eps) - 1.0)), dtype=torch.float32, device=dev)  # softplus + eps = 1
+            dg[:D] = diag
+            bp = z(FUSED_D)
+            bp[:D] = bias
+            pp = torch.arange(FUSED_D, device=dev, dtype=perm.dtype)
+            pp[:D] = perm
+            lu_out = (pp, Lm[LI[0], LI[1]].contiguous(), Um[UI[0], UI[1]].contiguous(), dg, bp)
+        return out, lu_out
 
     def _fused_blob(self, lu=None):
         net, u = self.transform_net, self.unconditional_transform
@@ -501,6 +565,10 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
         if self._fused_cache is None or self._fused_cache[0] != key:
             d = [t.detach() for t in tensors]
             nb = len(net.blocks)
+            if self._fused_padded():
+                d, lu_pad = self._padded_tensors(d, None if lu is None else [t.detach() for t in lu_t], lin.eps if lu is not None else 0.0)
+                if lu is not None:
+                    lu_t = list(lu_pad)
             wb = [d[2 + 2 * i] for i in range(2 * nb)]
             bb = [d[3 + 2 * i] for i in range(2 * nb)]
             o = 2 + 4 * nb
@@ -514,6 +582,12 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
 
     def _fused(self, inputs, direction, ld=None, acc=None, lu=None):
         self._check(inputs)
+        if inputs.shape[1] != FUSED_D:     # narrower layer: the kernel's 64 columns, padding in the tails
+            y, l = self._fused_run(self._pad_rows(inputs), direction, ld, acc, lu)
+            return y[:, :inputs.shape[1]].contiguous(), l
+        return self._fused_run(inputs, direction, ld, acc, lu)
+
+    def _fused_run(self, inputs, direction, ld=None, acc=None, lu=None):
         net = self.transform_net
         from .. import config
         if config.fused_gemm == "bf16x3":
@@ -521,12 +595,12 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
             key = self._fused_cache[0]
             if self._fused_x3_cache is None or self._fused_x3_cache[0] is not key:
                 self._fused_x3_cache = (key, ops.rqs_fused_x3_pack(blob, len(net.blocks), lu is not None))
-            return ops.rqs_fused_x3(inputs, self._fused_x3_cache[1], self._fused_parity, net.hidden_features,
+            return ops.rqs_fused_x3(inputs, self._fused_x3_cache[1], self._fused_parity, FUSED_H,
                                     len(net.blocks), self.num_bins, direction, logdet=ld, acc=acc,
                                     tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
                                     min_bin_height=self.min_bin_height, min_derivative=self.min_derivative,
                                     fuse_lu=lu is not None)
-        return ops.rqs_fused(inputs, self._fused_blob(lu), self._fused_parity, net.hidden_features, len(net.blocks),
+        return ops.rqs_fused(inputs, self._fused_blob(lu), self._fused_parity, FUSED_H, len(net.blocks),
                              self.num_bins, direction, logdet=ld, acc=acc, tail_bound=self.tail_bound,
                              min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
                              min_derivative=self.min_derivative, fuse_lu=lu is not None)

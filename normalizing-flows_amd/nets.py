@@ -261,7 +261,10 @@ class ConvNet2d(nn.Module):
             return None
         if (c1.kernel_size, c2.kernel_size, c3.kernel_size) != ((3, 3), (1, 1), (3, 3)):
             return None
-        if c1.out_channels != 256 or c2.out_channels != 256 or any(c.bias is None for c in (c1, c2, c3)):
+        hid = c1.out_channels
+        if hid > 256 or c2.out_channels != hid or c2.in_channels != hid or c3.in_channels != hid:
+            return None      # the kernels' hidden width is 256: narrower networks run on them zero-padded (below)
+        if any(c.bias is None for c in (c1, c2, c3)):
             return None
         if a1.negative_slope != a2.negative_slope or not 0.0 <= a1.negative_slope <= 1.0:
             return None
@@ -278,7 +281,21 @@ class ConvNet2d(nn.Module):
         cache = self.__dict__.setdefault("_gc_cache", {})
         hit = cache.get(layout)
         if hit is None or hit[0] != key:
-            hit = cache[layout] = (key, ops.glow_convnet_pack(*[p_.detach() for p_ in params], layout=layout))
+            ws = [p_.detach() for p_ in params]
+            if hid != 256:   # zero hidden channels stay zero through the bias-free LeakyReLU: pad up to the kernels' 256
+                w1, b1, w2, b2, w3, b3 = ws
+                W1 = w1.new_zeros(256, w1.shape[1], 3, 3)
+                W1[:hid] = w1
+                B1 = b1.new_zeros(256)
+                B1[:hid] = b1
+                W2 = w2.new_zeros(256, 256, 1, 1)
+                W2[:hid, :hid] = w2
+                B2 = b2.new_zeros(256)
+                B2[:hid] = b2
+                W3 = w3.new_zeros(w3.shape[0], 256, 3, 3)
+                W3[:, :hid] = w3
+                ws = [W1, B1, W2, B2, W3, b3]
+            hit = cache[layout] = (key, ops.glow_convnet_pack(*ws, layout=layout))
         return None if hit[1] is None else (hit[1], layout)
 
     def forward_split(self, x):

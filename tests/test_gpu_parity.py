@@ -717,7 +717,10 @@ def test_model_c1_realnvp_vs_reference(nfa):
     assert _rel(N(lq), g["sample_logq"]) < 1e-4
 
 
-def test_model_c4mini_glow_vs_reference(nfa):
+@pytest.mark.parametrize("force_block_kernels", [False, True])
+def test_model_c4mini_glow_vs_reference(nfa, force_block_kernels):
+    """Mini Glow (hidden 16) against the reference; with the thresholds lowered every GlowBlock runs on the one-launch
+    kernels, whose hidden width is 256: narrower conditioners ride them zero-padded."""
     g = load_golden("model_c4mini_glow")
     L_, K_, hidden, channels = 2, 2, 16, 3
     input_shape = (3, 8, 8)
@@ -736,7 +739,21 @@ def test_model_c4mini_glow_vs_reference(nfa):
     m = nfa.MultiscaleFlow(q0, flows, merges, class_cond=False)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in golden_state(g, "sd0__").items()}, strict=True)
     m = m.to(DEV)
+    cls = nfa.nets.ConvNet2d
+    saved = cls.FUSED_MIN_PIXELS, cls.FUSED_WIDE_MIN_PIXELS
+    if force_block_kernels:
+        cls.FUSED_MIN_PIXELS, cls.FUSED_WIDE_MIN_PIXELS = 0, 0
+    try:
+        _c4mini_checks(nfa, m, g, force_block_kernels)
+    finally:
+        cls.FUSED_MIN_PIXELS, cls.FUSED_WIDE_MIN_PIXELS = saved
+
+
+def _c4mini_checks(nfa, m, g, forced):
     lp = N(m.log_prob(T(g["x"])))
+    if forced:
+        assert all(b._whole_block(torch.empty(6, *shape, device=DEV)) is not None
+                   for fl, shape in zip(m.flows, ((24, 2, 2), (12, 4, 4))) for b in fl[:-1])
     assert _rel(lp, g["log_prob"]) < 1e-4, _rel(lp, g["log_prob"])
     assert _rel(N(m.log_prob(T(g["x"]))), g["log_prob_second"]) < 1e-4
     # sample / log_prob consistency (core_test.py:144-196)
@@ -1499,3 +1516,58 @@ def test_models_run_in_double_precision(nfa, oracle):
     assert a.dtype == torch.float64 and torch.allclose(a, ld + rn.q0.log_prob(z), atol=1e-12)
     xb, _ = rn.forward_and_log_det(z)
     assert_close(N(xb), N(xr), what="fp64 roundtrip", rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("D,hidden,blocks", [(2, 128, 2), (5, 32, 1), (7, 64, 2), (16, 16, 0), (32, 128, 3), (63, 100, 2), (64, 64, 2)])
+def test_fused_kernel_on_narrower_layers_vs_unfused_and_oracle(nfa, oracle, D, hidden, blocks):
+    """Layers narrower than the fused kernel's shape (64 features, 128 hidden units) run on it zero-padded -- padding columns
+    parked in the splines' tails, zero hidden units, LU factors extended by an identity block: same results as the unfused
+    path (library GEMMs + nf_rqs_coupling / nf_lu kernels) and as the CPU oracle, both directions, both mask parities, alone
+    and as a chain of [CoupledRQS, LULinearPermute] pairs."""
+    from normflows_amd.core import run_chain
+    torch.manual_seed(100 * D + hidden)
+    flows = []
+    for i in range(3):
+        c = nfa.flows.CoupledRationalQuadraticSpline(D, blocks, hidden, num_bins=8, init_identity=False, reverse_mask=bool(i % 2))
+        lu = nfa.flows.LULinearPermute(D, identity_init=False)
+        with torch.no_grad():
+            for p_ in list(c.parameters()) + list(lu.parameters()):
+                p_.add_(0.05 * torch.randn_like(p_))
+        flows += [c.to(DEV), lu.to(DEV)]
+    B = 333
+    g = torch.Generator().manual_seed(D)
+    x = 1.5 * torch.randn(B, D, generator=g)
+    x.view(-1)[:4] = torch.tensor([3.0, -3.0, 3.0000002, 0.0])[: min(4, x.numel())]
+    xd = x.to(DEV)
+    assert flows[0].prqct._fused_eligible(xd, None) and flows[0].prqct._fused_padded() == (D != 64 or hidden != 128)
+    st = {}
+    for i, f in enumerate(flows):
+        st.update({"flows.%d.%s" % (i, k): v.detach().cpu().numpy() for k, v in f.state_dict().items()})
+    for inverse in (True, False):
+        for f in flows[0::2]:
+            f.prqct.use_fused = True
+        ld_f = torch.zeros(B, device=DEV)
+        z_f = run_chain(flows, xd, inverse, ld_f, +1)                 # one persistent launch on padded rows
+        z1, l1 = (flows[0].inverse if inverse else flows[0].forward)(xd)   # a single layer through the fused kernel
+        for f in flows[0::2]:
+            f.prqct.use_fused = False
+        for f in flows[1::2]:
+            f.use_dense = False
+        ld_u = torch.zeros(B, device=DEV)
+        z_u = run_chain(flows, xd, inverse, ld_u, +1)                 # layer by layer, unfused kernels
+        z1u, l1u = (flows[0].inverse if inverse else flows[0].forward)(xd)
+        for f in flows[1::2]:
+            f.use_dense = True
+        assert z_f.shape == (B, D)
+        assert_close(N(z1), N(z1u), what="single layer z", rtol=2e-4, atol=2e-4)
+        assert_close(N(l1), N(l1u), what="single layer ld", rtol=2e-4, atol=2e-4)
+        assert_close(N(z_f), N(z_u), what="chain z", rtol=1e-3, atol=1e-3)
+        assert_close(N(ld_f), N(ld_u), what="chain ld", rtol=1e-3, atol=1e-3)
+        logq = np.zeros(B, np.float64)
+        zo = x.numpy().astype(np.float64)
+        st64 = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in st.items()}
+        ora64 = oracle.OracleNSF(st64, num_layers=6, K=8, tail_bound=3.0)
+        for i in (range(5, -1, -1) if inverse else range(6)):
+            zo = (ora64.coupling if ora64._is_coupling(i) else ora64.lu)(i, zo, 0 if inverse else 1, logq, +1)
+        assert_close(N(z_f).astype(np.float64), zo, what="chain vs oracle z", rtol=1e-3, atol=1e-3)
+        assert_close(N(ld_f).astype(np.float64), logq, what="chain vs oracle ld", rtol=1e-3, atol=1e-3)
