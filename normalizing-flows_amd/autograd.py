@@ -122,14 +122,28 @@ class LULinearPermuteFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, perm, lower_entries, upper_entries, udiag_raw, bias, eps, direction):
+        D = x.shape[1]
+        if direction == 0 and x.is_cuda and x.dtype == torch.float32 and D <= 64:
+            # density direction on the fp32-MFMA row mat-vec kernel: u = U x[perm] (kept for the backward), y = L u + b with
+            # the constant log-det in the same launch -- two 13 us launches against 64 us for the LDS-tile kernel
+            with torch.no_grad():
+                Lm, Um, diag, _, _ = _assemble_lu(lower_entries, upper_entries, udiag_raw, eps)
+                Up = torch.zeros_like(Um)
+                Up[:, perm] = Um
+                lad = torch.log(diag).sum().reshape(1)
+                u = ops.rows_matvec(x, Up)
+                y, ld = ops.rows_matvec_affine(u, Lm, bias.detach(), lad, +1.0)
+            ctx.save_for_backward(x, y, perm, lower_entries, upper_entries, udiag_raw, bias, u)
+            ctx.eps, ctx.direction = eps, direction
+            return y, ld
         y, ld = ops.lu_linear_permute(x, perm, lower_entries, upper_entries, udiag_raw, bias, direction, eps=eps)
-        ctx.save_for_backward(x, y, perm, lower_entries, upper_entries, udiag_raw, bias)
+        ctx.save_for_backward(x, y, perm, lower_entries, upper_entries, udiag_raw, bias, None)
         ctx.eps, ctx.direction = eps, direction
         return y, ld
 
     @staticmethod
     def backward(ctx, gy, gld):
-        x, y, perm, lower_entries, upper_entries, udiag_raw, bias = ctx.saved_tensors
+        x, y, perm, lower_entries, upper_entries, udiag_raw, bias, u_saved = ctx.saved_tensors
         Lm, Um, diag, li, ui = _assemble_lu(lower_entries, upper_entries, udiag_raw, ctx.eps)
         sig = torch.sigmoid(udiag_raw)
         sig = torch.where(udiag_raw > 20, torch.ones_like(sig), sig)  # softplus threshold
@@ -150,7 +164,7 @@ class LULinearPermuteFn(torch.autograd.Function):
         Up[:, perm] = Um
         if ctx.direction == 0:
             # y = L (U x_p) + b ; logdet = sum log diag
-            u = rows(x, Up)                 # U x[perm]
+            u = u_saved if u_saved is not None else rows(x, Up)     # U x[perm]
             gu = rows(gy, Lm.t())           # d/du = L^T gy
             gx = rows(gu, Up.t())           # d/dx = P (U^T gu)
             gL, g_bias = _batch_outer(gy, u, want_colsum=True)
