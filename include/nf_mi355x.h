@@ -181,6 +181,27 @@ int nf_rqs_fused_chain(const void *x, void *y, void *logdet, const void *const *
                        double tail_bound, double min_bin_width, double min_bin_height, double min_derivative,
                        int direction, int acc, nf_stream_t stream);
 
+/* Training forward of the layer's last stage (core.py:87-102 `forward_kld` over nsf/coupling.py:83-98): final Linear of the
+ * conditioner (nets/resnet.py:104) + the density-direction coupling transform in ONE launch of the fused kernel, the hidden
+ * activations h2 (B, 128) -- the output of the residual blocks, computed by the autograd-tracked trunk -- read from HBM.
+ * x, y (B, 64); logdet (B) per `acc`; cond_out (B, 32, 24): the conditioner output kept for the backward, 23 parameters + 1
+ * pad per transform feature, raw scale (nf_rqs_coupling_bwd_p24 reads this layout).  wpack: nf_rqs_fused_pack, or
+ * nf_rqs_fused_pack_final (header + final-layer stages + knot tables only: what this entry point reads).
+ * Shape: D = 64, hidden = 128, K = 8, linear tails (NF_ENOTSUP otherwise). */
+int nf_rqs_fused_pack_final(void *wpack, const void *w_final, const void *b_final, const void *uw, const void *uh,
+                            const void *ud, int hidden, int num_blocks, int K, double tail_bound, double min_bin_width,
+                            double min_bin_height, double min_derivative, nf_stream_t stream);
+int nf_rqs_fused_train_fwd(const void *x, const void *h2, void *y, void *logdet, void *cond_out, const void *wpack,
+                           int mask_parity, int64_t B, int D, int hidden, int num_blocks, int K, double tail_bound,
+                           double min_bin_width, double min_bin_height, double min_derivative, int acc, nf_stream_t stream);
+/* Backward of the density-direction coupling transform (nf_rqs_coupling_bwd, mode NF_RQS_DENSITY) on cond / grad_cond rows
+ * of 24 floats per transform feature (the layout above; 16-byte aligned).  float32, 8 bins, linear tails. */
+int nf_rqs_coupling_bwd_p24(const void *x, const void *grad_y, const void *grad_logdet, const void *cond24, const void *uw,
+                            const void *uh, const void *ud, const int64_t *identity_idx, int nI, const int64_t *transform_idx,
+                            int nT, int64_t B, int D, double tail_bound, double min_bin_width, double min_bin_height,
+                            double min_derivative, double wh_div, void *grad_x, void *grad_cond24, void *grad_uw,
+                            void *grad_uh, void *grad_ud, nf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * The same fused layer with the GEMMs on the bf16 matrix pipe by error-compensated splitting
  * (fp32 operand = hi + mid + lo bf16, six products accumulated in fp32; csrc/rqs_fused_x3.hip).

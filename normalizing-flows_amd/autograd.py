@@ -97,11 +97,64 @@ class CouplingDensityFn(torch.autograd.Function):
         return gx, gcond, guw, guh, gud, None, None, None, None
 
 
+class FinalSplineDensityFn(torch.autograd.Function):
+    """The conditioner's final Linear (nets/resnet.py:104) + the whole density-direction coupling transform
+    (nsf/coupling.py:83-98) as ONE forward launch of the fused kernel's training variant (nf_rqs_fused_train_fwd): the
+    736-wide conditioner output never makes the library-GEMM round trip through HBM -- it is written once, in the lanes' own
+    24-float rows, for the backward (nf_rqs_coupling_bwd_p24).  The final layer's input gradient is a library GEMM on the
+    padded rows, its weight / bias gradients the split-K kernel; pad rows are dropped on the way out.
+    Shape of the benchmark layer only: D = 64, hidden = 128, 8 bins, linear tails."""
+
+    @staticmethod
+    def forward(ctx, x, h2, wf, bf, uw, uh, ud, iidx, tidx, blob, parity, nblocks, kw):
+        ops.rqs_fused_pack_final(blob, wf.detach(), bf.detach(), uw.detach(), uh.detach(), ud.detach(), nblocks,
+                                 tail_bound=kw["tail_bound"], min_bin_width=kw["min_bin_width"],
+                                 min_bin_height=kw["min_bin_height"], min_derivative=kw["min_derivative"])
+        y, ld, cond24 = ops.rqs_fused_train_fwd(x, h2, blob, parity, nblocks, tail_bound=kw["tail_bound"],
+                                                min_bin_width=kw["min_bin_width"], min_bin_height=kw["min_bin_height"],
+                                                min_derivative=kw["min_derivative"])
+        ctx.save_for_backward(x, h2, wf, cond24, uw, uh, ud, iidx, tidx)
+        ctx.kw = kw
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, gy, gld):
+        x, h2, wf, cond24, uw, uh, ud, iidx, tidx = ctx.saved_tensors
+        kw = ctx.kw
+        if gy is None:
+            gy = torch.zeros_like(x)
+        if gld is None:
+            gld = torch.zeros(x.shape[0], dtype=x.dtype, device=x.device)
+        gx, gcond24, guw, guh, gud = ops.rqs_coupling_bwd_p24(x, gy, gld, cond24, uw, uh, ud, iidx, tidx,
+                                                              tail_bound=kw["tail_bound"], min_bin_width=kw["min_bin_width"],
+                                                              min_bin_height=kw["min_bin_height"],
+                                                              min_derivative=kw["min_derivative"], wh_div=kw["wh_div"])
+        B, nT, H = x.shape[0], cond24.shape[1], wf.shape[1]
+        g2 = gcond24.view(B, nT * 24)
+        wpad = torch.zeros(nT, 24, H, dtype=wf.dtype, device=wf.device)
+        wpad[:, :23] = wf.detach().view(nT, 23, H)           # the pad row of every feature stays zero
+        gh2 = g2 @ wpad.view(nT * 24, H)                     # input gradient of the final layer (library GEMM, padded rows)
+        gwp, gbp = ops.linear_wgrad(g2, h2, want_bias=True)  # (nT * 24, H), (nT * 24)
+        gwf = gwp.view(nT, 24, H)[:, :23].reshape(nT * 23, H)
+        gbf = gbp.view(nT, 24)[:, :23].reshape(nT * 23)
+        return gx, gh2, gwf, gbf, guw, guh, gud, None, None, None, None, None, None
+
+
+_tri_cache = {}
+
+
+def _tri_indices(D, dev):
+    """(strictly-lower, strictly-upper) index pairs of a D x D matrix on `dev`, built once (two launches each otherwise)."""
+    key = (D, str(dev))
+    if key not in _tri_cache:
+        _tri_cache[key] = (torch.tril_indices(D, D, -1, device=dev), torch.triu_indices(D, D, 1, device=dev))
+    return _tri_cache[key]
+
+
 def _assemble_lu(lower_entries, upper_entries, udiag_raw, eps):
     D = udiag_raw.numel()
     dev, dt = udiag_raw.device, udiag_raw.dtype
-    li = torch.tril_indices(D, D, -1, device=dev)
-    ui = torch.triu_indices(D, D, 1, device=dev)
+    li, ui = _tri_indices(D, dev)
     Lm = torch.eye(D, device=dev, dtype=dt)
     Lm[li[0], li[1]] = lower_entries
     diag = torch.nn.functional.softplus(udiag_raw) + eps
@@ -135,6 +188,7 @@ class LULinearPermuteFn(torch.autograd.Function):
                 y, ld = ops.rows_matvec_affine(u, Lm, bias.detach(), lad, +1.0)
             ctx.save_for_backward(x, y, perm, lower_entries, upper_entries, udiag_raw, bias, u)
             ctx.eps, ctx.direction = eps, direction
+            ctx.factors = (Lm, Um, diag, Up)      # assembled once per step: the backward reuses them
             return y, ld
         y, ld = ops.lu_linear_permute(x, perm, lower_entries, upper_entries, udiag_raw, bias, direction, eps=eps)
         ctx.save_for_backward(x, y, perm, lower_entries, upper_entries, udiag_raw, bias, None)
@@ -144,7 +198,14 @@ class LULinearPermuteFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, gld):
         x, y, perm, lower_entries, upper_entries, udiag_raw, bias, u_saved = ctx.saved_tensors
-        Lm, Um, diag, li, ui = _assemble_lu(lower_entries, upper_entries, udiag_raw, ctx.eps)
+        fac = getattr(ctx, "factors", None)
+        D_ = x.shape[1]
+        li, ui = _tri_indices(D_, x.device)
+        if fac is not None:
+            Lm, Um, diag, Up_saved = fac
+        else:
+            Lm, Um, diag, li, ui = _assemble_lu(lower_entries, upper_entries, udiag_raw, ctx.eps)
+            Up_saved = None
         sig = torch.sigmoid(udiag_raw)
         sig = torch.where(udiag_raw > 20, torch.ones_like(sig), sig)  # softplus threshold
         if gy is None:
@@ -160,8 +221,11 @@ class LULinearPermuteFn(torch.autograd.Function):
         def rows(v, W):   # r_b = W v_b for every row b
             return ops.rows_matvec(v, W) if hip_rows else v @ W.t()
 
-        Up = torch.zeros_like(Um)
-        Up[:, perm] = Um
+        if Up_saved is not None:
+            Up = Up_saved
+        else:
+            Up = torch.zeros_like(Um)
+            Up[:, perm] = Um
         if ctx.direction == 0:
             # y = L (U x_p) + b ; logdet = sum log diag
             u = u_saved if u_saved is not None else rows(x, Up)     # U x[perm]

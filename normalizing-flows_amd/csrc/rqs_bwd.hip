@@ -442,6 +442,9 @@ __device__ __forceinline__ float rqs_regs_bwd(const RqsParams<float> &p, float x
 #ifndef NF_BWD_WAVE_WAVES
 #define NF_BWD_WAVE_WAVES 8  // waves per workgroup: one workgroup per CU = fewest rounds of end-of-kernel global atomics
 #endif
+// CP: floats per (sample, transform feature) row of cond / grad_cond: 23 = the reference's layout (B, nT * 23); 24 = the
+// padded rows the training variant of the fused kernel writes (rqs_fused.hip, 16-byte aligned: read and written as f32x4)
+template <int CP>
 __global__ void __launch_bounds__(64 * NF_BWD_WAVE_WAVES, NF_BWD_WAVE_OCC)
 rqs_coupling_bwd_wave_kernel(const float *__restrict__ x, const float *__restrict__ gy, const float *__restrict__ gld,
                              const float *__restrict__ cond, const float *__restrict__ uw, const float *__restrict__ uh,
@@ -453,13 +456,13 @@ rqs_coupling_bwd_wave_kernel(const float *__restrict__ x, const float *__restric
     constexpr int K = F_K, M = F_M, nd = F_K - 1;
     const int PP = (2 * K) | 1;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nwv = blockDim.x >> 6;
-    const int per_wave = SPW * nT * M + 3 * SPW * D;
+    const int per_wave = SPW * nT * CP + 3 * SPW * D;
     float *s_acc = reinterpret_cast<float *>(smem_raw);           // nI * M
     float *s_prob = s_acc + (size_t)nI * M;                      // nI * PP
     float *s_ud = s_prob + (size_t)nI * PP;                      // nI * nd
     float *s_prm = s_ud + (size_t)nI * nd;                       // nI * 24: shared parameters in rqs_regs order (w, h x log2 e)
     float *w_cond = s_prm + (size_t)nI * 24 + (size_t)wid * per_wave;
-    float *w_x = w_cond + (size_t)SPW * nT * M, *w_gy = w_x + (size_t)SPW * D, *w_gx = w_gy + (size_t)SPW * D;
+    float *w_x = w_cond + (size_t)SPW * nT * CP, *w_gy = w_x + (size_t)SPW * D, *w_gx = w_gy + (size_t)SPW * D;
     int *s_iidx = reinterpret_cast<int *>(s_prm + (size_t)nI * 24 + (size_t)nwv * per_wave);
     int *s_tidx = s_iidx + nI;
     const bool do_t = mode != NF_RQS_SAMPLE_IDENTITY, do_i = mode != NF_RQS_SAMPLE_TRANSFORM;
@@ -502,8 +505,8 @@ rqs_coupling_bwd_wave_kernel(const float *__restrict__ x, const float *__restric
             w_gx[i] = 0.0f;
         }
         if (do_t) {
-            const float *src = cond + b0 * (int64_t)nT * M;
-            for (int i = lane; i < ns * nT * M; i += 64) w_cond[i] = src[i];
+            const float *src = cond + b0 * (int64_t)nT * CP;
+            for (int i = lane; i < ns * nT * CP; i += 64) w_cond[i] = src[i];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -511,18 +514,34 @@ rqs_coupling_bwd_wave_kernel(const float *__restrict__ x, const float *__restric
         if (do_t) {
             for (int e = lane; e < ns * nT; e += 64) {
                 const int s_ = e / nT, j = e - s_ * nT, col = s_tidx[j];
-                float *row = w_cond + (size_t)e * M;
+                float *row = w_cond + (size_t)e * CP;
                 float prm[24], g[24];
+                if constexpr (CP == 24) {
 #pragma unroll
-                for (int k = 0; k < 2 * K; ++k) prm[k] = row[k] * sc;
+                    for (int q = 0; q < 6; ++q) {
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(row + 4 * q);
 #pragma unroll
-                for (int k = 2 * K; k < M; ++k) prm[k] = row[k];
+                        for (int r = 0; r < 4; ++r) prm[4 * q + r] = q < 4 ? v[r] * sc : v[r];
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 2 * K; ++k) prm[k] = row[k] * sc;
+#pragma unroll
+                    for (int k = 2 * K; k < M; ++k) prm[k] = row[k];
+                }
                 prm[M] = 0.0f;
                 const float xv = w_x[s_ * D + col], gyv = w_gy[s_ * D + col], gl = gld[b0 + s_];
                 const float gxv = inverse ? rqs_regs_bwd<true>(p, xv, prm, gyv, gl, g, inv_div)
                                           : rqs_regs_bwd<false>(p, xv, prm, gyv, gl, g, inv_div);
+                if constexpr (CP == 24) {
+                    g[M] = 0.0f;
 #pragma unroll
-                for (int k = 0; k < M; ++k) row[k] = g[k];
+                    for (int q = 0; q < 6; ++q)
+                        *reinterpret_cast<f32x4 *>(row + 4 * q) = f32x4{g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]};
+                } else {
+#pragma unroll
+                    for (int k = 0; k < M; ++k) row[k] = g[k];
+                }
                 w_gx[s_ * D + col] = gxv;
             }
         }
@@ -566,8 +585,8 @@ rqs_coupling_bwd_wave_kernel(const float *__restrict__ x, const float *__restric
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (do_t) {
-            float *dst = gcond + b0 * (int64_t)nT * M;
-            for (int i = lane; i < ns * nT * M; i += 64) dst[i] = w_cond[i];
+            float *dst = gcond + b0 * (int64_t)nT * CP;
+            for (int i = lane; i < ns * nT * CP; i += 64) dst[i] = w_cond[i];
         }
         if (mode == NF_RQS_DENSITY) {
             for (int i = lane; i < ns * D; i += 64) gx[b0 * D + i] = w_gx[i];
@@ -631,6 +650,34 @@ static int launch_bwd(const void *x, const void *gy, const void *gld, const void
     return NF_OK;
 }
 
+// Launch of the wave-private kernel (float32, 8 bins, linear tails); NF_ENOTSUP when its LDS does not fit.
+template <int CP>
+static int launch_bwd_wave(const void *x, const void *grad_y, const void *grad_logdet, const void *cond, const void *uw,
+                           const void *uh, const void *ud, const int64_t *identity_idx, int nI, const int64_t *transform_idx,
+                           int nT, int64_t B, int D, const nf::RqsParams<float> &p, int mode, void *grad_x, void *grad_cond,
+                           void *grad_uw, void *grad_uh, void *grad_ud, hipStream_t st) {
+    using namespace nf;
+    const int nmax = nT > nI ? nT : nI;
+    int SPW = nmax > 0 ? 64 / nmax : 1;
+    if (SPW < 1) SPW = 1;
+    const size_t per_wave = (size_t)SPW * nT * CP + 3 * (size_t)SPW * D;
+    const size_t ldsw = ((size_t)nI * F_M + (size_t)nI * ((2 * F_K) | 1) + (size_t)nI * (F_K - 1) + (size_t)nI * 24 +
+                         NF_BWD_WAVE_WAVES * per_wave) * sizeof(float) + (size_t)(nI + nT) * sizeof(int) + 16;
+    if (ldsw > 128 * 1024) return NF_ENOTSUP;
+    // 8 waves per CU are resident (register-bound): one 8-wave workgroup per CU; more workgroups only add rounds
+    // of global atomics on the shared parameters' 23 nI addresses at the end of each
+    const int64_t nwaves = (B + SPW - 1) / SPW, gq = (nwaves + NF_BWD_WAVE_WAVES - 1) / NF_BWD_WAVE_WAVES;
+    const int grid = (int)(gq < 2048 / NF_BWD_WAVE_WAVES ? gq : 2048 / NF_BWD_WAVE_WAVES);
+    static LdsOptIn opted = {};   // one per CP instantiation
+    if (opt_in_lds(reinterpret_cast<const void *>(&rqs_coupling_bwd_wave_kernel<CP>), ldsw, opted) != NF_OK) return NF_ENOTSUP;
+    hipLaunchKernelGGL(rqs_coupling_bwd_wave_kernel<CP>, dim3(grid), dim3(64 * NF_BWD_WAVE_WAVES), ldsw, st, (const float *)x,
+                       (const float *)grad_y, (const float *)grad_logdet, (const float *)cond, (const float *)uw,
+                       (const float *)uh, (const float *)ud, identity_idx, nI, transform_idx, nT, B, D, p, mode,
+                       (float *)grad_x, (float *)grad_cond, (float *)grad_uw, (float *)grad_uh, (float *)grad_ud, SPW);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
 extern "C" int nf_rqs_coupling_bwd_ft(const void *x, const void *grad_y, const void *grad_logdet, const void *cond,
                                       const void *uw, const void *uh, const void *ud, const int64_t *identity_idx, int nI,
                                       const int64_t *transform_idx, int nT, int64_t B, int D, int K, int tails,
@@ -657,28 +704,9 @@ extern "C" int nf_rqs_coupling_bwd_ft(const void *x, const void *grad_y, const v
                                         wh_div);
         if (K == F_K && tails == NF_TAILS_LINEAR && !tails_t && !bound_t && !tails_i && !bound_i) {
             // default parametrisation: wave-private tiles + register-resident element routine
-            const int nmax = nT > nI ? nT : nI;
-            int SPW = nmax > 0 ? 64 / nmax : 1;
-            if (SPW < 1) SPW = 1;
-            const size_t per_wave = (size_t)SPW * nT * F_M + 3 * (size_t)SPW * D;
-            const size_t ldsw = ((size_t)nI * F_M + (size_t)nI * ((2 * F_K) | 1) + (size_t)nI * (F_K - 1) + (size_t)nI * 24 +
-                                 NF_BWD_WAVE_WAVES * per_wave) * sizeof(float) + (size_t)(nI + nT) * sizeof(int) + 16;
-            if (ldsw <= 128 * 1024) {
-                // 8 waves per CU are resident (register-bound): one 8-wave workgroup per CU; more workgroups only add rounds
-                // of global atomics on the shared parameters' 23 nI addresses at the end of each
-                const int64_t nwaves = (B + SPW - 1) / SPW, gq = (nwaves + NF_BWD_WAVE_WAVES - 1) / NF_BWD_WAVE_WAVES;
-                const int grid = (int)(gq < 2048 / NF_BWD_WAVE_WAVES ? gq : 2048 / NF_BWD_WAVE_WAVES);
-                static LdsOptIn opted = {};
-                if (opt_in_lds(reinterpret_cast<const void *>(&rqs_coupling_bwd_wave_kernel), ldsw, opted) != NF_OK)
-                    return NF_ENOTSUP;
-                hipLaunchKernelGGL(rqs_coupling_bwd_wave_kernel, dim3(grid), dim3(64 * NF_BWD_WAVE_WAVES), ldsw, st, (const float *)x,
-                                   (const float *)grad_y, (const float *)grad_logdet, (const float *)cond, (const float *)uw,
-                                   (const float *)uh, (const float *)ud, identity_idx, nI, transform_idx, nT, B, D, p, mode,
-                                   (float *)grad_x, (float *)grad_cond, (float *)grad_uw, (float *)grad_uh, (float *)grad_ud,
-                                   SPW);
-                NF_CHECK_LAUNCH();
-                return NF_OK;
-            }
+            const int rc = launch_bwd_wave<F_M>(x, grad_y, grad_logdet, cond, uw, uh, ud, identity_idx, nI, transform_idx, nT, B,
+                                                D, p, mode, grad_x, grad_cond, grad_uw, grad_uh, grad_ud, st);
+            if (rc != NF_ENOTSUP) return rc;
         }
         return launch_bwd<float>(x, grad_y, grad_logdet, cond, uw, uh, ud, identity_idx, nI, transform_idx, nT, B, D, p,
                                  mode, grad_x, grad_cond, grad_uw, grad_uh, grad_ud, st, tails_t, bound_t, tails_i, bound_i);
@@ -703,4 +731,25 @@ extern "C" int nf_rqs_coupling_bwd(const void *x, const void *grad_y, const void
     return nf_rqs_coupling_bwd_ft(x, grad_y, grad_logdet, cond, uw, uh, ud, identity_idx, nI, transform_idx, nT, B, D, K,
                                   tails, tail_bound, min_bin_width, min_bin_height, min_derivative, wh_div, mode, grad_x,
                                   grad_cond, grad_uw, grad_uh, grad_ud, dtype, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+// The density-direction backward on cond / grad_cond rows of 24 floats per transform feature (23 parameters + 1 pad): the
+// layout the training variant of the fused kernel writes (nf_rqs_fused_train_fwd).  float32, 8 bins, linear tails.
+extern "C" int nf_rqs_coupling_bwd_p24(const void *x, const void *grad_y, const void *grad_logdet, const void *cond24,
+                                       const void *uw, const void *uh, const void *ud, const int64_t *identity_idx, int nI,
+                                       const int64_t *transform_idx, int nT, int64_t B, int D, double tail_bound,
+                                       double min_bin_width, double min_bin_height, double min_derivative, double wh_div,
+                                       void *grad_x, void *grad_cond24, void *grad_uw, void *grad_uh, void *grad_ud,
+                                       nf_stream_t stream) {
+    using namespace nf;
+    if (B < 0 || D < 1 || nI < 0 || nT < 1 || nI + nT != D) return NF_EINVAL;
+    if (min_bin_width * F_K > 1.0 || min_bin_height * F_K > 1.0) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!x || !grad_y || !grad_logdet || !grad_x || !cond24 || !grad_cond24 || !transform_idx || (nI && !identity_idx)) return NF_EFAULT;
+    if (uw && (!uh || !ud || !grad_uw || !grad_uh || !grad_ud)) return NF_EFAULT;
+    if (((uintptr_t)cond24 | (uintptr_t)grad_cond24) & 15) return NF_EINVAL;
+    auto p = make_rqs_params<float>(F_K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height, min_derivative,
+                                    wh_div);
+    return launch_bwd_wave<24>(x, grad_y, grad_logdet, cond24, uw, uh, ud, identity_idx, nI, transform_idx, nT, B, D, p,
+                               NF_RQS_DENSITY, grad_x, grad_cond24, grad_uw, grad_uh, grad_ud, (hipStream_t)stream);
 }

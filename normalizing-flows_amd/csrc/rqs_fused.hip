@@ -287,10 +287,16 @@ struct FlowArgs {
 
 // DIR: 0 = density (wrapper.inverse), 1 = sample (wrapper.forward).  LU: fuse each layer's LULinearPermute
 // (density: LULinearPermute.inverse BEFORE the coupling; sample: LULinearPermute.forward AFTER it).
-template <int DIR, bool LU>
+// TRAIN (density direction, no LU, one layer): the training forward of the layer's LAST stage -- the hidden activations h2
+// (B x 128, the output of the residual blocks, computed by the autograd-tracked trunk) come from HBM instead of the
+// initial layer / blocks, the final layer + spline run as in inference, and the conditioner output is written for the
+// backward in the lane's own order: cond_out[row][transform feature][24] (23 parameters + 1 pad, raw scale), six 16-byte
+// stores per feature.  Replaces a library GEMM that materialises 193 MB plus the stand-alone spline kernel that reads them back.
+template <int DIR, bool LU, bool TRAIN = false>
 __global__ void __launch_bounds__(F_THREADS, 2)
 rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ logdet, FlowArgs fa,
-                 int64_t B, int nblk, RqsParams<float> p, int acc) {
+                 int64_t B, int nblk, RqsParams<float> p, int acc, const float *__restrict__ h_in = nullptr,
+                 float *__restrict__ cond_out = nullptr, float unscale = 1.0f) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     FusedLayout lay;
     lay.nblk = nblk;
@@ -303,10 +309,11 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     const int64_t row = (int64_t)blockIdx.x * F_ROWS + wid * 32 + (lane & 31);
     const bool valid = row < B;
     const int nbase = lay.nstages(false);
-    const int nstages = lay.nstages(LU);
+    const int nstages = TRAIN ? 24 : lay.nstages(LU);
     const int total_stages = nstages * fa.nlayers;
     // logical -> physical stage: the LU stage comes first in the density direction, last in the sample direction
     auto phys = [&](int s) -> int {
+        if (TRAIN) return 1 + 8 * nblk + s;      // the 24 final-layer stages only
         if (!LU) return s;
         if (DIR == 0) return s == 0 ? lay.lu_stage(0) : s - 1;
         return s < nbase ? s : lay.lu_stage(1);
@@ -427,6 +434,17 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
 
     // ---- initial layer: H = W0 xi + b0 (K = 32: 4 row-blocks x 4 k-groups in ONE stage) ----
     f32x16 H0, H1, H2, H3;
+    if constexpr (TRAIN) {
+        // h2 from HBM in C-register order: register 4 q + r of block m = unit 32 m + 8 q + 4 hh + r of the lane's row
+        const float *hr = h_in + (valid ? row : 0) * F_H + 4 * hh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(hr + 8 * q), a1 = *reinterpret_cast<const f32x4 *>(hr + 32 + 8 * q),
+                        a2 = *reinterpret_cast<const f32x4 *>(hr + 64 + 8 * q), a3 = *reinterpret_cast<const f32x4 *>(hr + 96 + 8 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { H0[4 * q + r] = a0[r]; H1[4 * q + r] = a1[r]; H2[4 * q + r] = a2[r]; H3[4 * q + r] = a3[r]; }
+        }
+    } else {
     {
         const float *bsrc = small + lay.off_bias_init() + hh * 16;
         H0 = load_bias16(bsrc);
@@ -487,6 +505,7 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
         mm128<false>(acquire(), lane, H3, T0, T1, T2, T3);
 #endif
     }
+    }  // !TRAIN
 
     // ---- final layer in 8 groups of 3 row-blocks; each group yields the parameters of 2 spline elements ----
     // Software pipeline: the spline evaluations of group g-1 (pure VALU work on registers) are placed in the same
@@ -577,6 +596,19 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
         mm128<false>(acquire(), lane, A1, H0, H1, H2, H3);
         mm128<false>(acquire(), lane, A2, H0, H1, H2, H3);
         extract(A0, A1, A2);
+        if constexpr (TRAIN) {
+            if (valid) {   // the two features' parameter sets, raw scale, for the backward kernel (pitch 24 floats per feature)
+                float *dst = cond_out + row * (F_NI * 24) + (8 * (g >> 1) + 4 * hh + 2 * (g & 1)) * 24;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const float u_ = q < 4 ? unscale : 1.0f;
+                    *reinterpret_cast<f32x4 *>(dst + 4 * q) =
+                        f32x4{prm0[4 * q] * u_, prm0[4 * q + 1] * u_, prm0[4 * q + 2] * u_, prm0[4 * q + 3] * u_};
+                    *reinterpret_cast<f32x4 *>(dst + 24 + 4 * q) =
+                        f32x4{prm1[4 * q] * u_, prm1[4 * q + 1] * u_, prm1[4 * q + 2] * u_, prm1[4 * q + 3] * u_};
+                }
+            }
+        }
         element(g, 0, prm0);
         element(g, 1, prm1);
         if (DIR == 0) uncond_pair(g);
@@ -665,6 +697,31 @@ extern "C" int nf_rqs_fused_pack(void *wpack, const void *w_init, const void *b_
     return NF_OK;
 }
 
+// Only what the training forward (nf_rqs_fused_train_fwd) reads: header, final-layer stages + bias, knot tables.
+extern "C" int nf_rqs_fused_pack_final(void *wpack, const void *w_final, const void *b_final, const void *uw, const void *uh,
+                                       const void *ud, int hidden, int num_blocks, int K, double tail_bound,
+                                       double min_bin_width, double min_bin_height, double min_derivative, nf_stream_t stream) {
+    if (hidden != F_H || K != F_K || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
+    if (!wpack || !w_final || !b_final || !uw || !uh || !ud) return NF_EFAULT;
+    if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    FusedLayout lay;
+    lay.nblk = num_blocks;
+    float *blob = (float *)wpack;
+    float *small = blob + F_HDR;
+    float *stages = blob + lay.off_stages();
+    hipLaunchKernelGGL(pack_header_kernel, dim3(1), dim3(64), 0, st, blob, num_blocks);
+    hipLaunchKernelGGL(pack_final_kernel, dim3(384), dim3(256), 0, st, (const float *)w_final, (const float *)b_final,
+                       stages + (size_t)(1 + 8 * num_blocks) * F_STAGE, small + lay.off_bias_final(),
+                       (float)(1.4426950408889634 / sqrt((double)hidden)));
+    auto p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
+                                    min_derivative, 1.0);
+    hipLaunchKernelGGL(pack_tables_kernel, dim3(1), dim3(64), 0, st, (const float *)uw, (const float *)uh,
+                       (const float *)ud, small + lay.off_tables(), p);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
 extern "C" int nf_rqs_fused_pack_lu(void *wpack, int num_blocks, const int64_t *perm, const void *lower_entries,
                                     const void *upper_entries, const void *unconstrained_upper_diag, const void *bias,
                                     int D, double eps, nf_stream_t stream) {
@@ -731,6 +788,35 @@ extern "C" int nf_rqs_fused_chain(const void *x, void *y, void *logdet, const vo
                        : launch_fused<0, false>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st);
     return fuse_lu ? launch_fused<1, true>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st)
                    : launch_fused<1, false>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st);
+}
+
+extern "C" int nf_rqs_fused_train_fwd(const void *x, const void *h2, void *y, void *logdet, void *cond_out, const void *wpack,
+                                      int mask_parity, int64_t B, int D, int hidden, int num_blocks, int K, double tail_bound,
+                                      double min_bin_width, double min_bin_height, double min_derivative, int acc,
+                                      nf_stream_t stream) {
+    if (D != F_D || hidden != F_H || K != F_K || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
+    if (B < 0 || (mask_parity != 0 && mask_parity != 1) || acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!x || !h2 || !y || !logdet || !cond_out || !wpack) return NF_EFAULT;
+    FlowArgs fa;
+    fa.parity = mask_parity ? 1ull : 0ull;
+    fa.nlayers = 1;
+    for (int l = 0; l < F_MAX_LAYERS; ++l) fa.blob[l] = nullptr;
+    fa.blob[0] = (const float *)wpack;
+    FusedLayout lay;
+    lay.nblk = num_blocks;
+    auto p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
+                                    min_derivative, sqrt((double)hidden));
+    const size_t lds = (size_t)(2 * F_STAGE + F_NW * 32 * 64 + 2 * lay.small_padded()) * sizeof(float);
+    if (lds > 160 * 1024) return NF_ENOTSUP;
+    static LdsOptIn opted = {};
+    if (opt_in_lds(reinterpret_cast<const void *>(&rqs_fused_kernel<0, false, true>), lds, opted) != NF_OK) return NF_ENOTSUP;
+    const int grid = (int)((B + F_ROWS - 1) / F_ROWS);
+    hipLaunchKernelGGL((rqs_fused_kernel<0, false, true>), dim3(grid), dim3(F_THREADS), lds, (hipStream_t)stream, (const float *)x,
+                       (float *)y, (float *)logdet, fa, B, num_blocks, p, acc, (const float *)h2, (float *)cond_out,
+                       (float)(sqrt((double)hidden) / 1.4426950408889634));
+    NF_CHECK_LAUNCH();
+    return NF_OK;
 }
 
 extern "C" int nf_rqs_fused(const void *x, void *y, void *logdet, const void *wpack, int mask_parity, int fuse_lu,

@@ -535,6 +535,63 @@ def rqs_coupling_bwd(x, grad_y, grad_logdet, cond, uw, uh, ud, identity_idx, tra
     return gx, gcond, guw, guh, gud
 
 
+# ---- training forward of the fused layer's last stage (csrc/rqs_fused.hip, TRAIN variant) ------------------------------
+def rqs_fused_train_blob(num_blocks, device):
+    """Empty packed-blob buffer of the fused layer (filled by rqs_fused_pack_final)."""
+    import ctypes
+    lib = L.lib()
+    lib.nf_rqs_fused_pack_size.restype = ctypes.c_int64
+    size = lib.nf_rqs_fused_pack_size(i32(32), i32(32), i32(128), i32(num_blocks), i32(8))
+    if size <= 0:
+        raise NotImplementedError("nf_rqs_fused: shape not supported")
+    return torch.zeros(size // 4, dtype=torch.float32, device=device)
+
+
+def rqs_fused_pack_final(blob, w_final, b_final, uw, uh, ud, num_blocks, tail_bound=3.0, min_bin_width=1e-3,
+                         min_bin_height=1e-3, min_derivative=1e-3):
+    L.require_device(blob, w_final, b_final, uw, uh, ud)
+    rc = L.lib().nf_rqs_fused_pack_final(ptr(blob), ptr(w_final.contiguous()), ptr(b_final.contiguous()), ptr(uw.contiguous()),
+                                         ptr(uh.contiguous()), ptr(ud.contiguous()), i32(128), i32(num_blocks), i32(8),
+                                         f64(tail_bound), f64(min_bin_width), f64(min_bin_height), f64(min_derivative), L.stream())
+    L.check(rc, "nf_rqs_fused_pack_final")
+    return blob
+
+
+def rqs_fused_train_fwd(x, h2, blob, mask_parity, num_blocks, tail_bound=3.0, min_bin_width=1e-3, min_bin_height=1e-3,
+                        min_derivative=1e-3):
+    """(y, logdet, cond24) of nf_rqs_fused_train_fwd: final Linear + density-direction coupling transform in one launch;
+    cond24 (B, 32, 24) is the conditioner output kept for rqs_coupling_bwd_p24."""
+    L.require_device(x, h2, blob)
+    x, h2 = x.contiguous(), h2.contiguous()
+    B = x.shape[0]
+    y = torch.empty_like(x)
+    ld = torch.empty(B, dtype=x.dtype, device=x.device)
+    cond = torch.empty(B, 32, 24, dtype=x.dtype, device=x.device)
+    rc = L.lib().nf_rqs_fused_train_fwd(ptr(x), ptr(h2), ptr(y), ptr(ld), ptr(cond), ptr(blob), i32(mask_parity), i64(B), i32(64),
+                                        i32(128), i32(num_blocks), i32(8), f64(tail_bound), f64(min_bin_width),
+                                        f64(min_bin_height), f64(min_derivative), i32(L.LD_WRITE), L.stream())
+    L.check(rc, "nf_rqs_fused_train_fwd")
+    return y, ld, cond
+
+
+def rqs_coupling_bwd_p24(x, grad_y, grad_logdet, cond24, uw, uh, ud, identity_idx, transform_idx, tail_bound=3.0,
+                         min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, wh_div=1.0):
+    """rqs_coupling_bwd (density direction) on the 24-float rows of rqs_fused_train_fwd.  Returns (gx, gcond24, guw, guh, gud)."""
+    L.require_device(x, grad_y, grad_logdet, cond24, uw, uh, ud, identity_idx, transform_idx)
+    B, D = x.shape
+    x, grad_y, grad_logdet = x.contiguous(), grad_y.contiguous(), grad_logdet.contiguous()
+    gx = torch.empty_like(x)
+    gcond = torch.empty_like(cond24)
+    guw, guh, gud = torch.zeros_like(uw), torch.zeros_like(uh), torch.zeros_like(ud)
+    rc = L.lib().nf_rqs_coupling_bwd_p24(ptr(x), ptr(grad_y), ptr(grad_logdet), ptr(cond24), ptr(uw), ptr(uh), ptr(ud),
+                                         ptr(identity_idx), i32(identity_idx.numel()), ptr(transform_idx),
+                                         i32(transform_idx.numel()), i64(B), i32(D), f64(tail_bound), f64(min_bin_width),
+                                         f64(min_bin_height), f64(min_derivative), f64(wh_div), ptr(gx), ptr(gcond), ptr(guw),
+                                         ptr(guh), ptr(gud), L.stream())
+    L.check(rc, "nf_rqs_coupling_bwd_p24")
+    return gx, gcond, guw, guh, gud
+
+
 # ---- bf16x3 (error-compensated split-bf16 MFMA) variant of the fused layer ----------------------------------------
 def rqs_fused_x3_pack(f32_blob, num_blocks, has_lu, nI=32, nT=32, hidden=128, K=8):
     """Derive the split-bf16 weight blob from an rqs_fused_pack blob of the same layer (nf_rqs_fused_x3_pack)."""

@@ -456,6 +456,10 @@ def N_(t):
     return t.detach().cpu().numpy()
 
 
+def _rel(a, b):
+    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
+
+
 def test_residual_block_and_linear_functions_vs_torch_autograd(nfa):
     """ResidualBlockFn / LinearFn (HIP forward, HIP input gradient, HIP weight gradients with ReLU on load) against PyTorch
     autograd of the reference block x + W2 relu(W1 relu(x) + b1) + b2 (resnet.py:37-50) and of the 736-row final layer."""
@@ -526,3 +530,38 @@ def test_rows_block_kernel_vs_torch(nfa, B, H):
     assert_close(N_(gx), N_(gx64.float()), what="gx", **tol)
     t2, y2 = nfa.ops.rows_block(x, W1, b1, W2, b2)
     assert torch.equal(t, t2) and torch.equal(y, y2)
+
+
+def test_fused_final_layer_and_spline_training_forward_vs_layerwise(nfa):
+    """Training step of the benchmark-shaped layer: final Linear + coupling transform as ONE forward launch
+    (FinalSplineDensityFn: nf_rqs_fused_train_fwd, conditioner output kept in 24-float rows, nf_rqs_coupling_bwd_p24)
+    against the layer-wise path (library GEMM for the final layer, nf_rqs_coupling / nf_rqs_coupling_bwd): loss, input
+    gradient and every parameter gradient; non-identity weights so that every bin and the tails are exercised."""
+    from bench import build_c2_model
+    torch.manual_seed(0)
+    m = build_c2_model(num_layers=2, sigma=0.05).to(DEV)
+    with torch.no_grad():
+        for f in m.flows[0::2]:
+            u = f.prqct.unconditional_transform
+            u.unnormalized_widths.normal_()
+            u.unnormalized_heights.normal_()
+            f.prqct.transform_net.final_layer.weight.add_(0.05 * torch.randn_like(f.prqct.transform_net.final_layer.weight))
+    x = 1.3 * torch.randn(3000, 64, device=DEV)
+    x[:4, :4] = torch.tensor([3.0, -3.0, 3.5, 0.0], device=DEV)
+    res = []
+    for fused in (True, False):
+        for f in m.flows[0::2]:
+            f.prqct.use_fused_train = fused
+        xa = x.clone().requires_grad_(True)
+        m.zero_grad()
+        lp = m.log_prob(xa)
+        (-lp.mean()).backward()
+        res.append((lp.detach().clone(), xa.grad.clone(), [p_.grad.clone() for p_ in m.parameters()]))
+    for f in m.flows[0::2]:
+        f.prqct.use_fused_train = True
+    (lp_f, gx_f, gp_f), (lp_u, gx_u, gp_u) = res
+    assert _rel(N(lp_f), N(lp_u)) < 2e-5, _rel(N(lp_f), N(lp_u))
+    assert_close(N(gx_f), N(gx_u), what="input gradient", rtol=2e-3, atol=2e-5)
+    for (name, _), a, b in zip(m.named_parameters(), gp_f, gp_u):
+        scale = max(float(b.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) < 2e-3 * scale, (name, float((a - b).abs().max()), scale)

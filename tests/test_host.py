@@ -390,4 +390,4 @@ def test_fused_kernels_have_no_register_spills(nfa):
                 seen += 1
                 assert d["vgpr_spill_count"] == 0 and d["sgpr_spill_count"] == 0 and d["private_segment_fixed_size"] == 0, (name, d)
                 assert d["vgpr_count"] <= 256
-    assert seen == 8, seen
+    assert seen == 9, seen     # 4 + the training variant of the exact-fp32 kernel, 4 split-bf16
