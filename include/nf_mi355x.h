@@ -499,6 +499,14 @@ int nf_rows_matvec_affine(const void *x, const void *W, const void *bias, void *
  * workgroup; D <= 64, float32 parameters), once per parameter version: out = Wd (D, D) | Ws (D, D) | bias_d (D) |
  * bias_s (D) | log|det| (1) with  .inverse (density): y = Wd x + bias_d, log_det = +log|det|;  .forward (sample):
  * y = Ws x + bias_s, log_det = -log|det|.  The layer then is ONE nf_rows_matvec_affine launch (HBM-bound). */
+/* Training-side helpers of LULinearPermute under autograd (mixing.py:402-473), float32, one launch each:
+ * nf_lu_factors: out = L (D, D) | U (D, D) | Up (D, D; Up[:, perm[j]] = U[:, j], i.e. Up x = U x[perm]) | diag (D) |
+ *   log|det| (1);  nf_lu_param_grads: packed parameter gradients (lower_entries, upper_entries, unconstrained_upper_diag)
+ *   from the dense factor gradients gL, gU and the summed log-det cotangent gl_sum (device scalar or NULL), times `sign`. */
+int nf_lu_factors(const int64_t *perm, const void *lower_entries, const void *upper_entries,
+                  const void *unconstrained_upper_diag, double eps, void *out, int D, nf_stream_t stream);
+int nf_lu_param_grads(const void *gL, const void *gU, const void *gl_sum, const void *unconstrained_upper_diag, double eps,
+                      double sign, void *g_lower, void *g_upper, void *g_udiag, int D, nf_stream_t stream);
 int nf_lu_compose(const int64_t *perm, const void *lower_entries, const void *upper_entries,
                   const void *unconstrained_upper_diag, const void *bias, double eps, void *out, int D,
                   nf_stream_t stream);

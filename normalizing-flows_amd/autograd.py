@@ -180,10 +180,8 @@ class LULinearPermuteFn(torch.autograd.Function):
             # density direction on the fp32-MFMA row mat-vec kernel: u = U x[perm] (kept for the backward), y = L u + b with
             # the constant log-det in the same launch -- two 13 us launches against 64 us for the LDS-tile kernel
             with torch.no_grad():
-                Lm, Um, diag, _, _ = _assemble_lu(lower_entries, upper_entries, udiag_raw, eps)
-                Up = torch.zeros_like(Um)
-                Up[:, perm] = Um
-                lad = torch.log(diag).sum().reshape(1)
+                Lm, Um, Up, diag, lad = ops.lu_factors(perm, lower_entries.detach(), upper_entries.detach(), udiag_raw.detach(),
+                                                       eps=eps)          # one launch (nf_lu_factors)
                 u = ops.rows_matvec(x, Up)
                 y, ld = ops.rows_matvec_affine(u, Lm, bias.detach(), lad, +1.0)
             ctx.save_for_backward(x, y, perm, lower_entries, upper_entries, udiag_raw, bias, u)
@@ -200,6 +198,19 @@ class LULinearPermuteFn(torch.autograd.Function):
         x, y, perm, lower_entries, upper_entries, udiag_raw, bias, u_saved = ctx.saved_tensors
         fac = getattr(ctx, "factors", None)
         D_ = x.shape[1]
+        if fac is not None and ctx.direction == 0:
+            # the density direction of the training step, all on hand-written kernels: three row mat-vecs, two split-K batch
+            # reductions, one launch for the packed parameter gradients
+            Lm, Um, diag, Up = fac
+            gy = torch.zeros_like(y) if gy is None else gy.contiguous()
+            gu = ops.rows_matvec(gy, Lm.t())            # d/du = L^T gy
+            gx = ops.rows_matvec(gu, Up.t())            # d/dx = P (U^T gu)
+            gL, g_bias = _batch_outer(gy, u_saved, want_colsum=True)
+            gUx, _ = _batch_outer(gu, x)                # gu^T x; gU = (gu^T x)[:, perm]: permute 64 columns, not 65 536 rows
+            gl_sum = None if gld is None else gld.sum().reshape(1)
+            g_lower, g_upper, g_udiag = ops.lu_param_grads(gL, gUx.index_select(1, perm), gl_sum, udiag_raw.detach(),
+                                                           lower_entries.numel(), eps=ctx.eps, sign=1.0)
+            return gx, None, g_lower, g_upper, g_udiag, g_bias, None, None
         li, ui = _tri_indices(D_, x.device)
         if fac is not None:
             Lm, Um, diag, Up_saved = fac

@@ -83,6 +83,57 @@ lu_compose_kernel(const int64_t *__restrict__ perm, const float *__restrict__ lo
     }
 }
 
+// Training-side helpers of LULinearPermute (mixing.py:402-473 under autograd): one launch instead of a dozen element-wise /
+// indexing launches each.  nf_lu_factors: out = L (D x D, unit diagonal) | U (D x D, diagonal softplus(u) + eps) | Up (D x D,
+// Up[:, perm[j]] = U[:, j], so that Up x = U x[perm]) | diag (D) | log|det| = sum log diag (1).
+__global__ void __launch_bounds__(256)
+lu_factors_kernel(const int64_t *__restrict__ perm, const float *__restrict__ lower_entries,
+                  const float *__restrict__ upper_entries, const float *__restrict__ udiag_raw, float eps,
+                  float *__restrict__ out, int D) {
+    __shared__ float sred[16];
+    const int N = D * D, tid = threadIdx.x;
+    float *Lm = out, *Um = out + N, *Up = out + 2 * N, *dg = out + 3 * N, *lad = dg + D;
+    for (int i = tid; i < N; i += 256) {
+        const int r = i / D, c = i - r * D;
+        float l = 0.0f, u = 0.0f;
+        if (c < r) l = lower_entries[r * (r - 1) / 2 + c];
+        else if (c == r) { l = 1.0f; u = softplus(udiag_raw[r]) + eps; }
+        else u = upper_entries[r * (D - 1) - r * (r - 1) / 2 + (c - r - 1)];
+        Lm[i] = l;
+        Um[i] = u;
+        Up[r * D + (int)perm[c]] = u;
+    }
+    float part = 0.0f;
+    for (int i = tid; i < D; i += 256) {
+        const float d = softplus(udiag_raw[i]) + eps;
+        dg[i] = d;
+        part += logf(d);
+    }
+    const float s = block_sum(part, sred);
+    if (tid == 0) *lad = s;
+}
+
+// Parameter gradients from the dense factor gradients gL, gU (D x D) and the summed log-det cotangent gl_sum (device
+// scalar): g_lower / g_upper = sign * the strictly triangular entries (packed row-major as the parameters are),
+// g_udiag = sign * (gU[r][r] + gl_sum / diag[r]) * softplus'(u_r).
+__global__ void __launch_bounds__(256)
+lu_param_grads_kernel(const float *__restrict__ gL, const float *__restrict__ gU, const float *__restrict__ gl_sum,
+                      const float *__restrict__ udiag_raw, float eps, float sign, float *__restrict__ g_lower,
+                      float *__restrict__ g_upper, float *__restrict__ g_udiag, int D) {
+    const int N = D * D;
+    const float gl = gl_sum ? *gl_sum : 0.0f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const int r = i / D, c = i - r * D;
+        if (c < r) g_lower[r * (r - 1) / 2 + c] = sign * gL[i];
+        else if (c > r) g_upper[r * (D - 1) - r * (r - 1) / 2 + (c - r - 1)] = sign * gU[i];
+        else {
+            const float u = udiag_raw[r], d = softplus(u) + eps;
+            const float sg = u > 20.0f ? 1.0f : sigmoid(u);
+            g_udiag[r] = sign * (gU[i] + gl / d) * sg;
+        }
+    }
+}
+
 // y_b = W x_b (+ bias); optionally logdet[b] (op)= ld_sign * (*ld_const) for every row (LULinearPermute's constant log-det).
 __global__ void __launch_bounds__(64 * RM_NW)
 rows_matvec_kernel(const float *__restrict__ x, const float *__restrict__ W, float *__restrict__ y, int64_t B, int D,
@@ -171,6 +222,29 @@ extern "C" int nf_rows_matvec_affine(const void *x, const void *W, const void *b
 
 extern "C" int nf_rows_matvec(const void *x, const void *W, void *y, int64_t B, int D, nf_stream_t stream) {
     return nf_rows_matvec_affine(x, W, nullptr, y, nullptr, nullptr, 0.0, NF_LD_WRITE, B, D, stream);
+}
+
+extern "C" int nf_lu_factors(const int64_t *perm, const void *lower_entries, const void *upper_entries,
+                             const void *unconstrained_upper_diag, double eps, void *out, int D, nf_stream_t stream) {
+    if (D < 1) return NF_EINVAL;
+    if (!perm || !unconstrained_upper_diag || !out || (D > 1 && (!lower_entries || !upper_entries))) return NF_EFAULT;
+    hipLaunchKernelGGL(lu_factors_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, perm, (const float *)lower_entries,
+                       (const float *)upper_entries, (const float *)unconstrained_upper_diag, (float)eps, (float *)out, D);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_lu_param_grads(const void *gL, const void *gU, const void *gl_sum, const void *unconstrained_upper_diag,
+                                 double eps, double sign, void *g_lower, void *g_upper, void *g_udiag, int D,
+                                 nf_stream_t stream) {
+    if (D < 1) return NF_EINVAL;
+    if (!gL || !gU || !unconstrained_upper_diag || !g_udiag || (D > 1 && (!g_lower || !g_upper))) return NF_EFAULT;
+    const int grid = (D * D + 255) / 256;
+    hipLaunchKernelGGL(lu_param_grads_kernel, dim3(grid < 64 ? grid : 64), dim3(256), 0, (hipStream_t)stream, (const float *)gL,
+                       (const float *)gU, (const float *)gl_sum, (const float *)unconstrained_upper_diag, (float)eps, (float)sign,
+                       (float *)g_lower, (float *)g_upper, (float *)g_udiag, D);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
 }
 
 extern "C" int nf_lu_compose(const int64_t *perm, const void *lower_entries, const void *upper_entries,

@@ -361,6 +361,32 @@ def lu_compose(perm, lower_entries, upper_entries, unconstrained_upper_diag, bia
     return out[:N].view(D, D), out[N:2 * N].view(D, D), out[2 * N:2 * N + D], out[2 * N + D:2 * N + 2 * D], out[2 * N + 2 * D:]
 
 
+def lu_factors(perm, lower_entries, upper_entries, unconstrained_upper_diag, eps=1e-3):
+    """(L, U, Up, diag, log|det| (1-element)) of LULinearPermute's factors in one launch (nf_lu_factors); float32."""
+    L.require_device(perm, lower_entries, upper_entries, unconstrained_upper_diag)
+    D = unconstrained_upper_diag.numel()
+    out = torch.empty(3 * D * D + D + 1, dtype=torch.float32, device=unconstrained_upper_diag.device)
+    rc = L.lib().nf_lu_factors(ptr(perm), ptr(lower_entries.contiguous()), ptr(upper_entries.contiguous()),
+                               ptr(unconstrained_upper_diag.contiguous()), f64(eps), ptr(out), i32(D), L.stream())
+    L.check(rc, "nf_lu_factors")
+    N = D * D
+    return out[:N].view(D, D), out[N:2 * N].view(D, D), out[2 * N:3 * N].view(D, D), out[3 * N:3 * N + D], out[3 * N + D:]
+
+
+def lu_param_grads(gL, gU, gl_sum, unconstrained_upper_diag, n_tri, eps=1e-3, sign=1.0):
+    """(g_lower, g_upper, g_udiag) from the dense factor gradients (nf_lu_param_grads); float32."""
+    L.require_device(gL, gU, gl_sum, unconstrained_upper_diag)
+    D = unconstrained_upper_diag.numel()
+    dev = gL.device
+    g_lower = torch.empty(n_tri, dtype=torch.float32, device=dev)
+    g_upper = torch.empty(n_tri, dtype=torch.float32, device=dev)
+    g_udiag = torch.empty(D, dtype=torch.float32, device=dev)
+    rc = L.lib().nf_lu_param_grads(ptr(gL.contiguous()), ptr(gU.contiguous()), ptr(gl_sum), ptr(unconstrained_upper_diag.contiguous()),
+                                   f64(eps), f64(sign), ptr(g_lower), ptr(g_upper), ptr(g_udiag), i32(D), L.stream())
+    L.check(rc, "nf_lu_param_grads")
+    return g_lower, g_upper, g_udiag
+
+
 def rows_matvec_affine(x, W, bias, ld_const=None, ld_sign=1.0, logdet=None, acc=None):
     """y_b = W x_b + bias and logdet[b] (acc) ld_sign * ld_const (nf_rows_matvec_affine); (B, D <= 64) float32."""
     L.require_device(x, W, bias, ld_const, logdet)
