@@ -75,6 +75,16 @@ def main():
     q = nfa.distributions.DiagGaussian(D, trainable=False).to(dev)
     t = timeit(lambda: q._log_prob_acc(x, ld, +1))
     report("nf_diag_gaussian_log_prob f32", t, B * (D * 4 + 8))
+    zr = torch.randn(B, D, device=dev)
+    bm = (torch.arange(D, device=dev) % 2).float()
+    sr, tr = 0.1 * torch.randn(B, D, device=dev), torch.randn(B, D, device=dev)
+    t = timeit(lambda: ops.masked_affine(zr, bm, sr, tr, 0, logdet=ld, acc=1))
+    report("nf_masked_affine (%d,%d)" % (B, D), t, B * D * 16 + B * 8)
+    t = timeit(lambda: ops.masked_affine_bwd(zr, bm, sr, tr, tr, ld, 0))
+    report("nf_masked_affine_bwd (%d,%d)" % (B, D), t, B * D * 28 + B * 4)
+    Wm = torch.randn(D, D, device=dev)
+    t = timeit(lambda: ops.rows_matvec(zr, Wm))
+    report("nf_rows_matvec (%d,%d)" % (B, D), t, B * D * 8)
     # image-side kernels at the Glow shapes of BASELINE configs[3] (B = 256)
     for C, HW in ((12, 16), (24, 8), (48, 4)):
         z = torch.randn(256, C, HW, HW, device=dev)
@@ -118,16 +128,6 @@ def main():
     zi = torch.randn(Bi, 3, 32, 32, device=dev)
     t = timeit(lambda: ops.squeeze(zi, 1))
     report("nf_squeeze (%d,3,32,32)" % Bi, t, zi.numel() * 8)
-    zr = torch.randn(B, D, device=dev)
-    bm = (torch.arange(D, device=dev) % 2).float()
-    sr, tr = 0.1 * torch.randn(B, D, device=dev), torch.randn(B, D, device=dev)
-    t = timeit(lambda: ops.masked_affine(zr, bm, sr, tr, 0, logdet=ld, acc=1))
-    report("nf_masked_affine (%d,%d)" % (B, D), t, B * D * 16 + B * 8)
-    t = timeit(lambda: ops.masked_affine_bwd(zr, bm, sr, tr, tr, ld, 0))
-    report("nf_masked_affine_bwd (%d,%d)" % (B, D), t, B * D * 28 + B * 4)
-    Wm = torch.randn(D, D, device=dev)
-    t = timeit(lambda: ops.rows_matvec(zr, Wm))
-    report("nf_rows_matvec (%d,%d)" % (B, D), t, B * D * 8)
     # conditioner GEMMs of the training path: the MFMA row-panel kernel against the library call it replaces
     for K_, N_ in ((128, 128), (32, 128), (128, 736), (736, 128)):
         xa = torch.randn(B, K_, device=dev)
