@@ -199,6 +199,114 @@ wgrad_partial_kernel(const float *__restrict__ dY, const float *__restrict__ X, 
     }
 }
 
+// ---- workgroup-tiled path: N in [96, 128], N % 4 == 0 (the 128-wide layers of the conditioner) ------------------------------
+// The wave-private kernels above take both MFMA operands straight from global memory: 1.5 KB per 8 MFMAs and wave, every
+// m-group re-reading X from L2, and nothing but its own two buffer sets hides a wave's load latency -- 0.43 of the fp32 MFMA
+// peak.  Here a 4-wave workgroup owns a 128 (M) x 128 (N) tile: a K-step of 32 batch rows of dY and X is loaded ONCE per
+// workgroup (coalesced 16-byte loads, the next step's into registers while the current step's 64 MFMAs per wave run from
+// LDS), each wave computes a 64 x 64 quadrant (4 accumulators) with ds_read_b32 operands -- half the operand traffic per MFMA
+// and a workgroup-wide prefetch.  Same partial-tile format and reduce kernel.
+constexpr int W2_KS = 32;     // batch rows per LDS tile
+constexpr int W2_T = 128;     // tile edge (M and N)
+
+__global__ void __launch_bounds__(256, 2)
+wgrad_tile_kernel(const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ part, int64_t B, int M, int N,
+                  int chunk_rows, int want_bias, int x_relu) {
+    __shared__ __attribute__((aligned(16))) float As[2][W2_KS][W2_T];
+    __shared__ __attribute__((aligned(16))) float Bs[2][W2_KS][W2_T];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i = lane & 31, h = lane >> 5;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int m0 = blockIdx.y * W2_T;
+    const int64_t b0 = (int64_t)blockIdx.x * chunk_rows;
+    int64_t b1 = b0 + chunk_rows;
+    if (b1 > B) b1 = B;
+    // loader mapping: thread t covers columns [4 (t & 31), +4) of rows (t >> 5) + 8 j, j = 0..3
+    const int lc = (tid & 31) * 4, lr = tid >> 5;
+    const bool a_ok = m0 + lc < M, x_ok = lc < N;     // M, N multiples of 4
+    f32x4 ra[4], rx[4];
+    auto fetch = [&](int64_t b) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t r = b + lr + 8 * j;
+            const int64_t rc = r < b1 ? r : b1 - 1;            // clamped address, zeroed when stored
+            ra[j] = a_ok ? *reinterpret_cast<const f32x4 *>(dY + rc * M + m0 + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rx[j] = x_ok ? *reinterpret_cast<const f32x4 *>(X + rc * N + lc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r >= b1) { ra[j] = f32x4{0.f, 0.f, 0.f, 0.f}; rx[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 xv = rx[j];
+            if (x_relu) { xv[0] = fmaxf(xv[0], 0.f); xv[1] = fmaxf(xv[1], 0.f); xv[2] = fmaxf(xv[2], 0.f); xv[3] = fmaxf(xv[3], 0.f); }
+            *reinterpret_cast<f32x4 *>(&As[buf][lr + 8 * j][lc]) = ra[j];
+            *reinterpret_cast<f32x4 *>(&Bs[buf][lr + 8 * j][lc]) = xv;
+        }
+    };
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    float bs0 = 0.0f, bs1 = 0.0f;
+    fetch(b0);
+    commit(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t b = b0; b < b1; b += W2_KS) {
+        const bool more = b + W2_KS < b1;
+        if (more) fetch(b + W2_KS);
+        const float *ap = &As[buf][h][wm * 64 + i], *bp = &Bs[buf][h][wn * 64 + i];
+#pragma unroll
+        for (int kp = 0; kp < W2_KS / 2; ++kp) {
+            const float a0 = ap[kp * 2 * W2_T], a1 = ap[kp * 2 * W2_T + 32];
+            const float x0 = bp[kp * 2 * W2_T], x1 = bp[kp * 2 * W2_T + 32];
+            bs0 += a0;
+            bs1 += a1;
+            acc00 = MFMA32(a0, x0, acc00);
+            acc01 = MFMA32(a0, x1, acc01);
+            acc10 = MFMA32(a1, x0, acc10);
+            acc11 = MFMA32(a1, x1, acc11);
+        }
+        if (more) commit(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // C layout: row (m within the 32-subtile) = (reg & 3) + 8 (reg >> 2) + 4 h, col (n within the subtile) = lane & 31
+    float *out = part + (size_t)blockIdx.x * ((size_t)M * N + M);
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+#pragma unroll
+        for (int t_ = 0; t_ < 2; ++t_) {
+            const f32x16 &acc = s_ == 0 ? (t_ == 0 ? acc00 : acc01) : (t_ == 0 ? acc10 : acc11);
+            const int n = wn * 64 + 32 * t_ + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mm = m0 + wm * 64 + 32 * s_ + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (mm < M && n < N) out[(size_t)mm * N + n] = acc[r];
+            }
+        }
+    }
+    if (want_bias && wn == 0) {
+        bs0 += __shfl_xor(bs0, 32);
+        bs1 += __shfl_xor(bs1, 32);
+        if (h == 0) {
+            const int ma = m0 + wm * 64 + i, mb = ma + 32;
+            if (ma < M) out[(size_t)M * N + ma] = bs0;
+            if (mb < M) out[(size_t)M * N + mb] = bs1;
+        }
+    }
+}
+
+static int wgrad_tile_chunk_rows(int64_t B, int M) {
+    const int mt = (M + W2_T - 1) / W2_T;
+#ifndef NF_W2_SLOTS
+#define NF_W2_SLOTS 512
+#endif
+    int64_t want = NF_W2_SLOTS / mt;               // at most 512 workgroups (two per CU): one more would cost a second round
+    if (want < 1) want = 1;
+    int64_t rows = (B + want - 1) / want;
+    rows = (rows + W2_KS - 1) / W2_KS * W2_KS;
+    if (rows < 4 * W2_KS) rows = 4 * W2_KS;
+    return (int)rows;
+}
+
 // out (dW then db) (=|+=) sum over chunks of part[c][e] in a fixed order; e < nW goes to dW, the rest to db.
 // Block = 64 elements x RL chunk lanes (lane q sums chunks q, q + RL, ... with four loads in flight), combined through
 // LDS in lane order: deterministic, and short dependent chains (the kernel is pure load latency).
@@ -248,8 +356,20 @@ static int wgrad_chunk_rows(int64_t B, int M, bool vec) {
 
 }  // namespace nf
 
+static inline bool wgrad_use_tile(int M, int N) {
+#ifdef NF_WGRAD_NO_TILE
+    return false;
+#else
+    return N >= 96 && N <= 128 && N % 4 == 0 && M % 4 == 0 && M >= 256;   // M = 128: 39 us vs 35 us wave-private (measured)
+#endif
+}
+
 extern "C" int64_t nf_linear_wgrad_scratch_floats(int64_t B, int M, int N) {
     if (B < 0 || M < 1 || N < 1) return NF_EINVAL;
+    if (wgrad_use_tile(M, N)) {
+        const int rows_t = nf::wgrad_tile_chunk_rows(B, M);
+        return ((B + rows_t - 1) / rows_t) * ((int64_t)M * N + M);
+    }
     const int rows = nf::wgrad_chunk_rows(B, M, N % 4 == 0);
     const int64_t chunks = (B + rows - 1) / rows;
     return chunks * ((int64_t)M * N + M);
@@ -269,11 +389,15 @@ extern "C" int nf_linear_wgrad_act(const void *dY, const void *X, void *dW, void
     if (!dY || !X || !dW || !scratch) return NF_EFAULT;
     hipStream_t st = (hipStream_t)stream;
     const bool vec = N % 4 == 0;
-    const int rows = nf::wgrad_chunk_rows(B, M, vec);
+    const bool tile = wgrad_use_tile(M, N);
+    const int rows = tile ? nf::wgrad_tile_chunk_rows(B, M) : nf::wgrad_chunk_rows(B, M, vec);
     const int chunks = (int)((B + rows - 1) / rows);
     float *part = (float *)scratch;
     const int want_bias = db ? 1 : 0;
-    if (vec) {
+    if (tile) {
+        hipLaunchKernelGGL(nf::wgrad_tile_kernel, dim3(chunks, (M + nf::W2_T - 1) / nf::W2_T), dim3(256), 0, st, (const float *)dY,
+                           (const float *)X, part, B, M, N, rows, want_bias, relu_x);
+    } else if (vec) {
 #define NF_WGRAD_VEC(AV, XR)                                                                                          \
     hipLaunchKernelGGL((nf::wgrad_partial_vec_kernel<AV, XR>), dim3(chunks, (M + 63) / 64), dim3(64), 0, st,          \
                        (const float *)dY, (const float *)X, part, B, M, N, rows, want_bias)

@@ -131,10 +131,11 @@ def test_spline_gradients_match_finite_differences_fp64(nfa):
                 assert abs(fd - float(gr.view(-1)[i])) < 1e-5 * max(1.0, abs(fd)), (inverse, i, fd, float(gr.view(-1)[i]))
 
 
-@pytest.mark.parametrize("B,M,N", [(65536, 128, 128), (65536, 128, 32), (65536, 736, 128), (4099, 70, 33), (1025, 5, 128)])
+@pytest.mark.parametrize("B,M,N", [(65536, 128, 128), (65536, 128, 32), (65536, 736, 128), (4099, 70, 33), (1025, 5, 128),
+                                   (65536, 768, 128), (4099, 300, 100), (777, 768, 128), (33, 256, 96)])
 def test_linear_wgrad_kernel(nfa, B, M, N):
     """nf_linear_wgrad (split-K fp32 MFMA + fixed-order reduction) against fp64 matmul; ragged K and tile edges;
-    bit-identical when repeated."""
+    bit-identical when repeated.  M >= 256 with N in [96, 128] takes the workgroup-tiled kernel (LDS operands)."""
     g = torch.Generator().manual_seed(B + M + N)
     dy = torch.randn(B, M, generator=g).to(DEV)
     x = torch.randn(B, N, generator=g).to(DEV)

@@ -36,7 +36,7 @@ def main():
     x = torch.randn(B, N, device=dev)
     dW = torch.empty(M, N, device=dev)
     db = torch.empty(M, device=dev)
-    n = libs[0].nf_linear_wgrad_scratch_floats(i64(B), i32(M), i32(N))
+    n = max(lib.nf_linear_wgrad_scratch_floats(i64(B), i32(M), i32(N)) for lib in libs)
     scratch = torch.empty(n, device=dev)
     st = nfa._lib.stream()
 
