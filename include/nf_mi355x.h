@@ -319,6 +319,12 @@ int nf_linear_wgrad(const void *dY, const void *X, void *dW, void *db, void *scr
  * pre-activation of the block, resnet.py:41-47). */
 int nf_linear_wgrad_act(const void *dY, const void *X, void *dW, void *db, void *scratch, int64_t B, int M, int N,
                         int accumulate, int relu_x, nf_stream_t stream);
+/* Same with pad rows: when skip_every > 1 (M % skip_every == 0), every skip_every-th row of dY (m % skip_every ==
+ * skip_every - 1) is padding and has no output row -- dW is (M - M / skip_every, N), db (M - M / skip_every).  The 24-float
+ * parameter rows of nf_rqs_fused_train_fwd / nf_rqs_coupling_bwd_p24 (23 parameters + 1 pad) against the reference's
+ * 23-row final layer: the un-padding happens in the reduction, not as two strided copies. */
+int nf_linear_wgrad_skip(const void *dY, const void *X, void *dW, void *db, void *scratch, int64_t B, int M, int N,
+                         int accumulate, int relu_x, int skip_every, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Logit preprocessing transform of image tensors.  Replaces normflows/transforms.py:8-47.
@@ -501,12 +507,15 @@ int nf_rows_matvec_affine(const void *x, const void *W, const void *bias, void *
  * y = Ws x + bias_s, log_det = -log|det|.  The layer then is ONE nf_rows_matvec_affine launch (HBM-bound). */
 /* Training-side helpers of LULinearPermute under autograd (mixing.py:402-473), float32, one launch each:
  * nf_lu_factors: out = L (D, D) | U (D, D) | Up (D, D; Up[:, perm[j]] = U[:, j], i.e. Up x = U x[perm]) | diag (D) |
- *   log|det| (1);  nf_lu_param_grads: packed parameter gradients (lower_entries, upper_entries, unconstrained_upper_diag)
- *   from the dense factor gradients gL, gU and the summed log-det cotangent gl_sum (device scalar or NULL), times `sign`. */
+ *   log|det| (1) | L^T (D, D) | Up^T (D, D): 5 D^2 + D + 1 floats;
+ * nf_lu_param_grads: packed parameter gradients (lower_entries, upper_entries, unconstrained_upper_diag) from the dense
+ *   factor gradients gL, gU (gU's columns read through perm when perm != NULL: gU = (gu^T x)[:, perm]) and the log-det
+ *   cotangent gld (B floats, summed inside the launch; NULL = none), times `sign`. */
 int nf_lu_factors(const int64_t *perm, const void *lower_entries, const void *upper_entries,
                   const void *unconstrained_upper_diag, double eps, void *out, int D, nf_stream_t stream);
-int nf_lu_param_grads(const void *gL, const void *gU, const void *gl_sum, const void *unconstrained_upper_diag, double eps,
-                      double sign, void *g_lower, void *g_upper, void *g_udiag, int D, nf_stream_t stream);
+int nf_lu_param_grads(const void *gL, const void *gU, const int64_t *perm, const void *gld, int64_t B,
+                      const void *unconstrained_upper_diag, double eps, double sign, void *g_lower, void *g_upper, void *g_udiag,
+                      int D, nf_stream_t stream);
 int nf_lu_compose(const int64_t *perm, const void *lower_entries, const void *upper_entries,
                   const void *unconstrained_upper_diag, const void *bias, double eps, void *out, int D,
                   nf_stream_t stream);

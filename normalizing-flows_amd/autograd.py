@@ -106,15 +106,27 @@ class FinalSplineDensityFn(torch.autograd.Function):
     Shape of the benchmark layer only: D = 64, hidden = 128, 8 bins, linear tails."""
 
     @staticmethod
-    def forward(ctx, x, h2, wf, bf, uw, uh, ud, iidx, tidx, blob, parity, nblocks, kw):
+    def forward(ctx, x, h2, wf, bf, uw, uh, ud, iidx, tidx, blob, parity, nblocks, kw, ld_acc=None, acc=1):
         ops.rqs_fused_pack_final(blob, wf.detach(), bf.detach(), uw.detach(), uh.detach(), ud.detach(), nblocks,
                                  tail_bound=kw["tail_bound"], min_bin_width=kw["min_bin_width"],
                                  min_bin_height=kw["min_bin_height"], min_derivative=kw["min_derivative"])
+        # the caller's running log-density is updated inside the launch (no (B) add per layer); autograd sees an in-place op
         y, ld, cond24 = ops.rqs_fused_train_fwd(x, h2, blob, parity, nblocks, tail_bound=kw["tail_bound"],
                                                 min_bin_width=kw["min_bin_width"], min_bin_height=kw["min_bin_height"],
-                                                min_derivative=kw["min_derivative"])
+                                                min_derivative=kw["min_derivative"], logdet=ld_acc,
+                                                acc=None if ld_acc is None else (L.LD_ADD if acc > 0 else L.LD_SUB))
+        if ld_acc is not None:
+            ctx.mark_dirty(ld_acc)
+        # final-layer weight on the 24-row layout of cond24 (pad row of every feature zero): a buffer kept per layer, one
+        # strided copy per step, read by the backward's input-gradient GEMM
+        nT, H = cond24.shape[1], wf.shape[1]
+        key = (wf.data_ptr(), nT, H, str(wf.device))
+        wpad = _wpad_cache.get(key)
+        if wpad is None:
+            wpad = _wpad_cache[key] = torch.zeros(nT, 24, H, dtype=wf.dtype, device=wf.device)
+        wpad[:, :23].copy_(wf.detach().view(nT, 23, H))
         ctx.save_for_backward(x, h2, wf, cond24, uw, uh, ud, iidx, tidx)
-        ctx.kw = kw
+        ctx.kw, ctx.wpad, ctx.acc, ctx.has_acc = kw, wpad, acc, ld_acc is not None
         return y, ld
 
     @staticmethod
@@ -125,20 +137,19 @@ class FinalSplineDensityFn(torch.autograd.Function):
             gy = torch.zeros_like(x)
         if gld is None:
             gld = torch.zeros(x.shape[0], dtype=x.dtype, device=x.device)
-        gx, gcond24, guw, guh, gud = ops.rqs_coupling_bwd_p24(x, gy, gld, cond24, uw, uh, ud, iidx, tidx,
+        gld_own = -gld if (ctx.has_acc and ctx.acc < 0) else gld
+        gx, gcond24, guw, guh, gud = ops.rqs_coupling_bwd_p24(x, gy, gld_own, cond24, uw, uh, ud, iidx, tidx,
                                                               tail_bound=kw["tail_bound"], min_bin_width=kw["min_bin_width"],
                                                               min_bin_height=kw["min_bin_height"],
                                                               min_derivative=kw["min_derivative"], wh_div=kw["wh_div"])
         B, nT, H = x.shape[0], cond24.shape[1], wf.shape[1]
         g2 = gcond24.view(B, nT * 24)
-        wpad = torch.zeros(nT, 24, H, dtype=wf.dtype, device=wf.device)
-        wpad[:, :23] = wf.detach().view(nT, 23, H)           # the pad row of every feature stays zero
-        gh2 = g2 @ wpad.view(nT * 24, H)                     # input gradient of the final layer (library GEMM, padded rows)
-        gwp, gbp = ops.linear_wgrad(g2, h2, want_bias=True)  # (nT * 24, H), (nT * 24)
-        gwf = gwp.view(nT, 24, H)[:, :23].reshape(nT * 23, H)
-        gbf = gbp.view(nT, 24)[:, :23].reshape(nT * 23)
-        return gx, gh2, gwf, gbf, guw, guh, gud, None, None, None, None, None, None
+        gh2 = g2 @ ctx.wpad.view(nT * 24, H)                 # input gradient of the final layer (library GEMM, padded rows)
+        gwf, gbf = ops.linear_wgrad(g2, h2, want_bias=True, skip_every=24)   # pad rows dropped in the reduction
+        return gx, gh2, gwf, gbf, guw, guh, gud, None, None, None, None, None, None, (gld if ctx.has_acc else None), None
 
+
+_wpad_cache = {}
 
 _tri_cache = {}
 
@@ -174,23 +185,29 @@ class LULinearPermuteFn(torch.autograd.Function):
     """LULinearPermute (mixing.py:535-563).  direction 0 = .inverse (density), 1 = .forward (sample)."""
 
     @staticmethod
-    def forward(ctx, x, perm, lower_entries, upper_entries, udiag_raw, bias, eps, direction):
+    def forward(ctx, x, perm, lower_entries, upper_entries, udiag_raw, bias, eps, direction, ld_acc=None, acc=1):
         D = x.shape[1]
+        ctx.acc, ctx.has_acc = acc, ld_acc is not None
+        if ld_acc is not None:
+            ctx.mark_dirty(ld_acc)      # the caller's running log-density, updated in place (inside the launch where possible)
         if direction == 0 and x.is_cuda and x.dtype == torch.float32 and D <= 64:
             # density direction on the fp32-MFMA row mat-vec kernel: u = U x[perm] (kept for the backward), y = L u + b with
             # the constant log-det in the same launch -- two 13 us launches against 64 us for the LDS-tile kernel
             with torch.no_grad():
-                Lm, Um, Up, diag, lad = ops.lu_factors(perm, lower_entries.detach(), upper_entries.detach(), udiag_raw.detach(),
-                                                       eps=eps)          # one launch (nf_lu_factors)
+                Lm, Um, Up, diag, lad, LT, UpT = ops.lu_factors(perm, lower_entries.detach(), upper_entries.detach(),
+                                                                udiag_raw.detach(), eps=eps)          # one launch (nf_lu_factors)
                 u = ops.rows_matvec(x, Up)
-                y, ld = ops.rows_matvec_affine(u, Lm, bias.detach(), lad, +1.0)
+                y, ld = ops.rows_matvec_affine(u, Lm, bias.detach(), lad, +1.0, logdet=ld_acc,
+                                               acc=None if ld_acc is None else (L.LD_ADD if acc > 0 else L.LD_SUB))
             ctx.save_for_backward(x, y, perm, lower_entries, upper_entries, udiag_raw, bias, u)
             ctx.eps, ctx.direction = eps, direction
-            ctx.factors = (Lm, Um, diag, Up)      # assembled once per step: the backward reuses them
+            ctx.factors = (Lm, Um, diag, Up, LT, UpT)      # assembled once per step: the backward reuses them
             return y, ld
         y, ld = ops.lu_linear_permute(x, perm, lower_entries, upper_entries, udiag_raw, bias, direction, eps=eps)
         ctx.save_for_backward(x, y, perm, lower_entries, upper_entries, udiag_raw, bias, None)
         ctx.eps, ctx.direction = eps, direction
+        if ld_acc is not None:
+            ld = ld_acc.add_(ld) if acc > 0 else ld_acc.sub_(ld)
         return y, ld
 
     @staticmethod
@@ -198,22 +215,24 @@ class LULinearPermuteFn(torch.autograd.Function):
         x, y, perm, lower_entries, upper_entries, udiag_raw, bias, u_saved = ctx.saved_tensors
         fac = getattr(ctx, "factors", None)
         D_ = x.shape[1]
+        g_acc = gld if ctx.has_acc else None            # the running log-density passes its cotangent straight through
+        if ctx.has_acc and ctx.acc < 0 and gld is not None:
+            gld = -gld
         if fac is not None and ctx.direction == 0:
             # the density direction of the training step, all on hand-written kernels: three row mat-vecs, two split-K batch
             # reductions, one launch for the packed parameter gradients
-            Lm, Um, diag, Up = fac
+            Lm, Um, diag, Up, LT, UpT = fac
             gy = torch.zeros_like(y) if gy is None else gy.contiguous()
-            gu = ops.rows_matvec(gy, Lm.t())            # d/du = L^T gy
-            gx = ops.rows_matvec(gu, Up.t())            # d/dx = P (U^T gu)
+            gu = ops.rows_matvec(gy, LT)                # d/du = L^T gy
+            gx = ops.rows_matvec(gu, UpT)               # d/dx = P (U^T gu)
             gL, g_bias = _batch_outer(gy, u_saved, want_colsum=True)
-            gUx, _ = _batch_outer(gu, x)                # gu^T x; gU = (gu^T x)[:, perm]: permute 64 columns, not 65 536 rows
-            gl_sum = None if gld is None else gld.sum().reshape(1)
-            g_lower, g_upper, g_udiag = ops.lu_param_grads(gL, gUx.index_select(1, perm), gl_sum, udiag_raw.detach(),
-                                                           lower_entries.numel(), eps=ctx.eps, sign=1.0)
-            return gx, None, g_lower, g_upper, g_udiag, g_bias, None, None
+            gUx, _ = _batch_outer(gu, x)                # gu^T x; gU = (gu^T x)[:, perm]: taken through perm inside the launch
+            g_lower, g_upper, g_udiag = ops.lu_param_grads(gL, gUx, gld, udiag_raw.detach(), lower_entries.numel(),
+                                                           eps=ctx.eps, sign=1.0, perm=perm)
+            return gx, None, g_lower, g_upper, g_udiag, g_bias, None, None, g_acc, None
         li, ui = _tri_indices(D_, x.device)
         if fac is not None:
-            Lm, Um, diag, Up_saved = fac
+            Lm, Um, diag, Up_saved = fac[:4]
         else:
             Lm, Um, diag, li, ui = _assemble_lu(lower_entries, upper_entries, udiag_raw, ctx.eps)
             Up_saved = None
@@ -263,7 +282,7 @@ class LULinearPermuteFn(torch.autograd.Function):
         g_lower = gL[li[0], li[1]]
         g_upper = gU[ui[0], ui[1]]
         g_udiag = gdiag * sig
-        return gx, None, g_lower, g_upper, g_udiag, g_bias, None, None
+        return gx, None, g_lower, g_upper, g_udiag, g_bias, None, None, g_acc, None
 
 
 class DiagGaussianLogProbFn(torch.autograd.Function):
@@ -334,6 +353,36 @@ def linear(x, weight, bias):
             and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad))):
         return LinearFn.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)
+
+
+class IdentLinearFn(torch.autograd.Function):
+    """The conditioner's initial Linear on the identity columns of a full-width row (nsf/coupling.py:71-76 `inputs[:,
+    identity_features]` + nets/resnet.py:92): y = x[:, iidx] W^T + b computed as x Wfull^T + b with W scattered into a
+    zero (H, D) matrix kept per layer.  No (B, nI) gather forward, and the backward's input gradient comes out full-width
+    from the GEMM (zero in the transform columns) instead of a zero fill + index_add over the batch."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, iidx):
+        H, D = weight.shape[0], x.shape[1]
+        key = (weight.data_ptr(), H, D, str(weight.device))
+        wfull = _wfull_cache.get(key)
+        if wfull is None:
+            wfull = _wfull_cache[key] = torch.zeros(H, D, dtype=weight.dtype, device=weight.device)
+        wfull.index_copy_(1, iidx, weight.detach())
+        ctx.save_for_backward(x, iidx)
+        ctx.wfull = wfull
+        return torch.addmm(bias.detach(), x, wfull.t())
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, iidx = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gy @ ctx.wfull if ctx.needs_input_grad[0] else None
+        gwf, gb = ops.linear_wgrad(gy, x, want_bias=True)
+        return gx, gwf.index_select(1, iidx), gb, None
+
+
+_wfull_cache = {}
 
 
 class ResidualBlockFn(torch.autograd.Function):

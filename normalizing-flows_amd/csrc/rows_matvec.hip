@@ -85,14 +85,15 @@ lu_compose_kernel(const int64_t *__restrict__ perm, const float *__restrict__ lo
 
 // Training-side helpers of LULinearPermute (mixing.py:402-473 under autograd): one launch instead of a dozen element-wise /
 // indexing launches each.  nf_lu_factors: out = L (D x D, unit diagonal) | U (D x D, diagonal softplus(u) + eps) | Up (D x D,
-// Up[:, perm[j]] = U[:, j], so that Up x = U x[perm]) | diag (D) | log|det| = sum log diag (1).
+// Up[:, perm[j]] = U[:, j], so that Up x = U x[perm]) | diag (D) | log|det| = sum log diag (1) | L^T (D x D) | Up^T (D x D)
+// (the backward's two row mat-vecs take the transposes: emitted here instead of two transpose-copy launches per layer).
 __global__ void __launch_bounds__(256)
 lu_factors_kernel(const int64_t *__restrict__ perm, const float *__restrict__ lower_entries,
                   const float *__restrict__ upper_entries, const float *__restrict__ udiag_raw, float eps,
                   float *__restrict__ out, int D) {
     __shared__ float sred[16];
     const int N = D * D, tid = threadIdx.x;
-    float *Lm = out, *Um = out + N, *Up = out + 2 * N, *dg = out + 3 * N, *lad = dg + D;
+    float *Lm = out, *Um = out + N, *Up = out + 2 * N, *dg = out + 3 * N, *lad = dg + D, *LT = lad + 1, *UpT = LT + N;
     for (int i = tid; i < N; i += 256) {
         const int r = i / D, c = i - r * D;
         float l = 0.0f, u = 0.0f;
@@ -102,6 +103,8 @@ lu_factors_kernel(const int64_t *__restrict__ perm, const float *__restrict__ lo
         Lm[i] = l;
         Um[i] = u;
         Up[r * D + (int)perm[c]] = u;
+        LT[c * D + r] = l;
+        UpT[(int)perm[c] * D + r] = u;
     }
     float part = 0.0f;
     for (int i = tid; i < D; i += 256) {
@@ -113,23 +116,37 @@ lu_factors_kernel(const int64_t *__restrict__ perm, const float *__restrict__ lo
     if (tid == 0) *lad = s;
 }
 
-// Parameter gradients from the dense factor gradients gL, gU (D x D) and the summed log-det cotangent gl_sum (device
-// scalar): g_lower / g_upper = sign * the strictly triangular entries (packed row-major as the parameters are),
+// Parameter gradients from the dense factor gradients gL, gU (D x D; gU's columns taken through perm when given) and the
+// log-det cotangent gld (B, summed here): g_lower / g_upper = sign * the strictly triangular entries (packed row-major as the parameters are),
 // g_udiag = sign * (gU[r][r] + gl_sum / diag[r]) * softplus'(u_r).
-__global__ void __launch_bounds__(256)
-lu_param_grads_kernel(const float *__restrict__ gL, const float *__restrict__ gU, const float *__restrict__ gl_sum,
-                      const float *__restrict__ udiag_raw, float eps, float sign, float *__restrict__ g_lower,
-                      float *__restrict__ g_upper, float *__restrict__ g_udiag, int D) {
+__global__ void __launch_bounds__(1024)
+lu_param_grads_kernel(const float *__restrict__ gL, const float *__restrict__ gU, const int64_t *__restrict__ perm,
+                      const float *__restrict__ gld, int64_t B, const float *__restrict__ udiag_raw, float eps, float sign,
+                      float *__restrict__ g_lower, float *__restrict__ g_upper, float *__restrict__ g_udiag, int D) {
+    __shared__ float sred[16];
     const int N = D * D;
-    const float gl = gl_sum ? *gl_sum : 0.0f;
+    float gl = 0.0f;
+    if (gld) {      // every workgroup sums the (B) cotangent itself, in the same order: no reduction launch, same value everywhere
+        float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+        const int64_t B4 = (reinterpret_cast<uintptr_t>(gld) & 15) == 0 ? B / 4 : 0;
+        const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gld);
+#pragma unroll 8
+        for (int64_t b = threadIdx.x; b < B4; b += 1024) {
+            const f32x4 v = g4[b];
+            p0 += v[0]; p1 += v[1]; p2 += v[2]; p3 += v[3];
+        }
+        for (int64_t b = 4 * B4 + threadIdx.x; b < B; b += 1024) p0 += gld[b];
+        gl = block_sum((p0 + p1) + (p2 + p3), sred);
+    }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
         const int r = i / D, c = i - r * D;
-        if (c < r) g_lower[r * (r - 1) / 2 + c] = sign * gL[i];
-        else if (c > r) g_upper[r * (D - 1) - r * (r - 1) / 2 + (c - r - 1)] = sign * gU[i];
+        if (c < r) { g_lower[r * (r - 1) / 2 + c] = sign * gL[i]; continue; }
+        const float gu = perm ? gU[r * D + (int)perm[c]] : gU[i];      // column select of gu^T x folded in
+        if (c > r) g_upper[r * (D - 1) - r * (r - 1) / 2 + (c - r - 1)] = sign * gu;
         else {
             const float u = udiag_raw[r], d = softplus(u) + eps;
             const float sg = u > 20.0f ? 1.0f : sigmoid(u);
-            g_udiag[r] = sign * (gU[i] + gl / d) * sg;
+            g_udiag[r] = sign * (gu + gl / d) * sg;
         }
     }
 }
@@ -234,14 +251,14 @@ extern "C" int nf_lu_factors(const int64_t *perm, const void *lower_entries, con
     return NF_OK;
 }
 
-extern "C" int nf_lu_param_grads(const void *gL, const void *gU, const void *gl_sum, const void *unconstrained_upper_diag,
-                                 double eps, double sign, void *g_lower, void *g_upper, void *g_udiag, int D,
-                                 nf_stream_t stream) {
+extern "C" int nf_lu_param_grads(const void *gL, const void *gU, const int64_t *perm, const void *gld, int64_t B,
+                                 const void *unconstrained_upper_diag, double eps, double sign, void *g_lower, void *g_upper,
+                                 void *g_udiag, int D, nf_stream_t stream) {
     if (D < 1) return NF_EINVAL;
     if (!gL || !gU || !unconstrained_upper_diag || !g_udiag || (D > 1 && (!g_lower || !g_upper))) return NF_EFAULT;
-    const int grid = (D * D + 255) / 256;
-    hipLaunchKernelGGL(lu_param_grads_kernel, dim3(grid < 64 ? grid : 64), dim3(256), 0, (hipStream_t)stream, (const float *)gL,
-                       (const float *)gU, (const float *)gl_sum, (const float *)unconstrained_upper_diag, (float)eps, (float)sign,
+    const int grid = (D * D + 1023) / 1024;
+    hipLaunchKernelGGL(lu_param_grads_kernel, dim3(grid < 64 ? grid : 64), dim3(1024), 0, (hipStream_t)stream, (const float *)gL,
+                       (const float *)gU, perm, (const float *)gld, B, (const float *)unconstrained_upper_diag, (float)eps, (float)sign,
                        (float *)g_lower, (float *)g_upper, (float *)g_udiag, D);
     NF_CHECK_LAUNCH();
     return NF_OK;

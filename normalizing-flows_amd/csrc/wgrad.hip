@@ -313,7 +313,7 @@ static int wgrad_tile_chunk_rows(int64_t B, int M) {
 constexpr int RL = 16;
 __global__ void __launch_bounds__(64 * RL)
 wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, float *__restrict__ db, int64_t nW, int64_t n,
-                    int64_t stride, int chunks, int accumulate) {
+                    int64_t stride, int chunks, int accumulate, int N, int skip_every) {
     __shared__ float sm[RL][64];
     const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
     for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < n; e0 += (int64_t)gridDim.x * 64) {
@@ -336,7 +336,11 @@ wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, floa
 #pragma unroll
             for (int i = 0; i < RL; ++i) s += sm[i][el];
             float *o = e < nW ? dW + e : db + (e - nW);
-            *o = accumulate ? *o + s : s;
+            if (skip_every) {       // every skip_every-th row of dY is padding: not part of the (M - M / skip_every)-row outputs
+                const int64_t m = e < nW ? e / N : e - nW, g = m / skip_every;
+                o = (m - g * skip_every == skip_every - 1) ? nullptr : (e < nW ? dW + e - g * N : db + (m - g));
+            }
+            if (o) *o = accumulate ? *o + s : s;
         }
         __syncthreads();
     }
@@ -375,16 +379,21 @@ extern "C" int64_t nf_linear_wgrad_scratch_floats(int64_t B, int M, int N) {
     return chunks * ((int64_t)M * N + M);
 }
 
-extern "C" int nf_linear_wgrad_act(const void *dY, const void *X, void *dW, void *db, void *scratch, int64_t B, int M, int N,
-                                   int accumulate, int relu_x, nf_stream_t stream);
-extern "C" int nf_linear_wgrad(const void *dY, const void *X, void *dW, void *db, void *scratch, int64_t B, int M, int N,
-                               int accumulate, nf_stream_t stream) {
-    return nf_linear_wgrad_act(dY, X, dW, db, scratch, B, M, N, accumulate, 0, stream);
-}
-
+extern "C" int nf_linear_wgrad_skip(const void *dY, const void *X, void *dW, void *db, void *scratch, int64_t B, int M, int N,
+                                    int accumulate, int relu_x, int skip_every, nf_stream_t stream);
 extern "C" int nf_linear_wgrad_act(const void *dY, const void *X, void *dW, void *db, void *scratch, int64_t B, int M, int N,
                                    int accumulate, int relu_x, nf_stream_t stream) {
+    return nf_linear_wgrad_skip(dY, X, dW, db, scratch, B, M, N, accumulate, relu_x, 0, stream);
+}
+extern "C" int nf_linear_wgrad(const void *dY, const void *X, void *dW, void *db, void *scratch, int64_t B, int M, int N,
+                               int accumulate, nf_stream_t stream) {
+    return nf_linear_wgrad_skip(dY, X, dW, db, scratch, B, M, N, accumulate, 0, 0, stream);
+}
+
+extern "C" int nf_linear_wgrad_skip(const void *dY, const void *X, void *dW, void *db, void *scratch, int64_t B, int M, int N,
+                                    int accumulate, int relu_x, int skip_every, nf_stream_t stream) {
     if (B < 1 || M < 1 || N < 1 || (accumulate != 0 && accumulate != 1) || (relu_x != 0 && relu_x != 1)) return NF_EINVAL;
+    if (skip_every < 0 || skip_every == 1 || (skip_every && M % skip_every != 0)) return NF_EINVAL;
     if (N > 128) return NF_ENOTSUP;  // four 32-column tiles of accumulators per wave
     if (!dY || !X || !dW || !scratch) return NF_EFAULT;
     hipStream_t st = (hipStream_t)stream;
@@ -420,7 +429,7 @@ extern "C" int nf_linear_wgrad_act(const void *dY, const void *X, void *dW, void
     NF_CHECK_LAUNCH();
     const int64_t nW = (int64_t)M * N, n = nW + (db ? M : 0);
     hipLaunchKernelGGL(nf::wgrad_reduce_kernel, dim3(nf::grid_for(n, 64)), dim3(64 * nf::RL), 0, st, part, (float *)dW, (float *)db,
-                       nW, n, nW + M, chunks, accumulate);
+                       nW, n, nW + M, chunks, accumulate, N, skip_every);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

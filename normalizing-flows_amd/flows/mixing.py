@@ -282,14 +282,9 @@ class LULinearPermute(Flow):
         lin = self.linear
         if needs_grad(z, self):   # training path (autograd.py): same forward kernel, GEMM-based backward
             y, log_det = LULinearPermuteFn.apply(z, self.permutation._permutation, lin.lower_entries, lin.upper_entries,
-                                                 lin.unconstrained_upper_diag, lin.bias, lin.eps, 0 if inverse else 1)
-            if ld is not None:
-                if acc is None or acc > 0:
-                    ld += log_det
-                else:
-                    ld -= log_det
-                return y, ld
-            return y, log_det
+                                                 lin.unconstrained_upper_diag, lin.bias, lin.eps, 0 if inverse else 1,
+                                                 ld, 1 if (acc is None or acc > 0) else -1)
+            return y, log_det            # log_det IS ld (updated in place) when the caller passed its accumulator
         if z.dtype == torch.float32 and z.is_cuda and lin.features <= 64 and self.use_dense:
             # the layer as ONE dense D x D product on fp32 MFMA (nf_lu_compose once per parameter version + nf_rows_matvec_affine):
             # HBM-bound, 5x the LDS-tile kernel below, which stays for D > 64 and float64

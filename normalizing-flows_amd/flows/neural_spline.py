@@ -18,7 +18,7 @@ from torch import nn
 
 from .. import _lib as L
 from .. import ops
-from ..autograd import CouplingDensityFn, FinalSplineDensityFn, SplineFn, needs_grad
+from ..autograd import CouplingDensityFn, FinalSplineDensityFn, IdentLinearFn, SplineFn, needs_grad
 from ..nets import PeriodicFeaturesElementwise, ResidualNet
 from ..utils.masks import create_alternating_binary_mask
 from .base import Flow
@@ -428,13 +428,13 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
     def _autograd(self, inputs, context, sample, ld, acc):
         kw = self._kernel_kwargs()
         u = self.unconditional_transform
-        ident = inputs.index_select(1, self.identity_features)
         if (not sample and self.use_fused and self.use_fused_train and inputs.is_cuda and inputs.shape[0] >= 1024
                 and self._fused_eligible(inputs, context) and not self._fused_padded() and u is not None):
             # the benchmark shape: trunk (initial layer + residual blocks, autograd-tracked), then the final Linear + the
             # coupling transform as ONE launch (FinalSplineDensityFn)
             net = self.transform_net
-            h2 = net.initial_layer(ident)
+            inputs = inputs.contiguous()
+            h2 = IdentLinearFn.apply(inputs, net.initial_layer.weight, net.initial_layer.bias, self.identity_features)
             for block in net.blocks:
                 h2 = block(h2)
             blob = self.__dict__.get("_train_blob")
@@ -445,14 +445,10 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
             outputs, log_det = FinalSplineDensityFn.apply(inputs.contiguous(), h2, net.final_layer.weight, net.final_layer.bias,
                                                           u.unnormalized_widths, u.unnormalized_heights,
                                                           u.unnormalized_derivatives, self.identity_features,
-                                                          self.transform_features, blob, self._fused_parity, len(net.blocks), fkw)
-            if ld is not None:
-                if acc is None or acc > 0:
-                    ld += log_det
-                else:
-                    ld -= log_det
-                return outputs, ld
-            return outputs, log_det
+                                                          self.transform_features, blob, self._fused_parity, len(net.blocks), fkw,
+                                                          ld, 1 if (acc is None or acc > 0) else -1)
+            return outputs, log_det      # log_det IS ld (updated inside the launch) when the caller passed its accumulator
+        ident = inputs.index_select(1, self.identity_features)
         if not sample:   # nsf/coupling.py:71-98 as one forward + one backward kernel on full rows
             cond = self.transform_net(ident, context)
             uw, uh, ud = (u.unnormalized_widths, u.unnormalized_heights, u.unnormalized_derivatives) if u is not None \

@@ -362,26 +362,32 @@ def lu_compose(perm, lower_entries, upper_entries, unconstrained_upper_diag, bia
 
 
 def lu_factors(perm, lower_entries, upper_entries, unconstrained_upper_diag, eps=1e-3):
-    """(L, U, Up, diag, log|det| (1-element)) of LULinearPermute's factors in one launch (nf_lu_factors); float32."""
+    """(L, U, Up, diag, log|det| (1-element), L^T, Up^T) of LULinearPermute's factors in one launch (nf_lu_factors); float32."""
     L.require_device(perm, lower_entries, upper_entries, unconstrained_upper_diag)
     D = unconstrained_upper_diag.numel()
-    out = torch.empty(3 * D * D + D + 1, dtype=torch.float32, device=unconstrained_upper_diag.device)
+    out = torch.empty(5 * D * D + D + 1, dtype=torch.float32, device=unconstrained_upper_diag.device)
     rc = L.lib().nf_lu_factors(ptr(perm), ptr(lower_entries.contiguous()), ptr(upper_entries.contiguous()),
                                ptr(unconstrained_upper_diag.contiguous()), f64(eps), ptr(out), i32(D), L.stream())
     L.check(rc, "nf_lu_factors")
     N = D * D
-    return out[:N].view(D, D), out[N:2 * N].view(D, D), out[2 * N:3 * N].view(D, D), out[3 * N:3 * N + D], out[3 * N + D:]
+    e = 3 * N + D + 1
+    return (out[:N].view(D, D), out[N:2 * N].view(D, D), out[2 * N:3 * N].view(D, D), out[3 * N:3 * N + D], out[3 * N + D:e],
+            out[e:e + N].view(D, D), out[e + N:e + 2 * N].view(D, D))
 
 
-def lu_param_grads(gL, gU, gl_sum, unconstrained_upper_diag, n_tri, eps=1e-3, sign=1.0):
-    """(g_lower, g_upper, g_udiag) from the dense factor gradients (nf_lu_param_grads); float32."""
-    L.require_device(gL, gU, gl_sum, unconstrained_upper_diag)
+def lu_param_grads(gL, gU, gld, unconstrained_upper_diag, n_tri, eps=1e-3, sign=1.0, perm=None):
+    """(g_lower, g_upper, g_udiag) from the dense factor gradients (nf_lu_param_grads); float32.  gld: the (B) log-det
+    cotangent (summed inside the launch) or None; perm: gU's columns are read through it (gU = (gu^T x)[:, perm])."""
+    L.require_device(gL, gU, gld, unconstrained_upper_diag, perm)
+    if gld is not None:
+        gld = gld.contiguous()
     D = unconstrained_upper_diag.numel()
     dev = gL.device
     g_lower = torch.empty(n_tri, dtype=torch.float32, device=dev)
     g_upper = torch.empty(n_tri, dtype=torch.float32, device=dev)
     g_udiag = torch.empty(D, dtype=torch.float32, device=dev)
-    rc = L.lib().nf_lu_param_grads(ptr(gL.contiguous()), ptr(gU.contiguous()), ptr(gl_sum), ptr(unconstrained_upper_diag.contiguous()),
+    rc = L.lib().nf_lu_param_grads(ptr(gL.contiguous()), ptr(gU.contiguous()), ptr(perm), ptr(gld),
+                                   i64(0 if gld is None else gld.numel()), ptr(unconstrained_upper_diag.contiguous()),
                                    f64(eps), f64(sign), ptr(g_lower), ptr(g_upper), ptr(g_udiag), i32(D), L.stream())
     L.check(rc, "nf_lu_param_grads")
     return g_lower, g_upper, g_udiag
@@ -584,18 +590,21 @@ def rqs_fused_pack_final(blob, w_final, b_final, uw, uh, ud, num_blocks, tail_bo
 
 
 def rqs_fused_train_fwd(x, h2, blob, mask_parity, num_blocks, tail_bound=3.0, min_bin_width=1e-3, min_bin_height=1e-3,
-                        min_derivative=1e-3):
+                        min_derivative=1e-3, logdet=None, acc=None):
     """(y, logdet, cond24) of nf_rqs_fused_train_fwd: final Linear + density-direction coupling transform in one launch;
-    cond24 (B, 32, 24) is the conditioner output kept for rqs_coupling_bwd_p24."""
+    cond24 (B, 32, 24) is the conditioner output kept for rqs_coupling_bwd_p24.  logdet given: folded into it per acc."""
     L.require_device(x, h2, blob)
     x, h2 = x.contiguous(), h2.contiguous()
     B = x.shape[0]
     y = torch.empty_like(x)
-    ld = torch.empty(B, dtype=x.dtype, device=x.device)
+    if logdet is None:
+        ld, acc = torch.empty(B, dtype=x.dtype, device=x.device), L.LD_WRITE
+    else:
+        ld, acc = logdet, (L.LD_ADD if acc is None else acc)
     cond = torch.empty(B, 32, 24, dtype=x.dtype, device=x.device)
     rc = L.lib().nf_rqs_fused_train_fwd(ptr(x), ptr(h2), ptr(y), ptr(ld), ptr(cond), ptr(blob), i32(mask_parity), i64(B), i32(64),
                                         i32(128), i32(num_blocks), i32(8), f64(tail_bound), f64(min_bin_width),
-                                        f64(min_bin_height), f64(min_derivative), i32(L.LD_WRITE), L.stream())
+                                        f64(min_bin_height), f64(min_derivative), i32(acc), L.stream())
     L.check(rc, "nf_rqs_fused_train_fwd")
     return y, ld, cond
 
@@ -608,7 +617,9 @@ def rqs_coupling_bwd_p24(x, grad_y, grad_logdet, cond24, uw, uh, ud, identity_id
     x, grad_y, grad_logdet = x.contiguous(), grad_y.contiguous(), grad_logdet.contiguous()
     gx = torch.empty_like(x)
     gcond = torch.empty_like(cond24)
-    guw, guh, gud = torch.zeros_like(uw), torch.zeros_like(uh), torch.zeros_like(ud)
+    nw, nh = uw.numel(), uh.numel()                        # one zero fill for the three atomically-accumulated outputs
+    gz = torch.zeros(nw + nh + ud.numel(), dtype=uw.dtype, device=uw.device)
+    guw, guh, gud = gz[:nw].view_as(uw), gz[nw:nw + nh].view_as(uh), gz[nw + nh:].view_as(ud)
     rc = L.lib().nf_rqs_coupling_bwd_p24(ptr(x), ptr(grad_y), ptr(grad_logdet), ptr(cond24), ptr(uw), ptr(uh), ptr(ud),
                                          ptr(identity_idx), i32(identity_idx.numel()), ptr(transform_idx),
                                          i32(transform_idx.numel()), i64(B), i32(D), f64(tail_bound), f64(min_bin_width),
@@ -890,22 +901,23 @@ def diag_gaussian_log_prob_rows(z, loc_rows, log_scale_rows, row_idx=None, ls_sh
     return out
 
 
-def linear_wgrad(dy, x, want_bias=True, relu_x=False):
-    """dW = dy^T x (x -> relu(x) with relu_x), db = dy.sum(0) for a Linear layer (nf_linear_wgrad[_act], split-K fp32 MFMA,
-    deterministic reduction)."""
+def linear_wgrad(dy, x, want_bias=True, relu_x=False, skip_every=0):
+    """dW = dy^T x (x -> relu(x) with relu_x), db = dy.sum(0) for a Linear layer (nf_linear_wgrad[_act|_skip], split-K fp32
+    MFMA, deterministic reduction).  skip_every > 1: every skip_every-th column of dy is padding and has no output row."""
     L.require_device(dy, x)
     if dy.dtype != torch.float32 or x.dtype != torch.float32:
         raise NotImplementedError("linear_wgrad: float32 only")
     dy, x = dy.contiguous(), x.contiguous()
     B, M = dy.shape
     N = x.shape[1]
-    dW = torch.empty(M, N, dtype=torch.float32, device=dy.device)
-    db = torch.empty(M, dtype=torch.float32, device=dy.device) if want_bias else None
+    Mo = M - M // skip_every if skip_every else M
+    dW = torch.empty(Mo, N, dtype=torch.float32, device=dy.device)
+    db = torch.empty(Mo, dtype=torch.float32, device=dy.device) if want_bias else None
     n = L.lib().nf_linear_wgrad_scratch_floats(i64(B), i32(M), i32(N))
     scratch = torch.empty(max(int(n), 1), dtype=torch.float32, device=dy.device)
-    rc = L.lib().nf_linear_wgrad_act(ptr(dy), ptr(x), ptr(dW), ptr(db), ptr(scratch), i64(B), i32(M), i32(N), i32(0),
-                                     i32(int(relu_x)), L.stream())
-    L.check(rc, "nf_linear_wgrad_act")
+    rc = L.lib().nf_linear_wgrad_skip(ptr(dy), ptr(x), ptr(dW), ptr(db), ptr(scratch), i64(B), i32(M), i32(N), i32(0),
+                                      i32(int(relu_x)), i32(int(skip_every)), L.stream())
+    L.check(rc, "nf_linear_wgrad_skip")
     return dW, db
 
 
