@@ -94,7 +94,7 @@ lu_factors_kernel(const int64_t *__restrict__ perm, const float *__restrict__ lo
     __shared__ float sred[16];
     const int N = D * D, tid = threadIdx.x;
     float *Lm = out, *Um = out + N, *Up = out + 2 * N, *dg = out + 3 * N, *lad = dg + D, *LT = lad + 1, *UpT = LT + N;
-    for (int i = tid; i < N; i += 256) {
+    for (int i = blockIdx.x * 256 + tid; i < N; i += gridDim.x * 256) {      // one element per thread at D = 64 (16 workgroups)
         const int r = i / D, c = i - r * D;
         float l = 0.0f, u = 0.0f;
         if (c < r) l = lower_entries[r * (r - 1) / 2 + c];
@@ -106,6 +106,7 @@ lu_factors_kernel(const int64_t *__restrict__ perm, const float *__restrict__ lo
         LT[c * D + r] = l;
         UpT[(int)perm[c] * D + r] = u;
     }
+    if (blockIdx.x != 0) return;
     float part = 0.0f;
     for (int i = tid; i < D; i += 256) {
         const float d = softplus(udiag_raw[i]) + eps;
@@ -245,7 +246,7 @@ extern "C" int nf_lu_factors(const int64_t *perm, const void *lower_entries, con
                              const void *unconstrained_upper_diag, double eps, void *out, int D, nf_stream_t stream) {
     if (D < 1) return NF_EINVAL;
     if (!perm || !unconstrained_upper_diag || !out || (D > 1 && (!lower_entries || !upper_entries))) return NF_EFAULT;
-    hipLaunchKernelGGL(lu_factors_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, perm, (const float *)lower_entries,
+    hipLaunchKernelGGL(lu_factors_kernel, dim3((D * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, perm, (const float *)lower_entries,
                        (const float *)upper_entries, (const float *)unconstrained_upper_diag, (float)eps, (float *)out, D);
     NF_CHECK_LAUNCH();
     return NF_OK;

@@ -106,6 +106,44 @@ __global__ void pack_header_kernel(float *__restrict__ hdr, int nblk) {
     }
 }
 
+// Header + final-layer stages + knot tables in ONE launch: what nf_rqs_fused_pack_final writes once per training step and
+// layer (three launches before).  The last workgroup also does the two single-wave jobs.
+__global__ void pack_final_all_kernel(const float *__restrict__ W, const float *__restrict__ b, float *__restrict__ stages,
+                                      float *__restrict__ bias_dst, float wh_scale, float *__restrict__ hdr, int nblk,
+                                      const float *__restrict__ uw, const float *__restrict__ uh,
+                                      const float *__restrict__ ud, float *__restrict__ tab, RqsParams<float> p) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 24 * F_STAGE; i += gridDim.x * blockDim.x) {
+        const int r4 = i & 3, lane = (i >> 2) & 63, s = (i >> 8) & 15, st = i >> 12;
+        const int g = st / 3, rb = st % 3;
+        const int row = final_row(g, rb, lane & 31);
+        const int k = 8 * s + 4 * (lane >> 5) + r4;
+        const float sc = (row >= 0 && (row % F_M) < 2 * F_K) ? wh_scale : 1.0f;
+        stages[i] = row >= 0 ? W[row * F_H + k] * sc : 0.0f;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 768; i += gridDim.x * blockDim.x) {
+        const int reg = i & 15, hh = (i >> 4) & 1, st = i >> 5;
+        const int g = st / 3, rb = st % 3;
+        const int row = final_row(g, rb, 8 * (reg >> 2) + 4 * hh + (reg & 3));
+        const float sc = (row >= 0 && (row % F_M) < 2 * F_K) ? wh_scale : 1.0f;
+        bias_dst[i] = row >= 0 ? b[row] * sc : 0.0f;
+    }
+    if (blockIdx.x != gridDim.x - 1) return;
+    const int j = threadIdx.x;
+    if (j == 0) {
+        hdr[0] = 355.0f;
+        hdr[1] = (float)nblk;
+        hdr[2] = 0.0f;
+        hdr[3] = 0.0f;
+    }
+    if (j < F_NI) {
+        const float *wj = uw + j * F_K, *hj = uh + j * F_K, *dj = ud + j * (F_K - 1);
+        auto wacc = [=](int k) { return wj[k]; };
+        auto hacc = [=](int k) { return hj[k]; };
+        auto dacc = [=](int k) { return dj[k]; };
+        rqs_build_table<float>(p, wacc, hacc, dacc, tab + j * F_TABW);
+    }
+}
+
 
 // LULinearPermute as ONE dense 64 x 64 matrix per direction (mixing.py:402-473, :535-563), composed in fp64:
 //   density: y = L (U x[perm]) + b            -> W_d[i][perm[j]] = (L U)[i][j],            bias_d = b
@@ -710,14 +748,12 @@ extern "C" int nf_rqs_fused_pack_final(void *wpack, const void *w_final, const v
     float *blob = (float *)wpack;
     float *small = blob + F_HDR;
     float *stages = blob + lay.off_stages();
-    hipLaunchKernelGGL(pack_header_kernel, dim3(1), dim3(64), 0, st, blob, num_blocks);
-    hipLaunchKernelGGL(pack_final_kernel, dim3(384), dim3(256), 0, st, (const float *)w_final, (const float *)b_final,
-                       stages + (size_t)(1 + 8 * num_blocks) * F_STAGE, small + lay.off_bias_final(),
-                       (float)(1.4426950408889634 / sqrt((double)hidden)));
     auto p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
                                     min_derivative, 1.0);
-    hipLaunchKernelGGL(pack_tables_kernel, dim3(1), dim3(64), 0, st, (const float *)uw, (const float *)uh,
-                       (const float *)ud, small + lay.off_tables(), p);
+    hipLaunchKernelGGL(pack_final_all_kernel, dim3(384), dim3(256), 0, st, (const float *)w_final, (const float *)b_final,
+                       stages + (size_t)(1 + 8 * num_blocks) * F_STAGE, small + lay.off_bias_final(),
+                       (float)(1.4426950408889634 / sqrt((double)hidden)), blob, num_blocks, (const float *)uw,
+                       (const float *)uh, (const float *)ud, small + lay.off_tables(), p);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

@@ -28,7 +28,7 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     step()
     torch.cuda.synchronize()
 by = collections.Counter()
@@ -42,6 +42,7 @@ for ev in prof.events():
             where = fr.split("/")[-1]
             if "ops.py" not in where and "_lib.py" not in where:
                 break
+    where = str(ev.input_shapes)[:70]
     by[(ev.name, where)] += 1
     tm[(ev.name, where)] += ev.self_device_time_total
 tot = sum(tm.values())
