@@ -463,7 +463,10 @@ rqs_coupling_bwd_wave_kernel(const float *__restrict__ x, const float *__restric
     float *s_prm = s_ud + (size_t)nI * nd;                       // nI * 24: shared parameters in rqs_regs order (w, h x log2 e)
     float *w_cond = s_prm + (size_t)nI * 24 + (size_t)wid * per_wave;
     float *w_x = w_cond + (size_t)SPW * nT * CP, *w_gy = w_x + (size_t)SPW * D, *w_gx = w_gy + (size_t)SPW * D;
-    int *s_iidx = reinterpret_cast<int *>(s_prm + (size_t)nI * 24 + (size_t)nwv * per_wave);
+    // the identity half's per-lane running sums (shared parameters): 64 lanes x 25 floats per wave, conflict-free stride.  In
+    // registers they cost 24 VGPRs across the whole loop, which spilled (19 VGPRs, 80 B of scratch per lane at 2 waves / SIMD)
+    float *w_racc = s_prm + (size_t)nI * 24 + (size_t)nwv * per_wave + (size_t)wid * 64 * 25 + (size_t)lane * 25;
+    int *s_iidx = reinterpret_cast<int *>(s_prm + (size_t)nI * 24 + (size_t)nwv * per_wave + (size_t)nwv * 64 * 25);
     int *s_tidx = s_iidx + nI;
     const bool do_t = mode != NF_RQS_SAMPLE_IDENTITY, do_i = mode != NF_RQS_SAMPLE_TRANSFORM;
     const bool inverse = mode != NF_RQS_DENSITY;
@@ -494,9 +497,8 @@ rqs_coupling_bwd_wave_kernel(const float *__restrict__ x, const float *__restric
     // identity half: when one pass covers its elements with one lane each (SPW nI <= 64), a lane keeps the same shared
     // feature for the whole launch: its parameter gradients accumulate in REGISTERS and meet the other lanes once, at the end
     const bool reg_acc = do_i && has_uncond && SPW * nI <= 64;
-    float racc[24];
 #pragma unroll
-    for (int k = 0; k < 24; ++k) racc[k] = 0.0f;
+    for (int k = 0; k < 25; ++k) w_racc[k] = 0.0f;
     for (int64_t b0 = gw * SPW; b0 < B; b0 += GW * SPW) {
         const int ns = (int)((B - b0) < SPW ? (B - b0) : SPW);
         for (int i = lane; i < ns * D; i += 64) {
@@ -564,7 +566,7 @@ rqs_coupling_bwd_wave_kernel(const float *__restrict__ x, const float *__restric
                     w_gx[s_ * D + col] = inverse ? rqs_regs_bwd<true>(p, xv, prm, gyv, gl, g, 1.0f)
                                                  : rqs_regs_bwd<false>(p, xv, prm, gyv, gl, g, 1.0f);
 #pragma unroll
-                    for (int k = 0; k < M; ++k) racc[k] += g[k];
+                    for (int k = 0; k < M; ++k) w_racc[k] += g[k];      // lane-private LDS words: plain read-add-write
                     continue;
                 }
                 RqsParams<float> pu = p;
@@ -603,7 +605,7 @@ rqs_coupling_bwd_wave_kernel(const float *__restrict__ x, const float *__restric
     if (reg_acc && lane < SPW * nI) {
         float *accj = s_acc + (size_t)(lane % nI) * M;
 #pragma unroll
-        for (int k = 0; k < M; ++k) atomicAdd(accj + k, racc[k]);
+        for (int k = 0; k < M; ++k) atomicAdd(accj + k, w_racc[k]);
     }
     __syncthreads();
     if (do_i && has_uncond) {
@@ -662,8 +664,8 @@ static int launch_bwd_wave(const void *x, const void *grad_y, const void *grad_l
     if (SPW < 1) SPW = 1;
     const size_t per_wave = (size_t)SPW * nT * CP + 3 * (size_t)SPW * D;
     const size_t ldsw = ((size_t)nI * F_M + (size_t)nI * ((2 * F_K) | 1) + (size_t)nI * (F_K - 1) + (size_t)nI * 24 +
-                         NF_BWD_WAVE_WAVES * per_wave) * sizeof(float) + (size_t)(nI + nT) * sizeof(int) + 16;
-    if (ldsw > 128 * 1024) return NF_ENOTSUP;
+                         NF_BWD_WAVE_WAVES * (per_wave + 64 * 25)) * sizeof(float) + (size_t)(nI + nT) * sizeof(int) + 16;
+    if (ldsw > 150 * 1024) return NF_ENOTSUP;
     // 8 waves per CU are resident (register-bound): one 8-wave workgroup per CU; more workgroups only add rounds
     // of global atomics on the shared parameters' 23 nI addresses at the end of each
     const int64_t nwaves = (B + SPW - 1) / SPW, gq = (nwaves + NF_BWD_WAVE_WAVES - 1) / NF_BWD_WAVE_WAVES;
