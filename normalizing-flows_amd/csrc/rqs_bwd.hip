@@ -621,6 +621,162 @@ rqs_coupling_bwd_wave_kernel(const float *__restrict__ x, const float *__restric
     }
 }
 
+
+// ---- the same kernel, software-pipelined, for the benchmark layer (nI = nT = 32, D = 64, density direction, shared identity
+// parameters, even B) --------------------------------------------------------------------------------------------------------
+// The wave-private kernel above runs load -> compute -> store per pass with nothing but the SIMD's second wave to hide the
+// round trips: measured 120 us of staging + 66 us of arithmetic = 186 us, the sum.  Here every pass's inputs (conditioner
+// rows, x, grad_y, grad_logdet of its 2 samples) arrive by LDS-DMA (global_load_lds, 16 bytes per lane, no registers) into
+// the buffer the PREVIOUS pass is not using, issued before the current pass's arithmetic; a counted s_waitcnt (memory
+// operations retire in order: everything younger than the current pass's loads may stay outstanding -- the previous pass's
+// S stores and the next pass's L loads) replaces the full drain.  No ordinary global load is left inside the loop, so the
+// compiler inserts no vmcnt wait of its own.  Gradient rows leave through 16-byte stores.
+template <int CP>
+__global__ void __launch_bounds__(64 * NF_BWD_WAVE_WAVES, NF_BWD_WAVE_OCC)
+rqs_coupling_bwd_pipe_kernel(const float *__restrict__ x, const float *__restrict__ gy, const float *__restrict__ gld,
+                             const float *__restrict__ cond, const float *__restrict__ uw, const float *__restrict__ uh,
+                             const float *__restrict__ ud, const int64_t *__restrict__ iidx,
+                             const int64_t *__restrict__ tidx, int64_t B, RqsParams<float> p, float *__restrict__ gx,
+                             float *__restrict__ gcond, float *__restrict__ guw, float *__restrict__ guh,
+                             float *__restrict__ gud) {
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int K = F_K, M = F_M, nd = F_K - 1, nI = 32, nT = 32, D = 64, SPW = 2;
+    constexpr int CONDF = SPW * nT * CP;            // 1536 | 1472 floats of conditioner rows per pass
+    constexpr int XOFF = 1536, GLOFF = XOFF + 2 * SPW * D, BUF = GLOFF + 4;     // cond | x | grad_y | grad_logdet (2 + pad)
+    constexpr int NC = (CONDF + 255) / 256;         // 1 KB DMA instructions for the rows
+    constexpr int LD_N = NC + 2, ST_N = NC + 1;     // VMEM instructions per pass: loads (rows, x|gy, gld), stores (rows, gx)
+    constexpr int PER_WAVE = 2 * BUF + SPW * D;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *s_acc = reinterpret_cast<float *>(smem_raw);           // nI * M: the workgroup's sums of the shared parameters
+    float *s_prm = s_acc + nI * M;                               // nI * 24: shared parameters in rqs_regs order (w, h x log2 e)
+    float *wbase = s_prm + nI * 24 + (size_t)wid * PER_WAVE;
+    float *w_gx = wbase + 2 * BUF;     // per wave: the pass's gx rows
+    int *s_iidx = reinterpret_cast<int *>(s_prm + nI * 24 + (size_t)NF_BWD_WAVE_WAVES * PER_WAVE);
+    int *s_tidx = s_iidx + nI;
+    for (int j = tid; j < nI; j += blockDim.x) s_iidx[j] = (int)iidx[j];
+    for (int j = tid; j < nT; j += blockDim.x) s_tidx[j] = (int)tidx[j];
+    for (int i = tid; i < nI * M; i += blockDim.x) s_acc[i] = 0.0f;
+    for (int i = tid; i < nI * 24; i += blockDim.x) {
+        const int j = i / 24, c = i - 24 * j;
+        s_prm[i] = c < K ? uw[(size_t)j * K + c] * 1.44269504088896340736f
+                         : (c < 2 * K ? uh[(size_t)j * K + c - K] * 1.44269504088896340736f
+                                      : (c < M ? ud[(size_t)j * nd + c - 2 * K] : 0.0f));
+    }
+    __syncthreads();
+
+    const float sc = 1.44269504088896340736f / p.wh_div, inv_div = 1.0f / p.wh_div;
+    const int64_t gw = (int64_t)blockIdx.x * NF_BWD_WAVE_WAVES + wid, GW = (int64_t)gridDim.x * NF_BWD_WAVE_WAVES;
+    auto issue = [&](int64_t b0, float *buf) {
+        const float *csrc = cond + b0 * (int64_t)(nT * CP);
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            if (q < NC - 1 || q * 256 + lane * 4 < CONDF)
+                __builtin_amdgcn_global_load_lds(csrc + q * 256 + lane * 4, (lds_ptr)(buf + q * 256), 16, 0, 0);
+        }
+        const float *xs = lane < 32 ? x + b0 * D + lane * 4 : gy + b0 * D + (lane - 32) * 4;
+        __builtin_amdgcn_global_load_lds(xs, (lds_ptr)(buf + XOFF), 16, 0, 0);
+        if (lane < SPW) __builtin_amdgcn_global_load_lds(gld + b0 + lane, (lds_ptr)(buf + GLOFF), 4, 0, 0);
+    };
+    const int s_ = lane >> 5, j = lane & 31;
+    const int col_t = s_tidx[j], col_i = s_iidx[j];
+    int64_t b0 = gw * SPW;
+    float *bufc = wbase, *bufn = wbase + BUF;
+    if (b0 < B) issue(b0, bufc);
+    bool first = true;
+    float racc[24];     // (this specialisation has the registers for it: 172 VGPRs without)
+#pragma unroll
+    for (int k = 0; k < 24; ++k) racc[k] = 0.0f;
+    for (; b0 < B; b0 += GW * SPW) {
+        const int64_t b1 = b0 + GW * SPW;
+        const bool more = b1 < B;
+        if (more) issue(b1, bufn);
+        if (first) {
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD_N) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD_N + ST_N) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST_N) : "memory");
+        }
+        first = false;
+        __builtin_amdgcn_wave_barrier();
+        const float gl = bufc[GLOFF + s_];
+        {   // transform half: lane = (sample, transform feature); gradient row written over the parameter row
+            float *row = bufc + (size_t)lane * CP;
+            float prm[24], g[24];
+            if constexpr (CP == 24) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(row + 4 * q);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) prm[4 * q + r] = q < 4 ? v[r] * sc : v[r];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 2 * K; ++k) prm[k] = row[k] * sc;
+#pragma unroll
+                for (int k = 2 * K; k < M; ++k) prm[k] = row[k];
+            }
+            prm[M] = 0.0f;
+            const float xv = bufc[XOFF + s_ * D + col_t], gyv = bufc[XOFF + SPW * D + s_ * D + col_t];
+            const float gxv = rqs_regs_bwd<false>(p, xv, prm, gyv, gl, g, inv_div);
+            if constexpr (CP == 24) {
+                g[M] = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+                    *reinterpret_cast<f32x4 *>(row + 4 * q) = f32x4{g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]};
+            } else {
+                // rows of 23 floats: the neighbour lane's parameters start right behind this lane's; every lane has read its
+                // row before any lane writes (the loads above are complete: g depends on all of them)
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < M; ++k) row[k] = g[k];
+            }
+            w_gx[s_ * D + col_t] = gxv;
+        }
+        {   // identity half: shared parameters, gradients summed per lane
+            float prm[24], g[24];
+            const float *pr = s_prm + (size_t)j * 24;
+#pragma unroll
+            for (int k = 0; k < 24; ++k) prm[k] = pr[k];
+            const float xv = bufc[XOFF + s_ * D + col_i], gyv = bufc[XOFF + SPW * D + s_ * D + col_i];
+            w_gx[s_ * D + col_i] = rqs_regs_bwd<false>(p, xv, prm, gyv, gl, g, 1.0f);
+#pragma unroll
+            for (int k = 0; k < M; ++k) racc[k] += g[k];      // a lane keeps its feature for the whole launch: register sums
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        {
+            float *dst = gcond + b0 * (int64_t)(nT * CP);
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                if (q < NC - 1 || q * 256 + lane * 4 < CONDF)
+                    *reinterpret_cast<f32x4 *>(dst + q * 256 + lane * 4) = *reinterpret_cast<const f32x4 *>(bufc + q * 256 + lane * 4);
+            }
+            if (lane < 32) *reinterpret_cast<f32x4 *>(gx + b0 * D + lane * 4) = *reinterpret_cast<const f32x4 *>(w_gx + lane * 4);
+        }
+        __builtin_amdgcn_wave_barrier();
+        float *t = bufc; bufc = bufn; bufn = t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+        float *accj = s_acc + (size_t)j * M;
+#pragma unroll
+        for (int k = 0; k < M; ++k) atomicAdd(accj + k, racc[k]);
+    }
+    __syncthreads();
+    for (int i = tid; i < nI * M; i += blockDim.x) {
+        const int jj = i / M, c = i - jj * M;
+        const float v = s_acc[i];
+        if (v != 0.0f) {
+            if (c < K) atomicAdd(guw + (size_t)jj * K + c, v);
+            else if (c < 2 * K) atomicAdd(guh + (size_t)jj * K + (c - K), v);
+            else atomicAdd(gud + (size_t)jj * nd + (c - 2 * K), v);
+        }
+    }
+}
+
 }  // namespace nf
 
 using namespace nf;
@@ -659,6 +815,25 @@ static int launch_bwd_wave(const void *x, const void *grad_y, const void *grad_l
                            int nT, int64_t B, int D, const nf::RqsParams<float> &p, int mode, void *grad_x, void *grad_cond,
                            void *grad_uw, void *grad_uh, void *grad_ud, hipStream_t st) {
     using namespace nf;
+#ifndef NF_BWD_NO_PIPE
+    if (nI == 32 && nT == 32 && D == 64 && mode == NF_RQS_DENSITY && uw && (B & 1) == 0 && B >= 2 &&
+        ((((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)cond | (uintptr_t)grad_cond | (uintptr_t)grad_x) & 15) == 0) &&
+        (((uintptr_t)grad_logdet & 3) == 0)) {
+        constexpr int BUFp = 1536 + 2 * 2 * 64 + 4, PERW = 2 * BUFp + 2 * 64;
+        const size_t ldsp = ((size_t)32 * F_M + 32 * 24 + (size_t)NF_BWD_WAVE_WAVES * PERW) * sizeof(float) + 64 * sizeof(int) + 16;
+        static LdsOptIn opted_p = {};
+        if (opt_in_lds(reinterpret_cast<const void *>(&rqs_coupling_bwd_pipe_kernel<CP>), ldsp, opted_p) == NF_OK) {
+            const int64_t nw2 = B / 2, gq2 = (nw2 + NF_BWD_WAVE_WAVES - 1) / NF_BWD_WAVE_WAVES;
+            const int grid2 = (int)(gq2 < 2048 / NF_BWD_WAVE_WAVES ? gq2 : 2048 / NF_BWD_WAVE_WAVES);
+            hipLaunchKernelGGL(rqs_coupling_bwd_pipe_kernel<CP>, dim3(grid2), dim3(64 * NF_BWD_WAVE_WAVES), ldsp, st,
+                               (const float *)x, (const float *)grad_y, (const float *)grad_logdet, (const float *)cond,
+                               (const float *)uw, (const float *)uh, (const float *)ud, identity_idx, transform_idx, B, p,
+                               (float *)grad_x, (float *)grad_cond, (float *)grad_uw, (float *)grad_uh, (float *)grad_ud);
+            NF_CHECK_LAUNCH();
+            return NF_OK;
+        }
+    }
+#endif
     const int nmax = nT > nI ? nT : nI;
     int SPW = nmax > 0 ? 64 / nmax : 1;
     if (SPW < 1) SPW = 1;
