@@ -325,6 +325,11 @@ int nf_linear_wgrad_act(const void *dY, const void *X, void *dW, void *db, void 
  * 23-row final layer: the un-padding happens in the reduction, not as two strided copies. */
 int nf_linear_wgrad_skip(const void *dY, const void *X, void *dW, void *db, void *scratch, int64_t B, int M, int N,
                          int accumulate, int relu_x, int skip_every, nf_stream_t stream);
+/* Two problems of the same shape (B, M, N) in one partial launch and one reduction -- the two weight gradients of a
+ * residual block (nets/resnet.py:37-50) become available together.  scratch: 2 x nf_linear_wgrad_scratch_floats(B, M, N);
+ * db0 / db1 both given or both NULL; vector / tile paths only (N % 4 == 0), NF_ENOTSUP otherwise. */
+int nf_linear_wgrad_pair(const void *dY0, const void *X0, void *dW0, void *db0, const void *dY1, const void *X1, void *dW1,
+                         void *db1, void *scratch, int64_t B, int M, int N, int accumulate, int relu_x, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Logit preprocessing transform of image tensors.  Replaces normflows/transforms.py:8-47.

@@ -225,8 +225,14 @@ class LULinearPermuteFn(torch.autograd.Function):
             gy = torch.zeros_like(y) if gy is None else gy.contiguous()
             gu = ops.rows_matvec(gy, LT)                # d/du = L^T gy
             gx = ops.rows_matvec(gu, UpT)               # d/dx = P (U^T gu)
-            gL, g_bias = _batch_outer(gy, u_saved, want_colsum=True)
-            gUx, _ = _batch_outer(gu, x)                # gu^T x; gU = (gu^T x)[:, perm]: taken through perm inside the launch
+            # gy^T u (+ the column sums of gy = the bias gradient) and gu^T x as ONE pair launch; gU = (gu^T x)[:, perm] is
+            # taken through perm inside nf_lu_param_grads
+            from . import config
+            if config.wgrad_pair and gy.shape[0] >= 1024:
+                gL, g_bias, gUx, _ = ops.linear_wgrad_pair(gy, u_saved, gu, x)
+            else:
+                gL, g_bias = _batch_outer(gy, u_saved, want_colsum=True)
+                gUx, _ = _batch_outer(gu, x)
             g_lower, g_upper, g_udiag = ops.lu_param_grads(gL, gUx, gld, udiag_raw.detach(), lower_entries.numel(),
                                                            eps=ctx.eps, sign=1.0, perm=perm)
             return gx, None, g_lower, g_upper, g_udiag, g_bias, None, None, g_acc, None
@@ -406,8 +412,12 @@ class ResidualBlockFn(torch.autograd.Function):
         gy = gy.contiguous()
         # gt = (gy W2) * (t > 0);  gx = gy + (gt W1) * (x > 0)
         gt, gx = ops.rows_block(gy, w2.detach(), None, w1.detach(), None, trans=True, mask1=t, mask2=x, relu=False)
-        gw2, gb2 = ops.linear_wgrad(gy, t, want_bias=True, relu_x=True)
-        gw1, gb1 = ops.linear_wgrad(gt, x, want_bias=True, relu_x=True)
+        from . import config
+        if config.wgrad_pair:
+            gw2, gb2, gw1, gb1 = ops.linear_wgrad_pair(gy, t, gt, x, relu_x=True)     # both layers: one launch + one reduction
+        else:
+            gw2, gb2 = ops.linear_wgrad(gy, t, want_bias=True, relu_x=True)
+            gw1, gb1 = ops.linear_wgrad(gt, x, want_bias=True, relu_x=True)
         return gx, gw1, gb1, gw2, gb2
 
 

@@ -42,3 +42,12 @@ def set_train_gemm(mode):
     if mode not in ("library", "rows"):
         raise ValueError("train_gemm must be 'library' or 'rows'")
     train_gemm = mode
+
+
+# The two weight gradients of a residual block as ONE pair launch (nf_linear_wgrad_pair); False = two single launches (ablation).
+wgrad_pair = True
+
+
+def set_wgrad_pair(mode=True):
+    global wgrad_pair
+    wgrad_pair = bool(mode)

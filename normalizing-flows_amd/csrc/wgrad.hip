@@ -24,7 +24,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <bool A_VEC, bool X_RELU>   // 8-byte dY loads need even M; template parameters keep the k loop a single basic block
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wgrad_partial_vec_kernel(const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ part, int64_t B,
-                         int M, int N, int chunk_rows, int want_bias) {
+                         int M, int N, int chunk_rows, int want_bias, int64_t zdY, int64_t zX, int64_t zpart) {
+    // blockIdx.z = 1: the second problem of a pair launch (same shape; its tensors sit at these element offsets from the first's)
+    dY += (int64_t)blockIdx.z * zdY;
+    X += (int64_t)blockIdx.z * zX;
+    part += (int64_t)blockIdx.z * zpart;
     const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.y * 64 + 2 * i;      // rows m0, m0 + 1 of dW
     const int n0 = 4 * i;                        // columns n0 .. n0 + 3
@@ -211,7 +215,10 @@ constexpr int W2_T = 128;     // tile edge (M and N)
 
 __global__ void __launch_bounds__(256, 2)
 wgrad_tile_kernel(const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ part, int64_t B, int M, int N,
-                  int chunk_rows, int want_bias, int x_relu) {
+                  int chunk_rows, int want_bias, int x_relu, int64_t zdY, int64_t zX, int64_t zpart) {
+    dY += (int64_t)blockIdx.z * zdY;
+    X += (int64_t)blockIdx.z * zX;
+    part += (int64_t)blockIdx.z * zpart;
     __shared__ __attribute__((aligned(16))) float As[2][W2_KS][W2_T];
     __shared__ __attribute__((aligned(16))) float Bs[2][W2_KS][W2_T];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i = lane & 31, h = lane >> 5;
@@ -313,7 +320,11 @@ static int wgrad_tile_chunk_rows(int64_t B, int M) {
 constexpr int RL = 16;
 __global__ void __launch_bounds__(64 * RL)
 wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, float *__restrict__ db, int64_t nW, int64_t n,
-                    int64_t stride, int chunks, int accumulate, int N, int skip_every) {
+                    int64_t stride, int chunks, int accumulate, int N, int skip_every, int64_t zpart, int64_t zdW,
+                    int64_t zdb) {
+    part += (int64_t)blockIdx.y * zpart;      // blockIdx.y = 1: the second problem of a pair launch
+    dW += (int64_t)blockIdx.y * zdW;
+    if (db) db += (int64_t)blockIdx.y * zdb;
     __shared__ float sm[RL][64];
     const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
     for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < n; e0 += (int64_t)gridDim.x * 64) {
@@ -390,8 +401,28 @@ extern "C" int nf_linear_wgrad(const void *dY, const void *X, void *dW, void *db
     return nf_linear_wgrad_skip(dY, X, dW, db, scratch, B, M, N, accumulate, 0, 0, stream);
 }
 
+static int wgrad_impl(const void *dY, const void *X, void *dW, void *db, void *scratch, int64_t B, int M, int N, int accumulate,
+                      int relu_x, int skip_every, nf_stream_t stream, const void *dY1, const void *X1, void *dW1, void *db1);
+
 extern "C" int nf_linear_wgrad_skip(const void *dY, const void *X, void *dW, void *db, void *scratch, int64_t B, int M, int N,
                                     int accumulate, int relu_x, int skip_every, nf_stream_t stream) {
+    return wgrad_impl(dY, X, dW, db, scratch, B, M, N, accumulate, relu_x, skip_every, stream, nullptr, nullptr, nullptr, nullptr);
+}
+
+// Two problems of the same shape in ONE partial launch and ONE reduction (a residual block's two weight gradients arrive
+// together: half the launches, and the second problem's workgroups fill the first's ramp and tail).  scratch: 2 x
+// nf_linear_wgrad_scratch_floats(B, M, N); db0 / db1 both given or both NULL.
+extern "C" int nf_linear_wgrad_pair(const void *dY0, const void *X0, void *dW0, void *db0, const void *dY1, const void *X1,
+                                    void *dW1, void *db1, void *scratch, int64_t B, int M, int N, int accumulate, int relu_x,
+                                    nf_stream_t stream) {
+    if (!dY1 || !X1 || !dW1 || ((db0 == nullptr) != (db1 == nullptr))) return NF_EFAULT;
+    if ((((uintptr_t)dY0 ^ (uintptr_t)dY1) | ((uintptr_t)X0 ^ (uintptr_t)X1) | ((uintptr_t)dW0 ^ (uintptr_t)dW1) |
+         ((uintptr_t)db0 ^ (uintptr_t)db1)) & 3) return NF_EINVAL;
+    return wgrad_impl(dY0, X0, dW0, db0, scratch, B, M, N, accumulate, relu_x, 0, stream, dY1, X1, dW1, db1);
+}
+
+static int wgrad_impl(const void *dY, const void *X, void *dW, void *db, void *scratch, int64_t B, int M, int N, int accumulate,
+                      int relu_x, int skip_every, nf_stream_t stream, const void *dY1, const void *X1, void *dW1, void *db1) {
     if (B < 1 || M < 1 || N < 1 || (accumulate != 0 && accumulate != 1) || (relu_x != 0 && relu_x != 1)) return NF_EINVAL;
     if (skip_every < 0 || skip_every == 1 || (skip_every && M % skip_every != 0)) return NF_EINVAL;
     if (N > 128) return NF_ENOTSUP;  // four 32-column tiles of accumulators per wave
@@ -403,13 +434,19 @@ extern "C" int nf_linear_wgrad_skip(const void *dY, const void *X, void *dW, voi
     const int chunks = (int)((B + rows - 1) / rows);
     float *part = (float *)scratch;
     const int want_bias = db ? 1 : 0;
+    const int np = dY1 ? 2 : 1;
+    if (np == 2 && !tile && !vec) return NF_ENOTSUP;
+    const int64_t single = (int64_t)chunks * ((int64_t)M * N + M);      // = nf_linear_wgrad_scratch_floats(B, M, N)
+    const int64_t zdY = np == 2 ? (const float *)dY1 - (const float *)dY : 0, zX = np == 2 ? (const float *)X1 - (const float *)X : 0;
+    const int64_t zdW = np == 2 ? (float *)dW1 - (float *)dW : 0, zdb = (np == 2 && db) ? (float *)db1 - (float *)db : 0;
+    const int64_t zpart = np == 2 ? single : 0;
     if (tile) {
-        hipLaunchKernelGGL(nf::wgrad_tile_kernel, dim3(chunks, (M + nf::W2_T - 1) / nf::W2_T), dim3(256), 0, st, (const float *)dY,
-                           (const float *)X, part, B, M, N, rows, want_bias, relu_x);
+        hipLaunchKernelGGL(nf::wgrad_tile_kernel, dim3(chunks, (M + nf::W2_T - 1) / nf::W2_T, np), dim3(256), 0, st,
+                           (const float *)dY, (const float *)X, part, B, M, N, rows, want_bias, relu_x, zdY, zX, zpart);
     } else if (vec) {
 #define NF_WGRAD_VEC(AV, XR)                                                                                          \
-    hipLaunchKernelGGL((nf::wgrad_partial_vec_kernel<AV, XR>), dim3(chunks, (M + 63) / 64), dim3(64), 0, st,          \
-                       (const float *)dY, (const float *)X, part, B, M, N, rows, want_bias)
+    hipLaunchKernelGGL((nf::wgrad_partial_vec_kernel<AV, XR>), dim3(chunks, (M + 63) / 64, np), dim3(64), 0, st,      \
+                       (const float *)dY, (const float *)X, part, B, M, N, rows, want_bias, zdY, zX, zpart)
         if (M % 2 == 0) { if (relu_x) NF_WGRAD_VEC(true, true); else NF_WGRAD_VEC(true, false); }
         else { if (relu_x) NF_WGRAD_VEC(false, true); else NF_WGRAD_VEC(false, false); }
 #undef NF_WGRAD_VEC
@@ -428,8 +465,8 @@ extern "C" int nf_linear_wgrad_skip(const void *dY, const void *X, void *dW, voi
     }
     NF_CHECK_LAUNCH();
     const int64_t nW = (int64_t)M * N, n = nW + (db ? M : 0);
-    hipLaunchKernelGGL(nf::wgrad_reduce_kernel, dim3(nf::grid_for(n, 64)), dim3(64 * nf::RL), 0, st, part, (float *)dW, (float *)db,
-                       nW, n, nW + M, chunks, accumulate, N, skip_every);
+    hipLaunchKernelGGL(nf::wgrad_reduce_kernel, dim3(nf::grid_for(n, 64), np), dim3(64 * nf::RL), 0, st, part, (float *)dW,
+                       (float *)db, nW, n, nW + M, chunks, accumulate, N, skip_every, zpart, zdW, zdb);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

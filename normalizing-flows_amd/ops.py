@@ -921,6 +921,24 @@ def linear_wgrad(dy, x, want_bias=True, relu_x=False, skip_every=0):
     return dW, db
 
 
+def linear_wgrad_pair(dy0, x0, dy1, x1, relu_x=False):
+    """(dW0, db0, dW1, db1) of two same-shape Linear layers in one partial launch + one reduction (nf_linear_wgrad_pair)."""
+    L.require_device(dy0, x0, dy1, x1)
+    dy0, x0, dy1, x1 = dy0.contiguous(), x0.contiguous(), dy1.contiguous(), x1.contiguous()
+    if dy0.shape != dy1.shape or x0.shape != x1.shape or any(t.dtype != torch.float32 for t in (dy0, x0, dy1, x1)):
+        raise ValueError("linear_wgrad_pair: two float32 problems of the same shape")
+    B, M = dy0.shape
+    N = x0.shape[1]
+    out = torch.empty(2, M * N + M, dtype=torch.float32, device=dy0.device)     # dW | db per problem
+    n = int(L.lib().nf_linear_wgrad_scratch_floats(i64(B), i32(M), i32(N)))
+    scratch = torch.empty(max(2 * n, 1), dtype=torch.float32, device=dy0.device)
+    w0, b0, w1, b1 = out[0, :M * N], out[0, M * N:], out[1, :M * N], out[1, M * N:]
+    rc = L.lib().nf_linear_wgrad_pair(ptr(dy0), ptr(x0), ptr(w0), ptr(b0), ptr(dy1), ptr(x1), ptr(w1), ptr(b1), ptr(scratch),
+                                      i64(B), i32(M), i32(N), i32(0), i32(int(relu_x)), L.stream())
+    L.check(rc, "nf_linear_wgrad_pair")
+    return w0.view(M, N), b0, w1.view(M, N), b1
+
+
 def bias_leaky_relu_(y, bias, negative_slope):
     """In place y = leaky_relu(y + bias[c]) on a contiguous NCHW tensor (nf_bias_leaky_relu)."""
     L.require_device(y, bias)

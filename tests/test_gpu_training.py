@@ -149,6 +149,19 @@ def test_linear_wgrad_kernel(nfa, B, M, N):
     assert torch.equal(dW, dW2) and torch.equal(db, db2)
 
 
+@pytest.mark.parametrize("B,M,N", [(65536, 128, 128), (4099, 64, 32), (3000, 768, 128)])
+def test_linear_wgrad_pair_equals_two_single_launches(nfa, B, M, N):
+    """nf_linear_wgrad_pair: same partial tiles and the same fixed-order reduction as two nf_linear_wgrad_act calls."""
+    g = torch.Generator().manual_seed(B + M)
+    dy0, dy1 = torch.randn(B, M, generator=g).to(DEV), torch.randn(B, M, generator=g).to(DEV)
+    x0, x1 = torch.randn(B, N, generator=g).to(DEV), torch.randn(B, N, generator=g).to(DEV)
+    for relu in (False, True):
+        w0, b0, w1, b1 = nfa.ops.linear_wgrad_pair(dy0, x0, dy1, x1, relu_x=relu)
+        rw0, rb0 = nfa.ops.linear_wgrad(dy0, x0, relu_x=relu)
+        rw1, rb1 = nfa.ops.linear_wgrad(dy1, x1, relu_x=relu)
+        assert torch.equal(w0, rw0) and torch.equal(b0, rb0) and torch.equal(w1, rw1) and torch.equal(b1, rb1)
+
+
 def test_linear_autograd_matches_torch(nfa):
     torch.manual_seed(0)
     lin = nfa.nets.Linear(48, 96).to(DEV)

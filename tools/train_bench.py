@@ -16,7 +16,11 @@ from bench import build_c2_model, c2_inputs  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=65536)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--no-wgrad-pair", action="store_true", help="ablation: the residual blocks' weight gradients as two launches")
 a = ap.parse_args()
+if a.no_wgrad_pair:
+    import normflows_amd
+    normflows_amd.config.set_wgrad_pair(False)
 dev = torch.device("cuda:0")
 m = build_c2_model().to(dev)
 x = c2_inputs(a.batch).to(dev)
