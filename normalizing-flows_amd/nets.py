@@ -41,9 +41,9 @@ class ResidualBlock(nn.Module):
     def forward(self, inputs, context=None):
         if context is None:
             from . import autograd
-            if autograd.residual_block_fused_ok(self, inputs):   # training: four launches of the MFMA row-panel kernel
-                l1, l2 = self.linear_layers
-                return autograd.ResidualBlockFn.apply(inputs, l1.weight, l1.bias, l2.weight, l2.bias)
+            if autograd.residual_block_fused_ok(self, inputs):   # training: one launch forward, one backward (nf_rows_block)
+                l1, l2 = self.linear_layers                      # on the MASKED weights (weight * mask stays in the graph)
+                return autograd.ResidualBlockFn.apply(inputs, l1.masked_weight(), l1.bias, l2.masked_weight(), l2.bias)
         temps = inputs
         if self.use_batch_norm:
             temps = self.batch_norm_layers[0](temps)
@@ -444,9 +444,9 @@ class MaskedResidualBlock(nn.Module):
     def forward(self, inputs, context=None):
         if context is None:
             from . import autograd
-            if autograd.residual_block_fused_ok(self, inputs):   # training: four launches of the MFMA row-panel kernel
-                l1, l2 = self.linear_layers
-                return autograd.ResidualBlockFn.apply(inputs, l1.weight, l1.bias, l2.weight, l2.bias)
+            if autograd.residual_block_fused_ok(self, inputs):   # training: one launch forward, one backward (nf_rows_block)
+                l1, l2 = self.linear_layers                      # on the MASKED weights (weight * mask stays in the graph)
+                return autograd.ResidualBlockFn.apply(inputs, l1.masked_weight(), l1.bias, l2.masked_weight(), l2.bias)
         temps = inputs
         if self.use_batch_norm:
             temps = self.batch_norm_layers[0](temps)

@@ -162,6 +162,33 @@ def test_linear_wgrad_pair_equals_two_single_launches(nfa, B, M, N):
         assert torch.equal(w0, rw0) and torch.equal(b0, rb0) and torch.equal(w1, rw1) and torch.equal(b1, rb1)
 
 
+def test_masked_residual_block_training_uses_masked_weights(nfa):
+    """MADE's residual block (nets/made.py:140-214) on the one-launch kernel: the products run on weight * mask, the
+    autoregressive structure survives (an output of degree d does not move with inputs of degree > d), gradients match the
+    plain formula."""
+    torch.manual_seed(3)
+    made = nfa.nets.MADE(features=16, hidden_features=64, num_blocks=1, output_multiplier=2).to(DEV)
+    blk = made.blocks[0]
+    for l in blk.linear_layers:
+        torch.nn.init.normal_(l.weight, std=0.3)
+    x = torch.randn(2048, 64, device=DEV, requires_grad=True)
+    assert nfa.autograd.residual_block_fused_ok(blk, x)
+    y = blk(x)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    got = [x.grad.clone()] + [p.grad.clone() for p in blk.parameters()]
+    x.grad = None
+    blk.zero_grad()
+    l1, l2 = blk.linear_layers
+    t = torch.nn.functional.linear(torch.relu(x), l1.weight * l1.mask, l1.bias)
+    y2 = x + torch.nn.functional.linear(torch.relu(t), l2.weight * l2.mask, l2.bias)
+    (y2 * w).sum().backward()
+    ref = [x.grad.clone()] + [p.grad.clone() for p in blk.parameters()]
+    assert _rel(N_(y), N_(y2)) < 1e-5
+    for a, b in zip(got, ref):
+        assert _rel(N_(a), N_(b)) < 2e-4 * max(1.0, float(b.abs().max())), (a.shape, _rel(N_(a), N_(b)))
+
+
 def test_linear_autograd_matches_torch(nfa):
     torch.manual_seed(0)
     lin = nfa.nets.Linear(48, 96).to(DEV)
