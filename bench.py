@@ -381,16 +381,16 @@ def main():
                 torch.cuda.synchronize()
                 dt3 = (time.perf_counter() - t1) / args.steps
             rel = float(((lp3 - lp).abs() / lp.abs().clamp_min(1.0)).max())
-            # roofline of ITS dominant kernel: nf::rqs_fused_x3_kernel<0, true>, one launch per layer pair; every fp32 product
-            # is six bf16 MFMA products (hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid), priced against the dense bf16 peak
+            # roofline of ITS dominant kernel: nf::rqs_fused_x3_kernel<0, true>, ONE persistent launch over all layer pairs
+            # (nf_rqs_fused_x3_chain); every fp32 product is six bf16 MFMA products (hi.hi + hi.mid + mid.hi + hi.lo + lo.hi +
+            # mid.mid), priced against the dense bf16 peak
             model.use_graphs(False)
             with torch.no_grad():
-                model.log_prob(x)
-                pass_ms, _ = _events_ms(lambda: model.log_prob(x), 5)
+                bd3 = kernel_breakdown(model, x)      # same instrumented pass as the exact kernel's, config still bf16x3
             model.use_graphs(not args.no_graph)
-            npairs3 = args.layers
-            fl3 = 6 * c2_flops_per_sample(layers=1) * args.batch          # executed bf16 FLOP per launch (one pair)
-            launch_ms = pass_ms / npairs3                                   # eager pass = npairs3 launches + the base density
+            launches3 = (args.layers + 63) // 64                            # chains of up to 64 pairs
+            fl3 = 6 * c2_flops_per_sample(layers=args.layers) * args.batch / launches3     # executed bf16 FLOP per launch
+            launch_ms = bd3["rqs_fused_chain"][0] / launches3               # HIP events around the chain launch(es)
             out["bf16x3_split_gemm"] = {"value": args.batch / dt3, "unit": "samples/s", "ms_per_step": 1e3 * dt3,
                                         "nll_nats_per_dim": float(-lp3.mean()) / DIM,
                                         "max_rel_diff_log_prob_vs_exact_f32": rel,
@@ -400,9 +400,9 @@ def main():
                                                      "achieved": fl3 / (launch_ms * 1e-3) / 1e12, "peak": 2500.0,
                                                      "frac": fl3 / (launch_ms * 1e-3) / 2.5e15, "traffic": None,
                                                      "flop_per_launch_executed_bf16": fl3, "avg_launch_ms": launch_ms,
-                                                     "launches_per_pass": npairs3,
-                                                     "note": "avg_launch_ms = HIP-event time of an eager pass / launches (includes "
-                                                             "launch gaps); algorithmic fp32 FLOP = executed / 6"}}
+                                                     "launches_per_pass": launches3, "layer_pairs_per_launch": min(args.layers, 64),
+                                                     "note": "avg_launch_ms = HIP events around the chain launch on its stream; "
+                                                             "algorithmic fp32 FLOP = executed / 6"}}
             nfa.config.set_fused_gemm("f32")
             model.use_graphs(False)
             model.use_graphs(not args.no_graph)

@@ -213,6 +213,13 @@ int nf_rqs_fused_x3_pack(void *x3pack, const void *f32pack, int num_blocks, int 
 int nf_rqs_fused_x3(const void *x, void *y, void *logdet, const void *x3pack, int mask_parity, int fuse_lu,
                     int64_t B, int D, int hidden, int num_blocks, int K, double tail_bound, double min_bin_width,
                     double min_bin_height, double min_derivative, int direction, int acc, nf_stream_t stream);
+/* The split-bf16 counterpart of nf_rqs_fused_chain: up to 64 layers of one shape in ONE persistent launch (rows stay in
+ * LDS between the layers, the weight stream runs through the layer boundaries).  x3packs (nf_rqs_fused_x3_pack) and
+ * mask_parities in PROCESSING order. */
+int nf_rqs_fused_x3_chain(const void *x, void *y, void *logdet, const void *const *x3packs, const int *mask_parities,
+                          int num_layers, int fuse_lu, int64_t B, int D, int hidden, int num_blocks, int K, double tail_bound,
+                          double min_bin_width, double min_bin_height, double min_derivative, int direction, int acc,
+                          nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LULinearPermute.  Replaces normflows/flows/mixing.py:535-563 (LULinearPermute), :229-244

@@ -51,3 +51,13 @@ wgrad_pair = True
 def set_wgrad_pair(mode=True):
     global wgrad_pair
     wgrad_pair = bool(mode)
+
+
+# Consecutive fused [CoupledRQS + LULinearPermute] pairs of one shape as ONE persistent launch (nf_rqs_fused_chain /
+# nf_rqs_fused_x3_chain); False = one launch per pair (ablation, tests).
+fused_chain = True
+
+
+def set_fused_chain(mode=True):
+    global fused_chain
+    fused_chain = bool(mode)

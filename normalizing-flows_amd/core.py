@@ -28,7 +28,7 @@ def _pair_signature(crqs):
 
 def _run_pairs(pairs, z, inverse, ld, acc):
     """`pairs` = [(CoupledRQS, LULinearPermute), ...] in processing order, all of one shape: one persistent launch
-    (exact-fp32 kernel) or one launch per pair (bf16x3 variant)."""
+    (exact-fp32 kernel nf_rqs_fused_chain, or its split-bf16 counterpart nf_rqs_fused_x3_chain)."""
     from . import _prof
     with _prof.range_("rqs_fused_chain[%d x (CoupledRQS + LULinearPermute)].%s" % (len(pairs), "inverse" if inverse else "forward")):
         return _run_pairs_impl(pairs, z, inverse, ld, acc)
@@ -36,10 +36,11 @@ def _run_pairs(pairs, z, inverse, ld, acc):
 
 def _run_pairs_impl(pairs, z, inverse, ld, acc):
     from . import config, ops
-    if config.fused_gemm != "f32" or len(pairs) == 1:
+    if config.fused_gemm not in ("f32", "bf16x3") or len(pairs) == 1 or not config.fused_chain:
         for c, lu in pairs:
             z = c._run_pair(z, lu, inverse, ld, acc)
         return z
+    x3 = config.fused_gemm == "bf16x3"
     feats, hidden, nblk, K, tb, mw, mh, md = _pair_signature(pairs[0][0])
     from .flows.neural_spline import FUSED_D, FUSED_H
     narrow = z.shape[1] != FUSED_D
@@ -47,10 +48,11 @@ def _run_pairs_impl(pairs, z, inverse, ld, acc):
         z = pairs[0][0].prqct._pad_rows(z)
     for i in range(0, len(pairs), 64):
         chunk = pairs[i:i + 64]
-        blobs = [c.prqct._fused_blob(lu) for c, lu in chunk]
+        blobs = [(c.prqct._fused_x3_blob(lu) if x3 else c.prqct._fused_blob(lu)) for c, lu in chunk]
         pars = [c.prqct._fused_parity for c, lu in chunk]
-        z, _ = ops.rqs_fused_chain(z, blobs, pars, FUSED_H, nblk, K, 0 if inverse else 1, logdet=ld, acc=acc, tail_bound=tb,
-                                   min_bin_width=mw, min_bin_height=mh, min_derivative=md, fuse_lu=True)
+        run = ops.rqs_fused_x3_chain if x3 else ops.rqs_fused_chain
+        z, _ = run(z, blobs, pars, FUSED_H, nblk, K, 0 if inverse else 1, logdet=ld, acc=acc, tail_bound=tb,
+                   min_bin_width=mw, min_bin_height=mh, min_derivative=md, fuse_lu=True)
     return z[:, :feats].contiguous() if narrow else z
 
 

@@ -5,6 +5,8 @@
 
 namespace nf {
 
+constexpr int F_MAX_LAYERS = 64;   // layers of one shape a persistent chain launch takes (rqs_fused.hip, rqs_fused_x3.hip)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -316,7 +316,6 @@ constexpr int F_ROWS = 32 * F_NW;
 // A chain of up to F_MAX_LAYERS fused layers handled by ONE persistent launch: the workgroup keeps its 256 rows in the
 // LDS stash across all layers (x is read from HBM once, y written once, the log-det lives in a register), the weight
 // stream runs straight through the layer boundaries and the next layer's small section is DMA-prefetched.
-constexpr int F_MAX_LAYERS = 64;
 struct FlowArgs {
     const float *blob[F_MAX_LAYERS];  // packed blobs in PROCESSING order
     unsigned long long parity;        // bit l: mask parity of layer l (0: transform features on odd columns)

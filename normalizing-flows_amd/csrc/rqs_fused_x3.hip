@@ -215,11 +215,19 @@ __device__ __forceinline__ Split3 split_regs(const f32x16 &src, int half) {  // 
     return split8(v);
 }
 
-// DIR: 0 = density (wrapper.inverse), 1 = sample (wrapper.forward).  LU: fuse the layer's LULinearPermute.
+// Up to F_MAX_LAYERS layers of one shape in ONE persistent launch (as rqs_fused.hip's FlowArgs): rows stay in the wave's LDS
+// stash between layers, the weight stream runs straight through the layer boundaries.
+struct X3Args {
+    const float *pack[F_MAX_LAYERS];  // split-bf16 blobs in PROCESSING order
+    unsigned long long parity;        // bit l: mask parity of layer l (0: transform features on odd columns)
+    int nlayers;
+};
+
+// DIR: 0 = density (wrapper.inverse), 1 = sample (wrapper.forward).  LU: fuse each layer's LULinearPermute.
 template <int DIR, bool LU>
 __global__ void __launch_bounds__(X3_THREADS, 2)
-rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ logdet,
-                    const float *__restrict__ pack, int64_t B, int nblk, int par_t, RqsParams<float> p, int acc) {
+rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ logdet, X3Args xa, int64_t B,
+                    int nblk, RqsParams<float> p, int acc) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     X3Layout lay;
     lay.nblk = nblk;
@@ -229,16 +237,12 @@ rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *_
     float *small = stash + X3_NW * 32 * 64;        // biases + tables
     const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t row = (int64_t)blockIdx.x * X3_ROWS + wid * 32 + (lane & 31);
-    const bool valid = row < B;
-    const int par_i = par_t ^ 1;
-    const char *stages = reinterpret_cast<const char *>(pack) + lay.off_stage_bytes();
     const int nbase = lay.n_base();
-    const int nstages = nbase + (LU ? 2 : 0);  // in K-step stages; the kernel walks them two at a time
-    (void)nstages;
+    const int SPL = (nbase + (LU ? 2 : 0)) / 2;    // acquires (pairs of K-step stages) per layer
     float *st = stash + wid * 2048 + lane;
 
-    // logical stage -> byte offset and shape (wide: 12 KB stage = 12 x 1 KB pieces; else 9 KB = 12 x 768 B pieces)
+    // acquire index local to a layer -> byte offset in that layer's stage area and shape (wide: 12 KB stage = 12 x 1 KB pieces;
+    // else 9 KB = 12 x 768 B pieces)
     auto stage_off = [&](int S, bool &wide) -> int64_t {
         const int s = 2 * S;  // first K-step stage of the pair (pairs are contiguous in the blob)
         int b = s;
@@ -248,8 +252,7 @@ rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *_
         }
         if (b >= nbase) {
             wide = true;
-            if (LU && DIR == 1 && b < nbase + 2) return lay.off_lu(1);
-            return lay.off_pad();  // prefetch past the end lands in padding
+            return lay.off_lu(1);          // LU && DIR == 1: the layer's last acquire
         }
 #ifdef NF_X3_WIDE_FINAL
         wide = true;
@@ -258,10 +261,19 @@ rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *_
 #endif
         return lay.base_off(b);
     };
+    // the DMA stream is issued in acquire order across the layers: (is_layer, is_local) = the next pair to request; past the
+    // last layer the look-ahead lands in the last blob's padding
+    int is_layer = 0, is_local = 0;
     // every wave issues exactly 3 LDS-DMA instructions per stage (counted vmcnt below relies on it)
     auto issue = [&](int s) {
-        bool wide;
-        const char *src = stages + stage_off(s, wide);
+        bool wide = true;
+        const char *src;
+        if (is_layer < xa.nlayers) {
+            src = reinterpret_cast<const char *>(xa.pack[is_layer]) + lay.off_stage_bytes() + stage_off(is_local, wide);
+            if (++is_local == SPL) { is_local = 0; ++is_layer; }
+        } else {
+            src = reinterpret_cast<const char *>(xa.pack[xa.nlayers - 1]) + lay.off_stage_bytes() + lay.off_pad();
+        }
         float *slot = ring + (s % 3) * X3_RING_FLOATS;
         if (wide) {
 #pragma unroll
@@ -301,10 +313,11 @@ rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *_
         return buf;
     };
 
-    // ---- prologue ----
-    float xin[32];
+    // ---- prologue: rows -> the wave's stash (they stay there between the layers) ----
 #pragma unroll
     for (int Q = 0; Q < 4; ++Q) {
+        const int64_t row = (int64_t)blockIdx.x * X3_ROWS + wid * 32 + (lane & 31);   // (recomputed in the epilogue: not
+        const bool valid = row < B;                                                    //  kept live across the layers)
         f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
         if (valid) {
             const float *src = x + row * F_D + 16 * Q + 8 * hh;
@@ -313,22 +326,44 @@ rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *_
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            xin[8 * Q + c] = a[c];
-            xin[8 * Q + 4 + c] = b[c];
+            st[(8 * Q + c) * 64] = a[c];
+            st[(8 * Q + 4 + c) * 64] = b[c];
         }
     }
-    for (int i = tid; i < fl.small_floats(); i += X3_THREADS) small[i] = pack[F_HDR + i];
-    issue(0);
-    issue(1);
-    __syncthreads();  // small section visible to all waves
     float ld = 0.0f;
 
-    // Counting: stages 0 and 1 are in flight (3 LDS-DMA instructions per wave each).  Every acquire() waits until at
+    // Counting: two stages are always in flight (3 LDS-DMA instructions per wave each).  Every acquire() waits until at
     // most 3 VMEM operations of this wave are outstanding -- memory operations retire in order, so the 3 pieces of
     // the stage about to be consumed (always older than the 3 pieces of the following stage) have landed -- then
     // passes the workgroup barrier (every wave's pieces landed, every wave done with the slot being refilled) and
-    // issues stage+2.
+    // issues stage+2.  (The small section's ordinary loads at a layer's start drain the queue once per layer: stricter,
+    // never weaker.)
+    const int lane_outer = lane;
+    for (int layer = 0; layer < xa.nlayers; ++layer) {
+    // every per-lane address below (bias rows, table rows) is derived from these two: opaque per layer, or the compiler hoists
+    // all of them out of the layer loop and keeps ~20 VGPRs live across it (spills at the final layer's peak)
+    int lane_l = lane_outer;
+    asm volatile("" : "+v"(lane_l));
+    const int lane = lane_l, hh = lane >> 5, tid = wid * 64 + lane;
+    int nblk_l = nblk;
+    asm volatile("" : "+s"(nblk_l));    // ... and the blob offsets (scalar) are recomputed per layer instead of held in SGPRs
+    FusedLayout fl;
+    fl.nblk = nblk_l;
+    float *st = stash + wid * 2048 + lane;
+    const float *pack = xa.pack[layer];
+    const int par_t = ((xa.parity >> layer) & 1ull) ? 0 : 1;
+    const int par_i = par_t ^ 1;
+    __syncthreads();  // every wave is done with the previous layer's small section
+    for (int i = tid; i < fl.small_floats(); i += X3_THREADS) small[i] = pack[F_HDR + i];
+    if (layer == 0) {
+        issue(0);
+        issue(1);
+    }
+    __syncthreads();  // small section visible to all waves
     if (LU && DIR == 0) {
+        float xin[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) xin[c] = st[c * 64];
         const float *bsrc = small + fl.off_bias_lu(0) + hh * 16;
         f32x16 o0 = load_bias16(bsrc), o1 = load_bias16(bsrc + 32);
         {
@@ -349,10 +384,8 @@ rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *_
             st[(16 + c) * 64] = o1[c];
         }
         if (hh == 0) ld += pack[3];
-    } else {
-#pragma unroll
-        for (int c = 0; c < 32; ++c) st[c * 64] = xin[c];
     }
+    __builtin_amdgcn_sched_barrier(0);   // nothing of the conditioner is hoisted above the LU product (register peak)
 
     // ---- unconditional spline on the identity half: sample direction first, density deferred ----
     float bx[16];
@@ -512,12 +545,11 @@ rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *_
     element(7, 1, prm1);
     if (DIR == 0) uncond_pair(7);
 
-    // ---- epilogue ----
-    ld += __shfl_xor(ld, 32, 64);
-    float yout[32];
-#pragma unroll
-    for (int c = 0; c < 32; ++c) yout[c] = st[c * 64];
+    // ---- end of the layer: the sample direction's LULinearPermute.forward on the finished rows ----
     if (LU && DIR == 1) {
+        float yout[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) yout[c] = st[c * 64];
         const float *bsrc = small + fl.off_bias_lu(1) + hh * 16;
         f32x16 o0 = load_bias16(bsrc), o1 = load_bias16(bsrc + 32);
         {
@@ -534,37 +566,46 @@ rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *_
         }
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-            yout[c] = o0[c];
-            yout[16 + c] = o1[c];
+            st[c * 64] = o0[c];
+            st[(16 + c) * 64] = o1[c];
         }
-        ld -= pack[3];
+        if (hh == 0) ld -= pack[3];
     }
+    }  // layers
+
+    // ---- epilogue ----
+    ld += __shfl_xor(ld, 32, 64);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the look-ahead DMAs before the workgroup retires
-    if (valid) {
+    int t_end = threadIdx.x;
+    asm volatile("" : "+v"(t_end));     // (not the prologue's value kept live: see above)
+    const int64_t row = (int64_t)blockIdx.x * X3_ROWS + (t_end >> 6) * 32 + (t_end & 31);
+    const int hh_end = (t_end >> 5) & 1;
+    const float *st_end = stash + (t_end >> 6) * 2048 + (t_end & 63);
+    if (row < B) {
 #pragma unroll
         for (int Q = 0; Q < 4; ++Q) {
             f32x4 a, b;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                a[c] = yout[8 * Q + c];
-                b[c] = yout[8 * Q + 4 + c];
+                a[c] = st_end[(8 * Q + c) * 64];
+                b[c] = st_end[(8 * Q + 4 + c) * 64];
             }
-            float *dst = y + row * F_D + 16 * Q + 8 * hh;
+            float *dst = y + row * F_D + 16 * Q + 8 * hh_end;
             *reinterpret_cast<f32x4 *>(dst) = a;
             *reinterpret_cast<f32x4 *>(dst + 4) = b;
         }
-        if (hh == 0) ld_store(logdet + row, ld, acc);
+        if (hh_end == 0) ld_store(logdet + row, ld, acc);
     }
 }
 
 template <int DIR, bool LU>
-static int launch_x3(const void *x, void *y, void *logdet, const void *wpack, int64_t B, int num_blocks, int par_t,
+static int launch_x3(const void *x, void *y, void *logdet, const X3Args &xa, int64_t B, int num_blocks,
                      const RqsParams<float> &p, int acc, size_t lds, hipStream_t st) {
     static LdsOptIn opted = {};  // one per <DIR, LU> instantiation
     if (opt_in_lds(reinterpret_cast<const void *>(&rqs_fused_x3_kernel<DIR, LU>), lds, opted) != NF_OK) return NF_ENOTSUP;
     const int grid = (int)((B + X3_ROWS - 1) / X3_ROWS);
     hipLaunchKernelGGL((rqs_fused_x3_kernel<DIR, LU>), dim3(grid), dim3(X3_THREADS), lds, st, (const float *)x, (float *)y,
-                       (float *)logdet, (const float *)wpack, B, num_blocks, par_t, p, acc);
+                       (float *)logdet, xa, B, num_blocks, p, acc);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -616,15 +657,14 @@ extern "C" int nf_rqs_fused_x3_pack(void *x3pack, const void *f32pack, int num_b
     return NF_OK;
 }
 
-extern "C" int nf_rqs_fused_x3(const void *x, void *y, void *logdet, const void *x3pack, int mask_parity, int fuse_lu,
-                               int64_t B, int D, int hidden, int num_blocks, int K, double tail_bound,
-                               double min_bin_width, double min_bin_height, double min_derivative, int direction, int acc,
-                               nf_stream_t stream) {
+static int x3_run(const void *x, void *y, void *logdet, const X3Args &xa, int fuse_lu, int64_t B, int D, int hidden,
+                  int num_blocks, int K, double tail_bound, double min_bin_width, double min_bin_height, double min_derivative,
+                  int direction, int acc, nf_stream_t stream) {
     if (D != F_D || hidden != F_H || K != F_K || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
-    if (B < 0 || (direction != 0 && direction != 1) || (mask_parity != 0 && mask_parity != 1)) return NF_EINVAL;
+    if (B < 0 || (direction != 0 && direction != 1)) return NF_EINVAL;
     if (acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
     if (B == 0) return NF_OK;
-    if (!x || !y || !logdet || !x3pack) return NF_EFAULT;
+    if (!x || !y || !logdet) return NF_EFAULT;
     hipStream_t st = (hipStream_t)stream;
     X3Layout lay;
     lay.nblk = num_blocks;
@@ -632,10 +672,46 @@ extern "C" int nf_rqs_fused_x3(const void *x, void *y, void *logdet, const void 
                                     min_derivative, sqrt((double)hidden));
     const size_t lds = (size_t)(3 * X3_RING_FLOATS + X3_NW * 32 * 64 + lay.f32().small_floats()) * sizeof(float);
     if (lds > 160 * 1024) return NF_ENOTSUP;
-    const int par_t = mask_parity == 0 ? 1 : 0;
     if (direction == 0)
-        return fuse_lu ? launch_x3<0, true>(x, y, logdet, x3pack, B, num_blocks, par_t, p, acc, lds, st)
-                       : launch_x3<0, false>(x, y, logdet, x3pack, B, num_blocks, par_t, p, acc, lds, st);
-    return fuse_lu ? launch_x3<1, true>(x, y, logdet, x3pack, B, num_blocks, par_t, p, acc, lds, st)
-                   : launch_x3<1, false>(x, y, logdet, x3pack, B, num_blocks, par_t, p, acc, lds, st);
+        return fuse_lu ? launch_x3<0, true>(x, y, logdet, xa, B, num_blocks, p, acc, lds, st)
+                       : launch_x3<0, false>(x, y, logdet, xa, B, num_blocks, p, acc, lds, st);
+    return fuse_lu ? launch_x3<1, true>(x, y, logdet, xa, B, num_blocks, p, acc, lds, st)
+                   : launch_x3<1, false>(x, y, logdet, xa, B, num_blocks, p, acc, lds, st);
+}
+
+extern "C" int nf_rqs_fused_x3(const void *x, void *y, void *logdet, const void *x3pack, int mask_parity, int fuse_lu,
+                               int64_t B, int D, int hidden, int num_blocks, int K, double tail_bound,
+                               double min_bin_width, double min_bin_height, double min_derivative, int direction, int acc,
+                               nf_stream_t stream) {
+    if (mask_parity != 0 && mask_parity != 1) return NF_EINVAL;
+    if (!x3pack) return NF_EFAULT;
+    X3Args xa;
+    for (int l = 0; l < F_MAX_LAYERS; ++l) xa.pack[l] = nullptr;
+    xa.pack[0] = (const float *)x3pack;
+    xa.parity = mask_parity ? 1ull : 0ull;
+    xa.nlayers = 1;
+    return x3_run(x, y, logdet, xa, fuse_lu, B, D, hidden, num_blocks, K, tail_bound, min_bin_width, min_bin_height,
+                  min_derivative, direction, acc, stream);
+}
+
+// Up to 64 layers of one shape in ONE persistent launch (the split-bf16 counterpart of nf_rqs_fused_chain): x3packs /
+// mask_parities in PROCESSING order.
+extern "C" int nf_rqs_fused_x3_chain(const void *x, void *y, void *logdet, const void *const *x3packs, const int *mask_parities,
+                                     int num_layers, int fuse_lu, int64_t B, int D, int hidden, int num_blocks, int K,
+                                     double tail_bound, double min_bin_width, double min_bin_height, double min_derivative,
+                                     int direction, int acc, nf_stream_t stream) {
+    if (num_layers < 1 || num_layers > F_MAX_LAYERS) return NF_EINVAL;
+    if (!x3packs || !mask_parities) return NF_EFAULT;
+    X3Args xa;
+    xa.parity = 0ull;
+    xa.nlayers = num_layers;
+    for (int l = 0; l < F_MAX_LAYERS; ++l) xa.pack[l] = nullptr;
+    for (int l = 0; l < num_layers; ++l) {
+        if (!x3packs[l]) return NF_EFAULT;
+        if (mask_parities[l] != 0 && mask_parities[l] != 1) return NF_EINVAL;
+        xa.pack[l] = (const float *)x3packs[l];
+        if (mask_parities[l]) xa.parity |= 1ull << l;
+    }
+    return x3_run(x, y, logdet, xa, fuse_lu, B, D, hidden, num_blocks, K, tail_bound, min_bin_width, min_bin_height,
+                  min_derivative, direction, acc, stream);
 }

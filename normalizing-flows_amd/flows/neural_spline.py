@@ -601,6 +601,14 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
             self._fused_cache = (key, blob)
         return self._fused_cache[1]
 
+    def _fused_x3_blob(self, lu):
+        """Split-bf16 blob of this layer (+ its LU), derived from the fp32 blob once per parameter version."""
+        blob = self._fused_blob(lu)
+        key = self._fused_cache[0]
+        if self._fused_x3_cache is None or self._fused_x3_cache[0] is not key:
+            self._fused_x3_cache = (key, ops.rqs_fused_x3_pack(blob, len(self.transform_net.blocks), lu is not None))
+        return self._fused_x3_cache[1]
+
     def _fused(self, inputs, direction, ld=None, acc=None, lu=None):
         self._check(inputs)
         if inputs.shape[1] != FUSED_D:     # narrower layer: the kernel's 64 columns, padding in the tails
@@ -612,11 +620,7 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
         net = self.transform_net
         from .. import config
         if config.fused_gemm == "bf16x3":
-            blob = self._fused_blob(lu)
-            key = self._fused_cache[0]
-            if self._fused_x3_cache is None or self._fused_x3_cache[0] is not key:
-                self._fused_x3_cache = (key, ops.rqs_fused_x3_pack(blob, len(net.blocks), lu is not None))
-            return ops.rqs_fused_x3(inputs, self._fused_x3_cache[1], self._fused_parity, FUSED_H,
+            return ops.rqs_fused_x3(inputs, self._fused_x3_blob(lu), self._fused_parity, FUSED_H,
                                     len(net.blocks), self.num_bins, direction, logdet=ld, acc=acc,
                                     tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
                                     min_bin_height=self.min_bin_height, min_derivative=self.min_derivative,

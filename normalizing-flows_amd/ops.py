@@ -709,6 +709,32 @@ def rqs_fused_chain(x, blobs, parities, hidden, num_blocks, K, direction, logdet
     return y, logdet
 
 
+def rqs_fused_x3_chain(x, blobs, parities, hidden, num_blocks, K, direction, logdet=None, acc=None, tail_bound=3.0,
+                       min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, fuse_lu=True):
+    """Up to 64 fused layers of identical shape on the split-bf16 matrix path in ONE persistent launch
+    (nf_rqs_fused_x3_chain).  `blobs` (rqs_fused_x3_pack) / `parities` are in processing order."""
+    import ctypes
+    L.require_device(x, *blobs)
+    if x.dtype != torch.float32:
+        raise TypeError("nf_rqs_fused_x3_chain is fp32 only")
+    x = x.contiguous()
+    B, D = x.shape
+    y = torch.empty_like(x)
+    if logdet is None:
+        logdet = torch.empty(B, dtype=x.dtype, device=x.device)
+        acc = L.LD_WRITE
+    elif acc is None:
+        acc = L.LD_ADD
+    n = len(blobs)
+    bp = (ctypes.c_void_p * n)(*[b.data_ptr() for b in blobs])
+    pp = (ctypes.c_int * n)(*[int(v) for v in parities])
+    rc = L.lib().nf_rqs_fused_x3_chain(ptr(x), ptr(y), ptr(logdet), bp, pp, i32(n), i32(int(fuse_lu)), i64(B), i32(D),
+                                       i32(hidden), i32(num_blocks), i32(K), f64(tail_bound), f64(min_bin_width),
+                                       f64(min_bin_height), f64(min_derivative), i32(direction), i32(acc), L.stream())
+    L.check(rc, "nf_rqs_fused_x3_chain")
+    return y, logdet
+
+
 def maf_inverse(z, blob, table, hidden_padded, logdet=None, acc=None):
     """autoregressive.py:29-38 + :114-128 in one pass (nf_maf_inverse); blob/table from flows/maf_pack.pack_made."""
     L.require_device(z, blob, table)

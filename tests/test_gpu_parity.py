@@ -926,6 +926,27 @@ def test_x3_model_c2_full_size_properties(nfa, oracle, bf16x3):
     test_model_c2_full_size_properties(nfa, oracle)
 
 
+@pytest.mark.parametrize("inverse", [True, False])
+def test_x3_chain_equals_layer_by_layer(nfa, bf16x3, inverse):
+    """nf_rqs_fused_x3_chain (one persistent launch, rows resident in LDS between the layers) against one nf_rqs_fused_x3
+    launch per layer pair: the same arithmetic in the same order."""
+    from bench import build_c2_model
+    m = build_c2_model(num_layers=5).to(DEV)
+    g = torch.Generator().manual_seed(17)
+    z = (torch.randn(777, 64, generator=g) * 1.5).to(DEV)
+    run = m.inverse_and_log_det if inverse else m.forward_and_log_det
+    try:
+        with torch.no_grad():
+            y1, ld1 = run(z)
+            nfa.config.set_fused_chain(False)
+            y2, ld2 = run(z)
+    finally:
+        nfa.config.set_fused_chain(True)
+    assert torch.isfinite(y1).all() and torch.isfinite(ld1).all()
+    assert float((y1 - y2).abs().max()) <= 1e-6 * float(y2.abs().max())
+    assert float((ld1 - ld2).abs().max()) <= 1e-6 * float(ld2.abs().max()) + 1e-6
+
+
 # ---- MAF (BASELINE configs[4]: inverse pass = D sequential MADE passes) ------------------------------------------
 def _perturb(module, sigma, seed):
     g = torch.Generator().manual_seed(seed)
