@@ -42,8 +42,8 @@ class ResidualBlock(nn.Module):
         if context is None:
             from . import autograd
             if autograd.residual_block_fused_ok(self, inputs):   # training: one launch forward, one backward (nf_rows_block)
-                l1, l2 = self.linear_layers                      # on the MASKED weights (weight * mask stays in the graph)
-                return autograd.ResidualBlockFn.apply(inputs, l1.masked_weight(), l1.bias, l2.masked_weight(), l2.bias)
+                l1, l2 = self.linear_layers
+                return autograd.ResidualBlockFn.apply(inputs, l1.weight, l1.bias, l2.weight, l2.bias)
         temps = inputs
         if self.use_batch_norm:
             temps = self.batch_norm_layers[0](temps)
