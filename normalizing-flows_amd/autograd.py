@@ -106,7 +106,7 @@ class FinalSplineDensityFn(torch.autograd.Function):
     Shape of the benchmark layer only: D = 64, hidden = 128, 8 bins, linear tails."""
 
     @staticmethod
-    def forward(ctx, x, h2, wf, bf, uw, uh, ud, iidx, tidx, blob, parity, nblocks, kw, ld_acc=None, acc=1):
+    def forward(ctx, x, h2, wf, bf, uw, uh, ud, iidx, tidx, blob, parity, nblocks, kw, wpad, ld_acc=None, acc=1):
         ops.rqs_fused_pack_final(blob, wf.detach(), bf.detach(), uw.detach(), uh.detach(), ud.detach(), nblocks,
                                  tail_bound=kw["tail_bound"], min_bin_width=kw["min_bin_width"],
                                  min_bin_height=kw["min_bin_height"], min_derivative=kw["min_derivative"])
@@ -117,13 +117,10 @@ class FinalSplineDensityFn(torch.autograd.Function):
                                                 acc=None if ld_acc is None else (L.LD_ADD if acc > 0 else L.LD_SUB))
         if ld_acc is not None:
             ctx.mark_dirty(ld_acc)
-        # final-layer weight on the 24-row layout of cond24 (pad row of every feature zero): a buffer kept per layer, one
-        # strided copy per step, read by the backward's input-gradient GEMM
+        # final-layer weight on the 24-row layout of cond24 (pad row of every feature zero): `wpad` (nT, 24, H) is a zero
+        # buffer OWNED BY THE LAYER (only its 23 real rows per feature are ever written), one strided copy per step, read by
+        # the backward's input-gradient GEMM
         nT, H = cond24.shape[1], wf.shape[1]
-        key = (wf.data_ptr(), nT, H, str(wf.device))
-        wpad = _wpad_cache.get(key)
-        if wpad is None:
-            wpad = _wpad_cache[key] = torch.zeros(nT, 24, H, dtype=wf.dtype, device=wf.device)
         wpad[:, :23].copy_(wf.detach().view(nT, 23, H))
         ctx.save_for_backward(x, h2, wf, cond24, uw, uh, ud, iidx, tidx)
         ctx.kw, ctx.wpad, ctx.acc, ctx.has_acc = kw, wpad, acc, ld_acc is not None
@@ -146,10 +143,8 @@ class FinalSplineDensityFn(torch.autograd.Function):
         g2 = gcond24.view(B, nT * 24)
         gh2 = g2 @ ctx.wpad.view(nT * 24, H)                 # input gradient of the final layer (library GEMM, padded rows)
         gwf, gbf = ops.linear_wgrad(g2, h2, want_bias=True, skip_every=24)   # pad rows dropped in the reduction
-        return gx, gh2, gwf, gbf, guw, guh, gud, None, None, None, None, None, None, (gld if ctx.has_acc else None), None
+        return gx, gh2, gwf, gbf, guw, guh, gud, None, None, None, None, None, None, None, (gld if ctx.has_acc else None), None
 
-
-_wpad_cache = {}
 
 _tri_cache = {}
 
@@ -364,16 +359,12 @@ def linear(x, weight, bias):
 class IdentLinearFn(torch.autograd.Function):
     """The conditioner's initial Linear on the identity columns of a full-width row (nsf/coupling.py:71-76 `inputs[:,
     identity_features]` + nets/resnet.py:92): y = x[:, iidx] W^T + b computed as x Wfull^T + b with W scattered into a
-    zero (H, D) matrix kept per layer.  No (B, nI) gather forward, and the backward's input gradient comes out full-width
+    zero (H, D) matrix kept by the layer.  No (B, nI) gather forward, and the backward's input gradient comes out full-width
     from the GEMM (zero in the transform columns) instead of a zero fill + index_add over the batch."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, iidx):
-        H, D = weight.shape[0], x.shape[1]
-        key = (weight.data_ptr(), H, D, str(weight.device))
-        wfull = _wfull_cache.get(key)
-        if wfull is None:
-            wfull = _wfull_cache[key] = torch.zeros(H, D, dtype=weight.dtype, device=weight.device)
+    def forward(ctx, x, weight, bias, iidx, wfull):
+        # wfull (H, D): a zero buffer OWNED BY THE LAYER; only its identity columns are ever written
         wfull.index_copy_(1, iidx, weight.detach())
         ctx.save_for_backward(x, iidx)
         ctx.wfull = wfull
@@ -385,10 +376,7 @@ class IdentLinearFn(torch.autograd.Function):
         gy = gy.contiguous()
         gx = gy @ ctx.wfull if ctx.needs_input_grad[0] else None
         gwf, gb = ops.linear_wgrad(gy, x, want_bias=True)
-        return gx, gwf.index_select(1, iidx), gb, None
-
-
-_wfull_cache = {}
+        return gx, gwf.index_select(1, iidx), gb, None, None
 
 
 class ResidualBlockFn(torch.autograd.Function):

@@ -424,6 +424,19 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
             return out, ld
         return out, log_det
 
+    def _train_buffers(self, inputs):
+        """Zero-padded images of the initial (H, D) and final (nT, 24, H) weights used by the fused training path: owned by
+        this layer (its identity columns / real rows are the only entries ever written, the rest stays zero)."""
+        net = self.transform_net
+        w0, wf = net.initial_layer.weight, net.final_layer.weight
+        buf = self.__dict__.get("_train_wbufs")
+        if buf is None or buf[0].device != inputs.device or buf[0].dtype != w0.dtype:
+            nT = self.transform_features.numel()
+            buf = (torch.zeros(w0.shape[0], inputs.shape[1], dtype=w0.dtype, device=inputs.device),
+                   torch.zeros(nT, 24, wf.shape[1], dtype=wf.dtype, device=inputs.device))
+            self.__dict__["_train_wbufs"] = buf
+        return buf
+
     # -- training path: same kernels through torch.autograd.Function (autograd.py), split/merge by torch indexing ---
     def _autograd(self, inputs, context, sample, ld, acc):
         kw = self._kernel_kwargs()
@@ -434,7 +447,8 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
             # coupling transform as ONE launch (FinalSplineDensityFn)
             net = self.transform_net
             inputs = inputs.contiguous()
-            h2 = IdentLinearFn.apply(inputs, net.initial_layer.weight, net.initial_layer.bias, self.identity_features)
+            wfull, wpad = self._train_buffers(inputs)
+            h2 = IdentLinearFn.apply(inputs, net.initial_layer.weight, net.initial_layer.bias, self.identity_features, wfull)
             for block in net.blocks:
                 h2 = block(h2)
             blob = self.__dict__.get("_train_blob")
@@ -446,7 +460,7 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
                                                           u.unnormalized_widths, u.unnormalized_heights,
                                                           u.unnormalized_derivatives, self.identity_features,
                                                           self.transform_features, blob, self._fused_parity, len(net.blocks), fkw,
-                                                          ld, 1 if (acc is None or acc > 0) else -1)
+                                                          wpad, ld, 1 if (acc is None or acc > 0) else -1)
             return outputs, log_det      # log_det IS ld (updated inside the launch) when the caller passed its accumulator
         ident = inputs.index_select(1, self.identity_features)
         if not sample:   # nsf/coupling.py:71-98 as one forward + one backward kernel on full rows
