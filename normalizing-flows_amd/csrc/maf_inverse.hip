@@ -38,10 +38,27 @@ typedef float f32x32 __attribute__((ext_vector_type(32)));
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 // ldsw[u][sample] = sum_k A[u][k] * act[k][sample] for the wave's 64 samples; K is a multiple of 32.
-__device__ __forceinline__ void block_part_lds(const float *__restrict__ A, const float *Sl, int K, float *ldsw, int lane) {
-    f32x16 c0 = {0}, c1 = {0};
+// Tile pairing (PAIR / INIT, affine variant): the activation scratch is what the kernel streams from HBM (every tile re-reads
+// ALL earlier tiles' activations: 5 GB per launch at config 5), so an even tile t also accumulates the NEXT tile's products
+// over the same operands -- second A stream A2 (tile t+1's weights for the same earlier units), accumulators stored raw
+// (C layout, 16-byte stores) in a per-wave stash -- and the odd tile starts from that stash (INIT) and only adds the 32 units
+// of tile t.  Activation re-reads: sum 32 t over all tiles -> over the even ones + 32 per odd one (-47 %).
+template <bool PAIR, bool INIT>
+__device__ __forceinline__ void block_part_lds_x(const float *__restrict__ A, const float *__restrict__ A2, const float *Sl,
+                                                 int K, float *ldsw, int lane, float *stash) {
+    f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
     const int half = lane >> 5, l31 = lane & 31;
+    if constexpr (INIT) {
+        const f32x4 *ps = reinterpret_cast<const f32x4 *>(stash) + lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const f32x4 v0 = ps[r * 64], v1 = ps[(4 + r) * 64];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { c0[4 * r + i] = v0[i]; c1[4 * r + i] = v1[i]; }
+        }
+    }
     const f32x4 *pa = reinterpret_cast<const f32x4 *>(A) + half * 32 + l31;
+    const f32x4 *pa2 = reinterpret_cast<const f32x4 *>(PAIR ? A2 : A) + half * 32 + l31;
     const f32x4 *pb = reinterpret_cast<const f32x4 *>(Sl) + half * 64 + l31;
 #ifdef NF_MAF_ABL_NOBLOCK
     const int nkb = 0;
@@ -52,32 +69,57 @@ __device__ __forceinline__ void block_part_lds(const float *__restrict__ A, cons
         // K is a multiple of 32 (host packer), i.e. nkb of 4: eight named operand stages, each refilled right after it is
         // consumed (prefetch distance = 8 k-blocks = 4096 MFMA cycles, no register rotation moves).
         // With one wave per SIMD nothing else hides the HBM/L2 latency of the activation scratch.
-        struct Stage { f32x4 a, b0, b1; };
+        struct Stage { f32x4 a, a2, b0, b1; };   // a2 is dead (never loaded) unless PAIR
         auto ld = [&](int kb, Stage &st) {
             const int k = kb < nkb ? kb : nkb - 1;
             st.a = pa[k * 64]; st.b0 = pb[k * 128]; st.b1 = pb[k * 128 + 32];
+            if constexpr (PAIR) st.a2 = pa2[k * 64];
         };
         auto mm = [&](const Stage &st) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 c0 = MFMA32(st.a[i], st.b0[i], c0);
                 c1 = MFMA32(st.a[i], st.b1[i], c1);
+                if constexpr (PAIR) {
+                    c2 = MFMA32(st.a2[i], st.b0[i], c2);
+                    c3 = MFMA32(st.a2[i], st.b1[i], c3);
+                }
             }
         };
-        Stage s0, s1, s2, s3, s4, s5, s6, s7;
-        ld(0, s0); ld(1, s1); ld(2, s2); ld(3, s3); ld(4, s4); ld(5, s5); ld(6, s6); ld(7, s7);
-        int kb = 0;
-        for (; kb + 8 <= nkb; kb += 8) {
-            mm(s0); ld(kb + 8, s0);
-            mm(s1); ld(kb + 9, s1);
-            mm(s2); ld(kb + 10, s2);
-            mm(s3); ld(kb + 11, s3);
-            mm(s4); ld(kb + 12, s4);
-            mm(s5); ld(kb + 13, s5);
-            mm(s6); ld(kb + 14, s6);
-            mm(s7); ld(kb + 15, s7);
+        if constexpr (PAIR) {
+            // four stages of 16 MFMAs each: the same 4096 MFMA cycles of look-ahead as eight stages of 8, in 64 registers
+            Stage s0, s1, s2, s3;
+            ld(0, s0); ld(1, s1); ld(2, s2); ld(3, s3);
+            for (int kb = 0; kb < nkb; kb += 4) {        // nkb is a multiple of 4
+                mm(s0); ld(kb + 4, s0);
+                mm(s1); ld(kb + 5, s1);
+                mm(s2); ld(kb + 6, s2);
+                mm(s3); ld(kb + 7, s3);
+            }
+        } else {
+            Stage s0, s1, s2, s3, s4, s5, s6, s7;
+            ld(0, s0); ld(1, s1); ld(2, s2); ld(3, s3); ld(4, s4); ld(5, s5); ld(6, s6); ld(7, s7);
+            int kb = 0;
+            for (; kb + 8 <= nkb; kb += 8) {
+                mm(s0); ld(kb + 8, s0);
+                mm(s1); ld(kb + 9, s1);
+                mm(s2); ld(kb + 10, s2);
+                mm(s3); ld(kb + 11, s3);
+                mm(s4); ld(kb + 12, s4);
+                mm(s5); ld(kb + 13, s5);
+                mm(s6); ld(kb + 14, s6);
+                mm(s7); ld(kb + 15, s7);
+            }
+            if (kb < nkb) { mm(s0); mm(s1); mm(s2); mm(s3); }
         }
-        if (kb < nkb) { mm(s0); mm(s1); mm(s2); mm(s3); }
+    }
+    if constexpr (PAIR) {
+        f32x4 *ps = reinterpret_cast<f32x4 *>(stash) + lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ps[r * 64] = f32x4{c2[4 * r], c2[4 * r + 1], c2[4 * r + 2], c2[4 * r + 3]};
+            ps[(4 + r) * 64] = f32x4{c3[4 * r], c3[4 * r + 1], c3[4 * r + 2], c3[4 * r + 3]};
+        }
     }
     // C layout: row = (reg & 3) + 8 (reg >> 2) + 4 half, col = lane & 31  ->  LDS [unit][64 samples]  ->  lane = sample
 #pragma unroll
@@ -89,10 +131,26 @@ __device__ __forceinline__ void block_part_lds(const float *__restrict__ A, cons
     __builtin_amdgcn_wave_barrier();
 }
 
+__device__ __forceinline__ void block_part_lds(const float *__restrict__ A, const float *Sl, int K, float *ldsw, int lane) {
+    block_part_lds_x<false, false>(A, nullptr, Sl, K, ldsw, lane, nullptr);
+}
+
 // Same product with lane = sample holding all 32 units in registers afterwards.
 __device__ __forceinline__ void block_part(const float *__restrict__ A, const float *Sl, int K, float *ldsw, int lane,
                                            f32x32 &out) {
     block_part_lds(A, Sl, K, ldsw, lane);
+#pragma unroll
+    for (int u = 0; u < MT; ++u) out[u] = ldsw[u * 64 + lane];
+    __builtin_amdgcn_wave_barrier();
+}
+
+// mode 1: first tile of a pair (also accumulates the next tile's products into the stash); mode 2: second tile (starts from
+// the stash, K = the 32 units of the first tile); mode 0: unpaired.
+__device__ __forceinline__ void block_part_mode(int mode, const float *__restrict__ A, const float *__restrict__ A2,
+                                                const float *Sl, int K, float *ldsw, int lane, float *stash, f32x32 &out) {
+    if (mode == 1) block_part_lds_x<true, false>(A, A2, Sl, K, ldsw, lane, stash);
+    else if (mode == 2) block_part_lds_x<false, true>(A, nullptr, Sl, K, ldsw, lane, stash);
+    else block_part_lds_x<false, false>(A, nullptr, Sl, K, ldsw, lane, nullptr);
 #pragma unroll
     for (int u = 0; u < MT; ++u) out[u] = ldsw[u * 64 + lane];
     __builtin_amdgcn_wave_barrier();
@@ -113,8 +171,8 @@ static inline size_t arnsf_lds_floats(int R) {
 template <bool SPL>
 __global__ void __launch_bounds__(64 * MW)
 maf_inverse_kernel(const float *__restrict__ z, float *__restrict__ y, float *__restrict__ logdet,
-                   const float *__restrict__ blob, const int *__restrict__ table, float *S, float *Xs, int64_t B, int acc,
-                   RqsParams<float> sp, int R) {
+                   const float *__restrict__ blob, const int *__restrict__ table, float *S, float *Xs, float *Ps, int64_t B,
+                   int acc, RqsParams<float> sp, int R) {
     __shared__ float lds[SPL ? 1 : MW][SPL ? 4 : MT * 64];
     __shared__ __attribute__((aligned(16))) float seqs[SPL ? 4 : M_SEQ];  // the tile's biases and diagonal blocks, shared by the 4 waves
     extern __shared__ __attribute__((aligned(16))) float dyn[];            // spline variant: everything lives here
@@ -134,6 +192,7 @@ maf_inverse_kernel(const float *__restrict__ z, float *__restrict__ y, float *__
     const float *zr = z + (valid ? sample : B - 1) * D;
     float *Sw = S + wts * ((int64_t)5 * Hp * 64);   // [layer][Hp/8][2][64][4]
     float *Xw = Xs + wts * ((int64_t)Dp * 64);      // [Dp/8][2][64][4]
+    float *Pw = Ps ? Ps + wts * ((int64_t)5 * MT * 64) : nullptr;   // pair stash: [product][8][64][4] raw accumulators
     float ld = 0.0f, xcarry;
     if constexpr (SPL) {   // feature 0 depends on no hidden unit: its parameters are the final layer's bias
         const int K = sp.K;
@@ -178,11 +237,34 @@ maf_inverse_kernel(const float *__restrict__ z, float *__restrict__ y, float *__
         __threadfence_block();  // the activation scratch written by the other lanes of this wave is read below
         f32x32 p0, p1, p2, p3, p4, pF;
         block_part(A0, Xw, K0, ldsw, lane, p0);
-        block_part(Ah + (size_t)0 * Kh * MT, Sw + (size_t)0 * Hp * 64, Kh, ldsw, lane, p1);
-        block_part(Ah + (size_t)1 * Kh * MT, Sw + (size_t)1 * Hp * 64, Kh, ldsw, lane, p2);
-        block_part(Ah + (size_t)2 * Kh * MT, Sw + (size_t)2 * Hp * 64, Kh, ldsw, lane, p3);
-        block_part(Ah + (size_t)3 * Kh * MT, Sw + (size_t)3 * Hp * 64, Kh, ldsw, lane, p4);
-        if constexpr (!SPL) block_part(Ah + (size_t)4 * Kh * MT, Sw + (size_t)4 * Hp * 64, Kh, ldsw, lane, pF);
+        if constexpr (SPL) {
+            block_part(Ah + (size_t)0 * Kh * MT, Sw + (size_t)0 * Hp * 64, Kh, ldsw, lane, p1);
+            block_part(Ah + (size_t)1 * Kh * MT, Sw + (size_t)1 * Hp * 64, Kh, ldsw, lane, p2);
+            block_part(Ah + (size_t)2 * Kh * MT, Sw + (size_t)2 * Hp * 64, Kh, ldsw, lane, p3);
+            block_part(Ah + (size_t)3 * Kh * MT, Sw + (size_t)3 * Hp * 64, Kh, ldsw, lane, p4);
+        } else {
+            // tile pairing (see block_part_lds_x): even tile = its own products + the next tile's over the same operands;
+            // odd tile = the stash + the 32 units of its partner
+            const int mode = !Pw ? 0 : ((t & 1) ? 2 : (t + 1 < T ? 1 : 0));
+            const float *Ah2 = Ah;
+            int Kh2 = 0;
+            if (mode == 1) {
+                const int *te2 = te + M_ENT;
+                Ah2 = blob + te2[3] + (size_t)te2[2] * MT;
+                Kh2 = Kh + MT;
+            }
+            const int koff = mode == 2 ? Kh - MT : 0;         // the partner's units: the last 32 of this tile's K range
+            const int Kb = mode == 2 ? MT : Kh;
+#define NF_MAF_BP(l, OUT)                                                                                                   \
+            block_part_mode(mode, Ah + (size_t)(l) * Kh * MT + (size_t)koff * MT, Ah2 + (size_t)(l) * Kh2 * MT,                \
+                            Sw + (size_t)(l) * Hp * 64 + (size_t)koff * 64, Kb, ldsw, lane, Pw + (size_t)(l) * MT * 64, OUT)
+            NF_MAF_BP(0, p1);
+            NF_MAF_BP(1, p2);
+            NF_MAF_BP(2, p3);
+            NF_MAF_BP(3, p4);
+            NF_MAF_BP(4, pF);
+#undef NF_MAF_BP
+        }
 #pragma unroll
         for (int u = 0; u < MT; ++u) {
             p0[u] += bias[u];
@@ -314,7 +396,7 @@ extern "C" int64_t nf_maf_inverse_scratch_floats(int64_t B, int D, int hidden_pa
     if (B < 0 || D < 1 || hidden_padded < 0) return NF_EINVAL;
     const int64_t nwt = (B + 63) / 64;
     const int64_t Dp = (D + 31) / 32 * 32;
-    return nwt * 64 * ((int64_t)5 * hidden_padded + Dp);
+    return nwt * 64 * ((int64_t)5 * hidden_padded + Dp + 5 * nf::MT);      // activations | features | pair stash
 }
 
 extern "C" int nf_maf_inverse(const void *z, void *y, void *logdet, const void *blob, const int32_t *table,
@@ -331,8 +413,13 @@ extern "C" int nf_maf_inverse(const void *z, void *y, void *logdet, const void *
     // the feature scratch is read with zero weights before it is written (K0 is padded to 32): it must hold finite values
     if (hipMemsetAsync(Xs, 0, (size_t)nwt * 64 * Dp * sizeof(float), st) != hipSuccess) return NF_EIO;
     const int grid = (int)((nwt + nf::MW - 1) / nf::MW);
+#ifdef NF_MAF_NO_PAIR
+    float *Ps = nullptr;
+#else
+    float *Ps = Xs + nwt * 64 * Dp;
+#endif
     hipLaunchKernelGGL(nf::maf_inverse_kernel<false>, dim3(grid), dim3(64 * nf::MW), 0, st, (const float *)z, (float *)y,
-                       (float *)logdet, (const float *)blob, (const int *)table, S, Xs, B, acc, nf::RqsParams<float>{}, 2);
+                       (float *)logdet, (const float *)blob, (const int *)table, S, Xs, Ps, B, acc, nf::RqsParams<float>{}, 2);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -362,7 +449,7 @@ extern "C" int nf_arnsf_inverse(const void *z, void *y, void *logdet, const void
     if (nf::opt_in_lds(reinterpret_cast<const void *>(&nf::maf_inverse_kernel<true>), lds, opted) != NF_OK) return NF_ENOTSUP;
     const int grid = (int)((nwt + nf::MW - 1) / nf::MW);
     hipLaunchKernelGGL(nf::maf_inverse_kernel<true>, dim3(grid), dim3(64 * nf::MW), lds, st, (const float *)z, (float *)y,
-                       (float *)logdet, (const float *)blob, (const int *)table, S, Xs, B, acc, sp, R);
+                       (float *)logdet, (const float *)blob, (const int *)table, S, Xs, (float *)nullptr, B, acc, sp, R);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
