@@ -401,7 +401,8 @@ int nf_maf_affine(const void *x, const void *params, void *y, void *logdet, int6
  *   blob, table : device copies of the arrays produced by the host packer (normflows_amd/flows/maf_pack.py;
  *                 layout documented there); table[3] = hidden_padded.
  *   scratch     : nf_maf_inverse_scratch_floats(B, D, hidden_padded) floats of device memory owned by the caller
- *                 (per-wave activation state, 10.5 KB per sample for D=128, H=512); contents need not be initialised.
+ *                 (per-wave activation state, 10.5 KB per sample for D=128, H=512, + 640 B per sample of tile-pair stash);
+ *                 contents need not be initialised.
  *   z, y (B, D) row-major; logdet (B) accumulated as `acc` says with -sum log(scale).
  */
 int64_t nf_maf_inverse_scratch_floats(int64_t B, int D, int hidden_padded);

@@ -74,7 +74,7 @@ def test_c_abi_argument_validation_newer_entry_points(nfa):
     assert lib.nf_maf_inverse(one, one, one, one, one, one, i64(8), i32(128), i32(500), i32(0), null) == -22
     assert lib.nf_maf_inverse(one, one, one, null, one, one, i64(8), i32(128), i32(512), i32(0), null) == -14
     assert lib.nf_maf_inverse(null, null, null, null, null, null, i64(0), i32(128), i32(512), i32(0), null) == 0
-    assert lib.nf_maf_inverse_scratch_floats(i64(65), i32(128), i32(512)) == 2 * 64 * (5 * 512 + 128)
+    assert lib.nf_maf_inverse_scratch_floats(i64(65), i32(128), i32(512)) == 2 * 64 * (5 * 512 + 128 + 5 * 32)   # + pair stash
 
     def arnsf(K, tails, hp=512, B=8, blob=one):
         return lib.nf_arnsf_inverse(one, one, one, blob, one, one, i64(B), i32(64), i32(hp), i32(K), i32(tails), f64(3.0),
