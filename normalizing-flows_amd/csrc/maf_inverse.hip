@@ -131,6 +131,96 @@ __device__ __forceinline__ void block_part_lds_x(const float *__restrict__ A, co
     __builtin_amdgcn_wave_barrier();
 }
 
+// The same product with the activation operand (B) streamed through a per-wave LDS ring by LDS-DMA, MRB k-blocks ahead
+// (affine variant).  With the operands loaded into registers eight k-blocks ahead the look-ahead is 4096 MFMA cycles (1.9 us):
+// ablation with an L2-resident scratch ran the block part 0.38 ms faster per launch, i.e. HBM latency was exposed.  The ring
+// costs no registers, so the look-ahead is MRB - 1 = 11 k-blocks; A (weights, L2-resident) stays on the register stages.
+// Synchronisation: loads retire in order, exactly 2 (MRB - 1) DMA instructions are younger than the k-block about to be
+// consumed while requests are being issued (the register loads of A in between only make the wait stricter), so
+// `s_waitcnt vmcnt(2 (MRB - 1))` means it has landed; the tail drains.  A slot is refilled one step after it was consumed (its
+// ds_reads completed before that step's MFMAs).
+constexpr int MRB = 12;
+template <bool PAIR, bool INIT>
+__device__ __forceinline__ void block_part_ring(const float *__restrict__ A, const float *__restrict__ A2, const float *Sl,
+                                                int K, float *ldsw, int lane, float *stash, float *ring) {
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    const int half = lane >> 5, l31 = lane & 31;
+    if constexpr (INIT) {
+        const f32x4 *ps = reinterpret_cast<const f32x4 *>(stash) + lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const f32x4 v0 = ps[r * 64], v1 = ps[(4 + r) * 64];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { c0[4 * r + i] = v0[i]; c1[4 * r + i] = v1[i]; }
+        }
+    }
+    const f32x4 *pa = reinterpret_cast<const f32x4 *>(A) + half * 32 + l31;
+    const f32x4 *pa2 = reinterpret_cast<const f32x4 *>(PAIR ? A2 : A) + half * 32 + l31;
+    const int nkb = K >> 3;
+    if (nkb > 0) {
+        auto dma = [&](int kb) {
+            const float *src = Sl + (size_t)kb * 512 + lane * 4;
+            float *slot = ring + (kb % MRB) * 512;
+            __builtin_amdgcn_global_load_lds(src, (lds_ptr)slot, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(src + 256, (lds_ptr)(slot + 256), 16, 0, 0);
+        };
+        struct Stage { f32x4 a, a2; };
+        auto ld = [&](int kb, Stage &st) {
+            const int k = kb < nkb ? kb : nkb - 1;
+            st.a = pa[k * 64];
+            if constexpr (PAIR) st.a2 = pa2[k * 64];
+        };
+        // one step: request k-block kb + MRB - 1 (if the product has one) and wait for k-block kb.  While requests are still
+        // being issued exactly 2 (MRB - 1) DMA instructions are younger than k-block kb's; in the tail nothing new is issued and
+        // the wait is a full drain (everything outstanding is needed within the next MRB - 1 steps anyway).  No DMA is ever issued
+        // past the product's end: with left-overs in flight two back-to-back products could exceed the 6-bit vmcnt counter.
+        auto mm = [&](int kb, const Stage &st) {
+            if (kb + MRB - 1 < nkb) {
+                dma(kb + MRB - 1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (MRB - 1)) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            const float *slot = ring + (kb % MRB) * 512 + (half * 64 + l31) * 4;
+            const f32x4 b0 = *reinterpret_cast<const f32x4 *>(slot), b1 = *reinterpret_cast<const f32x4 *>(slot + 128);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                c0 = MFMA32(st.a[i], b0[i], c0);
+                c1 = MFMA32(st.a[i], b1[i], c1);
+                if constexpr (PAIR) {
+                    c2 = MFMA32(st.a2[i], b0[i], c2);
+                    c3 = MFMA32(st.a2[i], b1[i], c3);
+                }
+            }
+        };
+        for (int j = 0; j < MRB - 1 && j < nkb; ++j) dma(j);
+        Stage s0, s1, s2, s3;
+        ld(0, s0); ld(1, s1); ld(2, s2); ld(3, s3);
+        for (int kb = 0; kb < nkb; kb += 4) {        // nkb is a multiple of 4
+            mm(kb, s0); ld(kb + 4, s0);
+            mm(kb + 1, s1); ld(kb + 5, s1);
+            mm(kb + 2, s2); ld(kb + 6, s2);
+            mm(kb + 3, s3); ld(kb + 7, s3);
+        }
+    }
+    if constexpr (PAIR) {
+        f32x4 *ps = reinterpret_cast<f32x4 *>(stash) + lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ps[r * 64] = f32x4{c2[4 * r], c2[4 * r + 1], c2[4 * r + 2], c2[4 * r + 3]};
+            ps[(4 + r) * 64] = f32x4{c3[4 * r], c3[4 * r + 1], c3[4 * r + 2], c3[4 * r + 3]};
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        ldsw[row * 64 + l31] = c0[r];
+        ldsw[row * 64 + 32 + l31] = c1[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ void block_part_lds(const float *__restrict__ A, const float *Sl, int K, float *ldsw, int lane) {
     block_part_lds_x<false, false>(A, nullptr, Sl, K, ldsw, lane, nullptr);
 }
@@ -147,10 +237,17 @@ __device__ __forceinline__ void block_part(const float *__restrict__ A, const fl
 // mode 1: first tile of a pair (also accumulates the next tile's products into the stash); mode 2: second tile (starts from
 // the stash, K = the 32 units of the first tile); mode 0: unpaired.
 __device__ __forceinline__ void block_part_mode(int mode, const float *__restrict__ A, const float *__restrict__ A2,
-                                                const float *Sl, int K, float *ldsw, int lane, float *stash, f32x32 &out) {
+                                                const float *Sl, int K, float *ldsw, int lane, float *stash, float *ring,
+                                                f32x32 &out) {
+#ifdef NF_MAF_NO_RING
     if (mode == 1) block_part_lds_x<true, false>(A, A2, Sl, K, ldsw, lane, stash);
     else if (mode == 2) block_part_lds_x<false, true>(A, nullptr, Sl, K, ldsw, lane, stash);
     else block_part_lds_x<false, false>(A, nullptr, Sl, K, ldsw, lane, nullptr);
+#else
+    if (mode == 1) block_part_ring<true, false>(A, A2, Sl, K, ldsw, lane, stash, ring);
+    else if (mode == 2) block_part_ring<false, true>(A, nullptr, Sl, K, ldsw, lane, stash, ring);
+    else block_part_ring<false, false>(A, nullptr, Sl, K, ldsw, lane, nullptr, ring);
+#endif
 #pragma unroll
     for (int u = 0; u < MT; ++u) out[u] = ldsw[u * 64 + lane];
     __builtin_amdgcn_wave_barrier();
@@ -178,6 +275,8 @@ maf_inverse_kernel(const float *__restrict__ z, float *__restrict__ y, float *__
     extern __shared__ __attribute__((aligned(16))) float dyn[];            // spline variant: everything lives here
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     float *ldsw = SPL ? dyn + wid * (MT * 64) : lds[SPL ? 0 : wid];
+    float *ringw = SPL ? nullptr : dyn + wid * (MRB * 512);      // affine variant: the wave's activation ring (dynamic LDS)
+    (void)ringw;
     float *seqw = SPL ? dyn + MW * MT * 64 : seqs;
     const int64_t wt = (int64_t)blockIdx.x * MW + wid;
     const bool active = wt * 64 < B;  // idle waves of the last workgroup still take part in the staging barriers
@@ -257,7 +356,8 @@ maf_inverse_kernel(const float *__restrict__ z, float *__restrict__ y, float *__
             const int Kb = mode == 2 ? MT : Kh;
 #define NF_MAF_BP(l, OUT)                                                                                                   \
             block_part_mode(mode, Ah + (size_t)(l) * Kh * MT + (size_t)koff * MT, Ah2 + (size_t)(l) * Kh2 * MT,                \
-                            Sw + (size_t)(l) * Hp * 64 + (size_t)koff * 64, Kb, ldsw, lane, Pw + (size_t)(l) * MT * 64, OUT)
+                            Sw + (size_t)(l) * Hp * 64 + (size_t)koff * 64, Kb, ldsw, lane, Pw + (size_t)(l) * MT * 64,    \
+                            ringw, OUT)
             NF_MAF_BP(0, p1);
             NF_MAF_BP(1, p2);
             NF_MAF_BP(2, p3);
@@ -418,7 +518,11 @@ extern "C" int nf_maf_inverse(const void *z, void *y, void *logdet, const void *
 #else
     float *Ps = Xs + nwt * 64 * Dp;
 #endif
-    hipLaunchKernelGGL(nf::maf_inverse_kernel<false>, dim3(grid), dim3(64 * nf::MW), 0, st, (const float *)z, (float *)y,
+    const size_t lds_ring = (size_t)nf::MW * nf::MRB * 512 * sizeof(float);
+    static nf::LdsOptIn opted_aff;
+    if (nf::opt_in_lds(reinterpret_cast<const void *>(&nf::maf_inverse_kernel<false>), lds_ring, opted_aff) != NF_OK)
+        return NF_ENOTSUP;
+    hipLaunchKernelGGL(nf::maf_inverse_kernel<false>, dim3(grid), dim3(64 * nf::MW), lds_ring, st, (const float *)z, (float *)y,
                        (float *)logdet, (const float *)blob, (const int *)table, S, Xs, Ps, B, acc, nf::RqsParams<float>{}, 2);
     NF_CHECK_LAUNCH();
     return NF_OK;
