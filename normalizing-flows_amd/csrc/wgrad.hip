@@ -301,6 +301,91 @@ wgrad_tile_kernel(const float *__restrict__ dY, const float *__restrict__ X, flo
     }
 }
 
+// ---- the same workgroup tile with both operands streamed by LDS-DMA through a 4-slot ring (N == 128, M % 128 == 0,
+// B % 16 == 0) ----------------------------------------------------------------------------------------------------------
+// The tile kernel above stages the next 32 rows through registers: one K-step (1.9 us of MFMAs) of look-ahead, which HBM
+// latency under load exceeds, plus the ds_write pass and two barriers per step.  Here a K-step is 16 rows (8 KB of dY + 8 KB
+// of X per workgroup = 4 DMA instructions per wave, no registers), four slots = three steps (2.8 us) of look-ahead, one
+// barrier per step; `s_waitcnt vmcnt(8)` = the two younger steps already requested may stay outstanding (loads retire in
+// order; the third is requested right after the barrier), drained in the tail.  ReLU of the second operand is applied on the LDS read.
+constexpr int W3_KS = 16, W3_NR = 4;
+__global__ void __launch_bounds__(256, 2)
+wgrad_ring_kernel(const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ part, int64_t B, int M,
+                  int chunk_rows, int want_bias, int x_relu, int64_t zdY, int64_t zX, int64_t zpart) {
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    constexpr int N = 128;
+    dY += (int64_t)blockIdx.z * zdY;
+    X += (int64_t)blockIdx.z * zX;
+    part += (int64_t)blockIdx.z * zpart;
+    __shared__ __attribute__((aligned(16))) float ring[W3_NR][2][W3_KS][W2_T];     // [slot][dY | X][row][128] = 64 KB
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int m0 = blockIdx.y * W2_T;
+    const int64_t b0 = (int64_t)blockIdx.x * chunk_rows;
+    int64_t b1 = b0 + chunk_rows;
+    if (b1 > B) b1 = B;
+    const int nsteps = (int)((b1 - b0) / W3_KS);       // chunk_rows and B are multiples of 16
+    // a wave's 4 DMA instructions of a step: rows 4 wid + {0,1} and + {2,3} of each operand (64 lanes x 16 B = two 128-float rows)
+    const int lrow = lane >> 5, lcol = (lane & 31) * 4;
+    auto issue = [&](int s) {
+        const int64_t r0 = b0 + (int64_t)s * W3_KS + 4 * wid + lrow;
+        float *slotA = &ring[s % W3_NR][0][4 * wid][0], *slotB = &ring[s % W3_NR][1][4 * wid][0];
+        __builtin_amdgcn_global_load_lds(dY + r0 * M + m0 + lcol, (lds_ptr)slotA, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(dY + (r0 + 2) * M + m0 + lcol, (lds_ptr)(slotA + 2 * W2_T), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(X + r0 * N + lcol, (lds_ptr)slotB, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(X + (r0 + 2) * N + lcol, (lds_ptr)(slotB + 2 * W2_T), 16, 0, 0);
+    };
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    float bs0 = 0.0f, bs1 = 0.0f;
+    for (int s = 0; s < W3_NR - 1 && s < nsteps; ++s) issue(s);
+    for (int s = 0; s < nsteps; ++s) {
+        // step s landed (this wave's pieces) once at most the younger steps' 4 (NR - 1) instructions are outstanding; in the
+        // tail fewer are younger: drain
+        if (s + W3_NR - 1 <= nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (W3_NR - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // every wave's pieces of step s landed; every wave is done with slot (s - 1) % NR
+        asm volatile("" ::: "memory");
+        if (s + W3_NR - 1 < nsteps) issue(s + W3_NR - 1);
+        const float *ap = &ring[s % W3_NR][0][h][wm * 64 + i], *bp = &ring[s % W3_NR][1][h][wn * 64 + i];
+#pragma unroll
+        for (int kp = 0; kp < W3_KS / 2; ++kp) {
+            const float a0 = ap[kp * 2 * W2_T], a1 = ap[kp * 2 * W2_T + 32];
+            float x0 = bp[kp * 2 * W2_T], x1 = bp[kp * 2 * W2_T + 32];
+            if (x_relu) { x0 = fmaxf(x0, 0.0f); x1 = fmaxf(x1, 0.0f); }
+            bs0 += a0;
+            bs1 += a1;
+            acc00 = MFMA32(a0, x0, acc00);
+            acc01 = MFMA32(a0, x1, acc01);
+            acc10 = MFMA32(a1, x0, acc10);
+            acc11 = MFMA32(a1, x1, acc11);
+        }
+    }
+    float *out = part + (size_t)blockIdx.x * ((size_t)M * N + M);
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+#pragma unroll
+        for (int t_ = 0; t_ < 2; ++t_) {
+            const f32x16 &acc = s_ == 0 ? (t_ == 0 ? acc00 : acc01) : (t_ == 0 ? acc10 : acc11);
+            const int n = wn * 64 + 32 * t_ + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mm = m0 + wm * 64 + 32 * s_ + (r & 3) + 8 * (r >> 2) + 4 * h;
+                out[(size_t)mm * N + n] = acc[r];
+            }
+        }
+    }
+    if (want_bias && wn == 0) {
+        bs0 += __shfl_xor(bs0, 32);
+        bs1 += __shfl_xor(bs1, 32);
+        if (h == 0) {
+            const int ma = m0 + wm * 64 + i;
+            out[(size_t)M * N + ma] = bs0;
+            out[(size_t)M * N + ma + 32] = bs1;
+        }
+    }
+}
+
 static int wgrad_tile_chunk_rows(int64_t B, int M) {
     const int mt = (M + W2_T - 1) / W2_T;
 #ifndef NF_W2_SLOTS
@@ -371,6 +456,19 @@ static int wgrad_chunk_rows(int64_t B, int M, bool vec) {
 
 }  // namespace nf
 
+static inline bool wgrad_use_ring(int64_t B, int M, int N) {
+#ifdef NF_WGRAD_NO_RING
+    return false;
+#else
+#ifdef NF_WGRAD_RING_M128
+    const int mmin = 128;
+#else
+    const int mmin = 256;
+#endif
+    return N == 128 && M % 128 == 0 && M >= mmin && B % 16 == 0;
+#endif
+}
+
 static inline bool wgrad_use_tile(int M, int N) {
 #ifdef NF_WGRAD_NO_TILE
     return false;
@@ -381,7 +479,7 @@ static inline bool wgrad_use_tile(int M, int N) {
 
 extern "C" int64_t nf_linear_wgrad_scratch_floats(int64_t B, int M, int N) {
     if (B < 0 || M < 1 || N < 1) return NF_EINVAL;
-    if (wgrad_use_tile(M, N)) {
+    if (wgrad_use_tile(M, N) || wgrad_use_ring(B, M, N)) {
         const int rows_t = nf::wgrad_tile_chunk_rows(B, M);
         return ((B + rows_t - 1) / rows_t) * ((int64_t)M * N + M);
     }
@@ -429,7 +527,8 @@ static int wgrad_impl(const void *dY, const void *X, void *dW, void *db, void *s
     if (!dY || !X || !dW || !scratch) return NF_EFAULT;
     hipStream_t st = (hipStream_t)stream;
     const bool vec = N % 4 == 0;
-    const bool tile = wgrad_use_tile(M, N);
+    const bool ring = wgrad_use_ring(B, M, N) && ((((uintptr_t)dY | (uintptr_t)X | (uintptr_t)dY1 | (uintptr_t)X1) & 15) == 0);
+    const bool tile = ring || wgrad_use_tile(M, N);
     const int rows = tile ? nf::wgrad_tile_chunk_rows(B, M) : nf::wgrad_chunk_rows(B, M, vec);
     const int chunks = (int)((B + rows - 1) / rows);
     float *part = (float *)scratch;
@@ -440,7 +539,10 @@ static int wgrad_impl(const void *dY, const void *X, void *dW, void *db, void *s
     const int64_t zdY = np == 2 ? (const float *)dY1 - (const float *)dY : 0, zX = np == 2 ? (const float *)X1 - (const float *)X : 0;
     const int64_t zdW = np == 2 ? (float *)dW1 - (float *)dW : 0, zdb = (np == 2 && db) ? (float *)db1 - (float *)db : 0;
     const int64_t zpart = np == 2 ? single : 0;
-    if (tile) {
+    if (ring) {
+        hipLaunchKernelGGL(nf::wgrad_ring_kernel, dim3(chunks, M / nf::W2_T, np), dim3(256), 0, st, (const float *)dY,
+                           (const float *)X, part, B, M, rows, want_bias, relu_x, zdY, zX, zpart);
+    } else if (tile) {
         hipLaunchKernelGGL(nf::wgrad_tile_kernel, dim3(chunks, (M + nf::W2_T - 1) / nf::W2_T, np), dim3(256), 0, st,
                            (const float *)dY, (const float *)X, part, B, M, N, rows, want_bias, relu_x, zdY, zX, zpart);
     } else if (vec) {
