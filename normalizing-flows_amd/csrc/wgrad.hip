@@ -305,11 +305,17 @@ wgrad_tile_kernel(const float *__restrict__ dY, const float *__restrict__ X, flo
 // B % 16 == 0) ----------------------------------------------------------------------------------------------------------
 // The tile kernel above stages the next 32 rows through registers: one K-step (1.9 us of MFMAs) of look-ahead, which HBM
 // latency under load exceeds, plus the ds_write pass and two barriers per step.  Here a K-step is 16 rows (8 KB of dY + 8 KB
-// of X per workgroup = 4 DMA instructions per wave, no registers), four slots = three steps (2.8 us) of look-ahead, one
-// barrier per step; `s_waitcnt vmcnt(8)` = the two younger steps already requested may stay outstanding (loads retire in
-// order; the third is requested right after the barrier), drained in the tail.  ReLU of the second operand is applied on the LDS read.
-constexpr int W3_KS = 16, W3_NR = 4;
-__global__ void __launch_bounds__(256, 2)
+// of X per workgroup = 4 DMA instructions per wave, no registers), NR slots = NR - 1 steps of look-ahead (0.95 us each), one
+// barrier per step; `s_waitcnt vmcnt(4 (NR - 2))` = the younger steps already requested may stay outstanding (loads retire
+// in order; one more is requested right after the barrier), drained in the tail.  ReLU of the second operand is applied on the LDS read.
+#ifndef NF_W3_NR
+#define NF_W3_NR 3      // measured 4 / 3 / 2 slots: 145 / 139 / 143 us at 768 x 128
+#endif
+#ifndef NF_W3_OCC
+#define NF_W3_OCC 3
+#endif
+constexpr int W3_KS = 16, W3_NR = NF_W3_NR;
+__global__ void __launch_bounds__(256, NF_W3_OCC)
 wgrad_ring_kernel(const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ part, int64_t B, int M,
                   int chunk_rows, int want_bias, int x_relu, int64_t zdY, int64_t zX, int64_t zpart) {
     typedef __attribute__((address_space(3))) void *lds_ptr;
