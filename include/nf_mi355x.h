@@ -514,6 +514,11 @@ int nf_rows_matvec(const void *x, const void *W, void *y, int64_t B, int D, nf_s
 /* Same with a bias (D, may be NULL) and, when logdet != NULL, logdet[b] (acc) ld_sign * (*ld_const) for every row. */
 int nf_rows_matvec_affine(const void *x, const void *W, const void *bias, void *y, void *logdet, const void *ld_const,
                           double ld_sign, int acc, int64_t B, int D, nf_stream_t stream);
+/* Two chained products in one launch: u_b = W1 x_b (written when u != NULL), y_b = W2 u_b + bias (bias may be NULL), logdet as
+ * nf_rows_matvec_affine.  LULinearPermute under autograd (mixing.py:535-563): forward u = U x[perm], y = L u + b; backward
+ * gu = L^T gy, gx = P U^T gu -- u / gu are kept for the factor gradients and never leave the registers between the products. */
+int nf_rows_matvec2(const void *x, const void *W1, const void *W2, const void *bias, void *u, void *y, void *logdet,
+                    const void *ld_const, double ld_sign, int acc, int64_t B, int D, nf_stream_t stream);
 /* LULinearPermute (mixing.py:402-473, :535-563) composed into one dense matrix per direction (fp64 arithmetic in one
  * workgroup; D <= 64, float32 parameters), once per parameter version: out = Wd (D, D) | Ws (D, D) | bias_d (D) |
  * bias_s (D) | log|det| (1) with  .inverse (density): y = Wd x + bias_d, log_det = +log|det|;  .forward (sample):

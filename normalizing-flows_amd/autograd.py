@@ -191,9 +191,14 @@ class LULinearPermuteFn(torch.autograd.Function):
             with torch.no_grad():
                 Lm, Um, Up, diag, lad, LT, UpT = ops.lu_factors(perm, lower_entries.detach(), upper_entries.detach(),
                                                                 udiag_raw.detach(), eps=eps)          # one launch (nf_lu_factors)
-                u = ops.rows_matvec(x, Up)
-                y, ld = ops.rows_matvec_affine(u, Lm, bias.detach(), lad, +1.0, logdet=ld_acc,
-                                               acc=None if ld_acc is None else (L.LD_ADD if acc > 0 else L.LD_SUB))
+                # u = U x[perm] (kept for the backward) and y = L u + b with the constant log-det: one launch (nf_rows_matvec2)
+                from . import config
+                lacc = None if ld_acc is None else (L.LD_ADD if acc > 0 else L.LD_SUB)
+                if config.lu_matvec2:
+                    u, y, ld = ops.rows_matvec2(x, Up, Lm, bias.detach(), lad, +1.0, logdet=ld_acc, acc=lacc)
+                else:
+                    u = ops.rows_matvec(x, Up)
+                    y, ld = ops.rows_matvec_affine(u, Lm, bias.detach(), lad, +1.0, logdet=ld_acc, acc=lacc)
             ctx.save_for_backward(x, y, perm, lower_entries, upper_entries, udiag_raw, bias, u)
             ctx.eps, ctx.direction = eps, direction
             ctx.factors = (Lm, Um, diag, Up, LT, UpT)      # assembled once per step: the backward reuses them
@@ -218,8 +223,12 @@ class LULinearPermuteFn(torch.autograd.Function):
             # reductions, one launch for the packed parameter gradients
             Lm, Um, diag, Up, LT, UpT = fac
             gy = torch.zeros_like(y) if gy is None else gy.contiguous()
-            gu = ops.rows_matvec(gy, LT)                # d/du = L^T gy
-            gx = ops.rows_matvec(gu, UpT)               # d/dx = P (U^T gu)
+            from . import config
+            if config.lu_matvec2:
+                gu, gx, _ = ops.rows_matvec2(gy, LT, UpT)   # d/du = L^T gy, d/dx = P (U^T gu): one launch
+            else:
+                gu = ops.rows_matvec(gy, LT)
+                gx = ops.rows_matvec(gu, UpT)
             # gy^T u (+ the column sums of gy = the bias gradient) and gu^T x as ONE pair launch; gU = (gu^T x)[:, perm] is
             # taken through perm inside nf_lu_param_grads
             from . import config

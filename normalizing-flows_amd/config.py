@@ -61,3 +61,13 @@ fused_chain = True
 def set_fused_chain(mode=True):
     global fused_chain
     fused_chain = bool(mode)
+
+
+# LULinearPermute under autograd: its two batch-side products per direction as ONE launch (nf_rows_matvec2); False = two
+# nf_rows_matvec launches (ablation).
+lu_matvec2 = True
+
+
+def set_lu_matvec2(mode=True):
+    global lu_matvec2
+    lu_matvec2 = bool(mode)

@@ -219,6 +219,95 @@ rows_matvec_kernel(const float *__restrict__ x, const float *__restrict__ W, flo
     }
 }
 
+// u_b = W1 x_b, y_b = W2 u_b (+ bias) in ONE launch: LULinearPermute's two batch-side products (forward: u = U x[perm] kept for
+// the backward, y = L u + b; backward: gu = L^T gy kept for the factor gradients, gx = P U^T gu).  The first product's C
+// registers are the second product's B operand: lane-half hh of C register c of row-block m1 holds unit
+// k = 32 m1 + 8 (c >> 2) + 4 hh + (c & 3), so W2 is laid out in LDS in that contraction order (the trick of rows_block / the fused
+// layer) and u never leaves the registers between the products.
+__global__ void __launch_bounds__(64 * RM_NW)
+rows_matvec2_kernel(const float *__restrict__ x, const float *__restrict__ W1, const float *__restrict__ W2,
+                    float *__restrict__ u, float *__restrict__ y, int64_t B, int D, const float *__restrict__ bias,
+                    float *__restrict__ logdet, const float *__restrict__ ld_const, float ld_sign, int acc) {
+    __shared__ __attribute__((aligned(16))) float Wl1[2 * 8 * 64 * 4];   // [m][s4][lane][4]: W1[32 m + (lane & 31)][4 s4 + r + 32 hh]
+    __shared__ __attribute__((aligned(16))) float Wl2[2 * 8 * 64 * 4];   // [m][c4][lane][4]: W2[32 m + (lane & 31)][32 (c4 >> 2) + 8 (c4 & 3) + 4 hh + r]
+    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
+    for (int i = tid; i < 2 * 8 * 64 * 4; i += 64 * RM_NW) {
+        const int r = i & 3, l = (i >> 2) & 63, s4 = (i >> 8) & 7, m = i >> 11;
+        const int row = 32 * m + (l & 31);
+        const int c1 = 4 * s4 + r + 32 * (l >> 5);
+        const int c2 = 32 * (s4 >> 2) + 8 * (s4 & 3) + 4 * (l >> 5) + r;
+        Wl1[i] = (row < D && c1 < D) ? W1[row * D + c1] : 0.0f;
+        Wl2[i] = (row < D && c2 < D) ? W2[row * D + c2] : 0.0f;
+    }
+    const int64_t row = ((int64_t)blockIdx.x * RM_NW + (tid >> 6)) * 32 + (lane & 31);
+    float xv[32];
+    if (D == RM_D && row < B) {
+        const float *src = x + row * RM_D + 32 * hh;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(src + 4 * q);
+            xv[4 * q] = v[0]; xv[4 * q + 1] = v[1]; xv[4 * q + 2] = v[2]; xv[4 * q + 3] = v[3];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) xv[k] = (row < B && 32 * hh + k < D) ? x[row * D + 32 * hh + k] : 0.0f;
+    }
+    __syncthreads();
+    f32x16 t0 = {0}, t1 = {0};
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        f32x16 &o = m == 0 ? t0 : t1;
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(Wl1 + ((m * 8 + s4) * 64 + lane) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], xv[4 * s4 + r], o, 0, 0, 0);
+        }
+    }
+    auto store_rows = [&](float *dst, const f32x16 &o0, const f32x16 &o1) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const f32x16 &o = m == 0 ? o0 : o1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = 32 * m + 8 * q + 4 * hh;   // C register 4 q + r = output row c0 + r of the product
+                if (D == RM_D) {
+                    *reinterpret_cast<f32x4 *>(dst + row * RM_D + c0) = f32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (c0 + r < D) dst[row * D + c0 + r] = o[4 * q + r];
+                }
+            }
+        }
+    };
+    if (row < B && u) store_rows(u, t0, t1);
+    f32x16 o0 = {0}, o1 = {0};
+    if (bias) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int r0 = 8 * (c >> 2) + 4 * hh + (c & 3);
+            o0[c] = r0 < D ? bias[r0] : 0.0f;
+            o1[c] = 32 + r0 < D ? bias[32 + r0] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        f32x16 &o = m == 0 ? o0 : o1;
+#pragma unroll
+        for (int c4 = 0; c4 < 8; ++c4) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(Wl2 + ((m * 8 + c4) * 64 + lane) * 4);
+            const f32x16 &t = (c4 >> 2) == 0 ? t0 : t1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], t[4 * (c4 & 3) + r], o, 0, 0, 0);
+        }
+    }
+    if (row < B) {
+        if (logdet && hh == 0) ld_store(logdet + row, ld_sign * (*ld_const), acc);
+        store_rows(y, o0, o1);
+    }
+}
+
 }  // namespace nf
 
 using namespace nf;
@@ -234,6 +323,21 @@ extern "C" int nf_rows_matvec_affine(const void *x, const void *W, const void *b
     hipLaunchKernelGGL(rows_matvec_kernel, dim3((unsigned)grid), dim3(64 * RM_NW), 0, (hipStream_t)stream, (const float *)x,
                        (const float *)W, (float *)y, B, D, (const float *)bias, (float *)logdet, (const float *)ld_const,
                        (float)ld_sign, acc);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_rows_matvec2(const void *x, const void *W1, const void *W2, const void *bias, void *u, void *y, void *logdet,
+                               const void *ld_const, double ld_sign, int acc, int64_t B, int D, nf_stream_t stream) {
+    if (B < 0 || D < 1 || acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
+    if (D > RM_D) return NF_ENOTSUP;
+    if (B == 0) return NF_OK;
+    if (!x || !W1 || !W2 || !y || (logdet && !ld_const)) return NF_EFAULT;
+    const int64_t grid = (B + 32 * RM_NW - 1) / (32 * RM_NW);
+    if (grid > 0x7fffffff) return NF_ERANGE;
+    hipLaunchKernelGGL(rows_matvec2_kernel, dim3((unsigned)grid), dim3(64 * RM_NW), 0, (hipStream_t)stream, (const float *)x,
+                       (const float *)W1, (const float *)W2, (float *)u, (float *)y, B, D, (const float *)bias, (float *)logdet,
+                       (const float *)ld_const, (float)ld_sign, acc);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

@@ -410,6 +410,25 @@ def rows_matvec_affine(x, W, bias, ld_const=None, ld_sign=1.0, logdet=None, acc=
     return y, logdet
 
 
+def rows_matvec2(x, W1, W2, bias=None, ld_const=None, ld_sign=1.0, logdet=None, acc=None, want_u=True):
+    """(u, y, logdet): u_b = W1 x_b, y_b = W2 u_b + bias in one launch (nf_rows_matvec2); (B, D <= 64) float32."""
+    L.require_device(x, W1, W2, bias, ld_const, logdet)
+    x = x.contiguous()
+    B, D = x.shape
+    u = torch.empty_like(x) if want_u else None
+    y = torch.empty_like(x)
+    if ld_const is not None and logdet is None:
+        logdet = torch.empty(B, dtype=x.dtype, device=x.device)
+        acc = L.LD_WRITE
+    elif acc is None:
+        acc = L.LD_ADD
+    rc = L.lib().nf_rows_matvec2(ptr(x), ptr(W1.contiguous()), ptr(W2.contiguous()), ptr(bias), ptr(u), ptr(y),
+                                 ptr(logdet if ld_const is not None else None), ptr(ld_const), f64(ld_sign), i32(acc), i64(B),
+                                 i32(D), L.stream())
+    L.check(rc, "nf_rows_matvec2")
+    return u, y, logdet
+
+
 def inv1x1_wgrad(z, gy, gld):
     """(gW (C, C), g log|det|-per-pixel (0-dim)) of the per-pixel product y = W z (mixing.py:106-133): gW = sum over
     pixels of gy z^T, partial sums per group of images added in a fixed order."""

@@ -214,6 +214,29 @@ def test_rows_matvec_kernel(nfa, B, D):
     assert torch.equal(y, nfa.ops.rows_matvec(x, Wm))     # deterministic
 
 
+@pytest.mark.parametrize("B,D", [(65536, 64), (1000, 64), (333, 20), (70, 5)])
+def test_rows_matvec2_equals_two_products(nfa, B, D):
+    """nf_rows_matvec2 (u = W1 x, y = W2 u + b in one launch, u through the permuted contraction order) against two
+    nf_rows_matvec launches and fp64."""
+    torch.manual_seed(B + D)
+    x = torch.randn(B, D, device=DEV)
+    W1, W2 = torch.randn(D, D, device=DEV), torch.randn(D, D, device=DEV)
+    b = torch.randn(D, device=DEV)
+    c = torch.tensor([0.75], device=DEV)
+    ld0 = torch.randn(B, device=DEV)
+    ld = ld0.clone()
+    u, y, ld = nfa.ops.rows_matvec2(x, W1, W2, b, c, -1.0, logdet=ld, acc=nfa._lib.LD_ADD)
+    u1 = nfa.ops.rows_matvec(x, W1)
+    y1, _ = nfa.ops.rows_matvec_affine(u1, W2, b)
+    assert torch.equal(u, u1)
+    ref = ((x.double() @ W1.double().t()) @ W2.double().t() + b.double()).float()
+    assert_close(y.cpu().numpy(), ref.cpu().numpy(), what="rows_matvec2", rtol=1e-5, atol=1e-3)
+    assert float((y - y1).abs().max()) <= 1e-5 * float(y1.abs().max())
+    assert torch.allclose(ld, ld0 - 0.75)
+    u2, y2, _ = nfa.ops.rows_matvec2(x, W1, W2, b)
+    assert torch.equal(y, y2) and torch.equal(u, u2)
+
+
 def test_roctx_ranges_do_not_change_results(nfa):
     torch.manual_seed(0)
     flows = [nfa.flows.CoupledRationalQuadraticSpline(64, 2, 128, num_bins=8), nfa.flows.LULinearPermute(64), nfa.flows.ActNorm(64)]

@@ -17,7 +17,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=65536)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--no-wgrad-pair", action="store_true", help="ablation: the residual blocks' weight gradients as two launches")
+ap.add_argument("--no-matvec2", action="store_true", help="ablation: LULinearPermute's chained products as two launches each")
 a = ap.parse_args()
+if a.no_matvec2:
+    import normflows_amd
+    normflows_amd.config.set_lu_matvec2(False)
 if a.no_wgrad_pair:
     import normflows_amd
     normflows_amd.config.set_wgrad_pair(False)
