@@ -18,6 +18,7 @@ ap.add_argument("--batch", type=int, default=65536)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--no-wgrad-pair", action="store_true", help="ablation: the residual blocks' weight gradients as two launches")
 ap.add_argument("--no-matvec2", action="store_true", help="ablation: LULinearPermute's chained products as two launches each")
+ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the default foreach implementation")
 a = ap.parse_args()
 if a.no_matvec2:
     import normflows_amd
@@ -28,7 +29,7 @@ if a.no_wgrad_pair:
 dev = torch.device("cuda:0")
 m = build_c2_model().to(dev)
 x = c2_inputs(a.batch).to(dev)
-opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=True) if a.fused_adam else torch.optim.Adam(m.parameters(), lr=1e-4)
 for i in range(2 + a.steps):
     if i == 2:
         torch.cuda.synchronize()
