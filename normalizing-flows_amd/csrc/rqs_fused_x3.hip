@@ -165,8 +165,13 @@ struct A3 {
 __device__ __forceinline__ A3 load_a3(const unsigned short *abuf, int lane) {
     A3 a;
     a.hi = *reinterpret_cast<const bf16x8 *>(abuf + lane * 8);
+#ifdef NF_X3_ABL_LDS13      // timing ablation (wrong results): one LDS read per row-block instead of three
+    a.mid = a.hi;
+    a.lo = a.hi;
+#else
     a.mid = *reinterpret_cast<const bf16x8 *>(abuf + 64 * 8 + lane * 8);
     a.lo = *reinterpret_cast<const bf16x8 *>(abuf + 2 * 64 * 8 + lane * 8);
+#endif
     return a;
 }
 __device__ __forceinline__ void mm_x3_4(const unsigned short *buf, int lane, const Split3 &b, f32x16 &c0, f32x16 &c1,
