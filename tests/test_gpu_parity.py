@@ -971,6 +971,26 @@ def test_maf_layer_vs_reference(nfa, oracle):
     assert_close(N(xr), g["x"], what="roundtrip", rtol=1e-4, atol=1e-4)
 
 
+def test_maf_inverse_full_batch_round_trip_and_determinism(nfa):
+    """BASELINE configs[4] geometry at the full batch (65 536 rows = 1024 waves, every CU busy): the one-pass inverse is
+    bit-identical run to run and inverts the forward pass.  Size-dependent by design: the kernel's counted `vmcnt` waits
+    (LDS-DMA ring, tile pairing) only misbehave under full memory load -- a too-permissive count passed every small-batch
+    parity test and failed here."""
+    torch.manual_seed(5)
+    layer = nfa.flows.MaskedAffineAutoregressive(128, 512, num_blocks=2)
+    _perturb(layer, 0.05, 9)
+    layer = layer.to(DEV)
+    x = torch.randn(65536, 128, device=DEV)
+    with torch.no_grad():
+        z1, ld1 = layer.inverse(x)
+        z2, ld2 = layer.inverse(x)
+        z3, ld3 = layer.inverse(x)
+        xr, ldf = layer.forward(z1)
+    assert torch.equal(z1, z2) and torch.equal(z1, z3) and torch.equal(ld1, ld2) and torch.equal(ld1, ld3)
+    assert float((xr - x).abs().max()) < 2e-4
+    assert float((ldf + ld1).abs().max()) < 2e-3
+
+
 def test_maf_config5_width_vs_reference(nfa):
     """d = 128, hidden 512 (the BASELINE config-5 layer): seeded construction + the fixture's perturbation reproduce the
     reference's weights; forward and the 128-pass inverse match its outputs."""

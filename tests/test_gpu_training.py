@@ -189,6 +189,38 @@ def test_masked_residual_block_training_uses_masked_weights(nfa):
         assert _rel(N_(a), N_(b)) < 2e-4 * max(1.0, float(b.abs().max())), (a.shape, _rel(N_(a), N_(b)))
 
 
+def test_spline_backward_pipelined_kernel_full_batch(nfa):
+    """The software-pipelined spline backward (counted vmcnt, LDS-DMA double buffering; even B, benchmark layer shape) at
+    the full batch against the wave-private kernel it specialises (odd B takes that one): same rows, same gradients to rounding; and
+    bit-identical row gradients run to run."""
+    torch.manual_seed(11)
+    B = 65536
+    x = (torch.randn(B + 1, 64) * 1.5).to(DEV)
+    gy = torch.randn(B + 1, 64).to(DEV)
+    gld = torch.randn(B + 1).to(DEV)
+    cond = torch.randn(B + 1, 32, 24).to(DEV)
+    cond[:, :, 23] = 0.0
+    uw, uh, ud = torch.randn(32, 8).to(DEV), torch.randn(32, 8).to(DEV), torch.randn(32, 7).to(DEV)
+    iidx = torch.arange(0, 64, 2, device=DEV)
+    tidx = torch.arange(1, 64, 2, device=DEV)
+    kw = dict(tail_bound=3.0, wh_div=float(np.sqrt(128.0)))
+    a = nfa.ops.rqs_coupling_bwd_p24(x[:B].contiguous(), gy[:B].contiguous(), gld[:B].contiguous(), cond[:B].contiguous(),
+                                     uw, uh, ud, iidx, tidx, **kw)
+    b = nfa.ops.rqs_coupling_bwd_p24(x[:B].contiguous(), gy[:B].contiguous(), gld[:B].contiguous(), cond[:B].contiguous(),
+                                     uw, uh, ud, iidx, tidx, **kw)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    c = nfa.ops.rqs_coupling_bwd_p24(x, gy, gld, cond, uw, uh, ud, iidx, tidx, **kw)       # odd B: the general kernel
+    for i in (0, 1):        # row gradients: the same arithmetic inlined into two kernels (fma contraction may differ by an ulp)
+        ref = c[i][:B].double()
+        err = (a[i].double() - ref).abs() / (1.0 + ref.abs())
+        assert float(err.max()) < 1e-4 and float((err > 1e-6).double().mean()) < 1e-3, (i, float(err.max()))
+    e = nfa.ops.rqs_coupling_bwd_p24(x[B:].contiguous(), gy[B:].contiguous(), gld[B:].contiguous(), cond[B:].contiguous(),
+                                     uw, uh, ud, iidx, tidx, **kw)                         # the extra row alone
+    for i in (2, 3, 4):     # shared parameters: fp32 sums over 65 536 rows in atomic order
+        ref = c[i].double() - e[i].double()
+        assert float((a[i].double() - ref).abs().max()) < 1e-3 * float(ref.abs().max()) + 1e-2
+
+
 def test_linear_autograd_matches_torch(nfa):
     torch.manual_seed(0)
     lin = nfa.nets.Linear(48, 96).to(DEV)
