@@ -155,6 +155,32 @@ def main():
         return xa + torch.nn.functional.linear(torch.relu(h), W2, b1)
     t = timeit(lib_block)
     report("  library residual block forward (2 GEMM + 3 elementwise)", t, B * 128 * 12)
+    # ---- round-2 training kernels of the benchmark layer ----
+    cond24 = torch.randn(B, 32, 24, device=dev)
+    cond24[:, :, 23] = 0.0
+    gy, gld = torch.randn(B, D, device=dev), torch.randn(B, device=dev)
+    iidx, tidx = p.identity_features, p.transform_features
+    t = timeit(lambda: ops.rqs_coupling_bwd_p24(x, gy, gld, cond24, uw, uh, ud, iidx, tidx, tail_bound=3.0,
+                                                wh_div=float(128 ** 0.5)))
+    report("nf_rqs_coupling_bwd_p24 (software-pipelined spline backward)", t, B * (3 * D * 4 + 4 + 2 * 32 * 24 * 4))
+    h2 = torch.randn(B, 128, device=dev)
+    g2 = torch.randn(B, 768, device=dev)
+    t = timeit(lambda: ops.linear_wgrad(g2, h2, skip_every=24))
+    report("nf_linear_wgrad_skip 768x128 (LDS-DMA ring tile) [%.0f TF]" % (2.0 * B * 768 * 128 / t / 1e12), t, B * (768 + 128) * 4)
+    ga, gb_ = torch.randn(B, 128, device=dev), torch.randn(B, 128, device=dev)
+    t = timeit(lambda: ops.linear_wgrad_pair(ga, xa, gb_, tt, relu_x=True))
+    report("nf_linear_wgrad_pair 2 x (128x128) [%.0f TF]" % (4.0 * B * 128 * 128 / t / 1e12), t, 4 * B * 128 * 4)
+    t = timeit(lambda: ops.linear_wgrad(ga, xa, relu_x=True))
+    report("  nf_linear_wgrad_act 128x128 alone [%.0f TF]" % (2.0 * B * 128 * 128 / t / 1e12), t, 2 * B * 128 * 4)
+    Wm1, Wm2 = torch.randn(D, D, device=dev), torch.randn(D, D, device=dev)
+    t = timeit(lambda: ops.rows_matvec2(x, Wm1, Wm2))
+    report("nf_rows_matvec2 (two chained 64x64 products, u kept)", t, B * D * 4 * 3)
+    blob = ops.rqs_fused_train_blob(2, dev)
+    wf, bf = torch.randn(736, 128, device=dev) * 0.05, torch.randn(736, device=dev) * 0.1
+    ops.rqs_fused_pack_final(blob, wf, bf, uw, uh, ud, 2)
+    t = timeit(lambda: ops.rqs_fused_train_fwd(x, h2, blob, 0, 2))
+    report("nf_rqs_fused_train_fwd (final Linear + coupling) [%.0f TF]" % (2.0 * B * 736 * 128 / t / 1e12), t,
+           B * (2 * D * 4 + 128 * 4 + 32 * 24 * 4 + 4))
     z2 = torch.randn(1024, 2, device=dev)
     b = torch.tensor([1.0, 0.0], device=dev)
     s2, t2 = torch.randn(1024, 2, device=dev), torch.randn(1024, 2, device=dev)
