@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Round-trip and run-to-run determinism of the one-pass MAF inverse (nf_maf_inverse) on the config-5 layer at growing batch
+sizes: the check that caught a too-permissive counted vmcnt wait which every small-batch parity test passed.
+NF_MI355X_LIB selects a build variant."""
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import normflows_amd as nfa
