@@ -147,7 +147,7 @@ int nf_rqs_coupling_bwd_ft(const void *x, const void *grad_y, const void *grad_l
  * nsf/coupling.py:71-128 + utils/splines.py:16-219, tails = linear.
  *
  * Supported shape (anything else returns NF_ENOTSUP and the caller uses nf_rqs_coupling): D = 64 with
- * the alternating mask of wrapper.py:69 (nI = nT = 32), hidden = 128, K = 8, fp32.
+ * the alternating mask of wrapper.py:69 (nI = nT = 32), hidden = 128, K = 4 | 8 | 16 (one kernel instantiation each), fp32.
  *   mask_parity 0: reverse_mask = False (identity = even columns, transform = odd), 1: the opposite.
  * `wpack` is the layer's weights re-laid-out in MFMA operand order by nf_rqs_fused_pack() (device
  * buffer of nf_rqs_fused_pack_size() bytes, 16-byte aligned); weights are torch nn.Linear layout
@@ -168,7 +168,7 @@ int nf_rqs_fused_pack(void *wpack, const void *w_init, const void *b_init, const
  * folded into the per-sample log-det. */
 int nf_rqs_fused_pack_lu(void *wpack, int num_blocks, const int64_t *perm, const void *lower_entries,
                          const void *upper_entries, const void *unconstrained_upper_diag, const void *bias, int D,
-                         double eps, nf_stream_t stream);
+                         double eps, int K, nf_stream_t stream);
 int nf_rqs_fused(const void *x, void *y, void *logdet, const void *wpack, int mask_parity, int fuse_lu, int64_t B,
                  int D, int hidden, int num_blocks, int K, double tail_bound, double min_bin_width,
                  double min_bin_height, double min_derivative, int direction, int acc, nf_stream_t stream);

@@ -40,7 +40,7 @@ def _run_pairs_impl(pairs, z, inverse, ld, acc):
         for c, lu in pairs:
             z = c._run_pair(z, lu, inverse, ld, acc)
         return z
-    x3 = config.fused_gemm == "bf16x3"
+    x3 = config.fused_gemm == "bf16x3" and pairs[0][0].prqct.num_bins == 8
     feats, hidden, nblk, K, tb, mw, mh, md = _pair_signature(pairs[0][0])
     from .flows.neural_spline import FUSED_D, FUSED_H
     narrow = z.shape[1] != FUSED_D

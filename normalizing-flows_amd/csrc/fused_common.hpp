@@ -30,29 +30,40 @@ constexpr int F_HDR = 64;          // header floats
 //   stages (16 KB each, 16-byte aligned): init | hidden (8 per block) | final (24) | lu density | lu sample
 struct FusedLayout {
     int nblk;
-    __host__ __device__ int small_floats() const { return 128 + 256 * nblk + 768 + F_NI * F_TABW + 128; }
+    int K = F_K;    // bins: 4 | 8 | 16 (exact-fp32 kernel; the split-bf16 and training variants are K = 8 only).  A transform
+                    // feature occupies MP = 3 K of the lane's slots (3 K - 1 parameters + 1 pad), a group of 3 row-blocks (96
+                    // rows, 48 slots per lane) holds 16 / K features per lane-half, so the final layer is K groups = 3 K stages
+    __host__ __device__ int ngroups() const { return K; }
+    __host__ __device__ int nfinal() const { return 3 * K; }
+    __host__ __device__ int tabw() const { return 3 * (K + 1); }
+    __host__ __device__ int bias_final_floats() const { return 96 * K; }
+    __host__ __device__ int small_floats() const { return 128 + 256 * nblk + bias_final_floats() + F_NI * tabw() + 128; }
     __host__ __device__ int off_bias_init() const { return 0; }
     __host__ __device__ int off_bias_hidden(int lin) const { return 128 + 128 * lin; }
     __host__ __device__ int off_bias_final() const { return 128 + 256 * nblk; }
-    __host__ __device__ int off_tables() const { return off_bias_final() + 768; }
-    __host__ __device__ int off_bias_lu(int dir) const { return off_tables() + F_NI * F_TABW + 64 * dir; }
-    __host__ __device__ int lu_stage(int dir) const { return 1 + 8 * nblk + 24 + dir; }
+    __host__ __device__ int off_tables() const { return off_bias_final() + bias_final_floats(); }
+    __host__ __device__ int off_bias_lu(int dir) const { return off_tables() + F_NI * tabw() + 64 * dir; }
+    __host__ __device__ int lu_stage(int dir) const { return 1 + 8 * nblk + nfinal() + dir; }
     __host__ __device__ int small_padded() const { return (small_floats() + 1023) / 1024 * 1024; }
     __host__ __device__ int off_stages() const { return F_HDR + small_padded(); }  // multiple of 4 floats
-    __host__ __device__ int nstages(bool lu) const { return 1 + 8 * nblk + 24 + (lu ? 1 : 0); }
+    __host__ __device__ int nstages(bool lu) const { return 1 + 8 * nblk + nfinal() + (lu ? 1 : 0); }
     __host__ __device__ int64_t total_floats() const { return (int64_t)off_stages() + (int64_t)(nstages(false) + 2) * F_STAGE; }
 };
 
-// Row of the final layer (0..735) held by MFMA row `rho` (0..31) of row-block rb (0..2) of group g (0..7), or -1
-// for a padding row.  A lane-half hh ends up with features tf(g, hh, f), f = 0,1, 24 slots each (23 used).
-__host__ __device__ inline int final_row(int g, int rb, int rho) {
+// Row of the final layer (0 .. 32 (3 K - 1) - 1) held by MFMA row `rho` (0..31) of row-block rb (0..2) of group g (0 .. K - 1),
+// or -1 for a padding row.  A lane-half hh ends up with FPL = 16 / K features per group, MP = 3 K slots each (3 K - 1 used):
+// feature tf = 8 Q + 4 hh + j, Q = g / (K / 4) the lane's 16-column chunk, j = (g % (K / 4)) FPL + f.
+template <int KB>
+__host__ __device__ inline int final_row_k(int g, int rb, int rho) {
+    constexpr int MP = 3 * KB, M = 3 * KB - 1, FPL = 16 / KB, GQ = KB / 4;
     const int q = rho >> 3, hh = (rho >> 2) & 1, r = rho & 3;
     const int v = 16 * rb + 4 * q + r;  // 0..47: position in the lane's parameter list
-    const int f = v / 24, prm = v % 24;
-    if (prm >= F_M) return -1;
-    const int tf = 8 * (g >> 1) + 4 * hh + 2 * (g & 1) + f;
-    return tf * F_M + prm;
+    const int f = v / MP, prm = v % MP;
+    if (prm >= M) return -1;
+    const int tf = 8 * (g / GQ) + 4 * hh + (g % GQ) * FPL + f;
+    return tf * M + prm;
 }
+__host__ __device__ inline int final_row(int g, int rb, int rho) { return final_row_k<F_K>(g, rb, rho); }
 
 // Output column of MFMA row rho (0..31) of LU row-block m (0..1): chosen so that C register `reg` of row-block m is
 // the lane's stash slot 16 m + reg (slot c = 8 Q + column-in-chunk, chunk Q = columns [16 Q + 8 hh, +8)).
@@ -111,36 +122,36 @@ __device__ __forceinline__ void rqs_eval_bin_fast(float x, float cw, float bw, f
     lad = INVERSE ? -l : l;
 }
 
-// ---- spline on register-resident parameters (K = 8, linear tails), static indexing only, branch-free ------
+// ---- spline on register-resident parameters (KB bins, linear tails), static indexing only, branch-free ------
 // prm[0..7] raw widths, prm[8..15] raw heights, prm[16..22] raw derivative logits.
-template <bool INVERSE>
-__device__ __forceinline__ void rqs_regs(const RqsParams<float> &p, float x, const float (&prm)[24], float &y,
+template <bool INVERSE, int KB = F_K>
+__device__ __forceinline__ void rqs_regs(const RqsParams<float> &p, float x, const float (&prm)[3 * KB], float &y,
                                          float &lad) {
     // prm[0..7] / prm[8..15] arrive pre-multiplied by log2(e)/sqrt(hidden) (pack_final_kernel): softmax = exp2(. - max)/sum.
     const bool inside = x >= p.left && x <= p.right;  // false for NaN (utils/splines.py:28)
-    float mw = prm[0], mh = prm[F_K];
+    float mw = prm[0], mh = prm[KB];
 #pragma unroll
-    for (int k = 1; k < F_K; ++k) {
+    for (int k = 1; k < KB; ++k) {
         mw = fmaxf(mw, prm[k]);
-        mh = fmaxf(mh, prm[F_K + k]);
+        mh = fmaxf(mh, prm[KB + k]);
     }
     // inclusive prefix sums of the un-normalised softmax terms; knot_k = lo + (hi - lo) (k min + scale P_{k-1} / P_7)
-    float pw[F_K], ph[F_K];
+    float pw[KB], ph[KB];
 #pragma unroll
-    for (int k = 0; k < F_K; ++k) {
-        const float ew = __builtin_amdgcn_exp2f(prm[k] - mw), eh = __builtin_amdgcn_exp2f(prm[F_K + k] - mh);
+    for (int k = 0; k < KB; ++k) {
+        const float ew = __builtin_amdgcn_exp2f(prm[k] - mw), eh = __builtin_amdgcn_exp2f(prm[KB + k] - mh);
         pw[k] = k == 0 ? ew : pw[k - 1] + ew;
         ph[k] = k == 0 ? eh : ph[k - 1] + eh;
     }
-    const float cw = (p.right - p.left) * p.scale_w * frcp(pw[F_K - 1]);
-    const float ch = (p.top - p.bottom) * p.scale_h * frcp(ph[F_K - 1]);
-    float kw[F_K + 1], kh[F_K + 1];
+    const float cw = (p.right - p.left) * p.scale_w * frcp(pw[KB - 1]);
+    const float ch = (p.top - p.bottom) * p.scale_h * frcp(ph[KB - 1]);
+    float kw[KB + 1], kh[KB + 1];
     kw[0] = p.left;
     kh[0] = p.bottom;
-    kw[F_K] = p.right;
-    kh[F_K] = p.top;
+    kw[KB] = p.right;
+    kh[KB] = p.top;
 #pragma unroll
-    for (int k = 1; k < F_K; ++k) {
+    for (int k = 1; k < KB; ++k) {
         kw[k] = fmaf(pw[k - 1], cw, p.left + (p.right - p.left) * p.min_w * (float)k);
         kh[k] = fmaf(ph[k - 1], ch, p.bottom + (p.top - p.bottom) * p.min_h * (float)k);
     }
@@ -148,7 +159,7 @@ __device__ __forceinline__ void rqs_regs(const RqsParams<float> &p, float x, con
     float slo = INVERSE ? kh[0] : kw[0], shi = INVERSE ? kh[1] : kw[1];
     float olo = INVERSE ? kw[0] : kh[0], ohi = INVERSE ? kw[1] : kh[1];
 #pragma unroll
-    for (int k = 1; k < F_K; ++k) {
+    for (int k = 1; k < KB; ++k) {
         const bool ge = x >= (INVERSE ? kh[k] : kw[k]);
         bin = ge ? k : bin;
         slo = ge ? (INVERSE ? kh[k] : kw[k]) : slo;
@@ -158,9 +169,9 @@ __device__ __forceinline__ void rqs_regs(const RqsParams<float> &p, float x, con
     }
     float dl0 = p.edge_logit, dl1 = p.edge_logit;
 #pragma unroll
-    for (int k = 0; k < F_K - 1; ++k) {
-        dl0 = (bin == k + 1) ? prm[2 * F_K + k] : dl0;  // padded logit j = bin  -> raw index bin - 1
-        dl1 = (bin == k) ? prm[2 * F_K + k] : dl1;      // padded logit j = bin+1 -> raw index bin
+    for (int k = 0; k < KB - 1; ++k) {
+        dl0 = (bin == k + 1) ? prm[2 * KB + k] : dl0;  // padded logit j = bin  -> raw index bin - 1
+        dl1 = (bin == k) ? prm[2 * KB + k] : dl1;      // padded logit j = bin+1 -> raw index bin
     }
     const float d0 = p.min_d + fsoftplus(dl0), d1 = p.min_d + fsoftplus(dl1);
     float yy, ll;
@@ -173,15 +184,15 @@ __device__ __forceinline__ void rqs_regs(const RqsParams<float> &p, float x, con
 }
 
 // Batch-shared spline from its LDS knot table (cumw[9] | cumh[9] | deriv[9]), branch-free.
-template <bool INVERSE>
+template <bool INVERSE, int KB = F_K>
 __device__ __forceinline__ void rqs_table_fast(const RqsParams<float> &p, float x, const float *tab, float &y, float &lad) {
     const bool inside = x >= p.left && x <= p.right;
-    const float *srch = INVERSE ? tab + (F_K + 1) : tab;
+    const float *srch = INVERSE ? tab + (KB + 1) : tab;
     int bin = 0;
 #pragma unroll
-    for (int k = 1; k < F_K; ++k) bin = (x >= srch[k]) ? k : bin;
-    const float cw0 = tab[bin], cw1 = tab[bin + 1], ch0 = tab[F_K + 1 + bin], ch1 = tab[F_K + 2 + bin];
-    const float d0 = tab[2 * (F_K + 1) + bin], d1 = tab[2 * (F_K + 1) + bin + 1];
+    for (int k = 1; k < KB; ++k) bin = (x >= srch[k]) ? k : bin;
+    const float cw0 = tab[bin], cw1 = tab[bin + 1], ch0 = tab[KB + 1 + bin], ch1 = tab[KB + 2 + bin];
+    const float d0 = tab[2 * (KB + 1) + bin], d1 = tab[2 * (KB + 1) + bin + 1];
     float yy, ll;
     rqs_eval_bin_fast<INVERSE>(x, cw0, cw1 - cw0, ch0, ch1 - ch0, d0, d1, yy, ll);
     y = inside ? yy : x;

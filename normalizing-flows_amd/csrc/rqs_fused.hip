@@ -66,22 +66,24 @@ __global__ void pack_hidden_kernel(const float *__restrict__ W /*128x128*/, cons
 
 // Rows holding unnormalised widths / heights are pre-multiplied by wh_scale = log2(e) / sqrt(hidden): the division of
 // nsf/coupling.py:334-339 and the exp -> exp2 conversion of the softmax cost nothing in the epilogue.
-__global__ void pack_final_kernel(const float *__restrict__ W /*736x128*/, const float *__restrict__ b,
-                                  float *__restrict__ stages /*24 stages*/, float *__restrict__ bias_dst,
+template <int KB>
+__global__ void pack_final_kernel(const float *__restrict__ W /* 32 (3 KB - 1) x 128 */, const float *__restrict__ b,
+                                  float *__restrict__ stages /* 3 KB stages */, float *__restrict__ bias_dst,
                                   float wh_scale) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 24 * F_STAGE; i += gridDim.x * blockDim.x) {
+    constexpr int M = 3 * KB - 1;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 3 * KB * F_STAGE; i += gridDim.x * blockDim.x) {
         const int r4 = i & 3, lane = (i >> 2) & 63, s = (i >> 8) & 15, st = i >> 12;
         const int g = st / 3, rb = st % 3;
-        const int row = final_row(g, rb, lane & 31);
+        const int row = final_row_k<KB>(g, rb, lane & 31);
         const int k = 8 * s + 4 * (lane >> 5) + r4;
-        const float sc = (row >= 0 && (row % F_M) < 2 * F_K) ? wh_scale : 1.0f;
+        const float sc = (row >= 0 && (row % M) < 2 * KB) ? wh_scale : 1.0f;
         stages[i] = row >= 0 ? W[row * F_H + k] * sc : 0.0f;
     }
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 768; i += gridDim.x * blockDim.x) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 96 * KB; i += gridDim.x * blockDim.x) {
         const int reg = i & 15, hh = (i >> 4) & 1, st = i >> 5;
         const int g = st / 3, rb = st % 3;
-        const int row = final_row(g, rb, 8 * (reg >> 2) + 4 * hh + (reg & 3));
-        const float sc = (row >= 0 && (row % F_M) < 2 * F_K) ? wh_scale : 1.0f;
+        const int row = final_row_k<KB>(g, rb, 8 * (reg >> 2) + 4 * hh + (reg & 3));
+        const float sc = (row >= 0 && (row % M) < 2 * KB) ? wh_scale : 1.0f;
         bias_dst[i] = row >= 0 ? b[row] * sc : 0.0f;
     }
 }
@@ -90,11 +92,12 @@ __global__ void pack_tables_kernel(const float *__restrict__ uw, const float *__
                                    float *__restrict__ tab, RqsParams<float> p) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= F_NI) return;
-    const float *wj = uw + j * F_K, *hj = uh + j * F_K, *dj = ud + j * (F_K - 1);
+    const int K = p.K;
+    const float *wj = uw + j * K, *hj = uh + j * K, *dj = ud + j * (K - 1);
     auto wacc = [=](int k) { return wj[k]; };
     auto hacc = [=](int k) { return hj[k]; };
     auto dacc = [=](int k) { return dj[k]; };
-    rqs_build_table<float>(p, wacc, hacc, dacc, tab + j * F_TABW);
+    rqs_build_table<float>(p, wacc, hacc, dacc, tab + j * 3 * (K + 1));
 }
 
 __global__ void pack_header_kernel(float *__restrict__ hdr, int nblk) {
@@ -329,14 +332,19 @@ struct FlowArgs {
 // initial layer / blocks, the final layer + spline run as in inference, and the conditioner output is written for the
 // backward in the lane's own order: cond_out[row][transform feature][24] (23 parameters + 1 pad, raw scale), six 16-byte
 // stores per feature.  Replaces a library GEMM that materialises 193 MB plus the stand-alone spline kernel that reads them back.
-template <int DIR, bool LU, bool TRAIN = false>
+template <int DIR, bool LU, bool TRAIN = false, int KB = F_K>
 __global__ void __launch_bounds__(F_THREADS, 2)
 rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ logdet, FlowArgs fa,
                  int64_t B, int nblk, RqsParams<float> p, int acc, const float *__restrict__ h_in = nullptr,
                  float *__restrict__ cond_out = nullptr, float unscale = 1.0f) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    static_assert(KB == 4 || KB == 8 || KB == 16, "bins");
+    static_assert(!TRAIN || KB == F_K, "the training variant writes the 24-float rows of 8 bins");
+    constexpr int MP = 3 * KB, FPL = 16 / KB, GQ = KB / 4, TABW = 3 * (KB + 1);   // slots per feature, features per lane-half and
+                                                                                 // group, groups per 16-column chunk, table row
     FusedLayout lay;
     lay.nblk = nblk;
+    lay.K = KB;
     float *ring = smem;                       // 2 x 4096
     float *stash = ring + 2 * F_STAGE;        // F_NW waves x 32 x 64
     float *small2 = stash + F_NW * 32 * 64;   // 2 x small_padded: biases + tables of the current / next layer
@@ -454,7 +462,7 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
                 const float xi = st[c * 64];
                 if (DIR == 1) {
                     float yi, l;
-                    rqs_table_fast<true>(p, xi, tabs + f * F_TABW, yi, l);
+                    rqs_table_fast<true, KB>(p, xi, tabs + f * TABW, yi, l);
                     st[c * 64] = yi;
                     ld += l;
                     bx[4 * Q + r] = yi;
@@ -549,45 +557,43 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     // scheduling regions as the 3 x 64 MFMAs of group g, so that they issue in the shadow of the 64-cycle MFMAs
     // instead of leaving the matrix pipe idle (ablation: epilogue + unconditional splines exposed = 22 % of the
     // kernel).  Region 1: element 0, region 2: element 1, region 3: two unconditional-spline elements (density).
-    float prm0[24], prm1[24];
+    float prm[FPL][MP];
     auto extract = [&](const f32x16 &A0, const f32x16 &A1, const f32x16 &A2) {
-        // lane's parameter list v = 16 rb + reg: feature f = v / 24, parameter v % 24
+        // lane's parameter list v = 16 rb + reg: feature f = v / MP, parameter v % MP
 #pragma unroll
-        for (int v = 0; v < 24; ++v) {
-            prm0[v] = v < 16 ? A0[v] : A1[v - 16];
-            prm1[v] = (v + 24) < 32 ? A1[v + 24 - 16] : A2[v + 24 - 32];
-        }
+        for (int v = 0; v < 48; ++v) prm[v / MP][v % MP] = v < 16 ? A0[v] : (v < 32 ? A1[v - 16] : A2[v - 32]);
     };
-    auto element = [&](int g, int f, const float (&prm)[24]) {
+    auto element = [&](int g, int f) {
 #ifdef NF_ABL_NOEPI
 #pragma unroll
-        for (int v = 0; v < 24; ++v) asm volatile("" ::"v"(prm[v]));
+        for (int v = 0; v < MP; ++v) asm volatile("" ::"v"(prm[f][v]));
         return;
 #endif
-        const int slot = 8 * (g >> 1) + 4 * (g & 1) + par_t + 2 * f;
+        const int slot = 8 * (g / GQ) + 2 * ((g % GQ) * FPL + f) + par_t;
         const float xt = st[slot * 64];
         float yt, l;
-        rqs_regs<DIR == 1>(p, xt, prm, yt, l);
+        rqs_regs<DIR == 1, KB>(p, xt, prm[f], yt, l);
         st[slot * 64] = yt;
         ld += l;
     };
-    auto uncond_pair = [&](int g) {  // density only: identity slots of chunk Q = g >> 1, r = 2 (g & 1) + {0, 1}
+    auto uncond_group = [&](int g) {  // density only: the FPL identity slots of chunk Q = g / GQ that go with this group
 #ifdef NF_ABL_NOUNCOND
         return;
 #endif
         const float *tabs = small + lay.off_tables();
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int r = 2 * (g & 1) + e;
-            const int c = 8 * (g >> 1) + 2 * r + par_i;
-            const int f = 8 * (g >> 1) + 4 * hh + r;
+        for (int e = 0; e < FPL; ++e) {
+            const int r = FPL * (g % GQ) + e;
+            const int c = 8 * (g / GQ) + 2 * r + par_i;
+            const int f = 8 * (g / GQ) + 4 * hh + r;
             float yi, l;
-            rqs_table_fast<false>(p, st[c * 64], tabs + f * F_TABW, yi, l);
+            rqs_table_fast<false, KB>(p, st[c * 64], tabs + f * TABW, yi, l);
             st[c * 64] = yi;
             ld += l;
         }
     };
 #ifdef NF_F32_SWPIPE
+    static_assert(KB == F_K, "the software-pipelined order is written for 8 bins");
     {   // group 0: MFMAs only
         const float *bsrc = small + lay.off_bias_final() + hh * 16;
         f32x16 A0 = load_bias16(bsrc), A1 = load_bias16(bsrc + 32), A2 = load_bias16(bsrc + 64);
@@ -602,31 +608,31 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
         {
             const float *buf = acquire();
             mm128<false>(buf, lane, A0, H0, H1, H2, H3);
-            element(g - 1, 0, prm0);
+            element(g - 1, 0);
             NF_SCHED_PIPE();
         }
         {
             const float *buf = acquire();
             mm128<false>(buf, lane, A1, H0, H1, H2, H3);
-            element(g - 1, 1, prm1);
+            element(g - 1, 1);
             NF_SCHED_PIPE();
         }
         {
             const float *buf = acquire();
             mm128<false>(buf, lane, A2, H0, H1, H2, H3);
-            if (DIR == 0) uncond_pair(g - 1);
+            if (DIR == 0) uncond_group(g - 1);
             NF_SCHED_PIPE();
         }
         extract(A0, A1, A2);
     }
-    element(7, 0, prm0);
-    element(7, 1, prm1);
-    if (DIR == 0) uncond_pair(7);
+    element(7, 0);
+    element(7, 1);
+    if (DIR == 0) uncond_group(7);
 #else
     // The exact-fp32 MFMA shares the vector ALU (tools/ubench/overlap.py): there is nothing to hide the epilogue
     // behind, so each group's spline elements are evaluated straight from its accumulators (no parameter copies, lower
     // register pressure); the software-pipelined order (NF_F32_SWPIPE) only pays on the bf16 matrix pipe.
-    for (int g = 0; g < 8; ++g) {
+    for (int g = 0; g < KB; ++g) {     // KB groups of 3 row-blocks
         const float *bsrc = small + lay.off_bias_final() + (g * 3) * 32 + hh * 16;
         f32x16 A0 = load_bias16(bsrc), A1 = load_bias16(bsrc + 32), A2 = load_bias16(bsrc + 64);
         mm128<false>(acquire(), lane, A0, H0, H1, H2, H3);
@@ -640,15 +646,15 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
                 for (int q = 0; q < 6; ++q) {
                     const float u_ = q < 4 ? unscale : 1.0f;
                     *reinterpret_cast<f32x4 *>(dst + 4 * q) =
-                        f32x4{prm0[4 * q] * u_, prm0[4 * q + 1] * u_, prm0[4 * q + 2] * u_, prm0[4 * q + 3] * u_};
+                        f32x4{prm[0][4 * q] * u_, prm[0][4 * q + 1] * u_, prm[0][4 * q + 2] * u_, prm[0][4 * q + 3] * u_};
                     *reinterpret_cast<f32x4 *>(dst + 24 + 4 * q) =
-                        f32x4{prm1[4 * q] * u_, prm1[4 * q + 1] * u_, prm1[4 * q + 2] * u_, prm1[4 * q + 3] * u_};
+                        f32x4{prm[1][4 * q] * u_, prm[1][4 * q + 1] * u_, prm[1][4 * q + 2] * u_, prm[1][4 * q + 3] * u_};
                 }
             }
         }
-        element(g, 0, prm0);
-        element(g, 1, prm1);
-        if (DIR == 0) uncond_pair(g);
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) element(g, f);
+        if (DIR == 0) uncond_group(g);
     }
 #endif
 
@@ -692,10 +698,13 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
 
 using namespace nf;
 
+static inline bool fused_bins_ok(int K) { return K == 4 || K == 8 || K == 16; }   // instantiations of the exact-fp32 kernel
+
 extern "C" int64_t nf_rqs_fused_pack_size(int nI, int nT, int hidden, int num_blocks, int K) {
-    if (nI != F_NI || nT != F_NI || hidden != F_H || K != F_K || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
+    if (nI != F_NI || nT != F_NI || hidden != F_H || !fused_bins_ok(K) || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
     FusedLayout lay;
     lay.nblk = num_blocks;
+    lay.K = K;
     return lay.total_floats() * (int64_t)sizeof(float);
 }
 
@@ -704,13 +713,14 @@ extern "C" int nf_rqs_fused_pack(void *wpack, const void *w_init, const void *b_
                                  const void *uh, const void *ud, int nI, int nT, int hidden, int num_blocks, int K,
                                  double tail_bound, double min_bin_width, double min_bin_height, double min_derivative,
                                  nf_stream_t stream) {
-    if (nI != F_NI || nT != F_NI || hidden != F_H || K != F_K || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
+    if (nI != F_NI || nT != F_NI || hidden != F_H || !fused_bins_ok(K) || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
     if (!wpack || !w_init || !b_init || !w_final || !b_final || !uw || !uh || !ud) return NF_EFAULT;
     if (num_blocks > 0 && (!w_blocks || !b_blocks)) return NF_EFAULT;
     if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     FusedLayout lay;
     lay.nblk = num_blocks;
+    lay.K = K;
     float *blob = (float *)wpack;
     float *small = blob + F_HDR;
     float *stages = blob + lay.off_stages();
@@ -723,9 +733,14 @@ extern "C" int nf_rqs_fused_pack(void *wpack, const void *w_init, const void *b_
                            (const float *)b_blocks[l], stages + (size_t)(1 + 4 * l) * F_STAGE,
                            small + lay.off_bias_hidden(l));
     }
-    hipLaunchKernelGGL(pack_final_kernel, dim3(384), dim3(256), 0, st, (const float *)w_final, (const float *)b_final,
-                       stages + (size_t)(1 + 8 * num_blocks) * F_STAGE, small + lay.off_bias_final(),
-                       (float)(1.4426950408889634 / sqrt((double)hidden)));
+#define NF_PACK_FINAL(KB)                                                                                            \
+    hipLaunchKernelGGL(pack_final_kernel<KB>, dim3(48 * KB), dim3(256), 0, st, (const float *)w_final,                   \
+                       (const float *)b_final, stages + (size_t)(1 + 8 * num_blocks) * F_STAGE,                          \
+                       small + lay.off_bias_final(), (float)(1.4426950408889634 / sqrt((double)hidden)))
+    if (K == 4) NF_PACK_FINAL(4);
+    else if (K == 8) NF_PACK_FINAL(8);
+    else NF_PACK_FINAL(16);
+#undef NF_PACK_FINAL
     auto p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
                                     min_derivative, 1.0);
     hipLaunchKernelGGL(pack_tables_kernel, dim3(1), dim3(64), 0, st, (const float *)uw, (const float *)uh,
@@ -759,12 +774,13 @@ extern "C" int nf_rqs_fused_pack_final(void *wpack, const void *w_final, const v
 
 extern "C" int nf_rqs_fused_pack_lu(void *wpack, int num_blocks, const int64_t *perm, const void *lower_entries,
                                     const void *upper_entries, const void *unconstrained_upper_diag, const void *bias,
-                                    int D, double eps, nf_stream_t stream) {
-    if (D != F_D || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
+                                    int D, double eps, int K, nf_stream_t stream) {
+    if (D != F_D || num_blocks < 0 || num_blocks > 16 || !fused_bins_ok(K)) return NF_ENOTSUP;
     if (!wpack || !perm || !lower_entries || !upper_entries || !unconstrained_upper_diag || !bias) return NF_EFAULT;
     hipStream_t st = (hipStream_t)stream;
     FusedLayout lay;
     lay.nblk = num_blocks;
+    lay.K = K;          // the layout of the blob the LU stages are added to (nf_rqs_fused_pack with the same K)
     float *blob = (float *)wpack;
     float *small = blob + F_HDR;
     float *stages = blob + lay.off_stages();
@@ -779,14 +795,14 @@ extern "C" int nf_rqs_fused_pack_lu(void *wpack, int num_blocks, const int64_t *
     return NF_OK;
 }
 
-template <int DIR, bool LU>
+template <int DIR, bool LU, int KB>
 static int launch_fused(const void *x, void *y, void *logdet, const FlowArgs &fa, int64_t B, int num_blocks,
                         const RqsParams<float> &p, int acc, size_t lds, hipStream_t st) {
-    static LdsOptIn opted = {};  // one per <DIR, LU> instantiation
-    if (opt_in_lds(reinterpret_cast<const void *>(&rqs_fused_kernel<DIR, LU>), lds, opted) != NF_OK) return NF_ENOTSUP;
+    static LdsOptIn opted = {};  // one per <DIR, LU, KB> instantiation
+    if (opt_in_lds(reinterpret_cast<const void *>(&rqs_fused_kernel<DIR, LU, false, KB>), lds, opted) != NF_OK) return NF_ENOTSUP;
     const int grid = (int)((B + F_ROWS - 1) / F_ROWS);
-    hipLaunchKernelGGL((rqs_fused_kernel<DIR, LU>), dim3(grid), dim3(F_THREADS), lds, st, (const float *)x, (float *)y,
-                       (float *)logdet, fa, B, num_blocks, p, acc);
+    hipLaunchKernelGGL((rqs_fused_kernel<DIR, LU, false, KB>), dim3(grid), dim3(F_THREADS), lds, st, (const float *)x, (float *)y,
+                       (float *)logdet, fa, B, num_blocks, p, acc, (const float *)nullptr, (float *)nullptr, 1.0f);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -795,8 +811,9 @@ extern "C" int nf_rqs_fused_chain(const void *x, void *y, void *logdet, const vo
                                   const int *mask_parities, int num_layers, int fuse_lu, int64_t B, int D, int hidden,
                                   int num_blocks, int K, double tail_bound, double min_bin_width, double min_bin_height,
                                   double min_derivative, int direction, int acc, nf_stream_t stream) {
-    if (D != F_D || hidden != F_H || K != F_K || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
+    if (D != F_D || hidden != F_H || !fused_bins_ok(K) || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
     if (num_layers < 1 || num_layers > F_MAX_LAYERS) return NF_ERANGE;
+    if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_EINVAL;
     if (B < 0 || (direction != 0 && direction != 1)) return NF_EINVAL;
     if (acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
     if (B == 0) return NF_OK;
@@ -814,15 +831,23 @@ extern "C" int nf_rqs_fused_chain(const void *x, void *y, void *logdet, const vo
     hipStream_t st = (hipStream_t)stream;
     FusedLayout lay;
     lay.nblk = num_blocks;
+    lay.K = K;
     auto p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
                                     min_derivative, sqrt((double)hidden));
     const size_t lds = (size_t)(2 * F_STAGE + F_NW * 32 * 64 + 2 * lay.small_padded()) * sizeof(float);
     if (lds > 160 * 1024) return NF_ENOTSUP;
-    if (direction == 0)
-        return fuse_lu ? launch_fused<0, true>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st)
-                       : launch_fused<0, false>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st);
-    return fuse_lu ? launch_fused<1, true>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st)
-                   : launch_fused<1, false>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st);
+#define NF_FUSED_DISPATCH(KB)                                                                                         \
+    do {                                                                                                              \
+        if (direction == 0)                                                                                           \
+            return fuse_lu ? launch_fused<0, true, KB>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st)              \
+                           : launch_fused<0, false, KB>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st);            \
+        return fuse_lu ? launch_fused<1, true, KB>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st)                  \
+                       : launch_fused<1, false, KB>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st);                \
+    } while (0)
+    if (K == 4) NF_FUSED_DISPATCH(4);
+    if (K == 16) NF_FUSED_DISPATCH(16);
+    NF_FUSED_DISPATCH(8);
+#undef NF_FUSED_DISPATCH
 }
 
 extern "C" int nf_rqs_fused_train_fwd(const void *x, const void *h2, void *y, void *logdet, void *cond_out, const void *wpack,

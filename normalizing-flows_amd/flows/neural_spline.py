@@ -442,7 +442,8 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
         kw = self._kernel_kwargs()
         u = self.unconditional_transform
         if (not sample and self.use_fused and self.use_fused_train and inputs.is_cuda and inputs.shape[0] >= 1024
-                and self._fused_eligible(inputs, context) and not self._fused_padded() and u is not None):
+                and self._fused_eligible(inputs, context) and not self._fused_padded() and u is not None
+                and self.num_bins == 8):
             # the benchmark shape: trunk (initial layer + residual blocks, autograd-tracked), then the final Linear + the
             # coupling transform as ONE launch (FinalSplineDensityFn)
             net = self.transform_net
@@ -516,9 +517,10 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
             n = self.features
             alt0 = torch.equal(ii, torch.arange(0, n, 2)) and torch.equal(ti, torch.arange(1, n, 2))
             alt1 = torch.equal(ii, torch.arange(1, n, 2)) and torch.equal(ti, torch.arange(0, n, 2))
-            # the kernel's shape is (64 features, 128 hidden units, 8 bins); narrower layers run on it zero-padded
+            # the kernel's shape is (64 features, 128 hidden units; 4, 8 or 16 bins); narrower layers run on it zero-padded
             # (_fused_blob / _pad_rows below): 2 <= features <= 64, hidden <= 128, any number of blocks
-            ok = ((alt0 or alt1) and 2 <= n <= FUSED_D and net.hidden_features <= FUSED_H and self.num_bins == 8
+            ok = ((alt0 or alt1) and 2 <= n <= FUSED_D and net.hidden_features <= FUSED_H and self.num_bins in (4, 8, 16)
+                  and self.min_bin_width * self.num_bins <= 1.0 and self.min_bin_height * self.num_bins <= 1.0
                   and ops.rqs_fused_supported(FUSED_D // 2, FUSED_D // 2, FUSED_H, len(net.blocks), self.num_bins))
             self._fused_ok = bool(ok)
             self._fused_parity = 0 if alt0 else 1
@@ -611,7 +613,7 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
                                       self.tail_bound, self.min_bin_width, self.min_bin_height, self.min_derivative)
             if lu is not None:
                 ops.rqs_fused_pack_lu(blob, nb, lu_t[0], lu_t[1].detach(), lu_t[2].detach(), lu_t[3].detach(),
-                                      lu_t[4].detach(), eps=lin.eps)
+                                      lu_t[4].detach(), eps=lin.eps, K=self.num_bins)
             self._fused_cache = (key, blob)
         return self._fused_cache[1]
 
@@ -633,7 +635,7 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
     def _fused_run(self, inputs, direction, ld=None, acc=None, lu=None):
         net = self.transform_net
         from .. import config
-        if config.fused_gemm == "bf16x3":
+        if config.fused_gemm == "bf16x3" and self.num_bins == 8:      # the split-bf16 kernel is instantiated for 8 bins only
             return ops.rqs_fused_x3(inputs, self._fused_x3_blob(lu), self._fused_parity, FUSED_H,
                                     len(net.blocks), self.num_bins, direction, logdet=ld, acc=acc,
                                     tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,

@@ -513,13 +513,13 @@ def rqs_fused_pack(w_init, b_init, w_blocks, b_blocks, w_final, b_final, uw, uh,
     return blob
 
 
-def rqs_fused_pack_lu(blob, num_blocks, perm, lower_entries, upper_entries, unconstrained_upper_diag, bias, eps=1e-3):
-    """Add the layer's LULinearPermute (composed dense 64 x 64 matrices, both directions) to a packed blob."""
+def rqs_fused_pack_lu(blob, num_blocks, perm, lower_entries, upper_entries, unconstrained_upper_diag, bias, eps=1e-3, K=8):
+    """Add the layer's LULinearPermute (composed dense 64 x 64 matrices, both directions) to a packed blob of K bins."""
     L.require_device(blob, perm, lower_entries, upper_entries, unconstrained_upper_diag, bias)
     D = bias.numel()
     rc = L.lib().nf_rqs_fused_pack_lu(ptr(blob), i32(num_blocks), ptr(perm), ptr(lower_entries.contiguous()),
                                       ptr(upper_entries.contiguous()), ptr(unconstrained_upper_diag.contiguous()),
-                                      ptr(bias.contiguous()), i32(D), f64(eps), L.stream())
+                                      ptr(bias.contiguous()), i32(D), f64(eps), i32(K), L.stream())
     L.check(rc, "nf_rqs_fused_pack_lu")
     return blob
 

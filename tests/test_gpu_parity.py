@@ -1559,17 +1559,20 @@ def test_models_run_in_double_precision(nfa, oracle):
     assert_close(N(xb), N(xr), what="fp64 roundtrip", rtol=1e-9, atol=1e-9)
 
 
-@pytest.mark.parametrize("D,hidden,blocks", [(2, 128, 2), (5, 32, 1), (7, 64, 2), (16, 16, 0), (32, 128, 3), (63, 100, 2), (64, 64, 2)])
-def test_fused_kernel_on_narrower_layers_vs_unfused_and_oracle(nfa, oracle, D, hidden, blocks):
+@pytest.mark.parametrize("D,hidden,blocks,bins", [(2, 128, 2, 8), (5, 32, 1, 8), (7, 64, 2, 8), (16, 16, 0, 8), (32, 128, 3, 8),
+                                                  (63, 100, 2, 8), (64, 64, 2, 8),
+                                                  # the 4- and 16-bin instantiations of the fused kernel (full shape and padded)
+                                                  (64, 128, 2, 4), (64, 128, 2, 16), (20, 64, 1, 4), (33, 96, 2, 16)])
+def test_fused_kernel_on_narrower_layers_vs_unfused_and_oracle(nfa, oracle, D, hidden, blocks, bins):
     """Layers narrower than the fused kernel's shape (64 features, 128 hidden units) run on it zero-padded -- padding columns
     parked in the splines' tails, zero hidden units, LU factors extended by an identity block: same results as the unfused
     path (library GEMMs + nf_rqs_coupling / nf_lu kernels) and as the CPU oracle, both directions, both mask parities, alone
     and as a chain of [CoupledRQS, LULinearPermute] pairs."""
     from normflows_amd.core import run_chain
-    torch.manual_seed(100 * D + hidden)
+    torch.manual_seed(100 * D + hidden + bins)
     flows = []
     for i in range(3):
-        c = nfa.flows.CoupledRationalQuadraticSpline(D, blocks, hidden, num_bins=8, init_identity=False, reverse_mask=bool(i % 2))
+        c = nfa.flows.CoupledRationalQuadraticSpline(D, blocks, hidden, num_bins=bins, init_identity=False, reverse_mask=bool(i % 2))
         lu = nfa.flows.LULinearPermute(D, identity_init=False)
         with torch.no_grad():
             for p_ in list(c.parameters()) + list(lu.parameters()):
@@ -1607,7 +1610,7 @@ def test_fused_kernel_on_narrower_layers_vs_unfused_and_oracle(nfa, oracle, D, h
         logq = np.zeros(B, np.float64)
         zo = x.numpy().astype(np.float64)
         st64 = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in st.items()}
-        ora64 = oracle.OracleNSF(st64, num_layers=6, K=8, tail_bound=3.0)
+        ora64 = oracle.OracleNSF(st64, num_layers=6, K=bins, tail_bound=3.0)
         for i in (range(5, -1, -1) if inverse else range(6)):
             zo = (ora64.coupling if ora64._is_coupling(i) else ora64.lu)(i, zo, 0 if inverse else 1, logq, +1)
         assert_close(N(z_f).astype(np.float64), zo, what="chain vs oracle z", rtol=1e-3, atol=1e-3)
