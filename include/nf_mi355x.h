@@ -155,6 +155,9 @@ int nf_rqs_coupling_bwd_ft(const void *x, const void *grad_y, const void *grad_l
  * [blk0.linear0, blk0.linear1, blk1.linear0, ...].  direction 0 = density (wrapper.inverse),
  * 1 = sample (wrapper.forward).
  */
+/* Row order of the packed final layer (host-side, for tests and tools): the row of the reference's (32 (3 K - 1), hidden)
+ * final-layer weight that MFMA row rho (0..31) of row-block rb (0..2) of group g (0 .. K - 1) holds, or -1 for a padding row. */
+int nf_rqs_fused_final_row(int K, int g, int rb, int rho);
 int64_t nf_rqs_fused_pack_size(int nI, int nT, int hidden, int num_blocks, int K);
 int nf_rqs_fused_pack(void *wpack, const void *w_init, const void *b_init, const void *const *w_blocks,
                       const void *const *b_blocks, const void *w_final, const void *b_final, const void *uw,

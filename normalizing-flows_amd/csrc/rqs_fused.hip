@@ -700,6 +700,14 @@ using namespace nf;
 
 static inline bool fused_bins_ok(int K) { return K == 4 || K == 8 || K == 16; }   // instantiations of the exact-fp32 kernel
 
+// Host-side view of the final layer's row order (tests): row of the (32 (3 K - 1), 128) weight held by MFMA row `rho` of
+// row-block `rb` of group `g`, -1 for a padding row, NF_ENOTSUP for an unsupported bin count.
+extern "C" int nf_rqs_fused_final_row(int K, int g, int rb, int rho) {
+    if (!fused_bins_ok(K)) return NF_ENOTSUP;
+    if (g < 0 || g >= K || rb < 0 || rb > 2 || rho < 0 || rho > 31) return NF_EINVAL;
+    return K == 4 ? final_row_k<4>(g, rb, rho) : (K == 8 ? final_row_k<8>(g, rb, rho) : final_row_k<16>(g, rb, rho));
+}
+
 extern "C" int64_t nf_rqs_fused_pack_size(int nI, int nT, int hidden, int num_blocks, int K) {
     if (nI != F_NI || nT != F_NI || hidden != F_H || !fused_bins_ok(K) || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
     FusedLayout lay;

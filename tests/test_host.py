@@ -377,6 +377,35 @@ def test_maf_pack_rejects_unsupported():
                                         use_residual_blocks=False)) is None
 
 
+@pytest.mark.parametrize("K", [4, 8, 16])
+def test_fused_final_layer_row_order_is_a_bijection(nfa, K):
+    """The packed final layer of the fused kernel for K bins: K groups x 3 row-blocks x 32 MFMA rows hold every row of the
+    (32 (3 K - 1), hidden) weight exactly once plus 32 padding rows; a lane-half's 48 slots of a group are whole features
+    (3 K slots each: 3 K - 1 parameters in order, then the pad); each lane-half sees the 16 transform features of its own
+    columns."""
+    lib = nfa._lib.lib()
+    M, MP, FPL = 3 * K - 1, 3 * K, 16 // K
+    seen, pads = set(), 0
+    for g in range(K):
+        for hh in range(2):
+            slots = []
+            for rb in range(3):
+                for reg in range(16):
+                    rho = 8 * (reg >> 2) + 4 * hh + (reg & 3)      # C register reg of lane-half hh is MFMA row rho
+                    slots.append(lib.nf_rqs_fused_final_row(K, g, rb, rho))
+            assert len(slots) == 48
+            for f in range(FPL):
+                rows = slots[f * MP:(f + 1) * MP]
+                assert rows[-1] == -1 and all(r >= 0 for r in rows[:-1])
+                tf = rows[0] // M
+                assert rows[:-1] == [tf * M + p for p in range(M)]
+                assert (tf % 8) // 4 == hh                        # features 8 Q + 4 hh + j live in lane-half hh
+                seen.update(rows[:-1])
+                pads += 1
+    assert seen == set(range(32 * M)) and pads == 32
+    assert lib.nf_rqs_fused_final_row(5, 0, 0, 0) == -95      # NF_ENOTSUP: no instantiation for 5 bins
+
+
 def test_fused_kernels_have_no_register_spills(nfa):
     """AMDGPU metadata of the built objects (tools/kernel_resources.py): the register-resident fused NSF kernels -- exact
     fp32 and split-bf16, both directions, with and without the fused LU -- use no scratch memory at all."""
