@@ -97,7 +97,7 @@ def _events_ms(fn, reps):
 def kernel_breakdown(model, x, reps=5):
     """HIP-event timing of the launches of one eager log_prob pass (instrumented run, NOT the timed region).
     All fused [LULinearPermute + CoupledRQS] layer pairs of the model run as ONE persistent launch of
-    nf::rqs_fused_kernel<0, true> (core.run_chain -> nf_rqs_fused_chain); it is bracketed by one event pair recorded on
+    nf::rqs_fused_kernel<0, true, false, 8> (core.run_chain -> nf_rqs_fused_chain); it is bracketed by one event pair recorded on
     torch's current stream (= the stream the C ABI launches on).  Returns {name: (avg_ms, launches_per_pass, layers)}."""
     import normflows_amd as nfa
     from normflows_amd.core import run_chain
@@ -338,14 +338,14 @@ def main():
                                 for k, v in bd.items()}
             chain_ms, _, npairs = bd["rqs_fused_chain"]
             if npairs:
-                # dominant kernel: nf::rqs_fused_kernel<0, true>, ONE persistent launch over all layer pairs.
+                # dominant kernel: nf::rqs_fused_kernel<0, true, false, 8>, ONE persistent launch over all layer pairs.
                 # Algorithmic FLOPs per launch: (327 680 conditioner + 16 384 LU) FLOP per sample and layer
                 # pair x rows x pairs; MFMA-bound (exact-fp32 MFMA, 157.3 TFLOP/s peak).  chain_ms also contains the
                 # torch.zeros fill of log_q (one 256 KB memset).
                 fl = c2_flops_per_sample(layers=npairs) * args.batch
                 ach = fl / (chain_ms * 1e-3) / 1e12
                 tr, tr_src = pmc_traffic()
-                out["roofline"] = {"kernel": "nf::rqs_fused_kernel<0, true>", "bound": "mfma", "achieved": ach,
+                out["roofline"] = {"kernel": "nf::rqs_fused_kernel<0, true, false, 8>", "bound": "mfma", "achieved": ach,
                                    "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": tr,
                                    "traffic_source": tr_src,
                                    "flop_per_launch": fl, "avg_launch_ms": chain_ms, "layer_pairs_per_launch": npairs,
