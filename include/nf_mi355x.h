@@ -148,6 +148,8 @@ int nf_rqs_coupling_bwd_ft(const void *x, const void *grad_y, const void *grad_l
  *
  * Supported shape (anything else returns NF_ENOTSUP and the caller uses nf_rqs_coupling): D = 64 with
  * the alternating mask of wrapper.py:69 (nI = nT = 32), hidden = 128, K = 4 | 8 | 16 (one kernel instantiation each), fp32.
+ * nf_rqs_fused / nf_rqs_fused_chain also take hidden = 64 or 32: the blob is still the 128-unit layout (packed with hidden = 128
+ * from a conditioner zero-padded by the caller) whose units >= hidden are all-zero; the kernel skips their row-blocks and k-groups.
  *   mask_parity 0: reverse_mask = False (identity = even columns, transform = odd), 1: the opposite.
  * `wpack` is the layer's weights re-laid-out in MFMA operand order by nf_rqs_fused_pack() (device
  * buffer of nf_rqs_fused_pack_size() bytes, 16-byte aligned); weights are torch nn.Linear layout

@@ -51,7 +51,8 @@ def _run_pairs_impl(pairs, z, inverse, ld, acc):
         blobs = [(c.prqct._fused_x3_blob(lu) if x3 else c.prqct._fused_blob(lu)) for c, lu in chunk]
         pars = [c.prqct._fused_parity for c, lu in chunk]
         run = ops.rqs_fused_x3_chain if x3 else ops.rqs_fused_chain
-        z, _ = run(z, blobs, pars, FUSED_H, nblk, K, 0 if inverse else 1, logdet=ld, acc=acc, tail_bound=tb,
+        z, _ = run(z, blobs, pars, FUSED_H if x3 else pairs[0][0].prqct._fused_hidden(), nblk, K, 0 if inverse else 1,
+                   logdet=ld, acc=acc, tail_bound=tb,
                    min_bin_width=mw, min_bin_height=mh, min_derivative=md, fuse_lu=True)
     return z[:, :feats].contiguous() if narrow else z
 

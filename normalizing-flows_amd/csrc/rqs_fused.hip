@@ -260,7 +260,9 @@ pack_lu_kernel(const int64_t *__restrict__ perm, const float *__restrict__ lower
 
 // acc += Wblock(32 x 128) * B, where the B operand for (k-group s, r) is `bsrc[s >> 2][4 (s & 3) + r]`
 // (optionally through ReLU): 16 ds_read_b128 + 64 MFMA.
-template <bool RELU>
+// HB: hidden row-blocks in use (4 = 128 units; 2 / 1 = layers of <= 64 / <= 32 hidden units packed into the same 128-unit
+// blob: the units beyond are zero rows / columns, so their k-groups and row-blocks are skipped -- exactly, not approximately).
+template <bool RELU, int HB = 4>
 __device__ __forceinline__ void mm128(const float *buf, int lane, f32x16 &acc, const f32x16 &b0, const f32x16 &b1,
                                       const f32x16 &b2, const f32x16 &b3) {
 #ifdef NF_EXP_SETPRIO
@@ -270,12 +272,12 @@ __device__ __forceinline__ void mm128(const float *buf, int lane, f32x16 &acc, c
     // A operand one k-group ahead of its use
     f32x4 a_next = *reinterpret_cast<const f32x4 *>(buf + lane * 4);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
+    for (int s = 0; s < 4 * HB; ++s) {
         const f32x4 a = a_next;
-        if (s + 1 < 16) a_next = *reinterpret_cast<const f32x4 *>(buf + (s + 1) * 256 + lane * 4);
+        if (s + 1 < 4 * HB) a_next = *reinterpret_cast<const f32x4 *>(buf + (s + 1) * 256 + lane * 4);
 #else
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
+    for (int s = 0; s < 4 * HB; ++s) {
         const f32x4 a = *reinterpret_cast<const f32x4 *>(buf + s * 256 + lane * 4);
 #endif
         const f32x16 &bs = (s >> 2) == 0 ? b0 : ((s >> 2) == 1 ? b1 : ((s >> 2) == 2 ? b2 : b3));
@@ -332,7 +334,7 @@ struct FlowArgs {
 // initial layer / blocks, the final layer + spline run as in inference, and the conditioner output is written for the
 // backward in the lane's own order: cond_out[row][transform feature][24] (23 parameters + 1 pad, raw scale), six 16-byte
 // stores per feature.  Replaces a library GEMM that materialises 193 MB plus the stand-alone spline kernel that reads them back.
-template <int DIR, bool LU, bool TRAIN = false, int KB = F_K>
+template <int DIR, bool LU, bool TRAIN = false, int KB = F_K, int HB = 4>
 __global__ void __launch_bounds__(F_THREADS, 2)
 rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ logdet, FlowArgs fa,
                  int64_t B, int nblk, RqsParams<float> p, int acc, const float *__restrict__ h_in = nullptr,
@@ -340,6 +342,7 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     extern __shared__ __attribute__((aligned(16))) float smem[];
     static_assert(KB == 4 || KB == 8 || KB == 16, "bins");
     static_assert(!TRAIN || KB == F_K, "the training variant writes the 24-float rows of 8 bins");
+    static_assert(HB == 4 || ((HB == 2 || HB == 1) && !TRAIN), "hidden row-blocks");
     constexpr int MP = 3 * KB, FPL = 16 / KB, GQ = KB / 4, TABW = 3 * (KB + 1);   // slots per feature, features per lane-half and
                                                                                  // group, groups per 16-column chunk, table row
     FusedLayout lay;
@@ -353,15 +356,23 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA bases are wave-uniform
     const int64_t row = (int64_t)blockIdx.x * F_ROWS + wid * 32 + (lane & 31);
     const bool valid = row < B;
-    const int nbase = lay.nstages(false);
-    const int nstages = TRAIN ? 24 : lay.nstages(LU);
+    // logical stages of a layer: init | 2 nblk x HB hidden row-blocks | 3 KB final | (LU)
+    const int nhid = 2 * nblk * HB;
+    const int nbase = 1 + nhid + lay.nfinal();
+    const int nstages = TRAIN ? 24 : nbase + (LU ? 1 : 0);
     const int total_stages = nstages * fa.nlayers;
+    // base stage (without the LU) -> stage of the blob, which always holds four row-blocks per hidden Linear
+    auto phys_base = [&](int b) -> int {
+        if (HB == 4 || b == 0) return b;
+        if (b <= nhid) return 1 + 4 * ((b - 1) / HB) + (b - 1) % HB;
+        return 1 + 8 * nblk + (b - 1 - nhid);
+    };
     // logical -> physical stage: the LU stage comes first in the density direction, last in the sample direction
     auto phys = [&](int s) -> int {
         if (TRAIN) return 1 + 8 * nblk + s;      // the 24 final-layer stages only
-        if (!LU) return s;
-        if (DIR == 0) return s == 0 ? lay.lu_stage(0) : s - 1;
-        return s < nbase ? s : lay.lu_stage(1);
+        if (!LU) return phys_base(s);
+        if (DIR == 0) return s == 0 ? lay.lu_stage(0) : phys_base(s - 1);
+        return s < nbase ? phys_base(s) : lay.lu_stage(1);
     };
     float *st = stash + wid * 2048 + lane;  // value c (0..31) of this lane at st[c * 64]; c = 8 Q + column-in-chunk
 
@@ -498,7 +509,7 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
         H3 = load_bias16(bsrc + 96);
         const float *buf = acquire();
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < HB; ++m) {
             f32x16 &acc_m = m == 0 ? H0 : (m == 1 ? H1 : (m == 2 ? H2 : H3));
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -519,10 +530,12 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
             T2 = load_bias16(bsrc + 64);
             T3 = load_bias16(bsrc + 96);
         }
-        mm128<true>(acquire(), lane, T0, H0, H1, H2, H3);
-        mm128<true>(acquire(), lane, T1, H0, H1, H2, H3);
-        mm128<true>(acquire(), lane, T2, H0, H1, H2, H3);
-        mm128<true>(acquire(), lane, T3, H0, H1, H2, H3);
+        mm128<true, HB>(acquire(), lane, T0, H0, H1, H2, H3);
+        if constexpr (HB >= 2) mm128<true, HB>(acquire(), lane, T1, H0, H1, H2, H3);
+        if constexpr (HB == 4) {
+            mm128<true, HB>(acquire(), lane, T2, H0, H1, H2, H3);
+            mm128<true, HB>(acquire(), lane, T3, H0, H1, H2, H3);
+        }
         {
             const float *bsrc = small + lay.off_bias_hidden(2 * blk + 1) + hh * 16;
             H0 += load_bias16(bsrc);
@@ -531,10 +544,12 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
             H3 += load_bias16(bsrc + 96);
         }
 #ifdef NF_EXP_RELU_PER_USE
-        mm128<true>(acquire(), lane, H0, T0, T1, T2, T3);
-        mm128<true>(acquire(), lane, H1, T0, T1, T2, T3);
-        mm128<true>(acquire(), lane, H2, T0, T1, T2, T3);
-        mm128<true>(acquire(), lane, H3, T0, T1, T2, T3);
+        mm128<true, HB>(acquire(), lane, H0, T0, T1, T2, T3);
+        if constexpr (HB >= 2) mm128<true, HB>(acquire(), lane, H1, T0, T1, T2, T3);
+        if constexpr (HB == 4) {
+            mm128<true, HB>(acquire(), lane, H2, T0, T1, T2, T3);
+            mm128<true, HB>(acquire(), lane, H3, T0, T1, T2, T3);
+        }
 #else
         // T is dead after this linear: ReLU it once in place (64 v_max) instead of once per use (256)
 #pragma unroll
@@ -544,10 +559,12 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
             T2[c] = fmaxf(T2[c], 0.0f);
             T3[c] = fmaxf(T3[c], 0.0f);
         }
-        mm128<false>(acquire(), lane, H0, T0, T1, T2, T3);
-        mm128<false>(acquire(), lane, H1, T0, T1, T2, T3);
-        mm128<false>(acquire(), lane, H2, T0, T1, T2, T3);
-        mm128<false>(acquire(), lane, H3, T0, T1, T2, T3);
+        mm128<false, HB>(acquire(), lane, H0, T0, T1, T2, T3);
+        if constexpr (HB >= 2) mm128<false, HB>(acquire(), lane, H1, T0, T1, T2, T3);
+        if constexpr (HB == 4) {
+            mm128<false, HB>(acquire(), lane, H2, T0, T1, T2, T3);
+            mm128<false, HB>(acquire(), lane, H3, T0, T1, T2, T3);
+        }
 #endif
     }
     }  // !TRAIN
@@ -593,7 +610,7 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
         }
     };
 #ifdef NF_F32_SWPIPE
-    static_assert(KB == F_K, "the software-pipelined order is written for 8 bins");
+    static_assert(KB == F_K && HB == 4, "the software-pipelined order is written for 8 bins, 128 hidden units");
     {   // group 0: MFMAs only
         const float *bsrc = small + lay.off_bias_final() + hh * 16;
         f32x16 A0 = load_bias16(bsrc), A1 = load_bias16(bsrc + 32), A2 = load_bias16(bsrc + 64);
@@ -635,9 +652,9 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     for (int g = 0; g < KB; ++g) {     // KB groups of 3 row-blocks
         const float *bsrc = small + lay.off_bias_final() + (g * 3) * 32 + hh * 16;
         f32x16 A0 = load_bias16(bsrc), A1 = load_bias16(bsrc + 32), A2 = load_bias16(bsrc + 64);
-        mm128<false>(acquire(), lane, A0, H0, H1, H2, H3);
-        mm128<false>(acquire(), lane, A1, H0, H1, H2, H3);
-        mm128<false>(acquire(), lane, A2, H0, H1, H2, H3);
+        mm128<false, HB>(acquire(), lane, A0, H0, H1, H2, H3);
+        mm128<false, HB>(acquire(), lane, A1, H0, H1, H2, H3);
+        mm128<false, HB>(acquire(), lane, A2, H0, H1, H2, H3);
         extract(A0, A1, A2);
         if constexpr (TRAIN) {
             if (valid) {   // the two features' parameter sets, raw scale, for the backward kernel (pitch 24 floats per feature)
@@ -803,13 +820,13 @@ extern "C" int nf_rqs_fused_pack_lu(void *wpack, int num_blocks, const int64_t *
     return NF_OK;
 }
 
-template <int DIR, bool LU, int KB>
+template <int DIR, bool LU, int KB, int HB>
 static int launch_fused(const void *x, void *y, void *logdet, const FlowArgs &fa, int64_t B, int num_blocks,
                         const RqsParams<float> &p, int acc, size_t lds, hipStream_t st) {
-    static LdsOptIn opted = {};  // one per <DIR, LU, KB> instantiation
-    if (opt_in_lds(reinterpret_cast<const void *>(&rqs_fused_kernel<DIR, LU, false, KB>), lds, opted) != NF_OK) return NF_ENOTSUP;
+    static LdsOptIn opted = {};  // one per <DIR, LU, KB, HB> instantiation
+    if (opt_in_lds(reinterpret_cast<const void *>(&rqs_fused_kernel<DIR, LU, false, KB, HB>), lds, opted) != NF_OK) return NF_ENOTSUP;
     const int grid = (int)((B + F_ROWS - 1) / F_ROWS);
-    hipLaunchKernelGGL((rqs_fused_kernel<DIR, LU, false, KB>), dim3(grid), dim3(F_THREADS), lds, st, (const float *)x, (float *)y,
+    hipLaunchKernelGGL((rqs_fused_kernel<DIR, LU, false, KB, HB>), dim3(grid), dim3(F_THREADS), lds, st, (const float *)x, (float *)y,
                        (float *)logdet, fa, B, num_blocks, p, acc, (const float *)nullptr, (float *)nullptr, 1.0f);
     NF_CHECK_LAUNCH();
     return NF_OK;
@@ -819,7 +836,10 @@ extern "C" int nf_rqs_fused_chain(const void *x, void *y, void *logdet, const vo
                                   const int *mask_parities, int num_layers, int fuse_lu, int64_t B, int D, int hidden,
                                   int num_blocks, int K, double tail_bound, double min_bin_width, double min_bin_height,
                                   double min_derivative, int direction, int acc, nf_stream_t stream) {
-    if (D != F_D || hidden != F_H || !fused_bins_ok(K) || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
+    // hidden = 128, or 64 / 32: the blobs are the 128-unit layout (nf_rqs_fused_pack) whose units >= hidden are all-zero rows and
+    // columns (a narrower conditioner zero-padded by the caller); the kernel then skips those row-blocks and k-groups
+    if (D != F_D || (hidden != F_H && hidden != F_H / 2 && hidden != F_H / 4) || !fused_bins_ok(K) || num_blocks < 0 || num_blocks > 16)
+        return NF_ENOTSUP;
     if (num_layers < 1 || num_layers > F_MAX_LAYERS) return NF_ERANGE;
     if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_EINVAL;
     if (B < 0 || (direction != 0 && direction != 1)) return NF_EINVAL;
@@ -841,20 +861,30 @@ extern "C" int nf_rqs_fused_chain(const void *x, void *y, void *logdet, const vo
     lay.nblk = num_blocks;
     lay.K = K;
     auto p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
-                                    min_derivative, sqrt((double)hidden));
+                                    min_derivative, sqrt((double)F_H));
     const size_t lds = (size_t)(2 * F_STAGE + F_NW * 32 * 64 + 2 * lay.small_padded()) * sizeof(float);
     if (lds > 160 * 1024) return NF_ENOTSUP;
-#define NF_FUSED_DISPATCH(KB)                                                                                         \
+#define NF_FUSED_DISPATCH(KB, HB)                                                                                     \
     do {                                                                                                              \
         if (direction == 0)                                                                                           \
-            return fuse_lu ? launch_fused<0, true, KB>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st)              \
-                           : launch_fused<0, false, KB>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st);            \
-        return fuse_lu ? launch_fused<1, true, KB>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st)                  \
-                       : launch_fused<1, false, KB>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st);                \
+            return fuse_lu ? launch_fused<0, true, KB, HB>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st)          \
+                           : launch_fused<0, false, KB, HB>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st);        \
+        return fuse_lu ? launch_fused<1, true, KB, HB>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st)              \
+                       : launch_fused<1, false, KB, HB>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st);            \
     } while (0)
-    if (K == 4) NF_FUSED_DISPATCH(4);
-    if (K == 16) NF_FUSED_DISPATCH(16);
-    NF_FUSED_DISPATCH(8);
+    if (hidden == F_H / 2) {
+        if (K == 4) NF_FUSED_DISPATCH(4, 2);
+        if (K == 16) NF_FUSED_DISPATCH(16, 2);
+        NF_FUSED_DISPATCH(8, 2);
+    }
+    if (hidden == F_H / 4) {
+        if (K == 4) NF_FUSED_DISPATCH(4, 1);
+        if (K == 16) NF_FUSED_DISPATCH(16, 1);
+        NF_FUSED_DISPATCH(8, 1);
+    }
+    if (K == 4) NF_FUSED_DISPATCH(4, 4);
+    if (K == 16) NF_FUSED_DISPATCH(16, 4);
+    NF_FUSED_DISPATCH(8, 4);
 #undef NF_FUSED_DISPATCH
 }
 

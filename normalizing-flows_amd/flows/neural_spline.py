@@ -526,6 +526,12 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
             self._fused_parity = 0 if alt0 else 1
         return self._fused_ok
 
+    def _fused_hidden(self):
+        """`hidden` argument of the fused entry points: 64 / 32 tell the kernel that the units beyond of the (always 128-unit)
+        blob are zero padding, so it skips their row-blocks and k-groups (the HB = 2 / 1 instantiations)."""
+        h = self.transform_net.hidden_features
+        return FUSED_H // 4 if h <= FUSED_H // 4 else (FUSED_H // 2 if h <= FUSED_H // 2 else FUSED_H)
+
     def _fused_padded(self):
         return self.features != FUSED_D or self.transform_net.hidden_features != FUSED_H
 
@@ -641,7 +647,7 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
                                     tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
                                     min_bin_height=self.min_bin_height, min_derivative=self.min_derivative,
                                     fuse_lu=lu is not None)
-        return ops.rqs_fused(inputs, self._fused_blob(lu), self._fused_parity, FUSED_H, len(net.blocks),
+        return ops.rqs_fused(inputs, self._fused_blob(lu), self._fused_parity, self._fused_hidden(), len(net.blocks),
                              self.num_bins, direction, logdet=ld, acc=acc, tail_bound=self.tail_bound,
                              min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
                              min_derivative=self.min_derivative, fuse_lu=lu is not None)
