@@ -150,6 +150,8 @@ int nf_rqs_coupling_bwd_ft(const void *x, const void *grad_y, const void *grad_l
  * the alternating mask of wrapper.py:69 (nI = nT = 32), hidden = 128, K = 4 | 8 | 16 (one kernel instantiation each), fp32.
  * nf_rqs_fused / nf_rqs_fused_chain also take hidden = 64 or 32: the blob is still the 128-unit layout (packed with hidden = 128
  * from a conditioner zero-padded by the caller) whose units >= hidden are all-zero; the kernel skips their row-blocks and k-groups.
+ * Likewise D = 16 | 32 | 48: rows are still 64 floats wide, columns >= D are the caller's padding (values outside the splines'
+ * interval, identity block in the packed LU): the final-layer groups of the all-padding 16-column chunks are skipped.
  *   mask_parity 0: reverse_mask = False (identity = even columns, transform = odd), 1: the opposite.
  * `wpack` is the layer's weights re-laid-out in MFMA operand order by nf_rqs_fused_pack() (device
  * buffer of nf_rqs_fused_pack_size() bytes, 16-byte aligned); weights are torch nn.Linear layout

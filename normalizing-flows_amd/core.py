@@ -52,7 +52,7 @@ def _run_pairs_impl(pairs, z, inverse, ld, acc):
         pars = [c.prqct._fused_parity for c, lu in chunk]
         run = ops.rqs_fused_x3_chain if x3 else ops.rqs_fused_chain
         z, _ = run(z, blobs, pars, FUSED_H if x3 else pairs[0][0].prqct._fused_hidden(), nblk, K, 0 if inverse else 1,
-                   logdet=ld, acc=acc, tail_bound=tb,
+                   logdet=ld, acc=acc, tail_bound=tb, live_d=pairs[0][0].prqct._fused_live_d(),
                    min_bin_width=mw, min_bin_height=mh, min_derivative=md, fuse_lu=True)
     return z[:, :feats].contiguous() if narrow else z
 

@@ -325,6 +325,9 @@ struct FlowArgs {
     const float *blob[F_MAX_LAYERS];  // packed blobs in PROCESSING order
     unsigned long long parity;        // bit l: mask parity of layer l (0: transform features on odd columns)
     int nlayers;
+    int ngroups;                      // final-layer groups in use (<= K): a layer of D <= 16 c live columns has transform features only
+                                      // in the first c 16-column chunks = the first c K / 4 groups; the padding columns sit outside
+                                      // the splines' interval (identity, log-det 0), so their groups are neither streamed nor computed
 };
 
 // DIR: 0 = density (wrapper.inverse), 1 = sample (wrapper.forward).  LU: fuse each layer's LULinearPermute
@@ -358,7 +361,8 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     const bool valid = row < B;
     // logical stages of a layer: init | 2 nblk x HB hidden row-blocks | 3 KB final | (LU)
     const int nhid = 2 * nblk * HB;
-    const int nbase = 1 + nhid + lay.nfinal();
+    const int ngrp = TRAIN ? KB : fa.ngroups;
+    const int nbase = 1 + nhid + 3 * ngrp;
     const int nstages = TRAIN ? 24 : nbase + (LU ? 1 : 0);
     const int total_stages = nstages * fa.nlayers;
     // base stage (without the LU) -> stage of the blob, which always holds four row-blocks per hidden Linear
@@ -649,7 +653,7 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     // The exact-fp32 MFMA shares the vector ALU (tools/ubench/overlap.py): there is nothing to hide the epilogue
     // behind, so each group's spline elements are evaluated straight from its accumulators (no parameter copies, lower
     // register pressure); the software-pipelined order (NF_F32_SWPIPE) only pays on the bf16 matrix pipe.
-    for (int g = 0; g < KB; ++g) {     // KB groups of 3 row-blocks
+    for (int g = 0; g < ngrp; ++g) {   // (up to) KB groups of 3 row-blocks
         const float *bsrc = small + lay.off_bias_final() + (g * 3) * 32 + hh * 16;
         f32x16 A0 = load_bias16(bsrc), A1 = load_bias16(bsrc + 32), A2 = load_bias16(bsrc + 64);
         mm128<false, HB>(acquire(), lane, A0, H0, H1, H2, H3);
@@ -838,7 +842,10 @@ extern "C" int nf_rqs_fused_chain(const void *x, void *y, void *logdet, const vo
                                   double min_derivative, int direction, int acc, nf_stream_t stream) {
     // hidden = 128, or 64 / 32: the blobs are the 128-unit layout (nf_rqs_fused_pack) whose units >= hidden are all-zero rows and
     // columns (a narrower conditioner zero-padded by the caller); the kernel then skips those row-blocks and k-groups
-    if (D != F_D || (hidden != F_H && hidden != F_H / 2 && hidden != F_H / 4) || !fused_bins_ok(K) || num_blocks < 0 || num_blocks > 16)
+    // D = 64, or 16 / 32 / 48: rows are still 64 floats wide, columns >= D are padding that holds values outside the splines'
+    // interval (the caller's _pad_rows); the final-layer groups of the padding chunks are skipped
+    if ((D != F_D && D != 16 && D != 32 && D != 48) || (hidden != F_H && hidden != F_H / 2 && hidden != F_H / 4) || !fused_bins_ok(K) ||
+        num_blocks < 0 || num_blocks > 16)
         return NF_ENOTSUP;
     if (num_layers < 1 || num_layers > F_MAX_LAYERS) return NF_ERANGE;
     if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_EINVAL;
@@ -849,6 +856,7 @@ extern "C" int nf_rqs_fused_chain(const void *x, void *y, void *logdet, const vo
     FlowArgs fa;
     fa.parity = 0ull;
     fa.nlayers = num_layers;
+    fa.ngroups = (D / 16) * (K / 4);
     for (int l = 0; l < F_MAX_LAYERS; ++l) fa.blob[l] = nullptr;
     for (int l = 0; l < num_layers; ++l) {
         if (!wpacks[l]) return NF_EFAULT;
@@ -899,6 +907,7 @@ extern "C" int nf_rqs_fused_train_fwd(const void *x, const void *h2, void *y, vo
     FlowArgs fa;
     fa.parity = mask_parity ? 1ull : 0ull;
     fa.nlayers = 1;
+    fa.ngroups = F_K;
     for (int l = 0; l < F_MAX_LAYERS; ++l) fa.blob[l] = nullptr;
     fa.blob[0] = (const float *)wpack;
     FusedLayout lay;

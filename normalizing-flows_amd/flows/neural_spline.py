@@ -532,6 +532,10 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
         h = self.transform_net.hidden_features
         return FUSED_H // 4 if h <= FUSED_H // 4 else (FUSED_H // 2 if h <= FUSED_H // 2 else FUSED_H)
 
+    def _fused_live_d(self):
+        """Columns in use, rounded up to the kernel's 16-column chunks: the final-layer groups of all-padding chunks are skipped."""
+        return min(FUSED_D, 16 * ((self.features + 15) // 16))
+
     def _fused_padded(self):
         return self.features != FUSED_D or self.transform_net.hidden_features != FUSED_H
 
@@ -650,7 +654,7 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
         return ops.rqs_fused(inputs, self._fused_blob(lu), self._fused_parity, self._fused_hidden(), len(net.blocks),
                              self.num_bins, direction, logdet=ld, acc=acc, tail_bound=self.tail_bound,
                              min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
-                             min_derivative=self.min_derivative, fuse_lu=lu is not None)
+                             min_derivative=self.min_derivative, fuse_lu=lu is not None, live_d=self._fused_live_d())
 
 
 class CoupledRationalQuadraticSpline(Flow):

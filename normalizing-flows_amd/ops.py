@@ -525,7 +525,7 @@ def rqs_fused_pack_lu(blob, num_blocks, perm, lower_entries, upper_entries, unco
 
 
 def rqs_fused(x, blob, mask_parity, hidden, num_blocks, K, direction, logdet=None, acc=None, tail_bound=3.0,
-              min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, fuse_lu=False):
+              min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, fuse_lu=False, live_d=None):
     """One launch for a whole CoupledRationalQuadraticSpline layer (+ its LULinearPermute when fuse_lu).
     direction 0 = density, 1 = sample."""
     L.require_device(x, blob)
@@ -539,8 +539,10 @@ def rqs_fused(x, blob, mask_parity, hidden, num_blocks, K, direction, logdet=Non
         acc = L.LD_WRITE
     elif acc is None:
         acc = L.LD_ADD
+    if D != 64:
+        raise ValueError("nf_rqs_fused: rows of 64 columns (narrower layers: padded by the caller, live_d = columns in use)")
     rc = L.lib().nf_rqs_fused(ptr(x), ptr(y), ptr(logdet), ptr(blob), i32(mask_parity), i32(int(fuse_lu)), i64(B),
-                              i32(D), i32(hidden),
+                              i32(D if live_d is None else live_d), i32(hidden),
                               i32(num_blocks), i32(K), f64(tail_bound), f64(min_bin_width), f64(min_bin_height),
                               f64(min_derivative), i32(direction), i32(acc), L.stream())
     L.check(rc, "nf_rqs_fused")
@@ -703,7 +705,7 @@ def maf_affine(x, params, direction, logdet=None, acc=None, want_logdet=True):
 
 
 def rqs_fused_chain(x, blobs, parities, hidden, num_blocks, K, direction, logdet=None, acc=None, tail_bound=3.0,
-                    min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, fuse_lu=True):
+                    min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, fuse_lu=True, live_d=None):
     """Up to 64 fused layers of identical shape in ONE persistent launch (nf_rqs_fused_chain).  `blobs` / `parities`
     are in processing order."""
     import ctypes
@@ -721,7 +723,10 @@ def rqs_fused_chain(x, blobs, parities, hidden, num_blocks, K, direction, logdet
     n = len(blobs)
     bp = (ctypes.c_void_p * n)(*[b.data_ptr() for b in blobs])
     pp = (ctypes.c_int * n)(*[int(v) for v in parities])
-    rc = L.lib().nf_rqs_fused_chain(ptr(x), ptr(y), ptr(logdet), bp, pp, i32(n), i32(int(fuse_lu)), i64(B), i32(D),
+    if D != 64:
+        raise ValueError("nf_rqs_fused_chain: rows of 64 columns (narrower layers: padded by the caller, live_d = columns in use)")
+    rc = L.lib().nf_rqs_fused_chain(ptr(x), ptr(y), ptr(logdet), bp, pp, i32(n), i32(int(fuse_lu)), i64(B),
+                                    i32(D if live_d is None else live_d),
                                     i32(hidden), i32(num_blocks), i32(K), f64(tail_bound), f64(min_bin_width),
                                     f64(min_bin_height), f64(min_derivative), i32(direction), i32(acc), L.stream())
     L.check(rc, "nf_rqs_fused_chain")
@@ -729,7 +734,7 @@ def rqs_fused_chain(x, blobs, parities, hidden, num_blocks, K, direction, logdet
 
 
 def rqs_fused_x3_chain(x, blobs, parities, hidden, num_blocks, K, direction, logdet=None, acc=None, tail_bound=3.0,
-                       min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, fuse_lu=True):
+                       min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, fuse_lu=True, live_d=None):
     """Up to 64 fused layers of identical shape on the split-bf16 matrix path in ONE persistent launch
     (nf_rqs_fused_x3_chain).  `blobs` (rqs_fused_x3_pack) / `parities` are in processing order."""
     import ctypes
