@@ -661,6 +661,7 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
         mm128<false, HB>(acquire(), lane, A2, H0, H1, H2, H3);
         extract(A0, A1, A2);
         if constexpr (TRAIN) {
+#ifdef NF_TRAIN_DIRECT_STORES
             if (valid) {   // the two features' parameter sets, raw scale, for the backward kernel (pitch 24 floats per feature)
                 float *dst = cond_out + row * (F_NI * 24) + (8 * (g >> 1) + 4 * hh + 2 * (g & 1)) * 24;
 #pragma unroll
@@ -672,6 +673,40 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
                         f32x4{prm[1][4 * q] * u_, prm[1][4 * q + 1] * u_, prm[1][4 * q + 2] * u_, prm[1][4 * q + 3] * u_};
                 }
             }
+#else
+            // The two features' parameter sets (raw scale, pitch 24 floats per feature) for the backward kernel, through a 6 KB
+            // transpose tile per wave: a lane holds ITS row's 192 contiguous bytes (rows 3 KB apart), so direct 16-byte stores
+            // touch 64 partial lines per instruction (280 MB of fabric writes for 218 MB of rows, 40 us of the launch);
+            // re-read row-major, 12 lanes cover one row's 192 bytes and an instruction writes five rows' full lines.
+            float *tw = small2 + small_pitch + wid * 1536;      // the second small buffer is free (one layer) + the extra LDS
+            const int64_t row0 = (int64_t)blockIdx.x * F_ROWS + wid * 32;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if (hh == half) {
+                    float *tr = tw + (lane & 31) * 48;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) {
+                        const float u_ = q < 4 ? unscale : 1.0f;
+                        *reinterpret_cast<f32x4 *>(tr + 4 * q) =
+                            f32x4{prm[0][4 * q] * u_, prm[0][4 * q + 1] * u_, prm[0][4 * q + 2] * u_, prm[0][4 * q + 3] * u_};
+                        *reinterpret_cast<f32x4 *>(tr + 24 + 4 * q) =
+                            f32x4{prm[1][4 * q] * u_, prm[1][4 * q + 1] * u_, prm[1][4 * q + 2] * u_, prm[1][4 * q + 3] * u_};
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int fo = (8 * (g >> 1) + 4 * half + 2 * (g & 1)) * 24;
+                const int rl = lane / 12, ql = lane - 12 * rl;          // 5 rows x 12 sixteen-byte pieces per instruction
+#pragma unroll
+                for (int it = 0; it < 7; ++it) {
+                    const int r = 5 * it + rl;
+                    if (lane < 60 && r < 32 && row0 + r < B)
+                        *reinterpret_cast<f32x4 *>(cond_out + (row0 + r) * (F_NI * 24) + fo + 4 * ql) =
+                            *reinterpret_cast<const f32x4 *>(tw + r * 48 + 4 * ql);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+#endif
         }
 #pragma unroll
         for (int f = 0; f < FPL; ++f) element(g, f);
@@ -914,7 +949,8 @@ extern "C" int nf_rqs_fused_train_fwd(const void *x, const void *h2, void *y, vo
     lay.nblk = num_blocks;
     auto p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
                                     min_derivative, sqrt((double)hidden));
-    const size_t lds = (size_t)(2 * F_STAGE + F_NW * 32 * 64 + 2 * lay.small_padded()) * sizeof(float);
+    // + the waves' 6 KB transpose tiles for the row stores (they start in the unused second small buffer)
+    const size_t lds = (size_t)(2 * F_STAGE + F_NW * 32 * 64 + lay.small_padded() + F_NW * 1536) * sizeof(float);
     if (lds > 160 * 1024) return NF_ENOTSUP;
     static LdsOptIn opted = {};
     if (opt_in_lds(reinterpret_cast<const void *>(&rqs_fused_kernel<0, false, true>), lds, opted) != NF_OK) return NF_ENOTSUP;
