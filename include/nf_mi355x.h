@@ -201,6 +201,17 @@ int nf_rqs_fused_pack_final(void *wpack, const void *w_final, const void *b_fina
 int nf_rqs_fused_train_fwd(const void *x, const void *h2, void *y, void *logdet, void *cond_out, const void *wpack,
                            int mask_parity, int64_t B, int D, int hidden, int num_blocks, int K, double tail_bound,
                            double min_bin_width, double min_bin_height, double min_derivative, int acc, nf_stream_t stream);
+/* Training forward of the WHOLE layer in one launch (the inference kernel + what the backward needs): act_out
+ * (2 num_blocks + 1, B, 128) = h0 (initial layer's output), then per residual block its pre-activation t and its output h
+ * (nets/resnet.py:37-50, :92-104); cond_out (B, 32, 24) as above.  wpack: nf_rqs_fused_pack_all (one launch; same layout as
+ * nf_rqs_fused_pack without the LU).  D = 64, hidden = 128, K = 8, linear tails. */
+int nf_rqs_fused_pack_all(void *wpack, const void *w_init, const void *b_init, const void *const *w_blocks,
+                          const void *const *b_blocks, const void *w_final, const void *b_final, const void *uw, const void *uh,
+                          const void *ud, int hidden, int num_blocks, int K, double tail_bound, double min_bin_width,
+                          double min_bin_height, double min_derivative, nf_stream_t stream);
+int nf_rqs_fused_train_full_fwd(const void *x, void *y, void *logdet, void *cond_out, void *act_out, const void *wpack,
+                                int mask_parity, int64_t B, int D, int hidden, int num_blocks, int K, double tail_bound,
+                                double min_bin_width, double min_bin_height, double min_derivative, int acc, nf_stream_t stream);
 /* Backward of the density-direction coupling transform (nf_rqs_coupling_bwd, mode NF_RQS_DENSITY) on cond / grad_cond rows
  * of 24 floats per transform feature (the layout above; 16-byte aligned).  float32, 8 bins, linear tails. */
 int nf_rqs_coupling_bwd_p24(const void *x, const void *grad_y, const void *grad_logdet, const void *cond24, const void *uw,

@@ -365,6 +365,66 @@ def linear(x, weight, bias):
     return torch.nn.functional.linear(x, weight, bias)
 
 
+class CouplingTrainFn(torch.autograd.Function):
+    """A whole CoupledRationalQuadraticSpline layer of the benchmark shape under autograd (density direction): ONE forward launch
+    (nf_rqs_fused_train_full_fwd: initial layer, residual blocks, final layer, spline -- exactly the inference kernel -- writing
+    the intermediates the backward needs), and a backward orchestrated here from the same kernels the per-module Functions use
+    (spline backward on the 24-float rows, the final layer's input gradient as a library GEMM, one nf_rows_block per residual
+    block, pair / ring weight-gradient launches, the initial layer's input gradient accumulated into the transform's with one
+    addmm).  Replaces IdentLinearFn + ResidualBlockFn x blocks + FinalSplineDensityFn: four launches fewer forward, no
+    per-module autograd nodes."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, wf, bf, uw, uh, ud, iidx, tidx, blob, parity, kw, wfull, wpad, ld_acc, acc, *blk):
+        nb = len(blk) // 4
+        wb = [blk[4 * i + j].detach() for i in range(nb) for j in (0, 2)]
+        bb = [blk[4 * i + j].detach() for i in range(nb) for j in (1, 3)]
+        fk = dict(tail_bound=kw["tail_bound"], min_bin_width=kw["min_bin_width"], min_bin_height=kw["min_bin_height"],
+                  min_derivative=kw["min_derivative"])
+        ops.rqs_fused_pack_all(blob, w0.detach(), b0.detach(), wb, bb, wf.detach(), bf.detach(), uw.detach(), uh.detach(),
+                               ud.detach(), **fk)
+        y, ld, cond24, acts = ops.rqs_fused_train_full_fwd(x, blob, parity, nb, logdet=ld_acc,
+                                                           acc=None if ld_acc is None else (L.LD_ADD if acc > 0 else L.LD_SUB), **fk)
+        if ld_acc is not None:
+            ctx.mark_dirty(ld_acc)
+        ctx.save_for_backward(x, cond24, acts, w0, wf, uw, uh, ud, iidx, tidx, *blk)
+        ctx.kw, ctx.wfull, ctx.wpad, ctx.acc, ctx.has_acc, ctx.nb = kw, wfull, wpad, acc, ld_acc is not None, nb
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, gy, gld):
+        x, cond24, acts, w0, wf, uw, uh, ud, iidx, tidx, *blk = ctx.saved_tensors
+        kw, nb = ctx.kw, ctx.nb
+        if gy is None:
+            gy = torch.zeros_like(x)
+        if gld is None:
+            gld = torch.zeros(x.shape[0], dtype=x.dtype, device=x.device)
+        gld_own = -gld if (ctx.has_acc and ctx.acc < 0) else gld
+        gx, gcond24, guw, guh, gud = ops.rqs_coupling_bwd_p24(x, gy, gld_own, cond24, uw, uh, ud, iidx, tidx,
+                                                              tail_bound=kw["tail_bound"], min_bin_width=kw["min_bin_width"],
+                                                              min_bin_height=kw["min_bin_height"],
+                                                              min_derivative=kw["min_derivative"], wh_div=kw["wh_div"])
+        B, nT, H = x.shape[0], cond24.shape[1], wf.shape[1]
+        g2 = gcond24.view(B, nT * 24)
+        ctx.wpad[:, :23].copy_(wf.detach().view(nT, 23, H))
+        gh = g2 @ ctx.wpad.view(nT * 24, H)
+        gwf, gbf = ops.linear_wgrad(g2, acts[2 * nb], want_bias=True, skip_every=24)
+        gblk = [None] * (4 * nb)
+        for b in range(nb - 1, -1, -1):
+            w1, w2 = blk[4 * b].detach(), blk[4 * b + 2].detach()
+            h_in, t = acts[2 * b], acts[2 * b + 1]
+            gt, gh_in = ops.rows_block(gh, w2, None, w1, None, trans=True, mask1=t, mask2=h_in, relu=False)
+            gw2, gb2, gw1, gb1 = ops.linear_wgrad_pair(gh, t, gt, h_in, relu_x=True)
+            gblk[4 * b:4 * b + 4] = [gw1, gb1, gw2, gb2]
+            gh = gh_in
+        ctx.wfull.index_copy_(1, iidx, w0.detach())
+        gx.addmm_(gh, ctx.wfull)                                   # + the conditioner's input gradient on the identity columns
+        gw0f, gb0 = ops.linear_wgrad(gh, x, want_bias=True)
+        gw0 = gw0f.index_select(1, iidx)
+        return (gx, gw0, gb0, gwf, gbf, guw, guh, gud, None, None, None, None, None, None, None,
+                (gld if ctx.has_acc else None), None, *gblk)
+
+
 class IdentLinearFn(torch.autograd.Function):
     """The conditioner's initial Linear on the identity columns of a full-width row (nsf/coupling.py:71-76 `inputs[:,
     identity_features]` + nets/resnet.py:92): y = x[:, iidx] W^T + b computed as x Wfull^T + b with W scattered into a

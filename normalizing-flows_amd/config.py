@@ -58,6 +58,15 @@ def set_wgrad_pair(mode=True):
 fused_chain = True
 
 
+# Training forward of an eligible NSF coupling layer as ONE launch (autograd.CouplingTrainFn) instead of per-module Functions.
+train_full = True
+
+
+def set_train_full(mode=True):
+    global train_full
+    train_full = bool(mode)
+
+
 def set_fused_chain(mode=True):
     global fused_chain
     fused_chain = bool(mode)

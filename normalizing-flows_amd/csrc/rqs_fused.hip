@@ -337,14 +337,18 @@ struct FlowArgs {
 // initial layer / blocks, the final layer + spline run as in inference, and the conditioner output is written for the
 // backward in the lane's own order: cond_out[row][transform feature][24] (23 parameters + 1 pad, raw scale), six 16-byte
 // stores per feature.  Replaces a library GEMM that materialises 193 MB plus the stand-alone spline kernel that reads them back.
-template <int DIR, bool LU, bool TRAIN = false, int KB = F_K, int HB = 4>
+// TRAIN = 2: the WHOLE conditioner + transform as in inference (initial layer, residual blocks, final layer, spline) and, for
+// the backward, every intermediate written on the way: act_out[t] (B x 128), t = 0: h0 (initial layer's output), then per
+// block its pre-activation t and its output h (2 nblk + 1 tensors), rows through the wave's LDS transpose tile; cond_out as
+// TRAIN = 1.  One launch replaces the library GEMM of the initial layer, the residual-block launches and the TRAIN = 1 launch.
+template <int DIR, bool LU, int TRAIN = 0, int KB = F_K, int HB = 4>
 __global__ void __launch_bounds__(F_THREADS, 2)
 rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ logdet, FlowArgs fa,
                  int64_t B, int nblk, RqsParams<float> p, int acc, const float *__restrict__ h_in = nullptr,
-                 float *__restrict__ cond_out = nullptr, float unscale = 1.0f) {
+                 float *__restrict__ cond_out = nullptr, float unscale = 1.0f, float *__restrict__ act_out = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     static_assert(KB == 4 || KB == 8 || KB == 16, "bins");
-    static_assert(!TRAIN || KB == F_K, "the training variant writes the 24-float rows of 8 bins");
+    static_assert(!TRAIN || (KB == F_K && !LU && DIR == 0), "the training variants: 8 bins, density direction, no fused LU");
     static_assert(HB == 4 || ((HB == 2 || HB == 1) && !TRAIN), "hidden row-blocks");
     constexpr int MP = 3 * KB, FPL = 16 / KB, GQ = KB / 4, TABW = 3 * (KB + 1);   // slots per feature, features per lane-half and
                                                                                  // group, groups per 16-column chunk, table row
@@ -363,7 +367,7 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     const int nhid = 2 * nblk * HB;
     const int ngrp = TRAIN ? KB : fa.ngroups;
     const int nbase = 1 + nhid + 3 * ngrp;
-    const int nstages = TRAIN ? 24 : nbase + (LU ? 1 : 0);
+    const int nstages = TRAIN == 1 ? 24 : nbase + (LU ? 1 : 0);
     const int total_stages = nstages * fa.nlayers;
     // base stage (without the LU) -> stage of the blob, which always holds four row-blocks per hidden Linear
     auto phys_base = [&](int b) -> int {
@@ -373,7 +377,7 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     };
     // logical -> physical stage: the LU stage comes first in the density direction, last in the sample direction
     auto phys = [&](int s) -> int {
-        if (TRAIN) return 1 + 8 * nblk + s;      // the 24 final-layer stages only
+        if (TRAIN == 1) return 1 + 8 * nblk + s;      // the 24 final-layer stages only
         if (!LU) return phys_base(s);
         if (DIR == 0) return s == 0 ? lay.lu_stage(0) : phys_base(s - 1);
         return s < nbase ? phys_base(s) : lay.lu_stage(1);
@@ -494,7 +498,37 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
 
     // ---- initial layer: H = W0 xi + b0 (K = 32: 4 row-blocks x 4 k-groups in ONE stage) ----
     f32x16 H0, H1, H2, H3;
-    if constexpr (TRAIN) {
+    // TRAIN = 2: a (B x 128) row tensor from the wave's C-layout registers (register 4 q + r of block m = unit 32 m + 8 q + 4 hh + r
+    // of the lane's row), one 32-unit row-block at a time through the transpose tile (row pitch 36 floats: conflict-free
+    // enough), written back as 128-byte row pieces: 8 lanes per row, 8 rows per instruction
+    auto store_act = [&](int t, const f32x16 &V0, const f32x16 &V1, const f32x16 &V2, const f32x16 &V3) {
+        if constexpr (TRAIN == 2) {
+            int l_ = lane;      // per-lane addresses derived afresh at every call: hoisted out of the kernel they cost ~30 VGPRs
+            asm volatile("" : "+v"(l_));
+            float *tw = small2 + small_pitch + wid * 1536;
+            float *twr = tw + (l_ & 31) * 36 + 4 * (l_ >> 5);
+            const int rl = l_ >> 3, cl = l_ & 7;
+            const float *tww = tw + rl * 36 + 4 * cl;
+            const int64_t row0 = (int64_t)blockIdx.x * F_ROWS + wid * 32 + rl;
+            float *dst = act_out + ((size_t)t * (size_t)B + row0) * F_H + 4 * cl;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f32x16 &V = m == 0 ? V0 : (m == 1 ? V1 : (m == 2 ? V2 : V3));
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<f32x4 *>(twr + 8 * q) = f32x4{V[4 * q], V[4 * q + 1], V[4 * q + 2], V[4 * q + 3]};
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    if (row0 + 8 * it < B)
+                        *reinterpret_cast<f32x4 *>(dst + (size_t)(8 * it) * F_H + 32 * m) = *reinterpret_cast<const f32x4 *>(tww + 8 * it * 36);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    };
+    if constexpr (TRAIN == 1) {
         // h2 from HBM in C-register order: register 4 q + r of block m = unit 32 m + 8 q + 4 hh + r of the lane's row
         const float *hr = h_in + (valid ? row : 0) * F_H + 4 * hh;
 #pragma unroll
@@ -524,6 +558,7 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
         }
     }
 
+    store_act(0, H0, H1, H2, H3);
     // ---- residual blocks: H += W2 relu(W1 relu(H) + b1) + b2 (resnet.py:37-50) ----
     for (int blk = 0; blk < nblk; ++blk) {
         f32x16 T0, T1, T2, T3;
@@ -547,6 +582,7 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
             H2 += load_bias16(bsrc + 64);
             H3 += load_bias16(bsrc + 96);
         }
+        store_act(1 + 2 * blk, T0, T1, T2, T3);      // the pre-activation (the backward's ReLU mask and weight-gradient operand)
 #ifdef NF_EXP_RELU_PER_USE
         mm128<true, HB>(acquire(), lane, H0, T0, T1, T2, T3);
         if constexpr (HB >= 2) mm128<true, HB>(acquire(), lane, H1, T0, T1, T2, T3);
@@ -570,8 +606,9 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
             mm128<false, HB>(acquire(), lane, H3, T0, T1, T2, T3);
         }
 #endif
+        store_act(2 + 2 * blk, H0, H1, H2, H3);
     }
-    }  // !TRAIN
+    }  // TRAIN != 1
 
     // ---- final layer in 8 groups of 3 row-blocks; each group yields the parameters of 2 spline elements ----
     // Software pipeline: the spline evaluations of group g-1 (pure VALU work on registers) are placed in the same
@@ -678,12 +715,14 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
             // transpose tile per wave: a lane holds ITS row's 192 contiguous bytes (rows 3 KB apart), so direct 16-byte stores
             // touch 64 partial lines per instruction (280 MB of fabric writes for 218 MB of rows, 40 us of the launch);
             // re-read row-major, 12 lanes cover one row's 192 bytes and an instruction writes five rows' full lines.
+            int l_ = lane;      // (addresses derived afresh per group: see store_act)
+            asm volatile("" : "+v"(l_));
             float *tw = small2 + small_pitch + wid * 1536;      // the second small buffer is free (one layer) + the extra LDS
             const int64_t row0 = (int64_t)blockIdx.x * F_ROWS + wid * 32;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                if (hh == half) {
-                    float *tr = tw + (lane & 31) * 48;
+                if ((l_ >> 5) == half) {
+                    float *tr = tw + (l_ & 31) * 48;
 #pragma unroll
                     for (int q = 0; q < 6; ++q) {
                         const float u_ = q < 4 ? unscale : 1.0f;
@@ -696,11 +735,11 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const int fo = (8 * (g >> 1) + 4 * half + 2 * (g & 1)) * 24;
-                const int rl = lane / 12, ql = lane - 12 * rl;          // 5 rows x 12 sixteen-byte pieces per instruction
+                const int rl = l_ / 12, ql = l_ - 12 * rl;          // 5 rows x 12 sixteen-byte pieces per instruction
 #pragma unroll
                 for (int it = 0; it < 7; ++it) {
                     const int r = 5 * it + rl;
-                    if (lane < 60 && r < 32 && row0 + r < B)
+                    if (l_ < 60 && r < 32 && row0 + r < B)
                         *reinterpret_cast<f32x4 *>(cond_out + (row0 + r) * (F_NI * 24) + fo + 4 * ql) =
                             *reinterpret_cast<const f32x4 *>(tw + r * 48 + 4 * ql);
                 }
@@ -750,11 +789,137 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     }
 }
 
+// The whole blob of a layer (without the LU) in ONE launch: what nf_rqs_fused_pack does with 4 + 2 nblk launches.  The training
+// step re-packs every layer's weights once per step, so the launches count (8 bins only: the training variants' shape).
+struct PackAllArgs {
+    const float *w_init, *b_init, *w_final, *b_final, *uw, *uh, *ud;
+    const float *w_blk[32], *b_blk[32];
+    int nblk;
+};
+__global__ void pack_all_kernel(PackAllArgs a, float *__restrict__ blob, float wh_scale, RqsParams<float> p) {
+    FusedLayout lay;
+    lay.nblk = a.nblk;
+    float *small = blob + F_HDR, *stages = blob + lay.off_stages();
+    const int nlin = 2 * a.nblk, nst = 1 + 4 * nlin + 24;
+    const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = tid0; i < (int64_t)nst * F_STAGE; i += nth) {
+        const int st = (int)(i >> 12), j = (int)(i & (F_STAGE - 1));
+        const int r4 = j & 3, lane = (j >> 2) & 63;
+        float v;
+        if (st == 0) {                       // initial layer: 4 row-blocks x 4 k-groups
+            const int s = (j >> 8) & 3, m = j >> 10;
+            v = a.w_init[(32 * m + (lane & 31)) * F_NI + 8 * s + 4 * (lane >> 5) + r4];
+        } else if (st <= 4 * nlin) {         // hidden Linear l, row-block m
+            const int l = (st - 1) >> 2, m = (st - 1) & 3, s = (j >> 8) & 15;
+            v = a.w_blk[l][(32 * m + (lane & 31)) * F_H + 8 * s + 4 * (lane >> 5) + r4];
+        } else {                             // final layer: group g, row-block rb
+            const int f = st - 1 - 4 * nlin, g = f / 3, rb = f % 3, s = (j >> 8) & 15;
+            const int row = final_row(g, rb, lane & 31);
+            const float sc = (row >= 0 && (row % F_M) < 2 * F_K) ? wh_scale : 1.0f;
+            v = row >= 0 ? a.w_final[row * F_H + 8 * s + 4 * (lane >> 5) + r4] * sc : 0.0f;
+        }
+        stages[i] = v;
+    }
+    const int nbias = 128 + 128 * nlin + 768;
+    for (int64_t i = tid0; i < nbias; i += nth) {
+        const int reg = i & 15, hh = (i >> 4) & 1;
+        float v;
+        if (i < 128 + 128 * nlin) {
+            const int blk = (int)(i >> 7), m = (int)((i >> 5) & 3);
+            const float *b = blk == 0 ? a.b_init : a.b_blk[blk - 1];
+            v = b[32 * m + 8 * (reg >> 2) + 4 * hh + (reg & 3)];
+        } else {
+            const int st = (int)((i - 128 - 128 * nlin) >> 5), g = st / 3, rb = st % 3;
+            const int row = final_row(g, rb, 8 * (reg >> 2) + 4 * hh + (reg & 3));
+            const float sc = (row >= 0 && (row % F_M) < 2 * F_K) ? wh_scale : 1.0f;
+            v = row >= 0 ? a.b_final[row] * sc : 0.0f;
+        }
+        small[i] = v;       // bias_init | bias_hidden | bias_final are contiguous at the start of the small section
+    }
+    if (blockIdx.x == gridDim.x - 1) {
+        const int j = threadIdx.x;
+        if (j == 0) {
+            blob[0] = 355.0f;
+            blob[1] = (float)a.nblk;
+            blob[2] = 0.0f;
+            blob[3] = 0.0f;
+        }
+        if (j < F_NI) {
+            const float *wj = a.uw + j * F_K, *hj = a.uh + j * F_K, *dj = a.ud + j * (F_K - 1);
+            auto wacc = [=](int k) { return wj[k]; };
+            auto hacc = [=](int k) { return hj[k]; };
+            auto dacc = [=](int k) { return dj[k]; };
+            rqs_build_table<float>(p, wacc, hacc, dacc, small + lay.off_tables() + j * F_TABW);
+        }
+    }
+}
+
 }  // namespace nf
 
 using namespace nf;
 
 static inline bool fused_bins_ok(int K) { return K == 4 || K == 8 || K == 16; }   // instantiations of the exact-fp32 kernel
+
+// One-launch pack of a whole layer (8 bins, no LU) for the training forward nf_rqs_fused_train_full_fwd.
+extern "C" int nf_rqs_fused_pack_all(void *wpack, const void *w_init, const void *b_init, const void *const *w_blocks,
+                                     const void *const *b_blocks, const void *w_final, const void *b_final, const void *uw,
+                                     const void *uh, const void *ud, int hidden, int num_blocks, int K, double tail_bound,
+                                     double min_bin_width, double min_bin_height, double min_derivative, nf_stream_t stream) {
+    if (hidden != F_H || K != F_K || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
+    if (!wpack || !w_init || !b_init || !w_final || !b_final || !uw || !uh || !ud) return NF_EFAULT;
+    if (num_blocks > 0 && (!w_blocks || !b_blocks)) return NF_EFAULT;
+    if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_EINVAL;
+    PackAllArgs a;
+    a.w_init = (const float *)w_init; a.b_init = (const float *)b_init;
+    a.w_final = (const float *)w_final; a.b_final = (const float *)b_final;
+    a.uw = (const float *)uw; a.uh = (const float *)uh; a.ud = (const float *)ud;
+    a.nblk = num_blocks;
+    for (int l = 0; l < 32; ++l) { a.w_blk[l] = nullptr; a.b_blk[l] = nullptr; }
+    for (int l = 0; l < 2 * num_blocks; ++l) {
+        if (!w_blocks[l] || !b_blocks[l]) return NF_EFAULT;
+        a.w_blk[l] = (const float *)w_blocks[l];
+        a.b_blk[l] = (const float *)b_blocks[l];
+    }
+    auto p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
+                                    min_derivative, 1.0);
+    hipLaunchKernelGGL(pack_all_kernel, dim3(16 * (1 + 8 * num_blocks + 24)), dim3(256), 0, (hipStream_t)stream, a, (float *)wpack,
+                       (float)(1.4426950408889634 / sqrt((double)hidden)), p);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// Training forward of a WHOLE layer (core.py:87-102 over nets/resnet.py:53-104 + nsf/coupling.py:83-98): the inference
+// launch plus the tensors the backward needs -- act_out (2 num_blocks + 1, B, 128): h0, then per block its pre-activation t and
+// its output h; cond_out (B, 32, 24) as nf_rqs_fused_train_fwd.  wpack: nf_rqs_fused_pack_all / nf_rqs_fused_pack (no LU).
+extern "C" int nf_rqs_fused_train_full_fwd(const void *x, void *y, void *logdet, void *cond_out, void *act_out, const void *wpack,
+                                           int mask_parity, int64_t B, int D, int hidden, int num_blocks, int K, double tail_bound,
+                                           double min_bin_width, double min_bin_height, double min_derivative, int acc,
+                                           nf_stream_t stream) {
+    if (D != F_D || hidden != F_H || K != F_K || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
+    if (B < 0 || (mask_parity != 0 && mask_parity != 1) || acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!x || !y || !logdet || !cond_out || !act_out || !wpack) return NF_EFAULT;
+    FlowArgs fa;
+    fa.parity = mask_parity ? 1ull : 0ull;
+    fa.nlayers = 1;
+    fa.ngroups = F_K;
+    for (int l = 0; l < F_MAX_LAYERS; ++l) fa.blob[l] = nullptr;
+    fa.blob[0] = (const float *)wpack;
+    FusedLayout lay;
+    lay.nblk = num_blocks;
+    auto p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
+                                    min_derivative, sqrt((double)hidden));
+    const size_t lds = (size_t)(2 * F_STAGE + F_NW * 32 * 64 + lay.small_padded() + F_NW * 1536) * sizeof(float);
+    if (lds > 160 * 1024) return NF_ENOTSUP;
+    static LdsOptIn opted = {};
+    if (opt_in_lds(reinterpret_cast<const void *>(&rqs_fused_kernel<0, false, 2>), lds, opted) != NF_OK) return NF_ENOTSUP;
+    const int grid = (int)((B + F_ROWS - 1) / F_ROWS);
+    hipLaunchKernelGGL((rqs_fused_kernel<0, false, 2>), dim3(grid), dim3(F_THREADS), lds, (hipStream_t)stream, (const float *)x,
+                       (float *)y, (float *)logdet, fa, B, num_blocks, p, acc, (const float *)nullptr, (float *)cond_out,
+                       (float)(sqrt((double)hidden) / 1.4426950408889634), (float *)act_out);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
 
 // Host-side view of the final layer's row order (tests): row of the (32 (3 K - 1), 128) weight held by MFMA row `rho` of
 // row-block `rb` of group `g`, -1 for a padding row, NF_ENOTSUP for an unsupported bin count.

@@ -17,8 +17,9 @@ import torch
 from torch import nn
 
 from .. import _lib as L
+from .. import config as _config
 from .. import ops
-from ..autograd import CouplingDensityFn, FinalSplineDensityFn, IdentLinearFn, SplineFn, needs_grad
+from ..autograd import CouplingDensityFn, CouplingTrainFn, FinalSplineDensityFn, IdentLinearFn, SplineFn, needs_grad
 from ..nets import PeriodicFeaturesElementwise, ResidualNet
 from ..utils.masks import create_alternating_binary_mask
 from .base import Flow
@@ -449,6 +450,18 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
             net = self.transform_net
             inputs = inputs.contiguous()
             wfull, wpad = self._train_buffers(inputs)
+            fkw = dict(tail_bound=float(self.tail_bound), min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+                       min_derivative=self.min_derivative, wh_div=self._wh_div())
+            if _config.train_full and inputs.shape[1] == 64 and net.initial_layer.weight.shape[0] == 128:
+                blob = self.__dict__.get("_train_blob")
+                if blob is None or blob.device != inputs.device:
+                    blob = self._train_blob = ops.rqs_fused_train_blob(len(net.blocks), inputs.device)
+                blk = [p for b in net.blocks for l in b.linear_layers for p in (l.weight, l.bias)]
+                return CouplingTrainFn.apply(inputs, net.initial_layer.weight, net.initial_layer.bias, net.final_layer.weight,
+                                             net.final_layer.bias, u.unnormalized_widths, u.unnormalized_heights,
+                                             u.unnormalized_derivatives, self.identity_features, self.transform_features, blob,
+                                             self._fused_parity, fkw, wfull, wpad, ld, 1 if (acc is None or acc > 0) else -1,
+                                             *blk)
             h2 = IdentLinearFn.apply(inputs, net.initial_layer.weight, net.initial_layer.bias, self.identity_features, wfull)
             for block in net.blocks:
                 h2 = block(h2)

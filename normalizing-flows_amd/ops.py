@@ -630,6 +630,42 @@ def rqs_fused_train_fwd(x, h2, blob, mask_parity, num_blocks, tail_bound=3.0, mi
     return y, ld, cond
 
 
+def rqs_fused_pack_all(blob, w_init, b_init, w_blocks, b_blocks, w_final, b_final, uw, uh, ud, tail_bound=3.0, min_bin_width=1e-3,
+                       min_bin_height=1e-3, min_derivative=1e-3):
+    """The whole layer's blob (no LU) in one launch (nf_rqs_fused_pack_all); hidden 128, 8 bins."""
+    import ctypes
+    L.require_device(blob, w_init, b_init, w_final, b_final, uw, uh, ud, *w_blocks, *b_blocks)
+    n = len(w_blocks)
+    wp = (ctypes.c_void_p * max(n, 1))(*[w.data_ptr() for w in w_blocks])
+    bp = (ctypes.c_void_p * max(n, 1))(*[b.data_ptr() for b in b_blocks])
+    rc = L.lib().nf_rqs_fused_pack_all(ptr(blob), ptr(w_init), ptr(b_init), wp, bp, ptr(w_final), ptr(b_final), ptr(uw), ptr(uh),
+                                       ptr(ud), i32(128), i32(n // 2), i32(8), f64(tail_bound), f64(min_bin_width),
+                                       f64(min_bin_height), f64(min_derivative), L.stream())
+    L.check(rc, "nf_rqs_fused_pack_all")
+    return blob
+
+
+def rqs_fused_train_full_fwd(x, blob, mask_parity, num_blocks, tail_bound=3.0, min_bin_width=1e-3, min_bin_height=1e-3,
+                             min_derivative=1e-3, logdet=None, acc=None):
+    """(y, logdet, cond24, acts) of nf_rqs_fused_train_full_fwd: the whole conditioner + coupling transform in one launch;
+    acts (2 num_blocks + 1, B, 128) = h0, then (t, h) per residual block."""
+    L.require_device(x, blob)
+    x = x.contiguous()
+    B = x.shape[0]
+    y = torch.empty_like(x)
+    if logdet is None:
+        ld, acc = torch.empty(B, dtype=x.dtype, device=x.device), L.LD_WRITE
+    else:
+        ld, acc = logdet, (L.LD_ADD if acc is None else acc)
+    cond = torch.empty(B, 32, 24, dtype=x.dtype, device=x.device)
+    acts = torch.empty(2 * num_blocks + 1, B, 128, dtype=x.dtype, device=x.device)
+    rc = L.lib().nf_rqs_fused_train_full_fwd(ptr(x), ptr(y), ptr(ld), ptr(cond), ptr(acts), ptr(blob), i32(mask_parity), i64(B),
+                                             i32(64), i32(128), i32(num_blocks), i32(8), f64(tail_bound), f64(min_bin_width),
+                                             f64(min_bin_height), f64(min_derivative), i32(acc), L.stream())
+    L.check(rc, "nf_rqs_fused_train_full_fwd")
+    return y, ld, cond, acts
+
+
 def rqs_coupling_bwd_p24(x, grad_y, grad_logdet, cond24, uw, uh, ud, identity_idx, transform_idx, tail_bound=3.0,
                          min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, wh_div=1.0):
     """rqs_coupling_bwd (density direction) on the 24-float rows of rqs_fused_train_fwd.  Returns (gx, gcond24, guw, guh, gud)."""

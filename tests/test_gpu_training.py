@@ -622,7 +622,9 @@ def test_fused_final_layer_and_spline_training_forward_vs_layerwise(nfa):
     x = 1.3 * torch.randn(3000, 64, device=DEV)
     x[:4, :4] = torch.tensor([3.0, -3.0, 3.5, 0.0], device=DEV)
     res = []
-    for fused in (True, False):
+    for fused, full in ((True, True), (True, False), (False, False)):
+        # whole layer in one forward launch (CouplingTrainFn) / final Linear + spline in one launch / layer-wise
+        nfa.config.set_train_full(full)
         for f in m.flows[0::2]:
             f.prqct.use_fused_train = fused
         xa = x.clone().requires_grad_(True)
@@ -630,8 +632,15 @@ def test_fused_final_layer_and_spline_training_forward_vs_layerwise(nfa):
         lp = m.log_prob(xa)
         (-lp.mean()).backward()
         res.append((lp.detach().clone(), xa.grad.clone(), [p_.grad.clone() for p_ in m.parameters()]))
+    nfa.config.set_train_full(True)
     for f in m.flows[0::2]:
         f.prqct.use_fused_train = True
+    (lp_w, gx_w, gp_w) = res.pop(0)
+    assert _rel(N(lp_w), N(res[1][0])) < 2e-5, _rel(N(lp_w), N(res[1][0]))
+    assert_close(N(gx_w), N(res[1][1]), what="input gradient (whole-layer launch)", rtol=2e-3, atol=2e-5)
+    for (name, _), a, b in zip(m.named_parameters(), gp_w, res[1][2]):
+        scale = max(float(b.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) < 2e-3 * scale, ("whole-layer", name, float((a - b).abs().max()), scale)
     (lp_f, gx_f, gp_f), (lp_u, gx_u, gp_u) = res
     assert _rel(N(lp_f), N(lp_u)) < 2e-5, _rel(N(lp_f), N(lp_u))
     assert_close(N(gx_f), N(gx_u), what="input gradient", rtol=2e-3, atol=2e-5)
