@@ -355,6 +355,17 @@ int nf_linear_wgrad_skip(const void *dY, const void *X, void *dW, void *db, void
  * db0 / db1 both given or both NULL; vector / tile paths only (N % 4 == 0), NF_ENOTSUP otherwise. */
 int nf_linear_wgrad_pair(const void *dY0, const void *X0, void *dW0, void *db0, const void *dY1, const void *X1, void *dW1,
                          void *db1, void *scratch, int64_t B, int M, int N, int accumulate, int relu_x, nf_stream_t stream);
+/* Backward of one residual block of the conditioner (nets/resnet.py:37-50; hidden H = 128) in ONE pass over the rows: the two
+ * input-gradient products and both weight / bias gradients: gt = (gh W2)[t > 0], gh_in = gh + (gt W1)[h_in > 0],
+ * dW2 = gh^T relu(t), db2 = colsum(gh), dW1 = gt^T relu(h_in), db1 = colsum(gt)  (t = the block's pre-activation, h_in its input,
+ * both (B, H) as the training forward saved them).  With x != NULL also the initial Linear layer behind the block
+ * (nets/resnet.py:92-104, D = 64): gx (B, D) += gh_in wfull (wfull (H, D) = the layer's weight on full rows, zero columns at the
+ * transformed features), dW0 (H, D) = gh_in^T x, db0 = colsum(gh_in); gh_in is then not written (may be NULL).
+ * B a multiple of 64; scratch: nf_resblock_bwd_scratch_floats(B, x != NULL) floats.  Deterministic (fixed-order reduction). */
+int64_t nf_resblock_bwd_scratch_floats(int64_t B, int with_init);
+int nf_resblock_bwd(const void *gh, const void *t, const void *h_in, const void *W1, const void *W2, void *gh_in, void *dW1,
+                    void *db1, void *dW2, void *db2, const void *x, const void *wfull, void *gx, void *dW0, void *db0,
+                    void *scratch, int64_t B, int H, int D, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Logit preprocessing transform of image tensors.  Replaces normflows/transforms.py:8-47.

@@ -15,6 +15,7 @@ import math
 import torch
 
 from . import _lib as L
+from . import config as _config
 from . import ops
 
 
@@ -410,16 +411,27 @@ class CouplingTrainFn(torch.autograd.Function):
         gh = g2 @ ctx.wpad.view(nT * 24, H)
         gwf, gbf = ops.linear_wgrad(g2, acts[2 * nb], want_bias=True, skip_every=24)
         gblk = [None] * (4 * nb)
+        ctx.wfull.index_copy_(1, iidx, w0.detach())
+        fused = _config.resblock_bwd and nb > 0 and B % 64 == 0 and H == 128 and x.shape[1] == 64
         for b in range(nb - 1, -1, -1):
             w1, w2 = blk[4 * b].detach(), blk[4 * b + 2].detach()
             h_in, t = acts[2 * b], acts[2 * b + 1]
+            if fused:
+                # one pass over the rows per block: both input-gradient products and both weight gradients
+                # (nf_resblock_bwd); behind the first block also the initial layer's (gx += gh0 @ wfull, dW0, db0)
+                if b == 0:
+                    _, gw1, gb1, gw2, gb2, gw0f, gb0 = ops.resblock_bwd(gh, t, h_in, w1, w2, x=x, wfull=ctx.wfull, gx=gx)
+                else:
+                    gh, gw1, gb1, gw2, gb2 = ops.resblock_bwd(gh, t, h_in, w1, w2)
+                gblk[4 * b:4 * b + 4] = [gw1, gb1, gw2, gb2]
+                continue
             gt, gh_in = ops.rows_block(gh, w2, None, w1, None, trans=True, mask1=t, mask2=h_in, relu=False)
             gw2, gb2, gw1, gb1 = ops.linear_wgrad_pair(gh, t, gt, h_in, relu_x=True)
             gblk[4 * b:4 * b + 4] = [gw1, gb1, gw2, gb2]
             gh = gh_in
-        ctx.wfull.index_copy_(1, iidx, w0.detach())
-        gx.addmm_(gh, ctx.wfull)                                   # + the conditioner's input gradient on the identity columns
-        gw0f, gb0 = ops.linear_wgrad(gh, x, want_bias=True)
+        if not fused:
+            gx.addmm_(gh, ctx.wfull)                               # + the conditioner's input gradient on the identity columns
+            gw0f, gb0 = ops.linear_wgrad(gh, x, want_bias=True)
         gw0 = gw0f.index_select(1, iidx)
         return (gx, gw0, gb0, gwf, gbf, guw, guh, gud, None, None, None, None, None, None, None,
                 (gld if ctx.has_acc else None), None, *gblk)

@@ -67,6 +67,15 @@ def set_train_full(mode=True):
     train_full = bool(mode)
 
 
+# Backward of a residual block (and the initial layer behind the first one) as one pass over the rows (nf_resblock_bwd).
+resblock_bwd = True
+
+
+def set_resblock_bwd(mode=True):
+    global resblock_bwd
+    resblock_bwd = bool(mode)
+
+
 def set_fused_chain(mode=True):
     global fused_chain
     fused_chain = bool(mode)

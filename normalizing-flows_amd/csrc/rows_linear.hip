@@ -288,14 +288,25 @@ rows_block_kernel(RowsBlockArgs a) {
         const int64_t row = (tile * RB_NW + (tid >> 6)) * 32 + (lane & 31);
         const bool rv = row < a.B;
         const int64_t rc = rv ? row : a.B - 1;
+#ifdef NF_RB_ABL_COALESCED   // ablation (wrong results): every global access of the tile as consecutive 16-byte pieces per lane
+        const int64_t row0 = (tile * RB_NW + (tid >> 6)) * 32;
+#define RB_ADDR(base, ld, c0, idx) ((base) + row0 * (ld) + ((idx) * 64 + lane) * 4)
+#else
+#define RB_ADDR(base, ld, c0, idx) ((base) + rc * (ld) + (c0))
+#endif
         float xv[64];
         {
-            const float *src = a.in + rc * a.ldi + 64 * hh;
+            const float *src = RB_ADDR(a.in, a.ldi, 64 * hh, 0);
+#ifdef NF_RB_ABL_COALESCED
+#define RB_XOFF(q) ((q) * 256)
+#else
+#define RB_XOFF(q) (4 * (q))
+#endif
             const int kleft = a.H - 64 * hh;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (4 * q + 3 < kleft) v = *reinterpret_cast<const f32x4 *>(src + 4 * q);
+                if (4 * q + 3 < kleft) v = *reinterpret_cast<const f32x4 *>(src + RB_XOFF(q));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xv[4 * q + r] = a.relu1 ? fmaxf(v[r], 0.0f) : v[r];
             }
@@ -313,7 +324,7 @@ rows_block_kernel(RowsBlockArgs a) {
                 for (int q = 0; q < 4; ++q) {
                     const int c0 = 32 * m + 8 * q + 4 * hh;
                     mk[q] = f32x4{1.f, 1.f, 1.f, 1.f};
-                    if (a.m1 && c0 < a.H) mk[q] = *reinterpret_cast<const f32x4 *>(a.m1 + rc * a.ldm1 + c0);
+                    if (a.m1 && c0 < a.H) mk[q] = *reinterpret_cast<const f32x4 *>(RB_ADDR(a.m1, a.ldm1, c0, m * 4 + q));
                 }
                 const float *wl = W1l + (size_t)m * 16 * 256 + lane * 4;
 #pragma unroll
@@ -330,7 +341,7 @@ rows_block_kernel(RowsBlockArgs a) {
                         if (a.c1) v += *reinterpret_cast<const f32x4 *>(a.c1 + c0);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = mk[q][r] > 0.0f ? v[r] : 0.0f;
-                        if (rv) *reinterpret_cast<f32x4 *>(a.out1 + row * a.ldo1 + c0) = v;
+                        if (rv) *reinterpret_cast<f32x4 *>(RB_ADDR(a.out1, a.ldo1, c0, m * 4 + q)) = v;
                     } else {
                         v = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
@@ -349,8 +360,8 @@ rows_block_kernel(RowsBlockArgs a) {
                 mk[q] = f32x4{1.f, 1.f, 1.f, 1.f};
                 rs[q] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (c0 < a.H) {
-                    if (a.m2) mk[q] = *reinterpret_cast<const f32x4 *>(a.m2 + rc * a.ldm2 + c0);
-                    rs[q] = *reinterpret_cast<const f32x4 *>(a.in + rc * a.ldi + c0);      // the residual: `in` itself (cache-hot)
+                    if (a.m2) mk[q] = *reinterpret_cast<const f32x4 *>(RB_ADDR(a.m2, a.ldm2, c0, mo * 4 + q));
+                    rs[q] = *reinterpret_cast<const f32x4 *>(RB_ADDR(a.in, a.ldi, c0, mo * 4 + q));      // the residual: `in` itself (cache-hot)
                 }
             }
             f32x16 o = {0};
@@ -371,7 +382,7 @@ rows_block_kernel(RowsBlockArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = mk[q][r] > 0.0f ? v[r] : 0.0f;
                 v += rs[q];
-                *reinterpret_cast<f32x4 *>(a.out2 + row * a.ldo2 + c0) = v;
+                *reinterpret_cast<f32x4 *>(RB_ADDR(a.out2, a.ldo2, c0, mo * 4 + q)) = v;
             }
         }
         RB_T(4);

@@ -448,6 +448,16 @@ wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, floa
     }
 }
 
+// The reduction as a host call for the kernels of other translation units (resblock_bwd.hip): part = [problem][chunk][nW + M].
+int wgrad_reduce_launch(const float *part, float *dW, float *db, int64_t nW, int M, int chunks, int N, int np, int64_t zpart,
+                        int64_t zdW, int64_t zdb, hipStream_t st) {
+    const int64_t n = nW + (db ? M : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(n, 64), np), dim3(64 * RL), 0, st, part, dW, db, nW, n, nW + M, chunks, 0,
+                       N, 0, zpart, zdW, zdb);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
 static int wgrad_chunk_rows(int64_t B, int M, bool vec) {
     // vector path: ~2048 waves in flight (two per SIMD), chunk rows a multiple of its 32-row loop step;
     // general path: ~1024 waves.  At least 64 rows (fewer, longer chunks = less partial traffic).

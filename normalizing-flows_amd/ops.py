@@ -1025,6 +1025,39 @@ def linear_wgrad_pair(dy0, x0, dy1, x1, relu_x=False):
     return w0.view(M, N), b0, w1.view(M, N), b1
 
 
+def resblock_bwd(gh, t, h_in, w1, w2, x=None, wfull=None, gx=None):
+    """Backward of one residual block (hidden 128) in one pass over the rows (nf_resblock_bwd): returns
+    (gh_in, dW1, db1, dW2, db2); with x / wfull / gx also the initial Linear layer behind the block:
+    gx += gh_in @ wfull in place, and (None, dW1, db1, dW2, db2, dW0 (128, 64), db0) is returned."""
+    L.require_device(gh, t, h_in, w1, w2, x, wfull, gx)
+    gh, t, h_in, w1, w2 = gh.contiguous(), t.contiguous(), h_in.contiguous(), w1.contiguous(), w2.contiguous()
+    if any(v.dtype != torch.float32 for v in (gh, t, h_in, w1, w2)):
+        raise ValueError("resblock_bwd: float32 only")
+    B, H = gh.shape
+    init = x is not None
+    lib = L.lib()
+    lib.nf_resblock_bwd_scratch_floats.restype = C.c_int64
+    n = int(lib.nf_resblock_bwd_scratch_floats(i64(B), i32(int(init))))
+    if n <= 0 or H != 128:
+        raise NotImplementedError("resblock_bwd: hidden 128, batch a multiple of 64")
+    scratch = torch.empty(n, dtype=torch.float32, device=gh.device)
+    out = torch.empty(2, H * H + H, dtype=torch.float32, device=gh.device)      # (dW2 | db2), (dW1 | db1)
+    w2g, b2g, w1g, b1g = out[0, :H * H], out[0, H * H:], out[1, :H * H], out[1, H * H:]
+    if init:
+        if not (x.is_contiguous() and gx.is_contiguous() and wfull.is_contiguous()) or x.shape[1] != 64:
+            raise ValueError("resblock_bwd: contiguous x / gx (B, 64) and wfull (128, 64)")
+        out0 = torch.empty(H * 64 + H, dtype=torch.float32, device=gh.device)
+        gh_in, w0g, b0g = None, out0[:H * 64], out0[H * 64:]
+    else:
+        gh_in, w0g, b0g = torch.empty_like(gh), None, None
+    rc = lib.nf_resblock_bwd(ptr(gh), ptr(t), ptr(h_in), ptr(w1), ptr(w2), ptr(gh_in), ptr(w1g), ptr(b1g), ptr(w2g), ptr(b2g),
+                             ptr(x), ptr(wfull), ptr(gx), ptr(w0g), ptr(b0g), ptr(scratch), i64(B), i32(H), i32(64), L.stream())
+    L.check(rc, "nf_resblock_bwd")
+    if init:
+        return None, w1g.view(H, H), b1g, w2g.view(H, H), b2g, w0g.view(H, 64), b0g
+    return gh_in, w1g.view(H, H), b1g, w2g.view(H, H), b2g
+
+
 def bias_leaky_relu_(y, bias, negative_slope):
     """In place y = leaky_relu(y + bias[c]) on a contiguous NCHW tensor (nf_bias_leaky_relu)."""
     L.require_device(y, bias)

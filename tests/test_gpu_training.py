@@ -605,6 +605,39 @@ def test_rows_block_kernel_vs_torch(nfa, B, H):
     assert torch.equal(t, t2) and torch.equal(y, y2)
 
 
+@pytest.mark.parametrize("B,init", [(65536, False), (65536, True), (192, True), (4096 + 64, False)])
+def test_resblock_backward_one_pass_kernel(nfa, B, init):
+    """nf_resblock_bwd (both input-gradient products and both weight / bias gradients of a residual block in one pass over the
+    rows; with init also the initial Linear layer behind it) against float64 torch on the same inputs, and bit-reproducible."""
+    torch.manual_seed(B + init)
+    gh, t, h = (torch.randn(B, 128, device=DEV) for _ in range(3))
+    W1, W2 = 0.1 * torch.randn(128, 128, device=DEV), 0.1 * torch.randn(128, 128, device=DEV)
+    x = torch.randn(B, 64, device=DEV)
+    wfull = 0.1 * torch.randn(128, 64, device=DEV)
+    wfull[:, 1::2] = 0
+    gx0 = torch.randn(B, 64, device=DEV)
+    d = lambda v: v.double()
+    gt = (d(gh) @ d(W2)) * (t > 0)
+    gh_in = d(gh) + (gt @ d(W1)) * (h > 0)
+    ref = [gh_in, gt.t() @ d(h).clamp(min=0), gt.sum(0), d(gh).t() @ d(t).clamp(min=0), d(gh).sum(0)]
+    if init:
+        ref = [d(gx0) + gh_in @ d(wfull)] + ref[1:] + [gh_in.t() @ d(x), gh_in.sum(0)]
+
+    def run():
+        if not init:
+            return list(nfa.ops.resblock_bwd(gh, t, h, W1, W2))
+        gx = gx0.clone()
+        return [gx] + list(nfa.ops.resblock_bwd(gh, t, h, W1, W2, x=x, wfull=wfull, gx=gx))[1:]
+
+    out, out2 = run(), run()
+    for nm, a, r in zip(["gh_in / gx", "dW1", "db1", "dW2", "db2", "dW0", "db0"], out, ref):
+        scale = float(r.abs().max())
+        assert float((a.double() - r).abs().max()) < 2e-5 * scale, (nm, float((a.double() - r).abs().max()), scale)
+    assert all(torch.equal(a, b) for a, b in zip(out, out2))
+    with pytest.raises(NotImplementedError):
+        nfa.ops.resblock_bwd(gh[:100], t[:100], h[:100], W1, W2)        # rows: multiples of 64
+
+
 def test_fused_final_layer_and_spline_training_forward_vs_layerwise(nfa):
     """Training step of the benchmark-shaped layer: final Linear + coupling transform as ONE forward launch
     (FinalSplineDensityFn: nf_rqs_fused_train_fwd, conditioner output kept in 24-float rows, nf_rqs_coupling_bwd_p24)
@@ -619,12 +652,14 @@ def test_fused_final_layer_and_spline_training_forward_vs_layerwise(nfa):
             u.unnormalized_widths.normal_()
             u.unnormalized_heights.normal_()
             f.prqct.transform_net.final_layer.weight.add_(0.05 * torch.randn_like(f.prqct.transform_net.final_layer.weight))
-    x = 1.3 * torch.randn(3000, 64, device=DEV)
+    x = 1.3 * torch.randn(3008, 64, device=DEV)      # a multiple of 64: the one-pass block backward is eligible
     x[:4, :4] = torch.tensor([3.0, -3.0, 3.5, 0.0], device=DEV)
     res = []
-    for fused, full in ((True, True), (True, False), (False, False)):
-        # whole layer in one forward launch (CouplingTrainFn) / final Linear + spline in one launch / layer-wise
+    for fused, full, rb in ((True, True, True), (True, True, False), (True, False, False), (False, False, False)):
+        # whole layer in one forward launch (CouplingTrainFn), with / without the one-pass residual-block backward /
+        # final Linear + spline in one launch / layer-wise
         nfa.config.set_train_full(full)
+        nfa.config.set_resblock_bwd(rb)
         for f in m.flows[0::2]:
             f.prqct.use_fused_train = fused
         xa = x.clone().requires_grad_(True)
@@ -633,14 +668,16 @@ def test_fused_final_layer_and_spline_training_forward_vs_layerwise(nfa):
         (-lp.mean()).backward()
         res.append((lp.detach().clone(), xa.grad.clone(), [p_.grad.clone() for p_ in m.parameters()]))
     nfa.config.set_train_full(True)
+    nfa.config.set_resblock_bwd(True)
     for f in m.flows[0::2]:
         f.prqct.use_fused_train = True
-    (lp_w, gx_w, gp_w) = res.pop(0)
-    assert _rel(N(lp_w), N(res[1][0])) < 2e-5, _rel(N(lp_w), N(res[1][0]))
-    assert_close(N(gx_w), N(res[1][1]), what="input gradient (whole-layer launch)", rtol=2e-3, atol=2e-5)
-    for (name, _), a, b in zip(m.named_parameters(), gp_w, res[1][2]):
-        scale = max(float(b.abs().max()), 1e-6)
-        assert float((a - b).abs().max()) < 2e-3 * scale, ("whole-layer", name, float((a - b).abs().max()), scale)
+    for what in ("whole-layer launch + one-pass block backward", "whole-layer launch"):
+        (lp_w, gx_w, gp_w) = res.pop(0)
+        assert _rel(N(lp_w), N(res[-1][0])) < 2e-5, (what, _rel(N(lp_w), N(res[-1][0])))
+        assert_close(N(gx_w), N(res[-1][1]), what="input gradient (%s)" % what, rtol=2e-3, atol=2e-5)
+        for (name, _), a, b in zip(m.named_parameters(), gp_w, res[-1][2]):
+            scale = max(float(b.abs().max()), 1e-6)
+            assert float((a - b).abs().max()) < 2e-3 * scale, (what, name, float((a - b).abs().max()), scale)
     (lp_f, gx_f, gp_f), (lp_u, gx_u, gp_u) = res
     assert _rel(N(lp_f), N(lp_u)) < 2e-5, _rel(N(lp_f), N(lp_u))
     assert_close(N(gx_f), N(gx_u), what="input gradient", rtol=2e-3, atol=2e-5)

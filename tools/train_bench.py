@@ -19,11 +19,15 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--no-wgrad-pair", action="store_true", help="ablation: the residual blocks' weight gradients as two launches")
 ap.add_argument("--no-matvec2", action="store_true", help="ablation: LULinearPermute's chained products as two launches each")
 ap.add_argument("--no-train-full", action="store_true", help="ablation: per-module Functions instead of the whole-layer forward launch")
+ap.add_argument("--no-resblock-bwd", action="store_true", help="ablation: residual-block backward as separate kernels")
 ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the default foreach implementation")
 a = ap.parse_args()
 if a.no_train_full:
     import normflows_amd
     normflows_amd.config.set_train_full(False)
+if a.no_resblock_bwd:
+    import normflows_amd
+    normflows_amd.config.set_resblock_bwd(False)
 if a.no_matvec2:
     import normflows_amd
     normflows_amd.config.set_lu_matvec2(False)
