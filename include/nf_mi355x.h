@@ -204,11 +204,14 @@ int nf_rqs_fused_train_fwd(const void *x, const void *h2, void *y, void *logdet,
 /* Training forward of the WHOLE layer in one launch (the inference kernel + what the backward needs): act_out
  * (2 num_blocks + 1, B, 128) = h0 (initial layer's output), then per residual block its pre-activation t and its output h
  * (nets/resnet.py:37-50, :92-104); cond_out (B, 32, 24) as above.  wpack: nf_rqs_fused_pack_all (one launch; same layout as
- * nf_rqs_fused_pack without the LU).  D = 64, hidden = 128, K = 8, linear tails. */
+ * nf_rqs_fused_pack without the LU).  D = 64, hidden = 128, K = 8, linear tails.  wfull / wpad / identity_idx (all or none): the
+ * same launch also leaves the initial weight transposed on full rows (64, hidden; the identity features' rows written, the caller
+ * keeps the rest zero) and the final weight in 24-row groups (32, 24, hidden; row 23 of a group untouched) for the backward's products. */
 int nf_rqs_fused_pack_all(void *wpack, const void *w_init, const void *b_init, const void *const *w_blocks,
                           const void *const *b_blocks, const void *w_final, const void *b_final, const void *uw, const void *uh,
                           const void *ud, int hidden, int num_blocks, int K, double tail_bound, double min_bin_width,
-                          double min_bin_height, double min_derivative, nf_stream_t stream);
+                          double min_bin_height, double min_derivative, void *wfull, void *wpad, const void *identity_idx,
+                          nf_stream_t stream);
 int nf_rqs_fused_train_full_fwd(const void *x, void *y, void *logdet, void *cond_out, void *act_out, const void *wpack,
                                 int mask_parity, int64_t B, int D, int hidden, int num_blocks, int K, double tail_bound,
                                 double min_bin_width, double min_bin_height, double min_derivative, int acc, nf_stream_t stream);
@@ -359,13 +362,15 @@ int nf_linear_wgrad_pair(const void *dY0, const void *X0, void *dW0, void *db0, 
  * input-gradient products and both weight / bias gradients: gt = (gh W2)[t > 0], gh_in = gh + (gt W1)[h_in > 0],
  * dW2 = gh^T relu(t), db2 = colsum(gh), dW1 = gt^T relu(h_in), db1 = colsum(gt)  (t = the block's pre-activation, h_in its input,
  * both (B, H) as the training forward saved them).  With x != NULL also the initial Linear layer behind the block
- * (nets/resnet.py:92-104, D = 64): gx (B, D) += gh_in wfull (wfull (H, D) = the layer's weight on full rows, zero columns at the
- * transformed features), dW0 (H, D) = gh_in^T x, db0 = colsum(gh_in); gh_in is then not written (may be NULL).
+ * (nets/resnet.py:92-104, D = 64): gx (B, D) += gh_in wfull^T (wfull (D, H) = the layer's weight transposed on full rows, zero rows
+ * at the transformed features), dW0 (H, D) = gh_in^T x, db0 = colsum(gh_in); gh_in is then not written (may be NULL).
+ * col_map (D int32, optional): dW0 keeps only the columns n with col_map[n] >= 0, as (H, n_cols) with column col_map[n] (the
+ * identity features: the initial layer's own (H, nI) weight gradient).
  * B a multiple of 64; scratch: nf_resblock_bwd_scratch_floats(B, x != NULL) floats.  Deterministic (fixed-order reduction). */
 int64_t nf_resblock_bwd_scratch_floats(int64_t B, int with_init);
 int nf_resblock_bwd(const void *gh, const void *t, const void *h_in, const void *W1, const void *W2, void *gh_in, void *dW1,
                     void *db1, void *dW2, void *db2, const void *x, const void *wfull, void *gx, void *dW0, void *db0,
-                    void *scratch, int64_t B, int H, int D, nf_stream_t stream);
+                    const void *col_map, int n_cols, void *scratch, int64_t B, int H, int D, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Logit preprocessing transform of image tensors.  Replaces normflows/transforms.py:8-47.

@@ -382,8 +382,9 @@ class CouplingTrainFn(torch.autograd.Function):
         bb = [blk[4 * i + j].detach() for i in range(nb) for j in (1, 3)]
         fk = dict(tail_bound=kw["tail_bound"], min_bin_width=kw["min_bin_width"], min_bin_height=kw["min_bin_height"],
                   min_derivative=kw["min_derivative"])
+        # the same launch leaves wfull / wpad (the zero-padded weight images of the backward's products) current
         ops.rqs_fused_pack_all(blob, w0.detach(), b0.detach(), wb, bb, wf.detach(), bf.detach(), uw.detach(), uh.detach(),
-                               ud.detach(), **fk)
+                               ud.detach(), wfull=wfull, wpad=wpad, identity_idx=iidx, **fk)
         y, ld, cond24, acts = ops.rqs_fused_train_full_fwd(x, blob, parity, nb, logdet=ld_acc,
                                                            acc=None if ld_acc is None else (L.LD_ADD if acc > 0 else L.LD_SUB), **fk)
         if ld_acc is not None:
@@ -407,11 +408,9 @@ class CouplingTrainFn(torch.autograd.Function):
                                                               min_derivative=kw["min_derivative"], wh_div=kw["wh_div"])
         B, nT, H = x.shape[0], cond24.shape[1], wf.shape[1]
         g2 = gcond24.view(B, nT * 24)
-        ctx.wpad[:, :23].copy_(wf.detach().view(nT, 23, H))
-        gh = g2 @ ctx.wpad.view(nT * 24, H)
+        gh = g2 @ ctx.wpad.view(nT * 24, H)        # wpad / wfull: written by the forward's pack launch
         gwf, gbf = ops.linear_wgrad(g2, acts[2 * nb], want_bias=True, skip_every=24)
         gblk = [None] * (4 * nb)
-        ctx.wfull.index_copy_(1, iidx, w0.detach())
         fused = _config.resblock_bwd and nb > 0 and B % 64 == 0 and H == 128 and x.shape[1] == 64
         for b in range(nb - 1, -1, -1):
             w1, w2 = blk[4 * b].detach(), blk[4 * b + 2].detach()
@@ -420,7 +419,8 @@ class CouplingTrainFn(torch.autograd.Function):
                 # one pass over the rows per block: both input-gradient products and both weight gradients
                 # (nf_resblock_bwd); behind the first block also the initial layer's (gx += gh0 @ wfull, dW0, db0)
                 if b == 0:
-                    _, gw1, gb1, gw2, gb2, gw0f, gb0 = ops.resblock_bwd(gh, t, h_in, w1, w2, x=x, wfull=ctx.wfull, gx=gx)
+                    _, gw1, gb1, gw2, gb2, gw0, gb0 = ops.resblock_bwd(gh, t, h_in, w1, w2, x=x, wfull=ctx.wfull, gx=gx,
+                                                                       col_map=kw["col_map"], n_cols=iidx.numel())
                 else:
                     gh, gw1, gb1, gw2, gb2 = ops.resblock_bwd(gh, t, h_in, w1, w2)
                 gblk[4 * b:4 * b + 4] = [gw1, gb1, gw2, gb2]
@@ -430,9 +430,9 @@ class CouplingTrainFn(torch.autograd.Function):
             gblk[4 * b:4 * b + 4] = [gw1, gb1, gw2, gb2]
             gh = gh_in
         if not fused:
-            gx.addmm_(gh, ctx.wfull)                               # + the conditioner's input gradient on the identity columns
+            gx.addmm_(gh, ctx.wfull.t())                           # + the conditioner's input gradient on the identity columns
             gw0f, gb0 = ops.linear_wgrad(gh, x, want_bias=True)
-        gw0 = gw0f.index_select(1, iidx)
+            gw0 = gw0f.index_select(1, iidx)
         return (gx, gw0, gb0, gwf, gbf, guw, guh, gud, None, None, None, None, None, None, None,
                 (gld if ctx.has_acc else None), None, *gblk)
 

@@ -5,8 +5,8 @@
 //   gt    = (gh W2) * [t > 0]                      t = the block's pre-activation (saved by the forward)
 //   gh_in = gh + (gt W1) * [h_in > 0]              h_in = the block's input
 //   dW2   = gh^T relu(t),   db2 = colsum(gh);      dW1 = gt^T relu(h_in),   db1 = colsum(gt)
-//   INIT: gx += gh_in Wfull,  dW0 = gh_in^T x,  db0 = colsum(gh_in)      (Wfull = the initial weight on full rows, zero columns
-//                                                                         at the transformed features)
+//   INIT: gx += gh_in Wfull^T, dW0 = gh_in^T x,  db0 = colsum(gh_in)     (Wfull (D, H) = the initial weight transposed on full rows,
+//                                                                         zero rows at the transformed features)
 //
 // Separate kernels read gh / t / h_in twice and round-trip gt through HBM (302 MB per block at B = 65 536); here each row is
 // read once, gt never leaves the CU (134 MB), and 8.6 GFLOP sit behind one launch ramp instead of three.
@@ -31,7 +31,7 @@ namespace nf {
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 int wgrad_reduce_launch(const float *part, float *dW, float *db, int64_t nW, int M, int chunks, int N, int np, int64_t zpart,
-                        int64_t zdW, int64_t zdb, hipStream_t st);       // wgrad.hip
+                        int64_t zdW, int64_t zdb, const int *colmap, int Nout, hipStream_t st);       // wgrad.hip
 
 constexpr int BB_R = 64, BB_P = 132, BB_TILE = BB_R * BB_P, BB_H = 128, BB_D = 64;
 constexpr int BB_SLOTS = BB_R * (BB_P / 4);          // 16-byte slots of a tile = 2112 = 33 DMA instructions of 64 lanes
@@ -40,7 +40,7 @@ constexpr int BB_NI = BB_SLOTS / 64;                 // 33
 #ifdef NF_BB_TRACE
 static unsigned long long *g_bb_trace = nullptr;
 extern "C" void nf_resblock_bwd_debug_trace(void *buf) { g_bb_trace = (unsigned long long *)buf; }
-#define BB_T(i) do { if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[tcount * 8 + (i)] = wall_clock64(); } while (0)
+#define BB_T(i) do { if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[tcount * 12 + (i)] = wall_clock64(); } while (0)
 #else
 #define BB_T(i) do {} while (0)
 #endif
@@ -53,12 +53,15 @@ struct BlockBwdArgs {
     float *gh_in;          // (B, 128); not written by the INIT variant
     float *part;           // [2][grid][128 * 128 + 128]: (dW2, db2) then (dW1, db1)
     const float *x;        // INIT: (B, 64)
-    const float *wfull;    // INIT: (128, 64)
+    const float *wfull;    // INIT: (64, 128), the initial weight transposed
     float *gx;             // INIT: (B, 64), accumulated into
     float *part0;          // INIT: [grid][128 * 64 + 128]
     int64_t B;
 };
 
+#ifndef NF_BB_EPI
+#define NF_BB_EPI 0      // 1: epilogues in the weight-gradient loops' shadow except in the INIT variant (registers); 2: everywhere; 0: nowhere
+#endif
 #define BB_BARRIER_ALL() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define BB_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -73,19 +76,29 @@ resblock_bwd_kernel(BlockBwdArgs a) {
     const int om = wid >> 1, in_ = wid & 1;          // this wave's 64 x 64 quadrant of dW2 / dW1; its (row half, column block) of gx
     const int grid = gridDim.x;
     const int64_t ntiles = a.B / BB_R;
+    constexpr bool EPI = NF_BB_EPI == 2 || (NF_BB_EPI == 1 && !INIT);
 
     // DMA slot map: instruction k of a tile fills LDS floats [256 k, 256 k + 256); lane's slot s = 64 k + lane is column
     // group c = s % 33 of row s / 33 (c = 32: the pad slot, loaded with the row's last group again)
-    auto issue = [&](const float *src, float *tile) {
-        int l_ = lane;
-        asm volatile("" : "+v"(l_));         // per-call addresses: hoisted, the 27 per-lane 64-bit pointers of a tile spill
+    // The 9 per-lane element offsets are loop-invariant 32-bit registers; the tile's base pointer is uniform (SGPR pair): the
+    // DMA takes them as saddr + voffset, no per-instruction address arithmetic.
+    unsigned goff[9];
 #pragma unroll
-        for (int q = 0; q < 9; ++q)
-            if (wid + 4 * q < BB_NI) {
-                const int s = 64 * (wid + 4 * q) + l_, row = s / 33, c = s - 33 * row;
-                __builtin_amdgcn_global_load_lds(src + (row * BB_H + 4 * (c < 32 ? c : 31)), (lds_ptr)(tile + 256 * (wid + 4 * q)),
-                                                 16, 0, 0);
-            }
+    for (int q = 0; q < 9; ++q) {
+        const int s = 64 * (wid + 4 * q) + lane, row = s / 33, c = s - 33 * row;
+        goff[q] = (unsigned)((row < BB_R ? row : 0) * BB_H + 4 * (c < 32 ? c : 31));
+    }
+    auto issue = [&](const float *src, float *tile) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            __builtin_amdgcn_global_load_lds(src + goff[q], (lds_ptr)(tile + 256 * (wid + 4 * q)), 16, 0, 0);
+        if (wid == 0) __builtin_amdgcn_global_load_lds(src + goff[8], (lds_ptr)(tile + 256 * 32), 16, 0, 0);   // instruction 33
+    };
+    // One DMA instruction costs its wave ~300 cycles of issue (measured: the product behind a tile's 18 requests ran 2.3 us
+    // longer); spread one per four MFMAs through the input-gradient products, that time sits in the MFMA pipe's shadow.
+    auto issue_one = [&](const float *src, float *tile, int q) {
+        if (q < 8) __builtin_amdgcn_global_load_lds(src + goff[q], (lds_ptr)(tile + 256 * (wid + 4 * q)), 16, 0, 0);
+        else if (wid == 0) __builtin_amdgcn_global_load_lds(src + goff[8], (lds_ptr)(tile + 256 * 32), 16, 0, 0);
     };
     auto issue_x = [&](const float *src) {          // 64 rows x 64 floats, contiguous: 16 instructions
 #pragma unroll
@@ -103,7 +116,7 @@ resblock_bwd_kernel(BlockBwdArgs a) {
         }
     }
     // weight slices: B operand of the input-gradient products, k = 8 Q + 4 hh + s (the order ds_read_b128 delivers A in)
-    float W2r[64], W1r[64], W0r[INIT ? 64 : 1];
+    float W2r[64], W1r[64];
 #pragma unroll
     for (int Q = 0; Q < 16; ++Q)
 #pragma unroll
@@ -111,7 +124,6 @@ resblock_bwd_kernel(BlockBwdArgs a) {
             const int k = 8 * Q + 4 * hh + s;
             W2r[4 * Q + s] = a.W2[k * BB_H + 32 * wid + i];
             W1r[4 * Q + s] = a.W1[k * BB_H + 32 * wid + i];
-            if (INIT) W0r[4 * Q + s] = a.wfull[k * BB_D + 32 * in_ + i];
         }
     f32x16 acc2[4], acc1[4], acc0[2];
 #pragma unroll
@@ -124,92 +136,129 @@ resblock_bwd_kernel(BlockBwdArgs a) {
     tcount = 1;
 
     for (; tile < ntiles; tile += grid, ++tcount) {
-        const bool more = tile + grid < ntiles;
+        const bool more = tile + grid < ntiles, first = tile == (int64_t)blockIdx.x;     // the first tile's h_in: requested above
         BB_T(0);
         // per-tile lane index: with the loop-invariant LDS / global addresses hoisted out of the tile loop (a hundred-odd
         // registers) the INIT variant spills; recomputing them costs a few VALU instructions per 512 MFMAs
         int l_ = lane;
         asm volatile("" : "+v"(l_));
         const int i = l_ & 31, hh = l_ >> 5;
-        // ---- gt = (gh W2) [t > 0] -> Dt; the residual term gh -> registers ----
+        // ---- gt = (gh W2) [t > 0]: the products ----
         float outv[32];
+        f32x16 C[2];
 #pragma unroll
         for (int rh = 0; rh < 2; ++rh) {
-            f32x16 C = {0};
+            C[rh] = f32x16{0};
             const float *ap = Gt + (32 * rh + i) * BB_P + 4 * hh;
 #pragma unroll
             for (int Q = 0; Q < 16; ++Q) {
                 const f32x4 av = *reinterpret_cast<const f32x4 *>(ap + 8 * Q);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) C = MFMA32(av[s], W2r[4 * Q + s], C);
+                for (int s = 0; s < 4; ++s) C[rh] = MFMA32(av[s], W2r[4 * Q + s], C[rh]);
+                if (rh == 0 && Q < 9 && !first) issue_one(a.hin + tile * (BB_R * BB_H), Ht, Q);     // this tile's h_in (Ht: free since E)
             }
+        }
+        if (!EPI) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int idx = (32 * rh + 8 * (r >> 2) + 4 * hh + (r & 3)) * BB_P + 32 * wid + i;
-                Dt[idx] = Tt[idx] > 0.0f ? C[r] : 0.0f;
-                outv[16 * rh + r] = Gt[idx];
+            for (int kp = 0; kp < 32; ++kp) {
+                const int rh = kp >> 4, r = kp & 15, idx = (32 * rh + 8 * (r >> 2) + 4 * hh + (r & 3)) * BB_P + 32 * wid + i;
+                Dt[idx] = Tt[idx] > 0.0f ? C[rh][r] : 0.0f;
+                outv[kp] = Gt[idx];
             }
         }
         BB_T(1);
-        // ---- dW2 += gh^T relu(t), db2 += colsum(gh) ----
+        // ---- dW2 += gh^T relu(t), db2 += colsum(gh); (EPI) in the MFMAs' shadow, one element per k-pair, the epilogue of the
+        //      product above: gt -> Dt (masked by t > 0), the residual term gh -> registers.  Operands are fetched one k-pair ahead.
+#define BB_WGRAD_BODY(ACC, BSA, BSB, EPILOGUE)                                                                 \
+            {                                                                                                    \
+                float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;                                                \
+                if (kp + 1 < BB_R / 2) {                                                                         \
+                    na0 = ap[(kp + 1) * 2 * BB_P]; na1 = ap[(kp + 1) * 2 * BB_P + 32];                           \
+                    nb0 = bp[(kp + 1) * 2 * BB_P]; nb1 = bp[(kp + 1) * 2 * BB_P + 32];                           \
+                }                                                                                                \
+                EPILOGUE                                                                                         \
+                b0 = fmaxf(b0, 0.0f);                                                                            \
+                b1 = fmaxf(b1, 0.0f);                                                                            \
+                BSA += a0;                                                                                       \
+                BSB += a1;                                                                                       \
+                ACC[0] = MFMA32(a0, b0, ACC[0]);                                                                 \
+                ACC[1] = MFMA32(a0, b1, ACC[1]);                                                                 \
+                ACC[2] = MFMA32(a1, b0, ACC[2]);                                                                 \
+                ACC[3] = MFMA32(a1, b1, ACC[3]);                                                                 \
+                a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;                                                          \
+            }
         {
             const float *ap = Gt + hh * BB_P + 64 * om + i, *bp = Tt + hh * BB_P + 64 * in_ + i;
+            const int ebase = 4 * hh * BB_P + 32 * wid + i;
+            float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
+            if (EPI) {
+#pragma unroll
+                for (int kp = 0; kp < BB_R / 2; ++kp) {
+                    BB_WGRAD_BODY(acc2, bs2a, bs2b, {
+                        const int rh = kp >> 4;
+                        const int r = kp & 15;
+                        const int idx = ebase + (32 * rh + 8 * (r >> 2) + (r & 3)) * BB_P;
+                        Dt[idx] = Tt[idx] > 0.0f ? C[rh][r] : 0.0f;
+                        outv[kp] = Gt[idx];
+                    })
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
 #pragma unroll 8
-            for (int kp = 0; kp < BB_R / 2; ++kp) {
-                const float a0 = ap[kp * 2 * BB_P], a1 = ap[kp * 2 * BB_P + 32];
-                const float b0 = fmaxf(bp[kp * 2 * BB_P], 0.0f), b1 = fmaxf(bp[kp * 2 * BB_P + 32], 0.0f);
-                bs2a += a0;
-                bs2b += a1;
-                acc2[0] = MFMA32(a0, b0, acc2[0]);
-                acc2[1] = MFMA32(a0, b1, acc2[1]);
-                acc2[2] = MFMA32(a1, b0, acc2[2]);
-                acc2[3] = MFMA32(a1, b1, acc2[3]);
+                for (int kp = 0; kp < BB_R / 2; ++kp) BB_WGRAD_BODY(acc2, bs2a, bs2b, {})
             }
         }
         BB_T(2);
         BB_BARRIER_ALL();          // Dt complete, h_in (and x) landed; every wave is done with Gt and Tt
         BB_T(3);
-        if (more) {
-            issue(a.gh + (tile + grid) * (BB_R * BB_H), Gt);
-            issue(a.t + (tile + grid) * (BB_R * BB_H), Tt);
-        }
-        // ---- gh_in = gh + (gt W1) [h_in > 0] ----
+        // ---- gh_in = gh + (gt W1) [h_in > 0]: the products; between them the next tile's gh / t requests (Gt, Tt: free since M) ----
 #pragma unroll
         for (int rh = 0; rh < 2; ++rh) {
-            f32x16 C = {0};
+            C[rh] = f32x16{0};
             const float *ap = Dt + (32 * rh + i) * BB_P + 4 * hh;
 #pragma unroll
             for (int Q = 0; Q < 16; ++Q) {
                 const f32x4 av = *reinterpret_cast<const f32x4 *>(ap + 8 * Q);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) C = MFMA32(av[s], W1r[4 * Q + s], C);
+                for (int s = 0; s < 4; ++s) C[rh] = MFMA32(av[s], W1r[4 * Q + s], C[rh]);
+                if (Q < 9 && more) {
+                    if (rh == 0) issue_one(a.gh + (tile + grid) * (BB_R * BB_H), Gt, Q);
+                    else issue_one(a.t + (tile + grid) * (BB_R * BB_H), Tt, Q);
+                }
             }
+        }
+        if (!EPI) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int idx = (32 * rh + 8 * (r >> 2) + 4 * hh + (r & 3)) * BB_P + 32 * wid + i;
-                outv[16 * rh + r] += Ht[idx] > 0.0f ? C[r] : 0.0f;
+            for (int kp = 0; kp < 32; ++kp) {
+                const int rh = kp >> 4, r = kp & 15, idx = (32 * rh + 8 * (r >> 2) + 4 * hh + (r & 3)) * BB_P + 32 * wid + i;
+                outv[kp] += Ht[idx] > 0.0f ? C[rh][r] : 0.0f;
             }
         }
         BB_T(4);
-        // ---- dW1 += gt^T relu(h_in), db1 += colsum(gt) ----
+        // ---- dW1 += gt^T relu(h_in), db1 += colsum(gt); (EPI) in the shadow: gh_in = gh + product masked by h_in > 0 ----
         {
             const float *ap = Dt + hh * BB_P + 64 * om + i, *bp = Ht + hh * BB_P + 64 * in_ + i;
+            const int ebase = 4 * hh * BB_P + 32 * wid + i;
+            float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
+            if (EPI) {
+#pragma unroll
+                for (int kp = 0; kp < BB_R / 2; ++kp) {
+                    BB_WGRAD_BODY(acc1, bs1a, bs1b, {
+                        const int rh = kp >> 4;
+                        const int r = kp & 15;
+                        const int idx = ebase + (32 * rh + 8 * (r >> 2) + (r & 3)) * BB_P;
+                        outv[kp] += Ht[idx] > 0.0f ? C[rh][r] : 0.0f;
+                    })
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
 #pragma unroll 8
-            for (int kp = 0; kp < BB_R / 2; ++kp) {
-                const float a0 = ap[kp * 2 * BB_P], a1 = ap[kp * 2 * BB_P + 32];
-                const float b0 = fmaxf(bp[kp * 2 * BB_P], 0.0f), b1 = fmaxf(bp[kp * 2 * BB_P + 32], 0.0f);
-                bs1a += a0;
-                bs1b += a1;
-                acc1[0] = MFMA32(a0, b0, acc1[0]);
-                acc1[1] = MFMA32(a0, b1, acc1[1]);
-                acc1[2] = MFMA32(a1, b0, acc1[2]);
-                acc1[3] = MFMA32(a1, b1, acc1[3]);
+                for (int kp = 0; kp < BB_R / 2; ++kp) BB_WGRAD_BODY(acc1, bs1a, bs1b, {})
             }
         }
         BB_T(5);
         BB_BARRIER_ALL();          // next tile's gh / t landed; every wave is done with Ht and Dt
         BB_T(6);
-        if (more) issue(a.hin + (tile + grid) * (BB_R * BB_H), Ht);
         if (!INIT) {
 #pragma unroll
             for (int rh = 0; rh < 2; ++rh)
@@ -225,34 +274,55 @@ resblock_bwd_kernel(BlockBwdArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     Dt[(32 * rh + 8 * (r >> 2) + 4 * hh + (r & 3)) * BB_P + 32 * wid + i] = outv[16 * rh + r];
+            BB_T(8);
             BB_BARRIER_LDS();
-            // gx[rows 32 om .. +32][32 in_ .. +32] += gh_in Wfull
+            BB_T(9);
+            // gx[rows 32 om .. +32][32 in_ .. +32] += gh_in Wfull.  The old values are requested here, BEFORE the weight-gradient
+            // loop: behind the h_in DMAs just issued their latency is ~5 us, more than the 64 MFMAs of this product cover
+            // (measured: requested right before it, 6.0 us for the product; fire-and-forget float adds were as slow).
+            // its weight slice (64 registers) is fetched per tile (L2, 16-byte loads of the transposed image) instead of living
+            // through the block's products: resident, the kernel spills, and a spill reload waits (vmcnt is in order) for every
+            // DMA in flight
+            f32x4 W0r[16];
+#pragma unroll
+            for (int Q = 0; Q < 16; ++Q)
+                W0r[Q] = *reinterpret_cast<const f32x4 *>(a.wfull + (32 * in_ + i) * BB_H + 8 * Q + 4 * hh);
+            float *gp = a.gx + (tile * BB_R + 32 * om + 4 * hh) * BB_D + 32 * in_ + i;
+            float old[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) old[r] = gp[(8 * (r >> 2) + (r & 3)) * BB_D];
+            // dW0[32 wid .. +32][0 .. 64] += gh_in^T x, db0 += colsum(gh_in)
             {
-                f32x16 C = {0};
+                const float *ap = Dt + hh * BB_P + 32 * wid + i, *bp = Xt + hh * BB_D + i;
+                float a0 = ap[0], b0 = bp[0], b1 = bp[32];
+#pragma unroll 8
+                for (int kp = 0; kp < BB_R / 2; ++kp) {     // two MFMAs per k-pair: without the look-ahead the LDS latency shows
+                    float na0 = 0.f, nb0 = 0.f, nb1 = 0.f;
+                    if (kp + 1 < BB_R / 2) {
+                        na0 = ap[(kp + 1) * 2 * BB_P];
+                        nb0 = bp[(kp + 1) * 2 * BB_D];
+                        nb1 = bp[(kp + 1) * 2 * BB_D + 32];
+                    }
+                    bs0 += a0;
+                    acc0[0] = MFMA32(a0, b0, acc0[0]);
+                    acc0[1] = MFMA32(a0, b1, acc0[1]);
+                    a0 = na0; b0 = nb0; b1 = nb1;
+                }
+            }
+            BB_T(10);
+            {
+                f32x16 C3 = {0};
                 const float *ap = Dt + (32 * om + i) * BB_P + 4 * hh;
 #pragma unroll
                 for (int Q = 0; Q < 16; ++Q) {
                     const f32x4 av = *reinterpret_cast<const f32x4 *>(ap + 8 * Q);
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) C = MFMA32(av[s], W0r[4 * Q + s], C);
+                    for (int s = 0; s < 4; ++s) C3 = MFMA32(av[s], W0r[Q][s], C3);
                 }
-                // every element of gx is touched by exactly one lane of one workgroup: the fire-and-forget float add is
-                // deterministic here, and needs neither the old value in registers nor a load in front of the epilogue
-                float *gp = a.gx + (tile * BB_R + 32 * om + 4 * hh) * BB_D + 32 * in_ + i;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) unsafeAtomicAdd(gp + (8 * (r >> 2) + (r & 3)) * BB_D, C[r]);
+                for (int r = 0; r < 16; ++r) gp[(8 * (r >> 2) + (r & 3)) * BB_D] = old[r] + C3[r];
             }
-            // dW0[32 wid .. +32][0 .. 64] += gh_in^T x, db0 += colsum(gh_in)
-            {
-                const float *ap = Dt + hh * BB_P + 32 * wid + i, *bp = Xt + hh * BB_D + i;
-#pragma unroll 8
-                for (int kp = 0; kp < BB_R / 2; ++kp) {
-                    const float a0 = ap[kp * 2 * BB_P];
-                    bs0 += a0;
-                    acc0[0] = MFMA32(a0, bp[kp * 2 * BB_D], acc0[0]);
-                    acc0[1] = MFMA32(a0, bp[kp * 2 * BB_D + 32], acc0[1]);
-                }
-            }
+            BB_T(11);
             BB_BARRIER_LDS();      // every wave is done with Dt and Xt
             if (more) {
                 issue_x(a.x + (tile + grid) * (BB_R * BB_D));
@@ -309,13 +379,15 @@ extern "C" int64_t nf_resblock_bwd_scratch_floats(int64_t B, int with_init) {
 
 extern "C" int nf_resblock_bwd(const void *gh, const void *t, const void *h_in, const void *W1, const void *W2, void *gh_in,
                                void *dW1, void *db1, void *dW2, void *db2, const void *x, const void *wfull, void *gx,
-                               void *dW0, void *db0, void *scratch, int64_t B, int H, int D, nf_stream_t stream) {
+                               void *dW0, void *db0, const void *col_map, int n_cols, void *scratch, int64_t B, int H, int D,
+                               nf_stream_t stream) {
     using namespace nf;
     if (H != BB_H || B < BB_R || B % BB_R) return NF_ENOTSUP;
     if (!gh || !t || !h_in || !W1 || !W2 || !dW1 || !db1 || !dW2 || !db2 || !scratch) return NF_EFAULT;
     const bool init = x != nullptr;
     if (init && D != BB_D) return NF_ENOTSUP;
     if (init && (!wfull || !gx || !dW0 || !db0)) return NF_EFAULT;
+    if (col_map && (n_cols < 1 || n_cols > BB_D)) return NF_EINVAL;
     if (!init && !gh_in) return NF_EFAULT;
     if (((uintptr_t)gh | (uintptr_t)t | (uintptr_t)h_in | (uintptr_t)x | (uintptr_t)gh_in | (uintptr_t)gx) & 15) return NF_EINVAL;
     if ((((uintptr_t)dW1 ^ (uintptr_t)dW2) | ((uintptr_t)db1 ^ (uintptr_t)db2)) & 3) return NF_EINVAL;
@@ -343,9 +415,10 @@ extern "C" int nf_resblock_bwd(const void *gh, const void *t, const void *h_in, 
     }
     NF_CHECK_LAUNCH();
     int rc = wgrad_reduce_launch(a.part, (float *)dW2, (float *)db2, (int64_t)BB_H * BB_H, BB_H, grid, BB_H, 2, grid * stride,
-                                 (float *)dW1 - (float *)dW2, (float *)db1 - (float *)db2, st);
+                                 (float *)dW1 - (float *)dW2, (float *)db1 - (float *)db2, nullptr, 0, st);
     if (rc != NF_OK) return rc;
     if (init)
-        rc = wgrad_reduce_launch(a.part0, (float *)dW0, (float *)db0, (int64_t)BB_H * BB_D, BB_H, grid, BB_D, 1, 0, 0, 0, st);
+        rc = wgrad_reduce_launch(a.part0, (float *)dW0, (float *)db0, (int64_t)BB_H * BB_D, BB_H, grid, BB_D, 1, 0, 0, 0,
+                                 (const int *)col_map, n_cols, st);
     return rc;
 }

@@ -795,6 +795,11 @@ struct PackAllArgs {
     const float *w_init, *b_init, *w_final, *b_final, *uw, *uh, *ud;
     const float *w_blk[32], *b_blk[32];
     int nblk;
+    // optional by-products for the backward (all three or none): the initial weight TRANSPOSED on full rows (64, hidden; only the
+    // identity features' rows are written, the rest of the caller's buffer stays zero) and the final weight in 24-row groups
+    // (32, 24, hidden; row 23 of a group stays zero)
+    float *wfull, *wpad;
+    const int64_t *iidx;
 };
 __global__ void pack_all_kernel(PackAllArgs a, float *__restrict__ blob, float wh_scale, RqsParams<float> p) {
     FusedLayout lay;
@@ -819,6 +824,13 @@ __global__ void pack_all_kernel(PackAllArgs a, float *__restrict__ blob, float w
             v = row >= 0 ? a.w_final[row * F_H + 8 * s + 4 * (lane >> 5) + r4] * sc : 0.0f;
         }
         stages[i] = v;
+    }
+    if (a.wfull) {
+        for (int64_t i = tid0; i < F_H * F_NI; i += nth) a.wfull[a.iidx[i & 31] * F_H + (i >> 5)] = a.w_init[i];
+        for (int64_t i = tid0; i < (int64_t)F_NI * 23 * F_H; i += nth) {
+            const int h = (int)(i & (F_H - 1)), row = (int)(i >> 7), t = row / 23;
+            a.wpad[(int64_t)(row + t) * F_H + h] = a.w_final[i];
+        }
     }
     const int nbias = 128 + 128 * nlin + 768;
     for (int64_t i = tid0; i < nbias; i += nth) {
@@ -864,9 +876,11 @@ static inline bool fused_bins_ok(int K) { return K == 4 || K == 8 || K == 16; } 
 extern "C" int nf_rqs_fused_pack_all(void *wpack, const void *w_init, const void *b_init, const void *const *w_blocks,
                                      const void *const *b_blocks, const void *w_final, const void *b_final, const void *uw,
                                      const void *uh, const void *ud, int hidden, int num_blocks, int K, double tail_bound,
-                                     double min_bin_width, double min_bin_height, double min_derivative, nf_stream_t stream) {
+                                     double min_bin_width, double min_bin_height, double min_derivative, void *wfull, void *wpad,
+                                     const void *identity_idx, nf_stream_t stream) {
     if (hidden != F_H || K != F_K || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
     if (!wpack || !w_init || !b_init || !w_final || !b_final || !uw || !uh || !ud) return NF_EFAULT;
+    if ((wfull || wpad || identity_idx) && !(wfull && wpad && identity_idx)) return NF_EFAULT;
     if (num_blocks > 0 && (!w_blocks || !b_blocks)) return NF_EFAULT;
     if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_EINVAL;
     PackAllArgs a;
@@ -874,6 +888,7 @@ extern "C" int nf_rqs_fused_pack_all(void *wpack, const void *w_init, const void
     a.w_final = (const float *)w_final; a.b_final = (const float *)b_final;
     a.uw = (const float *)uw; a.uh = (const float *)uh; a.ud = (const float *)ud;
     a.nblk = num_blocks;
+    a.wfull = (float *)wfull; a.wpad = (float *)wpad; a.iidx = (const int64_t *)identity_idx;
     for (int l = 0; l < 32; ++l) { a.w_blk[l] = nullptr; a.b_blk[l] = nullptr; }
     for (int l = 0; l < 2 * num_blocks; ++l) {
         if (!w_blocks[l] || !b_blocks[l]) return NF_EFAULT;

@@ -412,7 +412,7 @@ constexpr int RL = 16;
 __global__ void __launch_bounds__(64 * RL)
 wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, float *__restrict__ db, int64_t nW, int64_t n,
                     int64_t stride, int chunks, int accumulate, int N, int skip_every, int64_t zpart, int64_t zdW,
-                    int64_t zdb) {
+                    int64_t zdb, const int *__restrict__ colmap, int Nout) {
     part += (int64_t)blockIdx.y * zpart;      // blockIdx.y = 1: the second problem of a pair launch
     dW += (int64_t)blockIdx.y * zdW;
     if (db) db += (int64_t)blockIdx.y * zdb;
@@ -442,6 +442,11 @@ wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, floa
                 const int64_t m = e < nW ? e / N : e - nW, g = m / skip_every;
                 o = (m - g * skip_every == skip_every - 1) ? nullptr : (e < nW ? dW + e - g * N : db + (m - g));
             }
+            if (colmap && e < nW) {     // dW keeps the columns n with colmap[n] >= 0, compacted to Nout columns
+                const int64_t m = e / N;
+                const int c = colmap[e - m * N];
+                o = c < 0 ? nullptr : dW + m * Nout + c;
+            }
             if (o) *o = accumulate ? *o + s : s;
         }
         __syncthreads();
@@ -450,10 +455,10 @@ wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, floa
 
 // The reduction as a host call for the kernels of other translation units (resblock_bwd.hip): part = [problem][chunk][nW + M].
 int wgrad_reduce_launch(const float *part, float *dW, float *db, int64_t nW, int M, int chunks, int N, int np, int64_t zpart,
-                        int64_t zdW, int64_t zdb, hipStream_t st) {
+                        int64_t zdW, int64_t zdb, const int *colmap, int Nout, hipStream_t st) {
     const int64_t n = nW + (db ? M : 0);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(n, 64), np), dim3(64 * RL), 0, st, part, dW, db, nW, n, nW + M, chunks, 0,
-                       N, 0, zpart, zdW, zdb);
+                       N, 0, zpart, zdW, zdb, colmap, Nout);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -584,7 +589,7 @@ static int wgrad_impl(const void *dY, const void *X, void *dW, void *db, void *s
     NF_CHECK_LAUNCH();
     const int64_t nW = (int64_t)M * N, n = nW + (db ? M : 0);
     hipLaunchKernelGGL(nf::wgrad_reduce_kernel, dim3(nf::grid_for(n, 64), np), dim3(64 * nf::RL), 0, st, part, (float *)dW,
-                       (float *)db, nW, n, nW + M, chunks, accumulate, N, skip_every, zpart, zdW, zdb);
+                       (float *)db, nW, n, nW + M, chunks, accumulate, N, skip_every, zpart, zdW, zdb, (const int *)nullptr, 0);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

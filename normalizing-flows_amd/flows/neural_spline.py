@@ -433,8 +433,11 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
         buf = self.__dict__.get("_train_wbufs")
         if buf is None or buf[0].device != inputs.device or buf[0].dtype != w0.dtype:
             nT = self.transform_features.numel()
+            col_map = torch.full((inputs.shape[1],), -1, dtype=torch.int32, device=inputs.device)
+            col_map[self.identity_features] = torch.arange(self.identity_features.numel(), dtype=torch.int32, device=inputs.device)
             buf = (torch.zeros(w0.shape[0], inputs.shape[1], dtype=w0.dtype, device=inputs.device),
-                   torch.zeros(nT, 24, wf.shape[1], dtype=wf.dtype, device=inputs.device))
+                   torch.zeros(nT, 24, wf.shape[1], dtype=wf.dtype, device=inputs.device), col_map,
+                   torch.zeros(inputs.shape[1], w0.shape[0], dtype=w0.dtype, device=inputs.device))      # (D, H): w0^T on full rows
             self.__dict__["_train_wbufs"] = buf
         return buf
 
@@ -449,9 +452,9 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
             # coupling transform as ONE launch (FinalSplineDensityFn)
             net = self.transform_net
             inputs = inputs.contiguous()
-            wfull, wpad = self._train_buffers(inputs)
+            wfull, wpad, col_map, wfull_t = self._train_buffers(inputs)
             fkw = dict(tail_bound=float(self.tail_bound), min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
-                       min_derivative=self.min_derivative, wh_div=self._wh_div())
+                       min_derivative=self.min_derivative, wh_div=self._wh_div(), col_map=col_map)
             if _config.train_full and inputs.shape[1] == 64 and net.initial_layer.weight.shape[0] == 128:
                 blob = self.__dict__.get("_train_blob")
                 if blob is None or blob.device != inputs.device:
@@ -460,7 +463,7 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
                 return CouplingTrainFn.apply(inputs, net.initial_layer.weight, net.initial_layer.bias, net.final_layer.weight,
                                              net.final_layer.bias, u.unnormalized_widths, u.unnormalized_heights,
                                              u.unnormalized_derivatives, self.identity_features, self.transform_features, blob,
-                                             self._fused_parity, fkw, wfull, wpad, ld, 1 if (acc is None or acc > 0) else -1,
+                                             self._fused_parity, fkw, wfull_t, wpad, ld, 1 if (acc is None or acc > 0) else -1,
                                              *blk)
             h2 = IdentLinearFn.apply(inputs, net.initial_layer.weight, net.initial_layer.bias, self.identity_features, wfull)
             for block in net.blocks:

@@ -631,16 +631,17 @@ def rqs_fused_train_fwd(x, h2, blob, mask_parity, num_blocks, tail_bound=3.0, mi
 
 
 def rqs_fused_pack_all(blob, w_init, b_init, w_blocks, b_blocks, w_final, b_final, uw, uh, ud, tail_bound=3.0, min_bin_width=1e-3,
-                       min_bin_height=1e-3, min_derivative=1e-3):
+                       min_bin_height=1e-3, min_derivative=1e-3, wfull=None, wpad=None, identity_idx=None):
     """The whole layer's blob (no LU) in one launch (nf_rqs_fused_pack_all); hidden 128, 8 bins."""
     import ctypes
-    L.require_device(blob, w_init, b_init, w_final, b_final, uw, uh, ud, *w_blocks, *b_blocks)
+    L.require_device(blob, w_init, b_init, w_final, b_final, uw, uh, ud, wfull, wpad, identity_idx, *w_blocks, *b_blocks)
     n = len(w_blocks)
     wp = (ctypes.c_void_p * max(n, 1))(*[w.data_ptr() for w in w_blocks])
     bp = (ctypes.c_void_p * max(n, 1))(*[b.data_ptr() for b in b_blocks])
     rc = L.lib().nf_rqs_fused_pack_all(ptr(blob), ptr(w_init), ptr(b_init), wp, bp, ptr(w_final), ptr(b_final), ptr(uw), ptr(uh),
                                        ptr(ud), i32(128), i32(n // 2), i32(8), f64(tail_bound), f64(min_bin_width),
-                                       f64(min_bin_height), f64(min_derivative), L.stream())
+                                       f64(min_bin_height), f64(min_derivative), ptr(wfull), ptr(wpad), ptr(identity_idx),
+                                       L.stream())
     L.check(rc, "nf_rqs_fused_pack_all")
     return blob
 
@@ -1025,11 +1026,13 @@ def linear_wgrad_pair(dy0, x0, dy1, x1, relu_x=False):
     return w0.view(M, N), b0, w1.view(M, N), b1
 
 
-def resblock_bwd(gh, t, h_in, w1, w2, x=None, wfull=None, gx=None):
+def resblock_bwd(gh, t, h_in, w1, w2, x=None, wfull=None, gx=None, col_map=None, n_cols=0):
     """Backward of one residual block (hidden 128) in one pass over the rows (nf_resblock_bwd): returns
     (gh_in, dW1, db1, dW2, db2); with x / wfull / gx also the initial Linear layer behind the block:
-    gx += gh_in @ wfull in place, and (None, dW1, db1, dW2, db2, dW0 (128, 64), db0) is returned."""
-    L.require_device(gh, t, h_in, w1, w2, x, wfull, gx)
+    gx += gh_in @ wfull.t() in place (wfull (64, 128): the layer's weight transposed on full rows), and
+    (None, dW1, db1, dW2, db2, dW0 (128, 64), db0) is returned; col_map (64 int32, -1 = drop):
+    dW0 is compacted to the (128, n_cols) columns it names."""
+    L.require_device(gh, t, h_in, w1, w2, x, wfull, gx, col_map)
     gh, t, h_in, w1, w2 = gh.contiguous(), t.contiguous(), h_in.contiguous(), w1.contiguous(), w2.contiguous()
     if any(v.dtype != torch.float32 for v in (gh, t, h_in, w1, w2)):
         raise ValueError("resblock_bwd: float32 only")
@@ -1044,17 +1047,20 @@ def resblock_bwd(gh, t, h_in, w1, w2, x=None, wfull=None, gx=None):
     out = torch.empty(2, H * H + H, dtype=torch.float32, device=gh.device)      # (dW2 | db2), (dW1 | db1)
     w2g, b2g, w1g, b1g = out[0, :H * H], out[0, H * H:], out[1, :H * H], out[1, H * H:]
     if init:
-        if not (x.is_contiguous() and gx.is_contiguous() and wfull.is_contiguous()) or x.shape[1] != 64:
-            raise ValueError("resblock_bwd: contiguous x / gx (B, 64) and wfull (128, 64)")
-        out0 = torch.empty(H * 64 + H, dtype=torch.float32, device=gh.device)
-        gh_in, w0g, b0g = None, out0[:H * 64], out0[H * 64:]
+        if not (x.is_contiguous() and gx.is_contiguous() and wfull.is_contiguous()) or x.shape[1] != 64 or \
+                tuple(wfull.shape) != (64, 128):
+            raise ValueError("resblock_bwd: contiguous x / gx (B, 64) and wfull (64, 128)")
+        nc = int(n_cols) if col_map is not None else 64
+        out0 = torch.empty(H * nc + H, dtype=torch.float32, device=gh.device)
+        gh_in, w0g, b0g = None, out0[:H * nc], out0[H * nc:]
     else:
         gh_in, w0g, b0g = torch.empty_like(gh), None, None
     rc = lib.nf_resblock_bwd(ptr(gh), ptr(t), ptr(h_in), ptr(w1), ptr(w2), ptr(gh_in), ptr(w1g), ptr(b1g), ptr(w2g), ptr(b2g),
-                             ptr(x), ptr(wfull), ptr(gx), ptr(w0g), ptr(b0g), ptr(scratch), i64(B), i32(H), i32(64), L.stream())
+                             ptr(x), ptr(wfull), ptr(gx), ptr(w0g), ptr(b0g), ptr(col_map), i32(int(n_cols)), ptr(scratch),
+                             i64(B), i32(H), i32(64), L.stream())
     L.check(rc, "nf_resblock_bwd")
     if init:
-        return None, w1g.view(H, H), b1g, w2g.view(H, H), b2g, w0g.view(H, 64), b0g
+        return None, w1g.view(H, H), b1g, w2g.view(H, H), b2g, w0g.view(H, nc), b0g
     return gh_in, w1g.view(H, H), b1g, w2g.view(H, H), b2g
 
 

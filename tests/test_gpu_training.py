@@ -627,7 +627,7 @@ def test_resblock_backward_one_pass_kernel(nfa, B, init):
         if not init:
             return list(nfa.ops.resblock_bwd(gh, t, h, W1, W2))
         gx = gx0.clone()
-        return [gx] + list(nfa.ops.resblock_bwd(gh, t, h, W1, W2, x=x, wfull=wfull, gx=gx))[1:]
+        return [gx] + list(nfa.ops.resblock_bwd(gh, t, h, W1, W2, x=x, wfull=wfull.t().contiguous(), gx=gx))[1:]
 
     out, out2 = run(), run()
     for nm, a, r in zip(["gh_in / gx", "dW1", "db1", "dW2", "db2", "dW0", "db0"], out, ref):

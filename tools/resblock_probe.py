@@ -11,7 +11,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 torch.manual_seed(0)
 gh = torch.randn(B, 128, device=dev); t = torch.randn(B, 128, device=dev); h = torch.randn(B, 128, device=dev)
 W1 = torch.randn(128, 128, device=dev) * 0.1; W2 = torch.randn(128, 128, device=dev) * 0.1
-x = torch.randn(B, 64, device=dev); wfull = torch.randn(128, 64, device=dev) * 0.1; wfull[:, 1::2] = 0
+x = torch.randn(B, 64, device=dev); wfull = torch.randn(128, 64, device=dev) * 0.1; wfull[:, 1::2] = 0; wfull_t = wfull.t().contiguous()
 gx0 = torch.randn(B, 64, device=dev)
 
 def old(init):
@@ -27,7 +27,7 @@ def new(init):
     if not init:
         return ops.resblock_bwd(gh, t, h, W1, W2)
     gx = gx0.clone()
-    r = ops.resblock_bwd(gh, t, h, W1, W2, x=x, wfull=wfull, gx=gx)
+    r = ops.resblock_bwd(gh, t, h, W1, W2, x=x, wfull=wfull_t, gx=gx)
     return (gx,) + r[1:]
 
 def timeit(f, n=30):
