@@ -367,6 +367,13 @@ int nf_linear_wgrad_pair(const void *dY0, const void *X0, void *dW0, void *db0, 
  * col_map (D int32, optional): dW0 keeps only the columns n with col_map[n] >= 0, as (H, n_cols) with column col_map[n] (the
  * identity features: the initial layer's own (H, nI) weight gradient).
  * B a multiple of 64; scratch: nf_resblock_bwd_scratch_floats(B, x != NULL) floats.  Deterministic (fixed-order reduction). */
+/* Backward of LULinearPermute's batch side, density direction (mixing.py:535-563: u = U x[perm], y = L u + b), D = 64, in ONE
+ * pass over the rows: gx = (gy Lm) Up, dL = gy^T u, db = colsum(gy), dUp = (gy Lm)^T x.  Lm = L, Up = U with permuted columns
+ * (nf_lu_factors), u = the forward's intermediate (nf_rows_matvec2); nf_lu_param_grads turns (dL, dUp) into the packed
+ * parameter gradients.  B a multiple of 64; scratch: nf_lu_bwd_scratch_floats(B) floats.  Deterministic. */
+int64_t nf_lu_bwd_scratch_floats(int64_t B);
+int nf_lu_bwd(const void *gy, const void *u, const void *x, const void *Lm, const void *Up, void *gx, void *dL, void *db, void *dUp,
+              void *scratch, int64_t B, int D, nf_stream_t stream);
 int64_t nf_resblock_bwd_scratch_floats(int64_t B, int with_init);
 int nf_resblock_bwd(const void *gh, const void *t, const void *h_in, const void *W1, const void *W2, void *gh_in, void *dW1,
                     void *db1, void *dW2, void *db2, const void *x, const void *wfull, void *gx, void *dW0, void *db0,

@@ -225,6 +225,12 @@ class LULinearPermuteFn(torch.autograd.Function):
             Lm, Um, diag, Up, LT, UpT = fac
             gy = torch.zeros_like(y) if gy is None else gy.contiguous()
             from . import config
+            if config.lu_bwd_fused and D_ == 64 and gy.shape[0] % 64 == 0 and gy.shape[0] >= 1024 and u_saved is not None:
+                # both row products and both batch reductions in one pass over the rows (nf_lu_bwd)
+                gx, gL, g_bias, gUx = ops.lu_bwd(gy, u_saved, x, Lm, Up)
+                g_lower, g_upper, g_udiag = ops.lu_param_grads(gL, gUx, gld, udiag_raw.detach(), lower_entries.numel(),
+                                                               eps=ctx.eps, sign=1.0, perm=perm)
+                return gx, None, g_lower, g_upper, g_udiag, g_bias, None, None, g_acc, None
             if config.lu_matvec2:
                 gu, gx, _ = ops.rows_matvec2(gy, LT, UpT)   # d/du = L^T gy, d/dx = P (U^T gu): one launch
             else:

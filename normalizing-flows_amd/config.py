@@ -76,6 +76,15 @@ def set_resblock_bwd(mode=True):
     resblock_bwd = bool(mode)
 
 
+# LULinearPermute's density-direction backward (D = 64) as one pass over the rows (nf_lu_bwd).
+lu_bwd_fused = True
+
+
+def set_lu_bwd_fused(mode=True):
+    global lu_bwd_fused
+    lu_bwd_fused = bool(mode)
+
+
 def set_fused_chain(mode=True):
     global fused_chain
     fused_chain = bool(mode)

@@ -1026,6 +1026,26 @@ def linear_wgrad_pair(dy0, x0, dy1, x1, relu_x=False):
     return w0.view(M, N), b0, w1.view(M, N), b1
 
 
+def lu_bwd(gy, u, x, Lm, Up):
+    """(gx, dL, db, dUp) of LULinearPermute's batch side in the density direction, D = 64, one pass over the rows (nf_lu_bwd)."""
+    L.require_device(gy, u, x, Lm, Up)
+    gy, u, x, Lm, Up = gy.contiguous(), u.contiguous(), x.contiguous(), Lm.contiguous(), Up.contiguous()
+    B, D = gy.shape
+    lib = L.lib()
+    lib.nf_lu_bwd_scratch_floats.restype = C.c_int64
+    n = int(lib.nf_lu_bwd_scratch_floats(i64(B)))
+    if n <= 0 or D != 64 or gy.dtype != torch.float32:
+        raise NotImplementedError("lu_bwd: float32, D = 64, batch a multiple of 64")
+    scratch = torch.empty(n, dtype=torch.float32, device=gy.device)
+    out = torch.empty(2 * D * D + D, dtype=torch.float32, device=gy.device)
+    dL, dUp, db = out[:D * D], out[D * D:2 * D * D], out[2 * D * D:]
+    gx = torch.empty_like(gy)
+    rc = lib.nf_lu_bwd(ptr(gy), ptr(u), ptr(x), ptr(Lm), ptr(Up), ptr(gx), ptr(dL), ptr(db), ptr(dUp), ptr(scratch), i64(B),
+                       i32(D), L.stream())
+    L.check(rc, "nf_lu_bwd")
+    return gx, dL.view(D, D), db, dUp.view(D, D)
+
+
 def resblock_bwd(gh, t, h_in, w1, w2, x=None, wfull=None, gx=None, col_map=None, n_cols=0):
     """Backward of one residual block (hidden 128) in one pass over the rows (nf_resblock_bwd): returns
     (gh_in, dW1, db1, dW2, db2); with x / wfull / gx also the initial Linear layer behind the block:

@@ -638,6 +638,42 @@ def test_resblock_backward_one_pass_kernel(nfa, B, init):
         nfa.ops.resblock_bwd(gh[:100], t[:100], h[:100], W1, W2)        # rows: multiples of 64
 
 
+@pytest.mark.parametrize("B", [65536, 1024, 4096 + 64])
+def test_lu_backward_one_pass_kernel(nfa, B):
+    """nf_lu_bwd (LULinearPermute's batch-side backward, D = 64: both row products and both batch reductions in one pass)
+    against float64 torch, bit-reproducible; and the layer's gradients with / without it."""
+    torch.manual_seed(B)
+    gy, u, x = (torch.randn(B, 64, device=DEV) for _ in range(3))
+    Lm = torch.tril(0.2 * torch.randn(64, 64, device=DEV), -1) + torch.eye(64, device=DEV)
+    Up = 0.2 * torch.randn(64, 64, device=DEV)
+    d = lambda v: v.double()
+    gu = d(gy) @ d(Lm)
+    ref = [gu @ d(Up), d(gy).t() @ d(u), d(gy).sum(0), gu.t() @ d(x)]
+    out, out2 = nfa.ops.lu_bwd(gy, u, x, Lm, Up), nfa.ops.lu_bwd(gy, u, x, Lm, Up)
+    for nm, a, r in zip(["gx", "dL", "db", "dUp"], out, ref):
+        scale = float(r.abs().max())
+        assert float((a.double() - r).abs().max()) < 2e-5 * scale, (nm, float((a.double() - r).abs().max()), scale)
+    assert all(torch.equal(a, b) for a, b in zip(out, out2))
+    layer = nfa.flows.LULinearPermute(64).to(DEV)
+    with torch.no_grad():
+        layer.linear.lower_entries.normal_(0, 0.1)
+        layer.linear.upper_entries.normal_(0, 0.1)
+    xin = torch.randn(B, 64, device=DEV)
+    w = torch.randn(B, 64, device=DEV)
+    res = []
+    for fused in (True, False):
+        nfa.config.set_lu_bwd_fused(fused)
+        xa = xin.clone().requires_grad_(True)
+        layer.zero_grad()
+        z, ld = layer.inverse(xa)
+        ((z * w).sum() / B + ld.mean()).backward()
+        res.append([xa.grad.clone()] + [p_.grad.clone() for p_ in layer.parameters()])
+    nfa.config.set_lu_bwd_fused(True)
+    for a, b in zip(*res):
+        scale = max(float(b.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) < 1e-4 * scale, (float((a - b).abs().max()), scale)
+
+
 def test_fused_final_layer_and_spline_training_forward_vs_layerwise(nfa):
     """Training step of the benchmark-shaped layer: final Linear + coupling transform as ONE forward launch
     (FinalSplineDensityFn: nf_rqs_fused_train_fwd, conditioner output kept in 24-float rows, nf_rqs_coupling_bwd_p24)

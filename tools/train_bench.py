@@ -20,6 +20,7 @@ ap.add_argument("--no-wgrad-pair", action="store_true", help="ablation: the resi
 ap.add_argument("--no-matvec2", action="store_true", help="ablation: LULinearPermute's chained products as two launches each")
 ap.add_argument("--no-train-full", action="store_true", help="ablation: per-module Functions instead of the whole-layer forward launch")
 ap.add_argument("--no-resblock-bwd", action="store_true", help="ablation: residual-block backward as separate kernels")
+ap.add_argument("--no-lu-bwd", action="store_true", help="ablation: LULinearPermute's backward as separate kernels")
 ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the default foreach implementation")
 a = ap.parse_args()
 if a.no_train_full:
@@ -28,6 +29,9 @@ if a.no_train_full:
 if a.no_resblock_bwd:
     import normflows_amd
     normflows_amd.config.set_resblock_bwd(False)
+if a.no_lu_bwd:
+    import normflows_amd
+    normflows_amd.config.set_lu_bwd_fused(False)
 if a.no_matvec2:
     import normflows_amd
     normflows_amd.config.set_lu_matvec2(False)
