@@ -208,7 +208,9 @@ def secondary(model, x):
         res["config_bench"] = {"error": repr(exc)[:200]}
     try:
         model.use_graphs(False)
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+        # torch.optim.Adam with its single-launch implementation (fused=True): the optimizer is PyTorch's either way, the
+        # default for-each path is ~65 launches and 0.5 ms longer per step
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
         steps, ts = 10, []
 
         def one_step():
@@ -234,6 +236,7 @@ def secondary(model, x):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         res["train_step"] = {"workload": "forward_kld + backward + Adam on the benchmark model and batch", "ms_per_step": dt * 1e3,
+                             "optimizer": "torch.optim.Adam(lr=1e-4, fused=True)",
                              "statistic": "mean of 10 back-to-back steps", "ms_median_synchronised": med * 1e3,
                              "ms_min_synchronised": ts[0] * 1e3, "ms_max_synchronised": ts[-1] * 1e3, "steps": steps,
                              "samples_per_s": x.shape[0] / dt, "loss": float(loss.detach()),
