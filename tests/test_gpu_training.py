@@ -638,6 +638,36 @@ def test_resblock_backward_one_pass_kernel(nfa, B, init):
         nfa.ops.resblock_bwd(gh[:100], t[:100], h[:100], W1, W2)        # rows: multiples of 64
 
 
+@pytest.mark.parametrize("blocks,B", [(1, 2048), (3, 1088), (2, 1500), (0, 1024)])
+def test_whole_layer_training_path_other_depths_and_batches(nfa, blocks, B):
+    """The one-launch training forward + one-pass block backward with 1 / 3 / 0 residual blocks (the INIT variant behind the only
+    block; no block at all: the trunk-free fallback) and a batch that is no multiple of 64 (the backward falls back to the
+    separate kernels), against the layer-wise path on the same weights."""
+    from bench import build_c2_model
+    m = build_c2_model(num_layers=2, blocks=blocks, sigma=0.05).to(DEV)
+    torch.manual_seed(blocks)
+    x = 1.2 * torch.randn(B, 64, device=DEV)
+    res = []
+    for full in (True, False):
+        nfa.config.set_train_full(full)
+        for f in m.flows[0::2]:
+            f.prqct.use_fused_train = full
+        xa = x.clone().requires_grad_(True)
+        m.zero_grad()
+        lp = m.log_prob(xa)
+        (-lp.mean()).backward()
+        res.append((lp.detach().clone(), xa.grad.clone(), [p_.grad.clone() for p_ in m.parameters()]))
+    nfa.config.set_train_full(True)
+    for f in m.flows[0::2]:
+        f.prqct.use_fused_train = True
+    (lp_a, gx_a, gp_a), (lp_b, gx_b, gp_b) = res
+    assert _rel(N(lp_a), N(lp_b)) < 2e-5
+    assert_close(N(gx_a), N(gx_b), what="input gradient", rtol=2e-3, atol=2e-5)
+    for (name, _), a, b in zip(m.named_parameters(), gp_a, gp_b):
+        scale = max(float(b.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) < 2e-3 * scale, (name, float((a - b).abs().max()), scale)
+
+
 @pytest.mark.parametrize("B", [65536, 1024, 4096 + 64])
 def test_lu_backward_one_pass_kernel(nfa, B):
     """nf_lu_bwd (LULinearPermute's batch-side backward, D = 64: both row products and both batch reductions in one pass)
