@@ -181,6 +181,24 @@ def main():
     t = timeit(lambda: ops.rqs_fused_train_fwd(x, h2, blob, 0, 2))
     report("nf_rqs_fused_train_fwd (final Linear + coupling) [%.0f TF]" % (2.0 * B * 736 * 128 / t / 1e12), t,
            B * (2 * D * 4 + 128 * 4 + 32 * 24 * 4 + 4))
+    # whole-layer training forward and the one-pass backward kernels (round 2, second half)
+    w0, b0 = torch.randn(128, 32, device=dev) * 0.1, torch.randn(128, device=dev) * 0.1
+    wb = [torch.randn(128, 128, device=dev) * 0.05 for _ in range(4)]
+    bb = [torch.randn(128, device=dev) * 0.1 for _ in range(4)]
+    wfull_t, wpad = torch.zeros(64, 128, device=dev), torch.zeros(32, 24, 128, device=dev)
+    t = timeit(lambda: ops.rqs_fused_pack_all(blob, w0, b0, wb, bb, wf, bf, uw, uh, ud, wfull=wfull_t, wpad=wpad, identity_idx=iidx))
+    report("nf_rqs_fused_pack_all (whole layer's blob + backward weight images) [latency]", t, blob.numel() * 4)
+    t = timeit(lambda: ops.rqs_fused_train_full_fwd(x, blob, 0, 2))
+    report("nf_rqs_fused_train_full_fwd (whole layer forward + saved tensors) [%.0f TF]" % (2.0 * B * 128 * (32 + 4 * 128 + 736) / t / 1e12),
+           t, B * (2 * D * 4 + 5 * 128 * 4 + 32 * 24 * 4 + 4))
+    t = timeit(lambda: ops.resblock_bwd(ga, tt, xa, W1, W2))
+    report("nf_resblock_bwd (block backward: 2 dgrad + 2 wgrad, one pass) [%.0f TF]" % (8.0 * B * 128 * 128 / t / 1e12), t, 4 * B * 128 * 4)
+    gxx = torch.randn(B, D, device=dev)
+    t = timeit(lambda: ops.resblock_bwd(ga, tt, xa, W1, W2, x=x, wfull=wfull_t, gx=gxx))
+    report("nf_resblock_bwd + initial layer [%.0f TF]" % ((8.0 * 128 + 4.0 * 64) * B * 128 / t / 1e12), t, (3 * 128 + 3 * D) * B * 4)
+    uu = torch.randn(B, D, device=dev)
+    t = timeit(lambda: ops.lu_bwd(gy, uu, x, Wm1, Wm2))
+    report("nf_lu_bwd (LU backward, D = 64, one pass) [%.0f TF]" % (8.0 * B * D * D / t / 1e12), t, 4 * B * D * 4)
     z2 = torch.randn(1024, 2, device=dev)
     b = torch.tensor([1.0, 0.0], device=dev)
     s2, t2 = torch.randn(1024, 2, device=dev), torch.randn(1024, 2, device=dev)
