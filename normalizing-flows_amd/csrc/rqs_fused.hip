@@ -31,6 +31,13 @@
 // Arithmetic: 2 * 167 936 MAC per sample (768-row padded final layer) at the fp32 MFMA rate.
 #include "fused_common.hpp"
 
+// Rows the training variants write for the backward are not read again by this launch.
+#ifdef NF_TRAIN_NT_STORES
+#define NF_TRAIN_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define NF_TRAIN_STORE(ptr, val) (*(ptr) = (val))
+#endif
+
 namespace nf {
 
 // ---- pack kernels ---------------------------------------------------------------------------------------------
@@ -522,7 +529,7 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     if (row0 + 8 * it < B)
-                        *reinterpret_cast<f32x4 *>(dst + (size_t)(8 * it) * F_H + 32 * m) = *reinterpret_cast<const f32x4 *>(tww + 8 * it * 36);
+                        NF_TRAIN_STORE(reinterpret_cast<f32x4 *>(dst + (size_t)(8 * it) * F_H + 32 * m), *reinterpret_cast<const f32x4 *>(tww + 8 * it * 36));
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -740,8 +747,8 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
                 for (int it = 0; it < 7; ++it) {
                     const int r = 5 * it + rl;
                     if (l_ < 60 && r < 32 && row0 + r < B)
-                        *reinterpret_cast<f32x4 *>(cond_out + (row0 + r) * (F_NI * 24) + fo + 4 * ql) =
-                            *reinterpret_cast<const f32x4 *>(tw + r * 48 + 4 * ql);
+                        NF_TRAIN_STORE(reinterpret_cast<f32x4 *>(cond_out + (row0 + r) * (F_NI * 24) + fo + 4 * ql),
+                                       *reinterpret_cast<const f32x4 *>(tw + r * 48 + 4 * ql));
                 }
                 __builtin_amdgcn_wave_barrier();
             }
