@@ -147,6 +147,45 @@ def test_c_abi_argument_validation_newer_entry_points(nfa):
     assert lib.nf_realnvp_chain(one, one, one, one, i64(8), i32(2), i32(4), i32(2), i32(0), null) == -22
 
 
+def test_c_abi_argument_validation_training_entry_points(nfa):
+    """The one-pass backward kernels and the whole-layer training forward refuse what they do not implement before any launch."""
+    lib = nfa._lib.lib()
+    i32, i64, f64, vp = ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
+    null, one = vp(0), vp(16)
+    lib.nf_resblock_bwd_scratch_floats.restype = ctypes.c_int64
+    lib.nf_lu_bwd_scratch_floats.restype = ctypes.c_int64
+    per = 128 * 128 + 128
+    assert lib.nf_resblock_bwd_scratch_floats(i64(65536), i32(0)) == 2 * 256 * per
+    assert lib.nf_resblock_bwd_scratch_floats(i64(65536), i32(1)) == 2 * 256 * per + 256 * (128 * 64 + 128)
+    assert lib.nf_resblock_bwd_scratch_floats(i64(192), i32(0)) == 2 * 3 * per           # one workgroup per 64-row tile
+    assert lib.nf_resblock_bwd_scratch_floats(i64(100), i32(0)) == -22
+    assert lib.nf_lu_bwd_scratch_floats(i64(65536)) == 2 * 512 * (64 * 64 + 64) + 64 and lib.nf_lu_bwd_scratch_floats(i64(65)) == -22
+
+    def rb(B=128, H=128, D=64, gh=one, gh_in=one, x=null, wfull=null, gx=null, dw0=null, db0=null, cmap=null, nc=0):
+        return lib.nf_resblock_bwd(gh, one, one, one, one, gh_in, one, one, one, one, x, wfull, gx, dw0, db0, cmap, i32(nc), one,
+                                   i64(B), i32(H), i32(D), null)
+    assert rb(B=100) == -95 and rb(H=64) == -95 and rb(B=0) == -95        # 64-row tiles, hidden 128
+    assert rb(gh=null) == -14 and rb(gh_in=null) == -14                    # without the initial layer gh_in is an output
+    assert rb(x=one) == -14 and rb(x=one, wfull=one, gx=one, dw0=one, db0=one, D=32) == -95
+    assert rb(x=one, wfull=one, gx=one, dw0=one, db0=one, cmap=one, nc=65) == -22
+    assert rb(gh=vp(20)) == -22                                            # 16-byte aligned rows
+
+    def lu(B=128, D=64, gy=one, gx=one):
+        return lib.nf_lu_bwd(gy, one, one, one, one, gx, one, one, one, one, i64(B), i32(D), null)
+    assert lu(B=100) == -95 and lu(D=32) == -95 and lu(gy=null) == -14 and lu(gx=vp(24)) == -22
+
+    def full(B=128, D=64, H=128, nb=2, K=8, x=one, acc=1, parity=0):
+        return lib.nf_rqs_fused_train_full_fwd(x, one, one, one, one, one, i32(parity), i64(B), i32(D), i32(H), i32(nb), i32(K),
+                                               f64(3.0), f64(1e-3), f64(1e-3), f64(1e-3), i32(acc), null)
+    assert full(D=32) == -95 and full(H=64) == -95 and full(K=4) == -95 and full(nb=17) == -95
+    assert full(parity=2) == -22 and full(acc=7) == -22 and full(x=null) == -14 and full(B=0) == 0
+
+    def pack(wfull=null, wpad=null, iidx=null, K=8, w0=one):
+        return lib.nf_rqs_fused_pack_all(one, w0, one, null, null, one, one, one, one, one, i32(128), i32(0), i32(K), f64(3.0),
+                                         f64(1e-3), f64(1e-3), f64(1e-3), wfull, wpad, iidx, null)
+    assert pack(K=16) == -95 and pack(w0=null) == -14 and pack(wfull=one) == -14 and pack(wfull=one, wpad=one) == -14
+
+
 def test_masks_bit_exact(nfa):
     m = nfa.utils.create_alternating_binary_mask(7, even=False)
     assert m.dtype == torch.uint8 and m.tolist() == [0, 1, 0, 1, 0, 1, 0]
