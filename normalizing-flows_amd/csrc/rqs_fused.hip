@@ -518,6 +518,21 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
             const float *tww = tw + rl * 36 + 4 * cl;
             const int64_t row0 = (int64_t)blockIdx.x * F_ROWS + wid * 32 + rl;
             float *dst = act_out + ((size_t)t * (size_t)B + row0) * F_H + 4 * cl;
+#ifdef NF_TRAIN_ACT_DIRECT      // ablation: 16-byte pieces straight from the C-layout registers (32 bytes per row and instruction)
+            {
+                const int64_t rowd = (int64_t)blockIdx.x * F_ROWS + wid * 32 + (l_ & 31);
+                float *dd = act_out + ((size_t)t * (size_t)B + rowd) * F_H + 4 * (l_ >> 5);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const f32x16 &V = m == 0 ? V0 : (m == 1 ? V1 : (m == 2 ? V2 : V3));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (rowd < B)
+                            NF_TRAIN_STORE(reinterpret_cast<f32x4 *>(dd + 32 * m + 8 * q), (f32x4{V[4 * q], V[4 * q + 1], V[4 * q + 2], V[4 * q + 3]}));
+                }
+                return;
+            }
+#endif
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const f32x16 &V = m == 0 ? V0 : (m == 1 ? V1 : (m == 2 ? V2 : V3));
