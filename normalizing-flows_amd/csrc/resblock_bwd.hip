@@ -132,6 +132,9 @@ resblock_bwd_kernel(BlockBwdArgs a) {
     float bs2a = 0.f, bs2b = 0.f, bs1a = 0.f, bs1b = 0.f, bs0 = 0.f;
     int tcount = 0;
     BB_T(7);
+#ifdef NF_BB_TRACE
+    if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) a.trace[6] = clock64();
+#endif
     BB_BARRIER_ALL();
     tcount = 1;
 
@@ -331,6 +334,9 @@ resblock_bwd_kernel(BlockBwdArgs a) {
     }
 
     BB_T(0);
+#ifdef NF_BB_TRACE
+    if (a.trace && blockIdx.x == 0 && threadIdx.x == 0) { a.trace[5] = clock64(); a.trace[4] = wall_clock64(); }
+#endif
     // ---- partial tiles: [problem][workgroup][128 * 128 + 128] ----
     constexpr int64_t nW = BB_H * BB_H, stride = nW + BB_H;
     float *o2 = a.part + (int64_t)blockIdx.x * stride, *o1 = a.part + ((int64_t)grid + blockIdx.x) * stride;

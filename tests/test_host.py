@@ -464,3 +464,19 @@ def test_fused_kernels_have_no_register_spills(nfa):
                 assert d["sgpr_spill_count"] <= (0 if strict else 4), (name, d)
                 assert d["vgpr_count"] <= 256
     assert seen == 42, seen    # exact fp32: 4 x {4, 8, 16 bins} x {128, 64, 32 hidden units} + the two training variants; 4 split-bf16
+
+
+def test_one_pass_backward_kernels_use_no_scratch(nfa):
+    """The one-pass backward kernels keep their weight slices and accumulators in registers: a spill reload would wait for every
+    LDS-DMA in flight (vmcnt retires in order), which is what made the first INIT variant of nf_resblock_bwd twice as slow."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as kr
+    objdir = os.path.join(ROOT, "normalizing-flows_amd", "lib", "obj")
+    seen = 0
+    for obj, tag in (("resblock_bwd.o", "resblock_bwd_kernel"), ("lu_bwd.o", "lu_bwd_kernel")):
+        for name, d in kr.resources(os.path.join(objdir, obj)).items():
+            if tag in name:
+                seen += 1
+                assert d["vgpr_spill_count"] == 0 and d["private_segment_fixed_size"] == 0, (name, d)
+    assert seen == 3, seen
+

@@ -20,7 +20,8 @@ for init in (False, True):
         torch.cuda.synchronize()
     v = buf.cpu().tolist()
     t0 = v[7]
-    print("init", init)
+    print("init", init, "| shader clock during the tile loop: %.0f MHz (clock64 ticks per 100 MHz wall-clock tick x 100)"
+          % (100.0 * (v[5] - v[6]) / max(v[4] - v[7], 1)))
     for tc in range(1, 6):
         row = v[tc * 12: tc * 12 + 12]
         print("  tile %d: " % tc + "  ".join("%s %.2f" % (names[i], (row[i] - t0) / 100.0) for i in (0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11) if row[i]))
