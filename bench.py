@@ -353,6 +353,14 @@ def main():
                                    "traffic_source": tr_src,
                                    "flop_per_launch": fl, "avg_launch_ms": chain_ms, "layer_pairs_per_launch": npairs,
                                    "hbm_algorithmic_bytes_per_launch": (2 * DIM * 4 + 8) * args.batch}
+                try:        # extra, not part of the contract's fields: the clock the MFMA pipe actually runs at under load
+                    from normflows_amd import ops as _ops
+                    # a 5 ms burst of back-to-back fp32 MFMAs on every SIMD (the length of one chain launch) right after the
+                    # timed region: the clock rises with the length of the burst (2.18 GHz at 2 ms, 2.38 GHz at 90 ms measured),
+                    # the guide's 157.3 TFLOP/s assumes 2.4 GHz
+                    out["roofline"]["shader_clock_mhz_mfma_probe_5ms"] = _ops.mfma_clock_mhz(dev, 6000)
+                except Exception as exc:   # noqa: BLE001
+                    out["roofline"]["shader_clock_mhz_mfma_probe_5ms"] = repr(exc)[:100]
         if not args.no_breakdown:
             # secondary (SURVEY.md 8d reports both directions): generative pass = every layer's forward + log_q
             g = torch.Generator().manual_seed(4321)

@@ -41,6 +41,9 @@ enum { NF_RQS_DENSITY = 0, NF_RQS_SAMPLE_IDENTITY = 1, NF_RQS_SAMPLE_TRANSFORM =
 /* Library identification / diagnostics. */
 const char *nf_version(void);
 const char *nf_strerror(int code);
+/* Measurement aid (bench.py): shader clock under fp32-MFMA load.  A chip-filling launch issues iters x 8 independent
+ * v_mfma_f32_32x32x2_f32 per wave; out2_u64[0] = shader cycles, [1] = ticks of the 100 MHz wall clock around them. */
+int nf_mfma_clock_probe(void *out2_u64, void *sink_f32, int iters, nf_stream_t stream);
 /* Largest number of spline bins the compiled kernels accept. */
 int nf_max_bins(void);
 

@@ -1,5 +1,6 @@
-// capi.hip -- library identification and error strings of libnf_mi355x.so.
+// capi.hip -- library identification, error strings and the MFMA clock probe of libnf_mi355x.so.
 #include "common.hpp"
+#include "fused_common.hpp"
 
 extern "C" const char *nf_version(void) { return "nf_mi355x 0.1.0 (gfx950)"; }
 
@@ -15,4 +16,37 @@ extern "C" const char *nf_strerror(int code) {
         case NF_ENOTSUP: return "shape / dtype not supported by this build";
         default: return "unknown error code";
     }
+}
+
+// Shader clock under fp32-MFMA load: every wave of a chip-filling launch issues `iters` x 8 independent
+// v_mfma_f32_32x32x2_f32; wave 0 of workgroup 0 brackets them with the shader cycle counter (clock64) and the 100 MHz wall
+// clock.  out[0] = shader cycles, out[1] = wall ticks: MHz = 100 * out[0] / out[1].  The guide's fp32 MFMA peak (157.3 TFLOP/s)
+// assumes 2.4 GHz; the roofline fractions in bench.py are quoted against that peak, this probe says what the pipe can deliver.
+namespace nf {
+__global__ void __launch_bounds__(256) mfma_clock_probe_kernel(unsigned long long *out, float *sink, int iters) {
+    f32x16 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = f32x16{0};
+    float a = 1.0f + threadIdx.x * 1e-6f, b = 1.0f - threadIdx.x * 1e-6f;
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q], 0, 0, 0);
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += acc[q][0];
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    if (s == 12345.678f) sink[0] = s;            // keeps the chain alive
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; }
+}
+}  // namespace nf
+
+extern "C" int nf_mfma_clock_probe(void *out2_u64, void *sink_f32, int iters, nf_stream_t stream) {
+    if (!out2_u64 || !sink_f32) return NF_EFAULT;
+    if (iters < 1 || iters > (1 << 20)) return NF_EINVAL;
+    hipLaunchKernelGGL(nf::mfma_clock_probe_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, (unsigned long long *)out2_u64,
+                       (float *)sink_f32, iters);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
 }

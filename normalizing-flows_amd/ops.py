@@ -1026,6 +1026,15 @@ def linear_wgrad_pair(dy0, x0, dy1, x1, relu_x=False):
     return w0.view(M, N), b0, w1.view(M, N), b1
 
 
+def mfma_clock_mhz(device, iters=20000):
+    """Shader clock (MHz) under fp32-MFMA load (nf_mfma_clock_probe): what the matrix pipe runs at while a kernel keeps it busy."""
+    out = torch.zeros(2, dtype=torch.int64, device=device)
+    sink = torch.zeros(1, dtype=torch.float32, device=device)
+    L.check(L.lib().nf_mfma_clock_probe(ptr(out), ptr(sink), i32(iters), L.stream()), "nf_mfma_clock_probe")
+    c, w = out.tolist()
+    return 100.0 * c / max(w, 1)
+
+
 def lu_bwd(gy, u, x, Lm, Up):
     """(gx, dL, db, dUp) of LULinearPermute's batch side in the density direction, D = 64, one pass over the rows (nf_lu_bwd)."""
     L.require_device(gy, u, x, Lm, Up)

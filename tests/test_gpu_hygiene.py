@@ -286,3 +286,11 @@ def test_rccl_path_on_one_rank(nfa, tmp_path):
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
     assert "NCCL_OK nccl" in out.stdout
+
+
+def test_mfma_clock_probe_reports_a_plausible_clock(nfa):
+    """nf_mfma_clock_probe (bench.py's extra roofline field): between 1 and 2.6 GHz, and repeatable to a few per cent."""
+    a = nfa.ops.mfma_clock_mhz(DEV)
+    b = nfa.ops.mfma_clock_mhz(DEV)
+    assert 1000.0 < a < 2600.0 and 1000.0 < b < 2600.0, (a, b)
+    assert abs(a - b) < 0.1 * a, (a, b)
