@@ -218,6 +218,11 @@ int nf_rqs_fused_pack_all(void *wpack, const void *w_init, const void *b_init, c
 int nf_rqs_fused_train_full_fwd(const void *x, void *y, void *logdet, void *cond_out, void *act_out, const void *wpack,
                                 int mask_parity, int64_t B, int D, int hidden, int num_blocks, int K, double tail_bound,
                                 double min_bin_width, double min_bin_height, double min_derivative, int acc, nf_stream_t stream);
+/* nf_rqs_fused_pack_all for n_layers layers of one shape in ONE launch (a training step re-packs every layer once).  table
+ * (device memory): n_layers rows of 11 + 4 num_blocks pointers -- wpack, w_init, b_init, w_final, b_final, uw, uh, ud, wfull, wpad,
+ * identity_idx (the last three NULL together or not at all), the 2 num_blocks hidden weights, the 2 num_blocks hidden biases. */
+int nf_rqs_fused_pack_all_multi(const void *table, int n_layers, int hidden, int num_blocks, int K, double tail_bound,
+                                double min_bin_width, double min_bin_height, double min_derivative, nf_stream_t stream);
 /* Backward of the density-direction coupling transform (nf_rqs_coupling_bwd, mode NF_RQS_DENSITY) on cond / grad_cond rows
  * of 24 floats per transform feature (the layout above; 16-byte aligned).  float32, 8 bins, linear tails. */
 int nf_rqs_coupling_bwd_p24(const void *x, const void *grad_y, const void *grad_logdet, const void *cond24, const void *uw,
@@ -575,6 +580,9 @@ int nf_rows_matvec2(const void *x, const void *W1, const void *W2, const void *b
  *   cotangent gld (B floats, summed inside the launch; NULL = none), times `sign`. */
 int nf_lu_factors(const int64_t *perm, const void *lower_entries, const void *upper_entries,
                   const void *unconstrained_upper_diag, double eps, void *out, int D, nf_stream_t stream);
+/* nf_lu_factors for n_layers layers of one width in ONE launch; table (device memory): n_layers rows of 5 pointers -- perm,
+ * lower_entries, upper_entries, unconstrained_upper_diag, out. */
+int nf_lu_factors_multi(const void *table, int n_layers, double eps, int D, nf_stream_t stream);
 int nf_lu_param_grads(const void *gL, const void *gU, const int64_t *perm, const void *gld, int64_t B,
                       const void *unconstrained_upper_diag, double eps, double sign, void *g_lower, void *g_upper, void *g_udiag,
                       int D, nf_stream_t stream);

@@ -181,7 +181,7 @@ class LULinearPermuteFn(torch.autograd.Function):
     """LULinearPermute (mixing.py:535-563).  direction 0 = .inverse (density), 1 = .forward (sample)."""
 
     @staticmethod
-    def forward(ctx, x, perm, lower_entries, upper_entries, udiag_raw, bias, eps, direction, ld_acc=None, acc=1):
+    def forward(ctx, x, perm, lower_entries, upper_entries, udiag_raw, bias, eps, direction, ld_acc=None, acc=1, factors_out=None):
         D = x.shape[1]
         ctx.acc, ctx.has_acc = acc, ld_acc is not None
         if ld_acc is not None:
@@ -190,8 +190,11 @@ class LULinearPermuteFn(torch.autograd.Function):
             # density direction on the fp32-MFMA row mat-vec kernel: u = U x[perm] (kept for the backward), y = L u + b with
             # the constant log-det in the same launch -- two 13 us launches against 64 us for the LDS-tile kernel
             with torch.no_grad():
-                Lm, Um, Up, diag, lad, LT, UpT = ops.lu_factors(perm, lower_entries.detach(), upper_entries.detach(),
-                                                                udiag_raw.detach(), eps=eps)          # one launch (nf_lu_factors)
+                if factors_out is not None:    # assembled for every layer of the model by one launch (_prepack.py)
+                    Lm, Um, Up, diag, lad, LT, UpT = ops.lu_factors_views(factors_out, D)
+                else:
+                    Lm, Um, Up, diag, lad, LT, UpT = ops.lu_factors(perm, lower_entries.detach(), upper_entries.detach(),
+                                                                    udiag_raw.detach(), eps=eps)      # one launch (nf_lu_factors)
                 # u = U x[perm] (kept for the backward) and y = L u + b with the constant log-det: one launch (nf_rows_matvec2)
                 from . import config
                 lacc = None if ld_acc is None else (L.LD_ADD if acc > 0 else L.LD_SUB)
@@ -230,7 +233,7 @@ class LULinearPermuteFn(torch.autograd.Function):
                 gx, gL, g_bias, gUx = ops.lu_bwd(gy, u_saved, x, Lm, Up)
                 g_lower, g_upper, g_udiag = ops.lu_param_grads(gL, gUx, gld, udiag_raw.detach(), lower_entries.numel(),
                                                                eps=ctx.eps, sign=1.0, perm=perm)
-                return gx, None, g_lower, g_upper, g_udiag, g_bias, None, None, g_acc, None
+                return gx, None, g_lower, g_upper, g_udiag, g_bias, None, None, g_acc, None, None
             if config.lu_matvec2:
                 gu, gx, _ = ops.rows_matvec2(gy, LT, UpT)   # d/du = L^T gy, d/dx = P (U^T gu): one launch
             else:
@@ -246,7 +249,7 @@ class LULinearPermuteFn(torch.autograd.Function):
                 gUx, _ = _batch_outer(gu, x)
             g_lower, g_upper, g_udiag = ops.lu_param_grads(gL, gUx, gld, udiag_raw.detach(), lower_entries.numel(),
                                                            eps=ctx.eps, sign=1.0, perm=perm)
-            return gx, None, g_lower, g_upper, g_udiag, g_bias, None, None, g_acc, None
+            return gx, None, g_lower, g_upper, g_udiag, g_bias, None, None, g_acc, None, None
         li, ui = _tri_indices(D_, x.device)
         if fac is not None:
             Lm, Um, diag, Up_saved = fac[:4]
@@ -299,7 +302,7 @@ class LULinearPermuteFn(torch.autograd.Function):
         g_lower = gL[li[0], li[1]]
         g_upper = gU[ui[0], ui[1]]
         g_udiag = gdiag * sig
-        return gx, None, g_lower, g_upper, g_udiag, g_bias, None, None, g_acc, None
+        return gx, None, g_lower, g_upper, g_udiag, g_bias, None, None, g_acc, None, None
 
 
 class DiagGaussianLogProbFn(torch.autograd.Function):
@@ -389,8 +392,9 @@ class CouplingTrainFn(torch.autograd.Function):
         fk = dict(tail_bound=kw["tail_bound"], min_bin_width=kw["min_bin_width"], min_bin_height=kw["min_bin_height"],
                   min_derivative=kw["min_derivative"])
         # the same launch leaves wfull / wpad (the zero-padded weight images of the backward's products) current
-        ops.rqs_fused_pack_all(blob, w0.detach(), b0.detach(), wb, bb, wf.detach(), bf.detach(), uw.detach(), uh.detach(),
-                               ud.detach(), wfull=wfull, wpad=wpad, identity_idx=iidx, **fk)
+        if not kw.get("prepacked"):
+            ops.rqs_fused_pack_all(blob, w0.detach(), b0.detach(), wb, bb, wf.detach(), bf.detach(), uw.detach(), uh.detach(),
+                                   ud.detach(), wfull=wfull, wpad=wpad, identity_idx=iidx, **fk)
         y, ld, cond24, acts = ops.rqs_fused_train_full_fwd(x, blob, parity, nb, logdet=ld_acc,
                                                            acc=None if ld_acc is None else (L.LD_ADD if acc > 0 else L.LD_SUB), **fk)
         if ld_acc is not None:

@@ -85,6 +85,15 @@ def set_lu_bwd_fused(mode=True):
     lu_bwd_fused = bool(mode)
 
 
+# Training: every eligible layer's weights packed by ONE launch per kind at the start of a differentiable density pass (_prepack.py).
+train_prepack = True
+
+
+def set_train_prepack(mode=True):
+    global train_prepack
+    train_prepack = bool(mode)
+
+
 def set_fused_chain(mode=True):
     global fused_chain
     fused_chain = bool(mode)

@@ -15,6 +15,7 @@ Differences that are deliberate (MI355X-first):
 import torch
 from torch import nn
 
+from . import _prepack
 from .flows.base import run_flow
 from .flows.mixing import LULinearPermute
 from .flows.neural_spline import CoupledRationalQuadraticSpline
@@ -150,6 +151,16 @@ _realnvp_cache = {}
 
 
 def run_chain(flows, z, inverse, ld, acc):
+    """_run_chain_impl behind the training step's one-launch weight packing (_prepack.py): a differentiable density pass first
+    packs every eligible layer's weights / LU factors with one launch per kind; the layers then skip their own pack launches."""
+    token = _prepack.begin(flows, z, inverse)
+    try:
+        return _run_chain_impl(flows, z, inverse, ld, acc)
+    finally:
+        _prepack.end(token)
+
+
+def _run_chain_impl(flows, z, inverse, ld, acc):
     """Run a list of flows in order (inverse=False) or reversed with .inverse (inverse=True), folding log-dets into
     `ld`.  Adjacent [CoupledRationalQuadraticSpline, LULinearPermute] pairs of the supported shape are fused
     (csrc/rqs_fused.hip) and consecutive fused pairs of one shape run as ONE persistent launch; everything else goes

@@ -87,10 +87,9 @@ lu_compose_kernel(const int64_t *__restrict__ perm, const float *__restrict__ lo
 // indexing launches each.  nf_lu_factors: out = L (D x D, unit diagonal) | U (D x D, diagonal softplus(u) + eps) | Up (D x D,
 // Up[:, perm[j]] = U[:, j], so that Up x = U x[perm]) | diag (D) | log|det| = sum log diag (1) | L^T (D x D) | Up^T (D x D)
 // (the backward's two row mat-vecs take the transposes: emitted here instead of two transpose-copy launches per layer).
-__global__ void __launch_bounds__(256)
-lu_factors_kernel(const int64_t *__restrict__ perm, const float *__restrict__ lower_entries,
-                  const float *__restrict__ upper_entries, const float *__restrict__ udiag_raw, float eps,
-                  float *__restrict__ out, int D) {
+__device__ __forceinline__ void lu_factors_body(const int64_t *__restrict__ perm, const float *__restrict__ lower_entries,
+                                                const float *__restrict__ upper_entries, const float *__restrict__ udiag_raw,
+                                                float eps, float *__restrict__ out, int D) {
     __shared__ float sred[16];
     const int N = D * D, tid = threadIdx.x;
     float *Lm = out, *Um = out + N, *Up = out + 2 * N, *dg = out + 3 * N, *lad = dg + D, *LT = lad + 1, *UpT = LT + N;
@@ -115,6 +114,21 @@ lu_factors_kernel(const int64_t *__restrict__ perm, const float *__restrict__ lo
     }
     const float s = block_sum(part, sred);
     if (tid == 0) *lad = s;
+}
+
+__global__ void __launch_bounds__(256)
+lu_factors_kernel(const int64_t *__restrict__ perm, const float *__restrict__ lower_entries,
+                  const float *__restrict__ upper_entries, const float *__restrict__ udiag_raw, float eps,
+                  float *__restrict__ out, int D) {
+    lu_factors_body(perm, lower_entries, upper_entries, udiag_raw, eps, out, D);
+}
+
+// n layers in one launch (blockIdx.y = layer); table: n rows of 5 device pointers perm, lower, upper, udiag, out
+__global__ void __launch_bounds__(256)
+lu_factors_multi_kernel(const void *const *__restrict__ table, float eps, int D) {
+    const void *const *row = table + (size_t)blockIdx.y * 5;
+    lu_factors_body((const int64_t *)row[0], (const float *)row[1], (const float *)row[2], (const float *)row[3], eps,
+                    (float *)row[4], D);
 }
 
 // Parameter gradients from the dense factor gradients gL, gU (D x D; gU's columns taken through perm when given) and the
@@ -352,6 +366,16 @@ extern "C" int nf_lu_factors(const int64_t *perm, const void *lower_entries, con
     if (!perm || !unconstrained_upper_diag || !out || (D > 1 && (!lower_entries || !upper_entries))) return NF_EFAULT;
     hipLaunchKernelGGL(lu_factors_kernel, dim3((D * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, perm, (const float *)lower_entries,
                        (const float *)upper_entries, (const float *)unconstrained_upper_diag, (float)eps, (float *)out, D);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int nf_lu_factors_multi(const void *table, int n_layers, double eps, int D, nf_stream_t stream) {
+    if (D < 2 || n_layers < 0 || n_layers > 65535) return NF_EINVAL;
+    if (n_layers == 0) return NF_OK;
+    if (!table) return NF_EFAULT;
+    hipLaunchKernelGGL(lu_factors_multi_kernel, dim3((D * D + 255) / 256, n_layers), dim3(256), 0, (hipStream_t)stream,
+                       (const void *const *)table, (float)eps, D);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

@@ -823,7 +823,8 @@ struct PackAllArgs {
     float *wfull, *wpad;
     const int64_t *iidx;
 };
-__global__ void pack_all_kernel(PackAllArgs a, float *__restrict__ blob, float wh_scale, RqsParams<float> p) {
+__device__ __forceinline__ void pack_all_body(const PackAllArgs &a, float *__restrict__ blob, float wh_scale,
+                                              const RqsParams<float> &p) {
     FusedLayout lay;
     lay.nblk = a.nblk;
     float *small = blob + F_HDR, *stages = blob + lay.off_stages();
@@ -888,6 +889,32 @@ __global__ void pack_all_kernel(PackAllArgs a, float *__restrict__ blob, float w
     }
 }
 
+__global__ void pack_all_kernel(PackAllArgs a, float *__restrict__ blob, float wh_scale, RqsParams<float> p) {
+    pack_all_body(a, blob, wh_scale, p);
+}
+
+// Every layer of a model in ONE launch (blockIdx.y = layer): the training step re-packs all layers once per step, 32 launches of
+// ~12 us otherwise.  table: per layer NF_PACK_ALL_COLS(num_blocks) device pointers (include/nf_mi355x.h).
+__global__ void pack_all_multi_kernel(const void *const *__restrict__ table, int cols, int nblk, float wh_scale, RqsParams<float> p) {
+    __shared__ PackAllArgs a;
+    __shared__ float *blob;
+    const void *const *row = table + (size_t)blockIdx.y * cols;
+    if (threadIdx.x == 0) {
+        blob = (float *)row[0];
+        a.w_init = (const float *)row[1]; a.b_init = (const float *)row[2];
+        a.w_final = (const float *)row[3]; a.b_final = (const float *)row[4];
+        a.uw = (const float *)row[5]; a.uh = (const float *)row[6]; a.ud = (const float *)row[7];
+        a.wfull = (float *)row[8]; a.wpad = (float *)row[9]; a.iidx = (const int64_t *)row[10];
+        a.nblk = nblk;
+        for (int l = 0; l < 2 * nblk; ++l) {
+            a.w_blk[l] = (const float *)row[11 + l];
+            a.b_blk[l] = (const float *)row[11 + 2 * nblk + l];
+        }
+    }
+    __syncthreads();
+    pack_all_body(a, blob, wh_scale, p);
+}
+
 }  // namespace nf
 
 using namespace nf;
@@ -920,6 +947,25 @@ extern "C" int nf_rqs_fused_pack_all(void *wpack, const void *w_init, const void
     auto p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
                                     min_derivative, 1.0);
     hipLaunchKernelGGL(pack_all_kernel, dim3(16 * (1 + 8 * num_blocks + 24)), dim3(256), 0, (hipStream_t)stream, a, (float *)wpack,
+                       (float)(1.4426950408889634 / sqrt((double)hidden)), p);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// nf_rqs_fused_pack_all for n layers of one shape in ONE launch; table (device): n rows of 11 + 4 num_blocks pointers --
+// wpack, w_init, b_init, w_final, b_final, uw, uh, ud, wfull, wpad, identity_idx, then the 2 num_blocks hidden weights and the
+// 2 num_blocks hidden biases in layer order (wfull / wpad / identity_idx may be NULL together).
+extern "C" int nf_rqs_fused_pack_all_multi(const void *table, int n_layers, int hidden, int num_blocks, int K, double tail_bound,
+                                           double min_bin_width, double min_bin_height, double min_derivative, nf_stream_t stream) {
+    if (hidden != F_H || K != F_K || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
+    if (n_layers < 0 || n_layers > 65535) return NF_EINVAL;
+    if (n_layers == 0) return NF_OK;
+    if (!table) return NF_EFAULT;
+    if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_EINVAL;
+    auto p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
+                                    min_derivative, 1.0);
+    hipLaunchKernelGGL(pack_all_multi_kernel, dim3(16 * (1 + 8 * num_blocks + 24), n_layers), dim3(256), 0, (hipStream_t)stream,
+                       (const void *const *)table, 11 + 4 * num_blocks, num_blocks,
                        (float)(1.4426950408889634 / sqrt((double)hidden)), p);
     NF_CHECK_LAUNCH();
     return NF_OK;

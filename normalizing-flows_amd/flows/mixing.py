@@ -11,6 +11,7 @@ import torch
 from torch import nn
 from torch.nn import init
 
+from .. import _prepack
 from .. import ops
 from ..autograd import LULinearPermuteFn, needs_grad, refuse_grad
 from .base import Flow
@@ -281,9 +282,10 @@ class LULinearPermute(Flow):
             raise ValueError("Dimension 1 in inputs must be of size {}.".format(self.linear.features))
         lin = self.linear
         if needs_grad(z, self):   # training path (autograd.py): same forward kernel, GEMM-based backward
+            fout = self._factors_buffer(z.device) if (inverse and _prepack.take(self)) else None
             y, log_det = LULinearPermuteFn.apply(z, self.permutation._permutation, lin.lower_entries, lin.upper_entries,
                                                  lin.unconstrained_upper_diag, lin.bias, lin.eps, 0 if inverse else 1,
-                                                 ld, 1 if (acc is None or acc > 0) else -1)
+                                                 ld, 1 if (acc is None or acc > 0) else -1, fout)
             return y, log_det            # log_det IS ld (updated in place) when the caller passed its accumulator
         if z.dtype == torch.float32 and z.is_cuda and lin.features <= 64 and self.use_dense:
             # the layer as ONE dense D x D product on fp32 MFMA (nf_lu_compose once per parameter version + nf_rows_matvec_affine):
@@ -302,6 +304,19 @@ class LULinearPermute(Flow):
         return ops.lu_linear_permute(z, self.permutation._permutation, lin.lower_entries.detach(),
                                      lin.upper_entries.detach(), lin.unconstrained_upper_diag.detach(),
                                      lin.bias.detach(), 0 if inverse else 1, eps=lin.eps, logdet=ld, acc=acc)
+
+    def _train_factors_ok(self, z):
+        """The density direction under autograd assembles its factors with nf_lu_factors (LULinearPermuteFn.forward)."""
+        return z.is_cuda and z.dtype == torch.float32 and z.dim() == 2 and 2 <= self.linear.features <= 64 \
+            and z.shape[1] == self.linear.features
+
+    def _factors_buffer(self, device):
+        """(5 D^2 + D + 1) floats owned by the layer: the factor images a multi-layer launch (_prepack.py) writes."""
+        buf = self.__dict__.get("_lu_fbuf")
+        D = self.linear.features
+        if buf is None or buf.device != device:
+            buf = self.__dict__["_lu_fbuf"] = torch.empty(5 * D * D + D + 1, dtype=torch.float32, device=device)
+        return buf
 
     def forward(self, z, context=None):
         return self._apply_kernel(z, False)

@@ -17,6 +17,7 @@ import torch
 from torch import nn
 
 from .. import _lib as L
+from .. import _prepack
 from .. import config as _config
 from .. import ops
 from ..autograd import CouplingDensityFn, CouplingTrainFn, FinalSplineDensityFn, IdentLinearFn, SplineFn, needs_grad
@@ -441,13 +442,28 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
             self.__dict__["_train_wbufs"] = buf
         return buf
 
+    def _train_fused_ok(self, inputs, context, sample):
+        """The benchmark shape under autograd: trunk / whole layer on the fused training kernels."""
+        return (not sample and self.use_fused and self.use_fused_train and inputs.is_cuda and inputs.shape[0] >= 1024
+                and self._fused_eligible(inputs, context) and not self._fused_padded()
+                and self.unconditional_transform is not None and self.num_bins == 8)
+
+    def _train_full_ok(self, inputs, context, sample):
+        """... and the whole layer's forward as one launch (CouplingTrainFn)."""
+        return (self._train_fused_ok(inputs, context, sample) and _config.train_full and inputs.shape[1] == 64
+                and self.transform_net.initial_layer.weight.shape[0] == 128)
+
+    def _train_blob_for(self, inputs):
+        blob = self.__dict__.get("_train_blob")
+        if blob is None or blob.device != inputs.device:
+            blob = self._train_blob = ops.rqs_fused_train_blob(len(self.transform_net.blocks), inputs.device)
+        return blob
+
     # -- training path: same kernels through torch.autograd.Function (autograd.py), split/merge by torch indexing ---
     def _autograd(self, inputs, context, sample, ld, acc):
         kw = self._kernel_kwargs()
         u = self.unconditional_transform
-        if (not sample and self.use_fused and self.use_fused_train and inputs.is_cuda and inputs.shape[0] >= 1024
-                and self._fused_eligible(inputs, context) and not self._fused_padded() and u is not None
-                and self.num_bins == 8):
+        if self._train_fused_ok(inputs, context, sample):
             # the benchmark shape: trunk (initial layer + residual blocks, autograd-tracked), then the final Linear + the
             # coupling transform as ONE launch (FinalSplineDensityFn)
             net = self.transform_net
@@ -455,10 +471,9 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
             wfull, wpad, col_map, wfull_t = self._train_buffers(inputs)
             fkw = dict(tail_bound=float(self.tail_bound), min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
                        min_derivative=self.min_derivative, wh_div=self._wh_div(), col_map=col_map)
-            if _config.train_full and inputs.shape[1] == 64 and net.initial_layer.weight.shape[0] == 128:
-                blob = self.__dict__.get("_train_blob")
-                if blob is None or blob.device != inputs.device:
-                    blob = self._train_blob = ops.rqs_fused_train_blob(len(net.blocks), inputs.device)
+            if self._train_full_ok(inputs, context, sample):
+                blob = self._train_blob_for(inputs)
+                fkw["prepacked"] = _prepack.take(self)      # packed by run_chain's one launch for the whole model
                 blk = [p for b in net.blocks for l in b.linear_layers for p in (l.weight, l.bias)]
                 return CouplingTrainFn.apply(inputs, net.initial_layer.weight, net.initial_layer.bias, net.final_layer.weight,
                                              net.final_layer.bias, u.unnormalized_widths, u.unnormalized_heights,

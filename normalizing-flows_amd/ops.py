@@ -369,10 +369,30 @@ def lu_factors(perm, lower_entries, upper_entries, unconstrained_upper_diag, eps
     rc = L.lib().nf_lu_factors(ptr(perm), ptr(lower_entries.contiguous()), ptr(upper_entries.contiguous()),
                                ptr(unconstrained_upper_diag.contiguous()), f64(eps), ptr(out), i32(D), L.stream())
     L.check(rc, "nf_lu_factors")
+    return lu_factors_views(out, D)
+
+
+def lu_factors_views(out, D):
+    """The seven views (L, U, Up, diag, log|det|, L^T, Up^T) of a (5 D^2 + D + 1) factor buffer written by nf_lu_factors[_multi]."""
     N = D * D
     e = 3 * N + D + 1
     return (out[:N].view(D, D), out[N:2 * N].view(D, D), out[2 * N:3 * N].view(D, D), out[3 * N:3 * N + D], out[3 * N + D:e],
             out[e:e + N].view(D, D), out[e + N:e + 2 * N].view(D, D))
+
+
+def lu_factors_multi(table, n_layers, eps, D):
+    """nf_lu_factors for n_layers layers in one launch; table: (n_layers x 5) int64 device pointers (perm, lower, upper, udiag, out)."""
+    L.require_device(table)
+    L.check(L.lib().nf_lu_factors_multi(ptr(table), i32(n_layers), f64(eps), i32(D), L.stream()), "nf_lu_factors_multi")
+
+
+def rqs_fused_pack_all_multi(table, n_layers, num_blocks, tail_bound=3.0, min_bin_width=1e-3, min_bin_height=1e-3,
+                             min_derivative=1e-3):
+    """nf_rqs_fused_pack_all for n_layers layers in one launch; table: (n_layers x (11 + 4 num_blocks)) int64 device pointers."""
+    L.require_device(table)
+    rc = L.lib().nf_rqs_fused_pack_all_multi(ptr(table), i32(n_layers), i32(128), i32(num_blocks), i32(8), f64(tail_bound),
+                                             f64(min_bin_width), f64(min_bin_height), f64(min_derivative), L.stream())
+    L.check(rc, "nf_rqs_fused_pack_all_multi")
 
 
 def lu_param_grads(gL, gU, gld, unconstrained_upper_diag, n_tri, eps=1e-3, sign=1.0, perm=None):

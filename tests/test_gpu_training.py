@@ -668,6 +668,57 @@ def test_whole_layer_training_path_other_depths_and_batches(nfa, blocks, B):
         assert float((a - b).abs().max()) < 2e-3 * scale, (name, float((a - b).abs().max()), scale)
 
 
+def test_model_level_prepack_gives_identical_steps(nfa):
+    """config.train_prepack (all layers' weights / LU factors packed by one launch per kind at the start of the density pass)
+    against every layer packing for itself: the same loss, gradients and three-step Adam trajectory; a layer called on its
+    own after a model step packs for itself (the token is gone); a model whose layers differ in depth is packed in groups."""
+    import copy
+    from bench import build_c2_model
+    m0 = build_c2_model(num_layers=4, sigma=0.05).to(DEV)
+    x = torch.randn(2048, 64, device=DEV)
+    res = []
+    try:
+        for on in (True, False):
+            nfa.config.set_train_prepack(on)
+            m = copy.deepcopy(m0)
+            opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+            losses = []
+            for _ in range(3):
+                opt.zero_grad(set_to_none=True)
+                loss = m.forward_kld(x)
+                loss.backward()
+                losses.append(float(loss.detach()))
+                g = [p_.grad.clone() for p_ in m.parameters()]
+                opt.step()
+            res.append((losses, g, [p_.detach().clone() for p_ in m.parameters()]))
+        # (the spline backward adds the batch-shared parameters' gradients with atomics: equal to rounding, not bit for bit)
+        assert max(abs(a - b) for a, b in zip(res[0][0], res[1][0])) < 1e-5 * abs(res[1][0][0]), (res[0][0], res[1][0])
+        for k in (1, 2):
+            for a, b in zip(res[0][k], res[1][k]):
+                assert float((a - b).abs().max()) <= 1e-4 * max(float(b.abs().max()), 1e-6)
+        # a layer on its own, after the weights moved: no stale blob
+        nfa.config.set_train_prepack(True)
+        m = copy.deepcopy(m0)
+        m.forward_kld(x).backward()
+        with torch.no_grad():
+            for p_ in m.parameters():
+                p_.add_(0.01 * torch.randn_like(p_))
+        lay = m.flows[0]
+        xa = x.clone().requires_grad_(True)
+        z1, ld1 = lay.inverse(xa)
+        nfa.config.set_train_prepack(False)
+        z2, ld2 = lay.inverse(x.clone().requires_grad_(True))
+        assert torch.equal(z1, z2) and torch.equal(ld1, ld2)
+        lu = m.flows[1]
+        nfa.config.set_train_prepack(True)
+        z3, ld3 = lu.inverse(xa)
+        nfa.config.set_train_prepack(False)
+        z4, ld4 = lu.inverse(xa)
+        assert torch.equal(z3, z4) and torch.equal(ld3, ld4)
+    finally:
+        nfa.config.set_train_prepack(True)
+
+
 @pytest.mark.parametrize("B", [65536, 1024, 4096 + 64])
 def test_lu_backward_one_pass_kernel(nfa, B):
     """nf_lu_bwd (LULinearPermute's batch-side backward, D = 64: both row products and both batch reductions in one pass)
