@@ -184,6 +184,11 @@ def test_c_abi_argument_validation_training_entry_points(nfa):
         return lib.nf_rqs_fused_pack_all(one, w0, one, null, null, one, one, one, one, one, i32(128), i32(0), i32(K), f64(3.0),
                                          f64(1e-3), f64(1e-3), f64(1e-3), wfull, wpad, iidx, null)
     assert pack(K=16) == -95 and pack(w0=null) == -14 and pack(wfull=one) == -14 and pack(wfull=one, wpad=one) == -14
+    pm = lambda n=4, table=one, nb=2, K=8: lib.nf_rqs_fused_pack_all_multi(table, i32(n), i32(128), i32(nb), i32(K), f64(3.0),
+                                                                          f64(1e-3), f64(1e-3), f64(1e-3), null)
+    assert pm(K=4) == -95 and pm(nb=17) == -95 and pm(n=-1) == -22 and pm(table=null) == -14 and pm(n=0, table=null) == 0
+    lm = lambda n=4, table=one, D=64: lib.nf_lu_factors_multi(table, i32(n), f64(1e-3), i32(D), null)
+    assert lm(D=1) == -22 and lm(n=70000) == -22 and lm(table=null) == -14 and lm(n=0, table=null) == 0
 
 
 def test_masks_bit_exact(nfa):
