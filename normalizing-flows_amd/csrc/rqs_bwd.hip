@@ -719,7 +719,13 @@ rqs_coupling_bwd_pipe_kernel(const float *__restrict__ x, const float *__restric
             }
             prm[M] = 0.0f;
             const float xv = bufc[XOFF + s_ * D + col_t], gyv = bufc[XOFF + SPW * D + s_ * D + col_t];
+#ifdef NF_BWD_ABL_NOMATH      // ablation (wrong results): the pass without the spline arithmetic = staging + traffic only
+            float gxv = gyv + gl + xv;
+#pragma unroll
+            for (int k = 0; k < 24; ++k) g[k] = prm[k] * gyv;
+#else
             const float gxv = rqs_regs_bwd<false>(p, xv, prm, gyv, gl, g, inv_div);
+#endif
             if constexpr (CP == 24) {
                 g[M] = 0.0f;
 #pragma unroll
@@ -740,7 +746,13 @@ rqs_coupling_bwd_pipe_kernel(const float *__restrict__ x, const float *__restric
 #pragma unroll
             for (int k = 0; k < 24; ++k) prm[k] = pr[k];
             const float xv = bufc[XOFF + s_ * D + col_i], gyv = bufc[XOFF + SPW * D + s_ * D + col_i];
+#if defined(NF_BWD_ABL_NOMATH) || defined(NF_BWD_ABL_NOIDENT)     // ablation: without the identity half's arithmetic
+            w_gx[s_ * D + col_i] = gyv + xv;
+#pragma unroll
+            for (int k = 0; k < 24; ++k) g[k] = prm[k] * gyv;
+#else
             w_gx[s_ * D + col_i] = rqs_regs_bwd<false>(p, xv, prm, gyv, gl, g, 1.0f);
+#endif
 #pragma unroll
             for (int k = 0; k < M; ++k) racc[k] += g[k];      // a lane keeps its feature for the whole launch: register sums
         }
