@@ -29,59 +29,84 @@ def _table(key_name, rows, device):
     return hit[1]
 
 
+_plans = {}
+
+
+def _nsf_row(c, z):
+    net, u = c.transform_net, c.unconditional_transform
+    _, wpad, _, wfull_t = c._train_buffers(z)
+    lin = [l for blk in net.blocks for l in blk.linear_layers]
+    return [c._train_blob_for(z), net.initial_layer.weight, net.initial_layer.bias, net.final_layer.weight, net.final_layer.bias,
+            u.unnormalized_widths, u.unnormalized_heights, u.unnormalized_derivatives, wfull_t, wpad, c.identity_features] \
+        + [l.weight for l in lin] + [l.bias for l in lin]
+
+
+def _lu_row(f, z):
+    lin = f.linear
+    return [f.permutation._permutation, lin.lower_entries, lin.upper_entries, lin.unconstrained_upper_diag,
+            f._factors_buffer(z.device)]
+
+
+def _sentinels(kind, layer):
+    """Two of the layer's parameters, read from the module: the cached rows are valid while these are the cached objects and
+    still require gradients (.to() / load_state_dict keep the Parameter objects; only re-assigned attributes replace them)."""
+    if kind == "nsf":
+        return layer.transform_net.initial_layer.weight, layer.transform_net.final_layer.bias
+    return layer.linear.lower_entries, layer.linear.unconstrained_upper_diag
+
+
+def _plan(flows, z):
+    """Which layers of `flows` are packed together and the tensors of their table rows: decided once per (model, batch shape,
+    training flags, configuration) -- reading ~1300 module attributes every step costs the host several ms.  Per step only the
+    sentinels are re-read and the cached tensors asked for their (possibly new) data pointers."""
+    from .flows.mixing import LULinearPermute
+    from .flows.neural_spline import CoupledRationalQuadraticSpline
+    groups = {}
+    for f in flows:
+        if isinstance(f, CoupledRationalQuadraticSpline):
+            c = f.prqct
+            if c._train_full_ok(z, None, False) and all(p.requires_grad for p in c.parameters()):
+                key = ("nsf", len(c.transform_net.blocks), float(c.tail_bound), c.min_bin_width, c.min_bin_height, c.min_derivative)
+                groups.setdefault(key, []).append((c, _nsf_row(c, z), _sentinels("nsf", c)))
+        elif isinstance(f, LULinearPermute) and f._train_factors_ok(z) and all(p.requires_grad for p in f.parameters()):
+            groups.setdefault(("lu", f.linear.features, float(f.linear.eps)), []).append((f, _lu_row(f, z), _sentinels("lu", f)))
+    return list(groups.items())
+
+
+def _plan_valid(plan):
+    for key, entries in plan:
+        for layer, _, sen in entries:
+            a, b = _sentinels(key[0], layer)
+            if a is not sen[0] or b is not sen[1] or not a.requires_grad:
+                return False
+    return True
+
+
 def begin(flows, z, inverse):
     """Pack the eligible layers of `flows` for a differentiable density pass over z; returns the token (None: nothing done)."""
     global _current
     if not (_config.train_prepack and inverse and torch.is_grad_enabled() and torch.is_tensor(z) and z.is_cuda and z.dim() == 2
             and z.dtype == torch.float32 and z.shape[0] >= 1024 and _current is None):
         return None
-    from .flows.mixing import LULinearPermute
-    from .flows.neural_spline import CoupledRationalQuadraticSpline
-    nsf, lus = {}, []
-    for f in flows:
-        if isinstance(f, CoupledRationalQuadraticSpline):
-            c = f.prqct
-            if c._train_full_ok(z, None, False) and any(p.requires_grad for p in c.parameters()):
-                nsf.setdefault(len(c.transform_net.blocks), []).append(c)
-        elif isinstance(f, LULinearPermute) and f._train_factors_ok(z) and any(p.requires_grad for p in f.parameters()):
-            lus.append(f)
-    if sum(len(v) for v in nsf.values()) + len(lus) < 2:
+    # the plan depends on what decides the layers' training path: shapes, module flags, configuration
+    sig = (tuple(z.shape), z.device, _config.train_full, len(flows), tuple(f.training for f in flows))
+    hit = _plans.get(id(flows))
+    if hit is None or hit[0] != sig or not _plan_valid(hit[1]):
+        hit = _plans[id(flows)] = (sig, _plan(flows, z))
+    plan = hit[1]
+    if sum(len(es) for _, es in plan) < 2:
         return None
     token = object()
-    dev = z.device
-    for nb, layers in nsf.items():
-        rows, first = [], layers[0]
-        for c in layers:
-            net, u = c.transform_net, c.unconditional_transform
-            _, wpad, _, wfull_t = c._train_buffers(z)
-            blob = c._train_blob_for(z)
-            lin = [l for b in net.blocks for l in b.linear_layers]
-            rows.append([blob.data_ptr(), net.initial_layer.weight.data_ptr(), net.initial_layer.bias.data_ptr(),
-                         net.final_layer.weight.data_ptr(), net.final_layer.bias.data_ptr(), u.unnormalized_widths.data_ptr(),
-                         u.unnormalized_heights.data_ptr(), u.unnormalized_derivatives.data_ptr(), wfull_t.data_ptr(),
-                         wpad.data_ptr(), c.identity_features.data_ptr()] + [l.weight.data_ptr() for l in lin]
-                        + [l.bias.data_ptr() for l in lin])
-        same = all((float(c.tail_bound), c.min_bin_width, c.min_bin_height, c.min_derivative)
-                   == (float(first.tail_bound), first.min_bin_width, first.min_bin_height, first.min_derivative) for c in layers)
-        if not same:
-            continue
-        ops.rqs_fused_pack_all_multi(_table(("nsf", nb, id(flows)), rows, dev), len(layers), nb, tail_bound=float(first.tail_bound),
-                                     min_bin_width=first.min_bin_width, min_bin_height=first.min_bin_height,
-                                     min_derivative=first.min_derivative)
-        for c in layers:
-            c.__dict__["_prepacked"] = token
-    by_shape = {}
-    for f in lus:
-        by_shape.setdefault((f.linear.features, float(f.linear.eps)), []).append(f)
-    for (D, eps), layers in by_shape.items():
-        rows = []
-        for f in layers:
-            lin = f.linear
-            rows.append([f.permutation._permutation.data_ptr(), lin.lower_entries.data_ptr(), lin.upper_entries.data_ptr(),
-                         lin.unconstrained_upper_diag.data_ptr(), f._factors_buffer(dev).data_ptr()])
-        ops.lu_factors_multi(_table(("lu", D, eps, id(flows)), rows, dev), len(layers), eps, D)
-        for f in layers:
-            f.__dict__["_prepacked"] = token
+    for key, entries in plan:
+        rows = [[t.data_ptr() for t in row] for _, row, _ in entries]
+        table = _table((key, id(flows)), rows, z.device)
+        if key[0] == "nsf":
+            ops.rqs_fused_pack_all_multi(table, len(entries), key[1], tail_bound=key[2], min_bin_width=key[3], min_bin_height=key[4],
+                                         min_derivative=key[5])
+        else:
+            ops.lu_factors_multi(table, len(entries), key[2], key[1])
+        for layer, _, _ in entries:
+            layer.__dict__["_prepacked"] = token
     _current = token
     return token
 
