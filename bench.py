@@ -356,8 +356,8 @@ def main():
                 try:        # extra, not part of the contract's fields: the clock the MFMA pipe actually runs at under load
                     from normflows_amd import ops as _ops
                     # a 5 ms burst of back-to-back fp32 MFMAs on every SIMD (the length of one chain launch) right after the
-                    # timed region: the clock rises with the length of the burst (2.18 GHz at 2 ms, 2.38 GHz at 90 ms measured),
-                    # the guide's 157.3 TFLOP/s assumes 2.4 GHz
+                    # timed region, i.e. on a warm chip: ~2.4 GHz, the clock the guide's 157.3 TFLOP/s assumes (from idle the
+                    # same burst runs at 2.2 GHz: isolated micro-benchmarks see up to 10 % less MFMA rate than a sustained run)
                     out["roofline"]["shader_clock_mhz_mfma_probe_5ms"] = _ops.mfma_clock_mhz(dev, 6000)
                 except Exception as exc:   # noqa: BLE001
                     out["roofline"]["shader_clock_mhz_mfma_probe_5ms"] = repr(exc)[:100]
