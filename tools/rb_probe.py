@@ -1,3 +1,7 @@
+"""Stand-alone time of nf_rows_block (residual block forward / backward in one launch).  With NF_MI355X_LIB pointing at a build
+with -DNF_RB_ABL_COALESCED (tools/build_variant.py rbcoal "-DNF_RB_ABL_COALESCED" rows_linear.hip) every global access of a tile
+is issued as consecutive 16-byte pieces per lane (wrong results): measured 62 / 67 us -> 60 / 62 us, i.e. the kernel is not bound by
+its per-lane-row access pattern."""
 import sys, torch
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
