@@ -31,8 +31,9 @@
 // Arithmetic: 2 * 167 936 MAC per sample (768-row padded final layer) at the fp32 MFMA rate.
 #include "fused_common.hpp"
 
-// Rows the training variants write for the backward are not read again by this launch.
-#ifdef NF_TRAIN_NT_STORES
+// Rows the training variants write for the backward (386 MB per launch) are not read again by this launch: non-temporal stores
+// (measured 29.7-29.8 vs 29.9-30.0 ms per training step, three alternating runs; -DNF_TRAIN_TEMPORAL_STORES: ordinary stores).
+#ifndef NF_TRAIN_TEMPORAL_STORES
 #define NF_TRAIN_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 #else
 #define NF_TRAIN_STORE(ptr, val) (*(ptr) = (val))
