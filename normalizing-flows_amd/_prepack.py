@@ -7,6 +7,8 @@ LULinearPermute's factors (nf_lu_factors) once: 2 x 32 launches of 5-12 us in fr
 is handed a token; a layer whose token is the current one skips its own pack launch.  The token dies with the call (end()), so a
 layer used outside run_chain, or after an exception, packs itself as before.
 """
+import weakref
+
 import torch
 
 from . import config as _config
@@ -91,8 +93,11 @@ def begin(flows, z, inverse):
     # the plan depends on what decides the layers' training path: shapes, module flags, configuration
     sig = (tuple(z.shape), z.device, _config.train_full, len(flows), tuple(f.training for f in flows))
     hit = _plans.get(id(flows))
-    if hit is None or hit[0] != sig or not _plan_valid(hit[1]):
-        hit = _plans[id(flows)] = (sig, _plan(flows, z))
+    if hit is None or hit[2]() is not flows or hit[0] != sig or not _plan_valid(hit[1]):
+        if len(_plans) > 16:        # models come and go (tests, sweeps): do not keep their layers alive through old plans
+            _plans.clear()
+            _tables.clear()
+        hit = _plans[id(flows)] = (sig, _plan(flows, z), weakref.ref(flows))
     plan = hit[1]
     if sum(len(es) for _, es in plan) < 2:
         return None
