@@ -382,6 +382,11 @@ int nf_linear_wgrad_pair(const void *dY0, const void *X0, void *dW0, void *db0, 
 int64_t nf_lu_bwd_scratch_floats(int64_t B);
 int nf_lu_bwd(const void *gy, const void *u, const void *x, const void *Lm, const void *Up, void *gx, void *dL, void *db, void *dUp,
               void *scratch, int64_t B, int D, nf_stream_t stream);
+/* ... and its forward on the same tiles: u (B, D) = U x[perm] per row (kept for the backward), y = L u + bias, logdet (op)=
+ * ld_sign * *ld_const (acc = NF_LD_WRITE / ADD / SUB; logdet may be NULL).  UpT / LT: the transposed factor images of
+ * nf_lu_factors.  D = 64, B a multiple of 64. */
+int nf_lu_fwd(const void *x, const void *UpT, const void *LT, const void *bias, void *u, void *y, void *logdet,
+              const void *ld_const, double ld_sign, int acc, int64_t B, int D, nf_stream_t stream);
 int64_t nf_resblock_bwd_scratch_floats(int64_t B, int with_init);
 int nf_resblock_bwd(const void *gh, const void *t, const void *h_in, const void *W1, const void *W2, void *gh_in, void *dW1,
                     void *db1, void *dW2, void *db2, const void *x, const void *wfull, void *gx, void *dW0, void *db0,

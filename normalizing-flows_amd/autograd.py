@@ -198,7 +198,9 @@ class LULinearPermuteFn(torch.autograd.Function):
                 # u = U x[perm] (kept for the backward) and y = L u + b with the constant log-det: one launch (nf_rows_matvec2)
                 from . import config
                 lacc = None if ld_acc is None else (L.LD_ADD if acc > 0 else L.LD_SUB)
-                if config.lu_matvec2:
+                if config.lu_bwd_fused and D == 64 and x.shape[0] % 64 == 0 and x.shape[0] >= 1024:
+                    u, y, ld = ops.lu_fwd(x, UpT, LT, bias.detach(), lad, +1.0, logdet=ld_acc, acc=lacc)   # LDS-DMA tiles (nf_lu_fwd)
+                elif config.lu_matvec2:
                     u, y, ld = ops.rows_matvec2(x, Up, Lm, bias.detach(), lad, +1.0, logdet=ld_acc, acc=lacc)
                 else:
                     u = ops.rows_matvec(x, Up)

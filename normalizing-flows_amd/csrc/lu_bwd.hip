@@ -151,6 +151,97 @@ lu_bwd_kernel(LuBwdArgs a) {
     if (cb == 1 && hh == 0) oU[nW + 32 * rh + i] = 0.0f;       // the second problem has no bias; keep the slot defined
 }
 
+// The density direction's FORWARD on the same tiles (training keeps u for the backward): u = x UpT (= U x[perm] per row),
+// y = u LT + b (= L u + b), logdet (op)= ld_sign * *ld_const.  x tiles by LDS-DMA, both weight slices in registers, u goes to
+// LDS (A operand of the second product) and to HBM; 50 MB of traffic per launch at B = 65 536 = its algorithmic bytes.
+struct LuFwdArgs {
+    const float *x, *UpT, *LT, *bias, *ld_const;
+    float *u, *y, *logdet;
+    float ld_sign;
+    int acc;
+    int64_t B;
+};
+
+__global__ void __launch_bounds__(256, 2)
+lu_fwd_kernel(LuFwdArgs a) {
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    extern __shared__ __attribute__((aligned(16))) float smem_lb[];
+    float *Xt = smem_lb, *Dt = Xt + LB_TILE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rh = wid >> 1, cb = wid & 1;
+    const int grid = gridDim.x;
+    const int64_t ntiles = a.B / LB_R;
+    unsigned goff[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int s = 64 * (wid + 4 * q) + lane, row = s / 17, c = s - 17 * row;
+        goff[q] = (unsigned)((row < LB_R ? row : 0) * LB_D + 4 * (c < 16 ? c : 15));
+    }
+    auto issue = [&](const float *src, float *tile) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_global_load_lds(src + goff[q], (lds_ptr)(tile + 256 * (wid + 4 * q)), 16, 0, 0);
+        if (wid == 0) __builtin_amdgcn_global_load_lds(src + goff[4], (lds_ptr)(tile + 256 * 16), 16, 0, 0);
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < ntiles) issue(a.x + tile * (LB_R * LB_D), Xt);
+    float W1r[32], W2r[32], bv;
+    {
+        const int i = lane & 31, hh = lane >> 5;
+#pragma unroll
+        for (int Q = 0; Q < 8; ++Q)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int k = 8 * Q + 4 * hh + s;
+                W1r[4 * Q + s] = a.UpT[k * LB_D + 32 * cb + i];
+                W2r[4 * Q + s] = a.LT[k * LB_D + 32 * cb + i];
+            }
+        bv = a.bias ? a.bias[32 * cb + i] : 0.0f;
+    }
+    const float ldv = a.logdet ? a.ld_sign * a.ld_const[0] : 0.0f;
+    for (; tile < ntiles; tile += grid) {
+        const bool more = tile + grid < ntiles;
+        LB_BARRIER_ALL();          // x landed; every wave is done with Dt
+        int l_ = lane;
+        asm volatile("" : "+v"(l_));
+        const int i = l_ & 31, hh = l_ >> 5;
+        const int64_t r0 = tile * LB_R + 32 * rh + 4 * hh;
+        {
+            f32x16 C = {0};
+            const float *ap = Xt + (32 * rh + i) * LB_P + 4 * hh;
+#pragma unroll
+            for (int Q = 0; Q < 8; ++Q) {
+                const f32x4 av = *reinterpret_cast<const f32x4 *>(ap + 8 * Q);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) C = MFMA32(av[s], W1r[4 * Q + s], C);
+            }
+            float *up = a.u + r0 * LB_D + 32 * cb + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                Dt[(32 * rh + 8 * (r >> 2) + 4 * hh + (r & 3)) * LB_P + 32 * cb + i] = C[r];
+                up[(8 * (r >> 2) + (r & 3)) * LB_D] = C[r];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // u complete in LDS; every wave is done with Xt
+        if (more) issue(a.x + (tile + grid) * (LB_R * LB_D), Xt);
+        {
+            f32x16 C = {0};
+            const float *ap = Dt + (32 * rh + i) * LB_P + 4 * hh;
+#pragma unroll
+            for (int Q = 0; Q < 8; ++Q) {
+                const f32x4 av = *reinterpret_cast<const f32x4 *>(ap + 8 * Q);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) C = MFMA32(av[s], W2r[4 * Q + s], C);
+            }
+            float *yp = a.y + r0 * LB_D + 32 * cb + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yp[(8 * (r >> 2) + (r & 3)) * LB_D] = C[r] + bv;
+        }
+        if (a.logdet && tid < LB_R) ld_store(a.logdet + tile * LB_R + tid, ldv, a.acc);
+    }
+}
+
 static int lb_grid(int64_t B) {
     const int64_t nt = B / LB_R;
     return (int)(nt < 512 ? nt : 512);
@@ -188,4 +279,20 @@ extern "C" int nf_lu_bwd(const void *gy, const void *u, const void *x, const voi
     float *dummy = (float *)scratch + 2 * grid * stride;
     return wgrad_reduce_launch(a.part, (float *)dL, (float *)db, (int64_t)LB_D * LB_D, LB_D, grid, LB_D, 2, grid * stride,
                                (float *)dUp - (float *)dL, dummy - (float *)db, nullptr, 0, st);
+}
+
+extern "C" int nf_lu_fwd(const void *x, const void *UpT, const void *LT, const void *bias, void *u, void *y, void *logdet,
+                         const void *ld_const, double ld_sign, int acc, int64_t B, int D, nf_stream_t stream) {
+    using namespace nf;
+    if (D != LB_D || B < LB_R || B % LB_R) return NF_ENOTSUP;
+    if (acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
+    if (!x || !UpT || !LT || !u || !y || (logdet && !ld_const)) return NF_EFAULT;
+    if (((uintptr_t)x | (uintptr_t)u | (uintptr_t)y) & 15) return NF_EINVAL;
+    LuFwdArgs a;
+    a.x = (const float *)x; a.UpT = (const float *)UpT; a.LT = (const float *)LT; a.bias = (const float *)bias;
+    a.ld_const = (const float *)ld_const; a.u = (float *)u; a.y = (float *)y; a.logdet = (float *)logdet;
+    a.ld_sign = (float)ld_sign; a.acc = acc; a.B = B;
+    hipLaunchKernelGGL(lu_fwd_kernel, dim3(lb_grid(B)), dim3(256), (size_t)2 * LB_TILE * sizeof(float), (hipStream_t)stream, a);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
 }

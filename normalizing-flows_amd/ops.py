@@ -1055,6 +1055,24 @@ def mfma_clock_mhz(device, iters=20000):
     return 100.0 * c / max(w, 1)
 
 
+def lu_fwd(x, UpT, LT, bias=None, ld_const=None, ld_sign=1.0, logdet=None, acc=None):
+    """(u, y, logdet): u = U x[perm], y = L u + bias per row with the constant log-det, D = 64, LDS-DMA tiles (nf_lu_fwd); the
+    arguments of rows_matvec2 with the TRANSPOSED factor images (UpT, LT of lu_factors)."""
+    L.require_device(x, UpT, LT, bias, ld_const, logdet)
+    x = x.contiguous()
+    B, D = x.shape
+    u, y = torch.empty_like(x), torch.empty_like(x)
+    if ld_const is not None and logdet is None:
+        logdet, acc = torch.empty(B, dtype=x.dtype, device=x.device), L.LD_WRITE
+    elif acc is None:
+        acc = L.LD_ADD
+    rc = L.lib().nf_lu_fwd(ptr(x), ptr(UpT.contiguous()), ptr(LT.contiguous()), ptr(bias), ptr(u), ptr(y),
+                           ptr(logdet if ld_const is not None else None), ptr(ld_const), f64(ld_sign), i32(acc), i64(B), i32(D),
+                           L.stream())
+    L.check(rc, "nf_lu_fwd")
+    return u, y, logdet
+
+
 def lu_bwd(gy, u, x, Lm, Up):
     """(gx, dL, db, dUp) of LULinearPermute's batch side in the density direction, D = 64, one pass over the rows (nf_lu_bwd)."""
     L.require_device(gy, u, x, Lm, Up)

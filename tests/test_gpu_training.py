@@ -735,6 +735,13 @@ def test_lu_backward_one_pass_kernel(nfa, B):
         scale = float(r.abs().max())
         assert float((a.double() - r).abs().max()) < 2e-5 * scale, (nm, float((a.double() - r).abs().max()), scale)
     assert all(torch.equal(a, b) for a, b in zip(out, out2))
+    # the forward on the same tiles (nf_lu_fwd) against nf_rows_matvec2: u, y and the accumulated constant log-det
+    bias, lad = torch.randn(64, device=DEV), torch.tensor([0.37], device=DEV)
+    ld_a, ld_b = torch.ones(B, device=DEV), torch.ones(B, device=DEV)
+    u1, y1, _ = nfa.ops.lu_fwd(x, Up.t().contiguous(), Lm.t().contiguous(), bias, lad, +1.0, logdet=ld_a, acc=nfa._lib.LD_SUB)
+    u2, y2, _ = nfa.ops.rows_matvec2(x, Up, Lm, bias, lad, +1.0, logdet=ld_b, acc=nfa._lib.LD_SUB)
+    for nm, a, b in (("u", u1, u2), ("y", y1, y2), ("ld", ld_a, ld_b)):
+        assert float((a - b).abs().max()) < 1e-5 * max(float(b.abs().max()), 1.0), (nm, float((a - b).abs().max()))
     layer = nfa.flows.LULinearPermute(64).to(DEV)
     with torch.no_grad():
         layer.linear.lower_entries.normal_(0, 0.1)

@@ -173,6 +173,10 @@ def test_c_abi_argument_validation_training_entry_points(nfa):
     def lu(B=128, D=64, gy=one, gx=one):
         return lib.nf_lu_bwd(gy, one, one, one, one, gx, one, one, one, one, i64(B), i32(D), null)
     assert lu(B=100) == -95 and lu(D=32) == -95 and lu(gy=null) == -14 and lu(gx=vp(24)) == -22
+    lf = lambda B=128, D=64, x=one, acc=1, ld=one, ldc=one: lib.nf_lu_fwd(x, one, one, one, one, one, ld, ldc, f64(1.0), i32(acc),
+                                                                          i64(B), i32(D), null)
+    assert lf(B=100) == -95 and lf(D=32) == -95 and lf(acc=5) == -22 and lf(x=null) == -14 and lf(ldc=null) == -14
+    assert lf(x=vp(20)) == -22
 
     def full(B=128, D=64, H=128, nb=2, K=8, x=one, acc=1, parity=0):
         return lib.nf_rqs_fused_train_full_fwd(x, one, one, one, one, one, i32(parity), i64(B), i32(D), i32(H), i32(nb), i32(K),
