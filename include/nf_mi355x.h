@@ -596,20 +596,9 @@ int nf_lu_compose(const int64_t *perm, const void *lower_entries, const void *up
                   nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * One <= 128 x 128 panel of a Linear layer over batch rows on exact-fp32 MFMA with the neighbouring element-wise work
- * folded in -- the conditioner's forward and input-gradient GEMMs of the training path (nets/resnet.py:37-50, :92-104
- * under core.py:87-102), float32:
- *     out[b, j] (op)= post( sum_{k < Kc} pre(x[b, k]) Wp[j][k] + bias[j] ),   j < Nc
- *   pre  = ReLU on load when relu_in;  Wp[j][k] = W[j * ldw + k], or W[k * ldw + j] when trans_w (gx = gy W);
- *   post = zero where mask_src[b, j] <= 0 (ReLU backward through the saved pre-activation), then + residual[b, j];
- *   op   = store, or += when accumulate (K split over several launches).  bias / mask_src / residual may be NULL.
- * x, mask_src, residual, out: row-major with row pitches ldx / ldm / ldr / ldo (floats, multiples of 4, 16-byte aligned
- * origins) so that 128-column panels of wider tensors are addressed in place; Kc, Nc <= 128 (NF_ENOTSUP beyond:
- * callers split wider layers into panels).  out must not alias x.
+ * Training path of the conditioner (nets/resnet.py:37-50 under core.py:87-102), float32.
+ * (nf_rows_linear, round 2's single-panel kernel, was removed in round 3: the library GEMM was faster on every shape.)
  */
-int nf_rows_linear(const void *x, int64_t ldx, const void *W, int64_t ldw, int trans_w, const void *bias,
-                   const void *mask_src, int64_t ldm, const void *residual, int64_t ldr, void *out, int64_t ldo, int64_t B,
-                   int Kc, int Nc, int relu_in, int accumulate, nf_stream_t stream);
 
 /* A whole plain residual block (resnet.py:37-50: x + W2 relu(W1 relu(x) + b1) + b2, H <= 128 columns, float32) or its
  * backward in ONE launch:   out1 = mask1( M1 pre1(in) + c1 ),   out2 = in + mask2( M2 pre2(out1) + c2 )

@@ -6,7 +6,15 @@ LULinearPermute's factors (nf_lu_factors) once: 2 x 32 launches of 5-12 us in fr
 (nf_rqs_fused_pack_all_multi / nf_lu_factors_multi, blockIdx.y = layer) from a cached device table of pointers, and each layer
 is handed a token; a layer whose token is the current one skips its own pack launch.  The token dies with the call (end()), so a
 layer used outside run_chain, or after an exception, packs itself as before.
+
+State: the plan of a model (which layers, which tensors, the device pointer tables) lives in a WeakKeyDictionary keyed by the
+model's flow list object itself -- nothing is keyed by id(), nothing keeps a dead model's tensors alive; the token of the pass
+in flight is thread-local.  A plan is trusted for a step only if EVERY tensor of every row is still the object registered in
+its owning module (one dict lookup per entry, ~0.1 ms for the 32-pair model; re-walking the modules costs 3-8 ms) and the
+layers' path switches are unchanged: re-assigning any parameter / buffer, .requires_grad_(False), use_fused* or a config
+switch rebuilds it.
 """
+import threading
 import weakref
 
 import torch
@@ -14,53 +22,60 @@ import torch
 from . import config as _config
 from . import ops
 
-_current = None
-_tables = {}
+_tls = threading.local()
+_plans = weakref.WeakKeyDictionary()      # flow list (nn.ModuleList) -> _Plan
 
 
 def current():
-    return _current
+    return getattr(_tls, "token", None)
 
 
-def _table(key_name, rows, device):
-    """Device tensor of the rows' pointers, rebuilt only when a pointer changed (parameters are updated in place)."""
-    flat = tuple(p for r in rows for p in r)
-    hit = _tables.get(key_name)
-    if hit is None or hit[0] != flat or hit[1].device != device:
-        hit = _tables[key_name] = (flat, torch.tensor(flat, dtype=torch.int64, device=device))
-    return hit[1]
+class _Plan:
+    __slots__ = ("sig", "groups", "tables")
+
+    def __init__(self, sig, groups):
+        self.sig, self.groups, self.tables = sig, groups, {}
 
 
-_plans = {}
+def _owned(module, name):
+    """(tensor, owner dict, key): the registered parameter / buffer `name` of `module` and where to look it up again."""
+    d = module._parameters if name in module._parameters else module._buffers
+    return d[name], d, name
 
 
 def _nsf_row(c, z):
+    """Table row of one coupling layer (order = nf_rqs_fused_pack_all_multi's, include/nf_mi355x.h) + its ownership records."""
     net, u = c.transform_net, c.unconditional_transform
     _, wpad, _, wfull_t = c._train_buffers(z)
     lin = [l for blk in net.blocks for l in blk.linear_layers]
-    return [c._train_blob_for(z), net.initial_layer.weight, net.initial_layer.bias, net.final_layer.weight, net.final_layer.bias,
-            u.unnormalized_widths, u.unnormalized_heights, u.unnormalized_derivatives, wfull_t, wpad, c.identity_features] \
-        + [l.weight for l in lin] + [l.bias for l in lin]
+    own = [_owned(net.initial_layer, "weight"), _owned(net.initial_layer, "bias"), _owned(net.final_layer, "weight"),
+           _owned(net.final_layer, "bias"), _owned(u, "unnormalized_widths"), _owned(u, "unnormalized_heights"),
+           _owned(u, "unnormalized_derivatives"), _owned(c, "identity_features")] \
+        + [_owned(l, "weight") for l in lin] + [_owned(l, "bias") for l in lin]
+    t = [o[0] for o in own]
+    row = [c._train_blob_for(z)] + t[:7] + [wfull_t, wpad, t[7]] + t[8:]
+    # layer-owned images (blob, wfull_t, wpad) live in the layer's __dict__: checked by identity as well
+    held = [(row[0], c.__dict__, "_train_blob"), (c.__dict__["_train_wbufs"], c.__dict__, "_train_wbufs")]
+    return row, own + held
 
 
 def _lu_row(f, z):
     lin = f.linear
-    return [f.permutation._permutation, lin.lower_entries, lin.upper_entries, lin.unconstrained_upper_diag,
-            f._factors_buffer(z.device)]
+    own = [_owned(f.permutation, "_permutation"), _owned(lin, "lower_entries"), _owned(lin, "upper_entries"),
+           _owned(lin, "unconstrained_upper_diag")]
+    fbuf = f._factors_buffer(z.device)
+    return [o[0] for o in own] + [fbuf], own + [(fbuf, f.__dict__, "_lu_fbuf")]
 
 
-def _sentinels(kind, layer):
-    """Two of the layer's parameters, read from the module: the cached rows are valid while these are the cached objects and
-    still require gradients (.to() / load_state_dict keep the Parameter objects; only re-assigned attributes replace them)."""
+def _switches(kind, layer):
     if kind == "nsf":
-        return layer.transform_net.initial_layer.weight, layer.transform_net.final_layer.bias
-    return layer.linear.lower_entries, layer.linear.unconstrained_upper_diag
+        return (layer.use_fused, layer.use_fused_train, layer.training)
+    return (layer.training,)
 
 
-def _plan(flows, z):
+def _plan(flows, z, sig):
     """Which layers of `flows` are packed together and the tensors of their table rows: decided once per (model, batch shape,
-    training flags, configuration) -- reading ~1300 module attributes every step costs the host several ms.  Per step only the
-    sentinels are re-read and the cached tensors asked for their (possibly new) data pointers."""
+    training flags, configuration)."""
     from .flows.mixing import LULinearPermute
     from .flows.neural_spline import CoupledRationalQuadraticSpline
     groups = {}
@@ -69,63 +84,71 @@ def _plan(flows, z):
             c = f.prqct
             if c._train_full_ok(z, None, False) and all(p.requires_grad for p in c.parameters()):
                 key = ("nsf", len(c.transform_net.blocks), float(c.tail_bound), c.min_bin_width, c.min_bin_height, c.min_derivative)
-                groups.setdefault(key, []).append((c, _nsf_row(c, z), _sentinels("nsf", c)))
+                row, own = _nsf_row(c, z)
+                groups.setdefault(key, []).append((c, row, own, _switches("nsf", c)))
         elif isinstance(f, LULinearPermute) and f._train_factors_ok(z) and all(p.requires_grad for p in f.parameters()):
-            groups.setdefault(("lu", f.linear.features, float(f.linear.eps)), []).append((f, _lu_row(f, z), _sentinels("lu", f)))
-    return list(groups.items())
+            row, own = _lu_row(f, z)
+            groups.setdefault(("lu", f.linear.features, float(f.linear.eps)), []).append((f, row, own, _switches("lu", f)))
+    return _Plan(sig, list(groups.items()))
 
 
 def _plan_valid(plan):
-    for key, entries in plan:
-        for layer, _, sen in entries:
-            a, b = _sentinels(key[0], layer)
-            if a is not sen[0] or b is not sen[1] or not a.requires_grad:
+    for key, entries in plan.groups:
+        for layer, _, own, sw in entries:
+            if _switches(key[0], layer) != sw:
                 return False
+            for t, d, name in own:
+                cur = d.get(name)
+                if cur is not t or (t.__class__ is torch.nn.Parameter and not t.requires_grad):
+                    return False
     return True
+
+
+def _table(plan, key, rows, device):
+    """Device tensor of the rows' pointers, rebuilt only when a pointer changed (parameters are updated in place)."""
+    flat = tuple(p for r in rows for p in r)
+    hit = plan.tables.get(key)
+    if hit is None or hit[0] != flat or hit[1].device != device:
+        hit = plan.tables[key] = (flat, torch.tensor(flat, dtype=torch.int64, device=device))
+    return hit[1]
 
 
 def begin(flows, z, inverse):
     """Pack the eligible layers of `flows` for a differentiable density pass over z; returns the token (None: nothing done)."""
-    global _current
     if not (_config.train_prepack and inverse and torch.is_grad_enabled() and torch.is_tensor(z) and z.is_cuda and z.dim() == 2
-            and z.dtype == torch.float32 and z.shape[0] >= 1024 and _current is None):
+            and z.dtype == torch.float32 and z.shape[0] >= 1024 and current() is None and isinstance(flows, torch.nn.Module)):
         return None
-    # the plan depends on what decides the layers' training path: shapes, module flags, configuration
-    sig = (tuple(z.shape), z.device, _config.train_full, len(flows), tuple(f.training for f in flows))
-    hit = _plans.get(id(flows))
-    if hit is None or hit[2]() is not flows or hit[0] != sig or not _plan_valid(hit[1]):
-        if len(_plans) > 16:        # models come and go (tests, sweeps): do not keep their layers alive through old plans
-            _plans.clear()
-            _tables.clear()
-        hit = _plans[id(flows)] = (sig, _plan(flows, z), weakref.ref(flows))
-    plan = hit[1]
-    if sum(len(es) for _, es in plan) < 2:
+    # the plan depends on what decides the layers' training path: shapes, configuration, the list itself
+    sig = (tuple(z.shape), z.device, _config.train_full, _config.resblock_bwd, _config.lu_bwd_fused, len(flows))
+    plan = _plans.get(flows)
+    if plan is None or plan.sig != sig or not _plan_valid(plan):
+        plan = _plans[flows] = _plan(flows, z, sig)
+    if sum(len(es) for _, es in plan.groups) < 2:
         return None
     token = object()
-    for key, entries in plan:
-        rows = [[t.data_ptr() for t in row] for _, row, _ in entries]
-        table = _table((key, id(flows)), rows, z.device)
+    for key, entries in plan.groups:
+        rows = [[t.data_ptr() for t in row] for _, row, _, _ in entries]
+        table = _table(plan, key, rows, z.device)
         if key[0] == "nsf":
             ops.rqs_fused_pack_all_multi(table, len(entries), key[1], tail_bound=key[2], min_bin_width=key[3], min_bin_height=key[4],
                                          min_derivative=key[5])
         else:
             ops.lu_factors_multi(table, len(entries), key[2], key[1])
-        for layer, _, _ in entries:
+        for layer, _, _, _ in entries:
             layer.__dict__["_prepacked"] = token
-    _current = token
+    _tls.token = token
     return token
 
 
 def end(token):
-    global _current
-    if token is not None and _current is token:
-        _current = None
+    if token is not None and current() is token:
+        _tls.token = None
 
 
 def take(layer):
     """True once per prepack: the layer's blob / factors were written by the current call's multi-launch."""
     tok = layer.__dict__.get("_prepacked")
-    if tok is not None and tok is _current:
+    if tok is not None and tok is current():
         layer.__dict__["_prepacked"] = None
         return True
     return False

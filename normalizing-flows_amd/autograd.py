@@ -329,28 +329,19 @@ class DiagGaussianLogProbFn(torch.autograd.Function):
         return gz, gloc.view_as(loc), gls.view_as(log_scale), None
 
 
-def _rows_ok(x, weight):
-    """nf_rows_linear takes this Linear: float32 rows on the device, widths multiples of 4."""
-    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32
-            and weight.shape[0] % 4 == 0 and weight.shape[1] % 4 == 0 and x.shape[0] > 0)
-
-
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b with the weight / bias gradients on the split-K HIP kernel (nf_linear_wgrad): at the training batch
     sizes of the path (K = 65 536 rows, 128 x 128 outputs) the library runs that reduction at a few percent of peak.  The
-    forward and input-gradient products stay library GEMMs by default: measured on MI355X (tools/kernel_bench.py) hipBLASLt
-    does the 65 536 x 128 x 128 product in 28 us (77 TFLOP/s) and the 736-row final layer at 0.55-0.85 of the fp32 MFMA peak,
-    ahead of the stand-alone row-panel kernel nf_rows_linear (44 us; `config.set_train_gemm("rows")` routes them there);
-    what beats the library is keeping the block's intermediate on chip (ResidualBlockFn below)."""
+    forward and input-gradient products of a LONE Linear stay library GEMMs: measured on MI355X (tools/kernel_bench.py)
+    hipBLASLt does the 65 536 x 128 x 128 product in 28 us (77 TFLOP/s) and the 736-row final layer at 0.55-0.85 of the fp32
+    MFMA peak; round 2's stand-alone row-panel kernel lost to it on every shape and was removed -- what beats the library is
+    keeping intermediates on chip (ResidualBlockFn, CouplingTrainFn, nf_final_bwd).  Benchmark-shaped NSF layers never come
+    here: their whole forward and backward run on the one-pass kernels."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        from . import config
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        ctx.rows = config.train_gemm == "rows" and _rows_ok(x, weight)
-        if ctx.rows:
-            return ops.rows_linear(x, weight.detach(), None if bias is None else bias.detach())
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
@@ -359,7 +350,7 @@ class LinearFn(torch.autograd.Function):
         gx = gw = gb = None
         gy = gy.contiguous()
         if ctx.needs_input_grad[0]:
-            gx = ops.rows_linear(gy, weight.detach(), trans_w=True) if (ctx.rows and _rows_ok(gy, weight)) else gy @ weight
+            gx = gy @ weight
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             if weight.shape[1] <= 128:
                 gw, gb = ops.linear_wgrad(gy, x, want_bias=ctx.has_bias)

@@ -31,19 +31,6 @@ def set_roctx(mode=True):
     _prof.enabled = bool(mode)
 
 
-# Forward / input-gradient GEMMs of nets.Linear in training: "library" (hipBLASLt through torch: faster stand-alone, see
-# autograd.LinearFn) or "rows" (nf_rows_linear, the hand-written fp32-MFMA row-panel kernel; ablation).  The residual blocks
-# always run on the one-launch kernel nf_rows_block.
-train_gemm = "library"
-
-
-def set_train_gemm(mode):
-    global train_gemm
-    if mode not in ("library", "rows"):
-        raise ValueError("train_gemm must be 'library' or 'rows'")
-    train_gemm = mode
-
-
 # The two weight gradients of a residual block as ONE pair launch (nf_linear_wgrad_pair); False = two single launches (ablation).
 wgrad_pair = True
 

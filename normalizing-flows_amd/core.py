@@ -150,6 +150,24 @@ def _run_realnvp(run, cache, z, inverse, ld, acc):
 _realnvp_cache = {}
 
 
+class _frozen_parameters:
+    """requires_grad switched off on every parameter of `module` for the `with` body and ALWAYS restored (a layer without a
+    differentiable path raises mid-loop: the model must not stay frozen).  reverse_kld(score_fn=False), core.py:353-363."""
+
+    def __init__(self, module):
+        self.params = list(module.parameters())
+
+    def __enter__(self):
+        self.req = [p_.requires_grad for p_ in self.params]
+        for p_ in self.params:
+            p_.requires_grad_(False)
+
+    def __exit__(self, *exc):
+        for p_, r in zip(self.params, self.req):
+            p_.requires_grad_(r)
+        return False
+
+
 def run_chain(flows, z, inverse, ld, acc):
     """_run_chain_impl behind the training step's one-launch weight packing (_prepack.py): a differentiable density pass first
     packs every eligible layer's weights / LU factors with one launch per kind; the layers then skip their own pack launches."""
@@ -385,14 +403,10 @@ class NormalizingFlow(nn.Module):
         else:
             z, log_q = self.sample_from_noise(eps)
         if not score_fn:
-            req = [p_.requires_grad for p_ in self.parameters()]
-            for p_ in self.parameters():
-                p_.requires_grad_(False)
-            log_q = torch.zeros(len(z), dtype=z.dtype, device=z.device)
-            z_ = run_chain(self.flows, z, True, log_q, +1)
-            log_q = log_q + self.q0.log_prob(z_)
-            for p_, r in zip(self.parameters(), req):
-                p_.requires_grad_(r)
+            with _frozen_parameters(self):
+                log_q = torch.zeros(len(z), dtype=z.dtype, device=z.device)
+                z_ = run_chain(self.flows, z, True, log_q, +1)
+                log_q = log_q + self.q0.log_prob(z_)
         log_p = self.p.log_prob(z)
         return torch.mean(log_q) - beta * torch.mean(log_p)
 
@@ -450,16 +464,12 @@ class ConditionalNormalizingFlow(NormalizingFlow):
         """core.py:338-366; score_fn=False re-evaluates log q with the parameters frozen, as the reference does."""
         z, log_q = self.sample(num_samples, context=context)
         if not score_fn:
-            req = [p_.requires_grad for p_ in self.parameters()]
-            for p_ in self.parameters():
-                p_.requires_grad_(False)
-            log_q = torch.zeros(len(z), dtype=z.dtype, device=z.device)
-            z_ = z
-            for i in range(len(self.flows) - 1, -1, -1):
-                z_ = run_flow(self.flows[i], z_, True, log_q, +1, context=context)
-            log_q = log_q + self.q0.log_prob(z_, context=context)
-            for p_, r in zip(self.parameters(), req):
-                p_.requires_grad_(r)
+            with _frozen_parameters(self):
+                log_q = torch.zeros(len(z), dtype=z.dtype, device=z.device)
+                z_ = z
+                for i in range(len(self.flows) - 1, -1, -1):
+                    z_ = run_flow(self.flows[i], z_, True, log_q, +1, context=context)
+                log_q = log_q + self.q0.log_prob(z_, context=context)
         log_p = self.p.log_prob(z, context=context)
         return torch.mean(log_q) - beta * torch.mean(log_p)
 

@@ -290,44 +290,6 @@ def rows_matvec(x, W):
     return y
 
 
-def rows_linear(x, W, bias=None, relu_in=False, trans_w=False, mask_src=None, residual=None):
-    """out = post(pre(x) Wp^T + bias) for a whole Linear layer (nf_rows_linear, csrc/rows_linear.hip), any width: the layer
-    is cut into <= 128-column output panels and <= 128-wide contraction chunks (later chunks accumulate).
-    x (B, K) float32; W (N, K), or (K, N) with trans_w (the input gradient gx = gy W of a layer with weight W (K, N)... i.e.
-    out[b, j] = sum_k x[b, k] W[k, j]); pre = ReLU when relu_in; post: zero where mask_src <= 0, then + residual."""
-    L.require_device(x, W, bias, mask_src, residual)
-    if x.dtype != torch.float32 or x.dim() != 2:
-        raise NotImplementedError("rows_linear: (B, K) float32")
-    x = x.contiguous()
-    W = W.contiguous()
-    B, K = x.shape
-    N = W.shape[1] if trans_w else W.shape[0]
-    assert (W.shape[0] if trans_w else W.shape[1]) == K, (W.shape, K, trans_w)
-    if K % 4 or N % 4:
-        raise NotImplementedError("rows_linear: widths must be multiples of 4")
-    out = torch.empty(B, N, dtype=torch.float32, device=x.device)
-    bias = None if bias is None else bias.contiguous()
-    mask_src = None if mask_src is None else mask_src.contiguous()
-    residual = None if residual is None else residual.contiguous()
-    ldw = W.shape[1]
-    lib, st = L.lib(), L.stream()
-    e = 4   # bytes per element
-    for n0 in range(0, N, 128):
-        nc = min(128, N - n0)
-        for ki, k0 in enumerate(range(0, K, 128)):
-            kc = min(128, K - k0)
-            last = k0 + kc >= K
-            woff = (k0 * ldw + n0) if trans_w else (n0 * ldw + k0)
-            off = lambda t, c: None if t is None else C.c_void_p(t.data_ptr() + c * e)   # noqa: E731
-            rc = lib.nf_rows_linear(off(x, k0), i64(K), off(W, woff), i64(ldw), i32(int(trans_w)),
-                                    off(bias, n0) if ki == 0 else None,
-                                    off(mask_src, n0), i64(N),   # a 0/1 factor: applied to every chunk's contribution
-                                    off(residual, n0) if last else None, i64(N), off(out, n0), i64(N), i64(B), i32(kc), i32(nc),
-                                    i32(int(relu_in)), i32(1 if ki > 0 else 0), st)
-            L.check(rc, "nf_rows_linear")
-    return out
-
-
 def rows_block(x, M1, c1, M2, c2, trans=False, mask1=None, mask2=None, relu=True):
     """(out1, out2) of nf_rows_block: out1 = mask1(M1 pre(x) + c1), out2 = x + mask2(M2 pre(out1) + c2); (B, H <= 128)
     float32.  trans: M1 / M2 are used transposed (the block's backward); relu: pre = ReLU on both products."""

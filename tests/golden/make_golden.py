@@ -858,8 +858,17 @@ def gen_maf_model_full():
         z_fwd, ld_fwd = m.forward_and_log_det(eps)    # 10 x one MADE pass
         logq = m.q0.log_prob(eps) - ld_fwd
     chk = torch.stack([p_.double().abs().sum() for p_ in m.parameters()]).sum()
+    # the same model evaluated by the reference in DOUBLE precision (same fp32 weights, widened): what the fp32 results are
+    # rounded versions of -- lets the GPU test hold the 1e-4 bar against the value itself and bound the kernel's error by a
+    # small multiple of the reference's own fp32 error instead of a looser absolute tolerance
+    m64 = m.double()
+    with torch.no_grad():
+        z_inv64, ld_inv64 = m64.inverse_and_log_det(x.double())
+        lp64 = m64.log_prob(x.double())
+        z_fwd64, ld_fwd64 = m64.forward_and_log_det(eps.double())
     npz("model_maf_c5_full", x=x, eps=eps, z_inv=z_inv, ld_inv=ld_inv, log_prob=lp, z_fwd=z_fwd, ld_fwd=ld_fwd,
-        sample_logq=logq, checksum=chk)
+        sample_logq=logq, checksum=chk, z_inv_f64=z_inv64, ld_inv_f64=ld_inv64, log_prob_f64=lp64, z_fwd_f64=z_fwd64,
+        ld_fwd_f64=ld_fwd64)
 
 
 def gen_cdf():
@@ -949,6 +958,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "circular":
         gen_circular()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "maf_model_full":
+        gen_maf_model_full()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "full_models":
         gen_glow_model_full()

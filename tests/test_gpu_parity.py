@@ -538,9 +538,20 @@ def test_maf_config5_full_model_vs_reference(nfa):
     assert abs(chk - float(g["checksum"])) < 1e-6 * abs(chk)
     m = m.to(DEV)
     z, ld = m.inverse_and_log_det(T(g["x"]))
-    assert_close(N(z), g["z_inv"], what="z_inv", rtol=2e-4, atol=2e-4)
+    lp = m.log_prob(T(g["x"]))
+    # north-star bar (1e-4 relative) against the reference's fp32 outputs AND against the reference evaluated in double
+    # precision on the same weights (`*_f64`); the kernel's error against the double-precision values may also be no more
+    # than a small multiple of what the reference's own fp32 arithmetic loses there (1.8e-5 on z, 1.2e-5 on log_prob)
+    assert_close(N(z), g["z_inv"], what="z_inv", rtol=1e-4, atol=1e-4)
     assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=1e-4, atol=1e-4)
-    assert _rel(N(m.log_prob(T(g["x"]))), g["log_prob"]) < 2e-4
+    assert _rel(N(lp), g["log_prob"]) < 1e-4, _rel(N(lp), g["log_prob"])
+    for got, name in ((N(z), "z_inv"), (N(ld), "ld_inv"), (N(lp), "log_prob")):
+        r64 = g[name + "_f64"]
+        e_gpu = np.abs(got.astype(np.float64) - r64) / np.maximum(1.0, np.abs(r64))
+        e_ref = np.abs(g[name].astype(np.float64) - r64) / np.maximum(1.0, np.abs(r64))
+        assert e_gpu.max() < 1e-4, (name, e_gpu.max())
+        for q in (0.9, 0.99, 1.0):
+            assert np.quantile(e_gpu, q) <= 4 * np.quantile(e_ref, q) + 2e-6, (name, q, np.quantile(e_gpu, q), np.quantile(e_ref, q))
     zf, ldf = m.forward_and_log_det(T(g["eps"]))
     assert_close(N(zf), g["z_fwd"], what="z_fwd", rtol=1e-4, atol=1e-4)
     assert_close(N(ldf), g["ld_fwd"], what="ld_fwd", rtol=1e-4, atol=1e-4)
@@ -1615,3 +1626,20 @@ def test_fused_kernel_on_narrower_layers_vs_unfused_and_oracle(nfa, oracle, D, h
             zo = (ora64.coupling if ora64._is_coupling(i) else ora64.lu)(i, zo, 0 if inverse else 1, logq, +1)
         assert_close(N(z_f).astype(np.float64), zo, what="chain vs oracle z", rtol=1e-3, atol=1e-3)
         assert_close(N(ld_f).astype(np.float64), logq, what="chain vs oracle ld", rtol=1e-3, atol=1e-3)
+        # condition-aware bound (the layers are strongly non-identity, some bins have tiny slopes): against the
+        # double-precision oracle the kernel may lose no more than a small multiple of what the reference's own fp32
+        # arithmetic (the fp32 oracle on the same weights) loses, quantile by quantile and at the maximum
+        ora32 = oracle.OracleNSF(st, num_layers=6, K=bins, tail_bound=3.0)
+        logq32 = np.zeros(B, np.float32)
+        z32 = x.numpy().copy()
+        for i in (range(5, -1, -1) if inverse else range(6)):
+            z32 = (ora32.coupling if ora32._is_coupling(i) else ora32.lu)(i, z32, 0 if inverse else 1, logq32, +1)
+        fin = np.isfinite(zo)
+        e_gpu = (np.abs(N(z_f).astype(np.float64) - zo) / (1 + np.abs(zo)))[fin]
+        e_o32 = (np.abs(z32.astype(np.float64) - zo) / (1 + np.abs(zo)))[fin]
+        l_gpu = np.abs(N(ld_f).astype(np.float64) - logq) / np.maximum(1, np.abs(logq))
+        l_o32 = np.abs(logq32.astype(np.float64) - logq) / np.maximum(1, np.abs(logq))
+        for q in (0.9, 0.99, 0.999, 1.0):
+            assert np.quantile(e_gpu, q) <= 4 * np.quantile(e_o32, q) + 4e-6, ("z", q, np.quantile(e_gpu, q), np.quantile(e_o32, q))
+            assert np.quantile(l_gpu, q) <= 4 * np.quantile(l_o32, q) + 1e-5, ("ld", q, np.quantile(l_gpu, q), np.quantile(l_o32, q))
+        assert np.quantile(l_gpu, 0.99) < 1e-4, np.quantile(l_gpu, 0.99)      # the north-star bar on log-det, bulk of the rows

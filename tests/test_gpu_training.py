@@ -501,30 +501,6 @@ def test_layers_without_training_path_refuse_gradients(nfa):
     assert_close(N(ld1), N(ld0), what="logit ld torch vs kernel", rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize("B,K,N", [(1024, 128, 128), (1500, 32, 128), (2048, 128, 736), (1100, 736, 128), (1024, 128, 32),
-                                   (65536, 128, 128), (1, 64, 96)])
-def test_rows_linear_kernel_vs_torch(nfa, B, K, N):
-    """nf_rows_linear (csrc/rows_linear.hip) against float64 torch arithmetic: plain, with bias, ReLU on load, transposed
-    weight, ReLU mask by a saved pre-activation, residual; widths beyond one 128 x 128 panel (column panels, K chunks)."""
-    torch.manual_seed(B + K + N)
-    x = torch.randn(B, K, device=DEV)
-    W = torch.randn(N, K, device=DEV) / np.sqrt(K)
-    b = torch.randn(N, device=DEV)
-    m = torch.randn(B, N, device=DEV)
-    r = torch.randn(B, N, device=DEV)
-    x64, W64 = x.double(), W.double()
-    tol = dict(rtol=2e-5, atol=2e-5 * np.sqrt(K))
-    y = nfa.ops.rows_linear(x, W, b)
-    assert_close(N_(y), N_((x64 @ W64.t() + b.double()).float()), what="linear", **tol)
-    y = nfa.ops.rows_linear(x, W, b, relu_in=True, residual=r)
-    assert_close(N_(y), N_((x64.clamp_min(0) @ W64.t() + b.double() + r.double()).float()), what="relu_in + residual", **tol)
-    Wt = torch.randn(K, N, device=DEV) / np.sqrt(K)          # gx = gy W for a layer with weight (K_out = K, N_in = N)
-    y = nfa.ops.rows_linear(x, Wt, trans_w=True, mask_src=m, residual=r)
-    ref = (x64 @ Wt.double()) * (m > 0) + r.double()
-    assert_close(N_(y), N_(ref.float()), what="trans_w + mask + residual", **tol)
-    assert torch.equal(y, nfa.ops.rows_linear(x, Wt, trans_w=True, mask_src=m, residual=r))    # deterministic
-
-
 def N_(t):
     return t.detach().cpu().numpy()
 
@@ -547,15 +523,10 @@ def test_residual_block_and_linear_functions_vs_torch_autograd(nfa):
     cy = torch.randn(B, 736, device=DEV)
     assert ag.residual_block_fused_ok(net.blocks[0], torch.randn(B, H, device=DEV))
     results = []
-    for mode in ("library", "rows"):       # Linear layers on the library / on nf_rows_linear; the blocks on nf_rows_block
-        nfa.config.set_train_gemm(mode)
-        try:
-            xa = x.clone().requires_grad_(True)
-            (net(xa) * cy).sum().backward()                                # our Functions (B >= 1024)
-        finally:
-            nfa.config.set_train_gemm("library")
-        results.append([xa.grad.clone()] + [p_.grad.clone() for p_ in net.parameters()])
-        net.zero_grad()
+    xa = x.clone().requires_grad_(True)
+    (net(xa) * cy).sum().backward()                                # our Functions (B >= 1024): blocks on nf_rows_block
+    results.append([xa.grad.clone()] + [p_.grad.clone() for p_ in net.parameters()])
+    net.zero_grad()
     xb = x.clone().requires_grad_(True)
     h = torch.nn.functional.linear(xb, net.initial_layer.weight, net.initial_layer.bias)
     for blk in net.blocks:
@@ -670,32 +641,80 @@ def test_whole_layer_training_path_other_depths_and_batches(nfa, blocks, B):
 
 def test_model_level_prepack_gives_identical_steps(nfa):
     """config.train_prepack (all layers' weights / LU factors packed by one launch per kind at the start of the density pass)
-    against every layer packing for itself: the same loss, gradients and three-step Adam trajectory; a layer called on its
-    own after a model step packs for itself (the token is gone); a model whose layers differ in depth is packed in groups."""
+    against every layer packing for itself, over three Adam steps: before every step the prepack model takes the other model's
+    parameters (in place: the cached plan and its pointer tables stay in use), then both compute loss and gradients from the
+    SAME weights -- the forward is deterministic, so the losses are equal bit for bit and the gradients equal up to the
+    summation order of the spline backward's atomics on the batch-shared parameters (~1e-6 relative).  A stale or wrong weight
+    image (blob, wpad, wfull_t, LU factors) at step 2 or 3 shows up as a dense O(lr) difference.
+
+    Two free-running trajectories are NOT comparable at this tolerance: tools/prepack_diag.py (profiles/r03_prepack_diag.log)
+    shows prepack OFF vs OFF parting ways at step 3 by 7.6e-3 in one weight gradient -- the atomics' 1e-7 noise moves the
+    parameters by 1e-8, which flips one of the ~5 M ReLU pre-activations that lie within 1e-7 of zero (round-2 GPUTEST failure).
+    Then: a layer called on its own after a model step packs for itself (the token is gone); the pack images of the two modes
+    are equal byte for byte; re-assigning ANY parameter rebuilds the plan."""
     import copy
     from bench import build_c2_model
     m0 = build_c2_model(num_layers=4, sigma=0.05).to(DEV)
     x = torch.randn(2048, 64, device=DEV)
-    res = []
     try:
-        for on in (True, False):
-            nfa.config.set_train_prepack(on)
-            m = copy.deepcopy(m0)
-            opt = torch.optim.Adam(m.parameters(), lr=1e-3)
-            losses = []
-            for _ in range(3):
+        m_on, m_off = copy.deepcopy(m0), copy.deepcopy(m0)
+        names = [n for n, _ in m_on.named_parameters()]
+        o_on = torch.optim.Adam(m_on.parameters(), lr=1e-3)
+        o_off = torch.optim.Adam(m_off.parameters(), lr=1e-3)
+        losses = []
+        for step in range(3):
+            with torch.no_grad():
+                for a, b in zip(m_on.parameters(), m_off.parameters()):
+                    a.copy_(b)
+            out = []
+            for on, m, opt in ((True, m_on, o_on), (False, m_off, o_off)):
+                nfa.config.set_train_prepack(on)
                 opt.zero_grad(set_to_none=True)
                 loss = m.forward_kld(x)
                 loss.backward()
-                losses.append(float(loss.detach()))
-                g = [p_.grad.clone() for p_ in m.parameters()]
+                out.append((float(loss.detach()), [p_.grad.clone() for p_ in m.parameters()]))
                 opt.step()
-            res.append((losses, g, [p_.detach().clone() for p_ in m.parameters()]))
-        # (the spline backward adds the batch-shared parameters' gradients with atomics: equal to rounding, not bit for bit)
-        assert max(abs(a - b) for a, b in zip(res[0][0], res[1][0])) < 1e-5 * abs(res[1][0][0]), (res[0][0], res[1][0])
-        for k in (1, 2):
-            for a, b in zip(res[0][k], res[1][k]):
-                assert float((a - b).abs().max()) <= 1e-4 * max(float(b.abs().max()), 1e-6)
+            assert out[0][0] == out[1][0], (step, out[0][0], out[1][0])
+            for n, a, b in zip(names, out[0][1], out[1][1]):
+                scale = max(float(b.abs().max()), 1e-6)
+                assert float((a - b).abs().max()) <= 1e-5 * scale, (step, n, float((a - b).abs().max()), scale)
+            losses.append(out[1][0])
+        assert losses[2] < losses[0]
+        # the images the backward reads, multi-layer pack against per-layer pack of the same weights: byte for byte
+        for fa, fb in zip(m_on.flows, m_off.flows):
+            fb.load_state_dict(fa.state_dict())
+        nfa.config.set_train_prepack(True)
+        m_on.forward_kld(x).backward()
+        nfa.config.set_train_prepack(False)
+        m_off.forward_kld(x).backward()
+        for fa, fb in zip(m_on.flows, m_off.flows):
+            if hasattr(fa, "prqct"):
+                assert torch.equal(fa.prqct.__dict__["_train_blob"], fb.prqct.__dict__["_train_blob"])
+                for ta, tb in zip(fa.prqct.__dict__["_train_wbufs"], fb.prqct.__dict__["_train_wbufs"]):
+                    assert torch.equal(ta, tb)
+            else:
+                D = fa.linear.features
+                va = nfa.ops.lu_factors_views(fa.__dict__["_lu_fbuf"], D)
+                vb = nfa.ops.lu_factors(fb.permutation._permutation, fb.linear.lower_entries.detach(),
+                                        fb.linear.upper_entries.detach(), fb.linear.unconstrained_upper_diag.detach(),
+                                        eps=fb.linear.eps)
+                for ta, tb in zip(va, vb):
+                    assert torch.equal(ta, tb)
+        # re-assigning a parameter the old sentinel check did not look at: the plan is rebuilt, no stale row
+        nfa.config.set_train_prepack(True)
+        lin = m_on.flows[2].prqct.transform_net.blocks[1].linear_layers[0]
+        lin.weight = torch.nn.Parameter(lin.weight.detach() * 0.5)
+        m_off.flows[2].prqct.transform_net.blocks[1].linear_layers[0].weight.data.mul_(0.5)
+        res = []
+        for on, m in ((True, m_on), (False, m_off)):
+            nfa.config.set_train_prepack(on)
+            m.zero_grad(set_to_none=True)
+            loss = m.forward_kld(x)
+            loss.backward()
+            res.append((float(loss.detach()), [p_.grad.clone() for p_ in m.parameters()]))
+        assert res[0][0] == res[1][0]
+        for n, a, b in zip(names, res[0][1], res[1][1]):
+            assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-6), n
         # a layer on its own, after the weights moved: no stale blob
         nfa.config.set_train_prepack(True)
         m = copy.deepcopy(m0)

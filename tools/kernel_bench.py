@@ -128,20 +128,6 @@ def main():
     zi = torch.randn(Bi, 3, 32, 32, device=dev)
     t = timeit(lambda: ops.squeeze(zi, 1))
     report("nf_squeeze (%d,3,32,32)" % Bi, t, zi.numel() * 8)
-    # conditioner GEMMs of the training path: the MFMA row-panel kernel against the library call it replaces
-    for K_, N_ in ((128, 128), (32, 128), (128, 736), (736, 128)):
-        xa = torch.randn(B, K_, device=dev)
-        Wa = torch.randn(N_, K_, device=dev)
-        ba = torch.randn(N_, device=dev)
-        ra = torch.randn(B, N_, device=dev)
-        t = timeit(lambda: ops.rows_linear(xa, Wa, ba, relu_in=True, residual=ra))
-        fl = 2.0 * B * K_ * N_
-        report("nf_rows_linear %dx%d relu+bias+residual [%.0f TF]" % (K_, N_, fl / t / 1e12), t, B * (K_ + 2 * N_) * 4)
-        t = timeit(lambda: torch.nn.functional.linear(xa, Wa, ba))
-        report("  library F.linear %dx%d (bias only) [%.0f TF]" % (K_, N_, fl / t / 1e12), t, B * (K_ + N_) * 4)
-        Wt = torch.randn(K_, N_, device=dev)
-        t = timeit(lambda: ops.rows_linear(xa, Wt, trans_w=True, mask_src=ra, residual=ra))
-        report("nf_rows_linear %dx%d trans+mask+residual [%.0f TF]" % (K_, N_, fl / t / 1e12), t, B * (K_ + 3 * N_) * 4)
     xa, W1, W2 = torch.randn(B, 128, device=dev), torch.randn(128, 128, device=dev), torch.randn(128, 128, device=dev)
     b1 = torch.randn(128, device=dev)
     t = timeit(lambda: ops.rows_block(xa, W1, b1, W2, b1))
