@@ -209,7 +209,9 @@ int nf_rqs_fused_train_fwd(const void *x, const void *h2, void *y, void *logdet,
  * (nets/resnet.py:37-50, :92-104); cond_out (B, 32, 24) as above.  wpack: nf_rqs_fused_pack_all (one launch; same layout as
  * nf_rqs_fused_pack without the LU).  D = 64, hidden = 128, K = 8, linear tails.  wfull / wpad / identity_idx (all or none): the
  * same launch also leaves the initial weight transposed on full rows (64, hidden; the identity features' rows written, the caller
- * keeps the rest zero) and the final weight in 24-row groups (32, 24, hidden; row 23 of a group untouched) for the backward's products. */
+ * keeps the rest zero) and, in `wpad` (32 x 24 x hidden floats), the final weight as the 24 A-operand stages nf_final_bwd streams
+ * (w_t: stage 3 g + rb = [q][unit block mb][lane][4]; MFMA step (rb, reg = 4 q + r) of group g contracts over the final rows
+ * nf_rqs_fused_final_row(8, g, rb, 8 q + 4 hh + r), raw scale, zero for padding rows). */
 int nf_rqs_fused_pack_all(void *wpack, const void *w_init, const void *b_init, const void *const *w_blocks,
                           const void *const *b_blocks, const void *w_final, const void *b_final, const void *uw, const void *uh,
                           const void *ud, int hidden, int num_blocks, int K, double tail_bound, double min_bin_width,
@@ -230,6 +232,25 @@ int nf_rqs_coupling_bwd_p24(const void *x, const void *grad_y, const void *grad_
                             int nT, int64_t B, int D, double tail_bound, double min_bin_width, double min_bin_height,
                             double min_derivative, double wh_div, void *grad_x, void *grad_cond24, void *grad_uw,
                             void *grad_uh, void *grad_ud, nf_stream_t stream);
+
+/* Backward of the layer's LAST stage in one pass over the rows (final_bwd.hip): nf_rqs_coupling_bwd_p24 AND the input gradient of
+ * the conditioner's final Linear (nets/resnet.py:104 under core.py:87-102 `loss.backward()`), grad_h = grad_cond W_final, with the
+ * gradient rows fed to the fp32 MFMAs from the registers they were computed in (no library GEMM, no re-read of the 201 MB of
+ * rows; they are written once, to grad_cond24, for the final layer's weight gradient).  x, grad_y, grad_x (B, 64); grad_logdet (B);
+ * cond24, grad_cond24 (B, 32, 24) (may alias); grad_h (B, 128); w_t: the `wpad` by-product of nf_rqs_fused_pack_all[_multi];
+ * wpack: the layer's blob (its knot tables of the batch-shared spline are read).  The batch-shared parameters' gradients leave
+ * as knot-space partial sums, one row of 768 floats per workgroup: partials (nf_final_bwd_partials(B) x 768 floats, written,
+ * not accumulated); nf_final_bwd_reduce adds them in a fixed order (bit-reproducible, no atomics) and applies the softmax /
+ * cumulative-sum / softplus chain once: grad_uw, grad_uh (32, 8), grad_ud (32, 7), written.  D = 64, hidden = 128, K = 8, linear
+ * tails, float32 (NF_ENOTSUP otherwise); any B. */
+int nf_final_bwd_partials(int64_t B);
+int nf_final_bwd(const void *x, const void *grad_y, const void *grad_logdet, const void *cond24, const void *w_t, const void *wpack,
+                 void *grad_x, void *grad_cond24, void *grad_h, void *partials, int mask_parity, int64_t B, int D, int hidden,
+                 int num_blocks, int K, double tail_bound, double min_bin_width, double min_bin_height, double min_derivative,
+                 nf_stream_t stream);
+int nf_final_bwd_reduce(const void *partials, int n_partials, const void *uw, const void *uh, const void *ud, void *grad_uw,
+                        void *grad_uh, void *grad_ud, int K, double tail_bound, double min_bin_width, double min_bin_height,
+                        double min_derivative, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * The same fused layer with the GEMMs on the bf16 matrix pipe by error-compensated splitting

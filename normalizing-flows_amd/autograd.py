@@ -123,6 +123,7 @@ class FinalSplineDensityFn(torch.autograd.Function):
         # the backward's input-gradient GEMM
         nT, H = cond24.shape[1], wf.shape[1]
         wpad[:, :23].copy_(wf.detach().view(nT, 23, H))
+        wpad[:, 23].zero_()       # (the whole-layer path's pack leaves another image of the final weight in this buffer)
         ctx.save_for_backward(x, h2, wf, cond24, uw, uh, ud, iidx, tidx)
         ctx.kw, ctx.wpad, ctx.acc, ctx.has_acc = kw, wpad, acc, ld_acc is not None
         return y, ld
@@ -394,6 +395,7 @@ class CouplingTrainFn(torch.autograd.Function):
             ctx.mark_dirty(ld_acc)
         ctx.save_for_backward(x, cond24, acts, w0, wf, uw, uh, ud, iidx, tidx, *blk)
         ctx.kw, ctx.wfull, ctx.wpad, ctx.acc, ctx.has_acc, ctx.nb = kw, wfull, wpad, acc, ld_acc is not None, nb
+        ctx.blob, ctx.parity = blob, parity
         return y, ld
 
     @staticmethod
@@ -405,13 +407,20 @@ class CouplingTrainFn(torch.autograd.Function):
         if gld is None:
             gld = torch.zeros(x.shape[0], dtype=x.dtype, device=x.device)
         gld_own = -gld if (ctx.has_acc and ctx.acc < 0) else gld
-        gx, gcond24, guw, guh, gud = ops.rqs_coupling_bwd_p24(x, gy, gld_own, cond24, uw, uh, ud, iidx, tidx,
-                                                              tail_bound=kw["tail_bound"], min_bin_width=kw["min_bin_width"],
-                                                              min_bin_height=kw["min_bin_height"],
-                                                              min_derivative=kw["min_derivative"], wh_div=kw["wh_div"])
         B, nT, H = x.shape[0], cond24.shape[1], wf.shape[1]
-        g2 = gcond24.view(B, nT * 24)
-        gh = g2 @ ctx.wpad.view(nT * 24, H)        # wpad / wfull: written by the forward's pack launch
+        fk = dict(tail_bound=kw["tail_bound"], min_bin_width=kw["min_bin_width"], min_bin_height=kw["min_bin_height"],
+                  min_derivative=kw["min_derivative"])
+        if _config.final_bwd_fused:
+            # ONE pass over the rows: spline backward on the vector ALU, its gradient rows straight into the MFMAs of the final
+            # layer's input gradient (nf_final_bwd; ctx.wpad = the transposed stage image the forward's pack launch left)
+            gx, gcond24, gh, guw, guh, gud = ops.final_bwd(x, gy, gld_own, cond24, ctx.wpad, ctx.blob, uw, uh, ud, ctx.parity, nb, **fk)
+            g2 = gcond24.view(B, nT * 24)
+        else:
+            gx, gcond24, guw, guh, gud = ops.rqs_coupling_bwd_p24(x, gy, gld_own, cond24, uw, uh, ud, iidx, tidx, wh_div=kw["wh_div"], **fk)
+            g2 = gcond24.view(B, nT * 24)
+            wrows = torch.zeros(nT, 24, H, dtype=wf.dtype, device=wf.device)
+            wrows[:, :23].copy_(wf.detach().view(nT, 23, H))
+            gh = g2 @ wrows.view(nT * 24, H)        # (round 2: library GEMM on the padded rows)
         gwf, gbf = ops.linear_wgrad(g2, acts[2 * nb], want_bias=True, skip_every=24)
         gblk = [None] * (4 * nb)
         fused = _config.resblock_bwd and nb > 0 and B % 64 == 0 and H == 128 and x.shape[1] == 64

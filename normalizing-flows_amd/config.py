@@ -63,6 +63,16 @@ def set_resblock_bwd(mode=True):
     resblock_bwd = bool(mode)
 
 
+# The coupling transform's backward + the final Linear's input gradient as one pass over the rows (nf_final_bwd); False = the
+# stand-alone spline backward (nf_rqs_coupling_bwd_p24) + a library GEMM on the padded rows (round 2; ablation / differential tests).
+final_bwd_fused = True
+
+
+def set_final_bwd_fused(mode=True):
+    global final_bwd_fused
+    final_bwd_fused = bool(mode)
+
+
 # LULinearPermute's density-direction backward (D = 64) as one pass over the rows (nf_lu_bwd).
 lu_bwd_fused = True
 

@@ -17,93 +17,12 @@
 // gradients are accumulated per workgroup in LDS and then atomically into (nI, K | K | nd) buffers that the caller
 // zero-initialises (summation order across workgroups is not deterministic; fp32 atomics).
 #include "common.hpp"
-#include "fused_common.hpp"
+#include "rqs_bwd_common.hpp"
 
 // (the unroll hints below are meant for the compile-time bin count, KT > 0; the build passes -Wno-pass-failed for the
 // run-time-K instantiations, where they cannot apply)
 
 namespace nf {
-
-template <typename T, int N> struct Dual {
-    T v;
-    T d[N];
-    __device__ __forceinline__ Dual() {}
-    __device__ __forceinline__ Dual(T c) : v(c) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) d[i] = T(0);
-    }
-    static __device__ __forceinline__ Dual var(T c, int idx) {
-        Dual r(c);
-        r.d[idx] = T(1);
-        return r;
-    }
-};
-#define DU template <typename T, int N> __device__ __forceinline__ Dual<T, N>
-DU operator+(const Dual<T, N> &a, const Dual<T, N> &b) { Dual<T, N> r; r.v = a.v + b.v;
-#pragma unroll
-    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
-DU operator-(const Dual<T, N> &a, const Dual<T, N> &b) { Dual<T, N> r; r.v = a.v - b.v;
-#pragma unroll
-    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
-DU operator-(const Dual<T, N> &a) { Dual<T, N> r; r.v = -a.v;
-#pragma unroll
-    for (int i = 0; i < N; ++i) r.d[i] = -a.d[i]; return r; }
-DU operator*(const Dual<T, N> &a, const Dual<T, N> &b) { Dual<T, N> r; r.v = a.v * b.v;
-#pragma unroll
-    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
-DU operator/(const Dual<T, N> &a, const Dual<T, N> &b) { Dual<T, N> r; const T inv = T(1) / b.v; r.v = a.v * inv;
-#pragma unroll
-    for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv; return r; }
-DU dlog(const Dual<T, N> &a) { Dual<T, N> r; r.v = M<T>::log(a.v); const T inv = T(1) / a.v;
-#pragma unroll
-    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * inv; return r; }
-DU dsqrt(const Dual<T, N> &a) { Dual<T, N> r; r.v = M<T>::sqrt(a.v); const T h = T(0.5) / r.v;
-#pragma unroll
-    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * h; return r; }
-#undef DU
-
-// Same arithmetic as common.hpp::rqs_eval_bin on dual numbers.
-// variables: 0 = x, 1 = cw (x-axis knot lo), 2 = cw_hi, 3 = ch (y-axis knot lo), 4 = ch_hi, 5 = d0, 6 = d1
-template <typename T>
-__device__ __forceinline__ void rqs_eval_bin_dual(T x, T cw, T cwh, T ch, T chh, T d0, T d1, bool inverse, T (&gy)[7],
-                                                  T (&gl)[7]) {
-    typedef Dual<T, 7> D7;
-    const D7 X = D7::var(x, 0), CW = D7::var(cw, 1), CWH = D7::var(cwh, 2), CH = D7::var(ch, 3), CHH = D7::var(chh, 4),
-             D0 = D7::var(d0, 5), D1 = D7::var(d1, 6);
-    const D7 bw = CWH - CW, bh = CHH - CH;
-    const D7 delta = bh / bw;
-    const D7 two(T(2)), one(T(1)), four(T(4));
-    const D7 dsum = D0 + D1 - two * delta;
-    D7 y, lad;
-    if (!inverse) {
-        const D7 theta = (X - CW) / bw;
-        const D7 omt = one - theta;
-        const D7 t1mt = theta * omt;
-        const D7 num = bh * (delta * theta * theta + D0 * t1mt);
-        const D7 den = delta + dsum * t1mt;
-        y = CH + num / den;
-        const D7 dnum = delta * delta * (D1 * theta * theta + two * delta * t1mt + D0 * omt * omt);
-        lad = dlog(dnum) - two * dlog(den);
-    } else {
-        const D7 dy = X - CH;
-        const D7 a = dy * dsum + bh * (delta - D0);
-        const D7 b = bh * D0 - dy * dsum;
-        const D7 c = -(delta * dy);
-        const D7 disc = b * b - four * a * c;
-        const D7 root = (two * c) / (-b - dsqrt(disc));
-        y = root * bw + CW;
-        const D7 omr = one - root;
-        const D7 t1mt = root * omr;
-        const D7 den = delta + dsum * t1mt;
-        const D7 dnum = delta * delta * (D1 * root * root + two * delta * t1mt + D0 * omr * omr);
-        lad = -(dlog(dnum) - two * dlog(den));
-    }
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        gy[i] = y.d[i];
-        gl[i] = lad.d[i];
-    }
-}
 
 // Softmax probabilities of K logits read through `acc` (already divided by wh_div), written through `put`: the only
 // transcendental pass over the widths / heights; everything downstream works on the probabilities.
@@ -354,84 +273,6 @@ rqs_coupling_bwd_kernel(const T *__restrict__ x, const T *__restrict__ gy, const
     }
 }
 
-
-// ---- default parametrisation (8 bins, linear tails, float32): everything in registers, static indexing ----------------
-// Same derivation as rqs_element_bwd on the register layout of fused_common.hpp::rqs_regs: prm[0..7] / prm[8..15] arrive
-// multiplied by log2(e) / wh_div (softmax through exp2), prm[16..22] are the raw derivative logits.  Writes the gradients
-// of the RAW parameters to g[0..22] and returns gx.
-template <bool INVERSE>
-__device__ __forceinline__ float rqs_regs_bwd(const RqsParams<float> &p, float x, const float (&prm)[24], float gy_up,
-                                              float gl_up, float (&g)[24], float inv_div) {
-    const bool inside = x >= p.left && x <= p.right;
-    float mw = prm[0], mh = prm[F_K];
-#pragma unroll
-    for (int k = 1; k < F_K; ++k) {
-        mw = fmaxf(mw, prm[k]);
-        mh = fmaxf(mh, prm[F_K + k]);
-    }
-    float ew[F_K], eh[F_K], pw[F_K], ph[F_K];
-#pragma unroll
-    for (int k = 0; k < F_K; ++k) {
-        ew[k] = __builtin_amdgcn_exp2f(prm[k] - mw);
-        eh[k] = __builtin_amdgcn_exp2f(prm[F_K + k] - mh);
-        pw[k] = k == 0 ? ew[k] : pw[k - 1] + ew[k];
-        ph[k] = k == 0 ? eh[k] : ph[k - 1] + eh[k];
-    }
-    const float rsw = frcp(pw[F_K - 1]), rsh = frcp(ph[F_K - 1]);
-    const float cw = (p.right - p.left) * p.scale_w * rsw, ch = (p.top - p.bottom) * p.scale_h * rsh;
-    float kw[F_K + 1], kh[F_K + 1];
-    kw[0] = p.left; kh[0] = p.bottom; kw[F_K] = p.right; kh[F_K] = p.top;
-#pragma unroll
-    for (int k = 1; k < F_K; ++k) {
-        kw[k] = fmaf(pw[k - 1], cw, p.left + (p.right - p.left) * p.min_w * (float)k);
-        kh[k] = fmaf(ph[k - 1], ch, p.bottom + (p.top - p.bottom) * p.min_h * (float)k);
-    }
-    // bin on the searched axis (x axis for the forward spline, y axis for the inverse); knots and cumulative softmax
-    // C_bin, C_{bin+1} of BOTH axes at that bin
-    int bin = 0;
-    float xlo = kw[0], xhi = kw[1], ylo = kh[0], yhi = kh[1];
-    float Cw_lo = 0.0f, Cw_hi = pw[0] * rsw, Ch_lo = 0.0f, Ch_hi = ph[0] * rsh;
-#pragma unroll
-    for (int k = 1; k < F_K; ++k) {
-        const bool ge = x >= (INVERSE ? kh[k] : kw[k]);
-        bin = ge ? k : bin;
-        xlo = ge ? kw[k] : xlo; xhi = ge ? kw[k + 1] : xhi;
-        ylo = ge ? kh[k] : ylo; yhi = ge ? kh[k + 1] : yhi;
-        Cw_lo = ge ? pw[k - 1] * rsw : Cw_lo; Cw_hi = ge ? pw[k] * rsw : Cw_hi;
-        Ch_lo = ge ? ph[k - 1] * rsh : Ch_lo; Ch_hi = ge ? ph[k] * rsh : Ch_hi;
-    }
-    float dl0 = p.edge_logit, dl1 = p.edge_logit;
-#pragma unroll
-    for (int k = 0; k < F_K - 1; ++k) {
-        dl0 = (bin == k + 1) ? prm[2 * F_K + k] : dl0;
-        dl1 = (bin == k) ? prm[2 * F_K + k] : dl1;
-    }
-    const float d0 = p.min_d + fsoftplus(dl0), d1 = p.min_d + fsoftplus(dl1);
-    float jy[7], jl[7];
-    rqs_eval_bin_dual<float>(x, xlo, xhi, ylo, yhi, d0, d1, INVERSE, jy, jl);
-    float gv[7];
-#pragma unroll
-    for (int i = 0; i < 7; ++i) gv[i] = gy_up * jy[i] + gl_up * jl[i];
-    const float g_cw_lo = bin == 0 ? 0.0f : gv[1], g_cw_hi = bin == F_K - 1 ? 0.0f : gv[2];   // pinned end knots
-    const float g_ch_lo = bin == 0 ? 0.0f : gv[3], g_ch_hi = bin == F_K - 1 ? 0.0f : gv[4];
-    const float fw = (p.right - p.left) * p.scale_w * inv_div, fh = (p.top - p.bottom) * p.scale_h * inv_div;
-    const float base_w = g_cw_lo * Cw_lo + g_cw_hi * Cw_hi, base_h = g_ch_lo * Ch_lo + g_ch_hi * Ch_hi;
-#pragma unroll
-    for (int i = 0; i < F_K; ++i) {
-        const float tw = (i < bin ? g_cw_lo : 0.0f) + (i <= bin ? g_cw_hi : 0.0f) - base_w;
-        const float th = (i < bin ? g_ch_lo : 0.0f) + (i <= bin ? g_ch_hi : 0.0f) - base_h;
-        g[i] = inside ? fw * (ew[i] * rsw) * tw : 0.0f;
-        g[F_K + i] = inside ? fh * (eh[i] * rsh) * th : 0.0f;
-    }
-    const float s0 = dl0 > 20.0f ? 1.0f : sigmoid(dl0), s1 = dl1 > 20.0f ? 1.0f : sigmoid(dl1);
-#pragma unroll
-    for (int k = 0; k < F_K - 1; ++k) {
-        const float a = (bin == k + 1 ? gv[5] * s0 : 0.0f) + (bin == k ? gv[6] * s1 : 0.0f);
-        g[2 * F_K + k] = inside ? a : 0.0f;
-    }
-    g[F_M] = 0.0f;
-    return inside ? gv[0] : gy_up;
-}
 
 // Wave-private tiles (as rqs_coupling_wave_kernel): SPW samples per pass; conditioner rows in, gradient rows out through
 // the wave's own LDS region with unit-stride global accesses, x / grad_y rows staged, gx rows written whole.  The shared

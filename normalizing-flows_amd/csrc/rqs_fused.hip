@@ -819,8 +819,8 @@ struct PackAllArgs {
     const float *w_blk[32], *b_blk[32];
     int nblk;
     // optional by-products for the backward (all three or none): the initial weight TRANSPOSED on full rows (64, hidden; only the
-    // identity features' rows are written, the rest of the caller's buffer stays zero) and the final weight in 24-row groups
-    // (32, 24, hidden; row 23 of a group stays zero)
+    // identity features' rows are written, the rest of the caller's buffer stays zero) and the final weight as the 24 A-operand
+    // stages of nf_final_bwd (32 x 24 x hidden floats: the buffer round 2 filled with 24-row groups for a library GEMM)
     float *wfull, *wpad;
     const int64_t *iidx;
 };
@@ -851,9 +851,13 @@ __device__ __forceinline__ void pack_all_body(const PackAllArgs &a, float *__res
     }
     if (a.wfull) {
         for (int64_t i = tid0; i < F_H * F_NI; i += nth) a.wfull[a.iidx[i & 31] * F_H + (i >> 5)] = a.w_init[i];
-        for (int64_t i = tid0; i < (int64_t)F_NI * 23 * F_H; i += nth) {
-            const int h = (int)(i & (F_H - 1)), row = (int)(i >> 7), t = row / 23;
-            a.wpad[(int64_t)(row + t) * F_H + h] = a.w_final[i];
+        // the final weight as the A operand of the backward's gh = g W_final (final_bwd.hip): 24 stages [q][unit block mb][lane][4],
+        // step (rb, reg = 4 q + r) of group g contracts over the final rows its two lane-halves hold, raw scale
+        for (int64_t i = tid0; i < (int64_t)24 * F_STAGE; i += nth) {
+            const int st = (int)(i >> 12), j = (int)(i & (F_STAGE - 1));
+            const int r4 = j & 3, lane = (j >> 2) & 63, mb = (j >> 8) & 3, q = j >> 10;
+            const int row = final_row(st / 3, st % 3, 8 * q + 4 * (lane >> 5) + r4);
+            a.wpad[i] = row >= 0 ? a.w_final[row * F_H + 32 * mb + (lane & 31)] : 0.0f;
         }
     }
     const int nbias = 128 + 128 * nlin + 768;

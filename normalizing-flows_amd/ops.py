@@ -669,6 +669,32 @@ def rqs_coupling_bwd_p24(x, grad_y, grad_logdet, cond24, uw, uh, ud, identity_id
     return gx, gcond, guw, guh, gud
 
 
+def final_bwd(x, grad_y, grad_logdet, cond24, w_t, blob, uw, uh, ud, mask_parity, num_blocks, tail_bound=3.0, min_bin_width=1e-3,
+              min_bin_height=1e-3, min_derivative=1e-3):
+    """(gx, gcond24, gh, guw, guh, gud) of nf_final_bwd + nf_final_bwd_reduce: the coupling transform's backward and the final
+    Linear's input gradient in one pass over the rows; the batch-shared parameters' gradients by a fixed-order reduction."""
+    L.require_device(x, grad_y, grad_logdet, cond24, w_t, blob, uw, uh, ud)
+    B = x.shape[0]
+    x, grad_y, grad_logdet = x.contiguous(), grad_y.contiguous(), grad_logdet.contiguous()
+    gx = torch.empty_like(x)
+    gcond = torch.empty_like(cond24)
+    gh = torch.empty(B, 128, dtype=x.dtype, device=x.device)
+    lib = L.lib()
+    nparts = lib.nf_final_bwd_partials(i64(B))
+    part = torch.empty(max(nparts, 1) * 768, dtype=x.dtype, device=x.device)
+    gz = torch.empty(uw.numel() + uh.numel() + ud.numel(), dtype=uw.dtype, device=uw.device)
+    nw, nh = uw.numel(), uh.numel()
+    guw, guh, gud = gz[:nw].view_as(uw), gz[nw:nw + nh].view_as(uh), gz[nw + nh:].view_as(ud)
+    kw = (f64(tail_bound), f64(min_bin_width), f64(min_bin_height), f64(min_derivative))
+    rc = lib.nf_final_bwd(ptr(x), ptr(grad_y), ptr(grad_logdet), ptr(cond24), ptr(w_t), ptr(blob), ptr(gx), ptr(gcond), ptr(gh),
+                          ptr(part), i32(mask_parity), i64(B), i32(64), i32(128), i32(num_blocks), i32(8), *kw, L.stream())
+    L.check(rc, "nf_final_bwd")
+    rc = lib.nf_final_bwd_reduce(ptr(part), i32(nparts), ptr(uw.contiguous()), ptr(uh.contiguous()), ptr(ud.contiguous()), ptr(guw),
+                                 ptr(guh), ptr(gud), i32(8), *kw, L.stream())
+    L.check(rc, "nf_final_bwd_reduce")
+    return gx, gcond, gh, guw, guh, gud
+
+
 # ---- bf16x3 (error-compensated split-bf16 MFMA) variant of the fused layer ----------------------------------------
 def rqs_fused_x3_pack(f32_blob, num_blocks, has_lu, nI=32, nT=32, hidden=128, K=8):
     """Derive the split-bf16 weight blob from an rqs_fused_pack blob of the same layer (nf_rqs_fused_x3_pack)."""

@@ -21,6 +21,7 @@ ap.add_argument("--no-matvec2", action="store_true", help="ablation: LULinearPer
 ap.add_argument("--no-train-full", action="store_true", help="ablation: per-module Functions instead of the whole-layer forward launch")
 ap.add_argument("--no-resblock-bwd", action="store_true", help="ablation: residual-block backward as separate kernels")
 ap.add_argument("--no-lu-bwd", action="store_true", help="ablation: LULinearPermute's backward as separate kernels")
+ap.add_argument("--no-final-bwd", action="store_true", help="ablation: stand-alone spline backward + library GEMM instead of nf_final_bwd")
 ap.add_argument("--no-prepack", action="store_true", help="ablation: every layer packs its own weights / LU factors (2 x 32 launches)")
 ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the default foreach implementation")
 a = ap.parse_args()
@@ -33,6 +34,9 @@ if a.no_resblock_bwd:
 if a.no_lu_bwd:
     import normflows_amd
     normflows_amd.config.set_lu_bwd_fused(False)
+if a.no_final_bwd:
+    import normflows_amd
+    normflows_amd.config.set_final_bwd_fused(False)
 if a.no_prepack:
     import normflows_amd
     normflows_amd.config.set_train_prepack(False)
