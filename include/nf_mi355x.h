@@ -210,8 +210,9 @@ int nf_rqs_fused_train_fwd(const void *x, const void *h2, void *y, void *logdet,
  * nf_rqs_fused_pack without the LU).  D = 64, hidden = 128, K = 8, linear tails.  wfull / wpad / identity_idx (all or none): the
  * same launch also leaves the initial weight transposed on full rows (64, hidden; the identity features' rows written, the caller
  * keeps the rest zero) and, in `wpad` (32 x 24 x hidden floats), the final weight as the 24 A-operand stages nf_final_bwd streams
- * (w_t: stage 3 g + rb = [q][unit block mb][lane][4]; MFMA step (rb, reg = 4 q + r) of group g contracts over the final rows
- * nf_rqs_fused_final_row(8, g, rb, 8 q + 4 hh + r), raw scale, zero for padding rows). */
+ * (w_t: stage 3 g + rb = [k-step vv (8)][unit-block quad uq (2)][lane (64)][4]: lane (m = lane & 15, hq = lane >> 4) holds
+ * W_final[(8 (g >> 1) + 4 (hq >> 1) + 2 (g & 1) + (hq & 1)) * 23 + 8 rb + vv][16 (4 uq + j) + m], raw scale, zero for the pad
+ * step 8 rb + vv = 23: the A operand of v_mfma_f32_16x16x4_f32 whose four k-entries are the group's four transform features). */
 int nf_rqs_fused_pack_all(void *wpack, const void *w_init, const void *b_init, const void *const *w_blocks,
                           const void *const *b_blocks, const void *w_final, const void *b_final, const void *uw, const void *uh,
                           const void *ud, int hidden, int num_blocks, int K, double tail_bound, double min_bin_width,

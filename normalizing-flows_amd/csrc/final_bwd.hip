@@ -1,45 +1,53 @@
 // final_bwd.hip -- backward of a benchmark-shaped NSF coupling layer's LAST stage in one pass over the rows: the coupling
 // transform's backward (nsf/coupling.py:83-98 + utils/splines.py:16-219 under `loss.backward()`, core.py:87-102) AND the
-// input gradient of the conditioner's final Linear (nets/resnet.py:104), gh = g_cond W_final, as the mirror image of the fused
-// forward (rqs_fused.hip): the 736-wide gradient rows are produced group by group on the vector ALU in exactly the register
-// layout in which the forward's MFMAs produced the parameters, and go straight into the MFMAs of gh as their B operand.
+// input gradient of the conditioner's final Linear (nets/resnet.py:104), gh = g_cond W_final: the 736-wide gradient rows are
+// produced group by group on the vector ALU and go straight from the registers they were computed in into the MFMAs of gh.
 //
 // Replaces (round 2): nf_rqs_coupling_bwd_p24 (125 us, HBM-bound) + a library GEMM (`Cijk_*`, 104 us) that re-read the 201 MB of
 // gradient rows.  Here they are written once (for the final layer's weight gradient, nf_linear_wgrad_skip) and never read back.
 //
-// Mapping (4 waves x 32 rows per workgroup tile, persistent over tiles, ONE wave per SIMD = 512 registers):
-//   lane l: row (l & 31) of the wave, lane-half hh = l >> 5 owns columns [16 Q + 8 hh, +8), Q = 0..3, of its row = "slots"
-//   c = 8 Q + column-in-chunk (as in the forward); x / grad_y rows sit in a per-wave LDS stash [slot][65], lane position
-//   33 hh + row: conflict-free for lane = row AND for lane = feature accesses.
-//   1. identity half (batch-shared spline, nsf/coupling.py:88-92): lane = identity feature (x 2 row parities); the feature's
-//      knot table (27 floats, from the packed blob) lives in registers for the whole launch; per row only the bin search and
-//      the closed-form bin evaluation's partials -- the gradient is accumulated in KNOT space (7 + 7 + 7 register sums by
-//      select-accumulate) and taken through the softmax / cumulative-sum / softplus chain ONCE per launch by
-//      nf_final_bwd_reduce (linear in the knot gradients).  Round 2 repeated that chain per row: 44 us of a 157 us kernel.
-//      Deterministic: per-workgroup partial sums added in a fixed order, no atomics.
-//   2. transform half, per final-layer group g (4 features x 24 rows of W_final): the lane reads its two features'
-//      24-float parameter rows (192 contiguous bytes; next group's prefetched under this group's MFMAs), runs the register
-//      spline backward (rqs_regs_bwd) twice and stores the two gradient rows; gradient value v = 16 rb + reg of the lane is
-//      the B operand of MFMA step (rb, reg): gh^T[unit, row] += W_t[unit][final row (g, rb, 8 (reg >> 2) + 4 hh + (reg & 3))]
-//      g[...]; the A operand streams through a 2-slot LDS ring from the transposed stage image the per-step pack leaves
-//      (24 stages of 16 KB: [q][unit block mb][lane][4 steps]).  192 MFMAs per group into 4 x 16 accumulators.
-//   3. gh rows leave through a per-wave transpose tile (full 128-byte pieces), gx rows from the stash.
+// Mapping (second version).  The first version mirrored the forward kernel -- 32 rows per wave on v_mfma_f32_32x32x2_f32, a lane
+// owning TWO spline elements per group -- and needed 400+ registers: one wave per SIMD, and with nobody to share the SIMD with
+// every LDS round trip, every vector-memory issue (~100-250 cycles each) and every dependent transcendental was exposed: the
+// phase trace (tools/final_bwd_probe.py --trace) showed the spline arithmetic at ~7 cycles per instruction and the MFMAs at 0.78
+// of their issue rate, 250-265 us per launch (ablations were additive to the microsecond: nothing overlapped).  This version is
+// built for TWO waves per SIMD:
+//   * a wave owns 16 rows and multiplies on v_mfma_f32_16x16x4_f32: lane l = (row n = l & 15, quarter hq = l >> 4); the MFMA's
+//     four k-entries are the four transform features of a final-layer group, so a lane owns exactly ONE spline element per group
+//     (feature tf = 8 (g >> 1) + 4 (hq >> 1) + 2 (g & 1) + (hq & 1), its 24-float parameter row = 96 contiguous bytes) and its 24
+//     gradient values are the B operands of the group's 24 k-steps; 8 unit blocks x 4 accumulator registers hold gh of the row.
+//     32 + 24 + the spline routine's temporaries fit in 256 registers.
+//   * 8 waves per workgroup tile of 128 rows, persistent over tiles; the A operand (final weight, transposed roles) streams through
+//     the forward's 2-slot LDS ring from the image the per-step pack leaves: 24 stages [k-step vv][unit-block quad][lane][4].
+//   * x / grad_y rows sit row-major in a per-wave LDS stash (coalesced 16-byte loads, pitch 68); parameter rows come in and
+//     gradient rows leave through a per-wave 6 KB piece buffer with 7 coalesced instructions each way (a lane's own 96 bytes
+//     would be 64 different lines per instruction).
+//   * identity half (batch-shared spline, nsf/coupling.py:88-92): lane = identity feature (x 2 row parities) over the wave's 16
+//     rows; the feature's knot table comes from the packed blob; per row only the bin search and the reverse-mode VJP of the
+//     closed-form bin evaluation -- the gradient is accumulated in KNOT space (7 + 7 + 7 register sums by select-accumulate) and
+//     taken through the softmax / cumulative-sum / softplus chain ONCE per launch by nf_final_bwd_reduce (it is linear in the knot
+//     gradients).  Deterministic: per-workgroup partial sums added in a fixed order, no atomics.
 // Per row: reads 256 + 256 + 4 + 3072 B, writes 256 + 3072 + 512 B; 2 x 768 x 128 FLOP on fp32 MFMA + the spline backward
-// on the same vector ALU (bound: MFMA + VALU time, ~80 + ~60 us at B = 65 536).
+// on the same vector ALU (bound: MFMA + VALU time).
 #include "rqs_bwd_common.hpp"
+#include <type_traits>
 
 namespace nf {
 
-#define FB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+#define FB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-constexpr int FB_NW = 4;
+constexpr int FB_NW = 8;                          // waves per workgroup
 constexpr int FB_THREADS = 64 * FB_NW;
-constexpr int FB_ROWS = 32 * FB_NW;
-constexpr int FB_P = 65;                          // floats per stash slot (33 hh + row < 65)
-constexpr int FB_PLANE = 32 * FB_P;               // one plane (x or grad_y / grad_x) of a wave: 32 slots
-constexpr int FB_WAVE = 2 * FB_PLANE + 32 + 64 * 48;   // + the rows' grad_logdet + the piece buffer of the parameter / gradient rows
+constexpr int FB_WR = 16;                         // rows per wave
+constexpr int FB_ROWS = FB_WR * FB_NW;            // 128 rows per tile
+constexpr int FB_P = 68;                          // stash row pitch (floats): 16-byte aligned rows
+constexpr int FB_PLANE = FB_WR * FB_P;            // one plane (x or grad_y / grad_x) of a wave
+constexpr int FB_CS = FB_WR * 4 * 24;             // piece buffer: [row][quarter][24] = the group's parameter / gradient rows of the wave
+constexpr int FB_WAVE = 2 * FB_PLANE + FB_WR + FB_CS;
 constexpr int FB_NST = 24;                        // stages of the transposed final weight
 constexpr int FB_PART = F_NI * 24;                // knot-space sums of a workgroup: [feature][7 w | 7 h | 7 d | 3 pad]
+constexpr int FB_NI = 7;                          // coalesced instructions per direction for the 32 runs of 192 bytes of a group
 
 #ifdef FB_TRACE      // phase trace (tools/final_bwd_probe.py --trace): shader-clock cycles per phase, summed over the tiles of workgroup 0 / wave 0
 static unsigned long long *g_fb_trace = nullptr;
@@ -65,22 +73,14 @@ final_bwd_kernel(FinalBwdArgs a) {
     typedef __attribute__((address_space(3))) void *lds_ptr;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *ring = smem;                                    // 2 x F_STAGE
-    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5, srow = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, hq = lane >> 4, n = lane & 15;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float *X = ring + 2 * F_STAGE + wid * FB_WAVE, *G = X + FB_PLANE, *GL = G + FB_PLANE, *CS = GL + 32;
+    float *X = ring + 2 * F_STAGE + wid * FB_WAVE, *G = X + FB_PLANE, *GL = G + FB_PLANE, *CS = GL + FB_WR;
     const RqsParams<float> p = a.p;
     const int par_t = a.parity ? 0 : 1, par_i = par_t ^ 1;
-    const int soff = 33 * hh + srow;                       // lane = row: position inside a slot
-    // lane = identity feature fj (slot 8 Q + 2 r + par_i of lane-half fhh), rows of parity sp
+    // lane = identity feature fj (column 2 fj + par_i), rows of parity sp
     const int fj = lane & 31, sp = lane >> 5;
-    const int foff = (8 * (fj >> 3) + 2 * (fj & 3) + par_i) * FB_P + 33 * ((fj >> 2) & 1);
-    float kw[F_K + 1], kh[F_K + 1], kd[F_K + 1];
-#pragma unroll
-    for (int k = 0; k <= F_K; ++k) {
-        kw[k] = a.tables[fj * F_TABW + k];
-        kh[k] = a.tables[fj * F_TABW + (F_K + 1) + k];
-        kd[k] = a.tables[fj * F_TABW + 2 * (F_K + 1) + k];
-    }
+    const int fcol = 2 * fj + par_i;
     float Gw[F_K - 1], Gh[F_K - 1], Gd[F_K - 1];
 #pragma unroll
     for (int k = 0; k < F_K - 1; ++k) Gw[k] = Gh[k] = Gd[k] = 0.0f;
@@ -92,16 +92,17 @@ final_bwd_kernel(FinalBwdArgs a) {
     int stage = 0;
     auto issue = [&](int gs) {
         const int s = gs % FB_NST;
-        const float *src = a.wt + (size_t)s * F_STAGE + wid * 1024 + lane * 4;
-        float *dst = ring + (gs & 1) * F_STAGE + wid * 1024;
+        const float *src = a.wt + (size_t)s * F_STAGE + wid * 512 + lane * 4;
+        float *dst = ring + (gs & 1) * F_STAGE + wid * 512;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(src + i * 256, (lds_ptr)(dst + i * 256), 16, 0, 0);
+        for (int i = 0; i < 2; ++i) __builtin_amdgcn_global_load_lds(src + i * 256, (lds_ptr)(dst + i * 256), 16, 0, 0);
     };
     // 2-slot ring: stage s has landed for every wave; stage s + 1 is requested into the slot stage s - 1 just left.  `after`:
     // vector-memory operations this wave issued AFTER the requests of stage s (they retire in order, so they may stay in flight)
     auto acquire = [&](int after) -> const float * {
-        if (after == 26) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
-        else if (after == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+        if (after == 2 * FB_NI + 9) asm volatile("s_waitcnt vmcnt(23)" ::: "memory");
+        else if (after == 2 * FB_NI) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        else if (after == FB_NI) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (stage + 1 < total_stages) issue(stage + 1);
@@ -111,241 +112,235 @@ final_bwd_kernel(FinalBwdArgs a) {
     };
     if (total_stages > 0) issue(0);
 
-    // Row traffic (the 24-float parameter rows in, the gradient rows out): a lane's two features of a group are 192 contiguous
-    // bytes of ITS row -- as per-lane 16-byte accesses every instruction touches 64 different lines (first version: the row
-    // operations cost 80 us of a 264 us launch, nothing of it hidden).  Instead the wave moves its 64 pieces (32 rows x 2
-    // lane-halves) through a 12 KB LDS buffer `CS` with 13 coalesced instructions each way: instruction i, lane l handles 16-byte
-    // chunk l % 12 of piece 5 i + l / 12 (5 pieces = 10 lines per instruction); in LDS the pieces are contiguous (48 floats each),
-    // which is exactly the LDS-DMA's lane order.  Piece 2 row + hh belongs to lane (row, hh).
+    // Row traffic: the wave's 32 runs of 192 bytes per group (16 rows x 2 feature pairs) with 7 coalesced instructions each way:
+    // instruction i, lane l handles 16-byte chunk l % 12 of run 5 i + l / 12; in LDS the runs are contiguous (48 floats each:
+    // [row][quarter][24] is exactly that order), which is the LDS-DMA's lane order.
     const int l12 = lane / 12, lq = lane - 12 * l12;
-    unsigned poff[13];       // float offset of this lane's chunk of instruction i inside the wave's 32 rows (group 0)
+    unsigned poff[FB_NI];    // float offset of this lane's chunk of instruction i inside the wave's 16 rows (group 0)
 #pragma unroll
-    for (int i = 0; i < 13; ++i) {
-        const int pi = 5 * i + l12;
-        poff[i] = (unsigned)((pi >> 1) * (F_NI * 24) + (pi & 1) * 96 + 4 * lq);
+    for (int i = 0; i < FB_NI; ++i) {
+        const int ri = 5 * i + l12;
+        poff[i] = (unsigned)((ri >> 1) * (F_NI * 24) + (ri & 1) * 96 + 4 * lq);
     }
     auto piece_ok = [&](int i, int64_t row0_) -> bool {
-        const int pi = 5 * i + l12;
-        return lane < 60 && pi < 64 && row0_ + (pi >> 1) < a.B;
+        const int ri = 5 * i + l12;
+        return lane < 60 && ri < 2 * FB_WR && row0_ + (ri >> 1) < a.B;
     };
     auto group_off = [&](int g, int64_t row0_) -> int64_t { return row0_ * (int64_t)(F_NI * 24) + (8 * (g >> 1) + 2 * (g & 1)) * 24; };
     auto request_rows = [&](int g, int64_t row0_) {
         const float *base = a.cond + group_off(g, row0_);
 #pragma unroll
-        for (int i = 0; i < 13; ++i)
+        for (int i = 0; i < FB_NI; ++i)
             if (piece_ok(i, row0_)) __builtin_amdgcn_global_load_lds(base + poff[i], (lds_ptr)(CS + 240 * i), 16, 0, 0);
     };
 
 #ifdef FB_TRACE
     unsigned long long T_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0_ = clock64();
 #endif
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t row0 = tile * FB_ROWS + wid * 32;
-        const int64_t row = row0 + srow;
-        const bool valid = row < a.B;
-        const bool full = __builtin_amdgcn_readfirstlane((tile + 1) * FB_ROWS <= a.B ? 1 : 0) != 0;   // every row of the tile exists
-        request_rows(0, row0);
-        // ---- rows -> stash (rows beyond the batch: x outside the interval, zero cotangents: every gradient is zero) ----
+    // the NEXT tile's x / grad_y rows (and its first group's parameter rows) are requested under the last group's MFMA stages of
+    // the current one, where few registers are live: a tile used to start with every wave of the chip waiting ~10 us for 8 KB
+    f32x4 nx[4], ng[4];
+    float ngl = 0.0f;
+    auto fetch_rows = [&](int64_t row0_) {
 #pragma unroll
-        for (int Q = 0; Q < 4; ++Q) {
-            f32x4 xa = {1e30f, 1e30f, 1e30f, 1e30f}, xb = xa, ga = {0.f, 0.f, 0.f, 0.f}, gb = ga;
-            if (valid) {
-                const float *xs = a.x + row * F_D + 16 * Q + 8 * hh, *gs = a.gy + row * F_D + 16 * Q + 8 * hh;
-                xa = *reinterpret_cast<const f32x4 *>(xs);
-                xb = *reinterpret_cast<const f32x4 *>(xs + 4);
-                ga = *reinterpret_cast<const f32x4 *>(gs);
-                gb = *reinterpret_cast<const f32x4 *>(gs + 4);
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                X[(8 * Q + c) * FB_P + soff] = xa[c];
-                X[(8 * Q + 4 + c) * FB_P + soff] = xb[c];
-                G[(8 * Q + c) * FB_P + soff] = ga[c];
-                G[(8 * Q + 4 + c) * FB_P + soff] = gb[c];
+        for (int i = 0; i < 4; ++i) {
+            const int idx = lane + 64 * i, r = idx >> 4, c4 = idx & 15;
+            nx[i] = f32x4{1e30f, 1e30f, 1e30f, 1e30f};
+            ng[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row0_ + r < a.B) {
+                nx[i] = *reinterpret_cast<const f32x4 *>(a.x + (row0_ + r) * F_D + 4 * c4);
+                ng[i] = *reinterpret_cast<const f32x4 *>(a.gy + (row0_ + r) * F_D + 4 * c4);
             }
         }
-        const float gl = valid ? a.gld[row] : 0.0f;
-        if (hh == 0) GL[srow] = gl;
+        ngl = row0_ + n < a.B ? a.gld[row0_ + n] : 0.0f;
+    };
+    if (blockIdx.x < ntiles) {
+        request_rows(0, (int64_t)blockIdx.x * FB_ROWS + wid * FB_WR);
+        fetch_rows((int64_t)blockIdx.x * FB_ROWS + wid * FB_WR);
+    }
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * FB_ROWS + wid * FB_WR;
+        const int64_t next_tile = tile + gridDim.x;
+        const bool has_next = next_tile < ntiles;
+        const int64_t next_row0 = next_tile * FB_ROWS + wid * FB_WR;
+        // every row of this tile exists (and of the next one, whose prefetch rides in the counted waits)
+        const bool full = __builtin_amdgcn_readfirstlane(((tile + 1) * FB_ROWS <= a.B && (!has_next || (next_tile + 1) * FB_ROWS <= a.B)) ? 1 : 0) != 0;
+        // ---- the wave's 16 rows of x / grad_y -> stash, row-major (rows beyond the batch: x outside the interval, zero cotangents:
+        // every gradient is zero) ----
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = lane + 64 * i, r = idx >> 4, c4 = idx & 15;
+            *reinterpret_cast<f32x4 *>(X + r * FB_P + 4 * c4) = nx[i];
+            *reinterpret_cast<f32x4 *>(G + r * FB_P + 4 * c4) = ng[i];
+        }
+        const float gl = ngl;
+        if (hq == 0) GL[n] = gl;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-
         FB_T(0);      // tile prologue: requests, x / grad_y rows into the stash
-        // ---- identity half: lane = feature, the wave's 32 rows two at a time ----
+
+        // ---- identity half: lane = feature, the wave's 16 rows two at a time ----
 #ifndef FB_ABL_NOIDENT
-#pragma nounroll
-        for (int it = 0; it < 16; ++it) {
-            const int s = 2 * it + sp;
-            const float xv = X[foff + s], gyv = G[foff + s], glv = GL[s];
-            const bool inside = xv >= p.left && xv <= p.right;
-            int bin = 0;
-            float xlo = kw[0], xhi = kw[1], ylo = kh[0], yhi = kh[1], d0 = kd[0], d1 = kd[1];
+        {
+            float kw[F_K + 1], kh[F_K + 1], kd[F_K + 1];
 #pragma unroll
-            for (int k = 1; k < F_K; ++k) {
-                const bool ge = xv >= kw[k];
-                bin = ge ? k : bin;
-                xlo = ge ? kw[k] : xlo; xhi = ge ? kw[k + 1] : xhi;
-                ylo = ge ? kh[k] : ylo; yhi = ge ? kh[k + 1] : yhi;
-                d0 = ge ? kd[k] : d0; d1 = ge ? kd[k + 1] : d1;
+            for (int k = 0; k <= F_K; ++k) {
+                kw[k] = a.tables[fj * F_TABW + k];
+                kh[k] = a.tables[fj * F_TABW + (F_K + 1) + k];
+                kd[k] = a.tables[fj * F_TABW + 2 * (F_K + 1) + k];
             }
-            float gv[7];
-            rqs_eval_bin_vjp(xv, xlo, xhi, ylo, yhi, d0, d1, gyv, glv, gv);
+#pragma nounroll
+            for (int it = 0; it < FB_WR / 2; ++it) {
+                const int s = 2 * it + sp;
+                const float xv = X[s * FB_P + fcol], gyv = G[s * FB_P + fcol], glv = GL[s];
+                const bool inside = xv >= p.left && xv <= p.right;
+                int bin = 0;
+                float xlo = kw[0], xhi = kw[1], ylo = kh[0], yhi = kh[1], d0 = kd[0], d1 = kd[1];
 #pragma unroll
-            for (int i = 0; i < 7; ++i) gv[i] = inside ? gv[i] : 0.0f;
-            G[foff + s] = inside ? gv[0] : gyv;
+                for (int k = 1; k < F_K; ++k) {
+                    const bool ge = xv >= kw[k];
+                    bin = ge ? k : bin;
+                    xlo = ge ? kw[k] : xlo; xhi = ge ? kw[k + 1] : xhi;
+                    ylo = ge ? kh[k] : ylo; yhi = ge ? kh[k + 1] : yhi;
+                    d0 = ge ? kd[k] : d0; d1 = ge ? kd[k + 1] : d1;
+                }
+                float gv[7];
+                rqs_eval_bin_vjp(xv, xlo, xhi, ylo, yhi, d0, d1, gyv, glv, gv);
 #pragma unroll
-            for (int k = 1; k < F_K; ++k) {       // knot k is the bin's lower knot when bin == k, its upper knot when bin == k - 1
-                const bool lo = bin == k, hi = bin == k - 1;
-                Gw[k - 1] += (lo ? gv[1] : 0.0f) + (hi ? gv[2] : 0.0f);
-                Gh[k - 1] += (lo ? gv[3] : 0.0f) + (hi ? gv[4] : 0.0f);
-                Gd[k - 1] += (lo ? gv[5] : 0.0f) + (hi ? gv[6] : 0.0f);
+                for (int i = 0; i < 7; ++i) gv[i] = inside ? gv[i] : 0.0f;
+                G[s * FB_P + fcol] = inside ? gv[0] : gyv;
+#pragma unroll
+                for (int k = 1; k < F_K; ++k) {       // knot k is the bin's lower knot when bin == k, its upper knot when bin == k - 1
+                    const bool lo = bin == k, hi = bin == k - 1;
+                    Gw[k - 1] += (lo ? gv[1] : 0.0f) + (hi ? gv[2] : 0.0f);
+                    Gh[k - 1] += (lo ? gv[3] : 0.0f) + (hi ? gv[4] : 0.0f);
+                    Gd[k - 1] += (lo ? gv[5] : 0.0f) + (hi ? gv[6] : 0.0f);
+                }
             }
         }
 #endif
-
         FB_T(1);      // identity half
+
         // ---- transform half + gh = g W_final, group by group ----
-        f32x16 acc0, acc1, acc2, acc3;
+        f32x4a acc[8];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) acc0[c] = acc1[c] = acc2[c] = acc3[c] = 0.0f;
-        float *mine = CS + (2 * srow + hh) * 48;      // this lane's piece
-#pragma nounroll
-        for (int g = 0; g < F_K; ++g) {
-            // the group's parameter rows have landed (requested a whole group ago; everything younger may stay in flight: nothing is)
+        for (int ub = 0; ub < 8; ++ub) acc[ub] = f32x4a{0.f, 0.f, 0.f, 0.f};
+        float *mine = CS + (4 * n + hq) * 24;      // this lane's piece: the parameter row of its feature, then its gradient row
+        // (the last group is peeled: only there the next tile's rows are requested into registers, which then are live from that
+        // point to the next prologue instead of through every group's spline arithmetic)
+        auto group = [&](int g, auto last_c) __attribute__((always_inline)) {
+            constexpr bool LAST = decltype(last_c)::value;
+            // the group's parameter rows have landed (requested at least two stages ago)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             FB_T(2);  // wait for the group's parameter rows
-            float gcat[48];
+            float gq[24];
             {
-                float prm[2][24], gf[2][24], xt[2], gyt[2], gxt[2];
-                int so[2];
+                float prm[24];
 #pragma unroll
-                for (int f = 0; f < 2; ++f) {
+                for (int q = 0; q < 6; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(mine + 4 * q);
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) {
-                        const f32x4 v = *reinterpret_cast<const f32x4 *>(mine + 24 * f + 4 * q);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int k = 4 * q + r;
-                            prm[f][k] = k < 2 * F_K ? v[r] * sc : (k < F_M ? v[r] : 0.0f);
-                        }
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = 4 * q + r;
+                        prm[k] = k < 2 * F_K ? v[r] * sc : (k < F_M ? v[r] : 0.0f);
                     }
-                    so[f] = (8 * (g >> 1) + 2 * (2 * (g & 1) + f) + par_t) * FB_P + soff;
-                    xt[f] = X[so[f]];
-                    gyt[f] = G[so[f]];
                 }
+                const int so = n * FB_P + 2 * (8 * (g >> 1) + 4 * (hq >> 1) + 2 * (g & 1) + (hq & 1)) + par_t;
+                const float xt = X[so], gyt = G[so];
 #ifdef FB_ABL_NOSPLINE
+                G[so] = xt + gyt;
 #pragma unroll
-                for (int f = 0; f < 2; ++f) {
-                    gxt[f] = xt[f] + gyt[f];
-#pragma unroll
-                    for (int k = 0; k < 24; ++k) gf[f][k] = prm[f][k] * gyt[f];
-                }
+                for (int k = 0; k < 24; ++k) gq[k] = prm[k] * gyt;
 #else
-                rqs_regs_bwd_pair(p, xt, prm, gyt, gl, gf, inv_div, gxt);
+                G[so] = rqs_regs_bwd<false>(p, xt, prm, gyt, gl, gq, inv_div);
 #endif
-#pragma unroll
-                for (int f = 0; f < 2; ++f) {
-                    G[so[f]] = gxt[f];
-#pragma unroll
-                    for (int k = 0; k < 24; ++k) gcat[24 * f + k] = gf[f][k];
-                }
             }
-            // gradient rows -> the lane's piece (over the parameters it has just read)
+            // gradient row -> the lane's piece (over the parameters it has just read)
 #pragma unroll
-            for (int q = 0; q < 12; ++q)
-                *reinterpret_cast<f32x4 *>(mine + 4 * q) = f32x4{gcat[4 * q], gcat[4 * q + 1], gcat[4 * q + 2], gcat[4 * q + 3]};
+            for (int q = 0; q < 6; ++q)
+                *reinterpret_cast<f32x4 *>(mine + 4 * q) = f32x4{gq[4 * q], gq[4 * q + 1], gq[4 * q + 2], gq[4 * q + 3]};
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            FB_T(3);  // two spline backward elements + the piece write
-            // Row traffic: one burst per group right behind stage 0's acquire (13 coalesced gradient-row stores, 13 requests of the
+            FB_T(3);  // the spline backward element + the piece write
+            // Row traffic: one burst per group right behind stage 0's acquire (7 coalesced gradient-row stores, 7 requests of the
             // next group's parameter rows); they retire in order behind stage 1's requests, so they may stay in flight at its acquire.
-            // (Measured and dropped: the same 26 instructions spread one per four-MFMA slot over stages 0 and 1 -- the burst's 53 k
-            // cycles disappeared and 63 k came back inside the MFMA streams and at the stage barriers: with one wave per SIMD every
-            // vector-memory instruction costs the wave ~100-250 issue cycles wherever it stands.)
-            const bool more = g + 1 < F_K;
+            constexpr bool more = !LAST;
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) {
-                const float *buf = acquire((rb == 1 && full) ? (more ? 26 : 13) : 0);
+                const float *buf = acquire((rb == 1 && full) ? (more ? 2 * FB_NI : (has_next ? 2 * FB_NI + 9 : FB_NI)) : 0);
                 FB_T(4);  // stage wait + barrier + next stage's requests
                 if (rb == 0) {
 #ifndef FB_ABL_NOROWS
                     float *gbase = a.gcond + group_off(g, row0);
 #pragma unroll
-                    for (int i = 0; i < 13; ++i) {
-                        const f32x4 v = *reinterpret_cast<const f32x4 *>(CS + 240 * i + 4 * lane);
-                        if (piece_ok(i, row0)) *reinterpret_cast<f32x4 *>(gbase + poff[i]) = v;
+                    for (int i = 0; i < FB_NI; ++i) {
+                        if (piece_ok(i, row0))
+                            *reinterpret_cast<f32x4 *>(gbase + poff[i]) = *reinterpret_cast<const f32x4 *>(CS + 240 * i + 4 * lane);
                     }
                     // (the reads above are complete before the next group's parameters may overwrite the buffer)
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_wave_barrier();
-                    if (more) request_rows(g + 1, row0);
+                    if constexpr (more) request_rows(g + 1, row0);
+                    else if (has_next) {
+                        request_rows(0, next_row0);
+                        fetch_rows(next_row0);
+                    }
 #endif
                     FB_T(5);  // gradient-row stores + the next group's requests
                 }
 #ifndef FB_ABL_NOMFMA
-                f32x4 w4[16];        // the stage's A operands up front: one wave per SIMD has nobody to hide LDS latency behind
+                // stage rb: k-steps v = 8 rb .. 8 rb + 7 (B operand = the lane's gradient value v), 8 unit blocks each
 #pragma unroll
-                for (int i = 0; i < 16; ++i) w4[i] = *reinterpret_cast<const f32x4 *>(buf + (i * 64 + lane) * 4);
-                __builtin_amdgcn_sched_barrier(0);      // (left alone the scheduler sinks every read to its first use and waits for it there)
+                for (int vv = 0; vv < 8; ++vv) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                    for (int uq = 0; uq < 2; ++uq) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4 *>(buf + ((vv * 2 + uq) * 64 + lane) * 4);
 #pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) {
-                        f32x16 &acc = mb == 0 ? acc0 : (mb == 1 ? acc1 : (mb == 2 ? acc2 : acc3));
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc = FB_MFMA(w4[q * 4 + mb][r], gcat[16 * rb + 4 * q + r], acc);
+                        for (int j = 0; j < 4; ++j) acc[4 * uq + j] = FB_MFMA(w4[j], gq[8 * rb + vv], acc[4 * uq + j]);
                     }
                 }
 #else
                 (void)buf;
 #pragma unroll
-                for (int v = 0; v < 16; ++v) acc0[v] += gcat[16 * rb + v];
+                for (int v = 0; v < 8; ++v) acc[v][0] += gq[8 * rb + v];
 #endif
-                asm volatile("" ::"v"(acc0[0]), "v"(acc1[0]), "v"(acc2[0]), "v"(acc3[0]));
+                asm volatile("" ::"v"(acc[0][0]), "v"(acc[7][0]));
                 FB_T(6);  // 16 A-operand reads + 64 MFMAs (issue time: the last MFMAs may still be executing)
             }
-        }
+        };
+#pragma nounroll
+        for (int g = 0; g < F_K - 1; ++g) group(g, std::false_type{});
+        group(F_K - 1, std::true_type{});
 
-        // ---- gh rows through the wave's transpose tile (the x plane is dead), gx rows from the stash ----
+        // ---- gx rows from the stash, then gh rows through the wave's transpose tile (both planes are dead by then) ----
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = lane + 64 * i, r = idx >> 4, c4 = idx & 15;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(G + r * FB_P + 4 * c4);
+            if (row0 + r < a.B) *reinterpret_cast<f32x4 *>(a.gx + (row0 + r) * F_D + 4 * c4) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         {
-            float *twr = X + srow * 36 + 4 * hh;
-            const int rl = lane >> 3, cl = lane & 7;
-            const float *tww = X + rl * 36 + 4 * cl;
-            float *dst = a.gh + (row0 + rl) * F_H + 4 * cl;
+            float *T = X;                          // [16 rows][132]: 2112 floats <= the two planes (2176)
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const f32x16 &V = mb == 0 ? acc0 : (mb == 1 ? acc1 : (mb == 2 ? acc2 : acc3));
+            for (int ub = 0; ub < 8; ++ub)
+                *reinterpret_cast<f32x4 *>(T + n * 132 + 16 * ub + 4 * hq) = f32x4{acc[ub][0], acc[ub][1], acc[ub][2], acc[ub][3]};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<f32x4 *>(twr + 8 * q) = f32x4{V[4 * q], V[4 * q + 1], V[4 * q + 2], V[4 * q + 3]};
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int it = 0; it < 4; ++it)
-                    if (row0 + rl + 8 * it < a.B)
-                        *reinterpret_cast<f32x4 *>(dst + (size_t)(8 * it) * F_H + 32 * mb) = *reinterpret_cast<const f32x4 *>(tww + 8 * it * 36);
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        if (valid) {
-#pragma unroll
-            for (int Q = 0; Q < 4; ++Q) {
-                f32x4 ga, gb;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    ga[c] = G[(8 * Q + c) * FB_P + soff];
-                    gb[c] = G[(8 * Q + 4 + c) * FB_P + soff];
-                }
-                float *dst = a.gx + row * F_D + 16 * Q + 8 * hh;
-                *reinterpret_cast<f32x4 *>(dst) = ga;
-                *reinterpret_cast<f32x4 *>(dst + 4) = gb;
+            for (int i = 0; i < 8; ++i) {
+                const int idx = lane + 64 * i, r = idx >> 5, c4 = idx & 31;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(T + r * 132 + 4 * c4);
+                if (row0 + r < a.B) *reinterpret_cast<f32x4 *>(a.gh + (row0 + r) * F_H + 4 * c4) = v;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        FB_T(7);      // gh / gx rows out
+        FB_T(7);      // gx / gh rows out
     }
 #ifdef FB_TRACE
     if (a.trace && blockIdx.x == 0 && tid == 0) {
@@ -358,7 +353,7 @@ final_bwd_kernel(FinalBwdArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     {
-        float *red = ring + (wid * 2 + sp) * FB_PART + fj * 24;
+        float *red = ring + (wid * 2 + sp) * FB_PART + fj * 24;       // 16 x 768 floats: the ring and the first waves' stashes
 #pragma unroll
         for (int k = 0; k < F_K - 1; ++k) {
             red[k] = Gw[k];

@@ -65,6 +65,13 @@ __host__ __device__ inline int final_row_k(int g, int rb, int rho) {
 }
 __host__ __device__ inline int final_row(int g, int rb, int rho) { return final_row_k<F_K>(g, rb, rho); }
 
+// nf_final_bwd (final_bwd.hip): final-layer row (of the (32 * 23, hidden) weight) that k-entry hq (0..3) of k-step v (0..23) of
+// group g (0..7) contracts over on v_mfma_f32_16x16x4_f32 -- the four transform features of the group, parameter v; -1: the pad
+// slot (v = 23).
+__host__ __device__ inline int final_bwd_row(int g, int v, int hq) {
+    return v >= F_M ? -1 : (8 * (g >> 1) + 4 * (hq >> 1) + 2 * (g & 1) + (hq & 1)) * F_M + v;
+}
+
 // Output column of MFMA row rho (0..31) of LU row-block m (0..1): chosen so that C register `reg` of row-block m is
 // the lane's stash slot 16 m + reg (slot c = 8 Q + column-in-chunk, chunk Q = columns [16 Q + 8 hh, +8)).
 __host__ __device__ inline int lu_out_col(int m, int rho) {

@@ -851,13 +851,14 @@ __device__ __forceinline__ void pack_all_body(const PackAllArgs &a, float *__res
     }
     if (a.wfull) {
         for (int64_t i = tid0; i < F_H * F_NI; i += nth) a.wfull[a.iidx[i & 31] * F_H + (i >> 5)] = a.w_init[i];
-        // the final weight as the A operand of the backward's gh = g W_final (final_bwd.hip): 24 stages [q][unit block mb][lane][4],
-        // step (rb, reg = 4 q + r) of group g contracts over the final rows its two lane-halves hold, raw scale
+        // the final weight as the A operand of the backward's gh = g W_final (final_bwd.hip, v_mfma_f32_16x16x4_f32): 24 stages
+        // [k-step vv (8)][unit-block quad uq (2)][lane (64)][unit block j (4)]; stage 3 g + rb holds k-steps v = 8 rb + vv of group g,
+        // lane (m = lane & 15, hq = lane >> 4) supplies W[final_bwd_row(g, v, hq)][16 (4 uq + j) + m], raw scale
         for (int64_t i = tid0; i < (int64_t)24 * F_STAGE; i += nth) {
             const int st = (int)(i >> 12), j = (int)(i & (F_STAGE - 1));
-            const int r4 = j & 3, lane = (j >> 2) & 63, mb = (j >> 8) & 3, q = j >> 10;
-            const int row = final_row(st / 3, st % 3, 8 * q + 4 * (lane >> 5) + r4);
-            a.wpad[i] = row >= 0 ? a.w_final[row * F_H + 32 * mb + (lane & 31)] : 0.0f;
+            const int u4 = j & 3, lane = (j >> 2) & 63, uq = (j >> 8) & 1, vv = j >> 9;
+            const int row = final_bwd_row(st / 3, 8 * (st % 3) + vv, lane >> 4);
+            a.wpad[i] = row >= 0 ? a.w_final[row * F_H + 16 * (4 * uq + u4) + (lane & 15)] : 0.0f;
         }
     }
     const int nbias = 128 + 128 * nlin + 768;
