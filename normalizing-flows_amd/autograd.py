@@ -26,6 +26,26 @@ def refuse_grad(what, *tensors_or_modules):
                                   "torch.no_grad() or freeze its parameters and inputs" % what)
 
 
+def _stamp(*tensors):
+    """Identity + version of the tensors a layer-owned weight image (packed blob, transposed / padded weights, LU factors) was
+    built from.  The training Functions keep those images in buffers OWNED BY THE LAYER (they are rewritten once per step, not
+    per call, and a multi-layer pack launch writes them through a cached pointer table), so autograd's saved-tensor version
+    check cannot see them being overwritten: a forward pass records the stamp in the layer's holder and in its ctx, the
+    backward refuses to run when the holder has moved on (the same layer ran forward again with OTHER weights before this
+    graph's backward: retain_graph across an optimizer step, a two-optimizer schedule, checkpointing with an update in
+    between).  Two forwards on the SAME weights (gradient accumulation over micro-batches) leave the stamp unchanged."""
+    return tuple((id(t), t._version) for t in tensors if t is not None)
+
+
+def _check_stamp(ctx, what):
+    holder = getattr(ctx, "holder", None)
+    if holder is not None and holder.get("stamp") != ctx.stamp:
+        raise RuntimeError("%s: this layer ran forward again with modified parameters before the backward of an earlier forward; "
+                           "its layer-owned weight images now belong to the later call.  Run backward before the parameters "
+                           "change, or set normflows_amd.config.set_train_full(False) / set_train_prepack(False) is not enough: "
+                           "re-run the forward." % what)
+
+
 def needs_grad(*tensors_or_modules):
     if not torch.is_grad_enabled():
         return False
@@ -126,11 +146,15 @@ class FinalSplineDensityFn(torch.autograd.Function):
         wpad[:, 23].zero_()       # (the whole-layer path's pack leaves another image of the final weight in this buffer)
         ctx.save_for_backward(x, h2, wf, cond24, uw, uh, ud, iidx, tidx)
         ctx.kw, ctx.wpad, ctx.acc, ctx.has_acc = kw, wpad, acc, ld_acc is not None
+        ctx.holder, ctx.stamp = kw.get("holder"), _stamp(wf, bf, uw, uh, ud)
+        if ctx.holder is not None:
+            ctx.holder["stamp"] = ctx.stamp
         return y, ld
 
     @staticmethod
     def backward(ctx, gy, gld):
         x, h2, wf, cond24, uw, uh, ud, iidx, tidx = ctx.saved_tensors
+        _check_stamp(ctx, "FinalSplineDensityFn")
         kw = ctx.kw
         if gy is None:
             gy = torch.zeros_like(x)
@@ -182,7 +206,8 @@ class LULinearPermuteFn(torch.autograd.Function):
     """LULinearPermute (mixing.py:535-563).  direction 0 = .inverse (density), 1 = .forward (sample)."""
 
     @staticmethod
-    def forward(ctx, x, perm, lower_entries, upper_entries, udiag_raw, bias, eps, direction, ld_acc=None, acc=1, factors_out=None):
+    def forward(ctx, x, perm, lower_entries, upper_entries, udiag_raw, bias, eps, direction, ld_acc=None, acc=1, factors_out=None,
+                holder=None):
         D = x.shape[1]
         ctx.acc, ctx.has_acc = acc, ld_acc is not None
         if ld_acc is not None:
@@ -209,6 +234,11 @@ class LULinearPermuteFn(torch.autograd.Function):
             ctx.save_for_backward(x, y, perm, lower_entries, upper_entries, udiag_raw, bias, u)
             ctx.eps, ctx.direction = eps, direction
             ctx.factors = (Lm, Um, diag, Up, LT, UpT)      # assembled once per step: the backward reuses them
+            # (views of a LAYER-OWNED buffer when a multi-layer launch assembled them: see _stamp)
+            ctx.holder = holder if factors_out is not None else None
+            ctx.stamp = _stamp(lower_entries, upper_entries, udiag_raw)
+            if ctx.holder is not None:
+                ctx.holder["stamp"] = ctx.stamp
             return y, ld
         y, ld = ops.lu_linear_permute(x, perm, lower_entries, upper_entries, udiag_raw, bias, direction, eps=eps)
         ctx.save_for_backward(x, y, perm, lower_entries, upper_entries, udiag_raw, bias, None)
@@ -221,6 +251,7 @@ class LULinearPermuteFn(torch.autograd.Function):
     def backward(ctx, gy, gld):
         x, y, perm, lower_entries, upper_entries, udiag_raw, bias, u_saved = ctx.saved_tensors
         fac = getattr(ctx, "factors", None)
+        _check_stamp(ctx, "LULinearPermuteFn")
         D_ = x.shape[1]
         g_acc = gld if ctx.has_acc else None            # the running log-density passes its cotangent straight through
         if ctx.has_acc and ctx.acc < 0 and gld is not None:
@@ -236,7 +267,7 @@ class LULinearPermuteFn(torch.autograd.Function):
                 gx, gL, g_bias, gUx = ops.lu_bwd(gy, u_saved, x, Lm, Up)
                 g_lower, g_upper, g_udiag = ops.lu_param_grads(gL, gUx, gld, udiag_raw.detach(), lower_entries.numel(),
                                                                eps=ctx.eps, sign=1.0, perm=perm)
-                return gx, None, g_lower, g_upper, g_udiag, g_bias, None, None, g_acc, None, None
+                return gx, None, g_lower, g_upper, g_udiag, g_bias, None, None, g_acc, None, None, None
             if config.lu_matvec2:
                 gu, gx, _ = ops.rows_matvec2(gy, LT, UpT)   # d/du = L^T gy, d/dx = P (U^T gu): one launch
             else:
@@ -252,7 +283,7 @@ class LULinearPermuteFn(torch.autograd.Function):
                 gUx, _ = _batch_outer(gu, x)
             g_lower, g_upper, g_udiag = ops.lu_param_grads(gL, gUx, gld, udiag_raw.detach(), lower_entries.numel(),
                                                            eps=ctx.eps, sign=1.0, perm=perm)
-            return gx, None, g_lower, g_upper, g_udiag, g_bias, None, None, g_acc, None, None
+            return gx, None, g_lower, g_upper, g_udiag, g_bias, None, None, g_acc, None, None, None
         li, ui = _tri_indices(D_, x.device)
         if fac is not None:
             Lm, Um, diag, Up_saved = fac[:4]
@@ -305,7 +336,7 @@ class LULinearPermuteFn(torch.autograd.Function):
         g_lower = gL[li[0], li[1]]
         g_upper = gU[ui[0], ui[1]]
         g_udiag = gdiag * sig
-        return gx, None, g_lower, g_upper, g_udiag, g_bias, None, None, g_acc, None, None
+        return gx, None, g_lower, g_upper, g_udiag, g_bias, None, None, g_acc, None, None, None
 
 
 class DiagGaussianLogProbFn(torch.autograd.Function):
@@ -396,11 +427,15 @@ class CouplingTrainFn(torch.autograd.Function):
         ctx.save_for_backward(x, cond24, acts, w0, wf, uw, uh, ud, iidx, tidx, *blk)
         ctx.kw, ctx.wfull, ctx.wpad, ctx.acc, ctx.has_acc, ctx.nb = kw, wfull, wpad, acc, ld_acc is not None, nb
         ctx.blob, ctx.parity = blob, parity
+        ctx.holder, ctx.stamp = kw.get("holder"), _stamp(w0, b0, wf, bf, uw, uh, ud, *blk)
+        if ctx.holder is not None:
+            ctx.holder["stamp"] = ctx.stamp
         return y, ld
 
     @staticmethod
     def backward(ctx, gy, gld):
         x, cond24, acts, w0, wf, uw, uh, ud, iidx, tidx, *blk = ctx.saved_tensors
+        _check_stamp(ctx, "CouplingTrainFn")
         kw, nb = ctx.kw, ctx.nb
         if gy is None:
             gy = torch.zeros_like(x)

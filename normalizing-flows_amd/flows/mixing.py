@@ -285,7 +285,8 @@ class LULinearPermute(Flow):
             fout = self._factors_buffer(z.device) if (inverse and _prepack.take(self)) else None
             y, log_det = LULinearPermuteFn.apply(z, self.permutation._permutation, lin.lower_entries, lin.upper_entries,
                                                  lin.unconstrained_upper_diag, lin.bias, lin.eps, 0 if inverse else 1,
-                                                 ld, 1 if (acc is None or acc > 0) else -1, fout)
+                                                 ld, 1 if (acc is None or acc > 0) else -1, fout,
+                                                 self.__dict__.setdefault("_img_holder", {}) if fout is not None else None)
             return y, log_det            # log_det IS ld (updated in place) when the caller passed its accumulator
         if z.dtype == torch.float32 and z.is_cuda and lin.features <= 64 and self.use_dense:
             # the layer as ONE dense D x D product on fp32 MFMA (nf_lu_compose once per parameter version + nf_rows_matvec_affine):

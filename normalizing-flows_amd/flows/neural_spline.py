@@ -474,6 +474,7 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
             if self._train_full_ok(inputs, context, sample):
                 blob = self._train_blob_for(inputs)
                 fkw["prepacked"] = _prepack.take(self)      # packed by run_chain's one launch for the whole model
+                fkw["holder"] = self.__dict__.setdefault("_img_holder", {})    # whose weights the layer-owned images hold (autograd._stamp)
                 blk = [p for b in net.blocks for l in b.linear_layers for p in (l.weight, l.bias)]
                 return CouplingTrainFn.apply(inputs, net.initial_layer.weight, net.initial_layer.bias, net.final_layer.weight,
                                              net.final_layer.bias, u.unnormalized_widths, u.unnormalized_heights,
@@ -487,7 +488,8 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
             if blob is None or blob.device != inputs.device:
                 blob = self._train_blob = ops.rqs_fused_train_blob(len(net.blocks), inputs.device)
             fkw = dict(tail_bound=float(self.tail_bound), min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
-                       min_derivative=self.min_derivative, wh_div=self._wh_div())
+                       min_derivative=self.min_derivative, wh_div=self._wh_div(),
+                       holder=self.__dict__.setdefault("_img_holder", {}))
             outputs, log_det = FinalSplineDensityFn.apply(inputs.contiguous(), h2, net.final_layer.weight, net.final_layer.bias,
                                                           u.unnormalized_widths, u.unnormalized_heights,
                                                           u.unnormalized_derivatives, self.identity_features,

@@ -916,3 +916,27 @@ def test_training_step_fused_final_backward_vs_separate_kernels(nfa):
     assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-5 * float(res[1][1].abs().max())
     for (n, _), a, b in zip(m.named_parameters(), res[0][2], res[1][2]):
         assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-6), n
+
+
+def test_backward_after_reforward_with_other_weights_raises(nfa):
+    """The training Functions read layer-owned weight images (packed blob, transposed final weight, LU factors) in backward;
+    a second forward of the same layer with OTHER weights overwrites them.  autograd's saved-tensor check catches in-place
+    updates; a re-assigned Parameter it cannot see: the stamp check (autograd._stamp) raises instead of differentiating the
+    first graph with the second call's weights.  Two forwards on the same weights (micro-batches) stay legal."""
+    from bench import build_c2_model
+    m = build_c2_model(num_layers=2, sigma=0.05).to(DEV)
+    x = torch.randn(2048, 64, device=DEV)
+    loss1 = m.forward_kld(x)
+    lin = m.flows[0].prqct.transform_net.final_layer
+    lin.weight = torch.nn.Parameter(lin.weight.detach() * 0.5)
+    m.forward_kld(x)
+    with pytest.raises(RuntimeError, match="ran forward again"):
+        loss1.backward()
+    m.zero_grad(set_to_none=True)
+    l1, l2 = m.forward_kld(x[:1024]), m.forward_kld(x[1024:])
+    (0.5 * (l1 + l2)).backward()
+    g_two = [p_.grad.clone() for p_ in m.parameters()]
+    m.zero_grad(set_to_none=True)
+    m.forward_kld(x).backward()
+    for (nm, p_), a in zip(m.named_parameters(), g_two):
+        assert float((a - p_.grad).abs().max()) <= 1e-4 * max(float(p_.grad.abs().max()), 1e-6), nm
