@@ -91,6 +91,16 @@ def set_train_prepack(mode=True):
     train_prepack = bool(mode)
 
 
+# MAF inverse (nf_maf_inverse): the mapping with 32 samples per wave and the lane-halves sharing a sample's hidden units (two waves
+# per SIMD, csrc/maf_inverse_h.hip); False = round 2's 64-samples-per-wave kernel (csrc/maf_inverse.hip; ablation).
+maf_halves = True
+
+
+def set_maf_halves(mode=True):
+    global maf_halves
+    maf_halves = bool(mode)
+
+
 def set_fused_chain(mode=True):
     global fused_chain
     fused_chain = bool(mode)

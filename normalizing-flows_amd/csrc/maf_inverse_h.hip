@@ -1,0 +1,335 @@
+// maf_inverse_h.hip -- the incremental inverse of a masked autoregressive AFFINE layer (MAF sampling direction, BASELINE
+// configs[4]; normflows/flows/affine/autoregressive.py:29-38, :114-128 over nets/made.py:217-304), second mapping: 32 samples per
+// wave, the two lane-halves SHARE each sample's hidden units -- two waves per SIMD.
+//
+// The schedule, the packed blob and the table are those of maf_inverse.hip / flows/maf_pack.py (hidden units sorted by degree,
+// tiles of <= 32 units holding whole degrees, per tile a block part on MFMA over all earlier tiles and a sequential part over its
+// degrees); what changes is who holds what.  Round 1/2 (maf_inverse.hip, still the AR-NSF path): one wave = 64 samples, lane =
+// sample, six 32-float register vectors per lane + operand stages = 482 registers = ONE wave per SIMD: MFMA issue (0.60 ms),
+// the sequential vector-ALU part (0.46 ms), 96 product start-ups and every scratch / LDS round trip added up (1.8 ms per layer,
+// MFMA busy 0.30).  Here:
+//   * lane l = (sample n = l & 31, half hh = l >> 5).  A 32-unit tile's unit u belongs to half (u >> 2) & 1, register
+//     (u & 3) + 4 (u >> 3) -- exactly where v_mfma_f32_32x32x2_f32 leaves row u of a [32 units x 32 samples] product: the block
+//     part's accumulators ARE the per-lane vectors (no LDS transpose), 16 registers per layer instead of 32.
+//   * sequential part: a unit's dot product over the tile's 32 source units = each half's 16 + one cross-half add (ds_bpermute);
+//     the owner's pre-activation rides in the same sum, so one exchange gives both halves the total and the owner keeps it.  Half
+//     the multiply-adds per lane; the diagonal blocks are staged into LDS with their columns in (half, register) order.
+//   * activation scratch in B-operand order [k / 8][half][32 samples][4] as before: a tile is published with four 16-byte stores
+//     per layer straight from the register quads, read back through the per-wave LDS-DMA ring (one 1 KB request per k-block).
+// ~230 registers: 8 waves of 32 samples per workgroup = one workgroup per CU at B = 65 536, two waves per SIMD.
+#include "common.hpp"
+#include "fused_common.hpp"
+
+namespace nf {
+
+constexpr int HT = 32;    // units per tile (flows/maf_pack.py TILE)
+constexpr int HS = 16;    // degrees per tile
+constexpr int HNW = 4;    // waves per workgroup; two workgroups per CU (their tile phases drift apart: one's sequential part overlaps the other's block part)
+constexpr int H_HDR = 8, H_ENT = 24;
+constexpr int H_SEQ = 5 * HT + HT + HT * HS + 4 * HT * HT + HT * HT;  // floats of a tile record after the A operands
+constexpr int HRB = 12;   // k-blocks of the per-wave activation ring (look-ahead HRB - 1)
+
+#define HMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// c0[r] (+)= sum_k A[u(r, hh)][k] act[k][n] over K (a multiple of 32) features / units; PAIR: the NEXT tile's products over the
+// same operands go to `stash` raw; INIT: c0 starts from the stash (second tile of a pair).  A, A2: [K/8][2][32][4] (L2),
+// Sl: the wave's scratch [K/8][2][32][4], streamed through `ring` HRB - 1 k-blocks ahead (in-order retirement: while requests
+// are being issued exactly HRB - 1 DMA instructions are younger than the k-block about to be consumed).
+template <bool PAIR, bool INIT>
+__device__ __forceinline__ void h_block(const float *__restrict__ A, const float *__restrict__ A2, const float *Sl, int K, int lane,
+                                        float *stash, float *ring, f32x16 &c0) {
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    f32x16 c2 = {0};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c0[r] = 0.0f;
+    if constexpr (INIT) {
+        const f32x4 *ps = reinterpret_cast<const f32x4 *>(stash) + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = ps[q * 64];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c0[4 * q + i] = v[i];
+        }
+    }
+    const f32x4 *pa = reinterpret_cast<const f32x4 *>(A) + lane;
+    const f32x4 *pa2 = reinterpret_cast<const f32x4 *>(PAIR ? A2 : A) + lane;
+    const int nkb = K >> 3;
+    if (nkb > 0) {
+        auto dma = [&](int kb) {
+            __builtin_amdgcn_global_load_lds(Sl + (size_t)kb * 256 + lane * 4, (lds_ptr)(ring + (kb % HRB) * 256), 16, 0, 0);
+        };
+        struct Stage { f32x4 a, a2; };
+        auto ld = [&](int kb, Stage &st) {
+            const int k = kb < nkb ? kb : nkb - 1;
+            st.a = pa[k * 64];
+            if constexpr (PAIR) st.a2 = pa2[k * 64];
+        };
+        auto mm = [&](int kb, const Stage &st) {
+            if (kb + HRB - 1 < nkb) {
+                dma(kb + HRB - 1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HRB - 1) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(ring + (kb % HRB) * 256 + lane * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                c0 = HMFMA(st.a[i], b[i], c0);
+                if constexpr (PAIR) c2 = HMFMA(st.a2[i], b[i], c2);
+            }
+        };
+        for (int j = 0; j < HRB - 1 && j < nkb; ++j) dma(j);
+        Stage s0, s1, s2, s3;
+        ld(0, s0); ld(1, s1); ld(2, s2); ld(3, s3);
+        for (int kb = 0; kb < nkb; kb += 4) {        // nkb is a multiple of 4
+            mm(kb, s0); ld(kb + 4, s0);
+            mm(kb + 1, s1); ld(kb + 5, s1);
+            mm(kb + 2, s2); ld(kb + 6, s2);
+            mm(kb + 3, s3); ld(kb + 7, s3);
+        }
+    }
+    if constexpr (PAIR) {
+        f32x4 *ps = reinterpret_cast<f32x4 *>(stash) + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ps[q * 64] = f32x4{c2[4 * q], c2[4 * q + 1], c2[4 * q + 2], c2[4 * q + 3]};
+    }
+}
+
+__device__ __forceinline__ void h_block_mode(int mode, const float *__restrict__ A, const float *__restrict__ A2, const float *Sl,
+                                             int K, int lane, float *stash, float *ring, f32x16 &out) {
+    if (mode == 1) h_block<true, false>(A, A2, Sl, K, lane, stash, ring, out);
+    else if (mode == 2) h_block<false, true>(A, nullptr, Sl, K, lane, stash, ring, out);
+    else h_block<false, false>(A, nullptr, Sl, K, lane, nullptr, ring, out);
+}
+
+__device__ __forceinline__ void h_finish(float us, float sh, float zf, float &xn, float &ld) {
+    const float scale = 1.0f / (1.0f + __expf(-(us + 2.0f))) + 1e-3f;
+    xn = (zf - sh) / scale;
+    ld -= __logf(scale);
+}
+
+__global__ void __launch_bounds__(64 * HNW, 2)
+maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *__restrict__ logdet, const float *__restrict__ blob,
+                     const int *__restrict__ table, float *S, float *Xs, float *Ps, int64_t B, int acc) {
+    __shared__ __attribute__((aligned(16))) float seqw[H_SEQ];     // the tile's biases and diagonal blocks, shared by the workgroup's waves
+    extern __shared__ __attribute__((aligned(16))) float dyn[];      // the waves' activation rings
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, n = lane & 31, hh = lane >> 5;
+    float *ringw = dyn + wid * (HRB * 256);
+    const int64_t wt = (int64_t)blockIdx.x * HNW + wid;
+    const bool active = wt * 32 < B;   // idle waves of the last workgroup still take part in the staging barriers
+    const int D = table[0], Dp = table[1], Hp = table[3], T = table[4];
+    const int64_t sample = wt * 32 + n;
+    const bool valid = sample < B;
+    const int64_t wts = active ? wt : 0;
+    const float *zr = z + (valid ? sample : B - 1) * D;
+    float *Sw = S + wts * ((int64_t)5 * Hp * 32);    // [layer][Hp/8][2][32][4]
+    float *Xw = Xs + wts * ((int64_t)Dp * 32);       // [Dp/8][2][32][4]
+    float *Pw = Ps ? Ps + wts * ((int64_t)5 * HT * 32) : nullptr;   // pair stash: [product][4][64][4] raw accumulators
+    float ld = 0.0f, xcarry;
+    h_finish(blob[0], blob[1], zr[0], xcarry, ld);
+    if (active && hh == 0) Xw[n * 4] = xcarry;
+    if (valid && hh == 0) y[sample * D] = xcarry;
+    auto xsum = [](float v) { return v + __shfl_xor(v, 32, 64); };
+
+    for (int t = 0; t < T; ++t) {
+        const int *te = table + H_HDR + H_ENT * t;
+        const int dlo = te[0], ns = te[1], K0 = te[2];
+        const int Kh = HT * t;
+        const float *rec = blob + te[3];
+        const float *A0 = rec;
+        const float *Ah = A0 + K0 * HT;             // A1..A4, AF: Kh * 32 floats each
+        // stage the sequential part's weights, one copy per workgroup; the five 32 x 32 diagonal blocks with their columns
+        // in (half, register) order: source quad (u, v / 4 = 2 q + h) -> destination quad (u, 4 h + q)
+        __syncthreads();
+        {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(Ah + (size_t)5 * Kh * HT);
+            constexpr int HEAD4 = (5 * HT + HT + HT * HS) / 4;      // biases, final biases, window weights: copied as they are
+            for (int i = threadIdx.x; i < H_SEQ / 4; i += 64 * HNW) {
+                int d = i;
+                if (i >= HEAD4) {
+                    const int j = i - HEAD4, vq = j & 7;
+                    d = HEAD4 + (j & ~7) + 4 * (vq & 1) + (vq >> 1);
+                }
+                reinterpret_cast<f32x4 *>(seqw)[d] = src[i];
+            }
+        }
+        __syncthreads();
+        if (!active) continue;
+        const float *bias = seqw;
+        const float *biasF = bias + 5 * HT;
+        const float *W0d = biasF + HT;
+        const float *Wd = W0d + HT * HS;
+        const float *WFd = Wd + 4 * HT * HT;
+
+        f32x16 zin;
+#pragma unroll
+        for (int j = 0; j < HS; ++j) zin[j] = (j < ns) ? zr[dlo + j] : 0.0f;
+
+        __threadfence_block();  // the activation scratch written by the other lanes of this wave is read below
+        f32x16 p0, p1, p2, p3, p4, pF;
+        h_block<false, false>(A0, nullptr, Xw, K0, lane, nullptr, ringw, p0);
+        {
+            // tile pairing: even tile = its own products + the next tile's over the same operands (raw accumulators to the
+            // stash); odd tile = the stash + the 32 units of its partner
+            const int mode = !Pw ? 0 : ((t & 1) ? 2 : (t + 1 < T ? 1 : 0));
+            const float *Ah2 = Ah;
+            int Kh2 = 0;
+            if (mode == 1) {
+                const int *te2 = te + H_ENT;
+                Ah2 = blob + te2[3] + (size_t)te2[2] * HT;
+                Kh2 = Kh + HT;
+            }
+            const int koff = mode == 2 ? Kh - HT : 0;         // the partner's units: the last 32 of this tile's K range
+            const int Kb = mode == 2 ? HT : Kh;
+#define NF_MAFH_BP(l, OUT)                                                                                                 \
+            h_block_mode(mode, Ah + (size_t)(l) * Kh * HT + (size_t)koff * HT, Ah2 + (size_t)(l) * Kh2 * HT,                  \
+                         Sw + (size_t)(l) * Hp * 32 + (size_t)koff * 32, Kb, lane, Pw + (size_t)(l) * HT * 32, ringw, OUT)
+            NF_MAFH_BP(0, p1);
+            NF_MAFH_BP(1, p2);
+            NF_MAFH_BP(2, p3);
+            NF_MAFH_BP(3, p4);
+            NF_MAFH_BP(4, pF);
+#undef NF_MAFH_BP
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int u = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            p0[r] += bias[u];
+            p1[r] += bias[HT + u];
+            p2[r] += bias[2 * HT + u];
+            p3[r] += bias[3 * HT + u];
+            p4[r] += bias[4 * HT + u];
+            pF[r] += biasF[u];
+        }
+        f32x16 xg = {0};   // window features dlo-1 .. dlo+14 (0-based): xg[0] is the carry, xg[s+1] the output of step s
+        xg[0] = xcarry;
+
+        // partial dot product of row u of a diagonal block with the 16 source registers of this lane-half
+#define MAFH_DOT(WBASE, SRC)                                                                     \
+            const f32x4 *w_ = reinterpret_cast<const f32x4 *>(WBASE) + u * (HT / 4) + 4 * hh;    \
+            float a0 = 0.0f, a1 = 0.0f;                                                          \
+            _Pragma("unroll") for (int q = 0; q < 4; q += 2) {                                   \
+                const f32x4 wa = w_[q], wb = w_[q + 1];                                          \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                  \
+                    a0 = fmaf(wa[i], SRC[4 * q + i], a0);                                        \
+                    a1 = fmaf(wb[i], SRC[4 * q + 4 + i], a1);                                    \
+                }                                                                                \
+            }
+        for (int s = 0; s < ns; ++s) {
+            const unsigned m = (unsigned)te[4 + s];
+            // initial layer: h0 = pre + W0[window] . x ; the residual h0 is folded into the pre-activation of block 1's
+            // second linear (p2), p0 keeps relu(h0) = input of block 1's first linear
+            for (unsigned mm = m; mm; mm &= mm - 1) {
+                const int u = __builtin_amdgcn_readfirstlane(__builtin_ctz(mm));
+                const int ru = (u & 3) + 4 * (u >> 3);
+                const bool own = hh == ((u >> 2) & 1);
+                const f32x4 *w_ = reinterpret_cast<const f32x4 *>(W0d) + u * (HS / 4);
+                float a = p0[ru];
+#pragma unroll
+                for (int f = 0; f < HS; f += 4) {
+                    const f32x4 w = w_[f / 4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a = fmaf(w[i], xg[f + i], a);
+                }
+                p2[ru] = own ? p2[ru] + a : p2[ru];
+                p0[ru] = own ? fmaxf(a, 0.0f) : p0[ru];
+            }
+            for (unsigned mm = m; mm; mm &= mm - 1) {
+                const int u = __builtin_amdgcn_readfirstlane(__builtin_ctz(mm));
+                const int ru = (u & 3) + 4 * (u >> 3);
+                const bool own = hh == ((u >> 2) & 1);
+                MAFH_DOT(Wd, p0)
+                const float tot = xsum((own ? p1[ru] : 0.0f) + (a0 + a1));
+                p1[ru] = own ? fmaxf(tot, 0.0f) : p1[ru];
+            }
+            for (unsigned mm = m; mm; mm &= mm - 1) {
+                const int u = __builtin_amdgcn_readfirstlane(__builtin_ctz(mm));
+                const int ru = (u & 3) + 4 * (u >> 3);
+                const bool own = hh == ((u >> 2) & 1);
+                MAFH_DOT(Wd + HT * HT, p1)
+                const float h1 = xsum((own ? p2[ru] : 0.0f) + (a0 + a1));
+                p4[ru] = own ? p4[ru] + h1 : p4[ru];      // residual stream after block 1 feeds block 2's output
+                p2[ru] = own ? fmaxf(h1, 0.0f) : p2[ru];
+            }
+            for (unsigned mm = m; mm; mm &= mm - 1) {
+                const int u = __builtin_amdgcn_readfirstlane(__builtin_ctz(mm));
+                const int ru = (u & 3) + 4 * (u >> 3);
+                const bool own = hh == ((u >> 2) & 1);
+                MAFH_DOT(Wd + 2 * HT * HT, p2)
+                const float tot = xsum((own ? p3[ru] : 0.0f) + (a0 + a1));
+                p3[ru] = own ? fmaxf(tot, 0.0f) : p3[ru];
+            }
+            for (unsigned mm = m; mm; mm &= mm - 1) {
+                const int u = __builtin_amdgcn_readfirstlane(__builtin_ctz(mm));
+                const int ru = (u & 3) + 4 * (u >> 3);
+                const bool own = hh == ((u >> 2) & 1);
+                MAFH_DOT(Wd + 3 * HT * HT, p3)
+                const float tot = xsum((own ? p4[ru] : 0.0f) + (a0 + a1));
+                p4[ru] = own ? tot : p4[ru];   // = h2, the final layer's input (made.py:304: no activation before it)
+            }
+            {
+                float us, sh, xn;
+                {
+                    const int u = 2 * s, ru = (u & 3) + 4 * (u >> 3);
+                    const bool own = hh == ((u >> 2) & 1);
+                    MAFH_DOT(WFd, p4)
+                    us = xsum((own ? pF[ru] : 0.0f) + (a0 + a1));
+                }
+                {
+                    const int u = 2 * s + 1, ru = (u & 3) + 4 * (u >> 3);
+                    const bool own = hh == ((u >> 2) & 1);
+                    MAFH_DOT(WFd, p4)
+                    sh = xsum((own ? pF[ru] : 0.0f) + (a0 + a1));
+                }
+                h_finish(us, sh, zin[s], xn, ld);
+                if (s + 1 < HS) xg[s + 1] = xn;
+                xcarry = xn;
+                const int f = dlo + s;
+                if (hh == 0) {
+                    Xw[((size_t)((f >> 3) * 2 + ((f >> 2) & 1)) * 32 + n) * 4 + (f & 3)] = xn;
+                    if (valid) y[sample * D + f] = xn;
+                }
+            }
+        }
+#undef MAFH_DOT
+        // ---- publish the tile: the register quads ARE the B-operand entries (k-block 4 t + q, half hh) ----
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t o = ((size_t)((4 * t + q) * 2 + hh) * 32 + n) * 4;
+            *reinterpret_cast<f32x4 *>(Sw + (size_t)0 * Hp * 32 + o) = f32x4{p0[4 * q], p0[4 * q + 1], p0[4 * q + 2], p0[4 * q + 3]};
+            *reinterpret_cast<f32x4 *>(Sw + (size_t)1 * Hp * 32 + o) = f32x4{p1[4 * q], p1[4 * q + 1], p1[4 * q + 2], p1[4 * q + 3]};
+            *reinterpret_cast<f32x4 *>(Sw + (size_t)2 * Hp * 32 + o) = f32x4{p2[4 * q], p2[4 * q + 1], p2[4 * q + 2], p2[4 * q + 3]};
+            *reinterpret_cast<f32x4 *>(Sw + (size_t)3 * Hp * 32 + o) = f32x4{p3[4 * q], p3[4 * q + 1], p3[4 * q + 2], p3[4 * q + 3]};
+            *reinterpret_cast<f32x4 *>(Sw + (size_t)4 * Hp * 32 + o) = f32x4{p4[4 * q], p4[4 * q + 1], p4[4 * q + 2], p4[4 * q + 3]};
+        }
+    }
+    if (valid && hh == 0) ld_store(logdet + sample, ld, acc);
+}
+
+}  // namespace nf
+
+// nf_maf_inverse on the half-sharing mapping: same blob, table, scratch size and semantics as nf_maf_inverse (maf_inverse.hip).
+extern "C" int nf_maf_inverse_h(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, void *scratch,
+                                int64_t B, int D, int hidden_padded, int acc, nf_stream_t stream) {
+    using namespace nf;
+    if (B < 0 || D < 2 || hidden_padded < 32 || hidden_padded % 32) return NF_EINVAL;
+    if (acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!z || !y || !logdet || !blob || !table || !scratch) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nwt = (B + 31) / 32;
+    const int64_t Dp = (D + 31) / 32 * 32;
+    float *S = (float *)scratch;
+    float *Xs = S + nwt * 32 * (int64_t)5 * hidden_padded;
+    // the feature scratch is read with zero weights before it is written (K0 is padded to 32): it must hold finite values
+    if (hipMemsetAsync(Xs, 0, (size_t)nwt * 32 * Dp * sizeof(float), st) != hipSuccess) return NF_EIO;
+    float *Ps = Xs + nwt * 32 * Dp;
+    const int grid = (int)((nwt + HNW - 1) / HNW);
+    const size_t lds_ring = (size_t)HNW * HRB * 256 * sizeof(float);
+    static LdsOptIn opted;
+    if (opt_in_lds(reinterpret_cast<const void *>(&maf_inverse_h_kernel), lds_ring + sizeof(float) * H_SEQ, opted) != NF_OK) return NF_ENOTSUP;
+    hipLaunchKernelGGL(maf_inverse_h_kernel, dim3(grid), dim3(64 * HNW), lds_ring, st, (const float *)z, (float *)y, (float *)logdet,
+                       (const float *)blob, (const int *)table, S, Xs, Ps, B, acc);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

@@ -819,8 +819,9 @@ def maf_inverse(z, blob, table, hidden_padded, logdet=None, acc=None):
         acc = L.LD_ADD
     n = L.lib().nf_maf_inverse_scratch_floats(i64(B), i32(D), i32(hidden_padded))
     scratch = torch.empty(max(int(n), 1), dtype=torch.float32, device=z.device)
-    rc = L.lib().nf_maf_inverse(ptr(z), ptr(y), ptr(logdet), ptr(blob), ptr(table), ptr(scratch), i64(B), i32(D),
-                                i32(hidden_padded), i32(acc), L.stream())
+    from . import config
+    fn = L.lib().nf_maf_inverse_h if config.maf_halves else L.lib().nf_maf_inverse     # same arguments, two mappings (config.py)
+    rc = fn(ptr(z), ptr(y), ptr(logdet), ptr(blob), ptr(table), ptr(scratch), i64(B), i32(D), i32(hidden_padded), i32(acc), L.stream())
     L.check(rc, "nf_maf_inverse")
     return y, logdet
 

@@ -1643,3 +1643,31 @@ def test_fused_kernel_on_narrower_layers_vs_unfused_and_oracle(nfa, oracle, D, h
             assert np.quantile(e_gpu, q) <= 4 * np.quantile(e_o32, q) + 4e-6, ("z", q, np.quantile(e_gpu, q), np.quantile(e_o32, q))
             assert np.quantile(l_gpu, q) <= 4 * np.quantile(l_o32, q) + 1e-5, ("ld", q, np.quantile(l_gpu, q), np.quantile(l_o32, q))
         assert np.quantile(l_gpu, 0.99) < 1e-4, np.quantile(l_gpu, 0.99)      # the north-star bar on log-det, bulk of the rows
+
+
+@pytest.mark.parametrize("B", [65536, 1000, 33, 1])
+def test_maf_inverse_both_mappings_agree(nfa, B):
+    """nf_maf_inverse_h (32 samples per wave, lane-halves sharing a sample's hidden units: round 3) against nf_maf_inverse
+    (64 samples per wave: round 2) on the configs[4] layer shape -- same packed blob, table and scratch; different summation
+    order only (1e-5); batches off the 32-sample wave / the 256-sample workgroup; run-to-run bit equality."""
+    torch.manual_seed(B)
+    layer = nfa.flows.MaskedAffineAutoregressive(128, 512, num_blocks=2).to(DEV)
+    with torch.no_grad():
+        for p_ in layer.parameters():
+            p_.add_(0.02 * torch.randn_like(p_))
+    z = torch.randn(B, 128, device=DEV)
+    res = []
+    try:
+        for halves in (True, False):
+            nfa.config.set_maf_halves(halves)
+            x, ld = layer.forward(z)
+            res.append((x, ld))
+        nfa.config.set_maf_halves(True)
+        x2, ld2 = layer.forward(z)
+    finally:
+        nfa.config.set_maf_halves(True)
+    assert torch.equal(res[0][0], x2) and torch.equal(res[0][1], ld2)
+    assert_close(N(res[0][0]), N(res[1][0]), what="x", rtol=1e-5, atol=1e-5)
+    assert_close(N(res[0][1]), N(res[1][1]), what="logdet", rtol=1e-5, atol=1e-5)
+    zz, _ = layer.inverse(res[0][0])
+    assert_close(N(zz), N(z), what="round trip", rtol=1e-4, atol=1e-4)
