@@ -485,9 +485,11 @@ int64_t nf_maf_inverse_scratch_floats(int64_t B, int D, int hidden_padded);
 int nf_maf_inverse(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, void *scratch,
                    int64_t B, int D, int hidden_padded, int acc, nf_stream_t stream);
 /* The same inverse on the second mapping (maf_inverse_h.hip): 32 samples per wave, the lane-halves share each sample's hidden
- * units, two waves per SIMD.  Same blob, table, scratch size, arguments and results as nf_maf_inverse. */
+ * units, two waves per SIMD.  Same blob / table format, arguments and results as nf_maf_inverse, for MADE conditioners of
+ * num_blocks = 1, 2 or 3 residual blocks (table[6]; nets/made.py:140-214); scratch: nf_maf_inverse_h_scratch_floats floats. */
+int64_t nf_maf_inverse_h_scratch_floats(int64_t B, int D, int hidden_padded, int num_blocks);
 int nf_maf_inverse_h(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, void *scratch,
-                   int64_t B, int D, int hidden_padded, int acc, nf_stream_t stream);
+                     int64_t B, int D, int hidden_padded, int num_blocks, int acc, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * MaskedPiecewiseRationalQuadraticAutoregressive inverse (AR-NSF sampling direction) in ONE pass.  Replaces the D-pass

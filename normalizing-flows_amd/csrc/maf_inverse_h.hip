@@ -26,7 +26,8 @@ constexpr int HT = 32;    // units per tile (flows/maf_pack.py TILE)
 constexpr int HS = 16;    // degrees per tile
 constexpr int HNW = 4;    // waves per workgroup; two workgroups per CU (their tile phases drift apart: one's sequential part overlaps the other's block part)
 constexpr int H_HDR = 8, H_ENT = 24;
-constexpr int H_SEQ = 5 * HT + HT + HT * HS + 4 * HT * HT + HT * HT;  // floats of a tile record after the A operands
+// floats of a tile record after the A operands, NL = 1 + 2 num_blocks hidden layers: bias[NL][32] | biasF | W0d[32][16] | Wd[NL-1] | WFd
+constexpr int h_seq(int NL) { return NL * HT + HT + HT * HS + (NL - 1) * HT * HT + HT * HT; }
 constexpr int HRB = 12;   // k-blocks of the per-wave activation ring (look-ahead HRB - 1)
 
 #define HMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -108,9 +109,13 @@ __device__ __forceinline__ void h_finish(float us, float sh, float zf, float &xn
     ld -= __logf(scale);
 }
 
-__global__ void __launch_bounds__(64 * HNW, 2)
+// NB residual blocks (nets/made.py:140-214): NL = 1 + 2 NB hidden layers whose activations later tiles contract over
+// (S_0 = relu(h_0); per block b: S_{2b+1} = relu(t_b), S_{2b+2} = relu(h_{b+1}), the last one raw = the final layer's input).
+template <int NB>
+__global__ void __launch_bounds__(64 * HNW, NB <= 2 ? 2 : 1)
 maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *__restrict__ logdet, const float *__restrict__ blob,
                      const int *__restrict__ table, float *S, float *Xs, float *Ps, int64_t B, int acc) {
+    constexpr int NL = 1 + 2 * NB, H_SEQ = h_seq(NL);
     __shared__ __attribute__((aligned(16))) float seqw[H_SEQ];     // the tile's biases and diagonal blocks, shared by the workgroup's waves
     extern __shared__ __attribute__((aligned(16))) float dyn[];      // the waves' activation rings
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, n = lane & 31, hh = lane >> 5;
@@ -122,9 +127,9 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
     const bool valid = sample < B;
     const int64_t wts = active ? wt : 0;
     const float *zr = z + (valid ? sample : B - 1) * D;
-    float *Sw = S + wts * ((int64_t)5 * Hp * 32);    // [layer][Hp/8][2][32][4]
+    float *Sw = S + wts * ((int64_t)NL * Hp * 32);   // [layer][Hp/8][2][32][4]
     float *Xw = Xs + wts * ((int64_t)Dp * 32);       // [Dp/8][2][32][4]
-    float *Pw = Ps ? Ps + wts * ((int64_t)5 * HT * 32) : nullptr;   // pair stash: [product][4][64][4] raw accumulators
+    float *Pw = Ps ? Ps + wts * ((int64_t)NL * HT * 32) : nullptr;  // pair stash: [product][4][64][4] raw accumulators
     float ld = 0.0f, xcarry;
     h_finish(blob[0], blob[1], zr[0], xcarry, ld);
     if (active && hh == 0) Xw[n * 4] = xcarry;
@@ -137,13 +142,13 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
         const int Kh = HT * t;
         const float *rec = blob + te[3];
         const float *A0 = rec;
-        const float *Ah = A0 + K0 * HT;             // A1..A4, AF: Kh * 32 floats each
+        const float *Ah = A0 + K0 * HT;             // A1..A_{NL-1}, AF: Kh * 32 floats each
         // stage the sequential part's weights, one copy per workgroup; the five 32 x 32 diagonal blocks with their columns
         // in (half, register) order: source quad (u, v / 4 = 2 q + h) -> destination quad (u, 4 h + q)
         __syncthreads();
         {
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(Ah + (size_t)5 * Kh * HT);
-            constexpr int HEAD4 = (5 * HT + HT + HT * HS) / 4;      // biases, final biases, window weights: copied as they are
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(Ah + (size_t)NL * Kh * HT);
+            constexpr int HEAD4 = (NL * HT + HT + HT * HS) / 4;      // biases, final biases, window weights: copied as they are
             for (int i = threadIdx.x; i < H_SEQ / 4; i += 64 * HNW) {
                 int d = i;
                 if (i >= HEAD4) {
@@ -156,18 +161,18 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
         __syncthreads();
         if (!active) continue;
         const float *bias = seqw;
-        const float *biasF = bias + 5 * HT;
+        const float *biasF = bias + NL * HT;
         const float *W0d = biasF + HT;
         const float *Wd = W0d + HT * HS;
-        const float *WFd = Wd + 4 * HT * HT;
+        const float *WFd = Wd + (NL - 1) * HT * HT;
 
         f32x16 zin;
 #pragma unroll
         for (int j = 0; j < HS; ++j) zin[j] = (j < ns) ? zr[dlo + j] : 0.0f;
 
         __threadfence_block();  // the activation scratch written by the other lanes of this wave is read below
-        f32x16 p0, p1, p2, p3, p4, pF;
-        h_block<false, false>(A0, nullptr, Xw, K0, lane, nullptr, ringw, p0);
+        f32x16 p[NL], pF;
+        h_block<false, false>(A0, nullptr, Xw, K0, lane, nullptr, ringw, p[0]);
         {
             // tile pairing: even tile = its own products + the next tile's over the same operands (raw accumulators to the
             // stash); odd tile = the stash + the 32 units of its partner
@@ -181,24 +186,17 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
             }
             const int koff = mode == 2 ? Kh - HT : 0;         // the partner's units: the last 32 of this tile's K range
             const int Kb = mode == 2 ? HT : Kh;
-#define NF_MAFH_BP(l, OUT)                                                                                                 \
-            h_block_mode(mode, Ah + (size_t)(l) * Kh * HT + (size_t)koff * HT, Ah2 + (size_t)(l) * Kh2 * HT,                  \
-                         Sw + (size_t)(l) * Hp * 32 + (size_t)koff * 32, Kb, lane, Pw + (size_t)(l) * HT * 32, ringw, OUT)
-            NF_MAFH_BP(0, p1);
-            NF_MAFH_BP(1, p2);
-            NF_MAFH_BP(2, p3);
-            NF_MAFH_BP(3, p4);
-            NF_MAFH_BP(4, pF);
-#undef NF_MAFH_BP
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+                h_block_mode(mode, Ah + (size_t)l * Kh * HT + (size_t)koff * HT, Ah2 + (size_t)l * Kh2 * HT,
+                             Sw + (size_t)l * Hp * 32 + (size_t)koff * 32, Kb, lane, Pw + (size_t)l * HT * 32, ringw,
+                             l + 1 < NL ? p[l + 1 < NL ? l + 1 : 0] : pF);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int u = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            p0[r] += bias[u];
-            p1[r] += bias[HT + u];
-            p2[r] += bias[2 * HT + u];
-            p3[r] += bias[3 * HT + u];
-            p4[r] += bias[4 * HT + u];
+#pragma unroll
+            for (int l = 0; l < NL; ++l) p[l][r] += bias[l * HT + u];
             pF[r] += biasF[u];
         }
         f32x16 xg = {0};   // window features dlo-1 .. dlo+14 (0-based): xg[0] is the carry, xg[s+1] the output of step s
@@ -218,67 +216,63 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
         for (int s = 0; s < ns; ++s) {
             const unsigned m = (unsigned)te[4 + s];
             // initial layer: h0 = pre + W0[window] . x ; the residual h0 is folded into the pre-activation of block 1's
-            // second linear (p2), p0 keeps relu(h0) = input of block 1's first linear
+            // second linear (p[2]), p[0] keeps relu(h0) = input of block 1's first linear
             for (unsigned mm = m; mm; mm &= mm - 1) {
                 const int u = __builtin_amdgcn_readfirstlane(__builtin_ctz(mm));
                 const int ru = (u & 3) + 4 * (u >> 3);
                 const bool own = hh == ((u >> 2) & 1);
                 const f32x4 *w_ = reinterpret_cast<const f32x4 *>(W0d) + u * (HS / 4);
-                float a = p0[ru];
+                float a = p[0][ru];
 #pragma unroll
                 for (int f = 0; f < HS; f += 4) {
                     const f32x4 w = w_[f / 4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) a = fmaf(w[i], xg[f + i], a);
                 }
-                p2[ru] = own ? p2[ru] + a : p2[ru];
-                p0[ru] = own ? fmaxf(a, 0.0f) : p0[ru];
+                p[2][ru] = own ? p[2][ru] + a : p[2][ru];
+                p[0][ru] = own ? fmaxf(a, 0.0f) : p[0][ru];
             }
-            for (unsigned mm = m; mm; mm &= mm - 1) {
-                const int u = __builtin_amdgcn_readfirstlane(__builtin_ctz(mm));
-                const int ru = (u & 3) + 4 * (u >> 3);
-                const bool own = hh == ((u >> 2) & 1);
-                MAFH_DOT(Wd, p0)
-                const float tot = xsum((own ? p1[ru] : 0.0f) + (a0 + a1));
-                p1[ru] = own ? fmaxf(tot, 0.0f) : p1[ru];
-            }
-            for (unsigned mm = m; mm; mm &= mm - 1) {
-                const int u = __builtin_amdgcn_readfirstlane(__builtin_ctz(mm));
-                const int ru = (u & 3) + 4 * (u >> 3);
-                const bool own = hh == ((u >> 2) & 1);
-                MAFH_DOT(Wd + HT * HT, p1)
-                const float h1 = xsum((own ? p2[ru] : 0.0f) + (a0 + a1));
-                p4[ru] = own ? p4[ru] + h1 : p4[ru];      // residual stream after block 1 feeds block 2's output
-                p2[ru] = own ? fmaxf(h1, 0.0f) : p2[ru];
-            }
-            for (unsigned mm = m; mm; mm &= mm - 1) {
-                const int u = __builtin_amdgcn_readfirstlane(__builtin_ctz(mm));
-                const int ru = (u & 3) + 4 * (u >> 3);
-                const bool own = hh == ((u >> 2) & 1);
-                MAFH_DOT(Wd + 2 * HT * HT, p2)
-                const float tot = xsum((own ? p3[ru] : 0.0f) + (a0 + a1));
-                p3[ru] = own ? fmaxf(tot, 0.0f) : p3[ru];
-            }
-            for (unsigned mm = m; mm; mm &= mm - 1) {
-                const int u = __builtin_amdgcn_readfirstlane(__builtin_ctz(mm));
-                const int ru = (u & 3) + 4 * (u >> 3);
-                const bool own = hh == ((u >> 2) & 1);
-                MAFH_DOT(Wd + 3 * HT * HT, p3)
-                const float tot = xsum((own ? p4[ru] : 0.0f) + (a0 + a1));
-                p4[ru] = own ? tot : p4[ru];   // = h2, the final layer's input (made.py:304: no activation before it)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                // t_b = L0_b(relu(h_b)): every unit of the degree finishes a layer before the next one starts (same-degree
+                // units see each other across layers, made.py:63-81)
+                for (unsigned mm = m; mm; mm &= mm - 1) {
+                    const int u = __builtin_amdgcn_readfirstlane(__builtin_ctz(mm));
+                    const int ru = (u & 3) + 4 * (u >> 3);
+                    const bool own = hh == ((u >> 2) & 1);
+                    MAFH_DOT(Wd + (2 * b) * HT * HT, p[2 * b])
+                    const float tot = xsum((own ? p[2 * b + 1][ru] : 0.0f) + (a0 + a1));
+                    p[2 * b + 1][ru] = own ? fmaxf(tot, 0.0f) : p[2 * b + 1][ru];
+                }
+                // h_{b+1} = h_b + L1_b(relu(t_b)); h_b sits in the pre-activation already
+                for (unsigned mm = m; mm; mm &= mm - 1) {
+                    const int u = __builtin_amdgcn_readfirstlane(__builtin_ctz(mm));
+                    const int ru = (u & 3) + 4 * (u >> 3);
+                    const bool own = hh == ((u >> 2) & 1);
+                    MAFH_DOT(Wd + (2 * b + 1) * HT * HT, p[2 * b + 1])
+                    const float hn = xsum((own ? p[2 * b + 2][ru] : 0.0f) + (a0 + a1));
+                    if constexpr (true) {
+                        if (b + 1 < NB) {
+                            p[2 * b + 4 < NL ? 2 * b + 4 : 0][ru] = own ? p[2 * b + 4 < NL ? 2 * b + 4 : 0][ru] + hn : p[2 * b + 4 < NL ? 2 * b + 4 : 0][ru];
+                            p[2 * b + 2][ru] = own ? fmaxf(hn, 0.0f) : p[2 * b + 2][ru];
+                        } else {
+                            p[2 * b + 2][ru] = own ? hn : p[2 * b + 2][ru];   // the final layer's input (made.py:304: no activation before it)
+                        }
+                    }
+                }
             }
             {
                 float us, sh, xn;
                 {
                     const int u = 2 * s, ru = (u & 3) + 4 * (u >> 3);
                     const bool own = hh == ((u >> 2) & 1);
-                    MAFH_DOT(WFd, p4)
+                    MAFH_DOT(WFd, p[NL - 1])
                     us = xsum((own ? pF[ru] : 0.0f) + (a0 + a1));
                 }
                 {
                     const int u = 2 * s + 1, ru = (u & 3) + 4 * (u >> 3);
                     const bool own = hh == ((u >> 2) & 1);
-                    MAFH_DOT(WFd, p4)
+                    MAFH_DOT(WFd, p[NL - 1])
                     sh = xsum((own ? pF[ru] : 0.0f) + (a0 + a1));
                 }
                 h_finish(us, sh, zin[s], xn, ld);
@@ -296,11 +290,9 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const size_t o = ((size_t)((4 * t + q) * 2 + hh) * 32 + n) * 4;
-            *reinterpret_cast<f32x4 *>(Sw + (size_t)0 * Hp * 32 + o) = f32x4{p0[4 * q], p0[4 * q + 1], p0[4 * q + 2], p0[4 * q + 3]};
-            *reinterpret_cast<f32x4 *>(Sw + (size_t)1 * Hp * 32 + o) = f32x4{p1[4 * q], p1[4 * q + 1], p1[4 * q + 2], p1[4 * q + 3]};
-            *reinterpret_cast<f32x4 *>(Sw + (size_t)2 * Hp * 32 + o) = f32x4{p2[4 * q], p2[4 * q + 1], p2[4 * q + 2], p2[4 * q + 3]};
-            *reinterpret_cast<f32x4 *>(Sw + (size_t)3 * Hp * 32 + o) = f32x4{p3[4 * q], p3[4 * q + 1], p3[4 * q + 2], p3[4 * q + 3]};
-            *reinterpret_cast<f32x4 *>(Sw + (size_t)4 * Hp * 32 + o) = f32x4{p4[4 * q], p4[4 * q + 1], p4[4 * q + 2], p4[4 * q + 3]};
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+                *reinterpret_cast<f32x4 *>(Sw + (size_t)l * Hp * 32 + o) = f32x4{p[l][4 * q], p[l][4 * q + 1], p[l][4 * q + 2], p[l][4 * q + 3]};
         }
     }
     if (valid && hh == 0) ld_store(logdet + sample, ld, acc);
@@ -308,28 +300,47 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
 
 }  // namespace nf
 
-// nf_maf_inverse on the half-sharing mapping: same blob, table, scratch size and semantics as nf_maf_inverse (maf_inverse.hip).
-extern "C" int nf_maf_inverse_h(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, void *scratch,
-                                int64_t B, int D, int hidden_padded, int acc, nf_stream_t stream) {
+// Scratch of nf_maf_inverse_h: per sample NL hidden_padded activations + the padded feature row + the tile-pair stash.
+extern "C" int64_t nf_maf_inverse_h_scratch_floats(int64_t B, int D, int hidden_padded, int num_blocks) {
+    if (B < 0 || D < 1 || hidden_padded < 0 || num_blocks < 1 || num_blocks > 3) return NF_EINVAL;
+    const int64_t nwt = (B + 31) / 32, Dp = (D + 31) / 32 * 32, NL = 1 + 2 * num_blocks;
+    return nwt * 32 * (NL * (int64_t)hidden_padded + Dp + NL * nf::HT);
+}
+
+template <int NB>
+static int maf_h_launch(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, void *scratch, int64_t B, int D,
+                        int hidden_padded, int acc, hipStream_t st) {
     using namespace nf;
-    if (B < 0 || D < 2 || hidden_padded < 32 || hidden_padded % 32) return NF_EINVAL;
-    if (acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
-    if (B == 0) return NF_OK;
-    if (!z || !y || !logdet || !blob || !table || !scratch) return NF_EFAULT;
-    hipStream_t st = (hipStream_t)stream;
+    constexpr int NL = 1 + 2 * NB;
     const int64_t nwt = (B + 31) / 32;
     const int64_t Dp = (D + 31) / 32 * 32;
     float *S = (float *)scratch;
-    float *Xs = S + nwt * 32 * (int64_t)5 * hidden_padded;
+    float *Xs = S + nwt * 32 * (int64_t)NL * hidden_padded;
     // the feature scratch is read with zero weights before it is written (K0 is padded to 32): it must hold finite values
     if (hipMemsetAsync(Xs, 0, (size_t)nwt * 32 * Dp * sizeof(float), st) != hipSuccess) return NF_EIO;
     float *Ps = Xs + nwt * 32 * Dp;
     const int grid = (int)((nwt + HNW - 1) / HNW);
     const size_t lds_ring = (size_t)HNW * HRB * 256 * sizeof(float);
     static LdsOptIn opted;
-    if (opt_in_lds(reinterpret_cast<const void *>(&maf_inverse_h_kernel), lds_ring + sizeof(float) * H_SEQ, opted) != NF_OK) return NF_ENOTSUP;
-    hipLaunchKernelGGL(maf_inverse_h_kernel, dim3(grid), dim3(64 * HNW), lds_ring, st, (const float *)z, (float *)y, (float *)logdet,
+    if (opt_in_lds(reinterpret_cast<const void *>(&maf_inverse_h_kernel<NB>), lds_ring + sizeof(float) * h_seq(NL), opted) != NF_OK)
+        return NF_ENOTSUP;
+    hipLaunchKernelGGL(maf_inverse_h_kernel<NB>, dim3(grid), dim3(64 * HNW), lds_ring, st, (const float *)z, (float *)y, (float *)logdet,
                        (const float *)blob, (const int *)table, S, Xs, Ps, B, acc);
     NF_CHECK_LAUNCH();
     return NF_OK;
+}
+
+// nf_maf_inverse on the half-sharing mapping: same blob / table format and semantics as nf_maf_inverse (maf_inverse.hip), for
+// MADE conditioners of 1, 2 or 3 residual blocks (table[6]; flows/maf_pack.py).
+extern "C" int nf_maf_inverse_h(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, void *scratch,
+                                int64_t B, int D, int hidden_padded, int num_blocks, int acc, nf_stream_t stream) {
+    if (B < 0 || D < 2 || hidden_padded < 32 || hidden_padded % 32) return NF_EINVAL;
+    if (acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
+    if (num_blocks < 1 || num_blocks > 3) return NF_ENOTSUP;
+    if (B == 0) return NF_OK;
+    if (!z || !y || !logdet || !blob || !table || !scratch) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    if (num_blocks == 1) return maf_h_launch<1>(z, y, logdet, blob, table, scratch, B, D, hidden_padded, acc, st);
+    if (num_blocks == 2) return maf_h_launch<2>(z, y, logdet, blob, table, scratch, B, D, hidden_padded, acc, st);
+    return maf_h_launch<3>(z, y, logdet, blob, table, scratch, B, D, hidden_padded, acc, st);
 }

@@ -70,10 +70,10 @@ class MaskedAffineAutoregressive(Autoregressive):
         key = tuple((p.data_ptr(), p._version) for p in self.autoregressive_net.parameters()) + (str(device),)
         cache = getattr(self, "_maf_pack_cache", None)
         if cache is None or cache[0] != key:
-            packed = maf_pack.pack_made(self.autoregressive_net)
+            packed = maf_pack.pack_made(self.autoregressive_net, blocks=(1, 2, 3))    # 1..3 residual blocks: nf_maf_inverse_h
             if packed is not None:
                 blob, table = packed
-                packed = (torch.from_numpy(blob).to(device), torch.from_numpy(table).to(device), int(table[3]))
+                packed = (torch.from_numpy(blob).to(device), torch.from_numpy(table).to(device), int(table[3]), int(table[6]))
             self._maf_pack_cache = cache = (key, packed)
         return cache[1]
 
@@ -82,7 +82,7 @@ class MaskedAffineAutoregressive(Autoregressive):
                 and not autograd.needs_grad(inputs, *self.autoregressive_net.parameters())):
             packed = self._packed(inputs.device)
             if packed is not None:
-                return ops.maf_inverse(inputs, packed[0], packed[1], packed[2])
+                return ops.maf_inverse(inputs, packed[0], packed[1], packed[2], num_blocks=packed[3])
         return super().inverse(inputs, context)
 
     def _elementwise(self, inputs, params, direction, want_logdet=True):

@@ -15,7 +15,10 @@ This module only rearranges weights (no arithmetic on data).  Layout of the floa
   [0:4]                       final-layer bias of feature 0 (unconstrained scale, shift) + 2 pad: depends on no hidden unit
   per tile t, at table[t].rec : A0 [K0/8][2][32][4] | A1..A4, AF [4t][2][32][4] each | bias[5][32] | biasF[32]
                                 | W0d[32][16] | Wd[4][32][32] | WFd[32][32]
-and of the int32 table: [D, Dp, H, Hp, T, mult, 0, 0] then per tile 24 ints
+  (num_blocks = 2: five hidden layers.  In general NL = 1 + 2 num_blocks hidden layers: A1..A_{NL-1}, AF | bias[NL][32] | biasF
+  | W0d | Wd[NL-1][32][32] | WFd; num_blocks in 1..3 is taken by nf_maf_inverse_h, round 2's nf_maf_inverse / the rows layout
+  only num_blocks = 2)
+and of the int32 table: [D, Dp, H, Hp, T, mult, num_blocks, 0] then per tile 24 ints
   [dlo, nsteps, K0, rec, mask[0..15], 0, 0, 0, 0]   (mask[s] = bitmask of the tile's units that have degree dlo+s).
 
 With `mult` = 2 (affine: unconstrained scale, shift) the final-layer rows of a tile's <= 16 features fit ONE 32-row
@@ -64,13 +67,13 @@ def _a_operand(w_rows_by_k):
     return np.ascontiguousarray(w_rows_by_k.reshape(TILE, K // 8, 2, 4).transpose(1, 2, 0, 3)).reshape(-1)
 
 
-def supported(made, mult=2):
+def supported(made, mult=2, blocks=(2,)):
     from .. import nets
     if not isinstance(made, nets.MADE):
         return False
     if not isinstance(made.preprocessing, torch.nn.Identity) or hasattr(made, "context_layer"):
         return False
-    if len(made.blocks) != 2 or not all(isinstance(b, nets.MaskedResidualBlock) for b in made.blocks):
+    if len(made.blocks) not in blocks or not all(isinstance(b, nets.MaskedResidualBlock) for b in made.blocks):
         return False
     for b in made.blocks:
         if b.use_batch_norm or b.activation is not F.relu or b.dropout.p != 0.0 or hasattr(b, "context_layer"):
@@ -81,17 +84,17 @@ def supported(made, mult=2):
     return 2 <= mult <= TILE
 
 
-def pack_made(made, mult=2, rows=False):
+def pack_made(made, mult=2, rows=False, blocks=(2,)):
     """Returns (blob float32 ndarray, table int32 ndarray) or None if the MADE is not the supported structure.
     `mult` = final-layer outputs per feature (MADE's output_multiplier); `rows` selects the one-block-per-feature
-    layout of nf_arnsf_inverse."""
-    if not supported(made, mult):
+    layout of nf_arnsf_inverse; `blocks`: the residual-block counts the caller's kernel takes."""
+    if not supported(made, mult, blocks) or (rows and len(made.blocks) != 2):
         return None
     D = made.initial_layer.in_features
     H = made.initial_layer.out_features
     hid_deg = made.initial_layer.degrees.cpu().numpy()
-    lin = [made.initial_layer, made.blocks[0].linear_layers[0], made.blocks[0].linear_layers[1],
-           made.blocks[1].linear_layers[0], made.blocks[1].linear_layers[1]]
+    lin = [made.initial_layer] + [l for b in made.blocks for l in b.linear_layers]
+    NB = len(made.blocks)
     for l in lin[1:]:
         if not np.array_equal(l.degrees.cpu().numpy(), hid_deg):
             return None
@@ -161,7 +164,7 @@ def pack_made(made, mult=2, rows=False):
     chunks = [head]
     off = head.size
     table = np.zeros(TABLE_HDR + TABLE_ENT * T, dtype=np.int32)
-    table[0:6] = [D, Dp, H, Hp, T, mult]
+    table[0:7] = [D, Dp, H, Hp, T, mult, NB]
     for t, (dlo, ns, steps) in enumerate(tiles):
         r0, r1 = t * TILE, (t + 1) * TILE
         nprev = dlo - 1                    # features (0-based) 0..dlo-2 come from the block part; dlo-1.. from the window

@@ -804,11 +804,13 @@ def rqs_fused_x3_chain(x, blobs, parities, hidden, num_blocks, K, direction, log
     return y, logdet
 
 
-def maf_inverse(z, blob, table, hidden_padded, logdet=None, acc=None):
-    """autoregressive.py:29-38 + :114-128 in one pass (nf_maf_inverse); blob/table from flows/maf_pack.pack_made."""
+def maf_inverse(z, blob, table, hidden_padded, logdet=None, acc=None, num_blocks=2):
+    """autoregressive.py:29-38 + :114-128 in one pass; blob/table from flows/maf_pack.pack_made.  config.maf_halves (default):
+    nf_maf_inverse_h (32 samples per wave, 1..3 residual blocks); otherwise round 2's nf_maf_inverse (two blocks only)."""
     L.require_device(z, blob, table)
     if z.dtype != torch.float32:
         raise NotImplementedError("maf_inverse: float32 only")
+    from . import config
     B, D = z.shape
     z = z.contiguous()
     y = torch.empty_like(z)
@@ -817,11 +819,18 @@ def maf_inverse(z, blob, table, hidden_padded, logdet=None, acc=None):
         acc = L.LD_WRITE
     elif acc is None:
         acc = L.LD_ADD
-    n = L.lib().nf_maf_inverse_scratch_floats(i64(B), i32(D), i32(hidden_padded))
+    lib = L.lib()
+    if config.maf_halves or num_blocks != 2:
+        n = lib.nf_maf_inverse_h_scratch_floats(i64(B), i32(D), i32(hidden_padded), i32(num_blocks))
+        scratch = torch.empty(max(int(n), 1), dtype=torch.float32, device=z.device)
+        rc = lib.nf_maf_inverse_h(ptr(z), ptr(y), ptr(logdet), ptr(blob), ptr(table), ptr(scratch), i64(B), i32(D),
+                                  i32(hidden_padded), i32(num_blocks), i32(acc), L.stream())
+        L.check(rc, "nf_maf_inverse_h")
+        return y, logdet
+    n = lib.nf_maf_inverse_scratch_floats(i64(B), i32(D), i32(hidden_padded))
     scratch = torch.empty(max(int(n), 1), dtype=torch.float32, device=z.device)
-    from . import config
-    fn = L.lib().nf_maf_inverse_h if config.maf_halves else L.lib().nf_maf_inverse     # same arguments, two mappings (config.py)
-    rc = fn(ptr(z), ptr(y), ptr(logdet), ptr(blob), ptr(table), ptr(scratch), i64(B), i32(D), i32(hidden_padded), i32(acc), L.stream())
+    rc = lib.nf_maf_inverse(ptr(z), ptr(y), ptr(logdet), ptr(blob), ptr(table), ptr(scratch), i64(B), i32(D),
+                            i32(hidden_padded), i32(acc), L.stream())
     L.check(rc, "nf_maf_inverse")
     return y, logdet
 

@@ -18,8 +18,10 @@ def emulate_inverse(blob, table, z, element=None):
     if element is not None:
         return _emulate_rows(blob.astype(np.float64), table, z, element)
     blob = blob.astype(np.float64)
+    NB = int(table[6]) if int(table[6]) > 0 else 2      # residual blocks; NL = 1 + 2 NB hidden layers
+    NL = 1 + 2 * NB
     x = np.zeros((B, Dp))
-    S = np.zeros((5, B, Hp))
+    S = np.zeros((NL, B, Hp))
     ld = np.zeros(B)
 
     def finish(us, sh, zf):
@@ -35,43 +37,44 @@ def emulate_inverse(blob, table, z, element=None):
         Kh = TILE * t
         A0 = _from_a_operand(blob[off:off + K0 * TILE], K0) if K0 else np.zeros((TILE, 0)); off += K0 * TILE
         Ah = []
-        for _ in range(5):  # A1..A4, AF
+        for _ in range(NL):  # A1..A_{NL-1}, AF
             Ah.append(_from_a_operand(blob[off:off + Kh * TILE], Kh) if Kh else np.zeros((TILE, 0))); off += Kh * TILE
-        bias = blob[off:off + 5 * TILE].reshape(5, TILE); off += 5 * TILE
+        bias = blob[off:off + NL * TILE].reshape(NL, TILE); off += NL * TILE
         biasF = blob[off:off + TILE]; off += TILE
         W0d = blob[off:off + TILE * MAX_STEPS].reshape(TILE, MAX_STEPS); off += TILE * MAX_STEPS
-        Wd = blob[off:off + 4 * TILE * TILE].reshape(4, TILE, TILE); off += 4 * TILE * TILE
+        Wd = blob[off:off + (NL - 1) * TILE * TILE].reshape(NL - 1, TILE, TILE); off += (NL - 1) * TILE * TILE
         WFd = blob[off:off + TILE * TILE].reshape(TILE, TILE); off += TILE * TILE
-        pre = np.zeros((5, B, TILE))
+        pre = np.zeros((NL, B, TILE))
         pre[0] = x[:, :K0] @ A0.T + bias[0]
-        for l in range(1, 5):
+        for l in range(1, NL):
             pre[l] = S[l - 1][:, :Kh] @ Ah[l - 1].T + bias[l]
-        preF = S[4][:, :Kh] @ Ah[4].T + biasF
+        preF = S[NL - 1][:, :Kh] @ Ah[NL - 1].T + biasF
         xg = np.zeros((B, MAX_STEPS + 1))
         xg[:, 0] = x[:, dlo - 1]
         for s in range(ns):
             units = [u for u in range(TILE) if (int(masks[s]) >> u) & 1]
+            # initial layer; its output h0 is folded into the pre-activation of the first block's second linear
             for u in units:
                 h = pre[0][:, u] + xg[:, :MAX_STEPS] @ W0d[u]
                 pre[2][:, u] += h
                 pre[0][:, u] = np.maximum(h, 0)
-            for u in units:
-                pre[1][:, u] = np.maximum(pre[1][:, u] + pre[0] @ Wd[0][u], 0)
-            for u in units:
-                h1 = pre[2][:, u] + pre[1] @ Wd[1][u]
-                pre[4][:, u] += h1
-                pre[2][:, u] = np.maximum(h1, 0)
-            for u in units:
-                pre[3][:, u] = np.maximum(pre[3][:, u] + pre[2] @ Wd[2][u], 0)
-            for u in units:
-                pre[4][:, u] = pre[4][:, u] + pre[3] @ Wd[3][u]
-            us = preF[:, 2 * s] + pre[4] @ WFd[2 * s]
-            sh = preF[:, 2 * s + 1] + pre[4] @ WFd[2 * s + 1]
+            for b in range(NB):
+                for u in units:          # t_b = L0_b(relu(h_b))
+                    pre[2 * b + 1][:, u] = np.maximum(pre[2 * b + 1][:, u] + pre[2 * b] @ Wd[2 * b][u], 0)
+                for u in units:          # h_{b+1} = h_b + L1_b(relu(t_b))
+                    hn = pre[2 * b + 2][:, u] + pre[2 * b + 1] @ Wd[2 * b + 1][u]
+                    if b + 1 < NB:
+                        pre[2 * b + 4][:, u] += hn
+                        pre[2 * b + 2][:, u] = np.maximum(hn, 0)
+                    else:
+                        pre[2 * b + 2][:, u] = hn          # the final layer's input (made.py:304: no activation before it)
+            us = preF[:, 2 * s] + pre[NL - 1] @ WFd[2 * s]
+            sh = preF[:, 2 * s + 1] + pre[NL - 1] @ WFd[2 * s + 1]
             xn, d = finish(us, sh, z[:, dlo + s])
             ld += d
             x[:, dlo + s] = xn
             xg[:, s + 1] = xn
-        for l in range(5):
+        for l in range(NL):
             S[l][:, TILE * t:TILE * (t + 1)] = pre[l]
     return x[:, :D], ld
 

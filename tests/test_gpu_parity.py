@@ -1671,3 +1671,24 @@ def test_maf_inverse_both_mappings_agree(nfa, B):
     assert_close(N(res[0][1]), N(res[1][1]), what="logdet", rtol=1e-5, atol=1e-5)
     zz, _ = layer.inverse(res[0][0])
     assert_close(N(zz), N(z), what="round trip", rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("D,H,NB,B", [(128, 512, 1, 4096), (40, 100, 3, 777), (128, 512, 3, 2048), (17, 40, 1, 65)])
+def test_maf_incremental_inverse_other_block_counts(nfa, D, H, NB, B):
+    """nf_maf_inverse_h for MADE conditioners of 1 and 3 residual blocks (nets/made.py:140-214; round 2 took two blocks only and
+    sent the others through the D-pass loop): against the reference's D-pass structure on the same weights; the packer and
+    the schedule for these block counts are pinned on CPU by tests/test_host.py::test_maf_pack_schedule_matches_d_pass."""
+    from normflows_amd.flows.autoregressive import Autoregressive
+    torch.manual_seed(D * 1000 + H + NB)
+    layer = nfa.flows.MaskedAffineAutoregressive(D, H, num_blocks=NB)
+    _perturb(layer, 0.05 if D < 100 else 0.02, 3)
+    layer = layer.to(DEV)
+    packed = layer._packed(DEV)
+    assert packed is not None and packed[3] == NB
+    z = torch.randn(B, D, generator=torch.Generator().manual_seed(5)).to(DEV)
+    x1, ld1 = layer.inverse(z)                       # incremental kernel
+    x0, ld0 = Autoregressive.inverse(layer, z)       # D MADE passes
+    assert_close(N(x1), N(x0), what="x", rtol=2e-4, atol=2e-4)
+    assert_close(N(ld1), N(ld0), what="ld", rtol=2e-4, atol=2e-4)
+    xr, ldr = layer.forward(x1)
+    assert_close(N(xr), N(z), what="roundtrip", rtol=1e-3, atol=1e-3)

@@ -74,6 +74,12 @@ def test_c_abi_argument_validation_newer_entry_points(nfa):
     assert lib.nf_maf_inverse(one, one, one, one, one, one, i64(8), i32(128), i32(500), i32(0), null) == -22
     assert lib.nf_maf_inverse(one, one, one, null, one, one, i64(8), i32(128), i32(512), i32(0), null) == -14
     assert lib.nf_maf_inverse(null, null, null, null, null, null, i64(0), i32(128), i32(512), i32(0), null) == 0
+    lib.nf_maf_inverse_h_scratch_floats.restype = ctypes.c_int64
+    assert lib.nf_maf_inverse_h(one, one, one, one, one, one, i64(8), i32(128), i32(500), i32(2), i32(0), null) == -22
+    assert lib.nf_maf_inverse_h(one, one, one, one, one, one, i64(8), i32(128), i32(512), i32(4), i32(0), null) == -95   # 1..3 residual blocks
+    assert lib.nf_maf_inverse_h(one, one, one, null, one, one, i64(8), i32(128), i32(512), i32(2), i32(0), null) == -14
+    assert lib.nf_maf_inverse_h(null, null, null, null, null, null, i64(0), i32(128), i32(512), i32(1), i32(0), null) == 0
+    assert lib.nf_maf_inverse_h_scratch_floats(i64(64), i32(128), i32(512), i32(2)) == 64 * (5 * 512 + 128 + 5 * 32)
     assert lib.nf_maf_inverse_scratch_floats(i64(65), i32(128), i32(512)) == 2 * 64 * (5 * 512 + 128 + 5 * 32)   # + pair stash
 
     def arnsf(K, tails, hp=512, B=8, blob=one):
@@ -350,8 +356,8 @@ def test_dp_nll_matches_unsharded_under_gloo(nfa, tmp_path):
     assert "DP_OK" in out.stdout
 
 
-@pytest.mark.parametrize("D,H", [(128, 512), (17, 40), (3, 2), (40, 39), (6, 150)])
-def test_maf_pack_schedule_matches_d_pass(D, H):
+@pytest.mark.parametrize("D,H,NB", [(128, 512, 2), (17, 40, 2), (3, 2, 2), (40, 39, 2), (6, 150, 2), (17, 40, 1), (33, 70, 3), (128, 512, 1)])
+def test_maf_pack_schedule_matches_d_pass(D, H, NB):
     """flows/maf_pack.py + the kernel's tile/step schedule (tests/maf_emulator.py restates it in numpy) reproduce the
     fixed point of the reference's D-pass inverse (autoregressive.py:29-38) computed with plain torch in fp64."""
     import normflows_amd as nfa
@@ -359,11 +365,13 @@ def test_maf_pack_schedule_matches_d_pass(D, H):
     from normflows_amd.flows import maf_pack
     from maf_emulator import emulate_inverse
     torch.manual_seed(D + H)
-    made = nets.MADE(features=D, hidden_features=H, num_blocks=2, output_multiplier=2)
+    made = nets.MADE(features=D, hidden_features=H, num_blocks=NB, output_multiplier=2)
     with torch.no_grad():
         for p in made.parameters():
             p.add_((0.1 if D < 100 else 0.01) * torch.randn_like(p))
-    blob, table = maf_pack.pack_made(made)
+    assert maf_pack.pack_made(made) is None or NB == 2          # round 2's kernel / the rows layout: two blocks only
+    blob, table = maf_pack.pack_made(made, blocks=(1, 2, 3))
+    assert table[6] == NB
     assert table[0] == D and table[3] % 32 == 0 and table[3] >= H
     z = torch.randn(16, D)
     m64 = made.double()
