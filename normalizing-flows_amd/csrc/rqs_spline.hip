@@ -329,6 +329,134 @@ rqs_coupling_wave_kernel(const T *__restrict__ x, T *__restrict__ y, T *__restri
     }
 }
 
+// Software-pipelined specialisation of the wave kernel for the default NSF layer shape (D = 64, 32 identity / 32 transform
+// features, 8 bins, linear tails, float32, batch-shared spline on the identity half) -- the layer shapes the fused kernel does
+// not take (hidden > 128, context, ...) still have THIS coupling transform behind their library-GEMM conditioner.  The wave
+// kernel above runs load -> compute -> store per 2-sample pass (114 us at B = 65 536: 2.0 TB/s); here every pass's inputs (the
+// 23-float conditioner rows of its 2 samples, their x rows) arrive by LDS-DMA (global_load_lds, 16 bytes per lane, no
+// registers) into the buffer the PREVIOUS pass is not using, issued before the current pass's arithmetic, and a counted
+// s_waitcnt (memory operations retire in order) replaces the drain -- the scheme of rqs_coupling_bwd_pipe_kernel.
+// MODE: NF_RQS_DENSITY (both halves, forward splines) or NF_RQS_SAMPLE_TRANSFORM (transform half only, inverse spline).
+#define NF_FWD_PIPE_WAVES 8
+template <int MODE>
+__global__ void __launch_bounds__(64 * NF_FWD_PIPE_WAVES, 2)
+rqs_coupling_pipe_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ logdet,
+                         const float *__restrict__ cond, const float *__restrict__ uw, const float *__restrict__ uh,
+                         const float *__restrict__ ud, const int64_t *__restrict__ iidx, const int64_t *__restrict__ tidx,
+                         int64_t B, RqsParams<float> p, int acc) {
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int K = F_K, M = F_M, nI = 32, nT = 32, D = 64, SPW = 2, TW = 3 * (K + 1);
+    constexpr int CONDF = SPW * nT * M;             // 1472 floats of conditioner rows per pass
+    constexpr int XOFF = 1536, BUF = XOFF + SPW * D;  // cond | x
+    constexpr int NC = (CONDF + 255) / 256;         // 1 KB DMA instructions for the rows (6)
+    constexpr int LD_N = NC + 1, ST_N = 2;          // VMEM instructions per pass: loads (rows, x), stores (y rows, logdet)
+    constexpr int PER_WAVE = 2 * BUF + SPW * D;
+    constexpr bool DENS = MODE == NF_RQS_DENSITY;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *s_tab = reinterpret_cast<float *>(smem_raw);                          // nI * TW
+    float *wbase = s_tab + nI * TW + (size_t)wid * PER_WAVE;
+    float *w_y = wbase + 2 * BUF;
+    int *s_iidx = reinterpret_cast<int *>(s_tab + nI * TW + (size_t)NF_FWD_PIPE_WAVES * PER_WAVE);
+    int *s_tidx = s_iidx + nI;
+    for (int j = tid; j < nI; j += blockDim.x) s_iidx[j] = (int)iidx[j];
+    for (int j = tid; j < nT; j += blockDim.x) s_tidx[j] = (int)tidx[j];
+    if (DENS) {
+        for (int j = tid; j < nI; j += blockDim.x) {
+            const float *wj = uw + (size_t)j * K, *hj = uh + (size_t)j * K, *dj = ud + (size_t)j * (K - 1);
+            rqs_build_table<float>(p, [=](int k) { return wj[k]; }, [=](int k) { return hj[k]; }, [=](int k) { return dj[k]; },
+                                   s_tab + (size_t)j * TW);
+        }
+    }
+    __syncthreads();
+
+    const float sc = 1.44269504088896340736f / p.wh_div;
+    const int64_t gw = (int64_t)blockIdx.x * NF_FWD_PIPE_WAVES + wid, GW = (int64_t)gridDim.x * NF_FWD_PIPE_WAVES;
+    auto issue = [&](int64_t b0, float *buf) {
+        const float *csrc = cond + b0 * (int64_t)(nT * M);
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            if (q < NC - 1 || q * 256 + lane * 4 < CONDF)
+                __builtin_amdgcn_global_load_lds(csrc + q * 256 + lane * 4, (lds_ptr)(buf + q * 256), 16, 0, 0);
+        }
+        if (lane < 32) __builtin_amdgcn_global_load_lds(x + b0 * D + lane * 4, (lds_ptr)(buf + XOFF), 16, 0, 0);
+    };
+    const int s_ = lane >> 5, j = lane & 31;
+    const int col_t = s_tidx[j], col_i = s_iidx[j];
+    int64_t b0 = gw * SPW;
+    float *bufc = wbase, *bufn = wbase + BUF;
+    if (b0 < B) issue(b0, bufc);
+    bool first = true;
+    // accumulating into the caller's log-density (acc = add / subtract): its old value is requested FIRST in a pass -- behind the
+    // next pass's row requests the read-modify-write's load would be the youngest operation and waiting for it would drain them
+    const bool has_old = __builtin_amdgcn_readfirstlane(acc != NF_LD_WRITE ? 1 : 0) != 0;
+    for (; b0 < B; b0 += GW * SPW) {
+        const int64_t b1 = b0 + GW * SPW;
+        const bool more = b1 < B;
+        float old = 0.0f;
+        if (has_old && j == 0) old = logdet[b0 + s_];
+        if (more) issue(b1, bufn);
+        // operations younger than this pass's row requests: the previous pass's ST_N stores, this pass's old-value load, the
+        // next pass's LD_N requests
+        if (has_old) {
+            if (first) {
+                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD_N + 1) : "memory");
+                else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            } else {
+                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD_N + ST_N + 1) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST_N + 1) : "memory");
+            }
+        } else {
+            if (first) {
+                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD_N) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD_N + ST_N) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST_N) : "memory");
+            }
+        }
+        first = false;
+        __builtin_amdgcn_wave_barrier();
+        float lad;
+        {   // transform half: lane = (sample, transform feature)
+            const float *row = bufc + (size_t)lane * M;
+            float prm[24];
+#pragma unroll
+            for (int k = 0; k < 2 * K; ++k) prm[k] = row[k] * sc;
+#pragma unroll
+            for (int k = 2 * K; k < M; ++k) prm[k] = row[k];
+            prm[M] = 0.0f;
+            const float xv = bufc[XOFF + s_ * D + col_t];
+            float yy;
+            rqs_regs<!DENS>(p, xv, prm, yy, lad);
+            w_y[s_ * D + col_t] = yy;
+        }
+        {   // identity half: the batch-shared spline (density), or the values passed through (sampling: the caller has them already)
+            const float xv = bufc[XOFF + s_ * D + col_i];
+            float yy = xv;
+            if (DENS) {
+                float ll;
+                rqs_table_fast<false>(p, xv, s_tab + (size_t)j * TW, yy, ll);
+                lad += ll;
+            }
+            w_y[s_ * D + col_i] = yy;
+        }
+        // per-sample log-det: the 32 lanes of a half, fixed butterfly order (deterministic)
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) lad += __shfl_xor(lad, o, 64);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (DENS) {
+            if (lane < 32) *reinterpret_cast<f32x4 *>(y + b0 * D + lane * 4) = *reinterpret_cast<const f32x4 *>(w_y + lane * 4);
+        } else {
+            y[(b0 + s_) * D + col_t] = w_y[s_ * D + col_t];       // sampling: only the transform columns are this call's output
+        }
+        if (j == 0) logdet[b0 + s_] = acc == NF_LD_WRITE ? lad : (acc == NF_LD_ADD ? old + lad : old - lad);
+        __builtin_amdgcn_wave_barrier();
+        float *t = bufc; bufc = bufn; bufn = t;
+    }
+}
+
 #ifndef NF_FWD_TS_ELEMS
 #define NF_FWD_TS_ELEMS 256   // elements per tile and pass: ~one per lane
 #endif
@@ -343,6 +471,35 @@ static int launch_rqs_coupling(const void *x, void *y, void *logdet, const void 
     const int M = 2 * K + p.nd;
     const int Mp = M | 1;
     const int nmax = nT > nI ? nT : nI;
+#ifndef NF_FWD_NO_PIPE
+    if constexpr (std::is_same<T, float>::value) {
+        // the default NSF layer shape on the software-pipelined kernel
+        if (K == F_K && p.tails == NF_TAILS_LINEAR && !p.dfull && !tails_t && !bound_t && !tails_i && !bound_i && nI == 32 && nT == 32 &&
+            D == 64 && (mode == NF_RQS_DENSITY || mode == NF_RQS_SAMPLE_TRANSFORM) && uw && (B & 1) == 0 && B >= 1024 &&
+            ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)cond) & 15) == 0)) {
+            constexpr int BUFp = 1536 + 2 * 64, PERW = 2 * BUFp + 2 * 64;
+            const size_t ldsp = ((size_t)32 * 27 + (size_t)NF_FWD_PIPE_WAVES * PERW) * sizeof(float) + 64 * sizeof(int) + 16;
+            const int64_t nw2 = B / 2, gq2 = (nw2 + NF_FWD_PIPE_WAVES - 1) / NF_FWD_PIPE_WAVES;
+            const int grid2 = (int)(gq2 < 4096 / NF_FWD_PIPE_WAVES ? gq2 : 4096 / NF_FWD_PIPE_WAVES);
+            static LdsOptIn opt_d = {}, opt_s = {};
+            if (mode == NF_RQS_DENSITY) {
+                if (opt_in_lds(reinterpret_cast<const void *>(&rqs_coupling_pipe_kernel<NF_RQS_DENSITY>), ldsp, opt_d) == NF_OK) {
+                    hipLaunchKernelGGL(rqs_coupling_pipe_kernel<NF_RQS_DENSITY>, dim3(grid2), dim3(64 * NF_FWD_PIPE_WAVES), ldsp, st,
+                                       (const float *)x, (float *)y, (float *)logdet, (const float *)cond, (const float *)uw,
+                                       (const float *)uh, (const float *)ud, iidx, tidx, B, p, acc);
+                    NF_CHECK_LAUNCH();
+                    return NF_OK;
+                }
+            } else if (opt_in_lds(reinterpret_cast<const void *>(&rqs_coupling_pipe_kernel<NF_RQS_SAMPLE_TRANSFORM>), ldsp, opt_s) == NF_OK) {
+                hipLaunchKernelGGL(rqs_coupling_pipe_kernel<NF_RQS_SAMPLE_TRANSFORM>, dim3(grid2), dim3(64 * NF_FWD_PIPE_WAVES), ldsp, st,
+                                   (const float *)x, (float *)y, (float *)logdet, (const float *)cond, (const float *)uw,
+                                   (const float *)uh, (const float *)ud, iidx, tidx, B, p, acc);
+                NF_CHECK_LAUNCH();
+                return NF_OK;
+            }
+        }
+    }
+#endif
 #ifndef NF_FWD_NO_WAVE_KERNEL
     {   // wave-private tiles when four waves' regions fit 64 KB of LDS
         int SPW = nmax > 0 ? 64 / nmax : 1;
