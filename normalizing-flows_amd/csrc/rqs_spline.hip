@@ -337,8 +337,10 @@ rqs_coupling_wave_kernel(const T *__restrict__ x, T *__restrict__ y, T *__restri
 // registers) into the buffer the PREVIOUS pass is not using, issued before the current pass's arithmetic, and a counted
 // s_waitcnt (memory operations retire in order) replaces the drain -- the scheme of rqs_coupling_bwd_pipe_kernel.
 // MODE: NF_RQS_DENSITY (both halves, forward splines) or NF_RQS_SAMPLE_TRANSFORM (transform half only, inverse spline).
+// NT: transform (= identity) features, 32 or 64 (D = 64: two samples per pass and wave, D = 128: one); the pass moves the same
+// 1472 + 128 floats either way.
 #define NF_FWD_PIPE_WAVES 8
-template <int MODE>
+template <int MODE, int NT>
 __global__ void __launch_bounds__(64 * NF_FWD_PIPE_WAVES, 2)
 rqs_coupling_pipe_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ logdet,
                          const float *__restrict__ cond, const float *__restrict__ uw, const float *__restrict__ uh,
@@ -346,7 +348,7 @@ rqs_coupling_pipe_kernel(const float *__restrict__ x, float *__restrict__ y, flo
                          int64_t B, RqsParams<float> p, int acc) {
     typedef __attribute__((address_space(3))) void *lds_ptr;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int K = F_K, M = F_M, nI = 32, nT = 32, D = 64, SPW = 2, TW = 3 * (K + 1);
+    constexpr int K = F_K, M = F_M, nI = NT, nT = NT, D = 2 * NT, SPW = 64 / NT, TW = 3 * (K + 1);
     constexpr int CONDF = SPW * nT * M;             // 1472 floats of conditioner rows per pass
     constexpr int XOFF = 1536, BUF = XOFF + SPW * D;  // cond | x
     constexpr int NC = (CONDF + 255) / 256;         // 1 KB DMA instructions for the rows (6)
@@ -381,7 +383,7 @@ rqs_coupling_pipe_kernel(const float *__restrict__ x, float *__restrict__ y, flo
         }
         if (lane < 32) __builtin_amdgcn_global_load_lds(x + b0 * D + lane * 4, (lds_ptr)(buf + XOFF), 16, 0, 0);
     };
-    const int s_ = lane >> 5, j = lane & 31;
+    const int s_ = lane / NT, j = lane % NT;
     const int col_t = s_tidx[j], col_i = s_iidx[j];
     int64_t b0 = gw * SPW;
     float *bufc = wbase, *bufn = wbase + BUF;
@@ -441,9 +443,9 @@ rqs_coupling_pipe_kernel(const float *__restrict__ x, float *__restrict__ y, flo
             }
             w_y[s_ * D + col_i] = yy;
         }
-        // per-sample log-det: the 32 lanes of a half, fixed butterfly order (deterministic)
+        // per-sample log-det: the NT lanes of a sample, fixed butterfly order (deterministic)
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) lad += __shfl_xor(lad, o, 64);
+        for (int o = NT / 2; o > 0; o >>= 1) lad += __shfl_xor(lad, o, 64);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (DENS) {
@@ -473,30 +475,33 @@ static int launch_rqs_coupling(const void *x, void *y, void *logdet, const void 
     const int nmax = nT > nI ? nT : nI;
 #ifndef NF_FWD_NO_PIPE
     if constexpr (std::is_same<T, float>::value) {
-        // the default NSF layer shape on the software-pipelined kernel
-        if (K == F_K && p.tails == NF_TAILS_LINEAR && !p.dfull && !tails_t && !bound_t && !tails_i && !bound_i && nI == 32 && nT == 32 &&
-            D == 64 && (mode == NF_RQS_DENSITY || mode == NF_RQS_SAMPLE_TRANSFORM) && uw && (B & 1) == 0 && B >= 1024 &&
-            ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)cond) & 15) == 0)) {
-            constexpr int BUFp = 1536 + 2 * 64, PERW = 2 * BUFp + 2 * 64;
-            const size_t ldsp = ((size_t)32 * 27 + (size_t)NF_FWD_PIPE_WAVES * PERW) * sizeof(float) + 64 * sizeof(int) + 16;
-            const int64_t nw2 = B / 2, gq2 = (nw2 + NF_FWD_PIPE_WAVES - 1) / NF_FWD_PIPE_WAVES;
+        // the default NSF layer shape (D = 64 or 128, alternating halves) on the software-pipelined kernel
+        if (K == F_K && p.tails == NF_TAILS_LINEAR && !p.dfull && !tails_t && !bound_t && !tails_i && !bound_i && nI == nT &&
+            (nT == 32 || nT == 64) && D == 2 * nT && (mode == NF_RQS_DENSITY || mode == NF_RQS_SAMPLE_TRANSFORM) && uw &&
+            B % (64 / nT) == 0 && B >= 1024 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)cond) & 15) == 0)) {
+            constexpr int BUFp = 1536 + 128, PERW = 2 * BUFp + 128;
+            const size_t ldsp = ((size_t)nT * 27 + (size_t)NF_FWD_PIPE_WAVES * PERW) * sizeof(float) + 2 * nT * sizeof(int) + 16;
+            const int64_t nw2 = B / (64 / nT), gq2 = (nw2 + NF_FWD_PIPE_WAVES - 1) / NF_FWD_PIPE_WAVES;
             const int grid2 = (int)(gq2 < 4096 / NF_FWD_PIPE_WAVES ? gq2 : 4096 / NF_FWD_PIPE_WAVES);
-            static LdsOptIn opt_d = {}, opt_s = {};
+#define NF_FWD_PIPE_LAUNCH(MODE_, NT_)                                                                                              \
+            do {                                                                                                                    \
+                static LdsOptIn opt_ = {};                                                                                          \
+                if (opt_in_lds(reinterpret_cast<const void *>(&rqs_coupling_pipe_kernel<MODE_, NT_>), ldsp, opt_) == NF_OK) {         \
+                    hipLaunchKernelGGL((rqs_coupling_pipe_kernel<MODE_, NT_>), dim3(grid2), dim3(64 * NF_FWD_PIPE_WAVES), ldsp, st,  \
+                                       (const float *)x, (float *)y, (float *)logdet, (const float *)cond, (const float *)uw,       \
+                                       (const float *)uh, (const float *)ud, iidx, tidx, B, p, acc);                                \
+                    NF_CHECK_LAUNCH();                                                                                              \
+                    return NF_OK;                                                                                                   \
+                }                                                                                                                   \
+            } while (0)
             if (mode == NF_RQS_DENSITY) {
-                if (opt_in_lds(reinterpret_cast<const void *>(&rqs_coupling_pipe_kernel<NF_RQS_DENSITY>), ldsp, opt_d) == NF_OK) {
-                    hipLaunchKernelGGL(rqs_coupling_pipe_kernel<NF_RQS_DENSITY>, dim3(grid2), dim3(64 * NF_FWD_PIPE_WAVES), ldsp, st,
-                                       (const float *)x, (float *)y, (float *)logdet, (const float *)cond, (const float *)uw,
-                                       (const float *)uh, (const float *)ud, iidx, tidx, B, p, acc);
-                    NF_CHECK_LAUNCH();
-                    return NF_OK;
-                }
-            } else if (opt_in_lds(reinterpret_cast<const void *>(&rqs_coupling_pipe_kernel<NF_RQS_SAMPLE_TRANSFORM>), ldsp, opt_s) == NF_OK) {
-                hipLaunchKernelGGL(rqs_coupling_pipe_kernel<NF_RQS_SAMPLE_TRANSFORM>, dim3(grid2), dim3(64 * NF_FWD_PIPE_WAVES), ldsp, st,
-                                   (const float *)x, (float *)y, (float *)logdet, (const float *)cond, (const float *)uw,
-                                   (const float *)uh, (const float *)ud, iidx, tidx, B, p, acc);
-                NF_CHECK_LAUNCH();
-                return NF_OK;
+                if (nT == 32) NF_FWD_PIPE_LAUNCH(NF_RQS_DENSITY, 32);
+                else NF_FWD_PIPE_LAUNCH(NF_RQS_DENSITY, 64);
+            } else {
+                if (nT == 32) NF_FWD_PIPE_LAUNCH(NF_RQS_SAMPLE_TRANSFORM, 32);
+                else NF_FWD_PIPE_LAUNCH(NF_RQS_SAMPLE_TRANSFORM, 64);
             }
+#undef NF_FWD_PIPE_LAUNCH
         }
     }
 #endif

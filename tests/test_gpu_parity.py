@@ -1694,8 +1694,8 @@ def test_maf_incremental_inverse_other_block_counts(nfa, D, H, NB, B):
     assert_close(N(xr), N(z), what="roundtrip", rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("B,parity", [(65536, 0), (1024, 1), (4098, 0)])
-def test_rqs_coupling_pipelined_kernel_vs_wave_kernel(nfa, B, parity):
+@pytest.mark.parametrize("B,parity,NT", [(65536, 0, 32), (1024, 1, 32), (4098, 0, 32), (4097, 1, 64), (32768, 0, 64)])
+def test_rqs_coupling_pipelined_kernel_vs_wave_kernel(nfa, B, parity, NT):
     """rqs_coupling_pipe_kernel (round 3: the default NSF layer shape with the conditioner output materialised -- D = 64, 8 bins,
     linear tails, float32, B >= 1024 and even: LDS-DMA double buffering, 114 -> 54 us at B = 65 536) against the wave kernel (the
     same rows in chunks below 1024 rows), both mask parities, the three log-det accumulation modes, density and
@@ -1703,12 +1703,13 @@ def test_rqs_coupling_pipelined_kernel_vs_wave_kernel(nfa, B, parity):
     two kernels: contraction differences of a few ulp)."""
     torch.manual_seed(B + parity)
     dev = DEV
-    x = 1.6 * torch.randn(B, 64, device=dev)
+    D = 2 * NT                                   # 64, or 128 (one sample per pass and wave)
+    x = 1.6 * torch.randn(B, D, device=dev)
     x.view(-1)[:6] = torch.tensor([3.0, -3.0, 3.0000002, float("nan"), float("inf"), 0.0], device=dev)
-    cond = torch.randn(B, 32 * 23, device=dev)
-    uw, uh, ud = torch.randn(32, 8, device=dev), torch.randn(32, 8, device=dev), torch.randn(32, 7, device=dev)
-    ii = torch.arange(parity, 64, 2, device=dev)
-    ti = torch.arange(1 - parity, 64, 2, device=dev)
+    cond = torch.randn(B, NT * 23, device=dev)
+    uw, uh, ud = torch.randn(NT, 8, device=dev), torch.randn(NT, 8, device=dev), torch.randn(NT, 7, device=dev)
+    ii = torch.arange(parity, D, 2, device=dev)
+    ti = torch.arange(1 - parity, D, 2, device=dev)
     kw = dict(tail_bound=3.0, wh_div=float(np.sqrt(128.0)))
     L = nfa._lib
     for mode in (L.RQS_DENSITY, L.RQS_SAMPLE_TRANSFORM):
