@@ -587,7 +587,7 @@ int nf_inv1x1_wgrad(const void *z, const void *gy, const void *gld, void *gW, vo
                     int64_t HW, int dtype, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * y_b = W x_b for every row of a row-major (B, D) float32 matrix, W (D, D) row-major, D <= 64, on exact-fp32 MFMA
+ * y_b = W x_b for every row of a row-major (B, D) float32 matrix, W (D, D) row-major, D <= 128 (nf_rows_matvec2: D <= 64), on exact-fp32 MFMA
  * (HBM-bound: one read and one write of the rows).  The batch-side products of LULinearPermute's backward
  * (mixing.py:535-563 under autograd: u = U x[perm], gu = L^T gy, gx = P U^T gu) with the permutation folded into W.
  * y must not alias x.

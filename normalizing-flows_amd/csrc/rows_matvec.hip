@@ -1,4 +1,4 @@
-// rows_matvec.hip -- y_b = W x_b for every row b of a row-major (B, D) matrix, D <= 64, on exact-fp32 MFMA.
+// rows_matvec.hip -- y_b = W x_b for every row b of a row-major (B, D) matrix, D <= 64 (one product also D <= 128), on exact-fp32 MFMA.
 //
 // The training path's products of batch rows with D x D parameter matrices -- the input gradient of LULinearPermute
 // (mixing.py:535-563 under `loss.backward()`, core.py:87-102: gx = P U^T L^T gy and the triangular factors' inputs
@@ -233,6 +233,74 @@ rows_matvec_kernel(const float *__restrict__ x, const float *__restrict__ W, flo
     }
 }
 
+// The same product for 64 < D <= 128 (LULinearPermute of wider flows, mixing.py:535-563: round 2 sent them to the LDS-column kernel
+// at 0.07 of the HBM peak): four 32-row blocks of W (zero-padded to 128 x 128, 64 KB of LDS in A-operand order), lane-half hh
+// contracts over columns [64 hh, 64 hh + 64) of its own row (sixteen 16-byte loads), 64 accumulator registers.
+__global__ void __launch_bounds__(64 * RM_NW)
+rows_matvec128_kernel(const float *__restrict__ x, const float *__restrict__ W, float *__restrict__ y, int64_t B, int D,
+                      const float *__restrict__ bias, float *__restrict__ logdet, const float *__restrict__ ld_const,
+                      float ld_sign, int acc) {
+    // Wl[m][s4][lane][4]: W[32 m + (lane & 31)][4 s4 + r + 64 (lane >> 5)], m = 0..3, s4 = 0..15
+    extern __shared__ __attribute__((aligned(16))) float Wl[];
+    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
+    for (int i = tid; i < 4 * 16 * 64 * 4; i += 64 * RM_NW) {
+        const int r = i & 3, l = (i >> 2) & 63, s4 = (i >> 8) & 15, m = i >> 12;
+        const int row = 32 * m + (l & 31), col = 4 * s4 + r + 64 * (l >> 5);
+        Wl[i] = (row < D && col < D) ? W[row * D + col] : 0.0f;
+    }
+    const int64_t row = ((int64_t)blockIdx.x * RM_NW + (tid >> 6)) * 32 + (lane & 31);
+    float xv[64];
+    if (D == 128 && row < B) {
+        const float *src = x + row * 128 + 64 * hh;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(src + 4 * q);
+            xv[4 * q] = v[0]; xv[4 * q + 1] = v[1]; xv[4 * q + 2] = v[2]; xv[4 * q + 3] = v[3];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 64; ++k) xv[k] = (row < B && 64 * hh + k < D) ? x[row * D + 64 * hh + k] : 0.0f;
+    }
+    __syncthreads();
+    f32x16 o[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int r0 = 32 * m + 8 * (c >> 2) + 4 * hh + (c & 3);
+            o[m][c] = (bias && r0 < D) ? bias[r0] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float a = Wl[((m * 16 + s4) * 64 + lane) * 4 + r];
+                o[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xv[4 * s4 + r], o[m], 0, 0, 0);
+            }
+        }
+    }
+    if (row < B) {
+        if (logdet && hh == 0) ld_store(logdet + row, ld_sign * (*ld_const), acc);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = 32 * m + 8 * q + 4 * hh;   // C register 4 q + r = output row c0 + r of the product
+                if (D == 128) {
+                    *reinterpret_cast<f32x4 *>(y + row * 128 + c0) = f32x4{o[m][4 * q], o[m][4 * q + 1], o[m][4 * q + 2], o[m][4 * q + 3]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (c0 + r < D) y[row * D + c0 + r] = o[m][4 * q + r];
+                }
+            }
+        }
+    }
+}
+
 // u_b = W1 x_b, y_b = W2 u_b (+ bias) in ONE launch: LULinearPermute's two batch-side products (forward: u = U x[perm] kept for
 // the backward, y = L u + b; backward: gu = L^T gy kept for the factor gradients, gx = P U^T gu).  The first product's C
 // registers are the second product's B operand: lane-half hh of C register c of row-block m1 holds unit
@@ -329,11 +397,21 @@ using namespace nf;
 extern "C" int nf_rows_matvec_affine(const void *x, const void *W, const void *bias, void *y, void *logdet,
                                      const void *ld_const, double ld_sign, int acc, int64_t B, int D, nf_stream_t stream) {
     if (B < 0 || D < 1 || acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
-    if (D > RM_D) return NF_ENOTSUP;
+    if (D > 2 * RM_D) return NF_ENOTSUP;
     if (B == 0) return NF_OK;
     if (!x || !W || !y || (logdet && !ld_const)) return NF_EFAULT;
     const int64_t grid = (B + 32 * RM_NW - 1) / (32 * RM_NW);
     if (grid > 0x7fffffff) return NF_ERANGE;
+    if (D > RM_D) {
+        const size_t lds = (size_t)4 * 16 * 64 * 4 * sizeof(float);
+        static LdsOptIn opted = {};
+        if (opt_in_lds(reinterpret_cast<const void *>(&rows_matvec128_kernel), lds, opted) != NF_OK) return NF_ENOTSUP;
+        hipLaunchKernelGGL(rows_matvec128_kernel, dim3((unsigned)grid), dim3(64 * RM_NW), lds, (hipStream_t)stream, (const float *)x,
+                           (const float *)W, (float *)y, B, D, (const float *)bias, (float *)logdet, (const float *)ld_const,
+                           (float)ld_sign, acc);
+        NF_CHECK_LAUNCH();
+        return NF_OK;
+    }
     hipLaunchKernelGGL(rows_matvec_kernel, dim3((unsigned)grid), dim3(64 * RM_NW), 0, (hipStream_t)stream, (const float *)x,
                        (const float *)W, (float *)y, B, D, (const float *)bias, (float *)logdet, (const float *)ld_const,
                        (float)ld_sign, acc);

@@ -288,6 +288,19 @@ class LULinearPermute(Flow):
                                                  ld, 1 if (acc is None or acc > 0) else -1, fout,
                                                  self.__dict__.setdefault("_img_holder", {}) if fout is not None else None)
             return y, log_det            # log_det IS ld (updated in place) when the caller passed its accumulator
+        if z.dtype == torch.float32 and z.is_cuda and 64 < lin.features <= 128 and self.use_dense:
+            # wider layers (round 3): the same ONE dense product on fp32 MFMA (nf_rows_matvec_affine takes D <= 128); the
+            # D x D matrices are composed in float64 by a handful of torch launches once per parameter version (the one-workgroup
+            # composer keeps four D x D fp64 matrices in LDS: 64 x 64 at most)
+            params = (lin.lower_entries, lin.upper_entries, lin.unconstrained_upper_diag, lin.bias)
+            key = tuple((p_.data_ptr(), p_._version) for p_ in params)
+            cache = self.__dict__.get("_dense_cache")
+            if cache is None or cache[0] != key:
+                cache = self._dense_cache = (key, self._compose_wide())
+            Wd, Ws, bd, bs, lad = cache[1]
+            if inverse:
+                return ops.rows_matvec_affine(z, Wd, bd, lad, +1.0, logdet=ld, acc=acc)
+            return ops.rows_matvec_affine(z, Ws, bs, lad, -1.0, logdet=ld, acc=acc)
         if z.dtype == torch.float32 and z.is_cuda and lin.features <= 64 and self.use_dense:
             # the layer as ONE dense D x D product on fp32 MFMA (nf_lu_compose once per parameter version + nf_rows_matvec_affine):
             # HBM-bound, 5x the LDS-tile kernel below, which stays for D > 64 and float64
@@ -305,6 +318,31 @@ class LULinearPermute(Flow):
         return ops.lu_linear_permute(z, self.permutation._permutation, lin.lower_entries.detach(),
                                      lin.upper_entries.detach(), lin.unconstrained_upper_diag.detach(),
                                      lin.bias.detach(), 0 if inverse else 1, eps=lin.eps, logdet=ld, acc=acc)
+
+    def _compose_wide(self):
+        """(Wd, Ws, bias_d, bias_s, log|det|) of mixing.py:402-473, :535-563 as dense matrices, float64 arithmetic on the device:
+        density y = L (U x[perm]) + b -> Wd[:, perm] = L U; sample y[perm] = U^-1 L^-1 (x - b) -> Ws[perm] = U^-1 L^-1, bias_s = -Ws b."""
+        lin, perm = self.linear, self.permutation._permutation
+        D = lin.features
+        dev = lin.bias.device
+        with torch.no_grad():
+            Lm = torch.eye(D, dtype=torch.float64, device=dev)
+            Um = torch.zeros(D, D, dtype=torch.float64, device=dev)
+            li, ui = torch.tril_indices(D, D, -1, device=dev), torch.triu_indices(D, D, 1, device=dev)
+            Lm[li[0], li[1]] = lin.lower_entries.detach().double()
+            Um[ui[0], ui[1]] = lin.upper_entries.detach().double()
+            diag = (torch.nn.functional.softplus(lin.unconstrained_upper_diag.detach()) + lin.eps).double()
+            Um[torch.arange(D, device=dev), torch.arange(D, device=dev)] = diag
+            Wd = torch.zeros(D, D, dtype=torch.float64, device=dev)
+            Wd[:, perm] = Lm @ Um
+            eye = torch.eye(D, dtype=torch.float64, device=dev)
+            inv = torch.linalg.solve_triangular(Um, torch.linalg.solve_triangular(Lm, eye, upper=False, unitriangular=True), upper=True)
+            Ws = torch.zeros(D, D, dtype=torch.float64, device=dev)
+            Ws[perm] = inv
+            b = lin.bias.detach().double()
+            lad = torch.log(torch.nn.functional.softplus(lin.unconstrained_upper_diag.detach()) + lin.eps).sum().reshape(1)
+            return (Wd.float().contiguous(), Ws.float().contiguous(), b.float().contiguous(), (-(Ws @ b)).float().contiguous(),
+                    lad.float().contiguous())
 
     def _train_factors_ok(self, z):
         """The density direction under autograd assembles its factors with nf_lu_factors (LULinearPermuteFn.forward)."""

@@ -376,7 +376,7 @@ def lu_param_grads(gL, gU, gld, unconstrained_upper_diag, n_tri, eps=1e-3, sign=
 
 
 def rows_matvec_affine(x, W, bias, ld_const=None, ld_sign=1.0, logdet=None, acc=None):
-    """y_b = W x_b + bias and logdet[b] (acc) ld_sign * ld_const (nf_rows_matvec_affine); (B, D <= 64) float32."""
+    """y_b = W x_b + bias and logdet[b] (acc) ld_sign * ld_const (nf_rows_matvec_affine); (B, D <= 128) float32."""
     L.require_device(x, W, bias, ld_const, logdet)
     x = x.contiguous()
     B, D = x.shape

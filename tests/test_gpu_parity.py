@@ -1737,3 +1737,37 @@ def test_rqs_coupling_pipelined_kernel_vs_wave_kernel(nfa, B, parity, NT):
             if acc is None:
                 y3, l3 = nfa.ops.rqs_coupling(x, cond, uw, uh, ud, ii, ti, 8, mode, y=(x.clone() if ya is not None else None), **kw)
                 assert torch.equal(torch.nan_to_num(y1), torch.nan_to_num(y3)) and torch.equal(l1, l3)
+
+
+@pytest.mark.parametrize("D,B", [(128, 65536), (100, 1000), (65, 37)])
+def test_lu_linear_permute_wide_dense_path(nfa, oracle, D, B):
+    """LULinearPermute with 64 < D <= 128 as ONE dense product on fp32 MFMA (nf_rows_matvec_affine, round 3; the matrices composed
+    in float64 once per parameter version) against the LDS-column kernel nf_lu_linear_permute and the oracle, both directions,
+    log-det accumulation, round trip."""
+    torch.manual_seed(D)
+    layer = nfa.flows.LULinearPermute(D).to(DEV)
+    with torch.no_grad():
+        layer.linear.lower_entries.normal_(0, 0.1)
+        layer.linear.upper_entries.normal_(0, 0.1)
+        layer.linear.bias.normal_(0, 0.5)
+        layer.linear.unconstrained_upper_diag.normal_(0.5, 0.3)
+    x = torch.randn(B, D, device=DEV)
+    st = {"flows.0." + k: v.detach().cpu().numpy() for k, v in layer.state_dict().items()}
+    for inverse in (True, False):
+        layer.use_dense = True
+        acc = torch.full((B,), 0.25, device=DEV)
+        z1 = layer._run(x, inverse, acc, +1)
+        layer.use_dense = False
+        acc2 = torch.full((B,), 0.25, device=DEV)
+        z2 = layer._run(x, inverse, acc2, +1)
+        layer.use_dense = True
+        assert_close(N(z1), N(z2), what="dense vs LDS-column kernel", rtol=2e-5, atol=2e-5)
+        assert_close(N(acc), N(acc2), what="log-det", rtol=1e-5, atol=1e-5)
+    z, ld = layer.inverse(x)
+    xr, ldr = layer.forward(z)
+    assert_close(N(xr), N(x), what="round trip", rtol=1e-4, atol=1e-4)
+    assert_close(N(ldr), -N(ld), what="round trip log-det", rtol=1e-5, atol=1e-5)
+    with torch.no_grad():            # the cache follows parameter updates
+        layer.linear.bias.add_(1.0)
+    z3, _ = layer.inverse(x)
+    assert_close(N(z3), N(z) + 1.0, what="bias update", rtol=1e-5, atol=1e-5)
