@@ -124,10 +124,19 @@ __global__ void gc_pack_kernel(const float *__restrict__ W1, const float *__rest
 }
 
 #define GC_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+// Workgroup barrier of these kernels: LDS traffic of the wave drained, vector-memory operations left alone.  __syncthreads()
+// is a fence, which the compiler implements as s_waitcnt vmcnt(0): every barrier then waits for everything a wave has in
+// flight -- the younger stages of the weight rings (which made the depth of a ring irrelevant), the next block's first
+// stages during the serial phases, the 16-unit register stream of the 16-pixel kernel.  Whatever crosses waves here goes
+// through LDS; data that arrives by DMA is waited for explicitly (counted vmcnt) before the barrier that publishes it.
+#define GL_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define GC_RING_BARRIER() GL_BARRIER()
 
 // acc += Wblock(32 x 128) * B with the B operand of (k-group s, r) = bsrc[s >> 2][4 (s & 3) + r]: 16 ds_read_b128 + 64 MFMA
 __device__ __forceinline__ void gc_mm128(const float *buf, int lane, f32x16 &acc, const f32x16 &b0, const f32x16 &b1,
                                          const f32x16 &b2, const f32x16 &b3) {
+    // (requesting the A operands two k-groups ahead of their MFMAs was measured in round 3: slower here -- with two MFMA
+    // waves per SIMD the other wave covers the read latency and the extra registers cost more)
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         const f32x4 a = *reinterpret_cast<const f32x4 *>(buf + s * 256 + lane * 4);
@@ -255,6 +264,51 @@ __device__ __forceinline__ void gl_prefetch(const GlowLevel &lv, int b, int nsma
     if (wid == NW - 1 && lane < C) __builtin_amdgcn_global_load_lds(bp + lane, (lds_ptr)(wmix_dst + nw), 4, 0, 0);   // C <= 64
 }
 
+// The per-pixel mix zalt[c][p] = bp[c] + sum_k Wp[c][k] zin[k][p] (k ascending, one fma per term: the order of the plain
+// loop).  Thread = (pixel p, channel residue cg mod NG): the zin column of the pixel is read once per GL_MJ channels, the
+// matrix rows as 16-byte reads, four k at a time -- a thread of the plain loop waited for two LDS reads per fma, and the
+// prologue of a block was this loop (6 of 8 us at the 8x8 level of config 4).
+constexpr int GL_MJ = 3;
+template <int PXW, int NT>
+__device__ __forceinline__ void gl_mix(const float *wmix, const float *zin, float *zalt, int C, int tid) {
+    constexpr int NG = NT / PXW;
+    static_assert(NT % PXW == 0, "pixels must divide the workgroup");
+    const bool vec = (C & 3) == 0 && ((uint32_t)(uintptr_t)wmix & 15u) == 0;
+    if (!vec) {
+        for (int i = tid; i < C * PXW; i += NT) {
+            const int c = i / PXW, p = i - c * PXW;
+            float a = wmix[C * C + c];
+            for (int k = 0; k < C; ++k) a = fmaf(wmix[c * C + k], zin[k * PXW + p], a);
+            zalt[i] = a;
+        }
+        return;
+    }
+    const int p = tid % PXW, cg = tid / PXW;
+    for (int c0 = cg; c0 < C; c0 += NG * GL_MJ) {
+        int cj[GL_MJ];
+        float a[GL_MJ];
+#pragma unroll
+        for (int j = 0; j < GL_MJ; ++j) {
+            cj[j] = c0 + j * NG < C ? c0 + j * NG : c0;   // past the end: channel c0 again, not stored
+            a[j] = wmix[C * C + cj[j]];
+        }
+        for (int k = 0; k < C; k += 4) {
+            float z[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z[i] = zin[(k + i) * PXW + p];
+#pragma unroll
+            for (int j = 0; j < GL_MJ; ++j) {
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(wmix + cj[j] * C + k);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[j] = fmaf(w[i], z[i], a[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < GL_MJ; ++j)
+            if (c0 + j * NG < C) zalt[(c0 + j * NG) * PXW + p] = a[j];
+    }
+}
+
 // Start of block b (its mix matrix `wmix` was prefetched): direction 1 mixes zin -> zalt; the conditioner's zero-padded input
 // images come from the identity half of the mixed (direction 1) / raw (direction 0) planes.  Ends WITHOUT a barrier
 // (the caller's next barrier publishes xin).
@@ -266,16 +320,11 @@ __device__ __forceinline__ void gl_pre(const GlowLevel &lv, int b, const float *
     // the prefetched sections of this block (block 0's were issued last, just before this call)
     if (b == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
-    __syncthreads();   // ... and zin (the level load / the previous block's output)
+    GL_BARRIER();   // ... and zin (the level load / the previous block's output)
     const float *src = zin;
     if (lv.direction == 1) {
-        for (int i = tid; i < C * PXW; i += NT) {
-            const int c = i / PXW, p = i - c * PXW;
-            float a = wmix[C * C + c];
-            for (int k = 0; k < C; ++k) a = fmaf(wmix[c * C + k], zin[k * PXW + p], a);
-            zalt[i] = a;
-        }
-        __syncthreads();
+        gl_mix<PXW, NT>(wmix, zin, zalt, C, tid);
+        GL_BARRIER();
         src = zalt;
     }
     const int per_img = lv.c1 * PH * PW, n = IPW * per_img;
@@ -293,7 +342,7 @@ template <int PXW, int NT>
 __device__ __forceinline__ void gl_post(const GlowLevel &lv, int b, float *zin, float *zalt, const float *wmix, const float *prm,
                                         float *ldt, float *ldacc, int H, int W, int tid) {
     const int HW = H * W, IPW = PXW / HW, C = lv.C, c1 = lv.c1, n2 = C - c1;
-    __syncthreads();   // parameter planes complete
+    GL_BARRIER();   // parameter planes complete
     float *z2 = (lv.direction == 1 ? zalt : zin) + c1 * PXW;
     for (int e = tid; e < n2 * PXW; e += NT) {
         const int i = e / PXW, p = e - i * PXW;
@@ -310,15 +359,8 @@ __device__ __forceinline__ void gl_post(const GlowLevel &lv, int b, float *zin, 
         ldt[e] = lv.direction == 0 ? l : -l;
         z2[e] = o;
     }
-    __syncthreads();
-    if (lv.direction == 0) {
-        for (int i = tid; i < C * PXW; i += NT) {
-            const int c = i / PXW, p = i - c * PXW;
-            float a = wmix[C * C + c];
-            for (int k = 0; k < C; ++k) a = fmaf(wmix[c * C + k], zin[k * PXW + p], a);
-            zalt[i] = a;
-        }
-    }
+    GL_BARRIER();
+    if (lv.direction == 0) gl_mix<PXW, NT>(wmix, zin, zalt, C, tid);
     const int lane = tid & 63, wv = tid >> 6;
     const float ldu = *lv.ldu(b);
     for (int im = wv; im < IPW; im += NT / 64) {
@@ -330,7 +372,7 @@ __device__ __forceinline__ void gl_post(const GlowLevel &lv, int b, float *zin, 
         a = wave_sum(a);
         if (lane == 0) ldacc[im] += a + (float)HW * ldu;
     }
-    __syncthreads();
+    GL_BARRIER();
 }
 
 // Padded input images of the conditioner from global memory (plain call).
@@ -445,7 +487,9 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
     auto acquire = [&]() -> const float * {
         if (stage + GC_RING - 2 < all_stages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((GC_RING - 2) * PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // a raw barrier: __syncthreads() is a fence, which the compiler implements as s_waitcnt vmcnt(0) -- it waited for the
+        // DMAs of ALL stages in flight at every stage and made the depth of the ring irrelevant (found in round 3)
+        GC_RING_BARRIER();
         if (stage + GC_RING - 1 < all_stages) issue(stage + GC_RING - 1);   // runs on into the NEXT block's first stages
         const float *buf = ring + (stage % GC_RING) * GC_STAGE;
         ++stage;
@@ -517,7 +561,7 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
         }
         gc_leaky(acc, mt.slope);
     };
-    __syncthreads();   // the prologue's LDS writes
+    GL_BARRIER();   // the prologue's LDS writes
     GL_T(b, 1);
 #pragma unroll
     for (int s = 0; s < GC_KG1MAX; ++s) {
@@ -562,9 +606,9 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
             const f32x16 &o = mm == 0 ? O0 : (mm == 1 ? O1 : (mm == 2 ? O2 : O3));
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) P[(8 * (reg >> 2) + 4 * hh + (reg & 3)) * GC_PX + px] = o[reg];
-            __syncthreads();
+            GL_BARRIER();
             gc_gather_block<GC_PX, 64 * GC_NW>(P, blk, mt, H, W, img0, B, small, out, fused ? pl.prm : nullptr, tid);
-            __syncthreads();
+            GL_BARRIER();
             }
         }
     }
@@ -583,9 +627,19 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
 // workgroups).  Here a wave owns 16 pixels: h1 = 16 x f32x4 per lane, every output block fits the register file, so ONE
 // sweep over h2 serves all output channels (OBT = capacity in 32-row output blocks).  C layout of the 16x16x4 MFMA:
 // lane (g = lane >> 4, pixel = lane & 15) holds rows 4 g + r; the contraction k = 16 b + 4 g + r pairs lane group g with
-// the rows it holds, as in the wide kernel.  One wave per SIMD: the weight ring is 4 stages deep to cover L2 latency.
+// the rows it holds, as in the wide kernel.  One MFMA wave per SIMD: the weight ring is 4 stages deep to cover L2 latency.
+// Next to the GS_NW MFMA waves the workgroup has GS_HW helper waves (round 3): they issue ALL of the ring's LDS-DMAs and
+// prefetches (a vector-memory instruction costs the issuing wave 100-250 cycles, ~400 of the 2048 cycles of a stage when
+// the MFMA waves issued them) and do half of the serial phases around the GEMMs (mix, padded images, col2im, coupling),
+// which are latency-bound loops over the workgroup's threads.
 #define GC_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 constexpr int GS_NW = 4;
+#ifndef NF_GS_HW
+#define NF_GS_HW 4
+#endif
+// helper waves per instantiation (0: the MFMA waves do everything, as in round 2): with helpers the workgroup has two waves
+// per SIMD and 256 registers per lane, which the 16-block instantiation (64 output accumulators more) does not fit
+template <int OBT> struct GsHelpers { static constexpr int value = OBT <= 8 ? NF_GS_HW : 0; };
 constexpr int GS_PX = 16 * GS_NW;
 constexpr int GS_RING = 4;
 constexpr int GS_KB1MAX = 16;   // k-blocks of GEMM 1 whose gathered operands fit the register file (Cin <= 28)
@@ -596,9 +650,12 @@ __device__ __forceinline__ void gs_leaky(f32x4 &v, float slope) {
 }
 
 template <int OBT>
-__global__ void __launch_bounds__(64 * GS_NW)
+__global__ void __launch_bounds__(64 * (GS_NW + GsHelpers<OBT>::value))
 glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__restrict__ out,
                           const float *__restrict__ blob0, GcMeta mt, int64_t B, int H, int W, GlowLevel lv) {
+    constexpr int GS_HW = GsHelpers<OBT>::value;
+    constexpr int GS_DW = GS_HW ? GS_HW : GS_NW;   // waves that issue DMAs
+    constexpr int GS_NT = 64 * (GS_NW + GS_HW);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int HW = H * W, PH = H + 2, PW = W + 2, IPW = GS_PX / HW;
     const int nkb1 = (mt.K1 + 15) / 16, K1p = 16 * nkb1;
@@ -610,7 +667,10 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
     const GlPlanes pl = gl_planes(xin + IPW * mt.Cin * PH * PW, lv, mt.Cout, GS_PX);
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int px = wid * 16 + (lane & 15);
+    const bool mfma_wave = wid < GS_NW;                      // wave-uniform
+    const bool dma_wave = GS_HW ? !mfma_wave : true;
+    const int dwid = GS_HW ? wid - GS_NW : wid;              // index among the DMA waves
+    const int px = (wid % GS_NW) * 16 + (lane & 15);
     const int li = px / HW, pin = px - li * HW, py = pin / W, pxx = pin - py * W;
     const int base0 = li * mt.Cin * PH * PW + py * PW + pxx;
     const int64_t img0 = (int64_t)blockIdx.x * IPW;
@@ -624,16 +684,16 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
         const int q = s - nst_l1, j = q / per_j, t = q - per_j * j;
         return t < 2 ? nst_l1 + 2 * j + t : nst_l1 + 16 + 8 * (t - 2) + j;
     };
-    constexpr int PPW = 16 / GS_NW;
-    for (int k = tid; k < K1p; k += 64 * GS_NW) {
+    constexpr int PPW = 16 / GS_DW;
+    for (int k = tid; k < K1p; k += GS_NT) {
         const int kk = k < mt.K1 ? k : mt.K1 - 1;
         const int c = kk / 9, t = kk - 9 * c, ky = t / 3;
         koff[k] = c * PH * PW + ky * PW + (t - 3 * ky);
     }
     float *zin = pl.zA, *zalt = pl.zB;
     if (fused) {
-        gl_prefetch<GS_NW>(lv, 0, mt.small, small0, pl.wmix, wid, lane);
-        gl_load<GS_PX, 64 * GS_NW>(lv, zin, pl.ldacc, H, W, img0, B, tid);
+        if (dma_wave) gl_prefetch<GS_DW>(lv, 0, mt.small, small0, pl.wmix, dwid, lane);
+        gl_load<GS_PX, GS_NT>(lv, zin, pl.ldacc, H, W, img0, B, tid);
     }
 
     for (int b = 0; b < nb; ++b) {
@@ -642,18 +702,22 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
     const float *stages = blob + gc_off_stages(mt);
     int stage = 0;   // per block: the ring is the col2im scratch at the end of a block, so the stream restarts
     auto issue = [&](int gs) {
-        const float *src = stages + (size_t)phys(gs) * GC_STAGE + (wid * PPW) * 256 + lane * 4;
-        float *dst = ring + (gs % GS_RING) * GC_STAGE + (wid * PPW) * 256;
+        const float *src = stages + (size_t)phys(gs) * GC_STAGE + (dwid * PPW) * 256 + lane * 4;
+        float *dst = ring + (gs % GS_RING) * GC_STAGE + (dwid * PPW) * 256;
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
             __builtin_amdgcn_global_load_lds(src + i * 256, (__attribute__((address_space(3))) void *)(dst + i * 256), 16, 0, 0);
     };
     auto acquire = [&]() -> const float * {
         // stages stage+1 .. stage+RING-2 may stay in flight (loads retire in order); the tail drains everything
-        if (stage + GS_RING - 2 < total_stages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((GS_RING - 2) * PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();   // everyone's pieces of `stage` have landed; everyone is done with stage - 1 (slot reused below)
-        if (stage + GS_RING - 1 < total_stages) issue(stage + GS_RING - 1);
+        if (dma_wave) {
+            if (stage + GS_RING - 2 < total_stages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((GS_RING - 2) * PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        // everyone's pieces of `stage` have landed; everyone is done with stage - 1 (slot reused below).  (One barrier per
+        // PAIR of stages, 6 slots: measured in round 3, no gain -- the barrier count is not what is left.)
+        GC_RING_BARRIER();
+        if (dma_wave && stage + GS_RING - 1 < total_stages) issue(stage + GS_RING - 1);
         const float *buf = ring + (stage % GS_RING) * GC_STAGE;
         ++stage;
         return buf;
@@ -663,22 +727,30 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
     // the first stages go out FIRST (the ring is free: the previous block's col2im is behind a barrier) and land while
     // the biases, the mix and the padded images are prepared.  The ring's in-order accounting needs an empty queue in front.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (dma_wave) {
 #pragma unroll
-    for (int i = 0; i < GS_RING - 1; ++i)
-        if (i < total_stages) issue(i);
+        for (int i = 0; i < GS_RING - 1; ++i)
+            if (i < total_stages) issue(i);
+    }
     float *small = (fused && (b & 1)) ? pl.small2 : small0;
     const float *wmix = (b & 1) ? pl.wmix2 : pl.wmix;
     if (fused) {
-        gl_pre<GS_PX, 64 * GS_NW, (GS_RING - 1) * (16 / GS_NW)>(lv, b, zin, zalt, wmix, xin, H, W, tid);
-        if (b + 1 < nb) gl_prefetch<GS_NW>(lv, b + 1, mt.small, (b & 1) ? small0 : pl.small2, (b & 1) ? pl.wmix : pl.wmix2, wid, lane);
+        gl_pre<GS_PX, GS_NT, (GS_RING - 1) * PPW>(lv, b, zin, zalt, wmix, xin, H, W, tid);
+        if (dma_wave && b + 1 < nb)
+            gl_prefetch<GS_DW>(lv, b + 1, mt.small, (b & 1) ? small0 : pl.small2, (b & 1) ? pl.wmix : pl.wmix2, dwid, lane);
     } else {
-        for (int i = tid; i < mt.small; i += 64 * GS_NW) small[i] = blob[GC_HDR + i];
-        gc_fill_xin_global<GS_PX, 64 * GS_NW>(x, xs_img, xin, mt.Cin, H, W, img0, B, tid);
+        for (int i = tid; i < mt.small; i += GS_NT) small[i] = blob[GC_HDR + i];
+        gc_fill_xin_global<GS_PX, GS_NT>(x, xs_img, xin, mt.Cin, H, W, img0, B, tid);
     }
-    __syncthreads();
+    GL_BARRIER();
     GL_T(b, 1);
 
+    f32x4 O[2 * OBT];
+    if (!mfma_wave) {
+        for (int s = 0; s < total_stages; ++s) acquire();   // the helpers keep the ring turning
+    } else {
     // ---- GEMM 1: h1 (16 blocks of 16 channels) ----
+    auto lda = [&](const float *buf, int piece) { return *reinterpret_cast<const f32x4 *>(buf + piece * 256 + lane * 4); };
     f32x4 Hh[16];
 #pragma unroll
     for (int b = 0; b < 16; ++b) Hh[b] = *reinterpret_cast<const f32x4 *>(small + 16 * b + 4 * g);
@@ -696,17 +768,22 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
             for (int c = 0; c < GS_KB1MAX / 8; ++c) {
                 if (c < mt.nst1) {
                     const float *buf = acquire();
+                    f32x4 a0 = lda(buf, 0), a1 = lda(buf, 8);
 #pragma unroll
                     for (int kb = 0; kb < 8; ++kb) {
+                        // the next k-block's A operands are requested before this one's MFMAs (the compiler, left alone,
+                        // reads, waits, multiplies: an LDS latency per 8 MFMAs with one MFMA wave per SIMD)
+                        f32x4 n0 = a0, n1 = a1;
+                        if (kb < 7) { n0 = lda(buf, kb + 1); n1 = lda(buf, 9 + kb); }
+                        __builtin_amdgcn_sched_barrier(0);
                         if (8 * c + kb < nkb1) {
-                            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(buf + kb * 256 + lane * 4);
-                            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(buf + (8 + kb) * 256 + lane * 4);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 Hh[2 * mb] = GC_MFMA16(a0[r], bv[4 * (8 * c + kb) + r], Hh[2 * mb]);
                                 Hh[2 * mb + 1] = GC_MFMA16(a1[r], bv[4 * (8 * c + kb) + r], Hh[2 * mb + 1]);
                             }
                         }
+                        a0 = n0; a1 = n1;
                     }
                 }
             }
@@ -740,7 +817,6 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
 
     GL_T(b, 2);
     // ---- one sweep: h2 block by block (GEMM 2), each consumed at once by GEMM 3 ----
-    f32x4 O[2 * OBT];
 #pragma unroll
     for (int i = 0; i < 2 * OBT; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int j = 0; j < 8; ++j) {
@@ -749,15 +825,18 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const float *buf = acquire();
+            f32x4 a0 = lda(buf, 0), a1 = lda(buf, 8);
 #pragma unroll
             for (int kb = 0; kb < 8; ++kb) {
-                const f32x4 a0 = *reinterpret_cast<const f32x4 *>(buf + kb * 256 + lane * 4);
-                const f32x4 a1 = *reinterpret_cast<const f32x4 *>(buf + (8 + kb) * 256 + lane * 4);
+                f32x4 n0 = a0, n1 = a1;
+                if (kb < 7) { n0 = lda(buf, kb + 1); n1 = lda(buf, 9 + kb); }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     T0 = GC_MFMA16(a0[r], Hh[8 * half + kb][r], T0);
                     T1 = GC_MFMA16(a1[r], Hh[8 * half + kb][r], T1);
                 }
+                a0 = n0; a1 = n1;
             }
         }
         gs_leaky(T0, mt.slope);
@@ -766,13 +845,13 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
         for (int q4 = 0; q4 < OBT / 4; ++q4) {
             if (q4 < mt.npass) {
             const float *buf = acquire();
+            f32x4 a00 = lda(buf, 0), a01 = lda(buf, 1), a10 = lda(buf, 2), a11 = lda(buf, 3);
 #pragma unroll
             for (int mm = 0; mm < 4; ++mm) {
                 // units of output block mm: [ob][kb]; consecutive MFMAs alternate between the two accumulators
-                const f32x4 a00 = *reinterpret_cast<const f32x4 *>(buf + (mm * 4 + 0) * 256 + lane * 4);
-                const f32x4 a01 = *reinterpret_cast<const f32x4 *>(buf + (mm * 4 + 1) * 256 + lane * 4);
-                const f32x4 a10 = *reinterpret_cast<const f32x4 *>(buf + (mm * 4 + 2) * 256 + lane * 4);
-                const f32x4 a11 = *reinterpret_cast<const f32x4 *>(buf + (mm * 4 + 3) * 256 + lane * 4);
+                f32x4 n00 = a00, n01 = a01, n10 = a10, n11 = a11;
+                if (mm < 3) { n00 = lda(buf, mm * 4 + 4); n01 = lda(buf, mm * 4 + 5); n10 = lda(buf, mm * 4 + 6); n11 = lda(buf, mm * 4 + 7); }
+                __builtin_amdgcn_sched_barrier(0);
                 f32x4 &o0 = O[(4 * q4 + mm) * 2], &o1 = O[(4 * q4 + mm) * 2 + 1];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -784,27 +863,29 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
                     o0 = GC_MFMA16(a01[r], T1[r], o0);
                     o1 = GC_MFMA16(a11[r], T1[r], o1);
                 }
+                a00 = n00; a01 = n01; a10 = n10; a11 = n11;
             }
             }
         }
     }
 
+    }  // MFMA waves
     GL_T(b, 3);
     // ---- col2im: the weight ring is dead now; when all output blocks' tap products fit its 64 KB they go there at once
     // and ONE flat gather follows (two barriers in all), otherwise block by block through P ----
     if (mt.OB * 32 * GS_PX <= GS_RING * GC_STAGE) {
-        __syncthreads();   // every wave is done reading the last stage
+        GL_BARRIER();   // every wave is done reading the last stage
 #pragma unroll
         for (int blk = 0; blk < OBT; ++blk) {
-            if (blk < mt.OB) {
+            if (mfma_wave && blk < mt.OB) {
 #pragma unroll
                 for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ring[(32 * blk + 16 * ob + 4 * g + r) * GS_PX + px] = O[2 * blk + ob][r];
             }
         }
-        __syncthreads();
-        gc_gather_block<GS_PX, 64 * GS_NW>(ring, 0, mt, H, W, img0, B, small, out, fused ? pl.prm : nullptr, tid, mt.OB);
+        GL_BARRIER();
+        gc_gather_block<GS_PX, GS_NT>(ring, 0, mt, H, W, img0, B, small, out, fused ? pl.prm : nullptr, tid, mt.OB);
     } else {
 #pragma unroll
         for (int blk = 0; blk < OBT; ++blk) {
@@ -812,23 +893,24 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
 #pragma unroll
                 for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) P[(16 * ob + 4 * g + r) * GS_PX + px] = O[2 * blk + ob][r];
-                __syncthreads();
-                gc_gather_block<GS_PX, 64 * GS_NW>(P, blk, mt, H, W, img0, B, small, out, fused ? pl.prm : nullptr, tid);
-                __syncthreads();
+                    for (int r = 0; r < 4; ++r)
+                        if (mfma_wave) P[(16 * ob + 4 * g + r) * GS_PX + px] = O[2 * blk + ob][r];
+                GL_BARRIER();
+                gc_gather_block<GS_PX, GS_NT>(P, blk, mt, H, W, img0, B, small, out, fused ? pl.prm : nullptr, tid);
+                GL_BARRIER();
             }
         }
     }
     GL_T(b, 4);
     if (fused) {
-        gl_post<GS_PX, 64 * GS_NW>(lv, b, zin, zalt, wmix, pl.prm, pl.ldt, pl.ldacc, H, W, tid);
+        gl_post<GS_PX, GS_NT>(lv, b, zin, zalt, wmix, pl.prm, pl.ldt, pl.ldacc, H, W, tid);
         float *t_ = zin; zin = zalt; zalt = t_;
     } else {
-        __syncthreads();
+        GL_BARRIER();
     }
     GL_T(b, 5);
     }  // blocks
-    if (fused) gl_store<GS_PX, 64 * GS_NW>(lv, zin, pl.ldacc, H, W, img0, B, tid);
+    if (fused) gl_store<GS_PX, GS_NT>(lv, zin, pl.ldacc, H, W, img0, B, tid);
 }
 
 // ---- tiny images (H W | 16): one 16-pixel tile per workgroup, the waves split the ROWS of every GEMM -------------------
@@ -1006,20 +1088,20 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
     float *small = (fused && (b & 1)) ? pl.small2 : small0;
     const float *wmix = (b & 1) ? pl.wmix2 : pl.wmix;
     if (fused) {
-        gl_pre<GT_PX, 64 * GT_NW, 0>(lv, b, zin, zalt, wmix, xin, H, W, tid);
+        gl_pre<GT_PX, 64 * GT_NW, GT_PF>(lv, b, zin, zalt, wmix, xin, H, W, tid);
         if (b + 1 < nb) gl_prefetch<GT_NW>(lv, b + 1, mt.small, (b & 1) ? small0 : pl.small2, (b & 1) ? pl.wmix : pl.wmix2, wid, lane);
     } else {
         for (int i = tid; i < mt.small; i += 64 * GT_NW) small[i] = blob[GC_HDR + i];
         gc_fill_xin_global<GT_PX, 64 * GT_NW>(x, xs_img, xin, mt.Cin, H, W, img0, B, tid);
     }
-    __syncthreads();
+    GL_BARRIER();
     for (int i = tid; i < K1p * GT_PX; i += 64 * GT_NW) {
         // element (kb, g', px, r) of the column block: k = 16 kb + 4 g' + r
         const int r = i & 3, px = (i >> 2) & 15, gg = (i >> 6) & 3, kb = i >> 8;
         const int li = px / HW, pin = px - li * HW, py = pin / W, pxx = pin - py * W;
         cols[i] = xin[li * mt.Cin * PH * PW + py * PW + pxx + koff[16 * kb + 4 * gg + r]];
     }
-    __syncthreads();
+    GL_BARRIER();
     GL_T(b, 1);
 
     // ---- GEMM 1 -> h1s ----
@@ -1030,7 +1112,7 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
         gs_leaky(acc, mt.slope);
         *reinterpret_cast<f32x4 *>(h1s + ((b16 * 4 + g) * GT_PX + j16) * 4) = acc;
     }
-    __syncthreads();
+    GL_BARRIER();
     GL_T(b, 2);
     // ---- GEMM 2 -> h2s ----
     for (int bl = 0; bl < GT_BPW; ++bl) {
@@ -1040,7 +1122,7 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
         gs_leaky(acc, mt.slope);
         *reinterpret_cast<f32x4 *>(h2s + ((b16 * 4 + g) * GT_PX + j16) * 4) = acc;
     }
-    __syncthreads();   // h2 complete; cols / h1s are dead: P may overwrite them
+    GL_BARRIER();   // h2 complete; cols / h1s are dead: P may overwrite them
     // ---- GEMM 3 -> tap products ----
     for (int ol = 0; ol < tm.NB3; ++ol) {
         const int o16 = wid * tm.NB3 + ol;
@@ -1049,7 +1131,7 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
 #pragma unroll
         for (int r = 0; r < 4; ++r) P[(16 * o16 + 4 * g + r) * GT_PX + j16] = acc[r];
     }
-    __syncthreads();
+    GL_BARRIER();
     GL_T(b, 3);
     // ---- col2im over all output blocks in one flat loop ----
     gc_gather_block<GT_PX, 64 * GT_NW>(P, 0, mt, H, W, img0, B, small, out, fused ? pl.prm : nullptr, tid, mt.OB);
@@ -1058,7 +1140,7 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
         gl_post<GT_PX, 64 * GT_NW>(lv, b, zin, zalt, wmix, pl.prm, pl.ldt, pl.ldacc, H, W, tid);
         float *t_ = zin; zin = zalt; zalt = t_;
     } else {
-        __syncthreads();
+        GL_BARRIER();
     }
     GL_T(b, 5);
     }  // blocks
@@ -1148,7 +1230,7 @@ static int launch_small(const void *x, int64_t xs, void *out, const void *wpack,
     const int IPW = GS_PX / (H * W);
     const int64_t grid = (B + IPW - 1) / IPW;
     if (grid > 0x7fffffff) return NF_ERANGE;
-    hipLaunchKernelGGL(glow_convnet_small_kernel<OBT>, dim3((unsigned)grid), dim3(64 * GS_NW), lds, st, (const float *)x, xs,
+    hipLaunchKernelGGL(glow_convnet_small_kernel<OBT>, dim3((unsigned)grid), dim3(64 * (GS_NW + GsHelpers<OBT>::value)), lds, st, (const float *)x, xs,
                        (float *)out, (const float *)wpack, m, B, H, W, fu);
     NF_CHECK_LAUNCH();
     return NF_OK;
