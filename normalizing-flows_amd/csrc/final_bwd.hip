@@ -104,7 +104,9 @@ final_bwd_kernel(FinalBwdArgs a) {
         else if (after == 2 * FB_NI) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
         else if (after == FB_NI) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // the raw barrier: __syncthreads() is a fence, and with an LDS-DMA possibly pending the compiler implements it as
+        // s_waitcnt vmcnt(0) -- the counted waits above never took effect before this was found (round 3, in the Glow kernels)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (stage + 1 < total_stages) issue(stage + 1);
         const float *buf = ring + (stage & 1) * F_STAGE;
         ++stage;

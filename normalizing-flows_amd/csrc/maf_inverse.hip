@@ -315,12 +315,12 @@ maf_inverse_kernel(const float *__restrict__ z, float *__restrict__ y, float *__
         // stage the sequential part's weights (affine: 23 KB), one copy per workgroup, read back as LDS broadcasts
         const int nblk = SPL ? 4 + ns : 5;
         const int nseq = SPL ? 5 * MT + MT * MS + 4 * MT * MT + ns * MT + ns * R * MT : M_SEQ;
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only barrier: a fence would wait for the activation stores in flight
         {
             const f32x4 *src = reinterpret_cast<const f32x4 *>(Ah + (size_t)nblk * Kh * MT);
             for (int i = threadIdx.x; i < nseq / 4; i += 64 * MW) reinterpret_cast<f32x4 *>(seqw)[i] = src[i];
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only barrier: a fence would wait for the activation stores in flight
         if (!active) continue;
         const float *bias = seqw;
         const float *biasF = bias + 5 * MT;                            // affine layout only

@@ -145,7 +145,7 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
         const float *Ah = A0 + K0 * HT;             // A1..A_{NL-1}, AF: Kh * 32 floats each
         // stage the sequential part's weights, one copy per workgroup; the five 32 x 32 diagonal blocks with their columns
         // in (half, register) order: source quad (u, v / 4 = 2 q + h) -> destination quad (u, 4 h + q)
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only barrier: a fence would wait for the activation stores in flight
         {
             const f32x4 *src = reinterpret_cast<const f32x4 *>(Ah + (size_t)NL * Kh * HT);
             constexpr int HEAD4 = (NL * HT + HT + HT * HS) / 4;      // biases, final biases, window weights: copied as they are
@@ -158,7 +158,7 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
                 reinterpret_cast<f32x4 *>(seqw)[d] = src[i];
             }
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only barrier: a fence would wait for the activation stores in flight
         if (!active) continue;
         const float *bias = seqw;
         const float *biasF = bias + NL * HT;

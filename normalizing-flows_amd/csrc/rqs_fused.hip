@@ -410,10 +410,16 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
             __builtin_amdgcn_global_load_lds(src + piece * 256 + lane * 4,
                                              (__attribute__((address_space(3))) void *)(dst + piece * 256), 16, 0, 0);
     };
-    auto acquire = [&]() -> const float * {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // `after`: vector-memory operations (training stores) this wave issued AFTER the requests of the stage it now waits for;
+    // they retire in order, so they may stay in flight.  Only trusted for full tiles (every store instruction of the wave
+    // has active lanes, so the count is exact).  The barrier is the raw one: __syncthreads() is a fence and the compiler
+    // implements it as vmcnt(0) while an LDS-DMA may be pending -- it would wait for the stores after all.
+    const bool full_tile = (int64_t)(blockIdx.x + 1) * F_ROWS <= B;
+    auto acquire = [&](int after = 0) -> const float * {
+        if (TRAIN && after == 14 && full_tile) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifndef NF_ABL_NOBAR
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
 #ifndef NF_ABL_NODMA
         if (stage + 1 < total_stages) issue(stage + 1);
@@ -581,7 +587,8 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
         }
     }
 
-    store_act(0, H0, H1, H2, H3);
+    // TRAIN = 2: every store_act() goes out right BEHIND the next stage's barrier and DMA request -- issued in front of it, the
+    // acquire's wait for the DMA also waited for the write acknowledgements of 16 KB per wave (vector-memory operations retire in order)
     // ---- residual blocks: H += W2 relu(W1 relu(H) + b1) + b2 (resnet.py:37-50) ----
     for (int blk = 0; blk < nblk; ++blk) {
         f32x16 T0, T1, T2, T3;
@@ -592,7 +599,11 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
             T2 = load_bias16(bsrc + 64);
             T3 = load_bias16(bsrc + 96);
         }
-        mm128<true, HB>(acquire(), lane, T0, H0, H1, H2, H3);
+        {
+            const float *buf = acquire();
+            store_act(2 * blk, H0, H1, H2, H3);         // the block's input (blk = 0: the initial layer's output)
+            mm128<true, HB>(buf, lane, T0, H0, H1, H2, H3);
+        }
         if constexpr (HB >= 2) mm128<true, HB>(acquire(), lane, T1, H0, H1, H2, H3);
         if constexpr (HB == 4) {
             mm128<true, HB>(acquire(), lane, T2, H0, H1, H2, H3);
@@ -605,8 +616,8 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
             H2 += load_bias16(bsrc + 64);
             H3 += load_bias16(bsrc + 96);
         }
-        store_act(1 + 2 * blk, T0, T1, T2, T3);      // the pre-activation (the backward's ReLU mask and weight-gradient operand)
 #ifdef NF_EXP_RELU_PER_USE
+        store_act(1 + 2 * blk, T0, T1, T2, T3);
         mm128<true, HB>(acquire(), lane, H0, T0, T1, T2, T3);
         if constexpr (HB >= 2) mm128<true, HB>(acquire(), lane, H1, T0, T1, T2, T3);
         if constexpr (HB == 4) {
@@ -614,6 +625,8 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
             mm128<true, HB>(acquire(), lane, H3, T0, T1, T2, T3);
         }
 #else
+        const float *buf2 = acquire();
+        store_act(1 + 2 * blk, T0, T1, T2, T3);      // the pre-activation (the backward's ReLU mask and weight-gradient operand)
         // T is dead after this linear: ReLU it once in place (64 v_max) instead of once per use (256)
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
@@ -622,14 +635,16 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
             T2[c] = fmaxf(T2[c], 0.0f);
             T3[c] = fmaxf(T3[c], 0.0f);
         }
-        mm128<false, HB>(acquire(), lane, H0, T0, T1, T2, T3);
+        mm128<false, HB>(buf2, lane, H0, T0, T1, T2, T3);
         if constexpr (HB >= 2) mm128<false, HB>(acquire(), lane, H1, T0, T1, T2, T3);
         if constexpr (HB == 4) {
             mm128<false, HB>(acquire(), lane, H2, T0, T1, T2, T3);
             mm128<false, HB>(acquire(), lane, H3, T0, T1, T2, T3);
         }
 #endif
+#ifdef NF_EXP_RELU_PER_USE
         store_act(2 + 2 * blk, H0, H1, H2, H3);
+#endif
     }
     }  // TRAIN != 1
 
@@ -716,7 +731,14 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     for (int g = 0; g < ngrp; ++g) {   // (up to) KB groups of 3 row-blocks
         const float *bsrc = small + lay.off_bias_final() + (g * 3) * 32 + hh * 16;
         f32x16 A0 = load_bias16(bsrc), A1 = load_bias16(bsrc + 32), A2 = load_bias16(bsrc + 64);
-        mm128<false, HB>(acquire(), lane, A0, H0, H1, H2, H3);
+        {
+            // behind group g - 1's 14 parameter stores (training); group 0: the last residual block's output goes out here
+            const float *buf = acquire(g > 0 ? 14 : 0);
+#ifndef NF_EXP_RELU_PER_USE
+            if (g == 0) store_act(2 * nblk, H0, H1, H2, H3);
+#endif
+            mm128<false, HB>(buf, lane, A0, H0, H1, H2, H3);
+        }
         mm128<false, HB>(acquire(), lane, A1, H0, H1, H2, H3);
         mm128<false, HB>(acquire(), lane, A2, H0, H1, H2, H3);
         extract(A0, A1, A2);
