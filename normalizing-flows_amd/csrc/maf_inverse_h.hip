@@ -56,8 +56,15 @@ __device__ __forceinline__ void h_block(const float *__restrict__ A, const float
     const f32x4 *pa2 = reinterpret_cast<const f32x4 *>(PAIR ? A2 : A) + lane;
     const int nkb = K >> 3;
     if (nkb > 0) {
+        // The activation requests are INLINE ASM, i.e. invisible to the compiler's wait-count pass.  With the builtin, the
+        // compiler knows an LDS-DMA may be pending and then waits vmcnt(0) at the first use of any ORDINARY load result (the A
+        // operands below): every fourth k-block drained the whole ring and the block part ran at the latency of one request
+        // chain (2.9 TB/s; found in round 3).  Not knowing about them it counts only its own loads, which errs on the strict side.
+        const uint32_t ring_lds = (uint32_t)(uintptr_t)ring;      // LDS byte address of the wave's ring (wave-uniform)
         auto dma = [&](int kb) {
-            __builtin_amdgcn_global_load_lds(Sl + (size_t)kb * 256 + lane * 4, (lds_ptr)(ring + (kb % HRB) * 256), 16, 0, 0);
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(ring_lds + (uint32_t)(kb % HRB) * 1024u);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                         :: "s"(dst), "v"(Sl + (size_t)kb * 256 + lane * 4) : "memory", "m0");
         };
         struct Stage { f32x4 a, a2; };
         auto ld = [&](int kb, Stage &st) {
@@ -66,11 +73,15 @@ __device__ __forceinline__ void h_block(const float *__restrict__ A, const float
             if constexpr (PAIR) st.a2 = pa2[k * 64];
         };
         auto mm = [&](int kb, const Stage &st) {
+            // vector-memory operations retire in order; per k-block: dma(kb + HRB - 1) | wait | MFMAs | ld(kb + 4).  Younger than
+            // ld(kb) at this wait: 3 ld (x2 for a tile pair) + 4 requests; everything older -- k-block kb of the ring, requested
+            // HRB - 1 steps ago -- has landed.  Past the last request the three youngest ld may stay in flight.
+            constexpr int LPS = PAIR ? 2 : 1;
             if (kb + HRB - 1 < nkb) {
                 dma(kb + HRB - 1);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HRB - 1) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS + 4) : "memory");
             } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS) : "memory");
             }
             const f32x4 b = *reinterpret_cast<const f32x4 *>(ring + (kb % HRB) * 256 + lane * 4);
 #pragma unroll
@@ -79,9 +90,13 @@ __device__ __forceinline__ void h_block(const float *__restrict__ A, const float
                 if constexpr (PAIR) c2 = HMFMA(st.a2[i], b[i], c2);
             }
         };
-        for (int j = 0; j < HRB - 1 && j < nkb; ++j) dma(j);
+        // prologue in the steady state's order: dma(0 .. HRB - 5), then ld(i) / dma(HRB - 4 + i) alternating
         Stage s0, s1, s2, s3;
-        ld(0, s0); ld(1, s1); ld(2, s2); ld(3, s3);
+        for (int j = 0; j < HRB - 4 && j < nkb; ++j) dma(j);
+        ld(0, s0); if (HRB - 4 < nkb) dma(HRB - 4);
+        ld(1, s1); if (HRB - 3 < nkb) dma(HRB - 3);
+        ld(2, s2); if (HRB - 2 < nkb) dma(HRB - 2);
+        ld(3, s3);
         for (int kb = 0; kb < nkb; kb += 4) {        // nkb is a multiple of 4
             mm(kb, s0); ld(kb + 4, s0);
             mm(kb + 1, s1); ld(kb + 5, s1);

@@ -395,7 +395,12 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     // ---- weight-stream helpers (2-slot ring, global -> LDS DMA); the stage counter runs across layers ----
     int stage = 0;
     auto issue = [&](int gs) {
+#ifdef NF_DMA_WAVES
+        constexpr int PPW = 16 / NF_DMA_WAVES;  // only the first NF_DMA_WAVES waves request (one per SIMD: its partner keeps the MFMAs going)
+        if (wid >= NF_DMA_WAVES) return;
+#else
         constexpr int PPW = 16 / F_NW;  // 1 KB pieces per wave (16 per stage)
+#endif
         const int layer = gs / nstages, s = gs - layer * nstages;
         const float *src = fa.blob[layer] + lay.off_stages() + (size_t)phys(s) * F_STAGE + (wid * PPW) * 256 + lane * 4;
         float *dst = ring + (gs & 1) * F_STAGE + (wid * PPW) * 256;
