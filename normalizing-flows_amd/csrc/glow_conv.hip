@@ -1024,7 +1024,10 @@ glow_convnet_tiny_kernel(const float *__restrict__ x, int64_t xs_img, float *__r
     const float *cross = nb > 1 ? stream_of(1) : pf_base + (size_t)(nunits - 1) * 256;   // where the stream goes on after this block
     bool cross_last = nb <= 1;          // ... which is the dummy tail (the last unit again and again)
     auto pf_next = [&]() -> f32x4 {
-        const f32x4 v = *(reinterpret_cast<const f32x4 *>(pf_base) + lane);
+        // an explicitly GLOBAL load: the stream's base comes out of the level's pointer table, i.e. it is a generic pointer, and
+        // a FLAT load counts on lgkmcnt as well -- every wait for an LDS read then waited for the whole register stream
+        typedef const f32x4 __attribute__((address_space(1))) *gvec;
+        const f32x4 v = *((gvec)(reinterpret_cast<const f32x4 *>(pf_base)) + lane);
         --pf_left;
         const bool cr = pf_left == 0;
         pf_base = cr ? cross : pf_base + pf_stride;
