@@ -444,6 +444,7 @@ __device__ __forceinline__ GlPlanes gl_planes(float *base, const GlowLevel &lv, 
     return q;
 }
 
+template <bool PAIR1>     // GEMM 1's stages travel in pairs (K1 <= 64, see below)
 __global__ void __launch_bounds__(64 * GC_NW, 2)
 glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restrict__ out, const float *__restrict__ blob0,
                     GcMeta mt, int64_t B, int H, int W, GlowLevel lv) {
@@ -462,20 +463,27 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
     const bool fused = lv.nblocks > 0;
     const int nb = fused ? lv.nblocks : 1;
 
-    const int nst_l1 = 8 * mt.nst1;
+    // GEMM 1 with K1 <= 64 (Cin <= 7: the 16x16 level of config 4) fills only half of a blob stage per row-block: two
+    // row-blocks' used halves then travel as ONE ring stage (pieces 0..7 | 8..15): 4 barriers instead of 8 for the same MFMAs
+    constexpr bool pair1 = PAIR1;                         // = mt.nkg1 <= 8 (the launcher)
+    const int bl1 = 8 * mt.nst1;                          // GEMM 1's stages in the blob
+    const int nst_l1 = pair1 ? 4 : bl1;                   // ... and in the stream
     const int total_stages = nst_l1 + 24 * mt.npass;     // per block
     const int all_stages = total_stages * nb;            // the stream runs straight through the block boundaries
     auto phys = [&](int s) -> int {   // stream position -> stage of the blob (GEMM 2's stages are re-streamed every sweep)
         if (s < nst_l1) return s;
         const int q = s - nst_l1, pass = q / 24, w = q - 24 * pass, j = w / 3, t = w - 3 * j;
-        return t < 2 ? nst_l1 + 2 * j + t : nst_l1 + 16 + 8 * pass + j;
+        return t < 2 ? bl1 + 2 * j + t : bl1 + 16 + 8 * pass + j;
     };
     int stage = 0;   // global stage counter (all blocks)
     constexpr int PPW = 16 / GC_NW;  // 1 KB pieces per wave
     auto issue = [&](int gs) {
         const int bb = gs / total_stages, s = gs - bb * total_stages;
         const float *stages = (fused ? lv.blob(bb) : blob0) + gc_off_stages(mt);
-        const float *src = stages + (size_t)phys(s) * GC_STAGE + (wid * PPW) * 256 + (tid0 & 63) * 4;
+        static_assert(PPW == 2, "the paired GEMM 1 stages assume two pieces per wave");
+        const float *src = (pair1 && s < nst_l1)
+                               ? stages + (size_t)(2 * s + (wid >> 2)) * GC_STAGE + ((wid & 3) * PPW) * 256 + (tid0 & 63) * 4
+                               : stages + (size_t)phys(s) * GC_STAGE + (wid * PPW) * 256 + (tid0 & 63) * 4;
         float *dst = ring + (gs % GC_RING) * GC_STAGE + (wid * PPW) * 256;
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
@@ -536,6 +544,22 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
     // registers when K1 <= 128 (Cin <= 14), per use otherwise
     float bx[4 * GC_KG1MAX];
     const bool bx_cached = mt.nkg1 <= GC_KG1MAX;
+    auto gemm1_pair = [&](f32x16 &acc0, f32x16 &acc1) {
+        const float *buf = acquire();
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x16 &acc = half ? acc1 : acc0;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (s < mt.nkg1) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(buf + (8 * half + s) * 256 + lane * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = GC_MFMA(a[r], bx[4 * s + r], acc);
+                }
+            }
+            gc_leaky(acc, mt.slope);
+        }
+    };
     auto gemm1 = [&](f32x16 &acc) {
         if (bx_cached) {
             const float *buf = acquire();
@@ -574,7 +598,8 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
         H0 = load_bias16(bsrc);       H1 = load_bias16(bsrc + 32);  H2 = load_bias16(bsrc + 64);  H3 = load_bias16(bsrc + 96);
         H4 = load_bias16(bsrc + 128); H5 = load_bias16(bsrc + 160); H6 = load_bias16(bsrc + 192); H7 = load_bias16(bsrc + 224);
     }
-    gemm1(H0); gemm1(H1); gemm1(H2); gemm1(H3); gemm1(H4); gemm1(H5); gemm1(H6); gemm1(H7);
+    if constexpr (pair1) { gemm1_pair(H0, H1); gemm1_pair(H2, H3); gemm1_pair(H4, H5); gemm1_pair(H6, H7); }
+    else { gemm1(H0); gemm1(H1); gemm1(H2); gemm1(H3); gemm1(H4); gemm1(H5); gemm1(H6); gemm1(H7); }
     GL_T(b, 2);
 
     // ---- sweeps over h2: GEMM 2 block by block, each block consumed at once by GEMM 3 ----
@@ -1265,13 +1290,20 @@ static int gc_launch(const void *x, int64_t xs, void *out, const void *wpack, co
     }
     const size_t lds = gc_lds_bytes(m, H, W, fu);
     if (lds > 160 * 1024) return NF_ENOTSUP;
-    static LdsOptIn opted = {};
-    if (opt_in_lds(reinterpret_cast<const void *>(&glow_convnet_kernel), lds, opted) != NF_OK) return NF_ENOTSUP;
     const int IPW = GC_PX / (H * W);
     const int64_t grid = (B + IPW - 1) / IPW;
     if (grid > 0x7fffffff) return NF_ERANGE;
-    hipLaunchKernelGGL(glow_convnet_kernel, dim3((unsigned)grid), dim3(64 * GC_NW), lds, st, (const float *)x, xs, (float *)out,
-                       (const float *)wpack, m, B, H, W, fu);
+    if (m.nkg1 <= 8) {
+        static LdsOptIn opted = {};
+        if (opt_in_lds(reinterpret_cast<const void *>(&glow_convnet_kernel<true>), lds, opted) != NF_OK) return NF_ENOTSUP;
+        hipLaunchKernelGGL(glow_convnet_kernel<true>, dim3((unsigned)grid), dim3(64 * GC_NW), lds, st, (const float *)x, xs,
+                           (float *)out, (const float *)wpack, m, B, H, W, fu);
+    } else {
+        static LdsOptIn opted = {};
+        if (opt_in_lds(reinterpret_cast<const void *>(&glow_convnet_kernel<false>), lds, opted) != NF_OK) return NF_ENOTSUP;
+        hipLaunchKernelGGL(glow_convnet_kernel<false>, dim3((unsigned)grid), dim3(64 * GC_NW), lds, st, (const float *)x, xs,
+                           (float *)out, (const float *)wpack, m, B, H, W, fu);
+    }
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
