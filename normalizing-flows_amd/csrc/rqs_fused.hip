@@ -323,6 +323,10 @@ __device__ __forceinline__ void lu_mm(const float *buf, int lane, const float (&
 #define NF_FUSED_WAVES 8
 #endif
 constexpr int F_NW = NF_FUSED_WAVES;
+#ifndef NF_DMA_WAVES
+#define NF_DMA_WAVES 4
+#endif
+constexpr int F_DMA_WAVES = NF_DMA_WAVES < F_NW ? NF_DMA_WAVES : F_NW;   // waves that issue the weight ring's LDS-DMAs
 constexpr int F_THREADS = 64 * F_NW;
 constexpr int F_ROWS = 32 * F_NW;
 
@@ -395,12 +399,10 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     // ---- weight-stream helpers (2-slot ring, global -> LDS DMA); the stage counter runs across layers ----
     int stage = 0;
     auto issue = [&](int gs) {
-#ifdef NF_DMA_WAVES
-        constexpr int PPW = 16 / NF_DMA_WAVES;  // only the first NF_DMA_WAVES waves request (one per SIMD: its partner keeps the MFMAs going)
-        if (wid >= NF_DMA_WAVES) return;
-#else
-        constexpr int PPW = 16 / F_NW;  // 1 KB pieces per wave (16 per stage)
-#endif
+        // only the first F_DMA_WAVES waves request (one per SIMD: while it sits in the vector-memory issue its partner on the SIMD
+        // keeps the MFMAs going; all eight requesting: +0.6 % on the benchmark chain)
+        constexpr int PPW = 16 / F_DMA_WAVES;  // 1 KB pieces per requesting wave (16 per stage)
+        if (wid >= F_DMA_WAVES) return;
         const int layer = gs / nstages, s = gs - layer * nstages;
         const float *src = fa.blob[layer] + lay.off_stages() + (size_t)phys(s) * F_STAGE + (wid * PPW) * 256 + lane * 4;
         float *dst = ring + (gs & 1) * F_STAGE + (wid * PPW) * 256;

@@ -308,6 +308,9 @@ wgrad_tile_kernel(const float *__restrict__ dY, const float *__restrict__ X, flo
 // of X per workgroup = 4 DMA instructions per wave, no registers), NR slots = NR - 1 steps of look-ahead (0.95 us each), one
 // barrier per step; `s_waitcnt vmcnt(4 (NR - 2))` = the younger steps already requested may stay outstanding (loads retire
 // in order; one more is requested right after the barrier), drained in the tail.  ReLU of the second operand is applied on the LDS read.
+// (Round 3, measured and dropped: all M / 128 tiles of a row chunk on ONE XCD, so that the chunk of X comes from HBM once instead
+// of once per tile -- 147 -> 152 us at 768 x 128: the kernel is bound by its MFMA issue (busy 0.62), not by the 390 MB it reads;
+// 768 instead of 512 workgroups: 143 us.)
 #ifndef NF_W3_NR
 #define NF_W3_NR 3      // measured 4 / 3 / 2 slots: 145 / 139 / 143 us at 768 x 128
 #endif

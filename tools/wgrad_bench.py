@@ -24,7 +24,7 @@ def timeit(fn, n=20):
     return s.elapsed_time(e) / n * 1e3
 
 
-for B, M, N in [(65536, 128, 128), (65536, 128, 32), (65536, 736, 128), (65536, 64, 64)]:
+for B, M, N in [(65536, 128, 128), (65536, 128, 32), (65536, 736, 128), (65536, 768, 128), (65536, 64, 64)]:
     dy = torch.randn(B, M, device=dev)
     x = torch.randn(B, N, device=dev)
     t_ours = timeit(lambda: nfa.ops.linear_wgrad(dy, x))
