@@ -159,11 +159,14 @@ __device__ __forceinline__ void block_part_ring(const float *__restrict__ A, con
     const f32x4 *pa2 = reinterpret_cast<const f32x4 *>(PAIR ? A2 : A) + half * 32 + l31;
     const int nkb = K >> 3;
     if (nkb > 0) {
+        // inline asm, i.e. invisible to the compiler's wait-count pass (see maf_inverse_h.hip: with the builtin the compiler waits
+        // vmcnt(0) at every first use of the register-loaded A operands while an LDS-DMA may be pending, draining the ring)
+        const uint32_t ring_lds = (uint32_t)(uintptr_t)ring;
         auto dma = [&](int kb) {
             const float *src = Sl + (size_t)kb * 512 + lane * 4;
-            float *slot = ring + (kb % MRB) * 512;
-            __builtin_amdgcn_global_load_lds(src, (lds_ptr)slot, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(src + 256, (lds_ptr)(slot + 256), 16, 0, 0);
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(ring_lds + (uint32_t)(kb % MRB) * 2048u);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst + 1024u), "v"(src + 256) : "memory", "m0");
         };
         struct Stage { f32x4 a, a2; };
         auto ld = [&](int kb, Stage &st) {
@@ -176,11 +179,14 @@ __device__ __forceinline__ void block_part_ring(const float *__restrict__ A, con
         // the wait is a full drain (everything outstanding is needed within the next MRB - 1 steps anyway).  No DMA is ever issued
         // past the product's end: with left-overs in flight two back-to-back products could exceed the 6-bit vmcnt counter.
         auto mm = [&](int kb, const Stage &st) {
+            // in-order retirement; per k-block: dma(kb + MRB - 1) (2 requests) | wait | MFMAs | ld(kb + 4).  Younger than ld(kb) here:
+            // 3 ld (x2 for a tile pair) + 4 x 2 requests; past the last request the three youngest ld may stay in flight
+            constexpr int LPS = PAIR ? 2 : 1;
             if (kb + MRB - 1 < nkb) {
                 dma(kb + MRB - 1);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (MRB - 1)) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS + 8) : "memory");
             } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS) : "memory");
             }
             const float *slot = ring + (kb % MRB) * 512 + (half * 64 + l31) * 4;
             const f32x4 b0 = *reinterpret_cast<const f32x4 *>(slot), b1 = *reinterpret_cast<const f32x4 *>(slot + 128);
@@ -194,9 +200,12 @@ __device__ __forceinline__ void block_part_ring(const float *__restrict__ A, con
                 }
             }
         };
-        for (int j = 0; j < MRB - 1 && j < nkb; ++j) dma(j);
         Stage s0, s1, s2, s3;
-        ld(0, s0); ld(1, s1); ld(2, s2); ld(3, s3);
+        for (int j = 0; j < MRB - 4 && j < nkb; ++j) dma(j);     // the steady state's order: ld(i) / dma(MRB - 4 + i) alternating
+        ld(0, s0); if (MRB - 4 < nkb) dma(MRB - 4);
+        ld(1, s1); if (MRB - 3 < nkb) dma(MRB - 3);
+        ld(2, s2); if (MRB - 2 < nkb) dma(MRB - 2);
+        ld(3, s3);
         for (int kb = 0; kb < nkb; kb += 4) {        // nkb is a multiple of 4
             mm(kb, s0); ld(kb + 4, s0);
             mm(kb + 1, s1); ld(kb + 5, s1);
