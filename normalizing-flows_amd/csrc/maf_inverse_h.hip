@@ -111,6 +111,9 @@ __device__ __forceinline__ void h_block(const float *__restrict__ A, const float
     }
 }
 
+// (Round 3, measured and dropped: the NL products of a tile as ONE stream -- requests and A look-ahead running through the
+// product boundaries, one start-up per tile instead of one per product: 14.9 ms against 14.5-14.8, 18 spilled registers.  The
+// start-ups are not what is left either.)
 __device__ __forceinline__ void h_block_mode(int mode, const float *__restrict__ A, const float *__restrict__ A2, const float *Sl,
                                              int K, int lane, float *stash, float *ring, f32x16 &out) {
     if (mode == 1) h_block<true, false>(A, A2, Sl, K, lane, stash, ring, out);

@@ -524,6 +524,9 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     // enough), written back as 128-byte row pieces: 8 lanes per row, 8 rows per instruction
     auto store_act = [&](int t, const f32x16 &V0, const f32x16 &V1, const f32x16 &V2, const f32x16 &V3) {
         if constexpr (TRAIN == 2) {
+#ifdef NF_ABL_NOACT
+            return;
+#endif
             int l_ = lane;      // per-lane addresses derived afresh at every call: hoisted out of the kernel they cost ~30 VGPRs
             asm volatile("" : "+v"(l_));
             float *tw = small2 + small_pitch + wid * 1536;
@@ -749,7 +752,11 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
         mm128<false, HB>(acquire(), lane, A1, H0, H1, H2, H3);
         mm128<false, HB>(acquire(), lane, A2, H0, H1, H2, H3);
         extract(A0, A1, A2);
+#ifdef NF_ABL_NOCOND
+        if constexpr (false) {
+#else
         if constexpr (TRAIN) {
+#endif
 #ifdef NF_TRAIN_DIRECT_STORES
             if (valid) {   // the two features' parameter sets, raw scale, for the backward kernel (pitch 24 floats per feature)
                 float *dst = cond_out + row * (F_NI * 24) + (8 * (g >> 1) + 4 * hh + 2 * (g & 1)) * 24;

@@ -29,10 +29,10 @@ cd $R
 python tools/summarize_profiles.py r03_bench_chain --stats $(find $O/bench_stats -name "*kernel_stats.csv" | head -1) \
   --pmc $(find $O/bench_FETCH_SIZE $O/bench_WRITE_SIZE $O/bench_SQ_VALU_MFMA_BUSY_CYCLES -name "*counter_collection.csv") \
   --trace $(find $O/bench_SQ_VALU_MFMA_BUSY_CYCLES -name "*kernel_trace.csv" | head -1) --kernel "rqs_fused_kernel<0, true" > $O/summ_bench.log 2>&1
-python tools/summarize_profiles.py r03_config5_maf --pmc $(find $O/maf_FETCH_SIZE $O/maf_WRITE_SIZE $O/maf_SQ_VALU_MFMA_BUSY_CYCLES -name "*counter_collection.csv") \
-  --trace $(find $O/maf_SQ_VALU_MFMA_BUSY_CYCLES -name "*kernel_trace.csv" | head -1) --kernel "maf_inverse_kernel" > $O/summ_maf.log 2>&1
+python tools/summarize_profiles.py r03_config5_maf_h --pmc $(find $O/maf_FETCH_SIZE $O/maf_WRITE_SIZE $O/maf_SQ_VALU_MFMA_BUSY_CYCLES -name "*counter_collection.csv") \
+  --trace $(find $O/maf_SQ_VALU_MFMA_BUSY_CYCLES -name "*kernel_trace.csv" | head -1) --kernel "maf_inverse_h_kernel" > $O/summ_maf.log 2>&1
 python tools/pmc_summary.py $O train "python tools/train_bench.py --steps 3 --fused-adam" > $O/r03_train_step_pmc.json 2> $O/summ_train.log
 cp $(find $O/train_stats -name "*kernel_stats.csv" | head -1) $O/r03_train_step_kernel_stats.csv
-mkdir -p $O/profiles_out; cp profiles/r03_bench_chain* profiles/r03_config5_maf* $O/profiles_out/ 2>/dev/null
+mkdir -p $O/profiles_out; cp profiles/r03_bench_chain* profiles/r03_config5_maf_h* $O/profiles_out/ 2>/dev/null
 find $O -name "*counter_collection.csv" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete
 tail -3 $O/pytest_gpu.log; tail -2 $O/smoke.log; cat $O/bench_line.json | head -c 600
