@@ -317,8 +317,11 @@ wgrad_tile_kernel(const float *__restrict__ dY, const float *__restrict__ X, flo
 #ifndef NF_W3_OCC
 #define NF_W3_OCC 3
 #endif
-constexpr int W3_KS = 16, W3_NR = NF_W3_NR;
-__global__ void __launch_bounds__(256, NF_W3_OCC)
+#ifndef NF_W3_HW
+#define NF_W3_HW 4      // helper waves: they issue the ring's requests (a vector-memory instruction costs its wave 100-250 issue cycles:
+#endif                  // 4 per step against the step's 32 MFMAs = 2048 cycles when the MFMA waves issued them)
+constexpr int W3_KS = 16, W3_NR = NF_W3_NR, W3_HW = NF_W3_HW, W3_NT = 64 * (4 + W3_HW);
+__global__ void __launch_bounds__(W3_NT, W3_HW ? 4 : NF_W3_OCC)      // second argument = waves per SIMD: two 8-wave workgroups per CU
 wgrad_ring_kernel(const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ part, int64_t B, int M,
                   int chunk_rows, int want_bias, int x_relu, int64_t zdY, int64_t zX, int64_t zpart) {
     typedef __attribute__((address_space(3))) void *lds_ptr;
@@ -335,28 +338,46 @@ wgrad_ring_kernel(const float *__restrict__ dY, const float *__restrict__ X, flo
     int64_t b1 = b0 + chunk_rows;
     if (b1 > B) b1 = B;
     const int nsteps = (int)((b1 - b0) / W3_KS);       // chunk_rows and B are multiples of 16
-    // a wave's 4 DMA instructions of a step: rows 4 wid + {0,1} and + {2,3} of each operand (64 lanes x 16 B = two 128-float rows)
+    // a requesting wave's 4 DMA instructions of a step: rows 4 dw + {0,1} and + {2,3} of each operand (64 lanes x 16 B = two 128-float rows)
+    const bool mfma_wave = wid < 4, dma_wave = W3_HW ? !mfma_wave : true;
+    const int dw = W3_HW ? (wid - 4) : wid;
+    static_assert(W3_HW == 0 || W3_HW == 4, "four requesting waves");
     const int lrow = lane >> 5, lcol = (lane & 31) * 4;
     auto issue = [&](int s) {
-        const int64_t r0 = b0 + (int64_t)s * W3_KS + 4 * wid + lrow;
-        float *slotA = &ring[s % W3_NR][0][4 * wid][0], *slotB = &ring[s % W3_NR][1][4 * wid][0];
+        const int64_t r0 = b0 + (int64_t)s * W3_KS + 4 * dw + lrow;
+        float *slotA = &ring[s % W3_NR][0][4 * dw][0], *slotB = &ring[s % W3_NR][1][4 * dw][0];
         __builtin_amdgcn_global_load_lds(dY + r0 * M + m0 + lcol, (lds_ptr)slotA, 16, 0, 0);
         __builtin_amdgcn_global_load_lds(dY + (r0 + 2) * M + m0 + lcol, (lds_ptr)(slotA + 2 * W2_T), 16, 0, 0);
         __builtin_amdgcn_global_load_lds(X + r0 * N + lcol, (lds_ptr)slotB, 16, 0, 0);
         __builtin_amdgcn_global_load_lds(X + (r0 + 2) * N + lcol, (lds_ptr)(slotB + 2 * W2_T), 16, 0, 0);
     };
+    if (W3_HW && !mfma_wave) {
+        // helper waves: requests and barriers only (the same barrier sequence as the MFMA waves below)
+        for (int s = 0; s < W3_NR - 1 && s < nsteps; ++s) issue(s);
+        for (int s = 0; s < nsteps; ++s) {
+            if (s + W3_NR - 1 <= nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (W3_NR - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (s + W3_NR - 1 < nsteps) issue(s + W3_NR - 1);
+        }
+        return;
+    }
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
     float bs0 = 0.0f, bs1 = 0.0f;
-    for (int s = 0; s < W3_NR - 1 && s < nsteps; ++s) issue(s);
+    if (!W3_HW)
+        for (int s = 0; s < W3_NR - 1 && s < nsteps; ++s) issue(s);
     for (int s = 0; s < nsteps; ++s) {
-        // step s landed (this wave's pieces) once at most the younger steps' 4 (NR - 1) instructions are outstanding; in the
-        // tail fewer are younger: drain
-        if (s + W3_NR - 1 <= nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (W3_NR - 2)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();      // every wave's pieces of step s landed; every wave is done with slot (s - 1) % NR
-        asm volatile("" ::: "memory");
-        if (s + W3_NR - 1 < nsteps) issue(s + W3_NR - 1);
+        // step s landed (the requesting waves' pieces) once at most the younger steps' 4 (NR - 1) instructions are outstanding; in
+        // the tail fewer are younger: drain
+        if (!W3_HW) {
+            if (s + W3_NR - 1 <= nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (W3_NR - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every piece of step s landed; every wave is done with slot (s - 1) % NR
+        if (!W3_HW && s + W3_NR - 1 < nsteps) issue(s + W3_NR - 1);
         const float *ap = &ring[s % W3_NR][0][h][wm * 64 + i], *bp = &ring[s % W3_NR][1][h][wn * 64 + i];
+        // (all 32 operand reads of the step hoisted in front of its 32 MFMAs -- the compiler reads one k-pair, waits, multiplies --
+        // measured in round 3: 143 vs 141 us, no gain; helper waves 146 -> 141 us)
 #pragma unroll
         for (int kp = 0; kp < W3_KS / 2; ++kp) {
             const float a0 = ap[kp * 2 * W2_T], a1 = ap[kp * 2 * W2_T + 32];
@@ -564,7 +585,7 @@ static int wgrad_impl(const void *dY, const void *X, void *dW, void *db, void *s
     const int64_t zdW = np == 2 ? (float *)dW1 - (float *)dW : 0, zdb = (np == 2 && db) ? (float *)db1 - (float *)db : 0;
     const int64_t zpart = np == 2 ? single : 0;
     if (ring) {
-        hipLaunchKernelGGL(nf::wgrad_ring_kernel, dim3(chunks, M / nf::W2_T, np), dim3(256), 0, st, (const float *)dY,
+        hipLaunchKernelGGL(nf::wgrad_ring_kernel, dim3(chunks, M / nf::W2_T, np), dim3(nf::W3_NT), 0, st, (const float *)dY,
                            (const float *)X, part, B, M, rows, want_bias, relu_x, zdY, zX, zpart);
     } else if (tile) {
         hipLaunchKernelGGL(nf::wgrad_tile_kernel, dim3(chunks, (M + nf::W2_T - 1) / nf::W2_T, np), dim3(256), 0, st,
