@@ -421,7 +421,7 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     // they retire in order, so they may stay in flight.  Only trusted for full tiles (every store instruction of the wave
     // has active lanes, so the count is exact).  The barrier is the raw one: __syncthreads() is a fence and the compiler
     // implements it as vmcnt(0) while an LDS-DMA may be pending -- it would wait for the stores after all.
-    const bool full_tile = (int64_t)(blockIdx.x + 1) * F_ROWS <= B;
+    const bool full_tile = TRAIN ? (int64_t)(blockIdx.x + 1) * F_ROWS <= B : false;     // (inference: dead, no register)
     auto acquire = [&](int after = 0) -> const float * {
         if (TRAIN && after == 14 && full_tile) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
