@@ -1,26 +1,27 @@
 #!/usr/bin/env python3
-"""Round-trip and run-to-run determinism of the one-pass MAF inverse (nf_maf_inverse) on the config-5 layer at growing batch
-sizes: the check that caught a too-permissive counted vmcnt wait which every small-batch parity test passed.
-NF_MI355X_LIB selects a build variant."""
-import os, sys, torch
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-import normflows_amd as nfa
+"""python tools/maf_dbg.py D H B [num_blocks]: nf_maf_inverse (incremental) against the D-pass loop on one random layer."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import normflows_amd as nfa  # noqa: E402
+from normflows_amd.flows.autoregressive import Autoregressive  # noqa: E402
+
+D, H, B = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+NB = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 dev = torch.device("cuda:0")
-torch.manual_seed(0)
-f = nfa.flows.MaskedAffineAutoregressive(128, 512, num_blocks=2).to(dev)
-for B in (256, 4096, 16384, 65536):
-    x = torch.randn(B, 128, device=dev)
-    with torch.no_grad():
-        outs = []
-        for rep in range(3):
-            z, ld = f.inverse(x)
-            outs.append(z.clone())
-        xr, _ = f.forward(outs[0])
-    err = (xr - x).abs()
-    bad_rows = (err.max(1).values > 1e-3).nonzero().flatten()
-    print("B=%d roundtrip max %.2e  bad rows %d  rep-to-rep max diff %.2e" % (B, float(err.max()), bad_rows.numel(),
-          float((outs[0] - outs[1]).abs().max())))
-    if bad_rows.numel():
-        r = int(bad_rows[0]); fe = (err[r] > 1e-3).nonzero().flatten()
-        print("   first bad row %d (wave %d lane %d), first bad feature %d, n bad feats %d; bad rows mod 64 hist:" % (r, r // 64, r % 64, int(fe[0]), fe.numel()),
-              torch.bincount(bad_rows % 64, minlength=64).tolist()[:8], "waves:", torch.unique(bad_rows // 64)[:10].tolist())
+torch.manual_seed(D * 1000 + H)
+layer = nfa.flows.MaskedAffineAutoregressive(D, H, num_blocks=NB).to(dev)
+with torch.no_grad():
+    for p in layer.parameters():
+        p.add_(0.05 * torch.randn_like(p))
+z = torch.randn(B, D, device=dev)
+with torch.no_grad():
+    x1, ld1 = layer.inverse(z)
+    torch.cuda.synchronize()
+    print("kernel ok; finite:", bool(torch.isfinite(x1).all()))
+    x0, ld0 = Autoregressive.inverse(layer, z)
+    torch.cuda.synchronize()
+print("D=%d H=%d B=%d: max |dx| %.3e  max |dld| %.3e" % (D, H, B, float((x1 - x0).abs().max()), float((ld1 - ld0).abs().max())))
