@@ -136,7 +136,10 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
     constexpr int NL = 1 + 2 * NB, H_SEQ = h_seq(NL);
     __shared__ __attribute__((aligned(16))) float seqw[H_SEQ];     // the tile's biases and diagonal blocks, shared by the workgroup's waves
     extern __shared__ __attribute__((aligned(16))) float dyn[];      // the waves' activation rings
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, n = lane & 31, hh = lane >> 5;
+    const int lane = threadIdx.x & 63, n = lane & 31, hh = lane >> 5;
+    // wave-uniform BY CONSTRUCTION for the compiler too: every pointer and the tile mode below derive from it -- left in a vector
+    // register the whole product dispatch ran under exec masks with vector loop counters
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float *ringw = dyn + wid * (HRB * 256);
     const int64_t wt = (int64_t)blockIdx.x * HNW + wid;
     const bool active = wt * 32 < B;   // idle waves of the last workgroup still take part in the staging barriers
