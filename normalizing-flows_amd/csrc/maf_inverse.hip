@@ -165,8 +165,11 @@ __device__ __forceinline__ void block_part_ring(const float *__restrict__ A, con
         auto dma = [&](int kb) {
             const float *src = Sl + (size_t)kb * 512 + lane * 4;
             const uint32_t dst = __builtin_amdgcn_readfirstlane(ring_lds + (uint32_t)(kb % MRB) * 2048u);
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory", "m0");
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst + 1024u), "v"(src + 256) : "memory", "m0");
+            // (m0 is a reserved register: the compiler does not honour it as a clobber, so it is saved and restored here)
+            uint32_t m0_;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                         "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_) : "s"(dst), "v"(src), "s"(dst + 1024u), "v"(src + 256) : "memory");
         };
         struct Stage { f32x4 a, a2; };
         auto ld = [&](int kb, Stage &st) {

@@ -63,8 +63,10 @@ __device__ __forceinline__ void h_block(const float *__restrict__ A, const float
         const uint32_t ring_lds = (uint32_t)(uintptr_t)ring;      // LDS byte address of the wave's ring (wave-uniform)
         auto dma = [&](int kb) {
             const uint32_t dst = __builtin_amdgcn_readfirstlane(ring_lds + (uint32_t)(kb % HRB) * 1024u);
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-                         :: "s"(dst), "v"(Sl + (size_t)kb * 256 + lane * 4) : "memory", "m0");
+            // (m0 is a reserved register: the compiler does not honour it as a clobber, so it is saved and restored here)
+            uint32_t m0_;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_) : "s"(dst), "v"(Sl + (size_t)kb * 256 + lane * 4) : "memory");
         };
         struct Stage { f32x4 a, a2; };
         auto ld = [&](int kb, Stage &st) {
