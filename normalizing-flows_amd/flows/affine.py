@@ -10,7 +10,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from ..autograd import ActNormFn, AffineCouplingFn, MaskedAffineFn, needs_grad, refuse_grad
+from ..autograd import ActNormFn, AffineCouplingFn, MaskedAffineFn, needs_grad
 from .base import Flow, run_flow
 from .reshape import Merge, Split
 
@@ -97,8 +97,24 @@ class CCAffineConst(Flow):
         t = self.t.detach() + (y @ self.t_cc.detach()).view(-1, *self.shape)
         return s.expand_as(z).contiguous(), t.expand_as(z).contiguous()
 
+    def _torch(self, z, y, direction):
+        """Differentiable path (affine/coupling.py:57-96 as torch ops), taken only when a gradient is asked for; the per-sample
+        log-det counts every element the (broadcast) scale acts on."""
+        yv = y.to(self.s.dtype)
+        s = self.s + (yv @ self.s_cc).view(-1, *self.shape)
+        t = self.t + (yv @ self.t_cc).view(-1, *self.shape)
+        repeats = z[0].numel() // s[0].numel()
+        total = s.reshape(s.shape[0], -1).sum(1) * repeats
+        if direction == 0:
+            return z * torch.exp(s) + t, total
+        return (z - t) * torch.exp(-s), -total
+
     def _transform(self, z, y, direction, ld=None, acc=None):
-        refuse_grad("CCAffineConst", z, self)
+        if needs_grad(z, self):
+            out, l = self._torch(z, y, direction)
+            if ld is not None:
+                ld.add_(l, alpha=float(acc))
+            return out, l
         s, t = self._st(z, y)
         zero = torch.zeros(z.shape[1:], dtype=z.dtype, device=z.device)
         return ops.masked_affine(z, zero, s, t, direction, logdet=ld, acc=acc)

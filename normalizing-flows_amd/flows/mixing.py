@@ -13,7 +13,7 @@ from torch.nn import init
 
 from .. import _prepack
 from .. import ops
-from ..autograd import LULinearPermuteFn, needs_grad, refuse_grad
+from ..autograd import LULinearPermuteFn, needs_grad
 from .base import Flow
 
 
@@ -178,10 +178,33 @@ class InvertibleAffine(Flow):
             self._w_cache = cache
         return cache[1]
 
+    def _torch(self, z, inverse_dir):
+        """Differentiable path (mixing.py:165-207 as torch ops), taken only when a gradient is asked for: the matrix is assembled
+        from the parameters themselves, so L, U, log_S (or W) receive gradients.  Not a HIP path: the layer is not on the
+        benchmark's hot path; the inference kernels stay the default."""
+        if self.use_lu:
+            lower = torch.tril(self.L, -1) + self.eye
+            upper = torch.triu(self.U, 1) + torch.diag(self.sign_S * torch.exp(self.log_S))
+            logabs = self.log_S.sum()
+            if inverse_dir:                       # Flow.inverse: z @ (P L U)
+                return z @ (self.P @ lower @ upper), logabs
+            # Flow.forward: z @ (P L U)^-1 = ((z @ U^-1) @ L^-1) @ P^T, by two triangular solves from the right
+            t = torch.linalg.solve_triangular(upper, z, upper=True, left=False)
+            t = torch.linalg.solve_triangular(lower, t, upper=False, left=False, unitriangular=True)
+            return t @ self.P.t(), -logabs
+        logabs = torch.linalg.slogdet(self.W)[1]
+        if inverse_dir:
+            return z @ self.W, logabs
+        return torch.linalg.solve(self.W, z, left=False), -logabs
+
     def _mul(self, z, inverse_dir, ld=None, acc=None, want_scalar=True):
         if z.dim() != 2:
             raise NotImplementedError("InvertibleAffine: (batch, channels) inputs")
-        refuse_grad("InvertibleAffine", z, self)
+        if needs_grad(z, self):
+            y, l = self._torch(z, inverse_dir)
+            if ld is not None:
+                ld.add_(l, alpha=float(acc))
+            return y, l
         Wt, ldu = self._weight_t(inverse_dir)
         y, lds = ops.inv1x1_conv(z.reshape(z.shape[0], -1, 1, 1), Wt, ldu, logdet=ld, acc=acc, want_scalar=want_scalar)
         return y.view(z.shape), lds

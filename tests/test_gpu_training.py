@@ -482,14 +482,34 @@ def test_frozen_realnvp_stack_keeps_the_input_gradient(nfa):
     assert gs and all(torch.isfinite(g_).all() for g_ in gs) and sum(float(g_.abs().sum()) for g_ in gs) > 0
 
 
-def test_layers_without_training_path_refuse_gradients(nfa):
-    """Inference-only layers raise instead of silently detaching (the reference is differentiable there)."""
+def test_layers_with_torch_formula_training_path(nfa):
+    """InvertibleAffine / CCAffineConst (not on the hot path): inference kernels under no_grad, the reference's formulas as
+    differentiable torch ops when a gradient is asked for -- same values, gradients reach the parameters.  Logit likewise."""
     lay = nfa.flows.InvertibleAffine(4).to(DEV)
     x = torch.randn(5, 4, device=DEV)
-    with pytest.raises(NotImplementedError):
-        lay.forward(x)
+    for fn in (lay.forward, lay.inverse):
+        with torch.no_grad():
+            y0, l0 = fn(x)
+        y1, l1 = fn(x)
+        assert y1.requires_grad and l1.requires_grad
+        assert_close(N(y1), N(y0), what="InvertibleAffine torch vs kernel", rtol=1e-5, atol=1e-5)
+        assert_close(N(l1), N(l0), what="InvertibleAffine log-det", rtol=1e-5, atol=1e-6)
+    (y1.square().sum() + l1).backward()
+    assert all(p_.grad is not None and torch.isfinite(p_.grad).all() for p_ in lay.parameters())
+    cc = nfa.flows.CCAffineConst((3, 1, 1), 4).to(DEV)
     with torch.no_grad():
-        lay.forward(x)
+        for p_ in cc.parameters():
+            p_.normal_(0, 0.3)
+    zc = torch.randn(6, 3, 4, 4, device=DEV)
+    yc = torch.nn.functional.one_hot(torch.arange(6, device=DEV) % 4, 4).float()
+    for fn in (cc.forward, cc.inverse):
+        with torch.no_grad():
+            y0, l0 = fn(zc, yc)
+        y1, l1 = fn(zc, yc)
+        assert_close(N(y1), N(y0), what="CCAffineConst torch vs kernel", rtol=1e-5, atol=1e-5)
+        assert_close(N(l1), N(l0), what="CCAffineConst log-det", rtol=1e-5, atol=1e-5)
+    (y1.sum() + l1.sum()).backward()
+    assert all(p_.grad is not None for p_ in cc.parameters())
     lg = nfa.transforms.Logit(0.05)
     z = (torch.rand(3, 2, 4, 4, device=DEV) * 0.9 + 0.05)
     with torch.no_grad():

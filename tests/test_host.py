@@ -497,3 +497,40 @@ def test_one_pass_backward_kernels_use_no_scratch(nfa):
                 assert d["vgpr_spill_count"] == 0 and d["private_segment_fixed_size"] == 0, (name, d)
     assert seen == 3, seen
 
+
+
+@pytest.mark.parametrize("use_lu", [True, False])
+def test_invertible_affine_torch_path_vs_reference_fixture(nfa, use_lu):
+    """The differentiable path of InvertibleAffine (taken when a gradient is asked for) on CPU against the reference's outputs
+    (tests/golden/invertible_affine_lu*.npz); gradients reach every parameter."""
+    from conftest import assert_close, golden_state, load_golden
+    g = load_golden("invertible_affine_lu%d" % int(use_lu))
+    ia = nfa.flows.InvertibleAffine(7, use_lu=use_lu)
+    ia.load_state_dict({k: torch.from_numpy(v) for k, v in golden_state(g).items()}, strict=True)
+    z = torch.from_numpy(g["z"]).requires_grad_(True)
+    y, ld = ia.forward(z)
+    assert_close(y.detach().numpy(), g["z_fwd"], what="z_fwd", rtol=1e-4, atol=1e-5)
+    assert_close(ld.detach().numpy(), g["ld_fwd"], what="ld_fwd", rtol=1e-5, atol=1e-5)
+    yi, ldi = ia.inverse(z)
+    assert_close(yi.detach().numpy(), g["z_inv"], what="z_inv", rtol=1e-4, atol=1e-5)
+    assert_close(ldi.detach().numpy(), g["ld_inv"], what="ld_inv", rtol=1e-5, atol=1e-5)
+    (y.square().sum() + yi.square().sum() + ld + ldi).backward()
+    assert z.grad is not None and all(p.grad is not None and torch.isfinite(p.grad).all() for p in ia.parameters())
+
+
+def test_cc_affine_const_torch_path_vs_reference_fixture(nfa):
+    """The differentiable path of CCAffineConst on CPU against the reference's outputs (tests/golden/cc_affine_const.npz)."""
+    from conftest import assert_close, golden_state, load_golden
+    g = load_golden("cc_affine_const")
+    cc = nfa.flows.CCAffineConst((3, 1, 1), 4)
+    cc.load_state_dict({k: torch.from_numpy(v) for k, v in golden_state(g).items()}, strict=True)
+    z, y = torch.from_numpy(g["z"]), torch.from_numpy(g["y"])
+    out, ld = cc.forward(z, y)
+    assert out.requires_grad
+    assert_close(out.detach().numpy(), g["z_fwd"], what="z_fwd", rtol=1e-5, atol=1e-5)
+    assert_close(ld.detach().numpy(), g["ld_fwd"], what="ld_fwd", rtol=1e-5, atol=1e-5)
+    out, ld = cc.inverse(z, y)
+    assert_close(out.detach().numpy(), g["z_inv"], what="z_inv", rtol=1e-5, atol=1e-5)
+    assert_close(ld.detach().numpy(), g["ld_inv"], what="ld_inv", rtol=1e-5, atol=1e-5)
+    (out.sum() + ld.sum()).backward()
+    assert all(p.grad is not None for p in cc.parameters())
