@@ -49,18 +49,26 @@ class AffineConstFlow(Flow):
     def _geometry(self, z):
         if self._per_channel:
             return z
-        if self._elementwise:  # every element has its own (s, t): treat as C = prod(shape), HW = 1
-            return z.reshape(z.shape[0], -1)
-        raise NotImplementedError("AffineConstFlow parameters of shape %s (broadcast over inner dims other than "
-                                  "trailing ones) are not supported by the HIP kernel" % (tuple(self.s.shape),))
+        # every element has its own (s, t) -- or gets one by broadcasting, _operands(): C = prod(sample shape), HW = 1
+        return z.reshape(z.shape[0], -1)
+
+    def _operands(self, z, detach):
+        """(z as the kernel sees it, s, t as flat vectors).  Parameter shapes that broadcast over inner dimensions other than
+        trailing ones -- (1, H, W), (C, 1, W), ... (coupling.py:30-35 takes any broadcastable shape) -- are expanded to one
+        parameter per element of a sample; under autograd the expansion is a view, so the gradient is summed back by torch."""
+        s, t = (self.s.detach(), self.t.detach()) if detach else (self.s, self.t)
+        if not (self._per_channel or self._elementwise):
+            full = (1,) + tuple(z.shape[1:])
+            s, t = s.expand(full), t.expand(full)
+        return self._geometry(z), s.reshape(-1), t.reshape(-1)
 
     def _apply_kernel(self, z, inverse, ld=None, acc=None, want_scalar=True):
-        zz = self._geometry(z)
         if needs_grad(z, self.s, self.t):   # training: HIP forward through ActNormFn, per-sample log-det
-            y, log_det = ActNormFn.apply(zz.contiguous(), self.s.reshape(-1), self.t.reshape(-1), 1 if inverse else 0)
+            zz, sv, tv = self._operands(z, False)
+            y, log_det = ActNormFn.apply(zz.contiguous(), sv, tv, 1 if inverse else 0)
             return y.view(z.shape), _fold_ld(ld, acc, log_det)
-        y, lds = ops.actnorm(zz, self.s.detach(), self.t.detach(), 1 if inverse else 0, logdet=ld, acc=acc,
-                             want_scalar=want_scalar)
+        zz, sv, tv = self._operands(z, True)
+        y, lds = ops.actnorm(zz, sv, tv, 1 if inverse else 0, logdet=ld, acc=acc, want_scalar=want_scalar)
         return y.view(z.shape), lds
 
     def forward(self, z):

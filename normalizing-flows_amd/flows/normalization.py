@@ -30,6 +30,21 @@ class ActNorm(AffineConstFlow):
         if self._init_known:
             return
         assert self.s is not None and self.t is not None
+        if not (self._per_channel or self._elementwise):
+            # parameters that broadcast over inner dimensions (not a shape the reference's models use): the statistics over the
+            # broadcast dimensions as plain torch reductions, once (normalization.py:21-39; local batch only)
+            with torch.no_grad():
+                std = z.std(dim=self.batch_dims, keepdim=True) + 1e-6
+                mean = z.mean(dim=self.batch_dims, keepdim=True)
+                if inverse:
+                    self.s.data.copy_(torch.log(std))
+                    self.t.data.copy_(mean)
+                else:
+                    self.s.data.copy_(-torch.log(std))
+                    self.t.data.copy_(-mean / std)
+            self.data_dep_init_done.fill_(1.0)
+            self._init_known = True
+            return
         zz = self._geometry(z)
         mean, std = ops.actnorm_stats(zz)
         from .. import dp

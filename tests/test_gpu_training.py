@@ -960,3 +960,35 @@ def test_backward_after_reforward_with_other_weights_raises(nfa):
     m.forward_kld(x).backward()
     for (nm, p_), a in zip(m.named_parameters(), g_two):
         assert float((a - p_.grad).abs().max()) <= 1e-4 * max(float(p_.grad.abs().max()), 1e-6), nm
+
+
+@pytest.mark.parametrize("pshape", [(1, 4, 5), (3, 1, 5), (3, 4, 1)])
+def test_affine_const_flow_inner_broadcast_shapes(nfa, pshape):
+    """AffineConstFlow / ActNorm with parameters that broadcast over inner dimensions other than trailing ones (coupling.py:30-54,
+    normalization.py:21-39 take any broadcastable shape): values, log-det, data-dependent initialisation and parameter gradients
+    against the formulas written out in torch."""
+    torch.manual_seed(11)
+    z = (torch.randn(6, 3, 4, 5, device=DEV) * 1.7 + 0.3)
+    f = nfa.flows.AffineConstFlow(pshape).to(DEV)
+    with torch.no_grad():
+        f.s.normal_(0, 0.4)
+        f.t.normal_(0, 0.4)
+    reps = z[0].numel() // f.s[0].numel()
+    for inverse in (False, True):
+        with torch.no_grad():
+            y0, l0 = (f.inverse if inverse else f.forward)(z)
+        y1, l1 = (f.inverse if inverse else f.forward)(z)
+        ref = (z - f.t) * torch.exp(-f.s) if inverse else z * torch.exp(f.s) + f.t
+        lref = (-1.0 if inverse else 1.0) * reps * f.s.sum()
+        assert_close(N(y0), N(ref), what="inference values", rtol=1e-5, atol=1e-5)
+        assert_close(N(l0), N(lref), what="inference log-det", rtol=1e-5, atol=1e-5)
+        assert_close(N(y1), N(ref), what="training values", rtol=1e-5, atol=1e-5)
+        gs, gt = torch.autograd.grad((y1 * y1).sum() + l1.sum(), [f.s, f.t])
+        rs, rt = torch.autograd.grad((ref * ref).sum() + lref * (l1.numel() if l1.dim() else 1), [f.s, f.t])   # per-sample log-dets under autograd
+        assert_close(N(gt), N(rt), what="grad t", rtol=1e-4, atol=1e-4)
+        assert_close(N(gs), N(rs), what="grad s", rtol=1e-4, atol=1e-3)
+    an = nfa.flows.ActNorm(pshape).to(DEV)
+    with torch.no_grad():
+        y, _ = an.forward(z)
+    dims = [0] + [i + 1 for i, d in enumerate(pshape) if d == 1]
+    assert float(y.mean(dim=dims).abs().max()) < 1e-4 and float((y.std(dim=dims) - 1).abs().max()) < 1e-3
