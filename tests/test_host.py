@@ -534,3 +534,12 @@ def test_cc_affine_const_torch_path_vs_reference_fixture(nfa):
     assert_close(ld.detach().numpy(), g["ld_inv"], what="ld_inv", rtol=1e-5, atol=1e-5)
     (out.sum() + ld.sum()).backward()
     assert all(p.grad is not None for p in cc.parameters())
+
+
+def test_utils_nn_helpers(nfa):
+    """utils.sum_except_batch / utils.tile (utils/nn.py:181-193): per-sample reduction and element-wise repetition."""
+    x = torch.arange(24.0).reshape(2, 3, 4)
+    assert torch.equal(nfa.utils.sum_except_batch(x), x.sum(dim=(1, 2)))
+    assert torch.equal(nfa.utils.sum_except_batch(x, 2), x.sum(dim=2))
+    assert torch.equal(nfa.utils.sum_except_batch(torch.arange(3.0)), torch.tensor(3.0))
+    assert torch.equal(nfa.utils.tile(torch.tensor([[1, 2], [3, 4]]), 3), torch.tensor([1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4]))
