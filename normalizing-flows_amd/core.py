@@ -410,6 +410,28 @@ class NormalizingFlow(nn.Module):
         log_p = self.p.log_prob(z)
         return torch.mean(log_q) - beta * torch.mean(log_p)
 
+    def reverse_alpha_div(self, num_samples=1, alpha=1, dreg=False, eps=None):
+        """Alpha divergence estimated on samples of q (core.py:133-165).  Plain estimator: sign(alpha - 1) logsumexp(alpha log w)
+        with log w = log p - log q along the (differentiable) sampling path.  dreg=True: the doubly reparametrised estimator
+        (arXiv 1810.04152) -- the importance weights enter as constants, log w is re-evaluated through the density direction with
+        the parameters frozen.  `eps` fixes the base noise (tests)."""
+        if eps is None:
+            z, log_q = self.sample(num_samples)
+        else:
+            z, log_q = self.sample_from_noise(eps)
+        log_p = self.p.log_prob(z)
+        if not dreg:
+            return (1.0 if alpha > 1 else (-1.0 if alpha < 1 else 0.0)) * torch.logsumexp(alpha * (log_p - log_q), 0)
+        w_const = torch.exp(log_p - log_q).detach()
+        with _frozen_parameters(self):
+            log_q = torch.zeros(len(z), dtype=z.dtype, device=z.device)
+            z_ = run_chain(self.flows, z, True, log_q, +1)
+            log_q = log_q + self.q0.log_prob(z_)
+        w_alpha = w_const ** alpha
+        w_alpha = w_alpha / torch.mean(w_alpha)
+        weights = (1 - alpha) * w_alpha + alpha * w_alpha ** 2
+        return -alpha * torch.mean(weights * (log_p - log_q))
+
     def save(self, path):
         torch.save(self.state_dict(), path)
 

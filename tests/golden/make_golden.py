@@ -629,6 +629,30 @@ def gen_reverse_kld():
         npz("grad_reverse_kld_sf%d" % int(score_fn), eps=eps, loss=loss.detach(), **grads, **sd(m, "sd__"))
 
 
+def gen_reverse_alpha_div():
+    """reverse_alpha_div (core.py:133-165): loss and gradients, plain and doubly reparametrised estimator, alpha on both sides
+    of 1; the model and the base noise of gen_reverse_kld."""
+    for tag, alpha, dreg in (("a05", 0.5, False), ("a2", 2.0, False), ("a05_dreg", 0.5, True), ("a2_dreg", 2.0, True)):
+        torch.manual_seed(14)
+        flows = []
+        for _ in range(2):
+            flows += [nf.flows.CoupledRationalQuadraticSpline(6, 1, 16, num_bins=4, init_identity=False),
+                      nf.flows.LULinearPermute(6)]
+        target = nf.distributions.DiagGaussian(6, trainable=False)
+        target.loc.add_(0.5)
+        target.log_scale.add_(-0.3)
+        m = nf.NormalizingFlow(nf.distributions.DiagGaussian(6, trainable=True), flows, p=target)
+        perturb(m, 0.1, 17)
+        torch.manual_seed(99)
+        eps = torch.randn(32, 6)
+        torch.manual_seed(99)
+        loss = m.reverse_alpha_div(32, alpha=alpha, dreg=dreg)
+        loss.backward()
+        grads = {"g__" + k.replace(".", "__"): p_.grad for k, p_ in m.named_parameters() if p_.grad is not None}
+        npz("grad_reverse_alpha_div_" + tag, eps=eps, loss=loss.detach(), alpha=np.float64(alpha), dreg=np.int64(dreg),
+            **grads, **sd(m, "sd__"))
+
+
 def gen_glow_grads():
     """Training step of the class-conditional Glow model of examples/glow.ipynb (reduced) and of the RealNVP model of
     examples/real_nvp.ipynb: forward_kld loss and every parameter gradient from the reference's autograd."""
@@ -953,6 +977,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "reverse_kld":
         gen_reverse_kld()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "reverse_alpha_div":
+        gen_reverse_alpha_div()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "conditional":
         gen_conditional()
         sys.exit(0)
@@ -1008,6 +1035,7 @@ if __name__ == "__main__":
     gen_circular()
     gen_conditional()
     gen_reverse_kld()
+    gen_reverse_alpha_div()
     gen_glow_grads()
     gen_ar_grads()
     gen_image_coupling()
