@@ -1021,3 +1021,37 @@ def test_affine_const_flow_inner_broadcast_shapes(nfa, pshape):
         y, _ = an.forward(z)
     dims = [0] + [i + 1 for i, d in enumerate(pshape) if d == 1]
     assert float(y.mean(dim=dims).abs().max()) < 1e-4 and float((y.std(dim=dims) - 1).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("K", [8, 10])
+def test_utils_splines_entry_points_vs_reference(nfa, K):
+    """utils.splines.{unconstrained_,}rational_quadratic_spline (utils/splines.py:16-219 under the reference's own names): the
+    inference kernel (no_grad) and the forward + backward kernel pair (gradients asked for) against the reference's outputs
+    (tests/golden/spline_K*_f32.npz); gradients reach inputs and all three parameter tensors."""
+    g = load_golden("spline_K%d_f32" % K)
+    sp = nfa.utils.splines
+    w, h = T(g["w"]), T(g["h"])
+    for tails, dkey, bound, ykey, lkey in (("linear", "d_lin", 3.0, "yl", "ladl"), ("circular", "d_cir", 2.5, "yc", "ladc")):
+        with torch.no_grad():
+            y0, l0 = sp.unconstrained_rational_quadratic_spline(T(g["xl"]), w, h, T(g[dkey]), tails=tails, tail_bound=bound)
+        assert_close(N(y0), g[ykey], what=ykey, rtol=1e-5, atol=1e-5)
+        assert_close(N(l0), g[lkey], what=lkey, rtol=5e-5, atol=5e-5)
+        x = T(g["xl"]).clone().requires_grad_(True)
+        ps = [t_.clone().requires_grad_(True) for t_ in (w, h, T(g[dkey]))]
+        y1, l1 = sp.unconstrained_rational_quadratic_spline(x, *ps, tails=tails, tail_bound=bound)
+        assert y1.shape == x.shape and l1.shape == x.shape
+        assert_close(N(y1), g[ykey], what=ykey + " (training path)", rtol=1e-5, atol=1e-5)
+        assert_close(N(l1), g[lkey], what=lkey + " (training path)", rtol=5e-5, atol=5e-5)
+        (y1.sum() + l1.sum()).backward()
+        assert all(t_.grad is not None and torch.isfinite(t_.grad).all() for t_ in [x] + ps)
+        assert float(x.grad.abs().sum()) > 0 and float(ps[0].grad.abs().sum()) > 0
+    with torch.no_grad():
+        y, l = sp.rational_quadratic_spline(T(g["x01"]), w, h, T(g["d_none"]))
+        yi, li = sp.rational_quadratic_spline(T(g["y01"]), w, h, T(g["d_none"]), inverse=True)
+    assert_close(N(y), g["y01"], what="y01", rtol=1e-5, atol=1e-5)
+    assert_close(N(l), g["lad01"], what="lad01", rtol=5e-5, atol=5e-5)
+    assert_close(N(yi), g["x01_inv"], what="x01_inv", rtol=1e-5, atol=1e-5)
+    with pytest.raises(ValueError):
+        sp.rational_quadratic_spline(T(g["x01"]), w, h, T(g["d_none"]), min_bin_width=0.2)
+    knots = torch.tensor([0.0, 1.0, 2.0], device=DEV)
+    assert sp.searchsorted(knots, torch.tensor([0.5, 2.0, 1.0], device=DEV)).tolist() == [0, 1, 1] and float(knots[-1]) == 2.0
