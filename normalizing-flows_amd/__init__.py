@@ -14,6 +14,10 @@ from .distributions import DiagGaussian, ConditionalDiagGaussian, ClassCondDiagG
 
 __version__ = "0.1.0"
 
+from . import _refpaths as _refpaths   # noqa: E402
+import sys as _sys                      # noqa: E402
+_refpaths.install(_sys.modules[__name__])
+
 
 def native_library_path():
     return _lib.LIBPATH
