@@ -6,9 +6,9 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r3ev
 mkdir -p $O
 cd $R
-python -m pytest tests -m gpu -q 2>&1 | tail -8 > $O/pytest_gpu.log
-python __graft_entry__.py smoke > $O/smoke.log 2>&1
-python bench.py > $O/bench_line.json 2> $O/bench.err
+timeout 600 python -m pytest tests -m gpu -q --timeout 300 2>&1 | tail -8 > $O/pytest_gpu.log     # (bounded: one call of this script once sat 40 minutes in this line on a bad box)
+timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1
+timeout 600 python bench.py > $O/bench_line.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-breakdown --no-graph --no-secondary"
 T="python $R/tools/train_bench.py --steps 3 --fused-adam"
