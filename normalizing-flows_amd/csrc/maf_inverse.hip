@@ -477,7 +477,10 @@ maf_inverse_kernel(const float *__restrict__ z, float *__restrict__ y, float *__
                     }
                     maf_finish(us, sh, zin[s], xn, ld);
                 }
-                if (s + 1 < MS) xg[s + 1] = xn;
+                // statically indexed (16 selects): see maf_inverse_h.hip -- the dynamically indexed register write of this line went
+                // out of bounds in one build of the h mapping
+#pragma unroll
+                for (int j_ = 1; j_ < MS; ++j_) xg[j_] = (j_ == s + 1) ? xn : xg[j_];
                 xcarry = xn;
                 const int f = dlo + s;
                 Xw[((size_t)((f >> 3) * 2 + ((f >> 2) & 1)) * 64 + lane) * 4 + (f & 3)] = xn;

@@ -52,58 +52,57 @@ __device__ __forceinline__ void h_block(const float *__restrict__ A, const float
             for (int i = 0; i < 4; ++i) c0[4 * q + i] = v[i];
         }
     }
-    const f32x4 *pa = reinterpret_cast<const f32x4 *>(A) + lane;
-    const f32x4 *pa2 = reinterpret_cast<const f32x4 *>(PAIR ? A2 : A) + lane;
     const int nkb = K >> 3;
     if (nkb > 0) {
-        // The activation requests are INLINE ASM, i.e. invisible to the compiler's wait-count pass.  With the builtin, the
-        // compiler knows an LDS-DMA may be pending and then waits vmcnt(0) at the first use of any ORDINARY load result (the A
-        // operands below): every fourth k-block drained the whole ring and the block part ran at the latency of one request
-        // chain (2.9 TB/s; found in round 3).  Not knowing about them it counts only its own loads, which errs on the strict side.
-        const uint32_t ring_lds = (uint32_t)(uintptr_t)ring;      // LDS byte address of the wave's ring (wave-uniform)
-        auto dma = [&](int kb) {
-            const uint32_t dst = __builtin_amdgcn_readfirstlane(ring_lds + (uint32_t)(kb % HRB) * 1024u);
+        // ALL three streams of the product -- the activation k-blocks (HBM / L2) and the A [, A2] weight k-blocks (L2) -- arrive by
+        // LDS-DMA in the wave's own ring: 4 slots each (12 KB), slot = k-block mod 4, a slot is requested again (k-block + 4) as
+        // soon as its three reads have returned.  The requests are INLINE ASM and there is no ordinary load in the loop, so the
+        // compiler inserts no vector-memory wait of its own and the hand-counted ones are exact: vector-memory operations retire
+        // in order, block kb's requests went out 4 steps ago, younger than them are the 3 x (1 + LPS) requests of the blocks
+        // kb + 1 .. kb + 3 -- four steps' worth of requests are in flight under every step's MFMAs.
+        // History (round 3): (1) the builtin + A operands as ordinary register loads: the compiler waited vmcnt(0) at every first
+        // use of a loaded register while an LDS-DMA might be pending -- the ring drained every fourth k-block (2.9 TB/s, 16.1 ms);
+        // (2) activation requests as asm, A still in registers (14.5 ms): the compiler's counted waits for A (it counts only its
+        // own loads) stand in front of the interleaved requests it does not know of, so ~2.3 steps were in flight instead of 4.
+        constexpr int LPS = PAIR ? 2 : 1, OPS = 1 + LPS;
+        static_assert(HRB == 12, "4 slots per stream");
+        const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ring);
+        auto dma1 = [&](uint32_t dst, const float *src) {
             // (m0 is a reserved register: the compiler does not honour it as a clobber, so it is saved and restored here)
             uint32_t m0_;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(m0_) : "s"(dst), "v"(Sl + (size_t)kb * 256 + lane * 4) : "memory");
+                         : "=&s"(m0_) : "s"(dst), "v"(src) : "memory");
         };
-        struct Stage { f32x4 a, a2; };
-        auto ld = [&](int kb, Stage &st) {
-            const int k = kb < nkb ? kb : nkb - 1;
-            st.a = pa[k * 64];
-            if constexpr (PAIR) st.a2 = pa2[k * 64];
+        auto req = [&](int kb, int slot) {
+            const size_t off = (size_t)kb * 256 + lane * 4;
+            dma1(ring_lds + (uint32_t)slot * 1024u, Sl + off);
+            dma1(ring_lds + 4096u + (uint32_t)slot * 1024u, A + off);
+            if constexpr (PAIR) dma1(ring_lds + 8192u + (uint32_t)slot * 1024u, A2 + off);
         };
-        auto mm = [&](int kb, const Stage &st) {
-            // vector-memory operations retire in order; per k-block: dma(kb + HRB - 1) | wait | MFMAs | ld(kb + 4).  Younger than
-            // ld(kb) at this wait: 3 ld (x2 for a tile pair) + 4 requests; everything older -- k-block kb of the ring, requested
-            // HRB - 1 steps ago -- has landed.  Past the last request the three youngest ld may stay in flight.
-            constexpr int LPS = PAIR ? 2 : 1;
-            if (kb + HRB - 1 < nkb) {
-                dma(kb + HRB - 1);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS + 4) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS) : "memory");
-            }
-            const f32x4 b = *reinterpret_cast<const f32x4 *>(ring + (kb % HRB) * 256 + lane * 4);
+        auto step = [&](int kb, int slot) {
+            const int rem = nkb - 1 - kb;       // blocks requested after this one
+            if (rem >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * OPS) : "memory");
+            else if (rem == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(ring + slot * 256 + lane * 4);
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(ring + 1024 + slot * 256 + lane * 4);
+            f32x4 a2 = a;
+            if constexpr (PAIR) a2 = *reinterpret_cast<const f32x4 *>(ring + 2048 + slot * 256 + lane * 4);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot's reads have returned: it may be requested again
+            if (kb + 4 < nkb) req(kb + 4, slot);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                c0 = HMFMA(st.a[i], b[i], c0);
-                if constexpr (PAIR) c2 = HMFMA(st.a2[i], b[i], c2);
+                c0 = HMFMA(a[i], b[i], c0);
+                if constexpr (PAIR) c2 = HMFMA(a2[i], b[i], c2);
             }
         };
-        // prologue in the steady state's order: dma(0 .. HRB - 5), then ld(i) / dma(HRB - 4 + i) alternating
-        Stage s0, s1, s2, s3;
-        for (int j = 0; j < HRB - 4 && j < nkb; ++j) dma(j);
-        ld(0, s0); if (HRB - 4 < nkb) dma(HRB - 4);
-        ld(1, s1); if (HRB - 3 < nkb) dma(HRB - 3);
-        ld(2, s2); if (HRB - 2 < nkb) dma(HRB - 2);
-        ld(3, s3);
-        for (int kb = 0; kb < nkb; kb += 4) {        // nkb is a multiple of 4
-            mm(kb, s0); ld(kb + 4, s0);
-            mm(kb + 1, s1); ld(kb + 5, s1);
-            mm(kb + 2, s2); ld(kb + 6, s2);
-            mm(kb + 3, s3); ld(kb + 7, s3);
+        req(0, 0); req(1, 1); req(2, 2); req(3, 3);      // nkb is a multiple of 4
+        for (int kb = 0; kb < nkb; kb += 4) {
+            step(kb, 0);
+            step(kb + 1, 1);
+            step(kb + 2, 2);
+            step(kb + 3, 3);
         }
     }
     if constexpr (PAIR) {
@@ -299,7 +298,11 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
                     sh = xsum((own ? pF[ru] : 0.0f) + (a0 + a1));
                 }
                 h_finish(us, sh, zin[s], xn, ld);
-                if (s + 1 < HS) xg[s + 1] = xn;
+                // a STATICALLY indexed write (16 selects): with `xg[s + 1] = xn` the compiler's dynamically indexed register write
+                // went out of the vector's registers in the round-3 build of the block part (it overwrote request addresses that
+                // live across the tile loop: a memory fault on layers with 10-16 degrees per tile; bisected with debug builds)
+#pragma unroll
+                for (int j_ = 1; j_ < HS; ++j_) xg[j_] = (j_ == s + 1) ? xn : xg[j_];
                 xcarry = xn;
                 const int f = dlo + s;
                 if (hh == 0) {
