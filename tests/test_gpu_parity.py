@@ -1027,7 +1027,10 @@ def test_maf_config5_width_vs_reference(nfa):
     assert torch.equal(conn, torch.tril(torch.ones_like(conn), -1))
 
 
-@pytest.mark.parametrize("D,H,B", [(128, 512, 300), (17, 40, 64), (3, 2, 5), (40, 39, 129), (6, 150, 1)])
+@pytest.mark.parametrize("D,H,B", [(128, 512, 300), (17, 40, 64), (3, 2, 5), (40, 39, 129), (6, 150, 1),
+                                   # tiles of 10-16 degrees: the shapes on which a dynamically indexed register write of the
+                                   # sequential part went out of bounds in one build
+                                   (32, 64, 64), (64, 128, 64), (96, 256, 64), (33, 39, 129)])
 def test_maf_incremental_inverse_vs_d_pass(nfa, D, H, B):
     """nf_maf_inverse (one pass, every hidden unit finalised once) against the reference's D-pass structure
     (autoregressive.py:29-38) run through the same MADE; ragged batches; degrees with 1..32 units."""
@@ -1673,7 +1676,7 @@ def test_maf_inverse_both_mappings_agree(nfa, B):
     assert_close(N(zz), N(z), what="round trip", rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("D,H,NB,B", [(128, 512, 1, 4096), (40, 100, 3, 777), (128, 512, 3, 2048), (17, 40, 1, 65)])
+@pytest.mark.parametrize("D,H,NB,B", [(128, 512, 1, 4096), (40, 100, 3, 777), (128, 512, 3, 2048), (17, 40, 1, 65), (40, 39, 1, 129), (40, 39, 3, 129)])
 def test_maf_incremental_inverse_other_block_counts(nfa, D, H, NB, B):
     """nf_maf_inverse_h for MADE conditioners of 1 and 3 residual blocks (nets/made.py:140-214; round 2 took two blocks only and
     sent the others through the D-pass loop): against the reference's D-pass structure on the same weights; the packer and
