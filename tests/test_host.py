@@ -573,3 +573,54 @@ def test_reference_import_paths_resolve(nfa):
             top = flat.get(path.split(".")[0])
             if top is not None and hasattr(top, n):
                 assert obj is getattr(top, n), (path, n)
+
+
+def test_no_fence_barrier_behind_counted_vmcnt_waits():
+    """Source lint for DESIGN 3.5 item 1: `__syncthreads()` is a fence, and while an LDS-DMA may be pending the compiler turns it
+    into `s_waitcnt vmcnt(0)` -- a counted `s_waitcnt vmcnt(N)` directly in front of it never takes effect.  Every kernel source
+    that counts must use the raw barrier (`s_waitcnt lgkmcnt(0)` + `s_barrier`) there."""
+    import glob
+    import re
+    bad = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "normalizing-flows_amd", "csrc", "*.hip"))):
+        lines = open(path).read().split("\n")
+        for i, line in enumerate(lines):
+            code = line.split("//")[0]
+            if re.search(r"s_waitcnt vmcnt\((%0|[1-9][0-9]*)\)", code):
+                for j in range(i + 1, min(i + 6, len(lines))):
+                    nxt = lines[j].split("//")[0]
+                    if "__syncthreads()" in nxt:
+                        bad.append("%s:%d" % (os.path.basename(path), j + 1))
+                        break
+                    if "s_barrier" in nxt or "GL_BARRIER" in nxt or "GC_RING_BARRIER" in nxt or "BB_BARRIER" in nxt or "LB_BARRIER" in nxt:
+                        break
+    assert not bad, bad
+
+
+def test_streaming_kernels_have_no_flat_loads(nfa):
+    """Disassembly lint for DESIGN 3.5 item 3: a FLAT load counts on lgkmcnt as well as vmcnt, so every wait for an LDS read
+    also waits for it -- the 16-pixel Glow kernel's register weight stream was FLAT loads (its base comes out of a pointer
+    table = a generic pointer) until round 3.  The kernels that stream through registers / LDS-DMA rings must use global loads."""
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as kr
+    objdir = os.path.join(ROOT, "normalizing-flows_amd", "lib", "obj")
+    # (object, kernel-name fragment, allowed FLAT loads: the level table's pointer fetches in the block prologue)
+    checks = [("glow_conv.o", "glow_convnet_tiny_kernel", 4), ("glow_conv.o", "glow_convnet_small_kernel", 4),
+              ("glow_conv.o", "glow_convnet_kernel", 4), ("maf_inverse_h.o", "maf_inverse_h_kernel", 0),
+              ("final_bwd.o", "final_bwd_kernel", 0), ("rqs_fused.o", "rqs_fused_kernel", 0)]
+    with tempfile.TemporaryDirectory() as tmp:
+        cache = {}
+        for obj, frag, allowed in checks:
+            if obj not in cache:
+                co = kr.code_object(os.path.join(objdir, obj), tmp)
+                cache[obj] = subprocess.run([os.path.join(kr.LLVM, "llvm-objdump"), "-d", co], capture_output=True, text=True).stdout
+            cur, counts = None, {}
+            for line in cache[obj].split("\n"):
+                if line.endswith(">:"):
+                    cur = line.split("<")[-1][:-2]
+                elif cur and frag in cur and "flat_load" in line:
+                    counts[cur] = counts.get(cur, 0) + 1
+            worst = max(counts.values()) if counts else 0
+            assert worst <= allowed, (obj, frag, counts)
