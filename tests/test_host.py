@@ -356,7 +356,8 @@ def test_dp_nll_matches_unsharded_under_gloo(nfa, tmp_path):
     assert "DP_OK" in out.stdout
 
 
-@pytest.mark.parametrize("D,H,NB", [(128, 512, 2), (17, 40, 2), (3, 2, 2), (40, 39, 2), (6, 150, 2), (17, 40, 1), (33, 70, 3), (128, 512, 1)])
+@pytest.mark.parametrize("D,H,NB", [(128, 512, 2), (17, 40, 2), (3, 2, 2), (40, 39, 2), (6, 150, 2), (17, 40, 1), (33, 70, 3), (128, 512, 1),
+                                    (32, 64, 2), (96, 256, 2)])
 def test_maf_pack_schedule_matches_d_pass(D, H, NB):
     """flows/maf_pack.py + the kernel's tile/step schedule (tests/maf_emulator.py restates it in numpy) reproduce the
     fixed point of the reference's D-pass inverse (autoregressive.py:29-38) computed with plain torch in fp64."""
