@@ -261,6 +261,23 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=131072, help="rows of the same workload timed on the host oracle")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher ourselves -- one rank per GPU under torch.distributed.run on
+        # this node, rendezvous on 127.0.0.1 (the container hostname may not resolve), same arguments.  Under the driver's own
+        # `python -m torch.distributed.run ... bench.py --gpus N` WORLD_SIZE is set and this branch is not taken.
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        if os.environ.get("NF_BENCH_PRINT_LAUNCH") == "1":      # CPU test hook: show the launch line, start nothing
+            print(json.dumps({"launch": cmd}))
+            return
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+
     import torch.distributed as dist
     import normflows_amd as nfa
     from normflows_amd import dp
@@ -417,7 +434,7 @@ def main():
             nfa.config.set_fused_gemm("f32")
             model.use_graphs(False)
             model.use_graphs(not args.no_graph)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:     # rank 0 only, untimed (at N > 1 the other ranks wait at the closing barrier)
             out["cpu_baseline"] = cpu_baseline(model, args.cpu_rows, lp.cpu().numpy(),
                                                lp3.cpu().numpy() if not args.no_breakdown else None)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -411,6 +411,36 @@ def gen_grads():
     npz("grad_model_c2mini", x=x, loss=loss.detach(), **grads, **sd(m, "sd__"))
 
 
+def gen_train_c2_w64h128():
+    """The training step at the BENCHMARK layer shape (core.py:87-102 forward_kld + loss.backward() over
+    wrapper.py:14-85, nets/resnet.py:53-104, mixing.py:535-563): 2 x [CoupledRationalQuadraticSpline(64, 2, 128) +
+    LULinearPermute(64)], sigma = 0.05, B = 1024 rows -- the smallest batch from which our layers take the one-launch training
+    forward (nf_rqs_fused_train_full_fwd) and the one-pass backward kernels (nf_final_bwd, nf_resblock_bwd, nf_lu_bwd), so those
+    kernels are pinned to the reference's autograd and not only to our own layer-wise path.  float32 leg + float64 leg (the same
+    weights cast up); the model is rebuilt from its seed on the test side (bench.build_c2_model, bit-identical construction is
+    tests/test_host.py's business), the fixture carries per-parameter checksums instead of 1.4 MB of weights."""
+    sys.path.insert(0, os.path.join(OUT, "..", ".."))
+    from bench import build_c2_model, c2_inputs
+    m = build_c2_model(num_layers=2, dim=64, hidden=128, seed=0, sigma=0.05, lib=nf)
+    x = c2_inputs(1024, 64, seed=4321)
+    out = {"x": x}
+    for k, p_ in m.named_parameters():
+        out["chk__" + k.replace(".", "__")] = np.array([p_.detach().double().sum().item(), p_.detach().double().abs().sum().item()])
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        mm = build_c2_model(num_layers=2, dim=64, hidden=128, seed=0, sigma=0.05, lib=nf)   # fp32 weights ...
+        mm = mm.to(dt)                                                                    # ... cast up for the fp64 leg
+        xx = x.detach().clone().to(dt).requires_grad_(True)
+        loss = mm.forward_kld(xx)
+        loss.backward()
+        out["loss_" + tag] = loss.detach().double()
+        out["gx_" + tag] = xx.grad.float()
+        for k, p_ in mm.named_parameters():
+            out["g_%s__%s" % (tag, k.replace(".", "__"))] = p_.grad.float()       # fp64 gradients rounded to fp32: 6e-8 relative
+        with torch.no_grad():
+            out["log_prob_" + tag] = mm.log_prob(x.detach().clone().to(dt)).double()
+    npz("grad_model_c2_w64h128", **out)
+
+
 def gen_maf():
     """MaskedAffineAutoregressive (affine/autoregressive.py): forward = one MADE pass, inverse = D passes."""
     for d, hidden, B in ((20, 40, 9), (128, 512, 4)):
@@ -1020,6 +1050,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "maf":
         gen_maf()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "train_c2":
+        gen_train_c2_w64h128()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "grads":
         gen_grads()
         sys.exit(0)
@@ -1046,3 +1079,4 @@ if __name__ == "__main__":
     gen_glow_model256()
     gen_glow_model_full()
     gen_maf_model_full()
+    gen_train_c2_w64h128()

@@ -41,7 +41,7 @@ def test_bench_two_ranks_on_one_device():
     env = dict(os.environ, NF_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", "29683", os.path.join(ROOT, "bench.py"),
-                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8192", "--no-breakdown"],
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8192", "--no-breakdown", "--cpu-rows", "2048"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2500:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
@@ -49,5 +49,23 @@ def test_bench_two_ranks_on_one_device():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_rows"] == 16384 and d["config"]["parallelism"] == "dp2"
     assert abs(d["value"] - 2 * 8192 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
-    assert "cpu_baseline" not in d                              # rank 0 at N = 1 only
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0      # rank 0, untimed, also at N > 1
     assert abs(d["nll_nats_per_dim"] - 1.5416) < 2e-2
+
+
+def test_bench_launches_its_own_ranks():
+    """Plain `python bench.py --gpus 2` (no torch.distributed.run in front, WORLD_SIZE unset -- the way the driver starts the
+    N = 1 run): bench.py re-executes itself under torch.distributed.run with one rank per GPU, so the 8-GPU run needs no
+    launcher knowledge on the driver's side.  Two ranks share cuda:0 over gloo here (NF_BENCH_ONE_DEVICE=1)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(NF_BENCH_ONE_DEVICE="1", OMP_NUM_THREADS="4")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--batch", "8192", "--no-breakdown", "--cpu-rows", "2048"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2500:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_rows"] == 16384 and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 2 * 8192 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert "cpu_baseline" in d and abs(d["nll_nats_per_dim"] - 1.5416) < 2e-2

@@ -790,6 +790,82 @@ def test_drop_in_under_reference_style_container(nfa):
     assert torch.allclose(z, z2) and torch.allclose(log_q, ld2, atol=1e-5)
 
 
+def test_drop_in_under_the_reference_own_containers(nfa):
+    """The reference's REAL containers around our layers (runs wherever /root/reference and a GPU exist together; skipped on a
+    box without the reference): `nf.NormalizingFlow(q0, [ours...])` log_prob / sample / forward_kld (core.py:9-60, 87-102,
+    167-197) and `nf.MultiscaleFlow` (core.py:455-616) with our GlowBlock / Squeeze / Merge layers give bit-for-bit what our own
+    containers give on the same layers, and our layers load the reference's state_dict unchanged."""
+    import sys
+    if not os.path.isdir("/root/reference/normflows"):
+        pytest.skip("the reference is not on this box")
+    sys.path.insert(0, "/root/reference")
+    nf = pytest.importorskip("normflows")
+    torch.manual_seed(0)
+    flows = []
+    for _ in range(3):
+        flows += [nfa.flows.CoupledRationalQuadraticSpline(8, 1, 32), nfa.flows.LULinearPermute(8)]
+    flows += [nfa.flows.ActNorm(8)]
+    for f in flows:
+        f.to(DEV)
+    with torch.no_grad():
+        for f in flows:
+            for p_ in f.parameters():
+                p_.add_(0.05 * torch.randn_like(p_))
+    x = torch.randn(130, 8, device=DEV)
+    ours = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(8, trainable=False), flows).to(DEV)
+    with torch.no_grad():
+        ours.log_prob(x)                                   # ActNorm's data-dependent init happens once, here
+    theirs = nf.NormalizingFlow(nf.distributions.DiagGaussian(8, trainable=False), flows).to(DEV)
+    with torch.no_grad():
+        assert torch.equal(theirs.log_prob(x), ours.log_prob(x))
+        torch.manual_seed(5)
+        xs_t, lq_t = theirs.sample(64)
+        torch.manual_seed(5)
+        xs_o, lq_o = ours.sample(64)
+        assert torch.equal(xs_t, xs_o) and torch.equal(lq_t, lq_o)
+        z_t, ld_t = theirs.inverse_and_log_det(x)
+        z_o, ld_o = ours.inverse_and_log_det(x)
+        assert torch.equal(z_t, z_o) and torch.allclose(ld_t, ld_o, atol=1e-6)
+    lt = theirs.forward_kld(x)
+    lo = ours.forward_kld(x)
+    assert abs(float(lt) - float(lo)) < 1e-6 * abs(float(lo))
+    # MultiscaleFlow (Glow, examples/glow.ipynb cell 2, reduced): the reference's container over our blocks
+    torch.manual_seed(1)
+    L_, K_, C, hidden = 2, 2, 3, 16
+    q0, merges, gflows = [], [], []
+    for i in range(L_):
+        gflows += [[nfa.flows.GlowBlock(C * 2 ** (L_ + 1 - i), hidden, split_mode="channel", scale=True) for _ in range(K_)]
+                   + [nfa.flows.Squeeze()]]
+        if i > 0:
+            merges += [nfa.flows.Merge()]
+            shape = (C * 2 ** (L_ - i), 8 // 2 ** (L_ - i), 8 // 2 ** (L_ - i))
+        else:
+            shape = (C * 2 ** (L_ + 1), 8 // 2 ** L_, 8 // 2 ** L_)
+        q0 += [nfa.distributions.DiagGaussian(shape, trainable=False)]
+    img = torch.rand(16, C, 8, 8, device=DEV)
+    ours_ms = nfa.MultiscaleFlow(q0, gflows, merges).to(DEV)
+    with torch.no_grad():
+        lp_o = ours_ms.log_prob(img)                       # initialises every ActNorm
+    theirs_ms = nf.MultiscaleFlow(q0, gflows, merges).to(DEV)
+    with torch.no_grad():
+        lp_t = theirs_ms.log_prob(img)
+        assert _rel(N(lp_t), N(lp_o)) < 1e-5               # (ours runs whole levels as one launch: another summation order)
+        torch.manual_seed(9)
+        xs_t, lq_t = theirs_ms.sample(8)
+        torch.manual_seed(9)
+        xs_o, lq_o = ours_ms.sample(8)
+        assert torch.allclose(xs_t, xs_o, atol=1e-4) and _rel(N(lq_t), N(lq_o)) < 1e-5
+    # and the other way round: our layers take the reference layers' state_dict unchanged
+    torch.manual_seed(2)
+    ref_layer = nf.flows.CoupledRationalQuadraticSpline(8, 1, 32)
+    mine = nfa.flows.CoupledRationalQuadraticSpline(8, 1, 32)
+    mine.load_state_dict(ref_layer.state_dict(), strict=True)
+    with torch.no_grad():
+        a, la = ref_layer.inverse(x.cpu())
+        b, lb = mine.to(DEV).inverse(x)
+    assert torch.allclose(a, b.cpu(), atol=1e-5) and torch.allclose(la, lb.cpu(), atol=1e-5)
+
+
 def test_cpu_tensor_is_rejected(nfa):
     layer = nfa.flows.LULinearPermute(4)
     with pytest.raises(RuntimeError, match="no CPU path"):

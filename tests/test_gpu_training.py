@@ -100,6 +100,75 @@ def test_forward_kld_training_step_vs_reference(nfa):
     assert abs(float(-lp.mean()) - float(m.forward_kld(x))) < 1e-4 * abs(l0)
 
 
+def _c2_train_model_and_fixture(nfa):
+    """2 x [CoupledRationalQuadraticSpline(64, 2, 128) + LULinearPermute(64)], sigma 0.05, rebuilt from its seed; the fixture's
+    per-parameter checksums prove these are the weights the reference differentiated."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from bench import build_c2_model
+    g = load_golden("grad_model_c2_w64h128")
+    m = build_c2_model(num_layers=2, dim=64, hidden=128, seed=0, sigma=0.05)
+    for k, p_ in m.named_parameters():
+        chk = g["chk__" + k.replace(".", "__")]
+        assert abs(float(p_.detach().double().sum()) - float(chk[0])) <= 1e-12 * float(chk[1]), k       # (fp64 sums: the
+        assert abs(float(p_.detach().double().abs().sum()) - float(chk[1])) <= 1e-12 * float(chk[1]), k  # order may differ by host)
+    return m.to(DEV), g
+
+
+def test_benchmark_shape_training_step_vs_reference_autograd(nfa, monkeypatch):
+    """The kernels the training step of the BENCHMARK model runs -- the one-launch training forward
+    (nf_rqs_fused_train_full_fwd = rqs_fused_kernel<0,false,2>), nf_final_bwd, nf_resblock_bwd, nf_lu_fwd / nf_lu_bwd, the ring
+    weight gradient -- against the REFERENCE's autograd (core.py:87-102 forward_kld + loss.backward()) at the benchmark layer shape
+    (D = 64, hidden 128, un-padded) and B = 1024, the smallest batch that takes them (tests/golden/make_golden.py train_c2).
+    Bars: loss 1e-4 relative; every gradient within 1e-3 of its scale (max |reference gradient|) of the reference's fp32 leg;
+    against the fp64 leg, the 90th percentile of the entry errors within 4x the reference's OWN fp32-vs-fp64 90th percentile
+    (floor 1e-6 of the scale: the reference's fp32 run happens to have no ReLU pre-activation within rounding of zero on these
+    rows; a flipped mask moves single entries by O(1 / rows), which the max bar covers)."""
+    from normflows_amd import ops
+    m, g = _c2_train_model_and_fixture(nfa)
+    calls = {}
+    for name in ("rqs_fused_train_full_fwd", "final_bwd", "resblock_bwd", "lu_fwd", "lu_bwd"):
+        orig = getattr(ops, name)
+
+        def spy(*a, _orig=orig, _name=name, **kw):
+            calls[_name] = calls.get(_name, 0) + 1
+            return _orig(*a, **kw)
+        monkeypatch.setattr(ops, name, spy)
+    x = T(g["x"]).requires_grad_(True)
+    for f in m.flows[0::2]:
+        assert f.prqct._train_full_ok(x, None, False)
+    loss = m.forward_kld(x)
+    loss.backward()
+    assert calls.get("rqs_fused_train_full_fwd") == 2 and calls.get("final_bwd") == 2, calls
+    assert calls.get("resblock_bwd") == 4 and calls.get("lu_fwd") == 2 and calls.get("lu_bwd") == 2, calls
+    ref_loss = float(g["loss_f32"])
+    assert abs(float(loss) - ref_loss) < 1e-4 * abs(ref_loss), (float(loss), ref_loss)
+    assert abs(float(loss) - float(g["loss_f64"])) < 1e-4 * abs(ref_loss)
+    report = []
+
+    def check(name, got, r32, r64):
+        scale = max(float(np.abs(r64).max()), 1e-6)
+        e32 = np.abs(got - r32) / scale
+        e64 = np.abs(got - r64) / scale
+        own = np.abs(r32 - r64) / scale
+        q_ours, q_ref = float(np.quantile(e64, 0.9)), float(np.quantile(own, 0.9))
+        report.append((name, float(e32.max()), q_ours, q_ref))
+        assert float(e32.max()) < 1e-3, ("gradient of %s vs reference fp32 autograd" % name, float(e32.max()))
+        assert q_ours <= 4.0 * max(q_ref, 1e-6), ("gradient of %s vs reference fp64 autograd" % name, q_ours, q_ref)
+
+    check("x", N(x.grad), g["gx_f32"], g["gx_f64"])
+    for k, p_ in m.named_parameters():
+        key = k.replace(".", "__")
+        check(k, N(p_.grad), g["g_f32__" + key], g["g_f64__" + key])
+    worst = max(report, key=lambda r: r[1])
+    print("benchmark-shape step vs reference autograd: worst max-normalised error %.2e (%s); q90 vs fp64 worst %.2e (reference's own %.2e)"
+          % (worst[1], worst[0], max(r[2] for r in report), max(r[3] for r in report)))
+    # the inference kernels on the same weights and rows (no_grad path) against the reference's log_prob
+    with torch.no_grad():
+        lp = N(m.log_prob(T(g["x"])))
+    assert np.max(np.abs(lp - g["log_prob_f64"]) / np.maximum(1.0, np.abs(g["log_prob_f64"]))) < 1e-4
+
+
 def test_spline_gradients_match_finite_differences_fp64(nfa):
     """Independent check of nf_rqs_coupling_bwd: central differences of the fp64 forward kernel."""
     torch.manual_seed(0)

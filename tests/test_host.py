@@ -625,3 +625,20 @@ def test_streaming_kernels_have_no_flat_loads(nfa):
                     counts[cur] = counts.get(cur, 0) + 1
             worst = max(counts.values()) if counts else 0
             assert worst <= allowed, (obj, frag, counts)
+
+
+def test_bench_gpus_n_launches_itself():
+    """`python bench.py --gpus 8` with no launcher in front re-executes under torch.distributed.run, one rank per GPU on this
+    node, rendezvous on 127.0.0.1, same arguments (NF_BENCH_PRINT_LAUNCH=1 prints the line instead of exec'ing it)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["NF_BENCH_PRINT_LAUNCH"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    cmd = json.loads(out.stdout.strip().splitlines()[-1])["launch"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"]

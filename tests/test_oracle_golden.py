@@ -193,6 +193,27 @@ def test_c2mini_model(oracle):
     assert rel.max() < 1e-5, rel.max()
 
 
+def test_benchmark_shape_model_oracle_vs_reference():
+    """The oracle at the BENCHMARK layer shape (D = 64, hidden 128, 2 blocks, 8 bins; 2 layer pairs, sigma = 0.05, 1024 rows of
+    tests/golden/grad_model_c2_w64h128.npz): log_prob against the reference's float32 and float64 legs; the model is rebuilt from
+    its seed (bench.build_c2_model) and must reproduce the per-parameter checksums of the weights the reference ran on."""
+    import nf_oracle
+    from bench import build_c2_model, state_to_numpy
+    nf_oracle.build()
+    g = load_golden("grad_model_c2_w64h128")
+    m = build_c2_model(num_layers=2, dim=64, hidden=128, seed=0, sigma=0.05)
+    for k, p_ in m.named_parameters():
+        chk = g["chk__" + k.replace(".", "__")]
+        assert abs(float(p_.detach().double().sum()) - float(chk[0])) <= 1e-12 * float(chk[1]), k
+        assert abs(float(p_.detach().double().abs().sum()) - float(chk[1])) <= 1e-12 * float(chk[1]), k
+    ora = nf_oracle.OracleNSF(state_to_numpy(m), num_layers=len(m.flows), K=8, tail_bound=3.0)
+    lp = ora.log_prob(g["x"])
+    for tag in ("f32", "f64"):
+        ref = g["log_prob_" + tag]
+        assert np.max(np.abs(lp - ref) / np.maximum(1.0, np.abs(ref))) < 1e-5
+    assert abs(-float(np.mean(lp.astype(np.float64))) - float(g["loss_f64"])) < 1e-5 * abs(float(g["loss_f64"]))
+
+
 def test_whole_flow_entry_point_matches_layerwise_oracle_and_reference(oracle):
     """nfo_nsf_log_prob (the single-call, OpenMP-over-rows routine timed as bench.py's cpu_baseline) is bit-identical
     to the layer-by-layer oracle chain and matches the reference's log_prob on the C2-mini fixture."""
