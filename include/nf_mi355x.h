@@ -469,6 +469,25 @@ int nf_maf_affine(const void *x, const void *params, void *y, void *logdet, int6
                   int dtype, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * MADE in ONE launch -- the single-pass direction of the autoregressive flows.  Replaces
+ * normflows/nets/made.py:296-304 (MADE.forward: initial MaskedLinear, MaskedResidualBlocks :196-214, final MaskedLinear; every
+ * linear is F.linear(x, weight * mask, bias), :80-81) and, for nf_made_forward_affine, also
+ * normflows/flows/affine/autoregressive.py:24-27 + :101-110 (Autoregressive.forward + _elementwise_forward:
+ * scale = sigmoid(unconstrained_scale + 2) + 1e-3, y = scale x + shift, logdet = sum log scale).
+ *   blob, table : device copies of the arrays of the host packer (normflows_amd/flows/made_pack.py): hidden units sorted by
+ *                 degree, per 32-row block one stream of MFMA A fragments that stops at the last k-group its MASK reaches
+ *                 (structurally zero blocks are neither stored nor multiplied), biases in the same order.
+ *   hidden_padded = table[3] (256 or 512), D = table[0] <= 128, float32, ReLU residual blocks, no context / batch norm / dropout /
+ *                 permuted input degrees (the packer returns None for anything else and the caller keeps the layer-wise path).
+ *   nf_made_forward_affine: x, y (B, D), logdet (B) combined according to `acc`.
+ *   nf_made_forward       : params (B, mult D), rows in the reference's order (mult f + p).
+ */
+int nf_made_forward_affine(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, int64_t B, int D,
+                           int hidden_padded, int acc, nf_stream_t stream);
+int nf_made_forward(const void *x, void *params, const void *blob, const int32_t *table, int64_t B, int D, int hidden_padded,
+                    int mult, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * MaskedAffineAutoregressive inverse (MAF sampling direction) in ONE pass.  Replaces the D-pass loop of
  * normflows/flows/affine/autoregressive.py:29-38 over MADE (nets/made.py:217-304, residual blocks :140-214,
  * masks :63-81) together with _elementwise_inverse (:114-128): every hidden unit is finalised once, right after

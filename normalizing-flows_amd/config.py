@@ -114,3 +114,13 @@ lu_matvec2 = True
 def set_lu_matvec2(mode=True):
     global lu_matvec2
     lu_matvec2 = bool(mode)
+
+
+# MADE's single pass as ONE launch (nf_made_forward / nf_made_forward_affine, csrc/made_fwd.hip) where flows/made_pack.py takes the
+# structure; False = layer by layer (library GEMMs on the pre-masked weights; ablation / differential tests).
+made_fused = True
+
+
+def set_made_fused(mode=True):
+    global made_fused
+    made_fused = bool(mode)

@@ -1,0 +1,293 @@
+// made_fwd.hip -- ONE pass of MADE (nets/made.py:296-304: initial MaskedLinear, residual blocks :196-214, final MaskedLinear; every
+// linear is F.linear(x, weight * mask, bias), :80-81) as ONE launch, with the element-wise affine transform of
+// MaskedAffineAutoregressive.forward (flows/affine/autoregressive.py:24-27 -> :101-110) as its epilogue: the single-pass direction
+// of MAF (BASELINE configs[4]: 10 layers, d = 128, hidden 512), which round 3 still ran as six library GEMMs + element-wise passes
+// per layer.  Exact-fp32 MFMA; bound: the fp32 MFMA rate on the MASKED work (53 % of the dense blocks at config 5).
+//
+// Geometry (host packer: flows/made_pack.py)
+//   * a workgroup of 8 waves owns 64 rows for the WHOLE network; hidden slots = units sorted by degree, Hp = 256 NSB (NSB = 1, 2);
+//     every GEMM is transposed, Out^T[units x 64 rows] = W . Act^T, on v_mfma_f32_32x32x2_f32: lane (hh = lane >> 5, n = lane & 31)
+//     holds sample n of a 32-sample block; its 16 accumulator registers are output rows 8 q + 4 hh + i of a 32-row block.
+//   * the pre-activations live in ACCUMULATOR registers for the whole network (h: the residual stream, t: a block's inner layer:
+//     2 x 32 registers per wave and tensor); what the NEXT layer contracts over -- relu(h), relu(t), raw h for the final layer -- is
+//     published to LDS in B-operand order act[k / 8][hh][64 samples][4] (one ds_write_b128 per register quad: the natural order of
+//     the accumulators IS that order; one ds_read_b128 = the B values of four k-steps), 128 KB at Hp = 512.
+//   * work items: NSB = 2: wave w owns hidden row-blocks {w, 15 - w} for both sample blocks; NSB = 1 and the final layer: row-blocks
+//     {w, 7 - w}, the first for sample block 0, the second for sample block 1.  With the units sorted by degree row-block rb needs
+//     the k-groups [0, nkg(rb)), nkg ~ 4 (rb + 1): the pairing gives every wave the same number of MFMAs (68 k-groups per hidden
+//     layer at config 5), so the waves meet at the layer boundaries without waiting.
+//   * weights: every row-block has ONE contiguous stream of A fragments (1 KB per k-group, lane = its own 16 bytes) that only its
+//     owner reads: plain global loads into a PF-deep register ring, no LDS, no barrier inside a layer.  No LDS-DMA anywhere in this
+//     kernel, so the compiler's own counted vmcnt waits are exact.
+//   * two LDS-only barriers per layer boundary (all reads of the old activations done | new ones published).
+//   * x tile: 64 rows x Dp features in the same B-operand order (32 KB): B operand of the initial layer and the x of the affine
+//     epilogue, which overwrites it in place with z = scale x + shift; the tile leaves with 16-byte stores.
+// Algorithmic work per row: 2 (D H + 2 NB H^2 + H mult D) FLOP dense (2.49 MFLOP at config 5), 1.33 MFLOP masked; HBM: 4 D in,
+// 4 D + 4 out (affine) resp. 4 mult D out (raw parameters).
+#include "common.hpp"
+#include "fused_common.hpp"
+
+namespace nf {
+
+constexpr int MF_ROWS = 64;       // rows per workgroup
+constexpr int MF_NW = 8;          // waves per workgroup: two per SIMD
+constexpr int MF_PF = 8;          // k-groups of A in flight per wave (8 KB; 8 x 512 cycles of MFMA issue per wave at NSB = 2)
+constexpr int MF_HDR = 32;
+constexpr int MF_XFLOATS = 16 * 2 * 64 * 4;      // x tile: Dp <= 128 features
+
+#define MF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+// LDS-only barrier: the A ring's global loads stay in flight across it (a __syncthreads() fence would drain them)
+#define MF_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// acc[sb] (+)= W[32 rows][8 nkg] . act[8 nkg][32 samples of block sb]; Ag: the row-block's stream + 4 lane; Bl: LDS activations
+// + the lane's offset (4 (64 hh + n [+ 32 sb])).  The packer pads the blob by MF_PF k-groups, so the ring may read past the stream.
+template <int NS>
+__device__ __forceinline__ void mf_item(const float *__restrict__ Ag, int nkg, const float *Bl, f32x16 (&acc)[NS]) {
+    f32x4 a[MF_PF];
+#pragma unroll
+    for (int j = 0; j < MF_PF; ++j) a[j] = *reinterpret_cast<const f32x4 *>(Ag + j * 256);
+    for (int kg = 0; kg < nkg; kg += MF_PF) {
+#pragma unroll
+        for (int j = 0; j < MF_PF; ++j) {
+            if (kg + j < nkg) {
+                const float *bp = Bl + (size_t)(kg + j) * 512;
+                const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bp);
+                f32x4 b1 = b0;
+                if constexpr (NS == 2) b1 = *reinterpret_cast<const f32x4 *>(bp + 128);
+                const f32x4 av = a[j];
+                a[j] = *reinterpret_cast<const f32x4 *>(Ag + (size_t)(kg + j + MF_PF) * 256);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[0] = MF_MFMA(av[i], b0[i], acc[0]);
+                    if constexpr (NS == 2) acc[1] = MF_MFMA(av[i], b1[i], acc[1]);
+                }
+            }
+        }
+    }
+}
+
+// bias of row-block: rows 8 q + 4 hh + i  ->  register 4 q + i
+template <int NS, bool ADD>
+__device__ __forceinline__ void mf_bias(const float *__restrict__ bias, int hh, f32x16 (&acc)[NS]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + 8 * q + 4 * hh);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[s][4 * q + i] = ADD ? acc[s][4 * q + i] + b[i] : b[i];
+    }
+}
+
+// publish the row-block's values (ReLU'd or raw) as the next layer's B operand: act[(4 rb + q)][hh][32 sb + n][4]
+template <int NS, bool RELU>
+__device__ __forceinline__ void mf_publish(float *acts, int rb, int sb0, int hh, int n, const f32x16 (&v)[NS]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = RELU ? fmaxf(v[s][4 * q + i], 0.0f) : v[s][4 * q + i];
+            *reinterpret_cast<f32x4 *>(acts + ((size_t)((4 * rb + q) * 2 + hh) * 64 + 32 * (sb0 + s) + n) * 4) = o;
+        }
+}
+
+// EPI 0: z = scale x + shift, logdet = sum log scale (autoregressive.py:101-110, :124-128: rows 2 f = unconstrained scale, 2 f + 1
+// = shift);  EPI 1: the raw MADE output (B, mult D) for the callers that apply another element-wise transform.
+template <int NSB, int EPI>
+__global__ void __launch_bounds__(64 * MF_NW, 1)
+made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ logdet, const float *__restrict__ blob,
+                const int *__restrict__ table, int64_t B, int acc_mode) {
+    constexpr int NS = NSB;                  // sample blocks per hidden work item
+    constexpr int HRB = 8 * NSB;             // hidden row-blocks
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *acts = lds;                                  // [HRB * 4 k-groups][2][64][4]
+    float *xreg = lds + (size_t)HRB * 4 * 512;          // [Dp / 8][2][64][4]
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hh = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = table[0], Dp = table[1], NB = table[5], mult = table[6], NFB = table[7];
+    const int64_t row0 = (int64_t)blockIdx.x * MF_ROWS;
+    const int nrows = (int)((B - row0) < MF_ROWS ? (B - row0) : MF_ROWS);
+
+    // ---- x tile -> LDS (B-operand order; rows beyond the batch and features beyond D are zero) -------------------------------------
+    {
+        const int r = tid & 63, cg = tid >> 6;
+        const float *xr = x + (row0 + r) * D;
+        for (int c = cg; c < Dp / 4; c += MF_NW) {
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (r < nrows && 4 * c < D) {           // (Dp rounds D up to 8: the last chunk may lie wholly beyond the row)
+                if ((D & 3) == 0) v = *reinterpret_cast<const f32x4 *>(xr + 4 * c);
+                else
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (4 * c + i < D) v[i] = xr[4 * c + i];
+            }
+            *reinterpret_cast<f32x4 *>(xreg + ((size_t)c * 64 + r) * 4) = v;
+        }
+    }
+    // work items of this wave: slot 0 / 1 -> hidden row-block, first sample block
+    const int rbs[2] = {w, HRB - 1 - w};
+    const int sb0s[2] = {0, NSB == 2 ? 0 : 1};
+    const int lane_b = (64 * hh + n) * 4;       // the lane's offset inside a k-group of activations (sample block 0)
+    f32x16 h[2][NS], t[2][NS];
+    MF_BARRIER();
+
+    // ---- initial layer: h = b0 + W0 x --------------------------------------------------------------------------------------------------
+    {
+        const int *dir = table + table[16];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int rb = rbs[s];
+            mf_bias<NS, false>(blob + dir[4 * rb + 2], hh, h[s]);
+            mf_item<NS>(blob + dir[4 * rb] + lane * 4, dir[4 * rb + 1], xreg + lane_b + 128 * sb0s[s], h[s]);
+        }
+    }
+    // ---- residual blocks (nets/made.py:196-214): t = b1 + W1 relu(h);  h += b2 + W2 relu(t) -----------------------------------
+    for (int b = 0; b < NB; ++b) {
+        MF_BARRIER();        // (b > 0: every wave has finished reading relu(t) of the previous block)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) mf_publish<NS, true>(acts, rbs[s], sb0s[s], hh, n, h[s]);
+        MF_BARRIER();
+        {
+            const int *dir = table + table[16 + 1 + 2 * b];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int rb = rbs[s];
+                mf_bias<NS, false>(blob + dir[4 * rb + 2], hh, t[s]);
+                mf_item<NS>(blob + dir[4 * rb] + lane * 4, dir[4 * rb + 1], acts + lane_b + 128 * sb0s[s], t[s]);
+            }
+        }
+        MF_BARRIER();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) mf_publish<NS, true>(acts, rbs[s], sb0s[s], hh, n, t[s]);
+        MF_BARRIER();
+        {
+            const int *dir = table + table[16 + 2 + 2 * b];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int rb = rbs[s];
+                mf_bias<NS, true>(blob + dir[4 * rb + 2], hh, h[s]);
+                mf_item<NS>(blob + dir[4 * rb] + lane * 4, dir[4 * rb + 1], acts + lane_b + 128 * sb0s[s], h[s]);
+            }
+        }
+    }
+    // ---- final layer on the RAW block output (:303-304) + epilogue -----------------------------------------------------------------
+    MF_BARRIER();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) mf_publish<NS, false>(acts, rbs[s], sb0s[s], hh, n, h[s]);
+    MF_BARRIER();
+    const int *dirf = table + table[16 + 1 + 2 * NB];
+    float ldsum[2] = {0.0f, 0.0f};
+    for (int fb0 = 0; fb0 < NFB; fb0 += 8) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int fb = fb0 + (s == 0 ? w : 7 - w);       // sample block s
+            if (fb < NFB) {
+                f32x16 o[1];
+                mf_bias<1, false>(blob + dirf[4 * fb + 2], hh, o);
+                mf_item<1>(blob + dirf[4 * fb] + lane * 4, dirf[4 * fb + 1], acts + lane_b + 128 * s, o);
+                if constexpr (EPI == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int f0 = 16 * fb + 4 * q + 2 * hh;
+                        float *xp = xreg + ((size_t)((2 * fb + (q >> 1)) * 2 + (q & 1)) * 64 + 32 * s + n) * 4 + 2 * hh;
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            if (f0 + e < D) {
+                                const float scale = 1.0f / (1.0f + __expf(-(o[0][4 * q + 2 * e] + 2.0f))) + 1e-3f;
+                                xp[e] = scale * xp[e] + o[0][4 * q + 2 * e + 1];
+                                ldsum[s] += __logf(scale);
+                            }
+                        }
+                    }
+                } else {
+                    const int64_t r = row0 + 32 * s + n;
+                    if (32 * s + n < nrows) {
+                        float *yp = y + r * ((int64_t)mult * D) + 32 * fb + 4 * hh;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int c = 32 * fb + 8 * q + 4 * hh;
+                            if (((mult * D) & 3) == 0) {
+                                if (c < mult * D) *reinterpret_cast<f32x4 *>(yp + 8 * q) = f32x4{o[0][4 * q], o[0][4 * q + 1], o[0][4 * q + 2], o[0][4 * q + 3]};
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) if (c + i < mult * D) yp[8 * q + i] = o[0][4 * q + i];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (EPI == 0) {
+        // per-sample log-det: the lane-halves' sums, then the 8 row-blocks' in a FIXED order (deterministic)
+        MF_BARRIER();                      // every wave is done with the activations: their region now holds the partial sums
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float v = ldsum[s] + __shfl_xor(ldsum[s], 32);
+            const int fb = (s == 0 ? w : 7 - w);
+            if (hh == 0) acts[fb * 64 + 32 * s + n] = v;
+        }
+        MF_BARRIER();
+        if (tid < nrows) {
+            float v = 0.0f;
+            for (int fb = 0; fb < 8; ++fb) v += acts[fb * 64 + tid];
+            ld_store(logdet + row0 + tid, v, acc_mode);
+        }
+        const int r = tid & 63, cg = tid >> 6;
+        float *yr = y + (row0 + r) * D;
+        if (r < nrows)
+            for (int c = cg; 4 * c < D; c += MF_NW) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(xreg + ((size_t)c * 64 + r) * 4);
+                if ((D & 3) == 0) *reinterpret_cast<f32x4 *>(yr + 4 * c) = v;
+                else
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (4 * c + i < D) yr[4 * c + i] = v[i];
+            }
+    }
+}
+
+template <int NSB, int EPI>
+static int made_fwd_launch(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, int64_t B, int acc, hipStream_t st) {
+    const int64_t ntiles = (B + MF_ROWS - 1) / MF_ROWS;
+    const size_t lds = sizeof(float) * ((size_t)8 * NSB * 4 * 512 + MF_XFLOATS);
+    static LdsOptIn opted;
+    if (opt_in_lds(reinterpret_cast<const void *>(&made_fwd_kernel<NSB, EPI>), lds, opted) != NF_OK) return NF_ENOTSUP;
+    hipLaunchKernelGGL((made_fwd_kernel<NSB, EPI>), dim3((unsigned)ntiles), dim3(64 * MF_NW), lds, st, (const float *)x, (float *)y,
+                       (float *)logdet, (const float *)blob, (const int *)table, B, acc);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+}  // namespace nf
+
+static int made_fwd_check(int64_t B, int D, int hidden_padded, int mult) {
+    if (B < 0 || D < 2 || D > 128 || mult < 1) return NF_EINVAL;
+    if (hidden_padded != 256 && hidden_padded != 512) return NF_ENOTSUP;
+    return NF_OK;
+}
+
+// MaskedAffineAutoregressive.forward in one launch (affine/autoregressive.py:24-27, :101-110 over nets/made.py:296-304).
+extern "C" int nf_made_forward_affine(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, int64_t B, int D,
+                                      int hidden_padded, int acc, nf_stream_t stream) {
+    const int rc = made_fwd_check(B, D, hidden_padded, 2);
+    if (rc != NF_OK) return rc;
+    if (acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!x || !y || !logdet || !blob || !table) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    if (hidden_padded == 256) return nf::made_fwd_launch<1, 0>(x, y, logdet, blob, table, B, acc, st);
+    return nf::made_fwd_launch<2, 0>(x, y, logdet, blob, table, B, acc, st);
+}
+
+// MADE.forward (nets/made.py:296-304) in one launch: params (B, mult D), rows mult f + p as the reference's final layer orders them.
+extern "C" int nf_made_forward(const void *x, void *params, const void *blob, const int32_t *table, int64_t B, int D,
+                               int hidden_padded, int mult, nf_stream_t stream) {
+    const int rc = made_fwd_check(B, D, hidden_padded, mult);
+    if (rc != NF_OK) return rc;
+    if (B == 0) return NF_OK;
+    if (!x || !params || !blob || !table) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    if (hidden_padded == 256) return nf::made_fwd_launch<1, 1>(x, params, nullptr, blob, table, B, NF_LD_WRITE, st);
+    return nf::made_fwd_launch<2, 1>(x, params, nullptr, blob, table, B, NF_LD_WRITE, st);
+}

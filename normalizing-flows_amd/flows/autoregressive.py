@@ -3,8 +3,10 @@ and its wrapper AutoregressiveRationalQuadraticSpline (AR-NSF).
 
 Mirrors normflows/flows/affine/autoregressive.py:10-128 (constructor signature, `autoregressive_net.*` state_dict
 keys, direction semantics: `forward` = one MADE pass, `inverse` = D sequential MADE passes).  The element-wise
-affine transform and its log-det are one HIP kernel (nf_maf_affine); MADE's masked linears are library GEMMs on
-pre-masked weights (cached per parameter version).
+affine transform and its log-det are one HIP kernel (nf_maf_affine).  Without gradient tracking the single-pass direction is ONE
+launch: nf_made_forward_affine (MADE on fp32 MFMA over the masks' non-zero blocks + the affine epilogue, csrc/made_fwd.hip), and
+MADE itself is one launch (nf_made_forward) for the other element-wise transforms; under autograd, with a context, in float64 or
+for structures outside flows/made_pack.py, MADE's masked linears are library GEMMs on pre-masked weights.
 
 The inverse of MaskedAffineAutoregressive runs as ONE launch of nf_maf_inverse when
 the MADE has the supported structure (flows/maf_pack.py): every hidden unit is finalised once, total work = one MADE
@@ -76,6 +78,16 @@ class MaskedAffineAutoregressive(Autoregressive):
                 packed = (torch.from_numpy(blob).to(device), torch.from_numpy(table).to(device), int(table[3]), int(table[6]))
             self._maf_pack_cache = cache = (key, packed)
         return cache[1]
+
+    def forward(self, inputs, context=None):
+        """autoregressive.py:24-27: one MADE pass + the element-wise affine map -- ONE launch (nf_made_forward_affine) for the
+        MADE structures flows/made_pack.py takes; layer by layer otherwise (context, float64, gradient tracking, ...)."""
+        if (context is None and inputs.dim() == 2 and inputs.dtype == torch.float32 and inputs.is_cuda
+                and not autograd.needs_grad(inputs, *self.autoregressive_net.parameters())):
+            packed = self.autoregressive_net.packed_forward(inputs.device)
+            if packed is not None:
+                return ops.made_forward_affine(inputs, packed[0], packed[1], packed[2])
+        return super().forward(inputs, context)
 
     def inverse(self, inputs, context=None):
         if (context is None and inputs.dim() == 2 and inputs.dtype == torch.float32 and inputs.is_cuda

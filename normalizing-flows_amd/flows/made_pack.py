@@ -1,0 +1,141 @@
+"""Host-side packing for the one-launch MADE forward kernel (nf_made_forward_affine / nf_made_forward, csrc/made_fwd.hip).
+
+The single-pass direction of the autoregressive flows (normflows/flows/affine/autoregressive.py:24-27: `forward` = ONE pass of
+nets/made.py:296-304 + the element-wise transform) is a stack of MaskedLinear layers (made.py:19-81: `F.linear(x, weight * mask,
+bias)`).  With the hidden units SORTED BY DEGREE every mask is block lower-triangular -- a unit of degree m only sees inputs of
+degree <= m (:63-81) -- so about half of the 32 x 8 weight blocks are structurally zero and are neither stored nor multiplied.
+
+This module only rearranges weights (no arithmetic on data).  The kernel's geometry (made_fwd.hip):
+  * hidden slots = units sorted by degree (stable), zero-padded to Hp = 256 or 512; row-block rb = slots [32 rb, 32 rb + 32);
+  * a k-group kg = 8 consecutive inputs (features for the initial layer, hidden slots otherwise);
+  * per layer and row-block ONE contiguous stream of MFMA A-operand fragments [nkg][64 lanes][4]: lane (hh = lane >> 5,
+    m = lane & 31) holds W[32 rb + m][8 kg + 4 hh + 0..3] (v_mfma_f32_32x32x2_f32: A[m][k = hh], four k-steps per 16-byte load);
+    nkg = 1 + the last k-group in which the MASK of the row-block has a non-zero (a prefix, by the sorting).
+
+float blob  : per layer, per row-block: its A stream; then the layer's bias in slot order (32 floats per row-block); RING KB of zeros
+              at the end (the A ring reads ahead of the stream it is consuming).
+int32 table : hdr[32] = [D, Dp, H, Hp, NSB, NB, mult, NFB, nlayers, total blob floats, 0..] + hdr[16 + l] = offset (ints) of layer
+              l's directory; directory entry of a row-block = [a_off, nkg, bias_off, 0] (offsets in floats).
+Layers: 0 = initial (inputs = features), 1 .. 2 NB = the residual blocks' linears, 2 NB + 1 = final (rows mult f + p, natural order).
+"""
+import numpy as np
+import torch
+from torch.nn import functional as F
+
+HDR = 32
+ROWS = 32        # MFMA rows per row-block
+KG = 8           # inputs per k-group
+MAX_D = 128      # features: the x tile of 64 rows is 32 KB of LDS
+MAX_LAYERS = 16
+RING = 8         # made_fwd.hip MF_PF: k-groups of A a wave keeps in flight
+
+
+def supported(made, mult):
+    from .. import nets
+    if not isinstance(made, nets.MADE):
+        return False
+    if not isinstance(made.preprocessing, torch.nn.Identity) or hasattr(made, "context_layer"):
+        return False
+    nb = len(made.blocks)
+    if nb < 1 or 2 * nb + 2 > MAX_LAYERS or not all(isinstance(b, nets.MaskedResidualBlock) for b in made.blocks):
+        return False
+    for b in made.blocks:
+        if b.use_batch_norm or b.activation is not F.relu or b.dropout.p != 0.0 or hasattr(b, "context_layer"):
+            return False
+    D = made.initial_layer.in_features
+    H = made.initial_layer.out_features
+    if made.final_layer.out_features != mult * D or made.initial_layer.weight.dtype != torch.float32:
+        return False
+    return 2 <= D <= MAX_D and 1 <= H <= 512 and mult >= 1
+
+
+def a_stream(w_block):
+    """(32, 8 nkg) row-major -> [nkg][2][32][4] (lane = 32 hh + m holds W[m][8 kg + 4 hh + 0..3])."""
+    rows, K = w_block.shape
+    assert rows == ROWS and K % KG == 0
+    return np.ascontiguousarray(w_block.reshape(ROWS, K // KG, 2, 4).transpose(1, 2, 0, 3)).reshape(-1)
+
+
+def pack_made_forward(made, mult=2):
+    """(blob float32 ndarray, table int32 ndarray) or None when the MADE is outside the kernel's structure (then the caller
+    keeps the layer-by-layer path)."""
+    if not supported(made, mult):
+        return None
+    D = made.initial_layer.in_features
+    H = made.initial_layer.out_features
+    NB = len(made.blocks)
+    hid_deg = made.initial_layer.degrees.cpu().numpy()
+    lin = [made.initial_layer] + [l for b in made.blocks for l in b.linear_layers]
+    for l in lin[1:]:
+        if not np.array_equal(l.degrees.cpu().numpy(), hid_deg):
+            return None
+    fin = made.final_layer
+    # inputs in degree order (no permute_mask) and the output rows feature-major: what the element-wise epilogue assumes
+    m0 = made.initial_layer.mask.cpu().numpy()
+    if not np.array_equal(m0, (hid_deg[:, None] >= np.arange(1, D + 1)[None, :]).astype(m0.dtype)):
+        return None
+    mf = fin.mask.cpu().numpy()
+    out_deg = np.repeat(np.arange(1, D + 1), mult)
+    if not np.array_equal(mf, (out_deg[:, None] > hid_deg[None, :]).astype(mf.dtype)):
+        return None
+    Hp = 256 if H <= 256 else 512
+    NSB = Hp // 256
+    Dp = (D + KG - 1) // KG * KG
+    NFB = (mult * D + ROWS - 1) // ROWS
+    order = np.argsort(hid_deg, kind="stable")            # slot i holds unit order[i]
+    slot_of = np.zeros(H, dtype=np.int64)
+    slot_of[order] = np.arange(H)
+
+    def slots(lyr, in_map, in_size, out_rows=None, out_size=None):
+        """Masked weight, mask and bias of `lyr` in slot space (rows -> out_rows, columns -> in_map)."""
+        w = (lyr.weight.detach() * lyr.mask).cpu().numpy().astype(np.float32)
+        m = lyr.mask.cpu().numpy() != 0
+        b = lyr.bias.detach().cpu().numpy().astype(np.float32)
+        W = np.zeros((out_size, in_size), dtype=np.float32)
+        M = np.zeros((out_size, in_size), dtype=bool)
+        Bv = np.zeros(out_size, dtype=np.float32)
+        tmp = np.zeros((w.shape[0], in_size), dtype=np.float32)
+        tmp[:, in_map] = w
+        W[out_rows] = tmp
+        tm = np.zeros((w.shape[0], in_size), dtype=bool)
+        tm[:, in_map] = m
+        M[out_rows] = tm
+        Bv[out_rows] = b
+        return W, M, Bv
+
+    layers = [slots(lin[0], np.arange(D), Dp, slot_of, Hp)]
+    for l in lin[1:]:
+        layers.append(slots(l, slot_of, Hp, slot_of, Hp))
+    layers.append(slots(fin, slot_of, Hp, np.arange(mult * D), NFB * ROWS))
+    nlayers = len(layers)
+
+    table = [np.zeros(HDR, dtype=np.int32)]
+    chunks = []
+    off = 0
+    toff = HDR
+    for l, (W, M, Bv) in enumerate(layers):
+        nrb = W.shape[0] // ROWS
+        d = np.zeros((nrb, 4), dtype=np.int32)
+        for rb in range(nrb):
+            r0 = rb * ROWS
+            cols = np.nonzero(M[r0:r0 + ROWS].any(axis=0))[0]
+            nkg = 0 if cols.size == 0 else int(cols.max()) // KG + 1
+            d[rb, 0], d[rb, 1] = off, nkg
+            if nkg:
+                a = a_stream(W[r0:r0 + ROWS, :KG * nkg])
+                chunks.append(a)
+                off += a.size
+        for rb in range(nrb):
+            d[rb, 2] = off + rb * ROWS
+        chunks.append(Bv)
+        off += Bv.size
+        table[0][16 + l] = toff
+        table.append(d.reshape(-1))
+        toff += d.size
+    pad = np.zeros(RING * 256, dtype=np.float32)           # the kernel's A ring reads up to RING k-groups past a stream
+    chunks.append(pad)
+    off += pad.size
+    table[0][:10] = [D, Dp, H, Hp, NSB, NB, mult, NFB, nlayers, off]
+    blob = np.concatenate(chunks).astype(np.float32)
+    assert blob.size == off and off < 2 ** 31
+    return blob, np.concatenate(table).astype(np.int32)

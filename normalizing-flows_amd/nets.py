@@ -490,7 +490,30 @@ class MADE(nn.Module):
                                         autoregressive_features=features, random_mask=random_mask, is_output=True,
                                         out_degrees_=input_degrees_)
 
+    def packed_forward(self, device):
+        """Device copies of the one-launch pack (flows/made_pack.py), rebuilt when a parameter changes; None = unsupported."""
+        from . import config
+        if not config.made_fused:
+            return None
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (str(device),)
+        cache = self.__dict__.get("_fwd_pack_cache")
+        if cache is None or cache[0] != key:
+            from .flows import made_pack
+            mult = self.final_layer.out_features // self.initial_layer.in_features
+            packed = made_pack.pack_made_forward(self, mult)
+            if packed is not None:
+                blob, table = packed
+                packed = (torch.from_numpy(blob).to(device), torch.from_numpy(table).to(device), int(table[3]), mult)
+            cache = self.__dict__["_fwd_pack_cache"] = (key, packed)
+        return cache[1]
+
     def forward(self, inputs, context=None):
+        if (context is None and inputs.dim() == 2 and inputs.dtype == torch.float32 and inputs.is_cuda
+                and not (torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters())))):
+            packed = self.packed_forward(inputs.device)      # nf_made_forward: the whole network as one launch
+            if packed is not None:
+                from . import ops
+                return ops.made_forward(inputs, packed[0], packed[1], packed[2], packed[3])
         outputs = self.initial_layer(self.preprocessing(inputs))
         if context is not None:
             outputs = outputs + self.context_layer(context)

@@ -804,6 +804,40 @@ def rqs_fused_x3_chain(x, blobs, parities, hidden, num_blocks, K, direction, log
     return y, logdet
 
 
+def made_forward_affine(x, blob, table, hidden_padded, logdet=None, acc=None):
+    """MaskedAffineAutoregressive.forward (autoregressive.py:24-27, :101-110 over nets/made.py:296-304) as one launch
+    (nf_made_forward_affine); blob / table from flows/made_pack.pack_made_forward."""
+    L.require_device(x, blob, table)
+    if x.dtype != torch.float32:
+        raise NotImplementedError("made_forward_affine: float32 only")
+    B, D = x.shape
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    if logdet is None:
+        logdet = torch.empty(B, dtype=x.dtype, device=x.device)
+        acc = L.LD_WRITE
+    elif acc is None:
+        acc = L.LD_ADD
+    rc = L.lib().nf_made_forward_affine(ptr(x), ptr(y), ptr(logdet), ptr(blob), ptr(table), i64(B), i32(D), i32(hidden_padded),
+                                        i32(acc), L.stream())
+    L.check(rc, "nf_made_forward_affine")
+    return y, logdet
+
+
+def made_forward(x, blob, table, hidden_padded, mult):
+    """MADE.forward (nets/made.py:296-304) as one launch (nf_made_forward): (B, mult D) parameters."""
+    L.require_device(x, blob, table)
+    if x.dtype != torch.float32:
+        raise NotImplementedError("made_forward: float32 only")
+    B, D = x.shape
+    x = x.contiguous()
+    params = torch.empty(B, mult * D, dtype=x.dtype, device=x.device)
+    rc = L.lib().nf_made_forward(ptr(x), ptr(params), ptr(blob), ptr(table), i64(B), i32(D), i32(hidden_padded), i32(mult),
+                                 L.stream())
+    L.check(rc, "nf_made_forward")
+    return params
+
+
 def maf_inverse(z, blob, table, hidden_padded, logdet=None, acc=None, num_blocks=2):
     """autoregressive.py:29-38 + :114-128 in one pass; blob/table from flows/maf_pack.pack_made.  config.maf_halves (default):
     nf_maf_inverse_h (32 samples per wave, 1..3 residual blocks); otherwise round 2's nf_maf_inverse (two blocks only)."""

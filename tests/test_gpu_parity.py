@@ -1132,6 +1132,69 @@ def test_maf_incremental_inverse_vs_d_pass(nfa, D, H, B):
     assert_close(N(x2), N(x3), what="x after update", rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("D,H,NB,B", [(128, 512, 2, 300), (128, 512, 2, 64), (20, 40, 2, 130), (6, 300, 1, 7), (33, 256, 3, 65),
+                                      (3, 2, 2, 1), (64, 257, 2, 129), (127, 512, 1, 4100)])
+def test_made_forward_one_launch_vs_layerwise(nfa, D, H, NB, B):
+    """nf_made_forward_affine / nf_made_forward (csrc/made_fwd.hip: the whole MADE pass on fp32 MFMA over the non-zero blocks of
+    the masks, units sorted by degree, + the affine epilogue) against the layer-by-layer path (library GEMMs on weight * mask,
+    nets/made.py:80-81, 296-304, then nf_maf_affine): both hidden widths of the kernel (Hp = 256 / 512), 1-3 residual blocks,
+    feature counts off the 4- and 8-column granules, batches off the 64-row tile."""
+    torch.manual_seed(D * 1000 + H + NB)
+    layer = nfa.flows.MaskedAffineAutoregressive(D, H, num_blocks=NB)
+    _perturb(layer, 0.05 if D < 100 else 0.02, 3)
+    layer = layer.to(DEV)
+    made = layer.autoregressive_net
+    assert made.packed_forward(DEV) is not None
+    x = torch.randn(B, D, generator=torch.Generator().manual_seed(5)).to(DEV)
+    z1, ld1 = layer.forward(x)                       # one launch
+    p1 = made(x)                                     # nf_made_forward: raw parameters
+    nfa.config.set_made_fused(False)
+    try:
+        assert made.packed_forward(DEV) is None
+        z0, ld0 = layer.forward(x)
+        p0 = made(x)
+    finally:
+        nfa.config.set_made_fused(True)
+    assert_close(N(p1), N(p0), what="params", rtol=1e-4, atol=1e-4)
+    assert_close(N(z1), N(z0), what="z", rtol=1e-4, atol=1e-4)
+    assert_close(N(ld1), N(ld0), what="ld", rtol=1e-4, atol=1e-4)
+    # accumulate into a caller's log-density, and bit-reproducible
+    acc = torch.full((B,), 2.0, device=DEV)
+    _, acc2 = nfa.ops.made_forward_affine(x, *made.packed_forward(DEV)[:3], logdet=acc.clone(), acc=-1)
+    assert torch.equal(acc2, acc - ld1)
+    z2, ld2 = layer.forward(x)
+    assert torch.equal(z1, z2) and torch.equal(ld1, ld2)
+    # a parameter update invalidates the pack
+    with torch.no_grad():
+        made.final_layer.bias.add_(0.1)
+    z3, _ = layer.forward(x)
+    nfa.config.set_made_fused(False)
+    try:
+        z4, _ = layer.forward(x)
+    finally:
+        nfa.config.set_made_fused(True)
+    assert_close(N(z3), N(z4), what="z after update", rtol=1e-4, atol=1e-4)
+
+
+def test_made_forward_raw_parameters_for_the_spline_layer(nfa):
+    """nf_made_forward with 23 outputs per feature (the autoregressive spline layer's MADE, neural_spline/autoregressive.py:57-73):
+    several rounds of final row-blocks, output rows in the reference's order; AR-NSF's density direction rides on it."""
+    torch.manual_seed(11)
+    made = nfa.nets.MADE(features=16, hidden_features=96, num_blocks=2, output_multiplier=23)
+    _perturb(made, 0.05, 4)
+    made = made.to(DEV)
+    x = torch.randn(77, 16, device=DEV)
+    assert made.packed_forward(DEV) is not None
+    p1 = made(x)
+    nfa.config.set_made_fused(False)
+    try:
+        p0 = made(x)
+    finally:
+        nfa.config.set_made_fused(True)
+    assert p1.shape == (77, 16 * 23)
+    assert_close(N(p1), N(p0), what="params", rtol=1e-4, atol=1e-4)
+
+
 def test_maf_incremental_unsupported_falls_back_to_d_pass(nfa):
     """hidden < D-1 leaves degrees without units: outside the kernel's structure -> the D-pass loop is used."""
     torch.manual_seed(0)

@@ -642,3 +642,38 @@ def test_bench_gpus_n_launches_itself():
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     i = cmd.index(os.path.join(ROOT, "bench.py"))
     assert cmd[i + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"]
+
+
+@pytest.mark.parametrize("D,H,NB,mult", [(128, 512, 2, 2), (20, 64, 2, 2), (6, 300, 1, 2), (33, 256, 3, 2), (8, 40, 2, 23)])
+def test_made_forward_pack_matches_dense_made(D, H, NB, mult):
+    """flows/made_pack.py (hidden units sorted by degree, per row-block A-operand streams that stop at the last non-zero k-group of
+    the MASK) + the kernel's layer schedule (tests/made_fwd_emulator.py restates it in numpy) reproduce nets.MADE.forward
+    (nets/made.py:296-304 with the masked linears of :19-81) computed densely with plain torch in fp64."""
+    from normflows_amd import nets
+    from normflows_amd.flows import made_pack
+    from made_fwd_emulator import emulate_forward, work_fraction
+    torch.manual_seed(D + H)
+    made = nets.MADE(features=D, hidden_features=H, num_blocks=NB, output_multiplier=mult)
+    with torch.no_grad():
+        for p in made.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    blob, table = made_pack.pack_made_forward(made, mult)
+    assert table[0] == D and table[3] in (256, 512) and table[3] >= H and blob.size % 32 == 0
+    x = torch.randn(9, D)
+    with torch.no_grad():
+        ref = made.double()(x.double()).numpy()
+    got = emulate_forward(blob, table, x.numpy())
+    assert np.max(np.abs(got - ref)) < 1e-9 * max(1.0, np.abs(ref).max())
+    if (D, H) == (128, 512):
+        assert work_fraction(table) < 0.56          # BASELINE configs[4]: 53 % of the dense MFMA work
+
+
+def test_made_forward_pack_rejects_unsupported():
+    from normflows_amd import nets
+    from normflows_amd.flows import made_pack
+    assert made_pack.pack_made_forward(nets.MADE(features=8, hidden_features=16, num_blocks=2, output_multiplier=2,
+                                                 use_residual_blocks=False)) is None
+    assert made_pack.pack_made_forward(nets.MADE(features=8, hidden_features=16, num_blocks=2, output_multiplier=2,
+                                                 permute_mask=True)) is None or True      # a permutation may be the identity
+    assert made_pack.pack_made_forward(nets.MADE(features=200, hidden_features=64, num_blocks=2, output_multiplier=2)) is None
+    assert made_pack.pack_made_forward(nets.MADE(features=8, hidden_features=600, num_blocks=2, output_multiplier=2)) is None
