@@ -16,9 +16,12 @@
 //     {w, 7 - w}, the first for sample block 0, the second for sample block 1.  With the units sorted by degree row-block rb needs
 //     the k-groups [0, nkg(rb)), nkg ~ 4 (rb + 1): the pairing gives every wave the same number of MFMAs (68 k-groups per hidden
 //     layer at config 5), so the waves meet at the layer boundaries without waiting.
-//   * weights: every row-block has ONE contiguous stream of A fragments (1 KB per k-group, lane = its own 16 bytes) that only its
-//     owner reads: plain global loads into a PF-deep register ring, no LDS, no barrier inside a layer.  No LDS-DMA anywhere in this
-//     kernel, so the compiler's own counted vmcnt waits are exact.
+//   * weights: every WAVE walks one contiguous stream for the whole network (its items in consumption order; per item a bias group
+//     of 4 KB, then 1 KB per k-group, lane = its own 16 bytes) through an 8-entry register ring of plain global loads that is
+//     requested 8 entries (8 KB) ahead of the MFMAs -- across item, layer and TILE boundaries
+//     (the stream ends with a copy of its first 8 entries; the workgroups are persistent over the 64-row tiles): no LDS, no barrier
+//     and no start-up bubble for the weights anywhere.  No LDS-DMA in this kernel, so the compiler's own counted vmcnt waits are
+//     exact.
 //   * two LDS-only barriers per layer boundary (all reads of the old activations done | new ones published).
 //   * x tile: 64 rows x Dp features in the same B-operand order (32 KB): B operand of the initial layer and the x of the affine
 //     epilogue, which overwrites it in place with z = scale x + shift; the tile leaves with 16-byte stores.
@@ -29,54 +32,112 @@
 
 namespace nf {
 
-constexpr int MF_ROWS = 64;       // rows per workgroup
+constexpr int MF_ROWS = 64;       // rows per workgroup and tile
 constexpr int MF_NW = 8;          // waves per workgroup: two per SIMD
-constexpr int MF_PF = 8;          // k-groups of A in flight per wave (8 KB; 8 x 512 cycles of MFMA issue per wave at NSB = 2)
 constexpr int MF_HDR = 32;
 constexpr int MF_XFLOATS = 16 * 2 * 64 * 4;      // x tile: Dp <= 128 features
 
 #define MF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-// LDS-only barrier: the A ring's global loads stay in flight across it (a __syncthreads() fence would drain them)
+// LDS-only barrier: the weight ring's global loads stay in flight across it (a __syncthreads() fence would drain them)
 #define MF_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-// acc[sb] (+)= W[32 rows][8 nkg] . act[8 nkg][32 samples of block sb]; Ag: the row-block's stream + 4 lane; Bl: LDS activations
-// + the lane's offset (4 (64 hh + n [+ 32 sb])).  The packer pads the blob by MF_PF k-groups, so the ring may read past the stream.
-template <int NS>
-__device__ __forceinline__ void mf_item(const float *__restrict__ Ag, int nkg, const float *Bl, f32x16 (&acc)[NS]) {
-    f32x4 a[MF_PF];
+// The wave's weight stream: ring entry j holds stream entry (position of a[0]) + j at every item start; an entry is consumed from
+// its register and re-requested 8 entries ahead.  `ap` = the current item's first entry + 4 lane.
+struct MfRing {
+    f32x4 a[8];
+    const float *ap;
+};
+
+__device__ __forceinline__ void mf_ring_start(MfRing &r, const float *stream, int lane) {
+    r.ap = stream + lane * 4;
 #pragma unroll
-    for (int j = 0; j < MF_PF; ++j) a[j] = *reinterpret_cast<const f32x4 *>(Ag + j * 256);
-    for (int kg = 0; kg < nkg; kg += MF_PF) {
+    for (int j = 0; j < 8; ++j) r.a[j] = *reinterpret_cast<const f32x4 *>(r.ap + j * 256);
+}
+
+// four k-groups: ring entries HALF .. HALF + 3 = stream entries e0 .. e0 + 3 of the item; acc[sb] += W[32 x 32] . act[32 x 32 samples].
+// MF_SCHED (ablation switch, tools/build_variant.py; measured in ONE gpurun call at config 5's layer, B = 65 536):
+//   0 = the compiler's own schedule (default, 0.721 ms): hipcc sinks the eight re-requests of a loop iteration to its end and waits
+//       for the first of them at the top of the next one -- which turns the two waves of a SIMD into a ping-pong: one issues its 64
+//       MFMAs (4096 cycles) while the other's eight requests (one L2 round trip) are in flight;
+//   1 = every entry's re-request pinned right behind the MFMAs that consumed it (__builtin_amdgcn_sched_barrier): 0.772 ms -- the
+//       scheduling barriers also pin each k-group's LDS reads right in front of its MFMAs;
+//   2 = 1 + the B operand software-pipelined one k-group ahead (b = this k-group's values on entry, the next group's on exit;
+//       bp = the NEXT k-group's address, clamped to `blast`): 0.745 ms.
+#ifndef MF_SCHED
+#define MF_SCHED 0
+#endif
+template <int NS, int HALF>
+__device__ __forceinline__ void mf_group(MfRing &r, int e0, const float *&bp, const float *blast, f32x4 (&b)[2], f32x16 (&acc)[NS]) {
 #pragma unroll
-        for (int j = 0; j < MF_PF; ++j) {
-            if (kg + j < nkg) {
-                const float *bp = Bl + (size_t)(kg + j) * 512;
-                const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bp);
-                f32x4 b1 = b0;
-                if constexpr (NS == 2) b1 = *reinterpret_cast<const f32x4 *>(bp + 128);
-                const f32x4 av = a[j];
-                a[j] = *reinterpret_cast<const f32x4 *>(Ag + (size_t)(kg + j + MF_PF) * 256);
+    for (int j = 0; j < 4; ++j) {
+        f32x4 bn[2];
+        bn[0] = *reinterpret_cast<const f32x4 *>(bp);
+        if constexpr (NS == 2) bn[1] = *reinterpret_cast<const f32x4 *>(bp + 128);
+        if constexpr (MF_SCHED == 2) {
+            bp = bp + 512 < blast ? bp + 512 : blast;
+            __builtin_amdgcn_sched_barrier(0);       // (the reads go out IN FRONT of this k-group's MFMAs, not behind them)
+        } else {
+            bp += 512;
+            b[0] = bn[0];
+            if constexpr (NS == 2) b[1] = bn[1];
+        }
+        const f32x4 av = r.a[HALF + j];
+        if constexpr (MF_SCHED == 0) r.a[HALF + j] = *reinterpret_cast<const f32x4 *>(r.ap + (size_t)(e0 + j + 8) * 256);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    acc[0] = MF_MFMA(av[i], b0[i], acc[0]);
-                    if constexpr (NS == 2) acc[1] = MF_MFMA(av[i], b1[i], acc[1]);
-                }
-            }
+        for (int i = 0; i < 4; ++i) {
+            acc[0] = MF_MFMA(av[i], b[0][i], acc[0]);
+            if constexpr (NS == 2) acc[1] = MF_MFMA(av[i], b[1][i], acc[1]);
+        }
+        if constexpr (MF_SCHED != 0) {
+            r.a[HALF + j] = *reinterpret_cast<const f32x4 *>(r.ap + (size_t)(e0 + j + 8) * 256);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (MF_SCHED == 2) {
+            b[0] = bn[0];
+            if constexpr (NS == 2) b[1] = bn[1];
         }
     }
 }
 
-// bias of row-block: rows 8 q + 4 hh + i  ->  register 4 q + i
+// One work item: acc = (ADD ? acc : 0) + bias + W[32 rows][8 nkg] . act[8 nkg][32-sample blocks]; Bl = LDS activations + the lane's
+// offset 4 (64 hh + n [+ 32 sb]).  nkg is a multiple of 4 (packer).
 template <int NS, bool ADD>
-__device__ __forceinline__ void mf_bias(const float *__restrict__ bias, int hh, f32x16 (&acc)[NS]) {
+__device__ __forceinline__ void mf_item(MfRing &r, int nkg, const float *Bl, f32x16 (&acc)[NS]) {
+    f32x4 b[2];
+    const float *blast = Bl + (size_t)(nkg > 0 ? nkg - 1 : 0) * 512;
+    const float *bp = Bl;
+    if constexpr (MF_SCHED == 2) {
+        b[0] = *reinterpret_cast<const f32x4 *>(Bl);
+        if constexpr (NS == 2) b[1] = *reinterpret_cast<const f32x4 *>(Bl + 128);
+        bp = nkg > 1 ? Bl + 512 : Bl;
+    }
+    // bias group = ring entries 0..3: entry q holds bias[8 q + 4 hh + 0..3] = accumulator registers 4 q + i
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + 8 * q + 4 * hh);
+        const f32x4 bq = r.a[q];
+        r.a[q] = *reinterpret_cast<const f32x4 *>(r.ap + (size_t)(q + 8) * 256);
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[s][4 * q + i] = ADD ? acc[s][4 * q + i] + b[i] : b[i];
+            for (int i = 0; i < 4; ++i) acc[s][4 * q + i] = ADD ? acc[s][4 * q + i] + bq[i] : bq[i];
     }
+    if constexpr (MF_SCHED != 0) __builtin_amdgcn_sched_barrier(0);
+    int kg = 0;
+    for (; kg + 8 <= nkg; kg += 8) {
+        mf_group<NS, 4>(r, 4 + kg, bp, blast, b, acc);
+        mf_group<NS, 0>(r, 8 + kg, bp, blast, b, acc);
+    }
+    if (kg < nkg) {          // an odd number of A groups: bias + A groups is even, the next item starts in ring half 0
+        mf_group<NS, 4>(r, 4 + kg, bp, blast, b, acc);
+    } else {                 // the next item's first entries sit in ring half 1: swap the halves
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 tmp = r.a[j];
+            r.a[j] = r.a[4 + j];
+            r.a[4 + j] = tmp;
+        }
+    }
+    r.ap += (size_t)(4 + nkg) * 256;
 }
 
 // publish the row-block's values (ReLU'd or raw) as the next layer's B operand: act[(4 rb + q)][hh][32 sb + n][4]
@@ -106,154 +167,140 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
     float *xreg = lds + (size_t)HRB * 4 * 512;          // [Dp / 8][2][64][4]
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int D = table[0], Dp = table[1], NB = table[5], mult = table[6], NFB = table[7];
-    const int64_t row0 = (int64_t)blockIdx.x * MF_ROWS;
-    const int nrows = (int)((B - row0) < MF_ROWS ? (B - row0) : MF_ROWS);
-
-    // ---- x tile -> LDS (B-operand order; rows beyond the batch and features beyond D are zero) -------------------------------------
-    {
-        const int r = tid & 63, cg = tid >> 6;
-        const float *xr = x + (row0 + r) * D;
-        for (int c = cg; c < Dp / 4; c += MF_NW) {
-            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (r < nrows && 4 * c < D) {           // (Dp rounds D up to 8: the last chunk may lie wholly beyond the row)
-                if ((D & 3) == 0) v = *reinterpret_cast<const f32x4 *>(xr + 4 * c);
-                else
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) if (4 * c + i < D) v[i] = xr[4 * c + i];
-            }
-            *reinterpret_cast<f32x4 *>(xreg + ((size_t)c * 64 + r) * 4) = v;
-        }
-    }
-    // work items of this wave: slot 0 / 1 -> hidden row-block, first sample block
-    const int rbs[2] = {w, HRB - 1 - w};
+    const int D = table[0], Dp = table[1], NB = table[5], mult = table[6], NFB = table[7], nrounds = table[8], nitems = table[10];
+    const int *items = table + MF_HDR + w * nitems * 2;       // [nitems][nkg, rb]
+    const float *stream = blob + table[16 + w];
+    const int rbs[2] = {w, HRB - 1 - w};                      // (the packer's wave_items: the hidden row-blocks of this wave)
     const int sb0s[2] = {0, NSB == 2 ? 0 : 1};
     const int lane_b = (64 * hh + n) * 4;       // the lane's offset inside a k-group of activations (sample block 0)
-    f32x16 h[2][NS], t[2][NS];
-    MF_BARRIER();
+    const int64_t ntiles = (B + MF_ROWS - 1) / MF_ROWS;
+    MfRing ring;
+    mf_ring_start(ring, stream, lane);
 
-    // ---- initial layer: h = b0 + W0 x --------------------------------------------------------------------------------------------------
-    {
-        const int *dir = table + table[16];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int rb = rbs[s];
-            mf_bias<NS, false>(blob + dir[4 * rb + 2], hh, h[s]);
-            mf_item<NS>(blob + dir[4 * rb] + lane * 4, dir[4 * rb + 1], xreg + lane_b + 128 * sb0s[s], h[s]);
-        }
-    }
-    // ---- residual blocks (nets/made.py:196-214): t = b1 + W1 relu(h);  h += b2 + W2 relu(t) -----------------------------------
-    for (int b = 0; b < NB; ++b) {
-        MF_BARRIER();        // (b > 0: every wave has finished reading relu(t) of the previous block)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) mf_publish<NS, true>(acts, rbs[s], sb0s[s], hh, n, h[s]);
-        MF_BARRIER();
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * MF_ROWS;
+        const int nrows = (int)((B - row0) < MF_ROWS ? (B - row0) : MF_ROWS);
+        ring.ap = stream + lane * 4;            // (the ring already holds the stream's first entries: the wrap-around copy)
+        // ---- x tile -> LDS (B-operand order; rows beyond the batch and features beyond D are zero) ---------------------------------
         {
-            const int *dir = table + table[16 + 1 + 2 * b];
+            const int r = tid & 63, cg = tid >> 6;
+            const float *xr = x + (row0 + r) * D;
+            for (int c = cg; c < Dp / 4; c += MF_NW) {
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (r < nrows && 4 * c < D) {           // (Dp rounds D up to 32: the last chunks may lie wholly beyond the row)
+                    if ((D & 3) == 0) v = *reinterpret_cast<const f32x4 *>(xr + 4 * c);
+                    else
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int rb = rbs[s];
-                mf_bias<NS, false>(blob + dir[4 * rb + 2], hh, t[s]);
-                mf_item<NS>(blob + dir[4 * rb] + lane * 4, dir[4 * rb + 1], acts + lane_b + 128 * sb0s[s], t[s]);
+                        for (int i = 0; i < 4; ++i) if (4 * c + i < D) v[i] = xr[4 * c + i];
+                }
+                *reinterpret_cast<f32x4 *>(xreg + ((size_t)c * 64 + r) * 4) = v;
             }
         }
+        f32x16 h[2][NS], t[2][NS];
+        MF_BARRIER();
+        // ---- initial layer: h = b0 + W0 x ----------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int s = 0; s < 2; ++s) mf_item<NS, false>(ring, items[2 * s], xreg + lane_b + 128 * sb0s[s], h[s]);
+        // ---- residual blocks (nets/made.py:196-214): t = b1 + W1 relu(h);  h += b2 + W2 relu(t) -------------------------------
+        for (int b = 0; b < NB; ++b) {
+            MF_BARRIER();        // (b > 0: every wave has finished reading relu(t) of the previous block)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) mf_publish<NS, true>(acts, rbs[s], sb0s[s], hh, n, h[s]);
+            MF_BARRIER();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) mf_item<NS, false>(ring, items[2 * (2 + 4 * b + s)], acts + lane_b + 128 * sb0s[s], t[s]);
+            MF_BARRIER();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) mf_publish<NS, true>(acts, rbs[s], sb0s[s], hh, n, t[s]);
+            MF_BARRIER();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) mf_item<NS, true>(ring, items[2 * (4 + 4 * b + s)], acts + lane_b + 128 * sb0s[s], h[s]);
+        }
+        // ---- final layer on the RAW block output (:303-304) + epilogue -------------------------------------------------------------
         MF_BARRIER();
 #pragma unroll
-        for (int s = 0; s < 2; ++s) mf_publish<NS, true>(acts, rbs[s], sb0s[s], hh, n, t[s]);
+        for (int s = 0; s < 2; ++s) mf_publish<NS, false>(acts, rbs[s], sb0s[s], hh, n, h[s]);
         MF_BARRIER();
-        {
-            const int *dir = table + table[16 + 2 + 2 * b];
+        float ldsum[2] = {0.0f, 0.0f};
+        for (int rd = 0; rd < nrounds; ++rd) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const int rb = rbs[s];
-                mf_bias<NS, true>(blob + dir[4 * rb + 2], hh, h[s]);
-                mf_item<NS>(blob + dir[4 * rb] + lane * 4, dir[4 * rb + 1], acts + lane_b + 128 * sb0s[s], h[s]);
-            }
-        }
-    }
-    // ---- final layer on the RAW block output (:303-304) + epilogue -----------------------------------------------------------------
-    MF_BARRIER();
-#pragma unroll
-    for (int s = 0; s < 2; ++s) mf_publish<NS, false>(acts, rbs[s], sb0s[s], hh, n, h[s]);
-    MF_BARRIER();
-    const int *dirf = table + table[16 + 1 + 2 * NB];
-    float ldsum[2] = {0.0f, 0.0f};
-    for (int fb0 = 0; fb0 < NFB; fb0 += 8) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int fb = fb0 + (s == 0 ? w : 7 - w);       // sample block s
-            if (fb < NFB) {
-                f32x16 o[1];
-                mf_bias<1, false>(blob + dirf[4 * fb + 2], hh, o);
-                mf_item<1>(blob + dirf[4 * fb] + lane * 4, dirf[4 * fb + 1], acts + lane_b + 128 * s, o);
-                if constexpr (EPI == 0) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int f0 = 16 * fb + 4 * q + 2 * hh;
-                        float *xp = xreg + ((size_t)((2 * fb + (q >> 1)) * 2 + (q & 1)) * 64 + 32 * s + n) * 4 + 2 * hh;
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            if (f0 + e < D) {
-                                const float scale = 1.0f / (1.0f + __expf(-(o[0][4 * q + 2 * e] + 2.0f))) + 1e-3f;
-                                xp[e] = scale * xp[e] + o[0][4 * q + 2 * e + 1];
-                                ldsum[s] += __logf(scale);
-                            }
-                        }
-                    }
-                } else {
-                    const int64_t r = row0 + 32 * s + n;
-                    if (32 * s + n < nrows) {
-                        float *yp = y + r * ((int64_t)mult * D) + 32 * fb + 4 * hh;
+                const int *it = items + 2 * (2 + 4 * NB + 2 * rd + s);
+                const int fb = it[1];                         // sample block s
+                if (fb >= 0) {
+                    f32x16 o[1];
+                    mf_item<1, false>(ring, it[0], acts + lane_b + 128 * s, o);
+                    if constexpr (EPI == 0) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const int c = 32 * fb + 8 * q + 4 * hh;
-                            if (((mult * D) & 3) == 0) {
-                                if (c < mult * D) *reinterpret_cast<f32x4 *>(yp + 8 * q) = f32x4{o[0][4 * q], o[0][4 * q + 1], o[0][4 * q + 2], o[0][4 * q + 3]};
-                            } else {
+                            const int f0 = 16 * fb + 4 * q + 2 * hh;
+                            float *xp = xreg + ((size_t)((2 * fb + (q >> 1)) * 2 + (q & 1)) * 64 + 32 * s + n) * 4 + 2 * hh;
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) if (c + i < mult * D) yp[8 * q + i] = o[0][4 * q + i];
+                            for (int e = 0; e < 2; ++e) {
+                                if (f0 + e < D) {
+                                    const float scale = 1.0f / (1.0f + __expf(-(o[0][4 * q + 2 * e] + 2.0f))) + 1e-3f;
+                                    xp[e] = scale * xp[e] + o[0][4 * q + 2 * e + 1];
+                                    ldsum[s] += __logf(scale);
+                                }
+                            }
+                        }
+                    } else {
+                        const int64_t r = row0 + 32 * s + n;
+                        if (32 * s + n < nrows) {
+                            float *yp = y + r * ((int64_t)mult * D) + 32 * fb + 4 * hh;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int c = 32 * fb + 8 * q + 4 * hh;
+                                if (((mult * D) & 3) == 0) {
+                                    if (c < mult * D) *reinterpret_cast<f32x4 *>(yp + 8 * q) = f32x4{o[0][4 * q], o[0][4 * q + 1], o[0][4 * q + 2], o[0][4 * q + 3]};
+                                } else {
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) if (c + i < mult * D) yp[8 * q + i] = o[0][4 * q + i];
+                                }
                             }
                         }
                     }
                 }
             }
         }
-    }
-    if constexpr (EPI == 0) {
-        // per-sample log-det: the lane-halves' sums, then the 8 row-blocks' in a FIXED order (deterministic)
-        MF_BARRIER();                      // every wave is done with the activations: their region now holds the partial sums
+        MF_BARRIER();                          // every wave is done with the activations (and, EPI 0, has written its z values)
+        if constexpr (EPI == 0) {
+            // per-sample log-det: the lane-halves' sums, then the 8 row-blocks' in a FIXED order (deterministic)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const float v = ldsum[s] + __shfl_xor(ldsum[s], 32);
-            const int fb = (s == 0 ? w : 7 - w);
-            if (hh == 0) acts[fb * 64 + 32 * s + n] = v;
-        }
-        MF_BARRIER();
-        if (tid < nrows) {
-            float v = 0.0f;
-            for (int fb = 0; fb < 8; ++fb) v += acts[fb * 64 + tid];
-            ld_store(logdet + row0 + tid, v, acc_mode);
-        }
-        const int r = tid & 63, cg = tid >> 6;
-        float *yr = y + (row0 + r) * D;
-        if (r < nrows)
-            for (int c = cg; 4 * c < D; c += MF_NW) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(xreg + ((size_t)c * 64 + r) * 4);
-                if ((D & 3) == 0) *reinterpret_cast<f32x4 *>(yr + 4 * c) = v;
-                else
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) if (4 * c + i < D) yr[4 * c + i] = v[i];
+            for (int s = 0; s < 2; ++s) {
+                const float v = ldsum[s] + __shfl_xor(ldsum[s], 32);
+                const int fb = (s == 0 ? w : 7 - w);
+                if (hh == 0) acts[fb * 64 + 32 * s + n] = v;
             }
+            MF_BARRIER();
+            if (tid < nrows) {
+                float v = 0.0f;
+                for (int fb = 0; fb < 8; ++fb) v += acts[fb * 64 + tid];
+                ld_store(logdet + row0 + tid, v, acc_mode);
+            }
+            const int r = tid & 63, cg = tid >> 6;
+            float *yr = y + (row0 + r) * D;
+            if (r < nrows)
+                for (int c = cg; 4 * c < D; c += MF_NW) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(xreg + ((size_t)c * 64 + r) * 4);
+                    if ((D & 3) == 0) *reinterpret_cast<f32x4 *>(yr + 4 * c) = v;
+                    else
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (4 * c + i < D) yr[4 * c + i] = v[i];
+                }
+            MF_BARRIER();                      // the next tile overwrites the x tile and the activations
+        }
     }
 }
 
 template <int NSB, int EPI>
 static int made_fwd_launch(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, int64_t B, int acc, hipStream_t st) {
     const int64_t ntiles = (B + MF_ROWS - 1) / MF_ROWS;
+    const int grid = (int)(ntiles < 256 ? ntiles : 256);        // persistent: one workgroup per CU (160 KB of LDS at Hp = 512)
     const size_t lds = sizeof(float) * ((size_t)8 * NSB * 4 * 512 + MF_XFLOATS);
     static LdsOptIn opted;
     if (opt_in_lds(reinterpret_cast<const void *>(&made_fwd_kernel<NSB, EPI>), lds, opted) != NF_OK) return NF_ENOTSUP;
-    hipLaunchKernelGGL((made_fwd_kernel<NSB, EPI>), dim3((unsigned)ntiles), dim3(64 * MF_NW), lds, st, (const float *)x, (float *)y,
+    hipLaunchKernelGGL((made_fwd_kernel<NSB, EPI>), dim3((unsigned)grid), dim3(64 * MF_NW), lds, st, (const float *)x, (float *)y,
                        (float *)logdet, (const float *)blob, (const int *)table, B, acc);
     NF_CHECK_LAUNCH();
     return NF_OK;

@@ -7,16 +7,19 @@ degree <= m (:63-81) -- so about half of the 32 x 8 weight blocks are structural
 
 This module only rearranges weights (no arithmetic on data).  The kernel's geometry (made_fwd.hip):
   * hidden slots = units sorted by degree (stable), zero-padded to Hp = 256 or 512; row-block rb = slots [32 rb, 32 rb + 32);
-  * a k-group kg = 8 consecutive inputs (features for the initial layer, hidden slots otherwise);
-  * per layer and row-block ONE contiguous stream of MFMA A-operand fragments [nkg][64 lanes][4]: lane (hh = lane >> 5,
-    m = lane & 31) holds W[32 rb + m][8 kg + 4 hh + 0..3] (v_mfma_f32_32x32x2_f32: A[m][k = hh], four k-steps per 16-byte load);
-    nkg = 1 + the last k-group in which the MASK of the row-block has a non-zero (a prefix, by the sorting).
+  * a k-group kg = 8 consecutive inputs (features for the initial layer, hidden slots otherwise); features padded to Dp (x 32);
+  * a work item = one row-block of one layer: a BIAS group (4 KB: entry q, every lane of half hh = bias[32 rb + 8 q + 4 hh + 0..3])
+    followed by nkg A-operand fragments of 1 KB: lane (hh = lane >> 5, m = lane & 31) holds W[32 rb + m][8 kg + 4 hh + 0..3]
+    (v_mfma_f32_32x32x2_f32: A[m][k = hh], four k-steps per 16-byte load); nkg = the last k-group in which the MASK of the
+    row-block has a non-zero, + 1, rounded up to 4 (a prefix, by the sorting);
+  * each of the kernel's 8 waves walks ONE contiguous stream: its items in consumption order -- per producing layer (initial,
+    the residual blocks' linears) the row-blocks {w, HRB - 1 - w} (HRB = Hp / 32: equal work per wave, see work_per_wave), per
+    round r of the final layer the row-blocks {8 r + w, 8 r + 7 - w} -- followed by a copy of its first RING entries, so that the
+    register ring that reads RING entries ahead wraps into the next 64-row tile without a bubble.
 
-float blob  : per layer, per row-block: its A stream; then the layer's bias in slot order (32 floats per row-block); RING KB of zeros
-              at the end (the A ring reads ahead of the stream it is consuming).
-int32 table : hdr[32] = [D, Dp, H, Hp, NSB, NB, mult, NFB, nlayers, total blob floats, 0..] + hdr[16 + l] = offset (ints) of layer
-              l's directory; directory entry of a row-block = [a_off, nkg, bias_off, 0] (offsets in floats).
-Layers: 0 = initial (inputs = features), 1 .. 2 NB = the residual blocks' linears, 2 NB + 1 = final (rows mult f + p, natural order).
+float blob  : the 8 streams.
+int32 table : hdr[32] = [D, Dp, H, Hp, NSB, NB, mult, NFB, nrounds, total blob floats, nitems, 0..], hdr[16 + w] = offset (floats) of
+              wave w's stream; then per wave nitems entries [nkg, rb] (rb = -1: no such row-block, nkg = 0, no bias group either).
 """
 import numpy as np
 import torch
@@ -56,6 +59,27 @@ def a_stream(w_block):
     return np.ascontiguousarray(w_block.reshape(ROWS, K // KG, 2, 4).transpose(1, 2, 0, 3)).reshape(-1)
 
 
+def bias_group(b32):
+    """32 biases of a row-block -> [4 q][2 hh][32 m][4]: entry q, lane (hh, m) = b[8 q + 4 hh + 0..3] (accumulator register 4 q + i)."""
+    return np.ascontiguousarray(np.broadcast_to(b32.reshape(4, 2, 1, 4), (4, 2, ROWS, 4))).reshape(-1)
+
+
+def wave_items(NSB, NB, NFB):
+    """Row-blocks of wave w in consumption order: [(layer, rb or -1), ...] (layer 2 NB + 1 = final)."""
+    HRB = 8 * NSB
+    nrounds = (NFB + 7) // 8
+    out = []
+    for w in range(8):
+        it = []
+        for l in range(1 + 2 * NB):
+            it += [(l, w), (l, HRB - 1 - w)]
+        for r in range(nrounds):
+            for fb in (8 * r + w, 8 * r + 7 - w):
+                it.append((2 * NB + 1, fb if fb < NFB else -1))
+        out.append(it)
+    return out
+
+
 def pack_made_forward(made, mult=2):
     """(blob float32 ndarray, table int32 ndarray) or None when the MADE is outside the kernel's structure (then the caller
     keeps the layer-by-layer path)."""
@@ -80,13 +104,13 @@ def pack_made_forward(made, mult=2):
         return None
     Hp = 256 if H <= 256 else 512
     NSB = Hp // 256
-    Dp = (D + KG - 1) // KG * KG
+    Dp = (D + 31) // 32 * 32
     NFB = (mult * D + ROWS - 1) // ROWS
     order = np.argsort(hid_deg, kind="stable")            # slot i holds unit order[i]
     slot_of = np.zeros(H, dtype=np.int64)
     slot_of[order] = np.arange(H)
 
-    def slots(lyr, in_map, in_size, out_rows=None, out_size=None):
+    def slots(lyr, in_map, in_size, out_rows, out_size):
         """Masked weight, mask and bias of `lyr` in slot space (rows -> out_rows, columns -> in_map)."""
         w = (lyr.weight.detach() * lyr.mask).cpu().numpy().astype(np.float32)
         m = lyr.mask.cpu().numpy() != 0
@@ -107,35 +131,34 @@ def pack_made_forward(made, mult=2):
     for l in lin[1:]:
         layers.append(slots(l, slot_of, Hp, slot_of, Hp))
     layers.append(slots(fin, slot_of, Hp, np.arange(mult * D), NFB * ROWS))
-    nlayers = len(layers)
 
-    table = [np.zeros(HDR, dtype=np.int32)]
+    items = wave_items(NSB, NB, NFB)
+    nitems = len(items[0])
+    hdr = np.zeros(HDR, dtype=np.int32)
+    tab = np.zeros((8, nitems, 2), dtype=np.int32)
     chunks = []
     off = 0
-    toff = HDR
-    for l, (W, M, Bv) in enumerate(layers):
-        nrb = W.shape[0] // ROWS
-        d = np.zeros((nrb, 4), dtype=np.int32)
-        for rb in range(nrb):
+    for w in range(8):
+        hdr[16 + w] = off
+        stream = []
+        for i, (l, rb) in enumerate(items[w]):
+            if rb < 0:
+                tab[w, i] = (0, -1)
+                continue
+            W, M, Bv = layers[l]
             r0 = rb * ROWS
             cols = np.nonzero(M[r0:r0 + ROWS].any(axis=0))[0]
-            nkg = 0 if cols.size == 0 else int(cols.max()) // KG + 1
-            d[rb, 0], d[rb, 1] = off, nkg
+            nkg = 0 if cols.size == 0 else (int(cols.max()) // KG + 4) // 4 * 4        # + 1, rounded up to 4
+            assert KG * nkg <= W.shape[1]
+            tab[w, i] = (nkg, rb)
+            stream.append(bias_group(Bv[r0:r0 + ROWS]))
             if nkg:
-                a = a_stream(W[r0:r0 + ROWS, :KG * nkg])
-                chunks.append(a)
-                off += a.size
-        for rb in range(nrb):
-            d[rb, 2] = off + rb * ROWS
-        chunks.append(Bv)
-        off += Bv.size
-        table[0][16 + l] = toff
-        table.append(d.reshape(-1))
-        toff += d.size
-    pad = np.zeros(RING * 256, dtype=np.float32)           # the kernel's A ring reads up to RING k-groups past a stream
-    chunks.append(pad)
-    off += pad.size
-    table[0][:10] = [D, Dp, H, Hp, NSB, NB, mult, NFB, nlayers, off]
+                stream.append(a_stream(W[r0:r0 + ROWS, :KG * nkg]))
+        stream = np.concatenate(stream)
+        stream = np.concatenate([stream, np.resize(stream, RING * 256)])      # the ring wraps into the next tile
+        chunks.append(stream)
+        off += stream.size
+    hdr[:11] = [D, Dp, H, Hp, NSB, NB, mult, NFB, (NFB + 7) // 8, off, nitems]
     blob = np.concatenate(chunks).astype(np.float32)
     assert blob.size == off and off < 2 ** 31
-    return blob, np.concatenate(table).astype(np.int32)
+    return blob, np.concatenate([hdr, tab.reshape(-1)]).astype(np.int32)

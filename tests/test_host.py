@@ -651,7 +651,7 @@ def test_made_forward_pack_matches_dense_made(D, H, NB, mult):
     (nets/made.py:296-304 with the masked linears of :19-81) computed densely with plain torch in fp64."""
     from normflows_amd import nets
     from normflows_amd.flows import made_pack
-    from made_fwd_emulator import emulate_forward, work_fraction
+    from made_fwd_emulator import emulate_forward, work_fraction, work_per_wave
     torch.manual_seed(D + H)
     made = nets.MADE(features=D, hidden_features=H, num_blocks=NB, output_multiplier=mult)
     with torch.no_grad():
@@ -665,7 +665,9 @@ def test_made_forward_pack_matches_dense_made(D, H, NB, mult):
     got = emulate_forward(blob, table, x.numpy())
     assert np.max(np.abs(got - ref)) < 1e-9 * max(1.0, np.abs(ref).max())
     if (D, H) == (128, 512):
-        assert work_fraction(table) < 0.56          # BASELINE configs[4]: 53 % of the dense MFMA work
+        assert work_fraction(table) < 0.56          # BASELINE configs[4]: 54 % of the dense MFMA work ...
+        wpw = work_per_wave(table)
+        assert wpw.max() == wpw.min()               # ... and every wave of the workgroup gets the same share of it
 
 
 def test_made_forward_pack_rejects_unsupported():
