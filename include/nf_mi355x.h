@@ -469,6 +469,24 @@ int nf_maf_affine(const void *x, const void *params, void *y, void *logdet, int6
                   int dtype, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * CoupledRationalQuadraticSpline in ONE launch for the shapes beyond nf_rqs_fused's (D <= 64, hidden <= 128): up to 128 features,
+ * up to 512 hidden units, 8 bins, linear tails, float32.  Replaces normflows/flows/neural_spline/wrapper.py:79-85 ->
+ * nsf/coupling.py:71-128 (split, conditioner, coupling transform, unconditional transform, merge; the direction-dependent order),
+ * :150-164, :221-253, :329-362 (parameter rows, the 1/sqrt(hidden) scaling, the batch-shared spline), nets/resnet.py:37-50, 92-104
+ * (the ResidualNet conditioner) and utils/splines.py:16-219 (the spline itself); the conditioner output never exists in memory.
+ *   blob, table : device copies of the host packer's arrays (normflows_amd/flows/nsf_wide_pack.py; table[3] = hidden_padded).
+ *   tabs        : (n_identity, 27) knot tables of the batch-shared spline, written by nf_nsf_wide_tables from the raw
+ *                 unnormalized_widths (n_identity, 8), unnormalized_heights (n_identity, 8), unnormalized_derivatives (n_identity, 7).
+ *   direction 0 : density direction (wrapper.inverse = prqct.forward); 1: sampling direction (wrapper.forward = prqct.inverse).
+ *   x, y (B, D); logdet (B) combined according to `acc`.  -EINVAL for min_bin_width * 8 > 1 (utils/splines.py:121-124).
+ */
+int nf_nsf_wide_tables(const void *uw, const void *uh, const void *ud, void *tabs, int n_identity, int K, double tail_bound,
+                       double min_bin_width, double min_bin_height, double min_derivative, nf_stream_t stream);
+int nf_nsf_wide(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, const void *tabs, int64_t B, int D,
+                int hidden_padded, int direction, int acc, double tail_bound, double min_bin_width, double min_bin_height,
+                double min_derivative, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * MADE in ONE launch -- the single-pass direction of the autoregressive flows.  Replaces
  * normflows/nets/made.py:296-304 (MADE.forward: initial MaskedLinear, MaskedResidualBlocks :196-214, final MaskedLinear; every
  * linear is F.linear(x, weight * mask, bias), :80-81) and, for nf_made_forward_affine, also

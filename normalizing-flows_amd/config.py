@@ -124,3 +124,13 @@ made_fused = True
 def set_made_fused(mode=True):
     global made_fused
     made_fused = bool(mode)
+
+
+# CoupledRationalQuadraticSpline beyond the benchmark kernel's shapes (D <= 128, hidden <= 512, 8 bins) as ONE launch (nf_nsf_wide,
+# csrc/nsf_wide.hip); False = library GEMMs for the conditioner + nf_rqs_coupling (ablation / differential tests).
+nsf_wide = True
+
+
+def set_nsf_wide(mode=True):
+    global nsf_wide
+    nsf_wide = bool(mode)

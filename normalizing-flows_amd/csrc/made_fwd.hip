@@ -27,132 +27,9 @@
 //     epilogue, which overwrites it in place with z = scale x + shift; the tile leaves with 16-byte stores.
 // Algorithmic work per row: 2 (D H + 2 NB H^2 + H mult D) FLOP dense (2.49 MFLOP at config 5), 1.33 MFLOP masked; HBM: 4 D in,
 // 4 D + 4 out (affine) resp. 4 mult D out (raw parameters).
-#include "common.hpp"
-#include "fused_common.hpp"
+#include "mlp_tile.hpp"
 
 namespace nf {
-
-constexpr int MF_ROWS = 64;       // rows per workgroup and tile
-constexpr int MF_NW = 8;          // waves per workgroup: two per SIMD
-constexpr int MF_HDR = 32;
-constexpr int MF_XFLOATS = 16 * 2 * 64 * 4;      // x tile: Dp <= 128 features
-
-#define MF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-// LDS-only barrier: the weight ring's global loads stay in flight across it (a __syncthreads() fence would drain them)
-#define MF_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
-// The wave's weight stream: ring entry j holds stream entry (position of a[0]) + j at every item start; an entry is consumed from
-// its register and re-requested 8 entries ahead.  `ap` = the current item's first entry + 4 lane.
-struct MfRing {
-    f32x4 a[8];
-    const float *ap;
-};
-
-__device__ __forceinline__ void mf_ring_start(MfRing &r, const float *stream, int lane) {
-    r.ap = stream + lane * 4;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r.a[j] = *reinterpret_cast<const f32x4 *>(r.ap + j * 256);
-}
-
-// four k-groups: ring entries HALF .. HALF + 3 = stream entries e0 .. e0 + 3 of the item; acc[sb] += W[32 x 32] . act[32 x 32 samples].
-// MF_SCHED (ablation switch, tools/build_variant.py; measured in ONE gpurun call at config 5's layer, B = 65 536):
-//   0 = the compiler's own schedule (default, 0.721 ms): hipcc sinks the eight re-requests of a loop iteration to its end and waits
-//       for the first of them at the top of the next one -- which turns the two waves of a SIMD into a ping-pong: one issues its 64
-//       MFMAs (4096 cycles) while the other's eight requests (one L2 round trip) are in flight;
-//   1 = every entry's re-request pinned right behind the MFMAs that consumed it (__builtin_amdgcn_sched_barrier): 0.772 ms -- the
-//       scheduling barriers also pin each k-group's LDS reads right in front of its MFMAs;
-//   2 = 1 + the B operand software-pipelined one k-group ahead (b = this k-group's values on entry, the next group's on exit;
-//       bp = the NEXT k-group's address, clamped to `blast`): 0.745 ms.
-#ifndef MF_SCHED
-#define MF_SCHED 0
-#endif
-template <int NS, int HALF>
-__device__ __forceinline__ void mf_group(MfRing &r, int e0, const float *&bp, const float *blast, f32x4 (&b)[2], f32x16 (&acc)[NS]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        f32x4 bn[2];
-        bn[0] = *reinterpret_cast<const f32x4 *>(bp);
-        if constexpr (NS == 2) bn[1] = *reinterpret_cast<const f32x4 *>(bp + 128);
-        if constexpr (MF_SCHED == 2) {
-            bp = bp + 512 < blast ? bp + 512 : blast;
-            __builtin_amdgcn_sched_barrier(0);       // (the reads go out IN FRONT of this k-group's MFMAs, not behind them)
-        } else {
-            bp += 512;
-            b[0] = bn[0];
-            if constexpr (NS == 2) b[1] = bn[1];
-        }
-        const f32x4 av = r.a[HALF + j];
-        if constexpr (MF_SCHED == 0) r.a[HALF + j] = *reinterpret_cast<const f32x4 *>(r.ap + (size_t)(e0 + j + 8) * 256);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[0] = MF_MFMA(av[i], b[0][i], acc[0]);
-            if constexpr (NS == 2) acc[1] = MF_MFMA(av[i], b[1][i], acc[1]);
-        }
-        if constexpr (MF_SCHED != 0) {
-            r.a[HALF + j] = *reinterpret_cast<const f32x4 *>(r.ap + (size_t)(e0 + j + 8) * 256);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (MF_SCHED == 2) {
-            b[0] = bn[0];
-            if constexpr (NS == 2) b[1] = bn[1];
-        }
-    }
-}
-
-// One work item: acc = (ADD ? acc : 0) + bias + W[32 rows][8 nkg] . act[8 nkg][32-sample blocks]; Bl = LDS activations + the lane's
-// offset 4 (64 hh + n [+ 32 sb]).  nkg is a multiple of 4 (packer).
-template <int NS, bool ADD>
-__device__ __forceinline__ void mf_item(MfRing &r, int nkg, const float *Bl, f32x16 (&acc)[NS]) {
-    f32x4 b[2];
-    const float *blast = Bl + (size_t)(nkg > 0 ? nkg - 1 : 0) * 512;
-    const float *bp = Bl;
-    if constexpr (MF_SCHED == 2) {
-        b[0] = *reinterpret_cast<const f32x4 *>(Bl);
-        if constexpr (NS == 2) b[1] = *reinterpret_cast<const f32x4 *>(Bl + 128);
-        bp = nkg > 1 ? Bl + 512 : Bl;
-    }
-    // bias group = ring entries 0..3: entry q holds bias[8 q + 4 hh + 0..3] = accumulator registers 4 q + i
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 bq = r.a[q];
-        r.a[q] = *reinterpret_cast<const f32x4 *>(r.ap + (size_t)(q + 8) * 256);
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[s][4 * q + i] = ADD ? acc[s][4 * q + i] + bq[i] : bq[i];
-    }
-    if constexpr (MF_SCHED != 0) __builtin_amdgcn_sched_barrier(0);
-    int kg = 0;
-    for (; kg + 8 <= nkg; kg += 8) {
-        mf_group<NS, 4>(r, 4 + kg, bp, blast, b, acc);
-        mf_group<NS, 0>(r, 8 + kg, bp, blast, b, acc);
-    }
-    if (kg < nkg) {          // an odd number of A groups: bias + A groups is even, the next item starts in ring half 0
-        mf_group<NS, 4>(r, 4 + kg, bp, blast, b, acc);
-    } else {                 // the next item's first entries sit in ring half 1: swap the halves
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 tmp = r.a[j];
-            r.a[j] = r.a[4 + j];
-            r.a[4 + j] = tmp;
-        }
-    }
-    r.ap += (size_t)(4 + nkg) * 256;
-}
-
-// publish the row-block's values (ReLU'd or raw) as the next layer's B operand: act[(4 rb + q)][hh][32 sb + n][4]
-template <int NS, bool RELU>
-__device__ __forceinline__ void mf_publish(float *acts, int rb, int sb0, int hh, int n, const f32x16 (&v)[NS]) {
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 o;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = RELU ? fmaxf(v[s][4 * q + i], 0.0f) : v[s][4 * q + i];
-            *reinterpret_cast<f32x4 *>(acts + ((size_t)((4 * rb + q) * 2 + hh) * 64 + 32 * (sb0 + s) + n) * 4) = o;
-        }
-}
 
 // EPI 0: z = scale x + shift, logdet = sum log scale (autoregressive.py:101-110, :124-128: rows 2 f = unconstrained scale, 2 f + 1
 // = shift);  EPI 1: the raw MADE output (B, mult D) for the callers that apply another element-wise transform.

@@ -1,0 +1,307 @@
+// nsf_wide.hip -- CoupledRationalQuadraticSpline (normflows/flows/neural_spline/wrapper.py:14-85 -> nsf/coupling.py:71-128, 150-164,
+// 221-253, 329-362 over nets/resnet.py:37-50, 92-104 and utils/splines.py:16-219) as ONE launch for the shapes beyond the benchmark
+// kernel's (rqs_fused.hip: D <= 64, hidden <= 128): up to 128 features and 512 hidden units, 8 bins, linear tails, float32.  Round 3
+// ran these as library GEMMs + nf_rqs_coupling on a materialised conditioner output (2944 B per row and 32 transform features).
+//
+// The engine is mlp_tile.hpp's (made_fwd.hip describes it): 8 waves own 64 rows for the whole layer, pre-activations in accumulator
+// registers, the next layer's B operand in LDS in MFMA order, one contiguous weight stream per wave through a register ring,
+// persistent over the tiles.  What is specific here (host packer: flows/nsf_wide_pack.py):
+//   * the x tile (64 rows x Dp columns, B-operand order) is the initial layer's B operand as it stands: the packed initial weight
+//     has zero columns at the transform features (conditioner input = identity features, nsf/coupling.py:83-84);
+//   * the final layer runs in GROUPS of four transform features = 3 row-blocks for both sample blocks (6 accumulators); the packed
+//     row order makes a lane's 48 accumulator values of a sample block the 2 x 24 parameter lists (8 widths, 8 heights, 7
+//     derivatives, pad) of features 4 g + 2 hh + {0, 1}: the spline runs on them in registers (fused_common.hpp rqs_regs: branch-
+//     free, hardware transcendentals, log2(e) / sqrt(hidden) folded into the packed rows), reads x from the tile and writes y into it;
+//   * the identity features go through the batch-shared spline (nsf/coupling.py:221-253) from knot tables staged in the activation
+//     region while it is free: AFTER the network in the density direction (the conditioner sees the raw features, :83-92), BEFORE
+//     it in the sampling direction (:112-118);
+//   * per-row log-det: the lane-halves' sums, the groups' and the identity columns' partials through LDS in a fixed order.
+// Bound: fp32 MFMA.  FLOP per row: 2 (nI H + 4 H^2 + 23 nT H) algorithmic (executed: full-width initial layer, padded hidden
+// units, 24 rows per feature); HBM: 8 D + 4 bytes per row.
+#include "mlp_tile.hpp"
+
+namespace nf {
+
+constexpr int NW_TABW = 3 * (F_K + 1);          // 27 floats per identity feature: cumw[9] | cumh[9] | deriv[9]
+constexpr int NW_TAB_FLOATS = 2048;             // table region at the start of the activation region (64 features x 27)
+
+// knot tables of the batch-shared spline, once per parameter version (same arithmetic as rqs_fused.hip's pack_tables_kernel)
+__global__ void nsf_wide_tables_kernel(const float *__restrict__ uw, const float *__restrict__ uh, const float *__restrict__ ud,
+                                       float *__restrict__ tab, int nI, RqsParams<float> p) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nI) return;
+    const float *wj = uw + j * F_K, *hj = uh + j * F_K, *dj = ud + j * (F_K - 1);
+    auto wacc = [=](int k) { return wj[k]; };
+    auto hacc = [=](int k) { return hj[k]; };
+    auto dacc = [=](int k) { return dj[k]; };
+    rqs_build_table<float>(p, wacc, hacc, dacc, tab + j * NW_TABW);
+}
+
+// ring entry e of the current item (idx = e mod 8; a compile-time constant after unrolling at every call site): consume it,
+// re-request it 8 entries ahead
+__device__ __forceinline__ f32x4 nw_take(MfRing &r, int idx, int e) {
+    const f32x4 v = r.a[idx];
+    r.a[idx] = *reinterpret_cast<const f32x4 *>(r.ap + (size_t)(e + 8) * 256);
+    return v;
+}
+
+// eight k-groups of a final item: per k-group one A fragment per row-block (3 ring entries), both sample blocks
+template <int K0>
+__device__ __forceinline__ void nw_final_kgs(MfRing &r, int e0, const float *bp, f32x16 (&o)[3][2]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bp + k * 512);
+        const f32x4 b1 = *reinterpret_cast<const f32x4 *>(bp + k * 512 + 128);
+#pragma unroll
+        for (int r3 = 0; r3 < 3; ++r3) {
+            const f32x4 av = nw_take(r, (K0 + 3 * k + r3) & 7, e0 + 3 * k + r3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o[r3][0] = MF_MFMA(av[i], b0[i], o[r3][0]);
+                o[r3][1] = MF_MFMA(av[i], b1[i], o[r3][1]);
+            }
+        }
+    }
+}
+
+// one group of the final layer: o[r3][sb] = bias + W[32 rows] . h[., 32 samples]; nkg is a multiple of 8
+__device__ __forceinline__ void nw_final_item(MfRing &r, int nkg, const float *Bl, f32x16 (&o)[3][2]) {
+    // 12 bias entries (row-block r3, quad q): the item starts in ring phase 0; entries 8..11 come from the re-requested a[0..3]
+#pragma unroll
+    for (int e = 0; e < 12; ++e) {
+        const f32x4 bq = nw_take(r, e & 7, e);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[e >> 2][0][4 * (e & 3) + i] = bq[i];
+            o[e >> 2][1][4 * (e & 3) + i] = bq[i];
+        }
+    }
+    // A entries start at ring phase 4 (12 mod 8); 8 k-groups = 24 entries = three revolutions
+    for (int kg = 0; kg < nkg; kg += 8) nw_final_kgs<4>(r, 12 + 3 * kg, Bl + (size_t)kg * 512, o);
+    // 12 + 3 nkg = 4 (mod 8): the next item's first entries sit in ring half 1
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 tmp = r.a[j];
+        r.a[j] = r.a[4 + j];
+        r.a[4 + j] = tmp;
+    }
+    r.ap += (size_t)(12 + 3 * nkg) * 256;
+}
+
+// float index of column `col` of row `row` (0..63) of the tile in B-operand order [col / 4][row][4]
+__device__ __forceinline__ int nw_xidx(int col, int row) { return ((col >> 2) * 64 + row) * 4 + (col & 3); }
+
+// batch-shared spline on the identity columns of the tile, in place; thread = (row n = tid & 63, feature residue tid >> 6)
+template <bool INV>
+__device__ __forceinline__ float nw_identity(float *xreg, const float *tabs, const RqsParams<float> &p, int nI, int par_i, int tid) {
+    const int n = tid & 63;
+    float ld = 0.0f;
+    for (int i = tid >> 6; i < nI; i += MF_NW) {
+        float *xp = xreg + nw_xidx(2 * i + par_i, n);
+        float y, lad;
+        rqs_table_fast<INV>(p, *xp, tabs + i * NW_TABW, y, lad);
+        *xp = y;
+        ld += lad;
+    }
+    return ld;
+}
+
+// NHI hidden items per wave with NS sample blocks each: (1, 1) Hp = 128, (1, 2) Hp = 256, (2, 2) Hp = 512.
+// DIR 0: density direction = prqct.forward (nsf/coupling.py:71-98); DIR 1: sampling direction = prqct.inverse (:100-128).
+template <int NHI, int NS, int DIR>
+__global__ void __launch_bounds__(64 * MF_NW, 1)
+nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ logdet, const float *__restrict__ blob,
+                const int *__restrict__ table, const float *__restrict__ tabs, int64_t B, int acc_mode, RqsParams<float> p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hh = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = table[0], Dp = table[1], Hp = table[3], NB = table[4], nI = table[5], nT = table[6], par_i = table[7],
+              par_t = table[8], G = table[9], nfi = table[10];
+    float *acts = lds;                                       // [Hp / 8 k-groups][2][64][4]
+    float *xreg = lds + (size_t)(Hp / 8) * 512;              // [Dp / 8][2][64][4]
+    float *ldp = acts + NW_TAB_FLOATS;                       // log-det partials [G + 8][64], behind the staged tables
+    const int nitems = (1 + 2 * NB) * NHI + nfi;
+    const int *items = table + MF_HDR + w * nitems * 3;      // [nitems][nkg, rb | g, sb0]
+    const float *stream = blob + table[16 + w];
+    const int lane_b = (64 * hh + n) * 4;
+    const int64_t ntiles = (B + MF_ROWS - 1) / MF_ROWS;
+    MfRing ring;
+    mf_ring_start(ring, stream, lane);
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * MF_ROWS;
+        const int nrows = (int)((B - row0) < MF_ROWS ? (B - row0) : MF_ROWS);
+        ring.ap = stream + lane * 4;
+        {   // x tile -> LDS (rows beyond the batch and columns beyond D are zero)
+            const int r = tid & 63, cg = tid >> 6;
+            const float *xr = x + (row0 + r) * D;
+            for (int c = cg; c < Dp / 4; c += MF_NW) {
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (r < nrows && 4 * c < D) {
+                    if ((D & 3) == 0) v = *reinterpret_cast<const f32x4 *>(xr + 4 * c);
+                    else
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (4 * c + i < D) v[i] = xr[4 * c + i];
+                }
+                *reinterpret_cast<f32x4 *>(xreg + ((size_t)c * 64 + r) * 4) = v;
+            }
+        }
+        float ld_ident = 0.0f;
+        if constexpr (DIR == 1) {                            // sampling: the identity half's inverse spline comes first (:112-114)
+            for (int i = tid; i < nI * NW_TABW; i += 64 * MF_NW) acts[i] = tabs[i];
+            MF_BARRIER();
+            ld_ident = nw_identity<true>(xreg, acts, p, nI, par_i, tid);
+        }
+        f32x16 h[NHI][NS], t[NHI][NS];
+        MF_BARRIER();
+        // ---- initial layer: h = b0 + W0 x (zero columns at the transform features) ---------------------------------------------------
+#pragma unroll
+        for (int s = 0; s < NHI; ++s) mf_item<NS, false>(ring, items[3 * s], xreg + lane_b + 128 * items[3 * s + 2], h[s]);
+        // ---- residual blocks (nets/resnet.py:37-50): t = b1 + W1 relu(h);  h += b2 + W2 relu(t) ----------------------------------
+        for (int b = 0; b < NB; ++b) {
+            MF_BARRIER();
+#pragma unroll
+            for (int s = 0; s < NHI; ++s) mf_publish<NS, true>(acts, items[3 * s + 1], items[3 * s + 2], hh, n, h[s]);
+            MF_BARRIER();
+#pragma unroll
+            for (int s = 0; s < NHI; ++s) {
+                const int *it = items + 3 * ((1 + 2 * b) * NHI + s);
+                mf_item<NS, false>(ring, it[0], acts + lane_b + 128 * it[2], t[s]);
+            }
+            MF_BARRIER();
+#pragma unroll
+            for (int s = 0; s < NHI; ++s) mf_publish<NS, true>(acts, items[3 * s + 1], items[3 * s + 2], hh, n, t[s]);
+            MF_BARRIER();
+#pragma unroll
+            for (int s = 0; s < NHI; ++s) {
+                const int *it = items + 3 * ((2 + 2 * b) * NHI + s);
+                mf_item<NS, true>(ring, it[0], acts + lane_b + 128 * it[2], h[s]);
+            }
+        }
+        // ---- final layer on the raw block output (:104) in groups of four transform features + the spline ----------------------------
+        MF_BARRIER();
+#pragma unroll
+        for (int s = 0; s < NHI; ++s) mf_publish<NS, false>(acts, items[3 * s + 1], items[3 * s + 2], hh, n, h[s]);
+        MF_BARRIER();
+        float ldt[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};      // [final item][sample block] (nfi <= 2)
+        for (int j = 0; j < nfi; ++j) {
+            const int *it = items + 3 * ((1 + 2 * NB) * NHI + j);
+            const int g = it[1];
+            if (g < 0) continue;
+            f32x16 o[3][2];
+            nw_final_item(ring, it[0], acts + lane_b, o);
+            float lsum[2] = {0.0f, 0.0f};
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    float prm[24];
+#pragma unroll
+                    for (int v = 0; v < 24; ++v) prm[v] = o[(24 * f + v) >> 4][sb][(24 * f + v) & 15];
+                    const int tf = 4 * g + 2 * hh + f;
+                    const bool valid = tf < nT;
+                    float *xp = xreg + nw_xidx(valid ? 2 * tf + par_t : par_t, 32 * sb + n);
+                    float yv, lad;
+                    rqs_regs<DIR == 1>(p, *xp, prm, yv, lad);
+                    if (valid) {
+                        *xp = yv;
+                        lsum[sb] += lad;
+                    }
+                }
+            if (j == 0) { ldt[0][0] = lsum[0]; ldt[0][1] = lsum[1]; } else { ldt[1][0] = lsum[0]; ldt[1][1] = lsum[1]; }
+        }
+        MF_BARRIER();                                        // every wave is done with the activations
+        if constexpr (DIR == 0)
+            for (int i = tid; i < nI * NW_TABW; i += 64 * MF_NW) acts[i] = tabs[i];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int g = w + 8 * j;
+            if (j < nfi && g < G) {
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb) {
+                    const float v = ldt[j][sb] + __shfl_xor(ldt[j][sb], 32);
+                    if (hh == 0) ldp[g * 64 + 32 * sb + n] = v;
+                }
+            }
+        }
+        if constexpr (DIR == 0) {                            // density: the identity half's spline after the conditioner (:88-92)
+            MF_BARRIER();
+            ld_ident = nw_identity<false>(xreg, acts, p, nI, par_i, tid);
+        }
+        ldp[(G + (tid >> 6)) * 64 + (tid & 63)] = ld_ident;
+        MF_BARRIER();
+        if (tid < nrows) {
+            float v = 0.0f;
+            for (int s = 0; s < G + 8; ++s) v += ldp[s * 64 + tid];      // fixed order: deterministic
+            ld_store(logdet + row0 + tid, v, acc_mode);
+        }
+        {
+            const int r = tid & 63, cg = tid >> 6;
+            float *yr = y + (row0 + r) * D;
+            if (r < nrows)
+                for (int c = cg; 4 * c < D; c += MF_NW) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(xreg + ((size_t)c * 64 + r) * 4);
+                    if ((D & 3) == 0) *reinterpret_cast<f32x4 *>(yr + 4 * c) = v;
+                    else
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (4 * c + i < D) yr[4 * c + i] = v[i];
+                }
+        }
+        MF_BARRIER();                                        // the next tile overwrites the x tile and the activations
+    }
+}
+
+template <int NHI, int NS, int DIR>
+static int nsf_wide_launch(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, const void *tabs, int64_t B,
+                           int Hp, int acc, const RqsParams<float> &p, hipStream_t st) {
+    const int64_t ntiles = (B + MF_ROWS - 1) / MF_ROWS;
+    const int grid = (int)(ntiles < 256 ? ntiles : 256);
+    size_t act_floats = (size_t)(Hp / 8) * 512;
+    if (act_floats < (size_t)NW_TAB_FLOATS + (16 + 8) * 64) act_floats = (size_t)NW_TAB_FLOATS + (16 + 8) * 64;
+    const size_t lds = sizeof(float) * (act_floats + MF_XFLOATS);
+    static LdsOptIn opted;
+    if (opt_in_lds(reinterpret_cast<const void *>(&nsf_wide_kernel<NHI, NS, DIR>), lds, opted) != NF_OK) return NF_ENOTSUP;
+    hipLaunchKernelGGL((nsf_wide_kernel<NHI, NS, DIR>), dim3((unsigned)grid), dim3(64 * MF_NW), lds, st, (const float *)x, (float *)y,
+                       (float *)logdet, (const float *)blob, (const int *)table, (const float *)tabs, B, acc, p);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+}  // namespace nf
+
+// Knot tables (cumulative widths | cumulative heights | derivatives, 27 floats per identity feature) of the batch-shared spline
+// PiecewiseRationalQuadraticCDF (nsf/coupling.py:170-259), once per parameter version.
+extern "C" int nf_nsf_wide_tables(const void *uw, const void *uh, const void *ud, void *tabs, int n_identity, int K, double tail_bound,
+                                  double min_bin_width, double min_bin_height, double min_derivative, nf_stream_t stream) {
+    if (K != nf::F_K) return NF_ENOTSUP;
+    if (n_identity < 1 || n_identity > 64 || min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_EINVAL;
+    if (!uw || !uh || !ud || !tabs) return NF_EFAULT;
+    auto p = nf::make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height, min_derivative, 1.0);
+    hipLaunchKernelGGL(nf::nsf_wide_tables_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float *)uw, (const float *)uh,
+                       (const float *)ud, (float *)tabs, n_identity, p);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// The coupling layer in one launch; blob / table: flows/nsf_wide_pack.pack_nsf_wide; tabs: nf_nsf_wide_tables.
+extern "C" int nf_nsf_wide(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, const void *tabs, int64_t B,
+                           int D, int hidden_padded, int direction, int acc, double tail_bound, double min_bin_width,
+                           double min_bin_height, double min_derivative, nf_stream_t stream) {
+    if (B < 0 || D < 2 || D > 128 || direction < 0 || direction > 1) return NF_EINVAL;
+    if (acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
+    if (hidden_padded != 128 && hidden_padded != 256 && hidden_padded != 512) return NF_ENOTSUP;
+    if (min_bin_width * nf::F_K > 1.0 || min_bin_height * nf::F_K > 1.0) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!x || !y || !logdet || !blob || !table || !tabs) return NF_EFAULT;
+    auto p = nf::make_rqs_params<float>(nf::F_K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height, min_derivative, 1.0);
+    hipStream_t st = (hipStream_t)stream;
+    const int Hp = hidden_padded;
+    if (direction == 0) {
+        if (Hp == 128) return nf::nsf_wide_launch<1, 1, 0>(x, y, logdet, blob, table, tabs, B, Hp, acc, p, st);
+        if (Hp == 256) return nf::nsf_wide_launch<1, 2, 0>(x, y, logdet, blob, table, tabs, B, Hp, acc, p, st);
+        return nf::nsf_wide_launch<2, 2, 0>(x, y, logdet, blob, table, tabs, B, Hp, acc, p, st);
+    }
+    if (Hp == 128) return nf::nsf_wide_launch<1, 1, 1>(x, y, logdet, blob, table, tabs, B, Hp, acc, p, st);
+    if (Hp == 256) return nf::nsf_wide_launch<1, 2, 1>(x, y, logdet, blob, table, tabs, B, Hp, acc, p, st);
+    return nf::nsf_wide_launch<2, 2, 1>(x, y, logdet, blob, table, tabs, B, Hp, acc, p, st);
+}

@@ -288,6 +288,9 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
             return self._autograd(inputs, context, False, ld, acc)
         if self.use_fused and self._fused_eligible(inputs, context):
             return self._fused(inputs, 0, ld, acc)
+        wide = self._wide_pack(inputs, context)
+        if wide is not None:
+            return self._wide(inputs, wide, 0, ld, acc)
         cond = self._conditioner(inputs, context)
         uw, uh, ud = self._uncond()
         return ops.rqs_coupling(inputs, cond, uw, uh, ud, self.identity_features, self.transform_features,
@@ -302,6 +305,9 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
             return self._autograd(inputs, context, True, ld, acc)
         if self.use_fused and self._fused_eligible(inputs, context):
             return self._fused(inputs, 1, ld, acc)
+        wide = self._wide_pack(inputs, context)
+        if wide is not None:
+            return self._wide(inputs, wide, 1, ld, acc)
         uw, uh, ud = self._uncond()
         kw = self._kernel_kwargs()
         y, ld = ops.rqs_coupling(inputs, None, uw, uh, ud, self.identity_features, self.transform_features,
@@ -316,6 +322,36 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
 
     def inverse(self, inputs, context=None):
         return self._sample(inputs, context)
+
+    # -- shapes beyond the benchmark kernel's (D <= 128, hidden <= 512): the whole layer as one launch (csrc/nsf_wide.hip) ---
+    def _wide_pack(self, inputs, context):
+        """Device copies of flows/nsf_wide_pack.py's streams + the batch-shared spline's knot tables, rebuilt when a parameter
+        changes; None when the layer is outside nf_nsf_wide's structure (then: library GEMMs + nf_rqs_coupling)."""
+        if not (self.use_fused and _config.nsf_wide and context is None and inputs.dim() == 2 and inputs.dtype == torch.float32
+                and inputs.is_cuda):
+            return None
+        net, u = self.transform_net, self.unconditional_transform
+        if u is None or not isinstance(net, ResidualNet):
+            return None
+        tensors = list(net.parameters()) + [u.unnormalized_widths, u.unnormalized_heights, u.unnormalized_derivatives]
+        key = tuple((t.data_ptr(), t._version) for t in tensors) + (str(inputs.device),)
+        cache = self.__dict__.get("_wide_cache")
+        if cache is None or cache[0] != key:
+            from . import nsf_wide_pack
+            packed = nsf_wide_pack.pack_nsf_wide(self)
+            if packed is not None:
+                blob, table = packed
+                tabs = ops.nsf_wide_tables(u.unnormalized_widths.detach(), u.unnormalized_heights.detach(),
+                                           u.unnormalized_derivatives.detach(), self.num_bins, self.tail_bound, self.min_bin_width,
+                                           self.min_bin_height, self.min_derivative)
+                packed = (torch.from_numpy(blob).to(inputs.device), torch.from_numpy(table).to(inputs.device), tabs, int(table[3]))
+            cache = self.__dict__["_wide_cache"] = (key, packed)
+        return cache[1]
+
+    def _wide(self, inputs, packed, direction, ld, acc):
+        blob, table, tabs, hp = packed
+        return ops.nsf_wide(inputs, blob, table, tabs, hp, direction, self.tail_bound, self.min_bin_width, self.min_bin_height,
+                            self.min_derivative, logdet=ld, acc=acc)
 
     # -- images (nsf/coupling.py:150-160): every pixel is a row of C channel features for the 2-D coupling kernel ----
     def _image(self, inputs, context, sample, ld, acc):

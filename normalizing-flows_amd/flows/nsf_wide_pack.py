@@ -1,0 +1,156 @@
+"""Host-side packing for the one-launch NSF coupling layer on 64-row tiles (nf_nsf_wide, csrc/nsf_wide.hip): the shapes of
+CoupledRationalQuadraticSpline (normflows/flows/neural_spline/wrapper.py:20-35 over nets/resnet.py:53-104) beyond the benchmark
+kernel's (csrc/rqs_fused.hip: D <= 64, hidden <= 128) -- up to 128 features and 512 hidden units, 8 bins, linear tails.
+
+This module only rearranges weights (no arithmetic on data besides the constant log2(e) / sqrt(hidden) folded into the width / height
+rows, nsf/coupling.py:334-339).  Geometry (csrc/mlp_tile.hpp, nsf_wide.hip):
+  * hidden units zero-padded to Hp = 128 | 256 | 512; row-block rb = units [32 rb, 32 rb + 32); k-group = 8 consecutive inputs;
+  * the initial layer contracts over the FULL row (Dp = D rounded up to 32 columns): its weight has zero columns at the transform
+    features, so the x tile is the B operand as it stands;
+  * hidden work items per wave w: Hp 128: row-block w & 3 for sample block w >> 2; Hp 256: row-block w, both sample blocks;
+    Hp 512: row-blocks w and w + 8, both sample blocks;
+  * the final layer is cut into GROUPS of 4 transform features = 3 row-blocks (96 MFMA rows, 92 used): accumulator register `reg` of
+    row-block r3 in lane-half hh is slot v = 16 r3 + reg of the lane's parameter list, feature tf = 4 g + 2 hh + v // 24, parameter
+    v % 24 (8 widths | 8 heights | 7 derivatives | pad) -- a lane ends up with the 2 x 24 parameters of two whole features, in the
+    order the register spline routine (fused_common.hpp rqs_regs) reads them; group g belongs to wave g % 8 (both sample blocks);
+  * an item's stream = its bias group(s) (4 KB per row-block) followed, per k-group, by one 1 KB A fragment per row-block; a wave's
+    stream = its items in consumption order + a copy of its first 8 entries (the register ring wraps into the next tile).
+
+int32 table : hdr[32] = [D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, total floats, nhi, 0..], hdr[16 + w] = offset (floats) of wave
+              w's stream; then per wave (1 + 2 NB) nhi hidden entries [nkg, rb, sb0] and nfi final entries [nkg, g, 0] (g = -1: none).
+"""
+import numpy as np
+import torch
+
+from .made_pack import ROWS, KG, RING, a_stream, bias_group
+
+HDR = 32
+K_BINS = 8
+M = 3 * K_BINS - 1      # 23 parameters per transform feature
+MP = 3 * K_BINS         # 24 slots
+
+
+def geometry(Hp):
+    """(hidden items per wave, sample blocks per item)."""
+    return {128: (1, 1), 256: (1, 2), 512: (2, 2)}[Hp]
+
+
+def hidden_item(Hp, w, i):
+    """(row-block, first sample block) of hidden item i of wave w."""
+    if Hp == 128:
+        return w & 3, w >> 2
+    if Hp == 256:
+        return w, 0
+    return w + 8 * i, 0
+
+
+def final_row(g, r3, rho, nT):
+    """Row of the (23 nT, hidden) final weight held by MFMA row rho of row-block r3 of group g, or -1 (padding)."""
+    q, hh, i = rho >> 3, (rho >> 2) & 1, rho & 3
+    v = 16 * r3 + 4 * q + i
+    f, prm = v // MP, v % MP
+    tf = 4 * g + 2 * hh + f
+    if prm >= M or tf >= nT:
+        return -1
+    return tf * M + prm
+
+
+def supported(prqct):
+    from .. import nets
+    net = prqct.transform_net
+    if not (isinstance(net, nets.ResidualNet) and net.is_plain_relu()):
+        return False
+    if prqct.tails != "linear" or getattr(prqct, "_per_feature", False) or prqct.unconditional_transform is None:
+        return False
+    if prqct.num_bins != K_BINS or prqct.min_bin_width * K_BINS > 1.0 or prqct.min_bin_height * K_BINS > 1.0:
+        return False
+    D = prqct.features
+    if not (2 <= D <= 128 and 1 <= net.hidden_features <= 512 and len(net.blocks) >= 1 and len(net.blocks) <= 7):
+        return False
+    if net.initial_layer.weight.dtype != torch.float32:
+        return False
+    ii, ti = prqct.identity_features.cpu(), prqct.transform_features.cpu()
+    alt0 = torch.equal(ii, torch.arange(0, D, 2)) and torch.equal(ti, torch.arange(1, D, 2))
+    alt1 = torch.equal(ii, torch.arange(1, D, 2)) and torch.equal(ti, torch.arange(0, D, 2))
+    return alt0 or alt1
+
+
+def pack_nsf_wide(prqct):
+    """(blob float32 ndarray, table int32 ndarray) or None (the caller keeps the layer-wise path)."""
+    if not supported(prqct):
+        return None
+    net = prqct.transform_net
+    D, H, NB = prqct.features, net.hidden_features, len(net.blocks)
+    ident = prqct.identity_features.cpu().numpy()
+    trans = prqct.transform_features.cpu().numpy()
+    nI, nT = len(ident), len(trans)
+    par_i, par_t = int(ident[0]), int(trans[0])
+    Hp = 128 if H <= 128 else (256 if H <= 256 else 512)
+    Dp = (D + 31) // 32 * 32
+    nhi, NS = geometry(Hp)
+    G = (nT + 3) // 4
+    nfi = (G + 7) // 8
+    f32 = lambda t: t.detach().cpu().numpy().astype(np.float32)
+
+    W0 = np.zeros((Hp, Dp), dtype=np.float32)
+    W0[:H, ident] = f32(net.initial_layer.weight)
+    b0 = np.zeros(Hp, dtype=np.float32)
+    b0[:H] = f32(net.initial_layer.bias)
+    layers = [(W0, b0)]
+    for blk in net.blocks:
+        for lin in blk.linear_layers:
+            W = np.zeros((Hp, Hp), dtype=np.float32)
+            W[:H, :H] = f32(lin.weight)
+            b = np.zeros(Hp, dtype=np.float32)
+            b[:H] = f32(lin.bias)
+            layers.append((W, b))
+    wf, bf = f32(net.final_layer.weight), f32(net.final_layer.bias)        # (23 nT, H)
+    if wf.shape[0] != M * nT:
+        return None
+    wh_scale = np.float32(1.4426950408889634 / np.sqrt(float(H)))          # log2(e) / sqrt(hidden): rqs_regs takes exp2
+    WF = np.zeros((G, 3, ROWS, Hp), dtype=np.float32)
+    BF = np.zeros((G, 3, ROWS), dtype=np.float32)
+    for g in range(G):
+        for r3 in range(3):
+            for rho in range(ROWS):
+                row = final_row(g, r3, rho, nT)
+                if row >= 0:
+                    sc = wh_scale if (row % M) < 2 * K_BINS else np.float32(1.0)
+                    WF[g, r3, rho, :H] = wf[row] * sc
+                    BF[g, r3, rho] = bf[row] * sc
+
+    nhl = 1 + 2 * NB
+    nitems = nhl * nhi + nfi
+    hdr = np.zeros(HDR, dtype=np.int32)
+    tab = np.zeros((8, nitems, 3), dtype=np.int32)
+    chunks, off = [], 0
+    for w in range(8):
+        hdr[16 + w] = off
+        stream = []
+        for l in range(nhl):
+            Wl, bl = layers[l]
+            nkg = Wl.shape[1] // KG
+            for i in range(nhi):
+                rb, sb0 = hidden_item(Hp, w, i)
+                tab[w, l * nhi + i] = (nkg, rb, sb0)
+                stream.append(bias_group(bl[rb * ROWS:(rb + 1) * ROWS]))
+                stream.append(a_stream(Wl[rb * ROWS:(rb + 1) * ROWS]))
+        for j in range(nfi):
+            g = w + 8 * j
+            if g >= G:
+                tab[w, nhl * nhi + j] = (0, -1, 0)
+                continue
+            nkg = Hp // KG
+            tab[w, nhl * nhi + j] = (nkg, g, 0)
+            for r3 in range(3):
+                stream.append(bias_group(BF[g, r3]))
+            frag = np.stack([a_stream(WF[g, r3]).reshape(nkg, 256) for r3 in range(3)], axis=1)   # [nkg][3][256]
+            stream.append(frag.reshape(-1))
+        stream = np.concatenate(stream)
+        stream = np.concatenate([stream, np.resize(stream, RING * 256)])
+        chunks.append(stream)
+        off += stream.size
+    hdr[:13] = [D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, off, nhi]
+    blob = np.concatenate(chunks).astype(np.float32)
+    assert blob.size == off and off < 2 ** 31
+    return blob, np.concatenate([hdr, tab.reshape(-1)]).astype(np.int32)

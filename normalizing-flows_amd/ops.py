@@ -804,6 +804,39 @@ def rqs_fused_x3_chain(x, blobs, parities, hidden, num_blocks, K, direction, log
     return y, logdet
 
 
+def nsf_wide_tables(uw, uh, ud, K, tail_bound, min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3):
+    """Knot tables (n_identity, 27) of the batch-shared spline for nf_nsf_wide (nsf/coupling.py:170-259)."""
+    L.require_device(uw, uh, ud)
+    tabs = torch.empty(uw.shape[0], 3 * (K + 1), dtype=torch.float32, device=uw.device)
+    rc = L.lib().nf_nsf_wide_tables(ptr(uw.contiguous()), ptr(uh.contiguous()), ptr(ud.contiguous()), ptr(tabs), i32(uw.shape[0]),
+                                    i32(K), f64(float(tail_bound)), f64(min_bin_width), f64(min_bin_height), f64(min_derivative),
+                                    L.stream())
+    L.check(rc, "nf_nsf_wide_tables")
+    return tabs
+
+
+def nsf_wide(x, blob, table, tabs, hidden_padded, direction, tail_bound, min_bin_width=1e-3, min_bin_height=1e-3,
+             min_derivative=1e-3, logdet=None, acc=None):
+    """CoupledRationalQuadraticSpline beyond the benchmark kernel's shapes as one launch (nf_nsf_wide); blob / table from
+    flows/nsf_wide_pack.pack_nsf_wide, tabs from nsf_wide_tables."""
+    L.require_device(x, blob, table, tabs)
+    if x.dtype != torch.float32:
+        raise NotImplementedError("nsf_wide: float32 only")
+    B, D = x.shape
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    if logdet is None:
+        logdet = torch.empty(B, dtype=x.dtype, device=x.device)
+        acc = L.LD_WRITE
+    elif acc is None:
+        acc = L.LD_ADD
+    rc = L.lib().nf_nsf_wide(ptr(x), ptr(y), ptr(logdet), ptr(blob), ptr(table), ptr(tabs), i64(B), i32(D), i32(hidden_padded),
+                             i32(direction), i32(acc), f64(float(tail_bound)), f64(min_bin_width), f64(min_bin_height),
+                             f64(min_derivative), L.stream())
+    L.check(rc, "nf_nsf_wide")
+    return y, logdet
+
+
 def made_forward_affine(x, blob, table, hidden_padded, logdet=None, acc=None):
     """MaskedAffineAutoregressive.forward (autoregressive.py:24-27, :101-110 over nets/made.py:296-304) as one launch
     (nf_made_forward_affine); blob / table from flows/made_pack.pack_made_forward."""

@@ -1,0 +1,78 @@
+"""numpy walk-through of the NSF coupling layer's conditioner exactly as csrc/nsf_wide.hip walks the packed streams of
+flows/nsf_wide_pack.py (hidden items per wave, final layer in groups of 4 transform features = 3 row-blocks whose accumulator
+registers are the lane's parameter list).  Test infrastructure: pins the packing on CPU against the dense ResidualNet."""
+import numpy as np
+
+HDR, ROWS, KG, RING, M, MP = 32, 32, 8, 8, 23, 24
+
+
+def _rows(a, nkg):
+    return a.reshape(nkg, 2, ROWS, 4).transpose(2, 0, 1, 3).reshape(ROWS, KG * nkg)
+
+
+def _bias(g):
+    g = g.reshape(4, 2, ROWS, 4)
+    assert np.array_equal(g, np.broadcast_to(g[:, :, :1, :], g.shape))
+    return g[:, :, 0, :].reshape(32)
+
+
+def emulate_conditioner(blob, table, x):
+    """(B, nT, 24) parameter lists as the kernel's lanes hold them (widths / heights still carry log2(e) / sqrt(hidden)), from
+    full rows x (B, D)."""
+    blob = blob.astype(np.float64)
+    D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, total, nhi = [int(v) for v in table[:13]]
+    nhl = 1 + 2 * NB
+    nitems = nhl * nhi + nfi
+    tab = table[HDR:HDR + 8 * nitems * 3].reshape(8, nitems, 3)
+    x = np.asarray(x, dtype=np.float64)
+    B = x.shape[0]
+    xin = np.zeros((B, Dp))
+    xin[:, :D] = x
+    pos = [int(table[16 + w]) for w in range(8)]
+    start = list(pos)
+
+    def hidden_layer(l, act):
+        out = np.full((B, Hp), np.nan)
+        for w in range(8):
+            for i in range(nhi):
+                nkg, rb, sb0 = [int(v) for v in tab[w, l * nhi + i]]
+                acc = np.tile(_bias(blob[pos[w]:pos[w] + 1024]), (B, 1))
+                pos[w] += 1024
+                assert KG * nkg == act.shape[1]
+                acc = acc + act @ _rows(blob[pos[w]:pos[w] + 256 * nkg], nkg).T
+                pos[w] += 256 * nkg
+                # (a wave computes only its sample blocks; the emulation ignores the split: every owner must agree)
+                prev = out[:, rb * ROWS:(rb + 1) * ROWS]
+                assert np.isnan(prev).all() or np.array_equal(prev, acc)
+                out[:, rb * ROWS:(rb + 1) * ROWS] = acc
+        assert not np.isnan(out).any()
+        return out
+
+    h = hidden_layer(0, xin)
+    for b in range(NB):
+        t = hidden_layer(1 + 2 * b, np.maximum(h, 0.0))
+        h = h + hidden_layer(2 + 2 * b, np.maximum(t, 0.0))
+    prm = np.zeros((B, 4 * G, MP))
+    for w in range(8):
+        for j in range(nfi):
+            nkg, g, _ = [int(v) for v in tab[w, nhl * nhi + j]]
+            if g < 0:
+                continue
+            acc = np.zeros((3, B, ROWS))
+            for r3 in range(3):
+                acc[r3] = np.tile(_bias(blob[pos[w]:pos[w] + 1024]), (B, 1))
+                pos[w] += 1024
+            frag = blob[pos[w]:pos[w] + 3 * 256 * nkg].reshape(nkg, 3, 256)
+            pos[w] += 3 * 256 * nkg
+            for r3 in range(3):
+                acc[r3] += h @ _rows(np.ascontiguousarray(frag[:, r3]).reshape(-1), nkg).T
+            for r3 in range(3):
+                for rho in range(ROWS):
+                    q, hh, i = rho >> 3, (rho >> 2) & 1, rho & 3
+                    v = 16 * r3 + 4 * q + i
+                    prm[:, 4 * g + 2 * hh + v // MP, v % MP] = acc[r3][:, rho]
+    for w in range(8):
+        n = pos[w] - start[w]
+        assert np.array_equal(blob[pos[w]:pos[w] + RING * 256], np.resize(blob[start[w]:pos[w]], RING * 256)), w
+        assert pos[w] + RING * 256 == (int(table[16 + w + 1]) if w < 7 else total) and n > 0
+    return prm[:, :nT]

@@ -1132,6 +1132,69 @@ def test_maf_incremental_inverse_vs_d_pass(nfa, D, H, B):
     assert_close(N(x2), N(x3), what="x after update", rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("D,H,NB,rev,B", [(64, 256, 2, False, 300), (128, 128, 2, False, 65), (128, 256, 1, True, 129),
+                                          (96, 192, 2, False, 64), (7, 300, 2, True, 33), (66, 512, 3, False, 257),
+                                          (128, 512, 2, False, 4099), (65, 129, 2, True, 1)])
+def test_nsf_wide_one_launch_vs_layerwise_and_oracle(nfa, oracle, D, H, NB, rev, B):
+    """nf_nsf_wide (csrc/nsf_wide.hip: the coupling layer beyond the benchmark kernel's shapes as one launch -- ResidualNet on fp32
+    MFMA with the activations on chip, the spline on the accumulator registers, the batch-shared spline on the identity half)
+    against (a) the layer-wise path (library GEMMs + nf_rqs_coupling, itself pinned to the reference's fixtures) and (b) the CPU
+    oracle in double precision, both directions, on a strongly non-identity layer with inputs beyond the tails."""
+    torch.manual_seed(D * 7 + H)
+    layer = nfa.flows.CoupledRationalQuadraticSpline(D, NB, H, num_bins=8, init_identity=False, reverse_mask=rev)
+    with torch.no_grad():
+        for p_ in layer.parameters():
+            p_.add_(0.04 * torch.randn_like(p_))
+        u = layer.prqct.unconditional_transform
+        u.unnormalized_widths.normal_()
+        u.unnormalized_heights.normal_()
+        u.unnormalized_derivatives.normal_()
+    layer = layer.to(DEV)
+    assert layer.prqct._wide_pack(torch.zeros(1, D, device=DEV), None) is not None
+    x = (1.7 * torch.randn(B, D, generator=torch.Generator().manual_seed(3))).to(DEV)
+    x[0, 0] = 3.5
+    x[0, D - 1] = -4.0
+    outs = {}
+    for name, fn in (("inv", layer.inverse), ("fwd", layer.forward)):
+        z1, ld1 = fn(x)
+        nfa.config.set_nsf_wide(False)
+        try:
+            assert layer.prqct._wide_pack(x, None) is None
+            z0, ld0 = fn(x)
+        finally:
+            nfa.config.set_nsf_wide(True)
+        assert_close(N(z1), N(z0), what=name + " z", rtol=2e-5, atol=2e-5)
+        assert_close(N(ld1), N(ld0), what=name + " ld", rtol=1e-4, atol=1e-4)
+        z2, ld2 = fn(x)
+        assert torch.equal(z1, z2) and torch.equal(ld1, ld2)           # deterministic
+        acc = torch.full((B,), -1.5, device=DEV)
+        fnr = layer.prqct._density if name == "inv" else layer.prqct._sample
+        _, acc2 = fnr(x, None, acc.clone(), -1)
+        assert torch.allclose(acc2, acc - ld1, atol=1e-6)
+        outs[name] = (z1, ld1)
+    zi, ldi = outs["inv"]
+    xr, ldr = layer.forward(zi)                                        # round trip (flow_test.py:40-48)
+    # (random N(0, 1) spline logits: single bins with slopes of several hundred amplify the forward pass's 1e-6 -- the per-direction
+    # comparisons above and the oracle's below are the tight ones)
+    assert_close(N(xr), N(x), what="round trip", rtol=2e-3, atol=2e-3)
+    assert_close(N(ldr), -N(ldi), what="round trip ld", rtol=5e-3, atol=5e-3)
+    # the CPU oracle in double precision on the same weights (both directions)
+    st = {"flows.0." + k: (v.detach().cpu().double().numpy() if v.is_floating_point() else v.cpu().numpy())
+          for k, v in layer.state_dict().items()}
+    ora = oracle.OracleNSF(st, num_layers=1, K=8, tail_bound=3.0)
+    x64 = N(x).astype(np.float64)
+    for name, direction in (("inv", 0), ("fwd", 1)):
+        lq = np.zeros(B)
+        zo = ora.coupling(0, x64, direction, lq, +1)
+        # float32 kernel against float64 oracle: 99.9 % of the elements within 5e-5 (1 + |z|), all within 1e-3 -- with N(0, 1) spline
+        # logits a handful of elements per 100 000 sit in bins whose slope amplifies float32 rounding of the conditioner output
+        # (the float32 layer-wise path above agrees with the kernel to 2e-5 on every element)
+        ez = np.abs(N(outs[name][0]).astype(np.float64) - zo) / (1.0 + np.abs(zo))
+        assert np.quantile(ez, 0.999) < 5e-5 and ez.max() < 1e-3, (name, float(np.quantile(ez, 0.999)), float(ez.max()))
+        el = np.abs(N(outs[name][1]).astype(np.float64) - lq) / (1.0 + np.abs(lq))
+        assert np.quantile(el, 0.99) < 2e-4 and el.max() < 5e-3, (name, float(np.quantile(el, 0.99)), float(el.max()))
+
+
 @pytest.mark.parametrize("D,H,NB,B", [(128, 512, 2, 300), (128, 512, 2, 64), (20, 40, 2, 130), (6, 300, 1, 7), (33, 256, 3, 65),
                                       (3, 2, 2, 1), (64, 257, 2, 129), (127, 512, 1, 4100)])
 def test_made_forward_one_launch_vs_layerwise(nfa, D, H, NB, B):

@@ -679,3 +679,41 @@ def test_made_forward_pack_rejects_unsupported():
                                                  permute_mask=True)) is None or True      # a permutation may be the identity
     assert made_pack.pack_made_forward(nets.MADE(features=200, hidden_features=64, num_blocks=2, output_multiplier=2)) is None
     assert made_pack.pack_made_forward(nets.MADE(features=8, hidden_features=600, num_blocks=2, output_multiplier=2)) is None
+
+
+@pytest.mark.parametrize("D,H,NB,rev", [(64, 256, 2, False), (128, 128, 2, False), (128, 256, 1, True), (96, 192, 2, False),
+                                        (7, 300, 2, True), (66, 512, 3, False)])
+def test_nsf_wide_pack_matches_dense_conditioner(D, H, NB, rev):
+    """flows/nsf_wide_pack.py (zero-padded hidden units, the initial layer on full rows, the final layer in groups of four
+    transform features whose MFMA rows are the lanes' 2 x 24 parameter lists, width / height rows pre-scaled by log2(e) / sqrt(H))
+    + the kernel's walk over the per-wave streams (tests/nsf_wide_emulator.py) reproduce the reference-layout conditioner
+    ResidualNet(identity features) (nets/resnet.py:92-104, nsf/coupling.py:83-86, :334-339) computed densely in fp64."""
+    import normflows_amd as nfa
+    from normflows_amd.flows import nsf_wide_pack
+    from nsf_wide_emulator import emulate_conditioner
+    torch.manual_seed(D + H)
+    layer = nfa.flows.CoupledRationalQuadraticSpline(D, NB, H, num_bins=8, init_identity=False, reverse_mask=rev)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    prqct = layer.prqct
+    blob, table = nsf_wide_pack.pack_nsf_wide(prqct)
+    assert table[0] == D and table[3] in (128, 256, 512) and table[3] >= H and blob.size % 256 == 0
+    x = torch.randn(5, D)
+    nT = len(prqct.transform_features)
+    with torch.no_grad():
+        ref = prqct.transform_net.double()(x.double().index_select(1, prqct.identity_features)).numpy().reshape(5, nT, 23)
+    got = emulate_conditioner(blob, table, x.numpy())
+    sc = 1.4426950408889634 / np.sqrt(float(H))
+    ref_s = ref.copy()
+    ref_s[:, :, :16] *= sc
+    assert np.max(np.abs(got[:, :, :23] - ref_s)) < 1e-5 * max(1.0, np.abs(ref_s).max())     # (the scale is applied in float32)
+    assert np.all(got[:, :, 23] == 0.0)
+
+
+def test_nsf_wide_pack_rejects_unsupported():
+    import normflows_amd as nfa
+    from normflows_amd.flows import nsf_wide_pack
+    assert nsf_wide_pack.pack_nsf_wide(nfa.flows.CoupledRationalQuadraticSpline(64, 2, 256, num_bins=10).prqct) is None
+    assert nsf_wide_pack.pack_nsf_wide(nfa.flows.CoupledRationalQuadraticSpline(130, 2, 256).prqct) is None
+    assert nsf_wide_pack.pack_nsf_wide(nfa.flows.CoupledRationalQuadraticSpline(64, 2, 600).prqct) is None
