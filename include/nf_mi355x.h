@@ -478,13 +478,17 @@ int nf_maf_affine(const void *x, const void *params, void *y, void *logdet, int6
  *   tabs        : (n_identity, 27) knot tables of the batch-shared spline, written by nf_nsf_wide_tables from the raw
  *                 unnormalized_widths (n_identity, 8), unnormalized_heights (n_identity, 8), unnormalized_derivatives (n_identity, 7).
  *   direction 0 : density direction (wrapper.inverse = prqct.forward); 1: sampling direction (wrapper.forward = prqct.inverse).
+ *   lu_logdet   : NULL, or the device scalar sum(log(softplus(u_diag) + eps)) of the adjacent LULinearPermute (mixing.py:535-563,
+ *                 :402-473) whose dense matrix the pack carries for THIS direction: the pair [CoupledRationalQuadraticSpline,
+ *                 LULinearPermute] then runs as one launch -- density: y = coupling.inverse(LU.inverse(x)) (the order of
+ *                 core.py:193-195), sampling: y = LU.forward(coupling.forward(x)) (core.py:177-179); logdet gets both terms.
  *   x, y (B, D); logdet (B) combined according to `acc`.  -EINVAL for min_bin_width * 8 > 1 (utils/splines.py:121-124).
  */
 int nf_nsf_wide_tables(const void *uw, const void *uh, const void *ud, void *tabs, int n_identity, int K, double tail_bound,
                        double min_bin_width, double min_bin_height, double min_derivative, nf_stream_t stream);
-int nf_nsf_wide(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, const void *tabs, int64_t B, int D,
-                int hidden_padded, int direction, int acc, double tail_bound, double min_bin_width, double min_bin_height,
-                double min_derivative, nf_stream_t stream);
+int nf_nsf_wide(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, const void *tabs,
+                const void *lu_logdet, int64_t B, int D, int hidden_padded, int direction, int acc, double tail_bound,
+                double min_bin_width, double min_bin_height, double min_derivative, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * MADE in ONE launch -- the single-pass direction of the autoregressive flows.  Replaces

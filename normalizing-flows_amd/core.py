@@ -37,7 +37,8 @@ def _run_pairs(pairs, z, inverse, ld, acc):
 
 def _run_pairs_impl(pairs, z, inverse, ld, acc):
     from . import config, ops
-    if config.fused_gemm not in ("f32", "bf16x3") or len(pairs) == 1 or not config.fused_chain:
+    if (config.fused_gemm not in ("f32", "bf16x3") or len(pairs) == 1 or not config.fused_chain
+            or not pairs[0][0].prqct._fused_eligible(z, None)):       # (pairs beyond the benchmark kernel's shapes: nf_nsf_wide per pair)
         for c, lu in pairs:
             z = c._run_pair(z, lu, inverse, ld, acc)
         return z

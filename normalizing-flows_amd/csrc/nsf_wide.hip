@@ -106,12 +106,27 @@ __device__ __forceinline__ float nw_identity(float *xreg, const float *tabs, con
     return ld;
 }
 
+// The adjacent LULinearPermute (mixing.py:535-563) as one dense product on the tile, in place: every wave computes its 32 output
+// columns of one sample block from the tile (B operand as it stands), all waves meet, then the columns are written back in B-operand
+// order (the accumulator quads ARE 16-byte groups of that order).
+__device__ __forceinline__ void nw_lu_stage(MfRing &ring, const int *it, float *xreg, int lane_b, int hh, int n) {
+    const int rb = it[1];
+    f32x16 o1[1];
+    if (rb >= 0) mf_item<1, false>(ring, it[0], xreg + lane_b + 128 * it[2], o1);
+    MF_BARRIER();
+    if (rb >= 0) mf_publish<1, false>(xreg, rb, it[2], hh, n, o1);
+    MF_BARRIER();
+}
+
 // NHI hidden items per wave with NS sample blocks each: (1, 1) Hp = 128, (1, 2) Hp = 256, (2, 2) Hp = 512.
 // DIR 0: density direction = prqct.forward (nsf/coupling.py:71-98); DIR 1: sampling direction = prqct.inverse (:100-128).
-template <int NHI, int NS, int DIR>
+// LU: with the adjacent LULinearPermute -- applied BEFORE the coupling layer in the density direction (core.py:193-195 walks the
+// flows backwards: the LU layer behind a coupling layer comes first), AFTER it in the sampling direction (core.py:177-179).
+template <int NHI, int NS, int DIR, bool LU>
 __global__ void __launch_bounds__(64 * MF_NW, 1)
 nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ logdet, const float *__restrict__ blob,
-                const int *__restrict__ table, const float *__restrict__ tabs, int64_t B, int acc_mode, RqsParams<float> p) {
+                const int *__restrict__ table, const float *__restrict__ tabs, const float *__restrict__ lu_lad, int64_t B,
+                int acc_mode, RqsParams<float> p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -120,8 +135,10 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
     float *acts = lds;                                       // [Hp / 8 k-groups][2][64][4]
     float *xreg = lds + (size_t)(Hp / 8) * 512;              // [Dp / 8][2][64][4]
     float *ldp = acts + NW_TAB_FLOATS;                       // log-det partials [G + 8][64], behind the staged tables
-    const int nitems = (1 + 2 * NB) * NHI + nfi;
-    const int *items = table + MF_HDR + w * nitems * 3;      // [nitems][nkg, rb | g, sb0]
+    const int nitems = (1 + 2 * NB) * NHI + nfi + (LU ? 1 : 0);
+    const int *items_all = table + MF_HDR + w * nitems * 3;  // [nitems][nkg, rb | g, sb0]
+    const int *items = items_all + ((LU && DIR == 0) ? 3 : 0);   // the network's items (the density direction's LU entry comes first)
+    const float lu_ld = LU ? (DIR == 0 ? lu_lad[0] : -lu_lad[0]) : 0.0f;
     const float *stream = blob + table[16 + w];
     const int lane_b = (64 * hh + n) * 4;
     const int64_t ntiles = (B + MF_ROWS - 1) / MF_ROWS;
@@ -147,6 +164,10 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
             }
         }
         float ld_ident = 0.0f;
+        if constexpr (LU && DIR == 0) {
+            MF_BARRIER();
+            nw_lu_stage(ring, items_all, xreg, lane_b, hh, n);
+        }
         if constexpr (DIR == 1) {                            // sampling: the identity half's inverse spline comes first (:112-114)
             for (int i = tid; i < nI * NW_TABW; i += 64 * MF_NW) acts[i] = tabs[i];
             MF_BARRIER();
@@ -230,8 +251,9 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
         }
         ldp[(G + (tid >> 6)) * 64 + (tid & 63)] = ld_ident;
         MF_BARRIER();
+        if constexpr (LU && DIR == 1) nw_lu_stage(ring, items_all + 3 * (nitems - 1), xreg, lane_b, hh, n);
         if (tid < nrows) {
-            float v = 0.0f;
+            float v = lu_ld;
             for (int s = 0; s < G + 8; ++s) v += ldp[s * 64 + tid];      // fixed order: deterministic
             ld_store(logdet + row0 + tid, v, acc_mode);
         }
@@ -251,18 +273,18 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
     }
 }
 
-template <int NHI, int NS, int DIR>
-static int nsf_wide_launch(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, const void *tabs, int64_t B,
-                           int Hp, int acc, const RqsParams<float> &p, hipStream_t st) {
+template <int NHI, int NS, int DIR, bool LU>
+static int nsf_wide_launch(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, const void *tabs,
+                           const void *lu_lad, int64_t B, int Hp, int acc, const RqsParams<float> &p, hipStream_t st) {
     const int64_t ntiles = (B + MF_ROWS - 1) / MF_ROWS;
     const int grid = (int)(ntiles < 256 ? ntiles : 256);
     size_t act_floats = (size_t)(Hp / 8) * 512;
     if (act_floats < (size_t)NW_TAB_FLOATS + (16 + 8) * 64) act_floats = (size_t)NW_TAB_FLOATS + (16 + 8) * 64;
     const size_t lds = sizeof(float) * (act_floats + MF_XFLOATS);
     static LdsOptIn opted;
-    if (opt_in_lds(reinterpret_cast<const void *>(&nsf_wide_kernel<NHI, NS, DIR>), lds, opted) != NF_OK) return NF_ENOTSUP;
-    hipLaunchKernelGGL((nsf_wide_kernel<NHI, NS, DIR>), dim3((unsigned)grid), dim3(64 * MF_NW), lds, st, (const float *)x, (float *)y,
-                       (float *)logdet, (const float *)blob, (const int *)table, (const float *)tabs, B, acc, p);
+    if (opt_in_lds(reinterpret_cast<const void *>(&nsf_wide_kernel<NHI, NS, DIR, LU>), lds, opted) != NF_OK) return NF_ENOTSUP;
+    hipLaunchKernelGGL((nsf_wide_kernel<NHI, NS, DIR, LU>), dim3((unsigned)grid), dim3(64 * MF_NW), lds, st, (const float *)x, (float *)y,
+                       (float *)logdet, (const float *)blob, (const int *)table, (const float *)tabs, (const float *)lu_lad, B, acc, p);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -283,10 +305,19 @@ extern "C" int nf_nsf_wide_tables(const void *uw, const void *uh, const void *ud
     return NF_OK;
 }
 
-// The coupling layer in one launch; blob / table: flows/nsf_wide_pack.pack_nsf_wide; tabs: nf_nsf_wide_tables.
-extern "C" int nf_nsf_wide(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, const void *tabs, int64_t B,
-                           int D, int hidden_padded, int direction, int acc, double tail_bound, double min_bin_width,
-                           double min_bin_height, double min_derivative, nf_stream_t stream) {
+template <int DIR, bool LU>
+static int nsf_wide_dispatch(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, const void *tabs,
+                             const void *lu_lad, int64_t B, int Hp, int acc, const nf::RqsParams<float> &p, hipStream_t st) {
+    if (Hp == 128) return nf::nsf_wide_launch<1, 1, DIR, LU>(x, y, logdet, blob, table, tabs, lu_lad, B, Hp, acc, p, st);
+    if (Hp == 256) return nf::nsf_wide_launch<1, 2, DIR, LU>(x, y, logdet, blob, table, tabs, lu_lad, B, Hp, acc, p, st);
+    return nf::nsf_wide_launch<2, 2, DIR, LU>(x, y, logdet, blob, table, tabs, lu_lad, B, Hp, acc, p, st);
+}
+
+// The coupling layer in one launch; blob / table: flows/nsf_wide_pack.pack_nsf_wide (packed for THIS direction when it carries the
+// adjacent LULinearPermute); tabs: nf_nsf_wide_tables; lu_logdet: device scalar log|det| of the LU layer, or NULL (no LU in the pack).
+extern "C" int nf_nsf_wide(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, const void *tabs,
+                           const void *lu_logdet, int64_t B, int D, int hidden_padded, int direction, int acc, double tail_bound,
+                           double min_bin_width, double min_bin_height, double min_derivative, nf_stream_t stream) {
     if (B < 0 || D < 2 || D > 128 || direction < 0 || direction > 1) return NF_EINVAL;
     if (acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
     if (hidden_padded != 128 && hidden_padded != 256 && hidden_padded != 512) return NF_ENOTSUP;
@@ -297,11 +328,9 @@ extern "C" int nf_nsf_wide(const void *x, void *y, void *logdet, const void *blo
     hipStream_t st = (hipStream_t)stream;
     const int Hp = hidden_padded;
     if (direction == 0) {
-        if (Hp == 128) return nf::nsf_wide_launch<1, 1, 0>(x, y, logdet, blob, table, tabs, B, Hp, acc, p, st);
-        if (Hp == 256) return nf::nsf_wide_launch<1, 2, 0>(x, y, logdet, blob, table, tabs, B, Hp, acc, p, st);
-        return nf::nsf_wide_launch<2, 2, 0>(x, y, logdet, blob, table, tabs, B, Hp, acc, p, st);
+        if (lu_logdet) return nsf_wide_dispatch<0, true>(x, y, logdet, blob, table, tabs, lu_logdet, B, Hp, acc, p, st);
+        return nsf_wide_dispatch<0, false>(x, y, logdet, blob, table, tabs, nullptr, B, Hp, acc, p, st);
     }
-    if (Hp == 128) return nf::nsf_wide_launch<1, 1, 1>(x, y, logdet, blob, table, tabs, B, Hp, acc, p, st);
-    if (Hp == 256) return nf::nsf_wide_launch<1, 2, 1>(x, y, logdet, blob, table, tabs, B, Hp, acc, p, st);
-    return nf::nsf_wide_launch<2, 2, 1>(x, y, logdet, blob, table, tabs, B, Hp, acc, p, st);
+    if (lu_logdet) return nsf_wide_dispatch<1, true>(x, y, logdet, blob, table, tabs, lu_logdet, B, Hp, acc, p, st);
+    return nsf_wide_dispatch<1, false>(x, y, logdet, blob, table, tabs, nullptr, B, Hp, acc, p, st);
 }

@@ -342,6 +342,21 @@ class LULinearPermute(Flow):
                                      lin.upper_entries.detach(), lin.unconstrained_upper_diag.detach(),
                                      lin.bias.detach(), 0 if inverse else 1, eps=lin.eps, logdet=ld, acc=acc)
 
+    def _dense_matrices(self):
+        """(Wd, Ws, bias_d, bias_s, log|det|) on the device, cached per parameter version: density y = Wd x + bias_d, sampling
+        y = Ws x + bias_s (the dense form of mixing.py:402-473, :535-563 used by nf_rows_matvec_affine and by the fused pair kernels)."""
+        lin = self.linear
+        params = (lin.lower_entries, lin.upper_entries, lin.unconstrained_upper_diag, lin.bias)
+        key = tuple((p_.data_ptr(), p_._version) for p_ in params)
+        cache = self.__dict__.get("_dense_cache")
+        if cache is None or cache[0] != key:
+            if lin.features <= 64:
+                val = ops.lu_compose(self.permutation._permutation, *[p_.detach() for p_ in params], eps=lin.eps)
+            else:
+                val = self._compose_wide()
+            cache = self._dense_cache = (key, val)
+        return cache[1]
+
     def _compose_wide(self):
         """(Wd, Ws, bias_d, bias_s, log|det|) of mixing.py:402-473, :535-563 as dense matrices, float64 arithmetic on the device:
         density y = L (U x[perm]) + b -> Wd[:, perm] = L U; sample y[perm] = U^-1 L^-1 (x - b) -> Ws[perm] = U^-1 L^-1, bias_s = -Ws b."""

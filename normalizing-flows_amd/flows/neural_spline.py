@@ -324,9 +324,10 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
         return self._sample(inputs, context)
 
     # -- shapes beyond the benchmark kernel's (D <= 128, hidden <= 512): the whole layer as one launch (csrc/nsf_wide.hip) ---
-    def _wide_pack(self, inputs, context):
+    def _wide_pack(self, inputs, context, lu=None, direction=0):
         """Device copies of flows/nsf_wide_pack.py's streams + the batch-shared spline's knot tables, rebuilt when a parameter
-        changes; None when the layer is outside nf_nsf_wide's structure (then: library GEMMs + nf_rqs_coupling)."""
+        changes; None when the layer is outside nf_nsf_wide's structure (then: library GEMMs + nf_rqs_coupling).  With `lu` (the
+        adjacent LULinearPermute, D <= 128) the pack carries its dense matrix for `direction` and the pair runs as one launch."""
         if not (self.use_fused and _config.nsf_wide and context is None and inputs.dim() == 2 and inputs.dtype == torch.float32
                 and inputs.is_cuda):
             return None
@@ -334,24 +335,33 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
         if u is None or not isinstance(net, ResidualNet):
             return None
         tensors = list(net.parameters()) + [u.unnormalized_widths, u.unnormalized_heights, u.unnormalized_derivatives]
+        if lu is not None:
+            lin = lu.linear
+            tensors = tensors + [lin.lower_entries, lin.upper_entries, lin.unconstrained_upper_diag, lin.bias]
         key = tuple((t.data_ptr(), t._version) for t in tensors) + (str(inputs.device),)
-        cache = self.__dict__.get("_wide_cache")
+        caches = self.__dict__.setdefault("_wide_cache", {})
+        slot = (id(lu), direction) if lu is not None else None
+        cache = caches.get(slot)
         if cache is None or cache[0] != key:
             from . import nsf_wide_pack
-            packed = nsf_wide_pack.pack_nsf_wide(self)
+            lu_np = lad = None
+            if lu is not None:
+                Wd, Ws, bd, bs, lad = lu._dense_matrices()
+                lu_np = (Wd.cpu().numpy(), bd.cpu().numpy()) if direction == 0 else (Ws.cpu().numpy(), bs.cpu().numpy())
+            packed = nsf_wide_pack.pack_nsf_wide(self, lu=lu_np, direction=direction)
             if packed is not None:
                 blob, table = packed
                 tabs = ops.nsf_wide_tables(u.unnormalized_widths.detach(), u.unnormalized_heights.detach(),
                                            u.unnormalized_derivatives.detach(), self.num_bins, self.tail_bound, self.min_bin_width,
                                            self.min_bin_height, self.min_derivative)
-                packed = (torch.from_numpy(blob).to(inputs.device), torch.from_numpy(table).to(inputs.device), tabs, int(table[3]))
-            cache = self.__dict__["_wide_cache"] = (key, packed)
+                packed = (torch.from_numpy(blob).to(inputs.device), torch.from_numpy(table).to(inputs.device), tabs, int(table[3]), lad)
+            cache = caches[slot] = (key, packed)
         return cache[1]
 
     def _wide(self, inputs, packed, direction, ld, acc):
-        blob, table, tabs, hp = packed
+        blob, table, tabs, hp, lad = packed
         return ops.nsf_wide(inputs, blob, table, tabs, hp, direction, self.tail_bound, self.min_bin_width, self.min_bin_height,
-                            self.min_derivative, logdet=ld, acc=acc)
+                            self.min_derivative, logdet=ld, acc=acc, lu_logdet=lad)
 
     # -- images (nsf/coupling.py:150-160): every pixel is a row of C channel features for the 2-D coupling kernel ----
     def _image(self, inputs, context, sample, ld, acc):
@@ -772,11 +782,20 @@ class CoupledRationalQuadraticSpline(Flow):
         p = self.prqct
         if needs_grad(z, self, lu):
             return False
-        return (p.use_fused and p._fused_eligible(z, None) and lu.linear.features == p.features
-                and lu.linear.bias.dtype == torch.float32 and lu.linear.bias.is_cuda)
+        if not (lu.linear.features == p.features and lu.linear.bias.dtype == torch.float32 and lu.linear.bias.is_cuda):
+            return False
+        if p.use_fused and p._fused_eligible(z, None):
+            return True
+        # beyond the benchmark kernel's shapes: nf_nsf_wide with the LU layer's dense matrix in the same launch
+        return p.features <= 128 and lu.use_dense and p._wide_pack(z, None) is not None
 
     def _run_pair(self, z, lu, inverse, ld, acc):
-        y, _ = self.prqct._fused(z, 0 if inverse else 1, ld, acc, lu=lu)
+        p = self.prqct
+        if p.use_fused and p._fused_eligible(z, None):
+            y, _ = p._fused(z, 0 if inverse else 1, ld, acc, lu=lu)
+            return y
+        direction = 0 if inverse else 1
+        y, _ = p._wide(z, p._wide_pack(z, None, lu=lu, direction=direction), direction, ld, acc)
         return y
 
 

@@ -16,8 +16,14 @@ rows, nsf/coupling.py:334-339).  Geometry (csrc/mlp_tile.hpp, nsf_wide.hip):
   * an item's stream = its bias group(s) (4 KB per row-block) followed, per k-group, by one 1 KB A fragment per row-block; a wave's
     stream = its items in consumption order + a copy of its first 8 entries (the register ring wraps into the next tile).
 
-int32 table : hdr[32] = [D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, total floats, nhi, 0..], hdr[16 + w] = offset (floats) of wave
-              w's stream; then per wave (1 + 2 NB) nhi hidden entries [nkg, rb, sb0] and nfi final entries [nkg, g, 0] (g = -1: none).
+  * optionally the adjacent LULinearPermute (mixing.py:535-563) as ONE dense D x D product on the tile (W, b composed in float64 by
+    the layer: density y = L U x[perm] + b, sampling y = P^T U^-1 L^-1 (x - b)): an item of row-block w & 3 (32 output columns) for
+    sample block w >> 2, FIRST in the stream in the density direction (core.py:193-195 visits the LU layer before its coupling
+    layer), LAST in the sampling direction -- so a pack is per direction.
+
+int32 table : hdr[32] = [D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, total floats, nhi, has_lu, 0..], hdr[16 + w] = offset (floats)
+              of wave w's stream; then per wave: [LU entry (density)] | (1 + 2 NB) nhi hidden entries [nkg, rb, sb0] | nfi final
+              entries [nkg, g, 0] (g = -1: none) | [LU entry (sampling)]; LU entry = [nkg, rb, sb0] (rb = -1: none).
 """
 import numpy as np
 import torch
@@ -75,8 +81,9 @@ def supported(prqct):
     return alt0 or alt1
 
 
-def pack_nsf_wide(prqct):
-    """(blob float32 ndarray, table int32 ndarray) or None (the caller keeps the layer-wise path)."""
+def pack_nsf_wide(prqct, lu=None, direction=0):
+    """(blob float32 ndarray, table int32 ndarray) or None (the caller keeps the layer-wise path).  lu = (W (D, D), b (D,)) numpy
+    arrays of the adjacent LULinearPermute in `direction` (0 density, 1 sampling), or None."""
     if not supported(prqct):
         return None
     net = prqct.transform_net
@@ -120,37 +127,58 @@ def pack_nsf_wide(prqct):
                     BF[g, r3, rho] = bf[row] * sc
 
     nhl = 1 + 2 * NB
-    nitems = nhl * nhi + nfi
+    has_lu = lu is not None
+    nitems = nhl * nhi + nfi + (1 if has_lu else 0)
+    base = 1 if (has_lu and direction == 0) else 0
+    if has_lu:
+        WL = np.zeros((Dp, Dp), dtype=np.float32)
+        WL[:D, :D] = np.asarray(lu[0], dtype=np.float32)
+        bL = np.zeros(Dp, dtype=np.float32)
+        bL[:D] = np.asarray(lu[1], dtype=np.float32)
     hdr = np.zeros(HDR, dtype=np.int32)
     tab = np.zeros((8, nitems, 3), dtype=np.int32)
     chunks, off = [], 0
+
+    def lu_item(w, stream, idx):
+        rb, sb0 = w & 3, w >> 2
+        if rb >= Dp // ROWS:
+            tab[w, idx] = (0, -1, 0)
+            return
+        tab[w, idx] = (Dp // KG, rb, sb0)
+        stream.append(bias_group(bL[rb * ROWS:(rb + 1) * ROWS]))
+        stream.append(a_stream(WL[rb * ROWS:(rb + 1) * ROWS]))
+
     for w in range(8):
         hdr[16 + w] = off
         stream = []
+        if has_lu and direction == 0:
+            lu_item(w, stream, 0)
         for l in range(nhl):
             Wl, bl = layers[l]
             nkg = Wl.shape[1] // KG
             for i in range(nhi):
                 rb, sb0 = hidden_item(Hp, w, i)
-                tab[w, l * nhi + i] = (nkg, rb, sb0)
+                tab[w, base + l * nhi + i] = (nkg, rb, sb0)
                 stream.append(bias_group(bl[rb * ROWS:(rb + 1) * ROWS]))
                 stream.append(a_stream(Wl[rb * ROWS:(rb + 1) * ROWS]))
         for j in range(nfi):
             g = w + 8 * j
             if g >= G:
-                tab[w, nhl * nhi + j] = (0, -1, 0)
+                tab[w, base + nhl * nhi + j] = (0, -1, 0)
                 continue
             nkg = Hp // KG
-            tab[w, nhl * nhi + j] = (nkg, g, 0)
+            tab[w, base + nhl * nhi + j] = (nkg, g, 0)
             for r3 in range(3):
                 stream.append(bias_group(BF[g, r3]))
             frag = np.stack([a_stream(WF[g, r3]).reshape(nkg, 256) for r3 in range(3)], axis=1)   # [nkg][3][256]
             stream.append(frag.reshape(-1))
+        if has_lu and direction == 1:
+            lu_item(w, stream, nitems - 1)
         stream = np.concatenate(stream)
         stream = np.concatenate([stream, np.resize(stream, RING * 256)])
         chunks.append(stream)
         off += stream.size
-    hdr[:13] = [D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, off, nhi]
+    hdr[:14] = [D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, off, nhi, int(has_lu)]
     blob = np.concatenate(chunks).astype(np.float32)
     assert blob.size == off and off < 2 ** 31
     return blob, np.concatenate([hdr, tab.reshape(-1)]).astype(np.int32)

@@ -816,10 +816,10 @@ def nsf_wide_tables(uw, uh, ud, K, tail_bound, min_bin_width=1e-3, min_bin_heigh
 
 
 def nsf_wide(x, blob, table, tabs, hidden_padded, direction, tail_bound, min_bin_width=1e-3, min_bin_height=1e-3,
-             min_derivative=1e-3, logdet=None, acc=None):
+             min_derivative=1e-3, logdet=None, acc=None, lu_logdet=None):
     """CoupledRationalQuadraticSpline beyond the benchmark kernel's shapes as one launch (nf_nsf_wide); blob / table from
-    flows/nsf_wide_pack.pack_nsf_wide, tabs from nsf_wide_tables."""
-    L.require_device(x, blob, table, tabs)
+    flows/nsf_wide_pack.pack_nsf_wide, tabs from nsf_wide_tables; lu_logdet: device scalar of the LULinearPermute packed with it."""
+    L.require_device(x, blob, table, tabs, lu_logdet)
     if x.dtype != torch.float32:
         raise NotImplementedError("nsf_wide: float32 only")
     B, D = x.shape
@@ -830,7 +830,7 @@ def nsf_wide(x, blob, table, tabs, hidden_padded, direction, tail_bound, min_bin
         acc = L.LD_WRITE
     elif acc is None:
         acc = L.LD_ADD
-    rc = L.lib().nf_nsf_wide(ptr(x), ptr(y), ptr(logdet), ptr(blob), ptr(table), ptr(tabs), i64(B), i32(D), i32(hidden_padded),
+    rc = L.lib().nf_nsf_wide(ptr(x), ptr(y), ptr(logdet), ptr(blob), ptr(table), ptr(tabs), ptr(lu_logdet), i64(B), i32(D), i32(hidden_padded),
                              i32(direction), i32(acc), f64(float(tail_bound)), f64(min_bin_width), f64(min_bin_height),
                              f64(min_derivative), L.stream())
     L.check(rc, "nf_nsf_wide")

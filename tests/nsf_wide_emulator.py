@@ -16,13 +16,15 @@ def _bias(g):
     return g[:, :, 0, :].reshape(32)
 
 
-def emulate_conditioner(blob, table, x):
-    """(B, nT, 24) parameter lists as the kernel's lanes hold them (widths / heights still carry log2(e) / sqrt(hidden)), from
-    full rows x (B, D)."""
+def emulate_conditioner(blob, table, x, direction=0):
+    """((B, nT, 24) parameter lists as the kernel's lanes hold them (widths / heights still carry log2(e) / sqrt(hidden)), LU output
+    (B, D) or None), from full rows x (B, D).  With a fused LU: density = LU(x) first and the conditioner sees ITS output; sampling =
+    the LU item comes last in the streams and is applied to x here only to check its packing."""
     blob = blob.astype(np.float64)
-    D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, total, nhi = [int(v) for v in table[:13]]
+    D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, total, nhi, has_lu = [int(v) for v in table[:14]]
     nhl = 1 + 2 * NB
-    nitems = nhl * nhi + nfi
+    nitems = nhl * nhi + nfi + has_lu
+    base = 1 if (has_lu and direction == 0) else 0
     tab = table[HDR:HDR + 8 * nitems * 3].reshape(8, nitems, 3)
     x = np.asarray(x, dtype=np.float64)
     B = x.shape[0]
@@ -31,11 +33,28 @@ def emulate_conditioner(blob, table, x):
     pos = [int(table[16 + w]) for w in range(8)]
     start = list(pos)
 
+    def lu_stage(idx, act):
+        out = np.zeros((B, Dp))
+        for w in range(8):
+            nkg, rb, sb0 = [int(v) for v in tab[w, idx]]
+            if rb < 0:
+                continue
+            assert rb == (w & 3) and sb0 == (w >> 2) and KG * nkg == Dp
+            acc = np.tile(_bias(blob[pos[w]:pos[w] + 1024]), (B, 1)) + act @ _rows(blob[pos[w] + 1024:pos[w] + 1024 + 256 * nkg], nkg).T
+            pos[w] += 1024 + 256 * nkg
+            out[:, rb * ROWS:(rb + 1) * ROWS] = acc
+        return out
+
+    lu_out = None
+    if has_lu and direction == 0:
+        xin = lu_stage(0, xin)
+        lu_out = xin[:, :D].copy()
+
     def hidden_layer(l, act):
         out = np.full((B, Hp), np.nan)
         for w in range(8):
             for i in range(nhi):
-                nkg, rb, sb0 = [int(v) for v in tab[w, l * nhi + i]]
+                nkg, rb, sb0 = [int(v) for v in tab[w, base + l * nhi + i]]
                 acc = np.tile(_bias(blob[pos[w]:pos[w] + 1024]), (B, 1))
                 pos[w] += 1024
                 assert KG * nkg == act.shape[1]
@@ -55,7 +74,7 @@ def emulate_conditioner(blob, table, x):
     prm = np.zeros((B, 4 * G, MP))
     for w in range(8):
         for j in range(nfi):
-            nkg, g, _ = [int(v) for v in tab[w, nhl * nhi + j]]
+            nkg, g, _ = [int(v) for v in tab[w, base + nhl * nhi + j]]
             if g < 0:
                 continue
             acc = np.zeros((3, B, ROWS))
@@ -71,8 +90,10 @@ def emulate_conditioner(blob, table, x):
                     q, hh, i = rho >> 3, (rho >> 2) & 1, rho & 3
                     v = 16 * r3 + 4 * q + i
                     prm[:, 4 * g + 2 * hh + v // MP, v % MP] = acc[r3][:, rho]
+    if has_lu and direction == 1:
+        lu_out = lu_stage(nitems - 1, xin)[:, :D]
     for w in range(8):
         n = pos[w] - start[w]
         assert np.array_equal(blob[pos[w]:pos[w] + RING * 256], np.resize(blob[start[w]:pos[w]], RING * 256)), w
         assert pos[w] + RING * 256 == (int(table[16 + w + 1]) if w < 7 else total) and n > 0
-    return prm[:, :nT]
+    return prm[:, :nT], lu_out

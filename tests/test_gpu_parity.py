@@ -1195,6 +1195,44 @@ def test_nsf_wide_one_launch_vs_layerwise_and_oracle(nfa, oracle, D, H, NB, rev,
         assert np.quantile(el, 0.99) < 2e-4 and el.max() < 5e-3, (name, float(np.quantile(el, 0.99)), float(el.max()))
 
 
+@pytest.mark.parametrize("D,H", [(64, 256), (128, 128), (96, 192), (33, 300)])
+def test_nsf_wide_pairs_with_fused_lu_vs_layerwise(nfa, D, H):
+    """[CoupledRationalQuadraticSpline, LULinearPermute] pairs beyond the benchmark kernel's shapes: nf_nsf_wide with the LU layer's
+    dense matrix in the same launch (density: LU first, core.py:193-195; sampling: LU last, core.py:177-179) against the layer-wise
+    path on a 3-pair model: log_prob, sample, log_prob(sample) = log_q (core_test.py:144-196)."""
+    torch.manual_seed(D + H)
+    flows = []
+    for _ in range(3):
+        flows += [nfa.flows.CoupledRationalQuadraticSpline(D, 2, H, num_bins=8), nfa.flows.LULinearPermute(D, identity_init=False)]
+    m = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(D, trainable=False), flows)
+    _perturb(m, 0.03, 5)
+    m = m.to(DEV)
+    x = torch.randn(1000, D, generator=torch.Generator().manual_seed(2)).to(DEV)
+    eps = torch.randn(777, D, generator=torch.Generator().manual_seed(3)).to(DEV)
+    lp1 = m.log_prob(x)
+    xs1, lq1 = m.sample_from_noise(eps)
+    nfa.config.set_nsf_wide(False)
+    try:
+        lp0 = m.log_prob(x)
+        xs0, lq0 = m.sample_from_noise(eps)
+    finally:
+        nfa.config.set_nsf_wide(True)
+    assert _rel(N(lp1), N(lp0)) < 1e-4, _rel(N(lp1), N(lp0))
+    assert_close(N(xs1), N(xs0), what="sample", rtol=1e-4, atol=1e-4)
+    assert _rel(N(lq1), N(lq0)) < 1e-4
+    assert _rel(N(m.log_prob(xs1)), N(lq1)) < 1e-4
+    # a parameter update of the LU layer invalidates the pair's pack
+    with torch.no_grad():
+        flows[1].linear.bias.add_(0.05)
+    lp2 = m.log_prob(x)
+    nfa.config.set_nsf_wide(False)
+    try:
+        lp3 = m.log_prob(x)
+    finally:
+        nfa.config.set_nsf_wide(True)
+    assert _rel(N(lp2), N(lp3)) < 1e-4 and _rel(N(lp2), N(lp1)) > 1e-6
+
+
 @pytest.mark.parametrize("D,H,NB,B", [(128, 512, 2, 300), (128, 512, 2, 64), (20, 40, 2, 130), (6, 300, 1, 7), (33, 256, 3, 65),
                                       (3, 2, 2, 1), (64, 257, 2, 129), (127, 512, 1, 4100)])
 def test_made_forward_one_launch_vs_layerwise(nfa, D, H, NB, B):

@@ -701,14 +701,35 @@ def test_nsf_wide_pack_matches_dense_conditioner(D, H, NB, rev):
     assert table[0] == D and table[3] in (128, 256, 512) and table[3] >= H and blob.size % 256 == 0
     x = torch.randn(5, D)
     nT = len(prqct.transform_features)
-    with torch.no_grad():
-        ref = prqct.transform_net.double()(x.double().index_select(1, prqct.identity_features)).numpy().reshape(5, nT, 23)
-    got = emulate_conditioner(blob, table, x.numpy())
+    import copy
+    net64 = copy.deepcopy(prqct.transform_net).double()
     sc = 1.4426950408889634 / np.sqrt(float(H))
-    ref_s = ref.copy()
-    ref_s[:, :, :16] *= sc
+
+    def reference(rows):
+        with torch.no_grad():
+            r = net64(rows.double().index_select(1, prqct.identity_features)).numpy().reshape(5, nT, 23).copy()
+        r[:, :, :16] *= sc
+        return r
+
+    got, lu_out = emulate_conditioner(blob, table, x.numpy())
+    ref_s = reference(x)
+    assert lu_out is None
     assert np.max(np.abs(got[:, :, :23] - ref_s)) < 1e-5 * max(1.0, np.abs(ref_s).max())     # (the scale is applied in float32)
     assert np.all(got[:, :, 23] == 0.0)
+    # with the adjacent LULinearPermute as a dense product: first in the density direction, last in the sampling direction
+    g = torch.Generator().manual_seed(1)
+    Wl, bl = torch.randn(D, D, generator=g) / np.sqrt(D), torch.randn(D, generator=g)
+    xl = (x.double() @ Wl.double().T + bl.double())
+    blob, table = nsf_wide_pack.pack_nsf_wide(prqct, lu=(Wl.numpy(), bl.numpy()), direction=0)
+    got, lu_out = emulate_conditioner(blob, table, x.numpy(), 0)
+    assert np.max(np.abs(lu_out - xl.numpy())) < 1e-5
+    ref_s = reference(xl.float())
+    assert np.max(np.abs(got[:, :, :23] - ref_s)) < 1e-4 * max(1.0, np.abs(ref_s).max())
+    blob, table = nsf_wide_pack.pack_nsf_wide(prqct, lu=(Wl.numpy(), bl.numpy()), direction=1)
+    got, lu_out = emulate_conditioner(blob, table, x.numpy(), 1)
+    assert np.max(np.abs(lu_out - xl.numpy())) < 1e-5
+    ref_s = reference(x)
+    assert np.max(np.abs(got[:, :, :23] - ref_s)) < 1e-5 * max(1.0, np.abs(ref_s).max())
 
 
 def test_nsf_wide_pack_rejects_unsupported():

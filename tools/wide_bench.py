@@ -13,7 +13,11 @@ import normflows_amd as nfa                      # noqa: E402
 dev = torch.device("cuda:0")
 torch.set_grad_enabled(False)
 B, pairs, out = 65536, 4, []
-for D, hidden in ((64, 128), (64, 256), (128, 128), (128, 256), (96, 192)):
+shapes = ((64, 128), (64, 256), (128, 128), (128, 256), (96, 192))
+if "--only" in sys.argv:
+    i = sys.argv.index("--only")
+    shapes = ((int(sys.argv[i + 1]), int(sys.argv[i + 2])),)
+for D, hidden in shapes:
     torch.manual_seed(0)
     flows = []
     for _ in range(pairs):
