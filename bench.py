@@ -240,6 +240,11 @@ def secondary(model, x):
                              "statistic": "mean of 10 back-to-back steps", "ms_median_synchronised": med * 1e3,
                              "ms_min_synchronised": ts[0] * 1e3, "ms_max_synchronised": ts[-1] * 1e3, "steps": steps,
                              "samples_per_s": x.shape[0] / dt, "loss": float(loss.detach()),
+                             # forward + backward = 3 x the forward pass's FLOP (input and weight gradients each repeat its products)
+                             "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.3,
+                                          "achieved": 3 * c2_flops_per_sample(layers=len(model.flows) // 2) * x.shape[0] / dt / 1e12,
+                                          "frac": 3 * c2_flops_per_sample(layers=len(model.flows) // 2) * x.shape[0] / dt / 157.3e12,
+                                          "flop_per_step": 3 * c2_flops_per_sample(layers=len(model.flows) // 2) * x.shape[0]},
                              "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
     except Exception as exc:   # noqa: BLE001
         res["train_step"] = {"error": repr(exc)[:200]}

@@ -2,7 +2,9 @@
 
 The path is embarrassingly parallel over samples: no data-path collective.  The only
 exchange is ONE all-reduce of the fp64 pair [sum log_q, row count] (16 bytes) per evaluated batch for the NLL -- RCCL over
-xGMI when the process group backend is "nccl", gloo in the CPU tests.  The reference has no distributed code
+xGMI when the process group backend is "nccl", gloo in the CPU tests.  Training adds the gradient average: bucketed all-reduces
+started from autograd hooks while backward is still running (OverlappedGradientAverager), or one call after it
+(allreduce_gradients, optionally on ONE persistent flat buffer: FlatGradients).  The reference has no distributed code
 (`grep torch.distributed normflows/` is empty); semantics are those of core.py:87-102 `-mean(log_q)` over the
 GLOBAL batch.
 """
@@ -44,11 +46,145 @@ def sharded_forward_kld(log_prob_fn, x_local, group=None):
     return global_nll(log_prob_fn(x_local), group=group)
 
 
+class FlatGradients:
+    """ONE persistent flat gradient buffer per dtype; every parameter's `.grad` is a view into it.  autograd accumulates into the
+    views in place, `zero()` is one memset instead of one launch per parameter, and `allreduce()` hands the buffer itself to the
+    collective (bucket_bytes-sized views of it: no torch.cat, no copy back) -- for the benchmark model 21.8 MB per step that the
+    bucketed path below gathers and scatters again.  Keep gradients allocated: `optimizer.zero_grad(set_to_none=False)` or
+    `FlatGradients.zero()`; a `.grad` that was replaced (set_to_none=True, or assigned by hand) is re-attached by `attach()`."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        self.flat = {}
+        self.views = []
+        groups = {}
+        for p in self.params:
+            groups.setdefault((p.dtype, p.device), []).append(p)
+        for key, ps in groups.items():
+            n = sum(p.numel() for p in ps)
+            buf = torch.zeros(n, dtype=key[0], device=key[1])
+            self.flat[key] = buf
+            off = 0
+            for p in ps:
+                self.views.append((p, buf[off:off + p.numel()].view_as(p)))
+                off += p.numel()
+        self.attach()
+
+    def attach(self):
+        """(Re-)install the views as the parameters' gradients; an existing foreign gradient is copied in first."""
+        for p, v in self.views:
+            if p.grad is not v:
+                if p.grad is not None:
+                    v.copy_(p.grad)
+                p.grad = v
+
+    def zero(self):
+        self.attach()
+        for buf in self.flat.values():
+            buf.zero_()
+
+    def allreduce(self, group=None, bucket_bytes=64 << 20):
+        """Average over the ranks: all_reduce(SUM) on <= bucket_bytes views of the flat buffers, then one scale.  Returns the
+        number of collectives (0 without a process group of more than one rank)."""
+        if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+            return 0
+        self.attach()
+        world = dist.get_world_size(group)
+        n_coll = 0
+        for buf in self.flat.values():
+            step = max(1, bucket_bytes // buf.element_size())
+            for lo in range(0, buf.numel(), step):
+                dist.all_reduce(buf[lo:lo + step], op=dist.ReduceOp.SUM, group=group)
+                n_coll += 1
+            buf.div_(world)
+        return n_coll
+
+
+class OverlappedGradientAverager:
+    """Gradient averaging OVERLAPPED with the backward pass: parameters are grouped into buckets in reverse registration order
+    (the order loss.backward() finishes them); a post-accumulate hook counts a bucket's parameters down, and the moment the last
+    one has its gradient the bucket is flattened and its all_reduce(SUM) is started asynchronously (RCCL runs it on its own
+    stream over xGMI while the remaining layers' backward kernels keep the compute queue busy).  `finish()` after backward waits
+    for the collectives, scales by 1 / world_size and scatters the averages back.  Same result as allreduce_gradients.
+
+        avg = dp.OverlappedGradientAverager(model.parameters(), bucket_bytes=8 << 20)
+        loss.backward(); avg.finish(); optimizer.step()
+
+    Without a process group of more than one rank the hooks do nothing."""
+
+    def __init__(self, params, group=None, bucket_bytes=8 << 20):
+        self.group = group
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets, cur, cur_bytes = [], [], 0
+        for p in reversed(self.params):
+            nb = p.numel() * p.element_size()
+            if cur and (cur_bytes + nb > bucket_bytes or p.dtype != cur[0].dtype):
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nb
+        if cur:
+            self.buckets.append(cur)
+        self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+        self._left = [len(b) for b in self.buckets]
+        self._pending = []          # (bucket index, flat tensor, work handle)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._ready) for p in self.params]
+
+    def _active(self):
+        return dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def _ready(self, p):
+        if not self._active():
+            return
+        i = self._bucket_of[id(p)]
+        self._left[i] -= 1
+        if self._left[i] == 0:
+            flat = torch.cat([q.grad.reshape(-1) for q in self.buckets[i]])
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._pending.append((i, flat, work))
+
+    def finish(self):
+        """Wait for the started collectives, reduce the buckets backward() did not complete (parameters without a gradient this
+        step are skipped), write the averages back.  Returns the number of collectives."""
+        if not self._active():
+            return 0
+        world = dist.get_world_size(self.group)
+        started = {i for i, _, _ in self._pending}
+        for i, b in enumerate(self.buckets):
+            if i not in started:
+                have = [q for q in b if q.grad is not None]
+                if have:
+                    flat = torch.cat([q.grad.reshape(-1) for q in have])
+                    work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    self._pending.append((-1 - i, flat, work))
+        n = len(self._pending)
+        for i, flat, work in self._pending:
+            work.wait()
+            flat.div_(world)
+            b = self.buckets[i] if i >= 0 else [q for q in self.buckets[-1 - i] if q.grad is not None]
+            off = 0
+            for q in b:
+                q.grad.copy_(flat[off:off + q.numel()].view_as(q.grad))
+                off += q.numel()
+        self._pending = []
+        self._left = [len(b) for b in self.buckets]
+        return n
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
 def allreduce_gradients(params, group=None, bucket_bytes=64 << 20):
     """Average the gradients of `params` over all ranks: flat fp32/fp64 buckets (<= bucket_bytes each, sized for
     per-link-bound ring collectives on point-to-point xGMI: few large messages), one all_reduce(SUM) per bucket, then a
     scale by 1 / world_size.  Same math as the reference's single-process `-mean(log_q)` over the global batch when
-    every rank holds an equal share of the rows.  No-op without an initialised process group."""
+    every rank holds an equal share of the rows.  No-op without an initialised process group.  `params` may be a FlatGradients
+    (gradients as views of one persistent buffer: the collective runs on the buffer itself); for plain parameter lists the
+    buckets are gathered with torch.cat and copied back."""
+    if isinstance(params, FlatGradients):
+        return params.allreduce(group=group, bucket_bytes=bucket_bytes)
     params = [p for p in params if p.grad is not None]
     if not (dist.is_initialized() and dist.get_world_size(group) > 1) or not params:
         return 0

@@ -330,6 +330,39 @@ nb = nfa.dp.allreduce_gradients(lin.parameters(), bucket_bytes=32)   # tiny buck
 assert nb >= 2
 for p in lin.parameters():
     assert torch.allclose(p.grad, torch.full_like(p, (1 + world) / 2.0))
+# the same through ONE persistent flat gradient buffer (gradients are views of it; autograd accumulates in place; the
+# collective runs on the buffer itself -- no cat, no copy back), against the bucketed result of a real backward
+torch.manual_seed(5)
+net = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.Tanh(), torch.nn.Linear(4, 2))
+fg = nfa.dp.FlatGradients(net.parameters())
+xg = torch.randn(9, 6, generator=torch.Generator().manual_seed(100 + rank))      # rank-dependent rows
+for step in range(2):
+    fg.zero()
+    net(xg).pow(2).sum().backward()
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in fg.views)           # autograd accumulated in place
+    local = [p.grad.clone() for p in net.parameters()]
+    assert nfa.dp.allreduce_gradients(fg, bucket_bytes=40) >= 2
+    ref = [g_.clone() for g_ in local]
+    for g_ in ref:
+        dist.all_reduce(g_)
+        g_.div_(world)
+    assert all(torch.allclose(p.grad, r_, atol=1e-6) for p, r_ in zip(net.parameters(), ref))
+# ... and overlapped with backward: buckets in reverse parameter order, each all-reduce started from an autograd hook as soon as
+# the bucket's last gradient exists; finish() waits, scales, scatters -- same averages
+net2 = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.Tanh(), torch.nn.Linear(4, 2))
+net2.load_state_dict(net.state_dict())
+avg = nfa.dp.OverlappedGradientAverager(net2.parameters(), bucket_bytes=40)
+assert len(avg.buckets) >= 2 and avg.buckets[0][0] is list(net2.parameters())[-1]
+for step in range(2):
+    net2.zero_grad(set_to_none=True)
+    net2(xg).pow(2).sum().backward()
+    assert len(avg._pending) == len(avg.buckets)                                  # every bucket was started DURING backward
+    assert avg.finish() == len(avg.buckets)
+    assert all(torch.allclose(p.grad, r_, atol=1e-6) for p, r_ in zip(net2.parameters(), ref))
+avg.remove()
+net.zero_grad(set_to_none=True)                                                   # a dropped view is re-attached
+fg.zero()
+assert all(p.grad is v for p, v in fg.views)
 # ActNorm data-dependent init under DP: global per-channel mean / unbiased std from the ranks' local moments
 xa = torch.randn(23, 5, 3, generator=g) * 2.0 + 0.7            # (rows, channels, pixels), same on every rank
 lo, hi = nfa.dp.shard_bounds(23, world, rank)

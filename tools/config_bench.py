@@ -88,7 +88,7 @@ def c4():
 def c5():
     """config 5: MAF 10 x MaskedAffineAutoregressive(128, hidden 512, 2 blocks), batch 65536.  inverse pass = sampling
     direction: one nf_maf_inverse launch per layer (every hidden unit finalised once); forward pass = one MADE pass per
-    layer (library GEMMs on masked weights + nf_maf_affine)."""
+    layer = one launch of nf_made_forward_affine (csrc/made_fwd.hip)."""
     torch.manual_seed(0)
     flows = [nfa.flows.MaskedAffineAutoregressive(128, 512, num_blocks=2) for _ in range(10)]
     m = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(128, trainable=False), flows).to(dev)
@@ -99,11 +99,24 @@ def c5():
         dt = timed(lambda: m.inverse_and_log_det(x), 5)
         dtf = timed(lambda: m.forward_and_log_det(z), 5)
     err = float((zf - x).abs().max())
+    # algorithmic work of ONE MADE pass = 2 FLOP per structurally non-zero weight (the masks of nets/made.py:63-81) per row; the
+    # one-pass inverse (every hidden unit finalised once) and the forward pass both do exactly one MADE pass per layer
+    nnz = 0
+    for f in flows:
+        net = f.autoregressive_net
+        for lin in [net.initial_layer, net.final_layer] + [l for b in net.blocks for l in b.linear_layers]:
+            nnz += int(lin.mask.sum().item())
+    flop = 2.0 * nnz * 65536
+
+    def roof(ms):
+        return {"bound": "mfma", "achieved": flop / ms / 1e9, "peak": 157.3, "unit": "TFLOP/s", "frac": flop / ms / 1e9 / 157.3,
+                "flop_per_pass_masked": flop}
+
     print("config 5 MAF 10 layers d=128 B=65536: inverse pass %.1f ms (%.0f samples/s), forward pass %.1f ms, round-trip max err %.2e"
           % (dt * 1e3, 65536 / dt, dtf * 1e3, err))
     return {"workload": "BASELINE configs[4]: 10 x MaskedAffineAutoregressive(128, hidden 512), batch 65536",
             "inverse_pass_ms": dt * 1e3, "forward_pass_ms": dtf * 1e3, "inverse_samples_per_s": 65536 / dt,
-            "round_trip_max_abs_err": err}
+            "round_trip_max_abs_err": err, "roofline_inverse_pass": roof(dt * 1e3), "roofline_forward_pass": roof(dtf * 1e3)}
 
 
 if __name__ == "__main__":
