@@ -9,7 +9,7 @@ The on-disk package directory is `normalizing-flows_amd/`; import it as `normflo
 at the repository root).
 """
 from . import _lib, config, ops, nets, flows, distributions, transforms, utils, dp
-from .core import NormalizingFlow, ConditionalNormalizingFlow, MultiscaleFlow
+from .core import NormalizingFlow, ConditionalNormalizingFlow, MultiscaleFlow, invalidate_caches
 from .distributions import DiagGaussian, ConditionalDiagGaussian, ClassCondDiagGaussian, GlowBase
 
 __version__ = "0.1.0"

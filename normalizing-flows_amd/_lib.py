@@ -67,6 +67,39 @@ def build(force=False, verbose=False):
     return LIBPATH
 
 
+SAFE_WAITS_LIB = os.path.join(LIBDIR, "variants", "safe_waits.so")
+
+
+def build_safe_waits(force=False):
+    """The differential build of the counted-wait lint (tests/test_gpu_hygiene.py): every source that uses NF_WAIT_VMCNT recompiled
+    with -DNF_SAFE_WAITS (each hand-counted `s_waitcnt vmcnt(N)` becomes a full drain), the other objects reused; selected at run
+    time with NF_MI355X_LIB.  Built by __graft_entry__.build() so that it travels to the GPU box with the tree."""
+    build()
+    srcs = [s for s in sources() if "NF_WAIT_VMCNT" in open(s).read()]
+    deps = srcs + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(INCLUDE, "*.h")) + [LIBPATH]
+    if not force and os.path.exists(SAFE_WAITS_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(SAFE_WAITS_LIB) for d in deps):
+        return SAFE_WAITS_LIB
+    vdir = os.path.dirname(SAFE_WAITS_LIB)
+    os.makedirs(vdir, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    procs, objs = [], []
+    for s in sources():
+        base = os.path.basename(s)[:-4]
+        if s in srcs:
+            o = os.path.join(vdir, "safe_waits_%s.o" % base)
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-DNF_SAFE_WAITS", "-c", s, "-o", o]
+            procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        else:
+            o = os.path.join(LIBDIR, "obj", base + ".o")
+        objs.append(o)
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise NativeLibraryError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode(errors="replace")))
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SAFE_WAITS_LIB] + objs)
+    return SAFE_WAITS_LIB
+
+
 def exported_symbols_declared():
     """Names of every function declared in include/nf_mi355x.h (used by the symbol-export test)."""
     import re

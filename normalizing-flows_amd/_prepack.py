@@ -73,6 +73,15 @@ def _switches(kind, layer):
     return (layer.training,)
 
 
+def _trainable(flows):
+    """Cheap eligibility fingerprint: per layer, whether its FIRST parameter requires a gradient (one attribute read per layer)."""
+    out = []
+    for f in flows:
+        p = next(f.parameters(), None)
+        out.append(None if p is None else p.requires_grad)
+    return tuple(out)
+
+
 def _plan(flows, z, sig):
     """Which layers of `flows` are packed together and the tensors of their table rows: decided once per (model, batch shape,
     training flags, configuration)."""
@@ -118,11 +127,17 @@ def begin(flows, z, inverse):
     if not (_config.train_prepack and inverse and torch.is_grad_enabled() and torch.is_tensor(z) and z.is_cuda and z.dim() == 2
             and z.dtype == torch.float32 and z.shape[0] >= 1024 and current() is None and isinstance(flows, torch.nn.Module)):
         return None
-    # the plan depends on what decides the layers' training path: shapes, configuration, the list itself
-    sig = (tuple(z.shape), z.device, _config.train_full, _config.resblock_bwd, _config.lu_bwd_fused, len(flows))
+    # the plan depends on what decides the layers' training path: shapes, configuration, the list itself -- and WHICH layers are
+    # trainable right now: a plan built while parameters were frozen (reverse_kld(score_fn=False), a freeze-then-unfreeze
+    # fine-tune) holds too few layers and would otherwise stay valid for the same batch shape forever (round-3 ADVICE)
+    sig = (tuple(z.shape), z.device, _config.train_full, _config.resblock_bwd, _config.lu_bwd_fused, len(flows), _trainable(flows))
     plan = _plans.get(flows)
     if plan is None or plan.sig != sig or not _plan_valid(plan):
-        plan = _plans[flows] = _plan(flows, z, sig)
+        plan = _plan(flows, z, sig)
+        if sum(len(es) for _, es in plan.groups) >= 2:
+            _plans[flows] = plan            # (a plan with fewer than two eligible layers is not worth a launch and is not kept)
+        else:
+            _plans.pop(flows, None)
     if sum(len(es) for _, es in plan.groups) < 2:
         return None
     token = object()

@@ -40,10 +40,11 @@ def _stamp(*tensors):
 def _check_stamp(ctx, what):
     holder = getattr(ctx, "holder", None)
     if holder is not None and holder.get("stamp") != ctx.stamp:
-        raise RuntimeError("%s: this layer ran forward again with modified parameters before the backward of an earlier forward; "
-                           "its layer-owned weight images now belong to the later call.  Run backward before the parameters "
-                           "change, or set normflows_amd.config.set_train_full(False) / set_train_prepack(False) is not enough: "
-                           "re-run the forward." % what)
+        raise RuntimeError("%s: this layer ran forward again -- with modified parameters, or through its other training path (the "
+                           "one-launch and the layer-wise path keep DIFFERENT images in the same layer-owned buffers; the stamp "
+                           "carries the path) -- before the backward of an earlier forward; the weight images that backward needs "
+                           "now belong to the later call.  Run backward before the parameters (or config.set_train_full / a "
+                           "layer's use_fused_train) change, or run the forward again." % what)
 
 
 def needs_grad(*tensors_or_modules):
@@ -146,7 +147,7 @@ class FinalSplineDensityFn(torch.autograd.Function):
         wpad[:, 23].zero_()       # (the whole-layer path's pack leaves another image of the final weight in this buffer)
         ctx.save_for_backward(x, h2, wf, cond24, uw, uh, ud, iidx, tidx)
         ctx.kw, ctx.wpad, ctx.acc, ctx.has_acc = kw, wpad, acc, ld_acc is not None
-        ctx.holder, ctx.stamp = kw.get("holder"), _stamp(wf, bf, uw, uh, ud)
+        ctx.holder, ctx.stamp = kw.get("holder"), ("final",) + _stamp(wf, bf, uw, uh, ud)
         if ctx.holder is not None:
             ctx.holder["stamp"] = ctx.stamp
         return y, ld
@@ -427,7 +428,7 @@ class CouplingTrainFn(torch.autograd.Function):
         ctx.save_for_backward(x, cond24, acts, w0, wf, uw, uh, ud, iidx, tidx, *blk)
         ctx.kw, ctx.wfull, ctx.wpad, ctx.acc, ctx.has_acc, ctx.nb = kw, wfull, wpad, acc, ld_acc is not None, nb
         ctx.blob, ctx.parity = blob, parity
-        ctx.holder, ctx.stamp = kw.get("holder"), _stamp(w0, b0, wf, bf, uw, uh, ud, *blk)
+        ctx.holder, ctx.stamp = kw.get("holder"), ("full",) + _stamp(w0, b0, wf, bf, uw, uh, ud, *blk)
         if ctx.holder is not None:
             ctx.holder["stamp"] = ctx.stamp
         return y, ld

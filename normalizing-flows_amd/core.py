@@ -21,6 +21,22 @@ from .flows.mixing import LULinearPermute
 from .flows.neural_spline import CoupledRationalQuadraticSpline
 
 
+def invalidate_caches(module):
+    """Drop every packed-weight cache under `module` (fused blobs, one-launch packs, composed LU matrices, masked weights, recorded
+    graphs).  The caches are keyed by (data_ptr, _version) of the parameters they were built from, which every in-place update
+    through the parameter itself bumps (optimizers, load_state_dict, p.add_(...), p.copy_(...)).  Updates through `.data`
+    (`p.data.add_(...)`, `p.data.copy_(...)`, hand-written SGD / EMA on .data) do NOT bump `_version`: call this afterwards, or
+    update `p` under torch.no_grad() instead."""
+    for m in module.modules():
+        for k in list(m.__dict__.keys()):
+            if k.endswith("_cache") and not k.startswith("__"):
+                v = m.__dict__[k]
+                m.__dict__[k] = {} if isinstance(v, dict) else None
+        if hasattr(m, "refresh_graphs"):
+            m.refresh_graphs()
+    _realnvp_cache.clear()
+
+
 def _pair_signature(crqs):
     p = crqs.prqct
     return (p.features, p.transform_net.hidden_features, len(p.transform_net.blocks), p.num_bins, p.tail_bound,

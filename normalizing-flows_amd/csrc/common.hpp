@@ -9,6 +9,16 @@
 #define NF_MAX_BINS 64
 #define NF_WAVE 64
 
+// Hand-counted vector-memory waits (a ring acquire that lets N younger requests stay in flight) rely on the exact number of
+// vector-memory instructions the compiler emits between a request and its wait.  -DNF_SAFE_WAITS turns every one of them into a full
+// drain: the differential build of tests/test_gpu_hygiene.py::test_counted_waits_equal_full_drains (round-3 ADVICE) -- a count that
+// a compiler upgrade made too lax shows up as a bit difference against this build.
+#ifdef NF_SAFE_WAITS
+#define NF_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define NF_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+#endif
+
 #define NF_CHECK_LAUNCH()                            \
     do {                                             \
         hipError_t e__ = hipGetLastError();          \

@@ -100,9 +100,9 @@ final_bwd_kernel(FinalBwdArgs a) {
     // 2-slot ring: stage s has landed for every wave; stage s + 1 is requested into the slot stage s - 1 just left.  `after`:
     // vector-memory operations this wave issued AFTER the requests of stage s (they retire in order, so they may stay in flight)
     auto acquire = [&](int after) -> const float * {
-        if (after == 2 * FB_NI + 9) asm volatile("s_waitcnt vmcnt(23)" ::: "memory");
-        else if (after == 2 * FB_NI) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-        else if (after == FB_NI) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        if (after == 2 * FB_NI + 9) NF_WAIT_VMCNT(23);
+        else if (after == 2 * FB_NI) NF_WAIT_VMCNT(14);
+        else if (after == FB_NI) NF_WAIT_VMCNT(7);
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // the raw barrier: __syncthreads() is a fence, and with an LDS-DMA possibly pending the compiler implements it as
         // s_waitcnt vmcnt(0) -- the counted waits above never took effect before this was found (round 3, in the Glow kernels)

@@ -319,7 +319,7 @@ __device__ __forceinline__ void gl_pre(const GlowLevel &lv, int b, const float *
     const int HW = H * W, PH = H + 2, PW = W + 2, IPW = PXW / HW, C = lv.C;
     // the prefetched sections of this block (block 0's were issued last, just before this call)
     if (b == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+    else NF_WAIT_VMCNT(INFLIGHT);
     GL_BARRIER();   // ... and zin (the level load / the previous block's output)
     const float *src = zin;
     if (lv.direction == 1) {
@@ -493,7 +493,7 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
     // operations retire in order; anything else a wave has outstanding only makes the wait stricter).  With one stage ahead
     // the L2 -> LDS latency of a stage (~2 us under load) had to fit under the 28..64 MFMAs of ONE stage: GEMM 1 ran at 2/3.
     auto acquire = [&]() -> const float * {
-        if (stage + GC_RING - 2 < all_stages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((GC_RING - 2) * PPW) : "memory");
+        if (stage + GC_RING - 2 < all_stages) NF_WAIT_VMCNT((GC_RING - 2) * PPW);
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // a raw barrier: __syncthreads() is a fence, which the compiler implements as s_waitcnt vmcnt(0) -- it waited for the
         // DMAs of ALL stages in flight at every stage and made the depth of the ring irrelevant (found in round 3)
@@ -736,7 +736,7 @@ glow_convnet_small_kernel(const float *__restrict__ x, int64_t xs_img, float *__
     auto acquire = [&]() -> const float * {
         // stages stage+1 .. stage+RING-2 may stay in flight (loads retire in order); the tail drains everything
         if (dma_wave) {
-            if (stage + GS_RING - 2 < total_stages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((GS_RING - 2) * PPW) : "memory");
+            if (stage + GS_RING - 2 < total_stages) NF_WAIT_VMCNT((GS_RING - 2) * PPW);
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         // everyone's pieces of `stage` have landed; everyone is done with stage - 1 (slot reused below).  (One barrier per

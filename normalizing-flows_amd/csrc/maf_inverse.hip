@@ -187,9 +187,9 @@ __device__ __forceinline__ void block_part_ring(const float *__restrict__ A, con
             constexpr int LPS = PAIR ? 2 : 1;
             if (kb + MRB - 1 < nkb) {
                 dma(kb + MRB - 1);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS + 8) : "memory");
+                NF_WAIT_VMCNT(3 * LPS + 8);
             } else {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS) : "memory");
+                NF_WAIT_VMCNT(3 * LPS);
             }
             const float *slot = ring + (kb % MRB) * 512 + (half * 64 + l31) * 4;
             const f32x4 b0 = *reinterpret_cast<const f32x4 *>(slot), b1 = *reinterpret_cast<const f32x4 *>(slot + 128);

@@ -81,9 +81,9 @@ __device__ __forceinline__ void h_block(const float *__restrict__ A, const float
         };
         auto step = [&](int kb, int slot) {
             const int rem = nkb - 1 - kb;       // blocks requested after this one
-            if (rem >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * OPS) : "memory");
-            else if (rem == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
-            else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
+            if (rem >= 3) NF_WAIT_VMCNT(3 * OPS);
+            else if (rem == 2) NF_WAIT_VMCNT(2 * OPS);
+            else if (rem == 1) NF_WAIT_VMCNT(OPS);
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const f32x4 b = *reinterpret_cast<const f32x4 *>(ring + slot * 256 + lane * 4);
             const f32x4 a = *reinterpret_cast<const f32x4 *>(ring + 1024 + slot * 256 + lane * 4);

@@ -533,11 +533,11 @@ rqs_coupling_bwd_pipe_kernel(const float *__restrict__ x, const float *__restric
         const bool more = b1 < B;
         if (more) issue(b1, bufn);
         if (first) {
-            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD_N) : "memory");
+            if (more) NF_WAIT_VMCNT(LD_N);
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
-            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD_N + ST_N) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST_N) : "memory");
+            if (more) NF_WAIT_VMCNT(LD_N + ST_N);
+            else NF_WAIT_VMCNT(ST_N);
         }
         first = false;
         __builtin_amdgcn_wave_barrier();

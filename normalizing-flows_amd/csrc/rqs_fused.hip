@@ -423,7 +423,7 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     // implements it as vmcnt(0) while an LDS-DMA may be pending -- it would wait for the stores after all.
     const bool full_tile = TRAIN ? (int64_t)(blockIdx.x + 1) * F_ROWS <= B : false;     // (inference: dead, no register)
     auto acquire = [&](int after = 0) -> const float * {
-        if (TRAIN && after == 14 && full_tile) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        if (TRAIN && after == 14 && full_tile) NF_WAIT_VMCNT(14);
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifndef NF_ABL_NOBAR
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

@@ -304,7 +304,7 @@ rqs_fused_x3_kernel(const float *__restrict__ x, float *__restrict__ y, float *_
     auto acquire = [&]() -> const unsigned short * {
         // this wave's 3 pieces of `stage` have landed once at most the 3 pieces of stage+1 are outstanding
 #ifndef NF_ABL_NOWAIT
-        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        NF_WAIT_VMCNT(3);
 #endif
 #ifndef NF_ABL_NOBAR
         __builtin_amdgcn_s_barrier();

@@ -402,19 +402,19 @@ rqs_coupling_pipe_kernel(const float *__restrict__ x, float *__restrict__ y, flo
         // next pass's LD_N requests
         if (has_old) {
             if (first) {
-                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD_N + 1) : "memory");
-                else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                if (more) NF_WAIT_VMCNT(LD_N + 1);
+                else NF_WAIT_VMCNT(1);
             } else {
-                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD_N + ST_N + 1) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST_N + 1) : "memory");
+                if (more) NF_WAIT_VMCNT(LD_N + ST_N + 1);
+                else NF_WAIT_VMCNT(ST_N + 1);
             }
         } else {
             if (first) {
-                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD_N) : "memory");
+                if (more) NF_WAIT_VMCNT(LD_N);
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
-                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LD_N + ST_N) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST_N) : "memory");
+                if (more) NF_WAIT_VMCNT(LD_N + ST_N);
+                else NF_WAIT_VMCNT(ST_N);
             }
         }
         first = false;

@@ -355,7 +355,7 @@ wgrad_ring_kernel(const float *__restrict__ dY, const float *__restrict__ X, flo
         // helper waves: requests and barriers only (the same barrier sequence as the MFMA waves below)
         for (int s = 0; s < W3_NR - 1 && s < nsteps; ++s) issue(s);
         for (int s = 0; s < nsteps; ++s) {
-            if (s + W3_NR - 1 <= nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (W3_NR - 2)) : "memory");
+            if (s + W3_NR - 1 <= nsteps) NF_WAIT_VMCNT(4 * (W3_NR - 2));
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (s + W3_NR - 1 < nsteps) issue(s + W3_NR - 1);
@@ -370,7 +370,7 @@ wgrad_ring_kernel(const float *__restrict__ dY, const float *__restrict__ X, flo
         // step s landed (the requesting waves' pieces) once at most the younger steps' 4 (NR - 1) instructions are outstanding; in
         // the tail fewer are younger: drain
         if (!W3_HW) {
-            if (s + W3_NR - 1 <= nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (W3_NR - 2)) : "memory");
+            if (s + W3_NR - 1 <= nsteps) NF_WAIT_VMCNT(4 * (W3_NR - 2));
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every piece of step s landed; every wave is done with slot (s - 1) % NR

@@ -4,7 +4,8 @@
 (outputs, logabsdet), element-wise, on tensors of any leading shape; the arithmetic is nf_rqs_spline (csrc/rqs_spline.hip:
 softmax -> knots -> count-based bin search -> rational-quadratic piece, the reference's order of operations).  With gradients
 enabled and a tensor that requires them the call goes through the coupling kernels' forward + backward pair (one feature per
-row), so inputs and all three parameter tensors receive gradients.  Not mirrored: per-feature tail lists and tensor limits
+row), so inputs and all three parameter tensors receive gradients (`rational_quadratic_spline`: for square boxes, right - left ==
+top - bottom, which includes the reference's default [0, 1] x [0, 1]; other boxes only without gradients).  Not mirrored: per-feature tail lists and tensor limits
 (`utils/splines.py:48-66, 116-119`) -- the flow classes (`PiecewiseRationalQuadraticCDF`, the coupling layers) take those."""
 import torch
 
@@ -33,9 +34,7 @@ def _scalar(v, what):
 
 def _run(inputs, uw, uh, ud, inverse, tails, bound, box, mins):
     if needs_grad(inputs, uw, uh, ud):
-        if box is not None:
-            raise NotImplementedError("utils.splines.rational_quadratic_spline under autograd: only the symmetric box "
-                                      "[-b, b] x [-b, b] has a backward kernel")
+        assert box is None          # (rational_quadratic_spline reduces square boxes to the symmetric one before it gets here)
         K = uw.shape[-1]
         x = inputs.reshape(-1, 1)
         cond = torch.cat([uw, uh, ud], dim=-1).reshape(x.shape[0], -1)
@@ -74,8 +73,19 @@ def rational_quadratic_spline(inputs, unnormalized_widths, unnormalized_heights,
         raise ValueError("Minimal bin height too large for the number of bins")
     l, r, b, t = (_scalar(v, n) for v, n in ((left, "left"), (right, "right"), (bottom, "bottom"), (top, "top")))
     mins = (min_bin_width, min_bin_height, min_derivative)
-    if l == -r and b == -t and r == t:
-        # the symmetric box is the `tails=None` form of the kernels (and has a backward kernel)
-        if needs_grad(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives):
-            return _run(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives, inverse, None, r, None, mins)
+    if needs_grad(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives):
+        # The backward kernel works on the symmetric box [-h, h] x [-h, h] (the `tails=None` form of the coupling kernels).  Any
+        # SQUARE box -- the reference's default [0, 1] x [0, 1] included -- is that box translated: knots and the derivative
+        # parameters (slopes in actual coordinates, utils/splines.py:150-158) do not change under a shift, so
+        # spline_box(x) = spline_sym(x - cx) + cy with the same logabsdet (inverse: the roles of the two centres swap).  A box with
+        # right - left != top - bottom rescales the slopes and has no such reduction: not differentiable here (NotImplementedError).
+        if abs((r - l) - (t - b)) <= 1e-12 * max(abs(r - l), abs(t - b), 1.0):
+            half = 0.5 * (r - l)
+            cx, cy = 0.5 * (l + r), 0.5 * (b + t)
+            cin, cout = (cy, cx) if inverse else (cx, cy)
+            y, lad = _run(inputs - cin, unnormalized_widths, unnormalized_heights, unnormalized_derivatives, inverse, None, half,
+                          None, mins)
+            return y + cout, lad
+        raise NotImplementedError("utils.splines.rational_quadratic_spline under autograd: right - left must equal top - bottom "
+                                  "(any square box, e.g. the default [0, 1] x [0, 1]); other boxes run without gradients only")
     return _run(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives, inverse, None, 0.0, (l, r, b, t), mins)

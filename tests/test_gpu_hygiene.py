@@ -294,3 +294,95 @@ def test_mfma_clock_probe_reports_a_plausible_clock(nfa):
     b = nfa.ops.mfma_clock_mhz(DEV)
     assert 1000.0 < a < 2600.0 and 1000.0 < b < 2600.0, (a, b)
     assert abs(a - b) < 0.1 * a, (a, b)
+
+
+_WAITS_WORKER = r"""
+import hashlib, json, os, sys
+sys.path.insert(0, os.environ["NF_ROOT"])
+import torch
+import normflows_amd as nfa
+from bench import build_c2_model
+dev = "cuda:0"
+out = {}
+
+def digest(*ts):
+    h = hashlib.sha256()
+    for t in ts:
+        h.update(t.detach().float().cpu().numpy().tobytes())
+    return h.hexdigest()
+
+# (1) the training step at the benchmark layer shape on FULL tiles: rqs_fused_kernel<TRAIN> (vmcnt(14) behind the parameter-row
+#     stores), final_bwd_kernel (23 / 14 / 7), wgrad_ring_kernel, resblock_bwd / lu_bwd
+m = build_c2_model(num_layers=2, dim=64, hidden=128, seed=0, sigma=0.05).to(dev)
+x = torch.randn(4096, 64, generator=torch.Generator().manual_seed(1)).to(dev)
+loss = m.forward_kld(x)
+loss.backward()
+out["train_step"] = digest(loss, *[p.grad for p in m.parameters()])
+torch.set_grad_enabled(False)
+# (2) the software-pipelined spline kernels (rqs_spline.hip / rqs_bwd.hip: vmcnt(loads + stores) per pass)
+layer = nfa.flows.CoupledRationalQuadraticSpline(64, 2, 128, init_identity=False).to(dev)
+layer.prqct.use_fused = False
+xs = (1.5 * torch.randn(65536, 64, generator=torch.Generator().manual_seed(2))).to(dev)
+z, ld = layer.inverse(xs)
+zf, ldf = layer.forward(xs)
+out["spline_pipe"] = digest(z, ld, zf, ldf)
+# (3) the split-bf16 chain (rqs_fused_x3.hip: 3-slot ring, vmcnt(3))
+nfa.config.set_fused_gemm("bf16x3")
+m4 = build_c2_model(num_layers=4, dim=64, hidden=128, seed=1, sigma=0.02).to(dev)
+out["x3_chain"] = digest(m4.log_prob(xs[:8192]))
+nfa.config.set_fused_gemm("f32")
+# (4) Glow levels (glow_conv.hip: weight rings of all three kernels) and (5) the MAF inverse kernels
+import importlib.util
+spec = importlib.util.spec_from_file_location("cb", os.path.join(os.environ["NF_ROOT"], "tools", "config_bench.py"))
+torch.manual_seed(0)
+L_, K_, hidden, channels = 3, 4, 256, 3
+q0, merges, flows = [], [], []
+for i in range(L_):
+    fl = [nfa.flows.GlowBlock(channels * 2 ** (L_ + 1 - i), hidden, split_mode="channel", scale=True) for _ in range(K_)] + [nfa.flows.Squeeze()]
+    flows += [fl]
+    if i > 0:
+        merges += [nfa.flows.Merge()]
+        latent = (channels * 2 ** (L_ - i), 32 // 2 ** (L_ - i), 32 // 2 ** (L_ - i))
+    else:
+        latent = (channels * 2 ** (L_ + 1), 32 // 2 ** L_, 32 // 2 ** L_)
+    q0 += [nfa.distributions.DiagGaussian(latent)]
+g = nfa.MultiscaleFlow(q0, flows, merges, class_cond=False).to(dev)
+img = torch.rand(256, 3, 32, 32, generator=torch.Generator().manual_seed(3)).to(dev)
+g.log_prob(img)
+out["glow_levels"] = digest(g.log_prob(img))
+maf = nfa.flows.MaskedAffineAutoregressive(128, 512, num_blocks=2).to(dev)
+y, ldm = maf.inverse(xs.new_empty(8192, 128).normal_(generator=None) if False else torch.randn(8192, 128, generator=torch.Generator().manual_seed(4)).to(dev))
+out["maf_inverse"] = digest(y, ldm)
+ar = nfa.flows.AutoregressiveRationalQuadraticSpline(16, 2, 64).to(dev)
+ya, lda = ar.forward(torch.randn(4096, 16, generator=torch.Generator().manual_seed(5)).to(dev))
+out["arnsf_inverse"] = digest(ya, lda)
+print("DIGESTS " + json.dumps(out))
+"""
+
+
+def test_counted_waits_equal_full_drains(nfa, tmp_path):
+    """Every hand-counted `s_waitcnt vmcnt(N)` (NF_WAIT_VMCNT: ring acquires that leave N younger requests in flight -- correct only
+    while N equals what the compiler actually emits between request and wait) against a build in which each of them is a full
+    drain (lib/variants/safe_waits.so, -DNF_SAFE_WAITS, built by __graft_entry__.build()): the deterministic kernels that use them
+    -- the one-launch training forward, nf_final_bwd, the ring weight gradient, the pipelined spline kernels, the split-bf16 chain,
+    the Glow level kernels, both MAF inverse kernels -- must give BIT-identical results at sizes with full tiles.  A count that
+    has become too lax reads a stage that has not landed: silent corruption on full tiles only (round-3 ADVICE)."""
+    import json
+    from normflows_amd import _lib
+    if not os.path.exists(_lib.SAFE_WAITS_LIB):
+        pytest.skip("lib/variants/safe_waits.so was not built")
+    script = tmp_path / "waits_worker.py"
+    script.write_text(_WAITS_WORKER)
+    res = []
+    for variant in (None, _lib.SAFE_WAITS_LIB):
+        env = {k: v for k, v in os.environ.items() if k != "NF_MI355X_LIB"}
+        env["NF_ROOT"] = ROOT
+        if variant:
+            env["NF_MI355X_LIB"] = variant
+        out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2500:]
+        line = [l for l in out.stdout.splitlines() if l.startswith("DIGESTS ")][-1]
+        res.append(json.loads(line[len("DIGESTS "):]))
+    assert res[0].keys() == res[1].keys() and len(res[0]) == 6
+    for k in res[0]:
+        assert res[0][k] == res[1][k], "%s: the counted-wait build and the full-drain build differ" % k

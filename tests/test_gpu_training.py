@@ -1120,6 +1120,28 @@ def test_utils_splines_entry_points_vs_reference(nfa, K):
     assert_close(N(y), g["y01"], what="y01", rtol=1e-5, atol=1e-5)
     assert_close(N(l), g["lad01"], what="lad01", rtol=5e-5, atol=5e-5)
     assert_close(N(yi), g["x01_inv"], what="x01_inv", rtol=1e-5, atol=1e-5)
+    # the reference's DEFAULT box [0, 1] x [0, 1] under autograd (a square box = the symmetric one translated): values as above,
+    # gradients against central differences of the inference kernel in float64
+    x = T(g["x01"]).clone().requires_grad_(True)
+    ps = [t_.clone().requires_grad_(True) for t_ in (w, h, T(g["d_none"]))]
+    y2, l2 = sp.rational_quadratic_spline(x, *ps)
+    assert_close(N(y2), g["y01"], what="y01 (training path)", rtol=1e-5, atol=1e-5)
+    assert_close(N(l2), g["lad01"], what="lad01 (training path)", rtol=5e-5, atol=5e-5)
+    (y2.sum() + l2.sum()).backward()
+    assert all(t_.grad is not None and torch.isfinite(t_.grad).all() for t_ in [x] + ps)
+    x64 = T(g["x01"]).double()
+    p64 = [t_.detach().double() for t_ in ps]
+    eps_ = 1e-6
+    with torch.no_grad():
+        up = sp.rational_quadratic_spline(x64 + eps_, *p64)
+        dn = sp.rational_quadratic_spline(x64 - eps_, *p64)
+    fd = (up[0] + up[1] - dn[0] - dn[1]) / (2 * eps_)
+    inner = (x64 > 0.01) & (x64 < 0.99)
+    assert float(((x.grad.double() - fd).abs() / (1.0 + fd.abs()))[inner].max()) < 5e-3
+    yi2, _ = sp.rational_quadratic_spline(y2.detach().clone().requires_grad_(True), *ps, inverse=True)
+    assert_close(N(yi2), g["x01"], what="inverse (training path)", rtol=1e-4, atol=1e-4)
+    with pytest.raises(NotImplementedError):        # right - left != top - bottom: no reduction to the symmetric box
+        sp.rational_quadratic_spline(x, *ps, left=0.0, right=2.0, bottom=0.0, top=1.0)
     with pytest.raises(ValueError):
         sp.rational_quadratic_spline(T(g["x01"]), w, h, T(g["d_none"]), min_bin_width=0.2)
     knots = torch.tensor([0.0, 1.0, 2.0], device=DEV)

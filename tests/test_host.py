@@ -771,3 +771,23 @@ def test_nsf_wide_pack_rejects_unsupported():
     assert nsf_wide_pack.pack_nsf_wide(nfa.flows.CoupledRationalQuadraticSpline(64, 2, 256, num_bins=10).prqct) is None
     assert nsf_wide_pack.pack_nsf_wide(nfa.flows.CoupledRationalQuadraticSpline(130, 2, 256).prqct) is None
     assert nsf_wide_pack.pack_nsf_wide(nfa.flows.CoupledRationalQuadraticSpline(64, 2, 600).prqct) is None
+
+
+def test_invalidate_caches_drops_every_packed_image(nfa):
+    """normflows_amd.invalidate_caches: what a caller runs after updating parameters through `.data` (no `_version` bump, so the
+    (data_ptr, _version) keys of the packed-weight caches cannot see the change)."""
+    layer = nfa.flows.CoupledRationalQuadraticSpline(8, 1, 16)
+    lu = nfa.flows.LULinearPermute(8)
+    made = nfa.nets.MADE(features=6, hidden_features=12, num_blocks=1, output_multiplier=2)
+    m = torch.nn.ModuleList([layer, lu, made])
+    layer.prqct._fused_cache = ("k", object())
+    layer.prqct.__dict__["_wide_cache"] = {None: ("k", object())}
+    lu._dense_cache = ("k", object())
+    made.__dict__["_fwd_pack_cache"] = ("k", object())
+    made.initial_layer._masked_cache = ("k", object())
+    v0 = layer.prqct.transform_net.final_layer.bias._version
+    layer.prqct.transform_net.final_layer.bias.data.add_(1.0)
+    assert layer.prqct.transform_net.final_layer.bias._version == v0        # the reason the hook exists
+    nfa.invalidate_caches(m)
+    assert layer.prqct._fused_cache is None and layer.prqct.__dict__["_wide_cache"] == {} and lu._dense_cache is None
+    assert made.__dict__["_fwd_pack_cache"] is None and made.initial_layer._masked_cache is None
