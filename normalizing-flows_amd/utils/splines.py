@@ -34,7 +34,7 @@ def _scalar(v, what):
 
 def _run(inputs, uw, uh, ud, inverse, tails, bound, box, mins):
     if needs_grad(inputs, uw, uh, ud):
-        assert box is None          # (rational_quadratic_spline reduces square boxes to the symmetric one before it gets here)
+        assert box is None          # (rational_quadratic_spline reduces square boxes to the unit box before it gets here)
         K = uw.shape[-1]
         x = inputs.reshape(-1, 1)
         cond = torch.cat([uw, uh, ud], dim=-1).reshape(x.shape[0], -1)
@@ -74,18 +74,17 @@ def rational_quadratic_spline(inputs, unnormalized_widths, unnormalized_heights,
     l, r, b, t = (_scalar(v, n) for v, n in ((left, "left"), (right, "right"), (bottom, "bottom"), (top, "top")))
     mins = (min_bin_width, min_bin_height, min_derivative)
     if needs_grad(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives):
-        # The backward kernel works on the symmetric box [-h, h] x [-h, h] (the `tails=None` form of the coupling kernels).  Any
-        # SQUARE box -- the reference's default [0, 1] x [0, 1] included -- is that box translated: knots and the derivative
-        # parameters (slopes in actual coordinates, utils/splines.py:150-158) do not change under a shift, so
-        # spline_box(x) = spline_sym(x - cx) + cy with the same logabsdet (inverse: the roles of the two centres swap).  A box with
-        # right - left != top - bottom rescales the slopes and has no such reduction: not differentiable here (NotImplementedError).
+        # The backward kernel's `tails=None` form is the UNIT box [0, 1] x [0, 1] (the reference's default).  Any SQUARE box of
+        # side s is that box scaled by s in both coordinates and translated: bin widths and heights scale alike, so the slopes
+        # (the derivative parameters are slopes in actual coordinates, utils/splines.py:150-158), theta and logabsdet do not
+        # change: spline_box(x) = bottom + s * spline_unit((x - left) / s) (inverse: (y - bottom) / s -> left + s * .).  A box with
+        # right - left != top - bottom rescales the slopes and has no such reduction: not differentiable here.
         if abs((r - l) - (t - b)) <= 1e-12 * max(abs(r - l), abs(t - b), 1.0):
-            half = 0.5 * (r - l)
-            cx, cy = 0.5 * (l + r), 0.5 * (b + t)
-            cin, cout = (cy, cx) if inverse else (cx, cy)
-            y, lad = _run(inputs - cin, unnormalized_widths, unnormalized_heights, unnormalized_derivatives, inverse, None, half,
-                          None, mins)
-            return y + cout, lad
+            side = r - l
+            o_in, o_out = (b, l) if inverse else (l, b)
+            u = inputs if (side == 1.0 and o_in == 0.0) else (inputs - o_in) / side
+            y, lad = _run(u, unnormalized_widths, unnormalized_heights, unnormalized_derivatives, inverse, None, 1.0, None, mins)
+            return (y if (side == 1.0 and o_out == 0.0) else y * side + o_out), lad
         raise NotImplementedError("utils.splines.rational_quadratic_spline under autograd: right - left must equal top - bottom "
                                   "(any square box, e.g. the default [0, 1] x [0, 1]); other boxes run without gradients only")
     return _run(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives, inverse, None, 0.0, (l, r, b, t), mins)

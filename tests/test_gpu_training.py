@@ -1120,7 +1120,7 @@ def test_utils_splines_entry_points_vs_reference(nfa, K):
     assert_close(N(y), g["y01"], what="y01", rtol=1e-5, atol=1e-5)
     assert_close(N(l), g["lad01"], what="lad01", rtol=5e-5, atol=5e-5)
     assert_close(N(yi), g["x01_inv"], what="x01_inv", rtol=1e-5, atol=1e-5)
-    # the reference's DEFAULT box [0, 1] x [0, 1] under autograd (a square box = the symmetric one translated): values as above,
+    # the reference's DEFAULT box [0, 1] x [0, 1] under autograd (the backward kernel's `tails=None` box; other square boxes scale to it): values as above,
     # gradients against central differences of the inference kernel in float64
     x = T(g["x01"]).clone().requires_grad_(True)
     ps = [t_.clone().requires_grad_(True) for t_ in (w, h, T(g["d_none"]))]
@@ -1140,7 +1140,14 @@ def test_utils_splines_entry_points_vs_reference(nfa, K):
     assert float(((x.grad.double() - fd).abs() / (1.0 + fd.abs()))[inner].max()) < 5e-3
     yi2, _ = sp.rational_quadratic_spline(y2.detach().clone().requires_grad_(True), *ps, inverse=True)
     assert_close(N(yi2), g["x01"], what="inverse (training path)", rtol=1e-4, atol=1e-4)
-    with pytest.raises(NotImplementedError):        # right - left != top - bottom: no reduction to the symmetric box
+    # a square box that is not the unit one: [-1, 3] x [2, 6] against the inference kernel on the same box
+    xb = (4.0 * T(g["x01"]) - 1.0).clone().requires_grad_(True)
+    y3, l3 = sp.rational_quadratic_spline(xb, *ps, left=-1.0, right=3.0, bottom=2.0, top=6.0)
+    with torch.no_grad():
+        y3n, l3n = sp.rational_quadratic_spline(xb.detach(), *[t_.detach() for t_ in ps], left=-1.0, right=3.0, bottom=2.0, top=6.0)
+    assert_close(N(y3), N(y3n), what="square box y", rtol=1e-5, atol=1e-5)
+    assert_close(N(l3), N(l3n), what="square box lad", rtol=5e-5, atol=5e-5)
+    with pytest.raises(NotImplementedError):        # right - left != top - bottom: no reduction to the unit box
         sp.rational_quadratic_spline(x, *ps, left=0.0, right=2.0, bottom=0.0, top=1.0)
     with pytest.raises(ValueError):
         sp.rational_quadratic_spline(T(g["x01"]), w, h, T(g["d_none"]), min_bin_width=0.2)
