@@ -105,13 +105,21 @@ actnorm_bwd_kernel(const T *__restrict__ z, const T *__restrict__ s, const T *__
     const T e = M<T>::exp(direction == 0 ? sc : -sc);
     double as = 0.0, at = 0.0;
     const int64_t nimg = (B - j + nsplit - 1) / nsplit;       // images j, j + nsplit, ...
+    // (image, pixel) of a thread's next element follow incrementally: one 64-bit division per thread instead of one per element
+    int64_t k = threadIdx.x / HW, p = threadIdx.x - k * HW;
+    const int64_t dk = blockDim.x / HW, dp = blockDim.x - dk * HW;
     for (int64_t e_ = threadIdx.x; e_ < nimg * HW; e_ += blockDim.x) {
-        const int64_t k = e_ / HW, p = e_ - k * HW;
         const int64_t o = ((j + k * nsplit) * C + c) * HW + p;
         const T g = gy[o], v = z[o];
         gz[o] = g * e;
         if (direction == 0) { as += (double)(g * v * e); at += (double)g; }
         else { as -= (double)(g * (v - tc) * e); at -= (double)(g * e); }
+        k += dk;
+        p += dp;
+        if (p >= HW) {
+            p -= HW;
+            ++k;
+        }
     }
     as = block_sum(as, sred);
     at = block_sum(at, sred);
@@ -186,22 +194,94 @@ inv1x1_wgrad_partial_kernel(const T *__restrict__ z, const T *__restrict__ gy, T
     }
 }
 
+// The same partial sums on fp32 MFMA (round 4; float32, HW a multiple of 16): gW = Gy Z^T is a (C x C) x pixels product.  The
+// scalar kernel above reads two LDS words per multiply-add, leaves most threads idle for C = 12 (144 entries) and meets two
+// barriers per 64 pixels: 327 / 721 us at (8192, 12, 16, 16) / (8192, 48, 4, 4) = 0.08 / 0.01 of the HBM peak.  Here every WAVE
+// streams its own 16-pixel chunks straight into MFMA operands -- lane (m = lane & 15, kq = lane >> 4) loads the four consecutive
+// pixels 4 kq .. 4 kq + 3 of row 16 ib + m with ONE 16-byte load and uses element s as its k-entry of step s (the contraction
+// order over the chunk's pixels is free as long as both operands use the same one) -- no LDS, no barrier, four chunks of loads
+// in flight per wave; NB^2 accumulators of 4 registers; one partial per wave, summed in a fixed order by the reduce kernel.
+template <int NB>
+__global__ void __launch_bounds__(256)
+inv1x1_wgrad_mfma_kernel(const float *__restrict__ z, const float *__restrict__ gy, float *__restrict__ partial, int64_t B, int C,
+                         int64_t HW) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, m = lane & 15, kq = lane >> 4;
+    const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t cpi = HW >> 4, nchunks = B * cpi;           // 16-pixel chunks per image
+    f4 acc[NB * NB];
+#pragma unroll
+    for (int q = 0; q < NB * NB; ++q) acc[q] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    auto load = [&](const float *__restrict__ src, int64_t ch, f4 (&v)[NB]) {
+        const int64_t bb = ch / cpi, p = (ch - bb * cpi) * 16 + 4 * kq;
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib) {
+            const int c = 16 * ib + m;
+            v[ib] = c < C ? *reinterpret_cast<const f4 *>(src + (bb * C + c) * HW + p) : f4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    };
+    for (int64_t ch0 = gw; ch0 < nchunks; ch0 += 4 * nw) {
+        f4 a[4][NB], b[4][NB];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t ch = ch0 + u * nw;
+            if (ch < nchunks) {
+                load(gy, ch, a[u]);
+                load(z, ch, b[u]);
+            } else {
+#pragma unroll
+                for (int ib = 0; ib < NB; ++ib) a[u][ib] = b[u][ib] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+                for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+                        acc[ib * NB + jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][ib][s4], b[u][jb][s4], acc[ib * NB + jb], 0, 0, 0);
+    }
+    float *out = partial + gw * C * C;      // C register r of a block: row 4 (lane >> 4) + r, column lane & 15
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * ib + 4 * kq + r, jj = 16 * jb + m;
+                if (i < C && jj < C) out[i * C + jj] = acc[ib * NB + jb][r];
+            }
+}
+
+// 16 entries per workgroup; thread (entry e = tid & 15, slice q = tid >> 4) adds the partials q, q + 16, ... in order, the 16 slices
+// are then added in order by the entry's first thread: a fixed summation order (deterministic) without one thread walking all the
+// partials alone (256 and more serial loads per entry in round 3).
 template <typename T>
 __global__ void __launch_bounds__(256)
 inv1x1_wgrad_reduce_kernel(const T *__restrict__ partial, const T *__restrict__ gld, T *__restrict__ gW, T *__restrict__ gl,
                            int nparts, int CC, int64_t B, int64_t HW) {
     __shared__ double sred[16];
-    for (int ent = blockIdx.x * blockDim.x + threadIdx.x; ent < CC; ent += gridDim.x * blockDim.x) {
-        double a = 0.0;
-        for (int w = 0; w < nparts; ++w) a += (double)partial[(int64_t)w * CC + ent];
-        gW[ent] = (T)a;
+    __shared__ double slices[16][17];
+    const int e = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int ent = blockIdx.x * 16 + e;
+    double a = 0.0;
+    if (ent < CC)
+        for (int w = q; w < nparts; w += 16) a += (double)partial[(int64_t)w * CC + ent];
+    slices[q][e] = a;
+    __syncthreads();
+    if (q == 0 && ent < CC) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += slices[k][e];
+        gW[ent] = (T)t;
     }
     if (blockIdx.x == 0 && gl) {   // ld (every sample) = HW ldu  ->  d / d ldu = HW sum_b gld
-        double a = 0.0;
+        double g = 0.0;
         if (gld)
-            for (int64_t r = threadIdx.x; r < B; r += blockDim.x) a += (double)gld[r];
-        a = block_sum(a, sred);
-        if (threadIdx.x == 0) *gl = (T)((double)HW * a);
+            for (int64_t r = threadIdx.x; r < B; r += blockDim.x) g += (double)gld[r];
+        g = block_sum(g, sred);
+        if (threadIdx.x == 0) *gl = (T)((double)HW * g);
     }
 }
 
@@ -292,7 +372,7 @@ extern "C" int nf_actnorm_bwd(const void *z, const void *s, const void *t, const
 extern "C" int64_t nf_inv1x1_wgrad_scratch_elems(int64_t B, int C) {
     if (B < 0 || C < 1 || C > 64) return NF_EINVAL;
     const int64_t parts = B < 256 ? (B > 0 ? B : 1) : 256;
-    return parts * (int64_t)C * C;
+    return 4 * parts * (int64_t)C * C;        // the MFMA kernel leaves one partial per wave: 4 per workgroup
 }
 
 extern "C" int nf_inv1x1_wgrad(const void *z, const void *gy, const void *gld, void *gW, void *gldu, void *scratch, int64_t B,
@@ -306,14 +386,30 @@ extern "C" int nf_inv1x1_wgrad(const void *z, const void *gy, const void *gld, v
     const int nparts = (int)((B + ipw - 1) / ipw);
     const size_t esz = dtype == NF_F64 ? 8 : 4;
     const size_t lds = (size_t)2 * C * 64 * esz;
+    if (dtype == NF_F32 && (HW & 15) == 0 && (((uintptr_t)z | (uintptr_t)gy) & 15) == 0) {
+        const int NB = (C + 15) / 16;
+        const int64_t nchunks = B * (HW >> 4);
+        int64_t wg = (nchunks + 15) / 16;                     // >= 4 chunks per wave
+        if (wg > parts) wg = parts;                           // <= 256 workgroups = 1024 wave partials (nf_inv1x1_wgrad_scratch_elems)
+        if (wg < 1) wg = 1;
+#define NF_W1(NBV)                                                                                                            \
+    hipLaunchKernelGGL((inv1x1_wgrad_mfma_kernel<NBV>), dim3((unsigned)wg), dim3(256), 0, st, (const float *)z, (const float *)gy, \
+                       (float *)scratch, B, C, HW)
+        if (NB == 1) NF_W1(1); else if (NB == 2) NF_W1(2); else if (NB == 3) NF_W1(3); else NF_W1(4);
+#undef NF_W1
+        hipLaunchKernelGGL(inv1x1_wgrad_reduce_kernel<float>, dim3((C * C + 15) / 16), dim3(256), 0, st, (const float *)scratch,
+                           (const float *)gld, (float *)gW, (float *)gldu, (int)(4 * wg), C * C, B, HW);
+        NF_CHECK_LAUNCH();
+        return NF_OK;
+    }
     NF_DISPATCH(dtype,
                 hipLaunchKernelGGL(inv1x1_wgrad_partial_kernel<float>, dim3(nparts), dim3(256), lds, st, (const float *)z,
                                    (const float *)gy, (float *)scratch, B, C, HW, ipw);
-                hipLaunchKernelGGL(inv1x1_wgrad_reduce_kernel<float>, dim3((C * C + 255) / 256), dim3(256), 0, st,
+                hipLaunchKernelGGL(inv1x1_wgrad_reduce_kernel<float>, dim3((C * C + 15) / 16), dim3(256), 0, st,
                                    (const float *)scratch, (const float *)gld, (float *)gW, (float *)gldu, nparts, C * C, B, HW),
                 hipLaunchKernelGGL(inv1x1_wgrad_partial_kernel<double>, dim3(nparts), dim3(256), lds, st, (const double *)z,
                                    (const double *)gy, (double *)scratch, B, C, HW, ipw);
-                hipLaunchKernelGGL(inv1x1_wgrad_reduce_kernel<double>, dim3((C * C + 255) / 256), dim3(256), 0, st,
+                hipLaunchKernelGGL(inv1x1_wgrad_reduce_kernel<double>, dim3((C * C + 15) / 16), dim3(256), 0, st,
                                    (const double *)scratch, (const double *)gld, (double *)gW, (double *)gldu, nparts, C * C, B,
                                    HW));
     NF_CHECK_LAUNCH();
