@@ -42,18 +42,21 @@ __device__ __forceinline__ void mf_ring_start(MfRing &r, const float *stream, in
 #ifndef MF_SCHED
 #define MF_SCHED 0
 #endif
-template <int NS, int HALF>
+// TR = rows per tile (64; 128 for the narrow NSF networks whose activations leave room for it): a k-group of activations is
+// [2 hh][TR rows][4] = 8 TR floats.
+template <int NS, int HALF, int TR = 64>
 __device__ __forceinline__ void mf_group(MfRing &r, int e0, const float *&bp, const float *blast, f32x4 (&b)[2], f32x16 (&acc)[NS]) {
+    constexpr int KGS = 8 * TR;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         f32x4 bn[2];
         bn[0] = *reinterpret_cast<const f32x4 *>(bp);
         if constexpr (NS == 2) bn[1] = *reinterpret_cast<const f32x4 *>(bp + 128);
         if constexpr (MF_SCHED == 2) {
-            bp = bp + 512 < blast ? bp + 512 : blast;
+            bp = bp + KGS < blast ? bp + KGS : blast;
             __builtin_amdgcn_sched_barrier(0);       // (the reads go out IN FRONT of this k-group's MFMAs, not behind them)
         } else {
-            bp += 512;
+            bp += KGS;
             b[0] = bn[0];
             if constexpr (NS == 2) b[1] = bn[1];
         }
@@ -77,15 +80,16 @@ __device__ __forceinline__ void mf_group(MfRing &r, int e0, const float *&bp, co
 
 // One work item: acc = (ADD ? acc : 0) + bias + W[32 rows][8 nkg] . act[8 nkg][32-sample blocks]; Bl = LDS activations + the lane's
 // offset 4 (64 hh + n [+ 32 sb]).  nkg is a multiple of 4 (packer).
-template <int NS, bool ADD>
+template <int NS, bool ADD, int TR = 64>
 __device__ __forceinline__ void mf_item(MfRing &r, int nkg, const float *Bl, f32x16 (&acc)[NS]) {
+    constexpr int KGS = 8 * TR;
     f32x4 b[2];
-    const float *blast = Bl + (size_t)(nkg > 0 ? nkg - 1 : 0) * 512;
+    const float *blast = Bl + (size_t)(nkg > 0 ? nkg - 1 : 0) * KGS;
     const float *bp = Bl;
     if constexpr (MF_SCHED == 2) {
         b[0] = *reinterpret_cast<const f32x4 *>(Bl);
         if constexpr (NS == 2) b[1] = *reinterpret_cast<const f32x4 *>(Bl + 128);
-        bp = nkg > 1 ? Bl + 512 : Bl;
+        bp = nkg > 1 ? Bl + KGS : Bl;
     }
     // bias group = ring entries 0..3: entry q holds bias[8 q + 4 hh + 0..3] = accumulator registers 4 q + i
 #pragma unroll
@@ -100,11 +104,11 @@ __device__ __forceinline__ void mf_item(MfRing &r, int nkg, const float *Bl, f32
     if constexpr (MF_SCHED != 0) __builtin_amdgcn_sched_barrier(0);
     int kg = 0;
     for (; kg + 8 <= nkg; kg += 8) {
-        mf_group<NS, 4>(r, 4 + kg, bp, blast, b, acc);
-        mf_group<NS, 0>(r, 8 + kg, bp, blast, b, acc);
+        mf_group<NS, 4, TR>(r, 4 + kg, bp, blast, b, acc);
+        mf_group<NS, 0, TR>(r, 8 + kg, bp, blast, b, acc);
     }
     if (kg < nkg) {          // an odd number of A groups: bias + A groups is even, the next item starts in ring half 0
-        mf_group<NS, 4>(r, 4 + kg, bp, blast, b, acc);
+        mf_group<NS, 4, TR>(r, 4 + kg, bp, blast, b, acc);
     } else {                 // the next item's first entries sit in ring half 1: swap the halves
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -117,7 +121,7 @@ __device__ __forceinline__ void mf_item(MfRing &r, int nkg, const float *Bl, f32
 }
 
 // publish the row-block's values (ReLU'd or raw) as the next layer's B operand: act[(4 rb + q)][hh][32 sb + n][4]
-template <int NS, bool RELU>
+template <int NS, bool RELU, int TR = 64>
 __device__ __forceinline__ void mf_publish(float *acts, int rb, int sb0, int hh, int n, const f32x16 (&v)[NS]) {
 #pragma unroll
     for (int s = 0; s < NS; ++s)
@@ -126,7 +130,7 @@ __device__ __forceinline__ void mf_publish(float *acts, int rb, int sb0, int hh,
             f32x4 o;
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = RELU ? fmaxf(v[s][4 * q + i], 0.0f) : v[s][4 * q + i];
-            *reinterpret_cast<f32x4 *>(acts + ((size_t)((4 * rb + q) * 2 + hh) * 64 + 32 * (sb0 + s) + n) * 4) = o;
+            *reinterpret_cast<f32x4 *>(acts + ((size_t)((4 * rb + q) * 2 + hh) * TR + 32 * (sb0 + s) + n) * 4) = o;
         }
 }
 

@@ -46,12 +46,12 @@ __device__ __forceinline__ f32x4 nw_take(MfRing &r, int idx, int e) {
 }
 
 // eight k-groups of a final item: per k-group one A fragment per row-block (3 ring entries), both sample blocks
-template <int K0>
+template <int K0, int TR>
 __device__ __forceinline__ void nw_final_kgs(MfRing &r, int e0, const float *bp, f32x16 (&o)[3][2]) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bp + k * 512);
-        const f32x4 b1 = *reinterpret_cast<const f32x4 *>(bp + k * 512 + 128);
+        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bp + k * (8 * TR));
+        const f32x4 b1 = *reinterpret_cast<const f32x4 *>(bp + k * (8 * TR) + 128);
 #pragma unroll
         for (int r3 = 0; r3 < 3; ++r3) {
             const f32x4 av = nw_take(r, (K0 + 3 * k + r3) & 7, e0 + 3 * k + r3);
@@ -65,6 +65,7 @@ __device__ __forceinline__ void nw_final_kgs(MfRing &r, int e0, const float *bp,
 }
 
 // one group of the final layer: o[r3][sb] = bias + W[32 rows] . h[., 32 samples]; nkg is a multiple of 8
+template <int TR>
 __device__ __forceinline__ void nw_final_item(MfRing &r, int nkg, const float *Bl, f32x16 (&o)[3][2]) {
     // 12 bias entries (row-block r3, quad q): the item starts in ring phase 0; entries 8..11 come from the re-requested a[0..3]
 #pragma unroll
@@ -77,7 +78,7 @@ __device__ __forceinline__ void nw_final_item(MfRing &r, int nkg, const float *B
         }
     }
     // A entries start at ring phase 4 (12 mod 8); 8 k-groups = 24 entries = three revolutions
-    for (int kg = 0; kg < nkg; kg += 8) nw_final_kgs<4>(r, 12 + 3 * kg, Bl + (size_t)kg * 512, o);
+    for (int kg = 0; kg < nkg; kg += 8) nw_final_kgs<4, TR>(r, 12 + 3 * kg, Bl + (size_t)kg * (8 * TR), o);
     // 12 + 3 nkg = 4 (mod 8): the next item's first entries sit in ring half 1
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -88,16 +89,17 @@ __device__ __forceinline__ void nw_final_item(MfRing &r, int nkg, const float *B
     r.ap += (size_t)(12 + 3 * nkg) * 256;
 }
 
-// float index of column `col` of row `row` (0..63) of the tile in B-operand order [col / 4][row][4]
-__device__ __forceinline__ int nw_xidx(int col, int row) { return ((col >> 2) * 64 + row) * 4 + (col & 3); }
+// float index of column `col` of row `row` (0 .. TR - 1) of the tile in B-operand order [col / 4][row][4]
+template <int TR>
+__device__ __forceinline__ int nw_xidx(int col, int row) { return ((col >> 2) * TR + row) * 4 + (col & 3); }
 
-// batch-shared spline on the identity columns of the tile, in place; thread = (row n = tid & 63, feature residue tid >> 6)
-template <bool INV>
+// batch-shared spline on the identity columns of the tile, in place; thread = (row n = tid % TR, feature residue tid / TR)
+template <bool INV, int TR>
 __device__ __forceinline__ float nw_identity(float *xreg, const float *tabs, const RqsParams<float> &p, int nI, int par_i, int tid) {
-    const int n = tid & 63;
+    const int n = tid % TR;
     float ld = 0.0f;
-    for (int i = tid >> 6; i < nI; i += MF_NW) {
-        float *xp = xreg + nw_xidx(2 * i + par_i, n);
+    for (int i = tid / TR; i < nI; i += 64 * MF_NW / TR) {
+        float *xp = xreg + nw_xidx<TR>(2 * i + par_i, n);
         float y, lad;
         rqs_table_fast<INV>(p, *xp, tabs + i * NW_TABW, y, lad);
         *xp = y;
@@ -109,20 +111,24 @@ __device__ __forceinline__ float nw_identity(float *xreg, const float *tabs, con
 // The adjacent LULinearPermute (mixing.py:535-563) as one dense product on the tile, in place: every wave computes its 32 output
 // columns of one sample block from the tile (B operand as it stands), all waves meet, then the columns are written back in B-operand
 // order (the accumulator quads ARE 16-byte groups of that order).
+template <int TR>
 __device__ __forceinline__ void nw_lu_stage(MfRing &ring, const int *it, float *xreg, int lane_b, int hh, int n) {
+    constexpr int NSL = TR / 64;           // sample blocks per LU item: 4 row-blocks x TR / 32 sample blocks over 8 waves
     const int rb = it[1];
-    f32x16 o1[1];
-    if (rb >= 0) mf_item<1, false>(ring, it[0], xreg + lane_b + 128 * it[2], o1);
+    f32x16 o1[NSL];
+    if (rb >= 0) mf_item<NSL, false, TR>(ring, it[0], xreg + lane_b + 128 * it[2], o1);
     MF_BARRIER();
-    if (rb >= 0) mf_publish<1, false>(xreg, rb, it[2], hh, n, o1);
+    if (rb >= 0) mf_publish<NSL, false, TR>(xreg, rb, it[2], hh, n, o1);
     MF_BARRIER();
 }
 
-// NHI hidden items per wave with NS sample blocks each: (1, 1) Hp = 128, (1, 2) Hp = 256, (2, 2) Hp = 512.
+// NHI hidden items per wave with NS sample blocks each, TR rows per tile: (1, 2, 128) Hp = 128 -- the activations of a 128-wide
+// network leave room for 128-row tiles: half the barriers, tile prologues and weight-stream traffic per row --, (1, 2, 64) Hp = 256,
+// (2, 2, 64) Hp = 512.
 // DIR 0: density direction = prqct.forward (nsf/coupling.py:71-98); DIR 1: sampling direction = prqct.inverse (:100-128).
 // LU: with the adjacent LULinearPermute -- applied BEFORE the coupling layer in the density direction (core.py:193-195 walks the
 // flows backwards: the LU layer behind a coupling layer comes first), AFTER it in the sampling direction (core.py:177-179).
-template <int NHI, int NS, int DIR, bool LU>
+template <int NHI, int NS, int DIR, bool LU, int TR>
 __global__ void __launch_bounds__(64 * MF_NW, 1)
 nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ logdet, const float *__restrict__ blob,
                 const int *__restrict__ table, const float *__restrict__ tabs, const float *__restrict__ lu_lad, int64_t B,
@@ -132,27 +138,28 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = table[0], Dp = table[1], Hp = table[3], NB = table[4], nI = table[5], nT = table[6], par_i = table[7],
               par_t = table[8], G = table[9], nfi = table[10];
-    float *acts = lds;                                       // [Hp / 8 k-groups][2][64][4]
-    float *xreg = lds + (size_t)(Hp / 8) * 512;              // [Dp / 8][2][64][4]
-    float *ldp = acts + NW_TAB_FLOATS;                       // log-det partials [G + 8][64], behind the staged tables
+    constexpr int KGS = 8 * TR, NIG = 64 * MF_NW / TR;       // floats per k-group of activations; identity-feature residues
+    float *acts = lds;                                       // [Hp / 8 k-groups][2][TR][4]
+    float *xreg = lds + (size_t)(Hp / 8) * KGS;              // [Dp / 8][2][TR][4]
+    float *ldp = acts + NW_TAB_FLOATS;                       // log-det partials [G + NIG][TR], behind the staged tables
     const int nitems = (1 + 2 * NB) * NHI + nfi + (LU ? 1 : 0);
     const int *items_all = table + MF_HDR + w * nitems * 3;  // [nitems][nkg, rb | g, sb0]
     const int *items = items_all + ((LU && DIR == 0) ? 3 : 0);   // the network's items (the density direction's LU entry comes first)
     const float lu_ld = LU ? (DIR == 0 ? lu_lad[0] : -lu_lad[0]) : 0.0f;
     const float *stream = blob + table[16 + w];
-    const int lane_b = (64 * hh + n) * 4;
-    const int64_t ntiles = (B + MF_ROWS - 1) / MF_ROWS;
+    const int lane_b = (TR * hh + n) * 4;
+    const int64_t ntiles = (B + TR - 1) / TR;
     MfRing ring;
     mf_ring_start(ring, stream, lane);
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t row0 = tile * MF_ROWS;
-        const int nrows = (int)((B - row0) < MF_ROWS ? (B - row0) : MF_ROWS);
+        const int64_t row0 = tile * TR;
+        const int nrows = (int)((B - row0) < TR ? (B - row0) : TR);
         ring.ap = stream + lane * 4;
         {   // x tile -> LDS (rows beyond the batch and columns beyond D are zero)
-            const int r = tid & 63, cg = tid >> 6;
+            const int r = tid % TR, cg = tid / TR;
             const float *xr = x + (row0 + r) * D;
-            for (int c = cg; c < Dp / 4; c += MF_NW) {
+            for (int c = cg; c < Dp / 4; c += NIG) {
                 f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (r < nrows && 4 * c < D) {
                     if ((D & 3) == 0) v = *reinterpret_cast<const f32x4 *>(xr + 4 * c);
@@ -160,57 +167,58 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
 #pragma unroll
                         for (int i = 0; i < 4; ++i) if (4 * c + i < D) v[i] = xr[4 * c + i];
                 }
-                *reinterpret_cast<f32x4 *>(xreg + ((size_t)c * 64 + r) * 4) = v;
+                *reinterpret_cast<f32x4 *>(xreg + ((size_t)c * TR + r) * 4) = v;
             }
         }
         float ld_ident = 0.0f;
         if constexpr (LU && DIR == 0) {
             MF_BARRIER();
-            nw_lu_stage(ring, items_all, xreg, lane_b, hh, n);
+            nw_lu_stage<TR>(ring, items_all, xreg, lane_b, hh, n);
         }
         if constexpr (DIR == 1) {                            // sampling: the identity half's inverse spline comes first (:112-114)
             for (int i = tid; i < nI * NW_TABW; i += 64 * MF_NW) acts[i] = tabs[i];
             MF_BARRIER();
-            ld_ident = nw_identity<true>(xreg, acts, p, nI, par_i, tid);
+            ld_ident = nw_identity<true, TR>(xreg, acts, p, nI, par_i, tid);
         }
         f32x16 h[NHI][NS], t[NHI][NS];
         MF_BARRIER();
         // ---- initial layer: h = b0 + W0 x (zero columns at the transform features) ---------------------------------------------------
 #pragma unroll
-        for (int s = 0; s < NHI; ++s) mf_item<NS, false>(ring, items[3 * s], xreg + lane_b + 128 * items[3 * s + 2], h[s]);
+        for (int s = 0; s < NHI; ++s) mf_item<NS, false, TR>(ring, items[3 * s], xreg + lane_b + 128 * items[3 * s + 2], h[s]);
         // ---- residual blocks (nets/resnet.py:37-50): t = b1 + W1 relu(h);  h += b2 + W2 relu(t) ----------------------------------
         for (int b = 0; b < NB; ++b) {
             MF_BARRIER();
 #pragma unroll
-            for (int s = 0; s < NHI; ++s) mf_publish<NS, true>(acts, items[3 * s + 1], items[3 * s + 2], hh, n, h[s]);
+            for (int s = 0; s < NHI; ++s) mf_publish<NS, true, TR>(acts, items[3 * s + 1], items[3 * s + 2], hh, n, h[s]);
             MF_BARRIER();
 #pragma unroll
             for (int s = 0; s < NHI; ++s) {
                 const int *it = items + 3 * ((1 + 2 * b) * NHI + s);
-                mf_item<NS, false>(ring, it[0], acts + lane_b + 128 * it[2], t[s]);
+                mf_item<NS, false, TR>(ring, it[0], acts + lane_b + 128 * it[2], t[s]);
             }
             MF_BARRIER();
 #pragma unroll
-            for (int s = 0; s < NHI; ++s) mf_publish<NS, true>(acts, items[3 * s + 1], items[3 * s + 2], hh, n, t[s]);
+            for (int s = 0; s < NHI; ++s) mf_publish<NS, true, TR>(acts, items[3 * s + 1], items[3 * s + 2], hh, n, t[s]);
             MF_BARRIER();
 #pragma unroll
             for (int s = 0; s < NHI; ++s) {
                 const int *it = items + 3 * ((2 + 2 * b) * NHI + s);
-                mf_item<NS, true>(ring, it[0], acts + lane_b + 128 * it[2], h[s]);
+                mf_item<NS, true, TR>(ring, it[0], acts + lane_b + 128 * it[2], h[s]);
             }
         }
         // ---- final layer on the raw block output (:104) in groups of four transform features + the spline ----------------------------
         MF_BARRIER();
 #pragma unroll
-        for (int s = 0; s < NHI; ++s) mf_publish<NS, false>(acts, items[3 * s + 1], items[3 * s + 2], hh, n, h[s]);
+        for (int s = 0; s < NHI; ++s) mf_publish<NS, false, TR>(acts, items[3 * s + 1], items[3 * s + 2], hh, n, h[s]);
         MF_BARRIER();
-        float ldt[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};      // [final item][sample block] (nfi <= 2)
-        for (int j = 0; j < nfi; ++j) {
+        float ldt[4][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};     // [final item][sample block] (nfi <= 4)
+#pragma nounroll
+        for (int j = 0; j < nfi; ++j) {                       // (rolled: one copy of the item's code; the sums go to their slot by selects)
             const int *it = items + 3 * ((1 + 2 * NB) * NHI + j);
-            const int g = it[1];
+            const int g = it[1], sbo = it[2];                 // group of four transform features, first of its two sample blocks
             if (g < 0) continue;
             f32x16 o[3][2];
-            nw_final_item(ring, it[0], acts + lane_b, o);
+            nw_final_item<TR>(ring, it[0], acts + lane_b + 128 * sbo, o);
             float lsum[2] = {0.0f, 0.0f};
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb)
@@ -221,7 +229,7 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
                     for (int v = 0; v < 24; ++v) prm[v] = o[(24 * f + v) >> 4][sb][(24 * f + v) & 15];
                     const int tf = 4 * g + 2 * hh + f;
                     const bool valid = tf < nT;
-                    float *xp = xreg + nw_xidx(valid ? 2 * tf + par_t : par_t, 32 * sb + n);
+                    float *xp = xreg + nw_xidx<TR>(valid ? 2 * tf + par_t : par_t, 32 * (sbo + sb) + n);
                     float yv, lad;
                     rqs_regs<DIR == 1>(p, *xp, prm, yv, lad);
                     if (valid) {
@@ -229,40 +237,46 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
                         lsum[sb] += lad;
                     }
                 }
-            if (j == 0) { ldt[0][0] = lsum[0]; ldt[0][1] = lsum[1]; } else { ldt[1][0] = lsum[0]; ldt[1][1] = lsum[1]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ldt[q][0] = j == q ? lsum[0] : ldt[q][0];
+                ldt[q][1] = j == q ? lsum[1] : ldt[q][1];
+            }
         }
         MF_BARRIER();                                        // every wave is done with the activations
         if constexpr (DIR == 0)
             for (int i = tid; i < nI * NW_TABW; i += 64 * MF_NW) acts[i] = tabs[i];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int g = w + 8 * j;
-            if (j < nfi && g < G) {
+        for (int j = 0; j < 4; ++j) {
+            if (j >= nfi) break;
+            const int *it = items + 3 * ((1 + 2 * NB) * NHI + j);
+            const int g = it[1], sbo = it[2];
+            if (g >= 0) {
 #pragma unroll
                 for (int sb = 0; sb < 2; ++sb) {
                     const float v = ldt[j][sb] + __shfl_xor(ldt[j][sb], 32);
-                    if (hh == 0) ldp[g * 64 + 32 * sb + n] = v;
+                    if (hh == 0) ldp[g * TR + 32 * (sbo + sb) + n] = v;
                 }
             }
         }
         if constexpr (DIR == 0) {                            // density: the identity half's spline after the conditioner (:88-92)
             MF_BARRIER();
-            ld_ident = nw_identity<false>(xreg, acts, p, nI, par_i, tid);
+            ld_ident = nw_identity<false, TR>(xreg, acts, p, nI, par_i, tid);
         }
-        ldp[(G + (tid >> 6)) * 64 + (tid & 63)] = ld_ident;
+        ldp[(G + tid / TR) * TR + tid % TR] = ld_ident;
         MF_BARRIER();
-        if constexpr (LU && DIR == 1) nw_lu_stage(ring, items_all + 3 * (nitems - 1), xreg, lane_b, hh, n);
+        if constexpr (LU && DIR == 1) nw_lu_stage<TR>(ring, items_all + 3 * (nitems - 1), xreg, lane_b, hh, n);
         if (tid < nrows) {
             float v = lu_ld;
-            for (int s = 0; s < G + 8; ++s) v += ldp[s * 64 + tid];      // fixed order: deterministic
+            for (int s = 0; s < G + NIG; ++s) v += ldp[s * TR + tid];      // fixed order: deterministic
             ld_store(logdet + row0 + tid, v, acc_mode);
         }
         {
-            const int r = tid & 63, cg = tid >> 6;
+            const int r = tid % TR, cg = tid / TR;
             float *yr = y + (row0 + r) * D;
             if (r < nrows)
-                for (int c = cg; 4 * c < D; c += MF_NW) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(xreg + ((size_t)c * 64 + r) * 4);
+                for (int c = cg; 4 * c < D; c += NIG) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(xreg + ((size_t)c * TR + r) * 4);
                     if ((D & 3) == 0) *reinterpret_cast<f32x4 *>(yr + 4 * c) = v;
                     else
 #pragma unroll
@@ -273,17 +287,16 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
     }
 }
 
-template <int NHI, int NS, int DIR, bool LU>
+template <int NHI, int NS, int DIR, bool LU, int TR>
 static int nsf_wide_launch(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, const void *tabs,
                            const void *lu_lad, int64_t B, int Hp, int acc, const RqsParams<float> &p, hipStream_t st) {
-    const int64_t ntiles = (B + MF_ROWS - 1) / MF_ROWS;
+    const int64_t ntiles = (B + TR - 1) / TR;
     const int grid = (int)(ntiles < 256 ? ntiles : 256);
-    size_t act_floats = (size_t)(Hp / 8) * 512;
-    if (act_floats < (size_t)NW_TAB_FLOATS + (16 + 8) * 64) act_floats = (size_t)NW_TAB_FLOATS + (16 + 8) * 64;
-    const size_t lds = sizeof(float) * (act_floats + MF_XFLOATS);
+    const size_t act_floats = (size_t)(Hp / 8) * 8 * TR;       // (>= the staged tables + the log-det partials: 2048 + 24 TR floats)
+    const size_t lds = sizeof(float) * (act_floats + (size_t)16 * 8 * TR);
     static LdsOptIn opted;
-    if (opt_in_lds(reinterpret_cast<const void *>(&nsf_wide_kernel<NHI, NS, DIR, LU>), lds, opted) != NF_OK) return NF_ENOTSUP;
-    hipLaunchKernelGGL((nsf_wide_kernel<NHI, NS, DIR, LU>), dim3((unsigned)grid), dim3(64 * MF_NW), lds, st, (const float *)x, (float *)y,
+    if (opt_in_lds(reinterpret_cast<const void *>(&nsf_wide_kernel<NHI, NS, DIR, LU, TR>), lds, opted) != NF_OK) return NF_ENOTSUP;
+    hipLaunchKernelGGL((nsf_wide_kernel<NHI, NS, DIR, LU, TR>), dim3((unsigned)grid), dim3(64 * MF_NW), lds, st, (const float *)x, (float *)y,
                        (float *)logdet, (const float *)blob, (const int *)table, (const float *)tabs, (const float *)lu_lad, B, acc, p);
     NF_CHECK_LAUNCH();
     return NF_OK;
@@ -308,9 +321,9 @@ extern "C" int nf_nsf_wide_tables(const void *uw, const void *uh, const void *ud
 template <int DIR, bool LU>
 static int nsf_wide_dispatch(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, const void *tabs,
                              const void *lu_lad, int64_t B, int Hp, int acc, const nf::RqsParams<float> &p, hipStream_t st) {
-    if (Hp == 128) return nf::nsf_wide_launch<1, 1, DIR, LU>(x, y, logdet, blob, table, tabs, lu_lad, B, Hp, acc, p, st);
-    if (Hp == 256) return nf::nsf_wide_launch<1, 2, DIR, LU>(x, y, logdet, blob, table, tabs, lu_lad, B, Hp, acc, p, st);
-    return nf::nsf_wide_launch<2, 2, DIR, LU>(x, y, logdet, blob, table, tabs, lu_lad, B, Hp, acc, p, st);
+    if (Hp == 128) return nf::nsf_wide_launch<1, 2, DIR, LU, 128>(x, y, logdet, blob, table, tabs, lu_lad, B, Hp, acc, p, st);
+    if (Hp == 256) return nf::nsf_wide_launch<1, 2, DIR, LU, 64>(x, y, logdet, blob, table, tabs, lu_lad, B, Hp, acc, p, st);
+    return nf::nsf_wide_launch<2, 2, DIR, LU, 64>(x, y, logdet, blob, table, tabs, lu_lad, B, Hp, acc, p, st);
 }
 
 // The coupling layer in one launch; blob / table: flows/nsf_wide_pack.pack_nsf_wide (packed for THIS direction when it carries the

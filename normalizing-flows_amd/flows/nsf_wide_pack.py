@@ -7,8 +7,8 @@ rows, nsf/coupling.py:334-339).  Geometry (csrc/mlp_tile.hpp, nsf_wide.hip):
   * hidden units zero-padded to Hp = 128 | 256 | 512; row-block rb = units [32 rb, 32 rb + 32); k-group = 8 consecutive inputs;
   * the initial layer contracts over the FULL row (Dp = D rounded up to 32 columns): its weight has zero columns at the transform
     features, so the x tile is the B operand as it stands;
-  * hidden work items per wave w: Hp 128: row-block w & 3 for sample block w >> 2; Hp 256: row-block w, both sample blocks;
-    Hp 512: row-blocks w and w + 8, both sample blocks;
+  * hidden work items per wave w: Hp 128 (128-row tiles): row-block w & 3 for the sample blocks 2 (w >> 2), 2 (w >> 2) + 1; Hp 256:
+    row-block w, both sample blocks; Hp 512: row-blocks w and w + 8, both sample blocks;
   * the final layer is cut into GROUPS of 4 transform features = 3 row-blocks (96 MFMA rows, 92 used): accumulator register `reg` of
     row-block r3 in lane-half hh is slot v = 16 r3 + reg of the lane's parameter list, feature tf = 4 g + 2 hh + v // 24, parameter
     v % 24 (8 widths | 8 heights | 7 derivatives | pad) -- a lane ends up with the 2 x 24 parameters of two whole features, in the
@@ -21,9 +21,10 @@ rows, nsf/coupling.py:334-339).  Geometry (csrc/mlp_tile.hpp, nsf_wide.hip):
     sample block w >> 2, FIRST in the stream in the density direction (core.py:193-195 visits the LU layer before its coupling
     layer), LAST in the sampling direction -- so a pack is per direction.
 
-int32 table : hdr[32] = [D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, total floats, nhi, has_lu, 0..], hdr[16 + w] = offset (floats)
+int32 table : hdr[32] = [D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, total floats, nhi, has_lu, TR, 0..], hdr[16 + w] = offset (floats)
               of wave w's stream; then per wave: [LU entry (density)] | (1 + 2 NB) nhi hidden entries [nkg, rb, sb0] | nfi final
-              entries [nkg, g, 0] (g = -1: none) | [LU entry (sampling)]; LU entry = [nkg, rb, sb0] (rb = -1: none).
+              entries [nkg, g, sb0] (g = -1: none; a group's item covers sample blocks sb0, sb0 + 1) | [LU entry (sampling)]; LU entry =
+              [nkg, rb, sb0] (rb = -1: none).
 """
 import numpy as np
 import torch
@@ -37,14 +38,15 @@ MP = 3 * K_BINS         # 24 slots
 
 
 def geometry(Hp):
-    """(hidden items per wave, sample blocks per item)."""
-    return {128: (1, 1), 256: (1, 2), 512: (2, 2)}[Hp]
+    """(hidden items per wave, sample blocks per item, rows per tile).  A 128-wide network's activations (64 KB for 128 rows) leave
+    room for 128-row tiles: half the barriers, tile prologues and weight-stream traffic per row."""
+    return {128: (1, 2, 128), 256: (1, 2, 64), 512: (2, 2, 64)}[Hp]
 
 
 def hidden_item(Hp, w, i):
     """(row-block, first sample block) of hidden item i of wave w."""
     if Hp == 128:
-        return w & 3, w >> 2
+        return w & 3, 2 * (w >> 2)
     if Hp == 256:
         return w, 0
     return w + 8 * i, 0
@@ -94,9 +96,10 @@ def pack_nsf_wide(prqct, lu=None, direction=0):
     par_i, par_t = int(ident[0]), int(trans[0])
     Hp = 128 if H <= 128 else (256 if H <= 256 else 512)
     Dp = (D + 31) // 32 * 32
-    nhi, NS = geometry(Hp)
+    nhi, NS, TR = geometry(Hp)
     G = (nT + 3) // 4
-    nfi = (G + 7) // 8
+    nsp = TR // 64                      # pairs of sample blocks per tile: a final item = (group, pair)
+    nfi = (G * nsp + 7) // 8
     f32 = lambda t: t.detach().cpu().numpy().astype(np.float32)
 
     W0 = np.zeros((Hp, Dp), dtype=np.float32)
@@ -140,7 +143,7 @@ def pack_nsf_wide(prqct, lu=None, direction=0):
     chunks, off = [], 0
 
     def lu_item(w, stream, idx):
-        rb, sb0 = w & 3, w >> 2
+        rb, sb0 = w & 3, (w >> 2) * (TR // 64)          # TR = 128: both sample blocks of the wave's half of the tile
         if rb >= Dp // ROWS:
             tab[w, idx] = (0, -1, 0)
             return
@@ -162,12 +165,12 @@ def pack_nsf_wide(prqct, lu=None, direction=0):
                 stream.append(bias_group(bl[rb * ROWS:(rb + 1) * ROWS]))
                 stream.append(a_stream(Wl[rb * ROWS:(rb + 1) * ROWS]))
         for j in range(nfi):
-            g = w + 8 * j
+            g, sp = divmod(w + 8 * j, nsp)
             if g >= G:
                 tab[w, base + nhl * nhi + j] = (0, -1, 0)
                 continue
             nkg = Hp // KG
-            tab[w, base + nhl * nhi + j] = (nkg, g, 0)
+            tab[w, base + nhl * nhi + j] = (nkg, g, 2 * sp)
             for r3 in range(3):
                 stream.append(bias_group(BF[g, r3]))
             frag = np.stack([a_stream(WF[g, r3]).reshape(nkg, 256) for r3 in range(3)], axis=1)   # [nkg][3][256]
@@ -178,7 +181,7 @@ def pack_nsf_wide(prqct, lu=None, direction=0):
         stream = np.concatenate([stream, np.resize(stream, RING * 256)])
         chunks.append(stream)
         off += stream.size
-    hdr[:14] = [D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, off, nhi, int(has_lu)]
+    hdr[:15] = [D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, off, nhi, int(has_lu), TR]
     blob = np.concatenate(chunks).astype(np.float32)
     assert blob.size == off and off < 2 ** 31
     return blob, np.concatenate([hdr, tab.reshape(-1)]).astype(np.int32)

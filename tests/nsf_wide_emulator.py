@@ -21,7 +21,8 @@ def emulate_conditioner(blob, table, x, direction=0):
     (B, D) or None), from full rows x (B, D).  With a fused LU: density = LU(x) first and the conditioner sees ITS output; sampling =
     the LU item comes last in the streams and is applied to x here only to check its packing."""
     blob = blob.astype(np.float64)
-    D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, total, nhi, has_lu = [int(v) for v in table[:14]]
+    D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, total, nhi, has_lu, TR = [int(v) for v in table[:15]]
+    assert TR == (128 if Hp == 128 else 64)
     nhl = 1 + 2 * NB
     nitems = nhl * nhi + nfi + has_lu
     base = 1 if (has_lu and direction == 0) else 0
@@ -39,7 +40,7 @@ def emulate_conditioner(blob, table, x, direction=0):
             nkg, rb, sb0 = [int(v) for v in tab[w, idx]]
             if rb < 0:
                 continue
-            assert rb == (w & 3) and sb0 == (w >> 2) and KG * nkg == Dp
+            assert rb == (w & 3) and sb0 == (w >> 2) * (TR // 64) and KG * nkg == Dp
             acc = np.tile(_bias(blob[pos[w]:pos[w] + 1024]), (B, 1)) + act @ _rows(blob[pos[w] + 1024:pos[w] + 1024 + 256 * nkg], nkg).T
             pos[w] += 1024 + 256 * nkg
             out[:, rb * ROWS:(rb + 1) * ROWS] = acc
@@ -72,11 +73,14 @@ def emulate_conditioner(blob, table, x, direction=0):
         t = hidden_layer(1 + 2 * b, np.maximum(h, 0.0))
         h = h + hidden_layer(2 + 2 * b, np.maximum(t, 0.0))
     prm = np.zeros((B, 4 * G, MP))
+    seen = set()
     for w in range(8):
         for j in range(nfi):
-            nkg, g, _ = [int(v) for v in tab[w, base + nhl * nhi + j]]
+            nkg, g, sb0 = [int(v) for v in tab[w, base + nhl * nhi + j]]
             if g < 0:
                 continue
+            assert (g, sb0) not in seen and sb0 in range(0, TR // 32, 2)
+            seen.add((g, sb0))
             acc = np.zeros((3, B, ROWS))
             for r3 in range(3):
                 acc[r3] = np.tile(_bias(blob[pos[w]:pos[w] + 1024]), (B, 1))
@@ -90,6 +94,7 @@ def emulate_conditioner(blob, table, x, direction=0):
                     q, hh, i = rho >> 3, (rho >> 2) & 1, rho & 3
                     v = 16 * r3 + 4 * q + i
                     prm[:, 4 * g + 2 * hh + v // MP, v % MP] = acc[r3][:, rho]
+    assert seen == {(g, sb0) for g in range(G) for sb0 in range(0, TR // 32, 2)}      # every (group, sample-block pair) has one owner
     if has_lu and direction == 1:
         lu_out = lu_stage(nitems - 1, xin)[:, :D]
     for w in range(8):
