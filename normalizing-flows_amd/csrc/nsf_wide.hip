@@ -6,8 +6,11 @@
 // The engine is mlp_tile.hpp's (made_fwd.hip describes it): 8 waves own 64 rows for the whole layer, pre-activations in accumulator
 // registers, the next layer's B operand in LDS in MFMA order, one contiguous weight stream per wave through a register ring,
 // persistent over the tiles.  What is specific here (host packer: flows/nsf_wide_pack.py):
-//   * the x tile (64 rows x Dp columns, B-operand order) is the initial layer's B operand as it stands: the packed initial weight
-//     has zero columns at the transform features (conditioner input = identity features, nsf/coupling.py:83-84);
+//   * the x tile is held with its columns SORTED (B-operand order over POSITIONS: identity feature i at position i < PI, transform
+//     feature j at PI + j; PI = the identity count rounded up to 32, zeros at the padding positions): the initial layer contracts
+//     over the first PI positions only -- the conditioner sees the identity features alone (nsf/coupling.py:83-84), so a NaN / inf in
+//     a transform column passes through its own element (utils/splines.py:40-41) without reaching the conditioner through a zero
+//     weight; the LU matrix is packed in position order;
 //   * the final layer runs in GROUPS of four transform features = 3 row-blocks for both sample blocks (6 accumulators); the packed
 //     row order makes a lane's 48 accumulator values of a sample block the 2 x 24 parameter lists (8 widths, 8 heights, 7
 //     derivatives, pad) of features 4 g + 2 hh + {0, 1}: the spline runs on them in registers (fused_common.hpp rqs_regs: branch-
@@ -89,17 +92,17 @@ __device__ __forceinline__ void nw_final_item(MfRing &r, int nkg, const float *B
     r.ap += (size_t)(12 + 3 * nkg) * 256;
 }
 
-// float index of column `col` of row `row` (0 .. TR - 1) of the tile in B-operand order [col / 4][row][4]
+// float index of POSITION `pos` of row `row` (0 .. TR - 1) of the tile in B-operand order [pos / 4][row][4]
 template <int TR>
-__device__ __forceinline__ int nw_xidx(int col, int row) { return ((col >> 2) * TR + row) * 4 + (col & 3); }
+__device__ __forceinline__ int nw_xidx(int pos, int row) { return ((pos >> 2) * TR + row) * 4 + (pos & 3); }
 
 // batch-shared spline on the identity columns of the tile, in place; thread = (row n = tid % TR, feature residue tid / TR)
 template <bool INV, int TR>
-__device__ __forceinline__ float nw_identity(float *xreg, const float *tabs, const RqsParams<float> &p, int nI, int par_i, int tid) {
+__device__ __forceinline__ float nw_identity(float *xreg, const float *tabs, const RqsParams<float> &p, int nI, int tid) {
     const int n = tid % TR;
     float ld = 0.0f;
     for (int i = tid / TR; i < nI; i += 64 * MF_NW / TR) {
-        float *xp = xreg + nw_xidx<TR>(2 * i + par_i, n);
+        float *xp = xreg + nw_xidx<TR>(i, n);                 // identity feature i sits at position i
         float y, lad;
         rqs_table_fast<INV>(p, *xp, tabs + i * NW_TABW, y, lad);
         *xp = y;
@@ -137,7 +140,7 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = table[0], Dp = table[1], Hp = table[3], NB = table[4], nI = table[5], nT = table[6], par_i = table[7],
-              par_t = table[8], G = table[9], nfi = table[10];
+              par_t = table[8], G = table[9], nfi = table[10], PI = table[15];
     constexpr int KGS = 8 * TR, NIG = 64 * MF_NW / TR;       // floats per k-group of activations; identity-feature residues
     float *acts = lds;                                       // [Hp / 8 k-groups][2][TR][4]
     float *xreg = lds + (size_t)(Hp / 8) * KGS;              // [Dp / 8][2][TR][4]
@@ -156,19 +159,25 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
         const int64_t row0 = tile * TR;
         const int nrows = (int)((B - row0) < TR ? (B - row0) : TR);
         ring.ap = stream + lane * 4;
-        {   // x tile -> LDS (rows beyond the batch and columns beyond D are zero)
+        {   // x tile -> LDS, columns sorted into positions (rows beyond the batch and the padding positions are zero)
             const int r = tid % TR, cg = tid / TR;
             const float *xr = x + (row0 + r) * D;
-            for (int c = cg; c < Dp / 4; c += NIG) {
+            for (int c = cg; 4 * c < D; c += NIG) {
                 f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (r < nrows && 4 * c < D) {
+                if (r < nrows) {
                     if ((D & 3) == 0) v = *reinterpret_cast<const f32x4 *>(xr + 4 * c);
                     else
 #pragma unroll
                         for (int i = 0; i < 4; ++i) if (4 * c + i < D) v[i] = xr[4 * c + i];
                 }
-                *reinterpret_cast<f32x4 *>(xreg + ((size_t)c * TR + r) * 4) = v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int col = 4 * c + i;
+                    if (col < D) xreg[nw_xidx<TR>(((col ^ par_i) & 1) ? PI + (col >> 1) : (col >> 1), r)] = v[i];
+                }
             }
+            for (int ps = nI + cg; ps < PI; ps += NIG) xreg[nw_xidx<TR>(ps, r)] = 0.0f;
+            for (int ps = PI + nT + cg; ps < Dp; ps += NIG) xreg[nw_xidx<TR>(ps, r)] = 0.0f;
         }
         float ld_ident = 0.0f;
         if constexpr (LU && DIR == 0) {
@@ -178,7 +187,7 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
         if constexpr (DIR == 1) {                            // sampling: the identity half's inverse spline comes first (:112-114)
             for (int i = tid; i < nI * NW_TABW; i += 64 * MF_NW) acts[i] = tabs[i];
             MF_BARRIER();
-            ld_ident = nw_identity<true, TR>(xreg, acts, p, nI, par_i, tid);
+            ld_ident = nw_identity<true, TR>(xreg, acts, p, nI, tid);
         }
         f32x16 h[NHI][NS], t[NHI][NS];
         MF_BARRIER();
@@ -229,7 +238,7 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
                     for (int v = 0; v < 24; ++v) prm[v] = o[(24 * f + v) >> 4][sb][(24 * f + v) & 15];
                     const int tf = 4 * g + 2 * hh + f;
                     const bool valid = tf < nT;
-                    float *xp = xreg + nw_xidx<TR>(valid ? 2 * tf + par_t : par_t, 32 * (sbo + sb) + n);
+                    float *xp = xreg + nw_xidx<TR>(PI + (valid ? tf : 0), 32 * (sbo + sb) + n);
                     float yv, lad;
                     rqs_regs<DIR == 1>(p, *xp, prm, yv, lad);
                     if (valid) {
@@ -261,7 +270,7 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
         }
         if constexpr (DIR == 0) {                            // density: the identity half's spline after the conditioner (:88-92)
             MF_BARRIER();
-            ld_ident = nw_identity<false, TR>(xreg, acts, p, nI, par_i, tid);
+            ld_ident = nw_identity<false, TR>(xreg, acts, p, nI, tid);
         }
         ldp[(G + tid / TR) * TR + tid % TR] = ld_ident;
         MF_BARRIER();
@@ -276,7 +285,12 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
             float *yr = y + (row0 + r) * D;
             if (r < nrows)
                 for (int c = cg; 4 * c < D; c += NIG) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(xreg + ((size_t)c * TR + r) * 4);
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int col = 4 * c + i < D ? 4 * c + i : D - 1;
+                        v[i] = xreg[nw_xidx<TR>(((col ^ par_i) & 1) ? PI + (col >> 1) : (col >> 1), r)];
+                    }
                     if ((D & 3) == 0) *reinterpret_cast<f32x4 *>(yr + 4 * c) = v;
                     else
 #pragma unroll

@@ -5,8 +5,10 @@ kernel's (csrc/rqs_fused.hip: D <= 64, hidden <= 128) -- up to 128 features and 
 This module only rearranges weights (no arithmetic on data besides the constant log2(e) / sqrt(hidden) folded into the width / height
 rows, nsf/coupling.py:334-339).  Geometry (csrc/mlp_tile.hpp, nsf_wide.hip):
   * hidden units zero-padded to Hp = 128 | 256 | 512; row-block rb = units [32 rb, 32 rb + 32); k-group = 8 consecutive inputs;
-  * the initial layer contracts over the FULL row (Dp = D rounded up to 32 columns): its weight has zero columns at the transform
-    features, so the x tile is the B operand as it stands;
+  * the x tile is held with its columns SORTED: position i < PI = identity feature i, position PI + j = transform feature j
+    (PI, PT = the two counts rounded up to 32; Dp = PI + PT; padding positions hold zeros).  The initial layer contracts over the
+    first PI positions only -- the conditioner sees the identity features alone (nsf/coupling.py:83-84): a NaN in a TRANSFORM
+    column must not reach it through a zero weight -- and the LU layer's dense matrix is packed in the same position order;
   * hidden work items per wave w: Hp 128 (128-row tiles): row-block w & 3 for the sample blocks 2 (w >> 2), 2 (w >> 2) + 1; Hp 256:
     row-block w, both sample blocks; Hp 512: row-blocks w and w + 8, both sample blocks;
   * the final layer is cut into GROUPS of 4 transform features = 3 row-blocks (96 MFMA rows, 92 used): accumulator register `reg` of
@@ -21,7 +23,7 @@ rows, nsf/coupling.py:334-339).  Geometry (csrc/mlp_tile.hpp, nsf_wide.hip):
     sample block w >> 2, FIRST in the stream in the density direction (core.py:193-195 visits the LU layer before its coupling
     layer), LAST in the sampling direction -- so a pack is per direction.
 
-int32 table : hdr[32] = [D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, total floats, nhi, has_lu, TR, 0..], hdr[16 + w] = offset (floats)
+int32 table : hdr[32] = [D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, total floats, nhi, has_lu, TR, PI], hdr[16 + w] = offset (floats)
               of wave w's stream; then per wave: [LU entry (density)] | (1 + 2 NB) nhi hidden entries [nkg, rb, sb0] | nfi final
               entries [nkg, g, sb0] (g = -1: none; a group's item covers sample blocks sb0, sb0 + 1) | [LU entry (sampling)]; LU entry =
               [nkg, rb, sb0] (rb = -1: none).
@@ -95,15 +97,19 @@ def pack_nsf_wide(prqct, lu=None, direction=0):
     nI, nT = len(ident), len(trans)
     par_i, par_t = int(ident[0]), int(trans[0])
     Hp = 128 if H <= 128 else (256 if H <= 256 else 512)
-    Dp = (D + 31) // 32 * 32
+    PI, PT = (nI + 31) // 32 * 32, (nT + 31) // 32 * 32
+    Dp = PI + PT
+    col_of = -np.ones(Dp, dtype=np.int64)          # position -> column of the row (or -1: padding)
+    col_of[:nI] = ident
+    col_of[PI:PI + nT] = trans
     nhi, NS, TR = geometry(Hp)
     G = (nT + 3) // 4
     nsp = TR // 64                      # pairs of sample blocks per tile: a final item = (group, pair)
     nfi = (G * nsp + 7) // 8
     f32 = lambda t: t.detach().cpu().numpy().astype(np.float32)
 
-    W0 = np.zeros((Hp, Dp), dtype=np.float32)
-    W0[:H, ident] = f32(net.initial_layer.weight)
+    W0 = np.zeros((Hp, PI), dtype=np.float32)
+    W0[:H, :nI] = f32(net.initial_layer.weight)
     b0 = np.zeros(Hp, dtype=np.float32)
     b0[:H] = f32(net.initial_layer.bias)
     layers = [(W0, b0)]
@@ -134,10 +140,11 @@ def pack_nsf_wide(prqct, lu=None, direction=0):
     nitems = nhl * nhi + nfi + (1 if has_lu else 0)
     base = 1 if (has_lu and direction == 0) else 0
     if has_lu:
+        valid = col_of >= 0
         WL = np.zeros((Dp, Dp), dtype=np.float32)
-        WL[:D, :D] = np.asarray(lu[0], dtype=np.float32)
+        WL[np.ix_(valid, valid)] = np.asarray(lu[0], dtype=np.float32)[np.ix_(col_of[valid], col_of[valid])]
         bL = np.zeros(Dp, dtype=np.float32)
-        bL[:D] = np.asarray(lu[1], dtype=np.float32)
+        bL[valid] = np.asarray(lu[1], dtype=np.float32)[col_of[valid]]
     hdr = np.zeros(HDR, dtype=np.int32)
     tab = np.zeros((8, nitems, 3), dtype=np.int32)
     chunks, off = [], 0
@@ -181,7 +188,7 @@ def pack_nsf_wide(prqct, lu=None, direction=0):
         stream = np.concatenate([stream, np.resize(stream, RING * 256)])
         chunks.append(stream)
         off += stream.size
-    hdr[:15] = [D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, off, nhi, int(has_lu), TR]
+    hdr[:16] = [D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, off, nhi, int(has_lu), TR, PI]
     blob = np.concatenate(chunks).astype(np.float32)
     assert blob.size == off and off < 2 ** 31
     return blob, np.concatenate([hdr, tab.reshape(-1)]).astype(np.int32)

@@ -21,16 +21,17 @@ def emulate_conditioner(blob, table, x, direction=0):
     (B, D) or None), from full rows x (B, D).  With a fused LU: density = LU(x) first and the conditioner sees ITS output; sampling =
     the LU item comes last in the streams and is applied to x here only to check its packing."""
     blob = blob.astype(np.float64)
-    D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, total, nhi, has_lu, TR = [int(v) for v in table[:15]]
-    assert TR == (128 if Hp == 128 else 64)
+    D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, total, nhi, has_lu, TR, PI = [int(v) for v in table[:16]]
+    assert TR == (128 if Hp == 128 else 64) and PI % 32 == 0 and (Dp - PI) % 32 == 0 and PI >= nI and Dp - PI >= nT
     nhl = 1 + 2 * NB
     nitems = nhl * nhi + nfi + has_lu
     base = 1 if (has_lu and direction == 0) else 0
     tab = table[HDR:HDR + 8 * nitems * 3].reshape(8, nitems, 3)
     x = np.asarray(x, dtype=np.float64)
     B = x.shape[0]
-    xin = np.zeros((B, Dp))
-    xin[:, :D] = x
+    xin = np.zeros((B, Dp))                                   # the tile in position order: identity features, then transform features
+    xin[:, :nI] = x[:, par_i::2]
+    xin[:, PI:PI + nT] = x[:, par_t::2]
     pos = [int(table[16 + w]) for w in range(8)]
     start = list(pos)
 
@@ -46,10 +47,16 @@ def emulate_conditioner(blob, table, x, direction=0):
             out[:, rb * ROWS:(rb + 1) * ROWS] = acc
         return out
 
+    def to_columns(t):
+        out = np.zeros((B, D))
+        out[:, par_i::2] = t[:, :nI]
+        out[:, par_t::2] = t[:, PI:PI + nT]
+        return out
+
     lu_out = None
     if has_lu and direction == 0:
         xin = lu_stage(0, xin)
-        lu_out = xin[:, :D].copy()
+        lu_out = to_columns(xin)
 
     def hidden_layer(l, act):
         out = np.full((B, Hp), np.nan)
@@ -58,8 +65,8 @@ def emulate_conditioner(blob, table, x, direction=0):
                 nkg, rb, sb0 = [int(v) for v in tab[w, base + l * nhi + i]]
                 acc = np.tile(_bias(blob[pos[w]:pos[w] + 1024]), (B, 1))
                 pos[w] += 1024
-                assert KG * nkg == act.shape[1]
-                acc = acc + act @ _rows(blob[pos[w]:pos[w] + 256 * nkg], nkg).T
+                assert KG * nkg == (PI if l == 0 else act.shape[1])          # the initial layer contracts over the identity positions
+                acc = acc + act[:, :KG * nkg] @ _rows(blob[pos[w]:pos[w] + 256 * nkg], nkg).T
                 pos[w] += 256 * nkg
                 # (a wave computes only its sample blocks; the emulation ignores the split: every owner must agree)
                 prev = out[:, rb * ROWS:(rb + 1) * ROWS]
@@ -96,7 +103,7 @@ def emulate_conditioner(blob, table, x, direction=0):
                     prm[:, 4 * g + 2 * hh + v // MP, v % MP] = acc[r3][:, rho]
     assert seen == {(g, sb0) for g in range(G) for sb0 in range(0, TR // 32, 2)}      # every (group, sample-block pair) has one owner
     if has_lu and direction == 1:
-        lu_out = lu_stage(nitems - 1, xin)[:, :D]
+        lu_out = to_columns(lu_stage(nitems - 1, xin))
     for w in range(8):
         n = pos[w] - start[w]
         assert np.array_equal(blob[pos[w]:pos[w] + RING * 256], np.resize(blob[start[w]:pos[w]], RING * 256)), w
