@@ -1212,6 +1212,62 @@ def test_nsf_wide_one_launch_vs_layerwise_and_oracle(nfa, oracle, D, H, NB, rev,
         assert np.quantile(el, 0.99) < 2e-4 and el.max() < 5e-3, (name, float(np.quantile(el, 0.99)), float(el.max()))
 
 
+def test_round4_entry_points_reject_bad_arguments_and_replay_in_graphs(nfa):
+    """nf_made_forward[_affine] / nf_nsf_wide[_tables] through the raw C ABI: the errno codes of include/nf_mi355x.h (-22 EINVAL,
+    -14 EFAULT, -95 ENOTSUP) for bad arguments, success without touching memory for an empty batch; and both kernels inside a
+    recorded hipGraph (use_graphs): replay = eager, bit for bit."""
+    import ctypes as C
+    from normflows_amd import _lib as L
+    lib = L.lib()
+    nul, one = C.c_void_p(0), C.c_void_p(16)
+    st = L.stream()
+    i64, i32, f64 = C.c_int64, C.c_int, C.c_double
+    assert lib.nf_made_forward_affine(nul, nul, nul, nul, nul, i64(0), i32(8), i32(256), i32(0), st) == 0          # B = 0
+    assert lib.nf_made_forward_affine(nul, nul, nul, nul, nul, i64(4), i32(8), i32(256), i32(0), st) == -14        # NULL buffers
+    assert lib.nf_made_forward_affine(one, one, one, one, one, i64(4), i32(200), i32(256), i32(0), st) == -22      # D > 128
+    assert lib.nf_made_forward_affine(one, one, one, one, one, i64(4), i32(8), i32(300), i32(0), st) == -95        # hidden_padded
+    assert lib.nf_made_forward_affine(one, one, one, one, one, i64(4), i32(8), i32(256), i32(7), st) == -22        # acc
+    assert lib.nf_made_forward(one, one, one, one, i64(4), i32(8), i32(512), i32(0), st) == -22                    # mult < 1
+    assert lib.nf_nsf_wide(nul, nul, nul, nul, nul, nul, nul, i64(0), i32(64), i32(256), i32(0), i32(0), f64(3.0), f64(1e-3),
+                           f64(1e-3), f64(1e-3), st) == 0
+    assert lib.nf_nsf_wide(nul, nul, nul, nul, nul, nul, nul, i64(5), i32(64), i32(256), i32(0), i32(0), f64(3.0), f64(1e-3),
+                           f64(1e-3), f64(1e-3), st) == -14
+    assert lib.nf_nsf_wide(one, one, one, one, one, one, nul, i64(5), i32(64), i32(256), i32(2), i32(0), f64(3.0), f64(1e-3),
+                           f64(1e-3), f64(1e-3), st) == -22                                                        # direction
+    assert lib.nf_nsf_wide(one, one, one, one, one, one, nul, i64(5), i32(64), i32(192), i32(0), i32(0), f64(3.0), f64(1e-3),
+                           f64(1e-3), f64(1e-3), st) == -95                                                        # hidden_padded
+    assert lib.nf_nsf_wide(one, one, one, one, one, one, nul, i64(5), i32(64), i32(256), i32(0), i32(0), f64(3.0), f64(0.2),
+                           f64(1e-3), f64(1e-3), st) == -22                                  # min_bin_width * 8 > 1 (utils/splines.py:121-124)
+    assert lib.nf_nsf_wide_tables(one, one, one, one, i32(32), i32(10), f64(3.0), f64(1e-3), f64(1e-3), f64(1e-3), st) == -95   # bins
+    assert lib.nf_nsf_wide_tables(one, one, one, one, i32(80), i32(8), f64(3.0), f64(1e-3), f64(1e-3), f64(1e-3), st) == -22    # > 64 features
+    # hipGraph replay of a MAF model's forward direction and of a wide NSF model's log_prob
+    torch.manual_seed(3)
+    maf = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(24, trainable=False),
+                              [nfa.flows.MaskedAffineAutoregressive(24, 96, num_blocks=2) for _ in range(3)])
+    _perturb(maf, 0.05, 2)
+    maf = maf.to(DEV)
+    flows = []
+    for _ in range(2):
+        flows += [nfa.flows.CoupledRationalQuadraticSpline(80, 2, 200, num_bins=8), nfa.flows.LULinearPermute(80)]
+    wide = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(80, trainable=False), flows)
+    _perturb(wide, 0.03, 4)
+    wide = wide.to(DEV)
+    eps = torch.randn(500, 24, device=DEV)
+    x = torch.randn(700, 80, device=DEV)
+    e1 = maf.sample_from_noise(eps)
+    e2 = wide.log_prob(x)
+    maf.use_graphs(True)
+    wide.use_graphs(True)
+    try:
+        for _ in range(2):
+            g1 = maf.sample_from_noise(eps)
+            g2 = wide.log_prob(x)
+        assert torch.equal(g1[0], e1[0]) and torch.equal(g1[1], e1[1]) and torch.equal(g2, e2)
+    finally:
+        maf.use_graphs(False)
+        wide.use_graphs(False)
+
+
 @pytest.mark.parametrize("D,H", [(64, 256), (128, 128), (96, 192), (33, 300)])
 def test_nsf_wide_pairs_with_fused_lu_vs_layerwise(nfa, D, H):
     """[CoupledRationalQuadraticSpline, LULinearPermute] pairs beyond the benchmark kernel's shapes: nf_nsf_wide with the LU layer's
