@@ -1268,6 +1268,31 @@ def test_round4_entry_points_reject_bad_arguments_and_replay_in_graphs(nfa):
         wide.use_graphs(False)
 
 
+def test_nsf_wide_full_batch_properties(nfa):
+    """nf_nsf_wide at the BASELINE batch (65 536 rows = 1024 / 512 tiles, every CU busy, persistent workgroups walking several tiles
+    with the weight ring wrapping between them): size-independent properties -- run-to-run bit equality, log_prob(sample) = the
+    sampler's log_q (core_test.py:144-196), the inverse pass undoes the forward pass -- on a 4-pair model of each tile geometry."""
+    for D, H in ((64, 256), (128, 128), (128, 512)):
+        torch.manual_seed(D + H)
+        flows = []
+        for _ in range(4):
+            flows += [nfa.flows.CoupledRationalQuadraticSpline(D, 2, H, num_bins=8), nfa.flows.LULinearPermute(D, identity_init=False)]
+        m = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(D, trainable=False), flows)
+        _perturb(m, 0.01, 7)
+        m = m.to(DEV)
+        assert flows[0]._pair_eligible(torch.zeros(2, D, device=DEV), flows[1]) and not flows[0].prqct._fused_eligible(torch.zeros(2, D, device=DEV), None)
+        eps = torch.randn(65536, D, generator=torch.Generator().manual_seed(1)).to(DEV)
+        xs, lq = m.sample_from_noise(eps)
+        xs2, lq2 = m.sample_from_noise(eps)
+        assert torch.equal(xs, xs2) and torch.equal(lq, lq2)
+        lp = m.log_prob(xs)
+        assert torch.equal(lp, m.log_prob(xs))
+        assert _rel(N(lp), N(lq)) < 1e-4, (D, H, _rel(N(lp), N(lq)))
+        z, _ = m.inverse_and_log_det(xs)
+        z0 = m.q0.loc.reshape(1, -1) + torch.exp(m.q0.log_scale.reshape(1, -1)) * eps
+        assert float((z - z0).abs().max()) < 2e-3, (D, H, float((z - z0).abs().max()))
+
+
 @pytest.mark.parametrize("D,H", [(64, 256), (128, 128), (96, 192), (33, 300)])
 def test_nsf_wide_pairs_with_fused_lu_vs_layerwise(nfa, D, H):
     """[CoupledRationalQuadraticSpline, LULinearPermute] pairs beyond the benchmark kernel's shapes: nf_nsf_wide with the LU layer's
