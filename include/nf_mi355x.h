@@ -508,6 +508,15 @@ int nf_made_forward_affine(const void *x, void *y, void *logdet, const void *blo
                            int hidden_padded, int acc, nf_stream_t stream);
 int nf_made_forward(const void *x, void *params, const void *blob, const int32_t *table, int64_t B, int D, int hidden_padded,
                     int mult, nf_stream_t stream);
+/* The autoregressive rational-quadratic spline layer's density direction in one launch: replaces
+ * normflows/flows/neural_spline/autoregressive.py:94-134 (MaskedPiecewiseRationalQuadraticAutoregressive._elementwise_forward over
+ * Autoregressive.forward, flows/affine/autoregressive.py:24-27; what wrapper.py:241-245 AutoregressiveRationalQuadraticSpline.inverse
+ * calls): MADE with 23 = 3 * 8 - 1 outputs per feature, then utils/splines.py:16-219 element-wise (8 bins, linear tails, no
+ * 1 / sqrt(hidden) scaling: the reference's MADE has no `hidden_features`), row-summed log-det.
+ *   blob, table : made_pack.pack_made_forward(made, 23, spline=True); x, y (B, D); logdet (B) combined according to `acc`. */
+int nf_made_forward_spline(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, int64_t B, int D,
+                           int hidden_padded, int acc, double tail_bound, double min_bin_width, double min_bin_height,
+                           double min_derivative, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * MaskedAffineAutoregressive inverse (MAF sampling direction) in ONE pass.  Replaces the D-pass loop of

@@ -32,11 +32,15 @@
 namespace nf {
 
 // EPI 0: z = scale x + shift, logdet = sum log scale (autoregressive.py:101-110, :124-128: rows 2 f = unconstrained scale, 2 f + 1
-// = shift);  EPI 1: the raw MADE output (B, mult D) for the callers that apply another element-wise transform.
+// = shift);  EPI 1: the raw MADE output (B, mult D) for the callers that apply another element-wise transform;  EPI 2: the
+// autoregressive rational-quadratic spline of neural_spline/autoregressive.py:94-134 (density direction: one MADE pass, then
+// utils/splines.py:16-219 element-wise with 8 bins and linear tails) on the final layer's accumulators -- the final layer runs in
+// groups of four features whose rows are packed so that a lane holds the 2 x 24 parameters of two features (the layout of
+// nsf_wide.hip; mlp_tile.hpp mf_final_item), the spline runs in registers (rqs_regs), x is read from the tile and y written into it.
 template <int NSB, int EPI>
 __global__ void __launch_bounds__(64 * MF_NW, 1)
 made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ logdet, const float *__restrict__ blob,
-                const int *__restrict__ table, int64_t B, int acc_mode) {
+                const int *__restrict__ table, int64_t B, int acc_mode, RqsParams<float> p) {
     constexpr int NS = NSB;                  // sample blocks per hidden work item
     constexpr int HRB = 8 * NSB;             // hidden row-blocks
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -98,6 +102,74 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
 #pragma unroll
         for (int s = 0; s < 2; ++s) mf_publish<NS, false>(acts, rbs[s], sb0s[s], hh, n, h[s]);
         MF_BARRIER();
+        if constexpr (EPI == 2) {
+            const int G = NFB, nfi = nrounds;                 // (the header slots of the block variants: groups, final items per wave)
+            const int *fit = items + 2 * (2 + 4 * NB);
+            float ldt[4][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+#pragma nounroll
+            for (int j = 0; j < nfi; ++j) {
+                const int g = fit[2 * j + 1];
+                if (g < 0) continue;
+                f32x16 o[3][2];
+                mf_final_item<MF_ROWS>(ring, fit[2 * j], acts + lane_b, o);
+                float lsum[2] = {0.0f, 0.0f};
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        float prm[24];
+#pragma unroll
+                        for (int v = 0; v < 24; ++v) prm[v] = o[(24 * f + v) >> 4][sb][(24 * f + v) & 15];
+                        const int tf = 4 * g + 2 * hh + f;
+                        const bool valid = tf < D;
+                        const int col = valid ? tf : 0;
+                        float *xp = xreg + ((size_t)(col >> 2) * 64 + 32 * sb + n) * 4 + (col & 3);
+                        float yv, lad;
+                        rqs_regs<false>(p, *xp, prm, yv, lad);
+                        if (valid) {
+                            *xp = yv;
+                            lsum[sb] += lad;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);      // one evaluation at a time: interleaved, the four cost 7 spilled VGPRs at Hp = 512
+                    }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    ldt[q][0] = j == q ? lsum[0] : ldt[q][0];
+                    ldt[q][1] = j == q ? lsum[1] : ldt[q][1];
+                }
+            }
+            MF_BARRIER();                      // every wave is done with the activations: their region now holds the partial sums
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j >= nfi) break;
+                const int g = fit[2 * j + 1];
+                if (g >= 0) {
+#pragma unroll
+                    for (int sb = 0; sb < 2; ++sb) {
+                        const float v = ldt[j][sb] + __shfl_xor(ldt[j][sb], 32);
+                        if (hh == 0) acts[g * 64 + 32 * sb + n] = v;
+                    }
+                }
+            }
+            MF_BARRIER();
+            if (tid < nrows) {
+                float v = 0.0f;
+                for (int g = 0; g < G; ++g) v += acts[g * 64 + tid];      // fixed order: deterministic
+                ld_store(logdet + row0 + tid, v, acc_mode);
+            }
+            const int r = tid & 63, cg = tid >> 6;
+            float *yr = y + (row0 + r) * D;
+            if (r < nrows)
+                for (int c = cg; 4 * c < D; c += MF_NW) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(xreg + ((size_t)c * 64 + r) * 4);
+                    if ((D & 3) == 0) *reinterpret_cast<f32x4 *>(yr + 4 * c) = v;
+                    else
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (4 * c + i < D) yr[4 * c + i] = v[i];
+                }
+            MF_BARRIER();                      // the next tile overwrites the x tile and the activations
+            continue;
+        }
         float ldsum[2] = {0.0f, 0.0f};
         for (int rd = 0; rd < nrounds; ++rd) {
 #pragma unroll
@@ -171,14 +243,15 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
 }
 
 template <int NSB, int EPI>
-static int made_fwd_launch(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, int64_t B, int acc, hipStream_t st) {
+static int made_fwd_launch(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, int64_t B, int acc, hipStream_t st,
+                           const RqsParams<float> &p = RqsParams<float>()) {
     const int64_t ntiles = (B + MF_ROWS - 1) / MF_ROWS;
     const int grid = (int)(ntiles < 256 ? ntiles : 256);        // persistent: one workgroup per CU (160 KB of LDS at Hp = 512)
     const size_t lds = sizeof(float) * ((size_t)8 * NSB * 4 * 512 + MF_XFLOATS);
     static LdsOptIn opted;
     if (opt_in_lds(reinterpret_cast<const void *>(&made_fwd_kernel<NSB, EPI>), lds, opted) != NF_OK) return NF_ENOTSUP;
     hipLaunchKernelGGL((made_fwd_kernel<NSB, EPI>), dim3((unsigned)grid), dim3(64 * MF_NW), lds, st, (const float *)x, (float *)y,
-                       (float *)logdet, (const float *)blob, (const int *)table, B, acc);
+                       (float *)logdet, (const float *)blob, (const int *)table, B, acc, p);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -214,4 +287,22 @@ extern "C" int nf_made_forward(const void *x, void *params, const void *blob, co
     hipStream_t st = (hipStream_t)stream;
     if (hidden_padded == 256) return nf::made_fwd_launch<1, 1>(x, params, nullptr, blob, table, B, NF_LD_WRITE, st);
     return nf::made_fwd_launch<2, 1>(x, params, nullptr, blob, table, B, NF_LD_WRITE, st);
+}
+
+// MaskedPiecewiseRationalQuadraticAutoregressive.forward (neural_spline/autoregressive.py:94-134, density direction of the
+// autoregressive spline layer; wrapper.py:241-245) in one launch: MADE + the element-wise spline with 8 bins and linear tails.
+// blob / table: flows/made_pack.pack_made_forward(made, 23, spline=True).
+extern "C" int nf_made_forward_spline(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, int64_t B, int D,
+                                      int hidden_padded, int acc, double tail_bound, double min_bin_width, double min_bin_height,
+                                      double min_derivative, nf_stream_t stream) {
+    const int rc = made_fwd_check(B, D, hidden_padded, 23);
+    if (rc != NF_OK) return rc;
+    if (acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
+    if (min_bin_width * nf::F_K > 1.0 || min_bin_height * nf::F_K > 1.0) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!x || !y || !logdet || !blob || !table) return NF_EFAULT;
+    auto p = nf::make_rqs_params<float>(nf::F_K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height, min_derivative, 1.0);
+    hipStream_t st = (hipStream_t)stream;
+    if (hidden_padded == 256) return nf::made_fwd_launch<1, 2>(x, y, logdet, blob, table, B, acc, st, p);
+    return nf::made_fwd_launch<2, 2>(x, y, logdet, blob, table, B, acc, st, p);
 }

@@ -134,4 +134,67 @@ __device__ __forceinline__ void mf_publish(float *acts, int rb, int sb0, int hh,
         }
 }
 
+
+// ---- final layer of a spline conditioner in GROUPS of four features = 3 row-blocks, both sample blocks of a pair ------------------
+// (nsf_wide.hip, made_fwd.hip EPI 2): accumulator register `reg` of row-block r3 in lane-half hh is slot v = 16 r3 + reg of the lane's
+// parameter list, feature 4 g + 2 hh + v / 24, parameter v % 24 (8 widths | 8 heights | 7 derivatives | pad): the order the register
+// spline routine (fused_common.hpp rqs_regs) reads.  Stream of the item: 12 bias entries (row-block r3, quad q), then per k-group one
+// A fragment per row-block.
+
+// ring entry e of the current item (idx = e mod 8; a compile-time constant after unrolling at every call site): consume it,
+// re-request it 8 entries ahead
+__device__ __forceinline__ f32x4 mf_take(MfRing &r, int idx, int e) {
+    const f32x4 v = r.a[idx];
+    r.a[idx] = *reinterpret_cast<const f32x4 *>(r.ap + (size_t)(e + 8) * 256);
+    return v;
+}
+
+// NK (8 or 4) k-groups: 3 NK ring entries starting at ring phase K0
+template <int K0, int NK, int TR>
+__device__ __forceinline__ void mf_final_kgs(MfRing &r, int e0, const float *bp, f32x16 (&o)[3][2]) {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bp + k * (8 * TR));
+        const f32x4 b1 = *reinterpret_cast<const f32x4 *>(bp + k * (8 * TR) + 128);
+#pragma unroll
+        for (int r3 = 0; r3 < 3; ++r3) {
+            const f32x4 av = mf_take(r, (K0 + 3 * k + r3) & 7, e0 + 3 * k + r3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o[r3][0] = MF_MFMA(av[i], b0[i], o[r3][0]);
+                o[r3][1] = MF_MFMA(av[i], b1[i], o[r3][1]);
+            }
+        }
+    }
+}
+
+// one group: o[r3][sb] = bias + W[32 rows] . act[., 32 samples]; nkg a multiple of 4 (packer); leaves the ring in phase 0
+template <int TR>
+__device__ __forceinline__ void mf_final_item(MfRing &r, int nkg, const float *Bl, f32x16 (&o)[3][2]) {
+    // 12 bias entries: the item starts in ring phase 0; entries 8..11 come from the re-requested a[0..3]
+#pragma unroll
+    for (int e = 0; e < 12; ++e) {
+        const f32x4 bq = mf_take(r, e & 7, e);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[e >> 2][0][4 * (e & 3) + i] = bq[i];
+            o[e >> 2][1][4 * (e & 3) + i] = bq[i];
+        }
+    }
+    // A entries start at ring phase 4 (12 mod 8); 8 k-groups = 24 entries = three revolutions keep the phase
+    int kg = 0;
+    for (; kg + 8 <= nkg; kg += 8) mf_final_kgs<4, 8, TR>(r, 12 + 3 * kg, Bl + (size_t)kg * (8 * TR), o);
+    if (kg < nkg) {          // four more k-groups = 12 entries: 4 + 12 = 0 (mod 8), the next item starts in ring half 0
+        mf_final_kgs<4, 4, TR>(r, 12 + 3 * kg, Bl + (size_t)kg * (8 * TR), o);
+    } else {                 // 12 + 3 nkg = 4 (mod 8): the next item's first entries sit in ring half 1
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 tmp = r.a[j];
+            r.a[j] = r.a[4 + j];
+            r.a[4 + j] = tmp;
+        }
+    }
+    r.ap += (size_t)(12 + 3 * nkg) * 256;
+}
+
 }  // namespace nf

@@ -40,58 +40,6 @@ __global__ void nsf_wide_tables_kernel(const float *__restrict__ uw, const float
     rqs_build_table<float>(p, wacc, hacc, dacc, tab + j * NW_TABW);
 }
 
-// ring entry e of the current item (idx = e mod 8; a compile-time constant after unrolling at every call site): consume it,
-// re-request it 8 entries ahead
-__device__ __forceinline__ f32x4 nw_take(MfRing &r, int idx, int e) {
-    const f32x4 v = r.a[idx];
-    r.a[idx] = *reinterpret_cast<const f32x4 *>(r.ap + (size_t)(e + 8) * 256);
-    return v;
-}
-
-// eight k-groups of a final item: per k-group one A fragment per row-block (3 ring entries), both sample blocks
-template <int K0, int TR>
-__device__ __forceinline__ void nw_final_kgs(MfRing &r, int e0, const float *bp, f32x16 (&o)[3][2]) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bp + k * (8 * TR));
-        const f32x4 b1 = *reinterpret_cast<const f32x4 *>(bp + k * (8 * TR) + 128);
-#pragma unroll
-        for (int r3 = 0; r3 < 3; ++r3) {
-            const f32x4 av = nw_take(r, (K0 + 3 * k + r3) & 7, e0 + 3 * k + r3);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                o[r3][0] = MF_MFMA(av[i], b0[i], o[r3][0]);
-                o[r3][1] = MF_MFMA(av[i], b1[i], o[r3][1]);
-            }
-        }
-    }
-}
-
-// one group of the final layer: o[r3][sb] = bias + W[32 rows] . h[., 32 samples]; nkg is a multiple of 8
-template <int TR>
-__device__ __forceinline__ void nw_final_item(MfRing &r, int nkg, const float *Bl, f32x16 (&o)[3][2]) {
-    // 12 bias entries (row-block r3, quad q): the item starts in ring phase 0; entries 8..11 come from the re-requested a[0..3]
-#pragma unroll
-    for (int e = 0; e < 12; ++e) {
-        const f32x4 bq = nw_take(r, e & 7, e);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            o[e >> 2][0][4 * (e & 3) + i] = bq[i];
-            o[e >> 2][1][4 * (e & 3) + i] = bq[i];
-        }
-    }
-    // A entries start at ring phase 4 (12 mod 8); 8 k-groups = 24 entries = three revolutions
-    for (int kg = 0; kg < nkg; kg += 8) nw_final_kgs<4, TR>(r, 12 + 3 * kg, Bl + (size_t)kg * (8 * TR), o);
-    // 12 + 3 nkg = 4 (mod 8): the next item's first entries sit in ring half 1
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const f32x4 tmp = r.a[j];
-        r.a[j] = r.a[4 + j];
-        r.a[4 + j] = tmp;
-    }
-    r.ap += (size_t)(12 + 3 * nkg) * 256;
-}
-
 // float index of POSITION `pos` of row `row` (0 .. TR - 1) of the tile in B-operand order [pos / 4][row][4]
 template <int TR>
 __device__ __forceinline__ int nw_xidx(int pos, int row) { return ((pos >> 2) * TR + row) * 4 + (pos & 3); }
@@ -227,7 +175,7 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
             const int g = it[1], sbo = it[2];                 // group of four transform features, first of its two sample blocks
             if (g < 0) continue;
             f32x16 o[3][2];
-            nw_final_item<TR>(ring, it[0], acts + lane_b + 128 * sbo, o);
+            mf_final_item<TR>(ring, it[0], acts + lane_b + 128 * sbo, o);
             float lsum[2] = {0.0f, 0.0f};
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb)

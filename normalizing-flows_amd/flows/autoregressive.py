@@ -163,6 +163,21 @@ class MaskedPiecewiseRationalQuadraticAutoregressive(Autoregressive):
             self._arnsf_pack_cache = cache = (key, packed)
         return cache[1]
 
+    def forward(self, inputs, context=None):
+        """Density direction (autoregressive.py:24-27 + neural_spline/autoregressive.py:94-134): MADE + the element-wise spline as
+        ONE launch (nf_made_forward_spline) for 8 bins, linear tails, a scalar tail bound and the MADE structures
+        flows/made_pack.py takes; otherwise one MADE pass (one launch where possible) + nf_rqs_coupling."""
+        if (context is None and inputs.dim() == 2 and inputs.dtype == torch.float32 and inputs.is_cuda and self.tails == "linear"
+                and self.num_bins == 8 and not torch.is_tensor(self.tail_bound)
+                and not hasattr(self.autoregressive_net, "hidden_features")
+                and self.min_bin_width * 8 <= 1.0 and self.min_bin_height * 8 <= 1.0
+                and not autograd.needs_grad(inputs, *self.autoregressive_net.parameters())):
+            packed = self.autoregressive_net.packed_forward(inputs.device, spline=True)
+            if packed is not None:
+                return ops.made_forward_spline(inputs, packed[0], packed[1], packed[2], float(self.tail_bound), self.min_bin_width,
+                                               self.min_bin_height, self.min_derivative)
+        return super().forward(inputs, context)
+
     def inverse(self, inputs, context=None):
         """One launch of nf_arnsf_inverse for the supported MADE structure (scalar tails, float32, no context, no
         sqrt(hidden) scaling, no gradient tracking); the reference's D-pass loop otherwise."""

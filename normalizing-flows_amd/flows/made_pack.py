@@ -17,9 +17,15 @@ This module only rearranges weights (no arithmetic on data).  The kernel's geome
     round r of the final layer the row-blocks {8 r + w, 8 r + 7 - w} -- followed by a copy of its first RING entries, so that the
     register ring that reads RING entries ahead wraps into the next 64-row tile without a bubble.
 
+  * `spline=True` (the autoregressive spline layer's MADE, 23 = 3 * 8 - 1 outputs per feature; nf_made_forward_spline): the final
+    layer is cut into GROUPS of four features = 3 row-blocks for both sample blocks, rows ordered so that a lane's accumulators are
+    the 2 x 24 parameter lists of features 4 g + 2 hh + {0, 1} (flows/nsf_wide_pack.final_row: the layout of nf_nsf_wide), widths /
+    heights pre-scaled by log2(e); a group's stream = 12 bias entries, then per k-group one fragment per row-block; the groups are
+    dealt to the waves in a snake over their k-group counts (equal work); hdr[8] = final items per wave, entries [nkg, g].
+
 float blob  : the 8 streams.
-int32 table : hdr[32] = [D, Dp, H, Hp, NSB, NB, mult, NFB, nrounds, total blob floats, nitems, 0..], hdr[16 + w] = offset (floats) of
-              wave w's stream; then per wave nitems entries [nkg, rb] (rb = -1: no such row-block, nkg = 0, no bias group either).
+int32 table : hdr[32] = [D, Dp, H, Hp, NSB, NB, mult, NFB | G, nrounds | nfi, total blob floats, nitems, spline, 0..], hdr[16 + w] =
+              offset (floats) of wave w's stream; then per wave nitems entries [nkg, rb | g] (-1: none, nkg = 0, no bias group).
 """
 import numpy as np
 import torch
@@ -80,10 +86,10 @@ def wave_items(NSB, NB, NFB):
     return out
 
 
-def pack_made_forward(made, mult=2):
+def pack_made_forward(made, mult=2, spline=False):
     """(blob float32 ndarray, table int32 ndarray) or None when the MADE is outside the kernel's structure (then the caller
-    keeps the layer-by-layer path)."""
-    if not supported(made, mult):
+    keeps the layer-by-layer path).  spline: the final layer in groups for the fused spline epilogue (mult = 23)."""
+    if not supported(made, mult) or (spline and mult != 23):
         return None
     D = made.initial_layer.in_features
     H = made.initial_layer.out_features
@@ -132,6 +138,8 @@ def pack_made_forward(made, mult=2):
         layers.append(slots(l, slot_of, Hp, slot_of, Hp))
     layers.append(slots(fin, slot_of, Hp, np.arange(mult * D), NFB * ROWS))
 
+    if spline:
+        return _pack_spline(layers, D, Dp, H, Hp, NSB, NB, mult)
     items = wave_items(NSB, NB, NFB)
     nitems = len(items[0])
     hdr = np.zeros(HDR, dtype=np.int32)
@@ -159,6 +167,75 @@ def pack_made_forward(made, mult=2):
         chunks.append(stream)
         off += stream.size
     hdr[:11] = [D, Dp, H, Hp, NSB, NB, mult, NFB, (NFB + 7) // 8, off, nitems]
+    blob = np.concatenate(chunks).astype(np.float32)
+    assert blob.size == off and off < 2 ** 31
+    return blob, np.concatenate([hdr, tab.reshape(-1)]).astype(np.int32)
+
+
+def _pack_spline(layers, D, Dp, H, Hp, NSB, NB, mult):
+    """Streams with the final layer in groups of four features (see the module docstring)."""
+    from .nsf_wide_pack import final_row, K_BINS, M as MPRM
+    Wf, Mf, bf = layers[-1]                                   # (NFB * 32, Hp) in the reference's row order 23 f + p
+    G = (D + 3) // 4
+    scale = np.float32(1.4426950408889634)                    # log2(e): rqs_regs takes exp2; no 1 / sqrt(hidden) here (the reference
+    WG = np.zeros((G, 3, ROWS, Hp), dtype=np.float32)         # tests hasattr(net, "hidden_features"), which its MADE does not have)
+    BG = np.zeros((G, 3, ROWS), dtype=np.float32)
+    nkg_g = np.zeros(G, dtype=np.int64)
+    for g in range(G):
+        last = -1
+        for r3 in range(3):
+            for rho in range(ROWS):
+                row = final_row(g, r3, rho, D)
+                if row >= 0:
+                    sc = scale if (row % MPRM) < 2 * K_BINS else np.float32(1.0)
+                    WG[g, r3, rho] = Wf[row] * sc
+                    BG[g, r3, rho] = bf[row] * sc
+                    nz = np.nonzero(Mf[row])[0]
+                    if nz.size:
+                        last = max(last, int(nz.max()))
+        nkg_g[g] = 0 if last < 0 else (last // KG + 4) // 4 * 4
+    # deal the groups to the waves in a snake over their k-group counts
+    order = np.argsort(-nkg_g, kind="stable")
+    per_wave = [[] for _ in range(8)]
+    for k, g in enumerate(order):
+        r, c = divmod(k, 8)
+        per_wave[c if r % 2 == 0 else 7 - c].append(int(g))
+    nfi = max(len(v) for v in per_wave)
+    hidden = wave_items(NSB, NB, 0)                           # the producing layers' items (no final rounds)
+    nh = len(hidden[0])
+    nitems = nh + nfi
+    hdr = np.zeros(HDR, dtype=np.int32)
+    tab = np.zeros((8, nitems, 2), dtype=np.int32)
+    chunks, off = [], 0
+    for w in range(8):
+        hdr[16 + w] = off
+        stream = []
+        for i, (l, rb) in enumerate(hidden[w]):
+            W, M, Bv = layers[l]
+            r0 = rb * ROWS
+            cols = np.nonzero(M[r0:r0 + ROWS].any(axis=0))[0]
+            nkg = 0 if cols.size == 0 else (int(cols.max()) // KG + 4) // 4 * 4
+            tab[w, i] = (nkg, rb)
+            stream.append(bias_group(Bv[r0:r0 + ROWS]))
+            if nkg:
+                stream.append(a_stream(W[r0:r0 + ROWS, :KG * nkg]))
+        for j in range(nfi):
+            if j >= len(per_wave[w]):
+                tab[w, nh + j] = (0, -1)
+                continue
+            g = per_wave[w][j]
+            nkg = int(nkg_g[g])
+            tab[w, nh + j] = (nkg, g)
+            for r3 in range(3):
+                stream.append(bias_group(BG[g, r3]))
+            if nkg:
+                frag = np.stack([a_stream(WG[g, r3][:, :KG * nkg]).reshape(nkg, 256) for r3 in range(3)], axis=1)
+                stream.append(frag.reshape(-1))
+        stream = np.concatenate(stream)
+        stream = np.concatenate([stream, np.resize(stream, RING * 256)])
+        chunks.append(stream)
+        off += stream.size
+    hdr[:12] = [D, Dp, H, Hp, NSB, NB, mult, G, nfi, off, nitems, 1]
     blob = np.concatenate(chunks).astype(np.float32)
     assert blob.size == off and off < 2 ** 31
     return blob, np.concatenate([hdr, tab.reshape(-1)]).astype(np.int32)

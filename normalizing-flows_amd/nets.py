@@ -490,21 +490,25 @@ class MADE(nn.Module):
                                         autoregressive_features=features, random_mask=random_mask, is_output=True,
                                         out_degrees_=input_degrees_)
 
-    def packed_forward(self, device):
-        """Device copies of the one-launch pack (flows/made_pack.py), rebuilt when a parameter changes; None = unsupported."""
+    def packed_forward(self, device, spline=False):
+        """Device copies of the one-launch pack (flows/made_pack.py), rebuilt when a parameter changes; None = unsupported.
+        spline: the final layer in groups for the fused spline epilogue (nf_made_forward_spline)."""
         from . import config
         if not config.made_fused:
             return None
         key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (str(device),)
-        cache = self.__dict__.get("_fwd_pack_cache")
+        caches = self.__dict__.setdefault("_fwd_pack_cache", {})
+        if not isinstance(caches, dict):
+            caches = self.__dict__["_fwd_pack_cache"] = {}
+        cache = caches.get(bool(spline))
         if cache is None or cache[0] != key:
             from .flows import made_pack
             mult = self.final_layer.out_features // self.initial_layer.in_features
-            packed = made_pack.pack_made_forward(self, mult)
+            packed = made_pack.pack_made_forward(self, mult, spline=bool(spline))
             if packed is not None:
                 blob, table = packed
                 packed = (torch.from_numpy(blob).to(device), torch.from_numpy(table).to(device), int(table[3]), mult)
-            cache = self.__dict__["_fwd_pack_cache"] = (key, packed)
+            cache = caches[bool(spline)] = (key, packed)
         return cache[1]
 
     def forward(self, inputs, context=None):

@@ -857,6 +857,28 @@ def made_forward_affine(x, blob, table, hidden_padded, logdet=None, acc=None):
     return y, logdet
 
 
+def made_forward_spline(x, blob, table, hidden_padded, tail_bound, min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3,
+                        logdet=None, acc=None):
+    """neural_spline/autoregressive.py:94-134 density direction (MADE + 8-bin spline with linear tails) as one launch
+    (nf_made_forward_spline); blob / table from flows/made_pack.pack_made_forward(made, 23, spline=True)."""
+    L.require_device(x, blob, table)
+    if x.dtype != torch.float32:
+        raise NotImplementedError("made_forward_spline: float32 only")
+    B, D = x.shape
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    if logdet is None:
+        logdet = torch.empty(B, dtype=x.dtype, device=x.device)
+        acc = L.LD_WRITE
+    elif acc is None:
+        acc = L.LD_ADD
+    rc = L.lib().nf_made_forward_spline(ptr(x), ptr(y), ptr(logdet), ptr(blob), ptr(table), i64(B), i32(D), i32(hidden_padded),
+                                        i32(acc), f64(float(tail_bound)), f64(min_bin_width), f64(min_bin_height),
+                                        f64(min_derivative), L.stream())
+    L.check(rc, "nf_made_forward_spline")
+    return y, logdet
+
+
 def made_forward(x, blob, table, hidden_padded, mult):
     """MADE.forward (nets/made.py:296-304) as one launch (nf_made_forward): (B, mult D) parameters."""
     L.require_device(x, blob, table)

@@ -1375,6 +1375,51 @@ def test_made_forward_one_launch_vs_layerwise(nfa, D, H, NB, B):
     assert_close(N(z3), N(z4), what="z after update", rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("D,H,NB,B", [(64, 256, 2, 300), (6, 16, 2, 11), (33, 300, 1, 65), (128, 512, 2, 130), (5, 40, 3, 1)])
+def test_made_forward_spline_one_launch_vs_layerwise(nfa, D, H, NB, B):
+    """nf_made_forward_spline (the autoregressive spline layer's density direction as one launch: MADE on fp32 MFMA over the masks'
+    non-zero blocks, final layer in groups of four features, the spline on the accumulator registers) against the layer-wise
+    path (one-launch MADE or library GEMMs + nf_rqs_coupling): both hidden widths, 1-3 blocks, odd feature counts, ragged batches,
+    inputs beyond the tails and non-finite inputs."""
+    torch.manual_seed(D * 11 + H)
+    layer = nfa.flows.AutoregressiveRationalQuadraticSpline(D, NB, H, num_bins=8, tail_bound=3, init_identity=False)
+    _perturb(layer, 0.2 if D < 40 else 0.05, 9)
+    layer = layer.to(DEV)
+    t = layer.mprqat
+    assert t.autoregressive_net.packed_forward(DEV, spline=True) is not None
+    x = (1.7 * torch.randn(B, D, generator=torch.Generator().manual_seed(D))).to(DEV)
+    x[0, 0] = 3.5
+    if B > 8:
+        x[1, D - 1] = -4.0
+        x[2, 1] = float("nan")
+        x[3, 0] = float("inf")
+    z1, ld1 = layer.inverse(x)
+    nfa.config.set_made_fused(False)
+    try:
+        z0, ld0 = layer.inverse(x)
+    finally:
+        nfa.config.set_made_fused(True)
+    # strongly non-identity splines: single elements sit in bins whose slope amplifies the float32 rounding of the conditioner output
+    # (two summation orders): 99.9 % of the elements within 5e-5 (1 + |z|), every element within 2e-3; non-finite patterns identical
+    a, b_ = N(z1).astype(np.float64), N(z0).astype(np.float64)
+    assert np.array_equal(np.isfinite(a), np.isfinite(b_))
+    ez = (np.abs(a - b_) / (1.0 + np.abs(b_)))[np.isfinite(b_)]
+    assert np.quantile(ez, 0.999) < 5e-5 and ez.max() < 2e-3, (float(np.quantile(ez, 0.999)), float(ez.max()))
+    la, lb = N(ld1).astype(np.float64), N(ld0).astype(np.float64)
+    assert np.array_equal(np.isfinite(la), np.isfinite(lb))
+    el = (np.abs(la - lb) / (1.0 + np.abs(lb)))[np.isfinite(lb)]
+    assert np.quantile(el, 0.99) < 2e-4 and el.max() < 5e-3, (float(np.quantile(el, 0.99)), float(el.max()))
+    z2, ld2 = layer.inverse(x)
+    assert torch.equal(torch.nan_to_num(z1), torch.nan_to_num(z2)) and torch.equal(torch.nan_to_num(ld1), torch.nan_to_num(ld2))
+    acc = torch.full((B,), 0.5, device=DEV)
+    _, acc2 = nfa.ops.made_forward_spline(x, *t.autoregressive_net.packed_forward(DEV, spline=True)[:3], 3.0, logdet=acc.clone(), acc=-1)
+    assert torch.allclose(acc2, acc - ld1, atol=1e-6, equal_nan=True)
+    if D <= 8:      # (long autoregressive chains amplify float32 rounding feature by feature: the round trip is only tight for few features)
+        fin = torch.isfinite(x).all(dim=1)
+        xr, ldr = layer.forward(z1[fin])                # the one-pass sampling kernel undoes it (autoregressive_test.py round trip)
+        assert_close(N(xr), N(x[fin]), what="round trip", rtol=2e-3, atol=2e-3)
+
+
 def test_made_forward_raw_parameters_for_the_spline_layer(nfa):
     """nf_made_forward with 23 outputs per feature (the autoregressive spline layer's MADE, neural_spline/autoregressive.py:57-73):
     several rounds of final row-blocks, output rows in the reference's order; AR-NSF's density direction rides on it."""

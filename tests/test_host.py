@@ -791,3 +791,28 @@ def test_invalidate_caches_drops_every_packed_image(nfa):
     nfa.invalidate_caches(m)
     assert layer.prqct._fused_cache is None and layer.prqct.__dict__["_wide_cache"] == {} and lu._dense_cache is None
     assert made.__dict__["_fwd_pack_cache"] is None and made.initial_layer._masked_cache is None
+
+
+@pytest.mark.parametrize("D,H,NB", [(64, 256, 2), (6, 16, 2), (33, 300, 1), (128, 512, 2)])
+def test_made_forward_spline_pack_matches_dense_made(D, H, NB):
+    """flows/made_pack.py spline=True (the autoregressive spline layer's MADE: final layer in groups of four features whose MFMA rows
+    are the lanes' 2 x 24 parameter lists, widths / heights pre-scaled by log2(e), groups dealt to the waves by work) + the kernel's
+    walk (tests/made_fwd_emulator.py) reproduce nets.MADE.forward with 23 outputs per feature, computed densely in fp64."""
+    from normflows_amd import nets
+    from normflows_amd.flows import made_pack
+    from made_fwd_emulator import emulate_forward_spline
+    torch.manual_seed(D * 3 + H)
+    made = nets.MADE(features=D, hidden_features=H, num_blocks=NB, output_multiplier=23)
+    with torch.no_grad():
+        for p in made.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    blob, table = made_pack.pack_made_forward(made, 23, spline=True)
+    assert table[11] == 1 and table[7] == (D + 3) // 4
+    x = torch.randn(5, D)
+    import copy
+    with torch.no_grad():
+        ref = copy.deepcopy(made).double()(x.double()).numpy().reshape(5, D, 23).copy()
+    ref[:, :, :16] *= 1.4426950408889634
+    got = emulate_forward_spline(blob, table, x.numpy())
+    assert np.max(np.abs(got[:, :, :23] - ref)) < 1e-5 * max(1.0, np.abs(ref).max()) and np.all(got[:, :, 23] == 0.0)
+    assert made_pack.pack_made_forward(nets.MADE(features=8, hidden_features=16, num_blocks=2, output_multiplier=29), 29, spline=True) is None
