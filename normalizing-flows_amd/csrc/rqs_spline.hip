@@ -238,6 +238,51 @@ rqs_coupling_kernel(const T *__restrict__ x, T *__restrict__ y, T *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// NF_RQS_SAMPLE_IDENTITY alone (round 4): the batch-shared spline on the identity columns (nsf/coupling.py:221-253 in the sampling
+// direction, :112-114) needs no conditioner rows and no staging -- tables once per workgroup, then P lanes per row (P = the identity
+// count rounded up to a power of two, 64 / P rows per wave), each lane one element straight from / to global memory, the row's
+// log-det by a butterfly inside its P lanes.  The tiled kernel above spent 56 us on this at B = 65 536, D = 64 (0.08 of the HBM peak).
+template <typename T>
+__global__ void __launch_bounds__(256)
+rqs_identity_kernel(const T *__restrict__ x, T *__restrict__ y, T *__restrict__ logdet, const T *__restrict__ uw,
+                    const T *__restrict__ uh, const T *__restrict__ ud, const int64_t *__restrict__ iidx, int nI, int64_t B, int D,
+                    RqsParams<T> p, int acc, const int *__restrict__ tails_i, const T *__restrict__ bound_i) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int K = p.K, TW = 3 * (K + 1);
+    T *s_tab = reinterpret_cast<T *>(smem_raw);                 // nI * TW
+    int *s_iidx = reinterpret_cast<int *>(s_tab + (size_t)nI * TW);
+    const int tid = threadIdx.x;
+    for (int j = tid; j < nI; j += blockDim.x) {
+        s_iidx[j] = (int)iidx[j];
+        const RqsParams<T> pu = rqs_feature_params(p, tails_i, bound_i, j);
+        const T *wj = uw + (size_t)j * K, *hj = uh + (size_t)j * K, *dj = ud + (size_t)j * p.nd;
+        auto wacc = [=](int k) { return wj[k]; };
+        auto hacc = [=](int k) { return hj[k]; };
+        auto dacc = [=](int k) { return dj[k]; };
+        rqs_build_table<T>(pu, wacc, hacc, dacc, s_tab + (size_t)j * TW);
+    }
+    __syncthreads();
+    int P = 1;
+    while (P < nI && P < 64) P <<= 1;
+    const int rpw = 64 / P, lane = tid & 63, rin = lane / P, i0 = lane - rin * P;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + tid) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r0 = wave * rpw; r0 < B; r0 += nwaves * rpw) {
+        const int64_t r = r0 + rin;
+        T ld = T(0);
+        if (r < B)
+            for (int j = i0; j < nI; j += P) {
+                const int64_t o = r * D + s_iidx[j];
+                T yy, ll;
+                rqs_eval_table<T>(rqs_feature_params(p, tails_i, bound_i, j), x[o], s_tab + (size_t)j * TW, true, yy, ll);
+                y[o] = yy;
+                ld += ll;
+            }
+        for (int off = P >> 1; off >= 1; off >>= 1) ld += __shfl_xor(ld, off, 64);
+        if (r < B && i0 == 0) ld_store(logdet + r, ld, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Same transform with WAVE-private tiles: a wave owns SPW samples at a time (SPW x max(nT, nI) <= ~64 elements per pass),
 // stages their conditioner rows / x rows into its own LDS region with unit-stride loads and never meets the other waves
 // of the workgroup again after the shared tables are built -- no workgroup barrier in the main loop (the tiled kernel
@@ -538,6 +583,16 @@ static int launch_rqs_coupling(const void *x, void *y, void *logdet, const void 
     const int M = 2 * K + p.nd;
     const int Mp = M | 1;
     const int nmax = nT > nI ? nT : nI;
+    if (mode == NF_RQS_SAMPLE_IDENTITY && uw && nI >= 1) {
+        const size_t ldsi = (size_t)nI * 3 * (K + 1) * sizeof(T) + (size_t)nI * sizeof(int) + 16;
+        if (ldsi <= 64 * 1024) {
+            const int grid = grid_for(B * (int64_t)(nI < 64 ? nI : 64), 256);
+            hipLaunchKernelGGL(rqs_identity_kernel<T>, dim3(grid), dim3(256), ldsi, st, (const T *)x, (T *)y, (T *)logdet, (const T *)uw,
+                               (const T *)uh, (const T *)ud, iidx, nI, B, D, p, acc, (const int *)tails_i, (const T *)bound_i);
+            NF_CHECK_LAUNCH();
+            return NF_OK;
+        }
+    }
 #ifndef NF_FWD_NO_PIPE
     if constexpr (std::is_same<T, float>::value) {
         // the default NSF layer shape (D = 64 or 128, alternating halves) on the software-pipelined kernel
