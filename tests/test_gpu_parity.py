@@ -1293,6 +1293,56 @@ def test_nsf_wide_full_batch_properties(nfa):
         assert float((z - z0).abs().max()) < 2e-3, (D, H, float((z - z0).abs().max()))
 
 
+def test_one_launch_engines_on_random_shapes(nfa):
+    """Seeded sweep over shapes for the three kernels of the 64-row-tile engine (nf_made_forward_affine, nf_made_forward_spline,
+    nf_nsf_wide with and without the fused LU): feature counts 2..128 (odd ones, off every granule), hidden widths 1..512 (all
+    three padded widths), 1..4 residual blocks, batches off the tile height -- each against the layer-wise path on the same weights."""
+    rng = np.random.RandomState(20240924)
+    for trial in range(36):
+        kind = trial % 3
+        D = int(rng.choice([2, 3, 5, 8, 17, 31, 32, 33, 64, 65, 100, 127, 128]))
+        H = int(rng.choice([1, 7, 32, 100, 128, 129, 200, 256, 257, 400, 512]))
+        NB = int(rng.randint(1, 5))
+        B = int(rng.choice([1, 63, 64, 65, 127, 129, 200, 1000]))
+        torch.manual_seed(1000 + trial)
+        x = (1.5 * torch.randn(B, D, generator=torch.Generator().manual_seed(trial))).to(DEV)
+        what = (kind, D, H, NB, B)
+        if kind == 0:
+            layer = nfa.flows.MaskedAffineAutoregressive(D, H, num_blocks=NB)
+            _perturb(layer, 0.05, trial)
+            layer = layer.to(DEV)
+            assert layer.autoregressive_net.packed_forward(DEV) is not None, what
+            fn, off = layer.forward, nfa.config.set_made_fused
+        elif kind == 1:
+            layer = nfa.flows.AutoregressiveRationalQuadraticSpline(D, NB, H, num_bins=8, init_identity=False)
+            _perturb(layer, 0.05, trial)
+            layer = layer.to(DEV)
+            assert layer.mprqat.autoregressive_net.packed_forward(DEV, spline=True) is not None, what
+            fn, off = layer.inverse, nfa.config.set_made_fused
+        else:
+            c = nfa.flows.CoupledRationalQuadraticSpline(D, NB, H, num_bins=8, init_identity=False, reverse_mask=bool(trial & 1))
+            lu = nfa.flows.LULinearPermute(D, identity_init=False)
+            m = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(D, trainable=False), [c, lu])
+            _perturb(m, 0.03, trial)
+            m = m.to(DEV)
+            if c.prqct._fused_eligible(x, None):          # (the benchmark kernel's range: not this test's subject)
+                continue
+            assert c.prqct._wide_pack(x, None) is not None, what
+            fn = (lambda t, m=m: m.inverse_and_log_det(t)) if trial & 2 else (lambda t, m=m: m.forward_and_log_det(t))
+            off = nfa.config.set_nsf_wide
+        z1, l1 = fn(x)
+        off(False)
+        try:
+            z0, l0 = fn(x)
+        finally:
+            off(True)
+        ez = (np.abs(N(z1).astype(np.float64) - N(z0)) / (1.0 + np.abs(N(z0)))).ravel()
+        el = (np.abs(N(l1).astype(np.float64) - N(l0)) / (1.0 + np.abs(N(l0)))).ravel()
+        assert np.isfinite(ez).all() and np.isfinite(el).all(), what
+        assert np.quantile(ez, 0.999) < 5e-5 and ez.max() < 2e-3 and np.quantile(el, 0.99) < 2e-4 and el.max() < 5e-3, \
+            (what, float(ez.max()), float(el.max()))
+
+
 @pytest.mark.parametrize("D,H", [(64, 256), (128, 128), (96, 192), (33, 300)])
 def test_nsf_wide_pairs_with_fused_lu_vs_layerwise(nfa, D, H):
     """[CoupledRationalQuadraticSpline, LULinearPermute] pairs beyond the benchmark kernel's shapes: nf_nsf_wide with the LU layer's
