@@ -105,6 +105,42 @@ actnorm_bwd_kernel(const T *__restrict__ z, const T *__restrict__ s, const T *__
     const T e = M<T>::exp(direction == 0 ? sc : -sc);
     double as = 0.0, at = 0.0;
     const int64_t nimg = (B - j + nsplit - 1) / nsplit;       // images j, j + nsplit, ...
+    if constexpr (sizeof(T) == 4) {
+        if ((HW & 3) == 0) {
+            // float32 planes of a multiple of 4 pixels (round 4): a thread owns FOUR consecutive pixels per step (16-byte loads of z
+            // and gy, a 16-byte store of gz), (image, pixel quad) follow incrementally
+            typedef float v4 __attribute__((ext_vector_type(4)));
+            const int64_t Q = HW >> 2;
+            int64_t k = threadIdx.x / Q, q = threadIdx.x - k * Q;
+            const int64_t dk = blockDim.x / Q, dq = blockDim.x - dk * Q;
+            for (int64_t e_ = threadIdx.x; e_ < nimg * Q; e_ += blockDim.x) {
+                const int64_t o = ((j + k * nsplit) * C + c) * HW + 4 * q;
+                const v4 g = *reinterpret_cast<const v4 *>(reinterpret_cast<const float *>(gy) + o);
+                const v4 v = *reinterpret_cast<const v4 *>(reinterpret_cast<const float *>(z) + o);
+                v4 out;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    out[i] = g[i] * (float)e;
+                    if (direction == 0) { as += (double)(g[i] * v[i] * (float)e); at += (double)g[i]; }
+                    else { as -= (double)(g[i] * (v[i] - (float)tc) * (float)e); at -= (double)(g[i] * (float)e); }
+                }
+                *reinterpret_cast<v4 *>(reinterpret_cast<float *>(gz) + o) = out;
+                k += dk;
+                q += dq;
+                if (q >= Q) {
+                    q -= Q;
+                    ++k;
+                }
+            }
+            as = block_sum(as, sred);
+            at = block_sum(at, sred);
+            if (threadIdx.x == 0) {
+                partial[((int64_t)j * C + c) * 2] = as;
+                partial[((int64_t)j * C + c) * 2 + 1] = at;
+            }
+            return;
+        }
+    }
     // (image, pixel) of a thread's next element follow incrementally: one 64-bit division per thread instead of one per element
     int64_t k = threadIdx.x / HW, p = threadIdx.x - k * HW;
     const int64_t dk = blockDim.x / HW, dp = blockDim.x - dk * HW;
