@@ -24,7 +24,11 @@ namespace nf {
 
 constexpr int HT = 32;    // units per tile (flows/maf_pack.py TILE)
 constexpr int HS = 16;    // degrees per tile
-constexpr int HNW = 4;    // waves per workgroup; two workgroups per CU (their tile phases drift apart: one's sequential part overlaps the other's block part)
+#ifndef NF_MAF_HNW
+#define NF_MAF_HNW 4
+#endif
+constexpr int HNW = NF_MAF_HNW;    // waves per workgroup (ablation, round 4, config 5 in one gpurun call: 4 -> 13.9 ms, 8 = one 8-wave
+                                   // workgroup per CU -> 14.5 ms, 2 -> 24.5 ms); two workgroups per CU (their tile phases drift apart: one's sequential part overlaps the other's block part)
 constexpr int H_HDR = 8, H_ENT = 24;
 // floats of a tile record after the A operands, NL = 1 + 2 num_blocks hidden layers: bias[NL][32] | biasF | W0d[32][16] | Wd[NL-1] | WFd
 constexpr int h_seq(int NL) { return NL * HT + HT + HT * HS + (NL - 1) * HT * HT + HT * HT; }
@@ -131,7 +135,7 @@ __device__ __forceinline__ void h_finish(float us, float sh, float zf, float &xn
 // NB residual blocks (nets/made.py:140-214): NL = 1 + 2 NB hidden layers whose activations later tiles contract over
 // (S_0 = relu(h_0); per block b: S_{2b+1} = relu(t_b), S_{2b+2} = relu(h_{b+1}), the last one raw = the final layer's input).
 template <int NB>
-__global__ void __launch_bounds__(64 * HNW, NB <= 2 ? 2 : 1)
+__global__ void __launch_bounds__(64 * HNW, (NB <= 2 && HNW <= 4) ? 2 : 1)
 maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *__restrict__ logdet, const float *__restrict__ blob,
                      const int *__restrict__ table, float *S, float *Xs, float *Ps, int64_t B, int acc) {
     constexpr int NL = 1 + 2 * NB, H_SEQ = h_seq(NL);
