@@ -199,7 +199,7 @@ def secondary(model, x):
         cb = importlib.util.module_from_spec(spec)
         with contextlib.redirect_stdout(io.StringIO()):
             spec.loader.exec_module(cb)
-            for key, fn in (("config1_realnvp", cb.c1), ("config4_glow", cb.c4), ("config5_maf", cb.c5)):
+            for key, fn in (("config1_realnvp", cb.c1), ("config4_glow", cb.c4), ("config5_maf", cb.c5), ("nsf_wide", cb.wide)):
                 try:
                     res[key] = fn()
                 except Exception as exc:   # noqa: BLE001

@@ -139,7 +139,7 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
         }
         f32x16 h[NHI][NS], t[NHI][NS];
         MF_BARRIER();
-        // ---- initial layer: h = b0 + W0 x (zero columns at the transform features) ---------------------------------------------------
+        // ---- initial layer: h = b0 + W0 x over the identity positions [0, PI) of the tile ----------------------------------------------
 #pragma unroll
         for (int s = 0; s < NHI; ++s) mf_item<NS, false, TR>(ring, items[3 * s], xreg + lane_b + 128 * items[3 * s + 2], h[s]);
         // ---- residual blocks (nets/resnet.py:37-50): t = b1 + W1 relu(h);  h += b2 + W2 relu(t) ----------------------------------

@@ -119,8 +119,33 @@ def c5():
             "round_trip_max_abs_err": err, "roofline_inverse_pass": roof(dt * 1e3), "roofline_forward_pass": roof(dtf * 1e3)}
 
 
+def wide():
+    """NSF models beyond the benchmark kernel's shapes (round 4: nf_nsf_wide, one launch per [coupling + LU] pair): 4 pairs at
+    B = 65 536 for hidden 256 (D 64) and D 128 (hidden 128), with the algorithmic FLOP of SURVEY 8d against the fp32 MFMA peak."""
+    out = {}
+    for D, hidden in ((64, 256), (128, 128)):
+        torch.manual_seed(0)
+        flows = []
+        for _ in range(4):
+            flows += [nfa.flows.CoupledRationalQuadraticSpline(D, 2, hidden, num_bins=8), nfa.flows.LULinearPermute(D)]
+        m = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(D, trainable=False), flows).to(dev)
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(0.01 * torch.randn_like(p))
+            x = torch.randn(65536, D, device=dev)
+            m.log_prob(x)
+            dt = timed(lambda: m.log_prob(x), 10)
+        flop = 2.0 * 65536 * 4 * (D // 2 * hidden + 4 * hidden * hidden + hidden * (D // 2) * 23 + D * D)
+        out["d%d_h%d" % (D, hidden)] = {"us_per_pair": dt * 1e6 / 4, "rows_per_s": 65536 / dt,
+                                        "roofline": {"bound": "mfma", "achieved": flop / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                                                     "frac": flop / dt / 157.3e12}}
+        print("NSF D=%d hidden=%d, 4 pairs, B=65536: %.1f us per pair, %.1f TFLOP/s" % (D, hidden, dt * 1e6 / 4, flop / dt / 1e12))
+    out["workload"] = "4 x [CoupledRQS(D, 2, hidden, K=8) + LULinearPermute(D)] log_prob, B = 65536 (nf_nsf_wide: one launch per pair)"
+    return out
+
+
 if __name__ == "__main__":
     import sys
     which = sys.argv[1:] or ["1", "4", "5"]
     for w in which:
-        {"1": c1, "4": c4, "5": c5}[w]()
+        {"1": c1, "4": c4, "5": c5, "wide": wide}[w]()
