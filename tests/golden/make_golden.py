@@ -441,6 +441,31 @@ def gen_train_c2_w64h128():
     npz("grad_model_c2_w64h128", **out)
 
 
+def gen_nsf_wide():
+    """NSF models beyond the benchmark kernel's shapes (hidden 256, D = 128; wrapper.py:20-35 over nets/resnet.py:53-104): 3 x
+    [CoupledRationalQuadraticSpline + LULinearPermute], sigma 0.05, 96 rows, log_prob and the sampling pass, fp32 and fp64 legs.
+    Outputs only: the weights are reproduced by seeded construction (bench.build_c2_model with the same arguments)."""
+    sys.path.insert(0, os.path.join(OUT, "..", ".."))
+    from bench import build_c2_model, c2_inputs
+    for D, H in ((64, 256), (128, 128), (128, 256), (96, 192)):
+        out = {}
+        for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+            m = build_c2_model(num_layers=3, dim=D, hidden=H, seed=40 + D, sigma=0.05, lib=nf).to(dt)
+            x = c2_inputs(96, D, seed=D + H).to(dt)
+            eps = torch.randn(96, D, generator=torch.Generator().manual_seed(H)).to(dt)
+            with torch.no_grad():
+                lp = m.log_prob(x)
+                z = m.q0.loc + torch.exp(m.q0.log_scale) * eps
+                logq = -0.5 * D * np.log(2 * np.pi) - torch.sum(m.q0.log_scale + 0.5 * eps ** 2, 1)
+                for f in m.flows:
+                    z, ld = f(z)
+                    logq = logq - ld
+            out.update({"log_prob_" + tag: lp, "sample_" + tag: z, "sample_logq_" + tag: logq})
+            if dt == torch.float32:
+                out.update(x=x, eps=eps)
+        npz("model_nsf_wide_d%d_h%d" % (D, H), **out)
+
+
 def gen_maf():
     """MaskedAffineAutoregressive (affine/autoregressive.py): forward = one MADE pass, inverse = D passes."""
     for d, hidden, B in ((20, 40, 9), (128, 512, 4)):
@@ -998,6 +1023,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "image_coupling":
         gen_image_coupling()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "nsf_wide":
+        gen_nsf_wide()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ar_grads":
         gen_ar_grads()
         sys.exit(0)
@@ -1080,3 +1108,4 @@ if __name__ == "__main__":
     gen_glow_model_full()
     gen_maf_model_full()
     gen_train_c2_w64h128()
+    gen_nsf_wide()

@@ -1343,6 +1343,31 @@ def test_one_launch_engines_on_random_shapes(nfa):
             (what, float(ez.max()), float(el.max()))
 
 
+@pytest.mark.parametrize("D,H", [(64, 256), (128, 128), (128, 256), (96, 192)])
+def test_nsf_wide_models_vs_reference(nfa, monkeypatch, D, H):
+    """nf_nsf_wide against the REFERENCE itself at the shapes it exists for (tests/golden/model_nsf_wide_*.npz: 3 x
+    [CoupledRationalQuadraticSpline(D, 2, H) + LULinearPermute(D)], sigma 0.05, 96 rows; wrapper.py:20-35, nets/resnet.py:53-104,
+    mixing.py:535-563 under core.py:167-197): weights rebuilt from the seed, log_prob and the sampling pass to 1e-4 of the float32 leg
+    and no further from the float64 leg than 4 x the reference's own float32 leg; the one-launch kernel is what ran (spy)."""
+    from bench import build_c2_model
+    from normflows_amd import ops
+    g = load_golden("model_nsf_wide_d%d_h%d" % (D, H))
+    m = build_c2_model(num_layers=3, dim=D, hidden=H, seed=40 + D, sigma=0.05).to(DEV)
+    calls = []
+    real = ops.nsf_wide
+    monkeypatch.setattr(ops, "nsf_wide", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    lp = N(m.log_prob(T(g["x"])))
+    assert len(calls) == 3, calls
+    xs, lq = m.sample_from_noise(T(g["eps"]))
+    assert len(calls) == 6
+    assert _rel(lp, g["log_prob_f32"]) < 1e-4, _rel(lp, g["log_prob_f32"])
+    assert_close(N(xs), g["sample_f32"], what="sample", rtol=1e-4, atol=1e-4)
+    assert _rel(N(lq), g["sample_logq_f32"]) < 1e-4
+    for ours, key in ((lp, "log_prob"), (N(lq), "sample_logq")):
+        own = _rel(g[key + "_f32"], g[key + "_f64"])
+        assert _rel(ours, g[key + "_f64"]) <= max(4 * own, 2e-6), (key, _rel(ours, g[key + "_f64"]), own)
+
+
 @pytest.mark.parametrize("D,H", [(64, 256), (128, 128), (96, 192), (33, 300)])
 def test_nsf_wide_pairs_with_fused_lu_vs_layerwise(nfa, D, H):
     """[CoupledRationalQuadraticSpline, LULinearPermute] pairs beyond the benchmark kernel's shapes: nf_nsf_wide with the LU layer's

@@ -214,6 +214,22 @@ def test_benchmark_shape_model_oracle_vs_reference():
     assert abs(-float(np.mean(lp.astype(np.float64))) - float(g["loss_f64"])) < 1e-5 * abs(float(g["loss_f64"]))
 
 
+@pytest.mark.parametrize("D,H", [(64, 256), (128, 128), (128, 256), (96, 192)])
+def test_wide_shape_models_oracle_vs_reference(D, H):
+    """The oracle at the shapes nf_nsf_wide takes (hidden 256, D = 128; tests/golden/model_nsf_wide_*.npz: 3 layer pairs, sigma =
+    0.05, 96 rows): log_prob against the reference's float32 and float64 legs on weights rebuilt from the seed."""
+    import nf_oracle
+    from bench import build_c2_model, state_to_numpy
+    nf_oracle.build()
+    g = load_golden("model_nsf_wide_d%d_h%d" % (D, H))
+    m = build_c2_model(num_layers=3, dim=D, hidden=H, seed=40 + D, sigma=0.05)
+    ora = nf_oracle.OracleNSF(state_to_numpy(m), num_layers=len(m.flows), K=8, tail_bound=3.0)
+    lp = ora.log_prob(g["x"])
+    for tag in ("f32", "f64"):
+        ref = g["log_prob_" + tag]
+        assert np.max(np.abs(lp - ref) / np.maximum(1.0, np.abs(ref))) < 2e-5, tag
+
+
 def test_whole_flow_entry_point_matches_layerwise_oracle_and_reference(oracle):
     """nfo_nsf_log_prob (the single-call, OpenMP-over-rows routine timed as bench.py's cpu_baseline) is bit-identical
     to the layer-by-layer oracle chain and matches the reference's log_prob on the C2-mini fixture."""
