@@ -518,6 +518,26 @@ int nf_made_forward_spline(const void *x, void *y, void *logdet, const void *blo
                            int hidden_padded, int acc, double tail_bound, double min_bin_width, double min_bin_height,
                            double min_derivative, nf_stream_t stream);
 
+/* MADE under autograd.  Replaces what torch autograd records for normflows/nets/made.py:296-304 inside the training loop
+ * core.py:87-102 + loss.backward(): per MaskedLinear (:80-81) the products g W, g^T a and the mask multiplication of the weight
+ * gradient.  Bp = B rounded up to 64, NB = residual blocks, Hp = hidden_padded.
+ *   nf_made_forward_train : nf_made_forward + save ((2 NB + 1) x Bp x Hp floats: the pre-activations h0, t_b, h_(b+1) in slot order,
+ *                           rows beyond B zero) + bits ((Bp / 64) x 2 NB x 2 x 512 dwords: the signs of what a ReLU follows).
+ *   nf_made_backward      : g_params (B, mult D) -> g_x (B, D) and G ((2 NB + 1) x Bp x Hp: the gradient at every layer's output);
+ *                           blob / table: made_pack.pack_made_backward (transposed masked weights, k-group ranges per row-block).
+ *   nf_made_wgrad         : every weight / bias gradient in one launch over the non-zero 128 x 128 tiles + a fixed-order reduction
+ *                           (deterministic); grads = flat vector in the packer's layout, zero-filled by the caller, written where
+ *                           `mask` (bytes, same layout) is non-zero -- the reference's weight.grad is zero under the mask too;
+ *                           gp_pad / x_pad: g_params / x with Bp rows and the row length rounded up to 128 (zeros);
+ *                           part: nf_made_wgrad_scratch_floats(B, ntiles) floats. */
+int nf_made_forward_train(const void *x, void *params, void *save, void *bits, const void *blob, const int32_t *table, int64_t B,
+                          int D, int hidden_padded, int mult, nf_stream_t stream);
+int nf_made_backward(const void *g_params, const void *bits, void *g_x, void *G, const void *blob, const int32_t *table, int64_t B,
+                     int D, int hidden_padded, int mult, nf_stream_t stream);
+int64_t nf_made_wgrad_scratch_floats(int64_t B, int ntiles);
+int nf_made_wgrad(const void *gp_pad, const void *x_pad, const void *G, const void *save, void *grads, const void *mask, void *part,
+                  const int32_t *wtable, const int32_t *stable, int ntiles, int64_t B, nf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * MaskedAffineAutoregressive inverse (MAF sampling direction) in ONE pass.  Replaces the D-pass loop of
  * normflows/flows/affine/autoregressive.py:29-38 over MADE (nets/made.py:217-304, residual blocks :140-214,

@@ -735,6 +735,39 @@ class GaussianRowsLogProbFn(torch.autograd.Function):
         return gz, gl, gs, None, None
 
 
+class MadeFn(torch.autograd.Function):
+    """MADE.forward (nets/made.py:296-304; every linear F.linear(x, weight * mask, bias), :80-81) under autograd: forward =
+    nf_made_forward_train (the one-launch forward + saved pre-activations / ReLU signs), backward = nf_made_backward (input-gradient
+    chain on the transposed masked weights) + nf_made_wgrad (all weight / bias gradients, one launch + a fixed-order reduction).
+    `fwd` / `bwd`: the layer's packs as built at forward time (new tensors are built when a parameter changes, so the ones held here
+    stay what this graph's forward used); params = weight, bias of the initial layer, the blocks' linears, the final layer."""
+
+    @staticmethod
+    def forward(ctx, fwd, bwd, x, *params):
+        blob, table, hp, mult = fwd
+        x = x.contiguous()
+        out, save, bits = ops.made_forward_train(x, blob, table, hp, mult, bwd["NB"])
+        ctx.save_for_backward(x, save, bits)
+        ctx.bwd = bwd
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, save, bits = ctx.saved_tensors
+        bwd = ctx.bwd
+        gout = gout.contiguous()
+        gx, G = ops.made_backward(gout, bits, bwd["blob"], bwd["table"], x.shape[1], bwd["Hp"], bwd["mult"], bwd["NB"])
+        grads = [None] * len(ctx.shapes)
+        if any(ctx.needs_input_grad[3:]):
+            flat = ops.made_wgrad(gout, x, G, save, bwd["wtable"], bwd["stable"], bwd["mask"], bwd["ntiles"], bwd["nflat"],
+                                  bwd["Mp"], bwd["Dx"])
+            for k, (woff, shape, boff, n) in enumerate(bwd["offsets"]):
+                grads[2 * k] = flat[woff:woff + shape[0] * shape[1]].view(shape)
+                grads[2 * k + 1] = flat[boff:boff + n]
+        return (None, None, gx if ctx.needs_input_grad[2] else None) + tuple(grads)
+
+
 class MafAffineFn(torch.autograd.Function):
     """nf_maf_affine (affine/autoregressive.py:98-128) on given MADE output `params` (B, 2D)."""
 

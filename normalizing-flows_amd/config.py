@@ -126,6 +126,16 @@ def set_made_fused(mode=True):
     made_fused = bool(mode)
 
 
+# MADE under autograd (core.py:87-102 through an autoregressive flow's single-pass direction): forward nf_made_forward_train, backward
+# nf_made_backward + nf_made_wgrad (csrc/made_bwd.hip); False = torch autograd through library GEMMs on the pre-masked weights.
+made_train = True
+
+
+def set_made_train(mode=True):
+    global made_train
+    made_train = bool(mode)
+
+
 # CoupledRationalQuadraticSpline beyond the benchmark kernel's shapes (D <= 128, hidden <= 512, 8 bins) as ONE launch (nf_nsf_wide,
 # csrc/nsf_wide.hip); False = library GEMMs for the conditioner + nf_rqs_coupling (ablation / differential tests).
 nsf_wide = True

@@ -1,0 +1,360 @@
+// made_bwd.hip -- the backward pass of MADE (nets/made.py:296-304 under core.py:87-102 + loss.backward(): what torch autograd does
+// with F.linear(x, weight * mask, bias) per MaskedLinear, :80-81) as three launches per MADE: the input-gradient chain, every weight
+// / bias gradient of the network, and their fixed-order reduction.  Operands: what nf_made_forward_train (made_fwd.hip EPI 3) left:
+// save[l][Bp][Hp] pre-activations and the ReLU sign bits.
+//
+//   g_p (B, mult D)  ->  g_h = Wf^T g_p
+//   block b = NB-1 .. 0:   g_t = (W2^T g_h) . [t_b > 0];   g_h += (W1^T g_t) . [h_b > 0]
+//   g_x = W0^T g_h
+//   dWf = g_p (x) h_NB;  dW2_b = g_h(b+1) (x) relu(t_b);  dW1_b = g_t (x) relu(h_b);  dW0 = g_h(0) (x) x;  db = column sums
+//
+// 1. made_bwd_kernel<NSB>: the chain on the 64-row-tile engine of the forward pass (mlp_tile.hpp): the same kernel shape with the
+//    TRANSPOSED masked weights -- with the hidden units sorted by degree a row-block of W^T needs a SUFFIX of k-groups [kg0, kg0 +
+//    nkg) (item = [nkg, rb, kg0]); gradients live in accumulator registers, the next product's B operand is published to LDS, the
+//    ReLU masks are the forward's sign bits (one dword per lane and item); g_p enters in chunks of Hp columns (mult D = 2944 for the
+//    autoregressive spline layer does not fit the LDS at once).  Every g_h / g_t is also written row-major to G[l][Bp][Hp] for 2.
+// 2. made_wgrad_kernel: dW = dY^T X over the batch for ALL masked linears of the network in one launch: 128 x 128 output tiles that
+//    hold a mask non-zero (host table), both operands streamed by LDS-DMA through a 3-slot ring by four helper waves while four waves
+//    issue the MFMAs (the design of wgrad.hip's wgrad_ring_kernel, with row strides and per-problem operands); split over row chunks.
+// 3. made_wgrad_reduce_kernel: the chunks' partial tiles summed in a fixed order (deterministic) and scattered from slot space to
+//    the parameters' own layout, masked entries left zero.
+#include "mlp_tile.hpp"
+
+namespace nf {
+
+// ---- 1. input-gradient chain ---------------------------------------------------------------------------------------------------------
+template <int NSB>
+__global__ void __launch_bounds__(64 * MF_NW, 1)
+made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits, float *__restrict__ gx, float *__restrict__ G,
+                const float *__restrict__ blob, const int *__restrict__ table, int64_t B, int64_t Bp) {
+    constexpr int NS = NSB;
+    constexpr int HRB = 8 * NSB;
+    constexpr int HP = 256 * NSB;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *acts = lds;                                  // [HP / 8 k-groups][2][64][4]
+    float *xreg = lds + (size_t)HRB * 4 * 512;          // [Dp / 8][2][64][4]: the g_x tile on its way out
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hh = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = table[0], NB = table[5], mult = table[6], NC = table[7], nitems = table[10];
+    const int MD = mult * D;
+    const int *items = table + MF_HDR + w * nitems * 4;       // [nitems][nkg, rb, kg0, -]
+    const float *stream = blob + table[16 + w];
+    const int rbs[2] = {w, HRB - 1 - w};
+    const int sb0s[2] = {0, NSB == 2 ? 0 : 1};
+    const int lane_b = (64 * hh + n) * 4;
+    const int64_t ntiles = (B + MF_ROWS - 1) / MF_ROWS;
+    MfRing ring;
+    mf_ring_start(ring, stream, lane);
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * MF_ROWS;
+        const int nrows = (int)((B - row0) < MF_ROWS ? (B - row0) : MF_ROWS);
+        ring.ap = stream + lane * 4;
+        const unsigned *btile = bits + ((size_t)tile * 2 * NB * 2) * 512 + tid;
+        float *gtile = G + (size_t)row0 * HP;
+        f32x16 gh[2][NS], u[2][NS];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int ss = 0; ss < NS; ++ss)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gh[s][ss][r] = 0.0f;
+        // ---- g_h = Wf^T g_p, g_p in chunks of HP columns (B-operand order; rows beyond the batch and columns beyond mult D zero) ----
+        for (int c = 0; c < NC; ++c) {
+            MF_BARRIER();
+            {
+                const int r = tid & 63, cg = tid >> 6;
+                const float *gr = gp + (row0 + r) * MD;
+                for (int c4 = cg; c4 < HP / 4; c4 += MF_NW) {
+                    const int col = c * HP + 4 * c4;
+                    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (r < nrows && col < MD) {
+                        if ((MD & 3) == 0) v = *reinterpret_cast<const f32x4 *>(gr + col);
+                        else
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) if (col + i < MD) v[i] = gr[col + i];
+                    }
+                    *reinterpret_cast<f32x4 *>(acts + ((size_t)c4 * 64 + r) * 4) = v;
+                }
+            }
+            MF_BARRIER();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int *it = items + 4 * (2 * c + s);
+                mf_item<NS, true>(ring, it[0], acts + lane_b + 128 * sb0s[s] + it[2] * 512, gh[s]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) mf_save_rows<NS, false>(gtile + (size_t)(2 * NB) * Bp * HP, HP, nrows, rbs[s], sb0s[s], hh, n, gh[s]);
+        // ---- residual blocks, last first ------------------------------------------------------------------------------------------------
+        for (int b = NB - 1; b >= 0; --b) {
+            const int *itb = items + 4 * (2 * NC + 4 * (NB - 1 - b));
+            unsigned bt[2], bh[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bt[s] = btile[((size_t)(2 * b + 1) * 2 + s) * 512];
+                bh[s] = btile[((size_t)(2 * b) * 2 + s) * 512];
+            }
+            MF_BARRIER();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) mf_publish<NS, false>(acts, rbs[s], sb0s[s], hh, n, gh[s]);
+            MF_BARRIER();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int *it = itb + 4 * s;
+                mf_item<NS, false>(ring, it[0], acts + lane_b + 128 * sb0s[s] + it[2] * 512, u[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                mf_masked<NS, false>(u[s], u[s], bt[s]);                 // g_t
+                mf_save_rows<NS, false>(gtile + (size_t)(2 * b + 1) * Bp * HP, HP, nrows, rbs[s], sb0s[s], hh, n, u[s]);
+            }
+            MF_BARRIER();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) mf_publish<NS, false>(acts, rbs[s], sb0s[s], hh, n, u[s]);
+            MF_BARRIER();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int *it = itb + 4 * (2 + s);
+                mf_item<NS, false>(ring, it[0], acts + lane_b + 128 * sb0s[s] + it[2] * 512, u[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                mf_masked<NS, true>(gh[s], u[s], bh[s]);                 // g_h of the block's input
+                mf_save_rows<NS, false>(gtile + (size_t)(2 * b) * Bp * HP, HP, nrows, rbs[s], sb0s[s], hh, n, gh[s]);
+            }
+        }
+        // ---- g_x = W0^T g_h: one 32-feature row-block and sample block per wave ------------------------------------------------------
+        MF_BARRIER();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) mf_publish<NS, false>(acts, rbs[s], sb0s[s], hh, n, gh[s]);
+        MF_BARRIER();
+        {
+            const int *it = items + 4 * (2 * NC + 4 * NB);
+            const int rb = it[1], sf = w >> 2;
+            if (rb >= 0) {
+                f32x16 o[1];
+                mf_item<1, false>(ring, it[0], acts + lane_b + 128 * sf + it[2] * 512, o);
+                mf_publish<1, false>(xreg, rb, sf, hh, n, o);
+            }
+        }
+        MF_BARRIER();
+        {
+            const int r = tid & 63, cg = tid >> 6;
+            float *xr = gx + (row0 + r) * D;
+            if (r < nrows)
+                for (int c = cg; 4 * c < D; c += MF_NW) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(xreg + ((size_t)c * 64 + r) * 4);
+                    if ((D & 3) == 0) *reinterpret_cast<f32x4 *>(xr + 4 * c) = v;
+                    else
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (4 * c + i < D) xr[4 * c + i] = v[i];
+                }
+        }
+        MF_BARRIER();                              // the next tile overwrites the activations and the g_x tile
+    }
+}
+
+template <int NSB>
+static int made_bwd_launch(const void *gp, const void *bits, void *gx, void *G, const void *blob, const int32_t *table, int64_t B,
+                           hipStream_t st) {
+    const int64_t ntiles = (B + MF_ROWS - 1) / MF_ROWS;
+    const int grid = (int)(ntiles < 256 ? ntiles : 256);
+    const size_t lds = sizeof(float) * ((size_t)8 * NSB * 4 * 512 + MF_XFLOATS);
+    static LdsOptIn opted;
+    if (opt_in_lds(reinterpret_cast<const void *>(&made_bwd_kernel<NSB>), lds, opted) != NF_OK) return NF_ENOTSUP;
+    hipLaunchKernelGGL((made_bwd_kernel<NSB>), dim3((unsigned)grid), dim3(64 * MF_NW), lds, st, (const float *)gp,
+                       (const unsigned *)bits, (float *)gx, (float *)G, (const float *)blob, (const int *)table, B, ntiles * MF_ROWS);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// ---- 2. weight gradients --------------------------------------------------------------------------------------------------------------
+// wt (int32): hdr[16] = [ntiles, nproblems, ...]; problems at wt + 16: 8 ints [dY base, dY matrix index, ldY, X base, X matrix index,
+// ldX, relu(X), -] (base 0 = g_p padded, 1 = x padded, 2 = G, 3 = save; matrix index l = the l-th (Bp, ld) matrix behind the base);
+// tiles behind them: 8 ints [problem, m0, n0, want_bias, ...].  part: [chunk][tile][128 * 128 + 128].
+constexpr int MW_T = 128, MW_KS = 16, MW_NR = 3, MW_NT = 64 * 8, MW_PART = MW_T * MW_T + MW_T;
+#define MW_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__global__ void __launch_bounds__(MW_NT, 4)
+made_wgrad_kernel(const float *__restrict__ b0p, const float *__restrict__ b1p, const float *__restrict__ b2p,
+                  const float *__restrict__ b3p, float *__restrict__ part, const int *__restrict__ wt, int chunk_rows, int64_t Bp) {
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    __shared__ __attribute__((aligned(16))) float ring[MW_NR][2][MW_KS][MW_T];     // [slot][dY | X][row][128] = 48 KB
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntl = wt[0], npr = wt[1];
+    const int *tl = wt + 16 + 8 * npr + 8 * blockIdx.y;
+    const int *pr = wt + 16 + 8 * tl[0];
+    const int m0 = tl[1], n0 = tl[2], want_bias = tl[3];
+    auto base = [&](int k) { return k == 0 ? b0p : k == 1 ? b1p : k == 2 ? b2p : b3p; };
+    const int ldY = pr[2], ldX = pr[5], x_relu = pr[6];
+    const float *dY = base(pr[0]) + (size_t)pr[1] * Bp * ldY + m0;
+    const float *X = base(pr[3]) + (size_t)pr[4] * Bp * ldX + n0;
+    const int64_t r_begin = (int64_t)blockIdx.x * chunk_rows;
+    int64_t r_end = r_begin + chunk_rows;
+    if (r_end > Bp) r_end = Bp;
+    const int nsteps = (int)((r_end - r_begin) / MW_KS);         // chunk_rows and Bp are multiples of 16
+    const bool mfma_wave = wid < 4;
+    const int dw = wid - 4;
+    const int lrow = lane >> 5, lcol = (lane & 31) * 4;
+    auto issue = [&](int s) {
+        const int64_t r0 = r_begin + (int64_t)s * MW_KS + 4 * dw + lrow;
+        float *slotA = &ring[s % MW_NR][0][4 * dw][0], *slotB = &ring[s % MW_NR][1][4 * dw][0];
+        __builtin_amdgcn_global_load_lds(dY + r0 * ldY + lcol, (lds_ptr)slotA, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(dY + (r0 + 2) * ldY + lcol, (lds_ptr)(slotA + 2 * MW_T), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(X + r0 * ldX + lcol, (lds_ptr)slotB, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(X + (r0 + 2) * ldX + lcol, (lds_ptr)(slotB + 2 * MW_T), 16, 0, 0);
+    };
+    if (!mfma_wave) {
+        // helper waves: requests and barriers only (the same barrier sequence as the MFMA waves below)
+        for (int s = 0; s < MW_NR - 1 && s < nsteps; ++s) issue(s);
+        for (int s = 0; s < nsteps; ++s) {
+            if (s + MW_NR - 1 <= nsteps) NF_WAIT_VMCNT(4 * (MW_NR - 2));
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (s + MW_NR - 1 < nsteps) issue(s + MW_NR - 1);
+        }
+        return;
+    }
+    const int wm = wid >> 1, wn = wid & 1;
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    float bs0 = 0.0f, bs1 = 0.0f;
+    for (int s = 0; s < nsteps; ++s) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // step s landed; every wave is done with slot (s - 1) % NR
+        const float *ap = &ring[s % MW_NR][0][h][wm * 64 + i], *bp = &ring[s % MW_NR][1][h][wn * 64 + i];
+#pragma unroll
+        for (int kp = 0; kp < MW_KS / 2; ++kp) {
+            const float a0 = ap[kp * 2 * MW_T], a1 = ap[kp * 2 * MW_T + 32];
+            float x0 = bp[kp * 2 * MW_T], x1 = bp[kp * 2 * MW_T + 32];
+            if (x_relu) { x0 = fmaxf(x0, 0.0f); x1 = fmaxf(x1, 0.0f); }
+            bs0 += a0;
+            bs1 += a1;
+            acc00 = MW_MFMA(a0, x0, acc00);
+            acc01 = MW_MFMA(a0, x1, acc01);
+            acc10 = MW_MFMA(a1, x0, acc10);
+            acc11 = MW_MFMA(a1, x1, acc11);
+        }
+    }
+    float *out = part + ((size_t)blockIdx.x * ntl + blockIdx.y) * MW_PART;
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+#pragma unroll
+        for (int t_ = 0; t_ < 2; ++t_) {
+            const f32x16 &acc = s_ == 0 ? (t_ == 0 ? acc00 : acc01) : (t_ == 0 ? acc10 : acc11);
+            const int nn = wn * 64 + 32 * t_ + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mm = wm * 64 + 32 * s_ + (r & 3) + 8 * (r >> 2) + 4 * h;
+                out[(size_t)mm * MW_T + nn] = acc[r];
+            }
+        }
+    }
+    if (want_bias && wn == 0) {
+        bs0 += __shfl_xor(bs0, 32);
+        bs1 += __shfl_xor(bs1, 32);
+        if (h == 0) {
+            out[MW_T * MW_T + wm * 64 + i] = bs0;
+            out[MW_T * MW_T + wm * 64 + i + 32] = bs1;
+        }
+    }
+}
+
+// ---- 3. reduction + scatter -----------------------------------------------------------------------------------------------------------
+// sc (int32): per problem 8 ints [weight offset in `grads`, ld of the weight, bias offset, row-map offset, column-map offset, ...]
+// (maps: slot -> parameter row / column, -1 = padding; offsets into sc itself).  Element e of tile t: sum over the chunks in order;
+// written only where the parameter's mask is non-zero (`grads` is zero-filled by the host: the masked entries' gradient).
+__global__ void __launch_bounds__(256)
+made_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ grads, const unsigned char *__restrict__ mask,
+                         const int *__restrict__ wt, const int *__restrict__ sc, int chunks) {
+    const int ntl = wt[0], npr = wt[1];
+    const int t = blockIdx.y;
+    const int *tl = wt + 16 + 8 * npr + 8 * t;
+    const int *ps = sc + 8 * tl[0];
+    const int m0 = tl[1], n0 = tl[2], want_bias = tl[3];
+    const int *rowmap = sc + ps[3], *colmap = sc + ps[4];
+    const int nel = MW_T * MW_T + (want_bias ? MW_T : 0);
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < nel; e += gridDim.x * 256) {
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        const float *p = part + (size_t)t * MW_PART + e;
+        const size_t stride = (size_t)ntl * MW_PART;
+        int c = 0;
+        for (; c + 3 < chunks; c += 4) {
+            s0 += p[(size_t)c * stride];
+            s1 += p[(size_t)(c + 1) * stride];
+            s2 += p[(size_t)(c + 2) * stride];
+            s3 += p[(size_t)(c + 3) * stride];
+        }
+        for (; c < chunks; ++c) s0 += p[(size_t)c * stride];
+        const float s = (s0 + s1) + (s2 + s3);
+        if (e < MW_T * MW_T) {
+            const int row = rowmap[m0 + (e >> 7)], col = colmap[n0 + (e & 127)];
+            if (row >= 0 && col >= 0) {
+                const size_t dst = (size_t)ps[0] + (size_t)row * ps[1] + col;
+                if (mask[dst]) grads[dst] = s;
+            }
+        } else {
+            const int row = rowmap[m0 + (e - MW_T * MW_T)];
+            if (row >= 0) grads[(size_t)ps[2] + row] = s;
+        }
+    }
+}
+
+}  // namespace nf
+
+static int made_bwd_check(int64_t B, int D, int hidden_padded, int mult) {
+    if (B < 0 || D < 2 || D > 128 || mult < 1) return NF_EINVAL;
+    if (hidden_padded != 256 && hidden_padded != 512) return NF_ENOTSUP;
+    return NF_OK;
+}
+
+// The input-gradient chain of MADE: g_params (B, mult D) -> g_x (B, D), and every layer's output gradient to G ((2 num_blocks + 1) x
+// Bp x hidden_padded, Bp = B rounded up to 64).  bits: from nf_made_forward_train; blob / table: flows/made_pack.pack_made_backward.
+extern "C" int nf_made_backward(const void *g_params, const void *bits, void *g_x, void *G, const void *blob, const int32_t *table,
+                                int64_t B, int D, int hidden_padded, int mult, nf_stream_t stream) {
+    const int rc = made_bwd_check(B, D, hidden_padded, mult);
+    if (rc != NF_OK) return rc;
+    if (B == 0) return NF_OK;
+    if (!g_params || !bits || !g_x || !G || !blob || !table) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    if (hidden_padded == 256) return nf::made_bwd_launch<1>(g_params, bits, g_x, G, blob, table, B, st);
+    return nf::made_bwd_launch<2>(g_params, bits, g_x, G, blob, table, B, st);
+}
+
+static int made_wgrad_chunk_rows(int64_t Bp, int ntiles) {
+    int64_t want = (768 + ntiles - 1) / ntiles;                 // ~ three workgroups per CU
+    if (want < 1) want = 1;
+    int64_t rows = (Bp + want - 1) / want;
+    rows = (rows + 63) / 64 * 64;
+    if (rows < 256) rows = 256;
+    return (int)rows;
+}
+
+// floats of `part` for nf_made_wgrad (Bp = B rounded up to 64)
+extern "C" int64_t nf_made_wgrad_scratch_floats(int64_t B, int ntiles) {
+    if (B < 0 || ntiles < 1) return NF_EINVAL;
+    const int64_t Bp = (B + 63) / 64 * 64;
+    const int rows = made_wgrad_chunk_rows(Bp, ntiles);
+    return ((Bp + rows - 1) / rows) * (int64_t)ntiles * nf::MW_PART;
+}
+
+// Every weight and bias gradient of the MADE in one launch + one fixed-order reduction: grads (flat, zero-filled by the caller; the
+// layout of flows/made_pack.pack_made_backward) receives the sums where `mask` (bytes, the same layout) is non-zero.  gp_pad / x_pad:
+// g_params / x with Bp rows and the row length rounded up to 128 (zero padding; the tensors themselves when they already have it).
+extern "C" int nf_made_wgrad(const void *gp_pad, const void *x_pad, const void *G, const void *save, void *grads, const void *mask,
+                             void *part, const int32_t *wtable, const int32_t *stable, int ntiles, int64_t B, nf_stream_t stream) {
+    if (B < 0 || ntiles < 1) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!gp_pad || !x_pad || !G || !save || !grads || !mask || !part || !wtable || !stable) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t Bp = (B + 63) / 64 * 64;
+    const int rows = made_wgrad_chunk_rows(Bp, ntiles);
+    const int chunks = (int)((Bp + rows - 1) / rows);
+    hipLaunchKernelGGL(nf::made_wgrad_kernel, dim3((unsigned)chunks, (unsigned)ntiles), dim3(nf::MW_NT), 0, st, (const float *)gp_pad,
+                       (const float *)x_pad, (const float *)G, (const float *)save, (float *)part, (const int *)wtable, rows, Bp);
+    NF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nf::made_wgrad_reduce_kernel, dim3(16, (unsigned)ntiles), dim3(256), 0, st, (const float *)part, (float *)grads,
+                       (const unsigned char *)mask, (const int *)wtable, (const int *)stable, chunks);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

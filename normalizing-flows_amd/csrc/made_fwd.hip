@@ -37,11 +37,16 @@ namespace nf {
 // utils/splines.py:16-219 element-wise with 8 bins and linear tails) on the final layer's accumulators -- the final layer runs in
 // groups of four features whose rows are packed so that a lane holds the 2 x 24 parameters of two features (the layout of
 // nsf_wide.hip; mlp_tile.hpp mf_final_item), the spline runs in registers (rqs_regs), x is read from the tile and y written into it.
+// EPI 3: EPI 1 under autograd (core.py:87-102 through a MADE): every layer's pre-activations are also written row-major to
+// save[l][Bp][Hp] (l = 0: the initial layer's h; 2 b + 1: block b's inner t; 2 b + 2: its output h) and the signs of what a ReLU
+// follows to bits[tile][2 b | 2 b + 1][item][512 lanes] -- the operands of made_bwd.hip.
 template <int NSB, int EPI>
 __global__ void __launch_bounds__(64 * MF_NW, 1)
 made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ logdet, const float *__restrict__ blob,
-                const int *__restrict__ table, int64_t B, int acc_mode, RqsParams<float> p) {
+                const int *__restrict__ table, int64_t B, int acc_mode, RqsParams<float> p, float *__restrict__ save,
+                unsigned *__restrict__ bits, int64_t Bp) {
     constexpr int NS = NSB;                  // sample blocks per hidden work item
+    constexpr int HP = 256 * NSB;
     constexpr int HRB = 8 * NSB;             // hidden row-blocks
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *acts = lds;                                  // [HRB * 4 k-groups][2][64][4]
@@ -82,20 +87,41 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
         // ---- initial layer: h = b0 + W0 x ----------------------------------------------------------------------------------------------
 #pragma unroll
         for (int s = 0; s < 2; ++s) mf_item<NS, false>(ring, items[2 * s], xreg + lane_b + 128 * sb0s[s], h[s]);
+        float *stile = nullptr;
+        unsigned *btile = nullptr;
+        if constexpr (EPI == 3) {
+            stile = save + (size_t)row0 * HP;
+            btile = bits + ((size_t)tile * 2 * NB * 2) * 512 + tid;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) mf_save_rows<NS, true>(stile, HP, nrows, rbs[s], sb0s[s], hh, n, h[s]);
+        }
         // ---- residual blocks (nets/made.py:196-214): t = b1 + W1 relu(h);  h += b2 + W2 relu(t) -------------------------------
         for (int b = 0; b < NB; ++b) {
             MF_BARRIER();        // (b > 0: every wave has finished reading relu(t) of the previous block)
 #pragma unroll
             for (int s = 0; s < 2; ++s) mf_publish<NS, true>(acts, rbs[s], sb0s[s], hh, n, h[s]);
+            if constexpr (EPI == 3)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) btile[((size_t)(2 * b) * 2 + s) * 512] = mf_sign_bits<NS>(h[s]);
             MF_BARRIER();
 #pragma unroll
             for (int s = 0; s < 2; ++s) mf_item<NS, false>(ring, items[2 * (2 + 4 * b + s)], acts + lane_b + 128 * sb0s[s], t[s]);
             MF_BARRIER();
 #pragma unroll
             for (int s = 0; s < 2; ++s) mf_publish<NS, true>(acts, rbs[s], sb0s[s], hh, n, t[s]);
+            if constexpr (EPI == 3)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    btile[((size_t)(2 * b + 1) * 2 + s) * 512] = mf_sign_bits<NS>(t[s]);
+                    mf_save_rows<NS, true>(stile + (size_t)(2 * b + 1) * Bp * HP, HP, nrows, rbs[s], sb0s[s], hh, n, t[s]);
+                }
             MF_BARRIER();
 #pragma unroll
             for (int s = 0; s < 2; ++s) mf_item<NS, true>(ring, items[2 * (4 + 4 * b + s)], acts + lane_b + 128 * sb0s[s], h[s]);
+            if constexpr (EPI == 3)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    mf_save_rows<NS, true>(stile + (size_t)(2 * b + 2) * Bp * HP, HP, nrows, rbs[s], sb0s[s], hh, n, h[s]);
         }
         // ---- final layer on the RAW block output (:303-304) + epilogue -------------------------------------------------------------
         MF_BARRIER();
@@ -244,14 +270,15 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
 
 template <int NSB, int EPI>
 static int made_fwd_launch(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, int64_t B, int acc, hipStream_t st,
-                           const RqsParams<float> &p = RqsParams<float>()) {
+                           const RqsParams<float> &p = RqsParams<float>(), void *save = nullptr, void *bits = nullptr) {
     const int64_t ntiles = (B + MF_ROWS - 1) / MF_ROWS;
     const int grid = (int)(ntiles < 256 ? ntiles : 256);        // persistent: one workgroup per CU (160 KB of LDS at Hp = 512)
     const size_t lds = sizeof(float) * ((size_t)8 * NSB * 4 * 512 + MF_XFLOATS);
     static LdsOptIn opted;
     if (opt_in_lds(reinterpret_cast<const void *>(&made_fwd_kernel<NSB, EPI>), lds, opted) != NF_OK) return NF_ENOTSUP;
     hipLaunchKernelGGL((made_fwd_kernel<NSB, EPI>), dim3((unsigned)grid), dim3(64 * MF_NW), lds, st, (const float *)x, (float *)y,
-                       (float *)logdet, (const float *)blob, (const int *)table, B, acc, p);
+                       (float *)logdet, (const float *)blob, (const int *)table, B, acc, p, (float *)save, (unsigned *)bits,
+                       ntiles * MF_ROWS);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -305,4 +332,17 @@ extern "C" int nf_made_forward_spline(const void *x, void *y, void *logdet, cons
     hipStream_t st = (hipStream_t)stream;
     if (hidden_padded == 256) return nf::made_fwd_launch<1, 2>(x, y, logdet, blob, table, B, acc, st, p);
     return nf::made_fwd_launch<2, 2>(x, y, logdet, blob, table, B, acc, st, p);
+}
+
+// MADE.forward under autograd: nf_made_forward + the operands of nf_made_backward / nf_made_wgrad (csrc/made_bwd.hip).  Bp = B rounded
+// up to 64; save: (2 num_blocks + 1) x Bp x hidden_padded floats; bits: (Bp / 64) x 2 num_blocks x 2 x 512 dwords.
+extern "C" int nf_made_forward_train(const void *x, void *params, void *save, void *bits, const void *blob, const int32_t *table,
+                                     int64_t B, int D, int hidden_padded, int mult, nf_stream_t stream) {
+    const int rc = made_fwd_check(B, D, hidden_padded, mult);
+    if (rc != NF_OK) return rc;
+    if (B == 0) return NF_OK;
+    if (!x || !params || !save || !bits || !blob || !table) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    if (hidden_padded == 256) return nf::made_fwd_launch<1, 3>(x, params, nullptr, blob, table, B, NF_LD_WRITE, st, nf::RqsParams<float>(), save, bits);
+    return nf::made_fwd_launch<2, 3>(x, params, nullptr, blob, table, B, NF_LD_WRITE, st, nf::RqsParams<float>(), save, bits);
 }

@@ -197,4 +197,47 @@ __device__ __forceinline__ void mf_final_item(MfRing &r, int nkg, const float *B
     r.ap += (size_t)(12 + 3 * nkg) * 256;
 }
 
+// ---- training (made_fwd.hip EPI 3 -> made_bwd.hip): what the backward pass needs of a row-block's pre-activations -------------------
+// the values themselves, row-major [row][ld] (the weight-gradient kernel's operand order; rows beyond the batch are written as zeros
+// so that the padded rows of a tile contribute nothing), and their signs as one dword per lane and item (bit 16 s + r = register r of
+// sample block s: the ReLU mask of the input-gradient chain).
+template <int NS, bool GUARD>
+__device__ __forceinline__ void mf_save_rows(float *S, int ld, int nrows, int rb, int sb0, int hh, int n, const f32x16 (&v)[NS]) {
+    float *base = S + 32 * rb;                                          // wave-uniform
+    const unsigned lane_off = (unsigned)((32 * sb0 + n) * ld + 4 * hh);   // floats; < 64 ld
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const bool live = !GUARD || 32 * (sb0 + s) + n < nrows;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = live ? v[s][4 * q + i] : 0.0f;
+            *reinterpret_cast<f32x4 *>(base + (lane_off + (unsigned)(32 * s * ld + 8 * q))) = o;
+        }
+    }
+}
+
+template <int NS>
+__device__ __forceinline__ unsigned mf_sign_bits(const f32x16 (&v)[NS]) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bits |= (v[s][r] > 0.0f ? 1u : 0u) << (16 * s + r);
+    return bits;
+}
+
+// ADD: dst += src where the bit is set;  !ADD: dst = src where the bit is set, else 0
+template <int NS, bool ADD>
+__device__ __forceinline__ void mf_masked(f32x16 (&dst)[NS], const f32x16 (&src)[NS], unsigned bits) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float m = (bits >> (16 * s + r)) & 1u ? src[s][r] : 0.0f;
+            dst[s][r] = ADD ? dst[s][r] + m : m;
+        }
+}
+
 }  // namespace nf

@@ -86,10 +86,10 @@ def wave_items(NSB, NB, NFB):
     return out
 
 
-def pack_made_forward(made, mult=2, spline=False):
-    """(blob float32 ndarray, table int32 ndarray) or None when the MADE is outside the kernel's structure (then the caller
-    keeps the layer-by-layer path).  spline: the final layer in groups for the fused spline epilogue (mult = 23)."""
-    if not supported(made, mult) or (spline and mult != 23):
+def _slot_layers(made, mult):
+    """The MADE's masked linears in SLOT space (hidden units sorted by degree, zero-padded): dict with the sizes, `order` (slot ->
+    unit) and `layers` = [(W, M, b)] for the initial layer, the blocks' linears and the final layer; None outside the structure."""
+    if not supported(made, mult):
         return None
     D = made.initial_layer.in_features
     H = made.initial_layer.out_features
@@ -137,6 +137,18 @@ def pack_made_forward(made, mult=2, spline=False):
     for l in lin[1:]:
         layers.append(slots(l, slot_of, Hp, slot_of, Hp))
     layers.append(slots(fin, slot_of, Hp, np.arange(mult * D), NFB * ROWS))
+    return dict(D=D, H=H, NB=NB, Hp=Hp, NSB=NSB, Dp=Dp, NFB=NFB, order=order, slot_of=slot_of, layers=layers, lin=lin + [fin])
+
+
+def pack_made_forward(made, mult=2, spline=False):
+    """(blob float32 ndarray, table int32 ndarray) or None when the MADE is outside the kernel's structure (then the caller
+    keeps the layer-by-layer path).  spline: the final layer in groups for the fused spline epilogue (mult = 23)."""
+    if spline and mult != 23:
+        return None
+    sl = _slot_layers(made, mult)
+    if sl is None:
+        return None
+    D, H, NB, Hp, NSB, Dp, NFB, layers = (sl[k] for k in ("D", "H", "NB", "Hp", "NSB", "Dp", "NFB", "layers"))
 
     if spline:
         return _pack_spline(layers, D, Dp, H, Hp, NSB, NB, mult)
@@ -239,3 +251,130 @@ def _pack_spline(layers, D, Dp, H, Hp, NSB, NB, mult):
     blob = np.concatenate(chunks).astype(np.float32)
     assert blob.size == off and off < 2 ** 31
     return blob, np.concatenate([hdr, tab.reshape(-1)]).astype(np.int32)
+
+
+# ---- backward pass (csrc/made_bwd.hip) ------------------------------------------------------------------------------------------------
+W_TILE = 128     # made_wgrad_kernel: edge of an output tile
+
+
+def _suffix_item(WT, MT, rb, c0, c1):
+    """Row-block rb of a transposed masked weight restricted to the columns [c0, c1): (nkg, kg0 relative to c0, stream) -- the
+    k-groups between the first and the last mask non-zero, both rounded to multiples of 4 (a suffix once the units are sorted)."""
+    r0 = rb * ROWS
+    cols = np.nonzero(MT[r0:r0 + ROWS, c0:c1].any(axis=0))[0]
+    zero_bias = np.zeros(4 * 256, dtype=np.float32)
+    if cols.size == 0:
+        return 0, 0, [zero_bias]
+    kg0 = (int(cols.min()) // KG) // 4 * 4
+    kg1 = (int(cols.max()) // KG + 4) // 4 * 4
+    assert KG * kg1 <= c1 - c0
+    return kg1 - kg0, kg0, [zero_bias, a_stream(WT[r0:r0 + ROWS, c0 + KG * kg0:c0 + KG * kg1])]
+
+
+def pack_made_backward(made, mult=2):
+    """Tables of nf_made_backward / nf_made_wgrad for a MADE pack_made_forward takes, or None.  Returns a dict of numpy arrays:
+      blob, table        the input-gradient chain's 8 streams (zero bias group + the TRANSPOSED masked weight's fragments per item) and
+                         hdr[32] = [D, Dp, H, Hp, NSB, NB, mult, NC (chunks of Hp columns of g_params), 0, total, nitems], hdr[16 + w]
+                         = stream offsets, then per wave nitems entries [nkg, rb, kg0, 0]: NC x 2 items of Wf^T, per block (last
+                         first) 2 of W2^T and 2 of W1^T, one of W0^T (row-block w & 3 of the features for sample block w >> 2, -1: none)
+      wtable             hdr[16] = [ntiles, nproblems], problems [dY base, dY matrix, ldY, X base, X matrix, ldX, relu, 0], tiles
+                         [problem, m0, n0, want_bias, 0...] (bases: 0 = g_params padded, 1 = x padded, 2 = G, 3 = save)
+      stable             per problem [weight offset, ld, bias offset, row-map offset, column-map offset, 0, 0, 0], then the maps
+      mask               bytes over the flat gradient layout (1 where the parameter's mask is non-zero; biases 1)
+      offsets            [(weight offset, shape, bias offset, n)] per linear in the order initial, blocks' linears, final
+      nflat, ntiles, Mp (g_params row length padded to 128), Dx (x row length padded to 128)."""
+    sl = _slot_layers(made, mult)
+    if sl is None:
+        return None
+    D, H, NB, Hp, NSB, Dp, NFB, layers, order = (sl[k] for k in ("D", "H", "NB", "Hp", "NSB", "Dp", "NFB", "layers", "order"))
+    HRB = Hp // ROWS
+    MD = mult * D
+    NC = (MD + Hp - 1) // Hp
+    Wf, Mf, _ = layers[-1]
+    WfT = np.zeros((Hp, NC * Hp), dtype=np.float32)
+    MfT = np.zeros((Hp, NC * Hp), dtype=bool)
+    WfT[:, :Wf.shape[0]] = Wf.T
+    MfT[:, :Mf.shape[0]] = Mf.T
+    nitems = 2 * NC + 4 * NB + 1
+    hdr = np.zeros(HDR, dtype=np.int32)
+    tab = np.zeros((8, nitems, 4), dtype=np.int32)
+    chunks, off = [], 0
+    for w in range(8):
+        hdr[16 + w] = off
+        stream, i = [], 0
+        for c in range(NC):
+            for rb in (w, HRB - 1 - w):
+                nkg, kg0, st = _suffix_item(WfT, MfT, rb, c * Hp, (c + 1) * Hp)
+                tab[w, i] = (nkg, rb, kg0, 0)
+                stream += st
+                i += 1
+        for b in range(NB - 1, -1, -1):
+            for l in (2 + 2 * b, 1 + 2 * b):             # W2 of the block, then its W1
+                W, M, _ = layers[l]
+                for rb in (w, HRB - 1 - w):
+                    nkg, kg0, st = _suffix_item(W.T, M.T, rb, 0, Hp)
+                    tab[w, i] = (nkg, rb, kg0, 0)
+                    stream += st
+                    i += 1
+        W0, M0, _ = layers[0]
+        rb = w & 3
+        if rb < Dp // ROWS:
+            nkg, kg0, st = _suffix_item(W0.T, M0.T, rb, 0, Hp)
+            tab[w, i] = (nkg, rb, kg0, 0)
+            stream += st
+        else:
+            tab[w, i] = (0, -1, 0, 0)
+        stream = np.concatenate(stream)
+        stream = np.concatenate([stream, np.resize(stream, RING * 256)])
+        chunks.append(stream)
+        off += stream.size
+    hdr[:11] = [D, Dp, H, Hp, NSB, NB, mult, NC, 0, off, nitems]
+    blob = np.concatenate(chunks).astype(np.float32)
+    assert blob.size == off and off < 2 ** 31
+    table = np.concatenate([hdr, tab.reshape(-1)]).astype(np.int32)
+
+    # ---- weight gradients: problems, non-zero 128 x 128 tiles, scatter maps, flat layout ----
+    Mp = (MD + W_TILE - 1) // W_TILE * W_TILE
+    Dx = (D + W_TILE - 1) // W_TILE * W_TILE
+    slot_to_unit = np.full(Hp, -1, dtype=np.int32)
+    slot_to_unit[:H] = order
+    feat_map = np.full(Dx, -1, dtype=np.int32)
+    feat_map[:D] = np.arange(D)
+    out_map = np.full(Mp, -1, dtype=np.int32)
+    out_map[:MD] = np.arange(MD)
+    # (problem: dY base / matrix / ld, X base / matrix / ld, relu, slot-space mask [M x N], row map, column map, parameter shape)
+    probs = [(2, 0, Hp, 1, 0, Dx, 0, layers[0][1], slot_to_unit, feat_map, (H, D))]
+    for b in range(NB):
+        probs.append((2, 2 * b + 1, Hp, 3, 2 * b, Hp, 1, layers[1 + 2 * b][1], slot_to_unit, slot_to_unit, (H, H)))
+        probs.append((2, 2 * b + 2, Hp, 3, 2 * b + 1, Hp, 1, layers[2 + 2 * b][1], slot_to_unit, slot_to_unit, (H, H)))
+    probs.append((0, 0, Mp, 3, 2 * NB, Hp, 0, layers[-1][1], out_map, slot_to_unit, (MD, H)))
+    ptab, tiles, stab, maps = [], [], [], []
+    offsets, mask_parts, flat = [], [], 0
+    map_off = 8 * len(probs)
+    for pi, (dyb, dyl, ldy, xb, xl, ldx, relu, M, rmap, cmap, shape) in enumerate(probs):
+        ptab.append([dyb, dyl, ldy, xb, xl, ldx, relu, 0])
+        Mrows, Ncols = len(rmap), len(cmap)
+        Mfull = np.zeros((Mrows, Ncols), dtype=bool)
+        Mfull[:M.shape[0], :M.shape[1]] = M
+        for mt in range(Mrows // W_TILE):
+            nz = [nt for nt in range(Ncols // W_TILE) if Mfull[mt * W_TILE:(mt + 1) * W_TILE, nt * W_TILE:(nt + 1) * W_TILE].any()]
+            if not nz:
+                nz = [0]                                  # (the bias gradient still needs the tile row)
+            for k, nt in enumerate(nz):
+                tiles.append([pi, mt * W_TILE, nt * W_TILE, 1 if k == 0 else 0, 0, 0, 0, 0])
+        woff, boff = flat, flat + shape[0] * shape[1]
+        flat = boff + shape[0]
+        offsets.append((woff, shape, boff, shape[0]))
+        stab.append([woff, shape[1], boff, map_off, map_off + Mrows, 0, 0, 0])
+        maps += [np.asarray(rmap, dtype=np.int32), np.asarray(cmap, dtype=np.int32)]
+        map_off += Mrows + Ncols
+        lyr = sl["lin"][pi]
+        mask_parts += [(lyr.mask.cpu().numpy() != 0).astype(np.uint8).reshape(-1), np.ones(shape[0], dtype=np.uint8)]
+    whdr = np.zeros(16, dtype=np.int32)
+    whdr[:2] = [len(tiles), len(probs)]
+    wtable = np.concatenate([whdr, np.asarray(ptab, dtype=np.int32).reshape(-1), np.asarray(tiles, dtype=np.int32).reshape(-1)])
+    stable = np.concatenate([np.asarray(stab, dtype=np.int32).reshape(-1)] + maps).astype(np.int32)
+    mask = np.concatenate(mask_parts)
+    assert mask.size == flat and flat < 2 ** 31
+    return dict(blob=blob, table=table, wtable=wtable.astype(np.int32), stable=stable, mask=mask, offsets=offsets, nflat=flat,
+                ntiles=len(tiles), Mp=Mp, Dx=Dx, Hp=Hp, NB=NB, mult=mult)

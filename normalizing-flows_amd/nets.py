@@ -511,13 +511,37 @@ class MADE(nn.Module):
             cache = caches[bool(spline)] = (key, packed)
         return cache[1]
 
-    def forward(self, inputs, context=None):
-        if (context is None and inputs.dim() == 2 and inputs.dtype == torch.float32 and inputs.is_cuda
-                and not (torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters())))):
-            packed = self.packed_forward(inputs.device)      # nf_made_forward: the whole network as one launch
+    def packed_backward(self, device):
+        """Device copies of the backward tables (flows/made_pack.pack_made_backward), rebuilt when a parameter changes."""
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (str(device),)
+        cache = self.__dict__.get("_bwd_pack_cache")
+        if cache is None or cache[0] != key:
+            from .flows import made_pack
+            mult = self.final_layer.out_features // self.initial_layer.in_features
+            packed = made_pack.pack_made_backward(self, mult)
             if packed is not None:
+                for k in ("blob", "table", "wtable", "stable", "mask"):
+                    packed[k] = torch.from_numpy(packed[k]).to(device)
+            cache = self.__dict__["_bwd_pack_cache"] = (key, packed)
+        return cache[1]
+
+    def _linears(self):
+        return [self.initial_layer] + [l for b in self.blocks for l in b.linear_layers] + [self.final_layer]
+
+    def forward(self, inputs, context=None):
+        if context is None and inputs.dim() == 2 and inputs.dtype == torch.float32 and inputs.is_cuda:
+            from . import config
+            grad = torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters()))
+            packed = self.packed_forward(inputs.device) if (not grad or config.made_train) else None
+            if packed is not None and not grad:          # nf_made_forward: the whole network as one launch
                 from . import ops
                 return ops.made_forward(inputs, packed[0], packed[1], packed[2], packed[3])
+            if packed is not None:                       # under autograd: hand-written backward (csrc/made_bwd.hip)
+                bwd = self.packed_backward(inputs.device)
+                if bwd is not None:
+                    from . import autograd
+                    plist = [t for l in self._linears() for t in (l.weight, l.bias)]
+                    return autograd.MadeFn.apply(packed, bwd, inputs, *plist)
         outputs = self.initial_layer(self.preprocessing(inputs))
         if context is not None:
             outputs = outputs + self.context_layer(context)

@@ -893,6 +893,64 @@ def made_forward(x, blob, table, hidden_padded, mult):
     return params
 
 
+def made_forward_train(x, blob, table, hidden_padded, mult, num_blocks):
+    """MADE.forward under autograd (nf_made_forward_train): (params (B, mult D), save (2 NB + 1, Bp, Hp) pre-activations, bits
+    (Bp / 64, 2 NB, 2, 512) ReLU signs), Bp = B rounded up to 64 -- the operands of made_backward / made_wgrad."""
+    L.require_device(x, blob, table)
+    if x.dtype != torch.float32:
+        raise NotImplementedError("made_forward_train: float32 only")
+    B, D = x.shape
+    x = x.contiguous()
+    Bp = (B + 63) // 64 * 64
+    params = torch.empty(B, mult * D, dtype=x.dtype, device=x.device)
+    save = torch.empty(2 * num_blocks + 1, Bp, hidden_padded, dtype=x.dtype, device=x.device)
+    bits = torch.empty(max(Bp // 64, 1), 2 * num_blocks, 2, 512, dtype=torch.int32, device=x.device)
+    rc = L.lib().nf_made_forward_train(ptr(x), ptr(params), ptr(save), ptr(bits), ptr(blob), ptr(table), i64(B), i32(D),
+                                       i32(hidden_padded), i32(mult), L.stream())
+    L.check(rc, "nf_made_forward_train")
+    return params, save, bits
+
+
+def made_backward(g_params, bits, blob, table, D, hidden_padded, mult, num_blocks):
+    """The input-gradient chain of MADE (nf_made_backward): g_x (B, D) and every layer's output gradient G (2 NB + 1, Bp, Hp)."""
+    L.require_device(g_params, bits, blob, table)
+    B = g_params.shape[0]
+    g_params = g_params.contiguous()
+    Bp = (B + 63) // 64 * 64
+    gx = torch.empty(B, D, dtype=g_params.dtype, device=g_params.device)
+    G = torch.empty(2 * num_blocks + 1, Bp, hidden_padded, dtype=g_params.dtype, device=g_params.device)
+    rc = L.lib().nf_made_backward(ptr(g_params), ptr(bits), ptr(gx), ptr(G), ptr(blob), ptr(table), i64(B), i32(D),
+                                  i32(hidden_padded), i32(mult), L.stream())
+    L.check(rc, "nf_made_backward")
+    return gx, G
+
+
+def _pad_rows_cols(t, rows, cols):
+    if t.shape[0] == rows and t.shape[1] == cols:
+        return t.contiguous()
+    return torch.nn.functional.pad(t, (0, cols - t.shape[1], 0, rows - t.shape[0])).contiguous()
+
+
+def made_wgrad(g_params, x, G, save, wtable, stable, mask, ntiles, nflat, Mp, Dx):
+    """Every weight / bias gradient of the MADE (nf_made_wgrad): the flat vector in flows/made_pack.pack_made_backward's layout,
+    masked entries zero."""
+    L.require_device(g_params, x, G, save, wtable, stable, mask)
+    B = g_params.shape[0]
+    Bp = G.shape[1]
+    gp_pad = _pad_rows_cols(g_params, Bp, Mp)
+    x_pad = _pad_rows_cols(x, Bp, Dx)
+    grads = torch.zeros(nflat, dtype=torch.float32, device=x.device)
+    lib = L.lib()
+    n = int(lib.nf_made_wgrad_scratch_floats(i64(B), i32(ntiles)))
+    if n < 0:
+        L.check(n, "nf_made_wgrad_scratch_floats")
+    part = torch.empty(max(n, 1), dtype=torch.float32, device=x.device)
+    rc = lib.nf_made_wgrad(ptr(gp_pad), ptr(x_pad), ptr(G), ptr(save), ptr(grads), ptr(mask), ptr(part), ptr(wtable), ptr(stable),
+                           i32(ntiles), i64(B), L.stream())
+    L.check(rc, "nf_made_wgrad")
+    return grads
+
+
 def maf_inverse(z, blob, table, hidden_padded, logdet=None, acc=None, num_blocks=2):
     """autoregressive.py:29-38 + :114-128 in one pass; blob/table from flows/maf_pack.pack_made.  config.maf_halves (default):
     nf_maf_inverse_h (32 samples per wave, 1..3 residual blocks); otherwise round 2's nf_maf_inverse (two blocks only)."""
