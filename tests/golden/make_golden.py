@@ -466,6 +466,43 @@ def gen_nsf_wide():
         npz("model_nsf_wide_d%d_h%d" % (D, H), **out)
 
 
+def gen_made_train():
+    """Reference autograd through the single-pass direction of the autoregressive layers at widths the one-launch MADE kernels are
+    built for (affine/autoregressive.py:24-27, neural_spline/autoregressive.py:94-134 over nets/made.py:296-304): loss = sum(z * cz)
+    + sum(log_det * cl), float32 and float64 legs.  Weights by seeded construction (not stored); of every parameter gradient a strided
+    sample (every STRIDE-th element of the flattened tensor) plus its sum and absolute sum."""
+    STRIDE = 37
+    cases = (("grad_maf_d128_h512", lambda: nf.flows.MaskedAffineAutoregressive(128, 512, num_blocks=2), 128, 1128, 0.05, 96,
+              "forward"),
+             ("grad_arnsf_d32_h64", lambda: nf.flows.AutoregressiveRationalQuadraticSpline(32, 2, 64, num_bins=8, tail_bound=3,
+                                                                                           init_identity=False), 32, 2032, 0.2, 70,
+              "inverse"))
+    for tag, make, D, seed, sigma, B, direction in cases:
+        out = {}
+        for dt, leg in ((torch.float32, "f32"), (torch.float64, "f64")):
+            torch.manual_seed(seed)
+            layer = make()
+            perturb(layer, sigma, 8)
+            layer = layer.to(dt)
+            g = torch.Generator().manual_seed(seed + 1)
+            x = (1.3 * torch.randn(B, D, generator=g)).to(dt)
+            cz = torch.randn(x.shape, generator=g).to(dt)
+            cl = torch.randn(B, generator=g).to(dt)
+            xx = x.clone().requires_grad_(True)
+            z, ld = getattr(layer, direction)(xx)
+            ((z * cz).sum() + (ld * cl).sum()).backward()
+            out.update({"z_" + leg: z.detach(), "ld_" + leg: ld.detach(), "gx_" + leg: xx.grad})
+            for k, p_ in layer.named_parameters():
+                gflat = p_.grad.reshape(-1)
+                key = k.replace(".", "__")
+                out["g_%s__%s" % (leg, key)] = gflat[::STRIDE].clone()
+                out["chk_%s__%s" % (leg, key)] = torch.tensor([float(gflat.double().sum()), float(gflat.double().abs().sum())],
+                                                              dtype=torch.float64)
+            if dt == torch.float32:
+                out.update(x=x, cz=cz, cl=cl)
+        npz(tag, stride=np.array(STRIDE), **out)
+
+
 def gen_maf():
     """MaskedAffineAutoregressive (affine/autoregressive.py): forward = one MADE pass, inverse = D passes."""
     for d, hidden, B in ((20, 40, 9), (128, 512, 4)):
@@ -1023,6 +1060,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "image_coupling":
         gen_image_coupling()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "made_train":
+        gen_made_train()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "nsf_wide":
         gen_nsf_wide()
         sys.exit(0)
@@ -1109,3 +1149,4 @@ if __name__ == "__main__":
     gen_maf_model_full()
     gen_train_c2_w64h128()
     gen_nsf_wide()
+    gen_made_train()

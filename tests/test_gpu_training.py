@@ -428,11 +428,14 @@ def test_realnvp_training_step_vs_reference(nfa):
     _check_grads(m, g, min_checked=30)
 
 
-def test_maf_gradients_vs_reference_autograd(nfa):
-    """MaskedAffineAutoregressive, both directions (inverse = the D-pass loop under autograd)."""
+def test_maf_gradients_vs_reference_autograd(nfa, monkeypatch):
+    """MaskedAffineAutoregressive, both directions (inverse = the D-pass loop under autograd); every MADE pass through the
+    hand-written forward / backward kernels (1 single-pass call + 5 passes of the loop)."""
     g = load_golden("grad_maf_d5")
     layer = load_layer(nfa.flows.MaskedAffineAutoregressive(5, 12, num_blocks=2), golden_state(g), torch.float32)
+    calls = _spy_made(monkeypatch)
     check_layer_grads(layer, g, rtol=2e-3, atol=2e-4)
+    assert calls == {"fwd": 6, "bwd": 6, "wgrad": 6}, calls
 
 
 def test_arnsf_gradients_vs_reference_autograd(nfa):
@@ -1153,3 +1156,155 @@ def test_utils_splines_entry_points_vs_reference(nfa, K):
         sp.rational_quadratic_spline(T(g["x01"]), w, h, T(g["d_none"]), min_bin_width=0.2)
     knots = torch.tensor([0.0, 1.0, 2.0], device=DEV)
     assert sp.searchsorted(knots, torch.tensor([0.5, 2.0, 1.0], device=DEV)).tolist() == [0, 1, 1] and float(knots[-1]) == 2.0
+
+
+# ---- MADE under autograd on the hand-written kernels (csrc/made_fwd.hip EPI 3, csrc/made_bwd.hip) --------------------------------------
+def _spy_made(monkeypatch):
+    from normflows_amd import ops
+    calls = {"fwd": 0, "bwd": 0, "wgrad": 0}
+    for key, name in (("fwd", "made_forward_train"), ("bwd", "made_backward"), ("wgrad", "made_wgrad")):
+        real = getattr(ops, name)
+        monkeypatch.setattr(ops, name, (lambda real, key: lambda *a, **k: (calls.__setitem__(key, calls[key] + 1), real(*a, **k))[1])(
+            real, key))
+    return calls
+
+
+def _made_grads(made, x, gp):
+    made.zero_grad(set_to_none=True)
+    x = x.clone().requires_grad_(True)
+    out = made(x)
+    out.backward(gp.to(out.dtype))
+    return out.detach(), x.grad, [p.grad.clone() for p in made.parameters()]
+
+
+@pytest.mark.parametrize("D,H,NB,mult,B", [(20, 40, 2, 2, 130), (6, 16, 2, 23, 70), (33, 300, 1, 3, 65), (5, 7, 3, 2, 1),
+                                           (128, 512, 2, 2, 300), (128, 512, 2, 23, 64), (64, 256, 2, 2, 1000), (96, 400, 3, 5, 257),
+                                           (2, 3, 1, 1, 64), (128, 257, 1, 2, 129)])
+def test_made_training_kernels_vs_autograd(nfa, monkeypatch, D, H, NB, mult, B):
+    """MADE.forward under autograd (nets/made.py:296-304 inside core.py:87-102): nf_made_forward_train + nf_made_backward +
+    nf_made_wgrad against torch autograd through library GEMMs on the same module in float64 (2e-5 of each tensor's scale; measured
+    ~1e-6, the float32 library path's own error) -- output, input gradient, every weight / bias gradient (masked entries exactly zero);
+    ragged batches, padded hidden widths, 1..3 blocks, mult D beyond one LDS chunk; the three kernels ran (spy); deterministic."""
+    import copy
+    torch.manual_seed(D * 1000 + H)
+    made = nfa.nets.MADE(D, H, num_blocks=NB, output_multiplier=mult)
+    with torch.no_grad():
+        for p in made.parameters():
+            p.add_(0.2 * torch.randn_like(p))
+    made = made.to(DEV)
+    x = torch.randn(B, D, device=DEV)
+    gp = torch.randn(B, mult * D, device=DEV)
+    calls = _spy_made(monkeypatch)
+    o1, gx1, g1 = _made_grads(made, x, gp)
+    assert calls == {"fwd": 1, "bwd": 1, "wgrad": 1}, calls
+    o1b, gx1b, g1b = _made_grads(made, x, gp)
+    assert torch.equal(o1, o1b) and torch.equal(gx1, gx1b) and all(torch.equal(a, b) for a, b in zip(g1, g1b))
+    o2, gx2, g2 = _made_grads(copy.deepcopy(made).double(), x.double(), gp.double())
+    assert calls["fwd"] == 2                                   # (the float64 module took torch's path)
+
+    def rel(a, b):
+        return float((a.double() - b).abs().max() / (b.abs().max() + 1e-30))
+    assert rel(o1, o2) < 2e-5 and rel(gx1, gx2) < 2e-5, (rel(o1, o2), rel(gx1, gx2))
+    for (name, p), a, b in zip(made.named_parameters(), g1, g2):
+        assert rel(a, b) < 2e-5, (name, rel(a, b))
+    for lin in made._linears():                                # the reference's weight.grad is zero under the mask (:80-81)
+        assert float((lin.weight.grad * (1 - lin.mask)).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("tag,direction", [("grad_maf_d128_h512", "forward"), ("grad_arnsf_d32_h64", "inverse")])
+def test_autoregressive_layers_training_vs_reference_autograd(nfa, monkeypatch, tag, direction):
+    """The single-pass direction of the autoregressive layers under autograd against the REFERENCE's autograd at kernel-sized widths
+    (tests/golden/grad_maf_d128_h512.npz: MaskedAffineAutoregressive(128, 512), BASELINE configs[4]'s layer, affine/autoregressive.py:
+    24-27; grad_arnsf_d32_h64.npz: AutoregressiveRationalQuadraticSpline(32, 2, 64).inverse = the density direction, wrapper.py:241-245):
+    weights rebuilt from the seed; outputs, input gradient and a strided sample + sum of every parameter gradient: 1e-3 of scale vs the
+    float32 leg and no further from the float64 leg than 4 x the reference's own float32 leg (q90); the MADE kernels ran (spy)."""
+    g = load_golden(tag)
+    if tag.startswith("grad_maf"):
+        torch.manual_seed(1128)
+        layer = nfa.flows.MaskedAffineAutoregressive(128, 512, num_blocks=2)
+        sigma = 0.05
+    else:
+        torch.manual_seed(2032)
+        layer = nfa.flows.AutoregressiveRationalQuadraticSpline(32, 2, 64, num_bins=8, tail_bound=3, init_identity=False)
+        sigma = 0.2
+    gen = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.add_(sigma * torch.randn(p.shape, generator=gen, dtype=p.dtype))
+    layer = layer.to(DEV)
+    calls = _spy_made(monkeypatch)
+    x = T(g["x"]).requires_grad_(True)
+    z, ld = getattr(layer, direction)(x)
+    ((z * T(g["cz"])).sum() + (ld * T(g["cl"])).sum()).backward()
+    assert calls == {"fwd": 1, "bwd": 1, "wgrad": 1}, calls
+    stride = int(g["stride"])
+
+    def err(a, ref):
+        return np.abs(a.astype(np.float64) - ref) / max(1.0, float(np.abs(ref).max()))
+    ours = {"z": N(z), "ld": N(ld), "gx": N(x.grad)}
+    own, got = [], []
+    for k, a in ours.items():
+        assert err(a, g[k + "_f32"]).max() < 1e-3, (k, err(a, g[k + "_f32"]).max())
+        own.append(err(g[k + "_f32"], g[k + "_f64"]).max())
+        got.append(err(a, g[k + "_f64"]).max())
+    for k, p in layer.named_parameters():
+        key = k.replace(".", "__")
+        flat = N(p.grad).reshape(-1)
+        ref32, ref64 = g["g_f32__" + key], g["g_f64__" + key]
+        assert err(flat[::stride], ref32).max() < 1e-3, (k, err(flat[::stride], ref32).max())
+        chk = g["chk_f64__" + key]
+        assert abs(float(flat.astype(np.float64).sum()) - chk[0]) < 1e-4 * max(1.0, chk[1]), k
+        own.append(err(ref32, ref64).max())
+        got.append(err(flat[::stride], ref64).max())
+    assert np.quantile(got, 0.9) <= 4 * max(np.quantile(own, 0.9), 1e-7), (np.quantile(got, 0.9), np.quantile(own, 0.9))
+
+
+def test_made_training_full_batch_vs_library_path(nfa):
+    """BASELINE configs[4]'s layer at B = 65 536 (a multiple of the 64-row tiles and the weight-gradient chunks): hand-written path vs
+    torch autograd through library GEMMs (float32 both: two different summation orders over 65 536 rows), outputs to 1e-4, every
+    gradient to 1e-3 of its scale."""
+    torch.manual_seed(5)
+    layer = nfa.flows.MaskedAffineAutoregressive(128, 512, num_blocks=2)
+    gen = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.add_(0.02 * torch.randn(p.shape, generator=gen))
+    layer = layer.to(DEV)
+    x0 = torch.randn(65536, 128, generator=torch.Generator().manual_seed(1)).to(DEV)
+    res = []
+    for mode in (True, False):
+        nfa.config.set_made_train(mode)
+        try:
+            layer.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            z, ld = layer.forward(x)
+            (z.square().mean() - ld.mean()).backward()
+            res.append((z.detach(), x.grad, [p.grad.clone() for p in layer.parameters()]))
+        finally:
+            nfa.config.set_made_train(True)
+
+    def rel(a, b):
+        return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    assert rel(res[0][0], res[1][0]) < 1e-4 and rel(res[0][1], res[1][1]) < 1e-3, (rel(res[0][0], res[1][0]), rel(res[0][1], res[1][1]))
+    for (name, _), a, b in zip(layer.named_parameters(), res[0][2], res[1][2]):
+        assert rel(a, b) < 1e-3, (name, rel(a, b))
+
+
+def test_made_backward_uses_the_weights_of_its_forward(nfa):
+    """An in-place parameter update between forward and backward (an optimizer step on retained graphs): the backward still
+    differentiates the forward that ran -- the packs held by the graph are the forward-time ones, new ones are built for later calls."""
+    torch.manual_seed(3)
+    made = nfa.nets.MADE(12, 40, num_blocks=2, output_multiplier=2).to(DEV)
+    x = torch.randn(70, 12, device=DEV)
+    gp = torch.randn(70, 24, device=DEV)
+    ref = _made_grads(made, x, gp)
+    made.zero_grad(set_to_none=True)
+    xg = x.clone().requires_grad_(True)
+    out = made(xg)
+    with torch.no_grad():
+        for p in made.parameters():
+            p.add_(0.5)
+    out.backward(gp)
+    assert torch.equal(xg.grad, ref[1]) and all(torch.equal(p.grad, r) for p, r in zip(made.parameters(), ref[2]))
+    later = _made_grads(made, x, gp)                           # the next call sees the updated weights
+    assert not torch.equal(later[0], ref[0])

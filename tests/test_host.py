@@ -703,6 +703,44 @@ def test_made_forward_pack_matches_dense_made(D, H, NB, mult):
         assert wpw.max() == wpw.min()               # ... and every wave of the workgroup gets the same share of it
 
 
+@pytest.mark.parametrize("D,H,NB,mult,B", [(128, 512, 2, 2, 3), (20, 40, 2, 2, 7), (6, 16, 2, 23, 7), (33, 300, 1, 3, 5), (5, 7, 3, 2, 4)])
+def test_made_backward_pack_matches_autograd(D, H, NB, mult, B):
+    """flows/made_pack.pack_made_backward + the kernels' schedules (tests/made_bwd_emulator.py restates made_bwd.hip in numpy: the
+    input-gradient chain over the per-wave streams of TRANSPOSED masked weights with k-group ranges, the weight-gradient tile list,
+    the reduction's row / column maps and mask bytes) reproduce torch autograd through the dense masked MADE in float64
+    (nets/made.py:296-304 under core.py:87-102): g_x, every weight gradient (zero under the mask) and bias gradient."""
+    import copy
+    from normflows_amd import nets
+    from normflows_amd.flows import made_pack
+    import made_bwd_emulator as E
+    torch.manual_seed(D + H)
+    made = nets.MADE(features=D, hidden_features=H, num_blocks=NB, output_multiplier=mult)
+    with torch.no_grad():
+        for p in made.parameters():
+            p.add_(0.3 * torch.randn_like(p))
+    pack = made_pack.pack_made_backward(made, mult)
+    sl = made_pack._slot_layers(made, mult)
+    assert pack["table"][3] in (256, 512) and pack["nflat"] == sum(p.numel() for p in made.parameters())
+    md = copy.deepcopy(made).double()
+    x = torch.randn(B, D, dtype=torch.float64, requires_grad=True)
+    out = md(x)
+    gp = torch.randn_like(out)
+    out.backward(gp)
+    S, prm = E.slot_forward(sl["layers"], NB, x.detach().numpy(), sl["Dp"])
+    assert np.allclose(prm[:, :mult * D], out.detach().numpy(), atol=1e-9)
+    gx, G = E.emulate_chain(pack, gp.numpy(), S)
+    assert np.abs(gx - x.grad.numpy()).max() < 1e-9 * max(1.0, float(x.grad.abs().max()))
+    flat = E.emulate_wgrad(pack, gp.numpy(), x.detach().numpy(), G, S)
+    for (woff, shape, boff, n), lin in zip(pack["offsets"], md._linears()):
+        gw = flat[woff:woff + shape[0] * shape[1]].reshape(shape)
+        assert np.abs(gw - lin.weight.grad.numpy()).max() < 1e-9 * max(1.0, float(lin.weight.grad.abs().max()))
+        assert np.abs(flat[boff:boff + n] - lin.bias.grad.numpy()).max() < 1e-9 * max(1.0, float(lin.bias.grad.abs().max()))
+    if (D, H) == (128, 512):                                  # BASELINE configs[4]: 50 of the 80 dense 128 x 128 tiles
+        assert pack["ntiles"] == 50
+        nkg = pack["table"][32:32 + 8 * 11 * 4].reshape(8, 11, 4)[:, :, 0]
+        assert (nkg[:, :10].sum(axis=1) == nkg[0, :10].sum()).all()      # equal MFMA work per wave in the hidden products
+
+
 def test_made_forward_pack_rejects_unsupported():
     from normflows_amd import nets
     from normflows_amd.flows import made_pack
