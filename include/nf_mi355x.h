@@ -467,6 +467,10 @@ int nf_realnvp_chain(const void *z, void *y, void *logdet, const void *blob, int
  */
 int nf_maf_affine(const void *x, const void *params, void *y, void *logdet, int64_t B, int D, int direction, int acc,
                   int dtype, nf_stream_t stream);
+/* Its backward under autograd (core.py:87-102): g_x (B, D), g_params (B, D, 2) from the cotangents gy (B, D) and gld (B); either
+ * cotangent may be NULL (zero). */
+int nf_maf_affine_bwd(const void *x, const void *params, const void *gy, const void *gld, void *gx, void *gparams, int64_t B, int D,
+                      int direction, int dtype, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * CoupledRationalQuadraticSpline in ONE launch for the shapes beyond nf_rqs_fused's (D <= 64, hidden <= 128): up to 128 features,

@@ -769,27 +769,18 @@ class MadeFn(torch.autograd.Function):
 
 
 class MafAffineFn(torch.autograd.Function):
-    """nf_maf_affine (affine/autoregressive.py:98-128) on given MADE output `params` (B, 2D)."""
+    """nf_maf_affine (affine/autoregressive.py:98-128) on given MADE output `params` (B, 2D); backward = nf_maf_affine_bwd."""
 
     @staticmethod
     def forward(ctx, x, params, direction):
         y, ld = ops.maf_affine(x, params.contiguous(), direction)
         ctx.save_for_backward(x, params)
         ctx.direction = direction
+        ctx.set_materialize_grads(False)
         return y, ld
 
     @staticmethod
     def backward(ctx, gy, gld):
         x, params = ctx.saved_tensors
-        direction = ctx.direction
-
-        def formula(x_, p_):
-            pr = p_.view(x_.shape[0], x_.shape[1], 2)
-            scale = torch.sigmoid(pr[..., 0] + 2.0) + 1e-3
-            shift = pr[..., 1]
-            if direction == 0:
-                return scale * x_ + shift, torch.log(scale).sum(1)
-            return (x_ - shift) / scale, -torch.log(scale).sum(1)
-
-        gx, gp = _vjp(formula, (x, params), (gy, gld))
+        gx, gp = ops.maf_affine_bwd(x, params, gy, gld, ctx.direction)
         return gx, gp, None

@@ -321,6 +321,39 @@ inv1x1_wgrad_reduce_kernel(const T *__restrict__ partial, const T *__restrict__ 
     }
 }
 
+
+// ---- MaskedAffineAutoregressive element-wise transform (affine/autoregressive.py:98-128; forward: affine.hip maf_affine_kernel) -------
+//   scale = sigmoid(u + 2) + 1e-3 (u = params[.., 0], shift = params[.., 1])
+//   direction 0: y = scale x + shift, ld = +sum log scale;   direction 1: y = (x - shift) / scale, ld = -sum log scale
+// one element per thread-iteration: g_x, g_params (B, D, 2) from the cotangents gy (B, D) and gld (B), either may be NULL (= 0).
+template <typename T>
+__global__ void __launch_bounds__(256)
+maf_affine_bwd_kernel(const T *__restrict__ x, const T *__restrict__ params, const T *__restrict__ gy, const T *__restrict__ gld,
+                      T *__restrict__ gx, T *__restrict__ gparams, int64_t B, int D, int direction) {
+    const int64_t N = B * D;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < N; o += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = o / D;
+        const T u = params[2 * o], sh = params[2 * o + 1];
+        const T sg = sigmoid(u + T(2));
+        const T scale = sg + T(1e-3);
+        const T g = gy ? gy[o] : T(0), gl = gld ? gld[r] : T(0);
+        const T xv = x[o];
+        T gscale, gshift;
+        if (direction == 0) {
+            gx[o] = g * scale;
+            gshift = g;
+            gscale = g * xv + gl / scale;
+        } else {
+            const T inv = T(1) / scale;
+            gx[o] = g * inv;
+            gshift = -g * inv;
+            gscale = -(g * (xv - sh) * inv + gl) * inv;
+        }
+        gparams[2 * o] = gscale * sg * (T(1) - sg);
+        gparams[2 * o + 1] = gshift;
+    }
+}
+
 }  // namespace nf
 
 using namespace nf;
@@ -448,6 +481,24 @@ extern "C" int nf_inv1x1_wgrad(const void *z, const void *gy, const void *gld, v
                 hipLaunchKernelGGL(inv1x1_wgrad_reduce_kernel<double>, dim3((C * C + 15) / 16), dim3(256), 0, st,
                                    (const double *)scratch, (const double *)gld, (double *)gW, (double *)gldu, nparts, C * C, B,
                                    HW));
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// Backward of nf_maf_affine: g_x (B, D) and g_params (B, D, 2) from the cotangents gy (B, D) / gld (B) (either may be NULL).
+extern "C" int nf_maf_affine_bwd(const void *x, const void *params, const void *gy, const void *gld, void *gx, void *gparams,
+                                 int64_t B, int D, int direction, int dtype, nf_stream_t stream) {
+    if (B < 0 || D < 1 || (direction != 0 && direction != 1)) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!x || !params || !gx || !gparams) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_for(B * D, 256);
+    NF_DISPATCH(dtype,
+                hipLaunchKernelGGL(maf_affine_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, (const float *)params,
+                                   (const float *)gy, (const float *)gld, (float *)gx, (float *)gparams, B, D, direction),
+                hipLaunchKernelGGL(maf_affine_bwd_kernel<double>, dim3(grid), dim3(256), 0, st, (const double *)x,
+                                   (const double *)params, (const double *)gy, (const double *)gld, (double *)gx, (double *)gparams,
+                                   B, D, direction));
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

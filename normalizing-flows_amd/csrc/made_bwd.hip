@@ -18,6 +18,7 @@
 //    issue the MFMAs (the design of wgrad.hip's wgrad_ring_kernel, with row strides and per-problem operands); split over row chunks.
 // 3. made_wgrad_reduce_kernel: the chunks' partial tiles summed in a fixed order (deterministic) and scattered from slot space to
 //    the parameters' own layout, masked entries left zero.
+#include <cstdlib>
 #include "mlp_tile.hpp"
 
 namespace nf {
@@ -178,20 +179,22 @@ constexpr int MW_T = 128, MW_KS = 16, MW_NR = 3, MW_NT = 64 * 8, MW_PART = MW_T 
 
 __global__ void __launch_bounds__(MW_NT, 4)
 made_wgrad_kernel(const float *__restrict__ b0p, const float *__restrict__ b1p, const float *__restrict__ b2p,
-                  const float *__restrict__ b3p, float *__restrict__ part, const int *__restrict__ wt, int chunk_rows, int64_t Bp) {
+                  const float *__restrict__ b3p, float *__restrict__ part, const int *__restrict__ wt, int chunk_rows, int64_t Bp,
+                  int tile_major) {
     typedef __attribute__((address_space(3))) void *lds_ptr;
     __shared__ __attribute__((aligned(16))) float ring[MW_NR][2][MW_KS][MW_T];     // [slot][dY | X][row][128] = 48 KB
     const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntl = wt[0], npr = wt[1];
-    const int *tl = wt + 16 + 8 * npr + 8 * blockIdx.y;
+    const int bt = tile_major ? blockIdx.x : blockIdx.y, bc = tile_major ? blockIdx.y : blockIdx.x;
+    const int *tl = wt + 16 + 8 * npr + 8 * bt;
     const int *pr = wt + 16 + 8 * tl[0];
     const int m0 = tl[1], n0 = tl[2], want_bias = tl[3];
     auto base = [&](int k) { return k == 0 ? b0p : k == 1 ? b1p : k == 2 ? b2p : b3p; };
     const int ldY = pr[2], ldX = pr[5], x_relu = pr[6];
     const float *dY = base(pr[0]) + (size_t)pr[1] * Bp * ldY + m0;
     const float *X = base(pr[3]) + (size_t)pr[4] * Bp * ldX + n0;
-    const int64_t r_begin = (int64_t)blockIdx.x * chunk_rows;
+    const int64_t r_begin = (int64_t)bc * chunk_rows;
     int64_t r_end = r_begin + chunk_rows;
     if (r_end > Bp) r_end = Bp;
     const int nsteps = (int)((r_end - r_begin) / MW_KS);         // chunk_rows and Bp are multiples of 16
@@ -236,7 +239,7 @@ made_wgrad_kernel(const float *__restrict__ b0p, const float *__restrict__ b1p, 
             acc11 = MW_MFMA(a1, x1, acc11);
         }
     }
-    float *out = part + ((size_t)blockIdx.x * ntl + blockIdx.y) * MW_PART;
+    float *out = part + ((size_t)bc * ntl + bt) * MW_PART;
 #pragma unroll
     for (int s_ = 0; s_ < 2; ++s_) {
 #pragma unroll
@@ -321,8 +324,16 @@ extern "C" int nf_made_backward(const void *g_params, const void *bits, void *g_
     return nf::made_bwd_launch<2>(g_params, bits, g_x, G, blob, table, B, st);
 }
 
+static int made_env(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 static int made_wgrad_chunk_rows(int64_t Bp, int ntiles) {
-    int64_t want = (768 + ntiles - 1) / ntiles;                 // ~ three workgroups per CU
+    // measured at config 5's layer (50 tiles, B = 65 536; tools/scripts/mw_sweep.sh): 768 / 1024 / 1536 / 2048 / 3072 workgroups
+    // = 1.19 / 1.12 / 0.98 / 1.07 / 0.99 ms for this launch + 18 / 24 / 33 / 40 / 55 us for the reduction: three rounds of 512
+    static const int slots = made_env("NF_MW_SLOTS", 1536);
+    int64_t want = (slots + ntiles - 1) / ntiles;
     if (want < 1) want = 1;
     int64_t rows = (Bp + want - 1) / want;
     rows = (rows + 63) / 64 * 64;
@@ -350,8 +361,11 @@ extern "C" int nf_made_wgrad(const void *gp_pad, const void *x_pad, const void *
     const int64_t Bp = (B + 63) / 64 * 64;
     const int rows = made_wgrad_chunk_rows(Bp, ntiles);
     const int chunks = (int)((Bp + rows - 1) / rows);
-    hipLaunchKernelGGL(nf::made_wgrad_kernel, dim3((unsigned)chunks, (unsigned)ntiles), dim3(nf::MW_NT), 0, st, (const float *)gp_pad,
-                       (const float *)x_pad, (const float *)G, (const float *)save, (float *)part, (const int *)wtable, rows, Bp);
+    // tile-major: the workgroups in flight together work on the same row chunk (its operands are shared through L2 / MALL)
+    static const int tile_major = made_env("NF_MW_TILE_MAJOR", 1);
+    const dim3 grid = tile_major ? dim3((unsigned)ntiles, (unsigned)chunks) : dim3((unsigned)chunks, (unsigned)ntiles);
+    hipLaunchKernelGGL(nf::made_wgrad_kernel, grid, dim3(nf::MW_NT), 0, st, (const float *)gp_pad, (const float *)x_pad,
+                       (const float *)G, (const float *)save, (float *)part, (const int *)wtable, rows, Bp, tile_major);
     NF_CHECK_LAUNCH();
     hipLaunchKernelGGL(nf::made_wgrad_reduce_kernel, dim3(16, (unsigned)ntiles), dim3(256), 0, st, (const float *)part, (float *)grads,
                        (const unsigned char *)mask, (const int *)wtable, (const int *)stable, chunks);

@@ -749,6 +749,22 @@ def maf_affine(x, params, direction, logdet=None, acc=None, want_logdet=True):
     return y, logdet
 
 
+def maf_affine_bwd(x, params, gy, gld, direction):
+    """Backward of maf_affine (nf_maf_affine_bwd): (g_x (B, D), g_params shaped like params); gy / gld may be None."""
+    L.require_device(x, params)
+    x = x.contiguous()
+    params = params.contiguous()
+    B, D = x.shape
+    gx = torch.empty_like(x)
+    gparams = torch.empty_like(params)
+    gy = None if gy is None else gy.contiguous()
+    gld = None if gld is None else gld.contiguous()
+    rc = L.lib().nf_maf_affine_bwd(ptr(x), ptr(params), ptr(gy), ptr(gld), ptr(gx), ptr(gparams), i64(B), i32(D), i32(direction),
+                                   i32(L.dtype_code(x)), L.stream())
+    L.check(rc, "nf_maf_affine_bwd")
+    return gx, gparams
+
+
 def rqs_fused_chain(x, blobs, parities, hidden, num_blocks, K, direction, logdet=None, acc=None, tail_bound=3.0,
                     min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, fuse_lu=True, live_d=None):
     """Up to 64 fused layers of identical shape in ONE persistent launch (nf_rqs_fused_chain).  `blobs` / `parities`

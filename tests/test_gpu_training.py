@@ -1308,3 +1308,37 @@ def test_made_backward_uses_the_weights_of_its_forward(nfa):
     assert torch.equal(xg.grad, ref[1]) and all(torch.equal(p.grad, r) for p, r in zip(made.parameters(), ref[2]))
     later = _made_grads(made, x, gp)                           # the next call sees the updated weights
     assert not torch.equal(later[0], ref[0])
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("direction", [0, 1])
+def test_maf_affine_backward_kernel_vs_autograd(nfa, dt, direction):
+    """nf_maf_affine_bwd against torch autograd through the formula of affine/autoregressive.py:98-128, both directions, with either
+    cotangent absent (the D-pass inverse uses the outputs of intermediate passes without their log-dets)."""
+    from normflows_amd import autograd
+    g = torch.Generator().manual_seed(7)
+    B, D = 67, 13
+    x0 = torch.randn(B, D, generator=g).to(dt).to(DEV)
+    p0 = (1.5 * torch.randn(B, 2 * D, generator=g)).to(dt).to(DEV)
+    cz = torch.randn(B, D, generator=g).to(dt).to(DEV)
+    cl = torch.randn(B, generator=g).to(dt).to(DEV)
+
+    def formula(x_, p_):
+        pr = p_.view(B, D, 2)
+        scale = torch.sigmoid(pr[..., 0] + 2.0) + 1e-3
+        if direction == 0:
+            return scale * x_ + pr[..., 1], torch.log(scale).sum(1)
+        return (x_ - pr[..., 1]) / scale, -torch.log(scale).sum(1)
+    for use_z, use_l in ((True, True), (True, False), (False, True)):
+        res = []
+        for fn in (lambda a, b: autograd.MafAffineFn.apply(a, b, direction), formula):
+            x = x0.clone().requires_grad_(True)
+            p = p0.clone().requires_grad_(True)
+            z, ld = fn(x, p)
+            loss = (z * cz).sum() if use_z else 0.0
+            loss = loss + ((ld * cl).sum() if use_l else 0.0)
+            loss.backward()
+            res.append((z.detach(), ld.detach(), x.grad if x.grad is not None else torch.zeros_like(x), p.grad))
+        tol = 2e-5 if dt == torch.float32 else 1e-12
+        for a, b in zip(res[0], res[1]):
+            assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
