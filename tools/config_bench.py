@@ -112,11 +112,37 @@ def c5():
         return {"bound": "mfma", "achieved": flop / ms / 1e9, "peak": 157.3, "unit": "TFLOP/s", "frac": flop / ms / 1e9 / 157.3,
                 "flop_per_pass_masked": flop}
 
-    print("config 5 MAF 10 layers d=128 B=65536: inverse pass %.1f ms (%.0f samples/s), forward pass %.1f ms, round-trip max err %.2e"
-          % (dt * 1e3, 65536 / dt, dtf * 1e3, err))
+    # training step in the single-pass direction (core.py:167-180 under autograd: sample + log_q, a reverse-KLD-style loss, backward,
+    # Adam): MADE forward / input-gradient chain / weight gradients on the hand-written kernels (csrc/made_bwd.hip) vs torch autograd
+    # through library GEMMs on the pre-masked weights
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=True)
+    eps = torch.randn(65536, 128, device=dev)
+
+    def train_step():
+        opt.zero_grad(set_to_none=True)
+        zz, logq = eps, torch.zeros(65536, device=dev)
+        for f in m.flows:
+            zz, l_ = f(zz)
+            logq = logq - l_
+        (logq + 0.5 * (zz ** 2).sum(1)).mean().backward()
+        opt.step()
+    train_step()
+    dtt = timed(train_step, 3)
+    nfa.config.set_made_train(False)
+    try:
+        train_step()
+        dtl = timed(train_step, 2)
+    finally:
+        nfa.config.set_made_train(True)
+    print("config 5 MAF 10 layers d=128 B=65536: inverse pass %.1f ms (%.0f samples/s), forward pass %.1f ms, round-trip max err %.2e; "
+          "training step (single-pass direction) %.1f ms (library GEMMs: %.1f ms)" % (dt * 1e3, 65536 / dt, dtf * 1e3, err, dtt * 1e3,
+                                                                                    dtl * 1e3))
     return {"workload": "BASELINE configs[4]: 10 x MaskedAffineAutoregressive(128, hidden 512), batch 65536",
             "inverse_pass_ms": dt * 1e3, "forward_pass_ms": dtf * 1e3, "inverse_samples_per_s": 65536 / dt,
-            "round_trip_max_abs_err": err, "roofline_inverse_pass": roof(dt * 1e3), "roofline_forward_pass": roof(dtf * 1e3)}
+            "round_trip_max_abs_err": err, "roofline_inverse_pass": roof(dt * 1e3), "roofline_forward_pass": roof(dtf * 1e3),
+            "train_step_single_pass_ms": dtt * 1e3, "train_step_single_pass_library_gemm_ms": dtl * 1e3,
+            "roofline_train_step": {"bound": "mfma", "achieved": 3 * flop / dtt / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                                    "frac": 3 * flop / dtt / 157.3e12, "flop_per_step_masked": 3 * flop}}
 
 
 def wide():
