@@ -740,13 +740,15 @@ class MadeFn(torch.autograd.Function):
     nf_made_forward_train (the one-launch forward + saved pre-activations / ReLU signs), backward = nf_made_backward (input-gradient
     chain on the transposed masked weights) + nf_made_wgrad (all weight / bias gradients, one launch + a fixed-order reduction).
     `fwd` / `bwd`: the layer's packs as built at forward time (new tensors are built when a parameter changes, so the ones held here
-    stay what this graph's forward used); params = weight, bias of the initial layer, the blocks' linears, the final layer."""
+    stay what this graph's forward used); params = weight, bias of the initial layer, the blocks' linears, the final layer.
+    A plain ReLU ResidualNet (nets/resnet.py:53-104) is the same network without masks and runs through the same three kernels
+    (flows/made_pack.pack_resnet_forward / pack_resnet_backward)."""
 
     @staticmethod
     def forward(ctx, fwd, bwd, x, *params):
-        blob, table, hp, mult = fwd
+        blob, table, hp = fwd[:3]
         x = x.contiguous()
-        out, save, bits = ops.made_forward_train(x, blob, table, hp, mult, bwd["NB"])
+        out, save, bits = ops.made_forward_train(x, blob, table, hp, bwd["MD"], bwd["NB"])
         ctx.save_for_backward(x, save, bits)
         ctx.bwd = bwd
         ctx.shapes = [tuple(p.shape) for p in params]
@@ -757,7 +759,7 @@ class MadeFn(torch.autograd.Function):
         x, save, bits = ctx.saved_tensors
         bwd = ctx.bwd
         gout = gout.contiguous()
-        gx, G = ops.made_backward(gout, bits, bwd["blob"], bwd["table"], x.shape[1], bwd["Hp"], bwd["mult"], bwd["NB"])
+        gx, G = ops.made_backward(gout, bits, bwd["blob"], bwd["table"], x.shape[1], bwd["Hp"], bwd["NB"])
         grads = [None] * len(ctx.shapes)
         if any(ctx.needs_input_grad[3:]):
             flat = ops.made_wgrad(gout, x, G, save, bwd["wtable"], bwd["stable"], bwd["mask"], bwd["ntiles"], bwd["nflat"],

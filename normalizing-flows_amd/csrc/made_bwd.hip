@@ -36,8 +36,8 @@ made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits,
     float *xreg = lds + (size_t)HRB * 4 * 512;          // [Dp / 8][2][64][4]: the g_x tile on its way out
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int D = table[0], NB = table[5], mult = table[6], NC = table[7], nitems = table[10];
-    const int MD = mult * D;
+    const int D = table[0], NB = table[5], NC = table[7], nitems = table[10];
+    const int MD = table[12] ? table[12] : table[6] * D;       // row length of g_params
     const int *items = table + MF_HDR + w * nitems * 4;       // [nitems][nkg, rb, kg0, -]
     const float *stream = blob + table[16 + w];
     const int rbs[2] = {w, HRB - 1 - w};

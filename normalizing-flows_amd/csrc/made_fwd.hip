@@ -53,7 +53,8 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
     float *xreg = lds + (size_t)HRB * 4 * 512;          // [Dp / 8][2][64][4]
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int D = table[0], Dp = table[1], NB = table[5], mult = table[6], NFB = table[7], nrounds = table[8], nitems = table[10];
+    const int D = table[0], Dp = table[1], NB = table[5], NFB = table[7], nrounds = table[8], nitems = table[10];
+    const int MD = table[12] ? table[12] : table[6] * D;       // raw output row length: mult D for a MADE, out_features for a ResidualNet
     const int *items = table + MF_HDR + w * nitems * 2;       // [nitems][nkg, rb]
     const float *stream = blob + table[16 + w];
     const int rbs[2] = {w, HRB - 1 - w};                      // (the packer's wave_items: the hidden row-blocks of this wave)
@@ -222,15 +223,15 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
                     } else {
                         const int64_t r = row0 + 32 * s + n;
                         if (32 * s + n < nrows) {
-                            float *yp = y + r * ((int64_t)mult * D) + 32 * fb + 4 * hh;
+                            float *yp = y + r * (int64_t)MD + 32 * fb + 4 * hh;
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 const int c = 32 * fb + 8 * q + 4 * hh;
-                                if (((mult * D) & 3) == 0) {
-                                    if (c < mult * D) *reinterpret_cast<f32x4 *>(yp + 8 * q) = f32x4{o[0][4 * q], o[0][4 * q + 1], o[0][4 * q + 2], o[0][4 * q + 3]};
+                                if ((MD & 3) == 0) {
+                                    if (c < MD) *reinterpret_cast<f32x4 *>(yp + 8 * q) = f32x4{o[0][4 * q], o[0][4 * q + 1], o[0][4 * q + 2], o[0][4 * q + 3]};
                                 } else {
 #pragma unroll
-                                    for (int i = 0; i < 4; ++i) if (c + i < mult * D) yp[8 * q + i] = o[0][4 * q + i];
+                                    for (int i = 0; i < 4; ++i) if (c + i < MD) yp[8 * q + i] = o[0][4 * q + i];
                                 }
                             }
                         }

@@ -137,7 +137,44 @@ def _slot_layers(made, mult):
     for l in lin[1:]:
         layers.append(slots(l, slot_of, Hp, slot_of, Hp))
     layers.append(slots(fin, slot_of, Hp, np.arange(mult * D), NFB * ROWS))
-    return dict(D=D, H=H, NB=NB, Hp=Hp, NSB=NSB, Dp=Dp, NFB=NFB, order=order, slot_of=slot_of, layers=layers, lin=lin + [fin])
+    return dict(D=D, H=H, NB=NB, Hp=Hp, NSB=NSB, Dp=Dp, NFB=NFB, MD=mult * D, mult=mult, order=order, slot_of=slot_of,
+                layers=layers, masks=[l.mask.cpu().numpy() != 0 for l in lin + [fin]])
+
+
+def resnet_supported(net):
+    from .. import nets
+    if not isinstance(net, nets.ResidualNet) or not net.is_plain_relu():
+        return False
+    if len(net.blocks) < 1 or 2 * len(net.blocks) + 2 > MAX_LAYERS:
+        return False
+    D, H, MD = net.initial_layer.in_features, net.initial_layer.out_features, net.final_layer.out_features
+    return 2 <= D <= MAX_D and 1 <= H <= 512 and MD >= 1 and net.initial_layer.weight.dtype == torch.float32
+
+
+def _dense_layers(net):
+    """A ResidualNet (nets/resnet.py:53-104: the same layer structure as MADE without masks) as slot-space layers for the MADE
+    kernels: identity unit order, every mask all ones (no block is skipped), out_features = MD."""
+    if not resnet_supported(net):
+        return None
+    D, H, MD = net.initial_layer.in_features, net.initial_layer.out_features, net.final_layer.out_features
+    NB = len(net.blocks)
+    Hp = 256 if H <= 256 else 512
+    Dp = (D + 31) // 32 * 32
+    NFB = (MD + ROWS - 1) // ROWS
+    lin = [net.initial_layer] + [l for b in net.blocks for l in b.linear_layers] + [net.final_layer]
+    sizes = [(Hp, Dp)] + [(Hp, Hp)] * (2 * NB) + [(NFB * ROWS, Hp)]
+    layers = []
+    for l, (o, i) in zip(lin, sizes):
+        w = l.weight.detach().cpu().numpy().astype(np.float32)
+        W = np.zeros((o, i), dtype=np.float32)
+        M = np.zeros((o, i), dtype=bool)
+        Bv = np.zeros(o, dtype=np.float32)
+        W[:w.shape[0], :w.shape[1]] = w
+        M[:w.shape[0], :w.shape[1]] = True
+        Bv[:w.shape[0]] = l.bias.detach().cpu().numpy().astype(np.float32)
+        layers.append((W, M, Bv))
+    return dict(D=D, H=H, NB=NB, Hp=Hp, NSB=Hp // 256, Dp=Dp, NFB=NFB, MD=MD, mult=1, order=np.arange(H), slot_of=np.arange(H),
+                layers=layers, masks=[np.ones(tuple(l.weight.shape), dtype=bool) for l in lin])
 
 
 def pack_made_forward(made, mult=2, spline=False):
@@ -148,10 +185,20 @@ def pack_made_forward(made, mult=2, spline=False):
     sl = _slot_layers(made, mult)
     if sl is None:
         return None
-    D, H, NB, Hp, NSB, Dp, NFB, layers = (sl[k] for k in ("D", "H", "NB", "Hp", "NSB", "Dp", "NFB", "layers"))
-
     if spline:
+        D, H, NB, Hp, NSB, Dp, layers = (sl[k] for k in ("D", "H", "NB", "Hp", "NSB", "Dp", "layers"))
         return _pack_spline(layers, D, Dp, H, Hp, NSB, NB, mult)
+    return _pack_forward_from(sl)
+
+
+def pack_resnet_forward(net):
+    """The same blob / table for a ResidualNet (dense: no block skipped), hdr[12] = out_features; None outside the structure."""
+    sl = _dense_layers(net)
+    return None if sl is None else _pack_forward_from(sl)
+
+
+def _pack_forward_from(sl):
+    D, H, NB, Hp, NSB, Dp, NFB, layers, mult = (sl[k] for k in ("D", "H", "NB", "Hp", "NSB", "Dp", "NFB", "layers", "mult"))
     items = wave_items(NSB, NB, NFB)
     nitems = len(items[0])
     hdr = np.zeros(HDR, dtype=np.int32)
@@ -179,6 +226,7 @@ def pack_made_forward(made, mult=2, spline=False):
         chunks.append(stream)
         off += stream.size
     hdr[:11] = [D, Dp, H, Hp, NSB, NB, mult, NFB, (NFB + 7) // 8, off, nitems]
+    hdr[12] = sl["MD"]                                      # output row length (mult D for a MADE)
     blob = np.concatenate(chunks).astype(np.float32)
     assert blob.size == off and off < 2 ** 31
     return blob, np.concatenate([hdr, tab.reshape(-1)]).astype(np.int32)
@@ -284,11 +332,19 @@ def pack_made_backward(made, mult=2):
       offsets            [(weight offset, shape, bias offset, n)] per linear in the order initial, blocks' linears, final
       nflat, ntiles, Mp (g_params row length padded to 128), Dx (x row length padded to 128)."""
     sl = _slot_layers(made, mult)
-    if sl is None:
-        return None
-    D, H, NB, Hp, NSB, Dp, NFB, layers, order = (sl[k] for k in ("D", "H", "NB", "Hp", "NSB", "Dp", "NFB", "layers", "order"))
+    return None if sl is None else _pack_backward_from(sl)
+
+
+def pack_resnet_backward(net):
+    """pack_made_backward for a ResidualNet (all masks ones)."""
+    sl = _dense_layers(net)
+    return None if sl is None else _pack_backward_from(sl)
+
+
+def _pack_backward_from(sl):
+    D, H, NB, Hp, NSB, Dp, NFB, layers, order, mult, MD = (sl[k] for k in ("D", "H", "NB", "Hp", "NSB", "Dp", "NFB", "layers", "order",
+                                                                           "mult", "MD"))
     HRB = Hp // ROWS
-    MD = mult * D
     NC = (MD + Hp - 1) // Hp
     Wf, Mf, _ = layers[-1]
     WfT = np.zeros((Hp, NC * Hp), dtype=np.float32)
@@ -329,6 +385,7 @@ def pack_made_backward(made, mult=2):
         chunks.append(stream)
         off += stream.size
     hdr[:11] = [D, Dp, H, Hp, NSB, NB, mult, NC, 0, off, nitems]
+    hdr[12] = MD
     blob = np.concatenate(chunks).astype(np.float32)
     assert blob.size == off and off < 2 ** 31
     table = np.concatenate([hdr, tab.reshape(-1)]).astype(np.int32)
@@ -368,8 +425,7 @@ def pack_made_backward(made, mult=2):
         stab.append([woff, shape[1], boff, map_off, map_off + Mrows, 0, 0, 0])
         maps += [np.asarray(rmap, dtype=np.int32), np.asarray(cmap, dtype=np.int32)]
         map_off += Mrows + Ncols
-        lyr = sl["lin"][pi]
-        mask_parts += [(lyr.mask.cpu().numpy() != 0).astype(np.uint8).reshape(-1), np.ones(shape[0], dtype=np.uint8)]
+        mask_parts += [sl["masks"][pi].astype(np.uint8).reshape(-1), np.ones(shape[0], dtype=np.uint8)]
     whdr = np.zeros(16, dtype=np.int32)
     whdr[:2] = [len(tiles), len(probs)]
     wtable = np.concatenate([whdr, np.asarray(ptab, dtype=np.int32).reshape(-1), np.asarray(tiles, dtype=np.int32).reshape(-1)])
@@ -377,4 +433,4 @@ def pack_made_backward(made, mult=2):
     mask = np.concatenate(mask_parts)
     assert mask.size == flat and flat < 2 ** 31
     return dict(blob=blob, table=table, wtable=wtable.astype(np.int32), stable=stable, mask=mask, offsets=offsets, nflat=flat,
-                ntiles=len(tiles), Mp=Mp, Dx=Dx, Hp=Hp, NB=NB, mult=mult)
+                ntiles=len(tiles), Mp=Mp, Dx=Dx, Hp=Hp, NB=NB, mult=mult, MD=MD)

@@ -78,7 +78,34 @@ class ResidualNet(nn.Module):
         self.dropout_probability = dropout_probability
         self.use_batch_norm = use_batch_norm
 
+    def _train_packs(self, device):
+        """Device copies of (forward, backward) packs for the MADE training kernels (flows/made_pack.pack_resnet_*), rebuilt when a
+        parameter changes; None outside their structure."""
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (str(device),)
+        cache = self.__dict__.get("_train_pack_cache")
+        if cache is None or cache[0] != key:
+            from .flows import made_pack
+            packs = None
+            fwd = made_pack.pack_resnet_forward(self)
+            bwd = made_pack.pack_resnet_backward(self) if fwd is not None else None
+            if bwd is not None:
+                for k in ("blob", "table", "wtable", "stable", "mask"):
+                    bwd[k] = torch.from_numpy(bwd[k]).to(device)
+                packs = ((torch.from_numpy(fwd[0]).to(device), torch.from_numpy(fwd[1]).to(device), int(fwd[1][3])), bwd)
+            cache = self.__dict__["_train_pack_cache"] = (key, packs)
+        return cache[1]
+
     def forward(self, inputs, context=None):
+        # hidden widths beyond the 128-column training kernels (ResidualBlockFn, autograd.linear) under autograd: the whole net's
+        # forward, input-gradient chain and weight gradients on the MADE training kernels (csrc/made_bwd.hip; no mask = dense)
+        if (context is None and self.hidden_features > 128 and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
+                and torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            from . import config
+            packs = self._train_packs(inputs.device) if (config.made_train and config.made_fused) else None
+            if packs is not None:
+                from . import autograd
+                lins = [self.initial_layer] + [l for b in self.blocks for l in b.linear_layers] + [self.final_layer]
+                return autograd.MadeFn.apply(packs[0], packs[1], inputs, *[t for l in lins for t in (l.weight, l.bias)])
         temps = inputs if self.preprocessing is None else self.preprocessing(inputs)
         if context is None:
             temps = self.initial_layer(temps)

@@ -909,25 +909,26 @@ def made_forward(x, blob, table, hidden_padded, mult):
     return params
 
 
-def made_forward_train(x, blob, table, hidden_padded, mult, num_blocks):
-    """MADE.forward under autograd (nf_made_forward_train): (params (B, mult D), save (2 NB + 1, Bp, Hp) pre-activations, bits
-    (Bp / 64, 2 NB, 2, 512) ReLU signs), Bp = B rounded up to 64 -- the operands of made_backward / made_wgrad."""
+def made_forward_train(x, blob, table, hidden_padded, out_features, num_blocks):
+    """MADE.forward / ResidualNet.forward under autograd (nf_made_forward_train): (params (B, out_features), save (2 NB + 1, Bp, Hp)
+    pre-activations, bits (Bp / 64, 2 NB, 2, 512) ReLU signs), Bp = B rounded up to 64 -- the operands of made_backward / made_wgrad.
+    out_features = mult D for a MADE (the table's hdr[12])."""
     L.require_device(x, blob, table)
     if x.dtype != torch.float32:
         raise NotImplementedError("made_forward_train: float32 only")
     B, D = x.shape
     x = x.contiguous()
     Bp = (B + 63) // 64 * 64
-    params = torch.empty(B, mult * D, dtype=x.dtype, device=x.device)
+    params = torch.empty(B, out_features, dtype=x.dtype, device=x.device)
     save = torch.empty(2 * num_blocks + 1, Bp, hidden_padded, dtype=x.dtype, device=x.device)
     bits = torch.empty(max(Bp // 64, 1), 2 * num_blocks, 2, 512, dtype=torch.int32, device=x.device)
     rc = L.lib().nf_made_forward_train(ptr(x), ptr(params), ptr(save), ptr(bits), ptr(blob), ptr(table), i64(B), i32(D),
-                                       i32(hidden_padded), i32(mult), L.stream())
+                                       i32(hidden_padded), i32(max(1, out_features // D)), L.stream())
     L.check(rc, "nf_made_forward_train")
     return params, save, bits
 
 
-def made_backward(g_params, bits, blob, table, D, hidden_padded, mult, num_blocks):
+def made_backward(g_params, bits, blob, table, D, hidden_padded, num_blocks):
     """The input-gradient chain of MADE (nf_made_backward): g_x (B, D) and every layer's output gradient G (2 NB + 1, Bp, Hp)."""
     L.require_device(g_params, bits, blob, table)
     B = g_params.shape[0]
@@ -936,7 +937,7 @@ def made_backward(g_params, bits, blob, table, D, hidden_padded, mult, num_block
     gx = torch.empty(B, D, dtype=g_params.dtype, device=g_params.device)
     G = torch.empty(2 * num_blocks + 1, Bp, hidden_padded, dtype=g_params.dtype, device=g_params.device)
     rc = L.lib().nf_made_backward(ptr(g_params), ptr(bits), ptr(gx), ptr(G), ptr(blob), ptr(table), i64(B), i32(D),
-                                  i32(hidden_padded), i32(mult), L.stream())
+                                  i32(hidden_padded), i32(max(1, g_params.shape[1] // D)), L.stream())
     L.check(rc, "nf_made_backward")
     return gx, G
 

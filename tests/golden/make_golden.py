@@ -441,6 +441,35 @@ def gen_train_c2_w64h128():
     npz("grad_model_c2_w64h128", **out)
 
 
+def gen_train_nsf_wide():
+    """The training step (core.py:87-102 forward_kld + loss.backward()) of NSF models with conditioners beyond 128 hidden units
+    (wrapper.py:20-35, nets/resnet.py:53-104): 2 x [CoupledRationalQuadraticSpline(D, 2, hidden) + LULinearPermute(D)], sigma 0.05,
+    B = 200; loss, input gradient, of every parameter gradient a strided sample (every 37th element) + sum / absolute sum; float32
+    and float64 legs; weights by seeded construction (bench.build_c2_model)."""
+    sys.path.insert(0, os.path.join(OUT, "..", ".."))
+    from bench import build_c2_model, c2_inputs
+    STRIDE = 37
+    for D, H in ((64, 256), (128, 160)):
+        out = {"stride": np.array(STRIDE)}
+        for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+            mm = build_c2_model(num_layers=2, dim=D, hidden=H, seed=41 + D, sigma=0.05, lib=nf).to(dt)
+            x = c2_inputs(200, D, seed=5 + H)
+            xx = x.clone().to(dt).requires_grad_(True)
+            loss = mm.forward_kld(xx)
+            loss.backward()
+            out["loss_" + tag] = loss.detach().double()
+            out["gx_" + tag] = xx.grad
+            for k, p_ in mm.named_parameters():
+                key = k.replace(".", "__")
+                gflat = (torch.zeros_like(p_) if p_.grad is None else p_.grad).reshape(-1)
+                out["g_%s__%s" % (tag, key)] = gflat[::STRIDE].clone()
+                out["chk_%s__%s" % (tag, key)] = torch.tensor([float(gflat.double().sum()), float(gflat.double().abs().sum())],
+                                                              dtype=torch.float64)
+            if dt == torch.float32:
+                out["x"] = x
+        npz("grad_model_nsf_wide_d%d_h%d" % (D, H), **out)
+
+
 def gen_nsf_wide():
     """NSF models beyond the benchmark kernel's shapes (hidden 256, D = 128; wrapper.py:20-35 over nets/resnet.py:53-104): 3 x
     [CoupledRationalQuadraticSpline + LULinearPermute], sigma 0.05, 96 rows, log_prob and the sampling pass, fp32 and fp64 legs.
@@ -1063,6 +1092,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "made_train":
         gen_made_train()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "train_nsf_wide":
+        gen_train_nsf_wide()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "nsf_wide":
         gen_nsf_wide()
         sys.exit(0)
@@ -1150,3 +1182,4 @@ if __name__ == "__main__":
     gen_train_c2_w64h128()
     gen_nsf_wide()
     gen_made_train()
+    gen_train_nsf_wide()

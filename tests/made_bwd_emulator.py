@@ -36,7 +36,7 @@ def emulate_chain(pack, gp, S):
     assert blob.size == total and nitems == 2 * NC + 4 * NB + 1
     tab = table[HDR:HDR + 8 * nitems * 4].reshape(8, nitems, 4)
     B = gp.shape[0]
-    MD = mult * D
+    MD = int(table[12]) if table[12] else mult * D
     gpp = np.zeros((B, NC * Hp))
     gpp[:, :MD] = gp
     pos = [int(table[16 + w]) for w in range(8)]

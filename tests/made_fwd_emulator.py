@@ -68,7 +68,7 @@ def emulate_forward(blob, table, x):
         n = pos[w] - start[w]
         assert np.array_equal(blob[pos[w]:pos[w] + RING * 256], np.resize(blob[start[w]:pos[w]], RING * 256)), w
         assert pos[w] + RING * 256 == (int(table[16 + w + 1]) if w < 7 else total) and n > 0
-    return out[:, :mult * D]
+    return out[:, :(int(table[12]) if table[12] else mult * D)]
 
 
 def work_per_wave(table):

@@ -1342,3 +1342,49 @@ def test_maf_affine_backward_kernel_vs_autograd(nfa, dt, direction):
         tol = 2e-5 if dt == torch.float32 else 1e-12
         for a, b in zip(res[0], res[1]):
             assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("D,H", [(64, 256), (128, 160)])
+def test_wide_nsf_training_step_vs_reference_autograd(nfa, monkeypatch, D, H):
+    """forward_kld + backward (core.py:87-102) of NSF models whose conditioner has more than 128 hidden units against the REFERENCE's
+    autograd (tests/golden/grad_model_nsf_wide_*.npz: 2 x [CoupledRationalQuadraticSpline(D, 2, hidden) + LULinearPermute(D)], B = 200,
+    weights rebuilt from the seed): the ResidualNet runs forward, input-gradient chain and weight gradients on the MADE training kernels
+    (no mask; spy), the spline on nf_rqs_coupling(_bwd).  Loss 1e-4; gradients 1e-3 of scale vs the float32 leg and within 4 x the
+    reference's own float32-vs-float64 error (q90) vs the float64 leg."""
+    from bench import build_c2_model
+    g = load_golden("grad_model_nsf_wide_d%d_h%d" % (D, H))
+    m = build_c2_model(num_layers=2, dim=D, hidden=H, seed=41 + D, sigma=0.05).to(DEV)
+    calls = _spy_made(monkeypatch)
+    x = T(g["x"]).requires_grad_(True)
+    loss = m.forward_kld(x)
+    loss.backward()
+    assert calls == {"fwd": 2, "bwd": 2, "wgrad": 2}, calls
+    assert abs(float(loss.detach()) - float(g["loss_f32"])) < 1e-4 * abs(float(g["loss_f32"]))
+    stride = int(g["stride"])
+
+    def err(a, ref):
+        return np.abs(np.asarray(a, dtype=np.float64) - ref) / max(1e-6, float(np.abs(ref).max()))
+    own, got = [err(g["gx_f32"], g["gx_f64"]).max()], [err(N(x.grad), g["gx_f64"]).max()]
+    assert err(N(x.grad), g["gx_f32"]).max() < 1e-3
+    for k, p in m.named_parameters():
+        key = k.replace(".", "__")
+        flat = (np.zeros(p.numel(), dtype=np.float32) if p.grad is None else N(p.grad).reshape(-1))
+        ref32, ref64 = g["g_f32__" + key], g["g_f64__" + key]
+        if float(np.abs(ref64).max()) == 0.0:
+            assert float(np.abs(flat).max()) == 0.0, k
+            continue
+        assert err(flat[::stride], ref32).max() < 1e-3, (k, err(flat[::stride], ref32).max())
+        chk = g["chk_f64__" + key]
+        assert abs(float(flat.astype(np.float64).sum()) - chk[0]) < 1e-4 * max(1e-6, chk[1]), k
+        own.append(err(ref32, ref64).max())
+        got.append(err(flat[::stride], ref64).max())
+    assert np.quantile(got, 0.9) <= 4 * max(np.quantile(own, 0.9), 1e-7), (np.quantile(got, 0.9), np.quantile(own, 0.9))
+    # differential: torch autograd through library GEMMs on the same model
+    nfa.config.set_made_train(False)
+    try:
+        m.zero_grad(set_to_none=True)
+        x2 = T(g["x"]).requires_grad_(True)
+        m.forward_kld(x2).backward()
+    finally:
+        nfa.config.set_made_train(True)
+    assert calls["fwd"] == 2 and float((x2.grad - x.grad).abs().max()) < 1e-4 * float(x.grad.abs().max())
