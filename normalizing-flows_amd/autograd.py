@@ -213,9 +213,10 @@ class LULinearPermuteFn(torch.autograd.Function):
         ctx.acc, ctx.has_acc = acc, ld_acc is not None
         if ld_acc is not None:
             ctx.mark_dirty(ld_acc)      # the caller's running log-density, updated in place (inside the launch where possible)
-        if direction == 0 and x.is_cuda and x.dtype == torch.float32 and D <= 64:
+        if direction == 0 and x.is_cuda and x.dtype == torch.float32 and D <= 128:
             # density direction on the fp32-MFMA row mat-vec kernel: u = U x[perm] (kept for the backward), y = L u + b with
-            # the constant log-det in the same launch -- two 13 us launches against 64 us for the LDS-tile kernel
+            # the constant log-det in the same launch -- two 13 us launches against 64 us for the LDS-tile kernel (D = 128: two
+            # nf_rows_matvec_affine launches against 3 ms for that kernel at B = 65 536)
             with torch.no_grad():
                 if factors_out is not None:    # assembled for every layer of the model by one launch (_prepack.py)
                     Lm, Um, Up, diag, lad, LT, UpT = ops.lu_factors_views(factors_out, D)
@@ -227,7 +228,7 @@ class LULinearPermuteFn(torch.autograd.Function):
                 lacc = None if ld_acc is None else (L.LD_ADD if acc > 0 else L.LD_SUB)
                 if config.lu_bwd_fused and D == 64 and x.shape[0] % 64 == 0 and x.shape[0] >= 1024:
                     u, y, ld = ops.lu_fwd(x, UpT, LT, bias.detach(), lad, +1.0, logdet=ld_acc, acc=lacc)   # LDS-DMA tiles (nf_lu_fwd)
-                elif config.lu_matvec2:
+                elif config.lu_matvec2 and D <= 64:
                     u, y, ld = ops.rows_matvec2(x, Up, Lm, bias.detach(), lad, +1.0, logdet=ld_acc, acc=lacc)
                 else:
                     u = ops.rows_matvec(x, Up)
@@ -269,7 +270,7 @@ class LULinearPermuteFn(torch.autograd.Function):
                 g_lower, g_upper, g_udiag = ops.lu_param_grads(gL, gUx, gld, udiag_raw.detach(), lower_entries.numel(),
                                                                eps=ctx.eps, sign=1.0, perm=perm)
                 return gx, None, g_lower, g_upper, g_udiag, g_bias, None, None, g_acc, None, None, None
-            if config.lu_matvec2:
+            if config.lu_matvec2 and D_ <= 64:
                 gu, gx, _ = ops.rows_matvec2(gy, LT, UpT)   # d/du = L^T gy, d/dx = P (U^T gu): one launch
             else:
                 gu = ops.rows_matvec(gy, LT)

@@ -279,10 +279,10 @@ def actnorm_bwd(z, s, t, gy, gld, direction):
 
 
 def rows_matvec(x, W):
-    """y_b = W x_b for every row of x (B, D) float32, D <= 64 (nf_rows_matvec, csrc/rows_matvec.hip)."""
+    """y_b = W x_b for every row of x (B, D) float32, D <= 128 (nf_rows_matvec, csrc/rows_matvec.hip)."""
     L.require_device(x, W)
-    if x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] > 64:
-        raise NotImplementedError("rows_matvec: (B, D <= 64) float32")
+    if x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] > 128:
+        raise NotImplementedError("rows_matvec: (B, D <= 128) float32")
     x = x.contiguous()
     y = torch.empty_like(x)
     rc = L.lib().nf_rows_matvec(ptr(x), ptr(W.to(torch.float32).contiguous()), ptr(y), i64(x.shape[0]), i32(x.shape[1]), L.stream())
