@@ -318,6 +318,12 @@ x = torch.randn(4096, 64, generator=torch.Generator().manual_seed(1)).to(dev)
 loss = m.forward_kld(x)
 loss.backward()
 out["train_step"] = digest(loss, *[p.grad for p in m.parameters()])
+# (1b) MADE under autograd: made_wgrad_kernel's LDS-DMA ring (vmcnt(4) per step) over several steps and chunks
+mafl = nfa.flows.MaskedAffineAutoregressive(128, 512, num_blocks=2).to(dev)
+xm = torch.randn(8192, 128, generator=torch.Generator().manual_seed(6)).to(dev).requires_grad_(True)
+zm, ldm_ = mafl.forward(xm)
+(zm.square().sum() + ldm_.sum()).backward()
+out["made_train"] = digest(zm, xm.grad, *[p.grad for p in mafl.parameters()])
 torch.set_grad_enabled(False)
 # (2) the software-pipelined spline kernels (rqs_spline.hip / rqs_bwd.hip: vmcnt(loads + stores) per pass)
 layer = nfa.flows.CoupledRationalQuadraticSpline(64, 2, 128, init_identity=False).to(dev)
@@ -364,7 +370,8 @@ def test_counted_waits_equal_full_drains(nfa, tmp_path):
     """Every hand-counted `s_waitcnt vmcnt(N)` (NF_WAIT_VMCNT: ring acquires that leave N younger requests in flight -- correct only
     while N equals what the compiler actually emits between request and wait) against a build in which each of them is a full
     drain (lib/variants/safe_waits.so, -DNF_SAFE_WAITS, built by __graft_entry__.build()): the deterministic kernels that use them
-    -- the one-launch training forward, nf_final_bwd, the ring weight gradient, the pipelined spline kernels, the split-bf16 chain,
+    -- the one-launch training forward, nf_final_bwd, the ring weight gradients (wgrad.hip, made_bwd.hip), the pipelined spline
+    kernels, the split-bf16 chain,
     the Glow level kernels, both MAF inverse kernels -- must give BIT-identical results at sizes with full tiles.  A count that
     has become too lax reads a stage that has not landed: silent corruption on full tiles only (round-3 ADVICE)."""
     import json
@@ -383,6 +390,6 @@ def test_counted_waits_equal_full_drains(nfa, tmp_path):
         assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2500:]
         line = [l for l in out.stdout.splitlines() if l.startswith("DIGESTS ")][-1]
         res.append(json.loads(line[len("DIGESTS "):]))
-    assert res[0].keys() == res[1].keys() and len(res[0]) == 6
+    assert res[0].keys() == res[1].keys() and len(res[0]) == 7
     for k in res[0]:
         assert res[0][k] == res[1][k], "%s: the counted-wait build and the full-drain build differ" % k
