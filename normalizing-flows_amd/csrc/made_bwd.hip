@@ -18,7 +18,6 @@
 //    issue the MFMAs (the design of wgrad.hip's wgrad_ring_kernel, with row strides and per-problem operands); split over row chunks.
 // 3. made_wgrad_reduce_kernel: the chunks' partial tiles summed in a fixed order (deterministic) and scattered from slot space to
 //    the parameters' own layout, masked entries left zero.
-#include <cstdlib>
 #include "mlp_tile.hpp"
 
 namespace nf {
@@ -324,16 +323,13 @@ extern "C" int nf_made_backward(const void *g_params, const void *bits, void *g_
     return nf::made_bwd_launch<2>(g_params, bits, g_x, G, blob, table, B, st);
 }
 
-static int made_env(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 static int made_wgrad_chunk_rows(int64_t Bp, int ntiles) {
-    // measured at config 5's layer (50 tiles, B = 65 536; tools/scripts/mw_sweep.sh): 768 / 1024 / 1536 / 2048 / 3072 workgroups
+    // measured at config 5's layer (50 tiles, B = 65 536; ablation builds with -DNF_MW_SLOTS / -DNF_MW_TILE_MAJOR): 768 / 1024 / 1536 / 2048 / 3072 workgroups
     // = 1.19 / 1.12 / 0.98 / 1.07 / 0.99 ms for this launch + 18 / 24 / 33 / 40 / 55 us for the reduction: three rounds of 512
-    static const int slots = made_env("NF_MW_SLOTS", 1536);
-    int64_t want = (slots + ntiles - 1) / ntiles;
+#ifndef NF_MW_SLOTS
+#define NF_MW_SLOTS 1536
+#endif
+    int64_t want = (NF_MW_SLOTS + ntiles - 1) / ntiles;
     if (want < 1) want = 1;
     int64_t rows = (Bp + want - 1) / want;
     rows = (rows + 63) / 64 * 64;
@@ -362,7 +358,10 @@ extern "C" int nf_made_wgrad(const void *gp_pad, const void *x_pad, const void *
     const int rows = made_wgrad_chunk_rows(Bp, ntiles);
     const int chunks = (int)((Bp + rows - 1) / rows);
     // tile-major: the workgroups in flight together work on the same row chunk (its operands are shared through L2 / MALL)
-    static const int tile_major = made_env("NF_MW_TILE_MAJOR", 1);
+#ifndef NF_MW_TILE_MAJOR
+#define NF_MW_TILE_MAJOR 1
+#endif
+    const int tile_major = NF_MW_TILE_MAJOR;
     const dim3 grid = tile_major ? dim3((unsigned)ntiles, (unsigned)chunks) : dim3((unsigned)chunks, (unsigned)ntiles);
     hipLaunchKernelGGL(nf::made_wgrad_kernel, grid, dim3(nf::MW_NT), 0, st, (const float *)gp_pad, (const float *)x_pad,
                        (const float *)G, (const float *)save, (float *)part, (const int *)wtable, rows, Bp, tile_major);
