@@ -541,6 +541,21 @@ int nf_made_backward(const void *g_params, const void *bits, void *g_x, void *G,
 int64_t nf_made_wgrad_scratch_floats(int64_t B, int ntiles);
 int nf_made_wgrad(const void *gp_pad, const void *x_pad, const void *G, const void *save, void *grads, const void *mask, void *part,
                   const int32_t *wtable, const int32_t *stable, int ntiles, int64_t B, nf_stream_t stream);
+/* The weight streams of a training step from the parameters as they are now: out[i] = flat[src[i]], flat = [0, every parameter of
+ * the network flattened], src = the packer's stream with parameter positions in place of values (made_pack.train_structure) -- the
+ * reference re-reads its nn.Parameters in every forward; a host-side repack per optimizer step would cost more than the step. */
+int nf_pack_gather(const void *flat, const int32_t *src, void *out, int64_t n, nf_stream_t stream);
+
+/* GlowBlock's conv conditioner under autograd.  Replaces what torch autograd + the convolution library do for
+ * normflows/nets/cnn.py:5-63 (ConvNet2d: Conv2d 3x3 -> LeakyReLU(0) -> Conv2d 1x1 -> LeakyReLU(0) -> Conv2d 3x3, padding 1) inside
+ * core.py:87-102 + loss.backward() through flows/affine/glow.py:10-100: a 3x3 convolution over a few channels is a gather of the 9
+ * neighbours per pixel (nf_conv3x3_gather: col (B H W, 9 C)) in front of a per-pixel linear layer, or a per-pixel linear layer to 9 C
+ * tap products followed by a sum over the 9 neighbours (nf_conv3x3_gather_sum); the per-pixel MLP (9 Cin -> hidden -> hidden -> 9 Cout)
+ * runs on nf_made_forward_train / nf_made_backward / nf_made_wgrad with tables in plain-MLP mode (made_pack.pack_mlp_*).  flip = 1
+ * negates the offsets: the backward pass's gather of the output cotangent and gather-sum of the column cotangent. */
+int nf_conv3x3_gather(const void *in, void *col, int64_t B, int C, int H, int W, int ld, int flip, nf_stream_t stream);
+int nf_conv3x3_gather_sum(const void *P, const void *bias, void *out, int64_t B, int C, int H, int W, int ld, int flip,
+                          nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * MaskedAffineAutoregressive inverse (MAF sampling direction) in ONE pass.  Replaces the D-pass loop of

@@ -771,6 +771,44 @@ class MadeFn(torch.autograd.Function):
         return (None, None, gx if ctx.needs_input_grad[2] else None) + tuple(grads)
 
 
+class ConvNetFn(torch.autograd.Function):
+    """GlowBlock's conditioner ConvNet2d([Cin, hidden, hidden, Cout], kernels (3, 1, 3), LeakyReLU(0); nets/cnn.py:5-63) under
+    autograd (flows/affine/glow.py:10-100 inside core.py:87-102) without the convolution library: pixels are rows, the 3x3
+    convolutions a gather in front (nf_conv3x3_gather) and a neighbour sum behind (nf_conv3x3_gather_sum) of a per-pixel MLP
+    9 Cin -> hidden -> hidden -> 9 Cout, which runs -- forward, input-gradient chain, weight gradients -- on the MADE training kernels
+    in plain-MLP mode (csrc/made_fwd.hip EPI 3, csrc/made_bwd.hip; packs: flows/made_pack.pack_mlp_*)."""
+
+    @staticmethod
+    def forward(ctx, fwd, bwd, x, w1, b1, w2, b2, w3, b3):
+        B, Cin, H, W = x.shape
+        Cout = w3.shape[0]
+        col = ops.conv3x3_gather(x)
+        P, save, bits = ops.made_forward_train(col, fwd[0], fwd[1], fwd[2], 9 * Cout, 1)
+        out = ops.conv3x3_gather_sum(P, b3.detach(), (B, Cout, H, W))
+        ctx.save_for_backward(col, save, bits)
+        ctx.bwd, ctx.shape = bwd, (B, Cin, H, W)
+        ctx.wshapes = (tuple(w1.shape), tuple(w2.shape), tuple(w3.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        col, save, bits = ctx.saved_tensors
+        bwd = ctx.bwd
+        B, Cin, H, W = ctx.shape
+        gout = gout.contiguous()
+        gP = ops.conv3x3_gather(gout, flip=True)
+        gcol, G = ops.made_backward(gP, bits, bwd["blob"], bwd["table"], col.shape[1], bwd["Hp"], 1)
+        gx = ops.conv3x3_gather_sum(gcol, None, (B, Cin, H, W), flip=True) if ctx.needs_input_grad[2] else None
+        flat = ops.made_wgrad(gP, col, G, save, bwd["wtable"], bwd["stable"], bwd["mask"], bwd["ntiles"], bwd["nflat"], bwd["Mp"],
+                              bwd["Dx"])
+        (o0, s0, c0, n0), (o1, s1, c1, n1), (o2, s2, _, _) = bwd["offsets"]
+        hid, Cout = ctx.wshapes[0][0], ctx.wshapes[2][0]
+        gw1 = flat[o0:o0 + s0[0] * s0[1]].view(hid, 3, 3, Cin).permute(0, 3, 1, 2)
+        gw2 = flat[o1:o1 + s1[0] * s1[1]].view(hid, hid, 1, 1)
+        gw3 = flat[o2:o2 + s2[0] * s2[1]].view(3, 3, Cout, hid).permute(2, 3, 0, 1)
+        return None, None, gx, gw1, flat[c0:c0 + n0], gw2, flat[c1:c1 + n1], gw3, gout.sum((0, 2, 3))
+
+
 class MafAffineFn(torch.autograd.Function):
     """nf_maf_affine (affine/autoregressive.py:98-128) on given MADE output `params` (B, 2D); backward = nf_maf_affine_bwd."""
 

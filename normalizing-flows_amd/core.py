@@ -13,6 +13,7 @@ Differences that are deliberate (MI355X-first):
     bypassed whenever gradients are required.
 """
 import torch
+from . import _keys
 from torch import nn
 
 from . import _prepack
@@ -24,7 +25,9 @@ from .flows.neural_spline import CoupledRationalQuadraticSpline
 def invalidate_caches(module):
     """Drop every packed-weight cache under `module` (fused blobs, one-launch packs, composed LU matrices, masked weights, recorded
     graphs).  The caches are keyed by (data_ptr, _version) of the parameters they were built from, which every in-place update
-    through the parameter itself bumps (optimizers, load_state_dict, p.add_(...), p.copy_(...)).  Updates through `.data`
+    through the parameter itself bumps (load_state_dict, p.add_(...), p.copy_(...), the for-loop / foreach optimizers), plus a
+    process-wide epoch that a global optimizer post-step hook advances (_keys.py: torch's FUSED optimizers do not bump
+    `_version`).  Updates through `.data`
     (`p.data.add_(...)`, `p.data.copy_(...)`, hand-written SGD / EMA on .data) do NOT bump `_version`: call this afterwards, or
     update `p` under torch.no_grad() instead."""
     for m in module.modules():
@@ -155,7 +158,7 @@ def _pack_realnvp(run, d, device):
 def _run_realnvp(run, cache, z, inverse, ld, acc):
     from . import ops
     d = z.shape[1]
-    key = tuple((p.data_ptr(), p._version) for f in run for p in list(f.parameters()) + list(f.buffers())) + (str(z.device),)
+    key = _keys.pkey(p for f in run for p in list(f.parameters()) + list(f.buffers())) + (str(z.device),)
     ent = cache.get(id(run[0]))
     if ent is None or ent[0] != key:
         ent = (key,) + _pack_realnvp(run, d, z.device)
@@ -278,6 +281,7 @@ class _GraphCache:
     def __init__(self, owner=None):
         self.enabled = False
         self.graphs = {}
+        self.epoch = _keys.epoch()
         self.owner = None if owner is None else __import__("weakref").ref(owner)
 
     def clear(self):
@@ -286,6 +290,8 @@ class _GraphCache:
     def run(self, key, fn, *inputs):
         if not self.enabled:
             return fn(*inputs)
+        if self.epoch != _keys.epoch():       # an optimizer stepped since the capture: the graphs hold the old packed weights
+            self.graphs, self.epoch = {}, _keys.epoch()
         entry = self.graphs.get(key)
         if entry is None:
             static_in = [t.clone() for t in inputs]

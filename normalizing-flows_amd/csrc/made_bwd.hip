@@ -37,6 +37,8 @@ made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits,
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = table[0], NB = table[5], NC = table[7], nitems = table[10];
     const int MD = table[12] ? table[12] : table[6] * D;       // row length of g_params
+    const int plain = table[13];                               // plain MLP (made_fwd.hip): g_t = (Wf^T g_p).[t>0]; g_h = (W1^T g_t).[h>0]
+    const int nfin = table[8] > 0 ? table[8] : 1;              // rounds of the last product: 4 feature row-blocks x 2 sample blocks each
     const int *items = table + MF_HDR + w * nitems * 4;       // [nitems][nkg, rb, kg0, -]
     const float *stream = blob + table[16 + w];
     const int rbs[2] = {w, HRB - 1 - w};
@@ -87,7 +89,35 @@ made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits,
 #pragma unroll
         for (int s = 0; s < 2; ++s) mf_save_rows<NS, false>(gtile + (size_t)(2 * NB) * Bp * HP, HP, nrows, rbs[s], sb0s[s], hh, n, gh[s]);
         // ---- residual blocks, last first ------------------------------------------------------------------------------------------------
-        for (int b = NB - 1; b >= 0; --b) {
+        if (plain) {
+            const int *itb = items + 4 * (2 * NC);
+            unsigned bt[2], bh[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bt[s] = btile[((size_t)1 * 2 + s) * 512];
+                bh[s] = btile[((size_t)0 * 2 + s) * 512];
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                mf_masked<NS, false>(gh[s], gh[s], bt[s]);               // g_t (G[2] above holds the unmasked product: unused)
+                mf_save_rows<NS, false>(gtile + (size_t)1 * Bp * HP, HP, nrows, rbs[s], sb0s[s], hh, n, gh[s]);
+            }
+            MF_BARRIER();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) mf_publish<NS, false>(acts, rbs[s], sb0s[s], hh, n, gh[s]);
+            MF_BARRIER();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int *it = itb + 4 * (2 + s);
+                mf_item<NS, false>(ring, it[0], acts + lane_b + 128 * sb0s[s] + it[2] * 512, u[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                mf_masked<NS, false>(gh[s], u[s], bh[s]);                // g_h
+                mf_save_rows<NS, false>(gtile, HP, nrows, rbs[s], sb0s[s], hh, n, gh[s]);
+            }
+        }
+        for (int b = plain ? -1 : NB - 1; b >= 0; --b) {
             const int *itb = items + 4 * (2 * NC + 4 * (NB - 1 - b));
             unsigned bt[2], bh[2];
 #pragma unroll
@@ -129,8 +159,8 @@ made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits,
 #pragma unroll
         for (int s = 0; s < 2; ++s) mf_publish<NS, false>(acts, rbs[s], sb0s[s], hh, n, gh[s]);
         MF_BARRIER();
-        {
-            const int *it = items + 4 * (2 * NC + 4 * NB);
+        for (int rd = 0; rd < nfin; ++rd) {
+            const int *it = items + 4 * (2 * NC + 4 * NB + rd);
             const int rb = it[1], sf = w >> 2;
             if (rb >= 0) {
                 f32x16 o[1];
@@ -157,10 +187,10 @@ made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits,
 
 template <int NSB>
 static int made_bwd_launch(const void *gp, const void *bits, void *gx, void *G, const void *blob, const int32_t *table, int64_t B,
-                           hipStream_t st) {
+                           hipStream_t st, int dp) {
     const int64_t ntiles = (B + MF_ROWS - 1) / MF_ROWS;
     const int grid = (int)(ntiles < 256 ? ntiles : 256);
-    const size_t lds = sizeof(float) * ((size_t)8 * NSB * 4 * 512 + MF_XFLOATS);
+    const size_t lds = sizeof(float) * ((size_t)8 * NSB * 4 * 512 + (dp > 128 ? 2 * MF_XFLOATS : MF_XFLOATS));
     static LdsOptIn opted;
     if (opt_in_lds(reinterpret_cast<const void *>(&made_bwd_kernel<NSB>), lds, opted) != NF_OK) return NF_ENOTSUP;
     hipLaunchKernelGGL((made_bwd_kernel<NSB>), dim3((unsigned)grid), dim3(64 * MF_NW), lds, st, (const float *)gp,
@@ -302,10 +332,26 @@ made_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ gra
     }
 }
 
+// ---- 4. the streams of a training step from the parameters as they are NOW ---------------------------------------------------------------
+// out[i] = flat[src[i]]: `flat` = [0, the network's parameters flattened one after the other], `src` = the host packer's stream with
+// parameter POSITIONS in place of values (made_pack.train_structure; entry 0 = the zero of padded / masked slots).  Under autograd the
+// parameters change every step, so the value-independent part (tables, src) is built once and the streams by this gather.
+__global__ void __launch_bounds__(256)
+pack_gather_kernel(const float *__restrict__ flat, const int *__restrict__ src, float *__restrict__ out, int64_t n) {
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+        if (i + 3 < n) {
+            const int4 k = *reinterpret_cast<const int4 *>(src + i);
+            *reinterpret_cast<f32x4 *>(out + i) = f32x4{flat[k.x], flat[k.y], flat[k.z], flat[k.w]};
+        } else {
+            for (int64_t j = i; j < n; ++j) out[j] = flat[src[j]];
+        }
+    }
+}
+
 }  // namespace nf
 
 static int made_bwd_check(int64_t B, int D, int hidden_padded, int mult) {
-    if (B < 0 || D < 2 || D > 128 || mult < 1) return NF_EINVAL;
+    if (B < 0 || D < 2 || D > (hidden_padded == 256 ? 256 : 128) || mult < 1) return NF_EINVAL;   // (a 64 KB g_x tile fits next to 256 slots)
     if (hidden_padded != 256 && hidden_padded != 512) return NF_ENOTSUP;
     return NF_OK;
 }
@@ -319,8 +365,9 @@ extern "C" int nf_made_backward(const void *g_params, const void *bits, void *g_
     if (B == 0) return NF_OK;
     if (!g_params || !bits || !g_x || !G || !blob || !table) return NF_EFAULT;
     hipStream_t st = (hipStream_t)stream;
-    if (hidden_padded == 256) return nf::made_bwd_launch<1>(g_params, bits, g_x, G, blob, table, B, st);
-    return nf::made_bwd_launch<2>(g_params, bits, g_x, G, blob, table, B, st);
+    const int dp = (D + 31) / 32 * 32;
+    if (hidden_padded == 256) return nf::made_bwd_launch<1>(g_params, bits, g_x, G, blob, table, B, st, dp);
+    return nf::made_bwd_launch<2>(g_params, bits, g_x, G, blob, table, B, st, dp);
 }
 
 static int made_wgrad_chunk_rows(int64_t Bp, int ntiles) {
@@ -368,6 +415,18 @@ extern "C" int nf_made_wgrad(const void *gp_pad, const void *x_pad, const void *
     NF_CHECK_LAUNCH();
     hipLaunchKernelGGL(nf::made_wgrad_reduce_kernel, dim3(16, (unsigned)ntiles), dim3(256), 0, st, (const float *)part, (float *)grads,
                        (const unsigned char *)mask, (const int *)wtable, (const int *)stable, chunks);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// out (n) = flat[src (n)]: the packed weight streams of nf_made_forward_train / nf_made_backward from the current parameters.
+extern "C" int nf_pack_gather(const void *flat, const int32_t *src, void *out, int64_t n, nf_stream_t stream) {
+    if (n < 0) return NF_EINVAL;
+    if (n == 0) return NF_OK;
+    if (!flat || !src || !out) return NF_EFAULT;
+    if ((((uintptr_t)src) | ((uintptr_t)out)) & 15) return NF_EINVAL;
+    hipLaunchKernelGGL(nf::pack_gather_kernel, dim3(nf::grid_for((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, (const float *)flat,
+                       (const int *)src, (float *)out, n);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

@@ -55,6 +55,8 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = table[0], Dp = table[1], NB = table[5], NFB = table[7], nrounds = table[8], nitems = table[10];
     const int MD = table[12] ? table[12] : table[6] * D;       // raw output row length: mult D for a MADE, out_features for a ResidualNet
+    const int plain = table[13];     // 1: a plain MLP  x -> W0 -> relu -> W1 -> relu -> Wf  (NB = 1 without the block's second linear and
+                                     // its residual; EPI 1 / 3 only): the 3x3 -> 1x1 -> 3x3 conv conditioner over pixel rows (conv_rows.hip)
     const int *items = table + MF_HDR + w * nitems * 2;       // [nitems][nkg, rb]
     const float *stream = blob + table[16 + w];
     const int rbs[2] = {w, HRB - 1 - w};                      // (the packer's wave_items: the hidden row-blocks of this wave)
@@ -117,6 +119,7 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
                     mf_save_rows<NS, true>(stile + (size_t)(2 * b + 1) * Bp * HP, HP, nrows, rbs[s], sb0s[s], hh, n, t[s]);
                 }
             MF_BARRIER();
+            if (plain) break;            // (relu(t) is published: the final layer's input)
 #pragma unroll
             for (int s = 0; s < 2; ++s) mf_item<NS, true>(ring, items[2 * (4 + 4 * b + s)], acts + lane_b + 128 * sb0s[s], h[s]);
             if constexpr (EPI == 3)
@@ -125,10 +128,12 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
                     mf_save_rows<NS, true>(stile + (size_t)(2 * b + 2) * Bp * HP, HP, nrows, rbs[s], sb0s[s], hh, n, h[s]);
         }
         // ---- final layer on the RAW block output (:303-304) + epilogue -------------------------------------------------------------
-        MF_BARRIER();
+        if (!plain) {
+            MF_BARRIER();
 #pragma unroll
-        for (int s = 0; s < 2; ++s) mf_publish<NS, false>(acts, rbs[s], sb0s[s], hh, n, h[s]);
-        MF_BARRIER();
+            for (int s = 0; s < 2; ++s) mf_publish<NS, false>(acts, rbs[s], sb0s[s], hh, n, h[s]);
+            MF_BARRIER();
+        }
         if constexpr (EPI == 2) {
             const int G = NFB, nfi = nrounds;                 // (the header slots of the block variants: groups, final items per wave)
             const int *fit = items + 2 * (2 + 4 * NB);
@@ -271,10 +276,11 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
 
 template <int NSB, int EPI>
 static int made_fwd_launch(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, int64_t B, int acc, hipStream_t st,
-                           const RqsParams<float> &p = RqsParams<float>(), void *save = nullptr, void *bits = nullptr) {
+                           const RqsParams<float> &p = RqsParams<float>(), void *save = nullptr, void *bits = nullptr, int table_dp = 128) {
     const int64_t ntiles = (B + MF_ROWS - 1) / MF_ROWS;
     const int grid = (int)(ntiles < 256 ? ntiles : 256);        // persistent: one workgroup per CU (160 KB of LDS at Hp = 512)
-    const size_t lds = sizeof(float) * ((size_t)8 * NSB * 4 * 512 + MF_XFLOATS);
+    const int xfloats = table_dp > 128 ? 2 * MF_XFLOATS : MF_XFLOATS;       // x tile: 64 rows x Dp (<= 256 next to 256 hidden slots)
+    const size_t lds = sizeof(float) * ((size_t)8 * NSB * 4 * 512 + xfloats);
     static LdsOptIn opted;
     if (opt_in_lds(reinterpret_cast<const void *>(&made_fwd_kernel<NSB, EPI>), lds, opted) != NF_OK) return NF_ENOTSUP;
     hipLaunchKernelGGL((made_fwd_kernel<NSB, EPI>), dim3((unsigned)grid), dim3(64 * MF_NW), lds, st, (const float *)x, (float *)y,
@@ -286,8 +292,8 @@ static int made_fwd_launch(const void *x, void *y, void *logdet, const void *blo
 
 }  // namespace nf
 
-static int made_fwd_check(int64_t B, int D, int hidden_padded, int mult) {
-    if (B < 0 || D < 2 || D > 128 || mult < 1) return NF_EINVAL;
+static int made_fwd_check(int64_t B, int D, int hidden_padded, int mult, int dmax = 128) {
+    if (B < 0 || D < 2 || D > dmax || mult < 1) return NF_EINVAL;
     if (hidden_padded != 256 && hidden_padded != 512) return NF_ENOTSUP;
     return NF_OK;
 }
@@ -339,11 +345,12 @@ extern "C" int nf_made_forward_spline(const void *x, void *y, void *logdet, cons
 // up to 64; save: (2 num_blocks + 1) x Bp x hidden_padded floats; bits: (Bp / 64) x 2 num_blocks x 2 x 512 dwords.
 extern "C" int nf_made_forward_train(const void *x, void *params, void *save, void *bits, const void *blob, const int32_t *table,
                                      int64_t B, int D, int hidden_padded, int mult, nf_stream_t stream) {
-    const int rc = made_fwd_check(B, D, hidden_padded, mult);
+    const int rc = made_fwd_check(B, D, hidden_padded, mult, hidden_padded == 256 ? 256 : 128);   // (a 64 KB x tile fits next to 256 slots)
     if (rc != NF_OK) return rc;
     if (B == 0) return NF_OK;
     if (!x || !params || !save || !bits || !blob || !table) return NF_EFAULT;
     hipStream_t st = (hipStream_t)stream;
-    if (hidden_padded == 256) return nf::made_fwd_launch<1, 3>(x, params, nullptr, blob, table, B, NF_LD_WRITE, st, nf::RqsParams<float>(), save, bits);
-    return nf::made_fwd_launch<2, 3>(x, params, nullptr, blob, table, B, NF_LD_WRITE, st, nf::RqsParams<float>(), save, bits);
+    const int dp = (D + 31) / 32 * 32;
+    if (hidden_padded == 256) return nf::made_fwd_launch<1, 3>(x, params, nullptr, blob, table, B, NF_LD_WRITE, st, nf::RqsParams<float>(), save, bits, dp);
+    return nf::made_fwd_launch<2, 3>(x, params, nullptr, blob, table, B, NF_LD_WRITE, st, nf::RqsParams<float>(), save, bits, dp);
 }

@@ -6,6 +6,7 @@ sampling draws torch.randn on the device and evaluates the same closed form.
 """
 import numpy as np
 import torch
+from . import _keys
 from torch import nn
 
 from . import ops
@@ -115,7 +116,7 @@ class ClassCondDiagGaussian(BaseDistribution):
 
     def _rows(self):
         """(num_classes, d) copies of loc / log_scale."""
-        key = (self.loc.data_ptr(), self.loc._version, self.log_scale.data_ptr(), self.log_scale._version)
+        key = _keys.pkey((self.loc, self.log_scale))
         if self._rows_cache is None or self._rows_cache[0] != key:
             d = int(self.d)
             self._rows_cache = (key, self.loc.detach().reshape(d, self.num_classes).t().contiguous(),

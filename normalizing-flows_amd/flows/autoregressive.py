@@ -15,6 +15,7 @@ structures, float64 and gradient-tracking calls keep the reference's D-pass loop
 """
 import numpy as np
 import torch
+from .. import _keys
 from torch.nn import functional as F
 
 from .. import autograd, nets, ops
@@ -69,7 +70,7 @@ class MaskedAffineAutoregressive(Autoregressive):
 
     def _packed(self, device):
         """Device copies of the incremental-inverse pack, rebuilt when any MADE parameter changes."""
-        key = tuple((p.data_ptr(), p._version) for p in self.autoregressive_net.parameters()) + (str(device),)
+        key = _keys.pkey(self.autoregressive_net.parameters()) + (str(device),)
         cache = getattr(self, "_maf_pack_cache", None)
         if cache is None or cache[0] != key:
             packed = maf_pack.pack_made(self.autoregressive_net, blocks=(1, 2, 3))    # 1..3 residual blocks: nf_maf_inverse_h
@@ -153,7 +154,7 @@ class MaskedPiecewiseRationalQuadraticAutoregressive(Autoregressive):
 
     def _packed(self, device):
         """Device copies of the incremental-inverse pack (rows layout), rebuilt when any MADE parameter changes."""
-        key = tuple((p.data_ptr(), p._version) for p in self.autoregressive_net.parameters()) + (str(device),)
+        key = _keys.pkey(self.autoregressive_net.parameters()) + (str(device),)
         cache = getattr(self, "_arnsf_pack_cache", None)
         if cache is None or cache[0] != key:
             packed = maf_pack.pack_made(self.autoregressive_net, mult=self._output_dim_multiplier(), rows=True)

@@ -1,5 +1,6 @@
 """GlowBlock = [AffineCouplingBlock(ConvNet2d), Invertible1x1Conv, ActNorm] (normflows/flows/affine/glow.py:11-84)."""
 import torch
+from .. import _keys
 from torch import nn
 
 from .. import nets
@@ -45,7 +46,7 @@ class GlowBlock(Flow):
         if not an._init_known:
             return None
         params = [an.s, an.t] + ([conv.L, conv.U, conv.log_S] if conv.use_lu else [conv.W])
-        key = (inverse,) + tuple((p_.data_ptr(), p_._version) for p_ in params)
+        key = (inverse,) + _keys.pkey(params)
         cache = getattr(self, "_mix_cache", None)
         if cache is None or cache[0] != key:
             W, ldu = conv._weight(inverse)

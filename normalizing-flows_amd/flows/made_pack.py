@@ -86,9 +86,10 @@ def wave_items(NSB, NB, NFB):
     return out
 
 
-def _slot_layers(made, mult):
+def _slot_layers(made, mult, wb=None):
     """The MADE's masked linears in SLOT space (hidden units sorted by degree, zero-padded): dict with the sizes, `order` (slot ->
-    unit) and `layers` = [(W, M, b)] for the initial layer, the blocks' linears and the final layer; None outside the structure."""
+    unit) and `layers` = [(W, M, b)] for the initial layer, the blocks' linears and the final layer; None outside the structure.
+    wb: [(weight, bias)] arrays to rearrange instead of the module's parameters (index_arrays: the packs as gather indices)."""
     if not supported(made, mult):
         return None
     D = made.initial_layer.in_features
@@ -116,11 +117,18 @@ def _slot_layers(made, mult):
     slot_of = np.zeros(H, dtype=np.int64)
     slot_of[order] = np.arange(H)
 
+    all_lin = lin + [fin]
+
     def slots(lyr, in_map, in_size, out_rows, out_size):
         """Masked weight, mask and bias of `lyr` in slot space (rows -> out_rows, columns -> in_map)."""
-        w = (lyr.weight.detach() * lyr.mask).cpu().numpy().astype(np.float32)
         m = lyr.mask.cpu().numpy() != 0
-        b = lyr.bias.detach().cpu().numpy().astype(np.float32)
+        if wb is None:
+            w = (lyr.weight.detach() * lyr.mask).cpu().numpy().astype(np.float32)
+            b = lyr.bias.detach().cpu().numpy().astype(np.float32)
+        else:
+            k = [id(x) for x in all_lin].index(id(lyr))
+            w = (np.asarray(wb[k][0]) * m).astype(np.float32)
+            b = np.asarray(wb[k][1]).astype(np.float32)
         W = np.zeros((out_size, in_size), dtype=np.float32)
         M = np.zeros((out_size, in_size), dtype=bool)
         Bv = np.zeros(out_size, dtype=np.float32)
@@ -151,9 +159,9 @@ def resnet_supported(net):
     return 2 <= D <= MAX_D and 1 <= H <= 512 and MD >= 1 and net.initial_layer.weight.dtype == torch.float32
 
 
-def _dense_layers(net):
+def _dense_layers(net, wb=None):
     """A ResidualNet (nets/resnet.py:53-104: the same layer structure as MADE without masks) as slot-space layers for the MADE
-    kernels: identity unit order, every mask all ones (no block is skipped), out_features = MD."""
+    kernels: identity unit order, every mask all ones (no block is skipped), out_features = MD.  wb: as in _slot_layers."""
     if not resnet_supported(net):
         return None
     D, H, MD = net.initial_layer.in_features, net.initial_layer.out_features, net.final_layer.out_features
@@ -164,14 +172,14 @@ def _dense_layers(net):
     lin = [net.initial_layer] + [l for b in net.blocks for l in b.linear_layers] + [net.final_layer]
     sizes = [(Hp, Dp)] + [(Hp, Hp)] * (2 * NB) + [(NFB * ROWS, Hp)]
     layers = []
-    for l, (o, i) in zip(lin, sizes):
-        w = l.weight.detach().cpu().numpy().astype(np.float32)
+    for k, (l, (o, i)) in enumerate(zip(lin, sizes)):
+        w = (l.weight.detach().cpu().numpy() if wb is None else np.asarray(wb[k][0])).astype(np.float32)
         W = np.zeros((o, i), dtype=np.float32)
         M = np.zeros((o, i), dtype=bool)
         Bv = np.zeros(o, dtype=np.float32)
         W[:w.shape[0], :w.shape[1]] = w
         M[:w.shape[0], :w.shape[1]] = True
-        Bv[:w.shape[0]] = l.bias.detach().cpu().numpy().astype(np.float32)
+        Bv[:w.shape[0]] = (l.bias.detach().cpu().numpy() if wb is None else np.asarray(wb[k][1])).astype(np.float32)
         layers.append((W, M, Bv))
     return dict(D=D, H=H, NB=NB, Hp=Hp, NSB=Hp // 256, Dp=Dp, NFB=NFB, MD=MD, mult=1, order=np.arange(H), slot_of=np.arange(H),
                 layers=layers, masks=[np.ones(tuple(l.weight.shape), dtype=bool) for l in lin])
@@ -209,7 +217,7 @@ def _pack_forward_from(sl):
         hdr[16 + w] = off
         stream = []
         for i, (l, rb) in enumerate(items[w]):
-            if rb < 0:
+            if rb < 0 or layers[l] is None:          # (None: the block's second linear in plain-MLP mode)
                 tab[w, i] = (0, -1)
                 continue
             W, M, Bv = layers[l]
@@ -227,6 +235,7 @@ def _pack_forward_from(sl):
         off += stream.size
     hdr[:11] = [D, Dp, H, Hp, NSB, NB, mult, NFB, (NFB + 7) // 8, off, nitems]
     hdr[12] = sl["MD"]                                      # output row length (mult D for a MADE)
+    hdr[13] = 1 if sl.get("plain") else 0
     blob = np.concatenate(chunks).astype(np.float32)
     assert blob.size == off and off < 2 ** 31
     return blob, np.concatenate([hdr, tab.reshape(-1)]).astype(np.int32)
@@ -351,7 +360,9 @@ def _pack_backward_from(sl):
     MfT = np.zeros((Hp, NC * Hp), dtype=bool)
     WfT[:, :Wf.shape[0]] = Wf.T
     MfT[:, :Mf.shape[0]] = Mf.T
-    nitems = 2 * NC + 4 * NB + 1
+    plain = bool(sl.get("plain"))
+    nfin = (Dp // ROWS + 3) // 4                          # rounds of the last product (4 feature row-blocks x 2 sample blocks each)
+    nitems = 2 * NC + 4 * NB + nfin
     hdr = np.zeros(HDR, dtype=np.int32)
     tab = np.zeros((8, nitems, 4), dtype=np.int32)
     chunks, off = [], 0
@@ -366,26 +377,31 @@ def _pack_backward_from(sl):
                 i += 1
         for b in range(NB - 1, -1, -1):
             for l in (2 + 2 * b, 1 + 2 * b):             # W2 of the block, then its W1
-                W, M, _ = layers[l]
                 for rb in (w, HRB - 1 - w):
-                    nkg, kg0, st = _suffix_item(W.T, M.T, rb, 0, Hp)
-                    tab[w, i] = (nkg, rb, kg0, 0)
-                    stream += st
+                    if layers[l] is None:                # (plain-MLP mode: no second linear)
+                        tab[w, i] = (0, -1, 0, 0)
+                    else:
+                        nkg, kg0, st = _suffix_item(layers[l][0].T, layers[l][1].T, rb, 0, Hp)
+                        tab[w, i] = (nkg, rb, kg0, 0)
+                        stream += st
                     i += 1
         W0, M0, _ = layers[0]
-        rb = w & 3
-        if rb < Dp // ROWS:
-            nkg, kg0, st = _suffix_item(W0.T, M0.T, rb, 0, Hp)
-            tab[w, i] = (nkg, rb, kg0, 0)
-            stream += st
-        else:
-            tab[w, i] = (0, -1, 0, 0)
+        for rd in range(nfin):
+            rb = (w & 3) + 4 * rd
+            if rb < Dp // ROWS:
+                nkg, kg0, st = _suffix_item(W0.T, M0.T, rb, 0, Hp)
+                tab[w, i] = (nkg, rb, kg0, 0)
+                stream += st
+            else:
+                tab[w, i] = (0, -1, 0, 0)
+            i += 1
         stream = np.concatenate(stream)
         stream = np.concatenate([stream, np.resize(stream, RING * 256)])
         chunks.append(stream)
         off += stream.size
-    hdr[:11] = [D, Dp, H, Hp, NSB, NB, mult, NC, 0, off, nitems]
+    hdr[:11] = [D, Dp, H, Hp, NSB, NB, mult, NC, nfin, off, nitems]
     hdr[12] = MD
+    hdr[13] = 1 if plain else 0
     blob = np.concatenate(chunks).astype(np.float32)
     assert blob.size == off and off < 2 ** 31
     table = np.concatenate([hdr, tab.reshape(-1)]).astype(np.int32)
@@ -401,10 +417,14 @@ def _pack_backward_from(sl):
     out_map[:MD] = np.arange(MD)
     # (problem: dY base / matrix / ld, X base / matrix / ld, relu, slot-space mask [M x N], row map, column map, parameter shape)
     probs = [(2, 0, Hp, 1, 0, Dx, 0, layers[0][1], slot_to_unit, feat_map, (H, D))]
-    for b in range(NB):
-        probs.append((2, 2 * b + 1, Hp, 3, 2 * b, Hp, 1, layers[1 + 2 * b][1], slot_to_unit, slot_to_unit, (H, H)))
-        probs.append((2, 2 * b + 2, Hp, 3, 2 * b + 1, Hp, 1, layers[2 + 2 * b][1], slot_to_unit, slot_to_unit, (H, H)))
-    probs.append((0, 0, Mp, 3, 2 * NB, Hp, 0, layers[-1][1], out_map, slot_to_unit, (MD, H)))
+    if plain:      # x -> W0 -> relu -> W1 -> relu -> Wf: dW1 = G[1]^T relu(save[0]), dWf = g_p^T relu(save[1])
+        probs.append((2, 1, Hp, 3, 0, Hp, 1, layers[1][1], slot_to_unit, slot_to_unit, (H, H)))
+        probs.append((0, 0, Mp, 3, 1, Hp, 1, layers[-1][1], out_map, slot_to_unit, (MD, H)))
+    else:
+        for b in range(NB):
+            probs.append((2, 2 * b + 1, Hp, 3, 2 * b, Hp, 1, layers[1 + 2 * b][1], slot_to_unit, slot_to_unit, (H, H)))
+            probs.append((2, 2 * b + 2, Hp, 3, 2 * b + 1, Hp, 1, layers[2 + 2 * b][1], slot_to_unit, slot_to_unit, (H, H)))
+        probs.append((0, 0, Mp, 3, 2 * NB, Hp, 0, layers[-1][1], out_map, slot_to_unit, (MD, H)))
     ptab, tiles, stab, maps = [], [], [], []
     offsets, mask_parts, flat = [], [], 0
     map_off = 8 * len(probs)
@@ -434,3 +454,114 @@ def _pack_backward_from(sl):
     assert mask.size == flat and flat < 2 ** 31
     return dict(blob=blob, table=table, wtable=wtable.astype(np.int32), stable=stable, mask=mask, offsets=offsets, nflat=flat,
                 ntiles=len(tiles), Mp=Mp, Dx=Dx, Hp=Hp, NB=NB, mult=mult, MD=MD)
+
+
+# ---- plain MLP  x -> W0 -> relu -> W1 -> relu -> Wf  (the conv conditioner of GlowBlock over pixel rows, csrc/conv_rows.hip) -----------
+def _mlp_layers(W0, b0, W1, b1, Wf, bf):
+    """Slot-space layers of a two-hidden-layer ReLU MLP for the MADE kernels' plain mode (hdr[13] = 1): NB = 1 with the block's
+    second linear absent; D <= 256 inputs when the hidden width fits 256 slots (128 otherwise)."""
+    W0, W1, Wf = (np.asarray(a, dtype=np.float32) for a in (W0, W1, Wf))
+    H, D = W0.shape
+    MD = Wf.shape[0]
+    if W1.shape != (H, H) or Wf.shape[1] != H or not (1 <= H <= 512 and MD >= 1):
+        return None
+    Hp = 256 if H <= 256 else 512
+    if not (2 <= D <= (256 if Hp == 256 else MAX_D)):
+        return None
+    Dp = (D + 31) // 32 * 32
+    NFB = (MD + ROWS - 1) // ROWS
+
+    def pad(w, b, o, i):
+        W = np.zeros((o, i), dtype=np.float32)
+        M = np.zeros((o, i), dtype=bool)
+        Bv = np.zeros(o, dtype=np.float32)
+        W[:w.shape[0], :w.shape[1]] = w
+        M[:w.shape[0], :w.shape[1]] = True
+        if b is not None:
+            Bv[:w.shape[0]] = np.asarray(b, dtype=np.float32)
+        return W, M, Bv
+    layers = [pad(W0, b0, Hp, Dp), pad(W1, b1, Hp, Hp), None, pad(Wf, bf, NFB * ROWS, Hp)]
+    return dict(D=D, H=H, NB=1, Hp=Hp, NSB=Hp // 256, Dp=Dp, NFB=NFB, MD=MD, mult=1, order=np.arange(H), slot_of=np.arange(H),
+                layers=layers, masks=[np.ones(W0.shape, dtype=bool), np.ones(W1.shape, dtype=bool), np.ones(Wf.shape, dtype=bool)],
+                plain=True)
+
+
+def pack_mlp_forward(W0, b0, W1, b1, Wf, bf=None):
+    sl = _mlp_layers(W0, b0, W1, b1, Wf, bf)
+    return None if sl is None else _pack_forward_from(sl)
+
+
+def pack_mlp_backward(W0, b0, W1, b1, Wf, bf=None):
+    """pack_made_backward's dict for the plain MLP; offsets: (W0, b0), (W1, b1), (Wf, bf)."""
+    sl = _mlp_layers(W0, b0, W1, b1, Wf, bf)
+    return None if sl is None else _pack_backward_from(sl)
+
+
+# ---- the packs as GATHER INDICES (training: parameters change every step; the streams are rebuilt on the device) ------------------------
+def index_arrays(shapes):
+    """[(weight index array, bias index array)] for linears of the given (out, in) shapes over the flat parameter vector
+    [0, W_0.flatten(), b_0, W_1.flatten(), b_1, ...] (element 0 = the zero every padded / masked stream entry points at)."""
+    out, off = [], 1
+    for o, i in shapes:
+        w = off + np.arange(o * i, dtype=np.int64).reshape(o, i)
+        off += o * i
+        b = off + np.arange(o, dtype=np.int64)
+        off += o
+        out.append((w, b))
+    assert off < 2 ** 24          # (the packers move float32 arrays: indices stay exact)
+    return out
+
+
+def _as_src(blob):
+    src = np.rint(blob).astype(np.int32)
+    assert np.array_equal(src.astype(np.float32), blob)
+    return src
+
+
+def train_structure(sl_values, sl_index):
+    """The value-independent part of a network's training packs: tables + gather indices `src_fwd` / `src_bwd` (stream entry ->
+    position in the flat parameter vector of index_arrays) such that flat[src] reproduces the packed streams of the value packers."""
+    fwd_v = _pack_forward_from(sl_values)
+    fwd_i = _pack_forward_from(sl_index)
+    bwd = _pack_backward_from(sl_values)
+    bwd_i = _pack_backward_from(sl_index)
+    assert np.array_equal(fwd_v[1], fwd_i[1]) and np.array_equal(bwd["table"], bwd_i["table"])
+    bwd["src"] = _as_src(bwd_i["blob"])
+    return dict(table=fwd_v[1], src=_as_src(fwd_i[0]), hp=int(fwd_v[1][3]), bwd=bwd)
+
+
+def made_train_structure(made, mult):
+    sl = _slot_layers(made, mult)
+    if sl is None:
+        return None
+    lins = [made.initial_layer] + [l for b in made.blocks for l in b.linear_layers] + [made.final_layer]
+    return train_structure(sl, _slot_layers(made, mult, wb=index_arrays([tuple(l.weight.shape) for l in lins])))
+
+
+def resnet_train_structure(net):
+    sl = _dense_layers(net)
+    if sl is None:
+        return None
+    lins = [net.initial_layer] + [l for b in net.blocks for l in b.linear_layers] + [net.final_layer]
+    return train_structure(sl, _dense_layers(net, wb=index_arrays([tuple(l.weight.shape) for l in lins])))
+
+
+def convnet_train_structure(cin, hid, cout):
+    """3x3 -> 1x1 -> 3x3 conv conditioner over pixel rows (plain-MLP mode); flat vector = [0, conv1.weight, conv1.bias, conv2.weight,
+    conv2.bias, conv3.weight] flattened in their own layouts."""
+    o1 = 1
+    w1 = (o1 + np.arange(hid * cin * 9, dtype=np.int64)).reshape(hid, cin, 3, 3).transpose(0, 2, 3, 1).reshape(hid, 9 * cin)
+    ob1 = o1 + hid * cin * 9
+    b1 = ob1 + np.arange(hid, dtype=np.int64)
+    o2 = ob1 + hid
+    w2 = (o2 + np.arange(hid * hid, dtype=np.int64)).reshape(hid, hid)
+    ob2 = o2 + hid * hid
+    b2 = ob2 + np.arange(hid, dtype=np.int64)
+    o3 = ob2 + hid
+    w3 = (o3 + np.arange(cout * hid * 9, dtype=np.int64)).reshape(cout, hid, 3, 3).transpose(2, 3, 0, 1).reshape(9 * cout, hid)
+    assert o3 + cout * hid * 9 < 2 ** 24
+    ones = lambda a: np.ones(a.shape, dtype=np.float32)
+    sl_v = _mlp_layers(ones(w1), ones(b1), ones(w2), ones(b2), ones(w3), None)
+    if sl_v is None:
+        return None
+    return train_structure(sl_v, _mlp_layers(w1, b1, w2, b2, w3, None))

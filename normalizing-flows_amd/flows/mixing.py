@@ -8,6 +8,7 @@ nf_inv1x1_assemble and nf_inv1x1_conv.
 """
 import numpy as np
 import torch
+from .. import _keys
 from torch import nn
 from torch.nn import init
 
@@ -79,7 +80,7 @@ class Invertible1x1Conv(Flow):
         """W and the per-pixel log|det| (0-dim) for flow.inverse (inverse_dir=True) or flow.forward.  The assembled
         matrix is kept until a parameter changes: the reference re-assembles (and re-inverts) it on every call."""
         if self.use_lu:
-            key = (inverse_dir,) + tuple((t.data_ptr(), t._version) for t in (self.L, self.U, self.log_S, self.P))
+            key = (inverse_dir,) + _keys.pkey((self.L, self.U, self.log_S, self.P))
             cache = getattr(self, "_w_cache", None)
             if cache is None or cache[0] != key:
                 cache = (key, ops.inv1x1_assemble(self.P, self.L.detach(), self.U.detach(), self.sign_S,
@@ -162,7 +163,7 @@ class InvertibleAffine(Flow):
 
     def _weight_t(self, inverse_dir):
         params = (self.L, self.U, self.log_S, self.P) if self.use_lu else (self.W,)
-        key = (inverse_dir,) + tuple((t.data_ptr(), t._version) for t in params)
+        key = (inverse_dir,) + _keys.pkey(params)
         cache = getattr(self, "_w_cache", None)
         if cache is None or cache[0] != key:
             if self.use_lu:
@@ -316,7 +317,7 @@ class LULinearPermute(Flow):
             # D x D matrices are composed in float64 by a handful of torch launches once per parameter version (the one-workgroup
             # composer keeps four D x D fp64 matrices in LDS: 64 x 64 at most)
             params = (lin.lower_entries, lin.upper_entries, lin.unconstrained_upper_diag, lin.bias)
-            key = tuple((p_.data_ptr(), p_._version) for p_ in params)
+            key = _keys.pkey(params)
             cache = self.__dict__.get("_dense_cache")
             if cache is None or cache[0] != key:
                 cache = self._dense_cache = (key, self._compose_wide())
@@ -328,7 +329,7 @@ class LULinearPermute(Flow):
             # the layer as ONE dense D x D product on fp32 MFMA (nf_lu_compose once per parameter version + nf_rows_matvec_affine):
             # HBM-bound, 5x the LDS-tile kernel below, which stays for D > 64 and float64
             params = (lin.lower_entries, lin.upper_entries, lin.unconstrained_upper_diag, lin.bias)
-            key = tuple((p_.data_ptr(), p_._version) for p_ in params)
+            key = _keys.pkey(params)
             cache = self.__dict__.get("_dense_cache")
             if cache is None or cache[0] != key:
                 cache = self._dense_cache = (key, ops.lu_compose(self.permutation._permutation, *[p_.detach() for p_ in params],
@@ -347,7 +348,7 @@ class LULinearPermute(Flow):
         y = Ws x + bias_s (the dense form of mixing.py:402-473, :535-563 used by nf_rows_matvec_affine and by the fused pair kernels)."""
         lin = self.linear
         params = (lin.lower_entries, lin.upper_entries, lin.unconstrained_upper_diag, lin.bias)
-        key = tuple((p_.data_ptr(), p_._version) for p_ in params)
+        key = _keys.pkey(params)
         cache = self.__dict__.get("_dense_cache")
         if cache is None or cache[0] != key:
             if lin.features <= 64:

@@ -14,6 +14,7 @@ import warnings
 
 import numpy as np
 import torch
+from .. import _keys
 from torch import nn
 
 from .. import _lib as L
@@ -338,7 +339,7 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
         if lu is not None:
             lin = lu.linear
             tensors = tensors + [lin.lower_entries, lin.upper_entries, lin.unconstrained_upper_diag, lin.bias]
-        key = tuple((t.data_ptr(), t._version) for t in tensors) + (str(inputs.device),)
+        key = _keys.pkey(tensors) + (str(inputs.device),)
         caches = self.__dict__.setdefault("_wide_cache", {})
         slot = (id(lu), direction) if lu is not None else None
         cache = caches.get(slot)
@@ -682,12 +683,12 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
                 tensors += [lin.weight, lin.bias]
         tensors += [net.final_layer.weight, net.final_layer.bias, u.unnormalized_widths, u.unnormalized_heights,
                     u.unnormalized_derivatives]
-        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        key = _keys.pkey(tensors)
         if lu is not None:
             lin = lu.linear
             lu_t = [lu.permutation._permutation, lin.lower_entries, lin.upper_entries, lin.unconstrained_upper_diag,
                     lin.bias]
-            key = key + tuple((t.data_ptr(), t._version) for t in lu_t) + (lin.eps,)
+            key = key + _keys.pkey(lu_t) + (lin.eps,)
         if self._fused_cache is None or self._fused_cache[0] != key:
             d = [t.detach() for t in tensors]
             nb = len(net.blocks)

@@ -7,6 +7,7 @@ GEMMs / convolutions through torch (rocBLAS / hipBLASLt / MIOpen); the NSF coupl
 ResidualNet.forward and feeds the same weights to the hand-written fused MFMA kernel when the shape allows.
 """
 import torch
+from . import _keys
 from torch import nn
 from torch.nn import functional as F, init
 
@@ -56,6 +57,31 @@ class ResidualBlock(nn.Module):
         return inputs + temps
 
 
+def _train_packs_from(module, build, params, device, skey=()):
+    """(forward pack, backward pack) for autograd.MadeFn / ConvNetFn: the value-independent structure (tables, gather indices:
+    flows/made_pack.train_structure) is built once per module and device; the weight streams are gathered on the device from the
+    parameters as they are in THIS call (nf_pack_gather) -- under autograd they change every step."""
+    st = module.__dict__.get("_train_struct")
+    skey = (str(device),) + tuple(skey)             # (skey: what the structure itself depends on, e.g. MADE's mask buffers)
+    if st is None or st[0] != skey:
+        struct = build()
+        if struct is not None:
+            bwd = struct["bwd"]
+            for k in ("table", "wtable", "stable", "mask", "src"):
+                bwd[k] = torch.from_numpy(bwd[k]).to(device)
+            bwd.pop("blob", None)
+            struct["table"] = torch.from_numpy(struct["table"]).to(device)
+            struct["src"] = torch.from_numpy(struct["src"]).to(device)
+        st = module.__dict__["_train_struct"] = (skey, struct)
+    struct = st[1]
+    if struct is None:
+        return None
+    from . import ops
+    bwd = dict(struct["bwd"])
+    bwd["blob"] = ops.pack_gather(params, bwd["src"])
+    return (ops.pack_gather(params, struct["src"]), struct["table"], struct["hp"]), bwd
+
+
 class ResidualNet(nn.Module):
     """initial Linear -> num_blocks ResidualBlocks -> final Linear (resnet.py:53-104)."""
 
@@ -79,21 +105,11 @@ class ResidualNet(nn.Module):
         self.use_batch_norm = use_batch_norm
 
     def _train_packs(self, device):
-        """Device copies of (forward, backward) packs for the MADE training kernels (flows/made_pack.pack_resnet_*), rebuilt when a
-        parameter changes; None outside their structure."""
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (str(device),)
-        cache = self.__dict__.get("_train_pack_cache")
-        if cache is None or cache[0] != key:
-            from .flows import made_pack
-            packs = None
-            fwd = made_pack.pack_resnet_forward(self)
-            bwd = made_pack.pack_resnet_backward(self) if fwd is not None else None
-            if bwd is not None:
-                for k in ("blob", "table", "wtable", "stable", "mask"):
-                    bwd[k] = torch.from_numpy(bwd[k]).to(device)
-                packs = ((torch.from_numpy(fwd[0]).to(device), torch.from_numpy(fwd[1]).to(device), int(fwd[1][3])), bwd)
-            cache = self.__dict__["_train_pack_cache"] = (key, packs)
-        return cache[1]
+        """Packs for the MADE training kernels (dense); None outside their structure."""
+        from .flows import made_pack
+        lins = [self.initial_layer] + [l for b in self.blocks for l in b.linear_layers] + [self.final_layer]
+        return _train_packs_from(self, lambda: made_pack.resnet_train_structure(self), [t for l in lins for t in (l.weight, l.bias)],
+                                 device)
 
     def forward(self, inputs, context=None):
         # hidden widths beyond the 128-column training kernels (ResidualBlockFn, autograd.linear) under autograd: the whole net's
@@ -259,7 +275,38 @@ class ConvNet2d(nn.Module):
                 from . import ops
                 return ops.glow_convnet(x, fused[0], self.net[-1].out_channels, self.net[1].negative_slope, fused[1])
             return self._forward_inference(x)
+        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4:
+            packs = self._train_packs(x.device)
+            if packs is not None:
+                from . import autograd
+                c1, c2, c3 = self.net[0], self.net[2], self.net[4]
+                return autograd.ConvNetFn.apply(packs[0], packs[1], x, c1.weight, c1.bias, c2.weight, c2.bias, c3.weight, c3.bias)
         return self.net(x)
+
+    def _train_packs(self, device):
+        """Device copies of the plain-MLP packs (flows/made_pack.pack_mlp_*) of the 3x3 -> 1x1 -> 3x3 ReLU network for the MADE training
+        kernels (autograd.ConvNetFn), rebuilt when a parameter changes; None for any other structure (then the library path)."""
+        from . import config
+        mods = list(self.net)
+        if not (config.made_train and config.made_fused) or len(mods) != 5:
+            return None
+        c1, a1, c2, a2, c3 = mods
+        if not (isinstance(c1, nn.Conv2d) and isinstance(c2, nn.Conv2d) and isinstance(c3, nn.Conv2d)
+                and isinstance(a1, nn.LeakyReLU) and isinstance(a2, nn.LeakyReLU)):
+            return None
+        if (c1.kernel_size, c2.kernel_size, c3.kernel_size) != ((3, 3), (1, 1), (3, 3)) or any(c.bias is None for c in (c1, c2, c3)):
+            return None
+        if a1.negative_slope != 0.0 or a2.negative_slope != 0.0 or c1.weight.dtype != torch.float32:
+            return None
+        if any(c.padding != (k // 2, k // 2) or c.stride != (1, 1) or c.dilation != (1, 1) or c.groups != 1
+               for c, k in ((c1, 3), (c2, 1), (c3, 3))):
+            return None
+        hid, cin, cout = c1.out_channels, c1.in_channels, c3.out_channels
+        if not (c2.in_channels == hid and c2.out_channels == hid and c3.in_channels == hid):
+            return None
+        from .flows import made_pack
+        return _train_packs_from(self, lambda: made_pack.convnet_train_structure(cin, hid, cout),
+                                 [c1.weight, c1.bias, c2.weight, c2.bias, c3.weight], device)
 
     # below this many pixels per call the library path stays (the one-launch kernels are built for full-chip batches)
     FUSED_MIN_PIXELS = 2048
@@ -304,7 +351,7 @@ class ConvNet2d(nn.Module):
         if layout is None or (layout == ops.GLOW_CONV_WIDE and B * H * W < self.FUSED_WIDE_MIN_PIXELS):
             return None
         params = [c1.weight, c1.bias, c2.weight, c2.bias, c3.weight, c3.bias]
-        key = tuple((p_.data_ptr(), p_._version) for p_ in params)
+        key = _keys.pkey(params)
         cache = self.__dict__.setdefault("_gc_cache", {})
         hit = cache.get(layout)
         if hit is None or hit[0] != key:
@@ -406,7 +453,7 @@ class MaskedLinear(nn.Linear):
     def masked_weight(self):
         if torch.is_grad_enabled() and self.weight.requires_grad:
             return self.weight * self.mask
-        key = (self.weight.data_ptr(), self.weight._version, self.mask.data_ptr())
+        key = _keys.pkey((self.weight,)) + (self.mask.data_ptr(),)
         if self._masked_cache is None or self._masked_cache[0] != key:
             self._masked_cache = (key, (self.weight.detach() * self.mask).contiguous())
         return self._masked_cache[1]
@@ -523,7 +570,7 @@ class MADE(nn.Module):
         from . import config
         if not config.made_fused:
             return None
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (str(device),)
+        key = _keys.pkey(self.parameters()) + (str(device),)
         caches = self.__dict__.setdefault("_fwd_pack_cache", {})
         if not isinstance(caches, dict):
             caches = self.__dict__["_fwd_pack_cache"] = {}
@@ -538,20 +585,6 @@ class MADE(nn.Module):
             cache = caches[bool(spline)] = (key, packed)
         return cache[1]
 
-    def packed_backward(self, device):
-        """Device copies of the backward tables (flows/made_pack.pack_made_backward), rebuilt when a parameter changes."""
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (str(device),)
-        cache = self.__dict__.get("_bwd_pack_cache")
-        if cache is None or cache[0] != key:
-            from .flows import made_pack
-            mult = self.final_layer.out_features // self.initial_layer.in_features
-            packed = made_pack.pack_made_backward(self, mult)
-            if packed is not None:
-                for k in ("blob", "table", "wtable", "stable", "mask"):
-                    packed[k] = torch.from_numpy(packed[k]).to(device)
-            cache = self.__dict__["_bwd_pack_cache"] = (key, packed)
-        return cache[1]
-
     def _linears(self):
         return [self.initial_layer] + [l for b in self.blocks for l in b.linear_layers] + [self.final_layer]
 
@@ -559,16 +592,19 @@ class MADE(nn.Module):
         if context is None and inputs.dim() == 2 and inputs.dtype == torch.float32 and inputs.is_cuda:
             from . import config
             grad = torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters()))
-            packed = self.packed_forward(inputs.device) if (not grad or config.made_train) else None
+            packed = self.packed_forward(inputs.device) if not grad else (True if (config.made_train and config.made_fused) else None)
             if packed is not None and not grad:          # nf_made_forward: the whole network as one launch
                 from . import ops
                 return ops.made_forward(inputs, packed[0], packed[1], packed[2], packed[3])
             if packed is not None:                       # under autograd: hand-written backward (csrc/made_bwd.hip)
-                bwd = self.packed_backward(inputs.device)
-                if bwd is not None:
+                from .flows import made_pack
+                plist = [t for l in self._linears() for t in (l.weight, l.bias)]
+                mult = self.final_layer.out_features // self.initial_layer.in_features
+                packs = _train_packs_from(self, lambda: made_pack.made_train_structure(self, mult), plist, inputs.device,
+                                          skey=tuple((l.mask.data_ptr(), l.mask._version) for l in self._linears()))
+                if packs is not None:
                     from . import autograd
-                    plist = [t for l in self._linears() for t in (l.weight, l.bias)]
-                    return autograd.MadeFn.apply(packed, bwd, inputs, *plist)
+                    return autograd.MadeFn.apply(packs[0], packs[1], inputs, *plist)
         outputs = self.initial_layer(self.preprocessing(inputs))
         if context is not None:
             outputs = outputs + self.context_layer(context)

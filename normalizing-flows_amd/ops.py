@@ -749,6 +749,35 @@ def maf_affine(x, params, direction, logdet=None, acc=None, want_logdet=True):
     return y, logdet
 
 
+def conv3x3_gather(x, flip=False):
+    """col (B H W, 9 C) of an NCHW float32 tensor: col[r][tap C + c] = x[b][c][y + dy][x + dx] (nf_conv3x3_gather); flip negates the
+    offsets."""
+    L.require_device(x)
+    if x.dtype != torch.float32 or x.dim() != 4:
+        raise NotImplementedError("conv3x3_gather: (B, C, H, W) float32")
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    col = torch.empty(B * H * W, 9 * C, dtype=x.dtype, device=x.device)
+    rc = L.lib().nf_conv3x3_gather(ptr(x), ptr(col), i64(B), i32(C), i32(H), i32(W), i32(9 * C), i32(1 if flip else 0), L.stream())
+    L.check(rc, "nf_conv3x3_gather")
+    return col
+
+
+def conv3x3_gather_sum(P, bias, shape, flip=False):
+    """(B, C, H, W) from per-pixel tap products P (B H W, 9 C): out[b][c][y][x] = bias[c] + sum_tap P[(b, y + dy, x + dx)][tap C + c]
+    (nf_conv3x3_gather_sum); flip negates the offsets."""
+    L.require_device(P, bias)
+    B, C, H, W = shape
+    P = P.contiguous()
+    if P.dtype != torch.float32 or tuple(P.shape) != (B * H * W, 9 * C):
+        raise ValueError("conv3x3_gather_sum: P must be (B H W, 9 C) float32")
+    out = torch.empty(B, C, H, W, dtype=P.dtype, device=P.device)
+    rc = L.lib().nf_conv3x3_gather_sum(ptr(P), ptr(None if bias is None else bias.contiguous()), ptr(out), i64(B), i32(C), i32(H),
+                                       i32(W), i32(9 * C), i32(1 if flip else 0), L.stream())
+    L.check(rc, "nf_conv3x3_gather_sum")
+    return out
+
+
 def maf_affine_bwd(x, params, gy, gld, direction):
     """Backward of maf_affine (nf_maf_affine_bwd): (g_x (B, D), g_params shaped like params); gy / gld may be None."""
     L.require_device(x, params)
@@ -907,6 +936,16 @@ def made_forward(x, blob, table, hidden_padded, mult):
                                  L.stream())
     L.check(rc, "nf_made_forward")
     return params
+
+
+def pack_gather(params, src):
+    """The packed weight streams from the current parameters (nf_pack_gather): flat = [0, params flattened ...], out = flat[src]."""
+    L.require_device(src, *params)
+    flat = torch.cat([torch.zeros(1, dtype=torch.float32, device=src.device)] + [p.detach().reshape(-1) for p in params])
+    out = torch.empty(src.numel(), dtype=torch.float32, device=src.device)
+    rc = L.lib().nf_pack_gather(ptr(flat), ptr(src), ptr(out), i64(src.numel()), L.stream())
+    L.check(rc, "nf_pack_gather")
+    return out
 
 
 def made_forward_train(x, blob, table, hidden_padded, out_features, num_blocks):

@@ -32,8 +32,9 @@ def slot_forward(layers, NB, x, Dp):
 def emulate_chain(pack, gp, S):
     """(g_x (B, D), G[l] (B, Hp)) as made_bwd_kernel computes them; S = slot-space pre-activations (their signs = the forward's bits)."""
     blob, table = pack["blob"].astype(np.float64), pack["table"]
-    D, Dp, H, Hp, NSB, NB, mult, NC, _, total, nitems = [int(v) for v in table[:11]]
-    assert blob.size == total and nitems == 2 * NC + 4 * NB + 1
+    D, Dp, H, Hp, NSB, NB, mult, NC, nfin, total, nitems = [int(v) for v in table[:11]]
+    plain = bool(table[13])
+    assert blob.size == total and nitems == 2 * NC + 4 * NB + nfin and nfin == (Dp // 32 + 3) // 4
     tab = table[HDR:HDR + 8 * nitems * 4].reshape(8, nitems, 4)
     B = gp.shape[0]
     MD = int(table[12]) if table[12] else mult * D
@@ -71,7 +72,13 @@ def emulate_chain(pack, gp, S):
     for c in range(NC):
         gh = gh + layer(2 * c, gpp[:, c * Hp:(c + 1) * Hp])
     G[2 * NB] = gh
-    for k, b in enumerate(range(NB - 1, -1, -1)):
+    if plain:
+        assert NB == 1 and (tab[:, 2 * NC:2 * NC + 2, 1] == -1).all()
+        gt = gh * (S[1] > 0)
+        G[1] = gt
+        gh = layer(2 * NC + 2, gt) * (S[0] > 0)
+        G[0] = gh
+    for k, b in enumerate(range(NB - 1, -1, -1) if not plain else ()):
         i0 = 2 * NC + 4 * k
         gt = layer(i0, gh) * (S[2 * b + 1] > 0)
         G[2 * b + 1] = gt
@@ -80,13 +87,14 @@ def emulate_chain(pack, gp, S):
     gx = np.full((B, Dp), np.nan)
     seen = {}
     for w in range(8):
-        rb, acc = item(w, nitems - 1, gh)
-        if rb >= 0:
-            assert rb == (w & 3)
-            if rb in seen:
-                assert np.array_equal(seen[rb], acc)       # the two sample blocks' waves hold the same weights
-            seen[rb] = acc
-            gx[:, rb * ROWS:(rb + 1) * ROWS] = acc
+        for rd in range(nfin):
+            rb, acc = item(w, nitems - nfin + rd, gh)
+            if rb >= 0:
+                assert rb == (w & 3) + 4 * rd
+                if rb in seen:
+                    assert np.array_equal(seen[rb], acc)       # the two sample blocks' waves hold the same weights
+                seen[rb] = acc
+                gx[:, rb * ROWS:(rb + 1) * ROWS] = acc
     assert not np.isnan(gx).any()
     for w in range(8):
         assert np.array_equal(blob[pos[w]:pos[w] + RING * 256], np.resize(blob[start[w]:pos[w]], RING * 256)), w

@@ -53,8 +53,13 @@ def emulate_forward(blob, table, x):
         return out
 
     h = hidden_layer(0, xin)                                 # initial layer: raw h0
+    plain = bool(table[13])
     for b in range(NB):                                      # nets/made.py:196-214
         t = hidden_layer(1 + 2 * b, np.maximum(h, 0.0))
+        if plain:                                            # x -> W0 -> relu -> W1 -> relu -> Wf: the final layer sees relu(t)
+            assert NB == 1 and (tab[:, 4:6, 1] == -1).all()
+            h = np.maximum(t, 0.0)
+            break
         h = h + hidden_layer(2 + 2 * b, np.maximum(t, 0.0))
     out = np.full((B, NFB * ROWS), np.nan)
     for r in range(nrounds):                                 # the final layer sees the raw block output (:303-304)
