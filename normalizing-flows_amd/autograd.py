@@ -782,8 +782,9 @@ class ConvNetFn(torch.autograd.Function):
     def forward(ctx, fwd, bwd, x, w1, b1, w2, b2, w3, b3):
         B, Cin, H, W = x.shape
         Cout = w3.shape[0]
-        col = ops.conv3x3_gather(x)
-        P, save, bits = ops.made_forward_train(col, fwd[0], fwd[1], fwd[2], 9 * Cout, 1)
+        R = B * H * W
+        col = ops.conv3x3_gather(x, ld=bwd["Dx"])                 # (R up to 64, 9 Cin up to 128): also the weight gradient's operand
+        P, save, bits = ops.made_forward_train(col, fwd[0], fwd[1], fwd[2], 9 * Cout, 1, rows=R, features=9 * Cin)
         out = ops.conv3x3_gather_sum(P, b3.detach(), (B, Cout, H, W))
         ctx.save_for_backward(col, save, bits)
         ctx.bwd, ctx.shape = bwd, (B, Cin, H, W)
@@ -795,14 +796,16 @@ class ConvNetFn(torch.autograd.Function):
         col, save, bits = ctx.saved_tensors
         bwd = ctx.bwd
         B, Cin, H, W = ctx.shape
+        hid, Cout = ctx.wshapes[0][0], ctx.wshapes[2][0]
+        R = B * H * W
         gout = gout.contiguous()
-        gP = ops.conv3x3_gather(gout, flip=True)
-        gcol, G = ops.made_backward(gP, bits, bwd["blob"], bwd["table"], col.shape[1], bwd["Hp"], 1)
+        gP = ops.conv3x3_gather(gout, flip=True, ld=bwd["Mp"])
+        gcol, G = ops.made_backward(gP, bits, bwd["blob"], bwd["table"], 9 * Cin, bwd["Hp"], 1, rows=R, out_features=9 * Cout,
+                                    ld_out=bwd["Dx"])
         gx = ops.conv3x3_gather_sum(gcol, None, (B, Cin, H, W), flip=True) if ctx.needs_input_grad[2] else None
         flat = ops.made_wgrad(gP, col, G, save, bwd["wtable"], bwd["stable"], bwd["mask"], bwd["ntiles"], bwd["nflat"], bwd["Mp"],
-                              bwd["Dx"])
+                              bwd["Dx"], rows=R)
         (o0, s0, c0, n0), (o1, s1, c1, n1), (o2, s2, _, _) = bwd["offsets"]
-        hid, Cout = ctx.wshapes[0][0], ctx.wshapes[2][0]
         gw1 = flat[o0:o0 + s0[0] * s0[1]].view(hid, 3, 3, Cin).permute(0, 3, 1, 2)
         gw2 = flat[o1:o1 + s1[0] * s1[1]].view(hid, hid, 1, 1)
         gw3 = flat[o2:o2 + s2[0] * s2[1]].view(3, 3, Cout, hid).permute(2, 3, 0, 1)

@@ -37,6 +37,7 @@ made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits,
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = table[0], NB = table[5], NC = table[7], nitems = table[10];
     const int MD = table[12] ? table[12] : table[6] * D;       // row length of g_params
+    const int ldg = table[14] ? table[14] : MD, ldgx = table[15] ? table[15] : D;      // row strides of g_params / g_x (conv path: padded)
     const int plain = table[13];                               // plain MLP (made_fwd.hip): g_t = (Wf^T g_p).[t>0]; g_h = (W1^T g_t).[h>0]
     const int nfin = table[8] > 0 ? table[8] : 1;              // rounds of the last product: 4 feature row-blocks x 2 sample blocks each
     const int *items = table + MF_HDR + w * nitems * 4;       // [nitems][nkg, rb, kg0, -]
@@ -66,7 +67,7 @@ made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits,
             MF_BARRIER();
             {
                 const int r = tid & 63, cg = tid >> 6;
-                const float *gr = gp + (row0 + r) * MD;
+                const float *gr = gp + (row0 + r) * ldg;
                 for (int c4 = cg; c4 < HP / 4; c4 += MF_NW) {
                     const int col = c * HP + 4 * c4;
                     f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -171,7 +172,7 @@ made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits,
         MF_BARRIER();
         {
             const int r = tid & 63, cg = tid >> 6;
-            float *xr = gx + (row0 + r) * D;
+            float *xr = gx + (row0 + r) * ldgx;
             if (r < nrows)
                 for (int c = cg; 4 * c < D; c += MF_NW) {
                     const f32x4 v = *reinterpret_cast<const f32x4 *>(xreg + ((size_t)c * 64 + r) * 4);
@@ -380,7 +381,7 @@ static int made_wgrad_chunk_rows(int64_t Bp, int ntiles) {
     if (want < 1) want = 1;
     int64_t rows = (Bp + want - 1) / want;
     rows = (rows + 63) / 64 * 64;
-    if (rows < 256) rows = 256;
+    if (rows < 1024) rows = 1024;        // (few tiles: short chunks only multiply the partial-tile traffic and the ring's ramp)
     return (int)rows;
 }
 

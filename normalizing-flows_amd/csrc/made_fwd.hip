@@ -55,6 +55,7 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = table[0], Dp = table[1], NB = table[5], NFB = table[7], nrounds = table[8], nitems = table[10];
     const int MD = table[12] ? table[12] : table[6] * D;       // raw output row length: mult D for a MADE, out_features for a ResidualNet
+    const int ldx = table[14] ? table[14] : D;                 // row stride of x (the conv path hands over 128-padded rows)
     const int plain = table[13];     // 1: a plain MLP  x -> W0 -> relu -> W1 -> relu -> Wf  (NB = 1 without the block's second linear and
                                      // its residual; EPI 1 / 3 only): the 3x3 -> 1x1 -> 3x3 conv conditioner over pixel rows (conv_rows.hip)
     const int *items = table + MF_HDR + w * nitems * 2;       // [nitems][nkg, rb]
@@ -73,7 +74,7 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
         // ---- x tile -> LDS (B-operand order; rows beyond the batch and features beyond D are zero) ---------------------------------
         {
             const int r = tid & 63, cg = tid >> 6;
-            const float *xr = x + (row0 + r) * D;
+            const float *xr = x + (row0 + r) * ldx;
             for (int c = cg; c < Dp / 4; c += MF_NW) {
                 f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (r < nrows && 4 * c < D) {           // (Dp rounds D up to 32: the last chunks may lie wholly beyond the row)

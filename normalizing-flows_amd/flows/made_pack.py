@@ -518,7 +518,7 @@ def _as_src(blob):
     return src
 
 
-def train_structure(sl_values, sl_index):
+def train_structure(sl_values, sl_index, padded_rows=False):
     """The value-independent part of a network's training packs: tables + gather indices `src_fwd` / `src_bwd` (stream entry ->
     position in the flat parameter vector of index_arrays) such that flat[src] reproduces the packed streams of the value packers."""
     fwd_v = _pack_forward_from(sl_values)
@@ -527,6 +527,9 @@ def train_structure(sl_values, sl_index):
     bwd_i = _pack_backward_from(sl_index)
     assert np.array_equal(fwd_v[1], fwd_i[1]) and np.array_equal(bwd["table"], bwd_i["table"])
     bwd["src"] = _as_src(bwd_i["blob"])
+    if padded_rows:      # x, g_params and g_x live in rows padded to the weight-gradient tiles (hdr[14], hdr[15]: row strides)
+        fwd_v[1][14] = bwd["Dx"]
+        bwd["table"][14], bwd["table"][15] = bwd["Mp"], bwd["Dx"]
     return dict(table=fwd_v[1], src=_as_src(fwd_i[0]), hp=int(fwd_v[1][3]), bwd=bwd)
 
 
@@ -564,4 +567,4 @@ def convnet_train_structure(cin, hid, cout):
     sl_v = _mlp_layers(ones(w1), ones(b1), ones(w2), ones(b2), ones(w3), None)
     if sl_v is None:
         return None
-    return train_structure(sl_v, _mlp_layers(w1, b1, w2, b2, w3, None))
+    return train_structure(sl_v, _mlp_layers(w1, b1, w2, b2, w3, None), padded_rows=True)

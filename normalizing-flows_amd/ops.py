@@ -749,16 +749,23 @@ def maf_affine(x, params, direction, logdet=None, acc=None, want_logdet=True):
     return y, logdet
 
 
-def conv3x3_gather(x, flip=False):
+def conv3x3_gather(x, flip=False, ld=None):
     """col (B H W, 9 C) of an NCHW float32 tensor: col[r][tap C + c] = x[b][c][y + dy][x + dx] (nf_conv3x3_gather); flip negates the
-    offsets."""
+    offsets.  ld: row length of the returned buffer (>= 9 C; rows rounded up to 64: the layout the MADE training kernels' weight
+    gradients read directly) -- columns beyond 9 C are not written, rows beyond B H W are zero."""
     L.require_device(x)
     if x.dtype != torch.float32 or x.dim() != 4:
         raise NotImplementedError("conv3x3_gather: (B, C, H, W) float32")
     x = x.contiguous()
     B, C, H, W = x.shape
-    col = torch.empty(B * H * W, 9 * C, dtype=x.dtype, device=x.device)
-    rc = L.lib().nf_conv3x3_gather(ptr(x), ptr(col), i64(B), i32(C), i32(H), i32(W), i32(9 * C), i32(1 if flip else 0), L.stream())
+    R = B * H * W
+    if ld is None:
+        col = torch.empty(R, 9 * C, dtype=x.dtype, device=x.device)
+    else:
+        Rp = (R + 63) // 64 * 64
+        col = (torch.empty if Rp == R else torch.zeros)(Rp, ld, dtype=x.dtype, device=x.device)
+    rc = L.lib().nf_conv3x3_gather(ptr(x), ptr(col), i64(B), i32(C), i32(H), i32(W), i32(col.shape[1]), i32(1 if flip else 0),
+                                   L.stream())
     L.check(rc, "nf_conv3x3_gather")
     return col
 
@@ -769,11 +776,11 @@ def conv3x3_gather_sum(P, bias, shape, flip=False):
     L.require_device(P, bias)
     B, C, H, W = shape
     P = P.contiguous()
-    if P.dtype != torch.float32 or tuple(P.shape) != (B * H * W, 9 * C):
-        raise ValueError("conv3x3_gather_sum: P must be (B H W, 9 C) float32")
+    if P.dtype != torch.float32 or P.dim() != 2 or P.shape[0] < B * H * W or P.shape[1] < 9 * C:
+        raise ValueError("conv3x3_gather_sum: P must be (>= B H W, >= 9 C) float32")
     out = torch.empty(B, C, H, W, dtype=P.dtype, device=P.device)
     rc = L.lib().nf_conv3x3_gather_sum(ptr(P), ptr(None if bias is None else bias.contiguous()), ptr(out), i64(B), i32(C), i32(H),
-                                       i32(W), i32(9 * C), i32(1 if flip else 0), L.stream())
+                                       i32(W), i32(P.shape[1]), i32(1 if flip else 0), L.stream())
     L.check(rc, "nf_conv3x3_gather_sum")
     return out
 
@@ -948,7 +955,7 @@ def pack_gather(params, src):
     return out
 
 
-def made_forward_train(x, blob, table, hidden_padded, out_features, num_blocks):
+def made_forward_train(x, blob, table, hidden_padded, out_features, num_blocks, rows=None, features=None):
     """MADE.forward / ResidualNet.forward under autograd (nf_made_forward_train): (params (B, out_features), save (2 NB + 1, Bp, Hp)
     pre-activations, bits (Bp / 64, 2 NB, 2, 512) ReLU signs), Bp = B rounded up to 64 -- the operands of made_backward / made_wgrad.
     out_features = mult D for a MADE (the table's hdr[12])."""
@@ -956,6 +963,8 @@ def made_forward_train(x, blob, table, hidden_padded, out_features, num_blocks):
     if x.dtype != torch.float32:
         raise NotImplementedError("made_forward_train: float32 only")
     B, D = x.shape
+    if rows is not None:           # x is a padded buffer (rows >= B, row stride in the table's hdr[14]): the conv path
+        B, D = rows, features
     x = x.contiguous()
     Bp = (B + 63) // 64 * 64
     params = torch.empty(B, out_features, dtype=x.dtype, device=x.device)
@@ -967,16 +976,19 @@ def made_forward_train(x, blob, table, hidden_padded, out_features, num_blocks):
     return params, save, bits
 
 
-def made_backward(g_params, bits, blob, table, D, hidden_padded, num_blocks):
-    """The input-gradient chain of MADE (nf_made_backward): g_x (B, D) and every layer's output gradient G (2 NB + 1, Bp, Hp)."""
+def made_backward(g_params, bits, blob, table, D, hidden_padded, num_blocks, rows=None, out_features=None, ld_out=None):
+    """The input-gradient chain of MADE (nf_made_backward): g_x (B, D) and every layer's output gradient G (2 NB + 1, Bp, Hp).
+    rows / out_features / ld_out: g_params is a padded buffer (row strides in the table's hdr[14], hdr[15]) and so is the returned
+    g_x (rows, ld_out): the conv path."""
     L.require_device(g_params, bits, blob, table)
-    B = g_params.shape[0]
+    B = g_params.shape[0] if rows is None else rows
+    md = g_params.shape[1] if out_features is None else out_features
     g_params = g_params.contiguous()
     Bp = (B + 63) // 64 * 64
-    gx = torch.empty(B, D, dtype=g_params.dtype, device=g_params.device)
+    gx = torch.empty(B, D if ld_out is None else ld_out, dtype=g_params.dtype, device=g_params.device)
     G = torch.empty(2 * num_blocks + 1, Bp, hidden_padded, dtype=g_params.dtype, device=g_params.device)
     rc = L.lib().nf_made_backward(ptr(g_params), ptr(bits), ptr(gx), ptr(G), ptr(blob), ptr(table), i64(B), i32(D),
-                                  i32(hidden_padded), i32(max(1, g_params.shape[1] // D)), L.stream())
+                                  i32(hidden_padded), i32(max(1, md // D)), L.stream())
     L.check(rc, "nf_made_backward")
     return gx, G
 
@@ -987,11 +999,11 @@ def _pad_rows_cols(t, rows, cols):
     return torch.nn.functional.pad(t, (0, cols - t.shape[1], 0, rows - t.shape[0])).contiguous()
 
 
-def made_wgrad(g_params, x, G, save, wtable, stable, mask, ntiles, nflat, Mp, Dx):
+def made_wgrad(g_params, x, G, save, wtable, stable, mask, ntiles, nflat, Mp, Dx, rows=None):
     """Every weight / bias gradient of the MADE (nf_made_wgrad): the flat vector in flows/made_pack.pack_made_backward's layout,
     masked entries zero."""
     L.require_device(g_params, x, G, save, wtable, stable, mask)
-    B = g_params.shape[0]
+    B = g_params.shape[0] if rows is None else rows          # (rows: the operands are already padded buffers)
     Bp = G.shape[1]
     gp_pad = _pad_rows_cols(g_params, Bp, Mp)
     x_pad = _pad_rows_cols(x, Bp, Dx)

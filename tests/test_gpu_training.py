@@ -1423,3 +1423,73 @@ def test_lu_linear_permute_training_wide_vs_float64(nfa, D, B):
     ref = [zr.detach(), ldr.detach(), xd.grad, le.grad, ue.grad, ud.grad, b.grad]
     for a, r in zip(ours, ref):
         assert float((a.double() - r).abs().max()) <= 2e-5 * max(1.0, float(r.abs().max())), float((a.double() - r).abs().max())
+
+
+# ---- GlowBlock's conv conditioner under autograd without the convolution library (csrc/conv_rows.hip + MADE kernels, plain-MLP mode) ----
+@pytest.mark.parametrize("Cin,hid,Cout,B,H,W", [(6, 256, 12, 8, 16, 16), (12, 256, 24, 5, 8, 8), (24, 256, 48, 7, 4, 4), (3, 16, 5, 2, 2, 2),
+                                                (14, 300, 4, 3, 5, 7), (24, 64, 48, 256, 4, 4), (28, 256, 6, 2, 3, 3)])
+def test_convnet_training_kernels_vs_autograd(nfa, monkeypatch, Cin, hid, Cout, B, H, W):
+    """ConvNet2d([Cin, hid, hid, Cout], (3, 1, 3), LeakyReLU(0)) (nets/cnn.py:5-63) under autograd: nf_conv3x3_gather ->
+    nf_made_forward_train (plain MLP 9 Cin -> hid -> hid -> 9 Cout over pixel rows) -> nf_conv3x3_gather_sum, and the mirrored backward
+    (nf_made_backward, nf_made_wgrad) against torch autograd through the convolution library in float64: output, input gradient and
+    all six parameter gradients to 2e-5 of scale (measured ~5e-7); image borders, ragged pixel counts, 9 Cin up to 252, padded hidden
+    widths; the hand-written path ran (spy), twice bit-identical."""
+    import copy
+    from normflows_amd import ops
+    torch.manual_seed(Cin + hid)
+    net = nfa.nets.ConvNet2d([Cin, hid, hid, Cout], [3, 1, 3], init_zeros=False).to(DEV)
+    x = torch.randn(B, Cin, H, W, device=DEV)
+    go = torch.randn(B, Cout, H, W, device=DEV)
+    calls = _spy_made(monkeypatch)
+    res = []
+    for n_, dt in ((net, torch.float32), (net, torch.float32), (copy.deepcopy(net).double(), torch.float64)):
+        n_.zero_grad(set_to_none=True)
+        xx = x.detach().clone().to(dt).requires_grad_(True)
+        out = n_(xx)
+        out.backward(go.to(dt))
+        res.append([out.detach(), xx.grad] + [p.grad.clone() for p in n_.parameters()])
+    assert calls == {"fwd": 2, "bwd": 2, "wgrad": 2}, calls
+    assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
+    for a, b in zip(res[0], res[2]):
+        assert float((a.double() - b).abs().max()) <= 2e-5 * float(b.abs().max()), float((a.double() - b).abs().max() / b.abs().max())
+
+
+def test_training_follows_fused_optimizer_steps(nfa):
+    """torch.optim.Adam(fused=True) updates parameters WITHOUT bumping Tensor._version: the training packs are gathered from the current
+    parameters in every forward (nf_pack_gather) and every cached inference image carries the optimizer-step epoch (_keys.py) -- three
+    fused-Adam steps on the hand-written path end at the same parameters and the same log-density as three steps through torch's own
+    autograd, and the inference path right after a step sees the updated weights."""
+    import copy
+    torch.manual_seed(11)
+    base = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(12, trainable=False),
+                               [nfa.flows.MaskedAffineAutoregressive(12, 40, num_blocks=2) for _ in range(2)])
+    with torch.no_grad():
+        for p in base.parameters():
+            p.add_(0.1 * torch.randn_like(p))
+    eps = torch.randn(300, 12, generator=torch.Generator().manual_seed(1)).to(DEV)
+    xs = torch.randn(200, 12, generator=torch.Generator().manual_seed(2)).to(DEV)
+    outs = []
+    for mode in (True, False):
+        m = copy.deepcopy(base).to(DEV)
+        opt = torch.optim.Adam(m.parameters(), lr=5e-2, fused=True)
+        nfa.config.set_made_train(mode)
+        try:
+            lps = []
+            for _ in range(3):
+                opt.zero_grad(set_to_none=True)
+                z, logq = eps, torch.zeros(300, device=DEV)
+                for f in m.flows:
+                    z, ld = f(z)
+                    logq = logq - ld
+                (logq + 0.5 * (z ** 2).sum(1)).mean().backward()
+                opt.step()
+                with torch.no_grad():
+                    lps.append(m.log_prob(xs).clone())          # one-pass inverse kernel on a cached pack: must follow the step
+        finally:
+            nfa.config.set_made_train(True)
+        outs.append((lps, [p.detach().clone() for p in m.parameters()]))
+    assert float((outs[0][0][0] - outs[0][0][2]).abs().max()) > 1e-3                      # the steps changed the model ...
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert float((a - b).abs().max()) < 2e-3 * max(1.0, float(b.abs().max()))        # ... the same way on both paths
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert float((a - b).abs().max()) < 2e-3

@@ -741,6 +741,121 @@ def test_made_backward_pack_matches_autograd(D, H, NB, mult, B):
         assert (nkg[:, :10].sum(axis=1) == nkg[0, :10].sum()).all()      # equal MFMA work per wave in the hidden products
 
 
+@pytest.mark.parametrize("Cin,hid,Cout,B,H,W", [(6, 256, 12, 2, 4, 4), (24, 40, 48, 1, 3, 5), (3, 16, 5, 2, 2, 2), (14, 300, 4, 1, 4, 4)])
+def test_conv_conditioner_as_pixel_mlp_matches_conv2d_autograd(Cin, hid, Cout, B, H, W):
+    """The conv conditioner's training path restated in numpy: 3x3 convolutions as gather / neighbour-sum (csrc/conv_rows.hip) around
+    the plain-MLP packs (flows/made_pack.pack_mlp_*: W1c[o][tap Cin + c], W3t[tap Cout + o][c]) walked by the kernel emulators
+    (tests/made_fwd_emulator.py, tests/made_bwd_emulator.py) against torch conv2d + autograd in float64 (nets/cnn.py:5-63): output,
+    input gradient, every weight / bias gradient; 9 Cin up to 216 (two rounds of the last product), hidden padded to 256 / 512."""
+    from normflows_amd.flows import made_pack
+    import made_bwd_emulator as E
+    import made_fwd_emulator as F
+
+    def gather(x, flip=False):
+        Bn, C, Hn, Wn = x.shape
+        col = np.zeros((Bn, Hn, Wn, 9, C))
+        for tap in range(9):
+            dy, dx = (tap // 3 - 1, tap % 3 - 1) if not flip else (1 - tap // 3, 1 - tap % 3)
+            for y in range(Hn):
+                for xx in range(Wn):
+                    if 0 <= y + dy < Hn and 0 <= xx + dx < Wn:
+                        col[:, y, xx, tap, :] = x[:, :, y + dy, xx + dx]
+        return col.reshape(Bn * Hn * Wn, 9 * C)
+
+    def gather_sum(P, bias, shape, flip=False):
+        Bn, C, Hn, Wn = shape
+        P = P.reshape(Bn, Hn, Wn, 9, C)
+        out = np.zeros(shape)
+        for tap in range(9):
+            dy, dx = (tap // 3 - 1, tap % 3 - 1) if not flip else (1 - tap // 3, 1 - tap % 3)
+            for y in range(Hn):
+                for xx in range(Wn):
+                    if 0 <= y + dy < Hn and 0 <= xx + dx < Wn:
+                        out[:, :, y, xx] += P[:, y + dy, xx + dx, tap, :]
+        return out if bias is None else out + bias[None, :, None, None]
+    torch.manual_seed(Cin + hid)
+    net = torch.nn.Sequential(torch.nn.Conv2d(Cin, hid, 3, padding=1), torch.nn.LeakyReLU(0.0), torch.nn.Conv2d(hid, hid, 1),
+                              torch.nn.LeakyReLU(0.0), torch.nn.Conv2d(hid, Cout, 3, padding=1)).double()
+    x = torch.randn(B, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    out = net(x)
+    go = torch.randn_like(out)
+    out.backward(go)
+    c1, c2, c3 = net[0], net[2], net[4]
+    f32 = lambda t: t.detach().numpy().astype(np.float32)
+    args = (f32(c1.weight.permute(0, 2, 3, 1).reshape(hid, 9 * Cin)), f32(c1.bias), f32(c2.weight[:, :, 0, 0]), f32(c2.bias),
+            f32(c3.weight.permute(2, 3, 0, 1).reshape(9 * Cout, hid)))
+    blob, table = made_pack.pack_mlp_forward(*args)
+    pack = made_pack.pack_mlp_backward(*args)
+    sl = made_pack._mlp_layers(*args, None)
+    assert table[13] == 1 and pack["table"][13] == 1 and pack["table"][8] == (sl["Dp"] // 32 + 3) // 4
+    col = gather(x.detach().numpy())
+    o = gather_sum(F.emulate_forward(blob, table, col), c3.bias.detach().numpy(), tuple(out.shape))
+    assert np.abs(o - out.detach().numpy()).max() < 1e-9
+    xin = np.zeros((col.shape[0], sl["Dp"]))
+    xin[:, :col.shape[1]] = col
+    h = xin @ sl["layers"][0][0].astype(np.float64).T + sl["layers"][0][2]
+    t = np.maximum(h, 0) @ sl["layers"][1][0].astype(np.float64).T + sl["layers"][1][2]
+    S = [h, t, np.zeros_like(h)]
+    gP = gather(go.numpy(), flip=True)
+    gcol, G = E.emulate_chain(pack, gP, S)
+    assert np.abs(gather_sum(gcol, None, tuple(x.shape), flip=True) - x.grad.numpy()).max() < 1e-9
+    flat = E.emulate_wgrad(pack, gP, col, G, S)
+    (o0, s0, b0, n0), (o1, s1, b1, n1), (o2, s2, _, _) = pack["offsets"]
+    assert np.abs(flat[o0:o0 + s0[0] * s0[1]].reshape(hid, 3, 3, Cin).transpose(0, 3, 1, 2) - c1.weight.grad.numpy()).max() < 1e-9
+    assert np.abs(flat[o1:o1 + s1[0] * s1[1]].reshape(hid, hid) - c2.weight.grad.numpy()[:, :, 0, 0]).max() < 1e-9
+    assert np.abs(flat[o2:o2 + s2[0] * s2[1]].reshape(3, 3, Cout, hid).transpose(2, 3, 0, 1) - c3.weight.grad.numpy()).max() < 1e-9
+    assert np.abs(flat[b0:b0 + n0] - c1.bias.grad.numpy()).max() < 1e-9 and np.abs(flat[b1:b1 + n1] - c2.bias.grad.numpy()).max() < 1e-9
+
+
+def test_training_packs_as_gather_indices_reproduce_the_value_packs():
+    """flows/made_pack.*_train_structure: the packers run on parameter POSITIONS instead of values give gather indices with
+    flat[src] == the value packs, bit for bit, for a MADE (masked), a ResidualNet (dense) and the conv conditioner (permuted conv
+    weights) -- what nf_pack_gather rebuilds on the device in every training forward."""
+    import normflows_amd as nfa
+    from normflows_amd.flows import made_pack
+    torch.manual_seed(0)
+    made = nfa.nets.MADE(20, 40, num_blocks=2, output_multiplier=2)
+    net = nfa.nets.ResidualNet(17, 391, 300, num_blocks=2)
+    cn = nfa.nets.ConvNet2d([6, 256, 256, 12], [3, 1, 3], init_zeros=False)
+    with torch.no_grad():
+        for p in list(made.parameters()) + list(net.parameters()):
+            p.add_(torch.randn_like(p))
+    flat_of = lambda ts: np.concatenate([np.zeros(1, np.float32)] + [t.detach().numpy().reshape(-1) for t in ts])
+    st = made_pack.made_train_structure(made, 2)
+    flat = flat_of([t for l in made._linears() for t in (l.weight, l.bias)])
+    assert np.array_equal(flat[st["src"]], made_pack.pack_made_forward(made, 2)[0])
+    assert np.array_equal(flat[st["bwd"]["src"]], made_pack.pack_made_backward(made, 2)["blob"])
+    st = made_pack.resnet_train_structure(net)
+    lins = [net.initial_layer] + [l for b in net.blocks for l in b.linear_layers] + [net.final_layer]
+    flat = flat_of([t for l in lins for t in (l.weight, l.bias)])
+    assert np.array_equal(flat[st["src"]], made_pack.pack_resnet_forward(net)[0])
+    assert np.array_equal(flat[st["bwd"]["src"]], made_pack.pack_resnet_backward(net)["blob"])
+    c1, c2, c3 = cn.net[0], cn.net[2], cn.net[4]
+    st = made_pack.convnet_train_structure(6, 256, 12)
+    flat = flat_of([c1.weight, c1.bias, c2.weight, c2.bias, c3.weight])
+    args = (c1.weight.detach().permute(0, 2, 3, 1).reshape(256, 54).numpy(), c1.bias.detach().numpy(), c2.weight.detach()[:, :, 0, 0].numpy(),
+            c2.bias.detach().numpy(), c3.weight.detach().permute(2, 3, 0, 1).reshape(108, 256).numpy())
+    assert np.array_equal(flat[st["src"]], made_pack.pack_mlp_forward(*args)[0])
+    assert np.array_equal(flat[st["bwd"]["src"]], made_pack.pack_mlp_backward(*args)["blob"])
+    assert st["table"][14] == 128 and st["bwd"]["table"][14] == 128 and st["bwd"]["table"][15] == 128      # padded row strides
+
+
+def test_cache_keys_follow_fused_optimizer_steps():
+    """torch's fused optimizers leave Tensor._version untouched; the global post-step hook of _keys.py advances the epoch that every
+    packed-weight cache key carries."""
+    from normflows_amd import _keys
+    p = torch.nn.Parameter(torch.randn(4))
+    opt = torch.optim.Adam([p], lr=0.1, fused=True)
+    k0 = _keys.pkey([p])
+    p.grad = torch.ones(4)
+    opt.step()
+    assert _keys.pkey([p]) != k0
+    k1 = _keys.pkey([p])
+    with torch.no_grad():
+        p.add_(1.0)
+    assert _keys.pkey([p]) != k1
+
+
 def test_made_forward_pack_rejects_unsupported():
     from normflows_amd import nets
     from normflows_amd.flows import made_pack
