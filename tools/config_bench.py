@@ -77,8 +77,15 @@ def c4():
         es = timed(lambda: m.sample(256), 5)
         m.use_graphs(True)
         g = timed(lambda: m.log_prob(x), 10)
+    m.use_graphs(False)
+
+    def train_step():          # forward_kld + backward (core.py:87-102 through MultiscaleFlow): conv conditioners on csrc/conv_rows.hip +
+        m.zero_grad(set_to_none=True)       # the MADE training kernels (no convolution library)
+        m.forward_kld(x).backward()
+    tr = timed(train_step, 3)
     res = {"workload": "BASELINE configs[3]: Glow L=3, K=32, hidden 256, 32x32x3, batch 256", "log_prob_ms": g * 1e3,
-           "log_prob_ms_eager": e * 1e3, "sample_ms": es * 1e3, "images_per_s": 256 / g, "nll_nats_per_dim": nll}
+           "log_prob_ms_eager": e * 1e3, "sample_ms": es * 1e3, "images_per_s": 256 / g, "nll_nats_per_dim": nll,
+           "forward_kld_backward_ms": tr * 1e3}
     print("config 4 Glow L=3 K=32 B=256: log_prob eager %.1f ms (%.0f img/s), hipGraph %.1f ms (%.0f img/s); "
           "sample %.1f ms (%.0f img/s); NLL %.4f nats/dim (untrained, after ActNorm init)" % (
               e * 1e3, 256 / e, g * 1e3, 256 / g, es * 1e3, 256 / es, nll))
