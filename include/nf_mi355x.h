@@ -345,6 +345,10 @@ int nf_actnorm_init(const void *mean, const void *std_unbiased, void *s, void *t
  */
 int nf_inv1x1_assemble(const void *P, const void *L, const void *U, const void *sign_S, const void *log_S,
                        void *W, void *logdet_unit, int C, int inverse, int dtype, nf_stream_t stream);
+/* Its VJP in the density direction (W = P Lm Um, log|det| = sum log_S; mixing.py:88-104 under autograd): gL / gU (C x C, the strictly
+ * lower / upper parts; zero elsewhere) and g_log_S (C) from the cotangents gW (C x C) and gl (0-dim, may be NULL).  C <= 64. */
+int nf_inv1x1_lu_grads(const void *P, const void *L, const void *U, const void *sign_S, const void *log_S, const void *gW,
+                       const void *gl, void *gL, void *gU, void *glogS, int C, int dtype, nf_stream_t stream);
 int nf_inv1x1_conv(const void *z, const void *W, const void *logdet_unit, void *y, void *logdet_scalar,
                    void *logdet, int64_t B, int C, int64_t HW, int acc, int dtype, nf_stream_t stream);
 /* y = W z + bias per pixel (bias (C) may be NULL): the 1x1 convolution with the neighbouring ActNorm

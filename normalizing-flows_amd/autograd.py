@@ -665,6 +665,27 @@ class ActNormFn(torch.autograd.Function):
         return gz, gs.view_as(s), gt.view_as(t), None
 
 
+class Inv1x1WeightFn(torch.autograd.Function):
+    """(W, per-pixel log|det|) of Invertible1x1Conv's LU parametrisation in the density direction (mixing.py:88-104: W = P (tril(L, -1) +
+    I) (triu(U, 1) + diag(sign_S exp(log_S)))): nf_inv1x1_assemble forward, nf_inv1x1_lu_grads backward -- two launches where torch
+    autograd needs ~25 on C x C matrices."""
+
+    @staticmethod
+    def forward(ctx, P, Lm, U, sign_S, log_S):
+        W, ldu = ops.inv1x1_assemble(P, Lm.detach(), U.detach(), sign_S, log_S.detach(), inverse=False)
+        ctx.save_for_backward(P, Lm, U, sign_S, log_S)
+        ctx.set_materialize_grads(False)
+        return W, ldu
+
+    @staticmethod
+    def backward(ctx, gW, gl):
+        P, Lm, U, sign_S, log_S = ctx.saved_tensors
+        if gW is None:
+            gW = torch.zeros_like(Lm)
+        gL, gU, gs = ops.inv1x1_lu_grads(P, Lm.detach(), U.detach(), sign_S, log_S.detach(), gW, gl)
+        return None, gL, gU, None, gs
+
+
 class Inv1x1Fn(torch.autograd.Function):
     """Per-pixel C x C product (mixing.py:106-133) with a given matrix W and per-pixel log|det| `ldu` (0-dim)."""
 

@@ -103,6 +103,9 @@ class Invertible1x1Conv(Flow):
                 return W, sld
             Winv = torch.inverse(W) if W.dtype == torch.float64 else torch.inverse(W.double()).type(W.dtype)
             return Winv, -sld
+        if inverse_dir and self.L.is_cuda and self.num_channels <= 64:
+            from ..autograd import Inv1x1WeightFn      # density direction: assembly and its VJP as one launch each
+            return Inv1x1WeightFn.apply(self.P, self.L, self.U, self.sign_S, self.log_S)
         Lm = torch.tril(self.L, diagonal=-1) + self.eye
         Um = torch.triu(self.U, diagonal=1) + torch.diag(self.sign_S * torch.exp(self.log_S))
         if inverse_dir:

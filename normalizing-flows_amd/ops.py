@@ -204,6 +204,18 @@ def inv1x1_assemble(P, Lm, U, sign_S, log_S, inverse):
     return W, ldu
 
 
+def inv1x1_lu_grads(P, Lm, U, sign_S, log_S, gW, gl):
+    """(gL, gU, g_log_S) of Invertible1x1Conv's LU parametrisation in the density direction (nf_inv1x1_lu_grads)."""
+    L.require_device(P, Lm, U, sign_S, log_S, gW, gl)
+    Cc = Lm.shape[0]
+    gL, gU, gs = torch.empty_like(Lm), torch.empty_like(U), torch.empty_like(log_S)
+    rc = L.lib().nf_inv1x1_lu_grads(ptr(P.contiguous()), ptr(Lm.contiguous()), ptr(U.contiguous()), ptr(sign_S.contiguous()),
+                                    ptr(log_S.contiguous()), ptr(gW.contiguous()), ptr(None if gl is None else gl.contiguous()),
+                                    ptr(gL), ptr(gU), ptr(gs), i32(Cc), i32(L.dtype_code(Lm)), L.stream())
+    L.check(rc, "nf_inv1x1_lu_grads")
+    return gL, gU, gs
+
+
 def inv1x1_conv(z, W, logdet_unit, logdet=None, acc=None, want_scalar=True, bias=None):
     L.require_device(z, W, logdet_unit, bias)
     z = z.contiguous()

@@ -1493,3 +1493,32 @@ def test_training_follows_fused_optimizer_steps(nfa):
         assert float((a - b).abs().max()) < 2e-3 * max(1.0, float(b.abs().max()))        # ... the same way on both paths
     for a, b in zip(outs[0][1], outs[1][1]):
         assert float((a - b).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("C", [3, 12, 48])
+def test_inv1x1_lu_parametrisation_vjp_vs_autograd(nfa, dt, C):
+    """nf_inv1x1_assemble + nf_inv1x1_lu_grads (autograd.Inv1x1WeightFn) against torch autograd through the reference's assembly
+    (mixing.py:88-104: W = P (tril(L, -1) + I) (triu(U, 1) + diag(sign_S exp(log_S))), log|det| = sum log_S)."""
+    from normflows_amd.autograd import Inv1x1WeightFn
+    torch.manual_seed(C)
+    conv = nfa.flows.Invertible1x1Conv(C, use_lu=True).to(dt).to(DEV)
+    with torch.no_grad():
+        conv.L.add_(0.3 * torch.randn_like(conv.L))
+        conv.U.add_(0.3 * torch.randn_like(conv.U))
+        conv.log_S.add_(0.3 * torch.randn_like(conv.log_S))
+    cW, cl = torch.randn(C, C, device=DEV, dtype=dt), torch.randn((), device=DEV, dtype=dt)
+    res = []
+    for hand in (True, False):
+        conv.zero_grad(set_to_none=True)
+        if hand:
+            W, l = Inv1x1WeightFn.apply(conv.P, conv.L, conv.U, conv.sign_S, conv.log_S)
+        else:
+            Lm = torch.tril(conv.L, diagonal=-1) + conv.eye
+            Um = torch.triu(conv.U, diagonal=1) + torch.diag(conv.sign_S * torch.exp(conv.log_S))
+            W, l = conv.P @ Lm @ Um, torch.sum(conv.log_S)
+        ((W * cW).sum() + l * cl).backward()
+        res.append([W.detach(), l.detach(), conv.L.grad.clone(), conv.U.grad.clone(), conv.log_S.grad.clone()])
+    tol = 2e-5 if dt == torch.float32 else 1e-12
+    for a, b in zip(res[0], res[1]):
+        assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
