@@ -357,39 +357,36 @@ maf_affine_bwd_kernel(const T *__restrict__ x, const T *__restrict__ params, con
 
 // ---- Invertible1x1Conv's LU parametrisation (mixing.py:88-104), density direction: W = P (tril(L, -1) + I) (triu(U, 1) + diag(sign_S
 // exp(log_S))), log|det| per pixel = sum log_S.  VJP of (W, log|det|) -> (L, U, log_S) for the cotangents gW (C x C), gl (0-dim): what
-// torch autograd does with ~15 tiny tril / triu / diag / exp / matmul launches per layer and step.  One workgroup, C <= 64:
+// torch autograd does with ~15 tiny tril / triu / diag / exp / matmul launches per layer and step.  C <= 64, one workgroup per row:
 //   gLm = P^T gW Um^T -> strictly lower part;  gUm = (P Lm)^T gW -> strictly upper part;  g_log_S = diag(gUm) sign_S exp(log_S) + gl
 template <typename T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 inv1x1_lu_grads_kernel(const T *__restrict__ P, const T *__restrict__ L, const T *__restrict__ U, const T *__restrict__ sign_S,
                        const T *__restrict__ log_S, const T *__restrict__ gW, const T *__restrict__ gl, T *__restrict__ gL,
                        T *__restrict__ gU, T *__restrict__ glogS, int C) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T *A = reinterpret_cast<T *>(smem_raw);        // P^T gW
-    T *PL = A + C * C;                             // P Lm
-    const int tid = threadIdx.x;
-    for (int e = tid; e < C * C; e += blockDim.x) {
-        const int i = e / C, j = e - i * C;
-        T a = T(0), pl = T(0);
+    // one workgroup per output row i, thread j per column: row i of A = P^T gW and column i of P Lm through LDS
+    __shared__ T a[64], plc[64];
+    const int i = blockIdx.x, j = threadIdx.x;
+    if (j < C) {
+        T av = T(0), pl = T(0);
         for (int k = 0; k < C; ++k) {
-            a += P[k * C + i] * gW[k * C + j];
-            const T lm = k > j ? L[k * C + j] : (k == j ? T(1) : T(0));      // Lm[k][j]
-            pl += P[i * C + k] * lm;
+            av += P[k * C + i] * gW[k * C + j];                                       // A[i][j]
+            const T lm = k > i ? L[k * C + i] : (k == i ? T(1) : T(0));               // Lm[k][i]
+            pl += P[j * C + k] * lm;                                                  // (P Lm)[j][i]
         }
-        A[e] = a;
-        PL[e] = pl;
+        a[j] = av;
+        plc[j] = pl;
     }
     __syncthreads();
-    for (int e = tid; e < C * C; e += blockDim.x) {
-        const int i = e / C, j = e - i * C;
+    if (j < C) {
         T glm = T(0), gum = T(0);
         for (int k = 0; k < C; ++k) {
             const T um = k > j ? U[j * C + k] : (k == j ? sign_S[j] * M<T>::exp(log_S[j]) : T(0));     // Um[j][k]
-            glm += A[i * C + k] * um;                    // (A Um^T)[i][j]
-            gum += PL[k * C + i] * gW[k * C + j];        // (PL^T gW)[i][j]
+            glm += a[k] * um;                            // (A Um^T)[i][j]
+            gum += plc[k] * gW[k * C + j];               // ((P Lm)^T gW)[i][j]
         }
-        gL[e] = i > j ? glm : T(0);
-        gU[e] = j > i ? gum : T(0);
+        gL[i * C + j] = i > j ? glm : T(0);
+        gU[i * C + j] = j > i ? gum : T(0);
         if (i == j) glogS[i] = gum * sign_S[i] * M<T>::exp(log_S[i]) + (gl ? *gl : T(0));
     }
 }
@@ -551,12 +548,11 @@ extern "C" int nf_inv1x1_lu_grads(const void *P, const void *L, const void *U, c
     if (C > 64) return NF_ENOTSUP;
     if (!P || !L || !U || !sign_S || !log_S || !gW || !gL || !gU || !glogS) return NF_EFAULT;
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)2 * C * C * (dtype == NF_F64 ? 8 : 4);
     NF_DISPATCH(dtype,
-                hipLaunchKernelGGL(inv1x1_lu_grads_kernel<float>, dim3(1), dim3(256), lds, st, (const float *)P, (const float *)L,
+                hipLaunchKernelGGL(inv1x1_lu_grads_kernel<float>, dim3(C), dim3(64), 0, st, (const float *)P, (const float *)L,
                                    (const float *)U, (const float *)sign_S, (const float *)log_S, (const float *)gW, (const float *)gl,
                                    (float *)gL, (float *)gU, (float *)glogS, C),
-                hipLaunchKernelGGL(inv1x1_lu_grads_kernel<double>, dim3(1), dim3(256), lds, st, (const double *)P, (const double *)L,
+                hipLaunchKernelGGL(inv1x1_lu_grads_kernel<double>, dim3(C), dim3(64), 0, st, (const double *)P, (const double *)L,
                                    (const double *)U, (const double *)sign_S, (const double *)log_S, (const double *)gW,
                                    (const double *)gl, (double *)gL, (double *)gU, (double *)glogS, C));
     NF_CHECK_LAUNCH();

@@ -71,15 +71,17 @@ def _train_packs_from(module, build, params, device, skey=()):
                 bwd[k] = torch.from_numpy(bwd[k]).to(device)
             bwd.pop("blob", None)
             struct["table"] = torch.from_numpy(struct["table"]).to(device)
-            struct["src"] = torch.from_numpy(struct["src"]).to(device)
+            struct["nfwd"] = int(struct["src"].size)             # one gather for both streams: [forward | backward]
+            struct["src"] = torch.cat([torch.from_numpy(struct["src"]), bwd["src"].cpu()]).to(device)
         st = module.__dict__["_train_struct"] = (skey, struct)
     struct = st[1]
     if struct is None:
         return None
     from . import ops
     bwd = dict(struct["bwd"])
-    bwd["blob"] = ops.pack_gather(params, bwd["src"])
-    return (ops.pack_gather(params, struct["src"]), struct["table"], struct["hp"]), bwd
+    both = ops.pack_gather(params, struct["src"])
+    bwd["blob"] = both[struct["nfwd"]:]
+    return (both[:struct["nfwd"]], struct["table"], struct["hp"]), bwd
 
 
 class ResidualNet(nn.Module):

@@ -957,10 +957,16 @@ def made_forward(x, blob, table, hidden_padded, mult):
     return params
 
 
+_ZERO1 = {}
+
+
 def pack_gather(params, src):
     """The packed weight streams from the current parameters (nf_pack_gather): flat = [0, params flattened ...], out = flat[src]."""
     L.require_device(src, *params)
-    flat = torch.cat([torch.zeros(1, dtype=torch.float32, device=src.device)] + [p.detach().reshape(-1) for p in params])
+    zero = _ZERO1.get(src.device)
+    if zero is None:
+        zero = _ZERO1[src.device] = torch.zeros(1, dtype=torch.float32, device=src.device)
+    flat = torch.cat([zero] + [p.detach().reshape(-1) for p in params])
     out = torch.empty(src.numel(), dtype=torch.float32, device=src.device)
     rc = L.lib().nf_pack_gather(ptr(flat), ptr(src), ptr(out), i64(src.numel()), L.stream())
     L.check(rc, "nf_pack_gather")
