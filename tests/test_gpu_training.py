@@ -1522,3 +1522,46 @@ def test_inv1x1_lu_parametrisation_vjp_vs_autograd(nfa, dt, C):
     tol = 2e-5 if dt == torch.float32 else 1e-12
     for a, b in zip(res[0], res[1]):
         assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+
+
+def test_training_kernels_random_shapes(nfa):
+    """Seeded fuzz of the MADE / ResidualNet / conv-conditioner training paths over their whole envelope (features 2..128 resp. 9 Cin up
+    to 252, hidden 1..512, 1..3 blocks, output multipliers 1..23, batches 1..400 incl. non-multiples of the 64-row tile and of the
+    weight-gradient chunks) against float64 autograd through the library: every output and gradient to 3e-5 of its scale."""
+    import copy
+    rng = np.random.RandomState(4)
+
+    def compare(net, x, go):
+        res = []
+        for n_, dt in ((net, torch.float32), (copy.deepcopy(net).double(), torch.float64)):
+            n_.zero_grad(set_to_none=True)
+            xx = x.detach().clone().to(dt).requires_grad_(True)
+            out = n_(xx)
+            out.backward(go.to(dt))
+            res.append([out.detach(), xx.grad] + [p.grad for p in n_.parameters()])
+        for a, b in zip(res[0], res[1]):
+            assert float((a.double() - b).abs().max()) <= 3e-5 * max(float(b.abs().max()), 1e-6), (type(net).__name__, tuple(a.shape))
+    for k in range(14):
+        D, H, NB = int(rng.randint(2, 129)), int(rng.randint(1, 513)), int(rng.randint(1, 4))
+        mult, B = int(rng.choice([1, 2, 3, 5, 23])), int(rng.randint(1, 401))
+        torch.manual_seed(k)
+        if k % 2 == 0:
+            net = nfa.nets.MADE(D, H, num_blocks=NB, output_multiplier=mult)
+            out_f = mult * D
+        else:
+            H = max(H, 129)                                    # (the ResidualNet route starts beyond 128 hidden units)
+            out_f = int(rng.randint(1, 700))
+            net = nfa.nets.ResidualNet(D, out_f, H, num_blocks=NB)
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(0.1 * torch.randn_like(p))
+        net = net.to(DEV)
+        compare(net, torch.randn(B, D, device=DEV), torch.randn(B, out_f, device=DEV))
+    for k in range(6):
+        Cin, hid, Cout = int(rng.randint(1, 29)), int(rng.randint(1, 513)), int(rng.randint(1, 49))
+        if hid > 256:
+            Cin = min(Cin, 14)                                 # (9 Cin <= 128 next to 512 hidden slots)
+        B, H, W = int(rng.randint(1, 9)), int(rng.randint(1, 9)), int(rng.randint(1, 9))
+        torch.manual_seed(100 + k)
+        net = nfa.nets.ConvNet2d([Cin, hid, hid, Cout], [3, 1, 3], init_zeros=False).to(DEV)
+        compare(net, torch.randn(B, Cin, H, W, device=DEV), torch.randn(B, Cout, H, W, device=DEV))
