@@ -827,9 +827,10 @@ class ConvNetFn(torch.autograd.Function):
         flat = ops.made_wgrad(gP, col, G, save, bwd["wtable"], bwd["stable"], bwd["mask"], bwd["ntiles"], bwd["nflat"], bwd["Mp"],
                               bwd["Dx"], rows=R)
         (o0, s0, c0, n0), (o1, s1, c1, n1), (o2, s2, _, _) = bwd["offsets"]
-        gw1 = flat[o0:o0 + s0[0] * s0[1]].view(hid, 3, 3, Cin).permute(0, 3, 1, 2)
+        # (the reduction scatters straight into the conv parameters' own (o, c, ky, kx) layouts: made_pack.convnet_train_structure)
+        gw1 = flat[o0:o0 + s0[0] * s0[1]].view(hid, Cin, 3, 3)
         gw2 = flat[o1:o1 + s1[0] * s1[1]].view(hid, hid, 1, 1)
-        gw3 = flat[o2:o2 + s2[0] * s2[1]].view(3, 3, Cout, hid).permute(2, 3, 0, 1)
+        gw3 = flat[o2:o2 + s2[0] * s2[1]].view(Cout, hid, 3, 3)
         return None, None, gx, gw1, flat[c0:c0 + n0], gw2, flat[c1:c1 + n1], gw3, gout.sum((0, 2, 3))
 
 

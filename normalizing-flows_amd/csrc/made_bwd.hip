@@ -294,8 +294,9 @@ made_wgrad_kernel(const float *__restrict__ b0p, const float *__restrict__ b1p, 
 }
 
 // ---- 3. reduction + scatter -----------------------------------------------------------------------------------------------------------
-// sc (int32): per problem 8 ints [weight offset in `grads`, ld of the weight, bias offset, row-map offset, column-map offset, ...]
-// (maps: slot -> parameter row / column, -1 = padding; offsets into sc itself).  Element e of tile t: sum over the chunks in order;
+// sc (int32): per problem 8 ints [weight offset in `grads`, ld of the weight, bias offset, row-map offset, column-map offset, bias-map
+// offset (0: the row map), ...] (maps: slot -> parameter row / column, -1 = padding; offsets into sc itself; destination = weight
+// offset + row ld + column, so a map may also carry pre-multiplied positions with ld = 1: the conv weights' own (o, c, ky, kx) layout).  Element e of tile t: sum over the chunks in order;
 // written only where the parameter's mask is non-zero (`grads` is zero-filled by the host: the masked entries' gradient).
 __global__ void __launch_bounds__(256)
 made_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ grads, const unsigned char *__restrict__ mask,
@@ -327,7 +328,8 @@ made_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ gra
                 if (mask[dst]) grads[dst] = s;
             }
         } else {
-            const int row = rowmap[m0 + (e - MW_T * MW_T)];
+            const int *bmap = ps[5] ? sc + ps[5] : rowmap;
+            const int row = bmap[m0 + (e - MW_T * MW_T)];
             if (row >= 0) grads[(size_t)ps[2] + row] = s;
         }
     }

@@ -428,9 +428,18 @@ def _pack_backward_from(sl):
     ptab, tiles, stab, maps = [], [], [], []
     offsets, mask_parts, flat = [], [], 0
     map_off = 8 * len(probs)
+    wmaps = sl.get("wmaps")          # per problem (row map, column map, ld, bias map): destinations in the parameter's OWN layout
     for pi, (dyb, dyl, ldy, xb, xl, ldx, relu, M, rmap, cmap, shape) in enumerate(probs):
         ptab.append([dyb, dyl, ldy, xb, xl, ldx, relu, 0])
         Mrows, Ncols = len(rmap), len(cmap)
+        ldw, bmap = shape[1], None
+        if wmaps is not None:
+            r2, c2, ldw, b2 = wmaps[pi]
+            bmap = np.full(Mrows, -1, dtype=np.int32)
+            bmap[:len(b2)] = b2
+            rmap, cmap = np.full(Mrows, -1, dtype=np.int32), np.full(Ncols, -1, dtype=np.int32)
+            rmap[:len(r2)] = r2
+            cmap[:len(c2)] = c2
         Mfull = np.zeros((Mrows, Ncols), dtype=bool)
         Mfull[:M.shape[0], :M.shape[1]] = M
         for mt in range(Mrows // W_TILE):
@@ -442,9 +451,12 @@ def _pack_backward_from(sl):
         woff, boff = flat, flat + shape[0] * shape[1]
         flat = boff + shape[0]
         offsets.append((woff, shape, boff, shape[0]))
-        stab.append([woff, shape[1], boff, map_off, map_off + Mrows, 0, 0, 0])
+        stab.append([woff, ldw, boff, map_off, map_off + Mrows, 0 if bmap is None else map_off + Mrows + Ncols, 0, 0])
         maps += [np.asarray(rmap, dtype=np.int32), np.asarray(cmap, dtype=np.int32)]
         map_off += Mrows + Ncols
+        if bmap is not None:
+            maps.append(bmap)
+            map_off += Mrows
         mask_parts += [sl["masks"][pi].astype(np.uint8).reshape(-1), np.ones(shape[0], dtype=np.uint8)]
     whdr = np.zeros(16, dtype=np.int32)
     whdr[:2] = [len(tiles), len(probs)]
@@ -567,4 +579,11 @@ def convnet_train_structure(cin, hid, cout):
     sl_v = _mlp_layers(ones(w1), ones(b1), ones(w2), ones(b2), ones(w3), None)
     if sl_v is None:
         return None
+    # weight gradients straight into the conv parameters' (o, c, ky, kx) layouts: destination = row position + column position
+    tap, ch1, ch3 = np.arange(9), np.arange(cin), np.arange(hid)
+    sl_v["wmaps"] = [
+        (np.arange(hid) * cin * 9, (ch1[None, :] * 9 + tap[:, None]).reshape(-1), 1, np.arange(hid)),          # conv1: W1c[o][tap cin + c]
+        (np.arange(hid) * hid, np.arange(hid), 1, np.arange(hid)),                                                # conv2: (o, c, 1, 1)
+        ((np.arange(cout)[None, :] * hid * 9 + tap[:, None]).reshape(-1), ch3 * 9, 1, np.arange(9 * cout)),     # conv3: W3t[tap cout + o][c]
+    ]
     return train_structure(sl_v, _mlp_layers(w1, b1, w2, b2, w3, None), padded_rows=True)

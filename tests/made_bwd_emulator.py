@@ -123,8 +123,9 @@ def emulate_wgrad(pack, gp, x, G, S):
         assert dY.shape[1] == ldy and X.shape[1] == ldx and m0 + T <= ldy and n0 + T <= ldx
         Xn = np.maximum(X, 0) if relu else X
         tile = dY[:, m0:m0 + T].T @ Xn[:, n0:n0 + T]
-        woff, ldw, boff, ro, co = (int(v) for v in sc[8 * p:8 * p + 5])
+        woff, ldw, boff, ro, co, bo = (int(v) for v in sc[8 * p:8 * p + 6])
         rmap, cmap = sc[ro + m0:ro + m0 + T], sc[co + n0:co + n0 + T]
+        bmap = sc[bo + m0:bo + m0 + T] if bo else rmap
         for mm in range(T):
             if rmap[mm] < 0:
                 continue
@@ -138,7 +139,7 @@ def emulate_wgrad(pack, gp, x, G, S):
             if wb:
                 assert (p, m0 + mm) not in bias_rows
                 bias_rows.add((p, m0 + mm))
-                grads[boff + int(rmap[mm])] = dY[:, m0 + mm].sum()
-                written[boff + int(rmap[mm])] = True
+                grads[boff + int(bmap[mm])] = dY[:, m0 + mm].sum()
+                written[boff + int(bmap[mm])] = True
     assert np.array_equal(written, mask != 0)         # every unmasked entry and every bias exactly once, nothing else
     return grads

@@ -805,6 +805,13 @@ def test_conv_conditioner_as_pixel_mlp_matches_conv2d_autograd(Cin, hid, Cout, B
     assert np.abs(flat[o1:o1 + s1[0] * s1[1]].reshape(hid, hid) - c2.weight.grad.numpy()[:, :, 0, 0]).max() < 1e-9
     assert np.abs(flat[o2:o2 + s2[0] * s2[1]].reshape(3, 3, Cout, hid).transpose(2, 3, 0, 1) - c3.weight.grad.numpy()).max() < 1e-9
     assert np.abs(flat[b0:b0 + n0] - c1.bias.grad.numpy()).max() < 1e-9 and np.abs(flat[b1:b1 + n1] - c2.bias.grad.numpy()).max() < 1e-9
+    # the training structure's reduction maps scatter straight into the conv parameters' own (o, c, ky, kx) layouts
+    st = made_pack.convnet_train_structure(Cin, hid, Cout)
+    flat2 = E.emulate_wgrad(st["bwd"], gP, col, G, S)
+    assert np.abs(flat2[o0:o0 + s0[0] * s0[1]].reshape(hid, Cin, 3, 3) - c1.weight.grad.numpy()).max() < 1e-9
+    assert np.abs(flat2[o1:o1 + s1[0] * s1[1]].reshape(hid, hid, 1, 1) - c2.weight.grad.numpy()).max() < 1e-9
+    assert np.abs(flat2[o2:o2 + s2[0] * s2[1]].reshape(Cout, hid, 3, 3) - c3.weight.grad.numpy()).max() < 1e-9
+    assert np.abs(flat2[b0:b0 + n0] - c1.bias.grad.numpy()).max() < 1e-9 and np.abs(flat2[b1:b1 + n1] - c2.bias.grad.numpy()).max() < 1e-9
 
 
 def test_training_packs_as_gather_indices_reproduce_the_value_packs():
