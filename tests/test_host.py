@@ -863,6 +863,20 @@ def test_cache_keys_follow_fused_optimizer_steps():
     assert _keys.pkey([p]) != k1
 
 
+def test_conv_conditioner_training_path_declines_other_structures():
+    """autograd.ConvNetFn only takes the GlowBlock network (3x3 -> 1x1 -> 3x3, ReLU i.e. LeakyReLU(0), biases, 9 Cin <= 256 next to <= 256
+    hidden channels): anything else keeps the library path (nets.ConvNet2d._train_packs returns None before touching the device)."""
+    import normflows_amd as nfa
+    from normflows_amd.flows import made_pack
+    assert nfa.nets.ConvNet2d([6, 32, 32, 12], [3, 1, 3], leaky=0.1)._train_packs("cpu") is None            # leaky slope
+    assert nfa.nets.ConvNet2d([6, 32, 32, 12], [3, 3, 3])._train_packs("cpu") is None                       # kernel sizes
+    assert nfa.nets.ConvNet2d([6, 32, 12], [3, 3])._train_packs("cpu") is None                              # depth
+    assert nfa.nets.ConvNet2d([6, 32, 32, 12], [3, 1, 3], actnorm=True)._train_packs("cpu") is None         # no biases / extra layers
+    assert made_pack.convnet_train_structure(29, 256, 12) is None                                           # 9 Cin = 261 > 256
+    assert made_pack.convnet_train_structure(15, 300, 12) is None                                           # 9 Cin = 135 > 128 next to 512 slots
+    assert made_pack.convnet_train_structure(14, 300, 12) is not None
+
+
 def test_made_forward_pack_rejects_unsupported():
     from normflows_amd import nets
     from normflows_amd.flows import made_pack
