@@ -13,6 +13,7 @@ these Functions only when gradients are needed (`needs_grad`); under torch.no_gr
 import math
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _lib as L
 from . import config as _config
@@ -678,6 +679,7 @@ class Inv1x1WeightFn(torch.autograd.Function):
         return W, ldu
 
     @staticmethod
+    @once_differentiable          # (the backward is a set of kernels, not a differentiable graph: double backward raises)
     def backward(ctx, gW, gl):
         P, Lm, U, sign_S, log_S = ctx.saved_tensors
         if gW is None:
@@ -777,6 +779,7 @@ class MadeFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable          # (the backward is a set of kernels, not a differentiable graph: double backward raises)
     def backward(ctx, gout):
         x, save, bits = ctx.saved_tensors
         bwd = ctx.bwd
@@ -813,6 +816,7 @@ class ConvNetFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable          # (the backward is a set of kernels, not a differentiable graph: double backward raises)
     def backward(ctx, gout):
         col, save, bits = ctx.saved_tensors
         bwd = ctx.bwd
@@ -846,6 +850,7 @@ class MafAffineFn(torch.autograd.Function):
         return y, ld
 
     @staticmethod
+    @once_differentiable          # (the backward is a set of kernels, not a differentiable graph: double backward raises)
     def backward(ctx, gy, gld):
         x, params = ctx.saved_tensors
         gx, gp = ops.maf_affine_bwd(x, params, gy, gld, ctx.direction)
