@@ -838,6 +838,63 @@ class ConvNetFn(torch.autograd.Function):
         return None, None, gx, gw1, flat[c0:c0 + n0], gw2, flat[c1:c1 + n1], gw3, gout.sum((0, 2, 3))
 
 
+class MafInverseFn(torch.autograd.Function):
+    """MaskedAffineAutoregressive.inverse (affine/autoregressive.py:29-38 + :114-128: the DENSITY direction of the reference's MAF, D
+    sequential MADE passes) under autograd WITHOUT differentiating through the D passes.  x = T^-1(z) satisfies T(x; theta) = z with
+    T the single-pass direction (z = s(x) x + t(x), log|det| = sum log s), so for the cotangents (g_x, g_ld) of (x, -sum log s):
+
+        v solves   v s + J^T g_p(v, g_ld) = g_x      (J = dMADE/dx; g_p(a, c) = the affine transform's parameter cotangent for
+                                                      cotangent a on z and c on sum log s: nf_maf_affine_bwd)
+        g_z = v,   g_theta = MADE^T-weight-gradient of g_p(-v, -g_ld)
+
+    J^T is strictly upper triangular in the feature order (feature i only feeds features > i), so the iteration v <- (g_x - J^T g_p(v,
+    g_ld)) / s is EXACT after at most D sweeps (component i is final once the components > i are) and usually stops changing -- bit for
+    bit, the kernels are deterministic -- much earlier.  Forward: the one-pass inverse kernel (nf_maf_inverse_h); backward: one
+    nf_made_forward_train at x, one nf_made_backward per sweep, ONE nf_made_wgrad: memory of a single MADE pass instead of D."""
+
+    @staticmethod
+    def forward(ctx, inv, fwd, bwd, z, *params):
+        z = z.contiguous()
+        x, ld = ops.maf_inverse(z, inv[0], inv[1], inv[2], num_blocks=inv[3])
+        ctx.save_for_backward(x)
+        ctx.fwd, ctx.bwd = fwd, bwd
+        ctx.nparams = len(params)
+        ctx.set_materialize_grads(False)
+        return x, ld
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gx, gld):
+        (x,) = ctx.saved_tensors
+        fwd, bwd = ctx.fwd, ctx.bwd
+        B, D = x.shape
+        gx = torch.zeros_like(x) if gx is None else gx.contiguous()
+        gld = torch.zeros(B, dtype=x.dtype, device=x.device) if gld is None else gld.contiguous()
+        p, save, bits = ops.made_forward_train(x, fwd[0], fwd[1], fwd[2], 2 * D, bwd["NB"])
+        s = torch.sigmoid(p.view(B, D, 2)[..., 0] + 2.0) + 1e-3
+        v = gx / s
+        sweeps = 0
+        for sweeps in range(1, D + 1):
+            _, gp = ops.maf_affine_bwd(x, p, v, gld, 0)
+            gxm, _ = ops.made_backward(gp, bits, bwd["blob"], bwd["table"], D, bwd["Hp"], bwd["NB"])
+            vn = (gx - gxm) / s
+            done = torch.equal(vn, v)
+            v = vn
+            if done:
+                break
+        MafInverseFn.last_sweeps = sweeps
+        _, gp = ops.maf_affine_bwd(x, p, -v, -gld, 0)
+        grads = [None] * ctx.nparams
+        if any(ctx.needs_input_grad[4:]):
+            _, G = ops.made_backward(gp, bits, bwd["blob"], bwd["table"], D, bwd["Hp"], bwd["NB"])
+            flat = ops.made_wgrad(gp, x, G, save, bwd["wtable"], bwd["stable"], bwd["mask"], bwd["ntiles"], bwd["nflat"], bwd["Mp"],
+                                  bwd["Dx"])
+            for k, (woff, shape, boff, n) in enumerate(bwd["offsets"]):
+                grads[2 * k] = flat[woff:woff + shape[0] * shape[1]].view(shape)
+                grads[2 * k + 1] = flat[boff:boff + n]
+        return (None, None, None, v if ctx.needs_input_grad[3] else None) + tuple(grads)
+
+
 class MafAffineFn(torch.autograd.Function):
     """nf_maf_affine (affine/autoregressive.py:98-128) on given MADE output `params` (B, 2D); backward = nf_maf_affine_bwd."""
 

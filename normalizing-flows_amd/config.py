@@ -136,6 +136,17 @@ def set_made_train(mode=True):
     made_train = bool(mode)
 
 
+# MaskedAffineAutoregressive.inverse (the reference's DENSITY direction of MAF: D sequential MADE passes, autoregressive.py:29-38) under
+# autograd by implicit differentiation (autograd.MafInverseFn): the one-pass inverse kernel forward, the triangular system of the
+# backward solved with the MADE input-gradient chain, ONE weight-gradient launch; False = torch autograd through the D-pass loop.
+maf_implicit = True
+
+
+def set_maf_implicit(mode=True):
+    global maf_implicit
+    maf_implicit = bool(mode)
+
+
 # CoupledRationalQuadraticSpline beyond the benchmark kernel's shapes (D <= 128, hidden <= 512, 8 bins) as ONE launch (nf_nsf_wide,
 # csrc/nsf_wide.hip); False = library GEMMs for the conditioner + nf_rqs_coupling (ablation / differential tests).
 nsf_wide = True

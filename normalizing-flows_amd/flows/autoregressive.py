@@ -96,7 +96,36 @@ class MaskedAffineAutoregressive(Autoregressive):
             packed = self._packed(inputs.device)
             if packed is not None:
                 return ops.maf_inverse(inputs, packed[0], packed[1], packed[2], num_blocks=packed[3])
+        from .. import config
+        if (context is None and inputs.dim() == 2 and inputs.dtype == torch.float32 and inputs.is_cuda and config.maf_implicit
+                and config.made_train and config.made_fused):
+            packs = self._implicit_packs(inputs.device)
+            if packs is not None:          # autograd.MafInverseFn: implicit differentiation instead of autograd through the D passes
+                plist = [t for l in self.autoregressive_net._linears() for t in (l.weight, l.bias)]
+                return autograd.MafInverseFn.apply(packs[0], packs[1], packs[2], inputs, *plist)
         return super().inverse(inputs, context)
+
+    def _implicit_packs(self, device):
+        """(inverse pack, forward pack, backward pack) gathered on the device from the CURRENT parameters (value-independent structures
+        cached per module: flows/made_pack.maf_inverse_structure / made_train_structure); None outside those structures."""
+        from ..flows import made_pack
+        net = self.autoregressive_net
+        plist = [t for l in net._linears() for t in (l.weight, l.bias)]
+        skey = tuple((l.mask.data_ptr(), l.mask._version) for l in net._linears())
+        packs = nets._train_packs_from(net, lambda: made_pack.made_train_structure(net, 2), plist, device, skey=skey)
+        if packs is None:
+            return None
+        st = self.__dict__.get("_inv_struct")
+        if st is None or st[0] != (str(device),) + skey:
+            struct = made_pack.maf_inverse_structure(net)
+            if struct is not None:
+                struct = (torch.from_numpy(struct[0]).to(device), torch.from_numpy(struct[1]).to(device), int(struct[1][3]),
+                          int(struct[1][6]))
+            st = self.__dict__["_inv_struct"] = ((str(device),) + skey, struct)
+        if st[1] is None:
+            return None
+        src, table, hp, nb = st[1]
+        return (ops.pack_gather(plist, src), table, hp, nb), packs[0], packs[1]
 
     def _elementwise(self, inputs, params, direction, want_logdet=True):
         if inputs.dim() != 2:

@@ -587,3 +587,21 @@ def convnet_train_structure(cin, hid, cout):
         ((np.arange(cout)[None, :] * hid * 9 + tap[:, None]).reshape(-1), ch3 * 9, 1, np.arange(9 * cout)),     # conv3: W3t[tap cout + o][c]
     ]
     return train_structure(sl_v, _mlp_layers(w1, b1, w2, b2, w3, None), padded_rows=True)
+
+
+def maf_inverse_structure(made, blocks=(1, 2, 3)):
+    """(gather indices, table) of the one-pass inverse kernel's pack (flows/maf_pack.pack_made: a pure rearrangement as well) over
+    the same flat parameter vector as the training structures -- the packer run on a copy of the MADE that holds parameter
+    positions instead of values; None outside that packer's structure."""
+    import copy
+    from . import maf_pack
+    if maf_pack.pack_made(made, blocks=blocks) is None:
+        return None
+    twin = copy.deepcopy(made).cpu()
+    lins = [twin.initial_layer] + [l for b in twin.blocks for l in b.linear_layers] + [twin.final_layer]
+    with torch.no_grad():
+        for lin, (w, b) in zip(lins, index_arrays([tuple(l.weight.shape) for l in lins])):
+            lin.weight.copy_(torch.from_numpy(w.astype(np.float32)))
+            lin.bias.copy_(torch.from_numpy(b.astype(np.float32)))
+    blob, table = maf_pack.pack_made(twin, blocks=blocks)
+    return _as_src(blob), table

@@ -433,9 +433,13 @@ def test_maf_gradients_vs_reference_autograd(nfa, monkeypatch):
     hand-written forward / backward kernels (1 single-pass call + 5 passes of the loop)."""
     g = load_golden("grad_maf_d5")
     layer = load_layer(nfa.flows.MaskedAffineAutoregressive(5, 12, num_blocks=2), golden_state(g), torch.float32)
+    from normflows_amd.autograd import MafInverseFn
     calls = _spy_made(monkeypatch)
     check_layer_grads(layer, g, rtol=2e-3, atol=2e-4)
-    assert calls == {"fwd": 6, "bwd": 6, "wgrad": 6}, calls
+    # single-pass direction: one forward / chain / weight-gradient launch; density direction (autograd.MafInverseFn, implicit
+    # differentiation): one forward at the solution, one chain per sweep (<= D = 5) + one for the weight gradients, one weight-gradient launch
+    assert calls["fwd"] == 2 and calls["wgrad"] == 2 and 3 <= calls["bwd"] <= 2 + 5 + 1, calls
+    assert 1 <= MafInverseFn.last_sweeps <= 5
 
 
 def test_arnsf_gradients_vs_reference_autograd(nfa):
@@ -1565,3 +1569,37 @@ def test_training_kernels_random_shapes(nfa):
         torch.manual_seed(100 + k)
         net = nfa.nets.ConvNet2d([Cin, hid, hid, Cout], [3, 1, 3], init_zeros=False).to(DEV)
         compare(net, torch.randn(B, Cin, H, W, device=DEV), torch.randn(B, Cout, H, W, device=DEV))
+
+
+
+@pytest.mark.parametrize("D,H,NB,B", [(20, 40, 2, 130), (64, 256, 2, 300), (128, 512, 2, 200), (7, 24, 3, 5)])
+def test_maf_density_direction_implicit_vs_d_pass_autograd(nfa, D, H, NB, B):
+    """MaskedAffineAutoregressive.inverse under autograd (the reference's density direction: D sequential MADE passes,
+    autoregressive.py:29-38): implicit differentiation on the one-pass inverse kernel + MADE chain sweeps (autograd.MafInverseFn)
+    against torch autograd through the D-pass loop itself (config.set_maf_implicit(False); each pass on the MADE training kernels):
+    outputs 1e-4, every gradient 2e-4 of its scale; the sweep count stays at or below D."""
+    from normflows_amd.autograd import MafInverseFn
+    torch.manual_seed(D + H)
+    layer = nfa.flows.MaskedAffineAutoregressive(D, H, num_blocks=NB)
+    gen = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=gen))
+    layer = layer.to(DEV)
+    z0 = torch.randn(B, D, generator=torch.Generator().manual_seed(1)).to(DEV)
+    cx, cl = torch.randn(B, D, device=DEV), torch.randn(B, device=DEV)
+    res = []
+    for mode in (True, False):
+        nfa.config.set_maf_implicit(mode)
+        try:
+            layer.zero_grad(set_to_none=True)
+            z = z0.clone().requires_grad_(True)
+            x, ld = layer.inverse(z)
+            ((x * cx).sum() + (ld * cl).sum()).backward()
+            res.append([x.detach(), ld.detach(), z.grad] + [p.grad.clone() for p in layer.parameters()])
+        finally:
+            nfa.config.set_maf_implicit(True)
+    assert 1 <= MafInverseFn.last_sweeps <= D
+    for k, (a, b) in enumerate(zip(res[0], res[1])):
+        tol = 1e-4 if k < 2 else 2e-4
+        assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max())), (k, float((a - b).abs().max()), float(b.abs().max()))
