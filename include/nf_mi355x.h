@@ -531,7 +531,8 @@ int nf_made_forward_spline(const void *x, void *y, void *logdet, const void *blo
  * gradient.  Bp = B rounded up to 64, NB = residual blocks, Hp = hidden_padded.
  *   nf_made_forward_train : nf_made_forward + save ((2 NB + 1) x Bp x Hp floats: the pre-activations h0, t_b, h_(b+1) in slot order,
  *                           rows beyond B zero) + bits ((Bp / 64) x 2 NB x 2 x 512 dwords: the signs of what a ReLU follows).
- *   nf_made_backward      : g_params (B, mult D) -> g_x (B, D) and G ((2 NB + 1) x Bp x Hp: the gradient at every layer's output);
+ *   nf_made_backward      : g_params (B, mult D) -> g_x (B, D) and G ((2 NB + 1) x Bp x Hp: the gradient at every layer's output;
+ *                           NULL = not stored: the sweeps of the implicit MAF backward only want g_x);
  *                           blob / table: made_pack.pack_made_backward (transposed masked weights, k-group ranges per row-block).
  *   nf_made_wgrad         : every weight / bias gradient in one launch over the non-zero 128 x 128 tiles + a fixed-order reduction
  *                           (deterministic); grads = flat vector in the packer's layout, zero-filled by the caller, written where

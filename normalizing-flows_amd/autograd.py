@@ -876,7 +876,7 @@ class MafInverseFn(torch.autograd.Function):
         sweeps = 0
         for sweeps in range(1, D + 1):
             _, gp = ops.maf_affine_bwd(x, p, v, gld, 0)
-            gxm, _ = ops.made_backward(gp, bits, bwd["blob"], bwd["table"], D, bwd["Hp"], bwd["NB"])
+            gxm, _ = ops.made_backward(gp, bits, bwd["blob"], bwd["table"], D, bwd["Hp"], bwd["NB"], want_G=False)
             vn = (gx - gxm) / s
             done = torch.equal(vn, v)
             v = vn

@@ -88,7 +88,7 @@ made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits,
             }
         }
 #pragma unroll
-        for (int s = 0; s < 2; ++s) mf_save_rows<NS, false>(gtile + (size_t)(2 * NB) * Bp * HP, HP, nrows, rbs[s], sb0s[s], hh, n, gh[s]);
+        for (int s = 0; s < 2; ++s) if (G) mf_save_rows<NS, false>(gtile + (size_t)(2 * NB) * Bp * HP, HP, nrows, rbs[s], sb0s[s], hh, n, gh[s]);
         // ---- residual blocks, last first ------------------------------------------------------------------------------------------------
         if (plain) {
             const int *itb = items + 4 * (2 * NC);
@@ -101,7 +101,7 @@ made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits,
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 mf_masked<NS, false>(gh[s], gh[s], bt[s]);               // g_t (G[2] above holds the unmasked product: unused)
-                mf_save_rows<NS, false>(gtile + (size_t)1 * Bp * HP, HP, nrows, rbs[s], sb0s[s], hh, n, gh[s]);
+                if (G) mf_save_rows<NS, false>(gtile + (size_t)1 * Bp * HP, HP, nrows, rbs[s], sb0s[s], hh, n, gh[s]);
             }
             MF_BARRIER();
 #pragma unroll
@@ -115,7 +115,7 @@ made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits,
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 mf_masked<NS, false>(gh[s], u[s], bh[s]);                // g_h
-                mf_save_rows<NS, false>(gtile, HP, nrows, rbs[s], sb0s[s], hh, n, gh[s]);
+                if (G) mf_save_rows<NS, false>(gtile, HP, nrows, rbs[s], sb0s[s], hh, n, gh[s]);
             }
         }
         for (int b = plain ? -1 : NB - 1; b >= 0; --b) {
@@ -138,7 +138,7 @@ made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits,
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 mf_masked<NS, false>(u[s], u[s], bt[s]);                 // g_t
-                mf_save_rows<NS, false>(gtile + (size_t)(2 * b + 1) * Bp * HP, HP, nrows, rbs[s], sb0s[s], hh, n, u[s]);
+                if (G) mf_save_rows<NS, false>(gtile + (size_t)(2 * b + 1) * Bp * HP, HP, nrows, rbs[s], sb0s[s], hh, n, u[s]);
             }
             MF_BARRIER();
 #pragma unroll
@@ -152,7 +152,7 @@ made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits,
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 mf_masked<NS, true>(gh[s], u[s], bh[s]);                 // g_h of the block's input
-                mf_save_rows<NS, false>(gtile + (size_t)(2 * b) * Bp * HP, HP, nrows, rbs[s], sb0s[s], hh, n, gh[s]);
+                if (G) mf_save_rows<NS, false>(gtile + (size_t)(2 * b) * Bp * HP, HP, nrows, rbs[s], sb0s[s], hh, n, gh[s]);
             }
         }
         // ---- g_x = W0^T g_h: one 32-feature row-block and sample block per wave ------------------------------------------------------
@@ -360,13 +360,14 @@ static int made_bwd_check(int64_t B, int D, int hidden_padded, int mult) {
 }
 
 // The input-gradient chain of MADE: g_params (B, mult D) -> g_x (B, D), and every layer's output gradient to G ((2 num_blocks + 1) x
-// Bp x hidden_padded, Bp = B rounded up to 64).  bits: from nf_made_forward_train; blob / table: flows/made_pack.pack_made_backward.
+// Bp x hidden_padded, Bp = B rounded up to 64; NULL: not stored).  bits: from nf_made_forward_train; blob / table:
+// flows/made_pack.pack_made_backward.
 extern "C" int nf_made_backward(const void *g_params, const void *bits, void *g_x, void *G, const void *blob, const int32_t *table,
                                 int64_t B, int D, int hidden_padded, int mult, nf_stream_t stream) {
     const int rc = made_bwd_check(B, D, hidden_padded, mult);
     if (rc != NF_OK) return rc;
     if (B == 0) return NF_OK;
-    if (!g_params || !bits || !g_x || !G || !blob || !table) return NF_EFAULT;
+    if (!g_params || !bits || !g_x || !blob || !table) return NF_EFAULT;       // (G may be NULL: only g_x is wanted)
     hipStream_t st = (hipStream_t)stream;
     const int dp = (D + 31) / 32 * 32;
     if (hidden_padded == 256) return nf::made_bwd_launch<1>(g_params, bits, g_x, G, blob, table, B, st, dp);

@@ -994,7 +994,7 @@ def made_forward_train(x, blob, table, hidden_padded, out_features, num_blocks, 
     return params, save, bits
 
 
-def made_backward(g_params, bits, blob, table, D, hidden_padded, num_blocks, rows=None, out_features=None, ld_out=None):
+def made_backward(g_params, bits, blob, table, D, hidden_padded, num_blocks, rows=None, out_features=None, ld_out=None, want_G=True):
     """The input-gradient chain of MADE (nf_made_backward): g_x (B, D) and every layer's output gradient G (2 NB + 1, Bp, Hp).
     rows / out_features / ld_out: g_params is a padded buffer (row strides in the table's hdr[14], hdr[15]) and so is the returned
     g_x (rows, ld_out): the conv path."""
@@ -1004,7 +1004,7 @@ def made_backward(g_params, bits, blob, table, D, hidden_padded, num_blocks, row
     g_params = g_params.contiguous()
     Bp = (B + 63) // 64 * 64
     gx = torch.empty(B, D if ld_out is None else ld_out, dtype=g_params.dtype, device=g_params.device)
-    G = torch.empty(2 * num_blocks + 1, Bp, hidden_padded, dtype=g_params.dtype, device=g_params.device)
+    G = torch.empty(2 * num_blocks + 1, Bp, hidden_padded, dtype=g_params.dtype, device=g_params.device) if want_G else None
     rc = L.lib().nf_made_backward(ptr(g_params), ptr(bits), ptr(gx), ptr(G), ptr(blob), ptr(table), i64(B), i32(D),
                                   i32(hidden_padded), i32(max(1, md // D)), L.stream())
     L.check(rc, "nf_made_backward")

@@ -141,13 +141,30 @@ def c5():
         dtl = timed(train_step, 2)
     finally:
         nfa.config.set_made_train(True)
+    # forward_kld (core.py:87-102: the DENSITY direction = flow.inverse, D sequential MADE passes per layer in the reference) + backward +
+    # Adam by implicit differentiation (autograd.MafInverseFn): memory of one MADE pass per layer instead of D
+    from normflows_amd.autograd import MafInverseFn
+
+    def kld_step():
+        opt.zero_grad(set_to_none=True)
+        m.forward_kld(x).backward()
+        opt.step()
+    kld_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kld_step()
+    kld_step()
+    torch.cuda.synchronize()
+    dtk = (time.perf_counter() - t0) / 2
     print("config 5 MAF 10 layers d=128 B=65536: inverse pass %.1f ms (%.0f samples/s), forward pass %.1f ms, round-trip max err %.2e; "
-          "training step (single-pass direction) %.1f ms (library GEMMs: %.1f ms)" % (dt * 1e3, 65536 / dt, dtf * 1e3, err, dtt * 1e3,
-                                                                                    dtl * 1e3))
+          "training step (single-pass direction) %.1f ms (library GEMMs: %.1f ms); forward_kld step (density direction, implicit "
+          "differentiation) %.0f ms, %d sweeps in the last layer" % (dt * 1e3, 65536 / dt, dtf * 1e3, err, dtt * 1e3, dtl * 1e3,
+                                                                    dtk * 1e3, MafInverseFn.last_sweeps))
     return {"workload": "BASELINE configs[4]: 10 x MaskedAffineAutoregressive(128, hidden 512), batch 65536",
             "inverse_pass_ms": dt * 1e3, "forward_pass_ms": dtf * 1e3, "inverse_samples_per_s": 65536 / dt,
             "round_trip_max_abs_err": err, "roofline_inverse_pass": roof(dt * 1e3), "roofline_forward_pass": roof(dtf * 1e3),
             "train_step_single_pass_ms": dtt * 1e3, "train_step_single_pass_library_gemm_ms": dtl * 1e3,
+            "forward_kld_step_density_direction_ms": dtk * 1e3, "implicit_backward_sweeps_last_layer": MafInverseFn.last_sweeps,
             "roofline_train_step": {"bound": "mfma", "achieved": 3 * flop / dtt / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                                     "frac": 3 * flop / dtt / 157.3e12, "flop_per_step_masked": 3 * flop}}
 

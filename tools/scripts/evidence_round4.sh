@@ -43,7 +43,7 @@ bash tools/scripts/wide_pmc.sh 128 128 > $O/wide_pmc_128_128.log 2>&1
 # MADE under autograd (csrc/made_bwd.hip): per-kernel split at config 5's layer, hand-written vs library path, the 10-layer step
 (cd /tmp; timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/made_train_stats -- python $R/tools/made_train_bench.py --only > $O/made_train_stats.log 2>&1)
 cp $(find $O/made_train_stats -name "*kernel_stats.csv" | head -1) profiles/r04_made_train_kernel_stats.csv 2>/dev/null
-(python tools/made_train_bench.py; python tools/made_train_bench.py --mult 23 --batch 16384; python tools/maf_train_bench.py; python tools/wide_train_bench.py; python tools/glow_train_bench.py) 2> /dev/null | grep "^{" > profiles/r04_made_train.jsonl
+(python tools/made_train_bench.py; python tools/made_train_bench.py --mult 23 --batch 16384; python tools/maf_train_bench.py; python tools/wide_train_bench.py; python tools/glow_train_bench.py; python tools/maf_density_train_bench.py) 2> /dev/null | grep "^{" > profiles/r04_made_train.jsonl
 (cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/glow_train_stats -- python $R/tools/glow_train_bench.py > $O/glow_train_stats.log 2>&1)
 cp $(find $O/glow_train_stats -name "*kernel_stats.csv" | head -1) profiles/r04_glow_train_kernel_stats.csv 2>/dev/null
 cp profiles/r04_* $R/gpurun_out/profiles_out/ 2>/dev/null
