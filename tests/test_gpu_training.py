@@ -1603,3 +1603,45 @@ def test_maf_density_direction_implicit_vs_d_pass_autograd(nfa, D, H, NB, B):
     for k, (a, b) in enumerate(zip(res[0], res[1])):
         tol = 1e-4 if k < 2 else 2e-4
         assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max())), (k, float((a - b).abs().max()), float(b.abs().max()))
+
+
+def test_training_step_captures_into_one_graph(nfa):
+    """forward + backward of the hand-written training paths (MADE Function, conv conditioner, 1x1-conv LU parametrisation, couplings,
+    ActNorm) records into ONE hipGraph with PyTorch's whole-network capture recipe -- no host synchronisation, no host-side packing in
+    the step -- and a replay reproduces the eager step's gradients bit for bit (Glow config 4: 71 -> 57 ms, tools/train_graph_probe.py)."""
+    torch.manual_seed(0)
+    fl = [[nfa.flows.GlowBlock(12, 64, split_mode="channel", scale=True) for _ in range(2)] + [nfa.flows.Squeeze()]]
+    glow = nfa.MultiscaleFlow([nfa.distributions.DiagGaussian((12, 4, 4))], fl, [], class_cond=False).to(DEV)
+    ximg = torch.rand(16, 3, 8, 8, device=DEV)
+    with torch.no_grad():
+        glow.log_prob(ximg)                       # ActNorm's data-dependent init
+    maf = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(12, trainable=False),
+                              [nfa.flows.MaskedAffineAutoregressive(12, 40, num_blocks=2) for _ in range(2)]).to(DEV)
+    eps = torch.randn(200, 12, device=DEV)
+
+    def maf_loss(mm, e):
+        z, logq = e, torch.zeros(e.shape[0], device=DEV)
+        for f in mm.flows:
+            z, ld = f(z)
+            logq = logq - ld
+        return (logq + 0.5 * (z ** 2).sum(1)).mean()
+    for m, x, lossfn in ((glow, ximg, lambda mm, xx: mm.forward_kld(xx)), (maf, eps, maf_loss)):
+        def step():
+            m.zero_grad(set_to_none=True)
+            lossfn(m, x).backward()
+        step()
+        eager = [p.grad.clone() for p in m.parameters()]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        m.zero_grad(set_to_none=True)
+        with torch.cuda.graph(g):
+            lossfn(m, x).backward()
+        g.replay()
+        g.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, p.grad) for a, p in zip(eager, m.parameters()))
