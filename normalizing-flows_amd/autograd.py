@@ -878,7 +878,10 @@ class MafInverseFn(torch.autograd.Function):
             _, gp = ops.maf_affine_bwd(x, p, v, gld, 0)
             gxm, _ = ops.made_backward(gp, bits, bwd["blob"], bwd["table"], D, bwd["Hp"], bwd["NB"], want_G=False)
             vn = (gx - gxm) / s
-            done = torch.equal(vn, v)
+            if _config.maf_implicit_rtol > 0.0:
+                done = bool((vn - v).abs().max() <= _config.maf_implicit_rtol * vn.abs().max())
+            else:
+                done = torch.equal(vn, v)
             v = vn
             if done:
                 break

@@ -140,11 +140,16 @@ def set_made_train(mode=True):
 # autograd by implicit differentiation (autograd.MafInverseFn): the one-pass inverse kernel forward, the triangular system of the
 # backward solved with the MADE input-gradient chain, ONE weight-gradient launch; False = torch autograd through the D-pass loop.
 maf_implicit = True
+# stop the sweeps once max |v_new - v| <= rtol * max |v| (0.0 = until v stops changing bit for bit: the exact solution of the triangular
+# system; 1e-6 saves the last ~15 % of the sweeps at float32-noise-level gradient changes)
+maf_implicit_rtol = 0.0
 
 
-def set_maf_implicit(mode=True):
-    global maf_implicit
+def set_maf_implicit(mode=True, rtol=None):
+    global maf_implicit, maf_implicit_rtol
     maf_implicit = bool(mode)
+    if rtol is not None:
+        maf_implicit_rtol = float(rtol)
 
 
 # CoupledRationalQuadraticSpline beyond the benchmark kernel's shapes (D <= 128, hidden <= 512, 8 bins) as ONE launch (nf_nsf_wide,
