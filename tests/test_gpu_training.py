@@ -1645,3 +1645,31 @@ def test_training_step_captures_into_one_graph(nfa):
         g.replay()
         torch.cuda.synchronize()
         assert all(torch.equal(a, p.grad) for a, p in zip(eager, m.parameters()))
+
+
+@pytest.mark.parametrize("which", ["x_only", "ld_only"])
+def test_maf_implicit_backward_with_one_cotangent_absent(nfa, which):
+    """The implicit backward when the loss sees only the outputs or only the log-det (the other cotangent arrives as None), and with
+    the optional tolerance stop: same gradients as autograd through the D-pass loop."""
+    torch.manual_seed(4)
+    layer = nfa.flows.MaskedAffineAutoregressive(24, 64, num_blocks=2)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    layer = layer.to(DEV)
+    z0 = torch.randn(150, 24, device=DEV)
+    c = torch.randn(150, 24, device=DEV)
+    res = []
+    for mode, rtol in ((True, 0.0), (True, 1e-6), (False, 0.0)):
+        nfa.config.set_maf_implicit(mode, rtol=rtol)
+        try:
+            layer.zero_grad(set_to_none=True)
+            z = z0.clone().requires_grad_(True)
+            x, ld = layer.inverse(z)
+            ((x * c).sum() if which == "x_only" else (ld * c[:, 0]).sum()).backward()
+            res.append([z.grad] + [p.grad.clone() for p in layer.parameters()])
+        finally:
+            nfa.config.set_maf_implicit(True, rtol=0.0)
+    for r in res[:2]:
+        for a, b in zip(r, res[2]):
+            assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max()))
