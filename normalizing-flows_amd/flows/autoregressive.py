@@ -73,12 +73,33 @@ class MaskedAffineAutoregressive(Autoregressive):
         key = _keys.pkey(self.autoregressive_net.parameters()) + (str(device),)
         cache = getattr(self, "_maf_pack_cache", None)
         if cache is None or cache[0] != key:
-            packed = maf_pack.pack_made(self.autoregressive_net, blocks=(1, 2, 3))    # 1..3 residual blocks: nf_maf_inverse_h
-            if packed is not None:
-                blob, table = packed
-                packed = (torch.from_numpy(blob).to(device), torch.from_numpy(table).to(device), int(table[3]), int(table[6]))
+            if str(device) != "cpu":      # structure (shared by layers with these masks) + one gather on the device
+                st = self._inverse_struct(device)
+                packed = None
+                if st is not None:
+                    plist = [t for l in self.autoregressive_net._linears() for t in (l.weight, l.bias)]
+                    packed = (ops.pack_gather(plist, st[0]), st[1], st[2], st[3])
+            else:
+                packed = maf_pack.pack_made(self.autoregressive_net, blocks=(1, 2, 3))    # 1..3 residual blocks: nf_maf_inverse_h
+                if packed is not None:
+                    blob, table = packed
+                    packed = (torch.from_numpy(blob).to(device), torch.from_numpy(table).to(device), int(table[3]), int(table[6]))
             self._maf_pack_cache = cache = (key, packed)
         return cache[1]
+
+    def _inverse_struct(self, device):
+        """(gather indices, table, hidden_padded, num_blocks) of the one-pass inverse kernel's pack on the device; None = unsupported."""
+        from ..flows import made_pack
+        net = self.autoregressive_net
+        skey = (str(device),) + tuple((l.mask.data_ptr(), l.mask._version) for l in net._linears())
+        st = self.__dict__.get("_inv_struct")
+        if st is None or st[0] != skey:
+            struct = made_pack.maf_inverse_structure(net)
+            if struct is not None:
+                struct = (torch.from_numpy(struct[0]).to(device), torch.from_numpy(struct[1]).to(device), int(struct[1][3]),
+                          int(struct[1][6]))
+            st = self.__dict__["_inv_struct"] = (skey, struct)
+        return st[1]
 
     def forward(self, inputs, context=None):
         """autoregressive.py:24-27: one MADE pass + the element-wise affine map -- ONE launch (nf_made_forward_affine) for the
@@ -115,16 +136,10 @@ class MaskedAffineAutoregressive(Autoregressive):
         packs = nets._train_packs_from(net, lambda: made_pack.made_train_structure(net, 2), plist, device, skey=skey)
         if packs is None:
             return None
-        st = self.__dict__.get("_inv_struct")
-        if st is None or st[0] != (str(device),) + skey:
-            struct = made_pack.maf_inverse_structure(net)
-            if struct is not None:
-                struct = (torch.from_numpy(struct[0]).to(device), torch.from_numpy(struct[1]).to(device), int(struct[1][3]),
-                          int(struct[1][6]))
-            st = self.__dict__["_inv_struct"] = ((str(device),) + skey, struct)
-        if st[1] is None:
+        inv = self._inverse_struct(device)
+        if inv is None:
             return None
-        src, table, hp, nb = st[1]
+        src, table, hp, nb = inv
         return (ops.pack_gather(plist, src), table, hp, nb), packs[0], packs[1]
 
     def _elementwise(self, inputs, params, direction, want_logdet=True):

@@ -545,25 +545,62 @@ def train_structure(sl_values, sl_index, padded_rows=False):
     return dict(table=fwd_v[1], src=_as_src(fwd_i[0]), hp=int(fwd_v[1][3]), bwd=bwd)
 
 
-def made_train_structure(made, mult):
-    sl = _slot_layers(made, mult)
-    if sl is None:
+_STRUCTS = {}        # value-independent structures by what they depend on (masks / shapes): the layers of a model share them
+
+
+def _shared(key, build):
+    if key not in _STRUCTS:
+        if len(_STRUCTS) > 64:
+            _STRUCTS.clear()
+        _STRUCTS[key] = build()
+    st = _STRUCTS[key]
+    if st is None:
         return None
-    lins = [made.initial_layer] + [l for b in made.blocks for l in b.linear_layers] + [made.final_layer]
-    return train_structure(sl, _slot_layers(made, mult, wb=index_arrays([tuple(l.weight.shape) for l in lins])))
+    if isinstance(st, dict):          # the caller replaces entries by device tensors: hand out copies of the containers
+        st = dict(st)
+        st["bwd"] = dict(st["bwd"])
+    return st
+
+
+def _mask_key(made):
+    import hashlib
+    h = hashlib.sha1()
+    for l in [made.initial_layer] + [l for b in made.blocks for l in b.linear_layers] + [made.final_layer]:
+        h.update(np.ascontiguousarray(l.mask.cpu().numpy() != 0).tobytes())
+        h.update(str(tuple(l.mask.shape)).encode())
+    return h.hexdigest()
+
+
+def made_train_structure(made, mult):
+    def build():
+        sl = _slot_layers(made, mult)
+        if sl is None:
+            return None
+        lins = [made.initial_layer] + [l for b in made.blocks for l in b.linear_layers] + [made.final_layer]
+        return train_structure(sl, _slot_layers(made, mult, wb=index_arrays([tuple(l.weight.shape) for l in lins])))
+    if not supported(made, mult):
+        return None
+    return _shared(("made", mult, _mask_key(made)), build)
 
 
 def resnet_train_structure(net):
-    sl = _dense_layers(net)
-    if sl is None:
+    def build():
+        sl = _dense_layers(net)
+        lins = [net.initial_layer] + [l for b in net.blocks for l in b.linear_layers] + [net.final_layer]
+        return train_structure(sl, _dense_layers(net, wb=index_arrays([tuple(l.weight.shape) for l in lins])))
+    if not resnet_supported(net):
         return None
-    lins = [net.initial_layer] + [l for b in net.blocks for l in b.linear_layers] + [net.final_layer]
-    return train_structure(sl, _dense_layers(net, wb=index_arrays([tuple(l.weight.shape) for l in lins])))
+    return _shared(("resnet", net.initial_layer.in_features, net.initial_layer.out_features, len(net.blocks),
+                    net.final_layer.out_features), build)
 
 
 def convnet_train_structure(cin, hid, cout):
     """3x3 -> 1x1 -> 3x3 conv conditioner over pixel rows (plain-MLP mode); flat vector = [0, conv1.weight, conv1.bias, conv2.weight,
     conv2.bias, conv3.weight] flattened in their own layouts."""
+    return _shared(("conv", cin, hid, cout), lambda: _convnet_train_structure(cin, hid, cout))
+
+
+def _convnet_train_structure(cin, hid, cout):
     o1 = 1
     w1 = (o1 + np.arange(hid * cin * 9, dtype=np.int64)).reshape(hid, cin, 3, 3).transpose(0, 2, 3, 1).reshape(hid, 9 * cin)
     ob1 = o1 + hid * cin * 9
@@ -593,6 +630,18 @@ def maf_inverse_structure(made, blocks=(1, 2, 3)):
     """(gather indices, table) of the one-pass inverse kernel's pack (flows/maf_pack.pack_made: a pure rearrangement as well) over
     the same flat parameter vector as the training structures -- the packer run on a copy of the MADE that holds parameter
     positions instead of values; None outside that packer's structure."""
+    import copy
+    from . import maf_pack
+    if not maf_pack.supported(made, 2, blocks):
+        return None
+    key = ("maf_inverse", tuple(blocks), _mask_key(made))
+    if key in _STRUCTS:
+        return _STRUCTS[key]
+    _STRUCTS[key] = _maf_inverse_structure(made, blocks)
+    return _STRUCTS[key]
+
+
+def _maf_inverse_structure(made, blocks):
     import copy
     from . import maf_pack
     if maf_pack.pack_made(made, blocks=blocks) is None:

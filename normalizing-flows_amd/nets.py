@@ -61,6 +61,18 @@ def _train_packs_from(module, build, params, device, skey=()):
     """(forward pack, backward pack) for autograd.MadeFn / ConvNetFn: the value-independent structure (tables, gather indices:
     flows/made_pack.train_structure) is built once per module and device; the weight streams are gathered on the device from the
     parameters as they are in THIS call (nf_pack_gather) -- under autograd they change every step."""
+    struct = _train_struct_for(module, build, device, skey)
+    if struct is None:
+        return None
+    from . import ops
+    bwd = dict(struct["bwd"])
+    both = ops.pack_gather(params, struct["src"])
+    bwd["blob"] = both[struct["nfwd"]:]
+    return (both[:struct["nfwd"]], struct["table"], struct["hp"]), bwd
+
+
+def _train_struct_for(module, build, device, skey=()):
+    """The module's value-independent pack structure with device copies of its tables and gather indices (built once)."""
     st = module.__dict__.get("_train_struct")
     skey = (str(device),) + tuple(skey)             # (skey: what the structure itself depends on, e.g. MADE's mask buffers)
     if st is None or st[0] != skey:
@@ -74,14 +86,7 @@ def _train_packs_from(module, build, params, device, skey=()):
             struct["nfwd"] = int(struct["src"].size)             # one gather for both streams: [forward | backward]
             struct["src"] = torch.cat([torch.from_numpy(struct["src"]), bwd["src"].cpu()]).to(device)
         st = module.__dict__["_train_struct"] = (skey, struct)
-    struct = st[1]
-    if struct is None:
-        return None
-    from . import ops
-    bwd = dict(struct["bwd"])
-    both = ops.pack_gather(params, struct["src"])
-    bwd["blob"] = both[struct["nfwd"]:]
-    return (both[:struct["nfwd"]], struct["table"], struct["hp"]), bwd
+    return st[1]
 
 
 class ResidualNet(nn.Module):
@@ -580,10 +585,21 @@ class MADE(nn.Module):
         if cache is None or cache[0] != key:
             from .flows import made_pack
             mult = self.final_layer.out_features // self.initial_layer.in_features
-            packed = made_pack.pack_made_forward(self, mult, spline=bool(spline))
-            if packed is not None:
-                blob, table = packed
-                packed = (torch.from_numpy(blob).to(device), torch.from_numpy(table).to(device), int(table[3]), mult)
+            if not spline and str(device) != "cpu":
+                # the value-independent structure (shared by every layer with these masks) + ONE gather on the device: a changed
+                # parameter costs microseconds here, not a 0.4 s host repack (the spline pack carries scaled rows: host path below)
+                plist = [t for l in self._linears() for t in (l.weight, l.bias)]
+                st = _train_struct_for(self, lambda: made_pack.made_train_structure(self, mult), device,
+                                       skey=tuple((l.mask.data_ptr(), l.mask._version) for l in self._linears()))
+                packed = None
+                if st is not None:
+                    from . import ops
+                    packed = (ops.pack_gather(plist, st["src"][:st["nfwd"]]), st["table"], st["hp"], mult)
+            else:
+                packed = made_pack.pack_made_forward(self, mult, spline=bool(spline))
+                if packed is not None:
+                    blob, table = packed
+                    packed = (torch.from_numpy(blob).to(device), torch.from_numpy(table).to(device), int(table[3]), mult)
             cache = caches[bool(spline)] = (key, packed)
         return cache[1]
 
