@@ -557,8 +557,10 @@ int nf_pack_gather(const void *flat, const int32_t *src, void *out, int64_t n, n
  * neighbours per pixel (nf_conv3x3_gather: col (B H W, 9 C)) in front of a per-pixel linear layer, or a per-pixel linear layer to 9 C
  * tap products followed by a sum over the 9 neighbours (nf_conv3x3_gather_sum); the per-pixel MLP (9 Cin -> hidden -> hidden -> 9 Cout)
  * runs on nf_made_forward_train / nf_made_backward / nf_made_wgrad with tables in plain-MLP mode (made_pack.pack_mlp_*).  flip = 1
- * negates the offsets: the backward pass's gather of the output cotangent and gather-sum of the column cotangent. */
-int nf_conv3x3_gather(const void *in, void *col, int64_t B, int C, int H, int W, int ld, int flip, nf_stream_t stream);
+ * negates the offsets: the backward pass's gather of the output cotangent and gather-sum of the column cotangent; batch_stride
+ * (elements, >= C H W) lets the gather read a channel split of a wider NCHW tensor in place. */
+int nf_conv3x3_gather(const void *in, void *col, int64_t B, int C, int H, int W, int ld, int flip, int64_t batch_stride,
+                      nf_stream_t stream);
 int nf_conv3x3_gather_sum(const void *P, const void *bias, void *out, int64_t B, int C, int H, int W, int ld, int flip,
                           nf_stream_t stream);
 

@@ -693,8 +693,8 @@ class Inv1x1Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, W, ldu):
-        ld = torch.zeros(z.shape[0], dtype=z.dtype, device=z.device)
-        y, _ = ops.inv1x1_conv(z, W.detach().contiguous(), ldu.detach(), logdet=ld, acc=1, want_scalar=False)
+        ld = torch.empty(z.shape[0], dtype=z.dtype, device=z.device)
+        y, _ = ops.inv1x1_conv(z, W.detach().contiguous(), ldu.detach(), logdet=ld, acc=L.LD_WRITE, want_scalar=False)
         ctx.save_for_backward(z, W, ldu)
         return y, ld
 

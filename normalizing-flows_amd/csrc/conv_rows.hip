@@ -13,7 +13,8 @@ namespace nf {
 
 // col[r][k] for k < 9 C (k >= 9 C up to ld: untouched by the caller's choice of ld = 9 C); one thread per element, k fastest
 __global__ void __launch_bounds__(256)
-conv3x3_gather_kernel(const float *__restrict__ in, float *__restrict__ col, int64_t B, int C, int H, int W, int ld, int flip) {
+conv3x3_gather_kernel(const float *__restrict__ in, float *__restrict__ col, int64_t B, int C, int H, int W, int ld, int flip,
+                      int64_t sb) {
     const int K = 9 * C;
     const int64_t N = B * H * W * K;
     for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < N; o += (int64_t)gridDim.x * blockDim.x) {
@@ -26,7 +27,7 @@ conv3x3_gather_kernel(const float *__restrict__ in, float *__restrict__ col, int
         const int64_t b = r / ((int64_t)W * H);
         const int yy = yh + dy, xx = xw + dx;
         float v = 0.0f;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = in[((b * C + c) * H + yy) * W + xx];
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = in[b * sb + ((int64_t)c * H + yy) * W + xx];
         col[r * ld + k] = v;
     }
 }
@@ -53,13 +54,15 @@ conv3x3_gather_sum_kernel(const float *__restrict__ P, const float *__restrict__
 
 }  // namespace nf
 
-// col (B H W, ld >= 9 C) from the NCHW tensor `in`; flip = 1: offsets negated (the backward pass's gather of the output cotangent).
-extern "C" int nf_conv3x3_gather(const void *in, void *col, int64_t B, int C, int H, int W, int ld, int flip, nf_stream_t stream) {
-    if (B < 0 || C < 1 || H < 1 || W < 1 || ld < 9 * C || (flip != 0 && flip != 1)) return NF_EINVAL;
+// col (B H W, ld >= 9 C) from the NCHW tensor `in` (batch stride `batch_stride` elements >= C H W: a channel split of a wider tensor is
+// read in place); flip = 1: offsets negated (the backward pass's gather of the output cotangent).
+extern "C" int nf_conv3x3_gather(const void *in, void *col, int64_t B, int C, int H, int W, int ld, int flip, int64_t batch_stride,
+                                 nf_stream_t stream) {
+    if (B < 0 || C < 1 || H < 1 || W < 1 || ld < 9 * C || (flip != 0 && flip != 1) || batch_stride < (int64_t)C * H * W) return NF_EINVAL;
     if (B == 0) return NF_OK;
     if (!in || !col) return NF_EFAULT;
     hipLaunchKernelGGL(nf::conv3x3_gather_kernel, dim3(nf::grid_for(B * H * W * 9 * C, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float *)in, (float *)col, B, C, H, W, ld, flip);
+                       (const float *)in, (float *)col, B, C, H, W, ld, flip, batch_stride);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

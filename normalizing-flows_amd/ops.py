@@ -768,16 +768,17 @@ def conv3x3_gather(x, flip=False, ld=None):
     L.require_device(x)
     if x.dtype != torch.float32 or x.dim() != 4:
         raise NotImplementedError("conv3x3_gather: (B, C, H, W) float32")
-    x = x.contiguous()
     B, C, H, W = x.shape
+    if x.stride()[1:] != (H * W, W, 1) or x.stride(0) < C * H * W:       # (a channel split is read in place through its batch stride)
+        x = x.contiguous()
     R = B * H * W
     if ld is None:
         col = torch.empty(R, 9 * C, dtype=x.dtype, device=x.device)
     else:
         Rp = (R + 63) // 64 * 64
         col = (torch.empty if Rp == R else torch.zeros)(Rp, ld, dtype=x.dtype, device=x.device)
-    rc = L.lib().nf_conv3x3_gather(ptr(x), ptr(col), i64(B), i32(C), i32(H), i32(W), i32(col.shape[1]), i32(1 if flip else 0),
-                                   L.stream())
+    rc = L.lib().nf_conv3x3_gather(ptr_any(x), ptr(col), i64(B), i32(C), i32(H), i32(W), i32(col.shape[1]), i32(1 if flip else 0),
+                                   i64(x.stride(0) if B > 1 else C * H * W), L.stream())
     L.check(rc, "nf_conv3x3_gather")
     return col
 
