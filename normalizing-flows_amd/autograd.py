@@ -7,8 +7,10 @@ backward is
   * library GEMMs / triangular solves through torch for the batch reductions of LULinearPermute's parameter
     gradients (dL = tril(gy^T u), dU = triu(gu^T x_p): plain GEMMs over the batch),
   * closed-form elementwise expressions for DiagGaussian.
-The conditioner networks are ordinary torch modules and are differentiated by autograd itself.  Layers switch to
-these Functions only when gradients are needed (`needs_grad`); under torch.no_grad() the fused inference kernels run.
+The conditioner networks: the benchmark layer's ResidualNet through CouplingTrainFn / ResidualBlockFn / autograd.linear; MADE, wider
+ResidualNets and GlowBlock's ConvNet2d through MadeFn / ConvNetFn (csrc/made_fwd.hip EPI 3, csrc/made_bwd.hip, csrc/conv_rows.hip);
+anything else (contexts, batch norm, other activations) stays an ordinary torch module differentiated by autograd itself.  Layers
+switch to these Functions only when gradients are needed (`needs_grad`); under torch.no_grad() the fused inference kernels run.
 """
 import math
 

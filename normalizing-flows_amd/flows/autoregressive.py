@@ -5,13 +5,16 @@ Mirrors normflows/flows/affine/autoregressive.py:10-128 (constructor signature, 
 keys, direction semantics: `forward` = one MADE pass, `inverse` = D sequential MADE passes).  The element-wise
 affine transform and its log-det are one HIP kernel (nf_maf_affine).  Without gradient tracking the single-pass direction is ONE
 launch: nf_made_forward_affine (MADE on fp32 MFMA over the masks' non-zero blocks + the affine epilogue, csrc/made_fwd.hip), and
-MADE itself is one launch (nf_made_forward) for the other element-wise transforms; under autograd, with a context, in float64 or
-for structures outside flows/made_pack.py, MADE's masked linears are library GEMMs on pre-masked weights.
+MADE itself is one launch (nf_made_forward) for the other element-wise transforms; under autograd MADE runs on
+nf_made_forward_train / nf_made_backward / nf_made_wgrad (autograd.MadeFn, csrc/made_bwd.hip); with a context, in float64 or for
+structures outside flows/made_pack.py, MADE's masked linears are library GEMMs on pre-masked weights.
 
 The inverse of MaskedAffineAutoregressive runs as ONE launch of nf_maf_inverse when
 the MADE has the supported structure (flows/maf_pack.py): every hidden unit is finalised once, total work = one MADE
-pass instead of D; the autoregressive spline layer (AR-NSF sampling) does the same through nf_arnsf_inverse.  Other
-structures, float64 and gradient-tracking calls keep the reference's D-pass loop.
+pass instead of D; the autoregressive spline layer (AR-NSF sampling) does the same through nf_arnsf_inverse.  Under autograd the
+affine layer's inverse is differentiated implicitly (autograd.MafInverseFn: the one-pass kernel forward, chain sweeps + one
+weight-gradient launch backward); other structures, float64 and the spline layer's gradient-tracking inverse keep the reference's
+D-pass loop.
 """
 import numpy as np
 import torch

@@ -610,11 +610,12 @@ class MADE(nn.Module):
         if context is None and inputs.dim() == 2 and inputs.dtype == torch.float32 and inputs.is_cuda:
             from . import config
             grad = torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters()))
-            packed = self.packed_forward(inputs.device) if not grad else (True if (config.made_train and config.made_fused) else None)
-            if packed is not None and not grad:          # nf_made_forward: the whole network as one launch
-                from . import ops
-                return ops.made_forward(inputs, packed[0], packed[1], packed[2], packed[3])
-            if packed is not None:                       # under autograd: hand-written backward (csrc/made_bwd.hip)
+            if not grad:
+                packed = self.packed_forward(inputs.device)      # nf_made_forward: the whole network as one launch
+                if packed is not None:
+                    from . import ops
+                    return ops.made_forward(inputs, packed[0], packed[1], packed[2], packed[3])
+            elif config.made_train and config.made_fused:        # under autograd: hand-written backward (csrc/made_bwd.hip)
                 from .flows import made_pack
                 plist = [t for l in self._linears() for t in (l.weight, l.bias)]
                 mult = self.final_layer.out_features // self.initial_layer.in_features
