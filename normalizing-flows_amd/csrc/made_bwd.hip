@@ -384,7 +384,10 @@ static int made_wgrad_chunk_rows(int64_t Bp, int ntiles) {
     if (want < 1) want = 1;
     int64_t rows = (Bp + want - 1) / want;
     rows = (rows + 63) / 64 * 64;
-    if (rows < 1024) rows = 1024;        // (few tiles: short chunks only multiply the partial-tile traffic and the ring's ramp)
+    if (rows < 1024) {       // few tiles: short chunks multiply the partial-tile traffic and the ring's ramp -- but keep >= ~512 workgroups
+        rows = (Bp * ntiles / 512 + 63) / 64 * 64;
+        rows = rows > 1024 ? 1024 : (rows < 256 ? 256 : rows);
+    }
     return (int)rows;
 }
 
