@@ -83,12 +83,27 @@ def c4():
         m.zero_grad(set_to_none=True)       # the MADE training kernels (no convolution library)
         m.forward_kld(x).backward()
     tr = timed(train_step, 3)
+    trg = None
+    try:      # the same step recorded into ONE hipGraph (PyTorch's whole-network capture): the eager step is launch-bound (~4 000 launches)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            train_step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        m.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            m.forward_kld(x).backward()
+        trg = timed(graph.replay, 5)
+    except Exception as exc:                                     # noqa: BLE001
+        print("config 4: training-step graph capture failed: %r" % (exc,))
     res = {"workload": "BASELINE configs[3]: Glow L=3, K=32, hidden 256, 32x32x3, batch 256", "log_prob_ms": g * 1e3,
            "log_prob_ms_eager": e * 1e3, "sample_ms": es * 1e3, "images_per_s": 256 / g, "nll_nats_per_dim": nll,
-           "forward_kld_backward_ms": tr * 1e3}
+           "forward_kld_backward_ms": tr * 1e3, "forward_kld_backward_graph_replay_ms": None if trg is None else trg * 1e3}
     print("config 4 Glow L=3 K=32 B=256: log_prob eager %.1f ms (%.0f img/s), hipGraph %.1f ms (%.0f img/s); "
-          "sample %.1f ms (%.0f img/s); NLL %.4f nats/dim (untrained, after ActNorm init)" % (
-              e * 1e3, 256 / e, g * 1e3, 256 / g, es * 1e3, 256 / es, nll))
+          "sample %.1f ms (%.0f img/s); NLL %.4f nats/dim (untrained, after ActNorm init); forward_kld + backward %.1f ms eager, "
+          "%s ms as one hipGraph" % (e * 1e3, 256 / e, g * 1e3, 256 / g, es * 1e3, 256 / es, nll, tr * 1e3,
+                                     "n/a" if trg is None else "%.1f" % (trg * 1e3)))
     return res
 
 
