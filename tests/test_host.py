@@ -877,6 +877,49 @@ def test_conv_conditioner_training_path_declines_other_structures():
     assert made_pack.convnet_train_structure(14, 300, 12) is not None
 
 
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout only exists in the build container")
+def test_implicit_differentiation_of_the_maf_inverse_vs_reference_d_pass_autograd():
+    """The formula behind autograd.MafInverseFn, with the REFERENCE's own modules in float64 and no kernel involved: for x = T^-1(z)
+    (affine/autoregressive.py:29-38, D MADE passes) and cotangents (c_x, c_ld), the sweep v <- (c_x - J^T g_p(v, c_ld)) / s reaches a
+    bit-stable v in at most D sweeps, g_z = v and the parameter gradient = the VJP of ONE MADE pass with g_p(-v, -c_ld) -- equal to
+    torch autograd through the reference's D-pass loop to 1e-11 of scale."""
+    sys.path.insert(0, REF)
+    nf = pytest.importorskip("normflows")
+    torch.manual_seed(0)
+    D, H, B = 9, 28, 6
+    layer = nf.flows.MaskedAffineAutoregressive(D, H, num_blocks=2).double()
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.add_(0.3 * torch.randn_like(p))
+    z = torch.randn(B, D, dtype=torch.float64, requires_grad=True)
+    cx, cl = torch.randn(B, D, dtype=torch.float64), torch.randn(B, dtype=torch.float64)
+    x, ld = layer.inverse(z)
+    ((x * cx).sum() + (ld * cl).sum()).backward()
+    ref = [z.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+    layer.zero_grad()
+    with torch.no_grad():
+        xs, _ = layer.inverse(z.detach())
+    xq = xs.clone().requires_grad_(True)
+    prm = layer.autoregressive_net(xq)
+    pr = prm.view(B, D, 2)
+    sg = torch.sigmoid(pr[..., 0] + 2.0).detach()
+    s_ = sg + 1e-3
+
+    def g_p(a, c):                       # cotangent of the MADE output for cotangent a on z = s x + t and c on sum log s
+        return torch.stack([(a * xs + c[:, None] / s_) * sg * (1 - sg), a], -1).reshape(B, 2 * D)
+    v = cx / s_
+    for sweeps in range(1, D + 2):
+        vn = (cx - torch.autograd.grad(prm, xq, g_p(v, cl), retain_graph=True)[0]) / s_
+        done = torch.equal(vn, v)
+        v = vn
+        if done:
+            break
+    assert sweeps <= D
+    prm.backward(g_p(-v, -cl))
+    got = [v] + [q.grad for q in layer.parameters()]
+    assert all(float((a - b).abs().max()) <= 1e-11 * max(1.0, float(b.abs().max())) for a, b in zip(got, ref))
+
+
 def test_made_forward_pack_rejects_unsupported():
     from normflows_amd import nets
     from normflows_amd.flows import made_pack
