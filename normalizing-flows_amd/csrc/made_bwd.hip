@@ -388,6 +388,7 @@ static int made_wgrad_chunk_rows(int64_t Bp, int ntiles) {
         rows = (Bp * ntiles / 512 + 63) / 64 * 64;
         rows = rows > 1024 ? 1024 : (rows < 256 ? 256 : rows);
     }
+    if (rows > 8192) rows = 8192;      // (very large batches: bound the length of one float32 accumulation chain; more partial tiles instead)
     return (int)rows;
 }
 
