@@ -475,6 +475,11 @@ int nf_maf_affine(const void *x, const void *params, void *y, void *logdet, int6
  * cotangent may be NULL (zero). */
 int nf_maf_affine_bwd(const void *x, const void *params, const void *gy, const void *gld, void *gx, void *gparams, int64_t B, int D,
                       int direction, int dtype, nf_stream_t stream);
+/* One sweep of the implicit backward of the MAF inverse (the density direction under autograd; normflows_amd.autograd.MafInverseFn):
+ * v <- (gx - gxm) / scale in place (gxm NULL on the first sweep), g_p (B, D, 2) = the parameter cotangent for (v, gld) -- the input of
+ * the next nf_made_backward --, *changed (int, zeroed by the caller) set when any element of v moved. */
+int nf_maf_implicit_sweep(const void *x, const void *params, const void *gx, const void *gld, const void *gxm, void *v, void *gp,
+                          void *changed, int64_t B, int D, int dtype, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * CoupledRationalQuadraticSpline in ONE launch for the shapes beyond nf_rqs_fused's (D <= 64, hidden <= 128): up to 128 features,

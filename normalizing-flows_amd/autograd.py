@@ -873,20 +873,28 @@ class MafInverseFn(torch.autograd.Function):
         gx = torch.zeros_like(x) if gx is None else gx.contiguous()
         gld = torch.zeros(B, dtype=x.dtype, device=x.device) if gld is None else gld.contiguous()
         p, save, bits = ops.made_forward_train(x, fwd[0], fwd[1], fwd[2], 2 * D, bwd["NB"])
-        s = torch.sigmoid(p.view(B, D, 2)[..., 0] + 2.0) + 1e-3
-        v = gx / s
-        sweeps = 0
-        for sweeps in range(1, D + 1):
-            _, gp = ops.maf_affine_bwd(x, p, v, gld, 0)
+        v = torch.empty_like(x)
+        gp = torch.empty_like(p)
+        changed = torch.zeros(1, dtype=torch.int32, device=x.device)
+        rtol = _config.maf_implicit_rtol
+        gxm, sweeps = None, 0
+        # sweep 0 = the start value v = g_x / scale; then one element-wise launch (update of v, the next cotangent g_p, "did v move?")
+        # and one chain per sweep; the flag is read back every other sweep (a read is a host synchronisation)
+        while sweeps <= D:
+            v_prev = v.clone() if rtol > 0.0 and sweeps > 0 else None
+            ops.maf_implicit_sweep(x, p, gx, gld, gxm, v, gp, changed)
+            if sweeps > 0 and (sweeps % 2 == 0 or sweeps == D):
+                if rtol > 0.0:
+                    done = bool((v - v_prev).abs().max() <= rtol * v.abs().max())
+                else:
+                    done = int(changed.item()) == 0
+                if done:
+                    break
+                changed.zero_()
+            elif sweeps > 0 and sweeps % 2 == 1:
+                changed.zero_()          # (only the latest sweep's verdict counts)
             gxm, _ = ops.made_backward(gp, bits, bwd["blob"], bwd["table"], D, bwd["Hp"], bwd["NB"], want_G=False)
-            vn = (gx - gxm) / s
-            if _config.maf_implicit_rtol > 0.0:
-                done = bool((vn - v).abs().max() <= _config.maf_implicit_rtol * vn.abs().max())
-            else:
-                done = torch.equal(vn, v)
-            v = vn
-            if done:
-                break
+            sweeps += 1
         MafInverseFn.last_sweeps = sweeps
         _, gp = ops.maf_affine_bwd(x, p, -v, -gld, 0)
         grads = [None] * ctx.nparams

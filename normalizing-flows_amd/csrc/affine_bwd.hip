@@ -391,6 +391,30 @@ inv1x1_lu_grads_kernel(const T *__restrict__ P, const T *__restrict__ L, const T
     }
 }
 
+
+// ---- one sweep of the implicit backward of MaskedAffineAutoregressive.inverse (autograd.MafInverseFn) ----------------------------------
+//   v <- (g_x - gxm) / scale   (first sweep: gxm = NULL -> v = g_x / scale);   *changed |= any element of v differs bitwise from before;
+//   g_p (B, D, 2) = the parameter cotangent of z = scale x + shift, sum log scale for the cotangents (v, g_ld): the next chain's input.
+template <typename T>
+__global__ void __launch_bounds__(256)
+maf_implicit_sweep_kernel(const T *__restrict__ x, const T *__restrict__ params, const T *__restrict__ gx, const T *__restrict__ gld,
+                          const T *__restrict__ gxm, T *__restrict__ v, T *__restrict__ gp, int *__restrict__ changed, int64_t B, int D) {
+    const int64_t N = B * D;
+    int diff = 0;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < N; o += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = o / D;
+        const T sg = sigmoid(params[2 * o] + T(2));
+        const T scale = sg + T(1e-3);
+        const T vn = ((gx ? gx[o] : T(0)) - (gxm ? gxm[o] : T(0))) / scale;
+        const T vo = v[o];
+        diff |= !(vn == vo) && !(vn != vn && vo != vo);        // (NaN == NaN counts as unchanged: a diverged solve must still stop)
+        v[o] = vn;
+        gp[2 * o] = (vn * x[o] + (gld ? gld[r] : T(0)) / scale) * sg * (T(1) - sg);
+        gp[2 * o + 1] = vn;
+    }
+    if (__any(diff) && (threadIdx.x & 63) == 0) atomicOr(changed, 1);
+}
+
 }  // namespace nf
 
 using namespace nf;
@@ -555,6 +579,26 @@ extern "C" int nf_inv1x1_lu_grads(const void *P, const void *L, const void *U, c
                 hipLaunchKernelGGL(inv1x1_lu_grads_kernel<double>, dim3(C), dim3(64), 0, st, (const double *)P, (const double *)L,
                                    (const double *)U, (const double *)sign_S, (const double *)log_S, (const double *)gW,
                                    (const double *)gl, (double *)gL, (double *)gU, (double *)glogS, C));
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// One sweep of autograd.MafInverseFn's triangular solve: v (B, D) updated in place from gx, gxm (NULL on the first sweep), the next
+// chain's input g_p (B, D, 2) written, *changed (int, zeroed by the caller) set when any element of v moved.
+extern "C" int nf_maf_implicit_sweep(const void *x, const void *params, const void *gx, const void *gld, const void *gxm, void *v,
+                                     void *gp, void *changed, int64_t B, int D, int dtype, nf_stream_t stream) {
+    if (B < 0 || D < 1) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!x || !params || !v || !gp || !changed) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_for(B * D, 256);
+    NF_DISPATCH(dtype,
+                hipLaunchKernelGGL(maf_implicit_sweep_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, (const float *)params,
+                                   (const float *)gx, (const float *)gld, (const float *)gxm, (float *)v, (float *)gp, (int *)changed,
+                                   B, D),
+                hipLaunchKernelGGL(maf_implicit_sweep_kernel<double>, dim3(grid), dim3(256), 0, st, (const double *)x,
+                                   (const double *)params, (const double *)gx, (const double *)gld, (const double *)gxm, (double *)v,
+                                   (double *)gp, (int *)changed, B, D));
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

@@ -814,6 +814,15 @@ def maf_affine_bwd(x, params, gy, gld, direction):
     return gx, gparams
 
 
+def maf_implicit_sweep(x, params, gx, gld, gxm, v, gp, changed):
+    """nf_maf_implicit_sweep: v, gp updated in place; `changed` (int32 scalar tensor) set when v moved."""
+    L.require_device(x, params, gx, gld, gxm, v, gp, changed)
+    B, D = x.shape
+    rc = L.lib().nf_maf_implicit_sweep(ptr(x), ptr(params), ptr(gx), ptr(gld), ptr(gxm), ptr(v), ptr(gp), ptr(changed), i64(B), i32(D),
+                                       i32(L.dtype_code(x)), L.stream())
+    L.check(rc, "nf_maf_implicit_sweep")
+
+
 def rqs_fused_chain(x, blobs, parities, hidden, num_blocks, K, direction, logdet=None, acc=None, tail_bound=3.0,
                     min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, fuse_lu=True, live_d=None):
     """Up to 64 fused layers of identical shape in ONE persistent launch (nf_rqs_fused_chain).  `blobs` / `parities`
