@@ -137,19 +137,27 @@ def pmc_traffic():
 
 
 def reference_cpu_leg():
-    """The `kind: "reference"` leg: normflows itself (PyTorch CPU) timed by tools/cpu_reference.py in the build container --
-    /root/reference does not exist on the GPU box, so the committed JSON is reported, with where it was measured."""
+    """The `kind: "reference"` leg: normflows itself (PyTorch CPU) timed by tools/cpu_reference.py.  /root/reference does not exist
+    on the GPU box at bench time, so the newest committed JSON is reported with where it was measured: round 5 staged the package
+    for one gpurun call and timed it ON THE GPU BOX's host cores (profiles/r05_cpu_reference_gpubox.json, best of a thread sweep);
+    rounds 2-4: the 8-core build container (profiles/r02_cpu_reference.json)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*cpu_reference.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*cpu_reference*.json")), reverse=True):
         try:
             d = json.load(open(path))
-            return {"value": d["log_prob"]["samples_per_s"], "unit": "samples/s", "cores": d["cores"], "kind": "reference",
-                    "where": d.get("where", "build container"), "cpu_model": d.get("cpu_model"), "torch": d.get("torch"),
-                    "sample": "normflows (PyTorch CPU, %d threads) log_prob of the same model on all %d benchmark rows, best of %d "
-                              "(%.1f s); tools/cpu_reference.py" % (d["torch_threads"], d["rows"], d["repeats"], d["log_prob"]["best_s"]),
-                    "nll_nats_per_dim": d["log_prob"]["nll_nats_per_dim"],
-                    "sample_direction_samples_per_s": d["sample"]["samples_per_s"],
-                    "source": "profiles/" + os.path.basename(path)}
+            leg = {"value": d["log_prob"]["samples_per_s"], "unit": "samples/s", "cores": d["cores"], "kind": "reference",
+                   "where": d.get("where", "build container"), "host_threads": d.get("host_threads", d["cores"]),
+                   "cpu_model": d.get("cpu_model"), "torch": d.get("torch"),
+                   "sample": "normflows (PyTorch CPU, %d threads%s) log_prob of the same model on %d benchmark rows, best of %d "
+                             "(%.1f s); tools/cpu_reference.py" % (d["torch_threads"],
+                                                                   ", best of the sweep %s" % [e["torch_threads"] for e in d["sweep"]] if d.get("sweep") else "",
+                                                                   d["rows"], d["repeats"], d["log_prob"]["best_s"]),
+                   "nll_nats_per_dim": d["log_prob"]["nll_nats_per_dim"], "source": "profiles/" + os.path.basename(path)}
+            if "sample" in d:
+                leg["sample_direction_samples_per_s"] = d["sample"]["samples_per_s"]
+            if d.get("sweep"):
+                leg["thread_sweep_samples_per_s"] = {str(e["torch_threads"]): round(e["samples_per_s"], 1) for e in d["sweep"]}
+            return leg
         except Exception:
             pass
     return None

@@ -591,6 +591,16 @@ int nf_maf_inverse(const void *z, void *y, void *logdet, const void *blob, const
 int64_t nf_maf_inverse_h_scratch_floats(int64_t B, int D, int hidden_padded, int num_blocks);
 int nf_maf_inverse_h(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, void *scratch,
                      int64_t B, int D, int hidden_padded, int num_blocks, int acc, nf_stream_t stream);
+/* The same kernel family for FORMAT-1 packs (maf_pack.pack_made(..., tri=True); table[7] == 1; round 5).  REGULAR tiles -- at most 8
+ * degrees of at most 4 hidden units each: 15 of the 16 tiles of BASELINE configs[4] (d = 128, hidden 512) -- carry their
+ * sequential part's weights triangular and in reading order; they run a statically unrolled sequential part (packed multiply-adds
+ * over the registers the mask leaves non-zero, one v_permlane32_swap per target pair) and an 8-deep activation ring.  The other
+ * tiles keep the format-0 record and code.  `table_host` is the HOST copy of `table`: the launcher splits the tiles into maximal
+ * runs of one kind and issues one launch per run (no device read-back, no host synchronisation); -EINVAL when table_host does not
+ * describe this call (D, hidden_padded, num_blocks, format 1), -EFAULT when it is NULL.  Replaces the same reference lines as
+ * nf_maf_inverse (affine/autoregressive.py:29-38, :114-128 over nets/made.py:217-304). */
+int nf_maf_inverse_h_tri(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, const int32_t *table_host,
+                         void *scratch, int64_t B, int D, int hidden_padded, int num_blocks, int acc, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * MaskedPiecewiseRationalQuadraticAutoregressive inverse (AR-NSF sampling direction) in ONE pass.  Replaces the D-pass

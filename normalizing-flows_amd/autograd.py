@@ -857,7 +857,7 @@ class MafInverseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inv, fwd, bwd, z, *params):
         z = z.contiguous()
-        x, ld = ops.maf_inverse(z, inv[0], inv[1], inv[2], num_blocks=inv[3])
+        x, ld = ops.maf_inverse(z, inv[0], inv[1], inv[2], num_blocks=inv[3], table_host=inv[4] if len(inv) > 4 else None)
         ctx.save_for_backward(x)
         ctx.fwd, ctx.bwd = fwd, bwd
         ctx.nparams = len(params)

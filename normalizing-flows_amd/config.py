@@ -101,6 +101,17 @@ def set_maf_halves(mode=True):
     maf_halves = bool(mode)
 
 
+# MAF inverse, round 5: format-1 packs (flows/maf_pack.pack_made(tri=True)) -- regular tiles (<= 8 degrees of <= 4 hidden units) run
+# nf_maf_inverse_h_tri's statically unrolled triangular sequential part and 8-deep activation ring; False = format 0 on
+# nf_maf_inverse_h (round 3/4; ablation).  Only with maf_halves.
+maf_tri = True
+
+
+def set_maf_tri(mode=True):
+    global maf_tri
+    maf_tri = bool(mode)
+
+
 def set_fused_chain(mode=True):
     global fused_chain
     fused_chain = bool(mode)

@@ -19,6 +19,7 @@
 // ~230 registers: 8 waves of 32 samples per workgroup = one workgroup per CU at B = 65 536, two waves per SIMD.
 #include "common.hpp"
 #include "fused_common.hpp"
+#include <type_traits>
 
 namespace nf {
 
@@ -32,18 +33,18 @@ constexpr int HNW = NF_MAF_HNW;    // waves per workgroup (ablation, round 4, co
 constexpr int H_HDR = 8, H_ENT = 24;
 // floats of a tile record after the A operands, NL = 1 + 2 num_blocks hidden layers: bias[NL][32] | biasF | W0d[32][16] | Wd[NL-1] | WFd
 constexpr int h_seq(int NL) { return NL * HT + HT + HT * HS + (NL - 1) * HT * HT + HT * HT; }
-constexpr int HRB = 12;   // k-blocks of the per-wave activation ring (look-ahead HRB - 1)
+constexpr int h_lb(bool fast) { return fast ? 8 : 4; }     // activation slots of a wave's ring; + 4 + 4 weight slots of 1 KB
 
 #define HMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 // c0[r] (+)= sum_k A[u(r, hh)][k] act[k][n] over K (a multiple of 32) features / units; PAIR: the NEXT tile's products over the
 // same operands go to `stash` raw; INIT: c0 starts from the stash (second tile of a pair).  A, A2: [K/8][2][32][4] (L2),
-// Sl: the wave's scratch [K/8][2][32][4], streamed through `ring` HRB - 1 k-blocks ahead (in-order retirement: while requests
-// are being issued exactly HRB - 1 DMA instructions are younger than the k-block about to be consumed).
-template <bool PAIR, bool INIT>
+// Sl: the wave's scratch [K/8][2][32][4].  ALL three streams arrive by LDS-DMA in the wave's own ring: LB slots (1 KB each) for the
+// activation k-blocks -- requested LB steps ahead -- and 4 + 4 for the A [, A2] weight k-blocks, requested 4 steps ahead.
+template <bool PAIR, bool INIT, int LB>
 __device__ __forceinline__ void h_block(const float *__restrict__ A, const float *__restrict__ A2, const float *Sl, int K, int lane,
                                         float *stash, float *ring, f32x16 &c0) {
-    typedef __attribute__((address_space(3))) void *lds_ptr;
+    static_assert(LB == 4 || LB == 8, "activation slots: a power of two >= the 4 weight slots");
     f32x16 c2 = {0};
 #pragma unroll
     for (int r = 0; r < 16; ++r) c0[r] = 0.0f;
@@ -58,18 +59,18 @@ __device__ __forceinline__ void h_block(const float *__restrict__ A, const float
     }
     const int nkb = K >> 3;
     if (nkb > 0) {
-        // ALL three streams of the product -- the activation k-blocks (HBM / L2) and the A [, A2] weight k-blocks (L2) -- arrive by
-        // LDS-DMA in the wave's own ring: 4 slots each (12 KB), slot = k-block mod 4, a slot is requested again (k-block + 4) as
-        // soon as its three reads have returned.  The requests are INLINE ASM and there is no ordinary load in the loop, so the
-        // compiler inserts no vector-memory wait of its own and the hand-counted ones are exact: vector-memory operations retire
-        // in order, block kb's requests went out 4 steps ago, younger than them are the 3 x (1 + LPS) requests of the blocks
-        // kb + 1 .. kb + 3 -- four steps' worth of requests are in flight under every step's MFMAs.
+        // The requests are INLINE ASM and there is no ordinary load in the loop, so the compiler inserts no vector-memory wait of
+        // its own and the hand-counted ones are exact: vector-memory operations retire in order; step kb needs A(kb) [, A2(kb)],
+        // requested in (pseudo-)step kb - 4 AFTER that step's activation request, and B(kb), requested LB steps ago, i.e. earlier
+        // still.  Younger than A2(kb) are exactly the requests of steps kb - 3 .. kb - 1: per step one activation block while
+        // block (step + LB) exists and LPS weight blocks while block (step + 4) exists.
         // History (round 3): (1) the builtin + A operands as ordinary register loads: the compiler waited vmcnt(0) at every first
         // use of a loaded register while an LDS-DMA might be pending -- the ring drained every fourth k-block (2.9 TB/s, 16.1 ms);
         // (2) activation requests as asm, A still in registers (14.5 ms): the compiler's counted waits for A (it counts only its
-        // own loads) stand in front of the interleaved requests it does not know of, so ~2.3 steps were in flight instead of 4.
-        constexpr int LPS = PAIR ? 2 : 1, OPS = 1 + LPS;
-        static_assert(HRB == 12, "4 slots per stream");
+        // own loads) stand in front of the interleaved requests it does not know of, so ~2.3 steps were in flight instead of 4;
+        // (3) everything through the ring, 4 + 4 + 4 slots (13.9 ms, round 3/4); (4) round 5: LB = 8 activation slots for the
+        // regular-tile kernel (the activation stream is the one that comes from HBM; its window was 4 KB per wave).
+        constexpr int LPS = PAIR ? 2 : 1;
         const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ring);
         auto dma1 = [&](uint32_t dst, const float *src) {
             // (m0 is a reserved register: the compiler does not honour it as a clobber, so it is saved and restored here)
@@ -77,31 +78,52 @@ __device__ __forceinline__ void h_block(const float *__restrict__ A, const float
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(m0_) : "s"(dst), "v"(src) : "memory");
         };
-        auto req = [&](int kb, int slot) {
-            const size_t off = (size_t)kb * 256 + lane * 4;
-            dma1(ring_lds + (uint32_t)slot * 1024u, Sl + off);
-            dma1(ring_lds + 4096u + (uint32_t)slot * 1024u, A + off);
-            if constexpr (PAIR) dma1(ring_lds + 8192u + (uint32_t)slot * 1024u, A2 + off);
+        auto req_b = [&](int kb) {
+            if (kb < nkb) dma1(ring_lds + (uint32_t)(kb & (LB - 1)) * 1024u, Sl + (size_t)kb * 256 + lane * 4);
+        };
+        auto req_a = [&](int kb, int slot) {
+            if (kb < nkb) {
+                const size_t off = (size_t)kb * 256 + lane * 4;
+                dma1(ring_lds + (uint32_t)(LB + slot) * 1024u, A + off);
+                if constexpr (PAIR) dma1(ring_lds + (uint32_t)(LB + 4 + slot) * 1024u, A2 + off);
+            }
         };
         auto step = [&](int kb, int slot) {
-            const int rem = nkb - 1 - kb;       // blocks requested after this one
-            if (rem >= 3) NF_WAIT_VMCNT(3 * OPS);
-            else if (rem == 2) NF_WAIT_VMCNT(2 * OPS);
-            else if (rem == 1) NF_WAIT_VMCNT(OPS);
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const f32x4 b = *reinterpret_cast<const f32x4 *>(ring + slot * 256 + lane * 4);
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(ring + 1024 + slot * 256 + lane * 4);
+            const int ca = min(nkb - 1 - kb, 3);                         // steps kb-3 .. kb-1 that requested weight blocks
+            const int cb = max(min(nkb - LB - kb + 3, 3), 0);            // ... and activation blocks
+            switch (cb + LPS * ca) {
+                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1: NF_WAIT_VMCNT(1); break;
+                case 2: NF_WAIT_VMCNT(2); break;
+                case 3: NF_WAIT_VMCNT(3); break;
+                case 4: NF_WAIT_VMCNT(4); break;
+                case 5: NF_WAIT_VMCNT(5); break;
+                case 6: NF_WAIT_VMCNT(6); break;
+                case 7: NF_WAIT_VMCNT(7); break;
+                case 8: NF_WAIT_VMCNT(8); break;
+                default: NF_WAIT_VMCNT(9); break;
+            }
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(ring + (kb & (LB - 1)) * 256 + lane * 4);
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(ring + (LB + slot) * 256 + lane * 4);
             f32x4 a2 = a;
-            if constexpr (PAIR) a2 = *reinterpret_cast<const f32x4 *>(ring + 2048 + slot * 256 + lane * 4);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot's reads have returned: it may be requested again
-            if (kb + 4 < nkb) req(kb + 4, slot);
+            if constexpr (PAIR) a2 = *reinterpret_cast<const f32x4 *>(ring + (LB + 4 + slot) * 256 + lane * 4);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slots' reads have returned: they may be requested again
+            req_b(kb + LB);
+            req_a(kb + 4, slot);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 c0 = HMFMA(a[i], b[i], c0);
                 if constexpr (PAIR) c2 = HMFMA(a2[i], b[i], c2);
             }
         };
-        req(0, 0); req(1, 1); req(2, 2); req(3, 3);      // nkb is a multiple of 4
+        // prologue: the first LB - 4 activation blocks, then pseudo-steps -4 .. -1 in the steps' own order (nkb is a multiple of 4)
+#pragma unroll
+        for (int e = 0; e < LB - 4; ++e) req_b(e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            req_b(j + LB - 4);
+            req_a(j, j);
+        }
         for (int kb = 0; kb < nkb; kb += 4) {
             step(kb, 0);
             step(kb + 1, 1);
@@ -119,33 +141,156 @@ __device__ __forceinline__ void h_block(const float *__restrict__ A, const float
 // (Round 3, measured and dropped: the NL products of a tile as ONE stream -- requests and A look-ahead running through the
 // product boundaries, one start-up per tile instead of one per product: 14.9 ms against 14.5-14.8, 18 spilled registers.  The
 // start-ups are not what is left either.)
+template <int LB>
 __device__ __forceinline__ void h_block_mode(int mode, const float *__restrict__ A, const float *__restrict__ A2, const float *Sl,
                                              int K, int lane, float *stash, float *ring, f32x16 &out) {
-    if (mode == 1) h_block<true, false>(A, A2, Sl, K, lane, stash, ring, out);
-    else if (mode == 2) h_block<false, true>(A, nullptr, Sl, K, lane, stash, ring, out);
-    else h_block<false, false>(A, nullptr, Sl, K, lane, nullptr, ring, out);
+    if (mode == 1) h_block<true, false, LB>(A, A2, Sl, K, lane, stash, ring, out);
+    else if (mode == 2) h_block<false, true, LB>(A, nullptr, Sl, K, lane, stash, ring, out);
+    else h_block<false, false, LB>(A, nullptr, Sl, K, lane, nullptr, ring, out);
 }
 
 __device__ __forceinline__ void h_finish(float us, float sh, float zf, float &xn, float &ld) {
-    const float scale = 1.0f / (1.0f + __expf(-(us + 2.0f))) + 1e-3f;
-    xn = (zf - sh) / scale;
+    // v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 instructions each, twice per feature on the sequential chain)
+    const float scale = __builtin_amdgcn_rcpf(1.0f + __expf(-(us + 2.0f))) + 1e-3f;
+    xn = (zf - sh) * __builtin_amdgcn_rcpf(scale);
     ld -= __logf(scale);
+}
+
+// ---- round 5: REGULAR tiles (flows/maf_pack.py format 1: <= 8 degrees of <= 4 units) -- the sequential part statically unrolled ----
+// Unit i of step g sits at the row whose accumulator is register 2 g + (i & 1) of lane-half i >> 1: after step g registers
+// 0 .. 2 g + 1 of both halves are final, a step's four targets are two per half (every lane owns what it finishes: no selects),
+// and a dot product contracts only over the registers that can be non-zero under the mask (degree <= the step's): 4 (g + 1) packed
+// multiply-adds per layer and step instead of 4 x 16 plain ones, weights as float4 = two targets x one register pair straight from
+// the record (triangular, already in reading order), one v_permlane32_swap per target PAIR instead of one LDS permute per target.
+// Measured on config 5 (B = 65 536, 10 layers): see DESIGN.md section 5c.
+constexpr int HF_STEPS = 8;
+constexpr int hf_w0(int g) { int o = 0; for (int i = 0; i < g; ++i) o += i / 2 + 1; return o; }   // float4 units within a half
+constexpr int HF_W0 = hf_w0(HF_STEPS), HF_WD = HF_STEPS * (HF_STEPS + 1), HF_WF = HF_STEPS * (HF_STEPS + 1) / 2;
+constexpr int hf_half4(int NL) { return HF_W0 + (NL - 1) * HF_WD + HF_WF; }
+constexpr int hf_seq(int NL) { return (NL + 1) * HT + 8 * hf_half4(NL); }    // floats of a regular tile's record after the A operands
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 hf_fma(float w0, float w1, f32x2 s, f32x2 a) { return __builtin_elementwise_fma(f32x2{w0, w1}, s, a); }
+// lanes 0-31 receive the wave-wide (both halves') total of `lo`, lanes 32-63 that of `hi`
+__device__ __forceinline__ float hf_xchg(float lo, float hi) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// one hidden -> hidden product of step G: the four targets' partial sums over THIS half's registers 0 .. 2 G + 1 of `src`, the two
+// exchanges; returns the totals of the half's own targets (registers 2 G, 2 G + 1)
+// (the weights of a product are read HF_LA source pairs ahead of their multiply-adds and no further: left to itself the scheduler
+// hoists all 2 (G + 1) 16-byte reads of a product -- up to 64 registers -- in front of the first multiply-add, and the kernel spills)
+constexpr int HF_LA = 2;
+template <int G>
+__device__ __forceinline__ void hf_product(const f32x16 &src, const f32x4 *w, float &ta, float &tb) {
+    f32x2 a0 = {0.0f, 0.0f}, a1 = a0, a2 = a0, a3 = a0;
+    f32x4 wq[G + 1][2];
+#pragma unroll
+    for (int q = 0; q < HF_LA && q <= G; ++q) { wq[q][0] = w[2 * q]; wq[q][1] = w[2 * q + 1]; }
+#pragma unroll
+    for (int q = 0; q <= G; ++q) {
+        if (q + HF_LA <= G) { wq[q + HF_LA][0] = w[2 * (q + HF_LA)]; wq[q + HF_LA][1] = w[2 * (q + HF_LA) + 1]; }
+        const f32x4 w0 = wq[q][0], w1 = wq[q][1];
+        const f32x2 s = {src[2 * q], src[2 * q + 1]};
+        a0 = hf_fma(w0[0], w0[1], s, a0);
+        a1 = hf_fma(w0[2], w0[3], s, a1);
+        a2 = hf_fma(w1[0], w1[1], s, a2);
+        a3 = hf_fma(w1[2], w1[3], s, a3);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    ta = hf_xchg(a0[0] + a0[1], a2[0] + a2[1]);
+    tb = hf_xchg(a1[0] + a1[1], a3[0] + a3[1]);
+}
+
+template <int NB, int G>
+__device__ __forceinline__ void hf_step(f32x16 (&p)[1 + 2 * NB], const f32x16 &pF, f32x16 &xg, const f32x4 *wh, float zf, float &ld,
+                                        float &xn) {
+    constexpr int NL = 1 + 2 * NB;
+    {   // initial layer: h0 = pre + W0[window] . x for the half's own two targets; h0 folds into block 1's second pre-activation
+        const f32x4 *w = wh + hf_w0(G);
+        f32x2 a0 = {p[0][2 * G], 0.0f}, a1 = {p[0][2 * G + 1], 0.0f};
+#pragma unroll
+        for (int q = 0; q <= G / 2; ++q) {
+            const f32x4 wq = w[q];
+            const f32x2 x2 = {xg[2 * q], xg[2 * q + 1]};
+            a0 = hf_fma(wq[0], wq[1], x2, a0);
+            a1 = hf_fma(wq[2], wq[3], x2, a1);
+        }
+        const float ha = a0[0] + a0[1], hb = a1[0] + a1[1];
+        p[2][2 * G] += ha;
+        p[2][2 * G + 1] += hb;
+        p[0][2 * G] = fmaxf(ha, 0.0f);
+        p[0][2 * G + 1] = fmaxf(hb, 0.0f);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float ta, tb;
+        hf_product<G>(p[2 * b], wh + HF_W0 + (2 * b) * HF_WD + G * (G + 1), ta, tb);               // t_b = L0_b(relu(h_b))
+        p[2 * b + 1][2 * G] = fmaxf(p[2 * b + 1][2 * G] + ta, 0.0f);
+        p[2 * b + 1][2 * G + 1] = fmaxf(p[2 * b + 1][2 * G + 1] + tb, 0.0f);
+        hf_product<G>(p[2 * b + 1], wh + HF_W0 + (2 * b + 1) * HF_WD + G * (G + 1), ta, tb);       // h_{b+1} = h_b + L1_b(relu(t_b))
+        const float ha = p[2 * b + 2][2 * G] + ta, hb = p[2 * b + 2][2 * G + 1] + tb;
+        if (b + 1 < NB) {
+            const int nx = 2 * b + 4 < NL ? 2 * b + 4 : 0;
+            p[nx][2 * G] += ha;
+            p[nx][2 * G + 1] += hb;
+            p[2 * b + 2][2 * G] = fmaxf(ha, 0.0f);
+            p[2 * b + 2][2 * G + 1] = fmaxf(hb, 0.0f);
+        } else {
+            p[2 * b + 2][2 * G] = ha;          // the final layer's input (made.py:304: no activation before it)
+            p[2 * b + 2][2 * G + 1] = hb;
+        }
+    }
+    {   // the step's feature: (unconstrained scale, shift) = final rows over the registers 0 .. 2 G + 1 of both halves
+        const f32x4 *w = wh + HF_W0 + (NL - 1) * HF_WD + G * (G + 1) / 2;
+        f32x2 au = {0.0f, 0.0f}, as = au;
+        f32x4 wq[G + 1];
+#pragma unroll
+        for (int q = 0; q < 2 * HF_LA && q <= G; ++q) wq[q] = w[q];
+#pragma unroll
+        for (int q = 0; q <= G; ++q) {
+            if (q + 2 * HF_LA <= G) wq[q + 2 * HF_LA] = w[q + 2 * HF_LA];
+            const f32x2 s = {p[NL - 1][2 * q], p[NL - 1][2 * q + 1]};
+            au = hf_fma(wq[q][0], wq[q][1], s, au);
+            as = hf_fma(wq[q][2], wq[q][3], s, as);
+            if (q & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        // lower half: scale (its block part + bias sit in register G of half 0), upper half: shift (register G of half 1)
+        const float v = hf_xchg(au[0] + au[1], as[0] + as[1]) + pF[G];
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        h_finish(__uint_as_float(r[0]), __uint_as_float(r[1]), zf, xn, ld);
+    }
+    xg[G + 1] = xn;
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void h_static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        h_static_for<I + 1, N>(f);
+    }
 }
 
 // NB residual blocks (nets/made.py:140-214): NL = 1 + 2 NB hidden layers whose activations later tiles contract over
 // (S_0 = relu(h_0); per block b: S_{2b+1} = relu(t_b), S_{2b+2} = relu(h_{b+1}), the last one raw = the final layer's input).
-template <int NB>
+// FAST: the launch covers REGULAR tiles only (format 1) and runs their statically unrolled sequential part; otherwise the tiles
+// [t_beg, t_end) carry the format-0 record.  A layer whose tiles are of both kinds runs as consecutive launches (host:
+// maf_h_launch): the per-sample state between tiles -- the feature row, the activation scratch, the pair stash -- is in memory
+// anyway, the carry is the last feature written to y, and the log-determinant is accumulated launch by launch.  (One kernel holding
+// both sequential parts needed more than 256 registers: 56 spilled.)
+template <int NB, bool FAST>
 __global__ void __launch_bounds__(64 * HNW, (NB <= 2 && HNW <= 4) ? 2 : 1)
 maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *__restrict__ logdet, const float *__restrict__ blob,
-                     const int *__restrict__ table, float *S, float *Xs, float *Ps, int64_t B, int acc) {
-    constexpr int NL = 1 + 2 * NB, H_SEQ = h_seq(NL);
+                     const int *__restrict__ table, float *S, float *Xs, float *Ps, int64_t B, int acc, int t_beg, int t_end) {
+    constexpr int NL = 1 + 2 * NB, H_SEQ = FAST ? hf_seq(NL) : h_seq(NL), LB = h_lb(FAST);
     __shared__ __attribute__((aligned(16))) float seqw[H_SEQ];     // the tile's biases and diagonal blocks, shared by the workgroup's waves
-    extern __shared__ __attribute__((aligned(16))) float dyn[];      // the waves' activation rings
+    extern __shared__ __attribute__((aligned(16))) float dyn[];      // the waves' rings
     const int lane = threadIdx.x & 63, n = lane & 31, hh = lane >> 5;
     // wave-uniform BY CONSTRUCTION for the compiler too: every pointer and the tile mode below derive from it -- left in a vector
     // register the whole product dispatch ran under exec masks with vector loop counters
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float *ringw = dyn + wid * (HRB * 256);
+    float *ringw = dyn + wid * ((LB + 8) * 256);
     const int64_t wt = (int64_t)blockIdx.x * HNW + wid;
     const bool active = wt * 32 < B;   // idle waves of the last workgroup still take part in the staging barriers
     const int D = table[0], Dp = table[1], Hp = table[3], T = table[4];
@@ -157,22 +302,28 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
     float *Xw = Xs + wts * ((int64_t)Dp * 32);       // [Dp/8][2][32][4]
     float *Pw = Ps ? Ps + wts * ((int64_t)NL * HT * 32) : nullptr;  // pair stash: [product][4][64][4] raw accumulators
     float ld = 0.0f, xcarry;
-    h_finish(blob[0], blob[1], zr[0], xcarry, ld);
-    if (active && hh == 0) Xw[n * 4] = xcarry;
-    if (valid && hh == 0) y[sample * D] = xcarry;
-    auto xsum = [](float v) { return v + __shfl_xor(v, 32, 64); };
-
-    for (int t = 0; t < T; ++t) {
+    if (t_beg == 0) {
+        h_finish(blob[0], blob[1], zr[0], xcarry, ld);
+        if (active && hh == 0) Xw[n * 4] = xcarry;
+        if (valid && hh == 0) y[sample * D] = xcarry;
+    } else {
+        xcarry = y[(valid ? sample : B - 1) * D + table[H_HDR + H_ENT * t_beg] - 1];     // the last feature of the previous launch
+    }
+    const int t_stop = min(t_end, T);
+    for (int t = t_beg; t < t_stop; ++t) {
         const int *te = table + H_HDR + H_ENT * t;
         const int dlo = te[0], ns = te[1], K0 = te[2];
         const int Kh = HT * t;
         const float *rec = blob + te[3];
         const float *A0 = rec;
         const float *Ah = A0 + K0 * HT;             // A1..A_{NL-1}, AF: Kh * 32 floats each
-        // stage the sequential part's weights, one copy per workgroup; the five 32 x 32 diagonal blocks with their columns
-        // in (half, register) order: source quad (u, v / 4 = 2 q + h) -> destination quad (u, 4 h + q)
+        // stage the sequential part's weights, one copy per workgroup
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only barrier: a fence would wait for the activation stores in flight
-        {
+        if constexpr (FAST) {       // regular tile: triangular record in reading order, copied as it is
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(Ah + (size_t)NL * Kh * HT);
+            for (int i = threadIdx.x; i < H_SEQ / 4; i += 64 * HNW) reinterpret_cast<f32x4 *>(seqw)[i] = src[i];
+        } else {                    // the five 32 x 32 diagonal blocks with their columns in (half, register) order: source quad
+                                    // (u, v / 4 = 2 q + h) -> destination quad (u, 4 h + q)
             const f32x4 *src = reinterpret_cast<const f32x4 *>(Ah + (size_t)NL * Kh * HT);
             constexpr int HEAD4 = (NL * HT + HT + HT * HS) / 4;      // biases, final biases, window weights: copied as they are
             for (int i = threadIdx.x; i < H_SEQ / 4; i += 64 * HNW) {
@@ -188,17 +339,14 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
         if (!active) continue;
         const float *bias = seqw;
         const float *biasF = bias + NL * HT;
-        const float *W0d = biasF + HT;
-        const float *Wd = W0d + HT * HS;
-        const float *WFd = Wd + (NL - 1) * HT * HT;
 
         f32x16 zin;
 #pragma unroll
-        for (int j = 0; j < HS; ++j) zin[j] = (j < ns) ? zr[dlo + j] : 0.0f;
+        for (int j = 0; j < (FAST ? HF_STEPS : HS); ++j) zin[j] = (j < ns) ? zr[dlo + j] : 0.0f;
 
         __threadfence_block();  // the activation scratch written by the other lanes of this wave is read below
         f32x16 p[NL], pF;
-        h_block<false, false>(A0, nullptr, Xw, K0, lane, nullptr, ringw, p[0]);
+        h_block<false, false, LB>(A0, nullptr, Xw, K0, lane, nullptr, ringw, p[0]);
         {
             // tile pairing: even tile = its own products + the next tile's over the same operands (raw accumulators to the
             // stash); odd tile = the stash + the 32 units of its partner
@@ -214,7 +362,7 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
             const int Kb = mode == 2 ? HT : Kh;
 #pragma unroll
             for (int l = 0; l < NL; ++l)
-                h_block_mode(mode, Ah + (size_t)l * Kh * HT + (size_t)koff * HT, Ah2 + (size_t)l * Kh2 * HT,
+                h_block_mode<LB>(mode, Ah + (size_t)l * Kh * HT + (size_t)koff * HT, Ah2 + (size_t)l * Kh2 * HT,
                              Sw + (size_t)l * Hp * 32 + (size_t)koff * 32, Kb, lane, Pw + (size_t)l * HT * 32, ringw,
                              l + 1 < NL ? p[l + 1 < NL ? l + 1 : 0] : pF);
         }
@@ -227,6 +375,27 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
         }
         f32x16 xg = {0};   // window features dlo-1 .. dlo+14 (0-based): xg[0] is the carry, xg[s+1] the output of step s
         xg[0] = xcarry;
+
+        if constexpr (FAST) {
+            const f32x4 *wh = reinterpret_cast<const f32x4 *>(seqw + (NL + 1) * HT) + hh * hf_half4(NL);
+            h_static_for<0, HF_STEPS>([&](auto G_) {
+                constexpr int G = decltype(G_)::value;
+                if (G < ns) {
+                    float xn;
+                    hf_step<NB, G>(p, pF, xg, wh, zin[G], ld, xn);
+                    xcarry = xn;
+                    const int f = dlo + G;
+                    if (hh == 0) {
+                        Xw[((size_t)((f >> 3) * 2 + ((f >> 2) & 1)) * 32 + n) * 4 + (f & 3)] = xn;
+                        if (valid) y[sample * D + f] = xn;
+                    }
+                }
+            });
+        } else {
+        const float *W0d = biasF + HT;
+        const float *Wd = W0d + HT * HS;
+        const float *WFd = Wd + (NL - 1) * HT * HT;
+        auto xsum = [](float v) { return v + __shfl_xor(v, 32, 64); };
 
         // partial dot product of row u of a diagonal block with the 16 source registers of this lane-half
 #define MAFH_DOT(WBASE, SRC)                                                                     \
@@ -316,6 +485,7 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
             }
         }
 #undef MAFH_DOT
+        }
         // ---- publish the tile: the register quads ARE the B-operand entries (k-block 4 t + q, half hh) ----
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -337,9 +507,27 @@ extern "C" int64_t nf_maf_inverse_h_scratch_floats(int64_t B, int D, int hidden_
     return nwt * 32 * (NL * (int64_t)hidden_padded + Dp + NL * nf::HT);
 }
 
+template <int NB, bool FAST>
+static int maf_h_run(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, float *S, float *Xs, float *Ps,
+                     int64_t nwt, int64_t B, int acc, int t_beg, int t_end, hipStream_t st) {
+    using namespace nf;
+    constexpr int NL = 1 + 2 * NB;
+    const int grid = (int)((nwt + HNW - 1) / HNW);
+    const size_t lds_ring = (size_t)HNW * (h_lb(FAST) + 8) * 256 * sizeof(float);
+    static LdsOptIn opted;
+    if (opt_in_lds(reinterpret_cast<const void *>(&maf_inverse_h_kernel<NB, FAST>),
+                   lds_ring + sizeof(float) * (FAST ? hf_seq(NL) : h_seq(NL)), opted) != NF_OK)
+        return NF_ENOTSUP;
+    hipLaunchKernelGGL((maf_inverse_h_kernel<NB, FAST>), dim3(grid), dim3(64 * HNW), lds_ring, st, (const float *)z, (float *)y,
+                       (float *)logdet, (const float *)blob, (const int *)table, S, Xs, Ps, B, acc, t_beg, t_end);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// table_host: the host copy of `table` (format 1: the launcher needs the kinds of the tiles) or NULL (format 0: one launch)
 template <int NB>
-static int maf_h_launch(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, void *scratch, int64_t B, int D,
-                        int hidden_padded, int acc, hipStream_t st) {
+static int maf_h_launch(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, const int32_t *table_host,
+                        void *scratch, int64_t B, int D, int hidden_padded, int acc, hipStream_t st) {
     using namespace nf;
     constexpr int NL = 1 + 2 * NB;
     const int64_t nwt = (B + 31) / 32;
@@ -349,28 +537,52 @@ static int maf_h_launch(const void *z, void *y, void *logdet, const void *blob, 
     // the feature scratch is read with zero weights before it is written (K0 is padded to 32): it must hold finite values
     if (hipMemsetAsync(Xs, 0, (size_t)nwt * 32 * Dp * sizeof(float), st) != hipSuccess) return NF_EIO;
     float *Ps = Xs + nwt * 32 * Dp;
-    const int grid = (int)((nwt + HNW - 1) / HNW);
-    const size_t lds_ring = (size_t)HNW * HRB * 256 * sizeof(float);
-    static LdsOptIn opted;
-    if (opt_in_lds(reinterpret_cast<const void *>(&maf_inverse_h_kernel<NB>), lds_ring + sizeof(float) * h_seq(NL), opted) != NF_OK)
-        return NF_ENOTSUP;
-    hipLaunchKernelGGL(maf_inverse_h_kernel<NB>, dim3(grid), dim3(64 * HNW), lds_ring, st, (const float *)z, (float *)y, (float *)logdet,
-                       (const float *)blob, (const int *)table, S, Xs, Ps, B, acc);
-    NF_CHECK_LAUNCH();
+    if (!table_host) return maf_h_run<NB, false>(z, y, logdet, blob, table, S, Xs, Ps, nwt, B, acc, 0, 1 << 30, st);
+    // maximal runs of tiles of one kind, one launch each; the first accumulates as the caller says, the others on top of it
+    const int T = table_host[4];
+    for (int t0 = 0; t0 < T;) {
+        const bool fast = table_host[H_HDR + H_ENT * t0 + 20] == 1;
+        int t1 = t0 + 1;
+        while (t1 < T && (table_host[H_HDR + H_ENT * t1 + 20] == 1) == fast) ++t1;
+        const int a = t0 == 0 ? acc : (acc == NF_LD_SUB ? NF_LD_SUB : NF_LD_ADD);
+        const int rc = fast ? maf_h_run<NB, true>(z, y, logdet, blob, table, S, Xs, Ps, nwt, B, a, t0, t1, st)
+                            : maf_h_run<NB, false>(z, y, logdet, blob, table, S, Xs, Ps, nwt, B, a, t0, t1, st);
+        if (rc != NF_OK) return rc;
+        t0 = t1;
+    }
     return NF_OK;
 }
 
-// nf_maf_inverse on the half-sharing mapping: same blob / table format and semantics as nf_maf_inverse (maf_inverse.hip), for
-// MADE conditioners of 1, 2 or 3 residual blocks (table[6]; flows/maf_pack.py).
-extern "C" int nf_maf_inverse_h(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, void *scratch,
-                                int64_t B, int D, int hidden_padded, int num_blocks, int acc, nf_stream_t stream) {
+static int maf_h_entry(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, const int32_t *table_host,
+                       void *scratch, int64_t B, int D, int hidden_padded, int num_blocks, int acc, nf_stream_t stream) {
     if (B < 0 || D < 2 || hidden_padded < 32 || hidden_padded % 32) return NF_EINVAL;
     if (acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
     if (num_blocks < 1 || num_blocks > 3) return NF_ENOTSUP;
+    if (table_host && (table_host[0] != D || table_host[3] != hidden_padded || table_host[6] != num_blocks || table_host[7] != 1 ||
+                       table_host[4] < 1 || table_host[4] * nf::HT != hidden_padded))
+        return NF_EINVAL;
     if (B == 0) return NF_OK;
     if (!z || !y || !logdet || !blob || !table || !scratch) return NF_EFAULT;
     hipStream_t st = (hipStream_t)stream;
-    if (num_blocks == 1) return maf_h_launch<1>(z, y, logdet, blob, table, scratch, B, D, hidden_padded, acc, st);
-    if (num_blocks == 2) return maf_h_launch<2>(z, y, logdet, blob, table, scratch, B, D, hidden_padded, acc, st);
-    return maf_h_launch<3>(z, y, logdet, blob, table, scratch, B, D, hidden_padded, acc, st);
+    if (num_blocks == 1) return maf_h_launch<1>(z, y, logdet, blob, table, table_host, scratch, B, D, hidden_padded, acc, st);
+    if (num_blocks == 2) return maf_h_launch<2>(z, y, logdet, blob, table, table_host, scratch, B, D, hidden_padded, acc, st);
+    return maf_h_launch<3>(z, y, logdet, blob, table, table_host, scratch, B, D, hidden_padded, acc, st);
+}
+
+// nf_maf_inverse on the half-sharing mapping: same blob / table format and semantics as nf_maf_inverse (maf_inverse.hip), for
+// MADE conditioners of 1, 2 or 3 residual blocks (table[6]; flows/maf_pack.py).  Format-0 packs only (table[7] == 0).
+extern "C" int nf_maf_inverse_h(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, void *scratch,
+                                int64_t B, int D, int hidden_padded, int num_blocks, int acc, nf_stream_t stream) {
+    return maf_h_entry(z, y, logdet, blob, table, nullptr, scratch, B, D, hidden_padded, num_blocks, acc, stream);
+}
+
+// The same for format-1 packs (flows/maf_pack.pack_made(..., tri=True)): regular tiles -- at most 8 degrees of at most 4 hidden units,
+// 15 of the 16 tiles of BASELINE configs[4] -- run the triangular, statically unrolled sequential part and the 8-deep activation ring.
+// table_host = the HOST copy of the same table (the launcher splits the tiles into runs of one kind; nothing is read back from the
+// device); -EINVAL when it does not describe this call (D, hidden_padded, num_blocks, format).
+extern "C" int nf_maf_inverse_h_tri(const void *z, void *y, void *logdet, const void *blob, const int32_t *table,
+                                    const int32_t *table_host, void *scratch, int64_t B, int D, int hidden_padded, int num_blocks,
+                                    int acc, nf_stream_t stream) {
+    if (!table_host) return NF_EFAULT;
+    return maf_h_entry(z, y, logdet, blob, table, table_host, scratch, B, D, hidden_padded, num_blocks, acc, stream);
 }

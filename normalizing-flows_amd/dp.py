@@ -102,13 +102,22 @@ class FlatGradients:
 
 class OverlappedGradientAverager:
     """Gradient averaging OVERLAPPED with the backward pass: parameters are grouped into buckets in reverse registration order
-    (the order loss.backward() finishes them); a post-accumulate hook counts a bucket's parameters down, and the moment the last
-    one has its gradient the bucket is flattened and its all_reduce(SUM) is started asynchronously (RCCL runs it on its own
-    stream over xGMI while the remaining layers' backward kernels keep the compute queue busy).  `finish()` after backward waits
-    for the collectives, scales by 1 / world_size and scatters the averages back.  Same result as allreduce_gradients.
+    (the order loss.backward() finishes them); a post-accumulate hook counts a bucket's parameters down, and once the last one
+    has its gradient the bucket is flattened and its all_reduce(SUM) is started asynchronously (RCCL runs it on its own stream
+    over xGMI while the remaining layers' backward kernels keep the compute queue busy).  `finish()` after backward waits for
+    the collectives, scales by 1 / world_size and scatters the averages back.  Same result as allreduce_gradients.
 
         avg = dp.OverlappedGradientAverager(model.parameters(), bucket_bytes=8 << 20)
         loss.backward(); avg.finish(); optimizer.step()
+
+    Contract:
+      * collectives are issued in BUCKET-INDEX order on every rank, whatever order the hooks fire in: a completed bucket waits
+        for its predecessors, and what backward() did not complete is issued by finish(), still in index order, every bucket at
+        its FULL size (a parameter without a gradient contributes zeros and gets nothing written back) -- so ranks on which
+        different parameters went unused still run the same sequence of equally sized all_reduces;
+      * one backward per finish(): a second backward() before finish() raises instead of silently averaging the first
+        backward's gradients over the accumulated ones.  Gradient accumulation: run the extra backward passes under
+        `with avg.no_sync():` (hooks off, gradients accumulate locally) and the last one outside it.
 
     Without a process group of more than one rank the hooks do nothing."""
 
@@ -126,48 +135,69 @@ class OverlappedGradientAverager:
         if cur:
             self.buckets.append(cur)
         self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
-        self._left = [len(b) for b in self.buckets]
-        self._pending = []          # (bucket index, flat tensor, work handle)
+        self._sync = True
+        self._reset()
         self._hooks = [p.register_post_accumulate_grad_hook(self._ready) for p in self.params]
 
+    def _reset(self):
+        self._left = [len(b) for b in self.buckets]
+        self._next = 0              # the next bucket index to issue
+        self._pending = []          # (bucket index, flat tensor, work handle), in issue (= index) order
+
     def _active(self):
-        return dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return self._sync and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def no_sync(self):
+        """Context manager: backward passes inside it only accumulate into .grad (no collective, nothing counted)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            if self._pending or self._next:
+                raise RuntimeError("OverlappedGradientAverager.no_sync(): collectives of an unfinished step are in flight; call finish() first")
+            old, self._sync = self._sync, False
+            try:
+                yield
+            finally:
+                self._sync = old
+        return ctx()
+
+    def _issue(self, i):
+        flat = torch.cat([(q.grad if q.grad is not None else torch.zeros_like(q)).reshape(-1) for q in self.buckets[i]])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append((i, flat, work))
 
     def _ready(self, p):
         if not self._active():
             return
         i = self._bucket_of[id(p)]
+        if self._left[i] <= 0 or i < self._next:
+            raise RuntimeError("OverlappedGradientAverager: a second backward() reached a bucket whose all_reduce was already started; "
+                               "call finish() after every backward(), or accumulate under `with averager.no_sync():`")
         self._left[i] -= 1
-        if self._left[i] == 0:
-            flat = torch.cat([q.grad.reshape(-1) for q in self.buckets[i]])
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self._pending.append((i, flat, work))
+        while self._next < len(self.buckets) and self._left[self._next] == 0:     # index order on every rank
+            self._issue(self._next)
+            self._next += 1
 
     def finish(self):
-        """Wait for the started collectives, reduce the buckets backward() did not complete (parameters without a gradient this
-        step are skipped), write the averages back.  Returns the number of collectives."""
+        """Issue (in index order, full size) the buckets backward() did not complete, wait for everything, write the averages
+        back into the gradients that exist.  Returns the number of collectives (= the number of buckets)."""
         if not self._active():
             return 0
         world = dist.get_world_size(self.group)
-        started = {i for i, _, _ in self._pending}
-        for i, b in enumerate(self.buckets):
-            if i not in started:
-                have = [q for q in b if q.grad is not None]
-                if have:
-                    flat = torch.cat([q.grad.reshape(-1) for q in have])
-                    work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                    self._pending.append((-1 - i, flat, work))
+        while self._next < len(self.buckets):
+            self._issue(self._next)
+            self._next += 1
         n = len(self._pending)
         for i, flat, work in self._pending:
             work.wait()
             flat.div_(world)
-            b = self.buckets[i] if i >= 0 else [q for q in self.buckets[-1 - i] if q.grad is not None]
             off = 0
-            for q in b:
-                q.grad.copy_(flat[off:off + q.numel()].view_as(q.grad))
+            for q in self.buckets[i]:
+                if q.grad is not None:
+                    q.grad.copy_(flat[off:off + q.numel()].view_as(q.grad))
                 off += q.numel()
-        self._pending = []
-        self._left = [len(b) for b in self.buckets]
+        self._reset()
         return n
 
     def remove(self):

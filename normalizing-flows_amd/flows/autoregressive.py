@@ -71,9 +71,17 @@ class MaskedAffineAutoregressive(Autoregressive):
     def _output_dim_multiplier(self):
         return 2
 
+    @staticmethod
+    def _tri():
+        """Format 1 (regular tiles on the triangular sequential part, nf_maf_inverse_h_tri) -- the default on the half-sharing mapping."""
+        from .. import config
+        return bool(config.maf_halves and config.maf_tri)
+
     def _packed(self, device):
-        """Device copies of the incremental-inverse pack, rebuilt when any MADE parameter changes."""
-        key = _keys.pkey(self.autoregressive_net.parameters()) + (str(device),)
+        """Device copies of the incremental-inverse pack, rebuilt when any MADE parameter changes:
+        (blob, table, hidden_padded, num_blocks, table_host); table_host = the host copy of a format-1 table, else None."""
+        tri = self._tri()
+        key = _keys.pkey(self.autoregressive_net.parameters()) + (str(device), tri)
         cache = getattr(self, "_maf_pack_cache", None)
         if cache is None or cache[0] != key:
             if str(device) != "cpu":      # structure (shared by layers with these masks) + one gather on the device
@@ -81,26 +89,29 @@ class MaskedAffineAutoregressive(Autoregressive):
                 packed = None
                 if st is not None:
                     plist = [t for l in self.autoregressive_net._linears() for t in (l.weight, l.bias)]
-                    packed = (ops.pack_gather(plist, st[0]), st[1], st[2], st[3])
+                    packed = (ops.pack_gather(plist, st[0]), st[1], st[2], st[3], st[4])
             else:
-                packed = maf_pack.pack_made(self.autoregressive_net, blocks=(1, 2, 3))    # 1..3 residual blocks: nf_maf_inverse_h
+                packed = maf_pack.pack_made(self.autoregressive_net, blocks=(1, 2, 3), tri=tri)    # 1..3 residual blocks: nf_maf_inverse_h
                 if packed is not None:
                     blob, table = packed
-                    packed = (torch.from_numpy(blob).to(device), torch.from_numpy(table).to(device), int(table[3]), int(table[6]))
+                    packed = (torch.from_numpy(blob).to(device), torch.from_numpy(table).to(device), int(table[3]), int(table[6]),
+                              table if tri else None)
             self._maf_pack_cache = cache = (key, packed)
         return cache[1]
 
     def _inverse_struct(self, device):
-        """(gather indices, table, hidden_padded, num_blocks) of the one-pass inverse kernel's pack on the device; None = unsupported."""
+        """(gather indices, table, hidden_padded, num_blocks, table_host) of the one-pass inverse kernel's pack on the device;
+        None = unsupported."""
         from ..flows import made_pack
         net = self.autoregressive_net
-        skey = (str(device),) + tuple((l.mask.data_ptr(), l.mask._version) for l in net._linears())
+        tri = self._tri()
+        skey = (str(device), tri) + tuple((l.mask.data_ptr(), l.mask._version) for l in net._linears())
         st = self.__dict__.get("_inv_struct")
         if st is None or st[0] != skey:
-            struct = made_pack.maf_inverse_structure(net)
+            struct = made_pack.maf_inverse_structure(net, tri=tri)
             if struct is not None:
                 struct = (torch.from_numpy(struct[0]).to(device), torch.from_numpy(struct[1]).to(device), int(struct[1][3]),
-                          int(struct[1][6]))
+                          int(struct[1][6]), struct[1] if tri else None)
             st = self.__dict__["_inv_struct"] = (skey, struct)
         return st[1]
 
@@ -119,7 +130,7 @@ class MaskedAffineAutoregressive(Autoregressive):
                 and not autograd.needs_grad(inputs, *self.autoregressive_net.parameters())):
             packed = self._packed(inputs.device)
             if packed is not None:
-                return ops.maf_inverse(inputs, packed[0], packed[1], packed[2], num_blocks=packed[3])
+                return ops.maf_inverse(inputs, packed[0], packed[1], packed[2], num_blocks=packed[3], table_host=packed[4])
         from .. import config
         if (context is None and inputs.dim() == 2 and inputs.dtype == torch.float32 and inputs.is_cuda and config.maf_implicit
                 and config.made_train and config.made_fused):
@@ -142,8 +153,8 @@ class MaskedAffineAutoregressive(Autoregressive):
         inv = self._inverse_struct(device)
         if inv is None:
             return None
-        src, table, hp, nb = inv
-        return (ops.pack_gather(plist, src), table, hp, nb), packs[0], packs[1]
+        src, table, hp, nb, th = inv
+        return (ops.pack_gather(plist, src), table, hp, nb, th), packs[0], packs[1]
 
     def _elementwise(self, inputs, params, direction, want_logdet=True):
         if inputs.dim() != 2:

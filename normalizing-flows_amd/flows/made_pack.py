@@ -626,25 +626,25 @@ def _convnet_train_structure(cin, hid, cout):
     return train_structure(sl_v, _mlp_layers(w1, b1, w2, b2, w3, None), padded_rows=True)
 
 
-def maf_inverse_structure(made, blocks=(1, 2, 3)):
+def maf_inverse_structure(made, blocks=(1, 2, 3), tri=False):
     """(gather indices, table) of the one-pass inverse kernel's pack (flows/maf_pack.pack_made: a pure rearrangement as well) over
     the same flat parameter vector as the training structures -- the packer run on a copy of the MADE that holds parameter
-    positions instead of values; None outside that packer's structure."""
+    positions instead of values; None outside that packer's structure.  `tri`: format 1 (regular tiles triangular)."""
     import copy
     from . import maf_pack
     if not maf_pack.supported(made, 2, blocks):
         return None
-    key = ("maf_inverse", tuple(blocks), _mask_key(made))
+    key = ("maf_inverse", tuple(blocks), bool(tri), _mask_key(made))
     if key in _STRUCTS:
         return _STRUCTS[key]
-    _STRUCTS[key] = _maf_inverse_structure(made, blocks)
+    _STRUCTS[key] = _maf_inverse_structure(made, blocks, tri)
     return _STRUCTS[key]
 
 
-def _maf_inverse_structure(made, blocks):
+def _maf_inverse_structure(made, blocks, tri=False):
     import copy
     from . import maf_pack
-    if maf_pack.pack_made(made, blocks=blocks) is None:
+    if maf_pack.pack_made(made, blocks=blocks, tri=tri) is None:
         return None
     twin = copy.deepcopy(made).cpu()
     lins = [twin.initial_layer] + [l for b in twin.blocks for l in b.linear_layers] + [twin.final_layer]
@@ -652,5 +652,5 @@ def _maf_inverse_structure(made, blocks):
         for lin, (w, b) in zip(lins, index_arrays([tuple(l.weight.shape) for l in lins])):
             lin.weight.copy_(torch.from_numpy(w.astype(np.float32)))
             lin.bias.copy_(torch.from_numpy(b.astype(np.float32)))
-    blob, table = maf_pack.pack_made(twin, blocks=blocks)
+    blob, table = maf_pack.pack_made(twin, blocks=blocks, tri=tri)
     return _as_src(blob), table

@@ -28,6 +28,19 @@ nf_arnsf_inverse) every feature gets its own 32-row block, zero-padded:
   [0:32]                      final-layer bias of feature 0
   per tile t                  A0 | A1..A4 [4t][2][32][4] | AF_s [4t][2][32][4] for each step s | bias[5][32]
                               | W0d[32][16] | Wd[4][32][32] | biasF[nsteps][32] | WFd[nsteps][mult][32]
+
+Format 1 (`tri=True`, table[7] = 1; nf_maf_inverse_h only, round 5): REGULAR tiles -- at most FAST_STEPS = 8 degrees of at most 4
+units each (config 5: 15 of the 16 tiles) -- carry their sequential part's weights TRIANGULAR and in the order the kernel's
+statically unrolled steps read them; table entry [20] = 1 marks such a tile.  Unit i of step g sits at the MFMA row whose
+accumulator is register 2 g + (i & 1) of lane-half i >> 1 (row = (r & 3) + 8 (r >> 2) + 4 half), so after step g registers
+0 .. 2 g + 1 of BOTH halves are final and a step's four targets are two per half.  Record of a regular tile after the A operands:
+  bias[NL][32] | biasF[32] (row g = unconstrained scale of step g's feature on half 0, row g + 4.. = its shift: same register, half 1)
+  | half 0 | half 1, each half = W0f | Wdf[NL-1] | WFf in float4 units:
+     W0f  step g, q = 0..g/2      : (w[t0][x 2q], w[t0][x 2q+1], w[t1][x 2q], w[t1][x 2q+1])   t0, t1 = the half's OWN targets, x = window
+     Wdf  step g, q = 0..g, j=0,1 : (w[t 2j][s 2q], w[t 2j][s 2q+1], w[t 2j+1][s 2q], w[t 2j+1][s 2q+1])   t = all four targets,
+                                     s 2q, s 2q+1 = the half's registers 2q, 2q+1 of the source layer (slot q <= g only: triangular)
+     WFf  step g, q = 0..g        : (w[us][s 2q], w[us][s 2q+1], w[sh][s 2q], w[sh][s 2q+1])
+Other tiles keep the format-0 record.
 """
 import numpy as np
 import torch
@@ -37,6 +50,23 @@ TILE = 32        # hidden units per tile (MFMA rows)
 MAX_STEPS = 16   # degrees per tile (two final-layer rows per step -> 32 MFMA rows)
 TABLE_HDR = 8
 TABLE_ENT = 24
+FAST_STEPS = 8   # format 1: a REGULAR tile has <= 8 degrees of <= 4 units
+FAST_W0 = sum(g // 2 + 1 for g in range(FAST_STEPS))          # float4 per half
+FAST_WD = sum(2 * (g + 1) for g in range(FAST_STEPS))
+FAST_WF = sum(g + 1 for g in range(FAST_STEPS))
+
+
+def fast_half_floats(NL):
+    return 4 * (FAST_W0 + (NL - 1) * FAST_WD + FAST_WF)
+
+
+def _row_of(reg, half):
+    """MFMA row whose accumulator is register `reg` of lane-half `half` (v_mfma_f32_32x32x2_f32 C layout)."""
+    return (reg & 3) + 8 * (reg >> 2) + 4 * half
+
+
+def is_regular(steps):
+    return len(steps) <= FAST_STEPS and max(steps) <= 4
 
 
 def plan_tiles(D, hidden_degrees):
@@ -84,11 +114,14 @@ def supported(made, mult=2, blocks=(2,)):
     return 2 <= mult <= TILE
 
 
-def pack_made(made, mult=2, rows=False, blocks=(2,)):
+def pack_made(made, mult=2, rows=False, blocks=(2,), tri=False):
     """Returns (blob float32 ndarray, table int32 ndarray) or None if the MADE is not the supported structure.
     `mult` = final-layer outputs per feature (MADE's output_multiplier); `rows` selects the one-block-per-feature
-    layout of nf_arnsf_inverse; `blocks`: the residual-block counts the caller's kernel takes."""
+    layout of nf_arnsf_inverse; `blocks`: the residual-block counts the caller's kernel takes; `tri`: format 1 (module docstring;
+    nf_maf_inverse_h only)."""
     if not supported(made, mult, blocks) or (rows and len(made.blocks) != 2):
+        return None
+    if tri and (rows or mult != 2):
         return None
     D = made.initial_layer.in_features
     H = made.initial_layer.out_features
@@ -118,12 +151,17 @@ def pack_made(made, mult=2, rows=False, blocks=(2,)):
     pos = np.zeros(H, dtype=np.int64)
     slot_deg = np.zeros(Hp, dtype=np.int64)
     k = 0
+    regular = [bool(tri) and is_regular(steps) for (_, _, steps) in tiles]
     for t, (dlo, ns, steps) in enumerate(tiles):
         base = t * TILE
         for s, c in enumerate(steps):
-            for _ in range(c):
-                pos[k] = base
-                slot_deg[base] = dlo + s
+            for i in range(c):
+                if regular[t]:
+                    slot = t * TILE + _row_of(2 * s + (i & 1), i >> 1)
+                else:
+                    slot = base
+                pos[k] = slot
+                slot_deg[slot] = dlo + s
                 base += 1
                 k += 1
     assert k == H
@@ -164,7 +202,7 @@ def pack_made(made, mult=2, rows=False, blocks=(2,)):
     chunks = [head]
     off = head.size
     table = np.zeros(TABLE_HDR + TABLE_ENT * T, dtype=np.int32)
-    table[0:7] = [D, Dp, H, Hp, T, mult, NB]
+    table[0:8] = [D, Dp, H, Hp, T, mult, NB, int(bool(tri))]
     for t, (dlo, ns, steps) in enumerate(tiles):
         r0, r1 = t * TILE, (t + 1) * TILE
         nprev = dlo - 1                    # features (0-based) 0..dlo-2 come from the block part; dlo-1.. from the window
@@ -190,8 +228,10 @@ def pack_made(made, mult=2, rows=False, blocks=(2,)):
             bfo = np.zeros(TILE, dtype=np.float32)
             for j in range(ns):
                 f = dlo + j
-                fo[2 * j:2 * j + 2] = WF[2 * f:2 * f + 2]
-                bfo[2 * j:2 * j + 2] = bf[2 * f:2 * f + 2]
+                # format 0: rows 2 j, 2 j + 1; regular tile: register j of half 0 (scale) / half 1 (shift)
+                ra, rb = (_row_of(j, 0), _row_of(j, 1)) if regular[t] else (2 * j, 2 * j + 1)
+                fo[ra], fo[rb] = WF[2 * f], WF[2 * f + 1]
+                bfo[ra], bfo[rb] = bf[2 * f], bf[2 * f + 1]
             if t:
                 rec.append(_a_operand(fo[:, :r0]))
         rec.append(np.concatenate([b0[r0:r1]] + [b[r0:r1] for b in bh]))
@@ -201,10 +241,40 @@ def pack_made(made, mult=2, rows=False, blocks=(2,)):
         nwin = min(MAX_STEPS, D - (dlo - 1))
         w0d[:, :nwin] = W0[r0:r1, dlo - 1:dlo - 1 + nwin]
         # a unit of degree dlo+s must not see window features above its own degree: the mask already guarantees it
-        rec.append(w0d.reshape(-1))
-        for w in Wh:
-            rec.append(np.ascontiguousarray(w[r0:r1, r0:r1]).reshape(-1))
-        if rows:
+        if regular[t]:
+            halves = []
+            for hh in (0, 1):
+                part = []
+                trow = lambda g, i: _row_of(2 * g + (i & 1), i >> 1)          # row (within the tile) of unit i of step g
+                for g in range(FAST_STEPS):                                      # W0f: the half's own targets over the window pairs
+                    t0, t1 = trow(g, 2 * hh), trow(g, 2 * hh + 1)
+                    for q in range(g // 2 + 1):
+                        part.append([w0d[t0, 2 * q], w0d[t0, 2 * q + 1], w0d[t1, 2 * q], w0d[t1, 2 * q + 1]])
+                for w in Wh:                                                     # Wdf: all four targets over the half's registers <= 2 g + 1
+                    d = w[r0:r1, r0:r1]
+                    for g in range(FAST_STEPS):
+                        for q in range(g + 1):
+                            sa, sb = _row_of(2 * q, hh), _row_of(2 * q + 1, hh)
+                            for j in (0, 1):
+                                ta, tb = trow(g, 2 * j), trow(g, 2 * j + 1)
+                                part.append([d[ta, sa], d[ta, sb], d[tb, sa], d[tb, sb]])
+                d = fo[:, r0:r1]
+                for g in range(FAST_STEPS):                                      # WFf: (scale, shift) of step g's feature
+                    ru, rs = _row_of(g, 0), _row_of(g, 1)
+                    for q in range(g + 1):
+                        sa, sb = _row_of(2 * q, hh), _row_of(2 * q + 1, hh)
+                        part.append([d[ru, sa], d[ru, sb], d[rs, sa], d[rs, sb]])
+                part = np.asarray(part, dtype=np.float32).reshape(-1)
+                assert part.size == fast_half_floats(len(Wh) + 1)
+                halves.append(part)
+            rec.append(np.concatenate(halves))
+        else:
+            rec.append(w0d.reshape(-1))
+            for w in Wh:
+                rec.append(np.ascontiguousarray(w[r0:r1, r0:r1]).reshape(-1))
+        if regular[t]:
+            pass
+        elif rows:
             rec.append(bfo.reshape(-1))
             rec.append(np.ascontiguousarray(fo[:, :mult, r0:r1]).reshape(-1))
         else:
@@ -212,6 +282,7 @@ def pack_made(made, mult=2, rows=False, blocks=(2,)):
         rec = np.concatenate(rec)
         e = TABLE_HDR + TABLE_ENT * t
         table[e + 0], table[e + 1], table[e + 2], table[e + 3] = dlo, ns, K0, off
+        table[e + 20] = int(regular[t])
         u = 0
         for s, c in enumerate(steps):
             table[e + 4 + s] = np.array([((1 << c) - 1) << u], dtype=np.uint64).astype(np.uint32).view(np.int32)[0]

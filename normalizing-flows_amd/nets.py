@@ -112,8 +112,13 @@ class ResidualNet(nn.Module):
         self.use_batch_norm = use_batch_norm
 
     def _train_packs(self, device):
-        """Packs for the MADE training kernels (dense); None outside their structure."""
+        """Packs for the MADE training kernels (dense); None outside their structure.  Eligibility is re-checked on EVERY call:
+        `is_plain_relu` depends on the mode when dropout_probability > 0 (eval: dropout is the identity, train: it is not), so
+        neither a structure built in eval() may serve a later train() step (MadeFn has no dropout: it would be skipped
+        silently) nor may a `None` seen in train() stick to the module (nets.py:78)."""
         from .flows import made_pack
+        if not made_pack.resnet_supported(self):
+            return None
         lins = [self.initial_layer] + [l for b in self.blocks for l in b.linear_layers] + [self.final_layer]
         return _train_packs_from(self, lambda: made_pack.resnet_train_structure(self), [t for l in lins for t in (l.weight, l.bias)],
                                  device)

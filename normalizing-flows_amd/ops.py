@@ -1047,9 +1047,11 @@ def made_wgrad(g_params, x, G, save, wtable, stable, mask, ntiles, nflat, Mp, Dx
     return grads
 
 
-def maf_inverse(z, blob, table, hidden_padded, logdet=None, acc=None, num_blocks=2):
+def maf_inverse(z, blob, table, hidden_padded, logdet=None, acc=None, num_blocks=2, table_host=None):
     """autoregressive.py:29-38 + :114-128 in one pass; blob/table from flows/maf_pack.pack_made.  config.maf_halves (default):
-    nf_maf_inverse_h (32 samples per wave, 1..3 residual blocks); otherwise round 2's nf_maf_inverse (two blocks only)."""
+    nf_maf_inverse_h (32 samples per wave, 1..3 residual blocks); otherwise round 2's nf_maf_inverse (two blocks only).
+    `table_host`: the host (numpy int32) copy of a FORMAT-1 table (pack_made(tri=True)) -> nf_maf_inverse_h_tri; a format-1 pack
+    must come with it (the format-0 entry points cannot read its regular tiles)."""
     L.require_device(z, blob, table)
     if z.dtype != torch.float32:
         raise NotImplementedError("maf_inverse: float32 only")
@@ -1063,6 +1065,17 @@ def maf_inverse(z, blob, table, hidden_padded, logdet=None, acc=None, num_blocks
     elif acc is None:
         acc = L.LD_ADD
     lib = L.lib()
+    if table_host is not None:
+        import numpy as np
+        th = np.ascontiguousarray(table_host, dtype=np.int32)
+        if int(th[7]) != 1:
+            raise ValueError("maf_inverse: table_host is given for format-1 packs only")
+        n = lib.nf_maf_inverse_h_scratch_floats(i64(B), i32(D), i32(hidden_padded), i32(num_blocks))
+        scratch = torch.empty(max(int(n), 1), dtype=torch.float32, device=z.device)
+        rc = lib.nf_maf_inverse_h_tri(ptr(z), ptr(y), ptr(logdet), ptr(blob), ptr(table), C.c_void_p(th.ctypes.data), ptr(scratch),
+                                      i64(B), i32(D), i32(hidden_padded), i32(num_blocks), i32(acc), L.stream())
+        L.check(rc, "nf_maf_inverse_h_tri")
+        return y, logdet
     if config.maf_halves or num_blocks != 2:
         n = lib.nf_maf_inverse_h_scratch_floats(i64(B), i32(D), i32(hidden_padded), i32(num_blocks))
         scratch = torch.empty(max(int(n), 1), dtype=torch.float32, device=z.device)

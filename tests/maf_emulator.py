@@ -41,6 +41,83 @@ def emulate_inverse(blob, table, z, element=None):
             Ah.append(_from_a_operand(blob[off:off + Kh * TILE], Kh) if Kh else np.zeros((TILE, 0))); off += Kh * TILE
         bias = blob[off:off + NL * TILE].reshape(NL, TILE); off += NL * TILE
         biasF = blob[off:off + TILE]; off += TILE
+        if int(table[7]) == 1 and int(table[e + 20]) == 1:
+            # format 1, REGULAR tile: the statically unrolled triangular steps of maf_inverse_h.hip (fast path), lane-half by
+            # lane-half and register by register, reading the record exactly where the kernel reads it
+            pre = np.zeros((NL, B, TILE))
+            pre[0] = x[:, :K0] @ A0.T + bias[0]
+            for l in range(1, NL):
+                pre[l] = S[l - 1][:, :Kh] @ Ah[l - 1].T + bias[l]
+            preF = S[NL - 1][:, :Kh] @ Ah[NL - 1].T + biasF
+            row = lambda r, h: (r & 3) + 8 * (r >> 2) + 4 * h
+            HALF = 4 * (20 + (NL - 1) * 72 + 36)
+            P = np.zeros((NL, 2, 16, B))                 # P[l][half][reg] = accumulator register `reg` of lane-half `half`
+            for l in range(NL):
+                for h in (0, 1):
+                    for r in range(16):
+                        P[l, h, r] = pre[l][:, row(r, h)]
+            PF = np.stack([np.stack([preF[:, row(r, h)] for r in range(16)]) for h in (0, 1)])
+            half = [blob[off + h * HALF:off + (h + 1) * HALF].reshape(-1, 4) for h in (0, 1)]
+            xg = np.zeros((18, B))
+            xg[0] = x[:, dlo - 1]
+            o0, od, of = 0, 20, 20 + (NL - 1) * 72
+            for g in range(ns):
+                b0 = o0 + sum(gg // 2 + 1 for gg in range(g))
+                for h in (0, 1):                          # initial layer: each half finishes its own two targets
+                    a = [P[0, h, 2 * g].copy(), P[0, h, 2 * g + 1].copy()]
+                    for q in range(g // 2 + 1):
+                        w = half[h][b0 + q]
+                        a[0] += w[0] * xg[2 * q] + w[1] * xg[2 * q + 1]
+                        a[1] += w[2] * xg[2 * q] + w[3] * xg[2 * q + 1]
+                    for i in (0, 1):
+                        P[2, h, 2 * g + i] += a[i]
+                        P[0, h, 2 * g + i] = np.maximum(a[i], 0)
+
+                def product(l):
+                    """partials of the four targets over each half's registers 0..2g+1 of layer l, then the two exchanges:
+                    returns tot[half][i] for the half's own targets (registers 2g, 2g+1)"""
+                    bd = od + l * 72 + g * (g + 1)
+                    part = np.zeros((2, 4, B))
+                    for h in (0, 1):
+                        for q in range(g + 1):
+                            for j in (0, 1):
+                                w = half[h][bd + 2 * q + j]
+                                part[h, 2 * j] += w[0] * P[l, h, 2 * q] + w[1] * P[l, h, 2 * q + 1]
+                                part[h, 2 * j + 1] += w[2] * P[l, h, 2 * q] + w[3] * P[l, h, 2 * q + 1]
+                    # v_permlane32_swap(q0, q2) + add: half 0 <- target 0, half 1 <- target 2; (q1, q3): targets 1 / 3
+                    return [[part[0, 0] + part[1, 0], part[0, 1] + part[1, 1]], [part[0, 2] + part[1, 2], part[0, 3] + part[1, 3]]]
+                for b in range(NB):
+                    tot = product(2 * b)
+                    for h in (0, 1):
+                        for i in (0, 1):
+                            P[2 * b + 1, h, 2 * g + i] = np.maximum(P[2 * b + 1, h, 2 * g + i] + tot[h][i], 0)
+                    tot = product(2 * b + 1)
+                    for h in (0, 1):
+                        for i in (0, 1):
+                            hn = P[2 * b + 2, h, 2 * g + i] + tot[h][i]
+                            if b + 1 < NB:
+                                P[2 * b + 4, h, 2 * g + i] += hn
+                                P[2 * b + 2, h, 2 * g + i] = np.maximum(hn, 0)
+                            else:
+                                P[2 * b + 2, h, 2 * g + i] = hn
+                bf_ = of + g * (g + 1) // 2
+                pu, ps = np.zeros((2, B)), np.zeros((2, B))
+                for h in (0, 1):
+                    for q in range(g + 1):
+                        w = half[h][bf_ + q]
+                        pu[h] += w[0] * P[NL - 1, h, 2 * q] + w[1] * P[NL - 1, h, 2 * q + 1]
+                        ps[h] += w[2] * P[NL - 1, h, 2 * q] + w[3] * P[NL - 1, h, 2 * q + 1]
+                us = pu[0] + pu[1] + PF[0, g]             # half 0 holds the scale row in register g, half 1 the shift row
+                sh = ps[0] + ps[1] + PF[1, g]
+                xn, d = finish(us, sh, z[:, dlo + g])
+                ld += d
+                x[:, dlo + g] = xn
+                xg[g + 1] = xn
+            for l in range(NL):
+                for h in (0, 1):
+                    for r in range(16):
+                        S[l][:, TILE * t + row(r, h)] = P[l, h, r]
+            continue
         W0d = blob[off:off + TILE * MAX_STEPS].reshape(TILE, MAX_STEPS); off += TILE * MAX_STEPS
         Wd = blob[off:off + (NL - 1) * TILE * TILE].reshape(NL - 1, TILE, TILE); off += (NL - 1) * TILE * TILE
         WFd = blob[off:off + TILE * TILE].reshape(TILE, TILE); off += TILE * TILE

@@ -796,10 +796,16 @@ def test_drop_in_under_the_reference_own_containers(nfa):
     167-197) and `nf.MultiscaleFlow` (core.py:455-616) with our GlowBlock / Squeeze / Merge layers give bit-for-bit what our own
     containers give on the same layers, and our layers load the reference's state_dict unchanged."""
     import sys
-    if not os.path.isdir("/root/reference/normflows"):
-        pytest.skip("the reference is not on this box")
-    sys.path.insert(0, "/root/reference")
+    # the build container has /root/reference; on the GPU box the package arrives staged (tools/stage_reference.py -> .refstage/,
+    # git-ignored, NF_REFERENCE_PATH) -- round 5 ran it there: profiles/r05_reference_containers_gpubox.log
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cands = [os.environ.get("NF_REFERENCE_PATH"), os.path.join(here, ".refstage"), "/root/reference"]
+    ref = next((os.path.abspath(c) for c in cands if c and os.path.isdir(os.path.join(c, "normflows"))), None)
+    if ref is None:
+        pytest.skip("the reference is not on this box (stage it with tools/stage_reference.py)")
+    sys.path.insert(0, ref)
     nf = pytest.importorskip("normflows")
+    assert os.path.abspath(nf.__file__).startswith(ref), nf.__file__
     torch.manual_seed(0)
     flows = []
     for _ in range(3):
@@ -817,18 +823,35 @@ def test_drop_in_under_the_reference_own_containers(nfa):
         ours.log_prob(x)                                   # ActNorm's data-dependent init happens once, here
     theirs = nf.NormalizingFlow(nf.distributions.DiagGaussian(8, trainable=False), flows).to(DEV)
     with torch.no_grad():
-        assert torch.equal(theirs.log_prob(x), ours.log_prob(x))
+        # (1) the reference's loops (core.py:36-38, 193-195) call our layers one by one: BIT-identical to the same calls written out
+        # here.  (First run on the GPU box in round 5: the original version of this test expected bit equality against our own
+        # container, whose fused chain sums in another order, and failed by one unit in the fifth digit.)
+        q0 = theirs.q0                                      # (the reference's own base distribution: torch ops)
+        lp_t = theirs.log_prob(x)
+        z_, lq_ = x, torch.zeros(len(x), device=DEV)
+        for f in reversed(flows):
+            z_, ld_ = f.inverse(z_)
+            lq_ = lq_ + ld_
+        assert torch.equal(lp_t, lq_ + q0.log_prob(z_))
+        z_t, ld_t = theirs.inverse_and_log_det(x)
+        assert torch.equal(z_t, z_)
         torch.manual_seed(5)
         xs_t, lq_t = theirs.sample(64)
         torch.manual_seed(5)
-        xs_o, lq_o = ours.sample(64)
-        assert torch.equal(xs_t, xs_o) and torch.equal(lq_t, lq_o)
-        z_t, ld_t = theirs.inverse_and_log_det(x)
-        z_o, ld_o = ours.inverse_and_log_det(x)
-        assert torch.equal(z_t, z_o) and torch.allclose(ld_t, ld_o, atol=1e-6)
+        zs, lqs = q0(64)
+        for f in flows:
+            zs, ld_ = f(zs)
+            lqs = lqs - ld_
+        assert torch.equal(xs_t, zs) and torch.equal(lq_t, lqs)
+        # (2) against our default (layer pairs fused into one persistent launch): another summation order, 1e-5
+        lp_f = ours.log_prob(x)
+        assert _rel(N(lp_t), N(lp_f)) < 1e-5, _rel(N(lp_t), N(lp_f))
+        torch.manual_seed(5)
+        xs_f, lq_f = ours.sample(64)
+        assert torch.allclose(xs_t, xs_f, atol=2e-5) and _rel(N(lq_t), N(lq_f)) < 1e-5
     lt = theirs.forward_kld(x)
     lo = ours.forward_kld(x)
-    assert abs(float(lt) - float(lo)) < 1e-6 * abs(float(lo))
+    assert abs(float(lt) - float(lo)) < 2e-6 * abs(float(lo))
     # MultiscaleFlow (Glow, examples/glow.ipynb cell 2, reduced): the reference's container over our blocks
     torch.manual_seed(1)
     L_, K_, C, hidden = 2, 2, 3, 16
@@ -2108,9 +2131,10 @@ def test_fused_kernel_on_narrower_layers_vs_unfused_and_oracle(nfa, oracle, D, h
 
 @pytest.mark.parametrize("B", [65536, 1000, 33, 1])
 def test_maf_inverse_both_mappings_agree(nfa, B):
-    """nf_maf_inverse_h (32 samples per wave, lane-halves sharing a sample's hidden units: round 3) against nf_maf_inverse
-    (64 samples per wave: round 2) on the configs[4] layer shape -- same packed blob, table and scratch; different summation
-    order only (1e-5); batches off the 32-sample wave / the 256-sample workgroup; run-to-run bit equality."""
+    """The three generations of the one-pass inverse on the configs[4] layer shape: nf_maf_inverse_h_tri (round 5: format-1 pack,
+    regular tiles on the triangular statically unrolled sequential part, two launches: tile 0 generic + tiles 1..15 fast),
+    nf_maf_inverse_h (round 3: format 0) and nf_maf_inverse (round 2: 64 samples per wave) -- different summation orders only
+    (2e-5); batches off the 32-sample wave / the 256-sample workgroup; run-to-run bit equality; round trip."""
     torch.manual_seed(B)
     layer = nfa.flows.MaskedAffineAutoregressive(128, 512, num_blocks=2).to(DEV)
     with torch.no_grad():
@@ -2119,19 +2143,68 @@ def test_maf_inverse_both_mappings_agree(nfa, B):
     z = torch.randn(B, 128, device=DEV)
     res = []
     try:
-        for halves in (True, False):
+        for halves, tri in ((True, True), (True, False), (False, False)):
             nfa.config.set_maf_halves(halves)
-            x, ld = layer.forward(z)
+            nfa.config.set_maf_tri(tri)
+            pk = layer._packed(DEV)
+            assert (pk[4] is not None) == tri and int(N(pk[1])[7]) == int(tri)
+            x, ld = layer.inverse(z)
             res.append((x, ld))
         nfa.config.set_maf_halves(True)
-        x2, ld2 = layer.forward(z)
+        nfa.config.set_maf_tri(True)
+        x2, ld2 = layer.inverse(z)
     finally:
         nfa.config.set_maf_halves(True)
+        nfa.config.set_maf_tri(True)
     assert torch.equal(res[0][0], x2) and torch.equal(res[0][1], ld2)
-    assert_close(N(res[0][0]), N(res[1][0]), what="x", rtol=1e-5, atol=1e-5)
-    assert_close(N(res[0][1]), N(res[1][1]), what="logdet", rtol=1e-5, atol=1e-5)
-    zz, _ = layer.inverse(res[0][0])
+    for other in (1, 2):
+        assert_close(N(res[0][0]), N(res[other][0]), what="x", rtol=2e-5, atol=2e-5)
+        assert_close(N(res[0][1]), N(res[other][1]), what="logdet", rtol=2e-5, atol=2e-5)
+    zz, _ = layer.forward(res[0][0])
     assert_close(N(zz), N(z), what="round trip", rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("D,H,NB,B", [(128, 512, 2, 4099), (64, 252, 2, 1000), (10, 36, 1, 77), (12, 40, 3, 257), (96, 256, 2, 513),
+                                      (128, 512, 1, 64), (64, 252, 1, 31)])
+def test_maf_inverse_regular_tiles_triangular_path(nfa, D, H, NB, B):
+    """nf_maf_inverse_h_tri (round 5) on structures whose tiles are regular from the start (64 / 252: the fast kernel also does
+    feature 0), regular with short last tiles (10 / 36: one degree; 12 / 40: 3 units per degree), generic then regular (128 / 512:
+    degrees 1-4 own five units -> tile 0 generic; 96 / 256: eight generic tiles, then one regular) -- i.e. one, two launches per
+    layer in both orders: against the reference's D-pass structure on the same weights, the three log-det accumulation modes
+    ACROSS the launches, and bit-equal repeats.  Packer + schedule are pinned on CPU (tests/test_host.py, same shapes)."""
+    from normflows_amd.flows.autoregressive import Autoregressive
+    from normflows_amd.flows import maf_pack
+    torch.manual_seed(D * 1000 + H + NB)
+    layer = nfa.flows.MaskedAffineAutoregressive(D, H, num_blocks=NB)
+    _perturb(layer, 0.05 if D < 100 else 0.02, 3)
+    layer = layer.to(DEV)
+    pk = layer._packed(DEV)
+    assert pk is not None and pk[3] == NB and pk[4] is not None and int(pk[4][7]) == 1
+    T = int(pk[4][4])
+    kinds = [int(pk[4][8 + 24 * t + 20]) for t in range(T)]
+    assert any(kinds)
+    z = torch.randn(B, D, generator=torch.Generator().manual_seed(5)).to(DEV)
+    x1, ld1 = layer.inverse(z)
+    x0, ld0 = Autoregressive.inverse(layer, z)       # D MADE passes
+    assert_close(N(x1), N(x0), what="x", rtol=2e-4, atol=2e-4)
+    assert_close(N(ld1), N(ld0), what="ld", rtol=2e-4, atol=2e-4)
+    xr, _ = layer.forward(x1)
+    assert_close(N(xr), N(z), what="roundtrip", rtol=1e-3, atol=1e-3)
+    for mode, ref in ((nfa.ops.L.LD_ADD, 1.0 + N(ld1)), (nfa.ops.L.LD_SUB, 1.0 - N(ld1))):
+        acc = torch.ones(B, device=DEV)
+        x2, _ = nfa.ops.maf_inverse(z, pk[0], pk[1], pk[2], logdet=acc, acc=mode, num_blocks=NB, table_host=pk[4])
+        assert torch.equal(x2, x1)
+        assert_close(N(acc), ref, what="acc %d" % mode, rtol=1e-6, atol=1e-6)
+    # the C ABI's argument checks for the new entry point (nothing is launched on bad arguments)
+    import ctypes as C
+    lib, L = nfa.ops.L.lib(), nfa.ops.L
+    th = np.ascontiguousarray(pk[4], dtype=np.int32)
+    args = lambda t_host, hp: (L.ptr(z), L.ptr(x1), L.ptr(ld1), L.ptr(pk[0]), L.ptr(pk[1]), t_host, L.ptr(pk[0]), L.i64(B), L.i32(D),
+                               L.i32(hp), L.i32(NB), L.i32(0), L.stream())
+    assert lib.nf_maf_inverse_h_tri(*args(C.c_void_p(0), pk[2])) == -14
+    bad = th.copy(); bad[7] = 0
+    assert lib.nf_maf_inverse_h_tri(*args(C.c_void_p(bad.ctypes.data), pk[2])) == -22
+    assert lib.nf_maf_inverse_h_tri(*args(C.c_void_p(th.ctypes.data), pk[2] + 32)) == -22
 
 
 @pytest.mark.parametrize("D,H,NB,B", [(128, 512, 1, 4096), (40, 100, 3, 777), (128, 512, 3, 2048), (17, 40, 1, 65), (40, 39, 1, 129), (40, 39, 3, 129)])

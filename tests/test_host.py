@@ -80,6 +80,17 @@ def test_c_abi_argument_validation_newer_entry_points(nfa):
     assert lib.nf_maf_inverse_h(one, one, one, null, one, one, i64(8), i32(128), i32(512), i32(2), i32(0), null) == -14
     assert lib.nf_maf_inverse_h(null, null, null, null, null, null, i64(0), i32(128), i32(512), i32(1), i32(0), null) == 0
     assert lib.nf_maf_inverse_h_scratch_floats(i64(64), i32(128), i32(512), i32(2)) == 64 * (5 * 512 + 128 + 5 * 32)
+    # format-1 entry point (round 5): the HOST copy of the table is mandatory and must describe the call
+    th = np.zeros(8 + 24 * 16, dtype=np.int32)
+    th[:8] = [128, 128, 512, 512, 16, 2, 2, 1]
+    hp_ = vp(th.ctypes.data)
+    assert lib.nf_maf_inverse_h_tri(one, one, one, one, one, null, one, i64(8), i32(128), i32(512), i32(2), i32(0), null) == -14
+    assert lib.nf_maf_inverse_h_tri(one, one, one, one, one, hp_, one, i64(8), i32(128), i32(512), i32(1), i32(0), null) == -22   # num_blocks != table's
+    assert lib.nf_maf_inverse_h_tri(one, one, one, one, one, hp_, one, i64(8), i32(64), i32(512), i32(2), i32(0), null) == -22     # D != table's
+    assert lib.nf_maf_inverse_h_tri(one, one, one, null, one, hp_, one, i64(8), i32(128), i32(512), i32(2), i32(0), null) == -14   # blob
+    assert lib.nf_maf_inverse_h_tri(null, null, null, null, null, hp_, null, i64(0), i32(128), i32(512), i32(2), i32(0), null) == 0
+    th[7] = 0
+    assert lib.nf_maf_inverse_h_tri(one, one, one, one, one, hp_, one, i64(8), i32(128), i32(512), i32(2), i32(0), null) == -22   # a format-0 table
     assert lib.nf_maf_inverse_scratch_floats(i64(65), i32(128), i32(512)) == 2 * 64 * (5 * 512 + 128 + 5 * 32)   # + pair stash
 
     def arnsf(K, tails, hp=512, B=8, blob=one):
@@ -390,7 +401,7 @@ def test_dp_nll_matches_unsharded_under_gloo(nfa, tmp_path):
 
 
 @pytest.mark.parametrize("D,H,NB", [(128, 512, 2), (17, 40, 2), (3, 2, 2), (40, 39, 2), (6, 150, 2), (17, 40, 1), (33, 70, 3), (128, 512, 1),
-                                    (32, 64, 2), (96, 256, 2)])
+                                    (32, 64, 2), (96, 256, 2), (64, 252, 2), (10, 36, 1), (12, 40, 3)])
 def test_maf_pack_schedule_matches_d_pass(D, H, NB):
     """flows/maf_pack.py + the kernel's tile/step schedule (tests/maf_emulator.py restates it in numpy) reproduce the
     fixed point of the reference's D-pass inverse (autoregressive.py:29-38) computed with plain torch in fp64."""
@@ -407,6 +418,7 @@ def test_maf_pack_schedule_matches_d_pass(D, H, NB):
     blob, table = maf_pack.pack_made(made, blocks=(1, 2, 3))
     assert table[6] == NB
     assert table[0] == D and table[3] % 32 == 0 and table[3] >= H
+    blob1, table1 = maf_pack.pack_made(made, blocks=(1, 2, 3), tri=True)
     z = torch.randn(16, D)
     m64 = made.double()
     with torch.no_grad():
@@ -419,6 +431,17 @@ def test_maf_pack_schedule_matches_d_pass(D, H, NB):
     x, ld = emulate_inverse(blob, table, z.numpy())
     np.testing.assert_allclose(x, out.numpy(), rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(ld, ldref.numpy(), rtol=1e-9, atol=1e-9)
+    # format 1 (round 5): regular tiles (<= 8 degrees of <= 4 units) with triangular, statically ordered sequential weights
+    assert table1[7] == 1 and np.array_equal(table1[:7], table[:7])
+    T = int(table1[4])
+    reg = [int(table1[8 + 24 * t + 20]) for t in range(T)]
+    plan = maf_pack.plan_tiles(D, made.initial_layer.degrees.numpy())[1]
+    assert reg == [int(maf_pack.is_regular(st)) for (_, _, st) in plan]
+    if (D, H) == (128, 512):
+        assert reg == [0] + [1] * 15                     # config 5: degrees 1-4 own five units
+    x1, ld1 = emulate_inverse(blob1, table1, z.numpy())
+    np.testing.assert_allclose(x1, out.numpy(), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(ld1, ldref.numpy(), rtol=1e-9, atol=1e-9)
 
 
 @pytest.mark.parametrize("D,H,K,tails", [(64, 256, 8, "linear"), (9, 40, 4, None), (5, 12, 10, "circular"), (3, 2, 1, "linear")])
@@ -861,6 +884,28 @@ def test_cache_keys_follow_fused_optimizer_steps():
     with torch.no_grad():
         p.add_(1.0)
     assert _keys.pkey([p]) != k1
+
+
+def test_wide_resnet_training_path_rechecks_mode_dependent_eligibility():
+    """ADVICE r04 (nets.py:78): a ResidualNet with dropout is the kernels' plain ReLU MLP only in eval().  A structure cached by a
+    grad-enabled eval() call must not serve a later train() call (MadeFn has no dropout), and the train() verdict must not stick:
+    `_train_packs` asks made_pack.resnet_supported on EVERY call."""
+    import normflows_amd as nfa
+    from normflows_amd.flows import made_pack
+    net = nfa.nets.ResidualNet(8, 16, 256, num_blocks=2, dropout_probability=0.2)
+    net.eval()
+    assert made_pack.resnet_supported(net) and made_pack.resnet_train_structure(net) is not None
+    # as if an eval()-mode forward under autograd had cached the structure on the module
+    net.__dict__["_train_struct"] = (("cpu",), {"sentinel": True})
+    net.train()
+    assert not made_pack.resnet_supported(net)
+    assert net._train_packs("cpu") is None                       # dropout is live: the cached structure is not used
+    assert net.__dict__["_train_struct"][1] == {"sentinel": True}   # ... and the None verdict did not overwrite the cache
+    net.eval()
+    assert made_pack.resnet_supported(net)                       # eligible again once dropout is the identity
+    plain = nfa.nets.ResidualNet(8, 16, 256, num_blocks=2)
+    plain.train()
+    assert made_pack.resnet_supported(plain)
 
 
 def test_conv_conditioner_training_path_declines_other_structures():

@@ -3,14 +3,17 @@
 imported from /root/reference, PyTorch CPU, on the benchmark of record -- BASELINE configs[1], the same seeded model and the
 same rows bench.py runs on the GPU (bench.build_c2_model(lib=normflows), bench.c2_inputs).
 
-The reference tree exists only in the build container (the GPU box has no /root/reference), so this script runs THERE and
-its JSON output is committed under profiles/; bench.py reads that file and reports it as the `kind: "reference"` entry of
-`cpu_baseline` next to the `kind: "port"` entry it times live on the GPU box's own host cores.
+The reference tree exists only in the build container (the GPU box has no /root/reference).  Rounds 2-4 ran this script THERE
+(8 cores); round 5 stages the package for one `gpurun` call (tools/stage_reference.py -> .refstage/, git-ignored) and runs it ON
+THE GPU BOX's host cores with `--ref .refstage --where "gpu box"`.  The JSON output is committed under profiles/; bench.py reads
+the newest one and reports it as the `kind: "reference"` entry of `cpu_baseline` (with where it was measured and the core count)
+next to the `kind: "port"` entry it times live.
 
-    python tools/cpu_reference.py [--rows 65536] [--out profiles/r02_cpu_reference.json]
+    python tools/cpu_reference.py [--rows 65536] [--ref DIR] [--where TEXT] [--out profiles/rNN_cpu_reference.json]
 
-Threads = every core of the container, fp32, no_grad, 1 warm-up + best of 3 wall-clock passes for `log_prob`
-(core.py:182-197 over utils/splines.py:16-219) and for `sample` (core.py:167-180).
+Threads = every core of the container (or the best of a `--threads` sweep), fp32, no_grad, 1 warm-up + best of `--repeats`
+wall-clock passes for `log_prob` (core.py:182-197 over utils/splines.py:16-219) and for `sample` (core.py:167-180); the JSON is
+rewritten after every stage, so a run cut short by a time limit still leaves what it measured.
 """
 import argparse
 import json
@@ -24,7 +27,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, "/root/reference")
 
 
 def cpu_model():
@@ -51,37 +53,66 @@ def main():
     ap.add_argument("--rows", type=int, default=65536)
     ap.add_argument("--repeats", type=int, default=3)
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_cpu_reference.json"))
+    ap.add_argument("--ref", default=os.environ.get("NF_REFERENCE_PATH", "/root/reference"),
+                    help="directory that holds the reference's `normflows/` package")
+    ap.add_argument("--where", default="build container")
+    ap.add_argument("--threads", default="",
+                    help="comma-separated torch thread counts to try (default: every core); the best log_prob rate is reported. "
+                         "On the 256-thread GPU box ALL cores is pathological for the reference's thousands of small ATen ops "
+                         "(round 5: the all-core run did not finish 6 passes in 15 min), hence the sweep")
+    ap.add_argument("--quick", action="store_true", help="skip the per-layer in-bound scan and the sample direction")
     a = ap.parse_args()
+    sys.path.insert(0, os.path.abspath(a.ref))
     import normflows as nf
+    assert os.path.abspath(nf.__file__).startswith(os.path.abspath(a.ref)), (nf.__file__, a.ref)
     from bench import DIM, build_c2_model, c2_inputs
     cores = len(os.sched_getaffinity(0))
-    torch.set_num_threads(cores)
+    tlist = [int(t) for t in a.threads.split(",") if t] or [cores]
     model = build_c2_model(lib=nf)
     x = c2_inputs(a.rows, DIM)
-    res = {"what": "normflows %s (the reference itself, /root/reference) on BASELINE configs[1]: 32 x [CoupledRQS(64, 2, 128, "
+    res = {"what": "normflows %s (the reference itself) on BASELINE configs[1]: 32 x [CoupledRQS(64, 2, 128, "
                    "K=8) + LULinearPermute(64)] + DiagGaussian, fp32, no_grad" % nf.__version__,
-           "where": "build container", "cores": cores, "cpu_model": cpu_model(), "torch": torch.__version__,
-           "torch_threads": torch.get_num_threads(), "rows": a.rows, "repeats": a.repeats}
+           "where": a.where, "host_threads": cores, "cpu_model": cpu_model(), "torch": torch.__version__,
+           "rows": a.rows, "repeats": a.repeats, "sweep": []}
+
+    def dump():
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        json.dump(res, open(a.out, "w"), indent=1)
+
     with torch.no_grad():
-        # in-bound fraction per layer in the density direction (the reference's CPU time is data dependent: only
-        # in-bound elements enter the spline, utils/splines.py:77-80)
-        z, fr = x, []
-        for f in reversed(model.flows):
-            if isinstance(f, nf.flows.CoupledRationalQuadraticSpline):
-                fr.append(float(((z >= -3.0) & (z <= 3.0)).float().mean()))
-            z, _ = f.inverse(z)
-        res["in_bound_fraction_min_over_layers"] = min(fr)
-        model.log_prob(x[:4096])                                     # warm-up
-        t, ts, lp = best_of(lambda: model.log_prob(x), a.repeats)
-        res["log_prob"] = {"best_s": t, "all_s": ts, "samples_per_s": a.rows / t,
-                           "nll_nats_per_dim": float(-lp.mean() / DIM)}
-        torch.manual_seed(1)
-        model.sample(4096)
-        t, ts, (xs, lq) = best_of(lambda: model.sample(a.rows), a.repeats)
-        res["sample"] = {"best_s": t, "all_s": ts, "samples_per_s": a.rows / t,
-                         "in_bound_fraction_of_samples": float(((xs >= -3.0) & (xs <= 3.0)).float().mean())}
-    os.makedirs(os.path.dirname(a.out), exist_ok=True)
-    json.dump(res, open(a.out, "w"), indent=1)
+        if not a.quick:
+            # in-bound fraction per layer in the density direction (the reference's CPU time is data dependent: only
+            # in-bound elements enter the spline, utils/splines.py:77-80)
+            torch.set_num_threads(min(cores, 32))
+            z, fr = x, []
+            for f in reversed(model.flows):
+                if isinstance(f, nf.flows.CoupledRationalQuadraticSpline):
+                    fr.append(float(((z >= -3.0) & (z <= 3.0)).float().mean()))
+                z, _ = f.inverse(z)
+            res["in_bound_fraction_min_over_layers"] = min(fr)
+            dump()
+        best = None
+        for nt in tlist:
+            torch.set_num_threads(nt)
+            model.log_prob(x[:min(4096, a.rows)])                                     # warm-up
+            t, ts, lp = best_of(lambda: model.log_prob(x), a.repeats)
+            ent = {"torch_threads": nt, "best_s": t, "all_s": ts, "samples_per_s": a.rows / t,
+                   "nll_nats_per_dim": float(-lp.mean() / DIM)}
+            res["sweep"].append(ent)
+            if best is None or ent["samples_per_s"] > best["samples_per_s"]:
+                best = ent
+            res["log_prob"] = best
+            res["cores"] = res["torch_threads"] = best["torch_threads"]
+            dump()
+            print(json.dumps(ent), flush=True)
+        if not a.quick:
+            torch.set_num_threads(best["torch_threads"])
+            torch.manual_seed(1)
+            model.sample(min(4096, a.rows))
+            t, ts, (xs, lq) = best_of(lambda: model.sample(a.rows), a.repeats)
+            res["sample"] = {"best_s": t, "all_s": ts, "samples_per_s": a.rows / t,
+                             "in_bound_fraction_of_samples": float(((xs >= -3.0) & (xs <= 3.0)).float().mean())}
+    dump()
     print(json.dumps(res))
 
 
