@@ -332,10 +332,22 @@ def main():
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
+        # the data-path collectives of the timed region are COUNTED (calls, bytes) as they are issued: SURVEY.md 8e allows exactly
+        # one 16-byte all-reduce ([sum log_q, n], fp64) per step; the barriers / the max-over-ranks clock below are not data path
+        coll = {"calls": 0, "bytes": 0}
+        _all_reduce = dist.all_reduce
+
+        def _counted(t_, *a_, **k_):
+            coll["calls"] += 1
+            coll["bytes"] += t_.numel() * t_.element_size()
+            return _all_reduce(t_, *a_, **k_)
+        if world > 1:
+            dist.all_reduce = _counted
         t0 = time.perf_counter()
         for _ in range(args.steps):
             lp, nll_t = step()
         torch.cuda.synchronize()
+        dist.all_reduce = _all_reduce
         barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
@@ -356,7 +368,9 @@ def main():
                                "tail 3) + LULinearPermute(64)] + DiagGaussian, batch %d rows/GPU, N(0,I) inputs, "
                                "sigma=0.01 perturbed seeded weights" % (args.layers, args.batch),
                    "rows_per_gpu": args.batch, "global_rows": world * args.batch, "layers": args.layers,
-                   "launch": "eager" if args.no_graph else "hipGraph replay", "parallelism": "dp%d" % world},
+                   "launch": "eager" if args.no_graph else "hipGraph replay", "parallelism": "dp%d" % world,
+                   "collectives_per_step": coll["calls"] / max(args.steps, 1),
+                   "collective_bytes_per_step": coll["bytes"] / max(args.steps, 1)},
     }
     if rank == 0:
         flops = c2_flops_per_sample(layers=args.layers)

@@ -190,6 +190,121 @@ __device__ __forceinline__ void rqs_regs(const RqsParams<float> &p, float x, con
     lad = inside ? ll : 0.0f;
 }
 
+// ---- round 5: TWO spline elements per call (the fused kernels hand a lane the parameter lists of two features at a time) ----
+// Same arithmetic as rqs_regs, element by element, arranged so that (a) every add / multiply / fused multiply-add works on a
+// (feature 0, feature 1) register pair = one packed instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: gfx950 issues them at
+// the rate of the scalar forms), and (b) the bin is found by a 3-level binary descent that carries the candidate knots, heights and
+// derivative logits along (3 compares + 30 selects per element) instead of a linear scan (19 compares + 49 selects).  Knots are
+// non-decreasing (prefix sums of non-negative terms through a monotone fma), so the descent lands in the bin the scan finds.
+// Compiled stand-alone (tools/ubench/epilogue_count.sh): 558 -> 388 vector instructions per element PAIR (density direction).
+typedef float f32x2e __attribute__((ext_vector_type(2)));
+typedef int i32x2e __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2e pk_fma(f32x2e a, f32x2e b, f32x2e c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2e pk_rcp(f32x2e a) { return f32x2e{frcp(a[0]), frcp(a[1])}; }
+__device__ __forceinline__ f32x2e pk_log(f32x2e a) { return f32x2e{flog(a[0]), flog(a[1])}; }
+__device__ __forceinline__ f32x2e pk_bc(float a) { return f32x2e{a, a}; }
+
+// descent over N bins: s = search knots, o = the other axis' knots, d = padded derivative logits (N + 1 candidates each)
+template <int N>
+__device__ __forceinline__ void rqs_descend2(f32x2e x, const f32x2e (&s)[N + 1], const f32x2e (&o)[N + 1], const f32x2e (&d)[N + 1],
+                                             f32x2e &slo, f32x2e &shi, f32x2e &olo, f32x2e &ohi, f32x2e &dl0, f32x2e &dl1) {
+    if constexpr (N == 1) {
+        slo = s[0]; shi = s[1]; olo = o[0]; ohi = o[1]; dl0 = d[0]; dl1 = d[1];
+    } else {
+        constexpr int H = N / 2;
+        const i32x2e c = x >= s[H];
+        f32x2e s2[H + 1], o2[H + 1], d2[H + 1];
+#pragma unroll
+        for (int i = 0; i <= H; ++i) {
+            s2[i] = c ? s[H + i] : s[i];
+            o2[i] = c ? o[H + i] : o[i];
+            d2[i] = c ? d[H + i] : d[i];
+        }
+        rqs_descend2<H>(x, s2, o2, d2, slo, shi, olo, ohi, dl0, dl1);
+    }
+}
+
+template <bool INVERSE>
+__device__ __forceinline__ void rqs_eval_bin_fast2(f32x2e x, f32x2e cw, f32x2e bw, f32x2e ch, f32x2e bh, f32x2e d0, f32x2e d1,
+                                                   f32x2e &y, f32x2e &lad) {
+    const f32x2e delta = bh * pk_rcp(bw);
+    const f32x2e dsum = d0 + d1 - 2.0f * delta;
+    f32x2e theta, den;
+    if (!INVERSE) {
+        theta = (x - cw) * pk_rcp(bw);
+        const f32x2e t1mt = theta * (1.0f - theta);
+        const f32x2e num = bh * (delta * theta * theta + d0 * t1mt);
+        den = delta + dsum * t1mt;
+        y = ch + num * pk_rcp(den);
+    } else {
+        const f32x2e dy = x - ch;
+        const f32x2e a = dy * dsum + bh * (delta - d0);
+        const f32x2e b = bh * d0 - dy * dsum;
+        const f32x2e c = -delta * dy;
+        const f32x2e disc = b * b - 4.0f * a * c;
+        theta = (2.0f * c) * pk_rcp(-b - f32x2e{fsqrt(disc[0]), fsqrt(disc[1])});
+        y = theta * bw + cw;
+        den = delta + dsum * (theta * (1.0f - theta));
+    }
+    const f32x2e omt = 1.0f - theta;
+    const f32x2e dnum = delta * delta * (d1 * theta * theta + 2.0f * delta * (theta * omt) + d0 * omt * omt);
+    const f32x2e l = pk_log(dnum) - 2.0f * pk_log(den);
+    lad = INVERSE ? -l : l;
+}
+
+// elements (x0, prm0) and (x1, prm1); prm as in rqs_regs.  KB a power of two.
+template <bool INVERSE, int KB = F_K>
+__device__ __forceinline__ void rqs_regs2(const RqsParams<float> &p, float x0, float x1, const float (&prm0)[3 * KB],
+                                          const float (&prm1)[3 * KB], float &y0, float &y1, float &lad0, float &lad1) {
+    static_assert((KB & (KB - 1)) == 0, "binary descent");
+    const f32x2e x = {x0, x1};
+    const i32x2e inside = (x >= p.left) & (x <= p.right);          // false for NaN (utils/splines.py:28)
+    f32x2e mw = {prm0[0], prm1[0]}, mh = {prm0[KB], prm1[KB]};
+#pragma unroll
+    for (int k = 1; k < KB; ++k) {
+        mw = f32x2e{fmaxf(mw[0], prm0[k]), fmaxf(mw[1], prm1[k])};
+        mh = f32x2e{fmaxf(mh[0], prm0[KB + k]), fmaxf(mh[1], prm1[KB + k])};
+    }
+    f32x2e pw[KB], ph[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+        const f32x2e aw = f32x2e{prm0[k], prm1[k]} - mw, ah = f32x2e{prm0[KB + k], prm1[KB + k]} - mh;
+        const f32x2e ew = {__builtin_amdgcn_exp2f(aw[0]), __builtin_amdgcn_exp2f(aw[1])};
+        const f32x2e eh = {__builtin_amdgcn_exp2f(ah[0]), __builtin_amdgcn_exp2f(ah[1])};
+        pw[k] = k == 0 ? ew : pw[k - 1] + ew;
+        ph[k] = k == 0 ? eh : ph[k - 1] + eh;
+    }
+    const f32x2e cw = ((p.right - p.left) * p.scale_w) * pk_rcp(pw[KB - 1]);
+    const f32x2e ch = ((p.top - p.bottom) * p.scale_h) * pk_rcp(ph[KB - 1]);
+    f32x2e kw[KB + 1], kh[KB + 1], dp[KB + 1];
+    kw[0] = pk_bc(p.left);
+    kh[0] = pk_bc(p.bottom);
+    kw[KB] = pk_bc(p.right);
+    kh[KB] = pk_bc(p.top);
+    dp[0] = dp[KB] = pk_bc(p.edge_logit);
+#pragma unroll
+    for (int k = 1; k < KB; ++k) {
+        kw[k] = pk_fma(pw[k - 1], cw, pk_bc(p.left + (p.right - p.left) * p.min_w * (float)k));
+        kh[k] = pk_fma(ph[k - 1], ch, pk_bc(p.bottom + (p.top - p.bottom) * p.min_h * (float)k));
+        dp[k] = f32x2e{prm0[2 * KB + k - 1], prm1[2 * KB + k - 1]};
+    }
+    f32x2e slo, shi, olo, ohi, dl0, dl1;
+    if (!INVERSE)
+        rqs_descend2<KB>(x, kw, kh, dp, slo, shi, olo, ohi, dl0, dl1);
+    else
+        rqs_descend2<KB>(x, kh, kw, dp, slo, shi, olo, ohi, dl0, dl1);
+    const f32x2e d0 = p.min_d + f32x2e{fsoftplus(dl0[0]), fsoftplus(dl0[1])};
+    const f32x2e d1 = p.min_d + f32x2e{fsoftplus(dl1[0]), fsoftplus(dl1[1])};
+    f32x2e yy, ll;
+    if (!INVERSE)
+        rqs_eval_bin_fast2<false>(x, slo, shi - slo, olo, ohi - olo, d0, d1, yy, ll);
+    else
+        rqs_eval_bin_fast2<true>(x, olo, ohi - olo, slo, shi - slo, d0, d1, yy, ll);
+    const f32x2e yr = inside ? yy : x;       // linear tails: identity outside, also for NaN / +-inf (utils/splines.py:40-41)
+    const f32x2e lr = inside ? ll : pk_bc(0.0f);
+    y0 = yr[0]; y1 = yr[1]; lad0 = lr[0]; lad1 = lr[1];
+}
+
 // Batch-shared spline from its LDS knot table (cumw[9] | cumh[9] | deriv[9]), branch-free.
 template <bool INVERSE, int KB = F_K>
 __device__ __forceinline__ void rqs_table_fast(const RqsParams<float> &p, float x, const float *tab, float &y, float &lad) {

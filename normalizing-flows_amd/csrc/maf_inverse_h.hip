@@ -33,7 +33,10 @@ constexpr int HNW = NF_MAF_HNW;    // waves per workgroup (ablation, round 4, co
 constexpr int H_HDR = 8, H_ENT = 24;
 // floats of a tile record after the A operands, NL = 1 + 2 num_blocks hidden layers: bias[NL][32] | biasF | W0d[32][16] | Wd[NL-1] | WFd
 constexpr int h_seq(int NL) { return NL * HT + HT + HT * HS + (NL - 1) * HT * HT + HT * HT; }
-constexpr int h_lb(bool fast) { return fast ? 8 : 4; }     // activation slots of a wave's ring; + 4 + 4 weight slots of 1 KB
+#ifndef NF_MAF_LB
+#define NF_MAF_LB 4     // round 5, same gpurun call: 8 activation slots 11.74 ms, 4 slots 11.14 ms (config 5; tools/maf_ablate5.py)
+#endif
+constexpr int h_lb(bool fast) { return fast ? NF_MAF_LB : 4; }     // activation slots of a wave's ring; + 4 + 4 weight slots of 1 KB
 
 #define HMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -73,6 +76,9 @@ __device__ __forceinline__ void h_block(const float *__restrict__ A, const float
         constexpr int LPS = PAIR ? 2 : 1;
         const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ring);
         auto dma1 = [&](uint32_t dst, const float *src) {
+#ifdef NF_MAF_ABL_NO_DMA
+            return;
+#endif
             // (m0 is a reserved register: the compiler does not honour it as a clobber, so it is saved and restored here)
             uint32_t m0_;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
@@ -110,11 +116,15 @@ __device__ __forceinline__ void h_block(const float *__restrict__ A, const float
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slots' reads have returned: they may be requested again
             req_b(kb + LB);
             req_a(kb + 4, slot);
+#ifndef NF_MAF_ABL_NO_MFMA       // (ablation builds, tools/maf_ablate5.py: timing only, results are garbage)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 c0 = HMFMA(a[i], b[i], c0);
                 if constexpr (PAIR) c2 = HMFMA(a2[i], b[i], c2);
             }
+#else
+            c0[0] += a[0] * b[0] + a2[1];
+#endif
         };
         // prologue: the first LB - 4 activation blocks, then pseudo-steps -4 .. -1 in the steps' own order (nkb is a multiple of 4)
 #pragma unroll
@@ -280,7 +290,7 @@ __device__ __forceinline__ void h_static_for(F &&f) {
 // anyway, the carry is the last feature written to y, and the log-determinant is accumulated launch by launch.  (One kernel holding
 // both sequential parts needed more than 256 registers: 56 spilled.)
 template <int NB, bool FAST>
-__global__ void __launch_bounds__(64 * HNW, (NB <= 2 && HNW <= 4) ? 2 : 1)
+__global__ void __launch_bounds__(64 * HNW, (NB <= 2 && HNW <= 4) ? 8 / HNW : 1)
 maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *__restrict__ logdet, const float *__restrict__ blob,
                      const int *__restrict__ table, float *S, float *Xs, float *Ps, int64_t B, int acc, int t_beg, int t_end) {
     constexpr int NL = 1 + 2 * NB, H_SEQ = FAST ? hf_seq(NL) : h_seq(NL), LB = h_lb(FAST);
@@ -350,7 +360,11 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
         {
             // tile pairing: even tile = its own products + the next tile's over the same operands (raw accumulators to the
             // stash); odd tile = the stash + the 32 units of its partner
+#ifdef NF_MAF_ABL_NO_PAIR
+            const int mode = 0;
+#else
             const int mode = !Pw ? 0 : ((t & 1) ? 2 : (t + 1 < T ? 1 : 0));
+#endif
             const float *Ah2 = Ah;
             int Kh2 = 0;
             if (mode == 1) {
@@ -382,7 +396,11 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
                 constexpr int G = decltype(G_)::value;
                 if (G < ns) {
                     float xn;
+#ifndef NF_MAF_ABL_NO_SEQ
                     hf_step<NB, G>(p, pF, xg, wh, zin[G], ld, xn);
+#else
+                    xn = zin[G] + p[0][G] + pF[G] + wh[G][0];
+#endif
                     xcarry = xn;
                     const int f = dlo + G;
                     if (hh == 0) {

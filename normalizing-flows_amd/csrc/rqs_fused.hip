@@ -682,6 +682,24 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
         st[slot * 64] = yt;
         ld += l;
     };
+    // both elements of a group at once on packed arithmetic + the binary bin descent (fused_common.hpp rqs_regs2, round 5);
+    // -DNF_EPI_SCALAR = the element-by-element evaluation of rounds 1-4 (ablation)
+    auto element_pair = [&](int g) {
+#if defined(NF_ABL_NOEPI) || defined(NF_EPI_SCALAR)
+        element(g, 0);
+        element(g, 1);
+#else
+        if constexpr (FPL == 2) {
+            const int s0 = 8 * (g / GQ) + 2 * ((g % GQ) * FPL) + par_t, s1 = s0 + 2;
+            float y0, y1, l0, l1;
+            rqs_regs2<DIR == 1, KB>(p, st[s0 * 64], st[s1 * 64], prm[0], prm[FPL - 1], y0, y1, l0, l1);
+            st[s0 * 64] = y0;
+            st[s1 * 64] = y1;
+            ld += l0;
+            ld += l1;
+        }
+#endif
+    };
     auto uncond_group = [&](int g) {  // density only: the FPL identity slots of chunk Q = g / GQ that go with this group
 #ifdef NF_ABL_NOUNCOND
         return;
@@ -806,8 +824,12 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
             }
 #endif
         }
+        if constexpr (FPL == 2 && TRAIN != 2) {      // (the training forward's row stores leave no registers for the pair: 4 spills)
+            element_pair(g);
+        } else {
 #pragma unroll
-        for (int f = 0; f < FPL; ++f) element(g, f);
+            for (int f = 0; f < FPL; ++f) element(g, f);
+        }
         if (DIR == 0) uncond_group(g);
     }
 #endif

@@ -69,3 +69,24 @@ def test_bench_launches_its_own_ranks():
     assert d["n_gpus"] == 2 and d["config"]["global_rows"] == 16384 and d["config"]["parallelism"] == "dp2"
     assert abs(d["value"] - 2 * 8192 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert "cpu_baseline" in d and abs(d["nll_nats_per_dim"] - 1.5416) < 2e-2
+
+
+def test_bench_eight_ranks_contract_on_one_device():
+    """BASELINE configs[2]'s launch shape -- `python bench.py --gpus 8`, 65 536 rows per rank = 524 288 rows -- with the eight
+    ranks sharing cuda:0 over gloo (NF_BENCH_ONE_DEVICE=1; the real run is one rank per GPU over RCCL, which cannot be started
+    from a 1-GPU box: the line below is a CONTRACT check, its `value` is not a measurement of 8 GPUs).  n_gpus, the global row
+    count, weak scaling, and exactly ONE 16-byte data-path collective per step."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(NF_BENCH_ONE_DEVICE="1", OMP_NUM_THREADS="4")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                          "--no-breakdown", "--no-secondary", "--cpu-rows", "1024"],
+                         capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2500:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp8"
+    assert d["config"]["rows_per_gpu"] == 65536 and d["config"]["global_rows"] == 524288
+    assert d["config"]["collectives_per_step"] == 1 and d["config"]["collective_bytes_per_step"] == 16
+    assert abs(d["value"] - 524288 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert abs(d["nll_nats_per_dim"] - 1.5416) < 5e-3

@@ -697,9 +697,11 @@ def test_model_c2_full_size_properties(nfa, oracle):
     assert torch.equal(lp, lp2)                                        # deterministic
     assert torch.isfinite(lp).all()
     ora = oracle.OracleNSF(state_to_numpy(m), num_layers=len(m.flows))
-    sl = slice(1000, 1256)
-    ref = ora.log_prob(N(x[sl]))
-    assert _rel(N(lp[sl]), ref) < 1e-4
+    # every benchmark row against the CPU oracle on a many-core host (the GPU box: 256 threads, ~3 s through the OpenMP entry
+    # point), 8 192 rows elsewhere (round 4 checked 256)
+    rows = 65536 if (os.cpu_count() or 1) >= 64 else 8192
+    ref = ora.log_prob_whole(N(x[:rows]))
+    assert ref.shape == (rows,) and _rel(N(lp[:rows]), ref) < 1e-4, _rel(N(lp[:rows]), ref)
     nll = float(-lp.mean() / 64)
     assert 1.3 < nll < 1.8, nll                                        # reference: 1.5415 nats/dim
     g = torch.Generator().manual_seed(5)

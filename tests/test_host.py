@@ -370,7 +370,42 @@ for step in range(2):
     assert len(avg._pending) == len(avg.buckets)                                  # every bucket was started DURING backward
     assert avg.finish() == len(avg.buckets)
     assert all(torch.allclose(p.grad, r_, atol=1e-6) for p, r_ in zip(net2.parameters(), ref))
+# contract (ADVICE r04): a second backward before finish() raises instead of averaging stale buckets ...
+net2.zero_grad(set_to_none=True)
+net2(xg).pow(2).sum().backward()
+try:
+    net2(xg).pow(2).sum().backward()
+    raise SystemExit("a second backward() before finish() must raise")
+except RuntimeError as e:
+    assert "finish()" in str(e), e
+avg.finish()
+# ... gradient accumulation goes through no_sync(): two micro-batches, the first without collectives
+net2.zero_grad(set_to_none=True)
+with avg.no_sync():
+    net2(xg[:4]).pow(2).sum().backward()
+    assert not avg._pending and avg._next == 0
+net2(xg[4:]).pow(2).sum().backward()
+assert avg.finish() == len(avg.buckets)
+assert all(torch.allclose(p.grad, r_, atol=1e-5) for p, r_ in zip(net2.parameters(), ref)), "accumulated == full batch (sum loss)"
 avg.remove()
+# ... and a parameter that is unused on ONE rank only: same sequence of equally sized collectives on both ranks (no hang); the
+# rank without a gradient gets nothing written, the other the average with zeros
+heads = torch.nn.ModuleDict({"a": torch.nn.Linear(4, 3), "b": torch.nn.Linear(4, 3)})
+for p in heads.parameters():
+    torch.nn.init.constant_(p, 0.5)
+avg3 = nfa.dp.OverlappedGradientAverager(heads.parameters(), bucket_bytes=16)
+xh = torch.ones(2, 4)
+loss = heads["a"](xh).sum() * (rank + 1)
+if rank == 0:
+    loss = loss + heads["b"](xh).sum()
+loss.backward()
+assert avg3.finish() == len(avg3.buckets)
+assert torch.allclose(heads["a"].bias.grad, torch.full((3,), 2.0 * (1 + world) / 2.0))
+if rank == 0:
+    assert torch.allclose(heads["b"].bias.grad, torch.full((3,), 2.0 / world))
+else:
+    assert heads["b"].bias.grad is None
+avg3.remove()
 net.zero_grad(set_to_none=True)                                                   # a dropped view is re-attached
 fg.zero()
 assert all(p.grad is v for p, v in fg.views)
@@ -385,6 +420,66 @@ if rank == 0:
     print("DP_OK", float(nll))
 dist.destroy_process_group()
 """
+
+
+_DP8_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["NF_ROOT"])
+import torch, torch.distributed as dist
+import normflows_amd as nfa
+from bench import build_c2_model
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+assert world == 8
+# BASELINE configs[2]'s row count + 3: uneven shards (three ranks hold one row more); the count travels with the sum
+N = 524288 + 3
+lo, hi = nfa.dp.shard_bounds(N, world, rank)
+assert hi - lo == 65536 + (1 if rank < 3 else 0)
+g = torch.Generator().manual_seed(7)
+x = torch.randn(N, 4, generator=g)                               # the same global batch on every rank
+log_prob = lambda t: -0.5 * (t.double() ** 2).sum(1) - 3.0       # stand-in for the HIP log_prob: the test is the sharding
+calls = []
+real = dist.all_reduce
+def counted(t, *a, **k):
+    calls.append(t.numel() * t.element_size())
+    return real(t, *a, **k)
+dist.all_reduce = counted
+nll = nfa.dp.sharded_forward_kld(log_prob, nfa.dp.shard_rows(x))
+dist.all_reduce = real
+assert calls == [16], calls                                       # ONE 16-byte collective per evaluated batch
+full = -log_prob(x).mean()
+assert abs(float(nll) - float(full)) < 1e-9 * abs(float(full)), (float(nll), float(full))
+# the REAL configs[1] parameter list (5 443 584 floats = 21.8 MB) through the overlapped averager with 8 MB buckets
+m = build_c2_model()
+params = list(m.parameters())
+assert sum(p.numel() for p in params) == 5443584
+avg = nfa.dp.OverlappedGradientAverager(params, bucket_bytes=8 << 20)
+assert 3 <= len(avg.buckets) <= 4 and all(sum(q.numel() for q in b) * 4 <= (8 << 20) for b in avg.buckets)
+loss = sum((p * float(rank + 1)).sum() for p in params)
+loss.backward()
+assert len(avg._pending) == len(avg.buckets)                      # every bucket's all-reduce started during backward
+assert [i for i, _, _ in avg._pending] == list(range(len(avg.buckets)))   # ... in index order
+assert avg.finish() == len(avg.buckets)
+want = (1 + world) / 2.0
+assert all(bool((p.grad == want).all()) for p in params)
+if rank == 0:
+    print("DP8_OK", float(nll), len(avg.buckets))
+dist.destroy_process_group()
+"""
+
+
+def test_dp_world_size_8_uneven_shards_and_real_parameter_list(nfa, tmp_path):
+    """Readiness for the 8-GPU run nobody can launch from here: world size 8 over gloo -- 524 288 + 3 rows in
+    uneven shards give the unsharded NLL with ONE 16-byte all-reduce; the benchmark model's real parameter list (5.4 M floats)
+    goes through OverlappedGradientAverager's 8 MB buckets, every collective started during backward, in index order."""
+    script = tmp_path / "dp8_worker.py"
+    script.write_text(_DP8_WORKER)
+    env = dict(os.environ, NF_ROOT=ROOT, OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                          "--master-addr", "127.0.0.1", "--master-port", "29677", str(script)], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "DP8_OK" in out.stdout
 
 
 def test_dp_nll_matches_unsharded_under_gloo(nfa, tmp_path):
