@@ -66,6 +66,14 @@ int nf_rqs_spline(const void *x, const void *w, int64_t ldw, const void *h, int6
                   double left, double right, double bottom, double top, double min_bin_width,
                   double min_bin_height, double min_derivative, double wh_div, int inverse, int dtype,
                   nf_stream_t stream);
+/* Debug mode of the element-wise spline: the reference's run-time failures on this path as device-side flags, checked
+ * by a SEPARATE launch over one call's inputs x and outputs y -- the transform kernels stay branch-free and never synchronise.
+ * ORs into *flags (a device uint32 the caller zeroed): bit 0 = an input outside the domain with tails = NF_TAILS_NONE (the
+ * reference's gathers fail on bin index -1 / K there, utils/splines.py:154-160; the kernels clamp the bin), bit 1 = inverse
+ * direction, an in-domain input whose output is NaN, i.e. the square root of a negative discriminant (`assert (discriminant >= 0)`,
+ * utils/splines.py:181).  The shim launches it and reads the word back only under normflows_amd.config.set_debug_checks(True). */
+int nf_rqs_spline_check(const void *x, const void *y, int64_t N, int tails, double tail_bound, double left, double right,
+                        double bottom, double top, int inverse, int dtype, void *flags, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * NSF coupling transform on (B, D) rows with conditioner outputs materialised in HBM.

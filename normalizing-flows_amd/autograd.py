@@ -830,6 +830,8 @@ class ConvNetFn(torch.autograd.Function):
         gcol, G = ops.made_backward(gP, bits, bwd["blob"], bwd["table"], 9 * Cin, bwd["Hp"], 1, rows=R, out_features=9 * Cout,
                                     ld_out=bwd["Dx"])
         gx = ops.conv3x3_gather_sum(gcol, None, (B, Cin, H, W), flip=True) if ctx.needs_input_grad[2] else None
+        if not any(ctx.needs_input_grad[3:]):        # frozen conditioner: no weight-gradient launch
+            return (None, None, gx) + (None,) * 6
         flat = ops.made_wgrad(gP, col, G, save, bwd["wtable"], bwd["stable"], bwd["mask"], bwd["ntiles"], bwd["nflat"], bwd["Mp"],
                               bwd["Dx"], rows=R)
         (o0, s0, c0, n0), (o1, s1, c1, n1), (o2, s2, _, _) = bwd["offsets"]
@@ -878,12 +880,18 @@ class MafInverseFn(torch.autograd.Function):
         changed = torch.zeros(1, dtype=torch.int32, device=x.device)
         rtol = _config.maf_implicit_rtol
         gxm, sweeps = None, 0
+        # Under stream capture (a whole training step recorded into one hipGraph) nothing may be read back: the sweep count is
+        # then FIXED at its exact bound D (J^T is strictly triangular: D sweeps are exact whatever the data) -- slower than the
+        # early exit, but capturable and host-synchronisation free (autograd.py:890).
+        capturing = torch.cuda.is_current_stream_capturing()
         # sweep 0 = the start value v = g_x / scale; then one element-wise launch (update of v, the next cotangent g_p, "did v move?")
         # and one chain per sweep; the flag is read back every other sweep (a read is a host synchronisation)
         while sweeps <= D:
-            v_prev = v.clone() if rtol > 0.0 and sweeps > 0 else None
+            v_prev = v.clone() if rtol > 0.0 and sweeps > 0 and not capturing else None
             ops.maf_implicit_sweep(x, p, gx, gld, gxm, v, gp, changed)
-            if sweeps > 0 and (sweeps % 2 == 0 or sweeps == D):
+            if capturing:
+                pass
+            elif sweeps > 0 and (sweeps % 2 == 0 or sweeps == D):
                 if rtol > 0.0:
                     done = bool((v - v_prev).abs().max() <= rtol * v.abs().max())
                 else:
@@ -895,7 +903,7 @@ class MafInverseFn(torch.autograd.Function):
                 changed.zero_()          # (only the latest sweep's verdict counts)
             gxm, _ = ops.made_backward(gp, bits, bwd["blob"], bwd["table"], D, bwd["Hp"], bwd["NB"], want_G=False)
             sweeps += 1
-        MafInverseFn.last_sweeps = sweeps
+        MafInverseFn.last_sweeps = sweeps        # (debug / bench read-out only; not used by any computation)
         _, gp = ops.maf_affine_bwd(x, p, -v, -gld, 0)
         grads = [None] * ctx.nparams
         if any(ctx.needs_input_grad[4:]):

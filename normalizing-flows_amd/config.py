@@ -171,3 +171,16 @@ nsf_wide = True
 def set_nsf_wide(mode=True):
     global nsf_wide
     nsf_wide = bool(mode)
+
+
+# Debug mode of the element-wise spline API (utils.splines): after every call a check launch (nf_rqs_spline_check)
+# sets device-side flags and the shim reads them back -- a host synchronisation per call, which is why it is off by default -- and
+# raises what the reference raises: AssertionError for a negative discriminant in the inverse direction (utils/splines.py:181),
+# RuntimeError for tails=None inputs outside the domain (the reference's gather index error, utils/splines.py:154-160; without
+# debug mode the kernels clamp the bin).
+debug_checks = False
+
+
+def set_debug_checks(mode=True):
+    global debug_checks
+    debug_checks = bool(mode)

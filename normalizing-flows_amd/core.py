@@ -281,7 +281,7 @@ class _GraphCache:
     def __init__(self, owner=None):
         self.enabled = False
         self.graphs = {}
-        self.epoch = _keys.epoch()
+        self.stamp, self.sig = _keys.stamp(), None
         self.owner = None if owner is None else __import__("weakref").ref(owner)
 
     def clear(self):
@@ -290,8 +290,15 @@ class _GraphCache:
     def run(self, key, fn, *inputs):
         if not self.enabled:
             return fn(*inputs)
-        if self.epoch != _keys.epoch():       # an optimizer stepped since the capture: the graphs hold the old packed weights
-            self.graphs, self.epoch = {}, _keys.epoch()
+        if self.sig is None or self.stamp != _keys.stamp():
+            # some optimizer stepped (or caches were invalidated) since we last looked: were OUR parameters among the updated ones?
+            # Then the graphs hold the old packed weights.  (A step of another model's optimizer costs this one scan, not a
+            # re-capture: ADVICE r04.)
+            owner = self.owner() if self.owner is not None else None
+            sig = _keys.signature(owner.parameters()) if owner is not None else _keys.stamp()
+            if self.sig is not None and sig != self.sig:
+                self.graphs = {}
+            self.sig, self.stamp = sig, _keys.stamp()
         entry = self.graphs.get(key)
         if entry is None:
             static_in = [t.clone() for t in inputs]

@@ -738,6 +738,49 @@ extern "C" int nf_rqs_spline(const void *x, const void *w, int64_t ldw, const vo
     return NF_OK;
 }
 
+// ---- debug mode: the reference's run-time failures of this path as DEVICE-SIDE flags ----
+// utils/splines.py:181 `assert (discriminant >= 0).all()` (inverse direction) and the index error of the gathers behind
+// utils/splines.py:154-160 when `tails=None` inputs lie outside the domain (bin index -1 or K).  The transform kernels stay
+// branch-free and never synchronise; in debug mode (normflows_amd.config.set_debug_checks) the shim launches this check over
+// the call's inputs and outputs and reads the flag word back -- the only host synchronisation, and only in that mode.
+//   bit 0: an input outside [lo, hi] with tails=None (NaN counts as outside: the reference's count-based search gives bin -1)
+//   bit 1: inverse direction, a non-NaN input inside the domain whose output is NaN: sqrt of a negative (or NaN) discriminant
+template <typename T>
+__global__ void rqs_debug_check_kernel(const T *__restrict__ x, const T *__restrict__ y, int64_t N, T lo, T hi, int bounded,
+                                       int inverse, unsigned int *flags) {
+    unsigned int f = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const T xi = x[i];
+        const bool in = xi >= lo && xi <= hi;
+        if (bounded && !in) f |= 1u;
+        if (inverse && in && y[i] != y[i]) f |= 2u;
+    }
+    if (f) atomicOr(flags, f);
+}
+
+extern "C" int nf_rqs_spline_check(const void *x, const void *y, int64_t N, int tails, double tail_bound, double left, double right,
+                                   double bottom, double top, int inverse, int dtype, void *flags, nf_stream_t stream) {
+    if (N < 0) return NF_EINVAL;
+    if (tails != NF_TAILS_NONE && tails != NF_TAILS_LINEAR && tails != NF_TAILS_CIRCULAR) return NF_EINVAL;
+    if (N == 0) return NF_OK;
+    if (!x || !y || !flags) return NF_EFAULT;
+    const int bounded = tails == NF_TAILS_NONE;
+    double lo = inverse ? bottom : left, hi = inverse ? top : right;
+    if (!bounded) { lo = -tail_bound; hi = tail_bound; }
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_for(N, 256);
+    if (dtype == NF_F32)
+        hipLaunchKernelGGL(rqs_debug_check_kernel<float>, dim3(grid), dim3(256), 0, st, (const float *)x, (const float *)y, N, (float)lo,
+                           (float)hi, bounded, inverse, (unsigned int *)flags);
+    else if (dtype == NF_F64)
+        hipLaunchKernelGGL(rqs_debug_check_kernel<double>, dim3(grid), dim3(256), 0, st, (const double *)x, (const double *)y, N, lo, hi,
+                           bounded, inverse, (unsigned int *)flags);
+    else
+        return NF_ENOTSUP;
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
 extern "C" int nf_rqs_coupling(const void *x, void *y, void *logdet, const void *cond, const void *uw, const void *uh,
                                const void *ud, const int64_t *identity_idx, int nI, const int64_t *transform_idx,
                                int nT, int64_t B, int D, int K, int tails, double tail_bound, double min_bin_width,

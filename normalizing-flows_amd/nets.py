@@ -287,7 +287,10 @@ class ConvNet2d(nn.Module):
                 from . import ops
                 return ops.glow_convnet(x, fused[0], self.net[-1].out_channels, self.net[1].negative_slope, fused[1])
             return self._forward_inference(x)
-        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4:
+        from . import autograd
+        # (only when a gradient is actually wanted -- a grad-enabled call on frozen weights and a plain input takes the
+        # library path instead of a Function whose backward would never run)
+        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and autograd.needs_grad(x, *self.parameters()):
             packs = self._train_packs(x.device)
             if packs is not None:
                 from . import autograd
@@ -311,6 +314,7 @@ class ConvNet2d(nn.Module):
         if a1.negative_slope != 0.0 or a2.negative_slope != 0.0 or c1.weight.dtype != torch.float32:
             return None
         if any(c.padding != (k // 2, k // 2) or c.stride != (1, 1) or c.dilation != (1, 1) or c.groups != 1
+               or c.padding_mode != "zeros"          # (the gather kernels pad with zeros)
                for c, k in ((c1, 3), (c2, 1), (c3, 3))):
             return None
         hid, cin, cout = c1.out_channels, c1.in_channels, c3.out_channels

@@ -42,6 +42,18 @@ def rqs_spline(x, w, h, d, inverse=False, tails="linear", tail_bound=1.0, left=0
                                f64(bottom), f64(top), f64(min_bin_width), f64(min_bin_height), f64(min_derivative),
                                f64(wh_div), i32(int(inverse)), i32(L.dtype_code(x)), L.stream())
     L.check(rc, "nf_rqs_spline")
+    from . import config
+    if config.debug_checks and N > 0:      # device-side flags, read back only in debug mode (config.set_debug_checks)
+        flags = torch.zeros(1, dtype=torch.int32, device=x.device)
+        rc = L.lib().nf_rqs_spline_check(ptr_any(xs), ptr_any(y), i64(N), i32(L.TAILS[tails]), f64(tail_bound), f64(left), f64(right),
+                                         f64(bottom), f64(top), i32(int(inverse)), i32(L.dtype_code(x)), ptr_any(flags), L.stream())
+        L.check(rc, "nf_rqs_spline_check")
+        f = int(flags.item())
+        if f & 1:
+            raise RuntimeError("rational_quadratic_spline: input outside the domain with tails=None (the reference's gather fails on "
+                               "bin index -1 / K, utils/splines.py:154-160)")
+        if f & 2:
+            raise AssertionError("rational_quadratic_spline: negative discriminant in the inverse direction (utils/splines.py:181)")
     return y.view(x.shape), lad.view(x.shape)
 
 

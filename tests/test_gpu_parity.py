@@ -2307,3 +2307,37 @@ def test_lu_linear_permute_wide_dense_path(nfa, oracle, D, B):
         layer.linear.bias.add_(1.0)
     z3, _ = layer.inverse(x)
     assert_close(N(z3), N(z) + 1.0, what="bias update", rtol=1e-5, atol=1e-5)
+
+
+def test_spline_debug_mode_device_flags(nfa):
+    """the reference's run-time failures of utils/splines.py as device-side flags read back ONLY in debug mode --
+    tails=None inputs outside the domain (the reference's gathers raise on bin index -1 / K, :154-160; our kernels clamp) and
+    `assert (discriminant >= 0).all()` (:181; a NaN parameter row makes the discriminant NaN, which fails the reference's assert
+    and is the only way to fail it in exact arithmetic).  Off by default: the same calls return without a host synchronisation."""
+    from normflows_amd.utils import splines
+    torch.manual_seed(3)
+    K, n = 8, 257
+    w, h, d = (torch.randn(n, K, device=DEV), torch.randn(n, K, device=DEV), torch.randn(n, K + 1, device=DEV))
+    x = torch.rand(n, device=DEV)
+    y, lad = splines.rational_quadratic_spline(x, w, h, d)                    # clean call
+    xo = x.clone()
+    xo[5] = 1.5
+    yo, _ = splines.rational_quadratic_spline(xo, w, h, d)                    # default mode: clamped, no exception
+    assert torch.isfinite(yo).all()
+    wn = w.clone()
+    wn[7, 2] = float("nan")
+    nfa.config.set_debug_checks(True)
+    try:
+        y2, lad2 = splines.rational_quadratic_spline(x, w, h, d)
+        assert torch.equal(y2, y) and torch.equal(lad2, lad)                  # clean input: same results, no exception
+        xi, _ = splines.rational_quadratic_spline(y, w, h, d, inverse=True)
+        assert_close(N(xi), N(x), what="round trip", rtol=1e-4, atol=1e-5)
+        with pytest.raises(RuntimeError, match="outside the domain"):
+            splines.rational_quadratic_spline(xo, w, h, d)
+        with pytest.raises(AssertionError, match="discriminant"):
+            splines.rational_quadratic_spline(y, wn, h, d, inverse=True)
+        # linear tails: outside inputs are the identity, not an error
+        z, _ = splines.unconstrained_rational_quadratic_spline(4.0 * torch.randn(n, device=DEV), w, h, d[:, :K - 1], tail_bound=1.0)
+        assert torch.isfinite(z).all()
+    finally:
+        nfa.config.set_debug_checks(False)

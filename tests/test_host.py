@@ -979,6 +979,17 @@ def test_cache_keys_follow_fused_optimizer_steps():
     with torch.no_grad():
         p.add_(1.0)
     assert _keys.pkey([p]) != k1
+    # ... and ONLY the stepped optimizer's parameters go stale: a frozen model in the same process keeps its packs
+    # and its recorded graphs through another model's training steps
+    q = torch.nn.Parameter(torch.randn(4))              # e.g. a teacher / EMA model's weight
+    kq, sq, st = _keys.pkey([q]), _keys.signature([q]), _keys.stamp()
+    kp = _keys.pkey([p])
+    opt.step()
+    assert _keys.stamp() != st                          # holders of derived state take a look ...
+    assert _keys.pkey([q]) == kq and _keys.signature([q]) == sq      # ... and find the frozen tensor untouched
+    assert _keys.pkey([p]) != kp
+    _keys.bump()                                        # invalidate_caches(): everything
+    assert _keys.pkey([q]) != kq and _keys.signature([q]) != sq
 
 
 def test_wide_resnet_training_path_rechecks_mode_dependent_eligibility():
