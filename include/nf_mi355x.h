@@ -611,6 +611,25 @@ int nf_maf_inverse_h_tri(const void *z, void *y, void *logdet, const void *blob,
                          void *scratch, int64_t B, int D, int hidden_padded, int num_blocks, int acc, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The implicit backward of the MAF inverse in ONE pass (round 5; autograd.MafInverseFn).  The reference differentiates
+ * MaskedAffineAutoregressive.inverse by recording its D sequential MADE passes (affine/autoregressive.py:29-38 under
+ * core.py:87-102 `forward_kld` + backward).  x = T^-1(z) satisfies T(x) = z, so the cotangents solve the LINEAR system
+ * v s + J^T g_p(v, g_ld) = g_x (J = dMADE/dx at x; g_p = the affine transform's parameter cotangent); J^T is strictly triangular in
+ * the feature order and MADE's input-gradient chain has, with features and degrees counted from the top, exactly the structure the
+ * incremental inverse walks: nf_maf_solve_t back-substitutes it in one launch per layer (round 4: 15-25 sweeps of nf_made_backward
+ * with a host read-back every other sweep).
+ *   nf_maf_inverse_h_bits : nf_maf_inverse_h (format-0 pack) that also writes the ReLU masks of the pass: ceil(B / 32) * table[4] * 64 *
+ *                           num_blocks uint32.
+ *   nf_maf_solve_t        : x (B, D) the inverse's result, prm (B, 2 D) = MADE(x) (nf_made_forward_train), gx (B, D), gld (B) or NULL
+ *                           -> v (B, D); blob / table from maf_pack.pack_made_transposed (format 2: table[7] == 2);
+ *                           scratch: nf_maf_solve_t_scratch_floats floats, contents need not be initialised.  float32. */
+int nf_maf_inverse_h_bits(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, void *scratch, void *bits,
+                          int64_t B, int D, int hidden_padded, int num_blocks, int acc, nf_stream_t stream);
+int64_t nf_maf_solve_t_scratch_floats(int64_t B, int D, int hidden_padded, int num_blocks);
+int nf_maf_solve_t(const void *x, const void *prm, const void *gx, const void *gld, const void *bits, void *v, const void *blob,
+                   const int32_t *table, void *scratch, int64_t B, int D, int hidden_padded, int num_blocks, nf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * MaskedPiecewiseRationalQuadraticAutoregressive inverse (AR-NSF sampling direction) in ONE pass.  Replaces the D-pass
  * loop of normflows/flows/affine/autoregressive.py:29-38 over MADE with the element-wise inverse spline of
  * neural_spline/autoregressive.py:94-134 (utils/splines.py:16-219); same incremental schedule, same supported MADE

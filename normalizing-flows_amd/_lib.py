@@ -117,7 +117,7 @@ def lib():
             _lib.nf_version.restype = C.c_char_p
             _lib.nf_strerror.restype = C.c_char_p
             for fn in ("nf_rqs_fused_pack_size", "nf_linear_wgrad_scratch_floats", "nf_maf_inverse_scratch_floats",
-                       "nf_maf_inverse_h_scratch_floats", "nf_made_wgrad_scratch_floats"):
+                       "nf_maf_inverse_h_scratch_floats", "nf_made_wgrad_scratch_floats", "nf_maf_solve_t_scratch_floats"):
                 getattr(_lib, fn).restype = C.c_int64
             return _lib
         if not os.path.exists(LIBPATH):

@@ -859,8 +859,14 @@ class MafInverseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, inv, fwd, bwd, z, *params):
         z = z.contiguous()
-        x, ld = ops.maf_inverse(z, inv[0], inv[1], inv[2], num_blocks=inv[3], table_host=inv[4] if len(inv) > 4 else None)
-        ctx.save_for_backward(x)
+        if isinstance(inv, dict):       # round 5: format-0 inverse that leaves its ReLU masks + the transposed pack of the one-pass solve
+            x, ld, bits = ops.maf_inverse_bits(z, inv["blob"], inv["table"], inv["hp"], inv["nb"], inv["tiles"])
+            ctx.save_for_backward(x, bits)
+            ctx.tpack = (inv["tblob"], inv["ttable"], inv["hp"], inv["nb"])
+        else:
+            x, ld = ops.maf_inverse(z, inv[0], inv[1], inv[2], num_blocks=inv[3], table_host=inv[4] if len(inv) > 4 else None)
+            ctx.save_for_backward(x)
+            ctx.tpack = None
         ctx.fwd, ctx.bwd = fwd, bwd
         ctx.nparams = len(params)
         ctx.set_materialize_grads(False)
@@ -869,12 +875,19 @@ class MafInverseFn(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gx, gld):
-        (x,) = ctx.saved_tensors
+        x = ctx.saved_tensors[0]
         fwd, bwd = ctx.fwd, ctx.bwd
         B, D = x.shape
         gx = torch.zeros_like(x) if gx is None else gx.contiguous()
         gld = torch.zeros(B, dtype=x.dtype, device=x.device) if gld is None else gld.contiguous()
         p, save, bits = ops.made_forward_train(x, fwd[0], fwd[1], fwd[2], 2 * D, bwd["NB"])
+        if ctx.tpack is not None:
+            # ONE launch: back-substitution of v s + J^T g_p(v, g_ld) = g_x on the transposed pack (nf_maf_solve_t), the ReLU masks from
+            # the forward inverse's own pass; no sweeps, no host read-back (hipGraph-capturable)
+            tb, tt, hp, nb = ctx.tpack
+            v = ops.maf_solve_t(x, p, gx, gld, ctx.saved_tensors[1], tb, tt, hp, nb)
+            MafInverseFn.last_sweeps = 1
+            return MafInverseFn._finish(ctx, x, p, v, gld, save, bits)
         v = torch.empty_like(x)
         gp = torch.empty_like(p)
         changed = torch.zeros(1, dtype=torch.int32, device=x.device)
@@ -904,6 +917,13 @@ class MafInverseFn(torch.autograd.Function):
             gxm, _ = ops.made_backward(gp, bits, bwd["blob"], bwd["table"], D, bwd["Hp"], bwd["NB"], want_G=False)
             sweeps += 1
         MafInverseFn.last_sweeps = sweeps        # (debug / bench read-out only; not used by any computation)
+        return MafInverseFn._finish(ctx, x, p, v, gld, save, bits)
+
+    @staticmethod
+    def _finish(ctx, x, p, v, gld, save, bits):
+        """g_z = v; g_theta = MADE's weight gradients for the parameter cotangent g_p(-v, -g_ld): one chain + ONE weight-gradient launch."""
+        bwd = ctx.bwd
+        D = x.shape[1]
         _, gp = ops.maf_affine_bwd(x, p, -v, -gld, 0)
         grads = [None] * ctx.nparams
         if any(ctx.needs_input_grad[4:]):

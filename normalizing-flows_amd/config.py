@@ -184,3 +184,14 @@ debug_checks = False
 def set_debug_checks(mode=True):
     global debug_checks
     debug_checks = bool(mode)
+
+
+# The implicit backward of the MAF inverse (autograd.MafInverseFn): True = ONE pass of nf_maf_solve_t per layer (round 5: back-
+# substitution on the transposed pack, no host read-back); False = round 4's sweeps of nf_made_backward until v stops changing
+# (15-25 passes per layer; ablation / cross-check).
+maf_onepass = True
+
+
+def set_maf_onepass(mode=True):
+    global maf_onepass
+    maf_onepass = bool(mode)

@@ -292,7 +292,8 @@ __device__ __forceinline__ void h_static_for(F &&f) {
 template <int NB, bool FAST>
 __global__ void __launch_bounds__(64 * HNW, (NB <= 2 && HNW <= 4) ? 8 / HNW : 1)
 maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *__restrict__ logdet, const float *__restrict__ blob,
-                     const int *__restrict__ table, float *S, float *Xs, float *Ps, int64_t B, int acc, int t_beg, int t_end) {
+                     const int *__restrict__ table, float *S, float *Xs, float *Ps, int64_t B, int acc, int t_beg, int t_end,
+                     unsigned int *__restrict__ bits) {
     constexpr int NL = 1 + 2 * NB, H_SEQ = FAST ? hf_seq(NL) : h_seq(NL), LB = h_lb(FAST);
     __shared__ __attribute__((aligned(16))) float seqw[H_SEQ];     // the tile's biases and diagonal blocks, shared by the workgroup's waves
     extern __shared__ __attribute__((aligned(16))) float dyn[];      // the waves' rings
@@ -512,8 +513,217 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
             for (int l = 0; l < NL; ++l)
                 *reinterpret_cast<f32x4 *>(Sw + (size_t)l * Hp * 32 + o) = f32x4{p[l][4 * q], p[l][4 * q + 1], p[l][4 * q + 2], p[l][4 * q + 3]};
         }
+        // ... and, for the implicit backward (maf_solve_t_kernel below), the ReLU masks of the tile: per lane NB words, bit
+        // (l & 1) 16 + r of word l >> 1 = [activation of layer l in register r > 0] (S_l = relu(pre_l) for l < NL - 1)
+        if constexpr (!FAST) if (bits) {      // (format-0 positions only: the transposed pack mirrors the format-0 plan)
+            unsigned int *bw = bits + (((size_t)wts * T + t) * 64 + lane) * NB;
+#pragma unroll
+            for (int w = 0; w < NB; ++w) {
+                unsigned int word = 0;
+#pragma unroll
+                for (int b = 0; b < 32; ++b) word |= (p[2 * w + (b >> 4)][b & 15] > 0.0f ? 1u : 0u) << b;
+                bw[w] = word;
+            }
+        }
     }
     if (valid && hh == 0) ld_store(logdet + sample, ld, acc);
+}
+
+// ---- round 5: the implicit backward of the inverse in ONE pass (autograd.MafInverseFn; flows/maf_pack.pack_made_transposed) ----
+// Solves  v s + J^T g_p(v, g_ld) = g_x  (J = dMADE/dx at the solution x, g_p = the affine transform's parameter cotangent) by
+// back-substitution: with virtual feature f' = D - 1 - m and virtual degree d' = D - d the input-gradient chain of MADE has exactly
+// the structure the incremental inverse walks, for a virtual network whose initial layer is Wf^T (two inputs per feature: the
+// cotangents of the unconstrained scale and the shift), whose hidden layers are the transposed hidden layers in reverse order, whose
+// final layer is W0^T (one row per feature) and whose "activations" are the forward pass's ReLU masks (`bits`, as the format-0
+// inverse kernel above leaves them: the tiles are the forward plan's in reverse order with the forward positions).  Same mapping,
+// block part, ring, tile pairing and generic sequential part as maf_inverse_h_kernel<NB, false>; replaces the 15-25 sweeps of
+// nf_made_backward (with a host read-back every other sweep) the round-4 implicit backward iterated.
+constexpr int t_seq(int NL) { return HT * 2 * HS + (NL - 1) * HT * HT + HT * HT; }      // W0d'[32][32] | Wd'[NL-1] | WFd'
+
+__device__ __forceinline__ void t_finish(float gxm, float xf, float us, float gxf, float gl, float &vv, float &ga) {
+    const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-(us + 2.0f)));
+    const float rs = __builtin_amdgcn_rcpf(sg + 1e-3f);
+    vv = (gxf - gxm) * rs;
+    ga = (vv * xf + gl * rs) * (sg * (1.0f - sg));
+}
+
+template <int NB>
+__global__ void __launch_bounds__(64 * HNW, (NB <= 2 && HNW <= 4) ? 8 / HNW : 1)
+maf_solve_t_kernel(const float *__restrict__ x, const float *__restrict__ prm, const float *__restrict__ gx,
+                   const float *__restrict__ gld, const unsigned int *__restrict__ bits, float *__restrict__ v,
+                   const float *__restrict__ blob, const int *__restrict__ table, float *S, float *Xs, float *Ps, int64_t B) {
+    constexpr int NL = 1 + 2 * NB, H_SEQ = t_seq(NL), LB = 4;
+    __shared__ __attribute__((aligned(16))) float seqw[H_SEQ];
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    const int lane = threadIdx.x & 63, n = lane & 31, hh = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *ringw = dyn + wid * ((LB + 8) * 256);
+    const int64_t wt = (int64_t)blockIdx.x * HNW + wid;
+    const bool active = wt * 32 < B;
+    const int D = table[0], Dq = table[1], Hp = table[3], T = table[4];
+    const int64_t sample = wt * 32 + n;
+    const bool valid = sample < B;
+    const int64_t wts = active ? wt : 0;
+    const int64_t row = valid ? sample : B - 1;
+    const float *xr = x + row * D, *pr = prm + row * 2 * D, *gxr = gx + row * D;
+    const float gl = gld ? gld[row] : 0.0f;
+    float *Sw = S + wts * ((int64_t)NL * Hp * 32);
+    float *Xw = Xs + wts * ((int64_t)Dq * 32);
+    float *Pw = Ps ? Ps + wts * ((int64_t)NL * HT * 32) : nullptr;
+    const unsigned int *bwp = bits + ((size_t)wts * T * 64 + lane) * NB;
+    auto xpos = [&](int q) { return ((size_t)((q >> 3) * 2 + ((q >> 2) & 1)) * 32 + n) * 4 + (q & 3); };
+    float ca, cb;                                   // the carry: (g_us, g_sh) of the last feature produced
+    {
+        float vv;
+        t_finish(0.0f, xr[D - 1], pr[2 * (D - 1)], gxr[D - 1], gl, vv, ca);
+        cb = vv;
+        if (active && hh == 0) { Xw[xpos(0)] = ca; Xw[xpos(1)] = cb; }
+        if (valid && hh == 0) v[sample * D + D - 1] = vv;
+    }
+    auto xsum = [](float a) { return a + __shfl_xor(a, 32, 64); };
+
+    for (int t = 0; t < T; ++t) {
+        const int *te = table + H_HDR + H_ENT * t;
+        const int dlo = te[0], ns = te[1], K0 = te[2], tf = te[20];
+        const int Kh = HT * t;
+        const float *rec = blob + te[3];
+        const float *A0 = rec;
+        const float *Ah = A0 + K0 * HT;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(Ah + (size_t)NL * Kh * HT);
+            constexpr int HEAD4 = (HT * 2 * HS) / 4;       // the window weights: copied as they are; the diagonal blocks with their
+            for (int i = threadIdx.x; i < H_SEQ / 4; i += 64 * HNW) {      // columns in (half, register) order
+                int d = i;
+                if (i >= HEAD4) {
+                    const int j = i - HEAD4, vq = j & 7;
+                    d = HEAD4 + (j & ~7) + 4 * (vq & 1) + (vq >> 1);
+                }
+                reinterpret_cast<f32x4 *>(seqw)[d] = src[i];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!active) continue;
+        const float *W0d = seqw;
+        const float *Wd = W0d + HT * 2 * HS;
+        const float *WFd = Wd + (NL - 1) * HT * HT;
+
+        // step s produces real feature D - 1 - (dlo + s): its x, unconstrained scale and cotangent
+        f32x16 zx, zu, zg;
+#pragma unroll
+        for (int j = 0; j < HS; ++j) {
+            const int f = D - 1 - (dlo + j);
+            zx[j] = (j < ns) ? xr[f] : 0.0f;
+            zu[j] = (j < ns) ? pr[2 * f] : 0.0f;
+            zg[j] = (j < ns) ? gxr[f] : 0.0f;
+        }
+        unsigned int bw[NB];
+#pragma unroll
+        for (int w = 0; w < NB; ++w) bw[w] = bwp[(size_t)tf * 64 * NB + w];
+
+        __threadfence_block();
+        f32x16 p[NL], pF;
+        h_block<false, false, LB>(A0, nullptr, Xw, K0, lane, nullptr, ringw, p[0]);
+        {
+            const int mode = !Pw ? 0 : ((t & 1) ? 2 : (t + 1 < T ? 1 : 0));
+            const float *Ah2 = Ah;
+            int Kh2 = 0;
+            if (mode == 1) {
+                const int *te2 = te + H_ENT;
+                Ah2 = blob + te2[3] + (size_t)te2[2] * HT;
+                Kh2 = Kh + HT;
+            }
+            const int koff = mode == 2 ? Kh - HT : 0;
+            const int Kb = mode == 2 ? HT : Kh;
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+                h_block_mode<LB>(mode, Ah + (size_t)l * Kh * HT + (size_t)koff * HT, Ah2 + (size_t)l * Kh2 * HT,
+                                 Sw + (size_t)l * Hp * 32 + (size_t)koff * 32, Kb, lane, Pw + (size_t)l * HT * 32, ringw,
+                                 l + 1 < NL ? p[l + 1 < NL ? l + 1 : 0] : pF);
+        }
+        // window inputs: pair j = (g_us, g_sh) of virtual feature dlo - 1 + j; pair 0 is the carry
+        f32x16 xa = {0}, xb = {0};
+        xa[0] = ca;
+        xb[0] = cb;
+#define MAFT_DOT(WBASE, SRC)                                                                     \
+            const f32x4 *w_ = reinterpret_cast<const f32x4 *>(WBASE) + u * (HT / 4) + 4 * hh;    \
+            float a0 = 0.0f, a1 = 0.0f;                                                          \
+            _Pragma("unroll") for (int q = 0; q < 4; q += 2) {                                   \
+                const f32x4 wa = w_[q], wb = w_[q + 1];                                          \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                  \
+                    a0 = fmaf(wa[i], SRC[4 * q + i], a0);                                        \
+                    a1 = fmaf(wb[i], SRC[4 * q + 4 + i], a1);                                    \
+                }                                                                                \
+            }
+        for (int s = 0; s < ns; ++s) {
+            const unsigned m = (unsigned)te[4 + s];
+            // virtual layer 0: G_top = Wf^T g_p -- the block part + the window pairs; raw (no mask)
+            for (unsigned mm = m; mm; mm &= mm - 1) {
+                const int u = __builtin_amdgcn_readfirstlane(__builtin_ctz(mm));
+                const int ru = (u & 3) + 4 * (u >> 3);
+                const bool own = hh == ((u >> 2) & 1);
+                const f32x4 *w_ = reinterpret_cast<const f32x4 *>(W0d) + u * (2 * HS / 4);
+                float a = p[0][ru];
+#pragma unroll
+                for (int f = 0; f < HS; f += 2) {
+                    const f32x4 w = w_[f / 2];      // (us, sh) weights of window pairs f, f + 1
+                    a = fmaf(w[0], xa[f], a);
+                    a = fmaf(w[1], xb[f], a);
+                    a = fmaf(w[2], xa[f + 1], a);
+                    a = fmaf(w[3], xb[f + 1], a);
+                }
+                p[0][ru] = own ? a : p[0][ru];
+            }
+            // virtual layers k = 1 .. 2 NB: odd k: G = mask (V^T G_prev); even k: G = G_{k-2} + mask (V^T G_prev); the mask of
+            // virtual layer k is the forward pass's sign bit of layer 2 NB - k at the same unit
+#pragma unroll
+            for (int k = 1; k < NL; ++k) {
+                for (unsigned mm = m; mm; mm &= mm - 1) {
+                    const int u = __builtin_amdgcn_readfirstlane(__builtin_ctz(mm));
+                    const int ru = (u & 3) + 4 * (u >> 3);
+                    const bool own = hh == ((u >> 2) & 1);
+                    MAFT_DOT(Wd + (k - 1) * HT * HT, p[k - 1])
+                    const float tot = xsum((own ? p[k][ru] : 0.0f) + (a0 + a1));
+                    const int lf = 2 * NB - k;        // (constant after unrolling)
+                    const bool on = (bw[lf >> 1] >> ((lf & 1) * 16 + ru)) & 1u;
+                    const float val = on ? tot : 0.0f;
+                    p[k][ru] = own ? ((k & 1) ? val : p[k >= 2 ? k - 2 : 0][ru] + val) : p[k][ru];
+                }
+            }
+            {
+                float gxm;
+                {
+                    const int u = s, ru = (u & 3) + 4 * (u >> 3);
+                    const bool own = hh == ((u >> 2) & 1);
+                    MAFT_DOT(WFd, p[NL - 1])
+                    gxm = xsum((own ? pF[ru] : 0.0f) + (a0 + a1));
+                }
+                float vv, ga;
+                t_finish(gxm, zx[s], zu[s], zg[s], gl, vv, ga);
+#pragma unroll
+                for (int j_ = 1; j_ < HS; ++j_) {        // statically indexed writes (see maf_inverse_h_kernel)
+                    xa[j_] = (j_ == s + 1) ? ga : xa[j_];
+                    xb[j_] = (j_ == s + 1) ? vv : xb[j_];
+                }
+                ca = ga;
+                cb = vv;
+                const int fq = dlo + s;
+                if (hh == 0) {
+                    Xw[xpos(2 * fq)] = ga;
+                    Xw[xpos(2 * fq + 1)] = vv;
+                    if (valid) v[sample * D + (D - 1 - fq)] = vv;
+                }
+            }
+        }
+#undef MAFT_DOT
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t o = ((size_t)((4 * t + q) * 2 + hh) * 32 + n) * 4;
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+                *reinterpret_cast<f32x4 *>(Sw + (size_t)l * Hp * 32 + o) = f32x4{p[l][4 * q], p[l][4 * q + 1], p[l][4 * q + 2], p[l][4 * q + 3]};
+        }
+    }
 }
 
 }  // namespace nf
@@ -527,7 +737,7 @@ extern "C" int64_t nf_maf_inverse_h_scratch_floats(int64_t B, int D, int hidden_
 
 template <int NB, bool FAST>
 static int maf_h_run(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, float *S, float *Xs, float *Ps,
-                     int64_t nwt, int64_t B, int acc, int t_beg, int t_end, hipStream_t st) {
+                     int64_t nwt, int64_t B, int acc, int t_beg, int t_end, hipStream_t st, unsigned int *bits = nullptr) {
     using namespace nf;
     constexpr int NL = 1 + 2 * NB;
     const int grid = (int)((nwt + HNW - 1) / HNW);
@@ -537,7 +747,7 @@ static int maf_h_run(const void *z, void *y, void *logdet, const void *blob, con
                    lds_ring + sizeof(float) * (FAST ? hf_seq(NL) : h_seq(NL)), opted) != NF_OK)
         return NF_ENOTSUP;
     hipLaunchKernelGGL((maf_inverse_h_kernel<NB, FAST>), dim3(grid), dim3(64 * HNW), lds_ring, st, (const float *)z, (float *)y,
-                       (float *)logdet, (const float *)blob, (const int *)table, S, Xs, Ps, B, acc, t_beg, t_end);
+                       (float *)logdet, (const float *)blob, (const int *)table, S, Xs, Ps, B, acc, t_beg, t_end, bits);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -545,7 +755,7 @@ static int maf_h_run(const void *z, void *y, void *logdet, const void *blob, con
 // table_host: the host copy of `table` (format 1: the launcher needs the kinds of the tiles) or NULL (format 0: one launch)
 template <int NB>
 static int maf_h_launch(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, const int32_t *table_host,
-                        void *scratch, int64_t B, int D, int hidden_padded, int acc, hipStream_t st) {
+                        void *scratch, int64_t B, int D, int hidden_padded, int acc, hipStream_t st, unsigned int *bits = nullptr) {
     using namespace nf;
     constexpr int NL = 1 + 2 * NB;
     const int64_t nwt = (B + 31) / 32;
@@ -555,7 +765,8 @@ static int maf_h_launch(const void *z, void *y, void *logdet, const void *blob, 
     // the feature scratch is read with zero weights before it is written (K0 is padded to 32): it must hold finite values
     if (hipMemsetAsync(Xs, 0, (size_t)nwt * 32 * Dp * sizeof(float), st) != hipSuccess) return NF_EIO;
     float *Ps = Xs + nwt * 32 * Dp;
-    if (!table_host) return maf_h_run<NB, false>(z, y, logdet, blob, table, S, Xs, Ps, nwt, B, acc, 0, 1 << 30, st);
+    if (!table_host) return maf_h_run<NB, false>(z, y, logdet, blob, table, S, Xs, Ps, nwt, B, acc, 0, 1 << 30, st, bits);
+    if (bits) return NF_EINVAL;        // the sign bits are defined for format-0 positions
     // maximal runs of tiles of one kind, one launch each; the first accumulates as the caller says, the others on top of it
     const int T = table_host[4];
     for (int t0 = 0; t0 < T;) {
@@ -572,7 +783,8 @@ static int maf_h_launch(const void *z, void *y, void *logdet, const void *blob, 
 }
 
 static int maf_h_entry(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, const int32_t *table_host,
-                       void *scratch, int64_t B, int D, int hidden_padded, int num_blocks, int acc, nf_stream_t stream) {
+                       void *scratch, int64_t B, int D, int hidden_padded, int num_blocks, int acc, nf_stream_t stream,
+                       unsigned int *bits = nullptr) {
     if (B < 0 || D < 2 || hidden_padded < 32 || hidden_padded % 32) return NF_EINVAL;
     if (acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
     if (num_blocks < 1 || num_blocks > 3) return NF_ENOTSUP;
@@ -582,9 +794,9 @@ static int maf_h_entry(const void *z, void *y, void *logdet, const void *blob, c
     if (B == 0) return NF_OK;
     if (!z || !y || !logdet || !blob || !table || !scratch) return NF_EFAULT;
     hipStream_t st = (hipStream_t)stream;
-    if (num_blocks == 1) return maf_h_launch<1>(z, y, logdet, blob, table, table_host, scratch, B, D, hidden_padded, acc, st);
-    if (num_blocks == 2) return maf_h_launch<2>(z, y, logdet, blob, table, table_host, scratch, B, D, hidden_padded, acc, st);
-    return maf_h_launch<3>(z, y, logdet, blob, table, table_host, scratch, B, D, hidden_padded, acc, st);
+    if (num_blocks == 1) return maf_h_launch<1>(z, y, logdet, blob, table, table_host, scratch, B, D, hidden_padded, acc, st, bits);
+    if (num_blocks == 2) return maf_h_launch<2>(z, y, logdet, blob, table, table_host, scratch, B, D, hidden_padded, acc, st, bits);
+    return maf_h_launch<3>(z, y, logdet, blob, table, table_host, scratch, B, D, hidden_padded, acc, st, bits);
 }
 
 // nf_maf_inverse on the half-sharing mapping: same blob / table format and semantics as nf_maf_inverse (maf_inverse.hip), for
@@ -603,4 +815,59 @@ extern "C" int nf_maf_inverse_h_tri(const void *z, void *y, void *logdet, const 
                                     int acc, nf_stream_t stream) {
     if (!table_host) return NF_EFAULT;
     return maf_h_entry(z, y, logdet, blob, table, table_host, scratch, B, D, hidden_padded, num_blocks, acc, stream);
+}
+
+// nf_maf_inverse_h that also leaves the ReLU masks of the pass for nf_maf_solve_t: bits = ceil(B / 32) * T * 64 * num_blocks uint32
+// (T = table[4] tiles; per 32-row wave, tile and lane num_blocks words: bit (l & 1) 16 + r of word l >> 1 = [activation of hidden layer
+// l at the unit in accumulator register r of that lane > 0]).  Format-0 packs only.
+extern "C" int nf_maf_inverse_h_bits(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, void *scratch,
+                                     void *bits, int64_t B, int D, int hidden_padded, int num_blocks, int acc, nf_stream_t stream) {
+    if (!bits && B > 0) return NF_EFAULT;
+    return maf_h_entry(z, y, logdet, blob, table, nullptr, scratch, B, D, hidden_padded, num_blocks, acc, stream, (unsigned int *)bits);
+}
+
+// Scratch of nf_maf_solve_t: per row NL hidden_padded cotangents + the padded (g_us, g_sh) row + the tile-pair stash.
+extern "C" int64_t nf_maf_solve_t_scratch_floats(int64_t B, int D, int hidden_padded, int num_blocks) {
+    if (B < 0 || D < 1 || hidden_padded < 0 || num_blocks < 1 || num_blocks > 3) return NF_EINVAL;
+    const int64_t nwt = (B + 31) / 32, Dq = (2 * (int64_t)D + 31) / 32 * 32, NL = 1 + 2 * num_blocks;
+    return nwt * 32 * (NL * (int64_t)hidden_padded + Dq + NL * nf::HT);
+}
+
+template <int NB>
+static int maf_t_launch(const void *x, const void *prm, const void *gx, const void *gld, const void *bits, void *v, const void *blob,
+                        const int32_t *table, void *scratch, int64_t B, int D, int hidden_padded, hipStream_t st) {
+    using namespace nf;
+    constexpr int NL = 1 + 2 * NB;
+    const int64_t nwt = (B + 31) / 32;
+    const int64_t Dq = (2 * (int64_t)D + 31) / 32 * 32;
+    float *S = (float *)scratch;
+    float *Xs = S + nwt * 32 * (int64_t)NL * hidden_padded;
+    if (hipMemsetAsync(Xs, 0, (size_t)nwt * 32 * Dq * sizeof(float), st) != hipSuccess) return NF_EIO;
+    float *Ps = Xs + nwt * 32 * Dq;
+    const int grid = (int)((nwt + HNW - 1) / HNW);
+    const size_t lds_ring = (size_t)HNW * 12 * 256 * sizeof(float);
+    static LdsOptIn opted;
+    if (opt_in_lds(reinterpret_cast<const void *>(&maf_solve_t_kernel<NB>), lds_ring + sizeof(float) * t_seq(NL), opted) != NF_OK)
+        return NF_ENOTSUP;
+    hipLaunchKernelGGL((maf_solve_t_kernel<NB>), dim3(grid), dim3(64 * HNW), lds_ring, st, (const float *)x, (const float *)prm,
+                       (const float *)gx, (const float *)gld, (const unsigned int *)bits, (float *)v, (const float *)blob,
+                       (const int *)table, S, Xs, Ps, B);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// The implicit backward's linear solve in ONE pass (module comment above maf_solve_t_kernel): v (B, D) with
+// v s + J^T g_p(v, g_ld) = g_x at the solution x of the inverse; prm (B, 2 D) = MADE(x); bits from nf_maf_inverse_h_bits of the pass
+// that produced x; blob / table: flows/maf_pack.pack_made_transposed (format 2); gld may be NULL (= 0).
+extern "C" int nf_maf_solve_t(const void *x, const void *prm, const void *gx, const void *gld, const void *bits, void *v,
+                              const void *blob, const int32_t *table, void *scratch, int64_t B, int D, int hidden_padded,
+                              int num_blocks, nf_stream_t stream) {
+    if (B < 0 || D < 2 || hidden_padded < 32 || hidden_padded % 32) return NF_EINVAL;
+    if (num_blocks < 1 || num_blocks > 3) return NF_ENOTSUP;
+    if (B == 0) return NF_OK;
+    if (!x || !prm || !gx || !bits || !v || !blob || !table || !scratch) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    if (num_blocks == 1) return maf_t_launch<1>(x, prm, gx, gld, bits, v, blob, table, scratch, B, D, hidden_padded, st);
+    if (num_blocks == 2) return maf_t_launch<2>(x, prm, gx, gld, bits, v, blob, table, scratch, B, D, hidden_padded, st);
+    return maf_t_launch<3>(x, prm, gx, gld, bits, v, blob, table, scratch, B, D, hidden_padded, st);
 }

@@ -654,3 +654,27 @@ def _maf_inverse_structure(made, blocks, tri=False):
             lin.bias.copy_(torch.from_numpy(b.astype(np.float32)))
     blob, table = maf_pack.pack_made(twin, blocks=blocks, tri=tri)
     return _as_src(blob), table
+
+
+def maf_solve_t_structure(made, blocks=(1, 2, 3)):
+    """(gather indices, table) of the transposed one-pass solve's pack (flows/maf_pack.pack_made_transposed) over the flat parameter
+    vector of index_arrays -- the packer run on a copy of the MADE that holds parameter positions instead of values."""
+    import copy
+    from . import maf_pack
+    if not maf_pack.supported(made, 2, blocks):
+        return None
+    key = ("maf_solve_t", tuple(blocks), _mask_key(made))
+    if key in _STRUCTS:
+        return _STRUCTS[key]
+    st = None
+    if maf_pack.pack_made(made, blocks=blocks) is not None:
+        twin = copy.deepcopy(made).cpu()
+        lins = [twin.initial_layer] + [l for b in twin.blocks for l in b.linear_layers] + [twin.final_layer]
+        with torch.no_grad():
+            for lin, (w, b) in zip(lins, index_arrays([tuple(l.weight.shape) for l in lins])):
+                lin.weight.copy_(torch.from_numpy(w.astype(np.float32)))
+                lin.bias.copy_(torch.from_numpy(b.astype(np.float32)))
+        blob, table = maf_pack.pack_made_transposed(twin, blocks=blocks)
+        st = (_as_src(blob), table)
+    _STRUCTS[key] = st
+    return st

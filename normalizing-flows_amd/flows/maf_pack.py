@@ -291,3 +291,110 @@ def pack_made(made, mult=2, rows=False, blocks=(2,), tri=False):
         off += rec.size
     blob = np.concatenate(chunks).astype(np.float32)
     return blob, table
+
+
+# ---- format 2 (round 5): the TRANSPOSED one-pass solve of the implicit backward (csrc/maf_solve_t.hip, autograd.MafInverseFn) ----
+def pack_made_transposed(made, blocks=(1, 2, 3)):
+    """Pack of nf_maf_solve_t: the linear system  v s + J^T g_p(v, g_ld) = g_x  of the implicit backward of the MAF inverse
+    (J = dMADE/dx at the solution, g_p the affine transform's parameter cotangent) solved by back-substitution in ONE pass.
+
+    J^T g_p is MADE's input-gradient chain: G4 = Wf^T g_p; G3 = [t1>0] (L11^T G4); G2 = G4 + [h1>0] (L01^T G3); G1 = [t0>0] (L10^T G2);
+    G0 = G2 + [h0>0] (L00^T G1); (J^T g_p)_m = (W0^T G0)_m.  Feature m only receives from features > m, a hidden unit of degree d
+    only from features >= d and from units of degree >= d: with VIRTUAL feature index f' = D - 1 - m and virtual degree d' = D - d
+    this is exactly the structure the incremental inverse walks (a unit of virtual degree d' sees virtual features <= d' - 1, virtual
+    feature f' sees units of virtual degree <= f'), for a virtual network whose initial layer is Wf^T (TWO inputs per feature: the
+    cotangents of the unconstrained scale and of the shift), whose hidden layers are the transposed hidden layers in reverse order,
+    whose final layer is W0^T (ONE row per feature) and whose activations are the ReLU masks of the forward pass.  The tiles are the
+    FORWARD plan's tiles in reverse order with the forward (format 0) positions, so the sign bits nf_maf_inverse_h leaves per lane and
+    tile are read back as they are.  Record per tile (processing order): A0' [K0'/8][2][32][4] (K0' = 2 x the virtual features
+    before the tile, padded to 32) | A1'..A_{NL-1}', AF' [4t'][2][32][4] | W0d' [32][32] (window: 16 steps x 2 inputs) | Wd'[NL-1][32][32]
+    | WFd' [32][32] (row j = step j).  No biases.  table: [D, 2D padded to 32, H, Hp, T, 1, NB, 2], per tile
+    [dlo', nsteps, K0', rec, mask[16] (virtual step order), forward tile index, 0, 0, 0]."""
+    if not supported(made, 2, blocks):
+        return None
+    base = pack_made(made, blocks=blocks)          # structure checks (degrees, masks) + the forward plan
+    if base is None:
+        return None
+    D = made.initial_layer.in_features
+    H = made.initial_layer.out_features
+    hid_deg = made.initial_layer.degrees.cpu().numpy()
+    lin = [made.initial_layer] + [l for b in made.blocks for l in b.linear_layers]
+    NB = len(made.blocks)
+    NL = 1 + 2 * NB
+    order, tiles = plan_tiles(D, hid_deg)
+    T = len(tiles)
+    Hp = T * TILE
+    Dq = (2 * D + 31) // 32 * 32
+    # forward (format 0) padded slot of every unit, then the virtual slot: same position, tiles reversed
+    fslot = np.zeros(H, dtype=np.int64)
+    k = 0
+    for t, (dlo, ns, steps) in enumerate(tiles):
+        b_ = t * TILE
+        for c in steps:
+            for _ in range(c):
+                fslot[order[k]] = b_
+                b_ += 1
+                k += 1
+    vslot = (T - 1 - fslot // TILE) * TILE + fslot % TILE
+    mw = lambda l: (l.weight.detach() * l.mask).cpu().numpy().astype(np.float32)
+    W0 = mw(lin[0])                                   # (H, D)
+    Lh = [mw(l) for l in lin[1:]]                     # L00, L10, L01, L11, ... (H, H): [out, in]
+    WF = mw(made.final_layer)                         # (2 D, H), row 2 f + k
+    # virtual matrices in padded virtual slot space
+    W0v = np.zeros((Hp, Dq), dtype=np.float32)        # [unit][2 f' + k] = WF[2 (D-1-f') + k][unit]
+    for fq in range(D):
+        for kk in (0, 1):
+            W0v[vslot, 2 * fq + kk] = WF[2 * (D - 1 - fq) + kk, :]
+    Vh = []
+    for kk in range(2 * NB):                          # V_k = (hidden linear 2 NB - 1 - k)^T : [u (receiver = its input)][u' (its output)]
+        Lm = Lh[2 * NB - 1 - kk]
+        V = np.zeros((Hp, Hp), dtype=np.float32)
+        V[np.ix_(vslot, vslot)] = Lm.T
+        Vh.append(V)
+    WFv = np.zeros((D, Hp), dtype=np.float32)         # [f'][unit] = W0[unit][D-1-f']
+    for fq in range(D):
+        WFv[fq, vslot] = W0[:, D - 1 - fq]
+    chunks = [np.zeros(4, dtype=np.float32)]
+    off = 4
+    table = np.zeros(TABLE_HDR + TABLE_ENT * T, dtype=np.int32)
+    table[0:8] = [D, Dq, H, Hp, T, 1, NB, 2]
+    for tq in range(T):
+        t = T - 1 - tq
+        dlo, ns, steps = tiles[t]
+        dloq = D - dlo - ns + 1
+        r0, r1 = tq * TILE, (tq + 1) * TILE
+        nprev = dloq - 1
+        K0 = (2 * nprev + 31) // 32 * 32
+        a0 = np.zeros((TILE, K0), dtype=np.float32)
+        a0[:, :2 * nprev] = W0v[r0:r1, :2 * nprev]
+        rec = [_a_operand(a0)] if K0 else []
+        for V in Vh:
+            if tq:
+                rec.append(_a_operand(V[r0:r1, :r0]))
+        fo = np.zeros((TILE, Hp), dtype=np.float32)
+        for j in range(ns):
+            fo[j] = WFv[dloq + j]
+        if tq:
+            rec.append(_a_operand(fo[:, :r0]))
+        w0d = np.zeros((TILE, 2 * MAX_STEPS), dtype=np.float32)     # window inputs 2 (dlo'-1) ... : 16 steps x 2
+        nwin = min(2 * MAX_STEPS, 2 * D - 2 * (dloq - 1))
+        w0d[:, :nwin] = W0v[r0:r1, 2 * (dloq - 1):2 * (dloq - 1) + nwin]
+        rec.append(w0d.reshape(-1))
+        for V in Vh:
+            rec.append(np.ascontiguousarray(V[r0:r1, r0:r1]).reshape(-1))
+        rec.append(np.ascontiguousarray(fo[:, r0:r1]).reshape(-1))
+        rec = np.concatenate(rec)
+        e = TABLE_HDR + TABLE_ENT * tq
+        table[e + 0], table[e + 1], table[e + 2], table[e + 3] = dloq, ns, K0, off
+        # virtual step s' = forward step ns - 1 - s'; positions are the forward ones
+        u = 0
+        fmask = []
+        for c in steps:
+            fmask.append(np.array([((1 << c) - 1) << u], dtype=np.uint64).astype(np.uint32).view(np.int32)[0])
+            u += c
+        for sq in range(ns):
+            table[e + 4 + sq] = fmask[ns - 1 - sq]
+        table[e + 20] = t
+        chunks.append(rec)
+        off += rec.size
+    return np.concatenate(chunks).astype(np.float32), table

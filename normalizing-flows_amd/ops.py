@@ -1103,6 +1103,44 @@ def maf_inverse(z, blob, table, hidden_padded, logdet=None, acc=None, num_blocks
     return y, logdet
 
 
+def maf_inverse_bits(z, blob, table, hidden_padded, num_blocks, tiles):
+    """nf_maf_inverse_h_bits: the one-pass inverse on a FORMAT-0 pack that also leaves the pass's ReLU masks (uint32 words per
+    32-row wave, tile and lane) for maf_solve_t.  Returns (y, logdet, bits)."""
+    L.require_device(z, blob, table)
+    if z.dtype != torch.float32:
+        raise NotImplementedError("maf_inverse_bits: float32 only")
+    B, D = z.shape
+    z = z.contiguous()
+    y = torch.empty_like(z)
+    logdet = torch.empty(B, dtype=z.dtype, device=z.device)
+    lib = L.lib()
+    n = lib.nf_maf_inverse_h_scratch_floats(i64(B), i32(D), i32(hidden_padded), i32(num_blocks))
+    scratch = torch.empty(max(int(n), 1), dtype=torch.float32, device=z.device)
+    bits = torch.empty(max((B + 31) // 32 * tiles * 64 * num_blocks, 1), dtype=torch.int32, device=z.device)
+    rc = lib.nf_maf_inverse_h_bits(ptr(z), ptr(y), ptr(logdet), ptr(blob), ptr(table), ptr(scratch), ptr(bits), i64(B), i32(D),
+                                   i32(hidden_padded), i32(num_blocks), i32(L.LD_WRITE), L.stream())
+    L.check(rc, "nf_maf_inverse_h_bits")
+    return y, logdet, bits
+
+
+def maf_solve_t(x, params, gx, gld, bits, blob, table, hidden_padded, num_blocks):
+    """nf_maf_solve_t: v with  v s + J^T g_p(v, g_ld) = g_x  in one pass (the implicit backward of the MAF inverse);
+    blob / table from flows/maf_pack.pack_made_transposed."""
+    L.require_device(x, params, gx, gld, bits, blob, table)
+    if x.dtype != torch.float32:
+        raise NotImplementedError("maf_solve_t: float32 only")
+    B, D = x.shape
+    x, params, gx = x.contiguous(), params.contiguous(), gx.contiguous()
+    v = torch.empty_like(x)
+    lib = L.lib()
+    n = lib.nf_maf_solve_t_scratch_floats(i64(B), i32(D), i32(hidden_padded), i32(num_blocks))
+    scratch = torch.empty(max(int(n), 1), dtype=torch.float32, device=x.device)
+    rc = lib.nf_maf_solve_t(ptr(x), ptr(params), ptr(gx), ptr(None if gld is None else gld.contiguous()), ptr(bits), ptr(v), ptr(blob),
+                            ptr(table), ptr(scratch), i64(B), i32(D), i32(hidden_padded), i32(num_blocks), L.stream())
+    L.check(rc, "nf_maf_solve_t")
+    return v
+
+
 def arnsf_inverse(z, blob, table, hidden_padded, K, tails, tail_bound, min_bin_width=1e-3, min_bin_height=1e-3,
                   min_derivative=1e-3, logdet=None, acc=None):
     """neural_spline/autoregressive.py:94-134 inverse over affine/autoregressive.py:29-38 in one pass

@@ -212,3 +212,63 @@ def _emulate_rows(blob, table, z, element):
         for l in range(5):
             S[l][:, TILE * t:TILE * (t + 1)] = pre[l]
     return x[:, :D], ld
+
+
+def emulate_solve_t(blob, table, x, params, gx, gld, masks):
+    """numpy walk-through of csrc/maf_solve_t.hip (format 2 of flows/maf_pack.pack_made_transposed): the one-pass back-substitution of
+    v s + J^T g_p(v, g_ld) = g_x.  masks[k - 1] (B, Hp) = the ReLU mask of VIRTUAL layer k = 1 .. 2 NB in virtual slot order (the sign of
+    forward layer 2 NB - k's pre-activation of the unit in that slot)."""
+    blob = blob.astype(np.float64)
+    B = x.shape[0]
+    D, Dq, H, Hp, T = [int(v) for v in table[:5]]
+    assert int(table[7]) == 2 and int(table[5]) == 1
+    NB = int(table[6])
+    NL = 1 + 2 * NB
+    X = np.zeros((B, Dq))                 # virtual inputs: (g_us, g_sh) of virtual feature f' at 2 f', 2 f' + 1
+    S = np.zeros((NL, B, Hp))
+    v = np.zeros((B, D))
+
+    def finish(gxm, f):                   # real feature f
+        sg = 1.0 / (1.0 + np.exp(-(params[:, 2 * f] + 2.0)))
+        scale = sg + 1e-3
+        vf = (gx[:, f] - gxm) / scale
+        return vf, (vf * x[:, f] + gld / scale) * sg * (1.0 - sg), vf
+
+    v[:, D - 1], X[:, 0], X[:, 1] = finish(0.0, D - 1)
+    for t in range(T):
+        e = HDR + ENT * t
+        dlo, ns, K0, off = [int(q) for q in table[e:e + 4]]
+        msk = table[e + 4:e + 4 + MAX_STEPS].view(np.uint32)
+        Kh = TILE * t
+        A0 = _from_a_operand(blob[off:off + K0 * TILE], K0) if K0 else np.zeros((TILE, 0)); off += K0 * TILE
+        Ah = []
+        for _ in range(NL):
+            Ah.append(_from_a_operand(blob[off:off + Kh * TILE], Kh) if Kh else np.zeros((TILE, 0))); off += Kh * TILE
+        W0d = blob[off:off + TILE * 2 * MAX_STEPS].reshape(TILE, 2 * MAX_STEPS); off += TILE * 2 * MAX_STEPS
+        Wd = blob[off:off + (NL - 1) * TILE * TILE].reshape(NL - 1, TILE, TILE); off += (NL - 1) * TILE * TILE
+        WFd = blob[off:off + TILE * TILE].reshape(TILE, TILE); off += TILE * TILE
+        pre = np.zeros((NL, B, TILE))
+        pre[0] = X[:, :K0] @ A0.T
+        for l in range(1, NL):
+            pre[l] = S[l - 1][:, :Kh] @ Ah[l - 1].T
+        preF = S[NL - 1][:, :Kh] @ Ah[NL - 1].T
+        xg = np.zeros((B, 2 * (MAX_STEPS + 1)))
+        xg[:, 0], xg[:, 1] = X[:, 2 * (dlo - 1)], X[:, 2 * (dlo - 1) + 1]
+        sl = slice(TILE * t, TILE * (t + 1))
+        for s in range(ns):
+            units = [u for u in range(TILE) if (int(msk[s]) >> u) & 1]
+            for u in units:               # G_top = Wf^T g_p: raw
+                pre[0][:, u] = pre[0][:, u] + xg[:, :2 * MAX_STEPS] @ W0d[u]
+            for k in range(1, NL):
+                for u in units:
+                    tot = pre[k][:, u] + pre[k - 1] @ Wd[k - 1][u]
+                    tot = np.where(masks[k - 1][:, sl][:, u], tot, 0.0)
+                    pre[k][:, u] = tot if k % 2 == 1 else pre[k - 2][:, u] + tot
+            gxm = preF[:, s] + pre[NL - 1] @ WFd[s]
+            f = D - 1 - (dlo + s)
+            v[:, f], a, b = finish(gxm, f)
+            X[:, 2 * (dlo + s)], X[:, 2 * (dlo + s) + 1] = a, b
+            xg[:, 2 * (s + 1)], xg[:, 2 * (s + 1) + 1] = a, b
+        for l in range(NL):
+            S[l][:, sl] = pre[l]
+    return v

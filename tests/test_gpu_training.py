@@ -437,9 +437,10 @@ def test_maf_gradients_vs_reference_autograd(nfa, monkeypatch):
     calls = _spy_made(monkeypatch)
     check_layer_grads(layer, g, rtol=2e-3, atol=2e-4)
     # single-pass direction: one forward / chain / weight-gradient launch; density direction (autograd.MafInverseFn, implicit
-    # differentiation): one forward at the solution, one chain per sweep (<= D = 5) + one for the weight gradients, one weight-gradient launch
-    assert calls["fwd"] == 2 and calls["wgrad"] == 2 and 3 <= calls["bwd"] <= 2 + 5 + 1, calls
-    assert 1 <= MafInverseFn.last_sweeps <= 5
+    # differentiation): one forward at the solution, ONE nf_maf_solve_t launch for the linear system (round 5; round 4: one chain per
+    # sweep, <= D = 5), one chain for the weight gradients, one weight-gradient launch
+    assert calls["fwd"] == 2 and calls["wgrad"] == 2 and calls["bwd"] == 2, calls
+    assert MafInverseFn.last_sweeps == 1
 
 
 def test_arnsf_gradients_vs_reference_autograd(nfa):
@@ -1572,13 +1573,17 @@ def test_training_kernels_random_shapes(nfa):
 
 
 
-@pytest.mark.parametrize("D,H,NB,B", [(20, 40, 2, 130), (64, 256, 2, 300), (128, 512, 2, 200), (7, 24, 3, 5)])
-def test_maf_density_direction_implicit_vs_d_pass_autograd(nfa, D, H, NB, B):
+@pytest.mark.parametrize("onepass", [True, False])
+@pytest.mark.parametrize("D,H,NB,B", [(20, 40, 2, 130), (64, 256, 2, 300), (128, 512, 2, 200), (7, 24, 3, 5), (17, 40, 1, 65), (33, 70, 2, 1000),
+                                      (64, 252, 2, 77)])
+def test_maf_density_direction_implicit_vs_d_pass_autograd(nfa, D, H, NB, B, onepass):
     """MaskedAffineAutoregressive.inverse under autograd (the reference's density direction: D sequential MADE passes,
-    autoregressive.py:29-38): implicit differentiation on the one-pass inverse kernel + MADE chain sweeps (autograd.MafInverseFn)
-    against torch autograd through the D-pass loop itself (config.set_maf_implicit(False); each pass on the MADE training kernels):
-    outputs 1e-4, every gradient 2e-4 of its scale; the sweep count stays at or below D."""
+    autoregressive.py:29-38): implicit differentiation (autograd.MafInverseFn) -- round 5: the linear system solved in ONE pass of
+    nf_maf_solve_t on the transposed pack with the forward inverse's own ReLU masks (onepass); round 4: MADE chain sweeps until v stops
+    changing -- against torch autograd through the D-pass loop itself (config.set_maf_implicit(False); each pass on the MADE training
+    kernels): outputs 1e-4, every gradient 2e-4 of its scale; the sweep count stays at or below D (one pass: reported as 1)."""
     from normflows_amd.autograd import MafInverseFn
+    nfa.config.set_maf_onepass(onepass)
     torch.manual_seed(D + H)
     layer = nfa.flows.MaskedAffineAutoregressive(D, H, num_blocks=NB)
     gen = torch.Generator().manual_seed(3)
@@ -1599,7 +1604,8 @@ def test_maf_density_direction_implicit_vs_d_pass_autograd(nfa, D, H, NB, B):
             res.append([x.detach(), ld.detach(), z.grad] + [p.grad.clone() for p in layer.parameters()])
         finally:
             nfa.config.set_maf_implicit(True)
-    assert 1 <= MafInverseFn.last_sweeps <= D
+    nfa.config.set_maf_onepass(True)
+    assert (MafInverseFn.last_sweeps == 1) if onepass else (1 <= MafInverseFn.last_sweeps <= D)
     for k, (a, b) in enumerate(zip(res[0], res[1])):
         tol = 1e-4 if k < 2 else 2e-4
         assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max())), (k, float((a - b).abs().max()), float(b.abs().max()))
@@ -1625,7 +1631,13 @@ def test_training_step_captures_into_one_graph(nfa):
             z, ld = f(z)
             logq = logq - ld
         return (logq + 0.5 * (z ** 2).sum(1)).mean()
-    for m, x, lossfn in ((glow, ximg, lambda mm, xx: mm.forward_kld(xx)), (maf, eps, maf_loss)):
+    # round 5: the DENSITY direction of the MAF too (forward_kld = flow.inverse under autograd): the implicit backward is one
+    # nf_maf_solve_t launch per layer -- round 4's sweeps read a flag back every other sweep and could not be captured
+    maf_d = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(12, trainable=False),
+                                [nfa.flows.MaskedAffineAutoregressive(12, 40, num_blocks=2) for _ in range(2)]).to(DEV)
+    xd = torch.randn(200, 12, device=DEV)
+    for m, x, lossfn in ((glow, ximg, lambda mm, xx: mm.forward_kld(xx)), (maf, eps, maf_loss),
+                         (maf_d, xd, lambda mm, xx: mm.forward_kld(xx))):
         def step():
             m.zero_grad(set_to_none=True)
             lossfn(m, x).backward()

@@ -1184,3 +1184,68 @@ def test_made_forward_spline_pack_matches_dense_made(D, H, NB):
     got = emulate_forward_spline(blob, table, x.numpy())
     assert np.max(np.abs(got[:, :, :23] - ref)) < 1e-5 * max(1.0, np.abs(ref).max()) and np.all(got[:, :, 23] == 0.0)
     assert made_pack.pack_made_forward(nets.MADE(features=8, hidden_features=16, num_blocks=2, output_multiplier=29), 29, spline=True) is None
+
+
+@pytest.mark.parametrize("D,H,NB", [(12, 40, 2), (17, 40, 1), (20, 64, 2), (10, 36, 3), (40, 39, 2), (33, 70, 2)])
+def test_maf_transposed_pack_solves_the_implicit_system(D, H, NB):
+    """flows/maf_pack.pack_made_transposed + the schedule of csrc/maf_solve_t.hip (numpy emulation, tests/maf_emulator.py) solve
+    v s + J^T g_p(v, g_ld) = g_x -- the linear system of autograd.MafInverseFn's backward -- in ONE pass: against the dense solution
+    assembled from float64 autograd (J^T through torch.autograd.grad on the reference-structured MADE)."""
+    import normflows_amd as nfa
+    from normflows_amd import nets
+    from normflows_amd.flows import maf_pack
+    from maf_emulator import emulate_solve_t
+    torch.manual_seed(3 * D + H + NB)
+    made = nets.MADE(features=D, hidden_features=H, num_blocks=NB, output_multiplier=2)
+    with torch.no_grad():
+        for p in made.parameters():
+            p.add_(0.3 * torch.randn_like(p))
+    blob, table = maf_pack.pack_made_transposed(made, blocks=(1, 2, 3))
+    assert table[7] == 2 and table[6] == NB and table[1] % 32 == 0
+    T, Hp = int(table[4]), int(table[3])
+    B = 5
+    m64 = made.double()
+    x = torch.randn(B, D, dtype=torch.float64, requires_grad=True)
+    gx = torch.randn(B, D, dtype=torch.float64)
+    gld = torch.randn(B, dtype=torch.float64)
+    prm = m64(x)                                            # (B, 2 D): row 2 f = unconstrained scale, 2 f + 1 = shift
+    sg = torch.sigmoid(prm[:, 0::2] + 2.0)
+    scale = sg + 1e-3
+
+    def op(v):                                              # v s + J^T g_p(v, g_ld)
+        gp = torch.zeros_like(prm)
+        gp[:, 0::2] = (v * x.detach() + gld[:, None] / scale) * sg * (1.0 - sg)
+        gp[:, 1::2] = v
+        (jt,) = torch.autograd.grad(prm, x, grad_outputs=gp.detach(), retain_graph=True)
+        return (v * scale + jt).detach()
+    c = op(torch.zeros(B, D, dtype=torch.float64))
+    A = torch.stack([op(torch.eye(D, dtype=torch.float64)[i].expand(B, D)) - c for i in range(D)], dim=2)   # (B, D, D): column i
+    v_ref = torch.linalg.solve(A, (gx - c).unsqueeze(2)).squeeze(2)
+    # ReLU masks at x, per forward layer, in virtual slot order
+    lins = [m64.initial_layer] + [l for b in m64.blocks for l in b.linear_layers]
+    with torch.no_grad():
+        h = torch.nn.functional.linear(x, lins[0].weight * lins[0].mask, lins[0].bias)
+        pres = [h]
+        for b in range(NB):
+            t_ = torch.nn.functional.linear(torch.relu(h), lins[1 + 2 * b].weight * lins[1 + 2 * b].mask, lins[1 + 2 * b].bias)
+            pres.append(t_)
+            h = h + torch.nn.functional.linear(torch.relu(t_), lins[2 + 2 * b].weight * lins[2 + 2 * b].mask, lins[2 + 2 * b].bias)
+            pres.append(h)
+    order, tiles = maf_pack.plan_tiles(D, made.initial_layer.degrees.numpy())
+    fslot = np.zeros(H, dtype=np.int64)
+    k = 0
+    for t, (dlo, ns, steps) in enumerate(tiles):
+        b_ = 32 * t
+        for c_ in steps:
+            for _ in range(c_):
+                fslot[order[k]] = b_
+                b_ += 1
+                k += 1
+    vslot = (T - 1 - fslot // 32) * 32 + fslot % 32
+    masks = []
+    for kq in range(1, 2 * NB + 1):                         # virtual layer k <-> forward layer 2 NB - k
+        mk = np.zeros((B, Hp), dtype=bool)
+        mk[:, vslot] = (pres[2 * NB - kq] > 0).numpy()
+        masks.append(mk)
+    v = emulate_solve_t(blob, table, x.detach().numpy(), prm.detach().numpy(), gx.numpy(), gld.numpy(), masks)
+    np.testing.assert_allclose(v, v_ref.numpy(), rtol=1e-8, atol=1e-8)

@@ -16,7 +16,9 @@ with torch.no_grad():
         p.add_(sigma * torch.randn(p.shape, generator=gen))
 layer = layer.to(dev)
 out = {"sigma": sigma}
-for B, modes in ((65536, (True,)), (2048, (True, False))):
+# round 5: implicit differentiation = ONE pass of nf_maf_solve_t per layer (config.maf_onepass, default); "sweeps" = round 4's
+# iteration of nf_made_backward until v stops changing
+for B, modes in ((65536, ("onepass", "sweeps")), (2048, ("onepass", "sweeps", False))):
     z = torch.randn(B, 128, device=dev)
 
     def step():
@@ -25,15 +27,17 @@ for B, modes in ((65536, (True,)), (2048, (True, False))):
         x, ld = layer.inverse(zz)
         (0.5 * (x ** 2).sum(1) - ld).mean().backward()
     for mode in modes:
-        nfa.config.set_maf_implicit(mode)
+        nfa.config.set_maf_implicit(bool(mode))
+        nfa.config.set_maf_onepass(mode == "onepass")
         step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(2):
             step()
         torch.cuda.synchronize()
-        out["B%d_%s_ms" % (B, "implicit" if mode else "d_pass_autograd")] = (time.perf_counter() - t0) * 500
-        if mode:
+        out["B%d_%s_ms" % (B, ("implicit_" + mode) if mode else "d_pass_autograd")] = (time.perf_counter() - t0) * 500
+        if mode == "sweeps":
             out["B%d_sweeps" % B] = MafInverseFn.last_sweeps
     nfa.config.set_maf_implicit(True)
+    nfa.config.set_maf_onepass(True)
 print(json.dumps(out), flush=True)
