@@ -305,6 +305,73 @@ __device__ __forceinline__ void rqs_regs2(const RqsParams<float> &p, float x0, f
     y0 = yr[0]; y1 = yr[1]; lad0 = lr[0]; lad1 = lr[1];
 }
 
+// ONE element with the binary bin descent of rqs_regs2 and scalar arithmetic: for kernels that have no registers to spare for a
+// pair (nsf_wide.hip, made_fwd.hip: the pair version spilled 11-23 registers there); 279 -> 245 vector instructions per element.
+template <int N>
+__device__ __forceinline__ void rqs_descend1(float x, const float (&s)[N + 1], const float (&o)[N + 1], const float (&d)[N + 1],
+                                             float &slo, float &shi, float &olo, float &ohi, float &dl0, float &dl1) {
+    if constexpr (N == 1) {
+        slo = s[0]; shi = s[1]; olo = o[0]; ohi = o[1]; dl0 = d[0]; dl1 = d[1];
+    } else {
+        constexpr int H = N / 2;
+        const bool c = x >= s[H];
+        float s2[H + 1], o2[H + 1], d2[H + 1];
+#pragma unroll
+        for (int i = 0; i <= H; ++i) {
+            s2[i] = c ? s[H + i] : s[i];
+            o2[i] = c ? o[H + i] : o[i];
+            d2[i] = c ? d[H + i] : d[i];
+        }
+        rqs_descend1<H>(x, s2, o2, d2, slo, shi, olo, ohi, dl0, dl1);
+    }
+}
+
+template <bool INVERSE, int KB = F_K>
+__device__ __forceinline__ void rqs_regs_t(const RqsParams<float> &p, float x, const float (&prm)[3 * KB], float &y, float &lad) {
+    static_assert((KB & (KB - 1)) == 0, "binary descent");
+    const bool inside = x >= p.left && x <= p.right;
+    float mw = prm[0], mh = prm[KB];
+#pragma unroll
+    for (int k = 1; k < KB; ++k) {
+        mw = fmaxf(mw, prm[k]);
+        mh = fmaxf(mh, prm[KB + k]);
+    }
+    float pw[KB], ph[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+        const float ew = __builtin_amdgcn_exp2f(prm[k] - mw), eh = __builtin_amdgcn_exp2f(prm[KB + k] - mh);
+        pw[k] = k == 0 ? ew : pw[k - 1] + ew;
+        ph[k] = k == 0 ? eh : ph[k - 1] + eh;
+    }
+    const float cw = (p.right - p.left) * p.scale_w * frcp(pw[KB - 1]);
+    const float ch = (p.top - p.bottom) * p.scale_h * frcp(ph[KB - 1]);
+    float kw[KB + 1], kh[KB + 1], dp[KB + 1];
+    kw[0] = p.left;
+    kh[0] = p.bottom;
+    kw[KB] = p.right;
+    kh[KB] = p.top;
+    dp[0] = dp[KB] = p.edge_logit;
+#pragma unroll
+    for (int k = 1; k < KB; ++k) {
+        kw[k] = fmaf(pw[k - 1], cw, p.left + (p.right - p.left) * p.min_w * (float)k);
+        kh[k] = fmaf(ph[k - 1], ch, p.bottom + (p.top - p.bottom) * p.min_h * (float)k);
+        dp[k] = prm[2 * KB + k - 1];
+    }
+    float slo, shi, olo, ohi, dl0, dl1;
+    if (!INVERSE)
+        rqs_descend1<KB>(x, kw, kh, dp, slo, shi, olo, ohi, dl0, dl1);
+    else
+        rqs_descend1<KB>(x, kh, kw, dp, slo, shi, olo, ohi, dl0, dl1);
+    const float d0 = p.min_d + fsoftplus(dl0), d1 = p.min_d + fsoftplus(dl1);
+    float yy, ll;
+    if (!INVERSE)
+        rqs_eval_bin_fast<false>(x, slo, shi - slo, olo, ohi - olo, d0, d1, yy, ll);
+    else
+        rqs_eval_bin_fast<true>(x, olo, ohi - olo, slo, shi - slo, d0, d1, yy, ll);
+    y = inside ? yy : x;
+    lad = inside ? ll : 0.0f;
+}
+
 // Batch-shared spline from its LDS knot table (cumw[9] | cumh[9] | deriv[9]), branch-free.
 template <bool INVERSE, int KB = F_K>
 __device__ __forceinline__ void rqs_table_fast(const RqsParams<float> &p, float x, const float *tab, float &y, float &lad) {

@@ -158,7 +158,7 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
                         const int col = valid ? tf : 0;
                         float *xp = xreg + ((size_t)(col >> 2) * 64 + 32 * sb + n) * 4 + (col & 3);
                         float yv, lad;
-                        rqs_regs<false>(p, *xp, prm, yv, lad);
+                        rqs_regs_t<false>(p, *xp, prm, yv, lad);      // (round 5: binary bin descent)
                         if (valid) {
                             *xp = yv;
                             lsum[sb] += lad;

@@ -188,7 +188,12 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
                     const bool valid = tf < nT;
                     float *xp = xreg + nw_xidx<TR>(PI + (valid ? tf : 0), 32 * (sbo + sb) + n);
                     float yv, lad;
+                    // round 5: binary bin descent (rqs_regs_t; the packed PAIR version of the benchmark kernel spilled 11-23 registers here)
+#ifdef NF_EPI_SCALAR
                     rqs_regs<DIR == 1>(p, *xp, prm, yv, lad);
+#else
+                    rqs_regs_t<DIR == 1>(p, *xp, prm, yv, lad);
+#endif
                     if (valid) {
                         *xp = yv;
                         lsum[sb] += lad;

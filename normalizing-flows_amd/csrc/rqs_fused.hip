@@ -678,7 +678,11 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
         const int slot = 8 * (g / GQ) + 2 * ((g % GQ) * FPL + f) + par_t;
         const float xt = st[slot * 64];
         float yt, l;
+#ifdef NF_EPI_SCALAR
         rqs_regs<DIR == 1, KB>(p, xt, prm[f], yt, l);
+#else
+        rqs_regs_t<DIR == 1, KB>(p, xt, prm[f], yt, l);      // (round 5: binary bin descent; K = 4 / 16 and the training forward come here)
+#endif
         st[slot * 64] = yt;
         ld += l;
     };

@@ -91,6 +91,20 @@ def test_c_abi_argument_validation_newer_entry_points(nfa):
     assert lib.nf_maf_inverse_h_tri(null, null, null, null, null, hp_, null, i64(0), i32(128), i32(512), i32(2), i32(0), null) == 0
     th[7] = 0
     assert lib.nf_maf_inverse_h_tri(one, one, one, one, one, hp_, one, i64(8), i32(128), i32(512), i32(2), i32(0), null) == -22   # a format-0 table
+    # the one-pass implicit backward (round 5): forward with ReLU masks + the transposed solve
+    lib.nf_maf_solve_t_scratch_floats.restype = ctypes.c_int64
+    assert lib.nf_maf_inverse_h_bits(one, one, one, one, one, one, null, i64(8), i32(128), i32(512), i32(2), i32(0), null) == -14   # bits
+    assert lib.nf_maf_inverse_h_bits(one, one, one, one, one, one, one, i64(8), i32(128), i32(500), i32(2), i32(0), null) == -22
+    assert lib.nf_maf_solve_t_scratch_floats(i64(64), i32(128), i32(512), i32(2)) == 64 * (5 * 512 + 256 + 5 * 32)
+    assert lib.nf_maf_solve_t_scratch_floats(i64(64), i32(128), i32(512), i32(4)) == -22
+    assert lib.nf_maf_solve_t(one, one, one, null, one, one, one, one, one, i64(8), i32(128), i32(500), i32(2), null) == -22
+    assert lib.nf_maf_solve_t(one, one, one, null, one, one, one, one, one, i64(8), i32(128), i32(512), i32(4), null) == -95
+    assert lib.nf_maf_solve_t(one, one, one, null, null, one, one, one, one, i64(8), i32(128), i32(512), i32(2), null) == -14      # bits
+    assert lib.nf_maf_solve_t(null, null, null, null, null, null, null, null, null, i64(0), i32(128), i32(512), i32(2), null) == 0
+    # debug-mode spline check
+    assert lib.nf_rqs_spline_check(one, one, i64(8), i32(0), f64(1.0), f64(0.0), f64(1.0), f64(0.0), f64(1.0), i32(1), i32(0), null, null) == -14
+    assert lib.nf_rqs_spline_check(one, one, i64(8), i32(7), f64(1.0), f64(0.0), f64(1.0), f64(0.0), f64(1.0), i32(1), i32(0), one, null) == -22
+    assert lib.nf_rqs_spline_check(null, null, i64(0), i32(0), f64(1.0), f64(0.0), f64(1.0), f64(0.0), f64(1.0), i32(1), i32(0), null, null) == 0
     assert lib.nf_maf_inverse_scratch_floats(i64(65), i32(128), i32(512)) == 2 * 64 * (5 * 512 + 128 + 5 * 32)   # + pair stash
 
     def arnsf(K, tails, hp=512, B=8, blob=one):
