@@ -4,7 +4,8 @@ kernel's (csrc/rqs_fused.hip: D <= 64, hidden <= 128) -- up to 128 features and 
 
 This module only rearranges weights (no arithmetic on data besides the constant log2(e) / sqrt(hidden) folded into the width / height
 rows, nsf/coupling.py:334-339).  Geometry (csrc/mlp_tile.hpp, nsf_wide.hip):
-  * hidden units zero-padded to Hp = 128 | 256 | 512; row-block rb = units [32 rb, 32 rb + 32); k-group = 8 consecutive inputs;
+  * hidden units zero-padded to Hp = 128 | 256 | 512; row-block rb = units [32 rb, 32 rb + 32); k-group = 8 consecutive inputs; the
+    k-loops of the hidden -> hidden and final products run over the hidden width rounded up to 32 (round 5), not over Hp;
   * the x tile is held with its columns SORTED: position i < PI = identity feature i, position PI + j = transform feature j
     (PI, PT = the two counts rounded up to 32; Dp = PI + PT; padding positions hold zeros).  The initial layer contracts over the
     first PI positions only -- the conditioner sees the identity features alone (nsf/coupling.py:83-84): a NaN in a TRANSFORM
@@ -112,10 +113,14 @@ def pack_nsf_wide(prqct, lu=None, direction=0):
     W0[:H, :nI] = f32(net.initial_layer.weight)
     b0 = np.zeros(Hp, dtype=np.float32)
     b0[:H] = f32(net.initial_layer.bias)
+    # round 5: the CONTRACTION extent of the hidden -> hidden and final products is the hidden width rounded up to 32 (a k-loop runs
+    # in steps of four k-groups), not Hp: a 192-wide network keeps Hp = 256 for its row-blocks (8 waves x 32 units) but its k-loops
+    # run over 24 k-groups instead of 32 -- the padding is no longer paid for in K (D 96 / hidden 192: 675 -> see profiles/r05_*)
+    Kh = (H + 31) // 32 * 32
     layers = [(W0, b0)]
     for blk in net.blocks:
         for lin in blk.linear_layers:
-            W = np.zeros((Hp, Hp), dtype=np.float32)
+            W = np.zeros((Hp, Kh), dtype=np.float32)
             W[:H, :H] = f32(lin.weight)
             b = np.zeros(Hp, dtype=np.float32)
             b[:H] = f32(lin.bias)
@@ -124,7 +129,7 @@ def pack_nsf_wide(prqct, lu=None, direction=0):
     if wf.shape[0] != M * nT:
         return None
     wh_scale = np.float32(1.4426950408889634 / np.sqrt(float(H)))          # log2(e) / sqrt(hidden): rqs_regs takes exp2
-    WF = np.zeros((G, 3, ROWS, Hp), dtype=np.float32)
+    WF = np.zeros((G, 3, ROWS, Kh), dtype=np.float32)
     BF = np.zeros((G, 3, ROWS), dtype=np.float32)
     for g in range(G):
         for r3 in range(3):
@@ -176,7 +181,7 @@ def pack_nsf_wide(prqct, lu=None, direction=0):
             if g >= G:
                 tab[w, base + nhl * nhi + j] = (0, -1, 0)
                 continue
-            nkg = Hp // KG
+            nkg = Kh // KG
             tab[w, base + nhl * nhi + j] = (nkg, g, 2 * sp)
             for r3 in range(3):
                 stream.append(bias_group(BF[g, r3]))

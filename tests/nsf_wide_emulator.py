@@ -65,7 +65,10 @@ def emulate_conditioner(blob, table, x, direction=0):
                 nkg, rb, sb0 = [int(v) for v in tab[w, base + l * nhi + i]]
                 acc = np.tile(_bias(blob[pos[w]:pos[w] + 1024]), (B, 1))
                 pos[w] += 1024
-                assert KG * nkg == (PI if l == 0 else act.shape[1])          # the initial layer contracts over the identity positions
+                # the initial layer contracts over the identity positions; the others over the hidden width rounded up to 32 (round 5:
+                # not over Hp -- a 192-wide network does not pay for its padding to 256 in K)
+                assert KG * nkg == (PI if l == 0 else (H + 31) // 32 * 32) and KG * nkg <= act.shape[1]
+                assert l == 0 or not act[:, KG * nkg:].any()                # what the shorter k-loop skips is padding: exact zeros
                 acc = acc + act[:, :KG * nkg] @ _rows(blob[pos[w]:pos[w] + 256 * nkg], nkg).T
                 pos[w] += 256 * nkg
                 # (a wave computes only its sample blocks; the emulation ignores the split: every owner must agree)
@@ -94,8 +97,9 @@ def emulate_conditioner(blob, table, x, direction=0):
                 pos[w] += 1024
             frag = blob[pos[w]:pos[w] + 3 * 256 * nkg].reshape(nkg, 3, 256)
             pos[w] += 3 * 256 * nkg
+            assert KG * nkg == (H + 31) // 32 * 32 and not h[:, KG * nkg:].any()
             for r3 in range(3):
-                acc[r3] += h @ _rows(np.ascontiguousarray(frag[:, r3]).reshape(-1), nkg).T
+                acc[r3] += h[:, :KG * nkg] @ _rows(np.ascontiguousarray(frag[:, r3]).reshape(-1), nkg).T
             for r3 in range(3):
                 for rho in range(ROWS):
                     q, hh, i = rho >> 3, (rho >> 2) & 1, rho & 3
