@@ -34,7 +34,8 @@ def main():
     B, D, H = int(os.environ.get("NF_B", 65536)), 128, 512
     torch.manual_seed(0)
     layer = nfa.flows.MaskedAffineAutoregressive(D, H, num_blocks=2).to(dev)
-    blob, table, Hp = layer._packed(dev)
+    nfa.config.set_maf_tri(False)                  # round 2's kernel (maf_inverse.hip) reads format-0 packs only
+    blob, table, Hp = layer._packed(dev)[:3]
     z = torch.randn(B, D, device=dev)
     y = torch.empty_like(z)
     ld = torch.zeros(B, device=dev)
