@@ -44,9 +44,14 @@ constexpr int h_lb(bool fast) { return fast ? NF_MAF_LB : 4; }     // activation
 // same operands go to `stash` raw; INIT: c0 starts from the stash (second tile of a pair).  A, A2: [K/8][2][32][4] (L2),
 // Sl: the wave's scratch [K/8][2][32][4].  ALL three streams arrive by LDS-DMA in the wave's own ring: LB slots (1 KB each) for the
 // activation k-blocks -- requested LB steps ahead -- and 4 + 4 for the A [, A2] weight k-blocks, requested 4 steps ahead.
-template <bool PAIR, bool INIT, int LB>
+// TAIL (round 5): after the K features / units streamed from the scratch, 32 more whose activations are still IN REGISTERS -- the tile
+// this wave has just finished: `breg` = its accumulator vector of the source layer, whose quads ARE the B operands of the four
+// k-blocks -- contracted against the next four weight k-blocks of the same A [, A2] streams.  The newest tile then never makes the
+// round trip store -> wait -> DMA (ablation: without the tile's 20 stores 10.3 instead of 11.2 ms; most of that was the wait for
+// them in front of the next tile's first request), and an odd tile of a pair (K = its partner's 32 units) streams no activations.
+template <bool PAIR, bool INIT, int LB, bool TAIL = false>
 __device__ __forceinline__ void h_block(const float *__restrict__ A, const float *__restrict__ A2, const float *Sl, int K, int lane,
-                                        float *stash, float *ring, f32x16 &c0) {
+                                        float *stash, float *ring, f32x16 &c0, const f32x16 *breg = nullptr) {
     static_assert(LB == 4 || LB == 8, "activation slots: a power of two >= the 4 weight slots");
     f32x16 c2 = {0};
 #pragma unroll
@@ -60,7 +65,8 @@ __device__ __forceinline__ void h_block(const float *__restrict__ A, const float
             for (int i = 0; i < 4; ++i) c0[4 * q + i] = v[i];
         }
     }
-    const int nkb = K >> 3;
+    const int nkm = K >> 3;                       // k-blocks whose activations come from the scratch
+    const int nkb = nkm + (TAIL ? 4 : 0);         // + the register tail: weight k-blocks nkm .. nkm + 3
     if (nkb > 0) {
         // The requests are INLINE ASM and there is no ordinary load in the loop, so the compiler inserts no vector-memory wait of
         // its own and the hand-counted ones are exact: vector-memory operations retire in order; step kb needs A(kb) [, A2(kb)],
@@ -75,28 +81,31 @@ __device__ __forceinline__ void h_block(const float *__restrict__ A, const float
         // regular-tile kernel (the activation stream is the one that comes from HBM; its window was 4 KB per wave).
         constexpr int LPS = PAIR ? 2 : 1;
         const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ring);
-        auto dma1 = [&](uint32_t dst, const float *src) {
+        // SGPR base + 32-bit lane offset (round 5): the three streams' bases are wave-uniform, so no 64-bit per-lane address is
+        // computed or kept alive per stream (the VGPR-address form cost ~30 spilled registers once p stayed live across tiles)
+        auto dma1 = [&](uint32_t dst, const float *base, uint32_t byte_off) {
 #ifdef NF_MAF_ABL_NO_DMA
             return;
 #endif
             // (m0 is a reserved register: the compiler does not honour it as a clobber, so it is saved and restored here)
             uint32_t m0_;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(m0_) : "s"(dst), "v"(src) : "memory");
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(m0_) : "s"(dst), "v"(byte_off), "s"(base) : "memory");
         };
+        const uint32_t lane16 = (uint32_t)lane * 16u;
         auto req_b = [&](int kb) {
-            if (kb < nkb) dma1(ring_lds + (uint32_t)(kb & (LB - 1)) * 1024u, Sl + (size_t)kb * 256 + lane * 4);
+            if (kb < nkm) dma1(ring_lds + (uint32_t)(kb & (LB - 1)) * 1024u, Sl, (uint32_t)kb * 1024u + lane16);
         };
         auto req_a = [&](int kb, int slot) {
             if (kb < nkb) {
-                const size_t off = (size_t)kb * 256 + lane * 4;
-                dma1(ring_lds + (uint32_t)(LB + slot) * 1024u, A + off);
-                if constexpr (PAIR) dma1(ring_lds + (uint32_t)(LB + 4 + slot) * 1024u, A2 + off);
+                const uint32_t off = (uint32_t)kb * 1024u + lane16;
+                dma1(ring_lds + (uint32_t)(LB + slot) * 1024u, A, off);
+                if constexpr (PAIR) dma1(ring_lds + (uint32_t)(LB + 4 + slot) * 1024u, A2, off);
             }
         };
-        auto step = [&](int kb, int slot) {
+        auto wait_for = [&](int kb) {
             const int ca = min(nkb - 1 - kb, 3);                         // steps kb-3 .. kb-1 that requested weight blocks
-            const int cb = max(min(nkb - LB - kb + 3, 3), 0);            // ... and activation blocks
+            const int cb = max(min(nkm - LB - kb + 3, 3), 0);            // ... and activation blocks
             switch (cb + LPS * ca) {
                 case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
                 case 1: NF_WAIT_VMCNT(1); break;
@@ -109,6 +118,9 @@ __device__ __forceinline__ void h_block(const float *__restrict__ A, const float
                 case 8: NF_WAIT_VMCNT(8); break;
                 default: NF_WAIT_VMCNT(9); break;
             }
+        };
+        auto step = [&](int kb, int slot) {
+            wait_for(kb);
             const f32x4 b = *reinterpret_cast<const f32x4 *>(ring + (kb & (LB - 1)) * 256 + lane * 4);
             const f32x4 a = *reinterpret_cast<const f32x4 *>(ring + (LB + slot) * 256 + lane * 4);
             f32x4 a2 = a;
@@ -134,11 +146,28 @@ __device__ __forceinline__ void h_block(const float *__restrict__ A, const float
             req_b(j + LB - 4);
             req_a(j, j);
         }
-        for (int kb = 0; kb < nkb; kb += 4) {
+        for (int kb = 0; kb < nkm; kb += 4) {
             step(kb, 0);
             step(kb + 1, 1);
             step(kb + 2, 2);
             step(kb + 3, 3);
+        }
+        if constexpr (TAIL) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {         // weight k-block nkm + q (ring slot q: nkm is a multiple of 4) x register quad q
+                wait_for(nkm + q);
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(ring + (LB + q) * 256 + lane * 4);
+                f32x4 a2 = a;
+                if constexpr (PAIR) a2 = *reinterpret_cast<const f32x4 *>(ring + (LB + 4 + q) * 256 + lane * 4);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef NF_MAF_ABL_NO_MFMA
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    c0 = HMFMA(a[i], (*breg)[4 * q + i], c0);
+                    if constexpr (PAIR) c2 = HMFMA(a2[i], (*breg)[4 * q + i], c2);
+                }
+#endif
+            }
         }
     }
     if constexpr (PAIR) {
@@ -151,12 +180,12 @@ __device__ __forceinline__ void h_block(const float *__restrict__ A, const float
 // (Round 3, measured and dropped: the NL products of a tile as ONE stream -- requests and A look-ahead running through the
 // product boundaries, one start-up per tile instead of one per product: 14.9 ms against 14.5-14.8, 18 spilled registers.  The
 // start-ups are not what is left either.)
-template <int LB>
+template <int LB, bool TAIL = false>
 __device__ __forceinline__ void h_block_mode(int mode, const float *__restrict__ A, const float *__restrict__ A2, const float *Sl,
-                                             int K, int lane, float *stash, float *ring, f32x16 &out) {
-    if (mode == 1) h_block<true, false, LB>(A, A2, Sl, K, lane, stash, ring, out);
-    else if (mode == 2) h_block<false, true, LB>(A, nullptr, Sl, K, lane, stash, ring, out);
-    else h_block<false, false, LB>(A, nullptr, Sl, K, lane, nullptr, ring, out);
+                                             int K, int lane, float *stash, float *ring, f32x16 &out, const f32x16 *breg = nullptr) {
+    if (mode == 1) h_block<true, false, LB, TAIL>(A, A2, Sl, K, lane, stash, ring, out, breg);
+    else if (mode == 2) h_block<false, true, LB, TAIL>(A, nullptr, Sl, K, lane, stash, ring, out, breg);
+    else h_block<false, false, LB, TAIL>(A, nullptr, Sl, K, lane, nullptr, ring, out, breg);
 }
 
 __device__ __forceinline__ void h_finish(float us, float sh, float zf, float &xn, float &ld) {
@@ -321,6 +350,23 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
         xcarry = y[(valid ? sample : B - 1) * D + table[H_HDR + H_ENT * t_beg] - 1];     // the last feature of the previous launch
     }
     const int t_stop = min(t_end, T);
+    f32x16 p[NL], pF;       // p: the hidden layers' accumulators / activations of the CURRENT tile; FAST: kept across the tile boundary
+#pragma unroll              // (the next tile's block part contracts over them from the registers)
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[l][r] = 0.0f;
+    if constexpr (FAST) {
+        if (t_beg > 0 && active) {     // the predecessor tile ran in another launch: its published activations back into the registers
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(Sw + (size_t)l * Hp * 32 + ((size_t)((4 * (t_beg - 1) + q) * 2 + hh) * 32 + n) * 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) p[l][4 * q + i] = a[i];
+                }
+        }
+    }
     for (int t = t_beg; t < t_stop; ++t) {
         const int *te = table + H_HDR + H_ENT * t;
         const int dlo = te[0], ns = te[1], K0 = te[2];
@@ -329,9 +375,14 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
         const float *A0 = rec;
         const float *Ah = A0 + K0 * HT;             // A1..A_{NL-1}, AF: Kh * 32 floats each
         // stage the sequential part's weights, one copy per workgroup
+#ifndef NF_MAF_ABL_NO_BARRIER
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only barrier: a fence would wait for the activation stores in flight
+#endif
         if constexpr (FAST) {       // regular tile: triangular record in reading order, copied as it is
             const f32x4 *src = reinterpret_cast<const f32x4 *>(Ah + (size_t)NL * Kh * HT);
+#ifdef NF_MAF_ABL_NO_STAGE
+            if (t == t_beg)
+#endif
             for (int i = threadIdx.x; i < H_SEQ / 4; i += 64 * HNW) reinterpret_cast<f32x4 *>(seqw)[i] = src[i];
         } else {                    // the five 32 x 32 diagonal blocks with their columns in (half, register) order: source quad
                                     // (u, v / 4 = 2 q + h) -> destination quad (u, 4 h + q)
@@ -346,7 +397,9 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
                 reinterpret_cast<f32x4 *>(seqw)[d] = src[i];
             }
         }
+#ifndef NF_MAF_ABL_NO_BARRIER
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only barrier: a fence would wait for the activation stores in flight
+#endif
         if (!active) continue;
         const float *bias = seqw;
         const float *biasF = bias + NL * HT;
@@ -355,9 +408,6 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
 #pragma unroll
         for (int j = 0; j < (FAST ? HF_STEPS : HS); ++j) zin[j] = (j < ns) ? zr[dlo + j] : 0.0f;
 
-        __threadfence_block();  // the activation scratch written by the other lanes of this wave is read below
-        f32x16 p[NL], pF;
-        h_block<false, false, LB>(A0, nullptr, Xw, K0, lane, nullptr, ringw, p[0]);
         {
             // tile pairing: even tile = its own products + the next tile's over the same operands (raw accumulators to the
             // stash); odd tile = the stash + the 32 units of its partner
@@ -374,13 +424,49 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
                 Kh2 = Kh + HT;
             }
             const int koff = mode == 2 ? Kh - HT : 0;         // the partner's units: the last 32 of this tile's K range
-            const int Kb = mode == 2 ? HT : Kh;
+            if constexpr (FAST) {
+                // The previous tile's activations are still in p: the last 32 units of every product's K range come from the
+                // registers (h_block TAIL), the earlier ones from the scratch.  Products in DESCENDING layer order: product l
+                // reads p[l] (the previous tile's layer-l activations) and yields the new p[l + 1], whose old value product l + 1 has
+                // already consumed.  No fence: what is streamed was published at least one tile ago and every
+                // product since ended on vmcnt(0); the feature scratch (written by the previous tile's steps) is read LAST.
+                // (The first tile of a launch found its predecessor's activations loaded from the scratch, see the kernel's prologue;
+                // tile 0 has no predecessor: its hidden products are empty.)
+                if (t > 0) {
+                    const int Km = mode == 2 ? 0 : Kh - HT;
 #pragma unroll
-            for (int l = 0; l < NL; ++l)
-                h_block_mode<LB>(mode, Ah + (size_t)l * Kh * HT + (size_t)koff * HT, Ah2 + (size_t)l * Kh2 * HT,
-                             Sw + (size_t)l * Hp * 32 + (size_t)koff * 32, Kb, lane, Pw + (size_t)l * HT * 32, ringw,
-                             l + 1 < NL ? p[l + 1 < NL ? l + 1 : 0] : pF);
+                    for (int l = NL - 1; l >= 0; --l)      // (straight into p[l + 1]: its old value died with product l + 1)
+                        h_block_mode<LB, true>(mode, Ah + (size_t)l * Kh * HT + (size_t)koff * HT, Ah2 + (size_t)l * Kh2 * HT,
+                                               Sw + (size_t)l * Hp * 32, Km, lane, Pw + (size_t)l * HT * 32, ringw,
+                                               l + 1 < NL ? p[l + 1 < NL ? l + 1 : 0] : pF, &p[l]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        pF[r] = 0.0f;
+#pragma unroll
+                        for (int l = 1; l < NL; ++l) p[l][r] = 0.0f;
+                    }
+                    if (Pw && T > 1) {       // tile 0 leads the first pair: its partner's products over no operands = zeros in the stash
+#pragma unroll
+                        for (int l = 0; l < NL; ++l)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                reinterpret_cast<f32x4 *>(Pw + (size_t)l * HT * 32)[q * 64 + lane] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    }
+                }
+                h_block<false, false, LB>(A0, nullptr, Xw, K0, lane, nullptr, ringw, p[0]);
+            } else {
+                __threadfence_block();  // the activation scratch written by the other lanes of this wave is read below
+                const int Kb = mode == 2 ? HT : Kh;
+                h_block<false, false, LB>(A0, nullptr, Xw, K0, lane, nullptr, ringw, p[0]);
+#pragma unroll
+                for (int l = 0; l < NL; ++l)
+                    h_block_mode<LB>(mode, Ah + (size_t)l * Kh * HT + (size_t)koff * HT, Ah2 + (size_t)l * Kh2 * HT,
+                                     Sw + (size_t)l * Hp * 32 + (size_t)koff * 32, Kb, lane, Pw + (size_t)l * HT * 32, ringw,
+                                     l + 1 < NL ? p[l + 1 < NL ? l + 1 : 0] : pF);
+            }
         }
+#ifndef NF_MAF_ABL_NO_BIAS
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int u = (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -388,6 +474,7 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
             for (int l = 0; l < NL; ++l) p[l][r] += bias[l * HT + u];
             pF[r] += biasF[u];
         }
+#endif
         f32x16 xg = {0};   // window features dlo-1 .. dlo+14 (0-based): xg[0] is the carry, xg[s+1] the output of step s
         xg[0] = xcarry;
 
@@ -506,6 +593,9 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
 #undef MAFH_DOT
         }
         // ---- publish the tile: the register quads ARE the B-operand entries (k-block 4 t + q, half hh) ----
+#ifdef NF_MAF_ABL_NO_PUBLISH
+        if (p[0][0] == 1.2345f)
+#endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const size_t o = ((size_t)((4 * t + q) * 2 + hh) * 32 + n) * 4;

@@ -24,6 +24,15 @@ VARIANTS = {
     "hnw2": "-DNF_MAF_HNW=2",
     "lb8": "-DNF_MAF_LB=8",
     "nopair": "-DNF_MAF_ABL_NO_PAIR",
+    # what the 3 ms between "MFMA issue alone" (5.8 ms) and nodma_noseq (8.9 ms) are made of: the same build with more removed
+    "core": "-DNF_MAF_ABL_NO_DMA -DNF_MAF_ABL_NO_SEQ",
+    "core_nobarrier": "-DNF_MAF_ABL_NO_DMA -DNF_MAF_ABL_NO_SEQ -DNF_MAF_ABL_NO_BARRIER",
+    "core_nostage": "-DNF_MAF_ABL_NO_DMA -DNF_MAF_ABL_NO_SEQ -DNF_MAF_ABL_NO_STAGE",
+    "core_nopublish": "-DNF_MAF_ABL_NO_DMA -DNF_MAF_ABL_NO_SEQ -DNF_MAF_ABL_NO_PUBLISH",
+    "core_nobias": "-DNF_MAF_ABL_NO_DMA -DNF_MAF_ABL_NO_SEQ -DNF_MAF_ABL_NO_BIAS",
+    "core_all": "-DNF_MAF_ABL_NO_DMA -DNF_MAF_ABL_NO_SEQ -DNF_MAF_ABL_NO_BARRIER -DNF_MAF_ABL_NO_STAGE -DNF_MAF_ABL_NO_PUBLISH -DNF_MAF_ABL_NO_BIAS",
+    "nobarrier": "-DNF_MAF_ABL_NO_BARRIER",
+    "nopublish": "-DNF_MAF_ABL_NO_PUBLISH",
 }
 
 
