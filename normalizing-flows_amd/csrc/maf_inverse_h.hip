@@ -207,6 +207,13 @@ constexpr int hf_w0(int g) { int o = 0; for (int i = 0; i < g; ++i) o += i / 2 +
 constexpr int HF_W0 = hf_w0(HF_STEPS), HF_WD = HF_STEPS * (HF_STEPS + 1), HF_WF = HF_STEPS * (HF_STEPS + 1) / 2;
 constexpr int hf_half4(int NL) { return HF_W0 + (NL - 1) * HF_WD + HF_WF; }
 constexpr int hf_seq(int NL) { return (NL + 1) * HT + 8 * hf_half4(NL); }    // floats of a regular tile's record after the A operands
+// tile kind 2 ("regular with extras", flows/maf_pack.py): <= 7 degrees, the first m <= 4 own a FIFTH unit that sits in the otherwise
+// empty slot 7 (lane-half g & 1, register 14 + (g >> 1)); behind the two regular halves an extra region per half (float4 units):
+// X1 [NL-1][7][2] registers 14, 15 -> the four regular targets | X2 [NL-1][4][3] the extra target over pairs 0..g and (14, 15) |
+// XW [4] its window weights | XF [7] registers 14, 15 -> the scale / shift rows.  BASELINE configs[4]'s tile 0 is such a tile.
+constexpr int HX_STEPS = 7, HX_MAX = 4;
+constexpr int hx_half4(int NL) { return (NL - 1) * (HX_STEPS * 2 + HX_MAX * 3) + HX_MAX + HX_STEPS; }
+constexpr int hfx_seq(int NL) { return hf_seq(NL) + 8 * hx_half4(NL); }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 hf_fma(float w0, float w1, f32x2 s, f32x2 a) { return __builtin_elementwise_fma(f32x2{w0, w1}, s, a); }
@@ -221,8 +228,11 @@ __device__ __forceinline__ float hf_xchg(float lo, float hi) {
 // (the weights of a product are read HF_LA source pairs ahead of their multiply-adds and no further: left to itself the scheduler
 // hoists all 2 (G + 1) 16-byte reads of a product -- up to 64 registers -- in front of the first multiply-add, and the kernel spills)
 constexpr int HF_LA = 2;
-template <int G>
-__device__ __forceinline__ void hf_product(const f32x16 &src, const f32x4 *w, float &ta, float &tb) {
+// X: kind-2 tile -- registers 14, 15 (the extras) are sources too (wx1: two float4), and with `dox` (G < m) the step's own extra is
+// a fifth target (wx2: its weights over pairs 0..G and (14, 15), three float4); its wave-wide total comes back in tx on every lane.
+template <int G, bool X = false>
+__device__ __forceinline__ void hf_product(const f32x16 &src, const f32x4 *w, float &ta, float &tb, const f32x4 *wx1 = nullptr,
+                                           const f32x4 *wx2 = nullptr, bool dox = false, float *tx = nullptr) {
     f32x2 a0 = {0.0f, 0.0f}, a1 = a0, a2 = a0, a3 = a0;
     f32x4 wq[G + 1][2];
 #pragma unroll
@@ -238,14 +248,39 @@ __device__ __forceinline__ void hf_product(const f32x16 &src, const f32x4 *w, fl
         a3 = hf_fma(w1[2], w1[3], s, a3);
         __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (X) {
+        const f32x2 s7 = {src[14], src[15]};
+        const f32x4 w0 = wx1[0], w1 = wx1[1];
+        a0 = hf_fma(w0[0], w0[1], s7, a0);
+        a1 = hf_fma(w0[2], w0[3], s7, a1);
+        a2 = hf_fma(w1[0], w1[1], s7, a2);
+        a3 = hf_fma(w1[2], w1[3], s7, a3);
+        if constexpr (G < HX_MAX) {
+            if (dox) {
+                const f32x4 f0 = wx2[0], f1 = wx2[1], f2 = wx2[2];
+                const float f[12] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3], f2[0], f2[1], f2[2], f2[3]};
+                f32x2 ax = {0.0f, 0.0f};
+#pragma unroll
+                for (int q = 0; q <= G; ++q) ax = hf_fma(f[2 * q], f[2 * q + 1], f32x2{src[2 * q], src[2 * q + 1]}, ax);
+                ax = hf_fma(f[2 * (G + 1)], f[2 * (G + 1) + 1], s7, ax);
+                const float sx = ax[0] + ax[1];
+                *tx = hf_xchg(sx, sx);
+            }
+        }
+    }
     ta = hf_xchg(a0[0] + a0[1], a2[0] + a2[1]);
     tb = hf_xchg(a1[0] + a1[1], a3[0] + a3[1]);
 }
 
-template <int NB, int G>
+template <int NB, int G, bool X = false>
 __device__ __forceinline__ void hf_step(f32x16 (&p)[1 + 2 * NB], const f32x16 &pF, f32x16 &xg, const f32x4 *wh, float zf, float &ld,
-                                        float &xn) {
+                                        float &xn, const f32x4 *wx = nullptr, int m = 0, int hh = 0) {
     constexpr int NL = 1 + 2 * NB;
+    // kind-2 tile: the step's extra unit = register RX of lane-half G & 1 (the other half's RX belongs to another step's extra)
+    constexpr int RX = 14 + ((G < HX_MAX ? G : 0) >> 1);
+    constexpr int OX2 = (NL - 1) * HX_STEPS * 2, OXW = OX2 + (NL - 1) * HX_MAX * 3, OXF = OXW + HX_MAX;
+    const bool dox = X && G < HX_MAX && G < m;
+    const bool ownx = dox && hh == (G & 1);
     {   // initial layer: h0 = pre + W0[window] . x for the half's own two targets; h0 folds into block 1's second pre-activation
         const f32x4 *w = wh + hf_w0(G);
         f32x2 a0 = {p[0][2 * G], 0.0f}, a1 = {p[0][2 * G + 1], 0.0f};
@@ -261,15 +296,36 @@ __device__ __forceinline__ void hf_step(f32x16 (&p)[1 + 2 * NB], const f32x16 &p
         p[2][2 * G + 1] += hb;
         p[0][2 * G] = fmaxf(ha, 0.0f);
         p[0][2 * G + 1] = fmaxf(hb, 0.0f);
+        if constexpr (X && G < HX_MAX) {
+            if (dox) {          // the extra's initial layer: window pairs 0, 1 (G <= 3), weights on its own half only (zeros on the other)
+                const f32x4 wq = wx[OXW + G];
+                const float hx = p[0][RX] + (wq[0] * xg[0] + wq[1] * xg[1]) + (wq[2] * xg[2] + wq[3] * xg[3]);
+                p[2][RX] = ownx ? p[2][RX] + hx : p[2][RX];
+                p[0][RX] = ownx ? fmaxf(hx, 0.0f) : p[0][RX];
+            }
+        }
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        float ta, tb;
-        hf_product<G>(p[2 * b], wh + HF_W0 + (2 * b) * HF_WD + G * (G + 1), ta, tb);               // t_b = L0_b(relu(h_b))
+        float ta, tb, tx = 0.0f;
+        hf_product<G, X>(p[2 * b], wh + HF_W0 + (2 * b) * HF_WD + G * (G + 1), ta, tb, wx + ((2 * b) * HX_STEPS + G) * 2,
+                         wx + OX2 + ((2 * b) * HX_MAX + (G < HX_MAX ? G : 0)) * 3, dox, &tx);                  // t_b = L0_b(relu(h_b))
         p[2 * b + 1][2 * G] = fmaxf(p[2 * b + 1][2 * G] + ta, 0.0f);
         p[2 * b + 1][2 * G + 1] = fmaxf(p[2 * b + 1][2 * G + 1] + tb, 0.0f);
-        hf_product<G>(p[2 * b + 1], wh + HF_W0 + (2 * b + 1) * HF_WD + G * (G + 1), ta, tb);       // h_{b+1} = h_b + L1_b(relu(t_b))
+        if constexpr (X && G < HX_MAX) p[2 * b + 1][RX] = ownx ? fmaxf(p[2 * b + 1][RX] + tx, 0.0f) : p[2 * b + 1][RX];
+        hf_product<G, X>(p[2 * b + 1], wh + HF_W0 + (2 * b + 1) * HF_WD + G * (G + 1), ta, tb, wx + ((2 * b + 1) * HX_STEPS + G) * 2,
+                         wx + OX2 + ((2 * b + 1) * HX_MAX + (G < HX_MAX ? G : 0)) * 3, dox, &tx);              // h_{b+1} = h_b + L1_b(relu(t_b))
         const float ha = p[2 * b + 2][2 * G] + ta, hb = p[2 * b + 2][2 * G + 1] + tb;
+        if constexpr (X && G < HX_MAX) {
+            const float hx = p[2 * b + 2][RX] + tx;
+            if (b + 1 < NB) {
+                const int nx = 2 * b + 4 < NL ? 2 * b + 4 : 0;
+                p[nx][RX] = ownx ? p[nx][RX] + hx : p[nx][RX];
+                p[2 * b + 2][RX] = ownx ? fmaxf(hx, 0.0f) : p[2 * b + 2][RX];
+            } else {
+                p[2 * b + 2][RX] = ownx ? hx : p[2 * b + 2][RX];
+            }
+        }
         if (b + 1 < NB) {
             const int nx = 2 * b + 4 < NL ? 2 * b + 4 : 0;
             p[nx][2 * G] += ha;
@@ -294,6 +350,12 @@ __device__ __forceinline__ void hf_step(f32x16 (&p)[1 + 2 * NB], const f32x16 &p
             au = hf_fma(wq[q][0], wq[q][1], s, au);
             as = hf_fma(wq[q][2], wq[q][3], s, as);
             if (q & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (X) {
+            const f32x4 wf = wx[OXF + G];
+            const f32x2 s7 = {p[NL - 1][14], p[NL - 1][15]};
+            au = hf_fma(wf[0], wf[1], s7, au);
+            as = hf_fma(wf[2], wf[3], s7, as);
         }
         // lower half: scale (its block part + bias sit in register G of half 0), upper half: shift (register G of half 1)
         const float v = hf_xchg(au[0] + au[1], as[0] + as[1]) + pF[G];
@@ -323,7 +385,7 @@ __global__ void __launch_bounds__(64 * HNW, (NB <= 2 && HNW <= 4) ? 8 / HNW : 1)
 maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *__restrict__ logdet, const float *__restrict__ blob,
                      const int *__restrict__ table, float *S, float *Xs, float *Ps, int64_t B, int acc, int t_beg, int t_end,
                      unsigned int *__restrict__ bits) {
-    constexpr int NL = 1 + 2 * NB, H_SEQ = FAST ? hf_seq(NL) : h_seq(NL), LB = h_lb(FAST);
+    constexpr int NL = 1 + 2 * NB, H_SEQ = FAST ? hfx_seq(NL) : h_seq(NL), LB = h_lb(FAST);
     __shared__ __attribute__((aligned(16))) float seqw[H_SEQ];     // the tile's biases and diagonal blocks, shared by the workgroup's waves
     extern __shared__ __attribute__((aligned(16))) float dyn[];      // the waves' rings
     const int lane = threadIdx.x & 63, n = lane & 31, hh = lane >> 5;
@@ -383,7 +445,8 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
 #ifdef NF_MAF_ABL_NO_STAGE
             if (t == t_beg)
 #endif
-            for (int i = threadIdx.x; i < H_SEQ / 4; i += 64 * HNW) reinterpret_cast<f32x4 *>(seqw)[i] = src[i];
+            const int n4 = (te[20] == 2 ? hfx_seq(NL) : hf_seq(NL)) / 4;
+            for (int i = threadIdx.x; i < n4; i += 64 * HNW) reinterpret_cast<f32x4 *>(seqw)[i] = src[i];
         } else {                    // the five 32 x 32 diagonal blocks with their columns in (half, register) order: source quad
                                     // (u, v / 4 = 2 q + h) -> destination quad (u, 4 h + q)
             const f32x4 *src = reinterpret_cast<const f32x4 *>(Ah + (size_t)NL * Kh * HT);
@@ -480,12 +543,16 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
 
         if constexpr (FAST) {
             const f32x4 *wh = reinterpret_cast<const f32x4 *>(seqw + (NL + 1) * HT) + hh * hf_half4(NL);
+            const f32x4 *wx = reinterpret_cast<const f32x4 *>(seqw + hf_seq(NL)) + hh * hx_half4(NL);
+            const bool xtile = te[20] == 2;
+            const int mx = te[21];
             h_static_for<0, HF_STEPS>([&](auto G_) {
                 constexpr int G = decltype(G_)::value;
                 if (G < ns) {
                     float xn;
 #ifndef NF_MAF_ABL_NO_SEQ
-                    hf_step<NB, G>(p, pF, xg, wh, zin[G], ld, xn);
+                    if (G < HX_STEPS && xtile) hf_step<NB, (G < HX_STEPS ? G : 0), true>(p, pF, xg, wh, zin[G], ld, xn, wx, mx, hh);
+                    else hf_step<NB, G>(p, pF, xg, wh, zin[G], ld, xn);
 #else
                     xn = zin[G] + p[0][G] + pF[G] + wh[G][0];
 #endif
@@ -834,7 +901,7 @@ static int maf_h_run(const void *z, void *y, void *logdet, const void *blob, con
     const size_t lds_ring = (size_t)HNW * (h_lb(FAST) + 8) * 256 * sizeof(float);
     static LdsOptIn opted;
     if (opt_in_lds(reinterpret_cast<const void *>(&maf_inverse_h_kernel<NB, FAST>),
-                   lds_ring + sizeof(float) * (FAST ? hf_seq(NL) : h_seq(NL)), opted) != NF_OK)
+                   lds_ring + sizeof(float) * (FAST ? hfx_seq(NL) : h_seq(NL)), opted) != NF_OK)
         return NF_ENOTSUP;
     hipLaunchKernelGGL((maf_inverse_h_kernel<NB, FAST>), dim3(grid), dim3(64 * HNW), lds_ring, st, (const float *)z, (float *)y,
                        (float *)logdet, (const float *)blob, (const int *)table, S, Xs, Ps, B, acc, t_beg, t_end, bits);
@@ -860,9 +927,9 @@ static int maf_h_launch(const void *z, void *y, void *logdet, const void *blob, 
     // maximal runs of tiles of one kind, one launch each; the first accumulates as the caller says, the others on top of it
     const int T = table_host[4];
     for (int t0 = 0; t0 < T;) {
-        const bool fast = table_host[H_HDR + H_ENT * t0 + 20] == 1;
+        const bool fast = table_host[H_HDR + H_ENT * t0 + 20] != 0;       // kind 1 (regular) and 2 (regular with extras)
         int t1 = t0 + 1;
-        while (t1 < T && (table_host[H_HDR + H_ENT * t1 + 20] == 1) == fast) ++t1;
+        while (t1 < T && (table_host[H_HDR + H_ENT * t1 + 20] != 0) == fast) ++t1;
         const int a = t0 == 0 ? acc : (acc == NF_LD_SUB ? NF_LD_SUB : NF_LD_ADD);
         const int rc = fast ? maf_h_run<NB, true>(z, y, logdet, blob, table, S, Xs, Ps, nwt, B, a, t0, t1, st)
                             : maf_h_run<NB, false>(z, y, logdet, blob, table, S, Xs, Ps, nwt, B, a, t0, t1, st);

@@ -69,6 +69,39 @@ def is_regular(steps):
     return len(steps) <= FAST_STEPS and max(steps) <= 4
 
 
+# Format 1, tile kind 2 ("regular with extras", round 5): at most 7 degrees; the first m <= 4 of them own FIVE units, the others at
+# most four.  The four regular units of a step sit where a regular tile has them; the fifth unit of step g < m sits in the otherwise
+# empty slot 7: lane-half g & 1, accumulator register 14 + (g >> 1).  BASELINE configs[4]'s tile 0 (degrees 1-4 own five units) is
+# such a tile: with it every tile of that layer runs the statically unrolled sequential part and the layer is ONE launch.
+XTRA_STEPS = 7
+XTRA_MAX = 4
+
+
+def extras_prefix(steps):
+    """m if `steps` is a kind-2 tile (m >= 1 leading five-unit degrees), else 0."""
+    if len(steps) > XTRA_STEPS or max(steps) > 5 or max(steps) < 5:
+        return 0
+    m = 0
+    while m < len(steps) and steps[m] == 5:
+        m += 1
+    if m > XTRA_MAX or any(c > 4 for c in steps[m:]):
+        return 0
+    return m
+
+
+def xtra_half4(NL):
+    """float4 units of the extra region of one half: X1 (pair 7 -> the four regular targets) [NL-1][7][2] | X2 (the extra target over
+    pairs 0..g and 7) [NL-1][4][3] | XW (the extra target's window) [4] | XF (pair 7 -> scale / shift rows) [7]."""
+    return (NL - 1) * (XTRA_STEPS * 2 + XTRA_MAX * 3) + XTRA_MAX + XTRA_STEPS
+
+
+def tile_row(g, i):
+    """Row (within the tile) of unit i of step g in a regular (i < 4) or kind-2 (i == 4: the extra) tile."""
+    if i < 4:
+        return _row_of(2 * g + (i & 1), i >> 1)
+    return _row_of(14 + (g >> 1), g & 1)
+
+
 def plan_tiles(D, hidden_degrees):
     """Sort units by degree (stable) and cut into tiles.  Returns (order, tiles) with tiles = list of
     (dlo, nsteps, [unit-count per step]) or None when the structure is outside what the kernel handles."""
@@ -151,13 +184,14 @@ def pack_made(made, mult=2, rows=False, blocks=(2,), tri=False):
     pos = np.zeros(H, dtype=np.int64)
     slot_deg = np.zeros(Hp, dtype=np.int64)
     k = 0
-    regular = [bool(tri) and is_regular(steps) for (_, _, steps) in tiles]
+    kind = [0 if not tri else (1 if is_regular(steps) else (2 if extras_prefix(steps) else 0)) for (_, _, steps) in tiles]
+    regular = [k != 0 for k in kind]          # tiles on the statically unrolled sequential part
     for t, (dlo, ns, steps) in enumerate(tiles):
         base = t * TILE
         for s, c in enumerate(steps):
             for i in range(c):
                 if regular[t]:
-                    slot = t * TILE + _row_of(2 * s + (i & 1), i >> 1)
+                    slot = t * TILE + tile_row(s, i)
                 else:
                     slot = base
                 pos[k] = slot
@@ -268,6 +302,38 @@ def pack_made(made, mult=2, rows=False, blocks=(2,), tri=False):
                 assert part.size == fast_half_floats(len(Wh) + 1)
                 halves.append(part)
             rec.append(np.concatenate(halves))
+            if kind[t] == 2:
+                m = extras_prefix(steps)
+                for hh in (0, 1):
+                    part = []
+                    r14, r15 = _row_of(14, hh), _row_of(15, hh)
+                    for w in Wh:                           # X1: pair 7 of this half -> the four regular targets of step g
+                        d = w[r0:r1, r0:r1]
+                        for g in range(XTRA_STEPS):
+                            for j in (0, 1):
+                                ta, tb = trow(g, 2 * j), trow(g, 2 * j + 1)
+                                part.append([d[ta, r14], d[ta, r15], d[tb, r14], d[tb, r15]])
+                    for w in Wh:                           # X2: the extra target of step g over this half's pairs 0..g and 7
+                        d = w[r0:r1, r0:r1]
+                        for g in range(XTRA_MAX):
+                            te_ = tile_row(g, 4)
+                            pairs = [(_row_of(2 * q, hh), _row_of(2 * q + 1, hh)) for q in range(g + 1)] + [(r14, r15)]
+                            flat = [d[te_, c] if g < m else 0.0 for pr in pairs for c in pr]
+                            flat += [0.0] * (12 - len(flat))
+                            for k in range(3):
+                                part.append(flat[4 * k:4 * k + 4])
+                    for g in range(XTRA_MAX):              # XW: the extra target's window weights (pairs 0 .. g / 2), own half only
+                        te_ = tile_row(g, 4)
+                        own = g < m and hh == (g & 1)
+                        flat = [w0d[te_, c] if own and c <= g + 1 else 0.0 for c in range(4)]
+                        part.append(flat)
+                    d = fo[:, r0:r1]
+                    for g in range(XTRA_STEPS):            # XF: pair 7 -> (scale, shift) of step g's feature
+                        ru, rs = _row_of(g, 0), _row_of(g, 1)
+                        part.append([d[ru, r14], d[ru, r15], d[rs, r14], d[rs, r15]])
+                    part = np.asarray(part, dtype=np.float32).reshape(-1)
+                    assert part.size == 4 * xtra_half4(len(Wh) + 1)
+                    rec.append(part)
         else:
             rec.append(w0d.reshape(-1))
             for w in Wh:
@@ -282,7 +348,8 @@ def pack_made(made, mult=2, rows=False, blocks=(2,), tri=False):
         rec = np.concatenate(rec)
         e = TABLE_HDR + TABLE_ENT * t
         table[e + 0], table[e + 1], table[e + 2], table[e + 3] = dlo, ns, K0, off
-        table[e + 20] = int(regular[t])
+        table[e + 20] = kind[t]
+        table[e + 21] = extras_prefix(steps) if kind[t] == 2 else 0
         u = 0
         for s, c in enumerate(steps):
             table[e + 4 + s] = np.array([((1 << c) - 1) << u], dtype=np.uint64).astype(np.uint32).view(np.int32)[0]

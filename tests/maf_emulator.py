@@ -41,7 +41,7 @@ def emulate_inverse(blob, table, z, element=None):
             Ah.append(_from_a_operand(blob[off:off + Kh * TILE], Kh) if Kh else np.zeros((TILE, 0))); off += Kh * TILE
         bias = blob[off:off + NL * TILE].reshape(NL, TILE); off += NL * TILE
         biasF = blob[off:off + TILE]; off += TILE
-        if int(table[7]) == 1 and int(table[e + 20]) == 1:
+        if int(table[7]) == 1 and int(table[e + 20]) in (1, 2):
             # format 1, REGULAR tile: the statically unrolled triangular steps of maf_inverse_h.hip (fast path), lane-half by
             # lane-half and register by register, reading the record exactly where the kernel reads it
             pre = np.zeros((NL, B, TILE))
@@ -58,6 +58,13 @@ def emulate_inverse(blob, table, z, element=None):
                         P[l, h, r] = pre[l][:, row(r, h)]
             PF = np.stack([np.stack([preF[:, row(r, h)] for r in range(16)]) for h in (0, 1)])
             half = [blob[off + h * HALF:off + (h + 1) * HALF].reshape(-1, 4) for h in (0, 1)]
+            # kind 2 (regular with extras): the fifth unit of step g < m lives in lane-half g & 1, register 14 + (g >> 1); per half an
+            # extra region X1 [NL-1][7][2] | X2 [NL-1][4][3] | XW [4] | XF [7] (float4 units) behind the two regular halves
+            kind2 = int(table[e + 20]) == 2
+            m_x = int(table[e + 21])
+            XH = 4 * ((NL - 1) * (7 * 2 + 4 * 3) + 4 + 7)
+            xh = [blob[off + 2 * HALF + h * XH:off + 2 * HALF + (h + 1) * XH].reshape(-1, 4) for h in (0, 1)] if kind2 else None
+            oX1, oX2, oXW, oXF = 0, (NL - 1) * 14, (NL - 1) * 14 + (NL - 1) * 12, (NL - 1) * 14 + (NL - 1) * 12 + 4
             xg = np.zeros((18, B))
             xg[0] = x[:, dlo - 1]
             o0, od, of = 0, 20, 20 + (NL - 1) * 72
@@ -72,6 +79,12 @@ def emulate_inverse(blob, table, z, element=None):
                     for i in (0, 1):
                         P[2, h, 2 * g + i] += a[i]
                         P[0, h, 2 * g + i] = np.maximum(a[i], 0)
+                if kind2 and g < m_x:                     # the extra target's initial layer: its own half only
+                    ho, rx = g & 1, 14 + (g >> 1)
+                    w = xh[ho][oXW + g]
+                    ax = P[0, ho, rx] + w[0] * xg[0] + w[1] * xg[1] + w[2] * xg[2] + w[3] * xg[3]
+                    P[2, ho, rx] += ax
+                    P[0, ho, rx] = np.maximum(ax, 0)
 
                 def product(l):
                     """partials of the four targets over each half's registers 0..2g+1 of layer l, then the two exchanges:
@@ -84,14 +97,31 @@ def emulate_inverse(blob, table, z, element=None):
                                 w = half[h][bd + 2 * q + j]
                                 part[h, 2 * j] += w[0] * P[l, h, 2 * q] + w[1] * P[l, h, 2 * q + 1]
                                 part[h, 2 * j + 1] += w[2] * P[l, h, 2 * q] + w[3] * P[l, h, 2 * q + 1]
+                    totx = None
+                    if kind2:
+                        for h in (0, 1):                  # pair 7 (the extras' registers 14, 15) -> the four regular targets
+                            for j in (0, 1):
+                                w = xh[h][oX1 + (l * 7 + g) * 2 + j]
+                                part[h, 2 * j] += w[0] * P[l, h, 14] + w[1] * P[l, h, 15]
+                                part[h, 2 * j + 1] += w[2] * P[l, h, 14] + w[3] * P[l, h, 15]
+                        if g < m_x:                       # the extra target over pairs 0..g and 7 of both halves
+                            totx = np.zeros(B)
+                            for h in (0, 1):
+                                w = xh[h][oX2 + (l * 4 + g) * 3:oX2 + (l * 4 + g) * 3 + 3].reshape(-1)
+                                srcs = [P[l, h, r] for q in range(g + 1) for r in (2 * q, 2 * q + 1)] + [P[l, h, 14], P[l, h, 15]]
+                                for k, sv in enumerate(srcs):
+                                    totx = totx + w[k] * sv
                     # v_permlane32_swap(q0, q2) + add: half 0 <- target 0, half 1 <- target 2; (q1, q3): targets 1 / 3
-                    return [[part[0, 0] + part[1, 0], part[0, 1] + part[1, 1]], [part[0, 2] + part[1, 2], part[0, 3] + part[1, 3]]]
+                    return [[part[0, 0] + part[1, 0], part[0, 1] + part[1, 1]], [part[0, 2] + part[1, 2], part[0, 3] + part[1, 3]]], totx
+                hx, rxx = g & 1, 14 + (g >> 1)
                 for b in range(NB):
-                    tot = product(2 * b)
+                    tot, totx = product(2 * b)
                     for h in (0, 1):
                         for i in (0, 1):
                             P[2 * b + 1, h, 2 * g + i] = np.maximum(P[2 * b + 1, h, 2 * g + i] + tot[h][i], 0)
-                    tot = product(2 * b + 1)
+                    if totx is not None:
+                        P[2 * b + 1, hx, rxx] = np.maximum(P[2 * b + 1, hx, rxx] + totx, 0)
+                    tot, totx = product(2 * b + 1)
                     for h in (0, 1):
                         for i in (0, 1):
                             hn = P[2 * b + 2, h, 2 * g + i] + tot[h][i]
@@ -100,6 +130,13 @@ def emulate_inverse(blob, table, z, element=None):
                                 P[2 * b + 2, h, 2 * g + i] = np.maximum(hn, 0)
                             else:
                                 P[2 * b + 2, h, 2 * g + i] = hn
+                    if totx is not None:
+                        hn = P[2 * b + 2, hx, rxx] + totx
+                        if b + 1 < NB:
+                            P[2 * b + 4, hx, rxx] += hn
+                            P[2 * b + 2, hx, rxx] = np.maximum(hn, 0)
+                        else:
+                            P[2 * b + 2, hx, rxx] = hn
                 bf_ = of + g * (g + 1) // 2
                 pu, ps = np.zeros((2, B)), np.zeros((2, B))
                 for h in (0, 1):
@@ -107,6 +144,11 @@ def emulate_inverse(blob, table, z, element=None):
                         w = half[h][bf_ + q]
                         pu[h] += w[0] * P[NL - 1, h, 2 * q] + w[1] * P[NL - 1, h, 2 * q + 1]
                         ps[h] += w[2] * P[NL - 1, h, 2 * q] + w[3] * P[NL - 1, h, 2 * q + 1]
+                if kind2:
+                    for h in (0, 1):
+                        w = xh[h][oXF + g]
+                        pu[h] += w[0] * P[NL - 1, h, 14] + w[1] * P[NL - 1, h, 15]
+                        ps[h] += w[2] * P[NL - 1, h, 14] + w[3] * P[NL - 1, h, 15]
                 us = pu[0] + pu[1] + PF[0, g]             # half 0 holds the scale row in register g, half 1 the shift row
                 sh = ps[0] + ps[1] + PF[1, g]
                 xn, d = finish(us, sh, z[:, dlo + g])

@@ -510,7 +510,7 @@ def test_dp_nll_matches_unsharded_under_gloo(nfa, tmp_path):
 
 
 @pytest.mark.parametrize("D,H,NB", [(128, 512, 2), (17, 40, 2), (3, 2, 2), (40, 39, 2), (6, 150, 2), (17, 40, 1), (33, 70, 3), (128, 512, 1),
-                                    (32, 64, 2), (96, 256, 2), (64, 252, 2), (10, 36, 1), (12, 40, 3)])
+                                    (32, 64, 2), (96, 256, 2), (64, 252, 2), (10, 36, 1), (12, 40, 3), (64, 256, 2), (9, 34, 1), (8, 30, 3)])
 def test_maf_pack_schedule_matches_d_pass(D, H, NB):
     """flows/maf_pack.py + the kernel's tile/step schedule (tests/maf_emulator.py restates it in numpy) reproduce the
     fixed point of the reference's D-pass inverse (autoregressive.py:29-38) computed with plain torch in fp64."""
@@ -545,9 +545,9 @@ def test_maf_pack_schedule_matches_d_pass(D, H, NB):
     T = int(table1[4])
     reg = [int(table1[8 + 24 * t + 20]) for t in range(T)]
     plan = maf_pack.plan_tiles(D, made.initial_layer.degrees.numpy())[1]
-    assert reg == [int(maf_pack.is_regular(st)) for (_, _, st) in plan]
+    assert reg == [1 if maf_pack.is_regular(st) else (2 if maf_pack.extras_prefix(st) else 0) for (_, _, st) in plan]
     if (D, H) == (128, 512):
-        assert reg == [0] + [1] * 15                     # config 5: degrees 1-4 own five units
+        assert reg == [2] + [1] * 15                     # config 5: degrees 1-4 own five units -> tile 0 is "regular with extras"
     x1, ld1 = emulate_inverse(blob1, table1, z.numpy())
     np.testing.assert_allclose(x1, out.numpy(), rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(ld1, ldref.numpy(), rtol=1e-9, atol=1e-9)
