@@ -2167,11 +2167,12 @@ def test_maf_inverse_both_mappings_agree(nfa, B):
 
 
 @pytest.mark.parametrize("D,H,NB,B", [(128, 512, 2, 4099), (64, 252, 2, 1000), (10, 36, 1, 77), (12, 40, 3, 257), (96, 256, 2, 513),
-                                      (128, 512, 1, 64), (64, 252, 1, 31)])
+                                      (128, 512, 1, 64), (64, 252, 1, 31), (64, 256, 2, 300), (9, 34, 1, 65), (8, 30, 3, 129)])
 def test_maf_inverse_regular_tiles_triangular_path(nfa, D, H, NB, B):
     """nf_maf_inverse_h_tri (round 5) on structures whose tiles are regular from the start (64 / 252: the fast kernel also does
     feature 0), regular with short last tiles (10 / 36: one degree; 12 / 40: 3 units per degree), generic then regular (128 / 512:
-    degrees 1-4 own five units -> tile 0 generic; 96 / 256: eight generic tiles, then one regular) -- i.e. one, two launches per
+    degrees 1-4 own five units -> tile 0 is "regular with extras" (kind 2: the fifth units in slot 7), as are 64 / 256 (m = 4) and
+    9 / 34, 8 / 30 (m = 2, the latter a single tile); 96 / 256: eight generic tiles, then one regular) -- i.e. one, two launches per
     layer in both orders: against the reference's D-pass structure on the same weights, the three log-det accumulation modes
     ACROSS the launches, and bit-equal repeats.  Packer + schedule are pinned on CPU (tests/test_host.py, same shapes)."""
     from normflows_amd.flows.autoregressive import Autoregressive
