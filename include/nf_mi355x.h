@@ -625,6 +625,11 @@ int nf_maf_inverse_h_tri(const void *z, void *y, void *logdet, const void *blob,
  *                           scratch: nf_maf_solve_t_scratch_floats floats, contents need not be initialised.  float32. */
 int nf_maf_inverse_h_bits(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, void *scratch, void *bits,
                           int64_t B, int D, int hidden_padded, int num_blocks, int acc, nf_stream_t stream);
+/* the same on a format-1 pack (table_host as in nf_maf_inverse_h_tri): the masks in that pack's positions, for a transposed pack
+ * built with the same option (maf_pack.pack_made_transposed(tri=True)) -- the training forward then runs the fast inverse kernel */
+int nf_maf_inverse_h_tri_bits(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, const int32_t *table_host,
+                              void *scratch, void *bits, int64_t B, int D, int hidden_padded, int num_blocks, int acc,
+                              nf_stream_t stream);
 int64_t nf_maf_solve_t_scratch_floats(int64_t B, int D, int hidden_padded, int num_blocks);
 int nf_maf_solve_t(const void *x, const void *prm, const void *gx, const void *gld, const void *bits, void *v, const void *blob,
                    const int32_t *table, void *scratch, int64_t B, int D, int hidden_padded, int num_blocks, nf_stream_t stream);

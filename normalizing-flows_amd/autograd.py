@@ -860,7 +860,8 @@ class MafInverseFn(torch.autograd.Function):
     def forward(ctx, inv, fwd, bwd, z, *params):
         z = z.contiguous()
         if isinstance(inv, dict):       # round 5: format-0 inverse that leaves its ReLU masks + the transposed pack of the one-pass solve
-            x, ld, bits = ops.maf_inverse_bits(z, inv["blob"], inv["table"], inv["hp"], inv["nb"], inv["tiles"])
+            x, ld, bits = ops.maf_inverse_bits(z, inv["blob"], inv["table"], inv["hp"], inv["nb"], inv["tiles"],
+                                               table_host=inv.get("table_host"))
             ctx.save_for_backward(x, bits)
             ctx.tpack = (inv["tblob"], inv["ttable"], inv["hp"], inv["nb"])
         else:

@@ -672,7 +672,7 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
         }
         // ... and, for the implicit backward (maf_solve_t_kernel below), the ReLU masks of the tile: per lane NB words, bit
         // (l & 1) 16 + r of word l >> 1 = [activation of layer l in register r > 0] (S_l = relu(pre_l) for l < NL - 1)
-        if constexpr (!FAST) if (bits) {      // (format-0 positions only: the transposed pack mirrors the format-0 plan)
+        if (bits) {      // (positions = this pack's: the transposed pack of the solve mirrors the same plan and format)
             unsigned int *bw = bits + (((size_t)wts * T + t) * 64 + lane) * NB;
 #pragma unroll
             for (int w = 0; w < NB; ++w) {
@@ -923,7 +923,6 @@ static int maf_h_launch(const void *z, void *y, void *logdet, const void *blob, 
     if (hipMemsetAsync(Xs, 0, (size_t)nwt * 32 * Dp * sizeof(float), st) != hipSuccess) return NF_EIO;
     float *Ps = Xs + nwt * 32 * Dp;
     if (!table_host) return maf_h_run<NB, false>(z, y, logdet, blob, table, S, Xs, Ps, nwt, B, acc, 0, 1 << 30, st, bits);
-    if (bits) return NF_EINVAL;        // the sign bits are defined for format-0 positions
     // maximal runs of tiles of one kind, one launch each; the first accumulates as the caller says, the others on top of it
     const int T = table_host[4];
     for (int t0 = 0; t0 < T;) {
@@ -931,8 +930,8 @@ static int maf_h_launch(const void *z, void *y, void *logdet, const void *blob, 
         int t1 = t0 + 1;
         while (t1 < T && (table_host[H_HDR + H_ENT * t1 + 20] != 0) == fast) ++t1;
         const int a = t0 == 0 ? acc : (acc == NF_LD_SUB ? NF_LD_SUB : NF_LD_ADD);
-        const int rc = fast ? maf_h_run<NB, true>(z, y, logdet, blob, table, S, Xs, Ps, nwt, B, a, t0, t1, st)
-                            : maf_h_run<NB, false>(z, y, logdet, blob, table, S, Xs, Ps, nwt, B, a, t0, t1, st);
+        const int rc = fast ? maf_h_run<NB, true>(z, y, logdet, blob, table, S, Xs, Ps, nwt, B, a, t0, t1, st, bits)
+                            : maf_h_run<NB, false>(z, y, logdet, blob, table, S, Xs, Ps, nwt, B, a, t0, t1, st, bits);
         if (rc != NF_OK) return rc;
         t0 = t1;
     }
@@ -981,6 +980,15 @@ extern "C" int nf_maf_inverse_h_bits(const void *z, void *y, void *logdet, const
                                      void *bits, int64_t B, int D, int hidden_padded, int num_blocks, int acc, nf_stream_t stream) {
     if (!bits && B > 0) return NF_EFAULT;
     return maf_h_entry(z, y, logdet, blob, table, nullptr, scratch, B, D, hidden_padded, num_blocks, acc, stream, (unsigned int *)bits);
+}
+
+// ... and on a format-1 pack (table_host as in nf_maf_inverse_h_tri): the masks in THAT pack's positions, for a transposed pack built
+// with the same option (maf_pack.pack_made_transposed(tri=True)).
+extern "C" int nf_maf_inverse_h_tri_bits(const void *z, void *y, void *logdet, const void *blob, const int32_t *table,
+                                         const int32_t *table_host, void *scratch, void *bits, int64_t B, int D, int hidden_padded,
+                                         int num_blocks, int acc, nf_stream_t stream) {
+    if (!table_host || (!bits && B > 0)) return NF_EFAULT;
+    return maf_h_entry(z, y, logdet, blob, table, table_host, scratch, B, D, hidden_padded, num_blocks, acc, stream, (unsigned int *)bits);
 }
 
 // Scratch of nf_maf_solve_t: per row NL hidden_padded cotangents + the padded (g_us, g_sh) row + the tile-pair stash.

@@ -154,19 +154,21 @@ class MaskedAffineAutoregressive(Autoregressive):
         if config.maf_onepass and config.maf_halves:
             # round 5: the inverse on its FORMAT-0 pack (it leaves the ReLU masks in format-0 positions) + the transposed pack of the
             # one-pass solve (made_pack.maf_solve_t_structure), both gathered from the current parameters
+            tri = self._tri()          # the forward on the format-1 pack (fast kernel) when available; the masks follow its positions
             st = self.__dict__.get("_onepass_struct")
-            if st is None or st[0] != (str(device),) + skey:
-                s0 = made_pack.maf_inverse_structure(net, tri=False)
-                s2 = made_pack.maf_solve_t_structure(net)
+            if st is None or st[0] != (str(device), tri) + skey:
+                s0 = made_pack.maf_inverse_structure(net, tri=tri)
+                s2 = made_pack.maf_solve_t_structure(net, tri=tri)
                 val = None
                 if s0 is not None and s2 is not None:
                     dev = lambda a: torch.from_numpy(a).to(device)
-                    val = (dev(s0[0]), dev(s0[1]), int(s0[1][3]), int(s0[1][6]), int(s0[1][4]), dev(s2[0]), dev(s2[1]))
-                st = self.__dict__["_onepass_struct"] = ((str(device),) + skey, val)
+                    val = (dev(s0[0]), dev(s0[1]), int(s0[1][3]), int(s0[1][6]), int(s0[1][4]), dev(s2[0]), dev(s2[1]),
+                           s0[1] if tri else None)
+                st = self.__dict__["_onepass_struct"] = ((str(device), tri) + skey, val)
             if st[1] is not None:
-                src0, table0, hp, nb, tiles, src2, table2 = st[1]
+                src0, table0, hp, nb, tiles, src2, table2, th = st[1]
                 inv = {"blob": ops.pack_gather(plist, src0), "table": table0, "hp": hp, "nb": nb, "tiles": tiles,
-                       "tblob": ops.pack_gather(plist, src2), "ttable": table2}
+                       "tblob": ops.pack_gather(plist, src2), "ttable": table2, "table_host": th}
                 return inv, packs[0], packs[1]
         inv = self._inverse_struct(device)
         if inv is None:

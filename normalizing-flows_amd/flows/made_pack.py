@@ -656,14 +656,14 @@ def _maf_inverse_structure(made, blocks, tri=False):
     return _as_src(blob), table
 
 
-def maf_solve_t_structure(made, blocks=(1, 2, 3)):
+def maf_solve_t_structure(made, blocks=(1, 2, 3), tri=False):
     """(gather indices, table) of the transposed one-pass solve's pack (flows/maf_pack.pack_made_transposed) over the flat parameter
     vector of index_arrays -- the packer run on a copy of the MADE that holds parameter positions instead of values."""
     import copy
     from . import maf_pack
     if not maf_pack.supported(made, 2, blocks):
         return None
-    key = ("maf_solve_t", tuple(blocks), _mask_key(made))
+    key = ("maf_solve_t", tuple(blocks), bool(tri), _mask_key(made))
     if key in _STRUCTS:
         return _STRUCTS[key]
     st = None
@@ -674,7 +674,7 @@ def maf_solve_t_structure(made, blocks=(1, 2, 3)):
             for lin, (w, b) in zip(lins, index_arrays([tuple(l.weight.shape) for l in lins])):
                 lin.weight.copy_(torch.from_numpy(w.astype(np.float32)))
                 lin.bias.copy_(torch.from_numpy(b.astype(np.float32)))
-        blob, table = maf_pack.pack_made_transposed(twin, blocks=blocks)
+        blob, table = maf_pack.pack_made_transposed(twin, blocks=blocks, tri=tri)
         st = (_as_src(blob), table)
     _STRUCTS[key] = st
     return st

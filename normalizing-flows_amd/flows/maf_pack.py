@@ -361,7 +361,7 @@ def pack_made(made, mult=2, rows=False, blocks=(2,), tri=False):
 
 
 # ---- format 2 (round 5): the TRANSPOSED one-pass solve of the implicit backward (csrc/maf_solve_t.hip, autograd.MafInverseFn) ----
-def pack_made_transposed(made, blocks=(1, 2, 3)):
+def pack_made_transposed(made, blocks=(1, 2, 3), tri=False):
     """Pack of nf_maf_solve_t: the linear system  v s + J^T g_p(v, g_ld) = g_x  of the implicit backward of the MAF inverse
     (J = dMADE/dx at the solution, g_p the affine transform's parameter cotangent) solved by back-substitution in ONE pass.
 
@@ -376,7 +376,10 @@ def pack_made_transposed(made, blocks=(1, 2, 3)):
     tile are read back as they are.  Record per tile (processing order): A0' [K0'/8][2][32][4] (K0' = 2 x the virtual features
     before the tile, padded to 32) | A1'..A_{NL-1}', AF' [4t'][2][32][4] | W0d' [32][32] (window: 16 steps x 2 inputs) | Wd'[NL-1][32][32]
     | WFd' [32][32] (row j = step j).  No biases.  table: [D, 2D padded to 32, H, Hp, T, 1, NB, 2], per tile
-    [dlo', nsteps, K0', rec, mask[16] (virtual step order), forward tile index, 0, 0, 0]."""
+    [dlo', nsteps, K0', rec, mask[16] (virtual step order), forward tile index, 0, 0, 0].
+    `tri`: the positions of the FORMAT-1 forward pack (regular tiles / tiles with extras permuted, flows/maf_pack tile_row) -- for the
+    masks nf_maf_inverse_h_tri_bits leaves; the solve kernel's sequential part is driven by per-step position masks, so any position
+    assignment works."""
     if not supported(made, 2, blocks):
         return None
     base = pack_made(made, blocks=blocks)          # structure checks (degrees, masks) + the forward plan
@@ -394,14 +397,22 @@ def pack_made_transposed(made, blocks=(1, 2, 3)):
     Dq = (2 * D + 31) // 32 * 32
     # forward (format 0) padded slot of every unit, then the virtual slot: same position, tiles reversed
     fslot = np.zeros(H, dtype=np.int64)
+    step_masks = []                                   # per forward tile: position bitmask of every step
     k = 0
     for t, (dlo, ns, steps) in enumerate(tiles):
         b_ = t * TILE
-        for c in steps:
-            for _ in range(c):
-                fslot[order[k]] = b_
+        perm = bool(tri) and (is_regular(steps) or extras_prefix(steps) > 0)
+        sm = []
+        for g, c in enumerate(steps):
+            mk = 0
+            for i in range(c):
+                pos_ = tile_row(g, i) if perm else b_ - t * TILE
+                fslot[order[k]] = t * TILE + pos_
+                mk |= 1 << pos_
                 b_ += 1
                 k += 1
+            sm.append(mk)
+        step_masks.append(sm)
     vslot = (T - 1 - fslot // TILE) * TILE + fslot % TILE
     mw = lambda l: (l.weight.detach() * l.mask).cpu().numpy().astype(np.float32)
     W0 = mw(lin[0])                                   # (H, D)
@@ -454,11 +465,7 @@ def pack_made_transposed(made, blocks=(1, 2, 3)):
         e = TABLE_HDR + TABLE_ENT * tq
         table[e + 0], table[e + 1], table[e + 2], table[e + 3] = dloq, ns, K0, off
         # virtual step s' = forward step ns - 1 - s'; positions are the forward ones
-        u = 0
-        fmask = []
-        for c in steps:
-            fmask.append(np.array([((1 << c) - 1) << u], dtype=np.uint64).astype(np.uint32).view(np.int32)[0])
-            u += c
+        fmask = [np.array([mk], dtype=np.uint64).astype(np.uint32).view(np.int32)[0] for mk in step_masks[t]]
         for sq in range(ns):
             table[e + 4 + sq] = fmask[ns - 1 - sq]
         table[e + 20] = t

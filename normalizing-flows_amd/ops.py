@@ -1103,9 +1103,10 @@ def maf_inverse(z, blob, table, hidden_padded, logdet=None, acc=None, num_blocks
     return y, logdet
 
 
-def maf_inverse_bits(z, blob, table, hidden_padded, num_blocks, tiles):
-    """nf_maf_inverse_h_bits: the one-pass inverse on a FORMAT-0 pack that also leaves the pass's ReLU masks (uint32 words per
-    32-row wave, tile and lane) for maf_solve_t.  Returns (y, logdet, bits)."""
+def maf_inverse_bits(z, blob, table, hidden_padded, num_blocks, tiles, table_host=None):
+    """nf_maf_inverse_h_bits / nf_maf_inverse_h_tri_bits (table_host = the host copy of a format-1 table): the one-pass inverse that also
+    leaves the pass's ReLU masks (uint32 words per 32-row wave, tile and lane, in the pack's positions) for maf_solve_t on a
+    transposed pack of the same format.  Returns (y, logdet, bits)."""
     L.require_device(z, blob, table)
     if z.dtype != torch.float32:
         raise NotImplementedError("maf_inverse_bits: float32 only")
@@ -1117,6 +1118,13 @@ def maf_inverse_bits(z, blob, table, hidden_padded, num_blocks, tiles):
     n = lib.nf_maf_inverse_h_scratch_floats(i64(B), i32(D), i32(hidden_padded), i32(num_blocks))
     scratch = torch.empty(max(int(n), 1), dtype=torch.float32, device=z.device)
     bits = torch.empty(max((B + 31) // 32 * tiles * 64 * num_blocks, 1), dtype=torch.int32, device=z.device)
+    if table_host is not None:
+        import numpy as np
+        th = np.ascontiguousarray(table_host, dtype=np.int32)
+        rc = lib.nf_maf_inverse_h_tri_bits(ptr(z), ptr(y), ptr(logdet), ptr(blob), ptr(table), C.c_void_p(th.ctypes.data), ptr(scratch),
+                                           ptr(bits), i64(B), i32(D), i32(hidden_padded), i32(num_blocks), i32(L.LD_WRITE), L.stream())
+        L.check(rc, "nf_maf_inverse_h_tri_bits")
+        return y, logdet, bits
     rc = lib.nf_maf_inverse_h_bits(ptr(z), ptr(y), ptr(logdet), ptr(blob), ptr(table), ptr(scratch), ptr(bits), i64(B), i32(D),
                                    i32(hidden_padded), i32(num_blocks), i32(L.LD_WRITE), L.stream())
     L.check(rc, "nf_maf_inverse_h_bits")

@@ -1200,8 +1200,9 @@ def test_made_forward_spline_pack_matches_dense_made(D, H, NB):
     assert made_pack.pack_made_forward(nets.MADE(features=8, hidden_features=16, num_blocks=2, output_multiplier=29), 29, spline=True) is None
 
 
-@pytest.mark.parametrize("D,H,NB", [(12, 40, 2), (17, 40, 1), (20, 64, 2), (10, 36, 3), (40, 39, 2), (33, 70, 2)])
-def test_maf_transposed_pack_solves_the_implicit_system(D, H, NB):
+@pytest.mark.parametrize("tri", [False, True])
+@pytest.mark.parametrize("D,H,NB", [(12, 40, 2), (17, 40, 1), (20, 64, 2), (10, 36, 3), (40, 39, 2), (33, 70, 2), (9, 34, 1), (64, 256, 2)])
+def test_maf_transposed_pack_solves_the_implicit_system(D, H, NB, tri):
     """flows/maf_pack.pack_made_transposed + the schedule of csrc/maf_solve_t.hip (numpy emulation, tests/maf_emulator.py) solve
     v s + J^T g_p(v, g_ld) = g_x -- the linear system of autograd.MafInverseFn's backward -- in ONE pass: against the dense solution
     assembled from float64 autograd (J^T through torch.autograd.grad on the reference-structured MADE)."""
@@ -1213,8 +1214,8 @@ def test_maf_transposed_pack_solves_the_implicit_system(D, H, NB):
     made = nets.MADE(features=D, hidden_features=H, num_blocks=NB, output_multiplier=2)
     with torch.no_grad():
         for p in made.parameters():
-            p.add_(0.3 * torch.randn_like(p))
-    blob, table = maf_pack.pack_made_transposed(made, blocks=(1, 2, 3))
+            p.add_((0.3 if H < 100 else 0.03) * torch.randn_like(p))      # (wide nets: keep the triangular system well conditioned)
+    blob, table = maf_pack.pack_made_transposed(made, blocks=(1, 2, 3), tri=tri)    # tri: the format-1 forward pack's positions
     assert table[7] == 2 and table[6] == NB and table[1] % 32 == 0
     T, Hp = int(table[4]), int(table[3])
     B = 5
@@ -1250,9 +1251,10 @@ def test_maf_transposed_pack_solves_the_implicit_system(D, H, NB):
     k = 0
     for t, (dlo, ns, steps) in enumerate(tiles):
         b_ = 32 * t
-        for c_ in steps:
-            for _ in range(c_):
-                fslot[order[k]] = b_
+        perm = tri and (maf_pack.is_regular(steps) or maf_pack.extras_prefix(steps) > 0)
+        for g_, c_ in enumerate(steps):
+            for i_ in range(c_):
+                fslot[order[k]] = 32 * t + (maf_pack.tile_row(g_, i_) if perm else b_ - 32 * t)
                 b_ += 1
                 k += 1
     vslot = (T - 1 - fslot // 32) * 32 + fslot % 32

@@ -45,8 +45,27 @@ def maf():
     return m, eps, loss
 
 
+def c2():
+    """the benchmark model (BASELINE configs[1]) and batch: forward_kld + backward"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from bench import build_c2_model, c2_inputs
+    m = build_c2_model().to(dev)
+    return m, c2_inputs().to(dev), lambda mm, xx: mm.forward_kld(xx)
+
+
+def maf_density():
+    """config 5 in the DENSITY direction (forward_kld = flow.inverse under autograd): one-pass implicit backward (round 5)"""
+    torch.manual_seed(0)
+    m = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(128, trainable=False),
+                            [nfa.flows.MaskedAffineAutoregressive(128, 512, num_blocks=2) for _ in range(10)]).to(dev)
+    return m, torch.randn(65536, 128, device=dev), lambda mm, xx: mm.forward_kld(xx)
+
+
 out = {}
-for name, build in (("glow_c4", glow), ("maf_c5_single_pass", maf)):
+which = sys.argv[1:] or ["glow_c4", "maf_c5_single_pass", "c2_benchmark_model", "maf_c5_density"]
+for name, build in (("glow_c4", glow), ("maf_c5_single_pass", maf), ("c2_benchmark_model", c2), ("maf_c5_density", maf_density)):
+    if name not in which:
+        continue
     m, x, lossfn = build()
 
     def step():
