@@ -1659,6 +1659,35 @@ def test_training_step_captures_into_one_graph(nfa):
         assert all(torch.equal(a, p.grad) for a, p in zip(eager, m.parameters()))
 
 
+def test_maf_one_pass_backward_on_format0_and_format1_packs(nfa):
+    """The one-pass implicit backward with the forward on the format-1 pack (default: fast inverse kernel, masks in its positions,
+    nf_maf_inverse_h_tri_bits) and on the format-0 pack (config.set_maf_tri(False): nf_maf_inverse_h_bits): the two position
+    conventions give the same gradients (summation order differs: 2e-5), at config 5's layer shape (tile 0 = kind 2) and at a shape
+    whose tiles are all generic."""
+    for D, H in ((128, 512), (40, 100)):
+        torch.manual_seed(D)
+        layer = nfa.flows.MaskedAffineAutoregressive(D, H, num_blocks=2)
+        with torch.no_grad():
+            for p in layer.parameters():
+                p.add_(0.03 * torch.randn_like(p))
+        layer = layer.to(DEV)
+        z0 = torch.randn(300, D, device=DEV)
+        cx, cl = torch.randn(300, D, device=DEV), torch.randn(300, device=DEV)
+        res = []
+        try:
+            for tri in (True, False):
+                nfa.config.set_maf_tri(tri)
+                layer.zero_grad(set_to_none=True)
+                z = z0.clone().requires_grad_(True)
+                x, ld = layer.inverse(z)
+                ((x * cx).sum() + (ld * cl).sum()).backward()
+                res.append([x.detach(), ld.detach(), z.grad] + [p.grad.clone() for p in layer.parameters()])
+        finally:
+            nfa.config.set_maf_tri(True)
+        for a, b in zip(res[0], res[1]):
+            assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), (D, float((a - b).abs().max()))
+
+
 @pytest.mark.parametrize("which", ["x_only", "ld_only"])
 def test_maf_implicit_backward_with_one_cotangent_absent(nfa, which):
     """The implicit backward when the loss sees only the outputs or only the log-det (the other cotangent arrives as None), and with
