@@ -937,6 +937,91 @@ class MafInverseFn(torch.autograd.Function):
         return (None, None, None, v if ctx.needs_input_grad[3] else None) + tuple(grads)
 
 
+class ArInverseImplicitFn(torch.autograd.Function):
+    """`Autoregressive.inverse` (autoregressive.py:29-40: D passes of the autoregressive net, each recorded by autograd in the
+    reference) under autograd for ANY element-wise transform -- the autoregressive spline layer's sampling direction
+    (neural_spline/autoregressive.py:94-134 through wrapper.py:140-155), the circular variant, MAF structures the one-pass kernels do
+    not take -- differentiated IMPLICITLY like MafInverseFn, on the layer's own density-direction graph instead of special kernels:
+
+        forward   x, ld = layer.inverse(z) without a graph (one launch where nf_arnsf_inverse / nf_maf_inverse_h apply)
+        backward  with F(x, W) = f(x; theta(x, W)) (= z) and l(x, W) = log|dF/dx| (ld = -l) rebuilt ONCE at the final x
+                  (one autoregressive-net pass + the element-wise transform, parameters frozen):
+                  A^T v = g_x - g_ld dl/dx,  A^T = diag(s) + N^T,  s = df/dx at fixed theta,  N = (df/dtheta)(dtheta/dx)
+                  by v <- v + (g_x - VJP_x[(F, l); (v, g_ld)]) / s: N is strictly triangular in the feature order, the iteration is
+                  EXACT after at most D updates and stops earlier when v no longer moves (config.maf_implicit_rtol; checked every
+                  other sweep); then g_z = v and g_W = VJP_W[(F, l); (-v, -g_ld)] on a second pass with the parameters attached.
+
+    One backward of the net per sweep and ONE weight-gradient pass instead of D forward + D backward passes and D saved graphs."""
+    last_sweeps = 0
+
+    @staticmethod
+    def eligible(layer, inputs, context):
+        if context is not None or inputs.dim() != 2 or not _config.ar_implicit:
+            return False
+        for m in layer.modules():
+            if m.training and (isinstance(m, torch.nn.modules.batchnorm._BatchNorm) or (isinstance(m, torch.nn.Dropout) and m.p > 0)):
+                return False      # (the graph rebuilt in backward must be THE function the forward inverted)
+        return True
+
+    @staticmethod
+    def forward(ctx, layer, z, *params):
+        with torch.no_grad():
+            x, ld = layer.inverse(z)
+        ctx.layer, ctx.params = layer, params
+        ctx.save_for_backward(x, *params)          # (the parameters: autograd's in-place-modification check between forward and backward)
+        ctx.set_materialize_grads(False)
+        return x, ld
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gx, gld):
+        x = ctx.saved_tensors[0]
+        layer, params = ctx.layer, ctx.params
+        D = x.shape[1]
+        net = layer.autoregressive_net
+        capturing = x.is_cuda and torch.cuda.is_current_stream_capturing()
+        rtol = _config.maf_implicit_rtol
+        with torch.enable_grad():
+            xa = x.detach().requires_grad_(True)          # the transform's own argument
+            xb = x.detach().requires_grad_(True)          # the autoregressive net's input
+            frozen = {n: p.detach() for n, p in net.named_parameters()}
+            theta = torch.func.functional_call(net, frozen, (xb,))
+            zf, lf = layer._elementwise(xa, theta, 0)
+            (s,) = torch.autograd.grad([zf], [xa], [torch.ones_like(zf)], retain_graph=True)
+            rhs = torch.zeros_like(x) if gx is None else gx
+            if gld is not None:       # the log-determinant's direct dependence on x: independent of v, taken once
+                rhs = rhs - torch.autograd.grad([lf], [xa], [gld], retain_graph=True)[0]
+            outs, v, sweeps = ([zf] if gld is None else [zf, lf]), rhs / s, 1
+            # v_new = (rhs - N^T v - g_ld dl/dx_b) / s reads v only through the net (components > i of v for component i): a component
+            # is final -- and equal to back-substitution's -- one sweep after the components it depends on are
+            while sweeps < D + 1:
+                (gb,) = torch.autograd.grad(outs, [xb], [v] if gld is None else [v, gld], retain_graph=True, allow_unused=True)
+                if gb is None:
+                    break
+                v_new = (rhs - gb) / s
+                sweeps += 1
+                done = False
+                if not capturing and (sweeps % 2 == 0 or sweeps == D + 1):
+                    if rtol > 0.0:
+                        done = float((v_new - v).abs().max()) <= rtol * float(v_new.abs().max())
+                    else:
+                        done = bool(torch.equal(v_new, v))
+                v = v_new
+                if done:
+                    break
+            ArInverseImplicitFn.last_sweeps = sweeps
+            del zf, lf, theta, outs, xa, xb
+            grads = [None] * len(params)
+            want = [i for i, p in enumerate(params) if ctx.needs_input_grad[2 + i]]
+            if want:
+                zf, lf = layer.forward(x.detach())
+                got = torch.autograd.grad([zf] if gld is None else [zf, lf], [params[i] for i in want],
+                                          [-v] if gld is None else [-v, -gld], allow_unused=True)
+                for i, g in zip(want, got):
+                    grads[i] = g
+        return (None, v if ctx.needs_input_grad[1] else None) + tuple(grads)
+
+
 class MafAffineFn(torch.autograd.Function):
     """nf_maf_affine (affine/autoregressive.py:98-128) on given MADE output `params` (B, 2D); backward = nf_maf_affine_bwd."""
 

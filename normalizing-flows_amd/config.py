@@ -156,6 +156,17 @@ maf_implicit = True
 maf_implicit_rtol = 0.0
 
 
+# Autoregressive.inverse under autograd for the other element-wise transforms (AR-NSF sampling, circular splines, MAF structures
+# outside the one-pass kernels): implicit differentiation on the layer's own density-direction graph (autograd.ArInverseImplicitFn:
+# <= D backward sweeps of the net + one weight-gradient pass).  False = the reference's D recorded passes.
+ar_implicit = True
+
+
+def set_ar_implicit(mode=True):
+    global ar_implicit
+    ar_implicit = bool(mode)
+
+
 def set_maf_implicit(mode=True, rtol=None):
     global maf_implicit, maf_implicit_rtol
     maf_implicit = bool(mode)

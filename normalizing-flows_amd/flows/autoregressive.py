@@ -38,6 +38,13 @@ class Autoregressive(Flow):
         return self._elementwise(inputs, params, 0)
 
     def inverse(self, inputs, context=None):
+        if autograd.needs_grad(inputs, *self.parameters()) and autograd.ArInverseImplicitFn.eligible(self, inputs, context):
+            # implicit differentiation (one graph-free inverse + <= D backward sweeps) instead of D recorded passes
+            return autograd.ArInverseImplicitFn.apply(self, inputs, *self.parameters())
+        return self._inverse_loop(inputs, context)
+
+    def _inverse_loop(self, inputs, context=None):
+        """autoregressive.py:29-40: D passes of the net, feature i final after pass i (recorded one by one under autograd)."""
         num_inputs = int(np.prod(inputs.shape[1:]))
         outputs = torch.zeros_like(inputs)
         logabsdet = None
@@ -138,6 +145,8 @@ class MaskedAffineAutoregressive(Autoregressive):
             if packs is not None:          # autograd.MafInverseFn: implicit differentiation instead of autograd through the D passes
                 plist = [t for l in self.autoregressive_net._linears() for t in (l.weight, l.bias)]
                 return autograd.MafInverseFn.apply(packs[0], packs[1], packs[2], inputs, *plist)
+        if not config.maf_implicit:        # (the reference's D recorded passes, asked for explicitly)
+            return self._inverse_loop(inputs, context)
         return super().inverse(inputs, context)
 
     def _implicit_packs(self, device):

@@ -1611,6 +1611,69 @@ def test_maf_density_direction_implicit_vs_d_pass_autograd(nfa, D, H, NB, B, one
         assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max())), (k, float((a - b).abs().max()), float(b.abs().max()))
 
 
+@pytest.mark.parametrize("kind,D,H,B,dtype", [("arnsf", 12, 40, 300, torch.float32), ("arnsf", 33, 64, 130, torch.float32),
+                                              ("arnsf", 9, 24, 50, torch.float64), ("circular", 6, 32, 200, torch.float32),
+                                              ("circular", 5, 16, 40, torch.float64), ("maf_ctx_free_f64", 10, 24, 60, torch.float64)])
+def test_autoregressive_inverse_implicit_vs_d_pass_autograd(nfa, kind, D, H, B, dtype):
+    """`Autoregressive.inverse` under autograd beyond MAF's one-pass kernels -- the autoregressive spline layer's sampling direction
+    (neural_spline/autoregressive.py:94-134, wrapper.py:140-155), the circular variant (wrapper.py:158-235), a float64 MAF: implicit
+    differentiation on the layer's own density-direction graph (autograd.ArInverseImplicitFn: one graph-free inverse, <= D + 1 backward
+    sweeps of the net, one weight-gradient pass) against torch autograd through the reference's D recorded passes
+    (config.set_ar_implicit(False)): outputs and every gradient to 2e-4 of scale in float32, 1e-9 in float64."""
+    from normflows_amd.autograd import ArInverseImplicitFn
+    torch.manual_seed(D * 7 + H)
+    if kind == "arnsf":
+        layer = nfa.flows.AutoregressiveRationalQuadraticSpline(D, 2, H)
+        z0 = 1.5 * torch.randn(B, D)
+    elif kind == "circular":
+        layer = nfa.flows.CircularAutoregressiveRationalQuadraticSpline(D, 1, H, [1, 3],
+                                                                        tail_bound=torch.tensor(([5.0, 3.14159, 4.0, 3.14159] + [5.0] * D)[:D]))
+        z0 = torch.randn(B, D).clamp(-3.0, 3.0)
+    else:
+        layer = nfa.flows.MaskedAffineAutoregressive(D, H, num_blocks=2)
+        z0 = torch.randn(B, D)
+    gen = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=gen))
+    layer = layer.to(DEV).to(dtype)
+    z0 = z0.to(DEV).to(dtype)
+    cx, cl = torch.randn(B, D, device=DEV, dtype=dtype), torch.randn(B, device=DEV, dtype=dtype)
+    # AutoregressiveRationalQuadraticSpline.forward = the sampling direction = the inner transform's inverse (D passes in the reference)
+    run = (lambda zz: layer.inverse(zz)) if kind.startswith("maf") else (lambda zz: layer.forward(zz))
+    res = []
+    ArInverseImplicitFn.last_sweeps = 0
+    for mode in (True, False):
+        nfa.config.set_ar_implicit(mode)
+        try:
+            layer.zero_grad(set_to_none=True)
+            z = z0.clone().requires_grad_(True)
+            x, ld = run(z)
+            ((x * cx).sum() + (ld * cl).sum()).backward()
+            res.append([x.detach(), ld.detach(), z.grad] + [p.grad.clone() for p in layer.parameters()])
+        finally:
+            nfa.config.set_ar_implicit(True)
+    assert 1 <= ArInverseImplicitFn.last_sweeps <= D + 1
+    tol = 2e-4 if dtype == torch.float32 else 1e-9
+    for k, (a, b) in enumerate(zip(res[0], res[1])):
+        assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max())), (k, float((a - b).abs().max()), float(b.abs().max()))
+    # one cotangent absent (set_materialize_grads(False): None reaches the backward)
+    for which in ("x", "ld"):
+        out = []
+        for mode in (True, False):
+            nfa.config.set_ar_implicit(mode)
+            try:
+                layer.zero_grad(set_to_none=True)
+                z = z0.clone().requires_grad_(True)
+                x, ld = run(z)
+                ((x * cx).sum() if which == "x" else (ld * cl).sum()).backward()
+                out.append([z.grad] + [p.grad.clone() for p in layer.parameters()])
+            finally:
+                nfa.config.set_ar_implicit(True)
+        for k, (a, b) in enumerate(zip(out[0], out[1])):
+            assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max())), (which, k, float((a - b).abs().max()))
+
+
 def test_training_step_captures_into_one_graph(nfa):
     """forward + backward of the hand-written training paths (MADE Function, conv conditioner, 1x1-conv LU parametrisation, couplings,
     ActNorm) records into ONE hipGraph with PyTorch's whole-network capture recipe -- no host synchronisation, no host-side packing in
