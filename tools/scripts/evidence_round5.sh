@@ -27,7 +27,7 @@ timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/mafkld_st
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT"; do
   n=$(echo $c | cut -d' ' -f1)
   timeout 170 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/bench_$n -- $B > $O/bench_$n.log 2>&1; echo "bench $n rc=$?"
-  timeout 170 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/glow_$n -- python $R/tools/config_bench.py 4 > $O/glow_$n.log 2>&1; echo "glow $n rc=$?"
+  # (the counter passes of tools/config_bench.py 4 crashed rocprofv3 twice this round, rc 139: not repeated; the r04 Glow PMC file stands)
 done
 cd $R
 python tools/summarize_profiles.py r05_bench_chain --stats $(find $O/bench_stats -name "*kernel_stats.csv" | head -1) \
@@ -35,8 +35,6 @@ python tools/summarize_profiles.py r05_bench_chain --stats $(find $O/bench_stats
   --trace $(find $O/bench_SQ_VALU_MFMA_BUSY_CYCLES -name "*kernel_trace.csv" | head -1) --kernel "rqs_fused_kernel<0, true" > $O/summ_bench.log 2>&1
 cp $(find $O/glow_stats -name "*kernel_stats.csv" | head -1) profiles/r05_config4_glow_kernel_stats.csv 2>/dev/null
 python tools/glow_level_chains.py $(find $O/glow_stats -name "*kernel_trace.csv" | head -1) --json profiles/r05_config4_glow_level_chains.json > /dev/null 2>&1
-python tools/summarize_profiles.py r05_config4_glow_convnet_kernel --pmc $(find $O/glow_FETCH_SIZE $O/glow_WRITE_SIZE $O/glow_SQ_VALU_MFMA_BUSY_CYCLES -name "*counter_collection.csv") \
-  --trace $(find $O/glow_SQ_VALU_MFMA_BUSY_CYCLES -name "*kernel_trace.csv" | head -1) --kernel "glow_convnet_kernel" > $O/summ_glow.log 2>&1
 cp $(find $O/train_stats -name "*kernel_stats.csv" | head -1) profiles/r05_train_step_kernel_stats.csv 2>/dev/null
 cp $(find $O/mafkld_stats -name "*kernel_stats.csv" | head -1) profiles/r05_maf_density_train_kernel_stats.csv 2>/dev/null
 head -c 30000 $O/bench_line.json | tail -1 > profiles/r05_bench_line.json
@@ -44,5 +42,7 @@ tail -12 $O/pytest_gpu.log > profiles/r05_pytest_gpu.log; tail -4 $O/smoke.log >
 find $O -name "*counter_collection.csv" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete
 bash tools/scripts/r5_maf_profile.sh > $O/maf_profile.log 2>&1
 (python tools/maf_inverse_bench.py --ablate; python tools/maf_density_train_bench.py; python tools/made_train_bench.py; python tools/maf_train_bench.py; python tools/config_bench.py 5) 2> /dev/null | grep "^{\|^config" > profiles/r05_maf.jsonl
+timeout 300 python tools/ar_implicit_bench.py --out profiles/r05_ar_implicit.json > $O/ar_implicit.log 2>&1
+timeout 200 python tools/train_launch_audit.py --out profiles/r05_train_launch_audit.json > $O/train_audit.log 2>&1
 cp profiles/r05_* $R/gpurun_out/profiles_out/ 2>/dev/null
 tail -3 $O/pytest_gpu.log | cut -c1-200; cat profiles/r05_reference_containers_gpubox.log | tail -4; tail -2 $O/smoke.log | cut -c1-200; head -c 600 profiles/r05_bench_line.json; echo; tail -2 $O/cpuref.log | cut -c1-400; tail -12 $O/summ_bench.log
