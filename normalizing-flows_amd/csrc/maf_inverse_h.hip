@@ -660,8 +660,17 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
 #undef MAFH_DOT
         }
         // ---- publish the tile: the register quads ARE the B-operand entries (k-block 4 t + q, half hh) ----
+        // Not the tiles nobody streams back: the layer's last tile, and on the fast path (tile t + 1 contracts tile t from the
+        // registers) the one before it when this launch runs through the end of the layer (a later LAUNCH would reload it).
+#ifdef NF_MAF_ABL_PUBLISH_ALL
+        const bool pub = true;
+#else
+        const bool pub = FAST ? (t + 2 < T || (t + 1 < T && t_stop < T)) : t + 1 < T;
+#endif
 #ifdef NF_MAF_ABL_NO_PUBLISH
         if (p[0][0] == 1.2345f)
+#else
+        if (pub)
 #endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -873,6 +882,7 @@ maf_solve_t_kernel(const float *__restrict__ x, const float *__restrict__ prm, c
             }
         }
 #undef MAFT_DOT
+        if (t + 1 < T)       // (the last tile's activations are streamed back by nobody)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const size_t o = ((size_t)((4 * t + q) * 2 + hh) * 32 + n) * 4;

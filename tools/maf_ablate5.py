@@ -33,6 +33,7 @@ VARIANTS = {
     "core_all": "-DNF_MAF_ABL_NO_DMA -DNF_MAF_ABL_NO_SEQ -DNF_MAF_ABL_NO_BARRIER -DNF_MAF_ABL_NO_STAGE -DNF_MAF_ABL_NO_PUBLISH -DNF_MAF_ABL_NO_BIAS",
     "nobarrier": "-DNF_MAF_ABL_NO_BARRIER",
     "nopublish": "-DNF_MAF_ABL_NO_PUBLISH",
+    "puball": "-DNF_MAF_ABL_PUBLISH_ALL",      # also the tiles nobody streams back (the build before the last change of round 5)
 }
 
 
