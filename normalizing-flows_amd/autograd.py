@@ -989,8 +989,10 @@ class ArInverseImplicitFn(torch.autograd.Function):
             zf, lf = layer._elementwise(xa, theta, 0)
             (s,) = torch.autograd.grad([zf], [xa], [torch.ones_like(zf)], retain_graph=True)
             rhs = torch.zeros_like(x) if gx is None else gx
-            if gld is not None:       # the log-determinant's direct dependence on x: independent of v, taken once
-                rhs = rhs - torch.autograd.grad([lf], [xa], [gld], retain_graph=True)[0]
+            if gld is not None:       # the log-determinant's direct dependence on x: independent of v, taken once (none for affine maps)
+                (dl,) = torch.autograd.grad([lf], [xa], [gld], retain_graph=True, allow_unused=True)
+                if dl is not None:
+                    rhs = rhs - dl
             outs, v, sweeps = ([zf] if gld is None else [zf, lf]), rhs / s, 1
             # v_new = (rhs - N^T v - g_ld dl/dx_b) / s reads v only through the net (components > i of v for component i): a component
             # is final -- and equal to back-substitution's -- one sweep after the components it depends on are

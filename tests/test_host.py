@@ -1085,6 +1085,53 @@ def test_implicit_differentiation_of_the_maf_inverse_vs_reference_d_pass_autogra
     assert all(float((a - b).abs().max()) <= 1e-11 * max(1.0, float(b.abs().max())) for a, b in zip(got, ref))
 
 
+@pytest.mark.parametrize("kind", ["arnsf", "circular", "maf"])
+def test_generic_implicit_inverse_function_on_the_reference_own_layers(kind):
+    """autograd.ArInverseImplicitFn -- the Function itself, on the CPU, in float64 -- driving the REFERENCE's own autoregressive layers
+    through a three-method adapter (inverse / forward / the element-wise transform at given parameters): the autoregressive spline
+    layer (neural_spline/autoregressive.py:11-134), its circular variant, the affine layer.  Gradients of x = T^-1(z) and its
+    log-determinant for random cotangents against torch autograd through the reference's D recorded passes
+    (autoregressive.py:29-40): 1e-10 of scale, at most D + 1 sweeps; each cotangent alone as well."""
+    sys.path.insert(0, REF)
+    nf = pytest.importorskip("normflows")
+    from normflows_amd.autograd import ArInverseImplicitFn
+    torch.manual_seed(3)
+    D, H, B = 7, 20, 9
+    if kind == "arnsf":
+        ref = nf.flows.AutoregressiveRationalQuadraticSpline(D, 2, H).mprqat
+        z0 = 1.5 * torch.randn(B, D, dtype=torch.float64)
+    elif kind == "circular":
+        ref = nf.flows.CircularAutoregressiveRationalQuadraticSpline(D, 1, H, [1, 4], tail_bound=torch.tensor([5.0, 3.0, 4.0, 5.0, 3.14159, 5.0, 5.0])).mprqat
+        z0 = torch.randn(B, D, dtype=torch.float64).clamp(-2.9, 2.9)
+    else:
+        ref = nf.flows.MaskedAffineAutoregressive(D, H, num_blocks=2)
+        z0 = torch.randn(B, D, dtype=torch.float64)
+    ref = ref.double()
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.add_(0.2 * torch.randn_like(p))
+
+    class Adapter:
+        autoregressive_net = ref.autoregressive_net
+        inverse = staticmethod(lambda z: ref.inverse(z))
+        forward = staticmethod(lambda x: ref.forward(x))
+        _elementwise = staticmethod(lambda x, theta, direction: ref._elementwise_forward(x, theta))
+    params = tuple(ref.parameters())
+    cx, cl = torch.randn(B, D, dtype=torch.float64), torch.randn(B, dtype=torch.float64)
+    for use_x, use_l in ((True, True), (True, False), (False, True)):
+        out = []
+        for implicit in (False, True):
+            ref.zero_grad(set_to_none=True)
+            z = z0.clone().requires_grad_(True)
+            x, ld = ArInverseImplicitFn.apply(Adapter, z, *params) if implicit else ref.inverse(z)
+            ((x * cx).sum() * float(use_x) + (ld * cl).sum() * float(use_l) if (use_x and use_l) else
+             ((x * cx).sum() if use_x else (ld * cl).sum())).backward()
+            out.append([x.detach(), ld.detach(), z.grad] + [p.grad.clone() for p in params])
+        assert 1 <= ArInverseImplicitFn.last_sweeps <= D + 1
+        for k, (a, b) in enumerate(zip(out[1], out[0])):
+            assert float((a - b).abs().max()) <= 1e-10 * max(1.0, float(b.abs().max())), (kind, use_x, use_l, k, float((a - b).abs().max()))
+
+
 def test_made_forward_pack_rejects_unsupported():
     from normflows_amd import nets
     from normflows_amd.flows import made_pack
