@@ -653,8 +653,8 @@ class ActNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, s, t, direction):
-        ld = torch.zeros(z.shape[0], dtype=z.dtype, device=z.device)
-        y, _ = ops.actnorm(z, s.detach(), t.detach(), direction, logdet=ld, acc=1, want_scalar=False)
+        ld = torch.empty(z.shape[0], dtype=z.dtype, device=z.device)        # (written, not accumulated: no zero fill per call)
+        y, _ = ops.actnorm(z, s.detach(), t.detach(), direction, logdet=ld, acc=L.LD_WRITE, want_scalar=False)
         ctx.save_for_backward(z, s, t)
         ctx.direction = direction
         return y, ld
@@ -690,6 +690,9 @@ class Inv1x1WeightFn(torch.autograd.Function):
         return None, gL, gU, None, gs
 
 
+_ZERO0 = {}
+
+
 class Inv1x1Fn(torch.autograd.Function):
     """Per-pixel C x C product (mixing.py:106-133) with a given matrix W and per-pixel log|det| `ldu` (0-dim)."""
 
@@ -707,7 +710,9 @@ class Inv1x1Fn(torch.autograd.Function):
             gy = torch.zeros_like(z)
         gz = gW = gl = None
         if z.shape[1] <= 64:
-            zero = torch.zeros((), dtype=z.dtype, device=z.device)
+            zero = _ZERO0.get((z.device, z.dtype))        # (a cached device scalar: no fill launch per block and step)
+            if zero is None:
+                zero = _ZERO0[(z.device, z.dtype)] = torch.zeros((), dtype=z.dtype, device=z.device)
             if ctx.needs_input_grad[0]:      # gz = W^T gy per pixel: the forward kernel on the transposed matrix
                 gz, _ = ops.inv1x1_conv(gy.contiguous(), W.detach().t().contiguous(), zero, want_scalar=False)
             if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:

@@ -17,18 +17,35 @@ from bench import build_c2_model, c2_inputs  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=65536)
 ap.add_argument("--out", default="")
+ap.add_argument("--model", default="c2", choices=["c2", "glow"], help="c2: the benchmark model (+ Adam); glow: config 4, forward_kld + backward")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
-m = build_c2_model().to(dev)
-x = c2_inputs(a.batch).to(dev)
-opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+if a.model == "c2":
+    m = build_c2_model().to(dev)
+    x = c2_inputs(a.batch).to(dev)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+else:
+    import normflows_amd as nfa
+    torch.manual_seed(0)
+    q0, merges, flows = [], [], []
+    for i in range(3):
+        flows += [[nfa.flows.GlowBlock(3 * 2 ** (4 - i), 256, split_mode="channel", scale=True) for _ in range(32)] + [nfa.flows.Squeeze()]]
+        if i > 0:
+            merges += [nfa.flows.Merge()]
+        q0 += [nfa.distributions.DiagGaussian((3 * 2 ** (3 - i), 32 // 2 ** (3 - i), 32 // 2 ** (3 - i)) if i > 0 else (48, 4, 4))]
+    m = nfa.MultiscaleFlow(q0, flows, merges, class_cond=False).to(dev)
+    x = torch.rand(256, 3, 32, 32, device=dev)
+    with torch.no_grad():
+        m.log_prob(x)
+    opt = None
 
 
 def step():
-    opt.zero_grad(set_to_none=True)
+    m.zero_grad(set_to_none=True)
     loss = m.forward_kld(x)
     loss.backward()
-    opt.step()
+    if opt is not None:
+        opt.step()
 
 
 for _ in range(3):
@@ -39,7 +56,9 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     step()
     torch.cuda.synchronize()
 WATCH = ("aten::fill_", "aten::zero_", "aten::copy_", "aten::clone", "aten::index_select", "aten::contiguous", "aten::neg",
-         "aten::sum", "aten::add_", "aten::mul", "aten::add", "aten::index_copy_", "aten::zeros", "aten::zeros_like")
+         "aten::sum", "aten::add_", "aten::mul", "aten::add", "aten::index_copy_", "aten::zeros", "aten::zeros_like", "aten::cat",
+         "aten::sub", "aten::div", "aten::exp", "aten::mean", "aten::empty_like", "aten::view_as", "aten::mul_", "aten::sigmoid",
+         "aten::log", "aten::index", "aten::index_put_", "aten::triu", "aten::tril", "aten::diag", "aten::matmul", "aten::mm")
 by_site = collections.Counter()
 kernels = collections.Counter()
 for ev in prof.events():
@@ -50,7 +69,7 @@ for ev in prof.events():
         continue
     site = "?"
     for fr in ev.stack or ():
-        if "normalizing-flows_amd" in fr or "normflows_amd" in fr or "bench.py" in fr:
+        if ("normalizing-flows_amd" in fr or "normflows_amd" in fr or "bench.py" in fr) and "_lib.py" not in fr:
             site = fr.split("/")[-1]
             break
     by_site[(ev.name, site)] += 1
