@@ -177,11 +177,25 @@ actnorm_bwd_reduce_kernel(const double *__restrict__ partial, const T *__restric
     __shared__ double glb;
     if (threadIdx.x == 0) glb = gl;
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    // thread = (channel c0, slice q of the splits): Q slices per channel summed through LDS in slice order (deterministic).  Round 5:
+    // one thread per channel walked all ~2048 / C splits alone -- 26 us per call for 12-48 channels, 96 calls per Glow step.
+    __shared__ double pas[256], pat[256];
+    const int Cq = C < 256 ? C : 256, Q = 256 / Cq;
+    const int q = threadIdx.x / Cq, c0 = threadIdx.x - q * Cq;
+    for (int cb = 0; cb < C; cb += Cq) {
+        const int c = cb + c0;
         double as = 0.0, at = 0.0;
-        for (int j = 0; j < nsplit; ++j) { as += partial[((int64_t)j * C + c) * 2]; at += partial[((int64_t)j * C + c) * 2 + 1]; }
-        gs[c] = (T)(as + (direction == 0 ? 1.0 : -1.0) * (double)HW * glb);
-        gt[c] = (T)at;
+        if (q < Q && c < C)
+            for (int j = q; j < nsplit; j += Q) { as += partial[((int64_t)j * C + c) * 2]; at += partial[((int64_t)j * C + c) * 2 + 1]; }
+        pas[threadIdx.x] = as;
+        pat[threadIdx.x] = at;
+        __syncthreads();
+        if (q == 0 && c < C) {
+            for (int k = 1; k < Q; ++k) { as += pas[k * Cq + c0]; at += pat[k * Cq + c0]; }
+            gs[c] = (T)(as + (direction == 0 ? 1.0 : -1.0) * (double)HW * glb);
+            gt[c] = (T)at;
+        }
+        __syncthreads();
     }
 }
 
@@ -364,15 +378,20 @@ __global__ void __launch_bounds__(64)
 inv1x1_lu_grads_kernel(const T *__restrict__ P, const T *__restrict__ L, const T *__restrict__ U, const T *__restrict__ sign_S,
                        const T *__restrict__ log_S, const T *__restrict__ gW, const T *__restrict__ gl, T *__restrict__ gL,
                        T *__restrict__ gU, T *__restrict__ glogS, int C) {
-    // one workgroup per output row i, thread j per column: row i of A = P^T gW and column i of P Lm through LDS
+    // one workgroup per output row i, thread j per column: row i of A = P^T gW and column i of P Lm through LDS.  Round 5: P, gW, U and
+    // column i of Lm are staged in LDS first (coalesced) -- the loops below were ~6 C dependent global loads per thread, 18 us per call
+    extern __shared__ __attribute__((aligned(16))) unsigned char lg_raw[];
+    T *Ps = reinterpret_cast<T *>(lg_raw), *Gs = Ps + C * C, *Us = Gs + C * C, *lmc = Us + C * C;
     __shared__ T a[64], plc[64];
     const int i = blockIdx.x, j = threadIdx.x;
+    for (int e = j; e < C * C; e += 64) { Ps[e] = P[e]; Gs[e] = gW[e]; Us[e] = U[e]; }
+    for (int k = j; k < C; k += 64) lmc[k] = k > i ? L[k * C + i] : (k == i ? T(1) : T(0));     // Lm[k][i]
+    __syncthreads();
     if (j < C) {
         T av = T(0), pl = T(0);
         for (int k = 0; k < C; ++k) {
-            av += P[k * C + i] * gW[k * C + j];                                       // A[i][j]
-            const T lm = k > i ? L[k * C + i] : (k == i ? T(1) : T(0));               // Lm[k][i]
-            pl += P[j * C + k] * lm;                                                  // (P Lm)[j][i]
+            av += Ps[k * C + i] * Gs[k * C + j];                                      // A[i][j]
+            pl += Ps[j * C + k] * lmc[k];                                             // (P Lm)[j][i]
         }
         a[j] = av;
         plc[j] = pl;
@@ -381,9 +400,9 @@ inv1x1_lu_grads_kernel(const T *__restrict__ P, const T *__restrict__ L, const T
     if (j < C) {
         T glm = T(0), gum = T(0);
         for (int k = 0; k < C; ++k) {
-            const T um = k > j ? U[j * C + k] : (k == j ? sign_S[j] * M<T>::exp(log_S[j]) : T(0));     // Um[j][k]
+            const T um = k > j ? Us[j * C + k] : (k == j ? sign_S[j] * M<T>::exp(log_S[j]) : T(0));     // Um[j][k]
             glm += a[k] * um;                            // (A Um^T)[i][j]
-            gum += plc[k] * gW[k * C + j];               // ((P Lm)^T gW)[i][j]
+            gum += plc[k] * Gs[k * C + j];               // ((P Lm)^T gW)[i][j]
         }
         gL[i * C + j] = i > j ? glm : T(0);
         gU[i * C + j] = j > i ? gum : T(0);
@@ -572,11 +591,18 @@ extern "C" int nf_inv1x1_lu_grads(const void *P, const void *L, const void *U, c
     if (C > 64) return NF_ENOTSUP;
     if (!P || !L || !U || !sign_S || !log_S || !gW || !gL || !gU || !glogS) return NF_EFAULT;
     hipStream_t st = (hipStream_t)stream;
+    {   // (float64 at C > 52 stages more than the default 64 KB of dynamic LDS)
+        static LdsOptIn opt_f = {}, opt_d = {};
+        const int rc = dtype == NF_F64
+            ? opt_in_lds(reinterpret_cast<const void *>(&inv1x1_lu_grads_kernel<double>), (size_t)(3 * C * C + C) * sizeof(double), opt_d)
+            : opt_in_lds(reinterpret_cast<const void *>(&inv1x1_lu_grads_kernel<float>), (size_t)(3 * C * C + C) * sizeof(float), opt_f);
+        if (rc != NF_OK) return NF_ENOTSUP;
+    }
     NF_DISPATCH(dtype,
-                hipLaunchKernelGGL(inv1x1_lu_grads_kernel<float>, dim3(C), dim3(64), 0, st, (const float *)P, (const float *)L,
+                hipLaunchKernelGGL(inv1x1_lu_grads_kernel<float>, dim3(C), dim3(64), (size_t)(3 * C * C + C) * sizeof(float), st, (const float *)P, (const float *)L,
                                    (const float *)U, (const float *)sign_S, (const float *)log_S, (const float *)gW, (const float *)gl,
                                    (float *)gL, (float *)gU, (float *)glogS, C),
-                hipLaunchKernelGGL(inv1x1_lu_grads_kernel<double>, dim3(C), dim3(64), 0, st, (const double *)P, (const double *)L,
+                hipLaunchKernelGGL(inv1x1_lu_grads_kernel<double>, dim3(C), dim3(64), (size_t)(3 * C * C + C) * sizeof(double), st, (const double *)P, (const double *)L,
                                    (const double *)U, (const double *)sign_S, (const double *)log_S, (const double *)gW,
                                    (const double *)gl, (double *)gL, (double *)gU, (double *)glogS, C));
     NF_CHECK_LAUNCH();

@@ -23,8 +23,11 @@ inv1x1_assemble_kernel(const T *__restrict__ P, const T *__restrict__ L, const T
     T *Lt = reinterpret_cast<T *>(Ed + n);              // L' or L'^-1 in T
     T *Ut = Lt + n;                                     // U' or U'^-1 in T
     T *Tm = Ut + n;                                     // temp product
-    __shared__ T sred[16];
-    const int tid = threadIdx.x;
+    T *Pt = reinterpret_cast<T *>(Dd);                  // P staged in LDS (round 5: the products' inner loops were C dependent global
+    __shared__ T sred[16];                              // loads per output entry, 18 us per call at C = 48); it shares the fp64 factor's
+    const int tid = threadIdx.x;                        // space: unused in the density direction, free again before the last product
+    if (!inverse)
+        for (int i = tid; i < n; i += 256) Pt[i] = P[i];
 
     T part = T(0);
     for (int i = tid; i < C; i += 256) part += log_S[i];
@@ -44,7 +47,7 @@ inv1x1_assemble_kernel(const T *__restrict__ P, const T *__restrict__ L, const T
         for (int i = tid; i < n; i += 256) {
             const int r = i / C, c = i - r * C;
             T a = T(0);
-            for (int k = 0; k < C; ++k) a += P[r * C + k] * Lt[k * C + c];
+            for (int k = 0; k < C; ++k) a += Pt[r * C + k] * Lt[k * C + c];
             Tm[i] = a;
         }
         __syncthreads();
@@ -81,7 +84,7 @@ inv1x1_assemble_kernel(const T *__restrict__ P, const T *__restrict__ L, const T
         }
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 256) Ut[i] = (T)Ed[i];
+    for (int i = tid; i < n; i += 256) { Ut[i] = (T)Ed[i]; Pt[i] = P[i]; }       // (Dd is done: P moves in)
     __syncthreads();
     // ---- W = (U'^-1 @ L'^-1) @ P^T ----
     for (int i = tid; i < n; i += 256) {
@@ -94,7 +97,7 @@ inv1x1_assemble_kernel(const T *__restrict__ P, const T *__restrict__ L, const T
     for (int i = tid; i < n; i += 256) {
         const int r = i / C, c = i - r * C;
         T a = T(0);
-        for (int k = 0; k < C; ++k) a += Tm[r * C + k] * P[c * C + k];
+        for (int k = 0; k < C; ++k) a += Tm[r * C + k] * Pt[c * C + k];
         W[i] = a;
     }
 }

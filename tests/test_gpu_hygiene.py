@@ -164,6 +164,26 @@ def _vjp_check(out_fn, ref_fn, inputs, rtol, atol):
         assert_close(a.cpu().numpy(), b.cpu().numpy(), what="tensor %d" % i, rtol=rtol, atol=atol)
 
 
+@pytest.mark.parametrize("B,C,H,W", [(256, 12, 16, 16), (64, 48, 4, 4), (7, 3, 5, 3), (9, 300, 2, 2), (33, 256, 1, 2), (3, 1, 4, 4)])
+def test_actnorm_backward_reduction_over_channel_counts(nfa, B, C, H, W):
+    """nf_actnorm_bwd's second stage (round 5: thread = (channel, slice of the batch splits), slices added through LDS in slice order)
+    at Glow's channel counts, one channel, a count that leaves idle slices and counts >= the workgroup width: gradients of s and t
+    (and z) against torch autograd of coupling.py:38-54, float32 and float64, both directions."""
+    from normflows_amd import autograd as ag
+    for dtype, rtol in ((torch.float32, 3e-5), (torch.float64, 1e-11)):
+        torch.manual_seed(C + B)
+        z = torch.randn(B, C, H, W, dtype=dtype, device=DEV)
+        sv, tv = 0.2 * torch.randn(C, dtype=dtype, device=DEV), torch.randn(C, dtype=dtype, device=DEV)
+        for d in (0, 1):
+            def ref_an(z_, s_, t_):
+                s4, t4 = s_.view(1, C, 1, 1), t_.view(1, C, 1, 1)
+                ones = torch.ones(B, dtype=dtype, device=DEV)
+                if d == 0:
+                    return z_ * torch.exp(s4) + t4, H * W * s_.sum() * ones
+                return (z_ - t4) * torch.exp(-s4), -H * W * s_.sum() * ones
+            _vjp_check(lambda z_, s_, t_: ag.ActNormFn.apply(z_, s_, t_, d), ref_an, (z, sv, tv), rtol, 300 * rtol)
+
+
 @pytest.mark.parametrize("dtype,rtol", [(torch.float32, 2e-5), (torch.float64, 1e-11)])
 def test_affine_family_backward_kernels_vs_torch_autograd(nfa, dtype, rtol):
     """csrc/affine_bwd.hip against PyTorch autograd of the reference formulas (coupling.py:38-54, :117-171, :209-229,

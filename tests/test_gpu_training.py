@@ -1501,7 +1501,7 @@ def test_training_follows_fused_optimizer_steps(nfa):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float64])
-@pytest.mark.parametrize("C", [3, 12, 48])
+@pytest.mark.parametrize("C", [3, 12, 48, 60])
 def test_inv1x1_lu_parametrisation_vjp_vs_autograd(nfa, dt, C):
     """nf_inv1x1_assemble + nf_inv1x1_lu_grads (autograd.Inv1x1WeightFn) against torch autograd through the reference's assembly
     (mixing.py:88-104: W = P (tril(L, -1) + I) (triu(U, 1) + diag(sign_S exp(log_S))), log|det| = sum log_S)."""
