@@ -43,18 +43,36 @@ inv1x1_assemble_kernel(const T *__restrict__ P, const T *__restrict__ L, const T
     __syncthreads();
 
     if (!inverse) {
-        // W = (P @ L') @ U'
+        // W = (P @ L') @ U'.  P comes from torch.lu_unpack (mixing.py:76-80): rows with a single 1 -- then P @ L' is a row gather (the
+        // same values bit for bit: the product only adds exact zeros); any other P takes the product.  U' is upper triangular: the
+        // second product stops at the diagonal (C^3 LDS-bound multiply-adds on 256 threads were 16 us per call at C = 48).
+        __shared__ int perm[128], one_hot;         // (C <= 75: the LDS bound of launch_assemble)
+        if (tid == 0) one_hot = 1;
+        __syncthreads();
+        for (int r = tid; r < C; r += 256) {
+            int pk = -1, cnt = 0;
+            for (int k = 0; k < C; ++k) {
+                const T v = Pt[r * C + k];
+                if (v != T(0)) { ++cnt; pk = v == T(1) ? k : -1; }
+            }
+            perm[r] = pk;
+            if (cnt != 1 || pk < 0) one_hot = 0;
+        }
+        __syncthreads();
+        const bool gather = one_hot != 0;
         for (int i = tid; i < n; i += 256) {
             const int r = i / C, c = i - r * C;
             T a = T(0);
-            for (int k = 0; k < C; ++k) a += Pt[r * C + k] * Lt[k * C + c];
+            if (gather) a = Lt[perm[r] * C + c];
+            else
+                for (int k = 0; k < C; ++k) a += Pt[r * C + k] * Lt[k * C + c];
             Tm[i] = a;
         }
         __syncthreads();
         for (int i = tid; i < n; i += 256) {
             const int r = i / C, c = i - r * C;
             T a = T(0);
-            for (int k = 0; k < C; ++k) a += Tm[r * C + k] * Ut[k * C + c];
+            for (int k = 0; k <= c; ++k) a += Tm[r * C + k] * Ut[k * C + c];
             W[i] = a;
         }
         return;

@@ -1527,6 +1527,14 @@ def test_inv1x1_lu_parametrisation_vjp_vs_autograd(nfa, dt, C):
     tol = 2e-5 if dt == torch.float32 else 1e-12
     for a, b in zip(res[0], res[1]):
         assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+    # a P that is not a permutation matrix (nothing in mixing.py:88-104 needs it to be one): the assembly takes the product, not the gather
+    with torch.no_grad():
+        conv.P.copy_(torch.randn(C, C, device=DEV, dtype=dt) / C ** 0.5)
+        W, _ = Inv1x1WeightFn.apply(conv.P, conv.L, conv.U, conv.sign_S, conv.log_S)
+        Lm = torch.tril(conv.L, diagonal=-1) + conv.eye
+        Um = torch.triu(conv.U, diagonal=1) + torch.diag(conv.sign_S * torch.exp(conv.log_S))
+        Wr = conv.P @ Lm @ Um
+    assert float((W - Wr).abs().max()) <= 10 * tol * max(1.0, float(Wr.abs().max()))
 
 
 def test_training_kernels_random_shapes(nfa):
