@@ -633,6 +633,14 @@ int nf_maf_inverse_h_tri_bits(const void *z, void *y, void *logdet, const void *
 int64_t nf_maf_solve_t_scratch_floats(int64_t B, int D, int hidden_padded, int num_blocks);
 int nf_maf_solve_t(const void *x, const void *prm, const void *gx, const void *gld, const void *bits, void *v, const void *blob,
                    const int32_t *table, void *scratch, int64_t B, int D, int hidden_padded, int num_blocks, nf_stream_t stream);
+/* The scratch nf_maf_solve_t leaves behind IS MADE's input-gradient chain at the solution (every virtual unit is finalised once, from
+ * final values): the hidden-layer output gradients torch's autograd computes for `F.linear(x, weight * mask, bias)` per MaskedLinear
+ * (nets/made.py:73-81) on the way to the weight gradients.  nf_maf_scratch_rows rearranges it from the kernel's tile order into
+ * out (2 num_blocks + 1, B rounded up to 64, ldo) row-major float32 -- what nf_made_wgrad reads as G (instead of another
+ * nf_made_backward pass): column c = sign * position pos_of_col[c] of the scratch (ldo int32 on the device, < 0: zero column;
+ * maf_pack.solve_t_gradient_columns), layer order reversed with reverse_layers, rows >= B zero.  hidden_padded: the pack's table[3]. */
+int nf_maf_scratch_rows(const void *scratch, const int32_t *pos_of_col, void *out, int64_t B, int num_blocks, int hidden_padded, int ldo,
+                        double sign, int reverse_layers, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * MaskedPiecewiseRationalQuadraticAutoregressive inverse (AR-NSF sampling direction) in ONE pass.  Replaces the D-pass

@@ -868,7 +868,7 @@ class MafInverseFn(torch.autograd.Function):
             x, ld, bits = ops.maf_inverse_bits(z, inv["blob"], inv["table"], inv["hp"], inv["nb"], inv["tiles"],
                                                table_host=inv.get("table_host"))
             ctx.save_for_backward(x, bits)
-            ctx.tpack = (inv["tblob"], inv["ttable"], inv["hp"], inv["nb"])
+            ctx.tpack = (inv["tblob"], inv["ttable"], inv["hp"], inv["nb"], inv.get("gcols"))
         else:
             x, ld = ops.maf_inverse(z, inv[0], inv[1], inv[2], num_blocks=inv[3], table_host=inv[4] if len(inv) > 4 else None)
             ctx.save_for_backward(x)
@@ -890,10 +890,17 @@ class MafInverseFn(torch.autograd.Function):
         if ctx.tpack is not None:
             # ONE launch: back-substitution of v s + J^T g_p(v, g_ld) = g_x on the transposed pack (nf_maf_solve_t), the ReLU masks from
             # the forward inverse's own pass; no sweeps, no host read-back (hipGraph-capturable)
-            tb, tt, hp, nb = ctx.tpack
-            v = ops.maf_solve_t(x, p, gx, gld, ctx.saved_tensors[1], tb, tt, hp, nb)
+            tb, tt, hp, nb, gcols = ctx.tpack
+            G = None
+            if gcols is not None and _config.maf_solve_grads and any(ctx.needs_input_grad[4:]):
+                # the solve's activation scratch IS the input-gradient chain at the solution: rearranged into the weight-gradient
+                # launch's G (sign: the parameter cotangent below is g_p(-v, -g_ld)) instead of one more nf_made_backward pass
+                v, scratch = ops.maf_solve_t(x, p, gx, gld, ctx.saved_tensors[1], tb, tt, hp, nb, return_scratch=True)
+                G = ops.maf_scratch_rows(scratch, gcols, B, nb, hp, sign=-1.0, reverse_layers=True)
+            else:
+                v = ops.maf_solve_t(x, p, gx, gld, ctx.saved_tensors[1], tb, tt, hp, nb)
             MafInverseFn.last_sweeps = 1
-            return MafInverseFn._finish(ctx, x, p, v, gld, save, bits)
+            return MafInverseFn._finish(ctx, x, p, v, gld, save, bits, G)
         v = torch.empty_like(x)
         gp = torch.empty_like(p)
         changed = torch.zeros(1, dtype=torch.int32, device=x.device)
@@ -926,14 +933,16 @@ class MafInverseFn(torch.autograd.Function):
         return MafInverseFn._finish(ctx, x, p, v, gld, save, bits)
 
     @staticmethod
-    def _finish(ctx, x, p, v, gld, save, bits):
-        """g_z = v; g_theta = MADE's weight gradients for the parameter cotangent g_p(-v, -g_ld): one chain + ONE weight-gradient launch."""
+    def _finish(ctx, x, p, v, gld, save, bits, G=None):
+        """g_z = v; g_theta = MADE's weight gradients for the parameter cotangent g_p(-v, -g_ld): one chain (unless the one-pass solve
+        left its hidden gradients: G) + ONE weight-gradient launch."""
         bwd = ctx.bwd
         D = x.shape[1]
         _, gp = ops.maf_affine_bwd(x, p, -v, -gld, 0)
         grads = [None] * ctx.nparams
         if any(ctx.needs_input_grad[4:]):
-            _, G = ops.made_backward(gp, bits, bwd["blob"], bwd["table"], D, bwd["Hp"], bwd["NB"])
+            if G is None:
+                _, G = ops.made_backward(gp, bits, bwd["blob"], bwd["table"], D, bwd["Hp"], bwd["NB"])
             flat = ops.made_wgrad(gp, x, G, save, bwd["wtable"], bwd["stable"], bwd["mask"], bwd["ntiles"], bwd["nflat"], bwd["Mp"],
                                   bwd["Dx"])
             for k, (woff, shape, boff, n) in enumerate(bwd["offsets"]):

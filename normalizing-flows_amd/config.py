@@ -206,3 +206,14 @@ maf_onepass = True
 def set_maf_onepass(mode=True):
     global maf_onepass
     maf_onepass = bool(mode)
+
+
+# The weight-gradient launch of the one-pass implicit backward reads MADE's hidden gradients from the SOLVE's scratch (nf_maf_scratch_rows:
+# the solve finalises every unit of the transposed network once from final values = the input-gradient chain at the solution) instead of
+# running nf_made_backward once more.  False = the extra chain pass.
+maf_solve_grads = True
+
+
+def set_maf_solve_grads(mode=True):
+    global maf_solve_grads
+    maf_solve_grads = bool(mode)

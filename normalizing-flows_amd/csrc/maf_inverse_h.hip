@@ -882,8 +882,7 @@ maf_solve_t_kernel(const float *__restrict__ x, const float *__restrict__ prm, c
             }
         }
 #undef MAFT_DOT
-        if (t + 1 < T)       // (the last tile's activations are streamed back by nobody)
-#pragma unroll
+#pragma unroll          // (every tile, the last one too: nf_maf_scratch_rows reads the whole scratch back as MADE's hidden gradients)
         for (int q = 0; q < 4; ++q) {
             const size_t o = ((size_t)((4 * t + q) * 2 + hh) * 32 + n) * 4;
 #pragma unroll
@@ -1002,6 +1001,69 @@ extern "C" int nf_maf_inverse_h_tri_bits(const void *z, void *y, void *logdet, c
 }
 
 // Scratch of nf_maf_solve_t: per row NL hidden_padded cotangents + the padded (g_us, g_sh) row + the tile-pair stash.
+namespace nf {
+
+// ---- the one-pass kernels' activation scratch as row-major hidden tensors (round 5) ---------------------------------------------------
+// S: [wave tile of 32 rows][NL layers][Hp / 8][2][32][4] (B-operand order over padded POSITIONS, as maf_inverse_h_kernel /
+// maf_solve_t_kernel publish it) -> out[layer'][Bp rows][ldo]: column c of a row = sign * S[position pos_of_col[c]] (pos_of_col[c] < 0:
+// zero), layer' = NL - 1 - layer with `reverse`; rows >= B are zero.  For the transposed solve this IS MADE's input-gradient chain at
+// the solution (G[l] of nf_made_backward in the training kernels' column order: flows/maf_pack.solve_t_gradient_columns) -- the
+// weight-gradient launch of the implicit backward reads it instead of running the chain again.  Workgroup = (32 rows, layer): the
+// Hp x 32 block goes through LDS as [row][Hp + 4] (16-byte writes, row stride = 4 banks mod 32), rows leave as full lines.
+__global__ void __launch_bounds__(256)
+maf_scratch_rows_kernel(const float *__restrict__ S, const int *__restrict__ pos_of_col, float *__restrict__ out, int64_t B, int64_t Bp,
+                        int NL, int Hp, int ldo, float sign, int reverse) {
+    extern __shared__ __attribute__((aligned(16))) float buf[];
+    const int64_t wt = blockIdx.x;
+    const int l = blockIdx.y, pitch = Hp + 4;
+    const bool have = wt * 32 < B;
+    if (have) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(S + ((size_t)wt * NL + l) * (size_t)Hp * 32);
+        for (int i = threadIdx.x; i < Hp * 8; i += 256) {          // f32x4 index i = (position group g = i >> 5, row n = i & 31)
+            const int g = i >> 5, n = i & 31;
+            *reinterpret_cast<f32x4 *>(buf + n * pitch + 4 * g) = src[i];
+        }
+    }
+    __syncthreads();
+    const int lo = reverse ? NL - 1 - l : l;
+    const int c4n = ldo >> 2;
+    for (int e = threadIdx.x; e < 32 * c4n; e += 256) {
+        const int n = e / c4n, c4 = e - n * c4n;
+        const int64_t row = wt * 32 + n;
+        if (row >= Bp) continue;
+        f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (have && row < B) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = pos_of_col[4 * c4 + i];
+                if (k >= 0) o[i] = sign * buf[n * pitch + k];
+            }
+        }
+        *reinterpret_cast<f32x4 *>(out + ((size_t)lo * Bp + row) * ldo + 4 * c4) = o;
+    }
+}
+
+}  // namespace nf
+
+// The activation scratch of nf_maf_solve_t (or of the inverse kernels) as row-major hidden tensors out (NL, Bp, ldo) float32, Bp = B
+// rounded up to 64: see maf_scratch_rows_kernel.  pos_of_col: ldo int32 (device).  hidden_padded = the scratch's position count (the
+// pack's table[3]); scratch = the buffer handed to the kernel that filled it (its activation region comes first).
+extern "C" int nf_maf_scratch_rows(const void *scratch, const int32_t *pos_of_col, void *out, int64_t B, int num_blocks, int hidden_padded,
+                                   int ldo, double sign, int reverse_layers, nf_stream_t stream) {
+    if (B < 0 || num_blocks < 1 || num_blocks > 3 || hidden_padded < 32 || hidden_padded % 32 || ldo < 4 || ldo % 4) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!scratch || !pos_of_col || !out) return NF_EFAULT;
+    const int NL = 1 + 2 * num_blocks;
+    const int64_t Bp = (B + 63) / 64 * 64;
+    const size_t lds = (size_t)32 * (hidden_padded + 4) * sizeof(float);
+    static nf::LdsOptIn opted = {};
+    if (nf::opt_in_lds(reinterpret_cast<const void *>(&nf::maf_scratch_rows_kernel), lds, opted) != NF_OK) return NF_ENOTSUP;
+    hipLaunchKernelGGL(nf::maf_scratch_rows_kernel, dim3((unsigned)(Bp / 32), NL), dim3(256), lds, (hipStream_t)stream, (const float *)scratch,
+                       (const int *)pos_of_col, (float *)out, B, Bp, NL, hidden_padded, ldo, (float)sign, reverse_layers);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
 extern "C" int64_t nf_maf_solve_t_scratch_floats(int64_t B, int D, int hidden_padded, int num_blocks) {
     if (B < 0 || D < 1 || hidden_padded < 0 || num_blocks < 1 || num_blocks > 3) return NF_EINVAL;
     const int64_t nwt = (B + 31) / 32, Dq = (2 * (int64_t)D + 31) / 32 * 32, NL = 1 + 2 * num_blocks;

@@ -361,6 +361,36 @@ def pack_made(made, mult=2, rows=False, blocks=(2,), tri=False):
 
 
 # ---- format 2 (round 5): the TRANSPOSED one-pass solve of the implicit backward (csrc/maf_solve_t.hip, autograd.MafInverseFn) ----
+def solve_t_gradient_columns(made, blocks=(1, 2, 3), tri=False):
+    """int32 (Hp_train,): for column c of the training kernels' hidden tensors (flows/made_pack: units sorted by degree, stable) the
+    PADDED position of that unit in the transposed solve's activation scratch (pack_made_transposed: forward tiles reversed, forward
+    positions), -1 for the padding columns.  With it the solve's scratch IS every hidden layer's output gradient of MADE's
+    input-gradient chain (nf_maf_scratch_rows rearranges it into G[l][rows][Hp_train]): the solve finalises every virtual unit once from
+    final values, which is that chain at the solution."""
+    if not supported(made, 2, blocks) or pack_made(made, blocks=blocks) is None:
+        return None
+    D = made.initial_layer.in_features
+    H = made.initial_layer.out_features
+    hid_deg = made.initial_layer.degrees.cpu().numpy()
+    order, tiles = plan_tiles(D, hid_deg)
+    T = len(tiles)
+    fslot = np.zeros(H, dtype=np.int64)
+    k = 0
+    for t, (dlo, ns, steps) in enumerate(tiles):
+        b_ = 0
+        perm = bool(tri) and (is_regular(steps) or extras_prefix(steps) > 0)
+        for g, c in enumerate(steps):
+            for i in range(c):
+                fslot[order[k]] = t * TILE + (tile_row(g, i) if perm else b_)
+                b_ += 1
+                k += 1
+    vslot = (T - 1 - fslot // TILE) * TILE + fslot % TILE
+    hp_train = 256 if H <= 256 else 512
+    cols = np.full(hp_train, -1, dtype=np.int32)
+    cols[:H] = vslot[np.argsort(hid_deg, kind="stable")]
+    return cols
+
+
 def pack_made_transposed(made, blocks=(1, 2, 3), tri=False):
     """Pack of nf_maf_solve_t: the linear system  v s + J^T g_p(v, g_ld) = g_x  of the implicit backward of the MAF inverse
     (J = dMADE/dx at the solution, g_p the affine transform's parameter cotangent) solved by back-substitution in ONE pass.

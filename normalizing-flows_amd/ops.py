@@ -1131,9 +1131,10 @@ def maf_inverse_bits(z, blob, table, hidden_padded, num_blocks, tiles, table_hos
     return y, logdet, bits
 
 
-def maf_solve_t(x, params, gx, gld, bits, blob, table, hidden_padded, num_blocks):
+def maf_solve_t(x, params, gx, gld, bits, blob, table, hidden_padded, num_blocks, return_scratch=False):
     """nf_maf_solve_t: v with  v s + J^T g_p(v, g_ld) = g_x  in one pass (the implicit backward of the MAF inverse);
-    blob / table from flows/maf_pack.pack_made_transposed."""
+    blob / table from flows/maf_pack.pack_made_transposed.  return_scratch: (v, scratch) -- the activation scratch for
+    maf_scratch_rows."""
     L.require_device(x, params, gx, gld, bits, blob, table)
     if x.dtype != torch.float32:
         raise NotImplementedError("maf_solve_t: float32 only")
@@ -1146,7 +1147,19 @@ def maf_solve_t(x, params, gx, gld, bits, blob, table, hidden_padded, num_blocks
     rc = lib.nf_maf_solve_t(ptr(x), ptr(params), ptr(gx), ptr(None if gld is None else gld.contiguous()), ptr(bits), ptr(v), ptr(blob),
                             ptr(table), ptr(scratch), i64(B), i32(D), i32(hidden_padded), i32(num_blocks), L.stream())
     L.check(rc, "nf_maf_solve_t")
-    return v
+    return (v, scratch) if return_scratch else v
+
+
+def maf_scratch_rows(scratch, pos_of_col, B, num_blocks, hidden_padded, sign=1.0, reverse_layers=False):
+    """nf_maf_scratch_rows: the one-pass kernels' activation scratch as (2 num_blocks + 1, Bp, len(pos_of_col)) row-major tensors."""
+    L.require_device(scratch, pos_of_col)
+    ldo = pos_of_col.numel()
+    Bp = (B + 63) // 64 * 64
+    out = torch.empty(2 * num_blocks + 1, Bp, ldo, dtype=torch.float32, device=scratch.device)
+    rc = L.lib().nf_maf_scratch_rows(ptr(scratch), ptr(pos_of_col), ptr(out), i64(B), i32(num_blocks), i32(hidden_padded), i32(ldo),
+                                     f64(sign), i32(int(reverse_layers)), L.stream())
+    L.check(rc, "nf_maf_scratch_rows")
+    return out
 
 
 def arnsf_inverse(z, blob, table, hidden_padded, K, tails, tail_bound, min_bin_width=1e-3, min_bin_height=1e-3,

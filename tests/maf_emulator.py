@@ -256,7 +256,7 @@ def _emulate_rows(blob, table, z, element):
     return x[:, :D], ld
 
 
-def emulate_solve_t(blob, table, x, params, gx, gld, masks):
+def emulate_solve_t(blob, table, x, params, gx, gld, masks, return_scratch=False):
     """numpy walk-through of csrc/maf_solve_t.hip (format 2 of flows/maf_pack.pack_made_transposed): the one-pass back-substitution of
     v s + J^T g_p(v, g_ld) = g_x.  masks[k - 1] (B, Hp) = the ReLU mask of VIRTUAL layer k = 1 .. 2 NB in virtual slot order (the sign of
     forward layer 2 NB - k's pre-activation of the unit in that slot)."""
@@ -313,4 +313,4 @@ def emulate_solve_t(blob, table, x, params, gx, gld, masks):
             xg[:, 2 * (s + 1)], xg[:, 2 * (s + 1) + 1] = a, b
         for l in range(NL):
             S[l][:, sl] = pre[l]
-    return v
+    return (v, S) if return_scratch else v        # S (NL, B, Hp): the published activations in virtual position order

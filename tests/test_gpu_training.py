@@ -438,8 +438,9 @@ def test_maf_gradients_vs_reference_autograd(nfa, monkeypatch):
     check_layer_grads(layer, g, rtol=2e-3, atol=2e-4)
     # single-pass direction: one forward / chain / weight-gradient launch; density direction (autograd.MafInverseFn, implicit
     # differentiation): one forward at the solution, ONE nf_maf_solve_t launch for the linear system (round 5; round 4: one chain per
-    # sweep, <= D = 5), one chain for the weight gradients, one weight-gradient launch
-    assert calls["fwd"] == 2 and calls["wgrad"] == 2 and calls["bwd"] == 2, calls
+    # sweep, <= D = 5), NO chain for the weight gradients any more (the solve's scratch is that chain: nf_maf_scratch_rows), one
+    # weight-gradient launch
+    assert calls["fwd"] == 2 and calls["wgrad"] == 2 and calls["bwd"] == 1, calls
     assert MafInverseFn.last_sweeps == 1
 
 
@@ -1757,6 +1758,73 @@ def test_maf_one_pass_backward_on_format0_and_format1_packs(nfa):
             nfa.config.set_maf_tri(True)
         for a, b in zip(res[0], res[1]):
             assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), (D, float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("D,H,NB,B", [(128, 512, 2, 300), (40, 100, 2, 64), (20, 40, 2, 130), (64, 252, 2, 77), (17, 40, 1, 65), (33, 70, 3, 31)])
+def test_maf_weight_gradients_from_the_solve_scratch(nfa, D, H, NB, B):
+    """The one-pass implicit backward hands the weight-gradient launch MADE's hidden gradients straight from the SOLVE's activation scratch
+    (nf_maf_scratch_rows through maf_pack.solve_t_gradient_columns: the solve finalises every unit of the transposed network once from
+    final values = the input-gradient chain at the solution) instead of running nf_made_backward once more.
+
+    (1) G from the scratch against nf_made_backward's G for the same cotangent, ROW by row (a row of G depends on that sample alone): equal
+    to 2e-5 of scale on every row whose ReLU masks agree between the two float32 passes that produced them -- the inverse kernel's own
+    pass (the solve's masks) and nf_made_forward_train's (the chain's): a pre-activation within rounding of zero may fall on either side
+    (about one unit in a million) and then that ROW differs by a finite amount, so at most 1 % of the rows (+ 1) may; rows
+    beyond B of the padded tensors are zero.  (2) End to end: every gradient against the path with the extra chain pass
+    (config.set_maf_solve_grads(False)): 2e-5 of scale where no mask differs, summed absolute error <= 1e-3 of the summed gradient
+    otherwise; the chain launch is gone."""
+    from normflows_amd import ops
+    torch.manual_seed(D + H)
+    layer = nfa.flows.MaskedAffineAutoregressive(D, H, num_blocks=NB)
+    gen = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.add_(0.03 * torch.randn(p.shape, generator=gen))
+    layer = layer.to(DEV)
+    z0 = torch.randn(B, D, device=DEV)
+    cx, cl = torch.randn(B, D, device=DEV), torch.randn(B, device=DEV)
+    # (1) the two G tensors
+    inv, fwd, bwd = layer._implicit_packs(DEV)
+    assert isinstance(inv, dict) and inv["gcols"] is not None
+    x, _, bits = ops.maf_inverse_bits(z0, inv["blob"], inv["table"], inv["hp"], inv["nb"], inv["tiles"], table_host=inv.get("table_host"))
+    prm, save, tbits = ops.made_forward_train(x, fwd[0], fwd[1], fwd[2], 2 * D, bwd["NB"])
+    v, scratch = ops.maf_solve_t(x, prm, cx, cl, bits, inv["tblob"], inv["ttable"], inv["hp"], inv["nb"], return_scratch=True)
+    G1 = ops.maf_scratch_rows(scratch, inv["gcols"], B, inv["nb"], inv["hp"], sign=-1.0, reverse_layers=True)
+    _, gp = ops.maf_affine_bwd(x, prm, -v, -cl, 0)
+    _, G2 = ops.made_backward(gp, tbits, bwd["blob"], bwd["table"], D, bwd["Hp"], bwd["NB"])
+    assert G1.shape == G2.shape and float(G1[:, B:].abs().max() if G1.shape[1] > B else 0.0) == 0.0
+    scale = max(1.0, float(G2.abs().max()))
+    row_err = (G1[:, :B] - G2[:, :B]).abs().amax(dim=(0, 2))
+    flipped = int((row_err > 2e-5 * scale).sum())
+    assert flipped <= B // 100 + 1, (flipped, B, float(row_err.max()), scale)
+    # (2) end to end
+    res, chains = [], []
+    real = ops.made_backward
+    try:
+        for mode in (True, False):
+            nfa.config.set_maf_solve_grads(mode)
+            n = [0]
+
+            def spy(*a, **k):
+                n[0] += 1
+                return real(*a, **k)
+            ops.made_backward = spy
+            layer.zero_grad(set_to_none=True)
+            z = z0.clone().requires_grad_(True)
+            xx, ld = layer.inverse(z)
+            ((xx * cx).sum() + (ld * cl).sum()).backward()
+            chains.append(n[0])
+            res.append([z.grad] + [p.grad.clone() for p in layer.parameters()])
+    finally:
+        ops.made_backward = real
+        nfa.config.set_maf_solve_grads(True)
+    assert chains == [0, 1], chains
+    for k, (a, b) in enumerate(zip(res[0], res[1])):
+        err = (a - b).abs()
+        if flipped == 0:
+            assert float(err.max()) <= 2e-5 * max(1.0, float(b.abs().max())), (k, float(err.max()), float(b.abs().max()))
+        else:
+            assert float(err.sum()) <= 1e-3 * float(b.abs().sum()), (k, flipped, float(err.sum()), float(b.abs().sum()))
 
 
 @pytest.mark.parametrize("which", ["x_only", "ld_only"])

@@ -101,6 +101,12 @@ def test_c_abi_argument_validation_newer_entry_points(nfa):
     assert lib.nf_maf_solve_t(one, one, one, null, one, one, one, one, one, i64(8), i32(128), i32(512), i32(4), null) == -95
     assert lib.nf_maf_solve_t(one, one, one, null, null, one, one, one, one, i64(8), i32(128), i32(512), i32(2), null) == -14      # bits
     assert lib.nf_maf_solve_t(null, null, null, null, null, null, null, null, null, i64(0), i32(128), i32(512), i32(2), null) == 0
+    f64 = ctypes.c_double
+    assert lib.nf_maf_scratch_rows(one, one, one, i64(8), i32(2), i32(500), i32(512), f64(-1.0), i32(1), null) == -22     # positions % 32
+    assert lib.nf_maf_scratch_rows(one, one, one, i64(8), i32(4), i32(512), i32(512), f64(-1.0), i32(1), null) == -22     # blocks
+    assert lib.nf_maf_scratch_rows(one, one, one, i64(8), i32(2), i32(512), i32(510), f64(-1.0), i32(1), null) == -22     # ldo % 4
+    assert lib.nf_maf_scratch_rows(one, null, one, i64(8), i32(2), i32(512), i32(512), f64(-1.0), i32(1), null) == -14
+    assert lib.nf_maf_scratch_rows(null, null, null, i64(0), i32(2), i32(512), i32(512), f64(-1.0), i32(1), null) == 0
     # debug-mode spline check
     assert lib.nf_rqs_spline_check(one, one, i64(8), i32(0), f64(1.0), f64(0.0), f64(1.0), f64(0.0), f64(1.0), i32(1), i32(0), null, null) == -14
     assert lib.nf_rqs_spline_check(one, one, i64(8), i32(7), f64(1.0), f64(0.0), f64(1.0), f64(0.0), f64(1.0), i32(1), i32(0), one, null) == -22
@@ -1248,7 +1254,8 @@ def test_made_forward_spline_pack_matches_dense_made(D, H, NB):
 
 
 @pytest.mark.parametrize("tri", [False, True])
-@pytest.mark.parametrize("D,H,NB", [(12, 40, 2), (17, 40, 1), (20, 64, 2), (10, 36, 3), (40, 39, 2), (33, 70, 2), (9, 34, 1), (64, 256, 2)])
+@pytest.mark.parametrize("D,H,NB", [(12, 40, 2), (17, 40, 1), (20, 64, 2), (10, 36, 3), (40, 39, 2), (33, 70, 2), (9, 34, 1), (64, 256, 2),
+                                    (128, 512, 2)])
 def test_maf_transposed_pack_solves_the_implicit_system(D, H, NB, tri):
     """flows/maf_pack.pack_made_transposed + the schedule of csrc/maf_solve_t.hip (numpy emulation, tests/maf_emulator.py) solve
     v s + J^T g_p(v, g_ld) = g_x -- the linear system of autograd.MafInverseFn's backward -- in ONE pass: against the dense solution
@@ -1264,6 +1271,7 @@ def test_maf_transposed_pack_solves_the_implicit_system(D, H, NB, tri):
             p.add_((0.3 if H < 100 else 0.03) * torch.randn_like(p))      # (wide nets: keep the triangular system well conditioned)
     blob, table = maf_pack.pack_made_transposed(made, blocks=(1, 2, 3), tri=tri)    # tri: the format-1 forward pack's positions
     assert table[7] == 2 and table[6] == NB and table[1] % 32 == 0
+    cols = maf_pack.solve_t_gradient_columns(made, tri=tri)      # (the packers take the float32 module: before .double() below)
     T, Hp = int(table[4]), int(table[3])
     B = 5
     m64 = made.double()
@@ -1310,5 +1318,30 @@ def test_maf_transposed_pack_solves_the_implicit_system(D, H, NB, tri):
         mk = np.zeros((B, Hp), dtype=bool)
         mk[:, vslot] = (pres[2 * NB - kq] > 0).numpy()
         masks.append(mk)
-    v = emulate_solve_t(blob, table, x.detach().numpy(), prm.detach().numpy(), gx.numpy(), gld.numpy(), masks)
+    v, S = emulate_solve_t(blob, table, x.detach().numpy(), prm.detach().numpy(), gx.numpy(), gld.numpy(), masks, return_scratch=True)
     np.testing.assert_allclose(v, v_ref.numpy(), rtol=1e-8, atol=1e-8)
+    # The activations the solve publishes ARE MADE's input-gradient chain at the solution: through maf_pack.solve_t_gradient_columns
+    # (nf_maf_scratch_rows on the device) they give the weight-gradient launch its G[l] = d<prm, g_p(v, g_ld)> / d(pre-activation l) in the
+    # training kernels' column order (units sorted by degree), layer order reversed -- against float64 autograd on the written-out forward.
+    assert cols.shape == (256 if H <= 256 else 512,) and (cols[H:] == -1).all() and len(set(cols[:H].tolist())) == H
+    xq = x.detach()
+    h = torch.nn.functional.linear(xq, lins[0].weight * lins[0].mask, lins[0].bias)
+    h.retain_grad()
+    nodes, hcur = [h], h
+    for b in range(NB):
+        t_ = torch.nn.functional.linear(torch.relu(hcur), lins[1 + 2 * b].weight * lins[1 + 2 * b].mask, lins[1 + 2 * b].bias)
+        t_.retain_grad()
+        hcur = hcur + torch.nn.functional.linear(torch.relu(t_), lins[2 + 2 * b].weight * lins[2 + 2 * b].mask, lins[2 + 2 * b].bias)
+        hcur.retain_grad()
+        nodes += [t_, hcur]
+    fin = m64.final_layer
+    out = torch.nn.functional.linear(hcur, fin.weight * fin.mask, fin.bias)
+    vt = torch.from_numpy(v)
+    gp = torch.zeros_like(prm)
+    gp[:, 0::2] = ((vt * xq + gld[:, None] / scale) * sg * (1.0 - sg)).detach()
+    gp[:, 1::2] = vt
+    out.backward(gp.detach())
+    unit_of_col = np.argsort(made.initial_layer.degrees.numpy(), kind="stable")
+    for l, node in enumerate(nodes):                          # G[l] <-> virtual layer 2 NB - l
+        got = S[2 * NB - l][:, cols[:H]]
+        np.testing.assert_allclose(got, node.grad.numpy()[:, unit_of_col], rtol=1e-8, atol=1e-8, err_msg="hidden gradient %d" % l)
