@@ -865,16 +865,21 @@ class MafInverseFn(torch.autograd.Function):
     def forward(ctx, inv, fwd, bwd, z, *params):
         z = z.contiguous()
         if isinstance(inv, dict):       # round 5: format-0 inverse that leaves its ReLU masks + the transposed pack of the one-pass solve
-            x, ld, bits = ops.maf_inverse_bits(z, inv["blob"], inv["table"], inv["hp"], inv["nb"], inv["tiles"],
-                                               table_host=inv.get("table_host"))
+            keep = inv.get("fcols") is not None and _config.maf_solve_grads and any(ctx.needs_input_grad[4:])
+            x, ld, bits, scratch = ops.maf_inverse_bits(z, inv["blob"], inv["table"], inv["hp"], inv["nb"], inv["tiles"],
+                                                        table_host=inv.get("table_host"), return_scratch=True)
             ctx.save_for_backward(x, bits)
             ctx.tpack = (inv["tblob"], inv["ttable"], inv["hp"], inv["nb"], inv.get("gcols"))
+            # the pass's own activations (its scratch) are the inputs of MADE's linears at x: kept for the weight-gradient launch, so
+            # the backward does not run MADE forward again (671 MB per config-5 layer at B = 65 536 instead of a transient of that size)
+            ctx.fpack = (scratch, inv["fcols"], inv["wf_t"]) if keep else None
         else:
             x, ld = ops.maf_inverse(z, inv[0], inv[1], inv[2], num_blocks=inv[3], table_host=inv[4] if len(inv) > 4 else None)
             ctx.save_for_backward(x)
             ctx.tpack = None
         ctx.fwd, ctx.bwd = fwd, bwd
         ctx.nparams = len(params)
+        ctx.bias_f = params[-1].detach() if params else None        # (final layer's bias: the last of [w, b] per linear)
         ctx.set_materialize_grads(False)
         return x, ld
 
@@ -886,6 +891,19 @@ class MafInverseFn(torch.autograd.Function):
         B, D = x.shape
         gx = torch.zeros_like(x) if gx is None else gx.contiguous()
         gld = torch.zeros(B, dtype=x.dtype, device=x.device) if gld is None else gld.contiguous()
+        fpack = getattr(ctx, "fpack", None)
+        if ctx.tpack is not None and fpack is not None and ctx.tpack[4] is not None:
+            # round 5: nothing of MADE runs forward again -- `save` (the linears' inputs) from the inverse pass's own scratch, the
+            # parameters p = h_NB Wf^T + bf from its last hidden tensor by one library product, the hidden gradients from the solve's
+            tb, tt, hp, nb, gcols = ctx.tpack
+            fscratch, fcols, wf_t = fpack
+            save = ops.maf_scratch_rows(fscratch, fcols, B, nb, hp)
+            ctx.fpack = None
+            p = torch.nn.functional.linear(save[2 * nb, :B], wf_t, ctx.bias_f)
+            v, scratch = ops.maf_solve_t(x, p, gx, gld, ctx.saved_tensors[1], tb, tt, hp, nb, return_scratch=True)
+            G = ops.maf_scratch_rows(scratch, gcols, B, nb, hp, sign=-1.0, reverse_layers=True)
+            MafInverseFn.last_sweeps = 1
+            return MafInverseFn._finish(ctx, x, p, v, gld, save, None, G)
         p, save, bits = ops.made_forward_train(x, fwd[0], fwd[1], fwd[2], 2 * D, bwd["NB"])
         if ctx.tpack is not None:
             # ONE launch: back-substitution of v s + J^T g_p(v, g_ld) = g_x on the transposed pack (nf_maf_solve_t), the ReLU masks from

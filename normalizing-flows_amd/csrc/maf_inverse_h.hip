@@ -665,7 +665,8 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
 #ifdef NF_MAF_ABL_PUBLISH_ALL
         const bool pub = true;
 #else
-        const bool pub = FAST ? (t + 2 < T || (t + 1 < T && t_stop < T)) : t + 1 < T;
+        const bool pub = bits != nullptr || (FAST ? (t + 2 < T || (t + 1 < T && t_stop < T)) : t + 1 < T);   // (bits: the training
+        // forward -- nf_maf_scratch_rows reads the whole scratch back as the weight-gradient launch's activations)
 #endif
 #ifdef NF_MAF_ABL_NO_PUBLISH
         if (p[0][0] == 1.2345f)
@@ -1019,14 +1020,34 @@ maf_scratch_rows_kernel(const float *__restrict__ S, const int *__restrict__ pos
     const bool have = wt * 32 < B;
     if (have) {
         const f32x4 *src = reinterpret_cast<const f32x4 *>(S + ((size_t)wt * NL + l) * (size_t)Hp * 32);
+#pragma unroll 8
         for (int i = threadIdx.x; i < Hp * 8; i += 256) {          // f32x4 index i = (position group g = i >> 5, row n = i & 31)
             const int g = i >> 5, n = i & 31;
-            *reinterpret_cast<f32x4 *>(buf + n * pitch + 4 * g) = src[i];
+            *reinterpret_cast<f32x4 *>(buf + n * pitch + 4 * g) = __builtin_nontemporal_load(src + i);
         }
     }
     __syncthreads();
     const int lo = reverse ? NL - 1 - l : l;
     const int c4n = ldo >> 2;
+    if (256 % c4n == 0) {      // (ldo 256 / 512 / 1024: a thread keeps its four columns -- their positions are loaded once, not per row)
+        const int c4 = threadIdx.x % c4n, dn = 256 / c4n;
+        int k4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) k4[i] = pos_of_col[4 * c4 + i];
+        float *dst = out + ((size_t)lo * Bp + wt * 32) * ldo + 4 * c4;
+#pragma unroll 4
+        for (int n = threadIdx.x / c4n; n < 32; n += dn) {
+            const int64_t row = wt * 32 + n;
+            if (row >= Bp) break;
+            f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (have && row < B) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = k4[i] >= 0 ? sign * buf[n * pitch + k4[i]] : 0.0f;
+            }
+            *reinterpret_cast<f32x4 *>(dst + (size_t)n * ldo) = o;
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < 32 * c4n; e += 256) {
         const int n = e / c4n, c4 = e - n * c4n;
         const int64_t row = wt * 32 + n;

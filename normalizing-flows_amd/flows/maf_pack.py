@@ -361,12 +361,14 @@ def pack_made(made, mult=2, rows=False, blocks=(2,), tri=False):
 
 
 # ---- format 2 (round 5): the TRANSPOSED one-pass solve of the implicit backward (csrc/maf_solve_t.hip, autograd.MafInverseFn) ----
-def solve_t_gradient_columns(made, blocks=(1, 2, 3), tri=False):
+def solve_t_gradient_columns(made, blocks=(1, 2, 3), tri=False, forward=False):
     """int32 (Hp_train,): for column c of the training kernels' hidden tensors (flows/made_pack: units sorted by degree, stable) the
     PADDED position of that unit in the transposed solve's activation scratch (pack_made_transposed: forward tiles reversed, forward
     positions), -1 for the padding columns.  With it the solve's scratch IS every hidden layer's output gradient of MADE's
     input-gradient chain (nf_maf_scratch_rows rearranges it into G[l][rows][Hp_train]): the solve finalises every virtual unit once from
-    final values, which is that chain at the solution."""
+    final values, which is that chain at the solution.
+    forward=True: the positions in the INVERSE kernel's scratch (pack_made, format 0 / 1 with `tri`): its published activations are
+    relu(h_0), relu(t_0), relu(h_1), ..., h_NB -- the inputs of MADE's linears, what the weight-gradient launch multiplies G with."""
     if not supported(made, 2, blocks) or pack_made(made, blocks=blocks) is None:
         return None
     D = made.initial_layer.in_features
@@ -387,8 +389,24 @@ def solve_t_gradient_columns(made, blocks=(1, 2, 3), tri=False):
     vslot = (T - 1 - fslot // TILE) * TILE + fslot % TILE
     hp_train = 256 if H <= 256 else 512
     cols = np.full(hp_train, -1, dtype=np.int32)
-    cols[:H] = vslot[np.argsort(hid_deg, kind="stable")]
+    cols[:H] = (fslot if forward else vslot)[np.argsort(hid_deg, kind="stable")]
     return cols
+
+
+def final_layer_columns(made):
+    """int32 (2 D, Hp_train) gather indices into the flat parameter vector of flows/made_pack.index_arrays (0 = the zero entry): the
+    MASKED final-layer weight with its columns in the training kernels' column order -- params = F.linear(h_NB, this, bias) reproduces
+    MADE's output from the last hidden tensor (nets/made.py:296-304)."""
+    from . import made_pack
+    lins = [made.initial_layer] + [l for b in made.blocks for l in b.linear_layers] + [made.final_layer]
+    wi = made_pack.index_arrays([tuple(l.weight.shape) for l in lins])[-1][0]          # (2 D, H) positions
+    H = made.initial_layer.out_features
+    m = made.final_layer.mask.cpu().numpy() != 0
+    order = np.argsort(made.initial_layer.degrees.cpu().numpy(), kind="stable")
+    hp_train = 256 if H <= 256 else 512
+    src = np.zeros((wi.shape[0], hp_train), dtype=np.int32)
+    src[:, :H] = np.where(m, wi, 0)[:, order]
+    return src
 
 
 def pack_made_transposed(made, blocks=(1, 2, 3), tri=False):

@@ -1103,7 +1103,7 @@ def maf_inverse(z, blob, table, hidden_padded, logdet=None, acc=None, num_blocks
     return y, logdet
 
 
-def maf_inverse_bits(z, blob, table, hidden_padded, num_blocks, tiles, table_host=None):
+def maf_inverse_bits(z, blob, table, hidden_padded, num_blocks, tiles, table_host=None, return_scratch=False):
     """nf_maf_inverse_h_bits / nf_maf_inverse_h_tri_bits (table_host = the host copy of a format-1 table): the one-pass inverse that also
     leaves the pass's ReLU masks (uint32 words per 32-row wave, tile and lane, in the pack's positions) for maf_solve_t on a
     transposed pack of the same format.  Returns (y, logdet, bits)."""
@@ -1124,11 +1124,11 @@ def maf_inverse_bits(z, blob, table, hidden_padded, num_blocks, tiles, table_hos
         rc = lib.nf_maf_inverse_h_tri_bits(ptr(z), ptr(y), ptr(logdet), ptr(blob), ptr(table), C.c_void_p(th.ctypes.data), ptr(scratch),
                                            ptr(bits), i64(B), i32(D), i32(hidden_padded), i32(num_blocks), i32(L.LD_WRITE), L.stream())
         L.check(rc, "nf_maf_inverse_h_tri_bits")
-        return y, logdet, bits
+        return (y, logdet, bits, scratch) if return_scratch else (y, logdet, bits)
     rc = lib.nf_maf_inverse_h_bits(ptr(z), ptr(y), ptr(logdet), ptr(blob), ptr(table), ptr(scratch), ptr(bits), i64(B), i32(D),
                                    i32(hidden_padded), i32(num_blocks), i32(L.LD_WRITE), L.stream())
     L.check(rc, "nf_maf_inverse_h_bits")
-    return y, logdet, bits
+    return (y, logdet, bits, scratch) if return_scratch else (y, logdet, bits)
 
 
 def maf_solve_t(x, params, gx, gld, bits, blob, table, hidden_padded, num_blocks, return_scratch=False):

@@ -9,7 +9,7 @@ def _from_a_operand(a, K):
     return a.reshape(K // 8, 2, TILE, 4).transpose(2, 0, 1, 3).reshape(TILE, K)
 
 
-def emulate_inverse(blob, table, z, element=None):
+def emulate_inverse(blob, table, z, element=None, return_scratch=False):
     """`element(params (B, mult), z_f (B,)) -> (x_f, logabsdet_f)`: the element-wise inverse of the rows layout (one
     final-layer block per feature, nf_arnsf_inverse); None = the affine layout of nf_maf_inverse."""
     z = np.asarray(z, dtype=np.float64)
@@ -195,6 +195,8 @@ def emulate_inverse(blob, table, z, element=None):
             xg[:, s + 1] = xn
         for l in range(NL):
             S[l][:, TILE * t:TILE * (t + 1)] = pre[l]
+    if return_scratch:             # S (NL, B, Hp): the published activations (the inputs of MADE's linears) in position order
+        return x[:, :D], ld, S
     return x[:, :D], ld
 
 

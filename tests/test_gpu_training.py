@@ -438,9 +438,9 @@ def test_maf_gradients_vs_reference_autograd(nfa, monkeypatch):
     check_layer_grads(layer, g, rtol=2e-3, atol=2e-4)
     # single-pass direction: one forward / chain / weight-gradient launch; density direction (autograd.MafInverseFn, implicit
     # differentiation): one forward at the solution, ONE nf_maf_solve_t launch for the linear system (round 5; round 4: one chain per
-    # sweep, <= D = 5), NO chain for the weight gradients any more (the solve's scratch is that chain: nf_maf_scratch_rows), one
-    # weight-gradient launch
-    assert calls["fwd"] == 2 and calls["wgrad"] == 2 and calls["bwd"] == 1, calls
+    # sweep, <= D = 5), NO chain for the weight gradients and NO forward at the solution any more (the solve's scratch is that chain,
+    # the inverse pass's own scratch holds the linears' inputs: nf_maf_scratch_rows), one weight-gradient launch
+    assert calls["fwd"] == 1 and calls["wgrad"] == 2 and calls["bwd"] == 1, calls
     assert MafInverseFn.last_sweeps == 1
 
 
@@ -1772,7 +1772,8 @@ def test_maf_weight_gradients_from_the_solve_scratch(nfa, D, H, NB, B):
     (about one unit in a million) and then that ROW differs by a finite amount, so at most 1 % of the rows (+ 1) may; rows
     beyond B of the padded tensors are zero.  (2) End to end: every gradient against the path with the extra chain pass
     (config.set_maf_solve_grads(False)): 2e-5 of scale where no mask differs, summed absolute error <= 1e-3 of the summed gradient
-    otherwise; the chain launch is gone."""
+    otherwise; the chain launch is gone, and so is the MADE forward at the solution (`save` = the inverse pass's own scratch through
+    the same rearrangement, the parameters from its last hidden tensor by one product with the masked final weight)."""
     from normflows_amd import ops
     torch.manual_seed(D + H)
     layer = nfa.flows.MaskedAffineAutoregressive(D, H, num_blocks=NB)
@@ -1799,26 +1800,30 @@ def test_maf_weight_gradients_from_the_solve_scratch(nfa, D, H, NB, B):
     assert flipped <= B // 100 + 1, (flipped, B, float(row_err.max()), scale)
     # (2) end to end
     res, chains = [], []
-    real = ops.made_backward
+    real, real_f = ops.made_backward, ops.made_forward_train
     try:
         for mode in (True, False):
             nfa.config.set_maf_solve_grads(mode)
-            n = [0]
+            n = [0, 0]
 
             def spy(*a, **k):
                 n[0] += 1
                 return real(*a, **k)
-            ops.made_backward = spy
+
+            def spy_f(*a, **k):
+                n[1] += 1
+                return real_f(*a, **k)
+            ops.made_backward, ops.made_forward_train = spy, spy_f
             layer.zero_grad(set_to_none=True)
             z = z0.clone().requires_grad_(True)
             xx, ld = layer.inverse(z)
             ((xx * cx).sum() + (ld * cl).sum()).backward()
-            chains.append(n[0])
+            chains.append(tuple(n))
             res.append([z.grad] + [p.grad.clone() for p in layer.parameters()])
     finally:
-        ops.made_backward = real
+        ops.made_backward, ops.made_forward_train = real, real_f
         nfa.config.set_maf_solve_grads(True)
-    assert chains == [0, 1], chains
+    assert chains == [(0, 0), (1, 1)], chains          # (chain passes, MADE forward passes) inside the backward
     for k, (a, b) in enumerate(zip(res[0], res[1])):
         err = (a - b).abs()
         if flipped == 0:

@@ -534,6 +534,9 @@ def test_maf_pack_schedule_matches_d_pass(D, H, NB):
     assert table[6] == NB
     assert table[0] == D and table[3] % 32 == 0 and table[3] >= H
     blob1, table1 = maf_pack.pack_made(made, blocks=(1, 2, 3), tri=True)
+    fcols0 = maf_pack.solve_t_gradient_columns(made, forward=True)
+    fcols1 = maf_pack.solve_t_gradient_columns(made, tri=True, forward=True)
+    srcf = maf_pack.final_layer_columns(made)
     z = torch.randn(16, D)
     m64 = made.double()
     with torch.no_grad():
@@ -554,9 +557,34 @@ def test_maf_pack_schedule_matches_d_pass(D, H, NB):
     assert reg == [1 if maf_pack.is_regular(st) else (2 if maf_pack.extras_prefix(st) else 0) for (_, _, st) in plan]
     if (D, H) == (128, 512):
         assert reg == [2] + [1] * 15                     # config 5: degrees 1-4 own five units -> tile 0 is "regular with extras"
-    x1, ld1 = emulate_inverse(blob1, table1, z.numpy())
+    x1, ld1, S1 = emulate_inverse(blob1, table1, z.numpy(), return_scratch=True)
     np.testing.assert_allclose(x1, out.numpy(), rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(ld1, ldref.numpy(), rtol=1e-9, atol=1e-9)
+    # The activations the pass publishes are the inputs of MADE's linears at the solution: through solve_t_gradient_columns(forward=True)
+    # (nf_maf_scratch_rows on the device) they are the weight-gradient launch's `save` in the training kernels' column order, and
+    # h_NB @ flat[final_layer_columns] + bias is MADE's output there -- the implicit backward runs nothing of MADE forward again.
+    _, _, S0 = emulate_inverse(blob, table, z.numpy(), return_scratch=True)
+    lins = [m64.initial_layer] + [l for b in m64.blocks for l in b.linear_layers]
+    with torch.no_grad():
+        h = torch.nn.functional.linear(out, lins[0].weight * lins[0].mask, lins[0].bias)
+        acts = []
+        for b in range(NB):
+            acts.append(torch.relu(h))
+            t_ = torch.nn.functional.linear(torch.relu(h), lins[1 + 2 * b].weight * lins[1 + 2 * b].mask, lins[1 + 2 * b].bias)
+            acts.append(torch.relu(t_))
+            h = h + torch.nn.functional.linear(torch.relu(t_), lins[2 + 2 * b].weight * lins[2 + 2 * b].mask, lins[2 + 2 * b].bias)
+        acts.append(h)
+        prm_ref = m64(out)
+    unit_of_col = np.argsort(made.initial_layer.degrees.numpy(), kind="stable")
+    for S_, cols in ((S0, fcols0), (S1, fcols1)):
+        assert cols.shape == (256 if H <= 256 else 512,) and (cols[H:] == -1).all()
+        for l, a in enumerate(acts):
+            np.testing.assert_allclose(S_[l][:, cols[:H]], a.numpy()[:, unit_of_col], rtol=1e-9, atol=1e-9, err_msg="layer input %d" % l)
+    flat = np.concatenate([np.zeros(1)] + [q.detach().numpy().reshape(-1) for l in lins + [m64.final_layer] for q in (l.weight, l.bias)])
+    wf_t = flat[srcf]
+    hl = np.zeros((16, srcf.shape[1]))
+    hl[:, :H] = acts[-1].numpy()[:, unit_of_col]
+    np.testing.assert_allclose(hl @ wf_t.T + m64.final_layer.bias.detach().numpy(), prm_ref.numpy(), rtol=1e-9, atol=1e-9)
 
 
 @pytest.mark.parametrize("D,H,K,tails", [(64, 256, 8, "linear"), (9, 40, 4, None), (5, 12, 10, "circular"), (3, 2, 1, "linear")])
