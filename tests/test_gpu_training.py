@@ -1760,7 +1760,8 @@ def test_maf_one_pass_backward_on_format0_and_format1_packs(nfa):
             assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), (D, float((a - b).abs().max()))
 
 
-@pytest.mark.parametrize("D,H,NB,B", [(128, 512, 2, 300), (40, 100, 2, 64), (20, 40, 2, 130), (64, 252, 2, 77), (17, 40, 1, 65), (33, 70, 3, 31)])
+@pytest.mark.parametrize("D,H,NB,B", [(128, 512, 2, 300), (40, 100, 2, 64), (20, 40, 2, 130), (64, 252, 2, 77), (17, 40, 1, 65), (33, 70, 3, 31),
+                                      (5, 12, 2, 1), (20, 40, 2, 33)])
 def test_maf_weight_gradients_from_the_solve_scratch(nfa, D, H, NB, B):
     """The one-pass implicit backward hands the weight-gradient launch MADE's hidden gradients straight from the SOLVE's activation scratch
     (nf_maf_scratch_rows through maf_pack.solve_t_gradient_columns: the solve finalises every unit of the transposed network once from
