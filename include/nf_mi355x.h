@@ -491,7 +491,7 @@ int nf_maf_implicit_sweep(const void *x, const void *params, const void *gx, con
 
 /* ------------------------------------------------------------------------------------------------
  * CoupledRationalQuadraticSpline in ONE launch for the shapes beyond nf_rqs_fused's (D <= 64, hidden <= 128): up to 128 features,
- * up to 512 hidden units, 8 bins, linear tails, float32.  Replaces normflows/flows/neural_spline/wrapper.py:79-85 ->
+ * up to 512 hidden units, 8 bins (nf_nsf_wide_k: 4 | 8 | 16), linear tails, float32.  Replaces normflows/flows/neural_spline/wrapper.py:79-85 ->
  * nsf/coupling.py:71-128 (split, conditioner, coupling transform, unconditional transform, merge; the direction-dependent order),
  * :150-164, :221-253, :329-362 (parameter rows, the 1/sqrt(hidden) scaling, the batch-shared spline), nets/resnet.py:37-50, 92-104
  * (the ResidualNet conditioner) and utils/splines.py:16-219 (the spline itself); the conditioner output never exists in memory.
@@ -510,6 +510,12 @@ int nf_nsf_wide_tables(const void *uw, const void *uh, const void *ud, void *tab
 int nf_nsf_wide(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, const void *tabs,
                 const void *lu_logdet, int64_t B, int D, int hidden_padded, int direction, int acc, double tail_bound,
                 double min_bin_width, double min_bin_height, double min_derivative, nf_stream_t stream);
+/* the same with K = 4 | 8 | 16 bins (`num_bins` of wrapper.py:20-35; round 5): the pack (table[24] = K) and the tables
+ * (nf_nsf_wide_tables with the same K: (n_identity, 3 (K + 1)) floats from widths / heights (n_identity, K), derivatives
+ * (n_identity, K - 1)) are built for that K; a final-layer group then holds 8 / 4 / 2 transform features.  -ENOTSUP for other K. */
+int nf_nsf_wide_k(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, const void *tabs,
+                  const void *lu_logdet, int64_t B, int D, int hidden_padded, int K, int direction, int acc, double tail_bound,
+                  double min_bin_width, double min_bin_height, double min_derivative, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * MADE in ONE launch -- the single-pass direction of the autoregressive flows.  Replaces

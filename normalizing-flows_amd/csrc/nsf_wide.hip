@@ -1,6 +1,6 @@
 // nsf_wide.hip -- CoupledRationalQuadraticSpline (normflows/flows/neural_spline/wrapper.py:14-85 -> nsf/coupling.py:71-128, 150-164,
 // 221-253, 329-362 over nets/resnet.py:37-50, 92-104 and utils/splines.py:16-219) as ONE launch for the shapes beyond the benchmark
-// kernel's (rqs_fused.hip: D <= 64, hidden <= 128): up to 128 features and 512 hidden units, 8 bins, linear tails, float32.  Round 3
+// kernel's (rqs_fused.hip: D <= 64, hidden <= 128): up to 128 features and 512 hidden units, 4 / 8 / 16 bins, linear tails, float32.  Round 3
 // ran these as library GEMMs + nf_rqs_coupling on a materialised conditioner output (2944 B per row and 32 transform features).
 //
 // The engine is mlp_tile.hpp's (made_fwd.hip describes it): 8 waves own 64 rows for the whole layer, pre-activations in accumulator
@@ -25,19 +25,20 @@
 
 namespace nf {
 
-constexpr int NW_TABW = 3 * (F_K + 1);          // 27 floats per identity feature: cumw[9] | cumh[9] | deriv[9]
-constexpr int NW_TAB_FLOATS = 2048;             // table region at the start of the activation region (64 features x 27)
+constexpr int nw_tabw(int KB) { return 3 * (KB + 1); }          // floats per identity feature: cumw[K + 1] | cumh[K + 1] | deriv[K + 1]
+constexpr int nw_tab_floats(int KB) { return KB == 16 ? 3328 : 2048; }   // table region at the start of the activation region (64 features)
 
 // knot tables of the batch-shared spline, once per parameter version (same arithmetic as rqs_fused.hip's pack_tables_kernel)
 __global__ void nsf_wide_tables_kernel(const float *__restrict__ uw, const float *__restrict__ uh, const float *__restrict__ ud,
                                        float *__restrict__ tab, int nI, RqsParams<float> p) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nI) return;
-    const float *wj = uw + j * F_K, *hj = uh + j * F_K, *dj = ud + j * (F_K - 1);
+    const int K = p.K;
+    const float *wj = uw + j * K, *hj = uh + j * K, *dj = ud + j * (K - 1);
     auto wacc = [=](int k) { return wj[k]; };
     auto hacc = [=](int k) { return hj[k]; };
     auto dacc = [=](int k) { return dj[k]; };
-    rqs_build_table<float>(p, wacc, hacc, dacc, tab + j * NW_TABW);
+    rqs_build_table<float>(p, wacc, hacc, dacc, tab + j * 3 * (K + 1));
 }
 
 // float index of POSITION `pos` of row `row` (0 .. TR - 1) of the tile in B-operand order [pos / 4][row][4]
@@ -45,14 +46,14 @@ template <int TR>
 __device__ __forceinline__ int nw_xidx(int pos, int row) { return ((pos >> 2) * TR + row) * 4 + (pos & 3); }
 
 // batch-shared spline on the identity columns of the tile, in place; thread = (row n = tid % TR, feature residue tid / TR)
-template <bool INV, int TR>
+template <bool INV, int TR, int KB>
 __device__ __forceinline__ float nw_identity(float *xreg, const float *tabs, const RqsParams<float> &p, int nI, int tid) {
     const int n = tid % TR;
     float ld = 0.0f;
     for (int i = tid / TR; i < nI; i += 64 * MF_NW / TR) {
         float *xp = xreg + nw_xidx<TR>(i, n);                 // identity feature i sits at position i
         float y, lad;
-        rqs_table_fast<INV>(p, *xp, tabs + i * NW_TABW, y, lad);
+        rqs_table_fast<INV, KB>(p, *xp, tabs + i * nw_tabw(KB), y, lad);
         *xp = y;
         ld += lad;
     }
@@ -79,7 +80,9 @@ __device__ __forceinline__ void nw_lu_stage(MfRing &ring, const int *it, float *
 // DIR 0: density direction = prqct.forward (nsf/coupling.py:71-98); DIR 1: sampling direction = prqct.inverse (:100-128).
 // LU: with the adjacent LULinearPermute -- applied BEFORE the coupling layer in the density direction (core.py:193-195 walks the
 // flows backwards: the LU layer behind a coupling layer comes first), AFTER it in the sampling direction (core.py:177-179).
-template <int NHI, int NS, int DIR, bool LU, int TR>
+// KB bins (round 5: 4 and 16 beside 8): a lane-half's 48 accumulator values per sample block are FPL = 16 / KB whole parameter lists of
+// MP = 3 KB slots, so a final-layer group holds FPG = 2 FPL transform features (8 / 4 / 2).
+template <int NHI, int NS, int DIR, bool LU, int TR, int KB = F_K>
 __global__ void __launch_bounds__(64 * MF_NW, 1)
 nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ logdet, const float *__restrict__ blob,
                 const int *__restrict__ table, const float *__restrict__ tabs, const float *__restrict__ lu_lad, int64_t B,
@@ -90,9 +93,11 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
     const int D = table[0], Dp = table[1], Hp = table[3], NB = table[4], nI = table[5], nT = table[6], par_i = table[7],
               par_t = table[8], G = table[9], nfi = table[10], PI = table[15];
     constexpr int KGS = 8 * TR, NIG = 64 * MF_NW / TR;       // floats per k-group of activations; identity-feature residues
+    constexpr int MP = 3 * KB, FPL = 16 / KB, FPG = 2 * FPL, NW_TABW = nw_tabw(KB);
+    constexpr int NFI = KB == 16 ? 8 : 4;                    // final items a wave may own (flows/nsf_wide_pack.bins_geometry)
     float *acts = lds;                                       // [Hp / 8 k-groups][2][TR][4]
     float *xreg = lds + (size_t)(Hp / 8) * KGS;              // [Dp / 8][2][TR][4]
-    float *ldp = acts + NW_TAB_FLOATS;                       // log-det partials [G + NIG][TR], behind the staged tables
+    float *ldp = acts + nw_tab_floats(KB);                   // log-det partials [G + NIG][TR], behind the staged tables
     const int nitems = (1 + 2 * NB) * NHI + nfi + (LU ? 1 : 0);
     const int *items_all = table + MF_HDR + w * nitems * 3;  // [nitems][nkg, rb | g, sb0]
     const int *items = items_all + ((LU && DIR == 0) ? 3 : 0);   // the network's items (the density direction's LU entry comes first)
@@ -135,7 +140,7 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
         if constexpr (DIR == 1) {                            // sampling: the identity half's inverse spline comes first (:112-114)
             for (int i = tid; i < nI * NW_TABW; i += 64 * MF_NW) acts[i] = tabs[i];
             MF_BARRIER();
-            ld_ident = nw_identity<true, TR>(xreg, acts, p, nI, tid);
+            ld_ident = nw_identity<true, TR, KB>(xreg, acts, p, nI, tid);
         }
         f32x16 h[NHI][NS], t[NHI][NS];
         MF_BARRIER();
@@ -168,7 +173,9 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
 #pragma unroll
         for (int s = 0; s < NHI; ++s) mf_publish<NS, false, TR>(acts, items[3 * s + 1], items[3 * s + 2], hh, n, h[s]);
         MF_BARRIER();
-        float ldt[4][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};     // [final item][sample block] (nfi <= 4)
+        float ldt[NFI][2];                                   // [final item][sample block] (nfi <= NFI)
+#pragma unroll
+        for (int q = 0; q < NFI; ++q) ldt[q][0] = ldt[q][1] = 0.0f;
 #pragma nounroll
         for (int j = 0; j < nfi; ++j) {                       // (rolled: one copy of the item's code; the sums go to their slot by selects)
             const int *it = items + 3 * ((1 + 2 * NB) * NHI + j);
@@ -180,19 +187,19 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-                for (int f = 0; f < 2; ++f) {
-                    float prm[24];
+                for (int f = 0; f < FPL; ++f) {
+                    float prm[MP];
 #pragma unroll
-                    for (int v = 0; v < 24; ++v) prm[v] = o[(24 * f + v) >> 4][sb][(24 * f + v) & 15];
-                    const int tf = 4 * g + 2 * hh + f;
+                    for (int v = 0; v < MP; ++v) prm[v] = o[(MP * f + v) >> 4][sb][(MP * f + v) & 15];
+                    const int tf = FPG * g + FPL * hh + f;
                     const bool valid = tf < nT;
                     float *xp = xreg + nw_xidx<TR>(PI + (valid ? tf : 0), 32 * (sbo + sb) + n);
                     float yv, lad;
                     // round 5: binary bin descent (rqs_regs_t; the packed PAIR version of the benchmark kernel spilled 11-23 registers here)
 #ifdef NF_EPI_SCALAR
-                    rqs_regs<DIR == 1>(p, *xp, prm, yv, lad);
+                    rqs_regs<DIR == 1, KB>(p, *xp, prm, yv, lad);
 #else
-                    rqs_regs_t<DIR == 1>(p, *xp, prm, yv, lad);
+                    rqs_regs_t<DIR == 1, KB>(p, *xp, prm, yv, lad);
 #endif
                     if (valid) {
                         *xp = yv;
@@ -200,7 +207,7 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
                     }
                 }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NFI; ++q) {
                 ldt[q][0] = j == q ? lsum[0] : ldt[q][0];
                 ldt[q][1] = j == q ? lsum[1] : ldt[q][1];
             }
@@ -209,7 +216,7 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
         if constexpr (DIR == 0)
             for (int i = tid; i < nI * NW_TABW; i += 64 * MF_NW) acts[i] = tabs[i];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NFI; ++j) {
             if (j >= nfi) break;
             const int *it = items + 3 * ((1 + 2 * NB) * NHI + j);
             const int g = it[1], sbo = it[2];
@@ -223,7 +230,7 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
         }
         if constexpr (DIR == 0) {                            // density: the identity half's spline after the conditioner (:88-92)
             MF_BARRIER();
-            ld_ident = nw_identity<false, TR>(xreg, acts, p, nI, tid);
+            ld_ident = nw_identity<false, TR, KB>(xreg, acts, p, nI, tid);
         }
         ldp[(G + tid / TR) * TR + tid % TR] = ld_ident;
         MF_BARRIER();
@@ -254,7 +261,7 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
     }
 }
 
-template <int NHI, int NS, int DIR, bool LU, int TR>
+template <int NHI, int NS, int DIR, bool LU, int TR, int KB>
 static int nsf_wide_launch(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, const void *tabs,
                            const void *lu_lad, int64_t B, int Hp, int acc, const RqsParams<float> &p, hipStream_t st) {
     const int64_t ntiles = (B + TR - 1) / TR;
@@ -262,8 +269,8 @@ static int nsf_wide_launch(const void *x, void *y, void *logdet, const void *blo
     const size_t act_floats = (size_t)(Hp / 8) * 8 * TR;       // (>= the staged tables + the log-det partials: 2048 + 24 TR floats)
     const size_t lds = sizeof(float) * (act_floats + (size_t)16 * 8 * TR);
     static LdsOptIn opted;
-    if (opt_in_lds(reinterpret_cast<const void *>(&nsf_wide_kernel<NHI, NS, DIR, LU, TR>), lds, opted) != NF_OK) return NF_ENOTSUP;
-    hipLaunchKernelGGL((nsf_wide_kernel<NHI, NS, DIR, LU, TR>), dim3((unsigned)grid), dim3(64 * MF_NW), lds, st, (const float *)x, (float *)y,
+    if (opt_in_lds(reinterpret_cast<const void *>(&nsf_wide_kernel<NHI, NS, DIR, LU, TR, KB>), lds, opted) != NF_OK) return NF_ENOTSUP;
+    hipLaunchKernelGGL((nsf_wide_kernel<NHI, NS, DIR, LU, TR, KB>), dim3((unsigned)grid), dim3(64 * MF_NW), lds, st, (const float *)x, (float *)y,
                        (float *)logdet, (const float *)blob, (const int *)table, (const float *)tabs, (const float *)lu_lad, B, acc, p);
     NF_CHECK_LAUNCH();
     return NF_OK;
@@ -275,7 +282,7 @@ static int nsf_wide_launch(const void *x, void *y, void *logdet, const void *blo
 // PiecewiseRationalQuadraticCDF (nsf/coupling.py:170-259), once per parameter version.
 extern "C" int nf_nsf_wide_tables(const void *uw, const void *uh, const void *ud, void *tabs, int n_identity, int K, double tail_bound,
                                   double min_bin_width, double min_bin_height, double min_derivative, nf_stream_t stream) {
-    if (K != nf::F_K) return NF_ENOTSUP;
+    if (K != 4 && K != 8 && K != 16) return NF_ENOTSUP;
     if (n_identity < 1 || n_identity > 64 || min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_EINVAL;
     if (!uw || !uh || !ud || !tabs) return NF_EFAULT;
     auto p = nf::make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height, min_derivative, 1.0);
@@ -285,26 +292,36 @@ extern "C" int nf_nsf_wide_tables(const void *uw, const void *uh, const void *ud
     return NF_OK;
 }
 
+template <int DIR, bool LU, int KB>
+static int nsf_wide_dispatch_k(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, const void *tabs,
+                               const void *lu_lad, int64_t B, int Hp, int acc, const nf::RqsParams<float> &p, hipStream_t st) {
+    if (Hp == 128) return nf::nsf_wide_launch<1, 2, DIR, LU, 128, KB>(x, y, logdet, blob, table, tabs, lu_lad, B, Hp, acc, p, st);
+    if (Hp == 256) return nf::nsf_wide_launch<1, 2, DIR, LU, 64, KB>(x, y, logdet, blob, table, tabs, lu_lad, B, Hp, acc, p, st);
+    return nf::nsf_wide_launch<2, 2, DIR, LU, 64, KB>(x, y, logdet, blob, table, tabs, lu_lad, B, Hp, acc, p, st);
+}
+
 template <int DIR, bool LU>
 static int nsf_wide_dispatch(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, const void *tabs,
                              const void *lu_lad, int64_t B, int Hp, int acc, const nf::RqsParams<float> &p, hipStream_t st) {
-    if (Hp == 128) return nf::nsf_wide_launch<1, 2, DIR, LU, 128>(x, y, logdet, blob, table, tabs, lu_lad, B, Hp, acc, p, st);
-    if (Hp == 256) return nf::nsf_wide_launch<1, 2, DIR, LU, 64>(x, y, logdet, blob, table, tabs, lu_lad, B, Hp, acc, p, st);
-    return nf::nsf_wide_launch<2, 2, DIR, LU, 64>(x, y, logdet, blob, table, tabs, lu_lad, B, Hp, acc, p, st);
+    if (p.K == 4) return nsf_wide_dispatch_k<DIR, LU, 4>(x, y, logdet, blob, table, tabs, lu_lad, B, Hp, acc, p, st);
+    if (p.K == 16) return nsf_wide_dispatch_k<DIR, LU, 16>(x, y, logdet, blob, table, tabs, lu_lad, B, Hp, acc, p, st);
+    return nsf_wide_dispatch_k<DIR, LU, 8>(x, y, logdet, blob, table, tabs, lu_lad, B, Hp, acc, p, st);
 }
 
 // The coupling layer in one launch; blob / table: flows/nsf_wide_pack.pack_nsf_wide (packed for THIS direction when it carries the
 // adjacent LULinearPermute); tabs: nf_nsf_wide_tables; lu_logdet: device scalar log|det| of the LU layer, or NULL (no LU in the pack).
-extern "C" int nf_nsf_wide(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, const void *tabs,
-                           const void *lu_logdet, int64_t B, int D, int hidden_padded, int direction, int acc, double tail_bound,
-                           double min_bin_width, double min_bin_height, double min_derivative, nf_stream_t stream) {
+// ... with K bins (4 | 8 | 16; pack and tables built for the same K: flows/nsf_wide_pack.pack_nsf_wide writes it to table[24])
+extern "C" int nf_nsf_wide_k(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, const void *tabs,
+                             const void *lu_logdet, int64_t B, int D, int hidden_padded, int K, int direction, int acc, double tail_bound,
+                             double min_bin_width, double min_bin_height, double min_derivative, nf_stream_t stream) {
     if (B < 0 || D < 2 || D > 128 || direction < 0 || direction > 1) return NF_EINVAL;
     if (acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
     if (hidden_padded != 128 && hidden_padded != 256 && hidden_padded != 512) return NF_ENOTSUP;
-    if (min_bin_width * nf::F_K > 1.0 || min_bin_height * nf::F_K > 1.0) return NF_EINVAL;
+    if (K != 4 && K != 8 && K != 16) return NF_ENOTSUP;
+    if (min_bin_width * K > 1.0 || min_bin_height * K > 1.0) return NF_EINVAL;
     if (B == 0) return NF_OK;
     if (!x || !y || !logdet || !blob || !table || !tabs) return NF_EFAULT;
-    auto p = nf::make_rqs_params<float>(nf::F_K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height, min_derivative, 1.0);
+    auto p = nf::make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height, min_derivative, 1.0);
     hipStream_t st = (hipStream_t)stream;
     const int Hp = hidden_padded;
     if (direction == 0) {
@@ -313,4 +330,11 @@ extern "C" int nf_nsf_wide(const void *x, void *y, void *logdet, const void *blo
     }
     if (lu_logdet) return nsf_wide_dispatch<1, true>(x, y, logdet, blob, table, tabs, lu_logdet, B, Hp, acc, p, st);
     return nsf_wide_dispatch<1, false>(x, y, logdet, blob, table, tabs, nullptr, B, Hp, acc, p, st);
+}
+
+extern "C" int nf_nsf_wide(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, const void *tabs,
+                           const void *lu_logdet, int64_t B, int D, int hidden_padded, int direction, int acc, double tail_bound,
+                           double min_bin_width, double min_bin_height, double min_derivative, nf_stream_t stream) {
+    return nf_nsf_wide_k(x, y, logdet, blob, table, tabs, lu_logdet, B, D, hidden_padded, nf::F_K, direction, acc, tail_bound, min_bin_width,
+                         min_bin_height, min_derivative, stream);
 }

@@ -362,7 +362,7 @@ class PiecewiseRationalQuadraticCoupling(Coupling):
     def _wide(self, inputs, packed, direction, ld, acc):
         blob, table, tabs, hp, lad = packed
         return ops.nsf_wide(inputs, blob, table, tabs, hp, direction, self.tail_bound, self.min_bin_width, self.min_bin_height,
-                            self.min_derivative, logdet=ld, acc=acc, lu_logdet=lad)
+                            self.min_derivative, logdet=ld, acc=acc, lu_logdet=lad, K=self.num_bins)
 
     # -- images (nsf/coupling.py:150-160): every pixel is a row of C channel features for the 2-D coupling kernel ----
     def _image(self, inputs, context, sample, ld, acc):

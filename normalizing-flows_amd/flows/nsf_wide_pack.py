@@ -1,6 +1,6 @@
 """Host-side packing for the one-launch NSF coupling layer on 64-row tiles (nf_nsf_wide, csrc/nsf_wide.hip): the shapes of
 CoupledRationalQuadraticSpline (normflows/flows/neural_spline/wrapper.py:20-35 over nets/resnet.py:53-104) beyond the benchmark
-kernel's (csrc/rqs_fused.hip: D <= 64, hidden <= 128) -- up to 128 features and 512 hidden units, 8 bins, linear tails.
+kernel's (csrc/rqs_fused.hip: D <= 64, hidden <= 128) -- up to 128 features and 512 hidden units, 4 / 8 / 16 bins, linear tails.
 
 This module only rearranges weights (no arithmetic on data besides the constant log2(e) / sqrt(hidden) folded into the width / height
 rows, nsf/coupling.py:334-339).  Geometry (csrc/mlp_tile.hpp, nsf_wide.hip):
@@ -25,7 +25,7 @@ rows, nsf/coupling.py:334-339).  Geometry (csrc/mlp_tile.hpp, nsf_wide.hip):
     layer), LAST in the sampling direction -- so a pack is per direction.
 
 int32 table : hdr[32] = [D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, total floats, nhi, has_lu, TR, PI], hdr[16 + w] = offset (floats)
-              of wave w's stream; then per wave: [LU entry (density)] | (1 + 2 NB) nhi hidden entries [nkg, rb, sb0] | nfi final
+              of wave w's stream, hdr[24] = bins; then per wave: [LU entry (density)] | (1 + 2 NB) nhi hidden entries [nkg, rb, sb0] | nfi final
               entries [nkg, g, sb0] (g = -1: none; a group's item covers sample blocks sb0, sb0 + 1) | [LU entry (sampling)]; LU entry =
               [nkg, rb, sb0] (rb = -1: none).
 """
@@ -35,9 +35,17 @@ import torch
 from .made_pack import ROWS, KG, RING, a_stream, bias_group
 
 HDR = 32
-K_BINS = 8
-M = 3 * K_BINS - 1      # 23 parameters per transform feature
-MP = 3 * K_BINS         # 24 slots
+K_BINS = 8              # the default; 4 and 16 bins ride the same schedule (round 5): a lane's 48 accumulator values per sample block
+M = 3 * K_BINS - 1      # are 48 / (3 K) whole parameter lists -- K = 4: four features of 12 slots, 8: two of 24, 16: one of 48 -- so a
+MP = 3 * K_BINS         # group (3 row-blocks, both lane-halves) holds 8 / 4 / 2 transform features
+SUPPORTED_BINS = (4, 8, 16)
+
+
+def bins_geometry(K):
+    """(parameters per feature, slots per feature, features per lane-half, features per group, final items a wave may own)."""
+    mp = 3 * K
+    fpl = 48 // mp
+    return 3 * K - 1, mp, fpl, 2 * fpl, (8 if K == 16 else 4)
 
 
 def geometry(Hp):
@@ -55,15 +63,16 @@ def hidden_item(Hp, w, i):
     return w + 8 * i, 0
 
 
-def final_row(g, r3, rho, nT):
-    """Row of the (23 nT, hidden) final weight held by MFMA row rho of row-block r3 of group g, or -1 (padding)."""
+def final_row(g, r3, rho, nT, K=K_BINS):
+    """Row of the ((3 K - 1) nT, hidden) final weight held by MFMA row rho of row-block r3 of group g, or -1 (padding)."""
+    m, mp, fpl, fpg, _ = bins_geometry(K)
     q, hh, i = rho >> 3, (rho >> 2) & 1, rho & 3
     v = 16 * r3 + 4 * q + i
-    f, prm = v // MP, v % MP
-    tf = 4 * g + 2 * hh + f
-    if prm >= M or tf >= nT:
+    f, prm = v // mp, v % mp
+    tf = fpg * g + fpl * hh + f
+    if prm >= m or tf >= nT:
         return -1
-    return tf * M + prm
+    return tf * m + prm
 
 
 def supported(prqct):
@@ -73,7 +82,8 @@ def supported(prqct):
         return False
     if prqct.tails != "linear" or getattr(prqct, "_per_feature", False) or prqct.unconditional_transform is None:
         return False
-    if prqct.num_bins != K_BINS or prqct.min_bin_width * K_BINS > 1.0 or prqct.min_bin_height * K_BINS > 1.0:
+    K = prqct.num_bins
+    if K not in SUPPORTED_BINS or prqct.min_bin_width * K > 1.0 or prqct.min_bin_height * K > 1.0:
         return False
     D = prqct.features
     if not (2 <= D <= 128 and 1 <= net.hidden_features <= 512 and len(net.blocks) >= 1 and len(net.blocks) <= 7):
@@ -104,9 +114,13 @@ def pack_nsf_wide(prqct, lu=None, direction=0):
     col_of[:nI] = ident
     col_of[PI:PI + nT] = trans
     nhi, NS, TR = geometry(Hp)
-    G = (nT + 3) // 4
+    K = prqct.num_bins
+    M_, MP_, FPL, FPG, nfi_max = bins_geometry(K)
+    G = (nT + FPG - 1) // FPG
     nsp = TR // 64                      # pairs of sample blocks per tile: a final item = (group, pair)
     nfi = (G * nsp + 7) // 8
+    if nfi > nfi_max:                   # (the kernel keeps a wave's log-det sums per final item in registers)
+        return None
     f32 = lambda t: t.detach().cpu().numpy().astype(np.float32)
 
     W0 = np.zeros((Hp, PI), dtype=np.float32)
@@ -126,7 +140,7 @@ def pack_nsf_wide(prqct, lu=None, direction=0):
             b[:H] = f32(lin.bias)
             layers.append((W, b))
     wf, bf = f32(net.final_layer.weight), f32(net.final_layer.bias)        # (23 nT, H)
-    if wf.shape[0] != M * nT:
+    if wf.shape[0] != M_ * nT:
         return None
     wh_scale = np.float32(1.4426950408889634 / np.sqrt(float(H)))          # log2(e) / sqrt(hidden): rqs_regs takes exp2
     WF = np.zeros((G, 3, ROWS, Kh), dtype=np.float32)
@@ -134,9 +148,9 @@ def pack_nsf_wide(prqct, lu=None, direction=0):
     for g in range(G):
         for r3 in range(3):
             for rho in range(ROWS):
-                row = final_row(g, r3, rho, nT)
+                row = final_row(g, r3, rho, nT, K)
                 if row >= 0:
-                    sc = wh_scale if (row % M) < 2 * K_BINS else np.float32(1.0)
+                    sc = wh_scale if (row % M_) < 2 * K else np.float32(1.0)
                     WF[g, r3, rho, :H] = wf[row] * sc
                     BF[g, r3, rho] = bf[row] * sc
 
@@ -194,6 +208,7 @@ def pack_nsf_wide(prqct, lu=None, direction=0):
         chunks.append(stream)
         off += stream.size
     hdr[:16] = [D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, off, nhi, int(has_lu), TR, PI]
+    hdr[24] = K
     blob = np.concatenate(chunks).astype(np.float32)
     assert blob.size == off and off < 2 ** 31
     return blob, np.concatenate([hdr, tab.reshape(-1)]).astype(np.int32)

@@ -891,7 +891,7 @@ def rqs_fused_x3_chain(x, blobs, parities, hidden, num_blocks, K, direction, log
 
 
 def nsf_wide_tables(uw, uh, ud, K, tail_bound, min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3):
-    """Knot tables (n_identity, 27) of the batch-shared spline for nf_nsf_wide (nsf/coupling.py:170-259)."""
+    """Knot tables (n_identity, 3 (K + 1)) of the batch-shared spline for nf_nsf_wide (nsf/coupling.py:170-259)."""
     L.require_device(uw, uh, ud)
     tabs = torch.empty(uw.shape[0], 3 * (K + 1), dtype=torch.float32, device=uw.device)
     rc = L.lib().nf_nsf_wide_tables(ptr(uw.contiguous()), ptr(uh.contiguous()), ptr(ud.contiguous()), ptr(tabs), i32(uw.shape[0]),
@@ -902,9 +902,10 @@ def nsf_wide_tables(uw, uh, ud, K, tail_bound, min_bin_width=1e-3, min_bin_heigh
 
 
 def nsf_wide(x, blob, table, tabs, hidden_padded, direction, tail_bound, min_bin_width=1e-3, min_bin_height=1e-3,
-             min_derivative=1e-3, logdet=None, acc=None, lu_logdet=None):
-    """CoupledRationalQuadraticSpline beyond the benchmark kernel's shapes as one launch (nf_nsf_wide); blob / table from
-    flows/nsf_wide_pack.pack_nsf_wide, tabs from nsf_wide_tables; lu_logdet: device scalar of the LULinearPermute packed with it."""
+             min_derivative=1e-3, logdet=None, acc=None, lu_logdet=None, K=8):
+    """CoupledRationalQuadraticSpline beyond the benchmark kernel's shapes as one launch (nf_nsf_wide_k); blob / table from
+    flows/nsf_wide_pack.pack_nsf_wide, tabs from nsf_wide_tables (both for K bins: 4 | 8 | 16); lu_logdet: device scalar of the
+    LULinearPermute packed with it."""
     L.require_device(x, blob, table, tabs, lu_logdet)
     if x.dtype != torch.float32:
         raise NotImplementedError("nsf_wide: float32 only")
@@ -916,10 +917,10 @@ def nsf_wide(x, blob, table, tabs, hidden_padded, direction, tail_bound, min_bin
         acc = L.LD_WRITE
     elif acc is None:
         acc = L.LD_ADD
-    rc = L.lib().nf_nsf_wide(ptr(x), ptr(y), ptr(logdet), ptr(blob), ptr(table), ptr(tabs), ptr(lu_logdet), i64(B), i32(D), i32(hidden_padded),
-                             i32(direction), i32(acc), f64(float(tail_bound)), f64(min_bin_width), f64(min_bin_height),
-                             f64(min_derivative), L.stream())
-    L.check(rc, "nf_nsf_wide")
+    rc = L.lib().nf_nsf_wide_k(ptr(x), ptr(y), ptr(logdet), ptr(blob), ptr(table), ptr(tabs), ptr(lu_logdet), i64(B), i32(D), i32(hidden_padded),
+                               i32(int(K)), i32(direction), i32(acc), f64(float(tail_bound)), f64(min_bin_width), f64(min_bin_height),
+                               f64(min_derivative), L.stream())
+    L.check(rc, "nf_nsf_wide_k")
     return y, logdet
 
 

@@ -1,6 +1,6 @@
 """numpy walk-through of the NSF coupling layer's conditioner exactly as csrc/nsf_wide.hip walks the packed streams of
-flows/nsf_wide_pack.py (hidden items per wave, final layer in groups of 4 transform features = 3 row-blocks whose accumulator
-registers are the lane's parameter list).  Test infrastructure: pins the packing on CPU against the dense ResidualNet."""
+flows/nsf_wide_pack.py (hidden items per wave, final layer in groups of 8 / 4 / 2 transform features (4 / 8 / 16 bins) = 3 row-blocks
+whose accumulator registers are the lane's parameter lists).  Test infrastructure: pins the packing on CPU against the dense ResidualNet."""
 import numpy as np
 
 HDR, ROWS, KG, RING, M, MP = 32, 32, 8, 8, 23, 24
@@ -17,12 +17,17 @@ def _bias(g):
 
 
 def emulate_conditioner(blob, table, x, direction=0):
-    """((B, nT, 24) parameter lists as the kernel's lanes hold them (widths / heights still carry log2(e) / sqrt(hidden)), LU output
+    """((B, nT, 3 K) parameter lists as the kernel's lanes hold them (widths / heights still carry log2(e) / sqrt(hidden)), LU output
     (B, D) or None), from full rows x (B, D).  With a fused LU: density = LU(x) first and the conditioner sees ITS output; sampling =
     the LU item comes last in the streams and is applied to x here only to check its packing."""
     blob = blob.astype(np.float64)
     D, Dp, H, Hp, NB, nI, nT, par_i, par_t, G, nfi, total, nhi, has_lu, TR, PI = [int(v) for v in table[:16]]
     assert TR == (128 if Hp == 128 else 64) and PI % 32 == 0 and (Dp - PI) % 32 == 0 and PI >= nI and Dp - PI >= nT
+    K = int(table[24]) or 8
+    MP = 3 * K                       # slots per feature; a lane-half holds FPL = 48 / MP features per group
+    FPL = 48 // MP
+    FPG = 2 * FPL
+    assert G == (nT + FPG - 1) // FPG
     nhl = 1 + 2 * NB
     nitems = nhl * nhi + nfi + has_lu
     base = 1 if (has_lu and direction == 0) else 0
@@ -82,7 +87,7 @@ def emulate_conditioner(blob, table, x, direction=0):
     for b in range(NB):
         t = hidden_layer(1 + 2 * b, np.maximum(h, 0.0))
         h = h + hidden_layer(2 + 2 * b, np.maximum(t, 0.0))
-    prm = np.zeros((B, 4 * G, MP))
+    prm = np.zeros((B, FPG * G, MP))
     seen = set()
     for w in range(8):
         for j in range(nfi):
@@ -104,7 +109,7 @@ def emulate_conditioner(blob, table, x, direction=0):
                 for rho in range(ROWS):
                     q, hh, i = rho >> 3, (rho >> 2) & 1, rho & 3
                     v = 16 * r3 + 4 * q + i
-                    prm[:, 4 * g + 2 * hh + v // MP, v % MP] = acc[r3][:, rho]
+                    prm[:, FPG * g + FPL * hh + v // MP, v % MP] = acc[r3][:, rho]
     assert seen == {(g, sb0) for g in range(G) for sb0 in range(0, TR // 32, 2)}      # every (group, sample-block pair) has one owner
     if has_lu and direction == 1:
         lu_out = to_columns(lu_stage(nitems - 1, xin))

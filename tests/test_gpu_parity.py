@@ -1157,16 +1157,20 @@ def test_maf_incremental_inverse_vs_d_pass(nfa, D, H, B):
     assert_close(N(x2), N(x3), what="x after update", rtol=2e-4, atol=2e-4)
 
 
-@pytest.mark.parametrize("D,H,NB,rev,B", [(64, 256, 2, False, 300), (128, 128, 2, False, 65), (128, 256, 1, True, 129),
-                                          (96, 192, 2, False, 64), (7, 300, 2, True, 33), (66, 512, 3, False, 257),
-                                          (128, 512, 2, False, 4099), (65, 129, 2, True, 1)])
-def test_nsf_wide_one_launch_vs_layerwise_and_oracle(nfa, oracle, D, H, NB, rev, B):
+@pytest.mark.parametrize("D,H,NB,rev,B,K", [(64, 256, 2, False, 300, 8), (128, 128, 2, False, 65, 8), (128, 256, 1, True, 129, 8),
+                                            (96, 192, 2, False, 64, 8), (7, 300, 2, True, 33, 8), (66, 512, 3, False, 257, 8),
+                                            (128, 512, 2, False, 4099, 8), (65, 129, 2, True, 1, 8),
+                                            (64, 256, 2, False, 300, 4), (128, 128, 2, False, 65, 4), (66, 512, 3, True, 257, 4),
+                                            (7, 300, 2, True, 33, 4), (128, 256, 1, True, 129, 16), (128, 128, 2, False, 193, 16),
+                                            (128, 512, 2, False, 1030, 16), (30, 140, 2, False, 64, 16), (65, 129, 2, True, 1, 16)])
+def test_nsf_wide_one_launch_vs_layerwise_and_oracle(nfa, oracle, D, H, NB, rev, B, K):
     """nf_nsf_wide (csrc/nsf_wide.hip: the coupling layer beyond the benchmark kernel's shapes as one launch -- ResidualNet on fp32
     MFMA with the activations on chip, the spline on the accumulator registers, the batch-shared spline on the identity half)
     against (a) the layer-wise path (library GEMMs + nf_rqs_coupling, itself pinned to the reference's fixtures) and (b) the CPU
-    oracle in double precision, both directions, on a strongly non-identity layer with inputs beyond the tails."""
+    oracle in double precision, both directions, on a strongly non-identity layer with inputs beyond the tails.  Round 5: 4 and 16
+    bins on the same schedule (nf_nsf_wide_k: 8 / 2 transform features per final-layer group instead of 4)."""
     torch.manual_seed(D * 7 + H)
-    layer = nfa.flows.CoupledRationalQuadraticSpline(D, NB, H, num_bins=8, init_identity=False, reverse_mask=rev)
+    layer = nfa.flows.CoupledRationalQuadraticSpline(D, NB, H, num_bins=K, init_identity=False, reverse_mask=rev)
     with torch.no_grad():
         for p_ in layer.parameters():
             p_.add_(0.04 * torch.randn_like(p_))
@@ -1220,7 +1224,7 @@ def test_nsf_wide_one_launch_vs_layerwise_and_oracle(nfa, oracle, D, H, NB, rev,
     # the CPU oracle in double precision on the same weights (both directions)
     st = {"flows.0." + k: (v.detach().cpu().double().numpy() if v.is_floating_point() else v.cpu().numpy())
           for k, v in layer.state_dict().items()}
-    ora = oracle.OracleNSF(st, num_layers=1, K=8, tail_bound=3.0)
+    ora = oracle.OracleNSF(st, num_layers=1, K=K, tail_bound=3.0)
     x64 = N(x_all).astype(np.float64)
     for name, direction in (("inv", 0), ("fwd", 1)):
         lq = np.zeros(B)
@@ -1264,6 +1268,12 @@ def test_round4_entry_points_reject_bad_arguments_and_replay_in_graphs(nfa):
     assert lib.nf_nsf_wide(one, one, one, one, one, one, nul, i64(5), i32(64), i32(256), i32(0), i32(0), f64(3.0), f64(0.2),
                            f64(1e-3), f64(1e-3), st) == -22                                  # min_bin_width * 8 > 1 (utils/splines.py:121-124)
     assert lib.nf_nsf_wide_tables(one, one, one, one, i32(32), i32(10), f64(3.0), f64(1e-3), f64(1e-3), f64(1e-3), st) == -95   # bins
+    assert lib.nf_nsf_wide_k(one, one, one, one, one, one, nul, i64(5), i32(64), i32(256), i32(10), i32(0), i32(0), f64(3.0), f64(1e-3),
+                             f64(1e-3), f64(1e-3), st) == -95                                                      # bins: 4 | 8 | 16
+    assert lib.nf_nsf_wide_k(one, one, one, one, one, one, nul, i64(5), i32(64), i32(256), i32(16), i32(0), i32(0), f64(3.0), f64(0.07),
+                             f64(1e-3), f64(1e-3), st) == -22                                                      # min_bin_width * 16 > 1
+    assert lib.nf_nsf_wide_k(nul, nul, nul, nul, nul, nul, nul, i64(0), i32(64), i32(256), i32(4), i32(0), i32(0), f64(3.0), f64(1e-3),
+                             f64(1e-3), f64(1e-3), st) == 0
     assert lib.nf_nsf_wide_tables(one, one, one, one, i32(80), i32(8), f64(3.0), f64(1e-3), f64(1e-3), f64(1e-3), st) == -22    # > 64 features
     # hipGraph replay of a MAF model's forward direction and of a wide NSF model's log_prob
     torch.manual_seed(3)

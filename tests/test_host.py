@@ -1177,9 +1177,10 @@ def test_made_forward_pack_rejects_unsupported():
     assert made_pack.pack_made_forward(nets.MADE(features=8, hidden_features=600, num_blocks=2, output_multiplier=2)) is None
 
 
-@pytest.mark.parametrize("D,H,NB,rev", [(64, 256, 2, False), (128, 128, 2, False), (128, 256, 1, True), (96, 192, 2, False),
-                                        (7, 300, 2, True), (66, 512, 3, False)])
-def test_nsf_wide_pack_matches_dense_conditioner(D, H, NB, rev):
+@pytest.mark.parametrize("D,H,NB,rev,K", [(64, 256, 2, False, 8), (128, 128, 2, False, 8), (128, 256, 1, True, 8), (96, 192, 2, False, 8),
+                                          (7, 300, 2, True, 8), (66, 512, 3, False, 8), (64, 256, 2, False, 4), (128, 256, 1, True, 16),
+                                          (128, 128, 2, False, 4), (30, 100, 2, True, 16), (9, 200, 2, False, 4), (128, 512, 2, False, 16)])
+def test_nsf_wide_pack_matches_dense_conditioner(D, H, NB, rev, K):
     """flows/nsf_wide_pack.py (zero-padded hidden units, the initial layer on full rows, the final layer in groups of four
     transform features whose MFMA rows are the lanes' 2 x 24 parameter lists, width / height rows pre-scaled by log2(e) / sqrt(H))
     + the kernel's walk over the per-wave streams (tests/nsf_wide_emulator.py) reproduce the reference-layout conditioner
@@ -1188,13 +1189,14 @@ def test_nsf_wide_pack_matches_dense_conditioner(D, H, NB, rev):
     from normflows_amd.flows import nsf_wide_pack
     from nsf_wide_emulator import emulate_conditioner
     torch.manual_seed(D + H)
-    layer = nfa.flows.CoupledRationalQuadraticSpline(D, NB, H, num_bins=8, init_identity=False, reverse_mask=rev)
+    layer = nfa.flows.CoupledRationalQuadraticSpline(D, NB, H, num_bins=K, init_identity=False, reverse_mask=rev)
     with torch.no_grad():
         for p in layer.parameters():
             p.add_(0.05 * torch.randn_like(p))
     prqct = layer.prqct
     blob, table = nsf_wide_pack.pack_nsf_wide(prqct)
-    assert table[0] == D and table[3] in (128, 256, 512) and table[3] >= H and blob.size % 256 == 0
+    assert table[0] == D and table[3] in (128, 256, 512) and table[3] >= H and blob.size % 256 == 0 and table[24] == K
+    M_ = 3 * K - 1                   # (round 5: 4 / 16 bins on the same schedule: 8 / 2 transform features per group instead of 4)
     x = torch.randn(5, D)
     nT = len(prqct.transform_features)
     import copy
@@ -1203,15 +1205,15 @@ def test_nsf_wide_pack_matches_dense_conditioner(D, H, NB, rev):
 
     def reference(rows):
         with torch.no_grad():
-            r = net64(rows.double().index_select(1, prqct.identity_features)).numpy().reshape(5, nT, 23).copy()
-        r[:, :, :16] *= sc
+            r = net64(rows.double().index_select(1, prqct.identity_features)).numpy().reshape(5, nT, M_).copy()
+        r[:, :, :2 * K] *= sc
         return r
 
     got, lu_out = emulate_conditioner(blob, table, x.numpy())
     ref_s = reference(x)
     assert lu_out is None
-    assert np.max(np.abs(got[:, :, :23] - ref_s)) < 1e-5 * max(1.0, np.abs(ref_s).max())     # (the scale is applied in float32)
-    assert np.all(got[:, :, 23] == 0.0)
+    assert np.max(np.abs(got[:, :, :M_] - ref_s)) < 1e-5 * max(1.0, np.abs(ref_s).max())     # (the scale is applied in float32)
+    assert np.all(got[:, :, M_] == 0.0)
     # with the adjacent LULinearPermute as a dense product: first in the density direction, last in the sampling direction
     g = torch.Generator().manual_seed(1)
     Wl, bl = torch.randn(D, D, generator=g) / np.sqrt(D), torch.randn(D, generator=g)
@@ -1220,12 +1222,12 @@ def test_nsf_wide_pack_matches_dense_conditioner(D, H, NB, rev):
     got, lu_out = emulate_conditioner(blob, table, x.numpy(), 0)
     assert np.max(np.abs(lu_out - xl.numpy())) < 1e-5
     ref_s = reference(xl.float())
-    assert np.max(np.abs(got[:, :, :23] - ref_s)) < 1e-4 * max(1.0, np.abs(ref_s).max())
+    assert np.max(np.abs(got[:, :, :M_] - ref_s)) < 1e-4 * max(1.0, np.abs(ref_s).max())
     blob, table = nsf_wide_pack.pack_nsf_wide(prqct, lu=(Wl.numpy(), bl.numpy()), direction=1)
     got, lu_out = emulate_conditioner(blob, table, x.numpy(), 1)
     assert np.max(np.abs(lu_out - xl.numpy())) < 1e-5
     ref_s = reference(x)
-    assert np.max(np.abs(got[:, :, :23] - ref_s)) < 1e-5 * max(1.0, np.abs(ref_s).max())
+    assert np.max(np.abs(got[:, :, :M_] - ref_s)) < 1e-5 * max(1.0, np.abs(ref_s).max())
 
 
 def test_nsf_wide_pack_rejects_unsupported():

@@ -1,6 +1,6 @@
 """log_prob time of NSF models next to the benchmark shape: [CoupledRationalQuadraticSpline(D, 2, hidden) + LULinearPermute(D)] x 4
 at B = 65 536 for (D, hidden) in the fused kernel's range and beyond it (hidden 256, D 128: library GEMMs for the conditioner,
-nf_rqs_coupling's pipelined kernel, the dense LU product).  python tools/wide_bench.py [--json out.json]"""
+nf_rqs_coupling's pipelined kernel, the dense LU product).  python tools/wide_bench.py [--json out.json] [--only D hidden] [--bins K]"""
 import json
 import os
 import sys
@@ -17,11 +17,12 @@ shapes = ((64, 128), (64, 256), (128, 128), (128, 256), (96, 192))
 if "--only" in sys.argv:
     i = sys.argv.index("--only")
     shapes = ((int(sys.argv[i + 1]), int(sys.argv[i + 2])),)
+K = int(sys.argv[sys.argv.index("--bins") + 1]) if "--bins" in sys.argv else 8
 for D, hidden in shapes:
     torch.manual_seed(0)
     flows = []
     for _ in range(pairs):
-        flows += [nfa.flows.CoupledRationalQuadraticSpline(D, 2, hidden, num_bins=8), nfa.flows.LULinearPermute(D)]
+        flows += [nfa.flows.CoupledRationalQuadraticSpline(D, 2, hidden, num_bins=K), nfa.flows.LULinearPermute(D)]
     m = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(D, trainable=False), flows).to(dev)
     for p in m.parameters():
         p.add_(0.01 * torch.randn_like(p))
@@ -45,8 +46,8 @@ for D, hidden in shapes:
     ms_lw = timed()
     lp0 = m.log_prob(x)
     nfa.config.set_nsf_wide(True)
-    flop = 2.0 * B * pairs * (D // 2 * hidden + 4 * hidden * hidden + hidden * (D // 2) * 23 + D * D)
-    out.append(dict(D=D, hidden=hidden, pairs=pairs, rows=B, ms=round(ms, 3), us_per_pair=round(ms * 1e3 / pairs, 1),
+    flop = 2.0 * B * pairs * (D // 2 * hidden + 4 * hidden * hidden + hidden * (D // 2) * (3 * K - 1) + D * D)
+    out.append(dict(D=D, hidden=hidden, bins=K, pairs=pairs, rows=B, ms=round(ms, 3), us_per_pair=round(ms * 1e3 / pairs, 1),
                     mrows_per_s=round(B / ms / 1e3, 2), tflops=round(flop / ms / 1e9, 1),
                     frac_of_fp32_mfma_peak=round(flop / ms / 1e9 / 157.3, 3), layerwise_ms=round(ms_lw, 3),
                     max_rel_diff_log_prob_vs_layerwise=float(((lp1 - lp0).abs() / lp0.abs().clamp_min(1.0)).max())))
