@@ -194,6 +194,103 @@ def cpu_baseline(model, rows, gpu_lp=None, gpu_lp3=None):
     return res
 
 
+class CollectiveCounter:
+    """Counts the data-path collectives issued inside a `with` block (calls, payload bytes): EVERY torch.distributed collective
+    entry point is wrapped, not only all_reduce -- a contract test on `collectives_per_step` must not pass because the code under
+    test moved to all_gather -- and the originals are restored on exit, exception or not."""
+    NAMES = ("all_reduce", "all_gather", "all_gather_into_tensor", "reduce", "broadcast", "reduce_scatter", "reduce_scatter_tensor",
+             "all_to_all", "all_to_all_single", "gather", "scatter", "all_reduce_coalesced", "all_gather_coalesced")
+
+    def __init__(self, active=True):
+        self.active, self.coll, self.saved = active, {"calls": 0, "bytes": 0, "by_op": {}}, {}
+
+    def _wrap(self, name, fn):
+        def counted(*a, **k):
+            nbytes = 0
+            for t_ in list(a) + list(k.values()):
+                for u in (t_ if isinstance(t_, (list, tuple)) else (t_,)):
+                    if torch.is_tensor(u):
+                        nbytes = max(nbytes, u.numel() * u.element_size())
+            self.coll["calls"] += 1
+            self.coll["bytes"] += nbytes
+            self.coll["by_op"][name] = self.coll["by_op"].get(name, 0) + 1
+            return fn(*a, **k)
+        return counted
+
+    def __enter__(self):
+        import torch.distributed as dist
+        if self.active:
+            for name in self.NAMES:
+                fn = getattr(dist, name, None)
+                if fn is not None:
+                    self.saved[name] = fn
+                    setattr(dist, name, self._wrap(name, fn))
+        return self
+
+    def __exit__(self, *exc):
+        import torch.distributed as dist
+        for name, fn in self.saved.items():
+            setattr(dist, name, fn)
+        self.saved = {}
+        return False
+
+
+def make_train_step(model, x, world=1, group=None):
+    """One training step of the benchmark model as a closure: forward_kld (core.py:87-102) + backward + [gradient average over the
+    ranks, overlapped with backward] + Adam.  Round 6: the parameters are views of ONE flat tensor (dp.FlatParameters): the backward
+    kernels write every gradient into one flat buffer, torch.optim.Adam(fused=True) steps one tensor (one launch instead of 17) and
+    the data-parallel all-reduces run on slices of that buffer in place."""
+    from normflows_amd import dp
+    model.use_graphs(False)
+    flat = dp.FlatParameters(model)
+    opt = torch.optim.Adam(flat.parameters(), lr=1e-4, fused=True)
+    avg = dp.OverlappedGradientAverager(flat.params, group=group, bucket_bytes=8 << 20, flat=flat) if world > 1 else None
+
+    def one_step():
+        flat.zero_grad()
+        loss_ = model.forward_kld(x)          # -mean(log_q) of the rank's rows; equal shards: the average of the ranks' gradients
+        loss_.backward()                      # is the gradient of the global mean
+        if avg is not None:
+            avg.finish()
+        flat.sync()
+        opt.step()
+        return loss_
+    return one_step, flat, opt
+
+
+def train_step_record(model, x, world=1, steps=10):
+    """The `train_step` record of `secondary` (N = 1): median of individually synchronised steps and the mean of back-to-back ones."""
+    one_step, flat, opt = make_train_step(model, x, world)
+    ts = []
+    for i in range(3 + steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss = one_step()
+        torch.cuda.synchronize()
+        if i >= 3:
+            ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]     # median of 10 individually synchronised steps (the mean is sensitive to allocator warm-up)
+    torch.cuda.synchronize()   # ... and the same 10 steps back to back, as a training loop runs them (no sync in between)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    flop = 3 * c2_flops_per_sample(layers=len(model.flows) // 2) * x.shape[0]
+    rec = {"workload": "forward_kld + backward + Adam on the benchmark model and batch", "ms_per_step": dt * 1e3,
+           "optimizer": "torch.optim.Adam(lr=1e-4, fused=True) on dp.FlatParameters(model).parameters() (one flat tensor)",
+           "statistic": "mean of 10 back-to-back steps", "ms_median_synchronised": med * 1e3,
+           "ms_min_synchronised": ts[0] * 1e3, "ms_max_synchronised": ts[-1] * 1e3, "steps": steps,
+           "samples_per_s": x.shape[0] / dt, "loss": float(loss.detach()),
+           # forward + backward = 3 x the forward pass's FLOP (input and weight gradients each repeat its products)
+           "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.3, "achieved": flop / dt / 1e12,
+                        "frac": flop / dt / 157.3e12, "flop_per_step": flop},
+           "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
+    flat.release()
+    return rec
+
+
 def secondary(model, x):
     """Untimed extras for the record (never part of `value`; any failure is reported, not raised): the other BASELINE
     configurations through tools/config_bench.py and one training step of the benchmark model (forward_kld + backward +
@@ -215,48 +312,67 @@ def secondary(model, x):
     except Exception as exc:   # noqa: BLE001
         res["config_bench"] = {"error": repr(exc)[:200]}
     try:
-        model.use_graphs(False)
-        # torch.optim.Adam with its single-launch implementation (fused=True): the optimizer is PyTorch's either way, the
-        # default for-each path is ~65 launches and 0.5 ms longer per step
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
-        steps, ts = 10, []
-
-        def one_step():
-            opt.zero_grad(set_to_none=True)
-            loss_ = model.forward_kld(x)
-            loss_.backward()
-            opt.step()
-            return loss_
-
-        for i in range(3 + steps):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            loss = one_step()
-            torch.cuda.synchronize()
-            if i >= 3:
-                ts.append(time.perf_counter() - t0)
-        ts.sort()
-        med = ts[len(ts) // 2]     # median of 10 individually synchronised steps (the mean is sensitive to allocator warm-up)
-        torch.cuda.synchronize()   # ... and the same 10 steps back to back, as a training loop runs them (no sync in between)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = one_step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        res["train_step"] = {"workload": "forward_kld + backward + Adam on the benchmark model and batch", "ms_per_step": dt * 1e3,
-                             "optimizer": "torch.optim.Adam(lr=1e-4, fused=True)",
-                             "statistic": "mean of 10 back-to-back steps", "ms_median_synchronised": med * 1e3,
-                             "ms_min_synchronised": ts[0] * 1e3, "ms_max_synchronised": ts[-1] * 1e3, "steps": steps,
-                             "samples_per_s": x.shape[0] / dt, "loss": float(loss.detach()),
-                             # forward + backward = 3 x the forward pass's FLOP (input and weight gradients each repeat its products)
-                             "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.3,
-                                          "achieved": 3 * c2_flops_per_sample(layers=len(model.flows) // 2) * x.shape[0] / dt / 1e12,
-                                          "frac": 3 * c2_flops_per_sample(layers=len(model.flows) // 2) * x.shape[0] / dt / 157.3e12,
-                                          "flop_per_step": 3 * c2_flops_per_sample(layers=len(model.flows) // 2) * x.shape[0]},
-                             "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
+        res["train_step"] = train_step_record(model, x, world=1)
     except Exception as exc:   # noqa: BLE001
         res["train_step"] = {"error": repr(exc)[:200]}
     return res
+
+
+def train_mode(args, model, x, world, rank, dev):
+    """`bench.py --gpus N --train`: W untimed + K timed training steps per rank (make_train_step: forward_kld + backward with the
+    bucketed gradient all-reduce started from autograd hooks during backward + Adam on the flat parameter), barrier + synchronize on
+    both sides, max over ranks; rank 0 prints ONE JSON line.  Collectives of the timed region are counted (every entry point)."""
+    import torch.distributed as dist
+    one_step, flat, opt = make_train_step(model, x, world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    for _ in range(max(args.warmup, 1)):
+        loss = one_step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    counter = CollectiveCounter(world > 1)
+    with counter:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = one_step()
+        torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    # every rank ends the run with the same weights: the averaged gradient is the same on all of them
+    chk = flat.param.detach().double().sum().reshape(1)
+    same = True
+    if world > 1:
+        lo_, hi_ = chk.clone(), chk.clone()
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        same = bool((lo_ == hi_).item())
+    flop = 3 * c2_flops_per_sample(layers=args.layers) * args.batch
+    dt = elapsed / args.steps
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training samples/sec (forward_kld + backward + gradient all-reduce + Adam), 32-layer RQ-NSF d=64 B=65536",
+            "value": world * args.batch / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "loss": float(loss.detach()), "replicas_identical_after_run": same,
+            "config": {"workload": "BASELINE configs[1] model, TRAINING step: forward_kld + backward + Adam(fused) on "
+                                   "dp.FlatParameters, %d rows/GPU; gradients averaged by 8 MB in-place all-reduces of the flat "
+                                   "gradient buffer started during backward" % args.batch,
+                       "rows_per_gpu": args.batch, "global_rows": world * args.batch, "layers": args.layers,
+                       "parallelism": "dp%d" % world, "collectives_per_step": counter.coll["calls"] / max(args.steps, 1),
+                       "collective_bytes_per_step": counter.coll["bytes"] / max(args.steps, 1),
+                       "collectives_by_op": counter.coll["by_op"]},
+            "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.3, "achieved": flop / dt / 1e12,
+                         "frac": flop / dt / 157.3e12, "traffic": None, "flop_per_step_per_gpu": flop,
+                         "note": "3 x the forward pass's algorithmic FLOP per rank and step over the whole step's wall time"}}))
+    flat.release()
 
 
 def main():
@@ -272,6 +388,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the untimed extra measurements (other BASELINE configs, "
                     "training step) that rank 0 appends under \"secondary\" at N = 1")
     ap.add_argument("--cpu-rows", type=int, default=131072, help="rows of the same workload timed on the host oracle")
+    ap.add_argument("--train", action="store_true", help="time the TRAINING step instead (forward_kld + backward + overlapped gradient "
+                    "all-reduce + Adam per rank and step; rows/s over all ranks) and print its own JSON line: the second curve of a "
+                    "multi-GPU lease (VERDICT r05 #8); the default line (the BASELINE metric) is unchanged")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -314,6 +433,12 @@ def main():
 
     model = build_c2_model(num_layers=args.layers).to(dev)
     x = c2_inputs(args.batch, DIM, rank=rank).to(dev)
+    if args.train:
+        train_mode(args, model, x, world, rank, dev)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     model.use_graphs(not args.no_graph)
 
     def barrier():
@@ -334,20 +459,13 @@ def main():
         torch.cuda.synchronize()
         # the data-path collectives of the timed region are COUNTED (calls, bytes) as they are issued: SURVEY.md 8e allows exactly
         # one 16-byte all-reduce ([sum log_q, n], fp64) per step; the barriers / the max-over-ranks clock below are not data path
-        coll = {"calls": 0, "bytes": 0}
-        _all_reduce = dist.all_reduce
-
-        def _counted(t_, *a_, **k_):
-            coll["calls"] += 1
-            coll["bytes"] += t_.numel() * t_.element_size()
-            return _all_reduce(t_, *a_, **k_)
-        if world > 1:
-            dist.all_reduce = _counted
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            lp, nll_t = step()
-        torch.cuda.synchronize()
-        dist.all_reduce = _all_reduce
+        counter = CollectiveCounter(world > 1)
+        with counter:                       # (restores the entry points also when a step raises: ADVICE r05)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                lp, nll_t = step()
+            torch.cuda.synchronize()
+        coll = counter.coll
         barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0

@@ -425,6 +425,39 @@ int64_t nf_resblock_bwd_scratch_floats(int64_t B, int with_init);
 int nf_resblock_bwd(const void *gh, const void *t, const void *h_in, const void *W1, const void *W2, void *gh_in, void *dW1,
                     void *db1, void *dW2, void *db2, const void *x, const void *wfull, void *gx, void *dW0, void *db0,
                     const void *col_map, int n_cols, void *scratch, int64_t B, int H, int D, nf_stream_t stream);
+/* The passes over the rows WITHOUT their reduction launches (round 6): the partial tiles stay in `scratch` for a later reduction
+ * -- nf_coupling_train_bwd sums all of a layer's partial tiles with ONE launch.
+ *   nf_linear_wgrad_partials: scratch = [nf_linear_wgrad_chunks(B, M, N)][M * N + M] (dW tile then the column sums of dY);
+ *   nf_resblock_bwd_partials: scratch = [2][nf_resblock_bwd_grid(B)][128 * 128 + 128] ((dW2, db2) then (dW1, db1)), then with x
+ *   the initial layer's [grid][128 * 64 + 128]; arguments as nf_resblock_bwd. */
+int nf_linear_wgrad_chunks(int64_t B, int M, int N);
+int nf_linear_wgrad_partials(const void *dY, const void *X, void *scratch, int64_t B, int M, int N, int relu_x, int want_bias,
+                             nf_stream_t stream);
+int nf_resblock_bwd_grid(int64_t B);
+int nf_resblock_bwd_partials(const void *gh, const void *t, const void *h_in, const void *W1, const void *W2, void *gh_in,
+                             const void *x, const void *wfull, void *gx, void *scratch, int64_t B, int H, int D,
+                             nf_stream_t stream);
+/* The whole backward of a benchmark-shaped coupling layer behind one call (round 6): what `loss.backward()` (core.py:87-102) does
+ * for CoupledRationalQuadraticSpline's density direction (nsf/coupling.py:83-98, nets/resnet.py:37-50, 92-104,
+ * utils/splines.py:16-219) given what nf_rqs_fused_train_full_fwd saved.  Four passes over the rows (nf_final_bwd, the final
+ * layer's weight-gradient partials, nf_resblock_bwd_partials per residual block -- the first block's with the initial layer) and
+ * ONE reduction launch for every partial tile of the layer, in the fixed order of the stand-alone reductions (bit-identical
+ * gradients, deterministic, no atomics).
+ *   x, grad_y (B, 64), grad_logdet (B), cond24 (B, 32, 24), acts (2 num_blocks + 1, B, 128): as saved by the forward;
+ *   w_t / wpack / wfull_t: the images nf_rqs_fused_pack_all left (final weight as nf_final_bwd's stages; the blob; the initial
+ *   weight transposed on full rows (64, 128)); w_blocks: 2 num_blocks device pointers W1, W2 per block ((128, 128) as stored by
+ *   nn.Linear); uw, uh, ud: the batch-shared spline parameters; col_map / n_cols: as nf_resblock_bwd.
+ *   Outputs, all written (not accumulated): grad_x (B, 64); g_w0 (128, n_cols), g_b0 (128), g_wf (736, 128), g_bf (736), g_uw,
+ *   g_uh (32, 8), g_ud (32, 7); g_blocks: 4 num_blocks device pointers gW1, gb1, gW2, gb2 per block -- any addresses (e.g. views
+ *   of one flat gradient buffer).  scratch: nf_coupling_train_bwd_scratch_floats(B, num_blocks) floats.
+ *   D = 64, hidden = 128, K = 8, 1 <= num_blocks <= 5, B a multiple of 64, float32; NF_ENOTSUP otherwise. */
+int64_t nf_coupling_train_bwd_scratch_floats(int64_t B, int num_blocks);
+int nf_coupling_train_bwd(const void *x, const void *grad_y, const void *grad_logdet, const void *cond24, const void *acts,
+                          const void *w_t, const void *wpack, const void *wfull_t, const void *const *w_blocks, const void *uw,
+                          const void *uh, const void *ud, const void *col_map, int n_cols, void *grad_x, void *g_w0, void *g_b0,
+                          void *g_wf, void *g_bf, void *g_uw, void *g_uh, void *g_ud, void *const *g_blocks, void *scratch,
+                          int mask_parity, int64_t B, int D, int hidden, int num_blocks, int K, double tail_bound,
+                          double min_bin_width, double min_bin_height, double min_derivative, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Logit preprocessing transform of image tensors.  Replaces normflows/transforms.py:8-47.

@@ -17,6 +17,7 @@ import math
 import torch
 from torch.autograd.function import once_differentiable
 
+from . import _gradbuf
 from . import _lib as L
 from . import config as _config
 from . import ops
@@ -269,9 +270,12 @@ class LULinearPermuteFn(torch.autograd.Function):
             from . import config
             if config.lu_bwd_fused and D_ == 64 and gy.shape[0] % 64 == 0 and gy.shape[0] >= 1024 and u_saved is not None:
                 # both row products and both batch reductions in one pass over the rows (nf_lu_bwd)
-                gx, gL, g_bias, gUx = ops.lu_bwd(gy, u_saved, x, Lm, Up)
+                # (gradients go straight to their destinations: views of dp.FlatParameters' buffer when registered, _gradbuf.py)
+                gx, gL, g_bias, gUx = ops.lu_bwd(gy, u_saved, x, Lm, Up, db_out=_gradbuf.out(bias))
                 g_lower, g_upper, g_udiag = ops.lu_param_grads(gL, gUx, gld, udiag_raw.detach(), lower_entries.numel(),
-                                                               eps=ctx.eps, sign=1.0, perm=perm)
+                                                               eps=ctx.eps, sign=1.0, perm=perm,
+                                                               out=(_gradbuf.out(lower_entries), _gradbuf.out(upper_entries),
+                                                                    _gradbuf.out(udiag_raw)))
                 return gx, None, g_lower, g_upper, g_udiag, g_bias, None, None, g_acc, None, None, None
             if config.lu_matvec2 and D_ <= 64:
                 gu, gx, _ = ops.rows_matvec2(gy, LT, UpT)   # d/du = L^T gy, d/dx = P (U^T gu): one launch
@@ -431,6 +435,7 @@ class CouplingTrainFn(torch.autograd.Function):
             ctx.mark_dirty(ld_acc)
         ctx.save_for_backward(x, cond24, acts, w0, wf, uw, uh, ud, iidx, tidx, *blk)
         ctx.kw, ctx.wfull, ctx.wpad, ctx.acc, ctx.has_acc, ctx.nb = kw, wfull, wpad, acc, ld_acc is not None, nb
+        ctx.biases = (b0, bf)       # (identity only: where their gradients are written, _gradbuf.out)
         ctx.blob, ctx.parity = blob, parity
         ctx.holder, ctx.stamp = kw.get("holder"), ("full",) + _stamp(w0, b0, wf, bf, uw, uh, ud, *blk)
         if ctx.holder is not None:
@@ -450,6 +455,18 @@ class CouplingTrainFn(torch.autograd.Function):
         B, nT, H = x.shape[0], cond24.shape[1], wf.shape[1]
         fk = dict(tail_bound=kw["tail_bound"], min_bin_width=kw["min_bin_width"], min_bin_height=kw["min_bin_height"],
                   min_derivative=kw["min_derivative"])
+        if (_config.train_bwd_onecall and _config.final_bwd_fused and _config.resblock_bwd and 1 <= nb <= 5 and B % 64 == 0
+                and H == 128 and x.shape[1] == 64):
+            # round 6: the layer's whole backward behind one call -- four passes over the rows, ONE reduction launch, every gradient
+            # written straight to its destination (a view of dp.FlatParameters' flat buffer when the parameter is registered there)
+            b0, bf = ctx.biases
+            dest = dict(w0=_gradbuf.out(w0), b0=_gradbuf.out(b0), wf=_gradbuf.out(wf), bf=_gradbuf.out(bf), uw=_gradbuf.out(uw),
+                        uh=_gradbuf.out(uh), ud=_gradbuf.out(ud), blocks=[_gradbuf.out(p_) for p_ in blk])
+            gx = ops.coupling_train_bwd(x, gy, gld_own, cond24, acts, ctx.wpad, ctx.blob, ctx.wfull,
+                                        [blk[4 * b + j].detach() for b in range(nb) for j in (0, 2)], uw.detach(), uh.detach(),
+                                        ud.detach(), kw["col_map"], iidx.numel(), ctx.parity, nb, dest, **fk)
+            return (gx, dest["w0"], dest["b0"], dest["wf"], dest["bf"], dest["uw"], dest["uh"], dest["ud"], None, None, None, None,
+                    None, None, None, (gld if ctx.has_acc else None), None, *dest["blocks"])
         if _config.final_bwd_fused:
             # ONE pass over the rows: spline backward on the vector ALU, its gradient rows straight into the MFMAs of the final
             # layer's input gradient (nf_final_bwd; ctx.wpad = the transposed stage image the forward's pack launch left)

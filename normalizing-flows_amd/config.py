@@ -73,6 +73,17 @@ def set_final_bwd_fused(mode=True):
     final_bwd_fused = bool(mode)
 
 
+# The whole backward of a benchmark-shaped coupling layer behind one C-ABI call with ONE reduction launch for all of its partial
+# tiles (nf_coupling_train_bwd, round 6); False = the kernels issued one by one from autograd.CouplingTrainFn.backward, each with
+# its own reduction launch (rounds 3-5; ablation / differential tests: the gradients are bit-identical).
+train_bwd_onecall = True
+
+
+def set_train_bwd_onecall(mode=True):
+    global train_bwd_onecall
+    train_bwd_onecall = bool(mode)
+
+
 # LULinearPermute's density-direction backward (D = 64) as one pass over the rows (nf_lu_bwd).
 lu_bwd_fused = True
 

@@ -30,6 +30,7 @@
 // Per row: reads 256 + 256 + 4 + 3072 B, writes 256 + 3072 + 512 B; 2 x 768 x 128 FLOP on fp32 MFMA + the spline backward
 // on the same vector ALU (bound: MFMA + VALU time).
 #include "rqs_bwd_common.hpp"
+#include "train_reduce.hpp"
 #include <type_traits>
 
 namespace nf {
@@ -37,7 +38,20 @@ namespace nf {
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 #define FB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-constexpr int FB_NW = 8;                          // waves per workgroup
+// Round 6: NF_FB_NW = 4 -> 64-row tiles, TWO workgroups per CU (the 8-wave workgroup spent a third of its time at the ring's stage
+// barriers with every wave of the CU in the same phase: two independent workgroups drift apart and fill each other's waits); the ring
+// then streams half stages (NF_FB_KS = 4 k-steps, 8 KB per slot) so that both workgroups' LDS fits: 2 x (16 + 4 x 14.9) KB.
+#ifndef NF_FB_NW
+#define NF_FB_NW 8
+#endif
+#ifndef NF_FB_KS
+#define NF_FB_KS 8
+#endif
+constexpr int FB_NW = NF_FB_NW;                   // waves per workgroup
+constexpr int FB_KS = NF_FB_KS;                   // k-steps of the final weight per ring stage (8: 16 KB stages; 4: 8 KB)
+constexpr int FB_STG = FB_KS * 512;               // floats per ring stage
+constexpr int FB_SPG = 24 / FB_KS;                // stages per group
+static_assert((FB_NW == 8 || FB_NW == 4) && (FB_KS == 8 || FB_KS == 4) && FB_STG % (256 * FB_NW) == 0, "ring geometry");
 constexpr int FB_THREADS = 64 * FB_NW;
 constexpr int FB_WR = 16;                         // rows per wave
 constexpr int FB_ROWS = FB_WR * FB_NW;            // 128 rows per tile
@@ -45,8 +59,8 @@ constexpr int FB_P = 68;                          // stash row pitch (floats): 1
 constexpr int FB_PLANE = FB_WR * FB_P;            // one plane (x or grad_y / grad_x) of a wave
 constexpr int FB_CS = FB_WR * 4 * 24;             // piece buffer: [row][quarter][24] = the group's parameter / gradient rows of the wave
 constexpr int FB_WAVE = 2 * FB_PLANE + FB_WR + FB_CS;
-constexpr int FB_NST = 24;                        // stages of the transposed final weight
-constexpr int FB_PART = F_NI * 24;                // knot-space sums of a workgroup: [feature][7 w | 7 h | 7 d | 3 pad]
+constexpr int FB_NST = 8 * FB_SPG;                // stages of the transposed final weight (8 groups)
+constexpr int FB_PART = FBR_PART;                 // knot-space sums of a workgroup: [feature][7 w | 7 h | 7 d | 3 pad]
 constexpr int FB_NI = 7;                          // coalesced instructions per direction for the 32 runs of 192 bytes of a group
 
 #ifdef FB_TRACE      // phase trace (tools/final_bwd_probe.py --trace): shader-clock cycles per phase, summed over the tiles of workgroup 0 / wave 0
@@ -68,14 +82,14 @@ struct FinalBwdArgs {
     RqsParams<float> p;
 };
 
-__global__ void __launch_bounds__(FB_THREADS, 1)
+__global__ void __launch_bounds__(FB_THREADS, FB_NW == 4 ? 2 : 1)
 final_bwd_kernel(FinalBwdArgs a) {
     typedef __attribute__((address_space(3))) void *lds_ptr;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *ring = smem;                                    // 2 x F_STAGE
+    float *ring = smem;                                    // 2 x FB_STG
     const int tid = threadIdx.x, lane = tid & 63, hq = lane >> 4, n = lane & 15;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float *X = ring + 2 * F_STAGE + wid * FB_WAVE, *G = X + FB_PLANE, *GL = G + FB_PLANE, *CS = GL + FB_WR;
+    float *X = ring + 2 * FB_STG + wid * FB_WAVE, *G = X + FB_PLANE, *GL = G + FB_PLANE, *CS = GL + FB_WR;
     const RqsParams<float> p = a.p;
     const int par_t = a.parity ? 0 : 1, par_i = par_t ^ 1;
     // lane = identity feature fj (column 2 fj + par_i), rows of parity sp
@@ -92,10 +106,11 @@ final_bwd_kernel(FinalBwdArgs a) {
     int stage = 0;
     auto issue = [&](int gs) {
         const int s = gs % FB_NST;
-        const float *src = a.wt + (size_t)s * F_STAGE + wid * 512 + lane * 4;
-        float *dst = ring + (gs & 1) * F_STAGE + wid * 512;
+        constexpr int PW = FB_STG / FB_NW;     // floats of a stage per requesting wave
+        const float *src = a.wt + (size_t)s * FB_STG + wid * PW + lane * 4;
+        float *dst = ring + (gs & 1) * FB_STG + wid * PW;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) __builtin_amdgcn_global_load_lds(src + i * 256, (lds_ptr)(dst + i * 256), 16, 0, 0);
+        for (int i = 0; i < PW / 256; ++i) __builtin_amdgcn_global_load_lds(src + i * 256, (lds_ptr)(dst + i * 256), 16, 0, 0);
     };
     // 2-slot ring: stage s has landed for every wave; stage s + 1 is requested into the slot stage s - 1 just left.  `after`:
     // vector-memory operations this wave issued AFTER the requests of stage s (they retire in order, so they may stay in flight)
@@ -108,7 +123,7 @@ final_bwd_kernel(FinalBwdArgs a) {
         // s_waitcnt vmcnt(0) -- the counted waits above never took effect before this was found (round 3, in the Glow kernels)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (stage + 1 < total_stages) issue(stage + 1);
-        const float *buf = ring + (stage & 1) * F_STAGE;
+        const float *buf = ring + (stage & 1) * FB_STG;
         ++stage;
         return buf;
     };
@@ -269,7 +284,7 @@ final_bwd_kernel(FinalBwdArgs a) {
             // next group's parameter rows); they retire in order behind stage 1's requests, so they may stay in flight at its acquire.
             constexpr bool more = !LAST;
 #pragma unroll
-            for (int rb = 0; rb < 3; ++rb) {
+            for (int rb = 0; rb < FB_SPG; ++rb) {
                 const float *buf = acquire((rb == 1 && full) ? (more ? 2 * FB_NI : (has_next ? 2 * FB_NI + 9 : FB_NI)) : 0);
                 FB_T(4);  // stage wait + barrier + next stage's requests
                 if (rb == 0) {
@@ -292,20 +307,20 @@ final_bwd_kernel(FinalBwdArgs a) {
                     FB_T(5);  // gradient-row stores + the next group's requests
                 }
 #ifndef FB_ABL_NOMFMA
-                // stage rb: k-steps v = 8 rb .. 8 rb + 7 (B operand = the lane's gradient value v), 8 unit blocks each
+                // stage rb: k-steps v = KS rb .. KS rb + KS - 1 (B operand = the lane's gradient value v), 8 unit blocks each
 #pragma unroll
-                for (int vv = 0; vv < 8; ++vv) {
+                for (int vv = 0; vv < FB_KS; ++vv) {
 #pragma unroll
                     for (int uq = 0; uq < 2; ++uq) {
                         const f32x4 w4 = *reinterpret_cast<const f32x4 *>(buf + ((vv * 2 + uq) * 64 + lane) * 4);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[4 * uq + j] = FB_MFMA(w4[j], gq[8 * rb + vv], acc[4 * uq + j]);
+                        for (int j = 0; j < 4; ++j) acc[4 * uq + j] = FB_MFMA(w4[j], gq[FB_KS * rb + vv], acc[4 * uq + j]);
                     }
                 }
 #else
                 (void)buf;
 #pragma unroll
-                for (int v = 0; v < 8; ++v) acc[v][0] += gq[8 * rb + v];
+                for (int v = 0; v < FB_KS; ++v) acc[v][0] += gq[FB_KS * rb + v];
 #endif
                 asm volatile("" ::"v"(acc[0][0]), "v"(acc[7][0]));
                 FB_T(6);  // 16 A-operand reads + 64 MFMAs (issue time: the last MFMAs may still be executing)
@@ -374,57 +389,16 @@ final_bwd_kernel(FinalBwdArgs a) {
 }
 
 // Knot-space sums -> gradients of the raw batch-shared parameters (unnormalized_widths / heights / derivatives of the
-// unconditional transform, nsf/coupling.py:221-253 over utils/splines.py:100-157): one thread per (feature, parameter) sums the
-// workgroups' partials in a fixed order, then per feature the chain  knot_k = lo + (hi - lo) (k min + scale C_k),
-// C_k = sum_{i < k} softmax(raw)_i  =>  d/d raw_i = (hi - lo) scale softmax_i sum_k G_k ([i < k] - C_k);  d_j = min_d + softplus(raw_j).
+// unconditional transform, nsf/coupling.py:221-253 over utils/splines.py:100-157): one workgroup per feature
+// (train_reduce.hpp::final_bwd_reduce_feature: 10 thread groups x 24 sums walk the partial rows with stride 10, their results are
+// added in group order -- fixed: bit-reproducible; a single workgroup reading all 0.8 MB took 120 us).
 __global__ void __launch_bounds__(256)
 final_bwd_reduce_kernel(const float *__restrict__ part, int nparts, const float *__restrict__ uw, const float *__restrict__ uh,
                         const float *__restrict__ ud, float *__restrict__ guw, float *__restrict__ guh, float *__restrict__ gud,
                         RqsParams<float> p) {
-    // one workgroup per feature: 10 thread groups x 24 sums walk the partial rows with stride 10, their results are added in
-    // group order (fixed: bit-reproducible); a single workgroup reading all 0.8 MB took 120 us
     __shared__ float sub[10][24];
     __shared__ float sums[24];
-    const int j = blockIdx.x, t = threadIdx.x;
-    if (t < 240) {
-        const int k = t % 24, grp = t / 24;
-        float s = 0.0f;
-        for (int w = grp; w < nparts; w += 10) s += part[(size_t)w * FB_PART + j * 24 + k];
-        sub[grp][k] = s;
-    }
-    __syncthreads();
-    if (t < 24) {
-        float s = 0.0f;
-#pragma unroll
-        for (int grp = 0; grp < 10; ++grp) s += sub[grp][t];
-        sums[t] = s;
-    }
-    __syncthreads();
-    if (t < 2) {                              // axis
-        const int ax = t;
-        const float *raw = (ax ? uh : uw) + j * F_K, *Gk = sums + 7 * ax;
-        float m = raw[0];
-        for (int k = 1; k < F_K; ++k) m = fmaxf(m, raw[k]);
-        float e[F_K], tot = 0.0f;
-        for (int k = 0; k < F_K; ++k) { e[k] = expf(raw[k] - m); tot += e[k]; }
-        const float f = ax ? (p.top - p.bottom) * p.scale_h : (p.right - p.left) * p.scale_w;
-        float C[F_K + 1];
-        C[0] = 0.0f;
-        for (int k = 0; k < F_K; ++k) C[k + 1] = C[k] + e[k] / tot;
-        float base = 0.0f;                    // sum_k G_k C_k
-        for (int k = 1; k < F_K; ++k) base += Gk[k - 1] * C[k];
-        float tail = 0.0f;                    // sum_{k > i} G_k, built from the top
-        float *out = (ax ? guh : guw) + j * F_K;
-        for (int i = F_K - 1; i >= 0; --i) {
-            out[i] = f * (e[i] / tot) * (tail - base);
-            if (i >= 1) tail += Gk[i - 1];    // knot i joins the sum for parameter i - 1
-        }
-    }
-    if (t >= 64 && t < 64 + (F_K - 1)) {
-        const int k = t - 64;
-        const float r = ud[j * (F_K - 1) + k];
-        gud[j * (F_K - 1) + k] = sums[14 + k] * (r > 20.0f ? 1.0f : sigmoid(r));
-    }
+    final_bwd_reduce_feature(part, nparts, uw, uh, ud, guw, guh, gud, p, blockIdx.x, sub, sums);
 }
 
 }  // namespace nf
@@ -440,7 +414,8 @@ static int final_bwd_grid(int64_t B) {
         cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int64_t ntiles = (B + FB_ROWS - 1) / FB_ROWS;
-    return (int)(ntiles < cus ? ntiles : cus);
+    const int slots = cus * (FB_NW == 4 ? 2 : 1);       // resident workgroups
+    return (int)(ntiles < slots ? ntiles : slots);
 }
 
 // Rows of `partials` nf_final_bwd writes for a batch of B rows (one per resident workgroup: one per CU, fewer for small batches).
@@ -470,7 +445,7 @@ extern "C" int nf_final_bwd(const void *x, const void *grad_y, const void *grad_
     a.B = B; a.parity = mask_parity;
     a.p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height, min_derivative,
                                  sqrt((double)hidden));
-    const size_t lds = (size_t)(2 * F_STAGE + FB_NW * FB_WAVE) * sizeof(float);
+    const size_t lds = (size_t)(2 * FB_STG + FB_NW * FB_WAVE) * sizeof(float);
     static LdsOptIn opted = {};
     if (opt_in_lds(reinterpret_cast<const void *>(&final_bwd_kernel), lds, opted) != NF_OK) return NF_ENOTSUP;
     hipLaunchKernelGGL(final_bwd_kernel, dim3(final_bwd_grid(B)), dim3(FB_THREADS), lds, (hipStream_t)stream, a);

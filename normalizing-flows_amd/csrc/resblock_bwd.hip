@@ -349,20 +349,27 @@ extern "C" int64_t nf_resblock_bwd_scratch_floats(int64_t B, int with_init) {
     return 2 * g * ((int64_t)BB_H * BB_H + BB_H) + (with_init ? g * ((int64_t)BB_H * BB_D + BB_H) : 0);
 }
 
-extern "C" int nf_resblock_bwd(const void *gh, const void *t, const void *h_in, const void *W1, const void *W2, void *gh_in,
-                               void *dW1, void *db1, void *dW2, void *db2, const void *x, const void *wfull, void *gx,
-                               void *dW0, void *db0, const void *col_map, int n_cols, void *scratch, int64_t B, int H, int D,
-                               nf_stream_t stream) {
+// Workgroups (= partial tiles per problem) of a launch over B rows.
+extern "C" int nf_resblock_bwd_grid(int64_t B) {
+    using namespace nf;
+    if (B < BB_R || B % BB_R) return NF_EINVAL;
+    return bb_grid(B);
+}
+
+// The pass over the rows alone: partial tiles [2][grid][128 * 128 + 128] ((dW2, db2) then (dW1, db1)) and, with x, the initial
+// layer's [grid][128 * 64 + 128] behind them in `scratch` (nf_resblock_bwd_scratch_floats), summed later by the caller
+// (nf_resblock_bwd: three nf::wgrad_reduce_kernel problems; nf_coupling_train_bwd: the layer's one reduction launch).
+extern "C" int nf_resblock_bwd_partials(const void *gh, const void *t, const void *h_in, const void *W1, const void *W2, void *gh_in,
+                                        const void *x, const void *wfull, void *gx, void *scratch, int64_t B, int H, int D,
+                                        nf_stream_t stream) {
     using namespace nf;
     if (H != BB_H || B < BB_R || B % BB_R) return NF_ENOTSUP;
-    if (!gh || !t || !h_in || !W1 || !W2 || !dW1 || !db1 || !dW2 || !db2 || !scratch) return NF_EFAULT;
+    if (!gh || !t || !h_in || !W1 || !W2 || !scratch) return NF_EFAULT;
     const bool init = x != nullptr;
     if (init && D != BB_D) return NF_ENOTSUP;
-    if (init && (!wfull || !gx || !dW0 || !db0)) return NF_EFAULT;
-    if (col_map && (n_cols < 1 || n_cols > BB_D)) return NF_EINVAL;
+    if (init && (!wfull || !gx)) return NF_EFAULT;
     if (!init && !gh_in) return NF_EFAULT;
     if (((uintptr_t)gh | (uintptr_t)t | (uintptr_t)h_in | (uintptr_t)x | (uintptr_t)gh_in | (uintptr_t)gx) & 15) return NF_EINVAL;
-    if ((((uintptr_t)dW1 ^ (uintptr_t)dW2) | ((uintptr_t)db1 ^ (uintptr_t)db2)) & 3) return NF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int grid = bb_grid(B);
     BlockBwdArgs a;
@@ -386,11 +393,31 @@ extern "C" int nf_resblock_bwd(const void *gh, const void *t, const void *h_in, 
         hipLaunchKernelGGL(resblock_bwd_kernel<false>, dim3(grid), dim3(64 * BB_NW), lds, st, a);
     }
     NF_CHECK_LAUNCH();
-    int rc = wgrad_reduce_launch(a.part, (float *)dW2, (float *)db2, (int64_t)BB_H * BB_H, BB_H, grid, BB_H, 2, grid * stride,
-                                 (float *)dW1 - (float *)dW2, (float *)db1 - (float *)db2, nullptr, 0, st);
+    return NF_OK;
+}
+
+extern "C" int nf_resblock_bwd(const void *gh, const void *t, const void *h_in, const void *W1, const void *W2, void *gh_in,
+                               void *dW1, void *db1, void *dW2, void *db2, const void *x, const void *wfull, void *gx,
+                               void *dW0, void *db0, const void *col_map, int n_cols, void *scratch, int64_t B, int H, int D,
+                               nf_stream_t stream) {
+    using namespace nf;
+    if (H != BB_H || B < BB_R || B % BB_R) return NF_ENOTSUP;
+    if (!gh || !t || !h_in || !W1 || !W2 || !dW1 || !db1 || !dW2 || !db2 || !scratch) return NF_EFAULT;
+    const bool init = x != nullptr;
+    if (init && (!wfull || !gx || !dW0 || !db0)) return NF_EFAULT;
+    if (col_map && (n_cols < 1 || n_cols > BB_D)) return NF_EINVAL;
+    if ((((uintptr_t)dW1 ^ (uintptr_t)dW2) | ((uintptr_t)db1 ^ (uintptr_t)db2)) & 3) return NF_EINVAL;
+    int rc = nf_resblock_bwd_partials(gh, t, h_in, W1, W2, gh_in, x, wfull, gx, scratch, B, H, D, stream);
+    if (rc != NF_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = bb_grid(B);
+    const int64_t stride = (int64_t)BB_H * BB_H + BB_H;
+    const float *part = (const float *)scratch, *part0 = part + 2 * grid * stride;
+    rc = wgrad_reduce_launch(part, (float *)dW2, (float *)db2, (int64_t)BB_H * BB_H, BB_H, grid, BB_H, 2, grid * stride,
+                             (float *)dW1 - (float *)dW2, (float *)db1 - (float *)db2, nullptr, 0, st);
     if (rc != NF_OK) return rc;
     if (init)
-        rc = wgrad_reduce_launch(a.part0, (float *)dW0, (float *)db0, (int64_t)BB_H * BB_D, BB_H, grid, BB_D, 1, 0, 0, 0,
+        rc = wgrad_reduce_launch(part0, (float *)dW0, (float *)db0, (int64_t)BB_H * BB_D, BB_H, grid, BB_D, 1, 0, 0, 0,
                                  (const int *)col_map, n_cols, st);
     return rc;
 }

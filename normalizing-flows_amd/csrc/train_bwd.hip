@@ -1,0 +1,149 @@
+// train_bwd.hip -- the backward pass of a benchmark-shaped NSF coupling layer (CoupledRationalQuadraticSpline: D = 64, hidden 128,
+// 8 bins, linear tails, >= 1 residual block) behind ONE C-ABI call: what `loss.backward()` (core.py:87-102) does for
+// nsf/coupling.py:83-98 + nets/resnet.py:37-50, 92-104 + utils/splines.py:16-219.
+//
+// Round 6.  Until now the host issued the layer's backward kernel by kernel and every kernel that leaves partial tiles was followed
+// by its own reduction launch: per layer final_bwd + its reduction, the ring weight gradient + its reduction, two residual-block
+// launches + three reductions -- 11 launches, 6 of them 4-10 us reductions on grids too small to pull their partial tiles at more
+// than ~2 TB/s, each behind a dependent kernel boundary.  Here the four heavy kernels run back to back and ALL reductions of the
+// layer are one launch (nf::layer_reduce_kernel: the routines of train_reduce.hpp, one 64-element group or one spline feature
+// per block; the same fixed summation order, so the gradients are bit-identical to the launch-by-launch path): 5 launches.
+// Gradients go straight to the caller's destinations (e.g. views of one flat gradient buffer: no per-parameter tensors).
+#include "train_reduce.hpp"
+
+extern "C" {
+int nf_final_bwd_partials(int64_t B);
+int nf_final_bwd(const void *x, const void *grad_y, const void *grad_logdet, const void *cond24, const void *w_t, const void *wpack,
+                 void *grad_x, void *grad_cond24, void *grad_h, void *partials, int mask_parity, int64_t B, int D, int hidden,
+                 int num_blocks, int K, double tail_bound, double min_bin_width, double min_bin_height, double min_derivative,
+                 nf_stream_t stream);
+int nf_linear_wgrad_chunks(int64_t B, int M, int N);
+int nf_linear_wgrad_partials(const void *dY, const void *X, void *scratch, int64_t B, int M, int N, int relu_x, int want_bias,
+                             nf_stream_t stream);
+int64_t nf_resblock_bwd_scratch_floats(int64_t B, int with_init);
+int nf_resblock_bwd_grid(int64_t B);
+int nf_resblock_bwd_partials(const void *gh, const void *t, const void *h_in, const void *W1, const void *W2, void *gh_in,
+                             const void *x, const void *wfull, void *gx, void *scratch, int64_t B, int H, int D,
+                             nf_stream_t stream);
+}
+
+namespace nf {
+
+__global__ void __launch_bounds__(64 * RL)
+layer_reduce_kernel(ReduceJobs J) {
+    __shared__ f32x4 sm4[RL][64];
+    const int b = blockIdx.x;
+    if (b >= J.nblocks) {       // the batch-shared spline parameters: one block per identity feature
+        float *smf = reinterpret_cast<float *>(&sm4[0][0]);
+        final_bwd_reduce_feature(J.fb_part, J.fb_nparts, J.uw, J.uh, J.ud, J.guw, J.guh, J.gud, J.p, b - J.nblocks,
+                                 reinterpret_cast<float(*)[24]>(smf), smf + 512);
+        return;
+    }
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < RJ_MAX; ++i)
+        if (i < J.nj && b >= J.j[i].block0) j = i;
+    const ReduceJob &q = J.j[j];
+    wgrad_reduce_group4(q.part, q.dW, q.db, q.nW, q.n, q.stride, q.chunks, q.N, q.skip_every, q.colmap, q.Nout,
+                        (int64_t)(b - q.block0) * 256, sm4);
+}
+
+static void add_job(ReduceJobs &J, const float *part, float *dW, float *db, int64_t nW, int M, int chunks, int N, int skip_every,
+                    const int *colmap, int Nout) {
+    ReduceJob &q = J.j[J.nj++];
+    q.part = part; q.dW = dW; q.db = db;
+    q.nW = nW; q.n = nW + (db ? M : 0); q.stride = nW + M;
+    q.colmap = colmap; q.chunks = chunks; q.N = N; q.skip_every = skip_every; q.Nout = Nout;
+    q.block0 = J.nblocks;
+    J.nblocks += (int)((q.n + 255) / 256);
+}
+
+constexpr int TB_MP = 24 * F_NI;       // 768: rows of the final layer on the 24-float pitch of cond24
+
+}  // namespace nf
+
+using namespace nf;
+
+// floats of `scratch` for nf_coupling_train_bwd: gradient rows of the final layer (B x 768), two ping-pong hidden-gradient
+// tensors (B x 128) and every kernel's partial tiles
+extern "C" int64_t nf_coupling_train_bwd_scratch_floats(int64_t B, int num_blocks) {
+    if (B < 64 || B % 64 || num_blocks < 1 || 2 * num_blocks + 2 > RJ_MAX) return NF_ENOTSUP;
+    const int chunks = nf_linear_wgrad_chunks(B, TB_MP, F_H);
+    if (chunks < 0) return chunks;
+    int64_t n = B * (int64_t)TB_MP + 2 * B * (int64_t)F_H + (int64_t)nf_final_bwd_partials(B) * FBR_PART +
+                (int64_t)chunks * ((int64_t)TB_MP * F_H + TB_MP);
+    for (int b = 0; b < num_blocks; ++b) n += nf_resblock_bwd_scratch_floats(B, b == 0);
+    return n;
+}
+
+extern "C" int nf_coupling_train_bwd(const void *x, const void *grad_y, const void *grad_logdet, const void *cond24, const void *acts,
+                                     const void *w_t, const void *wpack, const void *wfull_t, const void *const *w_blocks,
+                                     const void *uw, const void *uh, const void *ud, const void *col_map, int n_cols, void *grad_x,
+                                     void *g_w0, void *g_b0, void *g_wf, void *g_bf, void *g_uw, void *g_uh, void *g_ud,
+                                     void *const *g_blocks, void *scratch, int mask_parity, int64_t B, int D, int hidden,
+                                     int num_blocks, int K, double tail_bound, double min_bin_width, double min_bin_height,
+                                     double min_derivative, nf_stream_t stream) {
+    if (D != F_D || hidden != F_H || K != F_K || num_blocks < 1 || 2 * num_blocks + 2 > RJ_MAX) return NF_ENOTSUP;
+    if (B < 64 || B % 64) return NF_ENOTSUP;
+    if (mask_parity != 0 && mask_parity != 1) return NF_EINVAL;
+    if (col_map && (n_cols < 1 || n_cols > F_D)) return NF_EINVAL;
+    if (!x || !grad_y || !grad_logdet || !cond24 || !acts || !w_t || !wpack || !wfull_t || !w_blocks || !uw || !uh || !ud || !grad_x ||
+        !g_w0 || !g_b0 || !g_wf || !g_bf || !g_uw || !g_uh || !g_ud || !g_blocks || !scratch)
+        return NF_EFAULT;
+    for (int i = 0; i < 2 * num_blocks; ++i)
+        if (!w_blocks[i]) return NF_EFAULT;
+    for (int i = 0; i < 4 * num_blocks; ++i)
+        if (!g_blocks[i]) return NF_EFAULT;
+    const int nparts = nf_final_bwd_partials(B), chunks = nf_linear_wgrad_chunks(B, TB_MP, F_H), grid = nf_resblock_bwd_grid(B);
+    if (nparts < 0 || chunks < 0 || grid < 0) return NF_ENOTSUP;
+    if ((uintptr_t)scratch & 15) return NF_EINVAL;      // (every region below is a multiple of 4 floats: 16-byte reduction loads)
+    float *s = (float *)scratch;
+    float *gcond = s;                       s += B * (int64_t)TB_MP;
+    float *ghA = s;                         s += B * (int64_t)F_H;
+    float *ghB = s;                         s += B * (int64_t)F_H;
+    float *fb_part = s;                     s += (int64_t)nparts * FBR_PART;
+    float *ring_part = s;                   s += (int64_t)chunks * ((int64_t)TB_MP * F_H + TB_MP);
+    const float *A = (const float *)acts;
+    const int64_t act = B * (int64_t)F_H;
+
+    // spline backward + the final layer's input gradient: gx, gradient rows, gh (the last block's output gradient)
+    int rc = nf_final_bwd(x, grad_y, grad_logdet, cond24, w_t, wpack, grad_x, gcond, ghA, fb_part, mask_parity, B, D, hidden,
+                          num_blocks, K, tail_bound, min_bin_width, min_bin_height, min_derivative, stream);
+    if (rc != NF_OK) return rc;
+    // the final layer's weight / bias gradient: dW = gcond^T h_last (pad rows dropped in the reduction)
+    rc = nf_linear_wgrad_partials(gcond, A + (int64_t)(2 * num_blocks) * act, ring_part, B, TB_MP, F_H, 0, 1, stream);
+    if (rc != NF_OK) return rc;
+
+    ReduceJobs J;
+    J.nj = 0;
+    J.nblocks = 0;
+    add_job(J, ring_part, (float *)g_wf, (float *)g_bf, (int64_t)TB_MP * F_H, TB_MP, chunks, F_H, 24, nullptr, 0);
+    float *gh = ghA, *gh_next = ghB;
+    const int64_t bstride = (int64_t)F_H * F_H + F_H;
+    for (int b = num_blocks - 1; b >= 0; --b) {
+        float *part = s;
+        s += nf_resblock_bwd_scratch_floats(B, b == 0);
+        const float *t = A + (int64_t)(2 * b + 1) * act, *h_in = A + (int64_t)(2 * b) * act;
+        if (b == 0)
+            rc = nf_resblock_bwd_partials(gh, t, h_in, w_blocks[0], w_blocks[1], nullptr, x, wfull_t, grad_x, part, B, F_H, F_D, stream);
+        else
+            rc = nf_resblock_bwd_partials(gh, t, h_in, w_blocks[2 * b], w_blocks[2 * b + 1], gh_next, nullptr, nullptr, nullptr, part, B,
+                                          F_H, F_D, stream);
+        if (rc != NF_OK) return rc;
+        // (dW2, db2) then (dW1, db1); g_blocks: gw1, gb1, gw2, gb2 per block
+        add_job(J, part, (float *)g_blocks[4 * b + 2], (float *)g_blocks[4 * b + 3], (int64_t)F_H * F_H, F_H, grid, F_H, 0, nullptr, 0);
+        add_job(J, part + (int64_t)grid * bstride, (float *)g_blocks[4 * b], (float *)g_blocks[4 * b + 1], (int64_t)F_H * F_H, F_H, grid,
+                F_H, 0, nullptr, 0);
+        if (b == 0)
+            add_job(J, part + 2 * (int64_t)grid * bstride, (float *)g_w0, (float *)g_b0, (int64_t)F_H * F_D, F_H, grid, F_D, 0,
+                    (const int *)col_map, col_map ? n_cols : 0);
+        float *tmp = gh; gh = gh_next; gh_next = tmp;
+    }
+    J.fb_part = fb_part; J.fb_nparts = nparts;
+    J.uw = (const float *)uw; J.uh = (const float *)uh; J.ud = (const float *)ud;
+    J.guw = (float *)g_uw; J.guh = (float *)g_uh; J.gud = (float *)g_ud;
+    J.p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height, min_derivative, 1.0);
+    hipLaunchKernelGGL(layer_reduce_kernel, dim3(J.nblocks + F_NI), dim3(64 * RL), 0, (hipStream_t)stream, J);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}

@@ -11,6 +11,7 @@
 // N not a multiple of 4 takes the dword path below (NT column tiles, lane i = column 32 t + i).
 #include "common.hpp"
 #include "fused_common.hpp"
+#include "train_reduce.hpp"
 
 namespace nf {
 
@@ -431,8 +432,8 @@ static int wgrad_tile_chunk_rows(int64_t B, int M) {
 
 // out (dW then db) (=|+=) sum over chunks of part[c][e] in a fixed order; e < nW goes to dW, the rest to db.
 // Block = 64 elements x RL chunk lanes (lane q sums chunks q, q + RL, ... with four loads in flight), combined through
-// LDS in lane order: deterministic, and short dependent chains (the kernel is pure load latency).
-constexpr int RL = 16;
+// LDS in lane order: deterministic, and short dependent chains (the kernel is pure load latency).  The group routine lives in
+// train_reduce.hpp: the one-launch-per-layer reduction of the training step (train_bwd.hip) runs the same code.
 __global__ void __launch_bounds__(64 * RL)
 wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, float *__restrict__ db, int64_t nW, int64_t n,
                     int64_t stride, int chunks, int accumulate, int N, int skip_every, int64_t zpart, int64_t zdW,
@@ -441,40 +442,8 @@ wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, floa
     dW += (int64_t)blockIdx.y * zdW;
     if (db) db += (int64_t)blockIdx.y * zdb;
     __shared__ float sm[RL][64];
-    const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
-    for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < n; e0 += (int64_t)gridDim.x * 64) {
-        const int64_t e = e0 + el;
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-        if (e < n) {
-            int c = q;
-            for (; c + 3 * RL < chunks; c += 4 * RL) {
-                s0 += part[(size_t)c * stride + e];
-                s1 += part[(size_t)(c + RL) * stride + e];
-                s2 += part[(size_t)(c + 2 * RL) * stride + e];
-                s3 += part[(size_t)(c + 3 * RL) * stride + e];
-            }
-            for (; c < chunks; c += RL) s0 += part[(size_t)c * stride + e];
-        }
-        sm[q][el] = (s0 + s1) + (s2 + s3);
-        __syncthreads();
-        if (q == 0 && e < n) {
-            float s = 0.0f;
-#pragma unroll
-            for (int i = 0; i < RL; ++i) s += sm[i][el];
-            float *o = e < nW ? dW + e : db + (e - nW);
-            if (skip_every) {       // every skip_every-th row of dY is padding: not part of the (M - M / skip_every)-row outputs
-                const int64_t m = e < nW ? e / N : e - nW, g = m / skip_every;
-                o = (m - g * skip_every == skip_every - 1) ? nullptr : (e < nW ? dW + e - g * N : db + (m - g));
-            }
-            if (colmap && e < nW) {     // dW keeps the columns n with colmap[n] >= 0, compacted to Nout columns
-                const int64_t m = e / N;
-                const int c = colmap[e - m * N];
-                o = c < 0 ? nullptr : dW + m * Nout + c;
-            }
-            if (o) *o = accumulate ? *o + s : s;
-        }
-        __syncthreads();
-    }
+    for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < n; e0 += (int64_t)gridDim.x * 64)
+        wgrad_reduce_group(part, dW, db, nW, n, stride, chunks, accumulate, N, skip_every, colmap, Nout, e0, sm);
 }
 
 // The reduction as a host call for the kernels of other translation units (resblock_bwd.hip): part = [problem][chunk][nW + M].
@@ -545,7 +514,22 @@ extern "C" int nf_linear_wgrad(const void *dY, const void *X, void *dW, void *db
 }
 
 static int wgrad_impl(const void *dY, const void *X, void *dW, void *db, void *scratch, int64_t B, int M, int N, int accumulate,
-                      int relu_x, int skip_every, nf_stream_t stream, const void *dY1, const void *X1, void *dW1, void *db1);
+                      int relu_x, int skip_every, nf_stream_t stream, const void *dY1, const void *X1, void *dW1, void *db1,
+                      bool reduce = true, int want_bias_partials = -1);
+
+// The partial launch of nf_linear_wgrad[_act] alone: scratch = [chunk][M * N + M] (nf_linear_wgrad_chunks(B, M, N) chunks), summed
+// later by nf_wgrad_reduce_jobs / nf_coupling_train_bwd's one reduction launch per layer.
+extern "C" int nf_linear_wgrad_chunks(int64_t B, int M, int N) {
+    if (B < 1 || M < 1 || N < 1) return NF_EINVAL;
+    const int64_t per = (int64_t)M * N + M, tot = nf_linear_wgrad_scratch_floats(B, M, N);
+    return tot < 0 ? (int)tot : (int)(tot / per);
+}
+extern "C" int nf_linear_wgrad_partials(const void *dY, const void *X, void *scratch, int64_t B, int M, int N, int relu_x,
+                                        int want_bias, nf_stream_t stream) {
+    if (want_bias != 0 && want_bias != 1) return NF_EINVAL;
+    return wgrad_impl(dY, X, scratch /* non-null stand-in, never written */, nullptr, scratch, B, M, N, 0, relu_x, 0, stream, nullptr,
+                      nullptr, nullptr, nullptr, false, want_bias);
+}
 
 extern "C" int nf_linear_wgrad_skip(const void *dY, const void *X, void *dW, void *db, void *scratch, int64_t B, int M, int N,
                                     int accumulate, int relu_x, int skip_every, nf_stream_t stream) {
@@ -565,7 +549,8 @@ extern "C" int nf_linear_wgrad_pair(const void *dY0, const void *X0, void *dW0, 
 }
 
 static int wgrad_impl(const void *dY, const void *X, void *dW, void *db, void *scratch, int64_t B, int M, int N, int accumulate,
-                      int relu_x, int skip_every, nf_stream_t stream, const void *dY1, const void *X1, void *dW1, void *db1) {
+                      int relu_x, int skip_every, nf_stream_t stream, const void *dY1, const void *X1, void *dW1, void *db1,
+                      bool reduce, int want_bias_partials) {
     if (B < 1 || M < 1 || N < 1 || (accumulate != 0 && accumulate != 1) || (relu_x != 0 && relu_x != 1)) return NF_EINVAL;
     if (skip_every < 0 || skip_every == 1 || (skip_every && M % skip_every != 0)) return NF_EINVAL;
     if (N > 128) return NF_ENOTSUP;  // four 32-column tiles of accumulators per wave
@@ -577,7 +562,7 @@ static int wgrad_impl(const void *dY, const void *X, void *dW, void *db, void *s
     const int rows = tile ? nf::wgrad_tile_chunk_rows(B, M) : nf::wgrad_chunk_rows(B, M, vec);
     const int chunks = (int)((B + rows - 1) / rows);
     float *part = (float *)scratch;
-    const int want_bias = db ? 1 : 0;
+    const int want_bias = want_bias_partials >= 0 ? want_bias_partials : (db ? 1 : 0);
     const int np = dY1 ? 2 : 1;
     if (np == 2 && !tile && !vec) return NF_ENOTSUP;
     const int64_t single = (int64_t)chunks * ((int64_t)M * N + M);      // = nf_linear_wgrad_scratch_floats(B, M, N)
@@ -611,6 +596,7 @@ static int wgrad_impl(const void *dY, const void *X, void *dW, void *db, void *s
 #undef NF_WGRAD_LAUNCH
     }
     NF_CHECK_LAUNCH();
+    if (!reduce) return NF_OK;
     const int64_t nW = (int64_t)M * N, n = nW + (db ? M : 0);
     hipLaunchKernelGGL(nf::wgrad_reduce_kernel, dim3(nf::grid_for(n, 64), np), dim3(64 * nf::RL), 0, st, part, (float *)dW,
                        (float *)db, nW, n, nW + M, chunks, accumulate, N, skip_every, zpart, zdW, zdb, (const int *)nullptr, 0);

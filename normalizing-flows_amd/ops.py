@@ -381,17 +381,24 @@ def rqs_fused_pack_all_multi(table, n_layers, num_blocks, tail_bound=3.0, min_bi
     L.check(rc, "nf_rqs_fused_pack_all_multi")
 
 
-def lu_param_grads(gL, gU, gld, unconstrained_upper_diag, n_tri, eps=1e-3, sign=1.0, perm=None):
+def lu_param_grads(gL, gU, gld, unconstrained_upper_diag, n_tri, eps=1e-3, sign=1.0, perm=None, out=None):
     """(g_lower, g_upper, g_udiag) from the dense factor gradients (nf_lu_param_grads); float32.  gld: the (B) log-det
-    cotangent (summed inside the launch) or None; perm: gU's columns are read through it (gU = (gu^T x)[:, perm])."""
+    cotangent (summed inside the launch) or None; perm: gU's columns are read through it (gU = (gu^T x)[:, perm]);
+    out: (g_lower, g_upper, g_udiag) destinations written in place (contiguous float32) instead of new tensors."""
     L.require_device(gL, gU, gld, unconstrained_upper_diag, perm)
     if gld is not None:
         gld = gld.contiguous()
     D = unconstrained_upper_diag.numel()
     dev = gL.device
-    g_lower = torch.empty(n_tri, dtype=torch.float32, device=dev)
-    g_upper = torch.empty(n_tri, dtype=torch.float32, device=dev)
-    g_udiag = torch.empty(D, dtype=torch.float32, device=dev)
+    if out is not None:
+        g_lower, g_upper, g_udiag = out
+        if (g_lower.numel() != n_tri or g_upper.numel() != n_tri or g_udiag.numel() != D
+                or any(t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev for t in out)):
+            raise ValueError("lu_param_grads: out = contiguous float32 (n_tri), (n_tri), (D) tensors on the inputs' device")
+    else:
+        g_lower = torch.empty(n_tri, dtype=torch.float32, device=dev)
+        g_upper = torch.empty(n_tri, dtype=torch.float32, device=dev)
+        g_udiag = torch.empty(D, dtype=torch.float32, device=dev)
     rc = L.lib().nf_lu_param_grads(ptr(gL.contiguous()), ptr(gU.contiguous()), ptr(perm), ptr(gld),
                                    i64(0 if gld is None else gld.numel()), ptr(unconstrained_upper_diag.contiguous()),
                                    f64(eps), f64(sign), ptr(g_lower), ptr(g_upper), ptr(g_udiag), i32(D), L.stream())
@@ -717,6 +724,41 @@ def final_bwd(x, grad_y, grad_logdet, cond24, w_t, blob, uw, uh, ud, mask_parity
                                  ptr(guh), ptr(gud), i32(8), *kw, L.stream())
     L.check(rc, "nf_final_bwd_reduce")
     return gx, gcond, gh, guw, guh, gud
+
+
+def coupling_train_bwd(x, grad_y, grad_logdet, cond24, acts, w_t, blob, wfull_t, w_blocks, uw, uh, ud, col_map, n_cols, mask_parity,
+                       num_blocks, dest, tail_bound=3.0, min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3):
+    """The whole backward of a benchmark-shaped coupling layer in one C-ABI call (nf_coupling_train_bwd): four passes over the rows
+    and ONE reduction launch.  w_blocks: [W1, W2] per residual block; dest: the gradient destinations, written in place --
+    dict(w0, b0, wf, bf, uw, uh, ud, blocks=[gW1, gb1, gW2, gb2 per block]) of contiguous float32 tensors of the parameters'
+    shapes (any addresses: fresh tensors or views of one flat gradient buffer).  Returns grad_x."""
+    L.require_device(x, grad_y, grad_logdet, cond24, acts, w_t, blob, wfull_t, uw, uh, ud, col_map, *w_blocks)
+    B = x.shape[0]
+    x, grad_y, grad_logdet = x.contiguous(), grad_y.contiguous(), grad_logdet.contiguous()
+    lib = L.lib()
+    lib.nf_coupling_train_bwd_scratch_floats.restype = C.c_int64
+    n = int(lib.nf_coupling_train_bwd_scratch_floats(i64(B), i32(num_blocks)))
+    if n <= 0:
+        raise NotImplementedError("coupling_train_bwd: batch a multiple of 64, 1 <= num_blocks <= 5")
+    tensors = [dest[k] for k in ("w0", "b0", "wf", "bf", "uw", "uh", "ud")] + list(dest["blocks"])
+    if len(w_blocks) != 2 * num_blocks or len(dest["blocks"]) != 4 * num_blocks:
+        raise ValueError("coupling_train_bwd: 2 weights and 4 gradient destinations per residual block")
+    L.require_device(*tensors)
+    if any(t.dtype != torch.float32 or not t.is_contiguous() for t in tensors):
+        raise ValueError("coupling_train_bwd: gradient destinations must be contiguous float32")
+    scratch = torch.empty(n, dtype=torch.float32, device=x.device)
+    gx = torch.empty_like(x)
+    wb = [w.contiguous() for w in w_blocks]
+    wp = (C.c_void_p * len(wb))(*[w.data_ptr() for w in wb])
+    gp = (C.c_void_p * len(dest["blocks"]))(*[t.data_ptr() for t in dest["blocks"]])
+    rc = lib.nf_coupling_train_bwd(ptr(x), ptr(grad_y), ptr(grad_logdet), ptr(cond24), ptr(acts), ptr(w_t), ptr(blob), ptr(wfull_t), wp,
+                                   ptr(uw.contiguous()), ptr(uh.contiguous()), ptr(ud.contiguous()), ptr(col_map), i32(int(n_cols)),
+                                   ptr(gx), ptr(dest["w0"]), ptr(dest["b0"]), ptr(dest["wf"]), ptr(dest["bf"]), ptr(dest["uw"]),
+                                   ptr(dest["uh"]), ptr(dest["ud"]), gp, ptr(scratch), i32(mask_parity), i64(B), i32(64), i32(128),
+                                   i32(num_blocks), i32(8), f64(tail_bound), f64(min_bin_width), f64(min_bin_height),
+                                   f64(min_derivative), L.stream())
+    L.check(rc, "nf_coupling_train_bwd")
+    return gx
 
 
 # ---- bf16x3 (error-compensated split-bf16 MFMA) variant of the fused layer ----------------------------------------
@@ -1399,8 +1441,9 @@ def lu_fwd(x, UpT, LT, bias=None, ld_const=None, ld_sign=1.0, logdet=None, acc=N
     return u, y, logdet
 
 
-def lu_bwd(gy, u, x, Lm, Up):
-    """(gx, dL, db, dUp) of LULinearPermute's batch side in the density direction, D = 64, one pass over the rows (nf_lu_bwd)."""
+def lu_bwd(gy, u, x, Lm, Up, db_out=None):
+    """(gx, dL, db, dUp) of LULinearPermute's batch side in the density direction, D = 64, one pass over the rows (nf_lu_bwd);
+    db_out: where the bias gradient (D floats) is written instead of a new tensor."""
     L.require_device(gy, u, x, Lm, Up)
     gy, u, x, Lm, Up = gy.contiguous(), u.contiguous(), x.contiguous(), Lm.contiguous(), Up.contiguous()
     B, D = gy.shape
@@ -1412,6 +1455,10 @@ def lu_bwd(gy, u, x, Lm, Up):
     scratch = torch.empty(n, dtype=torch.float32, device=gy.device)
     out = torch.empty(2 * D * D + D, dtype=torch.float32, device=gy.device)
     dL, dUp, db = out[:D * D], out[D * D:2 * D * D], out[2 * D * D:]
+    if db_out is not None:
+        if db_out.numel() != D or db_out.dtype != torch.float32 or not db_out.is_contiguous() or db_out.device != gy.device:
+            raise ValueError("lu_bwd: db_out = a contiguous float32 (D) tensor on the inputs' device")
+        db = db_out
     gx = torch.empty_like(gy)
     rc = lib.nf_lu_bwd(ptr(gy), ptr(u), ptr(x), ptr(Lm), ptr(Up), ptr(gx), ptr(dL), ptr(db), ptr(dUp), ptr(scratch), i64(B),
                        i32(D), L.stream())

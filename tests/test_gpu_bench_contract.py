@@ -90,3 +90,24 @@ def test_bench_eight_ranks_contract_on_one_device():
     assert d["config"]["collectives_per_step"] == 1 and d["config"]["collective_bytes_per_step"] == 16
     assert abs(d["value"] - 524288 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert abs(d["nll_nats_per_dim"] - 1.5416) < 5e-3
+
+
+def test_bench_train_mode_two_ranks_on_one_device():
+    """`bench.py --gpus 2 --train` (round 6): the timed step is forward_kld + backward + the overlapped in-place
+    gradient all-reduce on the flat buffer + Adam; two ranks share cuda:0 over gloo here.  Every collective entry point of the timed
+    region is counted: 3 all_reduce per step (the 21.8 MB of gradients in 8 MB slices) and nothing else; both replicas hold
+    identical weights after the run; the line carries the contract fields and a roofline object."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(NF_BENCH_ONE_DEVICE="1", OMP_NUM_THREADS="4")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--train", "--steps", "2", "--warmup", "1",
+                          "--batch", "8192"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2500:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_rows"] == 16384 and d["scaling"] == "weak" and d["dtype"] == "f32"
+    assert abs(d["value"] - 2 * 8192 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert d["config"]["collectives_by_op"] == {"all_reduce": 3 * 2} and d["config"]["collectives_per_step"] == 3
+    assert abs(d["config"]["collective_bytes_per_step"] - 4 * 5443584) < 1
+    assert d["replicas_identical_after_run"] is True
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1

@@ -127,7 +127,7 @@ def test_benchmark_shape_training_step_vs_reference_autograd(nfa, monkeypatch):
     from normflows_amd import ops
     m, g = _c2_train_model_and_fixture(nfa)
     calls = {}
-    for name in ("rqs_fused_train_full_fwd", "final_bwd", "resblock_bwd", "lu_fwd", "lu_bwd"):
+    for name in ("rqs_fused_train_full_fwd", "coupling_train_bwd", "final_bwd", "resblock_bwd", "lu_fwd", "lu_bwd"):
         orig = getattr(ops, name)
 
         def spy(*a, _orig=orig, _name=name, **kw):
@@ -139,8 +139,10 @@ def test_benchmark_shape_training_step_vs_reference_autograd(nfa, monkeypatch):
         assert f.prqct._train_full_ok(x, None, False)
     loss = m.forward_kld(x)
     loss.backward()
-    assert calls.get("rqs_fused_train_full_fwd") == 2 and calls.get("final_bwd") == 2, calls
-    assert calls.get("resblock_bwd") == 4 and calls.get("lu_fwd") == 2 and calls.get("lu_bwd") == 2, calls
+    # round 6: a layer's whole backward is ONE C-ABI call (nf_coupling_train_bwd: nf_final_bwd + the ring weight gradient +
+    # nf_resblock_bwd_partials per block + one reduction launch); the kernel-by-kernel wrappers are not called any more
+    assert calls.get("rqs_fused_train_full_fwd") == 2 and calls.get("coupling_train_bwd") == 2, calls
+    assert "final_bwd" not in calls and "resblock_bwd" not in calls and calls.get("lu_fwd") == 2 and calls.get("lu_bwd") == 2, calls
     ref_loss = float(g["loss_f32"])
     assert abs(float(loss) - ref_loss) < 1e-4 * abs(ref_loss), (float(loss), ref_loss)
     assert abs(float(loss) - float(g["loss_f64"])) < 1e-4 * abs(ref_loss)
@@ -1043,6 +1045,71 @@ def test_training_step_fused_final_backward_vs_separate_kernels(nfa):
     assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-5 * float(res[1][1].abs().max())
     for (n, _), a, b in zip(m.named_parameters(), res[0][2], res[1][2]):
         assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-6), n
+
+
+def test_one_call_layer_backward_is_bit_identical_to_kernel_by_kernel(nfa):
+    """Round 6: nf_coupling_train_bwd (four passes over the rows + ONE reduction launch for all of the layer's partial tiles) against
+    the same kernels issued one by one, each followed by its own reduction (config.set_train_bwd_onecall(False), rounds 3-5): the
+    summation order of every output element is unchanged, so loss, input gradient and EVERY parameter gradient are bit-identical;
+    1, 2 and 3 residual blocks, both mask parities, a batch that leaves the last workgroups' tile ranges ragged."""
+    from bench import build_c2_model
+    for blocks, B in ((2, 4096), (1, 1024), (3, 8192 + 64)):
+        m = build_c2_model(num_layers=3, sigma=0.05, blocks=blocks).to(DEV)      # 3 layers: both mask parities
+        x = torch.randn(B, 64, device=DEV)
+        res = []
+        try:
+            for on in (True, False):
+                nfa.config.set_train_bwd_onecall(on)
+                m.zero_grad(set_to_none=True)
+                xa = x.clone().requires_grad_(True)
+                loss = m.forward_kld(xa)
+                loss.backward()
+                res.append((float(loss.detach()), xa.grad.clone(), [p_.grad.clone() for p_ in m.parameters()]))
+        finally:
+            nfa.config.set_train_bwd_onecall(True)
+        assert res[0][0] == res[1][0]
+        assert torch.equal(res[0][1], res[1][1]), "input gradient"
+        for (n, _), a, b in zip(m.named_parameters(), res[0][2], res[1][2]):
+            assert torch.equal(a, b), (blocks, B, n, float((a - b).abs().max()))
+
+
+def test_flat_parameters_training_step_on_the_benchmark_kernels(nfa):
+    """dp.FlatParameters on the benchmark-shaped model (round 6): after backward every parameter's .grad IS its slice of the one flat
+    gradient buffer (the one-call layer backward and LULinearPermute's backward wrote there: sync() has nothing to copy), the
+    gradients equal those of the ordinary per-tensor run bit for bit, Adam(fused) on the ONE flat tensor gives the parameters Adam
+    on the 76 tensors gives, and the inference path sees the stepped weights (packed-weight caches follow the flat step)."""
+    import copy
+    from bench import build_c2_model
+    m = build_c2_model(num_layers=4, sigma=0.05).to(DEV)
+    ref = copy.deepcopy(m)
+    x = torch.randn(2048, 64, device=DEV)
+    with torch.no_grad():
+        lp0 = m.log_prob(x).clone()
+    flat = nfa.dp.FlatParameters(m)
+    opt = torch.optim.Adam(flat.parameters(), lr=1e-3, fused=True)
+    opt_ref = torch.optim.Adam(ref.parameters(), lr=1e-3, fused=True)
+    for step in range(2):
+        flat.zero_grad()
+        loss = m.forward_kld(x)
+        loss.backward()
+        views = {id(p_): v for p_, v in flat.views}
+        assert all(p_.grad is not None and p_.grad.data_ptr() == views[id(p_)].data_ptr() for p_ in m.parameters())
+        assert flat.sync() == 0
+        ref.zero_grad(set_to_none=True)
+        loss_ref = ref.forward_kld(x)
+        loss_ref.backward()
+        assert float(loss.detach()) == float(loss_ref.detach())
+        for (n, p_), q in zip(m.named_parameters(), ref.parameters()):
+            assert torch.equal(p_.grad, q.grad), (step, n)
+        opt.step()
+        opt_ref.step()
+        for (n, p_), q in zip(m.named_parameters(), ref.parameters()):
+            assert torch.allclose(p_, q, rtol=0, atol=1e-7), (step, n, float((p_ - q).abs().max()))
+    with torch.no_grad():
+        lp1, lp_ref = m.log_prob(x), ref.log_prob(x)
+    assert float((lp1 - lp0).abs().max()) > 1e-3, "the inference path must see the stepped weights"
+    assert torch.allclose(lp1, lp_ref, rtol=1e-5, atol=1e-4)
+    flat.release()
 
 
 def test_backward_after_reforward_with_other_weights_raises(nfa):

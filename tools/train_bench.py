@@ -24,6 +24,9 @@ ap.add_argument("--no-lu-bwd", action="store_true", help="ablation: LULinearPerm
 ap.add_argument("--no-final-bwd", action="store_true", help="ablation: stand-alone spline backward + library GEMM instead of nf_final_bwd")
 ap.add_argument("--no-prepack", action="store_true", help="ablation: every layer packs its own weights / LU factors (2 x 32 launches)")
 ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the default foreach implementation")
+ap.add_argument("--flat", action="store_true", help="round 6: dp.FlatParameters -- parameters as views of one flat tensor, gradients written into one "
+                "flat buffer by the kernels, Adam(fused) on ONE tensor")
+ap.add_argument("--no-onecall", action="store_true", help="ablation: the layer's backward kernel by kernel with one reduction launch each (rounds 3-5)")
 a = ap.parse_args()
 if a.no_train_full:
     import normflows_amd
@@ -46,19 +49,34 @@ if a.no_matvec2:
 if a.no_wgrad_pair:
     import normflows_amd
     normflows_amd.config.set_wgrad_pair(False)
+if a.no_onecall:
+    import normflows_amd
+    normflows_amd.config.set_train_bwd_onecall(False)
 dev = torch.device("cuda:0")
 m = build_c2_model().to(dev)
 x = c2_inputs(a.batch).to(dev)
-opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=True) if a.fused_adam else torch.optim.Adam(m.parameters(), lr=1e-4)
+flat = None
+if a.flat:
+    import normflows_amd
+    flat = normflows_amd.dp.FlatParameters(m)
+    opt = torch.optim.Adam(flat.parameters(), lr=1e-4, fused=True)
+else:
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=True) if a.fused_adam else torch.optim.Adam(m.parameters(), lr=1e-4)
 for i in range(2 + a.steps):
     if i == 2:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-    opt.zero_grad(set_to_none=True)
+    if flat is not None:
+        flat.zero_grad()
+    else:
+        opt.zero_grad(set_to_none=True)
     loss = m.forward_kld(x)
     loss.backward()
+    if flat is not None:
+        flat.sync()
     opt.step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
-print("train step: %.1f ms  -> %.0f samples/s  (loss %.4f, peak mem %.1f GB)" % (
-    dt * 1e3, a.batch / dt, float(loss), torch.cuda.max_memory_allocated() / 2 ** 30))
+print("train step: %.2f ms  -> %.0f samples/s  (loss %.4f, peak mem %.1f GB)%s" % (
+    dt * 1e3, a.batch / dt, float(loss), torch.cuda.max_memory_allocated() / 2 ** 30,
+    "  [flat parameters]" if flat is not None else ""))
