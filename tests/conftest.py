@@ -47,3 +47,15 @@ def oracle():
 
 
 TOL = {np.dtype("float32"): dict(rtol=2e-5, atol=2e-5), np.dtype("float64"): dict(rtol=1e-10, atol=1e-10)}
+
+
+def ld_tol(dtype, root_finding=False):
+    """Tolerance of a PER-LAYER log|det| against the reference's output in the same precision (round 6, VERDICT r05: was 1e-3).
+    Closed-form direction (the spline itself, the density direction of a coupling layer): 1e-4 relative + absolute, the north-star
+    bar.  Root-finding direction (the spline's inverse, a coupling layer's sampling direction): the quadratic's discriminant cancels
+    in float32 and the REFERENCE's own float32 evaluation sits 9.8e-5 (absolute) away from its float64 evaluation on these fixtures
+    (measured here by running the reference on spline_K10_f32 in both precisions: DESIGN.md section 5) -- two float32 orderings cannot agree better than that: 5e-4 absolute there."""
+    t = TOL[np.dtype(dtype)]
+    if root_finding:
+        return dict(rtol=t["rtol"] * 5, atol=t["atol"] * 25)
+    return dict(rtol=t["rtol"] * 5, atol=t["atol"] * 5)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import TOL, assert_close, golden_state, load_golden
+from conftest import TOL, assert_close, golden_state, ld_tol, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -51,20 +51,20 @@ def test_spline_kernel_vs_reference(nfa, K, tag):
     g = load_golden("spline_K%d_%s" % (K, tag))
     tol = TOL[g["w"].dtype]
     t10 = dict(rtol=tol["rtol"] * 10, atol=tol["atol"] * 10)
-    t50 = dict(rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
+    tld = (ld_tol(g["w"].dtype), ld_tol(g["w"].dtype, True))     # closed form | root finding (conftest.ld_tol)
     y, lad = nfa.ops.rqs_spline(T(g["x01"]), T(g["w"]), T(g["h"]), T(g["d_none"]), inverse=False, tails=None)
     assert_close(N(y), g["y01"], what="y01", **t10)
-    assert_close(N(lad), g["lad01"], what="lad01", **t50)
+    assert_close(N(lad), g["lad01"], what="lad01", **tld[0])
     y, lad = nfa.ops.rqs_spline(T(g["y01"]), T(g["w"]), T(g["h"]), T(g["d_none"]), inverse=True, tails=None)
     assert_close(N(y), g["x01_inv"], what="x01_inv", **t10)
-    assert_close(N(lad), g["lad01_inv"], what="lad01_inv", **t50)
+    assert_close(N(lad), g["lad01_inv"], what="lad01_inv", **tld[1])
     for tails, dkey, bound, keys in (("linear", "d_lin", 3.0, ("yl", "ladl", "yl_inv", "ladl_inv")),
                                      ("circular", "d_cir", 2.5, ("yc", "ladc", "yc_inv", "ladc_inv"))):
         for inv in (False, True):
             y, lad = nfa.ops.rqs_spline(T(g["xl"]), T(g["w"]), T(g["h"]), T(g[dkey]), inverse=inv, tails=tails,
                                         tail_bound=bound)
             assert_close(N(y), g[keys[2 * inv]], what=keys[2 * inv], **t10)
-            assert_close(N(lad), g[keys[2 * inv + 1]], what=keys[2 * inv + 1], **t50)
+            assert_close(N(lad), g[keys[2 * inv + 1]], what=keys[2 * inv + 1], **tld[int(inv)])
 
 
 @pytest.mark.parametrize("tag", ["f32", "f64"])
@@ -118,15 +118,15 @@ def test_coupled_rqs_layer_vs_reference(nfa, d, tag):
     y, ld = nfa.ops.rqs_coupling(x, T(g["cond_density"]), uw, uh, ud, p.identity_features, p.transform_features, K, 0,
                                  **kw)
     assert_close(N(y), g["z_inv"], what="kernel z_inv", rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
-    assert_close(N(ld), g["ld_inv"], what="kernel ld_inv", rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
+    assert_close(N(ld), g["ld_inv"], what="kernel ld_inv", **ld_tol(g["x"].dtype))
     # layer end to end, both directions (conditioner included)
     z, ld = layer.inverse(x)
     assert z.dtype == x.dtype and z.shape == x.shape and ld.shape == (x.shape[0],)
     assert_close(N(z), g["z_inv"], what="z_inv", rtol=tol["rtol"] * 10, atol=tol["atol"] * 10)
-    assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
+    assert_close(N(ld), g["ld_inv"], what="ld_inv", **ld_tol(g["x"].dtype))
     z, ld = layer.forward(x)
     assert_close(N(z), g["z_fwd"], what="z_fwd", rtol=tol["rtol"] * 20, atol=tol["atol"] * 20)
-    assert_close(N(ld), g["ld_fwd"], what="ld_fwd", rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
+    assert_close(N(ld), g["ld_fwd"], what="ld_fwd", **ld_tol(g["x"].dtype, True))
     # round trip (flows/flow_test.py:40-48)
     xr, ldr = layer.inverse(z)
     inside = np.abs(g["x"]) < 2.9
@@ -147,10 +147,10 @@ def test_lu_linear_permute_vs_reference(nfa, d, tag):
     x = T(g["x"])
     z, ld = layer.inverse(x)
     assert_close(N(z), g["z_inv"], what="z_inv", rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
-    assert_close(N(ld), g["ld_inv"], what="ld_inv", rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
+    assert_close(N(ld), g["ld_inv"], what="ld_inv", **ld_tol(g["x"].dtype))
     z, ld = layer.forward(x)
     assert_close(N(z), g["z_fwd"], what="z_fwd", rtol=tol["rtol"] * 200, atol=tol["atol"] * 200)
-    assert_close(N(ld), g["ld_fwd"], what="ld_fwd", rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
+    assert_close(N(ld), g["ld_fwd"], what="ld_fwd", **ld_tol(g["x"].dtype, True))
     # permutation is bit exact: a layer with L = U = I and zero bias reproduces index_select exactly
     with torch.no_grad():
         layer.linear.lower_entries.zero_()
