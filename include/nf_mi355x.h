@@ -421,6 +421,29 @@ int nf_lu_bwd(const void *gy, const void *u, const void *x, const void *Lm, cons
  * nf_lu_factors.  D = 64, B a multiple of 64. */
 int nf_lu_fwd(const void *x, const void *UpT, const void *LT, const void *bias, void *u, void *y, void *logdet,
               const void *ld_const, double ld_sign, int acc, int64_t B, int D, nf_stream_t stream);
+/* Round 6: the LULinearPermute of a benchmark-shaped pair fused into the training forward, and its backward on the composed matrix.
+ *   nf_lu_pack_train_multi: once per step (behind nf_rqs_fused_pack_all_multi), n layers in one launch: the density-direction LU
+ *   stage, bias and constant log|det| of each layer's training blob (W_d = L U with permuted columns, composed in float64:
+ *   mixing.py:402-473, 535-563) and W_d row-major (64, 64) for the backward.  table (device): n rows of 7 pointers perm (int64),
+ *   lower_entries, upper_entries, unconstrained_upper_diag, bias, wpack, wd_out.
+ *   nf_rqs_fused_train_pair_fwd: nf_rqs_fused_train_full_fwd with LULinearPermute.inverse in front of the coupling in the same
+ *   launch (the order NormalizingFlow.log_prob visits a [CoupledRQS, LULinearPermute] pair, core.py:193-195); xlu_out (B, 64) = the
+ *   LU's output = the coupling's input, kept for the backward; logdet takes both layers' terms.
+ *   nf_lu_bwd_composed: gx (B, 64) = g W_d, dWd (64, 64) = g^T x, db (64) = colsum(g) in one pass over the rows (x = the LU's
+ *   INPUT rows); scratch: nf_lu_bwd_composed_scratch_floats(B); B a multiple of 64; deterministic.
+ *   nf_lu_param_grads_composed: dWd -> (g_lower, g_upper, g_udiag): dM[:, j] = dWd[:, perm[j]], dL = dM U^T, dU = L^T dM, the
+ *   diagonal through softplus' with gl_sum / diag (gld (B): the log-det cotangent, summed inside; may be NULL); Lm, Um: the dense
+ *   factors of nf_lu_factors[_multi].  D = 64. */
+int nf_lu_pack_train_multi(const void *table, int n_layers, int num_blocks, int D, double eps, nf_stream_t stream);
+int nf_rqs_fused_train_pair_fwd(const void *x, void *xlu_out, void *y, void *logdet, void *cond_out, void *act_out, const void *wpack,
+                                int mask_parity, int64_t B, int D, int hidden, int num_blocks, int K, double tail_bound,
+                                double min_bin_width, double min_bin_height, double min_derivative, int acc, nf_stream_t stream);
+int64_t nf_lu_bwd_composed_scratch_floats(int64_t B);
+int nf_lu_bwd_composed(const void *g, const void *x, const void *Wd, void *gx, void *dWd, void *db, void *scratch, int64_t B, int D,
+                       nf_stream_t stream);
+int nf_lu_param_grads_composed(const void *dWd, const void *Lm, const void *Um, const int64_t *perm, const void *gld, int64_t B,
+                               const void *unconstrained_upper_diag, double eps, void *g_lower, void *g_upper, void *g_udiag, int D,
+                               nf_stream_t stream);
 int64_t nf_resblock_bwd_scratch_floats(int64_t B, int with_init);
 int nf_resblock_bwd(const void *gh, const void *t, const void *h_in, const void *W1, const void *W2, void *gh_in, void *dW1,
                     void *db1, void *dW2, void *db2, const void *x, const void *wfull, void *gx, void *dW0, void *db0,

@@ -67,6 +67,16 @@ def _lu_row(f, z):
     return [o[0] for o in own] + [fbuf], own + [(fbuf, f.__dict__, "_lu_fbuf")]
 
 
+def _pair_row(c, f, z):
+    """Table row of nf_lu_pack_train_multi for the pair (coupling c, LULinearPermute f): the LU's tensors, the coupling's training
+    blob and the LU's (64, 64) composed-matrix buffer (round 6)."""
+    lin = f.linear
+    own = [_owned(f.permutation, "_permutation"), _owned(lin, "lower_entries"), _owned(lin, "upper_entries"),
+           _owned(lin, "unconstrained_upper_diag"), _owned(lin, "bias")]
+    blob, wd = c._train_blob_for(z), f._wd_buffer(z.device)
+    return [o[0] for o in own] + [blob, wd], own + [(blob, c.__dict__, "_train_blob"), (wd, f.__dict__, "_lu_wd")]
+
+
 def _switches(kind, layer):
     if kind == "nsf":
         return (layer.use_fused, layer.use_fused_train, layer.training)
@@ -87,7 +97,7 @@ def _plan(flows, z, sig):
     training flags, configuration)."""
     from .flows.mixing import LULinearPermute
     from .flows.neural_spline import CoupledRationalQuadraticSpline
-    groups = {}
+    groups, packed = {}, set()
     for f in flows:
         if isinstance(f, CoupledRationalQuadraticSpline):
             c = f.prqct
@@ -95,16 +105,32 @@ def _plan(flows, z, sig):
                 key = ("nsf", len(c.transform_net.blocks), float(c.tail_bound), c.min_bin_width, c.min_bin_height, c.min_derivative)
                 row, own = _nsf_row(c, z)
                 groups.setdefault(key, []).append((c, row, own, _switches("nsf", c)))
+                packed.add(id(f))
         elif isinstance(f, LULinearPermute) and f._train_factors_ok(z) and all(p.requires_grad for p in f.parameters()):
             row, own = _lu_row(f, z)
             groups.setdefault(("lu", f.linear.features, float(f.linear.eps)), []).append((f, row, own, _switches("lu", f)))
-    return _Plan(sig, list(groups.items()))
+            packed.add(id(f))
+    out = list(groups.items())
+    # round 6: adjacent [CoupledRQS, LULinearPermute] pairs whose two layers are both packed above run as autograd.PairTrainFn: one
+    # more multi-layer launch writes the LU stage of the coupling's blob (AFTER the "nsf" launch: it re-initialises the header)
+    if _config.train_pair and _config.train_bwd_onecall and _config.final_bwd_fused and _config.resblock_bwd:
+        pairs = {}
+        fl = list(flows)
+        for a, b in zip(fl[:-1], fl[1:]):
+            if (isinstance(a, CoupledRationalQuadraticSpline) and isinstance(b, LULinearPermute) and id(a) in packed and id(b) in packed
+                    and b.linear.features == 64 and z.shape[0] % 64 == 0 and 1 <= len(a.prqct.transform_net.blocks) <= 5):
+                row, own = _pair_row(a.prqct, b, z)
+                key = ("pair", len(a.prqct.transform_net.blocks), float(b.linear.eps))
+                pairs.setdefault(key, []).append(((a.prqct, b), row, own, _switches("nsf", a.prqct) + _switches("lu", b)))
+        out += list(pairs.items())
+    return _Plan(sig, out)
 
 
 def _plan_valid(plan):
     for key, entries in plan.groups:
         for layer, _, own, sw in entries:
-            if _switches(key[0], layer) != sw:
+            cur = (_switches("nsf", layer[0]) + _switches("lu", layer[1])) if key[0] == "pair" else _switches(key[0], layer)
+            if cur != sw:
                 return False
             for t, d, name in own:
                 cur = d.get(name)
@@ -130,7 +156,8 @@ def begin(flows, z, inverse):
     # the plan depends on what decides the layers' training path: shapes, configuration, the list itself -- and WHICH layers are
     # trainable right now: a plan built while parameters were frozen (reverse_kld(score_fn=False), a freeze-then-unfreeze
     # fine-tune) holds too few layers and would otherwise stay valid for the same batch shape forever (round-3 ADVICE)
-    sig = (tuple(z.shape), z.device, _config.train_full, _config.resblock_bwd, _config.lu_bwd_fused, len(flows), _trainable(flows))
+    sig = (tuple(z.shape), z.device, _config.train_full, _config.resblock_bwd, _config.lu_bwd_fused, len(flows), _trainable(flows),
+           _config.train_pair, _config.train_bwd_onecall, _config.final_bwd_fused)
     plan = _plans.get(flows)
     if plan is None or plan.sig != sig or not _plan_valid(plan):
         plan = _plan(flows, z, sig)
@@ -138,7 +165,7 @@ def begin(flows, z, inverse):
             _plans[flows] = plan            # (a plan with fewer than two eligible layers is not worth a launch and is not kept)
         else:
             _plans.pop(flows, None)
-    if sum(len(es) for _, es in plan.groups) < 2:
+    if sum(len(es) for k_, es in plan.groups if k_[0] != "pair") < 2:
         return None
     token = object()
     for key, entries in plan.groups:
@@ -147,6 +174,11 @@ def begin(flows, z, inverse):
         if key[0] == "nsf":
             ops.rqs_fused_pack_all_multi(table, len(entries), key[1], tail_bound=key[2], min_bin_width=key[3], min_bin_height=key[4],
                                          min_derivative=key[5])
+        elif key[0] == "pair":
+            ops.lu_pack_train_multi(table, len(entries), key[1], key[2])
+            for (c, f), _, _, _ in entries:
+                c.__dict__["_pair_prepacked"] = (token, f)
+            continue
         else:
             ops.lu_factors_multi(table, len(entries), key[2], key[1])
         for layer, _, _, _ in entries:
@@ -158,6 +190,21 @@ def begin(flows, z, inverse):
 def end(token):
     if token is not None and current() is token:
         _tls.token = None
+
+
+def take_pair(c, f):
+    """True once per prepack: coupling c's blob holds LULinearPermute f's stage, both layers' own packs are current, and nobody has
+    consumed them yet (autograd.PairTrainFn then runs the pair; both layers' tokens are consumed with it)."""
+    ent = c.__dict__.get("_pair_prepacked")
+    tok = current()
+    if ent is None or tok is None or ent[0] is not tok or ent[1] is not f:
+        return False
+    if c.__dict__.get("_prepacked") is not tok or f.__dict__.get("_prepacked") is not tok:
+        return False
+    c.__dict__["_pair_prepacked"] = None
+    c.__dict__["_prepacked"] = None
+    f.__dict__["_prepacked"] = None
+    return True
 
 
 def take(layer):

@@ -506,6 +506,63 @@ class CouplingTrainFn(torch.autograd.Function):
                 (gld if ctx.has_acc else None), None, *gblk)
 
 
+class PairTrainFn(torch.autograd.Function):
+    """A benchmark-shaped [CoupledRationalQuadraticSpline, LULinearPermute] pair in the density direction under autograd (round 6):
+    ONE forward launch for LULinearPermute.inverse + the whole coupling layer (nf_rqs_fused_train_pair_fwd: the inference kernel's
+    pair fusion with the training variant's saved rows), and a backward of six launches: nf_coupling_train_bwd's five, then the
+    composed LU's backward in one pass (nf_lu_bwd_composed: gx = g W_d, dW_d = g^T x; no second product, no intermediate u) with the
+    factors' gradients on the parameter side (nf_lu_param_grads_composed).  Replaces LULinearPermuteFn (nf_lu_fwd 17 us + nf_lu_bwd
+    27 us + two small launches per layer at the benchmark batch) + CouplingTrainFn.  Only inside core.run_chain, whose per-step
+    multi-layer packs (_prepack.py) leave the blob's LU stage, W_d and the dense factors current."""
+
+    @staticmethod
+    def forward(ctx, x, perm, lower, upper, udiag, lbias, lu_eps, lu_fbuf, lu_wd, w0, b0, wf, bf, uw, uh, ud, iidx, tidx, blob, parity, kw,
+                wfull, wpad, ld_acc, acc, *blk):
+        nb = len(blk) // 4
+        fk = dict(tail_bound=kw["tail_bound"], min_bin_width=kw["min_bin_width"], min_bin_height=kw["min_bin_height"],
+                  min_derivative=kw["min_derivative"])
+        xlu, y, ld, cond24, acts = ops.rqs_fused_train_pair_fwd(x, blob, parity, nb, logdet=ld_acc,
+                                                                acc=None if ld_acc is None else (L.LD_ADD if acc > 0 else L.LD_SUB), **fk)
+        if ld_acc is not None:
+            ctx.mark_dirty(ld_acc)
+        ctx.save_for_backward(x, xlu, cond24, acts, perm, lower, upper, udiag, w0, wf, uw, uh, ud, iidx, *blk)
+        ctx.kw, ctx.wfull, ctx.wpad, ctx.acc, ctx.has_acc, ctx.nb = kw, wfull, wpad, acc, ld_acc is not None, nb
+        ctx.blob, ctx.parity, ctx.biases = blob, parity, (b0, bf, lbias)
+        ctx.lu = (lu_eps, lu_fbuf, lu_wd)
+        ctx.holder, ctx.stamp = kw.get("holder"), ("pair",) + _stamp(lower, upper, udiag, lbias, w0, b0, wf, bf, uw, uh, ud, *blk)
+        if ctx.holder is not None:
+            ctx.holder["stamp"] = ctx.stamp
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, gy, gld):
+        x, xlu, cond24, acts, perm, lower, upper, udiag, w0, wf, uw, uh, ud, iidx, *blk = ctx.saved_tensors
+        _check_stamp(ctx, "PairTrainFn")
+        kw, nb = ctx.kw, ctx.nb
+        if gy is None:
+            gy = torch.zeros_like(x)
+        if gld is None:
+            gld = torch.zeros(x.shape[0], dtype=x.dtype, device=x.device)
+        gld_own = -gld if (ctx.has_acc and ctx.acc < 0) else gld
+        fk = dict(tail_bound=kw["tail_bound"], min_bin_width=kw["min_bin_width"], min_bin_height=kw["min_bin_height"],
+                  min_derivative=kw["min_derivative"])
+        b0, bf, lbias = ctx.biases
+        lu_eps, lu_fbuf, lu_wd = ctx.lu
+        dest = dict(w0=_gradbuf.out(w0), b0=_gradbuf.out(b0), wf=_gradbuf.out(wf), bf=_gradbuf.out(bf), uw=_gradbuf.out(uw),
+                    uh=_gradbuf.out(uh), ud=_gradbuf.out(ud), blocks=[_gradbuf.out(p_) for p_ in blk])
+        g = ops.coupling_train_bwd(xlu, gy, gld_own, cond24, acts, ctx.wpad, ctx.blob, ctx.wfull,
+                                   [blk[4 * b + j].detach() for b in range(nb) for j in (0, 2)], uw.detach(), uh.detach(),
+                                   ud.detach(), kw["col_map"], iidx.numel(), ctx.parity, nb, dest, **fk)
+        gx, dWd, g_lbias = ops.lu_bwd_composed(g, x, lu_wd, db_out=_gradbuf.out(lbias))
+        D = x.shape[1]
+        Lm, Um = lu_fbuf[:D * D].view(D, D), lu_fbuf[D * D:2 * D * D].view(D, D)
+        g_lower, g_upper, g_udiag = ops.lu_param_grads_composed(dWd, Lm, Um, perm, gld_own, udiag.detach(), lower.numel(), eps=lu_eps,
+                                                                out=(_gradbuf.out(lower), _gradbuf.out(upper), _gradbuf.out(udiag)))
+        return (gx, None, g_lower, g_upper, g_udiag, g_lbias, None, None, None, dest["w0"], dest["b0"], dest["wf"], dest["bf"],
+                dest["uw"], dest["uh"], dest["ud"], None, None, None, None, None, None, None, (gld if ctx.has_acc else None), None,
+                *dest["blocks"])
+
+
 class IdentLinearFn(torch.autograd.Function):
     """The conditioner's initial Linear on the identity columns of a full-width row (nsf/coupling.py:71-76 `inputs[:,
     identity_features]` + nets/resnet.py:92): y = x[:, iidx] W^T + b computed as x Wfull^T + b with W scattered into a

@@ -84,6 +84,16 @@ def set_train_bwd_onecall(mode=True):
     train_bwd_onecall = bool(mode)
 
 
+# A benchmark-shaped [CoupledRQS, LULinearPermute] pair under autograd as ONE forward launch and the composed LU's one-product
+# backward (autograd.PairTrainFn, round 6); False = LULinearPermuteFn + CouplingTrainFn (rounds 3-5; ablation / differential tests).
+train_pair = True
+
+
+def set_train_pair(mode=True):
+    global train_pair
+    train_pair = bool(mode)
+
+
 # LULinearPermute's density-direction backward (D = 64) as one pass over the rows (nf_lu_bwd).
 lu_bwd_fused = True
 

@@ -234,6 +234,13 @@ def _run_chain_impl(flows, z, inverse, ld, acc):
         if k + 1 < n:
             j = order[k + 1]
             a, b = (flows[j], f) if inverse else (f, flows[j])   # a = CoupledRQS candidate, b = LU candidate
+            if (inverse and isinstance(a, CoupledRationalQuadraticSpline) and isinstance(b, LULinearPermute)
+                    and _prepack.take_pair(a.prqct, b)):
+                # training step (round 6): this step's multi-layer packs cover the pair -> one forward launch, composed LU backward
+                z = flush(z)
+                z = a._run_pair_train(z, b, ld, acc)
+                k += 2
+                continue
             if (isinstance(a, CoupledRationalQuadraticSpline) and isinstance(b, LULinearPermute)
                     and a._pair_eligible(z, b)):
                 pair = (a, b)

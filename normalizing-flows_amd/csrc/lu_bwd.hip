@@ -151,6 +151,153 @@ lu_bwd_kernel(LuBwdArgs a) {
     if (cb == 1 && hh == 0) oU[nW + 32 * rh + i] = 0.0f;       // the second problem has no bias; keep the slot defined
 }
 
+// Round 6: the same backward for the COMPOSED layer y = W_d x + b (W_d = L U with permuted columns: what the fused training forward
+// rqs_fused_kernel<0, true, 2> multiplies by): ONE product and ONE weight gradient per tile instead of two each, no intermediate u:
+//   gx = g W_d  (= W_d^T g per row),   dW_d = g^T x,   db = colsum(g);
+// the factors' gradients follow on the parameter side (nf_lu_param_grads_composed: dL = dM U^T, dU = L^T dM with
+// dM[:, j] = dW_d[:, perm[j]] -- 64^3 products once per layer instead of two more passes over the batch).
+// Reads g and x (34 MB at B = 65 536), writes gx (17 MB): HBM-bound; the tiles are double-buffered (one barrier per tile: the next
+// tile's 2 x 17 DMA instructions are in flight while this one multiplies), two workgroups per CU.
+struct LuBwdCArgs {
+    const float *g, *x, *Wd;
+    float *gx;
+    float *part;           // [grid][64 * 64 + 64]: (dW_d, db)
+    int64_t B;
+};
+
+__global__ void __launch_bounds__(256, 2)
+lu_bwd_c_kernel(LuBwdCArgs a) {
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    extern __shared__ __attribute__((aligned(16))) float smem_lb[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rh = wid >> 1, cb = wid & 1;
+    const int grid = gridDim.x;
+    const int64_t ntiles = a.B / LB_R;
+    unsigned goff[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int s = 64 * (wid + 4 * q) + lane, row = s / 17, c = s - 17 * row;
+        goff[q] = (unsigned)((row < LB_R ? row : 0) * LB_D + 4 * (c < 16 ? c : 15));
+    }
+    auto issue = [&](const float *src, float *tile) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_global_load_lds(src + goff[q], (lds_ptr)(tile + 256 * (wid + 4 * q)), 16, 0, 0);
+        if (wid == 0) __builtin_amdgcn_global_load_lds(src + goff[4], (lds_ptr)(tile + 256 * 16), 16, 0, 0);   // instruction 17
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < ntiles) {
+        issue(a.g + tile * (LB_R * LB_D), smem_lb);
+        issue(a.x + tile * (LB_R * LB_D), smem_lb + LB_TILE);
+    }
+    float Wr[32];
+    {
+        const int i = lane & 31, hh = lane >> 5;
+#pragma unroll
+        for (int Q = 0; Q < 8; ++Q)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) Wr[4 * Q + s] = a.Wd[(8 * Q + 4 * hh + s) * LB_D + 32 * cb + i];
+    }
+    f32x16 acc = {0};
+    float bs = 0.f;
+    int buf = 0;
+    for (; tile < ntiles; tile += grid, buf ^= 1) {
+        float *Gt = smem_lb + buf * 2 * LB_TILE, *Xt = Gt + LB_TILE;
+        LB_BARRIER_ALL();          // this tile landed; every wave is done with the other buffer set
+        if (tile + grid < ntiles) {
+            float *Gn = smem_lb + (buf ^ 1) * 2 * LB_TILE;
+            issue(a.g + (tile + grid) * (LB_R * LB_D), Gn);
+            issue(a.x + (tile + grid) * (LB_R * LB_D), Gn + LB_TILE);
+        }
+        int l_ = lane;
+        asm volatile("" : "+v"(l_));
+        const int i = l_ & 31, hh = l_ >> 5;
+        // ---- gx = g W_d ----
+        {
+            f32x16 C = {0};
+            const float *ap = Gt + (32 * rh + i) * LB_P + 4 * hh;
+#pragma unroll
+            for (int Q = 0; Q < 8; ++Q) {
+                const f32x4 av = *reinterpret_cast<const f32x4 *>(ap + 8 * Q);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) C = MFMA32(av[s], Wr[4 * Q + s], C);
+            }
+            float *gp = a.gx + (tile * LB_R + 32 * rh + 4 * hh) * LB_D + 32 * cb + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gp[(8 * (r >> 2) + (r & 3)) * LB_D] = C[r];
+        }
+        // ---- dW_d += g^T x, db += colsum(g) ----
+        {
+            const float *ap = Gt + hh * LB_P + 32 * rh + i, *bp = Xt + hh * LB_P + 32 * cb + i;
+#pragma unroll 8
+            for (int kp = 0; kp < LB_R / 2; ++kp) {
+                const float a0 = ap[kp * 2 * LB_P];
+                bs += a0;
+                acc = MFMA32(a0, bp[kp * 2 * LB_P], acc);
+            }
+        }
+    }
+    constexpr int64_t nW = LB_D * LB_D, stride = nW + LB_D;
+    float *o = a.part + (int64_t)blockIdx.x * stride;
+    const int i = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[(32 * rh + (r & 3) + 8 * (r >> 2) + 4 * hh) * LB_D + 32 * cb + i] = acc[r];
+    bs += __shfl_xor(bs, 32);
+    if (cb == 0 && hh == 0) o[nW + 32 * rh + i] = bs;
+}
+
+// dW_d (reduced) -> the packed parameter gradients of LULinearPermute (mixing.py:402-473 under autograd): W_d[:, perm[j]] =
+// (L U)[:, j], so dM[r][j] = dW_d[r][perm[j]];  dL = dM U^T (strictly lower part -> g_lower), dU = L^T dM (strictly upper part ->
+// g_upper; diagonal + gl_sum / diag through softplus' -> g_udiag), gl_sum = sum of the (B) log-det cotangent.  One workgroup:
+// L, U, dM in LDS, one 64-term dot product per entry.  Lm / Um: the dense factors nf_lu_factors[_multi] assembled this step.
+__global__ void __launch_bounds__(1024)
+lu_c_param_grads_kernel(const float *__restrict__ dWd, const float *__restrict__ Lm, const float *__restrict__ Um,
+                        const int64_t *__restrict__ perm, const float *__restrict__ gld, int64_t B,
+                        const float *__restrict__ udiag_raw, float eps, float *__restrict__ g_lower, float *__restrict__ g_upper,
+                        float *__restrict__ g_udiag) {
+    constexpr int D = LB_D, N = D * D, P = D + 1;
+    __shared__ float Ls[D * P], Us[D * P], Ms[D * P];
+    __shared__ float sred[16];
+    const int tid = threadIdx.x;
+    float gl = 0.0f;
+    if (gld) {
+        float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+        const int64_t B4 = (reinterpret_cast<uintptr_t>(gld) & 15) == 0 ? B / 4 : 0;
+        const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gld);
+#pragma unroll 8
+        for (int64_t b = tid; b < B4; b += 1024) {
+            const f32x4 v = g4[b];
+            p0 += v[0]; p1 += v[1]; p2 += v[2]; p3 += v[3];
+        }
+        for (int64_t b = 4 * B4 + tid; b < B; b += 1024) p0 += gld[b];
+        gl = block_sum((p0 + p1) + (p2 + p3), sred);
+    }
+    for (int i = tid; i < N; i += 1024) {
+        const int r = i / D, c = i - r * D;
+        Ls[r * P + c] = Lm[i];
+        Us[r * P + c] = Um[i];
+        Ms[r * P + c] = dWd[r * D + (int)perm[c]];
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += 1024) {
+        const int r = i / D, c = i - r * D;
+        if (c < r) {            // dL[r][c] = sum_k dM[r][k] U[c][k]   (U upper triangular: k >= c)
+            float s = 0.0f;
+            for (int k = c; k < D; ++k) s = fmaf(Ms[r * P + k], Us[c * P + k], s);
+            g_lower[r * (r - 1) / 2 + c] = s;
+        } else {                // dU[r][c] = sum_k L[k][r] dM[k][c]   (L unit lower triangular: k >= r)
+            float s = Ms[r * P + c];
+            for (int k = r + 1; k < D; ++k) s = fmaf(Ls[k * P + r], Ms[k * P + c], s);
+            if (c > r) g_upper[r * (D - 1) - r * (r - 1) / 2 + (c - r - 1)] = s;
+            else {
+                const float u = udiag_raw[r], d = softplus(u) + eps;
+                g_udiag[r] = (s + gl / d) * (u > 20.0f ? 1.0f : sigmoid(u));
+            }
+        }
+    }
+}
+
 // The density direction's FORWARD on the same tiles (training keeps u for the backward): u = x UpT (= U x[perm] per row),
 // y = u LT + b (= L u + b), logdet (op)= ld_sign * *ld_const.  x tiles by LDS-DMA, both weight slices in registers, u goes to
 // LDS (A operand of the second product) and to HBM; 50 MB of traffic per launch at B = 65 536 = its algorithmic bytes.
@@ -293,6 +440,48 @@ extern "C" int nf_lu_fwd(const void *x, const void *UpT, const void *LT, const v
     a.ld_const = (const float *)ld_const; a.u = (float *)u; a.y = (float *)y; a.logdet = (float *)logdet;
     a.ld_sign = (float)ld_sign; a.acc = acc; a.B = B;
     hipLaunchKernelGGL(lu_fwd_kernel, dim3(lb_grid(B)), dim3(256), (size_t)2 * LB_TILE * sizeof(float), (hipStream_t)stream, a);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+extern "C" int64_t nf_lu_bwd_composed_scratch_floats(int64_t B) {
+    using namespace nf;
+    if (B < LB_R || B % LB_R) return NF_EINVAL;
+    return (int64_t)lb_grid(B) * ((int64_t)LB_D * LB_D + LB_D);
+}
+
+// Backward of the composed LULinearPermute (density direction; the layer as the fused training forward evaluates it: y = W_d x + b),
+// D = 64, one pass over the rows: gx (B, 64) = g W_d, dWd (64, 64) = g^T x, db (64) = colsum(g); W_d (64, 64) row-major from
+// nf_lu_pack_train_multi.  B a multiple of 64; scratch: nf_lu_bwd_composed_scratch_floats(B).  Deterministic.
+extern "C" int nf_lu_bwd_composed(const void *g, const void *x, const void *Wd, void *gx, void *dWd, void *db, void *scratch, int64_t B,
+                                  int D, nf_stream_t stream) {
+    using namespace nf;
+    if (D != LB_D || B < LB_R || B % LB_R) return NF_ENOTSUP;
+    if (!g || !x || !Wd || !gx || !dWd || !db || !scratch) return NF_EFAULT;
+    if (((uintptr_t)g | (uintptr_t)x | (uintptr_t)gx) & 15) return NF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = lb_grid(B);
+    LuBwdCArgs a;
+    a.g = (const float *)g; a.x = (const float *)x; a.Wd = (const float *)Wd; a.gx = (float *)gx; a.part = (float *)scratch; a.B = B;
+    const size_t lds = (size_t)4 * LB_TILE * sizeof(float);
+    static LdsOptIn opted = {};
+    if (opt_in_lds(reinterpret_cast<const void *>(&lu_bwd_c_kernel), lds, opted) != NF_OK) return NF_ENOTSUP;
+    hipLaunchKernelGGL(lu_bwd_c_kernel, dim3(grid), dim3(256), lds, st, a);
+    NF_CHECK_LAUNCH();
+    return wgrad_reduce_launch(a.part, (float *)dWd, (float *)db, (int64_t)LB_D * LB_D, LB_D, grid, LB_D, 1, 0, 0, 0, nullptr, 0, st);
+}
+
+// (g_lower, g_upper, g_udiag) of LULinearPermute from the composed matrix's gradient dWd (nf_lu_bwd_composed), the dense factors
+// Lm, Um (nf_lu_factors[_multi]: out, out + D * D), the permutation and the (B) log-det cotangent gld (summed here; may be NULL).
+extern "C" int nf_lu_param_grads_composed(const void *dWd, const void *Lm, const void *Um, const int64_t *perm, const void *gld,
+                                          int64_t B, const void *unconstrained_upper_diag, double eps, void *g_lower, void *g_upper,
+                                          void *g_udiag, int D, nf_stream_t stream) {
+    using namespace nf;
+    if (D != LB_D) return NF_ENOTSUP;
+    if (!dWd || !Lm || !Um || !perm || !unconstrained_upper_diag || !g_lower || !g_upper || !g_udiag) return NF_EFAULT;
+    hipLaunchKernelGGL(lu_c_param_grads_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float *)dWd, (const float *)Lm,
+                       (const float *)Um, perm, (const float *)gld, gld ? B : 0, (const float *)unconstrained_upper_diag, (float)eps,
+                       (float *)g_lower, (float *)g_upper, (float *)g_udiag);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

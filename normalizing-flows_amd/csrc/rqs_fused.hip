@@ -245,6 +245,65 @@ pack_lu_kernel(const int64_t *__restrict__ perm, const float *__restrict__ lower
     }
 }
 
+// Training (round 6): the density-direction half of pack_lu_kernel for n layers in ONE launch (blockIdx.x = layer), once per step:
+// the composed matrix W_d = (L U) with permuted columns as the LU stage of each layer's TRAINING blob (the whole-layer forward
+// rqs_fused_kernel<0, true, 2> runs the LU in front of the coupling like inference does), its bias, the constant log|det| in the
+// header -- and W_d row-major (64 x 64) for the backward (nf_lu_bwd_composed: gx = g W_d, dW_d = g^T x).
+// table: n rows of 7 device pointers: perm, lower_entries, upper_entries, unconstrained_upper_diag, bias, blob, wd_out.
+__global__ void __launch_bounds__(256)
+pack_lu_train_multi_kernel(const void *const *__restrict__ table, float eps, int nblk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lu_raw[];
+    constexpr int D = F_D, N = F_D * F_D;
+    double *A = reinterpret_cast<double *>(lu_raw), *Bm = A + N, *Cm = Bm + N;
+    int *inv = reinterpret_cast<int *>(Cm + N);
+    __shared__ float sred[16];
+    const void *const *row = table + (size_t)blockIdx.x * 7;
+    const int64_t *perm = (const int64_t *)row[0];
+    const float *lower_entries = (const float *)row[1], *upper_entries = (const float *)row[2], *udiag_raw = (const float *)row[3],
+                *bias = (const float *)row[4];
+    float *blob = (float *)row[5], *wd = (float *)row[6];
+    FusedLayout lay;
+    lay.nblk = nblk;
+    float *stage_d = blob + lay.off_stages() + (size_t)lay.lu_stage(0) * F_STAGE, *bias_d = blob + F_HDR + lay.off_bias_lu(0);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N; i += 256) {
+        const int r = i / D, c = i - r * D;
+        double l = 0.0, u = 0.0;
+        if (c < r) l = (double)lower_entries[r * (r - 1) / 2 + c];
+        else if (c == r) { l = 1.0; u = (double)(softplus(udiag_raw[r]) + eps); }
+        else u = (double)upper_entries[r * (D - 1) - r * (r - 1) / 2 + (c - r - 1)];
+        A[i] = l;
+        Bm[i] = u;
+    }
+    for (int i = tid; i < D; i += 256) inv[(int)perm[i]] = i;
+    float part = 0.0f;
+    for (int i = tid; i < D; i += 256) part += logf(softplus(udiag_raw[i]) + eps);  // mixing.py:514-532
+    const float lad = block_sum(part, sred);
+    __syncthreads();
+    for (int i = tid; i < N; i += 256) {       // C = L U (fp64)
+        const int r = i / D, c = i - r * D;
+        double a = 0.0;
+        for (int k = 0; k <= (r < c ? r : c); ++k) a += A[r * D + k] * Bm[k * D + c];
+        Cm[i] = a;
+    }
+    __syncthreads();
+    for (int i = tid; i < F_STAGE; i += 256) {
+        const int r4 = i & 3, lane = (i >> 2) & 63, sg = (i >> 8) & 7, m = i >> 11;
+        const int rr = lu_out_col(m, lane & 31), k = lu_in_col(sg, lane >> 5, r4);
+        stage_d[i] = (float)Cm[rr * D + inv[k]];  // W_d[row][k] = (LU)[row][perm^-1[k]]
+    }
+    for (int i = tid; i < N; i += 256) {
+        const int r = i / D, k = i - r * D;
+        wd[i] = (float)Cm[r * D + inv[k]];
+    }
+    for (int i = tid; i < 64; i += 256) {
+        const int reg = i & 15, hh = (i >> 4) & 1, m = i >> 5;
+        bias_d[i] = bias[lu_out_col(m, 8 * (reg >> 2) + 4 * hh + (reg & 3))];
+    }
+    __syncthreads();                              // (orders this block's header words behind pack_all's: same stream, earlier launch)
+    if (tid == 0) { blob[2] = 1.0f; blob[3] = lad; }
+}
+
 // ---- the fused layer kernel -----------------------------------------------------------------------------------
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -349,6 +408,9 @@ struct FlowArgs {
 // initial layer / blocks, the final layer + spline run as in inference, and the conditioner output is written for the
 // backward in the lane's own order: cond_out[row][transform feature][24] (23 parameters + 1 pad, raw scale), six 16-byte
 // stores per feature.  Replaces a library GEMM that materialises 193 MB plus the stand-alone spline kernel that reads them back.
+// TRAIN = 2 with LU (round 6): the layer's LULinearPermute.inverse runs in the same launch in front of the coupling, as in inference
+// (one dense 64 x 64 product, composed per step by nf_lu_pack_train_multi); its output -- the coupling's input, which the backward
+// needs (spline, initial layer's weight gradient) -- is written to xlu_out (B x 64) from the LDS stash.
 // TRAIN = 2: the WHOLE conditioner + transform as in inference (initial layer, residual blocks, final layer, spline) and, for
 // the backward, every intermediate written on the way: act_out[t] (B x 128), t = 0: h0 (initial layer's output), then per
 // block its pre-activation t and its output h (2 nblk + 1 tensors), rows through the wave's LDS transpose tile; cond_out as
@@ -357,10 +419,12 @@ template <int DIR, bool LU, int TRAIN = 0, int KB = F_K, int HB = 4>
 __global__ void __launch_bounds__(F_THREADS, 2)
 rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ logdet, FlowArgs fa,
                  int64_t B, int nblk, RqsParams<float> p, int acc, const float *__restrict__ h_in = nullptr,
-                 float *__restrict__ cond_out = nullptr, float unscale = 1.0f, float *__restrict__ act_out = nullptr) {
+                 float *__restrict__ cond_out = nullptr, float unscale = 1.0f, float *__restrict__ act_out = nullptr,
+                 float *__restrict__ xlu_out = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     static_assert(KB == 4 || KB == 8 || KB == 16, "bins");
-    static_assert(!TRAIN || (KB == F_K && !LU && DIR == 0), "the training variants: 8 bins, density direction, no fused LU");
+    static_assert(!TRAIN || (KB == F_K && DIR == 0 && (!LU || TRAIN == 2)),
+                  "the training variants: 8 bins, density direction; the fused LU only with the whole-layer forward (TRAIN = 2)");
     static_assert(HB == 4 || ((HB == 2 || HB == 1) && !TRAIN), "hidden row-blocks");
     constexpr int MP = 3 * KB, FPL = 16 / KB, GQ = KB / 4, TABW = 3 * (KB + 1);   // slots per feature, features per lane-half and
                                                                                  // group, groups per 16-column chunk, table row
@@ -567,6 +631,26 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
             }
         }
     };
+    // TRAIN = 2 with the fused LU: the coupling's input rows (the LU's output, in the stash since the LU stage) for the backward;
+    // issued behind a stage's barrier + DMA request like store_act (the stash rows are not modified before the final layer's groups)
+    auto store_xlu = [&]() {
+        if constexpr (TRAIN == 2 && LU) {
+            if (valid) {
+#pragma unroll
+                for (int Q = 0; Q < 4; ++Q) {
+                    f32x4 a, b;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        a[c] = st[(8 * Q + c) * 64];
+                        b[c] = st[(8 * Q + 4 + c) * 64];
+                    }
+                    float *dst = xlu_out + row * F_D + 16 * Q + 8 * hh;
+                    NF_TRAIN_STORE(reinterpret_cast<f32x4 *>(dst), a);
+                    NF_TRAIN_STORE(reinterpret_cast<f32x4 *>(dst + 4), b);
+                }
+            }
+        }
+    };
     if constexpr (TRAIN == 1) {
         // h2 from HBM in C-register order: register 4 q + r of block m = unit 32 m + 8 q + 4 hh + r of the lane's row
         const float *hr = h_in + (valid ? row : 0) * F_H + 4 * hh;
@@ -611,6 +695,7 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
         }
         {
             const float *buf = acquire();
+            if (blk == 0) store_xlu();
             store_act(2 * blk, H0, H1, H2, H3);         // the block's input (blk = 0: the initial layer's output)
             mm128<true, HB>(buf, lane, T0, H0, H1, H2, H3);
         }
@@ -767,7 +852,10 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
             // behind group g - 1's 14 parameter stores (training); group 0: the last residual block's output goes out here
             const float *buf = acquire(g > 0 ? 14 : 0);
 #ifndef NF_EXP_RELU_PER_USE
-            if (g == 0) store_act(2 * nblk, H0, H1, H2, H3);
+            if (g == 0) {
+                if (nblk == 0) store_xlu();
+                store_act(2 * nblk, H0, H1, H2, H3);
+            }
 #endif
             mm128<false, HB>(buf, lane, A0, H0, H1, H2, H3);
         }
@@ -1068,6 +1156,56 @@ extern "C" int nf_rqs_fused_train_full_fwd(const void *x, void *y, void *logdet,
     hipLaunchKernelGGL((rqs_fused_kernel<0, false, 2>), dim3(grid), dim3(F_THREADS), lds, (hipStream_t)stream, (const float *)x,
                        (float *)y, (float *)logdet, fa, B, num_blocks, p, acc, (const float *)nullptr, (float *)cond_out,
                        (float)(sqrt((double)hidden) / 1.4426950408889634), (float *)act_out);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// Whole-layer training forward WITH the layer's LULinearPermute.inverse in front of the coupling (round 6): the launch of
+// nf_rqs_fused_train_full_fwd plus one LU stage; xlu_out (B, 64) = the LU's output = the coupling's input (the backward's `x`).
+// wpack: nf_rqs_fused_pack_all[_multi] then nf_lu_pack_train_multi (LU stage, bias, log|det| in the header).
+extern "C" int nf_rqs_fused_train_pair_fwd(const void *x, void *xlu_out, void *y, void *logdet, void *cond_out, void *act_out,
+                                           const void *wpack, int mask_parity, int64_t B, int D, int hidden, int num_blocks, int K,
+                                           double tail_bound, double min_bin_width, double min_bin_height, double min_derivative,
+                                           int acc, nf_stream_t stream) {
+    if (D != F_D || hidden != F_H || K != F_K || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
+    if (B < 0 || (mask_parity != 0 && mask_parity != 1) || acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!x || !xlu_out || !y || !logdet || !cond_out || !act_out || !wpack) return NF_EFAULT;
+    FlowArgs fa;
+    fa.parity = mask_parity ? 1ull : 0ull;
+    fa.nlayers = 1;
+    fa.ngroups = F_K;
+    for (int l = 0; l < F_MAX_LAYERS; ++l) fa.blob[l] = nullptr;
+    fa.blob[0] = (const float *)wpack;
+    FusedLayout lay;
+    lay.nblk = num_blocks;
+    auto p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
+                                    min_derivative, sqrt((double)hidden));
+    const size_t lds = (size_t)(2 * F_STAGE + F_NW * 32 * 64 + lay.small_padded() + F_NW * 1536) * sizeof(float);
+    if (lds > 160 * 1024) return NF_ENOTSUP;
+    static LdsOptIn opted = {};
+    if (opt_in_lds(reinterpret_cast<const void *>(&rqs_fused_kernel<0, true, 2>), lds, opted) != NF_OK) return NF_ENOTSUP;
+    const int grid = (int)((B + F_ROWS - 1) / F_ROWS);
+    hipLaunchKernelGGL((rqs_fused_kernel<0, true, 2>), dim3(grid), dim3(F_THREADS), lds, (hipStream_t)stream, (const float *)x,
+                       (float *)y, (float *)logdet, fa, B, num_blocks, p, acc, (const float *)nullptr, (float *)cond_out,
+                       (float)(sqrt((double)hidden) / 1.4426950408889634), (float *)act_out, (float *)xlu_out);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// The LU stage of n training blobs in one launch (once per step, behind nf_rqs_fused_pack_all_multi).  table (device): n rows of
+// 7 pointers perm (int64), lower_entries, upper_entries, unconstrained_upper_diag, bias, wpack, wd_out (64 x 64 floats: W_d
+// row-major, y = W_d x + bias, for nf_lu_bwd_composed).  D = 64, 8 bins.
+extern "C" int nf_lu_pack_train_multi(const void *table, int n_layers, int num_blocks, int D, double eps, nf_stream_t stream) {
+    if (D != F_D || num_blocks < 0 || num_blocks > 16) return NF_ENOTSUP;
+    if (n_layers < 0 || n_layers > 65535) return NF_EINVAL;
+    if (n_layers == 0) return NF_OK;
+    if (!table) return NF_EFAULT;
+    const size_t lds = (size_t)3 * F_D * F_D * sizeof(double) + F_D * sizeof(int) + 64;
+    static LdsOptIn opted = {};
+    if (opt_in_lds(reinterpret_cast<const void *>(&pack_lu_train_multi_kernel), lds, opted) != NF_OK) return NF_ENOTSUP;
+    hipLaunchKernelGGL(pack_lu_train_multi_kernel, dim3(n_layers), dim3(256), lds, (hipStream_t)stream, (const void *const *)table,
+                       (float)eps, num_blocks);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

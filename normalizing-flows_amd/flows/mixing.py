@@ -399,6 +399,15 @@ class LULinearPermute(Flow):
             buf = self.__dict__["_lu_fbuf"] = torch.empty(5 * D * D + D + 1, dtype=torch.float32, device=device)
         return buf
 
+    def _wd_buffer(self, device):
+        """(D, D) floats owned by the layer: the composed density-direction matrix W_d the per-step pair pack (_prepack.py,
+        nf_lu_pack_train_multi) leaves for the backward (nf_lu_bwd_composed)."""
+        buf = self.__dict__.get("_lu_wd")
+        D = self.linear.features
+        if buf is None or buf.device != device:
+            buf = self.__dict__["_lu_wd"] = torch.empty(D, D, dtype=torch.float32, device=device)
+        return buf
+
     def forward(self, z, context=None):
         return self._apply_kernel(z, False)
 

@@ -790,6 +790,26 @@ class CoupledRationalQuadraticSpline(Flow):
         # beyond the benchmark kernel's shapes: nf_nsf_wide with the LU layer's dense matrix in the same launch
         return p.features <= 128 and lu.use_dense and p._wide_pack(z, None) is not None
 
+    def _run_pair_train(self, z, lu, ld, acc):
+        """The pair's density direction under autograd as autograd.PairTrainFn (round 6); the caller (core._run_chain_impl) has
+        checked _prepack.take_pair: every image the kernels read was written by this step's multi-layer packs."""
+        from ..autograd import PairTrainFn
+        p = self.prqct
+        net, u, lin = p.transform_net, p.unconditional_transform, lu.linear
+        z = z.contiguous()
+        wfull, wpad, col_map, wfull_t = p._train_buffers(z)
+        fkw = dict(tail_bound=float(p.tail_bound), min_bin_width=p.min_bin_width, min_bin_height=p.min_bin_height,
+                   min_derivative=p.min_derivative, wh_div=p._wh_div(), col_map=col_map, prepacked=True,
+                   holder=p.__dict__.setdefault("_img_holder", {}))
+        blk = [q for b in net.blocks for l in b.linear_layers for q in (l.weight, l.bias)]
+        y, _ = PairTrainFn.apply(z, lu.permutation._permutation, lin.lower_entries, lin.upper_entries, lin.unconstrained_upper_diag,
+                                 lin.bias, lin.eps, lu._factors_buffer(z.device), lu._wd_buffer(z.device), net.initial_layer.weight,
+                                 net.initial_layer.bias, net.final_layer.weight, net.final_layer.bias, u.unnormalized_widths,
+                                 u.unnormalized_heights, u.unnormalized_derivatives, p.identity_features, p.transform_features,
+                                 p._train_blob_for(z), p._fused_parity, fkw, wfull_t, wpad, ld, 1 if (acc is None or acc > 0) else -1,
+                                 *blk)
+        return y
+
     def _run_pair(self, z, lu, inverse, ld, acc):
         p = self.prqct
         if p.use_fused and p._fused_eligible(z, None):

@@ -726,6 +726,78 @@ def final_bwd(x, grad_y, grad_logdet, cond24, w_t, blob, uw, uh, ud, mask_parity
     return gx, gcond, gh, guw, guh, gud
 
 
+def lu_pack_train_multi(table, n_layers, num_blocks, eps, D=64):
+    """The LU stage of n training blobs + the composed matrices for the backward in one launch (nf_lu_pack_train_multi)."""
+    L.check(L.lib().nf_lu_pack_train_multi(ptr(table), i32(n_layers), i32(num_blocks), i32(D), f64(eps), L.stream()),
+            "nf_lu_pack_train_multi")
+
+
+def rqs_fused_train_pair_fwd(x, blob, mask_parity, num_blocks, tail_bound=3.0, min_bin_width=1e-3, min_bin_height=1e-3,
+                             min_derivative=1e-3, logdet=None, acc=None):
+    """(xlu, y, logdet, cond24, acts) of nf_rqs_fused_train_pair_fwd: LULinearPermute.inverse + the whole coupling layer in one
+    launch; xlu (B, 64) = the LU's output (the coupling's input), the rest as rqs_fused_train_full_fwd."""
+    L.require_device(x, blob)
+    x = x.contiguous()
+    B = x.shape[0]
+    y, xlu = torch.empty_like(x), torch.empty_like(x)
+    if logdet is None:
+        ld, acc = torch.empty(B, dtype=x.dtype, device=x.device), L.LD_WRITE
+    else:
+        ld, acc = logdet, (L.LD_ADD if acc is None else acc)
+    cond = torch.empty(B, 32, 24, dtype=x.dtype, device=x.device)
+    acts = torch.empty(2 * num_blocks + 1, B, 128, dtype=x.dtype, device=x.device)
+    rc = L.lib().nf_rqs_fused_train_pair_fwd(ptr(x), ptr(xlu), ptr(y), ptr(ld), ptr(cond), ptr(acts), ptr(blob), i32(mask_parity),
+                                             i64(B), i32(64), i32(128), i32(num_blocks), i32(8), f64(tail_bound), f64(min_bin_width),
+                                             f64(min_bin_height), f64(min_derivative), i32(acc), L.stream())
+    L.check(rc, "nf_rqs_fused_train_pair_fwd")
+    return xlu, y, ld, cond, acts
+
+
+def lu_bwd_composed(g, x, Wd, db_out=None):
+    """(gx, dWd, db) of the composed LULinearPermute's backward, D = 64 (nf_lu_bwd_composed): gx = g Wd, dWd = g^T x, db = colsum(g)."""
+    L.require_device(g, x, Wd, db_out)
+    g, x, Wd = g.contiguous(), x.contiguous(), Wd.contiguous()
+    B, D = g.shape
+    lib = L.lib()
+    lib.nf_lu_bwd_composed_scratch_floats.restype = C.c_int64
+    n = int(lib.nf_lu_bwd_composed_scratch_floats(i64(B)))
+    if n <= 0 or D != 64 or g.dtype != torch.float32:
+        raise NotImplementedError("lu_bwd_composed: float32, D = 64, batch a multiple of 64")
+    scratch = torch.empty(n, dtype=torch.float32, device=g.device)
+    dWd = torch.empty(D, D, dtype=torch.float32, device=g.device)
+    if db_out is None:
+        db_out = torch.empty(D, dtype=torch.float32, device=g.device)
+    elif db_out.numel() != D or db_out.dtype != torch.float32 or not db_out.is_contiguous():
+        raise ValueError("lu_bwd_composed: db_out = a contiguous float32 (D) tensor")
+    gx = torch.empty_like(g)
+    rc = lib.nf_lu_bwd_composed(ptr(g), ptr(x), ptr(Wd), ptr(gx), ptr(dWd), ptr(db_out), ptr(scratch), i64(B), i32(D), L.stream())
+    L.check(rc, "nf_lu_bwd_composed")
+    return gx, dWd, db_out
+
+
+def lu_param_grads_composed(dWd, Lm, Um, perm, gld, unconstrained_upper_diag, n_tri, eps=1e-3, out=None):
+    """(g_lower, g_upper, g_udiag) from the composed matrix's gradient (nf_lu_param_grads_composed); out: destinations."""
+    L.require_device(dWd, Lm, Um, perm, gld, unconstrained_upper_diag)
+    D = unconstrained_upper_diag.numel()
+    dev = dWd.device
+    if gld is not None:
+        gld = gld.contiguous()
+    if out is not None:
+        g_lower, g_upper, g_udiag = out
+        if (g_lower.numel() != n_tri or g_upper.numel() != n_tri or g_udiag.numel() != D
+                or any(t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev for t in out)):
+            raise ValueError("lu_param_grads_composed: out = contiguous float32 (n_tri), (n_tri), (D) tensors")
+    else:
+        g_lower = torch.empty(n_tri, dtype=torch.float32, device=dev)
+        g_upper = torch.empty(n_tri, dtype=torch.float32, device=dev)
+        g_udiag = torch.empty(D, dtype=torch.float32, device=dev)
+    rc = L.lib().nf_lu_param_grads_composed(ptr(dWd.contiguous()), ptr(Lm.contiguous()), ptr(Um.contiguous()), ptr(perm), ptr(gld),
+                                            i64(0 if gld is None else gld.numel()), ptr(unconstrained_upper_diag.contiguous()),
+                                            f64(eps), ptr(g_lower), ptr(g_upper), ptr(g_udiag), i32(D), L.stream())
+    L.check(rc, "nf_lu_param_grads_composed")
+    return g_lower, g_upper, g_udiag
+
+
 def coupling_train_bwd(x, grad_y, grad_logdet, cond24, acts, w_t, blob, wfull_t, w_blocks, uw, uh, ud, col_map, n_cols, mask_parity,
                        num_blocks, dest, tail_bound=3.0, min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3):
     """The whole backward of a benchmark-shaped coupling layer in one C-ABI call (nf_coupling_train_bwd): four passes over the rows

@@ -714,10 +714,11 @@ def test_fused_kernels_have_no_register_spills(nfa):
                 # scalar registers: none spilled in the benchmark's instantiations (8 bins, 128 hidden units) of the exact-fp32
                 # kernel; the other instantiations and the split-bf16 chain (64 blob pointers + the layer loop's scalars) may
                 # park a few in VGPR lanes (v_writelane: registers, not memory; 5 in the 16-bin / 32-unit one since round 3)
-                strict = "x3" not in tag and "Li8ELi4EE" in name
+                # (round 6: the whole-layer training forward with the fused LU, <0, true, 2>, parks 2)
+                strict = "x3" not in tag and "Li8ELi4EE" in name and "ILi0ELb1ELi2E" not in name
                 assert d["sgpr_spill_count"] <= (0 if strict else 6), (name, d)
                 assert d["vgpr_count"] <= 256
-    assert seen == 42, seen    # exact fp32: 4 x {4, 8, 16 bins} x {128, 64, 32 hidden units} + the two training variants; 4 split-bf16
+    assert seen == 43, seen    # exact fp32: 4 x {4, 8, 16 bins} x {128, 64, 32 hidden units} + the three training variants; 4 split-bf16
 
 
 def test_one_pass_backward_kernels_use_no_scratch(nfa):
@@ -727,12 +728,12 @@ def test_one_pass_backward_kernels_use_no_scratch(nfa):
     import kernel_resources as kr
     objdir = os.path.join(ROOT, "normalizing-flows_amd", "lib", "obj")
     seen = 0
-    for obj, tag in (("resblock_bwd.o", "resblock_bwd_kernel"), ("lu_bwd.o", "lu_bwd_kernel")):
+    for obj, tag in (("resblock_bwd.o", "resblock_bwd_kernel"), ("lu_bwd.o", "lu_bwd_kernel"), ("lu_bwd.o", "lu_bwd_c_kernel")):
         for name, d in kr.resources(os.path.join(objdir, obj)).items():
             if tag in name:
                 seen += 1
                 assert d["vgpr_spill_count"] == 0 and d["private_segment_fixed_size"] == 0, (name, d)
-    assert seen == 3, seen
+    assert seen == 4, seen
 
 
 

@@ -26,6 +26,7 @@ ap.add_argument("--no-prepack", action="store_true", help="ablation: every layer
 ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the default foreach implementation")
 ap.add_argument("--flat", action="store_true", help="round 6: dp.FlatParameters -- parameters as views of one flat tensor, gradients written into one "
                 "flat buffer by the kernels, Adam(fused) on ONE tensor")
+ap.add_argument("--no-pair", action="store_true", help="ablation: LULinearPermuteFn + CouplingTrainFn instead of the fused pair (round 6)")
 ap.add_argument("--no-onecall", action="store_true", help="ablation: the layer's backward kernel by kernel with one reduction launch each (rounds 3-5)")
 a = ap.parse_args()
 if a.no_train_full:
@@ -52,6 +53,9 @@ if a.no_wgrad_pair:
 if a.no_onecall:
     import normflows_amd
     normflows_amd.config.set_train_bwd_onecall(False)
+if a.no_pair:
+    import normflows_amd
+    normflows_amd.config.set_train_pair(False)
 dev = torch.device("cuda:0")
 m = build_c2_model().to(dev)
 x = c2_inputs(a.batch).to(dev)
