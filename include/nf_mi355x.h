@@ -444,6 +444,23 @@ int nf_lu_bwd_composed(const void *g, const void *x, const void *Wd, void *gx, v
 int nf_lu_param_grads_composed(const void *dWd, const void *Lm, const void *Um, const int64_t *perm, const void *gld, int64_t B,
                                const void *unconstrained_upper_diag, double eps, void *g_lower, void *g_upper, void *g_udiag, int D,
                                nf_stream_t stream);
+/* The pass of nf_lu_bwd_composed without its reduction (partial tiles [nf_lu_bwd_composed_grid(B)][64 * 64 + 64] stay in scratch), and
+ * the whole backward of a [CoupledRQS, LULinearPermute] pair behind ONE call (autograd.PairTrainFn): nf_coupling_train_bwd's four
+ * passes on the coupling (x = xlu, the LU's output saved by nf_rqs_fused_train_pair_fwd), nf_lu_bwd_composed_partials on its input
+ * gradient, one reduction launch for the partial tiles of BOTH layers, nf_lu_param_grads_composed: seven launches.  Arguments as
+ * the two calls it replaces; grad_x_in (B, 64) = the pair's input gradient; scratch: nf_pair_train_bwd_scratch_floats(B, num_blocks). */
+int nf_lu_bwd_composed_grid(int64_t B);
+int nf_lu_bwd_composed_partials(const void *g, const void *x, const void *Wd, void *gx, void *scratch, int64_t B, int D,
+                                nf_stream_t stream);
+int64_t nf_pair_train_bwd_scratch_floats(int64_t B, int num_blocks);
+int nf_pair_train_bwd(const void *x_in, const void *xlu, const void *grad_y, const void *grad_logdet, const void *cond24,
+                      const void *acts, const void *w_t, const void *wpack, const void *wfull_t, const void *const *w_blocks,
+                      const void *uw, const void *uh, const void *ud, const void *col_map, int n_cols, const void *Wd, const void *Lm,
+                      const void *Um, const int64_t *perm, const void *unconstrained_upper_diag, double lu_eps, void *grad_x_in,
+                      void *g_lower, void *g_upper, void *g_udiag, void *g_lbias, void *g_w0, void *g_b0, void *g_wf, void *g_bf,
+                      void *g_uw, void *g_uh, void *g_ud, void *const *g_blocks, void *scratch, int mask_parity, int64_t B, int D,
+                      int hidden, int num_blocks, int K, double tail_bound, double min_bin_width, double min_bin_height,
+                      double min_derivative, nf_stream_t stream);
 int64_t nf_resblock_bwd_scratch_floats(int64_t B, int with_init);
 int nf_resblock_bwd(const void *gh, const void *t, const void *h_in, const void *W1, const void *W2, void *gh_in, void *dW1,
                     void *db1, void *dW2, void *db2, const void *x, const void *wfull, void *gx, void *dW0, void *db0,

@@ -549,15 +549,15 @@ class PairTrainFn(torch.autograd.Function):
         b0, bf, lbias = ctx.biases
         lu_eps, lu_fbuf, lu_wd = ctx.lu
         dest = dict(w0=_gradbuf.out(w0), b0=_gradbuf.out(b0), wf=_gradbuf.out(wf), bf=_gradbuf.out(bf), uw=_gradbuf.out(uw),
-                    uh=_gradbuf.out(uh), ud=_gradbuf.out(ud), blocks=[_gradbuf.out(p_) for p_ in blk])
-        g = ops.coupling_train_bwd(xlu, gy, gld_own, cond24, acts, ctx.wpad, ctx.blob, ctx.wfull,
-                                   [blk[4 * b + j].detach() for b in range(nb) for j in (0, 2)], uw.detach(), uh.detach(),
-                                   ud.detach(), kw["col_map"], iidx.numel(), ctx.parity, nb, dest, **fk)
-        gx, dWd, g_lbias = ops.lu_bwd_composed(g, x, lu_wd, db_out=_gradbuf.out(lbias))
+                    uh=_gradbuf.out(uh), ud=_gradbuf.out(ud), blocks=[_gradbuf.out(p_) for p_ in blk], lower=_gradbuf.out(lower),
+                    upper=_gradbuf.out(upper), udiag=_gradbuf.out(udiag), lbias=_gradbuf.out(lbias))
         D = x.shape[1]
         Lm, Um = lu_fbuf[:D * D].view(D, D), lu_fbuf[D * D:2 * D * D].view(D, D)
-        g_lower, g_upper, g_udiag = ops.lu_param_grads_composed(dWd, Lm, Um, perm, gld_own, udiag.detach(), lower.numel(), eps=lu_eps,
-                                                                out=(_gradbuf.out(lower), _gradbuf.out(upper), _gradbuf.out(udiag)))
+        # ONE C-ABI call, seven launches: the coupling's four passes, the composed LU's pass, one reduction for both, the LU's factors
+        gx = ops.pair_train_bwd(x, xlu, gy, gld_own, cond24, acts, ctx.wpad, ctx.blob, ctx.wfull,
+                                [blk[4 * b + j].detach() for b in range(nb) for j in (0, 2)], uw.detach(), uh.detach(), ud.detach(),
+                                kw["col_map"], iidx.numel(), ctx.parity, nb, lu_wd, Lm, Um, perm, udiag.detach(), lu_eps, dest, **fk)
+        g_lower, g_upper, g_udiag, g_lbias = dest["lower"], dest["upper"], dest["udiag"], dest["lbias"]
         return (gx, None, g_lower, g_upper, g_udiag, g_lbias, None, None, None, dest["w0"], dest["b0"], dest["wf"], dest["bf"],
                 dest["uw"], dest["uh"], dest["ud"], None, None, None, None, None, None, None, (gld if ctx.has_acc else None), None,
                 *dest["blocks"])

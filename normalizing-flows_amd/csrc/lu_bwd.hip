@@ -249,9 +249,13 @@ lu_bwd_c_kernel(LuBwdCArgs a) {
 
 // dW_d (reduced) -> the packed parameter gradients of LULinearPermute (mixing.py:402-473 under autograd): W_d[:, perm[j]] =
 // (L U)[:, j], so dM[r][j] = dW_d[r][perm[j]];  dL = dM U^T (strictly lower part -> g_lower), dU = L^T dM (strictly upper part ->
-// g_upper; diagonal + gl_sum / diag through softplus' -> g_udiag), gl_sum = sum of the (B) log-det cotangent.  One workgroup:
-// L, U, dM in LDS, one 64-term dot product per entry.  Lm / Um: the dense factors nf_lu_factors[_multi] assembled this step.
-__global__ void __launch_bounds__(1024)
+// g_upper; diagonal + gl_sum / diag through softplus' -> g_udiag), gl_sum = sum of the (B) log-det cotangent.
+// 16 workgroups x 256 threads, one output entry per thread (row r = 4 w + tid / 64, column c = tid % 64): L, U, dM in LDS (pitch 65:
+// the column walks are conflict-free), BOTH 64-term dot products of an entry evaluated over the full k range without a branch -- the
+// triangular zeros of L and U do the masking -- so the LDS reads pipeline (the first version walked the triangular ranges in
+// divergent, latency-bound loops in ONE workgroup: 29 us per layer).  Lm / Um: the dense factors nf_lu_factors[_multi] assembled
+// this step.
+__global__ void __launch_bounds__(256)
 lu_c_param_grads_kernel(const float *__restrict__ dWd, const float *__restrict__ Lm, const float *__restrict__ Um,
                         const int64_t *__restrict__ perm, const float *__restrict__ gld, int64_t B,
                         const float *__restrict__ udiag_raw, float eps, float *__restrict__ g_lower, float *__restrict__ g_upper,
@@ -260,41 +264,43 @@ lu_c_param_grads_kernel(const float *__restrict__ dWd, const float *__restrict__
     __shared__ float Ls[D * P], Us[D * P], Ms[D * P];
     __shared__ float sred[16];
     const int tid = threadIdx.x;
+    const int r = 4 * blockIdx.x + (tid >> 6), c = tid & 63;
     float gl = 0.0f;
+    // (every workgroup owns four diagonal entries, so every one of them sums the cotangent -- in the same order: the same value)
     if (gld) {
         float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
         const int64_t B4 = (reinterpret_cast<uintptr_t>(gld) & 15) == 0 ? B / 4 : 0;
         const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gld);
 #pragma unroll 8
-        for (int64_t b = tid; b < B4; b += 1024) {
+        for (int64_t b = tid; b < B4; b += 256) {
             const f32x4 v = g4[b];
             p0 += v[0]; p1 += v[1]; p2 += v[2]; p3 += v[3];
         }
-        for (int64_t b = 4 * B4 + tid; b < B; b += 1024) p0 += gld[b];
+        for (int64_t b = 4 * B4 + tid; b < B; b += 256) p0 += gld[b];
         gl = block_sum((p0 + p1) + (p2 + p3), sred);
     }
-    for (int i = tid; i < N; i += 1024) {
-        const int r = i / D, c = i - r * D;
-        Ls[r * P + c] = Lm[i];
-        Us[r * P + c] = Um[i];
-        Ms[r * P + c] = dWd[r * D + (int)perm[c]];
+    for (int i = tid; i < N; i += 256) {
+        const int rr = i / D, cc = i - rr * D;
+        Ls[rr * P + cc] = Lm[i];
+        Us[rr * P + cc] = Um[i];
+        Ms[rr * P + cc] = dWd[rr * D + (int)perm[cc]];
     }
     __syncthreads();
-    for (int i = tid; i < N; i += 1024) {
-        const int r = i / D, c = i - r * D;
-        if (c < r) {            // dL[r][c] = sum_k dM[r][k] U[c][k]   (U upper triangular: k >= c)
-            float s = 0.0f;
-            for (int k = c; k < D; ++k) s = fmaf(Ms[r * P + k], Us[c * P + k], s);
-            g_lower[r * (r - 1) / 2 + c] = s;
-        } else {                // dU[r][c] = sum_k L[k][r] dM[k][c]   (L unit lower triangular: k >= r)
-            float s = Ms[r * P + c];
-            for (int k = r + 1; k < D; ++k) s = fmaf(Ls[k * P + r], Ms[k * P + c], s);
-            if (c > r) g_upper[r * (D - 1) - r * (r - 1) / 2 + (c - r - 1)] = s;
-            else {
-                const float u = udiag_raw[r], d = softplus(u) + eps;
-                g_udiag[r] = (s + gl / d) * (u > 20.0f ? 1.0f : sigmoid(u));
-            }
-        }
+    // dL[r][c] = sum_k dM[r][k] U[c][k] (U[c][k] = 0 for k < c);  dU[r][c] = sum_k L[k][r] dM[k][c] (L[k][r] = 0 for k < r, 1 at k = r)
+    float sl0 = 0.0f, sl1 = 0.0f, su0 = 0.0f, su1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < D; k += 2) {
+        sl0 = fmaf(Ms[r * P + k], Us[c * P + k], sl0);
+        sl1 = fmaf(Ms[r * P + k + 1], Us[c * P + k + 1], sl1);
+        su0 = fmaf(Ls[k * P + r], Ms[k * P + c], su0);
+        su1 = fmaf(Ls[(k + 1) * P + r], Ms[(k + 1) * P + c], su1);
+    }
+    const float sl = sl0 + sl1, su = su0 + su1;
+    if (c < r) g_lower[r * (r - 1) / 2 + c] = sl;
+    else if (c > r) g_upper[r * (D - 1) - r * (r - 1) / 2 + (c - r - 1)] = su;
+    else {
+        const float u = udiag_raw[r], d = softplus(u) + eps;
+        g_udiag[r] = (su + gl / d) * (u > 20.0f ? 1.0f : sigmoid(u));
     }
 }
 
@@ -453,22 +459,37 @@ extern "C" int64_t nf_lu_bwd_composed_scratch_floats(int64_t B) {
 // Backward of the composed LULinearPermute (density direction; the layer as the fused training forward evaluates it: y = W_d x + b),
 // D = 64, one pass over the rows: gx (B, 64) = g W_d, dWd (64, 64) = g^T x, db (64) = colsum(g); W_d (64, 64) row-major from
 // nf_lu_pack_train_multi.  B a multiple of 64; scratch: nf_lu_bwd_composed_scratch_floats(B).  Deterministic.
-extern "C" int nf_lu_bwd_composed(const void *g, const void *x, const void *Wd, void *gx, void *dWd, void *db, void *scratch, int64_t B,
-                                  int D, nf_stream_t stream) {
+// ... the pass over the rows alone: partial tiles [nf_lu_bwd_composed_grid(B)][64 * 64 + 64] (dW_d then the column sums of g) stay
+// in `scratch` for the caller's reduction (nf_pair_train_bwd: the layer's one reduction launch).
+extern "C" int nf_lu_bwd_composed_grid(int64_t B) {
+    using namespace nf;
+    if (B < LB_R || B % LB_R) return NF_EINVAL;
+    return lb_grid(B);
+}
+extern "C" int nf_lu_bwd_composed_partials(const void *g, const void *x, const void *Wd, void *gx, void *scratch, int64_t B, int D,
+                                           nf_stream_t stream) {
     using namespace nf;
     if (D != LB_D || B < LB_R || B % LB_R) return NF_ENOTSUP;
-    if (!g || !x || !Wd || !gx || !dWd || !db || !scratch) return NF_EFAULT;
+    if (!g || !x || !Wd || !gx || !scratch) return NF_EFAULT;
     if (((uintptr_t)g | (uintptr_t)x | (uintptr_t)gx) & 15) return NF_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    const int grid = lb_grid(B);
     LuBwdCArgs a;
     a.g = (const float *)g; a.x = (const float *)x; a.Wd = (const float *)Wd; a.gx = (float *)gx; a.part = (float *)scratch; a.B = B;
     const size_t lds = (size_t)4 * LB_TILE * sizeof(float);
     static LdsOptIn opted = {};
     if (opt_in_lds(reinterpret_cast<const void *>(&lu_bwd_c_kernel), lds, opted) != NF_OK) return NF_ENOTSUP;
-    hipLaunchKernelGGL(lu_bwd_c_kernel, dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(lu_bwd_c_kernel, dim3(lb_grid(B)), dim3(256), lds, (hipStream_t)stream, a);
     NF_CHECK_LAUNCH();
-    return wgrad_reduce_launch(a.part, (float *)dWd, (float *)db, (int64_t)LB_D * LB_D, LB_D, grid, LB_D, 1, 0, 0, 0, nullptr, 0, st);
+    return NF_OK;
+}
+
+extern "C" int nf_lu_bwd_composed(const void *g, const void *x, const void *Wd, void *gx, void *dWd, void *db, void *scratch, int64_t B,
+                                  int D, nf_stream_t stream) {
+    using namespace nf;
+    if (!dWd || !db) return NF_EFAULT;
+    const int rc = nf_lu_bwd_composed_partials(g, x, Wd, gx, scratch, B, D, stream);
+    if (rc != NF_OK) return rc;
+    return wgrad_reduce_launch((const float *)scratch, (float *)dWd, (float *)db, (int64_t)LB_D * LB_D, LB_D, lb_grid(B), LB_D, 1, 0, 0, 0,
+                               nullptr, 0, (hipStream_t)stream);
 }
 
 // (g_lower, g_upper, g_udiag) of LULinearPermute from the composed matrix's gradient dWd (nf_lu_bwd_composed), the dense factors
@@ -479,7 +500,7 @@ extern "C" int nf_lu_param_grads_composed(const void *dWd, const void *Lm, const
     using namespace nf;
     if (D != LB_D) return NF_ENOTSUP;
     if (!dWd || !Lm || !Um || !perm || !unconstrained_upper_diag || !g_lower || !g_upper || !g_udiag) return NF_EFAULT;
-    hipLaunchKernelGGL(lu_c_param_grads_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float *)dWd, (const float *)Lm,
+    hipLaunchKernelGGL(lu_c_param_grads_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, (const float *)dWd, (const float *)Lm,
                        (const float *)Um, perm, (const float *)gld, gld ? B : 0, (const float *)unconstrained_upper_diag, (float)eps,
                        (float *)g_lower, (float *)g_upper, (float *)g_udiag);
     NF_CHECK_LAUNCH();

@@ -25,6 +25,12 @@ int nf_resblock_bwd_grid(int64_t B);
 int nf_resblock_bwd_partials(const void *gh, const void *t, const void *h_in, const void *W1, const void *W2, void *gh_in,
                              const void *x, const void *wfull, void *gx, void *scratch, int64_t B, int H, int D,
                              nf_stream_t stream);
+int nf_lu_bwd_composed_grid(int64_t B);
+int nf_lu_bwd_composed_partials(const void *g, const void *x, const void *Wd, void *gx, void *scratch, int64_t B, int D,
+                                nf_stream_t stream);
+int nf_lu_param_grads_composed(const void *dWd, const void *Lm, const void *Um, const int64_t *perm, const void *gld, int64_t B,
+                               const void *unconstrained_upper_diag, double eps, void *g_lower, void *g_upper, void *g_udiag, int D,
+                               nf_stream_t stream);
 }
 
 namespace nf {
@@ -76,13 +82,14 @@ extern "C" int64_t nf_coupling_train_bwd_scratch_floats(int64_t B, int num_block
     return n;
 }
 
-extern "C" int nf_coupling_train_bwd(const void *x, const void *grad_y, const void *grad_logdet, const void *cond24, const void *acts,
-                                     const void *w_t, const void *wpack, const void *wfull_t, const void *const *w_blocks,
-                                     const void *uw, const void *uh, const void *ud, const void *col_map, int n_cols, void *grad_x,
-                                     void *g_w0, void *g_b0, void *g_wf, void *g_bf, void *g_uw, void *g_uh, void *g_ud,
-                                     void *const *g_blocks, void *scratch, int mask_parity, int64_t B, int D, int hidden,
-                                     int num_blocks, int K, double tail_bound, double min_bin_width, double min_bin_height,
-                                     double min_derivative, nf_stream_t stream) {
+// The four passes over the rows; the reduction jobs are appended to J (not launched), *s_end = the first unused float of scratch.
+static int coupling_bwd_core(const void *x, const void *grad_y, const void *grad_logdet, const void *cond24, const void *acts,
+                             const void *w_t, const void *wpack, const void *wfull_t, const void *const *w_blocks,
+                             const void *uw, const void *uh, const void *ud, const void *col_map, int n_cols, void *grad_x,
+                             void *g_w0, void *g_b0, void *g_wf, void *g_bf, void *g_uw, void *g_uh, void *g_ud,
+                             void *const *g_blocks, void *scratch, int mask_parity, int64_t B, int D, int hidden,
+                             int num_blocks, int K, double tail_bound, double min_bin_width, double min_bin_height,
+                             double min_derivative, nf_stream_t stream, ReduceJobs &J, float **s_end) {
     if (D != F_D || hidden != F_H || K != F_K || num_blocks < 1 || 2 * num_blocks + 2 > RJ_MAX) return NF_ENOTSUP;
     if (B < 64 || B % 64) return NF_ENOTSUP;
     if (mask_parity != 0 && mask_parity != 1) return NF_EINVAL;
@@ -114,7 +121,6 @@ extern "C" int nf_coupling_train_bwd(const void *x, const void *grad_y, const vo
     rc = nf_linear_wgrad_partials(gcond, A + (int64_t)(2 * num_blocks) * act, ring_part, B, TB_MP, F_H, 0, 1, stream);
     if (rc != NF_OK) return rc;
 
-    ReduceJobs J;
     J.nj = 0;
     J.nblocks = 0;
     add_job(J, ring_part, (float *)g_wf, (float *)g_bf, (int64_t)TB_MP * F_H, TB_MP, chunks, F_H, 24, nullptr, 0);
@@ -143,7 +149,74 @@ extern "C" int nf_coupling_train_bwd(const void *x, const void *grad_y, const vo
     J.uw = (const float *)uw; J.uh = (const float *)uh; J.ud = (const float *)ud;
     J.guw = (float *)g_uw; J.guh = (float *)g_uh; J.gud = (float *)g_ud;
     J.p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height, min_derivative, 1.0);
+    *s_end = s;
+    return NF_OK;
+}
+
+extern "C" int nf_coupling_train_bwd(const void *x, const void *grad_y, const void *grad_logdet, const void *cond24, const void *acts,
+                                     const void *w_t, const void *wpack, const void *wfull_t, const void *const *w_blocks,
+                                     const void *uw, const void *uh, const void *ud, const void *col_map, int n_cols, void *grad_x,
+                                     void *g_w0, void *g_b0, void *g_wf, void *g_bf, void *g_uw, void *g_uh, void *g_ud,
+                                     void *const *g_blocks, void *scratch, int mask_parity, int64_t B, int D, int hidden,
+                                     int num_blocks, int K, double tail_bound, double min_bin_width, double min_bin_height,
+                                     double min_derivative, nf_stream_t stream) {
+    ReduceJobs J;
+    float *s_end = nullptr;
+    const int rc = coupling_bwd_core(x, grad_y, grad_logdet, cond24, acts, w_t, wpack, wfull_t, w_blocks, uw, uh, ud, col_map, n_cols,
+                                     grad_x, g_w0, g_b0, g_wf, g_bf, g_uw, g_uh, g_ud, g_blocks, scratch, mask_parity, B, D, hidden,
+                                     num_blocks, K, tail_bound, min_bin_width, min_bin_height, min_derivative, stream, J, &s_end);
+    if (rc != NF_OK) return rc;
     hipLaunchKernelGGL(layer_reduce_kernel, dim3(J.nblocks + F_NI), dim3(64 * RL), 0, (hipStream_t)stream, J);
     NF_CHECK_LAUNCH();
     return NF_OK;
+}
+
+// ---- a [CoupledRQS, LULinearPermute] pair: the coupling's backward, then the composed LU's (autograd.PairTrainFn) -------------------
+// floats of `scratch` for nf_pair_train_bwd: nf_coupling_train_bwd's + the coupling's input gradient (B x 64), the LU pass's
+// partial tiles and the reduced dW_d (64 x 64)
+extern "C" int64_t nf_pair_train_bwd_scratch_floats(int64_t B, int num_blocks) {
+    const int64_t n = nf_coupling_train_bwd_scratch_floats(B, num_blocks);
+    if (n < 0) return n;
+    const int g = nf_lu_bwd_composed_grid(B);
+    if (g < 0) return g;
+    return n + B * (int64_t)F_D + (int64_t)g * (F_D * F_D + F_D) + F_D * F_D;
+}
+
+// nf_coupling_train_bwd on the coupling of a pair (its input = xlu, the LU's output saved by nf_rqs_fused_train_pair_fwd), then
+// nf_lu_bwd_composed_partials on its input gradient, ONE reduction launch for the partial tiles of both layers, and
+// nf_lu_param_grads_composed: seven launches.  x_in: the LU's input rows; Wd: nf_lu_pack_train_multi's (64, 64); Lm, Um: the dense
+// factors of nf_lu_factors[_multi]; grad_x_in (B, 64): the pair's input gradient; g_lower, g_upper, g_udiag, g_lbias: written.
+extern "C" int nf_pair_train_bwd(const void *x_in, const void *xlu, const void *grad_y, const void *grad_logdet, const void *cond24,
+                                 const void *acts, const void *w_t, const void *wpack, const void *wfull_t,
+                                 const void *const *w_blocks, const void *uw, const void *uh, const void *ud, const void *col_map,
+                                 int n_cols, const void *Wd, const void *Lm, const void *Um, const int64_t *perm,
+                                 const void *unconstrained_upper_diag, double lu_eps, void *grad_x_in, void *g_lower, void *g_upper,
+                                 void *g_udiag, void *g_lbias, void *g_w0, void *g_b0, void *g_wf, void *g_bf, void *g_uw, void *g_uh,
+                                 void *g_ud, void *const *g_blocks, void *scratch, int mask_parity, int64_t B, int D, int hidden,
+                                 int num_blocks, int K, double tail_bound, double min_bin_width, double min_bin_height,
+                                 double min_derivative, nf_stream_t stream) {
+    if (!x_in || !Wd || !Lm || !Um || !perm || !unconstrained_upper_diag || !grad_x_in || !g_lower || !g_upper || !g_udiag || !g_lbias ||
+        !scratch)
+        return NF_EFAULT;
+    const int64_t n0 = nf_coupling_train_bwd_scratch_floats(B, num_blocks);
+    if (n0 < 0) return (int)n0;
+    float *gxl = (float *)scratch + n0;                       // the coupling's input gradient = the LU's output gradient
+    float *lu_part = gxl + B * (int64_t)F_D;
+    const int lgrid = nf_lu_bwd_composed_grid(B);
+    if (lgrid < 0) return NF_ENOTSUP;
+    float *dWd = lu_part + (int64_t)lgrid * (F_D * F_D + F_D);
+    ReduceJobs J;
+    float *s_end = nullptr;
+    int rc = coupling_bwd_core(xlu, grad_y, grad_logdet, cond24, acts, w_t, wpack, wfull_t, w_blocks, uw, uh, ud, col_map, n_cols, gxl,
+                               g_w0, g_b0, g_wf, g_bf, g_uw, g_uh, g_ud, g_blocks, scratch, mask_parity, B, D, hidden, num_blocks, K,
+                               tail_bound, min_bin_width, min_bin_height, min_derivative, stream, J, &s_end);
+    if (rc != NF_OK) return rc;
+    if (s_end > gxl) return NF_EINVAL;
+    rc = nf_lu_bwd_composed_partials(gxl, x_in, Wd, grad_x_in, lu_part, B, F_D, stream);
+    if (rc != NF_OK) return rc;
+    add_job(J, lu_part, dWd, (float *)g_lbias, (int64_t)F_D * F_D, F_D, lgrid, F_D, 0, nullptr, 0);
+    hipLaunchKernelGGL(layer_reduce_kernel, dim3(J.nblocks + F_NI), dim3(64 * RL), 0, (hipStream_t)stream, J);
+    NF_CHECK_LAUNCH();
+    return nf_lu_param_grads_composed(dWd, Lm, Um, perm, grad_logdet, B, unconstrained_upper_diag, lu_eps, g_lower, g_upper, g_udiag,
+                                      F_D, stream);
 }

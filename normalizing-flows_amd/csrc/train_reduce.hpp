@@ -166,7 +166,7 @@ struct ReduceJob {
     int chunks, N, skip_every, Nout;
     int block0;                 // first block of the job in the launch's grid (256-element groups, one per block)
 };
-constexpr int RJ_MAX = 12;
+constexpr int RJ_MAX = 14;
 struct ReduceJobs {
     ReduceJob j[RJ_MAX];
     int nj;

@@ -726,6 +726,43 @@ def final_bwd(x, grad_y, grad_logdet, cond24, w_t, blob, uw, uh, ud, mask_parity
     return gx, gcond, gh, guw, guh, gud
 
 
+def pair_train_bwd(x_in, xlu, grad_y, grad_logdet, cond24, acts, w_t, blob, wfull_t, w_blocks, uw, uh, ud, col_map, n_cols, mask_parity,
+                   num_blocks, Wd, Lm, Um, perm, udiag, lu_eps, dest, tail_bound=3.0, min_bin_width=1e-3, min_bin_height=1e-3,
+                   min_derivative=1e-3):
+    """The whole backward of a [CoupledRQS, LULinearPermute] pair in one C-ABI call (nf_pair_train_bwd: seven launches).  dest: as
+    coupling_train_bwd plus lower, upper, udiag, lbias (the LU's gradient destinations).  Returns the pair's input gradient."""
+    L.require_device(x_in, xlu, grad_y, grad_logdet, cond24, acts, w_t, blob, wfull_t, uw, uh, ud, col_map, Wd, Lm, Um, perm, udiag,
+                     *w_blocks)
+    B = x_in.shape[0]
+    x_in, xlu, grad_y, grad_logdet = x_in.contiguous(), xlu.contiguous(), grad_y.contiguous(), grad_logdet.contiguous()
+    lib = L.lib()
+    lib.nf_pair_train_bwd_scratch_floats.restype = C.c_int64
+    n = int(lib.nf_pair_train_bwd_scratch_floats(i64(B), i32(num_blocks)))
+    if n <= 0:
+        raise NotImplementedError("pair_train_bwd: batch a multiple of 64, 1 <= num_blocks <= 5")
+    keys = ("w0", "b0", "wf", "bf", "uw", "uh", "ud", "lower", "upper", "udiag", "lbias")
+    tensors = [dest[k] for k in keys] + list(dest["blocks"])
+    if len(w_blocks) != 2 * num_blocks or len(dest["blocks"]) != 4 * num_blocks:
+        raise ValueError("pair_train_bwd: 2 weights and 4 gradient destinations per residual block")
+    L.require_device(*tensors)
+    if any(t.dtype != torch.float32 or not t.is_contiguous() for t in tensors):
+        raise ValueError("pair_train_bwd: gradient destinations must be contiguous float32")
+    scratch = torch.empty(n, dtype=torch.float32, device=x_in.device)
+    gx = torch.empty_like(x_in)
+    wb = [w.contiguous() for w in w_blocks]
+    wp = (C.c_void_p * len(wb))(*[w.data_ptr() for w in wb])
+    gp = (C.c_void_p * len(dest["blocks"]))(*[t.data_ptr() for t in dest["blocks"]])
+    rc = lib.nf_pair_train_bwd(ptr(x_in), ptr(xlu), ptr(grad_y), ptr(grad_logdet), ptr(cond24), ptr(acts), ptr(w_t), ptr(blob),
+                               ptr(wfull_t), wp, ptr(uw.contiguous()), ptr(uh.contiguous()), ptr(ud.contiguous()), ptr(col_map),
+                               i32(int(n_cols)), ptr(Wd), ptr(Lm.contiguous()), ptr(Um.contiguous()), ptr(perm), ptr(udiag.contiguous()),
+                               f64(lu_eps), ptr(gx), ptr(dest["lower"]), ptr(dest["upper"]), ptr(dest["udiag"]), ptr(dest["lbias"]),
+                               ptr(dest["w0"]), ptr(dest["b0"]), ptr(dest["wf"]), ptr(dest["bf"]), ptr(dest["uw"]), ptr(dest["uh"]),
+                               ptr(dest["ud"]), gp, ptr(scratch), i32(mask_parity), i64(B), i32(64), i32(128), i32(num_blocks), i32(8),
+                               f64(tail_bound), f64(min_bin_width), f64(min_bin_height), f64(min_derivative), L.stream())
+    L.check(rc, "nf_pair_train_bwd")
+    return gx
+
+
 def lu_pack_train_multi(table, n_layers, num_blocks, eps, D=64):
     """The LU stage of n training blobs + the composed matrices for the backward in one launch (nf_lu_pack_train_multi)."""
     L.check(L.lib().nf_lu_pack_train_multi(ptr(table), i32(n_layers), i32(num_blocks), i32(D), f64(eps), L.stream()),

@@ -127,7 +127,7 @@ def test_benchmark_shape_training_step_vs_reference_autograd(nfa, monkeypatch):
     from normflows_amd import ops
     m, g = _c2_train_model_and_fixture(nfa)
     calls = {}
-    for name in ("rqs_fused_train_full_fwd", "rqs_fused_train_pair_fwd", "coupling_train_bwd", "lu_bwd_composed", "final_bwd",
+    for name in ("rqs_fused_train_full_fwd", "rqs_fused_train_pair_fwd", "coupling_train_bwd", "pair_train_bwd", "final_bwd",
                  "resblock_bwd", "lu_fwd", "lu_bwd"):
         orig = getattr(ops, name)
 
@@ -140,13 +140,12 @@ def test_benchmark_shape_training_step_vs_reference_autograd(nfa, monkeypatch):
         assert f.prqct._train_full_ok(x, None, False)
     loss = m.forward_kld(x)
     loss.backward()
-    # round 6: a layer's whole backward is ONE C-ABI call (nf_coupling_train_bwd: nf_final_bwd + the ring weight gradient +
-    # nf_resblock_bwd_partials per block + one reduction launch); the kernel-by-kernel wrappers are not called any more
-    # ... and the pair's LULinearPermute rides in the forward launch (nf_rqs_fused_train_pair_fwd = rqs_fused_kernel<0,true,2>), its
-    # backward is the composed one-product pass (nf_lu_bwd_composed): no nf_lu_fwd / nf_lu_bwd launches
-    assert calls.get("rqs_fused_train_pair_fwd") == 2 and calls.get("coupling_train_bwd") == 2, calls
-    assert calls.get("lu_bwd_composed") == 2 and not any(k in calls for k in ("rqs_fused_train_full_fwd", "final_bwd", "resblock_bwd",
-                                                                             "lu_fwd", "lu_bwd")), calls
+    # round 6: a [LU, coupling] pair is ONE forward launch (nf_rqs_fused_train_pair_fwd = rqs_fused_kernel<0,true,2>) and its whole
+    # backward ONE C-ABI call (nf_pair_train_bwd: nf_final_bwd, the ring weight gradient, nf_resblock_bwd_partials per block,
+    # nf_lu_bwd_composed_partials, one reduction launch, nf_lu_param_grads_composed); the kernel-by-kernel wrappers are not called
+    assert calls.get("rqs_fused_train_pair_fwd") == 2 and calls.get("pair_train_bwd") == 2, calls
+    assert not any(k in calls for k in ("rqs_fused_train_full_fwd", "coupling_train_bwd", "final_bwd", "resblock_bwd", "lu_fwd",
+                                        "lu_bwd")), calls
     ref_loss = float(g["loss_f32"])
     assert abs(float(loss) - ref_loss) < 1e-4 * abs(ref_loss), (float(loss), ref_loss)
     assert abs(float(loss) - float(g["loss_f64"])) < 1e-4 * abs(ref_loss)
@@ -1121,7 +1120,7 @@ def test_pair_training_path_vs_separate_layers(nfa, monkeypatch):
     from bench import build_c2_model
     from normflows_amd import ops
     calls = {}
-    for name in ("rqs_fused_train_pair_fwd", "lu_bwd_composed", "lu_param_grads_composed", "lu_fwd", "lu_bwd"):
+    for name in ("rqs_fused_train_pair_fwd", "pair_train_bwd", "lu_fwd", "lu_bwd"):
         orig = getattr(ops, name)
 
         def spy(*a, _orig=orig, _name=name, **kw):
@@ -1142,8 +1141,8 @@ def test_pair_training_path_vs_separate_layers(nfa, monkeypatch):
                 loss = m.forward_kld(xa)
                 loss.backward()
                 if on:
-                    assert calls.get("rqs_fused_train_pair_fwd") == 3 and calls.get("lu_bwd_composed") == 3, calls
-                    assert calls.get("lu_param_grads_composed") == 3 and "lu_fwd" not in calls and "lu_bwd" not in calls, calls
+                    assert calls.get("rqs_fused_train_pair_fwd") == 3 and calls.get("pair_train_bwd") == 3, calls
+                    assert "lu_fwd" not in calls and "lu_bwd" not in calls, calls
                 else:
                     assert calls.get("lu_fwd") == 3 and calls.get("lu_bwd") == 3 and "rqs_fused_train_pair_fwd" not in calls, calls
                 res.append((float(loss.detach()), xa.grad.clone(), [p_.grad.clone() for p_ in m.parameters()]))
