@@ -121,7 +121,9 @@ final_bwd_kernel(FinalBwdArgs a) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // the raw barrier: __syncthreads() is a fence, and with an LDS-DMA possibly pending the compiler implements it as
         // s_waitcnt vmcnt(0) -- the counted waits above never took effect before this was found (round 3, in the Glow kernels)
+#ifndef FB_ABL_NOBAR      // (timing-only ablation: how much of the launch is waves waiting for each other at the ring's stage barriers)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
         if (stage + 1 < total_stages) issue(stage + 1);
         const float *buf = ring + (stage & 1) * FB_STG;
         ++stage;

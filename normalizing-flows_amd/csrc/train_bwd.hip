@@ -39,6 +39,22 @@ __global__ void __launch_bounds__(64 * RL)
 layer_reduce_kernel(ReduceJobs J) {
     __shared__ f32x4 sm4[RL][64];
     const int b = blockIdx.x;
+    if (b >= J.nblocks + F_NI) {        // the (B) vector sum: one block, fixed order
+        float *smf = reinterpret_cast<float *>(&sm4[0][0]);
+        const int tid = threadIdx.x;
+        float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+        const int64_t n4 = (reinterpret_cast<uintptr_t>(J.vsum) & 15) == 0 ? J.vsum_n / 4 : 0;
+        const f32x4 *g4 = reinterpret_cast<const f32x4 *>(J.vsum);
+#pragma unroll 16
+        for (int64_t i = tid; i < n4; i += 64 * RL) {
+            const f32x4 v = g4[i];
+            p0 += v[0]; p1 += v[1]; p2 += v[2]; p3 += v[3];
+        }
+        for (int64_t i = 4 * n4 + tid; i < J.vsum_n; i += 64 * RL) p0 += J.vsum[i];
+        const float tot = block_sum((p0 + p1) + (p2 + p3), smf);
+        if (tid == 0) *J.vsum_out = tot;
+        return;
+    }
     if (b >= J.nblocks) {       // the batch-shared spline parameters: one block per identity feature
         float *smf = reinterpret_cast<float *>(&sm4[0][0]);
         final_bwd_reduce_feature(J.fb_part, J.fb_nparts, J.uw, J.uh, J.ud, J.guw, J.guh, J.gud, J.p, b - J.nblocks,
@@ -149,6 +165,7 @@ static int coupling_bwd_core(const void *x, const void *grad_y, const void *grad
     J.uw = (const float *)uw; J.uh = (const float *)uh; J.ud = (const float *)ud;
     J.guw = (float *)g_uw; J.guh = (float *)g_uh; J.gud = (float *)g_ud;
     J.p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height, min_derivative, 1.0);
+    J.vsum = nullptr; J.vsum_out = nullptr; J.vsum_n = 0;
     *s_end = s;
     return NF_OK;
 }
@@ -179,7 +196,7 @@ extern "C" int64_t nf_pair_train_bwd_scratch_floats(int64_t B, int num_blocks) {
     if (n < 0) return n;
     const int g = nf_lu_bwd_composed_grid(B);
     if (g < 0) return g;
-    return n + B * (int64_t)F_D + (int64_t)g * (F_D * F_D + F_D) + F_D * F_D;
+    return n + B * (int64_t)F_D + (int64_t)g * (F_D * F_D + F_D) + F_D * F_D + 4;
 }
 
 // nf_coupling_train_bwd on the coupling of a pair (its input = xlu, the LU's output saved by nf_rqs_fused_train_pair_fwd), then
@@ -215,8 +232,11 @@ extern "C" int nf_pair_train_bwd(const void *x_in, const void *xlu, const void *
     rc = nf_lu_bwd_composed_partials(gxl, x_in, Wd, grad_x_in, lu_part, B, F_D, stream);
     if (rc != NF_OK) return rc;
     add_job(J, lu_part, dWd, (float *)g_lbias, (int64_t)F_D * F_D, F_D, lgrid, F_D, 0, nullptr, 0);
-    hipLaunchKernelGGL(layer_reduce_kernel, dim3(J.nblocks + F_NI), dim3(64 * RL), 0, (hipStream_t)stream, J);
+    float *gl_sum = dWd + F_D * F_D;          // the log-det cotangent's sum, by one more block of the reduction launch
+    J.vsum = (const float *)grad_logdet; J.vsum_out = gl_sum; J.vsum_n = B;
+    hipLaunchKernelGGL(layer_reduce_kernel, dim3(J.nblocks + F_NI + 1), dim3(64 * RL), 0, (hipStream_t)stream, J);
     NF_CHECK_LAUNCH();
-    return nf_lu_param_grads_composed(dWd, Lm, Um, perm, grad_logdet, B, unconstrained_upper_diag, lu_eps, g_lower, g_upper, g_udiag,
-                                      F_D, stream);
+    // (gld = the one-element sum, B = 1: the parameter kernel's own summation loop degenerates to a single load)
+    return nf_lu_param_grads_composed(dWd, Lm, Um, perm, gl_sum, 1, unconstrained_upper_diag, lu_eps, g_lower, g_upper, g_udiag, F_D,
+                                      stream);
 }

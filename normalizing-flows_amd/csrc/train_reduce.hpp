@@ -176,6 +176,11 @@ struct ReduceJobs {
     float *guw, *guh, *gud;
     int fb_nparts;
     RqsParams<float> p;
+    // optional: sum of a (B) vector (the log-det cotangent LULinearPermute's diagonal gradient needs) -> *vsum_out, by ONE extra
+    // block in a fixed order (16-byte loads when aligned); vsum == nullptr: none
+    const float *vsum;
+    float *vsum_out;
+    int64_t vsum_n;
 };
 
 }  // namespace nf
