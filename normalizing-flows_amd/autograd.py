@@ -767,11 +767,26 @@ class Inv1x1WeightFn(torch.autograd.Function):
 _ZERO0 = {}
 
 
+def _zero_scalar(device, dtype):
+    """A cached device scalar 0 (no fill launch per block and step).  Created EAGERLY, never under hipGraph capture: a
+    tensor first allocated while capturing lives in the graph's private pool and its fill is only a captured node -- later eager
+    users would read memory that is zeroed on replay only.  Under capture a fresh (captured) zero is returned and nothing is cached."""
+    key = (device, dtype)
+    zero = _ZERO0.get(key)
+    if zero is None:
+        if torch.cuda.is_current_stream_capturing():
+            return torch.zeros((), dtype=dtype, device=device)
+        zero = _ZERO0[key] = torch.zeros((), dtype=dtype, device=device)
+    return zero
+
+
 class Inv1x1Fn(torch.autograd.Function):
     """Per-pixel C x C product (mixing.py:106-133) with a given matrix W and per-pixel log|det| `ldu` (0-dim)."""
 
     @staticmethod
     def forward(ctx, z, W, ldu):
+        if z.is_cuda:
+            _zero_scalar(z.device, z.dtype)       # (the backward's cached zero exists before any capture of a backward can start)
         ld = torch.empty(z.shape[0], dtype=z.dtype, device=z.device)
         y, _ = ops.inv1x1_conv(z, W.detach().contiguous(), ldu.detach(), logdet=ld, acc=L.LD_WRITE, want_scalar=False)
         ctx.save_for_backward(z, W, ldu)
@@ -784,9 +799,7 @@ class Inv1x1Fn(torch.autograd.Function):
             gy = torch.zeros_like(z)
         gz = gW = gl = None
         if z.shape[1] <= 64:
-            zero = _ZERO0.get((z.device, z.dtype))        # (a cached device scalar: no fill launch per block and step)
-            if zero is None:
-                zero = _ZERO0[(z.device, z.dtype)] = torch.zeros((), dtype=z.dtype, device=z.device)
+            zero = _zero_scalar(z.device, z.dtype)
             if ctx.needs_input_grad[0]:      # gz = W^T gy per pixel: the forward kernel on the transposed matrix
                 gz, _ = ops.inv1x1_conv(gy.contiguous(), W.detach().t().contiguous(), zero, want_scalar=False)
             if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
@@ -942,18 +955,22 @@ class MafInverseFn(torch.autograd.Function):
             keep = inv.get("fcols") is not None and _config.maf_solve_grads and any(ctx.needs_input_grad[4:])
             x, ld, bits, scratch = ops.maf_inverse_bits(z, inv["blob"], inv["table"], inv["hp"], inv["nb"], inv["tiles"],
                                                         table_host=inv.get("table_host"), return_scratch=True)
-            ctx.save_for_backward(x, bits)
+            ctx.save_for_backward(x, bits, *([params[-1]] if params else []))
             ctx.tpack = (inv["tblob"], inv["ttable"], inv["hp"], inv["nb"], inv.get("gcols"))
             # the pass's own activations (its scratch) are the inputs of MADE's linears at x: kept for the weight-gradient launch, so
             # the backward does not run MADE forward again (671 MB per config-5 layer at B = 65 536 instead of a transient of that size)
             ctx.fpack = (scratch, inv["fcols"], inv["wf_t"]) if keep else None
         else:
             x, ld = ops.maf_inverse(z, inv[0], inv[1], inv[2], num_blocks=inv[3], table_host=inv[4] if len(inv) > 4 else None)
-            ctx.save_for_backward(x)
+            ctx.save_for_backward(x, *([params[-1]] if params else []))
             ctx.tpack = None
         ctx.fwd, ctx.bwd = fwd, bwd
         ctx.nparams = len(params)
-        ctx.bias_f = params[-1].detach() if params else None        # (final layer's bias: the last of [w, b] per linear)
+        # (the final layer's bias -- the last of [w, b] per linear -- goes through save_for_backward: an in-place update between forward
+        # and backward trips autograd's version check instead of mixing new bias with old weights, ADVICE r05.  The kept scratch
+        # (ctx.fpack: 671 MB per config-5 layer at B = 65 536, for every MAF layer from forward to backward) is what config.
+        # set_maf_solve_grads(False) trades for one more MADE forward + chain per layer in the backward.)
+        ctx.has_bias_f = bool(params)
         ctx.set_materialize_grads(False)
         return x, ld
 
@@ -973,7 +990,7 @@ class MafInverseFn(torch.autograd.Function):
             fscratch, fcols, wf_t = fpack
             save = ops.maf_scratch_rows(fscratch, fcols, B, nb, hp)
             ctx.fpack = None
-            p = torch.nn.functional.linear(save[2 * nb, :B], wf_t, ctx.bias_f)
+            p = torch.nn.functional.linear(save[2 * nb, :B], wf_t, ctx.saved_tensors[-1].detach() if ctx.has_bias_f else None)
             v, scratch = ops.maf_solve_t(x, p, gx, gld, ctx.saved_tensors[1], tb, tt, hp, nb, return_scratch=True)
             G = ops.maf_scratch_rows(scratch, gcols, B, nb, hp, sign=-1.0, reverse_layers=True)
             MafInverseFn.last_sweeps = 1

@@ -180,7 +180,29 @@ maf_implicit_rtol = 0.0
 # Autoregressive.inverse under autograd for the other element-wise transforms (AR-NSF sampling, circular splines, MAF structures
 # outside the one-pass kernels): implicit differentiation on the layer's own density-direction graph (autograd.ArInverseImplicitFn:
 # <= D backward sweeps of the net + one weight-gradient pass).  False = the reference's D recorded passes.
+# Restriction: the implicit Functions are once_differentiable -- FIRST-order gradients only.  Double backward through
+# an autoregressive layer's inverse (create_graph=True: gradient penalties, Hessian-vector products through sampling) needs the D
+# recorded passes, which support it like the reference's loop: `with normflows_amd.config.higher_order_gradients():` (or
+# set_ar_implicit(False) / set_maf_implicit(False)) around the forward pass.
 ar_implicit = True
+
+
+class higher_order_gradients:
+    """Context manager: inside it Autoregressive.inverse / MaskedAffineAutoregressive.inverse run the reference's D recorded passes
+    under autograd instead of the once-differentiable implicit Functions, and MADE runs as plain torch modules: as differentiable
+    as the element-wise transform's own backward allows (the affine transform of MAF: any order)."""
+
+    def __enter__(self):
+        global ar_implicit, maf_implicit, made_train
+        self.saved = (ar_implicit, maf_implicit, made_train)
+        # (MADE itself then runs as torch modules on library GEMMs: the hand-written MadeFn backward is first-order as well)
+        ar_implicit = maf_implicit = made_train = False
+        return self
+
+    def __exit__(self, *exc):
+        global ar_implicit, maf_implicit, made_train
+        ar_implicit, maf_implicit, made_train = self.saved
+        return False
 
 
 def set_ar_implicit(mode=True):

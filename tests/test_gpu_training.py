@@ -2014,3 +2014,23 @@ def test_maf_implicit_backward_with_one_cotangent_absent(nfa, which):
     for r in res[:2]:
         for a, b in zip(r, res[2]):
             assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max()))
+
+
+def test_higher_order_gradients_context_through_maf_inverse(nfa):
+    """the implicit Functions behind Autoregressive.inverse are first-order only; config.higher_order_gradients() routes the
+    density direction of a MAF layer through the D recorded passes on torch modules, so a gradient penalty (create_graph=True, then a
+    second backward) works -- and outside the context the same request fails loudly instead of returning a wrong value."""
+    torch.manual_seed(0)
+    layer = nfa.flows.MaskedAffineAutoregressive(6, 16, num_blocks=1).to(DEV)
+    z = torch.randn(64, 6, device=DEV, requires_grad=True)
+    with nfa.config.higher_order_gradients():
+        x, ld = layer.inverse(z)
+        (gz,) = torch.autograd.grad((x.pow(2).sum() + ld.sum()), z, create_graph=True)
+        gz.pow(2).sum().backward()
+    assert all(p_.grad is not None and torch.isfinite(p_.grad).all() for p_ in layer.parameters())
+    assert nfa.config.ar_implicit and nfa.config.maf_implicit and nfa.config.made_train
+    layer.zero_grad(set_to_none=True)
+    x, ld = layer.inverse(z)
+    with pytest.raises(RuntimeError):
+        (gz,) = torch.autograd.grad((x.pow(2).sum() + ld.sum()), z, create_graph=True)
+        gz.pow(2).sum().backward()
