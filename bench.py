@@ -138,9 +138,10 @@ def pmc_traffic():
 
 def reference_cpu_leg():
     """The `kind: "reference"` leg: normflows itself (PyTorch CPU) timed by tools/cpu_reference.py.  /root/reference does not exist
-    on the GPU box at bench time, so the newest committed JSON is reported with where it was measured: round 5 staged the package
-    for one gpurun call and timed it ON THE GPU BOX's host cores (profiles/r05_cpu_reference_gpubox.json, best of a thread sweep);
-    rounds 2-4: the 8-core build container (profiles/r02_cpu_reference.json)."""
+    on the GPU box at bench time, so the newest committed JSON is reported with where it was measured: rounds 5-6 staged the package
+    for one gpurun call and timed it ON THE GPU BOX's host cores (profiles/r06_cpu_reference_gpubox.json: thread sweep 8 ... 256, each
+    setting in its own process under a time limit -- 128 and 256 threads do not finish and are recorded as such); rounds 2-4: the
+    8-core build container (profiles/r02_cpu_reference.json)."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*cpu_reference*.json")), reverse=True):
         try:
@@ -156,7 +157,9 @@ def reference_cpu_leg():
             if "sample" in d:
                 leg["sample_direction_samples_per_s"] = d["sample"]["samples_per_s"]
             if d.get("sweep"):
-                leg["thread_sweep_samples_per_s"] = {str(e["torch_threads"]): round(e["samples_per_s"], 1) for e in d["sweep"]}
+                leg["thread_sweep_samples_per_s"] = {str(e["torch_threads"]): (round(e["samples_per_s"], 1) if e.get("samples_per_s")
+                                                                               else "did not finish in %.0f s" % e.get("timeout_s", 0))
+                                                     for e in d["sweep"]}
             return leg
         except Exception:
             pass

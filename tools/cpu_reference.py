@@ -61,6 +61,11 @@ def main():
                          "On the 256-thread GPU box ALL cores is pathological for the reference's thousands of small ATen ops "
                          "(round 5: the all-core run did not finish 6 passes in 15 min), hence the sweep")
     ap.add_argument("--quick", action="store_true", help="skip the per-layer in-bound scan and the sample direction")
+    ap.add_argument("--per-setting-timeout", type=float, default=0.0,
+                    help="seconds; > 0: every thread count of the sweep runs in its OWN process under this limit, and a setting that "
+                         "does not finish is recorded as a data point (`timeout_s`) instead of stalling the sweep (round 6: the all-core "
+                         "setting of the 256-thread GPU box)")
+    ap.add_argument("--worker", type=int, default=0, help=argparse.SUPPRESS)      # internal: one setting, print its entry, exit
     a = ap.parse_args()
     sys.path.insert(0, os.path.abspath(a.ref))
     import normflows as nf
@@ -91,14 +96,39 @@ def main():
                 z, _ = f.inverse(z)
             res["in_bound_fraction_min_over_layers"] = min(fr)
             dump()
-        best = None
-        for nt in tlist:
+        def one_setting(nt):
             torch.set_num_threads(nt)
             model.log_prob(x[:min(4096, a.rows)])                                     # warm-up
             t, ts, lp = best_of(lambda: model.log_prob(x), a.repeats)
-            ent = {"torch_threads": nt, "best_s": t, "all_s": ts, "samples_per_s": a.rows / t,
-                   "nll_nats_per_dim": float(-lp.mean() / DIM)}
+            return {"torch_threads": nt, "best_s": t, "all_s": ts, "samples_per_s": a.rows / t,
+                    "nll_nats_per_dim": float(-lp.mean() / DIM)}
+
+        if a.worker:
+            print("ENTRY " + json.dumps(one_setting(a.worker)), flush=True)
+            return
+        best = None
+        for nt in tlist:
+            if a.per_setting_timeout > 0:
+                import subprocess
+                cmd = [sys.executable, os.path.abspath(__file__), "--worker", str(nt), "--rows", str(a.rows), "--repeats", str(a.repeats),
+                       "--ref", a.ref, "--quick"]
+                t0 = time.perf_counter()
+                try:
+                    out = subprocess.run(cmd, capture_output=True, text=True, timeout=a.per_setting_timeout)
+                    lines = [l for l in out.stdout.splitlines() if l.startswith("ENTRY ")]
+                    ent = json.loads(lines[-1][6:]) if lines else {"torch_threads": nt, "error": (out.stderr or out.stdout)[-300:],
+                                                                   "samples_per_s": None}
+                except subprocess.TimeoutExpired:
+                    ent = {"torch_threads": nt, "timeout_s": a.per_setting_timeout, "samples_per_s": None,
+                           "note": "1 warm-up (4096 rows) + %d passes did not finish within the limit" % a.repeats,
+                           "wall_s": time.perf_counter() - t0}
+            else:
+                ent = one_setting(nt)
             res["sweep"].append(ent)
+            if ent.get("samples_per_s") is None:
+                dump()
+                print(json.dumps(ent), flush=True)
+                continue
             if best is None or ent["samples_per_s"] > best["samples_per_s"]:
                 best = ent
             res["log_prob"] = best
