@@ -108,9 +108,21 @@ def c4():
         trg = timed(graph.replay, 5)
     except Exception as exc:                                     # noqa: BLE001
         print("config 4: training-step graph capture failed: %r" % (exc,))
+    # algorithmic FLOP of one pass: the GlowBlock conditioners' convolutions, 2 x (9 C/2 256 + 256^2 + 9 256 C) per
+    # pixel and block: 665 GFLOP per 256-image batch; a training step repeats every product for the input and the weight gradient
+    flop = 0.0
+    for i in range(L_):
+        C, px = channels * 2 ** (L_ + 1 - i), (input_shape[1] // 2 ** (L_ - i)) * (input_shape[2] // 2 ** (L_ - i))
+        flop += 2.0 * (9 * (C // 2) * hidden + hidden * hidden + 9 * hidden * C) * px * K_ * 256
+
+    def roof(ms, mult):
+        return {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.3, "achieved": mult * flop / ms / 1e9,
+                "frac": mult * flop / ms / 1e9 / 157.3, "flop": mult * flop, "traffic": None}
     res = {"workload": "BASELINE configs[3]: Glow L=3, K=32, hidden 256, 32x32x3, batch 256", "log_prob_ms": g * 1e3,
            "log_prob_ms_eager": e * 1e3, "sample_ms": es * 1e3, "images_per_s": 256 / g, "nll_nats_per_dim": nll,
-           "forward_kld_backward_ms": tr * 1e3, "forward_kld_backward_graph_replay_ms": None if trg is None else trg * 1e3}
+           "forward_kld_backward_ms": tr * 1e3, "forward_kld_backward_graph_replay_ms": None if trg is None else trg * 1e3,
+           "roofline_log_prob": roof(g * 1e3, 1.0),
+           "roofline_train_step": roof((trg if trg is not None else tr) * 1e3, 3.0)}
     print("config 4 Glow L=3 K=32 B=256: log_prob eager %.1f ms (%.0f img/s), hipGraph %.1f ms (%.0f img/s); "
           "sample %.1f ms (%.0f img/s); NLL %.4f nats/dim (untrained, after ActNorm init); forward_kld + backward %.1f ms eager, "
           "%s ms as one hipGraph" % (e * 1e3, 256 / e, g * 1e3, 256 / g, es * 1e3, 256 / es, nll, tr * 1e3,
