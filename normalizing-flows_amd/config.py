@@ -185,6 +185,9 @@ maf_implicit_rtol = 0.0
 # recorded passes, which support it like the reference's loop: `with normflows_amd.config.higher_order_gradients():` (or
 # set_ar_implicit(False) / set_maf_implicit(False)) around the forward pass.
 ar_implicit = True
+# MaskedAffineAutoregressive's element-wise map under autograd as torch formulas (affine/autoregressive.py:98-128 verbatim in torch
+# ops: differentiable to any order) instead of nf_maf_affine + nf_maf_affine_bwd; set by higher_order_gradients().
+torch_elementwise = False
 
 
 class higher_order_gradients:
@@ -193,15 +196,17 @@ class higher_order_gradients:
     as the element-wise transform's own backward allows (the affine transform of MAF: any order)."""
 
     def __enter__(self):
-        global ar_implicit, maf_implicit, made_train
-        self.saved = (ar_implicit, maf_implicit, made_train)
-        # (MADE itself then runs as torch modules on library GEMMs: the hand-written MadeFn backward is first-order as well)
+        global ar_implicit, maf_implicit, made_train, torch_elementwise
+        self.saved = (ar_implicit, maf_implicit, made_train, torch_elementwise)
+        # (MADE itself then runs as torch modules on library GEMMs and MAF's element-wise affine map as torch formulas: the
+        # hand-written MadeFn / MafAffineFn backwards are sets of kernels, first-order as well)
         ar_implicit = maf_implicit = made_train = False
+        torch_elementwise = True
         return self
 
     def __exit__(self, *exc):
-        global ar_implicit, maf_implicit, made_train
-        ar_implicit, maf_implicit, made_train = self.saved
+        global ar_implicit, maf_implicit, made_train, torch_elementwise
+        ar_implicit, maf_implicit, made_train, torch_elementwise = self.saved
         return False
 
 

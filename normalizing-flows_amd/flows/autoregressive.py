@@ -194,6 +194,14 @@ class MaskedAffineAutoregressive(Autoregressive):
         if inputs.dim() != 2:
             raise NotImplementedError("MaskedAffineAutoregressive: (batch, features) inputs only")
         if autograd.needs_grad(inputs, params):
+            from .. import config as _cfg
+            if _cfg.torch_elementwise:        # config.higher_order_gradients(): affine/autoregressive.py:98-128 in torch ops
+                prm = params.view(-1, inputs.shape[1], 2)
+                scale = torch.sigmoid(prm[..., 0] + 2.0) + 1e-3
+                log_scale = torch.log(scale).sum(1)
+                if direction == 0:
+                    return scale * inputs + prm[..., 1], log_scale
+                return (inputs - prm[..., 1]) / scale, -log_scale
             return autograd.MafAffineFn.apply(inputs.contiguous(), params, direction)
         return ops.maf_affine(inputs, params, direction, want_logdet=want_logdet)
 
