@@ -6,8 +6,10 @@
 // by its own reduction launch: per layer final_bwd + its reduction, the ring weight gradient + its reduction, two residual-block
 // launches + three reductions -- 11 launches, 6 of them 4-10 us reductions on grids too small to pull their partial tiles at more
 // than ~2 TB/s, each behind a dependent kernel boundary.  Here the four heavy kernels run back to back and ALL reductions of the
-// layer are one launch (nf::layer_reduce_kernel: the routines of train_reduce.hpp, one 64-element group or one spline feature
-// per block; the same fixed summation order, so the gradients are bit-identical to the launch-by-launch path): 5 launches.
+// layer are one launch (nf::layer_reduce_kernel: the routines of train_reduce.hpp, one 256-element group (16-byte loads), one spline
+// feature or the cotangent sum per block; the stand-alone reductions' summation order, so the gradients are bit-identical to the
+// launch-by-launch path): 5 launches.  nf_pair_train_bwd adds the adjacent LULinearPermute's composed backward (one pass over the
+// rows, its partial tiles in the same reduction launch, the factors' gradients on the parameter side): 7 launches for the pair.
 // Gradients go straight to the caller's destinations (e.g. views of one flat gradient buffer: no per-parameter tensors).
 #include "train_reduce.hpp"
 

@@ -32,6 +32,22 @@ def test_bench_emits_one_contract_line():
     assert abs(d["nll_nats_per_dim"] - 1.5416) < 5e-3          # the reference's NLL on this model is 1.5415
     acc = c["max_rel_err_log_prob_vs_fp64_oracle"]
     assert acc["gpu_exact_f32"] < 1e-4 and acc.get("gpu_bf16x3", 0.0) < 1e-4
+    # the untimed `secondary` records: every BASELINE config names its workload, every roofline object is well formed
+    s = d["secondary"]
+    for key in ("config1_realnvp", "config4_glow", "config5_maf", "nsf_wide", "train_step"):
+        assert key in s and "error" not in s[key], (key, s.get(key))
+        assert isinstance(s[key]["workload"], str) and "model" not in s[key]
+    assert "BASELINE configs[0]" in s["config1_realnvp"]["workload"] and "BASELINE configs[3]" in s["config4_glow"]["workload"]
+    assert "BASELINE configs[4]" in s["config5_maf"]["workload"]
+    roofs = [s["config4_glow"]["roofline_log_prob"], s["config4_glow"]["roofline_train_step"], s["config5_maf"]["roofline_inverse_pass"],
+             s["config5_maf"]["roofline_forward_pass"], s["train_step"]["roofline"], s["nsf_wide"]["d64_h256"]["roofline"],
+             s["nsf_wide"]["d128_h128"]["roofline"]]
+    for r_ in roofs:
+        assert r_["bound"] == "mfma" and r_["unit"] == "TFLOP/s" and r_["peak"] == 157.3
+        assert 0.05 < r_["frac"] < 1.0 and abs(r_["frac"] - r_["achieved"] / r_["peak"]) < 1e-9
+    assert abs(s["config4_glow"]["roofline_log_prob"]["flop"] - 665e9) < 5e9          # 665 GFLOP per 256-image batch
+    assert s["config4_glow"]["roofline_train_step"]["flop"] == 3 * s["config4_glow"]["roofline_log_prob"]["flop"]
+    assert "FlatParameters" in s["train_step"]["optimizer"] and s["train_step"]["ms_per_step"] < 40.0
 
 
 def test_bench_two_ranks_on_one_device():
