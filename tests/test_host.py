@@ -230,6 +230,51 @@ def test_c_abi_argument_validation_training_entry_points(nfa):
     assert pm(K=4) == -95 and pm(nb=17) == -95 and pm(n=-1) == -22 and pm(table=null) == -14 and pm(n=0, table=null) == 0
     lm = lambda n=4, table=one, D=64: lib.nf_lu_factors_multi(table, i32(n), f64(1e-3), i32(D), null)
     assert lm(D=1) == -22 and lm(n=70000) == -22 and lm(table=null) == -14 and lm(n=0, table=null) == 0
+    # round 6: the one-call layer / pair backward, the pair forward, the composed LU backward and the LU stage's pack
+    for fn in ("nf_coupling_train_bwd_scratch_floats", "nf_pair_train_bwd_scratch_floats", "nf_lu_bwd_composed_scratch_floats"):
+        getattr(lib, fn).restype = ctypes.c_int64
+    per768 = 768 * 128 + 768
+    chunks = lib.nf_linear_wgrad_chunks(i64(65536), i32(768), i32(128))
+    assert chunks == 82 and lib.nf_resblock_bwd_grid(i64(65536)) == 256 and lib.nf_resblock_bwd_grid(i64(100)) == -22
+    want = 65536 * 768 + 2 * 65536 * 128 + lib.nf_final_bwd_partials(i64(65536)) * 768 + chunks * per768 \
+        + lib.nf_resblock_bwd_scratch_floats(i64(65536), i32(1)) + lib.nf_resblock_bwd_scratch_floats(i64(65536), i32(0))
+    assert lib.nf_coupling_train_bwd_scratch_floats(i64(65536), i32(2)) == want
+    assert lib.nf_pair_train_bwd_scratch_floats(i64(65536), i32(2)) == want + 65536 * 64 + 512 * (64 * 64 + 64) + 64 * 64 + 4
+    assert lib.nf_coupling_train_bwd_scratch_floats(i64(100), i32(2)) == -95 and lib.nf_coupling_train_bwd_scratch_floats(i64(128), i32(0)) == -95
+    assert lib.nf_coupling_train_bwd_scratch_floats(i64(128), i32(7)) == -95
+    assert lib.nf_lu_bwd_composed_scratch_floats(i64(65536)) == 512 * (64 * 64 + 64) and lib.nf_lu_bwd_composed_scratch_floats(i64(65)) == -22
+    two = (vp * 2)(one, one)
+    four = (vp * 4)(one, one, one, one)
+
+    def cb(B=128, D=64, H=128, nb=1, K=8, x=one, parity=0, cmap=null, nc=0, wb=two, gb=four, scratch=one):
+        return lib.nf_coupling_train_bwd(x, one, one, one, one, one, one, one, wb, one, one, one, cmap, i32(nc), one, one, one, one, one,
+                                         one, one, one, gb, scratch, i32(parity), i64(B), i32(D), i32(H), i32(nb), i32(K), f64(3.0),
+                                         f64(1e-3), f64(1e-3), f64(1e-3), null)
+    assert cb(D=32) == -95 and cb(H=64) == -95 and cb(K=4) == -95 and cb(nb=0) == -95 and cb(nb=7) == -95 and cb(B=100) == -95
+    assert cb(parity=2) == -22 and cb(cmap=one, nc=65) == -22 and cb(x=null) == -14 and cb(wb=null) == -14 and cb(scratch=null) == -14
+    assert cb(wb=(vp * 2)(one, null)) == -14 and cb(gb=(vp * 4)(one, one, null, one)) == -14
+    assert cb(scratch=vp(20)) == -22                                       # 16-byte aligned scratch (the reduction's loads)
+
+    def pb(B=128, x_in=one, Wd=one, gl=one, nb=1):
+        return lib.nf_pair_train_bwd(x_in, one, one, one, one, one, one, one, one, two, one, one, one, null, i32(0), Wd, one, one, one,
+                                     one, f64(1e-3), one, gl, one, one, one, one, one, one, one, one, one, one, four, one, i32(0),
+                                     i64(B), i32(64), i32(128), i32(nb), i32(8), f64(3.0), f64(1e-3), f64(1e-3), f64(1e-3), null)
+    assert pb(x_in=null) == -14 and pb(Wd=null) == -14 and pb(gl=null) == -14 and pb(B=100) == -95 and pb(nb=0) == -95
+
+    def pf(B=128, D=64, H=128, nb=2, K=8, x=one, xlu=one, acc=1, parity=0):
+        return lib.nf_rqs_fused_train_pair_fwd(x, xlu, one, one, one, one, one, i32(parity), i64(B), i32(D), i32(H), i32(nb), i32(K),
+                                               f64(3.0), f64(1e-3), f64(1e-3), f64(1e-3), i32(acc), null)
+    assert pf(D=32) == -95 and pf(H=64) == -95 and pf(K=16) == -95 and pf(parity=3) == -22 and pf(acc=9) == -22
+    assert pf(x=null) == -14 and pf(xlu=null) == -14 and pf(B=0) == 0
+    lc = lambda B=128, D=64, g=one, gx=one, dW=one: lib.nf_lu_bwd_composed(g, one, one, gx, dW, one, one, i64(B), i32(D), null)
+    assert lc(B=100) == -95 and lc(D=32) == -95 and lc(g=null) == -14 and lc(dW=null) == -14 and lc(gx=vp(24)) == -22
+    lp = lambda D=64, dW=one, perm=one: lib.nf_lu_param_grads_composed(dW, one, one, perm, null, i64(0), one, f64(1e-3), one, one, one,
+                                                                       i32(D), null)
+    assert lp(D=32) == -95 and lp(dW=null) == -14 and lp(perm=null) == -14
+    lt = lambda n=4, table=one, nb=2, D=64: lib.nf_lu_pack_train_multi(table, i32(n), i32(nb), i32(D), f64(1e-3), null)
+    assert lt(D=32) == -95 and lt(nb=17) == -95 and lt(n=-1) == -22 and lt(table=null) == -14 and lt(n=0, table=null) == 0
+    wp = lambda B=128, M=768, N=128, dY=one, wb=1: lib.nf_linear_wgrad_partials(dY, one, one, i64(B), i32(M), i32(N), i32(0), i32(wb), null)
+    assert wp(N=200) == -95 and wp(dY=null) == -14 and wp(wb=2) == -22 and wp(B=0) == -22
 
 
 def test_masks_bit_exact(nfa):
