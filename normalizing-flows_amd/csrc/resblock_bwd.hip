@@ -89,8 +89,17 @@ resblock_bwd_kernel(BlockBwdArgs a) {
         goff[q] = (unsigned)((row < BB_R ? row : 0) * BB_H + 4 * (c < 32 ? c : 31));
     }
     // One DMA instruction costs its wave a few hundred cycles of issue: spread through the products' MFMA streams
+    // (round 6: the request is inline asm.  As a builtin the compiler knows an LDS-DMA is pending and answers the next LDS read's
+    // wait with lgkmcnt(0) -- which defeated the hand-made look-ahead of the products below on every step that follows a request.
+    // Landing is waited for by hand anyway: BB_BARRIER_ALL.  m0 is reserved: saved and restored around the instruction.)
+    auto dma16 = [&](const float *base, uint32_t byte_off, float *dst) {
+        uint32_t m0_;
+        const uint32_t ldsa = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dst);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(m0_) : "s"(ldsa), "v"(byte_off), "s"(base) : "memory");
+    };
     auto issue_one = [&](const float *src, float *tile, int q) {
-        if (wid + BB_NW * q < BB_NI) __builtin_amdgcn_global_load_lds(src + goff[q], (lds_ptr)(tile + 256 * (wid + BB_NW * q)), 16, 0, 0);
+        if (wid + BB_NW * q < BB_NI) dma16(src, goff[q] * 4u, tile + 256 * (wid + BB_NW * q));
     };
     auto issue = [&](const float *src, float *tile) {
 #pragma unroll
@@ -98,8 +107,7 @@ resblock_bwd_kernel(BlockBwdArgs a) {
     };
     auto issue_x = [&](const float *src) {          // 64 rows x 64 floats, contiguous: 16 instructions
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-            __builtin_amdgcn_global_load_lds(src + 256 * (wid + BB_NW * q) + 4 * lane, (lds_ptr)(Xt + 256 * (wid + BB_NW * q)), 16, 0, 0);
+        for (int q = 0; q < 2; ++q) dma16(src, (uint32_t)(256 * (wid + BB_NW * q) + 4 * lane) * 4u, Xt + 256 * (wid + BB_NW * q));
     };
 
     int64_t tile = blockIdx.x;
@@ -139,7 +147,73 @@ resblock_bwd_kernel(BlockBwdArgs a) {
     BB_BARRIER_ALL();
     tcount = 1;
 
-    // out[row][16 wid + c] = sum_k A[row][k] W[k][16 wid + c] for the 64 rows of an LDS tile: C[mb][r] = row 16 mb + 4 q4 + r
+    // out[row][16 wid + c] = sum_k A[row][k] W[k][16 wid + c] for the 64 rows of an LDS tile: C[mb][r] = row 16 mb + 4 q4 + r.
+    // Round 6: software-pipelined by hand.  hipcc emitted "4 ds_read_b128 -> s_waitcnt lgkmcnt(0) -> 16 MFMAs" per Q: every one of
+    // the 8 Q steps of a product paid an LDS round trip with the matrix pipe idle unless the SIMD's other wave happened to be in its
+    // MFMAs.  Here a step is HALF a Q (two 16-row blocks: 2 reads, 8 MFMAs alternating between two accumulators, so no MFMA waits
+    // for its predecessor's 40-cycle latency) and step p + 1's operands are requested before step p's MFMAs are issued: the same 16
+    // operand registers as before, now double-buffered; the scheduling barriers keep the compiler from undoing the order.
+#ifndef NF_BB_NOPIPE
+    auto product = [&](const float *At, const float (&Wr)[32], f32x4b (&C)[4], int c, int q4, auto &&between) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) C[mb] = f32x4b{0.f, 0.f, 0.f, 0.f};
+        const float *ap = At + c * BB_P + 4 * q4;
+        f32x4 cur0 = *reinterpret_cast<const f32x4 *>(ap), cur1 = *reinterpret_cast<const f32x4 *>(ap + 16 * BB_P);
+#pragma unroll
+        for (int p_ = 0; p_ < 16; ++p_) {
+            const int Q = p_ >> 1, mp = p_ & 1;
+            f32x4 nx0 = cur0, nx1 = cur1;
+            if (p_ + 1 < 16) {
+                const int Qn = (p_ + 1) >> 1, mn = (p_ + 1) & 1;
+                nx0 = *reinterpret_cast<const f32x4 *>(ap + 16 * (2 * mn) * BB_P + 16 * Qn);
+                nx1 = *reinterpret_cast<const f32x4 *>(ap + 16 * (2 * mn + 1) * BB_P + 16 * Qn);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                C[2 * mp] = MFMA16(cur0[j], Wr[4 * Q + j], C[2 * mp]);
+                C[2 * mp + 1] = MFMA16(cur1[j], Wr[4 * Q + j], C[2 * mp + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (mp == 1) between(Q);
+            cur0 = nx0;
+            cur1 = nx1;
+        }
+    };
+    // acc[ob][ib] += A^T B over the tile's rows: A columns [32 om + 16 ob ..], B columns [64 in_ + 16 ib ..] (ReLU on B); the next
+    // four rows' six operands are requested before this step's eight MFMAs
+    auto wgrad = [&](const float *At, const float *Bt, f32x4b (&acc)[2][4], float (&bs)[2], int c, int q4) {
+        const float *ap = At + q4 * BB_P + 32 * om + c, *bp = Bt + q4 * BB_P + 64 * in_ + c;
+        float av[2], bv[4];
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob) av[ob] = ap[16 * ob];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) bv[ib] = bp[16 * ib];
+#pragma unroll 4
+        for (int kb = 0; kb < BB_R / 4; ++kb) {
+            float an[2], bn[4];
+            const int kn = kb + 1 < BB_R / 4 ? kb + 1 : kb;        // (the last step re-reads its own operands: no branch in the loop)
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) an[ob] = ap[kn * 4 * BB_P + 16 * ob];
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) bn[ib] = bp[kn * 4 * BB_P + 16 * ib];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) bv[ib] = fmaxf(bv[ib], 0.0f);
+            bs[0] += av[0];
+            bs[1] += av[1];
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) acc[ob][ib] = MFMA16(av[ob], bv[ib], acc[ob][ib]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) av[ob] = an[ob];
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) bv[ib] = bn[ib];
+        }
+    };
+#else
     auto product = [&](const float *At, const float (&Wr)[32], f32x4b (&C)[4], int c, int q4, auto &&between) {
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) C[mb] = f32x4b{0.f, 0.f, 0.f, 0.f};
@@ -156,7 +230,6 @@ resblock_bwd_kernel(BlockBwdArgs a) {
             between(Q);
         }
     };
-    // acc[ob][ib] += A^T B over the tile's rows: A columns [32 om + 16 ob ..], B columns [64 in_ + 16 ib ..] (ReLU on B)
     auto wgrad = [&](const float *At, const float *Bt, f32x4b (&acc)[2][4], float (&bs)[2], int c, int q4) {
         const float *ap = At + q4 * BB_P + 32 * om + c, *bp = Bt + q4 * BB_P + 64 * in_ + c;
 #pragma unroll 4
@@ -174,6 +247,7 @@ resblock_bwd_kernel(BlockBwdArgs a) {
                 for (int ib = 0; ib < 4; ++ib) acc[ob][ib] = MFMA16(av[ob], bv[ib], acc[ob][ib]);
         }
     };
+#endif
 
     for (; tile < ntiles; tile += grid, ++tcount) {
         const bool more = tile + grid < ntiles, first = tile == (int64_t)blockIdx.x;     // the first tile's h_in: requested above
