@@ -137,6 +137,11 @@ __device__ __forceinline__ void gc_mm128(const float *buf, int lane, f32x16 &acc
                                          const f32x16 &b2, const f32x16 &b3) {
     // (requesting the A operands two k-groups ahead of their MFMAs was measured in round 3: slower here -- with two MFMA
     // waves per SIMD the other wave covers the read latency and the extra registers cost more)
+    // Round 6: that measurement was void -- with the ring's requests issued through the builtin the compiler knew an LDS-DMA was
+    // pending and answered EVERY later LDS read with s_waitcnt lgkmcnt(0) (the loop compiled to read -> full wait -> 4 MFMAs,
+    // look-ahead or not).  With the requests as inline asm (gc_dma16) the look-ahead below is real: k-group s + 2's operand is
+    // requested before k-group s's MFMAs (-DNF_GC_NOPIPE: the plain loop).
+#ifdef NF_GC_NOPIPE
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         const f32x4 a = *reinterpret_cast<const f32x4 *>(buf + s * 256 + lane * 4);
@@ -144,6 +149,35 @@ __device__ __forceinline__ void gc_mm128(const float *buf, int lane, f32x16 &acc
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc = GC_MFMA(a[r], bs[4 * (s & 3) + r], acc);
     }
+#else
+    f32x4 a0 = *reinterpret_cast<const f32x4 *>(buf + lane * 4), a1 = *reinterpret_cast<const f32x4 *>(buf + 256 + lane * 4);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const f32x4 a = a0;
+        a0 = a1;
+        if (s + 2 < 16) a1 = *reinterpret_cast<const f32x4 *>(buf + (s + 2) * 256 + lane * 4);
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x16 &bs = (s >> 2) == 0 ? b0 : ((s >> 2) == 1 ? b1 : ((s >> 2) == 2 ? b2 : b3));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = GC_MFMA(a[r], bs[4 * (s & 3) + r], acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+}
+
+// One 16-byte-per-lane LDS-DMA request as inline asm (round 6, see gc_mm128): base = wave-uniform global pointer (SGPR pair),
+// byte_off = the lane's 32-bit offset, dst = wave-uniform LDS address.  m0 is reserved: saved and restored.  Landing is waited for
+// by the counted NF_WAIT_VMCNT of the ring's acquire, as before.
+__device__ __forceinline__ void gc_dma16(const float *base, uint32_t byte_off, float *dst) {
+    uint32_t m0_;
+    const uint32_t ldsa = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dst);
+    // (the "s" constraint alone does not make the pointer scalar: a base the compiler cannot prove wave-uniform came out as a VGPR
+    // pair in the instruction -- both halves through v_readfirstlane)
+    const uint64_t b64 = (uint64_t)(uintptr_t)base;
+    base = reinterpret_cast<const float *>((uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b64 >> 32)) << 32) |
+                                                       (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b64)));
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_) : "s"(ldsa), "v"(byte_off), "s"(base) : "memory");
 }
 
 __device__ __forceinline__ void gc_leaky(f32x16 &v, float slope) {
@@ -477,17 +511,34 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
     };
     int stage = 0;   // global stage counter (all blocks)
     constexpr int PPW = 16 / GC_NW;  // 1 KB pieces per wave
+    // Round 6: the blobs of the block in flight and of the next one are read from the level's pointer table ONCE per block and kept
+    // in scalar registers.  issue() used to read lv.blob(bb) per stage: the table lives in memory the kernel may write, so the read
+    // is a VECTOR load -- and the wait for it (vmcnt retires in order) drained every ring stage still in flight before the next
+    // request went out: the ring never ran more than one stage ahead in the level chains.
+    auto sptr = [](const float *q) -> const float * {
+        const uint64_t b64 = (uint64_t)(uintptr_t)q;
+        return reinterpret_cast<const float *>((uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b64 >> 32)) << 32) |
+                                                           (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b64)));
+    };
+    int cur_b = 0;
+    const float *blob_cur = fused ? sptr(lv.blob(0)) : blob0;
+    const float *blob_nxt = (fused && nb > 1) ? sptr(lv.blob(1)) : blob_cur;
     auto issue = [&](int gs) {
         const int bb = gs / total_stages, s = gs - bb * total_stages;
-        const float *stages = (fused ? lv.blob(bb) : blob0) + gc_off_stages(mt);
+        const float *stages = (bb == cur_b ? blob_cur : blob_nxt) + gc_off_stages(mt);
         static_assert(PPW == 2, "the paired GEMM 1 stages assume two pieces per wave");
         const float *src = (pair1 && s < nst_l1)
-                               ? stages + (size_t)(2 * s + (wid >> 2)) * GC_STAGE + ((wid & 3) * PPW) * 256 + (tid0 & 63) * 4
-                               : stages + (size_t)phys(s) * GC_STAGE + (wid * PPW) * 256 + (tid0 & 63) * 4;
+                               ? stages + (size_t)(2 * s + (wid >> 2)) * GC_STAGE + ((wid & 3) * PPW) * 256
+                               : stages + (size_t)phys(s) * GC_STAGE + (wid * PPW) * 256;
         float *dst = ring + (gs % GC_RING) * GC_STAGE + (wid * PPW) * 256;
+#ifdef NF_GC_BUILTIN_DMA
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
-            __builtin_amdgcn_global_load_lds(src + i * 256, (__attribute__((address_space(3))) void *)(dst + i * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(src + (tid0 & 63) * 4 + i * 256, (__attribute__((address_space(3))) void *)(dst + i * 256), 16, 0, 0);
+#else
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) gc_dma16(src, (uint32_t)(((tid0 & 63) * 4 + i * 256) * 4), dst + i * 256);
+#endif
     };
     // GC_RING-slot ring, DMA GC_RING - 1 stages ahead: the wait leaves the younger stages' pieces in flight (vector-memory
     // operations retire in order; anything else a wave has outstanding only makes the wait stricter).  With one stage ahead
@@ -521,11 +572,16 @@ glow_convnet_kernel(const float *__restrict__ x, int64_t xs_img, float *__restri
 
     for (int b = 0; b < nb; ++b) {
     GL_T(b, 0);
+    if (b > 0) {        // (the stream has already run on into this block's first stages through blob_nxt)
+        blob_cur = blob_nxt;
+        cur_b = b;
+        blob_nxt = (b + 1 < nb) ? sptr(lv.blob(b + 1)) : blob_cur;
+    }
     const int tid = gl_opaque(tid0), lane = tid & 63, hh = lane >> 5;
     const int px = wid * 32 + (lane & 31);
     const int li = px / HW, pin = px - li * HW, py = pin / W, pxx = pin - py * W;
     const int base0 = li * mt.Cin * PH * PW + py * PW + pxx;
-    const float *blob = fused ? lv.blob(b) : blob0;
+    const float *blob = blob_cur;
     // biases and mix of this block: prefetched (fused level; double-buffered), padded input images
     float *small = (fused && (b & 1)) ? pl.small2 : small0;
     const float *wmix = (b & 1) ? pl.wmix2 : pl.wmix;

@@ -95,6 +95,11 @@ resblock_bwd_kernel(BlockBwdArgs a) {
     auto dma16 = [&](const float *base, uint32_t byte_off, float *dst) {
         uint32_t m0_;
         const uint32_t ldsa = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dst);
+    // (the "s" constraint alone does not make the pointer scalar: a base the compiler cannot prove wave-uniform came out as a VGPR
+    // pair in the instruction -- both halves through v_readfirstlane)
+    const uint64_t b64 = (uint64_t)(uintptr_t)base;
+    base = reinterpret_cast<const float *>((uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b64 >> 32)) << 32) |
+                                                       (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b64)));
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
                      : "=&s"(m0_) : "s"(ldsa), "v"(byte_off), "s"(base) : "memory");
     };
