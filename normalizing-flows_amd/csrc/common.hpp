@@ -19,6 +19,23 @@
 #define NF_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 #endif
 
+// One 16-byte-per-lane LDS-DMA request (global_load_lds_dwordx4) as inline asm instead of __builtin_amdgcn_global_load_lds (round 6).
+// Through the builtin hipcc knows an LDS-DMA is pending and answers EVERY later LDS read of the wave with `s_waitcnt lgkmcnt(0)`:
+// product loops compile to read -> full wait -> MFMAs whatever look-ahead the source asks for.  The asm form hides the request from that
+// bookkeeping; landing is waited for by hand anyway (vmcnt + barrier in the rings' acquire).  base: wave-uniform global pointer (forced
+// into an SGPR pair: the "s" constraint alone left a VGPR pair in the instruction when the compiler could not prove uniformity),
+// byte_off: the lane's 32-bit offset, lds_dst: wave-uniform LDS address of the 1 KB piece.  m0 is reserved: saved and restored.
+#define NF_DMA16(BASE, BYTE_OFF, LDS_DST)                                                                                          \
+    do {                                                                                                                           \
+        uint32_t m0__;                                                                                                             \
+        const uint32_t ldsa__ = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(LDS_DST));                                    \
+        const uint64_t b64__ = (uint64_t)(uintptr_t)(BASE);                                                                        \
+        const uint64_t sb__ = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b64__ >> 32)) << 32) |                \
+                              (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b64__);                                           \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"      \
+                     : "=&s"(m0__) : "s"(ldsa__), "v"((uint32_t)(BYTE_OFF)), "s"(sb__) : "memory");                                \
+    } while (0)
+
 #define NF_CHECK_LAUNCH()                            \
     do {                                             \
         hipError_t e__ = hipGetLastError();          \

@@ -110,7 +110,11 @@ final_bwd_kernel(FinalBwdArgs a) {
         const float *src = a.wt + (size_t)s * FB_STG + wid * PW + lane * 4;
         float *dst = ring + (gs & 1) * FB_STG + wid * PW;
 #pragma unroll
+#ifdef NF_BUILTIN_DMA
         for (int i = 0; i < PW / 256; ++i) __builtin_amdgcn_global_load_lds(src + i * 256, (lds_ptr)(dst + i * 256), 16, 0, 0);
+#else       // round 6: requests as inline asm (common.hpp NF_DMA16): the products' operand look-ahead survives compilation
+        for (int i = 0; i < PW / 256; ++i) NF_DMA16(src - lane * 4 + i * 256, lane * 16, dst + i * 256);
+#endif
     };
     // 2-slot ring: stage s has landed for every wave; stage s + 1 is requested into the slot stage s - 1 just left.  `after`:
     // vector-memory operations this wave issued AFTER the requests of stage s (they retire in order, so they may stay in flight)
@@ -150,7 +154,11 @@ final_bwd_kernel(FinalBwdArgs a) {
         const float *base = a.cond + group_off(g, row0_);
 #pragma unroll
         for (int i = 0; i < FB_NI; ++i)
+#ifdef NF_BUILTIN_DMA
             if (piece_ok(i, row0_)) __builtin_amdgcn_global_load_lds(base + poff[i], (lds_ptr)(CS + 240 * i), 16, 0, 0);
+#else
+            if (piece_ok(i, row0_)) NF_DMA16(base, poff[i] * 4u, CS + 240 * i);
+#endif
     };
 
 #ifdef FB_TRACE
@@ -310,6 +318,7 @@ final_bwd_kernel(FinalBwdArgs a) {
                 }
 #ifndef FB_ABL_NOMFMA
                 // stage rb: k-steps v = KS rb .. KS rb + KS - 1 (B operand = the lane's gradient value v), 8 unit blocks each
+#ifdef NF_NO_PREFETCH
 #pragma unroll
                 for (int vv = 0; vv < FB_KS; ++vv) {
 #pragma unroll
@@ -319,6 +328,21 @@ final_bwd_kernel(FinalBwdArgs a) {
                         for (int j = 0; j < 4; ++j) acc[4 * uq + j] = FB_MFMA(w4[j], gq[FB_KS * rb + vv], acc[4 * uq + j]);
                     }
                 }
+#else
+                {   // the A operands two reads (8 MFMAs) ahead of their use -- real since the requests are inline asm (NF_DMA16)
+                    f32x4 w0 = *reinterpret_cast<const f32x4 *>(buf + lane * 4), w1 = *reinterpret_cast<const f32x4 *>(buf + (64 + lane) * 4);
+#pragma unroll
+                    for (int t = 0; t < 2 * FB_KS; ++t) {
+                        const f32x4 w4 = w0;
+                        w0 = w1;
+                        if (t + 2 < 2 * FB_KS) w1 = *reinterpret_cast<const f32x4 *>(buf + ((t + 2) * 64 + lane) * 4);
+                        __builtin_amdgcn_sched_barrier(0);   // keeps the request in FRONT of the k-group's MFMAs (without it: +0.5 % lost again)
+                        const int vv = t >> 1, uq = t & 1;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[4 * uq + j] = FB_MFMA(w4[j], gq[FB_KS * rb + vv], acc[4 * uq + j]);
+                    }
+                }
+#endif
 #else
                 (void)buf;
 #pragma unroll

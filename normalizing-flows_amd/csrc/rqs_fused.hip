@@ -329,19 +329,27 @@ pack_lu_train_multi_kernel(const void *const *__restrict__ table, float eps, int
 // (optionally through ReLU): 16 ds_read_b128 + 64 MFMA.
 // HB: hidden row-blocks in use (4 = 128 units; 2 / 1 = layers of <= 64 / <= 32 hidden units packed into the same 128-unit
 // blob: the units beyond are zero rows / columns, so their k-groups and row-blocks are skipped -- exactly, not approximately).
-template <bool RELU, int HB = 4>
+template <bool RELU, int HB = 4, int LA = 2>
 __device__ __forceinline__ void mm128(const float *buf, int lane, f32x16 &acc, const f32x16 &b0, const f32x16 &b1,
                                       const f32x16 &b2, const f32x16 &b3) {
 #ifdef NF_EXP_SETPRIO
     __builtin_amdgcn_s_setprio(1);
 #endif
-#ifdef NF_EXP_PREFETCH
-    // A operand one k-group ahead of its use
-    f32x4 a_next = *reinterpret_cast<const f32x4 *>(buf + lane * 4);
+#ifndef NF_NO_PREFETCH
+    // A operands two k-groups ahead of their use (real since round 6: see NF_DMA16)
+    // LA = 1: one k-group ahead (the instantiations that sit at the 256-register limit: 8 registers fewer)
+    f32x4 a0 = *reinterpret_cast<const f32x4 *>(buf + lane * 4), a1 = a0;
+    if (LA == 2) a1 = *reinterpret_cast<const f32x4 *>(buf + 256 + lane * 4);
 #pragma unroll
     for (int s = 0; s < 4 * HB; ++s) {
-        const f32x4 a = a_next;
-        if (s + 1 < 4 * HB) a_next = *reinterpret_cast<const f32x4 *>(buf + (s + 1) * 256 + lane * 4);
+        const f32x4 a = a0;
+        if (LA == 2) {
+            a0 = a1;
+            if (s + 2 < 4 * HB) a1 = *reinterpret_cast<const f32x4 *>(buf + (s + 2) * 256 + lane * 4);
+        } else if (s + 1 < 4 * HB) {
+            a0 = *reinterpret_cast<const f32x4 *>(buf + (s + 1) * 256 + lane * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keeps the request in FRONT of the k-group's MFMAs (without it: +0.5 % lost again)
 #else
 #pragma unroll
     for (int s = 0; s < 4 * HB; ++s) {
@@ -422,6 +430,8 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
                  float *__restrict__ cond_out = nullptr, float unscale = 1.0f, float *__restrict__ act_out = nullptr,
                  float *__restrict__ xlu_out = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // operand look-ahead of the products (mm128): two k-groups where the registers allow it
+    constexpr int LA = (HB == 4 && !(DIR == 0 && LU) && TRAIN == 0) ? 1 : 2;
     static_assert(KB == 4 || KB == 8 || KB == 16, "bins");
     static_assert(!TRAIN || (KB == F_K && DIR == 0 && (!LU || TRAIN == 2)),
                   "the training variants: 8 bins, density direction; the fused LU only with the whole-layer forward (TRAIN = 2)");
@@ -470,16 +480,26 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
         const int layer = gs / nstages, s = gs - layer * nstages;
         const float *src = fa.blob[layer] + lay.off_stages() + (size_t)phys(s) * F_STAGE + (wid * PPW) * 256 + lane * 4;
         float *dst = ring + (gs & 1) * F_STAGE + (wid * PPW) * 256;
+#ifdef NF_BUILTIN_DMA
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
             __builtin_amdgcn_global_load_lds(src + i * 256, (__attribute__((address_space(3))) void *)(dst + i * 256), 16, 0, 0);
+#else
+        // round 6: requests as inline asm (common.hpp NF_DMA16) so that the products' operand look-ahead survives compilation
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) NF_DMA16(src - lane * 4 + i * 256, lane * 16, dst + i * 256);
+#endif
     };
     auto issue_small = [&](int layer) {  // small section of `layer` -> LDS buffer layer & 1 (1 KB pieces round-robin)
         const float *src = fa.blob[layer] + F_HDR;
         float *dst = small2 + (layer & 1) * small_pitch;
+#ifdef NF_BUILTIN_DMA
         for (int piece = wid; piece * 256 < small_pitch; piece += F_NW)
             __builtin_amdgcn_global_load_lds(src + piece * 256 + lane * 4,
                                              (__attribute__((address_space(3))) void *)(dst + piece * 256), 16, 0, 0);
+#else
+        for (int piece = wid; piece * 256 < small_pitch; piece += F_NW) NF_DMA16(src + piece * 256, lane * 16, dst + piece * 256);
+#endif
     };
     // `after`: vector-memory operations (training stores) this wave issued AFTER the requests of the stage it now waits for;
     // they retire in order, so they may stay in flight.  Only trusted for full tiles (every store instruction of the wave
@@ -697,12 +717,12 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
             const float *buf = acquire();
             if (blk == 0) store_xlu();
             store_act(2 * blk, H0, H1, H2, H3);         // the block's input (blk = 0: the initial layer's output)
-            mm128<true, HB>(buf, lane, T0, H0, H1, H2, H3);
+            mm128<true, HB, LA>(buf, lane, T0, H0, H1, H2, H3);
         }
-        if constexpr (HB >= 2) mm128<true, HB>(acquire(), lane, T1, H0, H1, H2, H3);
+        if constexpr (HB >= 2) mm128<true, HB, LA>(acquire(), lane, T1, H0, H1, H2, H3);
         if constexpr (HB == 4) {
-            mm128<true, HB>(acquire(), lane, T2, H0, H1, H2, H3);
-            mm128<true, HB>(acquire(), lane, T3, H0, H1, H2, H3);
+            mm128<true, HB, LA>(acquire(), lane, T2, H0, H1, H2, H3);
+            mm128<true, HB, LA>(acquire(), lane, T3, H0, H1, H2, H3);
         }
         {
             const float *bsrc = small + lay.off_bias_hidden(2 * blk + 1) + hh * 16;
@@ -713,11 +733,11 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
         }
 #ifdef NF_EXP_RELU_PER_USE
         store_act(1 + 2 * blk, T0, T1, T2, T3);
-        mm128<true, HB>(acquire(), lane, H0, T0, T1, T2, T3);
-        if constexpr (HB >= 2) mm128<true, HB>(acquire(), lane, H1, T0, T1, T2, T3);
+        mm128<true, HB, LA>(acquire(), lane, H0, T0, T1, T2, T3);
+        if constexpr (HB >= 2) mm128<true, HB, LA>(acquire(), lane, H1, T0, T1, T2, T3);
         if constexpr (HB == 4) {
-            mm128<true, HB>(acquire(), lane, H2, T0, T1, T2, T3);
-            mm128<true, HB>(acquire(), lane, H3, T0, T1, T2, T3);
+            mm128<true, HB, LA>(acquire(), lane, H2, T0, T1, T2, T3);
+            mm128<true, HB, LA>(acquire(), lane, H3, T0, T1, T2, T3);
         }
 #else
         const float *buf2 = acquire();
@@ -730,11 +750,11 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
             T2[c] = fmaxf(T2[c], 0.0f);
             T3[c] = fmaxf(T3[c], 0.0f);
         }
-        mm128<false, HB>(buf2, lane, H0, T0, T1, T2, T3);
-        if constexpr (HB >= 2) mm128<false, HB>(acquire(), lane, H1, T0, T1, T2, T3);
+        mm128<false, HB, LA>(buf2, lane, H0, T0, T1, T2, T3);
+        if constexpr (HB >= 2) mm128<false, HB, LA>(acquire(), lane, H1, T0, T1, T2, T3);
         if constexpr (HB == 4) {
-            mm128<false, HB>(acquire(), lane, H2, T0, T1, T2, T3);
-            mm128<false, HB>(acquire(), lane, H3, T0, T1, T2, T3);
+            mm128<false, HB, LA>(acquire(), lane, H2, T0, T1, T2, T3);
+            mm128<false, HB, LA>(acquire(), lane, H3, T0, T1, T2, T3);
         }
 #endif
 #ifdef NF_EXP_RELU_PER_USE
@@ -810,9 +830,9 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     {   // group 0: MFMAs only
         const float *bsrc = small + lay.off_bias_final() + hh * 16;
         f32x16 A0 = load_bias16(bsrc), A1 = load_bias16(bsrc + 32), A2 = load_bias16(bsrc + 64);
-        mm128<false>(acquire(), lane, A0, H0, H1, H2, H3);
-        mm128<false>(acquire(), lane, A1, H0, H1, H2, H3);
-        mm128<false>(acquire(), lane, A2, H0, H1, H2, H3);
+        mm128<false, 4, LA>(acquire(), lane, A0, H0, H1, H2, H3);
+        mm128<false, 4, LA>(acquire(), lane, A1, H0, H1, H2, H3);
+        mm128<false, 4, LA>(acquire(), lane, A2, H0, H1, H2, H3);
         extract(A0, A1, A2);
     }
     for (int g = 1; g < 8; ++g) {
@@ -820,19 +840,19 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
         f32x16 A0 = load_bias16(bsrc), A1 = load_bias16(bsrc + 32), A2 = load_bias16(bsrc + 64);
         {
             const float *buf = acquire();
-            mm128<false>(buf, lane, A0, H0, H1, H2, H3);
+            mm128<false, 4, LA>(buf, lane, A0, H0, H1, H2, H3);
             element(g - 1, 0);
             NF_SCHED_PIPE();
         }
         {
             const float *buf = acquire();
-            mm128<false>(buf, lane, A1, H0, H1, H2, H3);
+            mm128<false, 4, LA>(buf, lane, A1, H0, H1, H2, H3);
             element(g - 1, 1);
             NF_SCHED_PIPE();
         }
         {
             const float *buf = acquire();
-            mm128<false>(buf, lane, A2, H0, H1, H2, H3);
+            mm128<false, 4, LA>(buf, lane, A2, H0, H1, H2, H3);
             if (DIR == 0) uncond_group(g - 1);
             NF_SCHED_PIPE();
         }
@@ -857,10 +877,10 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
                 store_act(2 * nblk, H0, H1, H2, H3);
             }
 #endif
-            mm128<false, HB>(buf, lane, A0, H0, H1, H2, H3);
+            mm128<false, HB, LA>(buf, lane, A0, H0, H1, H2, H3);
         }
-        mm128<false, HB>(acquire(), lane, A1, H0, H1, H2, H3);
-        mm128<false, HB>(acquire(), lane, A2, H0, H1, H2, H3);
+        mm128<false, HB, LA>(acquire(), lane, A1, H0, H1, H2, H3);
+        mm128<false, HB, LA>(acquire(), lane, A2, H0, H1, H2, H3);
         extract(A0, A1, A2);
 #ifdef NF_ABL_NOCOND
         if constexpr (false) {
