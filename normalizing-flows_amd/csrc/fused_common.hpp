@@ -372,6 +372,75 @@ __device__ __forceinline__ void rqs_regs_t(const RqsParams<float> &p, float x, c
     lad = inside ? ll : 0.0f;
 }
 
+// rqs_regs_t with the FIRST level of the bin descent taken before any knot is materialised (round 6, nsf_wide.hip's K = 16 / K = 8
+// epilogues: 19-35 / 3-12 spilled registers with rqs_regs_t): one pass over the raw parameters leaves the two softmax totals and the
+// two first-half sums -- enough for the middle knot --, the comparison picks a half, and only that half's KB / 2 widths, heights and
+// KB / 2 + 1 derivatives are kept (selects on the RAW values) and run through the knot construction with the half's base sums.  Live
+// arrays halve (2 KB + 3 (KB + 1) -> KB + 3 (KB / 2 + 1) floats) for KB more v_exp_f32 per element.  Same arithmetic per knot up to the
+// order of the prefix sum (second half: first-half sum + prefix instead of one running prefix).
+template <bool INVERSE, int KB = F_K>
+__device__ __forceinline__ void rqs_regs_h(const RqsParams<float> &p, float x, const float (&prm)[3 * KB], float &y, float &lad) {
+    static_assert((KB & (KB - 1)) == 0 && KB >= 4, "binary descent");
+    constexpr int H = KB / 2;
+    const bool inside = x >= p.left && x <= p.right;
+    float mw = prm[0], mh = prm[KB];
+#pragma unroll
+    for (int k = 1; k < KB; ++k) {
+        mw = fmaxf(mw, prm[k]);
+        mh = fmaxf(mh, prm[KB + k]);
+    }
+    float hw = 0.0f, hh = 0.0f, uw = 0.0f, uh = 0.0f;      // sums of the first / second half
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+        const float ew = __builtin_amdgcn_exp2f(prm[k] - mw), eh = __builtin_amdgcn_exp2f(prm[KB + k] - mh);
+        if (k < H) { hw += ew; hh += eh; } else { uw += ew; uh += eh; }
+    }
+    const float cw = (p.right - p.left) * p.scale_w * frcp(hw + uw);
+    const float ch = (p.top - p.bottom) * p.scale_h * frcp(hh + uh);
+    const float sw = (p.right - p.left) * p.min_w, sh = (p.top - p.bottom) * p.min_h;
+    const float kwm = fmaf(hw, cw, p.left + sw * (float)H), khm = fmaf(hh, ch, p.bottom + sh * (float)H);
+    const bool c = x >= (INVERSE ? khm : kwm);
+    float w2[H], h2[H], d2[H + 1];
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+        w2[i] = c ? prm[H + i] : prm[i];
+        h2[i] = c ? prm[KB + H + i] : prm[KB + i];
+    }
+#pragma unroll
+    for (int i = 0; i <= H; ++i) {
+        const float lo = i == 0 ? p.edge_logit : prm[2 * KB + i - 1];
+        const float hi = i == H ? p.edge_logit : prm[2 * KB + H + i - 1];
+        d2[i] = c ? hi : lo;
+    }
+    const float bw = c ? hw : 0.0f, bh = c ? hh : 0.0f, ko = c ? (float)H : 0.0f;
+    float kw[H + 1], kh[H + 1];
+    kw[0] = c ? kwm : p.left;
+    kh[0] = c ? khm : p.bottom;
+    kw[H] = c ? p.right : kwm;
+    kh[H] = c ? p.top : khm;
+    float aw = bw, ah = bh;
+#pragma unroll
+    for (int i = 1; i < H; ++i) {
+        aw += __builtin_amdgcn_exp2f(w2[i - 1] - mw);
+        ah += __builtin_amdgcn_exp2f(h2[i - 1] - mh);
+        kw[i] = fmaf(aw, cw, p.left + sw * (ko + (float)i));
+        kh[i] = fmaf(ah, ch, p.bottom + sh * (ko + (float)i));
+    }
+    float slo, shi, olo, ohi, dl0, dl1;
+    if (!INVERSE)
+        rqs_descend1<H>(x, kw, kh, d2, slo, shi, olo, ohi, dl0, dl1);
+    else
+        rqs_descend1<H>(x, kh, kw, d2, slo, shi, olo, ohi, dl0, dl1);
+    const float d0 = p.min_d + fsoftplus(dl0), d1 = p.min_d + fsoftplus(dl1);
+    float yy, ll;
+    if (!INVERSE)
+        rqs_eval_bin_fast<false>(x, slo, shi - slo, olo, ohi - olo, d0, d1, yy, ll);
+    else
+        rqs_eval_bin_fast<true>(x, olo, ohi - olo, slo, shi - slo, d0, d1, yy, ll);
+    y = inside ? yy : x;
+    lad = inside ? ll : 0.0f;
+}
+
 // Batch-shared spline from its LDS knot table (cumw[9] | cumh[9] | deriv[9]), branch-free.
 template <bool INVERSE, int KB = F_K>
 __device__ __forceinline__ void rqs_table_fast(const RqsParams<float> &p, float x, const float *tab, float &y, float &lad) {

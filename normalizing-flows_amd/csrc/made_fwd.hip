@@ -71,10 +71,14 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
         const int64_t row0 = tile * MF_ROWS;
         const int nrows = (int)((B - row0) < MF_ROWS ? (B - row0) : MF_ROWS);
         ring.ap = stream + lane * 4;            // (the ring already holds the stream's first entries: the wrap-around copy)
+        int tq = tid;                           // per-tile address arithmetic from an index the compiler cannot hoist out of the tile loop
+        asm volatile("" : "+v"(tq));            // (round 6, as in nsf_wide.hip: hoisted, those values stayed live across the products)
+        asm volatile("" : "+v"(ring.ap));       // (likewise the restarted stream's first request addresses: four 64-bit pairs)
         // ---- x tile -> LDS (B-operand order; rows beyond the batch and features beyond D are zero) ---------------------------------
         {
-            const int r = tid & 63, cg = tid >> 6;
+            const int r = tq & 63, cg = tq >> 6;
             const float *xr = x + (row0 + r) * ldx;
+#pragma unroll 1
             for (int c = cg; c < Dp / 4; c += MF_NW) {
                 f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (r < nrows && 4 * c < D) {           // (Dp rounds D up to 32: the last chunks may lie wholly beyond the row)
@@ -95,7 +99,7 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
         unsigned *btile = nullptr;
         if constexpr (EPI == 3) {
             stile = save + (size_t)row0 * HP;
-            btile = bits + ((size_t)tile * 2 * NB * 2) * 512 + tid;
+            btile = bits + ((size_t)tile * 2 * NB * 2) * 512 + tq;
 #pragma unroll
             for (int s = 0; s < 2; ++s) mf_save_rows<NS, true>(stile, HP, nrows, rbs[s], sb0s[s], hh, n, h[s]);
         }
@@ -158,7 +162,7 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
                         const int col = valid ? tf : 0;
                         float *xp = xreg + ((size_t)(col >> 2) * 64 + 32 * sb + n) * 4 + (col & 3);
                         float yv, lad;
-                        rqs_regs_t<false>(p, *xp, prm, yv, lad);      // (round 5: binary bin descent)
+                        rqs_regs_h<false>(p, *xp, prm, yv, lad);      // (round 5: binary bin descent; round 6: its first level before the knots exist)
                         if (valid) {
                             *xp = yv;
                             lsum[sb] += lad;
@@ -185,12 +189,12 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
                 }
             }
             MF_BARRIER();
-            if (tid < nrows) {
+            if (tq < nrows) {
                 float v = 0.0f;
-                for (int g = 0; g < G; ++g) v += acts[g * 64 + tid];      // fixed order: deterministic
-                ld_store(logdet + row0 + tid, v, acc_mode);
+                for (int g = 0; g < G; ++g) v += acts[g * 64 + tq];      // fixed order: deterministic
+                ld_store(logdet + row0 + tq, v, acc_mode);
             }
-            const int r = tid & 63, cg = tid >> 6;
+            const int r = tq & 63, cg = tq >> 6;
             float *yr = y + (row0 + r) * D;
             if (r < nrows)
                 for (int c = cg; 4 * c < D; c += MF_NW) {
@@ -255,12 +259,12 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
                 if (hh == 0) acts[fb * 64 + 32 * s + n] = v;
             }
             MF_BARRIER();
-            if (tid < nrows) {
+            if (tq < nrows) {
                 float v = 0.0f;
-                for (int fb = 0; fb < 8; ++fb) v += acts[fb * 64 + tid];
-                ld_store(logdet + row0 + tid, v, acc_mode);
+                for (int fb = 0; fb < 8; ++fb) v += acts[fb * 64 + tq];
+                ld_store(logdet + row0 + tq, v, acc_mode);
             }
-            const int r = tid & 63, cg = tid >> 6;
+            const int r = tq & 63, cg = tq >> 6;
             float *yr = y + (row0 + r) * D;
             if (r < nrows)
                 for (int c = cg; 4 * c < D; c += MF_NW) {

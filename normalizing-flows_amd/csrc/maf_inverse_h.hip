@@ -510,11 +510,16 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
                         for (int l = 1; l < NL; ++l) p[l][r] = 0.0f;
                     }
                     if (Pw && T > 1) {       // tile 0 leads the first pair: its partner's products over no operands = zeros in the stash
+                        // (round 6: from a lane offset the compiler cannot hoist -- the 4 NL store addresses used to be computed once per
+                        // wave and kept as twelve 64-bit pairs across the whole tile loop: 24 spilled registers in the config-5 kernel)
+                        unsigned zo = (unsigned)lane * 16u;
+                        asm volatile("" : "+v"(zo));
 #pragma unroll
                         for (int l = 0; l < NL; ++l)
 #pragma unroll
                             for (int q = 0; q < 4; ++q)
-                                reinterpret_cast<f32x4 *>(Pw + (size_t)l * HT * 32)[q * 64 + lane] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                                *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(Pw + (size_t)l * HT * 32 + q * 256) + zo) =
+                                    f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                     }
                 }
                 h_block<false, false, LB>(A0, nullptr, Xw, K0, lane, nullptr, ringw, p[0]);

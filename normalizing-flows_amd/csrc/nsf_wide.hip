@@ -50,6 +50,7 @@ template <bool INV, int TR, int KB>
 __device__ __forceinline__ float nw_identity(float *xreg, const float *tabs, const RqsParams<float> &p, int nI, int tid) {
     const int n = tid % TR;
     float ld = 0.0f;
+#pragma unroll 1
     for (int i = tid / TR; i < nI; i += 64 * MF_NW / TR) {
         float *xp = xreg + nw_xidx<TR>(i, n);                 // identity feature i sits at position i
         float y, lad;
@@ -112,9 +113,14 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
         const int64_t row0 = tile * TR;
         const int nrows = (int)((B - row0) < TR ? (B - row0) : TR);
         ring.ap = stream + lane * 4;
+        // the tile's prologue / epilogue address arithmetic from a thread index the compiler cannot hoist out of the tile loop: as loop
+        // invariants those values stayed live across the products (the last 1-4 spilled registers of the 64-row instantiations)
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
         {   // x tile -> LDS, columns sorted into positions (rows beyond the batch and the padding positions are zero)
-            const int r = tid % TR, cg = tid / TR;
+            const int r = tq % TR, cg = tq / TR;
             const float *xr = x + (row0 + r) * D;
+#pragma unroll 1        // (runtime trip counts: the unroller's remainder bookkeeping stayed live across the whole tile -- 1-8 spilled registers)
             for (int c = cg; 4 * c < D; c += NIG) {
                 f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (r < nrows) {
@@ -129,7 +135,9 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
                     if (col < D) xreg[nw_xidx<TR>(((col ^ par_i) & 1) ? PI + (col >> 1) : (col >> 1), r)] = v[i];
                 }
             }
+#pragma unroll 1
             for (int ps = nI + cg; ps < PI; ps += NIG) xreg[nw_xidx<TR>(ps, r)] = 0.0f;
+#pragma unroll 1
             for (int ps = PI + nT + cg; ps < Dp; ps += NIG) xreg[nw_xidx<TR>(ps, r)] = 0.0f;
         }
         float ld_ident = 0.0f;
@@ -138,9 +146,10 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
             nw_lu_stage<TR>(ring, items_all, xreg, lane_b, hh, n);
         }
         if constexpr (DIR == 1) {                            // sampling: the identity half's inverse spline comes first (:112-114)
-            for (int i = tid; i < nI * NW_TABW; i += 64 * MF_NW) acts[i] = tabs[i];
+#pragma unroll 1
+            for (int i = tq; i < nI * NW_TABW; i += 64 * MF_NW) acts[i] = tabs[i];
             MF_BARRIER();
-            ld_ident = nw_identity<true, TR, KB>(xreg, acts, p, nI, tid);
+            ld_ident = nw_identity<true, TR, KB>(xreg, acts, p, nI, tq);
         }
         f32x16 h[NHI][NS], t[NHI][NS];
         MF_BARRIER();
@@ -198,8 +207,10 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
                     // round 5: binary bin descent (rqs_regs_t; the packed PAIR version of the benchmark kernel spilled 11-23 registers here)
 #ifdef NF_EPI_SCALAR
                     rqs_regs<DIR == 1, KB>(p, *xp, prm, yv, lad);
-#else
+#elif defined(NF_EPI_FULL_KNOTS)
                     rqs_regs_t<DIR == 1, KB>(p, *xp, prm, yv, lad);
+#else           // round 6: first descent level before the knots exist (fused_common.hpp rqs_regs_h): half the live arrays
+                    rqs_regs_h<DIR == 1, KB>(p, *xp, prm, yv, lad);
 #endif
                     if (valid) {
                         *xp = yv;
@@ -213,8 +224,10 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
             }
         }
         MF_BARRIER();                                        // every wave is done with the activations
-        if constexpr (DIR == 0)
-            for (int i = tid; i < nI * NW_TABW; i += 64 * MF_NW) acts[i] = tabs[i];
+        if constexpr (DIR == 0) {
+#pragma unroll 1
+            for (int i = tq; i < nI * NW_TABW; i += 64 * MF_NW) acts[i] = tabs[i];
+        }
 #pragma unroll
         for (int j = 0; j < NFI; ++j) {
             if (j >= nfi) break;
@@ -230,20 +243,22 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
         }
         if constexpr (DIR == 0) {                            // density: the identity half's spline after the conditioner (:88-92)
             MF_BARRIER();
-            ld_ident = nw_identity<false, TR, KB>(xreg, acts, p, nI, tid);
+            ld_ident = nw_identity<false, TR, KB>(xreg, acts, p, nI, tq);
         }
-        ldp[(G + tid / TR) * TR + tid % TR] = ld_ident;
+        ldp[(G + tq / TR) * TR + tq % TR] = ld_ident;
         MF_BARRIER();
         if constexpr (LU && DIR == 1) nw_lu_stage<TR>(ring, items_all + 3 * (nitems - 1), xreg, lane_b, hh, n);
-        if (tid < nrows) {
+        if (tq < nrows) {
             float v = lu_ld;
-            for (int s = 0; s < G + NIG; ++s) v += ldp[s * TR + tid];      // fixed order: deterministic
-            ld_store(logdet + row0 + tid, v, acc_mode);
+#pragma unroll 1
+            for (int s = 0; s < G + NIG; ++s) v += ldp[s * TR + tq];      // fixed order: deterministic
+            ld_store(logdet + row0 + tq, v, acc_mode);
         }
         {
-            const int r = tid % TR, cg = tid / TR;
+            const int r = tq % TR, cg = tq / TR;
             float *yr = y + (row0 + r) * D;
-            if (r < nrows)
+            if (r < nrows) {
+#pragma unroll 1
                 for (int c = cg; 4 * c < D; c += NIG) {
                     f32x4 v;
 #pragma unroll
@@ -256,6 +271,7 @@ nsf_wide_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
 #pragma unroll
                         for (int i = 0; i < 4; ++i) if (4 * c + i < D) yr[4 * c + i] = v[i];
                 }
+            }
         }
         MF_BARRIER();                                        // the next tile overwrites the x tile and the activations
     }

@@ -1201,7 +1201,18 @@ def test_nsf_wide_one_launch_vs_layerwise_and_oracle(nfa, oracle, D, H, NB, rev,
         finally:
             nfa.config.set_nsf_wide(True)
         assert_close(N(z1), N(z0), what=name + " z", rtol=2e-5, atol=2e-5)
-        assert_close(N(ld1), N(ld0), what=name + " ld", rtol=1e-4, atol=1e-4)
+        # log-det: 1e-4 on every row but at most one in 250 -- a row with an element in a bin whose slope is several hundred
+        # carries the float32 rounding of its knots amplified into the log-derivative: [66-512-3-False-257-8], sampling
+        # direction, row 52 (tools/wide_row_diag.py, profiles/r06_wide_row_diag.txt): float64 evaluation of the same layer
+        # -36.351265; layer-wise float32 -36.354618 (3.4e-3 off); the kernel with round 5's knot construction -36.352871
+        # (1.6e-3 off), with round 6's (rqs_regs_h: the second half of the softmax summed on top of the first half's sum)
+        # -36.347443 (3.8e-3 off) -- every float32 path is a few 1e-3 from the truth there, on different sides.  Such rows stay
+        # within 2e-2 of each other.
+        l1, l0 = N(ld1), N(ld0)
+        off = ~np.isclose(l1, l0, rtol=1e-4, atol=1e-4, equal_nan=True)
+        assert int(off.sum()) <= max(1, B // 250), (name, int(off.sum()), np.nonzero(off)[0][:8])
+        assert_close(l1[~off], l0[~off], what=name + " ld", rtol=1e-4, atol=1e-4)
+        assert_close(l1[off], l0[off], what=name + " ld (amplified rows)", rtol=2e-2, atol=2e-2)
         z2, ld2 = fn(x)
         assert torch.equal(torch.nan_to_num(z1), torch.nan_to_num(z2)) and torch.equal(torch.nan_to_num(ld1), torch.nan_to_num(ld2))   # deterministic
         acc = torch.full((B,), -1.5, device=DEV)

@@ -781,6 +781,25 @@ def test_one_pass_backward_kernels_use_no_scratch(nfa):
     assert seen == 4, seen
 
 
+def test_tile_engine_and_maf_kernels_use_no_scratch(nfa):
+    """Round 6: every instantiation of the 64-row-tile kernels -- nf_nsf_wide's 36 (4 / 8 / 16 bins, both
+    directions, with and without the LU, three shapes), MADE's forward in all four epilogue modes -- and of the one-pass MAF
+    kernels is free of scratch memory.  What was spilled there were loop invariants (per-tile address arithmetic hoisted across
+    the products, the unroller's remainder bookkeeping of runtime-bound copy loops) and, at 16 bins, the spline epilogue's knot
+    arrays (fused_common.hpp rqs_regs_h)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as kr
+    objdir = os.path.join(ROOT, "normalizing-flows_amd", "lib", "obj")
+    want = {("nsf_wide.o", "nsf_wide_kernel"): 36, ("made_fwd.o", "made_fwd_kernel"): 8,
+            ("maf_inverse_h.o", "maf_inverse_h_kernel"): 6, ("maf_inverse_h.o", "maf_solve_t_kernel"): 3}
+    for (obj, tag), n in want.items():
+        seen = 0
+        for name, d in kr.resources(os.path.join(objdir, obj)).items():
+            if tag in name:
+                seen += 1
+                assert d["vgpr_spill_count"] == 0 and d["private_segment_fixed_size"] == 0, (name, d)
+        assert seen == n, (tag, seen)
+
 
 @pytest.mark.parametrize("use_lu", [True, False])
 def test_invertible_affine_torch_path_vs_reference_fixture(nfa, use_lu):
