@@ -461,6 +461,23 @@ int nf_pair_train_bwd(const void *x_in, const void *xlu, const void *grad_y, con
                       void *g_uw, void *g_uh, void *g_ud, void *const *g_blocks, void *scratch, int mask_parity, int64_t B, int D,
                       int hidden, int num_blocks, int K, double tail_bound, double min_bin_width, double min_bin_height,
                       double min_derivative, nf_stream_t stream);
+/* nf_pair_train_bwd in two calls (round 6, late; replaces nothing in the reference -- `loss.backward()` of core.py:87-102 has no such
+ * boundary): _head issues the five launches the NEXT pair's backward waits for (the pair's input gradient) and fills `tail`
+ * (NF_PAIR_TAIL_BYTES of HOST memory, opaque) with what the last two launches need; _tail issues those two -- the reduction of every
+ * partial tile and the LU's factor gradients, which only produce PARAMETER gradients -- on any stream the caller has ordered behind
+ * _head's (event fork).  On a side stream they run under the next pair's MFMA-bound kernels (autograd.PairTrainFn).  `scratch`, the
+ * saved rows and every gradient destination stay in use until _tail's launches have run; a gradient may be read only on a stream
+ * ordered behind them.  _head followed by _tail on one stream is exactly nf_pair_train_bwd (same seven launches, same bits). */
+#define NF_PAIR_TAIL_BYTES 2048
+int nf_pair_train_bwd_head(const void *x_in, const void *xlu, const void *grad_y, const void *grad_logdet, const void *cond24,
+                           const void *acts, const void *w_t, const void *wpack, const void *wfull_t, const void *const *w_blocks,
+                           const void *uw, const void *uh, const void *ud, const void *col_map, int n_cols, const void *Wd,
+                           const void *Lm, const void *Um, const int64_t *perm, const void *unconstrained_upper_diag, double lu_eps,
+                           void *grad_x_in, void *g_lower, void *g_upper, void *g_udiag, void *g_lbias, void *g_w0, void *g_b0,
+                           void *g_wf, void *g_bf, void *g_uw, void *g_uh, void *g_ud, void *const *g_blocks, void *scratch,
+                           int mask_parity, int64_t B, int D, int hidden, int num_blocks, int K, double tail_bound,
+                           double min_bin_width, double min_bin_height, double min_derivative, void *tail, nf_stream_t stream);
+int nf_pair_train_bwd_tail(const void *tail, nf_stream_t stream);
 int64_t nf_resblock_bwd_scratch_floats(int64_t B, int with_init);
 int nf_resblock_bwd(const void *gh, const void *t, const void *h_in, const void *W1, const void *W2, void *gh_in, void *dW1,
                     void *db1, void *dW2, void *db2, const void *x, const void *wfull, void *gx, void *dW0, void *db0,

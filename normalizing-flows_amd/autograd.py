@@ -18,6 +18,7 @@ import torch
 from torch.autograd.function import once_differentiable
 
 from . import _gradbuf
+from . import _sidestream
 from . import _lib as L
 from . import config as _config
 from . import ops
@@ -553,10 +554,23 @@ class PairTrainFn(torch.autograd.Function):
                     upper=_gradbuf.out(upper), udiag=_gradbuf.out(udiag), lbias=_gradbuf.out(lbias))
         D = x.shape[1]
         Lm, Um = lu_fbuf[:D * D].view(D, D), lu_fbuf[D * D:2 * D * D].view(D, D)
+        # The last two of the seven launches only produce parameter gradients: on the side stream when nobody can read them before the
+        # join at the end of this backward pass (_sidestream.py) -- every gradient goes into a registered buffer that autograd will
+        # adopt as .grad without a kernel (no existing .grad to accumulate into) and no tensor hook looks at it on the way.
+        side = None
+        if _config.train_reduce_async:
+            params = (w0, b0, wf, bf, uw, uh, ud, lower, upper, udiag, lbias) + tuple(blk)
+            if all(_gradbuf.target(p_) is not None and _sidestream.nobody_reads_early(p_) for p_ in params):
+                side = _sidestream.stream(x.device)
         # ONE C-ABI call, seven launches: the coupling's four passes, the composed LU's pass, one reduction for both, the LU's factors
+        # (two calls when the last two launches go to the side stream)
         gx = ops.pair_train_bwd(x, xlu, gy, gld_own, cond24, acts, ctx.wpad, ctx.blob, ctx.wfull,
                                 [blk[4 * b + j].detach() for b in range(nb) for j in (0, 2)], uw.detach(), uh.detach(), ud.detach(),
-                                kw["col_map"], iidx.numel(), ctx.parity, nb, lu_wd, Lm, Um, perm, udiag.detach(), lu_eps, dest, **fk)
+                                kw["col_map"], iidx.numel(), ctx.parity, nb, lu_wd, Lm, Um, perm, udiag.detach(), lu_eps, dest, side=side,
+                                **fk)
+        if side is not None:
+            _sidestream.mark(x.device)
+            _sidestream.queue_join()
         g_lower, g_upper, g_udiag, g_lbias = dest["lower"], dest["upper"], dest["udiag"], dest["lbias"]
         return (gx, None, g_lower, g_upper, g_udiag, g_lbias, None, None, None, dest["w0"], dest["b0"], dest["wf"], dest["bf"],
                 dest["uw"], dest["uh"], dest["ud"], None, None, None, None, None, None, None, (gld if ctx.has_acc else None), None,

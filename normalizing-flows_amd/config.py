@@ -94,6 +94,24 @@ def set_train_pair(mode=True):
     train_pair = bool(mode)
 
 
+# The pair backward's last two launches (the reduction of the partial tiles, the LU's factor gradients: parameter gradients only, 46 us
+# of latency-bound work per pair) on a SIDE stream, under the next pair's MFMA-bound kernels (round 6, late; nf_pair_train_bwd_head /
+# _tail, _sidestream.py).  Taken only when nothing can read those gradients before the join at the end of the backward pass: every
+# parameter of the pair writes into a registered gradient buffer (dp.FlatParameters) whose .grad is unset (autograd adopts the view, no
+# accumulation kernel) and carries no hooks other than join-aware ones (dp.OverlappedGradientAverager's).
+# OFF by default -- measured (tools/train_bench.py --flat [--async], alternating on one box): without those two launches at all the step
+# is 1.46 ms shorter (25.28 -> 23.82 ms), but on the side stream only 0.2-0.3 ms of that came back (25.25 -> 25.0), and nothing once the
+# reduction launch issued its longest blocks first (25.1 either way): every heavy kernel of the step allocates the whole register file of
+# a CU (2 waves per SIMD x 219-256 registers), so a second kernel gets no wave slot while one runs -- the side stream only fills the
+# drain / ramp at kernel boundaries.
+train_reduce_async = False
+
+
+def set_train_reduce_async(mode=True):
+    global train_reduce_async
+    train_reduce_async = bool(mode)
+
+
 # LULinearPermute's density-direction backward (D = 64) as one pass over the rows (nf_lu_bwd).
 lu_bwd_fused = True
 

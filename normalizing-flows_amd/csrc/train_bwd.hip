@@ -12,6 +12,7 @@
 // rows, its partial tiles in the same reduction launch, the factors' gradients on the parameter side): 7 launches for the pair.
 // Gradients go straight to the caller's destinations (e.g. views of one flat gradient buffer: no per-parameter tensors).
 #include "train_reduce.hpp"
+#include <string.h>
 
 extern "C" {
 int nf_final_bwd_partials(int64_t B);
@@ -63,10 +64,10 @@ layer_reduce_kernel(ReduceJobs J) {
                                  reinterpret_cast<float(*)[24]>(smf), smf + 512);
         return;
     }
-    int j = 0;
+    int j = 0;           // (block ranges are not in job order: order_jobs() puts the longest chunk loops first)
 #pragma unroll
     for (int i = 1; i < RJ_MAX; ++i)
-        if (i < J.nj && b >= J.j[i].block0) j = i;
+        if (i < J.nj && b >= J.j[i].block0 && b < J.j[i].block0 + (int)((J.j[i].n + 255) >> 8)) j = i;
     const ReduceJob &q = J.j[j];
     wgrad_reduce_group4(q.part, q.dW, q.db, q.nW, q.n, q.stride, q.chunks, q.N, q.skip_every, q.colmap, q.Nout,
                         (int64_t)(b - q.block0) * 256, sm4);
@@ -80,6 +81,22 @@ static void add_job(ReduceJobs &J, const float *part, float *dW, float *db, int6
     q.colmap = colmap; q.chunks = chunks; q.N = N; q.skip_every = skip_every; q.Nout = Nout;
     q.block0 = J.nblocks;
     J.nblocks += (int)((q.n + 255) / 256);
+}
+
+// Blocks of the jobs with the most chunks first: a residual block's partial tiles come from 256 workgroups, the final layer's from
+// 82 row chunks -- a block of the former runs three times as long, and issued last (job order) they were the launch's tail on a chip
+// that holds 512 of the ~730 blocks at a time.  Longest first, the short blocks fill in behind them.  (Which block sums what does not
+// change a bit of the result.)
+static void order_jobs(ReduceJobs &J) {
+    int idx[RJ_MAX];
+    for (int i = 0; i < J.nj; ++i) idx[i] = i;
+    for (int i = 1; i < J.nj; ++i)          // insertion sort, stable, by chunks descending
+        for (int k = i; k > 0 && J.j[idx[k]].chunks > J.j[idx[k - 1]].chunks; --k) { const int t = idx[k]; idx[k] = idx[k - 1]; idx[k - 1] = t; }
+    int b0 = 0;
+    for (int i = 0; i < J.nj; ++i) {
+        J.j[idx[i]].block0 = b0;
+        b0 += (int)((J.j[idx[i]].n + 255) / 256);
+    }
 }
 
 constexpr int TB_MP = 24 * F_NI;       // 768: rows of the final layer on the 24-float pitch of cond24
@@ -185,6 +202,7 @@ extern "C" int nf_coupling_train_bwd(const void *x, const void *grad_y, const vo
                                      grad_x, g_w0, g_b0, g_wf, g_bf, g_uw, g_uh, g_ud, g_blocks, scratch, mask_parity, B, D, hidden,
                                      num_blocks, K, tail_bound, min_bin_width, min_bin_height, min_derivative, stream, J, &s_end);
     if (rc != NF_OK) return rc;
+    order_jobs(J);
     hipLaunchKernelGGL(layer_reduce_kernel, dim3(J.nblocks + F_NI), dim3(64 * RL), 0, (hipStream_t)stream, J);
     NF_CHECK_LAUNCH();
     return NF_OK;
@@ -205,15 +223,42 @@ extern "C" int64_t nf_pair_train_bwd_scratch_floats(int64_t B, int num_blocks) {
 // nf_lu_bwd_composed_partials on its input gradient, ONE reduction launch for the partial tiles of both layers, and
 // nf_lu_param_grads_composed: seven launches.  x_in: the LU's input rows; Wd: nf_lu_pack_train_multi's (64, 64); Lm, Um: the dense
 // factors of nf_lu_factors[_multi]; grad_x_in (B, 64): the pair's input gradient; g_lower, g_upper, g_udiag, g_lbias: written.
-extern "C" int nf_pair_train_bwd(const void *x_in, const void *xlu, const void *grad_y, const void *grad_logdet, const void *cond24,
-                                 const void *acts, const void *w_t, const void *wpack, const void *wfull_t,
-                                 const void *const *w_blocks, const void *uw, const void *uh, const void *ud, const void *col_map,
-                                 int n_cols, const void *Wd, const void *Lm, const void *Um, const int64_t *perm,
-                                 const void *unconstrained_upper_diag, double lu_eps, void *grad_x_in, void *g_lower, void *g_upper,
-                                 void *g_udiag, void *g_lbias, void *g_w0, void *g_b0, void *g_wf, void *g_bf, void *g_uw, void *g_uh,
-                                 void *g_ud, void *const *g_blocks, void *scratch, int mask_parity, int64_t B, int D, int hidden,
-                                 int num_blocks, int K, double tail_bound, double min_bin_width, double min_bin_height,
-                                 double min_derivative, nf_stream_t stream) {
+// What the pair's last two launches need (nf_pair_train_bwd_tail): the reduction's job list and the LU parameter kernel's arguments.
+// A plain host record: the caller keeps it between the two calls (NF_PAIR_TAIL_BYTES of include/nf_mi355x.h).
+namespace nf {
+struct PairTail {
+    ReduceJobs J;
+    const float *dWd, *gl_sum, *Lm, *Um, *udiag;
+    const int64_t *perm;
+    float *g_lower, *g_upper, *g_udiag;
+    double lu_eps;
+    unsigned magic;
+};
+constexpr unsigned PAIR_TAIL_MAGIC = 0x50544c36u;
+static_assert(sizeof(PairTail) <= 2048, "NF_PAIR_TAIL_BYTES");
+}  // namespace nf
+
+static int pair_tail_launch(const nf::PairTail &T, nf_stream_t stream) {
+    using namespace nf;
+#ifdef NF_ABL_NO_REDUCE       // timing-only ablation: what the step costs without the two launches that only produce parameter gradients
+    return NF_OK;
+#endif
+    hipLaunchKernelGGL(layer_reduce_kernel, dim3(T.J.nblocks + F_NI + 1), dim3(64 * RL), 0, (hipStream_t)stream, T.J);
+    NF_CHECK_LAUNCH();
+    // (gld = the one-element sum, B = 1: the parameter kernel's own summation loop degenerates to a single load)
+    return nf_lu_param_grads_composed(T.dWd, T.Lm, T.Um, T.perm, T.gl_sum, 1, T.udiag, T.lu_eps, T.g_lower, T.g_upper, T.g_udiag, F_D, stream);
+}
+
+static int pair_train_bwd_head(const void *x_in, const void *xlu, const void *grad_y, const void *grad_logdet, const void *cond24,
+                               const void *acts, const void *w_t, const void *wpack, const void *wfull_t,
+                               const void *const *w_blocks, const void *uw, const void *uh, const void *ud, const void *col_map,
+                               int n_cols, const void *Wd, const void *Lm, const void *Um, const int64_t *perm,
+                               const void *unconstrained_upper_diag, double lu_eps, void *grad_x_in, void *g_lower, void *g_upper,
+                               void *g_udiag, void *g_lbias, void *g_w0, void *g_b0, void *g_wf, void *g_bf, void *g_uw, void *g_uh,
+                               void *g_ud, void *const *g_blocks, void *scratch, int mask_parity, int64_t B, int D, int hidden,
+                               int num_blocks, int K, double tail_bound, double min_bin_width, double min_bin_height,
+                               double min_derivative, nf_stream_t stream, nf::PairTail &T) {
+    using namespace nf;
     if (!x_in || !Wd || !Lm || !Um || !perm || !unconstrained_upper_diag || !grad_x_in || !g_lower || !g_upper || !g_udiag || !g_lbias ||
         !scratch)
         return NF_EFAULT;
@@ -224,7 +269,7 @@ extern "C" int nf_pair_train_bwd(const void *x_in, const void *xlu, const void *
     const int lgrid = nf_lu_bwd_composed_grid(B);
     if (lgrid < 0) return NF_ENOTSUP;
     float *dWd = lu_part + (int64_t)lgrid * (F_D * F_D + F_D);
-    ReduceJobs J;
+    ReduceJobs &J = T.J;
     float *s_end = nullptr;
     int rc = coupling_bwd_core(xlu, grad_y, grad_logdet, cond24, acts, w_t, wpack, wfull_t, w_blocks, uw, uh, ud, col_map, n_cols, gxl,
                                g_w0, g_b0, g_wf, g_bf, g_uw, g_uh, g_ud, g_blocks, scratch, mask_parity, B, D, hidden, num_blocks, K,
@@ -236,9 +281,60 @@ extern "C" int nf_pair_train_bwd(const void *x_in, const void *xlu, const void *
     add_job(J, lu_part, dWd, (float *)g_lbias, (int64_t)F_D * F_D, F_D, lgrid, F_D, 0, nullptr, 0);
     float *gl_sum = dWd + F_D * F_D;          // the log-det cotangent's sum, by one more block of the reduction launch
     J.vsum = (const float *)grad_logdet; J.vsum_out = gl_sum; J.vsum_n = B;
-    hipLaunchKernelGGL(layer_reduce_kernel, dim3(J.nblocks + F_NI + 1), dim3(64 * RL), 0, (hipStream_t)stream, J);
-    NF_CHECK_LAUNCH();
-    // (gld = the one-element sum, B = 1: the parameter kernel's own summation loop degenerates to a single load)
-    return nf_lu_param_grads_composed(dWd, Lm, Um, perm, gl_sum, 1, unconstrained_upper_diag, lu_eps, g_lower, g_upper, g_udiag, F_D,
-                                      stream);
+    order_jobs(J);
+    T.dWd = dWd; T.gl_sum = gl_sum; T.Lm = (const float *)Lm; T.Um = (const float *)Um; T.udiag = (const float *)unconstrained_upper_diag;
+    T.perm = perm; T.g_lower = (float *)g_lower; T.g_upper = (float *)g_upper; T.g_udiag = (float *)g_udiag; T.lu_eps = lu_eps;
+    T.magic = PAIR_TAIL_MAGIC;
+    return NF_OK;
+}
+
+extern "C" int nf_pair_train_bwd(const void *x_in, const void *xlu, const void *grad_y, const void *grad_logdet, const void *cond24,
+                                 const void *acts, const void *w_t, const void *wpack, const void *wfull_t,
+                                 const void *const *w_blocks, const void *uw, const void *uh, const void *ud, const void *col_map,
+                                 int n_cols, const void *Wd, const void *Lm, const void *Um, const int64_t *perm,
+                                 const void *unconstrained_upper_diag, double lu_eps, void *grad_x_in, void *g_lower, void *g_upper,
+                                 void *g_udiag, void *g_lbias, void *g_w0, void *g_b0, void *g_wf, void *g_bf, void *g_uw, void *g_uh,
+                                 void *g_ud, void *const *g_blocks, void *scratch, int mask_parity, int64_t B, int D, int hidden,
+                                 int num_blocks, int K, double tail_bound, double min_bin_width, double min_bin_height,
+                                 double min_derivative, nf_stream_t stream) {
+    nf::PairTail T;
+    const int rc = pair_train_bwd_head(x_in, xlu, grad_y, grad_logdet, cond24, acts, w_t, wpack, wfull_t, w_blocks, uw, uh, ud, col_map,
+                                       n_cols, Wd, Lm, Um, perm, unconstrained_upper_diag, lu_eps, grad_x_in, g_lower, g_upper, g_udiag,
+                                       g_lbias, g_w0, g_b0, g_wf, g_bf, g_uw, g_uh, g_ud, g_blocks, scratch, mask_parity, B, D, hidden,
+                                       num_blocks, K, tail_bound, min_bin_width, min_bin_height, min_derivative, stream, T);
+    return rc != NF_OK ? rc : pair_tail_launch(T, stream);
+}
+
+// The same backward in two calls (round 6, late): `_head` issues the five launches the NEXT pair's backward waits for (the coupling's
+// four passes and the composed LU's pass: the pair's input gradient) and leaves, in `tail` (host memory, NF_PAIR_TAIL_BYTES), what the
+// last two launches need; `_tail` issues those -- the one reduction launch and the LU's factor gradients, which only produce PARAMETER
+// gradients -- on any stream the caller has ordered behind `_head`'s.  Off the critical path they cost 46 us per pair of pure
+// latency-bound work; on a side stream they run under the next pair's MFMA-bound kernels (autograd.PairTrainFn: fork by event, joined
+// before anything reads a gradient).  `scratch` and every gradient destination stay in use until the tail has run.
+extern "C" int nf_pair_train_bwd_head(const void *x_in, const void *xlu, const void *grad_y, const void *grad_logdet, const void *cond24,
+                                      const void *acts, const void *w_t, const void *wpack, const void *wfull_t,
+                                      const void *const *w_blocks, const void *uw, const void *uh, const void *ud, const void *col_map,
+                                      int n_cols, const void *Wd, const void *Lm, const void *Um, const int64_t *perm,
+                                      const void *unconstrained_upper_diag, double lu_eps, void *grad_x_in, void *g_lower, void *g_upper,
+                                      void *g_udiag, void *g_lbias, void *g_w0, void *g_b0, void *g_wf, void *g_bf, void *g_uw,
+                                      void *g_uh, void *g_ud, void *const *g_blocks, void *scratch, int mask_parity, int64_t B, int D,
+                                      int hidden, int num_blocks, int K, double tail_bound, double min_bin_width, double min_bin_height,
+                                      double min_derivative, void *tail, nf_stream_t stream) {
+    if (!tail) return NF_EFAULT;
+    nf::PairTail T;
+    const int rc = pair_train_bwd_head(x_in, xlu, grad_y, grad_logdet, cond24, acts, w_t, wpack, wfull_t, w_blocks, uw, uh, ud, col_map,
+                                       n_cols, Wd, Lm, Um, perm, unconstrained_upper_diag, lu_eps, grad_x_in, g_lower, g_upper, g_udiag,
+                                       g_lbias, g_w0, g_b0, g_wf, g_bf, g_uw, g_uh, g_ud, g_blocks, scratch, mask_parity, B, D, hidden,
+                                       num_blocks, K, tail_bound, min_bin_width, min_bin_height, min_derivative, stream, T);
+    if (rc != NF_OK) return rc;
+    memcpy(tail, &T, sizeof(T));
+    return NF_OK;
+}
+
+extern "C" int nf_pair_train_bwd_tail(const void *tail, nf_stream_t stream) {
+    if (!tail) return NF_EFAULT;
+    nf::PairTail T;
+    memcpy(&T, tail, sizeof(T));
+    if (T.magic != nf::PAIR_TAIL_MAGIC) return NF_EINVAL;
+    return pair_tail_launch(T, stream);
 }

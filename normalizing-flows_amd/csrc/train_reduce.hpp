@@ -12,7 +12,10 @@
 
 namespace nf {
 
-constexpr int RL = 16;                 // chunk lanes of a 64-element reduction group (block = 64 x RL threads)
+#ifndef NF_RL
+#define NF_RL 16
+#endif
+constexpr int RL = NF_RL;              // chunk lanes of a 64-element reduction group (block = 64 x RL threads)
 
 // One 64-element group [e0, e0 + 64) of a partial-tile reduction: out (dW then db) (=|+=) sum over chunks of part[c][e] in a fixed
 // order; e < nW goes to dW, the rest to db.  Called by ALL 64 * RL threads of the block (two block barriers inside).

@@ -11,6 +11,8 @@ GLOBAL batch.
 import torch
 import torch.distributed as dist
 
+from . import _sidestream
+
 
 def shard_bounds(n_rows, world_size, rank):
     """Contiguous row range [lo, hi) of `rank`: rows are split as evenly as possible, low ranks get the extras."""
@@ -240,7 +242,8 @@ class OverlappedGradientAverager:
         self._flat_ranges()
         self._sync = True
         self._reset()
-        self._hooks = [p.register_post_accumulate_grad_hook(self._ready) for p in self.params]
+        self._ready_fn = _sidestream.hook_is_aware(self._ready)     # one bound-method object for every parameter: it joins the side stream itself
+        self._hooks = [p.register_post_accumulate_grad_hook(self._ready_fn) for p in self.params]
 
     def _reset(self):
         self._left = [len(b) for b in self.buckets]
@@ -318,6 +321,7 @@ class OverlappedGradientAverager:
     def _ready(self, p):
         if not self._active():
             return
+        _sidestream.join()          # the pair backward's reduction launches may still be on the side stream (_sidestream.py)
         i = self._bucket_of[id(p)]
         if self._left[i] <= 0 or i < self._next:
             raise RuntimeError("OverlappedGradientAverager: a second backward() reached a bucket whose all_reduce was already started; "
@@ -365,6 +369,7 @@ class OverlappedGradientAverager:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        _sidestream._aware.discard(id(self._ready_fn))
 
 
 def allreduce_gradients(params, group=None, bucket_bytes=64 << 20):

@@ -728,9 +728,13 @@ def final_bwd(x, grad_y, grad_logdet, cond24, w_t, blob, uw, uh, ud, mask_parity
 
 def pair_train_bwd(x_in, xlu, grad_y, grad_logdet, cond24, acts, w_t, blob, wfull_t, w_blocks, uw, uh, ud, col_map, n_cols, mask_parity,
                    num_blocks, Wd, Lm, Um, perm, udiag, lu_eps, dest, tail_bound=3.0, min_bin_width=1e-3, min_bin_height=1e-3,
-                   min_derivative=1e-3):
+                   min_derivative=1e-3, side=None):
     """The whole backward of a [CoupledRQS, LULinearPermute] pair in one C-ABI call (nf_pair_train_bwd: seven launches).  dest: as
-    coupling_train_bwd plus lower, upper, udiag, lbias (the LU's gradient destinations).  Returns the pair's input gradient."""
+    coupling_train_bwd plus lower, upper, udiag, lbias (the LU's gradient destinations).  Returns the pair's input gradient.
+    side (a torch.cuda.Stream): the last two launches -- the reduction of the partial tiles and the LU's factor gradients, which only
+    produce parameter gradients -- go to that stream, forked from the current one by an event (nf_pair_train_bwd_head / _tail): they
+    run under whatever the current stream does next.  The CALLER joins (`current_stream().wait_stream(side)`) before a gradient in
+    `dest` is read; the scratch and the tensors the tail reads are kept from reuse through record_stream."""
     L.require_device(x_in, xlu, grad_y, grad_logdet, cond24, acts, w_t, blob, wfull_t, uw, uh, ud, col_map, Wd, Lm, Um, perm, udiag,
                      *w_blocks)
     B = x_in.shape[0]
@@ -752,14 +756,26 @@ def pair_train_bwd(x_in, xlu, grad_y, grad_logdet, cond24, acts, w_t, blob, wful
     wb = [w.contiguous() for w in w_blocks]
     wp = (C.c_void_p * len(wb))(*[w.data_ptr() for w in wb])
     gp = (C.c_void_p * len(dest["blocks"]))(*[t.data_ptr() for t in dest["blocks"]])
-    rc = lib.nf_pair_train_bwd(ptr(x_in), ptr(xlu), ptr(grad_y), ptr(grad_logdet), ptr(cond24), ptr(acts), ptr(w_t), ptr(blob),
-                               ptr(wfull_t), wp, ptr(uw.contiguous()), ptr(uh.contiguous()), ptr(ud.contiguous()), ptr(col_map),
-                               i32(int(n_cols)), ptr(Wd), ptr(Lm.contiguous()), ptr(Um.contiguous()), ptr(perm), ptr(udiag.contiguous()),
-                               f64(lu_eps), ptr(gx), ptr(dest["lower"]), ptr(dest["upper"]), ptr(dest["udiag"]), ptr(dest["lbias"]),
-                               ptr(dest["w0"]), ptr(dest["b0"]), ptr(dest["wf"]), ptr(dest["bf"]), ptr(dest["uw"]), ptr(dest["uh"]),
-                               ptr(dest["ud"]), gp, ptr(scratch), i32(mask_parity), i64(B), i32(64), i32(128), i32(num_blocks), i32(8),
-                               f64(tail_bound), f64(min_bin_width), f64(min_bin_height), f64(min_derivative), L.stream())
-    L.check(rc, "nf_pair_train_bwd")
+    uw_, uh_, ud_, Lm_, Um_, udiag_ = uw.contiguous(), uh.contiguous(), ud.contiguous(), Lm.contiguous(), Um.contiguous(), udiag.contiguous()
+    args = (ptr(x_in), ptr(xlu), ptr(grad_y), ptr(grad_logdet), ptr(cond24), ptr(acts), ptr(w_t), ptr(blob),
+            ptr(wfull_t), wp, ptr(uw_), ptr(uh_), ptr(ud_), ptr(col_map),
+            i32(int(n_cols)), ptr(Wd), ptr(Lm_), ptr(Um_), ptr(perm), ptr(udiag_),
+            f64(lu_eps), ptr(gx), ptr(dest["lower"]), ptr(dest["upper"]), ptr(dest["udiag"]), ptr(dest["lbias"]),
+            ptr(dest["w0"]), ptr(dest["b0"]), ptr(dest["wf"]), ptr(dest["bf"]), ptr(dest["uw"]), ptr(dest["uh"]),
+            ptr(dest["ud"]), gp, ptr(scratch), i32(mask_parity), i64(B), i32(64), i32(128), i32(num_blocks), i32(8),
+            f64(tail_bound), f64(min_bin_width), f64(min_bin_height), f64(min_derivative))
+    if side is None:
+        L.check(lib.nf_pair_train_bwd(*args, L.stream()), "nf_pair_train_bwd")
+        return gx
+    tail = C.create_string_buffer(2048)                       # NF_PAIR_TAIL_BYTES
+    L.check(lib.nf_pair_train_bwd_head(*args, tail, L.stream()), "nf_pair_train_bwd_head")
+    cur = torch.cuda.current_stream()
+    side.wait_stream(cur)                                     # fork: an event recorded here, behind the five launches
+    L.check(lib.nf_pair_train_bwd_tail(tail, C.c_void_p(side.cuda_stream)), "nf_pair_train_bwd_tail")
+    # what the side stream reads or writes must not go back to the allocator (or be rewritten on the current stream) before it is done
+    # (parameters, the prepacked factors and the flat gradient buffer outlive the step; the caller's join comes before they change)
+    for t in (scratch, grad_logdet):
+        t.record_stream(side)
     return gx
 
 

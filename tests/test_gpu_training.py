@@ -1200,6 +1200,79 @@ def test_flat_parameters_training_step_on_the_benchmark_kernels(nfa):
     flat.release()
 
 
+def test_pair_backward_tail_on_the_side_stream(nfa):
+    """Round 6 (late; opt-in, config.set_train_reduce_async): the pair backward's last two launches (reduction of the partial tiles, LU
+    factor gradients: parameter gradients only) on a side stream under the next pair's kernels (nf_pair_train_bwd_head / _tail,
+    _sidestream.py).  Taken when nothing can
+    read the gradients before the join at the end of the backward pass -- registered gradient buffers whose .grad is unset, no tensor
+    hooks --, otherwise the seven launches stay on one stream.  Either way the gradients are the same bits; what follows backward() on
+    the current stream sees them complete (the join is an autograd end-of-pass callback); the step also records into one hipGraph
+    (fork and join inside the capture)."""
+    from bench import build_c2_model
+    from normflows_amd import _sidestream, ops
+    m = build_c2_model(num_layers=4, sigma=0.05).to(DEV)
+    x = torch.randn(4096, 64, device=DEV)
+    flat = nfa.dp.FlatParameters(m)
+    sides = []
+    orig = ops.pair_train_bwd
+
+    def spy(*a, **k):
+        sides.append(k.get("side"))
+        return orig(*a, **k)
+    ops.pair_train_bwd = spy
+    try:
+        def step():
+            flat.zero_grad()
+            loss = m.forward_kld(x)
+            loss.backward()
+            assert not _sidestream._dirty, "backward() returns with the side stream joined"
+            assert flat.sync() == 0
+            return float(loss.detach()), flat.grad.clone()       # (a read on the current stream right behind backward())
+        nfa.config.set_train_reduce_async(False)
+        l0, g0 = step()
+        assert len(sides) == 4 and all(s_ is None for s_ in sides)
+        nfa.config.set_train_reduce_async(True)
+        del sides[:]
+        for _ in range(3):
+            l1, g1 = step()
+            assert l1 == l0 and torch.equal(g1, g0)
+        assert len(sides) == 12 and all(isinstance(s_, torch.cuda.Stream) for s_ in sides)
+        # an existing .grad (no zero_grad): autograd would ACCUMULATE on the current stream -> one stream
+        del sides[:]
+        m.forward_kld(x).backward()
+        assert len(sides) == 4 and all(s_ is None for s_ in sides)
+        # a tensor hook on one parameter of the second pair: that pair stays on one stream, the others do not
+        del sides[:]
+        flat.zero_grad()
+        seen = []
+        h = m.flows[2].prqct.transform_net.final_layer.weight.register_hook(lambda g_: seen.append(float(g_.abs().sum())))
+        m.forward_kld(x).backward()
+        h.remove()
+        assert len(seen) == 1 and sum(s_ is None for s_ in sides) == 1 and len(sides) == 4
+        assert flat.sync() == 0 and torch.equal(flat.grad, g0)
+        # the whole step in one hipGraph: the fork and the end-of-pass join are captured
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        flat.zero_grad()
+        del sides[:]
+        with torch.cuda.graph(g):
+            m.forward_kld(x).backward()
+        assert len(sides) == 4 and all(isinstance(s_, torch.cuda.Stream) for s_ in sides)
+        flat.grad.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(flat.grad, g0)
+    finally:
+        ops.pair_train_bwd = orig
+        nfa.config.set_train_reduce_async(False)          # (the default: measured, no gain -- config.py)
+        flat.release()
+
+
 def test_backward_after_reforward_with_other_weights_raises(nfa):
     """The training Functions read layer-owned weight images (packed blob, transposed final weight, LU factors) in backward;
     a second forward of the same layer with OTHER weights overwrites them.  autograd's saved-tensor check catches in-place

@@ -28,7 +28,11 @@ ap.add_argument("--flat", action="store_true", help="round 6: dp.FlatParameters 
                 "flat buffer by the kernels, Adam(fused) on ONE tensor")
 ap.add_argument("--no-pair", action="store_true", help="ablation: LULinearPermuteFn + CouplingTrainFn instead of the fused pair (round 6)")
 ap.add_argument("--no-onecall", action="store_true", help="ablation: the layer's backward kernel by kernel with one reduction launch each (rounds 3-5)")
+ap.add_argument("--async", dest="async_", action="store_true", help="the pair backward's reduction launches on a side stream (round 6, late; measured: no gain)")
 a = ap.parse_args()
+if a.async_:
+    import normflows_amd
+    normflows_amd.config.set_train_reduce_async(True)
 if a.no_train_full:
     import normflows_amd
     normflows_amd.config.set_train_full(False)
