@@ -14,6 +14,7 @@ Differences that are deliberate (MI355X-first):
 """
 import torch
 from . import _keys
+from . import config as _config
 from torch import nn
 
 from . import _prepack
@@ -390,14 +391,33 @@ class NormalizingFlow(nn.Module):
         x = run_chain(self.flows, x, True, log_det, +1)
         return x, log_det
 
+    def _train_pad_rows(self, x):
+        """Rows of zero padding that put a differentiable density pass on the 64-row-tile training kernels (config.train_pad_batch):
+        > 0 only for a ragged batch of >= 1024 rows through a model with a benchmark-shaped [CoupledRQS, LULinearPermute] pair."""
+        B = x.shape[0] if x.dim() == 2 else 0
+        if (B < 1024 or B % 64 == 0 or not _config.train_pad_batch or not x.is_cuda or x.dtype != torch.float32 or x.shape[1] != 64
+                or not torch.is_grad_enabled() or not (_config.train_pair and _config.train_bwd_onecall)):
+            return 0
+        fl = list(self.flows)
+        for a, b in zip(fl[:-1], fl[1:]):
+            if (isinstance(a, CoupledRationalQuadraticSpline) and isinstance(b, LULinearPermute) and b.linear.features == 64
+                    and a.prqct._train_full_ok(x, None, False) and all(p.requires_grad for p in a.parameters())
+                    and all(p.requires_grad for p in b.parameters())):
+                return (-B) % 64
+        return 0
+
     def _log_prob_impl(self, x):
+        pad = self._train_pad_rows(x)
+        if pad:       # whole 64-row tiles for the training kernels; the slice's backward gives the padding rows a zero cotangent
+            B = x.shape[0]
+            x = torch.cat([x, x.new_zeros((pad, x.shape[1]))])
         log_q = torch.zeros(len(x), dtype=x.dtype, device=x.device)
         z = run_chain(self.flows, x, True, log_q, +1)
         if hasattr(self.q0, "_log_prob_acc"):
             self.q0._log_prob_acc(z, log_q, +1)
         else:
             log_q += self.q0.log_prob(z)
-        return log_q
+        return log_q[:B] if pad else log_q
 
     def log_prob(self, x):
         """log q(x): every layer's inverse, accumulated log-dets, base log-density (core.py:182-197)."""

@@ -1273,6 +1273,49 @@ def test_pair_backward_tail_on_the_side_stream(nfa):
         flat.release()
 
 
+def test_ragged_training_batch_runs_padded_on_the_tile_kernels(nfa):
+    """A differentiable density pass on a batch that is not a multiple of 64 rows (round 6, late; config.train_pad_batch): the model pads
+    the batch with zero rows to whole 64-row tiles, runs the pair kernels and slices the result back -- the padding rows get a zero
+    cotangent from the slice's backward, so every gradient equals the general kernels' on the ragged batch (to the tolerance two float32
+    paths agree to), log_prob has the caller's shape, and the input gradient too."""
+    from bench import build_c2_model
+    from normflows_amd import ops
+    m = build_c2_model(num_layers=4, sigma=0.05).to(DEV)
+    B = 1024 + 77
+    x = torch.randn(B, 64, device=DEV, requires_grad=True)
+    calls = []
+    orig = ops.pair_train_bwd
+
+    def spy(*a, **k):
+        calls.append(a[0].shape[0])
+        return orig(*a, **k)
+    ops.pair_train_bwd = spy
+    try:
+        def run():
+            m.zero_grad(set_to_none=True)
+            x.grad = None
+            lp = m.log_prob(x)
+            assert lp.shape == (B,)
+            (-lp.mean()).backward()
+            return lp.detach().clone(), x.grad.clone(), {n: p_.grad.clone() for n, p_ in m.named_parameters()}
+        lp1, gx1, g1 = run()
+        assert calls == [1152] * 4, calls                     # the pair kernels, on the padded batch
+        nfa.config.set_train_pad_batch(False)
+        del calls[:]
+        lp0, gx0, g0 = run()
+        assert calls == []                                    # the general kernels
+    finally:
+        ops.pair_train_bwd = orig
+        nfa.config.set_train_pad_batch(True)
+    assert_close(N(lp1), N(lp0), what="log_prob", rtol=1e-5, atol=2e-4)
+    assert gx1.shape == (B, 64)
+    bad = ((gx1 - gx0).abs() > 1e-4 * float(gx0.abs().max())).any(dim=1)
+    assert int(bad.sum()) <= 2, int(bad.sum())                # (kink rows: a row within rounding of a knot, DESIGN 5)
+    for n in g0:
+        err = float((g1[n] - g0[n]).abs().max()) / max(float(g0[n].abs().max()), 1e-12)
+        assert err < 2e-3, (n, err)
+
+
 def test_backward_after_reforward_with_other_weights_raises(nfa):
     """The training Functions read layer-owned weight images (packed blob, transposed final weight, LU factors) in backward;
     a second forward of the same layer with OTHER weights overwrites them.  autograd's saved-tensor check catches in-place
