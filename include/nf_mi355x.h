@@ -198,6 +198,11 @@ int nf_rqs_fused_chain(const void *x, void *y, void *logdet, const void *const *
                        int num_layers, int fuse_lu, int64_t B, int D, int hidden, int num_blocks, int K,
                        double tail_bound, double min_bin_width, double min_bin_height, double min_derivative,
                        int direction, int acc, nf_stream_t stream);
+/* nf_rqs_fused_chain runs batches of at most 32 768 rows on 4-wave (128-row) workgroups (csrc/rqs_fused_nw4.hip: the same kernel built a
+ * second time) -- the 8-wave workgroups own 256 rows for the whole chain, so at <= 32 768 rows half of the CUs have no workgroup; same
+ * bits per row.  nf_rqs_fused_small_batch(0) keeps every batch on the 8-wave kernel, (1) restores the default, (-1) only queries; returns
+ * the previous setting.  (No counterpart in the reference: a tuning switch of this library, used by the differential tests.) */
+int nf_rqs_fused_small_batch(int enable);
 
 /* Training forward of the layer's last stage (core.py:87-102 `forward_kld` over nsf/coupling.py:83-98): final Linear of the
  * conditioner (nets/resnet.py:104) + the density-direction coupling transform in ONE launch of the fused kernel, the hidden

@@ -35,6 +35,12 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def _hip_includes(src):
+    """Other .hip sources a .hip source #includes (rqs_fused_nw4.hip is a second build of rqs_fused.hip)."""
+    import re
+    return [os.path.join(CSRC, m) for m in re.findall(r'^#include "([^"]+\.hip)"', open(src).read(), flags=re.M)]
+
+
 def build(force=False, verbose=False):
     """Compile every HIP source into lib/libnf_mi355x.so for gfx950 (cross-compiles without a GPU)."""
     srcs = sources()
@@ -52,7 +58,7 @@ def build(force=False, verbose=False):
         objs.append(o)
         if not force and os.path.exists(o) and all(
                 os.path.getmtime(d) <= os.path.getmtime(o)
-                for d in [s] + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(INCLUDE, "*.h"))):
+                for d in [s] + _hip_includes(s) + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(INCLUDE, "*.h"))):
             continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed"] + os.environ.get("NF_HIPCC_FLAGS", "").split() + ["-c", s, "-o", o]
         if verbose:
@@ -75,7 +81,7 @@ def build_safe_waits(force=False):
     with -DNF_SAFE_WAITS (each hand-counted `s_waitcnt vmcnt(N)` becomes a full drain), the other objects reused; selected at run
     time with NF_MI355X_LIB.  Built by __graft_entry__.build() so that it travels to the GPU box with the tree."""
     build()
-    srcs = [s for s in sources() if "NF_WAIT_VMCNT" in open(s).read()]
+    srcs = [s for s in sources() if "NF_WAIT_VMCNT" in open(s).read() or any("NF_WAIT_VMCNT" in open(i).read() for i in _hip_includes(s))]
     deps = srcs + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(INCLUDE, "*.h")) + [LIBPATH]
     if not force and os.path.exists(SAFE_WAITS_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(SAFE_WAITS_LIB) for d in deps):
         return SAFE_WAITS_LIB

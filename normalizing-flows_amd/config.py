@@ -124,6 +124,13 @@ def set_train_pad_batch(mode=True):
     train_pad_batch = bool(mode)
 
 
+def set_fused_small_batch(mode=True):
+    """nf_rqs_fused_chain on 128-row workgroups for batches of at most 32 768 rows (the default; csrc/rqs_fused_nw4.hip: 5.4 -> 3.0 ms
+    per pass of the benchmark chain).  False = every batch on the 256-row workgroups (differential tests).  Returns the old setting."""
+    from . import _lib as L
+    return bool(L.lib().nf_rqs_fused_small_batch(1 if mode else 0))
+
+
 # LULinearPermute's density-direction backward (D = 64) as one pass over the rows (nf_lu_bwd).
 lu_bwd_fused = True
 

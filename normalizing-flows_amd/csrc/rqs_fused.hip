@@ -39,8 +39,16 @@
 #define NF_TRAIN_STORE(ptr, val) (*(ptr) = (val))
 #endif
 
+// This file is compiled twice: as it stands (8 waves = 256 rows per workgroup, every entry point) and through rqs_fused_nw4.hip
+// (-DNF_FUSED_SECONDARY: 4 waves = 128 rows per workgroup, only the inference kernel under another name and its chain dispatch) for
+// batches that leave the 8-wave workgroups more than half of the chip idle (round 6, late: nf_rqs_fused_chain).
+#ifdef NF_FUSED_SECONDARY
+#define rqs_fused_kernel rqs_fused_kernel_nw4
+#endif
+
 namespace nf {
 
+#ifndef NF_FUSED_SECONDARY
 // ---- pack kernels ---------------------------------------------------------------------------------------------
 // A-operand image of one 32-row block: dst[s][lane][r4] = W[row(lane & 31)][kcol(s, lane >> 5, r4)]
 __global__ void pack_init_kernel(const float *__restrict__ W /*128x32*/, const float *__restrict__ b, float *__restrict__ stage,
@@ -303,6 +311,7 @@ pack_lu_train_multi_kernel(const void *const *__restrict__ table, float eps, int
     __syncthreads();                              // (orders this block's header words behind pack_all's: same stream, earlier launch)
     if (tid == 0) { blob[2] = 1.0f; blob[3] = lad; }
 }
+#endif  // !NF_FUSED_SECONDARY
 
 // ---- the fused layer kernel -----------------------------------------------------------------------------------
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -982,6 +991,7 @@ rqs_fused_kernel(const float *__restrict__ x, float *__restrict__ y, float *__re
     }
 }
 
+#ifndef NF_FUSED_SECONDARY
 // The whole blob of a layer (without the LU) in ONE launch: what nf_rqs_fused_pack does with 4 + 2 nblk launches.  The training
 // step re-packs every layer's weights once per step, so the launches count (8 bins only: the training variants' shape).
 struct PackAllArgs {
@@ -1090,12 +1100,15 @@ __global__ void pack_all_multi_kernel(const void *const *__restrict__ table, int
     __syncthreads();
     pack_all_body(a, blob, wh_scale, p);
 }
+#endif  // !NF_FUSED_SECONDARY
 
 }  // namespace nf
 
 using namespace nf;
 
 static inline bool fused_bins_ok(int K) { return K == 4 || K == 8 || K == 16; }   // instantiations of the exact-fp32 kernel
+
+#ifndef NF_FUSED_SECONDARY
 
 // One-launch pack of a whole layer (8 bins, no LU) for the training forward nf_rqs_fused_train_full_fwd.
 extern "C" int nf_rqs_fused_pack_all(void *wpack, const void *w_init, const void *b_init, const void *const *w_blocks,
@@ -1333,6 +1346,8 @@ extern "C" int nf_rqs_fused_pack_lu(void *wpack, int num_blocks, const int64_t *
     return NF_OK;
 }
 
+#endif  // !NF_FUSED_SECONDARY
+
 template <int DIR, bool LU, int KB, int HB>
 static int launch_fused(const void *x, void *y, void *logdet, const FlowArgs &fa, int64_t B, int num_blocks,
                         const RqsParams<float> &p, int acc, size_t lds, hipStream_t st) {
@@ -1343,6 +1358,66 @@ static int launch_fused(const void *x, void *y, void *logdet, const FlowArgs &fa
                        (float *)logdet, fa, B, num_blocks, p, acc, (const float *)nullptr, (float *)nullptr, 1.0f);
     NF_CHECK_LAUNCH();
     return NF_OK;
+}
+
+// The instantiation for (direction, LU, bins, hidden units) of THIS build's workgroup size.
+static int chain_dispatch(const void *x, void *y, void *logdet, const FlowArgs &fa, int64_t B, int hidden, int num_blocks, int K,
+                          const RqsParams<float> &p, int direction, int fuse_lu, int acc, hipStream_t st) {
+    FusedLayout lay;
+    lay.nblk = num_blocks;
+    lay.K = K;
+    const size_t lds = (size_t)(2 * F_STAGE + F_NW * 32 * 64 + 2 * lay.small_padded()) * sizeof(float);
+    if (lds > 160 * 1024) return NF_ENOTSUP;
+#define NF_FUSED_DISPATCH(KB, HB)                                                                                     \
+    do {                                                                                                              \
+        if (direction == 0)                                                                                           \
+            return fuse_lu ? launch_fused<0, true, KB, HB>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st)          \
+                           : launch_fused<0, false, KB, HB>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st);        \
+        return fuse_lu ? launch_fused<1, true, KB, HB>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st)              \
+                       : launch_fused<1, false, KB, HB>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st);            \
+    } while (0)
+    if (hidden == F_H / 2) {
+        if (K == 4) NF_FUSED_DISPATCH(4, 2);
+        if (K == 16) NF_FUSED_DISPATCH(16, 2);
+        NF_FUSED_DISPATCH(8, 2);
+    }
+    if (hidden == F_H / 4) {
+        if (K == 4) NF_FUSED_DISPATCH(4, 1);
+        if (K == 16) NF_FUSED_DISPATCH(16, 1);
+        NF_FUSED_DISPATCH(8, 1);
+    }
+    if (K == 4) NF_FUSED_DISPATCH(4, 4);
+    if (K == 16) NF_FUSED_DISPATCH(16, 4);
+    NF_FUSED_DISPATCH(8, 4);
+#undef NF_FUSED_DISPATCH
+}
+
+#ifdef NF_FUSED_SECONDARY
+// (internal: called by nf_rqs_fused_chain of the primary build; fa / p by pointer across the translation units)
+extern "C" int nf_rqs_fused_chain_nw4_(const void *x, void *y, void *logdet, const void *fa, int64_t B, int hidden, int num_blocks, int K,
+                                       const void *p, int direction, int fuse_lu, int acc, nf_stream_t stream) {
+    static_assert(F_NW == 4, "the secondary build is the 4-wave one");
+    return chain_dispatch(x, y, logdet, *static_cast<const FlowArgs *>(fa), B, hidden, num_blocks, K,
+                          *static_cast<const RqsParams<float> *>(p), direction, fuse_lu, acc, (hipStream_t)stream);
+}
+#else
+extern "C" int nf_rqs_fused_chain_nw4_(const void *x, void *y, void *logdet, const void *fa, int64_t B, int hidden, int num_blocks, int K,
+                                       const void *p, int direction, int fuse_lu, int acc, nf_stream_t stream);
+
+// Batches of at most NF_FUSED_SMALL_ROWS rows run on 128-row workgroups (rqs_fused_nw4.hip).  A workgroup owns its rows for the whole
+// chain, so a pass takes the same 5.4 ms for ANY batch the 8-wave workgroups hold in one round (<= 65 536 rows); at <= 32 768 rows half
+// of the CUs have no workgroup at all.  Four waves per workgroup put those rows on twice as many CUs, one wave per SIMD instead of two
+// sharing its matrix pipe: 3.0 ms per pass (32 768 rows: 6.0 -> 10.8 M rows/s).  Above that the 8-wave layout wins (one weight stream
+// and one barrier per 256 rows: 65 536 rows 12.07 vs 10.92 M rows/s).  nf_rqs_fused_small_batch(0) keeps every batch on the 8-wave
+// kernel (differential tests).
+#ifndef NF_FUSED_SMALL_ROWS
+#define NF_FUSED_SMALL_ROWS 32768
+#endif
+static int g_small_batch = 1;
+extern "C" int nf_rqs_fused_small_batch(int enable) {
+    const int old = g_small_batch;
+    if (enable >= 0) g_small_batch = enable ? 1 : 0;
+    return old;
 }
 
 extern "C" int nf_rqs_fused_chain(const void *x, void *y, void *logdet, const void *const *wpacks,
@@ -1373,36 +1448,11 @@ extern "C" int nf_rqs_fused_chain(const void *x, void *y, void *logdet, const vo
         fa.blob[l] = (const float *)wpacks[l];
         if (mask_parities[l]) fa.parity |= 1ull << l;
     }
-    hipStream_t st = (hipStream_t)stream;
-    FusedLayout lay;
-    lay.nblk = num_blocks;
-    lay.K = K;
     auto p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
                                     min_derivative, sqrt((double)F_H));
-    const size_t lds = (size_t)(2 * F_STAGE + F_NW * 32 * 64 + 2 * lay.small_padded()) * sizeof(float);
-    if (lds > 160 * 1024) return NF_ENOTSUP;
-#define NF_FUSED_DISPATCH(KB, HB)                                                                                     \
-    do {                                                                                                              \
-        if (direction == 0)                                                                                           \
-            return fuse_lu ? launch_fused<0, true, KB, HB>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st)          \
-                           : launch_fused<0, false, KB, HB>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st);        \
-        return fuse_lu ? launch_fused<1, true, KB, HB>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st)              \
-                       : launch_fused<1, false, KB, HB>(x, y, logdet, fa, B, num_blocks, p, acc, lds, st);            \
-    } while (0)
-    if (hidden == F_H / 2) {
-        if (K == 4) NF_FUSED_DISPATCH(4, 2);
-        if (K == 16) NF_FUSED_DISPATCH(16, 2);
-        NF_FUSED_DISPATCH(8, 2);
-    }
-    if (hidden == F_H / 4) {
-        if (K == 4) NF_FUSED_DISPATCH(4, 1);
-        if (K == 16) NF_FUSED_DISPATCH(16, 1);
-        NF_FUSED_DISPATCH(8, 1);
-    }
-    if (K == 4) NF_FUSED_DISPATCH(4, 4);
-    if (K == 16) NF_FUSED_DISPATCH(16, 4);
-    NF_FUSED_DISPATCH(8, 4);
-#undef NF_FUSED_DISPATCH
+    if (g_small_batch && B <= NF_FUSED_SMALL_ROWS)
+        return nf_rqs_fused_chain_nw4_(x, y, logdet, &fa, B, hidden, num_blocks, K, &p, direction, fuse_lu, acc, stream);
+    return chain_dispatch(x, y, logdet, fa, B, hidden, num_blocks, K, p, direction, fuse_lu, acc, (hipStream_t)stream);
 }
 
 extern "C" int nf_rqs_fused_train_fwd(const void *x, const void *h2, void *y, void *logdet, void *cond_out, const void *wpack,
@@ -1445,3 +1495,4 @@ extern "C" int nf_rqs_fused(const void *x, void *y, void *logdet, const void *wp
     return nf_rqs_fused_chain(x, y, logdet, packs, par, 1, fuse_lu, B, D, hidden, num_blocks, K, tail_bound, min_bin_width,
                               min_bin_height, min_derivative, direction, acc, stream);
 }
+#endif  // !NF_FUSED_SECONDARY

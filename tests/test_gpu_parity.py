@@ -658,7 +658,51 @@ def _rel(a, b):
     return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
 
 
-def test_model_c2mini_vs_reference(nfa):
+@pytest.fixture(params=["wg128", "wg256"])
+def chain_workgroups(request, nfa):
+    """The fused chain on both workgroup sizes (round 6, late): batches of <= 32 768 rows run on 128-row workgroups by default
+    (csrc/rqs_fused_nw4.hip); "wg256" keeps them on the 256-row workgroups of the headline configuration."""
+    old = nfa.config.set_fused_small_batch(request.param == "wg128")
+    yield request.param
+    nfa.config.set_fused_small_batch(old)
+
+
+@pytest.mark.parametrize("dim,hidden,bins,blocks,lu", [(64, 128, 8, 2, True), (64, 128, 8, 2, False), (64, 128, 4, 1, True),
+                                                       (64, 128, 16, 2, True), (32, 64, 8, 2, True), (16, 32, 16, 1, False)])
+def test_small_batch_workgroups_give_the_same_bits(nfa, dim, hidden, bins, blocks, lu):
+    """nf_rqs_fused_chain on 128-row workgroups (the default at <= 32 768 rows) and on 256-row workgroups (nf_rqs_fused_small_batch(0)):
+    the same kernel source built for two workgroup sizes -- a row's arithmetic does not depend on which wave of which workgroup owns it,
+    so log_prob and sample agree BIT FOR BIT, for ragged and tiny batches, every bin count, narrower layers, with and without the LU.
+    (The golden-vector tests of the chain therefore pin both builds; the whole-model ones also run on both: chain_workgroups.)"""
+    torch.manual_seed(dim + bins)
+    flows = []
+    for i in range(3):
+        flows += [nfa.flows.CoupledRationalQuadraticSpline(dim, blocks, hidden, num_bins=bins, init_identity=False, reverse_mask=bool(i & 1))]
+        if lu:
+            flows += [nfa.flows.LULinearPermute(dim)]
+    m = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(dim, trainable=False), flows)
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.add_(0.04 * torch.randn_like(p_))
+    m = m.to(DEV)
+    try:
+        with torch.no_grad():
+            for B in (1, 31, 257, 4099, 32768):
+                x = 1.3 * torch.randn(B, dim, device=DEV)
+                eps = torch.randn(B, dim, device=DEV)
+                nfa.config.set_fused_small_batch(True)
+                lp1 = m.log_prob(x)
+                xs1, lq1 = m.sample_from_noise(eps)
+                nfa.config.set_fused_small_batch(False)
+                lp0 = m.log_prob(x)
+                xs0, lq0 = m.sample_from_noise(eps)
+                assert torch.equal(lp1, lp0) and torch.equal(xs1, xs0) and torch.equal(lq1, lq0), B
+                assert torch.isfinite(lp1).all()
+    finally:
+        nfa.config.set_fused_small_batch(True)
+
+
+def test_model_c2mini_vs_reference(nfa, chain_workgroups):
     from bench import build_c2_model
     g = load_golden("model_c2mini")
     m = build_c2_model(num_layers=4, dim=16, hidden=32, seed=0, sigma=0.05)
@@ -676,7 +720,7 @@ def test_model_c2mini_vs_reference(nfa):
     assert np.array_equal(lp_g, lp) and np.array_equal(lp_g2, lp)
 
 
-def test_model_c2_full_width_head_vs_reference(nfa):
+def test_model_c2_full_width_head_vs_reference(nfa, chain_workgroups):
     """The benchmark model itself (32 layers, d=64, hidden 128): seeded construction reproduces the reference's
     weights, so the reference's log_prob on the first 128 benchmark rows is a golden vector for it."""
     from bench import build_c2_model
@@ -1957,7 +2001,7 @@ def test_image_spline_coupling_vs_reference(nfa):
 
 
 @pytest.mark.parametrize("seed", [0, 5, 9, 14, 19, 23])
-def test_fused_chain_vs_unfused_randomized(nfa, seed):
+def test_fused_chain_vs_unfused_randomized(nfa, seed, chain_workgroups):
     """Randomised models of the benchmark shape (2-4 layer pairs, both mask parities, identity / random inits, perturbed
     weights), ragged batches with NaN / +-inf / tail-boundary inputs: the persistent fused chain and the unfused path
     (library GEMMs + nf_rqs_coupling + nf_lu_linear_permute) agree, including which rows are non-finite."""

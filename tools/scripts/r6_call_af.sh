@@ -1,0 +1,6 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+timeout 2400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_hygiene.py -x -q 2>&1 | tail -3
+timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2
+timeout 600 python tools/batch_sweep.py --json gpurun_out/r06_batch_sweep.json 2>&1 | grep rows
+timeout 300 python bench.py --no-secondary --no-cpu-baseline --steps 40 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('roofline',{}).get('frac'))"
