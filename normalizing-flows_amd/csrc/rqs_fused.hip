@@ -1108,7 +1108,45 @@ using namespace nf;
 
 static inline bool fused_bins_ok(int K) { return K == 4 || K == 8 || K == 16; }   // instantiations of the exact-fp32 kernel
 
+// The whole-layer training forward (TRAIN = 2; LU: with the layer's LULinearPermute.inverse in front) on THIS build's workgroup size.
+template <bool LU>
+static int train_fwd_launch(const void *x, void *xlu_out, void *y, void *logdet, void *cond_out, void *act_out, const FlowArgs &fa,
+                            int64_t B, int hidden, int num_blocks, const RqsParams<float> &p, int acc, hipStream_t st) {
+    FusedLayout lay;
+    lay.nblk = num_blocks;
+    const size_t lds = (size_t)(2 * F_STAGE + F_NW * 32 * 64 + lay.small_padded() + F_NW * 1536) * sizeof(float);
+    if (lds > 160 * 1024) return NF_ENOTSUP;
+    static LdsOptIn opted = {};
+    if (opt_in_lds(reinterpret_cast<const void *>(&rqs_fused_kernel<0, LU, 2>), lds, opted) != NF_OK) return NF_ENOTSUP;
+    const int grid = (int)((B + F_ROWS - 1) / F_ROWS);
+    hipLaunchKernelGGL((rqs_fused_kernel<0, LU, 2>), dim3(grid), dim3(F_THREADS), lds, st, (const float *)x, (float *)y,
+                       (float *)logdet, fa, B, num_blocks, p, acc, (const float *)nullptr, (float *)cond_out,
+                       (float)(sqrt((double)hidden) / 1.4426950408889634), (float *)act_out, (float *)xlu_out);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+#ifdef NF_FUSED_SECONDARY
+// (internal: called by nf_rqs_fused_train_full_fwd / _pair_fwd of the primary build)
+extern "C" int nf_rqs_fused_train_fwd_nw4_(int lu, const void *x, void *xlu_out, void *y, void *logdet, void *cond_out, void *act_out,
+                                           const void *fa, int64_t B, int hidden, int num_blocks, const void *p, int acc,
+                                           nf_stream_t stream) {
+    const FlowArgs &f = *static_cast<const FlowArgs *>(fa);
+    const RqsParams<float> &pp = *static_cast<const RqsParams<float> *>(p);
+    return lu ? train_fwd_launch<true>(x, xlu_out, y, logdet, cond_out, act_out, f, B, hidden, num_blocks, pp, acc, (hipStream_t)stream)
+              : train_fwd_launch<false>(x, xlu_out, y, logdet, cond_out, act_out, f, B, hidden, num_blocks, pp, acc, (hipStream_t)stream);
+}
+#endif
+
 #ifndef NF_FUSED_SECONDARY
+extern "C" int nf_rqs_fused_train_fwd_nw4_(int lu, const void *x, void *xlu_out, void *y, void *logdet, void *cond_out, void *act_out,
+                                           const void *fa, int64_t B, int hidden, int num_blocks, const void *p, int acc,
+                                           nf_stream_t stream);
+// Batches of at most NF_FUSED_SMALL_ROWS rows run on 128-row workgroups (rqs_fused_nw4.hip; the note at nf_rqs_fused_chain).
+#ifndef NF_FUSED_SMALL_ROWS
+#define NF_FUSED_SMALL_ROWS 32768
+#endif
+static int g_small_batch = 1;
 
 // One-launch pack of a whole layer (8 bins, no LU) for the training forward nf_rqs_fused_train_full_fwd.
 extern "C" int nf_rqs_fused_pack_all(void *wpack, const void *w_init, const void *b_init, const void *const *w_blocks,
@@ -1177,20 +1215,11 @@ extern "C" int nf_rqs_fused_train_full_fwd(const void *x, void *y, void *logdet,
     fa.ngroups = F_K;
     for (int l = 0; l < F_MAX_LAYERS; ++l) fa.blob[l] = nullptr;
     fa.blob[0] = (const float *)wpack;
-    FusedLayout lay;
-    lay.nblk = num_blocks;
     auto p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
                                     min_derivative, sqrt((double)hidden));
-    const size_t lds = (size_t)(2 * F_STAGE + F_NW * 32 * 64 + lay.small_padded() + F_NW * 1536) * sizeof(float);
-    if (lds > 160 * 1024) return NF_ENOTSUP;
-    static LdsOptIn opted = {};
-    if (opt_in_lds(reinterpret_cast<const void *>(&rqs_fused_kernel<0, false, 2>), lds, opted) != NF_OK) return NF_ENOTSUP;
-    const int grid = (int)((B + F_ROWS - 1) / F_ROWS);
-    hipLaunchKernelGGL((rqs_fused_kernel<0, false, 2>), dim3(grid), dim3(F_THREADS), lds, (hipStream_t)stream, (const float *)x,
-                       (float *)y, (float *)logdet, fa, B, num_blocks, p, acc, (const float *)nullptr, (float *)cond_out,
-                       (float)(sqrt((double)hidden) / 1.4426950408889634), (float *)act_out);
-    NF_CHECK_LAUNCH();
-    return NF_OK;
+    if (g_small_batch && B <= NF_FUSED_SMALL_ROWS)
+        return nf_rqs_fused_train_fwd_nw4_(0, x, nullptr, y, logdet, cond_out, act_out, &fa, B, hidden, num_blocks, &p, acc, stream);
+    return train_fwd_launch<false>(x, nullptr, y, logdet, cond_out, act_out, fa, B, hidden, num_blocks, p, acc, (hipStream_t)stream);
 }
 
 // Whole-layer training forward WITH the layer's LULinearPermute.inverse in front of the coupling (round 6): the launch of
@@ -1210,20 +1239,11 @@ extern "C" int nf_rqs_fused_train_pair_fwd(const void *x, void *xlu_out, void *y
     fa.ngroups = F_K;
     for (int l = 0; l < F_MAX_LAYERS; ++l) fa.blob[l] = nullptr;
     fa.blob[0] = (const float *)wpack;
-    FusedLayout lay;
-    lay.nblk = num_blocks;
     auto p = make_rqs_params<float>(K, NF_TAILS_LINEAR, tail_bound, 0, 1, 0, 1, min_bin_width, min_bin_height,
                                     min_derivative, sqrt((double)hidden));
-    const size_t lds = (size_t)(2 * F_STAGE + F_NW * 32 * 64 + lay.small_padded() + F_NW * 1536) * sizeof(float);
-    if (lds > 160 * 1024) return NF_ENOTSUP;
-    static LdsOptIn opted = {};
-    if (opt_in_lds(reinterpret_cast<const void *>(&rqs_fused_kernel<0, true, 2>), lds, opted) != NF_OK) return NF_ENOTSUP;
-    const int grid = (int)((B + F_ROWS - 1) / F_ROWS);
-    hipLaunchKernelGGL((rqs_fused_kernel<0, true, 2>), dim3(grid), dim3(F_THREADS), lds, (hipStream_t)stream, (const float *)x,
-                       (float *)y, (float *)logdet, fa, B, num_blocks, p, acc, (const float *)nullptr, (float *)cond_out,
-                       (float)(sqrt((double)hidden) / 1.4426950408889634), (float *)act_out, (float *)xlu_out);
-    NF_CHECK_LAUNCH();
-    return NF_OK;
+    if (g_small_batch && B <= NF_FUSED_SMALL_ROWS)
+        return nf_rqs_fused_train_fwd_nw4_(1, x, xlu_out, y, logdet, cond_out, act_out, &fa, B, hidden, num_blocks, &p, acc, stream);
+    return train_fwd_launch<true>(x, xlu_out, y, logdet, cond_out, act_out, fa, B, hidden, num_blocks, p, acc, (hipStream_t)stream);
 }
 
 // The LU stage of n training blobs in one launch (once per step, behind nf_rqs_fused_pack_all_multi).  table (device): n rows of
@@ -1410,10 +1430,6 @@ extern "C" int nf_rqs_fused_chain_nw4_(const void *x, void *y, void *logdet, con
 // sharing its matrix pipe: 3.0 ms per pass (32 768 rows: 6.0 -> 10.8 M rows/s).  Above that the 8-wave layout wins (one weight stream
 // and one barrier per 256 rows: 65 536 rows 12.07 vs 10.92 M rows/s).  nf_rqs_fused_small_batch(0) keeps every batch on the 8-wave
 // kernel (differential tests).
-#ifndef NF_FUSED_SMALL_ROWS
-#define NF_FUSED_SMALL_ROWS 32768
-#endif
-static int g_small_batch = 1;
 extern "C" int nf_rqs_fused_small_batch(int enable) {
     const int old = g_small_batch;
     if (enable >= 0) g_small_batch = enable ? 1 : 0;

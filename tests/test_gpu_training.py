@@ -115,7 +115,7 @@ def _c2_train_model_and_fixture(nfa):
     return m.to(DEV), g
 
 
-def test_benchmark_shape_training_step_vs_reference_autograd(nfa, monkeypatch):
+def test_benchmark_shape_training_step_vs_reference_autograd(train_workgroups, nfa, monkeypatch):
     """The kernels the training step of the BENCHMARK model runs -- the one-launch training forward of a [LU, coupling] pair
     (nf_rqs_fused_train_pair_fwd = rqs_fused_kernel<0,true,2>), nf_coupling_train_bwd (nf_final_bwd, the ring weight gradient,
     nf_resblock_bwd_partials, one reduction), nf_lu_bwd_composed -- against the REFERENCE's autograd (core.py:87-102 forward_kld + loss.backward()) at the benchmark layer shape
@@ -1271,6 +1271,37 @@ def test_pair_backward_tail_on_the_side_stream(nfa):
         ops.pair_train_bwd = orig
         nfa.config.set_train_reduce_async(False)          # (the default: measured, no gain -- config.py)
         flat.release()
+
+
+@pytest.fixture(params=["wg128", "wg256"])
+def train_workgroups(request, nfa):
+    """The whole-layer training forward on both workgroup sizes (round 6, late): batches of <= 32 768 rows take the 128-row build
+    (csrc/rqs_fused_nw4.hip) by default; "wg256" keeps them on the 256-row workgroups the benchmark batch runs on."""
+    old = nfa.config.set_fused_small_batch(request.param == "wg128")
+    yield request.param
+    nfa.config.set_fused_small_batch(old)
+
+
+def test_training_forward_workgroup_sizes_give_the_same_bits(nfa):
+    """nf_rqs_fused_train_pair_fwd / _full_fwd on 128-row and on 256-row workgroups: same source, same arithmetic per row -- the loss
+    and EVERY gradient of a training step agree bit for bit (the backward kernels read what the forward left row by row)."""
+    from bench import build_c2_model
+    m = build_c2_model(num_layers=3, sigma=0.05).to(DEV)
+    res = {}
+    try:
+        for B in (1024, 4160):
+            x = torch.randn(B, 64, device=DEV)
+            for mode in (True, False):
+                nfa.config.set_fused_small_batch(mode)
+                m.zero_grad(set_to_none=True)
+                loss = m.forward_kld(x)
+                loss.backward()
+                res[mode] = (float(loss.detach()), [p_.grad.clone() for p_ in m.parameters()])
+            assert res[True][0] == res[False][0]
+            for (n, _), a_, b_ in zip(m.named_parameters(), res[True][1], res[False][1]):
+                assert torch.equal(a_, b_), (B, n)
+    finally:
+        nfa.config.set_fused_small_batch(True)
 
 
 def test_ragged_training_batch_runs_padded_on_the_tile_kernels(nfa):
