@@ -318,7 +318,31 @@ def secondary(model, x):
         res["train_step"] = train_step_record(model, x, world=1)
     except Exception as exc:   # noqa: BLE001
         res["train_step"] = {"error": repr(exc)[:200]}
+    try:
+        res["other_batches"] = other_batches_record(model, x)
+    except Exception as exc:   # noqa: BLE001
+        res["other_batches"] = {"error": repr(exc)[:200]}
     return res
+
+
+def other_batches_record(model, x):
+    """log_prob of the benchmark model at smaller batches (round 6, late): a workgroup owns its rows for the whole 32-layer chain, so a
+    pass costs the same for any batch one round of workgroups holds; at <= 32 768 rows nf_rqs_fused_chain switches to 128-row
+    workgroups (csrc/rqs_fused_nw4.hip, bit-identical per row).  Eager launches, 20 passes each."""
+    out = {"workload": "log_prob of the BASELINE configs[1] model on the first B benchmark rows (eager launches, mean of 20 passes)"}
+    with torch.no_grad():
+        for B in (4096, 16384, 32768):
+            xb = x[:B].contiguous()
+            for _ in range(3):
+                model.log_prob(xb)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                model.log_prob(xb)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3 / 20
+            out["rows_%d" % B] = {"log_prob_ms": ms, "rows_per_s": B / ms * 1e3}
+    return out
 
 
 def train_mode(args, model, x, world, rank, dev):

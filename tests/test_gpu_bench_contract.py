@@ -48,6 +48,10 @@ def test_bench_emits_one_contract_line():
     assert abs(s["config4_glow"]["roofline_log_prob"]["flop"] - 665e9) < 5e9          # 665 GFLOP per 256-image batch
     assert s["config4_glow"]["roofline_train_step"]["flop"] == 3 * s["config4_glow"]["roofline_log_prob"]["flop"]
     assert "FlatParameters" in s["train_step"]["optimizer"] and s["train_step"]["ms_per_step"] < 40.0
+    # round 6 (late): smaller batches of the same model -- 128-row workgroups at <= 32 768 rows (a pass used to cost 5.4 ms for ANY batch)
+    ob = s["other_batches"]
+    assert "error" not in ob and isinstance(ob["workload"], str)
+    assert all(0.5 < ob["rows_%d" % B_]["log_prob_ms"] < 4.5 for B_ in (4096, 16384, 32768)), ob
 
 
 def test_bench_two_ranks_on_one_device():
