@@ -781,6 +781,59 @@ def test_one_pass_backward_kernels_use_no_scratch(nfa):
     assert seen == 4, seen
 
 
+@pytest.mark.parametrize("KB", [4, 8, 16])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_first_descent_level_before_the_knots_selects_the_same_bin(KB, inverse):
+    """numpy emulation of fused_common.hpp rqs_regs_h (round 6: the spline epilogue of nsf_wide.hip / made_fwd.hip decides the first
+    level of the bin descent from the two half sums of the softmax and builds only that half's knots) against the full knot
+    construction of rqs_regs_t: the same bin, the same knots and derivative logits for random parameter lists and inputs, both
+    directions, every bin count -- in float64, where the two orders of the prefix sum agree to 1e-12."""
+    left, right, bottom, top, min_w, min_h, edge = -3.0, 3.0, -3.0, 3.0, 1e-3, 1e-3, 0.5413
+    H = KB // 2
+    rng = np.random.default_rng(KB + 7 * inverse)
+
+    def full(x, prm):
+        ew, eh = np.exp2(prm[:KB] - prm[:KB].max()), np.exp2(prm[KB:2 * KB] - prm[KB:2 * KB].max())
+        pw, ph = np.cumsum(ew), np.cumsum(eh)
+        cw, ch = (right - left) * (1 - min_w * KB) / pw[-1], (top - bottom) * (1 - min_h * KB) / ph[-1]
+        kw, kh, dp = np.zeros(KB + 1), np.zeros(KB + 1), np.zeros(KB + 1)
+        kw[0], kh[0], kw[KB], kh[KB], dp[0], dp[KB] = left, bottom, right, top, edge, edge
+        for k in range(1, KB):
+            kw[k] = pw[k - 1] * cw + left + (right - left) * min_w * k
+            kh[k] = ph[k - 1] * ch + bottom + (top - bottom) * min_h * k
+            dp[k] = prm[2 * KB + k - 1]
+        s_, o_ = (kh, kw) if inverse else (kw, kh)
+        b = max(0, min(KB - 1, np.searchsorted(s_, x, side="right") - 1))
+        return np.array([s_[b], s_[b + 1], o_[b], o_[b + 1], dp[b], dp[b + 1]])
+
+    def lean(x, prm):
+        mw, mh = prm[:KB].max(), prm[KB:2 * KB].max()
+        ew, eh = np.exp2(prm[:KB] - mw), np.exp2(prm[KB:2 * KB] - mh)
+        hw, uw, hh, uh = ew[:H].sum(), ew[H:].sum(), eh[:H].sum(), eh[H:].sum()
+        cw, ch = (right - left) * (1 - min_w * KB) / (hw + uw), (top - bottom) * (1 - min_h * KB) / (hh + uh)
+        sw, sh = (right - left) * min_w, (top - bottom) * min_h
+        kwm, khm = hw * cw + left + sw * H, hh * ch + bottom + sh * H
+        c = x >= (khm if inverse else kwm)
+        w2 = prm[H:KB] if c else prm[:H]
+        h2 = prm[KB + H:2 * KB] if c else prm[KB:KB + H]
+        d2 = [(edge if i == H else prm[2 * KB + H + i - 1]) if c else (edge if i == 0 else prm[2 * KB + i - 1]) for i in range(H + 1)]
+        kw, kh = np.zeros(H + 1), np.zeros(H + 1)
+        kw[0], kh[0], kw[H], kh[H] = (kwm, khm, right, top) if c else (left, bottom, kwm, khm)
+        aw, ah, ko = (hw, hh, H) if c else (0.0, 0.0, 0)
+        for i in range(1, H):
+            aw += np.exp2(w2[i - 1] - mw)
+            ah += np.exp2(h2[i - 1] - mh)
+            kw[i], kh[i] = aw * cw + left + sw * (ko + i), ah * ch + bottom + sh * (ko + i)
+        s_, o_ = (kh, kw) if inverse else (kw, kh)
+        b = max(0, min(H - 1, np.searchsorted(s_, x, side="right") - 1))
+        return np.array([s_[b], s_[b + 1], o_[b], o_[b + 1], d2[b], d2[b + 1]])
+
+    for _ in range(2000):
+        prm = 2.0 * rng.normal(size=3 * KB)
+        x = rng.uniform(-3.0, 3.0)
+        np.testing.assert_allclose(lean(x, prm), full(x, prm), rtol=1e-10, atol=1e-10)
+
+
 def test_tile_engine_and_maf_kernels_use_no_scratch(nfa):
     """Round 6: every instantiation of the 64-row-tile kernels -- nf_nsf_wide's 36 (4 / 8 / 16 bins, both
     directions, with and without the LU, three shapes), MADE's forward in all four epilogue modes -- and of the one-pass MAF
