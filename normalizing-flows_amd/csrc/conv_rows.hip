@@ -52,6 +52,101 @@ conv3x3_gather_sum_kernel(const float *__restrict__ P, const float *__restrict__
     }
 }
 
+// Round 6 (late): the two kernels above cost 17 + 23 us per call in config 4's training step (384 calls: 7.8 ms of 51.6) -- 64-bit
+// divisions per element in the gather, and in the gather-sum lanes along x reading rows of P that lie `ld` floats apart (4 useful
+// bytes per 64-byte sector, each sector re-read by every channel's threads).  Same arithmetic, other mappings:
+//   gather: a thread keeps one k = tap C + c (its tap / channel decomposition is computed once) and walks over pixels with 32-bit
+//     index arithmetic; writes are 9 C contiguous floats per pixel.
+//   gather-sum: a block takes 64 pixels x C channels, sums with the CHANNEL fastest across lanes (each tap read is a contiguous run
+//     of C floats of one row of P), transposes through LDS and writes NCHW runs along the pixels.
+__global__ void __launch_bounds__(256)
+conv3x3_gather_rows_kernel(const float *__restrict__ in, float *__restrict__ col, int npx, int C, int H, int W, int ld, int flip,
+                           int64_t sb, int KP) {
+    const int K = 9 * C, HW = H * W;
+    const int kl = threadIdx.x % KP, pl = threadIdx.x / KP, ppb = 256 / KP;
+    for (int k = kl; k < K; k += KP) {
+        const int tap = k / C, c = k - tap * C;
+        int dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
+        if (flip) { dy = -dy; dx = -dx; }
+        const int coff = c * HW;
+        for (int r = blockIdx.x * ppb + pl; r < npx; r += gridDim.x * ppb) {
+            const int b = r / HW, pin = r - b * HW, yh = pin / W, xw = pin - yh * W;
+            const int yy = yh + dy, xx = xw + dx;
+            float v = 0.0f;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = in[(int64_t)b * sb + coff + yy * W + xx];
+            col[(int64_t)r * ld + k] = v;
+        }
+    }
+}
+
+// gather, whole images through LDS (C H W <= 12288 floats): a block reads its image once, coalesced, and writes the 9 C-float rows of
+// its share of the pixels from LDS -- the rows kernel above reads every input value nine times as scattered 4-byte loads.  A thread
+// keeps one k; the pixels' (y, x) come from a table built with the image (no division in the element loop).
+__global__ void __launch_bounds__(256)
+conv3x3_gather_img_kernel(const float *__restrict__ in, float *__restrict__ col, int C, int H, int W, int ld, int flip, int64_t sb,
+                          int KP, int S) {
+    extern __shared__ float img[];                 // [C][H][W] then HW packed (y << 16 | x)
+    const int HW = H * W, n = C * HW, K = 9 * C;
+    int *pyx = reinterpret_cast<int *>(img + n);
+    const int b = blockIdx.x / S, part = blockIdx.x - b * S;
+    const float *src = in + (int64_t)b * sb;
+    for (int i = threadIdx.x; i < n; i += 256) img[i] = src[i];
+    for (int i = threadIdx.x; i < HW; i += 256) { const int y = i / W; pyx[i] = (y << 16) | (i - y * W); }
+    __syncthreads();
+    const int p0 = (int)((int64_t)HW * part / S), p1 = (int)((int64_t)HW * (part + 1) / S);
+    const int kl = threadIdx.x % KP, pl = threadIdx.x / KP, ppb = 256 / KP;
+    float *dst = col + (int64_t)b * HW * ld;
+    for (int k = kl; k < K; k += KP) {
+        const int tap = k / C, c = k - tap * C;
+        int dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
+        if (flip) { dy = -dy; dx = -dx; }
+        const float *ic = img + c * HW;
+        for (int pin = p0 + pl; pin < p1; pin += ppb) {
+            const int yx = pyx[pin], yy = (yx >> 16) + dy, xx = (yx & 0xffff) + dx;
+            float v = 0.0f;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = ic[yy * W + xx];
+            dst[(int64_t)pin * ld + k] = v;
+        }
+    }
+}
+
+// GS_PX pixels per block round of the gather-sum: the largest of 64 / 32 / 16 that still gives the launch >= 2048 blocks (each block
+// round is a chain of dependent-latency steps: the more rounds in flight, the better the loads overlap)
+template <int GS_PX>
+__global__ void __launch_bounds__(256)
+conv3x3_gather_sum_rows_kernel(const float *__restrict__ P, const float *__restrict__ bias, float *__restrict__ out, int npx, int C,
+                               int H, int W, int ld, int flip) {
+    extern __shared__ float tile[];          // [C][GS_PX + 1]
+    const int HW = H * W, n = GS_PX * C;
+    for (int r0 = blockIdx.x * GS_PX; r0 < npx; r0 += gridDim.x * GS_PX) {
+        for (int idx = threadIdx.x; idx < n; idx += 256) {
+            const int px = idx / C, c = idx - px * C, r = r0 + px;
+            float s = 0.0f;
+            if (r < npx) {
+                const int b = r / HW, pin = r - b * HW, yh = pin / W, xw = pin - yh * W;
+                s = bias ? bias[c] : 0.0f;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {       // (the order of the one-thread-per-element kernel: same bits)
+                    int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                    if (flip) { dy = -dy; dx = -dx; }
+                    const int yy = yh + dy, xx = xw + dx;
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) s += P[((int64_t)(b * HW + yy * W + xx)) * ld + tap * C + c];
+                }
+            }
+            tile[c * (GS_PX + 1) + px] = s;
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < n; idx += 256) {
+            const int c = idx / GS_PX, px = idx - c * GS_PX, r = r0 + px;
+            if (r < npx) {
+                const int b = r / HW, pin = r - b * HW;
+                out[((int64_t)b * C + c) * HW + pin] = tile[c * (GS_PX + 1) + px];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace nf
 
 // col (B H W, ld >= 9 C) from the NCHW tensor `in` (batch stride `batch_stride` elements >= C H W: a channel split of a wider tensor is
@@ -61,6 +156,29 @@ extern "C" int nf_conv3x3_gather(const void *in, void *col, int64_t B, int C, in
     if (B < 0 || C < 1 || H < 1 || W < 1 || ld < 9 * C || (flip != 0 && flip != 1) || batch_stride < (int64_t)C * H * W) return NF_EINVAL;
     if (B == 0) return NF_OK;
     if (!in || !col) return NF_EFAULT;
+#ifndef NF_CONV_ELEMENTWISE      // (-DNF_CONV_ELEMENTWISE: the one-thread-per-element kernels of rounds 4-5)
+    if (B * H * W < (1ll << 30) && (int64_t)C * H * W < (1ll << 30)) {
+        const int npx = (int)(B * H * W), K = 9 * C;
+        int KP = 1;
+        while (KP < K && KP < 256) KP <<= 1;
+        if ((int64_t)C * H * W <= 12288 && H < 32768 && W < 65536 && B <= 1 << 20) {
+            int S = 1;                                       // blocks per image: >= 1024 blocks where the images allow
+            while (B * S < 1024 && 2 * S <= H * W / 16 && S < 16) S *= 2;
+            hipLaunchKernelGGL(nf::conv3x3_gather_img_kernel, dim3((unsigned)(B * S)), dim3(256),
+                               (size_t)(C * H * W + H * W) * sizeof(float), (hipStream_t)stream, (const float *)in, (float *)col, C, H, W,
+                               ld, flip, batch_stride, KP, S);
+            NF_CHECK_LAUNCH();
+            return NF_OK;
+        }
+        const int ppb = 256 / KP;
+        int grid = (npx + ppb - 1) / ppb;
+        if (grid > 256 * 16) grid = 256 * 16;
+        hipLaunchKernelGGL(nf::conv3x3_gather_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float *)in, (float *)col,
+                           npx, C, H, W, ld, flip, batch_stride, KP);
+        NF_CHECK_LAUNCH();
+        return NF_OK;
+    }
+#endif
     hipLaunchKernelGGL(nf::conv3x3_gather_kernel, dim3(nf::grid_for(B * H * W * 9 * C, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float *)in, (float *)col, B, C, H, W, ld, flip, batch_stride);
     NF_CHECK_LAUNCH();
@@ -73,6 +191,26 @@ extern "C" int nf_conv3x3_gather_sum(const void *P, const void *bias, void *out,
     if (B < 0 || C < 1 || H < 1 || W < 1 || ld < 9 * C || (flip != 0 && flip != 1)) return NF_EINVAL;
     if (B == 0) return NF_OK;
     if (!P || !out) return NF_EFAULT;
+#ifndef NF_CONV_ELEMENTWISE
+    if (B * H * W < (1ll << 30) && C <= 128) {
+        const int npx = (int)(B * H * W);
+        const int gpx = npx / 64 >= 2048 ? 64 : (npx / 32 >= 2048 ? 32 : 16);
+        int grid = (npx + gpx - 1) / gpx;
+        if (grid > 256 * 64) grid = 256 * 64;
+        const size_t lds = (size_t)C * (gpx + 1) * sizeof(float);
+        if (gpx == 64)
+            hipLaunchKernelGGL(nf::conv3x3_gather_sum_rows_kernel<64>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const float *)P,
+                               (const float *)bias, (float *)out, npx, C, H, W, ld, flip);
+        else if (gpx == 32)
+            hipLaunchKernelGGL(nf::conv3x3_gather_sum_rows_kernel<32>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const float *)P,
+                               (const float *)bias, (float *)out, npx, C, H, W, ld, flip);
+        else
+            hipLaunchKernelGGL(nf::conv3x3_gather_sum_rows_kernel<16>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const float *)P,
+                               (const float *)bias, (float *)out, npx, C, H, W, ld, flip);
+        NF_CHECK_LAUNCH();
+        return NF_OK;
+    }
+#endif
     hipLaunchKernelGGL(nf::conv3x3_gather_sum_kernel, dim3(nf::grid_for(B * C * H * W, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float *)P, (const float *)bias, (float *)out, B, C, H, W, ld, flip);
     NF_CHECK_LAUNCH();
