@@ -147,7 +147,19 @@ inv1x1_conv_kernel(const T *__restrict__ z, const T *__restrict__ W, const T *__
 #pragma unroll
         for (int j = 0; j < OT; ++j) a[j] = (obias && ot * OT + j < C) ? obias[ot * OT + j] : T(0);
         const T *wrow = Wt + ot * OT;
-        for (int c = 0; c < C; ++c) {
+        int c = 0;
+        for (; c + 4 <= C; c += 4) {         // four channel loads in flight (round 6: the loop was one dependent load per iteration)
+            const T z0 = zb[(int64_t)c * HW], z1 = zb[(int64_t)(c + 1) * HW], z2 = zb[(int64_t)(c + 2) * HW], z3 = zb[(int64_t)(c + 3) * HW];
+#pragma unroll
+            for (int j = 0; j < OT; ++j) a[j] += wrow[c * Cp + j] * z0;
+#pragma unroll
+            for (int j = 0; j < OT; ++j) a[j] += wrow[(c + 1) * Cp + j] * z1;
+#pragma unroll
+            for (int j = 0; j < OT; ++j) a[j] += wrow[(c + 2) * Cp + j] * z2;
+#pragma unroll
+            for (int j = 0; j < OT; ++j) a[j] += wrow[(c + 3) * Cp + j] * z3;
+        }
+        for (; c < C; ++c) {
             const T zc = zb[(int64_t)c * HW];
 #pragma unroll
             for (int j = 0; j < OT; ++j) a[j] += wrow[c * Cp + j] * zc;

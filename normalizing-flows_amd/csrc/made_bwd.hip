@@ -308,30 +308,43 @@ made_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ gra
     const int m0 = tl[1], n0 = tl[2], want_bias = tl[3];
     const int *rowmap = sc + ps[3], *colmap = sc + ps[4];
     const int nel = MW_T * MW_T + (want_bias ? MW_T : 0);
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < nel; e += gridDim.x * 256) {
+    // Round 6 (late): 64 elements x 4 chunk lanes per block (lane q sums chunks q, q + 4, ... in four interleaved accumulators, the
+    // four lanes are combined in lane order through LDS: a fixed order, deterministic) -- one thread per element walked all chunks as
+    // one chain of dependent-latency loads (24 us per call in config 4's training step, 16 blocks per tile).
+    __shared__ float sm[4][64];
+    const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
+    for (int e0 = blockIdx.x * 64; e0 < nel; e0 += gridDim.x * 64) {
+        const int e = e0 + el;
         float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-        const float *p = part + (size_t)t * MW_PART + e;
-        const size_t stride = (size_t)ntl * MW_PART;
-        int c = 0;
-        for (; c + 3 < chunks; c += 4) {
-            s0 += p[(size_t)c * stride];
-            s1 += p[(size_t)(c + 1) * stride];
-            s2 += p[(size_t)(c + 2) * stride];
-            s3 += p[(size_t)(c + 3) * stride];
-        }
-        for (; c < chunks; ++c) s0 += p[(size_t)c * stride];
-        const float s = (s0 + s1) + (s2 + s3);
-        if (e < MW_T * MW_T) {
-            const int row = rowmap[m0 + (e >> 7)], col = colmap[n0 + (e & 127)];
-            if (row >= 0 && col >= 0) {
-                const size_t dst = (size_t)ps[0] + (size_t)row * ps[1] + col;
-                if (mask[dst]) grads[dst] = s;
+        if (e < nel) {
+            const float *p = part + (size_t)t * MW_PART + e;
+            const size_t stride = (size_t)ntl * MW_PART;
+            int c = q;
+            for (; c + 12 < chunks; c += 16) {
+                s0 += p[(size_t)c * stride];
+                s1 += p[(size_t)(c + 4) * stride];
+                s2 += p[(size_t)(c + 8) * stride];
+                s3 += p[(size_t)(c + 12) * stride];
             }
-        } else {
-            const int *bmap = ps[5] ? sc + ps[5] : rowmap;
-            const int row = bmap[m0 + (e - MW_T * MW_T)];
-            if (row >= 0) grads[(size_t)ps[2] + row] = s;
+            for (; c < chunks; c += 4) s0 += p[(size_t)c * stride];
         }
+        sm[q][el] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (q == 0 && e < nel) {
+            const float s = (sm[0][el] + sm[1][el]) + (sm[2][el] + sm[3][el]);
+            if (e < MW_T * MW_T) {
+                const int row = rowmap[m0 + (e >> 7)], col = colmap[n0 + (e & 127)];
+                if (row >= 0 && col >= 0) {
+                    const size_t dst = (size_t)ps[0] + (size_t)row * ps[1] + col;
+                    if (mask[dst]) grads[dst] = s;
+                }
+            } else {
+                const int *bmap = ps[5] ? sc + ps[5] : rowmap;
+                const int row = bmap[m0 + (e - MW_T * MW_T)];
+                if (row >= 0) grads[(size_t)ps[2] + row] = s;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -421,7 +434,7 @@ extern "C" int nf_made_wgrad(const void *gp_pad, const void *x_pad, const void *
     hipLaunchKernelGGL(nf::made_wgrad_kernel, grid, dim3(nf::MW_NT), 0, st, (const float *)gp_pad, (const float *)x_pad,
                        (const float *)G, (const float *)save, (float *)part, (const int *)wtable, rows, Bp, tile_major);
     NF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(nf::made_wgrad_reduce_kernel, dim3(16, (unsigned)ntiles), dim3(256), 0, st, (const float *)part, (float *)grads,
+    hipLaunchKernelGGL(nf::made_wgrad_reduce_kernel, dim3(64, (unsigned)ntiles), dim3(256), 0, st, (const float *)part, (float *)grads,
                        (const unsigned char *)mask, (const int *)wtable, (const int *)stable, chunks);
     NF_CHECK_LAUNCH();
     return NF_OK;
