@@ -677,6 +677,9 @@ int nf_conv3x3_gather(const void *in, void *col, int64_t B, int C, int H, int W,
                       nf_stream_t stream);
 int nf_conv3x3_gather_sum(const void *P, const void *bias, void *out, int64_t B, int C, int H, int W, int ld, int flip,
                           nf_stream_t stream);
+/* out (C) = sum over batch and pixels of g (B, C, H, W) (float32 NCHW): the bias gradient of the conditioner's last convolution
+ * (nets/cnn.py:5-63 under loss.backward(); torch: conv2d's bias backward).  One block per channel, fixed order. */
+int nf_channel_sum(const void *g, void *out, int64_t B, int C, int64_t HW, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * MaskedAffineAutoregressive inverse (MAF sampling direction) in ONE pass.  Replaces the D-pass loop of

@@ -945,7 +945,7 @@ class ConvNetFn(torch.autograd.Function):
         gw1 = flat[o0:o0 + s0[0] * s0[1]].view(hid, Cin, 3, 3)
         gw2 = flat[o1:o1 + s1[0] * s1[1]].view(hid, hid, 1, 1)
         gw3 = flat[o2:o2 + s2[0] * s2[1]].view(Cout, hid, 3, 3)
-        return None, None, gx, gw1, flat[c0:c0 + n0], gw2, flat[c1:c1 + n1], gw3, gout.sum((0, 2, 3))
+        return None, None, gx, gw1, flat[c0:c0 + n0], gw2, flat[c1:c1 + n1], gw3, ops.channel_sum(gout)
 
 
 class MafInverseFn(torch.autograd.Function):

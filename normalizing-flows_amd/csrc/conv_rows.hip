@@ -147,6 +147,34 @@ conv3x3_gather_sum_rows_kernel(const float *__restrict__ P, const float *__restr
     }
 }
 
+// out[c] = sum over b, y, x of g[b][c][y][x]: the last convolution's bias gradient (the reference's autograd: conv2d's bias backward).
+// One block per channel, 16-byte loads along the pixels, a fixed summation order (deterministic); replaces `gout.sum((0, 2, 3))`
+// (a generic strided torch reduction: 15-31 us per call in config 4's training step).
+typedef float cs_f32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(1024)
+channel_sum_kernel(const float *__restrict__ g, float *__restrict__ out, int B, int C, int HW) {
+    __shared__ float sc[32];
+    const int c = blockIdx.x;
+    float s0 = 0.0f, s1 = 0.0f;
+    if ((HW & 3) == 0) {
+        const int q = HW >> 2, n = B * q;
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const int b = i / q, p = i - b * q;
+            const cs_f32x4 v = *reinterpret_cast<const cs_f32x4 *>(g + ((int64_t)b * C + c) * HW + 4 * p);
+            s0 += v[0] + v[1];
+            s1 += v[2] + v[3];
+        }
+    } else {
+        const int n = B * HW;
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const int b = i / HW, p = i - b * HW;
+            s0 += g[((int64_t)b * C + c) * HW + p];
+        }
+    }
+    const float tot = block_sum(s0 + s1, sc);
+    if (threadIdx.x == 0) out[c] = tot;
+}
+
 }  // namespace nf
 
 // col (B H W, ld >= 9 C) from the NCHW tensor `in` (batch stride `batch_stride` elements >= C H W: a channel split of a wider tensor is
@@ -213,6 +241,17 @@ extern "C" int nf_conv3x3_gather_sum(const void *P, const void *bias, void *out,
 #endif
     hipLaunchKernelGGL(nf::conv3x3_gather_sum_kernel, dim3(nf::grid_for(B * C * H * W, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float *)P, (const float *)bias, (float *)out, B, C, H, W, ld, flip);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// out (C) = sum of g (B, C, H, W) over batch and pixels (float32, contiguous NCHW, 16-byte aligned when H W % 4 == 0).
+extern "C" int nf_channel_sum(const void *g, void *out, int64_t B, int C, int64_t HW, nf_stream_t stream) {
+    if (B < 0 || C < 1 || HW < 1 || B * HW >= (1ll << 31)) return NF_EINVAL;
+    if (!out || (B > 0 && !g)) return NF_EFAULT;
+    if ((HW & 3) == 0 && ((uintptr_t)g & 15)) return NF_EINVAL;
+    hipLaunchKernelGGL(nf::channel_sum_kernel, dim3(C), dim3(1024), 0, (hipStream_t)stream, (const float *)g, (float *)out, (int)B, C,
+                       (int)HW);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

@@ -977,6 +977,18 @@ def conv3x3_gather_sum(P, bias, shape, flip=False):
     return out
 
 
+def channel_sum(g):
+    """(C) = g (B, C, H, W).sum((0, 2, 3)) in one launch with a fixed summation order (nf_channel_sum)."""
+    L.require_device(g)
+    g = g.contiguous()
+    if g.dtype != torch.float32 or g.dim() != 4:
+        raise ValueError("channel_sum: a float32 (B, C, H, W) tensor")
+    B, C, H, W = g.shape
+    out = torch.empty(C, dtype=g.dtype, device=g.device)
+    L.check(L.lib().nf_channel_sum(ptr(g), ptr(out), i64(B), i32(C), i64(H * W), L.stream()), "nf_channel_sum")
+    return out
+
+
 def maf_affine_bwd(x, params, gy, gld, direction):
     """Backward of maf_affine (nf_maf_affine_bwd): (g_x (B, D), g_params shaped like params); gy / gld may be None."""
     L.require_device(x, params)

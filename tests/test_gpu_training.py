@@ -1304,6 +1304,24 @@ def test_training_forward_workgroup_sizes_give_the_same_bits(nfa):
         nfa.config.set_fused_small_batch(True)
 
 
+@pytest.mark.parametrize("shape", [(256, 12, 16, 16), (7, 5, 3, 3), (64, 48, 4, 4), (1, 1, 1, 1), (33, 3, 5, 7)])
+def test_channel_sum_vs_torch(nfa, shape):
+    """nf_channel_sum (the conditioner's last bias gradient, round 6): g.sum((0, 2, 3)) in one launch with a fixed order -- equal to the
+    float64 sum to float32 rounding, the same bits on every call, errno codes for bad arguments."""
+    import ctypes as C
+    from normflows_amd import _lib as L, ops
+    g = torch.randn(*shape, device=DEV)
+    s1, s2 = ops.channel_sum(g), ops.channel_sum(g)
+    ref = g.double().sum((0, 2, 3))
+    assert torch.equal(s1, s2)
+    assert float((s1.double() - ref).abs().max()) <= 1e-5 * max(float(g.abs().sum((0, 2, 3)).max()), 1.0)
+    lib, st = L.lib(), L.stream()
+    one = C.c_void_p(16)
+    assert lib.nf_channel_sum(C.c_void_p(0), one, C.c_int64(4), C.c_int(3), C.c_int64(16), st) == -14       # NULL input
+    assert lib.nf_channel_sum(one, one, C.c_int64(4), C.c_int(0), C.c_int64(16), st) == -22                 # C < 1
+    assert lib.nf_channel_sum(one, one, C.c_int64(-1), C.c_int(3), C.c_int64(16), st) == -22                # B < 0
+
+
 def test_ragged_training_batch_runs_padded_on_the_tile_kernels(nfa):
     """A differentiable density pass on a batch that is not a multiple of 64 rows (round 6, late; config.train_pad_batch): the model pads
     the batch with zero rows to whole 64-row tiles, runs the pair kernels and slices the result back -- the padding rows get a zero
