@@ -370,6 +370,9 @@ int nf_inv1x1_conv(const void *z, const void *W, const void *logdet_unit, void *
 int nf_inv1x1_conv_affine(const void *z, const void *W, const void *bias, const void *logdet_unit, void *y,
                           void *logdet_scalar, void *logdet, int64_t B, int C, int64_t HW, int acc, int dtype,
                           nf_stream_t stream);
+/* y = W^T z per pixel, no log-det: the 1x1 convolution's input gradient under autograd (mixing.py:106-133 through loss.backward())
+ * without a transposed copy of W. */
+int nf_inv1x1_conv_t(const void *z, const void *W, void *y, int64_t B, int C, int64_t HW, int dtype, nf_stream_t stream);
 
 
 /* ------------------------------------------------------------------------------------------------
@@ -664,6 +667,10 @@ int nf_made_wgrad(const void *gp_pad, const void *x_pad, const void *G, const vo
  * the network flattened], src = the packer's stream with parameter positions in place of values (made_pack.train_structure) -- the
  * reference re-reads its nn.Parameters in every forward; a host-side repack per optimizer step would cost more than the step. */
 int nf_pack_gather(const void *flat, const int32_t *src, void *out, int64_t n, nf_stream_t stream);
+/* nf_pack_gather from the parameter tensors in place (round 6): params = n_params <= 8 host pointers to device float32 tensors of
+ * numels[j] elements; the virtual flat vector is [0, params[0] ..., params[1] ..., ...] as above -- no concatenation per call. */
+int nf_pack_gather_multi(const void *const *params, const int64_t *numels, int n_params, const int32_t *src, void *out, int64_t n,
+                         nf_stream_t stream);
 
 /* GlowBlock's conv conditioner under autograd.  Replaces what torch autograd + the convolution library do for
  * normflows/nets/cnn.py:5-63 (ConvNet2d: Conv2d 3x3 -> LeakyReLU(0) -> Conv2d 1x1 -> LeakyReLU(0) -> Conv2d 3x3, padding 1) inside

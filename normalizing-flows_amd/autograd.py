@@ -813,9 +813,8 @@ class Inv1x1Fn(torch.autograd.Function):
             gy = torch.zeros_like(z)
         gz = gW = gl = None
         if z.shape[1] <= 64:
-            zero = _zero_scalar(z.device, z.dtype)
-            if ctx.needs_input_grad[0]:      # gz = W^T gy per pixel: the forward kernel on the transposed matrix
-                gz, _ = ops.inv1x1_conv(gy.contiguous(), W.detach().t().contiguous(), zero, want_scalar=False)
+            if ctx.needs_input_grad[0]:      # gz = W^T gy per pixel: the forward kernel reading W transposed (no copy)
+                gz = ops.inv1x1_conv_t(gy, W.detach())
             if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
                 gW, gl = ops.inv1x1_wgrad(z, gy, gld)                                 # csrc/affine_bwd.hip
             return gz, gW, gl

@@ -126,13 +126,13 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 inv1x1_conv_kernel(const T *__restrict__ z, const T *__restrict__ W, const T *__restrict__ logdet_unit,
                    T *__restrict__ y, T *__restrict__ logdet_scalar, T *__restrict__ logdet, int64_t B, int C,
-                   int64_t HW, int acc, const T *__restrict__ obias) {
+                   int64_t HW, int acc, const T *__restrict__ obias, int wt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *Wt = reinterpret_cast<T *>(smem_raw);  // [c][Cp] : Wt[c][o] = W[o][c], row pitch Cp = roundup(C, OT)
     const int Cp = (C + OT - 1) / OT * OT;
     for (int i = threadIdx.x; i < C * Cp; i += blockDim.x) {
         const int c = i / Cp, o = i - c * Cp;
-        Wt[i] = o < C ? W[o * C + c] : T(0);
+        Wt[i] = o < C ? (wt ? W[c * C + o] : W[o * C + c]) : T(0);      // wt: the product with W^T (the backward's gz = W^T gy)
     }
     __syncthreads();
     const int64_t npix = B * HW;
@@ -193,7 +193,7 @@ static int launch_assemble(const void *P, const void *L, const void *U, const vo
 
 template <typename T>
 static int launch_conv(const void *z, const void *W, const void *logdet_unit, void *y, void *logdet_scalar, void *logdet,
-                       int64_t B, int C, int64_t HW, int acc, hipStream_t st, const void *obias = nullptr) {
+                       int64_t B, int C, int64_t HW, int acc, hipStream_t st, const void *obias = nullptr, int wt = 0) {
     const int Cp = (C + OT - 1) / OT * OT;
     const size_t lds = (size_t)C * Cp * sizeof(T);
     if (lds > 160 * 1024) return NF_ENOTSUP;
@@ -202,7 +202,7 @@ static int launch_conv(const void *z, const void *W, const void *logdet_unit, vo
     const int64_t nwork = B * HW * (Cp / OT);
     const int grid = grid_for(nwork > 0 ? nwork : 1, 256);
     hipLaunchKernelGGL(inv1x1_conv_kernel<T>, dim3(grid), dim3(256), lds, st, (const T *)z, (const T *)W,
-                       (const T *)logdet_unit, (T *)y, (T *)logdet_scalar, (T *)logdet, B, C, HW, acc, (const T *)obias);
+                       (const T *)logdet_unit, (T *)y, (T *)logdet_scalar, (T *)logdet, B, C, HW, acc, (const T *)obias, wt);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -227,6 +227,18 @@ extern "C" int nf_inv1x1_conv(const void *z, const void *W, const void *logdet_u
     hipStream_t st = (hipStream_t)stream;
     if (dtype == NF_F32) return nf::launch_conv<float>(z, W, logdet_unit, y, logdet_scalar, logdet, B, C, HW, acc, st);
     if (dtype == NF_F64) return nf::launch_conv<double>(z, W, logdet_unit, y, logdet_scalar, logdet, B, C, HW, acc, st);
+    return NF_ENOTSUP;
+}
+
+// y = W^T z per pixel (no log-det): the input gradient of the 1x1 convolution under autograd (mixing.py:106-133 through
+// loss.backward()) without a transposed copy of W per call (round 6: 96 tiny transposes per step of config 4).
+extern "C" int nf_inv1x1_conv_t(const void *z, const void *W, void *y, int64_t B, int C, int64_t HW, int dtype, nf_stream_t stream) {
+    if (B < 0 || C < 1 || HW < 1) return NF_EINVAL;
+    if (!W) return NF_EFAULT;
+    if (B > 0 && (!z || !y)) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == NF_F32) return nf::launch_conv<float>(z, W, nullptr, y, nullptr, nullptr, B, C, HW, 0, st, nullptr, 1);
+    if (dtype == NF_F64) return nf::launch_conv<double>(z, W, nullptr, y, nullptr, nullptr, B, C, HW, 0, st, nullptr, 1);
     return NF_ENOTSUP;
 }
 

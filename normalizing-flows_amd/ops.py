@@ -244,6 +244,18 @@ def inv1x1_conv(z, W, logdet_unit, logdet=None, acc=None, want_scalar=True, bias
     return y, lds
 
 
+def inv1x1_conv_t(z, W):
+    """y = W^T z per pixel (nf_inv1x1_conv_t): the 1x1 convolution's input gradient without a transposed copy of W."""
+    L.require_device(z, W)
+    z = z.contiguous()
+    B, Cc = z.shape[:2]
+    HW = int(math.prod(z.shape[2:]))
+    y = torch.empty_like(z)
+    L.check(L.lib().nf_inv1x1_conv_t(ptr(z), ptr(W.contiguous()), ptr(y), i64(B), i32(Cc), i64(HW), i32(L.dtype_code(z)), L.stream()),
+            "nf_inv1x1_conv_t")
+    return y
+
+
 # ---- backward of the affine family (csrc/affine_bwd.hip): closed-form vector-Jacobian products ------------------------
 def masked_affine_bwd(z, b, s, t, gy, gld, direction):
     """(gz, gs, gt) of nf_masked_affine for cotangents gy (like z) and gld (B) -- coupling.py:209-229 under autograd."""
@@ -1168,8 +1180,15 @@ def pack_gather(params, src):
     zero = _ZERO1.get(src.device)
     if zero is None:
         zero = _ZERO1[src.device] = torch.zeros(1, dtype=torch.float32, device=src.device)
-    flat = torch.cat([zero] + [p.detach().reshape(-1) for p in params])
     out = torch.empty(src.numel(), dtype=torch.float32, device=src.device)
+    if len(params) <= 8 and all(p.dtype == torch.float32 and p.is_contiguous() for p in params):
+        # round 6: straight from the parameter tensors (no torch.cat per module and step)
+        pp = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
+        nn_ = (C.c_int64 * len(params))(*[p.numel() for p in params])
+        rc = L.lib().nf_pack_gather_multi(pp, nn_, i32(len(params)), ptr(src), ptr(out), i64(src.numel()), L.stream())
+        L.check(rc, "nf_pack_gather_multi")
+        return out
+    flat = torch.cat([zero] + [p.detach().reshape(-1) for p in params])
     rc = L.lib().nf_pack_gather(ptr(flat), ptr(src), ptr(out), i64(src.numel()), L.stream())
     L.check(rc, "nf_pack_gather")
     return out
