@@ -21,6 +21,7 @@ import torch
 
 _streams = {}         # device index -> torch.cuda.Stream
 _dirty = set()        # device indices with side work not yet joined
+_keep = {}            # device index -> tensors the side work reads or writes, kept alive until the join (see fork)
 _aware = set()        # id() of post-accumulate-grad hook callables that call join() themselves before they read a gradient
 
 
@@ -60,6 +61,27 @@ def join():
     while _dirty:
         idx = _dirty.pop()
         torch.cuda.current_stream(idx).wait_stream(_streams[idx])
+        _keep.pop(idx, None)      # released only now: whatever reuses their memory on the current stream is ordered behind the wait
+
+
+def fork(device, keep=()):
+    """Inside a backward function: the side stream, ordered behind everything the current stream has been given so far, for launches
+    that only produce PARAMETER gradients (Glow's leaves, round 6: a GlowBlock's backward hands the previous block an input gradient
+    after ~60 % of its launches; the conditioner's weight gradients, the 1x1 convolution's weight / LU-factor gradients and their
+    reductions feed nothing downstream, and at the 8x8 / 4x4 levels no kernel of the step fills the chip).  `keep`: every tensor
+    the side launches touch whose last Python reference may die before the join -- the caching allocator would hand their memory to
+    the next allocation on the CURRENT stream while the side stream still reads it; they are released by join().  Tensors allocated
+    while the side stream is current belong to its pool and need no entry.  The join is queued on the autograd engine.  None when
+    no side stream may be created (first use under capture)."""
+    s = stream(device)
+    if s is None:
+        return None
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    s.wait_stream(torch.cuda.current_stream(idx))
+    _keep.setdefault(idx, []).extend(keep)
+    _dirty.add(idx)
+    queue_join()
+    return s
 
 
 def queue_join():

@@ -12,6 +12,7 @@ ResidualNets and GlowBlock's ConvNet2d through MadeFn / ConvNetFn (csrc/made_fwd
 anything else (contexts, batch norm, other activations) stays an ordinary torch module differentiated by autograd itself.  Layers
 switch to these Functions only when gradients are needed (`needs_grad`); under torch.no_grad() the fused inference kernels run.
 """
+import contextlib
 import math
 
 import torch
@@ -713,6 +714,22 @@ def _coupling_formula(z, param, c1, flip, scale_map, direction):
     return (torch.cat([z1, y2], 1) if not flip else torch.cat([y2, z1], 1)), ld
 
 
+def _leaf_fork(device, params, keep=()):
+    """The side stream for launches that only feed `params`' gradients (config.train_leaf_async, _sidestream.fork), or None: switched
+    off, not a GPU, or one of `params` would have its gradient read on the current stream before the join (an existing .grad to
+    accumulate into, hooks)."""
+    if not _config.train_leaf_async or device.type != "cuda":
+        return None
+    # (a non-leaf's gradient travels on through autograd nodes that run on the current stream: leaves only)
+    if not all(p_.is_leaf and _sidestream.nobody_reads_early(p_) for p_ in params if p_ is not None and p_.requires_grad):
+        return None
+    return _sidestream.fork(device, keep=[t for t in keep if t is not None])
+
+
+def _on(side):
+    return contextlib.nullcontext() if side is None else torch.cuda.stream(side)
+
+
 class AffineCouplingFn(torch.autograd.Function):
     """nf_affine_coupling (coupling.py:117-171 with the channel split / merge folded in) on a given `param`."""
 
@@ -774,7 +791,12 @@ class Inv1x1WeightFn(torch.autograd.Function):
         P, Lm, U, sign_S, log_S = ctx.saved_tensors
         if gW is None:
             gW = torch.zeros_like(Lm)
-        gL, gU, gs = ops.inv1x1_lu_grads(P, Lm.detach(), U.detach(), sign_S, log_S.detach(), gW, gl)
+        # (gW / gl may come from Inv1x1Fn's side-stream launch: stay on that stream, or join before reading them)
+        side = _leaf_fork(Lm.device, (Lm, U, log_S), keep=(gW, gl))
+        if side is None:
+            _sidestream.join()
+        with _on(side):
+            gL, gU, gs = ops.inv1x1_lu_grads(P, Lm.detach(), U.detach(), sign_S, log_S.detach(), gW, gl)
         return None, gL, gU, None, gs
 
 
@@ -816,7 +838,14 @@ class Inv1x1Fn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:      # gz = W^T gy per pixel: the forward kernel reading W transposed (no copy)
                 gz = ops.inv1x1_conv_t(gy, W.detach())
             if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-                gW, gl = ops.inv1x1_wgrad(z, gy, gld)                                 # csrc/affine_bwd.hip
+                # feeds only W's side (Inv1x1WeightFn.backward, which follows onto the side stream, or W.grad itself)
+                # -- but not W's of any other origin (slogdet's backward etc. run on the current stream)
+                fn = W.grad_fn
+                mine = W.is_leaf and not ldu.requires_grad
+                mine = mine or (fn is not None and fn is ldu.grad_fn and fn.name().startswith("Inv1x1WeightFn"))
+                side = _leaf_fork(z.device, (W,) if W.is_leaf else (), keep=(z, gy, gld)) if mine else None
+                with _on(side):
+                    gW, gl = ops.inv1x1_wgrad(z, gy, gld)                             # csrc/affine_bwd.hip
             return gz, gW, gl
         hw = z[0, 0].numel() if z.dim() > 2 else 1
 
@@ -920,6 +949,7 @@ class ConvNetFn(torch.autograd.Function):
         ctx.save_for_backward(col, save, bits)
         ctx.bwd, ctx.shape = bwd, (B, Cin, H, W)
         ctx.wshapes = (tuple(w1.shape), tuple(w2.shape), tuple(w3.shape))
+        ctx.params = (w1, b1, w2, b2, w3, b3)           # (asked at backward time whether anything reads their gradients early)
         return out
 
     @staticmethod
@@ -937,14 +967,18 @@ class ConvNetFn(torch.autograd.Function):
         gx = ops.conv3x3_gather_sum(gcol, None, (B, Cin, H, W), flip=True) if ctx.needs_input_grad[2] else None
         if not any(ctx.needs_input_grad[3:]):        # frozen conditioner: no weight-gradient launch
             return (None, None, gx) + (None,) * 6
-        flat = ops.made_wgrad(gP, col, G, save, bwd["wtable"], bwd["stable"], bwd["mask"], bwd["ntiles"], bwd["nflat"], bwd["Mp"],
-                              bwd["Dx"], rows=R)
+        # weight / bias gradients: nothing downstream of this block's backward waits for them (config.train_leaf_async)
+        side = _leaf_fork(gout.device, ctx.params, keep=(gP, col, G, save, gout))
+        with _on(side):
+            flat = ops.made_wgrad(gP, col, G, save, bwd["wtable"], bwd["stable"], bwd["mask"], bwd["ntiles"], bwd["nflat"], bwd["Mp"],
+                                  bwd["Dx"], rows=R)
+            gb3 = ops.channel_sum(gout)
         (o0, s0, c0, n0), (o1, s1, c1, n1), (o2, s2, _, _) = bwd["offsets"]
         # (the reduction scatters straight into the conv parameters' own (o, c, ky, kx) layouts: made_pack.convnet_train_structure)
         gw1 = flat[o0:o0 + s0[0] * s0[1]].view(hid, Cin, 3, 3)
         gw2 = flat[o1:o1 + s1[0] * s1[1]].view(hid, hid, 1, 1)
         gw3 = flat[o2:o2 + s2[0] * s2[1]].view(Cout, hid, 3, 3)
-        return None, None, gx, gw1, flat[c0:c0 + n0], gw2, flat[c1:c1 + n1], gw3, ops.channel_sum(gout)
+        return None, None, gx, gw1, flat[c0:c0 + n0], gw2, flat[c1:c1 + n1], gw3, gb3
 
 
 class MafInverseFn(torch.autograd.Function):

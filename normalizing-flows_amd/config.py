@@ -112,6 +112,23 @@ def set_train_reduce_async(mode=True):
     train_reduce_async = bool(mode)
 
 
+# Glow's training step (BASELINE configs[3]): the launches of a GlowBlock's backward that only produce PARAMETER gradients -- the conditioner's
+# weight gradients (made_wgrad + its reduction + the last bias sum), the 1x1 convolution's weight gradient and its LU factors' -- on the
+# side stream (_sidestream.fork), joined at the end of the backward pass.  Unlike the benchmark model's pair (above) the Glow step is
+# made of kernels that do not fill the chip: the 8x8 / 4x4 levels give the row-tile kernels 256 / 64 workgroups, the LU-factor and
+# reduction kernels are one-workgroup launches.  Taken per Function only when every parameter it feeds has no .grad to accumulate into
+# and no hooks (autograd adopts the tensor without a kernel); anything else joins first.
+# OFF by default -- measured (tools/glow_leaf_ab.py, alternating on one box, config 4): the step recorded as one hipGraph 44.57 / 44.40 ms
+# without, 43.98 / 44.13 ms with (same gradient bits): 12.5 ms of leaf launches per step move to a parallel branch of the graph and 0.4 ms
+# comes back -- the replayed graph does not run the branches side by side to any useful degree.
+train_leaf_async = False
+
+
+def set_train_leaf_async(mode=True):
+    global train_leaf_async
+    train_leaf_async = bool(mode)
+
+
 # A differentiable density pass of a benchmark-shaped model on a batch that is NOT a multiple of 64 rows (>= 1024) is run on the batch
 # padded with zero rows to the next multiple (NormalizingFlow._log_prob_impl) and sliced back: the one-call / pair training kernels need
 # whole 64-row tiles, and the slice's backward hands the padding rows a zero cotangent, so they contribute exactly nothing to any

@@ -2051,6 +2051,65 @@ def test_training_step_captures_into_one_graph(nfa):
         assert all(torch.equal(a, p.grad) for a, p in zip(eager, m.parameters()))
 
 
+def test_glow_parameter_gradient_launches_on_the_side_stream(nfa):
+    """config.train_leaf_async (round 6): the launches of a GlowBlock's backward that only produce parameter gradients run on a side
+    stream forked inside the backward functions and joined when the pass ends.  Same bits as the one-stream step -- eager, repeated
+    (a race would show up as a difference between repeats), with gradient accumulation (an existing .grad: the Functions must stay
+    on the current stream) and recorded into one hipGraph."""
+    torch.manual_seed(3)
+    fl = [[nfa.flows.GlowBlock(12, 256, split_mode="channel", scale=True) for _ in range(4)] + [nfa.flows.Squeeze()]]
+    m = nfa.MultiscaleFlow([nfa.distributions.DiagGaussian((12, 16, 16))], fl, [], class_cond=False).to(DEV)
+    x = torch.rand(64, 3, 32, 32, device=DEV)
+    with torch.no_grad():
+        m.log_prob(x)
+        for p in m.parameters():
+            p.add_(0.02 * torch.randn_like(p))
+
+    def step(zero=True):
+        if zero:
+            m.zero_grad(set_to_none=True)
+        m.forward_kld(x).backward()
+    from importlib import import_module
+    ss = import_module("normflows_amd._sidestream")
+    orig = ss.fork
+    try:
+        nfa.config.set_train_leaf_async(False)
+        step()
+        ref = [p.grad.clone() for p in m.parameters()]
+        step(zero=False)
+        ref2 = [p.grad.clone() for p in m.parameters()]
+        nfa.config.set_train_leaf_async(True)
+        forks = []
+        ss.fork = lambda *a, **k: (forks.append(1), orig(*a, **k))[1]
+        for _ in range(3):
+            step()
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, p.grad) for a, p in zip(ref, m.parameters()))
+        assert len(forks) == 3 * 4 * 3, len(forks)       # conditioner, 1x1 weight, LU factors: per block and step
+        n0 = len(forks)
+        step(zero=False)                                  # accumulation into an existing .grad: nothing may leave the current stream
+        torch.cuda.synchronize()
+        assert len(forks) == n0 + 4       # (the 1x1 convolution's weight gradient still forks: its consumer, the LU factors' backward, joins first)
+        ss.fork = orig
+        assert all(torch.equal(a, p.grad) for a, p in zip(ref2, m.parameters()))
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            step()
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        m.zero_grad(set_to_none=True)
+        with torch.cuda.graph(g):
+            m.forward_kld(x).backward()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, p.grad) for a, p in zip(ref, m.parameters()))
+    finally:
+        ss.fork = orig
+        nfa.config.set_train_leaf_async(False)
+
+
 def test_maf_one_pass_backward_on_format0_and_format1_packs(nfa):
     """The one-pass implicit backward with the forward on the format-1 pack (default: fast inverse kernel, masks in its positions,
     nf_maf_inverse_h_tri_bits) and on the format-0 pack (config.set_maf_tri(False): nf_maf_inverse_h_bits): the two position
