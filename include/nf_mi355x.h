@@ -752,6 +752,20 @@ int nf_maf_solve_t(const void *x, const void *prm, const void *gx, const void *g
  * maf_pack.solve_t_gradient_columns), layer order reversed with reverse_layers, rows >= B zero.  hidden_padded: the pack's table[3]. */
 int nf_maf_scratch_rows(const void *scratch, const int32_t *pos_of_col, void *out, int64_t B, int num_blocks, int hidden_padded, int ldo,
                         double sign, int reverse_layers, nf_stream_t stream);
+/* Round 6: the weight gradients of the same MaskedLinears (nets/made.py:73-81 under loss.backward(), reached from
+ * flows/affine/autoregressive.py:29-38 in core.py:87-102's forward_kld) straight FROM the two scratches -- no rearrangement.
+ * nf_made_wgrad_pos = nf_made_wgrad whose hidden operands stay in the one-pass kernels' order over padded positions: gscratch = what
+ * nf_maf_solve_t left (the output gradients, negated inside: the solve runs on g_p(v, g_ld), the gradients belong to g_p(-v, -g_ld)),
+ * fscratch = what nf_maf_inverse_h_[tri_]bits left (the linears' inputs); wtable / stable = maf_pack.position_wgrad_tables (problems,
+ * mask-non-zero 128 x 128 tiles and scatter maps over POSITIONS); gp_pad, x_pad, grads, mask, part as for nf_made_wgrad;
+ * num_layers = 2 num_blocks + 1, positions = the packs' table[3].  B a multiple of 64 and positions a multiple of 128, else -ENOTSUP
+ * (the caller then rearranges with nf_maf_scratch_rows).  nf_maf_scratch_layer: ONE layer of a scratch as out (Bp, ldo) row-major --
+ * the inverse pass's last hidden tensor, from which MADE's output at the solution follows by one product. */
+int nf_made_wgrad_pos(const void *gp_pad, const void *x_pad, const void *gscratch, const void *fscratch, void *grads, const void *mask,
+                      void *part, const int32_t *wtable, const int32_t *stable, int ntiles, int64_t B, int num_layers, int positions,
+                      nf_stream_t stream);
+int nf_maf_scratch_layer(const void *scratch, const int32_t *pos_of_col, void *out, int64_t B, int num_blocks, int hidden_padded, int ldo,
+                         int layer, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * MaskedPiecewiseRationalQuadraticAutoregressive inverse (AR-NSF sampling direction) in ONE pass.  Replaces the D-pass

@@ -1004,6 +1004,7 @@ class MafInverseFn(torch.autograd.Function):
                                                         table_host=inv.get("table_host"), return_scratch=True)
             ctx.save_for_backward(x, bits, *([params[-1]] if params else []))
             ctx.tpack = (inv["tblob"], inv["ttable"], inv["hp"], inv["nb"], inv.get("gcols"))
+            ctx.pw = inv.get("pw") if _config.maf_wgrad_in_place else None
             # the pass's own activations (its scratch) are the inputs of MADE's linears at x: kept for the weight-gradient launch, so
             # the backward does not run MADE forward again (671 MB per config-5 layer at B = 65 536 instead of a transient of that size)
             ctx.fpack = (scratch, inv["fcols"], inv["wf_t"]) if keep else None
@@ -1035,9 +1036,19 @@ class MafInverseFn(torch.autograd.Function):
             # parameters p = h_NB Wf^T + bf from its last hidden tensor by one library product, the hidden gradients from the solve's
             tb, tt, hp, nb, gcols = ctx.tpack
             fscratch, fcols, wf_t = fpack
-            save = ops.maf_scratch_rows(fscratch, fcols, B, nb, hp)
             ctx.fpack = None
-            p = torch.nn.functional.linear(save[2 * nb, :B], wf_t, ctx.saved_tensors[-1].detach() if ctx.has_bias_f else None)
+            bias_f = ctx.saved_tensors[-1].detach() if ctx.has_bias_f else None
+            pw = getattr(ctx, "pw", None)
+            if pw is not None and B % 64 == 0 and pw["positions"] == hp:
+                # round 6: the weight-gradient launch reads both scratches where they are (nf_made_wgrad_pos: problems, tiles and
+                # scatter maps over scratch positions) -- only the last hidden tensor is still laid out in rows, for MADE's output
+                h_last = ops.maf_scratch_layer(fscratch, fcols, B, nb, hp, 2 * nb)
+                p = torch.nn.functional.linear(h_last[:B], wf_t, bias_f)
+                v, scratch = ops.maf_solve_t(x, p, gx, gld, ctx.saved_tensors[1], tb, tt, hp, nb, return_scratch=True)
+                MafInverseFn.last_sweeps = 1
+                return MafInverseFn._finish(ctx, x, p, v, gld, None, None, None, pos=(scratch, fscratch, pw))
+            save = ops.maf_scratch_rows(fscratch, fcols, B, nb, hp)
+            p = torch.nn.functional.linear(save[2 * nb, :B], wf_t, bias_f)
             v, scratch = ops.maf_solve_t(x, p, gx, gld, ctx.saved_tensors[1], tb, tt, hp, nb, return_scratch=True)
             G = ops.maf_scratch_rows(scratch, gcols, B, nb, hp, sign=-1.0, reverse_layers=True)
             MafInverseFn.last_sweeps = 1
@@ -1089,18 +1100,23 @@ class MafInverseFn(torch.autograd.Function):
         return MafInverseFn._finish(ctx, x, p, v, gld, save, bits)
 
     @staticmethod
-    def _finish(ctx, x, p, v, gld, save, bits, G=None):
+    def _finish(ctx, x, p, v, gld, save, bits, G=None, pos=None):
         """g_z = v; g_theta = MADE's weight gradients for the parameter cotangent g_p(-v, -g_ld): one chain (unless the one-pass solve
-        left its hidden gradients: G) + ONE weight-gradient launch."""
+        left its hidden gradients: G, or both scratches are read in place: pos) + ONE weight-gradient launch."""
         bwd = ctx.bwd
         D = x.shape[1]
         _, gp = ops.maf_affine_bwd(x, p, -v, -gld, 0)
         grads = [None] * ctx.nparams
         if any(ctx.needs_input_grad[4:]):
-            if G is None:
-                _, G = ops.made_backward(gp, bits, bwd["blob"], bwd["table"], D, bwd["Hp"], bwd["NB"])
-            flat = ops.made_wgrad(gp, x, G, save, bwd["wtable"], bwd["stable"], bwd["mask"], bwd["ntiles"], bwd["nflat"], bwd["Mp"],
-                                  bwd["Dx"])
+            if pos is not None:
+                gscratch, fscratch, pw = pos
+                flat = ops.made_wgrad_pos(gp, x, gscratch, fscratch, pw["wtable"], pw["stable"], bwd["mask"], pw["ntiles"], bwd["nflat"],
+                                          bwd["Mp"], bwd["Dx"], pw["NL"], pw["positions"])
+            else:
+                if G is None:
+                    _, G = ops.made_backward(gp, bits, bwd["blob"], bwd["table"], D, bwd["Hp"], bwd["NB"])
+                flat = ops.made_wgrad(gp, x, G, save, bwd["wtable"], bwd["stable"], bwd["mask"], bwd["ntiles"], bwd["nflat"], bwd["Mp"],
+                                      bwd["Dx"])
             for k, (woff, shape, boff, n) in enumerate(bwd["offsets"]):
                 grads[2 * k] = flat[woff:woff + shape[0] * shape[1]].view(shape)
                 grads[2 * k + 1] = flat[boff:boff + n]

@@ -319,3 +319,14 @@ maf_solve_grads = True
 def set_maf_solve_grads(mode=True):
     global maf_solve_grads
     maf_solve_grads = bool(mode)
+
+
+# Round 6: that weight-gradient launch reads BOTH scratches where the one-pass kernels left them (nf_made_wgrad_pos: problems, tiles and
+# scatter maps over scratch positions; batches that are a multiple of 64 rows, position counts that are a multiple of 128) instead of two
+# nf_maf_scratch_rows rearrangements per layer (2 x 245 us and 2.7 GB of traffic per config-5 layer at B = 65 536).  False = rearrange.
+maf_wgrad_in_place = True
+
+
+def set_maf_wgrad_in_place(mode=True):
+    global maf_wgrad_in_place
+    maf_wgrad_in_place = bool(mode)

@@ -293,6 +293,144 @@ made_wgrad_kernel(const float *__restrict__ b0p, const float *__restrict__ b1p, 
     }
 }
 
+// ---- 2b. weight gradients with operands in the one-pass kernels' scratch order (round 6) ------------------------------------------------
+// MAF's density direction under autograd (autograd.MafInverseFn): the hidden layers' output gradients ARE the transposed solve's
+// activation scratch and the linears' inputs ARE the inverse pass's (csrc/maf_inverse_h.hip), both [32-row wave tile][NL layers]
+// [position / 8][2 halves][32 samples][4] over padded POSITIONS.  Round 5 rearranged both into row-major tensors for the kernel above
+// (nf_maf_scratch_rows: 2 x 245 us per config-5 layer, 2.7 GB of traffic); here the contraction reads the scratches as they are and
+// works in position space -- the problems' row / column maps and the mask-non-zero tile list are built over positions
+// (flows/maf_pack.position_wgrad_tables), the reduction above scatters as before.
+//   * flags (problem int 7): 1 = dY in scratch order (matrix index = scratch layer, ld unused), 2 = X likewise, 4 = the product is
+//     negated (the solve runs on the cotangent g_p(v, g_ld), the weight gradients belong to g_p(-v, -g_ld)).
+//   * a step is still 16 rows x 128 slots per operand = 8 LDS-DMA requests of 1 KB: request j = k-groups 2 j, 2 j + 1 of the tile for
+//     the step's 16 samples (four 256-byte runs), written to LDS as [k-group][half][16][4] with 16 bytes between requests -- so the
+//     MFMA lanes' 16-byte reads (lane i = position quad i of the tile, its row = 2 kp + h) hit every bank group exactly four times:
+//     the minimum for 32 lanes x 16 bytes.  A lane's quad holds four POSITIONS of one sample where the row-major layout gives one
+//     position of four samples, so the wave (wm, wn) takes components 2 wm, 2 wm + 1 [2 wn, 2 wn + 1]: MFMA row [column] i of
+//     accumulator (s, t) is position 4 i + 2 wm + s [4 i + 2 wn + t] of the tile.
+// Rows: B a multiple of 64 (the scratch has no rows beyond the batch to read zeros from); slots: the scratch's position count a
+// multiple of 128.  Anything else keeps the rearrangement.
+constexpr int MWP_REQ = 2 * 2 * 16 * 4 + 4;          // floats of one request + 16 bytes
+constexpr int MWP_SLOT = 8 * MWP_REQ;                // >= MW_KS * MW_T (a row-major operand uses the first 2048 floats)
+static_assert(MWP_SLOT >= MW_KS * MW_T, "slot holds either layout");
+
+__global__ void __launch_bounds__(MW_NT, 4)
+made_wgrad_pos_kernel(const float *__restrict__ b0p, const float *__restrict__ b1p, const float *__restrict__ b2p,
+                      const float *__restrict__ b3p, float *__restrict__ part, const int *__restrict__ wt, int chunk_rows, int64_t Bp,
+                      int tile_major, int NL, int Hs) {
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    __shared__ __attribute__((aligned(16))) float ring[MW_NR][2][MWP_SLOT];
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, h = lane >> 5;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntl = wt[0], npr = wt[1];
+    const int bt = tile_major ? blockIdx.x : blockIdx.y, bc = tile_major ? blockIdx.y : blockIdx.x;
+    const int *tl = wt + 16 + 8 * npr + 8 * bt;
+    const int *pr = wt + 16 + 8 * tl[0];
+    const int m0 = tl[1], n0 = tl[2], want_bias = tl[3];
+    auto base = [&](int k) { return k == 0 ? b0p : k == 1 ? b1p : k == 2 ? b2p : b3p; };
+    const int ldY = pr[2], ldX = pr[5], x_relu = pr[6], flags = pr[7];
+    const bool sy = flags & 1, sx = flags & 2;
+    const float sgn = (flags & 4) ? -1.0f : 1.0f;
+    // row-major: the tile's first column of row 0; scratch order: the tile's first k-group of wave tile 0, layer pr[1] / pr[4]
+    const float *dY = sy ? base(pr[0]) + (size_t)pr[1] * Hs * 32 + (size_t)(m0 >> 3) * 256 : base(pr[0]) + (size_t)pr[1] * Bp * ldY + m0;
+    const float *X = sx ? base(pr[3]) + (size_t)pr[4] * Hs * 32 + (size_t)(n0 >> 3) * 256 : base(pr[3]) + (size_t)pr[4] * Bp * ldX + n0;
+    const size_t wtile = (size_t)NL * Hs * 32;              // floats of one 32-row wave tile of a scratch
+    const int64_t r_begin = (int64_t)bc * chunk_rows;
+    int64_t r_end = r_begin + chunk_rows;
+    if (r_end > Bp) r_end = Bp;
+    const int nsteps = (int)((r_end - r_begin) / MW_KS);
+    const bool mfma_wave = wid < 4;
+    const int dw = wid - 4;
+    const int lrow = lane >> 5, lcol = (lane & 31) * 4;
+    const int s_off = (lane >> 5) * 256 + ((lane >> 4) & 1) * 128 + (lane & 15) * 4;     // (k-group of the request, half, sample) of the lane
+    auto issue_op = [&](const float *P, bool scr, int ld, float *slot, int s) {
+        const int64_t row0 = r_begin + (int64_t)s * MW_KS;
+        if (scr) {
+            const float *src = P + (size_t)(row0 >> 5) * wtile + ((row0 >> 4) & 1) * 64 + s_off;
+            __builtin_amdgcn_global_load_lds(src + (size_t)(2 * dw) * 512, (lds_ptr)(slot + (2 * dw) * MWP_REQ), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(src + (size_t)(2 * dw + 1) * 512, (lds_ptr)(slot + (2 * dw + 1) * MWP_REQ), 16, 0, 0);
+        } else {
+            const int64_t r0 = row0 + 4 * dw + lrow;
+            __builtin_amdgcn_global_load_lds(P + r0 * ld + lcol, (lds_ptr)(slot + 4 * dw * MW_T), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(P + (r0 + 2) * ld + lcol, (lds_ptr)(slot + (4 * dw + 2) * MW_T), 16, 0, 0);
+        }
+    };
+    auto issue = [&](int s) {
+        issue_op(dY, sy, ldY, &ring[s % MW_NR][0][0], s);
+        issue_op(X, sx, ldX, &ring[s % MW_NR][1][0], s);
+    };
+    if (!mfma_wave) {
+        for (int s = 0; s < MW_NR - 1 && s < nsteps; ++s) issue(s);
+        for (int s = 0; s < nsteps; ++s) {
+            if (s + MW_NR - 1 <= nsteps) NF_WAIT_VMCNT(4 * (MW_NR - 2));
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (s + MW_NR - 1 < nsteps) issue(s + MW_NR - 1);
+        }
+        return;
+    }
+    const int wm = wid >> 1, wn = wid & 1;
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    float bs0 = 0.0f, bs1 = 0.0f;
+    const int q_off = (i >> 2) * MWP_REQ + (i & 3) * 64 + h * 4;      // the lane's position quad, row h of a pair
+    for (int s = 0; s < nsteps; ++s) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const float *sa = &ring[s % MW_NR][0][0], *sb = &ring[s % MW_NR][1][0];
+#pragma unroll
+        for (int kp = 0; kp < MW_KS / 2; ++kp) {
+            float a0, a1, x0, x1;
+            if (sy) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(sa + q_off + kp * 8);
+                a0 = wm ? v[2] : v[0];
+                a1 = wm ? v[3] : v[1];
+            } else {
+                const float *ap = sa + (2 * kp + h) * MW_T + wm * 64 + i;
+                a0 = ap[0];
+                a1 = ap[32];
+            }
+            if (sx) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(sb + q_off + kp * 8);
+                x0 = wn ? v[2] : v[0];
+                x1 = wn ? v[3] : v[1];
+            } else {
+                const float *bp = sb + (2 * kp + h) * MW_T + wn * 64 + i;
+                x0 = bp[0];
+                x1 = bp[32];
+            }
+            if (x_relu) { x0 = fmaxf(x0, 0.0f); x1 = fmaxf(x1, 0.0f); }
+            bs0 += a0;
+            bs1 += a1;
+            acc00 = MW_MFMA(a0, x0, acc00);
+            acc01 = MW_MFMA(a0, x1, acc01);
+            acc10 = MW_MFMA(a1, x0, acc10);
+            acc11 = MW_MFMA(a1, x1, acc11);
+        }
+    }
+    float *out = part + ((size_t)bc * ntl + bt) * MW_PART;
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+#pragma unroll
+        for (int t_ = 0; t_ < 2; ++t_) {
+            const f32x16 &acc = s_ == 0 ? (t_ == 0 ? acc00 : acc01) : (t_ == 0 ? acc10 : acc11);
+            const int nn = sx ? 4 * i + 2 * wn + t_ : wn * 64 + 32 * t_ + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rho = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int mm = sy ? 4 * rho + 2 * wm + s_ : wm * 64 + 32 * s_ + rho;
+                out[(size_t)mm * MW_T + nn] = sgn * acc[r];
+            }
+        }
+    }
+    if (want_bias && wn == 0) {
+        bs0 += __shfl_xor(bs0, 32);
+        bs1 += __shfl_xor(bs1, 32);
+        if (h == 0) {
+            out[MW_T * MW_T + (sy ? 4 * i + 2 * wm : wm * 64 + i)] = sgn * bs0;
+            out[MW_T * MW_T + (sy ? 4 * i + 2 * wm + 1 : wm * 64 + i + 32)] = sgn * bs1;
+        }
+    }
+}
+
 // ---- 3. reduction + scatter -----------------------------------------------------------------------------------------------------------
 // sc (int32): per problem 8 ints [weight offset in `grads`, ld of the weight, bias offset, row-map offset, column-map offset, bias-map
 // offset (0: the row map), ...] (maps: slot -> parameter row / column, -1 = padding; offsets into sc itself; destination = weight
@@ -433,6 +571,32 @@ extern "C" int nf_made_wgrad(const void *gp_pad, const void *x_pad, const void *
     const dim3 grid = tile_major ? dim3((unsigned)ntiles, (unsigned)chunks) : dim3((unsigned)chunks, (unsigned)ntiles);
     hipLaunchKernelGGL(nf::made_wgrad_kernel, grid, dim3(nf::MW_NT), 0, st, (const float *)gp_pad, (const float *)x_pad,
                        (const float *)G, (const float *)save, (float *)part, (const int *)wtable, rows, Bp, tile_major);
+    NF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nf::made_wgrad_reduce_kernel, dim3(64, (unsigned)ntiles), dim3(256), 0, st, (const float *)part, (float *)grads,
+                       (const unsigned char *)mask, (const int *)wtable, (const int *)stable, chunks);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// nf_made_wgrad with the hidden operands in the one-pass kernels' scratch order (made_wgrad_pos_kernel): gscratch = the activation
+// scratch nf_maf_solve_t left, fscratch = the one nf_maf_inverse_h_[tri_]bits left (both num_layers x positions per row, wave tiles of
+// 32 rows); wtable / stable: flows/maf_pack.position_wgrad_tables; grads, mask, part as for nf_made_wgrad.  B a multiple of 64,
+// positions a multiple of 128 (-ENOTSUP otherwise: the caller rearranges with nf_maf_scratch_rows and takes nf_made_wgrad).
+extern "C" int nf_made_wgrad_pos(const void *gp_pad, const void *x_pad, const void *gscratch, const void *fscratch, void *grads,
+                                 const void *mask, void *part, const int32_t *wtable, const int32_t *stable, int ntiles, int64_t B,
+                                 int num_layers, int positions, nf_stream_t stream) {
+    if (B < 0 || ntiles < 1 || num_layers < 1 || positions < 128) return NF_EINVAL;
+    if (B % 64 || positions % 128) return NF_ENOTSUP;
+    if (B == 0) return NF_OK;
+    if (!gp_pad || !x_pad || !gscratch || !fscratch || !grads || !mask || !part || !wtable || !stable) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = made_wgrad_chunk_rows(B, ntiles);
+    const int chunks = (int)((B + rows - 1) / rows);
+    const int tile_major = NF_MW_TILE_MAJOR;
+    const dim3 grid = tile_major ? dim3((unsigned)ntiles, (unsigned)chunks) : dim3((unsigned)chunks, (unsigned)ntiles);
+    hipLaunchKernelGGL(nf::made_wgrad_pos_kernel, grid, dim3(nf::MW_NT), 0, st, (const float *)gp_pad, (const float *)x_pad,
+                       (const float *)gscratch, (const float *)fscratch, (float *)part, (const int *)wtable, rows, B, tile_major,
+                       num_layers, positions);
     NF_CHECK_LAUNCH();
     hipLaunchKernelGGL(nf::made_wgrad_reduce_kernel, dim3(64, (unsigned)ntiles), dim3(256), 0, st, (const float *)part, (float *)grads,
                        (const unsigned char *)mask, (const int *)wtable, (const int *)stable, chunks);

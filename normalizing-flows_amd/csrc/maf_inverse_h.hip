@@ -1018,10 +1018,10 @@ namespace nf {
 // Hp x 32 block goes through LDS as [row][Hp + 4] (16-byte writes, row stride = 4 banks mod 32), rows leave as full lines.
 __global__ void __launch_bounds__(256)
 maf_scratch_rows_kernel(const float *__restrict__ S, const int *__restrict__ pos_of_col, float *__restrict__ out, int64_t B, int64_t Bp,
-                        int NL, int Hp, int ldo, float sign, int reverse) {
+                        int NL, int Hp, int ldo, float sign, int reverse, int l0) {
     extern __shared__ __attribute__((aligned(16))) float buf[];
     const int64_t wt = blockIdx.x;
-    const int l = blockIdx.y, pitch = Hp + 4;
+    const int l = blockIdx.y + l0, pitch = Hp + 4;      // (l0 > 0: nf_maf_scratch_layer -- one layer, written as out[0])
     const bool have = wt * 32 < B;
     if (have) {
         const f32x4 *src = reinterpret_cast<const f32x4 *>(S + ((size_t)wt * NL + l) * (size_t)Hp * 32);
@@ -1032,7 +1032,7 @@ maf_scratch_rows_kernel(const float *__restrict__ S, const int *__restrict__ pos
         }
     }
     __syncthreads();
-    const int lo = reverse ? NL - 1 - l : l;
+    const int lo = l0 > 0 || gridDim.y == 1 ? (int)blockIdx.y : (reverse ? NL - 1 - l : l);
     const int c4n = ldo >> 2;
     if (256 % c4n == 0) {      // (ldo 256 / 512 / 1024: a thread keeps its four columns -- their positions are loaded once, not per row)
         const int c4 = threadIdx.x % c4n, dn = 256 / c4n;
@@ -1085,7 +1085,27 @@ extern "C" int nf_maf_scratch_rows(const void *scratch, const int32_t *pos_of_co
     static nf::LdsOptIn opted = {};
     if (nf::opt_in_lds(reinterpret_cast<const void *>(&nf::maf_scratch_rows_kernel), lds, opted) != NF_OK) return NF_ENOTSUP;
     hipLaunchKernelGGL(nf::maf_scratch_rows_kernel, dim3((unsigned)(Bp / 32), NL), dim3(256), lds, (hipStream_t)stream, (const float *)scratch,
-                       (const int *)pos_of_col, (float *)out, B, Bp, NL, hidden_padded, ldo, (float)sign, reverse_layers);
+                       (const int *)pos_of_col, (float *)out, B, Bp, NL, hidden_padded, ldo, (float)sign, reverse_layers, 0);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// ONE layer of such a scratch as a row-major tensor out (Bp, ldo) (round 6: with nf_made_wgrad_pos reading the scratches in place, the
+// implicit backward only needs the inverse pass's last hidden tensor in rows -- the input of the library product that gives MADE's
+// output at the solution).
+extern "C" int nf_maf_scratch_layer(const void *scratch, const int32_t *pos_of_col, void *out, int64_t B, int num_blocks, int hidden_padded,
+                                    int ldo, int layer, nf_stream_t stream) {
+    if (B < 0 || num_blocks < 1 || num_blocks > 3 || hidden_padded < 32 || hidden_padded % 32 || ldo < 4 || ldo % 4) return NF_EINVAL;
+    const int NL = 1 + 2 * num_blocks;
+    if (layer < 0 || layer >= NL) return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!scratch || !pos_of_col || !out) return NF_EFAULT;
+    const int64_t Bp = (B + 63) / 64 * 64;
+    const size_t lds = (size_t)32 * (hidden_padded + 4) * sizeof(float);
+    static nf::LdsOptIn opted = {};
+    if (nf::opt_in_lds(reinterpret_cast<const void *>(&nf::maf_scratch_rows_kernel), lds, opted) != NF_OK) return NF_ENOTSUP;
+    hipLaunchKernelGGL(nf::maf_scratch_rows_kernel, dim3((unsigned)(Bp / 32), 1), dim3(256), lds, (hipStream_t)stream, (const float *)scratch,
+                       (const int *)pos_of_col, (float *)out, B, Bp, NL, hidden_padded, ldo, 1.0f, 0, layer);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }

@@ -361,16 +361,9 @@ def pack_made(made, mult=2, rows=False, blocks=(2,), tri=False):
 
 
 # ---- format 2 (round 5): the TRANSPOSED one-pass solve of the implicit backward (csrc/maf_solve_t.hip, autograd.MafInverseFn) ----
-def solve_t_gradient_columns(made, blocks=(1, 2, 3), tri=False, forward=False):
-    """int32 (Hp_train,): for column c of the training kernels' hidden tensors (flows/made_pack: units sorted by degree, stable) the
-    PADDED position of that unit in the transposed solve's activation scratch (pack_made_transposed: forward tiles reversed, forward
-    positions), -1 for the padding columns.  With it the solve's scratch IS every hidden layer's output gradient of MADE's
-    input-gradient chain (nf_maf_scratch_rows rearranges it into G[l][rows][Hp_train]): the solve finalises every virtual unit once from
-    final values, which is that chain at the solution.
-    forward=True: the positions in the INVERSE kernel's scratch (pack_made, format 0 / 1 with `tri`): its published activations are
-    relu(h_0), relu(t_0), relu(h_1), ..., h_NB -- the inputs of MADE's linears, what the weight-gradient launch multiplies G with."""
-    if not supported(made, 2, blocks) or pack_made(made, blocks=blocks) is None:
-        return None
+def _unit_positions(made, tri):
+    """(fslot, vslot, T): per hidden unit its PADDED position in the inverse kernel's scratch (pack_made, format 0 / 1 with `tri`) and
+    in the transposed solve's (pack_made_transposed: forward tiles reversed, forward positions within a tile); T tiles."""
     D = made.initial_layer.in_features
     H = made.initial_layer.out_features
     hid_deg = made.initial_layer.degrees.cpu().numpy()
@@ -387,10 +380,92 @@ def solve_t_gradient_columns(made, blocks=(1, 2, 3), tri=False, forward=False):
                 b_ += 1
                 k += 1
     vslot = (T - 1 - fslot // TILE) * TILE + fslot % TILE
+    return fslot, vslot, T
+
+
+def solve_t_gradient_columns(made, blocks=(1, 2, 3), tri=False, forward=False):
+    """int32 (Hp_train,): for column c of the training kernels' hidden tensors (flows/made_pack: units sorted by degree, stable) the
+    PADDED position of that unit in the transposed solve's activation scratch (pack_made_transposed: forward tiles reversed, forward
+    positions), -1 for the padding columns.  With it the solve's scratch IS every hidden layer's output gradient of MADE's
+    input-gradient chain (nf_maf_scratch_rows rearranges it into G[l][rows][Hp_train]): the solve finalises every virtual unit once from
+    final values, which is that chain at the solution.
+    forward=True: the positions in the INVERSE kernel's scratch (pack_made, format 0 / 1 with `tri`): its published activations are
+    relu(h_0), relu(t_0), relu(h_1), ..., h_NB -- the inputs of MADE's linears, what the weight-gradient launch multiplies G with."""
+    if not supported(made, 2, blocks) or pack_made(made, blocks=blocks) is None:
+        return None
+    H = made.initial_layer.out_features
+    hid_deg = made.initial_layer.degrees.cpu().numpy()
+    fslot, vslot, _ = _unit_positions(made, tri)
     hp_train = 256 if H <= 256 else 512
     cols = np.full(hp_train, -1, dtype=np.int32)
     cols[:H] = (fslot if forward else vslot)[np.argsort(hid_deg, kind="stable")]
     return cols
+
+
+def position_wgrad_tables(made, blocks=(1, 2, 3), tri=False):
+    """Round 6: (wtable, stable, ntiles, positions) for nf_made_wgrad_pos -- the weight-gradient launch of the implicit backward
+    reading the two one-pass kernels' scratches IN PLACE (csrc/made_bwd.hip made_wgrad_pos_kernel).  The problems are those of
+    flows/made_pack._pack_backward_from in the same order (so its flat gradient layout, `offsets` and byte mask stay valid), but a
+    hidden operand's slots are scratch POSITIONS: rows of dW_l (layer l's output gradient) = positions in the transposed solve's scratch,
+    layer NL - 1 - l, negated; columns (the linear's input) = positions in the inverse pass's scratch, layer l - 1.  The row / column
+    maps send a position to the parameter's own row / column (-1: a hole of a tile), the 128 x 128 tiles listed are those holding a
+    mask non-zero in position space.  None outside the one-pass kernels' structures or when the position count is not a multiple of
+    128 (the caller then rearranges: nf_maf_scratch_rows)."""
+    if not supported(made, 2, blocks) or pack_made(made, blocks=blocks) is None:
+        return None
+    W_TILE = 128
+    D = made.initial_layer.in_features
+    H = made.initial_layer.out_features
+    NB = len(made.blocks)
+    NL = 1 + 2 * NB
+    MD = made.final_layer.out_features
+    fslot, vslot, T = _unit_positions(made, tri)
+    P = T * TILE
+    if P % W_TILE:
+        return None
+    funit = np.full(P, -1, dtype=np.int32)
+    vunit = np.full(P, -1, dtype=np.int32)
+    funit[fslot] = np.arange(H)
+    vunit[vslot] = np.arange(H)
+    Mp = (MD + W_TILE - 1) // W_TILE * W_TILE
+    Dx = (D + W_TILE - 1) // W_TILE * W_TILE
+    feat_map = np.full(Dx, -1, dtype=np.int32)
+    feat_map[:D] = np.arange(D)
+    out_map = np.full(Mp, -1, dtype=np.int32)
+    out_map[:MD] = np.arange(MD)
+    lins = [made.initial_layer] + [l for b in made.blocks for l in b.linear_layers] + [made.final_layer]
+    masks = [l.mask.cpu().numpy() != 0 for l in lins]
+    SY, SX, NEG = 1, 2, 4
+    # (dY base, dY matrix / scratch layer, ldY, X base, X matrix / scratch layer, ldX, relu, flags, mask, row map, column map, shape)
+    probs = [(2, NL - 1, P, 1, 0, Dx, 0, SY | NEG, masks[0], vunit, feat_map, (H, D))]
+    for b in range(NB):
+        probs.append((2, NL - 1 - (2 * b + 1), P, 3, 2 * b, P, 1, SY | SX | NEG, masks[1 + 2 * b], vunit, funit, (H, H)))
+        probs.append((2, NL - 1 - (2 * b + 2), P, 3, 2 * b + 1, P, 1, SY | SX | NEG, masks[2 + 2 * b], vunit, funit, (H, H)))
+    probs.append((0, 0, Mp, 3, 2 * NB, P, 0, SX, masks[-1], out_map, funit, (MD, H)))
+    ptab, tiles, stab, maps = [], [], [], []
+    flat, map_off = 0, 8 * len(probs)
+    for pi, (dyb, dyl, ldy, xb, xl, ldx, relu, flags, M, rmap, cmap, shape) in enumerate(probs):
+        ptab.append([dyb, dyl, ldy, xb, xl, ldx, relu, flags])
+        Mrows, Ncols = len(rmap), len(cmap)
+        Mfull = np.zeros((Mrows, Ncols), dtype=bool)
+        rr, cc = np.nonzero(rmap >= 0)[0], np.nonzero(cmap >= 0)[0]
+        Mfull[np.ix_(rr, cc)] = M[np.ix_(rmap[rr], cmap[cc])]
+        for mt in range(Mrows // W_TILE):
+            nz = [nt for nt in range(Ncols // W_TILE) if Mfull[mt * W_TILE:(mt + 1) * W_TILE, nt * W_TILE:(nt + 1) * W_TILE].any()]
+            if not nz:
+                nz = [0]                                  # (the bias gradient still needs the tile row)
+            for k, nt in enumerate(nz):
+                tiles.append([pi, mt * W_TILE, nt * W_TILE, 1 if k == 0 else 0, 0, 0, 0, 0])
+        woff, boff = flat, flat + shape[0] * shape[1]
+        flat = boff + shape[0]
+        stab.append([woff, shape[1], boff, map_off, map_off + Mrows, 0, 0, 0])
+        maps += [np.asarray(rmap, dtype=np.int32), np.asarray(cmap, dtype=np.int32)]
+        map_off += Mrows + Ncols
+    whdr = np.zeros(16, dtype=np.int32)
+    whdr[:2] = [len(tiles), len(probs)]
+    wtable = np.concatenate([whdr, np.asarray(ptab, dtype=np.int32).reshape(-1), np.asarray(tiles, dtype=np.int32).reshape(-1)])
+    stable = np.concatenate([np.asarray(stab, dtype=np.int32).reshape(-1)] + maps).astype(np.int32)
+    return dict(wtable=wtable.astype(np.int32), stable=stable, ntiles=len(tiles), positions=P, nflat=flat, NL=NL)
 
 
 def final_layer_columns(made):

@@ -1258,6 +1258,29 @@ def made_wgrad(g_params, x, G, save, wtable, stable, mask, ntiles, nflat, Mp, Dx
     return grads
 
 
+def made_wgrad_pos(g_params, x, gscratch, fscratch, wtable, stable, mask, ntiles, nflat, Mp, Dx, num_layers, positions):
+    """nf_made_wgrad_pos (round 6): nf_made_wgrad with the hidden operands read from the one-pass kernels' scratches in place --
+    gscratch from maf_solve_t(return_scratch=True), fscratch from maf_inverse_bits(return_scratch=True); tables from
+    flows/maf_pack.position_wgrad_tables; mask / nflat / Mp / Dx of the MADE's ordinary backward pack (same flat layout).  The batch must
+    be a multiple of 64 rows."""
+    L.require_device(g_params, x, gscratch, fscratch, wtable, stable, mask)
+    B = g_params.shape[0]
+    if B % 64:
+        raise NotImplementedError("made_wgrad_pos: a multiple of 64 rows")
+    gp_pad = _pad_rows_cols(g_params, B, Mp)
+    x_pad = _pad_rows_cols(x, B, Dx)
+    grads = torch.zeros(nflat, dtype=torch.float32, device=x.device)
+    lib = L.lib()
+    n = int(lib.nf_made_wgrad_scratch_floats(i64(B), i32(ntiles)))
+    if n < 0:
+        L.check(n, "nf_made_wgrad_scratch_floats")
+    part = torch.empty(max(n, 1), dtype=torch.float32, device=x.device)
+    rc = lib.nf_made_wgrad_pos(ptr(gp_pad), ptr(x_pad), ptr(gscratch), ptr(fscratch), ptr(grads), ptr(mask), ptr(part), ptr(wtable),
+                               ptr(stable), i32(ntiles), i64(B), i32(num_layers), i32(positions), L.stream())
+    L.check(rc, "nf_made_wgrad_pos")
+    return grads
+
+
 def maf_inverse(z, blob, table, hidden_padded, logdet=None, acc=None, num_blocks=2, table_host=None):
     """autoregressive.py:29-38 + :114-128 in one pass; blob/table from flows/maf_pack.pack_made.  config.maf_halves (default):
     nf_maf_inverse_h (32 samples per wave, 1..3 residual blocks); otherwise round 2's nf_maf_inverse (two blocks only).
@@ -1358,6 +1381,18 @@ def maf_scratch_rows(scratch, pos_of_col, B, num_blocks, hidden_padded, sign=1.0
     rc = L.lib().nf_maf_scratch_rows(ptr(scratch), ptr(pos_of_col), ptr(out), i64(B), i32(num_blocks), i32(hidden_padded), i32(ldo),
                                      f64(sign), i32(int(reverse_layers)), L.stream())
     L.check(rc, "nf_maf_scratch_rows")
+    return out
+
+
+def maf_scratch_layer(scratch, pos_of_col, B, num_blocks, hidden_padded, layer):
+    """nf_maf_scratch_layer: ONE layer of a one-pass kernel's activation scratch as a (Bp, len(pos_of_col)) row-major tensor."""
+    L.require_device(scratch, pos_of_col)
+    ldo = pos_of_col.numel()
+    Bp = (B + 63) // 64 * 64
+    out = torch.empty(Bp, ldo, dtype=torch.float32, device=scratch.device)
+    rc = L.lib().nf_maf_scratch_layer(ptr(scratch), ptr(pos_of_col), ptr(out), i64(B), i32(num_blocks), i32(hidden_padded), i32(ldo),
+                                      i32(layer), L.stream())
+    L.check(rc, "nf_maf_scratch_layer")
     return out
 
 

@@ -2212,6 +2212,70 @@ def test_maf_weight_gradients_from_the_solve_scratch(nfa, D, H, NB, B):
             assert float(err.sum()) <= 1e-3 * float(b.abs().sum()), (k, flipped, float(err.sum()), float(b.abs().sum()))
 
 
+@pytest.mark.parametrize("D,H,NB,B", [(128, 512, 2, 320), (128, 512, 2, 4096), (40, 100, 2, 64), (64, 252, 2, 128), (33, 120, 3, 192),
+                                      (24, 100, 1, 64), (128, 512, 2, 300)])
+def test_maf_weight_gradients_read_the_scratches_in_place(nfa, D, H, NB, B):
+    """Round 6 (nf_made_wgrad_pos, maf_pack.position_wgrad_tables): the weight-gradient launch of the implicit backward contracts the
+    solve's and the inverse pass's activation scratches where they are -- problems, mask-non-zero tiles and scatter maps over scratch
+    positions, LDS-DMA requests of [two k-groups][half][16 samples][4] -- instead of over two row-major rearrangements
+    (config.set_maf_wgrad_in_place(False): nf_maf_scratch_rows x 2 + nf_made_wgrad).  Same operands, same order of summation over the
+    rows inside a chunk: the two paths agree to float32 rounding of the chunk sums (the chunk length follows the tile count, which may
+    differ between slot and position space).  A batch that is not a multiple of 64 rows, or a position count that is not a multiple of
+    128, keeps the rearrangement."""
+    from normflows_amd import ops
+    torch.manual_seed(D + H + B)
+    layer = nfa.flows.MaskedAffineAutoregressive(D, H, num_blocks=NB)
+    gen = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.add_(0.03 * torch.randn(p.shape, generator=gen))
+    layer = layer.to(DEV)
+    z0 = torch.randn(B, D, device=DEV)
+    cx, cl = torch.randn(B, D, device=DEV), torch.randn(B, device=DEV)
+    inv = layer._implicit_packs(DEV)[0]
+    assert isinstance(inv, dict)
+    direct = inv["pw"] is not None and B % 64 == 0 and inv["pw"]["positions"] == inv["hp"]
+    if (D, H, B) in ((128, 512, 320), (128, 512, 4096), (40, 100, 64)):
+        assert direct
+    if B == 300:
+        assert not direct
+    res, calls = [], []
+    real_r, real_p = ops.maf_scratch_rows, ops.made_wgrad_pos
+    try:
+        for mode in (True, False):
+            nfa.config.set_maf_wgrad_in_place(mode)
+            n = [0, 0]
+
+            def spy_r(*a, **k):
+                n[0] += 1
+                return real_r(*a, **k)
+
+            def spy_p(*a, **k):
+                n[1] += 1
+                return real_p(*a, **k)
+            ops.maf_scratch_rows, ops.made_wgrad_pos = spy_r, spy_p
+            layer.zero_grad(set_to_none=True)
+            z = z0.clone().requires_grad_(True)
+            xx, ld = layer.inverse(z)
+            ((xx * cx).sum() + (ld * cl).sum()).backward()
+            calls.append(tuple(n))
+            res.append([z.grad] + [p.grad.clone() for p in layer.parameters()])
+    finally:
+        ops.maf_scratch_rows, ops.made_wgrad_pos = real_r, real_p
+        nfa.config.set_maf_wgrad_in_place(True)
+    assert calls == [((0, 1) if direct else (2, 0)), (2, 0)], calls
+    for k, (a, b) in enumerate(zip(res[0], res[1])):
+        assert a.shape == b.shape and torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())), (k, float((a - b).abs().max()), float(b.abs().max()))
+    names = [n_ for n_, _ in layer.named_parameters()]
+    for n_, a in zip(names, res[0][1:]):       # the masked entries of weight.grad are exactly zero as in the reference (made.py:80-81)
+        if n_.endswith("weight"):
+            mod = layer.autoregressive_net
+            for part in n_.split(".")[1:-1] if n_.startswith("autoregressive_net.") else n_.split(".")[:-1]:
+                mod = getattr(mod, part) if not part.isdigit() else mod[int(part)]
+            assert float(a[mod.mask.to(DEV) == 0].abs().max() if (mod.mask == 0).any() else 0.0) == 0.0, n_
+
+
 @pytest.mark.parametrize("which", ["x_only", "ld_only"])
 def test_maf_implicit_backward_with_one_cotangent_absent(nfa, which):
     """The implicit backward when the loss sees only the outputs or only the log-det (the other cotangent arrives as None), and with

@@ -1,0 +1,4 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_training.py -x -q -m gpu -k "in_place or solve_scratch or captures_into_one_graph or maf" 2>&1 | grep -v Warn | tail -25
+timeout 600 python tools/maf_wgrad_pos_ab.py 2>&1 | grep -v Warn | tail -5
