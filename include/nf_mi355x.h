@@ -741,6 +741,12 @@ int nf_maf_inverse_h_bits(const void *z, void *y, void *logdet, const void *blob
 int nf_maf_inverse_h_tri_bits(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, const int32_t *table_host,
                               void *scratch, void *bits, int64_t B, int D, int hidden_padded, int num_blocks, int acc,
                               nf_stream_t stream);
+/* both in one entry point (table_host NULL: format-0 pack) that also writes prm (B, 2 D) float32 = MADE's output at the solution,
+ * (unconstrained scale, shift) per feature as nets/made.py:296-304 returns it and affine/autoregressive.py:98-128 reads it: what
+ * nf_maf_solve_t and nf_maf_affine_bwd take as `prm` -- no second evaluation of the final layer in the backward (round 6) */
+int nf_maf_inverse_h_train(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, const int32_t *table_host,
+                           void *scratch, void *bits, void *prm, int64_t B, int D, int hidden_padded, int num_blocks, int acc,
+                           nf_stream_t stream);
 int64_t nf_maf_solve_t_scratch_floats(int64_t B, int D, int hidden_padded, int num_blocks);
 int nf_maf_solve_t(const void *x, const void *prm, const void *gx, const void *gld, const void *bits, void *v, const void *blob,
                    const int32_t *table, void *scratch, int64_t B, int D, int hidden_padded, int num_blocks, nf_stream_t stream);

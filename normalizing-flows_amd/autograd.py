@@ -1000,8 +1000,14 @@ class MafInverseFn(torch.autograd.Function):
         z = z.contiguous()
         if isinstance(inv, dict):       # round 5: format-0 inverse that leaves its ReLU masks + the transposed pack of the one-pass solve
             keep = inv.get("fcols") is not None and _config.maf_solve_grads and any(ctx.needs_input_grad[4:])
-            x, ld, bits, scratch = ops.maf_inverse_bits(z, inv["blob"], inv["table"], inv["hp"], inv["nb"], inv["tiles"],
-                                                        table_host=inv.get("table_host"), return_scratch=True)
+            # round 6: the pass stores MADE's output at the solution itself (nf_maf_inverse_h_train) when the backward will read the
+            # scratches in place -- otherwise it is recomputed there from the last hidden tensor (round 5)
+            pw = inv.get("pw") if _config.maf_wgrad_in_place else None
+            want_p = keep and pw is not None and z.shape[0] % 64 == 0 and pw["positions"] == inv["hp"]
+            out = ops.maf_inverse_bits(z, inv["blob"], inv["table"], inv["hp"], inv["nb"], inv["tiles"],
+                                       table_host=inv.get("table_host"), return_scratch=True, want_params=want_p)
+            x, ld, bits, scratch = out[:4]
+            ctx.prm = out[4] if want_p else None
             ctx.save_for_backward(x, bits, *([params[-1]] if params else []))
             ctx.tpack = (inv["tblob"], inv["ttable"], inv["hp"], inv["nb"], inv.get("gcols"))
             ctx.pw = inv.get("pw") if _config.maf_wgrad_in_place else None
@@ -1042,8 +1048,11 @@ class MafInverseFn(torch.autograd.Function):
             if pw is not None and B % 64 == 0 and pw["positions"] == hp:
                 # round 6: the weight-gradient launch reads both scratches where they are (nf_made_wgrad_pos: problems, tiles and
                 # scatter maps over scratch positions) -- only the last hidden tensor is still laid out in rows, for MADE's output
-                h_last = ops.maf_scratch_layer(fscratch, fcols, B, nb, hp, 2 * nb)
-                p = torch.nn.functional.linear(h_last[:B], wf_t, bias_f)
+                p = getattr(ctx, "prm", None)
+                ctx.prm = None
+                if p is None:
+                    h_last = ops.maf_scratch_layer(fscratch, fcols, B, nb, hp, 2 * nb)
+                    p = torch.nn.functional.linear(h_last[:B], wf_t, bias_f)
                 v, scratch = ops.maf_solve_t(x, p, gx, gld, ctx.saved_tensors[1], tb, tt, hp, nb, return_scratch=True)
                 MafInverseFn.last_sweeps = 1
                 return MafInverseFn._finish(ctx, x, p, v, gld, None, None, None, pos=(scratch, fscratch, pw))

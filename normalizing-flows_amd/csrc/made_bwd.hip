@@ -379,19 +379,19 @@ made_wgrad_pos_kernel(const float *__restrict__ b0p, const float *__restrict__ b
 #pragma unroll
         for (int kp = 0; kp < MW_KS / 2; ++kp) {
             float a0, a1, x0, x1;
-            if (sy) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(sa + q_off + kp * 8);
-                a0 = wm ? v[2] : v[0];
-                a1 = wm ? v[3] : v[1];
+            if (sy) {           // (the wave's two components of the quad are adjacent: one 8-byte read)
+                const f32x2e v = *reinterpret_cast<const f32x2e *>(sa + q_off + 2 * wm + kp * 8);
+                a0 = v[0];
+                a1 = v[1];
             } else {
                 const float *ap = sa + (2 * kp + h) * MW_T + wm * 64 + i;
                 a0 = ap[0];
                 a1 = ap[32];
             }
             if (sx) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(sb + q_off + kp * 8);
-                x0 = wn ? v[2] : v[0];
-                x1 = wn ? v[3] : v[1];
+                const f32x2e v = *reinterpret_cast<const f32x2e *>(sb + q_off + 2 * wn + kp * 8);
+                x0 = v[0];
+                x1 = v[1];
             } else {
                 const float *bp = sb + (2 * kp + h) * MW_T + wn * 64 + i;
                 x0 = bp[0];

@@ -274,7 +274,7 @@ __device__ __forceinline__ void hf_product(const f32x16 &src, const f32x4 *w, fl
 
 template <int NB, int G, bool X = false>
 __device__ __forceinline__ void hf_step(f32x16 (&p)[1 + 2 * NB], const f32x16 &pF, f32x16 &xg, const f32x4 *wh, float zf, float &ld,
-                                        float &xn, const f32x4 *wx = nullptr, int m = 0, int hh = 0) {
+                                        float &xn, float &prm_out, const f32x4 *wx = nullptr, int m = 0, int hh = 0) {
     constexpr int NL = 1 + 2 * NB;
     // kind-2 tile: the step's extra unit = register RX of lane-half G & 1 (the other half's RX belongs to another step's extra)
     constexpr int RX = 14 + ((G < HX_MAX ? G : 0) >> 1);
@@ -360,6 +360,7 @@ __device__ __forceinline__ void hf_step(f32x16 (&p)[1 + 2 * NB], const f32x16 &p
         // lower half: scale (its block part + bias sit in register G of half 0), upper half: shift (register G of half 1)
         const float v = hf_xchg(au[0] + au[1], as[0] + as[1]) + pF[G];
         const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        prm_out = v;       // (the lane-half's own MADE output of the feature -- scale below, shift above: the training forward stores it)
         h_finish(__uint_as_float(r[0]), __uint_as_float(r[1]), zf, xn, ld);
     }
     xg[G + 1] = xn;
@@ -380,11 +381,13 @@ __device__ __forceinline__ void h_static_for(F &&f) {
 // maf_h_launch): the per-sample state between tiles -- the feature row, the activation scratch, the pair stash -- is in memory
 // anyway, the carry is the last feature written to y, and the log-determinant is accumulated launch by launch.  (One kernel holding
 // both sequential parts needed more than 256 registers: 56 spilled.)
-template <int NB, bool FAST>
+// TRAIN (round 6): the instantiation that also stores every feature's MADE outputs (`prm`); the inference instantiations carry none of
+// it -- the config-5 kernel sits at exactly 256 registers, and three more live values spilled.
+template <int NB, bool FAST, bool TRAIN = false>
 __global__ void __launch_bounds__(64 * HNW, (NB <= 2 && HNW <= 4) ? 8 / HNW : 1)
 maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *__restrict__ logdet, const float *__restrict__ blob,
                      const int *__restrict__ table, float *S, float *Xs, float *Ps, int64_t B, int acc, int t_beg, int t_end,
-                     unsigned int *__restrict__ bits) {
+                     unsigned int *__restrict__ bits, float *__restrict__ prm) {
     constexpr int NL = 1 + 2 * NB, H_SEQ = FAST ? hfx_seq(NL) : h_seq(NL), LB = h_lb(FAST);
     __shared__ __attribute__((aligned(16))) float seqw[H_SEQ];     // the tile's biases and diagonal blocks, shared by the workgroup's waves
     extern __shared__ __attribute__((aligned(16))) float dyn[];      // the waves' rings
@@ -408,6 +411,11 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
         h_finish(blob[0], blob[1], zr[0], xcarry, ld);
         if (active && hh == 0) Xw[n * 4] = xcarry;
         if (valid && hh == 0) y[sample * D] = xcarry;
+        // prm (round 6, the training forward): MADE's output at the solution, (B, 2 D) as nets/made.py:296-304 returns it -- every
+        // feature's (unconstrained scale, shift) exists here when the feature is finished; lane-half 0 stores the first, 1 the second
+        if constexpr (TRAIN) {
+            if (valid) prm[sample * 2 * D + hh] = blob[hh];
+        }
     } else {
         xcarry = y[(valid ? sample : B - 1) * D + table[H_HDR + H_ENT * t_beg] - 1];     // the last feature of the previous launch
     }
@@ -554,15 +562,18 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
             h_static_for<0, HF_STEPS>([&](auto G_) {
                 constexpr int G = decltype(G_)::value;
                 if (G < ns) {
-                    float xn;
+                    float xn, pv = 0.0f;
 #ifndef NF_MAF_ABL_NO_SEQ
-                    if (G < HX_STEPS && xtile) hf_step<NB, (G < HX_STEPS ? G : 0), true>(p, pF, xg, wh, zin[G], ld, xn, wx, mx, hh);
-                    else hf_step<NB, G>(p, pF, xg, wh, zin[G], ld, xn);
+                    if (G < HX_STEPS && xtile) hf_step<NB, (G < HX_STEPS ? G : 0), true>(p, pF, xg, wh, zin[G], ld, xn, pv, wx, mx, hh);
+                    else hf_step<NB, G>(p, pF, xg, wh, zin[G], ld, xn, pv);
 #else
                     xn = zin[G] + p[0][G] + pF[G] + wh[G][0];
 #endif
                     xcarry = xn;
                     const int f = dlo + G;
+                    if constexpr (TRAIN) {      // wave-uniform base + 32-bit lane offset: no 64-bit per-lane address kept across the steps
+                        if (valid) (prm + wts * 64 * D)[(unsigned)(n * 2 * D + hh) + (unsigned)(2 * f)] = pv;
+                    }
                     if (hh == 0) {
                         Xw[((size_t)((f >> 3) * 2 + ((f >> 2) & 1)) * 32 + n) * 4 + (f & 3)] = xn;
                         if (valid) y[sample * D + f] = xn;
@@ -649,6 +660,9 @@ maf_inverse_h_kernel(const float *__restrict__ z, float *__restrict__ y, float *
                     sh = xsum((own ? pF[ru] : 0.0f) + (a0 + a1));
                 }
                 h_finish(us, sh, zin[s], xn, ld);
+                if constexpr (TRAIN) {
+                    if (valid) (prm + wts * 64 * D)[(unsigned)(n * 2 * D + hh) + (unsigned)(2 * (dlo + s))] = hh ? sh : us;
+                }
                 // a STATICALLY indexed write (16 selects): with `xg[s + 1] = xn` the compiler's dynamically indexed register write
                 // went out of the vector's registers in the round-3 build of the block part (it overwrote request addresses that
                 // live across the tile loop: a memory fault on layers with 10-16 degrees per tile; bisected with debug builds)
@@ -909,17 +923,28 @@ extern "C" int64_t nf_maf_inverse_h_scratch_floats(int64_t B, int D, int hidden_
 
 template <int NB, bool FAST>
 static int maf_h_run(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, float *S, float *Xs, float *Ps,
-                     int64_t nwt, int64_t B, int acc, int t_beg, int t_end, hipStream_t st, unsigned int *bits = nullptr) {
+                     int64_t nwt, int64_t B, int acc, int t_beg, int t_end, hipStream_t st, unsigned int *bits = nullptr,
+                     float *prm = nullptr) {
     using namespace nf;
     constexpr int NL = 1 + 2 * NB;
     const int grid = (int)((nwt + HNW - 1) / HNW);
     const size_t lds_ring = (size_t)HNW * (h_lb(FAST) + 8) * 256 * sizeof(float);
+    if (prm) {
+        static LdsOptIn opted_t;
+        if (opt_in_lds(reinterpret_cast<const void *>(&maf_inverse_h_kernel<NB, FAST, true>),
+                       lds_ring + sizeof(float) * (FAST ? hfx_seq(NL) : h_seq(NL)), opted_t) != NF_OK)
+            return NF_ENOTSUP;
+        hipLaunchKernelGGL((maf_inverse_h_kernel<NB, FAST, true>), dim3(grid), dim3(64 * HNW), lds_ring, st, (const float *)z, (float *)y,
+                           (float *)logdet, (const float *)blob, (const int *)table, S, Xs, Ps, B, acc, t_beg, t_end, bits, prm);
+        NF_CHECK_LAUNCH();
+        return NF_OK;
+    }
     static LdsOptIn opted;
     if (opt_in_lds(reinterpret_cast<const void *>(&maf_inverse_h_kernel<NB, FAST>),
                    lds_ring + sizeof(float) * (FAST ? hfx_seq(NL) : h_seq(NL)), opted) != NF_OK)
         return NF_ENOTSUP;
     hipLaunchKernelGGL((maf_inverse_h_kernel<NB, FAST>), dim3(grid), dim3(64 * HNW), lds_ring, st, (const float *)z, (float *)y,
-                       (float *)logdet, (const float *)blob, (const int *)table, S, Xs, Ps, B, acc, t_beg, t_end, bits);
+                       (float *)logdet, (const float *)blob, (const int *)table, S, Xs, Ps, B, acc, t_beg, t_end, bits, prm);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -927,7 +952,8 @@ static int maf_h_run(const void *z, void *y, void *logdet, const void *blob, con
 // table_host: the host copy of `table` (format 1: the launcher needs the kinds of the tiles) or NULL (format 0: one launch)
 template <int NB>
 static int maf_h_launch(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, const int32_t *table_host,
-                        void *scratch, int64_t B, int D, int hidden_padded, int acc, hipStream_t st, unsigned int *bits = nullptr) {
+                        void *scratch, int64_t B, int D, int hidden_padded, int acc, hipStream_t st, unsigned int *bits = nullptr,
+                        float *prm = nullptr) {
     using namespace nf;
     constexpr int NL = 1 + 2 * NB;
     const int64_t nwt = (B + 31) / 32;
@@ -937,7 +963,7 @@ static int maf_h_launch(const void *z, void *y, void *logdet, const void *blob, 
     // the feature scratch is read with zero weights before it is written (K0 is padded to 32): it must hold finite values
     if (hipMemsetAsync(Xs, 0, (size_t)nwt * 32 * Dp * sizeof(float), st) != hipSuccess) return NF_EIO;
     float *Ps = Xs + nwt * 32 * Dp;
-    if (!table_host) return maf_h_run<NB, false>(z, y, logdet, blob, table, S, Xs, Ps, nwt, B, acc, 0, 1 << 30, st, bits);
+    if (!table_host) return maf_h_run<NB, false>(z, y, logdet, blob, table, S, Xs, Ps, nwt, B, acc, 0, 1 << 30, st, bits, prm);
     // maximal runs of tiles of one kind, one launch each; the first accumulates as the caller says, the others on top of it
     const int T = table_host[4];
     for (int t0 = 0; t0 < T;) {
@@ -945,8 +971,8 @@ static int maf_h_launch(const void *z, void *y, void *logdet, const void *blob, 
         int t1 = t0 + 1;
         while (t1 < T && (table_host[H_HDR + H_ENT * t1 + 20] != 0) == fast) ++t1;
         const int a = t0 == 0 ? acc : (acc == NF_LD_SUB ? NF_LD_SUB : NF_LD_ADD);
-        const int rc = fast ? maf_h_run<NB, true>(z, y, logdet, blob, table, S, Xs, Ps, nwt, B, a, t0, t1, st, bits)
-                            : maf_h_run<NB, false>(z, y, logdet, blob, table, S, Xs, Ps, nwt, B, a, t0, t1, st, bits);
+        const int rc = fast ? maf_h_run<NB, true>(z, y, logdet, blob, table, S, Xs, Ps, nwt, B, a, t0, t1, st, bits, prm)
+                            : maf_h_run<NB, false>(z, y, logdet, blob, table, S, Xs, Ps, nwt, B, a, t0, t1, st, bits, prm);
         if (rc != NF_OK) return rc;
         t0 = t1;
     }
@@ -955,7 +981,7 @@ static int maf_h_launch(const void *z, void *y, void *logdet, const void *blob, 
 
 static int maf_h_entry(const void *z, void *y, void *logdet, const void *blob, const int32_t *table, const int32_t *table_host,
                        void *scratch, int64_t B, int D, int hidden_padded, int num_blocks, int acc, nf_stream_t stream,
-                       unsigned int *bits = nullptr) {
+                       unsigned int *bits = nullptr, float *prm = nullptr) {
     if (B < 0 || D < 2 || hidden_padded < 32 || hidden_padded % 32) return NF_EINVAL;
     if (acc < NF_LD_SUB || acc > NF_LD_ADD) return NF_EINVAL;
     if (num_blocks < 1 || num_blocks > 3) return NF_ENOTSUP;
@@ -965,9 +991,9 @@ static int maf_h_entry(const void *z, void *y, void *logdet, const void *blob, c
     if (B == 0) return NF_OK;
     if (!z || !y || !logdet || !blob || !table || !scratch) return NF_EFAULT;
     hipStream_t st = (hipStream_t)stream;
-    if (num_blocks == 1) return maf_h_launch<1>(z, y, logdet, blob, table, table_host, scratch, B, D, hidden_padded, acc, st, bits);
-    if (num_blocks == 2) return maf_h_launch<2>(z, y, logdet, blob, table, table_host, scratch, B, D, hidden_padded, acc, st, bits);
-    return maf_h_launch<3>(z, y, logdet, blob, table, table_host, scratch, B, D, hidden_padded, acc, st, bits);
+    if (num_blocks == 1) return maf_h_launch<1>(z, y, logdet, blob, table, table_host, scratch, B, D, hidden_padded, acc, st, bits, prm);
+    if (num_blocks == 2) return maf_h_launch<2>(z, y, logdet, blob, table, table_host, scratch, B, D, hidden_padded, acc, st, bits, prm);
+    return maf_h_launch<3>(z, y, logdet, blob, table, table_host, scratch, B, D, hidden_padded, acc, st, bits, prm);
 }
 
 // nf_maf_inverse on the half-sharing mapping: same blob / table format and semantics as nf_maf_inverse (maf_inverse.hip), for
@@ -1004,6 +1030,19 @@ extern "C" int nf_maf_inverse_h_tri_bits(const void *z, void *y, void *logdet, c
                                          int num_blocks, int acc, nf_stream_t stream) {
     if (!table_host || (!bits && B > 0)) return NF_EFAULT;
     return maf_h_entry(z, y, logdet, blob, table, table_host, scratch, B, D, hidden_padded, num_blocks, acc, stream, (unsigned int *)bits);
+}
+
+// The training forward in one entry point (round 6): nf_maf_inverse_h_bits (table_host NULL: format-0 pack) / nf_maf_inverse_h_tri_bits
+// (format 1) that ALSO writes MADE's output at the solution, prm (B, 2 D) float32 = (unconstrained scale, shift) per feature in the
+// reference's order (nets/made.py:296-304 as affine/autoregressive.py:98-128 reads it) -- each pair exists in registers when its
+// feature is finished.  The implicit backward needs it (nf_maf_solve_t, nf_maf_affine_bwd); round 5 recomputed it from the pass's last
+// hidden tensor with one rearrangement and one library product per layer.
+extern "C" int nf_maf_inverse_h_train(const void *z, void *y, void *logdet, const void *blob, const int32_t *table,
+                                      const int32_t *table_host, void *scratch, void *bits, void *prm, int64_t B, int D,
+                                      int hidden_padded, int num_blocks, int acc, nf_stream_t stream) {
+    if ((!bits || !prm) && B > 0) return NF_EFAULT;
+    return maf_h_entry(z, y, logdet, blob, table, table_host, scratch, B, D, hidden_padded, num_blocks, acc, stream, (unsigned int *)bits,
+                       (float *)prm);
 }
 
 // Scratch of nf_maf_solve_t: per row NL hidden_padded cotangents + the padded (g_us, g_sh) row + the tile-pair stash.

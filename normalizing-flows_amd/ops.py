@@ -1325,10 +1325,11 @@ def maf_inverse(z, blob, table, hidden_padded, logdet=None, acc=None, num_blocks
     return y, logdet
 
 
-def maf_inverse_bits(z, blob, table, hidden_padded, num_blocks, tiles, table_host=None, return_scratch=False):
+def maf_inverse_bits(z, blob, table, hidden_padded, num_blocks, tiles, table_host=None, return_scratch=False, want_params=False):
     """nf_maf_inverse_h_bits / nf_maf_inverse_h_tri_bits (table_host = the host copy of a format-1 table): the one-pass inverse that also
     leaves the pass's ReLU masks (uint32 words per 32-row wave, tile and lane, in the pack's positions) for maf_solve_t on a
-    transposed pack of the same format.  Returns (y, logdet, bits)."""
+    transposed pack of the same format.  Returns (y, logdet, bits [, scratch]); want_params (round 6, nf_maf_inverse_h_train): MADE's
+    output at the solution, (B, 2 D), is appended."""
     L.require_device(z, blob, table)
     if z.dtype != torch.float32:
         raise NotImplementedError("maf_inverse_bits: float32 only")
@@ -1340,6 +1341,15 @@ def maf_inverse_bits(z, blob, table, hidden_padded, num_blocks, tiles, table_hos
     n = lib.nf_maf_inverse_h_scratch_floats(i64(B), i32(D), i32(hidden_padded), i32(num_blocks))
     scratch = torch.empty(max(int(n), 1), dtype=torch.float32, device=z.device)
     bits = torch.empty(max((B + 31) // 32 * tiles * 64 * num_blocks, 1), dtype=torch.int32, device=z.device)
+    if want_params:
+        import numpy as np
+        prm = torch.empty(B, 2 * D, dtype=torch.float32, device=z.device)
+        th = None if table_host is None else np.ascontiguousarray(table_host, dtype=np.int32)
+        rc = lib.nf_maf_inverse_h_train(ptr(z), ptr(y), ptr(logdet), ptr(blob), ptr(table), C.c_void_p(None if th is None else th.ctypes.data),
+                                        ptr(scratch), ptr(bits), ptr(prm), i64(B), i32(D), i32(hidden_padded), i32(num_blocks),
+                                        i32(L.LD_WRITE), L.stream())
+        L.check(rc, "nf_maf_inverse_h_train")
+        return (y, logdet, bits, scratch, prm) if return_scratch else (y, logdet, bits, prm)
     if table_host is not None:
         import numpy as np
         th = np.ascontiguousarray(table_host, dtype=np.int32)

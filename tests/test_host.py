@@ -107,6 +107,22 @@ def test_c_abi_argument_validation_newer_entry_points(nfa):
     assert lib.nf_maf_scratch_rows(one, one, one, i64(8), i32(2), i32(512), i32(510), f64(-1.0), i32(1), null) == -22     # ldo % 4
     assert lib.nf_maf_scratch_rows(one, null, one, i64(8), i32(2), i32(512), i32(512), f64(-1.0), i32(1), null) == -14
     assert lib.nf_maf_scratch_rows(null, null, null, i64(0), i32(2), i32(512), i32(512), f64(-1.0), i32(1), null) == 0
+    # round 6: one layer of a scratch; the weight gradients from the scratches in place; the training forward that stores MADE's output
+    assert lib.nf_maf_scratch_layer(one, one, one, i64(8), i32(2), i32(512), i32(512), i32(5), null) == -22                 # layer >= 2 blocks + 1
+    assert lib.nf_maf_scratch_layer(one, one, one, i64(8), i32(2), i32(500), i32(512), i32(4), null) == -22
+    assert lib.nf_maf_scratch_layer(one, null, one, i64(8), i32(2), i32(512), i32(512), i32(4), null) == -14
+    assert lib.nf_maf_scratch_layer(null, null, null, i64(0), i32(2), i32(512), i32(512), i32(4), null) == 0
+    wg = lambda B, ntiles, nl, pos, a=one: lib.nf_made_wgrad_pos(a, one, one, one, one, one, one, one, one, i32(ntiles), i64(B), i32(nl), i32(pos), null)
+    assert wg(64, 0, 5, 512) == -22 and wg(64, 4, 0, 512) == -22 and wg(-64, 4, 5, 512) == -22
+    assert wg(100, 4, 5, 512) == -95             # rows: a multiple of 64 (the scratch holds no zero rows beyond the batch)
+    assert wg(64, 4, 5, 160) == -95              # positions: a multiple of 128
+    assert wg(64, 4, 5, 512, null) == -14 and wg(0, 4, 5, 512, null) == 0
+    tr = lambda bits, prm, hp=512, th_=null: lib.nf_maf_inverse_h_train(one, one, one, one, one, th_, one, bits, prm, i64(8), i32(128), i32(hp),
+                                                                       i32(2), i32(0), null)
+    assert tr(null, one) == -14 and tr(one, null) == -14 and tr(one, one, 500) == -22
+    th[7] = 1
+    assert lib.nf_maf_inverse_h_train(one, one, one, one, one, hp_, one, one, one, i64(8), i32(64), i32(512), i32(2), i32(0), null) == -22   # D != table's
+    th[7] = 0
     # debug-mode spline check
     assert lib.nf_rqs_spline_check(one, one, i64(8), i32(0), f64(1.0), f64(0.0), f64(1.0), f64(0.0), f64(1.0), i32(1), i32(0), null, null) == -14
     assert lib.nf_rqs_spline_check(one, one, i64(8), i32(7), f64(1.0), f64(0.0), f64(1.0), f64(0.0), f64(1.0), i32(1), i32(0), one, null) == -22
@@ -845,12 +861,18 @@ def test_tile_engine_and_maf_kernels_use_no_scratch(nfa):
     objdir = os.path.join(ROOT, "normalizing-flows_amd", "lib", "obj")
     want = {("rqs_fused_nw4.o", "rqs_fused_kernel_nw4"): 38,      # the 128-row-workgroup build: 36 inference + 2 whole-layer training forwards (round 6, late)
             ("nsf_wide.o", "nsf_wide_kernel"): 36, ("made_fwd.o", "made_fwd_kernel"): 8,
-            ("maf_inverse_h.o", "maf_inverse_h_kernel"): 6, ("maf_inverse_h.o", "maf_solve_t_kernel"): 3}
+            ("maf_inverse_h.o", "maf_inverse_h_kernel"): 12, ("maf_inverse_h.o", "maf_solve_t_kernel"): 3}
     for (obj, tag), n in want.items():
         seen = 0
         for name, d in kr.resources(os.path.join(objdir, obj)).items():
             if tag in name:
                 seen += 1
+                if tag == "maf_inverse_h_kernel" and "ELb1EEEv" in name:
+                    # the TRAINING instantiations (round 6, late: they also store MADE's output per feature, nf_maf_inverse_h_train) of
+                    # the two-block kernels sit two registers over the 256 that two waves per SIMD leave: <= 16 bytes per lane; the
+                    # inference instantiations -- BASELINE configs[4]'s kernel among them -- stay free of scratch
+                    assert d["private_segment_fixed_size"] <= 16, (name, d)
+                    continue
                 assert d["vgpr_spill_count"] == 0 and d["private_segment_fixed_size"] == 0, (name, d)
         assert seen == n, (tag, seen)
 
