@@ -362,6 +362,15 @@ int nf_inv1x1_assemble(const void *P, const void *L, const void *U, const void *
  * lower / upper parts; zero elsewhere) and g_log_S (C) from the cotangents gW (C x C) and gl (0-dim, may be NULL).  C <= 64. */
 int nf_inv1x1_lu_grads(const void *P, const void *L, const void *U, const void *sign_S, const void *log_S, const void *gW,
                        const void *gl, void *gL, void *gU, void *glogS, int C, int dtype, nf_stream_t stream);
+/* Both for n layers of one size C in ceil(n / 32) launches (round 6, float32, density direction): a Glow level's K blocks
+ * (flows/affine/glow.py:72-84 inside core.py:588-616) assemble their matrices from parameters alone, and their LU factors' gradients
+ * need nothing but every block's gW -- one launch per level and direction instead of one per block (96 + 96 single-workgroup launches
+ * per training step of BASELINE configs[3]).  Every pointer argument is a HOST array of n device pointers (gl[i] may be NULL). */
+int nf_inv1x1_assemble_multi(const void *const *P, const void *const *L, const void *const *U, const void *const *sign_S,
+                             const void *const *log_S, void *const *W, void *const *logdet_unit, int n, int C, nf_stream_t stream);
+int nf_inv1x1_lu_grads_multi(const void *const *P, const void *const *L, const void *const *U, const void *const *sign_S,
+                             const void *const *log_S, const void *const *gW, const void *const *gl, void *const *gL, void *const *gU,
+                             void *const *glogS, int n, int C, nf_stream_t stream);
 int nf_inv1x1_conv(const void *z, const void *W, const void *logdet_unit, void *y, void *logdet_scalar,
                    void *logdet, int64_t B, int C, int64_t HW, int acc, int dtype, nf_stream_t stream);
 /* y = W z + bias per pixel (bias (C) may be NULL): the 1x1 convolution with the neighbouring ActNorm

@@ -800,6 +800,37 @@ class Inv1x1WeightFn(torch.autograd.Function):
         return None, gL, gU, None, gs
 
 
+class Inv1x1WeightsFn(torch.autograd.Function):
+    """Inv1x1WeightFn for ALL the Invertible1x1Convs of a Glow level at once (round 6, late): forward(n, P_0, L_0, U_0, sign_S_0,
+    log_S_0, P_1, ...) -> (W_0, ld_0, W_1, ld_1, ...) in one nf_inv1x1_assemble_multi launch per 32 layers; autograd runs the backward
+    when every block's (gW, gl) exists -- the end of the level's backward -- as one nf_inv1x1_lu_grads_multi launch.  The matrices
+    depend on parameters only, so nothing is gained or lost in precision or order: the same kernels' bodies per layer."""
+
+    @staticmethod
+    def forward(ctx, n, *tensors):
+        layers = [tuple(t.detach() for t in tensors[5 * i:5 * i + 5]) for i in range(n)]
+        out = ops.inv1x1_assemble_multi(layers)
+        ctx.save_for_backward(*tensors)
+        ctx.n = n
+        ctx.set_materialize_grads(False)
+        return tuple(t for pair in out for t in pair)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        tensors = ctx.saved_tensors
+        n = ctx.n
+        layers = [tuple(t.detach() for t in tensors[5 * i:5 * i + 5]) for i in range(n)]
+        _sidestream.join()          # (a gW may come from Inv1x1Fn's side-stream launch, config.train_leaf_async)
+        gWs = [grads[2 * i] if grads[2 * i] is not None else torch.zeros_like(layers[i][1]) for i in range(n)]
+        gls = [grads[2 * i + 1] for i in range(n)]
+        res = ops.inv1x1_lu_grads_multi(layers, gWs, gls)
+        out = [None]
+        for gL, gU, gs in res:
+            out += [None, gL, gU, None, gs]
+        return tuple(out)
+
+
 _ZERO0 = {}
 
 
@@ -842,7 +873,7 @@ class Inv1x1Fn(torch.autograd.Function):
                 # -- but not W's of any other origin (slogdet's backward etc. run on the current stream)
                 fn = W.grad_fn
                 mine = W.is_leaf and not ldu.requires_grad
-                mine = mine or (fn is not None and fn is ldu.grad_fn and fn.name().startswith("Inv1x1WeightFn"))
+                mine = mine or (fn is not None and fn is ldu.grad_fn and fn.name().startswith("Inv1x1Weight"))       # (Inv1x1WeightFn / Inv1x1WeightsFn: both join or follow)
                 side = _leaf_fork(z.device, (W,) if W.is_leaf else (), keep=(z, gy, gld)) if mine else None
                 with _on(side):
                     gW, gl = ops.inv1x1_wgrad(z, gy, gld)                             # csrc/affine_bwd.hip

@@ -129,6 +129,16 @@ def set_train_leaf_async(mode=True):
     train_leaf_async = bool(mode)
 
 
+# Glow's training step: the Invertible1x1Convs of a level assemble their matrices (and, in the backward, their LU factors' gradients) in
+# ONE launch per level (autograd.Inv1x1WeightsFn) instead of one single-workgroup launch per block and direction.  False = per block.
+glow_weights_batched = True
+
+
+def set_glow_weights_batched(mode=True):
+    global glow_weights_batched
+    glow_weights_batched = bool(mode)
+
+
 # A differentiable density pass of a benchmark-shaped model on a batch that is NOT a multiple of 64 rows (>= 1024) is run on the batch
 # padded with zero rows to the next multiple (NormalizingFlow._log_prob_impl) and sliced back: the one-call / pair training kernels need
 # whole 64-row tiles, and the slice's backward hands the padding rows a zero cotangent, so they contribute exactly nothing to any

@@ -629,6 +629,23 @@ class MultiscaleFlow(nn.Module):
         return z, log_det
 
     def _level_pass(self, i, z, z_other, inverse, ld, acc):
+        """_level_pass_impl; in the density direction under autograd the level's Invertible1x1Convs assemble their matrices in one
+        launch first (flows/mixing.prefetch_weights, round 6)."""
+        convs = []
+        if inverse and torch.is_grad_enabled() and z.is_cuda:
+            from .flows.glow import GlowBlock
+            from .flows.mixing import Invertible1x1Conv, clear_prefetched, prefetch_weights
+            convs = [f.flows[1] for f in self.flows[i]
+                     if isinstance(f, GlowBlock) and len(f.flows) == 3 and isinstance(f.flows[1], Invertible1x1Conv)]
+            if len(convs) > 1:
+                prefetch_weights(convs)
+        try:
+            return self._level_pass_impl(i, z, z_other, inverse, ld, acc)
+        finally:
+            if len(convs) > 1:
+                clear_prefetched(convs)
+
+    def _level_pass_impl(self, i, z, z_other, inverse, ld, acc):
         """Level i of the multi-scale flow with the log-dets folded into `ld`.
         inverse (density, core.py:600-611): flows[i] reversed, then the level's split -> (z, z_); z_ is None at i == 0.
         forward (sample, core.py:570-582): merge z with `z_other` (None at i == 0), then flows[i] -> (z, None).

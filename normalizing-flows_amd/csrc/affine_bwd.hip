@@ -374,10 +374,10 @@ maf_affine_bwd_kernel(const T *__restrict__ x, const T *__restrict__ params, con
 // torch autograd does with ~15 tiny tril / triu / diag / exp / matmul launches per layer and step.  C <= 64, one workgroup per row:
 //   gLm = P^T gW Um^T -> strictly lower part;  gUm = (P Lm)^T gW -> strictly upper part;  g_log_S = diag(gUm) sign_S exp(log_S) + gl
 template <typename T>
-__global__ void __launch_bounds__(64)
-inv1x1_lu_grads_kernel(const T *__restrict__ P, const T *__restrict__ L, const T *__restrict__ U, const T *__restrict__ sign_S,
-                       const T *__restrict__ log_S, const T *__restrict__ gW, const T *__restrict__ gl, T *__restrict__ gL,
-                       T *__restrict__ gU, T *__restrict__ glogS, int C) {
+__device__ __forceinline__ void inv1x1_lu_grads_body(const T *__restrict__ P, const T *__restrict__ L, const T *__restrict__ U,
+                                                     const T *__restrict__ sign_S, const T *__restrict__ log_S, const T *__restrict__ gW,
+                                                     const T *__restrict__ gl, T *__restrict__ gL, T *__restrict__ gU,
+                                                     T *__restrict__ glogS, int C) {
     // one workgroup per output row i, thread j per column: row i of A = P^T gW and column i of P Lm through LDS.  Round 5: P, gW, U and
     // column i of Lm are staged in LDS first (coalesced) -- the loops below were ~6 C dependent global loads per thread, 18 us per call
     extern __shared__ __attribute__((aligned(16))) unsigned char lg_raw[];
@@ -408,6 +408,30 @@ inv1x1_lu_grads_kernel(const T *__restrict__ P, const T *__restrict__ L, const T
         gU[i * C + j] = j > i ? gum : T(0);
         if (i == j) glogS[i] = gum * sign_S[i] * M<T>::exp(log_S[i]) + (gl ? *gl : T(0));
     }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64)
+inv1x1_lu_grads_kernel(const T *__restrict__ P, const T *__restrict__ L, const T *__restrict__ U, const T *__restrict__ sign_S,
+                       const T *__restrict__ log_S, const T *__restrict__ gW, const T *__restrict__ gl, T *__restrict__ gL,
+                       T *__restrict__ gU, T *__restrict__ glogS, int C) {
+    inv1x1_lu_grads_body<T>(P, L, U, sign_S, log_S, gW, gl, gL, gU, glogS, C);
+}
+
+// Round 6 (late): up to 32 layers of one size per launch (grid = rows x layers): the LU factors' gradients of a whole Glow level once
+// every block's gW exists, instead of one 14 us launch per block inside the backward pass.
+constexpr int I1G_MULTI = 32;
+struct Inv1x1LuGradsMulti {
+    const void *P[I1G_MULTI], *L[I1G_MULTI], *U[I1G_MULTI], *sign_S[I1G_MULTI], *log_S[I1G_MULTI], *gW[I1G_MULTI], *gl[I1G_MULTI];
+    void *gL[I1G_MULTI], *gU[I1G_MULTI], *glogS[I1G_MULTI];
+};
+
+__global__ void __launch_bounds__(64)
+inv1x1_lu_grads_multi_kernel(Inv1x1LuGradsMulti m, int C) {
+    const int b = blockIdx.y;
+    inv1x1_lu_grads_body<float>((const float *)m.P[b], (const float *)m.L[b], (const float *)m.U[b], (const float *)m.sign_S[b],
+                                (const float *)m.log_S[b], (const float *)m.gW[b], (const float *)m.gl[b], (float *)m.gL[b],
+                                (float *)m.gU[b], (float *)m.glogS[b], C);
 }
 
 
@@ -606,6 +630,32 @@ extern "C" int nf_inv1x1_lu_grads(const void *P, const void *L, const void *U, c
                                    (const double *)U, (const double *)sign_S, (const double *)log_S, (const double *)gW,
                                    (const double *)gl, (double *)gL, (double *)gU, (double *)glogS, C));
     NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// nf_inv1x1_lu_grads (float32) for n layers of one size: every argument a HOST array of n device pointers (gl[i] may be NULL).
+extern "C" int nf_inv1x1_lu_grads_multi(const void *const *P, const void *const *L, const void *const *U, const void *const *sign_S,
+                                        const void *const *log_S, const void *const *gW, const void *const *gl, void *const *gL,
+                                        void *const *gU, void *const *glogS, int n, int C, nf_stream_t stream) {
+    if (n < 0 || C < 1) return NF_EINVAL;
+    if (C > 64) return NF_ENOTSUP;
+    if (n == 0) return NF_OK;
+    if (!P || !L || !U || !sign_S || !log_S || !gW || !gl || !gL || !gU || !glogS) return NF_EFAULT;
+    for (int i = 0; i < n; ++i)
+        if (!P[i] || !L[i] || !U[i] || !sign_S[i] || !log_S[i] || !gW[i] || !gL[i] || !gU[i] || !glogS[i]) return NF_EFAULT;
+    static LdsOptIn opt_m = {};
+    const size_t lds = (size_t)(3 * C * C + C) * sizeof(float);
+    if (opt_in_lds(reinterpret_cast<const void *>(&inv1x1_lu_grads_multi_kernel), lds, opt_m) != NF_OK) return NF_ENOTSUP;
+    for (int i0 = 0; i0 < n; i0 += I1G_MULTI) {
+        const int m = n - i0 < I1G_MULTI ? n - i0 : I1G_MULTI;
+        Inv1x1LuGradsMulti t = {};
+        for (int i = 0; i < m; ++i) {
+            t.P[i] = P[i0 + i]; t.L[i] = L[i0 + i]; t.U[i] = U[i0 + i]; t.sign_S[i] = sign_S[i0 + i]; t.log_S[i] = log_S[i0 + i];
+            t.gW[i] = gW[i0 + i]; t.gl[i] = gl[i0 + i]; t.gL[i] = gL[i0 + i]; t.gU[i] = gU[i0 + i]; t.glogS[i] = glogS[i0 + i];
+        }
+        hipLaunchKernelGGL(inv1x1_lu_grads_multi_kernel, dim3(C, m), dim3(64), lds, (hipStream_t)stream, t, C);
+        NF_CHECK_LAUNCH();
+    }
     return NF_OK;
 }
 

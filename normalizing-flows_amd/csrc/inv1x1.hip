@@ -12,10 +12,9 @@
 namespace nf {
 
 template <typename T>
-__global__ void __launch_bounds__(256)
-inv1x1_assemble_kernel(const T *__restrict__ P, const T *__restrict__ L, const T *__restrict__ U,
-                       const T *__restrict__ sign_S, const T *__restrict__ log_S, T *__restrict__ W,
-                       T *__restrict__ logdet_unit, int C, int inverse) {
+__device__ __forceinline__ void inv1x1_assemble_body(const T *__restrict__ P, const T *__restrict__ L, const T *__restrict__ U,
+                                                     const T *__restrict__ sign_S, const T *__restrict__ log_S, T *__restrict__ W,
+                                                     T *__restrict__ logdet_unit, int C, int inverse) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int n = C * C;
     double *Dd = reinterpret_cast<double *>(smem_raw);  // fp64 triangular factor
@@ -120,6 +119,31 @@ inv1x1_assemble_kernel(const T *__restrict__ P, const T *__restrict__ L, const T
     }
 }
 
+template <typename T>
+__global__ void __launch_bounds__(256)
+inv1x1_assemble_kernel(const T *__restrict__ P, const T *__restrict__ L, const T *__restrict__ U,
+                       const T *__restrict__ sign_S, const T *__restrict__ log_S, T *__restrict__ W,
+                       T *__restrict__ logdet_unit, int C, int inverse) {
+    inv1x1_assemble_body<T>(P, L, U, sign_S, log_S, W, logdet_unit, C, inverse);
+}
+
+// Round 6 (late): the matrices of up to 32 Invertible1x1Convs of one size in ONE launch, workgroup b = layer b -- a Glow level's 32
+// blocks assemble their W from parameters only, so the training step need not spend one 4-30 us single-workgroup launch per block on
+// it (96 per step of BASELINE configs[3]).  Density direction (inverse = 0) only.
+constexpr int I1_MULTI = 32;
+struct Inv1x1AssembleMulti {
+    const void *P[I1_MULTI], *L[I1_MULTI], *U[I1_MULTI], *sign_S[I1_MULTI], *log_S[I1_MULTI];
+    void *W[I1_MULTI], *ld[I1_MULTI];
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+inv1x1_assemble_multi_kernel(Inv1x1AssembleMulti m, int C) {
+    const int b = blockIdx.x;
+    inv1x1_assemble_body<T>((const T *)m.P[b], (const T *)m.L[b], (const T *)m.U[b], (const T *)m.sign_S[b], (const T *)m.log_S[b],
+                            (T *)m.W[b], (T *)m.ld[b], C, 0);
+}
+
 constexpr int OT = 8;  // output channels per lane
 
 template <typename T>
@@ -217,6 +241,33 @@ extern "C" int nf_inv1x1_assemble(const void *P, const void *L, const void *U, c
     if (dtype == NF_F32) return nf::launch_assemble<float>(P, L, U, sign_S, log_S, W, logdet_unit, C, inverse, st);
     if (dtype == NF_F64) return nf::launch_assemble<double>(P, L, U, sign_S, log_S, W, logdet_unit, C, inverse, st);
     return NF_ENOTSUP;
+}
+
+// nf_inv1x1_assemble (density direction, float32) for n layers of one size C in ceil(n / 32) launches: P, L, U, sign_S, log_S, W,
+// logdet_unit = HOST arrays of n device pointers (mixing.py:88-104 per layer).
+extern "C" int nf_inv1x1_assemble_multi(const void *const *P, const void *const *L, const void *const *U, const void *const *sign_S,
+                                        const void *const *log_S, void *const *W, void *const *logdet_unit, int n, int C,
+                                        nf_stream_t stream) {
+    if (n < 0 || C < 1) return NF_EINVAL;
+    if (n == 0) return NF_OK;
+    if (!P || !L || !U || !sign_S || !log_S || !W || !logdet_unit) return NF_EFAULT;
+    for (int i = 0; i < n; ++i)
+        if (!P[i] || !L[i] || !U[i] || !sign_S[i] || !log_S[i] || !W[i]) return NF_EFAULT;
+    const size_t lds = (size_t)C * C * (2 * sizeof(double) + 3 * sizeof(float));
+    if (lds > 158 * 1024) return NF_ENOTSUP;
+    static nf::LdsOptIn opted = {};
+    if (nf::opt_in_lds(reinterpret_cast<const void *>(&nf::inv1x1_assemble_multi_kernel<float>), lds, opted) != NF_OK) return NF_ENOTSUP;
+    for (int i0 = 0; i0 < n; i0 += nf::I1_MULTI) {
+        const int m = n - i0 < nf::I1_MULTI ? n - i0 : nf::I1_MULTI;
+        nf::Inv1x1AssembleMulti t = {};
+        for (int i = 0; i < m; ++i) {
+            t.P[i] = P[i0 + i]; t.L[i] = L[i0 + i]; t.U[i] = U[i0 + i]; t.sign_S[i] = sign_S[i0 + i]; t.log_S[i] = log_S[i0 + i];
+            t.W[i] = W[i0 + i]; t.ld[i] = logdet_unit[i0 + i];
+        }
+        hipLaunchKernelGGL(nf::inv1x1_assemble_multi_kernel<float>, dim3(m), dim3(256), lds, (hipStream_t)stream, t, C);
+        NF_CHECK_LAUNCH();
+    }
+    return NF_OK;
 }
 
 extern "C" int nf_inv1x1_conv(const void *z, const void *W, const void *logdet_unit, void *y, void *logdet_scalar,

@@ -50,6 +50,34 @@ class Permute(Flow):
         return self._move(z, inverse)
 
 
+def prefetch_weights(convs):
+    """Round 6 (late): the density-direction matrices of several LU-parametrised Invertible1x1Convs under autograd in ONE launch per
+    size (autograd.Inv1x1WeightsFn: nf_inv1x1_assemble_multi forward, nf_inv1x1_lu_grads_multi backward) -- they depend on parameters
+    only, so a Glow level assembles its K matrices before its first block runs.  Each layer's (W, log|det| per pixel) waits in
+    `_w_prefetch` for that layer's next `_weight_train(True)`; the caller drops what was not consumed (clear_prefetched)."""
+    from .. import config
+    if not config.glow_weights_batched or not torch.is_grad_enabled():
+        return
+    groups = {}
+    for c in convs:
+        if (c.use_lu and c.L.is_cuda and c.L.dtype == torch.float32 and c.num_channels <= 64
+                and (c.L.requires_grad or c.U.requires_grad or c.log_S.requires_grad)):
+            groups.setdefault((c.num_channels, c.L.device), []).append(c)
+    from ..autograd import Inv1x1WeightsFn
+    for group in groups.values():
+        if len(group) < 2:
+            continue
+        flat = [t for c in group for t in (c.P, c.L, c.U, c.sign_S, c.log_S)]
+        out = Inv1x1WeightsFn.apply(len(group), *flat)
+        for i, c in enumerate(group):
+            c.__dict__["_w_prefetch"] = (out[2 * i], out[2 * i + 1])
+
+
+def clear_prefetched(convs):
+    for c in convs:
+        c.__dict__.pop("_w_prefetch", None)
+
+
 class Invertible1x1Conv(Flow):
     """Glow's invertible 1x1 convolution on NCHW tensors (mixing.py:57-133).
 
@@ -104,6 +132,9 @@ class Invertible1x1Conv(Flow):
             Winv = torch.inverse(W) if W.dtype == torch.float64 else torch.inverse(W.double()).type(W.dtype)
             return Winv, -sld
         if inverse_dir and self.L.is_cuda and self.num_channels <= 64:
+            pre = self.__dict__.pop("_w_prefetch", None)
+            if pre is not None:                          # (assembled with the level's other layers: prefetch_weights below)
+                return pre
             from ..autograd import Inv1x1WeightFn      # density direction: assembly and its VJP as one launch each
             return Inv1x1WeightFn.apply(self.P, self.L, self.U, self.sign_S, self.log_S)
         Lm = torch.tril(self.L, diagonal=-1) + self.eye

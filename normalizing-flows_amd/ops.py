@@ -228,6 +228,55 @@ def inv1x1_lu_grads(P, Lm, U, sign_S, log_S, gW, gl):
     return gL, gU, gs
 
 
+def _ptr_array(tensors):
+    """A ctypes array of device pointers (NULL for None) for the *_multi entry points; the tensors must stay alive through the call."""
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def inv1x1_assemble_multi(layers):
+    """nf_inv1x1_assemble_multi: [(W, per-pixel log|det|)] for `layers` = [(P, L, U, sign_S, log_S)] of ONE size, float32, density
+    direction -- one launch per 32 layers."""
+    n = len(layers)
+    Cc = layers[0][1].shape[0]
+    for tup in layers:
+        L.require_device(*tup)
+        if tup[1].shape != (Cc, Cc) or tup[1].dtype != torch.float32:
+            raise NotImplementedError("inv1x1_assemble_multi: float32 layers of one size")
+    dev = layers[0][1].device
+    cols = [[t.contiguous() for t in tup] for tup in layers]
+    W = torch.empty(n, Cc, Cc, dtype=torch.float32, device=dev)
+    ld = torch.empty(n, dtype=torch.float32, device=dev)
+    Ws, lds = list(W.unbind(0)), list(ld.unbind(0))
+    arrs = [_ptr_array([c[k] for c in cols]) for k in range(5)]
+    rc = L.lib().nf_inv1x1_assemble_multi(*arrs, _ptr_array(Ws), _ptr_array(lds), i32(n), i32(Cc), L.stream())
+    L.check(rc, "nf_inv1x1_assemble_multi")
+    return list(zip(Ws, lds))
+
+
+def inv1x1_lu_grads_multi(layers, gWs, gls):
+    """nf_inv1x1_lu_grads_multi: [(gL, gU, g_log_S)] for `layers` = [(P, L, U, sign_S, log_S)] of one size with cotangents gWs[i]
+    (C x C) and gls[i] (0-dim or None)."""
+    n = len(layers)
+    Cc = layers[0][1].shape[0]
+    dev = layers[0][1].device
+    cols = [[t.contiguous() for t in tup] for tup in layers]
+    gWs = [g.contiguous() for g in gWs]
+    gls = [None if g is None else g.contiguous() for g in gls]
+    L.require_device(*gWs)
+    gL = torch.empty(n, Cc, Cc, dtype=torch.float32, device=dev)
+    gU = torch.empty(n, Cc, Cc, dtype=torch.float32, device=dev)
+    gs = torch.empty(n, Cc, dtype=torch.float32, device=dev)
+    gLs, gUs, gss = list(gL.unbind(0)), list(gU.unbind(0)), list(gs.unbind(0))
+    arrs = [_ptr_array([c[k] for c in cols]) for k in range(5)]
+    rc = L.lib().nf_inv1x1_lu_grads_multi(*arrs, _ptr_array(gWs), _ptr_array(gls), _ptr_array(gLs), _ptr_array(gUs), _ptr_array(gss),
+                                          i32(n), i32(Cc), L.stream())
+    L.check(rc, "nf_inv1x1_lu_grads_multi")
+    return list(zip(gLs, gUs, gss))
+
+
 def inv1x1_conv(z, W, logdet_unit, logdet=None, acc=None, want_scalar=True, bias=None):
     L.require_device(z, W, logdet_unit, bias)
     z = z.contiguous()

@@ -2085,7 +2085,9 @@ def test_glow_parameter_gradient_launches_on_the_side_stream(nfa):
             step()
             torch.cuda.synchronize()
             assert all(torch.equal(a, p.grad) for a, p in zip(ref, m.parameters()))
-        assert len(forks) == 3 * 4 * 3, len(forks)       # conditioner, 1x1 weight, LU factors: per block and step
+        # conditioner + 1x1 weight per block and step (the LU factors' gradients of the level are one launch, config.glow_weights_batched:
+        # it joins first and runs on the current stream)
+        assert len(forks) == 3 * 4 * 2, len(forks)
         n0 = len(forks)
         step(zero=False)                                  # accumulation into an existing .grad: nothing may leave the current stream
         torch.cuda.synchronize()
@@ -2108,6 +2110,57 @@ def test_glow_parameter_gradient_launches_on_the_side_stream(nfa):
     finally:
         ss.fork = orig
         nfa.config.set_train_leaf_async(False)
+
+
+def test_glow_level_assembles_its_1x1_matrices_in_one_launch(nfa):
+    """config.glow_weights_batched (round 6, late): in the density direction under autograd a level's Invertible1x1Convs get their
+    matrices from ONE nf_inv1x1_assemble_multi launch before the first block runs and their LU factors' gradients from ONE
+    nf_inv1x1_lu_grads_multi launch once every block's gW exists (autograd.Inv1x1WeightsFn) -- the same kernel bodies per layer as the
+    per-block launches: loss and every gradient bit for bit; nothing is left waiting in the modules afterwards; a second backward
+    through the same graph is refused like any once-differentiable Function's."""
+    from normflows_amd import ops
+    torch.manual_seed(5)
+    L_, K_ = 2, 3
+    q0, merges, flows = [], [], []
+    for i in range(L_):
+        fl = [nfa.flows.GlowBlock(3 * 2 ** (L_ + 1 - i), 64, split_mode="channel", scale=True) for _ in range(K_)] + [nfa.flows.Squeeze()]
+        flows += [fl]
+        if i > 0:
+            merges += [nfa.flows.Merge()]
+            latent = (3 * 2 ** (L_ - i), 16 // 2 ** (L_ - i), 16 // 2 ** (L_ - i))
+        else:
+            latent = (3 * 2 ** (L_ + 1), 16 // 2 ** L_, 16 // 2 ** L_)
+        q0 += [nfa.distributions.DiagGaussian(latent)]
+    m = nfa.MultiscaleFlow(q0, flows, merges, class_cond=False).to(DEV)
+    x = torch.rand(32, 3, 16, 16, device=DEV)
+    with torch.no_grad():
+        m.log_prob(x)
+        for p in m.parameters():
+            p.add_(0.02 * torch.randn_like(p))
+    res, counts = [], []
+    real = (ops.inv1x1_assemble, ops.inv1x1_lu_grads, ops.inv1x1_assemble_multi, ops.inv1x1_lu_grads_multi)
+    try:
+        for mode in (False, True):
+            nfa.config.set_glow_weights_batched(mode)
+            n = [0, 0, 0, 0]
+
+            def spy(k):
+                def f(*a, **kw):
+                    n[k] += 1
+                    return real[k](*a, **kw)
+                return f
+            ops.inv1x1_assemble, ops.inv1x1_lu_grads, ops.inv1x1_assemble_multi, ops.inv1x1_lu_grads_multi = (spy(k) for k in range(4))
+            m.zero_grad(set_to_none=True)
+            loss = m.forward_kld(x)
+            loss.backward()
+            counts.append(tuple(n))
+            res.append([loss.detach().clone()] + [p.grad.clone() for p in m.parameters()])
+    finally:
+        ops.inv1x1_assemble, ops.inv1x1_lu_grads, ops.inv1x1_assemble_multi, ops.inv1x1_lu_grads_multi = real
+        nfa.config.set_glow_weights_batched(True)
+    assert counts == [(L_ * K_, L_ * K_, 0, 0), (0, 0, L_, L_)], counts
+    assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
+    assert all("_w_prefetch" not in mod.__dict__ for mod in m.modules())
 
 
 def test_maf_one_pass_backward_on_format0_and_format1_packs(nfa):
