@@ -696,6 +696,10 @@ int nf_conv3x3_gather_sum(const void *P, const void *bias, void *out, int64_t B,
 /* out (C) = sum over batch and pixels of g (B, C, H, W) (float32 NCHW): the bias gradient of the conditioner's last convolution
  * (nets/cnn.py:5-63 under loss.backward(); torch: conv2d's bias backward).  One block per channel, fixed order. */
 int nf_channel_sum(const void *g, void *out, int64_t B, int C, int64_t HW, nf_stream_t stream);
+/* ld (B) float32 = (((ld +- t_0) +- t_1) ...) for n per-sample log-det terms (terms: HOST array of n device pointers, negate[i] != 0:
+ * subtracted), in order: what the chain of `log_q += log_det` / `log_q -= log_det` statements in core.py:600-611 / :193-195 computes
+ * layer by layer under autograd, as one launch per 120 terms (a Glow level has 96) with the same bits. */
+int nf_ld_fold_multi(void *ld, const void *const *terms, const int *negate, int n, int64_t B, nf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * MaskedAffineAutoregressive inverse (MAF sampling direction) in ONE pass.  Replaces the D-pass loop of

@@ -800,6 +800,23 @@ class Inv1x1WeightFn(torch.autograd.Function):
         return None, gL, gU, None, gs
 
 
+class LdFoldFn(torch.autograd.Function):
+    """ld <- (((ld +- t_0) +- t_1) ...) in place, one launch (nf_ld_fold_multi): the `ld += log_det` statements of a chain of layers
+    under autograd, deferred and issued together (flows/affine.lazy_ld) -- same order, same bits."""
+
+    @staticmethod
+    def forward(ctx, ld, negate, *terms):
+        ops.ld_fold_multi(ld, [t.detach() for t in terms], negate)
+        ctx.mark_dirty(ld)
+        ctx.negate = negate
+        return ld
+
+    @staticmethod
+    def backward(ctx, g):
+        gn = -g if any(ctx.negate) else None
+        return (g, None) + tuple(gn if s else g for s in ctx.negate)
+
+
 class Inv1x1WeightsFn(torch.autograd.Function):
     """Inv1x1WeightFn for ALL the Invertible1x1Convs of a Glow level at once (round 6, late): forward(n, P_0, L_0, U_0, sign_S_0,
     log_S_0, P_1, ...) -> (W_0, ld_0, W_1, ld_1, ...) in one nf_inv1x1_assemble_multi launch per 32 layers; autograd runs the backward

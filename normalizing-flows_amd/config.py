@@ -139,6 +139,16 @@ def set_glow_weights_batched(mode=True):
     glow_weights_batched = bool(mode)
 
 
+# MultiscaleFlow under autograd: the per-layer `log_q += log_det` statements of a level are collected and applied as one launch in the same
+# order (flows/affine.lazy_ld, nf_ld_fold_multi: same bits).  False = one launch per layer.
+lazy_logdet = True
+
+
+def set_lazy_logdet(mode=True):
+    global lazy_logdet
+    lazy_logdet = bool(mode)
+
+
 # A differentiable density pass of a benchmark-shaped model on a batch that is NOT a multiple of 64 rows (>= 1024) is run on the batch
 # padded with zero rows to the next multiple (NormalizingFlow._log_prob_impl) and sliced back: the one-call / pair training kernels need
 # whole 64-row tiles, and the slice's backward hands the padding rows a zero cotangent, so they contribute exactly nothing to any

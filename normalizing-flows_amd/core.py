@@ -639,8 +639,10 @@ class MultiscaleFlow(nn.Module):
                      if isinstance(f, GlowBlock) and len(f.flows) == 3 and isinstance(f.flows[1], Invertible1x1Conv)]
             if len(convs) > 1:
                 prefetch_weights(convs)
+        from .flows.affine import lazy_ld
         try:
-            return self._level_pass_impl(i, z, z_other, inverse, ld, acc)
+            with lazy_ld(ld):          # (the level's layers only ADD to ld: their statements go out as one launch, same order)
+                return self._level_pass_impl(i, z, z_other, inverse, ld, acc)
         finally:
             if len(convs) > 1:
                 clear_prefetched(convs)

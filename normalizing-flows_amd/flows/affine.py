@@ -15,10 +15,49 @@ from .base import Flow, run_flow
 from .reshape import Merge, Split
 
 
+_LAZY = []       # innermost last: [accumulator tensor, [(negate, log_det), ...]] while a lazy_ld block is open
+
+
+class lazy_ld:
+    """with lazy_ld(ld): the `ld += log_det` / `ld -= log_det` statements the layers inside issue on THIS accumulator under autograd
+    (_fold_ld) are collected and applied when the block closes -- or at flush() -- as ONE launch in the same order (autograd.LdFoldFn,
+    nf_ld_fold_multi: same bits).  Nothing inside may read `ld` before that: MultiscaleFlow._level_pass (a level's GlowBlocks only
+    add to it; round 6, late: 96 launches of three microseconds per level).  A no-op for anything but a contiguous float32 CUDA
+    vector, and when config.lazy_logdet is off."""
+
+    def __init__(self, ld):
+        from .. import config
+        ok = (config.lazy_logdet and ld is not None and ld.is_cuda and ld.dtype == torch.float32 and ld.dim() == 1
+              and ld.is_contiguous() and torch.is_grad_enabled())
+        self.ent = [ld, []] if ok else None
+
+    def __enter__(self):
+        if self.ent is not None:
+            _LAZY.append(self.ent)
+        return self
+
+    def flush(self):
+        if self.ent is not None and self.ent[1]:
+            from ..autograd import LdFoldFn
+            ld, terms = self.ent
+            self.ent[1] = []
+            LdFoldFn.apply(ld, tuple(n for n, _ in terms), *[t for _, t in terms])
+
+    def __exit__(self, et, ev, tb):
+        if self.ent is not None:
+            _LAZY.remove(self.ent)
+            if et is None:
+                self.flush()
+        return False
+
+
 def _fold_ld(ld, acc, log_det):
     """Accumulate protocol under autograd: the kernels' in-place accumulation is not differentiable."""
     if ld is None:
         return log_det
+    if _LAZY and _LAZY[-1][0] is ld and log_det.shape == ld.shape and log_det.dtype == ld.dtype:
+        _LAZY[-1][1].append((not (acc is None or acc > 0), log_det))
+        return ld
     if acc is None or acc > 0:
         ld += log_det
     else:

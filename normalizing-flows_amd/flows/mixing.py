@@ -154,10 +154,8 @@ class Invertible1x1Conv(Flow):
             y, log_det = Inv1x1Fn.apply(z.contiguous(), W, ldu)
             if ld is None:
                 return y, log_det
-            if acc is None or acc > 0:
-                ld += log_det
-            else:
-                ld -= log_det
+            from .affine import _fold_ld
+            _fold_ld(ld, acc, log_det)
             return y, ld
         W, ldu = self._weight(inverse_dir)
         return ops.inv1x1_conv(z, W, ldu, logdet=ld, acc=acc, want_scalar=want_scalar)

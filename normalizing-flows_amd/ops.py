@@ -236,6 +236,18 @@ def _ptr_array(tensors):
     return arr
 
 
+def ld_fold_multi(ld, terms, negate):
+    """nf_ld_fold_multi: ld (B) float32 updated IN PLACE with the (B) terms in order (negate[i]: subtracted)."""
+    L.require_device(ld, *terms)
+    if ld.dtype != torch.float32 or not ld.is_contiguous() or any(t.dtype != torch.float32 or t.shape != ld.shape for t in terms):
+        raise NotImplementedError("ld_fold_multi: contiguous float32 vectors of one length")
+    terms = [t.contiguous() for t in terms]
+    neg = (C.c_int * len(terms))(*[1 if x else 0 for x in negate])
+    rc = L.lib().nf_ld_fold_multi(ptr(ld), _ptr_array(terms), neg, i32(len(terms)), i64(ld.numel()), L.stream())
+    L.check(rc, "nf_ld_fold_multi")
+    return ld
+
+
 def inv1x1_assemble_multi(layers):
     """nf_inv1x1_assemble_multi: [(W, per-pixel log|det|)] for `layers` = [(P, L, U, sign_S, log_S)] of ONE size, float32, density
     direction -- one launch per 32 layers."""

@@ -2163,6 +2163,51 @@ def test_glow_level_assembles_its_1x1_matrices_in_one_launch(nfa):
     assert all("_w_prefetch" not in mod.__dict__ for mod in m.modules())
 
 
+def test_glow_level_folds_its_log_dets_in_one_launch(nfa):
+    """config.lazy_logdet (round 6, late): under autograd the `log_q += log_det` statements of a level's layers are collected
+    (flows/affine.lazy_ld) and applied by ONE nf_ld_fold_multi launch in the same order -- loss and gradients bit for bit, with a
+    mixed-sign list too."""
+    from normflows_amd import ops
+    torch.manual_seed(6)
+    ld0 = torch.randn(300, device=DEV)
+    terms = [torch.randn(300, device=DEV) for _ in range(130)]          # (> 120: two launches)
+    neg = [bool(i % 3 == 1) for i in range(130)]
+    want = ld0.clone()
+    for t, s_ in zip(terms, neg):
+        want = want - t if s_ else want + t
+    got = ops.ld_fold_multi(ld0.clone(), terms, neg)
+    assert torch.equal(got, want)
+    fl = [[nfa.flows.GlowBlock(12, 64, split_mode="channel", scale=True) for _ in range(3)] + [nfa.flows.Squeeze()]]
+    m = nfa.MultiscaleFlow([nfa.distributions.DiagGaussian((12, 8, 8))], fl, [], class_cond=False).to(DEV)
+    x = torch.rand(32, 3, 16, 16, device=DEV)
+    with torch.no_grad():
+        m.log_prob(x)
+        for p in m.parameters():
+            p.add_(0.02 * torch.randn_like(p))
+    res, calls = [], []
+    real = ops.ld_fold_multi
+    try:
+        for mode in (False, True):
+            nfa.config.set_lazy_logdet(mode)
+            n = [0]
+
+            def spy(*a, **k):
+                n[0] += 1
+                return real(*a, **k)
+            ops.ld_fold_multi = spy
+            m.zero_grad(set_to_none=True)
+            xx = x.clone().requires_grad_(True)
+            loss = m.forward_kld(xx)
+            loss.backward()
+            calls.append(n[0])
+            res.append([loss.detach().clone(), xx.grad.clone()] + [p.grad.clone() for p in m.parameters()])
+    finally:
+        ops.ld_fold_multi = real
+        nfa.config.set_lazy_logdet(True)
+    assert calls == [0, 1], calls
+    assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
+
+
 def test_maf_one_pass_backward_on_format0_and_format1_packs(nfa):
     """The one-pass implicit backward with the forward on the format-1 pack (default: fast inverse kernel, masks in its positions,
     nf_maf_inverse_h_tri_bits) and on the format-0 pack (config.set_maf_tri(False): nf_maf_inverse_h_bits): the two position

@@ -1,6 +1,7 @@
 """Round 6: config 4's training step (forward_kld + backward, eager and as one hipGraph) with one switch of config.py on and off --
 alternating on one box; also checks that both give the same gradient bits.  NF_AB = leaf_async (the parameter-gradient launches on the
-side stream, default) | weights_batched (a level's 1x1-convolution matrices and LU-factor gradients in one launch each)."""
+side stream, default) | weights_batched (a level's 1x1-convolution matrices and LU-factor gradients in one launch each) | lazy_logdet
+(a level's log-det statements as one launch)."""
 import os, sys, time, json
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
@@ -58,7 +59,7 @@ res = {"eager_ms": {}, "graph_ms": {}}
 grads = {}
 for rnd in range(2):
     for mode in (False, True):
-        getattr(nfa.config, "set_glow_weights_batched" if os.environ.get("NF_AB") == "weights_batched" else "set_train_leaf_async")(mode)
+        getattr(nfa.config, {"weights_batched": "set_glow_weights_batched", "lazy_logdet": "set_lazy_logdet"}.get(os.environ.get("NF_AB"), "set_train_leaf_async"))(mode)
         step(); step()
         e = timed(step, 3)
         grads.setdefault(mode, [p.grad.clone() for p in m.parameters()])
