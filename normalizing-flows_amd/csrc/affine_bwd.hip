@@ -317,8 +317,18 @@ inv1x1_wgrad_reduce_kernel(const T *__restrict__ partial, const T *__restrict__ 
     const int e = threadIdx.x & 15, q = threadIdx.x >> 4;
     const int ent = blockIdx.x * 16 + e;
     double a = 0.0;
-    if (ent < CC)
-        for (int w = q; w < nparts; w += 16) a += (double)partial[(int64_t)w * CC + ent];
+    if (ent < CC) {      // four loads in flight (round 6, late: one accumulator = one load at a time, 10 us per call at 1024 partials)
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int w = q;
+        for (; w + 48 < nparts; w += 64) {
+            a0 += (double)partial[(int64_t)w * CC + ent];
+            a1 += (double)partial[(int64_t)(w + 16) * CC + ent];
+            a2 += (double)partial[(int64_t)(w + 32) * CC + ent];
+            a3 += (double)partial[(int64_t)(w + 48) * CC + ent];
+        }
+        for (; w < nparts; w += 16) a0 += (double)partial[(int64_t)w * CC + ent];
+        a = (a0 + a1) + (a2 + a3);
+    }
     slices[q][e] = a;
     __syncthreads();
     if (q == 0 && ent < CC) {
