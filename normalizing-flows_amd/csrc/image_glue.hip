@@ -137,7 +137,15 @@ __global__ void __launch_bounds__(256)
 ld_fold_multi_kernel(float *__restrict__ ld, LdFoldTerms m, int n, int64_t B) {
     for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (int64_t)gridDim.x * blockDim.x) {
         float a = ld[b];
-        for (int i = 0; i < n; ++i) {
+        int i = 0;
+        for (; i + 8 <= n; i += 8) {         // eight independent loads, then the adds in order (one load at a time: 40 us for 96 terms)
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = m.t[i + j][b];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a = (m.neg[(i + j) >> 5] >> ((i + j) & 31)) & 1u ? a - v[j] : a + v[j];
+        }
+        for (; i < n; ++i) {
             const float v = m.t[i][b];
             a = (m.neg[i >> 5] >> (i & 31)) & 1u ? a - v : a + v;
         }

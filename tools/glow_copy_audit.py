@@ -21,7 +21,7 @@ with profile(activities=[ProfilerActivity.CPU], with_stack=True,
 cnt = collections.Counter()
 for ev in prof.events():
     if ev.name in ("aten::copy_", "aten::clone", "aten::add", "aten::add_", "aten::fill_", "aten::zero_", "aten::zeros", "aten::cat"):
-        st = [fr for fr in (ev.stack or ()) if "normalizing-flows_amd" in fr or "normflows_amd" in fr or "autograd" in fr]
+        st = [fr for fr in (ev.stack or ()) if "normalizing-flows_amd" in fr or "normflows_amd" in fr or "autograd" in fr or "torch/" in fr]
         cnt[(ev.name, " <- ".join(s.split("/")[-1][:60] for s in st[:2]) or "(no python frame: inside the autograd engine)")] += 1
-for (n, s), c in cnt.most_common(40):
+for (n, s), c in cnt.most_common(60):
     print("%4d %-12s %s" % (c, n, s))
