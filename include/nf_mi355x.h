@@ -763,6 +763,12 @@ int nf_maf_inverse_h_train(const void *z, void *y, void *logdet, const void *blo
 int64_t nf_maf_solve_t_scratch_floats(int64_t B, int D, int hidden_padded, int num_blocks);
 int nf_maf_solve_t(const void *x, const void *prm, const void *gx, const void *gld, const void *bits, void *v, const void *blob,
                    const int32_t *table, void *scratch, int64_t B, int D, int hidden_padded, int num_blocks, nf_stream_t stream);
+/* nf_maf_solve_t on a transposed pack over the format-1 forward positions (pack_made_transposed(tri=True)); table_host = the HOST copy
+ * of `table`: the tiles it marks regular-8 (entry [21]) run a statically unrolled sequential part, launched per run of tiles of one
+ * kind (round 6).  Bit for bit the results of nf_maf_solve_t on the same pack. */
+int nf_maf_solve_t_tri(const void *x, const void *prm, const void *gx, const void *gld, const void *bits, void *v, const void *blob,
+                       const int32_t *table, const int32_t *table_host, void *scratch, int64_t B, int D, int hidden_padded,
+                       int num_blocks, nf_stream_t stream);
 /* The scratch nf_maf_solve_t leaves behind IS MADE's input-gradient chain at the solution (every virtual unit is finalised once, from
  * final values): the hidden-layer output gradients torch's autograd computes for `F.linear(x, weight * mask, bias)` per MaskedLinear
  * (nets/made.py:73-81) on the way to the weight gradients.  nf_maf_scratch_rows rearranges it from the kernel's tile order into

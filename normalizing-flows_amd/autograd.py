@@ -1058,6 +1058,7 @@ class MafInverseFn(torch.autograd.Function):
             ctx.prm = out[4] if want_p else None
             ctx.save_for_backward(x, bits, *([params[-1]] if params else []))
             ctx.tpack = (inv["tblob"], inv["ttable"], inv["hp"], inv["nb"], inv.get("gcols"))
+            ctx.tth = inv.get("ttable_host")
             ctx.pw = inv.get("pw") if _config.maf_wgrad_in_place else None
             # the pass's own activations (its scratch) are the inputs of MADE's linears at x: kept for the weight-gradient launch, so
             # the backward does not run MADE forward again (671 MB per config-5 layer at B = 65 536 instead of a transient of that size)
@@ -1101,12 +1102,12 @@ class MafInverseFn(torch.autograd.Function):
                 if p is None:
                     h_last = ops.maf_scratch_layer(fscratch, fcols, B, nb, hp, 2 * nb)
                     p = torch.nn.functional.linear(h_last[:B], wf_t, bias_f)
-                v, scratch = ops.maf_solve_t(x, p, gx, gld, ctx.saved_tensors[1], tb, tt, hp, nb, return_scratch=True)
+                v, scratch = ops.maf_solve_t(x, p, gx, gld, ctx.saved_tensors[1], tb, tt, hp, nb, return_scratch=True, table_host=getattr(ctx, "tth", None))
                 MafInverseFn.last_sweeps = 1
                 return MafInverseFn._finish(ctx, x, p, v, gld, None, None, None, pos=(scratch, fscratch, pw))
             save = ops.maf_scratch_rows(fscratch, fcols, B, nb, hp)
             p = torch.nn.functional.linear(save[2 * nb, :B], wf_t, bias_f)
-            v, scratch = ops.maf_solve_t(x, p, gx, gld, ctx.saved_tensors[1], tb, tt, hp, nb, return_scratch=True)
+            v, scratch = ops.maf_solve_t(x, p, gx, gld, ctx.saved_tensors[1], tb, tt, hp, nb, return_scratch=True, table_host=getattr(ctx, "tth", None))
             G = ops.maf_scratch_rows(scratch, gcols, B, nb, hp, sign=-1.0, reverse_layers=True)
             MafInverseFn.last_sweeps = 1
             return MafInverseFn._finish(ctx, x, p, v, gld, save, None, G)
@@ -1119,10 +1120,10 @@ class MafInverseFn(torch.autograd.Function):
             if gcols is not None and _config.maf_solve_grads and any(ctx.needs_input_grad[4:]):
                 # the solve's activation scratch IS the input-gradient chain at the solution: rearranged into the weight-gradient
                 # launch's G (sign: the parameter cotangent below is g_p(-v, -g_ld)) instead of one more nf_made_backward pass
-                v, scratch = ops.maf_solve_t(x, p, gx, gld, ctx.saved_tensors[1], tb, tt, hp, nb, return_scratch=True)
+                v, scratch = ops.maf_solve_t(x, p, gx, gld, ctx.saved_tensors[1], tb, tt, hp, nb, return_scratch=True, table_host=getattr(ctx, "tth", None))
                 G = ops.maf_scratch_rows(scratch, gcols, B, nb, hp, sign=-1.0, reverse_layers=True)
             else:
-                v = ops.maf_solve_t(x, p, gx, gld, ctx.saved_tensors[1], tb, tt, hp, nb)
+                v = ops.maf_solve_t(x, p, gx, gld, ctx.saved_tensors[1], tb, tt, hp, nb, table_host=getattr(ctx, "tth", None))
             MafInverseFn.last_sweeps = 1
             return MafInverseFn._finish(ctx, x, p, v, gld, save, bits, G)
         v = torch.empty_like(x)

@@ -341,6 +341,16 @@ def set_maf_solve_grads(mode=True):
     maf_solve_grads = bool(mode)
 
 
+# Round 6 (late): the one-pass solve runs the regular-8 tiles of a format-1 transposed pack on a statically unrolled sequential part
+# (nf_maf_solve_t_tri; bit-identical to the generic part).  False = every tile on the generic part.
+maf_solve_fast = True
+
+
+def set_maf_solve_fast(mode=True):
+    global maf_solve_fast
+    maf_solve_fast = bool(mode)
+
+
 # Round 6: that weight-gradient launch reads BOTH scratches where the one-pass kernels left them (nf_made_wgrad_pos: problems, tiles and
 # scatter maps over scratch positions; batches that are a multiple of 64 rows, position counts that are a multiple of 128) instead of two
 # nf_maf_scratch_rows rearrangements per layer (2 x 245 us and 2.7 GB of traffic per config-5 layer at B = 65 536).  False = rearrange.

@@ -733,11 +733,85 @@ __device__ __forceinline__ void t_finish(float gxm, float xf, float us, float gx
     ga = (vv * xf + gl * rs) * (sg * (1.0f - sg));
 }
 
-template <int NB>
+// Round 6 (late): REGULAR-8 tiles (table entry [21] = 1: the forward tile is a format-1 regular tile of exactly 8 degrees x 4 units, so
+// virtual step S finalises forward step G = 7 - S: registers 2 G, 2 G + 1 of both lane-halves) run a statically unrolled sequential
+// part: a step's four targets, their rows in the staged blocks and their mask bits are compile-time constants (the generic part walks
+// a position bitmask with readfirstlane and writes its targets through 16-way selects), and the dot products skip the register quads
+// that only hold units of LATER steps -- their weights are exact zeros under the masks, so skipping them leaves every sum as it is:
+// the same accumulators in the same order, BIT-IDENTICAL to the generic part on finite data.  FAST instantiation: launched over runs of
+// such tiles by nf_maf_solve_t_tri (host copy of the table), the other tiles by the generic instantiation; between launches the state
+// is in memory as for the inverse kernel (feature scratch = the carry, activation scratch, pair stash).
+template <int NB, int S_>
+__device__ __forceinline__ void tf_step(f32x16 (&p)[1 + 2 * NB], const f32x16 &pF, f32x16 &xa, f32x16 &xb, const float *W0d, const float *Wd,
+                                        const float *WFd, const unsigned int (&bw)[NB], int hh, float zx, float zu, float zg, float gl,
+                                        float &vv, float &ga) {
+    constexpr int NL = 1 + 2 * NB, G = 7 - S_, Q0 = G >> 1;       // the half's registers >= 2 G: quads Q0 .. 3
+    auto xsum = [](float a) { return a + __shfl_xor(a, 32, 64); };
+    // the two accumulators of the generic dot product (a0: quads 0, 2; a1: quads 1, 3) over the quads >= Q0
+    auto dot = [&](const float *WBASE, int u, const f32x16 &src) {
+        const f32x4 *w_ = reinterpret_cast<const f32x4 *>(WBASE) + u * (HT / 4) + 4 * hh;
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < Q0) continue;
+            const f32x4 w = w_[q];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (q & 1) a1 = fmaf(w[i], src[4 * q + i], a1);
+                else a0 = fmaf(w[i], src[4 * q + i], a0);
+            }
+        }
+        return a0 + a1;
+    };
+    // virtual layer 0: the block part + the window pairs 0 .. S (the later pairs are zeros)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int ru = 2 * G + (i & 1), half = i >> 1, u = (ru & 3) + 8 * (ru >> 2) + 4 * half;
+        const f32x4 *w_ = reinterpret_cast<const f32x4 *>(W0d) + u * (2 * HS / 4);
+        float a = p[0][ru];
+#pragma unroll
+        for (int f = 0; f <= S_; f += 2) {
+            const f32x4 w = w_[f / 2];
+            a = fmaf(w[0], xa[f], a);
+            a = fmaf(w[1], xb[f], a);
+            a = fmaf(w[2], xa[f + 1], a);
+            a = fmaf(w[3], xb[f + 1], a);
+        }
+        p[0][ru] = hh == half ? a : p[0][ru];
+    }
+#pragma unroll
+    for (int k = 1; k < NL; ++k) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ru = 2 * G + (i & 1), half = i >> 1, u = (ru & 3) + 8 * (ru >> 2) + 4 * half;
+            const bool own = hh == half;
+            const float d = dot(Wd + (k - 1) * HT * HT, u, p[k - 1]);
+            const float tot = xsum((own ? p[k][ru] : 0.0f) + d);
+            const int lf = 2 * NB - k;
+            const bool on = (bw[lf >> 1] >> ((lf & 1) * 16 + ru)) & 1u;
+            const float val = on ? tot : 0.0f;
+            p[k][ru] = own ? ((k & 1) ? val : p[k >= 2 ? k - 2 : 0][ru] + val) : p[k][ru];
+        }
+    }
+    {
+        constexpr int u = S_, ru = (u & 3) + 4 * (u >> 3);
+        const bool own = hh == ((u >> 2) & 1);
+        const float d = dot(WFd, u, p[NL - 1]);
+        const float gxm = xsum((own ? pF[ru] : 0.0f) + d);
+        t_finish(gxm, zx, zu, zg, gl, vv, ga);
+    }
+    xa[S_ + 1] = ga;
+    xb[S_ + 1] = vv;
+}
+
+template <int NB, bool FAST = false>
 __global__ void __launch_bounds__(64 * HNW, (NB <= 2 && HNW <= 4) ? 8 / HNW : 1)
 maf_solve_t_kernel(const float *__restrict__ x, const float *__restrict__ prm, const float *__restrict__ gx,
                    const float *__restrict__ gld, const unsigned int *__restrict__ bits, float *__restrict__ v,
-                   const float *__restrict__ blob, const int *__restrict__ table, float *S, float *Xs, float *Ps, int64_t B) {
+                   const float *__restrict__ blob, const int *__restrict__ table, float *S, float *Xs, float *Ps, int64_t B,
+                   int t_beg, int t_end) {
     constexpr int NL = 1 + 2 * NB, H_SEQ = t_seq(NL), LB = 4;
     __shared__ __attribute__((aligned(16))) float seqw[H_SEQ];
     extern __shared__ __attribute__((aligned(16))) float dyn[];
@@ -759,16 +833,21 @@ maf_solve_t_kernel(const float *__restrict__ x, const float *__restrict__ prm, c
     const unsigned int *bwp = bits + ((size_t)wts * T * 64 + lane) * NB;
     auto xpos = [&](int q) { return ((size_t)((q >> 3) * 2 + ((q >> 2) & 1)) * 32 + n) * 4 + (q & 3); };
     float ca, cb;                                   // the carry: (g_us, g_sh) of the last feature produced
-    {
+    if (t_beg == 0) {
         float vv;
         t_finish(0.0f, xr[D - 1], pr[2 * (D - 1)], gxr[D - 1], gl, vv, ca);
         cb = vv;
         if (active && hh == 0) { Xw[xpos(0)] = ca; Xw[xpos(1)] = cb; }
         if (valid && hh == 0) v[sample * D + D - 1] = vv;
+    } else {                                        // a later launch of the layer: the previous launch's last feature, from the scratch
+        const int fq = table[H_HDR + H_ENT * t_beg] - 1;
+        ca = Xw[xpos(2 * fq)];
+        cb = Xw[xpos(2 * fq + 1)];
     }
     auto xsum = [](float a) { return a + __shfl_xor(a, 32, 64); };
+    const int t_stop = min(t_end, T);
 
-    for (int t = 0; t < T; ++t) {
+    for (int t = t_beg; t < t_stop; ++t) {
         const int *te = table + H_HDR + H_ENT * t;
         const int dlo = te[0], ns = te[1], K0 = te[2], tf = te[20];
         const int Kh = HT * t;
@@ -797,7 +876,7 @@ maf_solve_t_kernel(const float *__restrict__ x, const float *__restrict__ prm, c
         // step s produces real feature D - 1 - (dlo + s): its x, unconstrained scale and cotangent
         f32x16 zx, zu, zg;
 #pragma unroll
-        for (int j = 0; j < HS; ++j) {
+        for (int j = 0; j < (FAST ? 8 : HS); ++j) {         // (FAST: eight steps -- the upper halves of the vectors are never touched)
             const int f = D - 1 - (dlo + j);
             zx[j] = (j < ns) ? xr[f] : 0.0f;
             zu[j] = (j < ns) ? pr[2 * f] : 0.0f;
@@ -841,6 +920,21 @@ maf_solve_t_kernel(const float *__restrict__ x, const float *__restrict__ prm, c
                     a1 = fmaf(wb[i], SRC[4 * q + 4 + i], a1);                                    \
                 }                                                                                \
             }
+        if constexpr (FAST) {
+            h_static_for<0, 8>([&](auto S_) {
+                constexpr int SS = decltype(S_)::value;
+                float vv, ga;
+                tf_step<NB, SS>(p, pF, xa, xb, W0d, Wd, WFd, bw, hh, zx[SS], zu[SS], zg[SS], gl, vv, ga);
+                ca = ga;
+                cb = vv;
+                const int fq = dlo + SS;
+                if (hh == 0) {
+                    Xw[xpos(2 * fq)] = ga;
+                    Xw[xpos(2 * fq + 1)] = vv;
+                    if (valid) v[sample * D + (D - 1 - fq)] = vv;
+                }
+            });
+        } else
         for (int s = 0; s < ns; ++s) {
             const unsigned m = (unsigned)te[4 + s];
             // virtual layer 0: G_top = Wf^T g_p -- the block part + the window pairs; raw (no mask)
@@ -1155,9 +1249,28 @@ extern "C" int64_t nf_maf_solve_t_scratch_floats(int64_t B, int D, int hidden_pa
     return nwt * 32 * (NL * (int64_t)hidden_padded + Dq + NL * nf::HT);
 }
 
+template <int NB, bool FAST>
+static int maf_t_run(const void *x, const void *prm, const void *gx, const void *gld, const void *bits, void *v, const void *blob,
+                     const int32_t *table, float *S, float *Xs, float *Ps, int64_t nwt, int64_t B, int t_beg, int t_end, hipStream_t st) {
+    using namespace nf;
+    constexpr int NL = 1 + 2 * NB;
+    const int grid = (int)((nwt + HNW - 1) / HNW);
+    const size_t lds_ring = (size_t)HNW * 12 * 256 * sizeof(float);
+    static LdsOptIn opted;
+    if (opt_in_lds(reinterpret_cast<const void *>(&maf_solve_t_kernel<NB, FAST>), lds_ring + sizeof(float) * t_seq(NL), opted) != NF_OK)
+        return NF_ENOTSUP;
+    hipLaunchKernelGGL((maf_solve_t_kernel<NB, FAST>), dim3(grid), dim3(64 * HNW), lds_ring, st, (const float *)x, (const float *)prm,
+                       (const float *)gx, (const float *)gld, (const unsigned int *)bits, (float *)v, (const float *)blob,
+                       (const int *)table, S, Xs, Ps, B, t_beg, t_end);
+    NF_CHECK_LAUNCH();
+    return NF_OK;
+}
+
+// table_host: the host copy of `table` (the launcher splits the tiles into runs of regular-8 tiles and others) or NULL (one generic launch)
 template <int NB>
 static int maf_t_launch(const void *x, const void *prm, const void *gx, const void *gld, const void *bits, void *v, const void *blob,
-                        const int32_t *table, void *scratch, int64_t B, int D, int hidden_padded, hipStream_t st) {
+                        const int32_t *table, const int32_t *table_host, void *scratch, int64_t B, int D, int hidden_padded,
+                        hipStream_t st) {
     using namespace nf;
     constexpr int NL = 1 + 2 * NB;
     const int64_t nwt = (B + 31) / 32;
@@ -1166,15 +1279,17 @@ static int maf_t_launch(const void *x, const void *prm, const void *gx, const vo
     float *Xs = S + nwt * 32 * (int64_t)NL * hidden_padded;
     if (hipMemsetAsync(Xs, 0, (size_t)nwt * 32 * Dq * sizeof(float), st) != hipSuccess) return NF_EIO;
     float *Ps = Xs + nwt * 32 * Dq;
-    const int grid = (int)((nwt + HNW - 1) / HNW);
-    const size_t lds_ring = (size_t)HNW * 12 * 256 * sizeof(float);
-    static LdsOptIn opted;
-    if (opt_in_lds(reinterpret_cast<const void *>(&maf_solve_t_kernel<NB>), lds_ring + sizeof(float) * t_seq(NL), opted) != NF_OK)
-        return NF_ENOTSUP;
-    hipLaunchKernelGGL((maf_solve_t_kernel<NB>), dim3(grid), dim3(64 * HNW), lds_ring, st, (const float *)x, (const float *)prm,
-                       (const float *)gx, (const float *)gld, (const unsigned int *)bits, (float *)v, (const float *)blob,
-                       (const int *)table, S, Xs, Ps, B);
-    NF_CHECK_LAUNCH();
+    if (!table_host) return maf_t_run<NB, false>(x, prm, gx, gld, bits, v, blob, table, S, Xs, Ps, nwt, B, 0, 1 << 30, st);
+    const int T = table_host[4];
+    for (int t0 = 0; t0 < T;) {
+        const bool fast = table_host[H_HDR + H_ENT * t0 + 21] != 0;
+        int t1 = t0 + 1;
+        while (t1 < T && (table_host[H_HDR + H_ENT * t1 + 21] != 0) == fast) ++t1;
+        const int rc = fast ? maf_t_run<NB, true>(x, prm, gx, gld, bits, v, blob, table, S, Xs, Ps, nwt, B, t0, t1, st)
+                            : maf_t_run<NB, false>(x, prm, gx, gld, bits, v, blob, table, S, Xs, Ps, nwt, B, t0, t1, st);
+        if (rc != NF_OK) return rc;
+        t0 = t1;
+    }
     return NF_OK;
 }
 
@@ -1189,7 +1304,28 @@ extern "C" int nf_maf_solve_t(const void *x, const void *prm, const void *gx, co
     if (B == 0) return NF_OK;
     if (!x || !prm || !gx || !bits || !v || !blob || !table || !scratch) return NF_EFAULT;
     hipStream_t st = (hipStream_t)stream;
-    if (num_blocks == 1) return maf_t_launch<1>(x, prm, gx, gld, bits, v, blob, table, scratch, B, D, hidden_padded, st);
-    if (num_blocks == 2) return maf_t_launch<2>(x, prm, gx, gld, bits, v, blob, table, scratch, B, D, hidden_padded, st);
-    return maf_t_launch<3>(x, prm, gx, gld, bits, v, blob, table, scratch, B, D, hidden_padded, st);
+    if (num_blocks == 1) return maf_t_launch<1>(x, prm, gx, gld, bits, v, blob, table, nullptr, scratch, B, D, hidden_padded, st);
+    if (num_blocks == 2) return maf_t_launch<2>(x, prm, gx, gld, bits, v, blob, table, nullptr, scratch, B, D, hidden_padded, st);
+    return maf_t_launch<3>(x, prm, gx, gld, bits, v, blob, table, nullptr, scratch, B, D, hidden_padded, st);
+}
+
+// nf_maf_solve_t on a transposed pack built over the FORMAT-1 forward positions (maf_pack.pack_made_transposed(tri=True)): the tiles
+// its table marks regular-8 (entry [21]) run the statically unrolled sequential part (tf_step), launched per maximal run of tiles of
+// one kind from the HOST copy of the table; -EINVAL when table_host does not describe this call.  Same results, bit for bit, as
+// nf_maf_solve_t on the same pack (finite data).
+extern "C" int nf_maf_solve_t_tri(const void *x, const void *prm, const void *gx, const void *gld, const void *bits, void *v,
+                                  const void *blob, const int32_t *table, const int32_t *table_host, void *scratch, int64_t B, int D,
+                                  int hidden_padded, int num_blocks, nf_stream_t stream) {
+    if (B < 0 || D < 2 || hidden_padded < 32 || hidden_padded % 32) return NF_EINVAL;
+    if (num_blocks < 1 || num_blocks > 3) return NF_ENOTSUP;
+    if (!table_host) return NF_EFAULT;
+    if (table_host[0] != D || table_host[3] != hidden_padded || table_host[6] != num_blocks || table_host[4] < 1 ||
+        table_host[4] * nf::HT != hidden_padded)
+        return NF_EINVAL;
+    if (B == 0) return NF_OK;
+    if (!x || !prm || !gx || !bits || !v || !blob || !table || !scratch) return NF_EFAULT;
+    hipStream_t st = (hipStream_t)stream;
+    if (num_blocks == 1) return maf_t_launch<1>(x, prm, gx, gld, bits, v, blob, table, table_host, scratch, B, D, hidden_padded, st);
+    if (num_blocks == 2) return maf_t_launch<2>(x, prm, gx, gld, bits, v, blob, table, table_host, scratch, B, D, hidden_padded, st);
+    return maf_t_launch<3>(x, prm, gx, gld, bits, v, blob, table, table_host, scratch, B, D, hidden_padded, st);
 }

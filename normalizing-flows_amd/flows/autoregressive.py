@@ -179,13 +179,14 @@ class MaskedAffineAutoregressive(Autoregressive):
                         pw = dict(pw, wtable=dev(pw["wtable"]), stable=dev(pw["stable"]))
                     val = (dev(s0[0]), dev(s0[1]), int(s0[1][3]), int(s0[1][6]), int(s0[1][4]), dev(s2[0]), dev(s2[1]),
                            s0[1] if tri else None, None if gc is None else dev(gc), None if fc is None else dev(fc),
-                           dev(maf_pack.final_layer_columns(net)), pw)
+                           dev(maf_pack.final_layer_columns(net)), pw, s2[1] if tri else None)
                 st = self.__dict__["_onepass_struct"] = ((str(device), tri) + skey, val)
             if st[1] is not None:
-                src0, table0, hp, nb, tiles, src2, table2, th, gcols, fcols, srcf, pw = st[1]
+                src0, table0, hp, nb, tiles, src2, table2, th, gcols, fcols, srcf, pw, tth = st[1]
                 inv = {"blob": ops.pack_gather(plist, src0), "table": table0, "hp": hp, "nb": nb, "tiles": tiles,
                        "tblob": ops.pack_gather(plist, src2), "ttable": table2, "table_host": th, "gcols": gcols, "fcols": fcols,
-                       "wf_t": ops.pack_gather(plist, srcf.view(-1)).view(srcf.shape) if fcols is not None else None, "pw": pw}
+                       "wf_t": ops.pack_gather(plist, srcf.view(-1)).view(srcf.shape) if fcols is not None else None, "pw": pw,
+                       "ttable_host": tth}
                 return inv, packs[0], packs[1]
         inv = self._inverse_struct(device)
         if inv is None:

@@ -499,7 +499,7 @@ def pack_made_transposed(made, blocks=(1, 2, 3), tri=False):
     tile are read back as they are.  Record per tile (processing order): A0' [K0'/8][2][32][4] (K0' = 2 x the virtual features
     before the tile, padded to 32) | A1'..A_{NL-1}', AF' [4t'][2][32][4] | W0d' [32][32] (window: 16 steps x 2 inputs) | Wd'[NL-1][32][32]
     | WFd' [32][32] (row j = step j).  No biases.  table: [D, 2D padded to 32, H, Hp, T, 1, NB, 2], per tile
-    [dlo', nsteps, K0', rec, mask[16] (virtual step order), forward tile index, 0, 0, 0].
+    [dlo', nsteps, K0', rec, mask[16] (virtual step order), forward tile index, regular-8 flag (round 6, `tri` only), 0, 0].
     `tri`: the positions of the FORMAT-1 forward pack (regular tiles / tiles with extras permuted, flows/maf_pack tile_row) -- for the
     masks nf_maf_inverse_h_tri_bits leaves; the solve kernel's sequential part is driven by per-step position masks, so any position
     assignment works."""
@@ -592,6 +592,8 @@ def pack_made_transposed(made, blocks=(1, 2, 3), tri=False):
         for sq in range(ns):
             table[e + 4 + sq] = fmask[ns - 1 - sq]
         table[e + 20] = t
+        # round 6: REGULAR-8 (format-1 positions, exactly 8 degrees of exactly 4 units): the solve's statically unrolled sequential part
+        table[e + 21] = 1 if (tri and ns == FAST_STEPS and all(c == 4 for c in steps)) else 0
         chunks.append(rec)
         off += rec.size
     return np.concatenate(chunks).astype(np.float32), table

@@ -1424,7 +1424,7 @@ def maf_inverse_bits(z, blob, table, hidden_padded, num_blocks, tiles, table_hos
     return (y, logdet, bits, scratch) if return_scratch else (y, logdet, bits)
 
 
-def maf_solve_t(x, params, gx, gld, bits, blob, table, hidden_padded, num_blocks, return_scratch=False):
+def maf_solve_t(x, params, gx, gld, bits, blob, table, hidden_padded, num_blocks, return_scratch=False, table_host=None):
     """nf_maf_solve_t: v with  v s + J^T g_p(v, g_ld) = g_x  in one pass (the implicit backward of the MAF inverse);
     blob / table from flows/maf_pack.pack_made_transposed.  return_scratch: (v, scratch) -- the activation scratch for
     maf_scratch_rows."""
@@ -1437,6 +1437,15 @@ def maf_solve_t(x, params, gx, gld, bits, blob, table, hidden_padded, num_blocks
     lib = L.lib()
     n = lib.nf_maf_solve_t_scratch_floats(i64(B), i32(D), i32(hidden_padded), i32(num_blocks))
     scratch = torch.empty(max(int(n), 1), dtype=torch.float32, device=x.device)
+    from . import config
+    if table_host is not None and config.maf_solve_fast:      # round 6: the regular-8 tiles on the statically unrolled sequential part
+        import numpy as np
+        th = np.ascontiguousarray(table_host, dtype=np.int32)
+        rc = lib.nf_maf_solve_t_tri(ptr(x), ptr(params), ptr(gx), ptr(None if gld is None else gld.contiguous()), ptr(bits), ptr(v),
+                                    ptr(blob), ptr(table), C.c_void_p(th.ctypes.data), ptr(scratch), i64(B), i32(D), i32(hidden_padded),
+                                    i32(num_blocks), L.stream())
+        L.check(rc, "nf_maf_solve_t_tri")
+        return (v, scratch) if return_scratch else v
     rc = lib.nf_maf_solve_t(ptr(x), ptr(params), ptr(gx), ptr(None if gld is None else gld.contiguous()), ptr(bits), ptr(v), ptr(blob),
                             ptr(table), ptr(scratch), i64(B), i32(D), i32(hidden_padded), i32(num_blocks), L.stream())
     L.check(rc, "nf_maf_solve_t")

@@ -2374,6 +2374,41 @@ def test_maf_weight_gradients_read_the_scratches_in_place(nfa, D, H, NB, B):
             assert float(a[mod.mask.to(DEV) == 0].abs().max() if (mod.mask == 0).any() else 0.0) == 0.0, n_
 
 
+@pytest.mark.parametrize("D,H,NB,B", [(128, 512, 2, 2048), (64, 252, 2, 640), (72, 284, 1, 1000), (24, 92, 3, 500), (40, 100, 2, 300)])
+def test_maf_solve_regular8_tiles_are_bit_identical_to_the_generic_part(nfa, D, H, NB, B):
+    """nf_maf_solve_t_tri (round 6, late): the tiles a format-1 transposed pack marks regular-8 run the statically unrolled sequential
+    part (tf_step: compile-time targets / rows / mask bits, dot products over the register quads that can hold a final unit) -- the
+    generic part's accumulators in the generic part's order with exact-zero terms left out: v and every value of the activation scratch
+    (= MADE's hidden gradients for the weight-gradient launch) bit for bit; (40, 100) has no such tile and takes the generic launch."""
+    from normflows_amd import ops
+    torch.manual_seed(D + B)
+    layer = nfa.flows.MaskedAffineAutoregressive(D, H, num_blocks=NB)
+    gen = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.add_(0.03 * torch.randn(p.shape, generator=gen))
+    layer = layer.to(DEV)
+    inv = layer._implicit_packs(DEV)[0]
+    th = inv["ttable_host"]
+    nfast = int(sum(int(th[8 + 24 * t + 21]) for t in range(int(th[4]))))
+    assert (nfast > 0) == ((D, H) != (40, 100))
+    z = torch.randn(B, D, device=DEV)
+    cx, cl = torch.randn(B, D, device=DEV), torch.randn(B, device=DEV)
+    x, _, bits, _, prm = ops.maf_inverse_bits(z, inv["blob"], inv["table"], inv["hp"], inv["nb"], inv["tiles"],
+                                              table_host=inv.get("table_host"), return_scratch=True, want_params=True)
+    v0, s0 = ops.maf_solve_t(x, prm, cx, cl, bits, inv["tblob"], inv["ttable"], inv["hp"], inv["nb"], return_scratch=True)
+    v1, s1 = ops.maf_solve_t(x, prm, cx, cl, bits, inv["tblob"], inv["ttable"], inv["hp"], inv["nb"], return_scratch=True, table_host=th)
+    assert torch.isfinite(v1).all() and torch.equal(v0, v1)
+    nS = B // 32 * 32 * (2 * NB + 1) * inv["hp"]
+    assert torch.equal(s0[:nS], s1[:nS])
+    try:       # the switch
+        nfa.config.set_maf_solve_fast(False)
+        v2 = ops.maf_solve_t(x, prm, cx, cl, bits, inv["tblob"], inv["ttable"], inv["hp"], inv["nb"], table_host=th)
+    finally:
+        nfa.config.set_maf_solve_fast(True)
+    assert torch.equal(v0, v2)
+
+
 @pytest.mark.parametrize("which", ["x_only", "ld_only"])
 def test_maf_implicit_backward_with_one_cotangent_absent(nfa, which):
     """The implicit backward when the loss sees only the outputs or only the log-det (the other cotangent arrives as None), and with

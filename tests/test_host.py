@@ -117,6 +117,11 @@ def test_c_abi_argument_validation_newer_entry_points(nfa):
     assert wg(100, 4, 5, 512) == -95             # rows: a multiple of 64 (the scratch holds no zero rows beyond the batch)
     assert wg(64, 4, 5, 160) == -95              # positions: a multiple of 128
     assert wg(64, 4, 5, 512, null) == -14 and wg(0, 4, 5, 512, null) == 0
+    th[7] = 2        # (a transposed pack's table)
+    so = lambda a, hp=512, D_=128, th_=hp_: lib.nf_maf_solve_t_tri(a, one, one, null, one, one, one, one, th_, one, i64(8), i32(D_), i32(hp), i32(2), null)
+    assert so(one, th_=null) == -14 and so(one, 500) == -22 and so(one, D_=64) == -22 and so(null) == -14
+    assert lib.nf_maf_solve_t_tri(null, null, null, null, null, null, null, null, hp_, null, i64(0), i32(128), i32(512), i32(2), null) == 0
+    th[7] = 0
     tr = lambda bits, prm, hp=512, th_=null: lib.nf_maf_inverse_h_train(one, one, one, one, one, th_, one, bits, prm, i64(8), i32(128), i32(hp),
                                                                        i32(2), i32(0), null)
     assert tr(null, one) == -14 and tr(one, null) == -14 and tr(one, one, 500) == -22
@@ -861,7 +866,7 @@ def test_tile_engine_and_maf_kernels_use_no_scratch(nfa):
     objdir = os.path.join(ROOT, "normalizing-flows_amd", "lib", "obj")
     want = {("rqs_fused_nw4.o", "rqs_fused_kernel_nw4"): 38,      # the 128-row-workgroup build: 36 inference + 2 whole-layer training forwards (round 6, late)
             ("nsf_wide.o", "nsf_wide_kernel"): 36, ("made_fwd.o", "made_fwd_kernel"): 8,
-            ("maf_inverse_h.o", "maf_inverse_h_kernel"): 12, ("maf_inverse_h.o", "maf_solve_t_kernel"): 3}
+            ("maf_inverse_h.o", "maf_inverse_h_kernel"): 12, ("maf_inverse_h.o", "maf_solve_t_kernel"): 6}
     for (obj, tag), n in want.items():
         seen = 0
         for name, d in kr.resources(os.path.join(objdir, obj)).items():
@@ -872,6 +877,11 @@ def test_tile_engine_and_maf_kernels_use_no_scratch(nfa):
                     # the two-block kernels sit two registers over the 256 that two waves per SIMD leave: <= 16 bytes per lane; the
                     # inference instantiations -- BASELINE configs[4]'s kernel among them -- stay free of scratch
                     assert d["private_segment_fixed_size"] <= 16, (name, d)
+                    continue
+                if tag == "maf_solve_t_kernel" and "ELb1EEEv" in name:
+                    # the regular-8 instantiations of the transposed solve (round 6, late): the two-block one keeps 7 values in 32 bytes of
+                    # scratch (scheduling barriers between the targets made it 81-108) and is still 0.34 ms per layer faster
+                    assert d["private_segment_fixed_size"] <= 32, (name, d)
                     continue
                 assert d["vgpr_spill_count"] == 0 and d["private_segment_fixed_size"] == 0, (name, d)
         assert seen == n, (tag, seen)
