@@ -36,7 +36,7 @@ python tools/summarize_profiles.py r06_bench_chain --stats $(find $O/bench_stats
   --trace $(find $O/bench_SQ_VALU_MFMA_BUSY_CYCLES -name "*kernel_trace.csv" | head -1) --kernel "rqs_fused_kernel<0, true" > $O/summ_bench.log 2>&1
 python tools/summarize_profiles.py r06_config5_maf_inverse --stats $(find $O/maf_stats -name "*kernel_stats.csv" | head -1) \
   --pmc $(find $O/maf_FETCH_SIZE $O/maf_WRITE_SIZE $O/maf_SQ_VALU_MFMA_BUSY_CYCLES -name "*counter_collection.csv") \
-  --trace $(find $O/maf_SQ_VALU_MFMA_BUSY_CYCLES -name "*kernel_trace.csv" | head -1) --kernel "maf_inverse_h_kernel<2, true>" > $O/summ_maf.log 2>&1
+  --trace $(find $O/maf_SQ_VALU_MFMA_BUSY_CYCLES -name "*kernel_trace.csv" | head -1) --kernel "maf_inverse_h_kernel<2, true" > $O/summ_maf.log 2>&1
 python tools/pmc_summary.py $O train "python tools/train_bench.py --steps 3 --flat" > profiles/r06_train_step_pmc.json 2> $O/summ_train.log
 python tools/pmc_summary.py $O glow "python tools/config_bench.py 4 (rocprofv3 --kernel-include-regex glow_convnet)" > profiles/r06_config4_glow_pmc.json 2> $O/summ_glow.log
 cp $(find $O/glow_stats -name "*kernel_stats.csv" | head -1) profiles/r06_config4_glow_kernel_stats.csv 2>/dev/null
