@@ -676,7 +676,7 @@ int nf_made_wgrad(const void *gp_pad, const void *x_pad, const void *G, const vo
  * the network flattened], src = the packer's stream with parameter positions in place of values (made_pack.train_structure) -- the
  * reference re-reads its nn.Parameters in every forward; a host-side repack per optimizer step would cost more than the step. */
 int nf_pack_gather(const void *flat, const int32_t *src, void *out, int64_t n, nf_stream_t stream);
-/* nf_pack_gather from the parameter tensors in place (round 6): params = n_params <= 8 host pointers to device float32 tensors of
+/* nf_pack_gather from the parameter tensors in place (round 6): params = n_params <= 16 host pointers to device float32 tensors of
  * numels[j] elements; the virtual flat vector is [0, params[0] ..., params[1] ..., ...] as above -- no concatenation per call. */
 int nf_pack_gather_multi(const void *const *params, const int64_t *numels, int n_params, const int32_t *src, void *out, int64_t n,
                          nf_stream_t stream);

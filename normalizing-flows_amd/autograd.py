@@ -1062,7 +1062,13 @@ class MafInverseFn(torch.autograd.Function):
             ctx.pw = inv.get("pw") if _config.maf_wgrad_in_place else None
             # the pass's own activations (its scratch) are the inputs of MADE's linears at x: kept for the weight-gradient launch, so
             # the backward does not run MADE forward again (671 MB per config-5 layer at B = 65 536 instead of a transient of that size)
-            ctx.fpack = (scratch, inv["fcols"], inv["wf_t"]) if keep else None
+            # (the masked final weight in the training kernels' column order: only where the backward rebuilds MADE's output itself)
+            wf_t = None
+            if keep and not want_p:
+                wf_t = inv.get("wf_t")
+                if wf_t is None and inv.get("wf_src") is not None:
+                    wf_t = ops.pack_gather(list(params), inv["wf_src"].view(-1)).view(inv["wf_src"].shape)
+            ctx.fpack = (scratch, inv["fcols"], wf_t) if keep else None
         else:
             x, ld = ops.maf_inverse(z, inv[0], inv[1], inv[2], num_blocks=inv[3], table_host=inv[4] if len(inv) > 4 else None)
             ctx.save_for_backward(x, *([params[-1]] if params else []))

@@ -605,12 +605,12 @@ extern "C" int nf_made_wgrad_pos(const void *gp_pad, const void *x_pad, const vo
 }
 
 // out (n) = flat[src (n)]: the packed weight streams of nf_made_forward_train / nf_made_backward from the current parameters.
-// The same gather from up to 8 parameter tensors in place (round 6): position k of the virtual `flat` = [0, p_0 ..., p_1 ..., ...]
+// The same gather from up to 16 parameter tensors in place (round 6; 16 since the last session: a MADE of two or three blocks has 12 / 16): position k of the virtual `flat` = [0, p_0 ..., p_1 ..., ...]
 // is found by its segment (first[j] <= k < first[j + 1]; position 0 is the zero) -- no torch.cat of the parameters per module and step.
 namespace nf {
 struct GatherSegs {
-    const float *p[8];
-    int first[9];            // first[0] = 1; first[j + 1] = first[j] + numel(p_j)
+    const float *p[16];
+    int first[17];           // first[0] = 1; first[j + 1] = first[j] + numel(p_j)
     int np;
 };
 __global__ void __launch_bounds__(256)
@@ -621,7 +621,7 @@ pack_gather_multi_kernel(GatherSegs g, const int *__restrict__ src, float *__res
         if (k > 0) {
             int j = 0;
 #pragma unroll
-            for (int q = 1; q < 8; ++q)
+            for (int q = 1; q < 16; ++q)
                 if (q < g.np && k >= g.first[q]) j = q;
             v = g.p[j][k - g.first[j]];
         }
@@ -632,12 +632,12 @@ pack_gather_multi_kernel(GatherSegs g, const int *__restrict__ src, float *__res
 
 extern "C" int nf_pack_gather_multi(const void *const *params, const int64_t *numels, int n_params, const int32_t *src, void *out,
                                     int64_t n, nf_stream_t stream) {
-    if (n < 0 || n_params < 1 || n_params > 8) return NF_EINVAL;
+    if (n < 0 || n_params < 1 || n_params > 16) return NF_EINVAL;
     if (n == 0) return NF_OK;
     if (!params || !numels || !src || !out) return NF_EFAULT;
     nf::GatherSegs g;
     int64_t first = 1;
-    for (int j = 0; j < 8; ++j) { g.p[j] = nullptr; g.first[j] = 0; }
+    for (int j = 0; j < 16; ++j) { g.p[j] = nullptr; g.first[j] = 0; }
     for (int j = 0; j < n_params; ++j) {
         if (!params[j] || numels[j] < 0 || first + numels[j] >= (1ll << 31)) return params[j] ? NF_EINVAL : NF_EFAULT;
         g.p[j] = (const float *)params[j];

@@ -185,8 +185,7 @@ class MaskedAffineAutoregressive(Autoregressive):
                 src0, table0, hp, nb, tiles, src2, table2, th, gcols, fcols, srcf, pw, tth = st[1]
                 inv = {"blob": ops.pack_gather(plist, src0), "table": table0, "hp": hp, "nb": nb, "tiles": tiles,
                        "tblob": ops.pack_gather(plist, src2), "ttable": table2, "table_host": th, "gcols": gcols, "fcols": fcols,
-                       "wf_t": ops.pack_gather(plist, srcf.view(-1)).view(srcf.shape) if fcols is not None else None, "pw": pw,
-                       "ttable_host": tth}
+                       "wf_src": srcf if fcols is not None else None, "pw": pw, "ttable_host": tth}
                 return inv, packs[0], packs[1]
         inv = self._inverse_struct(device)
         if inv is None:

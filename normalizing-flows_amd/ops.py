@@ -1242,7 +1242,7 @@ def pack_gather(params, src):
     if zero is None:
         zero = _ZERO1[src.device] = torch.zeros(1, dtype=torch.float32, device=src.device)
     out = torch.empty(src.numel(), dtype=torch.float32, device=src.device)
-    if len(params) <= 8 and all(p.dtype == torch.float32 and p.is_contiguous() for p in params):
+    if len(params) <= 16 and all(p.dtype == torch.float32 and p.is_contiguous() for p in params):
         # round 6: straight from the parameter tensors (no torch.cat per module and step)
         pp = (C.c_void_p * len(params))(*[p.data_ptr() for p in params])
         nn_ = (C.c_int64 * len(params))(*[p.numel() for p in params])
