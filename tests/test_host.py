@@ -690,6 +690,104 @@ def test_maf_pack_schedule_matches_d_pass(D, H, NB):
     np.testing.assert_allclose(hl @ wf_t.T + m64.final_layer.bias.detach().numpy(), prm_ref.numpy(), rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize("D,H,NB,tri", [(40, 100, 2, True), (40, 100, 2, False), (24, 120, 1, True), (128, 512, 2, True)])
+def test_position_space_weight_gradient_tables(nfa, D, H, NB, tri):
+    """flows/maf_pack.position_wgrad_tables (round 6, nf_made_wgrad_pos): problems, tiles and scatter maps over the one-pass kernels'
+    scratch POSITIONS.  A numpy emulation of the launch -- per listed 128 x 128 tile the (negated) product of the two operands as the
+    kernel addresses them, then the reduction's masked scatter -- on scratches whose holes hold garbage must reproduce, for arbitrary
+    hidden gradients and activations, every masked weight gradient dW_l = (dY_l^T X_l) * mask and bias gradient of MADE
+    (nets/made.py:73-81 under autograd) in the flat layout of the ordinary backward pack."""
+    from normflows_amd import nets
+    from normflows_amd.flows import made_pack, maf_pack
+    torch.manual_seed(D + H)
+    made = nets.MADE(D, H, num_blocks=NB, output_multiplier=2, use_residual_blocks=True, random_mask=False,
+                     activation=torch.nn.functional.relu)
+    pw = maf_pack.position_wgrad_tables(made, tri=tri)
+    assert pw is not None and pw["positions"] % 128 == 0 and pw["NL"] == 2 * NB + 1
+    bwd = made_pack.made_train_structure(made, 2)["bwd"]
+    assert pw["nflat"] == bwd["nflat"]
+    fslot, vslot, T = maf_pack._unit_positions(made, tri)
+    P, NL, B = pw["positions"], pw["NL"], 48
+    rng = np.random.default_rng(D)
+    Gu = [rng.standard_normal((B, H)) for _ in range(NL)]              # gradient at the output of hidden layer l
+    Xu = [np.abs(rng.standard_normal((B, H))) for _ in range(NL - 1)] + [rng.standard_normal((B, H))]     # the linears' inputs
+    x, gp = rng.standard_normal((B, D)), rng.standard_normal((B, 2 * D))
+    gscr = rng.standard_normal((NL, B, P)) * 1e3                      # garbage in the holes
+    fscr = np.abs(rng.standard_normal((NL, B, P))) * 1e3
+    for l in range(NL):
+        gscr[NL - 1 - l][:, vslot] = -Gu[l]
+        fscr[l][:, fslot] = Xu[l]
+    Mp, Dx = bwd["Mp"], bwd["Dx"]
+    gp_pad, x_pad = np.zeros((B, Mp)), np.zeros((B, Dx))
+    gp_pad[:, :2 * D], x_pad[:, :D] = gp, x
+    wt, sc, mask = pw["wtable"], pw["stable"], bwd["mask"]
+    ntl, npr = int(wt[0]), int(wt[1])
+    assert ntl == pw["ntiles"] and npr == 2 + 2 * NB
+    grads = np.zeros(pw["nflat"])
+    seen_bias = set()
+    for t in range(ntl):
+        pi, m0, n0, want_bias = (int(v) for v in wt[16 + 8 * npr + 8 * t:16 + 8 * npr + 8 * t + 4])
+        pr, ps = wt[16 + 8 * pi:16 + 8 * pi + 8], sc[8 * pi:8 * pi + 8]
+        flags = int(pr[7])
+        dY = gscr[int(pr[1])][:, m0:m0 + 128] if flags & 1 else {0: gp_pad, 1: x_pad}[int(pr[0])][:, m0:m0 + 128]
+        X = fscr[int(pr[4])][:, n0:n0 + 128] if flags & 2 else {0: gp_pad, 1: x_pad}[int(pr[3])][:, n0:n0 + 128]
+        assert (int(pr[0]) == 2) == bool(flags & 1) and (int(pr[3]) == 3) == bool(flags & 2)
+        if int(pr[6]):
+            X = np.maximum(X, 0.0)
+        sgn = -1.0 if flags & 4 else 1.0
+        part, bias = sgn * dY.T @ X, sgn * dY.sum(0)
+        rowmap, colmap = sc[int(ps[3]):int(ps[3]) + 4096], sc[int(ps[4]):int(ps[4]) + 4096]
+        for r in range(128):
+            row = int(rowmap[m0 + r])
+            if row < 0:
+                continue
+            if want_bias:
+                assert (pi, row) not in seen_bias
+                seen_bias.add((pi, row))
+                grads[int(ps[2]) + row] = bias[r]
+            for c in range(128):
+                col = int(colmap[n0 + c])
+                if col >= 0:
+                    dst = int(ps[0]) + row * int(ps[1]) + col
+                    if mask[dst]:
+                        grads[dst] = part[r, c]
+    lins = [made.initial_layer] + [l for b in made.blocks for l in b.linear_layers] + [made.final_layer]
+    dys = [Gu[0]] + [Gu[k] for b in range(NB) for k in (2 * b + 1, 2 * b + 2)] + [gp]
+    xs = [x] + [Xu[k] for b in range(NB) for k in (2 * b, 2 * b + 1)] + [Xu[2 * NB]]
+    for k, (lin, dy, xx, (woff, shape, boff, n)) in enumerate(zip(lins, dys, xs, bwd["offsets"])):
+        m = lin.mask.numpy() != 0
+        want = (dy.T @ xx) * m
+        np.testing.assert_allclose(grads[woff:woff + shape[0] * shape[1]].reshape(shape), want, rtol=1e-10, atol=1e-10, err_msg="dW %d" % k)
+        np.testing.assert_allclose(grads[boff:boff + n], dy.sum(0), rtol=1e-10, atol=1e-10, err_msg="db %d" % k)
+
+
+def test_transposed_pack_marks_regular8_tiles(nfa):
+    """pack_made_transposed(tri=True) marks (table entry [21]) the tiles whose FORWARD tile is a format-1 regular tile of exactly 8
+    degrees x 4 units -- the ones nf_maf_solve_t_tri runs on the statically unrolled sequential part; their step masks are then the
+    compile-time positions tf_step assumes: virtual step s = forward step 7 - s = registers 2 g, 2 g + 1 of both lane-halves."""
+    from normflows_amd import nets
+    from normflows_amd.flows import maf_pack
+    for (D, H), want in (((128, 512), [1] * 15 + [0]), ((40, 100), None), ((64, 252), None)):
+        made = nets.MADE(D, H, num_blocks=2, output_multiplier=2, use_residual_blocks=True, random_mask=False,
+                         activation=torch.nn.functional.relu)
+        _, t0 = maf_pack.pack_made_transposed(made, tri=False)
+        _, t1 = maf_pack.pack_made_transposed(made, tri=True)
+        T = int(t1[4])
+        assert all(int(t0[8 + 24 * t + 21]) == 0 for t in range(T))
+        flags = [int(t1[8 + 24 * t + 21]) for t in range(T)]
+        plan = maf_pack.plan_tiles(D, made.initial_layer.degrees.numpy())[1]
+        assert flags == [1 if (ns == 8 and all(c == 4 for c in st)) else 0 for (_, ns, st) in plan[::-1]]
+        if want is not None:
+            assert flags == want
+        row = lambda r, h: (r & 3) + 8 * (r >> 2) + 4 * h
+        for t in range(T):
+            if flags[t]:
+                for s_ in range(8):
+                    g = 7 - s_
+                    m = sum(1 << row(2 * g + (i & 1), i >> 1) for i in range(4))
+                    assert int(np.uint32(t1[8 + 24 * t + 4 + s_])) == m, (t, s_)
+
+
 @pytest.mark.parametrize("D,H,K,tails", [(64, 256, 8, "linear"), (9, 40, 4, None), (5, 12, 10, "circular"), (3, 2, 1, "linear")])
 def test_arnsf_pack_schedule_matches_d_pass(D, H, K, tails):
     """Rows layout of flows/maf_pack.py (one final-layer block per feature, nf_arnsf_inverse): the emulated schedule
