@@ -2028,8 +2028,17 @@ def test_training_step_captures_into_one_graph(nfa):
     maf_d = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(12, trainable=False),
                                 [nfa.flows.MaskedAffineAutoregressive(12, 40, num_blocks=2) for _ in range(2)]).to(DEV)
     xd = torch.randn(200, 12, device=DEV)
+    # round 6: ... and at a shape / batch that takes the in-place weight gradients (nf_made_wgrad_pos: 128 positions, 256 rows), MADE's
+    # output from the inverse pass (nf_maf_inverse_h_train) and the host-table launchers (nf_maf_solve_t_tri)
+    maf_p = nfa.NormalizingFlow(nfa.distributions.DiagGaussian(40, trainable=False),
+                                [nfa.flows.MaskedAffineAutoregressive(40, 100, num_blocks=2) for _ in range(2)]).to(DEV)
+    xp = torch.randn(256, 40, device=DEV)
+    from normflows_amd import ops as _ops
+    seen = []
+    real_pos = _ops.made_wgrad_pos
+    _ops.made_wgrad_pos = lambda *a, **k: (seen.append(1), real_pos(*a, **k))[1]
     for m, x, lossfn in ((glow, ximg, lambda mm, xx: mm.forward_kld(xx)), (maf, eps, maf_loss),
-                         (maf_d, xd, lambda mm, xx: mm.forward_kld(xx))):
+                         (maf_d, xd, lambda mm, xx: mm.forward_kld(xx)), (maf_p, xp, lambda mm, xx: mm.forward_kld(xx))):
         def step():
             m.zero_grad(set_to_none=True)
             lossfn(m, x).backward()
@@ -2049,6 +2058,8 @@ def test_training_step_captures_into_one_graph(nfa):
         g.replay()
         torch.cuda.synchronize()
         assert all(torch.equal(a, p.grad) for a, p in zip(eager, m.parameters()))
+    _ops.made_wgrad_pos = real_pos
+    assert len(seen) >= 2 * 4           # (maf_p's two layers, in the eager, warm-up and captured steps)
 
 
 def test_glow_parameter_gradient_launches_on_the_side_stream(nfa):
