@@ -505,8 +505,15 @@ def gen_made_train():
               "forward"),
              ("grad_arnsf_d32_h64", lambda: nf.flows.AutoregressiveRationalQuadraticSpline(32, 2, 64, num_bins=8, tail_bound=3,
                                                                                            init_identity=False), 32, 2032, 0.2, 70,
+              "inverse"),
+             # round 6: the DENSITY direction of config 5's layer (affine/autoregressive.py:29-38: D = 128 recorded MADE passes in the
+             # reference) at a batch that takes the in-place weight gradients / the statically unrolled solve (64 rows, 512 positions)
+             ("grad_maf_inv_d128_h512", lambda: nf.flows.MaskedAffineAutoregressive(128, 512, num_blocks=2), 128, 1129, 0.05, 64,
               "inverse"))
+    only = os.environ.get("NF_GOLDEN_ONLY")
     for tag, make, D, seed, sigma, B, direction in cases:
+        if only and tag != only:
+            continue
         out = {}
         for dt, leg in ((torch.float32, "f32"), (torch.float64, "f64")):
             torch.manual_seed(seed)

@@ -1585,6 +1585,62 @@ def test_autoregressive_layers_training_vs_reference_autograd(nfa, monkeypatch, 
     assert np.quantile(got, 0.9) <= 4 * max(np.quantile(own, 0.9), 1e-7), (np.quantile(got, 0.9), np.quantile(own, 0.9))
 
 
+def test_maf_density_direction_in_place_backward_vs_reference_autograd(nfa):
+    """The round-6 density-direction backward of BASELINE configs[4]'s layer against the REFERENCE's autograd through its D = 128
+    recorded MADE passes (tests/golden/grad_maf_inv_d128_h512.npz: MaskedAffineAutoregressive(128, 512).inverse, affine/
+    autoregressive.py:29-38, 64 rows -- a batch that takes nf_maf_inverse_h_train, nf_maf_solve_t_tri on 15 regular-8 tiles and
+    nf_made_wgrad_pos on the 512 scratch positions: spies): outputs, input gradient and a strided sample + sum of every parameter
+    gradient to 1e-3 of scale vs the float32 leg and no further from the float64 leg than 4 x the reference's own float32 leg (q90)."""
+    from normflows_amd import ops
+    g = load_golden("grad_maf_inv_d128_h512")
+    torch.manual_seed(1129)
+    layer = nfa.flows.MaskedAffineAutoregressive(128, 512, num_blocks=2)
+    gen = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=gen, dtype=p.dtype))
+    layer = layer.to(DEV)
+    calls = {}
+    real = {k: getattr(ops, k) for k in ("made_wgrad_pos", "maf_solve_t", "maf_inverse_bits", "maf_scratch_rows", "made_wgrad")}
+    try:
+        for k, f in real.items():
+            def spy(*a, _f=f, _k=k, **kw):
+                calls[_k] = calls.get(_k, 0) + 1
+                if _k == "maf_solve_t":
+                    assert kw.get("table_host") is not None
+                if _k == "maf_inverse_bits":
+                    assert kw.get("want_params")
+                return _f(*a, **kw)
+            setattr(ops, k, spy)
+        x = T(g["x"]).requires_grad_(True)
+        z, ld = layer.inverse(x)
+        ((z * T(g["cz"])).sum() + (ld * T(g["cl"])).sum()).backward()
+    finally:
+        for k, f in real.items():
+            setattr(ops, k, f)
+    assert calls == {"maf_inverse_bits": 1, "maf_solve_t": 1, "made_wgrad_pos": 1}, calls
+    stride = int(g["stride"])
+
+    def err(a, ref):
+        return np.abs(a.astype(np.float64) - ref) / max(1.0, float(np.abs(ref).max()))
+    ours = {"z": N(z), "ld": N(ld), "gx": N(x.grad)}
+    own, got = [], []
+    for k, a in ours.items():
+        assert err(a, g[k + "_f32"]).max() < 1e-3, (k, err(a, g[k + "_f32"]).max())
+        own.append(err(g[k + "_f32"], g[k + "_f64"]).max())
+        got.append(err(a, g[k + "_f64"]).max())
+    for k, p in layer.named_parameters():
+        key = k.replace(".", "__")
+        flat = N(p.grad).reshape(-1)
+        ref32, ref64 = g["g_f32__" + key], g["g_f64__" + key]
+        assert err(flat[::stride], ref32).max() < 1e-3, (k, err(flat[::stride], ref32).max())
+        chk = g["chk_f64__" + key]
+        assert abs(float(flat.astype(np.float64).sum()) - chk[0]) < 1e-4 * max(1.0, chk[1]), k
+        own.append(err(ref32, ref64).max())
+        got.append(err(flat[::stride], ref64).max())
+    assert np.quantile(got, 0.9) <= 4 * max(np.quantile(own, 0.9), 1e-7), (np.quantile(got, 0.9), np.quantile(own, 0.9))
+
+
 def test_made_training_full_batch_vs_library_path(nfa):
     """BASELINE configs[4]'s layer at B = 65 536 (a multiple of the 64-row tiles and the weight-gradient chunks): hand-written path vs
     torch autograd through library GEMMs (float32 both: two different summation orders over 65 536 rows), outputs to 1e-4, every
