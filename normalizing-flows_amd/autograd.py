@@ -1105,9 +1105,11 @@ class MafInverseFn(torch.autograd.Function):
                 # scatter maps over scratch positions) -- only the last hidden tensor is still laid out in rows, for MADE's output
                 p = getattr(ctx, "prm", None)
                 ctx.prm = None
-                if p is None:
+                if p is None and wf_t is not None:
                     h_last = ops.maf_scratch_layer(fscratch, fcols, B, nb, hp, 2 * nb)
                     p = torch.nn.functional.linear(h_last[:B], wf_t, bias_f)
+                elif p is None:       # (a switch of config.py flipped between forward and backward: one MADE pass at the solution)
+                    p = ops.made_forward_train(x, fwd[0], fwd[1], fwd[2], 2 * D, bwd["NB"])[0]
                 v, scratch = ops.maf_solve_t(x, p, gx, gld, ctx.saved_tensors[1], tb, tt, hp, nb, return_scratch=True, table_host=getattr(ctx, "tth", None))
                 MafInverseFn.last_sweeps = 1
                 return MafInverseFn._finish(ctx, x, p, v, gld, None, None, None, pos=(scratch, fscratch, pw))
