@@ -680,6 +680,11 @@ int nf_pack_gather(const void *flat, const int32_t *src, void *out, int64_t n, n
  * numels[j] elements; the virtual flat vector is [0, params[0] ..., params[1] ..., ...] as above -- no concatenation per call. */
 int nf_pack_gather_multi(const void *const *params, const int64_t *numels, int n_params, const int32_t *src, void *out, int64_t n,
                          nf_stream_t stream);
+/* ... for n_modules networks of ONE structure per launch (round 6: the conditioners of a Glow level's K blocks, nets/cnn.py:5-63 inside
+ * flows/affine/glow.py:72-84): params = HOST array of n_modules x n_params (<= 8) device pointers, module-major; numels = the n_params
+ * element counts shared by the modules; outs = HOST array of n_modules device pointers to n floats each. */
+int nf_pack_gather_batch(const void *const *params, const int64_t *numels, int n_params, const int32_t *src, void *const *outs, int64_t n,
+                         int n_modules, nf_stream_t stream);
 
 /* GlowBlock's conv conditioner under autograd.  Replaces what torch autograd + the convolution library do for
  * normflows/nets/cnn.py:5-63 (ConvNet2d: Conv2d 3x3 -> LeakyReLU(0) -> Conv2d 1x1 -> LeakyReLU(0) -> Conv2d 3x3, padding 1) inside

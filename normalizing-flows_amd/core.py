@@ -631,14 +631,21 @@ class MultiscaleFlow(nn.Module):
     def _level_pass(self, i, z, z_other, inverse, ld, acc):
         """_level_pass_impl; in the density direction under autograd the level's Invertible1x1Convs assemble their matrices in one
         launch first (flows/mixing.prefetch_weights, round 6)."""
-        convs = []
+        convs, cnets = [], []
         if inverse and torch.is_grad_enabled() and z.is_cuda:
+            from . import nets as _nets
             from .flows.glow import GlowBlock
             from .flows.mixing import Invertible1x1Conv, clear_prefetched, prefetch_weights
-            convs = [f.flows[1] for f in self.flows[i]
-                     if isinstance(f, GlowBlock) and len(f.flows) == 3 and isinstance(f.flows[1], Invertible1x1Conv)]
+            blocks = [f for f in self.flows[i] if isinstance(f, GlowBlock) and len(f.flows) == 3]
+            convs = [f.flows[1] for f in blocks if isinstance(f.flows[1], Invertible1x1Conv)]
             if len(convs) > 1:
                 prefetch_weights(convs)
+            # ... and the conditioners' packed weight streams of this step (nets.prefetch_train_packs: one gather launch per structure)
+            cnets = [getattr(f.flows[0].flows[1], "param_map", None) for f in blocks
+                     if hasattr(f.flows[0], "flows") and len(f.flows[0].flows) == 3]
+            cnets = [c for c in cnets if isinstance(c, _nets.ConvNet2d) and any(p.requires_grad for p in c.parameters())]
+            if len(cnets) > 1:
+                _nets.prefetch_train_packs(cnets, z.device)
         from .flows.affine import lazy_ld
         try:
             with lazy_ld(ld):          # (the level's layers only ADD to ld: their statements go out as one launch, same order)
@@ -646,6 +653,8 @@ class MultiscaleFlow(nn.Module):
         finally:
             if len(convs) > 1:
                 clear_prefetched(convs)
+            if len(cnets) > 1:
+                _nets.clear_prefetched_packs(cnets)
 
     def _level_pass_impl(self, i, z, z_other, inverse, ld, acc):
         """Level i of the multi-scale flow with the log-dets folded into `ld`.

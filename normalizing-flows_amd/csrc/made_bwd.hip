@@ -652,6 +652,69 @@ extern "C" int nf_pack_gather_multi(const void *const *params, const int64_t *nu
     return NF_OK;
 }
 
+// The same gather for up to 32 MODULES of one structure per launch (round 6, last session; blockIdx.y = module): the conditioners of a
+// Glow level's K blocks share `src`, so their packed streams for a training step are one launch instead of K (96 launches of ~7 us per
+// step of BASELINE configs[3]).  Up to 8 parameter tensors per module.
+namespace nf {
+constexpr int PGB_MOD = 32, PGB_NP = 8;
+struct GatherBatch {
+    const float *p[PGB_MOD][PGB_NP];
+    float *out[PGB_MOD];
+    int first[PGB_NP + 1];
+    int np;
+};
+__global__ void __launch_bounds__(256)
+pack_gather_batch_kernel(GatherBatch g, const int *__restrict__ src, int64_t n) {
+    const int m = blockIdx.y;
+    float *__restrict__ out = g.out[m];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = src[i];
+        float v = 0.0f;
+        if (k > 0) {
+            int j = 0;
+#pragma unroll
+            for (int q = 1; q < PGB_NP; ++q)
+                if (q < g.np && k >= g.first[q]) j = q;
+            v = g.p[m][j][k - g.first[j]];
+        }
+        out[i] = v;
+    }
+}
+}  // namespace nf
+
+// params: HOST array of n_modules x n_params device pointers (module-major); numels: the n_params element counts (the same for every
+// module); outs: HOST array of n_modules device pointers to n floats each.
+extern "C" int nf_pack_gather_batch(const void *const *params, const int64_t *numels, int n_params, const int32_t *src, void *const *outs,
+                                    int64_t n, int n_modules, nf_stream_t stream) {
+    if (n < 0 || n_modules < 0 || n_params < 1 || n_params > nf::PGB_NP) return NF_EINVAL;
+    if (n == 0 || n_modules == 0) return NF_OK;
+    if (!params || !numels || !src || !outs) return NF_EFAULT;
+    nf::GatherBatch g = {};
+    int64_t first = 1;
+    for (int j = 0; j < n_params; ++j) {
+        if (numels[j] < 0 || first + numels[j] >= (1ll << 31)) return NF_EINVAL;
+        g.first[j] = (int)first;
+        first += numels[j];
+    }
+    g.first[n_params] = (int)first;
+    g.np = n_params;
+    for (int m0 = 0; m0 < n_modules; m0 += nf::PGB_MOD) {
+        const int mm = n_modules - m0 < nf::PGB_MOD ? n_modules - m0 : nf::PGB_MOD;
+        for (int m = 0; m < mm; ++m) {
+            if (!outs[m0 + m]) return NF_EFAULT;
+            g.out[m] = (float *)outs[m0 + m];
+            for (int j = 0; j < n_params; ++j) {
+                if (!params[(size_t)(m0 + m) * n_params + j]) return NF_EFAULT;
+                g.p[m][j] = (const float *)params[(size_t)(m0 + m) * n_params + j];
+            }
+        }
+        hipLaunchKernelGGL(nf::pack_gather_batch_kernel, dim3(nf::grid_for(n, 256), (unsigned)mm), dim3(256), 0, (hipStream_t)stream, g,
+                           (const int *)src, n);
+        NF_CHECK_LAUNCH();
+    }
+    return NF_OK;
+}
+
 extern "C" int nf_pack_gather(const void *flat, const int32_t *src, void *out, int64_t n, nf_stream_t stream) {
     if (n < 0) return NF_EINVAL;
     if (n == 0) return NF_OK;

@@ -66,9 +66,47 @@ def _train_packs_from(module, build, params, device, skey=()):
         return None
     from . import ops
     bwd = dict(struct["bwd"])
-    both = ops.pack_gather(params, struct["src"])
+    both = module.__dict__.pop("_both_prefetch", None)        # (gathered with the level's other conditioners: prefetch_train_packs)
+    if both is None or both.numel() != struct["src"].numel():
+        both = ops.pack_gather(params, struct["src"])
     bwd["blob"] = both[struct["nfwd"]:]
     return (both[:struct["nfwd"]], struct["table"], struct["hp"]), bwd
+
+
+def prefetch_train_packs(convnets, device):
+    """Round 6 (last session): the packed weight streams of several ConvNet2d conditioners of ONE structure for this training step in
+    one launch (ops.pack_gather_batch) -- they depend on parameters only, so a Glow level gathers its K conditioners' streams before its
+    first block runs.  Each module's result waits in `_both_prefetch` for its next `_train_packs`; the caller drops what was not
+    consumed (clear_prefetched_packs)."""
+    from . import config, ops
+    if not config.glow_weights_batched or not torch.is_grad_enabled():
+        return
+    groups = {}
+    for net in convnets:
+        args = net._train_pack_args() if hasattr(net, "_train_pack_args") else None
+        if args is None:
+            continue
+        build, params, key = args
+        if not all(p.is_cuda and p.device == device and p.dtype == torch.float32 and p.is_contiguous() for p in params):
+            continue
+        struct = _train_struct_for(net, build, device)
+        if struct is None:
+            continue
+        groups.setdefault(key, []).append((net, params, struct))
+    for items in groups.values():
+        if len(items) < 2:
+            continue
+        src = items[0][2]["src"]
+        if any(it[2]["src"].numel() != src.numel() for it in items):
+            continue
+        outs = ops.pack_gather_batch([[p.detach() for p in it[1]] for it in items], src)
+        for it, o in zip(items, outs):
+            it[0].__dict__["_both_prefetch"] = o
+
+
+def clear_prefetched_packs(convnets):
+    for net in convnets:
+        net.__dict__.pop("_both_prefetch", None)
 
 
 def _train_struct_for(module, build, device, skey=()):
@@ -301,6 +339,13 @@ class ConvNet2d(nn.Module):
     def _train_packs(self, device):
         """Device copies of the plain-MLP packs (flows/made_pack.pack_mlp_*) of the 3x3 -> 1x1 -> 3x3 ReLU network for the MADE training
         kernels (autograd.ConvNetFn), rebuilt when a parameter changes; None for any other structure (then the library path)."""
+        args = self._train_pack_args()
+        if args is None:
+            return None
+        return _train_packs_from(self, args[0], args[1], device)
+
+    def _train_pack_args(self):
+        """(structure builder, parameter list, structure key) of _train_packs, or None."""
         from . import config
         mods = list(self.net)
         if not (config.made_train and config.made_fused) or len(mods) != 5:
@@ -321,8 +366,8 @@ class ConvNet2d(nn.Module):
         if not (c2.in_channels == hid and c2.out_channels == hid and c3.in_channels == hid):
             return None
         from .flows import made_pack
-        return _train_packs_from(self, lambda: made_pack.convnet_train_structure(cin, hid, cout),
-                                 [c1.weight, c1.bias, c2.weight, c2.bias, c3.weight], device)
+        return (lambda: made_pack.convnet_train_structure(cin, hid, cout), [c1.weight, c1.bias, c2.weight, c2.bias, c3.weight],
+                ("conv", cin, hid, cout))
 
     # below this many pixels per call the library path stays (the one-launch kernels are built for full-chip batches)
     FUSED_MIN_PIXELS = 2048

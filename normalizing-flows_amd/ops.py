@@ -1255,6 +1255,26 @@ def pack_gather(params, src):
     return out
 
 
+def pack_gather_batch(param_lists, src):
+    """nf_pack_gather_batch: [flat_m[src]] for modules m of ONE structure (param_lists[m] = its <= 8 contiguous float32 parameter
+    tensors, the same shapes for every module) -- one launch per 32 modules."""
+    L.require_device(src, *[p for pl in param_lists for p in pl])
+    n_mod, n_par = len(param_lists), len(param_lists[0])
+    if n_par > 8 or any(len(pl) != n_par for pl in param_lists):
+        raise NotImplementedError("pack_gather_batch: <= 8 parameters per module, the same number for all")
+    shapes = [tuple(p.shape) for p in param_lists[0]]
+    for pl in param_lists:
+        if [tuple(p.shape) for p in pl] != shapes or any(p.dtype != torch.float32 or not p.is_contiguous() for p in pl):
+            raise NotImplementedError("pack_gather_batch: contiguous float32 parameters of one structure")
+    out = torch.empty(n_mod, src.numel(), dtype=torch.float32, device=src.device)
+    outs = list(out.unbind(0))
+    pp = _ptr_array([p for pl in param_lists for p in pl])
+    nn_ = (C.c_int64 * n_par)(*[p.numel() for p in param_lists[0]])
+    rc = L.lib().nf_pack_gather_batch(pp, nn_, i32(n_par), ptr(src), _ptr_array(outs), i64(src.numel()), i32(n_mod), L.stream())
+    L.check(rc, "nf_pack_gather_batch")
+    return outs
+
+
 def made_forward_train(x, blob, table, hidden_padded, out_features, num_blocks, rows=None, features=None):
     """MADE.forward / ResidualNet.forward under autograd (nf_made_forward_train): (params (B, out_features), save (2 NB + 1, Bp, Hp)
     pre-activations, bits (Bp / 64, 2 NB, 2, 512) ReLU signs), Bp = B rounded up to 64 -- the operands of made_backward / made_wgrad.

@@ -2182,7 +2182,8 @@ def test_glow_parameter_gradient_launches_on_the_side_stream(nfa):
 def test_glow_level_assembles_its_1x1_matrices_in_one_launch(nfa):
     """config.glow_weights_batched (round 6, late): in the density direction under autograd a level's Invertible1x1Convs get their
     matrices from ONE nf_inv1x1_assemble_multi launch before the first block runs and their LU factors' gradients from ONE
-    nf_inv1x1_lu_grads_multi launch once every block's gW exists (autograd.Inv1x1WeightsFn) -- the same kernel bodies per layer as the
+    nf_inv1x1_lu_grads_multi launch once every block's gW exists (autograd.Inv1x1WeightsFn), and its conditioners their packed weight
+    streams from ONE nf_pack_gather_batch launch (nets.prefetch_train_packs) -- the same kernel bodies per layer as the
     per-block launches: loss and every gradient bit for bit; nothing is left waiting in the modules afterwards; a second backward
     through the same graph is refused like any once-differentiable Function's."""
     from normflows_amd import ops
@@ -2205,27 +2206,31 @@ def test_glow_level_assembles_its_1x1_matrices_in_one_launch(nfa):
         for p in m.parameters():
             p.add_(0.02 * torch.randn_like(p))
     res, counts = [], []
-    real = (ops.inv1x1_assemble, ops.inv1x1_lu_grads, ops.inv1x1_assemble_multi, ops.inv1x1_lu_grads_multi)
+    names = ("inv1x1_assemble", "inv1x1_lu_grads", "inv1x1_assemble_multi", "inv1x1_lu_grads_multi", "pack_gather", "pack_gather_batch")
+    real = tuple(getattr(ops, k) for k in names)
     try:
         for mode in (False, True):
             nfa.config.set_glow_weights_batched(mode)
-            n = [0, 0, 0, 0]
+            n = [0] * len(names)
 
             def spy(k):
                 def f(*a, **kw):
                     n[k] += 1
                     return real[k](*a, **kw)
                 return f
-            ops.inv1x1_assemble, ops.inv1x1_lu_grads, ops.inv1x1_assemble_multi, ops.inv1x1_lu_grads_multi = (spy(k) for k in range(4))
+            for k, name in enumerate(names):
+                setattr(ops, name, spy(k))
             m.zero_grad(set_to_none=True)
             loss = m.forward_kld(x)
             loss.backward()
             counts.append(tuple(n))
             res.append([loss.detach().clone()] + [p.grad.clone() for p in m.parameters()])
     finally:
-        ops.inv1x1_assemble, ops.inv1x1_lu_grads, ops.inv1x1_assemble_multi, ops.inv1x1_lu_grads_multi = real
+        for name, f in zip(names, real):
+            setattr(ops, name, f)
         nfa.config.set_glow_weights_batched(True)
-    assert counts == [(L_ * K_, L_ * K_, 0, 0), (0, 0, L_, L_)], counts
+    # (the conditioners' packed weight streams of the step likewise: one gather launch per level instead of one per block)
+    assert counts == [(L_ * K_, L_ * K_, 0, 0, L_ * K_, 0), (0, 0, L_, L_, 0, L_)], counts
     assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
     assert all("_w_prefetch" not in mod.__dict__ for mod in m.modules())
 
