@@ -139,6 +139,15 @@ def set_glow_weights_batched(mode=True):
     glow_weights_batched = bool(mode)
 
 
+# The 256-slot training kernels (nf_made_forward_train / nf_made_backward: GlowBlock's conv conditioner at the 16x16 level, ResidualNets /
+# MADEs of hidden width <= 256 on <= 64 features) on 128-row tiles at batches that are a multiple of 128 rows >= 32 768 (csrc/mlp_tile.hpp
+# mf_tr128: a weight fragment feeds eight MFMAs instead of four; same bits).  Lives in the library (nf_config_made_tr128).
+def set_made_tr128(mode=True):
+    """Returns the previous setting.  A forward and its backward must run under the same setting."""
+    from . import _lib
+    return bool(_lib.lib().nf_config_made_tr128(1 if mode else 0))
+
+
 # MultiscaleFlow under autograd: the per-layer `log_q += log_det` statements of a level are collected and applied as one launch in the same
 # order (flows/affine.lazy_ld, nf_ld_fold_multi: same bits).  False = one launch per layer.
 lazy_logdet = True

@@ -23,16 +23,18 @@
 namespace nf {
 
 // ---- 1. input-gradient chain ---------------------------------------------------------------------------------------------------------
-template <int NSB>
+template <int NSB, int TR = MF_ROWS>
 __global__ void __launch_bounds__(64 * MF_NW, 1)
 made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits, float *__restrict__ gx, float *__restrict__ G,
                 const float *__restrict__ blob, const int *__restrict__ table, int64_t B, int64_t Bp) {
-    constexpr int NS = NSB;
+    static_assert(TR == 64 || (TR == 128 && NSB == 1), "128-row tiles: 256-slot networks only (mlp_tile.hpp mf_tr128)");
+    constexpr int NSH = TR / 64;             // sample blocks per half of a tile
+    constexpr int NS = NSB * NSH;
     constexpr int HRB = 8 * NSB;
     constexpr int HP = 256 * NSB;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *acts = lds;                                  // [HP / 8 k-groups][2][64][4]
-    float *xreg = lds + (size_t)HRB * 4 * 512;          // [Dp / 8][2][64][4]: the g_x tile on its way out
+    float *acts = lds;                                  // [HP / 8 k-groups][2][TR][4]
+    float *xreg = lds + (size_t)HRB * 4 * 8 * TR;       // [Dp / 8][2][TR][4]: the g_x tile on its way out
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = table[0], NB = table[5], NC = table[7], nitems = table[10];
@@ -43,15 +45,16 @@ made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits,
     const int *items = table + MF_HDR + w * nitems * 4;       // [nitems][nkg, rb, kg0, -]
     const float *stream = blob + table[16 + w];
     const int rbs[2] = {w, HRB - 1 - w};
-    const int sb0s[2] = {0, NSB == 2 ? 0 : 1};
-    const int lane_b = (64 * hh + n) * 4;
-    const int64_t ntiles = (B + MF_ROWS - 1) / MF_ROWS;
+    const int sb0s[2] = {0, NSB == 2 ? 0 : NSH};
+    const int lane_b = (TR * hh + n) * 4;
+    constexpr int KG = 8 * TR;               // floats of one k-group of activations
+    const int64_t ntiles = (B + TR - 1) / TR;
     MfRing ring;
     mf_ring_start(ring, stream, lane);
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t row0 = tile * MF_ROWS;
-        const int nrows = (int)((B - row0) < MF_ROWS ? (B - row0) : MF_ROWS);
+        const int64_t row0 = tile * TR;
+        const int nrows = (int)((B - row0) < TR ? (B - row0) : TR);
         ring.ap = stream + lane * 4;
         const unsigned *btile = bits + ((size_t)tile * 2 * NB * 2) * 512 + tid;
         float *gtile = G + (size_t)row0 * HP;
@@ -66,9 +69,9 @@ made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits,
         for (int c = 0; c < NC; ++c) {
             MF_BARRIER();
             {
-                const int r = tid & 63, cg = tid >> 6;
+                const int r = tid & (TR - 1), cg = tid / TR;
                 const float *gr = gp + (row0 + r) * ldg;
-                for (int c4 = cg; c4 < HP / 4; c4 += MF_NW) {
+                for (int c4 = cg; c4 < HP / 4; c4 += 64 * MF_NW / TR) {
                     const int col = c * HP + 4 * c4;
                     f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
                     if (r < nrows && col < MD) {
@@ -77,14 +80,14 @@ made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits,
 #pragma unroll
                             for (int i = 0; i < 4; ++i) if (col + i < MD) v[i] = gr[col + i];
                     }
-                    *reinterpret_cast<f32x4 *>(acts + ((size_t)c4 * 64 + r) * 4) = v;
+                    *reinterpret_cast<f32x4 *>(acts + ((size_t)c4 * TR + r) * 4) = v;
                 }
             }
             MF_BARRIER();
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int *it = items + 4 * (2 * c + s);
-                mf_item<NS, true>(ring, it[0], acts + lane_b + 128 * sb0s[s] + it[2] * 512, gh[s]);
+                mf_item<NS, true, TR>(ring, it[0], acts + lane_b + 128 * sb0s[s] + it[2] * KG, gh[s]);
             }
         }
 #pragma unroll
@@ -105,12 +108,12 @@ made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits,
             }
             MF_BARRIER();
 #pragma unroll
-            for (int s = 0; s < 2; ++s) mf_publish<NS, false>(acts, rbs[s], sb0s[s], hh, n, gh[s]);
+            for (int s = 0; s < 2; ++s) mf_publish<NS, false, TR>(acts, rbs[s], sb0s[s], hh, n, gh[s]);
             MF_BARRIER();
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int *it = itb + 4 * (2 + s);
-                mf_item<NS, false>(ring, it[0], acts + lane_b + 128 * sb0s[s] + it[2] * 512, u[s]);
+                mf_item<NS, false, TR>(ring, it[0], acts + lane_b + 128 * sb0s[s] + it[2] * KG, u[s]);
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -128,12 +131,12 @@ made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits,
             }
             MF_BARRIER();
 #pragma unroll
-            for (int s = 0; s < 2; ++s) mf_publish<NS, false>(acts, rbs[s], sb0s[s], hh, n, gh[s]);
+            for (int s = 0; s < 2; ++s) mf_publish<NS, false, TR>(acts, rbs[s], sb0s[s], hh, n, gh[s]);
             MF_BARRIER();
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int *it = itb + 4 * s;
-                mf_item<NS, false>(ring, it[0], acts + lane_b + 128 * sb0s[s] + it[2] * 512, u[s]);
+                mf_item<NS, false, TR>(ring, it[0], acts + lane_b + 128 * sb0s[s] + it[2] * KG, u[s]);
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -142,12 +145,12 @@ made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits,
             }
             MF_BARRIER();
 #pragma unroll
-            for (int s = 0; s < 2; ++s) mf_publish<NS, false>(acts, rbs[s], sb0s[s], hh, n, u[s]);
+            for (int s = 0; s < 2; ++s) mf_publish<NS, false, TR>(acts, rbs[s], sb0s[s], hh, n, u[s]);
             MF_BARRIER();
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int *it = itb + 4 * (2 + s);
-                mf_item<NS, false>(ring, it[0], acts + lane_b + 128 * sb0s[s] + it[2] * 512, u[s]);
+                mf_item<NS, false, TR>(ring, it[0], acts + lane_b + 128 * sb0s[s] + it[2] * KG, u[s]);
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -158,24 +161,24 @@ made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits,
         // ---- g_x = W0^T g_h: one 32-feature row-block and sample block per wave ------------------------------------------------------
         MF_BARRIER();
 #pragma unroll
-        for (int s = 0; s < 2; ++s) mf_publish<NS, false>(acts, rbs[s], sb0s[s], hh, n, gh[s]);
+        for (int s = 0; s < 2; ++s) mf_publish<NS, false, TR>(acts, rbs[s], sb0s[s], hh, n, gh[s]);
         MF_BARRIER();
         for (int rd = 0; rd < nfin; ++rd) {
             const int *it = items + 4 * (2 * NC + 4 * NB + rd);
             const int rb = it[1], sf = w >> 2;
             if (rb >= 0) {
-                f32x16 o[1];
-                mf_item<1, false>(ring, it[0], acts + lane_b + 128 * sf + it[2] * 512, o);
-                mf_publish<1, false>(xreg, rb, sf, hh, n, o);
+                f32x16 o[NSH];
+                mf_item<NSH, false, TR>(ring, it[0], acts + lane_b + 128 * NSH * sf + it[2] * KG, o);
+                mf_publish<NSH, false, TR>(xreg, rb, NSH * sf, hh, n, o);
             }
         }
         MF_BARRIER();
         {
-            const int r = tid & 63, cg = tid >> 6;
+            const int r = tid & (TR - 1), cg = tid / TR;
             float *xr = gx + (row0 + r) * ldgx;
             if (r < nrows)
-                for (int c = cg; 4 * c < D; c += MF_NW) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(xreg + ((size_t)c * 64 + r) * 4);
+                for (int c = cg; 4 * c < D; c += 64 * MF_NW / TR) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(xreg + ((size_t)c * TR + r) * 4);
                     if ((D & 3) == 0) *reinterpret_cast<f32x4 *>(xr + 4 * c) = v;
                     else
 #pragma unroll
@@ -186,16 +189,17 @@ made_bwd_kernel(const float *__restrict__ gp, const unsigned *__restrict__ bits,
     }
 }
 
-template <int NSB>
+template <int NSB, int TR = MF_ROWS>
 static int made_bwd_launch(const void *gp, const void *bits, void *gx, void *G, const void *blob, const int32_t *table, int64_t B,
                            hipStream_t st, int dp) {
-    const int64_t ntiles = (B + MF_ROWS - 1) / MF_ROWS;
+    const int64_t ntiles = (B + TR - 1) / TR;
     const int grid = (int)(ntiles < 256 ? ntiles : 256);
-    const size_t lds = sizeof(float) * ((size_t)8 * NSB * 4 * 512 + (dp > 128 ? 2 * MF_XFLOATS : MF_XFLOATS));
+    const size_t lds = sizeof(float) * ((size_t)8 * NSB * 4 * 8 * TR + (dp > 128 ? 2 * MF_XFLOATS : MF_XFLOATS));
     static LdsOptIn opted;
-    if (opt_in_lds(reinterpret_cast<const void *>(&made_bwd_kernel<NSB>), lds, opted) != NF_OK) return NF_ENOTSUP;
-    hipLaunchKernelGGL((made_bwd_kernel<NSB>), dim3((unsigned)grid), dim3(64 * MF_NW), lds, st, (const float *)gp,
-                       (const unsigned *)bits, (float *)gx, (float *)G, (const float *)blob, (const int *)table, B, ntiles * MF_ROWS);
+    if (opt_in_lds(reinterpret_cast<const void *>(&made_bwd_kernel<NSB, TR>), lds, opted) != NF_OK) return NF_ENOTSUP;
+    hipLaunchKernelGGL((made_bwd_kernel<NSB, TR>), dim3((unsigned)grid), dim3(64 * MF_NW), lds, st, (const float *)gp,
+                       (const unsigned *)bits, (float *)gx, (float *)G, (const float *)blob, (const int *)table, B,
+                       (B + MF_ROWS - 1) / MF_ROWS * MF_ROWS);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -521,6 +525,7 @@ extern "C" int nf_made_backward(const void *g_params, const void *bits, void *g_
     if (!g_params || !bits || !g_x || !blob || !table) return NF_EFAULT;       // (G may be NULL: only g_x is wanted)
     hipStream_t st = (hipStream_t)stream;
     const int dp = (D + 31) / 32 * 32;
+    if (nf::mf_tr128(B, hidden_padded, dp)) return nf::made_bwd_launch<1, 128>(g_params, bits, g_x, G, blob, table, B, st, dp);    // (as the forward)
     if (hidden_padded == 256) return nf::made_bwd_launch<1>(g_params, bits, g_x, G, blob, table, B, st, dp);
     return nf::made_bwd_launch<2>(g_params, bits, g_x, G, blob, table, B, st, dp);
 }

@@ -40,17 +40,19 @@ namespace nf {
 // EPI 3: EPI 1 under autograd (core.py:87-102 through a MADE): every layer's pre-activations are also written row-major to
 // save[l][Bp][Hp] (l = 0: the initial layer's h; 2 b + 1: block b's inner t; 2 b + 2: its output h) and the signs of what a ReLU
 // follows to bits[tile][2 b | 2 b + 1][item][512 lanes] -- the operands of made_bwd.hip.
-template <int NSB, int EPI>
+template <int NSB, int EPI, int TR = MF_ROWS>
 __global__ void __launch_bounds__(64 * MF_NW, 1)
 made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ logdet, const float *__restrict__ blob,
                 const int *__restrict__ table, int64_t B, int acc_mode, RqsParams<float> p, float *__restrict__ save,
                 unsigned *__restrict__ bits, int64_t Bp) {
-    constexpr int NS = NSB;                  // sample blocks per hidden work item
+    static_assert(TR == 64 || (TR == 128 && NSB == 1 && EPI == 3), "128-row tiles: the 256-slot training forward only (mf_tr128)");
+    constexpr int NSH = TR / 64;             // sample blocks per HALF of a tile (a 256-slot item covers one half, a final-layer item too)
+    constexpr int NS = NSB * NSH;            // sample blocks per hidden work item
     constexpr int HP = 256 * NSB;
     constexpr int HRB = 8 * NSB;             // hidden row-blocks
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *acts = lds;                                  // [HRB * 4 k-groups][2][64][4]
-    float *xreg = lds + (size_t)HRB * 4 * 512;          // [Dp / 8][2][64][4]
+    float *acts = lds;                                  // [HRB * 4 k-groups][2][TR][4]
+    float *xreg = lds + (size_t)HRB * 4 * 8 * TR;       // [Dp / 8][2][TR][4]
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D = table[0], Dp = table[1], NB = table[5], NFB = table[7], nrounds = table[8], nitems = table[10];
@@ -61,25 +63,25 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
     const int *items = table + MF_HDR + w * nitems * 2;       // [nitems][nkg, rb]
     const float *stream = blob + table[16 + w];
     const int rbs[2] = {w, HRB - 1 - w};                      // (the packer's wave_items: the hidden row-blocks of this wave)
-    const int sb0s[2] = {0, NSB == 2 ? 0 : 1};
-    const int lane_b = (64 * hh + n) * 4;       // the lane's offset inside a k-group of activations (sample block 0)
-    const int64_t ntiles = (B + MF_ROWS - 1) / MF_ROWS;
+    const int sb0s[2] = {0, NSB == 2 ? 0 : NSH};
+    const int lane_b = (TR * hh + n) * 4;       // the lane's offset inside a k-group of activations (sample block 0)
+    const int64_t ntiles = (B + TR - 1) / TR;
     MfRing ring;
     mf_ring_start(ring, stream, lane);
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t row0 = tile * MF_ROWS;
-        const int nrows = (int)((B - row0) < MF_ROWS ? (B - row0) : MF_ROWS);
+        const int64_t row0 = tile * TR;
+        const int nrows = (int)((B - row0) < TR ? (B - row0) : TR);
         ring.ap = stream + lane * 4;            // (the ring already holds the stream's first entries: the wrap-around copy)
         int tq = tid;                           // per-tile address arithmetic from an index the compiler cannot hoist out of the tile loop
         asm volatile("" : "+v"(tq));            // (round 6, as in nsf_wide.hip: hoisted, those values stayed live across the products)
         asm volatile("" : "+v"(ring.ap));       // (likewise the restarted stream's first request addresses: four 64-bit pairs)
         // ---- x tile -> LDS (B-operand order; rows beyond the batch and features beyond D are zero) ---------------------------------
         {
-            const int r = tq & 63, cg = tq >> 6;
+            const int r = tq & (TR - 1), cg = tq / TR;
             const float *xr = x + (row0 + r) * ldx;
 #pragma unroll 1
-            for (int c = cg; c < Dp / 4; c += MF_NW) {
+            for (int c = cg; c < Dp / 4; c += 64 * MF_NW / TR) {
                 f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (r < nrows && 4 * c < D) {           // (Dp rounds D up to 32: the last chunks may lie wholly beyond the row)
                     if ((D & 3) == 0) v = *reinterpret_cast<const f32x4 *>(xr + 4 * c);
@@ -87,14 +89,14 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
 #pragma unroll
                         for (int i = 0; i < 4; ++i) if (4 * c + i < D) v[i] = xr[4 * c + i];
                 }
-                *reinterpret_cast<f32x4 *>(xreg + ((size_t)c * 64 + r) * 4) = v;
+                *reinterpret_cast<f32x4 *>(xreg + ((size_t)c * TR + r) * 4) = v;
             }
         }
         f32x16 h[2][NS], t[2][NS];
         MF_BARRIER();
         // ---- initial layer: h = b0 + W0 x ----------------------------------------------------------------------------------------------
 #pragma unroll
-        for (int s = 0; s < 2; ++s) mf_item<NS, false>(ring, items[2 * s], xreg + lane_b + 128 * sb0s[s], h[s]);
+        for (int s = 0; s < 2; ++s) mf_item<NS, false, TR>(ring, items[2 * s], xreg + lane_b + 128 * sb0s[s], h[s]);
         float *stile = nullptr;
         unsigned *btile = nullptr;
         if constexpr (EPI == 3) {
@@ -107,16 +109,16 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
         for (int b = 0; b < NB; ++b) {
             MF_BARRIER();        // (b > 0: every wave has finished reading relu(t) of the previous block)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) mf_publish<NS, true>(acts, rbs[s], sb0s[s], hh, n, h[s]);
+            for (int s = 0; s < 2; ++s) mf_publish<NS, true, TR>(acts, rbs[s], sb0s[s], hh, n, h[s]);
             if constexpr (EPI == 3)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) btile[((size_t)(2 * b) * 2 + s) * 512] = mf_sign_bits<NS>(h[s]);
             MF_BARRIER();
 #pragma unroll
-            for (int s = 0; s < 2; ++s) mf_item<NS, false>(ring, items[2 * (2 + 4 * b + s)], acts + lane_b + 128 * sb0s[s], t[s]);
+            for (int s = 0; s < 2; ++s) mf_item<NS, false, TR>(ring, items[2 * (2 + 4 * b + s)], acts + lane_b + 128 * sb0s[s], t[s]);
             MF_BARRIER();
 #pragma unroll
-            for (int s = 0; s < 2; ++s) mf_publish<NS, true>(acts, rbs[s], sb0s[s], hh, n, t[s]);
+            for (int s = 0; s < 2; ++s) mf_publish<NS, true, TR>(acts, rbs[s], sb0s[s], hh, n, t[s]);
             if constexpr (EPI == 3)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -126,7 +128,7 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
             MF_BARRIER();
             if (plain) break;            // (relu(t) is published: the final layer's input)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) mf_item<NS, true>(ring, items[2 * (4 + 4 * b + s)], acts + lane_b + 128 * sb0s[s], h[s]);
+            for (int s = 0; s < 2; ++s) mf_item<NS, true, TR>(ring, items[2 * (4 + 4 * b + s)], acts + lane_b + 128 * sb0s[s], h[s]);
             if constexpr (EPI == 3)
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
@@ -136,7 +138,7 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
         if (!plain) {
             MF_BARRIER();
 #pragma unroll
-            for (int s = 0; s < 2; ++s) mf_publish<NS, false>(acts, rbs[s], sb0s[s], hh, n, h[s]);
+            for (int s = 0; s < 2; ++s) mf_publish<NS, false, TR>(acts, rbs[s], sb0s[s], hh, n, h[s]);
             MF_BARRIER();
         }
         if constexpr (EPI == 2) {
@@ -212,10 +214,10 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int *it = items + 2 * (2 + 4 * NB + 2 * rd + s);
-                const int fb = it[1];                         // sample block s
+                const int fb = it[1];                         // sample half s (TR = 64: sample block s)
                 if (fb >= 0) {
-                    f32x16 o[1];
-                    mf_item<1, false>(ring, it[0], acts + lane_b + 128 * s, o);
+                    f32x16 o[NSH];
+                    mf_item<NSH, false, TR>(ring, it[0], acts + lane_b + 128 * NSH * s, o);
                     if constexpr (EPI == 0) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
@@ -231,17 +233,21 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
                             }
                         }
                     } else {
-                        const int64_t r = row0 + 32 * s + n;
-                        if (32 * s + n < nrows) {
-                            float *yp = y + r * (int64_t)MD + 32 * fb + 4 * hh;
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const int c = 32 * fb + 8 * q + 4 * hh;
-                                if ((MD & 3) == 0) {
-                                    if (c < MD) *reinterpret_cast<f32x4 *>(yp + 8 * q) = f32x4{o[0][4 * q], o[0][4 * q + 1], o[0][4 * q + 2], o[0][4 * q + 3]};
-                                } else {
+                        for (int ss = 0; ss < NSH; ++ss) {
+                            const int rl = 32 * (NSH * s + ss) + n;
+                            const int64_t r = row0 + rl;
+                            if (rl < nrows) {
+                                float *yp = y + r * (int64_t)MD + 32 * fb + 4 * hh;
 #pragma unroll
-                                    for (int i = 0; i < 4; ++i) if (c + i < MD) yp[8 * q + i] = o[0][4 * q + i];
+                                for (int q = 0; q < 4; ++q) {
+                                    const int c = 32 * fb + 8 * q + 4 * hh;
+                                    if ((MD & 3) == 0) {
+                                        if (c < MD) *reinterpret_cast<f32x4 *>(yp + 8 * q) = f32x4{o[ss][4 * q], o[ss][4 * q + 1], o[ss][4 * q + 2], o[ss][4 * q + 3]};
+                                    } else {
+#pragma unroll
+                                        for (int i = 0; i < 4; ++i) if (c + i < MD) yp[8 * q + i] = o[ss][4 * q + i];
+                                    }
                                 }
                             }
                         }
@@ -279,18 +285,18 @@ made_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, float *__res
     }
 }
 
-template <int NSB, int EPI>
+template <int NSB, int EPI, int TR = MF_ROWS>
 static int made_fwd_launch(const void *x, void *y, void *logdet, const void *blob, const int32_t *table, int64_t B, int acc, hipStream_t st,
                            const RqsParams<float> &p = RqsParams<float>(), void *save = nullptr, void *bits = nullptr, int table_dp = 128) {
-    const int64_t ntiles = (B + MF_ROWS - 1) / MF_ROWS;
+    const int64_t ntiles = (B + TR - 1) / TR;
     const int grid = (int)(ntiles < 256 ? ntiles : 256);        // persistent: one workgroup per CU (160 KB of LDS at Hp = 512)
     const int xfloats = table_dp > 128 ? 2 * MF_XFLOATS : MF_XFLOATS;       // x tile: 64 rows x Dp (<= 256 next to 256 hidden slots)
-    const size_t lds = sizeof(float) * ((size_t)8 * NSB * 4 * 512 + xfloats);
+    const size_t lds = sizeof(float) * ((size_t)8 * NSB * 4 * 8 * TR + xfloats);       // (TR = 128: 128 rows x Dp <= 64 = the same 32 KB)
     static LdsOptIn opted;
-    if (opt_in_lds(reinterpret_cast<const void *>(&made_fwd_kernel<NSB, EPI>), lds, opted) != NF_OK) return NF_ENOTSUP;
-    hipLaunchKernelGGL((made_fwd_kernel<NSB, EPI>), dim3((unsigned)grid), dim3(64 * MF_NW), lds, st, (const float *)x, (float *)y,
+    if (opt_in_lds(reinterpret_cast<const void *>(&made_fwd_kernel<NSB, EPI, TR>), lds, opted) != NF_OK) return NF_ENOTSUP;
+    hipLaunchKernelGGL((made_fwd_kernel<NSB, EPI, TR>), dim3((unsigned)grid), dim3(64 * MF_NW), lds, st, (const float *)x, (float *)y,
                        (float *)logdet, (const float *)blob, (const int *)table, B, acc, p, (float *)save, (unsigned *)bits,
-                       ntiles * MF_ROWS);
+                       (B + MF_ROWS - 1) / MF_ROWS * MF_ROWS);
     NF_CHECK_LAUNCH();
     return NF_OK;
 }
@@ -346,6 +352,14 @@ extern "C" int nf_made_forward_spline(const void *x, void *y, void *logdet, cons
     return nf::made_fwd_launch<2, 2>(x, y, logdet, blob, table, B, acc, st, p);
 }
 
+// 128-row tiles of the 256-slot training kernels on (1, default) / off (0); returns the previous setting.  A forward and its backward
+// must run under the same setting (the ReLU-sign words are indexed by tile).
+extern "C" int nf_config_made_tr128(int on) {
+    const int prev = nf::mf_tr128_switch();
+    nf::mf_tr128_switch() = on ? 1 : 0;
+    return prev;
+}
+
 // MADE.forward under autograd: nf_made_forward + the operands of nf_made_backward / nf_made_wgrad (csrc/made_bwd.hip).  Bp = B rounded
 // up to 64; save: (2 num_blocks + 1) x Bp x hidden_padded floats; bits: (Bp / 64) x 2 num_blocks x 2 x 512 dwords.
 extern "C" int nf_made_forward_train(const void *x, void *params, void *save, void *bits, const void *blob, const int32_t *table,
@@ -356,6 +370,8 @@ extern "C" int nf_made_forward_train(const void *x, void *params, void *save, vo
     if (!x || !params || !save || !bits || !blob || !table) return NF_EFAULT;
     hipStream_t st = (hipStream_t)stream;
     const int dp = (D + 31) / 32 * 32;
+    if (nf::mf_tr128(B, hidden_padded, dp))      // (256 slots, <= 64 features, whole 128-row tiles: nf_made_backward decides the same way)
+        return nf::made_fwd_launch<1, 3, 128>(x, params, nullptr, blob, table, B, NF_LD_WRITE, st, nf::RqsParams<float>(), save, bits, dp);
     if (hidden_padded == 256) return nf::made_fwd_launch<1, 3>(x, params, nullptr, blob, table, B, NF_LD_WRITE, st, nf::RqsParams<float>(), save, bits, dp);
     return nf::made_fwd_launch<2, 3>(x, params, nullptr, blob, table, B, NF_LD_WRITE, st, nf::RqsParams<float>(), save, bits, dp);
 }

@@ -3,6 +3,7 @@
 // whole network, pre-activations live in accumulator registers, the next layer's B operand in LDS in MFMA order, and every wave
 // walks ONE contiguous weight stream through an 8-entry register ring (see made_fwd.hip for the full description).
 #pragma once
+#include <cstdlib>
 #include "common.hpp"
 #include "fused_common.hpp"
 
@@ -12,6 +13,19 @@ constexpr int MF_ROWS = 64;       // rows per workgroup and tile
 constexpr int MF_NW = 8;          // waves per workgroup: two per SIMD
 constexpr int MF_HDR = 32;
 constexpr int MF_XFLOATS = 16 * 2 * 64 * 4;      // x tile: Dp <= 128 features
+
+// 128-ROW tiles for the training kernels of a 256-slot network with <= 64 input features (round 6, last session; made_fwd.hip EPI 3,
+// made_bwd.hip): a work item then spans TWO sample blocks (NS = 2) like the 512-slot kernels -- every weight fragment feeds eight MFMAs
+// instead of four, half as many layer barriers and weight requests per row -- and the activations + the x tile fill the LDS exactly
+// (128 + 32 KB).  Both kernels of a training step must take the same tile size (the ReLU-sign words are indexed by tile): this predicate
+// is the one place that decides.  NF_MADE_TR128=0 in the environment or nf_config_made_tr128(0) switches it off (A/B runs, tests).
+inline int &mf_tr128_switch() {       // (one instance for the library: nf_config_made_tr128 flips it -- tests, A/B runs)
+    static int on = [] { const char *e = getenv("NF_MADE_TR128"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on;
+}
+inline bool mf_tr128(int64_t B, int hidden_padded, int dp) {
+    return mf_tr128_switch() && hidden_padded == 256 && dp <= 64 && B % 128 == 0 && B >= 128 * 256;
+}
 
 #define MF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 // LDS-only barrier: the weight ring's global loads stay in flight across it (a __syncthreads() fence would drain them)

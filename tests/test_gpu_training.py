@@ -1641,6 +1641,35 @@ def test_maf_density_direction_in_place_backward_vs_reference_autograd(nfa):
     assert np.quantile(got, 0.9) <= 4 * max(np.quantile(own, 0.9), 1e-7), (np.quantile(got, 0.9), np.quantile(own, 0.9))
 
 
+def test_256_slot_training_kernels_on_128_row_tiles_give_the_same_bits(nfa):
+    """mlp_tile.hpp mf_tr128 (round 6, last session): nf_made_forward_train / nf_made_backward of a 256-slot network on <= 64 features run
+    batches of >= 32 768 rows (multiples of 128) on 128-row tiles -- a work item spans two sample blocks, every weight fragment feeds eight
+    MFMAs.  Each row's arithmetic is unchanged: outputs, input gradient and every parameter gradient bit for bit against the 64-row
+    tiles, for GlowBlock's conv conditioner at config 4's 16x16 level and for a dense ResidualNet (wrapper.py:20-35's conditioner)."""
+    torch.manual_seed(11)
+    conv = nfa.nets.ConvNet2d([6, 256, 256, 12], [3, 1, 3], 0.0, init_zeros=False).to(DEV)
+    xc, cc = torch.randn(128, 6, 16, 16, device=DEV), torch.randn(128, 12, 16, 16, device=DEV)
+    res = nfa.nets.ResidualNet(24, 40, 200, num_blocks=2).to(DEV)
+    xr, cr = torch.randn(32768 + 128, 24, device=DEV), torch.randn(32768 + 128, 40, device=DEV)
+    out = []
+    prev = nfa.config.set_made_tr128(True)
+    try:
+        for mode in (True, False):
+            nfa.config.set_made_tr128(mode)
+            r = []
+            for net, x, c in ((conv, xc, cc), (res, xr, cr)):
+                net.zero_grad(set_to_none=True)
+                xx = x.clone().requires_grad_(True)
+                y = net(xx)
+                (y * c).sum().backward()
+                r += [y.detach().clone(), xx.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+            out.append(r)
+    finally:
+        nfa.config.set_made_tr128(prev)
+    assert len(out[0]) == len(out[1]) and all(torch.isfinite(a).all() for a in out[0])
+    assert all(torch.equal(a, b) for a, b in zip(out[0], out[1]))
+
+
 def test_made_training_full_batch_vs_library_path(nfa):
     """BASELINE configs[4]'s layer at B = 65 536 (a multiple of the 64-row tiles and the weight-gradient chunks): hand-written path vs
     torch autograd through library GEMMs (float32 both: two different summation orders over 65 536 rows), outputs to 1e-4, every
