@@ -1651,13 +1651,24 @@ def test_256_slot_training_kernels_on_128_row_tiles_give_the_same_bits(nfa):
     xc, cc = torch.randn(128, 6, 16, 16, device=DEV), torch.randn(128, 12, 16, 16, device=DEV)
     res = nfa.nets.ResidualNet(24, 40, 200, num_blocks=2).to(DEV)
     xr, cr = torch.randn(32768 + 128, 24, device=DEV), torch.randn(32768 + 128, 40, device=DEV)
+    # ... and a MADE (triangular masks: row-blocks with different k ranges, k-group offsets in the backward's suffix items)
+    made = nfa.nets.MADE(40, 150, num_blocks=2, output_multiplier=2, use_residual_blocks=True, random_mask=False,
+                         activation=torch.nn.functional.relu).to(DEV)
+    with torch.no_grad():
+        for p in made.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    xm, cm = torch.randn(32768, 40, device=DEV), torch.randn(32768, 80, device=DEV)
     out = []
+    from normflows_amd import ops
+    seen = []
+    real_f = ops.made_forward_train
+    ops.made_forward_train = lambda *a, **k: (seen.append(1), real_f(*a, **k))[1]
     prev = nfa.config.set_made_tr128(True)
     try:
         for mode in (True, False):
             nfa.config.set_made_tr128(mode)
             r = []
-            for net, x, c in ((conv, xc, cc), (res, xr, cr)):
+            for net, x, c in ((conv, xc, cc), (res, xr, cr), (made, xm, cm)):
                 net.zero_grad(set_to_none=True)
                 xx = x.clone().requires_grad_(True)
                 y = net(xx)
@@ -1666,6 +1677,8 @@ def test_256_slot_training_kernels_on_128_row_tiles_give_the_same_bits(nfa):
             out.append(r)
     finally:
         nfa.config.set_made_tr128(prev)
+        ops.made_forward_train = real_f
+    assert len(seen) == 6, len(seen)            # (all three networks took the one-launch training forward, in both modes)
     assert len(out[0]) == len(out[1]) and all(torch.isfinite(a).all() for a in out[0])
     assert all(torch.equal(a, b) for a, b in zip(out[0], out[1]))
 
