@@ -2322,6 +2322,53 @@ def test_glow_level_folds_its_log_dets_in_one_launch(nfa):
     assert all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
 
 
+def test_glow_training_run_is_bit_identical_with_the_round6_switches_off(nfa):
+    """Three Adam steps of a two-level Glow (16x16 level at 32 768 pixel rows: the 128-row tiles apply) with every switch of the round's
+    last session ON (batched 1x1 matrices / LU-factor gradients / conditioner packs, lazy log-dets, 128-row tiles) and with all of them
+    OFF: every one of them re-orders launches, none re-orders arithmetic -- the loss sequence and the final parameters are bit for bit
+    the same."""
+    def run(on):
+        nfa.config.set_glow_weights_batched(on)
+        nfa.config.set_lazy_logdet(on)
+        nfa.config.set_made_tr128(on)
+        torch.manual_seed(13)
+        L_, K_ = 2, 2
+        q0, merges, flows = [], [], []
+        for i in range(L_):
+            fl = [nfa.flows.GlowBlock(3 * 2 ** (L_ + 1 - i), 256, split_mode="channel", scale=True) for _ in range(K_)] + [nfa.flows.Squeeze()]
+            flows += [fl]
+            if i > 0:
+                merges += [nfa.flows.Merge()]
+                latent = (3 * 2 ** (L_ - i), 32 // 2 ** (L_ - i), 32 // 2 ** (L_ - i))
+            else:
+                latent = (3 * 2 ** (L_ + 1), 32 // 2 ** L_, 32 // 2 ** L_)
+            q0 += [nfa.distributions.DiagGaussian(latent)]
+        m = nfa.MultiscaleFlow(q0, flows, merges, class_cond=False).to(DEV)
+        x = torch.rand(128, 3, 32, 32, generator=torch.Generator().manual_seed(1)).to(DEV)
+        with torch.no_grad():
+            m.log_prob(x)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        losses = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss = m.forward_kld(x)
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach().clone())
+        return losses, [p.detach().clone() for p in m.parameters()]
+    prev = nfa.config.set_made_tr128(True)
+    try:
+        a = run(True)
+        b = run(False)
+    finally:
+        nfa.config.set_glow_weights_batched(True)
+        nfa.config.set_lazy_logdet(True)
+        nfa.config.set_made_tr128(prev)
+    assert all(torch.isfinite(l) for l in a[0]) and not torch.equal(a[0][0], a[0][2])          # (the parameters moved)
+    assert all(torch.equal(x_, y_) for x_, y_ in zip(a[0], b[0]))
+    assert all(torch.equal(x_, y_) for x_, y_ in zip(a[1], b[1]))
+
+
 def test_maf_one_pass_backward_on_format0_and_format1_packs(nfa):
     """The one-pass implicit backward with the forward on the format-1 pack (default: fast inverse kernel, masks in its positions,
     nf_maf_inverse_h_tri_bits) and on the format-0 pack (config.set_maf_tri(False): nf_maf_inverse_h_bits): the two position
