@@ -114,35 +114,39 @@ def exported_symbols_declared():
     return sorted(set(re.findall(r"\b(nf_[a-z0-9_]+)\s*\(", txt)))
 
 
+def int64_functions_declared():
+    """Names of the functions include/nf_mi355x.h declares as returning int64_t (scratch / pack sizes): ctypes assumes a 32-bit int
+    unless told otherwise, and a size above 2^31 elements then arrives truncated.  (Round 6, last session: nf_maf_solve_t_scratch_floats
+    had its return type set only on the ablation-build path -- the density-direction backward of config 5's layer failed above
+    ~720 000 rows per call with a scratch buffer a fraction of the size the kernel addressed.)"""
+    import re
+    txt = open(os.path.join(INCLUDE, "nf_mi355x.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"^\s*int64_t\s+(nf_[a-z0-9_]+)\s*\(", txt, flags=re.M)))
+
+
+def _declare_return_types(handle):
+    handle.nf_version.restype = C.c_char_p
+    handle.nf_strerror.restype = C.c_char_p
+    for fn in int64_functions_declared():
+        if hasattr(handle, fn):
+            getattr(handle, fn).restype = C.c_int64
+
+
 def lib():
     global _lib
     if _lib is None:
         override = os.environ.get("NF_MI355X_LIB")   # ablation builds (tools/*_ablate.py): another build of the SAME sources
         if override:
             _lib = C.CDLL(override)
-            _lib.nf_version.restype = C.c_char_p
-            _lib.nf_strerror.restype = C.c_char_p
-            for fn in ("nf_rqs_fused_pack_size", "nf_linear_wgrad_scratch_floats", "nf_maf_inverse_scratch_floats",
-                       "nf_maf_inverse_h_scratch_floats", "nf_made_wgrad_scratch_floats", "nf_maf_solve_t_scratch_floats"):
-                getattr(_lib, fn).restype = C.c_int64
+            _declare_return_types(_lib)
             return _lib
         if not os.path.exists(LIBPATH):
             raise NativeLibraryError(
                 "libnf_mi355x.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; g.build()'`."
                 " There is no CPU or eager fallback." % LIBPATH)
         _lib = C.CDLL(LIBPATH)
-        _lib.nf_version.restype = C.c_char_p
-        _lib.nf_strerror.restype = C.c_char_p
-        if hasattr(_lib, "nf_rqs_fused_pack_size"):
-            _lib.nf_rqs_fused_pack_size.restype = C.c_int64
-        if hasattr(_lib, "nf_linear_wgrad_scratch_floats"):
-            _lib.nf_linear_wgrad_scratch_floats.restype = C.c_int64
-        if hasattr(_lib, "nf_maf_inverse_scratch_floats"):
-            _lib.nf_maf_inverse_scratch_floats.restype = C.c_int64
-        if hasattr(_lib, "nf_maf_inverse_h_scratch_floats"):
-            _lib.nf_maf_inverse_h_scratch_floats.restype = C.c_int64
-        if hasattr(_lib, "nf_made_wgrad_scratch_floats"):
-            _lib.nf_made_wgrad_scratch_floats.restype = C.c_int64
+        _declare_return_types(_lib)       # (every int64_t function of the header, not a hand-kept list)
     return _lib
 
 

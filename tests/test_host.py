@@ -63,6 +63,20 @@ def test_c_abi_argument_validation_without_gpu(nfa):
     assert lib.nf_rqs_fused_pack_size(i32(8), i32(8), i32(32), i32(2), i32(8)) == -95
 
 
+def test_every_int64_function_of_the_header_is_bound_as_int64(nfa):
+    """ctypes assumes `int` for a foreign function's return value: every function include/nf_mi355x.h declares `int64_t` (scratch and
+    pack sizes) must be bound as c_int64 by _lib.lib() -- derived from the header, not from a hand-kept list (round 6: the solve's
+    scratch size arrived truncated above 2^31 floats, ~720 000 rows of config 5's layer)."""
+    lib = nfa._lib.lib()
+    names = nfa._lib.int64_functions_declared()
+    assert "nf_maf_solve_t_scratch_floats" in names and "nf_maf_inverse_h_scratch_floats" in names and len(names) >= 15
+    for fn in names:
+        assert getattr(lib, fn).restype is ctypes.c_int64, fn
+    i32, i64 = ctypes.c_int, ctypes.c_int64
+    assert lib.nf_maf_solve_t_scratch_floats(i64(999936), i32(128), i32(512), i32(2)) == 999936 * (5 * 512 + 256 + 5 * 32)     # > 2^31
+    assert lib.nf_maf_inverse_h_scratch_floats(i64(999936), i32(128), i32(512), i32(2)) == 999936 * (5 * 512 + 128 + 5 * 32)
+
+
 def test_c_abi_argument_validation_newer_entry_points(nfa):
     """Same discipline for the entry points added after the first bench: nothing is launched on bad arguments."""
     lib = nfa._lib.lib()
