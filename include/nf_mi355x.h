@@ -670,7 +670,8 @@ int nf_made_forward_train(const void *x, void *params, void *save, void *bits, c
 int nf_made_backward(const void *g_params, const void *bits, void *g_x, void *G, const void *blob, const int32_t *table, int64_t B,
                      int D, int hidden_padded, int mult, nf_stream_t stream);
 /* nf_made_forward_train / nf_made_backward on 128-row tiles where a 256-slot network has <= 64 input features and the batch is a
- * multiple of 128 rows >= 32 768 (round 6: a work item spans two sample blocks like the 512-slot kernels; same bits as 64-row tiles):
+ * multiple of 128 rows whose rounds of 256 persistent workgroups come out shorter that way (32 768, 65 536, ... rows; round 6: a work item
+ * spans two sample blocks like the 512-slot kernels; same bits as 64-row tiles):
  * on (1, default) / off (0), returns the previous setting.  A forward and its backward must run under the same setting. */
 int nf_config_made_tr128(int on);
 int64_t nf_made_wgrad_scratch_floats(int64_t B, int ntiles);

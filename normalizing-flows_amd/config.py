@@ -140,7 +140,7 @@ def set_glow_weights_batched(mode=True):
 
 
 # The 256-slot training kernels (nf_made_forward_train / nf_made_backward: GlowBlock's conv conditioner at the 16x16 level, ResidualNets /
-# MADEs of hidden width <= 256 on <= 64 features) on 128-row tiles at batches that are a multiple of 128 rows >= 32 768 (csrc/mlp_tile.hpp
+# MADEs of hidden width <= 256 on <= 64 features) on 128-row tiles at batches that are a multiple of 128 rows where the persistent workgroups' rounds come out shorter (csrc/mlp_tile.hpp
 # mf_tr128: a weight fragment feeds eight MFMAs instead of four; same bits).  Lives in the library (nf_config_made_tr128).
 def set_made_tr128(mode=True):
     """Returns the previous setting.  A forward and its backward must run under the same setting."""

@@ -24,7 +24,12 @@ inline int &mf_tr128_switch() {       // (one instance for the library: nf_confi
     return on;
 }
 inline bool mf_tr128(int64_t B, int hidden_padded, int dp) {
-    return mf_tr128_switch() && hidden_padded == 256 && dp <= 64 && B % 128 == 0 && B >= 128 * 256;
+    if (!mf_tr128_switch() || hidden_padded != 256 || dp > 64 || B <= 0 || B % 128) return false;
+    // The kernels are persistent over min(tiles, 256) workgroups: a launch lasts ceil(tiles / 256) rounds, a 128-row tile about 15/8 of
+    // a 64-row tile (measured at 65 536 rows: -6.5 %).  128-row tiles only where the rounds come out shorter -- 32 768 rows: 1 round
+    // against 2, 65 536: 2 against 4; NOT 49 152: 2 long rounds against 3 short ones.
+    const int64_t r128 = (B / 128 + 255) / 256, r64 = (B / 64 + 255) / 256;
+    return 15 * r128 < 8 * r64;
 }
 
 #define MF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)

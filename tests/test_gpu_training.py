@@ -1648,9 +1648,9 @@ def test_256_slot_training_kernels_on_128_row_tiles_give_the_same_bits(nfa):
     tiles, for GlowBlock's conv conditioner at config 4's 16x16 level and for a dense ResidualNet (wrapper.py:20-35's conditioner)."""
     torch.manual_seed(11)
     conv = nfa.nets.ConvNet2d([6, 256, 256, 12], [3, 1, 3], 0.0, init_zeros=False).to(DEV)
-    xc, cc = torch.randn(129, 6, 16, 16, device=DEV), torch.randn(129, 12, 16, 16, device=DEV)     # (258 tiles: two workgroups take a second one)
+    xc, cc = torch.randn(256, 6, 16, 16, device=DEV), torch.randn(256, 12, 16, 16, device=DEV)     # (512 tiles: every workgroup takes a second one)
     res = nfa.nets.ResidualNet(24, 40, 200, num_blocks=2).to(DEV)
-    xr, cr = torch.randn(32768 + 128, 24, device=DEV), torch.randn(32768 + 128, 40, device=DEV)
+    xr, cr = torch.randn(24576, 24, device=DEV), torch.randn(24576, 40, device=DEV)                 # (192 tiles in one round against 384 in two)
     # ... and a MADE (triangular masks: row-blocks with different k ranges, k-group offsets in the backward's suffix items)
     made = nfa.nets.MADE(40, 150, num_blocks=2, output_multiplier=2, use_residual_blocks=True, random_mask=False,
                          activation=torch.nn.functional.relu).to(DEV)
